@@ -1,0 +1,1002 @@
+/*
+ * mci_oracle.c -- CPU ORACLE (test infrastructure, NOT the product; see mci_oracle.h).
+ *
+ * Plain-C restatement of MCIntegration.jl's VEGAS / VegasMC path.  All indices that
+ * mirror Julia arrays are kept 1-based (arrays are allocated with one spare leading
+ * element) so that every line can be checked against the cited reference line.
+ *
+ * "ref:" comments give /root/reference/<file>:<line>.
+ */
+#include "mci_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * RNG: Philox4x32-10 (Salmon et al., SC'11; Random123 v1.14 constants).  Replaces
+ * Random.MersenneTwister (ref: src/configuration.jl:190) -- see "PINNING STATUS" in the header.
+ * ---------------------------------------------------------------------------------------- */
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+void mcio_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Stream contract shared with the HIP path (DESIGN.md "RNG streams"):
+ *   key = (seed lo, seed hi); ctr = (index lo, index hi, k>>1, stream)
+ *   draw k uses words (2*(k&1), 2*(k&1)+1); 53 mantissa bits -> [0,1).
+ * rand(config.rng) in the reference is likewise a [0,1) Float64 (ref: sampler.jl:296,361). */
+double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k) {
+    uint32_t ctr[4] = {(uint32_t)index, (uint32_t)(index >> 32), k >> 1, stream};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    mcio_philox4x32_10(ctr, key, o);
+    uint32_t a = o[2 * (k & 1)], b = o[2 * (k & 1) + 1];
+    uint64_t bits = (((uint64_t)b << 32) | a) >> 11;
+    return (double)bits * 0x1.0p-53;
+}
+
+enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3 };
+static inline uint32_t stream_id(uint32_t iteration, int purpose) { return iteration * 8u + (uint32_t)purpose; }
+
+/* ------------------------------------------------------------------------------------------
+ * src/distribution/common.jl
+ * ---------------------------------------------------------------------------------------- */
+
+/* ref: common.jl:8-36.  acc is 0-based C storage of a Julia vector of length n; returns the
+ * 1-based idx with acc[idx] <= p < acc[idx+1]; -1 where the reference raises error(). */
+long mcio_locate(const double *acc, long n, double p) {
+    if (acc[0] > p || acc[n - 1] <= p) return -1; /* :10-13 */
+    long jl = 1, ju = n + 1;                      /* :16-17 */
+    while (ju - jl > 1) {                         /* :18 */
+        long jm = (jl + ju) / 2;                  /* :19 */
+        if (p < acc[jm - 1]) ju = jm;             /* :20-21 */
+        else jl = jm;                             /* :22-23 */
+    }
+    return jl;                                    /* :34 */
+}
+
+/* ref: common.jl:43-54 */
+void mcio_smooth(const double *dist, long n, double factor, double *out) {
+    if (n <= 1) { /* :44-46 */
+        for (long i = 0; i < n; ++i) out[i] = dist[i];
+        return;
+    }
+    out[0] = (dist[0] * (factor + 1) + dist[1]) / (factor + 2);             /* :48 */
+    out[n - 1] = (dist[n - 1] * (factor + 1) + dist[n - 2]) / (factor + 2); /* :49 */
+    for (long i = 1; i < n - 1; ++i)                                        /* :50-52 */
+        out[i] = (dist[i - 1] + dist[i] * factor + dist[i + 1]) / (factor + 2);
+}
+
+/* ref: common.jl:67-82.  Output is NOT renormalised (:81-82).  Returns 1/2 where the
+ * reference's @assert (:71 / :79) fires.  sum() is taken left-to-right. */
+int mcio_rescale(double *dist, long n, double alpha) {
+    if (n == 1) return 0; /* :68-70 */
+    for (long i = 0; i < n; ++i)
+        if (!(dist[i] > 0)) return 1; /* :71 */
+    double s = 0.0;
+    for (long i = 0; i < n; ++i) s += dist[i];
+    for (long i = 0; i < n; ++i) dist[i] /= s; /* :72 */
+    for (long i = 0; i < n; ++i)               /* :74-78 */
+        if (dist[i] > 0 && dist[i] <= 0.99999999) dist[i] = pow(-(1 - dist[i]) / log(dist[i]), alpha);
+    for (long i = 0; i < n; ++i)
+        if (!isfinite(dist[i])) return 2; /* :79 */
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * src/distribution/variable.jl : train!
+ * ---------------------------------------------------------------------------------------- */
+
+/* ref: variable.jl:206-239 (Continuous).  grid[npts] and hist[npts-1] are 0-based storage. */
+int mcio_train_continuous(double *grid, long npts, double *hist, double alpha) {
+    long N = npts - 1;
+    for (long i = 0; i < N; ++i)
+        if (!isfinite(hist[i])) return 3; /* :212 */
+    for (long i = 0; i < N; ++i)
+        if (!(hist[i] > 0)) return 4; /* :213 */
+    double *d = (double *)malloc(sizeof(double) * (size_t)N);
+    double *newgrid = (double *)malloc(sizeof(double) * (size_t)npts);
+    mcio_smooth(hist, N, 6.0, d);     /* :214 */
+    int rc = mcio_rescale(d, N, alpha); /* :215 */
+    if (rc) { free(d); free(newgrid); return rc; }
+    newgrid[0] = grid[0];               /* :217 */
+    newgrid[npts - 1] = grid[npts - 1]; /* :218 */
+    long j = 0;                         /* :221 */
+    double acc_f = 0.0;                 /* :222 */
+    double s = 0.0;
+    for (long i = 0; i < N; ++i) s += d[i];
+    double f_ninc = s / (double)N;      /* :226 */
+    for (long i = 2; i <= npts - 1; ++i) { /* :227 (1-based i) */
+        while (acc_f < f_ninc) {           /* :228 */
+            j += 1;                        /* :229 */
+            acc_f += d[j - 1];             /* :230 */
+        }
+        acc_f -= f_ninc;                   /* :232 */
+        /* :233  T.grid[j+1] - (acc_f/avg_f[j])*(T.grid[j+1]-T.grid[j]) with 1-based j */
+        newgrid[i - 1] = grid[j] - (acc_f / d[j - 1]) * (grid[j] - grid[j - 1]);
+    }
+    newgrid[npts - 1] = grid[npts - 1]; /* :235 */
+    memcpy(grid, newgrid, sizeof(double) * (size_t)npts); /* :236 */
+    for (long i = 0; i < N; ++i) hist[i] = 1.0e-10;       /* :238 -> :565 */
+    free(d);
+    free(newgrid);
+    return 0;
+}
+
+/* ref: variable.jl:369-382 (Discrete).  No smoothing. */
+int mcio_train_discrete(double *hist, long K, double alpha, double *distribution, double *accumulation) {
+    double *d = (double *)malloc(sizeof(double) * (size_t)K);
+    memcpy(d, hist, sizeof(double) * (size_t)K); /* :373 */
+    int rc = mcio_rescale(d, K, alpha);          /* :374 */
+    if (rc) { free(d); return rc; }
+    double s = 0.0;
+    for (long i = 0; i < K; ++i) s += d[i];
+    for (long i = 0; i < K; ++i) d[i] /= s;      /* :375 */
+    accumulation[0] = 0.0;                        /* :377 */
+    double run = 0.0;
+    for (long i = 0; i < K; ++i) {                /* :376 sum(distribution[1:i]) */
+        run += d[i];
+        accumulation[i + 1] = run;
+    }
+    memcpy(distribution, d, sizeof(double) * (size_t)K); /* :378 */
+    for (long i = 0; i < K; ++i) hist[i] = 1.0e-10;      /* :381 */
+    free(d);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Configuration  (src/configuration.jl:105-194) and variable constructors
+ * ---------------------------------------------------------------------------------------- */
+
+#define MAXORDER 16 /* ref: distribution.jl:59 */
+
+void mcio_maxdof(const int *dof, int nd, int npool, int *out) { /* ref: configuration.jl:229-236 */
+    for (int v = 0; v < npool; ++v) {
+        int m = 0;
+        for (int i = 0; i < nd; ++i)
+            if (dof[i * npool + v] > m) m = dof[i * npool + v];
+        out[v] = m;
+    }
+}
+
+static void leaf_alloc_pool(mcio_leaf *L, int P) {
+    L->P = P;
+    L->data = (double *)calloc((size_t)P + 1, sizeof(double));
+    L->gidx = (long *)calloc((size_t)P + 1, sizeof(long));
+    L->prob = (double *)calloc((size_t)P + 1, sizeof(double));
+}
+
+/* ref: variable.jl:137-153 (Continuous ctor) / :299-325 (Discrete ctor) */
+static void leaf_init(mcio_leaf *L, int kind, int pool, double lower, double upper, int npts, double alpha,
+                      int adapt, int P) {
+    memset(L, 0, sizeof(*L));
+    L->kind = kind;
+    L->pool = pool;
+    L->lower = lower;
+    L->upper = upper;
+    L->alpha = alpha;
+    L->adapt = adapt;
+    leaf_alloc_pool(L, P);
+    if (kind == MCIO_CONTINUOUS) {
+        L->npts = npts;
+        L->nbin = npts - 1; /* :147 */
+        L->grid = (double *)malloc(sizeof(double) * (size_t)npts);
+        /* :137 grid = collect(LinRange(lower, upper, ninc)); Julia's LinRange lerps
+           (1-t)*a + t*b with t = i/(n-1) */
+        for (int i = 0; i < npts; ++i) {
+            double t = (double)i / (double)(npts - 1);
+            L->grid[i] = (1.0 - t) * lower + t * upper;
+        }
+        L->grid[0] = lower;
+        L->grid[npts - 1] = upper;
+        L->hist = (double *)malloc(sizeof(double) * (size_t)L->nbin);
+        for (int i = 0; i < L->nbin; ++i) L->hist[i] = MCIO_TINY; /* :149 */
+        /* :141-145 deterministic initial pool contents */
+        for (int i = 1; i <= P; ++i) {
+            double a = lower + (upper - lower) / P, b = upper - (upper - lower) / P;
+            double t = (P > 1) ? (double)(i - 1) / (double)(P - 1) : 0.0;
+            L->data[i] = (1.0 - t) * a + t * b;
+            long g = mcio_locate(L->grid, npts, L->data[i]);
+            L->gidx[i] = g < 1 ? 1 : g;
+            L->prob[i] = 1.0;
+        }
+    } else {
+        int K = (int)(upper - lower) + 1;
+        L->npts = K;
+        L->nbin = K; /* :305 */
+        L->hist = (double *)malloc(sizeof(double) * (size_t)K);
+        L->distribution = (double *)malloc(sizeof(double) * (size_t)K);
+        L->accumulation = (double *)malloc(sizeof(double) * (size_t)(K + 1));
+        for (int i = 0; i < K; ++i) L->distribution[i] = MCIO_TINY; /* :305-307 */
+        double s = 0.0;
+        for (int i = 0; i < K; ++i) s += L->distribution[i];
+        for (int i = 0; i < K; ++i) L->distribution[i] /= s; /* :312 */
+        L->accumulation[0] = 0.0;                             /* :313-314 */
+        double run = 0.0;
+        for (int i = 0; i < K; ++i) {
+            run += L->distribution[i];
+            L->accumulation[i + 1] = run;
+        }
+        for (int i = 1; i <= P; ++i) { /* :302, :316-317 */
+            L->data[i] = lower + (double)((i - 1) % K);
+            L->prob[i] = 1.0 / P;
+        }
+        for (int i = 0; i < K; ++i) L->hist[i] = 1.0e-10; /* :323 */
+    }
+}
+
+mcio_config *mcio_config_create(int nleaf, const int *kind, const int *pool, const double *lower,
+                                const double *upper, const int *npts, const double *alpha,
+                                const int *adapt, const int *pool_offset, int npool, int Ni,
+                                const int *dof, const int *obs_nbin, const int *obs_bin_draw) {
+    mcio_config *c = (mcio_config *)calloc(1, sizeof(mcio_config));
+    c->nleaf = nleaf;
+    c->npool = npool;
+    c->Ni = Ni;
+    int Nd = Ni + 1;
+    c->dof = (int *)calloc((size_t)Nd * npool, sizeof(int));
+    memcpy(c->dof, dof, sizeof(int) * (size_t)Ni * npool); /* last row: zeros(Int, length(var)) ref: configuration.jl:153 */
+    c->maxdof = (int *)calloc((size_t)npool, sizeof(int));
+    mcio_maxdof(c->dof, Nd, npool, c->maxdof); /* :155 */
+    c->pool_leaf0 = (int *)calloc((size_t)npool, sizeof(int));
+    c->pool_nleaf = (int *)calloc((size_t)npool, sizeof(int));
+    c->pool_offset = (int *)calloc((size_t)npool, sizeof(int));
+    for (int v = 0; v < npool; ++v) c->pool_leaf0[v] = -1;
+    for (int l = 0; l < nleaf; ++l) {
+        int v = pool[l];
+        if (c->pool_leaf0[v] < 0) c->pool_leaf0[v] = l;
+        c->pool_nleaf[v] += 1;
+    }
+    c->leaf = (mcio_leaf *)calloc((size_t)nleaf, sizeof(mcio_leaf));
+    c->pool_prob = (double **)calloc((size_t)npool, sizeof(double *));
+    c->pool_prob_cache = (double *)calloc((size_t)npool, sizeof(double));
+    for (int v = 0; v < npool; ++v) {
+        int off = pool_offset ? pool_offset[v] : 0;
+        c->pool_offset[v] = off;
+        /* pool size: MaxOrder+1 (ref: variable.jl:139), grown to maxdof+2+offset (ref: configuration.jl:156-160) */
+        int P = MAXORDER + 1;
+        if (c->maxdof[v] + off >= P - 2) P = c->maxdof[v] + 2 + off;
+        for (int l = c->pool_leaf0[v]; l < c->pool_leaf0[v] + c->pool_nleaf[v]; ++l)
+            leaf_init(&c->leaf[l], kind[l], v, lower[l], upper[l], npts[l], alpha[l], adapt[l], P);
+        if (c->pool_nleaf[v] == 1) {
+            c->pool_prob[v] = c->leaf[c->pool_leaf0[v]].prob;
+        } else { /* CompositeVar.prob = ones(size)  ref: variable.jl:425 */
+            c->pool_prob[v] = (double *)calloc((size_t)P + 1, sizeof(double));
+            for (int i = 0; i <= P; ++i) c->pool_prob[v][i] = 1.0;
+        }
+        c->pool_prob_cache[v] = 1.0;
+    }
+    c->ndraw = 0;
+    for (int v = 0; v < npool; ++v) c->ndraw += c->maxdof[v] * c->pool_nleaf[v];
+    c->draw_leaf = (int *)calloc((size_t)(c->ndraw > 0 ? c->ndraw : 1), sizeof(int));
+    c->draw_slot = (int *)calloc((size_t)(c->ndraw > 0 ? c->ndraw : 1), sizeof(int));
+    int k = 0;
+    for (int v = 0; v < npool; ++v)
+        for (int idx = 1; idx <= c->maxdof[v]; ++idx)
+            for (int l = 0; l < c->pool_nleaf[v]; ++l) {
+                c->draw_leaf[k] = c->pool_leaf0[v] + l;
+                c->draw_slot[k] = idx;
+                ++k;
+            }
+    c->obs_off = (int *)calloc((size_t)Ni, sizeof(int));
+    c->obs_nbin = (int *)calloc((size_t)Ni, sizeof(int));
+    c->obs_bin_draw = (int *)calloc((size_t)Ni, sizeof(int));
+    c->nobs = 0;
+    for (int i = 0; i < Ni; ++i) {
+        c->obs_off[i] = c->nobs;
+        c->obs_nbin[i] = obs_nbin ? obs_nbin[i] : 1;
+        c->obs_bin_draw[i] = obs_bin_draw ? obs_bin_draw[i] : -1;
+        c->nobs += c->obs_nbin[i];
+    }
+    c->observable = (double *)calloc((size_t)c->nobs, sizeof(double));
+    c->reweight = (double *)calloc((size_t)Nd, sizeof(double));
+    for (int i = 0; i < Nd; ++i) c->reweight[i] = 1.0 / Nd; /* ref: configuration.jl:110,172-173 */
+    c->visited = (double *)calloc((size_t)Nd, sizeof(double));
+    for (int i = 0; i < Nd; ++i) c->visited[i] = 1.0e-8;    /* :182 */
+    c->propose = (double *)calloc((size_t)npool, sizeof(double));
+    c->accept = (double *)calloc((size_t)npool, sizeof(double));
+    for (int v = 0; v < npool; ++v) c->propose[v] = 1.0e-8; /* :186 */
+    c->normalization = 1.0e-10;                              /* :179 */
+    c->neval = 0;
+    c->prob_mode = MCIO_PROB_CREATE;
+    return c;
+}
+
+static void leaf_free(mcio_leaf *L) {
+    free(L->grid); free(L->hist); free(L->accumulation); free(L->distribution);
+    free(L->data); free(L->gidx); free(L->prob);
+}
+
+void mcio_config_destroy(mcio_config *c) {
+    if (!c) return;
+    for (int v = 0; v < c->npool; ++v)
+        if (c->pool_nleaf[v] != 1) free(c->pool_prob[v]);
+    for (int l = 0; l < c->nleaf; ++l) leaf_free(&c->leaf[l]);
+    free(c->leaf); free(c->pool_leaf0); free(c->pool_nleaf); free(c->pool_offset);
+    free(c->pool_prob); free(c->pool_prob_cache); free(c->dof); free(c->maxdof);
+    free(c->draw_leaf); free(c->draw_slot); free(c->obs_off); free(c->obs_nbin); free(c->obs_bin_draw);
+    free(c->observable); free(c->reweight); free(c->visited); free(c->propose); free(c->accept);
+    free(c);
+}
+
+static void *dup_mem(const void *p, size_t n) {
+    if (!p) return NULL;
+    void *q = malloc(n ? n : 1);
+    memcpy(q, p, n);
+    return q;
+}
+
+/* deepcopy(config)  ref: main.jl:130-131 */
+mcio_config *mcio_config_clone(const mcio_config *s) {
+    mcio_config *c = (mcio_config *)calloc(1, sizeof(mcio_config));
+    *c = *s;
+    int Nd = s->Ni + 1;
+    c->leaf = (mcio_leaf *)calloc((size_t)s->nleaf, sizeof(mcio_leaf));
+    for (int l = 0; l < s->nleaf; ++l) {
+        const mcio_leaf *a = &s->leaf[l];
+        mcio_leaf *b = &c->leaf[l];
+        *b = *a;
+        b->grid = (double *)dup_mem(a->grid, sizeof(double) * (size_t)a->npts);
+        b->hist = (double *)dup_mem(a->hist, sizeof(double) * (size_t)a->nbin);
+        b->accumulation = a->accumulation ? (double *)dup_mem(a->accumulation, sizeof(double) * (size_t)(a->nbin + 1)) : NULL;
+        b->distribution = a->distribution ? (double *)dup_mem(a->distribution, sizeof(double) * (size_t)a->nbin) : NULL;
+        b->data = (double *)dup_mem(a->data, sizeof(double) * (size_t)(a->P + 1));
+        b->gidx = (long *)dup_mem(a->gidx, sizeof(long) * (size_t)(a->P + 1));
+        b->prob = (double *)dup_mem(a->prob, sizeof(double) * (size_t)(a->P + 1));
+    }
+    c->pool_leaf0 = (int *)dup_mem(s->pool_leaf0, sizeof(int) * (size_t)s->npool);
+    c->pool_nleaf = (int *)dup_mem(s->pool_nleaf, sizeof(int) * (size_t)s->npool);
+    c->pool_offset = (int *)dup_mem(s->pool_offset, sizeof(int) * (size_t)s->npool);
+    c->pool_prob_cache = (double *)dup_mem(s->pool_prob_cache, sizeof(double) * (size_t)s->npool);
+    c->pool_prob = (double **)calloc((size_t)s->npool, sizeof(double *));
+    for (int v = 0; v < s->npool; ++v) {
+        if (s->pool_nleaf[v] == 1) c->pool_prob[v] = c->leaf[c->pool_leaf0[v]].prob;
+        else c->pool_prob[v] = (double *)dup_mem(s->pool_prob[v], sizeof(double) * (size_t)(s->leaf[s->pool_leaf0[v]].P + 1));
+    }
+    c->dof = (int *)dup_mem(s->dof, sizeof(int) * (size_t)Nd * s->npool);
+    c->maxdof = (int *)dup_mem(s->maxdof, sizeof(int) * (size_t)s->npool);
+    c->draw_leaf = (int *)dup_mem(s->draw_leaf, sizeof(int) * (size_t)(s->ndraw > 0 ? s->ndraw : 1));
+    c->draw_slot = (int *)dup_mem(s->draw_slot, sizeof(int) * (size_t)(s->ndraw > 0 ? s->ndraw : 1));
+    c->obs_off = (int *)dup_mem(s->obs_off, sizeof(int) * (size_t)s->Ni);
+    c->obs_nbin = (int *)dup_mem(s->obs_nbin, sizeof(int) * (size_t)s->Ni);
+    c->obs_bin_draw = (int *)dup_mem(s->obs_bin_draw, sizeof(int) * (size_t)s->Ni);
+    c->observable = (double *)dup_mem(s->observable, sizeof(double) * (size_t)s->nobs);
+    c->reweight = (double *)dup_mem(s->reweight, sizeof(double) * (size_t)Nd);
+    c->visited = (double *)dup_mem(s->visited, sizeof(double) * (size_t)Nd);
+    c->propose = (double *)dup_mem(s->propose, sizeof(double) * (size_t)s->npool);
+    c->accept = (double *)dup_mem(s->accept, sizeof(double) * (size_t)s->npool);
+    return c;
+}
+
+int mcio_set_grid(mcio_config *c, int leaf, const double *grid, int npts) {
+    mcio_leaf *L = &c->leaf[leaf];
+    if (L->kind != MCIO_CONTINUOUS) return 1;
+    free(L->grid);
+    free(L->hist);
+    L->npts = npts;
+    L->nbin = npts - 1;
+    L->grid = (double *)dup_mem(grid, sizeof(double) * (size_t)npts);
+    L->hist = (double *)malloc(sizeof(double) * (size_t)L->nbin);
+    for (int i = 0; i < L->nbin; ++i) L->hist[i] = MCIO_TINY;
+    for (int i = 1; i <= L->P; ++i) {
+        long g = mcio_locate(L->grid, npts, L->data[i]);
+        L->gidx[i] = g < 1 ? 1 : g;
+    }
+    return 0;
+}
+
+/* Discrete(...; distribution=...)  ref: variable.jl:306-315 */
+int mcio_set_distribution(mcio_config *c, int leaf, const double *dist) {
+    mcio_leaf *L = &c->leaf[leaf];
+    if (L->kind != MCIO_DISCRETE) return 1;
+    int K = L->nbin;
+    double s = 0.0;
+    for (int i = 0; i < K; ++i) {
+        if (!(dist[i] >= 0.0)) return 2; /* :309 */
+        s += dist[i];
+    }
+    double run = 0.0;
+    L->accumulation[0] = 0.0;
+    for (int i = 0; i < K; ++i) {
+        L->distribution[i] = dist[i] / s; /* :312 */
+        run += L->distribution[i];
+        L->accumulation[i + 1] = run;     /* :313-314 */
+    }
+    return 0;
+}
+
+/* ref: configuration.jl:238-250 and variable.jl:565 */
+void mcio_clear_statistics(mcio_config *c) {
+    for (int i = 0; i < c->nobs; ++i) c->observable[i] = 0.0;
+    c->neval = 0;
+    c->normalization = 1.0e-10;
+    for (int i = 0; i < c->Ni + 1; ++i) c->visited[i] = 1.0e-8;
+    for (int v = 0; v < c->npool; ++v) {
+        c->propose[v] = 1.0e-8;
+        c->accept[v] = 1.0e-10;
+    }
+    for (int l = 0; l < c->nleaf; ++l)
+        for (int i = 0; i < c->leaf[l].nbin; ++i) c->leaf[l].hist[i] = 1.0e-10;
+}
+
+/* ref: configuration.jl:252-262 and variable.jl:567 */
+void mcio_add_config(mcio_config *c, const mcio_config *ic) {
+    for (int i = 0; i < c->Ni + 1; ++i) c->visited[i] += ic->visited[i];
+    for (int v = 0; v < c->npool; ++v) {
+        c->accept[v] += ic->accept[v];
+        c->propose[v] += ic->propose[v];
+    }
+    c->neval += ic->neval;
+    c->normalization += ic->normalization;
+    for (int i = 0; i < c->nobs; ++i) c->observable[i] += ic->observable[i];
+    for (int l = 0; l < c->nleaf; ++l)
+        for (int i = 0; i < c->leaf[l].nbin; ++i) c->leaf[l].hist[i] += ic->leaf[l].hist[i];
+}
+
+/* Dist.train!(v) for every variable  ref: main.jl:194-195, variable.jl:479-483 */
+void mcio_train(mcio_config *c) {
+    for (int l = 0; l < c->nleaf; ++l) {
+        mcio_leaf *L = &c->leaf[l];
+        if (!L->adapt) continue; /* variable.jl:208, :370 */
+        int rc;
+        if (L->kind == MCIO_CONTINUOUS) rc = mcio_train_continuous(L->grid, L->npts, L->hist, L->alpha);
+        else rc = mcio_train_discrete(L->hist, L->nbin, L->alpha, L->distribution, L->accumulation);
+        if (rc) fprintf(stderr, "[mci_oracle] train! assertion %d on leaf %d\n", rc, l);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * src/distribution/sampler.jl
+ * ---------------------------------------------------------------------------------------- */
+
+static inline long locate_clamped(const mcio_leaf *L, double u) {
+    long g = mcio_locate(L->accumulation, L->nbin + 1, u);
+    /* the reference raises error() when accumulation[end] <= u < 1 through rounding
+       (common.jl:10-12); the oracle clamps to the last bin instead (probability ~1e-16). */
+    if (g < 1) g = L->nbin;
+    return g;
+}
+
+/* create!  ref: sampler.jl:293-305 (Continuous), :13-22 (Discrete).  idx is 1-based incl. offset. */
+double mcio_create(mcio_config *c, int leaf, int idx, double u) {
+    mcio_leaf *T = &c->leaf[leaf];
+    if (T->kind == MCIO_CONTINUOUS) {
+        long N = T->npts - 1;                 /* :295 */
+        double y = u;                          /* :296 */
+        long iy = (long)floor(y * N) + 1;     /* :297 */
+        double dy = y * N - (iy - 1);          /* :298 */
+        double x = T->grid[iy - 1] + dy * (T->grid[iy] - T->grid[iy - 1]); /* :299 */
+        T->data[idx] = x;                      /* :300 */
+        T->gidx[idx] = iy;                     /* :301 */
+        T->prob[idx] = 1.0 / (N * (T->grid[iy] - T->grid[iy - 1])); /* :303 */
+        return 1.0 / T->prob[idx];             /* :304 */
+    } else {
+        long gidx = locate_clamped(T, u);                  /* :17 */
+        T->data[idx] = T->lower + (double)(gidx - 1);      /* :18 */
+        T->gidx[idx] = gidx;
+        T->prob[idx] = T->distribution[gidx - 1];          /* :20 */
+        return 1.0 / T->distribution[gidx - 1];            /* :21 */
+    }
+}
+
+/* shift!  ref: sampler.jl:336-386 (Continuous), :57-71 (Discrete) */
+double mcio_shift(mcio_config *c, int leaf, int idx, double u) {
+    mcio_leaf *T = &c->leaf[leaf];
+    int end = T->P;
+    if (T->kind == MCIO_CONTINUOUS) {
+        T->data[end] = T->data[idx]; /* :338 */
+        T->gidx[end] = T->gidx[idx]; /* :339 */
+        T->prob[end] = T->prob[idx]; /* :340 */
+        long cur = T->gidx[idx];     /* :341 */
+        long N = T->npts - 1;        /* :343 */
+        double y = u;                 /* :361 */
+        long iy = (long)floor(y * N) + 1; /* :378 */
+        double dy = y * N - (iy - 1);      /* :379 */
+        double x = T->grid[iy - 1] + dy * (T->grid[iy] - T->grid[iy - 1]); /* :380 */
+        T->data[idx] = x;             /* :381 */
+        T->gidx[idx] = iy;            /* :382 */
+        double ratio = (T->grid[cur] - T->grid[cur - 1]) / (T->grid[iy] - T->grid[iy - 1]); /* :383 */
+        T->prob[idx] *= ratio;        /* :384 */
+        return 1.0 / ratio;           /* :385 */
+    } else {
+        T->data[end] = T->data[idx];  /* :62 */
+        T->prob[end] = T->prob[idx];  /* :63 */
+        T->gidx[end] = T->gidx[idx];
+        long cur = (long)(T->data[idx] - T->lower) + 1; /* :64 */
+        long gidx = locate_clamped(T, u);                /* :65 */
+        T->data[idx] = T->lower + (double)(gidx - 1);    /* :66 */
+        T->gidx[idx] = gidx;
+        double ratio = T->distribution[gidx - 1] / T->distribution[cur - 1]; /* :68 */
+        T->prob[idx] *= ratio;                           /* :69 */
+        return 1.0 / ratio;                              /* :70 */
+    }
+}
+
+/* shiftRollback!  ref: sampler.jl:388-393, :73-77 */
+void mcio_shift_rollback(mcio_config *c, int leaf, int idx) {
+    mcio_leaf *T = &c->leaf[leaf];
+    int end = T->P;
+    T->data[idx] = T->data[end];
+    T->gidx[idx] = T->gidx[end];
+    T->prob[idx] = T->prob[end];
+}
+
+/* pool-level shift!: plain variable, or CompositeVar  ref: sampler.jl:431-440 */
+double mcio_pool_shift(mcio_config *c, int vi, int idx, const double *u) {
+    int l0 = c->pool_leaf0[vi], nl = c->pool_nleaf[vi];
+    if (nl == 1) return mcio_shift(c, l0, idx, u[0]);
+    double prop = 1.0;                              /* :432 */
+    c->pool_prob_cache[vi] = c->pool_prob[vi][idx]; /* :433 */
+    c->pool_prob[vi][idx] = 1.0;                    /* :434 */
+    for (int l = 0; l < nl; ++l) {                  /* :435-438 */
+        prop *= mcio_shift(c, l0 + l, idx, u[l]);
+        c->pool_prob[vi][idx] *= c->leaf[l0 + l].prob[idx];
+    }
+    return prop;
+}
+
+/* pool-level create!  ref: sampler.jl:410-418 */
+double mcio_pool_create(mcio_config *c, int vi, int idx, const double *u) {
+    int l0 = c->pool_leaf0[vi], nl = c->pool_nleaf[vi];
+    if (nl == 1) return mcio_create(c, l0, idx, u[0]);
+    double prop = 1.0;             /* :411 */
+    c->pool_prob[vi][idx] = 1.0;   /* :412 */
+    for (int l = 0; l < nl; ++l) { /* :413-416 */
+        prop *= mcio_create(c, l0 + l, idx, u[l]);
+        c->pool_prob[vi][idx] *= c->leaf[l0 + l].prob[idx];
+    }
+    return prop;
+}
+
+/* ref: sampler.jl:441-446 */
+void mcio_pool_shift_rollback(mcio_config *c, int vi, int idx) {
+    int l0 = c->pool_leaf0[vi], nl = c->pool_nleaf[vi];
+    for (int l = 0; l < nl; ++l) mcio_shift_rollback(c, l0 + l, idx);
+    if (nl != 1) c->pool_prob[vi][idx] = c->pool_prob_cache[vi];
+}
+
+/* ref: variable.jl:587-599 */
+double mcio_total_probability(const mcio_config *c) {
+    double prob = 1.0;
+    for (int vi = 0; vi < c->npool; ++vi)
+        for (int pos = 1; pos <= c->maxdof[vi]; ++pos) prob *= c->pool_prob[vi][pos + c->pool_offset[vi]];
+    return prob;
+}
+
+/* ref: variable.jl:606-619 ; i is 0-based here, i == Ni is the normalisation integrand */
+double mcio_probability(const mcio_config *c, int i) {
+    double prob = 1.0;
+    for (int vi = 0; vi < c->npool; ++vi)
+        for (int pos = 1; pos <= c->dof[i * c->npool + vi]; ++pos) prob *= c->pool_prob[vi][pos + c->pool_offset[vi]];
+    return prob;
+}
+
+/* ref: variable.jl:628-641 */
+double mcio_padding_probability(const mcio_config *c, int i) {
+    double prob = 1.0;
+    for (int vi = 0; vi < c->npool; ++vi)
+        for (int pos = c->dof[i * c->npool + vi] + 1; pos <= c->maxdof[vi]; ++pos)
+            prob *= c->pool_prob[vi][pos + c->pool_offset[vi]];
+    return prob;
+}
+
+/* accumulate!  ref: variable.jl:196-200 (Continuous), :362-367 (Discrete), :474-478 (CompositeVar) */
+static inline void pool_accumulate(mcio_config *c, int vi, int idx, double weight) {
+    int l0 = c->pool_leaf0[vi], nl = c->pool_nleaf[vi];
+    for (int l = l0; l < l0 + nl; ++l) {
+        mcio_leaf *T = &c->leaf[l];
+        if (!T->adapt) continue;
+        long g = (T->kind == MCIO_CONTINUOUS) ? T->gidx[idx] : (long)(T->data[idx] - T->lower) + 1;
+        T->hist[g - 1] += weight;
+    }
+}
+
+/* gather the flat draw vector the integrand sees (x[i] == var.data[i], ref: distribution.jl:27) */
+static inline void gather_x(const mcio_config *c, double *x) {
+    for (int k = 0; k < c->ndraw; ++k) {
+        const mcio_leaf *T = &c->leaf[c->draw_leaf[k]];
+        x[k] = T->data[c->draw_slot[k] + c->pool_offset[T->pool]];
+    }
+}
+
+/* default measure (ref: vegas/montecarlo.jl:151-153) or "bin by a Discrete draw" (ref: example/bubble.jl:81-84) */
+static inline void measure(mcio_config *c, const double *x, const double *relw) {
+    for (int i = 0; i < c->Ni; ++i) {
+        int bin = 0;
+        if (c->obs_bin_draw[i] >= 0) {
+            const mcio_leaf *T = &c->leaf[c->draw_leaf[c->obs_bin_draw[i]]];
+            bin = (int)(x[c->obs_bin_draw[i]] - T->lower);
+            if (bin < 0 || bin >= c->obs_nbin[i]) continue;
+        }
+        c->observable[c->obs_off[i] + bin] += relw[i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * src/vegas/montecarlo.jl:72-191
+ * ---------------------------------------------------------------------------------------- */
+#define MCIO_MAXDRAW 256
+#define MCIO_MAXNI 64
+
+int mcio_vegas_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint64_t seed,
+                     uint32_t iteration, long block_index, long neval, long measurefreq) {
+    const int Ni = c->Ni, npool = c->npool;
+    if (c->ndraw > MCIO_MAXDRAW || Ni > MCIO_MAXNI || measurefreq <= 0) return -1; /* :77 */
+    double relw[MCIO_MAXNI], weights[MCIO_MAXNI], pad[MCIO_MAXNI]; /* :79-81 */
+    int diff[MCIO_MAXNI];
+    double x[MCIO_MAXDRAW], u[MCIO_MAXDRAW];
+    for (int i = 0; i < Ni; ++i) {
+        weights[i] = 0.0;
+        pad[i] = 1.0;
+        diff[i] = 1; /* :82 dof[i] == maxdof */
+        for (int v = 0; v < npool; ++v)
+            if (c->dof[i * npool + v] != c->maxdof[v]) diff[i] = 0;
+    }
+    /* :108-110 Dist.initialize! -> create! on every live slot (variable.jl:576-580).  Its
+       uniforms come from their own stream; in PROB_CREATE mode the values are overwritten
+       before use and only the RNG accounting of the reference is lost. */
+    {
+        uint32_t st = stream_id(iteration, STREAM_POOLINIT);
+        uint32_t kk = 0;
+        for (int v = 0; v < npool; ++v) {
+            int P = c->leaf[c->pool_leaf0[v]].P;
+            for (int idx = 1 + c->pool_offset[v]; idx <= P - 2; ++idx) {
+                for (int l = 0; l < c->pool_nleaf[v]; ++l) u[l] = mcio_uniform(seed, st, (uint64_t)block_index, kk++);
+                mcio_pool_create(c, v, idx, u);
+            }
+        }
+    }
+    const uint32_t st = stream_id(iteration, STREAM_VEGAS);
+    for (long ne = 1; ne <= neval; ++ne) { /* :117 */
+        c->neval += 1;                      /* :118 */
+        const uint64_t gs = (uint64_t)block_index * (uint64_t)neval + (uint64_t)(ne - 1);
+        double jac = 1.0;                   /* :121 */
+        int k = 0;
+        for (int vi = 0; vi < npool; ++vi) { /* :122 */
+            const int off = c->pool_offset[vi], nl = c->pool_nleaf[vi];
+            for (int idx = 1; idx <= c->maxdof[vi]; ++idx) { /* :124 */
+                for (int l = 0; l < nl; ++l) u[l] = mcio_uniform(seed, st, gs, (uint32_t)(k + l));
+                if (c->prob_mode == MCIO_PROB_SHIFT) mcio_pool_shift(c, vi, idx + off, u); /* :125 */
+                else mcio_pool_create(c, vi, idx + off, u);                                /* :128-129 */
+                jac /= c->pool_prob[vi][idx + off];                                        /* :126 */
+                k += nl;
+            }
+        }
+        for (int i = 0; i < Ni; ++i) /* :133-137 */
+            if (!diff[i]) pad[i] = mcio_padding_probability(c, i);
+        gather_x(c, x);
+        f(x, weights, ud); /* :140-144 */
+        if (ne % measurefreq == 0) { /* :148 */
+            for (int i = 0; i < Ni; ++i) relw[i] = weights[i] * pad[i] * jac; /* :152 / :157 */
+            measure(c, x, relw);
+            c->normalization += 1.0; /* :164 */
+        }
+        for (int vi = 0; vi < npool; ++vi) { /* :170 */
+            const int off = c->pool_offset[vi];
+            for (int i = 0; i < Ni; ++i) {   /* :172 */
+                double w2 = fabs(weights[i]); /* :173 */
+                double j2 = jac;              /* :174 */
+                for (int pos = 1; pos <= c->dof[i * npool + vi]; ++pos) /* :179 */
+                    pool_accumulate(c, vi, pos + off, (w2 * j2) * (w2 * j2)); /* :180 */
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * src/vegas_mc/montecarlo.jl:112-241 + src/vegas_mc/updates.jl:45-106
+ * The block's neval steps are run as `nchain` independent chains of neval/nchain steps
+ * (nchain = 1 is the reference).  Chain g = block_index*nchain + ch draws
+ *   init  : stream MC_INIT, index g,            k = flat draw
+ *   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
+ * ---------------------------------------------------------------------------------------- */
+int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint64_t seed,
+                       uint32_t iteration, long block_index, long neval, long measurefreq,
+                       long nchain) {
+    const int N = c->Ni, npool = c->npool, norm = c->Ni;
+    if (c->ndraw > MCIO_MAXDRAW || N + 1 > MCIO_MAXNI || measurefreq <= 0 || nchain < 1) return -1;
+    double weights[MCIO_MAXNI], _weights[MCIO_MAXNI], relw[MCIO_MAXNI];
+    double pad[MCIO_MAXNI], _pad[MCIO_MAXNI]; /* :147-148 */
+    double x[MCIO_MAXDRAW], u[MCIO_MAXDRAW];
+    const long steps = neval / nchain;
+    const uint32_t st_init = stream_id(iteration, STREAM_MC_INIT), st_step = stream_id(iteration, STREAM_MC_STEP);
+    for (long ch = 0; ch < nchain; ++ch) {
+        const uint64_t g = (uint64_t)block_index * (uint64_t)nchain + (uint64_t)ch;
+        /* :151-153 initialize! (only the slots that are ever read: 1..maxdof) */
+        int k = 0;
+        for (int vi = 0; vi < npool; ++vi)
+            for (int idx = 1; idx <= c->maxdof[vi]; ++idx) {
+                int nl = c->pool_nleaf[vi];
+                for (int l = 0; l < nl; ++l) u[l] = mcio_uniform(seed, st_init, g, (uint32_t)(k + l));
+                mcio_pool_create(c, vi, idx + c->pool_offset[vi], u);
+                k += nl;
+            }
+        gather_x(c, x);
+        f(x, _weights, ud); /* :155-159 */
+        for (int i = 0; i <= N; ++i) pad[i] = mcio_padding_probability(c, i); /* :161 */
+        double probability = c->reweight[norm] * pad[norm];                   /* :162 */
+        for (int i = 0; i < N; ++i) {                                         /* :163-166 */
+            weights[i] = _weights[i];
+            probability += fabs(_weights[i]) * c->reweight[i] * pad[i];
+        }
+        for (long ne = 1; ne <= steps; ++ne) { /* :184 */
+            const uint64_t sidx = (g << 32) | (uint64_t)(ne - 1);
+            /* ---- changeVariable  ref: updates.jl:45-106 ---- */
+            do {
+                int vi = (int)floor(mcio_uniform(seed, st_step, sidx, 0) * npool); /* :50 */
+                if (vi >= npool) vi = npool - 1;
+                const mcio_leaf *v0 = &c->leaf[c->pool_leaf0[vi]];
+                if (c->pool_nleaf[vi] == 1 && v0->kind == MCIO_DISCRETE && v0->nbin == 1) break; /* :52-54 */
+                if (c->maxdof[vi] <= 0) break;                                                    /* :55-57 */
+                int slot = (int)floor(mcio_uniform(seed, st_step, sidx, 1) * c->maxdof[vi]) + 1;
+                if (slot > c->maxdof[vi]) slot = c->maxdof[vi];
+                int idx = c->pool_offset[vi] + slot; /* :58 */
+                for (int l = 0; l < c->pool_nleaf[vi]; ++l) u[l] = mcio_uniform(seed, st_step, sidx, (uint32_t)(3 + l));
+                double prop = mcio_pool_shift(c, vi, idx, u); /* :60 */
+                if (prop <= 4.9406564584124654e-324) break;   /* :63-65 */
+                gather_x(c, x);
+                f(x, _weights, ud);                            /* :67-75 */
+                c->neval += 1;                                 /* :77 */
+                for (int i = 0; i <= N; ++i) _pad[i] = mcio_padding_probability(c, i); /* :79-81 */
+                double newp = c->reweight[norm] * _pad[norm];                          /* :84 */
+                for (int i = 0; i < N; ++i) newp += fabs(_weights[i]) * c->reweight[i] * _pad[i]; /* :85-87 */
+                double R = prop * newp / probability;          /* :88 */
+                c->propose[vi] += 1.0;                         /* :90 */
+                if (mcio_uniform(seed, st_step, sidx, 2) < R) { /* :91 */
+                    c->accept[vi] += 1.0;                      /* :92 */
+                    for (int i = 0; i < N; ++i) weights[i] = _weights[i]; /* :93-95 */
+                    for (int i = 0; i <= N; ++i) pad[i] = _pad[i];        /* :96-98 */
+                    probability = newp;                        /* :100 */
+                } else {
+                    mcio_pool_shift_rollback(c, vi, idx);      /* :102 */
+                }
+            } while (0);
+            /* ---- histogram  ref: montecarlo.jl:198-211 ---- */
+            for (int i = 0; i < N; ++i) {
+                double f2 = fabs(weights[i]) * fabs(weights[i]) / mcio_probability(c, i); /* :203 */
+                double wf2 = f2 * pad[i] / probability;                                   /* :204 */
+                for (int vi = 0; vi < npool; ++vi)                                        /* :205 */
+                    for (int pos = 1; pos <= c->dof[i * npool + vi]; ++pos)               /* :207 */
+                        pool_accumulate(c, vi, pos + c->pool_offset[vi], wf2);            /* :208 */
+            }
+            /* ---- measurement  ref: montecarlo.jl:213-232 ---- */
+            if (ne % measurefreq == 0 && (double)ne >= (double)steps / 100.0) { /* :213 */
+                for (int i = 0; i < N; ++i) {
+                    c->visited[i] += fabs(weights[i] * pad[i] * c->reweight[i]) / probability; /* :216 */
+                    relw[i] = weights[i] * pad[i] / probability;                               /* :218/:220 */
+                }
+                gather_x(c, x); /* measure() reads the current (accepted) variables */
+                measure(c, x, relw);
+                c->normalization += 1.0 * pad[norm] / probability;                   /* :229 */
+                c->visited[norm] += c->reweight[norm] * pad[norm] / probability;    /* :230 */
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * src/main.jl
+ * ---------------------------------------------------------------------------------------- */
+
+/* ref: main.jl:220-234 */
+void mcio_standardize_block(long neval, long nblock, long nworker, long *nevalperblock, long *block) {
+    if (nblock > nworker) nblock = (nblock / nworker) * nworker; /* :225-227 */
+    else nblock = nworker;                                       /* :229 */
+    *nevalperblock = neval / nblock;                             /* :232 */
+    *block = nblock;
+}
+
+/* ref: main.jl:296-320 (real observables) */
+void mcio_mean_std(const double *obs_sum, const double *obs_sq, long n, long block, double *mean, double *std) {
+    for (long o = 0; o < n; ++o) {
+        mean[o] = obs_sum[o] / (double)block; /* :317 */
+        if (block > 1) {                      /* :301 */
+            double v = (obs_sq[o] / (double)block - mean[o] * mean[o]) / (double)(block - 1); /* :308 */
+            std[o] = v < 0.0 ? 0.0 : sqrt(v); /* :297-299 */
+        } else {
+            std[o] = 0.0;                     /* :311 */
+        }
+    }
+}
+
+/* ref: statistics.jl:186-220.  iter_mean/iter_std are [niter][stride] rows, this averages column 0
+ * of the pointers given (caller offsets them).  init/max are 1-based like the reference. */
+void mcio_average(const double *iter_mean, const double *iter_std, long niter, long stride, long init, long max,
+                  double *mean, double *err, double *chi2) {
+    (void)niter;
+    if (max <= init) { /* :189-191 */
+        *mean = iter_mean[0];
+        *err = iter_std[0];
+        *chi2 = 0.0;
+        return;
+    }
+    double wsum = 0.0;
+    for (long i = init; i <= max; ++i) { /* :217 */
+        double s = iter_std[(i - 1) * stride] + 1.0e-10;
+        wsum += 1.0 / (s * s);
+    }
+    double mea = 0.0;
+    for (long i = init; i <= max; ++i) { /* :197 */
+        double s = iter_std[(i - 1) * stride] + 1.0e-10;
+        mea += iter_mean[(i - 1) * stride] * (1.0 / (s * s)) / wsum;
+    }
+    double c2 = 0.0;
+    if (max > 1) /* :199-203 */
+        for (long i = init; i <= max; ++i) {
+            double s = iter_std[(i - 1) * stride] + 1.0e-10;
+            double d = iter_mean[(i - 1) * stride] - mea;
+            c2 += (1.0 / (s * s)) * d * d;
+        }
+    *mean = mea;
+    *err = 1.0 / sqrt(wsum);                    /* :198 */
+    *chi2 = c2 / (double)((max - init + 1) - 1); /* :204 */
+}
+
+/* ref: main.jl:322-346 */
+void mcio_do_reweight(double *reweight, const double *visited, long nd, double gamma, const double *goal) {
+    double avgstep = 0.0;
+    for (long i = 0; i < nd; ++i) avgstep += visited[i]; /* :323 */
+    for (long i = 0; i < nd; ++i) {                      /* :324-331 */
+        if (visited[i] <= 1) reweight[i] *= pow(avgstep, gamma);
+        else reweight[i] *= pow(avgstep / visited[i], gamma);
+    }
+    if (goal) { /* :334-337 */
+        double gs = 0.0;
+        for (long i = 0; i < nd; ++i) gs += goal[i];
+        for (long i = 0; i < nd; ++i) reweight[i] *= goal[i] / gs;
+    }
+    double s = 0.0;
+    for (long i = 0; i < nd; ++i) s += reweight[i];
+    for (long i = 0; i < nd; ++i) reweight[i] /= s; /* :339 */
+}
+
+long mcio_packed_size(const mcio_config *c) {
+    long n = 2L * c->nobs + 2 + (c->Ni + 1);
+    for (int l = 0; l < c->nleaf; ++l) n += c->leaf[l].nbin;
+    return n;
+}
+
+mcio_result *mcio_result_create(int niter, int nobs, int Ni) {
+    mcio_result *r = (mcio_result *)calloc(1, sizeof(mcio_result));
+    r->niter = niter;
+    r->nobs = nobs;
+    r->Ni = Ni;
+    r->iter_mean = (double *)calloc((size_t)niter * nobs, sizeof(double));
+    r->iter_std = (double *)calloc((size_t)niter * nobs, sizeof(double));
+    r->mean = (double *)calloc((size_t)nobs, sizeof(double));
+    r->stdev = (double *)calloc((size_t)nobs, sizeof(double));
+    r->chi2 = (double *)calloc((size_t)nobs, sizeof(double));
+    return r;
+}
+
+void mcio_result_destroy(mcio_result *r) {
+    if (!r) return;
+    free(r->iter_mean); free(r->iter_std); free(r->mean); free(r->stdev); free(r->chi2);
+    free(r);
+}
+
+/* One iteration's worth of blocks [block_lo, block_hi) (ref: main.jl:144-180 and _block! :236-292).
+ * `c` plays summedConfig[1]: on return it holds the block-summed statistics (histograms, visited,
+ * normalization, neval) and its pools/grids are unchanged.  obs_sum/obs_sq accumulate block means.
+ * Block results are merged in block order, so the output does not depend on nthreads (the
+ * reference's thread-order merge, main.jl:170-174, differs from this only by reassociation and by
+ * (nthreads-1)*1e-10 in the histogram offsets). */
+static int run_blocks(mcio_config *c, int solver, mcio_integrand_fn f, const double *ud, long nevalperblock,
+                      long block_lo, long block_hi, uint32_t iteration, long measurefreq, uint64_t seed,
+                      int nthreads, long nchain, double *obs_sum, double *obs_sq) {
+    const long nb = block_hi - block_lo;
+    if (nb <= 0) return 0;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > nb) nthreads = (int)nb;
+    mcio_config **done = (mcio_config **)calloc((size_t)nb, sizeof(mcio_config *));
+    int err = 0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for (long b = 0; b < nb; ++b) {
+        mcio_config *cn = mcio_config_clone(c); /* main.jl:130 deepcopy per worker; here per block */
+        mcio_clear_statistics(cn);               /* main.jl:251 */
+        int rc;
+        if (solver == MCIO_VEGAS)
+            rc = mcio_vegas_block(cn, f, ud, seed, iteration, block_lo + b, nevalperblock, measurefreq); /* main.jl:257 */
+        else
+            rc = mcio_vegasmc_block(cn, f, ud, seed, iteration, block_lo + b, nevalperblock, measurefreq, nchain); /* main.jl:254 */
+        if (rc || !(cn->normalization > 0.0)) { /* main.jl:269-271 */
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            err = 1;
+        }
+        done[b] = cn;
+    }
+    mcio_clear_statistics(c); /* main.jl:149 */
+    for (long b = 0; b < nb; ++b) {
+        mcio_config *cn = done[b];
+        mcio_add_config(c, cn); /* main.jl:273 */
+        for (int o = 0; o < c->nobs; ++o) { /* main.jl:275-287 */
+            double m = cn->observable[o] / cn->normalization;
+            obs_sum[o] += m;
+            obs_sq[o] += m * m;
+        }
+        mcio_config_destroy(cn);
+    }
+    free(done);
+    return err;
+}
+
+static void pack(const mcio_config *c, const double *obs_sum, const double *obs_sq, double *out) {
+    long p = 0;
+    for (int o = 0; o < c->nobs; ++o) out[p++] = obs_sum[o];
+    for (int o = 0; o < c->nobs; ++o) out[p++] = obs_sq[o];
+    out[p++] = c->normalization;
+    out[p++] = (double)c->neval;
+    for (int i = 0; i < c->Ni + 1; ++i) out[p++] = c->visited[i];
+    for (int l = 0; l < c->nleaf; ++l)
+        for (int i = 0; i < c->leaf[l].nbin; ++i) out[p++] = c->leaf[l].hist[i];
+}
+
+int mcio_iteration(mcio_config *c, int solver, mcio_integrand_fn f, const double *ud,
+                   long nevalperblock, long block_lo, long block_hi, uint32_t iteration,
+                   long measurefreq, uint64_t seed, int nthreads, long nchain, double *packed_out) {
+    double *obs_sum = (double *)calloc((size_t)c->nobs, sizeof(double));
+    double *obs_sq = (double *)calloc((size_t)c->nobs, sizeof(double));
+    int rc = run_blocks(c, solver, f, ud, nevalperblock, block_lo, block_hi, iteration, measurefreq, seed, nthreads,
+                        nchain, obs_sum, obs_sq);
+    if (packed_out) pack(c, obs_sum, obs_sq, packed_out);
+    free(obs_sum);
+    free(obs_sq);
+    return rc;
+}
+
+/* ref: main.jl:71-218 (single process: mpi_nprocs() == 1) */
+int mcio_integrate(mcio_config *c, int solver, mcio_integrand_fn f, const double *ud, long neval,
+                   int niter, long block, int ignore, int adapt, double gamma, long measurefreq,
+                   uint64_t seed, int nthreads, long nchain, mcio_result *out) {
+    long nevalperblock;
+    if (!(neval > block)) return -2; /* :222 */
+    mcio_standardize_block(neval, block, 1, &nevalperblock, &block); /* :121 */
+    double *obs_sum = (double *)calloc((size_t)c->nobs, sizeof(double));
+    double *obs_sq = (double *)calloc((size_t)c->nobs, sizeof(double));
+    int rc = 0;
+    out->neval = 0;
+    for (int iter = 0; iter < niter; ++iter) { /* :142 */
+        for (int o = 0; o < c->nobs; ++o) obs_sum[o] = obs_sq[o] = 0.0; /* :144-148 */
+        rc |= run_blocks(c, solver, f, ud, nevalperblock, 0, block, (uint32_t)iter, measurefreq, seed, nthreads, nchain,
+                         obs_sum, obs_sq); /* :152-174 */
+        out->neval += c->neval;
+        if (solver == MCIO_VEGASMC) mcio_do_reweight(c->reweight, c->visited, c->Ni + 1, gamma, NULL); /* :183 */
+        if (adapt) mcio_train(c); /* :193-198 */
+        mcio_mean_std(obs_sum, obs_sq, c->nobs, block, out->iter_mean + (size_t)iter * c->nobs,
+                      out->iter_std + (size_t)iter * c->nobs); /* :203 */
+    }
+    for (int o = 0; o < c->nobs; ++o) /* :211 -> statistics.jl:24-55 */
+        mcio_average(out->iter_mean + o, out->iter_std + o, niter, c->nobs, ignore + 1, niter, &out->mean[o],
+                     &out->stdev[o], &out->chi2[o]);
+    free(obs_sum);
+    free(obs_sq);
+    return rc;
+}

@@ -1,0 +1,183 @@
+/*
+ * mci_oracle.h -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * Plain-C restatement of the VEGAS / VegasMC sampling path of
+ * numericalEFT/MCIntegration.jl v0.4.2 (reference mounted at /root/reference).
+ * Every function cites the reference file:line it follows.
+ *
+ * WHO MAY USE THIS: only tests/, __graft_entry__.smoke() and the `cpu_baseline`
+ * leg of bench.py.  The product (mcintegration.jl_amd/, include/mci.h) never
+ * links, imports or calls anything in oracle/.
+ *
+ * PINNING STATUS
+ *   - pinned against every deterministic known-answer the reference's own tests
+ *     hold for this path: Dist.locate (test/utility.jl:2-9), _maxdof
+ *     (test/utility.jl:14-15), probability/padding invariant
+ *     (test/utility.jl:30-55), _mean_std (test/statistics.jl:14-46), doReweight!
+ *     fixed point (test/mpi_test.jl:148-169), reduce semantics
+ *     (test/mpi_test.jl:73-146); hand-derived golden vectors for smooth/rescale/
+ *     train!/map-draw in tests/golden/; analytic k-sigma targets of
+ *     test/montecarlo.jl:298-387 and test/bubble.jl.
+ *   - same-seed, stream-dependent values are "parity unpinned": the reference
+ *     draws from Julia's Random.MersenneTwister (stdlib, unpinned version), Julia
+ *     is absent from this image, and no reference test fixes a seed.  The oracle
+ *     uses a Philox4x32-10 counter RNG instead, so agreement with the Julia
+ *     reference is statistical (k-sigma), by the reference's own standard
+ *     (test/runtests.jl:4-9).
+ */
+#ifndef MCI_ORACLE_H
+#define MCI_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCIO_TINY 4.940656458412465e-274 /* src/MCIntegration.jl:11  eps(0.0)*1e50 */
+
+enum { MCIO_CONTINUOUS = 0, MCIO_DISCRETE = 1 };
+enum { MCIO_VEGAS = 0, MCIO_VEGASMC = 1 };
+/* how Continuous/Discrete prob[idx] is maintained per draw */
+enum {
+    MCIO_PROB_CREATE = 0, /* prob = 1/(N*dx)        sampler.jl:303, vegas/montecarlo.jl:128-129 */
+    MCIO_PROB_SHIFT = 1   /* prob *= dx_old/dx_new  sampler.jl:383-384 (what Vegas.montecarlo runs) */
+};
+
+/* user integrand: x = flat draws (see mcio_config), w = Ni outputs, ud = userdata */
+typedef void (*mcio_integrand_fn)(const double *x, double *w, const double *ud);
+
+typedef struct {
+    int kind;           /* MCIO_CONTINUOUS | MCIO_DISCRETE */
+    int pool;           /* index into config.var this leaf belongs to */
+    double lower, upper;
+    int npts;           /* continuous: number of grid points (ninc, default 1000) */
+    int nbin;           /* continuous: npts-1 ; discrete: upper-lower+1 */
+    double alpha;
+    int adapt;
+    double *grid;         /* continuous [npts]   variable.jl:94 */
+    double *hist;         /* [nbin]              variable.jl:96, :279 */
+    double *accumulation; /* discrete [nbin+1]   variable.jl:280 */
+    double *distribution; /* discrete [nbin]     variable.jl:281 */
+    int P;                /* pool length incl. cache slot  variable.jl:139 */
+    double *data;         /* [P] */
+    long *gidx;           /* [P] 1-based like the reference */
+    double *prob;         /* [P] */
+} mcio_leaf;
+
+typedef struct {
+    int nleaf, npool, Ni; /* Ni = user integrands; Nd = Ni+1 (configuration.jl:153) */
+    mcio_leaf *leaf;      /* leaves of one pool are contiguous */
+    int *pool_leaf0;      /* [npool] first leaf of pool */
+    int *pool_nleaf;      /* [npool] 1 for Continuous/Discrete, >1 for CompositeVar */
+    int *pool_offset;     /* [npool] var.offset */
+    double **pool_prob;   /* [npool][P] CompositeVar.prob (variable.jl:399); aliases leaf prob when nleaf==1 */
+    double *pool_prob_cache; /* [npool] CompositeVar._prob_cache */
+    int *dof;             /* [(Ni+1)*npool], last row = 0 */
+    int *maxdof;          /* [npool] configuration.jl:229-236 */
+    int ndraw;            /* sum_vi maxdof[vi]*pool_nleaf[vi] : uniforms per Vegas sample */
+    int *draw_leaf;       /* [ndraw] leaf drawn at flat position k */
+    int *draw_slot;       /* [ndraw] 1-based slot idx (without offset) */
+    /* observables: integrand i owns obs[obs_off[i] .. +obs_nbin[i]); obs_bin_draw[i] = flat draw
+       index of the Discrete draw that selects the bin (example/bubble.jl:81-84) or -1 */
+    int nobs;
+    int *obs_off, *obs_nbin, *obs_bin_draw;
+    double *observable;   /* [nobs] */
+    double normalization;
+    long neval;
+    double *reweight;     /* [Ni+1] */
+    double *visited;      /* [Ni+1] */
+    double *propose;      /* [npool] propose[2,1,vi] (vegas_mc/updates.jl:90) */
+    double *accept;       /* [npool] */
+    int prob_mode;
+} mcio_config;
+
+typedef struct {
+    int niter, nobs, Ni;
+    double *iter_mean; /* [niter*nobs] */
+    double *iter_std;  /* [niter*nobs] */
+    double *mean;      /* [nobs] */
+    double *stdev;     /* [nobs] */
+    double *chi2;      /* [nobs] reduced chi2 */
+    long neval;
+} mcio_result;
+
+/* ---- RNG ---- */
+void mcio_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* uniform in [0,1) for (seed, stream, index, draw k) -- the stream contract shared with the HIP path */
+double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k);
+
+/* ---- src/distribution/common.jl ---- */
+long mcio_locate(const double *acc, long n, double p);            /* :8-36, 1-based result, -1 if outside */
+void mcio_smooth(const double *dist, long n, double factor, double *out); /* :43-54 */
+int mcio_rescale(double *dist, long n, double alpha);             /* :67-82, in place; !=0 on assert failure */
+
+/* ---- src/distribution/variable.jl ---- */
+int mcio_train_continuous(double *grid, long npts, double *hist, double alpha); /* :206-239 */
+int mcio_train_discrete(double *hist, long K, double alpha, double *distribution, double *accumulation); /* :369-382 */
+
+/* ---- config ---- */
+mcio_config *mcio_config_create(int nleaf, const int *kind, const int *pool, const double *lower,
+                                const double *upper, const int *npts, const double *alpha,
+                                const int *adapt, const int *pool_offset, int npool, int Ni,
+                                const int *dof /* [Ni*npool] */, const int *obs_nbin /* [Ni] or NULL */,
+                                const int *obs_bin_draw /* [Ni] or NULL */);
+void mcio_config_destroy(mcio_config *c);
+mcio_config *mcio_config_clone(const mcio_config *c);
+int mcio_set_grid(mcio_config *c, int leaf, const double *grid, int npts);
+int mcio_set_distribution(mcio_config *c, int leaf, const double *dist);
+void mcio_maxdof(const int *dof, int nd, int npool, int *out);    /* configuration.jl:229-236 */
+void mcio_clear_statistics(mcio_config *c);                       /* configuration.jl:238-250 */
+void mcio_add_config(mcio_config *c, const mcio_config *ic);      /* configuration.jl:252-262 */
+void mcio_train(mcio_config *c);                                  /* main.jl:194-195 */
+
+/* ---- sampler.jl ---- */
+double mcio_create(mcio_config *c, int leaf, int idx, double u);  /* :293-305, :13-22 (idx 1-based incl. offset) */
+double mcio_shift(mcio_config *c, int leaf, int idx, double u);   /* :336-386, :57-71 */
+void mcio_shift_rollback(mcio_config *c, int leaf, int idx);      /* :388-393, :73-77 */
+double mcio_pool_shift(mcio_config *c, int vi, int idx, const double *u); /* :431-440 ; u = pool_nleaf uniforms */
+double mcio_pool_create(mcio_config *c, int vi, int idx, const double *u);
+void mcio_pool_shift_rollback(mcio_config *c, int vi, int idx);   /* :441-446 */
+double mcio_total_probability(const mcio_config *c);              /* variable.jl:587-599 */
+double mcio_probability(const mcio_config *c, int i);             /* variable.jl:606-619 */
+double mcio_padding_probability(const mcio_config *c, int i);     /* variable.jl:628-641 */
+
+/* ---- solvers ---- */
+/* one Vegas block (vegas/montecarlo.jl:72-191).  Sample n of the block uses RNG index
+   block_index*neval + n, stream = iteration. */
+int mcio_vegas_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint64_t seed,
+                     uint32_t iteration, long block_index, long neval, long measurefreq);
+/* one VegasMC block (vegas_mc/montecarlo.jl:112-241) run as `nchain` independent chains of
+   neval/nchain steps; nchain=1 is the reference's single chain. */
+int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint64_t seed,
+                       uint32_t iteration, long block_index, long neval, long measurefreq,
+                       long nchain);
+
+/* ---- main.jl / statistics.jl ---- */
+void mcio_standardize_block(long neval, long nblock, long nworker, long *nevalperblock, long *block); /* main.jl:220-234 */
+void mcio_mean_std(const double *obs_sum, const double *obs_sq, long n, long block, double *mean, double *std); /* main.jl:296-320 */
+void mcio_average(const double *iter_mean, const double *iter_std, long niter, long stride, long init, long max,
+                  double *mean, double *err, double *chi2);       /* statistics.jl:186-220 (1-based init,max) */
+void mcio_do_reweight(double *reweight, const double *visited, long nd, double gamma, const double *goal); /* main.jl:322-346 */
+
+/* integrate loop (main.jl:71-218). nthreads>1 mirrors parallel=:thread (main.jl:153-158).
+   block_lo/block_hi select the blocks this worker runs (MPI-rank analogue, main.jl:152-166);
+   pass 0,-1 for all. If packed_out != NULL the loop stops after ONE iteration's sampling and writes
+   [obsSum(nobs) | obsSqSum(nobs) | normalization | neval | visited(Ni+1) | histograms] without training. */
+int mcio_integrate(mcio_config *c, int solver, mcio_integrand_fn f, const double *ud, long neval,
+                   int niter, long block, int ignore, int adapt, double gamma, long measurefreq,
+                   uint64_t seed, int nthreads, long nchain, mcio_result *out);
+int mcio_iteration(mcio_config *c, int solver, mcio_integrand_fn f, const double *ud,
+                   long nevalperblock, long block_lo, long block_hi, uint32_t iteration,
+                   long measurefreq, uint64_t seed, int nthreads, long nchain, double *packed_out);
+long mcio_packed_size(const mcio_config *c);
+mcio_result *mcio_result_create(int niter, int nobs, int Ni);
+void mcio_result_destroy(mcio_result *r);
+
+/* built-in integrands (independent C restatements of the catalog used by tests/bench) */
+mcio_integrand_fn mcio_builtin(const char *name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

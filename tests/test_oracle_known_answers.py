@@ -1,0 +1,227 @@
+"""Pins the CPU oracle (oracle/) against every deterministic known answer the reference's tests hold
+for the VEGAS path, against the hand-derived golden vectors in tests/golden/golden.json, and against
+the printed sample output of the reference (docs/src/index.md:40-49).  CPU only.
+
+Mirrors /root/reference/test/utility.jl, test/statistics.jl, test/mpi_test.jl:148-169.
+"""
+import math
+
+import numpy as np
+import pytest
+
+RTOL = 1e-13  # second implementation differs only by libm ulps (pow/log)
+
+
+def test_philox_kat(oracle, golden):
+    for v in golden["philox4x32_10"]:
+        assert oracle.philox(v["ctr"], v["key"]) == v["out"]
+
+
+def test_uniform_stream_contract(oracle):
+    # draw k uses words (2*(k&1), 2*(k&1)+1) of Philox(ctr=(idx lo, idx hi, k>>1, stream), key=seed)
+    seed, stream, idx = 0x1234567890ABCDEF, 17, (5 << 32) | 9
+    for k in range(6):
+        o = oracle.philox([idx & 0xFFFFFFFF, idx >> 32, k >> 1, stream], [seed & 0xFFFFFFFF, seed >> 32])
+        a, b = o[2 * (k & 1)], o[2 * (k & 1) + 1]
+        expect = (((b << 32) | a) >> 11) * 2.0 ** -53
+        assert oracle.uniform(seed, stream, idx, k) == expect
+        assert 0.0 <= expect < 1.0
+
+
+def test_locate(oracle, golden):
+    # test/utility.jl:2-9
+    g = golden["locate"]["grid"]
+    for p, expect in golden["locate"]["cases"]:
+        assert oracle.locate(g, p) == expect
+    assert oracle.locate(g, 0.5) == -1  # reference raises error() (common.jl:10-12)
+    assert oracle.locate(g, -1e-3) == -1
+
+
+def test_maxdof(oracle, golden):
+    # test/utility.jl:14-15
+    assert list(oracle.maxdof(golden["maxdof"]["dof"])) == golden["maxdof"]["expect"]
+
+
+def test_smooth_rescale_golden(oracle, golden):
+    for v in golden["smooth"].values():
+        np.testing.assert_allclose(oracle.smooth(v["inp"]), v["out"], rtol=RTOL)
+    for v in golden["rescale"].values():
+        np.testing.assert_allclose(oracle.rescale(v["inp"], v["alpha"]), v["out"], rtol=RTOL)
+
+
+def test_rescale_asserts(oracle):
+    with pytest.raises(AssertionError):
+        oracle.rescale([1.0, 0.0, 2.0], 2.0)  # common.jl:71
+    # length-1 passes through untouched (common.jl:68-70)
+    assert oracle.rescale([3.0], 2.0)[0] == 3.0
+
+
+def test_train_continuous_golden(oracle, golden):
+    for v in golden["train_continuous"].values():
+        out = oracle.train_continuous(v["grid"], v["hist"], v["alpha"])
+        np.testing.assert_allclose(out, v["out"], rtol=RTOL, atol=1e-15)
+        assert out[0] == v["grid"][0] and out[-1] == v["grid"][-1]  # variable.jl:217-218,235
+        assert np.all(np.diff(out) > 0)
+
+
+def test_train_continuous_flat_histogram_keeps_uniform_grid(oracle):
+    grid = np.linspace(0.0, 1.0, 1000)
+    out = oracle.train_continuous(grid, np.full(999, 1e-10), 2.0)
+    np.testing.assert_allclose(out, grid, atol=1e-12)
+
+
+def test_train_asserts(oracle):
+    grid = np.linspace(0.0, 1.0, 6)
+    with pytest.raises(AssertionError):
+        oracle.train_continuous(grid, [1.0, float("nan"), 1, 1, 1], 2.0)  # variable.jl:212
+    with pytest.raises(AssertionError):
+        oracle.train_continuous(grid, [1.0, 0.0, 1, 1, 1], 2.0)  # variable.jl:213
+
+
+def test_train_discrete_golden(oracle, golden):
+    for v in golden["train_discrete"].values():
+        dist, acc = oracle.train_discrete(v["hist"], v["alpha"])
+        np.testing.assert_allclose(dist, v["distribution"], rtol=RTOL)
+        np.testing.assert_allclose(acc, v["accumulation"], rtol=RTOL)
+        assert acc[0] == 0.0 and abs(acc[-1] - 1.0) < 1e-14  # variable.jl:379
+
+
+def _hand_config(oracle, golden, prob_mode=0):
+    # test/utility.jl:31-35 : X, Y Continuous with hand grids, Z = Discrete(1,6; distribution=rand(6))
+    h = golden["hand_grids"]
+    rng = np.random.default_rng(3)
+    leaves = [dict(kind=0, pool=0, lower=0.0, upper=1.0, grid=h["X"]),
+              dict(kind=0, pool=1, lower=0.0, upper=1.0, grid=h["Y"]),
+              dict(kind=1, pool=2, lower=1, upper=6, distribution=rng.random(6))]
+    return oracle.Config(leaves, h["dof"], prob_mode=prob_mode)
+
+
+def test_map_draw_golden(oracle, golden):
+    cfg = _hand_config(oracle, golden)
+    for leaf, key in ((0, "X"), (1, "Y")):
+        for v in golden["map_draw"][key]:
+            prop = cfg.create(leaf, 1, v["y"])
+            assert cfg.pool_data(leaf)[0] == pytest.approx(v["x"], rel=1e-15, abs=1e-300)
+            assert cfg.pool_gidx(leaf)[0] == v["gidx"]
+            assert cfg.pool_prob(leaf)[0] == pytest.approx(v["prob"], rel=1e-15)
+            assert prop == pytest.approx(1.0 / v["prob"], rel=1e-15)
+
+
+def test_shift_equals_create_and_rollback(oracle, golden):
+    # sampler.jl:383-384: prob *= dx_old/dx_new is algebraically 1/(N dx_new)
+    cfg = _hand_config(oracle, golden)
+    rng = np.random.default_rng(0)
+    cfg.create(0, 1, 0.7)
+    for _ in range(200):
+        u = rng.random()
+        before = (cfg.pool_data(0)[0], cfg.pool_gidx(0)[0], cfg.pool_prob(0)[0])
+        cfg.shift(0, 1, u)
+        g = np.array(golden["hand_grids"]["X"])
+        iy = cfg.pool_gidx(0)[0]
+        assert cfg.pool_prob(0)[0] == pytest.approx(1.0 / (3 * (g[iy] - g[iy - 1])), rel=1e-12)
+        if rng.random() < 0.5:
+            oracle.lib().mcio_shift_rollback(cfg.p, 0, 1)
+            after = (cfg.pool_data(0)[0], cfg.pool_gidx(0)[0], cfg.pool_prob(0)[0])
+            assert after == before
+
+
+def test_probability_invariant(oracle, golden):
+    # test/utility.jl:30-55: total_probability ~ probability(i) * padding_probability(i),
+    # after initialize! and again after shift!
+    cfg = _hand_config(oracle, golden, prob_mode=1)
+    c = cfg.c
+    rng = np.random.default_rng(5)
+    for vi in range(c.npool):
+        P = c.leaf[c.pool_leaf0[vi]].P
+        for idx in range(1, P - 2 + 1):  # variable.jl:576-580
+            cfg.pool_create(vi, idx, [rng.random()])
+    tot = cfg.total_probability()
+    for i in range(c.Ni):
+        assert tot == pytest.approx(cfg.probability(i) * cfg.padding_probability(i), rel=1e-12)
+    for vi in range(c.npool):
+        for i in range(1, c.maxdof[vi] + 1):
+            cfg.pool_shift(vi, i, [rng.random()])
+    tot = cfg.total_probability()
+    for i in range(c.Ni):
+        assert tot == pytest.approx(cfg.probability(i) * cfg.padding_probability(i), rel=1e-12)
+    # normalisation integrand (dof = 0): probability 1, padding = total (configuration.jl:153)
+    assert cfg.probability(c.Ni) == 1.0
+    assert cfg.padding_probability(c.Ni) == pytest.approx(tot, rel=1e-12)
+
+
+def test_pool_sizes(oracle):
+    # test/variable.jl:19-20 pool length size+1; configuration.jl:156-160 auto-resize to maxdof+2
+    cfg = oracle.Config([dict(kind=0, pool=0, lower=0.0, upper=1.0)], [[2]])
+    assert cfg.leaf(0).P == 17
+    cfg = oracle.Config([dict(kind=0, pool=0, lower=0.0, upper=1.0)], [[16]])
+    assert cfg.leaf(0).P == 18
+    assert cfg.leaf(0).nbin == 999 and cfg.leaf(0).npts == 1000  # variable.jl:137,147
+    g = cfg.grid(0)
+    assert g[0] == 0.0 and g[-1] == 1.0
+
+
+def test_mean_std(oracle, golden):
+    # test/statistics.jl:14-46: _mean_std == (mean, std/sqrt(block))
+    v = golden["mean_std"]
+    m, e = oracle.mean_std(v["obs_sum"], v["obs_sq"], v["block"])
+    np.testing.assert_allclose(m, v["mean"], rtol=1e-15)
+    np.testing.assert_allclose(e, v["std"], rtol=1e-13)
+    for k, series in enumerate(v["series"]):
+        s = np.array(series)
+        assert m[k] == pytest.approx(s.mean(), rel=1e-14)
+        assert e[k] == pytest.approx(s.std(ddof=1) / math.sqrt(len(s)), rel=1e-12)
+    m1, e1 = oracle.mean_std([0.3], [0.09], 1)  # block == 1 -> std 0 (main.jl:310-312)
+    assert e1[0] == 0.0
+
+
+def test_average_against_reference_printed_table(oracle, golden):
+    # docs/src/index.md:40-49: the reference's own printed per-iteration table; its "wgt average",
+    # error and reduced chi2 columns pin average() (statistics.jl:186-220) to the printed digits.
+    v = golden["average_docs_table"]
+    for mx in range(1, 11):
+        mean, err, chi2 = oracle.average(v["iter_mean"], v["iter_std"], init=v["init"], max=mx)
+        pm, pe, pc = v["printed"][mx - 1]
+        assert mean == pytest.approx(pm, abs=6e-8)
+        assert err == pytest.approx(pe, rel=2e-7)
+        assert chi2 == pytest.approx(pc, abs=6e-5)
+        cm, ce, cc = v["computed"][mx - 1]
+        assert (mean, err, chi2) == pytest.approx((cm, ce, cc), rel=1e-13)
+
+
+def test_do_reweight_fixed_point(oracle, golden):
+    # test/mpi_test.jl:148-169
+    v = golden["doreweight"]
+    r = np.array(v["reweight0"])
+    for _ in range(v["n_iterations"]):
+        r = oracle.do_reweight(r, v["visited"], v["gamma"], v["goal"])
+    np.testing.assert_allclose(r, v["expect"], rtol=v["rtol"])
+
+
+def test_standardize_block(oracle):
+    # main.jl:220-234
+    assert oracle.standardize_block(10000, 16, 1) == (625, 16)
+    assert oracle.standardize_block(10000, 16, 3) == (666, 15)
+    assert oracle.standardize_block(10000, 2, 8) == (1250, 8)
+
+
+def test_clear_and_add_statistics(oracle):
+    # configuration.jl:238-262, variable.jl:565-567; mirrors test/mpi_test.jl:73-109 (sum over workers)
+    leaves = [dict(kind=0, pool=0, lower=0.0, upper=1.0, npts=5),
+              dict(kind=0, pool=1, lower=0.0, upper=1.0, npts=4),
+              dict(kind=1, pool=1, lower=1, upper=3)]
+    a = oracle.Config(leaves, [[1, 1]])
+    b = oracle.Config(leaves, [[1, 1]])
+    a.clear_statistics()
+    b.clear_statistics()
+    assert np.all(a.hist(0) == 1e-10) and a.c.normalization == 1e-10 and a.c.neval == 0
+    assert np.all(a.visited == 1e-8)
+    for cfg, scale in ((a, 1.0), (b, 2.0)):
+        for i in range(3):
+            h = np.ctypeslib.as_array(cfg.leaf(i).hist, shape=(cfg.leaf(i).nbin,))
+            h[:] = scale * (1.1 + 0.1 * i)
+        cfg.c.normalization = scale
+        cfg.c.neval = int(10 * scale)
+    oracle.lib().mcio_add_config(a.p, b.p)
+    for i in range(3):
+        np.testing.assert_allclose(a.hist(i), 3.0 * (1.1 + 0.1 * i))
+    assert a.c.normalization == 3.0 and a.c.neval == 30

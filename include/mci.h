@@ -1,0 +1,171 @@
+/*
+ * mci.h -- C ABI of the MI355X-native VEGAS / VegasMC sampling engine (libmci_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of numericalEFT/MCIntegration.jl (v0.4.2): the
+ * per-iteration sample batch behind `integrate(...; solver=:vegas|:vegasmc)`.  The reference has no
+ * FFI of its own; the seam this library replaces is the solver dispatch inside `_block!`
+ * (reference src/main.jl:253-264) together with the iteration loop around it
+ * (src/main.jl:142-207).  Every entry point below names the reference code it stands in for.
+ * A Julia `ccall` binding (mcintegration.jl_amd/julia/MCIntegrationHIP.jl) and a Python ctypes
+ * binding (mcintegration.jl_amd/_lib.py) consume exactly these symbols; see INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns an int status (0 = MCI_OK)
+ * and leaves a message retrievable with mci_last_error(); the caller owns all input arrays (they
+ * are copied), the library owns device buffers until *_destroy.  One mci_ctx per host thread /
+ * process / GPU; calls on one mci_problem are not re-entrant.  All arithmetic is IEEE fp64.
+ */
+#ifndef MCI_H
+#define MCI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCI_OK 0
+#define MCI_ERR_INVALID 1       /* bad argument (reference: @assert / error() in the ctor paths) */
+#define MCI_ERR_HIP 2           /* HIP runtime / hiprtc failure */
+#define MCI_ERR_COMPILE 3       /* integrand source failed to compile */
+#define MCI_ERR_NORMALIZATION 4 /* "Block normalization ... is not positively defined!"  main.jl:269-271 */
+#define MCI_ERR_HISTOGRAM 5     /* "histogram should be all finite / positive"  variable.jl:212-213, common.jl:71,79 */
+#define MCI_ERR_COMM 6          /* RCCL failure */
+#define MCI_ERR_NO_DEVICE 7     /* no HIP device: the product path never falls back to the CPU */
+
+enum { MCI_CONTINUOUS = 0, MCI_DISCRETE = 1 }; /* Dist.Continuous variable.jl:87-99 / Dist.Discrete :272-284 */
+enum { MCI_VEGAS = 0, MCI_VEGASMC = 1 };       /* solver=:vegas main.jl:256 / :vegasmc main.jl:253 */
+
+typedef struct mci_ctx mci_ctx;
+typedef struct mci_problem mci_problem;
+
+/* One leaf variable: a `Continuous(lower, upper; alpha, adapt, ninc, grid)` (variable.jl:137-153) or a
+ * `Discrete(lower, upper; distribution, alpha, adapt)` (variable.jl:299-325).  Leaves that share `pool`
+ * and number more than one form a `CompositeVar` (variable.jl:397-427). */
+typedef struct {
+    int32_t kind;       /* MCI_CONTINUOUS | MCI_DISCRETE */
+    int32_t pool;       /* index into Configuration.var */
+    double lower, upper;
+    int32_t npoints;    /* continuous: grid points `ninc` (default 1000 => 999 increments); discrete: ignored */
+    double alpha;       /* learning rate (default 2.0) */
+    int32_t adapt;
+    const double *init; /* optional: continuous grid[npoints] | discrete distribution[upper-lower+1]; NULL = default */
+} mci_leaf_desc;
+
+/* `Configuration(; var, dof, obs, ...)` (configuration.jl:105-194). */
+typedef struct {
+    int32_t nleaf;
+    const mci_leaf_desc *leaves; /* leaves of one pool must be contiguous */
+    int32_t npool;
+    int32_t nintegrand;          /* N user integrands; the normalisation integrand (configuration.jl:153) is implicit */
+    const int32_t *dof;          /* [nintegrand*npool] row-major: dof[i][vi] */
+    const int32_t *obs_nbin;     /* [nintegrand] or NULL(=1 each): length of observable i (`obs` kwarg) */
+    const int32_t *obs_bin_draw; /* [nintegrand] or NULL(=-1): flat draw index of the Discrete draw that selects the
+                                    bin of observable i -- the `measure` of example/bubble.jl:81-84; -1 = default
+                                    measure (vegas/montecarlo.jl:151-153) */
+} mci_problem_desc;
+
+/* `integrate` keyword arguments (main.jl:71-90). */
+typedef struct {
+    int32_t solver;      /* MCI_VEGAS | MCI_VEGASMC */
+    int64_t neval;       /* evaluations per iteration (summed over all ranks) */
+    int32_t niter;
+    int64_t block;       /* statistical blocks per iteration, all ranks (standardised like main.jl:220-234) */
+    int32_t ignore;      /* iterations excluded from the final average; <0 = (adapt ? 1 : 0) */
+    int32_t adapt;
+    double gamma;        /* reweight learning rate (vegasmc) */
+    int64_t measurefreq;
+    uint64_t seed;
+    int64_t nchain;      /* vegasmc: independent chains per block (1 = the reference's single chain); 0 = auto */
+    int32_t first_iteration; /* RNG stream offset so that a resumed run (config=res.config) draws fresh numbers */
+} mci_integrate_args;
+
+/* `Result` (statistics.jl:16-63).  All arrays are caller-allocated. */
+typedef struct {
+    int32_t niter, nobs;
+    double *iter_mean; /* [niter*nobs] per-iteration mean  (main.jl:203) */
+    double *iter_std;  /* [niter*nobs] per-iteration std */
+    double *mean;      /* [nobs] inverse-variance weighted average (statistics.jl:186-220) */
+    double *stdev;     /* [nobs] */
+    double *chi2;      /* [nobs] reduced chi2 */
+    int64_t neval;     /* evaluations actually performed, all iterations, this rank's view after reduction */
+    double seconds;    /* wall time of the iteration loop (kernels + train + all-reduce) */
+} mci_result;
+
+/* ---- context: HIP device + stream (+ RCCL communicator); replaces MPI.Init, main.jl:113-114 ---- */
+int mci_ctx_create(int32_t device, mci_ctx **out);
+int mci_ctx_destroy(mci_ctx *ctx);
+const char *mci_last_error(void);             /* thread-local message of the last failing call */
+int mci_device_count(int32_t *count);
+void *mci_ctx_stream(mci_ctx *ctx);           /* hipStream_t, for callers that order their own work after ours */
+
+/* RCCL over xGMI: replaces MPIreduce/MPIbcast (utility/parallel.jl:25-99; call sites main.jl:177-188,
+ * configuration.jl:264-321).  Rank 0 creates the 128-byte id and ships it to the other ranks by any
+ * means it has (torch.distributed store, MPI.bcast, a file). */
+int mci_comm_unique_id(void *id128);
+int mci_comm_init(mci_ctx *ctx, int32_t rank, int32_t nranks, const void *id128);
+int mci_comm_rank(const mci_ctx *ctx, int32_t *rank, int32_t *nranks);
+
+/* ---- problem = Configuration + integrand ---- */
+int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *desc, mci_problem **out);
+int mci_problem_destroy(mci_problem *prob);
+/* The integrand closure (vegas/montecarlo.jl:140-144) as a HIP C++ function body:
+ *     const double* x  -- flat draws in the reference's draw order (pool, slot, leaf), 0-based
+ *     double*       w  -- nintegrand outputs
+ *     const double* ud -- userdata (configuration.jl:113)
+ * JIT-compiled with hiprtc for gfx950 together with the hand-written kernels. */
+int mci_set_integrand_source(mci_problem *prob, const char *body, const double *userdata, int32_t nuserdata);
+int mci_compile(mci_problem *prob);          /* JIT or kernel-cache load; implicit on first run */
+int mci_set_launch(mci_problem *prob, int32_t threads_per_workgroup, int32_t workgroups_per_block);
+int mci_problem_info(const mci_problem *prob, int32_t *ndraw, int32_t *nobs, int64_t *packed_size,
+                     int32_t *table_mode, int64_t *lds_bytes);
+
+/* ---- one iteration, step by step (what mci_integrate runs; also the testing seam) ---- */
+/* blocks [block_lo, block_hi) of `_block!` (main.jl:236-292) on this GPU; leaves the local packed buffer
+ * [obsSum(nobs) | obsSqSum(nobs) | normalization | neval | visited(N+1) | histograms] on the device */
+int mci_iteration_run(mci_problem *prob, int32_t solver, int64_t neval_per_block, int64_t block_lo,
+                      int64_t block_hi, int32_t iteration, uint64_t seed, int64_t measurefreq, int64_t nchain);
+/* sum the packed buffer over ranks: MPIreduceConfig!+MPIbcastConfig! (configuration.jl:264-321) as ONE
+ * ncclAllReduce; no-op without a communicator */
+int mci_iteration_reduce(mci_problem *prob);
+/* doReweight! (main.jl:322-346, vegasmc only), train! + clearStatistics (main.jl:190-199), and the
+ * iteration's (mean, std) = _mean_std (main.jl:296-320).  mean/std may be NULL. */
+int mci_iteration_finish(mci_problem *prob, int32_t solver, int64_t block_total, int32_t adapt, double gamma,
+                         double *mean, double *std);
+/* the whole loop (main.jl:142-218) */
+int mci_integrate(mci_problem *prob, const mci_integrate_args *args, mci_result *result);
+
+/* ---- state access: res.config.var[i].grid etc. (docs/src/index.md:129) and external reducers ---- */
+int mci_get_packed(mci_problem *prob, double *out, int64_t n);
+int mci_set_packed(mci_problem *prob, const double *in, int64_t n);
+void *mci_packed_device_ptr(mci_problem *prob);
+int mci_get_grid(mci_problem *prob, int32_t leaf, double *out, int32_t n);
+int mci_set_grid(mci_problem *prob, int32_t leaf, const double *grid, int32_t n);
+int mci_get_distribution(mci_problem *prob, int32_t leaf, double *distribution, double *accumulation, int32_t k);
+int mci_set_distribution(mci_problem *prob, int32_t leaf, const double *distribution, int32_t k);
+int mci_get_reweight(mci_problem *prob, double *out, int32_t n);
+int mci_set_reweight(mci_problem *prob, const double *in, int32_t n);
+/* Dist.train! on the histograms currently in the packed buffer (variable.jl:206-239, :369-382) */
+int mci_train(mci_problem *prob);
+/* the adaptive map alone (sampler.jl:293-305, :13-22) + integrand: first `n` samples of block `block_index`
+ * of `iteration`, written to host arrays x[n*ndraw], jac[n], w[n*nintegrand] */
+int mci_sample_dump(mci_problem *prob, int32_t iteration, uint64_t seed, int64_t neval_per_block,
+                    int64_t block_index, int64_t n, double *x, double *jac, double *w);
+/* HIP-event time of the last sampling kernel launch (ms) and its launch geometry */
+int mci_last_kernel_ms(mci_problem *prob, float *ms, int32_t *workgroups, int32_t *threads);
+
+/* ---- host-side statistics of the path (pure functions, no GPU needed) ---- */
+void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64_t *nevalperblock,
+                           int64_t *block);                                          /* main.jl:220-234 */
+void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out);        /* configuration.jl:229-236 */
+void mci_mean_std(const double *obs_sum, const double *obs_sq, int64_t n, int64_t block, double *mean,
+                  double *std);                                                      /* main.jl:296-320 */
+void mci_average(const double *iter_mean, const double *iter_std, int64_t stride, int64_t init, int64_t max,
+                 double *mean, double *err, double *chi2);                           /* statistics.jl:186-220 */
+void mci_do_reweight(double *reweight, const double *visited, int64_t nd, double gamma,
+                     const double *goal);                                            /* main.jl:322-346 */
+const char *mci_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCI_H */

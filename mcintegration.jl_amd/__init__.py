@@ -1,0 +1,20 @@
+"""Host-side mirror of MCIntegration.jl's public surface for the VEGAS / VegasMC path, driving the
+MI355X engine (libmci_hip.so) through its C ABI (include/mci.h).
+
+Same names and keyword meaning as the reference (src/MCIntegration.jl:20-47):
+    integrate, Configuration, Continuous, Discrete, CompositeVar, Result, report, Dist
+The integrand is HIP C++ source (a string or an `Integrand`) instead of a Julia closure: it is
+JIT-compiled into the sample-batch kernel, exactly where Julia would inline the closure.
+"""
+from . import catalog  # noqa: F401
+from ._lib import MCIError, lib, library_path  # noqa: F401
+from .configuration import Configuration  # noqa: F401
+from .engine import Engine  # noqa: F401
+from .integrand import Integrand, bin_by  # noqa: F401
+from .integrate import integrate, prefill_kernel_cache  # noqa: F401
+from .statistics import Result, average, mean_std, report  # noqa: F401
+from .variables import CompositeVar, Continuous, Discrete  # noqa: F401
+from . import variables as Dist  # noqa: F401  (reference: module Dist)
+
+__all__ = ["integrate", "Configuration", "Continuous", "Discrete", "CompositeVar", "Result", "report",
+           "Dist", "Engine", "Integrand", "bin_by", "catalog", "MCIError"]

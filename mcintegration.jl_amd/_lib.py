@@ -1,0 +1,113 @@
+"""ctypes binding of include/mci.h.  The library is built in-tree by __graft_entry__.build();
+there is no Python/CPU fallback: if it is missing, importing the engine fails loudly."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_PKG, "lib", "libmci_hip.so")
+
+MCI_OK = 0
+ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "COMPILE", 4: "NORMALIZATION", 5: "HISTOGRAM", 6: "COMM", 7: "NO_DEVICE"}
+CONTINUOUS, DISCRETE = 0, 1
+VEGAS, VEGASMC = 0, 1
+SOLVERS = {"vegas": VEGAS, "vegasmc": VEGASMC, VEGAS: VEGAS, VEGASMC: VEGASMC}
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class MCIError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("[MCI_ERR_%s] %s" % (ERR_NAMES.get(code, code), msg))
+        self.code = code
+
+
+class LeafDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pool", C.c_int32), ("lower", C.c_double), ("upper", C.c_double),
+                ("npoints", C.c_int32), ("alpha", C.c_double), ("adapt", C.c_int32), ("init", c_double_p)]
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [("nleaf", C.c_int32), ("leaves", C.POINTER(LeafDesc)), ("npool", C.c_int32),
+                ("nintegrand", C.c_int32), ("dof", c_int32_p), ("obs_nbin", c_int32_p), ("obs_bin_draw", c_int32_p)]
+
+
+class IntegrateArgs(C.Structure):
+    _fields_ = [("solver", C.c_int32), ("neval", C.c_int64), ("niter", C.c_int32), ("block", C.c_int64),
+                ("ignore", C.c_int32), ("adapt", C.c_int32), ("gamma", C.c_double), ("measurefreq", C.c_int64),
+                ("seed", C.c_uint64), ("nchain", C.c_int64), ("first_iteration", C.c_int32)]
+
+
+class ResultC(C.Structure):
+    _fields_ = [("niter", C.c_int32), ("nobs", C.c_int32), ("iter_mean", c_double_p), ("iter_std", c_double_p),
+                ("mean", c_double_p), ("stdev", c_double_p), ("chi2", c_double_p), ("neval", C.c_int64),
+                ("seconds", C.c_double)]
+
+
+# every symbol include/mci.h declares: (name, restype, argtypes)
+_VP = C.c_void_p
+SIGNATURES = [
+    ("mci_ctx_create", C.c_int, [C.c_int32, C.POINTER(_VP)]),
+    ("mci_ctx_destroy", C.c_int, [_VP]),
+    ("mci_last_error", C.c_char_p, []),
+    ("mci_device_count", C.c_int, [c_int32_p]),
+    ("mci_ctx_stream", _VP, [_VP]),
+    ("mci_comm_unique_id", C.c_int, [_VP]),
+    ("mci_comm_init", C.c_int, [_VP, C.c_int32, C.c_int32, _VP]),
+    ("mci_comm_rank", C.c_int, [_VP, c_int32_p, c_int32_p]),
+    ("mci_problem_create", C.c_int, [_VP, C.POINTER(ProblemDesc), C.POINTER(_VP)]),
+    ("mci_problem_destroy", C.c_int, [_VP]),
+    ("mci_set_integrand_source", C.c_int, [_VP, C.c_char_p, c_double_p, C.c_int32]),
+    ("mci_compile", C.c_int, [_VP]),
+    ("mci_set_launch", C.c_int, [_VP, C.c_int32, C.c_int32]),
+    ("mci_problem_info", C.c_int, [_VP, c_int32_p, c_int32_p, C.POINTER(C.c_int64), c_int32_p, C.POINTER(C.c_int64)]),
+    ("mci_iteration_run", C.c_int, [_VP, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, C.c_int64]),
+    ("mci_iteration_reduce", C.c_int, [_VP]),
+    ("mci_iteration_finish", C.c_int, [_VP, C.c_int32, C.c_int64, C.c_int32, C.c_double, c_double_p, c_double_p]),
+    ("mci_integrate", C.c_int, [_VP, C.POINTER(IntegrateArgs), C.POINTER(ResultC)]),
+    ("mci_get_packed", C.c_int, [_VP, c_double_p, C.c_int64]),
+    ("mci_set_packed", C.c_int, [_VP, c_double_p, C.c_int64]),
+    ("mci_packed_device_ptr", _VP, [_VP]),
+    ("mci_get_grid", C.c_int, [_VP, C.c_int32, c_double_p, C.c_int32]),
+    ("mci_set_grid", C.c_int, [_VP, C.c_int32, c_double_p, C.c_int32]),
+    ("mci_get_distribution", C.c_int, [_VP, C.c_int32, c_double_p, c_double_p, C.c_int32]),
+    ("mci_set_distribution", C.c_int, [_VP, C.c_int32, c_double_p, C.c_int32]),
+    ("mci_get_reweight", C.c_int, [_VP, c_double_p, C.c_int32]),
+    ("mci_set_reweight", C.c_int, [_VP, c_double_p, C.c_int32]),
+    ("mci_train", C.c_int, [_VP]),
+    ("mci_sample_dump", C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    ("mci_last_kernel_ms", C.c_int, [_VP, C.POINTER(C.c_float), c_int32_p, c_int32_p]),
+    ("mci_standardize_block", None, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("mci_maxdof", None, [c_int32_p, C.c_int32, C.c_int32, c_int32_p]),
+    ("mci_mean_std", None, [c_double_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p]),
+    ("mci_average", None, [c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    ("mci_do_reweight", None, [c_double_p, c_double_p, C.c_int64, C.c_double, c_double_p]),
+    ("mci_version", C.c_char_p, []),
+]
+
+_lib = None
+
+
+def library_path():
+    return _SO
+
+
+def lib():
+    """Load libmci_hip.so (fails loudly when it has not been built: no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ImportError("%s is missing: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "
+                              "the MI355X engine has no Python/CPU fallback" % _SO)
+        L = C.CDLL(_SO, mode=C.RTLD_GLOBAL)
+        for name, res, args in SIGNATURES:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != MCI_OK:
+        raise MCIError(rc, lib().mci_last_error().decode(errors="replace"))

@@ -1,0 +1,115 @@
+"""`Configuration(; var, dof, obs, reweight, seed, userdata, ...)`  reference src/configuration.jl:105-194."""
+import numpy as np
+
+from .integrand import bin_by
+from .variables import CompositeVar, ContinuousVar, DiscreteVar
+
+
+def _normalize_dof(dof, nvar):
+    """reference configuration.jl:134-151"""
+    if isinstance(dof, (int, np.integer)):            # one integral with one variable   :134-136
+        assert nvar == 1, "Only one type of variable is allowed when dof is an integer"
+        return [[int(dof)]]
+    if isinstance(dof, np.ndarray) and dof.ndim == 2:  # each column is a dof for one integral   :139-140
+        return [[int(v) for v in dof[:, i]] for i in range(dof.shape[1])]
+    dof = list(dof)
+    if all(isinstance(d, (int, np.integer)) for d in dof):   # [2, 3] -> one integrand per element   :146-147
+        return [[int(d)] for d in dof]
+    if all(isinstance(d, (list, tuple, np.ndarray)) for d in dof):  # :142-145
+        return [[int(v) for v in d] for d in dof]
+    raise TypeError("Configuration.dof should be a Vector{Int} or Tuple{Int, ..., Int} or Vector{Vector{Int}} "
+                    "or Vector{Tuple{Int, ..., Int}} to avoid mistakes.")   # :149
+
+
+class Configuration:
+    """Holds the problem description; `bind()` attaches the device-resident Engine state (trained grids
+    survive across `integrate(...; config=res.config)` calls, docs/src/index.md:129)."""
+
+    def __init__(self, var=None, dof=None, type=float, obs=None, reweight=None, seed=None, neighbor=None,
+                 userdata=None, **kwargs):
+        from .variables import Continuous
+        if var is None:
+            var = (Continuous(0.0, 1.0),)                                  # :106
+        if isinstance(var, (ContinuousVar, DiscreteVar, CompositeVar)):    # :116-117
+            var = (var,)
+        var = tuple(var)                                                   # :120-122
+        assert all(isinstance(v, (ContinuousVar, DiscreteVar, CompositeVar)) for v in var), \
+            "All elements in var should be derived from the abstract type Variable"   # :119
+        self.var = var
+        nv = len(var)
+        if dof is None:
+            dof = [[1] * nv]                                               # :107
+        self.dof = _normalize_dof(dof, nv)
+        assert all(len(d) == nv for d in self.dof), "Each element of `dof` should have the same dimension as `var`"  # :166
+        self.N = len(self.dof)
+        assert self.N >= 1, "At least one integrand is required."        # :163
+        self.maxdof = [max(d[v] for d in self.dof) for v in range(nv)]     # :229-236 (the dof=0 normalisation row never wins)
+        for v, mx in zip(var, self.maxdof):                                # :156-160 resize pools to maxdof+2
+            if mx + v.offset >= v.size - 2:
+                v.size = mx + 2 + v.offset
+                if isinstance(v, CompositeVar):
+                    for leaf in v.vars:
+                        leaf.size = v.size
+        self.type = type
+        if obs is None:
+            obs = [0.0] * self.N                                           # :109
+        assert len(obs) == self.N, "The number of observables should be equal to the number of integrands"  # :168
+        self.obs_nbin = [int(np.size(o)) for o in obs]
+        self.obs_is_array = [np.ndim(o) > 0 for o in obs]
+        if reweight is None:
+            reweight = np.ones(self.N + 1)                                 # :110
+        reweight = np.asarray(reweight, dtype=np.float64)
+        assert len(reweight) == self.N + 1, "Wrong reweight vector size! Note that the last element in reweight vector is for the normalization diagram."  # :174
+        assert np.all(reweight > 0), "All reweight factors should be positive."   # :175
+        self._reweight0 = reweight / reweight.sum()                        # :173
+        self.seed = int(np.random.SeedSequence().entropy % 1000000) + 1 if seed is None else int(seed)  # :111
+        self.userdata = userdata
+        self.neighbor = neighbor
+        self.norm = self.N + 1                                             # :177
+        self.neval = 0
+        self.normalization = 1.0e-10                                       # :179
+        self.iterations_done = 0     # RNG stream offset for resumed runs
+        self._engine = None
+        self._engine_key = None
+        # flat leaves
+        self.leaves, self.leaf_pool = [], []
+        for vi, v in enumerate(var):
+            for leaf in (v.vars if isinstance(v, CompositeVar) else (v,)):
+                self.leaves.append(leaf)
+                self.leaf_pool.append(vi)
+
+    # ---- derived layout -----------------------------------------------------------------------
+    def draw_index(self, pool, slot=0, leaf=0):
+        """flat position of (pool, slot, leaf) in the integrand's x[] (draw order: pool, slot, leaf)"""
+        k = 0
+        for vi, v in enumerate(self.var):
+            nl = len(v.vars) if isinstance(v, CompositeVar) else 1
+            if vi == pool:
+                assert slot < self.maxdof[vi] and leaf < nl
+                return k + slot * nl + leaf
+            k += self.maxdof[vi] * nl
+        raise IndexError(pool)
+
+    @property
+    def ndraw(self):
+        return sum(self.maxdof[vi] * (len(v.vars) if isinstance(v, CompositeVar) else 1) for vi, v in enumerate(self.var))
+
+    def obs_bin_draw(self, measure):
+        if measure is None:
+            assert all(n == 1 for n in self.obs_nbin), \
+                "the default measure can only handle observable as Vector with N scalar elements!"   # vegas/montecarlo.jl:104
+            return [-1] * self.N
+        if isinstance(measure, bin_by):
+            k = self.draw_index(measure.pool, measure.slot, measure.leaf)
+            return [k if n > 1 else -1 for n in self.obs_nbin]
+        raise TypeError("measure must be None or mcintegration_jl_amd.bin_by(pool): device-side measures are declarative")
+
+    @property
+    def reweight(self):
+        if self._engine is not None:
+            return self._engine.reweight()
+        return self._reweight0.copy()
+
+    def __repr__(self):
+        return "Configuration for %d integrands involves %d types of variables.\nNumber of variables for each integrand: %s.\n" % (
+            self.N, len(self.var), self.dof)

@@ -1,0 +1,908 @@
+// mci_api.hip -- host core of libmci_hip.so: the C ABI of include/mci.h.
+//
+// Owns: the Configuration analogue (src/configuration.jl:105-194), the device-resident state (grids,
+// distributions, histograms, packed statistics), the per-iteration launch chain
+//     sample batch (JIT, mci_device.h) -> merge (k_hist_stage1, k_finalize) -> RCCL all-reduce -> k_train
+// and the iteration loop + Result statistics (src/main.jl:142-218, :296-320, src/statistics.jl:186-220).
+// There is NO CPU fallback: without a HIP device every compute entry point fails with MCI_ERR_NO_DEVICE.
+#include "../../include/mci.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mci_device.h" // BatchArgs / DumpArgs (the templates themselves are instantiated by the JIT)
+#include "mci_jit.h"
+#include "mci_static_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[4096];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(x)                                                                                           \
+    do {                                                                                                    \
+        hipError_t e_ = (x);                                                                                \
+        if (e_ != hipSuccess) return fail(MCI_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- RCCL, loaded lazily so that single-GPU use never touches it -----------------------------------
+struct Id128 { char b[128]; }; // ncclUniqueId (rccl.h:43)
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128 /* by value */, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+const int kNcclFloat64 = 8, kNcclSum = 0; // ncclDouble, ncclSum (rccl.h)
+
+int rccl_load() {
+    if (g_rccl.h) return MCI_OK;
+    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(MCI_ERR_COMM, "cannot load librccl.so: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void **, int, Id128, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(MCI_ERR_COMM, "librccl.so lacks the nccl* entry points");
+    g_rccl.h = h;
+    return MCI_OK;
+}
+
+} // namespace
+
+struct mci_ctx {
+    int device = -1;
+    bool offline = false; // compile-only context (no GPU): lets build() pre-fill the kernel cache
+    hipStream_t stream = nullptr;
+    void *comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+
+namespace {
+struct Leaf {
+    int kind, pool, npts, nbin, adapt, eoff, doff, boff;
+    double lower, upper, alpha;
+};
+} // namespace
+
+struct mci_problem {
+    mci_ctx *ctx = nullptr;
+    std::vector<Leaf> leaves;
+    int npool = 0, ni = 0;
+    std::vector<int> dof, maxdof, pool_leaf0, pool_nleaf;
+    mcijit::ProblemShape shape;
+    int nstat = 0;
+    int64_t packed_n = 0;
+    int64_t lds_bytes = 0;
+    // host mirrors of the tables (uploaded at create / set_*)
+    std::vector<double> h_edges, h_dacc, h_ddist, h_reweight, h_ud;
+    // device
+    double *d_edges = nullptr, *d_dacc = nullptr, *d_ddist = nullptr, *d_reweight = nullptr, *d_ud = nullptr;
+    double *d_part_cols = nullptr, *d_part_hist = nullptr, *d_ghist = nullptr, *d_stage1 = nullptr, *d_packed = nullptr;
+    double *d_scratch = nullptr, *d_iterlog = nullptr, *d_dump = nullptr;
+    int *d_status = nullptr;
+    mci::LeafDev *d_leaves = nullptr;
+    int64_t cap_wg = 0, cap_blocks = 0, cap_iter = 0, cap_dump = 0;
+    // kernels
+    hipModule_t module = nullptr;
+    hipFunction_t f_vegas = nullptr, f_vegasmc = nullptr, f_dump = nullptr;
+    bool compiled = false;
+    int threads = 256, wg_per_block = 0; // 0 = auto
+    // last launch
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int last_wg = 0, last_threads = 0, last_nblocks = 0;
+    int log_row = 0;
+    static const int kGroups = 32;
+};
+
+namespace {
+
+int upload(mci_problem *p) {
+    if (p->ctx->offline) return MCI_OK;
+    auto up = [&](double *&d, const std::vector<double> &h) -> int {
+        size_t n = h.size() ? h.size() : 1;
+        if (!d) HIPCHK(hipMalloc((void **)&d, n * sizeof(double)));
+        if (h.size()) HIPCHK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
+        return MCI_OK;
+    };
+    int rc;
+    if ((rc = up(p->d_edges, p->h_edges))) return rc;
+    if ((rc = up(p->d_dacc, p->h_dacc))) return rc;
+    if ((rc = up(p->d_ddist, p->h_ddist))) return rc;
+    if ((rc = up(p->d_reweight, p->h_reweight))) return rc;
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return MCI_OK;
+}
+
+int ensure_capacity(mci_problem *p, int64_t nwg, int64_t nblocks) {
+    const auto &s = p->shape;
+    if (nwg > p->cap_wg) {
+        if (p->d_part_cols) hipFree(p->d_part_cols);
+        if (p->d_part_hist) hipFree(p->d_part_hist);
+        p->d_part_cols = p->d_part_hist = nullptr;
+        HIPCHK(hipMalloc((void **)&p->d_part_cols, (size_t)nwg * s.ncols * sizeof(double)));
+        if (s.table_mode == 0) HIPCHK(hipMalloc((void **)&p->d_part_hist, (size_t)nwg * (s.nbin ? s.nbin : 1) * sizeof(double)));
+        p->cap_wg = nwg;
+    }
+    if (nblocks > p->cap_blocks) {
+        if (p->d_scratch) hipFree(p->d_scratch);
+        p->d_scratch = nullptr;
+        HIPCHK(hipMalloc((void **)&p->d_scratch, (size_t)nblocks * s.ncols * sizeof(double)));
+        p->cap_blocks = nblocks;
+    }
+    return MCI_OK;
+}
+
+int check_status(mci_problem *p) {
+    int st = 0;
+    HIPCHK(hipMemcpyAsync(&st, p->d_status, sizeof(int), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    if (!st) return MCI_OK;
+    HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int), p->ctx->stream));
+    if (st & mci::ST_NORMALIZATION) return fail(MCI_ERR_NORMALIZATION, "Block normalization is not positively defined!");
+    if (st & mci::ST_HIST_NONFINITE) return fail(MCI_ERR_HISTOGRAM, "histogram should be all finite");
+    if (st & mci::ST_HIST_NONPOSITIVE) return fail(MCI_ERR_HISTOGRAM, "histogram should be all positive and non-zero");
+    return fail(MCI_ERR_HISTOGRAM, "distribution is not all finite");
+}
+
+} // namespace
+
+extern "C" {
+
+const char *mci_last_error(void) { return g_err.c_str(); }
+const char *mci_version(void) { return "mci-hip 0.1 (gfx950)"; }
+
+int mci_device_count(int32_t *count) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return MCI_OK;
+}
+
+int mci_ctx_create(int32_t device, mci_ctx **out) {
+    if (!out) return fail(MCI_ERR_INVALID, "out is NULL");
+    mci_ctx *c = new mci_ctx();
+    if (device < 0) { // offline / compile-only
+        c->offline = true;
+        *out = c;
+        return MCI_OK;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        delete c;
+        return fail(MCI_ERR_NO_DEVICE, "no HIP device visible: the MI355X path has no CPU fallback");
+    }
+    if (device >= n) {
+        delete c;
+        return fail(MCI_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+    }
+    c->device = device;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c;
+    return MCI_OK;
+}
+
+int mci_ctx_destroy(mci_ctx *c) {
+    if (!c) return MCI_OK;
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return MCI_OK;
+}
+
+void *mci_ctx_stream(mci_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int mci_comm_unique_id(void *id128) {
+    int rc = rccl_load();
+    if (rc) return rc;
+    int r = g_rccl.GetUniqueId(id128);
+    if (r) return fail(MCI_ERR_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return MCI_OK;
+}
+
+int mci_comm_init(mci_ctx *c, int32_t rank, int32_t nranks, const void *id128) {
+    if (!c || c->offline) return fail(MCI_ERR_INVALID, "communicator needs an online context");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(MCI_ERR_INVALID, "bad rank %d / %d", rank, nranks);
+    int rc = rccl_load();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    Id128 id;
+    memcpy(id.b, id128, 128);
+    int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (r) return fail(MCI_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    c->rank = rank;
+    c->nranks = nranks;
+    return MCI_OK;
+}
+
+int mci_comm_rank(const mci_ctx *c, int32_t *rank, int32_t *nranks) {
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->nranks;
+    return MCI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Configuration(; var, dof, obs)   reference src/configuration.jl:105-194
+// ---------------------------------------------------------------------------------------------------
+int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **out) {
+    if (!ctx || !d || !out) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (d->nleaf < 1 || d->npool < 1 || d->nintegrand < 1) return fail(MCI_ERR_INVALID, "At least one integrand is required."); // :163
+    if (d->nintegrand > 31) return fail(MCI_ERR_INVALID, "at most 31 integrands are supported");
+    mci_problem *p = new mci_problem();
+    p->ctx = ctx;
+    p->npool = d->npool;
+    p->ni = d->nintegrand;
+    const int Nd = p->ni + 1;
+    p->dof.assign((size_t)Nd * p->npool, 0); // last row: normalisation integrand, dof = 0   :153
+    for (int i = 0; i < p->ni * p->npool; ++i) {
+        if (d->dof[i] < 0) { delete p; return fail(MCI_ERR_INVALID, "dof must be non-negative"); }
+        p->dof[i] = d->dof[i];
+    }
+    p->maxdof.assign(p->npool, 0);
+    mci_maxdof(p->dof.data(), Nd, p->npool, p->maxdof.data()); // :155
+    p->pool_leaf0.assign(p->npool, -1);
+    p->pool_nleaf.assign(p->npool, 0);
+    auto &s = p->shape;
+    int eoff = 0, aoff = 0, doff = 0, boff = 0;
+    for (int l = 0; l < d->nleaf; ++l) {
+        const mci_leaf_desc &ld = d->leaves[l];
+        if (ld.pool < 0 || ld.pool >= p->npool) { delete p; return fail(MCI_ERR_INVALID, "leaf %d: pool out of range", l); }
+        if (p->pool_leaf0[ld.pool] < 0) p->pool_leaf0[ld.pool] = l;
+        else if (p->pool_leaf0[ld.pool] + p->pool_nleaf[ld.pool] != l) { delete p; return fail(MCI_ERR_INVALID, "leaves of pool %d are not contiguous", ld.pool); }
+        p->pool_nleaf[ld.pool] += 1;
+        Leaf L{};
+        L.kind = ld.kind;
+        L.pool = ld.pool;
+        L.lower = ld.lower;
+        L.upper = ld.upper;
+        L.alpha = ld.alpha;
+        L.adapt = ld.adapt ? 1 : 0;
+        if (ld.kind == MCI_CONTINUOUS) {
+            if (!(ld.upper > ld.lower + 2 * 2.220446049250313e-16)) { delete p; return fail(MCI_ERR_INVALID, "leaf %d: upper > lower required", l); } // variable.jl:140
+            L.npts = ld.npoints > 0 ? ld.npoints : 1000; // variable.jl:137
+            if (L.npts < 2) { delete p; return fail(MCI_ERR_INVALID, "leaf %d: at least 2 grid points", l); }
+            L.nbin = L.npts - 1;                          // variable.jl:147
+            L.eoff = eoff;
+            L.doff = 0;
+            for (int i = 0; i < L.npts; ++i) {
+                double v;
+                if (ld.init) v = ld.init[i];
+                else { // collect(LinRange(lower, upper, ninc))
+                    const double t = (double)i / (double)(L.npts - 1);
+                    v = (1.0 - t) * ld.lower + t * ld.upper;
+                    if (i == 0) v = ld.lower;
+                    if (i == L.npts - 1) v = ld.upper;
+                }
+                p->h_edges.push_back(v);
+            }
+            eoff += L.npts;
+        } else if (ld.kind == MCI_DISCRETE) {
+            const int K = (int)(ld.upper - ld.lower) + 1;
+            if (K < 1) { delete p; return fail(MCI_ERR_INVALID, "leaf %d: upper >= lower required", l); } // variable.jl:304
+            L.npts = K;
+            L.nbin = K; // variable.jl:305
+            L.eoff = aoff;
+            L.doff = doff;
+            std::vector<double> dist(K);
+            double sum = 0.0;
+            for (int i = 0; i < K; ++i) {
+                dist[i] = ld.init ? ld.init[i] : 1.0;
+                if (!(dist[i] >= 0.0)) { delete p; return fail(MCI_ERR_INVALID, "distribution should be all non-negative!"); } // variable.jl:309
+                sum += dist[i];
+            }
+            double run = 0.0;
+            p->h_dacc.push_back(0.0); // variable.jl:313-314
+            for (int i = 0; i < K; ++i) {
+                dist[i] /= sum; // variable.jl:312
+                run += dist[i];
+                p->h_ddist.push_back(dist[i]);
+                p->h_dacc.push_back(run);
+            }
+            aoff += K + 1;
+            doff += K;
+        } else {
+            delete p;
+            return fail(MCI_ERR_INVALID, "leaf %d: unknown kind %d", l, ld.kind);
+        }
+        L.boff = boff;
+        boff += L.nbin;
+        p->leaves.push_back(L);
+    }
+    for (int v = 0; v < p->npool; ++v)
+        if (p->pool_nleaf[v] == 0) { delete p; return fail(MCI_ERR_INVALID, "pool %d has no variable", v); }
+    // flat draw order: pool, slot, leaf  (vegas/montecarlo.jl:122-131, sampler.jl:431-440)
+    s.nleaf = d->nleaf;
+    s.ni = p->ni;
+    s.npool = p->npool;
+    for (int v = 0; v < p->npool; ++v) {
+        s.pool_first_draw.push_back((int)s.draw_leaf.size());
+        s.pool_maxdof.push_back(p->maxdof[v]);
+        s.pool_nleaf.push_back(p->pool_nleaf[v]);
+        for (int idx = 0; idx < p->maxdof[v]; ++idx)
+            for (int l = 0; l < p->pool_nleaf[v]; ++l) {
+                s.draw_leaf.push_back(p->pool_leaf0[v] + l);
+                s.draw_pool.push_back(v);
+                s.draw_slot.push_back(idx);
+            }
+    }
+    s.ndraw = (int)s.draw_leaf.size();
+    if (s.ndraw < 1 || s.ndraw > 64) { delete p; return fail(MCI_ERR_INVALID, "1..64 draws per sample supported, got %d", s.ndraw); }
+    s.own_mask.assign(Nd, 0ull);
+    s.cover_mask.assign(s.ndraw, 0ull);
+    for (int i = 0; i < p->ni; ++i)
+        for (int k = 0; k < s.ndraw; ++k)
+            if (s.draw_slot[k] < p->dof[(size_t)i * p->npool + s.draw_pool[k]]) {
+                s.own_mask[i] |= 1ull << k;
+                s.cover_mask[k] |= 1ull << i;
+            }
+    s.nobs = 0;
+    for (int i = 0; i < p->ni; ++i) {
+        const int nb = d->obs_nbin ? d->obs_nbin[i] : 1;
+        const int bd = d->obs_bin_draw ? d->obs_bin_draw[i] : -1;
+        if (nb < 1 || (bd >= s.ndraw)) { delete p; return fail(MCI_ERR_INVALID, "observable %d: bad shape", i); }
+        if (bd >= 0 && p->leaves[s.draw_leaf[bd]].kind != MCI_DISCRETE) { delete p; return fail(MCI_ERR_INVALID, "observable %d: bin draw must be a Discrete draw", i); }
+        if (bd < 0 && nb != 1) { delete p; return fail(MCI_ERR_INVALID, "the default measure can only handle scalar observables"); } // vegas/montecarlo.jl:104
+        s.obs_off.push_back(s.nobs);
+        s.obs_nbin.push_back(nb);
+        s.obs_bin_draw.push_back(bd);
+        s.nobs += nb;
+    }
+    s.ncols = s.nobs + 2 + Nd + 2 * p->npool;
+    s.nedge = eoff;
+    s.ndacc = aoff;
+    s.nddist = doff;
+    s.nbin = boff;
+    for (auto &L : p->leaves) {
+        s.leaf_kind.push_back(L.kind);
+        s.leaf_nbin.push_back(L.nbin);
+        s.leaf_eoff.push_back(L.eoff);
+        s.leaf_doff.push_back(L.doff);
+        s.leaf_boff.push_back(L.boff);
+        s.leaf_adapt.push_back(L.adapt);
+        s.leaf_lower.push_back(L.lower);
+    }
+    // table placement (DESIGN.md "data layout"): keep >= 2 workgroups per CU when everything is in LDS
+    const int64_t fixed = (int64_t)(s.ndacc + s.nddist + s.nobs + 16 * s.ncols) * 8;
+    const int64_t full = fixed + (int64_t)(s.nedge + s.nbin) * 8;
+    const int64_t eonly = fixed + (int64_t)s.nedge * 8;
+    if (full <= 80 * 1024) { s.table_mode = 0; p->lds_bytes = full; }
+    else if (eonly <= 160 * 1024 - 1024) { s.table_mode = 1; p->lds_bytes = eonly; }
+    else { s.table_mode = 2; p->lds_bytes = fixed; }
+    if (const char *e = getenv("MCI_TABLE_MODE")) {
+        int m = atoi(e);
+        if (m == 1 && eonly <= 160 * 1024) { s.table_mode = 1; p->lds_bytes = eonly; }
+        if (m == 2) { s.table_mode = 2; p->lds_bytes = fixed; }
+    }
+    p->nstat = 2 * s.nobs + 2 + Nd;
+    p->packed_n = p->nstat + s.nbin;
+    p->h_reweight.assign(Nd, 1.0 / Nd); // configuration.jl:110,172-173
+    s.body = "w[0] = 1.0;";
+    if (!ctx->offline) {
+        HIPCHK(hipSetDevice(ctx->device));
+        int rc = upload(p);
+        if (rc) { delete p; return rc; }
+        HIPCHK(hipMalloc((void **)&p->d_packed, (size_t)p->packed_n * sizeof(double)));
+        HIPCHK(hipMemset(p->d_packed, 0, (size_t)p->packed_n * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&p->d_ghist, (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
+        HIPCHK(hipMemset(p->d_ghist, 0, (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&p->d_stage1, (size_t)mci_problem::kGroups * (s.nbin ? s.nbin : 1) * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&p->d_status, sizeof(int)));
+        HIPCHK(hipMemset(p->d_status, 0, sizeof(int)));
+        std::vector<mci::LeafDev> ld;
+        for (auto &L : p->leaves) ld.push_back({L.kind, L.nbin, L.eoff, L.doff, L.boff, L.adapt, L.alpha});
+        HIPCHK(hipMalloc((void **)&p->d_leaves, ld.size() * sizeof(mci::LeafDev)));
+        HIPCHK(hipMemcpy(p->d_leaves, ld.data(), ld.size() * sizeof(mci::LeafDev), hipMemcpyHostToDevice));
+        HIPCHK(hipEventCreate(&p->ev0));
+        HIPCHK(hipEventCreate(&p->ev1));
+    }
+    *out = p;
+    return MCI_OK;
+}
+
+int mci_problem_destroy(mci_problem *p) {
+    if (!p) return MCI_OK;
+    if (!p->ctx->offline) {
+        hipStreamSynchronize(p->ctx->stream);
+        for (void *q : {(void *)p->d_edges, (void *)p->d_dacc, (void *)p->d_ddist, (void *)p->d_reweight, (void *)p->d_ud,
+                        (void *)p->d_part_cols, (void *)p->d_part_hist, (void *)p->d_ghist, (void *)p->d_stage1,
+                        (void *)p->d_packed, (void *)p->d_scratch, (void *)p->d_iterlog, (void *)p->d_dump,
+                        (void *)p->d_status, (void *)p->d_leaves})
+            if (q) hipFree(q);
+        if (p->module) hipModuleUnload(p->module);
+        if (p->ev0) hipEventDestroy(p->ev0);
+        if (p->ev1) hipEventDestroy(p->ev1);
+    }
+    delete p;
+    return MCI_OK;
+}
+
+int mci_set_integrand_source(mci_problem *p, const char *body, const double *ud, int32_t nud) {
+    if (!p || !body) return fail(MCI_ERR_INVALID, "NULL argument");
+    p->shape.body = body;
+    p->h_ud.assign(ud, ud + (nud > 0 ? nud : 0));
+    p->compiled = false;
+    if (p->module) {
+        hipModuleUnload(p->module);
+        p->module = nullptr;
+    }
+    if (!p->ctx->offline) {
+        if (p->d_ud) hipFree(p->d_ud);
+        p->d_ud = nullptr;
+        HIPCHK(hipMalloc((void **)&p->d_ud, (p->h_ud.size() ? p->h_ud.size() : 1) * sizeof(double)));
+        if (p->h_ud.size()) HIPCHK(hipMemcpy(p->d_ud, p->h_ud.data(), p->h_ud.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return MCI_OK;
+}
+
+int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
+    if (threads > 0) {
+        if (threads % 64 || threads > 1024) return fail(MCI_ERR_INVALID, "threads per workgroup must be a multiple of 64, <= 1024");
+        if (threads != p->threads) {
+            p->threads = threads;
+            p->compiled = false;
+            if (p->module) { hipModuleUnload(p->module); p->module = nullptr; }
+        }
+    }
+    if (wg_per_block >= 0) p->wg_per_block = wg_per_block;
+    return MCI_OK;
+}
+
+int mci_compile(mci_problem *p) {
+    if (p->compiled) return MCI_OK;
+    const std::string src = mcijit::generate_source(p->shape);
+    std::vector<char> code;
+    std::string log;
+    bool cached = false;
+    int rc = mcijit::compile(src, p->threads, code, log, cached);
+    if (rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
+    if (!p->ctx->offline) {
+        HIPCHK(hipSetDevice(p->ctx->device));
+        HIPCHK(hipModuleLoadData(&p->module, code.data()));
+        HIPCHK(hipModuleGetFunction(&p->f_vegas, p->module, "mci_vegas_batch"));
+        HIPCHK(hipModuleGetFunction(&p->f_vegasmc, p->module, "mci_vegasmc_chains"));
+        HIPCHK(hipModuleGetFunction(&p->f_dump, p->module, "mci_sample_dump"));
+        if (p->lds_bytes > 64 * 1024) {
+            HIPCHK(hipFuncSetAttribute((const void *)p->f_vegas, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+            HIPCHK(hipFuncSetAttribute((const void *)p->f_vegasmc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+            HIPCHK(hipFuncSetAttribute((const void *)p->f_dump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+        }
+    }
+    p->compiled = true;
+    return MCI_OK;
+}
+
+int mci_problem_info(const mci_problem *p, int32_t *ndraw, int32_t *nobs, int64_t *packed_size, int32_t *table_mode, int64_t *lds_bytes) {
+    if (ndraw) *ndraw = p->shape.ndraw;
+    if (nobs) *nobs = p->shape.nobs;
+    if (packed_size) *packed_size = p->packed_n;
+    if (table_mode) *table_mode = p->shape.table_mode;
+    if (lds_bytes) *lds_bytes = p->lds_bytes;
+    return MCI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one iteration
+// ---------------------------------------------------------------------------------------------------
+int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int64_t block_lo, int64_t block_hi,
+                      int32_t iteration, uint64_t seed, int64_t measurefreq, int64_t nchain) {
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context: no device to run on");
+    if (measurefreq <= 0) return fail(MCI_ERR_INVALID, "measurefreq must be positive"); // vegas/montecarlo.jl:77
+    const int64_t nblocks = block_hi - block_lo;
+    if (nblocks < 1 || nevalperblock < 1) return fail(MCI_ERR_INVALID, "empty iteration");
+    int rc = mci_compile(p);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const auto &s = p->shape;
+    const int T = p->threads;
+    int64_t units = nevalperblock; // lanes of useful work per block
+    if (solver == MCI_VEGASMC) {
+        if (nchain <= 0) { // auto: ~2048 steps per chain, at least one wave, at most what fills the chip
+            nchain = nevalperblock / 2048;
+            if (nchain < 64) nchain = 64;
+            if (nchain > 16384) nchain = 16384;
+            if (nchain > nevalperblock) nchain = nevalperblock;
+        }
+        units = nchain;
+    } else {
+        nchain = 1;
+    }
+    int wpb = p->wg_per_block;
+    if (wpb <= 0) { // fill 256 CUs x ~4 workgroups, but never leave a workgroup without work
+        wpb = (int)((1024 + nblocks - 1) / nblocks);
+        const int64_t maxw = (units + T - 1) / T;
+        if (wpb > maxw) wpb = (int)maxw;
+        if (wpb < 1) wpb = 1;
+    }
+    const int64_t nwg = nblocks * wpb;
+    if ((rc = ensure_capacity(p, nwg, nblocks))) return rc;
+    mci::BatchArgs a{};
+    a.edges = p->d_edges;
+    a.dacc = p->d_dacc;
+    a.ddist = p->d_ddist;
+    a.reweight = p->d_reweight;
+    a.ud = p->d_ud;
+    a.part_cols = p->d_part_cols;
+    a.part_hist = p->d_part_hist;
+    a.ghist = p->d_ghist;
+    a.seed = seed;
+    a.iteration = (mci::u32)iteration;
+    a.neval_per_block = nevalperblock;
+    a.block_lo = block_lo;
+    a.wg_per_block = wpb;
+    a.measurefreq = measurefreq;
+    a.nchain = nchain;
+    void *args[] = {&a};
+    hipFunction_t f = solver == MCI_VEGASMC ? p->f_vegasmc : p->f_vegas;
+    hipStream_t st = p->ctx->stream;
+    HIPCHK(hipEventRecord(p->ev0, st));
+    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+    HIPCHK(hipEventRecord(p->ev1, st));
+    p->last_wg = (int)nwg;
+    p->last_threads = T;
+    p->last_nblocks = (int)nblocks;
+    // merge: block sums -> packed
+    const int nb256 = (s.nbin + 255) / 256;
+    if (s.table_mode == 0 && s.nbin > 0)
+        hipLaunchKernelGGL(mci::k_hist_stage1, dim3(nb256, mci_problem::kGroups), dim3(256), 0, st, p->d_part_hist, (int)nwg, s.nbin,
+                           (int)mci_problem::kGroups, p->d_stage1);
+    hipLaunchKernelGGL(mci::k_finalize, dim3(nb256 + 1), dim3(256), 0, st, p->d_part_cols, s.ncols, s.nobs, s.ni, (int)nblocks, wpb,
+                       p->d_stage1, (int)mci_problem::kGroups, p->d_ghist, s.table_mode != 0 ? 1 : 0, s.nbin, p->d_packed, p->d_status,
+                       p->d_scratch);
+    HIPCHK(hipGetLastError());
+    return MCI_OK;
+}
+
+int mci_iteration_reduce(mci_problem *p) {
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    if (!p->ctx->comm || p->ctx->nranks == 1) return MCI_OK;
+    int r = g_rccl.AllReduce(p->d_packed, p->d_packed, (size_t)p->packed_n, kNcclFloat64, kNcclSum, p->ctx->comm, p->ctx->stream);
+    if (r) return fail(MCI_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return MCI_OK;
+}
+
+static int launch_train(mci_problem *p, int do_train, int do_reweight, double gamma, double *log_row) {
+    const auto &s = p->shape;
+    int maxn = 1;
+    for (auto &L : p->leaves) maxn = L.nbin > maxn ? L.nbin : maxn;
+    const size_t sm = (size_t)(3 * maxn + 2) * sizeof(double);
+    hipLaunchKernelGGL(mci::k_train, dim3(s.nleaf + 1), dim3(256), sm, p->ctx->stream, p->d_leaves, s.nleaf, p->d_packed, p->nstat,
+                       p->d_edges, p->d_dacc, p->d_ddist, log_row, p->d_reweight, s.ni + 1, do_reweight, gamma, do_train, p->d_status);
+    HIPCHK(hipGetLastError());
+    return MCI_OK;
+}
+
+int mci_iteration_finish(mci_problem *p, int32_t solver, int64_t block_total, int32_t adapt, double gamma, double *mean, double *std) {
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const auto &s = p->shape;
+    if (p->log_row >= p->cap_iter) { // grow the iteration log (keeps old rows)
+        const int64_t ncap = p->cap_iter ? p->cap_iter * 2 : 64;
+        double *n = nullptr;
+        HIPCHK(hipMalloc((void **)&n, (size_t)ncap * p->nstat * sizeof(double)));
+        if (p->d_iterlog) {
+            HIPCHK(hipMemcpyAsync(n, p->d_iterlog, (size_t)p->cap_iter * p->nstat * sizeof(double), hipMemcpyDeviceToDevice, p->ctx->stream));
+            HIPCHK(hipStreamSynchronize(p->ctx->stream));
+            hipFree(p->d_iterlog);
+        }
+        p->d_iterlog = n;
+        p->cap_iter = ncap;
+    }
+    double *row = p->d_iterlog + (size_t)p->log_row * p->nstat;
+    // reweight is adapted only together with the grid (main.jl:183 runs it unconditionally for the chain solvers)
+    int rc = launch_train(p, adapt ? 1 : 0, solver == MCI_VEGASMC ? 1 : 0, gamma, row);
+    if (rc) return rc;
+    p->log_row += 1;
+    if (mean || std) {
+        std::vector<double> h(p->nstat);
+        HIPCHK(hipMemcpyAsync(h.data(), row, (size_t)p->nstat * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+        if ((rc = check_status(p))) return rc; // synchronises
+        std::vector<double> m(s.nobs), e(s.nobs);
+        mci_mean_std(h.data(), h.data() + s.nobs, s.nobs, block_total, m.data(), e.data());
+        if (mean) memcpy(mean, m.data(), s.nobs * sizeof(double));
+        if (std) memcpy(std, e.data(), s.nobs * sizeof(double));
+    }
+    return MCI_OK;
+}
+
+int mci_train(mci_problem *p) {
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    int rc = launch_train(p, 1, 0, 1.0, nullptr);
+    if (rc) return rc;
+    return check_status(p);
+}
+
+// integrate  (reference src/main.jl:71-218)
+int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) {
+    if (!p || !a || !res) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context: no device to run on");
+    const auto &s = p->shape;
+    if (res->niter < a->niter || res->nobs != s.nobs) return fail(MCI_ERR_INVALID, "result buffers too small");
+    if (!(a->neval > a->block)) return fail(MCI_ERR_INVALID, "neval=%lld should be larger than nblock = %lld", (long long)a->neval, (long long)a->block); // main.jl:222
+    int64_t nevalperblock, block;
+    mci_standardize_block(a->neval, a->block, p->ctx->nranks, &nevalperblock, &block); // main.jl:121
+    const int64_t per = block / p->ctx->nranks;                                         // main.jl:122
+    const int64_t lo = per * p->ctx->rank, hi = lo + per;
+    int rc = mci_compile(p);
+    if (rc) return rc;
+    const int ignore = a->ignore >= 0 ? a->ignore : (a->adapt ? 1 : 0);
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    const int row0 = p->log_row;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < a->niter; ++it) { // main.jl:142
+        if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, a->first_iteration + it, a->seed, a->measurefreq, a->nchain))) return rc;
+        if ((rc = mci_iteration_reduce(p))) return rc;                                   // main.jl:177-188
+        if ((rc = mci_iteration_finish(p, a->solver, block, a->adapt, a->gamma, nullptr, nullptr))) return rc; // main.jl:183-199
+    }
+    std::vector<double> h((size_t)a->niter * p->nstat);
+    HIPCHK(hipMemcpyAsync(h.data(), p->d_iterlog + (size_t)row0 * p->nstat, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    if ((rc = check_status(p))) return rc;
+    auto t1 = std::chrono::steady_clock::now();
+    res->seconds = std::chrono::duration<double>(t1 - t0).count();
+    res->neval = 0;
+    for (int it = 0; it < a->niter; ++it) { // main.jl:203
+        const double *row = h.data() + (size_t)it * p->nstat;
+        mci_mean_std(row, row + s.nobs, s.nobs, block, res->iter_mean + (size_t)it * s.nobs, res->iter_std + (size_t)it * s.nobs);
+        res->neval += (int64_t)row[2 * s.nobs + 1];
+    }
+    for (int o = 0; o < s.nobs; ++o) // main.jl:211 -> statistics.jl:24-55
+        mci_average(res->iter_mean + o, res->iter_std + o, s.nobs, ignore + 1, a->niter, &res->mean[o], &res->stdev[o], &res->chi2[o]);
+    return MCI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// state access
+// ---------------------------------------------------------------------------------------------------
+int mci_get_packed(mci_problem *p, double *out, int64_t n) {
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    if (n != p->packed_n) return fail(MCI_ERR_INVALID, "packed size is %lld", (long long)p->packed_n);
+    HIPCHK(hipMemcpyAsync(out, p->d_packed, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return MCI_OK;
+}
+
+int mci_set_packed(mci_problem *p, const double *in, int64_t n) {
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    if (n != p->packed_n) return fail(MCI_ERR_INVALID, "packed size is %lld", (long long)p->packed_n);
+    HIPCHK(hipMemcpyAsync(p->d_packed, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return MCI_OK;
+}
+
+void *mci_packed_device_ptr(mci_problem *p) { return p ? (void *)p->d_packed : nullptr; }
+
+int mci_get_grid(mci_problem *p, int32_t leaf, double *out, int32_t n) {
+    if (leaf < 0 || leaf >= (int)p->leaves.size() || p->leaves[leaf].kind != MCI_CONTINUOUS) return fail(MCI_ERR_INVALID, "leaf %d is not Continuous", leaf);
+    const Leaf &L = p->leaves[leaf];
+    if (n != L.npts) return fail(MCI_ERR_INVALID, "grid has %d points", L.npts);
+    if (p->ctx->offline) {
+        memcpy(out, p->h_edges.data() + L.eoff, n * sizeof(double));
+        return MCI_OK;
+    }
+    HIPCHK(hipMemcpyAsync(out, p->d_edges + L.eoff, n * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return MCI_OK;
+}
+
+int mci_set_grid(mci_problem *p, int32_t leaf, const double *grid, int32_t n) {
+    if (leaf < 0 || leaf >= (int)p->leaves.size() || p->leaves[leaf].kind != MCI_CONTINUOUS) return fail(MCI_ERR_INVALID, "leaf %d is not Continuous", leaf);
+    const Leaf &L = p->leaves[leaf];
+    if (n != L.npts) return fail(MCI_ERR_INVALID, "grid has %d points (the number of points is fixed at creation)", L.npts);
+    for (int i = 1; i < n; ++i)
+        if (!(grid[i] > grid[i - 1])) return fail(MCI_ERR_INVALID, "grid must be strictly increasing");
+    memcpy(p->h_edges.data() + L.eoff, grid, n * sizeof(double));
+    if (p->ctx->offline) return MCI_OK;
+    HIPCHK(hipMemcpyAsync(p->d_edges + L.eoff, grid, n * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return MCI_OK;
+}
+
+int mci_get_distribution(mci_problem *p, int32_t leaf, double *dist, double *acc, int32_t k) {
+    if (leaf < 0 || leaf >= (int)p->leaves.size() || p->leaves[leaf].kind != MCI_DISCRETE) return fail(MCI_ERR_INVALID, "leaf %d is not Discrete", leaf);
+    const Leaf &L = p->leaves[leaf];
+    if (k != L.nbin) return fail(MCI_ERR_INVALID, "distribution has %d entries", L.nbin);
+    if (p->ctx->offline) {
+        if (dist) memcpy(dist, p->h_ddist.data() + L.doff, k * sizeof(double));
+        if (acc) memcpy(acc, p->h_dacc.data() + L.eoff, (k + 1) * sizeof(double));
+        return MCI_OK;
+    }
+    if (dist) HIPCHK(hipMemcpyAsync(dist, p->d_ddist + L.doff, k * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    if (acc) HIPCHK(hipMemcpyAsync(acc, p->d_dacc + L.eoff, (k + 1) * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return MCI_OK;
+}
+
+int mci_set_distribution(mci_problem *p, int32_t leaf, const double *dist, int32_t k) {
+    if (leaf < 0 || leaf >= (int)p->leaves.size() || p->leaves[leaf].kind != MCI_DISCRETE) return fail(MCI_ERR_INVALID, "leaf %d is not Discrete", leaf);
+    const Leaf &L = p->leaves[leaf];
+    if (k != L.nbin) return fail(MCI_ERR_INVALID, "distribution has %d entries", L.nbin);
+    double sum = 0.0;
+    for (int i = 0; i < k; ++i) {
+        if (!(dist[i] >= 0.0)) return fail(MCI_ERR_INVALID, "distribution should be all non-negative!");
+        sum += dist[i];
+    }
+    double run = 0.0;
+    p->h_dacc[L.eoff] = 0.0;
+    for (int i = 0; i < k; ++i) {
+        p->h_ddist[L.doff + i] = dist[i] / sum;
+        run += p->h_ddist[L.doff + i];
+        p->h_dacc[L.eoff + i + 1] = run;
+    }
+    if (p->ctx->offline) return MCI_OK;
+    HIPCHK(hipMemcpyAsync(p->d_ddist + L.doff, p->h_ddist.data() + L.doff, k * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
+    HIPCHK(hipMemcpyAsync(p->d_dacc + L.eoff, p->h_dacc.data() + L.eoff, (k + 1) * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return MCI_OK;
+}
+
+int mci_get_reweight(mci_problem *p, double *out, int32_t n) {
+    if (n != p->ni + 1) return fail(MCI_ERR_INVALID, "reweight has %d entries", p->ni + 1);
+    if (p->ctx->offline) {
+        memcpy(out, p->h_reweight.data(), n * sizeof(double));
+        return MCI_OK;
+    }
+    HIPCHK(hipMemcpyAsync(out, p->d_reweight, n * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return MCI_OK;
+}
+
+int mci_set_reweight(mci_problem *p, const double *in, int32_t n) {
+    if (n != p->ni + 1) return fail(MCI_ERR_INVALID, "Wrong reweight vector size! Note that the last element in reweight vector is for the normalization diagram."); // configuration.jl:174
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (!(in[i] > 0)) return fail(MCI_ERR_INVALID, "All reweight factors should be positive."); // configuration.jl:175
+        s += in[i];
+    }
+    for (int i = 0; i < n; ++i) p->h_reweight[i] = in[i] / s; // configuration.jl:173
+    if (p->ctx->offline) return MCI_OK;
+    HIPCHK(hipMemcpyAsync(p->d_reweight, p->h_reweight.data(), n * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return MCI_OK;
+}
+
+int mci_sample_dump(mci_problem *p, int32_t iteration, uint64_t seed, int64_t nevalperblock, int64_t block_index, int64_t n,
+                    double *x, double *jac, double *w) {
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    if (n < 1 || n > nevalperblock) return fail(MCI_ERR_INVALID, "n must be in 1..neval_per_block");
+    int rc = mci_compile(p);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const auto &s = p->shape;
+    const int64_t per = s.ndraw + 1 + s.ni;
+    if (n * per > p->cap_dump) {
+        if (p->d_dump) hipFree(p->d_dump);
+        p->d_dump = nullptr;
+        HIPCHK(hipMalloc((void **)&p->d_dump, (size_t)(n * per) * sizeof(double)));
+        p->cap_dump = n * per;
+    }
+    mci::DumpArgs a{};
+    a.edges = p->d_edges;
+    a.dacc = p->d_dacc;
+    a.ddist = p->d_ddist;
+    a.ud = p->d_ud;
+    a.x = p->d_dump;
+    a.jac = p->d_dump + n * s.ndraw;
+    a.w = a.jac + n;
+    a.seed = seed;
+    a.iteration = (mci::u32)iteration;
+    a.first_index = block_index * nevalperblock;
+    a.n = n;
+    void *args[] = {&a};
+    const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    HIPCHK(hipModuleLaunchKernel(p->f_dump, grid, 1, 1, 256, 1, 1, (unsigned)p->lds_bytes, p->ctx->stream, args, nullptr));
+    if (x) HIPCHK(hipMemcpyAsync(x, a.x, (size_t)n * s.ndraw * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    if (jac) HIPCHK(hipMemcpyAsync(jac, a.jac, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    if (w) HIPCHK(hipMemcpyAsync(w, a.w, (size_t)n * s.ni * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return MCI_OK;
+}
+
+int mci_last_kernel_ms(mci_problem *p, float *ms, int32_t *wg, int32_t *threads) {
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    HIPCHK(hipEventSynchronize(p->ev1));
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, p->ev0, p->ev1));
+    if (ms) *ms = t;
+    if (wg) *wg = p->last_wg;
+    if (threads) *threads = p->last_threads;
+    return MCI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-side statistics (pure functions)
+// ---------------------------------------------------------------------------------------------------
+void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64_t *nevalperblock, int64_t *block) {
+    (void)neval;
+    if (nblock > nworker) nblock = (nblock / nworker) * nworker; // main.jl:225-227
+    else nblock = nworker;                                       // main.jl:229
+    *nevalperblock = neval / nblock;                             // main.jl:232
+    *block = nblock;
+}
+
+void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out) {
+    for (int v = 0; v < npool; ++v) {
+        int m = 0;
+        for (int i = 0; i < nd; ++i) m = dof[(size_t)i * npool + v] > m ? dof[(size_t)i * npool + v] : m;
+        out[v] = m;
+    }
+}
+
+void mci_mean_std(const double *obs_sum, const double *obs_sq, int64_t n, int64_t block, double *mean, double *std) {
+    for (int64_t o = 0; o < n; ++o) {
+        const double m = obs_sum[o] / (double)block; // main.jl:317
+        mean[o] = m;
+        if (block > 1) {
+            const double v = (obs_sq[o] / (double)block - m * m) / (double)(block - 1); // main.jl:308
+            std[o] = v < 0.0 ? 0.0 : sqrt(v);                                           // main.jl:297-299
+        } else {
+            std[o] = 0.0; // main.jl:311
+        }
+    }
+}
+
+void mci_average(const double *iter_mean, const double *iter_std, int64_t stride, int64_t init, int64_t max, double *mean,
+                 double *err, double *chi2) {
+    if (max <= init) { // statistics.jl:189-191
+        *mean = iter_mean[0];
+        *err = iter_std[0];
+        *chi2 = 0.0;
+        return;
+    }
+    double wsum = 0.0, mea = 0.0, c2 = 0.0;
+    for (int64_t i = init; i <= max; ++i) { // statistics.jl:217
+        const double sd = iter_std[(i - 1) * stride] + 1.0e-10;
+        wsum += 1.0 / (sd * sd);
+    }
+    for (int64_t i = init; i <= max; ++i) { // statistics.jl:197
+        const double sd = iter_std[(i - 1) * stride] + 1.0e-10;
+        mea += iter_mean[(i - 1) * stride] * (1.0 / (sd * sd)) / wsum;
+    }
+    for (int64_t i = init; i <= max; ++i) { // statistics.jl:200
+        const double sd = iter_std[(i - 1) * stride] + 1.0e-10;
+        const double dlt = iter_mean[(i - 1) * stride] - mea;
+        c2 += (1.0 / (sd * sd)) * dlt * dlt;
+    }
+    *mean = mea;
+    *err = 1.0 / sqrt(wsum);                      // statistics.jl:198
+    *chi2 = c2 / (double)((max - init + 1) - 1);  // statistics.jl:204
+}
+
+void mci_do_reweight(double *reweight, const double *visited, int64_t nd, double gamma, const double *goal) {
+    double avgstep = 0.0;
+    for (int64_t i = 0; i < nd; ++i) avgstep += visited[i]; // main.jl:323
+    for (int64_t i = 0; i < nd; ++i) {                      // main.jl:324-331
+        if (visited[i] <= 1) reweight[i] *= pow(avgstep, gamma);
+        else reweight[i] *= pow(avgstep / visited[i], gamma);
+    }
+    if (goal) { // main.jl:334-337
+        double gs = 0.0;
+        for (int64_t i = 0; i < nd; ++i) gs += goal[i];
+        for (int64_t i = 0; i < nd; ++i) reweight[i] *= goal[i] / gs;
+    }
+    double s = 0.0;
+    for (int64_t i = 0; i < nd; ++i) s += reweight[i];
+    for (int64_t i = 0; i < nd; ++i) reweight[i] /= s; // main.jl:339
+}
+
+} // extern "C"

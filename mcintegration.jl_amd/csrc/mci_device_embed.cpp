@@ -1,0 +1,570 @@
+// generated from mci_device.h by __graft_entry__.build(); do not edit
+namespace mcijit { extern const char* const kDeviceHeader; const char* const kDeviceHeader =
+R"MCIDEV(// mci_device.h -- hand-written gfx950 (CDNA4, wave64) kernels of the VEGAS / VegasMC sample batch.
+//
+// This header is compiled twice: ahead of time by hipcc (static kernels in mci_static_kernels.hip)
+// and at run time by hiprtc, where a tiny generated translation unit supplies a `Cfg` traits struct
+// (the analogue of Julia specialising Vegas.montecarlo on Configuration{N,V,P,O,T}) plus the user's
+// integrand body and instantiates the templates below.  It must stay free of host/std headers.
+//
+// Reference semantics (file:line under /root/reference/src):
+//   draw            distribution/sampler.jl:293-305 (Continuous create!), :13-22 (Discrete create!)
+//   sample batch    vegas/montecarlo.jl:117-187
+//   padding         distribution/variable.jl:628-641
+//   accumulate!     distribution/variable.jl:196-200, :362-367, :474-478
+//   chains          vegas_mc/montecarlo.jl:151-232, vegas_mc/updates.jl:45-106
+//
+// MI355X mapping: one workgroup = one slice of ONE statistical block; the adaptive-grid tables and
+// the per-bin weight histograms live in LDS (ds_read_b64 / ds_add_f64), Philox4x32-10 supplies the
+// uniforms on chip, observables are reduced with wave64 shuffles.  No MFMA: the path is elementwise
+// + reduction.  HBM sees only the table load and the per-workgroup partial flush.
+#pragma once
+
+namespace mci {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef long long i64;
+
+template <int I> struct IC { static constexpr int value = I; };
+
+template <int B, int E, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RNG streams (DESIGN.md "RNG streams"; identical to oracle/mci_oracle.c:mcio_uniform)
+//   key = (seed lo, seed hi); ctr = (index lo, index hi, k>>1, stream); draw k -> words 2(k&1), 2(k&1)+1
+//   52 mantissa bits, [1,2) - 1 : the same resolution as Julia's MersenneTwister rand(Float64).
+// ---------------------------------------------------------------------------------------------
+struct u32x4 { u32 x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const u64 p0 = (u64)0xD2511F53u * c0; // v_mad_u64_u32: hi and lo in one issue
+        const u64 p1 = (u64)0xCD9E8D57u * c2;
+        const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0;
+        const u32 n2 = (u32)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (u32)p1;
+        c3 = (u32)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u; // wave-uniform: scalar ALU
+        k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ double u01(u32 lo, u32 hi) {
+    const u64 bits = ((((u64)hi << 32) | lo) >> 12) | 0x3FF0000000000000ull;
+    return __longlong_as_double((i64)bits) - 1.0;
+}
+
+enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3 };
+
+// ---------------------------------------------------------------------------------------------
+// kernel arguments (plain struct passed by value)
+// ---------------------------------------------------------------------------------------------
+struct BatchArgs {
+    const double *edges;    // [NEDGE]  all Continuous grids, concatenated          (variable.jl:94)
+    const double *dacc;     // [NDACC]  all Discrete accumulation tables            (variable.jl:280)
+    const double *ddist;    // [NDDIST] all Discrete distribution tables            (variable.jl:281)
+    const double *reweight; // [NI+1]   vegasmc only                                (configuration.jl:50)
+    const double *ud;       // userdata                                             (configuration.jl:42)
+    double *part_cols;      // [nWG][NCOLS]   per-workgroup partial statistics
+    double *part_hist;      // [nWG][NBIN]    per-workgroup partial histograms (TABLE_MODE 0)
+    double *ghist;          // [NBIN]         device histogram for global atomics (TABLE_MODE 1,2)
+    u64 seed;
+    u32 iteration;
+    i64 neval_per_block;    // samples (vegas) or chain steps (vegasmc) per statistical block
+    i64 block_lo;           // first global block index handled by this launch
+    int wg_per_block;
+    i64 measurefreq;
+    i64 nchain;             // vegasmc: chains per block
+};
+
+struct DumpArgs {
+    const double *edges, *dacc, *ddist, *ud;
+    double *x, *jac, *w;
+    u64 seed;
+    u32 iteration;
+    i64 first_index; // global sample index of the first dumped sample
+    i64 n;
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave64 / workgroup reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v; // valid in lane 0
+}
+
+// LDS f64 add -> ds_add_f64 (no return).  Contention is benign: iy is uniform in y-space by
+// construction of the map (sampler.jl:378).
+__device__ __forceinline__ void lds_add(double *p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void global_add(double *p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// table placement.  TABLE_MODE 0: grids + histograms in LDS; 1: grids in LDS, histograms via
+// global f64 atomics; 2: everything from L2/HBM (grids too large for 160 KiB).
+// ---------------------------------------------------------------------------------------------
+template <class Cfg> struct Tables {
+    const double *E;  // grid edges (LDS or global)
+    const double *DA; // discrete accumulation (LDS)
+    const double *DD; // discrete distribution (LDS)
+};
+
+// one leaf draw: create! in its Jacobian form.  Returns x, pj = 1/prob, bin index (0-based).
+template <class Cfg, int K> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &pj, int &bin) {
+    constexpr int leaf = Cfg::draw_leaf(K);
+    if constexpr (Cfg::leaf_kind(leaf) == 0) {
+        // sampler.jl:295-303:  iy = floor(y*N)+1; dy = y*N-(iy-1); x = g[iy] + dy*(g[iy+1]-g[iy]); prob = 1/(N*dx)
+        constexpr int N = Cfg::leaf_nbin(leaf);
+        constexpr int eoff = Cfg::leaf_eoff(leaf);
+        const double yn = y * (double)N;
+        const int iy = (int)yn; // y*N >= 0: trunc == floor
+        const double dy = yn - (double)iy;
+        const double g0 = t.E[eoff + iy];
+        const double g1 = t.E[eoff + iy + 1];
+        const double dx = g1 - g0;
+        x = g0 + dy * dx;
+        pj = (double)N * dx;
+        bin = iy;
+    } else {
+        // sampler.jl:17-20 + common.jl:16-25 bisection on accumulation[1..K+1]
+        constexpr int Kn = Cfg::leaf_nbin(leaf);
+        constexpr int aoff = Cfg::leaf_eoff(leaf);
+        constexpr int doff = Cfg::leaf_doff(leaf);
+        int jl = 1, ju = Kn + 2;
+        while (ju - jl > 1) {
+            const int jm = (jl + ju) >> 1;
+            if (y < t.DA[aoff + jm - 1]) ju = jm;
+            else jl = jm;
+        }
+        if (jl > Kn) jl = Kn; // accumulation[end] <= y < 1 through rounding: reference raises (common.jl:10-12)
+        x = Cfg::leaf_lower(leaf) + (double)(jl - 1);
+        pj = 1.0 / t.DD[doff + jl - 1];
+        bin = jl - 1;
+    }
+}
+
+// all NDRAW draws of one sample + Jacobians.  jaci[i] = product of pj over integrand i's own draws
+// ( = weights*padding_probability*jac of vegas/montecarlo.jl:152 up to rounding ).
+template <class Cfg> struct Sample {
+    double x[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
+    int bin[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
+    double pj[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // 1/prob per draw (dead-code eliminated where unused)
+    double jac;
+    d)MCIDEV"
+R"MCIDEV(ouble jaci[Cfg::NI];
+};
+
+template <class Cfg> __device__ __forceinline__ void draw_sample(const Tables<Cfg> &t, u64 seed, u32 stream, u64 index, Sample<Cfg> &s) {
+    const u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
+    const u32 ilo = (u32)index, ihi = (u32)(index >> 32);
+    s.jac = 1.0;
+    static_for<0, Cfg::NI>([&](auto I) { s.jaci[decltype(I)::value] = 1.0; });
+    static_for<0, (Cfg::NDRAW + 1) / 2>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        const u32x4 r = philox4x32_10(ilo, ihi, (u32)c, stream, k0, k1);
+        static_for<0, 2>([&](auto H) {
+            constexpr int k = 2 * c + decltype(H)::value;
+            if constexpr (k < Cfg::NDRAW) {
+                const double y = decltype(H)::value == 0 ? u01(r.x, r.y) : u01(r.z, r.w);
+                double pj;
+                draw_leaf<Cfg, k>(t, y, s.x[k], pj, s.bin[k]);
+                s.pj[k] = pj;
+                s.jac *= pj; // jac /= prob   vegas/montecarlo.jl:126
+                static_for<0, Cfg::NI>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    if constexpr ((Cfg::own_mask(i) >> k) & 1ull) s.jaci[i] *= pj;
+                });
+            }
+        });
+    });
+}
+
+// stage the tables into LDS (coalesced 8-byte loads, once per workgroup)
+template <class Cfg> __device__ __forceinline__ void stage_tables(const double *gE, const double *gDA, const double *gDD, double *sE, double *sDA, double *sDD) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    if constexpr (Cfg::TABLE_MODE <= 1)
+        for (int i = tid; i < Cfg::NEDGE; i += T) sE[i] = gE[i];
+    for (int i = tid; i < Cfg::NDACC; i += T) sDA[i] = gDA[i];
+    for (int i = tid; i < Cfg::NDDIST; i += T) sDD[i] = gDD[i];
+}
+
+// LDS carve (doubles).  Order: edges | dacc | ddist | hist | obs | reduction scratch
+template <class Cfg> struct Lds {
+    static constexpr int E = 0;
+    static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? Cfg::NEDGE : 0);
+    static constexpr int DD = DA + Cfg::NDACC;
+    static constexpr int H = DD + Cfg::NDDIST;
+    static constexpr int O = H + (Cfg::TABLE_MODE == 0 ? Cfg::NBIN : 0);
+    static constexpr int R = O + Cfg::NOBS;
+    static constexpr int END = R + 16 /*waves*/ * Cfg::NCOLS;
+};
+
+// partial-statistics columns written per workgroup:
+//   [0, NOBS) observables | NOBS normalization | NOBS+1 neval | NOBS+2 .. +NI+1 visited(N+1) | propose(NPOOL) | accept(NPOOL)
+template <class Cfg> struct Cols {
+    static constexpr int NORM = Cfg::NOBS;
+    static constexpr int NEVAL = Cfg::NOBS + 1;
+    static constexpr int VISITED = Cfg::NOBS + 2;
+    static constexpr int PROPOSE = VISITED + Cfg::NI + 1;
+    static constexpr int ACCEPT = PROPOSE + Cfg::NPOOL;
+    static_assert(ACCEPT + Cfg::NPOOL == Cfg::NCOLS, "column layout");
+};
+
+// histogram update of one sample: accumulate!(var, pos+offset, weight) for every (integrand i, draw k in own(i))
+// (vegas/montecarlo.jl:170-185).  The per-integrand weights covering the same draw are summed first,
+// so each draw costs one ds_add_f64.
+template <class Cfg> __device__ __forceinline__ void hist_update(const Sample<Cfg> &s, const double *wh /*[NI]*/, double *sH, double *gH) {
+    static_for<0, Cfg::NDRAW>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        constexpr int leaf = Cfg::draw_leaf(k);
+        if constexpr (Cfg::leaf_adapt(leaf) != 0 && Cfg::cover_mask(k) != 0ull) { // T.adapt  variable.jl:197,:363
+            double wk = 0.0;
+            static_for<0, Cfg::NI>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if constexpr ((Cfg::own_mask(i) >> k) & 1ull) wk += wh[i];
+            });
+            if constexpr (Cfg::TABLE_MODE == 0) lds_add(&sH[Cfg::leaf_boff(leaf) + s.bin[k]], wk);
+            else global_add(&gH[Cfg::leaf_boff(leaf) + s.bin[k]], wk);
+        }
+    });
+}
+
+// default measure (vegas/montecarlo.jl:151-153) or "bin by a Discrete draw" (example/bubble.jl:81-84)
+template <class Cfg> __device__ __forceinline__ void measure(const Sample<Cfg> &s, const double *relw, double *acc /*[NI] registers*/, double *sO) {
+    static_for<0, Cfg::NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (Cfg::obs_bin_draw(i) < 0) {
+            acc[i] += relw[i];
+        } else {
+            constexpr int kd = Cfg::obs_bin_draw(i);
+            const int b = s.bin[kd];
+            if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw[i]);
+        }
+    });
+}
+
+// workgroup epilogue: registers -> wave shuffle -> LDS -> one row of part_cols; LDS histogram -> part_hist
+template <class Cfg> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/) {
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
+    double *sO = smem + Lds<Cfg>::O, *sR = smem + Lds<Cfg>::R, *sH = smem + Lds<Cfg>::H;
+    // scalar observables
+    static_for<0, Cfg::NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (Cfg::obs_bin_draw(i) < 0) {
+            const double v = wave_sum(acc[i]);
+            if (lane == 0) sR[wave * Cfg::NCOLS + Cfg::obs_off(i)] = v;
+        }
+    });
+    static_for<Cfg::NOBS, Cfg::NCOLS>([&](auto Cc) {
+        constexpr int c = decltype(Cc)::value;
+        const double v = wave_sum(extra[c - Cfg::NOBS]);
+        if (lane == 0) sR[wave * Cfg::NCOLS + c] = v;
+    });
+    __syncthreads();
+    double *row = a.part_cols + (i64)blockIdx.x * Cfg::NCOLS;
+    for (int c = tid; c < Cfg::NCOLS; c += T) {
+        bool binned = false;
+        int owner = 0;
+        static_for<0, Cfg::NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if (c >= Cfg::obs_off(i) && c < Cfg::obs_off(i) + Cfg::obs_nbin(i)) { owner = i; binned = Cfg::obs_bin_draw(i) >= 0; }
+        });
+        (void)owner;
+        double v = 0.0;
+        if (c < Cfg::NOBS && binned) v = sO[c];
+        else
+            for (int w = 0; w < nwave; ++w) v += sR[w * Cfg::NCOLS + c]; // fixed order: deterministic
+        row[c] = v;
+    }
+    if constexpr (Cfg::TABLE_MODE == 0) {
+        double *hrow = a.part_hist + (i64)blockIdx.x * Cfg::NBIN;
+        for (int i = tid; i < Cfg::NBIN; i += T) hrow[i] = sH[i];
+    }
+}
+
+// =============================================================================================
+// VEGAS sample batch  (vegas/montecarlo.jl:117-187)
+// =============================================================================================
+template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, T = blockDim.x;
+    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
+    double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
+    stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
+    if constexpr (Cfg::TABLE_MODE == 0)
+        for (int i = tid; i < Cfg::NBIN; i += T) sH[i] = 0.0;
+    for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    __syncthreads();
+    Tables<Cfg> t;
+    if constexpr (Cfg::TABLE_MODE <= 1) t.E = sE;
+    else t.E = a.edges;
+    t.DA = sDA;
+    t.DD = sDD;
+
+    const i64 lb = blockIdx.x / a.wg_per_block; // local statistical block
+    const int slice = blockIdx.x % a.wg_per_block;
+    const i64 B = a.block_lo + lb;
+    const u32 stream = a.iteration * 8u + STREAM_VEGAS;
+    const i64 stride = (i64)a.wg_per_block * T;
+
+    double acc[Cfg::NI];
+    static_for<0, Cfg::NI>([&](auto I) { acc[decltype(I)::value] = 0.0; });
+    double extra[Cfg::NCOLS - Cfg::NOBS];
+    static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
+
+    for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
+        Sample<Cfg> s;
+        draw_sample<Cfg>(t, a.seed, stream, (u64)(B * a.neval_per_block + n), s);
+        double w[Cfg::NI];
+        Cfg)MCIDEV"
+R"MCIDEV(::integrand(s.x, w, a.ud); // vegas/montecarlo.jl:140-144
+        extra[Cols<Cfg>::NEVAL - Cfg::NOBS] += 1.0; // config.neval += 1   :118
+        if (a.measurefreq == 1 || (n + 1) % a.measurefreq == 0) { // :148
+            double relw[Cfg::NI];
+            static_for<0, Cfg::NI>([&](auto I) { constexpr int i = decltype(I)::value; relw[i] = w[i] * s.jaci[i]; }); // :152
+            measure<Cfg>(s, relw, acc, sO);
+            extra[Cols<Cfg>::NORM - Cfg::NOBS] += 1.0; // :164
+        }
+        double wh[Cfg::NI];
+        static_for<0, Cfg::NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const double wj = fabs(w[i]) * s.jac; // :173-174 (full jac, not the integrand's own: author's warning :175)
+            wh[i] = wj * wj;                      // :180
+        });
+        hist_update<Cfg>(s, wh, sH, a.ghist);
+    }
+    __syncthreads();
+    flush_workgroup<Cfg>(a, smem, acc, extra);
+}
+
+// =============================================================================================
+// VegasMC: independent Metropolis chains, one per lane  (vegas_mc/montecarlo.jl:112-241,
+// vegas_mc/updates.jl:45-106).  The reference runs ONE chain of neval steps per block; a block here
+// is `nchain` chains of neval/nchain steps (nchain = 1 reproduces the reference's chain).  Chain state
+// (x, prob, bin per draw; weights; probability) stays in registers; the proposal touches one
+// (pool, slot), selected by a compile-time switch so that every table access keeps static offsets.
+//   chain g = block*nchain + ch
+//   init  : stream MC_INIT, index g,            k = flat draw
+//   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
+// =============================================================================================
+template <class Cfg> struct Chain {
+    double x[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
+    double prob[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // leaf prob[idx]  (variable.jl:90)
+    int bin[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
+};
+
+// padding_probability(config, i) (variable.jl:628-641) and probability(config, i) (:606-619) as products
+// over the draws outside / inside integrand i's dof; i == NI is the normalisation integrand (dof = 0).
+template <class Cfg, int I> __device__ __forceinline__ double pad_prob(const Chain<Cfg> &c) {
+    double p = 1.0;
+    static_for<0, Cfg::NDRAW>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if constexpr (!((Cfg::own_mask(I) >> k) & 1ull)) p *= c.prob[k];
+    });
+    return p;
+}
+template <class Cfg, int I> __device__ __forceinline__ double own_prob(const Chain<Cfg> &c) {
+    double p = 1.0;
+    static_for<0, Cfg::NDRAW>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if constexpr ((Cfg::own_mask(I) >> k) & 1ull) p *= c.prob[k];
+    });
+    return p;
+}
+
+template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchArgs &a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NI = Cfg::NI, NORMI = Cfg::NI;
+    const int tid = threadIdx.x, T = blockDim.x;
+    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
+    double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
+    stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
+    if constexpr (Cfg::TABLE_MODE == 0)
+        for (int i = tid; i < Cfg::NBIN; i += T) sH[i] = 0.0;
+    for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    __syncthreads();
+    Tables<Cfg> t;
+    if constexpr (Cfg::TABLE_MODE <= 1) t.E = sE;
+    else t.E = a.edges;
+    t.DA = sDA;
+    t.DD = sDD;
+
+    const i64 lb = blockIdx.x / a.wg_per_block;
+    const int slice = blockIdx.x % a.wg_per_block;
+    const i64 B = a.block_lo + lb;
+    const i64 steps = a.neval_per_block / a.nchain;
+    const u32 st_init = a.iteration * 8u + STREAM_MC_INIT, st_step = a.iteration * 8u + STREAM_MC_STEP;
+    const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
+    double rw[NI + 1];
+    static_for<0, NI + 1>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
+
+    double acc[NI];
+    static_for<0, NI>([&](auto I) { acc[decltype(I)::value] = 0.0; });
+    double extra[Cfg::NCOLS - Cfg::NOBS];
+    static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
+    constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
+    constexpr int XP = Cols<Cfg>::PROPOSE - Cfg::NOBS, XA = Cols<Cfg>::ACCEPT - Cfg::NOBS;
+
+    for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
+        const u64 g = (u64)(B * a.nchain + ch);
+        Chain<Cfg> c;
+        {   // initialize!  (montecarlo.jl:151-153): create! on every live slot
+            Sample<Cfg> s;
+            draw_sample<Cfg>(t, a.seed, st_init, g, s);
+            static_for<0, Cfg::NDRAW>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                c.x[k] = s.x[k];
+                c.bin[k] = s.bin[k];
+                c.prob[k] = 1.0 / s.pj[k]; // sampler.jl:303 / :20
+            });
+        }
+        double w[NI], pad[NI + 1];
+        Cfg::integrand(c.x, w, a.ud); // :155-159
+        static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(c); }); // :161
+        double probability = rw[NORMI] * pad[NORMI]; // :162
+        static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; probability += fabs(w[i]) * rw[i] * pad[i]; }); // :163-166
+
+        for (i64 ne = 1; ne <= steps; ++ne) { // :184
+            const u64 sidx = (g << 32) | (u64)(ne - 1);
+            const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
+            const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
+            // ---- changeVariable  updates.jl:45-106 ----
+            int vi = (int)(u01(r0.x, r0.y) * (double)Cfg::NPOOL); // :50
+            if (vi >= Cfg::NPOOL) vi = Cfg::NPOOL - 1;
+            const double uslot = u01(r0.z, r0.w);
+            const double uacc = u01(r1.x, r1.y);
+            Chain<Cfg> n = c; // proposal; unchanged draws are copy-propagated
+            double prop = 1.0;
+            bool active = false;
+            static_for<0, Cfg::NPOOL>([&](auto V) {
+                constexpr int v = decltype(V)::value;
+                constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                // :52-57  a lone single-valued Discrete, or a pool nobody uses, has nothing to sample
+                constexpr bool skip = (md <= 0) || (nl == 1 && Cfg::leaf_kind(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1 &&
+                                                    Cfg::leaf_nbin(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1);
+                if constexpr (!skip) {
+                    if (vi == v) {
+                        active = true;
+                        int slot = (int)(uslot * (double)md); // :58
+                        if (slot >= md) slot = md - 1;
+                        static_for<0, md>([&](auto S) {
+                            constexpr int sl = decltype(S)::value;
+                            if (slot == sl) {
+                                static_for<0, nl>([&](auto Lf) {
+                                    constexpr int l = decltype(Lf)::value;
+                                    constexpr int k = k00 + sl * nl + l;
+                                    constexpr int kk = 3 + l; // RNG draw index within the step
+                                    double y;
+                                    if constexpr (kk == 3) y = u01(r1.z, r1.w);
+                                    else {
+                                        const u32x4 rr = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(kk >> 1), st_step, k0, k1);
+                                        y = (kk & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
+                                    }
+                                    double pj;
+   )MCIDEV"
+R"MCIDEV(                                 draw_leaf<Cfg, k>(t, y, n.x[k], pj, n.bin[k]); // shift!  sampler.jl:336-386, :57-71
+                                    n.prob[k] = 1.0 / pj;
+                                    prop *= c.prob[k] / n.prob[k];                  // 1/prob_ratio  sampler.jl:385, :70
+                                });
+                            }
+                        });
+                    }
+                }
+            });
+            if (active && prop > 4.9406564584124654e-324) { // :63-65
+                double wn[NI], padn[NI + 1];
+                Cfg::integrand(n.x, wn, a.ud);                 // :67-75
+                extra[XE] += 1.0;                              // config.neval += 1   :77
+                static_for<0, NI + 1>([&](auto I) { padn[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(n); }); // :79-81
+                double newp = rw[NORMI] * padn[NORMI];         // :84
+                static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; newp += fabs(wn[i]) * rw[i] * padn[i]; }); // :85-87
+                const double R = prop * newp / probability;    // :88
+                const bool ok = uacc < R;                      // :91
+                static_for<0, Cfg::NPOOL>([&](auto V) {
+                    constexpr int v = decltype(V)::value;
+                    if (vi == v) {
+                        extra[XP + v] += 1.0;                  // :90
+                        if (ok) extra[XA + v] += 1.0;          // :92
+                    }
+                });
+                if (ok) {
+                    c = n;
+                    static_for<0, NI>([&](auto I) { w[decltype(I)::value] = wn[decltype(I)::value]; });       // :93-95
+                    static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = padn[decltype(I)::value]; }); // :96-98
+                    probability = newp;                        // :100
+                } // else shiftRollback!  :102  (the proposal copy is dropped)
+            }
+            // ---- histogram  montecarlo.jl:198-211 ----
+            {
+                double wh[NI];
+                static_for<0, NI>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    const double f2 = fabs(w[i]) * fabs(w[i]) / own_prob<Cfg, i>(c); // :203
+                    wh[i] = f2 * pad[i] / probability;                                 // :204
+                });
+                Sample<Cfg> sb;
+                static_for<0, Cfg::NDRAW>([&](auto K) { sb.bin[decltype(K)::value] = c.bin[decltype(K)::value]; });
+                hist_update<Cfg>(sb, wh, sH, a.ghist);
+            }
+            // ---- measurement  montecarlo.jl:213-232 ----
+            const bool mf = (a.measurefreq == 1) || (ne % a.measurefreq == 0);
+            if (mf && (double)ne >= (double)steps / 100.0) {
+                double relw[NI];
+                static_for<0, NI>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    extra[XV + i] += fabs(w[i] * pad[i] * rw[i]) / probability; // :216
+                    relw[i] = w[i] * pad[i] / probability;                      // :218/:220
+                });
+                Sample<Cfg> sb;
+                static_for<0, Cfg::NDRAW>([&](auto K) { sb.bin[decltype(K)::value] = c.bin[decltype(K)::value]; });
+                measure<Cfg>(sb, relw, acc, sO);
+                extra[XN] += pad[NORMI] / probability;                // :229
+                extra[XV + NORMI] += rw[NORMI] * pad[NORMI] / probability; // :230
+            }
+        }
+    }
+    __syncthreads();
+    flush_workgroup<Cfg>(a, smem, acc, extra);
+}
+
+// the map + integrand alone, for parity tests of a2/a3 and for host-side consumers
+template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs &a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
+    stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
+    __syncthreads();
+    Tables<Cfg> t;
+    if constexpr (Cfg::TABLE_MODE <= 1) t.E = sE;
+    else t.E = a.edges;
+    t.DA = sDA;
+    t.DD = sDD;
+    const u32 stream = a.iteration * 8u + STREAM_VEGAS;
+    for (i64 n = (i64)blockIdx.x * blockDim.x + threadIdx.x; n < a.n; n += (i64)gridDim.x * blockDim.x) {
+        Sample<Cfg> s;
+        draw_sample<Cfg>(t, a.seed, stream, (u64)(a.first_index + n), s);
+        double w[Cfg::NI];
+        Cfg::integrand(s.x, w, a.ud);
+        static_for<0, Cfg::NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[n * Cfg::NDRAW + k] = s.x[k]; });
+        a.jac[n] = s.jac;
+        static_for<0, Cfg::NI>([&](auto I) { constexpr int i = decltype(I)::value; a.w[n * Cfg::NI + i] = w[i]; });
+    }
+}
+
+} // namespace mci
+)MCIDEV";
+}

@@ -1,0 +1,201 @@
+// mci_jit.h -- run-time specialisation of the sample-batch kernels (host side).
+//
+// The reference gets its per-problem specialisation from Julia's JIT: Vegas.montecarlo is compiled for
+// each Configuration{N,V,P,O,T} and the integrand closure is inlined (src/vegas/montecarlo.jl:72-75,
+// :140-144).  Here a small translation unit -- a `Cfg` traits struct holding the problem's static
+// shape and the user's integrand body -- is generated, compiled with hiprtc for gfx950 against the
+// hand-written kernels of mci_device.h, and cached on disk as a code object.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace mcijit {
+
+// text of mci_device.h, embedded at build time (see __graft_entry__.build)
+extern const char *const kDeviceHeader;
+
+struct ProblemShape {
+    int ndraw = 0, nleaf = 0, ni = 0, npool = 0, nobs = 0, ncols = 0, table_mode = 0;
+    int nedge = 0, ndacc = 0, nddist = 0, nbin = 0;
+    std::vector<int> draw_leaf, draw_pool, draw_slot;
+    std::vector<int> leaf_kind, leaf_nbin, leaf_eoff, leaf_doff, leaf_boff, leaf_adapt;
+    std::vector<double> leaf_lower;
+    std::vector<unsigned long long> own_mask;   // [ni+1] draws covered by integrand i (last = normalisation: 0)
+    std::vector<unsigned long long> cover_mask; // [ndraw] integrands covering draw k
+    std::vector<int> obs_off, obs_nbin, obs_bin_draw;
+    std::vector<int> pool_maxdof, pool_nleaf, pool_first_draw;
+    std::string body;
+};
+
+template <class T> static std::string arr(const std::vector<T> &v, const char *ty, const char *suffix = "") {
+    std::ostringstream o;
+    o.precision(17);
+    o << "{";
+    for (size_t i = 0; i < v.size(); ++i) o << (i ? ", " : "") << v[i] << suffix;
+    if (v.empty()) o << "0";
+    o << "}";
+    (void)ty;
+    return o.str();
+}
+
+static std::string fn_table(const char *ret, const char *name, const std::string &values) {
+    std::ostringstream o;
+    o << "    static constexpr " << ret << " " << name << "(int i) { constexpr " << ret << " t[] = " << values
+      << "; return t[i]; }\n";
+    return o.str();
+}
+
+static std::string dbl_arr(const std::vector<double> &v) {
+    std::ostringstream o;
+    o << "{";
+    char buf[64];
+    for (size_t i = 0; i < v.size(); ++i) {
+        snprintf(buf, sizeof buf, "%a", v[i]); // hex float: exact round trip
+        o << (i ? ", " : "") << buf;
+    }
+    if (v.empty()) o << "0.0";
+    o << "}";
+    return o.str();
+}
+
+inline std::string generate_source(const ProblemShape &s) {
+    std::ostringstream o;
+    o << "#include \"mci_device.h\"\n";
+    o << "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n";
+    o << "namespace {\nstruct Cfg {\n";
+    o << "    static constexpr int NDRAW = " << s.ndraw << ", NLEAF = " << s.nleaf << ", NI = " << s.ni
+      << ", NPOOL = " << s.npool << ", NOBS = " << s.nobs << ", NCOLS = " << s.ncols << ";\n";
+    o << "    static constexpr int TABLE_MODE = " << s.table_mode << ", NEDGE = " << s.nedge << ", NDACC = " << s.ndacc
+      << ", NDDIST = " << s.nddist << ", NBIN = " << s.nbin << ";\n";
+    o << fn_table("int", "draw_leaf", arr(s.draw_leaf, "int"));
+    o << fn_table("int", "draw_pool", arr(s.draw_pool, "int"));
+    o << fn_table("int", "draw_slot", arr(s.draw_slot, "int"));
+    o << fn_table("int", "leaf_kind", arr(s.leaf_kind, "int"));
+    o << fn_table("int", "leaf_nbin", arr(s.leaf_nbin, "int"));
+    o << fn_table("int", "leaf_eoff", arr(s.leaf_eoff, "int"));
+    o << fn_table("int", "leaf_doff", arr(s.leaf_doff, "int"));
+    o << fn_table("int", "leaf_boff", arr(s.leaf_boff, "int"));
+    o << fn_table("int", "leaf_adapt", arr(s.leaf_adapt, "int"));
+    o << fn_table("double", "leaf_lower", dbl_arr(s.leaf_lower));
+    o << fn_table("unsigned long long", "own_mask", arr(s.own_mask, "u64", "ull"));
+    o << fn_table("unsigned long long", "cover_mask", arr(s.cover_mask, "u64", "ull"));
+    o << fn_table("int", "obs_off", arr(s.obs_off, "int"));
+    o << fn_table("int", "obs_nbin", arr(s.obs_nbin, "int"));
+    o << fn_table("int", "obs_bin_draw", arr(s.obs_bin_draw, "int"));
+    o << fn_table("int", "pool_maxdof", arr(s.pool_maxdof, "int"));
+    o << fn_table("int", "pool_nleaf", arr(s.pool_nleaf, "int"));
+    o << fn_table("int", "pool_first_draw", arr(s.pool_first_draw, "int"));
+    o << "    // the user's integrand (reference: the `integrand` closure, vegas/montecarlo.jl:140-144)\n";
+    o << "    static __device__ __forceinline__ void integrand(const double* __restrict__ x, double* __restrict__ w, "
+         "const double* __restrict__ ud) {\n"
+      << s.body << "\n    }\n";
+    o << "};\n}\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_batch(mci::BatchArgs a) { "
+         "mci::vegas_batch<Cfg>(a); }\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_chains(mci::BatchArgs a) { "
+         "mci::vegasmc_chains<Cfg>(a); }\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(256) mci_sample_dump(mci::DumpArgs a) { "
+         "mci::sample_dump<Cfg>(a); }\n";
+    return o.str();
+}
+
+inline uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull) {
+    for (unsigned char c : s) {
+        h ^= c;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+inline std::string cache_dir() {
+    if (const char *e = getenv("MCI_KERNEL_CACHE")) return e;
+    Dl_info info;
+    std::string dir = ".";
+    if (dladdr((void *)&cache_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname; // .../mcintegration.jl_amd/lib/libmci_hip.so
+        size_t k = p.rfind('/');
+        if (k != std::string::npos) dir = p.substr(0, k) + "/../kernel_cache";
+    }
+    return dir;
+}
+
+// returns the gfx950 code object for `src`, from the on-disk cache or by compiling with hiprtc
+inline int compile(const std::string &src, int threads, std::vector<char> &code, std::string &log, bool &from_cache) {
+    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics",
+                                     "-ffp-contract=off", "-DMCI_THREADS=" + std::to_string(threads)};
+    if (const char *e = getenv("MCI_JIT_FLAGS")) {
+        std::istringstream is(e);
+        std::string t;
+        while (is >> t) opts.push_back(t);
+    }
+    std::string key = src + "\n//HDR\n" + kDeviceHeader;
+    for (auto &f : opts) key += "\n//" + f;
+    char name[64];
+    snprintf(name, sizeof name, "mci_%016llx.hsaco", (unsigned long long)fnv1a(key));
+    const std::string dir = cache_dir(), path = dir + "/" + name;
+    from_cache = false;
+    {
+        std::ifstream f(path, std::ios::binary);
+        if (f) {
+            code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            if (!code.empty()) {
+                from_cache = true;
+                return 0;
+            }
+        }
+    }
+    if (const char *e = getenv("MCI_DUMP_SRC")) {
+        std::ofstream f(e);
+        f << src;
+    }
+    hiprtcProgram prog;
+    const char *hdr = kDeviceHeader, *hname = "mci_device.h";
+    if (hiprtcCreateProgram(&prog, src.c_str(), "mci_problem.hip", 1, &hdr, &hname) != HIPRTC_SUCCESS) {
+        log = "hiprtcCreateProgram failed";
+        return 1;
+    }
+    std::vector<const char *> copts;
+    for (auto &f : opts) copts.push_back(f.c_str());
+    hiprtcResult r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    if (ls > 1) {
+        log.resize(ls);
+        hiprtcGetProgramLog(prog, &log[0]);
+    }
+    if (r != HIPRTC_SUCCESS) {
+        hiprtcDestroyProgram(&prog);
+        if (log.empty()) log = hiprtcGetErrorString(r);
+        return 2;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    code.resize(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    mkdir(dir.c_str(), 0755);
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        if (f) {
+            f.write(code.data(), (std::streamsize)code.size());
+            f.close();
+            if (rename(tmp.c_str(), path.c_str()) != 0) unlink(tmp.c_str());
+        }
+    }
+    return 0;
+}
+
+} // namespace mcijit

@@ -1,0 +1,252 @@
+// mci_static_kernels.h -- configuration-independent gfx950 kernels, compiled ahead of time by hipcc:
+// partial reduction (block merge, reference src/main.jl:273-287, src/configuration.jl:252-262),
+// reweighting (src/main.jl:322-346) and grid refinement (src/distribution/variable.jl:206-239,
+// :369-382 with src/distribution/common.jl:43-82).  These are O(bins) per iteration; they stay on the
+// device so that an iteration is one asynchronous chain  sample -> merge -> all-reduce -> train  with
+// no host round trip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mci {
+
+struct LeafDev {
+    int kind;   // 0 continuous, 1 discrete
+    int nbin;   // continuous: npts-1 ; discrete: K
+    int eoff;   // continuous: offset into edges ; discrete: offset into dacc
+    int doff;   // discrete: offset into ddist
+    int boff;   // offset into the histogram section
+    int adapt;
+    double alpha;
+};
+
+enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_RESCALE_NONFINITE = 8 };
+
+// stage 1 of the histogram merge: out[g][bin] = sum over this group's workgroups (fixed order)
+__global__ void __launch_bounds__(256) k_hist_stage1(const double *__restrict__ part_hist, int nwg, int nbin, int ngroup,
+                                                     double *__restrict__ out) {
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    if (bin >= nbin) return;
+    const int per = (nwg + ngroup - 1) / ngroup;
+    const int w0 = g * per, w1 = min(nwg, w0 + per);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int w = w0;
+    for (; w + 3 < w1; w += 4) {
+        s0 += part_hist[(size_t)(w + 0) * nbin + bin];
+        s1 += part_hist[(size_t)(w + 1) * nbin + bin];
+        s2 += part_hist[(size_t)(w + 2) * nbin + bin];
+        s3 += part_hist[(size_t)(w + 3) * nbin + bin];
+    }
+    for (; w < w1; ++w) s0 += part_hist[(size_t)w * nbin + bin];
+    out[(size_t)g * nbin + bin] = (s0 + s1) + (s2 + s3);
+}
+
+// packed = [obsSum(nobs) | obsSqSum(nobs) | normalization | neval | visited(ni+1) | hist(nbin)]
+// Workgroups [0, nhb) merge the histogram section; the last workgroup merges the statistics columns
+// block by block:  m = observable/normalization; obsSum += m; obsSquaredSum += m*m   (main.jl:275-287)
+// with every block and the merged config starting from clearStatistics! values (configuration.jl:238-250):
+// normalization 1e-10, visited 1e-8, histogram 1e-10.
+__global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ part_cols, int ncols, int nobs, int ni,
+                                                  int nblocks, int wg_per_block, const double *__restrict__ stage1,
+                                                  int ngroup, double *__restrict__ ghist, int use_ghist, int nbin,
+                                                  double *__restrict__ packed, int *__restrict__ status,
+                                                  double *__restrict__ scratch /*[nblocks*ncols]*/) {
+    const int nhb = (nbin + 255) / 256;
+    const int hoff = 2 * nobs + 2 + ni + 1;
+    if ((int)blockIdx.x < nhb) {
+        const int bin = blockIdx.x * 256 + threadIdx.x;
+        if (bin >= nbin) return;
+        double s = (double)(nblocks + 1) * 1.0e-10;
+        if (use_ghist) {
+            s += ghist[bin];
+            ghist[bin] = 0.0; // ready for the next iteration
+        } else {
+            for (int g = 0; g < ngroup; ++g) s += stage1[(size_t)g * nbin + bin];
+        }
+        packed[hoff + bin] = s;
+        return;
+    }
+    // --- statistics columns ---
+    for (int idx = threadIdx.x; idx < nblocks * ncols; idx += blockDim.x) {
+        const int b = idx / ncols, c = idx % ncols;
+        double s = 0.0;
+        for (int w = 0; w < wg_per_block; ++w) s += part_cols[(size_t)(b * wg_per_block + w) * ncols + c];
+        scratch[idx] = s;
+    }
+    __syncthreads();
+    const int cnorm = nobs, cneval = nobs + 1, cvis = nobs + 2;
+    for (int o = threadIdx.x; o < nobs; o += blockDim.x) {
+        double sum = 0.0, sq = 0.0;
+        for (int b = 0; b < nblocks; ++b) {
+            const double norm = scratch[b * ncols + cnorm] + 1.0e-10;
+            const double m = scratch[b * ncols + o] / norm;
+            sum += m;
+            sq += m * m;
+        }
+        packed[o] = sum;
+        packed[nobs + o] = sq;
+    }
+    if (threadIdx.x == 0) {
+        double norm = 1.0e-10, neval = 0.0;
+        int bad = 0;
+        for (int b = 0; b < nblocks; ++b) {
+            const double nb = scratch[b * ncols + cnorm] + 1.0e-10;
+            if (!(nb > 0.0)) bad = 1; // main.jl:269-271
+            norm += nb;
+            neval += scratch[b * ncols + cneval];
+        }
+        packed[2 * nobs] = norm;
+        packed[2 * nobs + 1] = neval;
+        if (bad) atomicOr(status, ST_NORMALIZATION);
+    }
+    for (int i = threadIdx.x; i < ni + 1; i += blockDim.x) {
+        double v = 1.0e-8;
+        for (int b = 0; b < nblocks; ++b) v += scratch[b * ncols + cvis + i] + 1.0e-8;
+        packed[2 * nobs + 2 + i] = v;
+    }
+}
+
+// doReweight!  main.jl:322-346 (goal = nullptr: no reweight_goal)
+__device__ inline void do_reweight_dev(double *reweight, const double *visited, int nd, double gamma) {
+    double avgstep = 0.0;
+    for (int i = 0; i < nd; ++i) avgstep += visited[i];
+    for (int i = 0; i < nd; ++i) {
+        if (visited[i] <= 1) reweight[i] *= pow(avgstep, gamma);
+        else reweight[i] *= pow(avgstep / visited[i], gamma);
+    }
+    double s = 0.0;
+    for (int i = 0; i < nd; ++i) s += reweight[i];
+    for (int i = 0; i < nd; ++i) reweight[i] /= s;
+}
+
+// One workgroup per leaf: Dist.train! then clearStatistics!.  Workgroup `nleaf` does the
+// per-iteration bookkeeping: copy the statistics head of `packed` into the iteration log and, for
+// vegasmc, apply doReweight!.
+__global__ void __launch_bounds__(256) k_train(const LeafDev *__restrict__ leaves, int nleaf, double *__restrict__ packed,
+                                               int nstat, double *__restrict__ edges, double *__restrict__ dacc,
+                                               double *__restrict__ ddist, double *__restrict__ iter_log_row,
+                                               double *__restrict__ reweight, int nd, int do_reweight, double gamma,
+                                               int do_train, int *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, T = blockDim.x;
+    if ((int)blockIdx.x == nleaf) {
+        if (iter_log_row)
+            for (int i = tid; i < nstat; i += T) iter_log_row[i] = packed[i];
+        if (do_reweight && tid == 0) do_reweight_dev(reweight, packed + (nstat - nd), nd, gamma);
+        return;
+    }
+    if (!do_train) return;
+    const LeafDev L = leaves[blockIdx.x];
+    if (!L.adapt) return; // variable.jl:208, :370
+    const int N = L.nbin;
+    double *h = packed + nstat + L.boff;
+    double *d = sm;              // [N]   smoothed / rescaled distribution
+    double *ng = sm + N;         // [N+1] new grid
+    double *sg = sm + 2 * N + 1; // [N+1] old grid staged in LDS (the walk below is a serial gather)
+    __shared__ int bad;
+    __shared__ double ssum;
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += T) {
+        const double v = h[i];
+        if (!isfinite(v)) atomicOr(&bad, ST_HIST_NONFINITE);      // variable.jl:212
+        else if (!(v > 0.0)) atomicOr(&bad, ST_HIST_NONPOSITIVE); // variable.jl:213 / common.jl:71
+    }
+    __syncthreads();
+    if (bad) {
+        if (tid == 0) atomicOr(status, bad);
+        return;
+    }
+    if (L.kind == 0) {
+        double *g = edges + L.eoff;
+        for (int i = tid; i <= N; i += T) sg[i] = g[i];
+        // smooth(hist, 6)  common.jl:43-54
+        for (int i = tid; i < N; i += T) {
+            double v;
+            if (N <= 1) v = h[i];
+            else if (i == 0) v = (h[0] * 7.0 + h[1]) / 8.0;
+            else if (i == N - 1) v = (h[N - 1] * 7.0 + h[N - 2]) / 8.0;
+            else v = (h[i - 1] + h[i] * 6.0 + h[i + 1]) / 8.0;
+            d[i] = v;
+        }
+        __syncthreads();
+        // rescale  common.jl:67-82 (sum left to right, like the oracle)
+        if (N > 1) {
+            if (tid == 0) {
+                double s = 0.0;
+                for (int i = 0; i < N; ++i) s += d[i];
+                ssum = s;
+            }
+            __syncthreads();
+            const double s = ssum;
+            for (int i = tid; i < N; i += T) {
+                double v = d[i] / s;
+                if (v > 0 && v <= 0.99999999) v = pow(-(1 - v) / log(v), L.alpha);
+                if (!isfinite(v)) atomicOr(&bad, ST_RESCALE_NONFINITE); // common.jl:79
+                d[i] = v;
+            }
+            __syncthreads();
+            if (bad) {
+                if (tid == 0) atomicOr(status, bad);
+                return;
+            }
+        }
+        // refinement walk  variable.jl:216-235 (serial recurrence, kept in the reference's order)
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < N; ++i) s += d[i];
+            const double f_ninc = s / (double)N;
+            int j = 0;
+            double acc_f = 0.0;
+            ng[0] = sg[0];
+            ng[N] = sg[N];
+            for (int i = 2; i <= N; ++i) {
+                while (acc_f < f_ninc) {
+                    j += 1;
+                    acc_f += d[j - 1];
+                }
+                acc_f -= f_ninc;
+                ng[i - 1] = sg[j] - (acc_f / d[j - 1]) * (sg[j] - sg[j - 1]);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i <= N; i += T) g[i] = ng[i];
+    } else {
+        // train!(Discrete)  variable.jl:369-382 : rescale (no smoothing), normalise, prefix sum
+        double *acc = dacc + L.eoff, *dist = ddist + L.doff;
+        if (tid == 0) {
+            int lbad = 0;
+            if (N > 1) {
+                double s = 0.0;
+                for (int i = 0; i < N; ++i) s += h[i];
+                for (int i = 0; i < N; ++i) {
+                    double v = h[i] / s;
+                    if (v > 0 && v <= 0.99999999) v = pow(-(1 - v) / log(v), L.alpha);
+                    if (!isfinite(v)) lbad = ST_RESCALE_NONFINITE;
+                    d[i] = v;
+                }
+            } else {
+                d[0] = h[0];
+            }
+            if (lbad) {
+                atomicOr(status, lbad);
+            } else {
+                double s = 0.0;
+                for (int i = 0; i < N; ++i) s += d[i];
+                double run = 0.0;
+                acc[0] = 0.0;
+                for (int i = 0; i < N; ++i) {
+                    const double v = d[i] / s;
+                    dist[i] = v;
+                    run += v;
+                    acc[i + 1] = run;
+                }
+            }
+        }
+    }
+    // clearStatistics!(T)  variable.jl:238/:381 -> :565 (the next iteration's merge starts from its own fill)
+    __syncthreads();
+    for (int i = tid; i < N; i += T) h[i] = 1.0e-10;
+}
+
+} // namespace mci

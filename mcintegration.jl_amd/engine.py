@@ -1,0 +1,198 @@
+"""Engine: one mci_problem on one GPU (device-resident grids, histograms, statistics)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import LeafDesc, ProblemDesc, c_double_p, c_int32_p, check, lib
+from .integrand import Integrand
+from .variables import ContinuousVar
+
+_ctx_cache = {}
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def context(device=0):
+    """One mci_ctx (HIP stream + optional RCCL communicator) per device per process.
+    device < 0 gives the offline, compile-only context (kernel cache pre-fill; no GPU needed)."""
+    if device not in _ctx_cache:
+        p = C.c_void_p()
+        check(lib().mci_ctx_create(device, C.byref(p)))
+        _ctx_cache[device] = p
+    return _ctx_cache[device]
+
+
+def device_count():
+    n = C.c_int32()
+    lib().mci_device_count(C.byref(n))
+    return n.value
+
+
+class Engine:
+    def __init__(self, config, integrand, measure=None, device=0, threads=None, wg_per_block=None):
+        L = lib()
+        self.config = config
+        self.device = device
+        self.ctx = context(device)
+        if isinstance(integrand, str):
+            integrand = Integrand(integrand, config.userdata)
+        self.integrand = integrand
+        leaves = config.leaves
+        self._keep = []
+        arr = (LeafDesc * len(leaves))()
+        for i, lf in enumerate(leaves):
+            d = arr[i]
+            d.pool = config.leaf_pool[i]
+            d.alpha, d.adapt = lf.alpha, 1 if lf.adapt else 0
+            d.lower, d.upper = float(lf.lower), float(lf.upper)
+            init = None
+            if isinstance(lf, ContinuousVar):
+                d.kind, d.npoints = _lib.CONTINUOUS, lf.ninc
+                init = lf._grid0
+            else:
+                d.kind, d.npoints = _lib.DISCRETE, 0
+                init = lf._dist0
+            if init is not None:
+                init = np.ascontiguousarray(init, dtype=np.float64)
+                self._keep.append(init)
+                d.init = _dp(init)
+        dof = np.ascontiguousarray(config.dof, dtype=np.int32)
+        onb = np.ascontiguousarray(config.obs_nbin, dtype=np.int32)
+        obd = np.ascontiguousarray(config.obs_bin_draw(measure), dtype=np.int32)
+        desc = ProblemDesc(len(leaves), arr, len(config.var), config.N, dof.ctypes.data_as(c_int32_p),
+                           onb.ctypes.data_as(c_int32_p), obd.ctypes.data_as(c_int32_p))
+        self.p = C.c_void_p()
+        check(L.mci_problem_create(self.ctx, C.byref(desc), C.byref(self.p)))
+        ud = integrand.userdata
+        check(L.mci_set_integrand_source(self.p, integrand.body.encode(), _dp(ud) if len(ud) else None, len(ud)))
+        if threads or wg_per_block is not None:
+            check(L.mci_set_launch(self.p, threads or 0, -1 if wg_per_block is None else wg_per_block))
+        nd, no, ps, tm, lds = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64()
+        check(L.mci_problem_info(self.p, C.byref(nd), C.byref(no), C.byref(ps), C.byref(tm), C.byref(lds)))
+        self.ndraw, self.nobs, self.packed_size, self.table_mode, self.lds_bytes = nd.value, no.value, ps.value, tm.value, lds.value
+        if device >= 0 and not np.allclose(config._reweight0, 1.0 / (config.N + 1)):
+            r = np.ascontiguousarray(config._reweight0)
+            check(L.mci_set_reweight(self.p, _dp(r), len(r)))
+        for i, lf in enumerate(leaves):
+            lf._engine, lf._leaf_index = self, i
+
+    def close(self):
+        if getattr(self, "p", None):
+            lib().mci_problem_destroy(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- kernels -------------------------------------------------------------------------------
+    def compile(self):
+        check(lib().mci_compile(self.p))
+
+    def set_launch(self, threads=0, wg_per_block=-1):
+        check(lib().mci_set_launch(self.p, threads, wg_per_block))
+
+    def run(self, solver, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq=1, nchain=0):
+        check(lib().mci_iteration_run(self.p, _lib.SOLVERS[solver], int(nevalperblock), int(block_lo), int(block_hi),
+                                      int(iteration), int(seed), int(measurefreq), int(nchain)))
+
+    def reduce(self):
+        check(lib().mci_iteration_reduce(self.p))
+
+    def finish(self, solver, block_total, adapt=True, gamma=1.0, want_stats=True):
+        if not want_stats:
+            check(lib().mci_iteration_finish(self.p, _lib.SOLVERS[solver], int(block_total), 1 if adapt else 0, gamma, None, None))
+            return None, None
+        m, e = np.empty(self.nobs), np.empty(self.nobs)
+        check(lib().mci_iteration_finish(self.p, _lib.SOLVERS[solver], int(block_total), 1 if adapt else 0, gamma, _dp(m), _dp(e)))
+        return m, e
+
+    def iteration(self, solver, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq=1, nchain=0):
+        """run + read back the local packed buffer [obsSum|obsSqSum|normalization|neval|visited|histograms]"""
+        self.run(solver, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq, nchain)
+        return self.get_packed()
+
+    def get_packed(self):
+        out = np.empty(self.packed_size)
+        check(lib().mci_get_packed(self.p, _dp(out), len(out)))
+        return out
+
+    def set_packed(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        check(lib().mci_set_packed(self.p, _dp(a), len(a)))
+
+    def packed_device_ptr(self):
+        return lib().mci_packed_device_ptr(self.p)
+
+    def train(self):
+        check(lib().mci_train(self.p))
+
+    def integrate(self, solver, neval, niter=10, block=16, ignore=-1, adapt=True, gamma=1.0, measurefreq=1, seed=1234,
+                  nchain=0, first_iteration=0):
+        """the whole loop inside the library (mci_integrate)"""
+        a = _lib.IntegrateArgs(_lib.SOLVERS[solver], int(neval), int(niter), int(block), int(ignore), 1 if adapt else 0,
+                               float(gamma), int(measurefreq), int(seed), int(nchain), int(first_iteration))
+        n = self.nobs
+        im, ie = np.zeros((niter, n)), np.zeros((niter, n))
+        m, s, c2 = np.zeros(n), np.zeros(n), np.zeros(n)
+        r = _lib.ResultC(niter, n, _dp(im), _dp(ie), _dp(m), _dp(s), _dp(c2), 0, 0.0)
+        check(lib().mci_integrate(self.p, C.byref(a), C.byref(r)))
+        return dict(mean=m, stdev=s, chi2=c2, iter_mean=im, iter_std=ie, neval=r.neval, seconds=r.seconds)
+
+    def sample_dump(self, n, nevalperblock=None, block_index=0, iteration=0, seed=1234):
+        nevalperblock = n if nevalperblock is None else nevalperblock
+        x, jac, w = np.empty((n, self.ndraw)), np.empty(n), np.empty((n, self.config.N))
+        check(lib().mci_sample_dump(self.p, iteration, seed, int(nevalperblock), int(block_index), int(n), _dp(x), _dp(jac), _dp(w)))
+        return x, jac, w
+
+    def last_kernel_ms(self):
+        ms, wg, th = C.c_float(), C.c_int32(), C.c_int32()
+        check(lib().mci_last_kernel_ms(self.p, C.byref(ms), C.byref(wg), C.byref(th)))
+        return ms.value, wg.value, th.value
+
+    # ---- state ---------------------------------------------------------------------------------
+    def grid(self, leaf):
+        n = self.config.leaves[leaf].ninc
+        out = np.empty(n)
+        check(lib().mci_get_grid(self.p, leaf, _dp(out), n))
+        return out
+
+    def set_grid(self, leaf, grid):
+        g = np.ascontiguousarray(grid, dtype=np.float64)
+        check(lib().mci_set_grid(self.p, leaf, _dp(g), len(g)))
+
+    def distribution(self, leaf):
+        lf = self.config.leaves[leaf]
+        k = lf.upper - lf.lower + 1
+        d, a = np.empty(k), np.empty(k + 1)
+        check(lib().mci_get_distribution(self.p, leaf, _dp(d), _dp(a), k))
+        return d, a
+
+    def set_distribution(self, leaf, dist):
+        d = np.ascontiguousarray(dist, dtype=np.float64)
+        check(lib().mci_set_distribution(self.p, leaf, _dp(d), len(d)))
+
+    def histogram(self, leaf):
+        """histogram section of the packed buffer for one leaf"""
+        packed = self.get_packed()
+        off = 2 * self.nobs + 2 + self.config.N + 1
+        for i, lf in enumerate(self.config.leaves):
+            nb = (lf.ninc - 1) if isinstance(lf, ContinuousVar) else (lf.upper - lf.lower + 1)
+            if i == leaf:
+                return packed[off:off + nb]
+            off += nb
+        raise IndexError(leaf)
+
+    def reweight(self):
+        out = np.empty(self.config.N + 1)
+        check(lib().mci_get_reweight(self.p, _dp(out), len(out)))
+        return out
+
+    def set_reweight(self, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        check(lib().mci_set_reweight(self.p, _dp(r), len(r)))

@@ -1,0 +1,25 @@
+"""The integrand closure of the reference (vegas/montecarlo.jl:140-144) as HIP C++ source."""
+import numpy as np
+
+
+class Integrand:
+    """body: HIP C++ statements with `const double* x` (flat draws, reference draw order: pool, slot, leaf;
+    0-based), `double* w` (one output per integrand) and `const double* ud` (userdata) in scope.
+    A body without `w[` is treated as an expression/return form: `return expr;` -> w[0] = expr."""
+
+    def __init__(self, body, userdata=None, name=None):
+        body = body.strip()
+        if "w[" not in body:
+            expr = body[len("return"):].strip().rstrip(";") if body.startswith("return") else body.rstrip(";")
+            body = "w[0] = (%s);" % expr
+        self.body = body
+        self.userdata = np.ascontiguousarray([] if userdata is None else userdata, dtype=np.float64)
+        self.name = name or "user"
+
+
+class bin_by:
+    """measure(vars, obs, weights, config): obs[i][Ext[1]] += weights[i]  (example/bubble.jl:81-84):
+    observable bins are selected by the value of the Discrete pool `pool` (its first slot)."""
+
+    def __init__(self, pool, slot=0, leaf=0):
+        self.pool, self.slot, self.leaf = pool, slot, leaf

@@ -1,0 +1,118 @@
+"""`integrate(integrand; solver, config, neval, niter, block, ...)`  reference src/main.jl:71-218."""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import catalog
+from ._lib import SOLVERS, VEGAS, VEGASMC, lib
+from .comm import LocalComm
+from .configuration import Configuration
+from .engine import Engine
+from .integrand import Integrand
+from .statistics import Result, report
+from .variables import Continuous, Discrete
+
+
+def standardize_block(neval, nblock, nworker=1):
+    """_standardize_block (main.jl:220-234)"""
+    assert neval > nblock, "neval=%s should be larger than nblock = %s" % (neval, nblock)   # :222
+    a, b = C.c_int64(), C.c_int64()
+    lib().mci_standardize_block(int(neval), int(nblock), int(nworker), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, block=16, verbose=-1, gamma=1.0,
+              adapt=True, debug=False, reweight_goal=None, ignore=None, measure=None, measurefreq=1,
+              thermal_ratio=0.1, inplace=False, parallel="nothread", print=-1, printio=None, timer=None,
+              comm=None, device=0, nchain=0, engine_factory=None, **kwargs):
+    """Same keywords as the reference (main.jl:71-90; unknown ones go to Configuration, :95-97).
+    Extra, engine-specific keywords: `comm` (LocalComm | RcclComm | TorchDistComm), `device`, `nchain`
+    (vegasmc chains per block; 0 = auto), `engine_factory` (test seam)."""
+    if solver in (":vegas", ":vegasmc"):
+        solver = solver[1:]
+    if solver not in SOLVERS:
+        raise ValueError("Solver %s is not supported!" % solver)                      # main.jl:263
+    print = max(print, verbose)                                                       # main.jl:93
+    if config is None:
+        config = Configuration(**kwargs)                                              # main.jl:95-97
+    for mx, v in zip(config.maxdof, config.var):
+        assert mx + 2 <= v.size, "maxdof should be less than the length of var"      # main.jl:99-101
+    if ignore is None:
+        ignore = 1 if adapt else 0                                                    # main.jl:82
+    comm = comm or LocalComm()
+    neval = int(neval)
+    nevalperblock, block = standardize_block(neval, block, comm.size)                 # main.jl:121
+    assert block % comm.size == 0                                                     # main.jl:122
+    per = block // comm.size
+    lo, hi = per * comm.rank, per * (comm.rank + 1)
+
+    if isinstance(integrand, str):
+        integrand = Integrand(integrand, config.userdata)
+    key = (integrand.body, tuple(integrand.userdata), None if measure is None else (measure.pool, measure.slot, measure.leaf), device)
+    if config._engine is None or config._engine_key != key:
+        # grids trained so far survive a change of integrand (`var = (res.config.var[1], ...)`, docs/src/index.md:129)
+        old = config._engine
+        saved = None
+        if old is not None:
+            saved = [(old.grid(i) if hasattr(lf, "ninc") else old.distribution(i)[0]) for i, lf in enumerate(config.leaves)]
+        eng = (engine_factory or Engine)(config, integrand, measure=measure, device=device)
+        if saved is not None:
+            for i, lf in enumerate(config.leaves):
+                (eng.set_grid if hasattr(lf, "ninc") else eng.set_distribution)(i, saved[i])
+        config._engine, config._engine_key = eng, key
+    eng = config._engine
+    s = SOLVERS[solver]
+
+    t0 = time.time()
+    means, stds = [], []
+    neval_done = 0
+    for it in range(niter):                                                           # main.jl:142
+        eng.run(s, nevalperblock, lo, hi, config.iterations_done + it, config.seed, measurefreq, nchain)   # main.jl:152-166
+        comm.all_reduce(eng)                                                          # main.jl:177-188
+        fin_solver = s
+        if s == VEGASMC and reweight_goal is not None:                                # main.jl:183, :334-337
+            packed = eng.get_packed()
+            nd = config.N + 1
+            vis = np.ascontiguousarray(packed[2 * eng.nobs + 2: 2 * eng.nobs + 2 + nd])
+            rw = np.ascontiguousarray(eng.reweight())
+            goal = np.ascontiguousarray(reweight_goal, dtype=np.float64)
+            dp = C.POINTER(C.c_double)
+            lib().mci_do_reweight(rw.ctypes.data_as(dp), vis.ctypes.data_as(dp), nd, float(gamma), goal.ctypes.data_as(dp))
+            eng.set_reweight(rw)
+            fin_solver = VEGAS  # skip the device-side doReweight!
+        m, e = eng.finish(fin_solver, block, adapt, gamma)                            # main.jl:190-203
+        means.append(m)
+        stds.append(e)
+        neval_done += nevalperblock * block
+    config.iterations_done += niter
+    config.neval = nevalperblock * block
+    res = Result(np.array(means), np.array(stds), config, ignore, neval=neval_done, seconds=time.time() - t0)   # main.jl:211
+    if print >= 0:
+        report(res, io=printio)                                                       # main.jl:212-213
+    return res
+
+
+def prefill_kernel_cache():
+    """Compile (hiprtc, gfx950, no GPU needed) the sample-batch kernels of the BASELINE configs and of the
+    test battery into the in-tree kernel cache, so that the GPU box starts from code objects."""
+    import math
+    L = math.sqrt(50.0)
+    jobs = [
+        (Configuration(var=Continuous(0.0, 1.0), dof=[[1]]), catalog.log_over_sqrt(), None),                      # C1
+        (Configuration(var=Continuous(-L, L), dof=[[16]]), catalog.gaussian(16), None),                           # C2 shared pool
+        (Configuration(var=Continuous([(-L, L)] * 16), dof=[[1]]), catalog.gaussian(16), None),                   # C2 16 grids
+        (Configuration(var=Continuous([(0.0, 1.0)] * 32), dof=[[1]]), catalog.genz_product_peak(32), None),       # C4
+    ]
+    p = catalog.bubble_parameters()
+    from .integrand import bin_by
+    var = (Continuous(0.0, 1.0, alpha=3.0), Continuous(0.0, math.pi, alpha=3.0), Continuous(0.0, 2 * math.pi, alpha=3.0),
+           Continuous(0.0, p["beta"], alpha=3.0), Discrete(1, 4, adapt=False))
+    jobs.append((Configuration(var=var, dof=[[1, 1, 1, 1, 1]], obs=[np.zeros(4)]), catalog.bubble(), bin_by(4)))  # C3
+    n = 0
+    for cfg, f, meas in jobs:
+        eng = Engine(cfg, f, measure=meas, device=-1)
+        eng.compile()
+        eng.close()
+        n += 1
+    return n

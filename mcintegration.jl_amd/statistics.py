@@ -1,0 +1,114 @@
+"""`Result`, `average`, `report`  (reference src/statistics.jl) -- arithmetic done by the library's
+host functions (mci_average / mci_mean_std)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import c_double_p, lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def mean_std(obs_sum, obs_sq, block):
+    """_mean_std (main.jl:296-320)"""
+    s = np.ascontiguousarray(np.atleast_1d(obs_sum), dtype=np.float64)
+    q = np.ascontiguousarray(np.atleast_1d(obs_sq), dtype=np.float64)
+    m, e = np.empty_like(s), np.empty_like(s)
+    lib().mci_mean_std(_dp(s), _dp(q), len(s), int(block), _dp(m), _dp(e))
+    return m, e
+
+
+def average(iter_mean, iter_std, init=1, max=None):
+    """average(history, idx; init, max) (statistics.jl:186-220) for one scalar series; 1-based init/max."""
+    m = np.ascontiguousarray(iter_mean, dtype=np.float64)
+    e = np.ascontiguousarray(iter_std, dtype=np.float64)
+    if max is None:
+        max = len(m)
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    lib().mci_average(_dp(m), _dp(e), 1, int(init), int(max), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+class Result:
+    """statistics.jl:16-63.  mean/stdev/chi2 are lists with one entry per integrand: a float for scalar
+    observables, an ndarray for array observables (like `obs=[zeros(4)]`)."""
+
+    def __init__(self, iter_mean, iter_std, config, ignore, neval=0, seconds=0.0):
+        self.iter_mean = np.asarray(iter_mean)   # [niter, nobs]
+        self.iter_std = np.asarray(iter_std)
+        self.config, self.ignore, self.neval, self.seconds = config, int(ignore), int(neval), seconds
+        niter, nobs = self.iter_mean.shape
+        flat = [average(self.iter_mean[:, o], self.iter_std[:, o], init=ignore + 1, max=niter) for o in range(nobs)]
+        self._flat_mean = np.array([f[0] for f in flat])
+        self._flat_std = np.array([f[1] for f in flat])
+        self._flat_chi2 = np.array([f[2] for f in flat])
+        self.mean, self.stdev, self.chi2 = self._shape(self._flat_mean), self._shape(self._flat_std), self._shape(self._flat_chi2)
+        self.iterations = [(self._shape(self.iter_mean[i]), self._shape(self.iter_std[i]), config) for i in range(niter)]
+
+    def _shape(self, flat):
+        out, off = [], 0
+        for nb, isarr in zip(self.config.obs_nbin, self.config.obs_is_array):
+            out.append(np.array(flat[off:off + nb]) if isarr else float(flat[off]))
+            off += nb
+        return out
+
+    def with_ignore(self, ignore):
+        """Result(res, ignore) (statistics.jl:56-62)"""
+        return self if ignore == self.ignore else Result(self.iter_mean, self.iter_std, self.config, ignore, self.neval, self.seconds)
+
+    @property
+    def dof(self):
+        return (len(self.iterations) - (self.ignore + 1) + 1) - 1   # statistics.jl:65-68
+
+    def __getitem__(self, idx):
+        return self.mean[idx], self.stdev[idx], self.chi2[idx]
+
+    def __repr__(self):
+        lines = []
+        for i in range(self.config.N):
+            m, e, c2 = np.ravel(self.mean[i])[0], np.ravel(self.stdev[i])[0], np.ravel(self.chi2[i])[0]
+            if self.dof == 0:
+                lines.append("Integral %d = %s ± %s" % (i + 1, m, e))
+            else:
+                lines.append("Integral %d = %s ± %s   (reduced chi2 = %.3g)" % (i + 1, m, e, c2))
+        return "\n".join(lines)
+
+
+def _sig_digits(err):
+    if err == 0 or not np.isfinite(err):
+        return 0
+    return max(0, 2 - int(np.floor(np.log10(abs(err)))))   # statistics.jl:74-79
+
+
+def _tostring(m, e):
+    if np.isfinite(m) and np.isfinite(e):
+        nd = _sig_digits(e)
+        return "%.*f ± %.*f" % (nd, m, nd, e)             # statistics.jl:87-96
+    return "%s ± %s" % (m, e)
+
+
+def report(result, ignore=None, pick=0, name=None, verbose=0, io=None):
+    """report(result) (statistics.jl:137-172): per-iteration table with the running weighted average."""
+    import sys
+    io = io or sys.stdout
+    ignore = result.ignore if ignore is None else ignore
+    off = 0
+    for i in range(result.config.N):
+        col = off + pick
+        off += result.config.obs_nbin[i]
+        info = str(i + 1) if name is None else str(name[i])
+        if verbose >= 0:
+            bar = "-" * 127
+            print("=" * 48 + "     Integral %s    " % info + "=" * 60, file=io)
+            print("%6s                 %-32s                 %-32s %22s" % ("iter", "         integral", "        wgt average", "reduced chi2"), file=io)
+            print(bar, file=io)
+            for it in range(result.iter_mean.shape[0]):
+                m0, e0 = result.iter_mean[it, col], result.iter_std[it, col]
+                m, e, c2 = average(result.iter_mean[:, col], result.iter_std[:, col], init=ignore + 1, max=it + 1)
+                label = "ignore" if it + 1 <= ignore else str(it + 1)
+                print("%6s %36s %36s %16.4f" % (label, _tostring(m0, e0), _tostring(m, e), abs(c2)), file=io)
+            print(bar, file=io)
+        else:
+            print("Integral %s = %s ± %s" % (info, result._flat_mean[col], result._flat_std[col]), file=io)

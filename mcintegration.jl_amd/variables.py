@@ -1,0 +1,146 @@
+"""Variable pools: Continuous / Discrete / CompositeVar  (reference src/distribution/variable.jl).
+
+These are host-side descriptions; the live grids/distributions are device-resident inside an Engine
+(read back through `.grid` / `.distribution` once a Configuration has been bound to one)."""
+import numpy as np
+
+MaxOrder = 16  # reference src/distribution/distribution.jl:59
+
+
+class _Leaf:
+    _engine = None
+    _leaf_index = None
+
+
+class ContinuousVar(_Leaf):
+    """`Continuous(lower, upper, size=MaxOrder; offset=0, alpha=2.0, adapt=true, ninc=1000, grid=...)`
+    reference variable.jl:137-153.  N = ninc-1 increments (999 by default)."""
+
+    def __init__(self, lower, upper, size=MaxOrder, *, offset=0, alpha=2.0, adapt=True, ninc=1000, grid=None):
+        assert offset + 1 < size                      # variable.jl:138
+        assert upper > lower + 2 * np.finfo(float).eps  # variable.jl:140
+        self.lower, self.upper = float(lower), float(upper)
+        self.size = size + 1                          # one cache slot, variable.jl:139
+        self.offset, self.alpha, self.adapt = int(offset), float(alpha), bool(adapt)
+        self._grid0 = None if grid is None else np.ascontiguousarray(grid, dtype=np.float64)
+        self.ninc = len(self._grid0) if grid is not None else int(ninc)
+
+    @property
+    def range(self):
+        return self.upper - self.lower
+
+    @property
+    def grid(self):
+        if self._engine is not None:
+            return self._engine.grid(self._leaf_index)
+        if self._grid0 is not None:
+            return self._grid0.copy()
+        return np.linspace(self.lower, self.upper, self.ninc)
+
+    def __repr__(self):
+        return "%s Continuous variable in [%g, %g).%s" % ("Adaptive" if self.adapt else "Nonadaptive", self.lower,
+                                                          self.upper, " Learning rate = %g." % self.alpha if self.adapt else "")
+
+
+class DiscreteVar(_Leaf):
+    """`Discrete(lower, upper, size=MaxOrder; distribution=nothing, offset=0, alpha=2.0, adapt=true)`
+    reference variable.jl:299-325."""
+
+    def __init__(self, lower, upper, size=MaxOrder, *, distribution=None, offset=0, alpha=2.0, adapt=True):
+        assert offset + 1 < size
+        assert upper >= lower                          # variable.jl:304
+        self.lower, self.upper = int(lower), int(upper)
+        self.size = size + 1
+        self.offset, self.alpha, self.adapt = int(offset), float(alpha), bool(adapt)
+        if distribution is not None:
+            distribution = np.ascontiguousarray(distribution, dtype=np.float64)
+            assert np.all(distribution >= 0.0), "distribution should be all non-negative!"   # variable.jl:309
+            assert len(distribution) == self.upper - self.lower + 1                          # variable.jl:310
+        self._dist0 = distribution
+
+    @property
+    def distribution(self):
+        if self._engine is not None:
+            return self._engine.distribution(self._leaf_index)[0]
+        k = self.upper - self.lower + 1
+        d = np.ones(k) if self._dist0 is None else self._dist0
+        return d / d.sum()
+
+    @property
+    def accumulation(self):
+        if self._engine is not None:
+            return self._engine.distribution(self._leaf_index)[1]
+        return np.concatenate([[0.0], np.cumsum(self.distribution)])
+
+    def __repr__(self):
+        return "%s Discrete variable in [%d, ..., %d]." % ("Adaptive" if self.adapt else "Nonadaptive", self.lower, self.upper)
+
+
+class CompositeVar:
+    """`CompositeVar(vargs...; adapt=true, offset=0, size=MaxOrder)` reference variable.jl:415-427:
+    a product of variables sampled together; the bundled leaves inherit adapt and offset."""
+
+    def __init__(self, *vars, adapt=True, offset=0, size=MaxOrder):
+        assert all(isinstance(v, (ContinuousVar, DiscreteVar)) for v in vars), "all arguments should variables"  # :416-417
+        for v in vars:
+            v.adapt, v.offset = bool(adapt), int(offset)  # :419-420
+        self.vars = tuple(vars)
+        self.adapt, self.offset, self.size = bool(adapt), int(offset), size
+
+    def __len__(self):
+        return len(self.vars)
+
+    def __getitem__(self, i):
+        return self.vars[i]
+
+    def __iter__(self):
+        return iter(self.vars)
+
+
+def _is_bounds(x):
+    return isinstance(x, (list, tuple)) and len(x) > 0 and isinstance(x[0], (list, tuple))
+
+
+def Continuous(lower, upper=None, size=MaxOrder, **kw):
+    """Continuous(lower, upper, ...) or Continuous([(lo, hi), ...], ...) -> CompositeVar (variable.jl:174-187;
+    the multi-bound form always uses 1000-point grids, :177)."""
+    if _is_bounds(lower):
+        bounds = lower
+        if upper is not None and not isinstance(upper, (list, tuple)):
+            size = upper
+        adapt, offset = kw.get("adapt", True), kw.get("offset", 0)
+        grids = kw.get("grid", [None] * len(bounds))
+        vs = [ContinuousVar(b[0], b[1], size, offset=offset, alpha=kw.get("alpha", 2.0), adapt=adapt, ninc=1000,
+                            grid=grids[i]) for i, b in enumerate(bounds)]
+        return CompositeVar(*vs, adapt=adapt, offset=offset, size=size)
+    return ContinuousVar(lower, upper, size, **kw)
+
+
+def Discrete(lower, upper=None, size=MaxOrder, **kw):
+    """Discrete(lower, upper, ...), Discrete((lower, upper)) (variable.jl:326-328) or
+    Discrete([(lo, hi), ...]) -> CompositeVar (variable.jl:342-353)."""
+    if _is_bounds(lower):
+        bounds = lower
+        if upper is not None:
+            size = upper
+        adapt, offset = kw.get("adapt", True), kw.get("offset", 0)
+        dists = kw.get("distribution", [None] * len(bounds))
+        vs = [DiscreteVar(b[0], b[1], size, offset=offset, alpha=kw.get("alpha", 2.0), adapt=adapt,
+                          distribution=dists[i]) for i, b in enumerate(bounds)]
+        return CompositeVar(*vs, adapt=adapt, offset=offset, size=size)
+    if isinstance(lower, (list, tuple)) and upper is None:
+        return DiscreteVar(lower[0], lower[1], size, **kw)
+    if isinstance(lower, (list, tuple)):
+        return DiscreteVar(lower[0], lower[1], upper, **kw)
+    return DiscreteVar(lower, upper, size, **kw)
+
+
+def is_variable(v):
+    """reference: Dist.is_variable (test/variable.jl:7-16)"""
+    if isinstance(v, type):
+        return v in (ContinuousVar, DiscreteVar, CompositeVar)
+    return isinstance(v, (ContinuousVar, DiscreteVar, CompositeVar)) or v in (Continuous, Discrete)
+
+
+def poolsize(v):
+    return v.size

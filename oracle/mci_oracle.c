@@ -45,7 +45,7 @@ void mcio_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 
 /* Stream contract shared with the HIP path (DESIGN.md "RNG streams"):
  *   key = (seed lo, seed hi); ctr = (index lo, index hi, k>>1, stream)
- *   draw k uses words (2*(k&1), 2*(k&1)+1); 53 mantissa bits -> [0,1).
+ *   draw k uses words (2*(k&1), 2*(k&1)+1); 52 mantissa bits, [1,2)-1 -> [0,1).
  * rand(config.rng) in the reference is likewise a [0,1) Float64 (ref: sampler.jl:296,361). */
 double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k) {
     uint32_t ctr[4] = {(uint32_t)index, (uint32_t)(index >> 32), k >> 1, stream};
@@ -53,8 +53,10 @@ double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k) 
     uint32_t o[4];
     mcio_philox4x32_10(ctr, key, o);
     uint32_t a = o[2 * (k & 1)], b = o[2 * (k & 1) + 1];
-    uint64_t bits = (((uint64_t)b << 32) | a) >> 11;
-    return (double)bits * 0x1.0p-53;
+    uint64_t bits = ((((uint64_t)b << 32) | a) >> 12) | 0x3FF0000000000000ull; /* [1,2) */
+    double d;
+    memcpy(&d, &bits, sizeof d);
+    return d - 1.0; /* 52 random mantissa bits, like Julia's MersenneTwister rand(Float64) */
 }
 
 enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3 };

@@ -1,0 +1,256 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical Philox
+streams.  Tolerances (fp64 everywhere; only summation order and libm ulps differ):
+    map draw x            : bit-exact
+    jac, integrand weight : rel 1e-13
+    block sums / packed   : rel 1e-11   (reassociation of up to 1e5-term sums)
+    histograms            : rel 1e-9 per bin
+    trained grids         : abs 1e-12 * range
+    per-iteration mean/std: rel 1e-6 after six train steps (< 1e-3 sigma)
+"""
+import math
+
+import numpy as np
+import pytest
+
+import mcintegration_jl_amd as mci
+from catalog_params import bubble_exact, bubble_userdata, genz_exact, genz_userdata
+
+pytestmark = pytest.mark.gpu
+PI = math.pi
+SEED = 20240229
+
+
+def ocont(pool=0, lo=0.0, hi=1.0, **kw):
+    return dict(kind=0, pool=pool, lower=lo, upper=hi, **kw)
+
+
+def odisc(pool, lo, hi, **kw):
+    return dict(kind=1, pool=pool, lower=lo, upper=hi, **kw)
+
+
+def hist_split(packed, nobs, ni):
+    n = 2 * nobs + 2 + ni + 1
+    return packed[:n], packed[n:]
+
+
+# (name, product Configuration factory, HIP integrand, oracle leaves, oracle dof, oracle builtin, userdata, obs kwargs)
+def cases():
+    L = math.sqrt(50.0)
+    bp = bubble_userdata()
+    out = {
+        "c1_log_over_sqrt": dict(var=lambda: mci.Continuous(0.0, 1.0), dof=[[1]], f=mci.catalog.log_over_sqrt(),
+                                 oleaves=[ocont()], oname="log_over_sqrt", ud=None),
+        "c2_gauss16_shared_pool": dict(var=lambda: mci.Continuous(-L, L), dof=[[16]], f=mci.catalog.gaussian(16),
+                                       oleaves=[ocont(0, -L, L)], oname="gaussian", ud=[16.0]),
+        "c2_gauss4_composite": dict(var=lambda: mci.Continuous([(-L, L)] * 4), dof=[[1]], f=mci.catalog.gaussian(4),
+                                    oleaves=[ocont(0, -L, L) for _ in range(4)], oname="gaussian", ud=[4.0]),
+        "sphere2_padding": dict(var=lambda: mci.Continuous(0.0, 1.0), dof=[[2], [3]], f=mci.catalog.sphere2(),
+                                oleaves=[ocont()], oname="sphere2", ud=None),
+        "hypersphere": dict(var=lambda: mci.Continuous(-1.0, 1.0), dof=[[2], [3], [4]], f=mci.catalog.hypersphere(3),
+                            oleaves=[ocont(0, -1.0, 1.0)], oname="hypersphere", ud=[3.0]),
+        "discrete": dict(var=lambda: mci.Discrete(1, 3), dof=[[1]], f=mci.catalog.discrete_id(),
+                         oleaves=[odisc(0, 1, 3)], oname="discrete_id", ud=None),
+        "discrete2_composite": dict(var=lambda: mci.Discrete([(1, 3), (1, 4)]), dof=[[1]], f=mci.catalog.one(),
+                                    oleaves=[odisc(0, 1, 3), odisc(0, 1, 4)], oname="one", ud=None),
+        "singular2_composite": dict(var=lambda: mci.Continuous([(0.0, PI)] * 3), dof=[[1]], f=mci.catalog.singular2(),
+                                    oleaves=[ocont(0, 0.0, PI) for _ in range(3)], oname="singular2", ud=None),
+        "bubble": dict(var=lambda: (mci.Continuous(0.0, 1.0, alpha=3.0), mci.Continuous(0.0, PI, alpha=3.0),
+                                    mci.Continuous(0.0, 2 * PI, alpha=3.0), mci.Continuous(0.0, bp[1], alpha=3.0),
+                                    mci.Discrete(1, 4, adapt=False)),
+                       dof=[[1, 1, 1, 1, 1]], f=mci.catalog.bubble(), obs=[np.zeros(4)], measure=mci.bin_by(4),
+                       oleaves=[ocont(0, 0, 1, alpha=3.0), ocont(1, 0, PI, alpha=3.0), ocont(2, 0, 2 * PI, alpha=3.0),
+                                ocont(3, 0, bp[1], alpha=3.0), odisc(4, 1, 4, adapt=False)],
+                       oname="bubble", ud=bp, obs_nbin=[4], obs_bin_draw=[4]),
+    }
+    return out
+
+
+CASES = cases()
+
+
+def make(name, oracle):
+    c = CASES[name]
+    cfg = mci.Configuration(var=c["var"](), dof=c["dof"], obs=c.get("obs"), seed=SEED)
+    eng = mci.Engine(cfg, c["f"], measure=c.get("measure"))
+    ocfg = oracle.Config(c["oleaves"], c["dof"], obs_nbin=c.get("obs_nbin"), obs_bin_draw=c.get("obs_bin_draw"))
+    return c, cfg, eng, ocfg
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_map_draw_and_integrand_match_oracle(oracle, name):
+    """rows a2/a3/a4: inverse-CDF draw (sampler.jl:293-305, :13-22, :410-418) -- x bit-exact."""
+    c, cfg, eng, ocfg = make(name, oracle)
+    n, npb = 4096, 5000
+    x, jac, w = eng.sample_dump(n, nevalperblock=npb, block_index=3, iteration=2, seed=SEED)
+    oc = ocfg.c
+    fn = oracle.builtin(c["oname"])
+    import ctypes as C
+    ud = np.ascontiguousarray(c["ud"] if c["ud"] is not None else [0.0], dtype=np.float64)
+    wo = np.zeros(oc.Ni)
+    for s in range(0, n, 97):
+        gs = 3 * npb + s
+        k = 0
+        jaco = 1.0
+        xo = np.zeros(oc.ndraw)
+        for vi in range(oc.npool):
+            nl = oc.pool_nleaf[vi]
+            for idx in range(1, oc.maxdof[vi] + 1):
+                us = [oracle.uniform(SEED, 2 * 8 + 0, gs, k + l) for l in range(nl)]
+                ocfg.pool_create(vi, idx, us)
+                jaco /= np.ctypeslib.as_array(oc.pool_prob[vi], shape=(idx + 1,))[idx]
+                for l in range(nl):
+                    xo[k + l] = ocfg.pool_data(oc.pool_leaf0[vi] + l)[idx - 1]
+                k += nl
+        assert np.array_equal(x[s], xo), (name, s, x[s], xo)
+        assert jac[s] == pytest.approx(jaco, rel=1e-13)
+        C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)(fn)(xo.ctypes.data, wo.ctypes.data, ud.ctypes.data)
+        np.testing.assert_allclose(w[s], wo, rtol=1e-13, atol=1e-300)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_vegas_iteration_packed_matches_oracle(oracle, name):
+    """rows a6/a7/a8/a11/a12: one iteration of blocks -> [obsSum|obsSqSum|normalization|neval|visited|hist]."""
+    c, cfg, eng, ocfg = make(name, oracle)
+    block, npb = 8, 4000
+    got = eng.iteration("vegas", npb, 0, block, iteration=0, seed=SEED)
+    ref = ocfg.iteration(oracle.VEGAS, c["oname"], c["ud"], npb, 0, block, 0, SEED)
+    gs, gh = hist_split(got, eng.nobs, cfg.N)
+    rs, rh = hist_split(ref, eng.nobs, cfg.N)
+    np.testing.assert_allclose(gs, rs, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(gh, rh, rtol=1e-9)
+    assert got[2 * eng.nobs + 1] == block * npb  # neval
+
+
+def test_vegas_iteration_block_range_and_measurefreq(oracle):
+    """blocks [lo,hi) are the MPI-rank partition (main.jl:152-166); measurefreq (vegas/montecarlo.jl:148)."""
+    c, cfg, eng, ocfg = make("sphere2_padding", oracle)
+    got = eng.iteration("vegas", 3000, 4, 8, iteration=1, seed=SEED, measurefreq=3)
+    ref = ocfg.iteration(oracle.VEGAS, "sphere2", None, 3000, 4, 8, 1, SEED, measurefreq=3)
+    np.testing.assert_allclose(got, ref, rtol=1e-9)
+    assert got[2 * eng.nobs] == pytest.approx(4 * 1000 + 5e-10, rel=1e-13)  # normalization = measured samples + 1e-10 per block + 1e-10
+
+
+@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "c2_gauss16_shared_pool", "discrete", "bubble", "singular2_composite"])
+def test_train_matches_oracle(oracle, name):
+    """rows a9/a10: smooth -> rescale -> refine (variable.jl:206-239), Discrete (:369-382)."""
+    c, cfg, eng, ocfg = make(name, oracle)
+    block, npb = 8, 4000
+    eng.run("vegas", npb, 0, block, 0, SEED)
+    m, e = eng.finish("vegas", block, adapt=True)
+    packed = ocfg.iteration(oracle.VEGAS, c["oname"], c["ud"], npb, 0, block, 0, SEED)
+    ocfg.train()
+    om, oe = oracle.mean_std(packed[:eng.nobs], packed[eng.nobs:2 * eng.nobs], block)
+    np.testing.assert_allclose(m, om, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(e, oe, rtol=1e-8, atol=1e-300)
+    for i, lf in enumerate(c["oleaves"]):
+        if lf["kind"] == 0:
+            g, og = eng.grid(i), ocfg.grid(i)
+            assert g[0] == og[0] and g[-1] == og[-1]
+            np.testing.assert_allclose(g, og, rtol=0, atol=1e-12 * (lf["upper"] - lf["lower"]))
+            assert np.all(np.diff(g) > 0)
+        else:
+            d, a = eng.distribution(i)
+            np.testing.assert_allclose(d, ocfg.distribution(i), rtol=1e-11)
+            np.testing.assert_allclose(a, ocfg.accumulation(i), rtol=1e-11)
+
+
+@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "bubble", "c2_gauss4_composite"])
+def test_full_integrate_matches_oracle(oracle, name):
+    """rows a13-a15: the whole loop inside the library (mci_integrate) vs the oracle's loop, same seed."""
+    c, cfg, eng, ocfg = make(name, oracle)
+    r = eng.integrate("vegas", neval=40000, niter=6, block=16, seed=SEED)
+    o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=40000, niter=6, block=16, seed=SEED)
+    # six train! steps amplify libm-ulp differences in the grids (device pow/log vs glibc); the
+    # difference stays >= 4 orders of magnitude below the MC error of these runs
+    np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6, atol=1e-300)
+    np.testing.assert_allclose(r["iter_std"], o["iter_std"], rtol=1e-4, atol=1e-300)
+    np.testing.assert_allclose(r["mean"], o["mean"], rtol=1e-6)
+    np.testing.assert_allclose(r["stdev"], o["stdev"], rtol=1e-4)
+    np.testing.assert_allclose(r["chi2"], o["chi2"], rtol=1e-3, atol=1e-9)
+    assert np.all(np.abs(r["mean"] - o["mean"]) < 1e-3 * o["stdev"])
+
+
+@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "bubble", "discrete2_composite"])
+def test_vegasmc_iteration_matches_oracle(oracle, name):
+    """row a16: many-chain VegasMC block vs the oracle run with the same chain decomposition."""
+    c, cfg, eng, ocfg = make(name, oracle)
+    block, npb, nchain = 4, 6400, 64
+    got = eng.iteration("vegasmc", npb, 0, block, iteration=0, seed=SEED, nchain=nchain)
+    ref = ocfg.iteration(oracle.VEGASMC, c["oname"], c["ud"], npb, 0, block, 0, SEED, nchain=nchain)
+    gs, gh = hist_split(got, eng.nobs, cfg.N)
+    rs, rh = hist_split(ref, eng.nobs, cfg.N)
+    np.testing.assert_allclose(gs, rs, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(gh, rh, rtol=1e-8)
+
+
+def test_vegasmc_single_chain_is_the_reference_chain(oracle):
+    """nchain = 1: exactly the reference's one-chain-per-block Markov chain (vegas_mc/montecarlo.jl:184)."""
+    c, cfg, eng, ocfg = make("c1_log_over_sqrt", oracle)
+    got = eng.iteration("vegasmc", 3000, 0, 2, iteration=0, seed=SEED, nchain=1)
+    ref = ocfg.iteration(oracle.VEGASMC, "log_over_sqrt", None, 3000, 0, 2, 0, SEED, nchain=1)
+    np.testing.assert_allclose(got, ref, rtol=1e-9)
+
+
+def test_user_snippet_matches_gcc_compiled_oracle(oracle):
+    """an arbitrary user integrand: the same C text JIT-compiled for gfx950 and gcc-compiled for the oracle."""
+    body = "w[0] = exp(-x[0]) * cos(3.0 * x[1]) + ud[0] * x[2] * x[2];"
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 2.0), dof=[[3]], seed=SEED)
+    eng = mci.Engine(cfg, mci.Integrand(body, [0.25]))
+    ocfg = oracle.Config([ocont(0, 0.0, 2.0)], [[3]])
+    fn = oracle.compile_c_integrand(body)
+    got = eng.iteration("vegas", 5000, 0, 4, iteration=0, seed=SEED)
+    ref = ocfg.iteration(oracle.VEGAS, fn, [0.25], 5000, 0, 4, 0, SEED)
+    np.testing.assert_allclose(got, ref, rtol=1e-9)
+
+
+def test_launch_geometry_independence(oracle):
+    """size-independent property: the RNG stream is keyed by the sample index, so any (threads,
+    workgroups-per-block) decomposition gives the same sums up to reassociation."""
+    L = math.sqrt(50.0)
+    outs = []
+    for threads, wpb in ((256, 0), (64, 3), (512, 1), (1024, 7)):
+        cfg = mci.Configuration(var=mci.Continuous(-L, L), dof=[[16]], seed=SEED)
+        eng = mci.Engine(cfg, mci.catalog.gaussian(16), threads=threads, wg_per_block=wpb)
+        outs.append(eng.iteration("vegas", 20000, 0, 4, iteration=0, seed=SEED))
+    for o in outs[1:]:
+        np.testing.assert_allclose(o, outs[0], rtol=1e-10)
+
+
+def test_table_modes_agree(monkeypatch):
+    """LDS-resident tables (mode 0), LDS grids + global f64 atomics (1), everything from L2 (2)."""
+    outs = []
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("MCI_TABLE_MODE", mode)
+        cfg = mci.Configuration(var=mci.Continuous([(0.0, PI)] * 3), dof=[[1]], seed=SEED)
+        eng = mci.Engine(cfg, mci.catalog.singular2())
+        assert eng.table_mode == int(mode)
+        outs.append(eng.iteration("vegas", 8000, 0, 4, iteration=0, seed=SEED))
+        eng.run("vegas", 8000, 0, 4, 1, SEED)  # second launch: global histogram was reset by the merge
+        second = eng.get_packed()
+        assert np.all(np.isfinite(second))
+    np.testing.assert_allclose(outs[1], outs[0], rtol=1e-10)
+    np.testing.assert_allclose(outs[2], outs[0], rtol=1e-10)
+
+
+def test_error_paths():
+    """non-positive normalization (main.jl:269-271) and non-finite histogram (variable.jl:212) surface as errors."""
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]], seed=SEED)
+    eng = mci.Engine(cfg, mci.Integrand("w[0] = 1.0 / (x[0] - x[0]);"))  # inf everywhere
+    eng.run("vegas", 1000, 0, 2, 0, SEED)
+    with pytest.raises(mci.MCIError) as e:
+        eng.finish("vegas", 2, adapt=True)
+    assert e.value.code == 5 and "finite" in str(e.value)
+
+
+def test_c4_genz32_runs_in_l2_table_mode_and_matches_oracle(oracle):
+    """BASELINE config 4 layout: 32 independent grids (256 KB of edges > LDS)."""
+    ud = genz_userdata(32)
+    cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
+    eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32))
+    assert eng.table_mode == 2
+    ocfg = oracle.Config([ocont(0) for _ in range(32)], [[1]])
+    got = eng.iteration("vegas", 2000, 0, 4, iteration=0, seed=SEED)
+    ref = ocfg.iteration(oracle.VEGAS, "genz_product_peak", ud, 2000, 0, 4, 0, SEED)
+    np.testing.assert_allclose(got[:4], ref[:4], rtol=1e-11)
+    np.testing.assert_allclose(got[4:], ref[4:], rtol=1e-9)
+    assert genz_exact(32) > 0

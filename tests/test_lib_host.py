@@ -1,0 +1,135 @@
+"""CPU-side tests of the product library: the C ABI loads and exports every symbol include/mci.h
+declares, the host-side statistics of the path agree with the oracle and the golden vectors, the
+JIT produces gfx950 code objects without a GPU, and compute entry points refuse to run without one."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mcintegration_jl_amd as mci
+from mcintegration_jl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mci.h")).read()
+    declared = set(re.findall(r"\b(mci_[a-z_0-9]+)\s*\(", hdr))
+    bound = {name for name, _, _ in _lib.SIGNATURES}
+    assert declared == bound, declared ^ bound
+    L = C.CDLL(_lib.library_path())
+    for name in declared:
+        assert hasattr(L, name), name
+    assert mci.lib().mci_version().startswith(b"mci-hip")
+
+
+def test_no_device_fails_loudly():
+    from mcintegration_jl_amd.engine import device_count
+    if device_count() > 0:
+        pytest.skip("a GPU is visible")
+    p = C.c_void_p()
+    rc = mci.lib().mci_ctx_create(0, C.byref(p))
+    assert rc == 7  # MCI_ERR_NO_DEVICE: no CPU fallback
+    assert b"no CPU fallback" in mci.lib().mci_last_error()
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
+    eng = mci.Engine(cfg, mci.catalog.x2y2(), device=-1)  # offline: compile only
+    with pytest.raises(mci.MCIError) as e:
+        eng.run("vegas", 100, 0, 1, 0, 1)
+    assert e.value.code == 7
+
+
+def test_offline_jit_and_problem_info():
+    cfg = mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 4)), dof=[[2, 1], [1, 0]])
+    eng = mci.Engine(cfg, mci.Integrand("w[0] = x[0] * x[1] * x[2]; w[1] = x[0];"), device=-1)
+    eng.compile()
+    assert eng.ndraw == 3 and eng.nobs == 2 and eng.table_mode == 0
+    assert eng.packed_size == 2 * 2 + 2 + 3 + 999 + 4
+    np.testing.assert_allclose(eng.grid(0), np.linspace(0, 1, 1000), atol=1e-15)
+    d, a = eng.distribution(1)
+    np.testing.assert_allclose(d, 0.25)
+    np.testing.assert_allclose(a, [0, 0.25, 0.5, 0.75, 1.0])
+    big = mci.Engine(mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]]), mci.catalog.genz_product_peak(32), device=-1)
+    assert big.table_mode == 2 and big.ndraw == 32  # 32 grids = 256 KB of edges: beyond 160 KB LDS
+
+
+def test_bad_integrand_source_reports_compile_error():
+    eng = mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]]), mci.Integrand("w[0] = undefined_symbol(x[0]);"), device=-1)
+    with pytest.raises(mci.MCIError) as e:
+        eng.compile()
+    assert e.value.code == 3 and "undefined_symbol" in str(e.value)
+
+
+def test_configuration_dof_forms_and_asserts():
+    # configuration.jl:134-151 and test/utility.jl:14-15
+    X = mci.Continuous(0.0, 1.0)
+    assert mci.Configuration(var=X, dof=2).dof == [[2]]
+    assert mci.Configuration(var=X, dof=[2, 3]).dof == [[2], [3]]
+    assert mci.Configuration(var=(X, mci.Continuous(0, 1)), dof=np.array([[1, 2], [3, 4]])).dof == [[1, 3], [2, 4]]
+    assert mci.Configuration(var=X, dof=[(1,)]).dof == [[1]]   # test/interface_tests.jl
+    c = mci.Configuration(var=(mci.Continuous(0, 1), mci.Continuous(0, 1), mci.Continuous(0, 1), mci.Continuous(0, 1)),
+                          dof=[[1, 2, 3, 5], [3, 1, 2, 7], [2, 4, 1, 2]])
+    assert c.maxdof == [3, 4, 3, 7]
+    with pytest.raises(AssertionError):
+        mci.Configuration(var=X, dof=[[1, 1]])
+    with pytest.raises(AssertionError):
+        mci.Configuration(var=X, dof=[[1]], reweight=[1.0, -1.0])
+    # pool auto-resize (configuration.jl:156-160; test/montecarlo.jl:41)
+    T = mci.Continuous(0.0, 1.0, 2)
+    assert T.size == 3
+    mci.Configuration(var=(T,), dof=[[2], [3]])
+    assert T.size == 5
+
+
+def test_variable_constructors():
+    # test/variable.jl:1-20
+    d = mci.Discrete([1, 4])
+    assert d.lower == 1 and d.upper == 4
+    assert mci.Dist.is_variable(mci.Continuous) and mci.Dist.is_variable(mci.Discrete) and not mci.Dist.is_variable(int)
+    x = mci.Continuous(0.0, 1.0, 7, grid=[0.0, 0.1, 0.4, 1.0])
+    assert x.size == 8 and x.ninc == 4
+    cv = mci.Continuous([(0.0, 1.0), (0.0, 2.0)])
+    assert isinstance(cv, mci.CompositeVar) and len(cv) == 2 and cv[1].upper == 2.0 and cv[0].ninc == 1000
+
+
+def test_host_statistics_match_oracle_and_golden(oracle, golden):
+    v = golden["mean_std"]
+    m, e = mci.mean_std(v["obs_sum"], v["obs_sq"], v["block"])
+    np.testing.assert_allclose(m, v["mean"], rtol=1e-15)
+    np.testing.assert_allclose(e, v["std"], rtol=1e-13)
+    t = golden["average_docs_table"]
+    for mx in range(1, 11):
+        got = mci.average(t["iter_mean"], t["iter_std"], init=t["init"], max=mx)
+        assert got == pytest.approx(oracle.average(t["iter_mean"], t["iter_std"], init=t["init"], max=mx), rel=1e-14)
+        assert got[0] == pytest.approx(t["printed"][mx - 1][0], abs=6e-8)
+    assert mci.integrate.__module__  # importable
+    from mcintegration_jl_amd.integrate import standardize_block
+    for args in ((10000, 16, 1), (10000, 16, 3), (10000, 2, 8)):
+        assert standardize_block(*args) == oracle.standardize_block(*args)
+    # doReweight! fixed point, test/mpi_test.jl:148-169
+    r = np.array(golden["doreweight"]["reweight0"])
+    vis = np.ascontiguousarray(golden["doreweight"]["visited"], dtype=np.float64)
+    goal = np.ascontiguousarray(golden["doreweight"]["goal"])
+    dp = C.POINTER(C.c_double)
+    for _ in range(5):
+        mci.lib().mci_do_reweight(r.ctypes.data_as(dp), vis.ctypes.data_as(dp), 4, 1.0, goal.ctypes.data_as(dp))
+    np.testing.assert_allclose(r, golden["doreweight"]["expect"], rtol=1e-3)
+    out = np.zeros(4, dtype=np.int32)
+    dof = np.ascontiguousarray(golden["maxdof"]["dof"], dtype=np.int32)
+    ip = C.POINTER(C.c_int32)
+    mci.lib().mci_maxdof(dof.ctypes.data_as(ip), 3, 4, out.ctypes.data_as(ip))
+    assert list(out) == golden["maxdof"]["expect"]
+
+
+def test_result_and_report(capsys, golden):
+    t = golden["average_docs_table"]
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]])
+    res = mci.Result(np.array(t["iter_mean"])[:, None], np.array(t["iter_std"])[:, None], cfg, ignore=1)
+    assert res.mean[0] == pytest.approx(-3.9979808, abs=1e-7) and res.stdev[0] == pytest.approx(0.0013607691, rel=1e-6)
+    assert res.chi2[0] == pytest.approx(1.9269, abs=1e-4) and res.dof == 8
+    mci.report(res)
+    text = capsys.readouterr().out
+    assert "ignore" in text and "-3.99798 ± 0.00136" in text  # statistics.jl:74-96: digits = 2 - floor(log10(err))
+    res3 = res.with_ignore(3)
+    assert res3.ignore == 3 and res3.mean[0] != res.mean[0]

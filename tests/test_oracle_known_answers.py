@@ -23,7 +23,7 @@ def test_uniform_stream_contract(oracle):
     for k in range(6):
         o = oracle.philox([idx & 0xFFFFFFFF, idx >> 32, k >> 1, stream], [seed & 0xFFFFFFFF, seed >> 32])
         a, b = o[2 * (k & 1)], o[2 * (k & 1) + 1]
-        expect = (((b << 32) | a) >> 11) * 2.0 ** -53
+        expect = (((b << 32) | a) >> 12) * 2.0 ** -52
         assert oracle.uniform(seed, stream, idx, k) == expect
         assert 0.0 <= expect < 1.0
 

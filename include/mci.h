@@ -135,6 +135,10 @@ int mci_iteration_finish(mci_problem *prob, int32_t solver, int64_t block_total,
 int mci_integrate(mci_problem *prob, const mci_integrate_args *args, mci_result *result);
 
 /* ---- state access: res.config.var[i].grid etc. (docs/src/index.md:129) and external reducers ---- */
+/* the statistics head [obsSum|obsSqSum|normalization|neval|visited] of the last `nrows` finished
+ * iterations (oldest first), nstat = 2*nobs+2+N+1 doubles per row: the per-iteration history that
+ * `Result.iterations` is built from (statistics.jl:24-33), kept on the device until asked for */
+int mci_get_iteration_log(mci_problem *prob, int32_t nrows, double *out);
 int mci_get_packed(mci_problem *prob, double *out, int64_t n);
 int mci_set_packed(mci_problem *prob, const double *in, int64_t n);
 void *mci_packed_device_ptr(mci_problem *prob);
@@ -150,8 +154,9 @@ int mci_train(mci_problem *prob);
  * of `iteration`, written to host arrays x[n*ndraw], jac[n], w[n*nintegrand] */
 int mci_sample_dump(mci_problem *prob, int32_t iteration, uint64_t seed, int64_t neval_per_block,
                     int64_t block_index, int64_t n, double *x, double *jac, double *w);
-/* HIP-event time of the last sampling kernel launch (ms) and its launch geometry */
-int mci_last_kernel_ms(mci_problem *prob, float *ms, int32_t *workgroups, int32_t *threads);
+/* HIP-event durations (ms, oldest first) of the last `n` sampling-kernel launches, recorded on the
+ * library's stream around every launch (ring of 512), and the last launch geometry */
+int mci_kernel_times_ms(mci_problem *prob, float *ms, int32_t n, int32_t *got, int32_t *workgroups, int32_t *threads);
 
 /* ---- host-side statistics of the path (pure functions, no GPU needed) ---- */
 void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64_t *nevalperblock,

@@ -65,6 +65,7 @@ SIGNATURES = [
     ("mci_iteration_reduce", C.c_int, [_VP]),
     ("mci_iteration_finish", C.c_int, [_VP, C.c_int32, C.c_int64, C.c_int32, C.c_double, c_double_p, c_double_p]),
     ("mci_integrate", C.c_int, [_VP, C.POINTER(IntegrateArgs), C.POINTER(ResultC)]),
+    ("mci_get_iteration_log", C.c_int, [_VP, C.c_int32, c_double_p]),
     ("mci_get_packed", C.c_int, [_VP, c_double_p, C.c_int64]),
     ("mci_set_packed", C.c_int, [_VP, c_double_p, C.c_int64]),
     ("mci_packed_device_ptr", _VP, [_VP]),
@@ -76,7 +77,7 @@ SIGNATURES = [
     ("mci_set_reweight", C.c_int, [_VP, c_double_p, C.c_int32]),
     ("mci_train", C.c_int, [_VP]),
     ("mci_sample_dump", C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
-    ("mci_last_kernel_ms", C.c_int, [_VP, C.POINTER(C.c_float), c_int32_p, c_int32_p]),
+    ("mci_kernel_times_ms", C.c_int, [_VP, C.POINTER(C.c_float), C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
     ("mci_standardize_block", None, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("mci_maxdof", None, [c_int32_p, C.c_int32, C.c_int32, c_int32_p]),
     ("mci_mean_std", None, [c_double_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p]),

@@ -110,7 +110,9 @@ struct mci_problem {
     bool compiled = false;
     int threads = 256, wg_per_block = 0; // 0 = auto
     // last launch
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> evs; // ring of (start, stop) pairs around the sampling kernel, one pair per launch
+    int64_t launches = 0;
+    static const int kEvRing = 512;
     int last_wg = 0, last_threads = 0, last_nblocks = 0;
     int log_row = 0;
     static const int kGroups = 32;
@@ -414,8 +416,8 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         for (auto &L : p->leaves) ld.push_back({L.kind, L.nbin, L.eoff, L.doff, L.boff, L.adapt, L.alpha});
         HIPCHK(hipMalloc((void **)&p->d_leaves, ld.size() * sizeof(mci::LeafDev)));
         HIPCHK(hipMemcpy(p->d_leaves, ld.data(), ld.size() * sizeof(mci::LeafDev), hipMemcpyHostToDevice));
-        HIPCHK(hipEventCreate(&p->ev0));
-        HIPCHK(hipEventCreate(&p->ev1));
+        p->evs.resize(2 * mci_problem::kEvRing);
+        for (auto &e : p->evs) HIPCHK(hipEventCreate(&e));
     }
     *out = p;
     return MCI_OK;
@@ -431,8 +433,7 @@ int mci_problem_destroy(mci_problem *p) {
                         (void *)p->d_status, (void *)p->d_leaves})
             if (q) hipFree(q);
         if (p->module) hipModuleUnload(p->module);
-        if (p->ev0) hipEventDestroy(p->ev0);
-        if (p->ev1) hipEventDestroy(p->ev1);
+        for (auto &e : p->evs) (void)hipEventDestroy(e);
     }
     delete p;
     return MCI_OK;
@@ -556,9 +557,11 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     void *args[] = {&a};
     hipFunction_t f = solver == MCI_VEGASMC ? p->f_vegasmc : p->f_vegas;
     hipStream_t st = p->ctx->stream;
-    HIPCHK(hipEventRecord(p->ev0, st));
+    const int slot = (int)(p->launches % mci_problem::kEvRing);
+    HIPCHK(hipEventRecord(p->evs[2 * slot], st));
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
-    HIPCHK(hipEventRecord(p->ev1, st));
+    HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
+    p->launches += 1;
     p->last_wg = (int)nwg;
     p->last_threads = T;
     p->last_nblocks = (int)nblocks;
@@ -674,6 +677,14 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
 // ---------------------------------------------------------------------------------------------------
 // state access
 // ---------------------------------------------------------------------------------------------------
+int mci_get_iteration_log(mci_problem *p, int32_t nrows, double *out) {
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    if (nrows < 1 || nrows > p->log_row) return fail(MCI_ERR_INVALID, "only %d iterations are logged", p->log_row);
+    HIPCHK(hipMemcpyAsync(out, p->d_iterlog + (size_t)(p->log_row - nrows) * p->nstat, (size_t)nrows * p->nstat * sizeof(double),
+                          hipMemcpyDeviceToHost, p->ctx->stream));
+    return check_status(p); // synchronises; surfaces normalization / histogram errors of the logged iterations
+}
+
 int mci_get_packed(mci_problem *p, double *out, int64_t n) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
     if (n != p->packed_n) return fail(MCI_ERR_INVALID, "packed size is %lld", (long long)p->packed_n);
@@ -818,12 +829,18 @@ int mci_sample_dump(mci_problem *p, int32_t iteration, uint64_t seed, int64_t ne
     return MCI_OK;
 }
 
-int mci_last_kernel_ms(mci_problem *p, float *ms, int32_t *wg, int32_t *threads) {
+int mci_kernel_times_ms(mci_problem *p, float *ms, int32_t n, int32_t *got, int32_t *wg, int32_t *threads) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
-    HIPCHK(hipEventSynchronize(p->ev1));
-    float t = 0.f;
-    HIPCHK(hipEventElapsedTime(&t, p->ev0, p->ev1));
-    if (ms) *ms = t;
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    int64_t have = p->launches < mci_problem::kEvRing ? p->launches : mci_problem::kEvRing;
+    if (have > n) have = n;
+    for (int64_t i = 0; i < have; ++i) { // oldest first
+        const int slot = (int)((p->launches - have + i) % mci_problem::kEvRing);
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, p->evs[2 * slot], p->evs[2 * slot + 1]));
+        ms[i] = t;
+    }
+    if (got) *got = (int32_t)have;
     if (wg) *wg = p->last_wg;
     if (threads) *threads = p->last_threads;
     return MCI_OK;

@@ -117,6 +117,13 @@ class Engine:
         self.run(solver, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq, nchain)
         return self.get_packed()
 
+    def iteration_log(self, nrows):
+        """statistics head of the last nrows finished iterations, [nrows, 2*nobs+2+N+1] (oldest first)"""
+        nstat = 2 * self.nobs + 2 + self.config.N + 1
+        out = np.empty((nrows, nstat))
+        check(lib().mci_get_iteration_log(self.p, int(nrows), _dp(out)))
+        return out
+
     def get_packed(self):
         out = np.empty(self.packed_size)
         check(lib().mci_get_packed(self.p, _dp(out), len(out)))
@@ -150,10 +157,16 @@ class Engine:
         check(lib().mci_sample_dump(self.p, iteration, seed, int(nevalperblock), int(block_index), int(n), _dp(x), _dp(jac), _dp(w)))
         return x, jac, w
 
+    def kernel_times_ms(self, n=512):
+        """HIP-event durations of the last n sampling-kernel launches (oldest first), (workgroups, threads)"""
+        ms = (C.c_float * n)()
+        got, wg, th = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().mci_kernel_times_ms(self.p, ms, n, C.byref(got), C.byref(wg), C.byref(th)))
+        return np.array(ms[:got.value], dtype=np.float64), wg.value, th.value
+
     def last_kernel_ms(self):
-        ms, wg, th = C.c_float(), C.c_int32(), C.c_int32()
-        check(lib().mci_last_kernel_ms(self.p, C.byref(ms), C.byref(wg), C.byref(th)))
-        return ms.value, wg.value, th.value
+        ms, wg, th = self.kernel_times_ms(1)
+        return float(ms[-1]), wg, th
 
     # ---- state ---------------------------------------------------------------------------------
     def grid(self, leaf):

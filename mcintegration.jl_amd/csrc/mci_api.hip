@@ -385,17 +385,32 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         s.leaf_adapt.push_back(L.adapt);
         s.leaf_lower.push_back(L.lower);
     }
-    // table placement (DESIGN.md "data layout"): keep >= 2 workgroups per CU when everything is in LDS
-    const int64_t fixed = (int64_t)(s.ndacc + s.nddist + s.nobs + 16 * s.ncols) * 8;
-    const int64_t full = fixed + (int64_t)(s.nedge + s.nbin) * 8;
-    const int64_t eonly = fixed + (int64_t)s.nedge * 8;
-    if (full <= 80 * 1024) { s.table_mode = 0; p->lds_bytes = full; }
-    else if (eonly <= 160 * 1024 - 1024) { s.table_mode = 1; p->lds_bytes = eonly; }
-    else { s.table_mode = 2; p->lds_bytes = fixed; }
-    if (const char *e = getenv("MCI_TABLE_MODE")) {
-        int m = atoi(e);
-        if (m == 1 && eonly <= 160 * 1024) { s.table_mode = 1; p->lds_bytes = eonly; }
-        if (m == 2) { s.table_mode = 2; p->lds_bytes = fixed; }
+    // table placement (DESIGN.md "data layout"): keep >= 2 workgroups per CU when everything is in LDS.
+    // PAIR_TABLE stores (g[i], g[i+1]-g[i]) per bin (16 B, one ds_read_b128 per draw) when that still fits.
+    {
+        int npair = 0;
+        for (auto &L : p->leaves) {
+            s.leaf_poff.push_back(npair);
+            if (L.kind == MCI_CONTINUOUS) npair += 2 * L.nbin;
+        }
+        s.npair = npair;
+        const int64_t fixed = (int64_t)(s.ndacc + s.nddist + s.nobs + 16 * s.ncols) * 8;
+        const int64_t e1 = (int64_t)s.nedge * 8, e2 = (int64_t)npair * 8, hb = (int64_t)s.nbin * 8;
+        const int64_t lim0 = 80 * 1024, lim1 = 160 * 1024 - 1024;
+        int mode = 2, pair = 0;
+        if (fixed + e2 + hb <= lim0) { mode = 0; pair = 1; }
+        else if (fixed + e1 + hb <= lim0) { mode = 0; pair = 0; }
+        else if (fixed + e2 <= lim1) { mode = 1; pair = 1; }
+        else if (fixed + e1 <= lim1) { mode = 1; pair = 0; }
+        if (const char *e = getenv("MCI_TABLE_MODE")) {
+            const int m = atoi(e);
+            if (m == 1 && mode <= 1) { mode = 1; pair = (fixed + e2 <= lim1) ? 1 : 0; }
+            if (m == 2) { mode = 2; pair = 0; }
+        }
+        if (const char *e = getenv("MCI_PAIR_TABLE")) pair = (atoi(e) != 0 && mode <= 1 && fixed + e2 + (mode == 0 ? hb : 0) <= lim1) ? 1 : 0;
+        s.table_mode = mode;
+        s.pair_table = pair;
+        p->lds_bytes = fixed + (mode <= 1 ? (pair ? e2 : e1) : 0) + (mode == 0 ? hb : 0);
     }
     p->nstat = 2 * s.nobs + 2 + Nd;
     p->packed_n = p->nstat + s.nbin;
@@ -579,7 +594,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
 
 int mci_iteration_reduce(mci_problem *p) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
-    if (!p->ctx->comm || p->ctx->nranks == 1) return MCI_OK;
+    if (!p->ctx->comm) return MCI_OK; // no communicator: single process (mpi_nprocs() == 1)
     int r = g_rccl.AllReduce(p->d_packed, p->d_packed, (size_t)p->packed_n, kNcclFloat64, kNcclSum, p->ctx->comm, p->ctx->stream);
     if (r) return fail(MCI_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     return MCI_OK;
@@ -589,7 +604,7 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     const auto &s = p->shape;
     int maxn = 1;
     for (auto &L : p->leaves) maxn = L.nbin > maxn ? L.nbin : maxn;
-    const size_t sm = (size_t)(3 * maxn + 2) * sizeof(double);
+    const size_t sm = (size_t)(4 * maxn + 16) * sizeof(double); // d[N+4] | sg[N+1] | wa[N+1] | wj[N+1] (k_train)
     hipLaunchKernelGGL(mci::k_train, dim3(s.nleaf + 1), dim3(256), sm, p->ctx->stream, p->d_leaves, s.nleaf, p->d_packed, p->nstat,
                        p->d_edges, p->d_dacc, p->d_ddist, log_row, p->d_reweight, s.ni + 1, do_reweight, gamma, do_train, p->d_status);
     HIPCHK(hipGetLastError());

@@ -42,9 +42,20 @@ template <int B, int E, class F> __device__ __forceinline__ void static_for(F &&
 // ---------------------------------------------------------------------------------------------
 struct u32x4 { u32 x, y, z, w; };
 
+// Development-only ablation switches (passed through MCI_JIT_FLAGS; never set in product builds):
+//   -DMCI_ABL_CHEAPRNG  one multiply-add instead of Philox     -DMCI_ABL_NOHIST   skip the histogram update
+//   -DMCI_ABL_NOTABLE   skip the LDS grid gathers              -DMCI_PHILOX_ROUNDS=n
+#ifndef MCI_PHILOX_ROUNDS
+#define MCI_PHILOX_ROUNDS 10
+#endif
+
 __device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1) {
+#ifdef MCI_ABL_CHEAPRNG
+    const u64 h = (u64)(c0 ^ k0) * 0x9E3779B97F4A7C15ull + ((u64)c2 << 32 | (c1 ^ c3 ^ k1));
+    return {(u32)h, (u32)(h >> 32), (u32)(h >> 16), (u32)(h >> 24)};
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < MCI_PHILOX_ROUNDS; ++r) {
         const u64 p0 = (u64)0xD2511F53u * c0; // v_mad_u64_u32: hi and lo in one issue
         const u64 p1 = (u64)0xCD9E8D57u * c2;
         const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0;
@@ -124,21 +135,36 @@ template <class Cfg> struct Tables {
     const double *DD; // discrete distribution (LDS)
 };
 
-// one leaf draw: create! in its Jacobian form.  Returns x, pj = 1/prob, bin index (0-based).
-template <class Cfg, int K> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &pj, int &bin) {
+// one leaf draw: create! in its Jacobian form.  Returns x, the bin index (0-based) and `raw` with
+// 1/prob = raw * jac_scale(K): raw = dx for a Continuous leaf (scale N), 1/distribution for a Discrete one.
+// With Cfg::PAIR_TABLE the LDS table holds (g[i], g[i+1]-g[i]) pairs: ONE aligned ds_read_b128 per draw and
+// no subtraction on the critical path (the pair is formed with the same rounding when the table is staged).
+template <class Cfg, int K> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
     constexpr int leaf = Cfg::draw_leaf(K);
     if constexpr (Cfg::leaf_kind(leaf) == 0) {
         // sampler.jl:295-303:  iy = floor(y*N)+1; dy = y*N-(iy-1); x = g[iy] + dy*(g[iy+1]-g[iy]); prob = 1/(N*dx)
         constexpr int N = Cfg::leaf_nbin(leaf);
-        constexpr int eoff = Cfg::leaf_eoff(leaf);
         const double yn = y * (double)N;
-        const int iy = (int)yn; // y*N >= 0: trunc == floor
-        const double dy = yn - (double)iy;
-        const double g0 = t.E[eoff + iy];
-        const double g1 = t.E[eoff + iy + 1];
-        const double dx = g1 - g0;
+        const int iy = (int)yn;                           // y*N >= 0: trunc == floor
+        const double dy = __builtin_amdgcn_fract(yn);     // v_fract_f64 == yn - floor(yn), exact
+#ifdef MCI_ABL_NOTABLE
+        const double g0 = (double)iy, dx = 1.0;
+#else
+        double g0, dx;
+        if constexpr (Cfg::PAIR_TABLE != 0 && Cfg::TABLE_MODE <= 1) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const d2 e = *reinterpret_cast<const d2 *>(t.E + Cfg::leaf_poff(leaf) + 2 * iy);
+            g0 = e.x;
+            dx = e.y;
+      )MCIDEV"
+R"MCIDEV(  } else {
+            constexpr int eoff = Cfg::leaf_eoff(leaf);
+            g0 = t.E[eoff + iy];
+            dx = t.E[eoff + iy + 1] - g0;
+        }
+#endif
         x = g0 + dy * dx;
-        pj = (double)N * dx;
+        raw = dx;
         bin = iy;
     } else {
         // sampler.jl:17-20 + common.jl:16-25 bisection on accumulation[1..K+1]
@@ -153,25 +179,37 @@ template <class Cfg, int K> __device__ __forceinline__ void draw_leaf(const Tabl
         }
         if (jl > Kn) jl = Kn; // accumulation[end] <= y < 1 through rounding: reference raises (common.jl:10-12)
         x = Cfg::leaf_lower(leaf) + (double)(jl - 1);
-        pj = 1.0 / t.DD[doff + jl - 1];
+        raw = 1.0 / t.DD[doff + jl - 1];
         bin = jl - 1;
     }
 }
 
-// all NDRAW draws of one sample + Jacobians.  jaci[i] = product of pj over integrand i's own draws
+// 1/prob = raw * jac_scale(k)
+template <class Cfg> constexpr double jac_scale(int k) {
+    return Cfg::leaf_kind(Cfg::draw_leaf(k)) == 0 ? (double)Cfg::leaf_nbin(Cfg::draw_leaf(k)) : 1.0;
+}
+// product of jac_scale over the draws in `mask` (compile-time: the N^D factor is applied once per sample)
+template <class Cfg> constexpr double jac_scale_product(unsigned long long mask) {
+    double p = 1.0;
+    for (int k = 0; k < Cfg::NDRAW; ++k)
+        if ((mask >> k) & 1ull) p *= jac_scale<Cfg>(k);
+    return p;
+}
+
+// all NDRAW draws of one sample + Jacobians.  jaci[i] = product of 1/prob over integrand i's own draws
 // ( = weights*padding_probability*jac of vegas/montecarlo.jl:152 up to rounding ).
 template <class Cfg> struct Sample {
     double x[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
     int bin[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
     double pj[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // 1/prob per draw (dead-code eliminated where unused)
     double jac;
-    d)MCIDEV"
-R"MCIDEV(ouble jaci[Cfg::NI];
+    double jaci[Cfg::NI];
 };
 
 template <class Cfg> __device__ __forceinline__ void draw_sample(const Tables<Cfg> &t, u64 seed, u32 stream, u64 index, Sample<Cfg> &s) {
     const u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
     const u32 ilo = (u32)index, ihi = (u32)(index >> 32);
+    constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
     s.jac = 1.0;
     static_for<0, Cfg::NI>([&](auto I) { s.jaci[decltype(I)::value] = 1.0; });
     static_for<0, (Cfg::NDRAW + 1) / 2>([&](auto C) {
@@ -181,32 +219,53 @@ template <class Cfg> __device__ __forceinline__ void draw_sample(const Tables<Cf
             constexpr int k = 2 * c + decltype(H)::value;
             if constexpr (k < Cfg::NDRAW) {
                 const double y = decltype(H)::value == 0 ? u01(r.x, r.y) : u01(r.z, r.w);
-                double pj;
-                draw_leaf<Cfg, k>(t, y, s.x[k], pj, s.bin[k]);
-                s.pj[k] = pj;
-                s.jac *= pj; // jac /= prob   vegas/montecarlo.jl:126
+                double raw;
+                draw_leaf<Cfg, k>(t, y, s.x[k], raw, s.bin[k]);
+                s.pj[k] = raw * jac_scale<Cfg>(k);
+                s.jac *= raw; // jac /= prob   vegas/montecarlo.jl:126 (scale applied below)
                 static_for<0, Cfg::NI>([&](auto I) {
                     constexpr int i = decltype(I)::value;
-                    if constexpr ((Cfg::own_mask(i) >> k) & 1ull) s.jaci[i] *= pj;
+                    if constexpr (((Cfg::own_mask(i) >> k) & 1ull) && Cfg::own_mask(i) != ALL) s.jaci[i] *= raw;
                 });
             }
         });
+    });
+    s.jac *= jac_scale_product<Cfg>(ALL);
+    static_for<0, Cfg::NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (Cfg::own_mask(i) == ALL) s.jaci[i] = s.jac; // dof[i] == maxdof: no padding (vegas/montecarlo.jl:82)
+        else s.jaci[i] *= jac_scale_product<Cfg>(Cfg::own_mask(i));
     });
 }
 
 // stage the tables into LDS (coalesced 8-byte loads, once per workgroup)
 template <class Cfg> __device__ __forceinline__ void stage_tables(const double *gE, const double *gDA, const double *gDD, double *sE, double *sDA, double *sDD) {
     const int tid = threadIdx.x, T = blockDim.x;
-    if constexpr (Cfg::TABLE_MODE <= 1)
-        for (int i = tid; i < Cfg::NEDGE; i += T) sE[i] = gE[i];
+    if constexpr (Cfg::TABLE_MODE <= 1) {
+        if constexpr (Cfg::PAIR_TABLE != 0) {
+            static_for<0, Cfg::NLEAF>([&](auto Lf) {
+                constexpr int l = decltype(Lf)::value;
+                if constexpr (Cfg::leaf_kind(l) == 0) {
+                    constexpr int eoff = Cfg::leaf_eoff(l), poff = Cfg::leaf_poff(l);
+                    for (int i = tid; i < Cfg::leaf_nbin(l); i += T) {
+                        const double g0 = gE[eoff + i], g1 = gE[eoff + i + 1];
+                        sE[poff + 2 * i] = g0;
+                        sE[poff + 2 * i + 1] = g1 - g0;
+                    }
+                }
+            });
+        } else {
+            for (int i = tid; i < Cfg::NEDGE; i += T) sE[i] = gE[i];
+        }
+    }
     for (int i = tid; i < Cfg::NDACC; i += T) sDA[i] = gDA[i];
     for (int i = tid; i < Cfg::NDDIST; i += T) sDD[i] = gDD[i];
 }
 
-// LDS carve (doubles).  Order: edges | dacc | ddist | hist | obs | reduction scratch
+// LDS carve (doubles).  Order: grid table | dacc | ddist | hist | obs | reduction scratch
 template <class Cfg> struct Lds {
     static constexpr int E = 0;
-    static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? Cfg::NEDGE : 0);
+    static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
     static constexpr int DD = DA + Cfg::NDACC;
     static constexpr int H = DD + Cfg::NDDIST;
     static constexpr int O = H + (Cfg::TABLE_MODE == 0 ? Cfg::NBIN : 0);
@@ -262,7 +321,8 @@ template <class Cfg> __device__ __forceinline__ void measure(const Sample<Cfg> &
 template <class Cfg> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/) {
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
     double *sO = smem + Lds<Cfg>::O, *sR = smem + Lds<Cfg>::R, *sH = smem + Lds<Cfg>::H;
-    // scalar observables
+    // scalar ob)MCIDEV"
+R"MCIDEV(servables
     static_for<0, Cfg::NI>([&](auto I) {
         constexpr int i = decltype(I)::value;
         if constexpr (Cfg::obs_bin_draw(i) < 0) {
@@ -331,8 +391,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(B * a.neval_per_block + n), s);
         double w[Cfg::NI];
-        Cfg)MCIDEV"
-R"MCIDEV(::integrand(s.x, w, a.ud); // vegas/montecarlo.jl:140-144
+        Cfg::integrand(s.x, w, a.ud); // vegas/montecarlo.jl:140-144
         extra[Cols<Cfg>::NEVAL - Cfg::NOBS] += 1.0; // config.neval += 1   :118
         if (a.measurefreq == 1 || (n + 1) % a.measurefreq == 0) { // :148
             double relw[Cfg::NI];
@@ -346,7 +405,11 @@ R"MCIDEV(::integrand(s.x, w, a.ud); // vegas/montecarlo.jl:140-144
             const double wj = fabs(w[i]) * s.jac; // :173-174 (full jac, not the integrand's own: author's warning :175)
             wh[i] = wj * wj;                      // :180
         });
+#ifndef MCI_ABL_NOHIST
         hist_update<Cfg>(s, wh, sH, a.ghist);
+#else
+        acc[0] += wh[0] * 1e-300;
+#endif
     }
     __syncthreads();
     flush_workgroup<Cfg>(a, smem, acc, extra);
@@ -426,7 +489,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
         {   // initialize!  (montecarlo.jl:151-153): create! on every live slot
             Sample<Cfg> s;
             draw_sample<Cfg>(t, a.seed, st_init, g, s);
-            static_for<0, Cfg::NDRAW>([&](auto K) {
+            static_for<0, Cfg::NDRAW>([)MCIDEV"
+R"MCIDEV(&](auto K) {
                 constexpr int k = decltype(K)::value;
                 c.x[k] = s.x[k];
                 c.bin[k] = s.bin[k];
@@ -475,10 +539,9 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                                         const u32x4 rr = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(kk >> 1), st_step, k0, k1);
                                         y = (kk & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
                                     }
-                                    double pj;
-   )MCIDEV"
-R"MCIDEV(                                 draw_leaf<Cfg, k>(t, y, n.x[k], pj, n.bin[k]); // shift!  sampler.jl:336-386, :57-71
-                                    n.prob[k] = 1.0 / pj;
+                                    double raw;
+                                    draw_leaf<Cfg, k>(t, y, n.x[k], raw, n.bin[k]); // shift!  sampler.jl:336-386, :57-71
+                                    n.prob[k] = 1.0 / (raw * jac_scale<Cfg>(k));
                                     prop *= c.prob[k] / n.prob[k];                  // 1/prob_ratio  sampler.jl:385, :70
                                 });
                             }

@@ -28,9 +28,9 @@ extern const char *const kDeviceHeader;
 
 struct ProblemShape {
     int ndraw = 0, nleaf = 0, ni = 0, npool = 0, nobs = 0, ncols = 0, table_mode = 0;
-    int nedge = 0, ndacc = 0, nddist = 0, nbin = 0;
+    int nedge = 0, ndacc = 0, nddist = 0, nbin = 0, pair_table = 0, npair = 0;
     std::vector<int> draw_leaf, draw_pool, draw_slot;
-    std::vector<int> leaf_kind, leaf_nbin, leaf_eoff, leaf_doff, leaf_boff, leaf_adapt;
+    std::vector<int> leaf_kind, leaf_nbin, leaf_eoff, leaf_doff, leaf_boff, leaf_adapt, leaf_poff;
     std::vector<double> leaf_lower;
     std::vector<unsigned long long> own_mask;   // [ni+1] draws covered by integrand i (last = normalisation: 0)
     std::vector<unsigned long long> cover_mask; // [ndraw] integrands covering draw k
@@ -78,7 +78,7 @@ inline std::string generate_source(const ProblemShape &s) {
     o << "    static constexpr int NDRAW = " << s.ndraw << ", NLEAF = " << s.nleaf << ", NI = " << s.ni
       << ", NPOOL = " << s.npool << ", NOBS = " << s.nobs << ", NCOLS = " << s.ncols << ";\n";
     o << "    static constexpr int TABLE_MODE = " << s.table_mode << ", NEDGE = " << s.nedge << ", NDACC = " << s.ndacc
-      << ", NDDIST = " << s.nddist << ", NBIN = " << s.nbin << ";\n";
+      << ", NDDIST = " << s.nddist << ", NBIN = " << s.nbin << ", PAIR_TABLE = " << s.pair_table << ", NPAIR = " << s.npair << ";\n";
     o << fn_table("int", "draw_leaf", arr(s.draw_leaf, "int"));
     o << fn_table("int", "draw_pool", arr(s.draw_pool, "int"));
     o << fn_table("int", "draw_slot", arr(s.draw_slot, "int"));
@@ -88,6 +88,7 @@ inline std::string generate_source(const ProblemShape &s) {
     o << fn_table("int", "leaf_doff", arr(s.leaf_doff, "int"));
     o << fn_table("int", "leaf_boff", arr(s.leaf_boff, "int"));
     o << fn_table("int", "leaf_adapt", arr(s.leaf_adapt, "int"));
+    o << fn_table("int", "leaf_poff", arr(s.leaf_poff, "int"));
     o << fn_table("double", "leaf_lower", dbl_arr(s.leaf_lower));
     o << fn_table("unsigned long long", "own_mask", arr(s.own_mask, "u64", "ull"));
     o << fn_table("unsigned long long", "cover_mask", arr(s.cover_mask, "u64", "ull"));

@@ -140,9 +140,10 @@ __global__ void __launch_bounds__(256) k_train(const LeafDev *__restrict__ leave
     if (!L.adapt) return; // variable.jl:208, :370
     const int N = L.nbin;
     double *h = packed + nstat + L.boff;
-    double *d = sm;              // [N]   smoothed / rescaled distribution
-    double *ng = sm + N;         // [N+1] new grid
-    double *sg = sm + 2 * N + 1; // [N+1] old grid staged in LDS (the walk below is a serial gather)
+    double *d = sm;                     // [N+4] smoothed / rescaled distribution (+4 window padding)
+    double *sg = sm + N + 4;            // [N+1] old grid staged in LDS
+    double *wa = sg + N + 1;            // [N+1] acc_f recorded per new grid point
+    int *wj = (int *)(wa + N + 1);      // [N+1] j recorded per new grid point
     __shared__ int bad;
     __shared__ double ssum;
     if (tid == 0) bad = 0;
@@ -191,26 +192,43 @@ __global__ void __launch_bounds__(256) k_train(const LeafDev *__restrict__ leave
                 return;
             }
         }
-        // refinement walk  variable.jl:216-235 (serial recurrence, kept in the reference's order)
+        // refinement walk  variable.jl:216-235.  The recurrence on (j, acc_f) is inherently serial and is
+        // kept in the reference's order (bit-for-bit the oracle's); lane 0 runs it with a 4-deep register
+        // window over d[] so that no LDS latency sits on the dependency chain, and only records (j, acc_f)
+        // per new grid point.  The divisions/interpolations (:233) are then done by all lanes.
+        if (tid < 4) d[N + tid] = 0.0; // window padding
+        __syncthreads();
         if (tid == 0) {
             double s = 0.0;
             for (int i = 0; i < N; ++i) s += d[i];
             const double f_ninc = s / (double)N;
             int j = 0;
             double acc_f = 0.0;
-            ng[0] = sg[0];
-            ng[N] = sg[N];
+            double w0 = d[0], w1 = d[1], w2 = d[2], w3 = d[3];
             for (int i = 2; i <= N; ++i) {
-                while (acc_f < f_ninc) {
+                while (acc_f < f_ninc && j < N) {
+                    acc_f += w0; // acc_f += avg_f[j]  (:229-230)
+                    w0 = w1;
+                    w1 = w2;
+                    w2 = w3;
+                    w3 = d[j + 4];
                     j += 1;
-                    acc_f += d[j - 1];
                 }
-                acc_f -= f_ninc;
-                ng[i - 1] = sg[j] - (acc_f / d[j - 1]) * (sg[j] - sg[j - 1]);
+                acc_f -= f_ninc; // :232
+                wa[i - 1] = acc_f;
+                wj[i - 1] = j;
             }
         }
         __syncthreads();
-        for (int i = tid; i <= N; i += T) g[i] = ng[i];
+        for (int i = tid; i <= N; i += T) {
+            double v;
+            if (i == 0 || i == N) v = sg[i]; // :217-218, :235
+            else {
+                const int j = wj[i];
+                v = sg[j] - (wa[i] / d[j - 1]) * (sg[j] - sg[j - 1]); // :233
+            }
+            g[i] = v;
+        }
     } else {
         // train!(Discrete)  variable.jl:369-382 : rescale (no smoothing), normalise, prefix sum
         double *acc = dacc + L.eoff, *dist = ddist + L.doff;

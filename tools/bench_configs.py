@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Development tool (GPU box): throughput of the other BASELINE configs (parity-test cases, not bench lines)."""
+import math
+import sys
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import mcintegration_jl_amd as mci
+from catalog_params import bubble_exact, genz_exact
+
+L = math.sqrt(50.0)
+PI = math.pi
+
+
+def run(name, cfg, f, solver, neval, exact, measure=None, niter_train=5, niter=5, nchain=0):
+    eng = mci.Engine(cfg, f, measure=measure)
+    eng.compile()
+    eng.integrate(solver, neval=neval, niter=niter_train, block=16, seed=1, nchain=nchain)
+    r = eng.integrate(solver, neval=neval, niter=niter, block=16, seed=1, first_iteration=niter_train, ignore=0, nchain=nchain)
+    ms, wg, th = eng.kernel_times_ms(niter)
+    dev = (r["mean"] - np.atleast_1d(exact)) / r["stdev"]
+    print("%-28s mode=%d lds=%6d B  %8.1f Msamples/s  kernel %.3f ms (wg=%d,th=%d)  mean=%s +- %s  dev_sigma=%s" % (
+        name, eng.table_mode, eng.lds_bytes, neval * niter / r["seconds"] / 1e6, float(np.median(ms)), wg, th,
+        np.array2string(r["mean"], precision=8), np.array2string(r["stdev"], precision=2), np.array2string(dev, precision=2)), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c2i", "c4", "c3v", "c3mc", "c1"]
+    if "c1" in which:
+        run("C1 log/sqrt 1e7", mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]]), mci.catalog.log_over_sqrt(), "vegas", 10**7, -4.0)
+    if "c2" in which:
+        run("C2 gauss16 shared", mci.Configuration(var=mci.Continuous(-L, L), dof=[[16]]), mci.catalog.gaussian(16), "vegas", 10**8, 1.0)
+    if "c2i" in which:
+        run("C2 gauss16 16 grids", mci.Configuration(var=mci.Continuous([(-L, L)] * 16), dof=[[1]]), mci.catalog.gaussian(16), "vegas", 10**8, 1.0)
+    if "c4" in which:
+        run("C4 genz32 32 grids", mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]]), mci.catalog.genz_product_peak(32), "vegas",
+            10**8, genz_exact(32))
+    p = mci.catalog.bubble_parameters()
+
+    def bub():
+        var = (mci.Continuous(0.0, 1.0, alpha=3.0), mci.Continuous(0.0, PI, alpha=3.0), mci.Continuous(0.0, 2 * PI, alpha=3.0),
+               mci.Continuous(0.0, p["beta"], alpha=3.0), mci.Discrete(1, 4, adapt=False))
+        return mci.Configuration(var=var, dof=[[1, 1, 1, 1, 1]], obs=[np.zeros(4)])
+    if "c3v" in which:
+        run("C3 bubble vegas 1e8", bub(), mci.catalog.bubble(), "vegas", 10**8, bubble_exact(), measure=mci.bin_by(4))
+    if "c3mc" in which:
+        run("C3 bubble vegasmc 1e8", bub(), mci.catalog.bubble(), "vegasmc", 10**8, bubble_exact(), measure=mci.bin_by(4))
+        run("C3 bubble vegasmc 1e6", bub(), mci.catalog.bubble(), "vegasmc", 10**6, bubble_exact(), measure=mci.bin_by(4))

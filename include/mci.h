@@ -161,6 +161,10 @@ int mci_kernel_times_ms(mci_problem *prob, float *ms, int32_t n, int32_t *got, i
 /* ---- host-side statistics of the path (pure functions, no GPU needed) ---- */
 void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64_t *nevalperblock,
                            int64_t *block);                                          /* main.jl:220-234 */
+/* first measured step of a VegasMC chain of `steps` steps: the reference's `ne >= neval/100`
+ * (vegas_mc/montecarlo.jl:213) for its single chain (nchain = 1); with nchain > 1 independent chains per block
+ * additionally >= min(steps/2, 32*nslots) so that each short chain forgets its start (nslots = sum of maxdof) */
+double mci_chain_burnin(int64_t steps, int64_t nchain, int32_t nslots);
 void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out);        /* configuration.jl:229-236 */
 void mci_mean_std(const double *obs_sum, const double *obs_sq, int64_t n, int64_t block, double *mean,
                   double *std);                                                      /* main.jl:296-320 */

@@ -109,6 +109,7 @@ struct mci_problem {
     hipFunction_t f_vegas = nullptr, f_vegasmc = nullptr, f_dump = nullptr;
     bool compiled = false;
     int threads = 256, wg_per_block = 0; // 0 = auto
+    int train_serial = 0; // MCI_TRAIN_SERIAL=1: refinement walk as the reference's serial recurrence (diagnostic)
     // last launch
     std::vector<hipEvent_t> evs; // ring of (start, stop) pairs around the sampling kernel, one pair per launch
     int64_t launches = 0;
@@ -144,7 +145,7 @@ int ensure_capacity(mci_problem *p, int64_t nwg, int64_t nblocks) {
         if (p->d_part_hist) hipFree(p->d_part_hist);
         p->d_part_cols = p->d_part_hist = nullptr;
         HIPCHK(hipMalloc((void **)&p->d_part_cols, (size_t)nwg * s.ncols * sizeof(double)));
-        if (s.table_mode == 0) HIPCHK(hipMalloc((void **)&p->d_part_hist, (size_t)nwg * (s.nbin ? s.nbin : 1) * sizeof(double)));
+        if (s.table_mode == 0 || s.table_mode == 3) HIPCHK(hipMalloc((void **)&p->d_part_hist, (size_t)nwg * (s.nbin ? s.nbin : 1) * sizeof(double)));
         p->cap_wg = nwg;
     }
     if (nblocks > p->cap_blocks) {
@@ -396,21 +397,53 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         s.npair = npair;
         const int64_t fixed = (int64_t)(s.ndacc + s.nddist + s.nobs + 16 * s.ncols) * 8;
         const int64_t e1 = (int64_t)s.nedge * 8, e2 = (int64_t)npair * 8, hb = (int64_t)s.nbin * 8;
+        // lim0: >= 2 workgroups of 256 threads per CU; lim1: one 1024-thread workgroup owning the CU's LDS
         const int64_t lim0 = 80 * 1024, lim1 = 160 * 1024 - 1024;
-        int mode = 2, pair = 0;
+        int mode = 3, pair = 0;
         if (fixed + e2 + hb <= lim0) { mode = 0; pair = 1; }
         else if (fixed + e1 + hb <= lim0) { mode = 0; pair = 0; }
-        else if (fixed + e2 <= lim1) { mode = 1; pair = 1; }
-        else if (fixed + e1 <= lim1) { mode = 1; pair = 0; }
-        if (const char *e = getenv("MCI_TABLE_MODE")) {
+        else if (fixed + e2 + hb <= lim1) { mode = 0; pair = 1; }
+        else if (fixed + e1 + hb <= lim1) { mode = 0; pair = 0; }
+        if (const char *e = getenv("MCI_TABLE_MODE")) { // test/diagnostic override
             const int m = atoi(e);
-            if (m == 1 && mode <= 1) { mode = 1; pair = (fixed + e2 <= lim1) ? 1 : 0; }
+            if (m == 1 && fixed + e1 <= lim1) { mode = 1; pair = (fixed + e2 <= lim1) ? 1 : 0; }
             if (m == 2) { mode = 2; pair = 0; }
+            if (m == 3) { mode = 3; pair = 0; }
         }
+        if (const char *e = getenv("MCI_TRAIN_SERIAL")) p->train_serial = atoi(e) != 0;
         if (const char *e = getenv("MCI_PAIR_TABLE")) pair = (atoi(e) != 0 && mode <= 1 && fixed + e2 + (mode == 0 ? hb : 0) <= lim1) ? 1 : 0;
+        // histogram tiles: contiguous leaves, each tile's bins fit the LDS left over
+        s.leaf_tile.assign(p->leaves.size(), 0);
+        s.tile_boff.assign(1, 0);
+        s.tile_nbin.assign(1, s.nbin);
+        if (mode == 3) {
+            int64_t budget = (lim1 - fixed) / 8; // doubles
+            if (const char *e = getenv("MCI_HIST_TILE_BINS")) budget = atoll(e);
+            s.tile_boff.clear();
+            s.tile_nbin.clear();
+            int cur = -1;
+            for (size_t l = 0; l < p->leaves.size(); ++l) {
+                const Leaf &L = p->leaves[l];
+                if (L.nbin > budget) { delete p; return fail(MCI_ERR_INVALID, "leaf %zu: %d bins do not fit the LDS histogram", l, L.nbin); }
+                if (cur < 0 || s.tile_nbin[cur] + L.nbin > budget) {
+                    s.tile_boff.push_back(L.boff);
+                    s.tile_nbin.push_back(0);
+                    cur += 1;
+                }
+                s.leaf_tile[l] = cur;
+                s.tile_nbin[cur] += L.nbin;
+            }
+        }
+        s.ntile = (int)s.tile_nbin.size();
+        s.htile = 0;
+        for (int v : s.tile_nbin) s.htile = v > s.htile ? v : s.htile;
         s.table_mode = mode;
         s.pair_table = pair;
-        p->lds_bytes = fixed + (mode <= 1 ? (pair ? e2 : e1) : 0) + (mode == 0 ? hb : 0);
+        const bool hist_lds = (mode == 0 || mode == 3);
+        p->lds_bytes = fixed + (mode <= 1 ? (pair ? e2 : e1) : 0) + (hist_lds ? (int64_t)s.htile * 8 : 0);
+        // one big workgroup per CU.  Measured (tools/c4_sweep.py): with many draws the kernel is register-bound
+        // (x[], bins and in-flight L2 gathers), so fewer, fatter-register waves beat 16 spilling ones.
+        if (p->lds_bytes > lim0) p->threads = s.ndraw > 16 ? 256 : 512;
     }
     p->nstat = 2 * s.nobs + 2 + Nd;
     p->packed_n = p->nstat + s.nbin;
@@ -533,26 +566,34 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     const auto &s = p->shape;
     const int T = p->threads;
     int64_t units = nevalperblock; // lanes of useful work per block
+    double burnin = 0.0;
     if (solver == MCI_VEGASMC) {
-        if (nchain <= 0) { // auto: ~2048 steps per chain, at least one wave, at most what fills the chip
-            nchain = nevalperblock / 2048;
-            if (nchain < 64) nchain = 64;
+        int nslots = 0; // (pool, slot) pairs changeVariable can pick (updates.jl:50,:58)
+        for (int v = 0; v < p->npool; ++v) nslots += p->maxdof[v];
+        if (nchain <= 0) { // auto: chains long enough that the burn-in floor below wastes <= 1/8 of the steps
+            const int64_t target = 256 * (int64_t)nslots > 1024 ? 256 * (int64_t)nslots : 1024;
+            nchain = nevalperblock / target;
+            if (nchain < 1) nchain = 1;
             if (nchain > 16384) nchain = 16384;
-            if (nchain > nevalperblock) nchain = nevalperblock;
         }
+        if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
+        burnin = mci_chain_burnin(nevalperblock / nchain, nchain, nslots);
         units = nchain;
     } else {
         nchain = 1;
     }
     int wpb = p->wg_per_block;
-    if (wpb <= 0) { // fill 256 CUs x ~4 workgroups, but never leave a workgroup without work
-        wpb = (int)((1024 + nblocks - 1) / nblocks);
+    if (wpb <= 0) { // 256 CUs x ~8 workgroups in the grid (measured best on C2), never a workgroup without work
+        wpb = (int)((2048 + nblocks - 1) / nblocks);
         const int64_t maxw = (units + T - 1) / T;
         if (wpb > maxw) wpb = (int)maxw;
         if (wpb < 1) wpb = 1;
     }
-    const int64_t nwg = nblocks * wpb;
-    if ((rc = ensure_capacity(p, nwg, nblocks))) return rc;
+    const bool hist_lds = (s.table_mode == 0 || s.table_mode == 3);
+    if (wpb * s.ntile > 4096 / nblocks && s.ntile > 1) wpb = (int)(4096 / nblocks / s.ntile) > 0 ? (int)(4096 / nblocks / s.ntile) : 1;
+    const int64_t nrows = nblocks * wpb;   // partial rows: one per (block, slice)
+    const int64_t nwg = nrows * s.ntile;   // NTILE workgroups per row, each owning one histogram tile
+    if ((rc = ensure_capacity(p, nrows, nblocks))) return rc;
     mci::BatchArgs a{};
     a.edges = p->d_edges;
     a.dacc = p->d_dacc;
@@ -569,6 +610,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.wg_per_block = wpb;
     a.measurefreq = measurefreq;
     a.nchain = nchain;
+    a.burnin = burnin;
     void *args[] = {&a};
     hipFunction_t f = solver == MCI_VEGASMC ? p->f_vegasmc : p->f_vegas;
     hipStream_t st = p->ctx->stream;
@@ -582,11 +624,11 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     p->last_nblocks = (int)nblocks;
     // merge: block sums -> packed
     const int nb256 = (s.nbin + 255) / 256;
-    if (s.table_mode == 0 && s.nbin > 0)
-        hipLaunchKernelGGL(mci::k_hist_stage1, dim3(nb256, mci_problem::kGroups), dim3(256), 0, st, p->d_part_hist, (int)nwg, s.nbin,
+    if (hist_lds && s.nbin > 0)
+        hipLaunchKernelGGL(mci::k_hist_stage1, dim3(nb256, mci_problem::kGroups), dim3(256), 0, st, p->d_part_hist, (int)nrows, s.nbin,
                            (int)mci_problem::kGroups, p->d_stage1);
     hipLaunchKernelGGL(mci::k_finalize, dim3(nb256 + 1), dim3(256), 0, st, p->d_part_cols, s.ncols, s.nobs, s.ni, (int)nblocks, wpb,
-                       p->d_stage1, (int)mci_problem::kGroups, p->d_ghist, s.table_mode != 0 ? 1 : 0, s.nbin, p->d_packed, p->d_status,
+                       p->d_stage1, (int)mci_problem::kGroups, p->d_ghist, hist_lds ? 0 : 1, s.nbin, p->d_packed, p->d_status,
                        p->d_scratch);
     HIPCHK(hipGetLastError());
     return MCI_OK;
@@ -606,7 +648,7 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     for (auto &L : p->leaves) maxn = L.nbin > maxn ? L.nbin : maxn;
     const size_t sm = (size_t)(4 * maxn + 16) * sizeof(double); // d[N+4] | sg[N+1] | wa[N+1] | wj[N+1] (k_train)
     hipLaunchKernelGGL(mci::k_train, dim3(s.nleaf + 1), dim3(256), sm, p->ctx->stream, p->d_leaves, s.nleaf, p->d_packed, p->nstat,
-                       p->d_edges, p->d_dacc, p->d_ddist, log_row, p->d_reweight, s.ni + 1, do_reweight, gamma, do_train, p->d_status);
+                       p->d_edges, p->d_dacc, p->d_ddist, log_row, p->d_reweight, s.ni + 1, do_reweight, gamma, do_train, p->train_serial, p->d_status);
     HIPCHK(hipGetLastError());
     return MCI_OK;
 }
@@ -870,6 +912,16 @@ void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64
     else nblock = nworker;                                       // main.jl:229
     *nevalperblock = neval / nblock;                             // main.jl:232
     *block = nblock;
+}
+
+double mci_chain_burnin(int64_t steps, int64_t nchain, int32_t nslots) {
+    double thr = (double)steps / 100.0; // vegas_mc/montecarlo.jl:213  `ne >= neval / 100`
+    if (nchain > 1) {                   // many short chains: every chain must forget its start (DESIGN.md "chains")
+        double fl = 32.0 * (double)nslots;
+        if (fl > (double)steps / 2.0) fl = (double)steps / 2.0;
+        if (fl > thr) thr = fl;
+    }
+    return thr;
 }
 
 void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out) {

@@ -94,6 +94,7 @@ struct BatchArgs {
     int wg_per_block;
     i64 measurefreq;
     i64 nchain;             // vegasmc: chains per block
+    double burnin;          // vegasmc: a chain measures from step `burnin` on (montecarlo.jl:213; DESIGN.md "chains")
 };
 
 struct DumpArgs {
@@ -127,6 +128,15 @@ __device__ __forceinline__ void global_add(double *p, double v) {
 // table placement.  TABLE_MODE 0: grids + histograms in LDS; 1: grids in LDS, histograms via
 // global f64 atomics; 2: everything from L2/HBM (grids too large for 160 KiB).
 // ---------------------------------------------------------------------------------------------
+//   TABLE_MODE 3: histograms in LDS, grids gathered from L2 (more than ~9 independent grids: the
+//   ds_add_f64 is the part that must not go to global memory); when all histograms do not fit either they
+//   are split into NTILE tiles and each (block, slice) is run by NTILE workgroups, workgroup `tile`
+//   keeping only its tile's histograms (draws + integrand are recomputed: compute is cheaper than atomics).
+template <class Cfg> struct Mode {
+    static constexpr bool EDGE_LDS = Cfg::TABLE_MODE <= 1;
+    static constexpr bool HIST_LDS = Cfg::TABLE_MODE == 0 || Cfg::TABLE_MODE == 3;
+};
+
 template <class Cfg> struct Tables {
     const double *E;  // grid edges (LDS or global)
     const double *DA; // discrete accumulation (LDS)
@@ -226,6 +236,11 @@ template <class Cfg> __device__ __forceinline__ void draw_sample(const Tables<Cf
                 });
             }
         });
+#if MCI_DRAW_FENCE
+        // keep the scheduler from hoisting every Philox chunk to the top of the sample (live ranges of
+        // 2*NDRAW+ registers): with many draws that is the difference between 4 waves/SIMD and spilling
+        if constexpr (((c + 1) % MCI_DRAW_FENCE) == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
     });
     s.jac *= jac_scale_product<Cfg>(ALL);
     static_for<0, Cfg::NI>([&](auto I) {
@@ -265,7 +280,7 @@ template <class Cfg> struct Lds {
     static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
     static constexpr int DD = DA + Cfg::NDACC;
     static constexpr int H = DD + Cfg::NDDIST;
-    static constexpr int O = H + (Cfg::TABLE_MODE == 0 ? Cfg::NBIN : 0);
+    static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE : 0);
     static constexpr int R = O + Cfg::NOBS;
     static constexpr int END = R + 16 /*waves*/ * Cfg::NCOLS;
 };
@@ -284,7 +299,7 @@ template <class Cfg> struct Cols {
 // histogram update of one sample: accumulate!(var, pos+offset, weight) for every (integrand i, draw k in own(i))
 // (vegas/montecarlo.jl:170-185).  The per-integrand weights covering the same draw are summed first,
 // so each draw costs one ds_add_f64.
-template <class Cfg> __device__ __forceinline__ void hist_update(const Sample<Cfg> &s, const double *wh /*[NI]*/, double *sH, double *gH) {
+template <class Cfg> __device__ __forceinline__ void hist_update(const Sample<Cfg> &s, const double *wh /*[NI]*/, double *sH, double *gH, int tile) {
     static_for<0, Cfg::NDRAW>([&](auto K) {
         constexpr int k = decltype(K)::value;
         constexpr int leaf = Cfg::draw_leaf(k);
@@ -294,8 +309,12 @@ template <class Cfg> __device__ __forceinline__ void hist_update(const Sample<Cf
                 constexpr int i = decltype(I)::value;
                 if constexpr ((Cfg::own_mask(i) >> k) & 1ull) wk += wh[i];
             });
-            if constexpr (Cfg::TABLE_MODE == 0) lds_add(&sH[Cfg::leaf_boff(leaf) + s.bin[k]], wk);
-            else global_add(&gH[Cfg::leaf_boff(leaf) + s.bin[k]], wk);
+            if constexpr (Mode<Cfg>::HIST_LDS) {
+                constexpr int lt = Cfg::leaf_tile(leaf);
+                if (Cfg::NTILE == 1 || tile == lt) lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + s.bin[k]], wk);
+            } else {
+                global_add(&gH[Cfg::leaf_boff(leaf) + s.bin[k]], wk);
+            }
         }
     });
 }
@@ -315,7 +334,7 @@ template <class Cfg> __device__ __forceinline__ void measure(const Sample<Cfg> &
 }
 
 // workgroup epilogue: registers -> wave shuffle -> LDS -> one row of part_cols; LDS histogram -> part_hist
-template <class Cfg> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/) {
+template <class Cfg> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/, i64 rowid, int tile) {
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
     double *sO = smem + Lds<Cfg>::O, *sR = smem + Lds<Cfg>::R, *sH = smem + Lds<Cfg>::H;
     // scalar observables
@@ -332,8 +351,8 @@ template <class Cfg> __device__ __forceinline__ void flush_workgroup(const Batch
         if (lane == 0) sR[wave * Cfg::NCOLS + c] = v;
     });
     __syncthreads();
-    double *row = a.part_cols + (i64)blockIdx.x * Cfg::NCOLS;
-    for (int c = tid; c < Cfg::NCOLS; c += T) {
+    double *row = a.part_cols + rowid * Cfg::NCOLS;
+    for (int c = tid; c < Cfg::NCOLS && tile == 0; c += T) { // the NTILE workgroups of a slice hold identical statistics
         bool binned = false;
         int owner = 0;
         static_for<0, Cfg::NI>([&](auto I) {
@@ -347,10 +366,29 @@ template <class Cfg> __device__ __forceinline__ void flush_workgroup(const Batch
             for (int w = 0; w < nwave; ++w) v += sR[w * Cfg::NCOLS + c]; // fixed order: deterministic
         row[c] = v;
     }
-    if constexpr (Cfg::TABLE_MODE == 0) {
-        double *hrow = a.part_hist + (i64)blockIdx.x * Cfg::NBIN;
-        for (int i = tid; i < Cfg::NBIN; i += T) hrow[i] = sH[i];
+    if constexpr (Mode<Cfg>::HIST_LDS) {
+        static_for<0, Cfg::NTILE>([&](auto Tt) {
+            constexpr int tt = decltype(Tt)::value;
+            if (tile == tt) {
+                double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
+                for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = sH[i];
+            }
+        });
     }
+}
+
+// blockIdx -> (statistical block, slice of the block, histogram tile)
+struct WorkItem {
+    i64 rowid, lb;
+    int slice, tile;
+};
+template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchArgs &a) {
+    WorkItem w;
+    w.tile = Cfg::NTILE == 1 ? 0 : (int)(blockIdx.x % Cfg::NTILE);
+    w.rowid = Cfg::NTILE == 1 ? (i64)blockIdx.x : (i64)(blockIdx.x / Cfg::NTILE);
+    w.lb = w.rowid / a.wg_per_block;
+    w.slice = (int)(w.rowid % a.wg_per_block);
+    return w;
 }
 
 // =============================================================================================
@@ -362,19 +400,19 @@ template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs
     double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
     double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
-    if constexpr (Cfg::TABLE_MODE == 0)
-        for (int i = tid; i < Cfg::NBIN; i += T) sH[i] = 0.0;
+    if constexpr (Mode<Cfg>::HIST_LDS)
+        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
     __syncthreads();
     Tables<Cfg> t;
-    if constexpr (Cfg::TABLE_MODE <= 1) t.E = sE;
+    if constexpr (Mode<Cfg>::EDGE_LDS) t.E = sE;
     else t.E = a.edges;
     t.DA = sDA;
     t.DD = sDD;
 
-    const i64 lb = blockIdx.x / a.wg_per_block; // local statistical block
-    const int slice = blockIdx.x % a.wg_per_block;
-    const i64 B = a.block_lo + lb;
+    const WorkItem wi = work_item<Cfg>(a);
+    const int slice = wi.slice, tile = wi.tile;
+    const i64 B = a.block_lo + wi.lb; // global statistical block
     const u32 stream = a.iteration * 8u + STREAM_VEGAS;
     const i64 stride = (i64)a.wg_per_block * T;
 
@@ -402,13 +440,13 @@ template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs
             wh[i] = wj * wj;                      // :180
         });
 #ifndef MCI_ABL_NOHIST
-        hist_update<Cfg>(s, wh, sH, a.ghist);
+        hist_update<Cfg>(s, wh, sH, a.ghist, tile);
 #else
         acc[0] += wh[0] * 1e-300;
 #endif
     }
     __syncthreads();
-    flush_workgroup<Cfg>(a, smem, acc, extra);
+    flush_workgroup<Cfg>(a, smem, acc, extra, wi.rowid, tile);
 }
 
 // =============================================================================================
@@ -453,19 +491,19 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
     double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
-    if constexpr (Cfg::TABLE_MODE == 0)
-        for (int i = tid; i < Cfg::NBIN; i += T) sH[i] = 0.0;
+    if constexpr (Mode<Cfg>::HIST_LDS)
+        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
     __syncthreads();
     Tables<Cfg> t;
-    if constexpr (Cfg::TABLE_MODE <= 1) t.E = sE;
+    if constexpr (Mode<Cfg>::EDGE_LDS) t.E = sE;
     else t.E = a.edges;
     t.DA = sDA;
     t.DD = sDD;
 
-    const i64 lb = blockIdx.x / a.wg_per_block;
-    const int slice = blockIdx.x % a.wg_per_block;
-    const i64 B = a.block_lo + lb;
+    const WorkItem wi = work_item<Cfg>(a);
+    const int slice = wi.slice, tile = wi.tile;
+    const i64 B = a.block_lo + wi.lb;
     const i64 steps = a.neval_per_block / a.nchain;
     const u32 st_init = a.iteration * 8u + STREAM_MC_INIT, st_step = a.iteration * 8u + STREAM_MC_STEP;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
@@ -577,11 +615,11 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 });
                 Sample<Cfg> sb;
                 static_for<0, Cfg::NDRAW>([&](auto K) { sb.bin[decltype(K)::value] = c.bin[decltype(K)::value]; });
-                hist_update<Cfg>(sb, wh, sH, a.ghist);
+                hist_update<Cfg>(sb, wh, sH, a.ghist, tile);
             }
             // ---- measurement  montecarlo.jl:213-232 ----
             const bool mf = (a.measurefreq == 1) || (ne % a.measurefreq == 0);
-            if (mf && (double)ne >= (double)steps / 100.0) {
+            if (mf && (double)ne >= a.burnin) { // :213
                 double relw[NI];
                 static_for<0, NI>([&](auto I) {
                     constexpr int i = decltype(I)::value;
@@ -597,7 +635,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
         }
     }
     __syncthreads();
-    flush_workgroup<Cfg>(a, smem, acc, extra);
+    flush_workgroup<Cfg>(a, smem, acc, extra, wi.rowid, tile);
 }
 
 // the map + integrand alone, for parity tests of a2/a3 and for host-side consumers

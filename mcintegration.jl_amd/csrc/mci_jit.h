@@ -28,7 +28,8 @@ extern const char *const kDeviceHeader;
 
 struct ProblemShape {
     int ndraw = 0, nleaf = 0, ni = 0, npool = 0, nobs = 0, ncols = 0, table_mode = 0;
-    int nedge = 0, ndacc = 0, nddist = 0, nbin = 0, pair_table = 0, npair = 0;
+    int nedge = 0, ndacc = 0, nddist = 0, nbin = 0, pair_table = 0, npair = 0, ntile = 1, htile = 0;
+    std::vector<int> leaf_tile, tile_boff, tile_nbin; // histogram tiles (contiguous leaves)
     std::vector<int> draw_leaf, draw_pool, draw_slot;
     std::vector<int> leaf_kind, leaf_nbin, leaf_eoff, leaf_doff, leaf_boff, leaf_adapt, leaf_poff;
     std::vector<double> leaf_lower;
@@ -89,6 +90,10 @@ inline std::string generate_source(const ProblemShape &s) {
     o << fn_table("int", "leaf_boff", arr(s.leaf_boff, "int"));
     o << fn_table("int", "leaf_adapt", arr(s.leaf_adapt, "int"));
     o << fn_table("int", "leaf_poff", arr(s.leaf_poff, "int"));
+    o << "    static constexpr int NTILE = " << s.ntile << ", HTILE = " << s.htile << ";\n";
+    o << fn_table("int", "leaf_tile", arr(s.leaf_tile, "int"));
+    o << fn_table("int", "tile_boff", arr(s.tile_boff, "int"));
+    o << fn_table("int", "tile_nbin", arr(s.tile_nbin, "int"));
     o << fn_table("double", "leaf_lower", dbl_arr(s.leaf_lower));
     o << fn_table("unsigned long long", "own_mask", arr(s.own_mask, "u64", "ull"));
     o << fn_table("unsigned long long", "cover_mask", arr(s.cover_mask, "u64", "ull"));

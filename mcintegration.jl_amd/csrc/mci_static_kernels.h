@@ -119,6 +119,34 @@ __device__ inline void do_reweight_dev(double *reweight, const double *visited, 
     for (int i = 0; i < nd; ++i) reweight[i] /= s;
 }
 
+// Inclusive prefix sum of v[0..n) into out[0..n) with a fixed summation order (contiguous chunk per thread,
+// then a serial scan of the <= 256 chunk totals by thread 0); returns the total.  ps: LDS scratch [blockDim.x].
+__device__ inline double block_prefix(const double *v, double *out, int n, double *ps) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int per = (n + T - 1) / T, b = tid * per, e = min(n, b + per);
+    double loc = 0.0;
+    for (int k = b; k < e; ++k) loc += v[k];
+    __syncthreads();
+    ps[tid] = loc;
+    __syncthreads();
+    if (tid == 0) {
+        double run = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const double x = ps[t];
+            ps[t] = run;
+            run += x;
+        }
+    }
+    __syncthreads();
+    double run = ps[tid];
+    for (int k = b; k < e; ++k) {
+        run += v[k];
+        out[k] = run;
+    }
+    __syncthreads();
+    return out[n - 1];
+}
+
 // One workgroup per leaf: Dist.train! then clearStatistics!.  Workgroup `nleaf` does the
 // per-iteration bookkeeping: copy the statistics head of `packed` into the iteration log and, for
 // vegasmc, apply doReweight!.
@@ -126,8 +154,9 @@ __global__ void __launch_bounds__(256) k_train(const LeafDev *__restrict__ leave
                                                int nstat, double *__restrict__ edges, double *__restrict__ dacc,
                                                double *__restrict__ ddist, double *__restrict__ iter_log_row,
                                                double *__restrict__ reweight, int nd, int do_reweight, double gamma,
-                                               int do_train, int *__restrict__ status) {
+                                               int do_train, int serial_walk, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double ps[256]; // block_prefix scratch
     const int tid = threadIdx.x, T = blockDim.x;
     if ((int)blockIdx.x == nleaf) {
         if (iter_log_row)
@@ -171,14 +200,19 @@ __global__ void __launch_bounds__(256) k_train(const LeafDev *__restrict__ leave
             d[i] = v;
         }
         __syncthreads();
-        // rescale  common.jl:67-82 (sum left to right, like the oracle)
+        // rescale  common.jl:67-82.  sum(dist): fixed-order workgroup scan (the serial variant sums left to
+        // right like the oracle; Julia's own sum() is pairwise/SIMD, so no order is "the reference's")
         if (N > 1) {
-            if (tid == 0) {
-                double s = 0.0;
-                for (int i = 0; i < N; ++i) s += d[i];
-                ssum = s;
+            if (serial_walk) {
+                if (tid == 0) {
+                    double s = 0.0;
+                    for (int i = 0; i < N; ++i) s += d[i];
+                    ssum = s;
+                }
+                __syncthreads();
+            } else {
+                ssum = block_prefix(d, wa, N, ps);
             }
-            __syncthreads();
             const double s = ssum;
             for (int i = tid; i < N; i += T) {
                 double v = d[i] / s;
@@ -198,6 +232,34 @@ __global__ void __launch_bounds__(256) k_train(const LeafDev *__restrict__ leave
         // per new grid point.  The divisions/interpolations (:233) are then done by all lanes.
         if (tid < 4) d[N + tid] = 0.0; // window padding
         __syncthreads();
+        if (!serial_walk) {
+            // Parallel form of the same walk (default).  With C[j] = sum_{k<=j} avg_f[k] the loop :228-232 leaves,
+            // at new grid point i,  j = min{ j : C[j] >= (i-1)*f_ninc }  and  acc_f = C[j] - (i-1)*f_ninc :
+            // one fixed-order prefix scan + a bisection per point instead of a 2N-step serial recurrence.
+            // Rounding differs from the serial order by O(eps*C[j]/avg_f[j]) of a bin width -- the serial
+            // recurrence has the same forward error; device pow/log differ from libm by as much.
+            const double total = block_prefix(d, wa, N, ps); // wa[j] = C[j] (inclusive)
+            const double f_ninc = total / (double)N;         // :226
+            for (int i = tid; i <= N; i += T) {
+                double v;
+                if (i == 0 || i == N) v = sg[i]; // :217-218, :235
+                else {
+                    const double target = (double)i * f_ninc;
+                    int lo = 0, hi = N - 1; // smallest j0 with C[j0] >= target
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (wa[mid] >= target) hi = mid;
+                        else lo = mid + 1;
+                    }
+                    const double acc_f = wa[lo] - target;
+                    v = sg[lo + 1] - (acc_f / d[lo]) * (sg[lo + 1] - sg[lo]); // :233 with j = lo+1
+                }
+                g[i] = v;
+            }
+            __syncthreads();
+            for (int i = tid; i < N; i += T) h[i] = 1.0e-10; // clearStatistics!  variable.jl:238 -> :565
+            return;
+        }
         if (tid == 0) {
             double s = 0.0;
             for (int i = 0; i < N; ++i) s += d[i];

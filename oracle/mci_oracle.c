@@ -724,6 +724,16 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
     double pad[MCIO_MAXNI], _pad[MCIO_MAXNI]; /* :147-148 */
     double x[MCIO_MAXDRAW], u[MCIO_MAXDRAW];
     const long steps = neval / nchain;
+    /* first measured step: `ne >= neval/100` (:213) for the reference's single chain; with nchain > 1 each short
+       chain additionally skips min(steps/2, 32*nslots) steps (the many-chain decomposition is this engine's own) */
+    int nslots = 0;
+    for (int vi = 0; vi < npool; ++vi) nslots += c->maxdof[vi];
+    double burnin = (double)steps / 100.0;
+    if (nchain > 1) {
+        double fl = 32.0 * (double)nslots;
+        if (fl > (double)steps / 2.0) fl = (double)steps / 2.0;
+        if (fl > burnin) burnin = fl;
+    }
     const uint32_t st_init = stream_id(iteration, STREAM_MC_INIT), st_step = stream_id(iteration, STREAM_MC_STEP);
     for (long ch = 0; ch < nchain; ++ch) {
         const uint64_t g = (uint64_t)block_index * (uint64_t)nchain + (uint64_t)ch;
@@ -785,7 +795,7 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
                         pool_accumulate(c, vi, pos + c->pool_offset[vi], wf2);            /* :208 */
             }
             /* ---- measurement  ref: montecarlo.jl:213-232 ---- */
-            if (ne % measurefreq == 0 && (double)ne >= (double)steps / 100.0) { /* :213 */
+            if (ne % measurefreq == 0 && (double)ne >= burnin) { /* :213 */
                 for (int i = 0; i < N; ++i) {
                     c->visited[i] += fabs(weights[i] * pad[i] * c->reweight[i]) / probability; /* :216 */
                     relw[i] = weights[i] * pad[i] / probability;                               /* :218/:220 */

@@ -130,9 +130,11 @@ def test_vegas_iteration_block_range_and_measurefreq(oracle):
     assert got[2 * eng.nobs] == pytest.approx(4 * 1000 + 5e-10, rel=1e-13)  # normalization = measured samples + 1e-10 per block + 1e-10
 
 
+@pytest.mark.parametrize("walk", ["serial", "prefix"])
 @pytest.mark.parametrize("name", ["c1_log_over_sqrt", "c2_gauss16_shared_pool", "discrete", "bubble", "singular2_composite"])
-def test_train_matches_oracle(oracle, name):
+def test_train_matches_oracle(oracle, name, walk, monkeypatch):
     """rows a9/a10: smooth -> rescale -> refine (variable.jl:206-239), Discrete (:369-382)."""
+    monkeypatch.setenv("MCI_TRAIN_SERIAL", "1" if walk == "serial" else "0")
     c, cfg, eng, ocfg = make(name, oracle)
     block, npb = 8, 4000
     eng.run("vegas", npb, 0, block, 0, SEED)
@@ -154,20 +156,27 @@ def test_train_matches_oracle(oracle, name):
             np.testing.assert_allclose(a, ocfg.accumulation(i), rtol=1e-11)
 
 
+@pytest.mark.parametrize("walk", ["serial", "prefix"])
 @pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "bubble", "c2_gauss4_composite"])
-def test_full_integrate_matches_oracle(oracle, name):
-    """rows a13-a15: the whole loop inside the library (mci_integrate) vs the oracle's loop, same seed."""
+def test_full_integrate_matches_oracle(oracle, name, walk, monkeypatch):
+    """rows a13-a15: the whole loop inside the library (mci_integrate) vs the oracle's loop, same seed.
+
+    The adaptation loop grid -> histogram -> grid amplifies rounding-level differences by ~1-2 orders of
+    magnitude per train! step (measured: 1 ulp of device pow/log becomes 1e-6 after six steps), so the run-level
+    tolerance depends on how the refinement walk rounds: `serial` = the reference's recurrence order
+    (variable.jl:227-234; MCI_TRAIN_SERIAL=1), `prefix` = the default scan + bisection form (one train! step of
+    either agrees with the oracle to 1e-12 of the range, test_train_matches_oracle)."""
+    monkeypatch.setenv("MCI_TRAIN_SERIAL", "1" if walk == "serial" else "0")
+    rtol, sig = (1e-6, 1e-3) if walk == "serial" else (1e-4, 5e-2)
     c, cfg, eng, ocfg = make(name, oracle)
     r = eng.integrate("vegas", neval=40000, niter=6, block=16, seed=SEED)
     o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=40000, niter=6, block=16, seed=SEED)
-    # six train! steps amplify libm-ulp differences in the grids (device pow/log vs glibc); the
-    # difference stays >= 4 orders of magnitude below the MC error of these runs
-    np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6, atol=1e-300)
-    np.testing.assert_allclose(r["iter_std"], o["iter_std"], rtol=1e-4, atol=1e-300)
-    np.testing.assert_allclose(r["mean"], o["mean"], rtol=1e-6)
-    np.testing.assert_allclose(r["stdev"], o["stdev"], rtol=1e-4)
-    np.testing.assert_allclose(r["chi2"], o["chi2"], rtol=1e-3, atol=1e-9)
-    assert np.all(np.abs(r["mean"] - o["mean"]) < 1e-3 * o["stdev"])
+    np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=rtol, atol=1e-300)
+    np.testing.assert_allclose(r["iter_std"], o["iter_std"], rtol=100 * rtol, atol=1e-300)
+    np.testing.assert_allclose(r["mean"], o["mean"], rtol=rtol)
+    np.testing.assert_allclose(r["stdev"], o["stdev"], rtol=100 * rtol)
+    np.testing.assert_allclose(r["chi2"], o["chi2"], rtol=1000 * rtol, atol=1e-9)
+    assert np.all(np.abs(r["mean"] - o["mean"]) < sig * o["stdev"])
 
 
 @pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "bubble", "discrete2_composite"])
@@ -219,8 +228,10 @@ def test_launch_geometry_independence(oracle):
 def test_table_modes_agree(monkeypatch):
     """LDS-resident tables (mode 0), LDS grids + global f64 atomics (1), everything from L2 (2)."""
     outs = []
-    for mode in ("0", "1", "2"):
+    for mode, tile_bins in (("0", None), ("1", None), ("2", None), ("3", None), ("3", "1000"), ("3", "2000")):
         monkeypatch.setenv("MCI_TABLE_MODE", mode)
+        if tile_bins:
+            monkeypatch.setenv("MCI_HIST_TILE_BINS", tile_bins)  # force 3 / 2 histogram tiles
         cfg = mci.Configuration(var=mci.Continuous([(0.0, PI)] * 3), dof=[[1]], seed=SEED)
         eng = mci.Engine(cfg, mci.catalog.singular2())
         assert eng.table_mode == int(mode)
@@ -228,8 +239,8 @@ def test_table_modes_agree(monkeypatch):
         eng.run("vegas", 8000, 0, 4, 1, SEED)  # second launch: global histogram was reset by the merge
         second = eng.get_packed()
         assert np.all(np.isfinite(second))
-    np.testing.assert_allclose(outs[1], outs[0], rtol=1e-10)
-    np.testing.assert_allclose(outs[2], outs[0], rtol=1e-10)
+    for o in outs[1:]:
+        np.testing.assert_allclose(o, outs[0], rtol=1e-10)
 
 
 def test_error_paths():
@@ -247,7 +258,7 @@ def test_c4_genz32_runs_in_l2_table_mode_and_matches_oracle(oracle):
     ud = genz_userdata(32)
     cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
     eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32))
-    assert eng.table_mode == 2
+    assert eng.table_mode == 3  # histograms in LDS (2 tiles of 16 grids), edges gathered from L2
     ocfg = oracle.Config([ocont(0) for _ in range(32)], [[1]])
     got = eng.iteration("vegas", 2000, 0, 4, iteration=0, seed=SEED)
     ref = ocfg.iteration(oracle.VEGAS, "genz_product_peak", ud, 2000, 0, 4, 0, SEED)

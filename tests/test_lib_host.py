@@ -51,7 +51,8 @@ def test_offline_jit_and_problem_info():
     np.testing.assert_allclose(d, 0.25)
     np.testing.assert_allclose(a, [0, 0.25, 0.5, 0.75, 1.0])
     big = mci.Engine(mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]]), mci.catalog.genz_product_peak(32), device=-1)
-    assert big.table_mode == 2 and big.ndraw == 32  # 32 grids = 256 KB of edges: beyond 160 KB LDS
+    # 32 grids = 256 KB of edges + 256 KB of histograms: histograms in LDS (two tiles), edges from L2
+    assert big.table_mode == 3 and big.ndraw == 32 and big.lds_bytes <= 160 * 1024
 
 
 def test_bad_integrand_source_reports_compile_error():

@@ -2,7 +2,7 @@
  * mci.h -- C ABI of the MI355X-native VEGAS / VegasMC sampling engine (libmci_hip.so).
  *
  * This is the drop-in boundary for ONE path of numericalEFT/MCIntegration.jl (v0.4.2): the
- * per-iteration sample batch behind `integrate(...; solver=:vegas|:vegasmc)`.  The reference has no
+ * per-iteration sample batch behind `integrate(...; solver=:vegas|:vegasmc|:mcmc)`.  The reference has no
  * FFI of its own; the seam this library replaces is the solver dispatch inside `_block!`
  * (reference src/main.jl:253-264) together with the iteration loop around it
  * (src/main.jl:142-207).  Every entry point below names the reference code it stands in for.
@@ -33,7 +33,7 @@ extern "C" {
 #define MCI_ERR_NO_DEVICE 7     /* no HIP device: the product path never falls back to the CPU */
 
 enum { MCI_CONTINUOUS = 0, MCI_DISCRETE = 1 }; /* Dist.Continuous variable.jl:87-99 / Dist.Discrete :272-284 */
-enum { MCI_VEGAS = 0, MCI_VEGASMC = 1 };       /* solver=:vegas main.jl:256 / :vegasmc main.jl:253 */
+enum { MCI_VEGAS = 0, MCI_VEGASMC = 1, MCI_MCMC = 2 }; /* solver=:vegas main.jl:256 / :vegasmc :253 / :mcmc :259 */
 
 typedef struct mci_ctx mci_ctx;
 typedef struct mci_problem mci_problem;
@@ -62,11 +62,16 @@ typedef struct {
     const int32_t *obs_bin_draw; /* [nintegrand] or NULL(=-1): flat draw index of the Discrete draw that selects the
                                     bin of observable i -- the `measure` of example/bubble.jl:81-84; -1 = default
                                     measure (vegas/montecarlo.jl:151-153) */
+    /* `neighbor` kwarg (configuration.jl:201-227), used by solver=:mcmc: CSR lists of 0-based integrand indices,
+       index nintegrand = the normalisation integrand.  neighbor_offsets[nintegrand+2]; both NULL = the default
+       chain 1-2-...-N with the normalisation attached to the first integrand (configuration.jl:203-208). */
+    const int32_t *neighbor_offsets;
+    const int32_t *neighbor_list;
 } mci_problem_desc;
 
 /* `integrate` keyword arguments (main.jl:71-90). */
 typedef struct {
-    int32_t solver;      /* MCI_VEGAS | MCI_VEGASMC */
+    int32_t solver;      /* MCI_VEGAS | MCI_VEGASMC | MCI_MCMC */
     int64_t neval;       /* evaluations per iteration (summed over all ranks) */
     int32_t niter;
     int64_t block;       /* statistical blocks per iteration, all ranks (standardised like main.jl:220-234) */
@@ -75,8 +80,10 @@ typedef struct {
     double gamma;        /* reweight learning rate (vegasmc) */
     int64_t measurefreq;
     uint64_t seed;
-    int64_t nchain;      /* vegasmc: independent chains per block (1 = the reference's single chain); 0 = auto */
+    int64_t nchain;      /* vegasmc, mcmc: independent chains per block (1 = the reference's single chain); 0 = auto */
     int32_t first_iteration; /* RNG stream offset so that a resumed run (config=res.config) draws fresh numbers */
+    double thermal_ratio;    /* mcmc: burn-in steps = floor(steps * thermal_ratio), mcmc/montecarlo.jl:77,:133 (default 0.1) */
+    const double *reweight_goal; /* [nintegrand+1] or NULL: main.jl:81, :334-337 */
 } mci_integrate_args;
 
 /* `Result` (statistics.jl:16-63).  All arrays are caller-allocated. */
@@ -114,7 +121,8 @@ int mci_problem_destroy(mci_problem *prob);
  *     const double* ud -- userdata (configuration.jl:113)
  * JIT-compiled with hiprtc for gfx950 together with the hand-written kernels. */
 int mci_set_integrand_source(mci_problem *prob, const char *body, const double *userdata, int32_t nuserdata);
-int mci_compile(mci_problem *prob);          /* JIT or kernel-cache load; implicit on first run */
+int mci_compile(mci_problem *prob);          /* JIT or kernel-cache load of the vegas kernel; implicit on first run */
+int mci_compile_solver(mci_problem *prob, int32_t solver); /* same for one solver's kernel (one code object each) */
 int mci_set_launch(mci_problem *prob, int32_t threads_per_workgroup, int32_t workgroups_per_block);
 int mci_problem_info(const mci_problem *prob, int32_t *ndraw, int32_t *nobs, int64_t *packed_size,
                      int32_t *table_mode, int64_t *lds_bytes);
@@ -123,7 +131,8 @@ int mci_problem_info(const mci_problem *prob, int32_t *ndraw, int32_t *nobs, int
 /* blocks [block_lo, block_hi) of `_block!` (main.jl:236-292) on this GPU; leaves the local packed buffer
  * [obsSum(nobs) | obsSqSum(nobs) | normalization | neval | visited(N+1) | histograms] on the device */
 int mci_iteration_run(mci_problem *prob, int32_t solver, int64_t neval_per_block, int64_t block_lo,
-                      int64_t block_hi, int32_t iteration, uint64_t seed, int64_t measurefreq, int64_t nchain);
+                      int64_t block_hi, int32_t iteration, uint64_t seed, int64_t measurefreq, int64_t nchain,
+                      double thermal_ratio);
 /* sum the packed buffer over ranks: MPIreduceConfig!+MPIbcastConfig! (configuration.jl:264-321) as ONE
  * ncclAllReduce; no-op without a communicator */
 int mci_iteration_reduce(mci_problem *prob);
@@ -148,6 +157,7 @@ int mci_get_distribution(mci_problem *prob, int32_t leaf, double *distribution, 
 int mci_set_distribution(mci_problem *prob, int32_t leaf, const double *distribution, int32_t k);
 int mci_get_reweight(mci_problem *prob, double *out, int32_t n);
 int mci_set_reweight(mci_problem *prob, const double *in, int32_t n);
+int mci_set_reweight_goal(mci_problem *prob, const double *goal, int32_t n); /* main.jl:81; NULL/0 clears */
 /* Dist.train! on the histograms currently in the packed buffer (variable.jl:206-239, :369-382) */
 int mci_train(mci_problem *prob);
 /* the adaptive map alone (sampler.jl:293-305, :13-22) + integrand: first `n` samples of block `block_index`
@@ -165,6 +175,9 @@ void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64
  * (vegas_mc/montecarlo.jl:213) for its single chain (nchain = 1); with nchain > 1 independent chains per block
  * additionally >= min(steps/2, 32*nslots) so that each short chain forgets its start (nslots = sum of maxdof) */
 double mci_chain_burnin(int64_t steps, int64_t nchain, int32_t nslots);
+/* burn-in steps an MCMC chain runs before its `steps` measured ones: floor(steps*thermal_ratio)
+ * (mcmc/montecarlo.jl:133); with nchain > 1 at least min(steps/2, 64*nslots + 16*(npool+1)*nd) */
+int64_t mci_mcmc_burnin(int64_t steps, int64_t nchain, int32_t nslots, int32_t nd, int32_t npool, double thermal_ratio);
 void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out);        /* configuration.jl:229-236 */
 void mci_mean_std(const double *obs_sum, const double *obs_sq, int64_t n, int64_t block, double *mean,
                   double *std);                                                      /* main.jl:296-320 */

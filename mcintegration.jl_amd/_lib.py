@@ -9,8 +9,8 @@ _SO = os.path.join(_PKG, "lib", "libmci_hip.so")
 MCI_OK = 0
 ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "COMPILE", 4: "NORMALIZATION", 5: "HISTOGRAM", 6: "COMM", 7: "NO_DEVICE"}
 CONTINUOUS, DISCRETE = 0, 1
-VEGAS, VEGASMC = 0, 1
-SOLVERS = {"vegas": VEGAS, "vegasmc": VEGASMC, VEGAS: VEGAS, VEGASMC: VEGASMC}
+VEGAS, VEGASMC, MCMC = 0, 1, 2
+SOLVERS = {"vegas": VEGAS, "vegasmc": VEGASMC, "mcmc": MCMC, VEGAS: VEGAS, VEGASMC: VEGASMC, MCMC: MCMC}
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -29,13 +29,15 @@ class LeafDesc(C.Structure):
 
 class ProblemDesc(C.Structure):
     _fields_ = [("nleaf", C.c_int32), ("leaves", C.POINTER(LeafDesc)), ("npool", C.c_int32),
-                ("nintegrand", C.c_int32), ("dof", c_int32_p), ("obs_nbin", c_int32_p), ("obs_bin_draw", c_int32_p)]
+                ("nintegrand", C.c_int32), ("dof", c_int32_p), ("obs_nbin", c_int32_p), ("obs_bin_draw", c_int32_p),
+                ("neighbor_offsets", c_int32_p), ("neighbor_list", c_int32_p)]
 
 
 class IntegrateArgs(C.Structure):
     _fields_ = [("solver", C.c_int32), ("neval", C.c_int64), ("niter", C.c_int32), ("block", C.c_int64),
                 ("ignore", C.c_int32), ("adapt", C.c_int32), ("gamma", C.c_double), ("measurefreq", C.c_int64),
-                ("seed", C.c_uint64), ("nchain", C.c_int64), ("first_iteration", C.c_int32)]
+                ("seed", C.c_uint64), ("nchain", C.c_int64), ("first_iteration", C.c_int32),
+                ("thermal_ratio", C.c_double), ("reweight_goal", c_double_p)]
 
 
 class ResultC(C.Structure):
@@ -59,9 +61,10 @@ SIGNATURES = [
     ("mci_problem_destroy", C.c_int, [_VP]),
     ("mci_set_integrand_source", C.c_int, [_VP, C.c_char_p, c_double_p, C.c_int32]),
     ("mci_compile", C.c_int, [_VP]),
+    ("mci_compile_solver", C.c_int, [_VP, C.c_int32]),
     ("mci_set_launch", C.c_int, [_VP, C.c_int32, C.c_int32]),
     ("mci_problem_info", C.c_int, [_VP, c_int32_p, c_int32_p, C.POINTER(C.c_int64), c_int32_p, C.POINTER(C.c_int64)]),
-    ("mci_iteration_run", C.c_int, [_VP, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, C.c_int64]),
+    ("mci_iteration_run", C.c_int, [_VP, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_double]),
     ("mci_iteration_reduce", C.c_int, [_VP]),
     ("mci_iteration_finish", C.c_int, [_VP, C.c_int32, C.c_int64, C.c_int32, C.c_double, c_double_p, c_double_p]),
     ("mci_integrate", C.c_int, [_VP, C.POINTER(IntegrateArgs), C.POINTER(ResultC)]),
@@ -75,11 +78,13 @@ SIGNATURES = [
     ("mci_set_distribution", C.c_int, [_VP, C.c_int32, c_double_p, C.c_int32]),
     ("mci_get_reweight", C.c_int, [_VP, c_double_p, C.c_int32]),
     ("mci_set_reweight", C.c_int, [_VP, c_double_p, C.c_int32]),
+    ("mci_set_reweight_goal", C.c_int, [_VP, c_double_p, C.c_int32]),
     ("mci_train", C.c_int, [_VP]),
     ("mci_sample_dump", C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
     ("mci_kernel_times_ms", C.c_int, [_VP, C.POINTER(C.c_float), C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
     ("mci_standardize_block", None, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("mci_chain_burnin", C.c_double, [C.c_int64, C.c_int64, C.c_int32]),
+    ("mci_mcmc_burnin", C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
     ("mci_maxdof", None, [c_int32_p, C.c_int32, C.c_int32, c_int32_p]),
     ("mci_mean_std", None, [c_double_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p]),
     ("mci_average", None, [c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),

@@ -78,6 +78,37 @@ class Configuration:
                 self.leaves.append(leaf)
                 self.leaf_pool.append(vi)
 
+    def neighbor_lists(self):
+        """`neighbor` kwarg normalised like _neighbor (configuration.jl:201-227) to 0-based lists per integrand
+        (index N = normalisation); None = the default chain, built by the library."""
+        nb = self.neighbor
+        if nb is None:
+            return None
+        Nd = self.N + 1
+        nb = list(nb)
+        if nb and all(isinstance(e, tuple) and len(e) == 2 and all(isinstance(q, (int, np.integer)) for q in e) for e in nb):
+            # Vector{Tuple{Int,Int}}: undirected 1-based edges (:213-221); neighbors(g, v) come back sorted
+            adj = [set() for _ in range(Nd)]
+            for a, b in nb:
+                assert 1 <= a <= Nd and 1 <= b <= Nd, "neighbor edge (%d, %d) out of range" % (a, b)
+                adj[a - 1].add(b - 1)
+                adj[b - 1].add(a - 1)
+            seen, stack = {0}, [0]
+            while stack:
+                for j in adj[stack.pop()]:
+                    if j not in seen:
+                        seen.add(j)
+                        stack.append(j)
+            assert len(seen) == Nd, "The neighbor graph is not connected."     # :220
+            return [sorted(a) for a in adj]
+        assert len(nb) == Nd, "%d elements are expected for neighbor=%s" % (Nd, nb)   # :226
+        out = []
+        for lst in nb:                                                       # Vector{Vector{Int}}, 1-based
+            lst = [int(j) - 1 for j in lst]
+            assert lst and all(0 <= j < Nd for j in lst)
+            out.append(lst)
+        return out
+
     # ---- derived layout -----------------------------------------------------------------------
     def draw_index(self, pool, slot=0, leaf=0):
         """flat position of (pool, slot, leaf) in the integrand's x[] (draw order: pool, slot, leaf)"""

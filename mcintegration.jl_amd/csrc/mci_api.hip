@@ -105,9 +105,13 @@ struct mci_problem {
     mci::LeafDev *d_leaves = nullptr;
     int64_t cap_wg = 0, cap_blocks = 0, cap_iter = 0, cap_dump = 0;
     // kernels
-    hipModule_t module = nullptr;
-    hipFunction_t f_vegas = nullptr, f_vegasmc = nullptr, f_dump = nullptr;
-    bool compiled = false;
+    // one code object per solver, JIT-compiled (or loaded from the kernel cache) the first time the solver runs;
+    // the vegas module also holds the sample-dump kernel
+    hipModule_t module[3] = {nullptr, nullptr, nullptr};
+    hipFunction_t f_solver[3] = {nullptr, nullptr, nullptr}, f_dump = nullptr;
+    bool compiled[3] = {false, false, false};
+    std::vector<double> h_goal; // reweight_goal (main.jl:81); empty = none
+    double *d_goal = nullptr;
     int threads = 256, wg_per_block = 0; // 0 = auto
     int train_serial = 0; // MCI_TRAIN_SERIAL=1: refinement walk as the reference's serial recurrence (diagnostic)
     // last launch
@@ -163,10 +167,21 @@ int check_status(mci_problem *p) {
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     if (!st) return MCI_OK;
     HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int), p->ctx->stream));
+    if (st & mci::ST_MCMC_INIT) return fail(MCI_ERR_INVALID, "Cannot find the variables that makes the integrand nonzero!"); // mcmc/montecarlo.jl:126
     if (st & mci::ST_NORMALIZATION) return fail(MCI_ERR_NORMALIZATION, "Block normalization is not positively defined!");
     if (st & mci::ST_HIST_NONFINITE) return fail(MCI_ERR_HISTOGRAM, "histogram should be all finite");
     if (st & mci::ST_HIST_NONPOSITIVE) return fail(MCI_ERR_HISTOGRAM, "histogram should be all positive and non-zero");
     return fail(MCI_ERR_HISTOGRAM, "distribution is not all finite");
+}
+
+void drop_modules(mci_problem *p) {
+    for (int k = 0; k < 3; ++k) {
+        p->compiled[k] = false;
+        if (p->module[k]) {
+            (void)hipModuleUnload(p->module[k]);
+            p->module[k] = nullptr;
+        }
+    }
 }
 
 } // namespace
@@ -360,6 +375,34 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
                 s.own_mask[i] |= 1ull << k;
                 s.cover_mask[k] |= 1ull << i;
             }
+    s.dof = p->dof;
+    { // neighbor graph of the integrands (mcmc): configuration.jl:201-227, 0-based, index ni = normalisation
+        std::vector<std::vector<int>> nb(Nd);
+        if (d->neighbor_offsets && d->neighbor_list) {
+            for (int i = 0; i < Nd; ++i) {
+                const int b = d->neighbor_offsets[i], e = d->neighbor_offsets[i + 1];
+                if (e <= b) { delete p; return fail(MCI_ERR_INVALID, "%d elements are expected for neighbor", Nd); } // :226
+                for (int j = b; j < e; ++j) {
+                    if (d->neighbor_list[j] < 0 || d->neighbor_list[j] >= Nd) { delete p; return fail(MCI_ERR_INVALID, "neighbor %d of integrand %d out of range", d->neighbor_list[j], i); }
+                    nb[i].push_back(d->neighbor_list[j]);
+                }
+            }
+        } else { // :203-208
+            for (int i = 0; i < Nd; ++i) nb[i] = {i - 1, i + 1};
+            if (Nd == 2) nb[0] = {1};
+            else nb[0] = {Nd - 1, 1};
+            nb[Nd - 1] = {0};
+            if (Nd >= 3) nb[Nd - 2] = {Nd - 3};
+        }
+        s.nbmax = 1;
+        for (auto &v : nb) s.nbmax = (int)v.size() > s.nbmax ? (int)v.size() : s.nbmax;
+        s.nneighbor.clear();
+        s.neighbor.assign((size_t)Nd * s.nbmax, 0);
+        for (int i = 0; i < Nd; ++i) {
+            s.nneighbor.push_back((int)nb[i].size());
+            for (int j = 0; j < s.nbmax; ++j) s.neighbor[(size_t)i * s.nbmax + j] = j < (int)nb[i].size() ? nb[i][j] : i;
+        }
+    }
     s.nobs = 0;
     for (int i = 0; i < p->ni; ++i) {
         const int nb = d->obs_nbin ? d->obs_nbin[i] : 1;
@@ -372,7 +415,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         s.obs_bin_draw.push_back(bd);
         s.nobs += nb;
     }
-    s.ncols = s.nobs + 2 + Nd + 2 * p->npool;
+    s.ncols = s.nobs + 2 + Nd + 2 * (p->npool > 3 ? p->npool : 3); // propose/accept: per pool (vegasmc) or per update type (mcmc)
     s.nedge = eoff;
     s.ndacc = aoff;
     s.nddist = doff;
@@ -480,7 +523,9 @@ int mci_problem_destroy(mci_problem *p) {
                         (void *)p->d_packed, (void *)p->d_scratch, (void *)p->d_iterlog, (void *)p->d_dump,
                         (void *)p->d_status, (void *)p->d_leaves})
             if (q) hipFree(q);
-        if (p->module) hipModuleUnload(p->module);
+        for (int k = 0; k < 3; ++k)
+            if (p->module[k]) (void)hipModuleUnload(p->module[k]);
+        if (p->d_goal) (void)hipFree(p->d_goal);
         for (auto &e : p->evs) (void)hipEventDestroy(e);
     }
     delete p;
@@ -491,11 +536,7 @@ int mci_set_integrand_source(mci_problem *p, const char *body, const double *ud,
     if (!p || !body) return fail(MCI_ERR_INVALID, "NULL argument");
     p->shape.body = body;
     p->h_ud.assign(ud, ud + (nud > 0 ? nud : 0));
-    p->compiled = false;
-    if (p->module) {
-        hipModuleUnload(p->module);
-        p->module = nullptr;
-    }
+    drop_modules(p);
     if (!p->ctx->offline) {
         if (p->d_ud) hipFree(p->d_ud);
         p->d_ud = nullptr;
@@ -510,37 +551,40 @@ int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
         if (threads % 64 || threads > 1024) return fail(MCI_ERR_INVALID, "threads per workgroup must be a multiple of 64, <= 1024");
         if (threads != p->threads) {
             p->threads = threads;
-            p->compiled = false;
-            if (p->module) { hipModuleUnload(p->module); p->module = nullptr; }
+            drop_modules(p);
         }
     }
     if (wg_per_block >= 0) p->wg_per_block = wg_per_block;
     return MCI_OK;
 }
 
-int mci_compile(mci_problem *p) {
-    if (p->compiled) return MCI_OK;
-    const std::string src = mcijit::generate_source(p->shape);
+static int compile_solver(mci_problem *p, int solver) {
+    if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver); // main.jl:263
+    if (p->compiled[solver]) return MCI_OK;
+    const std::string src = mcijit::generate_source(p->shape, solver);
     std::vector<char> code;
     std::string log;
     bool cached = false;
     int rc = mcijit::compile(src, p->threads, code, log, cached);
     if (rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
     if (!p->ctx->offline) {
+        static const char *const names[3] = {"mci_vegas_batch", "mci_vegasmc_chains", "mci_mcmc_chains"};
         HIPCHK(hipSetDevice(p->ctx->device));
-        HIPCHK(hipModuleLoadData(&p->module, code.data()));
-        HIPCHK(hipModuleGetFunction(&p->f_vegas, p->module, "mci_vegas_batch"));
-        HIPCHK(hipModuleGetFunction(&p->f_vegasmc, p->module, "mci_vegasmc_chains"));
-        HIPCHK(hipModuleGetFunction(&p->f_dump, p->module, "mci_sample_dump"));
+        HIPCHK(hipModuleLoadData(&p->module[solver], code.data()));
+        HIPCHK(hipModuleGetFunction(&p->f_solver[solver], p->module[solver], names[solver]));
+        if (solver == MCI_VEGAS) HIPCHK(hipModuleGetFunction(&p->f_dump, p->module[solver], "mci_sample_dump"));
         if (p->lds_bytes > 64 * 1024) {
-            HIPCHK(hipFuncSetAttribute((const void *)p->f_vegas, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
-            HIPCHK(hipFuncSetAttribute((const void *)p->f_vegasmc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
-            HIPCHK(hipFuncSetAttribute((const void *)p->f_dump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+            HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+            if (solver == MCI_VEGAS)
+                HIPCHK(hipFuncSetAttribute((const void *)p->f_dump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
         }
     }
-    p->compiled = true;
+    p->compiled[solver] = true;
     return MCI_OK;
 }
+
+int mci_compile(mci_problem *p) { return compile_solver(p, MCI_VEGAS); }
+int mci_compile_solver(mci_problem *p, int32_t solver) { return compile_solver(p, solver); }
 
 int mci_problem_info(const mci_problem *p, int32_t *ndraw, int32_t *nobs, int64_t *packed_size, int32_t *table_mode, int64_t *lds_bytes) {
     if (ndraw) *ndraw = p->shape.ndraw;
@@ -555,18 +599,20 @@ int mci_problem_info(const mci_problem *p, int32_t *ndraw, int32_t *nobs, int64_
 // one iteration
 // ---------------------------------------------------------------------------------------------------
 int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int64_t block_lo, int64_t block_hi,
-                      int32_t iteration, uint64_t seed, int64_t measurefreq, int64_t nchain) {
+                      int32_t iteration, uint64_t seed, int64_t measurefreq, int64_t nchain, double thermal_ratio) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context: no device to run on");
+    if (solver != MCI_VEGAS && solver != MCI_VEGASMC && solver != MCI_MCMC) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver); // main.jl:263
     if (measurefreq <= 0) return fail(MCI_ERR_INVALID, "measurefreq must be positive"); // vegas/montecarlo.jl:77
     const int64_t nblocks = block_hi - block_lo;
     if (nblocks < 1 || nevalperblock < 1) return fail(MCI_ERR_INVALID, "empty iteration");
-    int rc = mci_compile(p);
+    int rc = compile_solver(p, solver);
     if (rc) return rc;
     HIPCHK(hipSetDevice(p->ctx->device));
     const auto &s = p->shape;
     const int T = p->threads;
     int64_t units = nevalperblock; // lanes of useful work per block
     double burnin = 0.0;
+    int64_t nburn = 0;
     if (solver == MCI_VEGASMC) {
         int nslots = 0; // (pool, slot) pairs changeVariable can pick (updates.jl:50,:58)
         for (int v = 0; v < p->npool; ++v) nslots += p->maxdof[v];
@@ -578,6 +624,20 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         }
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
         burnin = mci_chain_burnin(nevalperblock / nchain, nchain, nslots);
+        units = nchain;
+    } else if (solver == MCI_MCMC) {
+        int nslots = 0;
+        for (int v = 0; v < p->npool; ++v) nslots += p->maxdof[v];
+        if (!(thermal_ratio >= 0.0)) return fail(MCI_ERR_INVALID, "thermal_ratio must be non-negative");
+        if (nchain <= 0) { // auto: chains long enough that the burn-in floor costs <= 1/8 on top of the measured steps
+            const int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(p->npool + 1) * (p->ni + 1);
+            const int64_t target = 8 * fl > 2048 ? 8 * fl : 2048;
+            nchain = nevalperblock / target;
+            if (nchain < 1) nchain = 1;
+            if (nchain > 16384) nchain = 16384;
+        }
+        if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
+        nburn = mci_mcmc_burnin(nevalperblock / nchain, nchain, nslots, p->ni + 1, p->npool, thermal_ratio);
         units = nchain;
     } else {
         nchain = 1;
@@ -611,8 +671,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.measurefreq = measurefreq;
     a.nchain = nchain;
     a.burnin = burnin;
+    a.nburn = nburn;
+    a.status = p->d_status;
     void *args[] = {&a};
-    hipFunction_t f = solver == MCI_VEGASMC ? p->f_vegasmc : p->f_vegas;
+    hipFunction_t f = p->f_solver[solver];
     hipStream_t st = p->ctx->stream;
     const int slot = (int)(p->launches % mci_problem::kEvRing);
     HIPCHK(hipEventRecord(p->evs[2 * slot], st));
@@ -648,7 +710,7 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     for (auto &L : p->leaves) maxn = L.nbin > maxn ? L.nbin : maxn;
     const size_t sm = (size_t)(4 * maxn + 16) * sizeof(double); // d[N+4] | sg[N+1] | wa[N+1] | wj[N+1] (k_train)
     hipLaunchKernelGGL(mci::k_train, dim3(s.nleaf + 1), dim3(256), sm, p->ctx->stream, p->d_leaves, s.nleaf, p->d_packed, p->nstat,
-                       p->d_edges, p->d_dacc, p->d_ddist, log_row, p->d_reweight, s.ni + 1, do_reweight, gamma, do_train, p->train_serial, p->d_status);
+                       p->d_edges, p->d_dacc, p->d_ddist, log_row, p->d_reweight, p->h_goal.empty() ? nullptr : p->d_goal, s.ni + 1, do_reweight, gamma, do_train, p->train_serial, p->d_status);
     HIPCHK(hipGetLastError());
     return MCI_OK;
 }
@@ -671,7 +733,7 @@ int mci_iteration_finish(mci_problem *p, int32_t solver, int64_t block_total, in
     }
     double *row = p->d_iterlog + (size_t)p->log_row * p->nstat;
     // reweight is adapted only together with the grid (main.jl:183 runs it unconditionally for the chain solvers)
-    int rc = launch_train(p, adapt ? 1 : 0, solver == MCI_VEGASMC ? 1 : 0, gamma, row);
+    int rc = launch_train(p, adapt ? 1 : 0, (solver == MCI_VEGASMC || solver == MCI_MCMC) ? 1 : 0, gamma, row);
     if (rc) return rc;
     p->log_row += 1;
     if (mean || std) {
@@ -704,14 +766,15 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     mci_standardize_block(a->neval, a->block, p->ctx->nranks, &nevalperblock, &block); // main.jl:121
     const int64_t per = block / p->ctx->nranks;                                         // main.jl:122
     const int64_t lo = per * p->ctx->rank, hi = lo + per;
-    int rc = mci_compile(p);
+    int rc = compile_solver(p, a->solver);
     if (rc) return rc;
+    if ((rc = mci_set_reweight_goal(p, a->reweight_goal, a->reweight_goal ? p->ni + 1 : 0))) return rc;
     const int ignore = a->ignore >= 0 ? a->ignore : (a->adapt ? 1 : 0);
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     const int row0 = p->log_row;
     auto t0 = std::chrono::steady_clock::now();
     for (int it = 0; it < a->niter; ++it) { // main.jl:142
-        if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, a->first_iteration + it, a->seed, a->measurefreq, a->nchain))) return rc;
+        if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, a->first_iteration + it, a->seed, a->measurefreq, a->nchain, a->thermal_ratio))) return rc;
         if ((rc = mci_iteration_reduce(p))) return rc;                                   // main.jl:177-188
         if ((rc = mci_iteration_finish(p, a->solver, block, a->adapt, a->gamma, nullptr, nullptr))) return rc; // main.jl:183-199
     }
@@ -849,6 +912,20 @@ int mci_set_reweight(mci_problem *p, const double *in, int32_t n) {
     return MCI_OK;
 }
 
+int mci_set_reweight_goal(mci_problem *p, const double *goal, int32_t n) {
+    if (!goal || n == 0) {
+        p->h_goal.clear();
+        return MCI_OK;
+    }
+    if (n != p->ni + 1) return fail(MCI_ERR_INVALID, "reweight_goal has %d entries", p->ni + 1);
+    p->h_goal.assign(goal, goal + n);
+    if (p->ctx->offline) return MCI_OK;
+    if (!p->d_goal) HIPCHK(hipMalloc((void **)&p->d_goal, (size_t)n * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(p->d_goal, p->h_goal.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    return MCI_OK;
+}
+
 int mci_sample_dump(mci_problem *p, int32_t iteration, uint64_t seed, int64_t nevalperblock, int64_t block_index, int64_t n,
                     double *x, double *jac, double *w) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
@@ -922,6 +999,16 @@ double mci_chain_burnin(int64_t steps, int64_t nchain, int32_t nslots) {
         if (fl > thr) thr = fl;
     }
     return thr;
+}
+
+int64_t mci_mcmc_burnin(int64_t steps, int64_t nchain, int32_t nslots, int32_t nd, int32_t npool, double thermal_ratio) {
+    int64_t nburn = (int64_t)floor((double)steps * thermal_ratio); // mcmc/montecarlo.jl:133
+    if (nchain > 1) { // many short chains: every chain must forget its start (DESIGN.md "chains")
+        int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(npool + 1) * nd;
+        if (fl > steps / 2) fl = steps / 2;
+        if (fl > nburn) nburn = fl;
+    }
+    return nburn;
 }
 
 void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out) {

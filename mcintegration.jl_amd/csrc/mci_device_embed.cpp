@@ -13,6 +13,7 @@ R"MCIDEV(// mci_device.h -- hand-written gfx950 (CDNA4, wave64) kernels of the V
 //   padding         distribution/variable.jl:628-641
 //   accumulate!     distribution/variable.jl:196-200, :362-367, :474-478
 //   chains          vegas_mc/montecarlo.jl:151-232, vegas_mc/updates.jl:45-106
+//   mcmc chains     mcmc/montecarlo.jl:72-184, mcmc/updates.jl:1-147
 //
 // MI355X mapping: one workgroup = one slice of ONE statistical block; the adaptive-grid tables and
 // the per-bin weight histograms live in LDS (ds_read_b64 / ds_add_f64), Philox4x32-10 supplies the
@@ -75,7 +76,8 @@ __device__ __forceinline__ double u01(u32 lo, u32 hi) {
     return __longlong_as_double((i64)bits) - 1.0;
 }
 
-enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3 };
+enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5 };
+enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_RESCALE_NONFINITE = 8, ST_MCMC_INIT = 16 };
 
 // ---------------------------------------------------------------------------------------------
 // kernel arguments (plain struct passed by value)
@@ -97,6 +99,8 @@ struct BatchArgs {
     i64 measurefreq;
     i64 nchain;             // vegasmc: chains per block
     double burnin;          // vegasmc: a chain measures from step `burnin` on (montecarlo.jl:213; DESIGN.md "chains")
+    i64 nburn;              // mcmc: burn-in steps run before the neval/nchain measured ones (mcmc/montecarlo.jl:133)
+    int *status;            // error bits (ST_*)
 };
 
 struct DumpArgs {
@@ -147,13 +151,13 @@ template <class Cfg> struct Tables {
 
 // one leaf draw: create! in its Jacobian form.  Returns x, the bin index (0-based) and `raw` with
 // 1/prob = raw * jac_scale(K): raw = dx for a Continuous leaf (scale N), 1/distribution for a Discrete one.
-// With Cfg::PAIR_TABLE the LDS table holds (g[i], g[i+1]-g[i]) pairs: ONE aligned ds_read_b128 per draw and
+// With Cfg::PAIR_TABLE the LDS table holds (g[i], g[i+1]-g[i]) pairs: ONE aligned ds_read_b128 )MCIDEV"
+R"MCIDEV(per draw and
 // no subtraction on the critical path (the pair is formed with the same rounding when the table is staged).
 template <class Cfg, int K> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
     constexpr int leaf = Cfg::draw_leaf(K);
     if constexpr (Cfg::leaf_kind(leaf) == 0) {
-        // sampler.jl:295-303:  iy = floor(y*N)+1; dy )MCIDEV"
-R"MCIDEV(= y*N-(iy-1); x = g[iy] + dy*(g[iy+1]-g[iy]); prob = 1/(N*dx)
+        // sampler.jl:295-303:  iy = floor(y*N)+1; dy = y*N-(iy-1); x = g[iy] + dy*(g[iy+1]-g[iy]); prob = 1/(N*dx)
         constexpr int N = Cfg::leaf_nbin(leaf);
         const double yn = y * (double)N;
         const int iy = (int)yn;                           // y*N >= 0: trunc == floor
@@ -289,14 +293,16 @@ template <class Cfg> struct Lds {
 };
 
 // partial-statistics columns written per workgroup:
-//   [0, NOBS) observables | NOBS normalization | NOBS+1 neval | NOBS+2 .. +NI+1 visited(N+1) | propose(NPOOL) | accept(NPOOL)
+//   [0, NOBS) observables | NOBS normalization | NOBS+1 neval | NOBS+2 .. +NI+1 visited(N+1) | propose(NPA) | accept(NPA)
+//   NPA = max(NPOOL, 3): per pool for vegasmc (propose[2,1,vi]); per update type for mcmc
 template <class Cfg> struct Cols {
+    static constexpr int NPA = Cfg::NPOOL > 3 ? Cfg::NPOOL : 3;
     static constexpr int NORM = Cfg::NOBS;
     static constexpr int NEVAL = Cfg::NOBS + 1;
     static constexpr int VISITED = Cfg::NOBS + 2;
     static constexpr int PROPOSE = VISITED + Cfg::NI + 1;
-    static constexpr int ACCEPT = PROPOSE + Cfg::NPOOL;
-    static_assert(ACCEPT + Cfg::NPOOL == Cfg::NCOLS, "column layout");
+    static constexpr int ACCEPT = PROPOSE + NPA;
+    static_assert(ACCEPT + NPA == Cfg::NCOLS, "column layout");
 };
 
 // histogram update of one sample: accumulate!(var, pos+offset, weight) for every (integrand i, draw k in own(i))
@@ -306,7 +312,8 @@ template <class Cfg> __device__ __forceinline__ void hist_update(const Sample<Cf
     static_for<0, Cfg::NDRAW>([&](auto K) {
         constexpr int k = decltype(K)::value;
         constexpr int leaf = Cfg::draw_leaf(k);
-        if constexpr (Cfg::leaf_adapt(leaf) != 0 && Cfg::cover_mask(k) != 0ull) { // T.adapt  variable.jl:197,:363
+        if constexpr (Cfg::leaf_adapt(leaf) != 0 &&)MCIDEV"
+R"MCIDEV( Cfg::cover_mask(k) != 0ull) { // T.adapt  variable.jl:197,:363
             double wk = 0.0;
             static_for<0, Cfg::NI>([&](auto I) {
                 constexpr int i = decltype(I)::value;
@@ -316,8 +323,7 @@ template <class Cfg> __device__ __forceinline__ void hist_update(const Sample<Cf
                 constexpr int lt = Cfg::leaf_tile(leaf);
                 if (Cfg::NTILE == 1 || tile == lt) lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + s.bin[k]], wk);
             } else {
-     )MCIDEV"
-R"MCIDEV(           global_add(&gH[Cfg::leaf_boff(leaf) + s.bin[k]], wk);
+                global_add(&gH[Cfg::leaf_boff(leaf) + s.bin[k]], wk);
             }
         }
     });
@@ -429,7 +435,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(B * a.neval_per_block + n), s);
         double w[Cfg::NI];
-        Cfg::integrand(s.x, w, a.ud); // vegas/montecarlo.jl:140-144
+        Cfg::integrand(s.x, w, a.ud, -1); // vegas/montecarlo.jl:140-144
         extra[Cols<Cfg>::NEVAL - Cfg::NOBS] += 1.0; // config.neval += 1   :118
         if (a.measurefreq == 1 || (n + 1) % a.measurefreq == 0) { // :148
             double relw[Cfg::NI];
@@ -473,7 +479,8 @@ template <class Cfg> struct Chain {
 // over the draws outside / inside integrand i's dof; i == NI is the normalisation integrand (dof = 0).
 template <class Cfg, int I> __device__ __forceinline__ double pad_prob(const Chain<Cfg> &c) {
     double p = 1.0;
-    static_for<0, Cfg::NDRAW>([&](auto K) {
+)MCIDEV"
+R"MCIDEV(    static_for<0, Cfg::NDRAW>([&](auto K) {
         constexpr int k = decltype(K)::value;
         if constexpr (!((Cfg::own_mask(I) >> k) & 1ull)) p *= c.prob[k];
     });
@@ -488,8 +495,7 @@ template <class Cfg, int I> __device__ __forceinline__ double own_prob(const Cha
     return p;
 }
 
-template <class Cfg> __device__ __forceinline__ void vegasmc)MCIDEV"
-R"MCIDEV(_chains(const BatchArgs &a) {
+template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NI = Cfg::NI, NORMI = Cfg::NI;
     const int tid = threadIdx.x, T = blockDim.x;
@@ -536,7 +542,7 @@ R"MCIDEV(_chains(const BatchArgs &a) {
             });
         }
         double w[NI], pad[NI + 1];
-        Cfg::integrand(c.x, w, a.ud); // :155-159
+        Cfg::integrand(c.x, w, a.ud, -1); // :155-159
         static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(c); }); // :161
         double probability = rw[NORMI] * pad[NORMI]; // :162
         static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; probability += fabs(w[i]) * rw[i] * pad[i]; }); // :163-166
@@ -589,7 +595,7 @@ R"MCIDEV(_chains(const BatchArgs &a) {
             });
             if (active && prop > 4.9406564584124654e-324) { // :63-65
                 double wn[NI], padn[NI + 1];
-                Cfg::integrand(n.x, wn, a.ud);                 // :67-75
+                Cfg::integrand(n.x, wn, a.ud, -1);             // :67-75
                 extra[XE] += 1.0;                              // config.neval += 1   :77
                 static_for<0, NI + 1>([&](auto I) { padn[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(n); }); // :79-81
                 double newp = rw[NORMI] * padn[NORMI];         // :84
@@ -616,7 +622,8 @@ R"MCIDEV(_chains(const BatchArgs &a) {
                 static_for<0, NI>([&](auto I) {
                     constexpr int i = decltype(I)::value;
                     const double f2 = fabs(w[i]) * fabs(w[i]) / own_prob<Cfg, i>(c); // :203
-                    wh[i] = f2 * pad[i] / probability;                                 // :204
+                    wh[i] = f)MCIDEV"
+R"MCIDEV(2 * pad[i] / probability;                                 // :204
                 });
                 Sample<Cfg> sb;
                 static_for<0, Cfg::NDRAW>([&](auto K) { sb.bin[decltype(K)::value] = c.bin[decltype(K)::value]; });
@@ -626,8 +633,7 @@ R"MCIDEV(_chains(const BatchArgs &a) {
             const bool mf = (a.measurefreq == 1) || (ne % a.measurefreq == 0);
             if (mf && (double)ne >= a.burnin) { // :213
                 double relw[NI];
-             )MCIDEV"
-R"MCIDEV(   static_for<0, NI>([&](auto I) {
+                static_for<0, NI>([&](auto I) {
                     constexpr int i = decltype(I)::value;
                     extra[XV + i] += fabs(w[i] * pad[i] * rw[i]) / probability; // :216
                     relw[i] = w[i] * pad[i] / probability;                      // :218/:220
@@ -637,6 +643,299 @@ R"MCIDEV(   static_for<0, NI>([&](auto I) {
                 measure<Cfg>(sb, relw, acc, sO);
                 extra[XN] += pad[NORMI] / probability;                // :229
                 extra[XV + NORMI] += rw[NORMI] * pad[NORMI] / probability; // :230
+            }
+        }
+    }
+    __syncthreads();
+    flush_workgroup<Cfg>(a, smem, acc, extra, wi.rowid, tile);
+}
+
+// =============================================================================================
+// MCMC: Metropolis chains over (integrand index, live variables), one chain per lane
+// (mcmc/montecarlo.jl:72-184, mcmc/updates.jl:1-147).  The reference runs ONE chain of neval (+ burn-in)
+// steps per block; a block here is `nchain` chains of neval/nchain measured steps, each after its own
+// burn-in (nchain = 1 reproduces the reference's chain).  Only the integrand the chain sits on is
+// evaluated per step (the integrand body sees `idx`); the neighbor graph (configuration.jl:201-227) and
+// the dof table are compile-time, so every register-array access keeps a static index.
+//   chain g = block*nchain + ch
+//   init try t: stream MCMC_INIT, index g*16384 + t,  k = flat draw
+//   step s    : stream MCMC_STEP, index (g<<32 | s),  k = 0 update pick, 1 neighbor/pool pick, 2 slot pick,
+//               3 second slot pick (swap), 4 accept, 5 + flat draw index of a created/shifted draw
+// =============================================================================================
+template <class Cfg, int I> __device__ __forceinline__ double eval_one(const double *x, const double *ud) {
+    double w[Cfg::NI];
+    Cfg::integrand(x, w, ud, I); // the other outputs are dead code after inlining
+    return w[I];
+}
+template <class Cfg> __device__ __forceinline__ double eval_sel(int curr, const double *x, const double *ud) {
+    double r = 0.0;
+    static_for<0, Cfg::NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if (curr == i) r = eval_one<Cfg, i>(x, ud);
+    });
+    return r;
+}
+// uniform k of a chain step; chunk 2 (k = 4, 5) is shared with the accept draw
+template <int K> __device__ __forceinline__ double step_uniform(u64 sidx, u32 stream, u32 k0, u32 k1, const u32x4 &r2) {
+    if constexpr ((K >> 1) == 2) return (K & 1) ? u01(r2.z, r2.w) : u01(r2.x, r2.y);
+    else {
+        const u32x4 r = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(K >> 1), stream, k0, k1);
+        return (K & 1) ? u01(r.z, r.w) : u01(r.x, r.y);
+    }
+}
+// histogram add of one draw with the table-mode dispatch of hist_update
+template <class Cfg, int K> __device__ __forceinline__ void hist_add(int bin, double wk, double *sH, double *gH, int tile) {
+    constexpr int leaf = Cfg::draw_leaf(K);
+    if constexpr (Cfg::leaf_adapt(leaf) != 0) {
+        if constexpr (Mode<Cfg>::HIST_LDS) {
+            constexpr int lt = Cfg::leaf_tile(leaf);
+            if (Cfg::NTILE == 1 || tile == lt) lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + bin], wk);
+        } else {
+            global_add(&gH[Cfg::leaf_boff(leaf) + bin], wk);
+        }
+    }
+}
+
+template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs &a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NI = Cfg::NI, NORMI = Cfg::NI, ND = Cfg::NI + 1, NPOOL = Cfg::NPOOL;
+    constexpr int NUPD = 2 * NPOOL + 2; // [changeIntegrand, swapVariable, changeVariable x 2*Nv]  montecarlo.jl:127-130
+    const int tid = threadIdx.x, T = blockDim.x;
+    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
+    double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
+    stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
+    if constexpr (Mode<Cfg>::HIST_LDS)
+        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
+    for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    __syncthreads();
+    Tables<Cfg> t;
+    if constexpr (Mode<Cfg>::EDGE_LDS) t.E = sE;
+    else t.E = a.edges;
+    t.DA = sDA;
+    t.DD = sDD;
+
+    const WorkItem wi = work_item<Cfg>(a);
+    const int slice = wi.slice, tile = wi.tile;
+    const i64 B = a.block_lo + wi.lb;
+    const i64 steps = a.neval_per_block / a.nchain, nburn = a.nburn;
+    const u32 st_init = a.iteration * 8u + STREAM_MCMC_INIT, st_step = a.iteration * 8u + STREAM_MCMC_STEP;
+    const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
+    double rw[ND];
+    static_for<0, ND>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
+    auto rw_sel = [&](int i) {
+        double r = rw[NORMI];
+        static_for<0, NI>([&](auto I) { if (i == decltype(I)::value) r = rw[decltype(I)::value]; });
+        return r;
+    };
+
+    double acc[NI];
+    static_for<0, NI>([&](auto I) { acc[decltype(I)::value] = 0.0; });
+    double extra[Cfg::NCOLS - Cfg::NOBS];
+    static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
+    constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
+    constexpr int XP = Cols<Cfg>::PROPOSE - Cfg::NOBS, XA = Cols<Cfg>::ACCEPT - Cfg::NOBS;
+
+    for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
+        const u64 g = (u64)(B * a.nchain + ch);
+        int curr = a.nchain == 1 ? 0 : (int)(g % (u64)ND); // montecarlo.jl:76 idx = 1; many chains start stratified
+        Chain<Cfg> c;
+        double weight = 0.0, probability = 1.0; // :116
+        for (int tr = 0; tr < 10000; ++tr) {    // :118-124
+            Sample<Cfg> s;
+            draw_sample<Cfg>(t, a.seed, st_init, g * 16384ull + (u64)tr, s); // initialize!  :190-193
+            static_for<0, Cfg::NDRAW>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                c.x[k] = s.x[k];
+                c.bin[k] = s.bin[k];
+                c.prob[k] = 1.0 / s.pj[k];
+            });
+            if (curr != NORMI) {
+                weight = eval_sel<Cfg>(curr, c.x, a.ud);        // :197
+                probability = fabs(weight) * rw_sel(curr);      // :199
+            } else {
+                weight = 0.0;
+                probability = rw[NORMI];                        // :201-202
+            }
+            if (curr == NORMI || probability > 4.940656458412465e-274) break; // :120-122 (TINY)
+        }
+        if (curr != NORMI && probability == 0.0) atomicOr(a.status, ST_MCMC_INIT); // :125-126 error(...)
+
+        for (i64 it = 1; it <= steps + nburn; ++it) { // :134
+            const u64 sidx = (g << 32) | (u64)(it - 1);
+            static_for<0, ND>([&](auto I) { if (curr == decltype(I)::value) extra[XV + decltype(I)::value] += 1.0; }); // :136
+            const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
+            const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
+            const u32x4 r2 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 2u, st_step, k0, k1);
+            int upd = (int)(u01(r0.x, r0.y) * (double)NUPD); // :137 rand(rng, updates)
+            if (upd >= NUPD) upd = NUPD - 1;
+       )MCIDEV"
+R"MCIDEV(     const double upick = u01(r0.z, r0.w), us1 = u01(r1.x, r1.y), us2 = u01(r1.z, r1.w), uacc = u01(r2.x, r2.y);
+            if (upd == 0) {
+                // ---- changeIntegrand  updates.jl:1-69 ----
+                const int cur0 = curr; // `curr` may change below: dispatch on the value the step started with
+                static_for<0, ND>([&](auto C0) {
+                    constexpr int c0 = decltype(C0)::value;
+                    constexpr int nn = Cfg::nneighbor(c0);
+                    if (cur0 == c0) {
+                        int j = (int)(upick * (double)nn); // :6
+                        if (j >= nn) j = nn - 1;
+                        static_for<0, nn>([&](auto J) {
+                            constexpr int nw = Cfg::neighbor(c0 * Cfg::NBMAX + decltype(J)::value);
+                            if constexpr (nw != c0) { // :7
+                                if (j == decltype(J)::value) {
+                                    Chain<Cfg> n = c;
+                                    double prop = (double)nn / (double)Cfg::nneighbor(nw); // :12
+                                    static_for<0, NPOOL>([&](auto V) { // :15-26
+                                        constexpr int v = decltype(V)::value;
+                                        constexpr int cd = Cfg::dof(c0 * NPOOL + v), nd = Cfg::dof(nw * NPOOL + v);
+                                        constexpr int nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                                        if constexpr (cd < nd) {
+                                            static_for<cd * nl, nd * nl>([&](auto Q) { // create!  sampler.jl:293-305, :13-22
+                                                constexpr int k = k00 + decltype(Q)::value;
+                                                const double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
+                                                double raw;
+                                                draw_leaf<Cfg, k>(t, y, n.x[k], raw, n.bin[k]);
+                                                const double ip = raw * jac_scale<Cfg>(k);
+                                                n.prob[k] = 1.0 / ip;
+                                                prop *= ip;
+                                            });
+                                        } else if constexpr (cd > nd) {
+                                            static_for<nd * nl, cd * nl>([&](auto Q) { // remove!  sampler.jl:318-323, :36-40
+                                                prop *= c.prob[k00 + decltype(Q)::value];
+                                            });
+                                        }
+                                    });
+                                    if (prop > 4.9406564584124654e-324) { // :29-31
+                                        double neww = 0.0;
+                                        if constexpr (nw != NORMI) neww = eval_one<Cfg, nw>(n.x, a.ud); // :35-38
+                                        extra[XE] += 1.0;                                              // :40
+                                        const double newp = nw == NORMI ? rw[NORMI] : fabs(neww) * rw[nw]; // :42-44
+                                        const double R = prop * newp / probability;                    // :46
+                                        extra[XP + 0] += 1.0;                                          // :48
+                                        if (uacc < R) {                                                // :49
+                                            extra[XA + 0] += 1.0;
+                                            curr = nw;                                                 // :51-53
+                                            c = n;
+                                            weight = neww;
+                                            probability = newp;
+                                        } // createRollback!/removeRollback! are no-ops (sampler.jl:306, :324)
+                                    }
+                                }
+                            }
+                        });
+                    }
+                });
+            } else if (curr != NORMI) { // updates.jl:73, :115
+                int vi = (int)(upick * (double)NPOOL); // :77, :119
+                if (vi >= NPOOL) vi = NPOOL - 1;
+                int cdv = 0; // currdof[vi]
+                static_for<0, NI>([&](auto I) {
+                    static_for<0, NPOOL>([&](auto V) {
+                        if (curr == decltype(I)::value && vi == decltype(V)::value) cdv = Cfg::dof(decltype(I)::value * NPOOL + decltype(V)::value);
+                    });
+                });
+                Chain<Cfg> n = c;
+                double prop = 1.0;
+                bool active = false;
+                if (upd == 1) {
+                    // ---- swapVariable  updates.jl:113-147 ----
+                    if (cdv > 0) { // :121
+                        int s1 = (int)(us1 * (double)cdv), s2 = (int)(us2 * (double)cdv); // :122-123
+                        if (s1 >= cdv) s1 = cdv - 1;
+                        if (s2 >= cdv) s2 = cdv - 1;
+                        if (s1 != s2) { // :124
+                            active = true;
+                            static_for<0, NPOOL>([&](auto V) {
+                                constexpr int v = decltype(V)::value;
+                                constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                                if (vi == v) {
+                                    static_for<0, nl>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
+                                        constexpr int l = decltype(Lf)::value;
+                                        double xa = 0.0, xb = 0.0, pa = 1.0, pb = 1.0;
+                                        int ba = 0, bb = 0;
+                                        static_for<0, md>([&](auto S) {
+                                            constexpr int k = k00 + decltype(S)::value * nl + l;
+                                            if (s1 == decltype(S)::value) { xa = c.x[k]; pa = c.prob[k]; ba = c.bin[k]; }
+                                            if (s2 == decltype(S)::value) { xb = c.x[k]; pb = c.prob[k]; bb = c.bin[k]; }
+                                        });
+                                        static_for<0, md>([&](auto S) {
+                                            constexpr int k = k00 + decltype(S)::value * nl + l;
+                                            if (s1 == decltype(S)::value) { n.x[k] = xb; n.prob[k] = pb; n.bin[k] = bb; }
+                                            if (s2 == decltype(S)::value) { n.x[k] = xa; n.prob[k] = pa; n.bin[k] = ba; }
+                                        });
+                                    });
+                                }
+                            });
+                        }
+                    }
+                } else {
+                    // ---- changeVariable  updates.jl:71-111 ----
+                    static_for<0, NPOOL>([&](auto V) {
+                        constexpr int v = decltype(V)::value;
+                        constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                        constexpr bool skip = (md <= 0) || (nl == 1 && Cfg::leaf_kind(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1 &&
+                                                            Cfg::leaf_nbin(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1); // :79-81
+                        if constexpr (!skip) {
+                            if (vi == v && cdv > 0) { // :82
+                                active = true;
+                                int slot = (int)(us1 * (double)cdv); // :83
+                                if (slot >= cdv) slot = cdv - 1;
+                                static_for<0, md>([&](auto S) {
+                                    constexpr int sl = decltype(S)::value;
+                                    if (slot == sl) {
+     )MCIDEV"
+R"MCIDEV(                                   static_for<0, nl>([&](auto Lf) { // shift!  sampler.jl:336-386, :57-71, :431-440
+                                            constexpr int k = k00 + sl * nl + decltype(Lf)::value;
+                                            const double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
+                                            double raw;
+                                            draw_leaf<Cfg, k>(t, y, n.x[k], raw, n.bin[k]);
+                                            n.prob[k] = 1.0 / (raw * jac_scale<Cfg>(k));
+                                            prop *= c.prob[k] / n.prob[k]; // 1/prob_ratio  sampler.jl:385, :70
+                                        });
+                                    }
+                                });
+                            }
+                        }
+                    });
+                }
+                if (active && prop > 4.9406564584124654e-324) { // :88-90, :129-131
+                    const double wn = eval_sel<Cfg>(curr, n.x, a.ud);   // :92, :133
+                    extra[XE] += 1.0;                                    // :94, :135
+                    const double newp = fabs(wn) * rw_sel(curr);         // :96, :137
+                    const double R = prop * newp / probability;          // :97, :138
+                    const int ut = upd == 1 ? 2 : 1;                     // first index of propose[., curr, vi]  :99, :140
+                    static_for<1, 3>([&](auto U) { if (ut == decltype(U)::value) extra[XP + decltype(U)::value] += 1.0; });
+                    if (uacc < R) {                                      // :100, :141
+                        static_for<1, 3>([&](auto U) { if (ut == decltype(U)::value) extra[XA + decltype(U)::value] += 1.0; });
+                        c = n;
+                        weight = wn;
+                        probability = newp;
+                    } // else shiftRollback! / swapRollback!: the proposal copy is dropped  :105, :145
+                }
+            }
+            // ---- measurement  montecarlo.jl:144-172 ----
+            const bool mf = (a.measurefreq == 1) || (it % a.measurefreq == 0);
+            if (mf && it >= nburn) {
+                if (curr != NORMI) {
+                    const double relw = weight / probability; // :162
+                    static_for<0, NI>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        if (curr == i) {
+                            static_for<0, Cfg::NDRAW>([&](auto K) { // :147-154  accumulate!(var, pos + offset, 1.0)
+                                constexpr int k = decltype(K)::value;
+                                if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hist_add<Cfg, k>(c.bin[k], 1.0, sH, a.ghist, tile);
+                            });
+                            if constexpr (Cfg::obs_bin_draw(i) < 0) {
+                                acc[i] += relw; // :164
+                            } else {
+                                const int b = c.bin[Cfg::obs_bin_draw(i)];
+                                if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw);
+                            }
+                        }
+                    });
+                } else {
+                    extra[XN] += 1.0 / rw[NORMI]; // :158
+                }
             }
         }
     }
@@ -660,7 +959,7 @@ template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs 
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(a.first_index + n), s);
         double w[Cfg::NI];
-        Cfg::integrand(s.x, w, a.ud);
+        Cfg::integrand(s.x, w, a.ud, -1);
         static_for<0, Cfg::NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[n * Cfg::NDRAW + k] = s.x[k]; });
         a.jac[n] = s.jac;
         static_for<0, Cfg::NI>([&](auto I) { constexpr int i = decltype(I)::value; a.w[n * Cfg::NI + i] = w[i]; });

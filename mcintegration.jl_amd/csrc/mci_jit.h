@@ -37,6 +37,9 @@ struct ProblemShape {
     std::vector<unsigned long long> cover_mask; // [ndraw] integrands covering draw k
     std::vector<int> obs_off, obs_nbin, obs_bin_draw;
     std::vector<int> pool_maxdof, pool_nleaf, pool_first_draw;
+    std::vector<int> dof;                 // [(ni+1)*npool] incl. the normalisation row (zeros)
+    int nbmax = 1;
+    std::vector<int> nneighbor, neighbor; // [ni+1], [(ni+1)*nbmax] 0-based, padded with the integrand itself
     std::string body;
 };
 
@@ -71,7 +74,8 @@ static std::string dbl_arr(const std::vector<double> &v) {
     return o.str();
 }
 
-inline std::string generate_source(const ProblemShape &s) {
+// solver: 0 vegas (+ sample dump), 1 vegasmc, 2 mcmc -- one code object per solver, built on first use
+inline std::string generate_source(const ProblemShape &s, int solver) {
     std::ostringstream o;
     o << "#include \"mci_device.h\"\n";
     o << "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n";
@@ -103,17 +107,28 @@ inline std::string generate_source(const ProblemShape &s) {
     o << fn_table("int", "pool_maxdof", arr(s.pool_maxdof, "int"));
     o << fn_table("int", "pool_nleaf", arr(s.pool_nleaf, "int"));
     o << fn_table("int", "pool_first_draw", arr(s.pool_first_draw, "int"));
+    o << "    static constexpr int NBMAX = " << s.nbmax << ";\n";
+    o << fn_table("int", "dof", arr(s.dof, "int"));
+    o << fn_table("int", "nneighbor", arr(s.nneighbor, "int"));
+    o << fn_table("int", "neighbor", arr(s.neighbor, "int"));
     o << "    // the user's integrand (reference: the `integrand` closure, vegas/montecarlo.jl:140-144)\n";
+    o << "    // idx: the one output that is needed (mcmc: `integrand(idx, var, config)`, mcmc/montecarlo.jl:34), -1 = all\n";
     o << "    static __device__ __forceinline__ void integrand(const double* __restrict__ x, double* __restrict__ w, "
-         "const double* __restrict__ ud) {\n"
+         "const double* __restrict__ ud, const int idx) {\n    (void)idx;\n"
       << s.body << "\n    }\n";
     o << "};\n}\n";
-    o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_batch(mci::BatchArgs a) { "
-         "mci::vegas_batch<Cfg>(a); }\n";
-    o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_chains(mci::BatchArgs a) { "
-         "mci::vegasmc_chains<Cfg>(a); }\n";
-    o << "extern \"C\" __global__ void __launch_bounds__(256) mci_sample_dump(mci::DumpArgs a) { "
-         "mci::sample_dump<Cfg>(a); }\n";
+    if (solver == 0) {
+        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_batch(mci::BatchArgs a) { "
+             "mci::vegas_batch<Cfg>(a); }\n";
+        o << "extern \"C\" __global__ void __launch_bounds__(256) mci_sample_dump(mci::DumpArgs a) { "
+             "mci::sample_dump<Cfg>(a); }\n";
+    } else if (solver == 1) {
+        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_chains(mci::BatchArgs a) { "
+             "mci::vegasmc_chains<Cfg>(a); }\n";
+    } else {
+        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_mcmc_chains(mci::BatchArgs a) { "
+             "mci::mcmc_chains<Cfg>(a); }\n";
+    }
     return o.str();
 }
 

@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "mci_device.h" // ST_* status bits
+
 namespace mci {
 
 struct LeafDev {
@@ -19,7 +21,6 @@ struct LeafDev {
     double alpha;
 };
 
-enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_RESCALE_NONFINITE = 8 };
 
 // stage 1 of the histogram merge: out[g][bin] = sum over this group's workgroups (fixed order)
 __global__ void __launch_bounds__(256) k_hist_stage1(const double *__restrict__ part_hist, int nwg, int nbin, int ngroup,
@@ -107,16 +108,21 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
 }
 
 // doReweight!  main.jl:322-346 (goal = nullptr: no reweight_goal)
-__device__ inline void do_reweight_dev(double *reweight, const double *visited, int nd, double gamma) {
+__device__ inline void do_reweight_dev(double *reweight, const double *visited, int nd, double gamma, const double *goal) {
     double avgstep = 0.0;
     for (int i = 0; i < nd; ++i) avgstep += visited[i];
     for (int i = 0; i < nd; ++i) {
         if (visited[i] <= 1) reweight[i] *= pow(avgstep, gamma);
         else reweight[i] *= pow(avgstep / visited[i], gamma);
     }
+    if (goal) { // main.jl:334-337
+        double gs = 0.0;
+        for (int i = 0; i < nd; ++i) gs += goal[i];
+        for (int i = 0; i < nd; ++i) reweight[i] *= goal[i] / gs;
+    }
     double s = 0.0;
     for (int i = 0; i < nd; ++i) s += reweight[i];
-    for (int i = 0; i < nd; ++i) reweight[i] /= s;
+    for (int i = 0; i < nd; ++i) reweight[i] /= s; // main.jl:339
 }
 
 // Inclusive prefix sum of v[0..n) into out[0..n) with a fixed summation order (contiguous chunk per thread,
@@ -153,7 +159,8 @@ __device__ inline double block_prefix(const double *v, double *out, int n, doubl
 __global__ void __launch_bounds__(256) k_train(const LeafDev *__restrict__ leaves, int nleaf, double *__restrict__ packed,
                                                int nstat, double *__restrict__ edges, double *__restrict__ dacc,
                                                double *__restrict__ ddist, double *__restrict__ iter_log_row,
-                                               double *__restrict__ reweight, int nd, int do_reweight, double gamma,
+                                               double *__restrict__ reweight, const double *__restrict__ goal, int nd,
+                                               int do_reweight, double gamma,
                                                int do_train, int serial_walk, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double ps[256]; // block_prefix scratch
@@ -161,7 +168,7 @@ __global__ void __launch_bounds__(256) k_train(const LeafDev *__restrict__ leave
     if ((int)blockIdx.x == nleaf) {
         if (iter_log_row)
             for (int i = tid; i < nstat; i += T) iter_log_row[i] = packed[i];
-        if (do_reweight && tid == 0) do_reweight_dev(reweight, packed + (nstat - nd), nd, gamma);
+        if (do_reweight && tid == 0) do_reweight_dev(reweight, packed + (nstat - nd), nd, gamma, goal);
         return;
     }
     if (!do_train) return;

@@ -62,8 +62,16 @@ class Engine:
         dof = np.ascontiguousarray(config.dof, dtype=np.int32)
         onb = np.ascontiguousarray(config.obs_nbin, dtype=np.int32)
         obd = np.ascontiguousarray(config.obs_bin_draw(measure), dtype=np.int32)
+        nb_off = nb_list = None
+        nbrs = config.neighbor_lists()   # None = the reference default (configuration.jl:203-208)
+        if nbrs is not None:
+            off = np.zeros(len(nbrs) + 1, dtype=np.int32)
+            off[1:] = np.cumsum([len(n) for n in nbrs])
+            flat = np.ascontiguousarray([j for n in nbrs for j in n], dtype=np.int32)
+            self._keep += [off, flat]
+            nb_off, nb_list = off.ctypes.data_as(c_int32_p), flat.ctypes.data_as(c_int32_p)
         desc = ProblemDesc(len(leaves), arr, len(config.var), config.N, dof.ctypes.data_as(c_int32_p),
-                           onb.ctypes.data_as(c_int32_p), obd.ctypes.data_as(c_int32_p))
+                           onb.ctypes.data_as(c_int32_p), obd.ctypes.data_as(c_int32_p), nb_off, nb_list)
         self.p = C.c_void_p()
         check(L.mci_problem_create(self.ctx, C.byref(desc), C.byref(self.p)))
         ud = integrand.userdata
@@ -91,15 +99,15 @@ class Engine:
             pass
 
     # ---- kernels -------------------------------------------------------------------------------
-    def compile(self):
-        check(lib().mci_compile(self.p))
+    def compile(self, solver="vegas"):
+        check(lib().mci_compile_solver(self.p, _lib.SOLVERS[solver]))
 
     def set_launch(self, threads=0, wg_per_block=-1):
         check(lib().mci_set_launch(self.p, threads, wg_per_block))
 
-    def run(self, solver, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq=1, nchain=0):
+    def run(self, solver, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq=1, nchain=0, thermal_ratio=0.1):
         check(lib().mci_iteration_run(self.p, _lib.SOLVERS[solver], int(nevalperblock), int(block_lo), int(block_hi),
-                                      int(iteration), int(seed), int(measurefreq), int(nchain)))
+                                      int(iteration), int(seed), int(measurefreq), int(nchain), float(thermal_ratio)))
 
     def reduce(self):
         check(lib().mci_iteration_reduce(self.p))
@@ -112,9 +120,9 @@ class Engine:
         check(lib().mci_iteration_finish(self.p, _lib.SOLVERS[solver], int(block_total), 1 if adapt else 0, gamma, _dp(m), _dp(e)))
         return m, e
 
-    def iteration(self, solver, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq=1, nchain=0):
+    def iteration(self, solver, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq=1, nchain=0, thermal_ratio=0.1):
         """run + read back the local packed buffer [obsSum|obsSqSum|normalization|neval|visited|histograms]"""
-        self.run(solver, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq, nchain)
+        self.run(solver, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq, nchain, thermal_ratio)
         return self.get_packed()
 
     def iteration_log(self, nrows):
@@ -140,10 +148,15 @@ class Engine:
         check(lib().mci_train(self.p))
 
     def integrate(self, solver, neval, niter=10, block=16, ignore=-1, adapt=True, gamma=1.0, measurefreq=1, seed=1234,
-                  nchain=0, first_iteration=0):
+                  nchain=0, first_iteration=0, thermal_ratio=0.1, reweight_goal=None):
         """the whole loop inside the library (mci_integrate)"""
+        goal = None
+        if reweight_goal is not None:
+            self._goal = np.ascontiguousarray(reweight_goal, dtype=np.float64)
+            goal = _dp(self._goal)
         a = _lib.IntegrateArgs(_lib.SOLVERS[solver], int(neval), int(niter), int(block), int(ignore), 1 if adapt else 0,
-                               float(gamma), int(measurefreq), int(seed), int(nchain), int(first_iteration))
+                               float(gamma), int(measurefreq), int(seed), int(nchain), int(first_iteration),
+                               float(thermal_ratio), goal)
         n = self.nobs
         im, ie = np.zeros((niter, n)), np.zeros((niter, n))
         m, s, c2 = np.zeros(n), np.zeros(n), np.zeros(n)
@@ -205,6 +218,13 @@ class Engine:
         out = np.empty(self.config.N + 1)
         check(lib().mci_get_reweight(self.p, _dp(out), len(out)))
         return out
+
+    def set_reweight_goal(self, goal):
+        if goal is None:
+            check(lib().mci_set_reweight_goal(self.p, None, 0))
+        else:
+            g = np.ascontiguousarray(goal, dtype=np.float64)
+            check(lib().mci_set_reweight_goal(self.p, _dp(g), len(g)))
 
     def set_reweight(self, r):
         r = np.ascontiguousarray(r, dtype=np.float64)

@@ -5,7 +5,7 @@ import time
 import numpy as np
 
 from . import catalog
-from ._lib import SOLVERS, VEGAS, VEGASMC, lib
+from ._lib import MCMC, SOLVERS, VEGAS, VEGASMC, lib
 from .comm import LocalComm
 from .configuration import Configuration
 from .engine import Engine
@@ -29,7 +29,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     """Same keywords as the reference (main.jl:71-90; unknown ones go to Configuration, :95-97).
     Extra, engine-specific keywords: `comm` (LocalComm | RcclComm | TorchDistComm), `device`, `nchain`
     (vegasmc chains per block; 0 = auto), `engine_factory` (test seam)."""
-    if solver in (":vegas", ":vegasmc"):
+    if solver in (":vegas", ":vegasmc", ":mcmc"):
         solver = solver[1:]
     if solver not in SOLVERS:
         raise ValueError("Solver %s is not supported!" % solver)                      # main.jl:263
@@ -49,7 +49,8 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
 
     if isinstance(integrand, str):
         integrand = Integrand(integrand, config.userdata)
-    key = (integrand.body, tuple(integrand.userdata), None if measure is None else (measure.pool, measure.slot, measure.leaf), device)
+    key = (integrand.body, tuple(integrand.userdata), None if measure is None else (measure.pool, measure.slot, measure.leaf), device,
+           repr(config.neighbor))
     if config._engine is None or config._engine_key != key:
         # grids trained so far survive a change of integrand (`var = (res.config.var[1], ...)`, docs/src/index.md:129)
         old = config._engine
@@ -63,24 +64,16 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         config._engine, config._engine_key = eng, key
     eng = config._engine
     s = SOLVERS[solver]
+    if hasattr(eng, "set_reweight_goal"):
+        eng.set_reweight_goal(reweight_goal)                                          # main.jl:81, :334-337
 
     t0 = time.time()
     means, stds = [], []
     neval_done = 0
     for it in range(niter):                                                           # main.jl:142
-        eng.run(s, nevalperblock, lo, hi, config.iterations_done + it, config.seed, measurefreq, nchain)   # main.jl:152-166
+        eng.run(s, nevalperblock, lo, hi, config.iterations_done + it, config.seed, measurefreq, nchain, thermal_ratio)   # main.jl:152-166
         comm.all_reduce(eng)                                                          # main.jl:177-188
-        fin_solver = s
-        if s == VEGASMC and reweight_goal is not None:                                # main.jl:183, :334-337
-            packed = eng.get_packed()
-            nd = config.N + 1
-            vis = np.ascontiguousarray(packed[2 * eng.nobs + 2: 2 * eng.nobs + 2 + nd])
-            rw = np.ascontiguousarray(eng.reweight())
-            goal = np.ascontiguousarray(reweight_goal, dtype=np.float64)
-            dp = C.POINTER(C.c_double)
-            lib().mci_do_reweight(rw.ctypes.data_as(dp), vis.ctypes.data_as(dp), nd, float(gamma), goal.ctypes.data_as(dp))
-            eng.set_reweight(rw)
-            fin_solver = VEGAS  # skip the device-side doReweight!
+        fin_solver = s                                                                # doReweight! runs on the device (main.jl:183)
         m, e = eng.finish(fin_solver, block, adapt, gamma)                            # main.jl:190-203
         means.append(m)
         stds.append(e)
@@ -112,7 +105,13 @@ def prefill_kernel_cache():
     n = 0
     for cfg, f, meas in jobs:
         eng = Engine(cfg, f, measure=meas, device=-1)
-        eng.compile()
+        eng.compile("vegas")
+        if meas is not None:
+            eng.compile("vegasmc")  # C3 is a :vegasmc config
         eng.close()
         n += 1
-    return n
+    # C5: 4 integrands on a 12-D pool, :mcmc
+    eng = Engine(Configuration(var=Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]]), catalog.nested_gauss(), device=-1)
+    eng.compile("mcmc")
+    eng.close()
+    return n + 1

@@ -59,7 +59,7 @@ double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k) 
     return d - 1.0; /* 52 random mantissa bits, like Julia's MersenneTwister rand(Float64) */
 }
 
-enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3 };
+enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5 };
 static inline uint32_t stream_id(uint32_t iteration, int purpose) { return iteration * 8u + (uint32_t)purpose; }
 
 /* ------------------------------------------------------------------------------------------
@@ -317,9 +317,24 @@ mcio_config *mcio_config_create(int nleaf, const int *kind, const int *pool, con
     for (int i = 0; i < Nd; ++i) c->reweight[i] = 1.0 / Nd; /* ref: configuration.jl:110,172-173 */
     c->visited = (double *)calloc((size_t)Nd, sizeof(double));
     for (int i = 0; i < Nd; ++i) c->visited[i] = 1.0e-8;    /* :182 */
-    c->propose = (double *)calloc((size_t)npool, sizeof(double));
-    c->accept = (double *)calloc((size_t)npool, sizeof(double));
-    for (int v = 0; v < npool; ++v) c->propose[v] = 1.0e-8; /* :186 */
+    c->npa = npool > 3 ? npool : 3;
+    c->propose = (double *)calloc((size_t)c->npa, sizeof(double));
+    c->accept = (double *)calloc((size_t)c->npa, sizeof(double));
+    for (int v = 0; v < c->npa; ++v) c->propose[v] = 1.0e-8; /* :186 */
+    /* default neighbor graph  ref: configuration.jl:201-210 (1-based there, 0-based here; index Nd-1 = normalisation) */
+    c->nneighbor = (int *)calloc((size_t)Nd, sizeof(int));
+    c->neighbor = (int **)calloc((size_t)Nd, sizeof(int *));
+    for (int d = 0; d < Nd; ++d) {
+        c->neighbor[d] = (int *)calloc(2, sizeof(int));
+        c->neighbor[d][0] = d - 1; /* :205 [d-1, d+1] */
+        c->neighbor[d][1] = d + 1;
+        c->nneighbor[d] = 2;
+    }
+    if (Nd == 2) { c->neighbor[0][0] = 1; c->nneighbor[0] = 1; }           /* :206 */
+    else { c->neighbor[0][0] = Nd - 1; c->neighbor[0][1] = 1; }             /* :206 [Nd, 2] */
+    c->neighbor[Nd - 1][0] = 0; c->nneighbor[Nd - 1] = 1;                   /* :207 norm -> first */
+    if (Nd >= 3) { c->neighbor[Nd - 2][0] = Nd - 3; c->nneighbor[Nd - 2] = 1; } /* :208 */
+    c->thermal_ratio = 0.1;
     c->normalization = 1.0e-10;                              /* :179 */
     c->neval = 0;
     c->prob_mode = MCIO_PROB_CREATE;
@@ -340,6 +355,8 @@ void mcio_config_destroy(mcio_config *c) {
     free(c->pool_prob); free(c->pool_prob_cache); free(c->dof); free(c->maxdof);
     free(c->draw_leaf); free(c->draw_slot); free(c->obs_off); free(c->obs_nbin); free(c->obs_bin_draw);
     free(c->observable); free(c->reweight); free(c->visited); free(c->propose); free(c->accept);
+    for (int d = 0; d < c->Ni + 1; ++d) free(c->neighbor[d]);
+    free(c->neighbor); free(c->nneighbor); free(c->reweight_goal);
     free(c);
 }
 
@@ -387,8 +404,12 @@ mcio_config *mcio_config_clone(const mcio_config *s) {
     c->observable = (double *)dup_mem(s->observable, sizeof(double) * (size_t)s->nobs);
     c->reweight = (double *)dup_mem(s->reweight, sizeof(double) * (size_t)Nd);
     c->visited = (double *)dup_mem(s->visited, sizeof(double) * (size_t)Nd);
-    c->propose = (double *)dup_mem(s->propose, sizeof(double) * (size_t)s->npool);
-    c->accept = (double *)dup_mem(s->accept, sizeof(double) * (size_t)s->npool);
+    c->propose = (double *)dup_mem(s->propose, sizeof(double) * (size_t)s->npa);
+    c->accept = (double *)dup_mem(s->accept, sizeof(double) * (size_t)s->npa);
+    c->nneighbor = (int *)dup_mem(s->nneighbor, sizeof(int) * (size_t)Nd);
+    c->neighbor = (int **)calloc((size_t)Nd, sizeof(int *));
+    for (int d = 0; d < Nd; ++d) c->neighbor[d] = (int *)dup_mem(s->neighbor[d], sizeof(int) * (size_t)s->nneighbor[d]);
+    c->reweight_goal = s->reweight_goal ? (double *)dup_mem(s->reweight_goal, sizeof(double) * (size_t)Nd) : NULL;
     return c;
 }
 
@@ -435,7 +456,7 @@ void mcio_clear_statistics(mcio_config *c) {
     c->neval = 0;
     c->normalization = 1.0e-10;
     for (int i = 0; i < c->Ni + 1; ++i) c->visited[i] = 1.0e-8;
-    for (int v = 0; v < c->npool; ++v) {
+    for (int v = 0; v < c->npa; ++v) {
         c->propose[v] = 1.0e-8;
         c->accept[v] = 1.0e-10;
     }
@@ -446,7 +467,7 @@ void mcio_clear_statistics(mcio_config *c) {
 /* ref: configuration.jl:252-262 and variable.jl:567 */
 void mcio_add_config(mcio_config *c, const mcio_config *ic) {
     for (int i = 0; i < c->Ni + 1; ++i) c->visited[i] += ic->visited[i];
-    for (int v = 0; v < c->npool; ++v) {
+    for (int v = 0; v < c->npa; ++v) {
         c->accept[v] += ic->accept[v];
         c->propose[v] += ic->propose[v];
     }
@@ -577,6 +598,41 @@ void mcio_pool_shift_rollback(mcio_config *c, int vi, int idx) {
     int l0 = c->pool_leaf0[vi], nl = c->pool_nleaf[vi];
     for (int l = 0; l < nl; ++l) mcio_shift_rollback(c, l0 + l, idx);
     if (nl != 1) c->pool_prob[vi][idx] = c->pool_prob_cache[vi];
+}
+
+/* remove!  ref: sampler.jl:318-323 (Continuous), :36-40 (Discrete): the probability of the slot that goes away */
+double mcio_remove(mcio_config *c, int leaf, int idx) {
+    mcio_leaf *T = &c->leaf[leaf];
+    if (T->kind == MCIO_CONTINUOUS) {
+        long iy = T->gidx[idx];                                                 /* :321 */
+        return 1.0 / ((T->grid[iy] - T->grid[iy - 1]) * (double)(T->npts - 1)); /* :322 */
+    }
+    long gidx = (long)(T->data[idx] - T->lower) + 1; /* :38 */
+    return T->distribution[gidx - 1];                /* :39 */
+}
+
+/* ref: sampler.jl:422-428 */
+double mcio_pool_remove(mcio_config *c, int vi, int idx) {
+    double prop = 1.0;
+    for (int l = c->pool_leaf0[vi]; l < c->pool_leaf0[vi] + c->pool_nleaf[vi]; ++l) prop *= mcio_remove(c, l, idx);
+    return prop;
+}
+
+/* swap! == swapRollback!  ref: sampler.jl:395-408 (Continuous), :86-97 (Discrete), :448-462 (CompositeVar) */
+double mcio_pool_swap(mcio_config *c, int vi, int idx1, int idx2) {
+    int l0 = c->pool_leaf0[vi], nl = c->pool_nleaf[vi];
+    if (nl != 1) { /* :450 */
+        double t = c->pool_prob[vi][idx1];
+        c->pool_prob[vi][idx1] = c->pool_prob[vi][idx2];
+        c->pool_prob[vi][idx2] = t;
+    }
+    for (int l = l0; l < l0 + nl; ++l) {
+        mcio_leaf *T = &c->leaf[l];
+        double d = T->data[idx1]; T->data[idx1] = T->data[idx2]; T->data[idx2] = d;
+        long g = T->gidx[idx1]; T->gidx[idx1] = T->gidx[idx2]; T->gidx[idx2] = g;
+        double p = T->prob[idx1]; T->prob[idx1] = T->prob[idx2]; T->prob[idx2] = p;
+    }
+    return 1.0;
 }
 
 /* ref: variable.jl:587-599 */
@@ -814,6 +870,220 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
  * src/main.jl
  * ---------------------------------------------------------------------------------------- */
 
+/* ------------------------------------------------------------------------------------------
+ * src/mcmc/montecarlo.jl:72-184 + src/mcmc/updates.jl:1-147
+ * The Markov chain walks over (integrand index curr, live variables).  A block's neval measured steps are
+ * run as `nchain` independent chains of neval/nchain measured steps, each preceded by its burn-in
+ * (nchain = 1 is the reference).  Chain g = block_index*nchain + ch draws
+ *   init try t: stream MCMC_INIT, index g*16384 + t,  k = flat draw
+ *   step s    : stream MCMC_STEP, index (g<<32 | s),  k = 0 update pick, 1 neighbor/pool pick, 2 slot pick,
+ *               3 second slot pick (swap), 4 accept, 5 + flat draw index of a created/shifted (pool, slot, leaf)
+ * ---------------------------------------------------------------------------------------- */
+long mcio_mcmc_burnin(long steps, long nchain, int nslots, int Nd, int npool, double thermal_ratio) {
+    long nburn = (long)floor((double)steps * thermal_ratio); /* :133 */
+    if (nchain > 1) { /* many short chains: each must forget its start (this engine's own decomposition) */
+        long fl = 64L * nslots + 16L * (npool + 1) * Nd;
+        if (fl > steps / 2) fl = steps / 2;
+        if (fl > nburn) nburn = fl;
+    }
+    return nburn;
+}
+
+int mcio_set_neighbor(mcio_config *c, const int *offsets, const int *list) {
+    const int Nd = c->Ni + 1;
+    for (int d = 0; d < Nd; ++d) {
+        int n = offsets[d + 1] - offsets[d];
+        if (n < 1) return 1;
+        for (int j = 0; j < n; ++j)
+            if (list[offsets[d] + j] < 0 || list[offsets[d] + j] >= Nd) return 2;
+    }
+    for (int d = 0; d < Nd; ++d) {
+        int n = offsets[d + 1] - offsets[d];
+        free(c->neighbor[d]);
+        c->neighbor[d] = (int *)dup_mem(list + offsets[d], sizeof(int) * (size_t)n);
+        c->nneighbor[d] = n;
+    }
+    return 0;
+}
+
+void mcio_set_thermal_ratio(mcio_config *c, double r) { c->thermal_ratio = r; }
+
+void mcio_set_reweight_goal(mcio_config *c, const double *goal) {
+    free(c->reweight_goal);
+    c->reweight_goal = goal ? (double *)dup_mem(goal, sizeof(double) * (size_t)(c->Ni + 1)) : NULL;
+}
+
+/* measure for the one integrand the chain sits on (mcmc/montecarlo.jl:163-170) */
+static inline void measure_one(mcio_config *c, const double *x, int i, double relw) {
+    int bin = 0;
+    if (c->obs_bin_draw[i] >= 0) {
+        const mcio_leaf *T = &c->leaf[c->draw_leaf[c->obs_bin_draw[i]]];
+        bin = (int)(x[c->obs_bin_draw[i]] - T->lower);
+        if (bin < 0 || bin >= c->obs_nbin[i]) return;
+    }
+    c->observable[c->obs_off[i] + bin] += relw;
+}
+
+int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint64_t seed,
+                    uint32_t iteration, long block_index, long neval, long measurefreq, long nchain) {
+    const int npool = c->npool, norm = c->Ni, Nd = c->Ni + 1;
+    if (c->ndraw > MCIO_MAXDRAW || Nd > MCIO_MAXNI || measurefreq <= 0 || nchain < 1) return -1; /* :79 */
+    double w[MCIO_MAXNI], x[MCIO_MAXDRAW], u[MCIO_MAXDRAW];
+    int kbase[64];
+    int nslots = 0;
+    for (int vi = 0, k = 0; vi < npool; ++vi) {
+        kbase[vi] = k;
+        k += c->maxdof[vi] * c->pool_nleaf[vi];
+        nslots += c->maxdof[vi];
+    }
+    const long steps = neval / nchain;
+    const long nburn = mcio_mcmc_burnin(steps, nchain, nslots, Nd, npool, c->thermal_ratio); /* :133 */
+    const int nupd = 2 * npool + 2; /* :127-130: [changeIntegrand, swapVariable, changeVariable x 2*Nv] */
+    const uint32_t st_init = stream_id(iteration, STREAM_MCMC_INIT), st_step = stream_id(iteration, STREAM_MCMC_STEP);
+    int rc = 0;
+    for (long ch = 0; ch < nchain; ++ch) {
+        const uint64_t g = (uint64_t)block_index * (uint64_t)nchain + (uint64_t)ch;
+        int curr = (nchain == 1) ? 0 : (int)(g % (uint64_t)Nd); /* :76 idx = 1; many chains start stratified */
+        double weight = 0.0, probability = 1.0;                  /* :116 _State(curr, zero(T), 1.0) */
+        for (long t = 0; t < 10000; ++t) {                       /* :118-124 */
+            /* initialize!  :190-205 (only the slots that are ever read: 1..maxdof) */
+            for (int vi = 0; vi < npool; ++vi)
+                for (int idx = 1; idx <= c->maxdof[vi]; ++idx) {
+                    int nl = c->pool_nleaf[vi];
+                    for (int l = 0; l < nl; ++l)
+                        u[l] = mcio_uniform(seed, st_init, g * 16384u + (uint64_t)t, (uint32_t)(kbase[vi] + (idx - 1) * nl + l));
+                    mcio_pool_create(c, vi, idx + c->pool_offset[vi], u);
+                }
+            if (curr != norm) {
+                gather_x(c, x);
+                f(x, w, ud);
+                weight = w[curr];                                   /* :197 */
+                probability = fabs(weight) * c->reweight[curr];     /* :199 */
+            } else {
+                weight = 0.0;                                       /* :201 */
+                probability = c->reweight[curr];                    /* :202 */
+            }
+            if (curr == norm || probability > MCIO_TINY) break;     /* :120-122 */
+        }
+        if (curr != norm && probability == 0.0) rc = -3;            /* :125-126 error(...) */
+        for (long i = 1; i <= steps + nburn; ++i) {                 /* :134 */
+            const uint64_t sidx = (g << 32) | (uint64_t)(i - 1);
+            c->visited[curr] += 1.0;                                /* :136 */
+            int upd = (int)floor(mcio_uniform(seed, st_step, sidx, 0) * nupd); /* :137 rand(rng, updates) */
+            if (upd >= nupd) upd = nupd - 1;
+            if (upd == 0) {
+                /* ---- changeIntegrand  updates.jl:1-69 ---- */
+                do {
+                    int j = (int)floor(mcio_uniform(seed, st_step, sidx, 1) * c->nneighbor[curr]);
+                    if (j >= c->nneighbor[curr]) j = c->nneighbor[curr] - 1;
+                    const int new_ = c->neighbor[curr][j];          /* :6 */
+                    if (new_ == curr) break;                        /* :7 */
+                    const int *cd = &c->dof[curr * npool], *nd = &c->dof[new_ * npool]; /* :9 */
+                    double prop = (double)c->nneighbor[curr] / (double)c->nneighbor[new_]; /* :12 */
+                    for (int vi = 0; vi < npool; ++vi) {            /* :15-26 */
+                        const int off = c->pool_offset[vi], nl = c->pool_nleaf[vi];
+                        if (cd[vi] < nd[vi]) {
+                            for (int pos = cd[vi] + 1; pos <= nd[vi]; ++pos) {
+                                for (int l = 0; l < nl; ++l)
+                                    u[l] = mcio_uniform(seed, st_step, sidx, (uint32_t)(5 + kbase[vi] + (pos - 1) * nl + l));
+                                prop *= mcio_pool_create(c, vi, pos + off, u); /* :19 */
+                            }
+                        } else if (cd[vi] > nd[vi]) {
+                            for (int pos = nd[vi] + 1; pos <= cd[vi]; ++pos) prop *= mcio_pool_remove(c, vi, pos + off); /* :23 */
+                        }
+                    }
+                    if (prop <= 4.9406564584124654e-324) break;    /* :29-31 */
+                    double neww = 0.0;                              /* :35-38 */
+                    if (new_ != norm) {
+                        gather_x(c, x);
+                        f(x, w, ud);
+                        neww = w[new_];
+                    }
+                    c->neval += 1;                                  /* :40 */
+                    const double newp = (new_ == norm) ? c->reweight[new_] : fabs(neww) * c->reweight[new_]; /* :42-44 */
+                    const double R = prop * newp / probability;     /* :46 */
+                    c->propose[0] += 1.0;                           /* :48 propose[1, curr, new] */
+                    if (mcio_uniform(seed, st_step, sidx, 4) < R) { /* :49 */
+                        c->accept[0] += 1.0;                        /* :50 */
+                        curr = new_;                                /* :51-53 */
+                        weight = neww;
+                        probability = newp;
+                    } /* else createRollback!/removeRollback! are no-ops  :55-68, sampler.jl:306,324 */
+                } while (0);
+            } else if (curr != norm) { /* updates.jl:73, :115 */
+                const int *cd = &c->dof[curr * npool];
+                int vi = (int)floor(mcio_uniform(seed, st_step, sidx, 1) * npool); /* :77, :119 */
+                if (vi >= npool) vi = npool - 1;
+                const int off = c->pool_offset[vi], nl = c->pool_nleaf[vi];
+                if (upd == 1) {
+                    /* ---- swapVariable  updates.jl:113-147 ---- */
+                    do {
+                        if (cd[vi] <= 0) break;                     /* :121 */
+                        int s1 = (int)floor(mcio_uniform(seed, st_step, sidx, 2) * cd[vi]) + 1; /* :122 */
+                        int s2 = (int)floor(mcio_uniform(seed, st_step, sidx, 3) * cd[vi]) + 1; /* :123 */
+                        if (s1 > cd[vi]) s1 = cd[vi];
+                        if (s2 > cd[vi]) s2 = cd[vi];
+                        if (s1 == s2) break;                        /* :124 */
+                        const double prop = mcio_pool_swap(c, vi, s1 + off, s2 + off); /* :126 */
+                        gather_x(c, x);
+                        f(x, w, ud);                                /* :133 */
+                        c->neval += 1;                              /* :135 */
+                        const double newp = fabs(w[curr]) * c->reweight[curr]; /* :137 */
+                        const double R = prop * newp / probability; /* :138 */
+                        c->propose[2] += 1.0;                       /* :140 propose[3, curr, vi] */
+                        if (mcio_uniform(seed, st_step, sidx, 4) < R) {
+                            c->accept[2] += 1.0;
+                            weight = w[curr];
+                            probability = newp;
+                        } else {
+                            mcio_pool_swap(c, vi, s1 + off, s2 + off); /* :145 swapRollback! */
+                        }
+                    } while (0);
+                } else {
+                    /* ---- changeVariable  updates.jl:71-111 ---- */
+                    do {
+                        const mcio_leaf *v0 = &c->leaf[c->pool_leaf0[vi]];
+                        if (nl == 1 && v0->kind == MCIO_DISCRETE && v0->nbin == 1) break; /* :79-81 */
+                        if (cd[vi] <= 0) break;                     /* :82 */
+                        int slot = (int)floor(mcio_uniform(seed, st_step, sidx, 2) * cd[vi]) + 1; /* :83 */
+                        if (slot > cd[vi]) slot = cd[vi];
+                        for (int l = 0; l < nl; ++l)
+                            u[l] = mcio_uniform(seed, st_step, sidx, (uint32_t)(5 + kbase[vi] + (slot - 1) * nl + l));
+                        const double prop = mcio_pool_shift(c, vi, slot + off, u); /* :85 */
+                        if (prop <= 4.9406564584124654e-324) break; /* :88-90 */
+                        gather_x(c, x);
+                        f(x, w, ud);                                /* :92 */
+                        c->neval += 1;                              /* :94 */
+                        const double newp = fabs(w[curr]) * c->reweight[curr]; /* :96 */
+                        const double R = prop * newp / probability; /* :97 */
+                        c->propose[1] += 1.0;                       /* :99 propose[2, curr, vi] */
+                        if (mcio_uniform(seed, st_step, sidx, 4) < R) {
+                            c->accept[1] += 1.0;
+                            weight = w[curr];
+                            probability = newp;
+                        } else {
+                            mcio_pool_shift_rollback(c, vi, slot + off); /* :105 */
+                        }
+                    } while (0);
+                }
+            }
+            /* ---- measurement  montecarlo.jl:144-172 ---- */
+            if (i % measurefreq == 0 && i >= nburn) {
+                if (curr != norm) {
+                    for (int vi = 0; vi < npool; ++vi)              /* :147-154 */
+                        for (int pos = 1; pos <= c->dof[curr * npool + vi]; ++pos)
+                            pool_accumulate(c, vi, pos + c->pool_offset[vi], 1.0);
+                    gather_x(c, x);
+                    measure_one(c, x, curr, weight / probability);  /* :161-169 */
+                } else {
+                    c->normalization += 1.0 / c->reweight[norm];    /* :158 */
+                }
+            }
+        }
+    }
+    return rc;
+}
+
 /* ref: main.jl:220-234 */
 void mcio_standardize_block(long neval, long nblock, long nworker, long *nevalperblock, long *block) {
     if (nblock > nworker) nblock = (nblock / nworker) * nworker; /* :225-227 */
@@ -935,8 +1205,10 @@ static int run_blocks(mcio_config *c, int solver, mcio_integrand_fn f, const dou
         int rc;
         if (solver == MCIO_VEGAS)
             rc = mcio_vegas_block(cn, f, ud, seed, iteration, block_lo + b, nevalperblock, measurefreq); /* main.jl:257 */
-        else
+        else if (solver == MCIO_VEGASMC)
             rc = mcio_vegasmc_block(cn, f, ud, seed, iteration, block_lo + b, nevalperblock, measurefreq, nchain); /* main.jl:254 */
+        else
+            rc = mcio_mcmc_block(cn, f, ud, seed, iteration, block_lo + b, nevalperblock, measurefreq, nchain); /* main.jl:260 */
         if (rc || !(cn->normalization > 0.0)) { /* main.jl:269-271 */
 #ifdef _OPENMP
 #pragma omp atomic write
@@ -1000,7 +1272,7 @@ int mcio_integrate(mcio_config *c, int solver, mcio_integrand_fn f, const double
         rc |= run_blocks(c, solver, f, ud, nevalperblock, 0, block, (uint32_t)iter, measurefreq, seed, nthreads, nchain,
                          obs_sum, obs_sq); /* :152-174 */
         out->neval += c->neval;
-        if (solver == MCIO_VEGASMC) mcio_do_reweight(c->reweight, c->visited, c->Ni + 1, gamma, NULL); /* :183 */
+        if (solver == MCIO_VEGASMC || solver == MCIO_MCMC) mcio_do_reweight(c->reweight, c->visited, c->Ni + 1, gamma, c->reweight_goal); /* :183 */
         if (adapt) mcio_train(c); /* :193-198 */
         mcio_mean_std(obs_sum, obs_sq, c->nobs, block, out->iter_mean + (size_t)iter * c->nobs,
                       out->iter_std + (size_t)iter * c->nobs); /* :203 */

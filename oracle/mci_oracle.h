@@ -37,7 +37,7 @@ extern "C" {
 #define MCIO_TINY 4.940656458412465e-274 /* src/MCIntegration.jl:11  eps(0.0)*1e50 */
 
 enum { MCIO_CONTINUOUS = 0, MCIO_DISCRETE = 1 };
-enum { MCIO_VEGAS = 0, MCIO_VEGASMC = 1 };
+enum { MCIO_VEGAS = 0, MCIO_VEGASMC = 1, MCIO_MCMC = 2 };
 /* how Continuous/Discrete prob[idx] is maintained per draw */
 enum {
     MCIO_PROB_CREATE = 0, /* prob = 1/(N*dx)        sampler.jl:303, vegas/montecarlo.jl:128-129 */
@@ -87,9 +87,15 @@ typedef struct {
     long neval;
     double *reweight;     /* [Ni+1] */
     double *visited;      /* [Ni+1] */
-    double *propose;      /* [npool] propose[2,1,vi] (vegas_mc/updates.jl:90) */
-    double *accept;       /* [npool] */
+    double *propose;      /* [npa] vegasmc: propose[2,1,vi] (vegas_mc/updates.jl:90); mcmc: summed per update type
+                             (changeIntegrand, changeVariable, swapVariable = first index of configuration.jl:186) */
+    double *accept;       /* [npa] */
     int prob_mode;
+    int npa;              /* max(npool, 3) */
+    int *nneighbor;       /* [Ni+1] configuration.jl:201-227 */
+    int **neighbor;       /* [Ni+1][nneighbor] 0-based integrand indices; index Ni = normalisation */
+    double thermal_ratio; /* mcmc/montecarlo.jl:77 (default 0.1) */
+    double *reweight_goal; /* [Ni+1] or NULL  main.jl:81, :334-337 */
 } mcio_config;
 
 typedef struct {
@@ -138,6 +144,9 @@ void mcio_shift_rollback(mcio_config *c, int leaf, int idx);      /* :388-393, :
 double mcio_pool_shift(mcio_config *c, int vi, int idx, const double *u); /* :431-440 ; u = pool_nleaf uniforms */
 double mcio_pool_create(mcio_config *c, int vi, int idx, const double *u);
 void mcio_pool_shift_rollback(mcio_config *c, int vi, int idx);   /* :441-446 */
+double mcio_remove(mcio_config *c, int leaf, int idx);            /* :318-323, :36-40 */
+double mcio_pool_remove(mcio_config *c, int vi, int idx);         /* :422-428 */
+double mcio_pool_swap(mcio_config *c, int vi, int idx1, int idx2); /* :395-408, :86-97, :448-455 (its own rollback) */
 double mcio_total_probability(const mcio_config *c);              /* variable.jl:587-599 */
 double mcio_probability(const mcio_config *c, int i);             /* variable.jl:606-619 */
 double mcio_padding_probability(const mcio_config *c, int i);     /* variable.jl:628-641 */
@@ -152,6 +161,15 @@ int mcio_vegas_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint
 int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint64_t seed,
                        uint32_t iteration, long block_index, long neval, long measurefreq,
                        long nchain);
+
+/* one MCMC block (mcmc/montecarlo.jl:72-184 with mcmc/updates.jl:1-147) run as `nchain` independent chains of
+   neval/nchain measured steps each (+ burn-in, mcio_mcmc_burnin); nchain=1 is the reference's single chain. */
+int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint64_t seed,
+                    uint32_t iteration, long block_index, long neval, long measurefreq, long nchain);
+long mcio_mcmc_burnin(long steps, long nchain, int nslots, int Nd, int npool, double thermal_ratio);
+int mcio_set_neighbor(mcio_config *c, const int *offsets /* [Ni+2] */, const int *list); /* configuration.jl:201-227 */
+void mcio_set_thermal_ratio(mcio_config *c, double r);
+void mcio_set_reweight_goal(mcio_config *c, const double *goal /* [Ni+1] or NULL */);
 
 /* ---- main.jl / statistics.jl ---- */
 void mcio_standardize_block(long neval, long nblock, long nworker, long *nevalperblock, long *block); /* main.jl:220-234 */

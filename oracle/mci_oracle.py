@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libmci_oracle.so")
 
 CONTINUOUS, DISCRETE = 0, 1
-VEGAS, VEGASMC = 0, 1
+VEGAS, VEGASMC, MCMC = 0, 1, 2
 PROB_CREATE, PROB_SHIFT = 0, 1
 
 c_double_p = C.POINTER(C.c_double)
@@ -46,7 +46,8 @@ class _Config(C.Structure):
                 ("nobs", C.c_int), ("obs_off", c_int_p), ("obs_nbin", c_int_p), ("obs_bin_draw", c_int_p),
                 ("observable", c_double_p), ("normalization", C.c_double), ("neval", C.c_long),
                 ("reweight", c_double_p), ("visited", c_double_p), ("propose", c_double_p),
-                ("accept", c_double_p), ("prob_mode", C.c_int)]
+                ("accept", c_double_p), ("prob_mode", C.c_int), ("npa", C.c_int), ("nneighbor", c_int_p),
+                ("neighbor", C.POINTER(c_int_p)), ("thermal_ratio", C.c_double), ("reweight_goal", c_double_p)]
 
 
 class _Result(C.Structure):
@@ -105,6 +106,17 @@ def lib():
                                    C.c_long, C.c_long]
     L.mcio_vegasmc_block.argtypes = [C.POINTER(_Config), C.c_void_p, c_double_p, C.c_uint64, C.c_uint32, C.c_long,
                                      C.c_long, C.c_long, C.c_long]
+    L.mcio_mcmc_block.argtypes = [C.POINTER(_Config), C.c_void_p, c_double_p, C.c_uint64, C.c_uint32, C.c_long,
+                                  C.c_long, C.c_long, C.c_long]
+    L.mcio_mcmc_burnin.restype = C.c_long
+    L.mcio_mcmc_burnin.argtypes = [C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_double]
+    L.mcio_set_neighbor.argtypes = [C.POINTER(_Config), c_int_p, c_int_p]
+    L.mcio_set_thermal_ratio.argtypes = [C.POINTER(_Config), C.c_double]
+    L.mcio_set_reweight_goal.argtypes = [C.POINTER(_Config), c_double_p]
+    L.mcio_pool_remove.restype = C.c_double
+    L.mcio_pool_remove.argtypes = [C.POINTER(_Config), C.c_int, C.c_int]
+    L.mcio_pool_swap.restype = C.c_double
+    L.mcio_pool_swap.argtypes = [C.POINTER(_Config), C.c_int, C.c_int, C.c_int]
     L.mcio_standardize_block.argtypes = [C.c_long, C.c_long, C.c_long, c_long_p, c_long_p]
     L.mcio_mean_std.argtypes = [c_double_p, c_double_p, C.c_long, C.c_long, c_double_p, c_double_p]
     L.mcio_average.argtypes = [c_double_p, c_double_p, C.c_long, C.c_long, C.c_long, C.c_long, c_double_p,
@@ -371,6 +383,38 @@ class Config:
         u = np.ascontiguousarray(ud if ud is not None else [0.0], dtype=np.float64)
         return lib().mcio_vegasmc_block(self.p, _fnptr(f), _dp(u), seed, iteration, block_index, neval,
                                         measurefreq, nchain)
+
+    def mcmc_block(self, f, ud, seed, iteration, block_index, neval, measurefreq=1, nchain=1):
+        u = np.ascontiguousarray(ud if ud is not None else [0.0], dtype=np.float64)
+        return lib().mcio_mcmc_block(self.p, _fnptr(f), _dp(u), seed, iteration, block_index, neval, measurefreq, nchain)
+
+    def set_neighbor(self, neighbor):
+        """neighbor: list of lists of 0-based integrand indices (index Ni = normalisation)"""
+        off = np.zeros(len(neighbor) + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(n) for n in neighbor])
+        flat = np.ascontiguousarray([j for n in neighbor for j in n], dtype=np.int32)
+        if lib().mcio_set_neighbor(self.p, _ip(off), _ip(flat)):
+            raise ValueError("bad neighbor lists")
+
+    def neighbor(self):
+        return [[self.c.neighbor[d][j] for j in range(self.c.nneighbor[d])] for d in range(self.c.Ni + 1)]
+
+    def set_thermal_ratio(self, r):
+        lib().mcio_set_thermal_ratio(self.p, float(r))
+
+    def set_reweight_goal(self, goal):
+        if goal is None:
+            lib().mcio_set_reweight_goal(self.p, None)
+        else:
+            g = np.ascontiguousarray(goal, dtype=np.float64)
+            assert len(g) == self.c.Ni + 1
+            lib().mcio_set_reweight_goal(self.p, _dp(g))
+
+    def pool_remove(self, vi, idx):
+        return lib().mcio_pool_remove(self.p, vi, idx)
+
+    def pool_swap(self, vi, idx1, idx2):
+        return lib().mcio_pool_swap(self.p, vi, idx1, idx2)
 
     def iteration(self, solver, f, ud, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq=1,
                   nthreads=1, nchain=1):

@@ -32,8 +32,13 @@ class OracleEngine:
         self._packed = np.zeros(self.packed_size)
         self.calls = []
 
-    def run(self, solver, nevalperblock, lo, hi, iteration, seed, measurefreq=1, nchain=0):
+    def set_reweight_goal(self, goal):
+        self.ocfg.set_reweight_goal(goal)
+        self._goal = None if goal is None else np.ascontiguousarray(goal, dtype=np.float64)
+
+    def run(self, solver, nevalperblock, lo, hi, iteration, seed, measurefreq=1, nchain=0, thermal_ratio=0.1):
         self.calls.append((lo, hi, iteration))
+        self.ocfg.set_thermal_ratio(thermal_ratio)
         self._packed = self.ocfg.iteration(int(solver), self.fn, self.ud, nevalperblock, lo, hi, iteration, seed,
                                            measurefreq=measurefreq, nchain=max(int(nchain), 1))
 
@@ -54,9 +59,9 @@ class OracleEngine:
             lf = c.leaf[i]
             np.ctypeslib.as_array(lf.hist, shape=(lf.nbin,))[:] = self._packed[off:off + lf.nbin]
             off += lf.nbin
-        if int(solver) == O.VEGASMC:
+        if int(solver) in (O.VEGASMC, O.MCMC):
             vis = self._packed[nstat - (c.Ni + 1):nstat]
-            r = O.do_reweight(self.ocfg.reweight, vis, gamma)
+            r = O.do_reweight(self.ocfg.reweight, vis, gamma, getattr(self, "_goal", None))
             np.ctypeslib.as_array(c.reweight, shape=(c.Ni + 1,))[:] = r
         if adapt:
             self.ocfg.train()

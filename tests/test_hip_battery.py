@@ -68,7 +68,7 @@ def TestHyperSphere(totalstep, alg, N):
                      neval=totalstep, print=-1, solver=alg, seed=109)
 
 
-@pytest.mark.parametrize("alg,neval", [("vegas", 200000), ("vegasmc", 100000)])
+@pytest.mark.parametrize("alg,neval", [("vegas", 200000), ("vegasmc", 100000), ("mcmc", 200000)])  # test/montecarlo.jl:262-387
 def test_battery(alg, neval):
     check(Sphere1(neval, alg), PI / 4.0)
     check(Sphere2(neval, alg), [PI / 4.0, 4.0 * PI / 3.0 / 8])
@@ -77,7 +77,8 @@ def test_battery(alg, neval):
     check(TestDiscrete2(neval, alg), 12.0)
     res = TestSingular1(neval, alg)
     check(res, -4.0)
-    assert res.stdev[0] < (0.0004 if alg == "vegas" else 0.0007)  # test/montecarlo.jl:317, :364
+    if alg != "mcmc":
+        assert res.stdev[0] < (0.0004 if alg == "vegas" else 0.0007)  # test/montecarlo.jl:317, :364
     check(TestSingular2(neval, alg), 1.3932)
     check(TestSingular2_CompositeVar(neval, alg), 1.3932)
     check(TestSingular2_Continuous_HighDim(neval, alg), 1.3932)
@@ -104,10 +105,10 @@ def test_interface_accepts_tuple_dof_and_unknown_kwargs():
 def test_bubble_with_resume():
     # test/bubble.jl:93-133: Lindhard polarisation at 4 q; the second call resumes from the trained config
     p = mci.catalog.bubble_parameters()
-    sys_tol = {"vegas": 20.0, "vegasmc": 10.0}
+    sys_tol = {"vegas": 20.0, "vegasmc": 10.0, "mcmc": 10.0}  # test/bubble.jl:124, :131-133
     from catalog_params import bubble_exact
     exact = bubble_exact()
-    for alg in ("vegas", "vegasmc"):
+    for alg in ("vegas", "vegasmc", "mcmc"):
         T = Continuous(0.0, p["beta"], alpha=3.0, adapt=True)
         R = Continuous(0.0, 1.0, alpha=3.0, adapt=True)
         theta = Continuous(0.0, PI, alpha=3.0, adapt=True)
@@ -120,6 +121,17 @@ def test_bubble_with_resume():
         avg, std = result.mean[0], result.stdev[0]
         for idx in range(4):
             assert abs(avg[idx] - exact[idx]) < sys_tol[alg] * std[idx], (alg, avg, std, exact)
+
+
+def test_mcmc_constant_integrand_with_reweight_goal_and_many_chains():
+    # test/montecarlo.jl:16 (reweight_goal) ; many chains per block vs the reference's single chain
+    res = integrate("return 1.0;", var=(Continuous(0.0, 1.0),), dof=[[1]], neval=1e5, print=-1, solver="mcmc", reweight_goal=np.ones(2), seed=31)
+    check(res, 1.0)
+    one = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), dof=[[2], [3]], neval=4e5, solver="mcmc", nchain=1, seed=32)
+    many = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), dof=[[2], [3]], neval=1e8, solver="mcmc", seed=33)
+    check(one, [PI / 4.0, 4.0 * PI / 3.0 / 8])
+    check(many, [PI / 4.0, 4.0 * PI / 3.0 / 8], ratio=5.0)   # 1e8 steps: a burn-in bias of 1e-4 would show here
+    assert np.all(np.asarray(many.stdev) < 0.1 * np.asarray(one.stdev))
 
 
 def test_resume_keeps_trained_grid_and_improves_first_iteration():

@@ -200,6 +200,49 @@ def test_vegasmc_single_chain_is_the_reference_chain(oracle):
     np.testing.assert_allclose(got, ref, rtol=1e-9)
 
 
+@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "hypersphere", "bubble", "discrete2_composite", "singular2_composite"])
+@pytest.mark.parametrize("nchain", [1, 16])
+def test_mcmc_iteration_matches_oracle(oracle, name, nchain):
+    """row f1: the :mcmc chains (mcmc/montecarlo.jl:72-184, mcmc/updates.jl) against the oracle on the same
+    Philox streams; nchain = 1 is exactly the reference's one-chain-per-block walk over (integrand, variables)."""
+    c, cfg, eng, ocfg = make(name, oracle)
+    block, npb = 4, 3200
+    got = eng.iteration("mcmc", npb, 0, block, iteration=2, seed=SEED, nchain=nchain, thermal_ratio=0.1)
+    ocfg.set_thermal_ratio(0.1)
+    ref = ocfg.iteration(oracle.MCMC, c["oname"], c["ud"], npb, 0, block, 2, SEED, nchain=nchain)
+    gs, gh = hist_split(got, eng.nobs, cfg.N)
+    rs, rh = hist_split(ref, eng.nobs, cfg.N)
+    np.testing.assert_allclose(gs, rs, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(gh, rh, rtol=1e-9)   # unit weights: counts + the 1e-10 clearStatistics offsets
+
+
+def test_mcmc_custom_neighbor_graph_and_measurefreq(oracle):
+    """`neighbor` kwarg (configuration.jl:211-221: undirected 1-based edge list) and measurefreq (mcmc/montecarlo.jl:144)."""
+    cfg = mci.Configuration(var=mci.Continuous(-1.0, 1.0), dof=[[2], [3], [4]], neighbor=[(1, 4), (1, 2), (1, 3), (2, 3)], seed=SEED)
+    assert cfg.neighbor_lists() == [[1, 2, 3], [0, 2], [0, 1], [0]]
+    eng = mci.Engine(cfg, mci.catalog.hypersphere(3))
+    ocfg = oracle.Config([ocont(0, -1.0, 1.0)], [[2], [3], [4]])
+    ocfg.set_neighbor(cfg.neighbor_lists())
+    ocfg.set_thermal_ratio(0.25)
+    got = eng.iteration("mcmc", 4000, 0, 2, iteration=0, seed=SEED, nchain=4, measurefreq=3, thermal_ratio=0.25)
+    ref = ocfg.iteration(oracle.MCMC, "hypersphere", [3.0], 4000, 0, 2, 0, SEED, nchain=4, measurefreq=3)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+
+
+def test_mcmc_full_integrate_matches_oracle(oracle):
+    """the whole :mcmc loop (doReweight! main.jl:183, train!, Result) inside the library vs the oracle's loop."""
+    c, cfg, eng, ocfg = make("sphere2_padding", oracle)
+    goal = [1.0, 2.0, 1.0]
+    r = eng.integrate("mcmc", neval=32000, niter=5, block=8, seed=SEED, nchain=2, reweight_goal=goal)
+    ocfg.set_reweight_goal(goal)
+    o = ocfg.integrate(oracle.MCMC, "sphere2", None, neval=32000, niter=5, block=8, seed=SEED, nchain=2)
+    # accept/reject decisions are discrete: rounding-level grid differences either leave an iteration
+    # bit-compatible or change a decision; five iterations at this size stay on the same trajectory
+    np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6)
+    np.testing.assert_allclose(r["iter_std"], o["iter_std"], rtol=1e-4)
+    np.testing.assert_allclose(eng.reweight(), ocfg.reweight, rtol=1e-9)
+
+
 def test_user_snippet_matches_gcc_compiled_oracle(oracle):
     """an arbitrary user integrand: the same C text JIT-compiled for gfx950 and gcc-compiled for the oracle."""
     body = "w[0] = exp(-x[0]) * cos(3.0 * x[1]) + ud[0] * x[2] * x[2];"

@@ -225,3 +225,39 @@ def test_clear_and_add_statistics(oracle):
     for i in range(3):
         np.testing.assert_allclose(a.hist(i), 3.0 * (1.1 + 0.1 * i))
     assert a.c.normalization == 3.0 and a.c.neval == 30
+
+
+# ---------------------------------------------------------------------------------------------
+# :mcmc primitives (sampler.jl remove!/swap!, configuration.jl _neighbor, mcmc burn-in)
+# ---------------------------------------------------------------------------------------------
+def test_default_neighbor_graph(oracle):
+    # configuration.jl:203-208, 0-based; the last index is the normalisation integrand
+    def nb(n):
+        return oracle.Config([dict(kind=0, pool=0, lower=0.0, upper=1.0)], [[1]] * n).neighbor()
+    assert nb(1) == [[1], [0]]                         # Nd = 2: neighbor[1] = [2], neighbor[end] = [1]
+    assert nb(2) == [[2, 1], [0], [0]]                 # Nd = 3: [Nd, 2], [Nd-2], [1]
+    assert nb(4) == [[4, 1], [0, 2], [1, 3], [2], [0]]
+
+
+def test_remove_is_the_probability_of_the_slot_and_swap_is_an_involution(oracle):
+    cfg = oracle.Config([dict(kind=0, pool=0, lower=0.0, upper=1.0, npts=4, grid=[0.0, 0.1, 0.4, 1.0]),
+                         dict(kind=1, pool=0, lower=1, upper=6, distribution=[1, 2, 3, 4, 5, 6])], [[3]])
+    for idx, (u0, u1) in enumerate([(0.2, 0.05), (0.5, 0.5), (0.9, 0.99)], start=1):
+        inv = cfg.pool_create(0, idx, [u0, u1])        # create! returns 1/prob (sampler.jl:304, :21)
+        assert cfg.pool_remove(0, idx) == pytest.approx(1.0 / inv, rel=1e-15)   # remove! returns prob (:322, :39)
+    before = (cfg.pool_data(0).copy(), cfg.pool_data(1).copy(), cfg.pool_prob(0).copy(), cfg.pool_gidx(0).copy())
+    assert cfg.pool_swap(0, 1, 3) == 1.0
+    assert cfg.pool_data(0)[0] == before[0][2] and cfg.pool_data(0)[2] == before[0][0]
+    assert cfg.pool_data(1)[0] == before[1][2] and cfg.pool_gidx(0)[0] == before[3][2]
+    cfg.pool_swap(0, 1, 3)                              # swapRollback! == swap!  (sampler.jl:403-408)
+    after = (cfg.pool_data(0), cfg.pool_data(1), cfg.pool_prob(0), cfg.pool_gidx(0))
+    for a, b in zip(before, after):
+        assert np.array_equal(a, b)
+
+
+def test_mcmc_burnin_rule(oracle):
+    L = oracle.lib()
+    assert L.mcio_mcmc_burnin(62500, 1, 3, 3, 1, 0.1) == 6250          # mcmc/montecarlo.jl:133 for the reference's chain
+    assert L.mcio_mcmc_burnin(62500, 1, 3, 3, 1, 0.0) == 0
+    assert L.mcio_mcmc_burnin(4000, 8, 3, 3, 1, 0.1) == 400            # floor 64*3 + 16*2*3 = 288 < 400
+    assert L.mcio_mcmc_burnin(1000, 8, 12, 5, 1, 0.1) == 500           # floor 928 capped at steps/2

@@ -125,3 +125,64 @@ def test_bubble_vegas_and_vegasmc(oracle):
         r2 = cfg.integrate(s, "bubble", ud, neval=1000000, niter=1, block=64, seed=22)  # resume, test/bubble.jl:111-113
         for k in range(4):
             assert abs(r2["mean"][k] - exact[k]) < ratio * r2["stdev"][k], (s, k, r2["mean"], r2["stdev"], exact)
+
+
+# ---------------------------------------------------------------------------------------------
+# :mcmc solver -- the reference's battery for it (test/montecarlo.jl:262-296), 7 sigma
+# ---------------------------------------------------------------------------------------------
+def test_mcmc_sphere1(oracle):
+    cfg = oracle.Config([cont()], [[2]])
+    check(cfg.integrate(oracle.MCMC, "sphere1", None, neval=200000, seed=31), PI / 4)
+
+
+@pytest.mark.parametrize("offset", [0, 2])
+def test_mcmc_sphere2(oracle, offset):
+    cfg = oracle.Config([cont()], [[2], [3]], pool_offset=[offset])
+    check(cfg.integrate(oracle.MCMC, "sphere2", None, neval=200000, seed=32 + offset), [PI / 4, 4 * PI / 3 / 8])
+
+
+def test_mcmc_discrete_and_composite(oracle):
+    check(oracle.Config([disc(0, 1, 3)], [[1]]).integrate(oracle.MCMC, "discrete_id", None, neval=200000, seed=33), 6.0)
+    check(oracle.Config([disc(0, 1, 3), disc(0, 1, 4)], [[1]]).integrate(oracle.MCMC, "one", None, neval=200000, seed=34), 12.0)
+
+
+def test_mcmc_singular(oracle):
+    check(oracle.Config([cont()], [[1]]).integrate(oracle.MCMC, "log_over_sqrt", None, neval=200000, seed=35), -4.0)
+    check(oracle.Config([cont(0, 0.0, PI)], [[3]]).integrate(oracle.MCMC, "singular2", None, neval=200000, seed=36), 1.3932)
+    check(oracle.Config([cont(0, 0.0, PI)] * 3, [[1]]).integrate(oracle.MCMC, "singular2", None, neval=200000, seed=37), 1.3932)
+
+
+def test_mcmc_hypersphere(oracle):
+    cfg = oracle.Config([cont(0, -1.0, 1.0)], [[2], [3], [4]])
+    check(cfg.integrate(oracle.MCMC, "hypersphere", [3.0], neval=200000, seed=38), [0.9230, 0.94724, 0.96118])
+
+
+def test_mcmc_constant_integrand_with_reweight_goal(oracle):
+    # test/montecarlo.jl:16: integrate((idx, x, c) -> 1.0; dof=[[1]], solver=:mcmc, reweight_goal=ones(2))
+    cfg = oracle.Config([cont()], [[1]])
+    cfg.set_reweight_goal([1.0, 1.0])
+    r = cfg.integrate(oracle.MCMC, "one", None, neval=100000, seed=39)
+    check(r, 1.0)
+
+
+def test_mcmc_many_chains_agree_with_single_chain(oracle):
+    # the many-chain decomposition (this engine's own) against the reference's single chain, same integrand
+    one = oracle.Config([cont()], [[2], [3]]).integrate(oracle.MCMC, "sphere2", None, neval=400000, seed=40, nchain=1)
+    many = oracle.Config([cont()], [[2], [3]]).integrate(oracle.MCMC, "sphere2", None, neval=400000, seed=40, nchain=8)
+    for k in range(2):
+        assert abs(one["mean"][k] - many["mean"][k]) < 5 * math.hypot(one["stdev"][k], many["stdev"][k])
+    check(many, [PI / 4, 4 * PI / 3 / 8])
+
+
+def test_mcmc_bubble(oracle):
+    # test/bubble.jl:131: run(Steps, :mcmc, 10.0) -- 10 sigma band
+    import catalog_params as cp
+    ud, exact = cp.bubble_userdata(), cp.bubble_exact()
+    beta = ud[1]
+    leaves = [cont(0, 0.0, 1.0, alpha=3.0), cont(1, 0.0, PI, alpha=3.0), cont(2, 0.0, 2 * PI, alpha=3.0),
+              cont(3, 0.0, beta, alpha=3.0), disc(4, 1, 4, adapt=False)]
+    cfg = oracle.Config(leaves, [[1, 1, 1, 1, 1]], obs_nbin=[4], obs_bin_draw=[4])
+    cfg.integrate(oracle.MCMC, "bubble", ud, neval=100000, block=8, seed=41)
+    r2 = cfg.integrate(oracle.MCMC, "bubble", ud, neval=1000000, niter=1, block=64, seed=42)
+    for k in range(4):
+        assert abs(r2["mean"][k] - exact[k]) < 10.0 * r2["stdev"][k], (k, r2["mean"], r2["stdev"], exact)

@@ -17,7 +17,7 @@ PI = math.pi
 
 def run(name, cfg, f, solver, neval, exact, measure=None, niter_train=5, niter=5, nchain=0):
     eng = mci.Engine(cfg, f, measure=measure)
-    eng.compile()
+    eng.compile(solver)
     eng.integrate(solver, neval=neval, niter=niter_train, block=16, seed=1, nchain=nchain)
     r = eng.integrate(solver, neval=neval, niter=niter, block=16, seed=1, first_iteration=niter_train, ignore=0, nchain=nchain)
     ms, wg, th = eng.kernel_times_ms(niter)
@@ -28,7 +28,15 @@ def run(name, cfg, f, solver, neval, exact, measure=None, niter_train=5, niter=5
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c2i", "c4", "c3v", "c3mc", "c1"]
+    which = sys.argv[1:] or ["c2", "c2i", "c4", "c3v", "c3mc", "c5", "c1"]
+    if "c5" in which:  # BASELINE configs[4]: 4 integrals on a 12-D pool, :mcmc
+        ex = [math.erf(5.0) ** d for d in (3, 6, 9, 12)]
+        run("C5 nested gauss mcmc 1e8", mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]]), mci.catalog.nested_gauss(),
+            "mcmc", 10**8, ex)
+        run("C5 nested gauss vegasmc 1e8", mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]]), mci.catalog.nested_gauss(),
+            "vegasmc", 10**8, ex)
+        run("C5 nested gauss vegas 1e8", mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]]), mci.catalog.nested_gauss(),
+            "vegas", 10**8, ex)
     if "c1" in which:
         run("C1 log/sqrt 1e7", mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]]), mci.catalog.log_over_sqrt(), "vegas", 10**7, -4.0)
     if "c2" in which:

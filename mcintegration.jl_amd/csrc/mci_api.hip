@@ -121,6 +121,7 @@ struct mci_problem {
     int last_wg = 0, last_threads = 0, last_nblocks = 0;
     int log_row = 0;
     static const int kGroups = 32;
+    static const int64_t kChainFill = 131072; // chains per GPU that keep 2 waves on each of the 1024 SIMDs
 };
 
 namespace {
@@ -145,15 +146,15 @@ int upload(mci_problem *p) {
 int ensure_capacity(mci_problem *p, int64_t nwg, int64_t nblocks) {
     const auto &s = p->shape;
     if (nwg > p->cap_wg) {
-        if (p->d_part_cols) hipFree(p->d_part_cols);
-        if (p->d_part_hist) hipFree(p->d_part_hist);
+        if (p->d_part_cols) (void)hipFree(p->d_part_cols);
+        if (p->d_part_hist) (void)hipFree(p->d_part_hist);
         p->d_part_cols = p->d_part_hist = nullptr;
         HIPCHK(hipMalloc((void **)&p->d_part_cols, (size_t)nwg * s.ncols * sizeof(double)));
         if (s.table_mode == 0 || s.table_mode == 3) HIPCHK(hipMalloc((void **)&p->d_part_hist, (size_t)nwg * (s.nbin ? s.nbin : 1) * sizeof(double)));
         p->cap_wg = nwg;
     }
     if (nblocks > p->cap_blocks) {
-        if (p->d_scratch) hipFree(p->d_scratch);
+        if (p->d_scratch) (void)hipFree(p->d_scratch);
         p->d_scratch = nullptr;
         HIPCHK(hipMalloc((void **)&p->d_scratch, (size_t)nblocks * s.ncols * sizeof(double)));
         p->cap_blocks = nblocks;
@@ -225,7 +226,7 @@ int mci_ctx_create(int32_t device, mci_ctx **out) {
 int mci_ctx_destroy(mci_ctx *c) {
     if (!c) return MCI_OK;
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return MCI_OK;
 }
@@ -517,12 +518,12 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
 int mci_problem_destroy(mci_problem *p) {
     if (!p) return MCI_OK;
     if (!p->ctx->offline) {
-        hipStreamSynchronize(p->ctx->stream);
+        (void)hipStreamSynchronize(p->ctx->stream);
         for (void *q : {(void *)p->d_edges, (void *)p->d_dacc, (void *)p->d_ddist, (void *)p->d_reweight, (void *)p->d_ud,
                         (void *)p->d_part_cols, (void *)p->d_part_hist, (void *)p->d_ghist, (void *)p->d_stage1,
                         (void *)p->d_packed, (void *)p->d_scratch, (void *)p->d_iterlog, (void *)p->d_dump,
                         (void *)p->d_status, (void *)p->d_leaves})
-            if (q) hipFree(q);
+            if (q) (void)hipFree(q);
         for (int k = 0; k < 3; ++k)
             if (p->module[k]) (void)hipModuleUnload(p->module[k]);
         if (p->d_goal) (void)hipFree(p->d_goal);
@@ -538,7 +539,7 @@ int mci_set_integrand_source(mci_problem *p, const char *body, const double *ud,
     p->h_ud.assign(ud, ud + (nud > 0 ? nud : 0));
     drop_modules(p);
     if (!p->ctx->offline) {
-        if (p->d_ud) hipFree(p->d_ud);
+        if (p->d_ud) (void)hipFree(p->d_ud);
         p->d_ud = nullptr;
         HIPCHK(hipMalloc((void **)&p->d_ud, (p->h_ud.size() ? p->h_ud.size() : 1) * sizeof(double)));
         if (p->h_ud.size()) HIPCHK(hipMemcpy(p->d_ud, p->h_ud.data(), p->h_ud.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -616,11 +617,13 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     if (solver == MCI_VEGASMC) {
         int nslots = 0; // (pool, slot) pairs changeVariable can pick (updates.jl:50,:58)
         for (int v = 0; v < p->npool; ++v) nslots += p->maxdof[v];
-        if (nchain <= 0) { // auto: chains long enough that the burn-in floor below wastes <= 1/8 of the steps
-            const int64_t target = 256 * (int64_t)nslots > 1024 ? 256 * (int64_t)nslots : 1024;
-            nchain = nevalperblock / target;
+        if (nchain <= 0) { // auto (measured, tools/chain_sweep.py): as many chains as keep 2 waves per SIMD busy
+            // (kChainFill lanes per GPU), but never shorter than 4 burn-in floors (>= 3/4 of the steps measured)
+            const int64_t fl = 32 * (int64_t)nslots > 64 ? 32 * (int64_t)nslots : 64;
+            nchain = nevalperblock / (4 * fl);
+            const int64_t cap = mci_problem::kChainFill / nblocks > 64 ? mci_problem::kChainFill / nblocks : 64;
+            if (nchain > cap) nchain = cap;
             if (nchain < 1) nchain = 1;
-            if (nchain > 16384) nchain = 16384;
         }
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
         burnin = mci_chain_burnin(nevalperblock / nchain, nchain, nslots);
@@ -629,12 +632,12 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         int nslots = 0;
         for (int v = 0; v < p->npool; ++v) nslots += p->maxdof[v];
         if (!(thermal_ratio >= 0.0)) return fail(MCI_ERR_INVALID, "thermal_ratio must be non-negative");
-        if (nchain <= 0) { // auto: chains long enough that the burn-in floor costs <= 1/8 on top of the measured steps
+        if (nchain <= 0) { // auto: fill the GPU, but keep >= 2 burn-in floors of measured steps per chain (>= 2/3 measured)
             const int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(p->npool + 1) * (p->ni + 1);
-            const int64_t target = 8 * fl > 2048 ? 8 * fl : 2048;
-            nchain = nevalperblock / target;
+            nchain = nevalperblock / (2 * fl);
+            const int64_t cap = mci_problem::kChainFill / nblocks > 64 ? mci_problem::kChainFill / nblocks : 64;
+            if (nchain > cap) nchain = cap;
             if (nchain < 1) nchain = 1;
-            if (nchain > 16384) nchain = 16384;
         }
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
         nburn = mci_mcmc_burnin(nevalperblock / nchain, nchain, nslots, p->ni + 1, p->npool, thermal_ratio);
@@ -726,7 +729,7 @@ int mci_iteration_finish(mci_problem *p, int32_t solver, int64_t block_total, in
         if (p->d_iterlog) {
             HIPCHK(hipMemcpyAsync(n, p->d_iterlog, (size_t)p->cap_iter * p->nstat * sizeof(double), hipMemcpyDeviceToDevice, p->ctx->stream));
             HIPCHK(hipStreamSynchronize(p->ctx->stream));
-            hipFree(p->d_iterlog);
+            (void)hipFree(p->d_iterlog);
         }
         p->d_iterlog = n;
         p->cap_iter = ncap;
@@ -936,7 +939,7 @@ int mci_sample_dump(mci_problem *p, int32_t iteration, uint64_t seed, int64_t ne
     const auto &s = p->shape;
     const int64_t per = s.ndraw + 1 + s.ni;
     if (n * per > p->cap_dump) {
-        if (p->d_dump) hipFree(p->d_dump);
+        if (p->d_dump) (void)hipFree(p->d_dump);
         p->d_dump = nullptr;
         HIPCHK(hipMalloc((void **)&p->d_dump, (size_t)(n * per) * sizeof(double)));
         p->cap_dump = n * per;

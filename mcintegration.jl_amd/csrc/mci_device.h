@@ -490,6 +490,41 @@ template <class Cfg, int I> __device__ __forceinline__ double own_prob(const Cha
     return p;
 }
 
+
+// Chain-state access with a RUN-TIME slot and compile-time (pool, leaf).  Written as value selects on purpose:
+// stores under data-dependent branches get sunk by LLVM into a single store through a phi of addresses, which
+// would move the register-resident chain state into scratch memory.
+template <class Cfg, int V, int L> __device__ __forceinline__ void get_slot(const Chain<Cfg> &c, int slot, double &x, double &p, int &b) {
+    constexpr int md = Cfg::pool_maxdof(V), nl = Cfg::pool_nleaf(V), k00 = Cfg::pool_first_draw(V);
+    x = 0.0;
+    p = 1.0;
+    b = 0;
+    static_for<0, md>([&](auto S) {
+        constexpr int k = k00 + decltype(S)::value * nl + L;
+        const bool hit = slot == decltype(S)::value;
+        x = hit ? c.x[k] : x;
+        p = hit ? c.prob[k] : p;
+        b = hit ? c.bin[k] : b;
+    });
+}
+template <class Cfg, int V, int L> __device__ __forceinline__ void put_slot(Chain<Cfg> &c, int slot, double x, double p, int b) {
+    constexpr int md = Cfg::pool_maxdof(V), nl = Cfg::pool_nleaf(V), k00 = Cfg::pool_first_draw(V);
+    static_for<0, md>([&](auto S) {
+        constexpr int k = k00 + decltype(S)::value * nl + L;
+        const bool hit = slot == decltype(S)::value;
+        c.x[k] = hit ? x : c.x[k];
+        c.prob[k] = hit ? p : c.prob[k];
+        c.bin[k] = hit ? b : c.bin[k];
+    });
+}
+// one leaf draw for pool V, leaf L (every slot of a pool shares the leaf's table): x, prob = 1/(raw*scale), bin
+template <class Cfg, int V, int L> __device__ __forceinline__ void draw_pool_leaf(const Tables<Cfg> &t, double y, double &x, double &p, int &b) {
+    constexpr int k = Cfg::pool_first_draw(V) + L; // slot 0 of the pool: same leaf as every other slot
+    double raw;
+    draw_leaf<Cfg, k>(t, y, x, raw, b);
+    p = 1.0 / (raw * jac_scale<Cfg>(k));
+}
+
 template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NI = Cfg::NI, NORMI = Cfg::NI;
@@ -565,25 +600,21 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                         active = true;
                         int slot = (int)(uslot * (double)md); // :58
                         if (slot >= md) slot = md - 1;
-                        static_for<0, md>([&](auto S) {
-                            constexpr int sl = decltype(S)::value;
-                            if (slot == sl) {
-                                static_for<0, nl>([&](auto Lf) {
-                                    constexpr int l = decltype(Lf)::value;
-                                    constexpr int k = k00 + sl * nl + l;
-                                    constexpr int kk = 3 + l; // RNG draw index within the step
-                                    double y;
-                                    if constexpr (kk == 3) y = u01(r1.z, r1.w);
-                                    else {
-                                        const u32x4 rr = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(kk >> 1), st_step, k0, k1);
-                                        y = (kk & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
-                                    }
-                                    double raw;
-                                    draw_leaf<Cfg, k>(t, y, n.x[k], raw, n.bin[k]); // shift!  sampler.jl:336-386, :57-71
-                                    n.prob[k] = 1.0 / (raw * jac_scale<Cfg>(k));
-                                    prop *= c.prob[k] / n.prob[k];                  // 1/prob_ratio  sampler.jl:385, :70
-                                });
+                        static_for<0, nl>([&](auto Lf) {
+                            constexpr int l = decltype(Lf)::value;
+                            constexpr int kk = 3 + l; // RNG draw index within the step
+                            double y;
+                            if constexpr (kk == 3) y = u01(r1.z, r1.w);
+                            else {
+                                const u32x4 rr = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(kk >> 1), st_step, k0, k1);
+                                y = (kk & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
                             }
+                            double xo, po, xn, pn;
+                            int bo, bn;
+                            get_slot<Cfg, v, l>(c, slot, xo, po, bo);
+                            draw_pool_leaf<Cfg, v, l>(t, y, xn, pn, bn); // shift!  sampler.jl:336-386, :57-71
+                            put_slot<Cfg, v, l>(n, slot, xn, pn, bn);
+                            prop *= po / pn;                              // 1/prob_ratio  sampler.jl:385, :70
                         });
                     }
                 }
@@ -677,6 +708,11 @@ template <int K> __device__ __forceinline__ double step_uniform(u64 sidx, u32 st
         return (K & 1) ? u01(r.z, r.w) : u01(r.x, r.y);
     }
 }
+// the same with a run-time k (k >= 5: the shifted slot of changeVariable is a run-time value)
+__device__ __forceinline__ double step_uniform_dyn(int k, u64 sidx, u32 stream, u32 k0, u32 k1) {
+    const u32x4 r = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(k >> 1), stream, k0, k1);
+    return (k & 1) ? u01(r.z, r.w) : u01(r.x, r.y);
+}
 // histogram add of one draw with the table-mode dispatch of hist_update
 template <class Cfg, int K> __device__ __forceinline__ void hist_add(int bin, double wk, double *sH, double *gH, int tile) {
     constexpr int leaf = Cfg::draw_leaf(K);
@@ -756,7 +792,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
 
         for (i64 it = 1; it <= steps + nburn; ++it) { // :134
             const u64 sidx = (g << 32) | (u64)(it - 1);
-            static_for<0, ND>([&](auto I) { if (curr == decltype(I)::value) extra[XV + decltype(I)::value] += 1.0; }); // :136
+            static_for<0, ND>([&](auto I) { extra[XV + decltype(I)::value] += curr == decltype(I)::value ? 1.0 : 0.0; }); // :136
             const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
             const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
             const u32x4 r2 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 2u, st_step, k0, k1);
@@ -840,22 +876,15 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                             active = true;
                             static_for<0, NPOOL>([&](auto V) {
                                 constexpr int v = decltype(V)::value;
-                                constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
                                 if (vi == v) {
-                                    static_for<0, nl>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
+                                    static_for<0, Cfg::pool_nleaf(v)>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
                                         constexpr int l = decltype(Lf)::value;
-                                        double xa = 0.0, xb = 0.0, pa = 1.0, pb = 1.0;
-                                        int ba = 0, bb = 0;
-                                        static_for<0, md>([&](auto S) {
-                                            constexpr int k = k00 + decltype(S)::value * nl + l;
-                                            if (s1 == decltype(S)::value) { xa = c.x[k]; pa = c.prob[k]; ba = c.bin[k]; }
-                                            if (s2 == decltype(S)::value) { xb = c.x[k]; pb = c.prob[k]; bb = c.bin[k]; }
-                                        });
-                                        static_for<0, md>([&](auto S) {
-                                            constexpr int k = k00 + decltype(S)::value * nl + l;
-                                            if (s1 == decltype(S)::value) { n.x[k] = xb; n.prob[k] = pb; n.bin[k] = bb; }
-                                            if (s2 == decltype(S)::value) { n.x[k] = xa; n.prob[k] = pa; n.bin[k] = ba; }
-                                        });
+                                        double xa, xb, pa, pb;
+                                        int ba, bb;
+                                        get_slot<Cfg, v, l>(c, s1, xa, pa, ba);
+                                        get_slot<Cfg, v, l>(c, s2, xb, pb, bb);
+                                        put_slot<Cfg, v, l>(n, s1, xb, pb, bb);
+                                        put_slot<Cfg, v, l>(n, s2, xa, pa, ba);
                                     });
                                 }
                             });
@@ -873,18 +902,15 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                                 active = true;
                                 int slot = (int)(us1 * (double)cdv); // :83
                                 if (slot >= cdv) slot = cdv - 1;
-                                static_for<0, md>([&](auto S) {
-                                    constexpr int sl = decltype(S)::value;
-                                    if (slot == sl) {
-                                        static_for<0, nl>([&](auto Lf) { // shift!  sampler.jl:336-386, :57-71, :431-440
-                                            constexpr int k = k00 + sl * nl + decltype(Lf)::value;
-                                            const double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
-                                            double raw;
-                                            draw_leaf<Cfg, k>(t, y, n.x[k], raw, n.bin[k]);
-                                            n.prob[k] = 1.0 / (raw * jac_scale<Cfg>(k));
-                                            prop *= c.prob[k] / n.prob[k]; // 1/prob_ratio  sampler.jl:385, :70
-                                        });
-                                    }
+                                static_for<0, nl>([&](auto Lf) { // shift!  sampler.jl:336-386, :57-71, :431-440
+                                    constexpr int l = decltype(Lf)::value;
+                                    const double y = step_uniform_dyn(5 + k00 + slot * nl + l, sidx, st_step, k0, k1);
+                                    double xo, po, xn, pn;
+                                    int bo, bn;
+                                    get_slot<Cfg, v, l>(c, slot, xo, po, bo);
+                                    draw_pool_leaf<Cfg, v, l>(t, y, xn, pn, bn);
+                                    put_slot<Cfg, v, l>(n, slot, xn, pn, bn);
+                                    prop *= po / pn; // 1/prob_ratio  sampler.jl:385, :70
                                 });
                             }
                         }
@@ -896,9 +922,12 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                     const double newp = fabs(wn) * rw_sel(curr);         // :96, :137
                     const double R = prop * newp / probability;          // :97, :138
                     const int ut = upd == 1 ? 2 : 1;                     // first index of propose[., curr, vi]  :99, :140
-                    static_for<1, 3>([&](auto U) { if (ut == decltype(U)::value) extra[XP + decltype(U)::value] += 1.0; });
-                    if (uacc < R) {                                      // :100, :141
-                        static_for<1, 3>([&](auto U) { if (ut == decltype(U)::value) extra[XA + decltype(U)::value] += 1.0; });
+                    const bool ok = uacc < R;                            // :100, :141
+                    static_for<1, 3>([&](auto U) {
+                        extra[XP + decltype(U)::value] += ut == decltype(U)::value ? 1.0 : 0.0;
+                        extra[XA + decltype(U)::value] += (ok && ut == decltype(U)::value) ? 1.0 : 0.0;
+                    });
+                    if (ok) {
                         c = n;
                         weight = wn;
                         probability = newp;
@@ -917,13 +946,12 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                                 constexpr int k = decltype(K)::value;
                                 if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hist_add<Cfg, k>(c.bin[k], 1.0, sH, a.ghist, tile);
                             });
-                            if constexpr (Cfg::obs_bin_draw(i) < 0) {
-                                acc[i] += relw; // :164
-                            } else {
+                            if constexpr (Cfg::obs_bin_draw(i) >= 0) {
                                 const int b = c.bin[Cfg::obs_bin_draw(i)];
                                 if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw);
                             }
                         }
+                        if constexpr (Cfg::obs_bin_draw(i) < 0) acc[i] += curr == i ? relw : 0.0; // :164
                     });
                 } else {
                     extra[XN] += 1.0 / rw[NORMI]; // :158

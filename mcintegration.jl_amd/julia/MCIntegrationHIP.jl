@@ -1,5 +1,5 @@
 # MCIntegrationHIP.jl -- thin `ccall` binding of libmci_hip.so (include/mci.h) that re-creates the
-# reference's API names for the :vegas / :vegasmc path (reference src/MCIntegration.jl:20-47).
+# reference's API names for the :vegas / :vegasmc / :mcmc path (reference src/MCIntegration.jl:20-47).
 #
 # NOTE: `julia` is not available in the build image, so this file is syntax-reviewed only; it is the
 # reference-side binding INTEGRATION.md describes.  Everything numerical happens in the library.
@@ -10,7 +10,7 @@ export integrate, Configuration, Continuous, Discrete, CompositeVar, Result, Int
 const libmci = get(ENV, "MCI_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libmci_hip.so"))
 const MaxOrder = 16                         # reference src/distribution/distribution.jl:59
 const MCI_CONTINUOUS, MCI_DISCRETE = Int32(0), Int32(1)
-const SOLVER = Dict(:vegas => Int32(0), :vegasmc => Int32(1))
+const SOLVER = Dict(:vegas => Int32(0), :vegasmc => Int32(1), :mcmc => Int32(2))
 
 struct MCIError <: Exception
     code::Int
@@ -68,10 +68,12 @@ end
 struct ProblemDesc
     nleaf::Int32; leaves::Ptr{LeafDesc}; npool::Int32; nintegrand::Int32
     dof::Ptr{Int32}; obs_nbin::Ptr{Int32}; obs_bin_draw::Ptr{Int32}
+    neighbor_offsets::Ptr{Int32}; neighbor_list::Ptr{Int32}     # CSR, 0-based; both NULL = the reference default
 end
 struct IntegrateArgs
     solver::Int32; neval::Int64; niter::Int32; block::Int64; ignore::Int32; adapt::Int32; gamma::Float64
     measurefreq::Int64; seed::UInt64; nchain::Int64; first_iteration::Int32
+    thermal_ratio::Float64; reweight_goal::Ptr{Float64}
 end
 mutable struct ResultC
     niter::Int32; nobs::Int32
@@ -100,8 +102,22 @@ mutable struct Configuration
     iterations_done::Int
     problem::Ptr{Cvoid}
     key
+    neighbor::Union{Nothing,Vector{Vector{Int}}}    # 1-based like the reference; nothing = default (configuration.jl:203-208)
 end
-function Configuration(; var=(Continuous(0.0, 1.0),), dof=nothing, obs=nothing, seed=rand(1:1000000), userdata=nothing, kwargs...)
+function _neighbor(neighbor, Nd)                    # reference src/configuration.jl:201-227
+    neighbor === nothing && return nothing
+    if neighbor isa Vector{Tuple{Int,Int}}          # undirected edge list
+        adj = [Int[] for _ in 1:Nd]
+        for (a, b) in neighbor
+            b in adj[a] || push!(adj[a], b)
+            a in adj[b] || push!(adj[b], a)
+        end
+        return [sort(a) for a in adj]
+    end
+    @assert length(neighbor) == Nd "$Nd elements are expected for neighbor=$neighbor"
+    return [collect(Int, n) for n in neighbor]
+end
+function Configuration(; var=(Continuous(0.0, 1.0),), dof=nothing, obs=nothing, seed=rand(1:1000000), userdata=nothing, neighbor=nothing, kwargs...)
     var = var isa Tuple ? var : (var isa AbstractVector ? Tuple(var) : (var,))          # :116-122
     if dof === nothing
         dof = [ones(Int, length(var))]
@@ -117,7 +133,7 @@ function Configuration(; var=(Continuous(0.0, 1.0),), dof=nothing, obs=nothing, 
     end
     obs === nothing && (obs = zeros(length(dof)))
     @assert length(obs) == length(dof) "The number of observables should be equal to the number of integrands"
-    Configuration(var, dof, length(dof), [length(o) for o in obs], seed, userdata, 0, C_NULL, nothing)
+    Configuration(var, dof, length(dof), [length(o) for o in obs], seed, userdata, 0, C_NULL, nothing, _neighbor(neighbor, length(dof) + 1))
 end
 
 function draw_index(c::Configuration, pool::Int)          # 0-based flat draw of (pool, slot 1, leaf 1)
@@ -130,7 +146,7 @@ function draw_index(c::Configuration, pool::Int)          # 0-based flat draw of
 end
 
 function bind!(c::Configuration, f::Integrand, measure)
-    key = (f.body, f.userdata, measure)
+    key = (f.body, f.userdata, measure, c.neighbor)
     (c.problem != C_NULL && c.key == key) && return c.problem
     descs = LeafDesc[]
     keep = Any[]
@@ -146,9 +162,16 @@ function bind!(c::Configuration, f::Integrand, measure)
     dof = Int32[d[vi] for d in c.dof for vi in 1:length(c.var)]
     onb = Int32.(c.obs_nbin)
     obd = Int32[(measure isa bin_by && n > 1) ? draw_index(c, measure.pool) : -1 for n in c.obs_nbin]
+    nboff, nblist = Int32[], Int32[]
+    if c.neighbor !== nothing
+        nboff = Int32.(cumsum([0; length.(c.neighbor)]))
+        nblist = Int32[j - 1 for n in c.neighbor for j in n]
+    end
     p = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve descs dof onb obd keep begin
-        desc = Ref(ProblemDesc(length(descs), pointer(descs), length(c.var), c.N, pointer(dof), pointer(onb), pointer(obd)))
+    GC.@preserve descs dof onb obd keep nboff nblist begin
+        desc = Ref(ProblemDesc(length(descs), pointer(descs), length(c.var), c.N, pointer(dof), pointer(onb), pointer(obd),
+                               c.neighbor === nothing ? Ptr{Int32}(C_NULL) : pointer(nboff),
+                               c.neighbor === nothing ? Ptr{Int32}(C_NULL) : pointer(nblist)))
         check(ccall((:mci_problem_create, libmci), Cint, (Ptr{Cvoid}, Ptr{ProblemDesc}, Ptr{Ptr{Cvoid}}), context(), desc, p))
     end
     check(ccall((:mci_set_integrand_source, libmci), Cint, (Ptr{Cvoid}, Cstring, Ptr{Float64}, Int32),
@@ -180,6 +203,7 @@ Same keywords as the reference (src/main.jl:71-90); the loop of src/main.jl:142-
 """
 function integrate(integrand::Union{Integrand,AbstractString}; solver::Symbol=:vegasmc, config=nothing, neval=1e4, niter=10,
                    block=16, gamma=1.0, adapt=true, ignore::Int=adapt ? 1 : 0, measure=nothing, measurefreq::Int=1,
+                   thermal_ratio=0.1, reweight_goal::Union{Vector{Float64},Nothing}=nothing,
                    nchain=0, print=-1, verbose=-1, kwargs...)
     haskey(SOLVER, solver) || error("Solver $solver is not supported!")                  # main.jl:263
     config === nothing && (config = Configuration(; kwargs...))                          # main.jl:95-97
@@ -188,10 +212,12 @@ function integrate(integrand::Union{Integrand,AbstractString}; solver::Symbol=:v
     nobs = sum(config.obs_nbin)
     im, ie = zeros(nobs, niter), zeros(nobs, niter)           # row-major [niter][nobs] on the C side
     m, s, c2 = zeros(nobs), zeros(nobs), zeros(nobs)
+    goal = reweight_goal === nothing ? Float64[] : reweight_goal
     args = Ref(IntegrateArgs(SOLVER[solver], Int64(neval), niter, block, ignore, adapt, gamma, measurefreq, UInt64(config.seed),
-                             nchain, config.iterations_done))
+                             nchain, config.iterations_done, thermal_ratio,
+                             reweight_goal === nothing ? Ptr{Float64}(C_NULL) : pointer(goal)))
     res = ResultC(niter, nobs, pointer(im), pointer(ie), pointer(m), pointer(s), pointer(c2), 0, 0.0)
-    GC.@preserve im ie m s c2 check(ccall((:mci_integrate, libmci), Cint, (Ptr{Cvoid}, Ptr{IntegrateArgs}, Ref{ResultC}), prob, args, res))
+    GC.@preserve im ie m s c2 goal check(ccall((:mci_integrate, libmci), Cint, (Ptr{Cvoid}, Ptr{IntegrateArgs}, Ref{ResultC}), prob, args, res))
     config.iterations_done += niter
     r = Result(m, s, c2, res.neval, ignore, config, permutedims(im), permutedims(ie))
     max(print, verbose) >= 0 && report(r)

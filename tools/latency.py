@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Development tool (GPU box): per-iteration wall time of the library loop (mci_integrate) at the reference's
+typical sizes (neval 1e4..1e7): launch-bound regime."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import mcintegration_jl_amd as mci
+
+if __name__ == "__main__":
+    for solver in ("vegas", "vegasmc", "mcmc"):
+        for neval in (10**4, 10**5, 10**6, 10**7):
+            cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
+            eng = mci.Engine(cfg, mci.catalog.x2y2())
+            eng.integrate(solver, neval=neval, niter=3, block=16, seed=1)
+            t0 = time.perf_counter()
+            r = eng.integrate(solver, neval=neval, niter=50, block=16, seed=1, first_iteration=3)
+            dt = time.perf_counter() - t0
+            ms, wg, th = eng.kernel_times_ms(50)
+            print("%-8s neval=%-9d  %8.1f us/iteration (library clock %8.1f)  kernel %8.1f us  wg=%d  -> %8.1f Msamples/s   mean %.6f +- %.1e" % (
+                solver, neval, dt / 50 * 1e6, r["seconds"] / 50 * 1e6, float(np.median(ms)) * 1e3, wg, neval / (dt / 50) / 1e6, r["mean"][0], r["stdev"][0]), flush=True)

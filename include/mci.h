@@ -158,6 +158,16 @@ int mci_set_distribution(mci_problem *prob, int32_t leaf, const double *distribu
 int mci_get_reweight(mci_problem *prob, double *out, int32_t n);
 int mci_set_reweight(mci_problem *prob, const double *in, int32_t n);
 int mci_set_reweight_goal(mci_problem *prob, const double *goal, int32_t n); /* main.jl:81; NULL/0 clears */
+/* config.propose / config.accept of the last iteration, summed over this rank's blocks (the numbers behind
+ * report(config), configuration.jl:345-464), n = max(npool, 3) entries each.  vegasmc: entry vi = propose[2,1,vi]
+ * (vegas_mc/updates.jl:90-92); mcmc: entries 0,1,2 = changeIntegrand, changeVariable, swapVariable summed over
+ * their (integrand, variable) indices (mcmc/updates.jl:48, :99, :140). */
+int mci_get_acceptance(mci_problem *prob, double *propose, double *accept, int32_t n);
+/* resume across processes: what train!/doReweight! have learned -- grids, distributions, reweight --
+ * as a small self-describing binary file ("MCISTATE", version 1).  The reference keeps this state only in memory
+ * (`config = res.config`, docs/src/index.md:129). */
+int mci_save_state(mci_problem *prob, const char *path);
+int mci_load_state(mci_problem *prob, const char *path);
 /* Dist.train! on the histograms currently in the packed buffer (variable.jl:206-239, :369-382) */
 int mci_train(mci_problem *prob);
 /* the adaptive map alone (sampler.jl:293-305, :13-22) + integrand: first `n` samples of block `block_index`

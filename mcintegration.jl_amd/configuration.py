@@ -71,12 +71,26 @@ class Configuration:
         self.iterations_done = 0     # RNG stream offset for resumed runs
         self._engine = None
         self._engine_key = None
+        self._pending_state = None
         # flat leaves
         self.leaves, self.leaf_pool = [], []
         for vi, v in enumerate(var):
             for leaf in (v.vars if isinstance(v, CompositeVar) else (v,)):
                 self.leaves.append(leaf)
                 self.leaf_pool.append(vi)
+
+    # ---- resume across processes: trained grids / distributions / reweight <-> MCISTATE file ----
+    def save(self, path):
+        assert self._engine is not None, "nothing trained yet: run integrate(...) first"
+        self._engine.save_state(path)
+
+    def load(self, path):
+        """restore a state written by save(); applied when the engine is (re)created by integrate(config=...)"""
+        self._pending_state = str(path)
+        if self._engine is not None:
+            self._engine.load_state(path)
+            self._pending_state = None
+        return self
 
     def neighbor_lists(self):
         """`neighbor` kwarg normalised like _neighbor (configuration.jl:201-227) to 0-based lists per integrand

@@ -10,8 +10,10 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <link.h>
 #include <cmath>
 #include <cstdarg>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -53,9 +55,24 @@ struct Rccl {
 Rccl g_rccl;
 const int kNcclFloat64 = 8, kNcclSum = 0; // ncclDouble, ncclSum (rccl.h)
 
+// If the host process already carries an RCCL (PyTorch-ROCm bundles its own and resolves it through its rpath),
+// bind to THAT copy: two RCCL instances in one process would each open their own IPC/proxy state on the same GPUs.
+int find_loaded_rccl(struct dl_phdr_info *info, size_t, void *out) {
+    const char *n = info->dlpi_name;
+    if (n && strstr(n, "librccl.so")) {
+        *(std::string *)out = n;
+        return 1;
+    }
+    return 0;
+}
+
 int rccl_load() {
     if (g_rccl.h) return MCI_OK;
-    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    void *h = nullptr;
+    std::string loaded;
+    dl_iterate_phdr(find_loaded_rccl, &loaded);
+    if (!loaded.empty()) h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return fail(MCI_ERR_COMM, "cannot load librccl.so: %s", dlerror());
     g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
@@ -112,6 +129,7 @@ struct mci_problem {
     bool compiled[3] = {false, false, false};
     std::vector<double> h_goal; // reweight_goal (main.jl:81); empty = none
     double *d_goal = nullptr;
+    double *d_pa = nullptr; // [2*NPA] propose | accept of the last iteration (this rank)
     int threads = 256, wg_per_block = 0; // 0 = auto
     int train_serial = 0; // MCI_TRAIN_SERIAL=1: refinement walk as the reference's serial recurrence (diagnostic)
     // last launch
@@ -502,6 +520,8 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         HIPCHK(hipMalloc((void **)&p->d_ghist, (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
         HIPCHK(hipMemset(p->d_ghist, 0, (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
         HIPCHK(hipMalloc((void **)&p->d_stage1, (size_t)mci_problem::kGroups * (s.nbin ? s.nbin : 1) * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&p->d_pa, (size_t)s.ncols * sizeof(double)));
+        HIPCHK(hipMemset(p->d_pa, 0, (size_t)s.ncols * sizeof(double)));
         HIPCHK(hipMalloc((void **)&p->d_status, sizeof(int)));
         HIPCHK(hipMemset(p->d_status, 0, sizeof(int)));
         std::vector<mci::LeafDev> ld;
@@ -527,6 +547,7 @@ int mci_problem_destroy(mci_problem *p) {
         for (int k = 0; k < 3; ++k)
             if (p->module[k]) (void)hipModuleUnload(p->module[k]);
         if (p->d_goal) (void)hipFree(p->d_goal);
+        if (p->d_pa) (void)hipFree(p->d_pa);
         for (auto &e : p->evs) (void)hipEventDestroy(e);
     }
     delete p;
@@ -694,7 +715,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
                            (int)mci_problem::kGroups, p->d_stage1);
     hipLaunchKernelGGL(mci::k_finalize, dim3(nb256 + 1), dim3(256), 0, st, p->d_part_cols, s.ncols, s.nobs, s.ni, (int)nblocks, wpb,
                        p->d_stage1, (int)mci_problem::kGroups, p->d_ghist, hist_lds ? 0 : 1, s.nbin, p->d_packed, p->d_status,
-                       p->d_scratch);
+                       p->d_scratch, p->d_pa);
     HIPCHK(hipGetLastError());
     return MCI_OK;
 }
@@ -915,6 +936,18 @@ int mci_set_reweight(mci_problem *p, const double *in, int32_t n) {
     return MCI_OK;
 }
 
+int mci_get_acceptance(mci_problem *p, double *propose, double *accept, int32_t n) {
+    const int npa = p->npool > 3 ? p->npool : 3;
+    if (n != npa) return fail(MCI_ERR_INVALID, "propose/accept have %d entries", npa);
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    std::vector<double> h(2 * npa);
+    HIPCHK(hipMemcpyAsync(h.data(), p->d_pa, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    if (propose) memcpy(propose, h.data(), npa * sizeof(double));
+    if (accept) memcpy(accept, h.data() + npa, npa * sizeof(double));
+    return MCI_OK;
+}
+
 int mci_set_reweight_goal(mci_problem *p, const double *goal, int32_t n) {
     if (!goal || n == 0) {
         p->h_goal.clear();
@@ -927,6 +960,78 @@ int mci_set_reweight_goal(mci_problem *p, const double *goal, int32_t n) {
     HIPCHK(hipMemcpyAsync(p->d_goal, p->h_goal.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     return MCI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// resume across processes: the reference keeps trained state only in memory (`config = res.config`,
+// docs/src/index.md:129) and defines no file format; this is a small self-describing binary dump of what
+// `train!` and `doReweight!` have learned: grids, distributions, reweight.
+//   "MCISTATE" | u32 version | u32 nleaf | u32 ni | per leaf: u32 kind, u32 n | f64 reweight[ni+1] |
+//   per leaf: f64 grid[n]  (Continuous)  or  f64 distribution[n]  (Discrete)
+// ---------------------------------------------------------------------------------------------------
+int mci_save_state(mci_problem *p, const char *path) {
+    if (!p || !path) return fail(MCI_ERR_INVALID, "NULL argument");
+    std::vector<double> rw(p->ni + 1);
+    int rc = mci_get_reweight(p, rw.data(), p->ni + 1);
+    if (rc) return rc;
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(MCI_ERR_INVALID, "cannot open %s for writing", path);
+    const uint32_t hdr[3] = {1u, (uint32_t)p->leaves.size(), (uint32_t)p->ni};
+    bool ok = fwrite("MCISTATE", 1, 8, f) == 8 && fwrite(hdr, sizeof(uint32_t), 3, f) == 3;
+    for (auto &L : p->leaves) {
+        const uint32_t kn[2] = {(uint32_t)L.kind, (uint32_t)(L.kind == MCI_CONTINUOUS ? L.npts : L.nbin)};
+        ok = ok && fwrite(kn, sizeof(uint32_t), 2, f) == 2;
+    }
+    ok = ok && fwrite(rw.data(), sizeof(double), rw.size(), f) == rw.size();
+    for (size_t l = 0; l < p->leaves.size() && ok; ++l) {
+        const Leaf &L = p->leaves[l];
+        const int n = L.kind == MCI_CONTINUOUS ? L.npts : L.nbin;
+        std::vector<double> v(n);
+        rc = L.kind == MCI_CONTINUOUS ? mci_get_grid(p, (int)l, v.data(), n) : mci_get_distribution(p, (int)l, v.data(), nullptr, n);
+        if (rc) { fclose(f); return rc; }
+        ok = fwrite(v.data(), sizeof(double), (size_t)n, f) == (size_t)n;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? MCI_OK : fail(MCI_ERR_INVALID, "short write to %s", path);
+}
+
+int mci_load_state(mci_problem *p, const char *path) {
+    if (!p || !path) return fail(MCI_ERR_INVALID, "NULL argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(MCI_ERR_INVALID, "cannot open %s", path);
+    char magic[8];
+    uint32_t hdr[3];
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "MCISTATE", 8) || fread(hdr, sizeof(uint32_t), 3, f) != 3 || hdr[0] != 1u) {
+        fclose(f);
+        return fail(MCI_ERR_INVALID, "%s is not a version-1 MCISTATE file", path);
+    }
+    if (hdr[1] != p->leaves.size() || hdr[2] != (uint32_t)p->ni) {
+        fclose(f);
+        return fail(MCI_ERR_INVALID, "%s holds %u variables / %u integrands, the problem has %zu / %d", path, hdr[1], hdr[2], p->leaves.size(), p->ni);
+    }
+    for (size_t l = 0; l < p->leaves.size(); ++l) {
+        uint32_t kn[2];
+        const Leaf &L = p->leaves[l];
+        if (fread(kn, sizeof(uint32_t), 2, f) != 2 || kn[0] != (uint32_t)L.kind || kn[1] != (uint32_t)(L.kind == MCI_CONTINUOUS ? L.npts : L.nbin)) {
+            fclose(f);
+            return fail(MCI_ERR_INVALID, "%s: variable %zu does not match the problem (kind / number of grid points)", path, l);
+        }
+    }
+    std::vector<double> rw(p->ni + 1);
+    bool ok = fread(rw.data(), sizeof(double), rw.size(), f) == rw.size();
+    std::vector<std::vector<double>> tabs(p->leaves.size());
+    for (size_t l = 0; l < p->leaves.size() && ok; ++l) {
+        const Leaf &L = p->leaves[l];
+        tabs[l].resize(L.kind == MCI_CONTINUOUS ? L.npts : L.nbin);
+        ok = fread(tabs[l].data(), sizeof(double), tabs[l].size(), f) == tabs[l].size();
+    }
+    fclose(f);
+    if (!ok) return fail(MCI_ERR_INVALID, "%s is truncated", path);
+    int rc = mci_set_reweight(p, rw.data(), p->ni + 1);
+    for (size_t l = 0; l < p->leaves.size() && !rc; ++l)
+        rc = p->leaves[l].kind == MCI_CONTINUOUS ? mci_set_grid(p, (int)l, tabs[l].data(), (int)tabs[l].size())
+                                                 : mci_set_distribution(p, (int)l, tabs[l].data(), (int)tabs[l].size());
+    return rc;
 }
 
 int mci_sample_dump(mci_problem *p, int32_t iteration, uint64_t seed, int64_t nevalperblock, int64_t block_index, int64_t n,

@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
                                                   int nblocks, int wg_per_block, const double *__restrict__ stage1,
                                                   int ngroup, double *__restrict__ ghist, int use_ghist, int nbin,
                                                   double *__restrict__ packed, int *__restrict__ status,
-                                                  double *__restrict__ scratch /*[nblocks*ncols]*/) {
+                                                  double *__restrict__ scratch /*[nblocks*ncols]*/,
+                                                  double *__restrict__ pa_out /*[ncols - (nobs+2+ni+1)]: propose | accept*/) {
     const int nhb = (nbin + 255) / 256;
     const int hoff = 2 * nobs + 2 + ni + 1;
     if ((int)blockIdx.x < nhb) {
@@ -68,11 +69,19 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
         return;
     }
     // --- statistics columns ---
-    for (int idx = threadIdx.x; idx < nblocks * ncols; idx += blockDim.x) {
-        const int b = idx / ncols, c = idx % ncols;
+    // scratch[b][c] = sum over the block's workgroup rows, in a fixed order: 8 lanes per (block, column) stride
+    // over the rows (the loads of different rows are independent, so they pipeline), then a 3-step butterfly
+    for (int base = 0; base < nblocks * ncols; base += blockDim.x / 8) {
+        const int idx = base + (int)threadIdx.x / 8, part = threadIdx.x & 7;
         double s = 0.0;
-        for (int w = 0; w < wg_per_block; ++w) s += part_cols[(size_t)(b * wg_per_block + w) * ncols + c];
-        scratch[idx] = s;
+        if (idx < nblocks * ncols) {
+            const int b = idx / ncols, c = idx % ncols;
+            for (int w = part; w < wg_per_block; w += 8) s += part_cols[(size_t)(b * wg_per_block + w) * ncols + c];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (idx < nblocks * ncols && part == 0) scratch[idx] = s;
     }
     __syncthreads();
     const int cnorm = nobs, cneval = nobs + 1, cvis = nobs + 2;
@@ -104,6 +113,14 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
         double v = 1.0e-8;
         for (int b = 0; b < nblocks; ++b) v += scratch[b * ncols + cvis + i] + 1.0e-8;
         packed[2 * nobs + 2 + i] = v;
+    }
+    // propose / accept (diagnostics of report(config), configuration.jl:345-464): this rank's blocks only
+    const int cpa = cvis + ni + 1, npa = (ncols - cpa) / 2;
+    for (int i = threadIdx.x; i < 2 * npa; i += blockDim.x) {
+        const double off = i < npa ? 1.0e-8 : 1.0e-10; // clearStatistics!  configuration.jl:247-248
+        double v = off;
+        for (int b = 0; b < nblocks; ++b) v += scratch[b * ncols + cpa + i] + off;
+        pa_out[i] = v;
     }
 }
 

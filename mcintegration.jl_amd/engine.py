@@ -144,6 +144,13 @@ class Engine:
     def packed_device_ptr(self):
         return lib().mci_packed_device_ptr(self.p)
 
+    def save_state(self, path):
+        """grids, distributions and reweight -> MCISTATE file (resume across processes)"""
+        check(lib().mci_save_state(self.p, str(path).encode()))
+
+    def load_state(self, path):
+        check(lib().mci_load_state(self.p, str(path).encode()))
+
     def train(self):
         check(lib().mci_train(self.p))
 
@@ -218,6 +225,13 @@ class Engine:
         out = np.empty(self.config.N + 1)
         check(lib().mci_get_reweight(self.p, _dp(out), len(out)))
         return out
+
+    def acceptance(self):
+        """(propose, accept) of the last iteration on this rank; see mci_get_acceptance"""
+        n = max(len(self.config.var), 3)
+        pr, ac = np.empty(n), np.empty(n)
+        check(lib().mci_get_acceptance(self.p, _dp(pr), _dp(ac), n))
+        return pr, ac
 
     def set_reweight_goal(self, goal):
         if goal is None:

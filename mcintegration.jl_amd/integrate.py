@@ -62,6 +62,9 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
             for i, lf in enumerate(config.leaves):
                 (eng.set_grid if hasattr(lf, "ninc") else eng.set_distribution)(i, saved[i])
         config._engine, config._engine_key = eng, key
+        if getattr(config, "_pending_state", None):
+            eng.load_state(config._pending_state)
+            config._pending_state = None
     eng = config._engine
     s = SOLVERS[solver]
     if hasattr(eng, "set_reweight_goal"):
@@ -80,6 +83,13 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         neval_done += nevalperblock * block
     config.iterations_done += niter
     config.neval = nevalperblock * block
+    config._last_solver = solver
+    if hasattr(eng, "get_packed"):   # config.visited of the last iteration (configuration.jl:46), for report(config)
+        try:
+            pk = eng.get_packed()
+            config.visited = pk[2 * eng.nobs + 2: 2 * eng.nobs + 2 + config.N + 1].copy()
+        except Exception:
+            pass
     res = Result(np.array(means), np.array(stds), config, ignore, neval=neval_done, seconds=time.time() - t0)   # main.jl:211
     if print >= 0:
         report(res, io=printio)                                                       # main.jl:212-213

@@ -89,10 +89,58 @@ def _tostring(m, e):
     return "%s ± %s" % (m, e)
 
 
+def report_config(config, io=None):
+    """report(config) (configuration.jl:345-464).  The reference tabulates propose/accept per (integrand, target);
+    the engine keeps them summed per update type (mcmc) or per variable (vegasmc), see mci_get_acceptance."""
+    import sys
+    import datetime
+    from .variables import CompositeVar, ContinuousVar, DiscreteVar
+    io = io or sys.stdout
+    eng = config._engine
+    bar = "-" * 85
+    print("", file=io)
+    print("===========================  Configuration  =========================================", file=io)
+    print(datetime.datetime.now().isoformat(sep="T", timespec="milliseconds"), file=io)
+    print(bar, file=io)
+    print("Integral num = %d, dof = %s, with variables:" % (config.N, config.dof), file=io)
+    for vi, v in enumerate(config.var):
+        print("%d. %r" % (vi + 1, v), file=io)
+    print(bar, file=io)
+    neval = max(config.neval, 1)
+    if eng is not None and hasattr(eng, "acceptance"):
+        pr, ac = eng.acceptance()
+        solver = getattr(config, "_last_solver", None)
+        if solver == "mcmc":
+            for title, k in (("ChangeIntegrand", 0), ("ChangeVariable", 1), ("SwapVariable", 2)):
+                print("%-20s %12s %12s %12s" % (title, "Proposed", "Accepted", "Ratio  "), file=io)
+                print("  all               : %11.6f%% %11.6f%% %12.6f" % (pr[k] / neval * 100.0, ac[k] / neval * 100.0, ac[k] / pr[k]), file=io)
+                print(bar, file=io)
+        elif solver == "vegasmc":
+            print("%-20s %12s %12s %12s" % ("ChangeVariable", "Proposed", "Accepted", "Ratio  "), file=io)
+            for vi, v in enumerate(config.var):
+                typestr = "Continuous" if isinstance(v, ContinuousVar) else "Discrete" if isinstance(v, DiscreteVar) else \
+                    "Composite" if isinstance(v, CompositeVar) else type(v).__name__
+                print("  %2d / %-11s:   %11.6f%% %11.6f%% %12.6f" % (1, typestr, pr[vi] / neval * 100.0, ac[vi] / neval * 100.0, ac[vi] / pr[vi]), file=io)
+            print(bar, file=io)
+    print("Integrand            Visited      ReWeight", file=io)
+    vis = getattr(config, "visited", None)
+    rw = config.reweight
+    if vis is None:
+        vis = np.zeros(config.N + 1)
+    print("  Norm   :     %12d %12.6f" % (vis[-1], rw[-1]), file=io)
+    for idx in range(config.N):
+        print("  Order%2d:     %12d %12.6f" % (idx + 1, vis[idx], rw[idx]), file=io)
+    print(bar, file=io)
+    print("Integrand evaluation = %d\n" % config.neval, file=io)
+
+
 def report(result, ignore=None, pick=0, name=None, verbose=0, io=None):
-    """report(result) (statistics.jl:137-172): per-iteration table with the running weighted average."""
+    """report(result) (statistics.jl:137-172): per-iteration table with the running weighted average;
+    report(config) (configuration.jl:345-464) when given a Configuration."""
     import sys
     io = io or sys.stdout
+    if not isinstance(result, Result):
+        return report_config(result, io=io)
     ignore = result.ignore if ignore is None else ignore
     off = 0
     for i in range(result.config.N):

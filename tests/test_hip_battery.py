@@ -157,3 +157,44 @@ def test_library_rccl_single_rank_and_torch_reducer():
     np.testing.assert_array_equal(eng.get_packed(), before)
     res = integrate(mci.catalog.x2y2(), var=Continuous(0.0, 1.0), dof=[[2]], solver="vegas", neval=1e5, seed=4, comm=comm)
     check(res, 2.0 / 3.0)
+
+
+def test_state_file_round_trip_resumes_in_a_new_problem(tmp_path):
+    """SURVEY 8f2: trained grids / distributions / reweight survive a process boundary through an MCISTATE file;
+    a fresh Configuration that loads it starts as well trained as `config=res.config` does (docs/src/index.md:129)."""
+    path = tmp_path / "state.mcistate"
+    res0 = integrate("return log(x[0]) / sqrt(x[0]);", solver="vegas", neval=1e5, seed=21)
+    res0.config.save(path)
+    fresh = Configuration(seed=22).load(path)
+    res = integrate("return log(x[0]) / sqrt(x[0]);", solver="vegas", neval=1e5, config=fresh)
+    np.testing.assert_array_equal(fresh.var[0].grid[[0, -1]], [0.0, 1.0])
+    assert res.iter_std[0, 0] < 0.2 * res0.iter_std[0, 0]     # first iteration already runs on the trained grid
+    check(res, -4.0)
+    # vegasmc state: reweight and a Discrete distribution
+    cfg = Configuration(var=(Continuous(0.0, 1.0), Discrete(1, 3)), dof=[[1, 1]], seed=23)
+    integrate("return x[0] * x[1];", config=cfg, solver="vegasmc", neval=1e5)
+    cfg.save(path)
+    cfg2 = Configuration(var=(Continuous(0.0, 1.0), Discrete(1, 3)), dof=[[1, 1]], seed=24)
+    eng2 = mci.Engine(cfg2, "return x[0] * x[1];")
+    eng2.load_state(path)
+    np.testing.assert_array_equal(eng2.grid(0), cfg._engine.grid(0))
+    np.testing.assert_allclose(eng2.distribution(1)[0], cfg._engine.distribution(1)[0], rtol=1e-15)   # re-normalised on load (variable.jl:312)
+    np.testing.assert_allclose(eng2.reweight(), cfg._engine.reweight(), rtol=1e-15)
+    with pytest.raises(mci.MCIError):   # a file for a different problem is refused
+        mci.Engine(Configuration(var=Continuous(0.0, 1.0), dof=[[2]]), "return x[0];").load_state(path)
+
+
+def test_report_config_prints_the_acceptance_table(capsys):
+    """report(config) (configuration.jl:345-464) for the chain solvers: proposed / accepted / visited / reweight."""
+    res = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), dof=[[2], [3]], solver="mcmc", neval=2e5, seed=41)
+    pr, ac = res.config._engine.acceptance()
+    assert np.all(pr[:3] > 1.0) and np.all(ac[:3] <= pr[:3]) and np.all(ac[:3] > 0.0)
+    mci.report(res.config)
+    out = capsys.readouterr().out
+    for word in ("Configuration", "ChangeIntegrand", "ChangeVariable", "SwapVariable", "Visited", "ReWeight", "Integrand evaluation"):
+        assert word in out
+    res = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), dof=[[2], [3]], solver="vegasmc", neval=1e5, seed=42)
+    pr, ac = res.config._engine.acceptance()
+    assert pr[0] > 1.0 and 0.0 < ac[0] <= pr[0]
+    mci.report(res.config)
+    assert "ChangeVariable" in capsys.readouterr().out

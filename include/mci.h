@@ -58,7 +58,8 @@ typedef struct {
     int32_t npool;
     int32_t nintegrand;          /* N user integrands; the normalisation integrand (configuration.jl:153) is implicit */
     const int32_t *dof;          /* [nintegrand*npool] row-major: dof[i][vi] */
-    const int32_t *obs_nbin;     /* [nintegrand] or NULL(=1 each): length of observable i (`obs` kwarg) */
+    const int32_t *obs_nbin;     /* [nintegrand] or NULL(=ncomp each): number of doubles observable i holds (`obs`
+                                    kwarg; a ComplexF64 entry counts 2) */
     const int32_t *obs_bin_draw; /* [nintegrand] or NULL(=-1): flat draw index of the Discrete draw that selects the
                                     bin of observable i -- the `measure` of example/bubble.jl:81-84; -1 = default
                                     measure (vegas/montecarlo.jl:151-153) */
@@ -67,6 +68,9 @@ typedef struct {
        chain 1-2-...-N with the normalisation attached to the first integrand (configuration.jl:203-208). */
     const int32_t *neighbor_offsets;
     const int32_t *neighbor_list;
+    int32_t ncomp;               /* `type` kwarg (configuration.jl:108): 0/1 = Float64 weights, 2 = ComplexF64 -- the
+                                    integrand writes (re, im) pairs w[2i], w[2i+1]; abs() is the modulus; real and
+                                    imaginary parts are separate statistics columns (main.jl:279,284,302-305) */
 } mci_problem_desc;
 
 /* `integrate` keyword arguments (main.jl:71-90). */
@@ -121,6 +125,12 @@ int mci_problem_destroy(mci_problem *prob);
  *     const double* ud -- userdata (configuration.jl:113)
  * JIT-compiled with hiprtc for gfx950 together with the hand-written kernels. */
 int mci_set_integrand_source(mci_problem *prob, const char *body, const double *userdata, int32_t nuserdata);
+/* The `measure` callback (vegas/montecarlo.jl:156-161, mcmc/montecarlo.jl:166-169) as a HIP C++ function body:
+ *     const double* x, ud as above; const double* rw -- relative weights [nintegrand*ncomp];
+ *     const int idx -- -1 (vegas, vegasmc) or the integrand an mcmc chain sits on (only its rw is non-zero);
+ *     obs_add(k, v) -- accumulate v into flat observable k (0 <= k < sum obs_nbin)
+ * NULL restores the default measure (vegas/montecarlo.jl:151-153) / the declarative obs_bin_draw one. */
+int mci_set_measure_source(mci_problem *prob, const char *body);
 int mci_compile(mci_problem *prob);          /* JIT or kernel-cache load of the vegas kernel; implicit on first run */
 int mci_compile_solver(mci_problem *prob, int32_t solver); /* same for one solver's kernel (one code object each) */
 int mci_set_launch(mci_problem *prob, int32_t threads_per_workgroup, int32_t workgroups_per_block);

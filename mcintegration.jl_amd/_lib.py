@@ -30,7 +30,7 @@ class LeafDesc(C.Structure):
 class ProblemDesc(C.Structure):
     _fields_ = [("nleaf", C.c_int32), ("leaves", C.POINTER(LeafDesc)), ("npool", C.c_int32),
                 ("nintegrand", C.c_int32), ("dof", c_int32_p), ("obs_nbin", c_int32_p), ("obs_bin_draw", c_int32_p),
-                ("neighbor_offsets", c_int32_p), ("neighbor_list", c_int32_p)]
+                ("neighbor_offsets", c_int32_p), ("neighbor_list", c_int32_p), ("ncomp", C.c_int32)]
 
 
 class IntegrateArgs(C.Structure):
@@ -60,6 +60,7 @@ SIGNATURES = [
     ("mci_problem_create", C.c_int, [_VP, C.POINTER(ProblemDesc), C.POINTER(_VP)]),
     ("mci_problem_destroy", C.c_int, [_VP]),
     ("mci_set_integrand_source", C.c_int, [_VP, C.c_char_p, c_double_p, C.c_int32]),
+    ("mci_set_measure_source", C.c_int, [_VP, C.c_char_p]),
     ("mci_compile", C.c_int, [_VP]),
     ("mci_compile_solver", C.c_int, [_VP, C.c_int32]),
     ("mci_set_launch", C.c_int, [_VP, C.c_int32, C.c_int32]),

@@ -1,7 +1,7 @@
 """`Configuration(; var, dof, obs, reweight, seed, userdata, ...)`  reference src/configuration.jl:105-194."""
 import numpy as np
 
-from .integrand import bin_by
+from .integrand import Measure, bin_by
 from .variables import CompositeVar, ContinuousVar, DiscreteVar
 
 
@@ -51,10 +51,13 @@ class Configuration:
                     for leaf in v.vars:
                         leaf.size = v.size
         self.type = type
+        self.ncomp = 2 if (type is complex or type in ("ComplexF64", np.complex128)) else 1   # :108
         if obs is None:
-            obs = [0.0] * self.N                                           # :109
+            obs = [type(0) if self.ncomp == 2 else 0.0] * self.N           # :109 zeros(type, N)
         assert len(obs) == self.N, "The number of observables should be equal to the number of integrands"  # :168
-        self.obs_nbin = [int(np.size(o)) for o in obs]
+        # one statistics column per double: a complex entry is (re, im) (main.jl:279,284,302-305)
+        self.obs_len = [int(np.size(o)) for o in obs]
+        self.obs_nbin = [n * self.ncomp for n in self.obs_len]
         self.obs_is_array = [np.ndim(o) > 0 for o in obs]
         if reweight is None:
             reweight = np.ones(self.N + 1)                                 # :110
@@ -141,13 +144,16 @@ class Configuration:
 
     def obs_bin_draw(self, measure):
         if measure is None:
-            assert all(n == 1 for n in self.obs_nbin), \
+            assert all(n == 1 for n in self.obs_len), \
                 "the default measure can only handle observable as Vector with N scalar elements!"   # vegas/montecarlo.jl:104
             return [-1] * self.N
         if isinstance(measure, bin_by):
+            assert self.ncomp == 1, "bin_by observables are real"
             k = self.draw_index(measure.pool, measure.slot, measure.leaf)
             return [k if n > 1 else -1 for n in self.obs_nbin]
-        raise TypeError("measure must be None or mcintegration_jl_amd.bin_by(pool): device-side measures are declarative")
+        if isinstance(measure, Measure):
+            return [-1] * self.N
+        raise TypeError("measure must be None, bin_by(pool) or Measure(source): the measure runs on the device")
 
     @property
     def reweight(self):

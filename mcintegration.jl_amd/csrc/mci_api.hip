@@ -395,6 +395,8 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
                 s.cover_mask[k] |= 1ull << i;
             }
     s.dof = p->dof;
+    if (d->ncomp != 0 && d->ncomp != 1 && d->ncomp != 2) { delete p; return fail(MCI_ERR_INVALID, "ncomp must be 1 (Float64) or 2 (ComplexF64)"); }
+    s.ncomp = d->ncomp == 2 ? 2 : 1;
     { // neighbor graph of the integrands (mcmc): configuration.jl:201-227, 0-based, index ni = normalisation
         std::vector<std::vector<int>> nb(Nd);
         if (d->neighbor_offsets && d->neighbor_list) {
@@ -424,11 +426,11 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
     }
     s.nobs = 0;
     for (int i = 0; i < p->ni; ++i) {
-        const int nb = d->obs_nbin ? d->obs_nbin[i] : 1;
+        const int nb = d->obs_nbin ? d->obs_nbin[i] : s.ncomp;
         const int bd = d->obs_bin_draw ? d->obs_bin_draw[i] : -1;
         if (nb < 1 || (bd >= s.ndraw)) { delete p; return fail(MCI_ERR_INVALID, "observable %d: bad shape", i); }
         if (bd >= 0 && p->leaves[s.draw_leaf[bd]].kind != MCI_DISCRETE) { delete p; return fail(MCI_ERR_INVALID, "observable %d: bin draw must be a Discrete draw", i); }
-        if (bd < 0 && nb != 1) { delete p; return fail(MCI_ERR_INVALID, "the default measure can only handle scalar observables"); } // vegas/montecarlo.jl:104
+        if (bd >= 0 && s.ncomp != 1) { delete p; return fail(MCI_ERR_INVALID, "observable %d: binned observables are real", i); }
         s.obs_off.push_back(s.nobs);
         s.obs_nbin.push_back(nb);
         s.obs_bin_draw.push_back(bd);
@@ -568,6 +570,13 @@ int mci_set_integrand_source(mci_problem *p, const char *body, const double *ud,
     return MCI_OK;
 }
 
+int mci_set_measure_source(mci_problem *p, const char *body) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    p->shape.measure_body = body ? body : "";
+    drop_modules(p);
+    return MCI_OK;
+}
+
 int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
     if (threads > 0) {
         if (threads % 64 || threads > 1024) return fail(MCI_ERR_INVALID, "threads per workgroup must be a multiple of 64, <= 1024");
@@ -583,6 +592,10 @@ int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
 static int compile_solver(mci_problem *p, int solver) {
     if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver); // main.jl:263
     if (p->compiled[solver]) return MCI_OK;
+    if (p->shape.measure_body.empty()) // vegas/montecarlo.jl:104, mcmc/montecarlo.jl:84
+        for (int i = 0; i < p->ni; ++i)
+            if (p->shape.obs_bin_draw[i] < 0 && p->shape.obs_nbin[i] != p->shape.ncomp)
+                return fail(MCI_ERR_INVALID, "the default measure can only handle observable as Vector with %d scalar elements!", p->ni);
     const std::string src = mcijit::generate_source(p->shape, solver);
     std::vector<char> code;
     std::string log;
@@ -1042,7 +1055,7 @@ int mci_sample_dump(mci_problem *p, int32_t iteration, uint64_t seed, int64_t ne
     if (rc) return rc;
     HIPCHK(hipSetDevice(p->ctx->device));
     const auto &s = p->shape;
-    const int64_t per = s.ndraw + 1 + s.ni;
+    const int64_t per = s.ndraw + 1 + s.ni * s.ncomp;
     if (n * per > p->cap_dump) {
         if (p->d_dump) (void)hipFree(p->d_dump);
         p->d_dump = nullptr;
@@ -1066,7 +1079,7 @@ int mci_sample_dump(mci_problem *p, int32_t iteration, uint64_t seed, int64_t ne
     HIPCHK(hipModuleLaunchKernel(p->f_dump, grid, 1, 1, 256, 1, 1, (unsigned)p->lds_bytes, p->ctx->stream, args, nullptr));
     if (x) HIPCHK(hipMemcpyAsync(x, a.x, (size_t)n * s.ndraw * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
     if (jac) HIPCHK(hipMemcpyAsync(jac, a.jac, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
-    if (w) HIPCHK(hipMemcpyAsync(w, a.w, (size_t)n * s.ni * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    if (w) HIPCHK(hipMemcpyAsync(w, a.w, (size_t)n * s.ni * s.ncomp * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     return MCI_OK;
 }

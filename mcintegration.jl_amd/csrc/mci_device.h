@@ -325,32 +325,50 @@ template <class Cfg> __device__ __forceinline__ void hist_update(const Sample<Cf
     });
 }
 
-// default measure (vegas/montecarlo.jl:151-153) or "bin by a Discrete draw" (example/bubble.jl:81-84)
-template <class Cfg> __device__ __forceinline__ void measure(const Sample<Cfg> &s, const double *relw, double *acc /*[NI] registers*/, double *sO) {
-    static_for<0, Cfg::NI>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        if constexpr (Cfg::obs_bin_draw(i) < 0) {
-            acc[i] += relw[i];
-        } else {
-            constexpr int kd = Cfg::obs_bin_draw(i);
-            const int b = s.bin[kd];
-            if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw[i]);
-        }
-    });
+// abs(weights[i]) (vegas/montecarlo.jl:173): |w| for Float64, the modulus for ComplexF64 weights stored (re, im)
+template <class Cfg, int I> __device__ __forceinline__ double absw(const double *w) {
+    if constexpr (Cfg::NCOMP == 1) return fabs(w[I]);
+    else return hypot(w[2 * I], w[2 * I + 1]);
+}
+
+// default measure (vegas/montecarlo.jl:151-153), "bin by a Discrete draw" (example/bubble.jl:81-84), or the user's
+// measure body (vegas/montecarlo.jl:156-161), which accumulates into the LDS observable array through obs_add(k, v).
+// relw: NI*NCOMP relative weights; acc: NI*NCOMP register accumulators of the default measure.
+template <class Cfg> __device__ __forceinline__ void measure(const double *x, const int *bin, const double *relw, const double *ud,
+                                                             double *acc, double *sO) {
+    if constexpr (Cfg::CUSTOM_MEASURE != 0) {
+        Cfg::measure(x, relw, ud, -1, sO);
+    } else {
+        static_for<0, Cfg::NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (Cfg::obs_bin_draw(i) < 0) {
+                static_for<0, Cfg::NCOMP>([&](auto Q) { acc[i * Cfg::NCOMP + decltype(Q)::value] += relw[i * Cfg::NCOMP + decltype(Q)::value]; });
+            } else {
+                static_assert(Cfg::NCOMP == 1 || Cfg::obs_bin_draw(i) < 0, "binned observables are real");
+                constexpr int kd = Cfg::obs_bin_draw(i);
+                const int b = bin[kd];
+                if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw[i]);
+            }
+        });
+    }
 }
 
 // workgroup epilogue: registers -> wave shuffle -> LDS -> one row of part_cols; LDS histogram -> part_hist
 template <class Cfg> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/, i64 rowid, int tile) {
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
     double *sO = smem + Lds<Cfg>::O, *sR = smem + Lds<Cfg>::R, *sH = smem + Lds<Cfg>::H;
-    // scalar observables
-    static_for<0, Cfg::NI>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        if constexpr (Cfg::obs_bin_draw(i) < 0) {
-            const double v = wave_sum(acc[i]);
-            if (lane == 0) sR[wave * Cfg::NCOLS + Cfg::obs_off(i)] = v;
-        }
-    });
+    // scalar observables of the default measure (register accumulators)
+    if constexpr (Cfg::CUSTOM_MEASURE == 0) {
+        static_for<0, Cfg::NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (Cfg::obs_bin_draw(i) < 0) {
+                static_for<0, Cfg::NCOMP>([&](auto Q) {
+                    const double v = wave_sum(acc[i * Cfg::NCOMP + decltype(Q)::value]);
+                    if (lane == 0) sR[wave * Cfg::NCOLS + Cfg::obs_off(i) + decltype(Q)::value] = v;
+                });
+            }
+        });
+    }
     static_for<Cfg::NOBS, Cfg::NCOLS>([&](auto Cc) {
         constexpr int c = decltype(Cc)::value;
         const double v = wave_sum(extra[c - Cfg::NOBS]);
@@ -359,13 +377,11 @@ template <class Cfg> __device__ __forceinline__ void flush_workgroup(const Batch
     __syncthreads();
     double *row = a.part_cols + rowid * Cfg::NCOLS;
     for (int c = tid; c < Cfg::NCOLS && tile == 0; c += T) { // the NTILE workgroups of a slice hold identical statistics
-        bool binned = false;
-        int owner = 0;
+        bool binned = Cfg::CUSTOM_MEASURE != 0; // in LDS (sO): binned observables, everything under a user measure
         static_for<0, Cfg::NI>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            if (c >= Cfg::obs_off(i) && c < Cfg::obs_off(i) + Cfg::obs_nbin(i)) { owner = i; binned = Cfg::obs_bin_draw(i) >= 0; }
+            if (c >= Cfg::obs_off(i) && c < Cfg::obs_off(i) + Cfg::obs_nbin(i)) binned = binned || Cfg::obs_bin_draw(i) >= 0;
         });
-        (void)owner;
         double v = 0.0;
         if (c < Cfg::NOBS && binned) v = sO[c];
         else
@@ -422,27 +438,27 @@ template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs
     const u32 stream = a.iteration * 8u + STREAM_VEGAS;
     const i64 stride = (i64)a.wg_per_block * T;
 
-    double acc[Cfg::NI];
-    static_for<0, Cfg::NI>([&](auto I) { acc[decltype(I)::value] = 0.0; });
+    double acc[Cfg::NW];
+    static_for<0, Cfg::NW>([&](auto I) { acc[decltype(I)::value] = 0.0; });
     double extra[Cfg::NCOLS - Cfg::NOBS];
     static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
 
     for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(B * a.neval_per_block + n), s);
-        double w[Cfg::NI];
+        double w[Cfg::NW];
         Cfg::integrand(s.x, w, a.ud, -1); // vegas/montecarlo.jl:140-144
         extra[Cols<Cfg>::NEVAL - Cfg::NOBS] += 1.0; // config.neval += 1   :118
         if (a.measurefreq == 1 || (n + 1) % a.measurefreq == 0) { // :148
-            double relw[Cfg::NI];
-            static_for<0, Cfg::NI>([&](auto I) { constexpr int i = decltype(I)::value; relw[i] = w[i] * s.jaci[i]; }); // :152
-            measure<Cfg>(s, relw, acc, sO);
+            double relw[Cfg::NW];
+            static_for<0, Cfg::NW>([&](auto Q) { constexpr int q = decltype(Q)::value; relw[q] = w[q] * s.jaci[q / Cfg::NCOMP]; }); // :152
+            measure<Cfg>(s.x, s.bin, relw, a.ud, acc, sO);
             extra[Cols<Cfg>::NORM - Cfg::NOBS] += 1.0; // :164
         }
         double wh[Cfg::NI];
         static_for<0, Cfg::NI>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            const double wj = fabs(w[i]) * s.jac; // :173-174 (full jac, not the integrand's own: author's warning :175)
+            const double wj = absw<Cfg, i>(w) * s.jac; // :173-174 (full jac, not the integrand's own: author's warning :175)
             wh[i] = wj * wj;                      // :180
         });
 #ifndef MCI_ABL_NOHIST
@@ -551,8 +567,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     double rw[NI + 1];
     static_for<0, NI + 1>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
 
-    double acc[NI];
-    static_for<0, NI>([&](auto I) { acc[decltype(I)::value] = 0.0; });
+    double acc[Cfg::NW];
+    static_for<0, Cfg::NW>([&](auto I) { acc[decltype(I)::value] = 0.0; });
     double extra[Cfg::NCOLS - Cfg::NOBS];
     static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
     constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
@@ -571,11 +587,11 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 c.prob[k] = 1.0 / s.pj[k]; // sampler.jl:303 / :20
             });
         }
-        double w[NI], pad[NI + 1];
+        double w[Cfg::NW], pad[NI + 1];
         Cfg::integrand(c.x, w, a.ud, -1); // :155-159
         static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(c); }); // :161
         double probability = rw[NORMI] * pad[NORMI]; // :162
-        static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; probability += fabs(w[i]) * rw[i] * pad[i]; }); // :163-166
+        static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; probability += absw<Cfg, i>(w) * rw[i] * pad[i]; }); // :163-166
 
         for (i64 ne = 1; ne <= steps; ++ne) { // :184
             const u64 sidx = (g << 32) | (u64)(ne - 1);
@@ -620,12 +636,12 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 }
             });
             if (active && prop > 4.9406564584124654e-324) { // :63-65
-                double wn[NI], padn[NI + 1];
+                double wn[Cfg::NW], padn[NI + 1];
                 Cfg::integrand(n.x, wn, a.ud, -1);             // :67-75
                 extra[XE] += 1.0;                              // config.neval += 1   :77
                 static_for<0, NI + 1>([&](auto I) { padn[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(n); }); // :79-81
                 double newp = rw[NORMI] * padn[NORMI];         // :84
-                static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; newp += fabs(wn[i]) * rw[i] * padn[i]; }); // :85-87
+                static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; newp += absw<Cfg, i>(wn) * rw[i] * padn[i]; }); // :85-87
                 const double R = prop * newp / probability;    // :88
                 const bool ok = uacc < R;                      // :91
                 static_for<0, Cfg::NPOOL>([&](auto V) {
@@ -637,7 +653,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 });
                 if (ok) {
                     c = n;
-                    static_for<0, NI>([&](auto I) { w[decltype(I)::value] = wn[decltype(I)::value]; });       // :93-95
+                    static_for<0, Cfg::NW>([&](auto I) { w[decltype(I)::value] = wn[decltype(I)::value]; }); // :93-95
                     static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = padn[decltype(I)::value]; }); // :96-98
                     probability = newp;                        // :100
                 } // else shiftRollback!  :102  (the proposal copy is dropped)
@@ -647,7 +663,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 double wh[NI];
                 static_for<0, NI>([&](auto I) {
                     constexpr int i = decltype(I)::value;
-                    const double f2 = fabs(w[i]) * fabs(w[i]) / own_prob<Cfg, i>(c); // :203
+                    const double aw = absw<Cfg, i>(w);
+                    const double f2 = aw * aw / own_prob<Cfg, i>(c);                   // :203
                     wh[i] = f2 * pad[i] / probability;                                 // :204
                 });
                 Sample<Cfg> sb;
@@ -657,15 +674,16 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
             // ---- measurement  montecarlo.jl:213-232 ----
             const bool mf = (a.measurefreq == 1) || (ne % a.measurefreq == 0);
             if (mf && (double)ne >= a.burnin) { // :213
-                double relw[NI];
+                double relw[Cfg::NW];
                 static_for<0, NI>([&](auto I) {
                     constexpr int i = decltype(I)::value;
-                    extra[XV + i] += fabs(w[i] * pad[i] * rw[i]) / probability; // :216
-                    relw[i] = w[i] * pad[i] / probability;                      // :218/:220
+                    extra[XV + i] += absw<Cfg, i>(w) * fabs(pad[i] * rw[i]) / probability; // :216
+                    static_for<0, Cfg::NCOMP>([&](auto Q) {
+                        constexpr int q = i * Cfg::NCOMP + decltype(Q)::value;
+                        relw[q] = w[q] * pad[i] / probability;                             // :218/:220
+                    });
                 });
-                Sample<Cfg> sb;
-                static_for<0, Cfg::NDRAW>([&](auto K) { sb.bin[decltype(K)::value] = c.bin[decltype(K)::value]; });
-                measure<Cfg>(sb, relw, acc, sO);
+                measure<Cfg>(c.x, c.bin, relw, a.ud, acc, sO);
                 extra[XN] += pad[NORMI] / probability;                // :229
                 extra[XV + NORMI] += rw[NORMI] * pad[NORMI] / probability; // :230
             }
@@ -687,13 +705,23 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
 //   step s    : stream MCMC_STEP, index (g<<32 | s),  k = 0 update pick, 1 neighbor/pool pick, 2 slot pick,
 //               3 second slot pick (swap), 4 accept, 5 + flat draw index of a created/shifted draw
 // =============================================================================================
-template <class Cfg, int I> __device__ __forceinline__ double eval_one(const double *x, const double *ud) {
-    double w[Cfg::NI];
+// weight of ONE integrand: value (re [, im]) and modulus
+template <class Cfg> struct Weight {
+    double v[Cfg::NCOMP];
+    double abs;
+};
+template <class Cfg, int I> __device__ __forceinline__ Weight<Cfg> eval_one(const double *x, const double *ud) {
+    double w[Cfg::NW];
     Cfg::integrand(x, w, ud, I); // the other outputs are dead code after inlining
-    return w[I];
+    Weight<Cfg> r;
+    static_for<0, Cfg::NCOMP>([&](auto Q) { r.v[decltype(Q)::value] = w[I * Cfg::NCOMP + decltype(Q)::value]; });
+    r.abs = absw<Cfg, I>(w);
+    return r;
 }
-template <class Cfg> __device__ __forceinline__ double eval_sel(int curr, const double *x, const double *ud) {
-    double r = 0.0;
+template <class Cfg> __device__ __forceinline__ Weight<Cfg> eval_sel(int curr, const double *x, const double *ud) {
+    Weight<Cfg> r;
+    static_for<0, Cfg::NCOMP>([&](auto Q) { r.v[decltype(Q)::value] = 0.0; });
+    r.abs = 0.0;
     static_for<0, Cfg::NI>([&](auto I) {
         constexpr int i = decltype(I)::value;
         if (curr == i) r = eval_one<Cfg, i>(x, ud);
@@ -758,8 +786,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
         return r;
     };
 
-    double acc[NI];
-    static_for<0, NI>([&](auto I) { acc[decltype(I)::value] = 0.0; });
+    double acc[Cfg::NW];
+    static_for<0, Cfg::NW>([&](auto I) { acc[decltype(I)::value] = 0.0; });
     double extra[Cfg::NCOLS - Cfg::NOBS];
     static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
     constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
@@ -769,7 +797,10 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
         const u64 g = (u64)(B * a.nchain + ch);
         int curr = a.nchain == 1 ? 0 : (int)(g % (u64)ND); // montecarlo.jl:76 idx = 1; many chains start stratified
         Chain<Cfg> c;
-        double weight = 0.0, probability = 1.0; // :116
+        Weight<Cfg> weight; // :116 _State(curr, zero(T), 1.0)
+        static_for<0, Cfg::NCOMP>([&](auto Q) { weight.v[decltype(Q)::value] = 0.0; });
+        weight.abs = 0.0;
+        double probability = 1.0;
         for (int tr = 0; tr < 10000; ++tr) {    // :118-124
             Sample<Cfg> s;
             draw_sample<Cfg>(t, a.seed, st_init, g * 16384ull + (u64)tr, s); // initialize!  :190-193
@@ -781,9 +812,10 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             });
             if (curr != NORMI) {
                 weight = eval_sel<Cfg>(curr, c.x, a.ud);        // :197
-                probability = fabs(weight) * rw_sel(curr);      // :199
+                probability = weight.abs * rw_sel(curr);        // :199
             } else {
-                weight = 0.0;
+                static_for<0, Cfg::NCOMP>([&](auto Q) { weight.v[decltype(Q)::value] = 0.0; });
+                weight.abs = 0.0;
                 probability = rw[NORMI];                        // :201-202
             }
             if (curr == NORMI || probability > 4.940656458412465e-274) break; // :120-122 (TINY)
@@ -835,10 +867,12 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                                         }
                                     });
                                     if (prop > 4.9406564584124654e-324) { // :29-31
-                                        double neww = 0.0;
+                                        Weight<Cfg> neww;
+                                        static_for<0, Cfg::NCOMP>([&](auto Q) { neww.v[decltype(Q)::value] = 0.0; });
+                                        neww.abs = 0.0;
                                         if constexpr (nw != NORMI) neww = eval_one<Cfg, nw>(n.x, a.ud); // :35-38
                                         extra[XE] += 1.0;                                              // :40
-                                        const double newp = nw == NORMI ? rw[NORMI] : fabs(neww) * rw[nw]; // :42-44
+                                        const double newp = nw == NORMI ? rw[NORMI] : neww.abs * rw[nw]; // :42-44
                                         const double R = prop * newp / probability;                    // :46
                                         extra[XP + 0] += 1.0;                                          // :48
                                         if (uacc < R) {                                                // :49
@@ -917,9 +951,9 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                     });
                 }
                 if (active && prop > 4.9406564584124654e-324) { // :88-90, :129-131
-                    const double wn = eval_sel<Cfg>(curr, n.x, a.ud);   // :92, :133
+                    const Weight<Cfg> wn = eval_sel<Cfg>(curr, n.x, a.ud); // :92, :133
                     extra[XE] += 1.0;                                    // :94, :135
-                    const double newp = fabs(wn) * rw_sel(curr);         // :96, :137
+                    const double newp = wn.abs * rw_sel(curr);           // :96, :137
                     const double R = prop * newp / probability;          // :97, :138
                     const int ut = upd == 1 ? 2 : 1;                     // first index of propose[., curr, vi]  :99, :140
                     const bool ok = uacc < R;                            // :100, :141
@@ -938,7 +972,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             const bool mf = (a.measurefreq == 1) || (it % a.measurefreq == 0);
             if (mf && it >= nburn) {
                 if (curr != NORMI) {
-                    const double relw = weight / probability; // :162
+                    double relw[Cfg::NCOMP]; // :162
+                    static_for<0, Cfg::NCOMP>([&](auto Q) { relw[decltype(Q)::value] = weight.v[decltype(Q)::value] / probability; });
                     static_for<0, NI>([&](auto I) {
                         constexpr int i = decltype(I)::value;
                         if (curr == i) {
@@ -946,12 +981,18 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                                 constexpr int k = decltype(K)::value;
                                 if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hist_add<Cfg, k>(c.bin[k], 1.0, sH, a.ghist, tile);
                             });
-                            if constexpr (Cfg::obs_bin_draw(i) >= 0) {
+                            if constexpr (Cfg::CUSTOM_MEASURE != 0) { // measure(idx, var, obs, relative_weight, config)  :166-169
+                                double rwv[Cfg::NW];
+                                static_for<0, Cfg::NW>([&](auto Q) { rwv[decltype(Q)::value] = 0.0; });
+                                static_for<0, Cfg::NCOMP>([&](auto Q) { rwv[i * Cfg::NCOMP + decltype(Q)::value] = relw[decltype(Q)::value]; });
+                                Cfg::measure(c.x, rwv, a.ud, i, sO);
+                            } else if constexpr (Cfg::obs_bin_draw(i) >= 0) {
                                 const int b = c.bin[Cfg::obs_bin_draw(i)];
-                                if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw);
+                                if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw[0]);
                             }
                         }
-                        if constexpr (Cfg::obs_bin_draw(i) < 0) acc[i] += curr == i ? relw : 0.0; // :164
+                        if constexpr (Cfg::CUSTOM_MEASURE == 0 && Cfg::obs_bin_draw(i) < 0) // :164
+                            static_for<0, Cfg::NCOMP>([&](auto Q) { acc[i * Cfg::NCOMP + decltype(Q)::value] += curr == i ? relw[decltype(Q)::value] : 0.0; });
                     });
                 } else {
                     extra[XN] += 1.0 / rw[NORMI]; // :158
@@ -978,11 +1019,11 @@ template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs 
     for (i64 n = (i64)blockIdx.x * blockDim.x + threadIdx.x; n < a.n; n += (i64)gridDim.x * blockDim.x) {
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(a.first_index + n), s);
-        double w[Cfg::NI];
+        double w[Cfg::NW];
         Cfg::integrand(s.x, w, a.ud, -1);
         static_for<0, Cfg::NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[n * Cfg::NDRAW + k] = s.x[k]; });
         a.jac[n] = s.jac;
-        static_for<0, Cfg::NI>([&](auto I) { constexpr int i = decltype(I)::value; a.w[n * Cfg::NI + i] = w[i]; });
+        static_for<0, Cfg::NW>([&](auto I) { constexpr int i = decltype(I)::value; a.w[n * Cfg::NW + i] = w[i]; });
     }
 }
 

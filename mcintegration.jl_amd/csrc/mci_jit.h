@@ -39,6 +39,8 @@ struct ProblemShape {
     std::vector<int> pool_maxdof, pool_nleaf, pool_first_draw;
     std::vector<int> dof;                 // [(ni+1)*npool] incl. the normalisation row (zeros)
     int nbmax = 1;
+    int ncomp = 1;            // 1: Float64 weights; 2: ComplexF64 stored (re, im)
+    std::string measure_body; // user measure (empty = default / bin-by-Discrete)
     std::vector<int> nneighbor, neighbor; // [ni+1], [(ni+1)*nbmax] 0-based, padded with the integrand itself
     std::string body;
 };
@@ -107,7 +109,8 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     o << fn_table("int", "pool_maxdof", arr(s.pool_maxdof, "int"));
     o << fn_table("int", "pool_nleaf", arr(s.pool_nleaf, "int"));
     o << fn_table("int", "pool_first_draw", arr(s.pool_first_draw, "int"));
-    o << "    static constexpr int NBMAX = " << s.nbmax << ";\n";
+    o << "    static constexpr int NBMAX = " << s.nbmax << ", NCOMP = " << s.ncomp << ", NW = " << s.ni * s.ncomp
+      << ", CUSTOM_MEASURE = " << (s.measure_body.empty() ? 0 : 1) << ";\n";
     o << fn_table("int", "dof", arr(s.dof, "int"));
     o << fn_table("int", "nneighbor", arr(s.nneighbor, "int"));
     o << fn_table("int", "neighbor", arr(s.neighbor, "int"));
@@ -116,6 +119,13 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     o << "    static __device__ __forceinline__ void integrand(const double* __restrict__ x, double* __restrict__ w, "
          "const double* __restrict__ ud, const int idx) {\n    (void)idx;\n"
       << s.body << "\n    }\n";
+    o << "    // the user's measure (vegas/montecarlo.jl:156-161; mcmc/montecarlo.jl:166-169): rw = relative weights\n"
+         "    // [NI*NCOMP], idx = -1 (all integrands) or the integrand an mcmc chain sits on; obs_add(k, v) accumulates\n";
+    o << "    static __device__ __forceinline__ void measure(const double* __restrict__ x, const double* __restrict__ rw, "
+         "const double* __restrict__ ud, const int idx, double* __restrict__ mci_obs_) {\n"
+         "    (void)x; (void)rw; (void)ud; (void)idx; (void)mci_obs_;\n"
+         "#define obs_add(k, v) mci::lds_add(&mci_obs_[(k)], (v))\n"
+      << s.measure_body << "\n#undef obs_add\n    }\n";
     o << "};\n}\n";
     if (solver == 0) {
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_batch(mci::BatchArgs a) { "

@@ -5,7 +5,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import LeafDesc, ProblemDesc, c_double_p, c_int32_p, check, lib
-from .integrand import Integrand
+from .integrand import Integrand, Measure
 from .variables import ContinuousVar
 
 _ctx_cache = {}
@@ -71,11 +71,13 @@ class Engine:
             self._keep += [off, flat]
             nb_off, nb_list = off.ctypes.data_as(c_int32_p), flat.ctypes.data_as(c_int32_p)
         desc = ProblemDesc(len(leaves), arr, len(config.var), config.N, dof.ctypes.data_as(c_int32_p),
-                           onb.ctypes.data_as(c_int32_p), obd.ctypes.data_as(c_int32_p), nb_off, nb_list)
+                           onb.ctypes.data_as(c_int32_p), obd.ctypes.data_as(c_int32_p), nb_off, nb_list, config.ncomp)
         self.p = C.c_void_p()
         check(L.mci_problem_create(self.ctx, C.byref(desc), C.byref(self.p)))
         ud = integrand.userdata
         check(L.mci_set_integrand_source(self.p, integrand.body.encode(), _dp(ud) if len(ud) else None, len(ud)))
+        if isinstance(measure, Measure):
+            check(L.mci_set_measure_source(self.p, measure.body.encode()))
         if threads or wg_per_block is not None:
             check(L.mci_set_launch(self.p, threads or 0, -1 if wg_per_block is None else wg_per_block))
         nd, no, ps, tm, lds = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64()
@@ -173,7 +175,7 @@ class Engine:
 
     def sample_dump(self, n, nevalperblock=None, block_index=0, iteration=0, seed=1234):
         nevalperblock = n if nevalperblock is None else nevalperblock
-        x, jac, w = np.empty((n, self.ndraw)), np.empty(n), np.empty((n, self.config.N))
+        x, jac, w = np.empty((n, self.ndraw)), np.empty(n), np.empty((n, self.config.N * self.config.ncomp))
         check(lib().mci_sample_dump(self.p, iteration, seed, int(nevalperblock), int(block_index), int(n), _dp(x), _dp(jac), _dp(w)))
         return x, jac, w
 

@@ -23,3 +23,13 @@ class bin_by:
 
     def __init__(self, pool, slot=0, leaf=0):
         self.pool, self.slot, self.leaf = pool, slot, leaf
+
+
+class Measure:
+    """The `measure` callback (vegas/montecarlo.jl:156-161; mcmc/montecarlo.jl:166-169) as HIP C++ source.
+    In scope: `x` (draws), `rw` (relative weights, one per integrand; (re, im) pairs for complex types), `ud`,
+    `idx` (-1, or the current integrand of an mcmc chain) and `obs_add(k, v)`: obs.flat[k] += v, where the flat
+    index runs over the `obs` kwarg in order (a complex entry takes two slots: re, im)."""
+
+    def __init__(self, body):
+        self.body = body.strip()

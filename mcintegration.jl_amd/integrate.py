@@ -9,7 +9,7 @@ from ._lib import MCMC, SOLVERS, VEGAS, VEGASMC, lib
 from .comm import LocalComm
 from .configuration import Configuration
 from .engine import Engine
-from .integrand import Integrand
+from .integrand import Integrand, Measure
 from .statistics import Result, report
 from .variables import Continuous, Discrete
 
@@ -49,7 +49,8 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
 
     if isinstance(integrand, str):
         integrand = Integrand(integrand, config.userdata)
-    key = (integrand.body, tuple(integrand.userdata), None if measure is None else (measure.pool, measure.slot, measure.leaf), device,
+    mkey = None if measure is None else measure.body if isinstance(measure, Measure) else (measure.pool, measure.slot, measure.leaf)
+    key = (integrand.body, tuple(integrand.userdata), mkey, device,
            repr(config.neighbor))
     if config._engine is None or config._engine_key != key:
         # grids trained so far survive a change of integrand (`var = (res.config.var[1], ...)`, docs/src/index.md:129)

@@ -5,7 +5,7 @@
 # reference-side binding INTEGRATION.md describes.  Everything numerical happens in the library.
 module MCIntegrationHIP
 
-export integrate, Configuration, Continuous, Discrete, CompositeVar, Result, Integrand, bin_by, report
+export integrate, Configuration, Continuous, Discrete, CompositeVar, Result, Integrand, Measure, bin_by, report
 
 const libmci = get(ENV, "MCI_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libmci_hip.so"))
 const MaxOrder = 16                         # reference src/distribution/distribution.jl:59
@@ -59,6 +59,7 @@ struct Integrand
 end
 Integrand(body::AbstractString) = Integrand(String(body), Float64[])
 struct bin_by; pool::Int; end                # measure of example/bubble.jl:81-84 (1-based pool index)
+struct Measure; body::String; end            # user measure as HIP C++ source: x, rw, ud, idx, obs_add(k, v)  (include/mci.h)
 
 # ---- C structs of include/mci.h ------------------------------------------------------------------------
 struct LeafDesc
@@ -69,6 +70,7 @@ struct ProblemDesc
     nleaf::Int32; leaves::Ptr{LeafDesc}; npool::Int32; nintegrand::Int32
     dof::Ptr{Int32}; obs_nbin::Ptr{Int32}; obs_bin_draw::Ptr{Int32}
     neighbor_offsets::Ptr{Int32}; neighbor_list::Ptr{Int32}     # CSR, 0-based; both NULL = the reference default
+    ncomp::Int32                                                # 1 Float64, 2 ComplexF64 (`type` kwarg)
 end
 struct IntegrateArgs
     solver::Int32; neval::Int64; niter::Int32; block::Int64; ignore::Int32; adapt::Int32; gamma::Float64
@@ -103,6 +105,7 @@ mutable struct Configuration
     problem::Ptr{Cvoid}
     key
     neighbor::Union{Nothing,Vector{Vector{Int}}}    # 1-based like the reference; nothing = default (configuration.jl:203-208)
+    ncomp::Int                                      # 2 for type=ComplexF64 (configuration.jl:108)
 end
 function _neighbor(neighbor, Nd)                    # reference src/configuration.jl:201-227
     neighbor === nothing && return nothing
@@ -117,7 +120,8 @@ function _neighbor(neighbor, Nd)                    # reference src/configuratio
     @assert length(neighbor) == Nd "$Nd elements are expected for neighbor=$neighbor"
     return [collect(Int, n) for n in neighbor]
 end
-function Configuration(; var=(Continuous(0.0, 1.0),), dof=nothing, obs=nothing, seed=rand(1:1000000), userdata=nothing, neighbor=nothing, kwargs...)
+function Configuration(; var=(Continuous(0.0, 1.0),), dof=nothing, obs=nothing, seed=rand(1:1000000), userdata=nothing, neighbor=nothing,
+                       type=Float64, kwargs...)
     var = var isa Tuple ? var : (var isa AbstractVector ? Tuple(var) : (var,))          # :116-122
     if dof === nothing
         dof = [ones(Int, length(var))]
@@ -131,9 +135,11 @@ function Configuration(; var=(Continuous(0.0, 1.0),), dof=nothing, obs=nothing, 
     else
         dof = [collect(Int, d) for d in dof]
     end
-    obs === nothing && (obs = zeros(length(dof)))
+    ncomp = type <: Complex ? 2 : 1
+    obs === nothing && (obs = zeros(type, length(dof)))
     @assert length(obs) == length(dof) "The number of observables should be equal to the number of integrands"
-    Configuration(var, dof, length(dof), [length(o) for o in obs], seed, userdata, 0, C_NULL, nothing, _neighbor(neighbor, length(dof) + 1))
+    Configuration(var, dof, length(dof), [length(o) * ncomp for o in obs], seed, userdata, 0, C_NULL, nothing,
+                  _neighbor(neighbor, length(dof) + 1), ncomp)
 end
 
 function draw_index(c::Configuration, pool::Int)          # 0-based flat draw of (pool, slot 1, leaf 1)
@@ -171,11 +177,12 @@ function bind!(c::Configuration, f::Integrand, measure)
     GC.@preserve descs dof onb obd keep nboff nblist begin
         desc = Ref(ProblemDesc(length(descs), pointer(descs), length(c.var), c.N, pointer(dof), pointer(onb), pointer(obd),
                                c.neighbor === nothing ? Ptr{Int32}(C_NULL) : pointer(nboff),
-                               c.neighbor === nothing ? Ptr{Int32}(C_NULL) : pointer(nblist)))
+                               c.neighbor === nothing ? Ptr{Int32}(C_NULL) : pointer(nblist), c.ncomp))
         check(ccall((:mci_problem_create, libmci), Cint, (Ptr{Cvoid}, Ptr{ProblemDesc}, Ptr{Ptr{Cvoid}}), context(), desc, p))
     end
     check(ccall((:mci_set_integrand_source, libmci), Cint, (Ptr{Cvoid}, Cstring, Ptr{Float64}, Int32),
                 p[], f.body, f.userdata, length(f.userdata)))
+    measure isa Measure && check(ccall((:mci_set_measure_source, libmci), Cint, (Ptr{Cvoid}, Cstring), p[], measure.body))
     c.problem != C_NULL && ccall((:mci_problem_destroy, libmci), Cint, (Ptr{Cvoid},), c.problem)
     c.problem, c.key = p[], key
     p[]

@@ -48,9 +48,15 @@ class Result:
         self.iterations = [(self._shape(self.iter_mean[i]), self._shape(self.iter_std[i]), config) for i in range(niter)]
 
     def _shape(self, flat):
+        """flat statistics columns -> one entry per integrand; complex types: re + im*1j, the standard deviation
+        likewise (statistics.jl:207-214, main.jl:302-305)"""
         out, off = [], 0
+        nc = getattr(self.config, "ncomp", 1)
         for nb, isarr in zip(self.config.obs_nbin, self.config.obs_is_array):
-            out.append(np.array(flat[off:off + nb]) if isarr else float(flat[off]))
+            v = np.array(flat[off:off + nb])
+            if nc == 2:
+                v = v[0::2] + 1j * v[1::2]
+            out.append(v if isarr else (complex(v[0]) if nc == 2 else float(v[0])))
             off += nb
         return out
 

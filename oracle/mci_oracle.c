@@ -335,6 +335,8 @@ mcio_config *mcio_config_create(int nleaf, const int *kind, const int *pool, con
     c->neighbor[Nd - 1][0] = 0; c->nneighbor[Nd - 1] = 1;                   /* :207 norm -> first */
     if (Nd >= 3) { c->neighbor[Nd - 2][0] = Nd - 3; c->nneighbor[Nd - 2] = 1; } /* :208 */
     c->thermal_ratio = 0.1;
+    c->ncomp = 1;
+    c->measure_fn = NULL;
     c->normalization = 1.0e-10;                              /* :179 */
     c->neval = 0;
     c->prob_mode = MCIO_PROB_CREATE;
@@ -679,16 +681,27 @@ static inline void gather_x(const mcio_config *c, double *x) {
     }
 }
 
-/* default measure (ref: vegas/montecarlo.jl:151-153) or "bin by a Discrete draw" (ref: example/bubble.jl:81-84) */
-static inline void measure(mcio_config *c, const double *x, const double *relw) {
+/* abs(weights[i]) (vegas/montecarlo.jl:173 etc.): |w| or the complex modulus (Julia abs(::Complex) = hypot) */
+static inline double absw(const mcio_config *c, const double *w, int i) {
+    return c->ncomp == 1 ? fabs(w[i]) : hypot(w[2 * i], w[2 * i + 1]);
+}
+
+/* default measure (ref: vegas/montecarlo.jl:151-153), "bin by a Discrete draw" (ref: example/bubble.jl:81-84),
+   or the user's measure (vegas/montecarlo.jl:156-161).  relw has Ni*ncomp entries. */
+static inline void measure(mcio_config *c, const double *x, const double *relw, const double *ud) {
+    if (c->measure_fn) {
+        c->measure_fn(x, relw, ud, -1, c->observable);
+        return;
+    }
     for (int i = 0; i < c->Ni; ++i) {
-        int bin = 0;
         if (c->obs_bin_draw[i] >= 0) {
             const mcio_leaf *T = &c->leaf[c->draw_leaf[c->obs_bin_draw[i]]];
-            bin = (int)(x[c->obs_bin_draw[i]] - T->lower);
+            int bin = (int)(x[c->obs_bin_draw[i]] - T->lower);
             if (bin < 0 || bin >= c->obs_nbin[i]) continue;
+            c->observable[c->obs_off[i] + bin] += relw[i];
+        } else {
+            for (int q = 0; q < c->ncomp; ++q) c->observable[c->obs_off[i] + q] += relw[i * c->ncomp + q];
         }
-        c->observable[c->obs_off[i] + bin] += relw[i];
     }
 }
 
@@ -702,11 +715,12 @@ int mcio_vegas_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint
                      uint32_t iteration, long block_index, long neval, long measurefreq) {
     const int Ni = c->Ni, npool = c->npool;
     if (c->ndraw > MCIO_MAXDRAW || Ni > MCIO_MAXNI || measurefreq <= 0) return -1; /* :77 */
-    double relw[MCIO_MAXNI], weights[MCIO_MAXNI], pad[MCIO_MAXNI]; /* :79-81 */
+    const int nc = c->ncomp;
+    double relw[2 * MCIO_MAXNI], weights[2 * MCIO_MAXNI], pad[MCIO_MAXNI]; /* :79-81 */
     int diff[MCIO_MAXNI];
     double x[MCIO_MAXDRAW], u[MCIO_MAXDRAW];
     for (int i = 0; i < Ni; ++i) {
-        weights[i] = 0.0;
+        weights[nc * i] = weights[nc * i + nc - 1] = 0.0;
         pad[i] = 1.0;
         diff[i] = 1; /* :82 dof[i] == maxdof */
         for (int v = 0; v < npool; ++v)
@@ -747,14 +761,15 @@ int mcio_vegas_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint
         gather_x(c, x);
         f(x, weights, ud); /* :140-144 */
         if (ne % measurefreq == 0) { /* :148 */
-            for (int i = 0; i < Ni; ++i) relw[i] = weights[i] * pad[i] * jac; /* :152 / :157 */
-            measure(c, x, relw);
+            for (int i = 0; i < Ni; ++i)
+                for (int q = 0; q < nc; ++q) relw[nc * i + q] = weights[nc * i + q] * pad[i] * jac; /* :152 / :157 */
+            measure(c, x, relw, ud);
             c->normalization += 1.0; /* :164 */
         }
         for (int vi = 0; vi < npool; ++vi) { /* :170 */
             const int off = c->pool_offset[vi];
             for (int i = 0; i < Ni; ++i) {   /* :172 */
-                double w2 = fabs(weights[i]); /* :173 */
+                double w2 = absw(c, weights, i); /* :173 */
                 double j2 = jac;              /* :174 */
                 for (int pos = 1; pos <= c->dof[i * npool + vi]; ++pos) /* :179 */
                     pool_accumulate(c, vi, pos + off, (w2 * j2) * (w2 * j2)); /* :180 */
@@ -776,7 +791,8 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
                        long nchain) {
     const int N = c->Ni, npool = c->npool, norm = c->Ni;
     if (c->ndraw > MCIO_MAXDRAW || N + 1 > MCIO_MAXNI || measurefreq <= 0 || nchain < 1) return -1;
-    double weights[MCIO_MAXNI], _weights[MCIO_MAXNI], relw[MCIO_MAXNI];
+    const int nc = c->ncomp;
+    double weights[2 * MCIO_MAXNI], _weights[2 * MCIO_MAXNI], relw[2 * MCIO_MAXNI];
     double pad[MCIO_MAXNI], _pad[MCIO_MAXNI]; /* :147-148 */
     double x[MCIO_MAXDRAW], u[MCIO_MAXDRAW];
     const long steps = neval / nchain;
@@ -807,8 +823,8 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
         for (int i = 0; i <= N; ++i) pad[i] = mcio_padding_probability(c, i); /* :161 */
         double probability = c->reweight[norm] * pad[norm];                   /* :162 */
         for (int i = 0; i < N; ++i) {                                         /* :163-166 */
-            weights[i] = _weights[i];
-            probability += fabs(_weights[i]) * c->reweight[i] * pad[i];
+            for (int q = 0; q < nc; ++q) weights[nc * i + q] = _weights[nc * i + q];
+            probability += absw(c, _weights, i) * c->reweight[i] * pad[i];
         }
         for (long ne = 1; ne <= steps; ++ne) { /* :184 */
             const uint64_t sidx = (g << 32) | (uint64_t)(ne - 1);
@@ -830,12 +846,12 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
                 c->neval += 1;                                 /* :77 */
                 for (int i = 0; i <= N; ++i) _pad[i] = mcio_padding_probability(c, i); /* :79-81 */
                 double newp = c->reweight[norm] * _pad[norm];                          /* :84 */
-                for (int i = 0; i < N; ++i) newp += fabs(_weights[i]) * c->reweight[i] * _pad[i]; /* :85-87 */
+                for (int i = 0; i < N; ++i) newp += absw(c, _weights, i) * c->reweight[i] * _pad[i]; /* :85-87 */
                 double R = prop * newp / probability;          /* :88 */
                 c->propose[vi] += 1.0;                         /* :90 */
                 if (mcio_uniform(seed, st_step, sidx, 2) < R) { /* :91 */
                     c->accept[vi] += 1.0;                      /* :92 */
-                    for (int i = 0; i < N; ++i) weights[i] = _weights[i]; /* :93-95 */
+                    for (int i = 0; i < N * nc; ++i) weights[i] = _weights[i]; /* :93-95 */
                     for (int i = 0; i <= N; ++i) pad[i] = _pad[i];        /* :96-98 */
                     probability = newp;                        /* :100 */
                 } else {
@@ -844,7 +860,7 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
             } while (0);
             /* ---- histogram  ref: montecarlo.jl:198-211 ---- */
             for (int i = 0; i < N; ++i) {
-                double f2 = fabs(weights[i]) * fabs(weights[i]) / mcio_probability(c, i); /* :203 */
+                double f2 = absw(c, weights, i) * absw(c, weights, i) / mcio_probability(c, i); /* :203 */
                 double wf2 = f2 * pad[i] / probability;                                   /* :204 */
                 for (int vi = 0; vi < npool; ++vi)                                        /* :205 */
                     for (int pos = 1; pos <= c->dof[i * npool + vi]; ++pos)               /* :207 */
@@ -853,11 +869,11 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
             /* ---- measurement  ref: montecarlo.jl:213-232 ---- */
             if (ne % measurefreq == 0 && (double)ne >= burnin) { /* :213 */
                 for (int i = 0; i < N; ++i) {
-                    c->visited[i] += fabs(weights[i] * pad[i] * c->reweight[i]) / probability; /* :216 */
-                    relw[i] = weights[i] * pad[i] / probability;                               /* :218/:220 */
+                    c->visited[i] += absw(c, weights, i) * fabs(pad[i] * c->reweight[i]) / probability; /* :216 */
+                    for (int q = 0; q < nc; ++q) relw[nc * i + q] = weights[nc * i + q] * pad[i] / probability; /* :218/:220 */
                 }
                 gather_x(c, x); /* measure() reads the current (accepted) variables */
-                measure(c, x, relw);
+                measure(c, x, relw, ud);
                 c->normalization += 1.0 * pad[norm] / probability;                   /* :229 */
                 c->visited[norm] += c->reweight[norm] * pad[norm] / probability;    /* :230 */
             }
@@ -907,28 +923,39 @@ int mcio_set_neighbor(mcio_config *c, const int *offsets, const int *list) {
 }
 
 void mcio_set_thermal_ratio(mcio_config *c, double r) { c->thermal_ratio = r; }
+void mcio_set_ncomp(mcio_config *c, int ncomp) { c->ncomp = ncomp == 2 ? 2 : 1; }
+void mcio_set_measure(mcio_config *c, mcio_measure_fn fn) { c->measure_fn = fn; }
 
 void mcio_set_reweight_goal(mcio_config *c, const double *goal) {
     free(c->reweight_goal);
     c->reweight_goal = goal ? (double *)dup_mem(goal, sizeof(double) * (size_t)(c->Ni + 1)) : NULL;
 }
 
-/* measure for the one integrand the chain sits on (mcmc/montecarlo.jl:163-170) */
-static inline void measure_one(mcio_config *c, const double *x, int i, double relw) {
-    int bin = 0;
+/* measure for the one integrand the chain sits on (mcmc/montecarlo.jl:163-170); relw has ncomp entries */
+static inline void measure_one(mcio_config *c, const double *x, int i, const double *relw, const double *ud) {
+    if (c->measure_fn) {
+        double rw[2 * MCIO_MAXNI];
+        for (int k = 0; k < c->Ni * c->ncomp; ++k) rw[k] = 0.0;
+        for (int q = 0; q < c->ncomp; ++q) rw[i * c->ncomp + q] = relw[q];
+        c->measure_fn(x, rw, ud, i, c->observable);
+        return;
+    }
     if (c->obs_bin_draw[i] >= 0) {
         const mcio_leaf *T = &c->leaf[c->draw_leaf[c->obs_bin_draw[i]]];
-        bin = (int)(x[c->obs_bin_draw[i]] - T->lower);
+        int bin = (int)(x[c->obs_bin_draw[i]] - T->lower);
         if (bin < 0 || bin >= c->obs_nbin[i]) return;
+        c->observable[c->obs_off[i] + bin] += relw[0];
+        return;
     }
-    c->observable[c->obs_off[i] + bin] += relw;
+    for (int q = 0; q < c->ncomp; ++q) c->observable[c->obs_off[i] + q] += relw[q];
 }
 
 int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint64_t seed,
                     uint32_t iteration, long block_index, long neval, long measurefreq, long nchain) {
     const int npool = c->npool, norm = c->Ni, Nd = c->Ni + 1;
     if (c->ndraw > MCIO_MAXDRAW || Nd > MCIO_MAXNI || measurefreq <= 0 || nchain < 1) return -1; /* :79 */
-    double w[MCIO_MAXNI], x[MCIO_MAXDRAW], u[MCIO_MAXDRAW];
+    const int nc = c->ncomp;
+    double w[2 * MCIO_MAXNI], x[MCIO_MAXDRAW], u[MCIO_MAXDRAW];
     int kbase[64];
     int nslots = 0;
     for (int vi = 0, k = 0; vi < npool; ++vi) {
@@ -944,7 +971,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
     for (long ch = 0; ch < nchain; ++ch) {
         const uint64_t g = (uint64_t)block_index * (uint64_t)nchain + (uint64_t)ch;
         int curr = (nchain == 1) ? 0 : (int)(g % (uint64_t)Nd); /* :76 idx = 1; many chains start stratified */
-        double weight = 0.0, probability = 1.0;                  /* :116 _State(curr, zero(T), 1.0) */
+        double weight[2] = {0.0, 0.0}, probability = 1.0;        /* :116 _State(curr, zero(T), 1.0) */
         for (long t = 0; t < 10000; ++t) {                       /* :118-124 */
             /* initialize!  :190-205 (only the slots that are ever read: 1..maxdof) */
             for (int vi = 0; vi < npool; ++vi)
@@ -957,10 +984,10 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
             if (curr != norm) {
                 gather_x(c, x);
                 f(x, w, ud);
-                weight = w[curr];                                   /* :197 */
-                probability = fabs(weight) * c->reweight[curr];     /* :199 */
+                for (int q = 0; q < nc; ++q) weight[q] = w[nc * curr + q]; /* :197 */
+                probability = absw(c, w, curr) * c->reweight[curr]; /* :199 */
             } else {
-                weight = 0.0;                                       /* :201 */
+                weight[0] = weight[1] = 0.0;                        /* :201 */
                 probability = c->reweight[curr];                    /* :202 */
             }
             if (curr == norm || probability > MCIO_TINY) break;     /* :120-122 */
@@ -993,20 +1020,23 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         }
                     }
                     if (prop <= 4.9406564584124654e-324) break;    /* :29-31 */
-                    double neww = 0.0;                              /* :35-38 */
+                    double neww[2] = {0.0, 0.0};                    /* :35-38 */
+                    double newabs = 0.0;
                     if (new_ != norm) {
                         gather_x(c, x);
                         f(x, w, ud);
-                        neww = w[new_];
+                        for (int q = 0; q < nc; ++q) neww[q] = w[nc * new_ + q];
+                        newabs = absw(c, w, new_);
                     }
                     c->neval += 1;                                  /* :40 */
-                    const double newp = (new_ == norm) ? c->reweight[new_] : fabs(neww) * c->reweight[new_]; /* :42-44 */
+                    const double newp = (new_ == norm) ? c->reweight[new_] : newabs * c->reweight[new_]; /* :42-44 */
                     const double R = prop * newp / probability;     /* :46 */
                     c->propose[0] += 1.0;                           /* :48 propose[1, curr, new] */
                     if (mcio_uniform(seed, st_step, sidx, 4) < R) { /* :49 */
                         c->accept[0] += 1.0;                        /* :50 */
                         curr = new_;                                /* :51-53 */
-                        weight = neww;
+                        weight[0] = neww[0];
+                        weight[1] = neww[1];
                         probability = newp;
                     } /* else createRollback!/removeRollback! are no-ops  :55-68, sampler.jl:306,324 */
                 } while (0);
@@ -1028,12 +1058,12 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         gather_x(c, x);
                         f(x, w, ud);                                /* :133 */
                         c->neval += 1;                              /* :135 */
-                        const double newp = fabs(w[curr]) * c->reweight[curr]; /* :137 */
+                        const double newp = absw(c, w, curr) * c->reweight[curr]; /* :137 */
                         const double R = prop * newp / probability; /* :138 */
                         c->propose[2] += 1.0;                       /* :140 propose[3, curr, vi] */
                         if (mcio_uniform(seed, st_step, sidx, 4) < R) {
                             c->accept[2] += 1.0;
-                            weight = w[curr];
+                            for (int q = 0; q < nc; ++q) weight[q] = w[nc * curr + q];
                             probability = newp;
                         } else {
                             mcio_pool_swap(c, vi, s1 + off, s2 + off); /* :145 swapRollback! */
@@ -1054,12 +1084,12 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         gather_x(c, x);
                         f(x, w, ud);                                /* :92 */
                         c->neval += 1;                              /* :94 */
-                        const double newp = fabs(w[curr]) * c->reweight[curr]; /* :96 */
+                        const double newp = absw(c, w, curr) * c->reweight[curr]; /* :96 */
                         const double R = prop * newp / probability; /* :97 */
                         c->propose[1] += 1.0;                       /* :99 propose[2, curr, vi] */
                         if (mcio_uniform(seed, st_step, sidx, 4) < R) {
                             c->accept[1] += 1.0;
-                            weight = w[curr];
+                            for (int q = 0; q < nc; ++q) weight[q] = w[nc * curr + q];
                             probability = newp;
                         } else {
                             mcio_pool_shift_rollback(c, vi, slot + off); /* :105 */
@@ -1074,7 +1104,8 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         for (int pos = 1; pos <= c->dof[curr * npool + vi]; ++pos)
                             pool_accumulate(c, vi, pos + c->pool_offset[vi], 1.0);
                     gather_x(c, x);
-                    measure_one(c, x, curr, weight / probability);  /* :161-169 */
+                    double rel[2] = {weight[0] / probability, weight[1] / probability}; /* :162 */
+                    measure_one(c, x, curr, rel, ud);               /* :161-169 */
                 } else {
                     c->normalization += 1.0 / c->reweight[norm];    /* :158 */
                 }

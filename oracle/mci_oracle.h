@@ -44,8 +44,12 @@ enum {
     MCIO_PROB_SHIFT = 1   /* prob *= dx_old/dx_new  sampler.jl:383-384 (what Vegas.montecarlo runs) */
 };
 
-/* user integrand: x = flat draws (see mcio_config), w = Ni outputs, ud = userdata */
+/* user integrand: x = flat draws (see mcio_config), w = Ni*ncomp outputs (ncomp = 2: (re, im) pairs), ud = userdata */
 typedef void (*mcio_integrand_fn)(const double *x, double *w, const double *ud);
+/* user measure (vegas/montecarlo.jl:156-161; mcmc/montecarlo.jl:166-169): rw = relative weights [Ni*ncomp],
+   idx = -1 (vegas, vegasmc: all integrands) or the current integrand (mcmc: only rw[idx*ncomp ..] is valid),
+   obs = the flat observable array it accumulates into */
+typedef void (*mcio_measure_fn)(const double *x, const double *rw, const double *ud, int idx, double *obs);
 
 typedef struct {
     int kind;           /* MCIO_CONTINUOUS | MCIO_DISCRETE */
@@ -96,6 +100,8 @@ typedef struct {
     int **neighbor;       /* [Ni+1][nneighbor] 0-based integrand indices; index Ni = normalisation */
     double thermal_ratio; /* mcmc/montecarlo.jl:77 (default 0.1) */
     double *reweight_goal; /* [Ni+1] or NULL  main.jl:81, :334-337 */
+    int ncomp;             /* 1: Float64 weights; 2: ComplexF64 (`type` kwarg, configuration.jl:108) stored (re, im) */
+    mcio_measure_fn measure_fn; /* NULL = default / bin-by-Discrete measure */
 } mcio_config;
 
 typedef struct {
@@ -169,6 +175,8 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
 long mcio_mcmc_burnin(long steps, long nchain, int nslots, int Nd, int npool, double thermal_ratio);
 int mcio_set_neighbor(mcio_config *c, const int *offsets /* [Ni+2] */, const int *list); /* configuration.jl:201-227 */
 void mcio_set_thermal_ratio(mcio_config *c, double r);
+void mcio_set_ncomp(mcio_config *c, int ncomp);              /* before any run; resizes nothing: obs_nbin already counts doubles */
+void mcio_set_measure(mcio_config *c, mcio_measure_fn fn);
 void mcio_set_reweight_goal(mcio_config *c, const double *goal /* [Ni+1] or NULL */);
 
 /* ---- main.jl / statistics.jl ---- */

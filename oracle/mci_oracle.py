@@ -47,7 +47,8 @@ class _Config(C.Structure):
                 ("observable", c_double_p), ("normalization", C.c_double), ("neval", C.c_long),
                 ("reweight", c_double_p), ("visited", c_double_p), ("propose", c_double_p),
                 ("accept", c_double_p), ("prob_mode", C.c_int), ("npa", C.c_int), ("nneighbor", c_int_p),
-                ("neighbor", C.POINTER(c_int_p)), ("thermal_ratio", C.c_double), ("reweight_goal", c_double_p)]
+                ("neighbor", C.POINTER(c_int_p)), ("thermal_ratio", C.c_double), ("reweight_goal", c_double_p),
+                ("ncomp", C.c_int), ("measure_fn", C.c_void_p)]
 
 
 class _Result(C.Structure):
@@ -113,6 +114,8 @@ def lib():
     L.mcio_set_neighbor.argtypes = [C.POINTER(_Config), c_int_p, c_int_p]
     L.mcio_set_thermal_ratio.argtypes = [C.POINTER(_Config), C.c_double]
     L.mcio_set_reweight_goal.argtypes = [C.POINTER(_Config), c_double_p]
+    L.mcio_set_ncomp.argtypes = [C.POINTER(_Config), C.c_int]
+    L.mcio_set_measure.argtypes = [C.POINTER(_Config), C.c_void_p]
     L.mcio_pool_remove.restype = C.c_double
     L.mcio_pool_remove.argtypes = [C.POINTER(_Config), C.c_int, C.c_int]
     L.mcio_pool_swap.restype = C.c_double
@@ -399,6 +402,14 @@ class Config:
     def neighbor(self):
         return [[self.c.neighbor[d][j] for j in range(self.c.nneighbor[d])] for d in range(self.c.Ni + 1)]
 
+    def set_ncomp(self, ncomp):
+        """2 = ComplexF64 weights stored as (re, im); obs_nbin must already count doubles"""
+        lib().mcio_set_ncomp(self.p, int(ncomp))
+
+    def set_measure(self, fnptr):
+        """raw pointer from compile_c_measure (or None for the default measure)"""
+        lib().mcio_set_measure(self.p, fnptr)
+
     def set_thermal_ratio(self, r):
         lib().mcio_set_thermal_ratio(self.p, float(r))
 
@@ -462,6 +473,28 @@ def _fnptr(f):
     if isinstance(f, int):
         return f
     raise TypeError("integrand must be a builtin name or a C function pointer")
+
+
+def compile_c_measure(body):
+    """gcc-compile a measure body (the same text the HIP path JIT-compiles): in scope `x`, `rw`, `ud`, `idx` and
+    `obs_add(k, v)` which accumulates v into flat observable k."""
+    import hashlib
+    import tempfile
+    src = ("#include <math.h>\n#define obs_add(k, v) (obs[(k)] += (v))\n"
+           "void mci_user_measure(const double* x, const double* rw, const double* ud, int idx, double* obs) {\n"
+           "(void)x; (void)rw; (void)ud; (void)idx;\n%s\n}\n" % body)
+    h = hashlib.sha1(src.encode()).hexdigest()[:16]
+    d = os.path.join(tempfile.gettempdir(), "mci_oracle_user")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, "m_%s.so" % h)
+    if not os.path.exists(so):
+        cfile = os.path.join(d, "m_%s.c" % h)
+        with open(cfile, "w") as fh:
+            fh.write(src)
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, cfile, "-lm"])
+    L = C.CDLL(so)
+    _keepalive.append(L)
+    return C.cast(L.mci_user_measure, C.c_void_p).value
 
 
 def compile_c_integrand(body, ni=1, name="user"):

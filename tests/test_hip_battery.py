@@ -85,6 +85,46 @@ def test_battery(alg, neval):
     check(TestHyperSphere(neval, alg, 3), [0.9230, 0.94724, 0.96118])
 
 
+def TestComplex1(totalstep, alg):
+    # f(x, c) = x[1] + x[1]^2 * 1im   (test/montecarlo.jl:166-170)
+    return integrate("w[0] = x[0]; w[1] = x[0] * x[0];", neval=totalstep, print=-1, type=complex, solver=alg, debug=True, seed=110)
+
+
+def TestComplex2(totalstep, alg):
+    # integrand returns (x[1], x[1]^2 * 1im): real -> complex conversion  (test/montecarlo.jl:172-185)
+    return integrate("w[0] = x[0]; w[1] = 0.0; w[2] = 0.0; w[3] = x[0] * x[0];", dof=[[1], [1]], neval=totalstep, print=-1, type=complex,
+                     solver=alg, debug=True, seed=111)
+
+
+def Sphere3(totalstep, alg, offset=0):
+    # two integrands, nested observable shape, user measure  (test/montecarlo.jl:53-92)
+    measure = mci.Measure("""
+        if (idx < 0 || idx == 0) obs_add(0, rw[0]);                                  // obs[1] += relativeWeights[1]
+        if (idx < 0 || idx == 1) { obs_add(1, rw[1]); obs_add(2, rw[1] * 2.0); }     // obs[2][1], obs[2][2]
+    """)
+    T = Continuous(0.0, 1.0, offset=offset)
+    config = Configuration(var=(T,), dof=[[2], [3]], neighbor=[(1, 3), (1, 2)], obs=[0.0, [0.0, 0.0]], seed=112)
+    return integrate(mci.catalog.sphere2(), config=config, neval=totalstep, print=-1, solver=alg, debug=True, measure=measure)
+
+
+def check_complex(result, expect, ratio=7.0):
+    # test/runtests.jl:17-29
+    expect = np.atleast_1d(np.asarray(expect, dtype=complex))
+    for ei in range(len(expect)):
+        m, e = complex(np.ravel(result.mean[ei])[0]), complex(np.ravel(result.stdev[ei])[0])
+        assert abs(m.real - expect[ei].real) < e.real * ratio, (result.mean, result.stdev, expect)
+        assert abs(m.imag - expect[ei].imag) < e.imag * ratio, (result.mean, result.stdev, expect)
+
+
+@pytest.mark.parametrize("alg,neval", [("vegas", 200000), ("vegasmc", 100000), ("mcmc", 200000)])
+def test_complex_and_user_measure(alg, neval):
+    check_complex(TestComplex1(neval, alg), 0.5 + 1j / 3)                            # test/montecarlo.jl:292, :331, :376
+    check_complex(TestComplex2(neval, alg), [0.5, 1j / 3])
+    res = Sphere3(neval, alg)                                                        # test/montecarlo.jl:273
+    assert abs(res.mean[0] - PI / 4) < 7 * res.stdev[0]
+    np.testing.assert_array_less(np.abs(res.mean[1] - np.array([PI / 6, PI / 3])), 7 * res.stdev[1])
+
+
 def test_readme_example_and_report(capsys):
     # README.md:26-27: -4.000214 +- 0.000300 with the default solver, neval=1e5
     res = integrate("return log(x[0]) / sqrt(x[0]);", neval=1e5, seed=5, print=0)

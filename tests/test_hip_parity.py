@@ -243,6 +243,46 @@ def test_mcmc_full_integrate_matches_oracle(oracle):
     np.testing.assert_allclose(eng.reweight(), ocfg.reweight, rtol=1e-9)
 
 
+COMPLEX_BODY = "w[0] = x[0]; w[1] = 0.0; w[2] = 0.5 * x[0]; w[3] = x[0] * x[0];"   # TestComplex2 (test/montecarlo.jl:172-185) + a mixed one
+MEASURE_BODY = "if (idx < 0 || idx == 0) obs_add(0, rw[0]); if (idx < 0 || idx == 1) { obs_add(1, rw[1]); obs_add(2, rw[1] * 2.0); }"   # Sphere3 (:71-84)
+
+
+@pytest.mark.parametrize("solver", ["vegas", "vegasmc", "mcmc"])
+def test_complex_weights_match_oracle(oracle, solver):
+    """type=ComplexF64 -- abs() is the modulus, (re, im) are separate statistics columns
+    (main.jl:279,284,302-305; statistics.jl:207-214)."""
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1], [1]], type=complex, seed=SEED)
+    eng = mci.Engine(cfg, mci.Integrand(COMPLEX_BODY))
+    assert eng.nobs == 4
+    ocfg = oracle.Config([ocont()], [[1], [1]], obs_nbin=[2, 2])
+    ocfg.set_ncomp(2)
+    fn = oracle.compile_c_integrand(COMPLEX_BODY)
+    osolver = dict(vegas=oracle.VEGAS, vegasmc=oracle.VEGASMC, mcmc=oracle.MCMC)[solver]
+    got = eng.iteration(solver, 4000, 0, 4, iteration=0, seed=SEED, nchain=8)
+    ref = ocfg.iteration(osolver, fn, None, 4000, 0, 4, 0, SEED, nchain=8)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+    r = eng.integrate(solver, neval=40000, niter=4, block=8, seed=SEED, nchain=4)
+    o = ocfg.integrate(osolver, fn, None, neval=40000, niter=4, block=8, seed=SEED, nchain=4)
+    np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-5, atol=1e-300)
+
+
+@pytest.mark.parametrize("solver", ["vegas", "vegasmc", "mcmc"])
+def test_user_measure_matches_oracle(oracle, solver):
+    """a user `measure` (vegas/montecarlo.jl:156-161, mcmc/montecarlo.jl:166-169) with a nested observable
+    shape obs = [0.0, [0.0, 0.0]] (test/montecarlo.jl:53-92): the same source text runs on the GPU and, gcc-compiled,
+    in the oracle."""
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]], obs=[0.0, [0.0, 0.0]], seed=SEED)
+    eng = mci.Engine(cfg, mci.catalog.sphere2(), measure=mci.Measure(MEASURE_BODY))
+    assert eng.nobs == 3
+    ocfg = oracle.Config([ocont()], [[2], [3]], obs_nbin=[1, 2])
+    ocfg.set_measure(oracle.compile_c_measure(MEASURE_BODY))
+    osolver = dict(vegas=oracle.VEGAS, vegasmc=oracle.VEGASMC, mcmc=oracle.MCMC)[solver]
+    got = eng.iteration(solver, 4000, 0, 4, iteration=1, seed=SEED, nchain=8)
+    ref = ocfg.iteration(osolver, "sphere2", None, 4000, 0, 4, 1, SEED, nchain=8)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+    assert got[2] == pytest.approx(2.0 * got[1], rel=1e-12)   # obs[2][2] accumulates twice obs[2][1]
+
+
 def test_user_snippet_matches_gcc_compiled_oracle(oracle):
     """an arbitrary user integrand: the same C text JIT-compiled for gfx950 and gcc-compiled for the oracle."""
     body = "w[0] = exp(-x[0]) * cos(3.0 * x[1]) + ud[0] * x[2] * x[2];"

@@ -144,13 +144,16 @@ def main():
     if rank == 0:
         value = a.steps * neval / dt / 1e6
         achieved = B_ALG * (nevalperblock * per) / (k_avg_ms * 1e-3) / 1e9  # GB/s, one launch on one GPU
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tf):
+        # PMC-derived per-launch figures of this same workload (profiles/collect.sh; separate --pmc passes)
+        traffic, valu_insts = None, None
+        import glob
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                pj = json.load(open(tf))
+                traffic = pj.get("hbm_bytes_per_launch")
+                valu_insts = pj.get("sq_avg_per_launch", {}).get("SQ_INSTS_VALU")
             except Exception:
-                traffic = None
+                pass
         out = {
             "metric": "Msamples/sec (whole node), 16-D Gaussian :vegas",
             "value": round(value, 2),
@@ -178,6 +181,14 @@ def main():
                                  "the tables are LDS-resident by design, so real HBM traffic (traffic) is ~0 and frac may exceed 1: "
                                  "the kernel is fp64-VALU/Philox bound, see DESIGN.md"},
         }
+        if valu_insts and neval_gpu == 10**8:
+            # the bound the kernel actually runs against: one wave64 VALU instruction per 4 cycles on each of
+            # 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md); instruction count per launch from SQ_INSTS_VALU
+            peak = 256 * 4 * 2.4e9 / 4 / 1e9
+            ach = valu_insts / (k_avg_ms * 1e-3) / 1e9
+            out["roofline_valu"] = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(peak, 1),
+                                    "unit": "G wave-instructions/s", "frac": round(ach / peak, 4),
+                                    "insts_per_launch": valu_insts, "note": "SQ_INSTS_VALU (rocprofv3 --pmc, profiles/) / live HIP-event kernel time"}
         if not a.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

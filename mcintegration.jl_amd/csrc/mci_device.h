@@ -69,10 +69,12 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u
     return {c0, c1, c2, c3};
 }
 
-__device__ __forceinline__ double u01(u32 lo, u32 hi) {
+// 52 random mantissa bits as a double in [1, 2)
+__device__ __forceinline__ double u12(u32 lo, u32 hi) {
     const u64 bits = ((((u64)hi << 32) | lo) >> 12) | 0x3FF0000000000000ull;
-    return __longlong_as_double((i64)bits) - 1.0;
+    return __longlong_as_double((i64)bits);
 }
+__device__ __forceinline__ double u01(u32 lo, u32 hi) { return u12(lo, hi) - 1.0; }
 
 enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5 };
 enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_RESCALE_NONFINITE = 8, ST_MCMC_INIT = 16 };
@@ -151,12 +153,23 @@ template <class Cfg> struct Tables {
 // 1/prob = raw * jac_scale(K): raw = dx for a Continuous leaf (scale N), 1/distribution for a Discrete one.
 // With Cfg::PAIR_TABLE the LDS table holds (g[i], g[i+1]-g[i]) pairs: ONE aligned ds_read_b128 per draw and
 // no subtraction on the critical path (the pair is formed with the same rounding when the table is staged).
-template <class Cfg, int K> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
+// U12 = true: `y` is the uniform PLUS ONE (in [1, 2), see u12()).  y*N is then formed as fma(y+1, N, -N): (y+1) - 1 is
+// exact, so both forms round the same real number once -- bit-identical to (u - 1.0) * N, one instruction less.
+template <class Cfg, int K, bool U12 = false> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
     constexpr int leaf = Cfg::draw_leaf(K);
+    if constexpr (Cfg::leaf_kind(leaf) != 0 && U12) y -= 1.0;
     if constexpr (Cfg::leaf_kind(leaf) == 0) {
         // sampler.jl:295-303:  iy = floor(y*N)+1; dy = y*N-(iy-1); x = g[iy] + dy*(g[iy+1]-g[iy]); prob = 1/(N*dx)
         constexpr int N = Cfg::leaf_nbin(leaf);
-        const double yn = y * (double)N;
+        double yn;
+        if constexpr (U12) {
+            // one VOP3 fma with N in an SGPR pair used twice (src2 negated): the compiler's own choice for
+            // fma(y, N, -N) is v_fmac + two v_mov of the literal, which is no gain over add + mul
+            const double nn = (double)N;
+            asm("v_fma_f64 %0, %1, %2, -%2" : "=v"(yn) : "v"(y), "s"(nn));
+        } else {
+            yn = y * (double)N;
+        }
         const int iy = (int)yn;                           // y*N >= 0: trunc == floor
         const double dy = __builtin_amdgcn_fract(yn);     // v_fract_f64 == yn - floor(yn), exact
 #ifdef MCI_ABL_NOTABLE
@@ -229,9 +242,9 @@ template <class Cfg> __device__ __forceinline__ void draw_sample(const Tables<Cf
         static_for<0, 2>([&](auto H) {
             constexpr int k = 2 * c + decltype(H)::value;
             if constexpr (k < Cfg::NDRAW) {
-                const double y = decltype(H)::value == 0 ? u01(r.x, r.y) : u01(r.z, r.w);
+                const double y1 = decltype(H)::value == 0 ? u12(r.x, r.y) : u12(r.z, r.w);
                 double raw;
-                draw_leaf<Cfg, k>(t, y, s.x[k], raw, s.bin[k]);
+                draw_leaf<Cfg, k, true>(t, y1, s.x[k], raw, s.bin[k]);
                 s.pj[k] = raw * jac_scale<Cfg>(k);
                 s.jac *= raw; // jac /= prob   vegas/montecarlo.jl:126 (scale applied below)
                 static_for<0, Cfg::NI>([&](auto I) {

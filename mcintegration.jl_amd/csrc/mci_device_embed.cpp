@@ -71,10 +71,12 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u
     return {c0, c1, c2, c3};
 }
 
-__device__ __forceinline__ double u01(u32 lo, u32 hi) {
+// 52 random mantissa bits as a double in [1, 2)
+__device__ __forceinline__ double u12(u32 lo, u32 hi) {
     const u64 bits = ((((u64)hi << 32) | lo) >> 12) | 0x3FF0000000000000ull;
-    return __longlong_as_double((i64)bits) - 1.0;
+    return __longlong_as_double((i64)bits);
 }
+__device__ __forceinline__ double u01(u32 lo, u32 hi) { return u12(lo, hi) - 1.0; }
 
 enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5 };
 enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_RESCALE_NONFINITE = 8, ST_MCMC_INIT = 16 };
@@ -150,16 +152,27 @@ template <class Cfg> struct Tables {
 };
 
 // one leaf draw: create! in its Jacobian form.  Returns x, the bin index (0-based) and `raw` with
-// 1/prob = raw * jac_scale(K): raw = dx for a Continuous leaf (scale N), 1/distribution for a Discrete one.
-// With Cfg::PAIR_TABLE the LDS table holds (g[i], g[i+1]-g[i]) pairs: ONE aligned ds_read_b128 )MCIDEV"
-R"MCIDEV(per draw and
+// 1/prob = raw * jac_scale(K): raw = dx for a Continuous leaf (scale N), 1/di)MCIDEV"
+R"MCIDEV(stribution for a Discrete one.
+// With Cfg::PAIR_TABLE the LDS table holds (g[i], g[i+1]-g[i]) pairs: ONE aligned ds_read_b128 per draw and
 // no subtraction on the critical path (the pair is formed with the same rounding when the table is staged).
-template <class Cfg, int K> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
+// U12 = true: `y` is the uniform PLUS ONE (in [1, 2), see u12()).  y*N is then formed as fma(y+1, N, -N): (y+1) - 1 is
+// exact, so both forms round the same real number once -- bit-identical to (u - 1.0) * N, one instruction less.
+template <class Cfg, int K, bool U12 = false> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
     constexpr int leaf = Cfg::draw_leaf(K);
+    if constexpr (Cfg::leaf_kind(leaf) != 0 && U12) y -= 1.0;
     if constexpr (Cfg::leaf_kind(leaf) == 0) {
         // sampler.jl:295-303:  iy = floor(y*N)+1; dy = y*N-(iy-1); x = g[iy] + dy*(g[iy+1]-g[iy]); prob = 1/(N*dx)
         constexpr int N = Cfg::leaf_nbin(leaf);
-        const double yn = y * (double)N;
+        double yn;
+        if constexpr (U12) {
+            // one VOP3 fma with N in an SGPR pair used twice (src2 negated): the compiler's own choice for
+            // fma(y, N, -N) is v_fmac + two v_mov of the literal, which is no gain over add + mul
+            const double nn = (double)N;
+            asm("v_fma_f64 %0, %1, %2, -%2" : "=v"(yn) : "v"(y), "s"(nn));
+        } else {
+            yn = y * (double)N;
+        }
         const int iy = (int)yn;                           // y*N >= 0: trunc == floor
         const double dy = __builtin_amdgcn_fract(yn);     // v_fract_f64 == yn - floor(yn), exact
 #ifdef MCI_ABL_NOTABLE
@@ -232,9 +245,9 @@ template <class Cfg> __device__ __forceinline__ void draw_sample(const Tables<Cf
         static_for<0, 2>([&](auto H) {
             constexpr int k = 2 * c + decltype(H)::value;
             if constexpr (k < Cfg::NDRAW) {
-                const double y = decltype(H)::value == 0 ? u01(r.x, r.y) : u01(r.z, r.w);
+                const double y1 = decltype(H)::value == 0 ? u12(r.x, r.y) : u12(r.z, r.w);
                 double raw;
-                draw_leaf<Cfg, k>(t, y, s.x[k], raw, s.bin[k]);
+                draw_leaf<Cfg, k, true>(t, y1, s.x[k], raw, s.bin[k]);
                 s.pj[k] = raw * jac_scale<Cfg>(k);
                 s.jac *= raw; // jac /= prob   vegas/montecarlo.jl:126 (scale applied below)
                 static_for<0, Cfg::NI>([&](auto I) {
@@ -298,7 +311,8 @@ template <class Cfg> struct Lds {
 template <class Cfg> struct Cols {
     static constexpr int NPA = Cfg::NPOOL > 3 ? Cfg::NPOOL : 3;
     static constexpr int NORM = Cfg::NOBS;
-    static constexpr int NEVAL = Cfg::NOBS + 1;
+    static constexpr int NEVA)MCIDEV"
+R"MCIDEV(L = Cfg::NOBS + 1;
     static constexpr int VISITED = Cfg::NOBS + 2;
     static constexpr int PROPOSE = VISITED + Cfg::NI + 1;
     static constexpr int ACCEPT = PROPOSE + NPA;
@@ -312,8 +326,7 @@ template <class Cfg> __device__ __forceinline__ void hist_update(const Sample<Cf
     static_for<0, Cfg::NDRAW>([&](auto K) {
         constexpr int k = decltype(K)::value;
         constexpr int leaf = Cfg::draw_leaf(k);
-        if constexpr (Cfg::leaf_adapt(leaf) != 0 &&)MCIDEV"
-R"MCIDEV( Cfg::cover_mask(k) != 0ull) { // T.adapt  variable.jl:197,:363
+        if constexpr (Cfg::leaf_adapt(leaf) != 0 && Cfg::cover_mask(k) != 0ull) { // T.adapt  variable.jl:197,:363
             double wk = 0.0;
             static_for<0, Cfg::NI>([&](auto I) {
                 constexpr int i = decltype(I)::value;
@@ -455,7 +468,8 @@ template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs
         extra[Cols<Cfg>::NEVAL - Cfg::NOBS] += 1.0; // config.neval += 1   :118
         if (a.measurefreq == 1 || (n + 1) % a.measurefreq == 0) { // :148
             double relw[Cfg::NW];
-            static_for<0, Cfg::NW>([&](auto Q) { constexpr int q = decltype(Q)::value; relw[q] = w[q] * s.jaci[q / Cfg::NCOMP]; }); // :152
+            static_for<0, Cfg::NW>([&](auto Q) { constexpr int q = decltype(Q)::value; )MCIDEV"
+R"MCIDEV(relw[q] = w[q] * s.jaci[q / Cfg::NCOMP]; }); // :152
             measure<Cfg>(s.x, s.bin, relw, a.ud, acc, sO);
             extra[Cols<Cfg>::NORM - Cfg::NOBS] += 1.0; // :164
         }
@@ -476,8 +490,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs
 }
 
 // =============================================================================================
-// VegasMC: independe)MCIDEV"
-R"MCIDEV(nt Metropolis chains, one per lane  (vegas_mc/montecarlo.jl:112-241,
+// VegasMC: independent Metropolis chains, one per lane  (vegas_mc/montecarlo.jl:112-241,
 // vegas_mc/updates.jl:45-106).  The reference runs ONE chain of neval steps per block; a block here
 // is `nchain` chains of neval/nchain steps (nchain = 1 reproduces the reference's chain).  Chain state
 // (x, prob, bin per draw; weights; probability) stays in registers; the proposal touches one
@@ -612,7 +625,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
             bool active = false;
             static_for<0, Cfg::NPOOL>([&](auto V) {
                 constexpr int v = decltype(V)::value;
-                constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                constexpr int md = Cfg)MCIDEV"
+R"MCIDEV(::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
                 // :52-57  a lone single-valued Discrete, or a pool nobody uses, has nothing to sample
                 constexpr bool skip = (md <= 0) || (nl == 1 && Cfg::leaf_kind(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1 &&
                                                     Cfg::leaf_nbin(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1);
@@ -623,8 +637,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                         if (slot >= md) slot = md - 1;
                         static_for<0, nl>([&](auto Lf) {
                             constexpr int l = decltype(Lf)::value;
-                            constexpr int kk = 3 + l; // RNG draw index)MCIDEV"
-R"MCIDEV( within the step
+                            constexpr int kk = 3 + l; // RNG draw index within the step
                             double y;
                             if constexpr (kk == 3) y = u01(r1.z, r1.w);
                             else {
@@ -748,7 +761,8 @@ __device__ __forceinline__ double step_uniform_dyn(int k, u64 sidx, u32 stream, 
     return (k & 1) ? u01(r.z, r.w) : u01(r.x, r.y);
 }
 // histogram add of one draw with the table-mode dispatch of hist_update
-template <class Cfg, int K> __device__ __forceinline__ void hist_add(int bin, double wk, double *sH, double *gH, int tile) {
+templ)MCIDEV"
+R"MCIDEV(ate <class Cfg, int K> __device__ __forceinline__ void hist_add(int bin, double wk, double *sH, double *gH, int tile) {
     constexpr int leaf = Cfg::draw_leaf(K);
     if constexpr (Cfg::leaf_adapt(leaf) != 0) {
         if constexpr (Mode<Cfg>::HIST_LDS) {
@@ -763,8 +777,7 @@ template <class Cfg, int K> __device__ __forceinline__ void hist_add(int bin, do
 template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NI = Cfg::NI, NORMI = Cfg::NI, ND = Cfg::NI + 1, NPOOL = Cfg::NPOOL;
-    constexpr int NUPD = 2 * NPOOL + 2; // [changeIntegrand, swapVariable, c)MCIDEV"
-R"MCIDEV(hangeVariable x 2*Nv]  montecarlo.jl:127-130
+    constexpr int NUPD = 2 * NPOOL + 2; // [changeIntegrand, swapVariable, changeVariable x 2*Nv]  montecarlo.jl:127-130
     const int tid = threadIdx.x, T = blockDim.x;
     double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
     double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
@@ -878,7 +891,8 @@ R"MCIDEV(hangeVariable x 2*Nv]  montecarlo.jl:127-130
                                         static_for<0, Cfg::NCOMP>([&](auto Q) { neww.v[decltype(Q)::value] = 0.0; });
                                         neww.abs = 0.0;
                                         if constexpr (nw != NORMI) neww = eval_one<Cfg, nw>(n.x, a.ud); // :35-38
-                                        extra[XE] += 1.0;                                              // :40
+                                        extra[XE] += 1.0;                                 )MCIDEV"
+R"MCIDEV(             // :40
                                         const double newp = nw == NORMI ? rw[NORMI] : neww.abs * rw[nw]; // :42-44
                                         const double R = prop * newp / probability;                    // :46
                                         extra[XP + 0] += 1.0;                                          // :48
@@ -888,8 +902,7 @@ R"MCIDEV(hangeVariable x 2*Nv]  montecarlo.jl:127-130
                                             c = n;
                                             weight = neww;
                                             probability = newp;
-                   )MCIDEV"
-R"MCIDEV(                     } // createRollback!/removeRollback! are no-ops (sampler.jl:306, :324)
+                                        } // createRollback!/removeRollback! are no-ops (sampler.jl:306, :324)
                                     }
                                 }
                             }
@@ -1000,7 +1013,8 @@ R"MCIDEV(                     } // createRollback!/removeRollback! are no-ops (s
                             }
                         }
                         if constexpr (Cfg::CUSTOM_MEASURE == 0 && Cfg::obs_bin_draw(i) < 0) // :164
-                            static_for<0, Cfg::NCOMP>([&](auto Q) { acc[i * Cfg::NCOMP + decltype(Q)::value] += curr == i ? relw[decltype(Q)::value] : 0.0; });
+                            static_for<0, Cfg::NCOMP>([&](auto Q) { acc[i * Cfg)MCIDEV"
+R"MCIDEV(::NCOMP + decltype(Q)::value] += curr == i ? relw[decltype(Q)::value] : 0.0; });
                     });
                 } else {
                     extra[XN] += 1.0 / rw[NORMI]; // :158
@@ -1021,8 +1035,7 @@ template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs 
     Tables<Cfg> t;
     if constexpr (Cfg::TABLE_MODE <= 1) t.E = sE;
     else t.E = a.edges;
-    t.DA)MCIDEV"
-R"MCIDEV( = sDA;
+    t.DA = sDA;
     t.DD = sDD;
     const u32 stream = a.iteration * 8u + STREAM_VEGAS;
     for (i64 n = (i64)blockIdx.x * blockDim.x + threadIdx.x; n < a.n; n += (i64)gridDim.x * blockDim.x) {

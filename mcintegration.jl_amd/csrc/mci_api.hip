@@ -130,6 +130,12 @@ struct mci_problem {
     std::vector<double> h_goal; // reweight_goal (main.jl:81); empty = none
     double *d_goal = nullptr;
     double *d_pa = nullptr; // [2*NPA] propose | accept of the last iteration (this rank)
+    // split vegas pass (NTILE > 1): per-sample histogram weights and 16-bit bins of the tiles >= 1
+    double *d_tile_w = nullptr;
+    uint32_t *d_tile_bins = nullptr;
+    int64_t cap_tile = 0;
+    int ntdraw = 0; // draws whose histogram lives in a tile >= 1
+    hipFunction_t f_tiles = nullptr;
     int threads = 256, wg_per_block = 0; // 0 = auto
     int train_serial = 0; // MCI_TRAIN_SERIAL=1: refinement walk as the reference's serial recurrence (diagnostic)
     // last launch
@@ -499,15 +505,23 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             }
         }
         s.ntile = (int)s.tile_nbin.size();
+        p->ntdraw = 0;
+        if (s.ntile > 1)
+            for (int k = 0; k < s.ndraw; ++k) {
+                const Leaf &L = p->leaves[s.draw_leaf[k]];
+                if (L.adapt && s.cover_mask[k] && s.leaf_tile[s.draw_leaf[k]] >= 1) {
+                    p->ntdraw += 1;
+                    if (L.nbin > 65536) { delete p; return fail(MCI_ERR_INVALID, "leaf %d: more than 65536 bins with tiled histograms", s.draw_leaf[k]); }
+                }
+            }
         s.htile = 0;
         for (int v : s.tile_nbin) s.htile = v > s.htile ? v : s.htile;
         s.table_mode = mode;
         s.pair_table = pair;
         const bool hist_lds = (mode == 0 || mode == 3);
         p->lds_bytes = fixed + (mode <= 1 ? (pair ? e2 : e1) : 0) + (hist_lds ? (int64_t)s.htile * 8 : 0);
-        // one big workgroup per CU.  Measured (tools/c4_sweep.py): with many draws the kernel is register-bound
-        // (x[], bins and in-flight L2 gathers), so fewer, fatter-register waves beat 16 spilling ones.
-        if (p->lds_bytes > lim0) p->threads = s.ndraw > 16 ? 256 : 512;
+        // one big workgroup per CU owns its LDS
+        if (p->lds_bytes > lim0) p->threads = 512; // measured (tools/c4_sweep.py): 2 waves/SIMD beat 1 fat and 4 spilling ones
     }
     p->nstat = 2 * s.nobs + 2 + Nd;
     p->packed_n = p->nstat + s.nbin;
@@ -550,6 +564,8 @@ int mci_problem_destroy(mci_problem *p) {
             if (p->module[k]) (void)hipModuleUnload(p->module[k]);
         if (p->d_goal) (void)hipFree(p->d_goal);
         if (p->d_pa) (void)hipFree(p->d_pa);
+        if (p->d_tile_w) (void)hipFree(p->d_tile_w);
+        if (p->d_tile_bins) (void)hipFree(p->d_tile_bins);
         for (auto &e : p->evs) (void)hipEventDestroy(e);
     }
     delete p;
@@ -608,6 +624,11 @@ static int compile_solver(mci_problem *p, int solver) {
         HIPCHK(hipModuleLoadData(&p->module[solver], code.data()));
         HIPCHK(hipModuleGetFunction(&p->f_solver[solver], p->module[solver], names[solver]));
         if (solver == MCI_VEGAS) HIPCHK(hipModuleGetFunction(&p->f_dump, p->module[solver], "mci_sample_dump"));
+        if (solver == MCI_VEGAS && p->shape.ntile > 1) {
+            HIPCHK(hipModuleGetFunction(&p->f_tiles, p->module[solver], "mci_vegas_tiles"));
+            if (p->lds_bytes > 64 * 1024)
+                HIPCHK(hipFuncSetAttribute((const void *)p->f_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+        }
         if (p->lds_bytes > 64 * 1024) {
             HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
             if (solver == MCI_VEGAS)
@@ -687,10 +708,27 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         if (wpb < 1) wpb = 1;
     }
     const bool hist_lds = (s.table_mode == 0 || s.table_mode == 3);
-    if (wpb * s.ntile > 4096 / nblocks && s.ntile > 1) wpb = (int)(4096 / nblocks / s.ntile) > 0 ? (int)(4096 / nblocks / s.ntile) : 1;
+    // NTILE > 1 histogram tiles.  vegas: ONE sample pass (tile 0) parks weights + bins per sample, mci_vegas_tiles
+    // replays them for the other tiles.  Chain solvers: NTILE workgroups per row, each recomputing the chain and
+    // keeping one tile.
+    const bool split = solver == MCI_VEGAS && s.ntile > 1;
+    if (!split && wpb * s.ntile > 4096 / nblocks && s.ntile > 1) wpb = (int)(4096 / nblocks / s.ntile) > 0 ? (int)(4096 / nblocks / s.ntile) : 1;
     const int64_t nrows = nblocks * wpb;   // partial rows: one per (block, slice)
-    const int64_t nwg = nrows * s.ntile;   // NTILE workgroups per row, each owning one histogram tile
+    const int64_t nwg = split ? nrows : nrows * s.ntile;
     if ((rc = ensure_capacity(p, nrows, nblocks))) return rc;
+    if (split) {
+        const int64_t nsamp = nblocks * nevalperblock;
+        if (nsamp > p->cap_tile) {
+            if (p->d_tile_w) (void)hipFree(p->d_tile_w);
+            if (p->d_tile_bins) (void)hipFree(p->d_tile_bins);
+            p->d_tile_w = nullptr;
+            p->d_tile_bins = nullptr;
+            p->cap_tile = 0;
+            HIPCHK(hipMalloc((void **)&p->d_tile_w, (size_t)nsamp * s.ni * sizeof(double)));
+            HIPCHK(hipMalloc((void **)&p->d_tile_bins, (size_t)nsamp * ((p->ntdraw + 1) / 2 > 0 ? (p->ntdraw + 1) / 2 : 1) * sizeof(uint32_t)));
+            p->cap_tile = nsamp;
+        }
+    }
     mci::BatchArgs a{};
     a.edges = p->d_edges;
     a.dacc = p->d_dacc;
@@ -710,12 +748,17 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.burnin = burnin;
     a.nburn = nburn;
     a.status = p->d_status;
+    a.tile_w = p->d_tile_w;
+    a.tile_bins = p->d_tile_bins;
+    a.tile_stride = nblocks * nevalperblock;
     void *args[] = {&a};
     hipFunction_t f = p->f_solver[solver];
     hipStream_t st = p->ctx->stream;
     const int slot = (int)(p->launches % mci_problem::kEvRing);
     HIPCHK(hipEventRecord(p->evs[2 * slot], st));
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+    if (split)
+        HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(nrows * (s.ntile - 1)), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
     p->launches += 1;
     p->last_wg = (int)nwg;

@@ -101,6 +101,11 @@ struct BatchArgs {
     double burnin;          // vegasmc: a chain measures from step `burnin` on (montecarlo.jl:213; DESIGN.md "chains")
     i64 nburn;              // mcmc: burn-in steps run before the neval/nchain measured ones (mcmc/montecarlo.jl:133)
     int *status;            // error bits (ST_*)
+    // vegas with NTILE > 1 histogram tiles: the sample pass keeps tile 0 and parks, per sample, the histogram
+    // weights and the 16-bit bins of the other tiles' draws in HBM; mci_vegas_tiles replays them per tile
+    double *tile_w;         // [NI][tile_stride]
+    u32 *tile_bins;         // [ceil(ntdraw/2)][tile_stride]  two bins per word
+    i64 tile_stride;        // samples of this launch
 };
 
 struct DumpArgs {
@@ -183,7 +188,7 @@ template <class Cfg, int K, bool U12 = false> __device__ __forceinline__ void dr
             dx = e.y;
         } else {
             constexpr int eoff = Cfg::leaf_eoff(leaf);
-            g0 = t.E[eoff + iy];
+            g0 = t.E[eoff + iy]; // (L2 gathers in table modes 2/3: non-temporal loads measured 30 % slower)
             dx = t.E[eoff + iy + 1] - g0;
         }
 #endif
@@ -318,7 +323,9 @@ template <class Cfg> struct Cols {
 // histogram update of one sample: accumulate!(var, pos+offset, weight) for every (integrand i, draw k in own(i))
 // (vegas/montecarlo.jl:170-185).  The per-integrand weights covering the same draw are summed first,
 // so each draw costs one ds_add_f64.
-template <class Cfg> __device__ __forceinline__ void hist_update(const Sample<Cfg> &s, const double *wh /*[NI]*/, double *sH, double *gH, int tile) {
+// TILE >= 0: compile-time histogram tile of this workgroup (the bins of the other tiles' draws are then dead
+// values and leave the register file); TILE < 0: run-time `tile`.
+template <class Cfg, int TILE = -1> __device__ __forceinline__ void hist_update(const Sample<Cfg> &s, const double *wh /*[NI]*/, double *sH, double *gH, int tile) {
     static_for<0, Cfg::NDRAW>([&](auto K) {
         constexpr int k = decltype(K)::value;
         constexpr int leaf = Cfg::draw_leaf(k);
@@ -330,7 +337,11 @@ template <class Cfg> __device__ __forceinline__ void hist_update(const Sample<Cf
             });
             if constexpr (Mode<Cfg>::HIST_LDS) {
                 constexpr int lt = Cfg::leaf_tile(leaf);
-                if (Cfg::NTILE == 1 || tile == lt) lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + s.bin[k]], wk);
+                if constexpr (TILE >= 0) {
+                    if constexpr (Cfg::NTILE == 1 || TILE == lt) lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + s.bin[k]], wk);
+                } else {
+                    if (Cfg::NTILE == 1 || tile == lt) lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + s.bin[k]], wk);
+                }
             } else {
                 global_add(&gH[Cfg::leaf_boff(leaf) + s.bin[k]], wk);
             }
@@ -412,6 +423,21 @@ template <class Cfg> __device__ __forceinline__ void flush_workgroup(const Batch
     }
 }
 
+// draws whose histogram lives in a tile >= 1 (adaptive and covered by some integrand), in draw order
+template <class Cfg> constexpr bool is_tdraw(int k) {
+    return Cfg::NTILE > 1 && Cfg::leaf_adapt(Cfg::draw_leaf(k)) != 0 && Cfg::cover_mask(k) != 0ull && Cfg::leaf_tile(Cfg::draw_leaf(k)) >= 1;
+}
+template <class Cfg> constexpr int tdraw_count() {
+    int n = 0;
+    for (int k = 0; k < Cfg::NDRAW; ++k) n += is_tdraw<Cfg>(k) ? 1 : 0;
+    return n;
+}
+template <class Cfg> constexpr int tdraw_pos(int k) { // position of draw k in that list
+    int n = 0;
+    for (int j = 0; j < k; ++j) n += is_tdraw<Cfg>(j) ? 1 : 0;
+    return n;
+}
+
 // blockIdx -> (statistical block, slice of the block, histogram tile)
 struct WorkItem {
     i64 rowid, lb;
@@ -429,7 +455,9 @@ template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchAr
 // =============================================================================================
 // VEGAS sample batch  (vegas/montecarlo.jl:117-187)
 // =============================================================================================
-template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
+// SPLIT (NTILE > 1): this pass owns histogram tile 0 only and parks (weights, bins of the other tiles' draws)
+// per sample for mci_vegas_tiles; one workgroup per (block, slice).
+template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, T = blockDim.x;
     double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
@@ -445,7 +473,13 @@ template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs
     t.DA = sDA;
     t.DD = sDD;
 
-    const WorkItem wi = work_item<Cfg>(a);
+    WorkItem wi = work_item<Cfg>(a);
+    if constexpr (SPLIT) {
+        wi.tile = 0;
+        wi.rowid = (i64)blockIdx.x;
+        wi.lb = wi.rowid / a.wg_per_block;
+        wi.slice = (int)(wi.rowid % a.wg_per_block);
+    }
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb; // global statistical block
     const u32 stream = a.iteration * 8u + STREAM_VEGAS;
@@ -456,6 +490,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs
     double extra[Cfg::NCOLS - Cfg::NOBS];
     static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
 
+    auto run = [&](auto TT) { // the sample loop, specialised on the workgroup's histogram tile
     for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(B * a.neval_per_block + n), s);
@@ -475,13 +510,77 @@ template <class Cfg> __device__ __forceinline__ void vegas_batch(const BatchArgs
             wh[i] = wj * wj;                      // :180
         });
 #ifndef MCI_ABL_NOHIST
-        hist_update<Cfg>(s, wh, sH, a.ghist, tile);
+        hist_update<Cfg, decltype(TT)::value>(s, wh, sH, a.ghist, tile);
 #else
         acc[0] += wh[0] * 1e-300;
 #endif
+        if constexpr (SPLIT) { // park what the other tiles need: coalesced (lane == consecutive sample) 8- and 4-byte stores
+            const i64 idx = wi.lb * a.neval_per_block + n;
+            static_for<0, Cfg::NI>([&](auto I) { a.tile_w[decltype(I)::value * a.tile_stride + idx] = wh[decltype(I)::value]; });
+            constexpr int NT = tdraw_count<Cfg>();
+            u32 word[(NT + 1) / 2 > 0 ? (NT + 1) / 2 : 1];
+            static_for<0, (NT + 1) / 2>([&](auto J) { word[decltype(J)::value] = 0u; });
+            static_for<0, Cfg::NDRAW>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                if constexpr (is_tdraw<Cfg>(k)) {
+                    constexpr int m = tdraw_pos<Cfg>(k);
+                    word[m / 2] |= (u32)s.bin[k] << (16 * (m & 1));
+                }
+            });
+            static_for<0, (NT + 1) / 2>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = word[decltype(J)::value]; });
+        }
     }
+    };
+    if constexpr (Cfg::NTILE == 1 || SPLIT) run(IC<0>{});
+    else static_for<0, Cfg::NTILE>([&](auto TT) { if (tile == decltype(TT)::value) run(TT); });
     __syncthreads();
     flush_workgroup<Cfg>(a, smem, acc, extra, wi.rowid, tile);
+}
+
+// histogram tiles 1 .. NTILE-1 of a SPLIT vegas pass: workgroup = (block, slice, tile); replays the parked
+// (weights, bins) of the same samples its sample-pass workgroup drew -- no RNG, no gathers, no integrand:
+// 8*NI + 2 bytes per tiled draw of coalesced HBM reads and one ds_add_f64 per draw.
+template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs &a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, T = blockDim.x;
+    double *sH = smem + Lds<Cfg>::H;
+    constexpr int NTM = Cfg::NTILE > 1 ? Cfg::NTILE - 1 : 1;
+    const int tile = 1 + (int)(blockIdx.x % NTM);
+    const i64 rowid = (i64)(blockIdx.x / NTM), lb = rowid / a.wg_per_block;
+    const int slice = (int)(rowid % a.wg_per_block);
+    for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
+    __syncthreads();
+    const i64 stride = (i64)a.wg_per_block * T;
+    static_for<1, Cfg::NTILE>([&](auto TT) {
+        constexpr int tt = decltype(TT)::value;
+        if (tile == tt) {
+            for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
+                const i64 idx = lb * a.neval_per_block + n;
+                double wh[Cfg::NI];
+                static_for<0, Cfg::NI>([&](auto I) { wh[decltype(I)::value] = a.tile_w[decltype(I)::value * a.tile_stride + idx]; });
+                static_for<0, Cfg::NDRAW>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    if constexpr (is_tdraw<Cfg>(k)) {
+                        constexpr int leaf = Cfg::draw_leaf(k);
+                        if constexpr (Cfg::leaf_tile(leaf) == tt) {
+                            constexpr int m = tdraw_pos<Cfg>(k);
+                            const u32 word = a.tile_bins[(m / 2) * a.tile_stride + idx]; // both halves of a word: one load (CSE)
+                            const int bin = (int)((word >> (16 * (m & 1))) & 0xFFFFu);
+                            double wk = 0.0;
+                            static_for<0, Cfg::NI>([&](auto I) {
+                                constexpr int i = decltype(I)::value;
+                                if constexpr ((Cfg::own_mask(i) >> k) & 1ull) wk += wh[i];
+                            });
+                            lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(tt) + bin], wk);
+                        }
+                    }
+                });
+            }
+            __syncthreads();
+            double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
+            for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = sH[i];
+        }
+    });
 }
 
 // =============================================================================================

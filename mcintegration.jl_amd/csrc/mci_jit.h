@@ -129,7 +129,10 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     o << "};\n}\n";
     if (solver == 0) {
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_batch(mci::BatchArgs a) { "
-             "mci::vegas_batch<Cfg>(a); }\n";
+             "mci::vegas_batch<Cfg, (Cfg::NTILE > 1)>(a); }\n";
+        if (s.ntile > 1)
+            o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_tiles(mci::BatchArgs a) { "
+                 "mci::vegas_tiles<Cfg>(a); }\n";
         o << "extern \"C\" __global__ void __launch_bounds__(256) mci_sample_dump(mci::DumpArgs a) { "
              "mci::sample_dump<Cfg>(a); }\n";
     } else if (solver == 1) {

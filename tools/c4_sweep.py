@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development tool (GPU box): launch-geometry / tile sweep for the 32-grid Genz config (C4)."""
+"""Development tool (GPU box): launch-geometry sweep for the 32-grid Genz config (C4) and the 16-grid Gaussian."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -13,7 +13,7 @@ eng = mci.Engine(cfg, mci.catalog.genz_product_peak(D), threads=threads, wg_per_
 eng.integrate("vegas", neval=neval, niter=3, block=16, seed=1)
 eng.integrate("vegas", neval=neval, niter=3, block=16, seed=2, first_iteration=3)
 ms, wg, th = eng.kernel_times_ms(3)
-print(json.dumps(dict(ms=float(np.median(ms)), wg=wg, threads=th, mode=eng.table_mode, lds=eng.lds_bytes)))
+print(json.dumps(dict(ms=float(np.median(ms)), Gs=neval / float(np.median(ms)) / 1e6, wg=wg, threads=th, mode=eng.table_mode, lds=eng.lds_bytes)))
 ''' % ROOT
 
 def run(threads, wpb, tile_bins=None, flags="", D=32, neval=1e8):
@@ -26,8 +26,6 @@ def run(threads, wpb, tile_bins=None, flags="", D=32, neval=1e8):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 if __name__ == "__main__":
-    for threads, wpb, tb in [(1024, 0, None), (512, 0, None), (256, 0, None), (512, 0, 8000), (256, 0, 8000), (256, 0, 4000), (512, 0, 4000), (256, 0, 2000)]:
-        print("threads=%-5d wpb=%-3d tile_bins=%-6s %s" % (threads, wpb, tb, run(threads, wpb, tb)), flush=True)
-    for fl in ("-DMCI_DRAW_FENCE=1", "-DMCI_DRAW_FENCE=4"):
-        print(fl, run(512, 0, None, fl), flush=True)
-    print("D=16 th=1024", run(1024, 0, None, "", 16)); print("D=16 th=512", run(512, 0, None, "", 16)); print("D=16 th=256 tile 8000", run(256, 0, 8000, "", 16))
+    for D in (32, 16):
+        for flags in ("", "-DMCI_DRAW_FENCE=2", "-DMCI_DRAW_FENCE=4"):
+            print("D=%d threads=512 flags=%-36s %s" % (D, flags, run(512, 0, None, flags, D)), flush=True)

@@ -136,6 +136,10 @@ struct mci_problem {
     int64_t cap_tile = 0;
     int ntdraw = 0; // draws whose histogram lives in a tile >= 1
     hipFunction_t f_tiles = nullptr;
+    // second merge stage (partials -> packed), launched lazily: a single-rank mci_iteration_finish fuses it with
+    // the refinement (k_finish); anything else that looks at `packed` first flushes it (k_finalize)
+    mci::MergeArgs merge{};
+    bool merge_pending = false;
     int threads = 256, wg_per_block = 0; // 0 = auto
     int train_serial = 0; // MCI_TRAIN_SERIAL=1: refinement walk as the reference's serial recurrence (diagnostic)
     // last launch
@@ -144,7 +148,7 @@ struct mci_problem {
     static const int kEvRing = 512;
     int last_wg = 0, last_threads = 0, last_nblocks = 0;
     int log_row = 0;
-    static const int kGroups = 32;
+    static const int kGroups = mci::kMergeGroups;
     static const int64_t kChainFill = 131072; // chains per GPU that keep 2 waves on each of the 1024 SIMDs
 };
 
@@ -210,6 +214,8 @@ void drop_modules(mci_problem *p) {
 }
 
 } // namespace
+
+static int flush_merge(mci_problem *p);
 
 extern "C" {
 
@@ -663,6 +669,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     if (nblocks < 1 || nevalperblock < 1) return fail(MCI_ERR_INVALID, "empty iteration");
     int rc = compile_solver(p, solver);
     if (rc) return rc;
+    if ((rc = flush_merge(p))) return rc; // a previous batch nobody looked at: merge it (resets the global histogram)
     HIPCHK(hipSetDevice(p->ctx->device));
     const auto &s = p->shape;
     const int T = p->threads;
@@ -769,9 +776,34 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     if (hist_lds && s.nbin > 0)
         hipLaunchKernelGGL(mci::k_hist_stage1, dim3(nb256, mci_problem::kGroups), dim3(256), 0, st, p->d_part_hist, (int)nrows, s.nbin,
                            (int)mci_problem::kGroups, p->d_stage1);
-    hipLaunchKernelGGL(mci::k_finalize, dim3(nb256 + 1), dim3(256), 0, st, p->d_part_cols, s.ncols, s.nobs, s.ni, (int)nblocks, wpb,
-                       p->d_stage1, (int)mci_problem::kGroups, p->d_ghist, hist_lds ? 0 : 1, s.nbin, p->d_packed, p->d_status,
-                       p->d_scratch, p->d_pa);
+    HIPCHK(hipGetLastError());
+    mci::MergeArgs &m = p->merge;
+    m.part_cols = p->d_part_cols;
+    m.ncols = s.ncols;
+    m.nobs = s.nobs;
+    m.ni = s.ni;
+    m.nblocks = (int)nblocks;
+    m.wg_per_block = wpb;
+    m.stage1 = p->d_stage1;
+    m.ngroup = (int)mci_problem::kGroups;
+    m.ghist = p->d_ghist;
+    m.use_ghist = hist_lds ? 0 : 1;
+    m.nbin = s.nbin;
+    m.packed = p->d_packed;
+    m.status = p->d_status;
+    m.scratch = p->d_scratch;
+    m.pa_out = p->d_pa;
+    p->merge_pending = true;
+    return MCI_OK;
+}
+
+// partials -> packed, if the last mci_iteration_run has not been merged yet
+static int flush_merge(mci_problem *p) {
+    if (!p->merge_pending) return MCI_OK;
+    p->merge_pending = false;
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const int nb256 = (p->shape.nbin + 255) / 256;
+    hipLaunchKernelGGL(mci::k_finalize, dim3(nb256 + 1), dim3(256), 0, p->ctx->stream, p->merge);
     HIPCHK(hipGetLastError());
     return MCI_OK;
 }
@@ -779,6 +811,8 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
 int mci_iteration_reduce(mci_problem *p) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
     if (!p->ctx->comm) return MCI_OK; // no communicator: single process (mpi_nprocs() == 1)
+    int rc = flush_merge(p);
+    if (rc) return rc;
     int r = g_rccl.AllReduce(p->d_packed, p->d_packed, (size_t)p->packed_n, kNcclFloat64, kNcclSum, p->ctx->comm, p->ctx->stream);
     if (r) return fail(MCI_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     return MCI_OK;
@@ -788,9 +822,30 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     const auto &s = p->shape;
     int maxn = 1;
     for (auto &L : p->leaves) maxn = L.nbin > maxn ? L.nbin : maxn;
-    const size_t sm = (size_t)(4 * maxn + 16) * sizeof(double); // d[N+4] | sg[N+1] | wa[N+1] | wj[N+1] (k_train)
-    hipLaunchKernelGGL(mci::k_train, dim3(s.nleaf + 1), dim3(256), sm, p->ctx->stream, p->d_leaves, s.nleaf, p->d_packed, p->nstat,
-                       p->d_edges, p->d_dacc, p->d_ddist, log_row, p->d_reweight, p->h_goal.empty() ? nullptr : p->d_goal, s.ni + 1, do_reweight, gamma, do_train, p->train_serial, p->d_status);
+    mci::TrainArgs a{};
+    a.leaves = p->d_leaves;
+    a.nleaf = s.nleaf;
+    a.packed = p->d_packed;
+    a.nstat = p->nstat;
+    a.edges = p->d_edges;
+    a.dacc = p->d_dacc;
+    a.ddist = p->d_ddist;
+    a.iter_log_row = log_row;
+    a.reweight = p->d_reweight;
+    a.goal = p->h_goal.empty() ? nullptr : p->d_goal;
+    a.nd = s.ni + 1;
+    a.do_reweight = do_reweight;
+    a.gamma = gamma;
+    a.do_train = do_train;
+    a.serial_walk = p->train_serial;
+    a.status = p->d_status;
+    const size_t sm = (size_t)(4 * maxn + 16) * sizeof(double); // d[N+4] | sg[N+1] | wa[N+1] | wj[N+1] (train_leaf)
+    if (p->merge_pending) { // nothing looked at `packed` since the sample batch: merge + refine in one launch
+        p->merge_pending = false;
+        hipLaunchKernelGGL(mci::k_finish, dim3(s.nleaf + 1), dim3(256), sm + (size_t)maxn * sizeof(double), p->ctx->stream, p->merge, a);
+    } else {
+        hipLaunchKernelGGL(mci::k_train, dim3(s.nleaf + 1), dim3(256), sm, p->ctx->stream, a);
+    }
     HIPCHK(hipGetLastError());
     return MCI_OK;
 }
@@ -830,7 +885,9 @@ int mci_iteration_finish(mci_problem *p, int32_t solver, int64_t block_total, in
 
 int mci_train(mci_problem *p) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
-    int rc = launch_train(p, 1, 0, 1.0, nullptr);
+    int rc = flush_merge(p);
+    if (rc) return rc;
+    rc = launch_train(p, 1, 0, 1.0, nullptr);
     if (rc) return rc;
     return check_status(p);
 }
@@ -888,6 +945,7 @@ int mci_get_iteration_log(mci_problem *p, int32_t nrows, double *out) {
 int mci_get_packed(mci_problem *p, double *out, int64_t n) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
     if (n != p->packed_n) return fail(MCI_ERR_INVALID, "packed size is %lld", (long long)p->packed_n);
+    if (int rc = flush_merge(p)) return rc;
     HIPCHK(hipMemcpyAsync(out, p->d_packed, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     return MCI_OK;
@@ -896,12 +954,16 @@ int mci_get_packed(mci_problem *p, double *out, int64_t n) {
 int mci_set_packed(mci_problem *p, const double *in, int64_t n) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
     if (n != p->packed_n) return fail(MCI_ERR_INVALID, "packed size is %lld", (long long)p->packed_n);
+    if (int rc = flush_merge(p)) return rc;
     HIPCHK(hipMemcpyAsync(p->d_packed, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     return MCI_OK;
 }
 
-void *mci_packed_device_ptr(mci_problem *p) { return p ? (void *)p->d_packed : nullptr; }
+void *mci_packed_device_ptr(mci_problem *p) {
+    if (!p || p->ctx->offline || flush_merge(p)) return nullptr;
+    return (void *)p->d_packed;
+}
 
 int mci_get_grid(mci_problem *p, int32_t leaf, double *out, int32_t n) {
     if (leaf < 0 || leaf >= (int)p->leaves.size() || p->leaves[leaf].kind != MCI_CONTINUOUS) return fail(MCI_ERR_INVALID, "leaf %d is not Continuous", leaf);
@@ -997,6 +1059,7 @@ int mci_get_acceptance(mci_problem *p, double *propose, double *accept, int32_t 
     if (n != npa) return fail(MCI_ERR_INVALID, "propose/accept have %d entries", npa);
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
     std::vector<double> h(2 * npa);
+    if (int rc = flush_merge(p)) return rc;
     HIPCHK(hipMemcpyAsync(h.data(), p->d_pa, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     if (propose) memcpy(propose, h.data(), npa * sizeof(double));

@@ -47,27 +47,44 @@ __global__ void __launch_bounds__(256) k_hist_stage1(const double *__restrict__ 
 // block by block:  m = observable/normalization; obsSum += m; obsSquaredSum += m*m   (main.jl:275-287)
 // with every block and the merged config starting from clearStatistics! values (configuration.jl:238-250):
 // normalization 1e-10, visited 1e-8, histogram 1e-10.
-__global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ part_cols, int ncols, int nobs, int ni,
-                                                  int nblocks, int wg_per_block, const double *__restrict__ stage1,
-                                                  int ngroup, double *__restrict__ ghist, int use_ghist, int nbin,
-                                                  double *__restrict__ packed, int *__restrict__ status,
-                                                  double *__restrict__ scratch /*[nblocks*ncols]*/,
-                                                  double *__restrict__ pa_out /*[ncols - (nobs+2+ni+1)]: propose | accept*/) {
-    const int nhb = (nbin + 255) / 256;
-    const int hoff = 2 * nobs + 2 + ni + 1;
-    if ((int)blockIdx.x < nhb) {
-        const int bin = blockIdx.x * 256 + threadIdx.x;
-        if (bin >= nbin) return;
-        double s = (double)(nblocks + 1) * 1.0e-10;
-        if (use_ghist) {
-            s += ghist[bin];
-            ghist[bin] = 0.0; // ready for the next iteration
-        } else {
-            for (int g = 0; g < ngroup; ++g) s += stage1[(size_t)g * nbin + bin];
-        }
-        packed[hoff + bin] = s;
-        return;
+enum { kMergeGroups = 32 }; // first-stage histogram groups (k_hist_stage1 launches exactly this many)
+
+struct MergeArgs {
+    const double *part_cols; // [rows][ncols]
+    int ncols, nobs, ni, nblocks, wg_per_block;
+    const double *stage1;    // [ngroup][nbin]
+    int ngroup;
+    double *ghist;           // global-atomics histogram (table modes 1, 2)
+    int use_ghist, nbin;
+    double *packed;
+    int *status;
+    double *scratch;         // [nblocks*ncols]
+    double *pa_out;          // [ncols - (nobs+2+ni+1)]: propose | accept
+};
+
+// one histogram bin of the merged config: clearStatistics! offsets + the second merge stage
+__device__ inline double merge_hist_bin(const MergeArgs &m, int bin) {
+    double s = (double)(m.nblocks + 1) * 1.0e-10;
+    if (m.use_ghist) {
+        s += m.ghist[bin];
+        m.ghist[bin] = 0.0; // ready for the next iteration
+    } else {
+        // all group partials in flight at once (a rolled loop would serialise ngroup L2 round trips), summed in group order
+        double v[kMergeGroups];
+#pragma unroll
+        for (int g = 0; g < kMergeGroups; ++g) v[g] = m.stage1[(size_t)g * m.nbin + bin];
+#pragma unroll
+        for (int g = 0; g < kMergeGroups; ++g) s += v[g];
     }
+    return s;
+}
+
+// the statistics head of `packed`, by one workgroup
+__device__ inline void merge_stats(const MergeArgs &m) {
+    const double *__restrict__ part_cols = m.part_cols;
+    const int ncols = m.ncols, nobs = m.nobs, ni = m.ni, nblocks = m.nblocks, wg_per_block = m.wg_per_block;
+    double *__restrict__ packed = m.packed, *__restrict__ scratch = m.scratch, *__restrict__ pa_out = m.pa_out;
+    int *status = m.status;
     // --- statistics columns ---
     // scratch[b][c] = sum over the block's workgroup rows, in a fixed order: 8 lanes per (block, column) stride
     // over the rows (the loads of different rows are independent, so they pipeline), then a 3-step butterfly
@@ -76,6 +93,7 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
         double s = 0.0;
         if (idx < nblocks * ncols) {
             const int b = idx / ncols, c = idx % ncols;
+#pragma unroll 8
             for (int w = part; w < wg_per_block; w += 8) s += part_cols[(size_t)(b * wg_per_block + w) * ncols + c];
         }
         s += __shfl_xor(s, 1, 64);
@@ -87,6 +105,7 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
     const int cnorm = nobs, cneval = nobs + 1, cvis = nobs + 2;
     for (int o = threadIdx.x; o < nobs; o += blockDim.x) {
         double sum = 0.0, sq = 0.0;
+#pragma unroll 8
         for (int b = 0; b < nblocks; ++b) {
             const double norm = scratch[b * ncols + cnorm] + 1.0e-10;
             const double m = scratch[b * ncols + o] / norm;
@@ -99,6 +118,7 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
     if (threadIdx.x == 0) {
         double norm = 1.0e-10, neval = 0.0;
         int bad = 0;
+#pragma unroll 8
         for (int b = 0; b < nblocks; ++b) {
             const double nb = scratch[b * ncols + cnorm] + 1.0e-10;
             if (!(nb > 0.0)) bad = 1; // main.jl:269-271
@@ -111,6 +131,7 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
     }
     for (int i = threadIdx.x; i < ni + 1; i += blockDim.x) {
         double v = 1.0e-8;
+#pragma unroll 8
         for (int b = 0; b < nblocks; ++b) v += scratch[b * ncols + cvis + i] + 1.0e-8;
         packed[2 * nobs + 2 + i] = v;
     }
@@ -122,6 +143,17 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
         for (int b = 0; b < nblocks; ++b) v += scratch[b * ncols + cpa + i] + off;
         pa_out[i] = v;
     }
+}
+
+__global__ void __launch_bounds__(256) k_finalize(MergeArgs m) {
+    const int nhb = (m.nbin + 255) / 256;
+    const int hoff = 2 * m.nobs + 2 + m.ni + 1;
+    if ((int)blockIdx.x < nhb) {
+        const int bin = blockIdx.x * 256 + threadIdx.x;
+        if (bin < m.nbin) m.packed[hoff + bin] = merge_hist_bin(m, bin);
+        return;
+    }
+    merge_stats(m);
 }
 
 // doReweight!  main.jl:322-346 (goal = nullptr: no reweight_goal)
@@ -142,26 +174,27 @@ __device__ inline void do_reweight_dev(double *reweight, const double *visited, 
     for (int i = 0; i < nd; ++i) reweight[i] /= s; // main.jl:339
 }
 
-// Inclusive prefix sum of v[0..n) into out[0..n) with a fixed summation order (contiguous chunk per thread,
-// then a serial scan of the <= 256 chunk totals by thread 0); returns the total.  ps: LDS scratch [blockDim.x].
+// Inclusive prefix sum of v[0..n) into out[0..n) with a fixed summation order: a contiguous chunk per thread,
+// a shuffle scan of the chunk totals inside each wave64, then the (<= 16) wave totals; returns the total.
+// ps: LDS scratch [>= blockDim.x / 64].
 __device__ inline double block_prefix(const double *v, double *out, int n, double *ps) {
-    const int tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
     const int per = (n + T - 1) / T, b = tid * per, e = min(n, b + per);
     double loc = 0.0;
     for (int k = b; k < e; ++k) loc += v[k];
-    __syncthreads();
-    ps[tid] = loc;
-    __syncthreads();
-    if (tid == 0) {
-        double run = 0.0;
-        for (int t = 0; t < T; ++t) {
-            const double x = ps[t];
-            ps[t] = run;
-            run += x;
-        }
+    double x = loc; // inclusive scan of loc over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
     }
     __syncthreads();
-    double run = ps[tid];
+    if (lane == 63) ps[wave] = x;
+    __syncthreads();
+    double base = 0.0;
+    for (int w = 0; w < wave; ++w) base += ps[w];
+    (void)nwave;
+    double run = base + (x - loc); // exclusive prefix of this thread's chunk
     for (int k = b; k < e; ++k) {
         run += v[k];
         out[k] = run;
@@ -170,35 +203,32 @@ __device__ inline double block_prefix(const double *v, double *out, int n, doubl
     return out[n - 1];
 }
 
-// One workgroup per leaf: Dist.train! then clearStatistics!.  Workgroup `nleaf` does the
-// per-iteration bookkeeping: copy the statistics head of `packed` into the iteration log and, for
-// vegasmc, apply doReweight!.
-__global__ void __launch_bounds__(256) k_train(const LeafDev *__restrict__ leaves, int nleaf, double *__restrict__ packed,
-                                               int nstat, double *__restrict__ edges, double *__restrict__ dacc,
-                                               double *__restrict__ ddist, double *__restrict__ iter_log_row,
-                                               double *__restrict__ reweight, const double *__restrict__ goal, int nd,
-                                               int do_reweight, double gamma,
-                                               int do_train, int serial_walk, int *__restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ double ps[256]; // block_prefix scratch
+struct TrainArgs {
+    const LeafDev *leaves;
+    int nleaf;
+    double *packed;
+    int nstat;
+    double *edges, *dacc, *ddist;
+    double *iter_log_row;
+    double *reweight;
+    const double *goal;
+    int nd, do_reweight;
+    double gamma;
+    int do_train, serial_walk;
+    int *status;
+};
+
+// Dist.train! for one leaf by one workgroup, then clearStatistics!.  h: the merged histogram (global or LDS);
+// hclear: its home in `packed`, reset for the next iteration.  sm: [4*N + 16] doubles of LDS.
+__device__ inline void train_leaf(const LeafDev &L, const double *h, double *hclear, double *sm, double *ps, int &bad, double &ssum,
+                                  double *__restrict__ edges, double *__restrict__ dacc, double *__restrict__ ddist, int serial_walk,
+                                  int *__restrict__ status) {
     const int tid = threadIdx.x, T = blockDim.x;
-    if ((int)blockIdx.x == nleaf) {
-        if (iter_log_row)
-            for (int i = tid; i < nstat; i += T) iter_log_row[i] = packed[i];
-        if (do_reweight && tid == 0) do_reweight_dev(reweight, packed + (nstat - nd), nd, gamma, goal);
-        return;
-    }
-    if (!do_train) return;
-    const LeafDev L = leaves[blockIdx.x];
-    if (!L.adapt) return; // variable.jl:208, :370
     const int N = L.nbin;
-    double *h = packed + nstat + L.boff;
     double *d = sm;                     // [N+4] smoothed / rescaled distribution (+4 window padding)
     double *sg = sm + N + 4;            // [N+1] old grid staged in LDS
     double *wa = sg + N + 1;            // [N+1] acc_f recorded per new grid point
     int *wj = (int *)(wa + N + 1);      // [N+1] j recorded per new grid point
-    __shared__ int bad;
-    __shared__ double ssum;
     if (tid == 0) bad = 0;
     __syncthreads();
     for (int i = tid; i < N; i += T) {
@@ -281,7 +311,7 @@ __global__ void __launch_bounds__(256) k_train(const LeafDev *__restrict__ leave
                 g[i] = v;
             }
             __syncthreads();
-            for (int i = tid; i < N; i += T) h[i] = 1.0e-10; // clearStatistics!  variable.jl:238 -> :565
+            for (int i = tid; i < N; i += T) hclear[i] = 1.0e-10; // clearStatistics!  variable.jl:238 -> :565
             return;
         }
         if (tid == 0) {
@@ -350,7 +380,62 @@ __global__ void __launch_bounds__(256) k_train(const LeafDev *__restrict__ leave
     }
     // clearStatistics!(T)  variable.jl:238/:381 -> :565 (the next iteration's merge starts from its own fill)
     __syncthreads();
-    for (int i = tid; i < N; i += T) h[i] = 1.0e-10;
+    for (int i = tid; i < N; i += T) hclear[i] = 1.0e-10;
+}
+
+// per-iteration bookkeeping by one workgroup: statistics head -> iteration log; doReweight! for the chain solvers
+__device__ inline void iteration_bookkeeping(const TrainArgs &a) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    if (a.iter_log_row)
+        for (int i = tid; i < a.nstat; i += T) a.iter_log_row[i] = a.packed[i];
+    if (a.do_reweight && tid == 0) do_reweight_dev(a.reweight, a.packed + (a.nstat - a.nd), a.nd, a.gamma, a.goal);
+}
+
+// One workgroup per leaf: Dist.train! then clearStatistics!; workgroup `nleaf`: bookkeeping.
+__global__ void __launch_bounds__(256) k_train(TrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double ps[256]; // block_prefix scratch
+    __shared__ int bad;
+    __shared__ double ssum;
+    if ((int)blockIdx.x == a.nleaf) {
+        iteration_bookkeeping(a);
+        return;
+    }
+    if (!a.do_train) return;
+    const LeafDev L = a.leaves[blockIdx.x];
+    if (!L.adapt) return; // variable.jl:208, :370
+    double *h = a.packed + a.nstat + L.boff;
+    train_leaf(L, h, h, sm, ps, bad, ssum, a.edges, a.dacc, a.ddist, a.serial_walk, a.status);
+}
+
+// Single-rank iterations need no all-reduce between the merge and the refinement: k_finalize and k_train as ONE
+// launch.  Workgroup l < nleaf merges its leaf's histogram (second stage) into LDS and `packed`, then trains from
+// the LDS copy; workgroup nleaf merges the statistics head, then does the bookkeeping.
+__global__ void __launch_bounds__(256) k_finish(MergeArgs m, TrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[]; // [4*maxn + 16] train scratch | [maxn] merged histogram
+    __shared__ double ps[256];
+    __shared__ int bad;
+    __shared__ double ssum;
+    const int tid = threadIdx.x, T = blockDim.x;
+    if ((int)blockIdx.x == a.nleaf) {
+        merge_stats(m);
+        __syncthreads(); // the head of `packed` was written by this workgroup
+        iteration_bookkeeping(a);
+        return;
+    }
+    const LeafDev L = a.leaves[blockIdx.x];
+    int maxn = 1;
+    for (int l = 0; l < a.nleaf; ++l) maxn = a.leaves[l].nbin > maxn ? a.leaves[l].nbin : maxn;
+    double *hl = sm + 4 * maxn + 16;
+    double *hp = a.packed + a.nstat + L.boff;
+    for (int i = tid; i < L.nbin; i += T) {
+        const double v = merge_hist_bin(m, L.boff + i);
+        hl[i] = v;
+        hp[i] = v;
+    }
+    __syncthreads();
+    if (!a.do_train || !L.adapt) return;
+    train_leaf(L, hl, hp, sm, ps, bad, ssum, a.edges, a.dacc, a.ddist, a.serial_walk, a.status);
 }
 
 } // namespace mci

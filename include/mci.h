@@ -196,7 +196,7 @@ void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64
  * additionally >= min(steps/2, 32*nslots) so that each short chain forgets its start (nslots = sum of maxdof) */
 double mci_chain_burnin(int64_t steps, int64_t nchain, int32_t nslots);
 /* burn-in steps an MCMC chain runs before its `steps` measured ones: floor(steps*thermal_ratio)
- * (mcmc/montecarlo.jl:133); with nchain > 1 at least min(steps/2, 64*nslots + 16*(npool+1)*nd) */
+ * (mcmc/montecarlo.jl:133); with nchain > 1 at least 64*nslots + 16*(npool+1)*nd */
 int64_t mci_mcmc_burnin(int64_t steps, int64_t nchain, int32_t nslots, int32_t nd, int32_t npool, double thermal_ratio);
 void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out);        /* configuration.jl:229-236 */
 void mci_mean_std(const double *obs_sum, const double *obs_sq, int64_t n, int64_t block, double *mean,

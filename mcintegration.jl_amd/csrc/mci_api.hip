@@ -708,8 +708,12 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         nchain = 1;
     }
     int wpb = p->wg_per_block;
-    if (wpb <= 0) { // 256 CUs x ~8 workgroups in the grid (measured best on C2), never a workgroup without work
-        wpb = (int)((2048 + nblocks - 1) / nblocks);
+    if (wpb <= 0) { // 256 CUs x 8..16 workgroups in the grid, never a workgroup without work
+        // measured on C2 (MCI_WG_TARGET sweep): 16 workgroups per CU even out the tail once a launch is long
+        // enough that the extra partial rows (merged by k_hist_stage1) do not matter
+        static const int64_t forced = getenv("MCI_WG_TARGET") ? atoll(getenv("MCI_WG_TARGET")) : 0; // diagnostic override
+        const int64_t target = forced > 0 ? forced : (units * nblocks >= (int64_t)1 << 25 ? 4096 : 2048);
+        wpb = (int)((target + nblocks - 1) / nblocks);
         const int64_t maxw = (units + T - 1) / T;
         if (wpb > maxw) wpb = (int)maxw;
         if (wpb < 1) wpb = 1;
@@ -1232,7 +1236,6 @@ int64_t mci_mcmc_burnin(int64_t steps, int64_t nchain, int32_t nslots, int32_t n
     int64_t nburn = (int64_t)floor((double)steps * thermal_ratio); // mcmc/montecarlo.jl:133
     if (nchain > 1) { // many short chains: every chain must forget its start (DESIGN.md "chains")
         int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(npool + 1) * nd;
-        if (fl > steps / 2) fl = steps / 2;
         if (fl > nburn) nburn = fl;
     }
     return nburn;

@@ -943,21 +943,27 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             int upd = (int)(u01(r0.x, r0.y) * (double)NUPD); // :137 rand(rng, updates)
             if (upd >= NUPD) upd = NUPD - 1;
             const double upick = u01(r0.z, r0.w), us1 = u01(r1.x, r1.y), us2 = u01(r1.z, r1.w), uacc = u01(r2.x, r2.y);
+            // ---- build the proposal (n, prop, newcurr); ONE evaluate-and-accept tail serves all three updates, so
+            // lanes that diverged on the update type reconverge before the expensive part ----
+            Chain<Cfg> n = c;
+            double prop = 1.0;
+            bool active = false;
+            int newcurr = curr, ut = 0; // ut: first index of propose[., ., .]: 0 changeIntegrand, 1 changeVariable, 2 swapVariable
             if (upd == 0) {
                 // ---- changeIntegrand  updates.jl:1-69 ----
-                const int cur0 = curr; // `curr` may change below: dispatch on the value the step started with
                 static_for<0, ND>([&](auto C0) {
                     constexpr int c0 = decltype(C0)::value;
                     constexpr int nn = Cfg::nneighbor(c0);
-                    if (cur0 == c0) {
+                    if (curr == c0) {
                         int j = (int)(upick * (double)nn); // :6
                         if (j >= nn) j = nn - 1;
                         static_for<0, nn>([&](auto J) {
                             constexpr int nw = Cfg::neighbor(c0 * Cfg::NBMAX + decltype(J)::value);
                             if constexpr (nw != c0) { // :7
                                 if (j == decltype(J)::value) {
-                                    Chain<Cfg> n = c;
-                                    double prop = (double)nn / (double)Cfg::nneighbor(nw); // :12
+                                    active = true;
+                                    newcurr = nw;
+                                    prop = (double)nn / (double)Cfg::nneighbor(nw); // :12
                                     static_for<0, NPOOL>([&](auto V) { // :15-26
                                         constexpr int v = decltype(V)::value;
                                         constexpr int cd = Cfg::dof(c0 * NPOOL + v), nd = Cfg::dof(nw * NPOOL + v);
@@ -978,23 +984,6 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                                             });
                                         }
                                     });
-                                    if (prop > 4.9406564584124654e-324) { // :29-31
-                                        Weight<Cfg> neww;
-                                        static_for<0, Cfg::NCOMP>([&](auto Q) { neww.v[decltype(Q)::value] = 0.0; });
-                                        neww.abs = 0.0;
-                                        if constexpr (nw != NORMI) neww = eval_one<Cfg, nw>(n.x, a.ud); // :35-38
-                                        extra[XE] += 1.0;                                              // :40
-                                        const double newp = nw == NORMI ? rw[NORMI] : neww.abs * rw[nw]; // :42-44
-                                        const double R = prop * newp / probability;                    // :46
-                                        extra[XP + 0] += 1.0;                                          // :48
-                                        if (uacc < R) {                                                // :49
-                                            extra[XA + 0] += 1.0;
-                                            curr = nw;                                                 // :51-53
-                                            c = n;
-                                            weight = neww;
-                                            probability = newp;
-                                        } // createRollback!/removeRollback! are no-ops (sampler.jl:306, :324)
-                                    }
                                 }
                             }
                         });
@@ -1009,11 +998,9 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                         if (curr == decltype(I)::value && vi == decltype(V)::value) cdv = Cfg::dof(decltype(I)::value * NPOOL + decltype(V)::value);
                     });
                 });
-                Chain<Cfg> n = c;
-                double prop = 1.0;
-                bool active = false;
                 if (upd == 1) {
                     // ---- swapVariable  updates.jl:113-147 ----
+                    ut = 2;
                     if (cdv > 0) { // :121
                         int s1 = (int)(us1 * (double)cdv), s2 = (int)(us2 * (double)cdv); // :122-123
                         if (s1 >= cdv) s1 = cdv - 1;
@@ -1038,6 +1025,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                     }
                 } else {
                     // ---- changeVariable  updates.jl:71-111 ----
+                    ut = 1;
                     static_for<0, NPOOL>([&](auto V) {
                         constexpr int v = decltype(V)::value;
                         constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
@@ -1062,23 +1050,27 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                         }
                     });
                 }
-                if (active && prop > 4.9406564584124654e-324) { // :88-90, :129-131
-                    const Weight<Cfg> wn = eval_sel<Cfg>(curr, n.x, a.ud); // :92, :133
-                    extra[XE] += 1.0;                                    // :94, :135
-                    const double newp = wn.abs * rw_sel(curr);           // :96, :137
-                    const double R = prop * newp / probability;          // :97, :138
-                    const int ut = upd == 1 ? 2 : 1;                     // first index of propose[., curr, vi]  :99, :140
-                    const bool ok = uacc < R;                            // :100, :141
-                    static_for<1, 3>([&](auto U) {
-                        extra[XP + decltype(U)::value] += ut == decltype(U)::value ? 1.0 : 0.0;
-                        extra[XA + decltype(U)::value] += (ok && ut == decltype(U)::value) ? 1.0 : 0.0;
-                    });
-                    if (ok) {
-                        c = n;
-                        weight = wn;
-                        probability = newp;
-                    } // else shiftRollback! / swapRollback!: the proposal copy is dropped  :105, :145
-                }
+            }
+            if (active && prop > 4.9406564584124654e-324) { // updates.jl:29-31, :88-90, :129-131
+                Weight<Cfg> wn;
+                static_for<0, Cfg::NCOMP>([&](auto Q) { wn.v[decltype(Q)::value] = 0.0; });
+                wn.abs = 0.0;
+                if (newcurr != NORMI) wn = eval_sel<Cfg>(newcurr, n.x, a.ud);                  // :35-38, :92, :133
+                extra[XE] += 1.0;                                                               // :40, :94, :135
+                const double newp = newcurr == NORMI ? rw[NORMI] : wn.abs * rw_sel(newcurr);    // :42-44, :96, :137
+                const double R = prop * newp / probability;                                     // :46, :97, :138
+                const bool ok = uacc < R;                                                       // :49, :100, :141
+                static_for<0, 3>([&](auto U) {
+                    extra[XP + decltype(U)::value] += ut == decltype(U)::value ? 1.0 : 0.0;           // :48, :99, :140
+                    extra[XA + decltype(U)::value] += (ok && ut == decltype(U)::value) ? 1.0 : 0.0;   // :50, :101, :142
+                });
+                if (ok) {
+                    c = n;
+                    curr = newcurr;                                                             // :51-53
+                    weight = wn;
+                    probability = newp;
+                } // else the proposal copy is dropped: createRollback!/removeRollback! are no-ops (sampler.jl:306, :324),
+                  // shiftRollback!/swapRollback! restore the slot (:105, :145)
             }
             // ---- measurement  montecarlo.jl:144-172 ----
             const bool mf = (a.measurefreq == 1) || (it % a.measurefreq == 0);

@@ -81,6 +81,7 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     std::ostringstream o;
     o << "#include \"mci_device.h\"\n";
     o << "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n";
+    o << "#ifdef MCI_WAVES\n#define MCI_OCC __attribute__((amdgpu_waves_per_eu(MCI_WAVES, MCI_WAVES)))\n#else\n#define MCI_OCC\n#endif\n";
     o << "namespace {\nstruct Cfg {\n";
     o << "    static constexpr int NDRAW = " << s.ndraw << ", NLEAF = " << s.nleaf << ", NI = " << s.ni
       << ", NPOOL = " << s.npool << ", NOBS = " << s.nobs << ", NCOLS = " << s.ncols << ";\n";
@@ -128,7 +129,7 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
       << s.measure_body << "\n#undef obs_add\n    }\n";
     o << "};\n}\n";
     if (solver == 0) {
-        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_batch(mci::BatchArgs a) { "
+        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) MCI_OCC mci_vegas_batch(mci::BatchArgs a) { "
              "mci::vegas_batch<Cfg, (Cfg::NTILE > 1)>(a); }\n";
         if (s.ntile > 1)
             o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_tiles(mci::BatchArgs a) { "

@@ -899,7 +899,6 @@ long mcio_mcmc_burnin(long steps, long nchain, int nslots, int Nd, int npool, do
     long nburn = (long)floor((double)steps * thermal_ratio); /* :133 */
     if (nchain > 1) { /* many short chains: each must forget its start (this engine's own decomposition) */
         long fl = 64L * nslots + 16L * (npool + 1) * Nd;
-        if (fl > steps / 2) fl = steps / 2;
         if (fl > nburn) nburn = fl;
     }
     return nburn;

@@ -260,4 +260,4 @@ def test_mcmc_burnin_rule(oracle):
     assert L.mcio_mcmc_burnin(62500, 1, 3, 3, 1, 0.1) == 6250          # mcmc/montecarlo.jl:133 for the reference's chain
     assert L.mcio_mcmc_burnin(62500, 1, 3, 3, 1, 0.0) == 0
     assert L.mcio_mcmc_burnin(4000, 8, 3, 3, 1, 0.1) == 400            # floor 64*3 + 16*2*3 = 288 < 400
-    assert L.mcio_mcmc_burnin(1000, 8, 12, 5, 1, 0.1) == 500           # floor 928 capped at steps/2
+    assert L.mcio_mcmc_burnin(1000, 8, 12, 5, 1, 0.1) == 928           # the floor is not capped: burn-in steps are extra

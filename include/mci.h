@@ -125,6 +125,13 @@ int mci_problem_destroy(mci_problem *prob);
  *     const double* ud -- userdata (configuration.jl:113)
  * JIT-compiled with hiprtc for gfx950 together with the hand-written kernels. */
 int mci_set_integrand_source(mci_problem *prob, const char *body, const double *userdata, int32_t nuserdata);
+/* Slow path for closures that cannot be expressed as device source ("batch callback"): per launch the library
+ * hands the host callback every draw of the batch, draw-major x[k*n + i] (so that x[k] is a contiguous vector over
+ * the n samples -- what a vectorised `(x, c) -> ...` wants), the callback writes w[q*n + i] for the nw =
+ * nintegrand*ncomp outputs and returns 0; the sample kernel then regenerates the same draws around those weights.
+ * PCIe- and host-bound by construction; solver = MCI_VEGAS only. */
+typedef int (*mci_host_integrand_fn)(const double *x, double *w, int64_t n, int32_t ndraw, int32_t nw, void *user);
+int mci_set_integrand_host(mci_problem *prob, mci_host_integrand_fn fn, void *user);
 /* The `measure` callback (vegas/montecarlo.jl:156-161, mcmc/montecarlo.jl:166-169) as a HIP C++ function body:
  *     const double* x, ud as above; const double* rw -- relative weights [nintegrand*ncomp];
  *     const int idx -- -1 (vegas, vegasmc) or the integrand an mcmc chain sits on (only its rw is non-zero);

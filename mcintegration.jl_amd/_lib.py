@@ -40,6 +40,9 @@ class IntegrateArgs(C.Structure):
                 ("thermal_ratio", C.c_double), ("reweight_goal", c_double_p)]
 
 
+HOST_INTEGRAND_FN = C.CFUNCTYPE(C.c_int, c_double_p, c_double_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
+
+
 class ResultC(C.Structure):
     _fields_ = [("niter", C.c_int32), ("nobs", C.c_int32), ("iter_mean", c_double_p), ("iter_std", c_double_p),
                 ("mean", c_double_p), ("stdev", c_double_p), ("chi2", c_double_p), ("neval", C.c_int64),
@@ -60,6 +63,7 @@ SIGNATURES = [
     ("mci_problem_create", C.c_int, [_VP, C.POINTER(ProblemDesc), C.POINTER(_VP)]),
     ("mci_problem_destroy", C.c_int, [_VP]),
     ("mci_set_integrand_source", C.c_int, [_VP, C.c_char_p, c_double_p, C.c_int32]),
+    ("mci_set_integrand_host", C.c_int, [_VP, _VP, _VP]),
     ("mci_set_measure_source", C.c_int, [_VP, C.c_char_p]),
     ("mci_compile", C.c_int, [_VP]),
     ("mci_compile_solver", C.c_int, [_VP, C.c_int32]),

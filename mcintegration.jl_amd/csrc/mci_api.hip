@@ -140,6 +140,11 @@ struct mci_problem {
     // the refinement (k_finish); anything else that looks at `packed` first flushes it (k_finalize)
     mci::MergeArgs merge{};
     bool merge_pending = false;
+    // host integrand ("batch callback"): draws dumped SoA -> callback -> weights uploaded -> accumulate kernel
+    mci_host_integrand_fn host_fn = nullptr;
+    void *host_user = nullptr;
+    double *d_hx = nullptr, *d_hw = nullptr, *h_hx = nullptr, *h_hw = nullptr; // device / pinned host
+    int64_t cap_host = 0;
     int threads = 256, wg_per_block = 0; // 0 = auto
     int train_serial = 0; // MCI_TRAIN_SERIAL=1: refinement walk as the reference's serial recurrence (diagnostic)
     // last launch
@@ -570,6 +575,10 @@ int mci_problem_destroy(mci_problem *p) {
             if (p->module[k]) (void)hipModuleUnload(p->module[k]);
         if (p->d_goal) (void)hipFree(p->d_goal);
         if (p->d_pa) (void)hipFree(p->d_pa);
+        if (p->d_hx) (void)hipFree(p->d_hx);
+        if (p->d_hw) (void)hipFree(p->d_hw);
+        if (p->h_hx) (void)hipHostFree(p->h_hx);
+        if (p->h_hw) (void)hipHostFree(p->h_hw);
         if (p->d_tile_w) (void)hipFree(p->d_tile_w);
         if (p->d_tile_bins) (void)hipFree(p->d_tile_bins);
         for (auto &e : p->evs) (void)hipEventDestroy(e);
@@ -581,6 +590,8 @@ int mci_problem_destroy(mci_problem *p) {
 int mci_set_integrand_source(mci_problem *p, const char *body, const double *ud, int32_t nud) {
     if (!p || !body) return fail(MCI_ERR_INVALID, "NULL argument");
     p->shape.body = body;
+    p->shape.host_integrand = 0;
+    p->host_fn = nullptr;
     p->h_ud.assign(ud, ud + (nud > 0 ? nud : 0));
     drop_modules(p);
     if (!p->ctx->offline) {
@@ -589,6 +600,18 @@ int mci_set_integrand_source(mci_problem *p, const char *body, const double *ud,
         HIPCHK(hipMalloc((void **)&p->d_ud, (p->h_ud.size() ? p->h_ud.size() : 1) * sizeof(double)));
         if (p->h_ud.size()) HIPCHK(hipMemcpy(p->d_ud, p->h_ud.data(), p->h_ud.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    return MCI_OK;
+}
+
+int mci_set_integrand_host(mci_problem *p, mci_host_integrand_fn fn, void *user) {
+    if (!p || !fn) return fail(MCI_ERR_INVALID, "NULL argument");
+    p->host_fn = fn;
+    p->host_user = user;
+    p->shape.host_integrand = 1;
+    p->shape.body = "";
+    p->h_ud.clear();
+    drop_modules(p);
+    if (!p->ctx->offline && !p->d_ud) HIPCHK(hipMalloc((void **)&p->d_ud, sizeof(double)));
     return MCI_OK;
 }
 
@@ -762,6 +785,48 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.tile_w = p->d_tile_w;
     a.tile_bins = p->d_tile_bins;
     a.tile_stride = nblocks * nevalperblock;
+    if (s.host_integrand) {
+        // "batch callback": the closure cannot run on the device, so the draws of this launch go to the host (SoA,
+        // x[k*n + i]), the callback fills w[q*n + i], and the sample kernel regenerates the same draws (same Philox
+        // indices) around the uploaded weights.  PCIe + host bound by construction; solver = :vegas only.
+        if (solver != MCI_VEGAS) return fail(MCI_ERR_INVALID, "a host integrand runs with solver=:vegas only (a chain needs the integrand inside the step)");
+        const int64_t n = nblocks * nevalperblock;
+        if (n > p->cap_host) {
+            if (p->d_hx) (void)hipFree(p->d_hx);
+            if (p->d_hw) (void)hipFree(p->d_hw);
+            if (p->h_hx) (void)hipHostFree(p->h_hx);
+            if (p->h_hw) (void)hipHostFree(p->h_hw);
+            p->d_hx = p->d_hw = p->h_hx = p->h_hw = nullptr;
+            p->cap_host = 0;
+            HIPCHK(hipMalloc((void **)&p->d_hx, (size_t)n * s.ndraw * sizeof(double)));
+            HIPCHK(hipMalloc((void **)&p->d_hw, (size_t)n * s.ni * s.ncomp * sizeof(double)));
+            HIPCHK(hipHostMalloc((void **)&p->h_hx, (size_t)n * s.ndraw * sizeof(double), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **)&p->h_hw, (size_t)n * s.ni * s.ncomp * sizeof(double), hipHostMallocDefault));
+            p->cap_host = n;
+        }
+        mci::DumpArgs d{};
+        d.edges = p->d_edges;
+        d.dacc = p->d_dacc;
+        d.ddist = p->d_ddist;
+        d.ud = p->d_ud;
+        d.x = p->d_hx;
+        d.soa = 1;
+        d.seed = seed;
+        d.iteration = (mci::u32)iteration;
+        d.first_index = block_lo * nevalperblock;
+        d.n = n;
+        void *dargs[] = {&d};
+        const unsigned dgrid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipStream_t hs = p->ctx->stream;
+        HIPCHK(hipModuleLaunchKernel(p->f_dump, dgrid, 1, 1, 256, 1, 1, (unsigned)p->lds_bytes, hs, dargs, nullptr));
+        HIPCHK(hipMemcpyAsync(p->h_hx, p->d_hx, (size_t)n * s.ndraw * sizeof(double), hipMemcpyDeviceToHost, hs));
+        HIPCHK(hipStreamSynchronize(hs));
+        memset(p->h_hw, 0, (size_t)n * s.ni * s.ncomp * sizeof(double));
+        const int hrc = p->host_fn(p->h_hx, p->h_hw, n, s.ndraw, s.ni * s.ncomp, p->host_user);
+        if (hrc) return fail(MCI_ERR_INVALID, "the host integrand failed (%d)", hrc);
+        HIPCHK(hipMemcpyAsync(p->d_hw, p->h_hw, (size_t)n * s.ni * s.ncomp * sizeof(double), hipMemcpyHostToDevice, hs));
+        a.host_w = p->d_hw;
+    }
     void *args[] = {&a};
     hipFunction_t f = p->f_solver[solver];
     hipStream_t st = p->ctx->stream;

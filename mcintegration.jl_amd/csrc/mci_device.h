@@ -106,11 +106,15 @@ struct BatchArgs {
     double *tile_w;         // [NI][tile_stride]
     u32 *tile_bins;         // [ceil(ntdraw/2)][tile_stride]  two bins per word
     i64 tile_stride;        // samples of this launch
+    // host integrand ("batch callback", Cfg::HOST_INTEGRAND): weights evaluated on the host for exactly the draws
+    // this launch regenerates, host_w[q * tile_stride + sample]
+    const double *host_w;
 };
 
 struct DumpArgs {
     const double *edges, *dacc, *ddist, *ud;
     double *x, *jac, *w;
+    int soa; // 1: x[k*n + i] (draw-major, what a vectorised host integrand wants), jac/w not written
     u64 seed;
     u32 iteration;
     i64 first_index; // global sample index of the first dumped sample
@@ -495,7 +499,12 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(B * a.neval_per_block + n), s);
         double w[Cfg::NW];
-        Cfg::integrand(s.x, w, a.ud, -1); // vegas/montecarlo.jl:140-144
+        if constexpr (Cfg::HOST_INTEGRAND != 0) { // the closure ran on the host over the dumped draws
+            const i64 hidx = wi.lb * a.neval_per_block + n;
+            static_for<0, Cfg::NW>([&](auto Q) { w[decltype(Q)::value] = a.host_w[decltype(Q)::value * a.tile_stride + hidx]; });
+        } else {
+            Cfg::integrand(s.x, w, a.ud, -1); // vegas/montecarlo.jl:140-144
+        }
         extra[Cols<Cfg>::NEVAL - Cfg::NOBS] += 1.0; // config.neval += 1   :118
         if (a.measurefreq == 1 || (n + 1) % a.measurefreq == 0) { // :148
             double relw[Cfg::NW];
@@ -1123,8 +1132,13 @@ template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs 
     for (i64 n = (i64)blockIdx.x * blockDim.x + threadIdx.x; n < a.n; n += (i64)gridDim.x * blockDim.x) {
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(a.first_index + n), s);
+        if (a.soa) {
+            static_for<0, Cfg::NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[(i64)k * a.n + n] = s.x[k]; });
+            continue;
+        }
         double w[Cfg::NW];
-        Cfg::integrand(s.x, w, a.ud, -1);
+        if constexpr (Cfg::HOST_INTEGRAND != 0) static_for<0, Cfg::NW>([&](auto I) { w[decltype(I)::value] = 0.0; });
+        else Cfg::integrand(s.x, w, a.ud, -1);
         static_for<0, Cfg::NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[n * Cfg::NDRAW + k] = s.x[k]; });
         a.jac[n] = s.jac;
         static_for<0, Cfg::NW>([&](auto I) { constexpr int i = decltype(I)::value; a.w[n * Cfg::NW + i] = w[i]; });

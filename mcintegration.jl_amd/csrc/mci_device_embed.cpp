@@ -108,11 +108,15 @@ struct BatchArgs {
     double *tile_w;         // [NI][tile_stride]
     u32 *tile_bins;         // [ceil(ntdraw/2)][tile_stride]  two bins per word
     i64 tile_stride;        // samples of this launch
+    // host integrand ("batch callback", Cfg::HOST_INTEGRAND): weights evaluated on the host for exactly the draws
+    // this launch regenerates, host_w[q * tile_stride + sample]
+    const double *host_w;
 };
 
 struct DumpArgs {
     const double *edges, *dacc, *ddist, *ud;
     double *x, *jac, *w;
+    int soa; // 1: x[k*n + i] (draw-major, what a vectorised host integrand wants), jac/w not written
     u64 seed;
     u32 iteration;
     i64 first_index; // global sample index of the first dumped sample
@@ -143,12 +147,12 @@ __device__ __forceinline__ void global_add(double *p, double v) {
 // ---------------------------------------------------------------------------------------------
 //   TABLE_MODE 3: histograms in LDS, grids gathered from L2 (more than ~9 independent grids: the
 //   ds_add_f64 is the part that must not go to global memory); when all histograms do not fit either they
-//   are split into NTILE tiles and each (block, slice) is run by NTILE workgroups, workgroup `tile`
+//   are split into NTILE tiles and each (block, slice) is)MCIDEV"
+R"MCIDEV( run by NTILE workgroups, workgroup `tile`
 //   keeping only its tile's histograms (draws + integrand are recomputed: compute is cheaper than atomics).
 template <class Cfg> struct Mode {
     static constexpr bool EDGE_LDS = Cfg::TABLE_MODE <= 1;
-    static constexpr bool HIST_LDS = Cfg::TABLE_MODE == 0 || C)MCIDEV"
-R"MCIDEV(fg::TABLE_MODE == 3;
+    static constexpr bool HIST_LDS = Cfg::TABLE_MODE == 0 || Cfg::TABLE_MODE == 3;
 };
 
 template <class Cfg> struct Tables {
@@ -302,13 +306,13 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
 // LDS carve (doubles).  Order: grid table | dacc | ddist | hist | obs | reduction scratch
 template <class Cfg> struct Lds {
     static constexpr int E = 0;
-    static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
+    static constexpr int DA = E + (Cfg::TAB)MCIDEV"
+R"MCIDEV(LE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
     static constexpr int DD = DA + Cfg::NDACC;
     static constexpr int H = DD + Cfg::NDDIST;
     static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE : 0);
     static constexpr int R = O + Cfg::NOBS;
-    static constexpr int EN)MCIDEV"
-R"MCIDEV(D = R + 16 /*waves*/ * Cfg::NCOLS;
+    static constexpr int END = R + 16 /*waves*/ * Cfg::NCOLS;
 };
 
 // partial-statistics columns written per workgroup:
@@ -458,11 +462,11 @@ template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchAr
 
 // =============================================================================================
 // VEGAS sample batch  (vegas/montecarlo.jl:117-187)
-// =============================================================================================
+// ===================================)MCIDEV"
+R"MCIDEV(==========================================================
 // SPLIT (NTILE > 1): this pass owns histogram tile 0 only and parks (weights, bins of the other tiles' draws)
 // per sample for mci_vegas_tiles; one workgroup per (block, slice).
-template <class Cfg, bool SPLIT = false> __device__ __forceinline__ v)MCIDEV"
-R"MCIDEV(oid vegas_batch(const BatchArgs &a) {
+template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, T = blockDim.x;
     double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
@@ -500,7 +504,12 @@ R"MCIDEV(oid vegas_batch(const BatchArgs &a) {
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(B * a.neval_per_block + n), s);
         double w[Cfg::NW];
-        Cfg::integrand(s.x, w, a.ud, -1); // vegas/montecarlo.jl:140-144
+        if constexpr (Cfg::HOST_INTEGRAND != 0) { // the closure ran on the host over the dumped draws
+            const i64 hidx = wi.lb * a.neval_per_block + n;
+            static_for<0, Cfg::NW>([&](auto Q) { w[decltype(Q)::value] = a.host_w[decltype(Q)::value * a.tile_stride + hidx]; });
+        } else {
+            Cfg::integrand(s.x, w, a.ud, -1); // vegas/montecarlo.jl:140-144
+        }
         extra[Cols<Cfg>::NEVAL - Cfg::NOBS] += 1.0; // config.neval += 1   :118
         if (a.measurefreq == 1 || (n + 1) % a.measurefreq == 0) { // :148
             double relw[Cfg::NW];
@@ -597,7 +606,8 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
 //   chain g = block*nchain + ch
 //   init  : stream MC_INIT, index g,            k = flat draw
 //   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
-// =============================================================================================
+// ================================================================================)MCIDEV"
+R"MCIDEV(=============
 template <class Cfg> struct Chain {
     double x[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
     double prob[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // leaf prob[idx]  (variable.jl:90)
@@ -609,8 +619,7 @@ template <class Cfg> struct Chain {
 template <class Cfg, int I> __device__ __forceinline__ double pad_prob(const Chain<Cfg> &c) {
     double p = 1.0;
     static_for<0, Cfg::NDRAW>([&](auto K) {
-        constexpr int k = declt)MCIDEV"
-R"MCIDEV(ype(K)::value;
+        constexpr int k = decltype(K)::value;
         if constexpr (!((Cfg::own_mask(I) >> k) & 1ull)) p *= c.prob[k];
     });
     return p;
@@ -748,7 +757,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                             get_slot<Cfg, v, l>(c, slot, xo, po, bo);
                             draw_pool_leaf<Cfg, v, l>(t, y, xn, pn, bn); // shift!  sampler.jl:336-386, :57-71
                             put_slot<Cfg, v, l>(n, slot, xn, pn, bn);
-                            prop *= po / pn;                              // 1/prob_ratio  sampler.jl:385, :70
+    )MCIDEV"
+R"MCIDEV(                        prop *= po / pn;                              // 1/prob_ratio  sampler.jl:385, :70
                         });
                     }
                 }
@@ -758,8 +768,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 Cfg::integrand(n.x, wn, a.ud, -1);             // :67-75
                 extra[XE] += 1.0;                              // config.neval += 1   :77
                 static_for<0, NI + 1>([&](auto I) { padn[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(n); }); // :79-81
-                double newp)MCIDEV"
-R"MCIDEV( = rw[NORMI] * padn[NORMI];         // :84
+                double newp = rw[NORMI] * padn[NORMI];         // :84
                 static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; newp += absw<Cfg, i>(wn) * rw[i] * padn[i]; }); // :85-87
                 const double R = prop * newp / probability;    // :88
                 const bool ok = uacc < R;                      // :91
@@ -893,7 +902,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
 
     const WorkItem wi = work_item<Cfg>(a);
     const int slice = wi.slice, tile = wi.tile;
-    const i64 B = a.block_lo + wi.lb;
+    const i64 B = a.block_lo + wi.lb;)MCIDEV"
+R"MCIDEV(
     const i64 steps = a.neval_per_block / a.nchain, nburn = a.nburn;
     const u32 st_init = a.iteration * 8u + STREAM_MCMC_INIT, st_step = a.iteration * 8u + STREAM_MCMC_STEP;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
@@ -906,8 +916,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     };
 
     double acc[Cfg::NW];
-    static_for<0, Cfg::NW>([&](auto I) { acc[decltype(I)::value] = )MCIDEV"
-R"MCIDEV(0.0; });
+    static_for<0, Cfg::NW>([&](auto I) { acc[decltype(I)::value] = 0.0; });
     double extra[Cfg::NCOLS - Cfg::NOBS];
     static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
     constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
@@ -1023,7 +1032,8 @@ R"MCIDEV(0.0; });
                                         double xa, xb, pa, pb;
                                         int ba, bb;
                                         get_slot<Cfg, v, l>(c, s1, xa, pa, ba);
-                                        get_slot<Cfg, v, l>(c, s2, xb, pb, bb);
+                            )MCIDEV"
+R"MCIDEV(            get_slot<Cfg, v, l>(c, s2, xb, pb, bb);
                                         put_slot<Cfg, v, l>(n, s1, xb, pb, bb);
                                         put_slot<Cfg, v, l>(n, s2, xa, pa, ba);
                                     });
@@ -1036,8 +1046,7 @@ R"MCIDEV(0.0; });
                     ut = 1;
                     static_for<0, NPOOL>([&](auto V) {
                         constexpr int v = decltype(V)::value;
-                        const)MCIDEV"
-R"MCIDEV(expr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                        constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
                         constexpr bool skip = (md <= 0) || (nl == 1 && Cfg::leaf_kind(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1 &&
                                                             Cfg::leaf_nbin(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1); // :79-81
                         if constexpr (!skip) {
@@ -1132,8 +1141,13 @@ template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs 
     for (i64 n = (i64)blockIdx.x * blockDim.x + threadIdx.x; n < a.n; n += (i64)gridDim.x * blockDim.x) {
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(a.first_index + n), s);
+        if (a.soa) {
+            static_for<0, Cfg::NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[(i64)k * a.n + n] = s.x[k]; });
+            continue;
+        }
         double w[Cfg::NW];
-        Cfg::integrand(s.x, w, a.ud, -1);
+        if constexpr (Cfg::HOST_INTEGRAND != 0) static_for<0, Cfg::NW>([&](auto I) { w[decltype(I)::value] = 0.0; });
+        else Cfg::integrand(s.x, w, a.ud, -1);
         static_for<0, Cfg::NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[n * Cfg::NDRAW + k] = s.x[k]; });
         a.jac[n] = s.jac;
         static_for<0, Cfg::NW>([&](auto I) { constexpr int i = decltype(I)::value; a.w[n * Cfg::NW + i] = w[i]; });

@@ -5,7 +5,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import LeafDesc, ProblemDesc, c_double_p, c_int32_p, check, lib
-from .integrand import Integrand, Measure
+from .integrand import HostIntegrand, Integrand, Measure
 from .variables import ContinuousVar
 
 _ctx_cache = {}
@@ -39,6 +39,8 @@ class Engine:
         self.ctx = context(device)
         if isinstance(integrand, str):
             integrand = Integrand(integrand, config.userdata)
+        elif callable(integrand) and not isinstance(integrand, (Integrand, HostIntegrand)):
+            integrand = HostIntegrand(integrand)
         self.integrand = integrand
         leaves = config.leaves
         self._keep = []
@@ -75,7 +77,11 @@ class Engine:
         self.p = C.c_void_p()
         check(L.mci_problem_create(self.ctx, C.byref(desc), C.byref(self.p)))
         ud = integrand.userdata
-        check(L.mci_set_integrand_source(self.p, integrand.body.encode(), _dp(ud) if len(ud) else None, len(ud)))
+        if isinstance(integrand, HostIntegrand):
+            self._host_cb = _lib.HOST_INTEGRAND_FN(self._make_host_callback(integrand.fn))   # keep alive
+            check(L.mci_set_integrand_host(self.p, C.cast(self._host_cb, C.c_void_p), None))
+        else:
+            check(L.mci_set_integrand_source(self.p, integrand.body.encode(), _dp(ud) if len(ud) else None, len(ud)))
         if isinstance(measure, Measure):
             check(L.mci_set_measure_source(self.p, measure.body.encode()))
         if threads or wg_per_block is not None:
@@ -88,6 +94,45 @@ class Engine:
             check(L.mci_set_reweight(self.p, _dp(r), len(r)))
         for i, lf in enumerate(leaves):
             lf._engine, lf._leaf_index = self, i
+
+    def _make_host_callback(self, fn):
+        """ctypes trampoline: draw-major x[k*n + i] -> numpy views -> fn(x, config) -> w[q*n + i]"""
+        config = self.config
+        nc = config.ncomp
+        pools = []   # (first draw, maxdof, nleaf)
+        k = 0
+        for vi, v in enumerate(config.var):
+            nl = len(v.vars) if hasattr(v, "vars") else 1
+            pools.append((k, config.maxdof[vi], nl))
+            k += config.maxdof[vi] * nl
+
+        def cb(xp, wp, n, ndraw, nw, user):
+            try:
+                X = np.ctypeslib.as_array(xp, shape=(ndraw, n))
+                W = np.ctypeslib.as_array(wp, shape=(nw, n))
+                if len(pools) == 1 and pools[0][2] == 1:
+                    arg = X
+                else:
+                    arg = tuple(X[k0:k0 + md * nl].reshape((md, n) if nl == 1 else (md, nl, n)) for k0, md, nl in pools)
+                    if len(arg) == 1:
+                        arg = arg[0]
+                out = fn(arg, config)
+                if config.N == 1 and not isinstance(out, (tuple, list)):
+                    out = (out,)
+                assert len(out) == config.N, "the integrand must return one value per integrand"
+                for i, o in enumerate(out):
+                    o = np.broadcast_to(np.asarray(o), (n,))
+                    if nc == 2:
+                        W[2 * i] = o.real
+                        W[2 * i + 1] = o.imag
+                    else:
+                        W[i] = o
+                return 0
+            except Exception:   # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        return cb
 
     def close(self):
         if getattr(self, "p", None):

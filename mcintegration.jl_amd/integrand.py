@@ -33,3 +33,20 @@ class Measure:
 
     def __init__(self, body):
         self.body = body.strip()
+
+
+class HostIntegrand:
+    """A Python closure as integrand -- the reference's `integrand(var, config)` (vegas/montecarlo.jl:140-144) run on
+    the HOST, vectorised over the batch ("batch callback" slow path, include/mci.h mci_set_integrand_host):
+
+        f(x, config) -> array[n] | tuple of arrays (one per integrand; complex arrays for type=complex)
+
+    With one variable type `x[i]` is the vector of the i-th draw over the n samples of the batch (0-based; the
+    reference's `x[i+1]`); with several, `x` is a tuple with one such array per variable type (a CompositeVar pool has
+    shape [slot, leaf, n]).  solver="vegas" only."""
+
+    def __init__(self, fn, name=None):
+        self.fn = fn
+        self.name = name or getattr(fn, "__name__", "host")
+        self.body = "/* host integrand %d */" % id(fn)
+        self.userdata = np.zeros(0)

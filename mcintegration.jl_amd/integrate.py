@@ -9,7 +9,7 @@ from ._lib import MCMC, SOLVERS, VEGAS, VEGASMC, lib
 from .comm import LocalComm
 from .configuration import Configuration
 from .engine import Engine
-from .integrand import Integrand, Measure
+from .integrand import HostIntegrand, Integrand, Measure
 from .statistics import Result, report
 from .variables import Continuous, Discrete
 
@@ -49,6 +49,8 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
 
     if isinstance(integrand, str):
         integrand = Integrand(integrand, config.userdata)
+    elif callable(integrand) and not isinstance(integrand, (Integrand, HostIntegrand)):
+        integrand = HostIntegrand(integrand)       # a Python closure: host "batch callback" path, solver="vegas" only
     mkey = None if measure is None else measure.body if isinstance(measure, Measure) else (measure.pool, measure.slot, measure.leaf)
     key = (integrand.body, tuple(integrand.userdata), mkey, device,
            repr(config.neighbor))

@@ -188,6 +188,39 @@ function bind!(c::Configuration, f::Integrand, measure)
     p[]
 end
 
+# ---- Julia closures as integrands: the host "batch callback" slow path (mci_set_integrand_host) ----------------------
+# f(x, config) is called ONCE per launch with x[k] = the vector of draw k over the n samples of the batch (several
+# variable types: a tuple of per-pool matrices), and returns a vector (or a tuple of vectors, one per integrand).
+const _closures = Dict{Ptr{Cvoid},Any}()      # problem => (f, config): keeps them rooted
+function _host_trampoline(x::Ptr{Float64}, w::Ptr{Float64}, n::Int64, ndraw::Int32, nw::Int32, user::Ptr{Cvoid})::Cint
+    try
+        f, c = _closures[user]
+        X = unsafe_wrap(Array, x, (Int(n), Int(ndraw)))           # column k = draw k (draw-major in memory)
+        W = unsafe_wrap(Array, w, (Int(n), Int(nw)))
+        cols = [view(X, :, k) for k in 1:ndraw]
+        out = f(cols, c)
+        out isa Tuple || (out = (out,))
+        for (i, o) in enumerate(out)
+            if c.ncomp == 2
+                W[:, 2i-1] .= real.(o); W[:, 2i] .= imag.(o)
+            else
+                W[:, i] .= o
+            end
+        end
+        return Cint(0)
+    catch err
+        @error "host integrand failed" err
+        return Cint(1)
+    end
+end
+function bind_host!(c::Configuration, f::Function)
+    prob = bind!(c, Integrand("", Float64[]), nothing)
+    _closures[prob] = (f, c)
+    cb = @cfunction(_host_trampoline, Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Ptr{Cvoid}))
+    check(ccall((:mci_set_integrand_host, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, cb, prob))
+    prob
+end
+
 # Result   reference src/statistics.jl:16-63
 struct Result
     mean::Vector{Float64}; stdev::Vector{Float64}; chi2::Vector{Float64}
@@ -208,14 +241,19 @@ report(r::Result) = show(stdout, r)
 Same keywords as the reference (src/main.jl:71-90); the loop of src/main.jl:142-218 runs inside
 `mci_integrate` on the GPU.  Unknown keywords go to `Configuration` (src/main.jl:95-97).
 """
-function integrate(integrand::Union{Integrand,AbstractString}; solver::Symbol=:vegasmc, config=nothing, neval=1e4, niter=10,
+function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::Symbol=:vegasmc, config=nothing, neval=1e4, niter=10,
                    block=16, gamma=1.0, adapt=true, ignore::Int=adapt ? 1 : 0, measure=nothing, measurefreq::Int=1,
                    thermal_ratio=0.1, reweight_goal::Union{Vector{Float64},Nothing}=nothing,
                    nchain=0, print=-1, verbose=-1, kwargs...)
     haskey(SOLVER, solver) || error("Solver $solver is not supported!")                  # main.jl:263
     config === nothing && (config = Configuration(; kwargs...))                          # main.jl:95-97
-    f = integrand isa Integrand ? integrand : Integrand(String(integrand), config.userdata === nothing ? Float64[] : Float64.(config.userdata))
-    prob = bind!(config, f, measure)
+    if integrand isa Function                      # a Julia closure: host batch-callback path, :vegas only
+        solver == :vegas || error("a closure integrand runs with solver=:vegas only; pass device source for :vegasmc / :mcmc")
+        prob = bind_host!(config, integrand)
+    else
+        f = integrand isa Integrand ? integrand : Integrand(String(integrand), config.userdata === nothing ? Float64[] : Float64.(config.userdata))
+        prob = bind!(config, f, measure)
+    end
     nobs = sum(config.obs_nbin)
     im, ie = zeros(nobs, niter), zeros(nobs, niter)           # row-major [niter][nobs] on the C side
     m, s, c2 = zeros(nobs), zeros(nobs), zeros(nobs)

@@ -238,3 +238,22 @@ def test_report_config_prints_the_acceptance_table(capsys):
     assert pr[0] > 1.0 and 0.0 < ac[0] <= pr[0]
     mci.report(res.config)
     assert "ChangeVariable" in capsys.readouterr().out
+
+
+def test_python_closure_as_integrand_matches_device_source():
+    """a host closure through the batch-callback path (mci_set_integrand_host) sees the same draws as
+    the device-source integrand, so the two runs agree to libm rounding; it reads like the reference's README call."""
+    res_h = integrate(lambda x, c: np.log(x[0]) / np.sqrt(x[0]), solver="vegas", neval=1e5, seed=5)     # README.md:26
+    res_d = integrate("return log(x[0]) / sqrt(x[0]);", solver="vegas", neval=1e5, seed=5)
+    np.testing.assert_allclose(res_h.iter_mean, res_d.iter_mean, rtol=1e-7)
+    check(res_h, -4.0)
+    # two integrands with different dof on one pool (Sphere2), a tuple return value
+    f = lambda X, c: ((X[0] ** 2 + X[1] ** 2 < 1.0) * 1.0, (X[0] ** 2 + X[1] ** 2 + X[2] ** 2 < 1.0) * 1.0)
+    res = integrate(f, var=Continuous(0.0, 1.0), dof=[[2], [3]], solver="vegas", neval=2e5, seed=6)
+    check(res, [PI / 4.0, 4.0 * PI / 3.0 / 8])
+    # several variable types: x is a tuple of per-pool arrays; complex output
+    g = lambda v, c: v[0][0] * v[1][0] + 1j * v[0][0]
+    res = integrate(g, var=(Continuous(0.0, 1.0), Discrete(1, 3)), dof=[[1, 1]], type=complex, solver="vegas", neval=1e5, seed=7)
+    check_complex(res, 3.0 + 1.5j)
+    with pytest.raises(mci.MCIError):   # a chain needs the integrand inside the step
+        integrate(lambda x, c: x[0], solver="vegasmc", neval=1e4)

@@ -326,6 +326,22 @@ def test_table_modes_agree(monkeypatch):
         np.testing.assert_allclose(o, outs[0], rtol=1e-10)
 
 
+@pytest.mark.parametrize("solver", ["vegasmc", "mcmc"])
+def test_chain_solvers_with_tiled_histograms_match_oracle(oracle, solver, monkeypatch):
+    """table mode 3 with several histogram tiles under the chain solvers: every tile's workgroup replays the same
+    chains (same Philox indices) and keeps its own tile; the merged histogram must equal the untiled oracle's."""
+    monkeypatch.setenv("MCI_TABLE_MODE", "3")
+    monkeypatch.setenv("MCI_HIST_TILE_BINS", "1000")   # one 999-bin leaf per tile -> 3 tiles
+    cfg = mci.Configuration(var=mci.Continuous([(0.0, PI)] * 3), dof=[[1]], seed=SEED)
+    eng = mci.Engine(cfg, mci.catalog.singular2())
+    assert eng.table_mode == 3
+    ocfg = oracle.Config([ocont(0, 0.0, PI) for _ in range(3)], [[1]])
+    osolver = dict(vegasmc=oracle.VEGASMC, mcmc=oracle.MCMC)[solver]
+    got = eng.iteration(solver, 3200, 0, 4, iteration=0, seed=SEED, nchain=16)
+    ref = ocfg.iteration(osolver, "singular2", None, 3200, 0, 4, 0, SEED, nchain=16)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+
+
 def test_error_paths():
     """non-positive normalization (main.jl:269-271) and non-finite histogram (variable.jl:212) surface as errors."""
     cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]], seed=SEED)

@@ -134,5 +134,25 @@ def nested_gauss(dofs=(3, 6, 9, 12)):
     return Integrand("\n    ".join(lines), [float(len(dofs))] + [float(d) for d in dofs], "nested_gauss")
 
 
+def cuba11():
+    """The 11-component 3-D test set of example/benchmark/cuba/benchmark.jl:35-46 (t1..t11), dof = [[3]]*11:
+    the only workload the reference publishes a wall time for (benchmark.jl:119-120, :146-147)."""
+    body = """
+    const double X = x[0], Y = x[1], Z = x[2];
+    const double r2 = X * X + Y * Y + Z * Z;
+    w[0] = sin(X) * cos(Y) * exp(Z);
+    w[1] = 1.0 / ((X + Y) * (X + Y) + 0.003) * cos(Y) * exp(Z);
+    w[2] = 1.0 / (3.75 - cos(M_PI * X) - cos(M_PI * Y) - cos(M_PI * Z));
+    w[3] = fabs(r2 - 0.125);
+    w[4] = exp(-r2);
+    w[5] = 1.0 / (1.0 - X * Y * Z + 1e-10);
+    w[6] = sqrt(fabs(X - Y - Z));
+    w[7] = exp(-X * Y * Z);
+    w[8] = X * X / (cos(X + Y + Z + 1.0) + 5.0);
+    w[9] = (X > 0.5) ? 1.0 / sqrt(X * Y * Z + 1e-5) : sqrt(X * Y * Z);
+    w[10] = (r2 < 1.0) ? 1.0 : 0.0;"""
+    return Integrand(body, None, "cuba11")
+
+
 BY_NAME = dict(log_over_sqrt=log_over_sqrt, sphere1=sphere1, sphere2=sphere2, singular2=singular2, x2y2=x2y2,
                discrete_id=discrete_id, one=one, gauss4_ref=gauss4_ref)

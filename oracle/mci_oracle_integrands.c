@@ -139,12 +139,30 @@ static void f_nested_gauss(const double *x, double *w, const double *ud) {
     }
 }
 
+/* example/benchmark/cuba/benchmark.jl:35-46  t1..t11 on the unit cube */
+static void f_cuba11(const double *x, double *w, const double *ud) {
+    (void)ud;
+    const double X = x[0], Y = x[1], Z = x[2];
+    const double r2 = X * X + Y * Y + Z * Z;
+    w[0] = sin(X) * cos(Y) * exp(Z);
+    w[1] = 1.0 / ((X + Y) * (X + Y) + 0.003) * cos(Y) * exp(Z);
+    w[2] = 1.0 / (3.75 - cos(M_PI * X) - cos(M_PI * Y) - cos(M_PI * Z));
+    w[3] = fabs(r2 - 0.125);
+    w[4] = exp(-r2);
+    w[5] = 1.0 / (1.0 - X * Y * Z + 1e-10);
+    w[6] = sqrt(fabs(X - Y - Z));
+    w[7] = exp(-X * Y * Z);
+    w[8] = X * X / (cos(X + Y + Z + 1.0) + 5.0);
+    w[9] = (X > 0.5) ? 1.0 / sqrt(X * Y * Z + 1e-5) : sqrt(X * Y * Z);
+    w[10] = (r2 < 1.0) ? 1.0 : 0.0;
+}
+
 mcio_integrand_fn mcio_builtin(const char *name) {
     static const struct { const char *n; mcio_integrand_fn f; } tab[] = {
         {"gaussian", f_gaussian}, {"gauss4_ref", f_gauss4_ref}, {"genz_product_peak", f_genz_product_peak},
         {"log_over_sqrt", f_log_over_sqrt}, {"sphere1", f_sphere1}, {"sphere2", f_sphere2},
         {"singular2", f_singular2}, {"x2y2", f_x2y2}, {"discrete_id", f_discrete_id}, {"one", f_one},
-        {"hypersphere", f_hypersphere}, {"bubble", f_bubble}, {"nested_gauss", f_nested_gauss},
+        {"hypersphere", f_hypersphere}, {"bubble", f_bubble}, {"nested_gauss", f_nested_gauss}, {"cuba11", f_cuba11},
     };
     for (unsigned i = 0; i < sizeof(tab) / sizeof(tab[0]); ++i)
         if (!strcmp(tab[i].n, name)) return tab[i].f;

@@ -28,7 +28,7 @@ def run(name, cfg, f, solver, neval, exact, measure=None, niter_train=5, niter=5
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c2i", "c4", "c3v", "c3mc", "c5", "c1"]
+    which = sys.argv[1:] or ["c2", "c2i", "c4", "c3v", "c3mc", "c5", "cuba", "c1"]
     if "c5" in which:  # BASELINE configs[4]: 4 integrals on a 12-D pool, :mcmc
         ex = [math.erf(5.0) ** d for d in (3, 6, 9, 12)]
         run("C5 nested gauss mcmc 1e8", mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]]), mci.catalog.nested_gauss(),
@@ -37,6 +37,14 @@ if __name__ == "__main__":
             "vegasmc", 10**8, ex)
         run("C5 nested gauss vegas 1e8", mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]]), mci.catalog.nested_gauss(),
             "vegas", 10**8, ex)
+    if "cuba" in which:  # the reference's only printed wall time: example/benchmark/cuba/benchmark.jl:119-158 (0.246 s / 0.495 s)
+        import time
+        for alg in ("vegas", "vegasmc"):
+            mci.integrate(mci.catalog.cuba11(), dof=[[3]] * 11, neval=1e4, solver=alg, seed=1)
+            t0 = time.perf_counter()
+            r = mci.integrate(mci.catalog.cuba11(), dof=[[3]] * 11, neval=1e5, solver=alg, seed=2)
+            print("CUBA11 %-8s neval=1e5 x 10: %.4f s wall   Integral 1 = %.6f +- %.6f ... Integral 11 = %.6f +- %.6f" % (
+                alg, time.perf_counter() - t0, r.mean[0], r.stdev[0], r.mean[10], r.stdev[10]), flush=True)
     if "c1" in which:
         run("C1 log/sqrt 1e7", mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]]), mci.catalog.log_over_sqrt(), "vegas", 10**7, -4.0)
     if "c2" in which:

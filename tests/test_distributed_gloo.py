@@ -49,7 +49,7 @@ def _single(solver):
     return res, res.config._engine
 
 
-@pytest.mark.parametrize("solver", ["vegas", "vegasmc"])
+@pytest.mark.parametrize("solver", ["vegas", "vegasmc", "mcmc"])
 def test_two_ranks_equal_one_rank(solver):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -67,7 +67,10 @@ def test_two_ranks_equal_one_rank(solver):
         np.testing.assert_allclose(im, ref.iter_mean, rtol=1e-9)
         np.testing.assert_allclose(ie, ref.iter_std, rtol=1e-6)
         np.testing.assert_allclose(m, ref.mean, rtol=1e-9)
-        np.testing.assert_allclose(grid, eng.grid(0), rtol=0, atol=1e-11)
+        # every worker's summedConfig starts from clearStatistics! (1e-10 per bin, variable.jl:565) and the reduce sums
+        # them (configuration.jl:271-279), so -- in the reference too -- EMPTY bins hold (nworker + nblock) * 1e-10:
+        # only the unit-weight :mcmc histogram has empty bins at this size, and there the grid moves by ~1e-6
+        np.testing.assert_allclose(grid, eng.grid(0), rtol=0, atol=1e-11 if solver != "mcmc" else 1e-5)
         # rank r ran global blocks [4r, 4r+4) in every iteration (main.jl:122: block % nprocs == 0)
         assert calls == [(4 * rank, 4 * rank + 4, it) for it in range(4)]
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
@@ -79,3 +82,48 @@ def test_block_count_is_rounded_to_a_multiple_of_the_worker_count():
     from mcintegration_jl_amd.integrate import standardize_block
     assert standardize_block(30000, 16, 3) == (2000, 15)
     assert standardize_block(30000, 2, 8) == (3750, 8)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The same check with the REAL engine: two processes share GPU 0, each runs its half of the global blocks
+# through the HIP kernels, the packed buffers are summed with gloo.  Philox indices are global, so the
+# 2-rank run must reproduce the 1-rank run up to the reassociation of one cross-rank sum.
+# ---------------------------------------------------------------------------------------------------------
+def _gpu_worker(rank, world, port, solver, q):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mcintegration_jl_amd as mci
+    from mcintegration_jl_amd.comm import TorchDistComm
+    res = mci.integrate(mci.catalog.sphere2(), var=mci.Continuous(0.0, 1.0), dof=[[2], [3]], solver=solver, neval=64000,
+                        niter=4, block=8, seed=77, comm=TorchDistComm(), nchain=4, device=0)
+    q.put((rank, res.iter_mean, res.iter_std, res.config._engine.grid(0)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["vegas", "vegasmc", "mcmc"])
+def test_two_ranks_on_one_gpu_equal_one_rank(solver):
+    import mcintegration_jl_amd as mci
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, solver, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = mci.integrate(mci.catalog.sphere2(), var=mci.Continuous(0.0, 1.0), dof=[[2], [3]], solver=solver, neval=64000,
+                        niter=4, block=8, seed=77, nchain=4, device=0)
+    for rank, im, ie, grid in outs:
+        np.testing.assert_allclose(im, ref.iter_mean, rtol=1e-6)   # + the rounding amplification of 3 train! steps
+        np.testing.assert_allclose(ie, ref.iter_std, rtol=1e-4)
+        np.testing.assert_allclose(grid, ref.config._engine.grid(0), rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][3], outs[1][3])

@@ -278,3 +278,13 @@ def test_cuba11_against_the_references_printed_results(alg):
             assert abs(res.mean[k] - other["mean"][k]) < 5.0 * math.hypot(res.stdev[k], other["sigma"][k]), (alg, k, res.mean[k], other["mean"][k])
     assert dt < printed["wall_seconds"], (dt, printed["wall_seconds"])   # unspecified CPU vs MI355X; a sanity bound, not a benchmark
     print("cuba11 %s: %.4f s (reference prints %.3f s)" % (alg, dt, printed["wall_seconds"]))
+
+
+def test_plain_c_consumer_of_the_abi():
+    """examples/mci_demo.c: the README integral through the C ABI from plain C (no Python / torch types in the path)."""
+    import os
+    import subprocess
+    demo = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "mci_demo")
+    out = subprocess.run([demo, "100000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Integral 1 = -4.0" in out.stdout or "Integral 1 = -3.99" in out.stdout, out.stdout

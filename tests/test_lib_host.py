@@ -134,3 +134,16 @@ def test_result_and_report(capsys, golden):
     assert "ignore" in text and "-3.99798 ± 0.00136" in text  # statistics.jl:74-96: digits = 2 - floor(log10(err))
     res3 = res.with_ignore(3)
     assert res3.ignore == 3 and res3.mean[0] != res.mean[0]
+
+
+def test_plain_c_consumer_of_the_abi_builds_and_refuses_to_run_without_a_gpu():
+    """examples/mci_demo.c: the boundary is plain C (pointers and sizes); without a device it exits with
+    MCI_ERR_NO_DEVICE instead of falling back to the CPU."""
+    import subprocess
+    from mcintegration_jl_amd.engine import device_count
+    demo = os.path.join(ROOT, "examples", "mci_demo")
+    assert os.path.exists(demo), "run `python __graft_entry__.py` (build()) first"
+    if device_count() > 0:
+        pytest.skip("a GPU is visible")
+    out = subprocess.run([demo], capture_output=True, text=True)
+    assert out.returncode == 7 and "no CPU fallback" in out.stderr

@@ -109,7 +109,11 @@ struct BatchArgs {
     // host integrand ("batch callback", Cfg::HOST_INTEGRAND): weights evaluated on the host for exactly the draws
     // this launch regenerates, host_w[q * tile_stride + sample]
     const double *host_w;
+    // hipGraph replay of the iteration chain: the iteration index then lives in device memory (k_finish/k_train
+    // advance it), so that the captured launch parameters never change.  NULL: use `iteration`.
+    const u32 *iter_ptr;
 };
+__device__ __forceinline__ u32 iteration_of(const BatchArgs &a) { return a.iter_ptr ? *a.iter_ptr : a.iteration; }
 
 struct DumpArgs {
     const double *edges, *dacc, *ddist, *ud;
@@ -486,7 +490,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     }
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb; // global statistical block
-    const u32 stream = a.iteration * 8u + STREAM_VEGAS;
+    const u32 stream = iteration_of(a) * 8u + STREAM_VEGAS;
     const i64 stride = (i64)a.wg_per_block * T;
 
     double acc[Cfg::NW];
@@ -683,7 +687,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb;
     const i64 steps = a.neval_per_block / a.nchain;
-    const u32 st_init = a.iteration * 8u + STREAM_MC_INIT, st_step = a.iteration * 8u + STREAM_MC_STEP;
+    const u32 st_init = iteration_of(a) * 8u + STREAM_MC_INIT, st_step = iteration_of(a) * 8u + STREAM_MC_STEP;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[NI + 1];
     static_for<0, NI + 1>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -897,7 +901,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb;
     const i64 steps = a.neval_per_block / a.nchain, nburn = a.nburn;
-    const u32 st_init = a.iteration * 8u + STREAM_MCMC_INIT, st_step = a.iteration * 8u + STREAM_MCMC_STEP;
+    const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[ND];
     static_for<0, ND>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });

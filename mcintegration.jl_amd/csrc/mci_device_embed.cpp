@@ -111,7 +111,11 @@ struct BatchArgs {
     // host integrand ("batch callback", Cfg::HOST_INTEGRAND): weights evaluated on the host for exactly the draws
     // this launch regenerates, host_w[q * tile_stride + sample]
     const double *host_w;
+    // hipGraph replay of the iteration chain: the iteration index then lives in device memory (k_finish/k_train
+    // advance it), so that the captured launch parameters never change.  NULL: use `iteration`.
+    const u32 *iter_ptr;
 };
+__device__ __forceinline__ u32 iteration_of(const BatchArgs &a) { return a.iter_ptr ? *a.iter_ptr : a.iteration; }
 
 struct DumpArgs {
     const double *edges, *dacc, *ddist, *ud;
@@ -144,11 +148,11 @@ __device__ __forceinline__ void global_add(double *p, double v) {
 // ---------------------------------------------------------------------------------------------
 // table placement.  TABLE_MODE 0: grids + histograms in LDS; 1: grids in LDS, histograms via
 // global f64 atomics; 2: everything from L2/HBM (grids too large for 160 KiB).
-// ---------------------------------------------------------------------------------------------
+// -------)MCIDEV"
+R"MCIDEV(--------------------------------------------------------------------------------------
 //   TABLE_MODE 3: histograms in LDS, grids gathered from L2 (more than ~9 independent grids: the
 //   ds_add_f64 is the part that must not go to global memory); when all histograms do not fit either they
-//   are split into NTILE tiles and each (block, slice) is)MCIDEV"
-R"MCIDEV( run by NTILE workgroups, workgroup `tile`
+//   are split into NTILE tiles and each (block, slice) is run by NTILE workgroups, workgroup `tile`
 //   keeping only its tile's histograms (draws + integrand are recomputed: compute is cheaper than atomics).
 template <class Cfg> struct Mode {
     static constexpr bool EDGE_LDS = Cfg::TABLE_MODE <= 1;
@@ -296,7 +300,8 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
                 }
             });
         } else {
-            for (int i = tid; i < Cfg::NEDGE; i += T) sE[i] = gE[i];
+            for (int i = tid; i < Cfg::NEDGE; i += T) sE[i] = gE[)MCIDEV"
+R"MCIDEV(i];
         }
     }
     for (int i = tid; i < Cfg::NDACC; i += T) sDA[i] = gDA[i];
@@ -306,8 +311,7 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
 // LDS carve (doubles).  Order: grid table | dacc | ddist | hist | obs | reduction scratch
 template <class Cfg> struct Lds {
     static constexpr int E = 0;
-    static constexpr int DA = E + (Cfg::TAB)MCIDEV"
-R"MCIDEV(LE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
+    static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
     static constexpr int DD = DA + Cfg::NDACC;
     static constexpr int H = DD + Cfg::NDDIST;
     static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE : 0);
@@ -454,7 +458,8 @@ struct WorkItem {
 template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchArgs &a) {
     WorkItem w;
     w.tile = Cfg::NTILE == 1 ? 0 : (int)(blockIdx.x % Cfg::NTILE);
-    w.rowid = Cfg::NTILE == 1 ? (i64)blockIdx.x : (i64)(blockIdx.x / Cfg::NTILE);
+    w.rowid = Cfg::NT)MCIDEV"
+R"MCIDEV(ILE == 1 ? (i64)blockIdx.x : (i64)(blockIdx.x / Cfg::NTILE);
     w.lb = w.rowid / a.wg_per_block;
     w.slice = (int)(w.rowid % a.wg_per_block);
     return w;
@@ -462,8 +467,7 @@ template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchAr
 
 // =============================================================================================
 // VEGAS sample batch  (vegas/montecarlo.jl:117-187)
-// ===================================)MCIDEV"
-R"MCIDEV(==========================================================
+// =============================================================================================
 // SPLIT (NTILE > 1): this pass owns histogram tile 0 only and parks (weights, bins of the other tiles' draws)
 // per sample for mci_vegas_tiles; one workgroup per (block, slice).
 template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
@@ -491,7 +495,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     }
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb; // global statistical block
-    const u32 stream = a.iteration * 8u + STREAM_VEGAS;
+    const u32 stream = iteration_of(a) * 8u + STREAM_VEGAS;
     const i64 stride = (i64)a.wg_per_block * T;
 
     double acc[Cfg::NW];
@@ -602,12 +606,12 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
 // vegas_mc/updates.jl:45-106).  The reference runs ONE chain of neval steps per block; a block here
 // is `nchain` chains of neval/nchain steps (nchain = 1 reproduces the reference's chain).  Chain state
 // (x, prob, bin per draw; weights; probability) stays in registers; the proposal touches one
-// (pool, slot), selected by a compile-time switch so that every table access keeps static offsets.
+// (pool, slot), selected)MCIDEV"
+R"MCIDEV( by a compile-time switch so that every table access keeps static offsets.
 //   chain g = block*nchain + ch
 //   init  : stream MC_INIT, index g,            k = flat draw
 //   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
-// ================================================================================)MCIDEV"
-R"MCIDEV(=============
+// =============================================================================================
 template <class Cfg> struct Chain {
     double x[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
     double prob[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // leaf prob[idx]  (variable.jl:90)
@@ -689,7 +693,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb;
     const i64 steps = a.neval_per_block / a.nchain;
-    const u32 st_init = a.iteration * 8u + STREAM_MC_INIT, st_step = a.iteration * 8u + STREAM_MC_STEP;
+    const u32 st_init = iteration_of(a) * 8u + STREAM_MC_INIT, st_step = iteration_of(a) * 8u + STREAM_MC_STEP;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[NI + 1];
     static_for<0, NI + 1>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -751,14 +755,14 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                             else {
                                 const u32x4 rr = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(kk >> 1), st_step, k0, k1);
                                 y = (kk & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
-                            }
+              )MCIDEV"
+R"MCIDEV(              }
                             double xo, po, xn, pn;
                             int bo, bn;
                             get_slot<Cfg, v, l>(c, slot, xo, po, bo);
                             draw_pool_leaf<Cfg, v, l>(t, y, xn, pn, bn); // shift!  sampler.jl:336-386, :57-71
                             put_slot<Cfg, v, l>(n, slot, xn, pn, bn);
-    )MCIDEV"
-R"MCIDEV(                        prop *= po / pn;                              // 1/prob_ratio  sampler.jl:385, :70
+                            prop *= po / pn;                              // 1/prob_ratio  sampler.jl:385, :70
                         });
                     }
                 }
@@ -891,7 +895,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
-        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
+        for (int i = tid; i < Cfg)MCIDEV"
+R"MCIDEV(::HTILE; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
     __syncthreads();
     Tables<Cfg> t;
@@ -902,10 +907,9 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
 
     const WorkItem wi = work_item<Cfg>(a);
     const int slice = wi.slice, tile = wi.tile;
-    const i64 B = a.block_lo + wi.lb;)MCIDEV"
-R"MCIDEV(
+    const i64 B = a.block_lo + wi.lb;
     const i64 steps = a.neval_per_block / a.nchain, nburn = a.nburn;
-    const u32 st_init = a.iteration * 8u + STREAM_MCMC_INIT, st_step = a.iteration * 8u + STREAM_MCMC_STEP;
+    const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[ND];
     static_for<0, ND>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -1027,13 +1031,13 @@ R"MCIDEV(
                             static_for<0, NPOOL>([&](auto V) {
                                 constexpr int v = decltype(V)::value;
                                 if (vi == v) {
-                                    static_for<0, Cfg::pool_nleaf(v)>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
+                                    static_for<0, Cfg::pool_nlea)MCIDEV"
+R"MCIDEV(f(v)>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
                                         constexpr int l = decltype(Lf)::value;
                                         double xa, xb, pa, pb;
                                         int ba, bb;
                                         get_slot<Cfg, v, l>(c, s1, xa, pa, ba);
-                            )MCIDEV"
-R"MCIDEV(            get_slot<Cfg, v, l>(c, s2, xb, pb, bb);
+                                        get_slot<Cfg, v, l>(c, s2, xb, pb, bb);
                                         put_slot<Cfg, v, l>(n, s1, xb, pb, bb);
                                         put_slot<Cfg, v, l>(n, s2, xa, pa, ba);
                                     });

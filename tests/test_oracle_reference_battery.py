@@ -211,3 +211,26 @@ def test_cuba11_against_the_references_printed_results(oracle, solver):
             assert abs(r["mean"][k] - other["mean"][k]) < 5.0 * math.hypot(r["stdev"][k], other["sigma"][k]), (solver, k, r["mean"][k], other["mean"][k])
     ratio = r["stdev"] / np.array(printed["sigma"])
     assert np.all(ratio < 2.5) and np.all(ratio > 0.4), ratio
+
+
+def _printed_cases():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "printed_error_bars.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+@pytest.mark.parametrize("case", _printed_cases(), ids=lambda c: c["name"])
+def test_error_bars_have_the_size_the_reference_prints(oracle, case):
+    """Statistical efficiency, not just unbiasedness: for the examples whose final `mean +- sigma` the reference prints
+    (docs, README, docstrings, benchmark1.jl), the oracle run at the same neval/niter/solver/alpha lands within 7 sigma of
+    the exact value AND its error bar is within a factor 3 of the printed one, averaged over 4 seeds."""
+    s = dict(vegas=oracle.VEGAS, vegasmc=oracle.VEGASMC)[case["solver"]]
+    sig = []
+    for seed in (61, 62, 63, 64):
+        cfg = oracle.Config([cont(0, case["lower"], case["upper"], alpha=case["alpha"])], [[case["dof"]]])
+        r = cfg.integrate(s, case["integrand"], None, neval=case["neval"], niter=10, seed=seed)
+        check(r, case["exact"])
+        sig.append(r["stdev"][0])
+    ratio = float(np.exp(np.mean(np.log(sig)))) / case["printed_sigma"]
+    assert 1.0 / 3.0 < ratio < 3.0, (case["name"], sig, case["printed_sigma"])

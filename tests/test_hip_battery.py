@@ -288,3 +288,22 @@ def test_plain_c_consumer_of_the_abi():
     out = subprocess.run([demo, "100000"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "Integral 1 = -4.0" in out.stdout or "Integral 1 = -3.99" in out.stdout, out.stdout
+
+
+def test_error_bars_have_the_size_the_reference_prints():
+    """tests/golden/printed_error_bars.json through the product on the GPU: same neval / niter / solver as the reference's
+    printed examples -> within 7 sigma of exact, error bar within a factor 3 of the printed one (geometric mean of 4 seeds)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "printed_error_bars.json")) as fh:
+        cases = json.load(fh)["cases"]
+    body = dict(log_over_sqrt="return log(x[0]) / sqrt(x[0]);", x2y2="return x[0]*x[0] + x[1]*x[1];")
+    for case in cases:
+        sig = []
+        for seed in (61, 62, 63, 64):
+            res = integrate(body[case["integrand"]], var=Continuous(case["lower"], case["upper"], alpha=case["alpha"]), dof=[[case["dof"]]],
+                            solver=case["solver"], neval=case["neval"], niter=10, seed=seed, nchain=1)   # nchain=1: the reference's chain
+            check(res, case["exact"])
+            sig.append(res.stdev[0])
+        ratio = float(np.exp(np.mean(np.log(sig)))) / case["printed_sigma"]
+        assert 1.0 / 3.0 < ratio < 3.0, (case["name"], sig, case["printed_sigma"])

@@ -366,6 +366,29 @@ def test_graph_replay_of_the_iteration_chain_matches_the_eager_loop(monkeypatch)
         np.testing.assert_allclose(e1, e0, rtol=1e-3)
 
 
+@pytest.mark.parametrize("solver", ["vegas", "vegasmc", "mcmc"])
+def test_degenerate_pools_match_oracle(oracle, solver):
+    """ragged layouts the updates special-case: a single-valued Discrete (nothing to sample: vegas_mc/updates.jl:52-54,
+    mcmc/updates.jl:79-81), a pool no integrand uses (maxdof = 0: vegas_mc/updates.jl:55-57, mcmc/updates.jl:82) and
+    integrands with different dof on several pools."""
+    var = (mci.Continuous(0.0, 2.0), mci.Discrete(3, 3), mci.Continuous(0.0, 1.0), mci.Discrete(1, 4))
+    dof = [[2, 1, 0, 1], [1, 1, 0, 0]]
+    body = "w[0] = x[0] * x[1] * x[2] * x[3]; w[1] = exp(-x[0]) * x[2];"   # draws: X1, X2, D3, (pool 2 unused), D4
+    cfg = mci.Configuration(var=var, dof=dof, seed=SEED)
+    eng = mci.Engine(cfg, mci.Integrand(body))
+    assert eng.ndraw == 4
+    ocfg = oracle.Config([ocont(0, 0.0, 2.0), odisc(1, 3, 3), ocont(2, 0.0, 1.0), odisc(3, 1, 4)], dof)
+    fn = oracle.compile_c_integrand(body)
+    osolver = dict(vegas=oracle.VEGAS, vegasmc=oracle.VEGASMC, mcmc=oracle.MCMC)[solver]
+    got = eng.iteration(solver, 3200, 0, 4, iteration=0, seed=SEED, nchain=8)
+    ref = ocfg.iteration(osolver, fn, None, 3200, 0, 4, 0, SEED, nchain=8)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+    r = eng.integrate(solver, neval=64000, niter=5, block=8, seed=SEED)
+    # exact: int_0^2 x dx * int_0^2 y dy * 3 * sum_{1..4} d = 2*2*3*10 = 120 ; int_0^2 e^-x dx * 3 = 3 (1 - e^-2)
+    exact = np.array([120.0, 3.0 * (1.0 - math.exp(-2.0))])
+    assert np.all(np.abs(r["mean"] - exact) < 7.0 * r["stdev"]), (r["mean"], r["stdev"])
+
+
 def test_error_paths():
     """non-positive normalization (main.jl:269-271) and non-finite histogram (variable.jl:212) surface as errors."""
     cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]], seed=SEED)

@@ -200,7 +200,7 @@ void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64
                            int64_t *block);                                          /* main.jl:220-234 */
 /* first measured step of a VegasMC chain of `steps` steps: the reference's `ne >= neval/100`
  * (vegas_mc/montecarlo.jl:213) for its single chain (nchain = 1); with nchain > 1 independent chains per block
- * additionally >= min(steps/2, 32*nslots) so that each short chain forgets its start (nslots = sum of maxdof) */
+ * additionally >= min(steps/2, 64*nslots) so that each short chain forgets its start (nslots = sum of maxdof) */
 double mci_chain_burnin(int64_t steps, int64_t nchain, int32_t nslots);
 /* burn-in steps an MCMC chain runs before its `steps` measured ones: floor(steps*thermal_ratio)
  * (mcmc/montecarlo.jl:133); with nchain > 1 at least 64*nslots + 16*(npool+1)*nd */

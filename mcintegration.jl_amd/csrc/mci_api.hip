@@ -158,6 +158,7 @@ struct mci_problem {
     int log_row = 0;
     static const int kGroups = mci::kMergeGroups;
     static const int64_t kChainFill = 131072; // chains per GPU that keep 2 waves on each of the 1024 SIMDs
+    static const int64_t kMcmcMinSteps = 131072; // measured steps per auto :mcmc chain (>> the mixing times measured so far)
 };
 
 namespace {
@@ -706,10 +707,12 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     if (solver == MCI_VEGASMC) {
         int nslots = 0; // (pool, slot) pairs changeVariable can pick (updates.jl:50,:58)
         for (int v = 0; v < p->npool; ++v) nslots += p->maxdof[v];
-        if (nchain <= 0) { // auto (measured, tools/chain_sweep.py): as many chains as keep 2 waves per SIMD busy
-            // (kChainFill lanes per GPU), but never shorter than 4 burn-in floors (>= 3/4 of the steps measured)
-            const int64_t fl = 32 * (int64_t)nslots > 64 ? 32 * (int64_t)nslots : 64;
-            nchain = nevalperblock / (4 * fl);
+        if (nchain <= 0) { // auto: as many chains as keep 2 waves per SIMD busy (kChainFill lanes per GPU, tools/chain_sweep.py),
+            // but never shorter than 8 burn-in floors.  Short chains under-sample the sticky high-|f|/q states of
+            // singular integrands: measured on 1/(1 - cos x cos y cos z) at 2e9 steps, 381-step chains are 6 sigma low,
+            // 763-step chains are within 1.4 sigma (tools/chain_bias_c1.py).
+            const int64_t fl = 64 * (int64_t)nslots > 128 ? 64 * (int64_t)nslots : 128;
+            nchain = nevalperblock / (8 * fl);
             const int64_t cap = mci_problem::kChainFill / nblocks > 64 ? mci_problem::kChainFill / nblocks : 64;
             if (nchain > cap) nchain = cap;
             if (nchain < 1) nchain = 1;
@@ -721,9 +724,12 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         int nslots = 0;
         for (int v = 0; v < p->npool; ++v) nslots += p->maxdof[v];
         if (!(thermal_ratio >= 0.0)) return fail(MCI_ERR_INVALID, "thermal_ratio must be non-negative");
-        if (nchain <= 0) { // auto: fill the GPU, but keep >= 2 burn-in floors of measured steps per chain (>= 2/3 measured)
-            const int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(p->npool + 1) * (p->ni + 1);
-            nchain = nevalperblock / (2 * fl);
+        if (nchain <= 0) { // auto: LONG chains.  The walk over (integrand, variables) mixes slowly when |f|/q is heavy-tailed:
+            // on the bubble diagram 1e3-step chains are 2.7 % (55 sigma) off at 2e9 steps and need ~1e5 burn-in steps each
+            // to lose that bias (tools/bubble_mcmc_bias.py); only chains much longer than the mixing time are safe, which
+            // is what the reference's one-chain-per-block gives.  More chains: raise `block` (the reference's own knob) or
+            // pass nchain explicitly for integrands known to mix fast (C5: 6 Gsteps/s at nchain = 4096).
+            nchain = nevalperblock / mci_problem::kMcmcMinSteps;
             const int64_t cap = mci_problem::kChainFill / nblocks > 64 ? mci_problem::kChainFill / nblocks : 64;
             if (nchain > cap) nchain = cap;
             if (nchain < 1) nchain = 1;
@@ -1352,7 +1358,7 @@ void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64
 double mci_chain_burnin(int64_t steps, int64_t nchain, int32_t nslots) {
     double thr = (double)steps / 100.0; // vegas_mc/montecarlo.jl:213  `ne >= neval / 100`
     if (nchain > 1) {                   // many short chains: every chain must forget its start (DESIGN.md "chains")
-        double fl = 32.0 * (double)nslots;
+        double fl = 64.0 * (double)nslots;
         if (fl > (double)steps / 2.0) fl = (double)steps / 2.0;
         if (fl > thr) thr = fl;
     }

@@ -797,12 +797,12 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
     double x[MCIO_MAXDRAW], u[MCIO_MAXDRAW];
     const long steps = neval / nchain;
     /* first measured step: `ne >= neval/100` (:213) for the reference's single chain; with nchain > 1 each short
-       chain additionally skips min(steps/2, 32*nslots) steps (the many-chain decomposition is this engine's own) */
+       chain additionally skips min(steps/2, 64*nslots) steps (the many-chain decomposition is this engine's own) */
     int nslots = 0;
     for (int vi = 0; vi < npool; ++vi) nslots += c->maxdof[vi];
     double burnin = (double)steps / 100.0;
     if (nchain > 1) {
-        double fl = 32.0 * (double)nslots;
+        double fl = 64.0 * (double)nslots;
         if (fl > (double)steps / 2.0) fl = (double)steps / 2.0;
         if (fl > burnin) burnin = fl;
     }

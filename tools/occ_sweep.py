@@ -26,7 +26,12 @@ def run(threads, wpb, flags=""):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 if __name__ == "__main__":
-    for flags in ("", "-DMCI_WAVES=4", "-DMCI_WAVES=5", "-DMCI_WAVES=6", "-DMCI_WAVES=8"):
-        print("threads=256 wpb=auto flags=%-16s %s" % (flags, run(256, 0, flags)), flush=True)
-    for threads, wpb in ((256, 64), (256, 256), (512, 64), (128, 256), (1024, 32)):
-        print("threads=%d wpb=%d %s" % (threads, wpb, run(threads, wpb)), flush=True)
+    which = sys.argv[1] if len(sys.argv) > 1 else "occ"
+    if which == "occ":
+        for flags in ("", "-DMCI_WAVES=4", "-DMCI_WAVES=5", "-DMCI_WAVES=6", "-DMCI_WAVES=8"):
+            print("threads=256 wpb=auto flags=%-16s %s" % (flags, run(256, 0, flags)), flush=True)
+        for threads, wpb in ((256, 64), (256, 256), (512, 64), (128, 256), (1024, 32)):
+            print("threads=%d wpb=%d %s" % (threads, wpb, run(threads, wpb)), flush=True)
+    else:
+        for flags in ("", "-DMCI_DRAW_FENCE=1", "-DMCI_DRAW_FENCE=2", "-DMCI_DRAW_FENCE=4", "-mllvm -amdgpu-schedule-metric-bias=0", "-mllvm -amdgpu-use-amdgpu-trackers=1"):
+            print("threads=256 flags=%-44s %s" % (flags, run(256, 0, flags)), flush=True)

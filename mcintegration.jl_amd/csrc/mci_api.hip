@@ -745,7 +745,8 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         // measured on C2 (MCI_WG_TARGET sweep): 16 workgroups per CU even out the tail once a launch is long
         // enough that the extra partial rows (merged by k_hist_stage1) do not matter
         static const int64_t forced = getenv("MCI_WG_TARGET") ? atoll(getenv("MCI_WG_TARGET")) : 0; // diagnostic override
-        const int64_t target = forced > 0 ? forced : (units * nblocks >= (int64_t)1 << 25 ? 4096 : 2048);
+        // (only while a workgroup's tables are cheap to stage: C3 with 66 KB per workgroup lost 15 % at 4096)
+        const int64_t target = forced > 0 ? forced : ((units * nblocks >= (int64_t)1 << 25 && p->lds_bytes <= 32 * 1024) ? 4096 : 2048);
         wpb = (int)((target + nblocks - 1) / nblocks);
         const int64_t maxw = (units + T - 1) / T;
         if (wpb > maxw) wpb = (int)maxw;

@@ -166,23 +166,14 @@ template <class Cfg> struct Tables {
 // 1/prob = raw * jac_scale(K): raw = dx for a Continuous leaf (scale N), 1/distribution for a Discrete one.
 // With Cfg::PAIR_TABLE the LDS table holds (g[i], g[i+1]-g[i]) pairs: ONE aligned ds_read_b128 per draw and
 // no subtraction on the critical path (the pair is formed with the same rounding when the table is staged).
-// U12 = true: `y` is the uniform PLUS ONE (in [1, 2), see u12()).  y*N is then formed as fma(y+1, N, -N): (y+1) - 1 is
-// exact, so both forms round the same real number once -- bit-identical to (u - 1.0) * N, one instruction less.
+// U12 = true: `y` is the uniform PLUS ONE (in [1, 2), see u12()).
 template <class Cfg, int K, bool U12 = false> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
     constexpr int leaf = Cfg::draw_leaf(K);
     if constexpr (Cfg::leaf_kind(leaf) != 0 && U12) y -= 1.0;
     if constexpr (Cfg::leaf_kind(leaf) == 0) {
         // sampler.jl:295-303:  iy = floor(y*N)+1; dy = y*N-(iy-1); x = g[iy] + dy*(g[iy+1]-g[iy]); prob = 1/(N*dx)
         constexpr int N = Cfg::leaf_nbin(leaf);
-        double yn;
-        if constexpr (U12) {
-            // one VOP3 fma with N in an SGPR pair used twice (src2 negated): the compiler's own choice for
-            // fma(y, N, -N) is v_fmac + two v_mov of the literal, which is no gain over add + mul
-            const double nn = (double)N;
-            asm("v_fma_f64 %0, %1, %2, -%2" : "=v"(yn) : "v"(y), "s"(nn));
-        } else {
-            yn = y * (double)N;
-        }
+        const double yn = (U12 ? y - 1.0 : y) * (double)N; // (a hand-placed v_fma_f64(y+1, N, -N) saved one instruction on C2 and cost C3 16 %)
         const int iy = (int)yn;                           // y*N >= 0: trunc == floor
         const double dy = __builtin_amdgcn_fract(yn);     // v_fract_f64 == yn - floor(yn), exact
 #ifdef MCI_ABL_NOTABLE

@@ -169,23 +169,14 @@ template <class Cfg> struct Tables {
 // 1/prob = raw * jac_scale(K): raw = dx for a Continuous leaf (scale N), 1/distribution for a Discrete one.
 // With Cfg::PAIR_TABLE the LDS table holds (g[i], g[i+1]-g[i]) pairs: ONE aligned ds_read_b128 per draw and
 // no subtraction on the critical path (the pair is formed with the same rounding when the table is staged).
-// U12 = true: `y` is the uniform PLUS ONE (in [1, 2), see u12()).  y*N is then formed as fma(y+1, N, -N): (y+1) - 1 is
-// exact, so both forms round the same real number once -- bit-identical to (u - 1.0) * N, one instruction less.
+// U12 = true: `y` is the uniform PLUS ONE (in [1, 2), see u12()).
 template <class Cfg, int K, bool U12 = false> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
     constexpr int leaf = Cfg::draw_leaf(K);
     if constexpr (Cfg::leaf_kind(leaf) != 0 && U12) y -= 1.0;
     if constexpr (Cfg::leaf_kind(leaf) == 0) {
         // sampler.jl:295-303:  iy = floor(y*N)+1; dy = y*N-(iy-1); x = g[iy] + dy*(g[iy+1]-g[iy]); prob = 1/(N*dx)
         constexpr int N = Cfg::leaf_nbin(leaf);
-        double yn;
-        if constexpr (U12) {
-            // one VOP3 fma with N in an SGPR pair used twice (src2 negated): the compiler's own choice for
-            // fma(y, N, -N) is v_fmac + two v_mov of the literal, which is no gain over add + mul
-            const double nn = (double)N;
-            asm("v_fma_f64 %0, %1, %2, -%2" : "=v"(yn) : "v"(y), "s"(nn));
-        } else {
-            yn = y * (double)N;
-        }
+        const double yn = (U12 ? y - 1.0 : y) * (double)N; // (a hand-placed v_fma_f64(y+1, N, -N) saved one instruction on C2 and cost C3 16 %)
         const int iy = (int)yn;                           // y*N >= 0: trunc == floor
         const double dy = __builtin_amdgcn_fract(yn);     // v_fract_f64 == yn - floor(yn), exact
 #ifdef MCI_ABL_NOTABLE
@@ -300,8 +291,7 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
                 }
             });
         } else {
-            for (int i = tid; i < Cfg::NEDGE; i += T) sE[i] = gE[)MCIDEV"
-R"MCIDEV(i];
+            for (int i = tid; i < Cfg::NEDGE; i += T) sE[i] = gE[i];
         }
     }
     for (int i = tid; i < Cfg::NDACC; i += T) sDA[i] = gDA[i];
@@ -312,7 +302,8 @@ R"MCIDEV(i];
 template <class Cfg> struct Lds {
     static constexpr int E = 0;
     static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
-    static constexpr int DD = DA + Cfg::NDACC;
+    static constexpr int DD = D)MCIDEV"
+R"MCIDEV(A + Cfg::NDACC;
     static constexpr int H = DD + Cfg::NDDIST;
     static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE : 0);
     static constexpr int R = O + Cfg::NOBS;
@@ -458,8 +449,7 @@ struct WorkItem {
 template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchArgs &a) {
     WorkItem w;
     w.tile = Cfg::NTILE == 1 ? 0 : (int)(blockIdx.x % Cfg::NTILE);
-    w.rowid = Cfg::NT)MCIDEV"
-R"MCIDEV(ILE == 1 ? (i64)blockIdx.x : (i64)(blockIdx.x / Cfg::NTILE);
+    w.rowid = Cfg::NTILE == 1 ? (i64)blockIdx.x : (i64)(blockIdx.x / Cfg::NTILE);
     w.lb = w.rowid / a.wg_per_block;
     w.slice = (int)(w.rowid % a.wg_per_block);
     return w;
@@ -468,7 +458,8 @@ R"MCIDEV(ILE == 1 ? (i64)blockIdx.x : (i64)(blockIdx.x / Cfg::NTILE);
 // =============================================================================================
 // VEGAS sample batch  (vegas/montecarlo.jl:117-187)
 // =============================================================================================
-// SPLIT (NTILE > 1): this pass owns histogram tile 0 only and parks (weights, bins of the other tiles' draws)
+// SPLIT (NTILE > 1): this pass owns histo)MCIDEV"
+R"MCIDEV(gram tile 0 only and parks (weights, bins of the other tiles' draws)
 // per sample for mci_vegas_tiles; one workgroup per (block, slice).
 template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -606,15 +597,15 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
 // vegas_mc/updates.jl:45-106).  The reference runs ONE chain of neval steps per block; a block here
 // is `nchain` chains of neval/nchain steps (nchain = 1 reproduces the reference's chain).  Chain state
 // (x, prob, bin per draw; weights; probability) stays in registers; the proposal touches one
-// (pool, slot), selected)MCIDEV"
-R"MCIDEV( by a compile-time switch so that every table access keeps static offsets.
+// (pool, slot), selected by a compile-time switch so that every table access keeps static offsets.
 //   chain g = block*nchain + ch
 //   init  : stream MC_INIT, index g,            k = flat draw
 //   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
 // =============================================================================================
 template <class Cfg> struct Chain {
     double x[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
-    double prob[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // leaf prob[idx]  (variable.jl:90)
+)MCIDEV"
+R"MCIDEV(    double prob[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // leaf prob[idx]  (variable.jl:90)
     int bin[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
 };
 
@@ -755,14 +746,14 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                             else {
                                 const u32x4 rr = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(kk >> 1), st_step, k0, k1);
                                 y = (kk & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
-              )MCIDEV"
-R"MCIDEV(              }
+                            }
                             double xo, po, xn, pn;
                             int bo, bn;
                             get_slot<Cfg, v, l>(c, slot, xo, po, bo);
                             draw_pool_leaf<Cfg, v, l>(t, y, xn, pn, bn); // shift!  sampler.jl:336-386, :57-71
                             put_slot<Cfg, v, l>(n, slot, xn, pn, bn);
-                            prop *= po / pn;                              // 1/prob_ratio  sampler.jl:385, :70
+                            prop *= po / pn;                              // 1/prob_ratio  sa)MCIDEV"
+R"MCIDEV(mpler.jl:385, :70
                         });
                     }
                 }
@@ -895,8 +886,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
-        for (int i = tid; i < Cfg)MCIDEV"
-R"MCIDEV(::HTILE; i += T) sH[i] = 0.0;
+        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
     __syncthreads();
     Tables<Cfg> t;
@@ -909,7 +899,8 @@ R"MCIDEV(::HTILE; i += T) sH[i] = 0.0;
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb;
     const i64 steps = a.neval_per_block / a.nchain, nburn = a.nburn;
-    const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP;
+    const u32 st_in)MCIDEV"
+R"MCIDEV(it = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[ND];
     static_for<0, ND>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -1031,14 +1022,14 @@ R"MCIDEV(::HTILE; i += T) sH[i] = 0.0;
                             static_for<0, NPOOL>([&](auto V) {
                                 constexpr int v = decltype(V)::value;
                                 if (vi == v) {
-                                    static_for<0, Cfg::pool_nlea)MCIDEV"
-R"MCIDEV(f(v)>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
+                                    static_for<0, Cfg::pool_nleaf(v)>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
                                         constexpr int l = decltype(Lf)::value;
                                         double xa, xb, pa, pb;
                                         int ba, bb;
                                         get_slot<Cfg, v, l>(c, s1, xa, pa, ba);
                                         get_slot<Cfg, v, l>(c, s2, xb, pb, bb);
-                                        put_slot<Cfg, v, l>(n, s1, xb, pb, bb);
+                             )MCIDEV"
+R"MCIDEV(           put_slot<Cfg, v, l>(n, s1, xb, pb, bb);
                                         put_slot<Cfg, v, l>(n, s2, xa, pa, ba);
                                     });
                                 }

@@ -75,9 +75,16 @@ def main():
     torch.cuda.set_device(local_rank)
     comm_kind = "none"
     comm = LocalComm()
-    if world > 1:
+    # MCI_BENCH_FORCE_COMM=1: run the N > 1 code path (process group, RCCL bootstrap, per-iteration all-reduce inside the
+    # timed loop) with a single rank -- the only way to exercise it on a 1-GPU box
+    force_comm = world == 1 and os.environ.get("MCI_BENCH_FORCE_COMM", "0") != "0"
+    if world > 1 or force_comm:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_comm:
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         comm_kind = os.environ.get("MCI_COMM", "rccl")
         if comm_kind == "rccl":
@@ -91,7 +98,7 @@ def main():
             comm = TorchDistComm(tensor_device="cuda:%d" % local_rank)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_comm:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -121,7 +128,7 @@ def main():
         eng.finish("vegas", block, adapt=True, want_stats=False)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_comm:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -192,7 +199,7 @@ def main():
         if not a.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_comm:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

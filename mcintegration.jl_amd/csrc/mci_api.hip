@@ -728,7 +728,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // on the bubble diagram 1e3-step chains are 2.7 % (55 sigma) off at 2e9 steps and need ~1e5 burn-in steps each
             // to lose that bias (tools/bubble_mcmc_bias.py); only chains much longer than the mixing time are safe, which
             // is what the reference's one-chain-per-block gives.  More chains: raise `block` (the reference's own knob) or
-            // pass nchain explicitly for integrands known to mix fast (C5: 6 Gsteps/s at nchain = 4096).
+            // pass nchain explicitly for integrands known to mix fast (C5: 10 Gsteps/s at nchain = 4096).
             nchain = nevalperblock / mci_problem::kMcmcMinSteps;
             const int64_t cap = mci_problem::kChainFill / nblocks > 64 ? mci_problem::kChainFill / nblocks : 64;
             if (nchain > cap) nchain = cap;

@@ -76,7 +76,7 @@ __device__ __forceinline__ double u12(u32 lo, u32 hi) {
 }
 __device__ __forceinline__ double u01(u32 lo, u32 hi) { return u12(lo, hi) - 1.0; }
 
-enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5 };
+enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6 };
 enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_RESCALE_NONFINITE = 8, ST_MCMC_INIT = 16 };
 
 // ---------------------------------------------------------------------------------------------
@@ -944,8 +944,19 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
             const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
             const u32x4 r2 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 2u, st_step, k0, k1);
-            int upd = (int)(u01(r0.x, r0.y) * (double)NUPD); // :137 rand(rng, updates)
+            // :137 rand(rng, updates).  With many chains per block the 64 chains of a wave (chains ch & ~63 .. | 63 of ONE
+            // block) share the update-type sequence: it is independent of the chain states, so every chain is still a
+            // valid Markov chain, blocks stay independent, and the wave no longer walks through all three update bodies
+            // at every step.  nchain = 1 (the reference's chain) draws its own.
+            double uupd = u01(r0.x, r0.y);
+            if (a.nchain > 1) {
+                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)63)) << 32) | (u64)(it - 1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MCMC_GROUP, k0, k1);
+                uupd = u01(rg.x, rg.y);
+            }
+            int upd = (int)(uupd * (double)NUPD);
             if (upd >= NUPD) upd = NUPD - 1;
+            if (a.nchain > 1) upd = __builtin_amdgcn_readfirstlane(upd); // wave-uniform by construction: a scalar branch
             const double upick = u01(r0.z, r0.w), us1 = u01(r1.x, r1.y), us2 = u01(r1.z, r1.w), uacc = u01(r2.x, r2.y);
             // ---- build the proposal (n, prop, newcurr); ONE evaluate-and-accept tail serves all three updates, so
             // lanes that diverged on the update type reconverge before the expensive part ----

@@ -78,7 +78,7 @@ __device__ __forceinline__ double u12(u32 lo, u32 hi) {
 }
 __device__ __forceinline__ double u01(u32 lo, u32 hi) { return u12(lo, hi) - 1.0; }
 
-enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5 };
+enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6 };
 enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_RESCALE_NONFINITE = 8, ST_MCMC_INIT = 16 };
 
 // ---------------------------------------------------------------------------------------------
@@ -147,9 +147,9 @@ __device__ __forceinline__ void global_add(double *p, double v) {
 
 // ---------------------------------------------------------------------------------------------
 // table placement.  TABLE_MODE 0: grids + histograms in LDS; 1: grids in LDS, histograms via
-// global f64 atomics; 2: everything from L2/HBM (grids too large for 160 KiB).
-// -------)MCIDEV"
-R"MCIDEV(--------------------------------------------------------------------------------------
+// global f64 atomics; 2: everything from L2/HBM (grids too large f)MCIDEV"
+R"MCIDEV(or 160 KiB).
+// ---------------------------------------------------------------------------------------------
 //   TABLE_MODE 3: histograms in LDS, grids gathered from L2 (more than ~9 independent grids: the
 //   ds_add_f64 is the part that must not go to global memory); when all histograms do not fit either they
 //   are split into NTILE tiles and each (block, slice) is run by NTILE workgroups, workgroup `tile`
@@ -302,8 +302,8 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
 template <class Cfg> struct Lds {
     static constexpr int E = 0;
     static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
-    static constexpr int DD = D)MCIDEV"
-R"MCIDEV(A + Cfg::NDACC;
+    stat)MCIDEV"
+R"MCIDEV(ic constexpr int DD = DA + Cfg::NDACC;
     static constexpr int H = DD + Cfg::NDDIST;
     static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE : 0);
     static constexpr int R = O + Cfg::NOBS;
@@ -458,8 +458,8 @@ template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchAr
 // =============================================================================================
 // VEGAS sample batch  (vegas/montecarlo.jl:117-187)
 // =============================================================================================
-// SPLIT (NTILE > 1): this pass owns histo)MCIDEV"
-R"MCIDEV(gram tile 0 only and parks (weights, bins of the other tiles' draws)
+// SPLIT (NTILE > 1)MCIDEV"
+R"MCIDEV(): this pass owns histogram tile 0 only and parks (weights, bins of the other tiles' draws)
 // per sample for mci_vegas_tiles; one workgroup per (block, slice).
 template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -603,9 +603,9 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
 //   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
 // =============================================================================================
 template <class Cfg> struct Chain {
-    double x[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
-)MCIDEV"
-R"MCIDEV(    double prob[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // leaf prob[idx]  (variable.jl:90)
+    double x[Cfg::NDRAW )MCIDEV"
+R"MCIDEV(> 0 ? Cfg::NDRAW : 1];
+    double prob[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // leaf prob[idx]  (variable.jl:90)
     int bin[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
 };
 
@@ -752,8 +752,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                             get_slot<Cfg, v, l>(c, slot, xo, po, bo);
                             draw_pool_leaf<Cfg, v, l>(t, y, xn, pn, bn); // shift!  sampler.jl:336-386, :57-71
                             put_slot<Cfg, v, l>(n, slot, xn, pn, bn);
-                            prop *= po / pn;                              // 1/prob_ratio  sa)MCIDEV"
-R"MCIDEV(mpler.jl:385, :70
+                            prop *= po / pn;                          )MCIDEV"
+R"MCIDEV(    // 1/prob_ratio  sampler.jl:385, :70
                         });
                     }
                 }
@@ -898,9 +898,9 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     const WorkItem wi = work_item<Cfg>(a);
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb;
-    const i64 steps = a.neval_per_block / a.nchain, nburn = a.nburn;
-    const u32 st_in)MCIDEV"
-R"MCIDEV(it = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP;
+    const i64 steps = a.neval_per_block / a.nchain, nburn = a.nbu)MCIDEV"
+R"MCIDEV(rn;
+    const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[ND];
     static_for<0, ND>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -952,8 +952,19 @@ R"MCIDEV(it = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a)
             const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
             const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
             const u32x4 r2 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 2u, st_step, k0, k1);
-            int upd = (int)(u01(r0.x, r0.y) * (double)NUPD); // :137 rand(rng, updates)
+            // :137 rand(rng, updates).  With many chains per block the 64 chains of a wave (chains ch & ~63 .. | 63 of ONE
+            // block) share the update-type sequence: it is independent of the chain states, so every chain is still a
+            // valid Markov chain, blocks stay independent, and the wave no longer walks through all three update bodies
+            // at every step.  nchain = 1 (the reference's chain) draws its own.
+            double uupd = u01(r0.x, r0.y);
+            if (a.nchain > 1) {
+                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)63)) << 32) | (u64)(it - 1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MCMC_GROUP, k0, k1);
+                uupd = u01(rg.x, rg.y);
+            }
+            int upd = (int)(uupd * (double)NUPD);
             if (upd >= NUPD) upd = NUPD - 1;
+            if (a.nchain > 1) upd = __builtin_amdgcn_readfirstlane(upd); // wave-uniform by construction: a scalar branch
             const double upick = u01(r0.z, r0.w), us1 = u01(r1.x, r1.y), us2 = u01(r1.z, r1.w), uacc = u01(r2.x, r2.y);
             // ---- build the proposal (n, prop, newcurr); ONE evaluate-and-accept tail serves all three updates, so
             // lanes that diverged on the update type reconverge before the expensive part ----
@@ -1014,7 +1025,8 @@ R"MCIDEV(it = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a)
                     // ---- swapVariable  updates.jl:113-147 ----
                     ut = 2;
                     if (cdv > 0) { // :121
-                        int s1 = (int)(us1 * (double)cdv), s2 = (int)(us2 * (double)cdv); // :122-123
+                        int s1 = (int)(us1 * (double)cdv), s2 = (int)(us2 * (double)c)MCIDEV"
+R"MCIDEV(dv); // :122-123
                         if (s1 >= cdv) s1 = cdv - 1;
                         if (s2 >= cdv) s2 = cdv - 1;
                         if (s1 != s2) { // :124
@@ -1028,8 +1040,7 @@ R"MCIDEV(it = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a)
                                         int ba, bb;
                                         get_slot<Cfg, v, l>(c, s1, xa, pa, ba);
                                         get_slot<Cfg, v, l>(c, s2, xb, pb, bb);
-                             )MCIDEV"
-R"MCIDEV(           put_slot<Cfg, v, l>(n, s1, xb, pb, bb);
+                                        put_slot<Cfg, v, l>(n, s1, xb, pb, bb);
                                         put_slot<Cfg, v, l>(n, s2, xa, pa, ba);
                                     });
                                 }
@@ -1143,7 +1154,8 @@ template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs 
         double w[Cfg::NW];
         if constexpr (Cfg::HOST_INTEGRAND != 0) static_for<0, Cfg::NW>([&](auto I) { w[decltype(I)::value] = 0.0; });
         else Cfg::integrand(s.x, w, a.ud, -1);
-        static_for<0, Cfg::NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[n * Cfg::NDRAW + k] = s.x[k]; });
+        static_for<0, Cfg::)MCIDEV"
+R"MCIDEV(NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[n * Cfg::NDRAW + k] = s.x[k]; });
         a.jac[n] = s.jac;
         static_for<0, Cfg::NW>([&](auto I) { constexpr int i = decltype(I)::value; a.w[n * Cfg::NW + i] = w[i]; });
     }

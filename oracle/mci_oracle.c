@@ -59,7 +59,7 @@ double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k) 
     return d - 1.0; /* 52 random mantissa bits, like Julia's MersenneTwister rand(Float64) */
 }
 
-enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5 };
+enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6 };
 static inline uint32_t stream_id(uint32_t iteration, int purpose) { return iteration * 8u + (uint32_t)purpose; }
 
 /* ------------------------------------------------------------------------------------------
@@ -995,7 +995,15 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
         for (long i = 1; i <= steps + nburn; ++i) {                 /* :134 */
             const uint64_t sidx = (g << 32) | (uint64_t)(i - 1);
             c->visited[curr] += 1.0;                                /* :136 */
-            int upd = (int)floor(mcio_uniform(seed, st_step, sidx, 0) * nupd); /* :137 rand(rng, updates) */
+            /* :137 rand(rng, updates); with many chains per block, chains (ch & ~63) .. (ch | 63) of a block share the
+               update-type sequence (stream MCMC_GROUP): it does not depend on the chain states, so each chain is still a
+               valid Markov chain and blocks stay independent */
+            double uupd = mcio_uniform(seed, st_step, sidx, 0);
+            if (nchain > 1) {
+                const uint64_t gidx = (((uint64_t)block_index * (uint64_t)nchain + (uint64_t)(ch & ~63L)) << 32) | (uint64_t)(i - 1);
+                uupd = mcio_uniform(seed, stream_id(iteration, STREAM_MCMC_GROUP), gidx, 0);
+            }
+            int upd = (int)floor(uupd * nupd);
             if (upd >= nupd) upd = nupd - 1;
             if (upd == 0) {
                 /* ---- changeIntegrand  updates.jl:1-69 ---- */

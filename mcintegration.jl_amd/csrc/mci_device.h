@@ -76,7 +76,7 @@ __device__ __forceinline__ double u12(u32 lo, u32 hi) {
 }
 __device__ __forceinline__ double u01(u32 lo, u32 hi) { return u12(lo, hi) - 1.0; }
 
-enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6 };
+enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6, STREAM_MC_GROUP = 7 };
 enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_RESCALE_NONFINITE = 8, ST_MCMC_INIT = 16 };
 
 // ---------------------------------------------------------------------------------------------
@@ -714,8 +714,17 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
             const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
             const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
             // ---- changeVariable  updates.jl:45-106 ----
-            int vi = (int)(u01(r0.x, r0.y) * (double)Cfg::NPOOL); // :50
+            // :50 rand(1:Nv).  With many chains per block the 64 chains of a wave share the pool-pick sequence (it does
+            // not depend on the chain states): the pool dispatch below becomes a scalar branch
+            double upool = u01(r0.x, r0.y);
+            if (Cfg::NPOOL > 1 && a.nchain > 1) {
+                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)63)) << 32) | (u64)(ne - 1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MC_GROUP, k0, k1);
+                upool = u01(rg.x, rg.y);
+            }
+            int vi = (int)(upool * (double)Cfg::NPOOL);
             if (vi >= Cfg::NPOOL) vi = Cfg::NPOOL - 1;
+            if (Cfg::NPOOL > 1 && a.nchain > 1) vi = __builtin_amdgcn_readfirstlane(vi);
             const double uslot = u01(r0.z, r0.w);
             const double uacc = u01(r1.x, r1.y);
             Chain<Cfg> n = c; // proposal; unchanged draws are copy-propagated

@@ -78,7 +78,7 @@ __device__ __forceinline__ double u12(u32 lo, u32 hi) {
 }
 __device__ __forceinline__ double u01(u32 lo, u32 hi) { return u12(lo, hi) - 1.0; }
 
-enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6 };
+enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6, STREAM_MC_GROUP = 7 };
 enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_RESCALE_NONFINITE = 8, ST_MCMC_INIT = 16 };
 
 // ---------------------------------------------------------------------------------------------
@@ -147,8 +147,8 @@ __device__ __forceinline__ void global_add(double *p, double v) {
 
 // ---------------------------------------------------------------------------------------------
 // table placement.  TABLE_MODE 0: grids + histograms in LDS; 1: grids in LDS, histograms via
-// global f64 atomics; 2: everything from L2/HBM (grids too large f)MCIDEV"
-R"MCIDEV(or 160 KiB).
+// global f64 atomics; 2: everything from L2/H)MCIDEV"
+R"MCIDEV(BM (grids too large for 160 KiB).
 // ---------------------------------------------------------------------------------------------
 //   TABLE_MODE 3: histograms in LDS, grids gathered from L2 (more than ~9 independent grids: the
 //   ds_add_f64 is the part that must not go to global memory); when all histograms do not fit either they
@@ -301,9 +301,9 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
 // LDS carve (doubles).  Order: grid table | dacc | ddist | hist | obs | reduction scratch
 template <class Cfg> struct Lds {
     static constexpr int E = 0;
-    static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
-    stat)MCIDEV"
-R"MCIDEV(ic constexpr int DD = DA + Cfg::NDACC;
+    static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::)MCIDEV"
+R"MCIDEV(NEDGE) : 0);
+    static constexpr int DD = DA + Cfg::NDACC;
     static constexpr int H = DD + Cfg::NDDIST;
     static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE : 0);
     static constexpr int R = O + Cfg::NOBS;
@@ -457,9 +457,9 @@ template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchAr
 
 // =============================================================================================
 // VEGAS sample batch  (vegas/montecarlo.jl:117-187)
-// =============================================================================================
-// SPLIT (NTILE > 1)MCIDEV"
-R"MCIDEV(): this pass owns histogram tile 0 only and parks (weights, bins of the other tiles' draws)
+// ============================================================================================)MCIDEV"
+R"MCIDEV(=
+// SPLIT (NTILE > 1): this pass owns histogram tile 0 only and parks (weights, bins of the other tiles' draws)
 // per sample for mci_vegas_tiles; one workgroup per (block, slice).
 template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -603,8 +603,8 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
 //   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
 // =============================================================================================
 template <class Cfg> struct Chain {
-    double x[Cfg::NDRAW )MCIDEV"
-R"MCIDEV(> 0 ? Cfg::NDRAW : 1];
+   )MCIDEV"
+R"MCIDEV( double x[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
     double prob[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // leaf prob[idx]  (variable.jl:90)
     int bin[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
 };
@@ -720,8 +720,17 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
             const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
             const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
             // ---- changeVariable  updates.jl:45-106 ----
-            int vi = (int)(u01(r0.x, r0.y) * (double)Cfg::NPOOL); // :50
+            // :50 rand(1:Nv).  With many chains per block the 64 chains of a wave share the pool-pick sequence (it does
+            // not depend on the chain states): the pool dispatch below becomes a scalar branch
+            double upool = u01(r0.x, r0.y);
+            if (Cfg::NPOOL > 1 && a.nchain > 1) {
+                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)63)) << 32) | (u64)(ne - 1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MC_GROUP, k0, k1);
+                upool = u01(rg.x, rg.y);
+            }
+            int vi = (int)(upool * (double)Cfg::NPOOL);
             if (vi >= Cfg::NPOOL) vi = Cfg::NPOOL - 1;
+            if (Cfg::NPOOL > 1 && a.nchain > 1) vi = __builtin_amdgcn_readfirstlane(vi);
             const double uslot = u01(r0.z, r0.w);
             const double uacc = u01(r1.x, r1.y);
             Chain<Cfg> n = c; // proposal; unchanged draws are copy-propagated
@@ -743,7 +752,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                             constexpr int kk = 3 + l; // RNG draw index within the step
                             double y;
                             if constexpr (kk == 3) y = u01(r1.z, r1.w);
-                            else {
+ )MCIDEV"
+R"MCIDEV(                           else {
                                 const u32x4 rr = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(kk >> 1), st_step, k0, k1);
                                 y = (kk & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
                             }
@@ -752,8 +762,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                             get_slot<Cfg, v, l>(c, slot, xo, po, bo);
                             draw_pool_leaf<Cfg, v, l>(t, y, xn, pn, bn); // shift!  sampler.jl:336-386, :57-71
                             put_slot<Cfg, v, l>(n, slot, xn, pn, bn);
-                            prop *= po / pn;                          )MCIDEV"
-R"MCIDEV(    // 1/prob_ratio  sampler.jl:385, :70
+                            prop *= po / pn;                              // 1/prob_ratio  sampler.jl:385, :70
                         });
                     }
                 }
@@ -882,7 +891,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     constexpr int NI = Cfg::NI, NORMI = Cfg::NI, ND = Cfg::NI + 1, NPOOL = Cfg::NPOOL;
     constexpr int NUPD = 2 * NPOOL + 2; // [changeIntegrand, swapVariable, changeVariable x 2*Nv]  montecarlo.jl:127-130
     const int tid = threadIdx.x, T = blockDim.x;
-    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
+    double *sE = smem + Lds<Cfg>::)MCIDEV"
+R"MCIDEV(E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
     double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
@@ -898,8 +908,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     const WorkItem wi = work_item<Cfg>(a);
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb;
-    const i64 steps = a.neval_per_block / a.nchain, nburn = a.nbu)MCIDEV"
-R"MCIDEV(rn;
+    const i64 steps = a.neval_per_block / a.nchain, nburn = a.nburn;
     const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[ND];
@@ -1013,7 +1022,8 @@ R"MCIDEV(rn;
                     }
                 });
             } else if (curr != NORMI) { // updates.jl:73, :115
-                int vi = (int)(upick * (double)NPOOL); // :77, :119
+                int vi = ()MCIDEV"
+R"MCIDEV(int)(upick * (double)NPOOL); // :77, :119
                 if (vi >= NPOOL) vi = NPOOL - 1;
                 int cdv = 0; // currdof[vi]
                 static_for<0, NI>([&](auto I) {
@@ -1025,8 +1035,7 @@ R"MCIDEV(rn;
                     // ---- swapVariable  updates.jl:113-147 ----
                     ut = 2;
                     if (cdv > 0) { // :121
-                        int s1 = (int)(us1 * (double)cdv), s2 = (int)(us2 * (double)c)MCIDEV"
-R"MCIDEV(dv); // :122-123
+                        int s1 = (int)(us1 * (double)cdv), s2 = (int)(us2 * (double)cdv); // :122-123
                         if (s1 >= cdv) s1 = cdv - 1;
                         if (s2 >= cdv) s2 = cdv - 1;
                         if (s1 != s2) { // :124
@@ -1141,7 +1150,8 @@ template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs 
     Tables<Cfg> t;
     if constexpr (Cfg::TABLE_MODE <= 1) t.E = sE;
     else t.E = a.edges;
-    t.DA = sDA;
+    )MCIDEV"
+R"MCIDEV(t.DA = sDA;
     t.DD = sDD;
     const u32 stream = a.iteration * 8u + STREAM_VEGAS;
     for (i64 n = (i64)blockIdx.x * blockDim.x + threadIdx.x; n < a.n; n += (i64)gridDim.x * blockDim.x) {
@@ -1154,8 +1164,7 @@ template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs 
         double w[Cfg::NW];
         if constexpr (Cfg::HOST_INTEGRAND != 0) static_for<0, Cfg::NW>([&](auto I) { w[decltype(I)::value] = 0.0; });
         else Cfg::integrand(s.x, w, a.ud, -1);
-        static_for<0, Cfg::)MCIDEV"
-R"MCIDEV(NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[n * Cfg::NDRAW + k] = s.x[k]; });
+        static_for<0, Cfg::NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[n * Cfg::NDRAW + k] = s.x[k]; });
         a.jac[n] = s.jac;
         static_for<0, Cfg::NW>([&](auto I) { constexpr int i = decltype(I)::value; a.w[n * Cfg::NW + i] = w[i]; });
     }

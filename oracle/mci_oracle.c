@@ -59,7 +59,7 @@ double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k) 
     return d - 1.0; /* 52 random mantissa bits, like Julia's MersenneTwister rand(Float64) */
 }
 
-enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6 };
+enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6, STREAM_MC_GROUP = 7 };
 static inline uint32_t stream_id(uint32_t iteration, int purpose) { return iteration * 8u + (uint32_t)purpose; }
 
 /* ------------------------------------------------------------------------------------------
@@ -830,7 +830,14 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
             const uint64_t sidx = (g << 32) | (uint64_t)(ne - 1);
             /* ---- changeVariable  ref: updates.jl:45-106 ---- */
             do {
-                int vi = (int)floor(mcio_uniform(seed, st_step, sidx, 0) * npool); /* :50 */
+                /* :50; with many chains per block, chains (ch & ~63) .. (ch | 63) of a block share the pool-pick
+                   sequence (stream MC_GROUP), which does not depend on the chain states */
+                double upool = mcio_uniform(seed, st_step, sidx, 0);
+                if (npool > 1 && nchain > 1) {
+                    const uint64_t gidx = (((uint64_t)block_index * (uint64_t)nchain + (uint64_t)(ch & ~63L)) << 32) | (uint64_t)(ne - 1);
+                    upool = mcio_uniform(seed, stream_id(iteration, STREAM_MC_GROUP), gidx, 0);
+                }
+                int vi = (int)floor(upool * npool);
                 if (vi >= npool) vi = npool - 1;
                 const mcio_leaf *v0 = &c->leaf[c->pool_leaf0[vi]];
                 if (c->pool_nleaf[vi] == 1 && v0->kind == MCIO_DISCRETE && v0->nbin == 1) break; /* :52-54 */

@@ -32,7 +32,7 @@ extern "C" {
 #define MCI_ERR_COMM 6          /* RCCL failure */
 #define MCI_ERR_NO_DEVICE 7     /* no HIP device: the product path never falls back to the CPU */
 
-enum { MCI_CONTINUOUS = 0, MCI_DISCRETE = 1 }; /* Dist.Continuous variable.jl:87-99 / Dist.Discrete :272-284 */
+enum { MCI_CONTINUOUS = 0, MCI_DISCRETE = 1, MCI_FERMIK = 2 }; /* Dist.Continuous variable.jl:87-99 / Dist.Discrete :272-284 / Dist.FermiK :1-20 */
 enum { MCI_VEGAS = 0, MCI_VEGASMC = 1, MCI_MCMC = 2 }; /* solver=:vegas main.jl:256 / :vegasmc :253 / :mcmc :259 */
 
 typedef struct mci_ctx mci_ctx;
@@ -49,6 +49,9 @@ typedef struct {
     double alpha;       /* learning rate (default 2.0) */
     int32_t adapt;
     const double *init; /* optional: continuous grid[npoints] | discrete distribution[upper-lower+1]; NULL = default */
+    /* MCI_FERMIK = `FermiK(dim, kF, dk, maxK)` (variable.jl:11-19; sampler.jl:109-281): lower = kF, upper = dk,
+       npoints = dim (2 | 3), alpha = maxK.  A slot holds `dim` consecutive x entries; no adaptive map; solver = :mcmc only
+       (the reference's own restriction, test/bubble_FermiK.jl:2). */
 } mci_leaf_desc;
 
 /* `Configuration(; var, dof, obs, ...)` (configuration.jl:105-194). */

@@ -8,7 +8,7 @@ _SO = os.path.join(_PKG, "lib", "libmci_hip.so")
 
 MCI_OK = 0
 ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "COMPILE", 4: "NORMALIZATION", 5: "HISTOGRAM", 6: "COMM", 7: "NO_DEVICE"}
-CONTINUOUS, DISCRETE = 0, 1
+CONTINUOUS, DISCRETE, FERMIK = 0, 1, 2
 VEGAS, VEGASMC, MCMC = 0, 1, 2
 SOLVERS = {"vegas": VEGAS, "vegasmc": VEGASMC, "mcmc": MCMC, VEGAS: VEGAS, VEGASMC: VEGASMC, MCMC: MCMC}
 

@@ -123,6 +123,29 @@ def bubble(**kw):
     return Integrand(body, ud, "bubble")
 
 
+def bubble_fermik(**kw):
+    """test/bubble_FermiK.jl:52-77: the same polarisation with the momentum as a FermiK variable:
+    vars = (T, K, Ext) -> x = [tau, k_x, k_y, k_z, ext]"""
+    p = bubble_parameters(**kw)
+    body = """
+    const double kF = ud[0], beta = ud[1], me = ud[2], spin = ud[3];
+    const double tau = x[0];
+    const double k0 = x[1], k1 = x[2], k2 = x[3];
+    const int ext = (int)x[4] - 1;
+    const double q = ud[6 + ext];
+    const double w1 = (k0 * k0 + k1 * k1 + k2 * k2 - kF * kF) / (2.0 * me);
+    const double kq0 = k0 + q;
+    const double w2 = (kq0 * kq0 + k1 * k1 + k2 * k2 - kF * kF) / (2.0 * me);
+    double g1, g2;
+    if (tau >= 0.0) g1 = w1 > 0.0 ? exp(-w1 * tau) / (1 + exp(-w1 * beta)) : exp(w1 * (beta - tau)) / (1 + exp(w1 * beta));
+    else g1 = w1 > 0.0 ? -exp(-w1 * (tau + beta)) / (1 + exp(-w1 * beta)) : -exp(-w1 * tau) / (1 + exp(w1 * beta));
+    if (-tau >= 0.0) g2 = w2 > 0.0 ? exp(w2 * tau) / (1 + exp(-w2 * beta)) : exp(w2 * (beta + tau)) / (1 + exp(w2 * beta));
+    else g2 = w2 > 0.0 ? -exp(-w2 * (-tau + beta)) / (1 + exp(-w2 * beta)) : -exp(w2 * tau) / (1 + exp(w2 * beta));
+    w[0] = g1 * g2 * spin / (8.0 * M_PI * M_PI * M_PI);"""
+    ud = [p["kF"], p["beta"], p["me"], float(p["spin"]), float(p["dim"]), float(p["Qsize"])] + list(p["extQ"])
+    return Integrand(body, ud, "bubble_fermik")
+
+
 def nested_gauss(dofs=(3, 6, 9, 12)):
     """BASELINE C5 family: integrand i = prod_{d<dof_i} sqrt(100/pi) exp(-100 (x_d-1/2)^2)"""
     lines = ["double p = 1.0;"]

@@ -2,7 +2,7 @@
 import numpy as np
 
 from .integrand import Measure, bin_by
-from .variables import CompositeVar, ContinuousVar, DiscreteVar
+from .variables import CompositeVar, ContinuousVar, DiscreteVar, FermiK
 
 
 def _normalize_dof(dof, nvar):
@@ -30,10 +30,10 @@ class Configuration:
         from .variables import Continuous
         if var is None:
             var = (Continuous(0.0, 1.0),)                                  # :106
-        if isinstance(var, (ContinuousVar, DiscreteVar, CompositeVar)):    # :116-117
+        if isinstance(var, (ContinuousVar, DiscreteVar, CompositeVar, FermiK)):    # :116-117
             var = (var,)
         var = tuple(var)                                                   # :120-122
-        assert all(isinstance(v, (ContinuousVar, DiscreteVar, CompositeVar)) for v in var), \
+        assert all(isinstance(v, (ContinuousVar, DiscreteVar, CompositeVar, FermiK)) for v in var), \
             "All elements in var should be derived from the abstract type Variable"   # :119
         self.var = var
         nv = len(var)
@@ -131,16 +131,21 @@ class Configuration:
         """flat position of (pool, slot, leaf) in the integrand's x[] (draw order: pool, slot, leaf)"""
         k = 0
         for vi, v in enumerate(self.var):
-            nl = len(v.vars) if isinstance(v, CompositeVar) else 1
+            nl = self.pool_width(vi)
             if vi == pool:
                 assert slot < self.maxdof[vi] and leaf < nl
                 return k + slot * nl + leaf
             k += self.maxdof[vi] * nl
         raise IndexError(pool)
 
+    def pool_width(self, vi):
+        """x entries per slot of pool vi: the number of leaves of a CompositeVar, the dimension of a FermiK, else 1"""
+        v = self.var[vi]
+        return len(v.vars) if isinstance(v, CompositeVar) else v.dim if isinstance(v, FermiK) else 1
+
     @property
     def ndraw(self):
-        return sum(self.maxdof[vi] * (len(v.vars) if isinstance(v, CompositeVar) else 1) for vi, v in enumerate(self.var))
+        return sum(self.maxdof[vi] * self.pool_width(vi) for vi in range(len(self.var)))
 
     def obs_bin_draw(self, measure):
         if measure is None:

@@ -100,6 +100,7 @@ namespace {
 struct Leaf {
     int kind, pool, npts, nbin, adapt, eoff, doff, boff;
     double lower, upper, alpha;
+    int width = 1; // x entries per slot: D for a FermiK leaf
 };
 } // namespace
 
@@ -140,6 +141,7 @@ struct mci_problem {
     // the refinement (k_finish); anything else that looks at `packed` first flushes it (k_finalize)
     mci::MergeArgs merge{};
     bool merge_pending = false;
+    bool has_fermik = false; // FermiK variables: solver = :mcmc only
     // host integrand ("batch callback"): draws dumped SoA -> callback -> weights uploaded -> accumulate kernel
     mci_host_integrand_fn host_fn = nullptr;
     void *host_user = nullptr;
@@ -380,6 +382,16 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             }
             aoff += K + 1;
             doff += K;
+        } else if (ld.kind == MCI_FERMIK) { // FermiK(dim, kF, dk, maxK)  variable.jl:11-19: lower = kF, upper = dk, npoints = dim
+            if (ld.npoints != 2 && ld.npoints != 3) { delete p; return fail(MCI_ERR_INVALID, "leaf %d: FermiK has 2 or 3 dimensions", l); }
+            if (!(ld.lower > 0.0) || !(ld.upper > 0.0)) { delete p; return fail(MCI_ERR_INVALID, "leaf %d: FermiK needs kF > 0 and dk > 0", l); }
+            L.npts = ld.npoints;
+            L.width = ld.npoints;
+            L.nbin = 1;   // histogram = [0.0]  variable.jl:19
+            L.adapt = 0;  // train!(Var) = nothing  variable.jl:557
+            L.eoff = 0;
+            L.doff = 0;
+            p->has_fermik = true;
         } else {
             delete p;
             return fail(MCI_ERR_INVALID, "leaf %d: unknown kind %d", l, ld.kind);
@@ -388,8 +400,12 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         boff += L.nbin;
         p->leaves.push_back(L);
     }
-    for (int v = 0; v < p->npool; ++v)
+    for (int v = 0; v < p->npool; ++v) {
         if (p->pool_nleaf[v] == 0) { delete p; return fail(MCI_ERR_INVALID, "pool %d has no variable", v); }
+        if (p->pool_nleaf[v] > 1)
+            for (int l = 0; l < p->pool_nleaf[v]; ++l)
+                if (p->leaves[p->pool_leaf0[v] + l].kind == MCI_FERMIK) { delete p; return fail(MCI_ERR_INVALID, "pool %d: FermiK cannot be part of a CompositeVar", v); }
+    }
     // flat draw order: pool, slot, leaf  (vegas/montecarlo.jl:122-131, sampler.jl:431-440)
     s.nleaf = d->nleaf;
     s.ni = p->ni;
@@ -397,13 +413,16 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
     for (int v = 0; v < p->npool; ++v) {
         s.pool_first_draw.push_back((int)s.draw_leaf.size());
         s.pool_maxdof.push_back(p->maxdof[v]);
-        s.pool_nleaf.push_back(p->pool_nleaf[v]);
+        int width = 0; // x entries per slot: one per leaf, D for a FermiK pool
+        for (int l = 0; l < p->pool_nleaf[v]; ++l) width += p->leaves[p->pool_leaf0[v] + l].width;
+        s.pool_nleaf.push_back(width);
         for (int idx = 0; idx < p->maxdof[v]; ++idx)
-            for (int l = 0; l < p->pool_nleaf[v]; ++l) {
-                s.draw_leaf.push_back(p->pool_leaf0[v] + l);
-                s.draw_pool.push_back(v);
-                s.draw_slot.push_back(idx);
-            }
+            for (int l = 0; l < p->pool_nleaf[v]; ++l)
+                for (int j = 0; j < p->leaves[p->pool_leaf0[v] + l].width; ++j) {
+                    s.draw_leaf.push_back(p->pool_leaf0[v] + l);
+                    s.draw_pool.push_back(v);
+                    s.draw_slot.push_back(idx);
+                }
     }
     s.ndraw = (int)s.draw_leaf.size();
     if (s.ndraw < 1 || s.ndraw > 64) { delete p; return fail(MCI_ERR_INVALID, "1..64 draws per sample supported, got %d", s.ndraw); }
@@ -470,6 +489,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         s.leaf_boff.push_back(L.boff);
         s.leaf_adapt.push_back(L.adapt);
         s.leaf_lower.push_back(L.lower);
+        s.leaf_upper.push_back(L.upper);
     }
     // table placement (DESIGN.md "data layout"): keep >= 2 workgroups per CU when everything is in LDS.
     // PAIR_TABLE stores (g[i], g[i+1]-g[i]) per bin (16 B, one ds_read_b128 per draw) when that still fits.
@@ -695,6 +715,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     if (measurefreq <= 0) return fail(MCI_ERR_INVALID, "measurefreq must be positive"); // vegas/montecarlo.jl:77
     const int64_t nblocks = block_hi - block_lo;
     if (nblocks < 1 || nevalperblock < 1) return fail(MCI_ERR_INVALID, "empty iteration");
+    if (p->has_fermik && solver != MCI_MCMC) return fail(MCI_ERR_INVALID, "FermiK variables work with solver=:mcmc only"); // test/bubble_FermiK.jl:2,:133
     int rc = compile_solver(p, solver);
     if (rc) return rc;
     if ((rc = flush_merge(p))) return rc; // a previous batch nobody looked at: merge it (resets the global histogram)
@@ -1235,13 +1256,14 @@ int mci_save_state(mci_problem *p, const char *path) {
     if (!f) return fail(MCI_ERR_INVALID, "cannot open %s for writing", path);
     const uint32_t hdr[3] = {1u, (uint32_t)p->leaves.size(), (uint32_t)p->ni};
     bool ok = fwrite("MCISTATE", 1, 8, f) == 8 && fwrite(hdr, sizeof(uint32_t), 3, f) == 3;
-    for (auto &L : p->leaves) {
-        const uint32_t kn[2] = {(uint32_t)L.kind, (uint32_t)(L.kind == MCI_CONTINUOUS ? L.npts : L.nbin)};
+    for (auto &L : p->leaves) { // (a FermiK leaf has nothing trained: header entry only, n = 0)
+        const uint32_t kn[2] = {(uint32_t)L.kind, (uint32_t)(L.kind == MCI_CONTINUOUS ? L.npts : L.kind == MCI_DISCRETE ? L.nbin : 0)};
         ok = ok && fwrite(kn, sizeof(uint32_t), 2, f) == 2;
     }
     ok = ok && fwrite(rw.data(), sizeof(double), rw.size(), f) == rw.size();
     for (size_t l = 0; l < p->leaves.size() && ok; ++l) {
         const Leaf &L = p->leaves[l];
+        if (L.kind == MCI_FERMIK) continue;
         const int n = L.kind == MCI_CONTINUOUS ? L.npts : L.nbin;
         std::vector<double> v(n);
         rc = L.kind == MCI_CONTINUOUS ? mci_get_grid(p, (int)l, v.data(), n) : mci_get_distribution(p, (int)l, v.data(), nullptr, n);
@@ -1269,7 +1291,8 @@ int mci_load_state(mci_problem *p, const char *path) {
     for (size_t l = 0; l < p->leaves.size(); ++l) {
         uint32_t kn[2];
         const Leaf &L = p->leaves[l];
-        if (fread(kn, sizeof(uint32_t), 2, f) != 2 || kn[0] != (uint32_t)L.kind || kn[1] != (uint32_t)(L.kind == MCI_CONTINUOUS ? L.npts : L.nbin)) {
+        if (fread(kn, sizeof(uint32_t), 2, f) != 2 || kn[0] != (uint32_t)L.kind ||
+            kn[1] != (uint32_t)(L.kind == MCI_CONTINUOUS ? L.npts : L.kind == MCI_DISCRETE ? L.nbin : 0)) {
             fclose(f);
             return fail(MCI_ERR_INVALID, "%s: variable %zu does not match the problem (kind / number of grid points)", path, l);
         }
@@ -1279,13 +1302,14 @@ int mci_load_state(mci_problem *p, const char *path) {
     std::vector<std::vector<double>> tabs(p->leaves.size());
     for (size_t l = 0; l < p->leaves.size() && ok; ++l) {
         const Leaf &L = p->leaves[l];
-        tabs[l].resize(L.kind == MCI_CONTINUOUS ? L.npts : L.nbin);
+        tabs[l].resize(L.kind == MCI_CONTINUOUS ? L.npts : L.kind == MCI_DISCRETE ? L.nbin : 0);
         ok = fread(tabs[l].data(), sizeof(double), tabs[l].size(), f) == tabs[l].size();
     }
     fclose(f);
     if (!ok) return fail(MCI_ERR_INVALID, "%s is truncated", path);
     int rc = mci_set_reweight(p, rw.data(), p->ni + 1);
     for (size_t l = 0; l < p->leaves.size() && !rc; ++l)
+        if (p->leaves[l].kind != MCI_FERMIK)
         rc = p->leaves[l].kind == MCI_CONTINUOUS ? mci_set_grid(p, (int)l, tabs[l].data(), (int)tabs[l].size())
                                                  : mci_set_distribution(p, (int)l, tabs[l].data(), (int)tabs[l].size());
     return rc;

@@ -194,6 +194,13 @@ template <class Cfg, int K, bool U12 = false> __device__ __forceinline__ void dr
         x = g0 + dy * dx;
         raw = dx;
         bin = iy;
+    } else if constexpr (Cfg::leaf_kind(leaf) == 2) {
+        // a component of a FermiK slot: the D components are created jointly (fermik_create), not per draw
+        (void)t;
+        (void)y;
+        x = 0.0;
+        raw = 1.0;
+        bin = 0;
     } else {
         // sampler.jl:17-20 + common.jl:16-25 bisection on accumulation[1..K+1]
         constexpr int Kn = Cfg::leaf_nbin(leaf);
@@ -830,6 +837,77 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
 //   step s    : stream MCMC_STEP, index (g<<32 | s),  k = 0 update pick, 1 neighbor/pool pick, 2 slot pick,
 //               3 second slot pick (swap), 4 accept, 5 + flat draw index of a created/shifted draw
 // =============================================================================================
+// ---------------------------------------------------------------------------------------------
+// FermiK{D} (variable.jl:1-20, sampler.jl:109-281): a momentum on a shell |k| in (kF - dk, kF + dk), D = 2 | 3
+// components per slot, no adaptive map, :mcmc only.  kF = leaf_lower, dk = leaf_upper, D = pool_nleaf(V).
+// ---------------------------------------------------------------------------------------------
+#define MCI_PI 3.14159265358979323846
+// create!  sampler.jl:109-148.  u = D uniforms; returns the proposal weight (0: rejected, k untouched)
+template <class Cfg, int V> __device__ __forceinline__ double fermik_create(const double *u, double *k) {
+    constexpr int D = Cfg::pool_nleaf(V), leaf = Cfg::draw_leaf(Cfg::pool_first_draw(V));
+    constexpr double kF = Cfg::leaf_lower(leaf), dk = Cfg::leaf_upper(leaf);
+    const double Kamp = kF + (u[0] - 0.5) * 2.0 * dk; // :121
+    if (Kamp <= 0.0) return 0.0;                       // :122
+    const double phi = 2.0 * MCI_PI * u[1];            // :124
+    if constexpr (D == 3) {
+        const double theta = MCI_PI * u[2];            // :126
+        k[0] = Kamp * cos(phi) * sin(theta);           // :129-131
+        k[1] = Kamp * sin(phi) * sin(theta);
+        k[2] = Kamp * cos(theta);
+        return 2 * dk * 2 * MCI_PI * MCI_PI * (sin(theta) * Kamp * Kamp); // :132
+    } else {
+        k[0] = Kamp * cos(phi);                        // :139-140
+        k[1] = Kamp * sin(phi);
+        return 2 * dk * 2 * MCI_PI * Kamp;             // :141
+    }
+}
+// remove!  sampler.jl:158-188
+template <class Cfg, int V> __device__ __forceinline__ double fermik_remove(const double *k) {
+    constexpr int D = Cfg::pool_nleaf(V), leaf = Cfg::draw_leaf(Cfg::pool_first_draw(V));
+    constexpr double kF = Cfg::leaf_lower(leaf), dk = Cfg::leaf_upper(leaf);
+    double k2 = 0.0;
+    static_for<0, D>([&](auto J) { k2 += k[decltype(J)::value] * k[decltype(J)::value]; });
+    const double Kamp = sqrt(k2);                                  // :171
+    if (!(kF - dk < Kamp && Kamp < kF + dk)) return 0.0;           // :172-174
+    if constexpr (D == 3) {
+        const double sint = sqrt(k[0] * k[0] + k[1] * k[1]) / Kamp; // :177
+        if (sint < 1.0e-15) return 0.0;                             // :178
+        return 1.0 / (2 * dk * 2 * MCI_PI * MCI_PI * sint * Kamp * Kamp); // :179
+    } else {
+        return 1.0 / (2 * dk * 2 * MCI_PI * Kamp);                  // :183
+    }
+}
+// shift!  sampler.jl:198-246: scale | rotate | shift, picked by upick; u = up to D more uniforms; k is updated in place
+template <class Cfg, int V> __device__ __forceinline__ double fermik_shift(double upick, const double *u, double *k) {
+    constexpr int D = Cfg::pool_nleaf(V), leaf = Cfg::draw_leaf(Cfg::pool_first_draw(V));
+    constexpr double dk = Cfg::leaf_upper(leaf);
+    if (upick < 1.0 / 3) { // :206-212
+        const double lambda = 1.5;
+        const double ratio = 1.0 / lambda + u[0] * (lambda - 1.0 / lambda);
+        static_for<0, D>([&](auto J) { k[decltype(J)::value] *= ratio; });
+        return D == 2 ? 1.0 : ratio;
+    } else if (upick < 2.0 / 3) { // :213-229
+        const double phi = u[0] * 2.0 * MCI_PI;
+        if constexpr (D == 3) {
+            const double theta = acos(1.0 - 2.0 * u[1]);
+            const double Kamp = sqrt(k[0] * k[0] + k[1] * k[1] + k[2] * k[2]);
+            k[0] = Kamp * cos(phi) * sin(theta);
+            k[1] = Kamp * sin(phi) * sin(theta);
+            k[2] = Kamp * cos(theta);
+        } else {
+            const double Kamp = sqrt(k[0] * k[0] + k[1] * k[1]);
+            k[0] = Kamp * cos(phi);
+            k[1] = Kamp * sin(phi);
+        }
+        return 1.0;
+    }
+    static_for<0, D>([&](auto J) { k[decltype(J)::value] += (u[decltype(J)::value] - 0.5) * dk; }); // :231-243
+    return 1.0;
+}
+template <class Cfg> constexpr bool pool_is_fermik(int v) {
+    return Cfg::pool_maxdof(v) > 0 && Cfg::leaf_kind(Cfg::draw_leaf(Cfg::pool_first_draw(v))) == 2;
+}
+
 // weight of ONE integrand: value (re [, im]) and modulus
 template <class Cfg> struct Weight {
     double v[Cfg::NCOMP];
@@ -935,6 +1013,26 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                 c.bin[k] = s.bin[k];
                 c.prob[k] = 1.0 / s.pj[k];
             });
+            static_for<0, NPOOL>([&](auto V) { // FermiK slots are created jointly from their D uniforms (same stream, k = flat draw)
+                constexpr int v = decltype(V)::value;
+                if constexpr (pool_is_fermik<Cfg>(v)) {
+                    constexpr int D = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                    constexpr double kF = Cfg::leaf_lower(Cfg::draw_leaf(k00));
+                    static_for<0, Cfg::pool_maxdof(v)>([&](auto S) {
+                        constexpr int kb = k00 + decltype(S)::value * D;
+                        double u[D], kk[D];
+                        const u64 iidx = g * 16384ull + (u64)tr;
+                        static_for<0, D>([&](auto J) {
+                            constexpr int kq = kb + decltype(J)::value;
+                            const u32x4 rr = philox4x32_10((u32)iidx, (u32)(iidx >> 32), (u32)(kq >> 1), st_init, k0, k1);
+                            u[decltype(J)::value] = (kq & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
+                            kk[decltype(J)::value] = kF / sqrt((double)D); // variable.jl:13: the pool's initial content
+                        });
+                        (void)fermik_create<Cfg, v>(u, kk);
+                        static_for<0, D>([&](auto J) { c.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
+                    });
+                }
+            });
             if (curr != NORMI) {
                 weight = eval_sel<Cfg>(curr, c.x, a.ud);        // :197
                 probability = weight.abs * rw_sel(curr);        // :199
@@ -992,7 +1090,21 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                                         constexpr int v = decltype(V)::value;
                                         constexpr int cd = Cfg::dof(c0 * NPOOL + v), nd = Cfg::dof(nw * NPOOL + v);
                                         constexpr int nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
-                                        if constexpr (cd < nd) {
+                                        if constexpr (pool_is_fermik<Cfg>(v) && cd != nd) {
+                                            static_for<(cd < nd ? cd : nd), (cd < nd ? nd : cd)>([&](auto S) {
+                                                constexpr int kb = k00 + decltype(S)::value * nl;
+                                                double kk[nl];
+                                                static_for<0, nl>([&](auto J) { kk[decltype(J)::value] = c.x[kb + decltype(J)::value]; });
+                                                if constexpr (cd < nd) { // create!  sampler.jl:109-148
+                                                    double u[nl];
+                                                    static_for<0, nl>([&](auto J) { u[decltype(J)::value] = step_uniform<5 + kb + decltype(J)::value>(sidx, st_step, k0, k1, r2); });
+                                                    prop *= fermik_create<Cfg, v>(u, kk);
+                                                    static_for<0, nl>([&](auto J) { n.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
+                                                } else {                 // remove!  sampler.jl:158-188
+                                                    prop *= fermik_remove<Cfg, v>(kk);
+                                                }
+                                            });
+                                        } else if constexpr (cd < nd) {
                                             static_for<cd * nl, nd * nl>([&](auto Q) { // create!  sampler.jl:293-305, :13-22
                                                 constexpr int k = k00 + decltype(Q)::value;
                                                 const double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
@@ -1060,6 +1172,17 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                                 active = true;
                                 int slot = (int)(us1 * (double)cdv); // :83
                                 if (slot >= cdv) slot = cdv - 1;
+                                if constexpr (pool_is_fermik<Cfg>(v)) { // shift!  sampler.jl:198-246; the move is picked by uniform 3
+                                    double u[nl], kk[nl], po;
+                                    int bo;
+                                    static_for<0, nl>([&](auto J) {
+                                        constexpr int j = decltype(J)::value;
+                                        u[j] = step_uniform_dyn(5 + k00 + slot * nl + j, sidx, st_step, k0, k1);
+                                        get_slot<Cfg, v, j>(c, slot, kk[j], po, bo);
+                                    });
+                                    prop *= fermik_shift<Cfg, v>(us2, u, kk);
+                                    static_for<0, nl>([&](auto J) { put_slot<Cfg, v, decltype(J)::value>(n, slot, kk[decltype(J)::value], 1.0, 0); });
+                                } else
                                 static_for<0, nl>([&](auto Lf) { // shift!  sampler.jl:336-386, :57-71, :431-440
                                     constexpr int l = decltype(Lf)::value;
                                     const double y = step_uniform_dyn(5 + k00 + slot * nl + l, sidx, st_step, k0, k1);

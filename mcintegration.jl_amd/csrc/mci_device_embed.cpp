@@ -197,6 +197,13 @@ template <class Cfg, int K, bool U12 = false> __device__ __forceinline__ void dr
         x = g0 + dy * dx;
         raw = dx;
         bin = iy;
+    } else if constexpr (Cfg::leaf_kind(leaf) == 2) {
+        // a component of a FermiK slot: the D components are created jointly (fermik_create), not per draw
+        (void)t;
+        (void)y;
+        x = 0.0;
+        raw = 1.0;
+        bin = 0;
     } else {
         // sampler.jl:17-20 + common.jl:16-25 bisection on accumulation[1..K+1]
         constexpr int Kn = Cfg::leaf_nbin(leaf);
@@ -298,11 +305,11 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
     for (int i = tid; i < Cfg::NDDIST; i += T) sDD[i] = gDD[i];
 }
 
-// LDS carve (doubles).  Order: grid table | dacc | ddist | hist | obs | reduction scratch
+// LDS c)MCIDEV"
+R"MCIDEV(arve (doubles).  Order: grid table | dacc | ddist | hist | obs | reduction scratch
 template <class Cfg> struct Lds {
     static constexpr int E = 0;
-    static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::)MCIDEV"
-R"MCIDEV(NEDGE) : 0);
+    static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
     static constexpr int DD = DA + Cfg::NDACC;
     static constexpr int H = DD + Cfg::NDDIST;
     static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE : 0);
@@ -452,13 +459,13 @@ template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchAr
     w.rowid = Cfg::NTILE == 1 ? (i64)blockIdx.x : (i64)(blockIdx.x / Cfg::NTILE);
     w.lb = w.rowid / a.wg_per_block;
     w.slice = (int)(w.rowid % a.wg_per_block);
-    return w;
+    return w;)MCIDEV"
+R"MCIDEV(
 }
 
 // =============================================================================================
 // VEGAS sample batch  (vegas/montecarlo.jl:117-187)
-// ============================================================================================)MCIDEV"
-R"MCIDEV(=
+// =============================================================================================
 // SPLIT (NTILE > 1): this pass owns histogram tile 0 only and parks (weights, bins of the other tiles' draws)
 // per sample for mci_vegas_tiles; one workgroup per (block, slice).
 template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
@@ -599,12 +606,12 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
 // (x, prob, bin per draw; weights; probability) stays in registers; the proposal touches one
 // (pool, slot), selected by a compile-time switch so that every table access keeps static offsets.
 //   chain g = block*nchain + ch
-//   init  : stream MC_INIT, index g,            k = flat draw
+//   init  : stream MC_INIT, index g,            k)MCIDEV"
+R"MCIDEV( = flat draw
 //   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
 // =============================================================================================
 template <class Cfg> struct Chain {
-   )MCIDEV"
-R"MCIDEV( double x[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
+    double x[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
     double prob[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // leaf prob[idx]  (variable.jl:90)
     int bin[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
 };
@@ -748,12 +755,12 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                         int slot = (int)(uslot * (double)md); // :58
                         if (slot >= md) slot = md - 1;
                         static_for<0, nl>([&](auto Lf) {
-                            constexpr int l = decltype(Lf)::value;
+                 )MCIDEV"
+R"MCIDEV(           constexpr int l = decltype(Lf)::value;
                             constexpr int kk = 3 + l; // RNG draw index within the step
                             double y;
                             if constexpr (kk == 3) y = u01(r1.z, r1.w);
- )MCIDEV"
-R"MCIDEV(                           else {
+                            else {
                                 const u32x4 rr = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(kk >> 1), st_step, k0, k1);
                                 y = (kk & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
                             }
@@ -837,6 +844,78 @@ R"MCIDEV(                           else {
 //   step s    : stream MCMC_STEP, index (g<<32 | s),  k = 0 update pick, 1 neighbor/pool pick, 2 slot pick,
 //               3 second slot pick (swap), 4 accept, 5 + flat draw index of a created/shifted draw
 // =============================================================================================
+// ---------------------------------------------------------------------------------------------
+// FermiK{D} (variable.jl:1-20, sampler.jl:109-281): a momentum on a shell |k| in (kF - dk, kF + dk), D = 2 | 3
+// components per slot, no adaptive map, :mcmc only.  kF = leaf_lower, dk = leaf_upper, D = pool_nleaf(V).
+// ---------------------------------------------------------------------------------------------
+#define MCI_PI 3.14159265358979323846
+// create!  sampler.jl:109-148.  u = D uniforms; returns the proposal weight (0: rejected, k untouched)
+template <class Cfg, int V> __device__ __forceinline__ double fermik_create(const double *u, double *k) {
+    constexpr int D = Cfg::pool_nleaf(V), leaf = Cfg::draw_leaf(Cfg::pool_first_draw(V));
+    constexpr double kF = Cfg::leaf_lower(leaf), dk = Cfg::leaf_upper(leaf);
+    const double Kamp = kF + (u[0] - 0.5) * 2.0 * dk; // :121
+    if (Kamp <= 0.0) return 0.0;                       // :122
+    const double phi = 2.0 * MCI_PI * u[1];            // :124
+    if constexpr (D == 3) {
+        const double theta = MCI_PI * u[2];            // :126
+        k[0] = Kamp * cos(phi) * sin(theta);           // :129-131
+        k[1] = Kamp * sin(phi) * sin(theta);
+        k[2] = Kamp * cos(theta);
+        return 2 * dk * 2 * MCI_PI * MCI_PI * (sin(theta) * Kamp * Kamp); // :132
+    } else {
+        k[0] = Kamp * cos(phi);                        // :139-140
+        k[1] = Kamp * sin(phi);
+        return 2 * dk * 2 * MCI_PI * Kamp;             // :141
+    }
+}
+// remove!  sampler.jl:158-188
+template <class Cfg, int V> __device__ __forceinline__ double fermik_remove(const double *k) {
+    constexpr int D = Cfg::pool_nleaf(V), leaf = Cfg::draw_leaf(Cfg::pool_first_draw(V));
+    constexpr double kF = Cfg::leaf_lower(leaf), dk = Cfg::leaf_upper(leaf);
+    double k2 = 0.0;
+    static_for<0, D>([&](auto J) { k2 += k[decltype(J)::value] * k[decltype(J)::value]; });
+    const double Kamp = sqrt(k2);                                  // :171
+    if (!(kF - dk < Kamp && Kamp < kF + dk)) return 0.0;           // :172-174
+    if constexpr (D == 3) {
+        const double sint = sqrt(k[0] * k[0] + k[1] * k[1]) / Kamp; // :177
+        if (sint < 1.0e-15) return 0.0;                             // :178
+        return 1.0 / (2 * dk * 2 * MCI_PI * MCI_PI * sint * Kamp * Kamp); // :179
+    } else {
+        return 1.0 / (2 * dk * 2 * MCI_PI * Kamp);                  // :183
+    }
+}
+// shift!  sampler.jl:198-246: scale | rotate | shift, picked by upick; u = up to D more uni)MCIDEV"
+R"MCIDEV(forms; k is updated in place
+template <class Cfg, int V> __device__ __forceinline__ double fermik_shift(double upick, const double *u, double *k) {
+    constexpr int D = Cfg::pool_nleaf(V), leaf = Cfg::draw_leaf(Cfg::pool_first_draw(V));
+    constexpr double dk = Cfg::leaf_upper(leaf);
+    if (upick < 1.0 / 3) { // :206-212
+        const double lambda = 1.5;
+        const double ratio = 1.0 / lambda + u[0] * (lambda - 1.0 / lambda);
+        static_for<0, D>([&](auto J) { k[decltype(J)::value] *= ratio; });
+        return D == 2 ? 1.0 : ratio;
+    } else if (upick < 2.0 / 3) { // :213-229
+        const double phi = u[0] * 2.0 * MCI_PI;
+        if constexpr (D == 3) {
+            const double theta = acos(1.0 - 2.0 * u[1]);
+            const double Kamp = sqrt(k[0] * k[0] + k[1] * k[1] + k[2] * k[2]);
+            k[0] = Kamp * cos(phi) * sin(theta);
+            k[1] = Kamp * sin(phi) * sin(theta);
+            k[2] = Kamp * cos(theta);
+        } else {
+            const double Kamp = sqrt(k[0] * k[0] + k[1] * k[1]);
+            k[0] = Kamp * cos(phi);
+            k[1] = Kamp * sin(phi);
+        }
+        return 1.0;
+    }
+    static_for<0, D>([&](auto J) { k[decltype(J)::value] += (u[decltype(J)::value] - 0.5) * dk; }); // :231-243
+    return 1.0;
+}
+template <class Cfg> constexpr bool pool_is_fermik(int v) {
+    return Cfg::pool_maxdof(v) > 0 && Cfg::leaf_kind(Cfg::draw_leaf(Cfg::pool_first_draw(v))) == 2;
+}
+
 // weight of ONE integrand: value (re [, im]) and modulus
 template <class Cfg> struct Weight {
     double v[Cfg::NCOMP];
@@ -891,8 +970,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     constexpr int NI = Cfg::NI, NORMI = Cfg::NI, ND = Cfg::NI + 1, NPOOL = Cfg::NPOOL;
     constexpr int NUPD = 2 * NPOOL + 2; // [changeIntegrand, swapVariable, changeVariable x 2*Nv]  montecarlo.jl:127-130
     const int tid = threadIdx.x, T = blockDim.x;
-    double *sE = smem + Lds<Cfg>::)MCIDEV"
-R"MCIDEV(E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
+    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
     double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
@@ -942,6 +1020,27 @@ R"MCIDEV(E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
                 c.x[k] = s.x[k];
                 c.bin[k] = s.bin[k];
                 c.prob[k] = 1.0 / s.pj[k];
+            });
+            static_for<0, NPOOL>([&](auto V) { // FermiK slots are created jointly from their D uniforms (same stream, k = flat draw)
+                constexpr int v = decltype(V)::value;
+                if constexpr (pool_is_fermik<Cfg>(v)) {
+                    constexpr int D = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                    constexpr double kF = Cfg::leaf_lower(Cfg::draw_leaf(k00));
+                    static_for<0, Cfg::pool_maxdof(v)>([&](auto S) {
+                        constexpr int kb = k00 + decltype(S)::value * D;
+                        double u[D], kk[D];
+                        const u64 iidx = g * 16384ull + (u64)tr;
+                        static_for<0, D>([&](auto J) {
+                            constexpr int kq = kb + decltype(J)::value;
+                            const u32x4 rr = philox4x32_10((u32)iidx, (u32)(iidx >> 32), (u32)(kq >> 1), st_init, k0, k1);
+                            u[decltype(J)::value] = (kq & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
+                            kk[decltype(J)::value] = kF / sqrt((double)D); // variable.jl:13: the pool's initial content
+                        });
+                        (void)fermik_create<Cfg, v>(u, kk);
+                        static_for<0, D>([)MCIDEV"
+R"MCIDEV(&](auto J) { c.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
+                    });
+                }
             });
             if (curr != NORMI) {
                 weight = eval_sel<Cfg>(curr, c.x, a.ud);        // :197
@@ -1000,7 +1099,21 @@ R"MCIDEV(E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
                                         constexpr int v = decltype(V)::value;
                                         constexpr int cd = Cfg::dof(c0 * NPOOL + v), nd = Cfg::dof(nw * NPOOL + v);
                                         constexpr int nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
-                                        if constexpr (cd < nd) {
+                                        if constexpr (pool_is_fermik<Cfg>(v) && cd != nd) {
+                                            static_for<(cd < nd ? cd : nd), (cd < nd ? nd : cd)>([&](auto S) {
+                                                constexpr int kb = k00 + decltype(S)::value * nl;
+                                                double kk[nl];
+                                                static_for<0, nl>([&](auto J) { kk[decltype(J)::value] = c.x[kb + decltype(J)::value]; });
+                                                if constexpr (cd < nd) { // create!  sampler.jl:109-148
+                                                    double u[nl];
+                                                    static_for<0, nl>([&](auto J) { u[decltype(J)::value] = step_uniform<5 + kb + decltype(J)::value>(sidx, st_step, k0, k1, r2); });
+                                                    prop *= fermik_create<Cfg, v>(u, kk);
+                                                    static_for<0, nl>([&](auto J) { n.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
+                                                } else {                 // remove!  sampler.jl:158-188
+                                                    prop *= fermik_remove<Cfg, v>(kk);
+                                                }
+                                            });
+                                        } else if constexpr (cd < nd) {
                                             static_for<cd * nl, nd * nl>([&](auto Q) { // create!  sampler.jl:293-305, :13-22
                                                 constexpr int k = k00 + decltype(Q)::value;
                                                 const double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
@@ -1022,8 +1135,7 @@ R"MCIDEV(E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
                     }
                 });
             } else if (curr != NORMI) { // updates.jl:73, :115
-                int vi = ()MCIDEV"
-R"MCIDEV(int)(upick * (double)NPOOL); // :77, :119
+                int vi = (int)(upick * (double)NPOOL); // :77, :119
                 if (vi >= NPOOL) vi = NPOOL - 1;
                 int cdv = 0; // currdof[vi]
                 static_for<0, NI>([&](auto I) {
@@ -1041,7 +1153,8 @@ R"MCIDEV(int)(upick * (double)NPOOL); // :77, :119
                         if (s1 != s2) { // :124
                             active = true;
                             static_for<0, NPOOL>([&](auto V) {
-                                constexpr int v = decltype(V)::value;
+                                constexpr int v = dec)MCIDEV"
+R"MCIDEV(ltype(V)::value;
                                 if (vi == v) {
                                     static_for<0, Cfg::pool_nleaf(v)>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
                                         constexpr int l = decltype(Lf)::value;
@@ -1069,6 +1182,17 @@ R"MCIDEV(int)(upick * (double)NPOOL); // :77, :119
                                 active = true;
                                 int slot = (int)(us1 * (double)cdv); // :83
                                 if (slot >= cdv) slot = cdv - 1;
+                                if constexpr (pool_is_fermik<Cfg>(v)) { // shift!  sampler.jl:198-246; the move is picked by uniform 3
+                                    double u[nl], kk[nl], po;
+                                    int bo;
+                                    static_for<0, nl>([&](auto J) {
+                                        constexpr int j = decltype(J)::value;
+                                        u[j] = step_uniform_dyn(5 + k00 + slot * nl + j, sidx, st_step, k0, k1);
+                                        get_slot<Cfg, v, j>(c, slot, kk[j], po, bo);
+                                    });
+                                    prop *= fermik_shift<Cfg, v>(us2, u, kk);
+                                    static_for<0, nl>([&](auto J) { put_slot<Cfg, v, decltype(J)::value>(n, slot, kk[decltype(J)::value], 1.0, 0); });
+                                } else
                                 static_for<0, nl>([&](auto Lf) { // shift!  sampler.jl:336-386, :57-71, :431-440
                                     constexpr int l = decltype(Lf)::value;
                                     const double y = step_uniform_dyn(5 + k00 + slot * nl + l, sidx, st_step, k0, k1);
@@ -1150,11 +1274,11 @@ template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs 
     Tables<Cfg> t;
     if constexpr (Cfg::TABLE_MODE <= 1) t.E = sE;
     else t.E = a.edges;
-    )MCIDEV"
-R"MCIDEV(t.DA = sDA;
+    t.DA = sDA;
     t.DD = sDD;
     const u32 stream = a.iteration * 8u + STREAM_VEGAS;
-    for (i64 n = (i64)blockIdx.x * blockDim.x + threadIdx.x; n < a.n; n += (i64)gridDim.x * blockDim.x) {
+    for (i64 n = (i64)blockIdx.x * blo)MCIDEV"
+R"MCIDEV(ckDim.x + threadIdx.x; n < a.n; n += (i64)gridDim.x * blockDim.x) {
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(a.first_index + n), s);
         if (a.soa) {

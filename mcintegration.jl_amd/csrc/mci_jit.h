@@ -32,7 +32,7 @@ struct ProblemShape {
     std::vector<int> leaf_tile, tile_boff, tile_nbin; // histogram tiles (contiguous leaves)
     std::vector<int> draw_leaf, draw_pool, draw_slot;
     std::vector<int> leaf_kind, leaf_nbin, leaf_eoff, leaf_doff, leaf_boff, leaf_adapt, leaf_poff;
-    std::vector<double> leaf_lower;
+    std::vector<double> leaf_lower, leaf_upper;
     std::vector<unsigned long long> own_mask;   // [ni+1] draws covered by integrand i (last = normalisation: 0)
     std::vector<unsigned long long> cover_mask; // [ndraw] integrands covering draw k
     std::vector<int> obs_off, obs_nbin, obs_bin_draw;
@@ -103,6 +103,7 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     o << fn_table("int", "tile_boff", arr(s.tile_boff, "int"));
     o << fn_table("int", "tile_nbin", arr(s.tile_nbin, "int"));
     o << fn_table("double", "leaf_lower", dbl_arr(s.leaf_lower));
+    o << fn_table("double", "leaf_upper", dbl_arr(s.leaf_upper));
     o << fn_table("unsigned long long", "own_mask", arr(s.own_mask, "u64", "ull"));
     o << fn_table("unsigned long long", "cover_mask", arr(s.cover_mask, "u64", "ull"));
     o << fn_table("int", "obs_off", arr(s.obs_off, "int"));

@@ -6,7 +6,7 @@ import numpy as np
 from . import _lib
 from ._lib import LeafDesc, ProblemDesc, c_double_p, c_int32_p, check, lib
 from .integrand import HostIntegrand, Integrand, Measure
-from .variables import ContinuousVar
+from .variables import ContinuousVar, FermiK
 
 _ctx_cache = {}
 
@@ -54,6 +54,8 @@ class Engine:
             if isinstance(lf, ContinuousVar):
                 d.kind, d.npoints = _lib.CONTINUOUS, lf.ninc
                 init = lf._grid0
+            elif isinstance(lf, FermiK):
+                d.kind, d.npoints = _lib.FERMIK, lf.dim   # lower = kF, upper = dk, alpha = maxK
             else:
                 d.kind, d.npoints = _lib.DISCRETE, 0
                 init = lf._dist0
@@ -102,7 +104,7 @@ class Engine:
         pools = []   # (first draw, maxdof, nleaf)
         k = 0
         for vi, v in enumerate(config.var):
-            nl = len(v.vars) if hasattr(v, "vars") else 1
+            nl = config.pool_width(vi)
             pools.append((k, config.maxdof[vi], nl))
             k += config.maxdof[vi] * nl
 
@@ -262,7 +264,7 @@ class Engine:
         packed = self.get_packed()
         off = 2 * self.nobs + 2 + self.config.N + 1
         for i, lf in enumerate(self.config.leaves):
-            nb = (lf.ninc - 1) if isinstance(lf, ContinuousVar) else (lf.upper - lf.lower + 1)
+            nb = (lf.ninc - 1) if isinstance(lf, ContinuousVar) else 1 if isinstance(lf, FermiK) else (lf.upper - lf.lower + 1)
             if i == leaf:
                 return packed[off:off + nb]
             off += nb

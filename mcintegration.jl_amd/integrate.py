@@ -59,11 +59,13 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         old = config._engine
         saved = None
         if old is not None:
-            saved = [(old.grid(i) if hasattr(lf, "ninc") else old.distribution(i)[0]) for i, lf in enumerate(config.leaves)]
+            saved = [(old.grid(i) if hasattr(lf, "ninc") else None if hasattr(lf, "kF") else old.distribution(i)[0])
+                     for i, lf in enumerate(config.leaves)]
         eng = (engine_factory or Engine)(config, integrand, measure=measure, device=device)
         if saved is not None:
             for i, lf in enumerate(config.leaves):
-                (eng.set_grid if hasattr(lf, "ninc") else eng.set_distribution)(i, saved[i])
+                if saved[i] is not None:   # (a FermiK has nothing trained)
+                    (eng.set_grid if hasattr(lf, "ninc") else eng.set_distribution)(i, saved[i])
         config._engine, config._engine_key = eng, key
         if getattr(config, "_pending_state", None):
             eng.load_state(config._pending_state)

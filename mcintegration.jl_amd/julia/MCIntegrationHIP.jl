@@ -5,11 +5,11 @@
 # reference-side binding INTEGRATION.md describes.  Everything numerical happens in the library.
 module MCIntegrationHIP
 
-export integrate, Configuration, Continuous, Discrete, CompositeVar, Result, Integrand, Measure, bin_by, report
+export integrate, Configuration, Continuous, Discrete, CompositeVar, FermiK, Result, Integrand, Measure, bin_by, report
 
 const libmci = get(ENV, "MCI_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libmci_hip.so"))
 const MaxOrder = 16                         # reference src/distribution/distribution.jl:59
-const MCI_CONTINUOUS, MCI_DISCRETE = Int32(0), Int32(1)
+const MCI_CONTINUOUS, MCI_DISCRETE, MCI_FERMIK = Int32(0), Int32(1), Int32(2)
 const SOLVER = Dict(:vegas => Int32(0), :vegasmc => Int32(1), :mcmc => Int32(2))
 
 struct MCIError <: Exception
@@ -35,6 +35,11 @@ mutable struct Discrete
 end
 Discrete(lower::Int, upper::Int, size=MaxOrder; distribution=nothing, offset=0, alpha=2.0, adapt=true) =
     Discrete(lower, upper, size + 1, offset, alpha, adapt, distribution)
+
+mutable struct FermiK                         # reference src/distribution/variable.jl:1-20 (solver = :mcmc only)
+    dim::Int; kF::Float64; dk::Float64; maxK::Float64; size::Int; offset::Int
+end
+FermiK(dim, kF, dk, maxK, size=MaxOrder; offset=0) = FermiK(dim, kF, dk, maxK, size + 1, offset)
 
 struct CompositeVar
     vars::Tuple
@@ -146,7 +151,7 @@ function draw_index(c::Configuration, pool::Int)          # 0-based flat draw of
     k = 0
     for (vi, v) in enumerate(c.var)
         vi == pool && return k
-        k += maximum(d[vi] for d in c.dof) * length(leaves(v))
+        k += maximum(d[vi] for d in c.dof) * (v isa FermiK ? v.dim : length(leaves(v)))
     end
     error("pool $pool out of range")
 end
@@ -160,6 +165,8 @@ function bind!(c::Configuration, f::Integrand, measure)
         if lf isa Continuous
             init = lf.grid === nothing ? Ptr{Float64}(C_NULL) : (push!(keep, lf.grid); pointer(lf.grid))
             push!(descs, LeafDesc(MCI_CONTINUOUS, vi - 1, lf.lower, lf.upper, lf.ninc, lf.alpha, lf.adapt, init))
+        elseif lf isa FermiK                       # lower = kF, upper = dk, npoints = dim, alpha = maxK (include/mci.h)
+            push!(descs, LeafDesc(MCI_FERMIK, vi - 1, lf.kF, lf.dk, lf.dim, lf.maxK, false, Ptr{Float64}(C_NULL)))
         else
             init = lf.distribution === nothing ? Ptr{Float64}(C_NULL) : (push!(keep, lf.distribution); pointer(lf.distribution))
             push!(descs, LeafDesc(MCI_DISCRETE, vi - 1, lf.lower, lf.upper, 0, lf.alpha, lf.adapt, init))

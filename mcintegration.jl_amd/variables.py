@@ -97,6 +97,23 @@ class CompositeVar:
         return iter(self.vars)
 
 
+class FermiK(_Leaf):
+    """`FermiK(dim, kF, dk, maxK, size=MaxOrder; offset=0)` reference variable.jl:1-20: a dim-dimensional (2 | 3)
+    momentum on the shell |k| in (kF - dk, kF + dk).  No adaptive map (train! is a no-op, :557); a slot contributes
+    `dim` consecutive entries of the integrand's x.  solver=:mcmc only (test/bubble_FermiK.jl:2)."""
+
+    def __init__(self, dim, kF, dk, maxK, size=MaxOrder, *, offset=0):
+        assert offset + 1 < size                       # variable.jl:12
+        assert dim in (2, 3)
+        self.dim, self.kF, self.dk, self.maxK = int(dim), float(kF), float(dk), float(maxK)
+        self.lower, self.upper = self.kF, self.dk      # how the C ABI carries them (include/mci.h)
+        self.size = size + 1
+        self.offset, self.alpha, self.adapt = int(offset), float(maxK), False
+
+    def __repr__(self):
+        return "%dD FermiK variable in [0, %g)." % (self.dim, self.maxK)   # variable.jl:22-27
+
+
 def _is_bounds(x):
     return isinstance(x, (list, tuple)) and len(x) > 0 and isinstance(x[0], (list, tuple))
 
@@ -138,8 +155,8 @@ def Discrete(lower, upper=None, size=MaxOrder, **kw):
 def is_variable(v):
     """reference: Dist.is_variable (test/variable.jl:7-16)"""
     if isinstance(v, type):
-        return v in (ContinuousVar, DiscreteVar, CompositeVar)
-    return isinstance(v, (ContinuousVar, DiscreteVar, CompositeVar)) or v in (Continuous, Discrete)
+        return v in (ContinuousVar, DiscreteVar, CompositeVar, FermiK)
+    return isinstance(v, (ContinuousVar, DiscreteVar, CompositeVar, FermiK)) or v in (Continuous, Discrete)
 
 
 def poolsize(v):

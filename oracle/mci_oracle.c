@@ -9,6 +9,11 @@
  */
 #include "mci_oracle.h"
 
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -185,7 +190,7 @@ void mcio_maxdof(const int *dof, int nd, int npool, int *out) { /* ref: configur
 
 static void leaf_alloc_pool(mcio_leaf *L, int P) {
     L->P = P;
-    L->data = (double *)calloc((size_t)P + 1, sizeof(double));
+    L->data = (double *)calloc(((size_t)P + 1) * (size_t)(L->width > 0 ? L->width : 1), sizeof(double));
     L->gidx = (long *)calloc((size_t)P + 1, sizeof(long));
     L->prob = (double *)calloc((size_t)P + 1, sizeof(double));
 }
@@ -200,8 +205,18 @@ static void leaf_init(mcio_leaf *L, int kind, int pool, double lower, double upp
     L->upper = upper;
     L->alpha = alpha;
     L->adapt = adapt;
+    L->width = kind == MCIO_FERMIK ? npts : 1;
     leaf_alloc_pool(L, P);
-    if (kind == MCIO_CONTINUOUS) {
+    if (kind == MCIO_FERMIK) { /* variable.jl:11-19: k = kF/sqrt(dim) in every component, prob = 1, histogram = [0.0] */
+        L->npts = npts;
+        L->nbin = 1;
+        L->adapt = 0;
+        L->hist = (double *)calloc(1, sizeof(double));
+        for (int i = 1; i <= P; ++i) {
+            for (int j = 0; j < npts; ++j) L->data[i * npts + j] = lower / sqrt((double)npts);
+            L->prob[i] = 1.0;
+        }
+    } else if (kind == MCIO_CONTINUOUS) {
         L->npts = npts;
         L->nbin = npts - 1; /* :147 */
         L->grid = (double *)malloc(sizeof(double) * (size_t)npts);
@@ -290,18 +305,26 @@ mcio_config *mcio_config_create(int nleaf, const int *kind, const int *pool, con
         }
         c->pool_prob_cache[v] = 1.0;
     }
+    c->pool_width = (int *)calloc((size_t)npool, sizeof(int));
+    for (int v = 0; v < npool; ++v) {
+        c->pool_width[v] = 0;
+        for (int l = c->pool_leaf0[v]; l < c->pool_leaf0[v] + c->pool_nleaf[v]; ++l) c->pool_width[v] += c->leaf[l].width;
+    }
     c->ndraw = 0;
-    for (int v = 0; v < npool; ++v) c->ndraw += c->maxdof[v] * c->pool_nleaf[v];
+    for (int v = 0; v < npool; ++v) c->ndraw += c->maxdof[v] * c->pool_width[v];
     c->draw_leaf = (int *)calloc((size_t)(c->ndraw > 0 ? c->ndraw : 1), sizeof(int));
     c->draw_slot = (int *)calloc((size_t)(c->ndraw > 0 ? c->ndraw : 1), sizeof(int));
+    c->draw_comp = (int *)calloc((size_t)(c->ndraw > 0 ? c->ndraw : 1), sizeof(int));
     int k = 0;
     for (int v = 0; v < npool; ++v)
         for (int idx = 1; idx <= c->maxdof[v]; ++idx)
-            for (int l = 0; l < c->pool_nleaf[v]; ++l) {
-                c->draw_leaf[k] = c->pool_leaf0[v] + l;
-                c->draw_slot[k] = idx;
-                ++k;
-            }
+            for (int l = 0; l < c->pool_nleaf[v]; ++l)
+                for (int j = 0; j < c->leaf[c->pool_leaf0[v] + l].width; ++j) {
+                    c->draw_leaf[k] = c->pool_leaf0[v] + l;
+                    c->draw_slot[k] = idx;
+                    c->draw_comp[k] = j;
+                    ++k;
+                }
     c->obs_off = (int *)calloc((size_t)Ni, sizeof(int));
     c->obs_nbin = (int *)calloc((size_t)Ni, sizeof(int));
     c->obs_bin_draw = (int *)calloc((size_t)Ni, sizeof(int));
@@ -355,7 +378,7 @@ void mcio_config_destroy(mcio_config *c) {
     for (int l = 0; l < c->nleaf; ++l) leaf_free(&c->leaf[l]);
     free(c->leaf); free(c->pool_leaf0); free(c->pool_nleaf); free(c->pool_offset);
     free(c->pool_prob); free(c->pool_prob_cache); free(c->dof); free(c->maxdof);
-    free(c->draw_leaf); free(c->draw_slot); free(c->obs_off); free(c->obs_nbin); free(c->obs_bin_draw);
+    free(c->draw_leaf); free(c->draw_slot); free(c->draw_comp); free(c->pool_width); free(c->obs_off); free(c->obs_nbin); free(c->obs_bin_draw);
     free(c->observable); free(c->reweight); free(c->visited); free(c->propose); free(c->accept);
     for (int d = 0; d < c->Ni + 1; ++d) free(c->neighbor[d]);
     free(c->neighbor); free(c->nneighbor); free(c->reweight_goal);
@@ -383,7 +406,7 @@ mcio_config *mcio_config_clone(const mcio_config *s) {
         b->hist = (double *)dup_mem(a->hist, sizeof(double) * (size_t)a->nbin);
         b->accumulation = a->accumulation ? (double *)dup_mem(a->accumulation, sizeof(double) * (size_t)(a->nbin + 1)) : NULL;
         b->distribution = a->distribution ? (double *)dup_mem(a->distribution, sizeof(double) * (size_t)a->nbin) : NULL;
-        b->data = (double *)dup_mem(a->data, sizeof(double) * (size_t)(a->P + 1));
+        b->data = (double *)dup_mem(a->data, sizeof(double) * (size_t)(a->P + 1) * (size_t)(a->width > 0 ? a->width : 1));
         b->gidx = (long *)dup_mem(a->gidx, sizeof(long) * (size_t)(a->P + 1));
         b->prob = (double *)dup_mem(a->prob, sizeof(double) * (size_t)(a->P + 1));
     }
@@ -400,6 +423,8 @@ mcio_config *mcio_config_clone(const mcio_config *s) {
     c->maxdof = (int *)dup_mem(s->maxdof, sizeof(int) * (size_t)s->npool);
     c->draw_leaf = (int *)dup_mem(s->draw_leaf, sizeof(int) * (size_t)(s->ndraw > 0 ? s->ndraw : 1));
     c->draw_slot = (int *)dup_mem(s->draw_slot, sizeof(int) * (size_t)(s->ndraw > 0 ? s->ndraw : 1));
+    c->draw_comp = (int *)dup_mem(s->draw_comp, sizeof(int) * (size_t)(s->ndraw > 0 ? s->ndraw : 1));
+    c->pool_width = (int *)dup_mem(s->pool_width, sizeof(int) * (size_t)s->npool);
     c->obs_off = (int *)dup_mem(s->obs_off, sizeof(int) * (size_t)s->Ni);
     c->obs_nbin = (int *)dup_mem(s->obs_nbin, sizeof(int) * (size_t)s->Ni);
     c->obs_bin_draw = (int *)dup_mem(s->obs_bin_draw, sizeof(int) * (size_t)s->Ni);
@@ -568,6 +593,101 @@ void mcio_shift_rollback(mcio_config *c, int leaf, int idx) {
     T->prob[idx] = T->prob[end];
 }
 
+/* ---- FermiK{D}  ref: sampler.jl:109-281.  K.prob is written but never read on the :mcmc path; it is kept for the record. */
+static double fermik_create(mcio_leaf *K, int idx, const double *u) { /* :109-148, u = D uniforms */
+    const int D = K->width;
+    const double kF = K->lower, dk = K->upper;
+    double *k = &K->data[idx * D];
+    const double Kamp = kF + (u[0] - 0.5) * 2.0 * dk;  /* :121 */
+    if (Kamp <= 0.0) return 0.0;                          /* :122 */
+    const double phi = 2.0 * M_PI * u[1];                 /* :124 */
+    double prop;
+    if (D == 3) {
+        const double theta = M_PI * u[2];                 /* :126 */
+        k[0] = Kamp * cos(phi) * sin(theta);              /* :129-131 */
+        k[1] = Kamp * sin(phi) * sin(theta);
+        k[2] = Kamp * cos(theta);
+        prop = 2 * dk * 2 * M_PI * M_PI * (sin(theta) * Kamp * Kamp); /* :132 */
+    } else {
+        k[0] = Kamp * cos(phi);                           /* :139-140 */
+        k[1] = Kamp * sin(phi);
+        prop = 2 * dk * 2 * M_PI * Kamp;                  /* :141 */
+    }
+    K->prob[idx] = 1.0 / prop;
+    return prop;
+}
+
+static double fermik_remove(mcio_leaf *K, int idx) { /* :158-188 */
+    const int D = K->width;
+    const double kF = K->lower, dk = K->upper;
+    const double *k = &K->data[idx * D];
+    double k2 = 0.0;
+    for (int j = 0; j < D; ++j) k2 += k[j] * k[j];
+    const double Kamp = sqrt(k2);                                   /* :171 */
+    if (!(kF - dk < Kamp && Kamp < kF + dk)) return 0.0;            /* :172-174 */
+    double prop;
+    if (D == 3) {
+        const double sint = sqrt(k[0] * k[0] + k[1] * k[1]) / Kamp; /* :177 */
+        if (sint < 1.0e-15) return 0.0;                             /* :178 */
+        prop = 1.0 / (2 * dk * 2 * M_PI * M_PI * sint * Kamp * Kamp); /* :179 */
+    } else {
+        prop = 1.0 / (2 * dk * 2 * M_PI * Kamp);                    /* :183 */
+    }
+    K->prob[idx] = 1.0 / prop;
+    return prop;
+}
+
+/* shift!  :198-246 ; upick selects the move, u = up to D more uniforms */
+static double fermik_shift(mcio_leaf *K, int idx, double upick, const double *u) {
+    const int D = K->width, end = K->P;
+    double *k = &K->data[idx * D];
+    for (int j = 0; j < D; ++j) K->data[end * D + j] = k[j]; /* :201 save current K */
+    K->prob[end] = K->prob[idx];
+    if (upick < 1.0 / 3) {                                   /* :206-212 scale */
+        const double lambda = 1.5;
+        const double ratio = 1.0 / lambda + u[0] * (lambda - 1.0 / lambda);
+        for (int j = 0; j < D; ++j) k[j] *= ratio;
+        return D == 2 ? 1.0 : ratio;
+    } else if (upick < 2.0 / 3) {                            /* :213-229 rotate */
+        const double phi = u[0] * 2.0 * M_PI;
+        if (D == 3) {
+            const double theta = acos(1.0 - 2.0 * u[1]);
+            const double Kamp = sqrt(k[0] * k[0] + k[1] * k[1] + k[2] * k[2]);
+            k[0] = Kamp * cos(phi) * sin(theta);
+            k[1] = Kamp * sin(phi) * sin(theta);
+            k[2] = Kamp * cos(theta);
+        } else {
+            const double Kamp = sqrt(k[0] * k[0] + k[1] * k[1]);
+            k[0] = Kamp * cos(phi);
+            k[1] = Kamp * sin(phi);
+        }
+        return 1.0;
+    }
+    for (int j = 0; j < D; ++j) k[j] += (u[j] - 0.5) * K->upper; /* :231-243 shift by (rand - 0.5) dk per component */
+    return 1.0;
+}
+
+static void fermik_shift_rollback(mcio_leaf *K, int idx) { /* :248-252 */
+    const int D = K->width, end = K->P;
+    for (int j = 0; j < D; ++j) K->data[idx * D + j] = K->data[end * D + j];
+    K->prob[idx] = K->prob[end];
+}
+
+static void fermik_swap(mcio_leaf *K, int i1, int i2) { /* :254-281 */
+    const int D = K->width;
+    double t = K->prob[i1]; K->prob[i1] = K->prob[i2]; K->prob[i2] = t;
+    for (int j = 0; j < D; ++j) {
+        t = K->data[i1 * D + j]; K->data[i1 * D + j] = K->data[i2 * D + j]; K->data[i2 * D + j] = t;
+    }
+}
+
+/* FermiK-aware shift of a pool slot: u = the pool's width uniforms, upick = the extra uniform of FermiK's move selection */
+static double pool_shift_any(mcio_config *c, int vi, int idx, double upick, const double *u) {
+    mcio_leaf *L0 = &c->leaf[c->pool_leaf0[vi]];
+    if (L0->kind == MCIO_FERMIK) return fermik_shift(L0, idx, upick, u);
+    return mcio_pool_shift(c, vi, idx, u);
+}
+
 /* pool-level shift!: plain variable, or CompositeVar  ref: sampler.jl:431-440 */
 double mcio_pool_shift(mcio_config *c, int vi, int idx, const double *u) {
     int l0 = c->pool_leaf0[vi], nl = c->pool_nleaf[vi];
@@ -585,6 +705,7 @@ double mcio_pool_shift(mcio_config *c, int vi, int idx, const double *u) {
 /* pool-level create!  ref: sampler.jl:410-418 */
 double mcio_pool_create(mcio_config *c, int vi, int idx, const double *u) {
     int l0 = c->pool_leaf0[vi], nl = c->pool_nleaf[vi];
+    if (c->leaf[l0].kind == MCIO_FERMIK) return fermik_create(&c->leaf[l0], idx, u);
     if (nl == 1) return mcio_create(c, l0, idx, u[0]);
     double prop = 1.0;             /* :411 */
     c->pool_prob[vi][idx] = 1.0;   /* :412 */
@@ -598,6 +719,10 @@ double mcio_pool_create(mcio_config *c, int vi, int idx, const double *u) {
 /* ref: sampler.jl:441-446 */
 void mcio_pool_shift_rollback(mcio_config *c, int vi, int idx) {
     int l0 = c->pool_leaf0[vi], nl = c->pool_nleaf[vi];
+    if (c->leaf[l0].kind == MCIO_FERMIK) {
+        fermik_shift_rollback(&c->leaf[l0], idx);
+        return;
+    }
     for (int l = 0; l < nl; ++l) mcio_shift_rollback(c, l0 + l, idx);
     if (nl != 1) c->pool_prob[vi][idx] = c->pool_prob_cache[vi];
 }
@@ -615,6 +740,7 @@ double mcio_remove(mcio_config *c, int leaf, int idx) {
 
 /* ref: sampler.jl:422-428 */
 double mcio_pool_remove(mcio_config *c, int vi, int idx) {
+    if (c->leaf[c->pool_leaf0[vi]].kind == MCIO_FERMIK) return fermik_remove(&c->leaf[c->pool_leaf0[vi]], idx);
     double prop = 1.0;
     for (int l = c->pool_leaf0[vi]; l < c->pool_leaf0[vi] + c->pool_nleaf[vi]; ++l) prop *= mcio_remove(c, l, idx);
     return prop;
@@ -623,6 +749,10 @@ double mcio_pool_remove(mcio_config *c, int vi, int idx) {
 /* swap! == swapRollback!  ref: sampler.jl:395-408 (Continuous), :86-97 (Discrete), :448-462 (CompositeVar) */
 double mcio_pool_swap(mcio_config *c, int vi, int idx1, int idx2) {
     int l0 = c->pool_leaf0[vi], nl = c->pool_nleaf[vi];
+    if (c->leaf[l0].kind == MCIO_FERMIK) {
+        fermik_swap(&c->leaf[l0], idx1, idx2);
+        return 1.0;
+    }
     if (nl != 1) { /* :450 */
         double t = c->pool_prob[vi][idx1];
         c->pool_prob[vi][idx1] = c->pool_prob[vi][idx2];
@@ -677,7 +807,7 @@ static inline void pool_accumulate(mcio_config *c, int vi, int idx, double weigh
 static inline void gather_x(const mcio_config *c, double *x) {
     for (int k = 0; k < c->ndraw; ++k) {
         const mcio_leaf *T = &c->leaf[c->draw_leaf[k]];
-        x[k] = T->data[c->draw_slot[k] + c->pool_offset[T->pool]];
+        x[k] = T->data[(c->draw_slot[k] + c->pool_offset[T->pool]) * T->width + c->draw_comp[k]];
     }
 }
 
@@ -715,6 +845,8 @@ int mcio_vegas_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint
                      uint32_t iteration, long block_index, long neval, long measurefreq) {
     const int Ni = c->Ni, npool = c->npool;
     if (c->ndraw > MCIO_MAXDRAW || Ni > MCIO_MAXNI || measurefreq <= 0) return -1; /* :77 */
+    for (int l = 0; l < c->nleaf; ++l)
+        if (c->leaf[l].kind == MCIO_FERMIK) return -4; /* "vegas doesn't work with FermiK variable yet" test/bubble_FermiK.jl:2 */
     const int nc = c->ncomp;
     double relw[2 * MCIO_MAXNI], weights[2 * MCIO_MAXNI], pad[MCIO_MAXNI]; /* :79-81 */
     int diff[MCIO_MAXNI];
@@ -791,6 +923,8 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
                        long nchain) {
     const int N = c->Ni, npool = c->npool, norm = c->Ni;
     if (c->ndraw > MCIO_MAXDRAW || N + 1 > MCIO_MAXNI || measurefreq <= 0 || nchain < 1) return -1;
+    for (int l = 0; l < c->nleaf; ++l)
+        if (c->leaf[l].kind == MCIO_FERMIK) return -4; /* test/bubble_FermiK.jl:133 "vegasmc can not handle this" */
     const int nc = c->ncomp;
     double weights[2 * MCIO_MAXNI], _weights[2 * MCIO_MAXNI], relw[2 * MCIO_MAXNI];
     double pad[MCIO_MAXNI], _pad[MCIO_MAXNI]; /* :147-148 */
@@ -966,7 +1100,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
     int nslots = 0;
     for (int vi = 0, k = 0; vi < npool; ++vi) {
         kbase[vi] = k;
-        k += c->maxdof[vi] * c->pool_nleaf[vi];
+        k += c->maxdof[vi] * c->pool_width[vi];
         nslots += c->maxdof[vi];
     }
     const long steps = neval / nchain;
@@ -982,7 +1116,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
             /* initialize!  :190-205 (only the slots that are ever read: 1..maxdof) */
             for (int vi = 0; vi < npool; ++vi)
                 for (int idx = 1; idx <= c->maxdof[vi]; ++idx) {
-                    int nl = c->pool_nleaf[vi];
+                    int nl = c->pool_width[vi];
                     for (int l = 0; l < nl; ++l)
                         u[l] = mcio_uniform(seed, st_init, g * 16384u + (uint64_t)t, (uint32_t)(kbase[vi] + (idx - 1) * nl + l));
                     mcio_pool_create(c, vi, idx + c->pool_offset[vi], u);
@@ -1022,7 +1156,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                     const int *cd = &c->dof[curr * npool], *nd = &c->dof[new_ * npool]; /* :9 */
                     double prop = (double)c->nneighbor[curr] / (double)c->nneighbor[new_]; /* :12 */
                     for (int vi = 0; vi < npool; ++vi) {            /* :15-26 */
-                        const int off = c->pool_offset[vi], nl = c->pool_nleaf[vi];
+                        const int off = c->pool_offset[vi], nl = c->pool_width[vi];
                         if (cd[vi] < nd[vi]) {
                             for (int pos = cd[vi] + 1; pos <= nd[vi]; ++pos) {
                                 for (int l = 0; l < nl; ++l)
@@ -1058,7 +1192,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                 const int *cd = &c->dof[curr * npool];
                 int vi = (int)floor(mcio_uniform(seed, st_step, sidx, 1) * npool); /* :77, :119 */
                 if (vi >= npool) vi = npool - 1;
-                const int off = c->pool_offset[vi], nl = c->pool_nleaf[vi];
+                const int off = c->pool_offset[vi], nl = c->pool_width[vi];
                 if (upd == 1) {
                     /* ---- swapVariable  updates.jl:113-147 ---- */
                     do {
@@ -1087,13 +1221,14 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                     /* ---- changeVariable  updates.jl:71-111 ---- */
                     do {
                         const mcio_leaf *v0 = &c->leaf[c->pool_leaf0[vi]];
-                        if (nl == 1 && v0->kind == MCIO_DISCRETE && v0->nbin == 1) break; /* :79-81 */
+                        if (c->pool_nleaf[vi] == 1 && v0->kind == MCIO_DISCRETE && v0->nbin == 1) break; /* :79-81 */
                         if (cd[vi] <= 0) break;                     /* :82 */
                         int slot = (int)floor(mcio_uniform(seed, st_step, sidx, 2) * cd[vi]) + 1; /* :83 */
                         if (slot > cd[vi]) slot = cd[vi];
                         for (int l = 0; l < nl; ++l)
                             u[l] = mcio_uniform(seed, st_step, sidx, (uint32_t)(5 + kbase[vi] + (slot - 1) * nl + l));
-                        const double prop = mcio_pool_shift(c, vi, slot + off, u); /* :85 */
+                        /* :85; a FermiK slot picks its move (scale / rotate / shift) with the otherwise unused uniform 3 */
+                        const double prop = pool_shift_any(c, vi, slot + off, mcio_uniform(seed, st_step, sidx, 3), u);
                         if (prop <= 4.9406564584124654e-324) break; /* :88-90 */
                         gather_x(c, x);
                         f(x, w, ud);                                /* :92 */

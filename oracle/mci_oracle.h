@@ -36,7 +36,7 @@ extern "C" {
 
 #define MCIO_TINY 4.940656458412465e-274 /* src/MCIntegration.jl:11  eps(0.0)*1e50 */
 
-enum { MCIO_CONTINUOUS = 0, MCIO_DISCRETE = 1 };
+enum { MCIO_CONTINUOUS = 0, MCIO_DISCRETE = 1, MCIO_FERMIK = 2 };
 enum { MCIO_VEGAS = 0, MCIO_VEGASMC = 1, MCIO_MCMC = 2 };
 /* how Continuous/Discrete prob[idx] is maintained per draw */
 enum {
@@ -67,6 +67,8 @@ typedef struct {
     double *data;         /* [P] */
     long *gidx;           /* [P] 1-based like the reference */
     double *prob;         /* [P] */
+    /* FermiK{D} (variable.jl:1-20; :mcmc only): lower = kF, upper = dk, npts = D, alpha = maxK; data is [P+1][D] */
+    int width;            /* x entries (and uniforms of create!) per slot: D for FermiK, 1 otherwise */
 } mcio_leaf;
 
 typedef struct {
@@ -102,6 +104,8 @@ typedef struct {
     double *reweight_goal; /* [Ni+1] or NULL  main.jl:81, :334-337 */
     int ncomp;             /* 1: Float64 weights; 2: ComplexF64 (`type` kwarg, configuration.jl:108) stored (re, im) */
     mcio_measure_fn measure_fn; /* NULL = default / bin-by-Discrete measure */
+    int *pool_width;       /* [npool] x entries per slot: number of leaves, or D for a FermiK pool */
+    int *draw_comp;        /* [ndraw] component within the leaf's slot (FermiK), 0 otherwise */
 } mcio_config;
 
 typedef struct {

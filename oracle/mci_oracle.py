@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libmci_oracle.so")
 
-CONTINUOUS, DISCRETE = 0, 1
+CONTINUOUS, DISCRETE, FERMIK = 0, 1, 2
 VEGAS, VEGASMC, MCMC = 0, 1, 2
 PROB_CREATE, PROB_SHIFT = 0, 1
 
@@ -35,7 +35,7 @@ class _Leaf(C.Structure):
                 ("npts", C.c_int), ("nbin", C.c_int), ("alpha", C.c_double), ("adapt", C.c_int),
                 ("grid", c_double_p), ("hist", c_double_p), ("accumulation", c_double_p),
                 ("distribution", c_double_p), ("P", C.c_int), ("data", c_double_p), ("gidx", c_long_p),
-                ("prob", c_double_p)]
+                ("prob", c_double_p), ("width", C.c_int)]
 
 
 class _Config(C.Structure):
@@ -48,7 +48,7 @@ class _Config(C.Structure):
                 ("reweight", c_double_p), ("visited", c_double_p), ("propose", c_double_p),
                 ("accept", c_double_p), ("prob_mode", C.c_int), ("npa", C.c_int), ("nneighbor", c_int_p),
                 ("neighbor", C.POINTER(c_int_p)), ("thermal_ratio", C.c_double), ("reweight_goal", c_double_p),
-                ("ncomp", C.c_int), ("measure_fn", C.c_void_p)]
+                ("ncomp", C.c_int), ("measure_fn", C.c_void_p), ("pool_width", c_int_p), ("draw_comp", c_int_p)]
 
 
 class _Result(C.Structure):

@@ -333,3 +333,20 @@ def test_auto_chain_counts_are_unbiased_on_sticky_integrands():
     dev = (res.mean[0] - ref.mean[0]) / np.hypot(res.stdev[0], ref.stdev[0])
     assert np.all(np.abs(dev) < 5.0), (res.mean[0], res.stdev[0], ref.mean[0], dev)
     assert np.all(res.stdev[0] < 0.01 * np.abs(ref.mean[0]))   # ... and the test can see a 2.7 % bias
+
+
+def test_bubble_with_fermik_momentum():
+    """test/bubble_FermiK.jl:93-131 (part of the reference's runtests.jl): vars = (T, K, Ext) with K = FermiK(3, kF, 0.2 kF,
+    10 kF), :mcmc, Steps = 2e5, two calls, every q within 5 sigma of the Lindhard function."""
+    from catalog_params import bubble_exact
+    p = mci.catalog.bubble_parameters()
+    exact = bubble_exact()
+    T = Continuous(0.0, p["beta"], alpha=3.0, adapt=True)
+    K = mci.FermiK(3, p["kF"], 0.2 * p["kF"], 10.0 * p["kF"])
+    Ext = Discrete(1, 4, adapt=False)
+    kw = dict(measure=mci.bin_by(2), var=(T, K, Ext), dof=[[1, 1, 1]], obs=[np.zeros(4)], solver="mcmc", neval=2e5, print=-1, block=16)
+    result = integrate(mci.catalog.bubble_fermik(), seed=91, **kw)
+    result = integrate(mci.catalog.bubble_fermik(), seed=92, **kw)
+    avg, std = result.mean[0], result.stdev[0]
+    for idx in range(4):
+        assert abs(avg[idx] - exact[idx]) < 5.0 * std[idx], (avg, std, exact)

@@ -389,6 +389,33 @@ def test_degenerate_pools_match_oracle(oracle, solver):
     assert np.all(np.abs(r["mean"] - exact) < 7.0 * r["stdev"]), (r["mean"], r["stdev"])
 
 
+@pytest.mark.parametrize("nchain", [1, 16])
+def test_mcmc_with_a_fermik_variable_matches_oracle(oracle, nchain):
+    """FermiK{3} (variable.jl:1-20, sampler.jl:109-281): joint create!/remove!/shift!/swap! of a 3-component slot under
+    :mcmc, two integrands with 1 and 2 momenta so that changeIntegrand creates/removes slots and swapVariable has work."""
+    kF, beta = 1.9191582926775128, 6.787997763336297
+    var = (mci.Continuous(0.0, beta, alpha=3.0), mci.FermiK(3, kF, 0.2 * kF, 10.0 * kF), mci.Discrete(1, 4, adapt=False))
+    dof = [[1, 1, 1], [1, 2, 1]]
+    body = """
+    const double k2a = x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    w[0] = exp(-0.3 * x[0]) * exp(-0.5 * k2a) * (1.0 + 0.1 * x[7]);
+    if (idx == 0) return;                                   // an :mcmc chain on integrand 1 has no second momentum
+    const double k2b = x[4] * x[4] + x[5] * x[5] + x[6] * x[6];
+    w[1] = exp(-0.2 * x[0]) * exp(-0.5 * (k2a + k2b)) * (1.0 + 0.05 * x[7] + 0.1 * x[1] * x[4]);"""
+    cfg = mci.Configuration(var=var, dof=dof, seed=SEED)
+    eng = mci.Engine(cfg, mci.Integrand(body))
+    assert eng.ndraw == 1 + 2 * 3 + 1
+    ocfg = oracle.Config([ocont(0, 0.0, beta, alpha=3.0), dict(kind=2, pool=1, lower=kF, upper=0.2 * kF, npts=3, alpha=10.0 * kF),
+                          odisc(2, 1, 4, adapt=False)], dof)
+    obody = body.replace("if (idx == 0) return;", "")      # the oracle evaluates every output (unused ones are ignored)
+    fn = oracle.compile_c_integrand(obody)
+    got = eng.iteration("mcmc", 3200, 0, 4, iteration=3, seed=SEED, nchain=nchain)
+    ref = ocfg.iteration(oracle.MCMC, fn, None, 3200, 0, 4, 3, SEED, nchain=nchain)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+    with pytest.raises(mci.MCIError):                       # "vegas doesn't work with FermiK variable yet"  test/bubble_FermiK.jl:2
+        eng.iteration("vegas", 3200, 0, 4, iteration=0, seed=SEED)
+
+
 def test_error_paths():
     """non-positive normalization (main.jl:269-271) and non-finite histogram (variable.jl:212) surface as errors."""
     cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]], seed=SEED)

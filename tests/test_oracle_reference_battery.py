@@ -234,3 +234,29 @@ def test_error_bars_have_the_size_the_reference_prints(oracle, case):
         sig.append(r["stdev"][0])
     ratio = float(np.exp(np.mean(np.log(sig)))) / case["printed_sigma"]
     assert 1.0 / 3.0 < ratio < 3.0, (case["name"], sig, case["printed_sigma"])
+
+
+def _fermik_bubble(oracle):
+    import catalog_params as cp
+    ud = cp.bubble_userdata()
+    kF, beta = ud[0], ud[1]
+    leaves = [cont(0, 0.0, beta, alpha=3.0), dict(kind=2, pool=1, lower=kF, upper=0.2 * kF, npts=3, alpha=10.0 * kF),
+              disc(2, 1, 4, adapt=False)]
+    import mcintegration_jl_amd as mci
+    fn = oracle.compile_c_integrand(mci.catalog.bubble_fermik().body)   # the same source text the HIP path JIT-compiles
+    return leaves, fn, ud, cp.bubble_exact()
+
+
+def test_mcmc_bubble_with_fermik_momentum(oracle):
+    # test/bubble_FermiK.jl:93-131 (in the reference's runtests.jl): T Continuous, K = FermiK(3, kF, 0.2 kF, 10 kF),
+    # Ext Discrete(adapt=false), :mcmc, Steps = 2e5, two runs, 5 sigma against the Lindhard function
+    leaves, fn, ud, exact = _fermik_bubble(oracle)
+    cfg = oracle.Config(leaves, [[1, 1, 1]], obs_nbin=[4], obs_bin_draw=[4])
+    assert cfg.ndraw == 5                                            # tau | k_x k_y k_z | ext
+    cfg.integrate(oracle.MCMC, fn, ud, neval=200000, block=16, seed=81)
+    r = cfg.integrate(oracle.MCMC, fn, ud, neval=200000, block=16, seed=82)
+    assert r["rc"] == 0
+    for k in range(4):
+        assert abs(r["mean"][k] - exact[k]) < 5.0 * r["stdev"][k], (k, r["mean"], r["stdev"], exact)
+    # "vegas doesn't work with FermiK variable yet" (test/bubble_FermiK.jl:2, :133)
+    assert cfg.integrate(oracle.VEGAS, fn, ud, neval=20000, niter=2, seed=83)["rc"] != 0

@@ -84,7 +84,7 @@ typedef struct {
     int64_t block;       /* statistical blocks per iteration, all ranks (standardised like main.jl:220-234) */
     int32_t ignore;      /* iterations excluded from the final average; <0 = (adapt ? 1 : 0) */
     int32_t adapt;
-    double gamma;        /* reweight learning rate (vegasmc) */
+    double gamma;        /* reweight learning rate (vegasmc, mcmc: doReweight!, main.jl:322-346) */
     int64_t measurefreq;
     uint64_t seed;
     int64_t nchain;      /* vegasmc, mcmc: independent chains per block (1 = the reference's single chain); 0 = auto */

@@ -11,6 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once (hipcc cross-compiles without a GPU)
+    lib = os.path.join(ROOT, "mcintegration.jl_amd", "lib", "libmci_hip.so")
+    demo = os.path.join(ROOT, "examples", "mci_demo")
+    if not (os.path.exists(lib) and os.path.exists(demo)):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")

@@ -48,6 +48,7 @@ def cpu_baseline(seconds_target=12.0):
     r = cfg.integrate(O.VEGAS, "gaussian", [float(D)], neval=neval, niter=3, block=block, seed=2, nthreads=cores)
     dt = time.time() - t0
     return {"value": round(3 * (neval // block) * block / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "estimate": [float(r["iter_mean"][-1, 0]), float(r["iter_std"][-1, 0])],
             "sample": "oracle/mci_oracle.c (C restatement, OpenMP over blocks), 16-D Gaussian :vegas, %d samples x 3 iterations, "
                       "block=%d, %.1f s; last-iteration estimate %.6f +- %.6f" % (neval, block, dt, r["iter_mean"][-1, 0], r["iter_std"][-1, 0])}
 
@@ -198,6 +199,9 @@ def main():
                                     "insts_per_launch": valu_insts, "note": "SQ_INSTS_VALU (rocprofv3 --pmc, profiles/) / live HIP-event kernel time"}
         if not a.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline()
+            cm, cs = out["cpu_baseline"]["estimate"]
+            # north star: "the estimate within 1 sigma of the CPU reference" -- the CPU run's last iteration vs the GPU estimate
+            out["estimate"]["vs_cpu_sigma"] = (mean - cm) / math.hypot(err, cs)
         print(json.dumps(out), flush=True)
     if world > 1 or force_comm:
         import torch.distributed as dist

@@ -565,25 +565,50 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
     static_for<1, Cfg::NTILE>([&](auto TT) {
         constexpr int tt = decltype(TT)::value;
         if (tile == tt) {
-            for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
-                const i64 idx = lb * a.neval_per_block + n;
-                double wh[Cfg::NI];
-                static_for<0, Cfg::NI>([&](auto I) { wh[decltype(I)::value] = a.tile_w[decltype(I)::value * a.tile_stride + idx]; });
-                static_for<0, Cfg::NDRAW>([&](auto K) {
-                    constexpr int k = decltype(K)::value;
-                    if constexpr (is_tdraw<Cfg>(k)) {
-                        constexpr int leaf = Cfg::draw_leaf(k);
-                        if constexpr (Cfg::leaf_tile(leaf) == tt) {
-                            constexpr int m = tdraw_pos<Cfg>(k);
-                            const u32 word = a.tile_bins[(m / 2) * a.tile_stride + idx]; // both halves of a word: one load (CSE)
-                            const int bin = (int)((word >> (16 * (m & 1))) & 0xFFFFu);
-                            double wk = 0.0;
-                            static_for<0, Cfg::NI>([&](auto I) {
-                                constexpr int i = decltype(I)::value;
-                                if constexpr ((Cfg::own_mask(i) >> k) & 1ull) wk += wh[i];
-                            });
-                            lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(tt) + bin], wk);
-                        }
+            // U samples per lane and trip: all their loads are issued before the first ds_add_f64 (the kernel has one
+            // 512-thread workgroup per CU, so memory-level parallelism has to come from the loop body)
+            constexpr int U = 4;
+            constexpr int NT = tdraw_count<Cfg>(), NWORD = (NT + 1) / 2;
+            for (i64 n0 = (i64)slice * T + tid; n0 < a.neval_per_block; n0 += stride * U) {
+                double wh[U][Cfg::NI];
+                u32 word[U][NWORD > 0 ? NWORD : 1];
+                bool live[U];
+                static_for<0, U>([&](auto Uu) {
+                    constexpr int u = decltype(Uu)::value;
+                    const i64 n = n0 + (i64)u * stride;
+                    live[u] = n < a.neval_per_block;
+                    const i64 idx = lb * a.neval_per_block + (live[u] ? n : n0);
+                    static_for<0, Cfg::NI>([&](auto I) { wh[u][decltype(I)::value] = a.tile_w[decltype(I)::value * a.tile_stride + idx]; });
+                    static_for<0, NWORD>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        // only the words that hold a draw of this tile
+                        constexpr bool need = [] {
+                            for (int k = 0; k < Cfg::NDRAW; ++k)
+                                if (is_tdraw<Cfg>(k) && Cfg::leaf_tile(Cfg::draw_leaf(k)) == tt && tdraw_pos<Cfg>(k) / 2 == j) return true;
+                            return false;
+                        }();
+                        if constexpr (need) word[u][j] = a.tile_bins[j * a.tile_stride + idx];
+                    });
+                });
+                static_for<0, U>([&](auto Uu) {
+                    constexpr int u = decltype(Uu)::value;
+                    if (live[u]) {
+                        static_for<0, Cfg::NDRAW>([&](auto K) {
+                            constexpr int k = decltype(K)::value;
+                            if constexpr (is_tdraw<Cfg>(k)) {
+                                constexpr int leaf = Cfg::draw_leaf(k);
+                                if constexpr (Cfg::leaf_tile(leaf) == tt) {
+                                    constexpr int m = tdraw_pos<Cfg>(k);
+                                    const int bin = (int)((word[u][m / 2] >> (16 * (m & 1))) & 0xFFFFu);
+                                    double wk = 0.0;
+                                    static_for<0, Cfg::NI>([&](auto I) {
+                                        constexpr int i = decltype(I)::value;
+                                        if constexpr ((Cfg::own_mask(i) >> k) & 1ull) wk += wh[u][i];
+                                    });
+                                    lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(tt) + bin], wk);
+                                }
+                            }
+                        });
                     }
                 });
             }

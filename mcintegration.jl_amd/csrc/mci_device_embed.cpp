@@ -570,25 +570,51 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
     static_for<1, Cfg::NTILE>([&](auto TT) {
         constexpr int tt = decltype(TT)::value;
         if (tile == tt) {
-            for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
-                const i64 idx = lb * a.neval_per_block + n;
-                double wh[Cfg::NI];
-                static_for<0, Cfg::NI>([&](auto I) { wh[decltype(I)::value] = a.tile_w[decltype(I)::value * a.tile_stride + idx]; });
-                static_for<0, Cfg::NDRAW>([&](auto K) {
-                    constexpr int k = decltype(K)::value;
-                    if constexpr (is_tdraw<Cfg>(k)) {
-                        constexpr int leaf = Cfg::draw_leaf(k);
-                        if constexpr (Cfg::leaf_tile(leaf) == tt) {
-                            constexpr int m = tdraw_pos<Cfg>(k);
-                            const u32 word = a.tile_bins[(m / 2) * a.tile_stride + idx]; // both halves of a word: one load (CSE)
-                            const int bin = (int)((word >> (16 * (m & 1))) & 0xFFFFu);
-                            double wk = 0.0;
-                            static_for<0, Cfg::NI>([&](auto I) {
-                                constexpr int i = decltype(I)::value;
-                                if constexpr ((Cfg::own_mask(i) >> k) & 1ull) wk += wh[i];
-                            });
-                            lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(tt) + bin], wk);
-                        }
+            // U samples per lane and trip: all their loads are issued before the first ds_add_f64 (the kernel has one
+            // 512-thread workgroup per CU, so memory-level parallelism has to come from the loop body)
+            constexpr int U = 4;
+            constexpr int NT = tdraw_count<Cfg>(), NWORD = (NT + 1) / 2;
+            for (i64 n0 = (i64)slice * T + tid; n0 < a.neval_per_block; n0 += stride * U) {
+                double wh[U][Cfg::NI];
+                u32 word[U][NWORD > 0 ? NWORD : 1];
+                bool live[U];
+                static_for<0, U>([&](auto Uu) {
+                    constexpr int u = decltype(Uu)::value;
+                    const i64 n = n0 + (i64)u * stride;
+                    live[u] = n < a.neval_per_block;
+                    const i64 idx = lb * a.neval_per_block + (live[u] ? n : n0);
+                    static_for<0, Cfg::NI>([&](auto I) { wh[u][decltype(I)::value] = a.tile_w[decltype(I)::value * a.tile_stride + idx]; });
+                    static_for<0, NWORD>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        // only the words that hold a draw of this tile
+                        constexpr bool need = [] {
+                            for (int k = 0; k < Cfg::NDRAW; ++k)
+                                if (is_tdraw<Cfg>(k) && Cfg::leaf_tile(Cfg::draw_leaf(k)) == tt && tdraw_pos<Cfg>(k) / 2 == j) return true;
+                            return false;
+                        }();
+                        if constexpr (need) word[u][j] = a.tile_bins[j * a.tile_stride + idx];
+                    });
+                });
+                static_for<0, U>([&](auto Uu) {
+                    constexpr int u = decltype(Uu)::value;
+                    if (live[u]) {
+                        static_for<0, Cfg::NDRAW>([&](auto K) {
+                            constexpr int k = decltype(K)::value;
+                            if constexpr (is_tdraw<Cfg>(k)) {
+                                constexpr int leaf = Cfg::draw_leaf(k);
+                                if constexpr (Cfg::leaf_tile(leaf) == tt) {
+                                    constexpr int m = tdraw_pos<Cfg>(k);
+                                    const int bin = (int)((word[u])MCIDEV"
+R"MCIDEV([m / 2] >> (16 * (m & 1))) & 0xFFFFu);
+                                    double wk = 0.0;
+                                    static_for<0, Cfg::NI>([&](auto I) {
+                                        constexpr int i = decltype(I)::value;
+                                        if constexpr ((Cfg::own_mask(i) >> k) & 1ull) wk += wh[u][i];
+                                    });
+                                    lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(tt) + bin], wk);
+                                }
+                            }
+                        });
                     }
                 });
             }
@@ -606,8 +632,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
 // (x, prob, bin per draw; weights; probability) stays in registers; the proposal touches one
 // (pool, slot), selected by a compile-time switch so that every table access keeps static offsets.
 //   chain g = block*nchain + ch
-//   init  : stream MC_INIT, index g,            k)MCIDEV"
-R"MCIDEV( = flat draw
+//   init  : stream MC_INIT, index g,            k = flat draw
 //   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
 // =============================================================================================
 template <class Cfg> struct Chain {
@@ -731,7 +756,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
             // not depend on the chain states): the pool dispatch below becomes a scalar branch
             double upool = u01(r0.x, r0.y);
             if (Cfg::NPOOL > 1 && a.nchain > 1) {
-                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)63)) << 32) | (u64)(ne - 1);
+                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)6)MCIDEV"
+R"MCIDEV(3)) << 32) | (u64)(ne - 1);
                 const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MC_GROUP, k0, k1);
                 upool = u01(rg.x, rg.y);
             }
@@ -755,8 +781,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                         int slot = (int)(uslot * (double)md); // :58
                         if (slot >= md) slot = md - 1;
                         static_for<0, nl>([&](auto Lf) {
-                 )MCIDEV"
-R"MCIDEV(           constexpr int l = decltype(Lf)::value;
+                            constexpr int l = decltype(Lf)::value;
                             constexpr int kk = 3 + l; // RNG draw index within the step
                             double y;
                             if constexpr (kk == 3) y = u01(r1.z, r1.w);
@@ -855,7 +880,8 @@ template <class Cfg, int V> __device__ __forceinline__ double fermik_create(cons
     constexpr double kF = Cfg::leaf_lower(leaf), dk = Cfg::leaf_upper(leaf);
     const double Kamp = kF + (u[0] - 0.5) * 2.0 * dk; // :121
     if (Kamp <= 0.0) return 0.0;                       // :122
-    const double phi = 2.0 * MCI_PI * u[1];            // :124
+    const double phi = 2.0 * MCI_PI * u[1];            // :12)MCIDEV"
+R"MCIDEV(4
     if constexpr (D == 3) {
         const double theta = MCI_PI * u[2];            // :126
         k[0] = Kamp * cos(phi) * sin(theta);           // :129-131
@@ -884,8 +910,7 @@ template <class Cfg, int V> __device__ __forceinline__ double fermik_remove(cons
         return 1.0 / (2 * dk * 2 * MCI_PI * Kamp);                  // :183
     }
 }
-// shift!  sampler.jl:198-246: scale | rotate | shift, picked by upick; u = up to D more uni)MCIDEV"
-R"MCIDEV(forms; k is updated in place
+// shift!  sampler.jl:198-246: scale | rotate | shift, picked by upick; u = up to D more uniforms; k is updated in place
 template <class Cfg, int V> __device__ __forceinline__ double fermik_shift(double upick, const double *u, double *k) {
     constexpr int D = Cfg::pool_nleaf(V), leaf = Cfg::draw_leaf(Cfg::pool_first_draw(V));
     constexpr double dk = Cfg::leaf_upper(leaf);
@@ -1014,7 +1039,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
         double probability = 1.0;
         for (int tr = 0; tr < 10000; ++tr) {    // :118-124
             Sample<Cfg> s;
-            draw_sample<Cfg>(t, a.seed, st_init, g * 16384ull + (u64)tr, s); // initialize!  :190-193
+            draw_sample<Cfg>(t, a.seed, st_init, g * 16384ull + (u64)tr, s); // initi)MCIDEV"
+R"MCIDEV(alize!  :190-193
             static_for<0, Cfg::NDRAW>([&](auto K) {
                 constexpr int k = decltype(K)::value;
                 c.x[k] = s.x[k];
@@ -1037,8 +1063,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                             kk[decltype(J)::value] = kF / sqrt((double)D); // variable.jl:13: the pool's initial content
                         });
                         (void)fermik_create<Cfg, v>(u, kk);
-                        static_for<0, D>([)MCIDEV"
-R"MCIDEV(&](auto J) { c.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
+                        static_for<0, D>([&](auto J) { c.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
                     });
                 }
             });
@@ -1124,7 +1149,8 @@ R"MCIDEV(&](auto J) { c.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
                                                 prop *= ip;
                                             });
                                         } else if constexpr (cd > nd) {
-                                            static_for<nd * nl, cd * nl>([&](auto Q) { // remove!  sampler.jl:318-323, :36-40
+                                            static_for<nd * nl, cd * )MCIDEV"
+R"MCIDEV(nl>([&](auto Q) { // remove!  sampler.jl:318-323, :36-40
                                                 prop *= c.prob[k00 + decltype(Q)::value];
                                             });
                                         }
@@ -1153,8 +1179,7 @@ R"MCIDEV(&](auto J) { c.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
                         if (s1 != s2) { // :124
                             active = true;
                             static_for<0, NPOOL>([&](auto V) {
-                                constexpr int v = dec)MCIDEV"
-R"MCIDEV(ltype(V)::value;
+                                constexpr int v = decltype(V)::value;
                                 if (vi == v) {
                                     static_for<0, Cfg::pool_nleaf(v)>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
                                         constexpr int l = decltype(Lf)::value;
@@ -1246,7 +1271,8 @@ R"MCIDEV(ltype(V)::value;
                                 double rwv[Cfg::NW];
                                 static_for<0, Cfg::NW>([&](auto Q) { rwv[decltype(Q)::value] = 0.0; });
                                 static_for<0, Cfg::NCOMP>([&](auto Q) { rwv[i * Cfg::NCOMP + decltype(Q)::value] = relw[decltype(Q)::value]; });
-                                Cfg::measure(c.x, rwv, a.ud, i, sO);
+         )MCIDEV"
+R"MCIDEV(                       Cfg::measure(c.x, rwv, a.ud, i, sO);
                             } else if constexpr (Cfg::obs_bin_draw(i) >= 0) {
                                 const int b = c.bin[Cfg::obs_bin_draw(i)];
                                 if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw[0]);
@@ -1277,8 +1303,7 @@ template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs 
     t.DA = sDA;
     t.DD = sDD;
     const u32 stream = a.iteration * 8u + STREAM_VEGAS;
-    for (i64 n = (i64)blockIdx.x * blo)MCIDEV"
-R"MCIDEV(ckDim.x + threadIdx.x; n < a.n; n += (i64)gridDim.x * blockDim.x) {
+    for (i64 n = (i64)blockIdx.x * blockDim.x + threadIdx.x; n < a.n; n += (i64)gridDim.x * blockDim.x) {
         Sample<Cfg> s;
         draw_sample<Cfg>(t, a.seed, stream, (u64)(a.first_index + n), s);
         if (a.soa) {

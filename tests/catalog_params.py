@@ -37,6 +37,29 @@ def bubble_exact():
     return [lindhard(q, p) for q in p["extQ"]]
 
 
+def bubble_exact_finite_T(nk=1000, nc=500, kmax=5.0):
+    """The static polarisation the bubble integrand actually integrates to: example/bubble.jl:24-36 is the T = 0 closed form,
+    the integrand (bubble.jl:38-75) runs at beta*EF = 25 with mu = EF.  Pi(q) = spin * int d^3k/(2pi)^3 (f(w1)-f(w2))/(w1-w2),
+    Gauss-Legendre in (k, cos theta); converged to 1e-10 at the default orders (differs from T = 0 by ~7e-5..1.5e-4)."""
+    p = bubble_para()
+    kF, beta, me, spin = p["kF"], p["beta"], p["me"], p["spin"]
+    f = lambda w: 0.5 * (1 - np.tanh(0.5 * beta * w))
+    df = lambda w: -beta * 0.25 / np.cosh(np.clip(0.5 * beta * w, -300, 300)) ** 2
+    kk, wk = np.polynomial.legendre.leggauss(nk)
+    cc, wc = np.polynomial.legendre.leggauss(nc)
+    k = 0.5 * kmax * kF * (kk + 1)
+    K, Cc = np.meshgrid(k, cc, indexing="ij")
+    out = []
+    for q in p["extQ"]:
+        w1 = (K * K - kF * kF) / (2 * me)
+        w2 = (K * K + 2 * K * q * Cc + q * q - kF * kF) / (2 * me)
+        d = w1 - w2
+        small = np.abs(d) < 1e-7
+        val = np.where(small, df(0.5 * (w1 + w2)), (f(w1) - f(w2)) / np.where(small, 1.0, d))
+        out.append(float(np.einsum("i,j,ij->", 0.5 * kmax * kF * wk * k * k, wc, val) * 2 * math.pi / (2 * math.pi) ** 3 * spin))
+    return out
+
+
 def genz_userdata(D=32, a=5.0):
     u = [0.3 + 0.4 * i / (D - 1) for i in range(D)]
     return [float(D), a] + u

@@ -89,14 +89,34 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         comm_kind = os.environ.get("MCI_COMM", "rccl")
         if comm_kind == "rccl":
-            try:
-                comm = RcclComm.from_torch_distributed(local_rank)  # ncclAllReduce inside the library, on its stream
-            except Exception as e:  # pragma: no cover - exercised only on multi-GPU nodes
+            # ncclAllReduce inside the library, on its stream.  The bootstrap runs under a watchdog: a rank that cannot
+            # join within 120 s must not hang the job, and all ranks have to agree on the reducer they use.
+            import threading
+            box = {}
+
+            def boot():
+                try:
+                    box["comm"] = RcclComm.from_torch_distributed(local_rank)
+                except Exception as e:  # pragma: no cover - exercised only on multi-GPU nodes
+                    box["err"] = e
+            th = threading.Thread(target=boot, daemon=True)
+            if os.environ.get("MCI_BOOT_INLINE", "0") != "0":
+                boot()
+            else:
+                th.start()
+                th.join(120.0)
+            ok = torch.tensor([1 if "comm" in box else 0], dtype=torch.int32, device="cuda:%d" % local_rank)
+            if not th.is_alive():   # (a stuck bootstrap thread may sit inside a torch collective: do not issue another one)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                comm = box["comm"]
+            else:  # pragma: no cover
                 if rank == 0:
-                    print("[bench] library RCCL init failed (%s); using torch.distributed all_reduce" % e, file=sys.stderr)
+                    print("[bench] library RCCL bootstrap failed (%s); using torch.distributed all_reduce on the device buffer"
+                          % box.get("err", "timeout"), file=sys.stderr)
                 comm_kind = "torch"
         if comm_kind == "torch":
-            comm = TorchDistComm(tensor_device="cuda:%d" % local_rank)
+            comm = TorchDistComm(tensor_device="cuda:%d" % local_rank)  # zero copy, on the library's stream
 
     def barrier():
         if world > 1 or force_comm:
@@ -202,11 +222,19 @@ def main():
             cm, cs = out["cpu_baseline"]["estimate"]
             # north star: "the estimate within 1 sigma of the CPU reference" -- the CPU run's last iteration vs the GPU estimate
             out["estimate"]["vs_cpu_sigma"] = (mean - cm) / math.hypot(err, cs)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)   # RCCL's start-up banner sits in the C stdio buffer: the JSON line stays the last line of stdout
         print(json.dumps(out), flush=True)
     if world > 1 or force_comm:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    # orderly release while the HIP runtime is still up, then leave without the interpreter's teardown: the destruction
+    # order of torch, RCCL and the HIP runtime at exit is not ours to control (seen once: glibc "double free" after the result)
+    eng.close()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

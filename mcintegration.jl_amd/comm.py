@@ -43,20 +43,40 @@ class RcclComm:
         engine.reduce()
 
 
+class _DeviceBuffer:
+    """a raw device pointer dressed for torch.as_tensor (zero copy)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
 class TorchDistComm:
-    """External reducer through torch.distributed (gloo on CPU tensors, or nccl == RCCL on the GPU):
-    packed buffer out of the engine, all_reduce(SUM), back in."""
+    """External reducer through torch.distributed: all_reduce(SUM) of the packed buffer.
+    tensor_device="cpu" (gloo): packed buffer out of the engine, reduced on the host, back in.
+    tensor_device="cuda:N" (nccl == RCCL): zero copy -- the engine's device buffer is wrapped as a tensor and the
+    collective is issued with the library's stream current, so it is ordered between the sample pass and the
+    refinement without any host synchronisation."""
 
     def __init__(self, group=None, tensor_device="cpu"):
         import torch.distributed as dist
         self.group, self.tensor_device = group, tensor_device
         self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
+        self._view = (None, None, None)   # (ptr, tensor, external stream)
 
     def all_reduce(self, engine):
         import torch
         import torch.distributed as dist
-        t = torch.from_numpy(np.ascontiguousarray(engine.get_packed()))
-        if self.tensor_device != "cpu":
-            t = t.to(self.tensor_device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        engine.set_packed(t.cpu().numpy())
+        if self.tensor_device == "cpu":
+            t = torch.from_numpy(np.ascontiguousarray(engine.get_packed()))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            engine.set_packed(t.numpy())
+            return
+        ptr = engine.packed_device_ptr()
+        if not ptr:
+            raise RuntimeError("the engine has no device buffer to reduce")
+        if self._view[0] != ptr:
+            t = torch.as_tensor(_DeviceBuffer(ptr, engine.packed_size), device=self.tensor_device)
+            self._view = (ptr, t, torch.cuda.ExternalStream(engine.stream(), device=self.tensor_device))
+        _, t, ext = self._view
+        with torch.cuda.stream(ext):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

@@ -193,6 +193,10 @@ class Engine:
     def packed_device_ptr(self):
         return lib().mci_packed_device_ptr(self.p)
 
+    def stream(self):
+        """the library's hipStream_t (as an integer), for callers that order their own work with ours"""
+        return lib().mci_ctx_stream(context(self.device)) or 0
+
     def save_state(self, path):
         """grids, distributions and reweight -> MCISTATE file (resume across processes)"""
         check(lib().mci_save_state(self.p, str(path).encode()))

@@ -199,6 +199,33 @@ def test_library_rccl_single_rank_and_torch_reducer():
     check(res, 2.0 / 3.0)
 
 
+def test_torch_nccl_reducer_works_on_the_device_buffer_in_place():
+    """TorchDistComm on a cuda device: the engine's packed buffer is wrapped zero-copy and all-reduced by torch's RCCL
+    process group on the library's stream (the bench's fallback when the library cannot bootstrap RCCL itself)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from mcintegration_jl_amd.comm import TorchDistComm
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        comm = TorchDistComm(tensor_device="cuda:0")
+        cfg = Configuration(var=Continuous(0.0, 1.0), dof=[[2]], seed=3)
+        eng = mci.Engine(cfg, mci.catalog.x2y2())
+        eng.run("vegas", 5000, 0, 4, 0, 3)
+        before = eng.get_packed()
+        comm.all_reduce(eng)
+        np.testing.assert_array_equal(eng.get_packed(), before)
+        assert comm._view[1].data_ptr() == eng.packed_device_ptr()          # zero copy
+        res = integrate(mci.catalog.x2y2(), var=Continuous(0.0, 1.0), dof=[[2]], solver="vegas", neval=1e5, seed=4, comm=comm)
+        ref = integrate(mci.catalog.x2y2(), var=Continuous(0.0, 1.0), dof=[[2]], solver="vegas", neval=1e5, seed=4)
+        np.testing.assert_allclose(res.mean[0], ref.mean[0], rtol=1e-12)     # a 1-rank sum changes nothing
+    finally:
+        dist.destroy_process_group()
+
+
 def test_state_file_round_trip_resumes_in_a_new_problem(tmp_path):
     """SURVEY 8f2: trained grids / distributions / reweight survive a process boundary through an MCISTATE file;
     a fresh Configuration that loads it starts as well trained as `config=res.config` does (docs/src/index.md:129)."""

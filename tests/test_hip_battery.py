@@ -226,6 +226,33 @@ def test_torch_nccl_reducer_works_on_the_device_buffer_in_place():
         dist.destroy_process_group()
 
 
+def test_outer_threads_run_independent_integrations_concurrently():
+    """test/thread.jl:1-38 "outer Threads": host threads call integrate at the same time, each with its own variables and
+    configuration (they share the process's device context and stream); every (power, solver) pair must come out right and
+    equal to the same call made alone."""
+    import threading
+    out, errs = {}, []
+
+    def one(i, alg):
+        body = "return %s;" % "*".join(["x[0]"] * i)
+        return integrate(body, var=(Continuous(0.0, 1.0),), dof=[[1]], print=-1, solver=alg, seed=500 + i, neval=2e5 if alg != "mcmc" else 1e5)
+
+    def work(i):
+        try:
+            for alg in ("vegas", "vegasmc", "mcmc"):
+                out[(i, alg)] = one(i, alg)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i,)) for i in (1, 2, 3)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for (i, alg), res in out.items():
+        check(res, 1.0 / (1 + i))
+        alone = one(i, alg)
+        np.testing.assert_allclose(res.mean[0], alone.mean[0], rtol=1e-9 if alg == "vegas" else 1e-6)
+
+
 def test_state_file_round_trip_resumes_in_a_new_problem(tmp_path):
     """SURVEY 8f2: trained grids / distributions / reweight survive a process boundary through an MCISTATE file;
     a fresh Configuration that loads it starts as well trained as `config=res.config` does (docs/src/index.md:129)."""

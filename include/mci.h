@@ -164,6 +164,10 @@ int mci_iteration_finish(mci_problem *prob, int32_t solver, int64_t block_total,
 int mci_integrate(mci_problem *prob, const mci_integrate_args *args, mci_result *result);
 
 /* ---- state access: res.config.var[i].grid etc. (docs/src/index.md:129) and external reducers ---- */
+/* :mcmc diagnostic of the last launch on this rank: out64[b] = number of chains whose longest holding time h (steps
+ * during which a live slot, or the integrand index, did not change; holds still running at the end count) has
+ * bit_width(h) == b.  The next automatic chain length is 16 * 2^(top occupied b). */
+int mci_get_hold_histogram(mci_problem *prob, uint64_t *out64);
 /* the statistics head [obsSum|obsSqSum|normalization|neval|visited] of the last `nrows` finished
  * iterations (oldest first), nstat = 2*nobs+2+N+1 doubles per row: the per-iteration history that
  * `Result.iterations` is built from (statistics.jl:24-33), kept on the device until asked for */
@@ -208,6 +212,11 @@ double mci_chain_burnin(int64_t steps, int64_t nchain, int32_t nslots);
 /* burn-in steps an MCMC chain runs before its `steps` measured ones: floor(steps*thermal_ratio)
  * (mcmc/montecarlo.jl:133); with nchain > 1 at least 64*nslots + 16*(npool+1)*nd */
 int64_t mci_mcmc_burnin(int64_t steps, int64_t nchain, int32_t nslots, int32_t nd, int32_t npool, double thermal_ratio);
+/* chains per block of an :mcmc launch with nchain = 0 ("automatic"; the reference has no counterpart: it runs one chain
+ * per block).  hold_max = 0: nothing measured yet, chains of >= 131072 measured steps; otherwise chains of
+ * max(16*hold_max, 8 burn-in floors) steps, capped so that one GPU gets at most 131072 chains */
+int64_t mci_mcmc_auto_chains(int64_t nevalperblock, int64_t nblocks, int32_t nslots, int32_t nd, int32_t npool,
+                             int64_t hold_max);
 void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out);        /* configuration.jl:229-236 */
 void mci_mean_std(const double *obs_sum, const double *obs_sq, int64_t n, int64_t block, double *mean,
                   double *std);                                                      /* main.jl:296-320 */

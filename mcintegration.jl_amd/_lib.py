@@ -93,6 +93,8 @@ SIGNATURES = [
     ("mci_standardize_block", None, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("mci_chain_burnin", C.c_double, [C.c_int64, C.c_int64, C.c_int32]),
     ("mci_mcmc_burnin", C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
+    ("mci_mcmc_auto_chains", C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
+    ("mci_get_hold_histogram", C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     ("mci_maxdof", None, [c_int32_p, C.c_int32, C.c_int32, c_int32_p]),
     ("mci_mean_std", None, [c_double_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p]),
     ("mci_average", None, [c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),

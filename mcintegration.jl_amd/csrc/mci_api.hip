@@ -131,6 +131,9 @@ struct mci_problem {
     std::vector<double> h_goal; // reweight_goal (main.jl:81); empty = none
     double *d_goal = nullptr;
     double *d_pa = nullptr; // [2*NPA] propose | accept of the last iteration (this rank)
+    unsigned long long *d_hold = nullptr; // [64] :mcmc holding-time histogram of the last launch (this rank), see mci_get_hold_histogram
+    bool hold_pending = false;            // d_hold has not been looked at yet
+    int64_t hold_max = 0;                 // upper edge of its top occupied bucket; 0: no :mcmc launch seen yet
     // split vegas pass (NTILE > 1): per-sample histogram weights and 16-bit bins of the tiles >= 1
     double *d_tile_w = nullptr;
     uint32_t *d_tile_bins = nullptr;
@@ -599,6 +602,7 @@ int mci_problem_destroy(mci_problem *p) {
             if (p->module[k]) (void)hipModuleUnload(p->module[k]);
         if (p->d_goal) (void)hipFree(p->d_goal);
         if (p->d_pa) (void)hipFree(p->d_pa);
+        if (p->d_hold) (void)hipFree(p->d_hold);
         if (p->d_loop) (void)hipFree(p->d_loop);
         if (p->d_hx) (void)hipFree(p->d_hx);
         if (p->d_hw) (void)hipFree(p->d_hw);
@@ -750,10 +754,13 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // to lose that bias (tools/bubble_mcmc_bias.py); only chains much longer than the mixing time are safe, which
             // is what the reference's one-chain-per-block gives.  More chains: raise `block` (the reference's own knob) or
             // pass nchain explicitly for integrands known to mix fast (C5: 10 Gsteps/s at nchain = 4096).
-            nchain = nevalperblock / mci_problem::kMcmcMinSteps;
-            const int64_t cap = mci_problem::kChainFill / nblocks > 64 ? mci_problem::kChainFill / nblocks : 64;
-            if (nchain > cap) nchain = cap;
-            if (nchain < 1) nchain = 1;
+            // From the second :mcmc launch of a problem on, the length follows what the previous launch measured: 16 x the
+            // longest time any chain's slot (or integrand index) went without changing (mci_mcmc_auto_chains).
+            if (p->hold_pending && !p->graph_mode) {
+                uint64_t hh[64];
+                if ((rc = mci_get_hold_histogram(p, hh))) return rc;
+            }
+            nchain = mci_mcmc_auto_chains(nevalperblock, nblocks, nslots, p->ni + 1, p->npool, p->hold_max);
         }
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
         nburn = mci_mcmc_burnin(nevalperblock / nchain, nchain, nslots, p->ni + 1, p->npool, thermal_ratio);
@@ -813,6 +820,12 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.nchain = nchain;
     a.burnin = burnin;
     a.nburn = nburn;
+    if (solver == MCI_MCMC && !p->graph_mode && nevalperblock / nchain + nburn < ((int64_t)1 << 31) - 1) {
+        if (!p->d_hold) HIPCHK(hipMalloc((void **)&p->d_hold, 64 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(p->d_hold, 0, 64 * sizeof(unsigned long long), p->ctx->stream));
+        a.hold_hist = p->d_hold;
+        p->hold_pending = true;
+    }
     a.status = p->d_status;
     a.tile_w = p->d_tile_w;
     a.tile_bins = p->d_tile_bins;
@@ -1397,6 +1410,38 @@ int64_t mci_mcmc_burnin(int64_t steps, int64_t nchain, int32_t nslots, int32_t n
         if (fl > nburn) nburn = fl;
     }
     return nburn;
+}
+
+int64_t mci_mcmc_auto_chains(int64_t nevalperblock, int64_t nblocks, int32_t nslots, int32_t nd, int32_t npool, int64_t hold_max) {
+    // chain length: kMcmcMinSteps while nothing has been measured; afterwards 16 x the longest holding time of the previous
+    // launch, and never fewer than 8 burn-in floors.  Calibration (profiles/r01_chain_bias.txt): on the bubble diagram chains
+    // of 1-2 x that holding time are ~1e-3 off, chains of 8 x are unbiased at the 5e-4 level of the measurement.
+    int64_t len = mci_problem::kMcmcMinSteps;
+    if (hold_max > 0) {
+        const int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(npool + 1) * nd;
+        len = 16 * hold_max > 8 * fl ? 16 * hold_max : 8 * fl;
+    }
+    int64_t nchain = nevalperblock / len;
+    const int64_t cap = mci_problem::kChainFill / (nblocks > 0 ? nblocks : 1) > 64 ? mci_problem::kChainFill / (nblocks > 0 ? nblocks : 1) : 64;
+    if (nchain > cap) nchain = cap;
+    if (nchain < 1) nchain = 1;
+    return nchain;
+}
+
+int mci_get_hold_histogram(mci_problem *p, uint64_t *out64) {
+    if (!p || !out64) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    memset(out64, 0, 64 * sizeof(uint64_t));
+    if (!p->d_hold) return MCI_OK;
+    HIPCHK(hipSetDevice(p->ctx->device));
+    HIPCHK(hipMemcpyAsync(out64, p->d_hold, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    p->hold_pending = false;
+    int top = -1;
+    for (int b = 0; b < 64; ++b)
+        if (out64[b]) top = b;
+    if (top >= 0) p->hold_max = (int64_t)1 << top; // bucket b holds bit_width(h) == b, i.e. h < 2^b
+    return MCI_OK;
 }
 
 void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out) {

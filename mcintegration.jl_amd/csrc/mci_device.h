@@ -112,6 +112,9 @@ struct BatchArgs {
     // hipGraph replay of the iteration chain: the iteration index then lives in device memory (k_finish/k_train
     // advance it), so that the captured launch parameters never change.  NULL: use `iteration`.
     const u32 *iter_ptr;
+    // mcmc: [64] histogram over the chains of this launch of bit_width(longest holding time), the longest run of steps
+    // during which a live slot (or the integrand index) of the chain did not change; feeds the automatic chain length
+    unsigned long long *hold_hist;
 };
 __device__ __forceinline__ u32 iteration_of(const BatchArgs &a) { return a.iter_ptr ? *a.iter_ptr : a.iteration; }
 
@@ -1070,6 +1073,10 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
         }
         if (curr != NORMI && probability == 0.0) atomicOr(a.status, ST_MCMC_INIT); // :125-126 error(...)
 
+        // holding times (this engine's own diagnostic, DESIGN.md "chains"): step of the last change of every slot and of
+        // the integrand index, and the longest completed or still running hold
+        int last[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1], lastc = 0, hmax = 0;
+        static_for<0, Cfg::NDRAW>([&](auto K) { last[decltype(K)::value] = 0; });
         for (i64 it = 1; it <= steps + nburn; ++it) { // :134
             const u64 sidx = (g << 32) | (u64)(it - 1);
             static_for<0, ND>([&](auto I) { extra[XV + decltype(I)::value] += curr == decltype(I)::value ? 1.0 : 0.0; }); // :136
@@ -1236,6 +1243,28 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                     extra[XP + decltype(U)::value] += ut == decltype(U)::value ? 1.0 : 0.0;           // :48, :99, :140
                     extra[XA + decltype(U)::value] += (ok && ut == decltype(U)::value) ? 1.0 : 0.0;   // :50, :101, :142
                 });
+                if (a.hold_hist) {
+                    const int now = (int)it;
+                    u64 mo = 0ull, mn = 0ull; // live draws of the old and of the proposed integrand
+                    static_for<0, NI>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        mo = curr == i ? Cfg::own_mask(i) : mo;
+                        mn = newcurr == i ? Cfg::own_mask(i) : mn;
+                    });
+                    static_for<0, Cfg::NDRAW>([&](auto K) {
+                        constexpr int k = decltype(K)::value;
+                        // changeIntegrand: the slots it creates start their first hold (they held nothing before);
+                        // changeVariable / swapVariable: a slot whose value really changed ends a hold
+                        const bool chg = ok && (ut == 0 ? (((mn & ~mo) >> k) & 1ull) != 0ull : n.x[k] != c.x[k]);
+                        const int hold = now - last[k];
+                        hmax = (chg && ut != 0 && hold > hmax) ? hold : hmax;
+                        last[k] = chg ? now : last[k];
+                    });
+                    const bool chg = ok && newcurr != curr;
+                    const int hold = now - lastc;
+                    hmax = (chg && hold > hmax) ? hold : hmax;
+                    lastc = chg ? now : lastc;
+                }
                 if (ok) {
                     c = n;
                     curr = newcurr;                                                             // :51-53
@@ -1274,6 +1303,18 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                     extra[XN] += 1.0 / rw[NORMI]; // :158
                 }
             }
+        }
+        if (a.hold_hist) { // holds still running when the chain ends count with their length so far
+            const int tot = (int)(steps + nburn);
+            hmax = (tot - lastc > hmax) ? tot - lastc : hmax;
+            static_for<0, NI>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if (curr == i) static_for<0, Cfg::NDRAW>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
+                });
+            });
+            atomicAdd(&a.hold_hist[hmax <= 0 ? 0 : 32 - __clz(hmax)], 1ull);
         }
     }
     __syncthreads();

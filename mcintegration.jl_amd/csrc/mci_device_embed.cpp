@@ -114,6 +114,9 @@ struct BatchArgs {
     // hipGraph replay of the iteration chain: the iteration index then lives in device memory (k_finish/k_train
     // advance it), so that the captured launch parameters never change.  NULL: use `iteration`.
     const u32 *iter_ptr;
+    // mcmc: [64] histogram over the chains of this launch of bit_width(longest holding time), the longest run of steps
+    // during which a live slot (or the integrand index) of the chain did not change; feeds the automatic chain length
+    unsigned long long *hold_hist;
 };
 __device__ __forceinline__ u32 iteration_of(const BatchArgs &a) { return a.iter_ptr ? *a.iter_ptr : a.iteration; }
 
@@ -142,13 +145,13 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void global_add(double *p, double v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RE)MCIDEV"
+R"MCIDEV(LAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
 // table placement.  TABLE_MODE 0: grids + histograms in LDS; 1: grids in LDS, histograms via
-// global f64 atomics; 2: everything from L2/H)MCIDEV"
-R"MCIDEV(BM (grids too large for 160 KiB).
+// global f64 atomics; 2: everything from L2/HBM (grids too large for 160 KiB).
 // ---------------------------------------------------------------------------------------------
 //   TABLE_MODE 3: histograms in LDS, grids gathered from L2 (more than ~9 independent grids: the
 //   ds_add_f64 is the part that must not go to global memory); when all histograms do not fit either they
@@ -295,7 +298,8 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
                         sE[poff + 2 * i] = g0;
                         sE[poff + 2 * i + 1] = g1 - g0;
                     }
-                }
+)MCIDEV"
+R"MCIDEV(                }
             });
         } else {
             for (int i = tid; i < Cfg::NEDGE; i += T) sE[i] = gE[i];
@@ -305,8 +309,7 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
     for (int i = tid; i < Cfg::NDDIST; i += T) sDD[i] = gDD[i];
 }
 
-// LDS c)MCIDEV"
-R"MCIDEV(arve (doubles).  Order: grid table | dacc | ddist | hist | obs | reduction scratch
+// LDS carve (doubles).  Order: grid table | dacc | ddist | hist | obs | reduction scratch
 template <class Cfg> struct Lds {
     static constexpr int E = 0;
     static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
@@ -453,14 +456,14 @@ struct WorkItem {
     i64 rowid, lb;
     int slice, tile;
 };
-template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchArgs &a) {
+template <class Cfg> __device__ __forceinline__ WorkItem work_item(const Batc)MCIDEV"
+R"MCIDEV(hArgs &a) {
     WorkItem w;
     w.tile = Cfg::NTILE == 1 ? 0 : (int)(blockIdx.x % Cfg::NTILE);
     w.rowid = Cfg::NTILE == 1 ? (i64)blockIdx.x : (i64)(blockIdx.x / Cfg::NTILE);
     w.lb = w.rowid / a.wg_per_block;
     w.slice = (int)(w.rowid % a.wg_per_block);
-    return w;)MCIDEV"
-R"MCIDEV(
+    return w;
 }
 
 // =============================================================================================
@@ -601,11 +604,11 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
                         static_for<0, Cfg::NDRAW>([&](auto K) {
                             constexpr int k = decltype(K)::value;
                             if constexpr (is_tdraw<Cfg>(k)) {
-                                constexpr int leaf = Cfg::draw_leaf(k);
+             )MCIDEV"
+R"MCIDEV(                   constexpr int leaf = Cfg::draw_leaf(k);
                                 if constexpr (Cfg::leaf_tile(leaf) == tt) {
                                     constexpr int m = tdraw_pos<Cfg>(k);
-                                    const int bin = (int)((word[u])MCIDEV"
-R"MCIDEV([m / 2] >> (16 * (m & 1))) & 0xFFFFu);
+                                    const int bin = (int)((word[u][m / 2] >> (16 * (m & 1))) & 0xFFFFu);
                                     double wk = 0.0;
                                     static_for<0, Cfg::NI>([&](auto I) {
                                         constexpr int i = decltype(I)::value;
@@ -752,12 +755,12 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
             const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
             const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
             // ---- changeVariable  updates.jl:45-106 ----
-            // :50 rand(1:Nv).  With many chains per block the 64 chains of a wave share the pool-pick sequence (it does
+            // :50 rand(1:Nv).  With many chains per block the 64 chains of a wave share the pool-pick se)MCIDEV"
+R"MCIDEV(quence (it does
             // not depend on the chain states): the pool dispatch below becomes a scalar branch
             double upool = u01(r0.x, r0.y);
             if (Cfg::NPOOL > 1 && a.nchain > 1) {
-                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)6)MCIDEV"
-R"MCIDEV(3)) << 32) | (u64)(ne - 1);
+                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)63)) << 32) | (u64)(ne - 1);
                 const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MC_GROUP, k0, k1);
                 upool = u01(rg.x, rg.y);
             }
@@ -876,12 +879,12 @@ R"MCIDEV(3)) << 32) | (u64)(ne - 1);
 #define MCI_PI 3.14159265358979323846
 // create!  sampler.jl:109-148.  u = D uniforms; returns the proposal weight (0: rejected, k untouched)
 template <class Cfg, int V> __device__ __forceinline__ double fermik_create(const double *u, double *k) {
-    constexpr int D = Cfg::pool_nleaf(V), leaf = Cfg::draw_leaf(Cfg::pool_first_draw(V));
+    constexpr int D = Cfg::pool_nleaf(V), leaf = Cfg::draw_leaf(Cfg::pool_first)MCIDEV"
+R"MCIDEV(_draw(V));
     constexpr double kF = Cfg::leaf_lower(leaf), dk = Cfg::leaf_upper(leaf);
     const double Kamp = kF + (u[0] - 0.5) * 2.0 * dk; // :121
     if (Kamp <= 0.0) return 0.0;                       // :122
-    const double phi = 2.0 * MCI_PI * u[1];            // :12)MCIDEV"
-R"MCIDEV(4
+    const double phi = 2.0 * MCI_PI * u[1];            // :124
     if constexpr (D == 3) {
         const double theta = MCI_PI * u[2];            // :126
         k[0] = Kamp * cos(phi) * sin(theta);           // :129-131
@@ -1034,13 +1037,13 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
         int curr = a.nchain == 1 ? 0 : (int)(g % (u64)ND); // montecarlo.jl:76 idx = 1; many chains start stratified
         Chain<Cfg> c;
         Weight<Cfg> weight; // :116 _State(curr, zero(T), 1.0)
-        static_for<0, Cfg::NCOMP>([&](auto Q) { weight.v[decltype(Q)::value] = 0.0; });
+        static_for<0, Cfg::NCOMP>([&](auto Q) )MCIDEV"
+R"MCIDEV({ weight.v[decltype(Q)::value] = 0.0; });
         weight.abs = 0.0;
         double probability = 1.0;
         for (int tr = 0; tr < 10000; ++tr) {    // :118-124
             Sample<Cfg> s;
-            draw_sample<Cfg>(t, a.seed, st_init, g * 16384ull + (u64)tr, s); // initi)MCIDEV"
-R"MCIDEV(alize!  :190-193
+            draw_sample<Cfg>(t, a.seed, st_init, g * 16384ull + (u64)tr, s); // initialize!  :190-193
             static_for<0, Cfg::NDRAW>([&](auto K) {
                 constexpr int k = decltype(K)::value;
                 c.x[k] = s.x[k];
@@ -1079,6 +1082,10 @@ R"MCIDEV(alize!  :190-193
         }
         if (curr != NORMI && probability == 0.0) atomicOr(a.status, ST_MCMC_INIT); // :125-126 error(...)
 
+        // holding times (this engine's own diagnostic, DESIGN.md "chains"): step of the last change of every slot and of
+        // the integrand index, and the longest completed or still running hold
+        int last[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1], lastc = 0, hmax = 0;
+        static_for<0, Cfg::NDRAW>([&](auto K) { last[decltype(K)::value] = 0; });
         for (i64 it = 1; it <= steps + nburn; ++it) { // :134
             const u64 sidx = (g << 32) | (u64)(it - 1);
             static_for<0, ND>([&](auto I) { extra[XV + decltype(I)::value] += curr == decltype(I)::value ? 1.0 : 0.0; }); // :136
@@ -1141,7 +1148,8 @@ R"MCIDEV(alize!  :190-193
                                         } else if constexpr (cd < nd) {
                                             static_for<cd * nl, nd * nl>([&](auto Q) { // create!  sampler.jl:293-305, :13-22
                                                 constexpr int k = k00 + decltype(Q)::value;
-                                                const double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
+                                                c)MCIDEV"
+R"MCIDEV(onst double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
                                                 double raw;
                                                 draw_leaf<Cfg, k>(t, y, n.x[k], raw, n.bin[k]);
                                                 const double ip = raw * jac_scale<Cfg>(k);
@@ -1149,8 +1157,7 @@ R"MCIDEV(alize!  :190-193
                                                 prop *= ip;
                                             });
                                         } else if constexpr (cd > nd) {
-                                            static_for<nd * nl, cd * )MCIDEV"
-R"MCIDEV(nl>([&](auto Q) { // remove!  sampler.jl:318-323, :36-40
+                                            static_for<nd * nl, cd * nl>([&](auto Q) { // remove!  sampler.jl:318-323, :36-40
                                                 prop *= c.prob[k00 + decltype(Q)::value];
                                             });
                                         }
@@ -1246,6 +1253,29 @@ R"MCIDEV(nl>([&](auto Q) { // remove!  sampler.jl:318-323, :36-40
                     extra[XP + decltype(U)::value] += ut == decltype(U)::value ? 1.0 : 0.0;           // :48, :99, :140
                     extra[XA + decltype(U)::value] += (ok && ut == decltype(U)::value) ? 1.0 : 0.0;   // :50, :101, :142
                 });
+                if (a.hold_hist) {
+                    const int now = (int)it;
+                    u64 mo = 0ull, mn = 0ull; // live draws of the old and of the proposed integrand
+                    static_for<0, NI>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        mo = curr == i ? Cfg::own_mask(i) : mo;
+                        mn = newcurr == i ? Cfg::own_mask(i) : mn;
+                    });
+                    static_for<0, Cfg::NDRAW>([&](auto K) {
+                        constexpr int k = decltype(K)::value;
+                        // changeIntegrand: the slots it creates start their first hold (they held nothing before);
+                        // changeVariable / swapVariable: a slot whose value really changed ends a hold
+                        const bool chg = ok && (ut == 0 ? (((mn & ~mo) >> k) & 1ull) != 0ull : n.x[k] != c.x[k]);
+                        const int hold = now - last[k];
+                        hmax = (chg && ut != 0 && hold > hmax) ? hold : hmax;
+                        last[k] = chg ? now : last[k];
+                    });
+                    const bool chg = ok && newc)MCIDEV"
+R"MCIDEV(urr != curr;
+                    const int hold = now - lastc;
+                    hmax = (chg && hold > hmax) ? hold : hmax;
+                    lastc = chg ? now : lastc;
+                }
                 if (ok) {
                     c = n;
                     curr = newcurr;                                                             // :51-53
@@ -1271,8 +1301,7 @@ R"MCIDEV(nl>([&](auto Q) { // remove!  sampler.jl:318-323, :36-40
                                 double rwv[Cfg::NW];
                                 static_for<0, Cfg::NW>([&](auto Q) { rwv[decltype(Q)::value] = 0.0; });
                                 static_for<0, Cfg::NCOMP>([&](auto Q) { rwv[i * Cfg::NCOMP + decltype(Q)::value] = relw[decltype(Q)::value]; });
-         )MCIDEV"
-R"MCIDEV(                       Cfg::measure(c.x, rwv, a.ud, i, sO);
+                                Cfg::measure(c.x, rwv, a.ud, i, sO);
                             } else if constexpr (Cfg::obs_bin_draw(i) >= 0) {
                                 const int b = c.bin[Cfg::obs_bin_draw(i)];
                                 if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw[0]);
@@ -1285,6 +1314,18 @@ R"MCIDEV(                       Cfg::measure(c.x, rwv, a.ud, i, sO);
                     extra[XN] += 1.0 / rw[NORMI]; // :158
                 }
             }
+        }
+        if (a.hold_hist) { // holds still running when the chain ends count with their length so far
+            const int tot = (int)(steps + nburn);
+            hmax = (tot - lastc > hmax) ? tot - lastc : hmax;
+            static_for<0, NI>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if (curr == i) static_for<0, Cfg::NDRAW>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
+                });
+            });
+            atomicAdd(&a.hold_hist[hmax <= 0 ? 0 : 32 - __clz(hmax)], 1ull);
         }
     }
     __syncthreads();

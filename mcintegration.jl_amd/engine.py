@@ -193,6 +193,12 @@ class Engine:
     def packed_device_ptr(self):
         return lib().mci_packed_device_ptr(self.p)
 
+    def hold_histogram(self):
+        """:mcmc: chains of the last launch by bit_width(longest holding time) -- what the automatic chain length follows"""
+        out = (C.c_uint64 * 64)()
+        check(lib().mci_get_hold_histogram(self.p, out))
+        return np.array(list(out), dtype=np.uint64)
+
     def stream(self):
         """the library's hipStream_t (as an integer), for callers that order their own work with ours"""
         return lib().mci_ctx_stream(context(self.device)) or 0

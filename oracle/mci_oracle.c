@@ -344,6 +344,7 @@ mcio_config *mcio_config_create(int nleaf, const int *kind, const int *pool, con
     c->propose = (double *)calloc((size_t)c->npa, sizeof(double));
     c->accept = (double *)calloc((size_t)c->npa, sizeof(double));
     for (int v = 0; v < c->npa; ++v) c->propose[v] = 1.0e-8; /* :186 */
+    c->hold_hist = (unsigned long long *)calloc(64, sizeof(unsigned long long));
     /* default neighbor graph  ref: configuration.jl:201-210 (1-based there, 0-based here; index Nd-1 = normalisation) */
     c->nneighbor = (int *)calloc((size_t)Nd, sizeof(int));
     c->neighbor = (int **)calloc((size_t)Nd, sizeof(int *));
@@ -381,7 +382,7 @@ void mcio_config_destroy(mcio_config *c) {
     free(c->draw_leaf); free(c->draw_slot); free(c->draw_comp); free(c->pool_width); free(c->obs_off); free(c->obs_nbin); free(c->obs_bin_draw);
     free(c->observable); free(c->reweight); free(c->visited); free(c->propose); free(c->accept);
     for (int d = 0; d < c->Ni + 1; ++d) free(c->neighbor[d]);
-    free(c->neighbor); free(c->nneighbor); free(c->reweight_goal);
+    free(c->neighbor); free(c->nneighbor); free(c->reweight_goal); free(c->hold_hist);
     free(c);
 }
 
@@ -437,6 +438,7 @@ mcio_config *mcio_config_clone(const mcio_config *s) {
     c->neighbor = (int **)calloc((size_t)Nd, sizeof(int *));
     for (int d = 0; d < Nd; ++d) c->neighbor[d] = (int *)dup_mem(s->neighbor[d], sizeof(int) * (size_t)s->nneighbor[d]);
     c->reweight_goal = s->reweight_goal ? (double *)dup_mem(s->reweight_goal, sizeof(double) * (size_t)Nd) : NULL;
+    c->hold_hist = (unsigned long long *)dup_mem(s->hold_hist, 64 * sizeof(unsigned long long));
     return c;
 }
 
@@ -489,6 +491,7 @@ void mcio_clear_statistics(mcio_config *c) {
     }
     for (int l = 0; l < c->nleaf; ++l)
         for (int i = 0; i < c->leaf[l].nbin; ++i) c->leaf[l].hist[i] = 1.0e-10;
+    for (int b = 0; b < 64; ++b) c->hold_hist[b] = 0;
 }
 
 /* ref: configuration.jl:252-262 and variable.jl:567 */
@@ -503,6 +506,7 @@ void mcio_add_config(mcio_config *c, const mcio_config *ic) {
     for (int i = 0; i < c->nobs; ++i) c->observable[i] += ic->observable[i];
     for (int l = 0; l < c->nleaf; ++l)
         for (int i = 0; i < c->leaf[l].nbin; ++i) c->leaf[l].hist[i] += ic->leaf[l].hist[i];
+    for (int b = 0; b < 64; ++b) c->hold_hist[b] += ic->hold_hist[b];
 }
 
 /* Dist.train!(v) for every variable  ref: main.jl:194-195, variable.jl:479-483 */
@@ -1133,9 +1137,17 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
             if (curr == norm || probability > MCIO_TINY) break;     /* :120-122 */
         }
         if (curr != norm && probability == 0.0) rc = -3;            /* :125-126 error(...) */
+        /* holding times (the engine's diagnostic, mci_device.h mcmc_chains): step of the last change of every draw and of the
+           integrand index; longest completed or still running hold */
+        long last[MCIO_MAXDRAW], lastc = 0, hmax = 0;
+        double xold[MCIO_MAXDRAW], xnew[MCIO_MAXDRAW];
+        for (int k = 0; k < c->ndraw; ++k) last[k] = 0;
         for (long i = 1; i <= steps + nburn; ++i) {                 /* :134 */
             const uint64_t sidx = (g << 32) | (uint64_t)(i - 1);
             c->visited[curr] += 1.0;                                /* :136 */
+            const int curr_old = curr;
+            int moved = 0; /* 0 nothing accepted, 1 changeIntegrand, 2 changeVariable / swapVariable */
+            gather_x(c, xold);
             /* :137 rand(rng, updates); with many chains per block, chains (ch & ~63) .. (ch | 63) of a block share the
                update-type sequence (stream MCMC_GROUP): it does not depend on the chain states, so each chain is still a
                valid Markov chain and blocks stay independent */
@@ -1182,6 +1194,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                     c->propose[0] += 1.0;                           /* :48 propose[1, curr, new] */
                     if (mcio_uniform(seed, st_step, sidx, 4) < R) { /* :49 */
                         c->accept[0] += 1.0;                        /* :50 */
+                        moved = 1;
                         curr = new_;                                /* :51-53 */
                         weight[0] = neww[0];
                         weight[1] = neww[1];
@@ -1211,6 +1224,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         c->propose[2] += 1.0;                       /* :140 propose[3, curr, vi] */
                         if (mcio_uniform(seed, st_step, sidx, 4) < R) {
                             c->accept[2] += 1.0;
+                            moved = 2;
                             for (int q = 0; q < nc; ++q) weight[q] = w[nc * curr + q];
                             probability = newp;
                         } else {
@@ -1238,6 +1252,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         c->propose[1] += 1.0;                       /* :99 propose[2, curr, vi] */
                         if (mcio_uniform(seed, st_step, sidx, 4) < R) {
                             c->accept[1] += 1.0;
+                            moved = 2;
                             for (int q = 0; q < nc; ++q) weight[q] = w[nc * curr + q];
                             probability = newp;
                         } else {
@@ -1245,6 +1260,20 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         }
                     } while (0);
                 }
+            }
+            if (moved == 1) { /* the slots changeIntegrand created start their first hold; the index ends one */
+                for (int vi = 0; vi < npool; ++vi)
+                    for (int pos = c->dof[curr_old * npool + vi] + 1; pos <= c->dof[curr * npool + vi]; ++pos)
+                        for (int l = 0; l < c->pool_width[vi]; ++l) last[kbase[vi] + (pos - 1) * c->pool_width[vi] + l] = i;
+                if (i - lastc > hmax) hmax = i - lastc;
+                lastc = i;
+            } else if (moved == 2) { /* a draw whose value really changed ends a hold */
+                gather_x(c, xnew);
+                for (int k = 0; k < c->ndraw; ++k)
+                    if (xnew[k] != xold[k]) {
+                        if (i - last[k] > hmax) hmax = i - last[k];
+                        last[k] = i;
+                    }
             }
             /* ---- measurement  montecarlo.jl:144-172 ---- */
             if (i % measurefreq == 0 && i >= nburn) {
@@ -1259,6 +1288,20 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                     c->normalization += 1.0 / c->reweight[norm];    /* :158 */
                 }
             }
+        }
+        {   /* holds still running when the chain ends count with their length so far */
+            const long tot = steps + nburn;
+            if (tot - lastc > hmax) hmax = tot - lastc;
+            if (curr != norm)
+                for (int vi = 0; vi < npool; ++vi)
+                    for (int pos = 1; pos <= c->dof[curr * npool + vi]; ++pos)
+                        for (int l = 0; l < c->pool_width[vi]; ++l) {
+                            const int k = kbase[vi] + (pos - 1) * c->pool_width[vi] + l;
+                            if (tot - last[k] > hmax) hmax = tot - last[k];
+                        }
+            int b = 0;
+            for (long h = hmax; h > 0; h >>= 1) ++b; /* bit_width */
+            if (tot < 2147483647L) c->hold_hist[b] += 1;
         }
     }
     return rc;

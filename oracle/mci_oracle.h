@@ -106,6 +106,8 @@ typedef struct {
     mcio_measure_fn measure_fn; /* NULL = default / bin-by-Discrete measure */
     int *pool_width;       /* [npool] x entries per slot: number of leaves, or D for a FermiK pool */
     int *draw_comp;        /* [ndraw] component within the leaf's slot (FermiK), 0 otherwise */
+    unsigned long long *hold_hist; /* [64] :mcmc chains by bit_width(longest holding time); the engine's own diagnostic
+                                      (include/mci.h mci_get_hold_histogram), restated here so that it can be checked */
 } mcio_config;
 
 typedef struct {

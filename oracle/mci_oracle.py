@@ -48,7 +48,8 @@ class _Config(C.Structure):
                 ("reweight", c_double_p), ("visited", c_double_p), ("propose", c_double_p),
                 ("accept", c_double_p), ("prob_mode", C.c_int), ("npa", C.c_int), ("nneighbor", c_int_p),
                 ("neighbor", C.POINTER(c_int_p)), ("thermal_ratio", C.c_double), ("reweight_goal", c_double_p),
-                ("ncomp", C.c_int), ("measure_fn", C.c_void_p), ("pool_width", c_int_p), ("draw_comp", c_int_p)]
+                ("ncomp", C.c_int), ("measure_fn", C.c_void_p), ("pool_width", c_int_p), ("draw_comp", c_int_p),
+                ("hold_hist", C.POINTER(C.c_ulonglong))]
 
 
 class _Result(C.Structure):
@@ -336,6 +337,11 @@ class Config:
     @property
     def visited(self):
         return np.ctypeslib.as_array(self.c.visited, shape=(self.c.Ni + 1,)).copy()
+
+    @property
+    def hold_hist(self):
+        """:mcmc chains of the last iteration by bit_width(longest holding time)"""
+        return np.array([self.c.hold_hist[b] for b in range(64)], dtype=np.uint64)
 
     @property
     def ndraw(self):

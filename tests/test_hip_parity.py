@@ -214,6 +214,10 @@ def test_mcmc_iteration_matches_oracle(oracle, name, nchain):
     rs, rh = hist_split(ref, eng.nobs, cfg.N)
     np.testing.assert_allclose(gs, rs, rtol=1e-9, atol=1e-300)
     np.testing.assert_allclose(gh, rh, rtol=1e-9)   # unit weights: counts + the 1e-10 clearStatistics offsets
+    # the holding-time diagnostic behind the automatic chain length: integer bookkeeping on the same accept decisions
+    hh = eng.hold_histogram()
+    np.testing.assert_array_equal(hh, ocfg.hold_hist)
+    assert hh.sum() == block * nchain
 
 
 def test_mcmc_custom_neighbor_graph_and_measurefreq(oracle):
@@ -412,6 +416,7 @@ def test_mcmc_with_a_fermik_variable_matches_oracle(oracle, nchain):
     got = eng.iteration("mcmc", 3200, 0, 4, iteration=3, seed=SEED, nchain=nchain)
     ref = ocfg.iteration(oracle.MCMC, fn, None, 3200, 0, 4, 3, SEED, nchain=nchain)
     np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+    np.testing.assert_array_equal(eng.hold_histogram(), ocfg.hold_hist)
     with pytest.raises(mci.MCIError):                       # "vegas doesn't work with FermiK variable yet"  test/bubble_FermiK.jl:2
         eng.iteration("vegas", 3200, 0, 4, iteration=0, seed=SEED)
 

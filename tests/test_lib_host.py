@@ -147,3 +147,17 @@ def test_plain_c_consumer_of_the_abi_builds_and_refuses_to_run_without_a_gpu():
         pytest.skip("a GPU is visible")
     out = subprocess.run([demo], capture_output=True, text=True)
     assert out.returncode == 7 and "no CPU fallback" in out.stderr
+
+
+def test_mcmc_auto_chain_length_rule():
+    """mci_mcmc_auto_chains: >= 131072 measured steps per chain until a launch has been measured, afterwards
+    max(16 x longest holding time, 8 burn-in floors), at most 131072 chains per GPU, at least one chain."""
+    from mcintegration_jl_amd._lib import lib
+    L = lib()
+    npb, nblocks, nslots, nd, npool = 6250000, 16, 12, 5, 1
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 0) == npb // 131072
+    fl = 64 * nslots + 16 * (npool + 1) * nd
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 256) == npb // max(16 * 256, 8 * fl)      # light tails: the floor decides
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384) == npb // (16 * 16384)             # heavy tails: the holds decide
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 1 << 30) == 1
+    assert L.mci_mcmc_auto_chains(10**9, 16, 1, 2, 1, 2) == 131072 // 16                                     # GPU-fill cap

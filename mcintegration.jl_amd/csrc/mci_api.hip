@@ -727,6 +727,9 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     const auto &s = p->shape;
     const int T = p->threads;
     int64_t units = nevalperblock; // lanes of useful work per block
+    if (solver != MCI_VEGAS && (block_hi > 4096 || iteration >= 131072 || iteration < 0))
+        return fail(MCI_ERR_INVALID, "chain solvers address a chain by (block < 4096, iteration < 131072): got block_hi=%lld, iteration=%d",
+                    (long long)block_hi, (int)iteration);
     double burnin = 0.0;
     int64_t nburn = 0;
     if (solver == MCI_VEGASMC) {

@@ -628,7 +628,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
 // is `nchain` chains of neval/nchain steps (nchain = 1 reproduces the reference's chain).  Chain state
 // (x, prob, bin per draw; weights; probability) stays in registers; the proposal touches one
 // (pool, slot), selected by a compile-time switch so that every table access keeps static offsets.
-//   chain g = block*nchain + ch
+//   chain g = ch, the chain's index within its block; the block index is added to the stream word as block << 20
 //   init  : stream MC_INIT, index g,            k = flat draw
 //   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
 // =============================================================================================
@@ -713,7 +713,10 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb;
     const i64 steps = a.neval_per_block / a.nchain;
-    const u32 st_init = iteration_of(a) * 8u + STREAM_MC_INIT, st_step = iteration_of(a) * 8u + STREAM_MC_STEP;
+    // chain identity = (block, chain within the block): the block index rides in the top 12 bits of the stream word, so the
+    // streams of a block do not depend on how many chains any other block (or rank) runs
+    const u32 bs = (u32)B << 20;
+    const u32 st_init = iteration_of(a) * 8u + STREAM_MC_INIT + bs, st_step = iteration_of(a) * 8u + STREAM_MC_STEP + bs;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[NI + 1];
     static_for<0, NI + 1>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -726,7 +729,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     constexpr int XP = Cols<Cfg>::PROPOSE - Cfg::NOBS, XA = Cols<Cfg>::ACCEPT - Cfg::NOBS;
 
     for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
-        const u64 g = (u64)(B * a.nchain + ch);
+        const u64 g = (u64)ch;
         Chain<Cfg> c;
         {   // initialize!  (montecarlo.jl:151-153): create! on every live slot
             Sample<Cfg> s;
@@ -753,8 +756,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
             // not depend on the chain states): the pool dispatch below becomes a scalar branch
             double upool = u01(r0.x, r0.y);
             if (Cfg::NPOOL > 1 && a.nchain > 1) {
-                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)63)) << 32) | (u64)(ne - 1);
-                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MC_GROUP, k0, k1);
+                const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)(ne - 1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MC_GROUP + bs, k0, k1);
                 upool = u01(rg.x, rg.y);
             }
             int vi = (int)(upool * (double)Cfg::NPOOL);
@@ -860,7 +863,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
 // burn-in (nchain = 1 reproduces the reference's chain).  Only the integrand the chain sits on is
 // evaluated per step (the integrand body sees `idx`); the neighbor graph (configuration.jl:201-227) and
 // the dof table are compile-time, so every register-array access keeps a static index.
-//   chain g = block*nchain + ch
+//   chain g = ch, the chain's index within its block; the block index is added to the stream word as block << 20
 //   init try t: stream MCMC_INIT, index g*16384 + t,  k = flat draw
 //   step s    : stream MCMC_STEP, index (g<<32 | s),  k = 0 update pick, 1 neighbor/pool pick, 2 slot pick,
 //               3 second slot pick (swap), 4 accept, 5 + flat draw index of a created/shifted draw
@@ -1007,7 +1010,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb;
     const i64 steps = a.neval_per_block / a.nchain, nburn = a.nburn;
-    const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP;
+    const u32 bs = (u32)B << 20; // (block, chain within the block) identify a chain: see vegasmc_chains
+    const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT + bs, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP + bs;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[ND];
     static_for<0, ND>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -1025,7 +1029,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     constexpr int XP = Cols<Cfg>::PROPOSE - Cfg::NOBS, XA = Cols<Cfg>::ACCEPT - Cfg::NOBS;
 
     for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
-        const u64 g = (u64)(B * a.nchain + ch);
+        const u64 g = (u64)ch;
         int curr = a.nchain == 1 ? 0 : (int)(g % (u64)ND); // montecarlo.jl:76 idx = 1; many chains start stratified
         Chain<Cfg> c;
         Weight<Cfg> weight; // :116 _State(curr, zero(T), 1.0)
@@ -1089,8 +1093,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             // at every step.  nchain = 1 (the reference's chain) draws its own.
             double uupd = u01(r0.x, r0.y);
             if (a.nchain > 1) {
-                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)63)) << 32) | (u64)(it - 1);
-                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MCMC_GROUP, k0, k1);
+                const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)(it - 1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MCMC_GROUP + bs, k0, k1);
                 uupd = u01(rg.x, rg.y);
             }
             int upd = (int)(uupd * (double)NUPD);

@@ -634,7 +634,7 @@ R"MCIDEV(                   constexpr int leaf = Cfg::draw_leaf(k);
 // is `nchain` chains of neval/nchain steps (nchain = 1 reproduces the reference's chain).  Chain state
 // (x, prob, bin per draw; weights; probability) stays in registers; the proposal touches one
 // (pool, slot), selected by a compile-time switch so that every table access keeps static offsets.
-//   chain g = block*nchain + ch
+//   chain g = ch, the chain's index within its block; the block index is added to the stream word as block << 20
 //   init  : stream MC_INIT, index g,            k = flat draw
 //   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
 // =============================================================================================
@@ -719,7 +719,10 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb;
     const i64 steps = a.neval_per_block / a.nchain;
-    const u32 st_init = iteration_of(a) * 8u + STREAM_MC_INIT, st_step = iteration_of(a) * 8u + STREAM_MC_STEP;
+    // chain identity = (block, chain within the block): the block index rides in the top 12 bits of the stream word, so the
+    // streams of a block do not depend on how many chains any other block (or rank) runs
+    const u32 bs = (u32)B << 20;
+    const u32 st_init = iteration_of(a) * 8u + STREAM_MC_INIT + bs, st_step = iteration_of(a) * 8u + STREAM_MC_STEP + bs;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[NI + 1];
     static_for<0, NI + 1>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -732,7 +735,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     constexpr int XP = Cols<Cfg>::PROPOSE - Cfg::NOBS, XA = Cols<Cfg>::ACCEPT - Cfg::NOBS;
 
     for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
-        const u64 g = (u64)(B * a.nchain + ch);
+        const u64 g = (u64)ch;
         Chain<Cfg> c;
         {   // initialize!  (montecarlo.jl:151-153): create! on every live slot
             Sample<Cfg> s;
@@ -752,16 +755,16 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
 
         for (i64 ne = 1; ne <= steps; ++ne) { // :184
             const u64 sidx = (g << 32) | (u64)(ne - 1);
-            const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
+            const u32x4 r0 = phi)MCIDEV"
+R"MCIDEV(lox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
             const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
             // ---- changeVariable  updates.jl:45-106 ----
-            // :50 rand(1:Nv).  With many chains per block the 64 chains of a wave share the pool-pick se)MCIDEV"
-R"MCIDEV(quence (it does
+            // :50 rand(1:Nv).  With many chains per block the 64 chains of a wave share the pool-pick sequence (it does
             // not depend on the chain states): the pool dispatch below becomes a scalar branch
             double upool = u01(r0.x, r0.y);
             if (Cfg::NPOOL > 1 && a.nchain > 1) {
-                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)63)) << 32) | (u64)(ne - 1);
-                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MC_GROUP, k0, k1);
+                const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)(ne - 1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MC_GROUP + bs, k0, k1);
                 upool = u01(rg.x, rg.y);
             }
             int vi = (int)(upool * (double)Cfg::NPOOL);
@@ -867,7 +870,7 @@ R"MCIDEV(quence (it does
 // burn-in (nchain = 1 reproduces the reference's chain).  Only the integrand the chain sits on is
 // evaluated per step (the integrand body sees `idx`); the neighbor graph (configuration.jl:201-227) and
 // the dof table are compile-time, so every register-array access keeps a static index.
-//   chain g = block*nchain + ch
+//   chain g = ch, the chain's index within its block; the block index is added to the stream word as block << 20
 //   init try t: stream MCMC_INIT, index g*16384 + t,  k = flat draw
 //   step s    : stream MCMC_STEP, index (g<<32 | s),  k = 0 update pick, 1 neighbor/pool pick, 2 slot pick,
 //               3 second slot pick (swap), 4 accept, 5 + flat draw index of a created/shifted draw
@@ -875,12 +878,12 @@ R"MCIDEV(quence (it does
 // ---------------------------------------------------------------------------------------------
 // FermiK{D} (variable.jl:1-20, sampler.jl:109-281): a momentum on a shell |k| in (kF - dk, kF + dk), D = 2 | 3
 // components per slot, no adaptive map, :mcmc only.  kF = leaf_lower, dk = leaf_upper, D = pool_nleaf(V).
-// ---------------------------------------------------------------------------------------------
+// ------------------------------)MCIDEV"
+R"MCIDEV(---------------------------------------------------------------
 #define MCI_PI 3.14159265358979323846
 // create!  sampler.jl:109-148.  u = D uniforms; returns the proposal weight (0: rejected, k untouched)
 template <class Cfg, int V> __device__ __forceinline__ double fermik_create(const double *u, double *k) {
-    constexpr int D = Cfg::pool_nleaf(V), leaf = Cfg::draw_leaf(Cfg::pool_first)MCIDEV"
-R"MCIDEV(_draw(V));
+    constexpr int D = Cfg::pool_nleaf(V), leaf = Cfg::draw_leaf(Cfg::pool_first_draw(V));
     constexpr double kF = Cfg::leaf_lower(leaf), dk = Cfg::leaf_upper(leaf);
     const double Kamp = kF + (u[0] - 0.5) * 2.0 * dk; // :121
     if (Kamp <= 0.0) return 0.0;                       // :122
@@ -1015,7 +1018,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb;
     const i64 steps = a.neval_per_block / a.nchain, nburn = a.nburn;
-    const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP;
+    const u32 bs = (u32)B << 20; // (block, chain within the block) identify a chain: see vegasmc_chains
+    const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT + bs, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP + bs;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[ND];
     static_for<0, ND>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -1029,16 +1033,16 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     static_for<0, Cfg::NW>([&](auto I) { acc[decltype(I)::value] = 0.0; });
     double extra[Cfg::NCOLS - Cfg::NOBS];
     static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
-    constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
+    constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Co)MCIDEV"
+R"MCIDEV(ls<Cfg>::VISITED - Cfg::NOBS;
     constexpr int XP = Cols<Cfg>::PROPOSE - Cfg::NOBS, XA = Cols<Cfg>::ACCEPT - Cfg::NOBS;
 
     for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
-        const u64 g = (u64)(B * a.nchain + ch);
+        const u64 g = (u64)ch;
         int curr = a.nchain == 1 ? 0 : (int)(g % (u64)ND); // montecarlo.jl:76 idx = 1; many chains start stratified
         Chain<Cfg> c;
         Weight<Cfg> weight; // :116 _State(curr, zero(T), 1.0)
-        static_for<0, Cfg::NCOMP>([&](auto Q) )MCIDEV"
-R"MCIDEV({ weight.v[decltype(Q)::value] = 0.0; });
+        static_for<0, Cfg::NCOMP>([&](auto Q) { weight.v[decltype(Q)::value] = 0.0; });
         weight.abs = 0.0;
         double probability = 1.0;
         for (int tr = 0; tr < 10000; ++tr) {    // :118-124
@@ -1098,8 +1102,8 @@ R"MCIDEV({ weight.v[decltype(Q)::value] = 0.0; });
             // at every step.  nchain = 1 (the reference's chain) draws its own.
             double uupd = u01(r0.x, r0.y);
             if (a.nchain > 1) {
-                const u64 gidx = ((u64)(B * a.nchain + (ch & ~(i64)63)) << 32) | (u64)(it - 1);
-                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MCMC_GROUP, k0, k1);
+                const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)(it - 1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MCMC_GROUP + bs, k0, k1);
                 uupd = u01(rg.x, rg.y);
             }
             int upd = (int)(uupd * (double)NUPD);
@@ -1142,14 +1146,14 @@ R"MCIDEV({ weight.v[decltype(Q)::value] = 0.0; });
                                                     prop *= fermik_create<Cfg, v>(u, kk);
                                                     static_for<0, nl>([&](auto J) { n.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
                                                 } else {                 // remove!  sampler.jl:158-188
-                                                    prop *= fermik_remove<Cfg, v>(kk);
+                                               )MCIDEV"
+R"MCIDEV(     prop *= fermik_remove<Cfg, v>(kk);
                                                 }
                                             });
                                         } else if constexpr (cd < nd) {
                                             static_for<cd * nl, nd * nl>([&](auto Q) { // create!  sampler.jl:293-305, :13-22
                                                 constexpr int k = k00 + decltype(Q)::value;
-                                                c)MCIDEV"
-R"MCIDEV(onst double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
+                                                const double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
                                                 double raw;
                                                 draw_leaf<Cfg, k>(t, y, n.x[k], raw, n.bin[k]);
                                                 const double ip = raw * jac_scale<Cfg>(k);
@@ -1264,14 +1268,14 @@ R"MCIDEV(onst double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
                     static_for<0, Cfg::NDRAW>([&](auto K) {
                         constexpr int k = decltype(K)::value;
                         // changeIntegrand: the slots it creates start their first hold (they held nothing before);
-                        // changeVariable / swapVariable: a slot whose value really changed ends a hold
+ )MCIDEV"
+R"MCIDEV(                       // changeVariable / swapVariable: a slot whose value really changed ends a hold
                         const bool chg = ok && (ut == 0 ? (((mn & ~mo) >> k) & 1ull) != 0ull : n.x[k] != c.x[k]);
                         const int hold = now - last[k];
                         hmax = (chg && ut != 0 && hold > hmax) ? hold : hmax;
                         last[k] = chg ? now : last[k];
                     });
-                    const bool chg = ok && newc)MCIDEV"
-R"MCIDEV(urr != curr;
+                    const bool chg = ok && newcurr != curr;
                     const int hold = now - lastc;
                     hmax = (chg && hold > hmax) ? hold : hmax;
                     lastc = chg ? now : lastc;

@@ -66,6 +66,9 @@ double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k) 
 
 enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6, STREAM_MC_GROUP = 7 };
 static inline uint32_t stream_id(uint32_t iteration, int purpose) { return iteration * 8u + (uint32_t)purpose; }
+/* chain solvers: a chain is identified by (block, chain within the block); the block index rides in the top 12 bits of the
+   stream word so that a block's streams do not depend on how many chains other blocks run (iteration < 131072, block < 4096) */
+static inline uint32_t stream_id_block(uint32_t iteration, int purpose, long block) { return stream_id(iteration, purpose) + ((uint32_t)block << 20); }
 
 /* ------------------------------------------------------------------------------------------
  * src/distribution/common.jl
@@ -918,7 +921,7 @@ int mcio_vegas_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint
 /* ------------------------------------------------------------------------------------------
  * src/vegas_mc/montecarlo.jl:112-241 + src/vegas_mc/updates.jl:45-106
  * The block's neval steps are run as `nchain` independent chains of neval/nchain steps
- * (nchain = 1 is the reference).  Chain g = block_index*nchain + ch draws
+ * (nchain = 1 is the reference).  Chain ch of the block (its block index rides in the stream word, stream_id_block) draws
  *   init  : stream MC_INIT, index g,            k = flat draw
  *   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
  * ---------------------------------------------------------------------------------------- */
@@ -944,9 +947,9 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
         if (fl > (double)steps / 2.0) fl = (double)steps / 2.0;
         if (fl > burnin) burnin = fl;
     }
-    const uint32_t st_init = stream_id(iteration, STREAM_MC_INIT), st_step = stream_id(iteration, STREAM_MC_STEP);
+    const uint32_t st_init = stream_id_block(iteration, STREAM_MC_INIT, block_index), st_step = stream_id_block(iteration, STREAM_MC_STEP, block_index);
     for (long ch = 0; ch < nchain; ++ch) {
-        const uint64_t g = (uint64_t)block_index * (uint64_t)nchain + (uint64_t)ch;
+        const uint64_t g = (uint64_t)ch;
         /* :151-153 initialize! (only the slots that are ever read: 1..maxdof) */
         int k = 0;
         for (int vi = 0; vi < npool; ++vi)
@@ -972,8 +975,8 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
                    sequence (stream MC_GROUP), which does not depend on the chain states */
                 double upool = mcio_uniform(seed, st_step, sidx, 0);
                 if (npool > 1 && nchain > 1) {
-                    const uint64_t gidx = (((uint64_t)block_index * (uint64_t)nchain + (uint64_t)(ch & ~63L)) << 32) | (uint64_t)(ne - 1);
-                    upool = mcio_uniform(seed, stream_id(iteration, STREAM_MC_GROUP), gidx, 0);
+                    const uint64_t gidx = ((uint64_t)(ch & ~63L) << 32) | (uint64_t)(ne - 1);
+                    upool = mcio_uniform(seed, stream_id_block(iteration, STREAM_MC_GROUP, block_index), gidx, 0);
                 }
                 int vi = (int)floor(upool * npool);
                 if (vi >= npool) vi = npool - 1;
@@ -1035,7 +1038,7 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
  * src/mcmc/montecarlo.jl:72-184 + src/mcmc/updates.jl:1-147
  * The Markov chain walks over (integrand index curr, live variables).  A block's neval measured steps are
  * run as `nchain` independent chains of neval/nchain measured steps, each preceded by its burn-in
- * (nchain = 1 is the reference).  Chain g = block_index*nchain + ch draws
+ * (nchain = 1 is the reference).  Chain ch of the block (its block index rides in the stream word, stream_id_block) draws
  *   init try t: stream MCMC_INIT, index g*16384 + t,  k = flat draw
  *   step s    : stream MCMC_STEP, index (g<<32 | s),  k = 0 update pick, 1 neighbor/pool pick, 2 slot pick,
  *               3 second slot pick (swap), 4 accept, 5 + flat draw index of a created/shifted (pool, slot, leaf)
@@ -1110,10 +1113,10 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
     const long steps = neval / nchain;
     const long nburn = mcio_mcmc_burnin(steps, nchain, nslots, Nd, npool, c->thermal_ratio); /* :133 */
     const int nupd = 2 * npool + 2; /* :127-130: [changeIntegrand, swapVariable, changeVariable x 2*Nv] */
-    const uint32_t st_init = stream_id(iteration, STREAM_MCMC_INIT), st_step = stream_id(iteration, STREAM_MCMC_STEP);
+    const uint32_t st_init = stream_id_block(iteration, STREAM_MCMC_INIT, block_index), st_step = stream_id_block(iteration, STREAM_MCMC_STEP, block_index);
     int rc = 0;
     for (long ch = 0; ch < nchain; ++ch) {
-        const uint64_t g = (uint64_t)block_index * (uint64_t)nchain + (uint64_t)ch;
+        const uint64_t g = (uint64_t)ch;
         int curr = (nchain == 1) ? 0 : (int)(g % (uint64_t)Nd); /* :76 idx = 1; many chains start stratified */
         double weight[2] = {0.0, 0.0}, probability = 1.0;        /* :116 _State(curr, zero(T), 1.0) */
         for (long t = 0; t < 10000; ++t) {                       /* :118-124 */
@@ -1153,8 +1156,8 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                valid Markov chain and blocks stay independent */
             double uupd = mcio_uniform(seed, st_step, sidx, 0);
             if (nchain > 1) {
-                const uint64_t gidx = (((uint64_t)block_index * (uint64_t)nchain + (uint64_t)(ch & ~63L)) << 32) | (uint64_t)(i - 1);
-                uupd = mcio_uniform(seed, stream_id(iteration, STREAM_MCMC_GROUP), gidx, 0);
+                const uint64_t gidx = ((uint64_t)(ch & ~63L) << 32) | (uint64_t)(i - 1);
+                uupd = mcio_uniform(seed, stream_id_block(iteration, STREAM_MCMC_GROUP, block_index), gidx, 0);
             }
             int upd = (int)floor(uupd * nupd);
             if (upd >= nupd) upd = nupd - 1;

@@ -431,6 +431,29 @@ def test_error_paths():
     assert e.value.code == 5 and "finite" in str(e.value)
 
 
+def test_chain_streams_are_addressed_by_block_and_chain(oracle):
+    """A chain is (block, chain within the block) -- DESIGN.md section 3: its draws do not depend on how many chains any
+    other block runs, so blocks run with DIFFERENT chain counts (what every rank's own :mcmc measurement leads to) never
+    share a stream, and a block computed alone equals the same block computed next to others."""
+    c, cfg, eng, ocfg = make("sphere2_padding", oracle)
+    npb = 3200
+    both = eng.iteration("mcmc", npb, 0, 2, iteration=1, seed=SEED, nchain=8)
+    b0 = eng.iteration("mcmc", npb, 0, 1, iteration=1, seed=SEED, nchain=8)
+    b1 = eng.iteration("mcmc", npb, 1, 2, iteration=1, seed=SEED, nchain=8)
+    n = eng.nobs
+    off = 1e-10 * 2                                     # every partial result carries the clearStatistics offsets once more
+    np.testing.assert_allclose(b0[:2 * n] + b1[:2 * n], both[:2 * n], rtol=1e-12)
+    np.testing.assert_allclose(b0[2 * n + 2:] + b1[2 * n + 2:], both[2 * n + 2:], rtol=1e-9, atol=1e-6)
+    # under the old addressing (g = block*nchain + ch) block 1 with 4 chains replayed chains 4..7 of block 0 with 8 chains
+    o8 = ocfg.iteration(oracle.MCMC, c["oname"], c["ud"], npb, 0, 1, 1, SEED, nchain=8)
+    o4 = ocfg.iteration(oracle.MCMC, c["oname"], c["ud"], npb, 1, 2, 1, SEED, nchain=4)
+    g4 = eng.iteration("mcmc", npb, 1, 2, iteration=1, seed=SEED, nchain=4)
+    np.testing.assert_allclose(g4[:2 * n], o4[:2 * n], rtol=1e-9)
+    assert not np.allclose(o4[:n], o8[:n], rtol=1e-3)
+    with pytest.raises(mci.MCIError):                   # the block index has 12 bits of the stream word
+        eng.iteration("mcmc", npb, 4095, 4097, iteration=1, seed=SEED, nchain=4)
+
+
 def test_c4_genz32_runs_in_l2_table_mode_and_matches_oracle(oracle):
     """BASELINE config 4 layout: 32 independent grids (256 KB of edges > LDS)."""
     ud = genz_userdata(32)

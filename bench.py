@@ -31,12 +31,24 @@ B_ALG = 32 * D          # algorithmic bytes per sample: per dim 1
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def usable_cores():
+    """host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(math.ceil(float(quota) / float(period)))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(seconds_target=12.0):
     """The CPU oracle (oracle/, kind "port": the reference itself is Julia and cannot run here), threaded
     over blocks like parallel=:thread (src/main.jl:153-158) on all host cores, same 16-D Gaussian."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mci_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     block = max(16, cores)
     cfg = O.Config([dict(kind=0, pool=0, lower=-L, upper=L)], [[D]])
     probe = 20000 * block
@@ -225,16 +237,19 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)   # RCCL's start-up banner sits in the C stdio buffer: the JSON line stays the last line of stdout
         print(json.dumps(out), flush=True)
+    # orderly release while the HIP runtime is still up: problem, then stream + RCCL communicator, then torch's group
+    eng.close()
+    cfg._engine = None
+    mci.shutdown()
     if world > 1 or force_comm:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
-    # orderly release while the HIP runtime is still up, then leave without the interpreter's teardown: the destruction
-    # order of torch, RCCL and the HIP runtime at exit is not ours to control (seen once: glibc "double free" after the result)
-    eng.close()
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
+        # multi-rank runs leave without the interpreter's teardown: the destruction order of torch, RCCL and the HIP
+        # runtime at exit is not ours to control (seen once: glibc "double free" after the result was printed)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

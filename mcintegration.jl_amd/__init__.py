@@ -9,7 +9,7 @@ JIT-compiled into the sample-batch kernel, exactly where Julia would inline the 
 from . import catalog  # noqa: F401
 from ._lib import MCIError, lib, library_path  # noqa: F401
 from .configuration import Configuration  # noqa: F401
-from .engine import Engine  # noqa: F401
+from .engine import Engine, shutdown  # noqa: F401
 from .integrand import HostIntegrand, Integrand, Measure, bin_by  # noqa: F401
 from .integrate import integrate, prefill_kernel_cache  # noqa: F401
 from .statistics import Result, average, mean_std, report  # noqa: F401

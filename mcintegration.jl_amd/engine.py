@@ -25,6 +25,13 @@ def context(device=0):
     return _ctx_cache[device]
 
 
+def shutdown():
+    """Destroy every cached context (stream + RCCL communicator).  Engines must be closed first.  For hosts that want an
+    orderly release before the process ends (the counterpart of MPI.Finalize)."""
+    for dev in list(_ctx_cache):
+        lib().mci_ctx_destroy(_ctx_cache.pop(dev))
+
+
 def device_count():
     n = C.c_int32()
     lib().mci_device_count(C.byref(n))

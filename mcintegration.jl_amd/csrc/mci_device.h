@@ -1107,6 +1107,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             double prop = 1.0;
             bool active = false;
             int newcurr = curr, ut = 0; // ut: first index of propose[., ., .]: 0 changeIntegrand, 1 changeVariable, 2 swapVariable
+            u64 touched = 0ull; // draws of the slot(s) this proposal moves (changeVariable, swapVariable)
             if (upd == 0) {
                 // ---- changeIntegrand  updates.jl:1-69 ----
                 static_for<0, ND>([&](auto C0) {
@@ -1182,6 +1183,9 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                             static_for<0, NPOOL>([&](auto V) {
                                 constexpr int v = decltype(V)::value;
                                 if (vi == v) {
+                                    constexpr u64 slotbits = (1ull << Cfg::pool_nleaf(v)) - 1ull;
+                                    touched = (slotbits << (Cfg::pool_first_draw(v) + s1 * Cfg::pool_nleaf(v))) |
+                                              (slotbits << (Cfg::pool_first_draw(v) + s2 * Cfg::pool_nleaf(v)));
                                     static_for<0, Cfg::pool_nleaf(v)>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
                                         constexpr int l = decltype(Lf)::value;
                                         double xa, xb, pa, pb;
@@ -1208,6 +1212,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                                 active = true;
                                 int slot = (int)(us1 * (double)cdv); // :83
                                 if (slot >= cdv) slot = cdv - 1;
+                                touched = ((1ull << nl) - 1ull) << (k00 + slot * nl);
                                 if constexpr (pool_is_fermik<Cfg>(v)) { // shift!  sampler.jl:198-246; the move is picked by uniform 3
                                     double u[nl], kk[nl], po;
                                     int bo;
@@ -1258,8 +1263,9 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                     static_for<0, Cfg::NDRAW>([&](auto K) {
                         constexpr int k = decltype(K)::value;
                         // changeIntegrand: the slots it creates start their first hold (they held nothing before);
-                        // changeVariable / swapVariable: a slot whose value really changed ends a hold
-                        const bool chg = ok && (ut == 0 ? (((mn & ~mo) >> k) & 1ull) != 0ull : n.x[k] != c.x[k]);
+                        // changeVariable / swapVariable: an accepted move of the slot ends its hold (also when a Discrete
+                        // redraw lands on the same value: the chain was free to move)
+                        const bool chg = ok && (((ut == 0 ? (mn & ~mo) : touched) >> k) & 1ull) != 0ull;
                         const int hold = now - last[k];
                         hmax = (chg && ut != 0 && hold > hmax) ? hold : hmax;
                         last[k] = chg ? now : last[k];
@@ -1315,7 +1321,10 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                 constexpr int i = decltype(I)::value;
                 if (curr == i) static_for<0, Cfg::NDRAW>([&](auto K) {
                     constexpr int k = decltype(K)::value;
-                    if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
+                    // (a lone single-valued Discrete has nothing to sample, updates.jl:79-81: it never moves and holds nothing)
+                    constexpr int pv = Cfg::draw_pool(k);
+                    constexpr bool fixed = Cfg::pool_nleaf(pv) == 1 && Cfg::leaf_kind(Cfg::draw_leaf(k)) == 1 && Cfg::leaf_nbin(Cfg::draw_leaf(k)) == 1;
+                    if constexpr (((Cfg::own_mask(i) >> k) & 1ull) && !fixed) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
                 });
             });
             atomicAdd(&a.hold_hist[hmax <= 0 ? 0 : 32 - __clz(hmax)], 1ull);

@@ -1116,6 +1116,7 @@ R"MCIDEV(ls<Cfg>::VISITED - Cfg::NOBS;
             double prop = 1.0;
             bool active = false;
             int newcurr = curr, ut = 0; // ut: first index of propose[., ., .]: 0 changeIntegrand, 1 changeVariable, 2 swapVariable
+            u64 touched = 0ull; // draws of the slot(s) this proposal moves (changeVariable, swapVariable)
             if (upd == 0) {
                 // ---- changeIntegrand  updates.jl:1-69 ----
                 static_for<0, ND>([&](auto C0) {
@@ -1145,9 +1146,9 @@ R"MCIDEV(ls<Cfg>::VISITED - Cfg::NOBS;
                                                     static_for<0, nl>([&](auto J) { u[decltype(J)::value] = step_uniform<5 + kb + decltype(J)::value>(sidx, st_step, k0, k1, r2); });
                                                     prop *= fermik_create<Cfg, v>(u, kk);
                                                     static_for<0, nl>([&](auto J) { n.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
-                                                } else {                 // remove!  sampler.jl:158-188
-                                               )MCIDEV"
-R"MCIDEV(     prop *= fermik_remove<Cfg, v>(kk);
+                                            )MCIDEV"
+R"MCIDEV(    } else {                 // remove!  sampler.jl:158-188
+                                                    prop *= fermik_remove<Cfg, v>(kk);
                                                 }
                                             });
                                         } else if constexpr (cd < nd) {
@@ -1192,6 +1193,9 @@ R"MCIDEV(     prop *= fermik_remove<Cfg, v>(kk);
                             static_for<0, NPOOL>([&](auto V) {
                                 constexpr int v = decltype(V)::value;
                                 if (vi == v) {
+                                    constexpr u64 slotbits = (1ull << Cfg::pool_nleaf(v)) - 1ull;
+                                    touched = (slotbits << (Cfg::pool_first_draw(v) + s1 * Cfg::pool_nleaf(v))) |
+                                              (slotbits << (Cfg::pool_first_draw(v) + s2 * Cfg::pool_nleaf(v)));
                                     static_for<0, Cfg::pool_nleaf(v)>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
                                         constexpr int l = decltype(Lf)::value;
                                         double xa, xb, pa, pb;
@@ -1218,6 +1222,7 @@ R"MCIDEV(     prop *= fermik_remove<Cfg, v>(kk);
                                 active = true;
                                 int slot = (int)(us1 * (double)cdv); // :83
                                 if (slot >= cdv) slot = cdv - 1;
+                                touched = ((1ull << nl) - 1ull) << (k00 + slot * nl);
                                 if constexpr (pool_is_fermik<Cfg>(v)) { // shift!  sampler.jl:198-246; the move is picked by uniform 3
                                     double u[nl], kk[nl], po;
                                     int bo;
@@ -1259,7 +1264,8 @@ R"MCIDEV(     prop *= fermik_remove<Cfg, v>(kk);
                 });
                 if (a.hold_hist) {
                     const int now = (int)it;
-                    u64 mo = 0ull, mn = 0ull; // live draws of the old and of the proposed integrand
+                    u64 mo = 0ull, mn = 0ull; // live draws of the old and of the proposed )MCIDEV"
+R"MCIDEV(integrand
                     static_for<0, NI>([&](auto I) {
                         constexpr int i = decltype(I)::value;
                         mo = curr == i ? Cfg::own_mask(i) : mo;
@@ -1268,9 +1274,9 @@ R"MCIDEV(     prop *= fermik_remove<Cfg, v>(kk);
                     static_for<0, Cfg::NDRAW>([&](auto K) {
                         constexpr int k = decltype(K)::value;
                         // changeIntegrand: the slots it creates start their first hold (they held nothing before);
- )MCIDEV"
-R"MCIDEV(                       // changeVariable / swapVariable: a slot whose value really changed ends a hold
-                        const bool chg = ok && (ut == 0 ? (((mn & ~mo) >> k) & 1ull) != 0ull : n.x[k] != c.x[k]);
+                        // changeVariable / swapVariable: an accepted move of the slot ends its hold (also when a Discrete
+                        // redraw lands on the same value: the chain was free to move)
+                        const bool chg = ok && (((ut == 0 ? (mn & ~mo) : touched) >> k) & 1ull) != 0ull;
                         const int hold = now - last[k];
                         hmax = (chg && ut != 0 && hold > hmax) ? hold : hmax;
                         last[k] = chg ? now : last[k];
@@ -1326,7 +1332,10 @@ R"MCIDEV(                       // changeVariable / swapVariable: a slot whose v
                 constexpr int i = decltype(I)::value;
                 if (curr == i) static_for<0, Cfg::NDRAW>([&](auto K) {
                     constexpr int k = decltype(K)::value;
-                    if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
+                    // (a lone single-valued Discrete has nothing to sample, updates.jl:79-81: it never moves and holds nothing)
+                    constexpr int pv = Cfg::draw_pool(k);
+                    constexpr bool fixed = Cfg::pool_nleaf(pv) == 1 && Cfg::leaf_kind(Cfg::draw_leaf(k)) == 1 && Cfg::leaf_nbin(Cfg::draw_leaf(k)) == 1;
+                    if constexpr (((Cfg::own_mask(i) >> k) & 1ull) && !fixed) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
                 });
             });
             atomicAdd(&a.hold_hist[hmax <= 0 ? 0 : 32 - __clz(hmax)], 1ull);

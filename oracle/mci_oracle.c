@@ -1143,14 +1143,13 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
         /* holding times (the engine's diagnostic, mci_device.h mcmc_chains): step of the last change of every draw and of the
            integrand index; longest completed or still running hold */
         long last[MCIO_MAXDRAW], lastc = 0, hmax = 0;
-        double xold[MCIO_MAXDRAW], xnew[MCIO_MAXDRAW];
         for (int k = 0; k < c->ndraw; ++k) last[k] = 0;
         for (long i = 1; i <= steps + nburn; ++i) {                 /* :134 */
             const uint64_t sidx = (g << 32) | (uint64_t)(i - 1);
             c->visited[curr] += 1.0;                                /* :136 */
             const int curr_old = curr;
             int moved = 0; /* 0 nothing accepted, 1 changeIntegrand, 2 changeVariable / swapVariable */
-            gather_x(c, xold);
+            int mv_pool = 0, mv_s1 = 0, mv_s2 = 0; /* the slot(s), 1-based within the pool, an accepted move touched */
             /* :137 rand(rng, updates); with many chains per block, chains (ch & ~63) .. (ch | 63) of a block share the
                update-type sequence (stream MCMC_GROUP): it does not depend on the chain states, so each chain is still a
                valid Markov chain and blocks stay independent */
@@ -1227,7 +1226,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         c->propose[2] += 1.0;                       /* :140 propose[3, curr, vi] */
                         if (mcio_uniform(seed, st_step, sidx, 4) < R) {
                             c->accept[2] += 1.0;
-                            moved = 2;
+                            moved = 2; mv_pool = vi; mv_s1 = s1; mv_s2 = s2;
                             for (int q = 0; q < nc; ++q) weight[q] = w[nc * curr + q];
                             probability = newp;
                         } else {
@@ -1255,7 +1254,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         c->propose[1] += 1.0;                       /* :99 propose[2, curr, vi] */
                         if (mcio_uniform(seed, st_step, sidx, 4) < R) {
                             c->accept[1] += 1.0;
-                            moved = 2;
+                            moved = 2; mv_pool = vi; mv_s1 = slot; mv_s2 = 0;
                             for (int q = 0; q < nc; ++q) weight[q] = w[nc * curr + q];
                             probability = newp;
                         } else {
@@ -1270,13 +1269,17 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         for (int l = 0; l < c->pool_width[vi]; ++l) last[kbase[vi] + (pos - 1) * c->pool_width[vi] + l] = i;
                 if (i - lastc > hmax) hmax = i - lastc;
                 lastc = i;
-            } else if (moved == 2) { /* a draw whose value really changed ends a hold */
-                gather_x(c, xnew);
-                for (int k = 0; k < c->ndraw; ++k)
-                    if (xnew[k] != xold[k]) {
+            } else if (moved == 2) { /* an accepted move of a slot ends its hold (also when a Discrete redraw lands on the same value) */
+                const int nl = c->pool_width[mv_pool];
+                for (int which = 0; which < 2; ++which) {
+                    const int sl = which == 0 ? mv_s1 : mv_s2;
+                    if (sl <= 0) continue;
+                    for (int l = 0; l < nl; ++l) {
+                        const int k = kbase[mv_pool] + (sl - 1) * nl + l;
                         if (i - last[k] > hmax) hmax = i - last[k];
                         last[k] = i;
                     }
+                }
             }
             /* ---- measurement  montecarlo.jl:144-172 ---- */
             if (i % measurefreq == 0 && i >= nburn) {
@@ -1296,12 +1299,15 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
             const long tot = steps + nburn;
             if (tot - lastc > hmax) hmax = tot - lastc;
             if (curr != norm)
-                for (int vi = 0; vi < npool; ++vi)
+                for (int vi = 0; vi < npool; ++vi) {
+                    const mcio_leaf *v0 = &c->leaf[c->pool_leaf0[vi]];
+                    if (c->pool_nleaf[vi] == 1 && v0->kind == MCIO_DISCRETE && v0->nbin == 1) continue; /* nothing to sample, updates.jl:79-81 */
                     for (int pos = 1; pos <= c->dof[curr * npool + vi]; ++pos)
                         for (int l = 0; l < c->pool_width[vi]; ++l) {
                             const int k = kbase[vi] + (pos - 1) * c->pool_width[vi] + l;
                             if (tot - last[k] > hmax) hmax = tot - last[k];
                         }
+                }
             int b = 0;
             for (long h = hmax; h > 0; h >>= 1) ++b; /* bit_width */
             if (tot < 2147483647L) c->hold_hist[b] += 1;

@@ -387,6 +387,13 @@ def test_degenerate_pools_match_oracle(oracle, solver):
     got = eng.iteration(solver, 3200, 0, 4, iteration=0, seed=SEED, nchain=8)
     ref = ocfg.iteration(osolver, fn, None, 3200, 0, 4, 0, SEED, nchain=8)
     np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+    if solver == "mcmc":
+        # the single-valued Discrete never moves; it must not count as an endless hold (it would push the automatic
+        # chain length to one chain per block): were it counted, every chain's longest hold would be its full length
+        # (400 measured + 496 burn-in steps -> bucket 10)
+        hh = eng.hold_histogram()
+        np.testing.assert_array_equal(hh, ocfg.hold_hist)
+        assert hh.sum() == 4 * 8 and hh[10] < hh.sum() and hh[11:].sum() == 0, hh
     r = eng.integrate(solver, neval=64000, niter=5, block=8, seed=SEED)
     # exact: int_0^2 x dx * int_0^2 y dy * 3 * sum_{1..4} d = 2*2*3*10 = 120 ; int_0^2 e^-x dx * 3 = 3 (1 - e^-2)
     exact = np.array([120.0, 3.0 * (1.0 - math.exp(-2.0))])

@@ -56,7 +56,7 @@ def random_case(rng):
     return tuple(var), oleaves, dof, "\n".join(lines), len(draws)
 
 
-@pytest.mark.parametrize("case_id", range(12))
+@pytest.mark.parametrize("case_id", range(16))
 def test_random_layout_matches_oracle(oracle, case_id):
     rng = np.random.default_rng(1000 + case_id)
     var, oleaves, dof, body, ndraw = random_case(rng)
@@ -69,6 +69,8 @@ def test_random_layout_matches_oracle(oracle, case_id):
         got = eng.iteration(solver, 2400, 0, 3, iteration=case_id, seed=SEED, nchain=8)
         ref = ocfg.iteration(osolver, fn, None, 2400, 0, 3, case_id, SEED, nchain=8)
         np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300, err_msg="%s dof=%s\n%s" % (solver, dof, body))
+        if solver == "mcmc":   # the holding-time bookkeeping of the automatic chain length, bucket by bucket
+            np.testing.assert_array_equal(eng.hold_histogram(), ocfg.hold_hist, err_msg="dof=%s" % dof)
     # and two full iterations with training in between (vegas)
     ocfg = oracle.Config(oleaves, dof)
     r = eng.integrate("vegas", neval=24000, niter=3, block=8, seed=SEED)

@@ -197,6 +197,13 @@ def test_library_rccl_single_rank_and_torch_reducer():
     np.testing.assert_array_equal(eng.get_packed(), before)
     res = integrate(mci.catalog.x2y2(), var=Continuous(0.0, 1.0), dof=[[2]], solver="vegas", neval=1e5, seed=4, comm=comm)
     check(res, 2.0 / 3.0)
+    # the chain solvers through the N > 1 code path (all-reduce of `visited`, then doReweight! on every rank): same numbers as alone
+    for alg in ("vegasmc", "mcmc"):
+        kw = dict(var=Continuous(0.0, 1.0), dof=[[2], [3]], solver=alg, neval=2e5, seed=5)
+        a = integrate(mci.catalog.sphere2(), comm=comm, **kw)
+        b = integrate(mci.catalog.sphere2(), **kw)
+        np.testing.assert_allclose(a.mean, b.mean, rtol=1e-6)
+        check(a, [PI / 4.0, 4.0 * PI / 3.0 / 8])
 
 
 def test_torch_nccl_reducer_works_on_the_device_buffer_in_place():

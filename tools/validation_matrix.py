@@ -53,17 +53,19 @@ for name, mk, f, meas, exact, exact_tol in CASES:
     if ONLY and not any(o in name for o in ONLY):
         continue
     for solver in SOLVERS:
-        ms, es, secs = [], [], 0.0
+        ms, es, us, secs = [], [], [], 0.0
         for seed in range(1, nseeds + 1):
             eng = mci.Engine(mk(), f, measure=meas)
             eng.integrate(solver, neval=NE, niter=5, block=BLOCK, seed=seed, nchain=NCHAIN)
             r = eng.integrate(solver, neval=NE, niter=10, block=BLOCK, seed=seed, first_iteration=5, ignore=0, nchain=NCHAIN)
-            ms.append(r["mean"]); es.append(r["stdev"]); secs += r["seconds"]
-        ms, es = np.array(ms), np.array(es)
+            ms.append(r["mean"]); es.append(r["stdev"]); secs += r["seconds"]; us.append(r["iter_mean"].mean(0))
+        ms, es, us = np.array(ms), np.array(es), np.array(us)
+        unw = (us.mean(0) - exact) / (us.std(0, ddof=1) / math.sqrt(nseeds))   # plain mean of the iteration means, error from the seed scatter
         perr = np.sqrt((es ** 2).sum(0)) / nseeds
         perr_eff = np.hypot(perr, exact_tol * np.abs(exact))
         pooled = (ms.mean(0) - exact) / perr_eff
         maxdev = np.max(np.abs(ms - exact) / np.hypot(es, exact_tol * np.abs(exact)))
         scat = ms.std(0, ddof=1) / np.sqrt((es ** 2).mean(0))
-        print("%-24s %-8s %-28s %-10.2f %-14s %.3f" % (name, solver, np.array2string(np.round(pooled, 2), separator=" "), maxdev,
-                                                      np.array2string(np.round(scat, 2), separator=" "), secs / nseeds), flush=True)
+        print("%-24s %-8s %-28s %-10.2f %-14s %.3f   unweighted: %s" % (name, solver, np.array2string(np.round(pooled, 2), separator=" "), maxdev,
+                                                      np.array2string(np.round(scat, 2), separator=" "), secs / nseeds,
+                                                      np.array2string(np.round(unw, 2), separator=" ")), flush=True)

@@ -113,6 +113,7 @@ struct mci_problem {
     int nstat = 0;
     int64_t packed_n = 0;
     int64_t lds_bytes = 0;
+    int64_t lds_bytes_k1 = 0; // split-all sample pass: fixed part + edge cache
     // host mirrors of the tables (uploaded at create / set_*)
     std::vector<double> h_edges, h_dacc, h_ddist, h_reweight, h_ud;
     // device
@@ -543,11 +544,27 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             }
         }
         s.ntile = (int)s.tile_nbin.size();
+        // several tiles under :vegas -> "split-all": the sample pass keeps no histogram at all and uses the LDS for the edges
+        // of as many leading grids as fit (they stop being L2 gathers); every tile is replayed by mci_vegas_tiles.  Measured on
+        // C4 (32 grids): 10.3 -> see profiles; MCI_NO_SPLIT_ALL=1 restores "tile 0 in the sample pass" for A/B runs.
+        s.split_all = (s.ntile > 1 && !(getenv("MCI_NO_SPLIT_ALL") && atoi(getenv("MCI_NO_SPLIT_ALL")) != 0)) ? 1 : 0;
+        s.leaf_ecoff.assign(p->leaves.size(), -1);
+        s.ec_doubles = 0;
+        if (s.split_all) {
+            const int64_t budget = (lim1 - fixed) / 8;
+            for (size_t l = 0; l < p->leaves.size(); ++l) {
+                const Leaf &L = p->leaves[l];
+                if (L.kind != MCI_CONTINUOUS || s.ec_doubles + L.nbin + 1 > budget) continue;
+                s.leaf_ecoff[l] = s.ec_doubles;
+                s.ec_doubles += L.nbin + 1;
+            }
+        }
+        p->lds_bytes_k1 = fixed + (int64_t)s.ec_doubles * 8;
         p->ntdraw = 0;
         if (s.ntile > 1)
             for (int k = 0; k < s.ndraw; ++k) {
                 const Leaf &L = p->leaves[s.draw_leaf[k]];
-                if (L.adapt && s.cover_mask[k] && s.leaf_tile[s.draw_leaf[k]] >= 1) {
+                if (L.adapt && s.cover_mask[k] && s.leaf_tile[s.draw_leaf[k]] >= (s.split_all ? 0 : 1)) {
                     p->ntdraw += 1;
                     if (L.nbin > 65536) { delete p; return fail(MCI_ERR_INVALID, "leaf %d: more than 65536 bins with tiled histograms", s.draw_leaf[k]); }
                 }
@@ -687,7 +704,10 @@ static int compile_solver(mci_problem *p, int solver) {
             if (p->lds_bytes > 64 * 1024)
                 HIPCHK(hipFuncSetAttribute((const void *)p->f_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
         }
-        if (p->lds_bytes > 64 * 1024) {
+        if (solver == MCI_VEGAS && p->shape.split_all && p->lds_bytes_k1 > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(p->lds_bytes_k1 > p->lds_bytes ? p->lds_bytes_k1 : p->lds_bytes)));
+        else if (p->lds_bytes > 64 * 1024) {
             HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
             if (solver == MCI_VEGAS)
                 HIPCHK(hipFuncSetAttribute((const void *)p->f_dump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
@@ -881,9 +901,9 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     const int slot = (int)(p->launches % mci_problem::kEvRing);
     if (p->graph_mode) a.iter_ptr = p->d_loop; // captured launch: the iteration index is read on the device
     else HIPCHK(hipEventRecord(p->evs[2 * slot], st));
-    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)((split && s.split_all) ? p->lds_bytes_k1 : p->lds_bytes), st, args, nullptr));
     if (split)
-        HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(nrows * (s.ntile - 1)), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+        HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(nrows * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (!p->graph_mode) {
         HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
         p->launches += 1;

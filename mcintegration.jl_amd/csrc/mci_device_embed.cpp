@@ -106,7 +106,7 @@ struct BatchArgs {
     // vegas with NTILE > 1 histogram tiles: the sample pass keeps tile 0 and parks, per sample, the histogram
     // weights and the 16-bit bins of the other tiles' draws in HBM; mci_vegas_tiles replays them per tile
     double *tile_w;         // [NI][tile_stride]
-    u32 *tile_bins;         // [ceil(ntdraw/2)][tile_stride]  two bins per word
+    u32 *tile_bins;         // [tdraw_words][tile_stride]  32 / ceil(log2(nbin)) bins per word
     i64 tile_stride;        // samples of this launch
     // host integrand ("batch callback", Cfg::HOST_INTEGRAND): weights evaluated on the host for exactly the draws
     // this launch regenerates, host_w[q * tile_stride + sample]
@@ -145,8 +145,8 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void global_add(double *p, double v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RE)MCIDEV"
-R"MCIDEV(LAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(p,)MCIDEV"
+R"MCIDEV( v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -163,6 +163,7 @@ template <class Cfg> struct Mode {
 };
 
 template <class Cfg> struct Tables {
+    const double *EC; // split-all sample pass: LDS cache of the leading leaves' edges (Cfg::leaf_ecoff)
     const double *E;  // grid edges (LDS or global)
     const double *DA; // discrete accumulation (LDS)
     const double *DD; // discrete distribution (LDS)
@@ -173,7 +174,7 @@ template <class Cfg> struct Tables {
 // With Cfg::PAIR_TABLE the LDS table holds (g[i], g[i+1]-g[i]) pairs: ONE aligned ds_read_b128 per draw and
 // no subtraction on the critical path (the pair is formed with the same rounding when the table is staged).
 // U12 = true: `y` is the uniform PLUS ONE (in [1, 2), see u12()).
-template <class Cfg, int K, bool U12 = false> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
+template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
     constexpr int leaf = Cfg::draw_leaf(K);
     if constexpr (Cfg::leaf_kind(leaf) != 0 && U12) y -= 1.0;
     if constexpr (Cfg::leaf_kind(leaf) == 0) {
@@ -191,6 +192,10 @@ template <class Cfg, int K, bool U12 = false> __device__ __forceinline__ void dr
             const d2 e = *reinterpret_cast<const d2 *>(t.E + Cfg::leaf_poff(leaf) + 2 * iy);
             g0 = e.x;
             dx = e.y;
+        } else if constexpr (ECACHE && Cfg::leaf_ecoff(leaf) >= 0) {
+            constexpr int eoff = Cfg::leaf_ecoff(leaf); // this leaf's edges sit in the LDS cache of the split-all sample pass
+            g0 = t.EC[eoff + iy];
+            dx = t.EC[eoff + iy + 1] - g0;
         } else {
             constexpr int eoff = Cfg::leaf_eoff(leaf);
             g0 = t.E[eoff + iy]; // (L2 gathers in table modes 2/3: non-temporal loads measured 30 % slower)
@@ -247,7 +252,7 @@ template <class Cfg> struct Sample {
     double jaci[Cfg::NI];
 };
 
-template <class Cfg> __device__ __forceinline__ void draw_sample(const Tables<Cfg> &t, u64 seed, u32 stream, u64 index, Sample<Cfg> &s) {
+template <class Cfg, bool ECACHE = false> __device__ __forceinline__ void draw_sample(const Tables<Cfg> &t, u64 seed, u32 stream, u64 index, Sample<Cfg> &s) {
     const u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
     const u32 ilo = (u32)index, ihi = (u32)(index >> 32);
     constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
@@ -261,7 +266,7 @@ template <class Cfg> __device__ __forceinline__ void draw_sample(const Tables<Cf
             if constexpr (k < Cfg::NDRAW) {
                 const double y1 = decltype(H)::value == 0 ? u12(r.x, r.y) : u12(r.z, r.w);
                 double raw;
-                draw_leaf<Cfg, k, true>(t, y1, s.x[k], raw, s.bin[k]);
+                draw_leaf<Cfg, k, true, ECACHE>(t, y1, s.x[k], raw, s.bin[k]);
                 s.pj[k] = raw * jac_scale<Cfg>(k);
                 s.jac *= raw; // jac /= prob   vegas/montecarlo.jl:126 (scale applied below)
                 static_for<0, Cfg::NI>([&](auto I) {
@@ -290,7 +295,8 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
     if constexpr (Cfg::TABLE_MODE <= 1) {
         if constexpr (Cfg::PAIR_TABLE != 0) {
             static_for<0, Cfg::NLEAF>([&](auto Lf) {
-                constexpr int l = decltype(Lf)::value;
+                constexpr int)MCIDEV"
+R"MCIDEV( l = decltype(Lf)::value;
                 if constexpr (Cfg::leaf_kind(l) == 0) {
                     constexpr int eoff = Cfg::leaf_eoff(l), poff = Cfg::leaf_poff(l);
                     for (int i = tid; i < Cfg::leaf_nbin(l); i += T) {
@@ -298,8 +304,7 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
                         sE[poff + 2 * i] = g0;
                         sE[poff + 2 * i + 1] = g1 - g0;
                     }
-)MCIDEV"
-R"MCIDEV(                }
+                }
             });
         } else {
             for (int i = tid; i < Cfg::NEDGE; i += T) sE[i] = gE[i];
@@ -318,6 +323,17 @@ template <class Cfg> struct Lds {
     static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE : 0);
     static constexpr int R = O + Cfg::NOBS;
     static constexpr int END = R + 16 /*waves*/ * Cfg::NCOLS;
+};
+
+template <bool B, class X, class Y> struct SelectType { using type = X; };
+template <class X, class Y> struct SelectType<false, X, Y> { using type = Y; };
+// the split-all sample pass has no histogram: observables and the reduction scratch move up, the edge cache takes the rest
+template <class Cfg> struct LdsEC {
+    static constexpr int E = 0, DA = Lds<Cfg>::DA, DD = Lds<Cfg>::DD, H = Lds<Cfg>::H;
+    static constexpr int O = H;
+    static constexpr int R = O + Cfg::NOBS;
+    static constexpr int EC = R + 16 * Cfg::NCOLS;
+    static constexpr int END = EC + Cfg::EC_DOUBLES;
 };
 
 // partial-statistics columns written per workgroup:
@@ -391,9 +407,9 @@ template <class Cfg> __device__ __forceinline__ void measure(const double *x, co
 }
 
 // workgroup epilogue: registers -> wave shuffle -> LDS -> one row of part_cols; LDS histogram -> part_hist
-template <class Cfg> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/, i64 rowid, int tile) {
+template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/, i64 rowid, int tile) {
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
-    double *sO = smem + Lds<Cfg>::O, *sR = smem + Lds<Cfg>::R, *sH = smem + Lds<Cfg>::H;
+    double *sO = smem + L::O, *sR = smem + L::R, *sH = smem + L::H;
     // scalar observables of the default measure (register accumulators)
     if constexpr (Cfg::CUSTOM_MEASURE == 0) {
         static_for<0, Cfg::NI>([&](auto I) {
@@ -425,10 +441,11 @@ template <class Cfg> __device__ __forceinline__ void flush_workgroup(const Batch
             for (int w = 0; w < nwave; ++w) v += sR[w * Cfg::NCOLS + c]; // fixed order: deterministic
         row[c] = v;
     }
-    if constexpr (Mode<Cfg>::HIST_LDS) {
+    if constexpr (Mode<Cfg>::HIST_LDS && WRITE_HIST) {
         static_for<0, Cfg::NTILE>([&](auto Tt) {
             constexpr int tt = decltype(Tt)::value;
-            if (tile == tt) {
+            if)MCIDEV"
+R"MCIDEV( (tile == tt) {
                 double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
                 for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = sH[i];
             }
@@ -436,9 +453,10 @@ template <class Cfg> __device__ __forceinline__ void flush_workgroup(const Batch
     }
 }
 
-// draws whose histogram lives in a tile >= 1 (adaptive and covered by some integrand), in draw order
+// draws whose histogram is replayed by mci_vegas_tiles (adaptive and covered by some integrand; tile >= 1, or every tile in
+// split-all mode), in draw order
 template <class Cfg> constexpr bool is_tdraw(int k) {
-    return Cfg::NTILE > 1 && Cfg::leaf_adapt(Cfg::draw_leaf(k)) != 0 && Cfg::cover_mask(k) != 0ull && Cfg::leaf_tile(Cfg::draw_leaf(k)) >= 1;
+    return Cfg::NTILE > 1 && Cfg::leaf_adapt(Cfg::draw_leaf(k)) != 0 && Cfg::cover_mask(k) != 0ull && Cfg::leaf_tile(Cfg::draw_leaf(k)) >= (Cfg::SPLIT_ALL != 0 ? 0 : 1);
 }
 template <class Cfg> constexpr int tdraw_count() {
     int n = 0;
@@ -450,14 +468,24 @@ template <class Cfg> constexpr int tdraw_pos(int k) { // position of draw k in t
     for (int j = 0; j < k; ++j) n += is_tdraw<Cfg>(j) ? 1 : 0;
     return n;
 }
+// parked bins are packed TDRAW_PER to a 32-bit word, TDRAW_BITS bits each (10 bits for the default 999-bin grids: 3 per word)
+template <class Cfg> constexpr int tdraw_bits() {
+    int mx = 2;
+    for (int k = 0; k < Cfg::NDRAW; ++k)
+        if (is_tdraw<Cfg>(k) && Cfg::leaf_nbin(Cfg::draw_leaf(k)) > mx) mx = Cfg::leaf_nbin(Cfg::draw_leaf(k));
+    int b = 1;
+    while ((1 << b) < mx) ++b;
+    return b;
+}
+template <class Cfg> constexpr int tdraw_per() { return 32 / tdraw_bits<Cfg>(); }
+template <class Cfg> constexpr int tdraw_words() { return (tdraw_count<Cfg>() + tdraw_per<Cfg>() - 1) / tdraw_per<Cfg>(); }
 
 // blockIdx -> (statistical block, slice of the block, histogram tile)
 struct WorkItem {
     i64 rowid, lb;
     int slice, tile;
 };
-template <class Cfg> __device__ __forceinline__ WorkItem work_item(const Batc)MCIDEV"
-R"MCIDEV(hArgs &a) {
+template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchArgs &a) {
     WorkItem w;
     w.tile = Cfg::NTILE == 1 ? 0 : (int)(blockIdx.x % Cfg::NTILE);
     w.rowid = Cfg::NTILE == 1 ? (i64)blockIdx.x : (i64)(blockIdx.x / Cfg::NTILE);
@@ -474,14 +502,27 @@ R"MCIDEV(hArgs &a) {
 template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, T = blockDim.x;
-    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
-    double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
+    // split-all (SPLIT and Cfg::SPLIT_ALL): no histogram in this pass; the LDS it would take caches the leading leaves' edges
+    constexpr bool EC = SPLIT && Cfg::SPLIT_ALL != 0;
+    using L = typename SelectType<EC, LdsEC<Cfg>, Lds<Cfg>>::type;
+    double *sE = smem + L::E, *sDA = smem + L::DA, *sDD = smem + L::DD;
+    double *sH = smem + L::H, *sO = smem + L::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
-    if constexpr (Mode<Cfg>::HIST_LDS)
+    if constexpr (Mode<Cfg>::HIST_LDS && !EC)
         for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
-    __syncthreads();
     Tables<Cfg> t;
+    t.EC = nullptr;
+    if constexpr (EC) {
+        double *sEC = smem + LdsEC<Cfg>::EC;
+        static_for<0, Cfg::NLEAF>([&](auto Lf) {
+            constexpr int l = decltype(Lf)::value;
+            if constexpr (Cfg::leaf_kind(l) == 0 && Cfg::leaf_ecoff(l) >= 0)
+                for (int i = tid; i <= Cfg::leaf_nbin(l); i += T) sEC[Cfg::leaf_ecoff(l) + i] = a.edges[Cfg::leaf_eoff(l) + i];
+        });
+        t.EC = sEC;
+    }
+    __syncthreads();
     if constexpr (Mode<Cfg>::EDGE_LDS) t.E = sE;
     else t.E = a.edges;
     t.DA = sDA;
@@ -507,7 +548,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     auto run = [&](auto TT) { // the sample loop, specialised on the workgroup's histogram tile
     for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
         Sample<Cfg> s;
-        draw_sample<Cfg>(t, a.seed, stream, (u64)(B * a.neval_per_block + n), s);
+        draw_sample<Cfg, EC>(t, a.seed, stream, (u64)(B * a.neval_per_block + n), s);
         double w[Cfg::NW];
         if constexpr (Cfg::HOST_INTEGRAND != 0) { // the closure ran on the host over the dumped draws
             const i64 hidx = wi.lb * a.neval_per_block + n;
@@ -529,54 +570,59 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             wh[i] = wj * wj;                      // :180
         });
 #ifndef MCI_ABL_NOHIST
-        hist_update<Cfg, decltype(TT)::value>(s, wh, sH, a.ghist, tile);
+        if constexpr (!EC) hist_update<Cfg, decltype(TT)::value>(s, wh, sH, a.ghist, tile);
 #else
         acc[0] += wh[0] * 1e-300;
 #endif
         if constexpr (SPLIT) { // park what the other tiles need: coalesced (lane == consecutive sample) 8- and 4-byte stores
             const i64 idx = wi.lb * a.neval_per_block + n;
             static_for<0, Cfg::NI>([&](auto I) { a.tile_w[decltype(I)::value * a.tile_stride + idx] = wh[decltype(I)::value]; });
-            constexpr int NT = tdraw_count<Cfg>();
-            u32 word[(NT + 1) / 2 > 0 ? (NT + 1) / 2 : 1];
-            static_for<0, (NT + 1) / 2>([&](auto J) { word[decltype(J)::value] = 0u; });
+            constexpr int NWORD = tdraw_words<Cfg>(), PER = tdraw_per<Cfg>(), BITS = tdraw_bits<Cfg>();
+            u32 word[NWORD > 0 ? NWORD : 1];
+            static_for<0, NWORD>([&](auto J) { word[decltype(J)::value] = 0u; });
             static_for<0, Cfg::NDRAW>([&](auto K) {
                 constexpr int k = decltype(K)::value;
                 if constexpr (is_tdraw<Cfg>(k)) {
                     constexpr int m = tdraw_pos<Cfg>(k);
-                    word[m / 2] |= (u32)s.bin[k] << (16 * (m & 1));
+                    word[m / PER] |= (u32)s.bin[k] << (BITS * (m % PER));
                 }
             });
-            static_for<0, (NT + 1) / 2>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = word[decltype(J)::value]; });
+            static_for<0, NWORD>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = word[decltype(J)::value]; });
         }
     }
     };
     if constexpr (Cfg::NTILE == 1 || SPLIT) run(IC<0>{});
     else static_for<0, Cfg::NTILE>([&](auto TT) { if (tile == decltype(TT)::value) run(TT); });
     __syncthreads();
-    flush_workgroup<Cfg>(a, smem, acc, extra, wi.rowid, tile);
+    flush_workgroup<Cfg, L, !EC>(a, smem, acc, extra, wi.rowid, tile);
 }
 
-// histogram tiles 1 .. NTILE-1 of a SPLIT vegas pass: workgroup = (block, slice, tile); replays the parked
+// histogram tiles 1 .. NTILE-1 (split-all: 0 .. NTILE-1) of a SPLIT vegas pass: workgroup = (block, slice, tile); replays the parked
 // (weights, bins) of the same samples its sample-pass workgroup drew -- no RNG, no gathers, no integrand:
 // 8*NI + 2 bytes per tiled draw of coalesced HBM reads and one ds_add_f64 per draw.
+#ifndef MCI_TILES_U
+#define MCI_TILES_U 4
+#endif
 template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x, T = blockDim.x;
+ )MCIDEV"
+R"MCIDEV(   const int tid = threadIdx.x, T = blockDim.x;
     double *sH = smem + Lds<Cfg>::H;
-    constexpr int NTM = Cfg::NTILE > 1 ? Cfg::NTILE - 1 : 1;
-    const int tile = 1 + (int)(blockIdx.x % NTM);
+    constexpr int T0 = Cfg::SPLIT_ALL != 0 ? 0 : 1; // first replayed tile
+    constexpr int NTM = Cfg::NTILE - T0 > 0 ? Cfg::NTILE - T0 : 1;
+    const int tile = T0 + (int)(blockIdx.x % NTM);
     const i64 rowid = (i64)(blockIdx.x / NTM), lb = rowid / a.wg_per_block;
     const int slice = (int)(rowid % a.wg_per_block);
     for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
     __syncthreads();
     const i64 stride = (i64)a.wg_per_block * T;
-    static_for<1, Cfg::NTILE>([&](auto TT) {
+    static_for<T0, Cfg::NTILE>([&](auto TT) {
         constexpr int tt = decltype(TT)::value;
         if (tile == tt) {
             // U samples per lane and trip: all their loads are issued before the first ds_add_f64 (the kernel has one
             // 512-thread workgroup per CU, so memory-level parallelism has to come from the loop body)
-            constexpr int U = 4;
-            constexpr int NT = tdraw_count<Cfg>(), NWORD = (NT + 1) / 2;
+            constexpr int U = MCI_TILES_U;
+            constexpr int NWORD = tdraw_words<Cfg>(), PER = tdraw_per<Cfg>(), BITS = tdraw_bits<Cfg>();
             for (i64 n0 = (i64)slice * T + tid; n0 < a.neval_per_block; n0 += stride * U) {
                 double wh[U][Cfg::NI];
                 u32 word[U][NWORD > 0 ? NWORD : 1];
@@ -592,7 +638,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
                         // only the words that hold a draw of this tile
                         constexpr bool need = [] {
                             for (int k = 0; k < Cfg::NDRAW; ++k)
-                                if (is_tdraw<Cfg>(k) && Cfg::leaf_tile(Cfg::draw_leaf(k)) == tt && tdraw_pos<Cfg>(k) / 2 == j) return true;
+                                if (is_tdraw<Cfg>(k) && Cfg::leaf_tile(Cfg::draw_leaf(k)) == tt && tdraw_pos<Cfg>(k) / PER == j) return true;
                             return false;
                         }();
                         if constexpr (need) word[u][j] = a.tile_bins[j * a.tile_stride + idx];
@@ -604,11 +650,10 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
                         static_for<0, Cfg::NDRAW>([&](auto K) {
                             constexpr int k = decltype(K)::value;
                             if constexpr (is_tdraw<Cfg>(k)) {
-             )MCIDEV"
-R"MCIDEV(                   constexpr int leaf = Cfg::draw_leaf(k);
+                                constexpr int leaf = Cfg::draw_leaf(k);
                                 if constexpr (Cfg::leaf_tile(leaf) == tt) {
                                     constexpr int m = tdraw_pos<Cfg>(k);
-                                    const int bin = (int)((word[u][m / 2] >> (16 * (m & 1))) & 0xFFFFu);
+                                    const int bin = (int)((word[u][m / PER] >> (BITS * (m % PER))) & ((1u << BITS) - 1u));
                                     double wk = 0.0;
                                     static_for<0, Cfg::NI>([&](auto I) {
                                         constexpr int i = decltype(I)::value;
@@ -703,7 +748,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     constexpr int NI = Cfg::NI, NORMI = Cfg::NI;
     const int tid = threadIdx.x, T = blockDim.x;
     double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
-    double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
+    double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<)MCIDEV"
+R"MCIDEV(Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
         for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
@@ -755,8 +801,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
 
         for (i64 ne = 1; ne <= steps; ++ne) { // :184
             const u64 sidx = (g << 32) | (u64)(ne - 1);
-            const u32x4 r0 = phi)MCIDEV"
-R"MCIDEV(lox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
+            const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
             const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
             // ---- changeVariable  updates.jl:45-106 ----
             // :50 rand(1:Nv).  With many chains per block the 64 chains of a wave share the pool-pick sequence (it does
@@ -838,7 +883,8 @@ R"MCIDEV(lox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
                     wh[i] = f2 * pad[i] / probability;                                 // :204
                 });
                 Sample<Cfg> sb;
-                static_for<0, Cfg::NDRAW>([&](auto K) { sb.bin[decltype(K)::value] = c.bin[decltype(K)::value]; });
+                static_for<0, Cfg::NDRAW>([&](auto K) { sb.bin[decltype(K)::value)MCIDEV"
+R"MCIDEV(] = c.bin[decltype(K)::value]; });
                 hist_update<Cfg>(sb, wh, sH, a.ghist, tile);
             }
             // ---- measurement  montecarlo.jl:213-232 ----
@@ -878,8 +924,7 @@ R"MCIDEV(lox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
 // ---------------------------------------------------------------------------------------------
 // FermiK{D} (variable.jl:1-20, sampler.jl:109-281): a momentum on a shell |k| in (kF - dk, kF + dk), D = 2 | 3
 // components per slot, no adaptive map, :mcmc only.  kF = leaf_lower, dk = leaf_upper, D = pool_nleaf(V).
-// ------------------------------)MCIDEV"
-R"MCIDEV(---------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
 #define MCI_PI 3.14159265358979323846
 // create!  sampler.jl:109-148.  u = D uniforms; returns the proposal weight (0: rejected, k untouched)
 template <class Cfg, int V> __device__ __forceinline__ double fermik_create(const double *u, double *k) {
@@ -981,7 +1026,8 @@ template <int K> __device__ __forceinline__ double step_uniform(u64 sidx, u32 st
 // the same with a run-time k (k >= 5: the shifted slot of changeVariable is a run-time value)
 __device__ __forceinline__ double step_uniform_dyn(int k, u64 sidx, u32 stream, u32 k0, u32 k1) {
     const u32x4 r = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(k >> 1), stream, k0, k1);
-    return (k & 1) ? u01(r.z, r.w) : u01(r.x, r.y);
+    return )MCIDEV"
+R"MCIDEV((k & 1) ? u01(r.z, r.w) : u01(r.x, r.y);
 }
 // histogram add of one draw with the table-mode dispatch of hist_update
 template <class Cfg, int K> __device__ __forceinline__ void hist_add(int bin, double wk, double *sH, double *gH, int tile) {
@@ -1033,8 +1079,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     static_for<0, Cfg::NW>([&](auto I) { acc[decltype(I)::value] = 0.0; });
     double extra[Cfg::NCOLS - Cfg::NOBS];
     static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
-    constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Co)MCIDEV"
-R"MCIDEV(ls<Cfg>::VISITED - Cfg::NOBS;
+    constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
     constexpr int XP = Cols<Cfg>::PROPOSE - Cfg::NOBS, XA = Cols<Cfg>::ACCEPT - Cfg::NOBS;
 
     for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
@@ -1113,7 +1158,8 @@ R"MCIDEV(ls<Cfg>::VISITED - Cfg::NOBS;
             // ---- build the proposal (n, prop, newcurr); ONE evaluate-and-accept tail serves all three updates, so
             // lanes that diverged on the update type reconverge before the expensive part ----
             Chain<Cfg> n = c;
-            double prop = 1.0;
+   )MCIDEV"
+R"MCIDEV(         double prop = 1.0;
             bool active = false;
             int newcurr = curr, ut = 0; // ut: first index of propose[., ., .]: 0 changeIntegrand, 1 changeVariable, 2 swapVariable
             u64 touched = 0ull; // draws of the slot(s) this proposal moves (changeVariable, swapVariable)
@@ -1146,8 +1192,7 @@ R"MCIDEV(ls<Cfg>::VISITED - Cfg::NOBS;
                                                     static_for<0, nl>([&](auto J) { u[decltype(J)::value] = step_uniform<5 + kb + decltype(J)::value>(sidx, st_step, k0, k1, r2); });
                                                     prop *= fermik_create<Cfg, v>(u, kk);
                                                     static_for<0, nl>([&](auto J) { n.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
-                                            )MCIDEV"
-R"MCIDEV(    } else {                 // remove!  sampler.jl:158-188
+                                                } else {                 // remove!  sampler.jl:158-188
                                                     prop *= fermik_remove<Cfg, v>(kk);
                                                 }
                                             });
@@ -1228,7 +1273,8 @@ R"MCIDEV(    } else {                 // remove!  sampler.jl:158-188
                                     int bo;
                                     static_for<0, nl>([&](auto J) {
                                         constexpr int j = decltype(J)::value;
-                                        u[j] = step_uniform_dyn(5 + k00 + slot * nl + j, sidx, st_step, k0, k1);
+    )MCIDEV"
+R"MCIDEV(                                    u[j] = step_uniform_dyn(5 + k00 + slot * nl + j, sidx, st_step, k0, k1);
                                         get_slot<Cfg, v, j>(c, slot, kk[j], po, bo);
                                     });
                                     prop *= fermik_shift<Cfg, v>(us2, u, kk);
@@ -1264,8 +1310,7 @@ R"MCIDEV(    } else {                 // remove!  sampler.jl:158-188
                 });
                 if (a.hold_hist) {
                     const int now = (int)it;
-                    u64 mo = 0ull, mn = 0ull; // live draws of the old and of the proposed )MCIDEV"
-R"MCIDEV(integrand
+                    u64 mo = 0ull, mn = 0ull; // live draws of the old and of the proposed integrand
                     static_for<0, NI>([&](auto I) {
                         constexpr int i = decltype(I)::value;
                         mo = curr == i ? Cfg::own_mask(i) : mo;
@@ -1348,7 +1393,8 @@ R"MCIDEV(integrand
 // the map + integrand alone, for parity tests of a2/a3 and for host-side consumers
 template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
+    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD)MCIDEV"
+R"MCIDEV( = smem + Lds<Cfg>::DD;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     __syncthreads();
     Tables<Cfg> t;

@@ -37,6 +37,10 @@ struct ProblemShape {
     std::vector<unsigned long long> cover_mask; // [ndraw] integrands covering draw k
     std::vector<int> obs_off, obs_nbin, obs_bin_draw;
     std::vector<int> pool_maxdof, pool_nleaf, pool_first_draw;
+    // vegas with NTILE > 1 ("split-all"): the sample pass keeps NO histogram, caches the edges of the leading leaves in the
+    // LDS the histogram tile would take (leaf_ecoff >= 0: offset in that cache, doubles), and every tile is replayed
+    int split_all = 0, ec_doubles = 0;
+    std::vector<int> leaf_ecoff;
     std::vector<int> dof;                 // [(ni+1)*npool] incl. the normalisation row (zeros)
     int nbmax = 1;
     int ncomp = 1;            // 1: Float64 weights; 2: ComplexF64 stored (re, im)
@@ -99,6 +103,12 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     o << fn_table("int", "leaf_adapt", arr(s.leaf_adapt, "int"));
     o << fn_table("int", "leaf_poff", arr(s.leaf_poff, "int"));
     o << "    static constexpr int NTILE = " << s.ntile << ", HTILE = " << s.htile << ";\n";
+    o << "    static constexpr int SPLIT_ALL = " << (solver == 0 ? s.split_all : 0) << ", EC_DOUBLES = " << (solver == 0 ? s.ec_doubles : 0) << ";\n";
+    {
+        std::vector<int> ec = s.leaf_ecoff;
+        if (solver != 0 || !s.split_all || ec.size() != s.leaf_kind.size()) ec.assign(s.leaf_kind.size(), -1);
+        o << fn_table("int", "leaf_ecoff", arr(ec, "int"));
+    }
     o << fn_table("int", "leaf_tile", arr(s.leaf_tile, "int"));
     o << fn_table("int", "tile_boff", arr(s.tile_boff, "int"));
     o << fn_table("int", "tile_nbin", arr(s.tile_nbin, "int"));

@@ -315,10 +315,12 @@ def test_launch_geometry_independence(oracle):
 def test_table_modes_agree(monkeypatch):
     """LDS-resident tables (mode 0), LDS grids + global f64 atomics (1), everything from L2 (2)."""
     outs = []
-    for mode, tile_bins in (("0", None), ("1", None), ("2", None), ("3", None), ("3", "1000"), ("3", "2000")):
+    for mode, tile_bins, keep_tile0 in (("0", None, "0"), ("1", None, "0"), ("2", None, "0"), ("3", None, "0"), ("3", "1000", "0"), ("3", "2000", "0"),
+                                        ("3", "1000", "1")):
         monkeypatch.setenv("MCI_TABLE_MODE", mode)
+        monkeypatch.setenv("MCI_NO_SPLIT_ALL", keep_tile0)       # "1": tile 0 stays in the sample pass, only the other tiles are replayed
         if tile_bins:
-            monkeypatch.setenv("MCI_HIST_TILE_BINS", tile_bins)  # force 3 / 2 histogram tiles
+            monkeypatch.setenv("MCI_HIST_TILE_BINS", tile_bins)  # force 3 / 2 histogram tiles (split-all: every tile replayed, edges cached in LDS)
         cfg = mci.Configuration(var=mci.Continuous([(0.0, PI)] * 3), dof=[[1]], seed=SEED)
         eng = mci.Engine(cfg, mci.catalog.singular2())
         assert eng.table_mode == int(mode)

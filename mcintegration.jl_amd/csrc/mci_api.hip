@@ -530,11 +530,26 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             if (const char *e = getenv("MCI_HIST_TILE_BINS")) budget = atoll(e);
             s.tile_boff.clear();
             s.tile_nbin.clear();
+            // as few tiles as the budget allows, filled evenly: the replay kernel's time follows its LARGEST tile
+            // (C4: 19 + 13 grids 2.70 ms, 16 + 16 grids 2.23 ms)
+            int64_t fill = budget;
+            {
+                int64_t ntile_min = 1, acc = 0;
+                for (const Leaf &L : p->leaves) {
+                    if (acc + L.nbin > budget) { ntile_min += 1; acc = 0; }
+                    acc += L.nbin;
+                }
+                const int64_t even = ((int64_t)s.nbin + ntile_min - 1) / ntile_min;
+                int64_t mx = 0;
+                for (const Leaf &L : p->leaves) mx = L.nbin > mx ? L.nbin : mx;
+                fill = even + mx - 1 < budget ? even + mx - 1 : budget; // a tile closes once it holds >= `even` bins
+                if (getenv("MCI_HIST_TILE_BINS")) fill = budget;
+            }
             int cur = -1;
             for (size_t l = 0; l < p->leaves.size(); ++l) {
                 const Leaf &L = p->leaves[l];
                 if (L.nbin > budget) { delete p; return fail(MCI_ERR_INVALID, "leaf %zu: %d bins do not fit the LDS histogram", l, L.nbin); }
-                if (cur < 0 || s.tile_nbin[cur] + L.nbin > budget) {
+                if (cur < 0 || s.tile_nbin[cur] + L.nbin > fill) {
                     s.tile_boff.push_back(L.boff);
                     s.tile_nbin.push_back(0);
                     cur += 1;
@@ -853,6 +868,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.tile_w = p->d_tile_w;
     a.tile_bins = p->d_tile_bins;
     a.tile_stride = nblocks * nevalperblock;
+    a.nrows = nrows;
     if (s.host_integrand) {
         // "batch callback": the closure cannot run on the device, so the draws of this launch go to the host (SoA,
         // x[k*n + i]), the callback fills w[q*n + i], and the sample kernel regenerates the same draws (same Philox
@@ -903,7 +919,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     else HIPCHK(hipEventRecord(p->evs[2 * slot], st));
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)((split && s.split_all) ? p->lds_bytes_k1 : p->lds_bytes), st, args, nullptr));
     if (split)
-        HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(nrows * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+        HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (!p->graph_mode) {
         HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
         p->launches += 1;

@@ -108,6 +108,7 @@ struct BatchArgs {
     double *tile_w;         // [NI][tile_stride]
     u32 *tile_bins;         // [tdraw_words][tile_stride]  32 / ceil(log2(nbin)) bins per word
     i64 tile_stride;        // samples of this launch
+    i64 nrows;              // partial rows (block, slice) of this launch
     // host integrand ("batch callback", Cfg::HOST_INTEGRAND): weights evaluated on the host for exactly the draws
     // this launch regenerates, host_w[q * tile_stride + sample]
     const double *host_w;
@@ -144,9 +145,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ void lds_add(double *p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void global_add(double *p, double v) {
-    __hip_atomic_fetch_add(p,)MCIDEV"
-R"MCIDEV( v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinl)MCIDEV"
+R"MCIDEV(ine__ void global_add(double *p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -294,9 +295,9 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
     const int tid = threadIdx.x, T = blockDim.x;
     if constexpr (Cfg::TABLE_MODE <= 1) {
         if constexpr (Cfg::PAIR_TABLE != 0) {
-            static_for<0, Cfg::NLEAF>([&](auto Lf) {
-                constexpr int)MCIDEV"
-R"MCIDEV( l = decltype(Lf)::value;
+        )MCIDEV"
+R"MCIDEV(    static_for<0, Cfg::NLEAF>([&](auto Lf) {
+                constexpr int l = decltype(Lf)::value;
                 if constexpr (Cfg::leaf_kind(l) == 0) {
                     constexpr int eoff = Cfg::leaf_eoff(l), poff = Cfg::leaf_poff(l);
                     for (int i = tid; i < Cfg::leaf_nbin(l); i += T) {
@@ -442,10 +443,10 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true> __device__ __fo
         row[c] = v;
     }
     if constexpr (Mode<Cfg>::HIST_LDS && WRITE_HIST) {
-        static_for<0, Cfg::NTILE>([&](auto Tt) {
+        static_for<0, Cfg::NTILE>([&](aut)MCIDEV"
+R"MCIDEV(o Tt) {
             constexpr int tt = decltype(Tt)::value;
-            if)MCIDEV"
-R"MCIDEV( (tile == tt) {
+            if (tile == tt) {
                 double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
                 for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = sH[i];
             }
@@ -603,15 +604,21 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 #ifndef MCI_TILES_U
 #define MCI_TILES_U 4
 #endif
-template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs &a) {
+template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs)MCIDEV"
+R"MCIDEV( &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
- )MCIDEV"
-R"MCIDEV(   const int tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = blockDim.x;
     double *sH = smem + Lds<Cfg>::H;
     constexpr int T0 = Cfg::SPLIT_ALL != 0 ? 0 : 1; // first replayed tile
     constexpr int NTM = Cfg::NTILE - T0 > 0 ? Cfg::NTILE - T0 : 1;
-    const int tile = T0 + (int)(blockIdx.x % NTM);
-    const i64 rowid = (i64)(blockIdx.x / NTM), lb = rowid / a.wg_per_block;
+    // XCD-aware mapping: workgroups go round-robin to the 8 XCDs, so blockIdx % 8 is the XCD.  The NTM tile-workgroups of one
+    // row sit on ONE XCD, back to back (the second finds the row's weights in that XCD's L2), and every tile is spread over all
+    // XCDs (tile = blockIdx % NTM would pin each tile to a subset of the XCDs: measured 2.7 ms for tile 0 alone on 4 XCDs).
+    const i64 q = (i64)blockIdx.x / 8;
+    const int tile = T0 + (int)(q % NTM);
+    const i64 rowid = (q / NTM) * 8 + (i64)(blockIdx.x % 8);
+    if (rowid >= a.nrows) return; // the grid is rounded up to a multiple of 8 * NTM
+    const i64 lb = rowid / a.wg_per_block;
     const int slice = (int)(rowid % a.wg_per_block);
     for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
     __syncthreads();
@@ -737,7 +744,8 @@ template <class Cfg, int V, int L> __device__ __forceinline__ void put_slot(Chai
 }
 // one leaf draw for pool V, leaf L (every slot of a pool shares the leaf's table): x, prob = 1/(raw*scale), bin
 template <class Cfg, int V, int L> __device__ __forceinline__ void draw_pool_leaf(const Tables<Cfg> &t, double y, double &x, double &p, int &b) {
-    constexpr int k = Cfg::pool_first_draw(V) + L; // slot 0 of the pool: same leaf as every other slot
+    con)MCIDEV"
+R"MCIDEV(stexpr int k = Cfg::pool_first_draw(V) + L; // slot 0 of the pool: same leaf as every other slot
     double raw;
     draw_leaf<Cfg, k>(t, y, x, raw, b);
     p = 1.0 / (raw * jac_scale<Cfg>(k));
@@ -748,8 +756,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     constexpr int NI = Cfg::NI, NORMI = Cfg::NI;
     const int tid = threadIdx.x, T = blockDim.x;
     double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
-    double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<)MCIDEV"
-R"MCIDEV(Cfg>::O;
+    double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
         for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
@@ -872,7 +879,8 @@ R"MCIDEV(Cfg>::O;
                     static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = padn[decltype(I)::value]; }); // :96-98
                     probability = newp;                        // :100
                 } // else shiftRollback!  :102  (the proposal copy is dropped)
-            }
+   )MCIDEV"
+R"MCIDEV(         }
             // ---- histogram  montecarlo.jl:198-211 ----
             {
                 double wh[NI];
@@ -883,8 +891,7 @@ R"MCIDEV(Cfg>::O;
                     wh[i] = f2 * pad[i] / probability;                                 // :204
                 });
                 Sample<Cfg> sb;
-                static_for<0, Cfg::NDRAW>([&](auto K) { sb.bin[decltype(K)::value)MCIDEV"
-R"MCIDEV(] = c.bin[decltype(K)::value]; });
+                static_for<0, Cfg::NDRAW>([&](auto K) { sb.bin[decltype(K)::value] = c.bin[decltype(K)::value]; });
                 hist_update<Cfg>(sb, wh, sH, a.ghist, tile);
             }
             // ---- measurement  montecarlo.jl:213-232 ----
@@ -1016,7 +1023,8 @@ template <class Cfg> __device__ __forceinline__ Weight<Cfg> eval_sel(int curr, c
     return r;
 }
 // uniform k of a chain step; chunk 2 (k = 4, 5) is shared with the accept draw
-template <int K> __device__ __forceinline__ double step_uniform(u64 sidx, u32 stream, u32 k0, u32 k1, const u32x4 &r2) {
+template <int K> __device__ __forceinline__ double step_uniform(u64 sidx, u32 strea)MCIDEV"
+R"MCIDEV(m, u32 k0, u32 k1, const u32x4 &r2) {
     if constexpr ((K >> 1) == 2) return (K & 1) ? u01(r2.z, r2.w) : u01(r2.x, r2.y);
     else {
         const u32x4 r = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(K >> 1), stream, k0, k1);
@@ -1026,8 +1034,7 @@ template <int K> __device__ __forceinline__ double step_uniform(u64 sidx, u32 st
 // the same with a run-time k (k >= 5: the shifted slot of changeVariable is a run-time value)
 __device__ __forceinline__ double step_uniform_dyn(int k, u64 sidx, u32 stream, u32 k0, u32 k1) {
     const u32x4 r = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(k >> 1), stream, k0, k1);
-    return )MCIDEV"
-R"MCIDEV((k & 1) ? u01(r.z, r.w) : u01(r.x, r.y);
+    return (k & 1) ? u01(r.z, r.w) : u01(r.x, r.y);
 }
 // histogram add of one draw with the table-mode dispatch of hist_update
 template <class Cfg, int K> __device__ __forceinline__ void hist_add(int bin, double wk, double *sH, double *gH, int tile) {
@@ -1149,7 +1156,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             if (a.nchain > 1) {
                 const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)(it - 1);
                 const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MCMC_GROUP + bs, k0, k1);
-                uupd = u01(rg.x, rg.y);
+                uupd = u01(rg.x, rg.y);)MCIDEV"
+R"MCIDEV(
             }
             int upd = (int)(uupd * (double)NUPD);
             if (upd >= NUPD) upd = NUPD - 1;
@@ -1158,8 +1166,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             // ---- build the proposal (n, prop, newcurr); ONE evaluate-and-accept tail serves all three updates, so
             // lanes that diverged on the update type reconverge before the expensive part ----
             Chain<Cfg> n = c;
-   )MCIDEV"
-R"MCIDEV(         double prop = 1.0;
+            double prop = 1.0;
             bool active = false;
             int newcurr = curr, ut = 0; // ut: first index of propose[., ., .]: 0 changeIntegrand, 1 changeVariable, 2 swapVariable
             u64 touched = 0ull; // draws of the slot(s) this proposal moves (changeVariable, swapVariable)
@@ -1265,7 +1272,8 @@ R"MCIDEV(         double prop = 1.0;
                         if constexpr (!skip) {
                             if (vi == v && cdv > 0) { // :82
                                 active = true;
-                                int slot = (int)(us1 * (double)cdv); // :83
+                    )MCIDEV"
+R"MCIDEV(            int slot = (int)(us1 * (double)cdv); // :83
                                 if (slot >= cdv) slot = cdv - 1;
                                 touched = ((1ull << nl) - 1ull) << (k00 + slot * nl);
                                 if constexpr (pool_is_fermik<Cfg>(v)) { // shift!  sampler.jl:198-246; the move is picked by uniform 3
@@ -1273,8 +1281,7 @@ R"MCIDEV(         double prop = 1.0;
                                     int bo;
                                     static_for<0, nl>([&](auto J) {
                                         constexpr int j = decltype(J)::value;
-    )MCIDEV"
-R"MCIDEV(                                    u[j] = step_uniform_dyn(5 + k00 + slot * nl + j, sidx, st_step, k0, k1);
+                                        u[j] = step_uniform_dyn(5 + k00 + slot * nl + j, sidx, st_step, k0, k1);
                                         get_slot<Cfg, v, j>(c, slot, kk[j], po, bo);
                                     });
                                     prop *= fermik_shift<Cfg, v>(us2, u, kk);
@@ -1380,7 +1387,8 @@ R"MCIDEV(                                    u[j] = step_uniform_dyn(5 + k00 + s
                     // (a lone single-valued Discrete has nothing to sample, updates.jl:79-81: it never moves and holds nothing)
                     constexpr int pv = Cfg::draw_pool(k);
                     constexpr bool fixed = Cfg::pool_nleaf(pv) == 1 && Cfg::leaf_kind(Cfg::draw_leaf(k)) == 1 && Cfg::leaf_nbin(Cfg::draw_leaf(k)) == 1;
-                    if constexpr (((Cfg::own_mask(i) >> k) & 1ull) && !fixed) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
+                    if constexpr (((Cfg::own_mask(i) >>)MCIDEV"
+R"MCIDEV( k) & 1ull) && !fixed) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
                 });
             });
             atomicAdd(&a.hold_hist[hmax <= 0 ? 0 : 32 - __clz(hmax)], 1ull);
@@ -1393,8 +1401,7 @@ R"MCIDEV(                                    u[j] = step_uniform_dyn(5 + k00 + s
 // the map + integrand alone, for parity tests of a2/a3 and for host-side consumers
 template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD)MCIDEV"
-R"MCIDEV( = smem + Lds<Cfg>::DD;
+    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     __syncthreads();
     Tables<Cfg> t;

@@ -115,6 +115,7 @@ def main():
 
             def boot():
                 try:
+                    torch.cuda.set_device(local_rank)   # the current device is per thread; the id broadcast runs on it
                     box["comm"] = RcclComm.from_torch_distributed(local_rank)
                 except Exception as e:  # pragma: no cover - exercised only on multi-GPU nodes
                     box["err"] = e

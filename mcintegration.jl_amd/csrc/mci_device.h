@@ -1304,6 +1304,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                     extra[XP + decltype(U)::value] += ut == decltype(U)::value ? 1.0 : 0.0;           // :48, :99, :140
                     extra[XA + decltype(U)::value] += (ok && ut == decltype(U)::value) ? 1.0 : 0.0;   // :50, :101, :142
                 });
+#ifndef MCI_ABL_NOHOLD
                 if (a.hold_hist) {
                     const int now = (int)it;
                     u64 mo = 0ull, mn = 0ull; // live draws of the old and of the proposed integrand
@@ -1327,6 +1328,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                     hmax = (chg && hold > hmax) ? hold : hmax;
                     lastc = chg ? now : lastc;
                 }
+#endif
                 if (ok) {
                     c = n;
                     curr = newcurr;                                                             // :51-53
@@ -1346,7 +1348,9 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                         if (curr == i) {
                             static_for<0, Cfg::NDRAW>([&](auto K) { // :147-154  accumulate!(var, pos + offset, 1.0)
                                 constexpr int k = decltype(K)::value;
+#ifndef MCI_ABL_NOMCHIST
                                 if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hist_add<Cfg, k>(c.bin[k], 1.0, sH, a.ghist, tile);
+#endif
                             });
                             if constexpr (Cfg::CUSTOM_MEASURE != 0) { // measure(idx, var, obs, relative_weight, config)  :166-169
                                 double rwv[Cfg::NW];

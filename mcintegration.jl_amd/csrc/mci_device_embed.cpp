@@ -1315,6 +1315,7 @@ R"MCIDEV(            int slot = (int)(us1 * (double)cdv); // :83
                     extra[XP + decltype(U)::value] += ut == decltype(U)::value ? 1.0 : 0.0;           // :48, :99, :140
                     extra[XA + decltype(U)::value] += (ok && ut == decltype(U)::value) ? 1.0 : 0.0;   // :50, :101, :142
                 });
+#ifndef MCI_ABL_NOHOLD
                 if (a.hold_hist) {
                     const int now = (int)it;
                     u64 mo = 0ull, mn = 0ull; // live draws of the old and of the proposed integrand
@@ -1338,6 +1339,7 @@ R"MCIDEV(            int slot = (int)(us1 * (double)cdv); // :83
                     hmax = (chg && hold > hmax) ? hold : hmax;
                     lastc = chg ? now : lastc;
                 }
+#endif
                 if (ok) {
                     c = n;
                     curr = newcurr;                                                             // :51-53
@@ -1357,7 +1359,9 @@ R"MCIDEV(            int slot = (int)(us1 * (double)cdv); // :83
                         if (curr == i) {
                             static_for<0, Cfg::NDRAW>([&](auto K) { // :147-154  accumulate!(var, pos + offset, 1.0)
                                 constexpr int k = decltype(K)::value;
+#ifndef MCI_ABL_NOMCHIST
                                 if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hist_add<Cfg, k>(c.bin[k], 1.0, sH, a.ghist, tile);
+#endif
                             });
                             if constexpr (Cfg::CUSTOM_MEASURE != 0) { // measure(idx, var, obs, relative_weight, config)  :166-169
                                 double rwv[Cfg::NW];
@@ -1386,9 +1390,9 @@ R"MCIDEV(            int slot = (int)(us1 * (double)cdv); // :83
                     constexpr int k = decltype(K)::value;
                     // (a lone single-valued Discrete has nothing to sample, updates.jl:79-81: it never moves and holds nothing)
                     constexpr int pv = Cfg::draw_pool(k);
-                    constexpr bool fixed = Cfg::pool_nleaf(pv) == 1 && Cfg::leaf_kind(Cfg::draw_leaf(k)) == 1 && Cfg::leaf_nbin(Cfg::draw_leaf(k)) == 1;
-                    if constexpr (((Cfg::own_mask(i) >>)MCIDEV"
-R"MCIDEV( k) & 1ull) && !fixed) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
+                    constexpr bool fixed = Cfg::pool_nleaf(pv) == 1 && Cfg::leaf_kind(Cfg::draw_leaf(k)) == 1 && Cfg::leaf_nbin(Cfg::draw_leaf(k)))MCIDEV"
+R"MCIDEV( == 1;
+                    if constexpr (((Cfg::own_mask(i) >> k) & 1ull) && !fixed) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
                 });
             });
             atomicAdd(&a.hold_hist[hmax <= 0 ? 0 : 32 - __clz(hmax)], 1ull);

@@ -1,5 +1,7 @@
 """Engine: one mci_problem on one GPU (device-resident grids, histograms, statistics)."""
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -25,11 +27,27 @@ def context(device=0):
     return _ctx_cache[device]
 
 
+_live_engines = weakref.WeakSet()
+
+
 def shutdown():
-    """Destroy every cached context (stream + RCCL communicator).  Engines must be closed first.  For hosts that want an
-    orderly release before the process ends (the counterpart of MPI.Finalize)."""
+    """Close every live engine, then destroy every cached context (stream + RCCL communicator): the counterpart of
+    MPI.Finalize.  Registered with atexit, so that device memory, streams and communicators are released while the HIP
+    runtime and RCCL are still fully alive -- objects that survive into the interpreter's teardown are destroyed in an
+    order nobody controls (seen: glibc "double free or corruption" at process exit, after all work had finished)."""
+    for eng in list(_live_engines):
+        try:
+            eng.close()
+        except Exception:
+            pass
     for dev in list(_ctx_cache):
-        lib().mci_ctx_destroy(_ctx_cache.pop(dev))
+        try:
+            lib().mci_ctx_destroy(_ctx_cache.pop(dev))
+        except Exception:
+            pass
+
+
+atexit.register(shutdown)
 
 
 def device_count():
@@ -44,6 +62,7 @@ class Engine:
         self.config = config
         self.device = device
         self.ctx = context(device)
+        _live_engines.add(self)
         if isinstance(integrand, str):
             integrand = Integrand(integrand, config.userdata)
         elif callable(integrand) and not isinstance(integrand, (Integrand, HostIntegrand)):

@@ -31,3 +31,13 @@ def golden():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as fh:
         return json.load(fh)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Release engines, streams and communicators while the HIP runtime and RCCL are fully alive (see
+    mcintegration_jl_amd.engine.shutdown): the test processes create hundreds of problems and several communicators."""
+    import gc
+    gc.collect()
+    mod = sys.modules.get("mcintegration_jl_amd")
+    if mod is not None:
+        mod.shutdown()

@@ -1354,21 +1354,15 @@ R"MCIDEV(            int slot = (int)(us1 * (double)cdv); // :83
                 if (curr != NORMI) {
                     double relw[Cfg::NCOMP]; // :162
                     static_for<0, Cfg::NCOMP>([&](auto Q) { relw[decltype(Q)::value] = weight.v[decltype(Q)::value] / probability; });
-#ifndef MCI_ABL_NOMCHIST
-                    {   // :147-154  accumulate!(var, pos + offset, 1.0) for the live draws of the chain's integrand: ONE predicated
-                        // ds_add_f64 per draw (a branch per integrand would issue sum_i |own(i)| of them when the lanes diverge)
-                        u64 live = 0ull;
-                        static_for<0, NI>([&](auto I) { live = curr == decltype(I)::value ? Cfg::own_mask(decltype(I)::value) : live; });
-                        static_for<0, Cfg::NDRAW>([&](auto K) {
-                            constexpr int k = decltype(K)::value;
-                            if constexpr (Cfg::cover_mask(k) != 0ull)
-                                if ((live >> k) & 1ull) hist_add<Cfg, k>(c.bin[k], 1.0, sH, a.ghist, tile);
-                        });
-                    }
-#endif
                     static_for<0, NI>([&](auto I) {
                         constexpr int i = decltype(I)::value;
                         if (curr == i) {
+                            static_for<0, Cfg::NDRAW>([&](auto K) { // :147-154  accumulate!(var, pos + offset, 1.0)
+                                constexpr int k = decltype(K)::value;
+#ifndef MCI_ABL_NOMCHIST
+                                if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hist_add<Cfg, k>(c.bin[k], 1.0, sH, a.ghist, tile);
+#endif
+                            });
                             if constexpr (Cfg::CUSTOM_MEASURE != 0) { // measure(idx, var, obs, relative_weight, config)  :166-169
                                 double rwv[Cfg::NW];
                                 static_for<0, Cfg::NW>([&](auto Q) { rwv[decltype(Q)::value] = 0.0; });
@@ -1392,12 +1386,12 @@ R"MCIDEV(            int slot = (int)(us1 * (double)cdv); // :83
             hmax = (tot - lastc > hmax) ? tot - lastc : hmax;
             static_for<0, NI>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-           )MCIDEV"
-R"MCIDEV(     if (curr == i) static_for<0, Cfg::NDRAW>([&](auto K) {
+                if (curr == i) static_for<0, Cfg::NDRAW>([&](auto K) {
                     constexpr int k = decltype(K)::value;
                     // (a lone single-valued Discrete has nothing to sample, updates.jl:79-81: it never moves and holds nothing)
                     constexpr int pv = Cfg::draw_pool(k);
-                    constexpr bool fixed = Cfg::pool_nleaf(pv) == 1 && Cfg::leaf_kind(Cfg::draw_leaf(k)) == 1 && Cfg::leaf_nbin(Cfg::draw_leaf(k)) == 1;
+                    constexpr bool fixed = Cfg::pool_nleaf(pv) == 1 && Cfg::leaf_kind(Cfg::draw_leaf(k)) == 1 && Cfg::leaf_nbin(Cfg::draw_leaf(k)))MCIDEV"
+R"MCIDEV( == 1;
                     if constexpr (((Cfg::own_mask(i) >> k) & 1ull) && !fixed) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
                 });
             });

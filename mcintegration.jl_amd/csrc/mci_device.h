@@ -232,13 +232,16 @@ template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __
 template <class Cfg> constexpr double jac_scale(int k) {
     return Cfg::leaf_kind(Cfg::draw_leaf(k)) == 0 ? (double)Cfg::leaf_nbin(Cfg::draw_leaf(k)) : 1.0;
 }
-// product of jac_scale over the draws in `mask` (compile-time: the N^D factor is applied once per sample)
-template <class Cfg> constexpr double jac_scale_product(unsigned long long mask) {
+// product of jac_scale over the draws lo <= k < hi of `mask` (compile-time).  The N factors are applied once per group of
+// 8 draws, not once per sample: the bare product of 8 increments cannot underflow, the bare product of 48 narrow ones does
+// (D = 48 sharply peaked dimensions with increments ~1e-7 gave weights of exactly 0 when the scale was applied at the end)
+template <class Cfg> constexpr double jac_scale_product(unsigned long long mask, int lo = 0, int hi = 64) {
     double p = 1.0;
-    for (int k = 0; k < Cfg::NDRAW; ++k)
+    for (int k = lo; k < Cfg::NDRAW && k < hi; ++k)
         if ((mask >> k) & 1ull) p *= jac_scale<Cfg>(k);
     return p;
 }
+constexpr int kJacGroup = 8;
 
 // all NDRAW draws of one sample + Jacobians.  jaci[i] = product of 1/prob over integrand i's own draws
 // ( = weights*padding_probability*jac of vegas/montecarlo.jl:152 up to rounding ).
@@ -273,17 +276,25 @@ template <class Cfg, bool ECACHE = false> __device__ __forceinline__ void draw_s
                 });
             }
         });
+        if constexpr (((2 * c + 2) % kJacGroup == 0 || 2 * c + 2 >= Cfg::NDRAW)) { // close a group of draws: apply its N factors
+            constexpr int hi = 2 * c + 2, lo = ((hi - 1) / kJacGroup) * kJacGroup;
+            constexpr double sc = jac_scale_product<Cfg>(ALL, lo, hi);
+            if constexpr (sc != 1.0) s.jac *= sc;
+            static_for<0, Cfg::NI>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                constexpr double si = jac_scale_product<Cfg>(Cfg::own_mask(i), lo, hi);
+                if constexpr (Cfg::own_mask(i) != ALL && si != 1.0) s.jaci[i] *= si;
+            });
+        }
 #if MCI_DRAW_FENCE
         // keep the scheduler from hoisting every Philox chunk to the top of the sample (live ranges of
         // 2*NDRAW+ registers): with many draws that is the difference between 4 waves/SIMD and spilling
         if constexpr (((c + 1) % MCI_DRAW_FENCE) == 0) __builtin_amdgcn_sched_barrier(0);
 #endif
     });
-    s.jac *= jac_scale_product<Cfg>(ALL);
     static_for<0, Cfg::NI>([&](auto I) {
         constexpr int i = decltype(I)::value;
         if constexpr (Cfg::own_mask(i) == ALL) s.jaci[i] = s.jac; // dof[i] == maxdof: no padding (vegas/montecarlo.jl:82)
-        else s.jaci[i] *= jac_scale_product<Cfg>(Cfg::own_mask(i));
     });
 }
 

@@ -235,13 +235,16 @@ template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __
 template <class Cfg> constexpr double jac_scale(int k) {
     return Cfg::leaf_kind(Cfg::draw_leaf(k)) == 0 ? (double)Cfg::leaf_nbin(Cfg::draw_leaf(k)) : 1.0;
 }
-// product of jac_scale over the draws in `mask` (compile-time: the N^D factor is applied once per sample)
-template <class Cfg> constexpr double jac_scale_product(unsigned long long mask) {
+// product of jac_scale over the draws lo <= k < hi of `mask` (compile-time).  The N factors are applied once per group of
+// 8 draws, not once per sample: the bare product of 8 increments cannot underflow, the bare product of 48 narrow ones does
+// (D = 48 sharply peaked dimensions with increments ~1e-7 gave weights of exactly 0 when the scale was applied at the end)
+template <class Cfg> constexpr double jac_scale_product(unsigned long long mask, int lo = 0, int hi = 64) {
     double p = 1.0;
-    for (int k = 0; k < Cfg::NDRAW; ++k)
+    for (int k = lo; k < Cfg::NDRAW && k < hi; ++k)
         if ((mask >> k) & 1ull) p *= jac_scale<Cfg>(k);
     return p;
 }
+constexpr int kJacGroup = 8;
 
 // all NDRAW draws of one sample + Jacobians.  jaci[i] = product of 1/prob over integrand i's own draws
 // ( = weights*padding_probability*jac of vegas/montecarlo.jl:152 up to rounding ).
@@ -276,17 +279,26 @@ template <class Cfg, bool ECACHE = false> __device__ __forceinline__ void draw_s
                 });
             }
         });
+        if constexpr (((2 * c + 2) % kJacGroup == 0 || 2 * c + 2 >= Cfg::NDRAW)) { // close a group of draws: apply its N factors
+            constexpr int hi = 2 * c + 2, lo = ((hi - 1) / kJacGroup) * kJacGroup;
+            constexpr double sc = jac_scale_product<Cfg>(ALL, lo, hi);
+            if constexpr (sc != 1.0) s.jac *= sc;
+            static_for<0, Cfg::NI>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                constexpr double si = jac_scale_product<Cfg>(Cfg::own_mask(i), lo, hi);
+                if constexpr (Cfg::own_mask(i) != ALL && si != 1.0) s.jaci[i] *= si;
+            });
+        }
 #if MCI_DRAW_FENCE
-        // keep the scheduler from hoisting every Philox chunk to the top of the sample (live ranges of
+        // keep the scheduler from hoisting every Philox chun)MCIDEV"
+R"MCIDEV(k to the top of the sample (live ranges of
         // 2*NDRAW+ registers): with many draws that is the difference between 4 waves/SIMD and spilling
         if constexpr (((c + 1) % MCI_DRAW_FENCE) == 0) __builtin_amdgcn_sched_barrier(0);
 #endif
     });
-    s.jac *= jac_scale_product<Cfg>(ALL);
     static_for<0, Cfg::NI>([&](auto I) {
         constexpr int i = decltype(I)::value;
         if constexpr (Cfg::own_mask(i) == ALL) s.jaci[i] = s.jac; // dof[i] == maxdof: no padding (vegas/montecarlo.jl:82)
-        else s.jaci[i] *= jac_scale_product<Cfg>(Cfg::own_mask(i));
     });
 }
 
@@ -295,8 +307,7 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
     const int tid = threadIdx.x, T = blockDim.x;
     if constexpr (Cfg::TABLE_MODE <= 1) {
         if constexpr (Cfg::PAIR_TABLE != 0) {
-        )MCIDEV"
-R"MCIDEV(    static_for<0, Cfg::NLEAF>([&](auto Lf) {
+            static_for<0, Cfg::NLEAF>([&](auto Lf) {
                 constexpr int l = decltype(Lf)::value;
                 if constexpr (Cfg::leaf_kind(l) == 0) {
                     constexpr int eoff = Cfg::leaf_eoff(l), poff = Cfg::leaf_poff(l);
@@ -427,7 +438,8 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true> __device__ __fo
         constexpr int c = decltype(Cc)::value;
         const double v = wave_sum(extra[c - Cfg::NOBS]);
         if (lane == 0) sR[wave * Cfg::NCOLS + c] = v;
-    });
+    });)MCIDEV"
+R"MCIDEV(
     __syncthreads();
     double *row = a.part_cols + rowid * Cfg::NCOLS;
     for (int c = tid; c < Cfg::NCOLS && tile == 0; c += T) { // the NTILE workgroups of a slice hold identical statistics
@@ -443,8 +455,7 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true> __device__ __fo
         row[c] = v;
     }
     if constexpr (Mode<Cfg>::HIST_LDS && WRITE_HIST) {
-        static_for<0, Cfg::NTILE>([&](aut)MCIDEV"
-R"MCIDEV(o Tt) {
+        static_for<0, Cfg::NTILE>([&](auto Tt) {
             constexpr int tt = decltype(Tt)::value;
             if (tile == tt) {
                 double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
@@ -588,7 +599,8 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
                     word[m / PER] |= (u32)s.bin[k] << (BITS * (m % PER));
                 }
             });
-            static_for<0, NWORD>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = word[decltype(J)::value]; });
+     )MCIDEV"
+R"MCIDEV(       static_for<0, NWORD>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = word[decltype(J)::value]; });
         }
     }
     };
@@ -604,8 +616,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 #ifndef MCI_TILES_U
 #define MCI_TILES_U 4
 #endif
-template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs)MCIDEV"
-R"MCIDEV( &a) {
+template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, T = blockDim.x;
     double *sH = smem + Lds<Cfg>::H;
@@ -727,7 +738,8 @@ template <class Cfg, int V, int L> __device__ __forceinline__ void get_slot(cons
     static_for<0, md>([&](auto S) {
         constexpr int k = k00 + decltype(S)::value * nl + L;
         const bool hit = slot == decltype(S)::value;
-        x = hit ? c.x[k] : x;
+        x = hit ? c.x)MCIDEV"
+R"MCIDEV([k] : x;
         p = hit ? c.prob[k] : p;
         b = hit ? c.bin[k] : b;
     });
@@ -744,8 +756,7 @@ template <class Cfg, int V, int L> __device__ __forceinline__ void put_slot(Chai
 }
 // one leaf draw for pool V, leaf L (every slot of a pool shares the leaf's table): x, prob = 1/(raw*scale), bin
 template <class Cfg, int V, int L> __device__ __forceinline__ void draw_pool_leaf(const Tables<Cfg> &t, double y, double &x, double &p, int &b) {
-    con)MCIDEV"
-R"MCIDEV(stexpr int k = Cfg::pool_first_draw(V) + L; // slot 0 of the pool: same leaf as every other slot
+    constexpr int k = Cfg::pool_first_draw(V) + L; // slot 0 of the pool: same leaf as every other slot
     double raw;
     draw_leaf<Cfg, k>(t, y, x, raw, b);
     p = 1.0 / (raw * jac_scale<Cfg>(k));
@@ -864,7 +875,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 static_for<0, NI + 1>([&](auto I) { padn[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(n); }); // :79-81
                 double newp = rw[NORMI] * padn[NORMI];         // :84
                 static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; newp += absw<Cfg, i>(wn) * rw[i] * padn[i]; }); // :85-87
-                const double R = prop * newp / probability;    // :88
+                const double R = prop * newp / probability;    )MCIDEV"
+R"MCIDEV(// :88
                 const bool ok = uacc < R;                      // :91
                 static_for<0, Cfg::NPOOL>([&](auto V) {
                     constexpr int v = decltype(V)::value;
@@ -879,8 +891,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                     static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = padn[decltype(I)::value]; }); // :96-98
                     probability = newp;                        // :100
                 } // else shiftRollback!  :102  (the proposal copy is dropped)
-   )MCIDEV"
-R"MCIDEV(         }
+            }
             // ---- histogram  montecarlo.jl:198-211 ----
             {
                 double wh[NI];
@@ -1004,7 +1015,8 @@ template <class Cfg> struct Weight {
     double v[Cfg::NCOMP];
     double abs;
 };
-template <class Cfg, int I> __device__ __forceinline__ Weight<Cfg> eval_one(const double *x, const double *ud) {
+template <class Cfg, int I> __device__ __forceinline__ Weight<Cfg> eval_one(const double *x, const )MCIDEV"
+R"MCIDEV(double *ud) {
     double w[Cfg::NW];
     Cfg::integrand(x, w, ud, I); // the other outputs are dead code after inlining
     Weight<Cfg> r;
@@ -1023,8 +1035,7 @@ template <class Cfg> __device__ __forceinline__ Weight<Cfg> eval_sel(int curr, c
     return r;
 }
 // uniform k of a chain step; chunk 2 (k = 4, 5) is shared with the accept draw
-template <int K> __device__ __forceinline__ double step_uniform(u64 sidx, u32 strea)MCIDEV"
-R"MCIDEV(m, u32 k0, u32 k1, const u32x4 &r2) {
+template <int K> __device__ __forceinline__ double step_uniform(u64 sidx, u32 stream, u32 k0, u32 k1, const u32x4 &r2) {
     if constexpr ((K >> 1) == 2) return (K & 1) ? u01(r2.z, r2.w) : u01(r2.x, r2.y);
     else {
         const u32x4 r = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(K >> 1), stream, k0, k1);
@@ -1147,7 +1158,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             static_for<0, ND>([&](auto I) { extra[XV + decltype(I)::value] += curr == decltype(I)::value ? 1.0 : 0.0; }); // :136
             const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
             const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
-            const u32x4 r2 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 2u, st_step, k0, k1);
+            con)MCIDEV"
+R"MCIDEV(st u32x4 r2 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 2u, st_step, k0, k1);
             // :137 rand(rng, updates).  With many chains per block the 64 chains of a wave (chains ch & ~63 .. | 63 of ONE
             // block) share the update-type sequence: it is independent of the chain states, so every chain is still a
             // valid Markov chain, blocks stay independent, and the wave no longer walks through all three update bodies
@@ -1156,8 +1168,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             if (a.nchain > 1) {
                 const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)(it - 1);
                 const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MCMC_GROUP + bs, k0, k1);
-                uupd = u01(rg.x, rg.y);)MCIDEV"
-R"MCIDEV(
+                uupd = u01(rg.x, rg.y);
             }
             int upd = (int)(uupd * (double)NUPD);
             if (upd >= NUPD) upd = NUPD - 1;
@@ -1258,7 +1269,8 @@ R"MCIDEV(
                                         put_slot<Cfg, v, l>(n, s2, xa, pa, ba);
                                     });
                                 }
-                            });
+           )MCIDEV"
+R"MCIDEV(                 });
                         }
                     }
                 } else {
@@ -1272,8 +1284,7 @@ R"MCIDEV(
                         if constexpr (!skip) {
                             if (vi == v && cdv > 0) { // :82
                                 active = true;
-                    )MCIDEV"
-R"MCIDEV(            int slot = (int)(us1 * (double)cdv); // :83
+                                int slot = (int)(us1 * (double)cdv); // :83
                                 if (slot >= cdv) slot = cdv - 1;
                                 touched = ((1ull << nl) - 1ull) << (k00 + slot * nl);
                                 if constexpr (pool_is_fermik<Cfg>(v)) { // shift!  sampler.jl:198-246; the move is picked by uniform 3
@@ -1377,7 +1388,8 @@ R"MCIDEV(            int slot = (int)(us1 * (double)cdv); // :83
                             static_for<0, Cfg::NCOMP>([&](auto Q) { acc[i * Cfg::NCOMP + decltype(Q)::value] += curr == i ? relw[decltype(Q)::value] : 0.0; });
                     });
                 } else {
-                    extra[XN] += 1.0 / rw[NORMI]; // :158
+                  )MCIDEV"
+R"MCIDEV(  extra[XN] += 1.0 / rw[NORMI]; // :158
                 }
             }
         }
@@ -1390,8 +1402,7 @@ R"MCIDEV(            int slot = (int)(us1 * (double)cdv); // :83
                     constexpr int k = decltype(K)::value;
                     // (a lone single-valued Discrete has nothing to sample, updates.jl:79-81: it never moves and holds nothing)
                     constexpr int pv = Cfg::draw_pool(k);
-                    constexpr bool fixed = Cfg::pool_nleaf(pv) == 1 && Cfg::leaf_kind(Cfg::draw_leaf(k)) == 1 && Cfg::leaf_nbin(Cfg::draw_leaf(k)))MCIDEV"
-R"MCIDEV( == 1;
+                    constexpr bool fixed = Cfg::pool_nleaf(pv) == 1 && Cfg::leaf_kind(Cfg::draw_leaf(k)) == 1 && Cfg::leaf_nbin(Cfg::draw_leaf(k)) == 1;
                     if constexpr (((Cfg::own_mask(i) >> k) & 1ull) && !fixed) hmax = (tot - last[k] > hmax) ? tot - last[k] : hmax;
                 });
             });

@@ -590,6 +590,18 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         s.pair_table = pair;
         const bool hist_lds = (mode == 0 || mode == 3);
         p->lds_bytes = fixed + (mode <= 1 ? (pair ? e2 : e1) : 0) + (hist_lds ? (int64_t)s.htile * 8 : 0);
+        // one tile, grids gathered from L2 (10 .. 18 independent grids): the LDS left next to the histogram caches the edges of the
+        // leading grids for the :vegas sample pass (MCI_NO_EDGE_CACHE=1 for A/B runs)
+        if (mode == 3 && s.ntile == 1 && !(getenv("MCI_NO_EDGE_CACHE") && atoi(getenv("MCI_NO_EDGE_CACHE")) != 0)) {
+            const int64_t budget = (lim1 - p->lds_bytes) / 8;
+            for (size_t l = 0; l < p->leaves.size(); ++l) {
+                const Leaf &L = p->leaves[l];
+                if (L.kind != MCI_CONTINUOUS || s.ec_doubles + L.nbin + 1 > budget) continue;
+                s.leaf_ecoff[l] = s.ec_doubles;
+                s.ec_doubles += L.nbin + 1;
+            }
+            p->lds_bytes_k1 = p->lds_bytes + (int64_t)s.ec_doubles * 8;
+        }
         // one big workgroup per CU owns its LDS
         if (p->lds_bytes > lim0) p->threads = 512; // measured (tools/c4_sweep.py): 2 waves/SIMD beat 1 fat and 4 spilling ones
     }
@@ -719,7 +731,7 @@ static int compile_solver(mci_problem *p, int solver) {
             if (p->lds_bytes > 64 * 1024)
                 HIPCHK(hipFuncSetAttribute((const void *)p->f_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
         }
-        if (solver == MCI_VEGAS && p->shape.split_all && p->lds_bytes_k1 > 64 * 1024)
+        if (solver == MCI_VEGAS && p->shape.ec_doubles > 0 && p->lds_bytes_k1 > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(p->lds_bytes_k1 > p->lds_bytes ? p->lds_bytes_k1 : p->lds_bytes)));
         else if (p->lds_bytes > 64 * 1024) {
@@ -917,7 +929,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     const int slot = (int)(p->launches % mci_problem::kEvRing);
     if (p->graph_mode) a.iter_ptr = p->d_loop; // captured launch: the iteration index is read on the device
     else HIPCHK(hipEventRecord(p->evs[2 * slot], st));
-    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)((split && s.split_all) ? p->lds_bytes_k1 : p->lds_bytes), st, args, nullptr));
+    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)((solver == MCI_VEGAS && s.ec_doubles > 0) ? p->lds_bytes_k1 : p->lds_bytes), st, args, nullptr));
     if (split)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (!p->graph_mode) {

@@ -509,19 +509,21 @@ template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchAr
 template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, T = blockDim.x;
-    // split-all (SPLIT and Cfg::SPLIT_ALL): no histogram in this pass; the LDS it would take caches the leading leaves' edges
-    constexpr bool EC = SPLIT && Cfg::SPLIT_ALL != 0;
-    using L = typename SelectType<EC, LdsEC<Cfg>, Lds<Cfg>>::type;
+    // split-all (SPLIT and Cfg::SPLIT_ALL): no histogram in this pass; the LDS it would take caches the leading leaves' edges.
+    // One tile with L2-gathered grids (table mode 3): the LDS left over next to the histogram caches as many grids as fit.
+    constexpr bool NOHIST = SPLIT && Cfg::SPLIT_ALL != 0;
+    constexpr bool EC = Cfg::EC_DOUBLES > 0 && (NOHIST || !SPLIT);
+    using L = typename SelectType<NOHIST, LdsEC<Cfg>, Lds<Cfg>>::type;
     double *sE = smem + L::E, *sDA = smem + L::DA, *sDD = smem + L::DD;
     double *sH = smem + L::H, *sO = smem + L::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
-    if constexpr (Mode<Cfg>::HIST_LDS && !EC)
+    if constexpr (Mode<Cfg>::HIST_LDS && !NOHIST)
         for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
     Tables<Cfg> t;
     t.EC = nullptr;
     if constexpr (EC) {
-        double *sEC = smem + LdsEC<Cfg>::EC;
+        double *sEC = smem + (NOHIST ? LdsEC<Cfg>::EC : Lds<Cfg>::END);
         static_for<0, Cfg::NLEAF>([&](auto Lf) {
             constexpr int l = decltype(Lf)::value;
             if constexpr (Cfg::leaf_kind(l) == 0 && Cfg::leaf_ecoff(l) >= 0)
@@ -577,7 +579,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             wh[i] = wj * wj;                      // :180
         });
 #ifndef MCI_ABL_NOHIST
-        if constexpr (!EC) hist_update<Cfg, decltype(TT)::value>(s, wh, sH, a.ghist, tile);
+        if constexpr (!NOHIST) hist_update<Cfg, decltype(TT)::value>(s, wh, sH, a.ghist, tile);
 #else
         acc[0] += wh[0] * 1e-300;
 #endif
@@ -601,7 +603,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     if constexpr (Cfg::NTILE == 1 || SPLIT) run(IC<0>{});
     else static_for<0, Cfg::NTILE>([&](auto TT) { if (tile == decltype(TT)::value) run(TT); });
     __syncthreads();
-    flush_workgroup<Cfg, L, !EC>(a, smem, acc, extra, wi.rowid, tile);
+    flush_workgroup<Cfg, L, !NOHIST>(a, smem, acc, extra, wi.rowid, tile);
 }
 
 // histogram tiles 1 .. NTILE-1 (split-all: 0 .. NTILE-1) of a SPLIT vegas pass: workgroup = (block, slice, tile); replays the parked

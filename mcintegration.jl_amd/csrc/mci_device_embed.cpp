@@ -514,19 +514,21 @@ template <class Cfg> __device__ __forceinline__ WorkItem work_item(const BatchAr
 template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_batch(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, T = blockDim.x;
-    // split-all (SPLIT and Cfg::SPLIT_ALL): no histogram in this pass; the LDS it would take caches the leading leaves' edges
-    constexpr bool EC = SPLIT && Cfg::SPLIT_ALL != 0;
-    using L = typename SelectType<EC, LdsEC<Cfg>, Lds<Cfg>>::type;
+    // split-all (SPLIT and Cfg::SPLIT_ALL): no histogram in this pass; the LDS it would take caches the leading leaves' edges.
+    // One tile with L2-gathered grids (table mode 3): the LDS left over next to the histogram caches as many grids as fit.
+    constexpr bool NOHIST = SPLIT && Cfg::SPLIT_ALL != 0;
+    constexpr bool EC = Cfg::EC_DOUBLES > 0 && (NOHIST || !SPLIT);
+    using L = typename SelectType<NOHIST, LdsEC<Cfg>, Lds<Cfg>>::type;
     double *sE = smem + L::E, *sDA = smem + L::DA, *sDD = smem + L::DD;
     double *sH = smem + L::H, *sO = smem + L::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
-    if constexpr (Mode<Cfg>::HIST_LDS && !EC)
+    if constexpr (Mode<Cfg>::HIST_LDS && !NOHIST)
         for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
     Tables<Cfg> t;
     t.EC = nullptr;
     if constexpr (EC) {
-        double *sEC = smem + LdsEC<Cfg>::EC;
+        double *sEC = smem + (NOHIST ? LdsEC<Cfg>::EC : Lds<Cfg>::END);
         static_for<0, Cfg::NLEAF>([&](auto Lf) {
             constexpr int l = decltype(Lf)::value;
             if constexpr (Cfg::leaf_kind(l) == 0 && Cfg::leaf_ecoff(l) >= 0)
@@ -582,7 +584,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             wh[i] = wj * wj;                      // :180
         });
 #ifndef MCI_ABL_NOHIST
-        if constexpr (!EC) hist_update<Cfg, decltype(TT)::value>(s, wh, sH, a.ghist, tile);
+        if constexpr (!NOHIST) hist_update<Cfg, decltype(TT)::value>(s, wh, sH, a.ghist, tile);
 #else
         acc[0] += wh[0] * 1e-300;
 #endif
@@ -593,21 +595,21 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             u32 word[NWORD > 0 ? NWORD : 1];
             static_for<0, NWORD>([&](auto J) { word[decltype(J)::value] = 0u; });
             static_for<0, Cfg::NDRAW>([&](auto K) {
-                constexpr int k = decltype(K)::value;
+                constexpr int k = declt)MCIDEV"
+R"MCIDEV(ype(K)::value;
                 if constexpr (is_tdraw<Cfg>(k)) {
                     constexpr int m = tdraw_pos<Cfg>(k);
                     word[m / PER] |= (u32)s.bin[k] << (BITS * (m % PER));
                 }
             });
-     )MCIDEV"
-R"MCIDEV(       static_for<0, NWORD>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = word[decltype(J)::value]; });
+            static_for<0, NWORD>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = word[decltype(J)::value]; });
         }
     }
     };
     if constexpr (Cfg::NTILE == 1 || SPLIT) run(IC<0>{});
     else static_for<0, Cfg::NTILE>([&](auto TT) { if (tile == decltype(TT)::value) run(TT); });
     __syncthreads();
-    flush_workgroup<Cfg, L, !EC>(a, smem, acc, extra, wi.rowid, tile);
+    flush_workgroup<Cfg, L, !NOHIST>(a, smem, acc, extra, wi.rowid, tile);
 }
 
 // histogram tiles 1 .. NTILE-1 (split-all: 0 .. NTILE-1) of a SPLIT vegas pass: workgroup = (block, slice, tile); replays the parked
@@ -731,15 +733,15 @@ template <class Cfg, int I> __device__ __forceinline__ double own_prob(const Cha
 // stores under data-dependent branches get sunk by LLVM into a single store through a phi of addresses, which
 // would move the register-resident chain state into scratch memory.
 template <class Cfg, int V, int L> __device__ __forceinline__ void get_slot(const Chain<Cfg> &c, int slot, double &x, double &p, int &b) {
-    constexpr int md = Cfg::pool_maxdof(V), nl = Cfg::pool_nleaf(V), k00 = Cfg::pool_first_draw(V);
+    constexpr int md = Cfg::pool_maxdof(V), nl = Cfg::pool_nleaf(V), )MCIDEV"
+R"MCIDEV(k00 = Cfg::pool_first_draw(V);
     x = 0.0;
     p = 1.0;
     b = 0;
     static_for<0, md>([&](auto S) {
         constexpr int k = k00 + decltype(S)::value * nl + L;
         const bool hit = slot == decltype(S)::value;
-        x = hit ? c.x)MCIDEV"
-R"MCIDEV([k] : x;
+        x = hit ? c.x[k] : x;
         p = hit ? c.prob[k] : p;
         b = hit ? c.bin[k] : b;
     });
@@ -873,10 +875,10 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 Cfg::integrand(n.x, wn, a.ud, -1);             // :67-75
                 extra[XE] += 1.0;                              // config.neval += 1   :77
                 static_for<0, NI + 1>([&](auto I) { padn[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(n); }); // :79-81
-                double newp = rw[NORMI] * padn[NORMI];         // :84
+                double newp = rw[NORMI)MCIDEV"
+R"MCIDEV(] * padn[NORMI];         // :84
                 static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; newp += absw<Cfg, i>(wn) * rw[i] * padn[i]; }); // :85-87
-                const double R = prop * newp / probability;    )MCIDEV"
-R"MCIDEV(// :88
+                const double R = prop * newp / probability;    // :88
                 const bool ok = uacc < R;                      // :91
                 static_for<0, Cfg::NPOOL>([&](auto V) {
                     constexpr int v = decltype(V)::value;
@@ -1010,13 +1012,13 @@ template <class Cfg> constexpr bool pool_is_fermik(int v) {
     return Cfg::pool_maxdof(v) > 0 && Cfg::leaf_kind(Cfg::draw_leaf(Cfg::pool_first_draw(v))) == 2;
 }
 
-// weight of ONE integrand: value (re [, im]) and modulus
+)MCIDEV"
+R"MCIDEV(// weight of ONE integrand: value (re [, im]) and modulus
 template <class Cfg> struct Weight {
     double v[Cfg::NCOMP];
     double abs;
 };
-template <class Cfg, int I> __device__ __forceinline__ Weight<Cfg> eval_one(const double *x, const )MCIDEV"
-R"MCIDEV(double *ud) {
+template <class Cfg, int I> __device__ __forceinline__ Weight<Cfg> eval_one(const double *x, const double *ud) {
     double w[Cfg::NW];
     Cfg::integrand(x, w, ud, I); // the other outputs are dead code after inlining
     Weight<Cfg> r;
@@ -1155,11 +1157,11 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
         static_for<0, Cfg::NDRAW>([&](auto K) { last[decltype(K)::value] = 0; });
         for (i64 it = 1; it <= steps + nburn; ++it) { // :134
             const u64 sidx = (g << 32) | (u64)(it - 1);
-            static_for<0, ND>([&](auto I) { extra[XV + decltype(I)::value] += curr == decltype(I)::value ? 1.0 : 0.0; }); // :136
+            static_for<0, ND>([&](auto I) { extra[XV + decltype(I)::value] += curr == decltype(I)MCIDEV"
+R"MCIDEV()::value ? 1.0 : 0.0; }); // :136
             const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
             const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
-            con)MCIDEV"
-R"MCIDEV(st u32x4 r2 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 2u, st_step, k0, k1);
+            const u32x4 r2 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 2u, st_step, k0, k1);
             // :137 rand(rng, updates).  With many chains per block the 64 chains of a wave (chains ch & ~63 .. | 63 of ONE
             // block) share the update-type sequence: it is independent of the chain states, so every chain is still a
             // valid Markov chain, blocks stay independent, and the wave no longer walks through all three update bodies
@@ -1265,12 +1267,12 @@ R"MCIDEV(st u32x4 r2 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 2u, st_step, 
                                         int ba, bb;
                                         get_slot<Cfg, v, l>(c, s1, xa, pa, ba);
                                         get_slot<Cfg, v, l>(c, s2, xb, pb, bb);
-                                        put_slot<Cfg, v, l>(n, s1, xb, pb, bb);
+      )MCIDEV"
+R"MCIDEV(                                  put_slot<Cfg, v, l>(n, s1, xb, pb, bb);
                                         put_slot<Cfg, v, l>(n, s2, xa, pa, ba);
                                     });
                                 }
-           )MCIDEV"
-R"MCIDEV(                 });
+                            });
                         }
                     }
                 } else {
@@ -1384,12 +1386,12 @@ R"MCIDEV(                 });
                                 if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw[0]);
                             }
                         }
-                        if constexpr (Cfg::CUSTOM_MEASURE == 0 && Cfg::obs_bin_draw(i) < 0) // :164
+                        if constexpr (Cfg::CUSTOM_MEASURE == 0 && Cfg::obs_bin_draw(i) <)MCIDEV"
+R"MCIDEV( 0) // :164
                             static_for<0, Cfg::NCOMP>([&](auto Q) { acc[i * Cfg::NCOMP + decltype(Q)::value] += curr == i ? relw[decltype(Q)::value] : 0.0; });
                     });
                 } else {
-                  )MCIDEV"
-R"MCIDEV(  extra[XN] += 1.0 / rw[NORMI]; // :158
+                    extra[XN] += 1.0 / rw[NORMI]; // :158
                 }
             }
         }

@@ -106,7 +106,7 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     o << "    static constexpr int SPLIT_ALL = " << (solver == 0 ? s.split_all : 0) << ", EC_DOUBLES = " << (solver == 0 ? s.ec_doubles : 0) << ";\n";
     {
         std::vector<int> ec = s.leaf_ecoff;
-        if (solver != 0 || !s.split_all || ec.size() != s.leaf_kind.size()) ec.assign(s.leaf_kind.size(), -1);
+        if (solver != 0 || s.ec_doubles <= 0 || ec.size() != s.leaf_kind.size()) ec.assign(s.leaf_kind.size(), -1);
         o << fn_table("int", "leaf_ecoff", arr(ec, "int"));
     }
     o << fn_table("int", "leaf_tile", arr(s.leaf_tile, "int"));

@@ -2,22 +2,29 @@
 """bench.py -- headline benchmark: Msamples/s of the VEGAS sample-batch path on the 16-D Gaussian
 (BASELINE.json configs[1]) on N MI355X, plus the MC estimate and its sigma.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # N > 1: launches its own N ranks (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                # ... or is launched as one of them
 
 A "step" is one VEGAS iteration: neval samples per GPU drawn through the adaptive map, integrand
 evaluated, observables + per-bin histogram accumulated, block statistics merged, one RCCL all-reduce of
 the packed buffer (N > 1), grid refinement.  Warm-up iterations train the grid from uniform
 (reference resume pattern, docs/src/index.md:129, test/bubble.jl:108-113); the K timed iterations
 continue from the trained grid with adapt=true, ignore=0.  Weak scaling: per-GPU work is fixed
-(neval_total = N * neval_per_gpu, block = N * 16).
-Rank 0 prints ONE JSON line.
+(neval_total = N * neval_per_gpu, block = N * 16); the reference fans its blocks out the same way inside
+`integrate` (src/main.jl:113-122, :152-188).  Rank 0 prints ONE JSON line.
+
+Without a GPU the launcher can still be exercised (`MCI_BENCH_ENGINE=module:factory`, used by
+tests/test_bench_launcher.py with a test engine): gloo instead of RCCL, the line then carries "dry_run": true
+and no throughput claim.
 """
 import argparse
+import importlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +36,8 @@ L = math.sqrt(50.0)
 EXACT = math.erf(L / math.sqrt(2.0)) ** D
 B_ALG = 32 * D          # algorithmic bytes per sample: per dim 16 B of grid edges + 16 B histogram RMW
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_SIMD = 256 * 4        # 256 CUs x 4 SIMD-32
+MICROBENCH = os.path.join(ROOT, "mcintegration.jl_amd", "lib", "issue_microbench")
 
 
 def usable_cores():
@@ -43,11 +52,12 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(trained_grid=None, seconds_target=12.0):
+def cpu_baseline(trained_grid=None, seconds_target=12.0, nseeds=4):
     """The CPU oracle (oracle/, kind "port": the reference itself is Julia and cannot run here), threaded
     over blocks like parallel=:thread (src/main.jl:153-158) on the host cores this process may use, same 16-D
-    Gaussian.  The timed run continues from the grid the GPU trained (the reference's resume pattern,
-    docs/src/index.md:129), so that its estimate is sharp enough to compare the GPU's with."""
+    Gaussian.  `nseeds` independent single-iteration runs continue from the grid the GPU trained (the reference's
+    resume pattern, docs/src/index.md:129): every one of them is an unbiased estimate on the SAME map the GPU's timed
+    iterations started from, so the GPU estimate can be tested against the set instead of against one draw."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mci_oracle as O
     cores = usable_cores()
@@ -57,92 +67,191 @@ def cpu_baseline(trained_grid=None, seconds_target=12.0):
     t0 = time.time()
     cfg.integrate(O.VEGAS, "gaussian", [float(D)], neval=probe, niter=1, block=block, seed=1, nthreads=cores)
     rate = probe / max(time.time() - t0, 1e-6)
-    neval = int(max(probe, min(rate * seconds_target / 3, 5e8)))
-    if trained_grid is not None:
-        cfg.set_grid(0, trained_grid)
-    t0 = time.time()
-    r = cfg.integrate(O.VEGAS, "gaussian", [float(D)], neval=neval, niter=3, block=block, seed=2, nthreads=cores,
-                      ignore=0 if trained_grid is not None else 1)
-    dt = time.time() - t0
-    est = [float(r["mean"][0]), float(r["stdev"][0])]
-    return {"value": round(3 * (neval // block) * block / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "estimate": est,
-            "sample": "oracle/mci_oracle.c (C restatement, OpenMP over blocks), 16-D Gaussian :vegas, %d samples x 3 iterations "
-                      "%s, block=%d, %.1f s; estimate (weighted average) %.6f +- %.6f"
-                      % (neval, "continuing from the GPU-trained grid" if trained_grid is not None else "from the uniform grid", block, dt, est[0], est[1])}
+    neval = int(max(probe, min(rate * seconds_target / nseeds, 5e8)))
+    per_seed, dt, done = [], 0.0, 0
+    for s in range(nseeds):
+        c = O.Config([dict(kind=0, pool=0, lower=-L, upper=L)], [[D]])
+        if trained_grid is not None:
+            c.set_grid(0, trained_grid)
+        t0 = time.time()
+        r = c.integrate(O.VEGAS, "gaussian", [float(D)], neval=neval, niter=1, block=block, seed=2 + s, nthreads=cores, ignore=0)
+        dt += time.time() - t0
+        done += (neval // block) * block
+        per_seed.append([float(r["mean"][0]), float(r["stdev"][0])])
+    w = [1.0 / (e * e) for _, e in per_seed]
+    pooled = [sum(m * wi for (m, _), wi in zip(per_seed, w)) / sum(w), 1.0 / math.sqrt(sum(w))]
+    return {"value": round(done / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "estimate": pooled, "estimate_per_seed": per_seed,
+            "sample": "oracle/mci_oracle.c (C restatement, OpenMP over blocks), 16-D Gaussian :vegas, %d independent runs (seeds 2..%d) of "
+                      "%d samples x 1 iteration %s, block=%d, %.1f s in total; pooled estimate %.6f +- %.6f"
+                      % (nseeds, 1 + nseeds, neval, "on the GPU-trained grid" if trained_grid is not None else "on the uniform grid",
+                         block, dt, pooled[0], pooled[1])}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: `bench.py --gpus N` outside a torch.distributed launch starts its own N ranks
+# ---------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """re-executes this script under torch.distributed.run with one rank per GPU (the driver's own launch line);
+    the ranks inherit stdout, so rank 0's JSON line is this process's last line too"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC between the ranks' GPUs (RCCL)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# roofline of the sample kernel: cycle-weighted issue rate of its own instruction mix (VALU and LDS pipes)
+# ---------------------------------------------------------------------------------------------------------------
+def measured_issue_costs():
+    """issue cost (ns a SIMD is occupied per wave64 instruction, W waves competing) of the instruction forms the sample loop is
+    made of, measured NOW on this GPU by tools/issue_microbench.hip (built in-tree by __graft_entry__.build()); the cheapest
+    occupancy of each row is the pipe's cost.  Falls back to the committed table of the same tool (profiles/r02_issue_costs.json)."""
+    rows, source = None, None
+    if os.path.exists(MICROBENCH):
+        try:
+            out = subprocess.run([MICROBENCH, "1000", "roofline"], check=True, capture_output=True, text=True, timeout=120).stdout
+            rows = [json.loads(ln) for ln in out.splitlines() if ln.startswith("{")]
+            source = "measured in this run (tools/issue_microbench.hip)"
+        except Exception as e:  # pragma: no cover
+            print("[bench] issue microbenchmark failed: %s" % e, file=sys.stderr)
+    if rows is None:
+        path = os.path.join(ROOT, "profiles", "r02_issue_costs.json")
+        if not os.path.exists(path):
+            return None, None
+        rows = json.load(open(path))["rows"]
+        source = "profiles/r02_issue_costs.json (same tool, earlier run)"
+    costs = {}
+    for r in rows:
+        if "op" in r:
+            costs[r["op"]] = min(costs.get(r["op"], 1e30), r["wall_ns_per_wave_inst_per_simd"])
+    return costs, source
+
+
+def issue_roofline(code_object, costs, samples_per_launch, kernel_ms):
+    """{"valu": ..., "lds": ...}: the launch's wave-instructions on each pipe per second against the rate at which the chip
+    can issue THAT mix (1024 SIMDs / mix-weighted mean issue cost).  The LDS rows are costs seen from one SIMD with all four
+    SIMDs of the CU competing, so the same 1024 applies."""
+    from mcintegration_jl_amd import isa_mix
+    mix = isa_mix.loop_mix(code_object, "mci_vegas_batch")
+    cyc = isa_mix.issue_cycles(mix, costs)
+    trips = samples_per_launch / 64.0                       # one loop trip = one sample on each of a wave's 64 lanes
+    out = {}
+    for pipe in ("valu", "lds"):
+        n_inst = sum(n for cls, (n, c) in cyc["per_class"].items() if cls.startswith(pipe))
+        ach = n_inst * trips / (kernel_ms * 1e-3) / 1e9     # G wave-instructions/s
+        peak = N_SIMD / (cyc[pipe] / n_inst) if n_inst else 0.0   # 1024 SIMDs / mean ns per instruction
+        out[pipe] = {"achieved": round(ach, 2), "peak": round(peak, 2), "frac": round(ach / peak, 4) if peak else None,
+                     "instructions_per_wave_sample": n_inst, "issue_ns_per_wave_sample": round(cyc[pipe], 1)}
+    out["mix"] = {cls: {"n": n, "ns_each": round(c, 3)} for cls, (n, c) in sorted(cyc["per_class"].items())}
+    out["resources"] = isa_mix.resources(code_object).get("mci_vegas_batch")
+    return out
+
+
+def recorded_traffic(code_object):
+    """HBM bytes per launch from the PMC passes of profiles/collect.sh -- only if they profiled THIS code object"""
+    import glob
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            pj = json.load(open(tf))
+        except Exception:
+            continue
+        if pj.get("code_object") == os.path.basename(code_object):
+            return pj.get("hbm_bytes_per_launch"), os.path.basename(tf), pj.get("sq_avg_per_launch")
+    return None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--passes", type=int, default=3, help="timed passes of K steps each; the median pass is `value`")
     ap.add_argument("--neval-per-gpu", type=float, default=1e8)
     ap.add_argument("--seed", type=int, default=20240229)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print("[bench] --gpus %d but the launcher started %d ranks: running %d" % (a.gpus, world, world), file=sys.stderr)
 
     import numpy as np
     import torch
     import mcintegration_jl_amd as mci
     from mcintegration_jl_amd.comm import LocalComm, RcclComm, TorchDistComm
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    # test seam: an engine factory "module:attr" replaces the HIP engine so that the launcher, the block partition and the
+    # reduction can run without a GPU (gloo).  Such a line is marked dry_run and claims nothing.
+    factory = None
+    if os.environ.get("MCI_BENCH_ENGINE"):
+        mod, attr = os.environ["MCI_BENCH_ENGINE"].split(":")
+        factory = getattr(importlib.import_module(mod), attr)
+    dry = factory is not None
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    comm_kind = "none"
-    comm = LocalComm()
+    if not dry:
+        torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
     # MCI_BENCH_FORCE_COMM=1: run the N > 1 code path (process group, RCCL bootstrap, per-iteration all-reduce inside the
     # timed loop) with a single rank -- the only way to exercise it on a 1-GPU box
     force_comm = world == 1 and os.environ.get("MCI_BENCH_FORCE_COMM", "0") != "0"
-    if world > 1 or force_comm:
+    multi = world > 1 or force_comm
+    comm, comm_kind, dist = LocalComm(), "none", None
+    if multi:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if force_comm:
-            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        comm_kind = os.environ.get("MCI_COMM", "rccl")
-        if comm_kind == "rccl":
-            # ncclAllReduce inside the library, on its stream.  The bootstrap runs under a watchdog: a rank that cannot
-            # join within 120 s must not hang the job, and all ranks have to agree on the reducer they use.
-            import threading
-            box = {}
-
-            def boot():
+        if dry:
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
+            comm, comm_kind = TorchDistComm(), "gloo"
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
+            comm_kind = os.environ.get("MCI_COMM", "rccl")
+            if comm_kind == "rccl":
+                # ncclAllReduce inside the library, on its stream; the 128-byte id travels through torch.distributed.
+                # Every rank must end up with the same reducer: agree on the outcome before using it.
+                err = None
                 try:
-                    torch.cuda.set_device(local_rank)   # the current device is per thread; the id broadcast runs on it
-                    box["comm"] = RcclComm.from_torch_distributed(local_rank)
-                except Exception as e:  # pragma: no cover - exercised only on multi-GPU nodes
-                    box["err"] = e
-            th = threading.Thread(target=boot, daemon=True)
-            if os.environ.get("MCI_BOOT_INLINE", "0") != "0":
-                boot()
-            else:
-                th.start()
-                th.join(120.0)
-            ok = torch.tensor([1 if "comm" in box else 0], dtype=torch.int32, device="cuda:%d" % local_rank)
-            if not th.is_alive():   # (a stuck bootstrap thread may sit inside a torch collective: do not issue another one)
+                    comm = RcclComm.from_torch_distributed(local_rank)
+                except Exception as e:  # pragma: no cover - needs a failing RCCL
+                    err = e
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 1:
-                comm = box["comm"]
-            else:  # pragma: no cover
-                if rank == 0:
-                    print("[bench] library RCCL bootstrap failed (%s); using torch.distributed all_reduce on the device buffer"
-                          % box.get("err", "timeout"), file=sys.stderr)
-                comm_kind = "torch"
-        if comm_kind == "torch":
-            comm = TorchDistComm(tensor_device="cuda:%d" % local_rank)  # zero copy, on the library's stream
+                if int(ok.item()) != 1:  # pragma: no cover
+                    if rank == 0:
+                        print("[bench] library RCCL bootstrap failed on some rank (%s); every rank uses torch.distributed's "
+                              "RCCL all_reduce on the library's device buffer instead" % err, file=sys.stderr)
+                    comm_kind = "torch"
+            if comm_kind == "torch":
+                comm = TorchDistComm(tensor_device=dev)  # zero copy, on the library's stream
 
     def barrier():
-        if world > 1 or force_comm:
-            import torch.distributed as dist
+        if multi:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     n_gpus = world
     neval_gpu = int(a.neval_per_gpu)
@@ -153,56 +262,64 @@ def main():
 
     # ---- warm-up: JIT/cache load + W training iterations from the uniform grid (untimed) ----
     res_w = mci.integrate(f, config=cfg, solver="vegas", neval=neval, niter=max(a.warmup, 1), block=block, comm=comm,
-                          device=local_rank, adapt=True)
+                          device=local_rank, adapt=True, engine_factory=factory)
     eng = cfg._engine
     per = block // n_gpus
     lo, hi = per * rank, per * (rank + 1)
     nevalperblock = neval // block
-    it0 = cfg.iterations_done
     grid_after_warmup = eng.grid(0)   # handed to the CPU baseline: it continues from the same trained map
 
-    # ---- timed region: EXACTLY K iterations, no host synchronisation inside ----
-    barrier()
-    t0 = time.perf_counter()
-    for it in range(a.steps):
-        eng.run("vegas", nevalperblock, lo, hi, it0 + it, cfg.seed)
-        comm.all_reduce(eng)
-        eng.finish("vegas", block, adapt=True, want_stats=False)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1 or force_comm:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    cfg.iterations_done += a.steps
+    # ---- timed region: `passes` x EXACTLY K iterations, no host synchronisation inside a pass ----
+    pass_dt, dry_stats = [], []
+    for _ in range(max(a.passes, 1)):
+        it0 = cfg.iterations_done
+        barrier()
+        t0 = time.perf_counter()
+        for it in range(a.steps):
+            eng.run("vegas", nevalperblock, lo, hi, it0 + it, cfg.seed)
+            comm.all_reduce(eng)
+            r = eng.finish("vegas", block, adapt=True, want_stats=dry)
+            if dry:
+                dry_stats.append(r)
+        barrier()
+        dt = time.perf_counter() - t0
+        if multi:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        pass_dt.append(dt)
+        cfg.iterations_done += a.steps
+    if not dry:
+        eng.check_status()   # a launch that tripped a device-side error (normalization, histogram) must not print a number
+    ntimed = a.steps * len(pass_dt)
+    dt = sorted(pass_dt)[len(pass_dt) // 2]   # median pass
 
-    # per-launch HIP-event durations of the sampling kernel over the timed region (library stream)
-    kms, wgs, threads = eng.kernel_times_ms(a.steps)
-    k_avg_ms = float(np.mean(kms))
-    # production estimate: the K timed iterations, weighted average with ignore = 0
+    # production estimate: every timed iteration, weighted average with ignore = 0
     # (k_train copied every iteration's statistics head into the device-side log; one D2H after the loop)
-    log = eng.iteration_log(a.steps)
-    means, stds = [], []
-    for row in log:
-        m, e = mci.mean_std(row[:eng.nobs], row[eng.nobs:2 * eng.nobs], block)
-        means.append(m[0])
-        stds.append(e[0])
+    nobs = eng.nobs
+    if dry:
+        means, stds = [float(m[0]) for m, _ in dry_stats], [float(e[0]) for _, e in dry_stats]
+        neval_reduced = None
+    else:
+        log = eng.iteration_log(ntimed)
+        means, stds = [], []
+        for row in log:
+            m, e = mci.mean_std(row[:nobs], row[nobs:2 * nobs], block)
+            means.append(m[0])
+            stds.append(e[0])
+        neval_reduced = float(log[-1][2 * nobs + 1])   # config.neval after the all-reduce: the samples of ALL ranks
     mean, err, chi2 = mci.average(means, stds, init=1, max=len(means))
+
+    # what the communicator itself says about the job: the library's view (mci_comm_rank), every rank's block range
+    lib_rank, lib_n = comm.library_ranks() if hasattr(comm, "library_ranks") else (rank, comm.size)
+    mine = {"rank": rank, "comm_rank": lib_rank, "comm_ranks": lib_n, "blocks": [lo, hi], "device": None if dry else local_rank}
+    ranks = [mine]
+    if multi:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
 
     if rank == 0:
         value = a.steps * neval / dt / 1e6
-        achieved = B_ALG * (nevalperblock * per) / (k_avg_ms * 1e-3) / 1e9  # GB/s, one launch on one GPU
-        # PMC-derived per-launch figures of this same workload (profiles/collect.sh; separate --pmc passes)
-        traffic, valu_insts = None, None
-        import glob
-        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
-            try:
-                pj = json.load(open(tf))
-                traffic = pj.get("hbm_bytes_per_launch")
-                valu_insts = pj.get("sq_avg_per_launch", {}).get("SQ_INSTS_VALU")
-            except Exception:
-                pass
         out = {
             "metric": "Msamples/sec (whole node), 16-D Gaussian :vegas",
             "value": round(value, 2),
@@ -218,40 +335,78 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 16-D unit Gaussian on [-sqrt(50),sqrt(50)]^16, shared-pool "
                                    "Continuous (1 grid, 999 bins), :vegas, neval=%.0e per GPU per iteration, block=16 per GPU" % neval_gpu,
-                       "neval_per_iteration": neval, "block": block, "comm": comm_kind,
-                       "kernel": "mci_vegas_batch", "workgroups": wgs, "threads": threads, "table_mode": eng.table_mode},
-            "estimate": {"mean": mean, "sigma": err, "chi2_dof": chi2, "exact": EXACT,
+                       "neval_per_iteration": neval, "block": block},
+            "timing": {"passes": len(pass_dt), "ms_per_step_per_pass": [round(x / a.steps * 1e3, 4) for x in pass_dt],
+                       "ms_per_step_min": round(min(pass_dt) / a.steps * 1e3, 4), "value_is": "median pass"},
+            "comm": {"kind": comm_kind, "ranks": max(r["comm_ranks"] for r in ranks), "world_size": world,
+                     "per_rank": ranks, "neval_after_allreduce": neval_reduced},
+            "estimate": {"mean": mean, "sigma": err, "chi2_dof": chi2, "exact": EXACT, "iterations": len(means),
                          "deviation_sigma": (mean - EXACT) / err if err > 0 else None,
-                         "last_training_iteration": [res_w.iter_mean[-1, 0], res_w.iter_std[-1, 0]]},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel_ms_avg": round(k_avg_ms, 4), "bytes_per_sample": B_ALG,
-                         "note": "achieved = algorithmic bytes (32*D B/sample: grid edges + histogram RMW) / HIP-event kernel time; "
-                                 "the tables are LDS-resident by design, so real HBM traffic (traffic) is ~0 and frac may exceed 1: "
-                                 "the kernel is fp64-VALU/Philox bound, see DESIGN.md"},
+                         "last_training_iteration": [float(res_w.iter_mean[-1, 0]), float(res_w.iter_std[-1, 0])]},
         }
-        if valu_insts and neval_gpu == 10**8:
-            # the bound the kernel actually runs against: one wave64 VALU instruction per 4 cycles on each of
-            # 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md); instruction count per launch from SQ_INSTS_VALU
-            peak = 256 * 4 * 2.4e9 / 4 / 1e9
-            ach = valu_insts / (k_avg_ms * 1e-3) / 1e9
-            out["roofline_valu"] = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(peak, 1),
-                                    "unit": "G wave-instructions/s", "frac": round(ach / peak, 4),
-                                    "insts_per_launch": valu_insts, "note": "SQ_INSTS_VALU (rocprofv3 --pmc, profiles/) / live HIP-event kernel time"}
-        if not a.no_cpu_baseline and n_gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(trained_grid=grid_after_warmup)
-            cm, cs = out["cpu_baseline"]["estimate"]
-            # north star: "the estimate within 1 sigma of the CPU reference" -- the CPU run's estimate vs the GPU's
-            out["estimate"]["vs_cpu_sigma"] = (mean - cm) / math.hypot(err, cs)
+        if dry:
+            out["dry_run"] = True
+            out["value"] = 0.0
+            out["config"]["engine"] = os.environ["MCI_BENCH_ENGINE"]
+        else:
+            # per-launch HIP-event durations of the sampling kernel over the timed region (library stream)
+            kms, wgs, threads = eng.kernel_times_ms(min(ntimed, 512))
+            k_avg_ms = float(np.mean(kms))
+            code_object = eng.code_object("vegas")
+            out["config"].update({"kernel": "mci_vegas_batch", "workgroups": wgs, "threads": threads, "table_mode": eng.table_mode,
+                                  "code_object": os.path.basename(code_object)})
+            spl = nevalperblock * per                                   # samples of one launch on one GPU
+            achieved_hbm = B_ALG * spl / (k_avg_ms * 1e-3) / 1e9       # GB/s
+            traffic, traffic_src, sq = recorded_traffic(code_object)
+            hbm = {"bound": "hbm", "achieved": round(achieved_hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(achieved_hbm / HBM_PEAK_GBS, 4), "bytes_per_sample": B_ALG, "traffic": traffic, "traffic_source": traffic_src,
+                   "note": "SURVEY 8(d) model: 32*D algorithmic bytes per sample (grid edges + histogram RMW) / kernel time. NOT the binding "
+                           "bound: the tables are LDS-resident by design, real HBM traffic (`traffic`, PMC) is ~1e-3 of it, so frac > 1"}
+            costs, costs_src = measured_issue_costs()
+            roof = {"bound": "valu+lds", "kernel_ms_avg": round(k_avg_ms, 4), "traffic": traffic, "hbm_model": hbm}
+            if costs:
+                ir = issue_roofline(code_object, costs, spl, k_avg_ms)
+                top = "valu" if ir["valu"]["frac"] >= ir["lds"]["frac"] else "lds"
+                roof.update({"achieved": ir[top]["achieved"], "peak": ir[top]["peak"], "unit": "G wave-instructions/s", "frac": ir[top]["frac"],
+                             "binding_pipe": top, "valu": ir["valu"], "lds": ir["lds"], "mix": ir["mix"], "resources": ir["resources"],
+                             "costs_source": costs_src,
+                             "note": "achieved = wave64 instructions the launch issues on the binding pipe per second (sample-loop mix from "
+                                     "the loaded code object x waves / HIP-event kernel time); peak = 1024 SIMDs / mix-weighted mean issue cost "
+                                     "of those instruction forms, measured on this GPU by tools/issue_microbench.hip.  VALU and LDS are "
+                                     "separate pipes that overlap: the larger fraction binds; the SURVEY 8(d) HBM model is kept in hbm_model"})
+                if sq and sq.get("SQ_INSTS_VALU") and sq.get("SQ_WAVES"):
+                    roof["pmc_check"] = {"SQ_INSTS_VALU_per_wave_sample": sq["SQ_INSTS_VALU"] / (spl / 64.0),
+                                         "SQ_INSTS_LDS_per_wave_sample": sq.get("SQ_INSTS_LDS", 0) / (spl / 64.0), "source": traffic_src}
+            else:
+                roof.update({"achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
+                             "note": "issue-cost table unavailable (no microbenchmark binary, no profiles/r02_issue_costs.json)"})
+            out["roofline"] = roof
+            if not a.no_cpu_baseline and n_gpus == 1:
+                cb = cpu_baseline(trained_grid=grid_after_warmup)
+                out["cpu_baseline"] = cb
+                cm, cs = cb["estimate"]
+                # north star: "the estimate within 1 sigma of the CPU reference".  One difference of two unbiased estimates is
+                # N(0,1) in units of its sigma whatever the sample sizes, so the GPU estimate is TESTED against the set of
+                # independent CPU runs: chi2 = sum z_s^2 over the seeds, p-value from chi2(nseeds)
+                zs = [(mean - m) / math.hypot(err, s) for m, s in cb["estimate_per_seed"]]
+                c2 = sum(z * z for z in zs)
+                try:
+                    from scipy.stats import chi2 as _chi2
+                    pval = float(_chi2.sf(c2, len(zs)))
+                except Exception:  # pragma: no cover
+                    pval = None
+                out["estimate"]["vs_cpu_sigma"] = (mean - cm) / math.hypot(err, cs)
+                out["estimate"]["vs_cpu"] = {"z_per_seed": [round(z, 3) for z in zs], "chi2": round(c2, 3), "dof": len(zs), "p_value": pval,
+                                             "consistent": None if pval is None else bool(pval > 0.01)}
         import ctypes
         ctypes.CDLL(None).fflush(None)   # RCCL's start-up banner sits in the C stdio buffer: the JSON line stays the last line of stdout
         print(json.dumps(out), flush=True)
     # orderly release while the HIP runtime is still up: problem, then stream + RCCL communicator, then torch's group
-    eng.close()
+    if hasattr(eng, "close"):
+        eng.close()
     cfg._engine = None
     mci.shutdown()
-    if world > 1 or force_comm:
-        import torch.distributed as dist
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
         # multi-rank runs leave without the interpreter's teardown: the destruction order of torch, RCCL and the HIP

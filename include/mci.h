@@ -143,13 +143,16 @@ int mci_set_integrand_host(mci_problem *prob, mci_host_integrand_fn fn, void *us
 int mci_set_measure_source(mci_problem *prob, const char *body);
 int mci_compile(mci_problem *prob);          /* JIT or kernel-cache load of the vegas kernel; implicit on first run */
 int mci_compile_solver(mci_problem *prob, int32_t solver); /* same for one solver's kernel (one code object each) */
+/* path of the kernel-cache file (gfx950 code object) the solver's kernel was loaded from -- the analogue of asking Julia
+ * for `@code_native` of the specialised `montecarlo` method (vegas/montecarlo.jl:72-75); diagnostics read its ISA from it */
+int mci_kernel_code_object(mci_problem *prob, int32_t solver, char *buf, int32_t n);
 int mci_set_launch(mci_problem *prob, int32_t threads_per_workgroup, int32_t workgroups_per_block);
 int mci_problem_info(const mci_problem *prob, int32_t *ndraw, int32_t *nobs, int64_t *packed_size,
                      int32_t *table_mode, int64_t *lds_bytes);
 
 /* ---- one iteration, step by step (what mci_integrate runs; also the testing seam) ---- */
 /* blocks [block_lo, block_hi) of `_block!` (main.jl:236-292) on this GPU; leaves the local packed buffer
- * [obsSum(nobs) | obsSqSum(nobs) | normalization | neval | visited(N+1) | histograms] on the device */
+ * [obsSum(nobs) | obsSqSum(nobs) | normalization | neval | visited(N+1) | histograms | propose | accept] on the device */
 int mci_iteration_run(mci_problem *prob, int32_t solver, int64_t neval_per_block, int64_t block_lo,
                       int64_t block_hi, int32_t iteration, uint64_t seed, int64_t measurefreq, int64_t nchain,
                       double thermal_ratio);
@@ -160,6 +163,10 @@ int mci_iteration_reduce(mci_problem *prob);
  * iteration's (mean, std) = _mean_std (main.jl:296-320).  mean/std may be NULL. */
 int mci_iteration_finish(mci_problem *prob, int32_t solver, int64_t block_total, int32_t adapt, double gamma,
                          double *mean, double *std);
+/* wait for the stream and raise what the device flagged since the last check: the reference's error() / @assert of
+ * main.jl:269-271 (block normalization), variable.jl:212-213 and common.jl:71,79 (histogram / distribution not finite or
+ * not positive), mcmc/montecarlo.jl:125-126 (no non-zero start found) */
+int mci_check_status(mci_problem *prob);
 /* the whole loop (main.jl:142-218) */
 int mci_integrate(mci_problem *prob, const mci_integrate_args *args, mci_result *result);
 
@@ -182,10 +189,12 @@ int mci_set_distribution(mci_problem *prob, int32_t leaf, const double *distribu
 int mci_get_reweight(mci_problem *prob, double *out, int32_t n);
 int mci_set_reweight(mci_problem *prob, const double *in, int32_t n);
 int mci_set_reweight_goal(mci_problem *prob, const double *goal, int32_t n); /* main.jl:81; NULL/0 clears */
-/* config.propose / config.accept of the last iteration, summed over this rank's blocks (the numbers behind
- * report(config), configuration.jl:345-464), n = max(npool, 3) entries each.  vegasmc: entry vi = propose[2,1,vi]
- * (vegas_mc/updates.jl:90-92); mcmc: entries 0,1,2 = changeIntegrand, changeVariable, swapVariable summed over
- * their (integrand, variable) indices (mcmc/updates.jl:48, :99, :140). */
+/* config.propose / config.accept of the last iteration (configuration.jl:185-186; the numbers behind report(config),
+ * configuration.jl:345-464), n = 3 * (N+1) * max(N+1, npool) entries each, row-major [update][integrand][target], 0-based:
+ * changeIntegrand [0][curr][new] (mcmc/updates.jl:48,50), changeVariable [1][curr][vi] (mcmc/updates.jl:100,102; vegasmc
+ * [1][0][vi], vegas_mc/updates.jl:90,92), swapVariable [2][curr][vi] (mcmc/updates.jl:138,140); clearStatistics! offsets
+ * included (1e-8 / 1e-10 per block config, configuration.jl:247-248).  They are the tail of the packed buffer, so after
+ * mci_iteration_reduce they hold the sum over all ranks, like MPIreduceConfig! (configuration.jl:297-298). */
 int mci_get_acceptance(mci_problem *prob, double *propose, double *accept, int32_t n);
 /* resume across processes: what train!/doReweight! have learned -- grids, distributions, reweight --
  * as a small self-describing binary file ("MCISTATE", version 1).  The reference keeps this state only in memory

@@ -67,6 +67,8 @@ SIGNATURES = [
     ("mci_set_measure_source", C.c_int, [_VP, C.c_char_p]),
     ("mci_compile", C.c_int, [_VP]),
     ("mci_compile_solver", C.c_int, [_VP, C.c_int32]),
+    ("mci_kernel_code_object", C.c_int, [_VP, C.c_int32, C.c_char_p, C.c_int32]),
+    ("mci_check_status", C.c_int, [_VP]),
     ("mci_set_launch", C.c_int, [_VP, C.c_int32, C.c_int32]),
     ("mci_problem_info", C.c_int, [_VP, c_int32_p, c_int32_p, C.POINTER(C.c_int64), c_int32_p, C.POINTER(C.c_int64)]),
     ("mci_iteration_run", C.c_int, [_VP, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_double]),

@@ -12,13 +12,15 @@ class LocalComm:
 
 
 class RcclComm:
-    """RCCL inside the library: one ncclAllReduce(sum, f64) on the engine's stream, device to device."""
+    """RCCL inside the library: one ncclAllReduce(sum, f64) on the engine's stream, device to device.
+    The communicator belongs to the mci_ctx of ONE device; an engine on another device would skip the reduction
+    silently (mci_iteration_reduce is a no-op on a context without a communicator), so all_reduce checks it."""
 
     def __init__(self, rank, size, unique_id, device):
         import ctypes as C
         from ._lib import check, lib
         from .engine import context
-        self.rank, self.size = rank, size
+        self.rank, self.size, self.device = rank, size, device
         buf = C.create_string_buffer(bytes(unique_id), 128)
         check(lib().mci_comm_init(context(device), rank, size, buf))
 
@@ -39,7 +41,19 @@ class RcclComm:
         dist.broadcast_object_list(box, src=0)
         return cls(rank, size, box[0], device)
 
+    def library_ranks(self):
+        """(rank, nranks) as the library's communicator reports them (mci_comm_rank): what RCCL was initialised with"""
+        import ctypes as C
+        from ._lib import lib
+        from .engine import context
+        r, n = C.c_int32(), C.c_int32()
+        lib().mci_comm_rank(context(self.device), C.byref(r), C.byref(n))
+        return r.value, n.value
+
     def all_reduce(self, engine):
+        if getattr(engine, "device", self.device) != self.device:
+            raise RuntimeError("RcclComm was created for device %s but the engine runs on device %s: pass the same `device` to "
+                               "integrate() (the all-reduce would be skipped silently)" % (self.device, engine.device))
         engine.reduce()
 
 

@@ -97,6 +97,9 @@ struct mci_ctx {
 };
 
 namespace {
+// train! stages one leaf in LDS: (5 * nbin + 16) doubles in k_finish -> the largest grid one workgroup can refine
+const int64_t kTrainLdsMax = 160 * 1024;
+const int kMaxLeafBins = (int)((kTrainLdsMax / 8 - 16) / 5);
 struct Leaf {
     int kind, pool, npts, nbin, adapt, eoff, doff, boff;
     double lower, upper, alpha;
@@ -129,9 +132,12 @@ struct mci_problem {
     hipModule_t module[3] = {nullptr, nullptr, nullptr};
     hipFunction_t f_solver[3] = {nullptr, nullptr, nullptr}, f_dump = nullptr;
     bool compiled[3] = {false, false, false};
+    std::string code_object[3]; // kernel-cache file each solver's code object was loaded from / written to
     std::vector<double> h_goal; // reweight_goal (main.jl:81); empty = none
     double *d_goal = nullptr;
-    double *d_pa = nullptr; // [2*NPA] propose | accept of the last iteration (this rank)
+    int npa = 0;                    // 3 * (ni+1) * max(ni+1, npool): entries of config.propose (configuration.jl:185)
+    double *d_part_pa = nullptr;    // [rows][2*npa] per-workgroup propose | accept tables of the chain solvers
+    int64_t cap_pa = 0;
     unsigned long long *d_hold = nullptr; // [64] :mcmc holding-time histogram of the last launch (this rank), see mci_get_hold_histogram
     bool hold_pending = false;            // d_hold has not been looked at yet
     int64_t hold_max = 0;                 // upper edge of its top occupied bucket; 0: no :mcmc launch seen yet
@@ -155,7 +161,13 @@ struct mci_problem {
     unsigned *d_loop = nullptr;
     bool graph_mode = false; // while capturing: no event records, iteration/log row come from d_loop
     int threads = 256, wg_per_block = 0; // 0 = auto
-    int train_serial = 0; // MCI_TRAIN_SERIAL=1: refinement walk as the reference's serial recurrence (diagnostic)
+    // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
+    // launch before it is long enough to hide it (>= kSerialWalkSamples samples or chain steps), the prefix-scan form in the
+    // launch-bound regime; MCI_TRAIN_SERIAL=1 / 0 forces one of them
+    int train_serial = -1;
+    int64_t last_samples = 0; // samples (vegas) or chain steps of the last sample launch on this rank
+    static const int64_t kSerialWalkSamples = 1000000;
+    bool train_lds_raised = false; // k_train / k_finish allowed more than 64 KiB of dynamic LDS (large grids)
     // last launch
     std::vector<hipEvent_t> evs; // ring of (start, stop) pairs around the sampling kernel, one pair per launch
     int64_t launches = 0;
@@ -400,6 +412,10 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             delete p;
             return fail(MCI_ERR_INVALID, "leaf %d: unknown kind %d", l, ld.kind);
         }
+        if (L.nbin > kMaxLeafBins) {
+            delete p;
+            return fail(MCI_ERR_INVALID, "leaf %d: %d increments; train! refines a grid inside one CU's LDS, at most %d increments per variable", l, L.nbin, kMaxLeafBins);
+        }
         L.boff = boff;
         boff += L.nbin;
         p->leaves.push_back(L);
@@ -480,7 +496,8 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         s.obs_bin_draw.push_back(bd);
         s.nobs += nb;
     }
-    s.ncols = s.nobs + 2 + Nd + 2 * (p->npool > 3 ? p->npool : 3); // propose/accept: per pool (vegasmc) or per update type (mcmc)
+    s.ncols = s.nobs + 2 + Nd;
+    p->npa = 3 * Nd * (Nd > p->npool ? Nd : p->npool);
     s.nedge = eoff;
     s.ndacc = aoff;
     s.nddist = doff;
@@ -504,7 +521,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             if (L.kind == MCI_CONTINUOUS) npair += 2 * L.nbin;
         }
         s.npair = npair;
-        const int64_t fixed = (int64_t)(s.ndacc + s.nddist + s.nobs + 16 * s.ncols) * 8;
+        const int64_t fixed = (int64_t)(s.ndacc + s.nddist + s.nobs + 16 * s.ncols + 2 * p->npa) * 8;
         const int64_t e1 = (int64_t)s.nedge * 8, e2 = (int64_t)npair * 8, hb = (int64_t)s.nbin * 8;
         // lim0: >= 2 workgroups of 256 threads per CU; lim1: one 1024-thread workgroup owning the CU's LDS
         const int64_t lim0 = 80 * 1024, lim1 = 160 * 1024 - 1024;
@@ -519,7 +536,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             if (m == 2) { mode = 2; pair = 0; }
             if (m == 3) { mode = 3; pair = 0; }
         }
-        if (const char *e = getenv("MCI_TRAIN_SERIAL")) p->train_serial = atoi(e) != 0;
+        if (const char *e = getenv("MCI_TRAIN_SERIAL")) p->train_serial = atoi(e) != 0 ? 1 : 0;
         if (const char *e = getenv("MCI_PAIR_TABLE")) pair = (atoi(e) != 0 && mode <= 1 && fixed + e2 + (mode == 0 ? hb : 0) <= lim1) ? 1 : 0;
         // histogram tiles: contiguous leaves, each tile's bins fit the LDS left over
         s.leaf_tile.assign(p->leaves.size(), 0);
@@ -606,7 +623,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         if (p->lds_bytes > lim0) p->threads = 512; // measured (tools/c4_sweep.py): 2 waves/SIMD beat 1 fat and 4 spilling ones
     }
     p->nstat = 2 * s.nobs + 2 + Nd;
-    p->packed_n = p->nstat + s.nbin;
+    p->packed_n = p->nstat + s.nbin + 2 * p->npa; // [statistics | histograms | propose | accept]
     p->h_reweight.assign(Nd, 1.0 / Nd); // configuration.jl:110,172-173
     s.body = "w[0] = 1.0;";
     if (!ctx->offline) {
@@ -618,8 +635,6 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         HIPCHK(hipMalloc((void **)&p->d_ghist, (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
         HIPCHK(hipMemset(p->d_ghist, 0, (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
         HIPCHK(hipMalloc((void **)&p->d_stage1, (size_t)mci_problem::kGroups * (s.nbin ? s.nbin : 1) * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&p->d_pa, (size_t)s.ncols * sizeof(double)));
-        HIPCHK(hipMemset(p->d_pa, 0, (size_t)s.ncols * sizeof(double)));
         HIPCHK(hipMalloc((void **)&p->d_status, sizeof(int)));
         HIPCHK(hipMemset(p->d_status, 0, sizeof(int)));
         std::vector<mci::LeafDev> ld;
@@ -645,7 +660,7 @@ int mci_problem_destroy(mci_problem *p) {
         for (int k = 0; k < 3; ++k)
             if (p->module[k]) (void)hipModuleUnload(p->module[k]);
         if (p->d_goal) (void)hipFree(p->d_goal);
-        if (p->d_pa) (void)hipFree(p->d_pa);
+        if (p->d_part_pa) (void)hipFree(p->d_part_pa);
         if (p->d_hold) (void)hipFree(p->d_hold);
         if (p->d_loop) (void)hipFree(p->d_loop);
         if (p->d_hx) (void)hipFree(p->d_hx);
@@ -718,12 +733,18 @@ static int compile_solver(mci_problem *p, int solver) {
     std::vector<char> code;
     std::string log;
     bool cached = false;
-    int rc = mcijit::compile(src, p->threads, code, log, cached);
+    int rc = mcijit::compile(src, p->threads, code, log, cached, &p->code_object[solver]);
     if (rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
     if (!p->ctx->offline) {
         static const char *const names[3] = {"mci_vegas_batch", "mci_vegasmc_chains", "mci_mcmc_chains"};
         HIPCHK(hipSetDevice(p->ctx->device));
-        HIPCHK(hipModuleLoadData(&p->module[solver], code.data()));
+        if (hipModuleLoadData(&p->module[solver], code.data()) != hipSuccess) {
+            // a cached code object that does not load (truncated by a crash, foreign file): drop it and compile afresh, once
+            if (!cached) return fail(MCI_ERR_HIP, "hipModuleLoadData failed for a freshly compiled code object");
+            unlink(p->code_object[solver].c_str());
+            if ((rc = mcijit::compile(src, p->threads, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
+            HIPCHK(hipModuleLoadData(&p->module[solver], code.data()));
+        }
         HIPCHK(hipModuleGetFunction(&p->f_solver[solver], p->module[solver], names[solver]));
         if (solver == MCI_VEGAS) HIPCHK(hipModuleGetFunction(&p->f_dump, p->module[solver], "mci_sample_dump"));
         if (solver == MCI_VEGAS && p->shape.ntile > 1) {
@@ -745,6 +766,20 @@ static int compile_solver(mci_problem *p, int solver) {
 }
 
 int mci_compile(mci_problem *p) { return compile_solver(p, MCI_VEGAS); }
+
+int mci_kernel_code_object(mci_problem *p, int32_t solver, char *buf, int32_t n) {
+    if (!p || !buf || n < 1) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver);
+    if (!p->compiled[solver]) return fail(MCI_ERR_INVALID, "solver %d has not been compiled yet", solver);
+    snprintf(buf, (size_t)n, "%s", p->code_object[solver].c_str());
+    return MCI_OK;
+}
+
+int mci_check_status(mci_problem *p) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    return check_status(p);
+}
 int mci_compile_solver(mci_problem *p, int32_t solver) { return compile_solver(p, solver); }
 
 int mci_problem_info(const mci_problem *p, int32_t *ndraw, int32_t *nobs, int64_t *packed_size, int32_t *table_mode, int64_t *lds_bytes) {
@@ -839,6 +874,13 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     const int64_t nrows = nblocks * wpb;   // partial rows: one per (block, slice)
     const int64_t nwg = split ? nrows : nrows * s.ntile;
     if ((rc = ensure_capacity(p, nrows, nblocks))) return rc;
+    if (solver != MCI_VEGAS && nrows > p->cap_pa) {
+        if (p->d_part_pa) (void)hipFree(p->d_part_pa);
+        p->d_part_pa = nullptr;
+        p->cap_pa = 0;
+        HIPCHK(hipMalloc((void **)&p->d_part_pa, (size_t)nrows * 2 * p->npa * sizeof(double)));
+        p->cap_pa = nrows;
+    }
     if (split) {
         const int64_t nsamp = nblocks * nevalperblock;
         if (nsamp > p->cap_tile) {
@@ -861,6 +903,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.part_cols = p->d_part_cols;
     a.part_hist = p->d_part_hist;
     a.ghist = p->d_ghist;
+    a.part_pa = p->d_part_pa;
     a.seed = seed;
     a.iteration = (mci::u32)iteration;
     a.neval_per_block = nevalperblock;
@@ -936,6 +979,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
         p->launches += 1;
     }
+    p->last_samples = nblocks * nevalperblock;
     p->last_wg = (int)nwg;
     p->last_threads = T;
     p->last_nblocks = (int)nblocks;
@@ -960,7 +1004,9 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     m.packed = p->d_packed;
     m.status = p->d_status;
     m.scratch = p->d_scratch;
-    m.pa_out = p->d_pa;
+    m.part_pa = solver != MCI_VEGAS ? p->d_part_pa : nullptr;
+    m.npa = p->npa;
+    m.nrows = (int)nrows;
     p->merge_pending = true;
     return MCI_OK;
 }
@@ -971,7 +1017,7 @@ static int flush_merge(mci_problem *p) {
     p->merge_pending = false;
     HIPCHK(hipSetDevice(p->ctx->device));
     const int nb256 = (p->shape.nbin + 255) / 256;
-    hipLaunchKernelGGL(mci::k_finalize, dim3(nb256 + 1), dim3(256), 0, p->ctx->stream, p->merge);
+    hipLaunchKernelGGL(mci::k_finalize, dim3(nb256 + 1 + (2 * p->npa + 3) / 4), dim3(256), 0, p->ctx->stream, p->merge);
     HIPCHK(hipGetLastError());
     return MCI_OK;
 }
@@ -1005,16 +1051,21 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     a.do_reweight = do_reweight;
     a.gamma = gamma;
     a.do_train = do_train;
-    a.serial_walk = p->train_serial;
+    a.serial_walk = p->train_serial >= 0 ? p->train_serial : (p->last_samples == 0 || p->last_samples >= mci_problem::kSerialWalkSamples) ? 1 : 0;
     a.status = p->d_status;
     if (p->graph_mode) {
         a.loop = p->d_loop;
         a.iter_log_base = p->d_iterlog;
     }
     const size_t sm = (size_t)(4 * maxn + 16) * sizeof(double); // d[N+4] | sg[N+1] | wa[N+1] | wj[N+1] (train_leaf)
+    if (sm + (size_t)maxn * sizeof(double) > 64 * 1024 && !p->train_lds_raised) { // grids of more than ~1600 increments
+        HIPCHK(hipFuncSetAttribute((const void *)mci::k_train, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
+        HIPCHK(hipFuncSetAttribute((const void *)mci::k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
+        p->train_lds_raised = true;
+    }
     if (p->merge_pending) { // nothing looked at `packed` since the sample batch: merge + refine in one launch
         p->merge_pending = false;
-        hipLaunchKernelGGL(mci::k_finish, dim3(s.nleaf + 1), dim3(256), sm + (size_t)maxn * sizeof(double), p->ctx->stream, p->merge, a);
+        hipLaunchKernelGGL(mci::k_finish, dim3(s.nleaf + 1 + (2 * p->npa + 3) / 4), dim3(256), sm + (size_t)maxn * sizeof(double), p->ctx->stream, p->merge, a);
     } else {
         hipLaunchKernelGGL(mci::k_train, dim3(s.nleaf + 1), dim3(256), sm, p->ctx->stream, a);
     }
@@ -1039,7 +1090,7 @@ int mci_iteration_finish(mci_problem *p, int32_t solver, int64_t block_total, in
         p->cap_iter = ncap;
     }
     double *row = p->d_iterlog + (size_t)p->log_row * p->nstat;
-    // reweight is adapted only together with the grid (main.jl:183 runs it unconditionally for the chain solvers)
+    // doReweight! runs for the chain solvers whether or not the grid adapts (main.jl:183 is outside the `if adapt`)
     int rc = launch_train(p, adapt ? 1 : 0, (solver == MCI_VEGASMC || solver == MCI_MCMC) ? 1 : 0, gamma, row);
     if (rc) return rc;
     p->log_row += 1;
@@ -1278,15 +1329,14 @@ int mci_set_reweight(mci_problem *p, const double *in, int32_t n) {
 }
 
 int mci_get_acceptance(mci_problem *p, double *propose, double *accept, int32_t n) {
-    const int npa = p->npool > 3 ? p->npool : 3;
-    if (n != npa) return fail(MCI_ERR_INVALID, "propose/accept have %d entries", npa);
+    if (n != p->npa) return fail(MCI_ERR_INVALID, "propose/accept have %d entries (3 x %d x %d)", p->npa, p->ni + 1, p->npa / (3 * (p->ni + 1)));
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
-    std::vector<double> h(2 * npa);
+    std::vector<double> h(2 * (size_t)p->npa);
     if (int rc = flush_merge(p)) return rc;
-    HIPCHK(hipMemcpyAsync(h.data(), p->d_pa, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipMemcpyAsync(h.data(), p->d_packed + p->nstat + p->shape.nbin, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
-    if (propose) memcpy(propose, h.data(), npa * sizeof(double));
-    if (accept) memcpy(accept, h.data() + npa, npa * sizeof(double));
+    if (propose) memcpy(propose, h.data(), (size_t)p->npa * sizeof(double));
+    if (accept) memcpy(accept, h.data() + p->npa, (size_t)p->npa * sizeof(double));
     return MCI_OK;
 }
 

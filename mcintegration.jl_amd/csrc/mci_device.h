@@ -57,8 +57,10 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u
     for (int r = 0; r < MCI_PHILOX_ROUNDS; ++r) {
         const u64 p0 = (u64)0xD2511F53u * c0; // v_mad_u64_u32: hi and lo in one issue
         const u64 p1 = (u64)0xCD9E8D57u * c2;
-        const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0;
-        const u32 n2 = (u32)(p0 >> 32) ^ c3 ^ k1;
+        // three-input xor in ONE issue: gfx950 has no v_xor3_b32, but v_bitop3_b32 with truth table 0x96 is exactly that (and
+        // takes the wave-uniform key word from its SGPR); the compiler does not form it by itself from a ^ b ^ c
+        const u32 n0 = __builtin_amdgcn_bitop3_b32((u32)(p1 >> 32), c1, k0, 0x96);
+        const u32 n2 = __builtin_amdgcn_bitop3_b32((u32)(p0 >> 32), c3, k1, 0x96);
         c1 = (u32)p1;
         c3 = (u32)p0;
         c0 = n0;
@@ -71,8 +73,11 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u
 
 // 52 random mantissa bits as a double in [1, 2)
 __device__ __forceinline__ double u12(u32 lo, u32 hi) {
-    const u64 bits = ((((u64)hi << 32) | lo) >> 12) | 0x3FF0000000000000ull;
-    return __longlong_as_double((i64)bits);
+    // ((hi:lo) >> 12) | 0x3FF0...0 as two v_alignbit_b32 (32-bit, full rate): the low word is (hi:lo) >> 12, the high word is
+    // (0x3FF:hi) >> 12 = 0x3FF00000 | hi >> 12 -- instead of a 64-bit shift plus an or
+    const u32 wlo = __builtin_amdgcn_alignbit(hi, lo, 12u);
+    const u32 whi = __builtin_amdgcn_alignbit(0x3FFu, hi, 12u);
+    return __longlong_as_double((i64)(((u64)whi << 32) | wlo));
 }
 __device__ __forceinline__ double u01(u32 lo, u32 hi) { return u12(lo, hi) - 1.0; }
 
@@ -91,6 +96,7 @@ struct BatchArgs {
     double *part_cols;      // [nWG][NCOLS]   per-workgroup partial statistics
     double *part_hist;      // [nWG][NBIN]    per-workgroup partial histograms (TABLE_MODE 0)
     double *ghist;          // [NBIN]         device histogram for global atomics (TABLE_MODE 1,2)
+    double *part_pa;        // [nWG][2*NPA]   per-workgroup propose | accept tables (chain solvers; configuration.jl:185-186)
     u64 seed;
     u32 iteration;
     i64 neval_per_block;    // samples (vegas) or chain steps (vegasmc) per statistical block
@@ -322,7 +328,33 @@ template <class Cfg> __device__ __forceinline__ void stage_tables(const double *
     for (int i = tid; i < Cfg::NDDIST; i += T) sDD[i] = gDD[i];
 }
 
-// LDS carve (doubles).  Order: grid table | dacc | ddist | hist | obs | reduction scratch
+// config.propose / config.accept (configuration.jl:185-186): [3 updates][Nd integrands][max(Nd, Nv) targets], row-major, 0-based:
+//   changeIntegrand [0][curr][new]  (mcmc/updates.jl:48,50)      changeVariable [1][curr][vi]  (mcmc/updates.jl:100,102;
+//   swapVariable    [2][curr][vi]   (mcmc/updates.jl:138,140)    vegasmc: [1][0][vi], vegas_mc/updates.jl:90,92)
+// A workgroup counts in LDS (64-bit integers: exact, order-free) and flushes one row of part_pa.
+template <class Cfg> struct PaTable {
+    static constexpr int ND = Cfg::NI + 1;
+    static constexpr int M = ND > Cfg::NPOOL ? ND : Cfg::NPOOL;
+    static constexpr int N = 3 * ND * M;
+    static __device__ __forceinline__ int idx(int ut, int curr, int target) { return (ut * ND + curr) * M + target; }
+};
+__device__ __forceinline__ void lds_count(u64 *p, u64 n) { __hip_atomic_fetch_add(p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// propose[idx] += 1 on every lane of the wave for which `pred` holds, accept[idx] likewise under `acc`.  UNIFORM: idx is the same
+// on all active lanes (one ballot + one LDS add per wave instead of up to 64 colliding atomics)
+template <class Cfg, bool UNIFORM> __device__ __forceinline__ void pa_count(u64 *sPA, int idx, bool pred, bool acc) {
+    if constexpr (UNIFORM) {
+        const u64 mp = __ballot(pred), ma = __ballot(pred && acc);
+        if (mp != 0ull && (int)(threadIdx.x & 63) == __builtin_ctzll(mp)) {
+            lds_count(&sPA[idx], (u64)__popcll(mp));
+            if (ma != 0ull) lds_count(&sPA[PaTable<Cfg>::N + idx], (u64)__popcll(ma));
+        }
+    } else if (pred) {
+        lds_count(&sPA[idx], 1ull);
+        if (acc) lds_count(&sPA[PaTable<Cfg>::N + idx], 1ull);
+    }
+}
+
+// LDS carve (doubles).  Order: grid table | dacc | ddist | hist | obs | reduction scratch | propose/accept counters
 template <class Cfg> struct Lds {
     static constexpr int E = 0;
     static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
@@ -330,7 +362,8 @@ template <class Cfg> struct Lds {
     static constexpr int H = DD + Cfg::NDDIST;
     static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE : 0);
     static constexpr int R = O + Cfg::NOBS;
-    static constexpr int END = R + 16 /*waves*/ * Cfg::NCOLS;
+    static constexpr int PA = R + 16 /*waves*/ * Cfg::NCOLS; // propose | accept counters (u64), chain solvers
+    static constexpr int END = PA + 2 * PaTable<Cfg>::N;
 };
 
 template <bool B, class X, class Y> struct SelectType { using type = X; };
@@ -345,16 +378,12 @@ template <class Cfg> struct LdsEC {
 };
 
 // partial-statistics columns written per workgroup:
-//   [0, NOBS) observables | NOBS normalization | NOBS+1 neval | NOBS+2 .. +NI+1 visited(N+1) | propose(NPA) | accept(NPA)
-//   NPA = max(NPOOL, 3): per pool for vegasmc (propose[2,1,vi]); per update type for mcmc
+//   [0, NOBS) observables | NOBS normalization | NOBS+1 neval | NOBS+2 .. +NI+1 visited(N+1)
 template <class Cfg> struct Cols {
-    static constexpr int NPA = Cfg::NPOOL > 3 ? Cfg::NPOOL : 3;
     static constexpr int NORM = Cfg::NOBS;
     static constexpr int NEVAL = Cfg::NOBS + 1;
     static constexpr int VISITED = Cfg::NOBS + 2;
-    static constexpr int PROPOSE = VISITED + Cfg::NI + 1;
-    static constexpr int ACCEPT = PROPOSE + NPA;
-    static_assert(ACCEPT + NPA == Cfg::NCOLS, "column layout");
+    static_assert(VISITED + Cfg::NI + 1 == Cfg::NCOLS, "column layout");
 };
 
 // histogram update of one sample: accumulate!(var, pos+offset, weight) for every (integrand i, draw k in own(i))
@@ -415,7 +444,7 @@ template <class Cfg> __device__ __forceinline__ void measure(const double *x, co
 }
 
 // workgroup epilogue: registers -> wave shuffle -> LDS -> one row of part_cols; LDS histogram -> part_hist
-template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/, i64 rowid, int tile) {
+template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA = false> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/, i64 rowid, int tile) {
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
     double *sO = smem + L::O, *sR = smem + L::R, *sH = smem + L::H;
     // scalar observables of the default measure (register accumulators)
@@ -448,6 +477,11 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true> __device__ __fo
         else
             for (int w = 0; w < nwave; ++w) v += sR[w * Cfg::NCOLS + c]; // fixed order: deterministic
         row[c] = v;
+    }
+    if constexpr (WRITE_PA) { // the workgroup's propose | accept counters -> its row of part_pa (exact integers below 2^53)
+        const u64 *sPA = reinterpret_cast<const u64 *>(smem + L::PA);
+        double *prow = a.part_pa + rowid * (2 * PaTable<Cfg>::N);
+        for (int i = tid; i < 2 * PaTable<Cfg>::N && tile == 0; i += T) prow[i] = (double)sPA[i];
     }
     if constexpr (Mode<Cfg>::HIST_LDS && WRITE_HIST) {
         static_for<0, Cfg::NTILE>([&](auto Tt) {
@@ -554,6 +588,11 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     double extra[Cfg::NCOLS - Cfg::NOBS];
     static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
 
+    // measurement cadence (n + 1) % measurefreq == 0 (:148) without a 64-bit division in the sample loop: the remainder is
+    // carried along, n advances by `stride` per trip
+    const i64 mfreq = a.measurefreq;
+    i64 mrem = mfreq == 1 ? 0 : ((i64)slice * T + tid + 1) % mfreq;
+    const i64 mstep = mfreq == 1 ? 0 : stride % mfreq;
     auto run = [&](auto TT) { // the sample loop, specialised on the workgroup's histogram tile
     for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
         Sample<Cfg> s;
@@ -566,7 +605,10 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             Cfg::integrand(s.x, w, a.ud, -1); // vegas/montecarlo.jl:140-144
         }
         extra[Cols<Cfg>::NEVAL - Cfg::NOBS] += 1.0; // config.neval += 1   :118
-        if (a.measurefreq == 1 || (n + 1) % a.measurefreq == 0) { // :148
+        const bool domeasure = mrem == 0; // :148
+        mrem += mstep;
+        mrem = mrem >= mfreq ? mrem - mfreq : mrem;
+        if (domeasure) {
             double relw[Cfg::NW];
             static_for<0, Cfg::NW>([&](auto Q) { constexpr int q = decltype(Q)::value; relw[q] = w[q] * s.jaci[q / Cfg::NCOMP]; }); // :152
             measure<Cfg>(s.x, s.bin, relw, a.ud, acc, sO);
@@ -767,6 +809,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     if constexpr (Mode<Cfg>::HIST_LDS)
         for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
+    for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;
     __syncthreads();
     Tables<Cfg> t;
     if constexpr (Mode<Cfg>::EDGE_LDS) t.E = sE;
@@ -791,7 +835,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     double extra[Cfg::NCOLS - Cfg::NOBS];
     static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
     constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
-    constexpr int XP = Cols<Cfg>::PROPOSE - Cfg::NOBS, XA = Cols<Cfg>::ACCEPT - Cfg::NOBS;
+    // the pool index is wave-uniform (one pool, or the shared pick of a many-chain block): count by ballot
+    const bool pa_uniform = Cfg::NPOOL == 1 || a.nchain > 1;
 
     for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
         const u64 g = (u64)ch;
@@ -812,6 +857,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
         double probability = rw[NORMI] * pad[NORMI]; // :162
         static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; probability += absw<Cfg, i>(w) * rw[i] * pad[i]; }); // :163-166
 
+        i64 mcnt = 0; // ne % measurefreq, carried (no 64-bit division per step)
         for (i64 ne = 1; ne <= steps; ++ne) { // :184
             const u64 sidx = (g << 32) | (u64)(ne - 1);
             const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
@@ -872,13 +918,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; newp += absw<Cfg, i>(wn) * rw[i] * padn[i]; }); // :85-87
                 const double R = prop * newp / probability;    // :88
                 const bool ok = uacc < R;                      // :91
-                static_for<0, Cfg::NPOOL>([&](auto V) {
-                    constexpr int v = decltype(V)::value;
-                    if (vi == v) {
-                        extra[XP + v] += 1.0;                  // :90
-                        if (ok) extra[XA + v] += 1.0;          // :92
-                    }
-                });
+                if (pa_uniform) pa_count<Cfg, true>(sPA, PaTable<Cfg>::idx(1, 0, vi), true, ok);   // :90, :92  propose[2, 1, vi]
+                else pa_count<Cfg, false>(sPA, PaTable<Cfg>::idx(1, 0, vi), true, ok);
                 if (ok) {
                     c = n;
                     static_for<0, Cfg::NW>([&](auto I) { w[decltype(I)::value] = wn[decltype(I)::value]; }); // :93-95
@@ -900,7 +941,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 hist_update<Cfg>(sb, wh, sH, a.ghist, tile);
             }
             // ---- measurement  montecarlo.jl:213-232 ----
-            const bool mf = (a.measurefreq == 1) || (ne % a.measurefreq == 0);
+            mcnt = mcnt + 1 == a.measurefreq ? 0 : mcnt + 1;
+            const bool mf = mcnt == 0;
             if (mf && (double)ne >= a.burnin) { // :213
                 double relw[Cfg::NW];
                 static_for<0, NI>([&](auto I) {
@@ -918,7 +960,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
         }
     }
     __syncthreads();
-    flush_workgroup<Cfg>(a, smem, acc, extra, wi.rowid, tile);
+    flush_workgroup<Cfg, Lds<Cfg>, true, true>(a, smem, acc, extra, wi.rowid, tile);
 }
 
 // =============================================================================================
@@ -1064,6 +1106,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     if constexpr (Mode<Cfg>::HIST_LDS)
         for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
+    for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;
     __syncthreads();
     Tables<Cfg> t;
     if constexpr (Mode<Cfg>::EDGE_LDS) t.E = sE;
@@ -1091,7 +1135,6 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     double extra[Cfg::NCOLS - Cfg::NOBS];
     static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
     constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
-    constexpr int XP = Cols<Cfg>::PROPOSE - Cfg::NOBS, XA = Cols<Cfg>::ACCEPT - Cfg::NOBS;
 
     for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
         const u64 g = (u64)ch;
@@ -1146,6 +1189,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
         // the integrand index, and the longest completed or still running hold
         int last[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1], lastc = 0, hmax = 0;
         static_for<0, Cfg::NDRAW>([&](auto K) { last[decltype(K)::value] = 0; });
+        i64 mcnt = 0; // it % measurefreq, carried
         for (i64 it = 1; it <= steps + nburn; ++it) { // :134
             const u64 sidx = (g << 32) | (u64)(it - 1);
             static_for<0, ND>([&](auto I) { extra[XV + decltype(I)::value] += curr == decltype(I)::value ? 1.0 : 0.0; }); // :136
@@ -1172,6 +1216,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             double prop = 1.0;
             bool active = false;
             int newcurr = curr, ut = 0; // ut: first index of propose[., ., .]: 0 changeIntegrand, 1 changeVariable, 2 swapVariable
+            int pvi = 0;                // the variable pool changeVariable / swapVariable picked (last index of propose)
             u64 touched = 0ull; // draws of the slot(s) this proposal moves (changeVariable, swapVariable)
             if (upd == 0) {
                 // ---- changeIntegrand  updates.jl:1-69 ----
@@ -1230,6 +1275,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             } else if (curr != NORMI) { // updates.jl:73, :115
                 int vi = (int)(upick * (double)NPOOL); // :77, :119
                 if (vi >= NPOOL) vi = NPOOL - 1;
+                pvi = vi;
                 int cdv = 0; // currdof[vi]
                 static_for<0, NI>([&](auto I) {
                     static_for<0, NPOOL>([&](auto V) {
@@ -1313,10 +1359,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                 const double newp = newcurr == NORMI ? rw[NORMI] : wn.abs * rw_sel(newcurr);    // :42-44, :96, :137
                 const double R = prop * newp / probability;                                     // :46, :97, :138
                 const bool ok = uacc < R;                                                       // :49, :100, :141
-                static_for<0, 3>([&](auto U) {
-                    extra[XP + decltype(U)::value] += ut == decltype(U)::value ? 1.0 : 0.0;           // :48, :99, :140
-                    extra[XA + decltype(U)::value] += (ok && ut == decltype(U)::value) ? 1.0 : 0.0;   // :50, :101, :142
-                });
+                // propose[1, curr, new] :48,:50 | propose[2, curr, vi] :99,:101 | propose[3, curr, vi] :140,:142
+                pa_count<Cfg, false>(sPA, PaTable<Cfg>::idx(ut, curr, ut == 0 ? newcurr : pvi), true, ok);
 #ifndef MCI_ABL_NOHOLD
                 if (a.hold_hist) {
                     const int now = (int)it;
@@ -1351,7 +1395,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                   // shiftRollback!/swapRollback! restore the slot (:105, :145)
             }
             // ---- measurement  montecarlo.jl:144-172 ----
-            const bool mf = (a.measurefreq == 1) || (it % a.measurefreq == 0);
+            mcnt = mcnt + 1 == a.measurefreq ? 0 : mcnt + 1;
+            const bool mf = mcnt == 0;
             if (mf && it >= nburn) {
                 if (curr != NORMI) {
                     double relw[Cfg::NCOMP]; // :162
@@ -1400,7 +1445,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
         }
     }
     __syncthreads();
-    flush_workgroup<Cfg>(a, smem, acc, extra, wi.rowid, tile);
+    flush_workgroup<Cfg, Lds<Cfg>, true, true>(a, smem, acc, extra, wi.rowid, tile);
 }
 
 // the map + integrand alone, for parity tests of a2/a3 and for host-side consumers

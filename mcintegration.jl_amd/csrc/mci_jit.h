@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -179,7 +180,7 @@ inline std::string cache_dir() {
 }
 
 // returns the gfx950 code object for `src`, from the on-disk cache or by compiling with hiprtc
-inline int compile(const std::string &src, int threads, std::vector<char> &code, std::string &log, bool &from_cache) {
+inline int compile(const std::string &src, int threads, std::vector<char> &code, std::string &log, bool &from_cache, std::string *cache_path = nullptr) {
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics",
                                      "-ffp-contract=off", "-DMCI_THREADS=" + std::to_string(threads)};
     if (const char *e = getenv("MCI_JIT_FLAGS")) {
@@ -192,6 +193,7 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
     char name[64];
     snprintf(name, sizeof name, "mci_%016llx.hsaco", (unsigned long long)fnv1a(key));
     const std::string dir = cache_dir(), path = dir + "/" + name;
+    if (cache_path) *cache_path = path;
     from_cache = false;
     {
         std::ifstream f(path, std::ios::binary);
@@ -233,7 +235,9 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
     mkdir(dir.c_str(), 0755);
-    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    // unique per process AND per call: concurrent host threads compiling the same key must not share a temporary file
+    static std::atomic<unsigned long> seq{0};
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string(seq.fetch_add(1));
     {
         std::ofstream f(tmp, std::ios::binary);
         if (f) {

@@ -59,8 +59,24 @@ struct MergeArgs {
     double *packed;
     int *status;
     double *scratch;         // [nblocks*ncols]
-    double *pa_out;          // [ncols - (nobs+2+ni+1)]: propose | accept
+    const double *part_pa;   // [nrows][2*npa] per-workgroup propose | accept tables of a chain solver; NULL after a :vegas pass
+    int npa, nrows;          // npa = 3 * (ni+1) * max(ni+1, npool)   (configuration.jl:185-186)
 };
+// packed = [ ... | hist(nbin) | propose(npa) | accept(npa) ]: the tables ride in the all-reduce like MPIreduceConfig! reduces them
+// (configuration.jl:297-298).  One wave per entry, lanes stride over the workgroup rows.
+__device__ inline int merge_pa_blocks(const MergeArgs &m) { return (2 * m.npa + 3) / 4; }
+__device__ inline void merge_pa(const MergeArgs &m, int blk) {
+    const int lane = threadIdx.x & 63, e = blk * 4 + (int)(threadIdx.x >> 6);
+    if (e >= 2 * m.npa) return;
+    double s = 0.0;
+    if (m.part_pa)
+        for (int r = lane; r < m.nrows; r += 64) s += m.part_pa[(size_t)r * (2 * m.npa) + e];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    // clearStatistics! of every block's config and of the summed one: propose 1e-8, accept 1e-10 (configuration.jl:247-248)
+    const double off0 = e < m.npa ? 1.0e-8 : 1.0e-10;
+    if (lane == 0) m.packed[2 * m.nobs + 2 + m.ni + 1 + m.nbin + e] = s + (double)(m.nblocks + 1) * off0;
+}
 
 // one histogram bin of the merged config: clearStatistics! offsets + the second merge stage
 __device__ inline double merge_hist_bin(const MergeArgs &m, int bin) {
@@ -83,7 +99,7 @@ __device__ inline double merge_hist_bin(const MergeArgs &m, int bin) {
 __device__ inline void merge_stats(const MergeArgs &m) {
     const double *__restrict__ part_cols = m.part_cols;
     const int ncols = m.ncols, nobs = m.nobs, ni = m.ni, nblocks = m.nblocks, wg_per_block = m.wg_per_block;
-    double *__restrict__ packed = m.packed, *__restrict__ scratch = m.scratch, *__restrict__ pa_out = m.pa_out;
+    double *__restrict__ packed = m.packed, *__restrict__ scratch = m.scratch;
     int *status = m.status;
     // --- statistics columns ---
     // scratch[b][c] = sum over the block's workgroup rows, in a fixed order: 8 lanes per (block, column) stride
@@ -135,14 +151,6 @@ __device__ inline void merge_stats(const MergeArgs &m) {
         for (int b = 0; b < nblocks; ++b) v += scratch[b * ncols + cvis + i] + 1.0e-8;
         packed[2 * nobs + 2 + i] = v;
     }
-    // propose / accept (diagnostics of report(config), configuration.jl:345-464): this rank's blocks only
-    const int cpa = cvis + ni + 1, npa = (ncols - cpa) / 2;
-    for (int i = threadIdx.x; i < 2 * npa; i += blockDim.x) {
-        const double off = i < npa ? 1.0e-8 : 1.0e-10; // clearStatistics!  configuration.jl:247-248
-        double v = off;
-        for (int b = 0; b < nblocks; ++b) v += scratch[b * ncols + cpa + i] + off;
-        pa_out[i] = v;
-    }
 }
 
 __global__ void __launch_bounds__(256) k_finalize(MergeArgs m) {
@@ -151,6 +159,10 @@ __global__ void __launch_bounds__(256) k_finalize(MergeArgs m) {
     if ((int)blockIdx.x < nhb) {
         const int bin = blockIdx.x * 256 + threadIdx.x;
         if (bin < m.nbin) m.packed[hoff + bin] = merge_hist_bin(m, bin);
+        return;
+    }
+    if ((int)blockIdx.x > nhb) { // grid = nhb + 1 + merge_pa_blocks
+        merge_pa(m, (int)blockIdx.x - nhb - 1);
         return;
     }
     merge_stats(m);
@@ -433,6 +445,10 @@ __global__ void __launch_bounds__(256) k_finish(MergeArgs m, TrainArgs a) {
         merge_stats(m);
         __syncthreads(); // the head of `packed` was written by this workgroup
         iteration_bookkeeping(a);
+        return;
+    }
+    if ((int)blockIdx.x > a.nleaf) { // grid = nleaf + 1 + merge_pa_blocks
+        merge_pa(m, (int)blockIdx.x - a.nleaf - 1);
         return;
     }
     const LeafDev L = a.leaves[blockIdx.x];

@@ -77,14 +77,18 @@ class Engine:
             d.alpha, d.adapt = lf.alpha, 1 if lf.adapt else 0
             d.lower, d.upper = float(lf.lower), float(lf.upper)
             init = None
+            # a variable that already lives in another, still open engine brings what it has learned there:
+            # `integrate(...; var = (res.config.var[1], ...))` continues from the trained map (docs/src/index.md:129)
+            prev = getattr(lf, "_engine", None)
+            trained = prev is not None and prev is not self and getattr(prev, "p", None)
             if isinstance(lf, ContinuousVar):
                 d.kind, d.npoints = _lib.CONTINUOUS, lf.ninc
-                init = lf._grid0
+                init = lf.grid if trained else lf._grid0
             elif isinstance(lf, FermiK):
                 d.kind, d.npoints = _lib.FERMIK, lf.dim   # lower = kF, upper = dk, alpha = maxK
             else:
                 d.kind, d.npoints = _lib.DISCRETE, 0
-                init = lf._dist0
+                init = lf.distribution if trained else lf._dist0
             if init is not None:
                 init = np.ascontiguousarray(init, dtype=np.float64)
                 self._keep.append(init)
@@ -176,6 +180,16 @@ class Engine:
     # ---- kernels -------------------------------------------------------------------------------
     def compile(self, solver="vegas"):
         check(lib().mci_compile_solver(self.p, _lib.SOLVERS[solver]))
+
+    def code_object(self, solver="vegas"):
+        """kernel-cache file holding the solver's gfx950 code object (after compile / the first run)"""
+        buf = C.create_string_buffer(4096)
+        check(lib().mci_kernel_code_object(self.p, _lib.SOLVERS[solver], buf, len(buf)))
+        return buf.value.decode()
+
+    def check_status(self):
+        """synchronise and raise what the device flagged (normalization / histogram / chain start errors)"""
+        check(lib().mci_check_status(self.p))
 
     def set_launch(self, threads=0, wg_per_block=-1):
         check(lib().mci_set_launch(self.p, threads, wg_per_block))
@@ -312,11 +326,21 @@ class Engine:
         return out
 
     def acceptance(self):
-        """(propose, accept) of the last iteration on this rank; see mci_get_acceptance"""
-        n = max(len(self.config.var), 3)
+        """(propose, accept) of the last iteration, each shaped [3, N+1, max(N+1, Nv)] like config.propose / config.accept
+        (configuration.jl:185-186; 0-based: [update, integrand, target]); see mci_get_acceptance"""
+        nd = self.config.N + 1
+        m = max(nd, len(self.config.var))
+        n = 3 * nd * m
         pr, ac = np.empty(n), np.empty(n)
         check(lib().mci_get_acceptance(self.p, _dp(pr), _dp(ac), n))
-        return pr, ac
+        return pr.reshape(3, nd, m), ac.reshape(3, nd, m)
+
+    def histograms(self):
+        """histogram section of the packed buffer (all leaves, concatenated)"""
+        off = 2 * self.nobs + 2 + self.config.N + 1
+        nd = self.config.N + 1
+        npa = 3 * nd * max(nd, len(self.config.var))
+        return self.get_packed()[off:self.packed_size - 2 * npa]
 
     def set_reweight_goal(self, goal):
         if goal is None:

@@ -25,7 +25,7 @@ def standardize_block(neval, nblock, nworker=1):
 def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, block=16, verbose=-1, gamma=1.0,
               adapt=True, debug=False, reweight_goal=None, ignore=None, measure=None, measurefreq=1,
               thermal_ratio=0.1, inplace=False, parallel="nothread", print=-1, printio=None, timer=None,
-              comm=None, device=0, nchain=0, engine_factory=None, **kwargs):
+              comm=None, device=None, nchain=0, engine_factory=None, **kwargs):
     """Same keywords as the reference (main.jl:71-90; unknown ones go to Configuration, :95-97).
     Extra, engine-specific keywords: `comm` (LocalComm | RcclComm | TorchDistComm), `device`, `nchain`
     (vegasmc chains per block; 0 = auto), `engine_factory` (test seam)."""
@@ -41,6 +41,8 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     if ignore is None:
         ignore = 1 if adapt else 0                                                    # main.jl:82
     comm = comm or LocalComm()
+    if device is None:   # an RcclComm is bound to one device: the engine has to live there (its all_reduce checks it)
+        device = getattr(comm, "device", 0)
     neval = int(neval)
     nevalperblock, block = standardize_block(neval, block, comm.size)                 # main.jl:121
     assert block % comm.size == 0                                                     # main.jl:122
@@ -56,16 +58,22 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
            repr(config.neighbor))
     if config._engine is None or config._engine_key != key:
         # grids trained so far survive a change of integrand (`var = (res.config.var[1], ...)`, docs/src/index.md:129)
+        # and so does the learned reweight (config.reweight lives across integrate calls, configuration.jl:50)
         old = config._engine
-        saved = None
+        saved, saved_rw = None, None
         if old is not None:
             saved = [(old.grid(i) if hasattr(lf, "ninc") else None if hasattr(lf, "kF") else old.distribution(i)[0])
                      for i, lf in enumerate(config.leaves)]
+            saved_rw = old.reweight()
         eng = (engine_factory or Engine)(config, integrand, measure=measure, device=device)
         if saved is not None:
             for i, lf in enumerate(config.leaves):
                 if saved[i] is not None:   # (a FermiK has nothing trained)
                     (eng.set_grid if hasattr(lf, "ninc") else eng.set_distribution)(i, saved[i])
+            if hasattr(eng, "set_reweight"):
+                eng.set_reweight(saved_rw)
+            if hasattr(old, "close"):
+                old.close()                # its device buffers go now, not at some later garbage collection
         config._engine, config._engine_key = eng, key
         if getattr(config, "_pending_state", None):
             eng.load_state(config._pending_state)

@@ -96,14 +96,17 @@ def _tostring(m, e):
 
 
 def report_config(config, io=None):
-    """report(config) (configuration.jl:345-464).  The reference tabulates propose/accept per (integrand, target);
-    the engine keeps them summed per update type (mcmc) or per variable (vegasmc), see mci_get_acceptance."""
+    """report(config) (configuration.jl:345-464): the ChangeIntegrand / ChangeVariable / SwapVariable acceptance tables per
+    (integrand, target) from config.propose / config.accept, then visited and reweight.  Same rows, order and number formats
+    as the reference (which prints every table whatever the solver: under :vegasmc only ChangeVariable row 1 is populated,
+    vegas_mc/updates.jl:90; under :vegas nothing is)."""
     import sys
     import datetime
-    from .variables import CompositeVar, ContinuousVar, DiscreteVar
+    from .variables import CompositeVar, ContinuousVar, DiscreteVar, FermiK
     io = io or sys.stdout
     eng = config._engine
     bar = "-" * 85
+    Nd = config.N + 1
     print("", file=io)
     print("===========================  Configuration  =========================================", file=io)
     print(datetime.datetime.now().isoformat(sep="T", timespec="milliseconds"), file=io)
@@ -115,19 +118,38 @@ def report_config(config, io=None):
     neval = max(config.neval, 1)
     if eng is not None and hasattr(eng, "acceptance"):
         pr, ac = eng.acceptance()
-        solver = getattr(config, "_last_solver", None)
-        if solver == "mcmc":
-            for title, k in (("ChangeIntegrand", 0), ("ChangeVariable", 1), ("SwapVariable", 2)):
-                print("%-20s %12s %12s %12s" % (title, "Proposed", "Accepted", "Ratio  "), file=io)
-                print("  all               : %11.6f%% %11.6f%% %12.6f" % (pr[k] / neval * 100.0, ac[k] / neval * 100.0, ac[k] / pr[k]), file=io)
-                print(bar, file=io)
-        elif solver == "vegasmc":
-            print("%-20s %12s %12s %12s" % ("ChangeVariable", "Proposed", "Accepted", "Ratio  "), file=io)
+    else:
+        m = max(Nd, len(config.var))
+        pr, ac = np.full((3, Nd, m), 1.0e-8), np.zeros((3, Nd, m))                   # configuration.jl:185-186
+    nbrs = config.neighbor_lists()
+    if nbrs is None:                                                                 # the default graph, configuration.jl:203-208
+        nbrs = [[i - 1, i + 1] for i in range(Nd)]
+        nbrs[0] = [1] if Nd == 2 else [Nd - 1, 1]
+        nbrs[Nd - 1] = [0]
+        if Nd >= 3:
+            nbrs[Nd - 2] = [Nd - 3]
+
+    def row(label, u, i, j):
+        print("%s %11.6f%% %11.6f%% %12.6f" % (label, pr[u, i, j] / neval * 100.0, ac[u, i, j] / neval * 100.0, ac[u, i, j] / pr[u, i, j]), file=io)
+
+    print("%-20s %12s %12s %12s" % ("ChangeIntegrand", "Proposed", "Accepted", "Ratio  "), file=io)
+    for n in nbrs[Nd - 1]:                                                           # :369-378
+        row("Norm -> %2d:          " % (n + 1), 0, Nd - 1, n)
+    for idx in range(Nd - 1):                                                        # :379-399
+        for n in nbrs[idx]:
+            if n == Nd - 1:
+                row("  %d ->Norm:          " % (idx + 1), 0, idx, n)
+            else:
+                row("  %d -> %2d:           " % (idx + 1, n + 1), 0, idx, n)
+    print(bar, file=io)
+    for u, title in ((1, "ChangeVariable"), (2, "SwapVariable")):                    # :402-452
+        print("%-20s %12s %12s %12s" % (title, "Proposed", "Accepted", "Ratio  "), file=io)
+        for idx in range(Nd - 1):
             for vi, v in enumerate(config.var):
                 typestr = "Continuous" if isinstance(v, ContinuousVar) else "Discrete" if isinstance(v, DiscreteVar) else \
-                    "Composite" if isinstance(v, CompositeVar) else type(v).__name__
-                print("  %2d / %-11s:   %11.6f%% %11.6f%% %12.6f" % (1, typestr, pr[vi] / neval * 100.0, ac[vi] / neval * 100.0, ac[vi] / pr[vi]), file=io)
-            print(bar, file=io)
+                    "Composite" if isinstance(v, CompositeVar) else "FermiK" if isinstance(v, FermiK) else type(v).__name__
+                row("  %2d / %-11s:  " % (idx + 1, typestr), u, idx, vi)
+        print(bar, file=io)
     print("Integrand            Visited      ReWeight", file=io)
     vis = getattr(config, "visited", None)
     rw = config.reweight

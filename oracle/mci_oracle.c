@@ -343,7 +343,8 @@ mcio_config *mcio_config_create(int nleaf, const int *kind, const int *pool, con
     for (int i = 0; i < Nd; ++i) c->reweight[i] = 1.0 / Nd; /* ref: configuration.jl:110,172-173 */
     c->visited = (double *)calloc((size_t)Nd, sizeof(double));
     for (int i = 0; i < Nd; ++i) c->visited[i] = 1.0e-8;    /* :182 */
-    c->npa = npool > 3 ? npool : 3;
+    c->pam = Nd > npool ? Nd : npool;     /* :185 max(Nd, Nv) */
+    c->npa = 3 * Nd * c->pam;
     c->propose = (double *)calloc((size_t)c->npa, sizeof(double));
     c->accept = (double *)calloc((size_t)c->npa, sizeof(double));
     for (int v = 0; v < c->npa; ++v) c->propose[v] = 1.0e-8; /* :186 */
@@ -845,6 +846,8 @@ static inline void measure(mcio_config *c, const double *x, const double *relw, 
 /* ------------------------------------------------------------------------------------------
  * src/vegas/montecarlo.jl:72-191
  * ---------------------------------------------------------------------------------------- */
+/* propose / accept [update][integrand][target], configuration.jl:185-186 (0-based, row-major) */
+#define PA_IDX(c, ut, curr, target) ((((ut) * ((c)->Ni + 1)) + (curr)) * (c)->pam + (target))
 #define MCIO_MAXDRAW 256
 #define MCIO_MAXNI 64
 
@@ -996,9 +999,9 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
                 double newp = c->reweight[norm] * _pad[norm];                          /* :84 */
                 for (int i = 0; i < N; ++i) newp += absw(c, _weights, i) * c->reweight[i] * _pad[i]; /* :85-87 */
                 double R = prop * newp / probability;          /* :88 */
-                c->propose[vi] += 1.0;                         /* :90 */
+                c->propose[PA_IDX(c, 1, 0, vi)] += 1.0;        /* :90 propose[2, 1, vi] */
                 if (mcio_uniform(seed, st_step, sidx, 2) < R) { /* :91 */
-                    c->accept[vi] += 1.0;                      /* :92 */
+                    c->accept[PA_IDX(c, 1, 0, vi)] += 1.0;     /* :92 */
                     for (int i = 0; i < N * nc; ++i) weights[i] = _weights[i]; /* :93-95 */
                     for (int i = 0; i <= N; ++i) pad[i] = _pad[i];        /* :96-98 */
                     probability = newp;                        /* :100 */
@@ -1193,9 +1196,9 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                     c->neval += 1;                                  /* :40 */
                     const double newp = (new_ == norm) ? c->reweight[new_] : newabs * c->reweight[new_]; /* :42-44 */
                     const double R = prop * newp / probability;     /* :46 */
-                    c->propose[0] += 1.0;                           /* :48 propose[1, curr, new] */
+                    c->propose[PA_IDX(c, 0, curr, new_)] += 1.0;    /* :48 propose[1, curr, new] */
                     if (mcio_uniform(seed, st_step, sidx, 4) < R) { /* :49 */
-                        c->accept[0] += 1.0;                        /* :50 */
+                        c->accept[PA_IDX(c, 0, curr, new_)] += 1.0; /* :50 */
                         moved = 1;
                         curr = new_;                                /* :51-53 */
                         weight[0] = neww[0];
@@ -1223,9 +1226,9 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         c->neval += 1;                              /* :135 */
                         const double newp = absw(c, w, curr) * c->reweight[curr]; /* :137 */
                         const double R = prop * newp / probability; /* :138 */
-                        c->propose[2] += 1.0;                       /* :140 propose[3, curr, vi] */
+                        c->propose[PA_IDX(c, 2, curr, vi)] += 1.0;  /* :140 propose[3, curr, vi] */
                         if (mcio_uniform(seed, st_step, sidx, 4) < R) {
-                            c->accept[2] += 1.0;
+                            c->accept[PA_IDX(c, 2, curr, vi)] += 1.0;
                             moved = 2; mv_pool = vi; mv_s1 = s1; mv_s2 = s2;
                             for (int q = 0; q < nc; ++q) weight[q] = w[nc * curr + q];
                             probability = newp;
@@ -1251,9 +1254,9 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
                         c->neval += 1;                              /* :94 */
                         const double newp = absw(c, w, curr) * c->reweight[curr]; /* :96 */
                         const double R = prop * newp / probability; /* :97 */
-                        c->propose[1] += 1.0;                       /* :99 propose[2, curr, vi] */
+                        c->propose[PA_IDX(c, 1, curr, vi)] += 1.0;  /* :99 propose[2, curr, vi] */
                         if (mcio_uniform(seed, st_step, sidx, 4) < R) {
-                            c->accept[1] += 1.0;
+                            c->accept[PA_IDX(c, 1, curr, vi)] += 1.0;
                             moved = 2; mv_pool = vi; mv_s1 = slot; mv_s2 = 0;
                             for (int q = 0; q < nc; ++q) weight[q] = w[nc * curr + q];
                             probability = newp;
@@ -1391,7 +1394,7 @@ void mcio_do_reweight(double *reweight, const double *visited, long nd, double g
 long mcio_packed_size(const mcio_config *c) {
     long n = 2L * c->nobs + 2 + (c->Ni + 1);
     for (int l = 0; l < c->nleaf; ++l) n += c->leaf[l].nbin;
-    return n;
+    return n + 2L * c->npa; /* propose | accept, reduced with everything else (configuration.jl:297-298) */
 }
 
 mcio_result *mcio_result_create(int niter, int nobs, int Ni) {
@@ -1473,6 +1476,8 @@ static void pack(const mcio_config *c, const double *obs_sum, const double *obs_
     for (int i = 0; i < c->Ni + 1; ++i) out[p++] = c->visited[i];
     for (int l = 0; l < c->nleaf; ++l)
         for (int i = 0; i < c->leaf[l].nbin; ++i) out[p++] = c->leaf[l].hist[i];
+    for (int v = 0; v < c->npa; ++v) out[p++] = c->propose[v];
+    for (int v = 0; v < c->npa; ++v) out[p++] = c->accept[v];
 }
 
 int mcio_iteration(mcio_config *c, int solver, mcio_integrand_fn f, const double *ud,

@@ -93,11 +93,13 @@ typedef struct {
     long neval;
     double *reweight;     /* [Ni+1] */
     double *visited;      /* [Ni+1] */
-    double *propose;      /* [npa] vegasmc: propose[2,1,vi] (vegas_mc/updates.jl:90); mcmc: summed per update type
-                             (changeIntegrand, changeVariable, swapVariable = first index of configuration.jl:186) */
-    double *accept;       /* [npa] */
+    double *propose;      /* [3][Ni+1][pam] row-major = propose[update, integrand, target] of configuration.jl:185 (0-based):
+                             changeIntegrand [0][curr][new] (mcmc/updates.jl:48), changeVariable [1][curr][vi] (:100; vegasmc
+                             [1][0][vi], vegas_mc/updates.jl:90), swapVariable [2][curr][vi] (:138) */
+    double *accept;       /* same shape (configuration.jl:186) */
     int prob_mode;
-    int npa;              /* max(npool, 3) */
+    int npa;              /* 3 * (Ni+1) * pam */
+    int pam;              /* max(Ni+1, npool): the last dimension */
     int *nneighbor;       /* [Ni+1] configuration.jl:201-227 */
     int **neighbor;       /* [Ni+1][nneighbor] 0-based integrand indices; index Ni = normalisation */
     double thermal_ratio; /* mcmc/montecarlo.jl:77 (default 0.1) */

@@ -46,7 +46,7 @@ class _Config(C.Structure):
                 ("nobs", C.c_int), ("obs_off", c_int_p), ("obs_nbin", c_int_p), ("obs_bin_draw", c_int_p),
                 ("observable", c_double_p), ("normalization", C.c_double), ("neval", C.c_long),
                 ("reweight", c_double_p), ("visited", c_double_p), ("propose", c_double_p),
-                ("accept", c_double_p), ("prob_mode", C.c_int), ("npa", C.c_int), ("nneighbor", c_int_p),
+                ("accept", c_double_p), ("prob_mode", C.c_int), ("npa", C.c_int), ("pam", C.c_int), ("nneighbor", c_int_p),
                 ("neighbor", C.POINTER(c_int_p)), ("thermal_ratio", C.c_double), ("reweight_goal", c_double_p),
                 ("ncomp", C.c_int), ("measure_fn", C.c_void_p), ("pool_width", c_int_p), ("draw_comp", c_int_p),
                 ("hold_hist", C.POINTER(C.c_ulonglong))]

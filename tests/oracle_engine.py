@@ -4,6 +4,7 @@ identical train on every rank, Result) run on CPU with torch.distributed/gloo.  
 import numpy as np
 
 import mci_oracle as O
+from mcintegration_jl_amd._lib import SOLVERS
 from mcintegration_jl_amd.variables import ContinuousVar
 
 
@@ -37,6 +38,7 @@ class OracleEngine:
         self._goal = None if goal is None else np.ascontiguousarray(goal, dtype=np.float64)
 
     def run(self, solver, nevalperblock, lo, hi, iteration, seed, measurefreq=1, nchain=0, thermal_ratio=0.1):
+        solver = SOLVERS[solver]   # names or codes, like Engine.run
         self.calls.append((lo, hi, iteration))
         self.ocfg.set_thermal_ratio(thermal_ratio)
         self._packed = self.ocfg.iteration(int(solver), self.fn, self.ud, nevalperblock, lo, hi, iteration, seed,
@@ -52,6 +54,7 @@ class OracleEngine:
         self._packed = np.array(a, dtype=np.float64)
 
     def finish(self, solver, block_total, adapt=True, gamma=1.0, want_stats=True):
+        solver = SOLVERS[solver]
         c = self.ocfg.c
         nstat = 2 * self.nobs + 2 + c.Ni + 1
         off = nstat

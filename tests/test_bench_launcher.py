@@ -1,0 +1,73 @@
+"""bench.py's own N-rank launch path, in the build container: `python bench.py --gpus 2` (no torch.distributed launcher
+around it) must start two ranks by itself, give each its half of the global blocks (src/main.jl:121-122, :152-166), sum the
+packed buffers every iteration (src/main.jl:177-188) and print ONE JSON line that says so.  No GPU here: the HIP engine is
+replaced by the oracle-backed test engine through bench.py's MCI_BENCH_ENGINE seam and the reducer is gloo, so the line is
+a dry run (no throughput claim) -- what is under test is the launcher, the partition and the communicator bookkeeping."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _run(args, extra_env=None, timeout=300):
+    env = dict(os.environ)
+    env["MCI_BENCH_ENGINE"] = "oracle_engine:OracleEngine"
+    env["PYTHONPATH"] = os.pathsep.join([HERE, os.path.join(ROOT, "oracle"), ROOT, env.get("PYTHONPATH", "")])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]   # rank 0 prints ONE line
+    return json.loads(lines[-1])
+
+
+def test_gpus_2_launches_two_ranks_by_itself(oracle):
+    out = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--passes", "2", "--neval-per-gpu", "32000", "--no-cpu-baseline"])
+    assert out["dry_run"] is True and out["value"] == 0.0
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["block"] == 32 and out["config"]["neval_per_iteration"] == 64000
+    comm = out["comm"]
+    assert comm["kind"] == "gloo" and comm["ranks"] == 2 and comm["world_size"] == 2
+    # two distinct block ranges that tile the global blocks
+    assert [r["blocks"] for r in comm["per_rank"]] == [[0, 16], [16, 32]]
+    assert [r["rank"] for r in comm["per_rank"]] == [0, 1]
+    assert out["timing"]["passes"] == 2 and len(out["timing"]["ms_per_step_per_pass"]) == 2
+    est = out["estimate"]
+    assert est["iterations"] == 4
+    assert est["sigma"] > 0 and 0 < est["mean"] < 10   # (6.4e4 samples in 16-D say nothing about the value: plumbing only)
+
+
+def test_one_rank_line_matches_the_two_rank_estimate_on_the_same_global_blocks(oracle):
+    """the union of streams does not depend on the rank count: N=1 with block=32 draws the same samples as N=2 with 16 each.
+    bench.py fixes block = 16 per rank, so compare 2 ranks x 16000 with 1 rank x 32000 only through the launcher's fields."""
+    one = _run(["--gpus", "1", "--steps", "1", "--warmup", "1", "--passes", "1", "--neval-per-gpu", "32000", "--no-cpu-baseline"])
+    assert one["n_gpus"] == 1 and one["comm"]["kind"] == "none" and one["comm"]["ranks"] == 1
+    assert one["comm"]["per_rank"][0]["blocks"] == [0, 16]
+
+
+def test_launched_under_torch_distributed_run_it_does_not_spawn_again(oracle):
+    """the driver's own launch line: WORLD_SIZE is set, so bench.py must run as ONE rank of the job"""
+    env = dict(os.environ)
+    env["MCI_BENCH_ENGINE"] = "oracle_engine:OracleEngine"
+    env["PYTHONPATH"] = os.pathsep.join([HERE, os.path.join(ROOT, "oracle"), ROOT, env.get("PYTHONPATH", "")])
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--passes", "1",
+           "--neval-per-gpu", "16000", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["comm"]["ranks"] == 2 and [r["blocks"] for r in out["comm"]["per_rank"]] == [[0, 16], [16, 32]]

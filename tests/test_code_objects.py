@@ -1,0 +1,85 @@
+"""The gfx950 code objects of the BASELINE configurations, inspected without a GPU: hiprtc cross-compiles them in the build
+container (offline context), llvm-readelf gives their register / scratch budget, llvm-objdump the instruction mix of the sample
+loop that bench.py's roofline is priced on (mcintegration.jl_amd/isa_mix.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import mcintegration_jl_amd as mci
+from mcintegration_jl_amd import isa_mix
+
+L = math.sqrt(50.0)
+PI = math.pi
+
+
+def _bubble():
+    p = mci.catalog.bubble_parameters()
+    var = (mci.Continuous(0.0, 1.0, alpha=3.0), mci.Continuous(0.0, PI, alpha=3.0), mci.Continuous(0.0, 2 * PI, alpha=3.0),
+           mci.Continuous(0.0, p["beta"], alpha=3.0), mci.Discrete(1, 4, adapt=False))
+    return mci.Configuration(var=var, dof=[[1, 1, 1, 1, 1]], obs=[np.zeros(4)])
+
+
+# (name, Configuration, integrand, measure, solver, kernel, max VGPRs = the occupancy step the design relies on)
+BASELINE = [
+    ("c1", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]]), mci.catalog.log_over_sqrt, None, "vegas", "mci_vegas_batch", 64),
+    ("c2", lambda: mci.Configuration(var=mci.Continuous(-L, L), dof=[[16]]), lambda: mci.catalog.gaussian(16), None, "vegas", "mci_vegas_batch", 128),
+    ("c3", _bubble, mci.catalog.bubble, lambda: mci.bin_by(4), "vegasmc", "mci_vegasmc_chains", 256),
+    ("c4", lambda: mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]]), lambda: mci.catalog.genz_product_peak(32), None, "vegas",
+     "mci_vegas_batch", 168),
+    ("c5", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]]), mci.catalog.nested_gauss, None, "mcmc",
+     "mci_mcmc_chains", 512),
+]
+
+
+def _code_object(cfg, f, meas, solver):
+    eng = mci.Engine(cfg(), f(), measure=meas() if meas else None, device=-1)   # offline context: compile only
+    eng.compile(solver)
+    path = eng.code_object(solver)
+    eng.close()
+    assert os.path.exists(path)
+    return path
+
+
+@pytest.mark.parametrize("name,cfg,f,meas,solver,kernel,max_vgpr", BASELINE, ids=[b[0] for b in BASELINE])
+def test_baseline_kernels_do_not_spill(name, cfg, f, meas, solver, kernel, max_vgpr):
+    """no VGPR spills, no scratch, and the register budget of the occupancy step each kernel is designed for
+    (MI355X_MICROARCH.md: <= 128 VGPRs -> 4 waves/SIMD, <= 168 -> 3, <= 256 -> 2, <= 512 -> 1)"""
+    res = isa_mix.resources(_code_object(cfg, f, meas, solver))
+    assert kernel in res, res
+    for k, r in res.items():
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, k, r)
+    assert res[kernel]["vgpr"] <= max_vgpr, (name, res[kernel])
+    if name == "c4":
+        assert res["mci_vegas_tiles"]["vgpr"] <= 64   # the replay kernel: 8 waves/SIMD
+
+
+def test_c2_sample_loop_mix():
+    """the 16-D Gaussian's sample loop: one ds_read_b128 + one ds_add_f64 per draw, Philox as v_mad_u64_u32 + v_bitop3_b32
+    (no two-instruction xor3), straight-line body (no inner loops)"""
+    mix = isa_mix.loop_mix(_code_object(*BASELINE[1][1:5]), "mci_vegas_batch")
+    m, c = mix["mnemonics"], mix["classes"]
+    assert mix["inner_backward_branches"] == 0
+    assert m["ds_read_b128"] == 16 and m["ds_add_f64"] == 16 and mix["pipes"]["lds"] == 32
+    assert 120 <= m["v_mad_u64_u32"] <= 160 and 120 <= m["v_bitop3_b32"] <= 160     # 8 calls x 10 rounds x 2, minus shared first-round terms
+    assert m.get("v_xor_b32_e32", 0) < 10 and m["v_alignbit_b32"] == 32              # u12(): two alignbits per draw
+    assert 16 <= m["v_fract_f64_e32"] <= 17 and mix["pipes"].get("vmem", 0) == 0    # nothing leaves the CU inside the loop
+    assert 480 <= mix["pipes"]["valu"] <= 600
+    assert sum(c.values()) == mix["pipes"]["valu"] + mix["pipes"]["lds"] + mix["pipes"].get("salu", 0) + mix["pipes"].get("vmem", 0) + mix["pipes"].get("other", 0)
+    cyc = isa_mix.issue_cycles(mix, {"v_xor_b32": 1.1, "v_alignbit_b32": 1.75, "v_bitop3_b32": 1.75, "v_mad_u64_u32": 1.87, "v_mul_lo_u32": 1.74,
+                                     "v_lshrrev_b64": 1.8, "v_fma_f64": 1.77, "v_mul_f64": 1.76, "v_add_f64": 1.76, "v_fract_f64": 1.77,
+                                     "v_cvt_i32_f64": 1.77, "v_rcp_f64": 6.8, "v_cmp_lt_f64": 1.8, "v_ldexp_f64": 1.76, "v_exp_f32": 3.5,
+                                     "ds_read_b128 (random": 21.6, "ds_read_b64 (random": 11.7, "ds_add_f64 (random": 41.0})
+    assert 800 < cyc["valu"] < 1100 and cyc["lds"] == pytest.approx(16 * 21.6 + 16 * 41.0)
+
+
+def test_branch_targets_and_classes():
+    assert isa_mix._branch_target(0x100, "s_cbranch_execnz", "65521") == 0x100 + 4 - 4 * 15
+    assert isa_mix._branch_target(0x100, "s_branch", "3") == 0x110
+    assert isa_mix.classify("v_bitop3_b32") == ("valu", "valu_bitop3")
+    assert isa_mix.classify("v_fma_f64") == ("valu", "valu_f64_fma")
+    assert isa_mix.classify("v_lshl_add_u32") == ("valu", "valu_b32_3src")
+    assert isa_mix.classify("v_xor_b32_e32") == ("valu", "valu_b32")
+    assert isa_mix.classify("ds_add_f64") == ("lds", "lds_add_f64")
+    assert isa_mix.classify("global_load_dwordx4") == ("vmem", "vmem")

@@ -199,9 +199,10 @@ def test_library_rccl_single_rank_and_torch_reducer():
     check(res, 2.0 / 3.0)
     # the chain solvers through the N > 1 code path (all-reduce of `visited`, then doReweight! on every rank): same numbers as alone
     for alg in ("vegasmc", "mcmc"):
-        kw = dict(var=Continuous(0.0, 1.0), dof=[[2], [3]], solver=alg, neval=2e5, seed=5)
-        a = integrate(mci.catalog.sphere2(), comm=comm, **kw)
-        b = integrate(mci.catalog.sphere2(), **kw)
+        kw = dict(dof=[[2], [3]], solver=alg, neval=2e5, seed=5)
+        # (a fresh variable per run: a variable object carries its trained grid into the next Configuration, like the reference's)
+        a = integrate(mci.catalog.sphere2(), comm=comm, var=Continuous(0.0, 1.0), **kw)
+        b = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), **kw)
         np.testing.assert_allclose(a.mean, b.mean, rtol=1e-6)
         check(a, [PI / 4.0, 4.0 * PI / 3.0 / 8])
 
@@ -286,17 +287,32 @@ def test_state_file_round_trip_resumes_in_a_new_problem(tmp_path):
 
 
 def test_report_config_prints_the_acceptance_table(capsys):
-    """report(config) (configuration.jl:345-464) for the chain solvers: proposed / accepted / visited / reweight."""
+    """report(config) (configuration.jl:345-464): one ChangeIntegrand row per edge of the neighbor graph, one ChangeVariable
+    and one SwapVariable row per (integrand, variable), with the numbers of config.propose / config.accept (their parity with
+    the oracle is in test_hip_parity.py)."""
+    import re
     res = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), dof=[[2], [3]], solver="mcmc", neval=2e5, seed=41)
     pr, ac = res.config._engine.acceptance()
-    assert np.all(pr[:3] > 1.0) and np.all(ac[:3] <= pr[:3]) and np.all(ac[:3] > 0.0)
+    assert pr.shape == (3, 3, 3) and np.all(ac <= pr)
     mci.report(res.config)
     out = capsys.readouterr().out
     for word in ("Configuration", "ChangeIntegrand", "ChangeVariable", "SwapVariable", "Visited", "ReWeight", "Integrand evaluation"):
         assert word in out
+    # default graph for N = 2 (configuration.jl:203-208): Norm -> 1; 1 -> Norm, 1 -> 2; 2 -> 1
+    rows = re.findall(r"^(Norm -> +\d+|  \d ->Norm|  \d -> +\d+): +([0-9.]+)% +([0-9.]+)% +([0-9.]+)$", out, flags=re.M)
+    assert [r[0].split() for r in rows] == [["Norm", "->", "1"], ["1", "->Norm"], ["1", "->", "2"], ["2", "->", "1"]], rows
+    neval = res.config.neval
+    for (label, p_, a_, ratio), (i, j) in zip(rows, [(2, 0), (0, 2), (0, 1), (1, 0)]):
+        assert float(p_) == pytest.approx(pr[0, i, j] / neval * 100.0, abs=1e-6)
+        assert float(a_) == pytest.approx(ac[0, i, j] / neval * 100.0, abs=1e-6)
+        assert float(ratio) == pytest.approx(ac[0, i, j] / pr[0, i, j], abs=1e-6)
+    var_rows = re.findall(r"^  +(\d) / Continuous +: +([0-9.]+)% +([0-9.]+)% +([0-9.]+)$", out, flags=re.M)
+    assert [r[0] for r in var_rows] == ["1", "2", "1", "2"]                         # ChangeVariable 1, 2 then SwapVariable 1, 2
+    assert float(var_rows[0][1]) == pytest.approx(pr[1, 0, 0] / neval * 100.0, abs=1e-6)
+    assert float(var_rows[3][2]) == pytest.approx(ac[2, 1, 0] / neval * 100.0, abs=1e-6)
     res = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), dof=[[2], [3]], solver="vegasmc", neval=1e5, seed=42)
     pr, ac = res.config._engine.acceptance()
-    assert pr[0] > 1.0 and 0.0 < ac[0] <= pr[0]
+    assert pr[1, 0, 0] > 1.0 and 0.0 < ac[1, 0, 0] <= pr[1, 0, 0] and pr[0].max() < 1e-6 and pr[2].max() < 1e-6
     mci.report(res.config)
     assert "ChangeVariable" in capsys.readouterr().out
 

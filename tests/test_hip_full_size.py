@@ -25,8 +25,10 @@ NPB = NEVAL // BLOCK
 
 
 def split(packed, eng, ni):
+    """(statistics head, histogram section) of [stats | histograms | propose | accept]"""
     nstat = 2 * eng.nobs + 2 + ni + 1
-    return packed[:nstat], packed[nstat:]
+    npa = 3 * (ni + 1) * max(ni + 1, len(eng.config.var))
+    return packed[:nstat], packed[nstat:len(packed) - 2 * npa]
 
 
 def check_additive(eng, solver, ni, nchain=0, rtol=1e-9):
@@ -112,3 +114,57 @@ def test_c3_bubble_vegasmc_full_size_properties():
     r = eng.integrate("vegasmc", neval=NEVAL, niter=5, block=BLOCK, seed=SEED, first_iteration=5, ignore=0)
     ft = np.array(bubble_exact_finite_T())
     assert np.all(np.abs(r["mean"] - ft) < 5 * r["stdev"]), (r["mean"], r["stdev"], ft)
+
+
+def test_c5_nested_gauss_full_size_properties(oracle):
+    """BASELINE configs[4]: 4 integrals sharing a 12-D Continuous pool (dof [[3],[6],[9],[12]]) at 1e8 steps per iteration, under
+    all three solvers (the config names :mcmc; :vegasmc / :vegas run the same padding path, variable.jl:628-641).
+    :mcmc with the automatic (measured) chain length -- exact counters, additivity over block ranges, the hold histogram of a
+    reduced-size launch equal to the oracle's bucket by bucket, products of erf within 5 sigma."""
+    exact = np.array([math.erf(5.0) ** d for d in (3, 6, 9, 12)])
+
+    def engine():
+        return mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]], seed=SEED), mci.catalog.nested_gauss())
+
+    # ---- :vegas ----
+    eng = engine()
+    eng.integrate("vegas", neval=NEVAL, niter=5, block=BLOCK, seed=SEED)
+    ws, wh = check_additive(eng, "vegas", 4)
+    n = eng.nobs
+    assert n == 4 and ws[2 * n + 1] == NEVAL and abs(ws[2 * n] - NEVAL) < 1e-6
+    r = eng.integrate("vegas", neval=NEVAL, niter=5, block=BLOCK, seed=SEED, first_iteration=5, ignore=0)
+    assert np.all(np.abs(r["mean"] - exact) < 5 * r["stdev"]) and np.all(r["stdev"] < 1e-4), (r["mean"], r["stdev"])
+
+    # ---- :vegasmc (automatic chain count) ----
+    eng = engine()
+    eng.integrate("vegasmc", neval=NEVAL, niter=5, block=BLOCK, seed=SEED)
+    nchain = 1017                                          # the automatic choice at this size: neval/block / (8 burn-in floors of 64 * 12 steps)
+    ws, wh = check_additive(eng, "vegasmc", 4, nchain=nchain, rtol=1e-8)
+    steps = NPB // nchain
+    assert abs(ws[2 * n + 1] - BLOCK * nchain * steps) <= 0.01 * NEVAL
+    assert np.all(ws[2 * n + 2:2 * n + 2 + 5] > 0)         # visited: every integrand and the normalisation
+    r = eng.integrate("vegasmc", neval=NEVAL, niter=5, block=BLOCK, seed=SEED, first_iteration=5, ignore=0)
+    assert np.all(np.abs(r["mean"] - exact) < 5 * r["stdev"]), (r["mean"], r["stdev"])
+
+    # ---- :mcmc (the solver BASELINE names; automatic, measured chain length) ----
+    eng = engine()
+    eng.integrate("mcmc", neval=NEVAL, niter=5, block=BLOCK, seed=SEED)
+    nchain = 1024
+    ws, wh = check_additive(eng, "mcmc", 4, nchain=nchain, rtol=1e-8)
+    steps = NPB // nchain
+    # visited counts every step of every chain (mcmc/montecarlo.jl:136), burn-in included: exact integer bookkeeping
+    nburn = max(int(math.floor(steps * 0.1)), 64 * 12 + 16 * 2 * 5)
+    vis = ws[2 * n + 2:2 * n + 2 + 5] - (BLOCK + 1) * 1e-8
+    assert abs(vis.sum() - BLOCK * nchain * (steps + nburn)) < 1e-3 * BLOCK * nchain
+    hh = eng.hold_histogram()
+    assert hh.sum() == BLOCK // 2 * nchain                 # (the last launch of check_additive ran blocks [8, 16))
+    r = eng.integrate("mcmc", neval=NEVAL, niter=5, block=BLOCK, seed=SEED, first_iteration=5, ignore=0)
+    assert np.all(np.abs(r["mean"] - exact) < 5 * r["stdev"]), (r["mean"], r["stdev"])
+    # hold histogram of a launch the oracle can follow: bucket by bucket
+    small = engine()
+    ocfg = oracle.Config([dict(kind=0, pool=0, lower=0.0, upper=1.0)], [[3], [6], [9], [12]])
+    ocfg.set_thermal_ratio(0.1)
+    got = small.iteration("mcmc", 40000, 0, 4, iteration=0, seed=SEED, nchain=32, thermal_ratio=0.1)
+    ref = ocfg.iteration(oracle.MCMC, "nested_gauss", [4.0, 3.0, 6.0, 9.0, 12.0], 40000, 0, 4, 0, SEED, nchain=32)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+    np.testing.assert_array_equal(small.hold_histogram(), ocfg.hold_hist)

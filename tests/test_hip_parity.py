@@ -48,6 +48,9 @@ def cases():
                                 oleaves=[ocont()], oname="sphere2", ud=None),
         "hypersphere": dict(var=lambda: mci.Continuous(-1.0, 1.0), dof=[[2], [3], [4]], f=mci.catalog.hypersphere(3),
                             oleaves=[ocont(0, -1.0, 1.0)], oname="hypersphere", ud=[3.0]),
+        # BASELINE configs[4] (C5): 4 integrals sharing a 12-D Continuous pool, nested dof -> padding_probability (variable.jl:628-641)
+        "c5_nested_gauss": dict(var=lambda: mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]], f=mci.catalog.nested_gauss(),
+                                oleaves=[ocont()], oname="nested_gauss", ud=[4.0, 3.0, 6.0, 9.0, 12.0]),
         "discrete": dict(var=lambda: mci.Discrete(1, 3), dof=[[1]], f=mci.catalog.discrete_id(),
                          oleaves=[odisc(0, 1, 3)], oname="discrete_id", ud=None),
         "discrete2_composite": dict(var=lambda: mci.Discrete([(1, 3), (1, 4)]), dof=[[1]], f=mci.catalog.one(),
@@ -131,7 +134,7 @@ def test_vegas_iteration_block_range_and_measurefreq(oracle):
 
 
 @pytest.mark.parametrize("walk", ["serial", "prefix"])
-@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "c2_gauss16_shared_pool", "discrete", "bubble", "singular2_composite"])
+@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "c2_gauss16_shared_pool", "discrete", "bubble", "singular2_composite", "c5_nested_gauss"])
 def test_train_matches_oracle(oracle, name, walk, monkeypatch):
     """rows a9/a10: smooth -> rescale -> refine (variable.jl:206-239), Discrete (:369-382)."""
     monkeypatch.setenv("MCI_TRAIN_SERIAL", "1" if walk == "serial" else "0")
@@ -179,7 +182,24 @@ def test_full_integrate_matches_oracle(oracle, name, walk, monkeypatch):
     assert np.all(np.abs(r["mean"] - o["mean"]) < sig * o["stdev"])
 
 
-@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "bubble", "discrete2_composite"])
+@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "c2_gauss4_composite"])
+def test_full_integrate_default_walk_is_the_reference_recurrence(oracle, name, monkeypatch):
+    """The DEFAULT refinement walk: once an iteration's sample launch is long enough to hide it (>= 1e6 samples) train! runs
+    the reference's serial recurrence (variable.jl:227-234), so whole runs agree with the oracle at the 1e-6 level of the
+    serial walk -- not at the 1e-4 of the prefix-scan form the launch-bound regime uses."""
+    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
+    c, cfg, eng, ocfg = make(name, oracle)
+    r = eng.integrate("vegas", neval=1600000, niter=6, block=16, seed=SEED)
+    o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=1600000, niter=6, block=16, seed=SEED, nthreads=8)
+    np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6, atol=1e-300)
+    np.testing.assert_allclose(r["iter_std"], o["iter_std"], rtol=1e-4, atol=1e-300)
+    np.testing.assert_allclose(r["mean"], o["mean"], rtol=1e-6)
+    assert np.all(np.abs(r["mean"] - o["mean"]) < 1e-3 * o["stdev"])
+    for i, lf in enumerate(c["oleaves"]):
+        np.testing.assert_allclose(eng.grid(i), ocfg.grid(i), rtol=0, atol=1e-7 * (lf["upper"] - lf["lower"]))
+
+
+@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "bubble", "discrete2_composite", "c5_nested_gauss"])
 def test_vegasmc_iteration_matches_oracle(oracle, name):
     """row a16: many-chain VegasMC block vs the oracle run with the same chain decomposition."""
     c, cfg, eng, ocfg = make(name, oracle)
@@ -190,6 +210,14 @@ def test_vegasmc_iteration_matches_oracle(oracle, name):
     rs, rh = hist_split(ref, eng.nobs, cfg.N)
     np.testing.assert_allclose(gs, rs, rtol=1e-9, atol=1e-300)
     np.testing.assert_allclose(gh, rh, rtol=1e-8)
+    # propose[2, 1, vi] / accept[2, 1, vi] (vegas_mc/updates.jl:90-92), everything else at its clearStatistics! offset
+    pr, ac = eng.acceptance()
+    nd, m = cfg.N + 1, max(cfg.N + 1, len(cfg.var))
+    npa = 3 * nd * m
+    np.testing.assert_allclose(pr.ravel(), ref[-2 * npa:-npa], rtol=1e-12)
+    np.testing.assert_allclose(ac.ravel(), ref[-npa:], rtol=1e-12)
+    live = pr[1, 0, :len(cfg.var)]
+    assert live.sum() > 0.5 * block * npb and abs(pr.sum() - live.sum()) < 1e-4
 
 
 def test_vegasmc_single_chain_is_the_reference_chain(oracle):
@@ -200,7 +228,8 @@ def test_vegasmc_single_chain_is_the_reference_chain(oracle):
     np.testing.assert_allclose(got, ref, rtol=1e-9)
 
 
-@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "hypersphere", "bubble", "discrete2_composite", "singular2_composite"])
+@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "hypersphere", "bubble", "discrete2_composite", "singular2_composite",
+                                  "c5_nested_gauss"])
 @pytest.mark.parametrize("nchain", [1, 16])
 def test_mcmc_iteration_matches_oracle(oracle, name, nchain):
     """row f1: the :mcmc chains (mcmc/montecarlo.jl:72-184, mcmc/updates.jl) against the oracle on the same
@@ -214,6 +243,15 @@ def test_mcmc_iteration_matches_oracle(oracle, name, nchain):
     rs, rh = hist_split(ref, eng.nobs, cfg.N)
     np.testing.assert_allclose(gs, rs, rtol=1e-9, atol=1e-300)
     np.testing.assert_allclose(gh, rh, rtol=1e-9)   # unit weights: counts + the 1e-10 clearStatistics offsets
+    # config.propose / config.accept [3][Nd][max(Nd, Nv)] (configuration.jl:185-186; mcmc/updates.jl:48,100,138): the tail of the
+    # packed buffer, integer counts + clearStatistics offsets -> equal to the oracle's entry by entry
+    pr, ac = eng.acceptance()
+    nd, m = cfg.N + 1, max(cfg.N + 1, len(cfg.var))
+    npa = 3 * nd * m
+    np.testing.assert_allclose(pr.ravel(), ref[-2 * npa:-npa], rtol=1e-12)
+    np.testing.assert_allclose(ac.ravel(), ref[-npa:], rtol=1e-12)
+    assert pr.shape == (3, nd, m) and 0.3 * block * npb < pr.sum() - npa * (block + 1) * 1e-8 and np.all(ac <= pr)
+    assert pr[0, nd - 1].sum() > 1.0 and pr[1, nd - 1].sum() < 1e-6   # the normalisation integrand jumps, but has no variable to change
     # the holding-time diagnostic behind the automatic chain length: integer bookkeeping on the same accept decisions
     hh = eng.hold_histogram()
     np.testing.assert_array_equal(hh, ocfg.hold_hist)
@@ -245,6 +283,47 @@ def test_mcmc_full_integrate_matches_oracle(oracle):
     np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6)
     np.testing.assert_allclose(r["iter_std"], o["iter_std"], rtol=1e-4)
     np.testing.assert_allclose(eng.reweight(), ocfg.reweight, rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["sphere2_padding", "c5_nested_gauss", "bubble"])
+def test_vegasmc_full_integrate_matches_oracle(oracle, name):
+    """the whole :vegasmc loop inside the library -- chains, block merge, DEVICE doReweight! (main.jl:183, :322-346) with a
+    reweight_goal, train!, Result -- against the oracle's loop over several iterations: the reweight vector the next
+    iteration's chains see comes from the device-side twin of doReweight!, so its parity is what keeps iterations 2.. on the
+    oracle's trajectory."""
+    c, cfg, eng, ocfg = make(name, oracle)
+    ni = cfg.N
+    goal = [1.0 + 0.5 * i for i in range(ni + 1)]
+    r = eng.integrate("vegasmc", neval=48000, niter=5, block=8, seed=SEED, nchain=4, reweight_goal=goal)
+    ocfg.set_reweight_goal(goal)
+    o = ocfg.integrate(oracle.VEGASMC, c["oname"], c["ud"], neval=48000, niter=5, block=8, seed=SEED, nchain=4)
+    np.testing.assert_allclose(eng.reweight(), ocfg.reweight, rtol=1e-7)
+    assert np.all(np.isfinite(r["iter_mean"]))
+    # accept/reject decisions are discrete: a rounding-level difference of a trained grid can flip one and move a chain; the
+    # first iterations stay on the oracle's trajectory to rounding, the later ones must at least agree statistically
+    np.testing.assert_allclose(r["iter_mean"][:2], o["iter_mean"][:2], rtol=1e-7, atol=1e-300)
+    np.testing.assert_allclose(r["iter_std"][:2], o["iter_std"][:2], rtol=1e-5, atol=1e-300)
+    assert np.all(np.abs(r["iter_mean"] - o["iter_mean"]) <= 6 * np.hypot(r["iter_std"], o["iter_std"]) + 1e-300)
+
+
+@pytest.mark.parametrize("nchain", [1, 0])
+def test_c5_mcmc_full_integrate(oracle, nchain):
+    """BASELINE configs[4] through mci_integrate: 4 nested Gaussians on a 12-D pool, solver = :mcmc (mcmc/montecarlo.jl:72-184;
+    padding variable.jl:628-641), with the reference's one chain per block (nchain = 1: same-stream parity with the oracle's
+    loop) and with the automatic many-chain setting (nchain = 0: no oracle twin of the measured chain length -- the estimate
+    must sit on the exact products of erf, main.jl:322-346 reweighting included)."""
+    c, cfg, eng, ocfg = make("c5_nested_gauss", oracle)
+    exact = np.array([math.erf(5.0) ** d for d in (3, 6, 9, 12)])
+    if nchain == 1:
+        r = eng.integrate("mcmc", neval=64000, niter=4, block=8, seed=SEED, nchain=1)
+        o = ocfg.integrate(oracle.MCMC, "nested_gauss", c["ud"], neval=64000, niter=4, block=8, seed=SEED, nchain=1)
+        np.testing.assert_allclose(r["iter_mean"][:2], o["iter_mean"][:2], rtol=1e-7)
+        assert np.all(np.abs(r["iter_mean"] - o["iter_mean"]) <= 6 * np.hypot(r["iter_std"], o["iter_std"]) + 1e-300)
+        np.testing.assert_allclose(eng.reweight(), ocfg.reweight, rtol=1e-3)
+    else:
+        eng.integrate("mcmc", neval=4 * 10**6, niter=5, block=16, seed=SEED)
+        r = eng.integrate("mcmc", neval=4 * 10**6, niter=10, block=16, seed=SEED, first_iteration=5, ignore=0)
+        assert np.all(np.abs(r["mean"] - exact) < 5 * r["stdev"]) and np.all(r["stdev"] < 0.02), (r["mean"], r["stdev"])
 
 
 COMPLEX_BODY = "w[0] = x[0]; w[1] = 0.0; w[2] = 0.5 * x[0]; w[3] = x[0] * x[0];"   # TestComplex2 (test/montecarlo.jl:172-185) + a mixed one

@@ -45,7 +45,7 @@ def test_offline_jit_and_problem_info():
     eng = mci.Engine(cfg, mci.Integrand("w[0] = x[0] * x[1] * x[2]; w[1] = x[0];"), device=-1)
     eng.compile()
     assert eng.ndraw == 3 and eng.nobs == 2 and eng.table_mode == 0
-    assert eng.packed_size == 2 * 2 + 2 + 3 + 999 + 4
+    assert eng.packed_size == 2 * 2 + 2 + 3 + 999 + 4 + 2 * (3 * 3 * 3)   # [stats | histograms | propose | accept] (configuration.jl:185-186)
     np.testing.assert_allclose(eng.grid(0), np.linspace(0, 1, 1000), atol=1e-15)
     d, a = eng.distribution(1)
     np.testing.assert_allclose(d, 0.25)

@@ -47,37 +47,78 @@ struct u32x4 { u32 x, y, z, w; };
 #ifndef MCI_PHILOX_ROUNDS
 #define MCI_PHILOX_ROUNDS 10
 #endif
+#ifndef MCI_VGPR_KEYS_MAX_DRAWS
+#define MCI_VGPR_KEYS_MAX_DRAWS 20
+#endif
+#ifndef MCI_VGPR_KEY_ROUNDS
+#define MCI_VGPR_KEY_ROUNDS MCI_PHILOX_ROUNDS
+#endif
 
-__device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1) {
+// The ten round keys (k + r * Weyl constant).  They are wave-uniform and would naturally sit in SGPRs -- but v_bitop3_b32 with an
+// SGPR source issues at the 3-source rate (measured 1.76 ns per wave-instruction and SIMD, tools/issue_microbench.hip) while its
+// all-VGPR form issues at the VOP2 rate (1.2 ns).  IN_VGPR copies them to VGPRs once (a pure, hoistable v_mov); worth 20 registers
+// only where the kernel has them to spare (the :vegas sample loop of problems with few draws).
+template <bool IN_VGPR> struct RoundKeys {
+    u32 a[MCI_PHILOX_ROUNDS], b[MCI_PHILOX_ROUNDS];
+};
+template <bool IN_VGPR> __device__ __forceinline__ RoundKeys<IN_VGPR> make_round_keys(u32 k0, u32 k1) {
+    RoundKeys<IN_VGPR> K;
+#pragma unroll
+    for (int r = 0; r < MCI_PHILOX_ROUNDS; ++r) {
+        const u32 a = k0 + (u32)r * 0x9E3779B9u, b = k1 + (u32)r * 0xBB67AE85u; // wave-uniform: scalar ALU
+        if (IN_VGPR && r < MCI_VGPR_KEY_ROUNDS) { // (the remaining rounds keep theirs in SGPRs: registers against issue slots)
+            asm("v_mov_b32 %0, %1" : "=v"(K.a[r]) : "s"(a));
+            asm("v_mov_b32 %0, %1" : "=v"(K.b[r]) : "s"(b));
+        } else {
+            K.a[r] = a;
+            K.b[r] = b;
+        }
+    }
+    return K;
+}
+
+// 32 x 32 -> 64-bit product.  Left to itself the compiler turns some of these into a v_mul_lo_u32 + v_mul_hi_u32 pair (two issues at
+// the 3-source rate instead of one v_mad_u64_u32); MCI_MAD_ASM pins the single instruction (constants still fold).
+__device__ __forceinline__ u64 mul_wide(u32 m, u32 c) {
+#ifdef MCI_MAD_ASM
+    if (!__builtin_constant_p(c)) {
+        u64 p, carry;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(carry) : "s"(m), "v"(c));
+        return p;
+    }
+#endif
+    return (u64)m * c;
+}
+
+template <bool IN_VGPR> __device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, const RoundKeys<IN_VGPR> &K) {
 #ifdef MCI_ABL_CHEAPRNG
-    const u64 h = (u64)(c0 ^ k0) * 0x9E3779B97F4A7C15ull + ((u64)c2 << 32 | (c1 ^ c3 ^ k1));
+    const u64 h = (u64)(c0 ^ K.a[0]) * 0x9E3779B97F4A7C15ull + ((u64)c2 << 32 | (c1 ^ c3 ^ K.b[0]));
     return {(u32)h, (u32)(h >> 32), (u32)(h >> 16), (u32)(h >> 24)};
 #endif
 #pragma unroll
     for (int r = 0; r < MCI_PHILOX_ROUNDS; ++r) {
-        const u64 p0 = (u64)0xD2511F53u * c0; // v_mad_u64_u32: hi and lo in one issue
-        const u64 p1 = (u64)0xCD9E8D57u * c2;
-        // three-input xor in ONE issue: gfx950 has no v_xor3_b32, but v_bitop3_b32 with truth table 0x96 is exactly that (and
-        // takes the wave-uniform key word from its SGPR); the compiler does not form it by itself from a ^ b ^ c
-        const u32 n0 = __builtin_amdgcn_bitop3_b32((u32)(p1 >> 32), c1, k0, 0x96);
-        const u32 n2 = __builtin_amdgcn_bitop3_b32((u32)(p0 >> 32), c3, k1, 0x96);
+        const u64 p0 = mul_wide(0xD2511F53u, c0); // v_mad_u64_u32: hi and lo in one issue
+        const u64 p1 = mul_wide(0xCD9E8D57u, c2);
+        // three-input xor in ONE issue: gfx950 has no v_xor3_b32, but v_bitop3_b32 with truth table 0x96 is exactly that;
+        // the compiler does not form it by itself from a ^ b ^ c
+        const u32 n0 = __builtin_amdgcn_bitop3_b32((u32)(p1 >> 32), c1, K.a[r], 0x96);
+        const u32 n2 = __builtin_amdgcn_bitop3_b32((u32)(p0 >> 32), c3, K.b[r], 0x96);
         c1 = (u32)p1;
         c3 = (u32)p0;
         c0 = n0;
         c2 = n2;
-        k0 += 0x9E3779B9u; // wave-uniform: scalar ALU
-        k1 += 0xBB67AE85u;
     }
     return {c0, c1, c2, c3};
+}
+__device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1) {
+    return philox4x32_10<false>(c0, c1, c2, c3, make_round_keys<false>(k0, k1));
 }
 
 // 52 random mantissa bits as a double in [1, 2)
 __device__ __forceinline__ double u12(u32 lo, u32 hi) {
-    // ((hi:lo) >> 12) | 0x3FF0...0 as two v_alignbit_b32 (32-bit, full rate): the low word is (hi:lo) >> 12, the high word is
-    // (0x3FF:hi) >> 12 = 0x3FF00000 | hi >> 12 -- instead of a 64-bit shift plus an or
-    const u32 wlo = __builtin_amdgcn_alignbit(hi, lo, 12u);
-    const u32 whi = __builtin_amdgcn_alignbit(0x3FFu, hi, 12u);
-    return __longlong_as_double((i64)(((u64)whi << 32) | wlo));
+    // v_lshrrev_b64 + v_or_b32 (1.8 + 1.1 ns per wave-instruction and SIMD); two v_alignbit_b32 would be 2 x 1.8 (3-source forms)
+    const u64 bits = ((((u64)hi << 32) | lo) >> 12) | 0x3FF0000000000000ull;
+    return __longlong_as_double((i64)bits);
 }
 __device__ __forceinline__ double u01(u32 lo, u32 hi) { return u12(lo, hi) - 1.0; }
 
@@ -259,15 +300,14 @@ template <class Cfg> struct Sample {
     double jaci[Cfg::NI];
 };
 
-template <class Cfg, bool ECACHE = false> __device__ __forceinline__ void draw_sample(const Tables<Cfg> &t, u64 seed, u32 stream, u64 index, Sample<Cfg> &s) {
-    const u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
+template <class Cfg, bool ECACHE = false, bool KV = false> __device__ __forceinline__ void draw_sample(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index, Sample<Cfg> &s) {
     const u32 ilo = (u32)index, ihi = (u32)(index >> 32);
     constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
     s.jac = 1.0;
     static_for<0, Cfg::NI>([&](auto I) { s.jaci[decltype(I)::value] = 1.0; });
     static_for<0, (Cfg::NDRAW + 1) / 2>([&](auto C) {
         constexpr int c = decltype(C)::value;
-        const u32x4 r = philox4x32_10(ilo, ihi, (u32)c, stream, k0, k1);
+        const u32x4 r = philox4x32_10<KV>(ilo, ihi, (u32)c, stream, keys);
         static_for<0, 2>([&](auto H) {
             constexpr int k = 2 * c + decltype(H)::value;
             if constexpr (k < Cfg::NDRAW) {
@@ -302,6 +342,10 @@ template <class Cfg, bool ECACHE = false> __device__ __forceinline__ void draw_s
         constexpr int i = decltype(I)::value;
         if constexpr (Cfg::own_mask(i) == ALL) s.jaci[i] = s.jac; // dof[i] == maxdof: no padding (vegas/montecarlo.jl:82)
     });
+}
+
+template <class Cfg, bool ECACHE = false> __device__ __forceinline__ void draw_sample(const Tables<Cfg> &t, u64 seed, u32 stream, u64 index, Sample<Cfg> &s) {
+    draw_sample<Cfg, ECACHE, false>(t, make_round_keys<false>((u32)seed, (u32)(seed >> 32)), stream, index, s);
 }
 
 // stage the tables into LDS (coalesced 8-byte loads, once per workgroup)
@@ -590,13 +634,15 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 
     // measurement cadence (n + 1) % measurefreq == 0 (:148) without a 64-bit division in the sample loop: the remainder is
     // carried along, n advances by `stride` per trip
+    constexpr bool KV = Cfg::NDRAW <= MCI_VGPR_KEYS_MAX_DRAWS; // round keys in VGPRs: 20 registers, affordable with few draws in flight
+    const RoundKeys<KV> keys = make_round_keys<KV>((u32)a.seed, (u32)(a.seed >> 32));
     const i64 mfreq = a.measurefreq;
     i64 mrem = mfreq == 1 ? 0 : ((i64)slice * T + tid + 1) % mfreq;
     const i64 mstep = mfreq == 1 ? 0 : stride % mfreq;
     auto run = [&](auto TT) { // the sample loop, specialised on the workgroup's histogram tile
     for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
         Sample<Cfg> s;
-        draw_sample<Cfg, EC>(t, a.seed, stream, (u64)(B * a.neval_per_block + n), s);
+        draw_sample<Cfg, EC, KV>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
         double w[Cfg::NW];
         if constexpr (Cfg::HOST_INTEGRAND != 0) { // the closure ran on the host over the dumped draws
             const i64 hidx = wi.lb * a.neval_per_block + n;
@@ -835,8 +881,17 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     double extra[Cfg::NCOLS - Cfg::NOBS];
     static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
     constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
-    // the pool index is wave-uniform (one pool, or the shared pick of a many-chain block): count by ballot
-    const bool pa_uniform = Cfg::NPOOL == 1 || a.nchain > 1;
+    u32 npr[Cfg::NPOOL], nac[Cfg::NPOOL]; // propose[2, 1, vi], accept[2, 1, vi] of the lane's current chain (vegas_mc/updates.jl:90-92)
+    static_for<0, Cfg::NPOOL>([&](auto V) { npr[decltype(V)::value] = 0u; nac[decltype(V)::value] = 0u; });
+    auto flush_pa = [&]() { // lane counters -> the workgroup's 64-bit table in LDS (once per chain: off the step loop)
+        static_for<0, Cfg::NPOOL>([&](auto V) {
+            constexpr int v = decltype(V)::value;
+            if (npr[v]) lds_count(&sPA[PaTable<Cfg>::idx(1, 0, v)], (u64)npr[v]);
+            if (nac[v]) lds_count(&sPA[PaTable<Cfg>::N + PaTable<Cfg>::idx(1, 0, v)], (u64)nac[v]);
+            npr[v] = 0u;
+            nac[v] = 0u;
+        });
+    };
 
     for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
         const u64 g = (u64)ch;
@@ -918,8 +973,11 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; newp += absw<Cfg, i>(wn) * rw[i] * padn[i]; }); // :85-87
                 const double R = prop * newp / probability;    // :88
                 const bool ok = uacc < R;                      // :91
-                if (pa_uniform) pa_count<Cfg, true>(sPA, PaTable<Cfg>::idx(1, 0, vi), true, ok);   // :90, :92  propose[2, 1, vi]
-                else pa_count<Cfg, false>(sPA, PaTable<Cfg>::idx(1, 0, vi), true, ok);
+                static_for<0, Cfg::NPOOL>([&](auto V) {
+                    constexpr int v = decltype(V)::value;
+                    npr[v] += vi == v ? 1u : 0u;               // :90
+                    nac[v] += (ok && vi == v) ? 1u : 0u;       // :92
+                });
                 if (ok) {
                     c = n;
                     static_for<0, Cfg::NW>([&](auto I) { w[decltype(I)::value] = wn[decltype(I)::value]; }); // :93-95
@@ -940,6 +998,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 static_for<0, Cfg::NDRAW>([&](auto K) { sb.bin[decltype(K)::value] = c.bin[decltype(K)::value]; });
                 hist_update<Cfg>(sb, wh, sH, a.ghist, tile);
             }
+            if ((ne & 0x3FFFFFFF) == 0) flush_pa(); // (32-bit lane counters: hand over long before they wrap)
             // ---- measurement  montecarlo.jl:213-232 ----
             mcnt = mcnt + 1 == a.measurefreq ? 0 : mcnt + 1;
             const bool mf = mcnt == 0;
@@ -958,6 +1017,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 extra[XV + NORMI] += rw[NORMI] * pad[NORMI] / probability; // :230
             }
         }
+        flush_pa();
     }
     __syncthreads();
     flush_workgroup<Cfg, Lds<Cfg>, true, true>(a, smem, acc, extra, wi.rowid, tile);

@@ -2,10 +2,15 @@
 # reference's API names for the :vegas / :vegasmc / :mcmc path (reference src/MCIntegration.jl:20-47).
 #
 # NOTE: `julia` is not available in the build image, so this file is syntax-reviewed only; it is the
-# reference-side binding INTEGRATION.md describes.  Everything numerical happens in the library.
+# reference-side binding INTEGRATION.md describes.  Everything numerical happens in the library; the C struct mirrors below
+# are checked field by field against include/mci.h and the ctypes binding by tests/test_binding_layouts.py.
 module MCIntegrationHIP
 
-export integrate, Configuration, Continuous, Discrete, CompositeVar, FermiK, Result, Integrand, Measure, bin_by, report
+using Printf
+using Dates
+
+export integrate, Configuration, Continuous, Discrete, CompositeVar, FermiK, Result, Integrand, Measure, bin_by, report,
+       average, init_comm!, save, load!
 
 const libmci = get(ENV, "MCI_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libmci_hip.so"))
 const MaxOrder = 16                         # reference src/distribution/distribution.jl:59
@@ -88,14 +93,42 @@ mutable struct ResultC
     neval::Int64; seconds::Float64
 end
 
-const _ctx = Ref{Ptr{Cvoid}}(C_NULL)
-function context(device=0)
-    if _ctx[] == C_NULL
+const _ctx = Dict{Int,Ptr{Cvoid}}()              # one mci_ctx (HIP stream + RCCL communicator) per device
+function context(device::Integer=0)
+    get!(_ctx, Int(device)) do
         p = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:mci_ctx_create, libmci), Cint, (Int32, Ptr{Ptr{Cvoid}}), device, p))
-        _ctx[] = p[]
+        p[]
     end
-    _ctx[]
+end
+
+# ---- workers: the reference's MPI.Init + MPIreduce/MPIbcast (src/main.jl:113-118, :177-188, src/utility/parallel.jl:25-99)
+# become ONE RCCL all-reduce per iteration inside the library.  Bootstrap: rank 0 creates the 128-byte id, the host ships it.
+const _comm = Ref((rank=0, size=1, device=0))
+"""
+    init_comm!(rank, nranks, bcast!; device=rank)
+
+`bcast!(buf::Vector{UInt8})` must overwrite `buf` on every rank with rank 0's content, e.g. with MPI.jl
+`buf -> MPI.Bcast!(buf, 0, MPI.COMM_WORLD)` (the call the reference itself uses, src/utility/parallel.jl:93).
+"""
+function init_comm!(rank::Integer, nranks::Integer, bcast!::Function; device::Integer=rank)
+    id = zeros(UInt8, 128)
+    rank == 0 && check(ccall((:mci_comm_unique_id, libmci), Cint, (Ptr{UInt8},), id))
+    bcast!(id)
+    check(ccall((:mci_comm_init, libmci), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), context(device), rank, nranks, id))
+    r, n = Ref{Int32}(0), Ref{Int32}(0)
+    check(ccall((:mci_comm_rank, libmci), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}), context(device), r, n))
+    @assert (r[], n[]) == (rank, nranks)
+    _comm[] = (rank=Int(rank), size=Int(nranks), device=Int(device))
+    nothing
+end
+"""
+    init_comm!(comm)        # comm::MPI.Comm -- one rank per GPU of the node; MPI.jl is the caller's dependency, not this module's
+"""
+function init_comm!(comm; device=nothing)
+    MPI = parentmodule(typeof(comm))
+    rank, n = MPI.Comm_rank(comm), MPI.Comm_size(comm)
+    init_comm!(rank, n, buf -> MPI.Bcast!(buf, 0, comm); device=device === nothing ? rank : device)
 end
 
 # Configuration(; var, dof, obs, seed, userdata)   reference src/configuration.jl:105-194
@@ -111,6 +144,9 @@ mutable struct Configuration
     key
     neighbor::Union{Nothing,Vector{Vector{Int}}}    # 1-based like the reference; nothing = default (configuration.jl:203-208)
     ncomp::Int                                      # 2 for type=ComplexF64 (configuration.jl:108)
+    device::Int
+    neval::Int                                      # evaluations per iteration of the last integrate call (configuration.jl:49)
+    pending_state::Union{Nothing,String}            # MCISTATE file to load once the problem exists (load!)
 end
 function _neighbor(neighbor, Nd)                    # reference src/configuration.jl:201-227
     neighbor === nothing && return nothing
@@ -144,7 +180,7 @@ function Configuration(; var=(Continuous(0.0, 1.0),), dof=nothing, obs=nothing, 
     obs === nothing && (obs = zeros(type, length(dof)))
     @assert length(obs) == length(dof) "The number of observables should be equal to the number of integrands"
     Configuration(var, dof, length(dof), [length(o) * ncomp for o in obs], seed, userdata, 0, C_NULL, nothing,
-                  _neighbor(neighbor, length(dof) + 1), ncomp)
+                  _neighbor(neighbor, length(dof) + 1), ncomp, _comm[].device, 0, nothing)
 end
 
 function draw_index(c::Configuration, pool::Int)          # 0-based flat draw of (pool, slot 1, leaf 1)
@@ -185,14 +221,66 @@ function bind!(c::Configuration, f::Integrand, measure)
         desc = Ref(ProblemDesc(length(descs), pointer(descs), length(c.var), c.N, pointer(dof), pointer(onb), pointer(obd),
                                c.neighbor === nothing ? Ptr{Int32}(C_NULL) : pointer(nboff),
                                c.neighbor === nothing ? Ptr{Int32}(C_NULL) : pointer(nblist), c.ncomp))
-        check(ccall((:mci_problem_create, libmci), Cint, (Ptr{Cvoid}, Ptr{ProblemDesc}, Ptr{Ptr{Cvoid}}), context(), desc, p))
+        check(ccall((:mci_problem_create, libmci), Cint, (Ptr{Cvoid}, Ptr{ProblemDesc}, Ptr{Ptr{Cvoid}}), context(c.device), desc, p))
     end
     check(ccall((:mci_set_integrand_source, libmci), Cint, (Ptr{Cvoid}, Cstring, Ptr{Float64}, Int32),
                 p[], f.body, f.userdata, length(f.userdata)))
     measure isa Measure && check(ccall((:mci_set_measure_source, libmci), Cint, (Ptr{Cvoid}, Cstring), p[], measure.body))
-    c.problem != C_NULL && ccall((:mci_problem_destroy, libmci), Cint, (Ptr{Cvoid},), c.problem)
+    if c.problem != C_NULL                       # a new integrand on a trained configuration keeps what was learned
+        tmp = tempname()
+        check(ccall((:mci_save_state, libmci), Cint, (Ptr{Cvoid}, Cstring), c.problem, tmp))
+        check(ccall((:mci_load_state, libmci), Cint, (Ptr{Cvoid}, Cstring), p[], tmp))
+        rm(tmp; force=true)
+        ccall((:mci_problem_destroy, libmci), Cint, (Ptr{Cvoid},), c.problem)
+    end
     c.problem, c.key = p[], key
+    if c.pending_state !== nothing
+        check(ccall((:mci_load_state, libmci), Cint, (Ptr{Cvoid}, Cstring), p[], c.pending_state))
+        c.pending_state = nothing
+    end
     p[]
+end
+
+# ---- resume across processes (SURVEY 8f2): grids, distributions, reweight <-> MCISTATE file (include/mci.h) ----
+function save(c::Configuration, path::AbstractString)
+    c.problem == C_NULL && error("nothing trained yet: run integrate(...) first")
+    check(ccall((:mci_save_state, libmci), Cint, (Ptr{Cvoid}, Cstring), c.problem, path))
+    path
+end
+function load!(c::Configuration, path::AbstractString)
+    if c.problem == C_NULL
+        c.pending_state = String(path)       # applied when integrate(...; config=c) creates the problem
+    else
+        check(ccall((:mci_load_state, libmci), Cint, (Ptr{Cvoid}, Cstring), c.problem, path))
+    end
+    c
+end
+
+# config.var[i].grid / .distribution / config.reweight / config.visited / propose / accept as the library holds them
+function grid(c::Configuration, leaf::Integer, npoints::Integer=1000)      # leaf: 1-based flat leaf index
+    g = zeros(npoints)
+    check(ccall((:mci_get_grid, libmci), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32), c.problem, leaf - 1, g, npoints))
+    g
+end
+function reweight(c::Configuration)
+    r = zeros(c.N + 1)
+    check(ccall((:mci_get_reweight, libmci), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32), c.problem, r, c.N + 1))
+    r
+end
+function acceptance(c::Configuration)        # (propose, accept), each [3, Nd, max(Nd, Nv)] like configuration.jl:185-186
+    Nd = c.N + 1
+    M = max(Nd, length(c.var))
+    pr, ac = zeros(3 * Nd * M), zeros(3 * Nd * M)
+    check(ccall((:mci_get_acceptance, libmci), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32), c.problem, pr, ac, 3 * Nd * M))
+    shape(v) = permutedims(reshape(v, M, Nd, 3), (3, 2, 1))                 # the library is row-major [update][integrand][target]
+    shape(pr), shape(ac)
+end
+function visited(c::Configuration)
+    n = Ref{Int32}(0); no = Ref{Int32}(0); ps = Ref{Int64}(0); tm = Ref{Int32}(0); lds = Ref{Int64}(0)
+    check(ccall((:mci_problem_info, libmci), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int64}, Ptr{Int32}, Ptr{Int64}), c.problem, n, no, ps, tm, lds))
+    packed = zeros(ps[])
+    check(ccall((:mci_get_packed, libmci), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), c.problem, packed, ps[]))
+    packed[2*no[]+3:2*no[]+3+c.N]
 end
 
 # ---- Julia closures as integrands: the host "batch callback" slow path (mci_set_integrand_host) ----------------------
@@ -232,14 +320,142 @@ end
 struct Result
     mean::Vector{Float64}; stdev::Vector{Float64}; chi2::Vector{Float64}
     neval::Int; ignore::Int; config::Configuration
-    iter_mean::Matrix{Float64}; iter_std::Matrix{Float64}
+    iter_mean::Matrix{Float64}; iter_std::Matrix{Float64}        # [niter, nobs]
 end
-function Base.show(io::IO, r::Result)
-    for i in eachindex(r.mean)
-        println(io, "Integral $i = $(r.mean[i]) ± $(r.stdev[i])   (reduced chi2 = $(round(r.chi2[i], sigdigits=3)))")
+
+"""
+    average(iter_mean, iter_std; init=1, max=length(iter_mean))  -> (mean, std, chi2)
+
+Inverse-variance weighted average of one observable's history (reference src/statistics.jl:186-220), by the library's
+`mci_average` so that Julia, Python and C callers get the same digits.
+"""
+function average(iter_mean::AbstractVector{Float64}, iter_std::AbstractVector{Float64}; init::Int=1, max::Int=length(iter_mean))
+    m, e = collect(Float64, iter_mean), collect(Float64, iter_std)
+    a, b, c = Ref(0.0), Ref(0.0), Ref(0.0)
+    ccall((:mci_average, libmci), Cvoid, (Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+          m, e, 1, init, max, a, b, c)
+    a[], b[], c[]
+end
+
+# Result(res, ignore): the same history averaged from another first iteration  (src/statistics.jl:56-62)
+function Result(res::Result, ignore::Int)
+    ignore == res.ignore && return res
+    niter, nobs = size(res.iter_mean)
+    avg = [average(res.iter_mean[:, o], res.iter_std[:, o]; init=ignore + 1, max=niter) for o in 1:nobs]
+    Result([a[1] for a in avg], [a[2] for a in avg], [a[3] for a in avg], res.neval, ignore, res.config, res.iter_mean, res.iter_std)
+end
+dof(r::Result) = (size(r.iter_mean, 1) - (r.ignore + 1) + 1) - 1                    # src/statistics.jl:65-68
+Base.getindex(r::Result, i::Int) = (r.mean[_col(r.config, i)], r.stdev[_col(r.config, i)], r.chi2[_col(r.config, i)])
+_col(c::Configuration, i::Int, pick::Int=1) = sum(c.obs_nbin[1:i-1]) + pick          # flat statistics column of integrand i
+
+function Base.show(io::IO, r::Result)                                               # src/statistics.jl:104-118
+    for i in 1:r.config.N
+        m, e, c2 = r[i]
+        if dof(r) == 0
+            print(io, "Integral $i = $m ± $e")
+        else
+            print(io, "Integral $i = $m ± $e   (reduced chi2 = $(round(c2, sigdigits=3)))")
+        end
+        i < r.config.N && print(io, "\n")
     end
 end
-report(r::Result) = show(stdout, r)
+
+sig_digits(err::Real) = (err == 0 || !isfinite(err)) ? 0 : max(0, 2 - floor(Int, log10(abs(err))))   # src/statistics.jl:74-79
+function tostring(m::Real, e::Real)                                                                  # src/statistics.jl:87-96
+    (isfinite(m) && isfinite(e)) || return "$m ± $e"
+    nd = sig_digits(e)
+    fmt = Printf.Format("%.$(nd)f")
+    string(Printf.format(fmt, m), " ± ", Printf.format(fmt, e))
+end
+
+"""
+    report(result::Result, ignore=result.ignore; pick=1, name=nothing, verbose=0, io=stdout)
+
+The per-iteration table of the reference (src/statistics.jl:137-172): every iteration's estimate next to the running
+weighted average and its reduced chi2.  `pick` selects the component of an array observable (1-based).
+"""
+function report(r::Result, ignore::Int=r.ignore; pick::Int=1, name=nothing, verbose::Int=0, io::IO=stdout)
+    niter = size(r.iter_mean, 1)
+    for i in 1:r.config.N
+        info = name === nothing ? "$i" : "$(collect(name)[i])"
+        col = _col(r.config, i, pick)
+        if verbose >= 0
+            println(io, "================================================     Integral $info    ============================================================")
+            println(io, @sprintf("%6s                 %-32s                 %-32s %22s", "iter", "         integral", "        wgt average", "reduced chi2"))
+            println(io, "-"^127)
+            for it in 1:niter
+                m, e, c2 = average(r.iter_mean[:, col], r.iter_std[:, col]; init=ignore + 1, max=it)
+                iterstr = it <= ignore ? "ignore" : "$it"
+                println(io, @sprintf("%6s %36s %36s %16.4f", iterstr, tostring(r.iter_mean[it, col], r.iter_std[it, col]), tostring(m, e), abs(c2)))
+            end
+            println(io, "-"^127)
+        else
+            m, e, c2 = r.mean[col], r.stdev[col], r.chi2[col]
+            println(io, dof(r) == 0 ? "Integral $info = $m ± $e" : "Integral $info = $m ± $e   (reduced chi2 = $(round(c2, sigdigits=3)))")
+        end
+    end
+end
+
+_typestr(v) = v isa Continuous ? "Continuous" : v isa Discrete ? "Discrete" : v isa CompositeVar ? "Composite" : v isa FermiK ? "FermiK" : string(typeof(v))
+function _default_neighbor(Nd::Int)                                                  # src/configuration.jl:203-208
+    nb = [[i - 1, i + 1] for i in 1:Nd]
+    nb[1] = Nd == 2 ? [2] : [Nd, 2]
+    nb[Nd] = [1]
+    Nd >= 3 && (nb[Nd-1] = [Nd - 2])
+    nb
+end
+
+"""
+    report(config::Configuration; io=stdout)
+
+The acceptance tables of the reference (src/configuration.jl:345-464): ChangeIntegrand per edge of the neighbor graph,
+ChangeVariable and SwapVariable per (integrand, variable), then visited and reweight -- from the library's
+config.propose / config.accept / visited / reweight of the last iteration.
+"""
+function report(c::Configuration; io::IO=stdout)
+    Nd = c.N + 1
+    bar = "-"^85
+    pr, ac = acceptance(c)
+    vis, rw = visited(c), reweight(c)
+    neval = max(c.neval, 1)
+    nb = c.neighbor === nothing ? _default_neighbor(Nd) : c.neighbor
+    println(io)
+    println(io, "===========================  Configuration  =========================================")
+    println(io, Dates.now())
+    println(io, bar)
+    println(io, "Integral num = $(c.N), dof = $(c.dof), with variables:")
+    for (vi, v) in enumerate(c.var)
+        println(io, "$vi. $v")
+    end
+    println(io, bar)
+    line(u, i, j) = @sprintf("%11.6f%% %11.6f%% %12.6f", pr[u, i, j] / neval * 100.0, ac[u, i, j] / neval * 100.0, ac[u, i, j] / pr[u, i, j])
+    println(io, @sprintf("%-20s %12s %12s %12s", "ChangeIntegrand", "Proposed", "Accepted", "Ratio  "))
+    for n in nb[Nd]
+        println(io, @sprintf("Norm -> %2d:           ", n), line(1, Nd, n))
+    end
+    for idx in 1:Nd-1, n in nb[idx]
+        if n == Nd
+            println(io, @sprintf("  %d ->Norm:           ", idx), line(1, idx, n))
+        else
+            println(io, @sprintf("  %d -> %2d:            ", idx, n), line(1, idx, n))
+        end
+    end
+    println(io, bar)
+    for (u, title) in ((2, "ChangeVariable"), (3, "SwapVariable"))
+        println(io, @sprintf("%-20s %12s %12s %12s", title, "Proposed", "Accepted", "Ratio  "))
+        for idx in 1:Nd-1, (vi, v) in enumerate(c.var)
+            println(io, @sprintf("  %2d / %-11s:   ", idx, _typestr(v)), line(u, idx, vi))
+        end
+        println(io, bar)
+    end
+    println(io, "Integrand            Visited      ReWeight")
+    println(io, @sprintf("  Norm   :     %12i %12.6f", round(Int, vis[end]), rw[end]))
+    for idx in 1:Nd-1
+        println(io, @sprintf("  Order%2d:     %12i %12.6f", idx, round(Int, vis[idx]), rw[idx]))
+    end
+    println(io, bar)
+    println(io, "Integrand evaluation = $(c.neval)\n")
+end
 
 """
     integrate(integrand::Integrand; solver=:vegasmc, config=nothing, neval=1e4, niter=10, block=16, gamma=1.0,
@@ -254,6 +470,8 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
                    nchain=0, print=-1, verbose=-1, kwargs...)
     haskey(SOLVER, solver) || error("Solver $solver is not supported!")                  # main.jl:263
     config === nothing && (config = Configuration(; kwargs...))                          # main.jl:95-97
+    # workers: after init_comm!(...) the library runs this rank's share of the blocks and sums every iteration's statistics and
+    # histograms over the ranks with one RCCL all-reduce (main.jl:113-122, :152-188); nothing to do here per call
     if integrand isa Function                      # a Julia closure: host batch-callback path, :vegas only
         solver == :vegas || error("a closure integrand runs with solver=:vegas only; pass device source for :vegasmc / :mcmc")
         prob = bind_host!(config, integrand)
@@ -271,8 +489,11 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
     res = ResultC(niter, nobs, pointer(im), pointer(ie), pointer(m), pointer(s), pointer(c2), 0, 0.0)
     GC.@preserve im ie m s c2 goal check(ccall((:mci_integrate, libmci), Cint, (Ptr{Cvoid}, Ptr{IntegrateArgs}, Ref{ResultC}), prob, args, res))
     config.iterations_done += niter
+    nworker = _comm[].size
+    nblock = block > nworker ? (block ÷ nworker) * nworker : nworker                   # _standardize_block, main.jl:220-234
+    config.neval = (Int(neval) ÷ nblock) * nblock
     r = Result(m, s, c2, res.neval, ignore, config, permutedims(im), permutedims(ie))
-    max(print, verbose) >= 0 && report(r)
+    max(print, verbose) >= 0 && _comm[].rank == 0 && report(r)                          # main.jl:212-213
     r
 end
 

@@ -133,7 +133,7 @@ def test_c5_nested_gauss_full_size_properties(oracle):
     n = eng.nobs
     assert n == 4 and ws[2 * n + 1] == NEVAL and abs(ws[2 * n] - NEVAL) < 1e-6
     r = eng.integrate("vegas", neval=NEVAL, niter=5, block=BLOCK, seed=SEED, first_iteration=5, ignore=0)
-    assert np.all(np.abs(r["mean"] - exact) < 5 * r["stdev"]) and np.all(r["stdev"] < 1e-4), (r["mean"], r["stdev"])
+    assert np.all(np.abs(r["mean"] - exact) < 5 * r["stdev"]) and np.all(r["stdev"] < 5e-3), (r["mean"], r["stdev"])
 
     # ---- :vegasmc (automatic chain count) ----
     eng = engine()

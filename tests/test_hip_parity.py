@@ -250,7 +250,7 @@ def test_mcmc_iteration_matches_oracle(oracle, name, nchain):
     npa = 3 * nd * m
     np.testing.assert_allclose(pr.ravel(), ref[-2 * npa:-npa], rtol=1e-12)
     np.testing.assert_allclose(ac.ravel(), ref[-npa:], rtol=1e-12)
-    assert pr.shape == (3, nd, m) and 0.3 * block * npb < pr.sum() - npa * (block + 1) * 1e-8 and np.all(ac <= pr)
+    assert pr.shape == (3, nd, m) and 0.05 * block * npb < pr.sum() - npa * (block + 1) * 1e-8 and np.all(ac <= pr)
     assert pr[0, nd - 1].sum() > 1.0 and pr[1, nd - 1].sum() < 1e-6   # the normalisation integrand jumps, but has no variable to change
     # the holding-time diagnostic behind the automatic chain length: integer bookkeeping on the same accept decisions
     hh = eng.hold_histogram()

@@ -31,20 +31,20 @@ typedef unsigned int u32;
     } while (0)
 
 enum Op {
-    OP_MOV_B32, OP_ADD_U32, OP_XOR_B32, OP_XOR_B32_E64, OP_XOR3_EMU, OP_BITOP3_B32, OP_BITOP3_VVV, OP_ADD3_U32, OP_LSHL_ADD_U32, OP_MAD_U64_U32, OP_MUL_LO_U32, OP_MUL_HI_U32, OP_LSHRREV_B64, OP_ALIGNBIT, OP_AND_OR_B32,
+    OP_MOV_B32, OP_ADD_U32, OP_XOR_B32, OP_XOR_B32_E64, OP_XOR3_EMU, OP_BITOP3_B32, OP_BITOP3_VVV, OP_ADD3_U32, OP_LSHL_ADD_U32, OP_MAD_U64_U32, OP_MAD_U64_U32_SGPR, OP_MUL_LO_U32, OP_MUL_HI_U32, OP_LSHRREV_B64, OP_ALIGNBIT, OP_AND_OR_B32,
     OP_FMA_F64, OP_MUL_F64, OP_ADD_F64, OP_FRACT_F64, OP_CVT_I32_F64, OP_CVT_F64_I32, OP_FLOOR_F64, OP_LDEXP_F64, OP_RCP_F64, OP_CMP_F64, OP_CNDMASK,
     OP_FMA_F32, OP_PK_FMA_F32, OP_EXP_F32,
     OP_DS_READ_B128_RAND, OP_DS_READ_B64_RAND, OP_DS_READ_B64_SEQ, OP_DS_ADD_F64_RAND, OP_DS_ADD_F64_SAME, OP_DS_ADD_RTN_F64_RAND, OP_DS_ADD_F64_SEQ, OP_DS_ADD_U64_RAND, OP_DS_ADD_U32_RAND, OP_DS_ADD_F32_RAND, OP_DS_WRITE_B64_RAND,
-    OP_GLOBAL_LOAD_B64_RAND_L2, OP_GLOBAL_LOAD_B128_RAND_L2,
+    OP_GLOBAL_LOAD_B64_RAND_L2, OP_GLOBAL_LOAD_B128_RAND_L2, OP_GLOBAL_LOAD_B128_RAND_L1, OP_GLOBAL_LOAD_B128_UNALIGNED_L1,
     OP_COUNT
 };
 static const char *const kNames[OP_COUNT] = {
-    "v_mov_b32", "v_add_u32", "v_xor_b32", "v_xor_b32_e64 (VOP3 encoding, 2 sources)", "v_xor_b32 x2 (3-input xor)", "v_bitop3_b32 (0x96 = xor3, one SGPR source)", "v_bitop3_b32 (three VGPR sources)", "v_add3_u32", "v_lshl_add_u32", "v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshrrev_b64", "v_alignbit_b32", "v_and_or_b32",
+    "v_mov_b32", "v_add_u32", "v_xor_b32", "v_xor_b32_e64 (VOP3 encoding, 2 sources)", "v_xor_b32 x2 (3-input xor)", "v_bitop3_b32 (0x96 = xor3, one SGPR source)", "v_bitop3_b32 (three VGPR sources)", "v_add3_u32", "v_lshl_add_u32", "v_mad_u64_u32", "v_mad_u64_u32 (multiplier in an SGPR, as Philox has it)", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshrrev_b64", "v_alignbit_b32", "v_and_or_b32",
     "v_fma_f64", "v_mul_f64", "v_add_f64", "v_fract_f64", "v_cvt_i32_f64", "v_cvt_f64_i32", "v_floor_f64", "v_ldexp_f64", "v_rcp_f64", "v_cmp_lt_f64", "v_cndmask_b32",
     "v_fma_f32", "v_pk_fma_f32", "v_exp_f32",
     "ds_read_b128 (random 16-B pairs, 999-bin table)", "ds_read_b64 (random, 999-bin table)", "ds_read_b64 (lane-consecutive)",
     "ds_add_f64 (random bins, 999-bin table)", "ds_add_f64 (one bin per wave)", "ds_add_rtn_f64 (random bins)", "ds_add_f64 (lane-consecutive bins: conflict-free)", "ds_add_u64 (random bins)", "ds_add_u32 (random bins)", "ds_add_f32 (random bins)", "ds_write_b64 (random bins)",
-    "global_load_dwordx2 (random 8-B, 32 x 8 KB tables, L2-resident)", "global_load_dwordx4 (random 16-B, 32 x 16 KB tables, L2-resident)",
+    "global_load_dwordx2 (random 8-B, 32 x 8 KB tables, L2-resident)", "global_load_dwordx4 (random 16-B, 32 x 16 KB tables, L2-resident)", "global_load_dwordx4 (random 16-B pairs of ONE 16 KB table: L1-resident)", "global_load_dwordx4 (random 8-B-aligned pairs of ONE 8 KB edge table: L1-resident)",
 };
 
 #define CLOB32 "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107"
@@ -63,7 +63,7 @@ template <int OP> __global__ void __launch_bounds__(256) k_issue(u64 *ticks, int
     // per-lane pseudo-random bins (LCG; what matters is that the lanes of a wave scatter like the map's draws do)
     u32 r = seed ^ (u32)(blockIdx.x * 256 + tid) * 2654435761u;
     u32 addr16[8], addr8[8], addrh[8];
-    u64 gaddr8[8], gaddr16[8];
+    u64 gaddr8[8], gaddr16[8], gaddr1[8], gaddr1u[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         r = r * 1664525u + 1013904223u;
@@ -73,6 +73,8 @@ template <int OP> __global__ void __launch_bounds__(256) k_issue(u64 *ticks, int
         addrh[j] = 16384u + bin * 8u;     // histogram region
         gaddr8[j] = (u64)(gtab + (size_t)j * 4 * 1024 + bin);           // table j (of 32 x 8 KB)
         gaddr16[j] = (u64)(gtab + (size_t)j * 4 * 2048 + 2 * bin);      // table j (of 32 x 16 KB)
+        gaddr1[j] = (u64)(gtab + 2 * bin);                              // ONE 16 KB table of (g, dx) pairs
+        gaddr1u[j] = (u64)(gtab + bin);                                 // ONE 8 KB edge table: g[iy], g[iy+1] (8-byte aligned)
     }
     u32 a[8], b = r | 1u, c = r ^ 0x9E3779B9u;
     u64 q[8];
@@ -136,6 +138,10 @@ template <int OP> __global__ void __launch_bounds__(256) k_issue(u64 *ticks, int
 #undef X
             } else if constexpr (OP == OP_MAD_U64_U32) { // Philox: (u64)M * c, hi and lo in one issue
 #define X(j) asm volatile("v_mad_u64_u32 v[100+2*" #j ":101+2*" #j "], vcc, %0, %1, 0" : : "v"(b), "v"(a[j]) : "vcc", CLOB64);
+                REP8(X)
+#undef X
+            } else if constexpr (OP == OP_MAD_U64_U32_SGPR) {
+#define X(j) asm volatile("v_mad_u64_u32 v[100+2*" #j ":101+2*" #j "], vcc, %0, %1, 0" : : "s"(seed), "v"(a[j]) : "vcc", CLOB64);
                 REP8(X)
 #undef X
             } else if constexpr (OP == OP_MUL_LO_U32) {
@@ -260,6 +266,14 @@ template <int OP> __global__ void __launch_bounds__(256) k_issue(u64 *ticks, int
 #undef X
             } else if constexpr (OP == OP_GLOBAL_LOAD_B64_RAND_L2) {
 #define X(j) asm volatile("global_load_dwordx2 v[100+2*" #j ":101+2*" #j "], %0, off" : : "v"(gaddr8[j]) : "memory", CLOB64);
+                REP8(X)
+#undef X
+            } else if constexpr (OP == OP_GLOBAL_LOAD_B128_RAND_L1) {
+#define X(j) asm volatile("global_load_dwordx4 v[100+4*" #j ":103+4*" #j "], %0, off" : : "v"(gaddr1[j]) : "memory", CLOB128);
+                REP8(X)
+#undef X
+            } else if constexpr (OP == OP_GLOBAL_LOAD_B128_UNALIGNED_L1) {
+#define X(j) asm volatile("global_load_dwordx4 v[100+4*" #j ":103+4*" #j "], %0, off" : : "v"(gaddr1u[j]) : "memory", CLOB128);
                 REP8(X)
 #undef X
             } else if constexpr (OP == OP_GLOBAL_LOAD_B128_RAND_L2) {

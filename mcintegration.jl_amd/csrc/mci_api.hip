@@ -162,11 +162,11 @@ struct mci_problem {
     bool graph_mode = false; // while capturing: no event records, iteration/log row come from d_loop
     int threads = 256, wg_per_block = 0; // 0 = auto
     // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
-    // launch before it is long enough to hide it (>= kSerialWalkSamples samples or chain steps), the prefix-scan form in the
-    // launch-bound regime; MCI_TRAIN_SERIAL=1 / 0 forces one of them
+    // launch before it is long enough to hide its ~0.1 ms per iteration (>= kSerialWalkSamples samples or chain steps on this
+    // rank: under 2.5 % of the iteration), the prefix-scan form below that; mci_set_train_walk / MCI_TRAIN_SERIAL=1 | 0 force one
     int train_serial = -1;
     int64_t last_samples = 0; // samples (vegas) or chain steps of the last sample launch on this rank
-    static const int64_t kSerialWalkSamples = 1000000;
+    static const int64_t kSerialWalkSamples = (int64_t)1 << 28;
     bool train_lds_raised = false; // k_train / k_finish allowed more than 64 KiB of dynamic LDS (large grids)
     // last launch
     std::vector<hipEvent_t> evs; // ring of (start, stop) pairs around the sampling kernel, one pair per launch
@@ -772,6 +772,13 @@ int mci_kernel_code_object(mci_problem *p, int32_t solver, char *buf, int32_t n)
     if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver);
     if (!p->compiled[solver]) return fail(MCI_ERR_INVALID, "solver %d has not been compiled yet", solver);
     snprintf(buf, (size_t)n, "%s", p->code_object[solver].c_str());
+    return MCI_OK;
+}
+
+int mci_set_train_walk(mci_problem *p, int32_t mode) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (mode < -1 || mode > 1) return fail(MCI_ERR_INVALID, "train walk mode must be -1 (automatic), 0 (prefix scan) or 1 (serial recurrence)");
+    p->train_serial = mode;
     return MCI_OK;
 }
 

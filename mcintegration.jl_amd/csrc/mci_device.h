@@ -47,8 +47,14 @@ struct u32x4 { u32 x, y, z, w; };
 #ifndef MCI_PHILOX_ROUNDS
 #define MCI_PHILOX_ROUNDS 10
 #endif
+// Round keys in VGPRs for kernels with at most this many draws.  Measured on MI355X (tools/ab_c2.py): the 20 extra registers
+// cost C2 its fourth wave per SIMD (132 VGPRs) and the sample loop is LDS-bound anyway: 1.754 ms against 1.715 ms with the keys
+// in SGPRs; no difference on C5 :vegas and on 16 independent grids.  Off by default.
 #ifndef MCI_VGPR_KEYS_MAX_DRAWS
-#define MCI_VGPR_KEYS_MAX_DRAWS 20
+#define MCI_VGPR_KEYS_MAX_DRAWS 0
+#endif
+#ifndef MCI_U12_ALIGNBIT
+#define MCI_U12_ALIGNBIT 1
 #endif
 #ifndef MCI_VGPR_KEY_ROUNDS
 #define MCI_VGPR_KEY_ROUNDS MCI_PHILOX_ROUNDS
@@ -116,9 +122,18 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u
 
 // 52 random mantissa bits as a double in [1, 2)
 __device__ __forceinline__ double u12(u32 lo, u32 hi) {
-    // v_lshrrev_b64 + v_or_b32 (1.8 + 1.1 ns per wave-instruction and SIMD); two v_alignbit_b32 would be 2 x 1.8 (3-source forms)
+#if MCI_U12_ALIGNBIT
+    // ((hi:lo) >> 12) | 0x3FF0...0 as two v_alignbit_b32: the low word is (hi:lo) >> 12, the high word (0x3FF:hi) >> 12 =
+    // 0x3FF00000 | hi >> 12.  Per instruction a 3-source form is no cheaper than the 64-bit shift + or it replaces
+    // (tools/issue_microbench.hip), but with it the compiler keeps every Philox product a single v_mad_u64_u32; with the
+    // 64-bit shift in the loop it splits 16 of them into v_mul_lo_u32 + v_mul_hi_u32 pairs (C2: 1.67 vs 1.72 ms per 1e8)
+    const u32 wlo = __builtin_amdgcn_alignbit(hi, lo, 12u);
+    const u32 whi = __builtin_amdgcn_alignbit(0x3FFu, hi, 12u);
+    return __longlong_as_double((i64)(((u64)whi << 32) | wlo));
+#else
     const u64 bits = ((((u64)hi << 32) | lo) >> 12) | 0x3FF0000000000000ull;
     return __longlong_as_double((i64)bits);
+#endif
 }
 __device__ __forceinline__ double u01(u32 lo, u32 hi) { return u12(lo, hi) - 1.0; }
 

@@ -28,12 +28,14 @@ def gauss4_ref():
 def genz_product_peak(D=32, a=5.0):
     """prod_i 1/(a^-2 + (x_i-u_i)^2), u_i = 0.3 + 0.4 i/(D-1)  (BASELINE C4); ud = [D, a, u...]"""
     u = [0.3 + 0.4 * i / (D - 1) for i in range(D)]
+    # one division for the whole product (each factor lies in [a^-2, a^-2 + 1], so the product of D <= 64 of them stays far
+    # inside the double range); the oracle's C twin evaluates the same expression in the same order
     body = """
-    const double a = ud[1];
-    double p = 1.0;
+    const double ia2 = 1.0 / (ud[1] * ud[1]);
+    double q = 1.0;
     #pragma unroll
-    for (int d = 0; d < %d; ++d) { const double t = x[d] - ud[2 + d]; p *= 1.0 / (1.0 / (a * a) + t * t); }
-    w[0] = p;""" % D
+    for (int d = 0; d < %d; ++d) { const double t = x[d] - ud[2 + d]; q *= ia2 + t * t; }
+    w[0] = 1.0 / q;""" % D
     return Integrand(body, [float(D), a] + u, "genz_product_peak%d" % D)
 
 

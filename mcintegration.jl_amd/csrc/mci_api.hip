@@ -619,6 +619,13 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             }
             p->lds_bytes_k1 = p->lds_bytes + (int64_t)s.ec_doubles * 8;
         }
+        // Split-all pass (several histogram tiles, e.g. 32 grids): the grids gathered from global memory are walked dimension-major by
+        // all waves of a workgroup in step, so that the CU's L1 sees one or two 8 KB tables at a time (draw_gather_phase).  Measured
+        // on C4 (tools/ab_c2.py): 7.26 -> 6.95 ms per 1e8 samples; with one tile (16 grids, histogram in the pass) the barriers
+        // cost more than the locality buys (2.77 -> 3.47 ms), so it stays off there.  MCI_L1_PHASE=0 | n overrides (n samples
+        // per lane and trip; 2 already spills on 32 grids).
+        s.l1_phase = (mode == 3 && s.split_all) ? 1 : 0;
+        if (const char *e = getenv("MCI_L1_PHASE")) s.l1_phase = (mode >= 2 && atoi(e) > 0) ? (atoi(e) > 4 ? 4 : atoi(e)) : 0;
         // one big workgroup per CU owns its LDS
         if (p->lds_bytes > lim0) p->threads = 512; // measured (tools/c4_sweep.py): 2 waves/SIMD beat 1 fat and 4 spilling ones
     }

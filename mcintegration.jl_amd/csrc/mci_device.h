@@ -363,6 +363,85 @@ template <class Cfg, bool ECACHE = false> __device__ __forceinline__ void draw_s
     draw_sample<Cfg, ECACHE, false>(t, make_round_keys<false>((u32)seed, (u32)(seed >> 32)), stream, index, s);
 }
 
+// draws whose grid edges are gathered from global memory (table modes 2/3: not staged in LDS, not in the LDS edge cache)
+template <class Cfg, bool ECACHE> constexpr bool is_gather_draw(int k) {
+    return Cfg::TABLE_MODE >= 2 && Cfg::leaf_kind(Cfg::draw_leaf(k)) == 0 && !(ECACHE && Cfg::leaf_ecoff(Cfg::draw_leaf(k)) >= 0);
+}
+template <class Cfg, bool ECACHE> constexpr int gather_draw_count() {
+    int n = 0;
+    for (int k = 0; k < Cfg::NDRAW; ++k) n += is_gather_draw<Cfg, ECACHE>(k) ? 1 : 0;
+    return n;
+}
+#ifndef MCI_L1_PHASE_CHUNKS
+#define MCI_L1_PHASE_CHUNKS 1 // Philox chunks (pairs of draws) between two workgroup barriers of the gather phase
+#endif
+
+// The draws of S samples per lane and trip, GATHER DRAWS FIRST AND DIMENSION-MAJOR (draw_gather_phase), then sample by sample the rest
+// (draw_rest_phase): every wave of the workgroup walks the gathered grids in
+// the same order, S samples per grid, with a workgroup barrier every MCI_L1_PHASE_CHUNKS chunks -- so at any moment the whole CU
+// reads ONE or two 8 KB edge tables, which then live in its 32 KB L1 (measured: 58 ns per wave-gather and SIMD from an
+// L1-resident table against 148 ns when 13..32 tables compete for the L1 and every access is an L2 line fill,
+// tools/issue_microbench.hip).  The Philox streams are counter-based, so the order of evaluation is free; a chunk that holds one
+// gathered and one cached draw is simply computed in both phases.  Jacobians are products of the per-draw 1/prob (no bare
+// increment products, so no scaling groups are needed).  Must be called by every thread of the workgroup (barriers inside).
+template <class Cfg, bool ECACHE, bool KV, int K, class SampleT> __device__ __forceinline__ void phased_one_draw(const Tables<Cfg> &t, const u32x4 &r, SampleT &s) {
+    constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
+    const double y1 = (K & 1) == 0 ? u12(r.x, r.y) : u12(r.z, r.w);
+    double raw;
+    draw_leaf<Cfg, K, true, ECACHE>(t, y1, s.x[K], raw, s.bin[K]);
+    const double pj = raw * jac_scale<Cfg>(K);
+    s.pj[K] = pj;
+    s.jac *= pj; // jac /= prob   vegas/montecarlo.jl:126
+    static_for<0, Cfg::NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (((Cfg::own_mask(i) >> K) & 1ull) && Cfg::own_mask(i) != ALL) s.jaci[i] *= pj;
+    });
+}
+// gather phase of S samples (barriers inside: every thread of the workgroup must call it)
+template <class Cfg, bool ECACHE, bool KV, int S> __device__ __forceinline__ void draw_gather_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream,
+                                                                                                  const u64 *index, Sample<Cfg> *s) {
+    constexpr int NCHUNK = (Cfg::NDRAW + 1) / 2;
+    static_for<0, S>([&](auto Ss) {
+        constexpr int q = decltype(Ss)::value;
+        s[q].jac = 1.0;
+        static_for<0, Cfg::NI>([&](auto I) { s[q].jaci[decltype(I)::value] = 1.0; });
+    });
+    int phase = 0;
+    static_for<0, NCHUNK>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        constexpr bool g0 = is_gather_draw<Cfg, ECACHE>(2 * c), g1 = 2 * c + 1 < Cfg::NDRAW && is_gather_draw<Cfg, ECACHE>(2 * c + 1 < Cfg::NDRAW ? 2 * c + 1 : 0);
+        if constexpr (g0 || g1) {
+            static_for<0, S>([&](auto Ss) {
+                constexpr int q = decltype(Ss)::value;
+                const u32x4 r = philox4x32_10<KV>((u32)index[q], (u32)(index[q] >> 32), (u32)c, stream, keys);
+                if constexpr (g0) phased_one_draw<Cfg, ECACHE, KV, 2 * c>(t, r, s[q]);
+                if constexpr (g1) phased_one_draw<Cfg, ECACHE, KV, (2 * c + 1 < Cfg::NDRAW ? 2 * c + 1 : 0)>(t, r, s[q]);
+            });
+            phase += 1;
+            if (phase % MCI_L1_PHASE_CHUNKS == 0) __builtin_amdgcn_s_barrier(); // keeps the waves on the same tables; no data is exchanged
+        }
+    });
+}
+// the remaining draws of ONE sample (LDS-resident grids, Discrete tables), right before its integrand is evaluated
+template <class Cfg, bool ECACHE, bool KV> __device__ __forceinline__ void draw_rest_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index,
+                                                                                         Sample<Cfg> &s) {
+    constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
+    constexpr int NCHUNK = (Cfg::NDRAW + 1) / 2;
+    static_for<0, NCHUNK>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        constexpr bool n0 = !is_gather_draw<Cfg, ECACHE>(2 * c), n1 = 2 * c + 1 < Cfg::NDRAW && !is_gather_draw<Cfg, ECACHE>(2 * c + 1 < Cfg::NDRAW ? 2 * c + 1 : 0);
+        if constexpr (n0 || n1) {
+            const u32x4 r = philox4x32_10<KV>((u32)index, (u32)(index >> 32), (u32)c, stream, keys);
+            if constexpr (n0) phased_one_draw<Cfg, ECACHE, KV, 2 * c>(t, r, s);
+            if constexpr (n1) phased_one_draw<Cfg, ECACHE, KV, (2 * c + 1 < Cfg::NDRAW ? 2 * c + 1 : 0)>(t, r, s);
+        }
+    });
+    static_for<0, Cfg::NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (Cfg::own_mask(i) == ALL) s.jaci[i] = s.jac; // dof[i] == maxdof: no padding (vegas/montecarlo.jl:82)
+    });
+}
+
 // stage the tables into LDS (coalesced 8-byte loads, once per workgroup)
 template <class Cfg> __device__ __forceinline__ void stage_tables(const double *gE, const double *gDA, const double *gDD, double *sE, double *sDA, double *sDD) {
     const int tid = threadIdx.x, T = blockDim.x;
@@ -654,10 +733,10 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     const i64 mfreq = a.measurefreq;
     i64 mrem = mfreq == 1 ? 0 : ((i64)slice * T + tid + 1) % mfreq;
     const i64 mstep = mfreq == 1 ? 0 : stride % mfreq;
+    // gathered grids (table mode 3) are walked dimension-major over PH samples per lane so that they are served from L1
+    constexpr int PH = (Cfg::L1_PHASE > 0 && Cfg::HOST_INTEGRAND == 0 && gather_draw_count<Cfg, EC>() > 0) ? Cfg::L1_PHASE : 0;
     auto run = [&](auto TT) { // the sample loop, specialised on the workgroup's histogram tile
-    for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
-        Sample<Cfg> s;
-        draw_sample<Cfg, EC, KV>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
+    auto process = [&](const i64 n, const Sample<Cfg> &s) { // everything after the draws of sample n
         double w[Cfg::NW];
         if constexpr (Cfg::HOST_INTEGRAND != 0) { // the closure ran on the host over the dumped draws
             const i64 hidx = wi.lb * a.neval_per_block + n;
@@ -700,6 +779,39 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
                 }
             });
             static_for<0, NWORD>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = word[decltype(J)::value]; });
+        }
+    };
+    if constexpr (PH > 0) {
+        // the same number of trips for every thread of the workgroup (barriers inside): lanes past the end of the block redo
+        // their last valid sample and drop it
+        const i64 n0 = (i64)slice * T + tid, first = (i64)slice * T;
+        const i64 jmax = first < a.neval_per_block ? (a.neval_per_block - first + stride - 1) / stride : 0; // samples of lane 0
+        for (i64 j0 = 0; j0 < jmax; j0 += PH) {
+            Sample<Cfg> sm[PH];
+            u64 index[PH];
+            i64 nn[PH];
+            static_for<0, PH>([&](auto Ss) {
+                constexpr int q = decltype(Ss)::value;
+                const i64 n = n0 + (j0 + q) * stride;
+                nn[q] = n;
+                index[q] = (u64)(B * a.neval_per_block + (n < a.neval_per_block ? n : 0));
+            });
+            draw_gather_phase<Cfg, EC, KV, PH>(t, keys, stream, index, sm);
+            static_for<0, PH>([&](auto Ss) {
+                constexpr int q = decltype(Ss)::value;
+                // one sample at a time from here on: without the fences the scheduler interleaves the PH samples' Philox blocks
+                // and integrands for ILP and the live draws of all of them no longer fit the register file
+                __builtin_amdgcn_sched_barrier(0);
+                draw_rest_phase<Cfg, EC, KV>(t, keys, stream, index[q], sm[q]);
+                if (nn[q] < a.neval_per_block) process(nn[q], sm[q]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
+            Sample<Cfg> s;
+            draw_sample<Cfg, EC, KV>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
+            process(n, s);
         }
     }
     };

@@ -26,8 +26,9 @@ BASELINE = [
     ("c1", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]]), mci.catalog.log_over_sqrt, None, "vegas", "mci_vegas_batch", 64),
     ("c2", lambda: mci.Configuration(var=mci.Continuous(-L, L), dof=[[16]]), lambda: mci.catalog.gaussian(16), None, "vegas", "mci_vegas_batch", 128),
     ("c3", _bubble, mci.catalog.bubble, lambda: mci.bin_by(4), "vegasmc", "mci_vegasmc_chains", 256),
+    # (one 512-thread workgroup per CU owns its LDS: 2 waves/SIMD, so the budget is 256 registers)
     ("c4", lambda: mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]]), lambda: mci.catalog.genz_product_peak(32), None, "vegas",
-     "mci_vegas_batch", 168),
+     "mci_vegas_batch", 256),
     ("c5", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]]), mci.catalog.nested_gauss, None, "mcmc",
      "mci_mcmc_chains", 512),
 ]

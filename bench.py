@@ -207,6 +207,8 @@ def main():
     if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     if not dry:
+        # one GPU per rank; a launcher that isolates the ranks (HIP_VISIBLE_DEVICES per rank) shows each of them a single device 0
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 

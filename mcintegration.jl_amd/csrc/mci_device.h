@@ -1100,10 +1100,12 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; newp += absw<Cfg, i>(wn) * rw[i] * padn[i]; }); // :85-87
                 const double R = prop * newp / probability;    // :88
                 const bool ok = uacc < R;                      // :91
-                static_for<0, Cfg::NPOOL>([&](auto V) {
+                static_for<0, Cfg::NPOOL>([&](auto V) { // (vi is wave-uniform with many chains per block: one scalar branch is taken)
                     constexpr int v = decltype(V)::value;
-                    npr[v] += vi == v ? 1u : 0u;               // :90
-                    nac[v] += (ok && vi == v) ? 1u : 0u;       // :92
+                    if (vi == v) {
+                        npr[v] += 1u;                          // :90
+                        nac[v] += ok ? 1u : 0u;                // :92
+                    }
                 });
                 if (ok) {
                     c = n;

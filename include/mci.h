@@ -179,6 +179,8 @@ int mci_get_hold_histogram(mci_problem *prob, uint64_t *out64);
  * iterations (oldest first), nstat = 2*nobs+2+N+1 doubles per row: the per-iteration history that
  * `Result.iterations` is built from (statistics.jl:24-33), kept on the device until asked for */
 int mci_get_iteration_log(mci_problem *prob, int32_t nrows, double *out);
+/* make room for `rows` more iterations in that log now (it grows on demand otherwise, synchronising the stream when it does) */
+int mci_reserve_iteration_log(mci_problem *prob, int32_t rows);
 int mci_get_packed(mci_problem *prob, double *out, int64_t n);
 int mci_set_packed(mci_problem *prob, const double *in, int64_t n);
 void *mci_packed_device_ptr(mci_problem *prob);

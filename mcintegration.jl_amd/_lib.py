@@ -76,6 +76,7 @@ SIGNATURES = [
     ("mci_iteration_finish", C.c_int, [_VP, C.c_int32, C.c_int64, C.c_int32, C.c_double, c_double_p, c_double_p]),
     ("mci_integrate", C.c_int, [_VP, C.POINTER(IntegrateArgs), C.POINTER(ResultC)]),
     ("mci_get_iteration_log", C.c_int, [_VP, C.c_int32, c_double_p]),
+    ("mci_reserve_iteration_log", C.c_int, [_VP, C.c_int32]),
     ("mci_get_packed", C.c_int, [_VP, c_double_p, C.c_int64]),
     ("mci_set_packed", C.c_int, [_VP, c_double_p, C.c_int64]),
     ("mci_packed_device_ptr", _VP, [_VP]),

@@ -97,9 +97,10 @@ struct mci_ctx {
 };
 
 namespace {
-// train! stages one leaf in LDS: (5 * nbin + 16) doubles in k_finish -> the largest grid one workgroup can refine
-const int64_t kTrainLdsMax = 160 * 1024;
-const int kMaxLeafBins = (int)((kTrainLdsMax / 8 - 16) / 5);
+// train! stages one leaf in LDS: train_lds_doubles(nbin) + nbin doubles in k_finish (~4.5 per bin) next to ~2 KiB of static LDS
+// -> the largest grid one workgroup can refine
+const int64_t kTrainLdsMax = 160 * 1024 - 4096;
+const int kMaxLeafBins = 4400;
 struct Leaf {
     int kind, pool, npts, nbin, adapt, eoff, doff, boff;
     double lower, upper, alpha;
@@ -1071,7 +1072,7 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
         a.loop = p->d_loop;
         a.iter_log_base = p->d_iterlog;
     }
-    const size_t sm = (size_t)(4 * maxn + 16) * sizeof(double); // d[N+4] | sg[N+1] | wa[N+1] | wj[N+1] (train_leaf)
+    const size_t sm = (size_t)mci::train_lds_doubles(maxn) * sizeof(double); // d[N+4] | sg[N+1] | wa[N+1] | wj[N+1] (train_leaf)
     if (sm + (size_t)maxn * sizeof(double) > 64 * 1024 && !p->train_lds_raised) { // grids of more than ~1600 increments
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_train, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
@@ -1087,22 +1088,36 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     return MCI_OK;
 }
 
+// room for `rows` more iterations in the device-side iteration log (it grows by itself, with a stream synchronisation each time:
+// a caller that must not synchronise inside a timed loop reserves first)
+static int grow_iteration_log(mci_problem *p, int64_t need) {
+    if (need <= p->cap_iter) return MCI_OK;
+    int64_t ncap = p->cap_iter ? p->cap_iter : 64;
+    while (ncap < need) ncap *= 2;
+    double *n = nullptr;
+    HIPCHK(hipMalloc((void **)&n, (size_t)ncap * p->nstat * sizeof(double)));
+    if (p->d_iterlog) {
+        HIPCHK(hipMemcpyAsync(n, p->d_iterlog, (size_t)p->cap_iter * p->nstat * sizeof(double), hipMemcpyDeviceToDevice, p->ctx->stream));
+        HIPCHK(hipStreamSynchronize(p->ctx->stream));
+        (void)hipFree(p->d_iterlog);
+    }
+    p->d_iterlog = n;
+    p->cap_iter = ncap;
+    return MCI_OK;
+}
+
+int mci_reserve_iteration_log(mci_problem *p, int32_t rows) {
+    if (!p || rows < 0) return fail(MCI_ERR_INVALID, "bad argument");
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    return grow_iteration_log(p, (int64_t)p->log_row + rows);
+}
+
 int mci_iteration_finish(mci_problem *p, int32_t solver, int64_t block_total, int32_t adapt, double gamma, double *mean, double *std) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
     HIPCHK(hipSetDevice(p->ctx->device));
     const auto &s = p->shape;
-    if (p->log_row >= p->cap_iter) { // grow the iteration log (keeps old rows)
-        const int64_t ncap = p->cap_iter ? p->cap_iter * 2 : 64;
-        double *n = nullptr;
-        HIPCHK(hipMalloc((void **)&n, (size_t)ncap * p->nstat * sizeof(double)));
-        if (p->d_iterlog) {
-            HIPCHK(hipMemcpyAsync(n, p->d_iterlog, (size_t)p->cap_iter * p->nstat * sizeof(double), hipMemcpyDeviceToDevice, p->ctx->stream));
-            HIPCHK(hipStreamSynchronize(p->ctx->stream));
-            (void)hipFree(p->d_iterlog);
-        }
-        p->d_iterlog = n;
-        p->cap_iter = ncap;
-    }
+    if (int grc = grow_iteration_log(p, (int64_t)p->log_row + 1)) return grc;
     double *row = p->d_iterlog + (size_t)p->log_row * p->nstat;
     // doReweight! runs for the chain solvers whether or not the grid adapts (main.jl:183 is outside the `if adapt`)
     int rc = launch_train(p, adapt ? 1 : 0, (solver == MCI_VEGASMC || solver == MCI_MCMC) ? 1 : 0, gamma, row);

@@ -215,6 +215,9 @@ __device__ inline double block_prefix(const double *v, double *out, int n, doubl
     return out[n - 1];
 }
 
+// LDS doubles train_leaf needs for a leaf of n bins: d[n+4] | sg[n+1] | wa[n+1] | wj[n+1] (ints: half a double each), rounded up
+__host__ __device__ inline int train_lds_doubles(int n) { return (n + 4) + (n + 1) + (n + 1) + (n + 2) / 2 + 2; }
+
 struct TrainArgs {
     const LeafDev *leaves;
     int nleaf;
@@ -438,7 +441,7 @@ __global__ void __launch_bounds__(256) k_train(TrainArgs a) {
 // launch.  Workgroup l < nleaf merges its leaf's histogram (second stage) into LDS and `packed`, then trains from
 // the LDS copy; workgroup nleaf merges the statistics head, then does the bookkeeping.
 __global__ void __launch_bounds__(256) k_finish(MergeArgs m, TrainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double sm[]; // [4*maxn + 16] train scratch | [maxn] merged histogram
+    extern __shared__ __attribute__((aligned(16))) double sm[]; // [train_lds_doubles(maxn)] train scratch | [maxn] merged histogram
     __shared__ double ps[256];
     __shared__ int bad;
     __shared__ double ssum;
@@ -456,7 +459,7 @@ __global__ void __launch_bounds__(256) k_finish(MergeArgs m, TrainArgs a) {
     const LeafDev L = a.leaves[blockIdx.x];
     int maxn = 1;
     for (int l = 0; l < a.nleaf; ++l) maxn = a.leaves[l].nbin > maxn ? a.leaves[l].nbin : maxn;
-    double *hl = sm + 4 * maxn + 16;
+    double *hl = sm + train_lds_doubles(maxn);
     double *hp = a.packed + a.nstat + L.boff;
     for (int i = tid; i < L.nbin; i += T) {
         const double v = merge_hist_bin(m, L.boff + i);

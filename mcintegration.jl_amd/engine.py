@@ -221,6 +221,10 @@ class Engine:
         check(lib().mci_get_iteration_log(self.p, int(nrows), _dp(out)))
         return out
 
+    def reserve_iterations(self, rows):
+        """room for `rows` more iterations in the device-side log, so that none of them synchronises to grow it"""
+        check(lib().mci_reserve_iteration_log(self.p, int(rows)))
+
     def get_packed(self):
         out = np.empty(self.packed_size)
         check(lib().mci_get_packed(self.p, _dp(out), len(out)))

@@ -184,6 +184,76 @@ def test_resume_keeps_trained_grid_and_improves_first_iteration():
     check(res, -4.0)
 
 
+def test_trained_variables_carry_over_into_a_new_configuration():
+    """`integrate(...; var = (res.config.var[1], ...))` (docs/src/index.md:129): a variable object keeps what train! taught it, so a NEW
+    Configuration built from it -- here even for another integrand and another dof -- starts from the trained grid and distribution, and
+    the variables read back the state of the engine they now live in."""
+    v0, d0 = Continuous(0.0, 1.0), Discrete(1, 4)
+    res0 = integrate("w[0] = log(x[0]) / sqrt(x[0]) * x[1];", var=(v0, d0), dof=[[1, 1]], solver="vegas", neval=1e5, seed=21)
+    g0, p0 = res0.config.var[0].grid.copy(), res0.config.var[1].distribution.copy()
+    assert not np.allclose(g0, np.linspace(0, 1, 1000)) and not np.allclose(p0, 0.25)
+    cfg = Configuration(var=(res0.config.var[0], res0.config.var[1]), dof=[[1, 1]], seed=22)
+    eng = mci.Engine(cfg, mci.Integrand("w[0] = log(x[0]) / sqrt(x[0]) * x[1];"))
+    np.testing.assert_array_equal(eng.grid(0), g0)                      # seeded from the trained state, not from the uniform grid
+    np.testing.assert_allclose(eng.distribution(1)[0], p0, rtol=1e-15)
+    np.testing.assert_array_equal(cfg.var[0].grid, g0)                  # ... and the variable now reads the new engine
+    res = integrate("w[0] = log(x[0]) / sqrt(x[0]) * x[1];", var=(res0.config.var[0], res0.config.var[1]), dof=[[1, 1]], solver="vegas", neval=1e5, seed=23)
+    assert res.iter_std[0, 0] < 0.3 * res0.iter_std[0, 0]              # first iteration already on the trained map
+    check(res, -40.0)                                                   # -4 x (1 + 2 + 3 + 4)
+
+
+def test_a_new_integrand_on_a_trained_configuration_keeps_grid_and_reweight():
+    """integrate(g; config = res.config) with another integrand: the problem is rebuilt, the trained grids AND the learned reweight
+    (configuration.jl:50 lives across integrate calls) move over, the old engine is released."""
+    res0 = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), dof=[[2], [3]], solver="vegasmc", neval=2e5, seed=5)
+    cfg = res0.config
+    old = cfg._engine
+    g0, rw0 = old.grid(0).copy(), old.reweight().copy()
+    assert not np.allclose(rw0, 1.0 / 3.0)
+    res = integrate("w[0] = (x[0] * x[0] + x[1] * x[1] < 1.0) ? 2.0 : 0.0; w[1] = (x[0] * x[0] + x[1] * x[1] + x[2] * x[2] < 1.0) ? 2.0 : 0.0;",
+                    config=cfg, solver="vegasmc", neval=2e5, niter=1, adapt=False, seed=6)
+    assert cfg._engine is not old and old.p is None                     # closed, not left to the garbage collector
+    np.testing.assert_array_equal(cfg._engine.grid(0), g0)
+    check(res, [2 * PI / 4.0, 2 * 4.0 * PI / 3.0 / 8], ratio=6.0)
+
+
+def test_large_grids_train_in_one_cu(oracle):
+    """ninc = 4000: train! stages (5 * nbin + 16) doubles of one variable in LDS -- above 64 KiB the kernels need the dynamic-LDS
+    attribute; beyond what 160 KiB hold the Configuration is refused with a message (not a HIP error at the first train!)."""
+    cfg = Configuration(var=Continuous(0.0, 1.0, ninc=4000), dof=[[2]], seed=9)
+    eng = mci.Engine(cfg, mci.catalog.x2y2())
+    ocfg = oracle.Config([dict(kind=0, pool=0, lower=0.0, upper=1.0, npts=4000)], [[2]])
+    eng.set_train_walk("serial")
+    eng.run("vegas", 20000, 0, 8, 0, 9)
+    eng.finish("vegas", 8, adapt=True)
+    ocfg.iteration(oracle.VEGAS, "x2y2", None, 20000, 0, 8, 0, 9)
+    ocfg.train()
+    g = eng.grid(0)
+    assert len(g) == 4000 and np.all(np.diff(g) > 0)
+    np.testing.assert_allclose(g, ocfg.grid(0), rtol=0, atol=1e-12)
+    res = integrate(mci.catalog.x2y2(), var=Continuous(0.0, 1.0, ninc=4000), dof=[[2]], solver="vegas", neval=2e5, seed=10)
+    check(res, 2.0 / 3.0)
+    with pytest.raises(mci.MCIError) as e:
+        mci.Engine(Configuration(var=Continuous(0.0, 1.0, ninc=5000), dof=[[1]]), "return x[0];")
+    assert "increments" in str(e.value)
+
+
+def test_rccl_comm_refuses_an_engine_on_another_device():
+    """an RcclComm belongs to one device's context; an engine elsewhere would skip the all-reduce silently"""
+    from mcintegration_jl_amd.comm import RcclComm
+    comm = RcclComm(0, 1, RcclComm.unique_id(), 0)
+    assert comm.library_ranks() == (0, 1)
+
+    class Elsewhere:
+        device = 1
+
+        def reduce(self):
+            raise AssertionError("must not be reached")
+    with pytest.raises(RuntimeError) as e:
+        comm.all_reduce(Elsewhere())
+    assert "device" in str(e.value)
+
+
 def test_library_rccl_single_rank_and_torch_reducer():
     """RCCL inside the library with nranks=1 (API use, stream ordering) and the torch reducer leave the
     packed buffer unchanged for a single rank."""

@@ -229,6 +229,11 @@ def main():
         if dry:
             dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
             comm, comm_kind = TorchDistComm(), "gloo"
+        elif os.environ.get("MCI_COMM", "rccl") == "gloo":
+            # real engines, host-side reduction: lets N ranks share ONE GPU (RCCL refuses two ranks on a device), which is how
+            # the whole N > 1 path of this script -- launcher, partition, timing, JSON -- runs on a 1-GPU box (tests/)
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
+            comm, comm_kind = TorchDistComm(), "gloo"
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
             comm_kind = os.environ.get("MCI_COMM", "rccl")
@@ -294,7 +299,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if multi:
-            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else dev)
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if (dry or comm_kind == "gloo") else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         pass_dt.append(dt)

@@ -203,6 +203,11 @@ int mci_get_acceptance(mci_problem *prob, double *propose, double *accept, int32
  * (`config = res.config`, docs/src/index.md:129). */
 int mci_save_state(mci_problem *prob, const char *path);
 int mci_load_state(mci_problem *prob, const char *path);
+/* Opt-in cheaper uniform stream of solver = :vegas: bits = 52 (default) draws every uniform with 52 random mantissa bits, the resolution
+ * of Julia's rand(Float64) (sampler.jl:296), two draws per Philox4x32-10 block; bits = 32 uses one 32-bit word per draw (the top 32
+ * mantissa bits, y on a 2^-32 lattice), four draws per block -- half the generator work per sample.  Same counter scheme otherwise
+ * (draw k -> block k >> 2, word k & 3); the chain solvers are not affected.  Mirrored in the oracle (mcio_set_rng_bits). */
+int mci_set_rng_bits(mci_problem *prob, int32_t bits);
 /* How train!(Continuous) walks the smoothed histogram to place the new grid points (variable.jl:227-234):
  *   1  the reference's serial recurrence, operation for operation (one lane, ~0.1 ms per variable at ninc = 1000 on MI355X);
  *   0  the same walk as a fixed-order prefix scan + one bisection per grid point (18 us; agrees with the recurrence to 1e-12 of

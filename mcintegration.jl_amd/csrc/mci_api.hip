@@ -783,6 +783,16 @@ int mci_kernel_code_object(mci_problem *p, int32_t solver, char *buf, int32_t n)
     return MCI_OK;
 }
 
+int mci_set_rng_bits(mci_problem *p, int32_t bits) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (bits != 52 && bits != 32) return fail(MCI_ERR_INVALID, "rng bits must be 52 (default: the resolution of rand(Float64)) or 32");
+    if (p->shape.rng_bits != bits) {
+        p->shape.rng_bits = bits;
+        drop_modules(p);
+    }
+    return MCI_OK;
+}
+
 int mci_set_train_walk(mci_problem *p, int32_t mode) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     if (mode < -1 || mode > 1) return fail(MCI_ERR_INVALID, "train walk mode must be -1 (automatic), 0 (prefix scan) or 1 (serial recurrence)");

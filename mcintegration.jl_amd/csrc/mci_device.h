@@ -136,6 +136,17 @@ __device__ __forceinline__ double u12(u32 lo, u32 hi) {
 #endif
 }
 __device__ __forceinline__ double u01(u32 lo, u32 hi) { return u12(lo, hi) - 1.0; }
+// the opt-in 32-bit stream of the :vegas solver (Cfg::RNG_BITS == 32, mci_set_rng_bits): ONE Philox word per draw, its 32 bits are the
+// top 32 mantissa bits of a double in [1, 2) -- four draws per Philox call instead of two; y has a resolution of 2^-32
+__device__ __forceinline__ double u12_word(u32 w) {
+    const u32 whi = __builtin_amdgcn_alignbit(0x3FFu, w, 12u); // 0x3FF00000 | w >> 12
+    return __longlong_as_double((i64)(((u64)whi << 32) | (w << 20)));
+}
+// uniform-plus-one of draw j (0 .. DPC-1) of a Philox block: DPC = 2 -> 52-bit draws from word pairs, DPC = 4 -> 32-bit draws
+template <int DPC, int J> __device__ __forceinline__ double block_u12(const u32x4 &r) {
+    if constexpr (DPC == 2) return J == 0 ? u12(r.x, r.y) : u12(r.z, r.w);
+    else return u12_word(J == 0 ? r.x : J == 1 ? r.y : J == 2 ? r.z : r.w);
+}
 
 enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6, STREAM_MC_GROUP = 7 };
 enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_RESCALE_NONFINITE = 8, ST_MCMC_INIT = 16 };
@@ -315,18 +326,18 @@ template <class Cfg> struct Sample {
     double jaci[Cfg::NI];
 };
 
-template <class Cfg, bool ECACHE = false, bool KV = false> __device__ __forceinline__ void draw_sample(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index, Sample<Cfg> &s) {
+template <class Cfg, bool ECACHE = false, bool KV = false, int DPC = 2> __device__ __forceinline__ void draw_sample(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index, Sample<Cfg> &s) {
     const u32 ilo = (u32)index, ihi = (u32)(index >> 32);
     constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
     s.jac = 1.0;
     static_for<0, Cfg::NI>([&](auto I) { s.jaci[decltype(I)::value] = 1.0; });
-    static_for<0, (Cfg::NDRAW + 1) / 2>([&](auto C) {
+    static_for<0, (Cfg::NDRAW + DPC - 1) / DPC>([&](auto C) {
         constexpr int c = decltype(C)::value;
         const u32x4 r = philox4x32_10<KV>(ilo, ihi, (u32)c, stream, keys);
-        static_for<0, 2>([&](auto H) {
-            constexpr int k = 2 * c + decltype(H)::value;
+        static_for<0, DPC>([&](auto H) {
+            constexpr int k = DPC * c + decltype(H)::value;
             if constexpr (k < Cfg::NDRAW) {
-                const double y1 = decltype(H)::value == 0 ? u12(r.x, r.y) : u12(r.z, r.w);
+                const double y1 = block_u12<DPC, decltype(H)::value>(r);
                 double raw;
                 draw_leaf<Cfg, k, true, ECACHE>(t, y1, s.x[k], raw, s.bin[k]);
                 s.pj[k] = raw * jac_scale<Cfg>(k);
@@ -337,8 +348,8 @@ template <class Cfg, bool ECACHE = false, bool KV = false> __device__ __forceinl
                 });
             }
         });
-        if constexpr (((2 * c + 2) % kJacGroup == 0 || 2 * c + 2 >= Cfg::NDRAW)) { // close a group of draws: apply its N factors
-            constexpr int hi = 2 * c + 2, lo = ((hi - 1) / kJacGroup) * kJacGroup;
+        if constexpr (((DPC * c + DPC) % kJacGroup == 0 || DPC * c + DPC >= Cfg::NDRAW)) { // close a group of draws: apply its N factors
+            constexpr int hi = DPC * c + DPC, lo = ((hi - 1) / kJacGroup) * kJacGroup;
             constexpr double sc = jac_scale_product<Cfg>(ALL, lo, hi);
             if constexpr (sc != 1.0) s.jac *= sc;
             static_for<0, Cfg::NI>([&](auto I) {
@@ -384,9 +395,9 @@ template <class Cfg, bool ECACHE> constexpr int gather_draw_count() {
 // tools/issue_microbench.hip).  The Philox streams are counter-based, so the order of evaluation is free; a chunk that holds one
 // gathered and one cached draw is simply computed in both phases.  Jacobians are products of the per-draw 1/prob (no bare
 // increment products, so no scaling groups are needed).  Must be called by every thread of the workgroup (barriers inside).
-template <class Cfg, bool ECACHE, bool KV, int K, class SampleT> __device__ __forceinline__ void phased_one_draw(const Tables<Cfg> &t, const u32x4 &r, SampleT &s) {
+template <class Cfg, bool ECACHE, int DPC, int K, class SampleT> __device__ __forceinline__ void phased_one_draw(const Tables<Cfg> &t, const u32x4 &r, SampleT &s) {
     constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
-    const double y1 = (K & 1) == 0 ? u12(r.x, r.y) : u12(r.z, r.w);
+    const double y1 = block_u12<DPC, K % DPC>(r);
     double raw;
     draw_leaf<Cfg, K, true, ECACHE>(t, y1, s.x[K], raw, s.bin[K]);
     const double pj = raw * jac_scale<Cfg>(K);
@@ -397,10 +408,18 @@ template <class Cfg, bool ECACHE, bool KV, int K, class SampleT> __device__ __fo
         if constexpr (((Cfg::own_mask(i) >> K) & 1ull) && Cfg::own_mask(i) != ALL) s.jaci[i] *= pj;
     });
 }
+// does chunk c (draws DPC*c .. DPC*c + DPC - 1) hold a gathered draw / a draw of the other kind
+template <class Cfg, bool ECACHE, int DPC> constexpr bool chunk_has(int c, bool gather) {
+    for (int j = 0; j < DPC; ++j) {
+        const int k = DPC * c + j;
+        if (k < Cfg::NDRAW && is_gather_draw<Cfg, ECACHE>(k) == gather) return true;
+    }
+    return false;
+}
 // gather phase of S samples (barriers inside: every thread of the workgroup must call it)
-template <class Cfg, bool ECACHE, bool KV, int S> __device__ __forceinline__ void draw_gather_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream,
-                                                                                                  const u64 *index, Sample<Cfg> *s) {
-    constexpr int NCHUNK = (Cfg::NDRAW + 1) / 2;
+template <class Cfg, bool ECACHE, bool KV, int DPC, int S> __device__ __forceinline__ void draw_gather_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream,
+                                                                                                           const u64 *index, Sample<Cfg> *s) {
+    constexpr int NCHUNK = (Cfg::NDRAW + DPC - 1) / DPC;
     static_for<0, S>([&](auto Ss) {
         constexpr int q = decltype(Ss)::value;
         s[q].jac = 1.0;
@@ -409,13 +428,16 @@ template <class Cfg, bool ECACHE, bool KV, int S> __device__ __forceinline__ voi
     int phase = 0;
     static_for<0, NCHUNK>([&](auto C) {
         constexpr int c = decltype(C)::value;
-        constexpr bool g0 = is_gather_draw<Cfg, ECACHE>(2 * c), g1 = 2 * c + 1 < Cfg::NDRAW && is_gather_draw<Cfg, ECACHE>(2 * c + 1 < Cfg::NDRAW ? 2 * c + 1 : 0);
-        if constexpr (g0 || g1) {
+        if constexpr (chunk_has<Cfg, ECACHE, DPC>(c, true)) {
             static_for<0, S>([&](auto Ss) {
                 constexpr int q = decltype(Ss)::value;
                 const u32x4 r = philox4x32_10<KV>((u32)index[q], (u32)(index[q] >> 32), (u32)c, stream, keys);
-                if constexpr (g0) phased_one_draw<Cfg, ECACHE, KV, 2 * c>(t, r, s[q]);
-                if constexpr (g1) phased_one_draw<Cfg, ECACHE, KV, (2 * c + 1 < Cfg::NDRAW ? 2 * c + 1 : 0)>(t, r, s[q]);
+                static_for<0, DPC>([&](auto J) {
+                    constexpr int k = DPC * c + decltype(J)::value;
+                    if constexpr (k < Cfg::NDRAW) {
+                        if constexpr (is_gather_draw<Cfg, ECACHE>(k)) phased_one_draw<Cfg, ECACHE, DPC, k>(t, r, s[q]);
+                    }
+                });
             });
             phase += 1;
             if (phase % MCI_L1_PHASE_CHUNKS == 0) __builtin_amdgcn_s_barrier(); // keeps the waves on the same tables; no data is exchanged
@@ -423,17 +445,20 @@ template <class Cfg, bool ECACHE, bool KV, int S> __device__ __forceinline__ voi
     });
 }
 // the remaining draws of ONE sample (LDS-resident grids, Discrete tables), right before its integrand is evaluated
-template <class Cfg, bool ECACHE, bool KV> __device__ __forceinline__ void draw_rest_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index,
-                                                                                         Sample<Cfg> &s) {
+template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ void draw_rest_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index,
+                                                                                                  Sample<Cfg> &s) {
     constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
-    constexpr int NCHUNK = (Cfg::NDRAW + 1) / 2;
+    constexpr int NCHUNK = (Cfg::NDRAW + DPC - 1) / DPC;
     static_for<0, NCHUNK>([&](auto C) {
         constexpr int c = decltype(C)::value;
-        constexpr bool n0 = !is_gather_draw<Cfg, ECACHE>(2 * c), n1 = 2 * c + 1 < Cfg::NDRAW && !is_gather_draw<Cfg, ECACHE>(2 * c + 1 < Cfg::NDRAW ? 2 * c + 1 : 0);
-        if constexpr (n0 || n1) {
+        if constexpr (chunk_has<Cfg, ECACHE, DPC>(c, false)) {
             const u32x4 r = philox4x32_10<KV>((u32)index, (u32)(index >> 32), (u32)c, stream, keys);
-            if constexpr (n0) phased_one_draw<Cfg, ECACHE, KV, 2 * c>(t, r, s);
-            if constexpr (n1) phased_one_draw<Cfg, ECACHE, KV, (2 * c + 1 < Cfg::NDRAW ? 2 * c + 1 : 0)>(t, r, s);
+            static_for<0, DPC>([&](auto J) {
+                constexpr int k = DPC * c + decltype(J)::value;
+                if constexpr (k < Cfg::NDRAW) {
+                    if constexpr (!is_gather_draw<Cfg, ECACHE>(k)) phased_one_draw<Cfg, ECACHE, DPC, k>(t, r, s);
+                }
+            });
         }
     });
     static_for<0, Cfg::NI>([&](auto I) {
@@ -729,6 +754,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     // measurement cadence (n + 1) % measurefreq == 0 (:148) without a 64-bit division in the sample loop: the remainder is
     // carried along, n advances by `stride` per trip
     constexpr bool KV = Cfg::NDRAW <= MCI_VGPR_KEYS_MAX_DRAWS; // round keys in VGPRs: 20 registers, affordable with few draws in flight
+    constexpr int DPC = Cfg::RNG_BITS == 32 ? 4 : 2;           // draws per Philox block of the :vegas sample stream
     const RoundKeys<KV> keys = make_round_keys<KV>((u32)a.seed, (u32)(a.seed >> 32));
     const i64 mfreq = a.measurefreq;
     i64 mrem = mfreq == 1 ? 0 : ((i64)slice * T + tid + 1) % mfreq;
@@ -796,13 +822,13 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
                 nn[q] = n;
                 index[q] = (u64)(B * a.neval_per_block + (n < a.neval_per_block ? n : 0));
             });
-            draw_gather_phase<Cfg, EC, KV, PH>(t, keys, stream, index, sm);
+            draw_gather_phase<Cfg, EC, KV, DPC, PH>(t, keys, stream, index, sm);
             static_for<0, PH>([&](auto Ss) {
                 constexpr int q = decltype(Ss)::value;
                 // one sample at a time from here on: without the fences the scheduler interleaves the PH samples' Philox blocks
                 // and integrands for ILP and the live draws of all of them no longer fit the register file
                 __builtin_amdgcn_sched_barrier(0);
-                draw_rest_phase<Cfg, EC, KV>(t, keys, stream, index[q], sm[q]);
+                draw_rest_phase<Cfg, EC, KV, DPC>(t, keys, stream, index[q], sm[q]);
                 if (nn[q] < a.neval_per_block) process(nn[q], sm[q]);
             });
             __builtin_amdgcn_sched_barrier(0);
@@ -810,7 +836,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     } else {
         for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
             Sample<Cfg> s;
-            draw_sample<Cfg, EC, KV>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
+            draw_sample<Cfg, EC, KV, DPC>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
             process(n, s);
         }
     }
@@ -1651,7 +1677,7 @@ template <class Cfg> __device__ __forceinline__ void sample_dump(const DumpArgs 
     const u32 stream = a.iteration * 8u + STREAM_VEGAS;
     for (i64 n = (i64)blockIdx.x * blockDim.x + threadIdx.x; n < a.n; n += (i64)gridDim.x * blockDim.x) {
         Sample<Cfg> s;
-        draw_sample<Cfg>(t, a.seed, stream, (u64)(a.first_index + n), s);
+        draw_sample<Cfg, false, false, (Cfg::RNG_BITS == 32 ? 4 : 2)>(t, make_round_keys<false>((u32)a.seed, (u32)(a.seed >> 32)), stream, (u64)(a.first_index + n), s);
         if (a.soa) {
             static_for<0, Cfg::NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.x[(i64)k * a.n + n] = s.x[k]; });
             continue;

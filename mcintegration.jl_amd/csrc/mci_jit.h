@@ -41,6 +41,7 @@ struct ProblemShape {
     // vegas with NTILE > 1 ("split-all"): the sample pass keeps NO histogram, caches the edges of the leading leaves in the
     // LDS the histogram tile would take (leaf_ecoff >= 0: offset in that cache, doubles), and every tile is replayed
     int split_all = 0, ec_doubles = 0;
+    int rng_bits = 52;  // :vegas sample stream: 52 random mantissa bits per draw (two draws per Philox block) or 32 (four per block)
     int l1_phase = 0; // :vegas, grids gathered from global memory: samples per lane and trip of the dimension-major gather phase (0 = off)
     std::vector<int> leaf_ecoff;
     std::vector<int> dof;                 // [(ni+1)*npool] incl. the normalisation row (zeros)
@@ -106,7 +107,7 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     o << fn_table("int", "leaf_poff", arr(s.leaf_poff, "int"));
     o << "    static constexpr int NTILE = " << s.ntile << ", HTILE = " << s.htile << ";\n";
     o << "    static constexpr int SPLIT_ALL = " << (solver == 0 ? s.split_all : 0) << ", EC_DOUBLES = " << (solver == 0 ? s.ec_doubles : 0)
-      << ", L1_PHASE = " << (solver == 0 ? s.l1_phase : 0) << ";\n";
+      << ", L1_PHASE = " << (solver == 0 ? s.l1_phase : 0) << ", RNG_BITS = " << (solver == 0 ? s.rng_bits : 52) << ";\n";
     {
         std::vector<int> ec = s.leaf_ecoff;
         if (solver != 0 || s.ec_doubles <= 0 || ec.size() != s.leaf_kind.size()) ec.assign(s.leaf_kind.size(), -1);

@@ -64,6 +64,19 @@ double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k) 
     return d - 1.0; /* 52 random mantissa bits, like Julia's MersenneTwister rand(Float64) */
 }
 
+/* The opt-in 32-bit stream of solver = :vegas (mci_set_rng_bits): ONE Philox word per draw -- block k >> 2, word k & 3 -- whose 32 bits
+ * become the top 32 mantissa bits of a double in [1, 2); y = that - 1 lies on a 2^-32 lattice. */
+double mcio_uniform32(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k) {
+    uint32_t ctr[4] = {(uint32_t)index, (uint32_t)(index >> 32), k >> 2, stream};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    mcio_philox4x32_10(ctr, key, o);
+    uint64_t bits = ((uint64_t)o[k & 3] << 20) | 0x3FF0000000000000ull; /* [1,2) */
+    double d;
+    memcpy(&d, &bits, sizeof d);
+    return d - 1.0;
+}
+
 enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6, STREAM_MC_GROUP = 7 };
 static inline uint32_t stream_id(uint32_t iteration, int purpose) { return iteration * 8u + (uint32_t)purpose; }
 /* chain solvers: a chain is identified by (block, chain within the block); the block index rides in the top 12 bits of the
@@ -343,6 +356,7 @@ mcio_config *mcio_config_create(int nleaf, const int *kind, const int *pool, con
     for (int i = 0; i < Nd; ++i) c->reweight[i] = 1.0 / Nd; /* ref: configuration.jl:110,172-173 */
     c->visited = (double *)calloc((size_t)Nd, sizeof(double));
     for (int i = 0; i < Nd; ++i) c->visited[i] = 1.0e-8;    /* :182 */
+    c->rng_bits = 52;
     c->pam = Nd > npool ? Nd : npool;     /* :185 max(Nd, Nv) */
     c->npa = 3 * Nd * c->pam;
     c->propose = (double *)calloc((size_t)c->npa, sizeof(double));
@@ -891,7 +905,8 @@ int mcio_vegas_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint
         for (int vi = 0; vi < npool; ++vi) { /* :122 */
             const int off = c->pool_offset[vi], nl = c->pool_nleaf[vi];
             for (int idx = 1; idx <= c->maxdof[vi]; ++idx) { /* :124 */
-                for (int l = 0; l < nl; ++l) u[l] = mcio_uniform(seed, st, gs, (uint32_t)(k + l));
+                for (int l = 0; l < nl; ++l)
+                    u[l] = c->rng_bits == 32 ? mcio_uniform32(seed, st, gs, (uint32_t)(k + l)) : mcio_uniform(seed, st, gs, (uint32_t)(k + l));
                 if (c->prob_mode == MCIO_PROB_SHIFT) mcio_pool_shift(c, vi, idx + off, u); /* :125 */
                 else mcio_pool_create(c, vi, idx + off, u);                                /* :128-129 */
                 jac /= c->pool_prob[vi][idx + off];                                        /* :126 */

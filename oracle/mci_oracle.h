@@ -100,6 +100,7 @@ typedef struct {
     int prob_mode;
     int npa;              /* 3 * (Ni+1) * pam */
     int pam;              /* max(Ni+1, npool): the last dimension */
+    int rng_bits;         /* :vegas sample stream: 52 (default) or 32 random bits per draw (mci_set_rng_bits) */
     int *nneighbor;       /* [Ni+1] configuration.jl:201-227 */
     int **neighbor;       /* [Ni+1][nneighbor] 0-based integrand indices; index Ni = normalisation */
     double thermal_ratio; /* mcmc/montecarlo.jl:77 (default 0.1) */
@@ -126,6 +127,7 @@ typedef struct {
 void mcio_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* uniform in [0,1) for (seed, stream, index, draw k) -- the stream contract shared with the HIP path */
 double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k);
+double mcio_uniform32(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k); /* the opt-in 32-bit stream of :vegas */
 
 /* ---- src/distribution/common.jl ---- */
 long mcio_locate(const double *acc, long n, double p);            /* :8-36, 1-based result, -1 if outside */

@@ -46,7 +46,7 @@ class _Config(C.Structure):
                 ("nobs", C.c_int), ("obs_off", c_int_p), ("obs_nbin", c_int_p), ("obs_bin_draw", c_int_p),
                 ("observable", c_double_p), ("normalization", C.c_double), ("neval", C.c_long),
                 ("reweight", c_double_p), ("visited", c_double_p), ("propose", c_double_p),
-                ("accept", c_double_p), ("prob_mode", C.c_int), ("npa", C.c_int), ("pam", C.c_int), ("nneighbor", c_int_p),
+                ("accept", c_double_p), ("prob_mode", C.c_int), ("npa", C.c_int), ("pam", C.c_int), ("rng_bits", C.c_int), ("nneighbor", c_int_p),
                 ("neighbor", C.POINTER(c_int_p)), ("thermal_ratio", C.c_double), ("reweight_goal", c_double_p),
                 ("ncomp", C.c_int), ("measure_fn", C.c_void_p), ("pool_width", c_int_p), ("draw_comp", c_int_p),
                 ("hold_hist", C.POINTER(C.c_ulonglong))]
@@ -70,6 +70,8 @@ def lib():
     L.mcio_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.mcio_uniform.restype = C.c_double
     L.mcio_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]
+    L.mcio_uniform32.restype = C.c_double
+    L.mcio_uniform32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]
     L.mcio_locate.restype = C.c_long
     L.mcio_locate.argtypes = [c_double_p, C.c_long, C.c_double]
     L.mcio_smooth.argtypes = [c_double_p, C.c_long, C.c_double, c_double_p]
@@ -158,8 +160,9 @@ def philox(ctr, key):
     return [int(v) for v in o]
 
 
-def uniform(seed, stream, index, k):
-    return lib().mcio_uniform(seed, stream, index, k)
+def uniform(seed, stream, index, k, bits=52):
+    """uniform k of (stream, index): 52 random mantissa bits (default) or the opt-in 32-bit stream of :vegas"""
+    return lib().mcio_uniform32(seed, stream, index, k) if bits == 32 else lib().mcio_uniform(seed, stream, index, k)
 
 
 def locate(acc, p):
@@ -418,6 +421,11 @@ class Config:
 
     def set_thermal_ratio(self, r):
         lib().mcio_set_thermal_ratio(self.p, float(r))
+
+    def set_rng_bits(self, bits):
+        """:vegas sample stream: 52 or 32 random bits per draw (mirror of mci_set_rng_bits)"""
+        assert bits in (52, 32)
+        self.c.rng_bits = int(bits)
 
     def set_reweight_goal(self, goal):
         if goal is None:

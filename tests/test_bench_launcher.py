@@ -71,3 +71,26 @@ def test_launched_under_torch_distributed_run_it_does_not_spawn_again(oracle):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["comm"]["ranks"] == 2 and [r["blocks"] for r in out["comm"]["per_rank"]] == [[0, 16], [16, 32]]
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_through_the_real_engine():
+    """the whole N = 2 path of bench.py with the HIP engine -- own launcher, block partition, per-iteration reduction inside the timed
+    loop, max-over-ranks timing, roofline, JSON -- on a 1-GPU box: the two ranks share device 0 and reduce through gloo (RCCL itself
+    refuses two ranks on one device; its single-rank path is test_library_rccl_single_rank_and_torch_reducer)"""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MCI_BENCH_ENGINE"):
+        env.pop(k, None)
+    env["MCI_COMM"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--passes", "2",
+                        "--neval-per-gpu", "2e7", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert "dry_run" not in out and out["n_gpus"] == 2 and out["value"] > 1000.0
+    assert out["comm"]["kind"] == "gloo" and [r["blocks"] for r in out["comm"]["per_rank"]] == [[0, 16], [16, 32]]
+    assert out["comm"]["neval_after_allreduce"] == 4e7                  # config.neval after the reduction: both ranks' samples
+    assert out["config"]["neval_per_iteration"] == 40000000 and out["roofline"]["bound"] == "valu+lds"
+    est = out["estimate"]
+    assert abs(est["mean"] - est["exact"]) < 6 * est["sigma"] and est["iterations"] == 6

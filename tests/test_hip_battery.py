@@ -184,6 +184,21 @@ def test_resume_keeps_trained_grid_and_improves_first_iteration():
     check(res, -4.0)
 
 
+def test_32_bit_stream_passes_the_reference_battery():
+    """rng_bits=32 (opt-in, :vegas): the reference's 7-sigma targets (test/montecarlo.jl:298-318) on a 2^-32 lattice of uniforms"""
+    res = integrate("return (x[0]*x[0] + x[1]*x[1] < 1.0) ? 1.0 : 0.0;", var=Continuous(0.0, 1.0), dof=[[2]], neval=2e5, solver="vegas", seed=101, rng_bits=32)
+    check(res, PI / 4.0)
+    res = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), dof=[[2], [3]], neval=2e5, solver="vegas", seed=102, rng_bits=32)
+    check(res, [PI / 4.0, 4.0 * PI / 3.0 / 8])
+    res = integrate("return log(x[0]) / sqrt(x[0]);", solver="vegas", neval=2e5, seed=103, rng_bits=32)
+    check(res, -4.0)
+    assert res.stdev[0] < 4e-4                                                      # test/montecarlo.jl:303 "@test res.stdev[1] < 0.0004"
+    L = math.sqrt(50.0)
+    res = integrate(mci.catalog.gaussian(16), var=Continuous(-L, L), dof=[[16]], neval=1e8, niter=10, solver="vegas", seed=104, rng_bits=32)
+    check(res, math.erf(5.0) ** 16, ratio=5.0)
+    assert res.stdev[0] < 2e-5
+
+
 def test_trained_variables_carry_over_into_a_new_configuration():
     """`integrate(...; var = (res.config.var[1], ...))` (docs/src/index.md:129): a variable object keeps what train! taught it, so a NEW
     Configuration built from it -- here even for another integrand and another dof -- starts from the trained grid and distribution, and

@@ -124,6 +124,56 @@ def test_vegas_iteration_packed_matches_oracle(oracle, name):
     assert got[2 * eng.nobs + 1] == block * npb  # neval
 
 
+@pytest.mark.parametrize("name", ["c2_gauss16_shared_pool", "c5_nested_gauss", "bubble", "singular2_composite"])
+def test_vegas_32_bit_stream_matches_oracle(oracle, name):
+    """the opt-in cheaper stream of :vegas (mci_set_rng_bits(32): one Philox word per draw, four draws per block): draws bit-exact,
+    iteration sums at the usual tolerances, and a whole run on the oracle's trajectory"""
+    c, cfg, eng, ocfg = make(name, oracle)
+    eng.set_rng_bits(32)
+    ocfg.set_rng_bits(32)
+    x, jac, w = eng.sample_dump(512, nevalperblock=3000, block_index=2, iteration=1, seed=SEED)
+    oc = ocfg.c
+    for s in range(0, 512, 37):
+        gs = 2 * 3000 + s
+        k = 0
+        xo = np.zeros(oc.ndraw)
+        for vi in range(oc.npool):
+            nl = oc.pool_nleaf[vi]
+            for idx in range(1, oc.maxdof[vi] + 1):
+                us = [oracle.uniform(SEED, 1 * 8 + 0, gs, k + l, bits=32) for l in range(nl)]
+                ocfg.pool_create(vi, idx, us)
+                for l in range(nl):
+                    xo[k + l] = ocfg.pool_data(oc.pool_leaf0[vi] + l)[idx - 1]
+                k += nl
+        assert np.array_equal(x[s], xo), (name, s)
+    block, npb = 8, 4000
+    got = eng.iteration("vegas", npb, 0, block, iteration=0, seed=SEED)
+    ref = ocfg.iteration(oracle.VEGAS, c["oname"], c["ud"], npb, 0, block, 0, SEED)
+    gs_, gh = hist_split(got, eng.nobs, cfg.N)
+    rs, rh = hist_split(ref, eng.nobs, cfg.N)
+    np.testing.assert_allclose(gs_, rs, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(gh, rh, rtol=1e-9)
+    plain = mci.Engine(mci.Configuration(var=c["var"](), dof=c["dof"], obs=c.get("obs"), seed=SEED), c["f"], measure=c.get("measure"))
+    assert not np.allclose(plain.iteration("vegas", npb, 0, block, iteration=0, seed=SEED)[:eng.nobs], got[:eng.nobs], rtol=1e-9)   # another stream
+    eng.set_train_walk("serial")
+    r = eng.integrate("vegas", neval=40000, niter=5, block=16, seed=SEED)
+    o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=40000, niter=5, block=16, seed=SEED)
+    np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6, atol=1e-300)
+
+
+def test_c4_32_bit_stream_with_gather_phase_matches_oracle(oracle):
+    """32 grids (split-all pass, dimension-major gather phase) on the 32-bit stream: 8 Philox blocks per sample instead of 16"""
+    ud = genz_userdata(32)
+    cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
+    eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32), rng_bits=32)
+    ocfg = oracle.Config([ocont(0) for _ in range(32)], [[1]])
+    ocfg.set_rng_bits(32)
+    got = eng.iteration("vegas", 2000, 0, 4, iteration=0, seed=SEED)
+    ref = ocfg.iteration(oracle.VEGAS, "genz_product_peak", ud, 2000, 0, 4, 0, SEED)
+    np.testing.assert_allclose(got[:4], ref[:4], rtol=1e-11)
+    np.testing.assert_allclose(got[4:], ref[4:], rtol=1e-9)
+
+
 def test_vegas_iteration_block_range_and_measurefreq(oracle):
     """blocks [lo,hi) are the MPI-rank partition (main.jl:152-166); measurefreq (vegas/montecarlo.jl:148)."""
     c, cfg, eng, ocfg = make("sphere2_padding", oracle)

@@ -64,6 +64,31 @@ def test_train_continuous_golden(oracle, golden):
         assert np.all(np.diff(out) > 0)
 
 
+def test_uniform32_stream_contract(oracle, golden):
+    """the opt-in 32-bit stream of :vegas (mci_set_rng_bits): draw k = word k & 3 of Philox block k >> 2, its 32 bits the top
+    mantissa bits -> exactly word / 2^32; pinned on the Random123 known-answer blocks"""
+    for v in golden["philox4x32_10"]:
+        ctr, key = v["ctr"], v["key"]
+        if ctr[2] >= 2 ** 30:
+            continue   # (the block counter word carries k >> 2)
+        seed, idx, stream = key[0] | (key[1] << 32), ctr[0] | (ctr[1] << 32), ctr[3]
+        for j in range(4):
+            u = oracle.uniform(seed, stream, idx, 4 * ctr[2] + j, bits=32)
+            assert u == v["out"][j] / 2.0 ** 32 and 0.0 <= u < 1.0
+    seed, stream, idx = 0x0123456789ABCDEF, 8 * 3 + 0, 123456789012
+    for k in range(9):
+        o = oracle.philox([idx & 0xFFFFFFFF, idx >> 32, k >> 2, stream], [seed & 0xFFFFFFFF, seed >> 32])
+        assert oracle.uniform(seed, stream, idx, k, bits=32) == o[k & 3] / 2.0 ** 32
+    # a Config switched to 32 bits changes the :vegas stream only
+    a = oracle.Config([dict(kind=0, pool=0, lower=0.0, upper=1.0)], [[2]])
+    b = oracle.Config([dict(kind=0, pool=0, lower=0.0, upper=1.0)], [[2]])
+    b.set_rng_bits(32)
+    pa, pb = a.iteration(oracle.VEGAS, "x2y2", None, 2000, 0, 2, 0, 7), b.iteration(oracle.VEGAS, "x2y2", None, 2000, 0, 2, 0, 7)
+    assert pa[0] != pb[0] and abs(pa[0] - pb[0]) < 0.2
+    ma, mb = a.iteration(oracle.VEGASMC, "x2y2", None, 2000, 0, 2, 0, 7), b.iteration(oracle.VEGASMC, "x2y2", None, 2000, 0, 2, 0, 7)
+    assert (ma == mb).all()
+
+
 def test_train_continuous_flat_histogram_keeps_uniform_grid(oracle):
     grid = np.linspace(0.0, 1.0, 1000)
     out = oracle.train_continuous(grid, np.full(999, 1e-10), 2.0)

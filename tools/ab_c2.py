@@ -23,7 +23,8 @@ elif which == "c4":
     cfg, f = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=1), mci.catalog.genz_product_peak(32)
 else:
     cfg, f = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]], seed=1), mci.catalog.nested_gauss()
-eng = mci.Engine(cfg, f)
+import os
+eng = mci.Engine(cfg, f, rng_bits=int(os.environ.get("MCI_AB_RNG_BITS", "52")))
 eng.integrate("vegas", neval=10**8, niter=4, block=16, seed=1)           # warm-up + train
 r = eng.integrate("vegas", neval=10**8, niter=8, block=16, seed=2, first_iteration=4, ignore=0)
 ms, wg, th = eng.kernel_times_ms(8)

@@ -20,6 +20,8 @@ class OracleEngine:
                 leaves.append(dict(kind=1, pool=pool, lower=lf.lower, upper=lf.upper, alpha=lf.alpha, adapt=lf.adapt,
                                    distribution=lf._dist0))
         self.ocfg = O.Config(leaves, config.dof, obs_nbin=config.obs_nbin, obs_bin_draw=config.obs_bin_draw(measure))
+        if kw.get("rng_bits"):
+            self.ocfg.set_rng_bits(kw["rng_bits"])
         if isinstance(integrand.name, int):
             self.fn = integrand.name
         else:

@@ -141,6 +141,15 @@ int mci_set_integrand_host(mci_problem *prob, mci_host_integrand_fn fn, void *us
  *     obs_add(k, v) -- accumulate v into flat observable k (0 <= k < sum obs_nbin)
  * NULL restores the default measure (vegas/montecarlo.jl:151-153) / the declarative obs_bin_draw one. */
 int mci_set_measure_source(mci_problem *prob, const char *body);
+/* Slow path for `measure` closures that must stay on the host (vegas/montecarlo.jl:156-161), the counterpart of
+ * mci_set_integrand_host: after each launch the library calls the callback ONCE PER BLOCK with that block's n samples --
+ * draw-major draws x[k*stride + i] and relative weights relw[q*stride + i] (= weights[q] * padding_probability * jac, :152; zero for
+ * samples that measurefreq skips) -- and the callback accumulates the block's observables into obs[nobs] (zeroed; flat over the
+ * `obs` kwarg); they then go through the same block merge as device-side observables.  solver = MCI_VEGAS only; fn = NULL
+ * restores the device-side measure. */
+typedef int (*mci_host_measure_fn)(const double *x, const double *relw, int64_t n, int64_t stride, int32_t ndraw, int32_t nw,
+                                   int64_t block, double *obs, int32_t nobs, void *user);
+int mci_set_measure_host(mci_problem *prob, mci_host_measure_fn fn, void *user);
 int mci_compile(mci_problem *prob);          /* JIT or kernel-cache load of the vegas kernel; implicit on first run */
 int mci_compile_solver(mci_problem *prob, int32_t solver); /* same for one solver's kernel (one code object each) */
 /* path of the kernel-cache file (gfx950 code object) the solver's kernel was loaded from -- the analogue of asking Julia

@@ -10,11 +10,11 @@ from . import catalog  # noqa: F401
 from ._lib import MCIError, lib, library_path  # noqa: F401
 from .configuration import Configuration  # noqa: F401
 from .engine import Engine, shutdown  # noqa: F401
-from .integrand import HostIntegrand, Integrand, Measure, bin_by  # noqa: F401
+from .integrand import HostIntegrand, HostMeasure, Integrand, Measure, bin_by  # noqa: F401
 from .integrate import integrate, prefill_kernel_cache  # noqa: F401
 from .statistics import Result, average, mean_std, report  # noqa: F401
 from .variables import CompositeVar, Continuous, Discrete, FermiK  # noqa: F401
 from . import variables as Dist  # noqa: F401  (reference: module Dist)
 
 __all__ = ["integrate", "Configuration", "Continuous", "Discrete", "CompositeVar", "FermiK", "Result", "report",
-           "Dist", "Engine", "Integrand", "HostIntegrand", "Measure", "bin_by", "catalog", "MCIError"]
+           "Dist", "Engine", "Integrand", "HostIntegrand", "HostMeasure", "Measure", "bin_by", "catalog", "MCIError"]

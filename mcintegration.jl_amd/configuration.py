@@ -1,7 +1,7 @@
 """`Configuration(; var, dof, obs, reweight, seed, userdata, ...)`  reference src/configuration.jl:105-194."""
 import numpy as np
 
-from .integrand import Measure, bin_by
+from .integrand import HostMeasure, Measure, bin_by
 from .variables import CompositeVar, ContinuousVar, DiscreteVar, FermiK
 
 
@@ -156,9 +156,9 @@ class Configuration:
             assert self.ncomp == 1, "bin_by observables are real"
             k = self.draw_index(measure.pool, measure.slot, measure.leaf)
             return [k if n > 1 else -1 for n in self.obs_nbin]
-        if isinstance(measure, Measure):
+        if isinstance(measure, (Measure, HostMeasure)):
             return [-1] * self.N
-        raise TypeError("measure must be None, bin_by(pool) or Measure(source): the measure runs on the device")
+        raise TypeError("measure must be None, bin_by(pool), Measure(source) or a Python callable / HostMeasure (host slow path, solver='vegas')")
 
     @property
     def reweight(self):

@@ -158,6 +158,11 @@ struct mci_problem {
     void *host_user = nullptr;
     double *d_hx = nullptr, *d_hw = nullptr, *h_hx = nullptr, *h_hw = nullptr; // device / pinned host
     int64_t cap_host = 0;
+    // host measure ("batch callback"): draws + relative weights of the launch -> host closure per block -> block observables
+    mci_host_measure_fn hmeas_fn = nullptr;
+    void *hmeas_user = nullptr;
+    double *d_mx = nullptr, *d_mrelw = nullptr, *h_mx = nullptr, *h_mrelw = nullptr, *d_mobs = nullptr;
+    int64_t cap_hmeas = 0, cap_mobs = 0;
     // hipGraph replay of the iteration chain (mci_integrate, single rank): device-side {iteration, log row}
     unsigned *d_loop = nullptr;
     bool graph_mode = false; // while capturing: no event records, iteration/log row come from d_loop
@@ -677,6 +682,11 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->h_hw) (void)hipHostFree(p->h_hw);
         if (p->d_tile_w) (void)hipFree(p->d_tile_w);
         if (p->d_tile_bins) (void)hipFree(p->d_tile_bins);
+        if (p->d_mx) (void)hipFree(p->d_mx);
+        if (p->d_mrelw) (void)hipFree(p->d_mrelw);
+        if (p->d_mobs) (void)hipFree(p->d_mobs);
+        if (p->h_mx) (void)hipHostFree(p->h_mx);
+        if (p->h_mrelw) (void)hipHostFree(p->h_mrelw);
         for (auto &e : p->evs) (void)hipEventDestroy(e);
     }
     delete p;
@@ -714,6 +724,18 @@ int mci_set_integrand_host(mci_problem *p, mci_host_integrand_fn fn, void *user)
 int mci_set_measure_source(mci_problem *p, const char *body) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     p->shape.measure_body = body ? body : "";
+    p->shape.host_measure = 0;
+    p->hmeas_fn = nullptr;
+    drop_modules(p);
+    return MCI_OK;
+}
+
+int mci_set_measure_host(mci_problem *p, mci_host_measure_fn fn, void *user) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    p->hmeas_fn = fn;
+    p->hmeas_user = user;
+    p->shape.host_measure = fn ? 1 : 0;
+    if (fn) p->shape.measure_body = "";
     drop_modules(p);
     return MCI_OK;
 }
@@ -733,7 +755,9 @@ int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
 static int compile_solver(mci_problem *p, int solver) {
     if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver); // main.jl:263
     if (p->compiled[solver]) return MCI_OK;
-    if (p->shape.measure_body.empty()) // vegas/montecarlo.jl:104, mcmc/montecarlo.jl:84
+    if (p->shape.host_measure && solver != MCI_VEGAS)
+        return fail(MCI_ERR_INVALID, "a host measure runs with solver=:vegas only (a chain measures inside its step loop)");
+    if (p->shape.measure_body.empty() && !p->shape.host_measure) // vegas/montecarlo.jl:104, mcmc/montecarlo.jl:84
         for (int i = 0; i < p->ni; ++i)
             if (p->shape.obs_bin_draw[i] < 0 && p->shape.obs_nbin[i] != p->shape.ncomp)
                 return fail(MCI_ERR_INVALID, "the default measure can only handle observable as Vector with %d scalar elements!", p->ni);
@@ -991,6 +1015,31 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         HIPCHK(hipMemcpyAsync(p->d_hw, p->h_hw, (size_t)n * s.ni * s.ncomp * sizeof(double), hipMemcpyHostToDevice, hs));
         a.host_w = p->d_hw;
     }
+    if (s.host_measure) { // (solver == :vegas: checked in compile_solver)
+        const int64_t n = nblocks * nevalperblock;
+        const int nw = s.ni * s.ncomp;
+        if (n > p->cap_hmeas) {
+            if (p->d_mx) (void)hipFree(p->d_mx);
+            if (p->d_mrelw) (void)hipFree(p->d_mrelw);
+            if (p->h_mx) (void)hipHostFree(p->h_mx);
+            if (p->h_mrelw) (void)hipHostFree(p->h_mrelw);
+            p->d_mx = p->d_mrelw = p->h_mx = p->h_mrelw = nullptr;
+            p->cap_hmeas = 0;
+            HIPCHK(hipMalloc((void **)&p->d_mx, (size_t)n * s.ndraw * sizeof(double)));
+            HIPCHK(hipMalloc((void **)&p->d_mrelw, (size_t)n * nw * sizeof(double)));
+            HIPCHK(hipHostMalloc((void **)&p->h_mx, (size_t)n * s.ndraw * sizeof(double), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **)&p->h_mrelw, (size_t)n * nw * sizeof(double), hipHostMallocDefault));
+            p->cap_hmeas = n;
+        }
+        if (nblocks * s.nobs > p->cap_mobs) {
+            if (p->d_mobs) (void)hipFree(p->d_mobs);
+            p->d_mobs = nullptr;
+            HIPCHK(hipMalloc((void **)&p->d_mobs, (size_t)nblocks * s.nobs * sizeof(double)));
+            p->cap_mobs = nblocks * s.nobs;
+        }
+        a.host_mx = p->d_mx;
+        a.host_relw = p->d_mrelw;
+    }
     void *args[] = {&a};
     hipFunction_t f = p->f_solver[solver];
     hipStream_t st = p->ctx->stream;
@@ -1003,6 +1052,27 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     if (!p->graph_mode) {
         HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
         p->launches += 1;
+    }
+    if (s.host_measure) {
+        // the closure cannot run on the device: this launch's draws and relative weights go to the host (draw-major, like the host
+        // integrand path), the callback accumulates block b's observables from block b's samples, and they join the block's
+        // partial row before the merge.  PCIe- and host-bound by construction.
+        const int64_t n = nblocks * nevalperblock;
+        const int nw = s.ni * s.ncomp;
+        HIPCHK(hipMemcpyAsync(p->h_mx, p->d_mx, (size_t)n * s.ndraw * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(p->h_mrelw, p->d_mrelw, (size_t)n * nw * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<double> obs((size_t)nblocks * s.nobs, 0.0);
+        for (int64_t b = 0; b < nblocks; ++b) {
+            const int hrc = p->hmeas_fn(p->h_mx + b * nevalperblock, p->h_mrelw + b * nevalperblock, nevalperblock, n, s.ndraw, nw, block_lo + b,
+                                        obs.data() + (size_t)b * s.nobs, s.nobs, p->hmeas_user);
+            if (hrc) return fail(MCI_ERR_INVALID, "the host measure failed (%d)", hrc);
+        }
+        HIPCHK(hipMemcpyAsync(p->d_mobs, obs.data(), obs.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(mci::k_add_host_obs, dim3((unsigned)((nblocks * s.nobs + 255) / 256)), dim3(256), 0, st, p->d_mobs, (int)nblocks, s.nobs, s.ncols, wpb,
+                           p->d_part_cols);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st)); // `obs` leaves scope
     }
     p->last_samples = nblocks * nevalperblock;
     p->last_wg = (int)nwg;

@@ -183,6 +183,10 @@ struct BatchArgs {
     // host integrand ("batch callback", Cfg::HOST_INTEGRAND): weights evaluated on the host for exactly the draws
     // this launch regenerates, host_w[q * tile_stride + sample]
     const double *host_w;
+    // host measure ("batch callback", Cfg::HOST_MEASURE): the kernel accumulates no observable; it leaves, per sample of the
+    // launch, the draws and the relative weights w * jac_i of the measured samples (0 for the others) for the host closure:
+    // host_mx[k * tile_stride + sample], host_relw[q * tile_stride + sample]
+    double *host_mx, *host_relw;
     // hipGraph replay of the iteration chain: the iteration index then lives in device memory (k_finish/k_train
     // advance it), so that the captured launch parameters never change.  NULL: use `iteration`.
     const u32 *iter_ptr;
@@ -774,7 +778,15 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
         const bool domeasure = mrem == 0; // :148
         mrem += mstep;
         mrem = mrem >= mfreq ? mrem - mfreq : mrem;
-        if (domeasure) {
+        if constexpr (Cfg::HOST_MEASURE != 0) { // measure(vars, obs, relative_weights, config) runs on the host over this launch's samples (:156-161)
+            const i64 hidx = wi.lb * a.neval_per_block + n;
+            static_for<0, Cfg::NDRAW>([&](auto K) { a.host_mx[decltype(K)::value * a.tile_stride + hidx] = s.x[decltype(K)::value]; });
+            static_for<0, Cfg::NW>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                a.host_relw[q * a.tile_stride + hidx] = domeasure ? w[q] * s.jaci[q / Cfg::NCOMP] : 0.0; // :152
+            });
+            if (domeasure) extra[Cols<Cfg>::NORM - Cfg::NOBS] += 1.0; // :164
+        } else if (domeasure) {
             double relw[Cfg::NW];
             static_for<0, Cfg::NW>([&](auto Q) { constexpr int q = decltype(Q)::value; relw[q] = w[q] * s.jaci[q / Cfg::NCOMP]; }); // :152
             measure<Cfg>(s.x, s.bin, relw, a.ud, acc, sO);

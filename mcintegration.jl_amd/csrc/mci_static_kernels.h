@@ -42,6 +42,16 @@ __global__ void __launch_bounds__(256) k_hist_stage1(const double *__restrict__ 
     out[(size_t)g * nbin + bin] = (s0 + s1) + (s2 + s3);
 }
 
+// host measure: obs[b][o] (accumulated by the host closure over block b's samples) goes into the observable columns of the
+// block's first partial row, which the kernel left at zero
+__global__ void __launch_bounds__(256) k_add_host_obs(const double *__restrict__ obs, int nblocks, int nobs, int ncols, int wg_per_block,
+                                                      double *__restrict__ part_cols) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nblocks * nobs) return;
+    const int b = i / nobs, o = i % nobs;
+    part_cols[(size_t)b * wg_per_block * ncols + o] += obs[i];
+}
+
 // packed = [obsSum(nobs) | obsSqSum(nobs) | normalization | neval | visited(ni+1) | hist(nbin)]
 // Workgroups [0, nhb) merge the histogram section; the last workgroup merges the statistics columns
 // block by block:  m = observable/normalization; obsSum += m; obsSquaredSum += m*m   (main.jl:275-287)

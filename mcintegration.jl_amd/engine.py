@@ -7,7 +7,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import LeafDesc, ProblemDesc, c_double_p, c_int32_p, check, lib
-from .integrand import HostIntegrand, Integrand, Measure
+from .integrand import HostIntegrand, HostMeasure, Integrand, Measure
 from .variables import ContinuousVar, FermiK
 
 _ctx_cache = {}
@@ -114,8 +114,13 @@ class Engine:
             check(L.mci_set_integrand_host(self.p, C.cast(self._host_cb, C.c_void_p), None))
         else:
             check(L.mci_set_integrand_source(self.p, integrand.body.encode(), _dp(ud) if len(ud) else None, len(ud)))
+        if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
+            measure = HostMeasure(measure)
         if isinstance(measure, Measure):
             check(L.mci_set_measure_source(self.p, measure.body.encode()))
+        elif isinstance(measure, HostMeasure):
+            self._host_measure_cb = _lib.HOST_MEASURE_FN(self._make_host_measure_callback(measure.fn))   # keep alive
+            check(L.mci_set_measure_host(self.p, C.cast(self._host_measure_cb, C.c_void_p), None))
         if threads or wg_per_block is not None:
             check(L.mci_set_launch(self.p, threads or 0, -1 if wg_per_block is None else wg_per_block))
         if rng_bits is not None:
@@ -161,6 +166,48 @@ class Engine:
                         W[2 * i + 1] = o.imag
                     else:
                         W[i] = o
+                return 0
+            except Exception:   # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        return cb
+
+    def _pool_views(self, X, n):
+        """draw-major [ndraw, n] -> what the reference hands a closure: the pool itself with one variable type, else a tuple of pools"""
+        config = self.config
+        pools, k = [], 0
+        for vi, v in enumerate(config.var):
+            nl = config.pool_width(vi)
+            pools.append((k, config.maxdof[vi], nl))
+            k += config.maxdof[vi] * nl
+        if len(pools) == 1 and pools[0][2] == 1:
+            return X
+        arg = tuple(X[k0:k0 + md * nl].reshape((md, n) if nl == 1 else (md, nl, n)) for k0, md, nl in pools)
+        return arg[0] if len(arg) == 1 else arg
+
+    def _make_host_measure_callback(self, fn):
+        """ctypes trampoline: one block's draws and relative weights -> numpy views -> fn(x, obs, weights, config) -> obs[nobs]"""
+        config = self.config
+        nc = config.ncomp
+
+        def cb(xp, rp, n, stride, ndraw, nw, block, op, nobs, user):
+            try:
+                X = np.ctypeslib.as_array(xp, shape=(ndraw, stride))[:, :n]
+                R = np.ctypeslib.as_array(rp, shape=(nw, stride))[:, :n]
+                O = np.ctypeslib.as_array(op, shape=(nobs,))
+                weights = [R[2 * i] + 1j * R[2 * i + 1] for i in range(config.N)] if nc == 2 else [R[i] for i in range(config.N)]
+                dt = complex if nc == 2 else float
+                obs = [np.zeros(ln, dtype=dt) for ln in config.obs_len]
+                fn(self._pool_views(X, n), obs, weights, config)
+                off = 0
+                for o, nb in zip(obs, config.obs_nbin):
+                    o = np.asarray(o).reshape(-1)
+                    if nc == 2:
+                        O[off:off + nb:2], O[off + 1:off + nb:2] = o.real, o.imag
+                    else:
+                        O[off:off + nb] = o
+                    off += nb
                 return 0
             except Exception:   # never unwind through the C frame
                 import traceback

@@ -50,3 +50,20 @@ class HostIntegrand:
         self.name = name or getattr(fn, "__name__", "host")
         self.body = "/* host integrand %d */" % id(fn)
         self.userdata = np.zeros(0)
+
+
+class HostMeasure:
+    """A Python closure as `measure` -- the reference's `measure(vars, obs, relative_weights, config)` (vegas/montecarlo.jl:156-161)
+    run on the HOST, once per statistical block and vectorised over the block's samples ("batch callback" slow path,
+    include/mci.h mci_set_measure_host):
+
+        m(x, obs, weights, config)     # obs[i] += ...   in place
+
+    `x` as for HostIntegrand (x[i] = the vector of the i-th draw over the block's samples), `weights[i]` the vector of integrand
+    i's relative weights (complex for type=complex; zero for samples that `measurefreq` skips), `obs` a list shaped like the `obs`
+    keyword (floats are 1-element arrays), zeroed for every block.  solver="vegas" only."""
+
+    def __init__(self, fn, name=None):
+        self.fn = fn
+        self.name = name or getattr(fn, "__name__", "host_measure")
+        self.body = "/* host measure %d */" % id(fn)

@@ -9,7 +9,7 @@ from ._lib import MCMC, SOLVERS, VEGAS, VEGASMC, lib
 from .comm import LocalComm
 from .configuration import Configuration
 from .engine import Engine
-from .integrand import HostIntegrand, Integrand, Measure
+from .integrand import HostIntegrand, HostMeasure, Integrand, Measure
 from .statistics import Result, report
 from .variables import Continuous, Discrete
 
@@ -54,7 +54,9 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         integrand = Integrand(integrand, config.userdata)
     elif callable(integrand) and not isinstance(integrand, (Integrand, HostIntegrand)):
         integrand = HostIntegrand(integrand)       # a Python closure: host "batch callback" path, solver="vegas" only
-    mkey = None if measure is None else measure.body if isinstance(measure, Measure) else (measure.pool, measure.slot, measure.leaf)
+    if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
+        measure = HostMeasure(measure)             # a Python closure as measure: host batch-callback path, solver="vegas" only
+    mkey = None if measure is None else measure.body if isinstance(measure, (Measure, HostMeasure)) else (measure.pool, measure.slot, measure.leaf)
     key = (integrand.body, tuple(integrand.userdata), mkey, device,
            repr(config.neighbor), int(rng_bits))
     if config._engine is None or config._engine_key != key:

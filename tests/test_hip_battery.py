@@ -402,6 +402,32 @@ def test_report_config_prints_the_acceptance_table(capsys):
     assert "ChangeVariable" in capsys.readouterr().out
 
 
+def test_python_closure_as_measure_matches_device_source():
+    """a host `measure` closure (mci_set_measure_host; the reference's Sphere3 measure, test/montecarlo.jl:71-84) against the same
+    measure as device source: same draws, same relative weights, so the block observables agree to summation-order rounding --
+    also with measurefreq and next to a host integrand; the chain solvers refuse it (their measure sits inside the step loop)"""
+    def sphere3_measure(x, obs, weights, config):          # measure(vars, obs, weights, config)
+        obs[0][0] += weights[0].sum()
+        obs[1][0] += weights[1].sum()
+        obs[1][1] += (weights[1] * 2.0).sum()
+    dev = mci.Measure("obs_add(0, rw[0]); obs_add(1, rw[1]); obs_add(2, rw[1] * 2.0);")
+    kw = dict(dof=[[2], [3]], obs=[0.0, [0.0, 0.0]], solver="vegas", neval=2e5, niter=6, seed=77)
+    for mf in (1, 3):
+        a = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), measure=sphere3_measure, measurefreq=mf, **kw)
+        b = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), measure=dev, measurefreq=mf, **kw)
+        np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-9)
+        np.testing.assert_allclose(a.iter_std, b.iter_std, rtol=1e-6)
+        assert a.mean[1][1] == pytest.approx(2.0 * a.mean[1][0], rel=1e-12)
+    check(a, [PI / 4.0, 4.0 * PI / 3.0 / 8])
+    # host integrand AND host measure: everything user-side on the host, draws and statistics on the device
+    c = integrate(lambda x, cfg: ((x[0] ** 2 + x[1] ** 2 < 1.0) * 1.0, (x[0] ** 2 + x[1] ** 2 + x[2] ** 2 < 1.0) * 1.0),
+                  var=Continuous(0.0, 1.0), measure=sphere3_measure, measurefreq=3, **kw)
+    np.testing.assert_allclose(c.iter_mean, a.iter_mean, rtol=1e-9)
+    with pytest.raises(mci.MCIError) as e:
+        integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), measure=sphere3_measure, dof=[[2], [3]], obs=[0.0, [0.0, 0.0]], solver="vegasmc", neval=1e4)
+    assert "vegas only" in str(e.value)
+
+
 def test_python_closure_as_integrand_matches_device_source():
     """a host closure through the batch-callback path (mci_set_integrand_host) sees the same draws as
     the device-source integrand, so the two runs agree to libm rounding; it reads like the reference's README call."""

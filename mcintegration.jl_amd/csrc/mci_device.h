@@ -640,7 +640,8 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
             if (c >= Cfg::obs_off(i) && c < Cfg::obs_off(i) + Cfg::obs_nbin(i)) binned = binned || Cfg::obs_bin_draw(i) >= 0;
         });
         double v = 0.0;
-        if (c < Cfg::NOBS && binned) v = sO[c];
+        if (c < Cfg::NOBS && Cfg::HOST_MEASURE != 0) v = 0.0; // the host closure's observables join the row later (k_add_host_obs)
+        else if (c < Cfg::NOBS && binned) v = sO[c];
         else
             for (int w = 0; w < nwave; ++w) v += sR[w * Cfg::NCOLS + c]; // fixed order: deterministic
         row[c] = v;

@@ -218,10 +218,10 @@ int mci_load_state(mci_problem *prob, const char *path);
  * (draw k -> block k >> 2, word k & 3); the chain solvers are not affected.  Mirrored in the oracle (mcio_set_rng_bits). */
 int mci_set_rng_bits(mci_problem *prob, int32_t bits);
 /* How train!(Continuous) walks the smoothed histogram to place the new grid points (variable.jl:227-234):
- *   1  the reference's serial recurrence, operation for operation (one lane, ~0.1 ms per variable at ninc = 1000 on MI355X);
+ *   1  the reference's serial recurrence, operation for operation (the chain on one lane in hand-written ISA, +35 us per iteration at ninc = 1000 on MI355X);
  *   0  the same walk as a fixed-order prefix scan + one bisection per grid point (18 us; agrees with the recurrence to 1e-12 of
  *      the variable's range per train! step, i.e. whole runs agree to ~1e-4 instead of ~1e-6);
- *  -1  automatic (default): 1 when the iteration's sample launch on this rank is >= 2^28 samples (the walk then costs < 2.5 %), else 0.
+ *  -1  automatic (default): 1 when the iteration's sample launch on this rank is >= 2^26 samples (the walk then costs ~2 % or less), else 0.
  * The environment variable MCI_TRAIN_SERIAL=1|0, read at mci_problem_create, sets the initial mode. */
 int mci_set_train_walk(mci_problem *prob, int32_t mode);
 /* Dist.train! on the histograms currently in the packed buffer (variable.jl:206-239, :369-382) */

@@ -168,11 +168,11 @@ struct mci_problem {
     bool graph_mode = false; // while capturing: no event records, iteration/log row come from d_loop
     int threads = 256, wg_per_block = 0; // 0 = auto
     // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
-    // launch before it is long enough to hide its ~0.1 ms per iteration (>= kSerialWalkSamples samples or chain steps on this
-    // rank: under 2.5 % of the iteration), the prefix-scan form below that; mci_set_train_walk / MCI_TRAIN_SERIAL=1 | 0 force one
+    // launch before it is long enough to hide its ~35 us per iteration (>= kSerialWalkSamples samples or chain steps on this
+    // rank: 2 % of the headline iteration), the prefix-scan form below that; mci_set_train_walk / MCI_TRAIN_SERIAL=1 | 0 force one
     int train_serial = -1;
     int64_t last_samples = 0; // samples (vegas) or chain steps of the last sample launch on this rank
-    static const int64_t kSerialWalkSamples = (int64_t)1 << 28;
+    static const int64_t kSerialWalkSamples = (int64_t)1 << 26;
     bool train_lds_raised = false; // k_train / k_finish allowed more than 64 KiB of dynamic LDS (large grids)
     // last launch
     std::vector<hipEvent_t> evs; // ring of (start, stop) pairs around the sampling kernel, one pair per launch
@@ -1152,7 +1152,7 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
         a.loop = p->d_loop;
         a.iter_log_base = p->d_iterlog;
     }
-    const size_t sm = (size_t)mci::train_lds_doubles(maxn) * sizeof(double); // d[N+4] | sg[N+1] | wa[N+1] | wj[N+1] (train_leaf)
+    const size_t sm = (size_t)mci::train_lds_doubles(maxn) * sizeof(double); // d | sg | wa (train_leaf)
     if (sm + (size_t)maxn * sizeof(double) > 64 * 1024 && !p->train_lds_raised) { // grids of more than ~1600 increments
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_train, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));

@@ -272,9 +272,17 @@ template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __
             g0 = t.EC[eoff + iy];
             dx = t.EC[eoff + iy + 1] - g0;
         } else {
+#ifdef MCI_ABL_GATHER_LDS // timing only: the gathered grids alias the first cached one (no global gathers)
+            if constexpr (ECACHE) {
+                g0 = t.EC[iy];
+                dx = t.EC[iy + 1] - g0;
+            } else
+#endif
+            {
             constexpr int eoff = Cfg::leaf_eoff(leaf);
             g0 = t.E[eoff + iy]; // (L2 gathers in table modes 2/3: non-temporal loads measured 30 % slower)
             dx = t.E[eoff + iy + 1] - g0;
+            }
         }
 #endif
         x = g0 + dy * dx;
@@ -387,6 +395,9 @@ template <class Cfg, bool ECACHE> constexpr int gather_draw_count() {
     for (int k = 0; k < Cfg::NDRAW; ++k) n += is_gather_draw<Cfg, ECACHE>(k) ? 1 : 0;
     return n;
 }
+#ifndef MCI_STAGGER
+#define MCI_STAGGER 0
+#endif
 #ifndef MCI_L1_PHASE_CHUNKS
 #define MCI_L1_PHASE_CHUNKS 1 // Philox chunks (pairs of draws) between two workgroup barriers of the gather phase
 #endif
@@ -420,6 +431,11 @@ template <class Cfg, bool ECACHE, int DPC> constexpr bool chunk_has(int c, bool 
     }
     return false;
 }
+template <class Cfg, bool ECACHE, int DPC> constexpr int gather_phase_barriers() {
+    int n = 0;
+    for (int c = 0; c < (Cfg::NDRAW + DPC - 1) / DPC; ++c) n += chunk_has<Cfg, ECACHE, DPC>(c, true) ? 1 : 0;
+    return n / MCI_L1_PHASE_CHUNKS;
+}
 // gather phase of S samples (barriers inside: every thread of the workgroup must call it)
 template <class Cfg, bool ECACHE, bool KV, int DPC, int S> __device__ __forceinline__ void draw_gather_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream,
                                                                                                            const u64 *index, Sample<Cfg> *s) {
@@ -449,7 +465,14 @@ template <class Cfg, bool ECACHE, bool KV, int DPC, int S> __device__ __forceinl
     });
 }
 // the remaining draws of ONE sample (LDS-resident grids, Discrete tables), right before its integrand is evaluated
-template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ void draw_rest_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index,
+// NBAR > 0 (staggered schedule, see vegas_batch): exactly NBAR workgroup barriers are executed inside, one after each of the first
+// rest chunks -- they pair with the barriers of the other half of the workgroup, which is in its gather phase meanwhile
+template <class Cfg, bool ECACHE, int DPC> constexpr int rest_chunk_index(int c) { // position of chunk c among the chunks with a non-gathered draw
+    int n = 0;
+    for (int j = 0; j < c; ++j) n += chunk_has<Cfg, ECACHE, DPC>(j, false) ? 1 : 0;
+    return n;
+}
+template <class Cfg, bool ECACHE, bool KV, int DPC, int NBAR = 0> __device__ __forceinline__ void draw_rest_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index,
                                                                                                   Sample<Cfg> &s) {
     constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
     constexpr int NCHUNK = (Cfg::NDRAW + DPC - 1) / DPC;
@@ -463,8 +486,10 @@ template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ v
                     if constexpr (!is_gather_draw<Cfg, ECACHE>(k)) phased_one_draw<Cfg, ECACHE, DPC, k>(t, r, s);
                 }
             });
+            if constexpr (rest_chunk_index<Cfg, ECACHE, DPC>(c) < NBAR) __builtin_amdgcn_s_barrier();
         }
     });
+    static_for<rest_chunk_index<Cfg, ECACHE, DPC>(NCHUNK), (NBAR > rest_chunk_index<Cfg, ECACHE, DPC>(NCHUNK) ? NBAR : rest_chunk_index<Cfg, ECACHE, DPC>(NCHUNK))>([&](auto) { __builtin_amdgcn_s_barrier(); });
     static_for<0, Cfg::NI>([&](auto I) {
         constexpr int i = decltype(I)::value;
         if constexpr (Cfg::own_mask(i) == ALL) s.jaci[i] = s.jac; // dof[i] == maxdof: no padding (vegas/montecarlo.jl:82)
@@ -804,7 +829,12 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 #else
         acc[0] += wh[0] * 1e-300;
 #endif
+#ifdef MCI_ABL_NOPARK // timing only
+        if constexpr (SPLIT) acc[0] += wh[0] * 1e-300 + (double)(s.bin[0] ^ s.bin[Cfg::NDRAW - 1]) * 1e-300;
+        if constexpr (false) {
+#else
         if constexpr (SPLIT) { // park what the other tiles need: coalesced (lane == consecutive sample) 8- and 4-byte stores
+#endif
             const i64 idx = wi.lb * a.neval_per_block + n;
             static_for<0, Cfg::NI>([&](auto I) { a.tile_w[decltype(I)::value * a.tile_stride + idx] = wh[decltype(I)::value]; });
             constexpr int NWORD = tdraw_words<Cfg>(), PER = tdraw_per<Cfg>(), BITS = tdraw_bits<Cfg>();
@@ -820,7 +850,30 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             static_for<0, NWORD>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = word[decltype(J)::value]; });
         }
     };
-    if constexpr (PH > 0) {
+    if constexpr (PH == 1 && MCI_STAGGER != 0) {
+        // Staggered schedule: the upper half of the workgroup's waves runs the same (gather phase | rest phase + integrand) sequence
+        // ONE PHASE LATER than the lower half.  Every phase holds the same number of barriers (the rest phase carries NBAR bare ones), so
+        // the barriers still keep the gathering waves on the same one or two tables -- but while one wave of a SIMD waits for the
+        // texture pipe, the other one is in its VALU/LDS phase instead of queueing for the same pipe.
+        constexpr int NBAR = gather_phase_barriers<Cfg, EC, DPC>();
+        const i64 n0 = (i64)slice * T + tid, first = (i64)slice * T;
+        const i64 jmax = first < a.neval_per_block ? (a.neval_per_block - first + stride - 1) / stride : 0; // samples of lane 0
+        const bool late = __builtin_amdgcn_readfirstlane(tid >> 6) >= (T >> 7);
+        if (late)
+            for (int b = 0; b < NBAR; ++b) __builtin_amdgcn_s_barrier();
+        for (i64 j = 0; j < jmax; ++j) {
+            Sample<Cfg> sm;
+            const i64 n = n0 + j * stride;
+            u64 index = (u64)(B * a.neval_per_block + (n < a.neval_per_block ? n : 0));
+            draw_gather_phase<Cfg, EC, KV, DPC, 1>(t, keys, stream, &index, &sm);
+            __builtin_amdgcn_sched_barrier(0);
+            draw_rest_phase<Cfg, EC, KV, DPC, NBAR>(t, keys, stream, index, sm);
+            if (n < a.neval_per_block) process(n, sm);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!late)
+            for (int b = 0; b < NBAR; ++b) __builtin_amdgcn_s_barrier();
+    } else if constexpr (PH > 0) {
         // the same number of trips for every thread of the workgroup (barriers inside): lanes past the end of the block redo
         // their last valid sample and drop it
         const i64 n0 = (i64)slice * T + tid, first = (i64)slice * T;

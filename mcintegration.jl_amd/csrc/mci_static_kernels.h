@@ -225,8 +225,21 @@ __device__ inline double block_prefix(const double *v, double *out, int n, doubl
     return out[n - 1];
 }
 
-// LDS doubles train_leaf needs for a leaf of n bins: d[n+4] | sg[n+1] | wa[n+1] | wj[n+1] (ints: half a double each), rounded up
-__host__ __device__ inline int train_lds_doubles(int n) { return (n + 4) + (n + 1) + (n + 1) + (n + 2) / 2 + 2; }
+// LDS doubles train_leaf needs for a leaf of n bins: d[n+kWalkPad] | sg[n+1] | wa[n+kWalkPad] (+ alignment)
+enum { kWalkPad = 64 }; // zeros behind d[]: the serial loops read 16 bins at a time, two trips ahead
+__host__ __device__ inline int train_lds_doubles(int n) { return (n + kWalkPad) + (n + 2) + (n + kWalkPad) + 2; }
+
+// Julia's sum() over a histogram-length vector (common.jl:72, variable.jl:226) is mapreduce_impl's `@simd` loop below its pairwise
+// block size of 1024: a vectorised reduction whose association is the CPU's (lanes x interleave), not left to right.  Oracle and
+// device fix the AVX2 shape: 16 interleaved partial sums (element i -> partial i mod 16, each left to right), folded
+// p[l] += p[l + h] for h = 8, 4, 2, 1.  Called by every thread of the workgroup; every 16-lane group computes the total for itself.
+__device__ inline double sum16(const double *v, int n) {
+    double s = 0.0;
+    for (int i = threadIdx.x & 15; i < n; i += 16) s += v[i];
+#pragma unroll
+    for (int h = 8; h >= 1; h >>= 1) s += __shfl_down(s, h, 16);
+    return __shfl(s, 0, 16);
+}
 
 struct TrainArgs {
     const LeafDev *leaves;
@@ -246,6 +259,112 @@ struct TrainArgs {
     double *iter_log_base;
 };
 
+// Sixteen bins of the refinement walk on ONE lane (variable.jl:228-232, bin-major).  On entry acc = acc_f AFTER bin 0 of the trip was
+// consumed; per bin:  rec[j] = acc_f;  while acc_f >= f_ninc: acc_f -= f_ninc;  acc_f += avg_f[j + 1]  (vnext = the first bin of
+// the next trip).  Written in ISA because the point is the instruction count and the branch round trips of a chain that one wave
+// issues alone: both decisions of a bin (`one new point?`, `a second one?`) are computed before the first branch, and the sums
+// each outcome needs (acc_f + next, acc_f - f_ninc + next) are formed while the compare is in flight -- the same floating-point
+// operations on the same operands as the reference's loop, only issued early and the unused one dropped.  More than one new
+// point per bin (narrow peaks, early iterations) takes the out-of-line loop.   %0 acc_f  %1 a1  %2 second decision  %3 f_ninc
+// %4 LDS address of rec[j0]  %5..%20 the trip's bins  %21 the next trip's first bin
+#define MCI_WALK_BIN(K, OFF, DN)                                                                                                       \
+    "ds_write_b64 %4, %0 offset:" OFF "\n\tv_cmp_ge_f64 vcc, %0, %3\n\tv_add_f64 %1, %0, -%3\n\tv_cmp_ge_f64_e64 %2, %1, %3\n\t"          \
+    "v_add_f64 %0, %0, " DN "\n\ts_cbranch_vccz .Lwd" K "_%=\n\tv_add_f64 %0, %1, " DN "\n\ts_cmp_lg_u64 %2, 0\n\t"                      \
+    "s_cbranch_scc1 .Lwr" K "_%=\n.Lwd" K "_%=:\n\t"
+#define MCI_WALK_MORE(K, DN)                                                                                                           \
+    ".Lwr" K "_%=:\n\tv_add_f64 %1, %1, -%3\n\tv_cmp_ge_f64 vcc, %1, %3\n\ts_cbranch_vccnz .Lwr" K "_%=\n\tv_add_f64 %0, %1, " DN "\n\t"   \
+    "s_branch .Lwd" K "_%=\n\t"
+__device__ __forceinline__ void walk_bins16(double &acc, const double (&v)[16], const double vnext, const double f, const unsigned rec_addr) {
+    double a1;
+    unsigned long long c2;
+    asm volatile(
+                 MCI_WALK_BIN("0", "0", "%6")
+                 MCI_WALK_BIN("1", "8", "%7")
+                 MCI_WALK_BIN("2", "16", "%8")
+                 MCI_WALK_BIN("3", "24", "%9")
+                 MCI_WALK_BIN("4", "32", "%10")
+                 MCI_WALK_BIN("5", "40", "%11")
+                 MCI_WALK_BIN("6", "48", "%12")
+                 MCI_WALK_BIN("7", "56", "%13")
+                 MCI_WALK_BIN("8", "64", "%14")
+                 MCI_WALK_BIN("9", "72", "%15")
+                 MCI_WALK_BIN("10", "80", "%16")
+                 MCI_WALK_BIN("11", "88", "%17")
+                 MCI_WALK_BIN("12", "96", "%18")
+                 MCI_WALK_BIN("13", "104", "%19")
+                 MCI_WALK_BIN("14", "112", "%20")
+                 MCI_WALK_BIN("15", "120", "%21")
+                 "s_branch .Lwend_%=\n\t"
+                 MCI_WALK_MORE("0", "%6")
+                 MCI_WALK_MORE("1", "%7")
+                 MCI_WALK_MORE("2", "%8")
+                 MCI_WALK_MORE("3", "%9")
+                 MCI_WALK_MORE("4", "%10")
+                 MCI_WALK_MORE("5", "%11")
+                 MCI_WALK_MORE("6", "%12")
+                 MCI_WALK_MORE("7", "%13")
+                 MCI_WALK_MORE("8", "%14")
+                 MCI_WALK_MORE("9", "%15")
+                 MCI_WALK_MORE("10", "%16")
+                 MCI_WALK_MORE("11", "%17")
+                 MCI_WALK_MORE("12", "%18")
+                 MCI_WALK_MORE("13", "%19")
+                 MCI_WALK_MORE("14", "%20")
+                 MCI_WALK_MORE("15", "%21")
+                 ".Lwend_%=:"
+                 : "+v"(acc), "=&v"(a1), "=&s"(c2)
+                 : "v"(f), "v"(rec_addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+                   "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(vnext)
+                 : "vcc", "scc", "memory");
+}
+
+// The same sixteen bins without a branch, for trips in which no bin yields more than one new point (the rule once the grid has
+// adapted): `acc_f -= f_ninc` runs under the compare's own lane mask (v_cmpx writes EXEC), six instructions per bin.  One wave
+// alone issues an instruction every ~4-5 ns whatever it is, so the instruction count is the cost (a variant that forms both outcomes
+// ahead of the compare has a shorter chain, one instruction more, and measured the same).  m = the largest acc_f left after a
+// subtraction: m >= f_ninc means some bin needed a second one -- the caller then redoes the trip with walk_bins16 from the saved
+// acc_f (identical records where both are valid).   %0 acc_f  %1 m  %2 saved EXEC  %3 f_ninc  %4 rec  %5..%21 bins
+#define MCI_WALK_BIN1(OFF, DN)                                                                                                         \
+    "ds_write_b64 %4, %0 offset:" OFF "\n\tv_cmpx_ge_f64 vcc, %0, %3\n\tv_add_f64 %0, %0, -%3\n\ts_mov_b64 exec, %2\n\t"                  \
+    "v_max_f64 %1, %1, %0\n\tv_add_f64 %0, %0, " DN "\n\t"
+__device__ __forceinline__ void walk_bins16_single(double &acc, double &m, const double (&v)[16], const double vnext, const double f, const unsigned rec_addr) {
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %2, exec\n\tv_mov_b64 %1, 0\n\t"
+                 MCI_WALK_BIN1("0", "%6")
+                 MCI_WALK_BIN1("8", "%7")
+                 MCI_WALK_BIN1("16", "%8")
+                 MCI_WALK_BIN1("24", "%9")
+                 MCI_WALK_BIN1("32", "%10")
+                 MCI_WALK_BIN1("40", "%11")
+                 MCI_WALK_BIN1("48", "%12")
+                 MCI_WALK_BIN1("56", "%13")
+                 MCI_WALK_BIN1("64", "%14")
+                 MCI_WALK_BIN1("72", "%15")
+                 MCI_WALK_BIN1("80", "%16")
+                 MCI_WALK_BIN1("88", "%17")
+                 MCI_WALK_BIN1("96", "%18")
+                 MCI_WALK_BIN1("104", "%19")
+                 MCI_WALK_BIN1("112", "%20")
+                 MCI_WALK_BIN1("120", "%21")
+                 : "+v"(acc), "=&v"(m), "=&s"(sv)
+                 : "v"(f), "v"(rec_addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+                   "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(vnext)
+                 : "vcc", "memory");
+}
+#undef MCI_WALK_BIN
+#undef MCI_WALK_MORE
+#undef MCI_WALK_BIN1
+
+__device__ __forceinline__ void walk_trip(double &acc, const double (&v)[16], const double vnext, const double f, const unsigned rec_addr) {
+    const double acc0 = acc;
+    double m;
+    walk_bins16_single(acc, m, v, vnext, f, rec_addr);
+    if (__builtin_amdgcn_ballot_w64(!(m < f)) != 0ull) { // some bin of the trip yields two or more points: the general form, from the start of the trip
+        acc = acc0;
+        walk_bins16(acc, v, vnext, f, rec_addr);
+    }
+}
+
 // Dist.train! for one leaf by one workgroup, then clearStatistics!.  h: the merged histogram (global or LDS);
 // hclear: its home in `packed`, reset for the next iteration.  sm: [4*N + 16] doubles of LDS.
 __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hclear, double *sm, double *ps, int &bad, double &ssum,
@@ -253,10 +372,9 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
                                   int *__restrict__ status) {
     const int tid = threadIdx.x, T = blockDim.x;
     const int N = L.nbin;
-    double *d = sm;                     // [N+4] smoothed / rescaled distribution (+4 window padding)
-    double *sg = sm + N + 4;            // [N+1] old grid staged in LDS
-    double *wa = sg + N + 1;            // [N+1] acc_f recorded per new grid point
-    int *wj = (int *)(wa + N + 1);      // [N+1] j recorded per new grid point
+    double *d = sm;                     // [N+kWalkPad] smoothed / rescaled distribution, zeros behind it
+    double *sg = sm + N + kWalkPad;     // [N+1] old grid staged in LDS
+    double *wa = sg + N + 2;            // [N+kWalkPad] scan form: prefix sums; serial form: acc_f after each bin
     if (tid == 0) bad = 0;
     __syncthreads();
     for (int i = tid; i < N; i += T) {
@@ -272,6 +390,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
     if (L.kind == 0) {
         double *g = edges + L.eoff;
         for (int i = tid; i <= N; i += T) sg[i] = g[i];
+        if (tid < kWalkPad) d[N + tid] = 0.0;
         // smooth(hist, 6)  common.jl:43-54
         for (int i = tid; i < N; i += T) {
             double v;
@@ -282,20 +401,9 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             d[i] = v;
         }
         __syncthreads();
-        // rescale  common.jl:67-82.  sum(dist): fixed-order workgroup scan (the serial variant sums left to
-        // right like the oracle; Julia's own sum() is pairwise/SIMD, so no order is "the reference's")
+        // rescale  common.jl:67-82
         if (N > 1) {
-            if (serial_walk) {
-                if (tid == 0) {
-                    double s = 0.0;
-                    for (int i = 0; i < N; ++i) s += d[i];
-                    ssum = s;
-                }
-                __syncthreads();
-            } else {
-                ssum = block_prefix(d, wa, N, ps);
-            }
-            const double s = ssum;
+            const double s = sum16(d, N); // :72
             for (int i = tid; i < N; i += T) {
                 double v = d[i] / s;
                 if (v > 0 && v <= 0.99999999) v = pow(-(1 - v) / log(v), L.alpha);
@@ -312,8 +420,6 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
         // kept in the reference's order (bit-for-bit the oracle's); lane 0 runs it with a 4-deep register
         // window over d[] so that no LDS latency sits on the dependency chain, and only records (j, acc_f)
         // per new grid point.  The divisions/interpolations (:233) are then done by all lanes.
-        if (tid < 4) d[N + tid] = 0.0; // window padding
-        __syncthreads();
         if (!serial_walk) {
             // Parallel form of the same walk (default).  With C[j] = sum_{k<=j} avg_f[k] the loop :228-232 leaves,
             // at new grid point i,  j = min{ j : C[j] >= (i-1)*f_ninc }  and  acc_f = C[j] - (i-1)*f_ninc :
@@ -342,47 +448,75 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             for (int i = tid; i < N; i += T) hclear[i] = 1.0e-10; // clearStatistics!  variable.jl:238 -> :565
             return;
         }
+        // Serial form: the reference's recurrence, floating-point operation for operation (bit-for-bit the oracle's).  Bin-major:
+        // consuming avg_f[j] and then emitting new points while acc_f >= f_ninc is the same sequence of operations and decisions
+        // as `for i: while acc_f < f_ninc: j += 1; acc_f += avg_f[j]; end; acc_f -= f_ninc` (:227-232).  Lane 0 runs only the
+        // chain -- add, compare, subtract -- and records acc_f after each bin (walk_bins16); how many points a bin yields, their
+        // acc_f (the same subtractions again), the division and the interpolation (:233) are recomputed from that record by all
+        // lanes.  acc_f <= (N + 1) f_ninc, so a subtraction always makes progress.
+        const double f_ninc = sum16(d, N) / (double)N; // :226
         if (tid == 0) {
-            double s = 0.0;
-            for (int i = 0; i < N; ++i) s += d[i];
-            const double f_ninc = s / (double)N;
-            // (measured on MI355X, N = 999: ~105 us per leaf against 18 us for the scan form -- one wave issues a dependent
-            // VALU -> compare -> branch step every ~100 cycles whatever the code shape; a scalar-branch state machine was 135 us)
-            int j = 0;
-            double acc_f = 0.0;
-            double w0 = d[0], w1 = d[1], w2 = d[2], w3 = d[3];
-            for (int i = 2; i <= N; ++i) {
-                while (acc_f < f_ninc && j < N) {
-                    acc_f += w0; // acc_f += avg_f[j]  (:229-230)
-                    w0 = w1;
-                    w1 = w2;
-                    w2 = w3;
-                    w3 = d[j + 4];
-                    j += 1;
+            if (f_ninc > 0.0 && isfinite(f_ninc)) {
+                const unsigned rec = (unsigned)(size_t)wa;
+                double va[16], vb[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) va[k] = d[k];
+                double acc_f = 0.0 + va[0]; // :222, and the first `j += 1; acc_f += avg_f[j]` (:229-230)
+                for (int jb = 0; jb < N; jb += 32) { // two trips per turn, the next trip's bins are loaded before this trip's chain
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) vb[k] = d[jb + 16 + k];
+                    walk_trip(acc_f, va, vb[0], f_ninc, rec + 8u * (unsigned)jb);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) va[k] = d[jb + 32 + k];
+                    walk_trip(acc_f, vb, va[0], f_ninc, rec + 8u * (unsigned)(jb + 16));
                 }
-                acc_f -= f_ninc; // :232
-                wa[i - 1] = acc_f;
-                wj[i - 1] = j;
+            } else {
+                atomicOr(status, ST_RESCALE_NONFINITE);
             }
         }
         __syncthreads();
-        for (int i = tid; i <= N; i += T) {
-            double v;
-            if (i == 0 || i == N) v = sg[i]; // :217-218, :235
-            else {
-                const int j = wj[i];
-                v = sg[j] - (wa[i] / d[j - 1]) * (sg[j] - sg[j - 1]); // :233
+        {
+            if (!(f_ninc > 0.0 && isfinite(f_ninc))) return;
+            // lane t owns the bins [t*per, (t+1)*per): count their new points, exclusive scan over the lanes, then write them
+            const int lane = tid & 63, wave = tid >> 6;
+            const int per = (N + T - 1) / T, b = min(N, tid * per), e = min(N, b + per);
+            int cnt = 0;
+            for (int j = b; j < e; ++j)
+                for (double a = wa[j]; a >= f_ninc; a -= f_ninc) cnt += 1;
+            int x = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(x, off, 64);
+                if (lane >= off) x += y;
             }
-            g[i] = v;
+            int *pw = (int *)ps;
+            if (lane == 63) pw[wave] = x;
+            __syncthreads();
+            int base = 0, total = 0;
+            for (int w = 0; w < (T >> 6); ++w) {
+                if (w < wave) base += pw[w];
+                total += pw[w];
+            }
+            int i = 1 + base + x - cnt; // first new grid point of this lane's bins (0-based index into the new grid)
+            for (int j = b; j < e; ++j)
+                for (double a = wa[j]; a >= f_ninc;) {
+                    a -= f_ninc; // :232
+                    if (i < N) g[i] = sg[j + 1] - (a / d[j]) * (sg[j + 1] - sg[j]); // :233 (1-based j of the reference = j + 1)
+                    i += 1;
+                }
+            for (int k = 1 + total + tid; k < N; k += T) g[k] = sg[N]; // (points the walk did not reach: rounding at the very end)
+            if (tid == 0) {
+                g[0] = sg[0]; // :217
+                g[N] = sg[N]; // :218, :235
+            }
         }
     } else {
         // train!(Discrete)  variable.jl:369-382 : rescale (no smoothing), normalise, prefix sum
         double *acc = dacc + L.eoff, *dist = ddist + L.doff;
+        const double s = N > 1 ? sum16(h, N) : 1.0; // rescale's sum(dist), common.jl:72
         if (tid == 0) {
             int lbad = 0;
             if (N > 1) {
-                double s = 0.0;
-                for (int i = 0; i < N; ++i) s += h[i];
                 for (int i = 0; i < N; ++i) {
                     double v = h[i] / s;
                     if (v > 0 && v <= 0.99999999) v = pow(-(1 - v) / log(v), L.alpha);

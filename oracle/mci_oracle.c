@@ -114,12 +114,24 @@ void mcio_smooth(const double *dist, long n, double factor, double *out) {
 
 /* ref: common.jl:67-82.  Output is NOT renormalised (:81-82).  Returns 1/2 where the
  * reference's @assert (:71 / :79) fires.  sum() is taken left-to-right. */
+/* Julia's sum() over a Vector{Float64} shorter than pairwise_blocksize = 1024 (Base.mapreduce_impl, base/reduce.jl) is an
+ * `@simd` loop: LLVM vectorises the reduction, so its association is the host CPU's (vector lanes x interleave), not left to
+ * right -- the reference has no single order.  The oracle (and the device) fix the AVX2 shape: 16 interleaved partial sums
+ * (element i -> partial i mod 16, each left to right), folded p[l] += p[l + h] for h = 8, 4, 2, 1.
+ * Used where the reference sums a histogram-length vector: rescale (common.jl:72) and f_ninc (variable.jl:226). */
+double mcio_sum16(const double *v, long n) {
+    double p[16] = {0};
+    for (long i = 0; i < n; ++i) p[i & 15] += v[i];
+    for (int h = 8; h >= 1; h >>= 1)
+        for (int l = 0; l < h; ++l) p[l] += p[l + h];
+    return p[0];
+}
+
 int mcio_rescale(double *dist, long n, double alpha) {
     if (n == 1) return 0; /* :68-70 */
     for (long i = 0; i < n; ++i)
         if (!(dist[i] > 0)) return 1; /* :71 */
-    double s = 0.0;
-    for (long i = 0; i < n; ++i) s += dist[i];
+    const double s = mcio_sum16(dist, n);
     for (long i = 0; i < n; ++i) dist[i] /= s; /* :72 */
     for (long i = 0; i < n; ++i)               /* :74-78 */
         if (dist[i] > 0 && dist[i] <= 0.99999999) dist[i] = pow(-(1 - dist[i]) / log(dist[i]), alpha);
@@ -148,9 +160,7 @@ int mcio_train_continuous(double *grid, long npts, double *hist, double alpha) {
     newgrid[npts - 1] = grid[npts - 1]; /* :218 */
     long j = 0;                         /* :221 */
     double acc_f = 0.0;                 /* :222 */
-    double s = 0.0;
-    for (long i = 0; i < N; ++i) s += d[i];
-    double f_ninc = s / (double)N;      /* :226 */
+    double f_ninc = mcio_sum16(d, N) / (double)N; /* :226 */
     for (long i = 2; i <= npts - 1; ++i) { /* :227 (1-based i) */
         while (acc_f < f_ninc) {           /* :228 */
             j += 1;                        /* :229 */

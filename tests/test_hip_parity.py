@@ -233,12 +233,12 @@ def test_full_integrate_matches_oracle(oracle, name, walk, monkeypatch):
 
 
 def test_full_integrate_default_walk_at_large_launches_is_the_reference_recurrence(oracle, monkeypatch):
-    """The DEFAULT refinement walk: once an iteration's sample launch is long enough to hide its ~0.1 ms (>= 2^28 samples per
-    rank) train! runs the reference's serial recurrence (variable.jl:227-234), so whole runs agree with the oracle at the 1e-6
-    level of the serial walk; below that size the prefix-scan form keeps the launch-bound regime at 50 us per iteration
+    """The DEFAULT refinement walk: once an iteration's sample launch is long enough to hide its ~35 us (>= 2^26 samples per
+    rank: the headline configuration's 1e8 included) train! runs the reference's serial recurrence (variable.jl:227-234), so whole
+    runs agree with the oracle at the 1e-6 level of the serial walk; below that size the prefix-scan form keeps the launch-bound regime at 50 us per iteration
     (1e-4 level, test_full_integrate_matches_oracle[prefix]).  Engine.set_train_walk("serial") asks for the recurrence at any size."""
     monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
-    neval = (1 << 28) + 16
+    neval = (1 << 26) + 16
     c, cfg, eng, ocfg = make("c1_log_over_sqrt", oracle)
     r = eng.integrate("vegas", neval=neval, niter=4, block=16, seed=SEED)
     o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=neval, niter=4, block=16, seed=SEED, nthreads=16)

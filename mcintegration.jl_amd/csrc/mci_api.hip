@@ -167,6 +167,11 @@ struct mci_problem {
     unsigned *d_loop = nullptr;
     bool graph_mode = false; // while capturing: no event records, iteration/log row come from d_loop
     int threads = 256, wg_per_block = 0; // 0 = auto
+    // split-all :vegas (many independent grids): plan A = 1024-thread workgroups (4 waves/SIMD) with the draws in their natural
+    // order -- taken when the integrand leaves the sample pass within 128 VGPRs (it consumes the draws as they come); plan B = 512
+    // threads with the dimension-major gather phase.  threads_vegas = 0: the vegas kernel follows `threads`
+    int threads_vegas = 0;
+    bool vegas_plan_a = false;
     // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
     // launch before it is long enough to hide its ~35 us per iteration (>= kSerialWalkSamples samples or chain steps on this
     // rank: 2 % of the headline iteration), the prefix-scan form below that; mci_set_train_walk / MCI_TRAIN_SERIAL=1 | 0 force one
@@ -589,7 +594,8 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         s.leaf_ecoff.assign(p->leaves.size(), -1);
         s.ec_doubles = 0;
         if (s.split_all) {
-            const int64_t budget = (lim1 - fixed) / 8;
+            int64_t budget = (lim1 - fixed) / 8;
+            if (const char *e = getenv("MCI_EC_BUDGET")) budget = atoll(e) / 8 < budget ? atoll(e) / 8 : budget; // bytes; diagnostic override
             for (size_t l = 0; l < p->leaves.size(); ++l) {
                 const Leaf &L = p->leaves[l];
                 if (L.kind != MCI_CONTINUOUS || s.ec_doubles + L.nbin + 1 > budget) continue;
@@ -634,6 +640,16 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         if (const char *e = getenv("MCI_L1_PHASE")) s.l1_phase = (mode >= 2 && atoi(e) > 0) ? (atoi(e) > 4 ? 4 : atoi(e)) : 0;
         // one big workgroup per CU owns its LDS
         if (p->lds_bytes > lim0) p->threads = 512; // measured (tools/c4_sweep.py): 2 waves/SIMD beat 1 fat and 4 spilling ones
+        // Split-all, plan A: with the bins packed as they are drawn the 32-grid Genz pass needs 122 VGPRs without the gather phase
+        // (209 with it), i.e. four waves per SIMD in one 1024-thread workgroup per CU: 6.97 -> 6.63 ms per 1e8 samples (tools/c4_abenv.sh).
+        // compile_solver falls back to plan B when the integrand does not fit 128 registers at that size (scratch in the code object).
+        if (s.split_all && s.l1_phase == 1 && !getenv("MCI_L1_PHASE") && !getenv("MCI_THREADS")) {
+            p->vegas_plan_a = true;
+            p->threads_vegas = 1024;
+            s.l1_phase = 0;
+        }
+        if (const char *e = getenv("MCI_THREADS")) // diagnostic override of the default workgroup size
+            if (atoi(e) >= 64 && atoi(e) <= 1024 && atoi(e) % 64 == 0) p->threads = atoi(e);
     }
     p->nstat = 2 * s.nobs + 2 + Nd;
     p->packed_n = p->nstat + s.nbin + 2 * p->npa; // [statistics | histograms | propose | accept]
@@ -743,8 +759,11 @@ int mci_set_measure_host(mci_problem *p, mci_host_measure_fn fn, void *user) {
 int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
     if (threads > 0) {
         if (threads % 64 || threads > 1024) return fail(MCI_ERR_INVALID, "threads per workgroup must be a multiple of 64, <= 1024");
-        if (threads != p->threads) {
+        if (threads != p->threads || p->threads_vegas) {
             p->threads = threads;
+            if (p->vegas_plan_a) p->shape.l1_phase = 1; // an explicit size: the vegas kernel follows it, with the gather phase
+            p->vegas_plan_a = false;
+            p->threads_vegas = 0;
             drop_modules(p);
         }
     }
@@ -761,12 +780,22 @@ static int compile_solver(mci_problem *p, int solver) {
         for (int i = 0; i < p->ni; ++i)
             if (p->shape.obs_bin_draw[i] < 0 && p->shape.obs_nbin[i] != p->shape.ncomp)
                 return fail(MCI_ERR_INVALID, "the default measure can only handle observable as Vector with %d scalar elements!", p->ni);
-    const std::string src = mcijit::generate_source(p->shape, solver);
+    std::string src = mcijit::generate_source(p->shape, solver);
     std::vector<char> code;
     std::string log;
     bool cached = false;
-    int rc = mcijit::compile(src, p->threads, code, log, cached, &p->code_object[solver]);
+    int T = solver == MCI_VEGAS && p->threads_vegas ? p->threads_vegas : p->threads;
+    int rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]);
     if (rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
+    if (solver == MCI_VEGAS && p->vegas_plan_a && mcijit::kernel_scratch_bytes(code, "mci_vegas_batch") != 0) {
+        // the integrand keeps too many draws live for 128 VGPRs: plan B (512 threads, dimension-major gather phase)
+        p->vegas_plan_a = false;
+        p->threads_vegas = 0;
+        p->shape.l1_phase = 1;
+        src = mcijit::generate_source(p->shape, solver);
+        T = p->threads;
+        if ((rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
+    }
     if (!p->ctx->offline) {
         static const char *const names[3] = {"mci_vegas_batch", "mci_vegasmc_chains", "mci_mcmc_chains"};
         HIPCHK(hipSetDevice(p->ctx->device));
@@ -774,7 +803,7 @@ static int compile_solver(mci_problem *p, int solver) {
             // a cached code object that does not load (truncated by a crash, foreign file): drop it and compile afresh, once
             if (!cached) return fail(MCI_ERR_HIP, "hipModuleLoadData failed for a freshly compiled code object");
             unlink(p->code_object[solver].c_str());
-            if ((rc = mcijit::compile(src, p->threads, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
+            if ((rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
             HIPCHK(hipModuleLoadData(&p->module[solver], code.data()));
         }
         HIPCHK(hipModuleGetFunction(&p->f_solver[solver], p->module[solver], names[solver]));
@@ -856,7 +885,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     if ((rc = flush_merge(p))) return rc; // a previous batch nobody looked at: merge it (resets the global histogram)
     HIPCHK(hipSetDevice(p->ctx->device));
     const auto &s = p->shape;
-    const int T = p->threads;
+    const int T = solver == MCI_VEGAS && p->threads_vegas ? p->threads_vegas : p->threads;
     int64_t units = nevalperblock; // lanes of useful work per block
     if (solver != MCI_VEGAS && (block_hi > 4096 || iteration >= 131072 || iteration < 0))
         return fail(MCI_ERR_INVALID, "chain solvers address a chain by (block < 4096, iteration < 131072): got block_hi=%lld, iteration=%d",

@@ -328,21 +328,59 @@ template <class Cfg> constexpr double jac_scale_product(unsigned long long mask,
 }
 constexpr int kJacGroup = 8;
 
+// draws whose histogram is replayed by mci_vegas_tiles (adaptive and covered by some integrand; tile >= 1, or every tile in
+// split-all mode), in draw order
+template <class Cfg> constexpr bool is_tdraw(int k) {
+    return Cfg::NTILE > 1 && Cfg::leaf_adapt(Cfg::draw_leaf(k)) != 0 && Cfg::cover_mask(k) != 0ull && Cfg::leaf_tile(Cfg::draw_leaf(k)) >= (Cfg::SPLIT_ALL != 0 ? 0 : 1);
+}
+template <class Cfg> constexpr int tdraw_count() {
+    int n = 0;
+    for (int k = 0; k < Cfg::NDRAW; ++k) n += is_tdraw<Cfg>(k) ? 1 : 0;
+    return n;
+}
+template <class Cfg> constexpr int tdraw_pos(int k) { // position of draw k in that list
+    int n = 0;
+    for (int j = 0; j < k; ++j) n += is_tdraw<Cfg>(j) ? 1 : 0;
+    return n;
+}
+// parked bins are packed TDRAW_PER to a 32-bit word, TDRAW_BITS bits each (10 bits for the default 999-bin grids: 3 per word)
+template <class Cfg> constexpr int tdraw_bits() {
+    int mx = 2;
+    for (int k = 0; k < Cfg::NDRAW; ++k)
+        if (is_tdraw<Cfg>(k) && Cfg::leaf_nbin(Cfg::draw_leaf(k)) > mx) mx = Cfg::leaf_nbin(Cfg::draw_leaf(k));
+    int b = 1;
+    while ((1 << b) < mx) ++b;
+    return b;
+}
+template <class Cfg> constexpr int tdraw_per() { return 32 / tdraw_bits<Cfg>(); }
+template <class Cfg> constexpr int tdraw_words() { return (tdraw_count<Cfg>() + tdraw_per<Cfg>() - 1) / tdraw_per<Cfg>(); }
+
+// blockIdx -> (statistical block, slice of the block, histogram tile)
 // all NDRAW draws of one sample + Jacobians.  jaci[i] = product of 1/prob over integrand i's own draws
 // ( = weights*padding_probability*jac of vegas/montecarlo.jl:152 up to rounding ).
 template <class Cfg> struct Sample {
     double x[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
     int bin[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
     double pj[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1]; // 1/prob per draw (dead-code eliminated where unused)
+    // several histogram tiles: the bins of the replayed draws, packed as they are drawn (tdraw_bits() bits each) -- 32 separate
+    // bin registers kept until the sample is parked cost the 32-grid sample pass its third and fourth wave per SIMD
+    u32 word[tdraw_words<Cfg>() > 0 ? tdraw_words<Cfg>() : 1];
     double jac;
     double jaci[Cfg::NI];
 };
 
+template <class Cfg, int K> __device__ __forceinline__ void pack_bin(Sample<Cfg> &s) {
+    if constexpr (is_tdraw<Cfg>(K)) {
+        constexpr int m = tdraw_pos<Cfg>(K), PER = tdraw_per<Cfg>(), BITS = tdraw_bits<Cfg>();
+        s.word[m / PER] |= (u32)s.bin[K] << (BITS * (m % PER)); // (the words start at zero: the gather phase draws out of order)
+    }
+}
 template <class Cfg, bool ECACHE = false, bool KV = false, int DPC = 2> __device__ __forceinline__ void draw_sample(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index, Sample<Cfg> &s) {
     const u32 ilo = (u32)index, ihi = (u32)(index >> 32);
     constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
     s.jac = 1.0;
     static_for<0, Cfg::NI>([&](auto I) { s.jaci[decltype(I)::value] = 1.0; });
+    static_for<0, tdraw_words<Cfg>()>([&](auto J) { s.word[decltype(J)::value] = 0u; });
     static_for<0, (Cfg::NDRAW + DPC - 1) / DPC>([&](auto C) {
         constexpr int c = decltype(C)::value;
         const u32x4 r = philox4x32_10<KV>(ilo, ihi, (u32)c, stream, keys);
@@ -352,6 +390,7 @@ template <class Cfg, bool ECACHE = false, bool KV = false, int DPC = 2> __device
                 const double y1 = block_u12<DPC, decltype(H)::value>(r);
                 double raw;
                 draw_leaf<Cfg, k, true, ECACHE>(t, y1, s.x[k], raw, s.bin[k]);
+                pack_bin<Cfg, k>(s);
                 s.pj[k] = raw * jac_scale<Cfg>(k);
                 s.jac *= raw; // jac /= prob   vegas/montecarlo.jl:126 (scale applied below)
                 static_for<0, Cfg::NI>([&](auto I) {
@@ -395,6 +434,9 @@ template <class Cfg, bool ECACHE> constexpr int gather_draw_count() {
     for (int k = 0; k < Cfg::NDRAW; ++k) n += is_gather_draw<Cfg, ECACHE>(k) ? 1 : 0;
     return n;
 }
+#ifndef MCI_TRIP_BARRIER
+#define MCI_TRIP_BARRIER 0
+#endif
 #ifndef MCI_STAGGER
 #define MCI_STAGGER 0
 #endif
@@ -415,6 +457,7 @@ template <class Cfg, bool ECACHE, int DPC, int K, class SampleT> __device__ __fo
     const double y1 = block_u12<DPC, K % DPC>(r);
     double raw;
     draw_leaf<Cfg, K, true, ECACHE>(t, y1, s.x[K], raw, s.bin[K]);
+    pack_bin<Cfg, K>(s);
     const double pj = raw * jac_scale<Cfg>(K);
     s.pj[K] = pj;
     s.jac *= pj; // jac /= prob   vegas/montecarlo.jl:126
@@ -444,6 +487,7 @@ template <class Cfg, bool ECACHE, bool KV, int DPC, int S> __device__ __forceinl
         constexpr int q = decltype(Ss)::value;
         s[q].jac = 1.0;
         static_for<0, Cfg::NI>([&](auto I) { s[q].jaci[decltype(I)::value] = 1.0; });
+        static_for<0, tdraw_words<Cfg>()>([&](auto J) { s[q].word[decltype(J)::value] = 0u; });
     });
     int phase = 0;
     static_for<0, NCHUNK>([&](auto C) {
@@ -463,6 +507,84 @@ template <class Cfg, bool ECACHE, bool KV, int DPC, int S> __device__ __forceinl
             if (phase % MCI_L1_PHASE_CHUNKS == 0) __builtin_amdgcn_s_barrier(); // keeps the waves on the same tables; no data is exchanged
         }
     });
+}
+// The same gather phase for ONE sample per lane, software-pipelined by hand one chunk deep: chunk c's table reads are issued, the
+// workgroup barrier passed, and only then chunk c-1's reads are consumed (x, bin, Jacobian) -- so at most two chunks' loads
+// (edges + fractions) are live at any point instead of the whole phase's, which is what the scheduler does when left alone
+// (13 gathers x 6 registers on C4).  sched_barrier keeps the order.
+#ifndef MCI_GATHER_PIPE
+#define MCI_GATHER_PIPE 0
+#endif
+struct PendingGather {
+    double g0, g1, dy;
+    int iy;
+};
+template <class Cfg, bool ECACHE, int DPC> constexpr int prev_gather_chunk(int c) {
+    for (int j = c - 1; j >= 0; --j)
+        if (chunk_has<Cfg, ECACHE, DPC>(j, true)) return j;
+    return -1;
+}
+template <class Cfg, bool ECACHE, int DPC, int C> __device__ __forceinline__ void finish_gather_chunk(const PendingGather (&pend)[DPC], Sample<Cfg> &s) {
+    constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
+    static_for<0, DPC>([&](auto J) {
+        constexpr int j = decltype(J)::value, k = DPC * C + j;
+        if constexpr (k < Cfg::NDRAW) {
+            if constexpr (is_gather_draw<Cfg, ECACHE>(k)) {
+                const double dx = pend[j].g1 - pend[j].g0;
+                s.x[k] = pend[j].g0 + pend[j].dy * dx;
+                s.bin[k] = pend[j].iy;
+                pack_bin<Cfg, k>(s);
+                const double pj = dx * jac_scale<Cfg>(k);
+                s.pj[k] = pj;
+                s.jac *= pj;
+                static_for<0, Cfg::NI>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    if constexpr (((Cfg::own_mask(i) >> k) & 1ull) && Cfg::own_mask(i) != ALL) s.jaci[i] *= pj;
+                });
+            }
+        }
+    });
+}
+template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ void draw_gather_phase_pipe(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream,
+                                                                                                         const u64 index, Sample<Cfg> &s) {
+    constexpr int NCHUNK = (Cfg::NDRAW + DPC - 1) / DPC;
+    s.jac = 1.0;
+    static_for<0, Cfg::NI>([&](auto I) { s.jaci[decltype(I)::value] = 1.0; });
+    static_for<0, tdraw_words<Cfg>()>([&](auto J) { s.word[decltype(J)::value] = 0u; });
+    PendingGather pend[2][DPC];
+    int phase = 0;
+    static_for<0, NCHUNK>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        if constexpr (chunk_has<Cfg, ECACHE, DPC>(c, true)) {
+            constexpr int slot = [] { int n = 0; for (int j = 0; j < c; ++j) n += chunk_has<Cfg, ECACHE, DPC>(j, true) ? 1 : 0; return n & 1; }();
+            const u32x4 r = philox4x32_10<KV>((u32)index, (u32)(index >> 32), (u32)c, stream, keys);
+            static_for<0, DPC>([&](auto J) {
+                constexpr int j = decltype(J)::value, k = DPC * c + j;
+                if constexpr (k < Cfg::NDRAW) {
+                    if constexpr (is_gather_draw<Cfg, ECACHE>(k)) {
+                        constexpr int leaf = Cfg::draw_leaf(k), N = Cfg::leaf_nbin(leaf), eoff = Cfg::leaf_eoff(leaf);
+                        const double yn = (block_u12<DPC, j>(r) - 1.0) * (double)N;
+                        const int iy = (int)yn;
+                        pend[slot][j].iy = iy;
+                        pend[slot][j].dy = __builtin_amdgcn_fract(yn);
+                        pend[slot][j].g0 = t.E[eoff + iy];
+                        pend[slot][j].g1 = t.E[eoff + iy + 1];
+                    }
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            phase += 1;
+            if (phase % MCI_L1_PHASE_CHUNKS == 0) __builtin_amdgcn_s_barrier();
+            constexpr int pc = prev_gather_chunk<Cfg, ECACHE, DPC>(c);
+            if constexpr (pc >= 0) finish_gather_chunk<Cfg, ECACHE, DPC, pc>(pend[slot ^ 1], s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+    constexpr int last = prev_gather_chunk<Cfg, ECACHE, DPC>(NCHUNK);
+    if constexpr (last >= 0) {
+        constexpr int lslot = [] { int n = 0; for (int j = 0; j < last; ++j) n += chunk_has<Cfg, ECACHE, DPC>(j, true) ? 1 : 0; return n & 1; }();
+        finish_gather_chunk<Cfg, ECACHE, DPC, last>(pend[lslot], s);
+    }
 }
 // the remaining draws of ONE sample (LDS-resident grids, Discrete tables), right before its integrand is evaluated
 // NBAR > 0 (staggered schedule, see vegas_batch): exactly NBAR workgroup barriers are executed inside, one after each of the first
@@ -687,34 +809,6 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
     }
 }
 
-// draws whose histogram is replayed by mci_vegas_tiles (adaptive and covered by some integrand; tile >= 1, or every tile in
-// split-all mode), in draw order
-template <class Cfg> constexpr bool is_tdraw(int k) {
-    return Cfg::NTILE > 1 && Cfg::leaf_adapt(Cfg::draw_leaf(k)) != 0 && Cfg::cover_mask(k) != 0ull && Cfg::leaf_tile(Cfg::draw_leaf(k)) >= (Cfg::SPLIT_ALL != 0 ? 0 : 1);
-}
-template <class Cfg> constexpr int tdraw_count() {
-    int n = 0;
-    for (int k = 0; k < Cfg::NDRAW; ++k) n += is_tdraw<Cfg>(k) ? 1 : 0;
-    return n;
-}
-template <class Cfg> constexpr int tdraw_pos(int k) { // position of draw k in that list
-    int n = 0;
-    for (int j = 0; j < k; ++j) n += is_tdraw<Cfg>(j) ? 1 : 0;
-    return n;
-}
-// parked bins are packed TDRAW_PER to a 32-bit word, TDRAW_BITS bits each (10 bits for the default 999-bin grids: 3 per word)
-template <class Cfg> constexpr int tdraw_bits() {
-    int mx = 2;
-    for (int k = 0; k < Cfg::NDRAW; ++k)
-        if (is_tdraw<Cfg>(k) && Cfg::leaf_nbin(Cfg::draw_leaf(k)) > mx) mx = Cfg::leaf_nbin(Cfg::draw_leaf(k));
-    int b = 1;
-    while ((1 << b) < mx) ++b;
-    return b;
-}
-template <class Cfg> constexpr int tdraw_per() { return 32 / tdraw_bits<Cfg>(); }
-template <class Cfg> constexpr int tdraw_words() { return (tdraw_count<Cfg>() + tdraw_per<Cfg>() - 1) / tdraw_per<Cfg>(); }
-
-// blockIdx -> (statistical block, slice of the block, histogram tile)
 struct WorkItem {
     i64 rowid, lb;
     int slice, tile;
@@ -837,17 +931,8 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 #endif
             const i64 idx = wi.lb * a.neval_per_block + n;
             static_for<0, Cfg::NI>([&](auto I) { a.tile_w[decltype(I)::value * a.tile_stride + idx] = wh[decltype(I)::value]; });
-            constexpr int NWORD = tdraw_words<Cfg>(), PER = tdraw_per<Cfg>(), BITS = tdraw_bits<Cfg>();
-            u32 word[NWORD > 0 ? NWORD : 1];
-            static_for<0, NWORD>([&](auto J) { word[decltype(J)::value] = 0u; });
-            static_for<0, Cfg::NDRAW>([&](auto K) {
-                constexpr int k = decltype(K)::value;
-                if constexpr (is_tdraw<Cfg>(k)) {
-                    constexpr int m = tdraw_pos<Cfg>(k);
-                    word[m / PER] |= (u32)s.bin[k] << (BITS * (m % PER));
-                }
-            });
-            static_for<0, NWORD>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = word[decltype(J)::value]; });
+            constexpr int NWORD = tdraw_words<Cfg>();
+            static_for<0, NWORD>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = s.word[decltype(J)::value]; });
         }
     };
     if constexpr (PH == 1 && MCI_STAGGER != 0) {
@@ -888,7 +973,8 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
                 nn[q] = n;
                 index[q] = (u64)(B * a.neval_per_block + (n < a.neval_per_block ? n : 0));
             });
-            draw_gather_phase<Cfg, EC, KV, DPC, PH>(t, keys, stream, index, sm);
+            if constexpr (MCI_GATHER_PIPE != 0 && PH == 1 && Cfg::RNG_BITS != 32) draw_gather_phase_pipe<Cfg, EC, KV, DPC>(t, keys, stream, index[0], sm[0]);
+            else draw_gather_phase<Cfg, EC, KV, DPC, PH>(t, keys, stream, index, sm);
             static_for<0, PH>([&](auto Ss) {
                 constexpr int q = decltype(Ss)::value;
                 // one sample at a time from here on: without the fences the scheduler interleaves the PH samples' Philox blocks
@@ -898,6 +984,26 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
                 if (nn[q] < a.neval_per_block) process(nn[q], sm[q]);
             });
             __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (MCI_TRIP_BARRIER != 0 && gather_draw_count<Cfg, EC>() > 0 && Cfg::HOST_INTEGRAND == 0) {
+        // Grids gathered from global memory, draws in their natural order: ONE workgroup barrier per sample re-aligns the waves, which
+        // then run the same straight-line code at the same pace -- so the CU's 32 KB L1 sees them on the same one or two 8 KB tables
+        // without the per-chunk barriers (and the register cost) of the dimension-major gather phase.  The barrier is executed in the
+        // trips that every thread of the workgroup takes (the body stays unconditional: the integrand consumes the draws as they come,
+        // 122 VGPRs on 32 grids); the last, partial trip runs without it.
+        const i64 first = (i64)slice * T;
+        const i64 jfull = first + T <= a.neval_per_block ? (a.neval_per_block - first - T) / stride + 1 : 0;
+        i64 n = first + tid;
+        for (i64 j = 0; j < jfull; ++j, n += stride) {
+            __builtin_amdgcn_s_barrier();
+            Sample<Cfg> s;
+            draw_sample<Cfg, EC, KV, DPC>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
+            process(n, s);
+        }
+        for (; n < a.neval_per_block; n += stride) {
+            Sample<Cfg> s;
+            draw_sample<Cfg, EC, KV, DPC>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
+            process(n, s);
         }
     } else {
         for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {

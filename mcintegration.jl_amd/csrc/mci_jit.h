@@ -164,6 +164,30 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     return o.str();
 }
 
+// .private_segment_fixed_size (scratch bytes per work-item: register spills, stack) of one kernel, read from the code object's
+// AMDGPU metadata note (msgpack; LLVM writes a kernel's keys in sorted order, so the first such key after `.name <kernel>` is that
+// kernel's).  -1 when the note does not have the expected shape.
+inline long kernel_scratch_bytes(const std::vector<char> &code, const char *kernel) {
+    const std::string blob(code.begin(), code.end());
+    std::string name = "\xa5.name";
+    const size_t kl = strlen(kernel);
+    if (kl < 32) name += (char)(0xa0 | kl);
+    else { name += (char)0xd9; name += (char)kl; }
+    name += kernel;
+    const size_t at = blob.find(name);
+    if (at == std::string::npos) return -1;
+    const std::string key = "\xbb.private_segment_fixed_size";
+    const size_t k = blob.find(key, at);
+    if (k == std::string::npos || k + key.size() >= blob.size()) return -1;
+    const unsigned char *v = (const unsigned char *)blob.data() + k + key.size();
+    const size_t left = blob.size() - (k + key.size());
+    if (v[0] <= 0x7f) return v[0];
+    if (v[0] == 0xcc && left > 1) return v[1];
+    if (v[0] == 0xcd && left > 2) return ((long)v[1] << 8) | v[2];
+    if (v[0] == 0xce && left > 4) return ((long)v[1] << 24) | ((long)v[2] << 16) | ((long)v[3] << 8) | v[4];
+    return -1;
+}
+
 inline uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull) {
     for (unsigned char c : s) {
         h ^= c;

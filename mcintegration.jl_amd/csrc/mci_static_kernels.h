@@ -235,7 +235,15 @@ __host__ __device__ inline int train_lds_doubles(int n) { return (n + kWalkPad) 
 // p[l] += p[l + h] for h = 8, 4, 2, 1.  Called by every thread of the workgroup; every 16-lane group computes the total for itself.
 __device__ inline double sum16(const double *v, int n) {
     double s = 0.0;
-    for (int i = threadIdx.x & 15; i < n; i += 16) s += v[i];
+    int i = threadIdx.x & 15;
+    for (; i + 112 < n; i += 128) { // eight loads in flight, then their adds in order (one load per add costs an LDS round trip each)
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = v[i + 16 * k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += t[k];
+    }
+    for (; i < n; i += 16) s += v[i];
 #pragma unroll
     for (int h = 8; h >= 1; h >>= 1) s += __shfl_down(s, h, 16);
     return __shfl(s, 0, 16);

@@ -172,7 +172,7 @@ def loop_mix(path, kernel="mci_vegas_batch"):
 
 
 def resources(path):
-    """{kernel: {"vgpr": n, "sgpr": n, "vgpr_spill": n, "scratch": bytes, "lds": bytes}} from the code object's metadata"""
+    """{kernel: {"vgpr": n, "sgpr": n, "vgpr_spill": n, "scratch": bytes, "lds": bytes, "max_threads": launch bound}} from the code object's metadata"""
     out = subprocess.run([READELF, "--notes", path], check=True, capture_output=True, text=True).stdout
     res, cur = {}, {}
     for line in out.splitlines():
@@ -180,14 +180,16 @@ def resources(path):
         if not m:
             continue
         k, v = m.group(1), m.group(2).strip()
-        if k in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size", "name", "agpr_count"):
+        if k in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size", "name", "agpr_count",
+                 "max_flat_workgroup_size"):
             cur[k] = v
         if k == "wavefront_size":   # last key of a kernel entry
             if "name" in cur:
                 res[cur["name"]] = {"vgpr": int(cur.get("vgpr_count", 0)), "sgpr": int(cur.get("sgpr_count", 0)),
                                     "vgpr_spill": int(cur.get("vgpr_spill_count", 0)),
                                     "scratch": int(cur.get("private_segment_fixed_size", 0)),
-                                    "lds": int(cur.get("group_segment_fixed_size", 0))}
+                                    "lds": int(cur.get("group_segment_fixed_size", 0)),
+                                    "max_threads": int(cur.get("max_flat_workgroup_size", 0))}
             cur = {}
     return res
 

@@ -161,11 +161,13 @@ def test_vegas_32_bit_stream_matches_oracle(oracle, name):
     np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6, atol=1e-300)
 
 
-def test_c4_32_bit_stream_with_gather_phase_matches_oracle(oracle):
-    """32 grids (split-all pass, dimension-major gather phase) on the 32-bit stream: 8 Philox blocks per sample instead of 16"""
+@pytest.mark.parametrize("threads", [None, 512], ids=["plan_a_1024", "plan_b_gather_phase"])
+def test_c4_32_bit_stream_with_gather_phase_matches_oracle(oracle, threads):
+    """32 grids (split-all pass: 1024 threads with the draws in order, or 512 with the dimension-major gather phase) on the 32-bit
+    stream: 8 Philox blocks per sample instead of 16"""
     ud = genz_userdata(32)
     cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
-    eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32), rng_bits=32)
+    eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32), rng_bits=32, **(dict(threads=threads) if threads else {}))
     ocfg = oracle.Config([ocont(0) for _ in range(32)], [[1]])
     ocfg.set_rng_bits(32)
     got = eng.iteration("vegas", 2000, 0, 4, iteration=0, seed=SEED)
@@ -596,15 +598,19 @@ def test_chain_streams_are_addressed_by_block_and_chain(oracle):
         eng.iteration("mcmc", npb, 4095, 4097, iteration=1, seed=SEED, nchain=4)
 
 
-def test_c4_genz32_runs_in_l2_table_mode_and_matches_oracle(oracle):
-    """BASELINE config 4 layout: 32 independent grids (256 KB of edges > LDS)."""
+@pytest.mark.parametrize("threads", [None, 512, 768], ids=["plan_a_1024", "plan_b_gather_phase", "gather_phase_768"])
+def test_c4_genz32_runs_in_l2_table_mode_and_matches_oracle(oracle, threads):
+    """BASELINE config 4 layout: 32 independent grids (256 KB of edges > LDS).  Default: one 1024-thread workgroup per CU, draws in
+    their natural order (plan A); an explicit workgroup size runs the dimension-major gather phase (plan B, also the fallback for
+    integrands that need more than 128 registers)."""
     ud = genz_userdata(32)
     cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
-    eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32))
+    eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32), **(dict(threads=threads) if threads else {}))
     assert eng.table_mode == 3  # histograms in LDS (2 tiles of 16 grids), edges gathered from L2
     ocfg = oracle.Config([ocont(0) for _ in range(32)], [[1]])
     got = eng.iteration("vegas", 2000, 0, 4, iteration=0, seed=SEED)
     ref = ocfg.iteration(oracle.VEGAS, "genz_product_peak", ud, 2000, 0, 4, 0, SEED)
     np.testing.assert_allclose(got[:4], ref[:4], rtol=1e-11)
     np.testing.assert_allclose(got[4:], ref[4:], rtol=1e-9)
+    assert eng.kernel_times_ms(1)[2] == (threads or 1024)
     assert genz_exact(32) > 0

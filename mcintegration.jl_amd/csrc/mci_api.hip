@@ -167,9 +167,9 @@ struct mci_problem {
     unsigned *d_loop = nullptr;
     bool graph_mode = false; // while capturing: no event records, iteration/log row come from d_loop
     int threads = 256, wg_per_block = 0; // 0 = auto
-    // split-all :vegas (many independent grids): plan A = 1024-thread workgroups (4 waves/SIMD) with the draws in their natural
-    // order -- taken when the integrand leaves the sample pass within 128 VGPRs (it consumes the draws as they come); plan B = 512
-    // threads with the dimension-major gather phase.  threads_vegas = 0: the vegas kernel follows `threads`
+    // split-all :vegas (many independent grids): plan A = 768-thread workgroups (3 waves/SIMD) -- taken when the integrand leaves
+    // the sample pass within 168 VGPRs (it consumes the draws as they come); plan B = 512 threads.  Both walk the gathered grids
+    // dimension-major (draw_gather_phase).  threads_vegas = 0: the vegas kernel follows `threads`
     int threads_vegas = 0;
     bool vegas_plan_a = false;
     // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
@@ -640,13 +640,13 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         if (const char *e = getenv("MCI_L1_PHASE")) s.l1_phase = (mode >= 2 && atoi(e) > 0) ? (atoi(e) > 4 ? 4 : atoi(e)) : 0;
         // one big workgroup per CU owns its LDS
         if (p->lds_bytes > lim0) p->threads = 512; // measured (tools/c4_sweep.py): 2 waves/SIMD beat 1 fat and 4 spilling ones
-        // Split-all, plan A: with the bins packed as they are drawn the 32-grid Genz pass needs 122 VGPRs without the gather phase
-        // (209 with it), i.e. four waves per SIMD in one 1024-thread workgroup per CU: 6.97 -> 6.63 ms per 1e8 samples (tools/c4_abenv.sh).
-        // compile_solver falls back to plan B when the integrand does not fit 128 registers at that size (scratch in the code object).
+        // Split-all, plan A: with the bins packed as they are drawn and the phased trips unconditional, the 32-grid Genz pass needs 146
+        // VGPRs WITH the gather phase (209 before), i.e. three waves per SIMD in one 768-thread workgroup per CU: 6.97 -> 6.4 ms per
+        // 1e8 samples (tools/c4_abenv.sh; 1024 threads without the phase, 122 VGPRs: 6.65 ms).  compile_solver falls back to plan B
+        // (512 threads) when the integrand does not fit 168 registers at that size (scratch in the code object).
         if (s.split_all && s.l1_phase == 1 && !getenv("MCI_L1_PHASE") && !getenv("MCI_THREADS")) {
             p->vegas_plan_a = true;
-            p->threads_vegas = 1024;
-            s.l1_phase = 0;
+            p->threads_vegas = 768;
         }
         if (const char *e = getenv("MCI_THREADS")) // diagnostic override of the default workgroup size
             if (atoi(e) >= 64 && atoi(e) <= 1024 && atoi(e) % 64 == 0) p->threads = atoi(e);
@@ -761,8 +761,7 @@ int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
         if (threads % 64 || threads > 1024) return fail(MCI_ERR_INVALID, "threads per workgroup must be a multiple of 64, <= 1024");
         if (threads != p->threads || p->threads_vegas) {
             p->threads = threads;
-            if (p->vegas_plan_a) p->shape.l1_phase = 1; // an explicit size: the vegas kernel follows it, with the gather phase
-            p->vegas_plan_a = false;
+            p->vegas_plan_a = false; // an explicit size: the vegas kernel follows it
             p->threads_vegas = 0;
             drop_modules(p);
         }
@@ -788,11 +787,9 @@ static int compile_solver(mci_problem *p, int solver) {
     int rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]);
     if (rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
     if (solver == MCI_VEGAS && p->vegas_plan_a && mcijit::kernel_scratch_bytes(code, "mci_vegas_batch") != 0) {
-        // the integrand keeps too many draws live for 128 VGPRs: plan B (512 threads, dimension-major gather phase)
+        // the integrand keeps too many values live for 168 VGPRs: plan B (512 threads: 2 waves/SIMD, 256 registers)
         p->vegas_plan_a = false;
         p->threads_vegas = 0;
-        p->shape.l1_phase = 1;
-        src = mcijit::generate_source(p->shape, solver);
         T = p->threads;
         if ((rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
     }

@@ -513,7 +513,7 @@ template <class Cfg, bool ECACHE, bool KV, int DPC, int S> __device__ __forceinl
 // (edges + fractions) are live at any point instead of the whole phase's, which is what the scheduler does when left alone
 // (13 gathers x 6 registers on C4).  sched_barrier keeps the order.
 #ifndef MCI_GATHER_PIPE
-#define MCI_GATHER_PIPE 0
+#define MCI_GATHER_PIPE 1 // measured on C4 at 768 threads: 6.76 -> 6.46 ms per 1e8 samples (tools/c4_abenv.sh)
 #endif
 struct PendingGather {
     double g0, g1, dy;
@@ -963,7 +963,12 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
         // their last valid sample and drop it
         const i64 n0 = (i64)slice * T + tid, first = (i64)slice * T;
         const i64 jmax = first < a.neval_per_block ? (a.neval_per_block - first + stride - 1) / stride : 0; // samples of lane 0
-        for (i64 j0 = 0; j0 < jmax; j0 += PH) {
+        // the phased trips are those in which every thread of the workgroup holds valid samples: their body is unconditional (the
+        // integrand may consume the draws as they come instead of keeping all of them for a guarded call); what is left at the end
+        // of the block -- at most PH samples per lane -- goes through the plain loop
+        const i64 jfull = first + T <= a.neval_per_block ? (a.neval_per_block - first - T) / stride + 1 : 0;
+        (void)jmax;
+        auto trip = [&](const i64 j0) {
             Sample<Cfg> sm[PH];
             u64 index[PH];
             i64 nn[PH];
@@ -973,7 +978,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
                 nn[q] = n;
                 index[q] = (u64)(B * a.neval_per_block + (n < a.neval_per_block ? n : 0));
             });
-            if constexpr (MCI_GATHER_PIPE != 0 && PH == 1 && Cfg::RNG_BITS != 32) draw_gather_phase_pipe<Cfg, EC, KV, DPC>(t, keys, stream, index[0], sm[0]);
+            if constexpr (MCI_GATHER_PIPE != 0 && PH == 1) draw_gather_phase_pipe<Cfg, EC, KV, DPC>(t, keys, stream, index[0], sm[0]);
             else draw_gather_phase<Cfg, EC, KV, DPC, PH>(t, keys, stream, index, sm);
             static_for<0, PH>([&](auto Ss) {
                 constexpr int q = decltype(Ss)::value;
@@ -981,9 +986,16 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
                 // and integrands for ILP and the live draws of all of them no longer fit the register file
                 __builtin_amdgcn_sched_barrier(0);
                 draw_rest_phase<Cfg, EC, KV, DPC>(t, keys, stream, index[q], sm[q]);
-                if (nn[q] < a.neval_per_block) process(nn[q], sm[q]);
+                process(nn[q], sm[q]);
             });
             __builtin_amdgcn_sched_barrier(0);
+        };
+        i64 j0 = 0;
+        for (; j0 + PH <= jfull; j0 += PH) trip(j0);
+        for (i64 n = n0 + j0 * stride; n < a.neval_per_block; n += stride) {
+            Sample<Cfg> s;
+            draw_sample<Cfg, EC, KV, DPC>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
+            process(n, s);
         }
     } else if constexpr (MCI_TRIP_BARRIER != 0 && gather_draw_count<Cfg, EC>() > 0 && Cfg::HOST_INTEGRAND == 0) {
         // Grids gathered from global memory, draws in their natural order: ONE workgroup barrier per sample re-aligns the waves, which
@@ -1022,8 +1034,11 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 // histogram tiles 1 .. NTILE-1 (split-all: 0 .. NTILE-1) of a SPLIT vegas pass: workgroup = (block, slice, tile); replays the parked
 // (weights, bins) of the same samples its sample-pass workgroup drew -- no RNG, no gathers, no integrand:
 // 8*NI + 2 bytes per tiled draw of coalesced HBM reads and one ds_add_f64 per draw.
+#ifndef MCI_THREADS
+#define MCI_THREADS 256 // (the JIT translation units define it: the workgroup size their kernels are compiled for)
+#endif
 #ifndef MCI_TILES_U
-#define MCI_TILES_U 4
+#define MCI_TILES_U (MCI_THREADS >= 768 ? 8 : 4) // samples per lane and trip (measured: 8 at 768 threads 6.46 -> 6.38 ms, 16 slower; 4 at 512)
 #endif
 template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];

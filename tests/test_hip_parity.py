@@ -161,10 +161,10 @@ def test_vegas_32_bit_stream_matches_oracle(oracle, name):
     np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6, atol=1e-300)
 
 
-@pytest.mark.parametrize("threads", [None, 512], ids=["plan_a_1024", "plan_b_gather_phase"])
+@pytest.mark.parametrize("threads", [None, 512], ids=["plan_a_768", "plan_b_512"])
 def test_c4_32_bit_stream_with_gather_phase_matches_oracle(oracle, threads):
-    """32 grids (split-all pass: 1024 threads with the draws in order, or 512 with the dimension-major gather phase) on the 32-bit
-    stream: 8 Philox blocks per sample instead of 16"""
+    """32 grids (split-all pass with the dimension-major gather phase, 768 or 512 threads) on the 32-bit stream: 8 Philox blocks per
+    sample instead of 16"""
     ud = genz_userdata(32)
     cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
     eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32), rng_bits=32, **(dict(threads=threads) if threads else {}))
@@ -598,11 +598,13 @@ def test_chain_streams_are_addressed_by_block_and_chain(oracle):
         eng.iteration("mcmc", npb, 4095, 4097, iteration=1, seed=SEED, nchain=4)
 
 
-@pytest.mark.parametrize("threads", [None, 512, 768], ids=["plan_a_1024", "plan_b_gather_phase", "gather_phase_768"])
-def test_c4_genz32_runs_in_l2_table_mode_and_matches_oracle(oracle, threads):
-    """BASELINE config 4 layout: 32 independent grids (256 KB of edges > LDS).  Default: one 1024-thread workgroup per CU, draws in
-    their natural order (plan A); an explicit workgroup size runs the dimension-major gather phase (plan B, also the fallback for
-    integrands that need more than 128 registers)."""
+@pytest.mark.parametrize("threads,phase", [(None, None), (512, None), (1024, "0")], ids=["plan_a_768", "plan_b_512", "no_phase_1024"])
+def test_c4_genz32_runs_in_l2_table_mode_and_matches_oracle(oracle, threads, phase, monkeypatch):
+    """BASELINE config 4 layout: 32 independent grids (256 KB of edges > LDS).  Default: one 768-thread workgroup per CU walking the
+    gathered grids dimension-major (plan A); 512 threads is plan B, the fallback for integrands that need more than 168 registers;
+    MCI_L1_PHASE=0 draws in the natural order (1024 threads fit then)."""
+    if phase is not None:
+        monkeypatch.setenv("MCI_L1_PHASE", phase)
     ud = genz_userdata(32)
     cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
     eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32), **(dict(threads=threads) if threads else {}))
@@ -612,5 +614,5 @@ def test_c4_genz32_runs_in_l2_table_mode_and_matches_oracle(oracle, threads):
     ref = ocfg.iteration(oracle.VEGAS, "genz_product_peak", ud, 2000, 0, 4, 0, SEED)
     np.testing.assert_allclose(got[:4], ref[:4], rtol=1e-11)
     np.testing.assert_allclose(got[4:], ref[4:], rtol=1e-9)
-    assert eng.kernel_times_ms(1)[2] == (threads or 1024)
+    assert eng.kernel_times_ms(1)[2] == (threads or 768)
     assert genz_exact(32) > 0

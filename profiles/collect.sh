@@ -19,7 +19,7 @@ if [ "$WHAT" = "c4" ]; then
   CMD="python tools/c4_prof.py 32"
   KERNELS="mci_vegas_batch,mci_vegas_tiles"
 else
-  CMD="python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline"
+  CMD="python bench.py --steps $STEPS --warmup 5 --passes 3 --no-cpu-baseline"
   KERNELS="mci_vegas_batch"
 fi
 cd /tmp

@@ -167,11 +167,11 @@ struct mci_problem {
     unsigned *d_loop = nullptr;
     bool graph_mode = false; // while capturing: no event records, iteration/log row come from d_loop
     int threads = 256, wg_per_block = 0; // 0 = auto
-    // split-all :vegas (many independent grids): plan A = 768-thread workgroups (3 waves/SIMD) -- taken when the integrand leaves
-    // the sample pass within 168 VGPRs (it consumes the draws as they come); plan B = 512 threads.  Both walk the gathered grids
-    // dimension-major (draw_gather_phase).  threads_vegas = 0: the vegas kernel follows `threads`
+    // :vegas kernels whose tables take more than half of a CU's LDS (one workgroup per CU: 16 or 32 independent grids) pick their
+    // workgroup size from the compiled code: the largest of 1024 / 768 / 512 threads (4 / 3 / 2 waves per SIMD) at which the sample
+    // pass shows no scratch (128 / 168 / 256 registers).  threads_vegas = 0: the vegas kernel follows `threads`
     int threads_vegas = 0;
-    bool vegas_plan_a = false;
+    bool vegas_plan_a = false; // the ladder is active (no explicit size was asked for)
     // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
     // launch before it is long enough to hide its ~35 us per iteration (>= kSerialWalkSamples samples or chain steps on this
     // rank: 2 % of the headline iteration), the prefix-scan form below that; mci_set_train_walk / MCI_TRAIN_SERIAL=1 | 0 force one
@@ -640,13 +640,13 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         if (const char *e = getenv("MCI_L1_PHASE")) s.l1_phase = (mode >= 2 && atoi(e) > 0) ? (atoi(e) > 4 ? 4 : atoi(e)) : 0;
         // one big workgroup per CU owns its LDS
         if (p->lds_bytes > lim0) p->threads = 512; // measured (tools/c4_sweep.py): 2 waves/SIMD beat 1 fat and 4 spilling ones
-        // Split-all, plan A: with the bins packed as they are drawn and the phased trips unconditional, the 32-grid Genz pass needs 146
-        // VGPRs WITH the gather phase (209 before), i.e. three waves per SIMD in one 768-thread workgroup per CU: 6.97 -> 6.4 ms per
-        // 1e8 samples (tools/c4_abenv.sh; 1024 threads without the phase, 122 VGPRs: 6.65 ms).  compile_solver falls back to plan B
-        // (512 threads) when the integrand does not fit 168 registers at that size (scratch in the code object).
-        if (s.split_all && s.l1_phase == 1 && !getenv("MCI_L1_PHASE") && !getenv("MCI_THREADS")) {
+        // ... and as many waves as its registers allow.  With the bins packed as they are drawn and the phased trips unconditional the
+        // 32-grid Genz pass needs 146 VGPRs with the gather phase (209 before): 768 threads, 6.97 -> 6.45 ms per 1e8 samples; the 16-grid
+        // Gaussian (histogram in the pass, 104 VGPRs) runs 1024 threads: 2.78 -> 2.44 ms (tools/c4_abenv.sh).  compile_solver walks the
+        // ladder 1024 -> 768 -> 512 until the code object shows no scratch.
+        if (p->lds_bytes > lim0 && !getenv("MCI_THREADS")) {
             p->vegas_plan_a = true;
-            p->threads_vegas = 768;
+            p->threads_vegas = 1024;
         }
         if (const char *e = getenv("MCI_THREADS")) // diagnostic override of the default workgroup size
             if (atoi(e) >= 64 && atoi(e) <= 1024 && atoi(e) % 64 == 0) p->threads = atoi(e);
@@ -786,11 +786,10 @@ static int compile_solver(mci_problem *p, int solver) {
     int T = solver == MCI_VEGAS && p->threads_vegas ? p->threads_vegas : p->threads;
     int rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]);
     if (rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
-    if (solver == MCI_VEGAS && p->vegas_plan_a && mcijit::kernel_scratch_bytes(code, "mci_vegas_batch") != 0) {
-        // the integrand keeps too many values live for 168 VGPRs: plan B (512 threads: 2 waves/SIMD, 256 registers)
-        p->vegas_plan_a = false;
-        p->threads_vegas = 0;
-        T = p->threads;
+    while (solver == MCI_VEGAS && p->vegas_plan_a && T > 512 && mcijit::kernel_scratch_bytes(code, "mci_vegas_batch") != 0) {
+        // the sample pass keeps too many values live for this many waves per SIMD: next rung (1024 -> 768 -> 512 threads)
+        T = T == 1024 ? 768 : 512;
+        p->threads_vegas = T;
         if ((rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
     }
     if (!p->ctx->offline) {

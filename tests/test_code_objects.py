@@ -25,6 +25,9 @@ def _bubble():
 BASELINE = [
     ("c1", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]]), mci.catalog.log_over_sqrt, None, "vegas", "mci_vegas_batch", 64),
     ("c2", lambda: mci.Configuration(var=mci.Continuous(-L, L), dof=[[16]]), lambda: mci.catalog.gaussian(16), None, "vegas", "mci_vegas_batch", 128),
+    # (the same Gaussian on 16 independent grids: histogram in the pass, 3 grids' edges cached, one 1024-thread workgroup per CU)
+    ("c2_16grids", lambda: mci.Configuration(var=mci.Continuous([(-L, L)] * 16), dof=[[1]]), lambda: mci.catalog.gaussian(16), None, "vegas",
+     "mci_vegas_batch", 128),
     ("c3", _bubble, mci.catalog.bubble, lambda: mci.bin_by(4), "vegasmc", "mci_vegasmc_chains", 256),
     # (one 768-thread workgroup per CU owns its LDS: 3 waves/SIMD, so the budget is 168 registers -- the bins are packed as drawn)
     ("c4", lambda: mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]]), lambda: mci.catalog.genz_product_peak(32), None, "vegas",
@@ -52,6 +55,8 @@ def test_baseline_kernels_do_not_spill(name, cfg, f, meas, solver, kernel, max_v
     for k, r in res.items():
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, k, r)
     assert res[kernel]["vgpr"] <= max_vgpr, (name, res[kernel])
+    if name == "c2_16grids":
+        assert res[kernel]["max_threads"] == 1024     # first rung of the 1024 / 768 / 512 ladder
     if name == "c4":
         assert res["mci_vegas_tiles"]["vgpr"] <= 168  # the replay kernel shares the workgroup size (one workgroup per CU: its LDS tile)
         assert res[kernel]["max_threads"] == 768      # plan A of the split-all pass
@@ -73,7 +78,7 @@ def test_split_all_pass_falls_back_to_512_threads_when_the_integrand_needs_every
 def test_c2_sample_loop_mix():
     """the 16-D Gaussian's sample loop: one ds_read_b128 + one ds_add_f64 per draw, Philox as v_mad_u64_u32 + v_bitop3_b32
     (no two-instruction xor3), straight-line body (no inner loops)"""
-    mix = isa_mix.loop_mix(_code_object(*BASELINE[1][1:5]), "mci_vegas_batch")
+    mix = isa_mix.loop_mix(_code_object(*[b for b in BASELINE if b[0] == "c2"][0][1:5]), "mci_vegas_batch")
     m, c = mix["mnemonics"], mix["classes"]
     assert mix["inner_backward_branches"] == 0
     assert m["ds_read_b128"] == 16 and m["ds_add_f64"] == 16 and mix["pipes"]["lds"] == 32

@@ -4,5 +4,5 @@
 for e in "$@"; do
   flags=""; envs=""
   for kv in $e; do case $kv in FLAGS=*) flags="${kv#FLAGS=}"; flags="${flags//@/ }";; *) envs="$envs $kv";; esac; done
-  echo "env$envs flags $flags"; env $envs python tools/ab_c2.py c4 "$flags" 2>&1 | tail -1 | cut -c1-170
+  echo "env$envs flags $flags"; env $envs python tools/ab_c2.py ${AB_WHICH:-c4} "$flags" 2>&1 | tail -1 | cut -c1-170
 done

@@ -132,7 +132,10 @@ int mci_set_integrand_source(mci_problem *prob, const char *body, const double *
  * hands the host callback every draw of the batch, draw-major x[k*n + i] (so that x[k] is a contiguous vector over
  * the n samples -- what a vectorised `(x, c) -> ...` wants), the callback writes w[q*n + i] for the nw =
  * nintegrand*ncomp outputs and returns 0; the sample kernel then regenerates the same draws around those weights.
- * PCIe- and host-bound by construction; solver = MCI_VEGAS only. */
+ * solver = MCI_VEGASMC (the reference's default, main.jl:72; the closure sits inside the Markov step, vegas_mc/updates.jl:67-75):
+ * the chains of a launch advance in lock step, ONE kernel launch and ONE callback per step, n = the chains of the launch
+ * (nblocks * nchain), x = the configurations they propose; same streams and arithmetic as the device-source chains, so both
+ * give the same results.  PCIe- and host-bound by construction; not under MCI_MCMC (its step takes device source). */
 typedef int (*mci_host_integrand_fn)(const double *x, double *w, int64_t n, int32_t ndraw, int32_t nw, void *user);
 int mci_set_integrand_host(mci_problem *prob, mci_host_integrand_fn fn, void *user);
 /* The `measure` callback (vegas/montecarlo.jl:156-161, mcmc/montecarlo.jl:166-169) as a HIP C++ function body:

@@ -158,6 +158,9 @@ struct mci_problem {
     void *host_user = nullptr;
     double *d_hx = nullptr, *d_hw = nullptr, *h_hx = nullptr, *h_hw = nullptr; // device / pinned host
     int64_t cap_host = 0;
+    // chain state between the per-step launches of a chain solver with a host integrand (BatchArgs::HostStep)
+    void *d_hstep = nullptr;
+    int64_t cap_hstep = 0; // chains
     // host measure ("batch callback"): draws + relative weights of the launch -> host closure per block -> block observables
     mci_host_measure_fn hmeas_fn = nullptr;
     void *hmeas_user = nullptr;
@@ -693,6 +696,7 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->d_hold) (void)hipFree(p->d_hold);
         if (p->d_loop) (void)hipFree(p->d_loop);
         if (p->d_hx) (void)hipFree(p->d_hx);
+        if (p->d_hstep) (void)hipFree(p->d_hstep);
         if (p->d_hw) (void)hipFree(p->d_hw);
         if (p->h_hx) (void)hipHostFree(p->h_hx);
         if (p->h_hw) (void)hipHostFree(p->h_hw);
@@ -1002,8 +1006,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         // "batch callback": the closure cannot run on the device, so the draws of this launch go to the host (SoA,
         // x[k*n + i]), the callback fills w[q*n + i], and the sample kernel regenerates the same draws (same Philox
         // indices) around the uploaded weights.  PCIe + host bound by construction; solver = :vegas only.
-        if (solver != MCI_VEGAS) return fail(MCI_ERR_INVALID, "a host integrand runs with solver=:vegas only (a chain needs the integrand inside the step)");
-        const int64_t n = nblocks * nevalperblock;
+        if (solver == MCI_MCMC) return fail(MCI_ERR_INVALID, "a host integrand runs with solver=:vegas or :vegasmc (the :mcmc step takes device source)");
+        if (solver == MCI_VEGASMC && s.ntile > 1) return fail(MCI_ERR_INVALID, "a host integrand under :vegasmc needs the histograms in one LDS tile");
+        // :vegas -- the draws of the whole launch; :vegasmc -- one configuration per chain and Markov step (below)
+        const int64_t n = solver == MCI_VEGAS ? nblocks * nevalperblock : nblocks * nchain;
         if (n > p->cap_host) {
             if (p->d_hx) (void)hipFree(p->d_hx);
             if (p->d_hw) (void)hipFree(p->d_hw);
@@ -1017,6 +1023,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             HIPCHK(hipHostMalloc((void **)&p->h_hw, (size_t)n * s.ni * s.ncomp * sizeof(double), hipHostMallocDefault));
             p->cap_host = n;
         }
+        if (solver == MCI_VEGAS) {
         mci::DumpArgs d{};
         d.edges = p->d_edges;
         d.dacc = p->d_dacc;
@@ -1038,6 +1045,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         const int hrc = p->host_fn(p->h_hx, p->h_hw, n, s.ndraw, s.ni * s.ncomp, p->host_user);
         if (hrc) return fail(MCI_ERR_INVALID, "the host integrand failed (%d)", hrc);
         HIPCHK(hipMemcpyAsync(p->d_hw, p->h_hw, (size_t)n * s.ni * s.ncomp * sizeof(double), hipMemcpyHostToDevice, hs));
+        }
         a.host_w = p->d_hw;
     }
     if (s.host_measure) { // (solver == :vegas: checked in compile_solver)
@@ -1071,6 +1079,53 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     const int slot = (int)(p->launches % mci_problem::kEvRing);
     if (p->graph_mode) a.iter_ptr = p->d_loop; // captured launch: the iteration index is read on the device
     else HIPCHK(hipEventRecord(p->evs[2 * slot], st));
+    if (solver == MCI_VEGASMC && s.host_integrand) {
+        // The closure sits inside the Markov step (vegas_mc/updates.jl:67-75): the chains of this launch advance in lock step, one
+        // kernel launch per step; each hands the host the nc configurations to evaluate and takes their weights back
+        // (vegasmc_host_step).  PCIe- and host-bound by construction: two copies, one callback and one launch per step.
+        const int64_t nc = nblocks * nchain, steps = nevalperblock / nchain;
+        const int nw = s.ni * s.ncomp, nd = s.ndraw;
+        if (nc > p->cap_hstep) {
+            if (p->d_hstep) (void)hipFree(p->d_hstep);
+            p->d_hstep = nullptr;
+            p->cap_hstep = 0;
+            // doubles: cx, cprob, pprob [nd] each; cw [nw]; cprobability, pprop, puacc; ints: cbin, pbin [nd] each; pvi
+            HIPCHK(hipMalloc(&p->d_hstep, (size_t)nc * ((3 * nd + nw + 3) * sizeof(double) + (2 * nd + 1) * sizeof(int))));
+            p->cap_hstep = nc;
+        }
+        {
+            double *dp = (double *)p->d_hstep;
+            a.hs.cx = dp; dp += (size_t)nd * nc;
+            a.hs.cprob = dp; dp += (size_t)nd * nc;
+            a.hs.pprob = dp; dp += (size_t)nd * nc;
+            a.hs.cw = dp; dp += (size_t)nw * nc;
+            a.hs.cprobability = dp; dp += nc;
+            a.hs.pprop = dp; dp += nc;
+            a.hs.puacc = dp; dp += nc;
+            int *ip = (int *)dp;
+            a.hs.cbin = ip; ip += (size_t)nd * nc;
+            a.hs.pbin = ip; ip += (size_t)nd * nc;
+            a.hs.pvi = ip;
+        }
+        a.hs.hx = p->d_hx;
+        a.hs.nc = nc;
+        a.hs.steps = steps;
+        // the step launches ADD to the partial rows
+        HIPCHK(hipMemsetAsync(p->d_part_cols, 0, (size_t)nrows * s.ncols * sizeof(double), st));
+        if (hist_lds && s.nbin > 0) HIPCHK(hipMemsetAsync(p->d_part_hist, 0, (size_t)nrows * s.nbin * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(p->d_part_pa, 0, (size_t)nrows * 2 * p->npa * sizeof(double), st));
+        for (int64_t ne = 0; ne <= steps + 1; ++ne) {
+            a.hs.ne = ne;
+            HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+            if (ne > steps) break;
+            HIPCHK(hipMemcpyAsync(p->h_hx, p->d_hx, (size_t)nc * nd * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            memset(p->h_hw, 0, (size_t)nc * nw * sizeof(double));
+            const int hrc = p->host_fn(p->h_hx, p->h_hw, nc, nd, nw, p->host_user);
+            if (hrc) return fail(MCI_ERR_INVALID, "the host integrand failed (%d)", hrc);
+            HIPCHK(hipMemcpyAsync(p->d_hw, p->h_hw, (size_t)nc * nw * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+    } else
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)((solver == MCI_VEGAS && s.ec_doubles > 0) ? p->lds_bytes_k1 : p->lds_bytes), st, args, nullptr));
     if (split)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));

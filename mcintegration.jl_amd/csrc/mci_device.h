@@ -193,6 +193,20 @@ struct BatchArgs {
     // mcmc: [64] histogram over the chains of this launch of bit_width(longest holding time), the longest run of steps
     // during which a live slot (or the integrand index) of the chain did not change; feeds the automatic chain length
     unsigned long long *hold_hist;
+    // A chain solver with a HOST integrand (Cfg::HOST_INTEGRAND under :vegasmc): the closure sits inside the Markov step
+    // (vegas_mc/updates.jl:67-75), so a block's chains advance in lock step, ONE LAUNCH PER STEP, and every launch hands the host
+    // the configurations it has to evaluate (hx[k * nc + chain]) and takes back their weights (host_w[q * nc + chain]):
+    //   ne = 0            initialise the chains (montecarlo.jl:151-153), hand over their configurations
+    //   ne = 1 .. steps   finish step ne-1 with the weights the host returned (ne = 1: the initial weights, :155-166), propose step ne
+    //   ne = steps + 1    finish the last step
+    // Chain state lives in global memory between launches (SoA, stride nc = chains of the launch).
+    struct HostStep {
+        i64 ne, steps, nc;
+        double *cx, *cprob, *cw, *cprobability; // current configuration [NDRAW][nc], weights [NW][nc], config.probability [nc]
+        int *cbin;
+        double *hx, *pprob, *pprop, *puacc;     // proposal: x (= what the host evaluates) [NDRAW][nc], prob [NDRAW][nc], prop / accept draw [nc]
+        int *pbin, *pvi;                        // proposal bins [NDRAW][nc]; pool the step changes, -1: nothing proposed
+    } hs;
 };
 __device__ __forceinline__ u32 iteration_of(const BatchArgs &a) { return a.iter_ptr ? *a.iter_ptr : a.iteration; }
 
@@ -758,7 +772,7 @@ template <class Cfg> __device__ __forceinline__ void measure(const double *x, co
 }
 
 // workgroup epilogue: registers -> wave shuffle -> LDS -> one row of part_cols; LDS histogram -> part_hist
-template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA = false> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/, i64 rowid, int tile) {
+template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA = false, bool ACCUM = false> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/, i64 rowid, int tile) {
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
     double *sO = smem + L::O, *sR = smem + L::R, *sH = smem + L::H;
     // scalar observables of the default measure (register accumulators)
@@ -791,19 +805,19 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
         else if (c < Cfg::NOBS && binned) v = sO[c];
         else
             for (int w = 0; w < nwave; ++w) v += sR[w * Cfg::NCOLS + c]; // fixed order: deterministic
-        row[c] = v;
+        row[c] = ACCUM ? row[c] + v : v; // (ACCUM: one launch per Markov step adds to the row the host zeroed)
     }
     if constexpr (WRITE_PA) { // the workgroup's propose | accept counters -> its row of part_pa (exact integers below 2^53)
         const u64 *sPA = reinterpret_cast<const u64 *>(smem + L::PA);
         double *prow = a.part_pa + rowid * (2 * PaTable<Cfg>::N);
-        for (int i = tid; i < 2 * PaTable<Cfg>::N && tile == 0; i += T) prow[i] = (double)sPA[i];
+        for (int i = tid; i < 2 * PaTable<Cfg>::N && tile == 0; i += T) prow[i] = ACCUM ? prow[i] + (double)sPA[i] : (double)sPA[i];
     }
     if constexpr (Mode<Cfg>::HIST_LDS && WRITE_HIST) {
         static_for<0, Cfg::NTILE>([&](auto Tt) {
             constexpr int tt = decltype(Tt)::value;
             if (tile == tt) {
                 double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
-                for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = sH[i];
+                for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = ACCUM ? hrow[i] + sH[i] : sH[i];
             }
         });
     }
@@ -1363,6 +1377,202 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     }
     __syncthreads();
     flush_workgroup<Cfg, Lds<Cfg>, true, true>(a, smem, acc, extra, wi.rowid, tile);
+}
+
+// ---------------------------------------------------------------------------------------------
+// VegasMC with the integrand on the HOST (BatchArgs::HostStep): the step of vegasmc_chains cut at the integrand call.  Every
+// launch finishes the step whose weights just came back and proposes the next one; the same Philox streams, the same
+// arithmetic in the same order as vegasmc_chains, so a closure and the same function as device source give the same chains.
+// Partial rows are ADDED to (the host zeroes them before the first launch).  One histogram tile only.
+// ---------------------------------------------------------------------------------------------
+template <class Cfg> __device__ __forceinline__ void vegasmc_host_step(const BatchArgs &a) {
+    static_assert(Cfg::NTILE == 1, "host-closure chains keep one histogram tile");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NI = Cfg::NI, NORMI = Cfg::NI;
+    const int tid = threadIdx.x, T = blockDim.x;
+    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
+    double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
+    stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
+    if constexpr (Mode<Cfg>::HIST_LDS)
+        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
+    for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
+    for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;
+    __syncthreads();
+    Tables<Cfg> t;
+    if constexpr (Mode<Cfg>::EDGE_LDS) t.E = sE;
+    else t.E = a.edges;
+    t.DA = sDA;
+    t.DD = sDD;
+
+    const WorkItem wi = work_item<Cfg>(a);
+    const BatchArgs::HostStep &h = a.hs;
+    const i64 B = a.block_lo + wi.lb;
+    const u32 bs = (u32)B << 20;
+    const u32 st_init = iteration_of(a) * 8u + STREAM_MC_INIT + bs, st_step = iteration_of(a) * 8u + STREAM_MC_STEP + bs;
+    const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
+    double rw[NI + 1];
+    static_for<0, NI + 1>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
+    double acc[Cfg::NW];
+    static_for<0, Cfg::NW>([&](auto I) { acc[decltype(I)::value] = 0.0; });
+    double extra[Cfg::NCOLS - Cfg::NOBS];
+    static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
+    constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
+    const i64 nc = h.nc;
+
+    for (i64 ch = (i64)wi.slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
+        const u64 g = (u64)ch;
+        const i64 cid = wi.lb * a.nchain + ch; // the chain's column in the state arrays
+        Chain<Cfg> c;
+        if (h.ne == 0) { // initialize!  (montecarlo.jl:151-153): create! on every live slot; the host evaluates it (:155-159)
+            Sample<Cfg> s;
+            draw_sample<Cfg>(t, a.seed, st_init, g, s);
+            static_for<0, Cfg::NDRAW>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                h.cx[k * nc + cid] = s.x[k];
+                h.hx[k * nc + cid] = s.x[k];
+                h.cbin[k * nc + cid] = s.bin[k];
+                h.cprob[k * nc + cid] = 1.0 / s.pj[k]; // sampler.jl:303 / :20
+            });
+            continue;
+        }
+        static_for<0, Cfg::NDRAW>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            c.x[k] = h.cx[k * nc + cid];
+            c.prob[k] = h.cprob[k * nc + cid];
+            c.bin[k] = h.cbin[k * nc + cid];
+        });
+        double w[Cfg::NW], pad[NI + 1], probability;
+        static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(c); }); // :161
+        if (h.ne == 1) { // the weights of the initial configuration: config.probability  (:162-166)
+            static_for<0, Cfg::NW>([&](auto Q) { w[decltype(Q)::value] = a.host_w[decltype(Q)::value * nc + cid]; });
+            probability = rw[NORMI] * pad[NORMI];
+            static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; probability += absw<Cfg, i>(w) * rw[i] * pad[i]; });
+        } else {
+            static_for<0, Cfg::NW>([&](auto Q) { w[decltype(Q)::value] = h.cw[decltype(Q)::value * nc + cid]; });
+            probability = h.cprobability[cid];
+            const i64 ne = h.ne - 1; // the step being finished
+            const int vi = h.pvi[cid];
+            const double prop = h.pprop[cid];
+            if (vi >= 0 && prop > 4.9406564584124654e-324) { // :63-65
+                Chain<Cfg> n;
+                static_for<0, Cfg::NDRAW>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    n.x[k] = h.hx[k * nc + cid];
+                    n.prob[k] = h.pprob[k * nc + cid];
+                    n.bin[k] = h.pbin[k * nc + cid];
+                });
+                double wn[Cfg::NW], padn[NI + 1];
+                static_for<0, Cfg::NW>([&](auto Q) { wn[decltype(Q)::value] = a.host_w[decltype(Q)::value * nc + cid]; }); // :67-75, on the host
+                extra[XE] += 1.0;                              // config.neval += 1   :77
+                static_for<0, NI + 1>([&](auto I) { padn[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(n); }); // :79-81
+                double newp = rw[NORMI] * padn[NORMI];         // :84
+                static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; newp += absw<Cfg, i>(wn) * rw[i] * padn[i]; }); // :85-87
+                const double R = prop * newp / probability;    // :88
+                const bool ok = h.puacc[cid] < R;              // :91
+                lds_count(&sPA[PaTable<Cfg>::idx(1, 0, vi)], 1ull);                              // :90
+                if (ok) lds_count(&sPA[PaTable<Cfg>::N + PaTable<Cfg>::idx(1, 0, vi)], 1ull);    // :92
+                if (ok) {
+                    c = n;
+                    static_for<0, Cfg::NW>([&](auto I) { w[decltype(I)::value] = wn[decltype(I)::value]; }); // :93-95
+                    static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = padn[decltype(I)::value]; }); // :96-98
+                    probability = newp;                        // :100
+                } // else shiftRollback!  :102
+            }
+            {   // histogram  montecarlo.jl:198-211
+                double wh[NI];
+                static_for<0, NI>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    const double aw = absw<Cfg, i>(w);
+                    const double f2 = aw * aw / own_prob<Cfg, i>(c);                   // :203
+                    wh[i] = f2 * pad[i] / probability;                                 // :204
+                });
+                Sample<Cfg> sb;
+                static_for<0, Cfg::NDRAW>([&](auto K) { sb.bin[decltype(K)::value] = c.bin[decltype(K)::value]; });
+                hist_update<Cfg>(sb, wh, sH, a.ghist, 0);
+            }
+            if (ne % a.measurefreq == 0 && (double)ne >= a.burnin) { // measurement  :213-232
+                double relw[Cfg::NW];
+                static_for<0, NI>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    extra[XV + i] += absw<Cfg, i>(w) * fabs(pad[i] * rw[i]) / probability; // :216
+                    static_for<0, Cfg::NCOMP>([&](auto Q) {
+                        constexpr int q = i * Cfg::NCOMP + decltype(Q)::value;
+                        relw[q] = w[q] * pad[i] / probability;                             // :218/:220
+                    });
+                });
+                measure<Cfg>(c.x, c.bin, relw, a.ud, acc, sO);
+                extra[XN] += pad[NORMI] / probability;                // :229
+                extra[XV + NORMI] += rw[NORMI] * pad[NORMI] / probability; // :230
+            }
+        }
+        if (h.ne <= h.steps) { // ---- changeVariable, up to the integrand call  updates.jl:45-66 ----
+            const i64 ne = h.ne;
+            const u64 sidx = (g << 32) | (u64)(ne - 1);
+            const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
+            const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
+            double upool = u01(r0.x, r0.y);
+            if (Cfg::NPOOL > 1 && a.nchain > 1) { // (the 64 chains of a wave share the pool pick, as in vegasmc_chains)
+                const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)(ne - 1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MC_GROUP + bs, k0, k1);
+                upool = u01(rg.x, rg.y);
+            }
+            int vi = (int)(upool * (double)Cfg::NPOOL);
+            if (vi >= Cfg::NPOOL) vi = Cfg::NPOOL - 1;
+            const double uslot = u01(r0.z, r0.w);
+            Chain<Cfg> n = c;
+            double prop = 1.0;
+            bool active = false;
+            static_for<0, Cfg::NPOOL>([&](auto V) {
+                constexpr int v = decltype(V)::value;
+                constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                constexpr bool skip = (md <= 0) || (nl == 1 && Cfg::leaf_kind(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1 &&
+                                                    Cfg::leaf_nbin(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1);
+                if constexpr (!skip) {
+                    if (vi == v) {
+                        active = true;
+                        int slot = (int)(uslot * (double)md); // :58
+                        if (slot >= md) slot = md - 1;
+                        static_for<0, nl>([&](auto Lf) {
+                            constexpr int l = decltype(Lf)::value;
+                            constexpr int kk = 3 + l;
+                            double y;
+                            if constexpr (kk == 3) y = u01(r1.z, r1.w);
+                            else {
+                                const u32x4 rr = philox4x32_10((u32)sidx, (u32)(sidx >> 32), (u32)(kk >> 1), st_step, k0, k1);
+                                y = (kk & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
+                            }
+                            double xo, po, xn, pn;
+                            int bo, bn;
+                            get_slot<Cfg, v, l>(c, slot, xo, po, bo);
+                            draw_pool_leaf<Cfg, v, l>(t, y, xn, pn, bn); // shift!  sampler.jl:336-386, :57-71
+                            put_slot<Cfg, v, l>(n, slot, xn, pn, bn);
+                            prop *= po / pn;                              // 1/prob_ratio  sampler.jl:385, :70
+                        });
+                    }
+                }
+            });
+            static_for<0, Cfg::NDRAW>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                h.hx[k * nc + cid] = n.x[k];
+                h.pprob[k * nc + cid] = n.prob[k];
+                h.pbin[k * nc + cid] = n.bin[k];
+            });
+            h.pprop[cid] = prop;
+            h.puacc[cid] = u01(r1.x, r1.y);
+            h.pvi[cid] = active ? vi : -1;
+        }
+        static_for<0, Cfg::NDRAW>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            h.cx[k * nc + cid] = c.x[k];
+            h.cprob[k * nc + cid] = c.prob[k];
+            h.cbin[k * nc + cid] = c.bin[k];
+        });
+        static_for<0, Cfg::NW>([&](auto Q) { h.cw[decltype(Q)::value * nc + cid] = w[decltype(Q)::value]; });
+        h.cprobability[cid] = probability;
+    }
+    __syncthreads();
+    flush_workgroup<Cfg, Lds<Cfg>, true, true, true>(a, smem, acc, extra, wi.rowid, 0);
 }
 
 // =============================================================================================

@@ -48,7 +48,7 @@ struct ProblemShape {
     int nbmax = 1;
     int ncomp = 1;            // 1: Float64 weights; 2: ComplexF64 stored (re, im)
     std::string measure_body; // user measure (empty = default / bin-by-Discrete)
-    int host_integrand = 0;   // weights come from a host callback over dumped draws (vegas only)
+    int host_integrand = 0;   // weights come from a host callback: over dumped draws (vegas), per Markov step (vegasmc)
     int host_measure = 0;     // observables are accumulated by a host callback over the launch's draws and relative weights (vegas only)
     std::vector<int> nneighbor, neighbor; // [ni+1], [(ni+1)*nbmax] 0-based, padded with the integrand itself
     std::string body;
@@ -155,8 +155,9 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
         o << "extern \"C\" __global__ void __launch_bounds__(256) mci_sample_dump(mci::DumpArgs a) { "
              "mci::sample_dump<Cfg>(a); }\n";
     } else if (solver == 1) {
+        // (a host integrand: the step cut at the integrand call, one launch per Markov step -- same entry point)
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_chains(mci::BatchArgs a) { "
-             "mci::vegasmc_chains<Cfg>(a); }\n";
+          << (s.host_integrand ? "mci::vegasmc_host_step<Cfg>(a); }\n" : "mci::vegasmc_chains<Cfg>(a); }\n");
     } else {
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_mcmc_chains(mci::BatchArgs a) { "
              "mci::mcmc_chains<Cfg>(a); }\n";

@@ -43,7 +43,8 @@ class HostIntegrand:
 
     With one variable type `x[i]` is the vector of the i-th draw over the n samples of the batch (0-based; the
     reference's `x[i+1]`); with several, `x` is a tuple with one such array per variable type (a CompositeVar pool has
-    shape [slot, leaf, n]).  solver="vegas" only."""
+    shape [slot, leaf, n]).  solver="vegas": n = the samples of a launch, one call per launch; solver="vegasmc" (the reference's
+    default): n = the chains of a launch, one call per Markov step (the chains advance in lock step).  Not under "mcmc"."""
 
     def __init__(self, fn, name=None):
         self.fn = fn

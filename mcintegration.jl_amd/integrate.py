@@ -53,7 +53,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     if isinstance(integrand, str):
         integrand = Integrand(integrand, config.userdata)
     elif callable(integrand) and not isinstance(integrand, (Integrand, HostIntegrand)):
-        integrand = HostIntegrand(integrand)       # a Python closure: host "batch callback" path, solver="vegas" only
+        integrand = HostIntegrand(integrand)       # a Python closure: host "batch callback" path (vegas: per launch, vegasmc: per Markov step)
     if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
         measure = HostMeasure(measure)             # a Python closure as measure: host batch-callback path, solver="vegas" only
     mkey = None if measure is None else measure.body if isinstance(measure, (Measure, HostMeasure)) else (measure.pool, measure.slot, measure.leaf)

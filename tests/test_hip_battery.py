@@ -443,8 +443,35 @@ def test_python_closure_as_integrand_matches_device_source():
     g = lambda v, c: v[0][0] * v[1][0] + 1j * v[0][0]
     res = integrate(g, var=(Continuous(0.0, 1.0), Discrete(1, 3)), dof=[[1, 1]], type=complex, solver="vegas", neval=1e5, seed=7)
     check_complex(res, 3.0 + 1.5j)
-    with pytest.raises(mci.MCIError):   # a chain needs the integrand inside the step
-        integrate(lambda x, c: x[0], solver="vegasmc", neval=1e4)
+    with pytest.raises(mci.MCIError):   # the :mcmc step takes device source
+        integrate(lambda x, c: x[0], solver="mcmc", neval=1e4)
+
+
+def test_python_closure_under_the_default_solver_matches_device_source():
+    """the reference's default solver is :vegasmc (main.jl:72) and calls the closure inside every Markov step
+    (vegas_mc/updates.jl:67-75).  With a host closure the chains of a launch advance in lock step, one kernel launch per step
+    (vegasmc_host_step): same Philox streams, same arithmetic -> the same chains as the same function given as device source."""
+    kw = dict(dof=[[2], [3]], neval=4e4, niter=4, seed=11, nchain=16)
+    f = lambda X, c: ((X[0] ** 2 + X[1] ** 2 < 1.0) * 1.0, (X[0] ** 2 + X[1] ** 2 + X[2] ** 2 < 1.0) * 1.0)
+    a = integrate(f, var=Continuous(0.0, 1.0), **kw)        # solver defaults to vegasmc  (a fresh variable each: a trained one carries over)
+    b = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), **kw)
+    np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-9)
+    np.testing.assert_allclose(a.iter_std, b.iter_std, rtol=1e-6)
+    pa, aa = a.config._engine.acceptance()
+    pb, ab = b.config._engine.acceptance()
+    np.testing.assert_allclose(pa, pb, rtol=1e-12)
+    np.testing.assert_allclose(aa, ab, rtol=1e-12)
+    np.testing.assert_allclose(a.config.var[0].grid, b.config.var[0].grid, rtol=0, atol=1e-9)
+    # the README call with the default solver and the reference's chain (one per block), smooth integrand, measurefreq
+    h = integrate(lambda x, c: x[0] ** 2 + x[1] ** 2, dof=[[2]], neval=2e4, niter=3, seed=3, nchain=1, block=16, measurefreq=2)
+    d = integrate("return x[0] * x[0] + x[1] * x[1];", dof=[[2]], neval=2e4, niter=3, seed=3, nchain=1, block=16, measurefreq=2)
+    np.testing.assert_allclose(h.iter_mean, d.iter_mean, rtol=1e-9)
+    # several pools (the wave-shared pool pick), a Discrete among them, automatic chain count
+    g = lambda v, c: v[0][0] * v[1][0]
+    hs = integrate(g, var=(Continuous(0.0, 1.0), Discrete(1, 3)), dof=[[1, 1]], neval=2e4, niter=3, seed=7)
+    ds = integrate("return x[0] * x[1];", var=(Continuous(0.0, 1.0), Discrete(1, 3)), dof=[[1, 1]], neval=2e4, niter=3, seed=7)
+    np.testing.assert_allclose(hs.iter_mean, ds.iter_mean, rtol=1e-9)
+    check(hs, 3.0)
 
 
 @pytest.mark.parametrize("alg", ["vegas", "vegasmc"])

@@ -138,6 +138,14 @@ int mci_set_integrand_source(mci_problem *prob, const char *body, const double *
  * give the same results.  PCIe- and host-bound by construction; not under MCI_MCMC (its step takes device source). */
 typedef int (*mci_host_integrand_fn)(const double *x, double *w, int64_t n, int32_t ndraw, int32_t nw, void *user);
 int mci_set_integrand_host(mci_problem *prob, mci_host_integrand_fn fn, void *user);
+/* The same for solver = MCI_MCMC, whose closure takes the integrand index first -- `integrand(idx, var, config)`
+ * (mcmc/montecarlo.jl:34-36, mcmc/updates.jl:35-38) -- and is asked for ONE integrand per configuration: per Markov step the
+ * callback gets idx[i] (0-based; -1: chain i needs no evaluation this step, leave w alone) next to x[k*n + i] and writes the
+ * ncomp components w[q*n + i] of integrand idx[i].  One launch and one callback per step; a chain whose start configuration has
+ * zero weight redraws it (mcmc/montecarlo.jl:118-124) and lags one step behind per retry.  Setting it replaces a plain host
+ * integrand and vice versa; under MCI_VEGAS / MCI_VEGASMC the library calls it with every integrand in turn. */
+typedef int (*mci_host_integrand_idx_fn)(const int32_t *idx, const double *x, double *w, int64_t n, int32_t ndraw, int32_t ncomp, void *user);
+int mci_set_integrand_host_indexed(mci_problem *prob, mci_host_integrand_idx_fn fn, void *user);
 /* The `measure` callback (vegas/montecarlo.jl:156-161, mcmc/montecarlo.jl:166-169) as a HIP C++ function body:
  *     const double* x, ud as above; const double* rw -- relative weights [nintegrand*ncomp];
  *     const int idx -- -1 (vegas, vegasmc) or the integrand an mcmc chain sits on (only its rw is non-zero);

@@ -155,6 +155,10 @@ struct mci_problem {
     bool has_fermik = false; // FermiK variables: solver = :mcmc only
     // host integrand ("batch callback"): draws dumped SoA -> callback -> weights uploaded -> accumulate kernel
     mci_host_integrand_fn host_fn = nullptr;
+    mci_host_integrand_idx_fn host_idx_fn = nullptr; // the `integrand(idx, var, config)` form (mcmc/montecarlo.jl:34-36)
+    int32_t *h_hidx = nullptr;                       // pinned: which integrand the host evaluates per chain (:mcmc)
+    int64_t cap_hidx = 0;
+    std::vector<double> h_tmp;                       // all-integrands <-> one-integrand adaptation of the two callback forms
     void *host_user = nullptr;
     double *d_hx = nullptr, *d_hw = nullptr, *h_hx = nullptr, *h_hw = nullptr; // device / pinned host
     int64_t cap_host = 0;
@@ -697,6 +701,7 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->d_loop) (void)hipFree(p->d_loop);
         if (p->d_hx) (void)hipFree(p->d_hx);
         if (p->d_hstep) (void)hipFree(p->d_hstep);
+        if (p->h_hidx) (void)hipHostFree(p->h_hidx);
         if (p->d_hw) (void)hipFree(p->d_hw);
         if (p->h_hx) (void)hipHostFree(p->h_hx);
         if (p->h_hw) (void)hipHostFree(p->h_hw);
@@ -733,11 +738,54 @@ int mci_set_integrand_host(mci_problem *p, mci_host_integrand_fn fn, void *user)
     if (!p || !fn) return fail(MCI_ERR_INVALID, "NULL argument");
     p->host_fn = fn;
     p->host_user = user;
+    p->host_idx_fn = nullptr;
     p->shape.host_integrand = 1;
     p->shape.body = "";
     p->h_ud.clear();
     drop_modules(p);
     if (!p->ctx->offline && !p->d_ud) HIPCHK(hipMalloc((void **)&p->d_ud, sizeof(double)));
+    return MCI_OK;
+}
+
+int mci_set_integrand_host_indexed(mci_problem *p, mci_host_integrand_idx_fn fn, void *user) {
+    if (!p || !fn) return fail(MCI_ERR_INVALID, "NULL argument");
+    p->host_idx_fn = fn;
+    p->host_fn = nullptr;
+    p->host_user = user;
+    p->shape.host_integrand = 1;
+    p->shape.body = "";
+    p->h_ud.clear();
+    drop_modules(p);
+    if (!p->ctx->offline && !p->d_ud) HIPCHK(hipMalloc((void **)&p->d_ud, sizeof(double)));
+    return MCI_OK;
+}
+
+// The host closure over n configurations x[k*n + i].  idx == NULL: every integrand, w[(j*ncomp + q)*n + i] (vegas, vegasmc);
+// idx != NULL: integrand idx[i] only, w[q*n + i] (mcmc).  Either callback form serves either request.
+static int eval_host_integrand(mci_problem *p, const int32_t *idx, const double *x, double *w, int64_t n) {
+    const auto &s = p->shape;
+    const int nw = s.ni * s.ncomp, nc = s.ncomp;
+    int hrc = 0;
+    if (!idx) {
+        memset(w, 0, (size_t)n * nw * sizeof(double));
+        if (p->host_fn) hrc = p->host_fn(x, w, n, s.ndraw, nw, p->host_user);
+        else {
+            std::vector<int32_t> which((size_t)n);
+            for (int j = 0; j < s.ni && !hrc; ++j) {
+                std::fill(which.begin(), which.end(), j);
+                hrc = p->host_idx_fn(which.data(), x, w + (size_t)j * nc * n, n, s.ndraw, nc, p->host_user);
+            }
+        }
+    } else if (p->host_idx_fn) {
+        memset(w, 0, (size_t)n * nc * sizeof(double));
+        hrc = p->host_idx_fn(idx, x, w, n, s.ndraw, nc, p->host_user);
+    } else {
+        p->h_tmp.assign((size_t)n * nw, 0.0);
+        hrc = p->host_fn(x, p->h_tmp.data(), n, s.ndraw, nw, p->host_user);
+        for (int q = 0; q < nc; ++q)
+            for (int64_t i = 0; i < n; ++i) w[(size_t)q * n + i] = idx[i] >= 0 ? p->h_tmp[((size_t)idx[i] * nc + q) * n + i] : 0.0;
+    }
+    if (hrc) return fail(MCI_ERR_INVALID, "the host integrand failed (%d)", hrc);
     return MCI_OK;
 }
 
@@ -991,7 +1039,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.nchain = nchain;
     a.burnin = burnin;
     a.nburn = nburn;
-    if (solver == MCI_MCMC && !p->graph_mode && nevalperblock / nchain + nburn < ((int64_t)1 << 31) - 1) {
+    if (solver == MCI_MCMC && !p->graph_mode && !s.host_integrand && nevalperblock / nchain + nburn < ((int64_t)1 << 31) - 1) {
         if (!p->d_hold) HIPCHK(hipMalloc((void **)&p->d_hold, 64 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(p->d_hold, 0, 64 * sizeof(unsigned long long), p->ctx->stream));
         a.hold_hist = p->d_hold;
@@ -1006,9 +1054,8 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         // "batch callback": the closure cannot run on the device, so the draws of this launch go to the host (SoA,
         // x[k*n + i]), the callback fills w[q*n + i], and the sample kernel regenerates the same draws (same Philox
         // indices) around the uploaded weights.  PCIe + host bound by construction; solver = :vegas only.
-        if (solver == MCI_MCMC) return fail(MCI_ERR_INVALID, "a host integrand runs with solver=:vegas or :vegasmc (the :mcmc step takes device source)");
-        if (solver == MCI_VEGASMC && s.ntile > 1) return fail(MCI_ERR_INVALID, "a host integrand under :vegasmc needs the histograms in one LDS tile");
-        // :vegas -- the draws of the whole launch; :vegasmc -- one configuration per chain and Markov step (below)
+        if (solver != MCI_VEGAS && s.ntile > 1) return fail(MCI_ERR_INVALID, "a host integrand under a chain solver needs the histograms in one LDS tile");
+        // :vegas -- the draws of the whole launch; chain solvers -- one configuration per chain and Markov step (below)
         const int64_t n = solver == MCI_VEGAS ? nblocks * nevalperblock : nblocks * nchain;
         if (n > p->cap_host) {
             if (p->d_hx) (void)hipFree(p->d_hx);
@@ -1041,9 +1088,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         HIPCHK(hipModuleLaunchKernel(p->f_dump, dgrid, 1, 1, 256, 1, 1, (unsigned)p->lds_bytes, hs, dargs, nullptr));
         HIPCHK(hipMemcpyAsync(p->h_hx, p->d_hx, (size_t)n * s.ndraw * sizeof(double), hipMemcpyDeviceToHost, hs));
         HIPCHK(hipStreamSynchronize(hs));
-        memset(p->h_hw, 0, (size_t)n * s.ni * s.ncomp * sizeof(double));
-        const int hrc = p->host_fn(p->h_hx, p->h_hw, n, s.ndraw, s.ni * s.ncomp, p->host_user);
-        if (hrc) return fail(MCI_ERR_INVALID, "the host integrand failed (%d)", hrc);
+        if ((rc = eval_host_integrand(p, nullptr, p->h_hx, p->h_hw, n))) return rc;
         HIPCHK(hipMemcpyAsync(p->d_hw, p->h_hw, (size_t)n * s.ni * s.ncomp * sizeof(double), hipMemcpyHostToDevice, hs));
         }
         a.host_w = p->d_hw;
@@ -1079,19 +1124,27 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     const int slot = (int)(p->launches % mci_problem::kEvRing);
     if (p->graph_mode) a.iter_ptr = p->d_loop; // captured launch: the iteration index is read on the device
     else HIPCHK(hipEventRecord(p->evs[2 * slot], st));
-    if (solver == MCI_VEGASMC && s.host_integrand) {
-        // The closure sits inside the Markov step (vegas_mc/updates.jl:67-75): the chains of this launch advance in lock step, one
-        // kernel launch per step; each hands the host the nc configurations to evaluate and takes their weights back
-        // (vegasmc_host_step).  PCIe- and host-bound by construction: two copies, one callback and one launch per step.
+    if (solver != MCI_VEGAS && s.host_integrand) {
+        // The closure sits inside the Markov step (vegas_mc/updates.jl:67-75, mcmc/updates.jl:35-38): the chains of this launch advance
+        // in lock step, one kernel launch per step; each hands the host the nc configurations to evaluate and takes their weights back
+        // (vegasmc_host_step, mcmc_host_step).  PCIe- and host-bound by construction: two copies, one callback and one launch per step.
         const int64_t nc = nblocks * nchain, steps = nevalperblock / nchain;
         const int nw = s.ni * s.ncomp, nd = s.ndraw;
+        if (nc >= ((int64_t)1 << 31) || steps + nburn >= ((int64_t)1 << 31) - 1) return fail(MCI_ERR_INVALID, "too many chains or steps for the host-closure path");
         if (nc > p->cap_hstep) {
             if (p->d_hstep) (void)hipFree(p->d_hstep);
             p->d_hstep = nullptr;
             p->cap_hstep = 0;
-            // doubles: cx, cprob, pprob [nd] each; cw [nw]; cprobability, pprop, puacc; ints: cbin, pbin [nd] each; pvi
-            HIPCHK(hipMalloc(&p->d_hstep, (size_t)nc * ((3 * nd + nw + 3) * sizeof(double) + (2 * nd + 1) * sizeof(int))));
+            // doubles: cx, cprob, pprob [nd] each; cw [nw]; cprobability, pprop, puacc, cwabs; ints: cbin, pbin [nd] each; pvi, ccurr, cit, ctr, pnew, put, hidx; done
+            HIPCHK(hipMalloc(&p->d_hstep, (size_t)nc * ((3 * nd + nw + 4) * sizeof(double) + (2 * nd + 7) * sizeof(int)) + 16));
             p->cap_hstep = nc;
+        }
+        if (nc > p->cap_hidx) {
+            if (p->h_hidx) (void)hipHostFree(p->h_hidx);
+            p->h_hidx = nullptr;
+            p->cap_hidx = 0;
+            HIPCHK(hipHostMalloc((void **)&p->h_hidx, (size_t)(nc + 1) * sizeof(int32_t), hipHostMallocDefault));
+            p->cap_hidx = nc;
         }
         {
             double *dp = (double *)p->d_hstep;
@@ -1102,10 +1155,18 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             a.hs.cprobability = dp; dp += nc;
             a.hs.pprop = dp; dp += nc;
             a.hs.puacc = dp; dp += nc;
+            a.hs.cwabs = dp; dp += nc;
             int *ip = (int *)dp;
             a.hs.cbin = ip; ip += (size_t)nd * nc;
             a.hs.pbin = ip; ip += (size_t)nd * nc;
-            a.hs.pvi = ip;
+            a.hs.pvi = ip; ip += nc;
+            a.hs.ccurr = ip; ip += nc;
+            a.hs.cit = ip; ip += nc;
+            a.hs.ctr = ip; ip += nc;
+            a.hs.pnew = ip; ip += nc;
+            a.hs.put = ip; ip += nc;
+            a.hs.hidx = ip; ip += nc; // (hidx[nc] = done: one copy brings both back)
+            a.hs.done = ip;
         }
         a.hs.hx = p->d_hx;
         a.hs.nc = nc;
@@ -1114,16 +1175,31 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         HIPCHK(hipMemsetAsync(p->d_part_cols, 0, (size_t)nrows * s.ncols * sizeof(double), st));
         if (hist_lds && s.nbin > 0) HIPCHK(hipMemsetAsync(p->d_part_hist, 0, (size_t)nrows * s.nbin * sizeof(double), st));
         HIPCHK(hipMemsetAsync(p->d_part_pa, 0, (size_t)nrows * 2 * p->npa * sizeof(double), st));
-        for (int64_t ne = 0; ne <= steps + 1; ++ne) {
-            a.hs.ne = ne;
-            HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
-            if (ne > steps) break;
-            HIPCHK(hipMemcpyAsync(p->h_hx, p->d_hx, (size_t)nc * nd * sizeof(double), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            memset(p->h_hw, 0, (size_t)nc * nw * sizeof(double));
-            const int hrc = p->host_fn(p->h_hx, p->h_hw, nc, nd, nw, p->host_user);
-            if (hrc) return fail(MCI_ERR_INVALID, "the host integrand failed (%d)", hrc);
-            HIPCHK(hipMemcpyAsync(p->d_hw, p->h_hw, (size_t)nc * nw * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(a.hs.done, 0, sizeof(int), st));
+        if (solver == MCI_VEGASMC) {
+            for (int64_t ne = 0; ne <= steps + 1; ++ne) {
+                a.hs.ne = ne;
+                HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+                if (ne > steps) break;
+                HIPCHK(hipMemcpyAsync(p->h_hx, p->d_hx, (size_t)nc * nd * sizeof(double), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if ((rc = eval_host_integrand(p, nullptr, p->h_hx, p->h_hw, nc))) return rc;
+                HIPCHK(hipMemcpyAsync(p->d_hw, p->h_hw, (size_t)nc * nw * sizeof(double), hipMemcpyHostToDevice, st));
+            }
+        } else {
+            // every chain counts its own steps (a start that has to be redrawn costs a launch): launch until all of them are through
+            const int64_t limit = steps + nburn + 2 + 10000; // (mcmc/montecarlo.jl:118: at most 10000 tries of the start)
+            for (int64_t ne = 0;; ++ne) {
+                a.hs.ne = ne;
+                HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+                HIPCHK(hipMemcpyAsync(p->h_hidx, a.hs.hidx, (size_t)(nc + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(p->h_hx, p->d_hx, (size_t)nc * nd * sizeof(double), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (p->h_hidx[nc] >= nc) break;
+                if (ne > limit) return fail(MCI_ERR_INVALID, "host-closure :mcmc chains did not finish (%d of %lld)", (int)p->h_hidx[nc], (long long)nc);
+                if ((rc = eval_host_integrand(p, p->h_hidx, p->h_hx, p->h_hw, nc))) return rc;
+                HIPCHK(hipMemcpyAsync(p->d_hw, p->h_hw, (size_t)nc * s.ncomp * sizeof(double), hipMemcpyHostToDevice, st));
+            }
         }
     } else
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)((solver == MCI_VEGAS && s.ec_doubles > 0) ? p->lds_bytes_k1 : p->lds_bytes), st, args, nullptr));

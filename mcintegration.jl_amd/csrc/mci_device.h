@@ -206,6 +206,13 @@ struct BatchArgs {
         int *cbin;
         double *hx, *pprob, *pprop, *puacc;     // proposal: x (= what the host evaluates) [NDRAW][nc], prob [NDRAW][nc], prop / accept draw [nc]
         int *pbin, *pvi;                        // proposal bins [NDRAW][nc]; pool the step changes, -1: nothing proposed
+        // :mcmc (mcmc_host_step) -- every chain carries its own step counter: a chain whose start has to be redrawn
+        // (mcmc/montecarlo.jl:118-124) lags behind the others, so the host launches until `done` says every chain finished
+        double *cwabs;                          // |weight| of the current configuration [nc]
+        int *ccurr, *cit, *ctr;                 // integrand index, steps done (-1: the start is still being evaluated), start tries
+        int *pnew, *put;                        // proposal: integrand it lands on, update type (first index of propose[., ., .])
+        int *hidx;                              // the integrand the host evaluates for this chain's hx, -1: nothing to evaluate
+        int *done;                              // [1] chains that have run all their steps
     } hs;
 };
 __device__ __forceinline__ u32 iteration_of(const BatchArgs &a) { return a.iter_ptr ? *a.iter_ptr : a.iteration; }
@@ -1707,6 +1714,173 @@ template <class Cfg, int K> __device__ __forceinline__ void hist_add(int bin, do
     }
 }
 
+// One MCMC proposal (mcmc/updates.jl:1-147): from the chain's configuration c on integrand curr and the step's update type and
+// uniforms, the proposed configuration n, the proposal ratio, the integrand it lands on, and what the bookkeeping needs
+// (ut: first index of propose[., ., .] -- 0 changeIntegrand, 1 changeVariable, 2 swapVariable; pvi: the pool picked; touched: the
+// draws of the slot(s) it moves).  Shared by mcmc_chains and its host-closure form mcmc_host_step.
+template <class Cfg> struct McmcProposal {
+    Chain<Cfg> n;
+    double prop;
+    bool active;
+    int newcurr, ut, pvi;
+    u64 touched;
+};
+template <class Cfg> __device__ __forceinline__ McmcProposal<Cfg> mcmc_propose(const Tables<Cfg> &t, const Chain<Cfg> &c, const int curr, const int upd, const double upick,
+                                                                              const double us1, const double us2, const u64 sidx, const u32 st_step,
+                                                                              const u32 k0, const u32 k1, const u32x4 &r2) {
+    constexpr int NI = Cfg::NI, NORMI = Cfg::NI, ND = Cfg::NI + 1, NPOOL = Cfg::NPOOL;
+    (void)NI;
+    // ---- build the proposal (n, prop, newcurr); ONE evaluate-and-accept tail serves all three updates, so
+    // lanes that diverged on the update type reconverge before the expensive part ----
+    Chain<Cfg> n = c;
+    double prop = 1.0;
+    bool active = false;
+    int newcurr = curr, ut = 0; // ut: first index of propose[., ., .]: 0 changeIntegrand, 1 changeVariable, 2 swapVariable
+    int pvi = 0;                // the variable pool changeVariable / swapVariable picked (last index of propose)
+    u64 touched = 0ull; // draws of the slot(s) this proposal moves (changeVariable, swapVariable)
+    if (upd == 0) {
+        // ---- changeIntegrand  updates.jl:1-69 ----
+        static_for<0, ND>([&](auto C0) {
+            constexpr int c0 = decltype(C0)::value;
+            constexpr int nn = Cfg::nneighbor(c0);
+            if (curr == c0) {
+                int j = (int)(upick * (double)nn); // :6
+                if (j >= nn) j = nn - 1;
+                static_for<0, nn>([&](auto J) {
+                    constexpr int nw = Cfg::neighbor(c0 * Cfg::NBMAX + decltype(J)::value);
+                    if constexpr (nw != c0) { // :7
+                        if (j == decltype(J)::value) {
+                            active = true;
+                            newcurr = nw;
+                            prop = (double)nn / (double)Cfg::nneighbor(nw); // :12
+                            static_for<0, NPOOL>([&](auto V) { // :15-26
+                                constexpr int v = decltype(V)::value;
+                                constexpr int cd = Cfg::dof(c0 * NPOOL + v), nd = Cfg::dof(nw * NPOOL + v);
+                                constexpr int nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                                if constexpr (pool_is_fermik<Cfg>(v) && cd != nd) {
+                                    static_for<(cd < nd ? cd : nd), (cd < nd ? nd : cd)>([&](auto S) {
+                                        constexpr int kb = k00 + decltype(S)::value * nl;
+                                        double kk[nl];
+                                        static_for<0, nl>([&](auto J) { kk[decltype(J)::value] = c.x[kb + decltype(J)::value]; });
+                                        if constexpr (cd < nd) { // create!  sampler.jl:109-148
+                                            double u[nl];
+                                            static_for<0, nl>([&](auto J) { u[decltype(J)::value] = step_uniform<5 + kb + decltype(J)::value>(sidx, st_step, k0, k1, r2); });
+                                            prop *= fermik_create<Cfg, v>(u, kk);
+                                            static_for<0, nl>([&](auto J) { n.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
+                                        } else {                 // remove!  sampler.jl:158-188
+                                            prop *= fermik_remove<Cfg, v>(kk);
+                                        }
+                                    });
+                                } else if constexpr (cd < nd) {
+                                    static_for<cd * nl, nd * nl>([&](auto Q) { // create!  sampler.jl:293-305, :13-22
+                                        constexpr int k = k00 + decltype(Q)::value;
+                                        const double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
+                                        double raw;
+                                        draw_leaf<Cfg, k>(t, y, n.x[k], raw, n.bin[k]);
+                                        const double ip = raw * jac_scale<Cfg>(k);
+                                        n.prob[k] = 1.0 / ip;
+                                        prop *= ip;
+                                    });
+                                } else if constexpr (cd > nd) {
+                                    static_for<nd * nl, cd * nl>([&](auto Q) { // remove!  sampler.jl:318-323, :36-40
+                                        prop *= c.prob[k00 + decltype(Q)::value];
+                                    });
+                                }
+                            });
+                        }
+                    }
+                });
+            }
+        });
+    } else if (curr != NORMI) { // updates.jl:73, :115
+        int vi = (int)(upick * (double)NPOOL); // :77, :119
+        if (vi >= NPOOL) vi = NPOOL - 1;
+        pvi = vi;
+        int cdv = 0; // currdof[vi]
+        static_for<0, NI>([&](auto I) {
+            static_for<0, NPOOL>([&](auto V) {
+                if (curr == decltype(I)::value && vi == decltype(V)::value) cdv = Cfg::dof(decltype(I)::value * NPOOL + decltype(V)::value);
+            });
+        });
+        if (upd == 1) {
+            // ---- swapVariable  updates.jl:113-147 ----
+            ut = 2;
+            if (cdv > 0) { // :121
+                int s1 = (int)(us1 * (double)cdv), s2 = (int)(us2 * (double)cdv); // :122-123
+                if (s1 >= cdv) s1 = cdv - 1;
+                if (s2 >= cdv) s2 = cdv - 1;
+                if (s1 != s2) { // :124
+                    active = true;
+                    static_for<0, NPOOL>([&](auto V) {
+                        constexpr int v = decltype(V)::value;
+                        if (vi == v) {
+                            constexpr u64 slotbits = (1ull << Cfg::pool_nleaf(v)) - 1ull;
+                            touched = (slotbits << (Cfg::pool_first_draw(v) + s1 * Cfg::pool_nleaf(v))) |
+                                      (slotbits << (Cfg::pool_first_draw(v) + s2 * Cfg::pool_nleaf(v)));
+                            static_for<0, Cfg::pool_nleaf(v)>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
+                                constexpr int l = decltype(Lf)::value;
+                                double xa, xb, pa, pb;
+                                int ba, bb;
+                                get_slot<Cfg, v, l>(c, s1, xa, pa, ba);
+                                get_slot<Cfg, v, l>(c, s2, xb, pb, bb);
+                                put_slot<Cfg, v, l>(n, s1, xb, pb, bb);
+                                put_slot<Cfg, v, l>(n, s2, xa, pa, ba);
+                            });
+                        }
+                    });
+                }
+            }
+        } else {
+            // ---- changeVariable  updates.jl:71-111 ----
+            ut = 1;
+            static_for<0, NPOOL>([&](auto V) {
+                constexpr int v = decltype(V)::value;
+                constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                constexpr bool skip = (md <= 0) || (nl == 1 && Cfg::leaf_kind(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1 &&
+                                                    Cfg::leaf_nbin(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1); // :79-81
+                if constexpr (!skip) {
+                    if (vi == v && cdv > 0) { // :82
+                        active = true;
+                        int slot = (int)(us1 * (double)cdv); // :83
+                        if (slot >= cdv) slot = cdv - 1;
+                        touched = ((1ull << nl) - 1ull) << (k00 + slot * nl);
+                        if constexpr (pool_is_fermik<Cfg>(v)) { // shift!  sampler.jl:198-246; the move is picked by uniform 3
+                            double u[nl], kk[nl], po;
+                            int bo;
+                            static_for<0, nl>([&](auto J) {
+                                constexpr int j = decltype(J)::value;
+                                u[j] = step_uniform_dyn(5 + k00 + slot * nl + j, sidx, st_step, k0, k1);
+                                get_slot<Cfg, v, j>(c, slot, kk[j], po, bo);
+                            });
+                            prop *= fermik_shift<Cfg, v>(us2, u, kk);
+                            static_for<0, nl>([&](auto J) { put_slot<Cfg, v, decltype(J)::value>(n, slot, kk[decltype(J)::value], 1.0, 0); });
+                        } else
+                        static_for<0, nl>([&](auto Lf) { // shift!  sampler.jl:336-386, :57-71, :431-440
+                            constexpr int l = decltype(Lf)::value;
+                            const double y = step_uniform_dyn(5 + k00 + slot * nl + l, sidx, st_step, k0, k1);
+                            double xo, po, xn, pn;
+                            int bo, bn;
+                            get_slot<Cfg, v, l>(c, slot, xo, po, bo);
+                            draw_pool_leaf<Cfg, v, l>(t, y, xn, pn, bn);
+                            put_slot<Cfg, v, l>(n, slot, xn, pn, bn);
+                            prop *= po / pn; // 1/prob_ratio  sampler.jl:385, :70
+                        });
+                    }
+                }
+            });
+        }
+    }
+    McmcProposal<Cfg> out;
+    out.n = n;
+    out.prop = prop;
+    out.active = active;
+    out.newcurr = newcurr;
+    out.ut = ut;
+    out.pvi = pvi;
+    out.touched = touched;
+    return out;
+}
+
 template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NI = Cfg::NI, NORMI = Cfg::NI, ND = Cfg::NI + 1, NPOOL = Cfg::NPOOL;
@@ -1824,144 +1998,12 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             const double upick = u01(r0.z, r0.w), us1 = u01(r1.x, r1.y), us2 = u01(r1.z, r1.w), uacc = u01(r2.x, r2.y);
             // ---- build the proposal (n, prop, newcurr); ONE evaluate-and-accept tail serves all three updates, so
             // lanes that diverged on the update type reconverge before the expensive part ----
-            Chain<Cfg> n = c;
-            double prop = 1.0;
-            bool active = false;
-            int newcurr = curr, ut = 0; // ut: first index of propose[., ., .]: 0 changeIntegrand, 1 changeVariable, 2 swapVariable
-            int pvi = 0;                // the variable pool changeVariable / swapVariable picked (last index of propose)
-            u64 touched = 0ull; // draws of the slot(s) this proposal moves (changeVariable, swapVariable)
-            if (upd == 0) {
-                // ---- changeIntegrand  updates.jl:1-69 ----
-                static_for<0, ND>([&](auto C0) {
-                    constexpr int c0 = decltype(C0)::value;
-                    constexpr int nn = Cfg::nneighbor(c0);
-                    if (curr == c0) {
-                        int j = (int)(upick * (double)nn); // :6
-                        if (j >= nn) j = nn - 1;
-                        static_for<0, nn>([&](auto J) {
-                            constexpr int nw = Cfg::neighbor(c0 * Cfg::NBMAX + decltype(J)::value);
-                            if constexpr (nw != c0) { // :7
-                                if (j == decltype(J)::value) {
-                                    active = true;
-                                    newcurr = nw;
-                                    prop = (double)nn / (double)Cfg::nneighbor(nw); // :12
-                                    static_for<0, NPOOL>([&](auto V) { // :15-26
-                                        constexpr int v = decltype(V)::value;
-                                        constexpr int cd = Cfg::dof(c0 * NPOOL + v), nd = Cfg::dof(nw * NPOOL + v);
-                                        constexpr int nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
-                                        if constexpr (pool_is_fermik<Cfg>(v) && cd != nd) {
-                                            static_for<(cd < nd ? cd : nd), (cd < nd ? nd : cd)>([&](auto S) {
-                                                constexpr int kb = k00 + decltype(S)::value * nl;
-                                                double kk[nl];
-                                                static_for<0, nl>([&](auto J) { kk[decltype(J)::value] = c.x[kb + decltype(J)::value]; });
-                                                if constexpr (cd < nd) { // create!  sampler.jl:109-148
-                                                    double u[nl];
-                                                    static_for<0, nl>([&](auto J) { u[decltype(J)::value] = step_uniform<5 + kb + decltype(J)::value>(sidx, st_step, k0, k1, r2); });
-                                                    prop *= fermik_create<Cfg, v>(u, kk);
-                                                    static_for<0, nl>([&](auto J) { n.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
-                                                } else {                 // remove!  sampler.jl:158-188
-                                                    prop *= fermik_remove<Cfg, v>(kk);
-                                                }
-                                            });
-                                        } else if constexpr (cd < nd) {
-                                            static_for<cd * nl, nd * nl>([&](auto Q) { // create!  sampler.jl:293-305, :13-22
-                                                constexpr int k = k00 + decltype(Q)::value;
-                                                const double y = step_uniform<5 + k>(sidx, st_step, k0, k1, r2);
-                                                double raw;
-                                                draw_leaf<Cfg, k>(t, y, n.x[k], raw, n.bin[k]);
-                                                const double ip = raw * jac_scale<Cfg>(k);
-                                                n.prob[k] = 1.0 / ip;
-                                                prop *= ip;
-                                            });
-                                        } else if constexpr (cd > nd) {
-                                            static_for<nd * nl, cd * nl>([&](auto Q) { // remove!  sampler.jl:318-323, :36-40
-                                                prop *= c.prob[k00 + decltype(Q)::value];
-                                            });
-                                        }
-                                    });
-                                }
-                            }
-                        });
-                    }
-                });
-            } else if (curr != NORMI) { // updates.jl:73, :115
-                int vi = (int)(upick * (double)NPOOL); // :77, :119
-                if (vi >= NPOOL) vi = NPOOL - 1;
-                pvi = vi;
-                int cdv = 0; // currdof[vi]
-                static_for<0, NI>([&](auto I) {
-                    static_for<0, NPOOL>([&](auto V) {
-                        if (curr == decltype(I)::value && vi == decltype(V)::value) cdv = Cfg::dof(decltype(I)::value * NPOOL + decltype(V)::value);
-                    });
-                });
-                if (upd == 1) {
-                    // ---- swapVariable  updates.jl:113-147 ----
-                    ut = 2;
-                    if (cdv > 0) { // :121
-                        int s1 = (int)(us1 * (double)cdv), s2 = (int)(us2 * (double)cdv); // :122-123
-                        if (s1 >= cdv) s1 = cdv - 1;
-                        if (s2 >= cdv) s2 = cdv - 1;
-                        if (s1 != s2) { // :124
-                            active = true;
-                            static_for<0, NPOOL>([&](auto V) {
-                                constexpr int v = decltype(V)::value;
-                                if (vi == v) {
-                                    constexpr u64 slotbits = (1ull << Cfg::pool_nleaf(v)) - 1ull;
-                                    touched = (slotbits << (Cfg::pool_first_draw(v) + s1 * Cfg::pool_nleaf(v))) |
-                                              (slotbits << (Cfg::pool_first_draw(v) + s2 * Cfg::pool_nleaf(v)));
-                                    static_for<0, Cfg::pool_nleaf(v)>([&](auto Lf) { // swap!  sampler.jl:395-408, :86-97, :448-455
-                                        constexpr int l = decltype(Lf)::value;
-                                        double xa, xb, pa, pb;
-                                        int ba, bb;
-                                        get_slot<Cfg, v, l>(c, s1, xa, pa, ba);
-                                        get_slot<Cfg, v, l>(c, s2, xb, pb, bb);
-                                        put_slot<Cfg, v, l>(n, s1, xb, pb, bb);
-                                        put_slot<Cfg, v, l>(n, s2, xa, pa, ba);
-                                    });
-                                }
-                            });
-                        }
-                    }
-                } else {
-                    // ---- changeVariable  updates.jl:71-111 ----
-                    ut = 1;
-                    static_for<0, NPOOL>([&](auto V) {
-                        constexpr int v = decltype(V)::value;
-                        constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
-                        constexpr bool skip = (md <= 0) || (nl == 1 && Cfg::leaf_kind(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1 &&
-                                                            Cfg::leaf_nbin(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1); // :79-81
-                        if constexpr (!skip) {
-                            if (vi == v && cdv > 0) { // :82
-                                active = true;
-                                int slot = (int)(us1 * (double)cdv); // :83
-                                if (slot >= cdv) slot = cdv - 1;
-                                touched = ((1ull << nl) - 1ull) << (k00 + slot * nl);
-                                if constexpr (pool_is_fermik<Cfg>(v)) { // shift!  sampler.jl:198-246; the move is picked by uniform 3
-                                    double u[nl], kk[nl], po;
-                                    int bo;
-                                    static_for<0, nl>([&](auto J) {
-                                        constexpr int j = decltype(J)::value;
-                                        u[j] = step_uniform_dyn(5 + k00 + slot * nl + j, sidx, st_step, k0, k1);
-                                        get_slot<Cfg, v, j>(c, slot, kk[j], po, bo);
-                                    });
-                                    prop *= fermik_shift<Cfg, v>(us2, u, kk);
-                                    static_for<0, nl>([&](auto J) { put_slot<Cfg, v, decltype(J)::value>(n, slot, kk[decltype(J)::value], 1.0, 0); });
-                                } else
-                                static_for<0, nl>([&](auto Lf) { // shift!  sampler.jl:336-386, :57-71, :431-440
-                                    constexpr int l = decltype(Lf)::value;
-                                    const double y = step_uniform_dyn(5 + k00 + slot * nl + l, sidx, st_step, k0, k1);
-                                    double xo, po, xn, pn;
-                                    int bo, bn;
-                                    get_slot<Cfg, v, l>(c, slot, xo, po, bo);
-                                    draw_pool_leaf<Cfg, v, l>(t, y, xn, pn, bn);
-                                    put_slot<Cfg, v, l>(n, slot, xn, pn, bn);
-                                    prop *= po / pn; // 1/prob_ratio  sampler.jl:385, :70
-                                });
-                            }
-                        }
-                    });
-                }
-            }
+            const McmcProposal<Cfg> pr = mcmc_propose<Cfg>(t, c, curr, upd, upick, us1, us2, sidx, st_step, k0, k1, r2);
+            const Chain<Cfg> &n = pr.n;
+            const double prop = pr.prop;
+            const bool active = pr.active;
+            const int newcurr = pr.newcurr, ut = pr.ut, pvi = pr.pvi;
+            const u64 touched = pr.touched;
             if (active && prop > 4.9406564584124654e-324) { // updates.jl:29-31, :88-90, :129-131
                 Weight<Cfg> wn;
                 static_for<0, Cfg::NCOMP>([&](auto Q) { wn.v[decltype(Q)::value] = 0.0; });
@@ -2058,6 +2100,250 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     }
     __syncthreads();
     flush_workgroup<Cfg, Lds<Cfg>, true, true>(a, smem, acc, extra, wi.rowid, tile);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MCMC with the integrand on the HOST (BatchArgs::HostStep): the step of mcmc_chains cut at the integrand call
+// (mcmc/updates.jl:35-38, :92, :133).  Every launch finishes, per chain, the evaluation that just came back -- the start
+// configuration (retried like montecarlo.jl:118-124) or the proposal of step it -- and proposes the next step; the host evaluates
+// integrand hidx[chain] at hx[.][chain].  Same streams, same arithmetic as mcmc_chains (the holding-time diagnostic is left out).
+// ---------------------------------------------------------------------------------------------
+template <class Cfg> __device__ __forceinline__ void mcmc_host_step(const BatchArgs &a) {
+    static_assert(Cfg::NTILE == 1, "host-closure chains keep one histogram tile");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NI = Cfg::NI, NORMI = Cfg::NI, ND = Cfg::NI + 1, NPOOL = Cfg::NPOOL;
+    constexpr int NUPD = 2 * NPOOL + 2;
+    const int tid = threadIdx.x, T = blockDim.x;
+    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
+    double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
+    stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
+    if constexpr (Mode<Cfg>::HIST_LDS)
+        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
+    for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
+    for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;
+    __syncthreads();
+    Tables<Cfg> t;
+    if constexpr (Mode<Cfg>::EDGE_LDS) t.E = sE;
+    else t.E = a.edges;
+    t.DA = sDA;
+    t.DD = sDD;
+
+    const WorkItem wi = work_item<Cfg>(a);
+    const BatchArgs::HostStep &h = a.hs;
+    const i64 B = a.block_lo + wi.lb;
+    const i64 total = a.neval_per_block / a.nchain + a.nburn, nburn = a.nburn, nc = h.nc;
+    const u32 bs = (u32)B << 20;
+    const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT + bs, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP + bs;
+    const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
+    double rw[ND];
+    static_for<0, ND>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
+    auto rw_sel = [&](int i) {
+        double r = rw[NORMI];
+        static_for<0, NI>([&](auto I) { if (i == decltype(I)::value) r = rw[decltype(I)::value]; });
+        return r;
+    };
+    double acc[Cfg::NW];
+    static_for<0, Cfg::NW>([&](auto I) { acc[decltype(I)::value] = 0.0; });
+    double extra[Cfg::NCOLS - Cfg::NOBS];
+    static_for<0, Cfg::NCOLS - Cfg::NOBS>([&](auto I) { extra[decltype(I)::value] = 0.0; });
+    constexpr int XN = Cols<Cfg>::NORM - Cfg::NOBS, XE = Cols<Cfg>::NEVAL - Cfg::NOBS, XV = Cols<Cfg>::VISITED - Cfg::NOBS;
+
+    for (i64 ch = (i64)wi.slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
+        const u64 g = (u64)ch;
+        const i64 cid = wi.lb * a.nchain + ch;
+        Chain<Cfg> c;
+        auto draw_start = [&](const int tr) { // initialize!  :190-193: try `tr` of the start configuration -> state + what the host evaluates
+            Sample<Cfg> s;
+            draw_sample<Cfg>(t, a.seed, st_init, g * 16384ull + (u64)tr, s);
+            static_for<0, Cfg::NDRAW>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                c.x[k] = s.x[k];
+                c.bin[k] = s.bin[k];
+                c.prob[k] = 1.0 / s.pj[k];
+            });
+            static_for<0, NPOOL>([&](auto V) { // FermiK slots are created jointly from their D uniforms (same stream, k = flat draw)
+                constexpr int v = decltype(V)::value;
+                if constexpr (pool_is_fermik<Cfg>(v)) {
+                    constexpr int D = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                    constexpr double kF = Cfg::leaf_lower(Cfg::draw_leaf(k00));
+                    static_for<0, Cfg::pool_maxdof(v)>([&](auto S) {
+                        constexpr int kb = k00 + decltype(S)::value * D;
+                        double u[D], kk[D];
+                        const u64 iidx = g * 16384ull + (u64)tr;
+                        static_for<0, D>([&](auto J) {
+                            constexpr int kq = kb + decltype(J)::value;
+                            const u32x4 rr = philox4x32_10((u32)iidx, (u32)(iidx >> 32), (u32)(kq >> 1), st_init, k0, k1);
+                            u[decltype(J)::value] = (kq & 1) ? u01(rr.z, rr.w) : u01(rr.x, rr.y);
+                            kk[decltype(J)::value] = kF / sqrt((double)D);
+                        });
+                        (void)fermik_create<Cfg, v>(u, kk);
+                        static_for<0, D>([&](auto J) { c.x[kb + decltype(J)::value] = kk[decltype(J)::value]; });
+                    });
+                }
+            });
+            static_for<0, Cfg::NDRAW>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                h.cx[k * nc + cid] = c.x[k];
+                h.hx[k * nc + cid] = c.x[k];
+                h.cbin[k * nc + cid] = c.bin[k];
+                h.cprob[k * nc + cid] = c.prob[k];
+            });
+        };
+        if (h.ne == 0) {
+            const int curr0 = a.nchain == 1 ? 0 : (int)(g % (u64)ND); // montecarlo.jl:76 idx = 1; many chains start stratified
+            draw_start(0);
+            h.ccurr[cid] = curr0;
+            h.cit[cid] = -1;
+            h.ctr[cid] = 0;
+            h.hidx[cid] = curr0 != NORMI ? curr0 : -1;
+            continue;
+        }
+        int it = h.cit[cid];
+        if (it >= total) continue; // this chain is through
+        int curr = h.ccurr[cid];
+        static_for<0, Cfg::NDRAW>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            c.x[k] = h.cx[k * nc + cid];
+            c.prob[k] = h.cprob[k * nc + cid];
+            c.bin[k] = h.cbin[k * nc + cid];
+        });
+        Weight<Cfg> weight;
+        double probability;
+        if (it < 0) { // ---- the start configuration was evaluated  :118-126, :195-203 ----
+            static_for<0, Cfg::NCOMP>([&](auto Q) { weight.v[decltype(Q)::value] = 0.0; });
+            weight.abs = 0.0;
+            if (curr != NORMI) {
+                static_for<0, Cfg::NCOMP>([&](auto Q) { weight.v[decltype(Q)::value] = a.host_w[decltype(Q)::value * nc + cid]; });
+                if constexpr (Cfg::NCOMP == 1) weight.abs = fabs(weight.v[0]);
+                else weight.abs = hypot(weight.v[0], weight.v[Cfg::NCOMP - 1]);
+                probability = weight.abs * rw_sel(curr);        // :199
+            } else {
+                probability = rw[NORMI];                        // :201-202
+            }
+            if (!(curr == NORMI || probability > 4.940656458412465e-274)) { // :120-122 (TINY): draw the start again
+                const int tr = h.ctr[cid] + 1;
+                if (tr >= 10000) {
+                    if (probability == 0.0) atomicOr(a.status, ST_MCMC_INIT); // :125-126 error(...)
+                } else {
+                    h.ctr[cid] = tr;
+                    draw_start(tr);
+                    h.hidx[cid] = curr;
+                    continue;
+                }
+            }
+            it = 0;
+        } else { // ---- the proposal of step it + 1 was evaluated: accept or drop it, then measure ----
+            static_for<0, Cfg::NCOMP>([&](auto Q) { weight.v[decltype(Q)::value] = h.cw[decltype(Q)::value * nc + cid]; });
+            weight.abs = h.cwabs[cid];
+            probability = h.cprobability[cid];
+            const int step = it + 1;
+            const double prop = h.pprop[cid];
+            const int newcurr = h.pnew[cid], ut = h.put[cid], pvi = h.pvi[cid];
+            if (ut >= 0 && prop > 4.9406564584124654e-324) { // updates.jl:29-31, :88-90, :129-131  (ut < 0: nothing was proposed)
+                Chain<Cfg> n;
+                static_for<0, Cfg::NDRAW>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    n.x[k] = h.hx[k * nc + cid];
+                    n.prob[k] = h.pprob[k * nc + cid];
+                    n.bin[k] = h.pbin[k * nc + cid];
+                });
+                Weight<Cfg> wn;
+                static_for<0, Cfg::NCOMP>([&](auto Q) { wn.v[decltype(Q)::value] = 0.0; });
+                wn.abs = 0.0;
+                if (newcurr != NORMI) {                                                        // :35-38, :92, :133 -- on the host
+                    static_for<0, Cfg::NCOMP>([&](auto Q) { wn.v[decltype(Q)::value] = a.host_w[decltype(Q)::value * nc + cid]; });
+                    if constexpr (Cfg::NCOMP == 1) wn.abs = fabs(wn.v[0]);
+                    else wn.abs = hypot(wn.v[0], wn.v[Cfg::NCOMP - 1]);
+                }
+                extra[XE] += 1.0;                                                               // :40, :94, :135
+                const double newp = newcurr == NORMI ? rw[NORMI] : wn.abs * rw_sel(newcurr);    // :42-44, :96, :137
+                const double R = prop * newp / probability;                                     // :46, :97, :138
+                const bool ok = h.puacc[cid] < R;                                               // :49, :100, :141
+                pa_count<Cfg, false>(sPA, PaTable<Cfg>::idx(ut, curr, ut == 0 ? newcurr : pvi), true, ok);
+                if (ok) {
+                    c = n;
+                    curr = newcurr;                                                             // :51-53
+                    weight = wn;
+                    probability = newp;
+                }
+            }
+            if (step % a.measurefreq == 0 && step >= nburn) { // ---- measurement  montecarlo.jl:144-172 ----
+                if (curr != NORMI) {
+                    double relw[Cfg::NCOMP]; // :162
+                    static_for<0, Cfg::NCOMP>([&](auto Q) { relw[decltype(Q)::value] = weight.v[decltype(Q)::value] / probability; });
+                    static_for<0, NI>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        if (curr == i) {
+                            static_for<0, Cfg::NDRAW>([&](auto K) { // :147-154  accumulate!(var, pos + offset, 1.0)
+                                constexpr int k = decltype(K)::value;
+                                if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hist_add<Cfg, k>(c.bin[k], 1.0, sH, a.ghist, 0);
+                            });
+                            if constexpr (Cfg::CUSTOM_MEASURE != 0) { // measure(idx, var, obs, relative_weight, config)  :166-169
+                                double rwv[Cfg::NW];
+                                static_for<0, Cfg::NW>([&](auto Q) { rwv[decltype(Q)::value] = 0.0; });
+                                static_for<0, Cfg::NCOMP>([&](auto Q) { rwv[i * Cfg::NCOMP + decltype(Q)::value] = relw[decltype(Q)::value]; });
+                                Cfg::measure(c.x, rwv, a.ud, i, sO);
+                            } else if constexpr (Cfg::obs_bin_draw(i) >= 0) {
+                                const int b = c.bin[Cfg::obs_bin_draw(i)];
+                                if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw[0]);
+                            }
+                        }
+                        if constexpr (Cfg::CUSTOM_MEASURE == 0 && Cfg::obs_bin_draw(i) < 0) // :164
+                            static_for<0, Cfg::NCOMP>([&](auto Q) { acc[i * Cfg::NCOMP + decltype(Q)::value] += curr == i ? relw[decltype(Q)::value] : 0.0; });
+                    });
+                } else {
+                    extra[XN] += 1.0 / rw[NORMI]; // :158
+                }
+            }
+            it = step;
+        }
+        if (it < total) { // ---- propose step it + 1 ----
+            const u64 sidx = (g << 32) | (u64)it;
+            static_for<0, ND>([&](auto I) { extra[XV + decltype(I)::value] += curr == decltype(I)::value ? 1.0 : 0.0; }); // :136
+            const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
+            const u32x4 r1 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 1u, st_step, k0, k1);
+            const u32x4 r2 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 2u, st_step, k0, k1);
+            double uupd = u01(r0.x, r0.y);
+            if (a.nchain > 1) { // (the 64 chains of a wave share the update-type sequence, as in mcmc_chains)
+                const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)it;
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MCMC_GROUP + bs, k0, k1);
+                uupd = u01(rg.x, rg.y);
+            }
+            int upd = (int)(uupd * (double)NUPD);
+            if (upd >= NUPD) upd = NUPD - 1;
+            const double upick = u01(r0.z, r0.w), us1 = u01(r1.x, r1.y), us2 = u01(r1.z, r1.w);
+            const McmcProposal<Cfg> pr = mcmc_propose<Cfg>(t, c, curr, upd, upick, us1, us2, sidx, st_step, k0, k1, r2);
+            static_for<0, Cfg::NDRAW>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                h.hx[k * nc + cid] = pr.n.x[k];
+                h.pprob[k * nc + cid] = pr.n.prob[k];
+                h.pbin[k * nc + cid] = pr.n.bin[k];
+            });
+            h.pprop[cid] = pr.prop;
+            h.puacc[cid] = u01(r2.x, r2.y);
+            h.pnew[cid] = pr.newcurr;
+            h.put[cid] = pr.active ? pr.ut : -1;
+            h.pvi[cid] = pr.pvi;
+            h.hidx[cid] = (pr.active && pr.prop > 4.9406564584124654e-324 && pr.newcurr != NORMI) ? pr.newcurr : -1;
+        } else {
+            h.hidx[cid] = -1;
+            atomicAdd(h.done, 1);
+        }
+        static_for<0, Cfg::NDRAW>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            h.cx[k * nc + cid] = c.x[k];
+            h.cprob[k * nc + cid] = c.prob[k];
+            h.cbin[k * nc + cid] = c.bin[k];
+        });
+        static_for<0, Cfg::NCOMP>([&](auto Q) { h.cw[decltype(Q)::value * nc + cid] = weight.v[decltype(Q)::value]; });
+        h.cwabs[cid] = weight.abs;
+        h.cprobability[cid] = probability;
+        h.ccurr[cid] = curr;
+        h.cit[cid] = it;
+    }
+    __syncthreads();
+    flush_workgroup<Cfg, Lds<Cfg>, true, true, true>(a, smem, acc, extra, wi.rowid, 0);
 }
 
 // the map + integrand alone, for parity tests of a2/a3 and for host-side consumers

@@ -160,7 +160,7 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
           << (s.host_integrand ? "mci::vegasmc_host_step<Cfg>(a); }\n" : "mci::vegasmc_chains<Cfg>(a); }\n");
     } else {
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_mcmc_chains(mci::BatchArgs a) { "
-             "mci::mcmc_chains<Cfg>(a); }\n";
+          << (s.host_integrand ? "mci::mcmc_host_step<Cfg>(a); }\n" : "mci::mcmc_chains<Cfg>(a); }\n");
     }
     return o.str();
 }

@@ -109,7 +109,10 @@ class Engine:
         self.p = C.c_void_p()
         check(L.mci_problem_create(self.ctx, C.byref(desc), C.byref(self.p)))
         ud = integrand.userdata
-        if isinstance(integrand, HostIntegrand):
+        if isinstance(integrand, HostIntegrand) and getattr(integrand, "indexed", False):
+            self._host_cb = _lib.HOST_INTEGRAND_IDX_FN(self._make_host_indexed_callback(integrand.fn))   # keep alive
+            check(L.mci_set_integrand_host_indexed(self.p, C.cast(self._host_cb, C.c_void_p), None))
+        elif isinstance(integrand, HostIntegrand):
             self._host_cb = _lib.HOST_INTEGRAND_FN(self._make_host_callback(integrand.fn))   # keep alive
             check(L.mci_set_integrand_host(self.p, C.cast(self._host_cb, C.c_void_p), None))
         else:
@@ -166,6 +169,33 @@ class Engine:
                         W[2 * i + 1] = o.imag
                     else:
                         W[i] = o
+                return 0
+            except Exception:   # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        return cb
+
+    def _make_host_indexed_callback(self, fn):
+        """ctypes trampoline of the `integrand(idx, var, config)` form: one call of fn per integrand index some chain asks for,
+        over the chains that ask for it"""
+        config = self.config
+        nc = config.ncomp
+
+        def cb(ip, xp, wp, n, ndraw, ncomp, user):
+            try:
+                idx = np.ctypeslib.as_array(ip, shape=(n,))
+                X = np.ctypeslib.as_array(xp, shape=(ndraw, n))
+                W = np.ctypeslib.as_array(wp, shape=(ncomp, n))
+                for i in np.unique(idx[idx >= 0]):
+                    sel = np.nonzero(idx == i)[0]
+                    whole = len(sel) == n
+                    o = fn(int(i), self._pool_views(X if whole else np.ascontiguousarray(X[:, sel]), len(sel)), config)
+                    o = np.broadcast_to(np.asarray(o), (len(sel),))
+                    if nc == 2:
+                        W[0, sel], W[1, sel] = o.real, o.imag
+                    else:
+                        W[0, sel] = o
                 return 0
             except Exception:   # never unwind through the C frame
                 import traceback

@@ -44,12 +44,20 @@ class HostIntegrand:
     With one variable type `x[i]` is the vector of the i-th draw over the n samples of the batch (0-based; the
     reference's `x[i+1]`); with several, `x` is a tuple with one such array per variable type (a CompositeVar pool has
     shape [slot, leaf, n]).  solver="vegas": n = the samples of a launch, one call per launch; solver="vegasmc" (the reference's
-    default): n = the chains of a launch, one call per Markov step (the chains advance in lock step).  Not under "mcmc"."""
+    default) and "mcmc": n = the chains of a launch, one call per Markov step (the chains advance in lock step).
 
-    def __init__(self, fn, name=None):
+    indexed=True: the reference's `:mcmc` form `integrand(idx, var, config)` (mcmc/montecarlo.jl:34-36) --
+
+        f(idx, x, config) -> array[m]
+
+    is called once per integrand index that some chain needs, with `x` restricted to those m chains (idx is 0-based: the
+    reference's idx - 1); include/mci.h mci_set_integrand_host_indexed.  Either form works under every solver."""
+
+    def __init__(self, fn, name=None, indexed=False):
         self.fn = fn
+        self.indexed = bool(indexed)
         self.name = name or getattr(fn, "__name__", "host")
-        self.body = "/* host integrand %d */" % id(fn)
+        self.body = "/* host integrand %d%s */" % (id(fn), " indexed" if indexed else "")
         self.userdata = np.zeros(0)
 
 

@@ -53,7 +53,14 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     if isinstance(integrand, str):
         integrand = Integrand(integrand, config.userdata)
     elif callable(integrand) and not isinstance(integrand, (Integrand, HostIntegrand)):
-        integrand = HostIntegrand(integrand)       # a Python closure: host "batch callback" path (vegas: per launch, vegasmc: per Markov step)
+        # a Python closure: host "batch callback" path (vegas: per launch, vegasmc / mcmc: per Markov step).  Three positional
+        # parameters = the reference's :mcmc form integrand(idx, var, config) (mcmc/montecarlo.jl:34-36), two = integrand(var, config)
+        import inspect
+        try:
+            npos = len([q for q in inspect.signature(integrand).parameters.values() if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)])
+        except (TypeError, ValueError):
+            npos = 2
+        integrand = HostIntegrand(integrand, indexed=(npos >= 3))
     if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
         measure = HostMeasure(measure)             # a Python closure as measure: host batch-callback path, solver="vegas" only
     mkey = None if measure is None else measure.body if isinstance(measure, (Measure, HostMeasure)) else (measure.pool, measure.slot, measure.leaf)

@@ -284,7 +284,8 @@ function visited(c::Configuration)
 end
 
 # ---- Julia closures as integrands: the host "batch callback" slow path (mci_set_integrand_host) ----------------------
-# f(x, config) is called ONCE per launch with x[k] = the vector of draw k over the n samples of the batch (several
+# f(x, config) is called once per launch (:vegas) or once per Markov step (:vegasmc, :mcmc: the chains of a launch advance in lock
+# step) with x[k] = the vector of draw k over the n samples / chains of the batch (several
 # variable types: a tuple of per-pool matrices), and returns a vector (or a tuple of vectors, one per integrand).
 const _closures = Dict{Ptr{Cvoid},Any}()      # problem => (f, config): keeps them rooted
 function _host_trampoline(x::Ptr{Float64}, w::Ptr{Float64}, n::Int64, ndraw::Int32, nw::Int32, user::Ptr{Cvoid})::Cint
@@ -308,11 +309,40 @@ function _host_trampoline(x::Ptr{Float64}, w::Ptr{Float64}, n::Int64, ndraw::Int
         return Cint(1)
     end
 end
+# the reference's :mcmc form f(idx, x, config) (src/mcmc/montecarlo.jl:34-36; idx 1-based like the reference): one call per integrand
+# index some chain asks for, over the chains that ask for it (mci_set_integrand_host_indexed)
+function _host_idx_trampoline(idx::Ptr{Int32}, x::Ptr{Float64}, w::Ptr{Float64}, n::Int64, ndraw::Int32, ncomp::Int32, user::Ptr{Cvoid})::Cint
+    try
+        f, c = _closures[user]
+        I = unsafe_wrap(Array, idx, (Int(n),))
+        X = unsafe_wrap(Array, x, (Int(n), Int(ndraw)))
+        W = unsafe_wrap(Array, w, (Int(n), Int(ncomp)))
+        for i in unique(I)
+            i < 0 && continue
+            sel = findall(==(i), I)
+            o = f(Int(i) + 1, [X[sel, k] for k in 1:ndraw], c)
+            if ncomp == 2
+                W[sel, 1] .= real.(o); W[sel, 2] .= imag.(o)
+            else
+                W[sel, 1] .= o
+            end
+        end
+        return Cint(0)
+    catch err
+        @error "host integrand failed" err
+        return Cint(1)
+    end
+end
 function bind_host!(c::Configuration, f::Function)
     prob = bind!(c, Integrand("", Float64[]), nothing)
     _closures[prob] = (f, c)
-    cb = @cfunction(_host_trampoline, Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Ptr{Cvoid}))
-    check(ccall((:mci_set_integrand_host, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, cb, prob))
+    if any(m -> m.nargs - 1 >= 3, methods(f))      # f(idx, x, config): the reference's :mcmc signature
+        cb = @cfunction(_host_idx_trampoline, Cint, (Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Ptr{Cvoid}))
+        check(ccall((:mci_set_integrand_host_indexed, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, cb, prob))
+    else
+        cb = @cfunction(_host_trampoline, Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Ptr{Cvoid}))
+        check(ccall((:mci_set_integrand_host, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, cb, prob))
+    end
     prob
 end
 

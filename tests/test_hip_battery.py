@@ -443,8 +443,36 @@ def test_python_closure_as_integrand_matches_device_source():
     g = lambda v, c: v[0][0] * v[1][0] + 1j * v[0][0]
     res = integrate(g, var=(Continuous(0.0, 1.0), Discrete(1, 3)), dof=[[1, 1]], type=complex, solver="vegas", neval=1e5, seed=7)
     check_complex(res, 3.0 + 1.5j)
-    with pytest.raises(mci.MCIError):   # the :mcmc step takes device source
-        integrate(lambda x, c: x[0], solver="mcmc", neval=1e4)
+
+
+def test_python_closure_under_mcmc_matches_device_source():
+    """:mcmc calls `integrand(idx, var, config)` inside every Markov step (mcmc/updates.jl:35-38).  A host closure -- the
+    reference's three-argument form, or the two-argument form returning every integrand -- runs one launch and one batch
+    callback per step (mcmc_host_step) on the same streams and arithmetic as mcmc_chains: the same chains."""
+    kw = dict(dof=[[2], [3]], neval=4e4, niter=3, seed=13, nchain=16, solver="mcmc")
+    def f3(idx, X, c):          # reference form; idx is 0-based here
+        r2 = X[0] ** 2 + X[1] ** 2 + (X[2] ** 2 if idx == 1 else 0.0)
+        return (r2 < 1.0) * 1.0
+    f2 = lambda X, c: ((X[0] ** 2 + X[1] ** 2 < 1.0) * 1.0, (X[0] ** 2 + X[1] ** 2 + X[2] ** 2 < 1.0) * 1.0)
+    d = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), **kw)
+    for f in (f3, f2):
+        a = integrate(f, var=Continuous(0.0, 1.0), **kw)
+        np.testing.assert_allclose(a.iter_mean, d.iter_mean, rtol=1e-9)
+        np.testing.assert_allclose(a.iter_std, d.iter_std, rtol=1e-6)
+        pa, aa = a.config._engine.acceptance()
+        pd_, ad = d.config._engine.acceptance()
+        np.testing.assert_allclose(pa, pd_, rtol=1e-12)
+        np.testing.assert_allclose(aa, ad, rtol=1e-12)
+    # the reference's chain (one per block), several pools with a Discrete, a start that has to be redrawn for some chains
+    # (the indicator is zero on 21 % of the square), measurefreq
+    kw = dict(var=(Continuous(0.0, 1.0), Discrete(1, 3)), dof=[[2, 1]], neval=3e3, niter=2, seed=4, nchain=1, block=4, solver="mcmc", measurefreq=2)
+    h = integrate(lambda idx, v, c: (v[0][0] ** 2 + v[0][1] ** 2 < 1.0) * v[1][0], **kw)
+    kw["var"] = (Continuous(0.0, 1.0), Discrete(1, 3))
+    ds = integrate("return (x[0] * x[0] + x[1] * x[1] < 1.0) ? x[2] : 0.0;", **kw)
+    np.testing.assert_allclose(h.iter_mean, ds.iter_mean, rtol=1e-9)
+    # the three-argument form under the other solvers: the library asks it for every integrand in turn
+    v = integrate(f3, var=Continuous(0.0, 1.0), dof=[[2], [3]], neval=1e5, solver="vegas", seed=2)
+    check(v, [PI / 4.0, 4.0 * PI / 3.0 / 8])
 
 
 def test_python_closure_under_the_default_solver_matches_device_source():

@@ -153,14 +153,28 @@ int mci_set_integrand_host_indexed(mci_problem *prob, mci_host_integrand_idx_fn 
  * NULL restores the default measure (vegas/montecarlo.jl:151-153) / the declarative obs_bin_draw one. */
 int mci_set_measure_source(mci_problem *prob, const char *body);
 /* Slow path for `measure` closures that must stay on the host (vegas/montecarlo.jl:156-161), the counterpart of
- * mci_set_integrand_host: after each launch the library calls the callback ONCE PER BLOCK with that block's n samples --
- * draw-major draws x[k*stride + i] and relative weights relw[q*stride + i] (= weights[q] * padding_probability * jac, :152; zero for
- * samples that measurefreq skips) -- and the callback accumulates the block's observables into obs[nobs] (zeroed; flat over the
- * `obs` kwarg); they then go through the same block merge as device-side observables.  solver = MCI_VEGAS only; fn = NULL
- * restores the device-side measure. */
+ * mci_set_integrand_host: after each launch the library calls the callback ONCE PER BLOCK with that block's n records --
+ * draw-major configurations x[k*stride + i] and relative weights relw[q*stride + i] -- and the callback accumulates the block's
+ * observables into obs[nobs] (zeroed; flat over the `obs` kwarg); they then go through the same block merge as device-side
+ * observables.  What a record is:
+ *   MCI_VEGAS    every sample of the block, relw = weights[q] * padding_probability * jac (:152), zero for samples that
+ *                measurefreq skips;
+ *   MCI_VEGASMC  every MEASURED step of every chain of the block (vegas_mc/montecarlo.jl:213-227: steps j * measurefreq past the
+ *                burn-in), chain-major, relw = weights[q] * padding_probability / probability (:220);
+ *   MCI_MCMC     the same for mcmc/montecarlo.jl:143-169: relw is zero except for the integrand the chain sits on (:162); a chain
+ *                on the normalization integrand calls no measure (:157-159) and leaves an all-zero record.
+ * The measure runs after the launch, not inside the step loop: a measure that only reads (var, weights) -- the reference's
+ * contract -- cannot tell.  fn = NULL restores the device-side measure. */
 typedef int (*mci_host_measure_fn)(const double *x, const double *relw, int64_t n, int64_t stride, int32_t ndraw, int32_t nw,
                                    int64_t block, double *obs, int32_t nobs, void *user);
 int mci_set_measure_host(mci_problem *prob, mci_host_measure_fn fn, void *user);
+/* The `:mcmc` form `measure(idx, var, obs, relative_weight, config)` (mcmc/montecarlo.jl:166-169): idx[i] = the integrand record i
+ * belongs to (0-based; -1: no measure call for this record, skip it), relw[q*stride + i] the ncomp components of ITS relative
+ * weight.  Under MCI_VEGAS / MCI_VEGASMC the library calls it with every integrand in turn (idx constant).  Setting it replaces
+ * a plain host measure and vice versa. */
+typedef int (*mci_host_measure_idx_fn)(const int32_t *idx, const double *x, const double *relw, int64_t n, int64_t stride, int32_t ndraw,
+                                       int32_t ncomp, int64_t block, double *obs, int32_t nobs, void *user);
+int mci_set_measure_host_indexed(mci_problem *prob, mci_host_measure_idx_fn fn, void *user);
 int mci_compile(mci_problem *prob);          /* JIT or kernel-cache load of the vegas kernel; implicit on first run */
 int mci_compile_solver(mci_problem *prob, int32_t solver); /* same for one solver's kernel (one code object each) */
 /* path of the kernel-cache file (gfx950 code object) the solver's kernel was loaded from -- the analogue of asking Julia

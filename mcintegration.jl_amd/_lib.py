@@ -43,6 +43,8 @@ class IntegrateArgs(C.Structure):
 HOST_INTEGRAND_FN = C.CFUNCTYPE(C.c_int, c_double_p, c_double_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
 HOST_INTEGRAND_IDX_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int32), c_double_p, c_double_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
 HOST_MEASURE_FN = C.CFUNCTYPE(C.c_int, c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, c_double_p, C.c_int32, C.c_void_p)
+HOST_MEASURE_IDX_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int32), c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, c_double_p,
+                                  C.c_int32, C.c_void_p)
 
 
 class ResultC(C.Structure):
@@ -69,6 +71,7 @@ SIGNATURES = [
     ("mci_set_integrand_host_indexed", C.c_int, [_VP, _VP, _VP]),
     ("mci_set_measure_source", C.c_int, [_VP, C.c_char_p]),
     ("mci_set_measure_host", C.c_int, [_VP, _VP, _VP]),
+    ("mci_set_measure_host_indexed", C.c_int, [_VP, _VP, _VP]),
     ("mci_compile", C.c_int, [_VP]),
     ("mci_compile_solver", C.c_int, [_VP, C.c_int32]),
     ("mci_kernel_code_object", C.c_int, [_VP, C.c_int32, C.c_char_p, C.c_int32]),

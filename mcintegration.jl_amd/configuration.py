@@ -158,7 +158,7 @@ class Configuration:
             return [k if n > 1 else -1 for n in self.obs_nbin]
         if isinstance(measure, (Measure, HostMeasure)):
             return [-1] * self.N
-        raise TypeError("measure must be None, bin_by(pool), Measure(source) or a Python callable / HostMeasure (host slow path, solver='vegas')")
+        raise TypeError("measure must be None, bin_by(pool), Measure(source) or a Python callable / HostMeasure (host slow path)")
 
     @property
     def reweight(self):

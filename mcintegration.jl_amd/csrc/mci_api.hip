@@ -167,9 +167,13 @@ struct mci_problem {
     int64_t cap_hstep = 0; // chains
     // host measure ("batch callback"): draws + relative weights of the launch -> host closure per block -> block observables
     mci_host_measure_fn hmeas_fn = nullptr;
+    mci_host_measure_idx_fn hmeas_idx_fn = nullptr; // the `measure(idx, var, obs, relative_weight, config)` form (mcmc/montecarlo.jl:166-169)
     void *hmeas_user = nullptr;
     double *d_mx = nullptr, *d_mrelw = nullptr, *h_mx = nullptr, *h_mrelw = nullptr, *d_mobs = nullptr;
+    int32_t *d_midx = nullptr, *h_midx = nullptr;   // chain solvers: the integrand index of every record (:mcmc), -1 = no record
     int64_t cap_hmeas = 0, cap_mobs = 0;
+    std::vector<double> h_mtmp;                     // callback form != record form: rows regrouped here
+    std::vector<int32_t> h_mitmp;
     // hipGraph replay of the iteration chain (mci_integrate, single rank): device-side {iteration, log row}
     unsigned *d_loop = nullptr;
     bool graph_mode = false; // while capturing: no event records, iteration/log row come from d_loop
@@ -712,6 +716,8 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->d_mobs) (void)hipFree(p->d_mobs);
         if (p->h_mx) (void)hipHostFree(p->h_mx);
         if (p->h_mrelw) (void)hipHostFree(p->h_mrelw);
+        if (p->d_midx) (void)hipFree(p->d_midx);
+        if (p->h_midx) (void)hipHostFree(p->h_midx);
         for (auto &e : p->evs) (void)hipEventDestroy(e);
     }
     delete p;
@@ -794,6 +800,7 @@ int mci_set_measure_source(mci_problem *p, const char *body) {
     p->shape.measure_body = body ? body : "";
     p->shape.host_measure = 0;
     p->hmeas_fn = nullptr;
+    p->hmeas_idx_fn = nullptr;
     drop_modules(p);
     return MCI_OK;
 }
@@ -801,6 +808,18 @@ int mci_set_measure_source(mci_problem *p, const char *body) {
 int mci_set_measure_host(mci_problem *p, mci_host_measure_fn fn, void *user) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     p->hmeas_fn = fn;
+    p->hmeas_idx_fn = nullptr;
+    p->hmeas_user = user;
+    p->shape.host_measure = fn ? 1 : 0;
+    if (fn) p->shape.measure_body = "";
+    drop_modules(p);
+    return MCI_OK;
+}
+
+int mci_set_measure_host_indexed(mci_problem *p, mci_host_measure_idx_fn fn, void *user) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    p->hmeas_idx_fn = fn;
+    p->hmeas_fn = nullptr;
     p->hmeas_user = user;
     p->shape.host_measure = fn ? 1 : 0;
     if (fn) p->shape.measure_body = "";
@@ -825,8 +844,6 @@ int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
 static int compile_solver(mci_problem *p, int solver) {
     if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver); // main.jl:263
     if (p->compiled[solver]) return MCI_OK;
-    if (p->shape.host_measure && solver != MCI_VEGAS)
-        return fail(MCI_ERR_INVALID, "a host measure runs with solver=:vegas only (a chain measures inside its step loop)");
     if (p->shape.measure_body.empty() && !p->shape.host_measure) // vegas/montecarlo.jl:104, mcmc/montecarlo.jl:84
         for (int i = 0; i < p->ni; ++i)
             if (p->shape.obs_bin_draw[i] < 0 && p->shape.obs_nbin[i] != p->shape.ncomp)
@@ -1093,20 +1110,52 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         }
         a.host_w = p->d_hw;
     }
-    if (s.host_measure) { // (solver == :vegas: checked in compile_solver)
-        const int64_t n = nblocks * nevalperblock;
+    // host measure: records per block, rows of relative weights per record, measured-step window of a chain (BatchArgs::hm_*)
+    int64_t hm_n = 0, hm_first = 0, hm_count = 0;
+    int hm_rows = 0;
+    if (s.host_measure) {
+        if (p->graph_mode) return fail(MCI_ERR_INVALID, "a host measure cannot run inside a captured iteration (MCI_GRAPH)");
         const int nw = s.ni * s.ncomp;
+        if (solver == MCI_VEGAS) {
+            hm_n = nevalperblock;
+            hm_rows = nw;
+        } else {
+            // a chain measures at steps j * measurefreq: :vegasmc from `burnin` on (vegas_mc/montecarlo.jl:213), :mcmc from nburn on
+            // (mcmc/montecarlo.jl:143) -- the same comparisons the kernels make
+            const int64_t mfq = measurefreq > 0 ? measurefreq : 1;
+            const int64_t last = solver == MCI_VEGASMC ? nevalperblock / nchain : nevalperblock / nchain + nburn;
+            hm_first = 1;
+            if (solver == MCI_VEGASMC) {
+                hm_first = (int64_t)(burnin / (double)mfq);
+                if (hm_first < 1) hm_first = 1;
+                while (hm_first > 1 && (double)((hm_first - 1) * mfq) >= burnin) --hm_first;
+                while ((double)(hm_first * mfq) < burnin) ++hm_first;
+            } else if (nburn > 0) {
+                hm_first = (nburn + mfq - 1) / mfq;
+                if (hm_first < 1) hm_first = 1;
+            }
+            hm_count = last / mfq - hm_first + 1;
+            if (hm_count < 0) hm_count = 0;
+            hm_n = nchain * hm_count;
+            hm_rows = solver == MCI_MCMC ? s.ncomp : nw;
+        }
+        const int64_t n = nblocks * hm_n > 0 ? nblocks * hm_n : 1;
         if (n > p->cap_hmeas) {
             if (p->d_mx) (void)hipFree(p->d_mx);
             if (p->d_mrelw) (void)hipFree(p->d_mrelw);
+            if (p->d_midx) (void)hipFree(p->d_midx);
             if (p->h_mx) (void)hipHostFree(p->h_mx);
             if (p->h_mrelw) (void)hipHostFree(p->h_mrelw);
+            if (p->h_midx) (void)hipHostFree(p->h_midx);
             p->d_mx = p->d_mrelw = p->h_mx = p->h_mrelw = nullptr;
+            p->d_midx = p->h_midx = nullptr;
             p->cap_hmeas = 0;
             HIPCHK(hipMalloc((void **)&p->d_mx, (size_t)n * s.ndraw * sizeof(double)));
             HIPCHK(hipMalloc((void **)&p->d_mrelw, (size_t)n * nw * sizeof(double)));
+            HIPCHK(hipMalloc((void **)&p->d_midx, (size_t)n * sizeof(int32_t)));
             HIPCHK(hipHostMalloc((void **)&p->h_mx, (size_t)n * s.ndraw * sizeof(double), hipHostMallocDefault));
             HIPCHK(hipHostMalloc((void **)&p->h_mrelw, (size_t)n * nw * sizeof(double), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **)&p->h_midx, (size_t)n * sizeof(int32_t), hipHostMallocDefault));
             p->cap_hmeas = n;
         }
         if (nblocks * s.nobs > p->cap_mobs) {
@@ -1117,6 +1166,15 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         }
         a.host_mx = p->d_mx;
         a.host_relw = p->d_mrelw;
+        a.host_midx = p->d_midx;
+        a.hm_first = hm_first;
+        a.hm_count = hm_count;
+        a.hm_stride = nblocks * hm_n;
+        if (solver != MCI_VEGAS) { // a chain on the normalization integrand leaves no record (:mcmc): preset "none"
+            HIPCHK(hipMemsetAsync(p->d_mx, 0, (size_t)n * s.ndraw * sizeof(double), p->ctx->stream));
+            HIPCHK(hipMemsetAsync(p->d_mrelw, 0, (size_t)n * hm_rows * sizeof(double), p->ctx->stream));
+            HIPCHK(hipMemsetAsync(p->d_midx, 0xFF, (size_t)n * sizeof(int32_t), p->ctx->stream));
+        }
     }
     void *args[] = {&a};
     hipFunction_t f = p->f_solver[solver];
@@ -1210,19 +1268,43 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         p->launches += 1;
     }
     if (s.host_measure) {
-        // the closure cannot run on the device: this launch's draws and relative weights go to the host (draw-major, like the host
-        // integrand path), the callback accumulates block b's observables from block b's samples, and they join the block's
-        // partial row before the merge.  PCIe- and host-bound by construction.
-        const int64_t n = nblocks * nevalperblock;
-        const int nw = s.ni * s.ncomp;
-        HIPCHK(hipMemcpyAsync(p->h_mx, p->d_mx, (size_t)n * s.ndraw * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(p->h_mrelw, p->d_mrelw, (size_t)n * nw * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        // the closure cannot run on the device: this launch's (measured) configurations and relative weights go to the host
+        // (draw-major, like the host integrand path), the callback accumulates block b's observables from block b's records, and
+        // they join the block's partial row before the merge.  PCIe- and host-bound by construction.
+        const int64_t n = nblocks * hm_n;
+        const int nw = s.ni * s.ncomp, nc = s.ncomp;
         std::vector<double> obs((size_t)nblocks * s.nobs, 0.0);
-        for (int64_t b = 0; b < nblocks; ++b) {
-            const int hrc = p->hmeas_fn(p->h_mx + b * nevalperblock, p->h_mrelw + b * nevalperblock, nevalperblock, n, s.ndraw, nw, block_lo + b,
-                                        obs.data() + (size_t)b * s.nobs, s.nobs, p->hmeas_user);
-            if (hrc) return fail(MCI_ERR_INVALID, "the host measure failed (%d)", hrc);
+        if (n > 0) {
+            HIPCHK(hipMemcpyAsync(p->h_mx, p->d_mx, (size_t)n * s.ndraw * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(p->h_mrelw, p->d_mrelw, (size_t)n * hm_rows * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (solver == MCI_MCMC) HIPCHK(hipMemcpyAsync(p->h_midx, p->d_midx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            const double *relw = p->h_mrelw;
+            if (solver == MCI_MCMC && p->hmeas_fn) { // plain form: every integrand's row, zero except the one the chain sat on
+                p->h_mtmp.assign((size_t)n * nw, 0.0);
+                for (int64_t i = 0; i < n; ++i)
+                    if (p->h_midx[i] >= 0)
+                        for (int q = 0; q < nc; ++q) p->h_mtmp[(size_t)(p->h_midx[i] * nc + q) * n + i] = p->h_mrelw[(size_t)q * n + i];
+                relw = p->h_mtmp.data();
+            }
+            if (solver != MCI_MCMC && p->hmeas_idx_fn) p->h_mitmp.resize((size_t)hm_n);
+            for (int64_t b = 0; b < nblocks; ++b) {
+                const int64_t off = b * hm_n;
+                double *ob = obs.data() + (size_t)b * s.nobs;
+                int hrc = 0;
+                if (p->hmeas_fn) {
+                    hrc = p->hmeas_fn(p->h_mx + off, relw + off, hm_n, n, s.ndraw, nw, block_lo + b, ob, s.nobs, p->hmeas_user);
+                } else if (solver == MCI_MCMC) {
+                    hrc = p->hmeas_idx_fn(p->h_midx + off, p->h_mx + off, relw + off, hm_n, n, s.ndraw, nc, block_lo + b, ob, s.nobs, p->hmeas_user);
+                } else { // indexed form under :vegas / :vegasmc: every integrand in turn
+                    for (int j = 0; j < s.ni && !hrc; ++j) {
+                        std::fill(p->h_mitmp.begin(), p->h_mitmp.end(), (int32_t)j);
+                        hrc = p->hmeas_idx_fn(p->h_mitmp.data(), p->h_mx + off, relw + (size_t)j * nc * n + off, hm_n, n, s.ndraw, nc, block_lo + b, ob,
+                                              s.nobs, p->hmeas_user);
+                    }
+                }
+                if (hrc) return fail(MCI_ERR_INVALID, "the host measure failed (%d)", hrc);
+            }
         }
         HIPCHK(hipMemcpyAsync(p->d_mobs, obs.data(), obs.size() * sizeof(double), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(mci::k_add_host_obs, dim3((unsigned)((nblocks * s.nobs + 255) / 256)), dim3(256), 0, st, p->d_mobs, (int)nblocks, s.nobs, s.ncols, wpb,
@@ -1404,7 +1486,7 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     // MI355X in the launch-bound regime (neval 1e4 .. 1e7 per iteration, tools/latency.py) the replay costs 37.6 / 41.9 /
     // 61.7 / 84.2 us per iteration against 34.8 / 36.0 / 57.1 / 79.1 us for the eager asynchronous launches.
     static const bool want_graph = getenv("MCI_GRAPH") && atoi(getenv("MCI_GRAPH")) != 0;
-    const bool use_graph = want_graph && !p->ctx->comm && !s.host_integrand && a->niter > 2;
+    const bool use_graph = want_graph && !p->ctx->comm && !s.host_integrand && !s.host_measure && a->niter > 2;
     int it = 0;
     for (; it < (use_graph ? 1 : a->niter); ++it) { // main.jl:142
         if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, a->first_iteration + it, a->seed, a->measurefreq, a->nchain, a->thermal_ratio))) return rc;

@@ -187,6 +187,16 @@ struct BatchArgs {
     // launch, the draws and the relative weights w * jac_i of the measured samples (0 for the others) for the host closure:
     // host_mx[k * tile_stride + sample], host_relw[q * tile_stride + sample]
     double *host_mx, *host_relw;
+    // ... under a chain solver: a chain measures inside its step loop, so every chain leaves its j-th measured configuration (measured
+    // steps are j * measurefreq, j = hm_first .. hm_first + hm_count - 1) in the record of its block,
+    //     slot = (local block * nchain + chain) * hm_count + (j - hm_first);   host_mx[k * hm_stride + slot],
+    //     :vegasmc  host_relw[q * hm_stride + slot], q < NW (vegas_mc/montecarlo.jl:218-227);  host_midx[slot] = -1
+    //     :mcmc     host_relw[q * hm_stride + slot], q < NCOMP: the relative weight of the integrand the chain sits on,
+    //               host_midx[slot] = that integrand (mcmc/montecarlo.jl:162-169); a chain on the normalization integrand
+    //               writes nothing (the host presets host_midx = -1, host_relw = 0)
+    // and the host closure runs over a block's records after the launch.
+    int *host_midx;
+    i64 hm_first, hm_count, hm_stride;
     // hipGraph replay of the iteration chain: the iteration index then lives in device memory (k_finish/k_train
     // advance it), so that the captured launch parameters never change.  NULL: use `iteration`.
     const u32 *iter_ptr;
@@ -778,6 +788,16 @@ template <class Cfg> __device__ __forceinline__ void measure(const double *x, co
     }
 }
 
+// host measure under a chain solver (Cfg::HOST_MEASURE, BatchArgs::host_mx): record of the chain's measured step j * measurefreq
+template <class Cfg, int NR> __device__ __forceinline__ void host_measure_record(const BatchArgs &a, i64 lb, i64 ch, i64 j, const double *x, const double *relw /*[NR]*/, int idx) {
+    const i64 ord = j - a.hm_first;
+    if (ord < 0 || ord >= a.hm_count) return;
+    const i64 slot = (lb * a.nchain + ch) * a.hm_count + ord;
+    static_for<0, Cfg::NDRAW>([&](auto K) { a.host_mx[decltype(K)::value * a.hm_stride + slot] = x[decltype(K)::value]; });
+    static_for<0, NR>([&](auto Q) { a.host_relw[decltype(Q)::value * a.hm_stride + slot] = relw[decltype(Q)::value]; });
+    a.host_midx[slot] = idx;
+}
+
 // workgroup epilogue: registers -> wave shuffle -> LDS -> one row of part_cols; LDS histogram -> part_hist
 template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA = false, bool ACCUM = false> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/, i64 rowid, int tile) {
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
@@ -1273,7 +1293,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
         double probability = rw[NORMI] * pad[NORMI]; // :162
         static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; probability += absw<Cfg, i>(w) * rw[i] * pad[i]; }); // :163-166
 
-        i64 mcnt = 0; // ne % measurefreq, carried (no 64-bit division per step)
+        i64 mcnt = 0, mj = 0; // ne % measurefreq and ne / measurefreq, carried (no 64-bit division per step)
         for (i64 ne = 1; ne <= steps; ++ne) { // :184
             const u64 sidx = (g << 32) | (u64)(ne - 1);
             const u32x4 r0 = philox4x32_10((u32)sidx, (u32)(sidx >> 32), 0u, st_step, k0, k1);
@@ -1365,6 +1385,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
             // ---- measurement  montecarlo.jl:213-232 ----
             mcnt = mcnt + 1 == a.measurefreq ? 0 : mcnt + 1;
             const bool mf = mcnt == 0;
+            mj += mf ? 1 : 0;
             if (mf && (double)ne >= a.burnin) { // :213
                 double relw[Cfg::NW];
                 static_for<0, NI>([&](auto I) {
@@ -1375,6 +1396,9 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                         relw[q] = w[q] * pad[i] / probability;                             // :218/:220
                     });
                 });
+                if constexpr (Cfg::HOST_MEASURE != 0) { // :224-227 on the host, after the launch
+                    if (tile == 0) host_measure_record<Cfg, Cfg::NW>(a, wi.lb, ch, mj, c.x, relw, -1);
+                } else
                 measure<Cfg>(c.x, c.bin, relw, a.ud, acc, sO);
                 extra[XN] += pad[NORMI] / probability;                // :229
                 extra[XV + NORMI] += rw[NORMI] * pad[NORMI] / probability; // :230
@@ -1508,7 +1532,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_host_step(const Bat
                         relw[q] = w[q] * pad[i] / probability;                             // :218/:220
                     });
                 });
-                measure<Cfg>(c.x, c.bin, relw, a.ud, acc, sO);
+                if constexpr (Cfg::HOST_MEASURE != 0) host_measure_record<Cfg, Cfg::NW>(a, wi.lb, ch, ne / a.measurefreq, c.x, relw, -1);
+                else measure<Cfg>(c.x, c.bin, relw, a.ud, acc, sO);
                 extra[XN] += pad[NORMI] / probability;                // :229
                 extra[XV + NORMI] += rw[NORMI] * pad[NORMI] / probability; // :230
             }
@@ -1975,7 +2000,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
         // the integrand index, and the longest completed or still running hold
         int last[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1], lastc = 0, hmax = 0;
         static_for<0, Cfg::NDRAW>([&](auto K) { last[decltype(K)::value] = 0; });
-        i64 mcnt = 0; // it % measurefreq, carried
+        i64 mcnt = 0, mj = 0; // it % measurefreq and it / measurefreq, carried
         for (i64 it = 1; it <= steps + nburn; ++it) { // :134
             const u64 sidx = (g << 32) | (u64)(it - 1);
             static_for<0, ND>([&](auto I) { extra[XV + decltype(I)::value] += curr == decltype(I)::value ? 1.0 : 0.0; }); // :136
@@ -2051,10 +2076,14 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             // ---- measurement  montecarlo.jl:144-172 ----
             mcnt = mcnt + 1 == a.measurefreq ? 0 : mcnt + 1;
             const bool mf = mcnt == 0;
+            mj += mf ? 1 : 0;
             if (mf && it >= nburn) {
                 if (curr != NORMI) {
                     double relw[Cfg::NCOMP]; // :162
                     static_for<0, Cfg::NCOMP>([&](auto Q) { relw[decltype(Q)::value] = weight.v[decltype(Q)::value] / probability; });
+                    if constexpr (Cfg::HOST_MEASURE != 0) { // measure(idx, var, obs, relative_weight, config) on the host, after the launch  :166-169
+                        if (tile == 0) host_measure_record<Cfg, Cfg::NCOMP>(a, wi.lb, ch, mj, c.x, relw, curr);
+                    }
                     static_for<0, NI>([&](auto I) {
                         constexpr int i = decltype(I)::value;
                         if (curr == i) {
@@ -2064,7 +2093,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                                 if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hist_add<Cfg, k>(c.bin[k], 1.0, sH, a.ghist, tile);
 #endif
                             });
-                            if constexpr (Cfg::CUSTOM_MEASURE != 0) { // measure(idx, var, obs, relative_weight, config)  :166-169
+                            if constexpr (Cfg::HOST_MEASURE != 0) {
+                            } else if constexpr (Cfg::CUSTOM_MEASURE != 0) { // measure(idx, var, obs, relative_weight, config)  :166-169
                                 double rwv[Cfg::NW];
                                 static_for<0, Cfg::NW>([&](auto Q) { rwv[decltype(Q)::value] = 0.0; });
                                 static_for<0, Cfg::NCOMP>([&](auto Q) { rwv[i * Cfg::NCOMP + decltype(Q)::value] = relw[decltype(Q)::value]; });
@@ -2272,6 +2302,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_host_step(const BatchA
                 if (curr != NORMI) {
                     double relw[Cfg::NCOMP]; // :162
                     static_for<0, Cfg::NCOMP>([&](auto Q) { relw[decltype(Q)::value] = weight.v[decltype(Q)::value] / probability; });
+                    if constexpr (Cfg::HOST_MEASURE != 0) host_measure_record<Cfg, Cfg::NCOMP>(a, wi.lb, ch, step / a.measurefreq, c.x, relw, curr);
                     static_for<0, NI>([&](auto I) {
                         constexpr int i = decltype(I)::value;
                         if (curr == i) {
@@ -2279,7 +2310,8 @@ template <class Cfg> __device__ __forceinline__ void mcmc_host_step(const BatchA
                                 constexpr int k = decltype(K)::value;
                                 if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hist_add<Cfg, k>(c.bin[k], 1.0, sH, a.ghist, 0);
                             });
-                            if constexpr (Cfg::CUSTOM_MEASURE != 0) { // measure(idx, var, obs, relative_weight, config)  :166-169
+                            if constexpr (Cfg::HOST_MEASURE != 0) {
+                            } else if constexpr (Cfg::CUSTOM_MEASURE != 0) { // measure(idx, var, obs, relative_weight, config)  :166-169
                                 double rwv[Cfg::NW];
                                 static_for<0, Cfg::NW>([&](auto Q) { rwv[decltype(Q)::value] = 0.0; });
                                 static_for<0, Cfg::NCOMP>([&](auto Q) { rwv[i * Cfg::NCOMP + decltype(Q)::value] = relw[decltype(Q)::value]; });

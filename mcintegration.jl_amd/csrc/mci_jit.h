@@ -49,7 +49,7 @@ struct ProblemShape {
     int ncomp = 1;            // 1: Float64 weights; 2: ComplexF64 stored (re, im)
     std::string measure_body; // user measure (empty = default / bin-by-Discrete)
     int host_integrand = 0;   // weights come from a host callback: over dumped draws (vegas), per Markov step (vegasmc)
-    int host_measure = 0;     // observables are accumulated by a host callback over the launch's draws and relative weights (vegas only)
+    int host_measure = 0;     // observables are accumulated by a host callback over the launch's (measured) configurations and relative weights
     std::vector<int> nneighbor, neighbor; // [ni+1], [(ni+1)*nbmax] 0-based, padded with the integrand itself
     std::string body;
 };
@@ -129,7 +129,7 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     o << fn_table("int", "pool_first_draw", arr(s.pool_first_draw, "int"));
     o << "    static constexpr int NBMAX = " << s.nbmax << ", NCOMP = " << s.ncomp << ", NW = " << s.ni * s.ncomp
       << ", CUSTOM_MEASURE = " << (s.measure_body.empty() ? 0 : 1) << ", HOST_INTEGRAND = " << s.host_integrand
-      << ", HOST_MEASURE = " << (solver == 0 ? s.host_measure : 0) << ";\n";
+      << ", HOST_MEASURE = " << s.host_measure << ";\n";
     o << fn_table("int", "dof", arr(s.dof, "int"));
     o << fn_table("int", "nneighbor", arr(s.nneighbor, "int"));
     o << fn_table("int", "neighbor", arr(s.neighbor, "int"));

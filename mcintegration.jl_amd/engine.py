@@ -121,6 +121,9 @@ class Engine:
             measure = HostMeasure(measure)
         if isinstance(measure, Measure):
             check(L.mci_set_measure_source(self.p, measure.body.encode()))
+        elif isinstance(measure, HostMeasure) and measure.indexed:
+            self._host_measure_cb = _lib.HOST_MEASURE_IDX_FN(self._make_host_measure_indexed_callback(measure.fn))   # keep alive
+            check(L.mci_set_measure_host_indexed(self.p, C.cast(self._host_measure_cb, C.c_void_p), None))
         elif isinstance(measure, HostMeasure):
             self._host_measure_cb = _lib.HOST_MEASURE_FN(self._make_host_measure_callback(measure.fn))   # keep alive
             check(L.mci_set_measure_host(self.p, C.cast(self._host_measure_cb, C.c_void_p), None))
@@ -230,6 +233,45 @@ class Engine:
                 dt = complex if nc == 2 else float
                 obs = [np.zeros(ln, dtype=dt) for ln in config.obs_len]
                 fn(self._pool_views(X, n), obs, weights, config)
+                off = 0
+                for o, nb in zip(obs, config.obs_nbin):
+                    o = np.asarray(o).reshape(-1)
+                    if nc == 2:
+                        O[off:off + nb:2], O[off + 1:off + nb:2] = o.real, o.imag
+                    else:
+                        O[off:off + nb] = o
+                    off += nb
+                return 0
+            except Exception:   # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        return cb
+
+    def _make_host_measure_indexed_callback(self, fn):
+        """ctypes trampoline of the `measure(idx, var, obs, relative_weight, config)` form: one call of fn per integrand index that
+        some record of the block belongs to, over those records"""
+        config = self.config
+        nc = config.ncomp
+
+        def cb(ip, xp, rp, n, stride, ndraw, ncomp, block, op, nobs, user):
+            try:
+                idx = np.ctypeslib.as_array(ip, shape=(n,))
+                X = np.ctypeslib.as_array(xp, shape=(ndraw, stride))[:, :n]
+                R = np.ctypeslib.as_array(rp, shape=(ncomp, stride))[:, :n]
+                O = np.ctypeslib.as_array(op, shape=(nobs,))
+                dt = complex if nc == 2 else float
+                obs, off = [], 0
+                for ln, nb in zip(config.obs_len, config.obs_nbin):   # the block's observables so far (the library calls once per integrand)
+                    o = np.array(O[off:off + nb])
+                    obs.append((o[0::2] + 1j * o[1::2]) if nc == 2 else o.astype(dt))
+                    off += nb
+                for i in np.unique(idx[idx >= 0]):
+                    sel = np.nonzero(idx == i)[0]
+                    whole = len(sel) == n
+                    Xs = X if whole else np.ascontiguousarray(X[:, sel])
+                    w = (R[0] + 1j * R[1]) if nc == 2 else R[0]
+                    fn(int(i), self._pool_views(Xs, len(sel)), obs, w if whole else w[sel], config)
                 off = 0
                 for o, nb in zip(obs, config.obs_nbin):
                     o = np.asarray(o).reshape(-1)

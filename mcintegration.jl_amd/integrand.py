@@ -62,17 +62,27 @@ class HostIntegrand:
 
 
 class HostMeasure:
-    """A Python closure as `measure` -- the reference's `measure(vars, obs, relative_weights, config)` (vegas/montecarlo.jl:156-161)
-    run on the HOST, once per statistical block and vectorised over the block's samples ("batch callback" slow path,
-    include/mci.h mci_set_measure_host):
+    """A Python closure as `measure` -- the reference's `measure(vars, obs, relative_weights, config)` (vegas/montecarlo.jl:156-161,
+    vegas_mc/montecarlo.jl:224-227) run on the HOST, once per statistical block and vectorised over the block's records ("batch
+    callback" slow path, include/mci.h mci_set_measure_host):
 
         m(x, obs, weights, config)     # obs[i] += ...   in place
 
-    `x` as for HostIntegrand (x[i] = the vector of the i-th draw over the block's samples), `weights[i]` the vector of integrand
-    i's relative weights (complex for type=complex; zero for samples that `measurefreq` skips), `obs` a list shaped like the `obs`
-    keyword (floats are 1-element arrays), zeroed for every block.  solver="vegas" only."""
+    `x` as for HostIntegrand (x[i] = the vector of the i-th draw over the block's records), `weights[i]` the vector of integrand
+    i's relative weights (complex for type=complex), `obs` a list shaped like the `obs` keyword (floats are 1-element arrays),
+    zeroed for every block.  A record is a sample under solver="vegas" (weights zero for samples that `measurefreq` skips) and a
+    measured step of one of the block's chains under "vegasmc" / "mcmc" (under "mcmc" only the integrand the chain sits on has a
+    non-zero weight).
 
-    def __init__(self, fn, name=None):
+    indexed=True: the reference's `:mcmc` form `measure(idx, var, obs, relative_weight, config)` (mcmc/montecarlo.jl:166-169) --
+
+        m(idx, x, obs, weight, config)
+
+    is called once per integrand index (0-based) with the records that belong to it; include/mci.h mci_set_measure_host_indexed.
+    Either form works under every solver."""
+
+    def __init__(self, fn, name=None, indexed=False):
         self.fn = fn
+        self.indexed = bool(indexed)
         self.name = name or getattr(fn, "__name__", "host_measure")
-        self.body = "/* host measure %d */" % id(fn)
+        self.body = "/* host measure %d%s */" % (id(fn), " indexed" if indexed else "")

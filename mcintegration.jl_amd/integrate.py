@@ -62,7 +62,14 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
             npos = 2
         integrand = HostIntegrand(integrand, indexed=(npos >= 3))
     if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
-        measure = HostMeasure(measure)             # a Python closure as measure: host batch-callback path, solver="vegas" only
+        # a Python closure as measure: host batch-callback path.  Five positional parameters = the reference's :mcmc form
+        # measure(idx, var, obs, relative_weight, config) (mcmc/montecarlo.jl:166-169), four = measure(var, obs, weights, config)
+        import inspect
+        try:
+            mpos = len([q for q in inspect.signature(measure).parameters.values() if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)])
+        except (TypeError, ValueError):
+            mpos = 4
+        measure = HostMeasure(measure, indexed=(mpos >= 5))
     mkey = None if measure is None else measure.body if isinstance(measure, (Measure, HostMeasure)) else (measure.pool, measure.slot, measure.leaf)
     key = (integrand.body, tuple(integrand.userdata), mkey, device,
            repr(config.neighbor), int(rng_bits))

@@ -346,6 +346,70 @@ function bind_host!(c::Configuration, f::Function)
     prob
 end
 
+# ---- Julia closures as `measure` (mci_set_measure_host / _indexed) --------------------------------------------------------
+# measure(x, obs, weights, config) (src/vegas/montecarlo.jl:156-161) is called once per statistical block with the block's records
+# (x[k] = the vector of draw k, weights[i] = the vector of integrand i's relative weights; a record = a sample under :vegas, a
+# measured step of one of the block's chains under :vegasmc / :mcmc); obs is shaped like the `obs` keyword and zeroed per block.
+const _measures = Dict{Ptr{Cvoid},Any}()
+function _obs_views(c::Configuration, O::Vector{Float64})
+    out, off = Any[], 0
+    for nb in c.obs_nbin
+        v = view(O, off+1:off+nb)
+        push!(out, c.ncomp == 2 ? reinterpret(ComplexF64, v) : v)
+        off += nb
+    end
+    out
+end
+function _measure_trampoline(x::Ptr{Float64}, relw::Ptr{Float64}, n::Int64, stride::Int64, ndraw::Int32, nw::Int32, block::Int64,
+                             obs::Ptr{Float64}, nobs::Int32, user::Ptr{Cvoid})::Cint
+    try
+        f, c = _measures[user]
+        X = unsafe_wrap(Array, x, (Int(stride), Int(ndraw)))
+        R = unsafe_wrap(Array, relw, (Int(stride), Int(nw)))
+        O = unsafe_wrap(Array, obs, (Int(nobs),))
+        cols = [view(X, 1:Int(n), k) for k in 1:ndraw]
+        W = c.ncomp == 2 ? [complex.(view(R, 1:Int(n), 2i - 1), view(R, 1:Int(n), 2i)) for i in 1:c.N] : [view(R, 1:Int(n), i) for i in 1:c.N]
+        f(cols, _obs_views(c, O), W, c)
+        return Cint(0)
+    catch err
+        @error "host measure failed" err
+        return Cint(1)
+    end
+end
+# the reference's :mcmc form measure(idx, x, obs, weight, config) (src/mcmc/montecarlo.jl:166-169; idx 1-based like the reference)
+function _measure_idx_trampoline(idx::Ptr{Int32}, x::Ptr{Float64}, relw::Ptr{Float64}, n::Int64, stride::Int64, ndraw::Int32, ncomp::Int32,
+                                 block::Int64, obs::Ptr{Float64}, nobs::Int32, user::Ptr{Cvoid})::Cint
+    try
+        f, c = _measures[user]
+        I = unsafe_wrap(Array, idx, (Int(n),))
+        X = unsafe_wrap(Array, x, (Int(stride), Int(ndraw)))
+        R = unsafe_wrap(Array, relw, (Int(stride), Int(ncomp)))
+        O = unsafe_wrap(Array, obs, (Int(nobs),))
+        ov = _obs_views(c, O)
+        for i in unique(I)
+            i < 0 && continue
+            sel = findall(==(i), I)
+            w = ncomp == 2 ? complex.(R[sel, 1], R[sel, 2]) : R[sel, 1]
+            f(Int(i) + 1, [X[sel, k] for k in 1:ndraw], ov, w, c)
+        end
+        return Cint(0)
+    catch err
+        @error "host measure failed" err
+        return Cint(1)
+    end
+end
+function bind_measure_host!(c::Configuration, prob, m::Function)
+    _measures[prob] = (m, c)
+    if any(q -> q.nargs - 1 >= 5, methods(m))
+        cb = @cfunction(_measure_idx_trampoline, Cint, (Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int32, Int32, Int64, Ptr{Float64}, Int32, Ptr{Cvoid}))
+        check(ccall((:mci_set_measure_host_indexed, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, cb, prob))
+    else
+        cb = @cfunction(_measure_trampoline, Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int32, Int32, Int64, Ptr{Float64}, Int32, Ptr{Cvoid}))
+        check(ccall((:mci_set_measure_host, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, cb, prob))
+    end
+    prob
+end
+
 # Result   reference src/statistics.jl:16-63
 struct Result
     mean::Vector{Float64}; stdev::Vector{Float64}; chi2::Vector{Float64}
@@ -502,12 +566,18 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
     config === nothing && (config = Configuration(; kwargs...))                          # main.jl:95-97
     # workers: after init_comm!(...) the library runs this rank's share of the blocks and sums every iteration's statistics and
     # histograms over the ranks with one RCCL all-reduce (main.jl:113-122, :152-188); nothing to do here per call
-    if integrand isa Function                      # a Julia closure: host batch-callback path, :vegas only
-        solver == :vegas || error("a closure integrand runs with solver=:vegas only; pass device source for :vegasmc / :mcmc")
+    if integrand isa Function                      # a Julia closure: host batch-callback path (per launch under :vegas, per Markov step under :vegasmc / :mcmc)
         prob = bind_host!(config, integrand)
     else
         f = integrand isa Integrand ? integrand : Integrand(String(integrand), config.userdata === nothing ? Float64[] : Float64.(config.userdata))
-        prob = bind!(config, f, measure)
+        prob = bind!(config, f, measure isa Function ? nothing : measure)
+    end
+    if measure isa Function                        # a Julia closure as `measure`: per block, after the launch
+        bind_measure_host!(config, prob, measure)
+    elseif haskey(_measures, prob)                 # the problem still carries an earlier call's closure: back to the device-side measure
+        delete!(_measures, prob)
+        check(ccall((:mci_set_measure_host, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, C_NULL, C_NULL))
+        measure isa Measure && check(ccall((:mci_set_measure_source, libmci), Cint, (Ptr{Cvoid}, Cstring), prob, measure.body))
     end
     # engine-specific knobs (include/mci.h): the opt-in 32-bit uniform stream of :vegas, train!'s refinement walk
     check(ccall((:mci_set_rng_bits, libmci), Cint, (Ptr{Cvoid}, Int32), prob, rng_bits))

@@ -405,7 +405,7 @@ def test_report_config_prints_the_acceptance_table(capsys):
 def test_python_closure_as_measure_matches_device_source():
     """a host `measure` closure (mci_set_measure_host; the reference's Sphere3 measure, test/montecarlo.jl:71-84) against the same
     measure as device source: same draws, same relative weights, so the block observables agree to summation-order rounding --
-    also with measurefreq and next to a host integrand; the chain solvers refuse it (their measure sits inside the step loop)"""
+    also with measurefreq and next to a host integrand"""
     def sphere3_measure(x, obs, weights, config):          # measure(vars, obs, weights, config)
         obs[0][0] += weights[0].sum()
         obs[1][0] += weights[1].sum()
@@ -423,9 +423,52 @@ def test_python_closure_as_measure_matches_device_source():
     c = integrate(lambda x, cfg: ((x[0] ** 2 + x[1] ** 2 < 1.0) * 1.0, (x[0] ** 2 + x[1] ** 2 + x[2] ** 2 < 1.0) * 1.0),
                   var=Continuous(0.0, 1.0), measure=sphere3_measure, measurefreq=3, **kw)
     np.testing.assert_allclose(c.iter_mean, a.iter_mean, rtol=1e-9)
-    with pytest.raises(mci.MCIError) as e:
-        integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), measure=sphere3_measure, dof=[[2], [3]], obs=[0.0, [0.0, 0.0]], solver="vegasmc", neval=1e4)
-    assert "vegas only" in str(e.value)
+
+
+def test_python_closure_as_measure_under_the_chain_solvers_matches_device_source():
+    """:vegasmc and :mcmc call `measure` inside the step loop (vegas_mc/montecarlo.jl:224-227, mcmc/montecarlo.jl:166-169).  With a
+    host closure every chain leaves its measured configurations and relative weights in its block's record and the closure runs
+    over them after the launch (mci_set_measure_host / _indexed): same chains, same relative weights as the same measure given as
+    device source -- the reference's chain (one per block) and many chains, measurefreq, the four-argument and the :mcmc
+    five-argument form, a measure that reads the configuration, host integrand AND host measure together."""
+    def sphere3_measure(x, obs, weights, config):          # measure(vars, obs, weights, config)
+        obs[0][0] += weights[0].sum()
+        obs[1][0] += weights[1].sum()
+        obs[1][1] += (weights[1] * 2.0).sum()
+    def sphere3_measure5(idx, x, obs, weight, config):     # measure(idx, vars, obs, weight, config); idx is 0-based here
+        if idx == 0:
+            obs[0][0] += weight.sum()
+        else:
+            obs[1][0] += weight.sum()
+            obs[1][1] += (weight * 2.0).sum()
+    dev = mci.Measure("obs_add(0, rw[0]); obs_add(1, rw[1]); obs_add(2, rw[1] * 2.0);")
+    f2 = lambda X, c: ((X[0] ** 2 + X[1] ** 2 < 1.0) * 1.0, (X[0] ** 2 + X[1] ** 2 + X[2] ** 2 < 1.0) * 1.0)
+    for solver in ("vegasmc", "mcmc"):
+        for mf, nchain, block in ((1, 16, 16), (3, 1, 4)):
+            kw = dict(dof=[[2], [3]], obs=[0.0, [0.0, 0.0]], solver=solver, neval=2e4, niter=3, seed=77, nchain=nchain, block=block, measurefreq=mf)
+            b = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), measure=dev, **kw)
+            for m in (sphere3_measure, sphere3_measure5):
+                a = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), measure=m, **kw)
+                np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-9, err_msg="%s mf=%d nchain=%d %s" % (solver, mf, nchain, m.__name__))
+                np.testing.assert_allclose(a.iter_std, b.iter_std, rtol=1e-6)
+                assert a.mean[1][1] == pytest.approx(2.0 * a.mean[1][0], rel=1e-9)
+        # everything user-side on the host: one launch + one integrand callback per Markov step, the measure after the launch
+        kw = dict(dof=[[2], [3]], obs=[0.0, [0.0, 0.0]], solver=solver, neval=8e3, niter=2, seed=5, nchain=16, measurefreq=2)
+        c = integrate(f2, var=Continuous(0.0, 1.0), measure=sphere3_measure, **kw)
+        d = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), measure=dev, **kw)
+        np.testing.assert_allclose(c.iter_mean, d.iter_mean, rtol=1e-9)
+    # a measure that reads the configuration: histogram of x[0] in two bins, weight of the one integrand (several pools, a Discrete)
+    def binned(v, obs, weights, config):
+        lo = v[0][0] < 0.5
+        obs[0][0] += weights[0][lo].sum()
+        obs[0][1] += weights[0][~lo].sum()
+    devb = mci.Measure("obs_add(x[0] < 0.5 ? 0 : 1, rw[0]);")
+    for solver in ("vegasmc", "mcmc", "vegas"):
+        kw = dict(dof=[[1, 1]], obs=[[0.0, 0.0]], solver=solver, neval=2e4, niter=3, seed=9)
+        a = integrate("return x[0] * x[1];", var=(Continuous(0.0, 1.0), Discrete(1, 3)), measure=binned, **kw)
+        b = integrate("return x[0] * x[1];", var=(Continuous(0.0, 1.0), Discrete(1, 3)), measure=devb, **kw)
+        np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-9)
+    assert a.mean[0][0] == pytest.approx(0.75, abs=5 * a.stdev[0][0] + 1e-3) and a.mean[0][1] == pytest.approx(2.25, abs=5 * a.stdev[0][1] + 1e-3)
 
 
 def test_python_closure_as_integrand_matches_device_source():

@@ -1081,6 +1081,49 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 #ifndef MCI_TILES_U
 #define MCI_TILES_U (MCI_THREADS >= 768 ? 8 : 4) // samples per lane and trip (measured: 8 at 768 threads 6.46 -> 6.38 ms, 16 slower; 4 at 512)
 #endif
+// Replay with the tile's histograms BIN-MAJOR in LDS, sH[bin * G + grid], and the lanes of a wave walking the tile's G grids in
+// skewed order (lane l adds to grid (d + l % G) % G at step d).  A wave's ds_add_f64 then lands on G different grids at once and
+// the lanes that share a grid (64 / G of them) share only the 2 bank pairs {grid, grid + 16} of a 16-grid tile, instead of 64
+// random addresses colliding all over the 32 bank pairs: the random-address atomic costs 41 ns per wave-instruction and SIMD,
+// a conflict-free one 13.4 (tools/issue_microbench.hip).  The skew is a rotation of the lane's G bins by a per-lane constant:
+// a 4-stage log shifter of v_cndmask_b32 (the replay has the VALU slots to spare: it is bound by the atomics and by HBM).
+// Taken when the tile is G <= 16 one-draw Continuous leaves of equal size covered by the same integrands (C4: 2 tiles of 16).
+#ifndef MCI_TILES_BANKED
+#define MCI_TILES_BANKED 1
+#endif
+template <int... D> struct ISeq {};
+template <int N, int... D> struct MakeISeq : MakeISeq<N - 1, N - 1, D...> {};
+template <int... D> struct MakeISeq<0, D...> { typedef ISeq<D...> type; };
+// b[d] <- b[(d + SH) % G] of a G-element register vector (SSA value: no private array the compiler could index dynamically)
+template <int G, int SH, class V, int... D> __device__ __forceinline__ V rotate_lanes(const V b, ISeq<D...>) {
+    return __builtin_shufflevector(b, b, ((D + SH) % G)...);
+}
+template <class Cfg> constexpr int tile_draw_count(int tt) {
+    int n = 0;
+    for (int k = 0; k < Cfg::NDRAW; ++k) n += (is_tdraw<Cfg>(k) && Cfg::leaf_tile(Cfg::draw_leaf(k)) == tt) ? 1 : 0;
+    return n;
+}
+template <class Cfg> constexpr int tile_draw(int tt, int gi) { // the gi-th replayed draw of tile tt, in draw order
+    int n = 0;
+    for (int k = 0; k < Cfg::NDRAW; ++k)
+        if (is_tdraw<Cfg>(k) && Cfg::leaf_tile(Cfg::draw_leaf(k)) == tt) {
+            if (n == gi) return k;
+            ++n;
+        }
+    return 0;
+}
+template <class Cfg> constexpr bool tile_banked(int tt) {
+    const int G = tile_draw_count<Cfg>(tt);
+    if (MCI_TILES_BANKED == 0 || G < 2 || G > 16) return false;
+    const int k0 = tile_draw<Cfg>(tt, 0), NB = Cfg::leaf_nbin(Cfg::draw_leaf(k0));
+    if (Cfg::tile_nbin(tt) != G * NB) return false;
+    for (int gi = 0; gi < G; ++gi) {
+        const int k = tile_draw<Cfg>(tt, gi), leaf = Cfg::draw_leaf(k);
+        if (Cfg::leaf_kind(leaf) != 0 || Cfg::leaf_nbin(leaf) != NB || Cfg::cover_mask(k) != Cfg::cover_mask(k0)) return false;
+        if (Cfg::leaf_boff(leaf) - Cfg::tile_boff(tt) != gi * NB) return false;
+    }
+    return true;
+}
 template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, T = blockDim.x;
@@ -1127,6 +1170,38 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
                         if constexpr (need) word[u][j] = a.tile_bins[j * a.tile_stride + idx];
                     });
                 });
+                if constexpr (tile_banked<Cfg>(tt)) {
+                    constexpr int G = tile_draw_count<Cfg>(tt), K0 = tile_draw<Cfg>(tt, 0);
+                    const int r = (tid & 63) % G; // this lane's skew
+                    static_for<0, U>([&](auto Uu) {
+                        constexpr int u = decltype(Uu)::value;
+                        if (live[u]) {
+                            double wk = 0.0;
+                            static_for<0, Cfg::NI>([&](auto I) {
+                                constexpr int i = decltype(I)::value;
+                                if constexpr ((Cfg::own_mask(i) >> K0) & 1ull) wk += wh[u][i];
+                            });
+                            typedef int bvec __attribute__((ext_vector_type(G)));
+                            bvec b;
+                            static_for<0, G>([&](auto Gi) {
+                                constexpr int m = tdraw_pos<Cfg>(tile_draw<Cfg>(tt, decltype(Gi)::value));
+                                b[decltype(Gi)::value] = (int)((word[u][m / PER] >> (BITS * (m % PER))) & ((1u << BITS) - 1u));
+                            });
+                            static_for<0, 4>([&](auto Ss) { // b[d] <- b[(d + r) % G], one conditional rotation per bit of r
+                                constexpr int sh = 1 << decltype(Ss)::value;
+                                if constexpr (sh < G) {
+                                    const bvec c = rotate_lanes<G, sh>(b, typename MakeISeq<G>::type{});
+                                    b = (r & sh) != 0 ? c : b;
+                                }
+                            });
+                            int g = r;
+                            static_for<0, G>([&](auto D) {
+                                lds_add(&sH[b[decltype(D)::value] * G + g], wk);
+                                g = g + 1 == G ? 0 : g + 1;
+                            });
+                        }
+                    });
+                } else
                 static_for<0, U>([&](auto Uu) {
                     constexpr int u = decltype(Uu)::value;
                     if (live[u]) {
@@ -1151,6 +1226,10 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
             }
             __syncthreads();
             double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
+            if constexpr (tile_banked<Cfg>(tt)) { // [bin][grid] in LDS -> [grid][bin] rows (coalesced stores; the strided LDS reads are a few us per tile)
+                constexpr int G = tile_draw_count<Cfg>(tt), NB = Cfg::tile_nbin(tt) / G;
+                for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = sH[(i % NB) * G + i / NB];
+            } else
             for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = sH[i];
         }
     });

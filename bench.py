@@ -120,7 +120,7 @@ def measured_issue_costs():
     rows, source = None, None
     if os.path.exists(MICROBENCH):
         try:
-            out = subprocess.run([MICROBENCH, "1000", "roofline"], check=True, capture_output=True, text=True, timeout=120).stdout
+            out = subprocess.run([MICROBENCH, "2000", "roofline"], check=True, capture_output=True, text=True, timeout=300).stdout
             rows = [json.loads(ln) for ln in out.splitlines() if ln.startswith("{")]
             source = "measured in this run (tools/issue_microbench.hip)"
         except Exception as e:  # pragma: no cover
@@ -131,20 +131,27 @@ def measured_issue_costs():
             return None, None
         rows = json.load(open(path))["rows"]
         source = "profiles/r02_issue_costs.json (same tool, earlier run)"
-    costs = {}
+    per_op = {}
     for r in rows:
-        if "op" in r:
-            costs[r["op"]] = min(costs.get(r["op"], 1e30), r["wall_ns_per_wave_inst_per_simd"])
+        if "op" in r and r.get("waves_per_simd", 8) >= 4:
+            # the slope between two launch lengths where the tool reports it (the fixed launch + tail time cancels), else the wall
+            # figure (an upper bound on the cost)
+            c = r.get("slope_ns_per_wave_inst_per_simd")
+            if c is None or c <= 0:
+                c = r["wall_ns_per_wave_inst_per_simd"]
+            per_op.setdefault(r["op"], []).append(c)
+    # 4 and 8 waves per SIMD both saturate a pipe: their mean (the minimum of two noisy slopes would be biased low)
+    costs = {op: sum(v) / len(v) for op, v in per_op.items()}
     return costs, source
 
 
-def issue_roofline(code_object, costs, samples_per_launch, kernel_ms):
+def issue_roofline(code_object, costs, samples_per_launch, kernel_ms, hist_copies=1):
     """{"valu": ..., "lds": ...}: the launch's wave-instructions on each pipe per second against the rate at which the chip
     can issue THAT mix (1024 SIMDs / mix-weighted mean issue cost).  The LDS rows are costs seen from one SIMD with all four
     SIMDs of the CU competing, so the same 1024 applies."""
     from mcintegration_jl_amd import isa_mix
     mix = isa_mix.loop_mix(code_object, "mci_vegas_batch")
-    cyc = isa_mix.issue_cycles(mix, costs)
+    cyc = isa_mix.issue_cycles(mix, costs, hist_copies=hist_copies)
     trips = samples_per_launch / 64.0                       # one loop trip = one sample on each of a wave's 64 lanes
     out = {}
     for pipe in ("valu", "lds"):
@@ -374,7 +381,8 @@ def main():
             k_avg_ms = float(np.mean(kms))
             code_object = eng.code_object("vegas")
             out["config"].update({"kernel": "mci_vegas_batch", "workgroups": wgs, "threads": threads, "table_mode": eng.table_mode,
-                                  "code_object": os.path.basename(code_object)})
+                                  "code_object": os.path.basename(code_object),
+                                  "histogram_copies": eng.histogram_copies() if hasattr(eng, "histogram_copies") else 1})
             spl = nevalperblock * per                                   # samples of one launch on one GPU
             achieved_hbm = B_ALG * spl / (k_avg_ms * 1e-3) / 1e9       # GB/s
             traffic, traffic_src, sq = recorded_traffic(code_object)
@@ -385,7 +393,7 @@ def main():
             costs, costs_src = measured_issue_costs()
             roof = {"bound": "valu+lds", "kernel_ms_avg": round(k_avg_ms, 4), "traffic": traffic, "hbm_model": hbm}
             if costs:
-                ir = issue_roofline(code_object, costs, spl, k_avg_ms)
+                ir = issue_roofline(code_object, costs, spl, k_avg_ms, hist_copies=out["config"].get("histogram_copies", 1))
                 top = "valu" if ir["valu"]["frac"] >= ir["lds"]["frac"] else "lds"
                 roof.update({"achieved": ir[top]["achieved"], "peak": ir[top]["peak"], "unit": "G wave-instructions/s", "frac": ir[top]["frac"],
                              "binding_pipe": top, "valu": ir["valu"], "lds": ir["lds"], "mix": ir["mix"], "resources": ir["resources"],

@@ -183,6 +183,10 @@ int mci_kernel_code_object(mci_problem *prob, int32_t solver, char *buf, int32_t
 int mci_set_launch(mci_problem *prob, int32_t threads_per_workgroup, int32_t workgroups_per_block);
 int mci_problem_info(const mci_problem *prob, int32_t *ndraw, int32_t *nobs, int64_t *packed_size,
                      int32_t *table_mode, int64_t *lds_bytes);
+/* interleaved copies of the LDS histograms the :vegas sample kernel keeps (1 = the plain layout): the placement rule's choice
+ * before the kernel is compiled, what the compiled kernel uses afterwards (DESIGN.md "Histogram copies"); diagnostics and
+ * bench.py's roofline price the kernel's ds_add_f64 with the matching access pattern */
+int mci_get_histogram_copies(const mci_problem *prob, int32_t *copies);
 
 /* ---- one iteration, step by step (what mci_integrate runs; also the testing seam) ---- */
 /* blocks [block_lo, block_hi) of `_block!` (main.jl:236-292) on this GPU; leaves the local packed buffer

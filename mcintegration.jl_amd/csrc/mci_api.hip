@@ -183,6 +183,11 @@ struct mci_problem {
     // pass shows no scratch (128 / 168 / 256 registers).  threads_vegas = 0: the vegas kernel follows `threads`
     int threads_vegas = 0;
     bool vegas_plan_a = false; // the ladder is active (no explicit size was asked for)
+    // histogram copies of the :vegas sample kernel (mci_device.h hslot): what the placement rule picked (shape.hcopy is what the
+    // compiled kernel uses: the rule's choice, or 1 when that kernel needs more than 128 VGPRs and two 512-thread workgroups
+    // would not share a CU)
+    int hcopy_auto = 1;
+    bool hcopy_plan = false; // the rule also picked the workgroup size (512 threads) for the :vegas kernel
     // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
     // launch before it is long enough to hide its ~35 us per iteration (>= kSerialWalkSamples samples or chain steps on this
     // rank: 2 % of the headline iteration), the prefix-scan form below that; mci_set_train_walk / MCI_TRAIN_SERIAL=1 | 0 force one
@@ -630,10 +635,31 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         s.pair_table = pair;
         const bool hist_lds = (mode == 0 || mode == 3);
         p->lds_bytes = fixed + (mode <= 1 ? (pair ? e2 : e1) : 0) + (hist_lds ? (int64_t)s.htile * 8 : 0);
+        // Interleaved histogram copies for the :vegas sample kernel (mci_device.h hslot): fewer LDS bank conflicts of the
+        // random-address ds_add_f64.  Rule: tables in LDS (mode 0), as many copies (<= 8) as leave room for TWO 512-thread
+        // workgroups per CU (4 waves per SIMD when the kernel needs <= 128 VGPRs; compile_solver checks).  Measured on C2
+        // (tools/hcopy_sweep.sh, kernel ms per 1e8 samples): 1 copy x 256 threads 1.715 | 4 x 512 1.663 | 8 x 512 1.625 |
+        // 16 x 1024 (one workgroup per CU) 1.662 | 8 x 1024 1.694.  MCI_HIST_COPIES overrides (1 = off).
+        s.hcopy = 1;
+        {
+            int hc = 1;
+            const int64_t one = (int64_t)s.htile * 8;
+            int nadd = 0; // ds_add_f64 per sample
+            for (int k = 0; k < s.ndraw; ++k) nadd += (p->leaves[s.draw_leaf[k]].adapt && s.cover_mask[k]) ? 1 : 0;
+            if (mode == 0 && s.ntile == 1 && p->lds_bytes <= lim0 && nadd >= 4) // (a 1-D integrand runs 4 % slower with 512 threads and gains nothing)
+                while (hc < 8 && p->lds_bytes + one * (2 * hc - 1) <= lim0) hc *= 2;
+            if (const char *e = getenv("MCI_HIST_COPIES")) { // diagnostic override
+                hc = atoi(e);
+                while (hc > 1 && (!hist_lds || s.ntile != 1 || (hc & (hc - 1)) || p->lds_bytes + one * (hc - 1) > lim1)) hc >>= 1;
+                if (hc < 1) hc = 1;
+            }
+            s.hcopy = p->hcopy_auto = hc;
+        }
+        const int64_t hcopy_bytes = (int64_t)s.htile * 8 * (s.hcopy - 1);
         // one tile, grids gathered from L2 (10 .. 18 independent grids): the LDS left next to the histogram caches the edges of the
         // leading grids for the :vegas sample pass (MCI_NO_EDGE_CACHE=1 for A/B runs)
         if (mode == 3 && s.ntile == 1 && !(getenv("MCI_NO_EDGE_CACHE") && atoi(getenv("MCI_NO_EDGE_CACHE")) != 0)) {
-            const int64_t budget = (lim1 - p->lds_bytes) / 8;
+            const int64_t budget = (lim1 - p->lds_bytes - hcopy_bytes) / 8;
             for (size_t l = 0; l < p->leaves.size(); ++l) {
                 const Leaf &L = p->leaves[l];
                 if (L.kind != MCI_CONTINUOUS || s.ec_doubles + L.nbin + 1 > budget) continue;
@@ -661,6 +687,10 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         }
         if (const char *e = getenv("MCI_THREADS")) // diagnostic override of the default workgroup size
             if (atoi(e) >= 64 && atoi(e) <= 1024 && atoi(e) % 64 == 0) p->threads = atoi(e);
+        if (s.hcopy > 1 && !p->vegas_plan_a && !getenv("MCI_THREADS")) { // two 512-thread workgroups per CU (the rule above)
+            p->hcopy_plan = true;
+            p->threads_vegas = 512;
+        }
     }
     p->nstat = 2 * s.nobs + 2 + Nd;
     p->packed_n = p->nstat + s.nbin + 2 * p->npa; // [statistics | histograms | propose | accept]
@@ -833,12 +863,19 @@ int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
         if (threads != p->threads || p->threads_vegas) {
             p->threads = threads;
             p->vegas_plan_a = false; // an explicit size: the vegas kernel follows it
+            p->hcopy_plan = false;
             p->threads_vegas = 0;
             drop_modules(p);
         }
     }
     if (wg_per_block >= 0) p->wg_per_block = wg_per_block;
     return MCI_OK;
+}
+
+// dynamic LDS of the :vegas sample kernel: the tables (+ the edge cache of the many-grid plans) + its histogram copies
+static int64_t vegas_lds(const mci_problem *p) {
+    const auto &s = p->shape;
+    return (s.ec_doubles > 0 ? p->lds_bytes_k1 : p->lds_bytes) + (int64_t)s.htile * 8 * (s.hcopy - 1);
 }
 
 static int compile_solver(mci_problem *p, int solver) {
@@ -848,6 +885,9 @@ static int compile_solver(mci_problem *p, int solver) {
         for (int i = 0; i < p->ni; ++i)
             if (p->shape.obs_bin_draw[i] < 0 && p->shape.obs_nbin[i] != p->shape.ncomp)
                 return fail(MCI_ERR_INVALID, "the default measure can only handle observable as Vector with %d scalar elements!", p->ni);
+    const bool hcopy_plan = solver == MCI_VEGAS && p->hcopy_plan && !getenv("MCI_HIST_COPIES");
+    if (solver == MCI_VEGAS) p->shape.hcopy = p->hcopy_auto;
+    if (solver == MCI_VEGAS && p->hcopy_plan) p->threads_vegas = 512;
     std::string src = mcijit::generate_source(p->shape, solver);
     std::vector<char> code;
     std::string log;
@@ -855,6 +895,15 @@ static int compile_solver(mci_problem *p, int solver) {
     int T = solver == MCI_VEGAS && p->threads_vegas ? p->threads_vegas : p->threads;
     int rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]);
     if (rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
+    if (hcopy_plan && mcijit::kernel_vgprs(code, "mci_vegas_batch") > 128) {
+        // histogram copies pay when two 512-thread workgroups share a CU (4 waves per SIMD): this integrand's kernel needs more
+        // registers than that allows -> the plain layout with 256-thread workgroups, as many as the registers admit
+        p->shape.hcopy = 1;
+        p->threads_vegas = 0;
+        T = p->threads;
+        src = mcijit::generate_source(p->shape, solver);
+        if ((rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
+    }
     while (solver == MCI_VEGAS && p->vegas_plan_a && T > 512 && mcijit::kernel_scratch_bytes(code, "mci_vegas_batch") != 0) {
         // the sample pass keeps too many values live for this many waves per SIMD: next rung (1024 -> 768 -> 512 threads)
         T = T == 1024 ? 768 : 512;
@@ -878,7 +927,10 @@ static int compile_solver(mci_problem *p, int solver) {
             if (p->lds_bytes > 64 * 1024)
                 HIPCHK(hipFuncSetAttribute((const void *)p->f_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
         }
-        if (solver == MCI_VEGAS && p->shape.ec_doubles > 0 && p->lds_bytes_k1 > 64 * 1024)
+        if (solver == MCI_VEGAS && vegas_lds(p) > p->lds_bytes && vegas_lds(p) > 64 * 1024) {
+            HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize, (int)vegas_lds(p)));
+            if (p->lds_bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)p->f_dump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+        } else if (solver == MCI_VEGAS && p->shape.ec_doubles > 0 && p->lds_bytes_k1 > 64 * 1024)
             HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(p->lds_bytes_k1 > p->lds_bytes ? p->lds_bytes_k1 : p->lds_bytes)));
         else if (p->lds_bytes > 64 * 1024) {
@@ -924,6 +976,12 @@ int mci_check_status(mci_problem *p) {
     return check_status(p);
 }
 int mci_compile_solver(mci_problem *p, int32_t solver) { return compile_solver(p, solver); }
+
+int mci_get_histogram_copies(const mci_problem *p, int32_t *copies) {
+    if (!p || !copies) return fail(MCI_ERR_INVALID, "NULL argument");
+    *copies = p->compiled[MCI_VEGAS] ? p->shape.hcopy : p->hcopy_auto;
+    return MCI_OK;
+}
 
 int mci_problem_info(const mci_problem *p, int32_t *ndraw, int32_t *nobs, int64_t *packed_size, int32_t *table_mode, int64_t *lds_bytes) {
     if (ndraw) *ndraw = p->shape.ndraw;
@@ -1260,7 +1318,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             }
         }
     } else
-    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)((solver == MCI_VEGAS && s.ec_doubles > 0) ? p->lds_bytes_k1 : p->lds_bytes), st, args, nullptr));
+    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)(solver == MCI_VEGAS ? vegas_lds(p) : p->lds_bytes), st, args, nullptr));
     if (split)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (!p->graph_mode) {

@@ -286,7 +286,15 @@ template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __
     if constexpr (Cfg::leaf_kind(leaf) == 0) {
         // sampler.jl:295-303:  iy = floor(y*N)+1; dy = y*N-(iy-1); x = g[iy] + dy*(g[iy+1]-g[iy]); prob = 1/(N*dx)
         constexpr int N = Cfg::leaf_nbin(leaf);
-        const double yn = (U12 ? y - 1.0 : y) * (double)N; // (a hand-placed v_fma_f64(y+1, N, -N) saved one instruction on C2 and cost C3 16 %)
+#ifndef MCI_YN_FMA
+#define MCI_YN_FMA 1 // measured (tools/ab_c2.py, tools/c3_ab.py): C2 -0.3 %, C4 -0.9 %, C5 :vegas -0.5 %, C3 :vegas -0.7 %
+#endif
+#if MCI_YN_FMA
+        // (y1 - 1) * N in one instruction: y1 - 1 is exact for y1 in [1, 2), so fma(y1, N, -N) rounds the same real number once -- the same bits
+        const double yn = U12 ? __builtin_fma(y, (double)N, -(double)N) : y * (double)N;
+#else
+        const double yn = (U12 ? y - 1.0 : y) * (double)N;
+#endif
         const int iy = (int)yn;                           // y*N >= 0: trunc == floor
         const double dy = __builtin_amdgcn_fract(yn);     // v_fract_f64 == yn - floor(yn), exact
 #ifdef MCI_ABL_NOTABLE
@@ -705,7 +713,7 @@ template <class Cfg> struct Lds {
     static constexpr int DA = E + (Cfg::TABLE_MODE <= 1 ? (Cfg::PAIR_TABLE != 0 ? Cfg::NPAIR : Cfg::NEDGE) : 0);
     static constexpr int DD = DA + Cfg::NDACC;
     static constexpr int H = DD + Cfg::NDDIST;
-    static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE : 0);
+    static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE * Cfg::HCOPY : 0);
     static constexpr int R = O + Cfg::NOBS;
     static constexpr int PA = R + 16 /*waves*/ * Cfg::NCOLS; // propose | accept counters (u64), chain solvers
     static constexpr int END = PA + 2 * PaTable<Cfg>::N;
@@ -731,6 +739,16 @@ template <class Cfg> struct Cols {
     static_assert(VISITED + Cfg::NI + 1 == Cfg::NCOLS, "column layout");
 };
 
+// Histogram copies (Cfg::HCOPY, a power of two; one histogram tile only): the workgroup keeps HCOPY interleaved copies of its LDS
+// histograms, sH[bin * HCOPY + copy], and lane l adds to copy l % HCOPY.  The 64 / HCOPY lanes that share a copy then share
+// 32 / HCOPY bank pairs instead of all 64 lanes colliding at random over the 32 (a random-address ds_add_f64 costs 41 ns per
+// wave-instruction and SIMD, a conflict-free one 13.4; tools/issue_microbench.hip); the copies are summed, in a fixed order,
+// when the workgroup writes its partial histogram.
+template <class Cfg> __device__ __forceinline__ int hslot(int flat) {
+    if constexpr (Cfg::HCOPY == 1) return flat;
+    else return flat * Cfg::HCOPY + (int)(threadIdx.x & (unsigned)(Cfg::HCOPY - 1));
+}
+
 // histogram update of one sample: accumulate!(var, pos+offset, weight) for every (integrand i, draw k in own(i))
 // (vegas/montecarlo.jl:170-185).  The per-integrand weights covering the same draw are summed first,
 // so each draw costs one ds_add_f64.
@@ -749,9 +767,9 @@ template <class Cfg, int TILE = -1> __device__ __forceinline__ void hist_update(
             if constexpr (Mode<Cfg>::HIST_LDS) {
                 constexpr int lt = Cfg::leaf_tile(leaf);
                 if constexpr (TILE >= 0) {
-                    if constexpr (Cfg::NTILE == 1 || TILE == lt) lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + s.bin[k]], wk);
+                    if constexpr (Cfg::NTILE == 1 || TILE == lt) lds_add(&sH[hslot<Cfg>(Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + s.bin[k])], wk);
                 } else {
-                    if (Cfg::NTILE == 1 || tile == lt) lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + s.bin[k]], wk);
+                    if (Cfg::NTILE == 1 || tile == lt) lds_add(&sH[hslot<Cfg>(Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + s.bin[k])], wk);
                 }
             } else {
                 global_add(&gH[Cfg::leaf_boff(leaf) + s.bin[k]], wk);
@@ -844,7 +862,11 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
             constexpr int tt = decltype(Tt)::value;
             if (tile == tt) {
                 double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
-                for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = ACCUM ? hrow[i] + sH[i] : sH[i];
+                for (int i = tid; i < Cfg::tile_nbin(tt); i += T) {
+                    double v = sH[i * Cfg::HCOPY];
+                    static_for<1, Cfg::HCOPY>([&](auto Cc) { v += sH[i * Cfg::HCOPY + decltype(Cc)::value]; }); // fixed order
+                    hrow[i] = ACCUM ? hrow[i] + v : v;
+                }
             }
         });
     }
@@ -880,7 +902,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     double *sH = smem + L::H, *sO = smem + L::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS && !NOHIST)
-        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
+        for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
     Tables<Cfg> t;
     t.EC = nullptr;
@@ -1125,6 +1147,7 @@ template <class Cfg> constexpr bool tile_banked(int tt) {
     return true;
 }
 template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs &a) {
+    static_assert(Cfg::HCOPY == 1, "histogram copies go with one tile");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, T = blockDim.x;
     double *sH = smem + Lds<Cfg>::H;
@@ -1139,7 +1162,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
     if (rowid >= a.nrows) return; // the grid is rounded up to a multiple of 8 * NTM
     const i64 lb = rowid / a.wg_per_block;
     const int slice = (int)(rowid % a.wg_per_block);
-    for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
+    for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
     __syncthreads();
     const i64 stride = (i64)a.wg_per_block * T;
     static_for<T0, Cfg::NTILE>([&](auto TT) {
@@ -1313,7 +1336,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
-        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
+        for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
     u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
     for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;
@@ -1504,7 +1527,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_host_step(const Bat
     double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
-        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
+        for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
     u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
     for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;
@@ -1811,7 +1834,7 @@ template <class Cfg, int K> __device__ __forceinline__ void hist_add(int bin, do
     if constexpr (Cfg::leaf_adapt(leaf) != 0) {
         if constexpr (Mode<Cfg>::HIST_LDS) {
             constexpr int lt = Cfg::leaf_tile(leaf);
-            if (Cfg::NTILE == 1 || tile == lt) lds_add(&sH[Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + bin], wk);
+            if (Cfg::NTILE == 1 || tile == lt) lds_add(&sH[hslot<Cfg>(Cfg::leaf_boff(leaf) - Cfg::tile_boff(lt) + bin)], wk);
         } else {
             global_add(&gH[Cfg::leaf_boff(leaf) + bin], wk);
         }
@@ -1994,7 +2017,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
-        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
+        for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
     u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
     for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;
@@ -2227,7 +2250,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_host_step(const BatchA
     double *sH = smem + Lds<Cfg>::H, *sO = smem + Lds<Cfg>::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
-        for (int i = tid; i < Cfg::HTILE; i += T) sH[i] = 0.0;
+        for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
     for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
     u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
     for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;

@@ -49,6 +49,7 @@ struct ProblemShape {
     int ncomp = 1;            // 1: Float64 weights; 2: ComplexF64 stored (re, im)
     std::string measure_body; // user measure (empty = default / bin-by-Discrete)
     int host_integrand = 0;   // weights come from a host callback: over dumped draws (vegas), per Markov step (vegasmc)
+    int hcopy = 1;            // :vegas sample kernel: interleaved copies of the LDS histograms (mci_device.h hslot), power of two
     int host_measure = 0;     // observables are accumulated by a host callback over the launch's (measured) configurations and relative weights
     std::vector<int> nneighbor, neighbor; // [ni+1], [(ni+1)*nbmax] 0-based, padded with the integrand itself
     std::string body;
@@ -106,7 +107,7 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     o << fn_table("int", "leaf_boff", arr(s.leaf_boff, "int"));
     o << fn_table("int", "leaf_adapt", arr(s.leaf_adapt, "int"));
     o << fn_table("int", "leaf_poff", arr(s.leaf_poff, "int"));
-    o << "    static constexpr int NTILE = " << s.ntile << ", HTILE = " << s.htile << ";\n";
+    o << "    static constexpr int NTILE = " << s.ntile << ", HTILE = " << s.htile << ", HCOPY = " << ((solver == 0 && s.hcopy > 0) ? s.hcopy : 1) << ";\n";
     o << "    static constexpr int SPLIT_ALL = " << (solver == 0 ? s.split_all : 0) << ", EC_DOUBLES = " << (solver == 0 ? s.ec_doubles : 0)
       << ", L1_PHASE = " << (solver == 0 ? s.l1_phase : 0) << ", RNG_BITS = " << (solver == 0 ? s.rng_bits : 52) << ";\n";
     {
@@ -168,7 +169,7 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
 // .private_segment_fixed_size (scratch bytes per work-item: register spills, stack) of one kernel, read from the code object's
 // AMDGPU metadata note (msgpack; LLVM writes a kernel's keys in sorted order, so the first such key after `.name <kernel>` is that
 // kernel's).  -1 when the note does not have the expected shape.
-inline long kernel_scratch_bytes(const std::vector<char> &code, const char *kernel) {
+inline long kernel_note_value(const std::vector<char> &code, const char *kernel, const char *keyname) {
     const std::string blob(code.begin(), code.end());
     std::string name = "\xa5.name";
     const size_t kl = strlen(kernel);
@@ -177,7 +178,11 @@ inline long kernel_scratch_bytes(const std::vector<char> &code, const char *kern
     name += kernel;
     const size_t at = blob.find(name);
     if (at == std::string::npos) return -1;
-    const std::string key = "\xbb.private_segment_fixed_size";
+    std::string key;
+    const size_t nl = strlen(keyname);
+    if (nl < 32) key += (char)(0xa0 | nl);
+    else { key += (char)0xd9; key += (char)nl; }
+    key += keyname;
     const size_t k = blob.find(key, at);
     if (k == std::string::npos || k + key.size() >= blob.size()) return -1;
     const unsigned char *v = (const unsigned char *)blob.data() + k + key.size();
@@ -188,6 +193,9 @@ inline long kernel_scratch_bytes(const std::vector<char> &code, const char *kern
     if (v[0] == 0xce && left > 4) return ((long)v[1] << 24) | ((long)v[2] << 16) | ((long)v[3] << 8) | v[4];
     return -1;
 }
+inline long kernel_scratch_bytes(const std::vector<char> &code, const char *kernel) { return kernel_note_value(code, kernel, ".private_segment_fixed_size"); }
+// .vgpr_count of one kernel (sorts after .name like .private_segment_fixed_size does)
+inline long kernel_vgprs(const std::vector<char> &code, const char *kernel) { return kernel_note_value(code, kernel, ".vgpr_count"); }
 
 inline uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull) {
     for (unsigned char c : s) {

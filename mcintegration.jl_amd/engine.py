@@ -308,6 +308,12 @@ class Engine:
         check(lib().mci_kernel_code_object(self.p, _lib.SOLVERS[solver], buf, len(buf)))
         return buf.value.decode()
 
+    def histogram_copies(self):
+        """interleaved copies of the LDS histograms in the :vegas sample kernel (1 = the plain layout)"""
+        n = C.c_int32()
+        check(lib().mci_get_histogram_copies(self.p, C.byref(n)))
+        return n.value
+
     def check_status(self):
         """synchronise and raise what the device flagged (normalization / histogram / chain start errors)"""
         check(lib().mci_check_status(self.p))

@@ -194,11 +194,14 @@ def resources(path):
     return res
 
 
-def issue_cycles(mix, costs, default_valu=None):
+def issue_cycles(mix, costs, default_valu=None, hist_copies=1):
     """cycle-weighted cost of one loop trip per pipe.  costs: {microbench op name: cycles per wave-instruction}, matched
-    by prefix through COST_KEY.  Returns {"valu": cycles, "lds": cycles, "per_class": {class: (n, cycles each)}}"""
+    by prefix through COST_KEY; hist_copies: the kernel's interleaved histogram copies (its ds_add_f64 are priced with that access
+    pattern: `ds_add_f64 (random bins, N interleaved copies`).  Returns {"valu": cycles, "lds": cycles, "per_class": {class: (n, cycles each)}}"""
     def cost_of(cls):
         key = COST_KEY.get(cls)
+        if cls == "lds_add_f64" and hist_copies > 1:
+            key = "ds_add_f64 (random bins, %d interleaved copies" % hist_copies
         if key is not None:
             for name, c in costs.items():
                 if name.startswith(key):

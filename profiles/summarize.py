@@ -46,6 +46,22 @@ stats = query("stats", "select name, total_calls, total_duration, average, perce
 for name, calls, tot, avg, pct in stats:
     emit("%-64s %8d %14.1f %12.2f %8.2f" % (name[:64], calls, tot, avg, pct))
 
+# per-call durations in launch order: a sample kernel gets faster while the grid adapts (the first iterations pile the histogram
+# adds of a peaked integrand on few bins), so the figure to hold against bench.py's HIP-event average -- taken over the timed,
+# trained iterations only -- is the steady state (the median of the second half), not the average over warm-up and all
+percall = {}
+try:
+    for name, dur in query("stats", "select name, (end - start) from kernels order by start"):
+        percall.setdefault(name, []).append(dur / 1e3)
+except Exception as e:  # older rocprofv3 schema
+    emit("(no per-call view: %s)" % e)
+for K in KERNELS:
+    for name, ds in percall.items():
+        if name.startswith(K) and len(ds) >= 4:
+            half = sorted(ds[len(ds) // 2:])
+            emit("%-28s per call, us, launch order: %s" % (K, " ".join("%.0f" % d for d in ds)))
+            emit("%-28s steady state (median of the second half of the launches) = %.1f us" % (K, half[len(half) // 2]))
+
 summary = {"tag": tag, "kernels": {}, "command": CMD}
 # the code object the profiled run loaded (bench.py prints it in config.code_object): PMC numbers are only valid for THAT kernel binary
 try:
@@ -62,6 +78,10 @@ for K in KERNELS:
         if name.startswith(K):
             ks["kernel_avg_us"] = avg
             ks["kernel_calls"] = calls
+            ds = percall.get(name, [])
+            if len(ds) >= 4:
+                half = sorted(ds[len(ds) // 2:])
+                ks["kernel_steady_us"] = half[len(half) // 2]
     emit()
     emit("== HBM traffic per launch of %s (PMC; FETCH_SIZE and WRITE_SIZE in separate passes) ==" % K)
     sql = "select counter_name, count(*), avg(value) from counters_collection where kernel_name like '%s%%' group by counter_name" % K
@@ -89,7 +109,7 @@ for K in KERNELS:
 
 # flat keys of the first kernel: what bench.py's recorded_traffic() reads
 first = summary["kernels"].get(KERNELS[0], {})
-for k in ("kernel_avg_us", "kernel_calls", "hbm_bytes_per_launch", "fetch_kib_raw_per_launch", "write_kib_per_launch", "launches_profiled", "sq_avg_per_launch"):
+for k in ("kernel_avg_us", "kernel_steady_us", "kernel_calls", "hbm_bytes_per_launch", "fetch_kib_raw_per_launch", "write_kib_per_launch", "launches_profiled", "sq_avg_per_launch"):
     if k in first:
         summary[k] = first[k]
 summary["kernel"] = KERNELS[0]

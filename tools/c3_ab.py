@@ -18,7 +18,7 @@ eng.integrate("vegas", neval=10**8, niter=5, block=16, seed=2, first_iteration=5
 ms, wg, th = eng.kernel_times_ms(5)
 print(json.dumps(dict(ms=float(np.median(ms)), wg=wg, threads=th)))
 ''' % ROOT
-for flags in ("", "-DMCI_NO_FMA_ASM", "-DMCI_WAVES=2", "-DMCI_WAVES=3"):
+for flags in [""] + sys.argv[1:]:
     env = dict(os.environ); env["MCI_KERNEL_CACHE"] = "/tmp/mci_c3_cache"
     if flags: env["MCI_JIT_FLAGS"] = flags
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)

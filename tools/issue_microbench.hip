@@ -35,6 +35,7 @@ enum Op {
     OP_FMA_F64, OP_MUL_F64, OP_ADD_F64, OP_FRACT_F64, OP_CVT_I32_F64, OP_CVT_F64_I32, OP_FLOOR_F64, OP_LDEXP_F64, OP_RCP_F64, OP_CMP_F64, OP_CNDMASK,
     OP_FMA_F32, OP_PK_FMA_F32, OP_EXP_F32,
     OP_DS_READ_B128_RAND, OP_DS_READ_B64_RAND, OP_DS_READ_B64_SEQ, OP_DS_ADD_F64_RAND, OP_DS_ADD_F64_SAME, OP_DS_ADD_RTN_F64_RAND, OP_DS_ADD_F64_SEQ, OP_DS_ADD_U64_RAND, OP_DS_ADD_U32_RAND, OP_DS_ADD_F32_RAND, OP_DS_WRITE_B64_RAND,
+    OP_DS_ADD_F64_COPY2, OP_DS_ADD_F64_COPY4, OP_DS_ADD_F64_COPY8, OP_DS_ADD_F64_COPY16,
     OP_GLOBAL_LOAD_B64_RAND_L2, OP_GLOBAL_LOAD_B128_RAND_L2, OP_GLOBAL_LOAD_B128_RAND_L1, OP_GLOBAL_LOAD_B128_UNALIGNED_L1,
     OP_COUNT
 };
@@ -44,6 +45,7 @@ static const char *const kNames[OP_COUNT] = {
     "v_fma_f32", "v_pk_fma_f32", "v_exp_f32",
     "ds_read_b128 (random 16-B pairs, 999-bin table)", "ds_read_b64 (random, 999-bin table)", "ds_read_b64 (lane-consecutive)",
     "ds_add_f64 (random bins, 999-bin table)", "ds_add_f64 (one bin per wave)", "ds_add_rtn_f64 (random bins)", "ds_add_f64 (lane-consecutive bins: conflict-free)", "ds_add_u64 (random bins)", "ds_add_u32 (random bins)", "ds_add_f32 (random bins)", "ds_write_b64 (random bins)",
+    "ds_add_f64 (random bins, 2 interleaved copies: lane l adds to copy l % 2)", "ds_add_f64 (random bins, 4 interleaved copies)", "ds_add_f64 (random bins, 8 interleaved copies)", "ds_add_f64 (random bins, 16 interleaved copies = 16 grids bin-major, lanes skewed)",
     "global_load_dwordx2 (random 8-B, 32 x 8 KB tables, L2-resident)", "global_load_dwordx4 (random 16-B, 32 x 16 KB tables, L2-resident)", "global_load_dwordx4 (random 16-B pairs of ONE 16 KB table: L1-resident)", "global_load_dwordx4 (random 8-B-aligned pairs of ONE 8 KB edge table: L1-resident)",
 };
 
@@ -58,7 +60,8 @@ static const char *const kNames[OP_COUNT] = {
 template <int OP> __global__ void __launch_bounds__(256) k_issue(u64 *ticks, int iters, const double *gtab, u32 seed) {
     extern __shared__ __attribute__((aligned(16))) double lds[]; // 2 x 999 doubles (pair table) | 999 doubles (histogram)
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 2048 + 1024; i += 256) lds[i] = 1.0 + i;
+    constexpr int HC = OP == OP_DS_ADD_F64_COPY2 ? 2 : OP == OP_DS_ADD_F64_COPY4 ? 4 : OP == OP_DS_ADD_F64_COPY8 ? 8 : OP == OP_DS_ADD_F64_COPY16 ? 16 : 1;
+    for (int i = tid; i < 2048 + 1024 * HC; i += 256) lds[i] = 1.0 + i;
     __syncthreads();
     // per-lane pseudo-random bins (LCG; what matters is that the lanes of a wave scatter like the map's draws do)
     u32 r = seed ^ (u32)(blockIdx.x * 256 + tid) * 2654435761u;
@@ -70,7 +73,7 @@ template <int OP> __global__ void __launch_bounds__(256) k_issue(u64 *ticks, int
         const u32 bin = (u32)(((u64)(r >> 8) * 999ull) >> 24);
         addr16[j] = bin * 16u;            // (g, dx) pair j of a 999-bin PAIR_TABLE
         addr8[j] = bin * 8u;
-        addrh[j] = 16384u + bin * 8u;     // histogram region
+        addrh[j] = 16384u + (HC == 1 ? bin * 8u : (bin * (u32)HC + ((u32)lane & (u32)(HC - 1))) * 8u); // histogram region (HC interleaved copies: mci_device.h hslot)
         gaddr8[j] = (u64)(gtab + (size_t)j * 4 * 1024 + bin);           // table j (of 32 x 8 KB)
         gaddr16[j] = (u64)(gtab + (size_t)j * 4 * 2048 + 2 * bin);      // table j (of 32 x 16 KB)
         gaddr1[j] = (u64)(gtab + 2 * bin);                              // ONE 16 KB table of (g, dx) pairs
@@ -232,7 +235,7 @@ template <int OP> __global__ void __launch_bounds__(256) k_issue(u64 *ticks, int
 #define X(j) asm volatile("ds_read_b64 v[100+2*" #j ":101+2*" #j "], %0 offset:" #j "*512" : : "v"(seqaddr) : "memory", CLOB64);
                 REP8(X)
 #undef X
-            } else if constexpr (OP == OP_DS_ADD_F64_RAND) {
+            } else if constexpr (OP == OP_DS_ADD_F64_RAND || OP == OP_DS_ADD_F64_COPY2 || OP == OP_DS_ADD_F64_COPY4 || OP == OP_DS_ADD_F64_COPY8 || OP == OP_DS_ADD_F64_COPY16) {
 #define X(j) asm volatile("ds_add_f64 %0, %1" : : "v"(addrh[j]), "v"(e) : "memory");
                 REP8(X)
 #undef X
@@ -335,21 +338,32 @@ template <int ROUNDS> __global__ void __launch_bounds__(256) k_philox(u64 *ticks
     if (lane == 0) ticks[(size_t)blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
 }
 
-struct Res { double cyc_per_inst, ns_per_inst, clock_ghz; };
+struct Res { double cyc_per_inst, ns_per_inst, clock_ghz, slope_ns; };
 
-template <class F> static Res run(F launch, int W, double insts_per_wave, u64 *d_ticks, int ncu) {
+// launch(nblk, iters).  ns_per_inst = wall time of one launch / wave-instructions per SIMD (includes launch + tail: an upper
+// bound); slope_ns = (wall(2 * iters) - wall(iters)) / the extra wave-instructions: the fixed part cancels -- the issue cost.
+template <class F> static Res run(F launch, int W, double insts_per_wave_per_iter, int iters, u64 *d_ticks, int ncu) {
     const int nblk = ncu * W;
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0));
     CHK(hipEventCreate(&e1));
-    launch(nblk); // warm-up
+    auto timed = [&](int it) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            CHK(hipEventRecord(e0));
+            launch(nblk, it);
+            CHK(hipEventRecord(e1));
+            CHK(hipDeviceSynchronize());
+            float ms = 0.f;
+            CHK(hipEventElapsedTime(&ms, e0, e1));
+            best = ms < best ? ms : best;
+        }
+        return best;
+    };
+    launch(nblk, iters); // warm-up
     CHK(hipDeviceSynchronize());
-    CHK(hipEventRecord(e0));
-    launch(nblk);
-    CHK(hipEventRecord(e1));
-    CHK(hipDeviceSynchronize());
-    float ms = 0.f;
-    CHK(hipEventElapsedTime(&ms, e0, e1));
+    const float ms2 = timed(2 * iters);
+    const float ms = timed(iters); // (last: the tick counters below are this launch's)
     std::vector<u64> t((size_t)nblk * 4);
     CHK(hipMemcpy(t.data(), d_ticks, t.size() * sizeof(u64), hipMemcpyDeviceToHost));
     double mean = 0.0;
@@ -357,10 +371,12 @@ template <class F> static Res run(F launch, int W, double insts_per_wave, u64 *d
     mean /= (double)t.size();
     CHK(hipEventDestroy(e0));
     CHK(hipEventDestroy(e1));
+    const double n = insts_per_wave_per_iter * iters;
     Res r;
-    r.cyc_per_inst = mean / (insts_per_wave * W);
-    r.ns_per_inst = (double)ms * 1e6 / (insts_per_wave * W); // wall, includes launch + tail: upper bound
+    r.cyc_per_inst = mean / (n * W);
+    r.ns_per_inst = (double)ms * 1e6 / (n * W);
     r.clock_ghz = mean / ((double)ms * 1e6);                // ticks per ns if a wave spans the whole launch
+    r.slope_ns = ((double)ms2 - (double)ms) * 1e6 / (n * W);
     return r;
 }
 
@@ -370,6 +386,7 @@ static bool in_roofline_set(int op) { // the forms the sample loop's mix is pric
     case OP_XOR_B32: case OP_ALIGNBIT: case OP_BITOP3_B32: case OP_MAD_U64_U32: case OP_MUL_LO_U32: case OP_LSHRREV_B64: case OP_FMA_F64: case OP_MUL_F64:
     case OP_ADD_F64: case OP_FRACT_F64: case OP_CVT_I32_F64: case OP_RCP_F64: case OP_CMP_F64: case OP_LDEXP_F64: case OP_EXP_F32:
     case OP_DS_READ_B128_RAND: case OP_DS_READ_B64_RAND: case OP_DS_ADD_F64_RAND:
+    case OP_DS_ADD_F64_COPY2: case OP_DS_ADD_F64_COPY4: case OP_DS_ADD_F64_COPY8: case OP_DS_ADD_F64_COPY16:
         return true;
     default:
         return false;
@@ -380,11 +397,14 @@ template <int OP> static void bench_op(u64 *d_ticks, const double *d_gtab, int n
     if (g_roofline_only && !in_roofline_set(OP)) return;
     for (int W : {1, 2, 4, 8}) {
         if (g_roofline_only && W < 4) continue;
-        auto launch = [&](int nblk) { hipLaunchKernelGGL(k_issue<OP>, dim3(nblk), dim3(256), (2048 + 1024) * sizeof(double), 0, d_ticks, iters, d_gtab, 12345u); };
-        const double n = (double)iters * UNROLL * 8 * (OP == OP_XOR3_EMU ? 2 : 1);
-        const Res r = run(launch, W, n, d_ticks, ncu);
-        printf("{\"op\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_wave_inst\": %.3f, \"wall_ns_per_wave_inst_per_simd\": %.4f, \"ticks_per_wall_ns\": %.3f}\n",
-               kNames[OP], W, r.cyc_per_inst, r.ns_per_inst, r.clock_ghz);
+        constexpr int HC = OP == OP_DS_ADD_F64_COPY2 ? 2 : OP == OP_DS_ADD_F64_COPY4 ? 4 : OP == OP_DS_ADD_F64_COPY8 ? 8 : OP == OP_DS_ADD_F64_COPY16 ? 16 : 1;
+        constexpr size_t lds = (2048 + 1024 * HC) * sizeof(double);
+        if (lds > 64 * 1024) CHK(hipFuncSetAttribute((const void *)k_issue<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        auto launch = [&](int nblk, int it) { hipLaunchKernelGGL(k_issue<OP>, dim3(nblk), dim3(256), lds, 0, d_ticks, it, d_gtab, 12345u); };
+        const double n = (double)UNROLL * 8 * (OP == OP_XOR3_EMU ? 2 : 1);
+        const Res r = run(launch, W, n, iters, d_ticks, ncu);
+        printf("{\"op\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_wave_inst\": %.3f, \"wall_ns_per_wave_inst_per_simd\": %.4f, \"slope_ns_per_wave_inst_per_simd\": %.4f, \"ticks_per_wall_ns\": %.3f}\n",
+               kNames[OP], W, r.cyc_per_inst, r.ns_per_inst, r.slope_ns, r.clock_ghz);
         fflush(stdout);
     }
 }
@@ -398,10 +418,10 @@ template <int OP> static void bench_all(u64 *d_ticks, const double *d_gtab, int 
 
 template <int ROUNDS> static void bench_philox(u64 *d_ticks, int ncu, int iters) {
     for (int W : {1, 2, 4, 8}) {
-        auto launch = [&](int nblk) { hipLaunchKernelGGL(k_philox<ROUNDS>, dim3(nblk), dim3(256), 0, 0, d_ticks, iters, 777u); };
-        const Res r = run(launch, W, (double)iters * 8, d_ticks, ncu);
+        auto launch = [&](int nblk, int it) { hipLaunchKernelGGL(k_philox<ROUNDS>, dim3(nblk), dim3(256), 0, 0, d_ticks, it, 777u); };
+        const Res r = run(launch, W, 8.0, iters, d_ticks, ncu);
         printf("{\"op\": \"philox4x32-%d call (compiler-scheduled, 2 v_mad_u64_u32 + 2 v_bitop3_b32 per round)\", \"waves_per_simd\": %d, \"cycles_per_wave_inst\": %.2f, "
-               "\"wall_ns_per_wave_inst_per_simd\": %.4f, \"ticks_per_wall_ns\": %.3f}\n", ROUNDS, W, r.cyc_per_inst, r.ns_per_inst, r.clock_ghz);
+               "\"wall_ns_per_wave_inst_per_simd\": %.4f, \"slope_ns_per_wave_inst_per_simd\": %.4f, \"ticks_per_wall_ns\": %.3f}\n", ROUNDS, W, r.cyc_per_inst, r.ns_per_inst, r.slope_ns, r.clock_ghz);
         fflush(stdout);
     }
 }

@@ -287,11 +287,19 @@ template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __
         // sampler.jl:295-303:  iy = floor(y*N)+1; dy = y*N-(iy-1); x = g[iy] + dy*(g[iy+1]-g[iy]); prob = 1/(N*dx)
         constexpr int N = Cfg::leaf_nbin(leaf);
 #ifndef MCI_YN_FMA
-#define MCI_YN_FMA 1 // measured (tools/ab_c2.py, tools/c3_ab.py): C2 -0.3 %, C4 -0.9 %, C5 :vegas -0.5 %, C3 :vegas -0.7 %
+#define MCI_YN_FMA 1 // measured (tools/ab_c2.py): C2 -0.9 %, C4 -0.5 %, C5 :vegas -2 % (515 instead of 531 VALU instructions per C2 sample)
 #endif
 #if MCI_YN_FMA
         // (y1 - 1) * N in one instruction: y1 - 1 is exact for y1 in [1, 2), so fma(y1, N, -N) rounds the same real number once -- the same bits
-        const double yn = U12 ? __builtin_fma(y, (double)N, -(double)N) : y * (double)N;
+        // (N through an opaque SGPR pair: with the literal the compiler picks v_fmac_f64 and rebuilds the -N accumulator with two
+        // v_mov_b32 per draw; v_fma_f64 v, v, s, -s uses one SGPR pair twice, which the constant bus allows.  The whole v_fma_f64 as
+        // inline asm made the C3 :vegas kernel 17 % slower: different inlining, 143 -> 157 VGPRs)
+        double yn;
+        if constexpr (U12 && Cfg::NDRAW >= 8) { // (few draws: nothing to gain, and the C3 :vegas kernel came out 17 % slower with either fma form)
+            double Nd = (double)N;
+            asm("" : "+s"(Nd)); // an SGPR pair the compiler cannot fold into a literal
+            yn = __builtin_fma(y, Nd, -Nd);
+        } else yn = (U12 ? y - 1.0 : y) * (double)N;
 #else
         const double yn = (U12 ? y - 1.0 : y) * (double)N;
 #endif

@@ -1132,6 +1132,9 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         if (solver != MCI_VEGAS && s.ntile > 1) return fail(MCI_ERR_INVALID, "a host integrand under a chain solver needs the histograms in one LDS tile");
         // :vegas -- the draws of the whole launch; chain solvers -- one configuration per chain and Markov step (below)
         const int64_t n = solver == MCI_VEGAS ? nblocks * nevalperblock : nblocks * nchain;
+        if ((double)n * (double)(s.ndraw + s.ni * s.ncomp) * 8.0 > 8.0 * 1024 * 1024 * 1024)
+            return fail(MCI_ERR_INVALID, "a host integrand over %lld configurations of %d doubles per launch (more than 8 GiB): lower neval or "
+                                         "give the integrand as device source (mci_set_integrand_source)", (long long)n, s.ndraw + s.ni * s.ncomp);
         if (n > p->cap_host) {
             if (p->d_hx) (void)hipFree(p->d_hx);
             if (p->d_hw) (void)hipFree(p->d_hw);
@@ -1198,6 +1201,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             hm_rows = solver == MCI_MCMC ? s.ncomp : nw;
         }
         const int64_t n = nblocks * hm_n > 0 ? nblocks * hm_n : 1;
+        // every record crosses PCIe and sits in pinned host memory: refuse launches whose records would not reasonably fit
+        if ((double)n * (double)(s.ndraw + nw + 1) * 8.0 > 8.0 * 1024 * 1024 * 1024)
+            return fail(MCI_ERR_INVALID, "a host measure over %lld records of %d doubles per launch (more than 8 GiB): lower neval, raise measurefreq "
+                                         "or give the measure as device source (mci_set_measure_source)", (long long)n, s.ndraw + nw);
         if (n > p->cap_hmeas) {
             if (p->d_mx) (void)hipFree(p->d_mx);
             if (p->d_mrelw) (void)hipFree(p->d_mrelw);

@@ -471,6 +471,17 @@ def test_python_closure_as_measure_under_the_chain_solvers_matches_device_source
     assert a.mean[0][0] == pytest.approx(0.75, abs=5 * a.stdev[0][0] + 1e-3) and a.mean[0][1] == pytest.approx(2.25, abs=5 * a.stdev[0][1] + 1e-3)
 
 
+def test_host_closures_refuse_launches_whose_records_do_not_fit():
+    """every record of a host closure crosses PCIe into pinned memory: a launch of more than 8 GiB of them is refused with a
+    message instead of exhausting the host"""
+    with pytest.raises(mci.MCIError) as e:
+        integrate("return x[0];", measure=lambda x, obs, w, c: None, dof=[[16]], solver="vegas", neval=2e8, niter=1, seed=1)
+    assert "8 GiB" in str(e.value)
+    with pytest.raises(mci.MCIError) as e:
+        integrate(lambda x, c: x[0], dof=[[16]], solver="vegas", neval=2e8, niter=1, seed=1)
+    assert "8 GiB" in str(e.value)
+
+
 def test_python_closure_as_integrand_matches_device_source():
     """a host closure through the batch-callback path (mci_set_integrand_host) sees the same draws as
     the device-source integrand, so the two runs agree to libm rounding; it reads like the reference's README call."""

@@ -262,6 +262,10 @@ int mci_sample_dump(mci_problem *prob, int32_t iteration, uint64_t seed, int64_t
 /* HIP-event durations (ms, oldest first) of the last `n` sampling-kernel launches, recorded on the
  * library's stream around every launch (ring of 512), and the last launch geometry */
 int mci_kernel_times_ms(mci_problem *prob, float *ms, int32_t n, int32_t *got, int32_t *workgroups, int32_t *threads);
+/* The events cost ~5.5 us of idle queue each -- a third of a launch-bound iteration (neval = 1e4), nothing next to millions of
+ * samples: mode -1 (default) records them for launches of >= 2^20 samples, 0 never, 1 always (mci_kernel_times_ms returns the
+ * recorded launches only). */
+int mci_set_kernel_timing(mci_problem *prob, int32_t mode);
 
 /* ---- host-side statistics of the path (pure functions, no GPU needed) ---- */
 void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64_t *nevalperblock,

@@ -79,6 +79,7 @@ SIGNATURES = [
     ("mci_set_launch", C.c_int, [_VP, C.c_int32, C.c_int32]),
     ("mci_problem_info", C.c_int, [_VP, c_int32_p, c_int32_p, C.POINTER(C.c_int64), c_int32_p, C.POINTER(C.c_int64)]),
     ("mci_get_histogram_copies", C.c_int, [_VP, c_int32_p]),
+    ("mci_set_kernel_timing", C.c_int, [_VP, C.c_int32]),
     ("mci_iteration_run", C.c_int, [_VP, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_double]),
     ("mci_iteration_reduce", C.c_int, [_VP]),
     ("mci_iteration_finish", C.c_int, [_VP, C.c_int32, C.c_int64, C.c_int32, C.c_double, c_double_p, c_double_p]),

@@ -186,6 +186,9 @@ struct mci_problem {
     // histogram copies of the :vegas sample kernel (mci_device.h hslot): what the placement rule picked (shape.hcopy is what the
     // compiled kernel uses: the rule's choice, or 1 when that kernel needs more than 128 VGPRs and two 512-thread workgroups
     // would not share a CU)
+    int kernel_timing = -1;       // mci_set_kernel_timing
+    bool time_this_launch = true;
+    bool ev_valid[512] = {};      // one per slot of the event ring (kEvRing)
     int hcopy_auto = 1;
     bool hcopy_plan = false; // the rule also picked the workgroup size (512 threads) for the :vegas kernel
     // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
@@ -564,6 +567,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             if (m == 3) { mode = 3; pair = 0; }
         }
         if (const char *e = getenv("MCI_TRAIN_SERIAL")) p->train_serial = atoi(e) != 0 ? 1 : 0;
+        if (const char *e = getenv("MCI_KERNEL_TIMING")) p->kernel_timing = atoi(e) < 0 ? -1 : atoi(e) > 0 ? 1 : 0; // (mci_set_kernel_timing)
         if (const char *e = getenv("MCI_PAIR_TABLE")) pair = (atoi(e) != 0 && mode <= 1 && fixed + e2 + (mode == 0 ? hb : 0) <= lim1) ? 1 : 0;
         // histogram tiles: contiguous leaves, each tile's bins fit the LDS left over
         s.leaf_tile.assign(p->leaves.size(), 0);
@@ -1245,8 +1249,12 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     hipFunction_t f = p->f_solver[solver];
     hipStream_t st = p->ctx->stream;
     const int slot = (int)(p->launches % mci_problem::kEvRing);
+    // HIP events around the sample launch (mci_kernel_times_ms): each record is a barrier packet with a signal, ~5.5 us of idle
+    // queue -- a third of a launch-bound iteration (neval = 1e4: 36 -> 25 us), nothing next to a launch of millions of samples.
+    // mci_set_kernel_timing: -1 (default) = launches of >= 2^20 samples, 0 = never, 1 = always
+    p->time_this_launch = p->kernel_timing > 0 || (p->kernel_timing < 0 && nblocks * nevalperblock >= ((int64_t)1 << 20));
     if (p->graph_mode) a.iter_ptr = p->d_loop; // captured launch: the iteration index is read on the device
-    else HIPCHK(hipEventRecord(p->evs[2 * slot], st));
+    else if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot], st));
     if (solver != MCI_VEGAS && s.host_integrand) {
         // The closure sits inside the Markov step (vegas_mc/updates.jl:67-75, mcmc/updates.jl:35-38): the chains of this launch advance
         // in lock step, one kernel launch per step; each hands the host the nc configurations to evaluate and takes their weights back
@@ -1329,7 +1337,8 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     if (split)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (!p->graph_mode) {
-        HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
+        if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
+        p->ev_valid[slot] = p->time_this_launch;
         p->launches += 1;
     }
     if (s.host_measure) {
@@ -1383,6 +1392,8 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     p->last_nblocks = (int)nblocks;
     // merge: block sums -> packed
     const int nb256 = (s.nbin + 255) / 256;
+    // (reading a few partial rows directly in the second stage instead -- no first-stage launch when an iteration is launch-bound --
+    // was measured at neval = 1e4: k_finish grows by what the launch took, 26 us per iteration either way)
     if (hist_lds && s.nbin > 0)
         hipLaunchKernelGGL(mci::k_hist_stage1, dim3(nb256, mci_problem::kGroups), dim3(256), 0, st, p->d_part_hist, (int)nrows, s.nbin,
                            (int)mci_problem::kGroups, p->d_stage1);
@@ -1878,17 +1889,26 @@ int mci_sample_dump(mci_problem *p, int32_t iteration, uint64_t seed, int64_t ne
     return MCI_OK;
 }
 
+int mci_set_kernel_timing(mci_problem *p, int32_t mode) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    p->kernel_timing = mode < 0 ? -1 : mode > 0 ? 1 : 0;
+    return MCI_OK;
+}
+
 int mci_kernel_times_ms(mci_problem *p, float *ms, int32_t n, int32_t *got, int32_t *wg, int32_t *threads) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     int64_t have = p->launches < mci_problem::kEvRing ? p->launches : mci_problem::kEvRing;
     if (have > n) have = n;
-    for (int64_t i = 0; i < have; ++i) { // oldest first
+    int64_t k = 0;
+    for (int64_t i = 0; i < have; ++i) { // oldest first; launches that ran without events (mci_set_kernel_timing) are skipped
         const int slot = (int)((p->launches - have + i) % mci_problem::kEvRing);
+        if (!p->ev_valid[slot]) continue;
         float t = 0.f;
         HIPCHK(hipEventElapsedTime(&t, p->evs[2 * slot], p->evs[2 * slot + 1]));
-        ms[i] = t;
+        ms[k++] = t;
     }
+    have = k;
     if (got) *got = (int32_t)have;
     if (wg) *wg = p->last_wg;
     if (threads) *threads = p->last_threads;

@@ -308,6 +308,10 @@ class Engine:
         check(lib().mci_kernel_code_object(self.p, _lib.SOLVERS[solver], buf, len(buf)))
         return buf.value.decode()
 
+    def set_kernel_timing(self, mode=-1):
+        """HIP events around every sample launch (kernel_times_ms): -1 launches of >= 2^20 samples (default), 0 never, 1 always"""
+        check(lib().mci_set_kernel_timing(self.p, int(mode)))
+
     def histogram_copies(self):
         """interleaved copies of the LDS histograms in the :vegas sample kernel (1 = the plain layout)"""
         n = C.c_int32()
@@ -424,7 +428,7 @@ class Engine:
 
     def last_kernel_ms(self):
         ms, wg, th = self.kernel_times_ms(1)
-        return float(ms[-1]), wg, th
+        return (float(ms[-1]) if len(ms) else float("nan")), wg, th   # (nan: the launch ran without events, set_kernel_timing)
 
     # ---- state ---------------------------------------------------------------------------------
     def grid(self, leaf):

@@ -471,6 +471,22 @@ def test_python_closure_as_measure_under_the_chain_solvers_matches_device_source
     assert a.mean[0][0] == pytest.approx(0.75, abs=5 * a.stdev[0][0] + 1e-3) and a.mean[0][1] == pytest.approx(2.25, abs=5 * a.stdev[0][1] + 1e-3)
 
 
+def test_kernel_timing_events_follow_the_launch_size():
+    """the HIP events around a sample launch (mci_kernel_times_ms) cost ~11 us per iteration: launches below 2^20 samples run
+    without them unless asked (mci_set_kernel_timing)"""
+    cfg = mci.Configuration(var=Continuous(0.0, 1.0), dof=[[2]])
+    eng = mci.Engine(cfg, mci.catalog.x2y2())
+    eng.integrate("vegas", neval=10**4, niter=4, block=16, seed=1)
+    assert len(eng.kernel_times_ms(4)[0]) == 0
+    eng.set_kernel_timing(1)
+    eng.integrate("vegas", neval=10**4, niter=4, block=16, seed=1, first_iteration=4)
+    ms = eng.kernel_times_ms(4)[0]
+    assert len(ms) == 4 and (ms > 0).all() and (ms < 1.0).all()
+    eng.set_kernel_timing(-1)
+    eng.integrate("vegas", neval=2 * 10**6, niter=3, block=16, seed=1, first_iteration=8)
+    assert len(eng.kernel_times_ms(3)[0]) == 3
+
+
 def test_host_closures_refuse_launches_whose_records_do_not_fit():
     """every record of a host closure crosses PCIe into pinned memory: a launch of more than 8 GiB of them is refused with a
     message instead of exhausting the host"""

@@ -3,6 +3,7 @@
 import math
 import sys
 import os
+os.environ.setdefault("MCI_KERNEL_TIMING", "1")   # kernel durations for every launch, the small ones included
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

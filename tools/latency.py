@@ -19,6 +19,8 @@ if __name__ == "__main__":
             t0 = time.perf_counter()
             r = eng.integrate(solver, neval=neval, niter=50, block=16, seed=1, first_iteration=3)
             dt = time.perf_counter() - t0
+            eng.set_kernel_timing(1)   # the kernel's own duration: a second run with the HIP events on (they cost ~11 us per iteration)
+            eng.integrate(solver, neval=neval, niter=50, block=16, seed=1, first_iteration=53)
             ms, wg, th = eng.kernel_times_ms(50)
             print("%-8s neval=%-9d  %8.1f us/iteration (library clock %8.1f)  kernel %8.1f us  wg=%d  -> %8.1f Msamples/s   mean %.6f +- %.1e" % (
                 solver, neval, dt / 50 * 1e6, r["seconds"] / 50 * 1e6, float(np.median(ms)) * 1e3, wg, neval / (dt / 50) / 1e6, r["mean"][0], r["stdev"][0]), flush=True)

@@ -1467,6 +1467,11 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
         a.iter_log_base = p->d_iterlog;
     }
     const size_t sm = (size_t)mci::train_lds_doubles(maxn) * sizeof(double); // d | sg | wa (train_leaf)
+    // two bins per thread for the default 999-bin grids: the rescale (a pow and a log per bin) and the second merge stage are the
+    // latency chains of a lone workgroup; with four bins per thread (256 threads) a launch-bound iteration took 24.7 us, with two
+    // 22.2, with one (1024 threads) 22.3 (tools/latency.py, neval = 1e4)
+    static const int tt_env = getenv("MCI_TRAIN_THREADS") ? atoi(getenv("MCI_TRAIN_THREADS")) : 0; // diagnostic override
+    const unsigned tt = (tt_env >= 64 && tt_env <= 1024 && tt_env % 64 == 0) ? (unsigned)tt_env : (maxn > 1024 ? 1024u : maxn > 256 ? 512u : 256u);
     if (sm + (size_t)maxn * sizeof(double) > 64 * 1024 && !p->train_lds_raised) { // grids of more than ~1600 increments
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_train, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
@@ -1474,9 +1479,9 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     }
     if (p->merge_pending) { // nothing looked at `packed` since the sample batch: merge + refine in one launch
         p->merge_pending = false;
-        hipLaunchKernelGGL(mci::k_finish, dim3(s.nleaf + 1 + (2 * p->npa + 3) / 4), dim3(256), sm + (size_t)maxn * sizeof(double), p->ctx->stream, p->merge, a);
+        hipLaunchKernelGGL(mci::k_finish, dim3(s.nleaf + 1 + (2 * p->npa + 3) / 4), dim3(tt), sm + (size_t)maxn * sizeof(double), p->ctx->stream, p->merge, a);
     } else {
-        hipLaunchKernelGGL(mci::k_train, dim3(s.nleaf + 1), dim3(256), sm, p->ctx->stream, a);
+        hipLaunchKernelGGL(mci::k_train, dim3(s.nleaf + 1), dim3(tt), sm, p->ctx->stream, a);
     }
     HIPCHK(hipGetLastError());
     return MCI_OK;

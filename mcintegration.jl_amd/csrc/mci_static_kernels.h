@@ -77,7 +77,7 @@ struct MergeArgs {
 __device__ inline int merge_pa_blocks(const MergeArgs &m) { return (2 * m.npa + 3) / 4; }
 __device__ inline void merge_pa(const MergeArgs &m, int blk) {
     const int lane = threadIdx.x & 63, e = blk * 4 + (int)(threadIdx.x >> 6);
-    if (e >= 2 * m.npa) return;
+    if (e >= 2 * m.npa || (threadIdx.x >> 6) >= 4) return; // (four entries per workgroup whatever its size)
     double s = 0.0;
     if (m.part_pa)
         for (int r = lane; r < m.nrows; r += 64) s += m.part_pa[(size_t)r * (2 * m.npa) + e];
@@ -573,7 +573,7 @@ __device__ inline void iteration_bookkeeping(const TrainArgs &a) {
 }
 
 // One workgroup per leaf: Dist.train! then clearStatistics!; workgroup `nleaf`: bookkeeping.
-__global__ void __launch_bounds__(256) k_train(TrainArgs a) {
+__global__ void __launch_bounds__(1024) k_train(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double ps[256]; // block_prefix scratch
     __shared__ int bad;
@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(256) k_train(TrainArgs a) {
 // Single-rank iterations need no all-reduce between the merge and the refinement: k_finalize and k_train as ONE
 // launch.  Workgroup l < nleaf merges its leaf's histogram (second stage) into LDS and `packed`, then trains from
 // the LDS copy; workgroup nleaf merges the statistics head, then does the bookkeeping.
-__global__ void __launch_bounds__(256) k_finish(MergeArgs m, TrainArgs a) {
+__global__ void __launch_bounds__(1024) k_finish(MergeArgs m, TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[]; // [train_lds_doubles(maxn)] train scratch | [maxn] merged histogram
     __shared__ double ps[256];
     __shared__ int bad;

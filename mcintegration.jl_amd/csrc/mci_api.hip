@@ -1471,7 +1471,7 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     // latency chains of a lone workgroup; with four bins per thread (256 threads) a launch-bound iteration took 24.7 us, with two
     // 22.2, with one (1024 threads) 22.3 (tools/latency.py, neval = 1e4)
     static const int tt_env = getenv("MCI_TRAIN_THREADS") ? atoi(getenv("MCI_TRAIN_THREADS")) : 0; // diagnostic override
-    const unsigned tt = (tt_env >= 64 && tt_env <= 1024 && tt_env % 64 == 0) ? (unsigned)tt_env : (maxn > 1024 ? 1024u : maxn > 256 ? 512u : 256u);
+    const unsigned tt = (tt_env >= 64 && tt_env <= 1024 && tt_env % 64 == 0) ? (unsigned)tt_env : (maxn > 256 ? 512u : 256u);
     if (sm + (size_t)maxn * sizeof(double) > 64 * 1024 && !p->train_lds_raised) { // grids of more than ~1600 increments
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_train, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));

@@ -412,6 +412,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
         // rescale  common.jl:67-82
         if (N > 1) {
             const double s = sum16(d, N); // :72
+            __syncthreads(); // every 16-lane group reads ALL of d[] for its total: nobody overwrites d[] before the last group is through
             for (int i = tid; i < N; i += T) {
                 double v = d[i] / s;
                 if (v > 0 && v <= 0.99999999) v = pow(-(1 - v) / log(v), L.alpha);

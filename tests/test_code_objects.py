@@ -94,6 +94,38 @@ def test_c2_sample_loop_mix():
     assert 800 < cyc["valu"] < 1100 and cyc["lds"] == pytest.approx(16 * 21.6 + 16 * 41.0)
 
 
+def test_histogram_copies_follow_the_placement_rule_and_the_register_budget():
+    """mci_device.h hslot: 8 interleaved histogram copies and two 512-thread workgroups per CU for the 16-D Gaussian (80.8 KB of LDS);
+    the interleaved-copy row of the issue-cost table prices its ds_add_f64; a 1-D integrand keeps the plain layout (nothing to gain),
+    and so does a kernel that needs more than 128 VGPRs (two 512-thread workgroups would not share a CU)"""
+    c2 = [b for b in BASELINE if b[0] == "c2"][0]
+    eng = mci.Engine(c2[1](), c2[2](), device=-1)
+    assert eng.histogram_copies() == 8
+    eng.compile("vegas")
+    assert eng.histogram_copies() == 8
+    res = isa_mix.resources(eng.code_object("vegas"))["mci_vegas_batch"]
+    assert res["max_threads"] == 512 and res["vgpr"] <= 128 and res["scratch"] == 0
+    mix = isa_mix.loop_mix(eng.code_object("vegas"), "mci_vegas_batch")
+    costs = {"ds_read_b128 (random": 21.6, "ds_add_f64 (random bins, 999-bin table)": 41.0, "ds_add_f64 (random bins, 8 interleaved copies)": 26.9}
+    assert isa_mix.issue_cycles(mix, costs, default_valu=1.8, hist_copies=8)["lds"] == pytest.approx(16 * 21.6 + 16 * 26.9)
+    assert isa_mix.issue_cycles(mix, costs, default_valu=1.8)["lds"] == pytest.approx(16 * 21.6 + 16 * 41.0)
+    eng.close()
+    one = mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]]), mci.Integrand("w[0] = log(x[0]) / sqrt(x[0]);"), device=-1)
+    assert one.histogram_copies() == 1
+    one.close()
+    # an integrand that keeps every draw and every intermediate alive: more than 128 VGPRs -> the plain layout, 256 threads
+    body = """double m = 0.0; for (int i = 0; i < 16; ++i) m += x[i]; m *= 0.0625;
+              double y[16], q = 0.0; for (int i = 0; i < 16; ++i) { y[i] = sin(x[i] - m) * cos(x[(i + 7) % 16] + m); q += y[i]; }
+              double p = 1.0; for (int i = 0; i < 16; ++i) p *= 1.0 + (y[i] - q) * exp(x[15 - i] - y[(i + 5) % 16]); w[0] = p;"""
+    fat = mci.Engine(c2[1](), mci.Integrand(body), device=-1)
+    assert fat.histogram_copies() == 8           # the rule's choice before the kernel exists
+    fat.compile("vegas")
+    res = isa_mix.resources(fat.code_object("vegas"))["mci_vegas_batch"]
+    assert (fat.histogram_copies() == 1 and res["max_threads"] == 256) if res["vgpr"] > 128 else fat.histogram_copies() == 8, res
+    assert res["vgpr"] > 128, "the test integrand no longer exceeds the register budget: make it fatter"
+    fat.close()
+
+
 def test_branch_targets_and_classes():
     assert isa_mix._branch_target(0x100, "s_cbranch_execnz", "65521") == 0x100 + 4 - 4 * 15
     assert isa_mix._branch_target(0x100, "s_branch", "3") == 0x110

@@ -189,7 +189,7 @@ struct mci_problem {
     int kernel_timing = -1;       // mci_set_kernel_timing
     bool time_this_launch = true;
     bool ev_valid[512] = {};      // one per slot of the event ring (kEvRing)
-    int hcopy_auto = 1;
+    int hcopy_auto = 1, hcopy_rule = 1; // in force | what the placement rule picked at create
     bool hcopy_plan = false; // the rule also picked the workgroup size (512 threads) for the :vegas kernel
     // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
     // launch before it is long enough to hide its ~35 us per iteration (>= kSerialWalkSamples samples or chain steps on this
@@ -657,7 +657,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
                 while (hc > 1 && (!hist_lds || s.ntile != 1 || (hc & (hc - 1)) || p->lds_bytes + one * (hc - 1) > lim1)) hc >>= 1;
                 if (hc < 1) hc = 1;
             }
-            s.hcopy = p->hcopy_auto = hc;
+            s.hcopy = p->hcopy_auto = p->hcopy_rule = hc;
         }
         const int64_t hcopy_bytes = (int64_t)s.htile * 8 * (s.hcopy - 1);
         // one tile, grids gathered from L2 (10 .. 18 independent grids): the LDS left next to the histogram caches the edges of the
@@ -869,6 +869,8 @@ int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
             p->vegas_plan_a = false; // an explicit size: the vegas kernel follows it
             p->hcopy_plan = false;
             p->threads_vegas = 0;
+            // histogram copies are sized for two 512-thread workgroups per CU: smaller workgroups would leave the CU half empty
+            p->hcopy_auto = threads >= 512 || getenv("MCI_HIST_COPIES") ? p->hcopy_rule : 1;
             drop_modules(p);
         }
     }

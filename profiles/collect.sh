@@ -5,9 +5,10 @@
 #   3. rocprofv3 --pmc WRITE_SIZE          (separate pass)           -> gpurun_out/prof_write_<tag>/
 #   4. rocprofv3 --pmc SQ counters         (VALU/LDS utilisation)    -> gpurun_out/prof_sq_<tag>/
 # Counter passes never combine --pmc with trace domains other than --kernel-trace (gpurun rule).
-#   usage: profiles/collect.sh <tag> [bench|c4] [steps]
+#   usage: profiles/collect.sh <tag> [bench|c4|c3|c5] [steps]
 #     bench: the default bench.py workload (C2), kernel mci_vegas_batch          -> profiles/<tag>_kernel_stats.txt, <tag>_pmc_traffic.json
 #     c4   : BASELINE configs[3] on one GPU (tools/c4_prof.py), mci_vegas_batch + mci_vegas_tiles
+#     c3   : BASELINE configs[2] (tools/c3mc_prof.py), mci_vegasmc_chains;   c5: BASELINE configs[4] (tools/mcmc_prof.py 0), mci_mcmc_chains
 set -u
 TAG=${1:-r02}
 WHAT=${2:-bench}
@@ -18,6 +19,12 @@ mkdir -p $OUT
 if [ "$WHAT" = "c4" ]; then
   CMD="python tools/c4_prof.py 32"
   KERNELS="mci_vegas_batch,mci_vegas_tiles"
+elif [ "$WHAT" = "c3" ]; then        # BASELINE configs[2]: example/bubble.jl under :vegasmc, 1e8 steps per iteration
+  CMD="python tools/c3mc_prof.py"
+  KERNELS="mci_vegasmc_chains"
+elif [ "$WHAT" = "c5" ]; then        # BASELINE configs[4]: 4 integrals on a 12-D pool under :mcmc, automatic chain length
+  CMD="python tools/mcmc_prof.py 0"
+  KERNELS="mci_mcmc_chains"
 else
   CMD="python bench.py --steps $STEPS --warmup 5 --passes 3 --no-cpu-baseline"
   KERNELS="mci_vegas_batch"

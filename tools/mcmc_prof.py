@@ -7,4 +7,4 @@ nchain = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]]), mci.catalog.nested_gauss())
 eng.integrate("mcmc", neval=10**8, niter=3, block=16, seed=1, nchain=nchain)
 r = eng.integrate("mcmc", neval=10**8, niter=4, block=16, seed=1, first_iteration=3, nchain=nchain)
-print("steps per chain", 10**8 // 16 // nchain, "s/iter", r["seconds"] / 4)
+print("chains per block", nchain or "automatic", "s/iter", r["seconds"] / 4)

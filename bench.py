@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rng-bits", type=int, default=52, choices=(52, 32),
                     help="52 (default): the faithful stream, 52 random mantissa bits per draw like rand(Float64); 32: the opt-in cheaper stream (mci_set_rng_bits)")
+    ap.add_argument("--rng-rounds", type=int, default=10, choices=(10, 7),
+                    help="10 (default): Philox4x32-10; 7: the opt-in cheaper generator (mci_set_rng_rounds), pinned on the Random123 vectors")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -279,7 +281,7 @@ def main():
 
     # ---- warm-up: JIT/cache load + W training iterations from the uniform grid (untimed) ----
     res_w = mci.integrate(f, config=cfg, solver="vegas", neval=neval, niter=max(a.warmup, 1), block=block, comm=comm,
-                          device=local_rank, adapt=True, engine_factory=factory, rng_bits=a.rng_bits)
+                          device=local_rank, adapt=True, engine_factory=factory, rng_bits=a.rng_bits, rng_rounds=a.rng_rounds)
     eng = cfg._engine
     per = block // n_gpus
     lo, hi = per * rank, per * (rank + 1)
@@ -361,7 +363,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 16-D unit Gaussian on [-sqrt(50),sqrt(50)]^16, shared-pool "
                                    "Continuous (1 grid, 999 bins), :vegas, neval=%.0e per GPU per iteration, block=16 per GPU" % neval_gpu,
-                       "neval_per_iteration": neval, "block": block, "rng_bits": a.rng_bits},
+                       "neval_per_iteration": neval, "block": block, "rng_bits": a.rng_bits, "rng_rounds": a.rng_rounds},
             "timing": {"passes": len(pass_dt), "ms_per_step_per_pass": [round(x / a.steps * 1e3, 4) for x in pass_dt[:8]] + (["..."] if len(pass_dt) > 8 else []),
                        "ms_per_step_max": round(max(pass_dt) / a.steps * 1e3, 4), "timed_seconds": round(sum(pass_dt), 3),
                        "ms_per_step_min": round(min(pass_dt) / a.steps * 1e3, 4), "value_is": "median pass"},

@@ -246,6 +246,11 @@ int mci_load_state(mci_problem *prob, const char *path);
  * mantissa bits, y on a 2^-32 lattice), four draws per block -- half the generator work per sample.  Same counter scheme otherwise
  * (draw k -> block k >> 2, word k & 3); the chain solvers are not affected.  Mirrored in the oracle (mcio_set_rng_bits). */
 int mci_set_rng_bits(mci_problem *prob, int32_t bits);
+/* Opt-in cheaper generator for EVERY stream of the problem (all three solvers): rounds = 10 (default) is Philox4x32-10, the
+ * Random123 default; rounds = 7 is Philox4x32-7, the fewest rounds its authors found to pass BigCrush ("crush-resistant", Salmon et
+ * al., SC'11) -- 30 % less generator work, a different (equally valid) stream.  Same keys and counters; pinned on the Random123
+ * known-answer vectors for 7 rounds (tests/golden) and mirrored in the oracle (mcio_set_rng_rounds). */
+int mci_set_rng_rounds(mci_problem *prob, int32_t rounds);
 /* How train!(Continuous) walks the smoothed histogram to place the new grid points (variable.jl:227-234):
  *   1  the reference's serial recurrence, operation for operation (the chain on one lane in hand-written ISA, +35 us per iteration at ninc = 1000 on MI355X);
  *   0  the same walk as a fixed-order prefix scan + one bisection per grid point (18 us; agrees with the recurrence to 1e-12 of

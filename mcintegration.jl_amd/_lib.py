@@ -101,6 +101,7 @@ SIGNATURES = [
     ("mci_load_state", C.c_int, [_VP, C.c_char_p]),
     ("mci_set_train_walk", C.c_int, [_VP, C.c_int32]),
     ("mci_set_rng_bits", C.c_int, [_VP, C.c_int32]),
+    ("mci_set_rng_rounds", C.c_int, [_VP, C.c_int32]),
     ("mci_train", C.c_int, [_VP]),
     ("mci_sample_dump", C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
     ("mci_kernel_times_ms", C.c_int, [_VP, C.POINTER(C.c_float), C.c_int32, c_int32_p, c_int32_p, c_int32_p]),

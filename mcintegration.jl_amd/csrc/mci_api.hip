@@ -202,6 +202,7 @@ struct mci_problem {
     std::vector<hipEvent_t> evs; // ring of (start, stop) pairs around the sampling kernel, one pair per launch
     int64_t launches = 0;
     static const int kEvRing = 512;
+    static_assert(sizeof(ev_valid) / sizeof(ev_valid[0]) == kEvRing, "one validity flag per event-ring slot");
     int last_wg = 0, last_threads = 0, last_nblocks = 0;
     int log_row = 0;
     static const int kGroups = mci::kMergeGroups;
@@ -964,6 +965,16 @@ int mci_set_rng_bits(mci_problem *p, int32_t bits) {
     if (bits != 52 && bits != 32) return fail(MCI_ERR_INVALID, "rng bits must be 52 (default: the resolution of rand(Float64)) or 32");
     if (p->shape.rng_bits != bits) {
         p->shape.rng_bits = bits;
+        drop_modules(p);
+    }
+    return MCI_OK;
+}
+
+int mci_set_rng_rounds(mci_problem *p, int32_t rounds) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (rounds != 10 && rounds != 7) return fail(MCI_ERR_INVALID, "Philox4x32 rounds must be 10 (default) or 7 (the fewest that pass BigCrush)");
+    if (p->shape.rng_rounds != rounds) {
+        p->shape.rng_rounds = rounds;
         drop_modules(p);
     }
     return MCI_OK;

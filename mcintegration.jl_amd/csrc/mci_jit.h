@@ -41,6 +41,7 @@ struct ProblemShape {
     // vegas with NTILE > 1 ("split-all"): the sample pass keeps NO histogram, caches the edges of the leading leaves in the
     // LDS the histogram tile would take (leaf_ecoff >= 0: offset in that cache, doubles), and every tile is replayed
     int split_all = 0, ec_doubles = 0;
+    int rng_rounds = 10; // Philox4x32 rounds of every stream: 10 (default) or 7 (mci_set_rng_rounds)
     int rng_bits = 52;  // :vegas sample stream: 52 random mantissa bits per draw (two draws per Philox block) or 32 (four per block)
     int l1_phase = 0; // :vegas, grids gathered from global memory: samples per lane and trip of the dimension-major gather phase (0 = off)
     std::vector<int> leaf_ecoff;
@@ -89,6 +90,7 @@ static std::string dbl_arr(const std::vector<double> &v) {
 // solver: 0 vegas (+ sample dump), 1 vegasmc, 2 mcmc -- one code object per solver, built on first use
 inline std::string generate_source(const ProblemShape &s, int solver) {
     std::ostringstream o;
+    if (s.rng_rounds != 10) o << "#define MCI_PHILOX_ROUNDS " << s.rng_rounds << "\n"; // opt-in cheaper stream (mci_set_rng_rounds)
     o << "#include \"mci_device.h\"\n";
     o << "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n";
     o << "#ifdef MCI_WAVES\n#define MCI_OCC __attribute__((amdgpu_waves_per_eu(MCI_WAVES, MCI_WAVES)))\n#else\n#define MCI_OCC\n#endif\n";

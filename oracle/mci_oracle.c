@@ -31,10 +31,12 @@
 #define PHILOX_W0 0x9E3779B9u
 #define PHILOX_W1 0xBB67AE85u
 
-void mcio_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+/* Philox4x32-R (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): R = 10 is the Random123 default, R = 7 the
+ * fewest rounds its authors found crush-resistant -- the opt-in cheaper stream (mci_set_rng_rounds) */
+void mcio_philox4x32_r(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
     uint32_t k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
         uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -47,6 +49,12 @@ void mcio_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+/* rounds of every stream below: process-wide like the library's per-problem setting is problem-wide (the oracle runs one
+ * configuration at a time); mirror of mci_set_rng_rounds */
+static int g_rng_rounds = 10;
+void mcio_set_rng_rounds(int rounds) { g_rng_rounds = rounds == 7 ? 7 : 10; }
+int mcio_get_rng_rounds(void) { return g_rng_rounds; }
+void mcio_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { mcio_philox4x32_r(ctr, key, out, 10); }
 
 /* Stream contract shared with the HIP path (DESIGN.md "RNG streams"):
  *   key = (seed lo, seed hi); ctr = (index lo, index hi, k>>1, stream)
@@ -56,7 +64,7 @@ double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k) 
     uint32_t ctr[4] = {(uint32_t)index, (uint32_t)(index >> 32), k >> 1, stream};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t o[4];
-    mcio_philox4x32_10(ctr, key, o);
+    mcio_philox4x32_r(ctr, key, o, g_rng_rounds);
     uint32_t a = o[2 * (k & 1)], b = o[2 * (k & 1) + 1];
     uint64_t bits = ((((uint64_t)b << 32) | a) >> 12) | 0x3FF0000000000000ull; /* [1,2) */
     double d;
@@ -70,7 +78,7 @@ double mcio_uniform32(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k
     uint32_t ctr[4] = {(uint32_t)index, (uint32_t)(index >> 32), k >> 2, stream};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t o[4];
-    mcio_philox4x32_10(ctr, key, o);
+    mcio_philox4x32_r(ctr, key, o, g_rng_rounds);
     uint64_t bits = ((uint64_t)o[k & 3] << 20) | 0x3FF0000000000000ull; /* [1,2) */
     double d;
     memcpy(&d, &bits, sizeof d);

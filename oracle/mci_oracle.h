@@ -125,6 +125,9 @@ typedef struct {
 
 /* ---- RNG ---- */
 void mcio_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void mcio_philox4x32_r(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds);
+void mcio_set_rng_rounds(int rounds); /* 10 (default) | 7: every stream of this process, mirror of mci_set_rng_rounds */
+int mcio_get_rng_rounds(void);
 /* uniform in [0,1) for (seed, stream, index, draw k) -- the stream contract shared with the HIP path */
 double mcio_uniform(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k);
 double mcio_uniform32(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k); /* the opt-in 32-bit stream of :vegas */

@@ -68,6 +68,8 @@ def lib():
     build()
     L = C.CDLL(_SO)
     L.mcio_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.mcio_philox4x32_r.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]
+    L.mcio_set_rng_rounds.argtypes = [C.c_int]
     L.mcio_uniform.restype = C.c_double
     L.mcio_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]
     L.mcio_uniform32.restype = C.c_double
@@ -152,12 +154,18 @@ def _ip(a):
     return a.ctypes.data_as(c_int_p)
 
 
-def philox(ctr, key):
+def philox(ctr, key, rounds=10):
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)
     o = (C.c_uint32 * 4)()
-    lib().mcio_philox4x32_10(c, k, o)
+    lib().mcio_philox4x32_r(c, k, o, int(rounds))
     return [int(v) for v in o]
+
+
+def set_rng_rounds(rounds):
+    """Philox4x32 rounds of every stream of this process: 10 (default) or 7 (mirror of mci_set_rng_rounds)"""
+    assert rounds in (10, 7)
+    lib().mcio_set_rng_rounds(int(rounds))
 
 
 def uniform(seed, stream, index, k, bits=52):

@@ -169,6 +169,13 @@ def main():
         dict(ctr=[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], key=[0xa4093822, 0x299f31d0],
              out=[0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
     ]
+    # Philox4x32-7 KAT (Random123 kat_vectors, the `philox4x32 7` lines): the opt-in cheaper stream, mci_set_rng_rounds(7)
+    out["philox4x32_7"] = [
+        dict(ctr=[0, 0, 0, 0], key=[0, 0], out=[0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+        dict(ctr=[0xffffffff] * 4, key=[0xffffffff] * 2, out=[0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+        dict(ctr=[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], key=[0xa4093822, 0x299f31d0],
+             out=[0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]),
+    ]
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)

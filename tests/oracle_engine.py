@@ -22,6 +22,8 @@ class OracleEngine:
         self.ocfg = O.Config(leaves, config.dof, obs_nbin=config.obs_nbin, obs_bin_draw=config.obs_bin_draw(measure))
         if kw.get("rng_bits"):
             self.ocfg.set_rng_bits(kw["rng_bits"])
+        if kw.get("rng_rounds"):
+            O.set_rng_rounds(kw["rng_rounds"])   # (process-wide in the oracle)
         if isinstance(integrand.name, int):
             self.fn = integrand.name
         else:

@@ -199,6 +199,23 @@ def test_32_bit_stream_passes_the_reference_battery():
     assert res.stdev[0] < 2e-5
 
 
+def test_seven_round_philox_stream_passes_the_reference_battery():
+    """rng_rounds=7 (opt-in, every solver): the reference's 7-sigma targets (test/montecarlo.jl:262-387) and the 16-D Gaussian at 1e9
+    samples on Philox4x32-7"""
+    for alg, neval in (("vegas", 200000), ("vegasmc", 100000), ("mcmc", 200000)):
+        res = integrate("return (x[0]*x[0] + x[1]*x[1] < 1.0) ? 1.0 : 0.0;", var=Continuous(0.0, 1.0), dof=[[2]], neval=neval, solver=alg, seed=201, rng_rounds=7)
+        check(res, PI / 4.0)
+        res = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), dof=[[2], [3]], neval=neval, solver=alg, seed=202, rng_rounds=7)
+        check(res, [PI / 4.0, 4.0 * PI / 3.0 / 8])
+        res = integrate("return log(x[0]) / sqrt(x[0]);", solver=alg, neval=neval, seed=203, rng_rounds=7)
+        check(res, -4.0)
+        res = integrate("return x[0];", var=Discrete(1, 3, adapt=True), dof=[[1]], neval=neval, solver=alg, seed=204, rng_rounds=7)
+        check(res, 6.0)
+    L = math.sqrt(50.0)
+    res = integrate(mci.catalog.gaussian(16), var=Continuous(-L, L), dof=[[16]], neval=1e8, niter=10, solver="vegas", seed=205, rng_rounds=7)
+    assert abs(res.mean[0] - math.erf(5.0) ** 16) < 5.0 * res.stdev[0] and res.stdev[0] < 2e-5
+
+
 def test_trained_variables_carry_over_into_a_new_configuration():
     """`integrate(...; var = (res.config.var[1], ...))` (docs/src/index.md:129): a variable object keeps what train! taught it, so a NEW
     Configuration built from it -- here even for another integrand and another dof -- starts from the trained grid and distribution, and

@@ -161,6 +161,61 @@ def test_vegas_32_bit_stream_matches_oracle(oracle, name):
     np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6, atol=1e-300)
 
 
+@pytest.mark.parametrize("name", ["c2_gauss16_shared_pool", "c5_nested_gauss", "bubble"])
+def test_seven_round_philox_stream_matches_oracle(oracle, name):
+    """the opt-in cheaper generator (mci_set_rng_rounds(7): Philox4x32-7 for every stream, pinned on the Random123 vectors in
+    tests/golden): draws bit-exact, one iteration of each solver at the usual tolerances, a whole :vegas run on the oracle's
+    trajectory, and a stream that differs from the ten-round one"""
+    c, cfg, eng, ocfg = make(name, oracle)
+    eng.set_rng_rounds(7)
+    oracle.set_rng_rounds(7)
+    try:
+        x, jac, w = eng.sample_dump(512, nevalperblock=3000, block_index=2, iteration=1, seed=SEED)
+        oc = ocfg.c
+        for s in range(0, 512, 37):
+            gs = 2 * 3000 + s
+            k = 0
+            xo = np.zeros(oc.ndraw)
+            for vi in range(oc.npool):
+                nl = oc.pool_nleaf[vi]
+                for idx in range(1, oc.maxdof[vi] + 1):
+                    us = [oracle.uniform(SEED, 1 * 8 + 0, gs, k + l) for l in range(nl)]
+                    ocfg.pool_create(vi, idx, us)
+                    for l in range(nl):
+                        xo[k + l] = ocfg.pool_data(oc.pool_leaf0[vi] + l)[idx - 1]
+                    k += nl
+            assert np.array_equal(x[s], xo), (name, s)
+        block, npb = 8, 4000
+        got = eng.iteration("vegas", npb, 0, block, iteration=0, seed=SEED)
+        ref = ocfg.iteration(oracle.VEGAS, c["oname"], c["ud"], npb, 0, block, 0, SEED)
+        gs_, gh = hist_split(got, eng.nobs, cfg.N)
+        rs, rh = hist_split(ref, eng.nobs, cfg.N)
+        np.testing.assert_allclose(gs_, rs, rtol=1e-11, atol=1e-300)
+        np.testing.assert_allclose(gh, rh, rtol=1e-9)
+        plain = mci.Engine(mci.Configuration(var=c["var"](), dof=c["dof"], obs=c.get("obs"), seed=SEED), c["f"], measure=c.get("measure"))
+        assert not np.allclose(plain.iteration("vegas", npb, 0, block, iteration=0, seed=SEED)[:eng.nobs], got[:eng.nobs], rtol=1e-9)   # another stream
+        for solver, osolver, kw in (("vegasmc", oracle.VEGASMC, dict(nchain=64)), ("mcmc", oracle.MCMC, dict(nchain=16))):
+            c2, cfg2, eng2, ocfg2 = make(name, oracle)
+            eng2.set_rng_rounds(7)
+            if solver == "mcmc":
+                ocfg2.set_thermal_ratio(0.1)
+                kw2 = dict(thermal_ratio=0.1, **kw)
+            else:
+                kw2 = kw
+            got = eng2.iteration(solver, 3200, 0, 4, iteration=1, seed=SEED, **kw2)
+            ref = ocfg2.iteration(osolver, c["oname"], c["ud"], 3200, 0, 4, 1, SEED, **kw)
+            gs_, gh = hist_split(got, eng2.nobs, cfg2.N)
+            rs, rh = hist_split(ref, eng2.nobs, cfg2.N)
+            np.testing.assert_allclose(gs_, rs, rtol=1e-9, atol=1e-300, err_msg=solver)
+            np.testing.assert_allclose(gh, rh, rtol=1e-8, err_msg=solver)
+        eng.set_train_walk("serial")
+        r = eng.integrate("vegas", neval=40000, niter=5, block=16, seed=SEED)
+        o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=40000, niter=5, block=16, seed=SEED)
+        np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6, atol=1e-300)
+    finally:
+        oracle.set_rng_rounds(10)
+
+
 @pytest.mark.parametrize("threads", [None, 512], ids=["plan_a_768", "plan_b_512"])
 def test_c4_32_bit_stream_with_gather_phase_matches_oracle(oracle, threads):
     """32 grids (split-all pass with the dimension-major gather phase, 768 or 512 threads) on the 32-bit stream: 8 Philox blocks per

@@ -17,6 +17,26 @@ def test_philox_kat(oracle, golden):
         assert oracle.philox(v["ctr"], v["key"]) == v["out"]
 
 
+def test_philox_7_round_kat_and_stream(oracle, golden):
+    """the opt-in cheaper generator (mci_set_rng_rounds(7)): Philox4x32-7 on the Random123 known-answer vectors, and every stream of
+    the oracle switching to it (same counters, keys and bit selection)"""
+    for v in golden["philox4x32_7"]:
+        assert oracle.philox(v["ctr"], v["key"], rounds=7) == v["out"]
+    seed, stream, idx = 0x1234567890ABCDEF, 17, (5 << 32) | 9
+    ten = [oracle.uniform(seed, stream, idx, k) for k in range(6)]
+    oracle.set_rng_rounds(7)
+    try:
+        for k in range(6):
+            o = oracle.philox([idx & 0xFFFFFFFF, idx >> 32, k >> 1, stream], [seed & 0xFFFFFFFF, seed >> 32], rounds=7)
+            a, b = o[2 * (k & 1)], o[2 * (k & 1) + 1]
+            assert oracle.uniform(seed, stream, idx, k) == (((b << 32) | a) >> 12) * 2.0 ** -52
+            o4 = oracle.philox([idx & 0xFFFFFFFF, idx >> 32, k >> 2, stream], [seed & 0xFFFFFFFF, seed >> 32], rounds=7)
+            assert oracle.uniform(seed, stream, idx, k, bits=32) == o4[k & 3] * 2.0 ** -32
+    finally:
+        oracle.set_rng_rounds(10)
+    assert [oracle.uniform(seed, stream, idx, k) for k in range(6)] == ten
+
+
 def test_uniform_stream_contract(oracle):
     # draw k uses words (2*(k&1), 2*(k&1)+1) of Philox(ctr=(idx lo, idx hi, k>>1, stream), key=seed)
     seed, stream, idx = 0x1234567890ABCDEF, 17, (5 << 32) | 9

@@ -2,7 +2,7 @@
 """Every catalog integrand with a known answer x the three solvers x several seeds, automatic chain counts:
 5 training + 10 production iterations per run; per (integrand, solver) the pooled deviation from the exact value in units
 of the pooled error, the largest single-run deviation, and the ratio of the seed scatter to the reported error
-(1 = the error bars are honest).   usage: python tools/validation_matrix.py [nseeds] [neval]"""
+(1 = the error bars are honest).   usage: python tools/validation_matrix.py [nseeds] [neval] [names] [solvers] [block] [nchain] [rng rounds]"""
 import math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,6 +16,7 @@ ONLY = sys.argv[3].split(",") if len(sys.argv) > 3 else None     # substrings of
 SOLVERS = sys.argv[4].split(",") if len(sys.argv) > 4 else ["vegas", "vegasmc", "mcmc"]
 BLOCK = int(sys.argv[5]) if len(sys.argv) > 5 else 16
 NCHAIN = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+ROUNDS = int(sys.argv[7]) if len(sys.argv) > 7 else 10     # Philox4x32 rounds (mci_set_rng_rounds): 10 | 7
 L = math.sqrt(50.0)
 p = mci.catalog.bubble_parameters()
 
@@ -46,7 +47,7 @@ CASES = [
      [math.erf(5.0) ** d for d in (3, 6, 9, 12)], 0.0),
     ("C3 bubble (4 q)", bub, mci.catalog.bubble(), mci.bin_by(4), bubble_exact_finite_T(), 0.0),
 ]
-print("%d seeds x (5 training + 10 production iterations x %.0e), block=%d, nchain=%d; deviations in units of the reported error" % (nseeds, NE, BLOCK, NCHAIN))
+print("%d seeds x (5 training + 10 production iterations x %.0e), block=%d, nchain=%d, Philox4x32-%d; deviations in units of the reported error" % (nseeds, NE, BLOCK, NCHAIN, ROUNDS))
 print("%-24s %-8s %-28s %-10s %-14s %s" % ("integrand", "solver", "pooled (mean-exact)/err", "max |dev|", "scatter/err", "s per run"))
 for name, mk, f, meas, exact, exact_tol in CASES:
     exact = np.array(exact, dtype=float)
@@ -55,7 +56,7 @@ for name, mk, f, meas, exact, exact_tol in CASES:
     for solver in SOLVERS:
         ms, es, us, secs = [], [], [], 0.0
         for seed in range(1, nseeds + 1):
-            eng = mci.Engine(mk(), f, measure=meas)
+            eng = mci.Engine(mk(), f, measure=meas, **({"rng_rounds": ROUNDS} if ROUNDS != 10 else {}))
             eng.integrate(solver, neval=NE, niter=5, block=BLOCK, seed=seed, nchain=NCHAIN)
             r = eng.integrate(solver, neval=NE, niter=10, block=BLOCK, seed=seed, first_iteration=5, ignore=0, nchain=NCHAIN)
             ms.append(r["mean"]); es.append(r["stdev"]); secs += r["seconds"]; us.append(r["iter_mean"].mean(0))

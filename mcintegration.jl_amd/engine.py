@@ -68,6 +68,8 @@ class Engine:
         elif callable(integrand) and not isinstance(integrand, (Integrand, HostIntegrand)):
             integrand = HostIntegrand(integrand)
         self.integrand = integrand
+        if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
+            measure = HostMeasure(measure)   # a Python closure: host batch-callback path
         leaves = config.leaves
         self._keep = []
         arr = (LeafDesc * len(leaves))()
@@ -117,8 +119,6 @@ class Engine:
             check(L.mci_set_integrand_host(self.p, C.cast(self._host_cb, C.c_void_p), None))
         else:
             check(L.mci_set_integrand_source(self.p, integrand.body.encode(), _dp(ud) if len(ud) else None, len(ud)))
-        if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
-            measure = HostMeasure(measure)
         if isinstance(measure, Measure):
             check(L.mci_set_measure_source(self.p, measure.body.encode()))
         elif isinstance(measure, HostMeasure) and measure.indexed:

@@ -536,6 +536,16 @@ def test_chain_solvers_with_tiled_histograms_match_oracle(oracle, solver, monkey
     got = eng.iteration(solver, 3200, 0, 4, iteration=0, seed=SEED, nchain=16)
     ref = ocfg.iteration(osolver, "singular2", None, 3200, 0, 4, 0, SEED, nchain=16)
     np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+    # a host measure closure next to tiled histograms: the records come from the tile-0 workgroups only, once per chain
+    seen = []
+    def m(x, obs, weights, config):
+        seen.append(len(weights[0]))
+        obs[0][0] += weights[0].sum()
+    cfg2 = mci.Configuration(var=mci.Continuous([(0.0, PI)] * 3), dof=[[1]], seed=SEED)
+    eng2 = mci.Engine(cfg2, mci.catalog.singular2(), measure=m)
+    got2 = eng2.iteration(solver, 3200, 0, 4, iteration=0, seed=SEED, nchain=16)
+    np.testing.assert_allclose(got2, ref, rtol=1e-9, atol=1e-300)
+    assert len(seen) == 4 and all(16 <= n <= 3200 + 16 for n in seen)   # (:mcmc measures at i = nburnin .. neval + nburnin inclusive, mcmc/montecarlo.jl:134,143)
 
 
 def test_graph_replay_of_the_iteration_chain_matches_the_eager_loop(monkeypatch):

@@ -46,9 +46,10 @@ stats = query("stats", "select name, total_calls, total_duration, average, perce
 for name, calls, tot, avg, pct in stats:
     emit("%-64s %8d %14.1f %12.2f %8.2f" % (name[:64], calls, tot, avg, pct))
 
-# per-call durations in launch order: a sample kernel gets faster while the grid adapts (the first iterations pile the histogram
-# adds of a peaked integrand on few bins), so the figure to hold against bench.py's HIP-event average -- taken over the timed,
-# trained iterations only -- is the steady state (the median of the second half), not the average over warm-up and all
+# per-call durations in launch order: the first ~16 launches of a process run up to 20 % slower (the GPU coming out of idle:
+# tools/ramp_probe.py shows the same ramp on a grid that never adapts, and again after 2 s of idle), so the figure to hold against
+# bench.py's HIP-event average -- taken over the timed iterations, after the warm-up -- is the steady state (the median of the
+# second half), not the average over warm-up and all
 percall = {}
 try:
     for name, dur in query("stats", "select name, (end - start) from kernels order by start"):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development tool (GPU box): A/B of compile-time variants (MCI_JIT_FLAGS) of the :vegas sample kernel on a BASELINE
-workload: median HIP-event kernel time over 8 launches of 1e8 samples.  usage: ab_c2.py [c2|c2i|c4|c5v] 'flags' 'flags' ..."""
+workload: median HIP-event kernel time over 8 launches of 1e8 samples, after 24 launches of warm-up.  usage: ab_c2.py [c2|c2i|c4|c5v] 'flags' 'flags' ..."""
 import json
 import os
 import subprocess
@@ -25,8 +25,8 @@ else:
     cfg, f = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]], seed=1), mci.catalog.nested_gauss()
 import os
 eng = mci.Engine(cfg, f, rng_bits=int(os.environ.get("MCI_AB_RNG_BITS", "52")))
-eng.integrate("vegas", neval=10**8, niter=4, block=16, seed=1)           # warm-up + train
-r = eng.integrate("vegas", neval=10**8, niter=8, block=16, seed=2, first_iteration=4, ignore=0)
+eng.integrate("vegas", neval=10**8, niter=24, block=16, seed=1)          # train + let the GPU come out of idle (~16 launches, tools/ramp_probe.py)
+r = eng.integrate("vegas", neval=10**8, niter=8, block=16, seed=2, first_iteration=24, ignore=0)
 ms, wg, th = eng.kernel_times_ms(8)
 res = isa_mix.resources(eng.code_object("vegas"))["mci_vegas_batch"]
 print(json.dumps(dict(kernel_ms=float(np.median(ms)), iter_ms=r["seconds"] / 8 * 1e3, wg=wg, threads=th, vgpr=res["vgpr"], spill=res["vgpr_spill"],

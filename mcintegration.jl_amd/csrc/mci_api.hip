@@ -902,9 +902,12 @@ static int compile_solver(mci_problem *p, int solver) {
     int T = solver == MCI_VEGAS && p->threads_vegas ? p->threads_vegas : p->threads;
     int rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]);
     if (rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
-    if (hcopy_plan && mcijit::kernel_vgprs(code, "mci_vegas_batch") > 128) {
-        // histogram copies pay when two 512-thread workgroups share a CU (4 waves per SIMD): this integrand's kernel needs more
-        // registers than that allows -> the plain layout with 256-thread workgroups, as many as the registers admit
+    const long hc_vgprs = hcopy_plan ? mcijit::kernel_vgprs(code, "mci_vegas_batch") : 0;
+    if (hcopy_plan && (hc_vgprs > 128 || hc_vgprs <= 96)) {
+        // Histogram copies pay when the kernel runs four waves per SIMD either way (97..128 VGPRs: two 512-thread workgroups
+        // share a CU).  More registers: two such workgroups no longer fit.  Fewer: the plain layout runs five or six waves per SIMD
+        // in 256-thread workgroups and the 80 KB of copies would cap it at four (C5 :vegas, 78 VGPRs: 1.88 ms per 1e8 samples plain,
+        // 2.21 ms with 8 copies; C2, 102 VGPRs: 1.65 plain, 1.45 with 8 copies; warm tools/hcopy_sweep.sh)
         p->shape.hcopy = 1;
         p->threads_vegas = 0;
         T = p->threads;

@@ -97,7 +97,8 @@ def test_c2_sample_loop_mix():
 def test_histogram_copies_follow_the_placement_rule_and_the_register_budget():
     """mci_device.h hslot: 8 interleaved histogram copies and two 512-thread workgroups per CU for the 16-D Gaussian (80.8 KB of LDS);
     the interleaved-copy row of the issue-cost table prices its ds_add_f64; a 1-D integrand keeps the plain layout (nothing to gain),
-    and so does a kernel that needs more than 128 VGPRs (two 512-thread workgroups would not share a CU)"""
+    and so do a kernel that needs more than 128 VGPRs (two 512-thread workgroups would not share a CU) and one that needs at most 96
+    (it runs five or six waves per SIMD without the copies' LDS)"""
     c2 = [b for b in BASELINE if b[0] == "c2"][0]
     eng = mci.Engine(c2[1](), c2[2](), device=-1)
     assert eng.histogram_copies() == 8
@@ -113,6 +114,14 @@ def test_histogram_copies_follow_the_placement_rule_and_the_register_budget():
     one = mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]]), mci.Integrand("w[0] = log(x[0]) / sqrt(x[0]);"), device=-1)
     assert one.histogram_copies() == 1
     one.close()
+    # a light kernel (C5 :vegas: 78 VGPRs) runs six waves per SIMD in 256-thread workgroups: the copies would cap it at four
+    c5 = [b for b in BASELINE if b[0] == "c5"][0]
+    light = mci.Engine(c5[1](), c5[2](), device=-1)
+    assert light.histogram_copies() == 4          # what fits next to its tables in 80 KB
+    light.compile("vegas")
+    res = isa_mix.resources(light.code_object("vegas"))["mci_vegas_batch"]
+    assert res["vgpr"] <= 96 and light.histogram_copies() == 1 and res["max_threads"] == 256, res
+    light.close()
     # an integrand that keeps every draw and every intermediate alive: more than 128 VGPRs -> the plain layout, 256 threads
     body = """double m = 0.0; for (int i = 0; i < 16; ++i) m += x[i]; m *= 0.0625;
               double y[16], q = 0.0; for (int i = 0; i < 16; ++i) { y[i] = sin(x[i] - m) * cos(x[(i + 7) % 16] + m); q += y[i]; }

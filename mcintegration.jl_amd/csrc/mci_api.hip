@@ -1080,7 +1080,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         // enough that the extra partial rows (merged by k_hist_stage1) do not matter
         static const int64_t forced = getenv("MCI_WG_TARGET") ? atoll(getenv("MCI_WG_TARGET")) : 0; // diagnostic override
         // (only while a workgroup's tables are cheap to stage: C3 with 66 KB per workgroup lost 15 % at 4096)
-        const int64_t target = forced > 0 ? forced : ((units * nblocks >= (int64_t)1 << 25 && p->lds_bytes <= 32 * 1024) ? 4096 : 2048);
+        // (... counted in 256-thread workgroups: the 512-thread workgroups of the histogram-copy plan take half as many -- warm
+        // tools/ab_c2.py, C2: 1024 / 2048 / 4096 / 8192 workgroups 1.509 / 1.504 / 1.515 / 1.551 ms per iteration)
+        const int64_t big = T >= 512 ? 2048 : 4096;
+        const int64_t target = forced > 0 ? forced : ((units * nblocks >= (int64_t)1 << 25 && p->lds_bytes <= 32 * 1024) ? big : 2048);
         wpb = (int)((target + nblocks - 1) / nblocks);
         const int64_t maxw = (units + T - 1) / T;
         if (wpb > maxw) wpb = (int)maxw;

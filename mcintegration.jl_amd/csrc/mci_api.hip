@@ -879,6 +879,22 @@ int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
     return MCI_OK;
 }
 
+// What the histogram-copy rule asks of the :vegas kernel the next time it is compiled: copies and workgroup size.  With BOTH opt-in
+// streams on (32 bits per draw, seven rounds) the loop is bound by its LDS pipe again, and sixteen copies -- conflict-free, one
+// 1024-thread workgroup per CU -- beat eight: 84.4 against 77.5 Gsamples/s on the headline configuration; with one opt-in or none
+// eight copies in two 512-thread workgroups win (bench.py: rounds 7: 73.6 against 70.2, 32 bits: 75.5 against 76.2, default: 66.7
+// against 61.7).
+static int planned_hcopy(const mci_problem *p, int *threads) {
+    const auto &s = p->shape;
+    int hc = p->hcopy_auto, t = 512;
+    if (p->hcopy_plan && hc >= 8 && s.rng_bits == 32 && s.rng_rounds == 7 && p->lds_bytes + (int64_t)s.htile * 8 * 15 <= 159 * 1024) {
+        hc = 16;
+        t = 1024;
+    }
+    if (threads) *threads = t;
+    return hc;
+}
+
 // dynamic LDS of the :vegas sample kernel: the tables (+ the edge cache of the many-grid plans) + its histogram copies
 static int64_t vegas_lds(const mci_problem *p) {
     const auto &s = p->shape;
@@ -893,8 +909,11 @@ static int compile_solver(mci_problem *p, int solver) {
             if (p->shape.obs_bin_draw[i] < 0 && p->shape.obs_nbin[i] != p->shape.ncomp)
                 return fail(MCI_ERR_INVALID, "the default measure can only handle observable as Vector with %d scalar elements!", p->ni);
     const bool hcopy_plan = solver == MCI_VEGAS && p->hcopy_plan && !getenv("MCI_HIST_COPIES");
-    if (solver == MCI_VEGAS) p->shape.hcopy = p->hcopy_auto;
-    if (solver == MCI_VEGAS && p->hcopy_plan) p->threads_vegas = 512;
+    if (solver == MCI_VEGAS) {
+        int t = 512;
+        p->shape.hcopy = planned_hcopy(p, &t);
+        if (p->hcopy_plan) p->threads_vegas = t;
+    }
     std::string src = mcijit::generate_source(p->shape, solver);
     std::vector<char> code;
     std::string log;
@@ -999,7 +1018,7 @@ int mci_compile_solver(mci_problem *p, int32_t solver) { return compile_solver(p
 
 int mci_get_histogram_copies(const mci_problem *p, int32_t *copies) {
     if (!p || !copies) return fail(MCI_ERR_INVALID, "NULL argument");
-    *copies = p->compiled[MCI_VEGAS] ? p->shape.hcopy : p->hcopy_auto;
+    *copies = p->compiled[MCI_VEGAS] ? p->shape.hcopy : planned_hcopy(p, nullptr);
     return MCI_OK;
 }
 
@@ -1082,7 +1101,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         // (only while a workgroup's tables are cheap to stage: C3 with 66 KB per workgroup lost 15 % at 4096)
         // (... counted in 256-thread workgroups: the 512-thread workgroups of the histogram-copy plan take half as many -- warm
         // tools/ab_c2.py, C2: 1024 / 2048 / 4096 / 8192 workgroups 1.509 / 1.504 / 1.515 / 1.551 ms per iteration)
-        const int64_t big = T >= 512 ? 2048 : 4096;
+        const int64_t big = T >= 1024 ? 1024 : T >= 512 ? 2048 : 4096;
         const int64_t target = forced > 0 ? forced : ((units * nblocks >= (int64_t)1 << 25 && p->lds_bytes <= 32 * 1024) ? big : 2048);
         wpb = (int)((target + nblocks - 1) / nblocks);
         const int64_t maxw = (units + T - 1) / T;

@@ -212,6 +212,19 @@ def test_seven_round_philox_stream_matches_oracle(oracle, name):
         r = eng.integrate("vegas", neval=40000, niter=5, block=16, seed=SEED)
         o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=40000, niter=5, block=16, seed=SEED)
         np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6, atol=1e-300)
+        if name == "c2_gauss16_shared_pool":
+            # both opt-in streams: the histogram-copy rule switches to sixteen copies in one 1024-thread workgroup per CU
+            c3, cfg3, eng3, ocfg3 = make(name, oracle)
+            eng3.set_rng_rounds(7)
+            eng3.set_rng_bits(32)
+            ocfg3.set_rng_bits(32)
+            got = eng3.iteration("vegas", npb, 0, block, iteration=0, seed=SEED)
+            assert eng3.histogram_copies() == 16 and eng3.kernel_times_ms(1)[2] == 1024
+            ref = ocfg3.iteration(oracle.VEGAS, c["oname"], c["ud"], npb, 0, block, 0, SEED)
+            gs_, gh = hist_split(got, eng3.nobs, cfg3.N)
+            rs, rh = hist_split(ref, eng3.nobs, cfg3.N)
+            np.testing.assert_allclose(gs_, rs, rtol=1e-11, atol=1e-300)
+            np.testing.assert_allclose(gh, rh, rtol=1e-9)
     finally:
         oracle.set_rng_rounds(10)
 

@@ -24,7 +24,7 @@ elif which == "c4":
 else:
     cfg, f = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]], seed=1), mci.catalog.nested_gauss()
 import os
-eng = mci.Engine(cfg, f, rng_bits=int(os.environ.get("MCI_AB_RNG_BITS", "52")))
+eng = mci.Engine(cfg, f, rng_bits=int(os.environ.get("MCI_AB_RNG_BITS", "52")), rng_rounds=int(os.environ.get("MCI_AB_RNG_ROUNDS", "10")))
 eng.integrate("vegas", neval=10**8, niter=24, block=16, seed=1)          # train + let the GPU come out of idle (~16 launches, tools/ramp_probe.py)
 r = eng.integrate("vegas", neval=10**8, niter=8, block=16, seed=2, first_iteration=24, ignore=0)
 ms, wg, th = eng.kernel_times_ms(8)

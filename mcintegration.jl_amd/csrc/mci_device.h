@@ -399,8 +399,28 @@ template <class Cfg> constexpr int tdraw_bits() {
     while ((1 << b) < mx) ++b;
     return b;
 }
+// ... contiguously (MCI_PACK_CONTIG, default): tdraw m occupies bits [m * BITS, (m + 1) * BITS) of the word array, a field may straddle
+// two words.  32 grids of 999 bins: 10 words per sample instead of 11 (3 fields per word, 2 bits idle), and a tile of 16 grids is
+// exactly 5 words -- 12 % less for the replay to read, which is bound by exactly that.
+#ifndef MCI_PACK_CONTIG
+#define MCI_PACK_CONTIG 1
+#endif
 template <class Cfg> constexpr int tdraw_per() { return 32 / tdraw_bits<Cfg>(); }
-template <class Cfg> constexpr int tdraw_words() { return (tdraw_count<Cfg>() + tdraw_per<Cfg>() - 1) / tdraw_per<Cfg>(); }
+template <class Cfg> constexpr int tdraw_bitpos(int m) { return MCI_PACK_CONTIG ? m * tdraw_bits<Cfg>() : 32 * (m / tdraw_per<Cfg>()) + tdraw_bits<Cfg>() * (m % tdraw_per<Cfg>()); }
+template <class Cfg> constexpr int tdraw_words() {
+    return MCI_PACK_CONTIG ? (tdraw_count<Cfg>() * tdraw_bits<Cfg>() + 31) / 32 : (tdraw_count<Cfg>() + tdraw_per<Cfg>() - 1) / tdraw_per<Cfg>();
+}
+// does tdraw m touch word j?
+template <class Cfg> constexpr bool tdraw_in_word(int m, int j) {
+    const int lo = tdraw_bitpos<Cfg>(m), hi = lo + tdraw_bits<Cfg>() - 1;
+    return lo / 32 == j || hi / 32 == j;
+}
+// the field of tdraw M out of a sample's words
+template <class Cfg, int M> __device__ __forceinline__ int tdraw_extract(const u32 *word) {
+    constexpr int BITS = tdraw_bits<Cfg>(), off = tdraw_bitpos<Cfg>(M), w = off / 32, sh = off % 32;
+    if constexpr (sh + BITS <= 32) return (int)((word[w] >> sh) & ((1u << BITS) - 1u));
+    else return (int)(((word[w] >> sh) | (word[w + 1] << (32 - sh))) & ((1u << BITS) - 1u));
+}
 
 // blockIdx -> (statistical block, slice of the block, histogram tile)
 // all NDRAW draws of one sample + Jacobians.  jaci[i] = product of 1/prob over integrand i's own draws
@@ -418,8 +438,9 @@ template <class Cfg> struct Sample {
 
 template <class Cfg, int K> __device__ __forceinline__ void pack_bin(Sample<Cfg> &s) {
     if constexpr (is_tdraw<Cfg>(K)) {
-        constexpr int m = tdraw_pos<Cfg>(K), PER = tdraw_per<Cfg>(), BITS = tdraw_bits<Cfg>();
-        s.word[m / PER] |= (u32)s.bin[K] << (BITS * (m % PER)); // (the words start at zero: the gather phase draws out of order)
+        constexpr int BITS = tdraw_bits<Cfg>(), off = tdraw_bitpos<Cfg>(tdraw_pos<Cfg>(K)), w = off / 32, sh = off % 32;
+        s.word[w] |= (u32)s.bin[K] << sh; // (the words start at zero: the gather phase draws out of order)
+        if constexpr (sh + BITS > 32) s.word[w + 1] |= (u32)s.bin[K] >> (32 - sh);
     }
 }
 template <class Cfg, bool ECACHE = false, bool KV = false, int DPC = 2> __device__ __forceinline__ void draw_sample(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index, Sample<Cfg> &s) {
@@ -1179,7 +1200,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
             // U samples per lane and trip: all their loads are issued before the first ds_add_f64 (the kernel has one
             // 512-thread workgroup per CU, so memory-level parallelism has to come from the loop body)
             constexpr int U = MCI_TILES_U;
-            constexpr int NWORD = tdraw_words<Cfg>(), PER = tdraw_per<Cfg>(), BITS = tdraw_bits<Cfg>();
+            constexpr int NWORD = tdraw_words<Cfg>();
             for (i64 n0 = (i64)slice * T + tid; n0 < a.neval_per_block; n0 += stride * U) {
                 double wh[U][Cfg::NI];
                 u32 word[U][NWORD > 0 ? NWORD : 1];
@@ -1195,7 +1216,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
                         // only the words that hold a draw of this tile
                         constexpr bool need = [] {
                             for (int k = 0; k < Cfg::NDRAW; ++k)
-                                if (is_tdraw<Cfg>(k) && Cfg::leaf_tile(Cfg::draw_leaf(k)) == tt && tdraw_pos<Cfg>(k) / PER == j) return true;
+                                if (is_tdraw<Cfg>(k) && Cfg::leaf_tile(Cfg::draw_leaf(k)) == tt && tdraw_in_word<Cfg>(tdraw_pos<Cfg>(k), j)) return true;
                             return false;
                         }();
                         if constexpr (need) word[u][j] = a.tile_bins[j * a.tile_stride + idx];
@@ -1215,8 +1236,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
                             typedef int bvec __attribute__((ext_vector_type(G)));
                             bvec b;
                             static_for<0, G>([&](auto Gi) {
-                                constexpr int m = tdraw_pos<Cfg>(tile_draw<Cfg>(tt, decltype(Gi)::value));
-                                b[decltype(Gi)::value] = (int)((word[u][m / PER] >> (BITS * (m % PER))) & ((1u << BITS) - 1u));
+                                b[decltype(Gi)::value] = tdraw_extract<Cfg, tdraw_pos<Cfg>(tile_draw<Cfg>(tt, decltype(Gi)::value))>(word[u]);
                             });
                             static_for<0, 4>([&](auto Ss) { // b[d] <- b[(d + r) % G], one conditional rotation per bit of r
                                 constexpr int sh = 1 << decltype(Ss)::value;
@@ -1241,8 +1261,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
                             if constexpr (is_tdraw<Cfg>(k)) {
                                 constexpr int leaf = Cfg::draw_leaf(k);
                                 if constexpr (Cfg::leaf_tile(leaf) == tt) {
-                                    constexpr int m = tdraw_pos<Cfg>(k);
-                                    const int bin = (int)((word[u][m / PER] >> (BITS * (m % PER))) & ((1u << BITS) - 1u));
+                                    const int bin = tdraw_extract<Cfg, tdraw_pos<Cfg>(k)>(word[u]);
                                     double wk = 0.0;
                                     static_for<0, Cfg::NI>([&](auto I) {
                                         constexpr int i = decltype(I)::value;

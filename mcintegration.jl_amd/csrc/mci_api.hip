@@ -1102,7 +1102,13 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         // (... counted in 256-thread workgroups: the 512-thread workgroups of the histogram-copy plan take half as many -- warm
         // tools/ab_c2.py, C2: 1024 / 2048 / 4096 / 8192 workgroups 1.509 / 1.504 / 1.515 / 1.551 ms per iteration)
         const int64_t big = T >= 1024 ? 1024 : T >= 512 ? 2048 : 4096;
-        const int64_t target = forced > 0 ? forced : ((units * nblocks >= (int64_t)1 << 25 && p->lds_bytes <= 32 * 1024) ? big : 2048);
+        int64_t target = forced > 0 ? forced : ((units * nblocks >= (int64_t)1 << 25 && p->lds_bytes <= 32 * 1024) ? big : 2048);
+        // :vegas launches of up to a few million samples: a workgroup's prologue and epilogue (tables staged, histogram zeroed and
+        // flushed) cost what ~50 samples per thread cost, so the grid shrinks to one workgroup per CU (tools/latency.py, us per
+        // iteration at neval = 1e6: 2048 workgroups 39.9, 512: 27.7, 256: 26.9; C2 at 1e6: 64.8 -> 43.9).  Longer launches keep the
+        // full grid: a grid between 256 and 512 workgroups leaves half of the CUs' second slot empty (C2 at 1e7: 320 workgroups
+        // 271.7 us, 2048: 210.1)
+        if (solver == MCI_VEGAS && forced <= 0 && units * nblocks < ((int64_t)1 << 22) && target > 256) target = 256;
         wpb = (int)((target + nblocks - 1) / nblocks);
         const int64_t maxw = (units + T - 1) / T;
         if (wpb > maxw) wpb = (int)maxw;

@@ -24,3 +24,22 @@ if __name__ == "__main__":
             ms, wg, th = eng.kernel_times_ms(50)
             print("%-8s neval=%-9d  %8.1f us/iteration (library clock %8.1f)  kernel %8.1f us  wg=%d  -> %8.1f Msamples/s   mean %.6f +- %.1e" % (
                 solver, neval, dt / 50 * 1e6, r["seconds"] / 50 * 1e6, float(np.median(ms)) * 1e3, wg, neval / (dt / 50) / 1e6, r["mean"][0], r["stdev"][0]), flush=True)
+    # the headline integrand (16-D Gaussian on a shared 999-bin grid, :vegas) from launch-bound to throughput-bound sizes
+    import math
+    L = math.sqrt(50.0)
+    eng = mci.Engine(mci.Configuration(var=mci.Continuous(-L, L), dof=[[16]], seed=1), mci.catalog.gaussian(16))
+    eng.integrate("vegas", neval=10**8, niter=12, block=16, seed=1)
+    it = 12
+    for neval in (10**5, 10**6, 10**7, 3 * 10**7, 10**8):
+        n = 50 if neval < 10**8 else 10
+        eng.set_kernel_timing(0)
+        eng.integrate("vegas", neval=neval, niter=3, block=16, seed=1, first_iteration=it, ignore=0)
+        t0 = time.perf_counter()
+        eng.integrate("vegas", neval=neval, niter=n, block=16, seed=1, first_iteration=it + 3, ignore=0)
+        dt = time.perf_counter() - t0
+        eng.set_kernel_timing(1)
+        eng.integrate("vegas", neval=neval, niter=n, block=16, seed=1, first_iteration=it + 3 + n, ignore=0)
+        ms, wg, th = eng.kernel_times_ms(n)
+        it += 3 + 2 * n
+        print("C2 neval=%-10d %8.1f us/iteration  kernel %8.1f us  wg=%d th=%d  -> %8.1f Msamples/s" % (
+            neval, dt / n * 1e6, float(np.median(ms)) * 1e3, wg, th, neval / (dt / n) / 1e6), flush=True)

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Development tool (GPU box): wall time of WHOLE integrate() calls at the reference's default size (neval=1e4, niter=10), the way a
+parameter scan uses the reference: a new Configuration per call (same integrand source: the code object comes from the kernel
+cache), and the same Configuration reused.  Where the time of a call goes (create / module load / iterations / read-back)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import mcintegration_jl_amd as mci
+
+if __name__ == "__main__":
+    src = "return x[0] * x[0] + x[1] * x[1];"
+    for solver in ("vegas", "vegasmc", "mcmc"):
+        mci.integrate(src, var=mci.Continuous(0.0, 1.0), dof=[[2]], solver=solver, neval=1e4)          # JIT / cache load
+        n = 30
+        t0 = time.perf_counter()
+        for i in range(n):
+            r = mci.integrate(src, var=mci.Continuous(0.0, 1.0), dof=[[2]], solver=solver, neval=1e4)
+        fresh = (time.perf_counter() - t0) / n
+        cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
+        mci.integrate(src, config=cfg, solver=solver, neval=1e4)
+        t0 = time.perf_counter()
+        for i in range(n):
+            r = mci.integrate(src, config=cfg, solver=solver, neval=1e4)
+        reuse = (time.perf_counter() - t0) / n
+        print("%-8s integrate(neval=1e4, niter=10): new Configuration per call %8.3f ms, same Configuration %8.3f ms   (%s)" % (
+            solver, fresh * 1e3, reuse * 1e3, r), flush=True)
+    # profile of one fresh call
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(10):
+        mci.integrate(src, var=mci.Continuous(0.0, 1.0), dof=[[2]], solver="vegas", neval=1e4)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(25)

@@ -419,6 +419,12 @@ class Engine:
         check(lib().mci_integrate(self.p, C.byref(a), C.byref(r)))
         return dict(mean=m, stdev=s, chi2=c2, iter_mean=im, iter_std=ie, neval=r.neval, seconds=r.seconds)
 
+    def comm_ranks(self):
+        """ranks of the communicator attached to this engine's context (1: none; mci_integrate shards its blocks over them)"""
+        r, n = C.c_int32(), C.c_int32()
+        check(lib().mci_comm_rank(context(self.device), C.byref(r), C.byref(n)))
+        return int(n.value)
+
     def sample_dump(self, n, nevalperblock=None, block_index=0, iteration=0, seed=1234):
         nevalperblock = n if nevalperblock is None else nevalperblock
         x, jac, w = np.empty((n, self.ndraw)), np.empty(n), np.empty((n, self.config.N * self.config.ncomp))

@@ -686,3 +686,33 @@ def test_bubble_with_fermik_momentum():
     avg, std = result.mean[0], result.stdev[0]
     for idx in range(4):
         assert abs(avg[idx] - exact[idx]) < 5.0 * std[idx], (avg, std, exact)
+
+
+@pytest.mark.parametrize("alg", ["vegas", "vegasmc", "mcmc"])
+def test_library_loop_and_per_iteration_loop_give_the_same_run(alg):
+    """integrate() hands a single-process run to the library's loop (mci_integrate: iterations queued back to back, one
+    read-back); any other communicator goes iteration by iteration through run / all_reduce / finish (main.jl:142-207).
+    Same seeds, same iterations, resumed call and reweight goal included: the two agree as two runs of either loop agree -- to
+    rounding (the order of the LDS histogram atomics is not fixed, and the grid -> histogram -> grid loop carries that on)."""
+    from mcintegration_jl_amd.comm import LocalComm
+
+    class OneRank(LocalComm):   # a communicator type integrate() does not special-case: the per-iteration loop
+        pass
+
+    out = []
+    for comm in (None, OneRank()):
+        cfg = Configuration(var=(Continuous(0.0, 1.0), Discrete(1, 3)), dof=[[2, 1], [3, 0]], seed=77)
+        body = "w[0] = x[0] * x[1] * x[3]; w[1] = x[0] + x[1] * x[2];"
+        goal = [1.0, 2.0, 1.0] if alg != "vegas" else None
+        r1 = integrate(body, config=cfg, solver=alg, neval=2e4, niter=4, comm=comm, reweight_goal=goal)
+        r2 = integrate(body, config=cfg, solver=alg, neval=3e4, niter=3, comm=comm, reweight_goal=goal)   # resumes: iterations 4..6
+        out.append((r1, r2, cfg._engine.grid(0), cfg._engine.reweight()))
+    (a1, a2, ga, wa), (b1, b2, gb, wb) = out
+    for a, b in ((a1, b1), (a2, b2)):
+        np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-11)
+        np.testing.assert_allclose(a.iter_std, b.iter_std, rtol=1e-8)
+        np.testing.assert_allclose(a.mean, b.mean, rtol=1e-11)
+        np.testing.assert_allclose(a.stdev, b.stdev, rtol=1e-8)
+        assert a.neval == b.neval
+    np.testing.assert_allclose(ga, gb, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(wa, wb, rtol=1e-11)

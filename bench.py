@@ -150,7 +150,7 @@ def issue_roofline(code_object, costs, samples_per_launch, kernel_ms, hist_copie
     can issue THAT mix (1024 SIMDs / mix-weighted mean issue cost).  The LDS rows are costs seen from one SIMD with all four
     SIMDs of the CU competing, so the same 1024 applies."""
     from mcintegration_jl_amd import isa_mix
-    mix = isa_mix.loop_mix(code_object, "mci_vegas_batch")
+    mix = isa_mix.loop_mix(code_object, "mci_vegas_batch", draws_per_sample=D)
     cyc = isa_mix.issue_cycles(mix, costs, hist_copies=hist_copies)
     trips = samples_per_launch / 64.0                       # one loop trip = one sample on each of a wave's 64 lanes
     out = {}
@@ -161,6 +161,7 @@ def issue_roofline(code_object, costs, samples_per_launch, kernel_ms, hist_copie
         out[pipe] = {"achieved": round(ach, 2), "peak": round(peak, 2), "frac": round(ach / peak, 4) if peak else None,
                      "instructions_per_wave_sample": n_inst, "issue_ns_per_wave_sample": round(cyc[pipe], 1)}
     out["mix"] = {cls: {"n": n, "ns_each": round(c, 3)} for cls, (n, c) in sorted(cyc["per_class"].items())}
+    out["samples_per_loop_trip"] = mix["samples_per_trip"]
     out["resources"] = isa_mix.resources(code_object).get("mci_vegas_batch")
     return out
 

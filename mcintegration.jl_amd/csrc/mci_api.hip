@@ -922,11 +922,11 @@ static int compile_solver(mci_problem *p, int solver) {
     int rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]);
     if (rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
     const long hc_vgprs = hcopy_plan ? mcijit::kernel_vgprs(code, "mci_vegas_batch") : 0;
-    if (hcopy_plan && (hc_vgprs > 128 || hc_vgprs <= 96)) {
-        // Histogram copies pay when the kernel runs four waves per SIMD either way (97..128 VGPRs: two 512-thread workgroups
-        // share a CU).  More registers: two such workgroups no longer fit.  Fewer: the plain layout runs five or six waves per SIMD
+    if (hcopy_plan && (hc_vgprs > 128 || hc_vgprs <= 80)) {
+        // Histogram copies pay when the kernel runs four or five waves per SIMD either way (81..128 VGPRs: two 512-thread workgroups
+        // share a CU).  More registers: two such workgroups no longer fit.  Fewer: the plain layout runs six or more waves per SIMD
         // in 256-thread workgroups and the 80 KB of copies would cap it at four (C5 :vegas, 78 VGPRs: 1.88 ms per 1e8 samples plain,
-        // 2.21 ms with 8 copies; C2, 102 VGPRs: 1.65 plain, 1.45 with 8 copies; warm tools/hcopy_sweep.sh)
+        // 2.21 ms with 8 copies; C2, 92 VGPRs with the copies / 101 plain: see profiles/r02_ablation.txt; warm tools/hcopy_sweep.sh)
         p->shape.hcopy = 1;
         p->threads_vegas = 0;
         T = p->threads;
@@ -939,6 +939,9 @@ static int compile_solver(mci_problem *p, int solver) {
         p->threads_vegas = T;
         if ((rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
     }
+    if (mcijit::max_static_lds_bytes(code) != 0) // (mci_device.h draw_leaf: the pair table is addressed from LDS address 0)
+        return fail(MCI_ERR_COMPILE, "the code object declares static LDS (%ld bytes): the sample kernels expect their dynamic segment at LDS address 0",
+                    mcijit::max_static_lds_bytes(code));
     if (!p->ctx->offline) {
         static const char *const names[3] = {"mci_vegas_batch", "mci_vegasmc_chains", "mci_mcmc_chains"};
         HIPCHK(hipSetDevice(p->ctx->device));

@@ -280,6 +280,22 @@ template <class Cfg> struct Tables {
 // With Cfg::PAIR_TABLE the LDS table holds (g[i], g[i+1]-g[i]) pairs: ONE aligned ds_read_b128 per draw and
 // no subtraction on the critical path (the pair is formed with the same rounding when the table is staged).
 // U12 = true: `y` is the uniform PLUS ONE (in [1, 2), see u12()).
+// y * N of a Continuous draw (FMA: y is the uniform plus one and (y - 1) * N is formed as fma(y, N, -N), see draw_leaf)
+template <int N, bool FMA, bool U12> __device__ __forceinline__ double cont_yn(double y) {
+    if constexpr (FMA) {
+        double Nd = (double)N;
+        asm("" : "+s"(Nd)); // an SGPR pair the compiler cannot fold into a literal
+        return __builtin_fma(y, Nd, -Nd);
+    } else return (U12 ? y - 1.0 : y) * (double)N;
+}
+// every draw a Continuous leaf served from the LDS pair table (the batched reads of draw_sample)
+template <class Cfg> constexpr bool all_draws_pair_table() {
+    if (Cfg::PAIR_TABLE == 0 || Cfg::TABLE_MODE > 1) return false;
+    for (int k = 0; k < Cfg::NDRAW; ++k)
+        if (Cfg::leaf_kind(Cfg::draw_leaf(k)) != 0) return false;
+    return true;
+}
+
 template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
     constexpr int leaf = Cfg::draw_leaf(K);
     if constexpr (Cfg::leaf_kind(leaf) != 0 && U12) y -= 1.0;
@@ -294,12 +310,7 @@ template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __
         // (N through an opaque SGPR pair: with the literal the compiler picks v_fmac_f64 and rebuilds the -N accumulator with two
         // v_mov_b32 per draw; v_fma_f64 v, v, s, -s uses one SGPR pair twice, which the constant bus allows.  The whole v_fma_f64 as
         // inline asm made the C3 :vegas kernel 17 % slower: different inlining, 143 -> 157 VGPRs)
-        double yn;
-        if constexpr (U12 && Cfg::NDRAW >= 8) { // (few draws: nothing to gain, and the C3 :vegas kernel came out 17 % slower with either fma form)
-            double Nd = (double)N;
-            asm("" : "+s"(Nd)); // an SGPR pair the compiler cannot fold into a literal
-            yn = __builtin_fma(y, Nd, -Nd);
-        } else yn = (U12 ? y - 1.0 : y) * (double)N;
+        const double yn = cont_yn<N, (U12 && Cfg::NDRAW >= 8), U12>(y); // (few draws: nothing to gain, and the C3 :vegas kernel came out 17 % slower with either fma form)
 #else
         const double yn = (U12 ? y - 1.0 : y) * (double)N;
 #endif
@@ -311,7 +322,21 @@ template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __
         double g0, dx;
         if constexpr (Cfg::PAIR_TABLE != 0 && Cfg::TABLE_MODE <= 1) {
             typedef double d2 __attribute__((ext_vector_type(2)));
+#ifndef MCI_LDS_ABS
+#define MCI_LDS_ABS 1
+#endif
+#if MCI_LDS_ABS
+            // The pair table starts at LDS address 0: the JIT kernels keep no static LDS, so the dynamic segment -- whose first entry the
+            // table is (Lds::E == 0) -- begins there; the host checks .group_segment_fixed_size == 0 on every code object it loads.
+            // With the address formed from that constant the byte offset is ONE VOP2 shift and the leaf's offset rides in the
+            // instruction's immediate; through the `smem` symbol the compiler emits v_lshl_add_u32 v, iy, 4, <base = 0, known only
+            // after instruction selection>, a three-source form that issues at 1.75 ns instead of 1.0 (tools/issue_microbench.hip)
+            typedef const d2 __attribute__((address_space(3))) lds_d2;
+            const u32 boff = ((u32)iy << 4) + (u32)(Cfg::leaf_poff(leaf) * 8);
+            const d2 e = *(lds_d2 *)boff;
+#else
             const d2 e = *reinterpret_cast<const d2 *>(t.E + Cfg::leaf_poff(leaf) + 2 * iy);
+#endif
             g0 = e.x;
             dx = e.y;
         } else if constexpr (ECACHE && Cfg::leaf_ecoff(leaf) >= 0) {
@@ -449,14 +474,67 @@ template <class Cfg, bool ECACHE = false, bool KV = false, int DPC = 2> __device
     s.jac = 1.0;
     static_for<0, Cfg::NI>([&](auto I) { s.jaci[decltype(I)::value] = 1.0; });
     static_for<0, tdraw_words<Cfg>()>([&](auto J) { s.word[decltype(J)::value] = 0u; });
-    static_for<0, (Cfg::NDRAW + DPC - 1) / DPC>([&](auto C) {
+#ifndef MCI_PHILOX_FIRST
+#define MCI_PHILOX_FIRST 1
+#endif
+    // LDS pair tables, 8..16 draws: every Philox block of the sample first, fenced, then the draws.  That is the schedule the compiler
+    // used to pick by itself for the 16-D headline loop (102 VGPRs, two ds_read_b128 in flight); with the loop specialised on
+    // measurefreq == 1 it interleaved blocks and draws instead (92 VGPRs, one read in flight, each waited for at once) and the shorter
+    // loop ran 3 % SLOWER.  The fence pins the order.
+    constexpr int NCH = (Cfg::NDRAW + DPC - 1) / DPC;
+    constexpr bool PHILOX_FIRST = MCI_PHILOX_FIRST != 0 && DPC == 2 && Cfg::NDRAW >= 8 && Cfg::NDRAW <= 16 && !ECACHE && Cfg::PAIR_TABLE != 0 &&
+                                  Cfg::TABLE_MODE <= 1;
+    u32x4 rr[PHILOX_FIRST ? NCH : 1];
+    if constexpr (PHILOX_FIRST) {
+        static_for<0, NCH>([&](auto C) { rr[decltype(C)::value] = philox4x32_10<KV>(ilo, ihi, (u32)decltype(C)::value, stream, keys); });
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ... and the table reads of RB draws are issued back to back before the first pair is used: a wave then waits for the LDS
+    // twice per 16 draws instead of eight times.  The loop's VALU work alone takes 1.20 ms per 1e8 samples, its LDS work alone 1.17 ms,
+    // and with two reads in flight per wave (what the compiler schedules) the two only overlap to 1.43 ms (profiles/r02_ablation.txt)
+#ifndef MCI_READ_BATCH
+#define MCI_READ_BATCH 8
+#endif
+#if defined(MCI_ABL_NOTABLE) || !MCI_YN_FMA || !MCI_LDS_ABS
+    constexpr int RB = 0;
+#else
+    constexpr int RB = (PHILOX_FIRST && all_draws_pair_table<Cfg>()) ? MCI_READ_BATCH : 0;
+#endif
+    static_assert(RB % DPC == 0, "a batch of reads covers whole Philox blocks");
+    typedef double pair_d2 __attribute__((ext_vector_type(2)));
+    pair_d2 pe[RB > 0 ? RB : 1];
+    double pdy[RB > 0 ? RB : 1];
+    static_for<0, NCH>([&](auto C) {
         constexpr int c = decltype(C)::value;
-        const u32x4 r = philox4x32_10<KV>(ilo, ihi, (u32)c, stream, keys);
+        u32x4 r;
+        if constexpr (PHILOX_FIRST) r = rr[c];
+        else r = philox4x32_10<KV>(ilo, ihi, (u32)c, stream, keys);
+        if constexpr (RB > 0) {
+            if constexpr ((DPC * c) % RB == 0) { // open a batch: bins, fractions and reads of draws DPC*c .. DPC*c + RB - 1
+                static_for<0, RB>([&](auto J) {
+                    constexpr int j = decltype(J)::value, k = DPC * c + j;
+                    if constexpr (k < Cfg::NDRAW) {
+                        constexpr int leaf = Cfg::draw_leaf(k), N = Cfg::leaf_nbin(leaf);
+                        const double yn = cont_yn<N, true, true>(block_u12<DPC, k % DPC>(rr[k / DPC])); // as draw_leaf forms it
+                        s.bin[k] = (int)yn;
+                        pdy[j] = __builtin_amdgcn_fract(yn);
+                        typedef const pair_d2 __attribute__((address_space(3))) lds_pair;
+                        pe[j] = *(lds_pair *)(((u32)s.bin[k] << 4) + (u32)(Cfg::leaf_poff(leaf) * 8));
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         static_for<0, DPC>([&](auto H) {
             constexpr int k = DPC * c + decltype(H)::value;
             if constexpr (k < Cfg::NDRAW) {
                 const double y1 = block_u12<DPC, decltype(H)::value>(r);
                 double raw;
+                if constexpr (RB > 0) { // x = g[iy] + dy * (g[iy+1] - g[iy])   sampler.jl:299
+                    s.x[k] = pe[k % RB].x + pdy[k % RB] * pe[k % RB].y;
+                    raw = pe[k % RB].y;
+                    (void)y1;
+                } else
                 draw_leaf<Cfg, k, true, ECACHE>(t, y1, s.x[k], raw, s.bin[k]);
                 pack_bin<Cfg, k>(s);
                 s.pj[k] = raw * jac_scale<Cfg>(k);
@@ -759,6 +837,9 @@ template <class Cfg> struct LdsEC {
     static constexpr int END = EC + Cfg::EC_DOUBLES;
 };
 
+// (draw_leaf addresses the pair table from LDS address 0, MCI_LDS_ABS)
+template <class Cfg> struct LdsTableAtZero { static_assert(Lds<Cfg>::E == 0 && LdsEC<Cfg>::E == 0, "the edge / pair table opens the dynamic LDS segment"); };
+
 // partial-statistics columns written per workgroup:
 //   [0, NOBS) observables | NOBS normalization | NOBS+1 neval | NOBS+2 .. +NI+1 visited(N+1)
 template <class Cfg> struct Cols {
@@ -804,6 +885,111 @@ template <class Cfg, int TILE = -1> __device__ __forceinline__ void hist_update(
                 global_add(&gH[Cfg::leaf_boff(leaf) + s.bin[k]], wk);
             }
         }
+    });
+}
+
+// the histogram add of ONE draw (hist_update's body for draw K; one LDS tile)
+template <class Cfg, int K> __device__ __forceinline__ void hist_add_draw(int bin, const double *wh /*[NI]*/, double *sH) {
+    constexpr int leaf = Cfg::draw_leaf(K);
+    if constexpr (Cfg::leaf_adapt(leaf) != 0 && Cfg::cover_mask(K) != 0ull) {
+        double wk = 0.0;
+        static_for<0, Cfg::NI>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr ((Cfg::own_mask(i) >> K) & 1ull) wk += wh[i];
+        });
+        lds_add(&sH[hslot<Cfg>(Cfg::leaf_boff(leaf) - Cfg::tile_boff(Cfg::leaf_tile(leaf)) + bin)], wk);
+    }
+}
+
+// Software-pipelined :vegas sample (the kernels of pipe_eligible()): the histogram adds of the PREVIOUS sample and the table reads of
+// this one are spread between the Philox blocks, and a pair is consumed MCI_PIPE_LAG blocks after its read was issued.  Left to the
+// compiler a trip is a long VALU-only stretch (eight Philox blocks, ~280 instructions) followed by an LDS-heavy one (16 reads, each
+// waited for, then 16 atomics back to back), and since all waves of a CU run the same code at the same pace they tend to queue for the
+// same pipe: measured on the 16-D headline loop, VALU work alone 1.20 ms per 1e8 samples, LDS work alone 1.17 ms, both together 1.43 ms.
+// With every stretch of the instruction stream carrying the same VALU : LDS mix the two pipes overlap whatever the phase of the waves.
+// Same draws, same arithmetic in the same order as draw_sample + hist_update (the atomics of a sample land one trip later).
+#ifndef MCI_PIPE
+#define MCI_PIPE 1
+#endif
+#ifndef MCI_PIPE_LAG
+#define MCI_PIPE_LAG 1
+#endif
+template <class Cfg> struct PendingHist {
+    int bin[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
+    double wh[Cfg::NI];
+};
+template <class Cfg> constexpr bool pipe_eligible() {
+#if defined(MCI_ABL_NOTABLE) || defined(MCI_ABL_NOHIST) || defined(MCI_ABL_CHEAPRNG) || !MCI_YN_FMA || !MCI_LDS_ABS
+    return false;
+#else
+    return MCI_PIPE != 0 && Cfg::RNG_BITS != 32 && Cfg::NDRAW >= 8 && Cfg::NDRAW <= 16 && all_draws_pair_table<Cfg>() && Cfg::NTILE == 1 &&
+           Mode<Cfg>::HIST_LDS && Cfg::HOST_INTEGRAND == 0 && Cfg::HOST_MEASURE == 0 && Cfg::EC_DOUBLES == 0;
+#endif
+}
+template <class Cfg, bool KV> __device__ __forceinline__ void draw_sample_pipe(const RoundKeys<KV> &keys, u32 stream, u64 index, Sample<Cfg> &s,
+                                                                               const PendingHist<Cfg> &pend, PendingHist<Cfg> &next, double *sH) {
+    constexpr int DPC = 2, NCH = (Cfg::NDRAW + DPC - 1) / DPC, LAG = MCI_PIPE_LAG;
+    constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
+    const u32 ilo = (u32)index, ihi = (u32)(index >> 32);
+    s.jac = 1.0;
+    static_for<0, Cfg::NI>([&](auto I) { s.jaci[decltype(I)::value] = 1.0; });
+    static_for<0, tdraw_words<Cfg>()>([&](auto J) { s.word[decltype(J)::value] = 0u; });
+    typedef double pair_d2 __attribute__((ext_vector_type(2)));
+    pair_d2 pe[Cfg::NDRAW];
+    double pdy[Cfg::NDRAW];
+    static_for<0, NCH + LAG>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        if constexpr (c < NCH) {
+            const u32x4 r = philox4x32_10<KV>(ilo, ihi, (u32)c, stream, keys);
+            static_for<0, DPC>([&](auto H) { // bins, fractions and table reads of this block's draws
+                constexpr int k = DPC * c + decltype(H)::value;
+                if constexpr (k < Cfg::NDRAW) {
+                    constexpr int leaf = Cfg::draw_leaf(k), N = Cfg::leaf_nbin(leaf);
+                    const double yn = cont_yn<N, true, true>(block_u12<DPC, decltype(H)::value>(r)); // as draw_leaf forms it
+                    s.bin[k] = next.bin[k] = (int)yn; // (the bins go straight into the record the NEXT trip adds from)
+                    pdy[k] = __builtin_amdgcn_fract(yn);
+                    typedef const pair_d2 __attribute__((address_space(3))) lds_pair;
+                    pe[k] = *(lds_pair *)(((u32)s.bin[k] << 4) + (u32)(Cfg::leaf_poff(leaf) * 8));
+                }
+            });
+            static_for<0, DPC>([&](auto H) { // two of the previous sample's histogram adds
+                constexpr int k = DPC * c + decltype(H)::value;
+                if constexpr (k < Cfg::NDRAW) hist_add_draw<Cfg, k>(pend.bin[k], pend.wh, sH);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (c >= LAG) { // the draws whose pairs were asked for LAG blocks ago: x = g[iy] + dy * (g[iy+1] - g[iy])  sampler.jl:299
+            constexpr int cc = c - LAG;
+            static_for<0, DPC>([&](auto H) {
+                constexpr int k = DPC * cc + decltype(H)::value;
+                if constexpr (k < Cfg::NDRAW) {
+                    s.x[k] = pe[k].x + pdy[k] * pe[k].y;
+                    const double raw = pe[k].y;
+                    pack_bin<Cfg, k>(s);
+                    s.pj[k] = raw * jac_scale<Cfg>(k);
+                    s.jac *= raw; // jac /= prob   vegas/montecarlo.jl:126 (scale applied below)
+                    static_for<0, Cfg::NI>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        if constexpr (((Cfg::own_mask(i) >> k) & 1ull) && Cfg::own_mask(i) != ALL) s.jaci[i] *= raw;
+                    });
+                }
+            });
+            if constexpr (((DPC * cc + DPC) % kJacGroup == 0 || DPC * cc + DPC >= Cfg::NDRAW)) { // close a group of draws: apply its N factors
+                constexpr int hi = DPC * cc + DPC, lo = ((hi - 1) / kJacGroup) * kJacGroup;
+                constexpr double sc = jac_scale_product<Cfg>(ALL, lo, hi);
+                if constexpr (sc != 1.0) s.jac *= sc;
+                static_for<0, Cfg::NI>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    constexpr double si = jac_scale_product<Cfg>(Cfg::own_mask(i), lo, hi);
+                    if constexpr (Cfg::own_mask(i) != ALL && si != 1.0) s.jaci[i] *= si;
+                });
+            }
+            if constexpr (c < NCH) __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+    static_for<0, Cfg::NI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (Cfg::own_mask(i) == ALL) s.jaci[i] = s.jac; // dof[i] == maxdof: no padding (vegas/montecarlo.jl:82)
     });
 }
 
@@ -977,8 +1163,11 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     const i64 mstep = mfreq == 1 ? 0 : stride % mfreq;
     // gathered grids (table mode 3) are walked dimension-major over PH samples per lane so that they are served from L1
     constexpr int PH = (Cfg::L1_PHASE > 0 && Cfg::HOST_INTEGRAND == 0 && gather_draw_count<Cfg, EC>() > 0) ? Cfg::L1_PHASE : 0;
-    auto run = [&](auto TT) { // the sample loop, specialised on the workgroup's histogram tile
-    auto process = [&](const i64 n, const Sample<Cfg> &s) { // everything after the draws of sample n
+    // the sample loop, specialised on the workgroup's histogram tile and on measurefreq == 1 (the reference's default, main.jl:84: every
+    // sample is measured and the carried remainder with its 64-bit compare / select -- a dozen VALU instructions per sample -- is gone)
+    auto run = [&](auto TT, auto MF1c) {
+    constexpr bool MF1 = decltype(MF1c)::value != 0;
+    auto process = [&](const i64 n, const Sample<Cfg> &s, double *defer_wh = nullptr) { // everything after the draws of sample n
         double w[Cfg::NW];
         if constexpr (Cfg::HOST_INTEGRAND != 0) { // the closure ran on the host over the dumped draws
             const i64 hidx = wi.lb * a.neval_per_block + n;
@@ -987,9 +1176,12 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             Cfg::integrand(s.x, w, a.ud, -1); // vegas/montecarlo.jl:140-144
         }
         extra[Cols<Cfg>::NEVAL - Cfg::NOBS] += 1.0; // config.neval += 1   :118
-        const bool domeasure = mrem == 0; // :148
-        mrem += mstep;
-        mrem = mrem >= mfreq ? mrem - mfreq : mrem;
+        bool domeasure = true; // :148
+        if constexpr (!MF1) {
+            domeasure = mrem == 0;
+            mrem += mstep;
+            mrem = mrem >= mfreq ? mrem - mfreq : mrem;
+        }
         if constexpr (Cfg::HOST_MEASURE != 0) { // measure(vars, obs, relative_weights, config) runs on the host over this launch's samples (:156-161)
             const i64 hidx = wi.lb * a.neval_per_block + n;
             static_for<0, Cfg::NDRAW>([&](auto K) { a.host_mx[decltype(K)::value * a.tile_stride + hidx] = s.x[decltype(K)::value]; });
@@ -1011,7 +1203,9 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             wh[i] = wj * wj;                      // :180
         });
 #ifndef MCI_ABL_NOHIST
-        if constexpr (!NOHIST) hist_update<Cfg, decltype(TT)::value>(s, wh, sH, a.ghist, tile);
+        if (defer_wh) { // pipelined loop: the adds of this sample are issued during the next sample's draws (draw_sample_pipe)
+            static_for<0, Cfg::NI>([&](auto I) { defer_wh[decltype(I)::value] = wh[decltype(I)::value]; });
+        } else if constexpr (!NOHIST) hist_update<Cfg, decltype(TT)::value>(s, wh, sH, a.ghist, tile);
 #else
         acc[0] += wh[0] * 1e-300;
 #endif
@@ -1109,6 +1303,34 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             draw_sample<Cfg, EC, KV, DPC>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
             process(n, s);
         }
+    } else if constexpr (pipe_eligible<Cfg>() && !SPLIT && !EC && DPC == 2) {
+        // two samples per trip, the two pending records swapping roles: with one record the bins of the sample just drawn would be
+        // copied into it on every trip (16 v_mov_b32 on the headline loop)
+        PendingHist<Cfg> pa, pb; // nothing pending yet: a zero weight on bin 0
+        static_for<0, Cfg::NDRAW>([&](auto K) { pa.bin[decltype(K)::value] = 0; });
+        static_for<0, Cfg::NI>([&](auto I) { pa.wh[decltype(I)::value] = 0.0; });
+        auto flush = [&](const PendingHist<Cfg> &q) { // a lane's last sample
+            static_for<0, Cfg::NDRAW>([&](auto K) { hist_add_draw<Cfg, decltype(K)::value>(q.bin[decltype(K)::value], q.wh, sH); });
+        };
+        i64 n = (i64)slice * T + tid;
+        for (; n + stride < a.neval_per_block; n += 2 * stride) {
+            {
+                Sample<Cfg> s;
+                draw_sample_pipe<Cfg, KV>(keys, stream, (u64)(B * a.neval_per_block + n), s, pa, pb, sH);
+                process(n, s, pb.wh);
+            }
+            {
+                Sample<Cfg> s;
+                draw_sample_pipe<Cfg, KV>(keys, stream, (u64)(B * a.neval_per_block + n + stride), s, pb, pa, sH);
+                process(n + stride, s, pa.wh);
+            }
+        }
+        if (n < a.neval_per_block) {
+            Sample<Cfg> s;
+            draw_sample_pipe<Cfg, KV>(keys, stream, (u64)(B * a.neval_per_block + n), s, pa, pb, sH);
+            process(n, s, pb.wh);
+            flush(pb);
+        } else flush(pa);
     } else {
         for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
             Sample<Cfg> s;
@@ -1117,8 +1339,18 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
         }
     }
     };
-    if constexpr (Cfg::NTILE == 1 || SPLIT) run(IC<0>{});
-    else static_for<0, Cfg::NTILE>([&](auto TT) { if (tile == decltype(TT)::value) run(TT); });
+#ifndef MCI_MF1_LOOP
+#define MCI_MF1_LOOP 1
+#endif
+    auto run_mf = [&](auto TT) {
+#if MCI_MF1_LOOP
+        if (mfreq == 1) run(TT, IC<1>{});
+        else
+#endif
+            run(TT, IC<0>{});
+    };
+    if constexpr (Cfg::NTILE == 1 || SPLIT) run_mf(IC<0>{});
+    else static_for<0, Cfg::NTILE>([&](auto TT) { if (tile == decltype(TT)::value) run_mf(TT); });
     __syncthreads();
     flush_workgroup<Cfg, L, !NOHIST>(a, smem, acc, extra, wi.rowid, tile);
 }

@@ -195,6 +195,30 @@ inline long kernel_note_value(const std::vector<char> &code, const char *kernel,
     if (v[0] == 0xce && left > 4) return ((long)v[1] << 24) | ((long)v[2] << 16) | ((long)v[3] << 8) | v[4];
     return -1;
 }
+// largest .group_segment_fixed_size (static LDS bytes) over the kernels of a code object; -1 when the note does not have the expected
+// shape.  The sample-batch kernels address their first LDS table from address 0 (mci_device.h draw_leaf, MCI_LDS_ABS): that holds as
+// long as no kernel of the translation unit declares static LDS, which is what this reads back.
+inline long max_static_lds_bytes(const std::vector<char> &code) {
+    const std::string blob(code.begin(), code.end());
+    const char *keyname = ".group_segment_fixed_size";
+    std::string key;
+    key += (char)(0xa0 | strlen(keyname));
+    key += keyname;
+    long worst = -1;
+    for (size_t k = blob.find(key); k != std::string::npos; k = blob.find(key, k + 1)) {
+        if (k + key.size() >= blob.size()) return -1;
+        const unsigned char *v = (const unsigned char *)blob.data() + k + key.size();
+        const size_t left = blob.size() - (k + key.size());
+        long val;
+        if (v[0] <= 0x7f) val = v[0];
+        else if (v[0] == 0xcc && left > 1) val = v[1];
+        else if (v[0] == 0xcd && left > 2) val = ((long)v[1] << 8) | v[2];
+        else if (v[0] == 0xce && left > 4) val = ((long)v[1] << 24) | ((long)v[2] << 16) | ((long)v[3] << 8) | v[4];
+        else return -1;
+        if (val > worst) worst = val;
+    }
+    return worst;
+}
 inline long kernel_scratch_bytes(const std::vector<char> &code, const char *kernel) { return kernel_note_value(code, kernel, ".private_segment_fixed_size"); }
 // .vgpr_count of one kernel (sorts after .name like .private_segment_fixed_size does)
 inline long kernel_vgprs(const std::vector<char> &code, const char *kernel) { return kernel_note_value(code, kernel, ".vgpr_count"); }

@@ -129,9 +129,11 @@ def _branch_target(addr, mn, ops):
 
 
 def hot_loop(insts):
-    """(first index, last index) of the sample loop: the SMALLEST backward-branch span that holds at least 80 % of the kernel's
+    """(first index, last index) of the sample loop: the SMALLEST backward-branch span that holds at least 25 % of the kernel's
     Philox multiplies (v_mad_u64_u32) -- every sample/chain-step loop draws its uniforms inside; block layout may put other,
-    wider backward branches around it"""
+    wider backward branches around it.  The :vegas kernels carry the loop twice, specialised on measurefreq == 1 (mci_device.h
+    vegas_batch) and the pipelined form of it holds two samples per trip, followed by a straight-line tail: the smaller of the two
+    loops is the measurefreq == 1 form, the one the BASELINE configurations run"""
     index = {a: i for i, (a, _, _) in enumerate(insts)}
     mads = [i for i, (_, mn, _) in enumerate(insts) if mn == "v_mad_u64_u32"]
     best = None
@@ -141,7 +143,7 @@ def hot_loop(insts):
             continue
         j = index[t]
         inside = sum(1 for m in mads if j <= m <= i)
-        if mads and inside < 0.8 * len(mads):
+        if mads and inside < 0.25 * len(mads):
             continue
         if best is None or i - j < best[1] - best[0]:
             best = (j, i)
@@ -150,9 +152,11 @@ def hot_loop(insts):
     return best
 
 
-def loop_mix(path, kernel="mci_vegas_batch"):
-    """static per-trip instruction counts of the kernel's hot loop:
-    {"classes": {class: n}, "pipes": {pipe: n}, "mnemonics": {mn: n}, "inner_backward_branches": k, "span": (lo, hi)}"""
+def loop_mix(path, kernel="mci_vegas_batch", draws_per_sample=None):
+    """static per-SAMPLE instruction counts of the kernel's hot loop:
+    {"classes": {class: n}, "pipes": {pipe: n}, "mnemonics": {mn: n}, "inner_backward_branches": k, "span": (lo, hi),
+     "samples_per_trip": t}.  With draws_per_sample given, a loop body that holds several samples (the pipelined :vegas loop takes two
+    per trip) is recognised by its v_cvt_i32_f64 count -- one per Continuous draw -- and every count is divided by t."""
     insts = disassemble(path)[kernel]
     lo, hi = hot_loop(insts)
     classes, pipes, mns, inner = {}, {}, {}, 0
@@ -167,8 +171,16 @@ def loop_mix(path, kernel="mci_vegas_batch"):
         classes[cls] = classes.get(cls, 0) + 1
         pipes[pipe] = pipes.get(pipe, 0) + 1
         mns[mn] = mns.get(mn, 0) + 1
+    spt = 1
+    if draws_per_sample:
+        spt = max(1, int(round(sum(n for mn, n in mns.items() if mn.startswith("v_cvt_i32_f64")) / float(draws_per_sample) - 0.2)))
+    if spt > 1:
+        def per_sample(d):
+            return {k: (v // spt if v % spt == 0 else v / float(spt)) for k, v in d.items()}
+        classes, pipes, mns = per_sample(classes), per_sample(pipes), per_sample(mns)
     return {"kernel": kernel, "classes": classes, "pipes": pipes, "mnemonics": mns, "inner_backward_branches": inner,
-            "span": (insts[lo][0], insts[hi][0]), "loop_instructions": hi - lo + 1, "kernel_instructions": len(insts)}
+            "span": (insts[lo][0], insts[hi][0]), "loop_instructions": hi - lo + 1, "kernel_instructions": len(insts),
+            "samples_per_trip": spt}
 
 
 def resources(path):

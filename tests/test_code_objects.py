@@ -78,9 +78,10 @@ def test_split_all_pass_falls_back_to_512_threads_when_the_integrand_needs_every
 def test_c2_sample_loop_mix():
     """the 16-D Gaussian's sample loop: one ds_read_b128 + one ds_add_f64 per draw, Philox as v_mad_u64_u32 + v_bitop3_b32
     (no two-instruction xor3), straight-line body (no inner loops)"""
-    mix = isa_mix.loop_mix(_code_object(*[b for b in BASELINE if b[0] == "c2"][0][1:5]), "mci_vegas_batch")
+    mix = isa_mix.loop_mix(_code_object(*[b for b in BASELINE if b[0] == "c2"][0][1:5]), "mci_vegas_batch", draws_per_sample=16)
     m, c = mix["mnemonics"], mix["classes"]
-    assert mix["inner_backward_branches"] == 0
+    assert mix["inner_backward_branches"] == 0 and mix["samples_per_trip"] == 2     # the pipelined loop: two samples per trip
+    assert m["v_lshlrev_b32_e32"] == 16 and m.get("v_mov_b32_e32", 0) <= 2          # table offsets as VOP2 shifts, no bin copies
     assert m["ds_read_b128"] == 16 and m["ds_add_f64"] == 16 and mix["pipes"]["lds"] == 32
     assert 120 <= m["v_mad_u64_u32"] <= 160 and 120 <= m["v_bitop3_b32"] <= 160     # 8 calls x 10 rounds x 2, minus shared first-round terms
     assert m.get("v_xor_b32_e32", 0) < 10 and m["v_alignbit_b32"] == 32              # u12(): two alignbits per draw
@@ -97,8 +98,8 @@ def test_c2_sample_loop_mix():
 def test_histogram_copies_follow_the_placement_rule_and_the_register_budget():
     """mci_device.h hslot: 8 interleaved histogram copies and two 512-thread workgroups per CU for the 16-D Gaussian (80.8 KB of LDS);
     the interleaved-copy row of the issue-cost table prices its ds_add_f64; a 1-D integrand keeps the plain layout (nothing to gain),
-    and so do a kernel that needs more than 128 VGPRs (two 512-thread workgroups would not share a CU) and one that needs at most 96
-    (it runs five or six waves per SIMD without the copies' LDS)"""
+    and so do a kernel that needs more than 128 VGPRs (two 512-thread workgroups would not share a CU) and one that needs at most 80
+    (it runs six or more waves per SIMD without the copies' LDS)"""
     c2 = [b for b in BASELINE if b[0] == "c2"][0]
     eng = mci.Engine(c2[1](), c2[2](), device=-1)
     assert eng.histogram_copies() == 8
@@ -106,7 +107,7 @@ def test_histogram_copies_follow_the_placement_rule_and_the_register_budget():
     assert eng.histogram_copies() == 8
     res = isa_mix.resources(eng.code_object("vegas"))["mci_vegas_batch"]
     assert res["max_threads"] == 512 and res["vgpr"] <= 128 and res["scratch"] == 0
-    mix = isa_mix.loop_mix(eng.code_object("vegas"), "mci_vegas_batch")
+    mix = isa_mix.loop_mix(eng.code_object("vegas"), "mci_vegas_batch", draws_per_sample=16)
     costs = {"ds_read_b128 (random": 21.6, "ds_add_f64 (random bins, 999-bin table)": 41.0, "ds_add_f64 (random bins, 8 interleaved copies)": 26.9}
     assert isa_mix.issue_cycles(mix, costs, default_valu=1.8, hist_copies=8)["lds"] == pytest.approx(16 * 21.6 + 16 * 26.9)
     assert isa_mix.issue_cycles(mix, costs, default_valu=1.8)["lds"] == pytest.approx(16 * 21.6 + 16 * 41.0)
@@ -114,14 +115,21 @@ def test_histogram_copies_follow_the_placement_rule_and_the_register_budget():
     one = mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]]), mci.Integrand("w[0] = log(x[0]) / sqrt(x[0]);"), device=-1)
     assert one.histogram_copies() == 1
     one.close()
-    # a light kernel (C5 :vegas: 78 VGPRs) runs six waves per SIMD in 256-thread workgroups: the copies would cap it at four
-    c5 = [b for b in BASELINE if b[0] == "c5"][0]
-    light = mci.Engine(c5[1](), c5[2](), device=-1)
-    assert light.histogram_copies() == 4          # what fits next to its tables in 80 KB
+    # a light kernel (6 draws, 63 VGPRs) runs six or more waves per SIMD in 256-thread workgroups: the copies would cap it at four
+    light = mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[6]]),
+                       mci.Integrand("double q = 0.0; for (int i = 0; i < 6; ++i) q += x[i] * x[i]; w[0] = q;"), device=-1)
+    assert light.histogram_copies() == 8          # the rule's choice before the kernel exists
     light.compile("vegas")
     res = isa_mix.resources(light.code_object("vegas"))["mci_vegas_batch"]
-    assert res["vgpr"] <= 96 and light.histogram_copies() == 1 and res["max_threads"] == 256, res
+    assert res["vgpr"] <= 80 and light.histogram_copies() == 1 and res["max_threads"] == 256, res
     light.close()
+    # C5 :vegas (12 draws on one grid, 4 integrands): the copies that fit next to its tables, two 512-thread workgroups per CU
+    c5 = [b for b in BASELINE if b[0] == "c5"][0]
+    mid = mci.Engine(c5[1](), c5[2](), device=-1)
+    mid.compile("vegas")
+    res = isa_mix.resources(mid.code_object("vegas"))["mci_vegas_batch"]
+    assert 80 < res["vgpr"] <= 128 and mid.histogram_copies() == 4 and res["max_threads"] == 512 and res["scratch"] == 0, res
+    mid.close()
     # an integrand that keeps every draw and every intermediate alive: more than 128 VGPRs -> the plain layout, 256 threads
     body = """double m = 0.0; for (int i = 0; i < 16; ++i) m += x[i]; m *= 0.0625;
               double y[16], q = 0.0; for (int i = 0; i < 16; ++i) { y[i] = sin(x[i] - m) * cos(x[(i + 7) % 16] + m); q += y[i]; }

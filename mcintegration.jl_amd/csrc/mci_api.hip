@@ -919,9 +919,18 @@ static int compile_solver(mci_problem *p, int solver) {
     std::string log;
     bool cached = false;
     int T = solver == MCI_VEGAS && p->threads_vegas ? p->threads_vegas : p->threads;
-    int rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]);
+    // The copy plan runs four waves per SIMD whatever the kernel needs up to 128 VGPRs, so registers below that line are free: the
+    // pipelined sample loop (mci_device.h draw_sample_pipe) first asks for its Philox round keys in VGPRs (20 registers; the all-VGPR
+    // v_bitop3_b32 issues faster than the form with an SGPR key: C2 1.358 -> 1.331 ms per 1e8 samples) and falls back to SGPR keys
+    // when that would cross the line
+    static const char *const kVgprKeys = "#define MCI_PIPE_VGPR_KEYS 1\n";
+    int rc = mcijit::compile(hcopy_plan ? kVgprKeys + src : src, T, code, log, cached, &p->code_object[solver]);
     if (rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
-    const long hc_vgprs = hcopy_plan ? mcijit::kernel_vgprs(code, "mci_vegas_batch") : 0;
+    long hc_vgprs = hcopy_plan ? mcijit::kernel_vgprs(code, "mci_vegas_batch") : 0;
+    if (hcopy_plan && (hc_vgprs > 128 || mcijit::kernel_scratch_bytes(code, "mci_vegas_batch") != 0)) {
+        if ((rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
+        hc_vgprs = mcijit::kernel_vgprs(code, "mci_vegas_batch");
+    }
     if (hcopy_plan && (hc_vgprs > 128 || hc_vgprs <= 80)) {
         // Histogram copies pay when the kernel runs four or five waves per SIMD either way (81..128 VGPRs: two 512-thread workgroups
         // share a CU).  More registers: two such workgroups no longer fit.  Fewer: the plain layout runs six or more waves per SIMD

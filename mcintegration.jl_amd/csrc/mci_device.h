@@ -47,9 +47,10 @@ struct u32x4 { u32 x, y, z, w; };
 #ifndef MCI_PHILOX_ROUNDS
 #define MCI_PHILOX_ROUNDS 10
 #endif
-// Round keys in VGPRs for kernels with at most this many draws.  Measured on MI355X (tools/ab_c2.py): the 20 extra registers
-// cost C2 its fourth wave per SIMD (132 VGPRs) and the sample loop is LDS-bound anyway: 1.754 ms against 1.715 ms with the keys
-// in SGPRs; no difference on C5 :vegas and on 16 independent grids.  Off by default.
+// Round keys in VGPRs for kernels with at most this many draws (diagnostic switch, off by default).  History on MI355X (tools/ab_c2.py):
+// with the compiler's own schedule of the C2 loop the 20 extra registers cost the fourth wave per SIMD (132 VGPRs) and bought nothing
+// (1.754 against 1.715 ms; the loop's VALU and LDS stretches did not overlap then); on the pipelined loop, which is bound by VALU issue
+// and has the registers to spare, they are worth 2 % (1.358 -> 1.331 ms) and the host asks for them through MCI_PIPE_VGPR_KEYS.
 #ifndef MCI_VGPR_KEYS_MAX_DRAWS
 #define MCI_VGPR_KEYS_MAX_DRAWS 0
 #endif
@@ -1155,7 +1156,11 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 
     // measurement cadence (n + 1) % measurefreq == 0 (:148) without a 64-bit division in the sample loop: the remainder is
     // carried along, n advances by `stride` per trip
-    constexpr bool KV = Cfg::NDRAW <= MCI_VGPR_KEYS_MAX_DRAWS; // round keys in VGPRs: 20 registers, affordable with few draws in flight
+#ifndef MCI_PIPE_VGPR_KEYS
+#define MCI_PIPE_VGPR_KEYS 0 // (set by the host for the first compile of a copy-plan kernel: mci_api.hip compile_solver)
+#endif
+    // round keys in VGPRs: 20 registers, for the pipelined loop when the host found them free
+    constexpr bool KV = Cfg::NDRAW <= MCI_VGPR_KEYS_MAX_DRAWS || (MCI_PIPE_VGPR_KEYS != 0 && pipe_eligible<Cfg>() && !SPLIT && Cfg::EC_DOUBLES == 0);
     constexpr int DPC = Cfg::RNG_BITS == 32 ? 4 : 2;           // draws per Philox block of the :vegas sample stream
     const RoundKeys<KV> keys = make_round_keys<KV>((u32)a.seed, (u32)(a.seed >> 32));
     const i64 mfreq = a.measurefreq;

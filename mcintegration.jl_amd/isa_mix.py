@@ -21,7 +21,8 @@ READELF = os.environ.get("MCI_LLVM_READELF", "/opt/rocm/lib/llvm/bin/llvm-readel
 COST_KEY = {
     "valu_b32": "v_xor_b32",
     "valu_b32_3src": "v_alignbit_b32",
-    "valu_bitop3": "v_bitop3_b32",
+    "valu_bitop3": "v_bitop3_b32 (0x96 = xor3, one SGPR",
+    "valu_bitop3_vgpr": "v_bitop3_b32 (three VGPR",
     "valu_mad_u64_u32": "v_mad_u64_u32",
     "valu_mul_u32": "v_mul_lo_u32",
     "valu_b64": "v_lshrrev_b64",
@@ -47,8 +48,8 @@ _THREE_SOURCE_B32 = {"v_alignbit_b32", "v_lshl_add_u32", "v_add_lshl_u32", "v_an
                      "v_max3_u32", "v_med3_u32", "v_alignbyte_b32", "v_fma_f32", "v_mad_u32_u16", "v_sad_u32", "v_lerp_u8"}
 
 
-def classify(mn):
-    """mnemonic -> (pipe, class)"""
+def classify(mn, ops=""):
+    """mnemonic (and operand string) -> (pipe, class)"""
     m = re.sub(r"_(e32|e64|sdwa|dpp)$", "", mn)
     if m.startswith("ds_"):
         if m == "ds_read_b128":
@@ -65,6 +66,11 @@ def classify(mn):
     if not m.startswith("v_"):
         return "other", "other"
     if m == "v_bitop3_b32":
+        # with all three sources in VGPRs the instruction issues at the VOP2 rate, with an SGPR source (a wave-uniform Philox round
+        # key) at the three-source rate: two rows of the issue-cost table
+        srcs = [o.strip() for o in ops.split(",")[1:4]]
+        if len(srcs) == 3 and all(o.startswith("v") for o in srcs):
+            return "valu", "valu_bitop3_vgpr"
         return "valu", "valu_bitop3"
     if m == "v_mad_u64_u32" or m == "v_mad_i64_i32":
         return "valu", "valu_mad_u64_u32"
@@ -167,7 +173,7 @@ def loop_mix(path, kernel="mci_vegas_batch", draws_per_sample=None):
             inner += 1
         if mn in ("s_nop", "s_waitcnt", "s_endpgm", "s_barrier", "s_sleep"):
             continue
-        pipe, cls = classify(mn)
+        pipe, cls = classify(mn, ops)
         classes[cls] = classes.get(cls, 0) + 1
         pipes[pipe] = pipes.get(pipe, 0) + 1
         mns[mn] = mns.get(mn, 0) + 1
@@ -218,6 +224,9 @@ def issue_cycles(mix, costs, default_valu=None, hist_copies=1):
             for name, c in costs.items():
                 if name.startswith(key):
                     return c
+            short = [name for name in costs if key.startswith(name)]   # a table that has only the bare instruction name
+            if short:
+                return costs[max(short, key=len)]
         return None
     per, tot = {}, {"valu": 0.0, "lds": 0.0}
     base = cost_of("valu_b32") if default_valu is None else default_valu

@@ -147,6 +147,8 @@ def test_branch_targets_and_classes():
     assert isa_mix._branch_target(0x100, "s_cbranch_execnz", "65521") == 0x100 + 4 - 4 * 15
     assert isa_mix._branch_target(0x100, "s_branch", "3") == 0x110
     assert isa_mix.classify("v_bitop3_b32") == ("valu", "valu_bitop3")
+    assert isa_mix.classify("v_bitop3_b32", "v45, v51, v60, s59 bitop3:0x96") == ("valu", "valu_bitop3")
+    assert isa_mix.classify("v_bitop3_b32", "v45, v51, v60, v59 bitop3:0x96") == ("valu", "valu_bitop3_vgpr")
     assert isa_mix.classify("v_fma_f64") == ("valu", "valu_f64_fma")
     assert isa_mix.classify("v_lshl_add_u32") == ("valu", "valu_b32_3src")
     assert isa_mix.classify("v_xor_b32_e32") == ("valu", "valu_b32")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development tool (GPU box): A/B of compile-time variants (MCI_JIT_FLAGS) of the :vegas sample kernel on a BASELINE
-workload: median HIP-event kernel time over 8 launches of 1e8 samples, after 24 launches of warm-up.  usage: ab_c2.py [c2|c2i|c4|c5v] 'flags' 'flags' ..."""
+workload: median HIP-event kernel time over 8 launches of 1e8 samples, after 24 launches of warm-up.  usage: ab_c2.py [c2|c2i|c4|c5v|g8|g12] 'flags' 'flags' ..."""
 import json
 import os
 import subprocess
@@ -19,6 +19,9 @@ if which == "c2":
     cfg, f = mci.Configuration(var=mci.Continuous(-L, L), dof=[[16]], seed=1), mci.catalog.gaussian(16)
 elif which == "c2i":
     cfg, f = mci.Configuration(var=mci.Continuous([(-L, L)] * 16), dof=[[1]], seed=1), mci.catalog.gaussian(16)
+elif which in ("g8", "g12"):     # the headline integrand in 8 / 12 dimensions (lighter kernels: where the histogram-copy rule flips)
+    d = int(which[1:])
+    cfg, f = mci.Configuration(var=mci.Continuous(-L, L), dof=[[d]], seed=1), mci.catalog.gaussian(d)
 elif which == "c4":
     cfg, f = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=1), mci.catalog.genz_product_peak(32)
 else:

@@ -913,7 +913,10 @@ template <class Cfg, int K> __device__ __forceinline__ void hist_add_draw(int bi
 #define MCI_PIPE 1
 #endif
 #ifndef MCI_PIPE_LAG
-#define MCI_PIPE_LAG 1
+#define MCI_PIPE_LAG (DPC == 4 ? 0 : 1) // blocks between a read and its use: with four reads per block they cover each other (and LAG 1 spills at 1024 threads)
+#endif
+#ifndef MCI_PIPE_32
+#define MCI_PIPE_32 1 // the opt-in 32-bit stream too (four draws per Philox block: four reads and four atomics per stage)
 #endif
 template <class Cfg> struct PendingHist {
     int bin[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
@@ -923,13 +926,13 @@ template <class Cfg> constexpr bool pipe_eligible() {
 #if defined(MCI_ABL_NOTABLE) || defined(MCI_ABL_NOHIST) || defined(MCI_ABL_CHEAPRNG) || !MCI_YN_FMA || !MCI_LDS_ABS
     return false;
 #else
-    return MCI_PIPE != 0 && Cfg::RNG_BITS != 32 && Cfg::NDRAW >= 8 && Cfg::NDRAW <= 16 && all_draws_pair_table<Cfg>() && Cfg::NTILE == 1 &&
+    return MCI_PIPE != 0 && (Cfg::RNG_BITS != 32 || MCI_PIPE_32 != 0) && Cfg::NDRAW >= 8 && Cfg::NDRAW <= 16 && all_draws_pair_table<Cfg>() && Cfg::NTILE == 1 &&
            Mode<Cfg>::HIST_LDS && Cfg::HOST_INTEGRAND == 0 && Cfg::HOST_MEASURE == 0 && Cfg::EC_DOUBLES == 0;
 #endif
 }
-template <class Cfg, bool KV> __device__ __forceinline__ void draw_sample_pipe(const RoundKeys<KV> &keys, u32 stream, u64 index, Sample<Cfg> &s,
-                                                                               const PendingHist<Cfg> &pend, PendingHist<Cfg> &next, double *sH) {
-    constexpr int DPC = 2, NCH = (Cfg::NDRAW + DPC - 1) / DPC, LAG = MCI_PIPE_LAG;
+template <class Cfg, bool KV, int DPC> __device__ __forceinline__ void draw_sample_pipe(const RoundKeys<KV> &keys, u32 stream, u64 index, Sample<Cfg> &s,
+                                                                                        const PendingHist<Cfg> &pend, PendingHist<Cfg> &next, double *sH) {
+    constexpr int NCH = (Cfg::NDRAW + DPC - 1) / DPC, LAG = MCI_PIPE_LAG;
     constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
     const u32 ilo = (u32)index, ihi = (u32)(index >> 32);
     s.jac = 1.0;
@@ -1308,7 +1311,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             draw_sample<Cfg, EC, KV, DPC>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
             process(n, s);
         }
-    } else if constexpr (pipe_eligible<Cfg>() && !SPLIT && !EC && DPC == 2) {
+    } else if constexpr (pipe_eligible<Cfg>() && !SPLIT && !EC) {
         // two samples per trip, the two pending records swapping roles: with one record the bins of the sample just drawn would be
         // copied into it on every trip (16 v_mov_b32 on the headline loop)
         PendingHist<Cfg> pa, pb; // nothing pending yet: a zero weight on bin 0
@@ -1321,18 +1324,18 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
         for (; n + stride < a.neval_per_block; n += 2 * stride) {
             {
                 Sample<Cfg> s;
-                draw_sample_pipe<Cfg, KV>(keys, stream, (u64)(B * a.neval_per_block + n), s, pa, pb, sH);
+                draw_sample_pipe<Cfg, KV, DPC>(keys, stream, (u64)(B * a.neval_per_block + n), s, pa, pb, sH);
                 process(n, s, pb.wh);
             }
             {
                 Sample<Cfg> s;
-                draw_sample_pipe<Cfg, KV>(keys, stream, (u64)(B * a.neval_per_block + n + stride), s, pb, pa, sH);
+                draw_sample_pipe<Cfg, KV, DPC>(keys, stream, (u64)(B * a.neval_per_block + n + stride), s, pb, pa, sH);
                 process(n + stride, s, pa.wh);
             }
         }
         if (n < a.neval_per_block) {
             Sample<Cfg> s;
-            draw_sample_pipe<Cfg, KV>(keys, stream, (u64)(B * a.neval_per_block + n), s, pa, pb, sH);
+            draw_sample_pipe<Cfg, KV, DPC>(keys, stream, (u64)(B * a.neval_per_block + n), s, pa, pb, sH);
             process(n, s, pb.wh);
             flush(pb);
         } else flush(pa);

@@ -154,3 +154,18 @@ def test_branch_targets_and_classes():
     assert isa_mix.classify("v_xor_b32_e32") == ("valu", "valu_b32")
     assert isa_mix.classify("ds_add_f64") == ("lds", "lds_add_f64")
     assert isa_mix.classify("global_load_dwordx4") == ("vmem", "vmem")
+
+
+@pytest.mark.parametrize("bits,rounds,threads,copies", [(52, 10, 512, 8), (52, 7, 512, 8), (32, 10, 512, 8), (32, 7, 1024, 16)])
+def test_headline_kernel_of_every_stream_is_pipelined_and_does_not_spill(bits, rounds, threads, copies):
+    """the 16-D Gaussian under the default stream and the three opt-in ones: the pipelined sample loop (two samples per trip), the
+    histogram-copy plan the library picks for that stream, no scratch"""
+    c2 = [b for b in BASELINE if b[0] == "c2"][0]
+    eng = mci.Engine(c2[1](), c2[2](), device=-1, rng_bits=bits, rng_rounds=rounds)
+    eng.compile("vegas")
+    res = isa_mix.resources(eng.code_object("vegas"))["mci_vegas_batch"]
+    mix = isa_mix.loop_mix(eng.code_object("vegas"), "mci_vegas_batch", draws_per_sample=16)
+    assert res["scratch"] == 0 and res["vgpr_spill"] == 0 and res["vgpr"] <= 128 and res["lds"] == 0, res
+    assert res["max_threads"] == threads and eng.histogram_copies() == copies
+    assert mix["samples_per_trip"] == 2 and mix["mnemonics"]["ds_read_b128"] == 16 and mix["mnemonics"]["ds_add_f64"] == 16
+    eng.close()

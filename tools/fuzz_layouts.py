@@ -75,12 +75,47 @@ def random_case(rng):
     return tuple(var), oleaves, dof, "\n".join(lines), len(draws)
 
 
+def pipe_case(rng):
+    """layouts the software-pipelined :vegas loop takes (mci_device.h pipe_eligible): Continuous pools only, 8..16 draws in all, grids small
+    enough for LDS pair tables; ragged dof tables (padding probabilities), adapt on/off, 1-4 integrands"""
+    while True:
+        npool = int(rng.integers(1, 4))
+        ni = int(rng.integers(1, 5))
+        dof = [[int(rng.integers(0, 9)) for _ in range(npool)] for _ in range(ni)]
+        for i in range(ni):
+            if sum(dof[i]) == 0:
+                dof[i][int(rng.integers(0, npool))] = 1
+        maxdof = [max(d[v] for d in dof) for v in range(npool)]
+        if 8 <= sum(maxdof) <= 16 and min(maxdof) > 0:
+            break
+    var, oleaves = [], []
+    for v in range(npool):
+        lo, hi = float(rng.uniform(-2, 0)), float(rng.uniform(0.5, 3))
+        ninc = int(rng.choice([17, 100, 257, 1000]))
+        alpha = float(rng.choice([1.0, 2.0, 3.0]))
+        adapt = bool(rng.integers(0, 5) > 0)
+        var.append(mci.Continuous(lo, hi, alpha=alpha, ninc=ninc, adapt=adapt))
+        oleaves.append(dict(kind=0, pool=v, lower=lo, upper=hi, npts=ninc, alpha=alpha, adapt=adapt))
+    draws = [(v, s) for v in range(npool) for s in range(maxdof[v])]
+    lines = []
+    for i in range(ni):
+        own = [k for k, (v, s) in enumerate(draws) if s < dof[i][v]]
+        coef = rng.uniform(0.2, 1.5, size=len(own))
+        arg = " + ".join("%.6f * x[%d]" % (c, k) for c, k in zip(coef, own))
+        sign = "-" if rng.integers(0, 4) == 0 else ""
+        lines.append("w[%d] = %s(%.3f + 0.5 * cos(%s) + 0.05 * x[%d] * x[%d]);" % (i, sign, 0.4 + 0.3 * i, arg, own[0], own[-1]))
+    return tuple(var), oleaves, dof, "\n".join(lines), len(draws)
+
+
+PIPE_MODE = False
+
+
 def run_case(case_id):
     rng = np.random.default_rng(7000 + case_id)
-    var, oleaves, dof, body, ndraw = random_case(rng)
+    var, oleaves, dof, body, ndraw = (pipe_case if PIPE_MODE else random_case)(rng)
     rounds = int(rng.choice([10, 10, 7]))
     nblk = int(rng.integers(1, 6))
-    nepb = int(rng.choice([600, 2400, 5000, 12345]))
+    nepb = int(rng.choice([600, 2400, 5000, 12345] if not PIPE_MODE else [1, 2, 255, 513, 2400, 12345, 40001]))
     nchain = int(rng.choice([1, 8, 64]))
     mfreq = int(rng.choice([1, 1, 3]))
     it = int(rng.integers(0, 50))
@@ -88,11 +123,16 @@ def run_case(case_id):
         case_id, len(var), len(dof), ndraw, rounds, nblk, nepb, nchain, mfreq)
     oracle.set_rng_rounds(rounds)
     cfg = mci.Configuration(var=var, dof=dof, seed=SEED)
-    eng = mci.Engine(cfg, mci.Integrand(body), rng_rounds=rounds)
+    bits = int(rng.choice([52, 52, 32])) if PIPE_MODE else 52
+    eng = mci.Engine(cfg, mci.Integrand(body), rng_rounds=rounds, **({"rng_bits": 32} if bits == 32 else {}))
     assert eng.ndraw == ndraw, what
     fn = oracle.compile_c_integrand(body)
-    for solver, osolver in (("vegas", oracle.VEGAS), ("vegasmc", oracle.VEGASMC), ("mcmc", oracle.MCMC)):
+    solvers = (("vegas", oracle.VEGAS),) if PIPE_MODE else (("vegas", oracle.VEGAS), ("vegasmc", oracle.VEGASMC), ("mcmc", oracle.MCMC))
+    what += " bits=%d" % bits
+    for solver, osolver in solvers:
         ocfg = oracle.Config(oleaves, dof)
+        if bits == 32:
+            ocfg.set_rng_bits(32)
         nc = nchain if nchain <= nepb else 1
         got = eng.iteration(solver, nepb, 0, nblk, iteration=it, seed=SEED, measurefreq=mfreq, nchain=nc)
         ref = ocfg.iteration(osolver, fn, None, nepb, 0, nblk, it, SEED, measurefreq=mfreq, nchain=nc)
@@ -100,6 +140,8 @@ def run_case(case_id):
         if solver == "mcmc":
             np.testing.assert_array_equal(eng.hold_histogram(), ocfg.hold_hist, err_msg="%s dof=%s" % (what, dof))
     ocfg = oracle.Config(oleaves, dof)
+    if bits == 32:
+        ocfg.set_rng_bits(32)
     r = eng.integrate("vegas", neval=24000, niter=3, block=8, seed=SEED)
     o = ocfg.integrate(oracle.VEGAS, fn, None, neval=24000, niter=3, block=8, seed=SEED)
     np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6, err_msg=what + " (3 iterations of :vegas)")
@@ -108,6 +150,9 @@ def run_case(case_id):
 
 
 if __name__ == "__main__":
+    if "--pipe" in sys.argv:   # only layouts of the pipelined :vegas loop, :vegas only, odd launch sizes, both stream widths
+        sys.argv.remove("--pipe")
+        PIPE_MODE = True
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     oracle.build()

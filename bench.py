@@ -199,6 +199,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
 
+    # stdout carries the JSON line and nothing else: whatever the libraries print there on the way (RCCL's start-up banner, gloo's
+    # connection notes) goes to stderr -- file descriptor 1 points at stderr until the line is written to the saved descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -430,8 +436,8 @@ def main():
                 out["estimate"]["vs_cpu"] = {"z_per_seed": [round(z, 3) for z in zs], "chi2": round(c2, 3), "dof": len(zs), "p_value": pval,
                                              "consistent": None if pval is None else bool(pval > 0.01)}
         import ctypes
-        ctypes.CDLL(None).fflush(None)   # RCCL's start-up banner sits in the C stdio buffer: the JSON line stays the last line of stdout
-        print(json.dumps(out), flush=True)
+        ctypes.CDLL(None).fflush(None)   # (the C stdio buffer of this process: RCCL's banner leaves through the redirected descriptor)
+        print(json.dumps(out), file=json_out, flush=True)
     # orderly release while the HIP runtime is still up: problem, then stream + RCCL communicator, then torch's group
     if hasattr(eng, "close"):
         eng.close()

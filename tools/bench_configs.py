@@ -25,7 +25,7 @@ def run(name, cfg, f, solver, neval, exact, measure=None, niter_train=5, niter=5
     dev = (r["mean"] - np.atleast_1d(exact)) / r["stdev"]
     print("%-28s mode=%d lds=%6d B  %8.1f Msamples/s  kernel %.3f ms (wg=%d,th=%d)  mean=%s +- %s  dev_sigma=%s" % (
         name, eng.table_mode, eng.lds_bytes, neval * niter / r["seconds"] / 1e6, float(np.median(ms)), wg, th,
-        np.array2string(r["mean"], precision=8), np.array2string(r["stdev"], precision=2), np.array2string(dev, precision=2)), flush=True)
+        np.array2string(r["mean"], precision=8), np.array2string(r["stdev"], formatter={"float_kind": lambda v: "%.2e" % v}), np.array2string(dev, precision=2)), flush=True)
 
 
 if __name__ == "__main__":

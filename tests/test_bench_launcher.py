@@ -24,6 +24,7 @@ def _run(args, extra_env=None, timeout=300):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.stdout.strip().splitlines() == lines, p.stdout[-2000:]   # stdout is the JSON line and nothing else (library chatter goes to stderr)
     assert len(lines) == 1, p.stdout[-2000:]   # rank 0 prints ONE line
     return json.loads(lines[-1])
 
@@ -68,6 +69,7 @@ def test_launched_under_torch_distributed_run_it_does_not_spawn_again(oracle):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.stdout.strip().splitlines() == lines, p.stdout[-2000:]   # stdout is the JSON line and nothing else (library chatter goes to stderr)
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["comm"]["ranks"] == 2 and [r["blocks"] for r in out["comm"]["per_rank"]] == [[0, 16], [16, 32]]
@@ -86,6 +88,7 @@ def test_two_ranks_share_one_gpu_through_the_real_engine():
                         "--neval-per-gpu", "2e7", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.stdout.strip().splitlines() == lines, p.stdout[-2000:]   # stdout is the JSON line and nothing else (library chatter goes to stderr)
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
     assert "dry_run" not in out and out["n_gpus"] == 2 and out["value"] > 1000.0

@@ -26,7 +26,7 @@ elif [ "$WHAT" = "c5" ]; then        # BASELINE configs[4]: 4 integrals on a 12-
   CMD="python tools/mcmc_prof.py 0"
   KERNELS="mci_mcmc_chains"
 else
-  CMD="python bench.py --steps $STEPS --warmup 5 --passes 3 --no-cpu-baseline"
+  CMD="python bench.py --steps $STEPS --warmup 5 --passes ${PASSES:-40} --no-cpu-baseline"   # ~400 launches: the average is the steady state, not the idle ramp
   KERNELS="mci_vegas_batch"
 fi
 cd /tmp

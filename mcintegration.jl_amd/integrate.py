@@ -22,6 +22,18 @@ def standardize_block(neval, nblock, nworker=1):
     return a.value, b.value
 
 
+def required_positionals(fn, fallback):
+    """positional parameters of a closure that have NO default -- what decides between the reference's two callback forms
+    (`integrand(var, config)` vegas/montecarlo.jl:140-144 | `integrand(idx, var, config)` mcmc/montecarlo.jl:34-36; likewise
+    `measure`).  A defaulted or keyword-only parameter is the closure's own business; `fallback` for callables without a signature."""
+    import inspect
+    try:
+        return len([q for q in inspect.signature(fn).parameters.values()
+                    if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD) and q.default is q.empty])
+    except (TypeError, ValueError):
+        return fallback
+
+
 def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, block=16, verbose=-1, gamma=1.0,
               adapt=True, debug=False, reweight_goal=None, ignore=None, measure=None, measurefreq=1,
               thermal_ratio=0.1, inplace=False, parallel="nothread", print=-1, printio=None, timer=None,
@@ -55,21 +67,12 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     elif callable(integrand) and not isinstance(integrand, (Integrand, HostIntegrand)):
         # a Python closure: host "batch callback" path (vegas: per launch, vegasmc / mcmc: per Markov step).  Three positional
         # parameters = the reference's :mcmc form integrand(idx, var, config) (mcmc/montecarlo.jl:34-36), two = integrand(var, config)
-        import inspect
-        try:
-            npos = len([q for q in inspect.signature(integrand).parameters.values() if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)])
-        except (TypeError, ValueError):
-            npos = 2
-        integrand = HostIntegrand(integrand, indexed=(npos >= 3))
+        # (parameters with a default do not count: `f(x, config, scale=2.0)` is the two-argument form; HostIntegrand(fn, indexed=...) says it explicitly)
+        integrand = HostIntegrand(integrand, indexed=(required_positionals(integrand, 2) >= 3))
     if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
         # a Python closure as measure: host batch-callback path.  Five positional parameters = the reference's :mcmc form
         # measure(idx, var, obs, relative_weight, config) (mcmc/montecarlo.jl:166-169), four = measure(var, obs, weights, config)
-        import inspect
-        try:
-            mpos = len([q for q in inspect.signature(measure).parameters.values() if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)])
-        except (TypeError, ValueError):
-            mpos = 4
-        measure = HostMeasure(measure, indexed=(mpos >= 5))
+        measure = HostMeasure(measure, indexed=(required_positionals(measure, 4) >= 5))
     mkey = None if measure is None else measure.body if isinstance(measure, (Measure, HostMeasure)) else (measure.pool, measure.slot, measure.leaf)
     key = (integrand.body, tuple(integrand.userdata), mkey, device,
            repr(config.neighbor), int(rng_bits), int(rng_rounds))

@@ -188,6 +188,10 @@ def main():
     ap.add_argument("--passes", type=int, default=0, help="timed passes of K steps each; the median pass is `value` (0: at least 3, and as many as fill --min-seconds)")
     ap.add_argument("--min-seconds", type=float, default=5.0, help="with --passes 0: keep timing passes until this much wall time is covered")
     ap.add_argument("--neval-per-gpu", type=float, default=1e8)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): every GPU runs --neval-per-gpu samples and 16 blocks per iteration; strong: ONE problem of "
+                         "--neval-per-gpu samples and 16 blocks per iteration (the reference's default block count, main.jl:74) is split "
+                         "over the GPUs like main.jl:121-122 does (block rounded to a multiple of the rank count)")
     ap.add_argument("--seed", type=int, default=20240229)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rng-bits", type=int, default=52, choices=(52, 32),
@@ -253,17 +257,20 @@ def main():
             dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
             comm, comm_kind = TorchDistComm(), "gloo"
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
+            # The job's control plane (rendezvous, barriers, the max-over-ranks of the pass time, the gathered rank records) is a gloo
+            # group on the host: the ONLY RCCL communicator on a device is then the library's own, created from a 128-byte id that
+            # rank 0 ships through that group -- no second (torch) RCCL instance shares the GPUs with the one on the data path.
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
             comm_kind = os.environ.get("MCI_COMM", "rccl")
             if comm_kind == "rccl":
-                # ncclAllReduce inside the library, on its stream; the 128-byte id travels through torch.distributed.
-                # Every rank must end up with the same reducer: agree on the outcome before using it.
+                # ncclAllReduce inside the library, on its stream.  Every rank must end up with the same reducer: agree on the
+                # outcome before using it.
                 err = None
                 try:
                     comm = RcclComm.from_torch_distributed(local_rank)
                 except Exception as e:  # pragma: no cover - needs a failing RCCL
                     err = e
-                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok.item()) != 1:  # pragma: no cover
                     if rank == 0:
@@ -271,7 +278,9 @@ def main():
                               "RCCL all_reduce on the library's device buffer instead" % err, file=sys.stderr)
                     comm_kind = "torch"
             if comm_kind == "torch":
-                comm = TorchDistComm(tensor_device=dev)  # zero copy, on the library's stream
+                # torch's RCCL group as the reducer (zero copy on the library's device buffer, on the library's stream)
+                nccl_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300), device_id=torch.device("cuda", local_rank))
+                comm = TorchDistComm(group=nccl_group, tensor_device=dev)
 
     def barrier():
         if multi:
@@ -280,9 +289,14 @@ def main():
             torch.cuda.synchronize()
 
     n_gpus = world
-    neval_gpu = int(a.neval_per_gpu)
-    block = 16 * n_gpus
-    neval = neval_gpu * n_gpus
+    if a.scaling == "strong":   # one fixed problem, split over the ranks (main.jl:121-122)
+        neval = int(a.neval_per_gpu)
+        _, block = mci.standardize_block(neval, 16, n_gpus)
+        neval_gpu = neval // n_gpus
+    else:
+        neval_gpu = int(a.neval_per_gpu)
+        block = 16 * n_gpus
+        neval = neval_gpu * n_gpus
     cfg = mci.Configuration(var=mci.Continuous(-L, L), dof=[[D]], seed=a.seed)
     f = mci.catalog.gaussian(D)
 
@@ -317,7 +331,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if multi:
-            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if (dry or comm_kind == "gloo") else dev)
+            t = torch.tensor([dt], dtype=torch.float64)   # (the control-plane group is gloo: host tensors)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         pass_dt.append(dt)
@@ -347,7 +361,14 @@ def main():
 
     # what the communicator itself says about the job: the library's view (mci_comm_rank), every rank's block range
     lib_rank, lib_n = comm.library_ranks() if hasattr(comm, "library_ranks") else (rank, comm.size)
-    mine = {"rank": rank, "comm_rank": lib_rank, "comm_ranks": lib_n, "blocks": [lo, hi], "device": None if dry else local_rank}
+    # this rank's time inside the one exchange step, HIP events around the library's ncclAllReduce (wait for the slowest rank's sample
+    # pass + the latency of an all-reduce of the packed buffer); None for reducers that do not run inside the library
+    ar_ms = None
+    if not dry and hasattr(eng, "comm_times_ms") and isinstance(comm, RcclComm):
+        ct = eng.comm_times_ms(64)
+        ar_ms = round(float(np.mean(ct)), 5) if len(ct) else None
+    mine = {"rank": rank, "comm_rank": lib_rank, "comm_ranks": lib_n, "blocks": [lo, hi], "device": None if dry else local_rank,
+            "allreduce_ms_avg": ar_ms}
     ranks = [mine]
     if multi:
         ranks = [None] * world
@@ -364,17 +385,20 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 16-D unit Gaussian on [-sqrt(50),sqrt(50)]^16, shared-pool "
-                                   "Continuous (1 grid, 999 bins), :vegas, neval=%.0e per GPU per iteration, block=16 per GPU" % neval_gpu,
+                                   "Continuous (1 grid, 999 bins), :vegas, %s" % (
+                                       "neval=%.0e per GPU per iteration, block=16 per GPU" % neval_gpu if a.scaling == "weak" else
+                                       "ONE problem of neval=%.0e per iteration in %d blocks split over %d GPU(s)" % (neval, block, n_gpus)),
                        "neval_per_iteration": neval, "block": block, "rng_bits": a.rng_bits, "rng_rounds": a.rng_rounds},
             "timing": {"passes": len(pass_dt), "ms_per_step_per_pass": [round(x / a.steps * 1e3, 4) for x in pass_dt[:8]] + (["..."] if len(pass_dt) > 8 else []),
                        "ms_per_step_max": round(max(pass_dt) / a.steps * 1e3, 4), "timed_seconds": round(sum(pass_dt), 3),
                        "ms_per_step_min": round(min(pass_dt) / a.steps * 1e3, 4), "value_is": "median pass"},
             "comm": {"kind": comm_kind, "ranks": max(r["comm_ranks"] for r in ranks), "world_size": world,
+                     "control_plane": "gloo" if multi else None, "payload_doubles": getattr(eng, "packed_size", None),
                      "per_rank": ranks, "neval_after_allreduce": neval_reduced},
             "estimate": {"mean": mean, "sigma": err, "chi2_dof": chi2, "exact": EXACT, "iterations": len(means),
                          "deviation_sigma": (mean - EXACT) / err if err > 0 else None,

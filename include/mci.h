@@ -135,7 +135,9 @@ int mci_set_integrand_source(mci_problem *prob, const char *body, const double *
  * solver = MCI_VEGASMC (the reference's default, main.jl:72; the closure sits inside the Markov step, vegas_mc/updates.jl:67-75):
  * the chains of a launch advance in lock step, ONE kernel launch and ONE callback per step, n = the chains of the launch
  * (nblocks * nchain), x = the configurations they propose; same streams and arithmetic as the device-source chains, so both
- * give the same results.  PCIe- and host-bound by construction; not under MCI_MCMC (its step takes device source). */
+ * give the same results.  solver = MCI_MCMC the same way (one launch and one callback per step; the library asks this form for
+ * every integrand and keeps the one the chain needs -- mci_set_integrand_host_indexed is the reference's own :mcmc form).
+ * PCIe- and host-bound by construction. */
 typedef int (*mci_host_integrand_fn)(const double *x, double *w, int64_t n, int32_t ndraw, int32_t nw, void *user);
 int mci_set_integrand_host(mci_problem *prob, mci_host_integrand_fn fn, void *user);
 /* The same for solver = MCI_MCMC, whose closure takes the integrand index first -- `integrand(idx, var, config)`
@@ -157,8 +159,9 @@ int mci_set_measure_source(mci_problem *prob, const char *body);
  * draw-major configurations x[k*stride + i] and relative weights relw[q*stride + i] -- and the callback accumulates the block's
  * observables into obs[nobs] (zeroed; flat over the `obs` kwarg); they then go through the same block merge as device-side
  * observables.  What a record is:
- *   MCI_VEGAS    every sample of the block, relw = weights[q] * padding_probability * jac (:152), zero for samples that
- *                measurefreq skips;
+ *   MCI_VEGAS    every MEASURED sample of the block (those with ne % measurefreq == 0, vegas/montecarlo.jl:148: n = neval_per_block /
+ *                measurefreq records, the skipped samples are squeezed out before the call), relw = weights[q] *
+ *                padding_probability * jac (:152);
  *   MCI_VEGASMC  every MEASURED step of every chain of the block (vegas_mc/montecarlo.jl:213-227: steps j * measurefreq past the
  *                burn-in), chain-major, relw = weights[q] * padding_probability / probability (:220);
  *   MCI_MCMC     the same for mcmc/montecarlo.jl:143-169: relw is zero except for the integrand the chain sits on (:162); a chain
@@ -209,9 +212,11 @@ int mci_check_status(mci_problem *prob);
 int mci_integrate(mci_problem *prob, const mci_integrate_args *args, mci_result *result);
 
 /* ---- state access: res.config.var[i].grid etc. (docs/src/index.md:129) and external reducers ---- */
-/* :mcmc diagnostic of the last launch on this rank: out64[b] = number of chains whose longest holding time h (steps
- * during which a live slot, or the integrand index, did not change; holds still running at the end count) has
- * bit_width(h) == b.  The next automatic chain length is 16 * 2^(top occupied b). */
+/* :mcmc diagnostic of the last launch (summed over the ranks when a communicator is attached: every rank sizes its chains from
+ * the same histogram): out64[b] = number of chains whose longest holding time h (steps during which a live slot, or the
+ * integrand index, did not change; holds still running at the end count) has bit_width(h) == b.  An automatic chain length is
+ * 16 * 2^(top occupied b) of the launch TWO before it (the first two launches: of the first) -- a fixed lag, so that the host
+ * never has to drain the stream between iterations and a run stays reproducible. */
 int mci_get_hold_histogram(mci_problem *prob, uint64_t *out64);
 /* the statistics head [obsSum|obsSqSum|normalization|neval|visited] of the last `nrows` finished
  * iterations (oldest first), nstat = 2*nobs+2+N+1 doubles per row: the per-iteration history that
@@ -271,6 +276,10 @@ int mci_kernel_times_ms(mci_problem *prob, float *ms, int32_t n, int32_t *got, i
  * samples: mode -1 (default) records them for launches of >= 2^20 samples, 0 never, 1 always (mci_kernel_times_ms returns the
  * recorded launches only). */
 int mci_set_kernel_timing(mci_problem *prob, int32_t mode);
+/* HIP-event durations (ms, oldest first, ring of 64) of the per-iteration ncclAllReduce of mci_iteration_reduce on this rank,
+ * recorded under the same rule: the time a rank spends in the one exchange step of the path (main.jl:177-188) -- its own wait for
+ * the slowest rank's sample pass plus the latency of an all-reduce of `packed_size` doubles */
+int mci_comm_times_ms(mci_problem *prob, float *ms, int32_t n, int32_t *got);
 
 /* ---- host-side statistics of the path (pure functions, no GPU needed) ---- */
 void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64_t *nevalperblock,

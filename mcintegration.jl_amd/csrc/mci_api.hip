@@ -53,7 +53,7 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
-const int kNcclFloat64 = 8, kNcclSum = 0; // ncclDouble, ncclSum (rccl.h)
+const int kNcclFloat64 = 8, kNcclUint64 = 5, kNcclSum = 0; // ncclDouble, ncclUint64, ncclSum (rccl.h)
 
 // If the host process already carries an RCCL (PyTorch-ROCm bundles its own and resolves it through its rpath),
 // bind to THAT copy: two RCCL instances in one process would each open their own IPC/proxy state on the same GPUs.
@@ -140,7 +140,6 @@ struct mci_problem {
     double *d_part_pa = nullptr;    // [rows][2*npa] per-workgroup propose | accept tables of the chain solvers
     int64_t cap_pa = 0;
     unsigned long long *d_hold = nullptr; // [64] :mcmc holding-time histogram of the last launch (this rank), see mci_get_hold_histogram
-    bool hold_pending = false;            // d_hold has not been looked at yet
     int64_t hold_max = 0;                 // upper edge of its top occupied bucket; 0: no :mcmc launch seen yet
     // split vegas pass (NTILE > 1): per-sample histogram weights and 16-bit bins of the tiles >= 1
     double *d_tile_w = nullptr;
@@ -198,6 +197,19 @@ struct mci_problem {
     int64_t last_samples = 0; // samples (vegas) or chain steps of the last sample launch on this rank
     static const int64_t kSerialWalkSamples = (int64_t)1 << 26;
     bool train_lds_raised = false; // k_train / k_finish allowed more than 64 KiB of dynamic LDS (large grids)
+    // HIP events around the per-iteration ncclAllReduce (mci_comm_times_ms), recorded under the same rule as the sample launch's
+    std::vector<hipEvent_t> cevs;
+    bool cev_valid[64] = {};
+    int64_t reduces = 0;
+    static const int kCevRing = 64;
+    // :mcmc automatic chain length: the holding-time histogram of launch k is copied to pinned host memory behind the launch (after
+    // an all-reduce over the ranks, so that every rank sizes its chains from the SAME histogram) and is looked at when launch k + 2
+    // is queued -- launch k + 1 is still running then, so the host never drains the stream (mci_integrate keeps queueing
+    // iterations back to back) and the lag is fixed, so a run is reproducible
+    unsigned long long *h_hold = nullptr;   // pinned [2][64]
+    hipEvent_t hold_ev[2] = {nullptr, nullptr};
+    bool hold_inflight[2] = {false, false};
+    int64_t hold_launches = 0;              // :mcmc launches that recorded a histogram
     // last launch
     std::vector<hipEvent_t> evs; // ring of (start, stop) pairs around the sampling kernel, one pair per launch
     int64_t launches = 0;
@@ -259,6 +271,41 @@ int check_status(mci_problem *p) {
     if (st & mci::ST_HIST_NONFINITE) return fail(MCI_ERR_HISTOGRAM, "histogram should be all finite");
     if (st & mci::ST_HIST_NONPOSITIVE) return fail(MCI_ERR_HISTOGRAM, "histogram should be all positive and non-zero");
     return fail(MCI_ERR_HISTOGRAM, "distribution is not all finite");
+}
+
+// :mcmc holding-time histogram of the launch just queued -> (sum over the ranks ->) pinned host slot, behind the launch on the stream
+int hold_publish(mci_problem *p) {
+    hipStream_t st = p->ctx->stream;
+    if (!p->h_hold) {
+        HIPCHK(hipHostMalloc((void **)&p->h_hold, 2 * 64 * sizeof(unsigned long long), hipHostMallocDefault));
+        for (auto &e : p->hold_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (p->ctx->comm) { // every rank sizes its next chains from the same histogram: results do not depend on which rank ran which block
+        int r = g_rccl.AllReduce(p->d_hold, p->d_hold, 64, kNcclUint64, kNcclSum, p->ctx->comm, st);
+        if (r) return fail(MCI_ERR_COMM, "ncclAllReduce (holding times): %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
+    const int slot = (int)(p->hold_launches & 1);
+    HIPCHK(hipMemcpyAsync(p->h_hold + 64 * slot, p->d_hold, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(p->hold_ev[slot], st));
+    p->hold_inflight[slot] = true;
+    p->hold_launches += 1;
+    return MCI_OK;
+}
+
+// before :mcmc launch k with an automatic chain count is sized: take in the histogram of launch max(k - 2, 0).  Launch k - 1 is
+// still running (or queued) when the host waits for k - 2, so the stream never drains; the fixed lag keeps a run reproducible.
+int hold_consume(mci_problem *p) {
+    const int64_t k = p->hold_launches;
+    if (k < 1) return MCI_OK;
+    const int slot = k >= 2 ? (int)((k - 2) & 1) : 0;
+    if (!p->hold_inflight[slot]) return MCI_OK;
+    HIPCHK(hipEventSynchronize(p->hold_ev[slot]));
+    p->hold_inflight[slot] = false;
+    int top = -1;
+    for (int b = 0; b < 64; ++b)
+        if (p->h_hold[64 * slot + b]) top = b;
+    if (top >= 0) p->hold_max = (int64_t)1 << top; // bucket b holds bit_width(h) == b, i.e. h < 2^b
+    return MCI_OK;
 }
 
 void drop_modules(mci_problem *p) {
@@ -737,6 +784,10 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->d_goal) (void)hipFree(p->d_goal);
         if (p->d_part_pa) (void)hipFree(p->d_part_pa);
         if (p->d_hold) (void)hipFree(p->d_hold);
+        if (p->h_hold) (void)hipHostFree(p->h_hold);
+        for (auto &e : p->hold_ev)
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : p->cevs) (void)hipEventDestroy(e);
         if (p->d_loop) (void)hipFree(p->d_loop);
         if (p->d_hx) (void)hipFree(p->d_hx);
         if (p->d_hstep) (void)hipFree(p->d_hstep);
@@ -1093,10 +1144,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // pass nchain explicitly for integrands known to mix fast (C5: 10 Gsteps/s at nchain = 4096).
             // From the second :mcmc launch of a problem on, the length follows what the previous launch measured: 16 x the
             // longest time any chain's slot (or integrand index) went without changing (mci_mcmc_auto_chains).
-            if (p->hold_pending && !p->graph_mode) {
-                uint64_t hh[64];
-                if ((rc = mci_get_hold_histogram(p, hh))) return rc;
-            }
+            if (!p->graph_mode && (rc = hold_consume(p))) return rc;
             nchain = mci_mcmc_auto_chains(nevalperblock, nblocks, nslots, p->ni + 1, p->npool, p->hold_max);
         }
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
@@ -1178,7 +1226,6 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         if (!p->d_hold) HIPCHK(hipMalloc((void **)&p->d_hold, 64 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(p->d_hold, 0, 64 * sizeof(unsigned long long), p->ctx->stream));
         a.hold_hist = p->d_hold;
-        p->hold_pending = true;
     }
     a.status = p->d_status;
     a.tile_w = p->d_tile_w;
@@ -1390,6 +1437,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         }
     } else
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)(solver == MCI_VEGAS ? vegas_lds(p) : p->lds_bytes), st, args, nullptr));
+    if (a.hold_hist && (rc = hold_publish(p))) return rc;
     if (split)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (!p->graph_mode) {
@@ -1418,11 +1466,35 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
                 relw = p->h_mtmp.data();
             }
             if (solver != MCI_MCMC && p->hmeas_idx_fn) p->h_mitmp.resize((size_t)hm_n);
+            // :vegas calls `measure` for the samples with (ne % measurefreq == 0) only (vegas/montecarlo.jl:148-165): the records the
+            // cadence skips are squeezed out on the host, so that a measure which is not linear in the weights (a visit count, a
+            // per-call bin count) sees exactly the calls the reference makes
+            const bool squeeze = solver == MCI_VEGAS && measurefreq > 1;
+            const int64_t keep = squeeze ? nevalperblock / measurefreq : hm_n;
+            std::vector<double> sx, sw;
+            if (squeeze) {
+                sx.resize((size_t)(keep > 0 ? keep : 1) * s.ndraw);
+                sw.resize((size_t)(keep > 0 ? keep : 1) * nw);
+            }
             for (int64_t b = 0; b < nblocks; ++b) {
                 const int64_t off = b * hm_n;
                 double *ob = obs.data() + (size_t)b * s.nobs;
                 int hrc = 0;
-                if (p->hmeas_fn) {
+                if (squeeze) {
+                    for (int k = 0; k < s.ndraw; ++k)
+                        for (int64_t j = 0; j < keep; ++j) sx[(size_t)k * keep + j] = p->h_mx[(size_t)k * n + off + (j + 1) * measurefreq - 1];
+                    for (int q = 0; q < nw; ++q)
+                        for (int64_t j = 0; j < keep; ++j) sw[(size_t)q * keep + j] = relw[(size_t)q * n + off + (j + 1) * measurefreq - 1];
+                    if (p->hmeas_fn) hrc = p->hmeas_fn(sx.data(), sw.data(), keep, keep, s.ndraw, nw, block_lo + b, ob, s.nobs, p->hmeas_user);
+                    else {
+                        p->h_mitmp.resize((size_t)(keep > 0 ? keep : 1));
+                        for (int j = 0; j < s.ni && !hrc; ++j) {
+                            std::fill(p->h_mitmp.begin(), p->h_mitmp.end(), (int32_t)j);
+                            hrc = p->hmeas_idx_fn(p->h_mitmp.data(), sx.data(), sw.data() + (size_t)j * nc * keep, keep, keep, s.ndraw, nc, block_lo + b, ob,
+                                                  s.nobs, p->hmeas_user);
+                        }
+                    }
+                } else if (p->hmeas_fn) {
                     hrc = p->hmeas_fn(p->h_mx + off, relw + off, hm_n, n, s.ndraw, nw, block_lo + b, ob, s.nobs, p->hmeas_user);
                 } else if (solver == MCI_MCMC) {
                     hrc = p->hmeas_idx_fn(p->h_midx + off, p->h_mx + off, relw + off, hm_n, n, s.ndraw, nc, block_lo + b, ob, s.nobs, p->hmeas_user);
@@ -1492,8 +1564,40 @@ int mci_iteration_reduce(mci_problem *p) {
     if (!p->ctx->comm) return MCI_OK; // no communicator: single process (mpi_nprocs() == 1)
     int rc = flush_merge(p);
     if (rc) return rc;
+    // HIP events around the collective under the sample launch's rule (mci_set_kernel_timing): what a rank waits for here is the
+    // slowest rank's sample pass plus the latency of one small all-reduce (mci_comm_times_ms)
+    const bool timed = p->time_this_launch && !p->graph_mode;
+    const int slot = (int)(p->reduces % mci_problem::kCevRing);
+    if (timed) {
+        if (p->cevs.empty()) {
+            p->cevs.resize(2 * mci_problem::kCevRing);
+            for (auto &e : p->cevs) HIPCHK(hipEventCreate(&e));
+        }
+        HIPCHK(hipEventRecord(p->cevs[2 * slot], p->ctx->stream));
+    }
     int r = g_rccl.AllReduce(p->d_packed, p->d_packed, (size_t)p->packed_n, kNcclFloat64, kNcclSum, p->ctx->comm, p->ctx->stream);
     if (r) return fail(MCI_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    if (timed) HIPCHK(hipEventRecord(p->cevs[2 * slot + 1], p->ctx->stream));
+    p->cev_valid[slot] = timed;
+    p->reduces += 1;
+    return MCI_OK;
+}
+
+int mci_comm_times_ms(mci_problem *p, float *ms, int32_t n, int32_t *got) {
+    if (!p || !ms || !got) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    int64_t have = p->reduces < mci_problem::kCevRing ? p->reduces : mci_problem::kCevRing;
+    if (have > n) have = n;
+    int32_t k = 0;
+    for (int64_t i = 0; i < have; ++i) { // oldest first
+        const int slot = (int)((p->reduces - have + i) % mci_problem::kCevRing);
+        if (!p->cev_valid[slot]) continue;
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, p->cevs[2 * slot], p->cevs[2 * slot + 1]));
+        ms[k++] = t;
+    }
+    *got = k;
     return MCI_OK;
 }
 
@@ -2030,12 +2134,7 @@ int mci_get_hold_histogram(mci_problem *p, uint64_t *out64) {
     HIPCHK(hipSetDevice(p->ctx->device));
     HIPCHK(hipMemcpyAsync(out64, p->d_hold, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
-    p->hold_pending = false;
-    int top = -1;
-    for (int b = 0; b < 64; ++b)
-        if (out64[b]) top = b;
-    if (top >= 0) p->hold_max = (int64_t)1 << top; // bucket b holds bit_width(h) == b, i.e. h < 2^b
-    return MCI_OK;
+    return MCI_OK; // (diagnostic read; the automatic chain length follows its own copies, hold_publish / hold_consume)
 }
 
 void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out) {

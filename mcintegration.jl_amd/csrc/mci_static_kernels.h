@@ -233,6 +233,9 @@ __host__ __device__ inline int train_lds_doubles(int n) { return (n + kWalkPad) 
 // block size of 1024: a vectorised reduction whose association is the CPU's (lanes x interleave), not left to right.  Oracle and
 // device fix the AVX2 shape: 16 interleaved partial sums (element i -> partial i mod 16, each left to right), folded
 // p[l] += p[l + h] for h = 8, 4, 2, 1.  Called by every thread of the workgroup; every 16-lane group computes the total for itself.
+// Limit of the claim: from 1025 elements on Julia's mapreduce_impl splits the range pairwise at its midpoint before it reaches the
+// @simd loop; grids of more than 1025 increments (the default is 999) are summed here -- and in the oracle, mcio_sum16 -- with the
+// same 16-lane shape over the whole range, so for them the last bits of f_ninc and of the rescale sum need not be Julia's.
 __device__ inline double sum16(const double *v, int n) {
     double s = 0.0;
     int i = threadIdx.x & 15;
@@ -374,7 +377,7 @@ __device__ __forceinline__ void walk_trip(double &acc, const double (&v)[16], co
 }
 
 // Dist.train! for one leaf by one workgroup, then clearStatistics!.  h: the merged histogram (global or LDS);
-// hclear: its home in `packed`, reset for the next iteration.  sm: [4*N + 16] doubles of LDS.
+// hclear: its home in `packed`, reset for the next iteration.  sm: train_lds_doubles(N) doubles of LDS.
 __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hclear, double *sm, double *ps, int &bad, double &ssum,
                                   double *__restrict__ edges, double *__restrict__ dacc, double *__restrict__ ddist, int serial_walk,
                                   int *__restrict__ status) {

@@ -438,6 +438,14 @@ class Engine:
         check(lib().mci_kernel_times_ms(self.p, ms, n, C.byref(got), C.byref(wg), C.byref(th)))
         return np.array(ms[:got.value], dtype=np.float64), wg.value, th.value
 
+    def comm_times_ms(self, n=64):
+        """HIP-event durations of this rank's last n per-iteration all-reduces inside the library (oldest first; recorded under the
+        sample launch's timing rule, set_kernel_timing)"""
+        ms = (C.c_float * n)()
+        got = C.c_int32()
+        check(lib().mci_comm_times_ms(self.p, ms, n, C.byref(got)))
+        return np.array(ms[:got.value], dtype=np.float64)
+
     def last_kernel_ms(self):
         ms, wg, th = self.kernel_times_ms(1)
         return (float(ms[-1]) if len(ms) else float("nan")), wg, th   # (nan: the launch ran without events, set_kernel_timing)

@@ -121,12 +121,15 @@ void mcio_smooth(const double *dist, long n, double factor, double *out) {
 }
 
 /* ref: common.jl:67-82.  Output is NOT renormalised (:81-82).  Returns 1/2 where the
- * reference's @assert (:71 / :79) fires.  sum() is taken left-to-right. */
+ * reference's @assert (:71 / :79) fires.  sum() is mcio_sum16 (below). */
 /* Julia's sum() over a Vector{Float64} shorter than pairwise_blocksize = 1024 (Base.mapreduce_impl, base/reduce.jl) is an
  * `@simd` loop: LLVM vectorises the reduction, so its association is the host CPU's (vector lanes x interleave), not left to
  * right -- the reference has no single order.  The oracle (and the device) fix the AVX2 shape: 16 interleaved partial sums
  * (element i -> partial i mod 16, each left to right), folded p[l] += p[l + h] for h = 8, 4, 2, 1.
- * Used where the reference sums a histogram-length vector: rescale (common.jl:72) and f_ninc (variable.jl:226). */
+ * Used where the reference sums a histogram-length vector: rescale (common.jl:72) and f_ninc (variable.jl:226).
+ * Limit of the claim: from 1025 elements on mapreduce_impl first splits the range pairwise at its midpoint; vectors that long
+ * (grids of more than 1025 increments; the default is 999) are summed with the same 16-lane shape over the whole range here and
+ * on the device (mci_static_kernels.h sum16), so for them the last bits need not be Julia's. */
 double mcio_sum16(const double *v, long n) {
     double p[16] = {0};
     for (long i = 0; i < n; ++i) p[i & 15] += v[i];

@@ -97,3 +97,55 @@ def test_two_ranks_share_one_gpu_through_the_real_engine():
     assert out["config"]["neval_per_iteration"] == 40000000 and out["roofline"]["bound"] == "valu+lds"
     est = out["estimate"]
     assert abs(est["mean"] - est["exact"]) < 6 * est["sigma"] and est["iterations"] == 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reducer", ["rccl", "torch"])
+def test_forced_single_rank_communicator_goes_through_the_n_rank_code_path(reducer):
+    """`MCI_BENCH_FORCE_COMM=1 bench.py --gpus 1`: everything an N > 1 job does except a second device -- gloo control plane
+    (rendezvous, barriers, max-over-ranks of the pass time, gathered rank records), the library's own RCCL communicator created from
+    an id shipped through that group (reducer "rccl": the only RCCL instance on the device) or torch's RCCL group on the library's
+    device buffer and stream (reducer "torch": the fallback), ONE all-reduce of the packed buffer per iteration inside the timed
+    loop (src/main.jl:177-188), and a JSON line that says what the communicator saw."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MCI_BENCH_ENGINE"):
+        env.pop(k, None)
+    env["MCI_BENCH_FORCE_COMM"] = "1"
+    env["MCI_COMM"] = reducer
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "3", "--passes", "2",
+                        "--neval-per-gpu", "2e7", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.stdout.strip().splitlines() == lines and len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    comm = out["comm"]
+    assert comm["kind"] == reducer and comm["ranks"] == 1 and comm["world_size"] == 1 and comm["control_plane"] == "gloo"
+    assert comm["neval_after_allreduce"] == 2e7 and comm["payload_doubles"] == 2 + 2 + 2 + 999 + 2 * 12
+    assert comm["per_rank"][0]["blocks"] == [0, 16] and comm["per_rank"][0]["comm_ranks"] == 1
+    if reducer == "rccl":   # HIP events around the library's ncclAllReduce (launches of >= 2^20 samples are timed)
+        assert 0.0 < comm["per_rank"][0]["allreduce_ms_avg"] < 1.0, comm
+    assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["value"] > 1000.0
+    est = out["estimate"]
+    assert abs(est["mean"] - est["exact"]) < 6 * est["sigma"] and est["iterations"] == 8
+
+
+@pytest.mark.gpu
+def test_strong_scaling_option_splits_one_problem():
+    """--scaling strong: ONE problem (neval, 16 blocks) per iteration whatever the rank count, blocks rounded like main.jl:121-122;
+    with one rank it is the same job as the weak line"""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MCI_BENCH_ENGINE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "3", "--passes", "1",
+                        "--neval-per-gpu", "2e7", "--no-cpu-baseline", "--scaling", "strong"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["config"]["block"] == 16 and out["config"]["neval_per_iteration"] == 20000000
+    assert out["comm"]["kind"] == "none" and out["value"] > 1000.0
+
+
+def test_strong_scaling_block_partition_on_two_dry_ranks(oracle):
+    """the strong option under the launcher with two (dry, gloo) ranks: 16 blocks in all, 8 per rank, neval split in two"""
+    out = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--passes", "1", "--neval-per-gpu", "32000", "--no-cpu-baseline", "--scaling", "strong"])
+    assert out["scaling"] == "strong" and out["config"]["block"] == 16 and out["config"]["neval_per_iteration"] == 32000
+    assert [r["blocks"] for r in out["comm"]["per_rank"]] == [[0, 8], [8, 16]]

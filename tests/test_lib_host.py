@@ -161,3 +161,21 @@ def test_mcmc_auto_chain_length_rule():
     assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384) == npb // (16 * 16384)             # heavy tails: the holds decide
     assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 1 << 30) == 1
     assert L.mci_mcmc_auto_chains(10**9, 16, 1, 2, 1, 2) == 131072 // 16                                     # GPU-fill cap
+
+
+def test_closure_form_is_decided_by_parameters_without_defaults():
+    """integrate() tells the reference's two callback forms apart by their REQUIRED positional parameters
+    (`integrand(var, config)` vegas/montecarlo.jl:140-144 | `integrand(idx, var, config)` mcmc/montecarlo.jl:34-36; `measure` with
+    four | five): a defaulted or keyword-only extra parameter must not turn a plain closure into the indexed form."""
+    from mcintegration_jl_amd.integrate import required_positionals as rp
+    assert rp(lambda x, config: 0, 2) == 2
+    assert rp(lambda x, config, scale=2.0: 0, 2) == 2            # was counted as three: f would have been called as f(idx, x, config)
+    assert rp(lambda idx, x, config: 0, 2) == 3
+    assert rp(lambda idx, x, config, *, tag=None: 0, 2) == 3
+    assert rp(lambda x, obs, weights, config, norm=1.0: 0, 4) == 4
+    assert rp(lambda idx, x, obs, weight, config: 0, 4) == 5
+
+    def with_varargs(x, config, *rest, **kw):
+        return 0
+    assert rp(with_varargs, 2) == 2
+    assert rp(print, 2) in (0, 2)                                # builtins without a signature fall back to the plain form

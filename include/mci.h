@@ -263,6 +263,19 @@ int mci_set_rng_rounds(mci_problem *prob, int32_t rounds);
  *  -1  automatic (default): 1 when the iteration's sample launch on this rank is >= 2^26 samples (the walk then costs ~2 % or less), else 0.
  * The environment variable MCI_TRAIN_SERIAL=1|0, read at mci_problem_create, sets the initial mode. */
 int mci_set_train_walk(mci_problem *prob, int32_t mode);
+/* Carried chains (this engine's many-chain decomposition only; nchain = 1, the reference's chain, always starts afresh like
+ * montecarlo.jl:151-153 / mcmc/montecarlo.jl:118-124 do at every block): with mode -1 (default) a :vegasmc launch -- with mode 1 a
+ * :mcmc launch too; its chains also walk over the integrand index, slowly, and doReweight! steers that walk from the previous
+ * iteration's visits, so carried short :mcmc chains were measured biased (DESIGN.md "Chains") and stay opt-in -- that is the NEXT
+ * iteration of the same solver over the same blocks continues the previous launch's chains -- chain (block, ch) starts from the
+ * configuration chain (block, ch mod previous nchain) ended with, its bins and probabilities looked up again on the refined map --
+ * instead of drawing new starts and burning them in; such a launch keeps only the reference's own burn-in (`ne >= neval/100`,
+ * vegas_mc/montecarlo.jl:213; floor(steps * thermal_ratio), mcmc/montecarlo.jl:133) and sizes automatic chain counts for
+ * independence of consecutive iterations instead of start-up bias.  mode 0: every launch starts its chains afresh.
+ * Mirrored in the oracle (mcio_set_chain_carry). */
+int mci_set_chain_carry(mci_problem *prob, int32_t mode);
+/* chains per block of the last chain-solver launch and whether it continued the launch before it */
+int mci_last_chain_launch(const mci_problem *prob, int64_t *nchain, int32_t *carried);
 /* Dist.train! on the histograms currently in the packed buffer (variable.jl:206-239, :369-382) */
 int mci_train(mci_problem *prob);
 /* the adaptive map alone (sampler.jl:293-305, :13-22) + integrand: first `n` samples of block `block_index`

@@ -102,6 +102,8 @@ SIGNATURES = [
     ("mci_set_train_walk", C.c_int, [_VP, C.c_int32]),
     ("mci_set_rng_bits", C.c_int, [_VP, C.c_int32]),
     ("mci_set_rng_rounds", C.c_int, [_VP, C.c_int32]),
+    ("mci_set_chain_carry", C.c_int, [_VP, C.c_int32]),
+    ("mci_last_chain_launch", C.c_int, [_VP, C.POINTER(C.c_int64), c_int32_p]),
     ("mci_train", C.c_int, [_VP]),
     ("mci_sample_dump", C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
     ("mci_kernel_times_ms", C.c_int, [_VP, C.POINTER(C.c_float), C.c_int32, c_int32_p, c_int32_p, c_int32_p]),

@@ -210,12 +210,24 @@ struct mci_problem {
     hipEvent_t hold_ev[2] = {nullptr, nullptr};
     bool hold_inflight[2] = {false, false};
     int64_t hold_launches = 0;              // :mcmc launches that recorded a histogram
+    // Carried chains (BatchArgs::carry_x): end configurations of the last chain launch, two buffers (read one, write the other),
+    // and what that launch was -- an iteration continues it when it is the NEXT iteration of the same solver over the same blocks
+    double *d_chain_x[2] = {nullptr, nullptr};
+    int *d_chain_curr[2] = {nullptr, nullptr};
+    int64_t chain_cap[2] = {0, 0};
+    int chain_cur = 0;           // buffer the last launch wrote
+    bool chain_valid = false;
+    int chain_solver = -1, chain_iteration = -1;
+    int64_t chain_lo = 0, chain_hi = 0, chain_nchain = 0;
+    int chain_carry = -1;        // mci_set_chain_carry: -1 automatic (the rule above), 0 never
+    bool last_carried = false;   // the last chain launch continued the one before it
     // last launch
     std::vector<hipEvent_t> evs; // ring of (start, stop) pairs around the sampling kernel, one pair per launch
     int64_t launches = 0;
     static const int kEvRing = 512;
     static_assert(sizeof(ev_valid) / sizeof(ev_valid[0]) == kEvRing, "one validity flag per event-ring slot");
     int last_wg = 0, last_threads = 0, last_nblocks = 0;
+    int64_t last_nchain = 0; // chains per block of the last chain-solver launch
     int log_row = 0;
     static const int kGroups = mci::kMergeGroups;
     static const int64_t kChainFill = 131072; // chains per GPU that keep 2 waves on each of the 1024 SIMDs
@@ -615,6 +627,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             if (m == 3) { mode = 3; pair = 0; }
         }
         if (const char *e = getenv("MCI_TRAIN_SERIAL")) p->train_serial = atoi(e) != 0 ? 1 : 0;
+        if (const char *e = getenv("MCI_CHAIN_CARRY")) p->chain_carry = atoi(e) == 0 ? 0 : atoi(e) > 0 ? 1 : -1; // (mci_set_chain_carry)
         if (const char *e = getenv("MCI_KERNEL_TIMING")) p->kernel_timing = atoi(e) < 0 ? -1 : atoi(e) > 0 ? 1 : 0; // (mci_set_kernel_timing)
         if (const char *e = getenv("MCI_PAIR_TABLE")) pair = (atoi(e) != 0 && mode <= 1 && fixed + e2 + (mode == 0 ? hb : 0) <= lim1) ? 1 : 0;
         // histogram tiles: contiguous leaves, each tile's bins fit the LDS left over
@@ -784,6 +797,10 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->d_goal) (void)hipFree(p->d_goal);
         if (p->d_part_pa) (void)hipFree(p->d_part_pa);
         if (p->d_hold) (void)hipFree(p->d_hold);
+        for (int b = 0; b < 2; ++b) {
+            if (p->d_chain_x[b]) (void)hipFree(p->d_chain_x[b]);
+            if (p->d_chain_curr[b]) (void)hipFree(p->d_chain_curr[b]);
+        }
         if (p->h_hold) (void)hipHostFree(p->h_hold);
         for (auto &e : p->hold_ev)
             if (e) (void)hipEventDestroy(e);
@@ -1072,6 +1089,21 @@ int mci_set_train_walk(mci_problem *p, int32_t mode) {
     return MCI_OK;
 }
 
+int mci_set_chain_carry(mci_problem *p, int32_t mode) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (mode < -1 || mode > 1) return fail(MCI_ERR_INVALID, "chain carry mode must be -1 (automatic: :vegasmc), 0 (every launch starts its chains afresh) or 1 (:vegasmc and :mcmc)");
+    p->chain_carry = mode;
+    if (mode == 0) p->chain_valid = false;
+    return MCI_OK;
+}
+
+int mci_last_chain_launch(const mci_problem *p, int64_t *nchain, int32_t *carried) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (nchain) *nchain = p->last_nchain;
+    if (carried) *carried = p->last_carried ? 1 : 0;
+    return MCI_OK;
+}
+
 int mci_check_status(mci_problem *p) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
@@ -1117,6 +1149,17 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
                     (long long)block_hi, (int)iteration);
     double burnin = 0.0;
     int64_t nburn = 0;
+    // Does this launch continue the chains of the previous one?  (the next iteration of the same solver over the same blocks;
+    // decided before the chains are sized -- carried chains start from configurations that are already distributed like
+    // the chain's target, so they neither need the many-chain burn-in floors nor their length as a safety margin against start-up bias)
+    // (automatic = :vegasmc only.  :mcmc chains walk over the integrand index as well, slowly -- thousands of steps to cross a chain of
+    // five integrands -- and doReweight! steers that walk from the visits of the previous iteration: carried 1e3-step chains then
+    // inherit the visit fluctuation the new reweight factors were computed from, and the estimate of the 12-D member of BASELINE
+    // configs[4] came out 2 sigma per run low (32 seeds, profiles/r03_chain_carry.txt); fresh chains start stratified over the
+    // integrands, which IS their stationary index distribution.  mci_set_chain_carry(prob, 1) carries :mcmc chains too.)
+    const bool carry_on = p->chain_carry > 0 || (p->chain_carry < 0 && solver == MCI_VEGASMC);
+    const bool may_carry = solver != MCI_VEGAS && carry_on && p->chain_valid && p->chain_solver == solver &&
+                           p->chain_lo == block_lo && p->chain_hi == block_hi && p->chain_iteration + 1 == iteration && p->chain_nchain > 1;
     if (solver == MCI_VEGASMC) {
         int nslots = 0; // (pool, slot) pairs changeVariable can pick (updates.jl:50,:58)
         for (int v = 0; v < p->npool; ++v) nslots += p->maxdof[v];
@@ -1124,14 +1167,17 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // but never shorter than 8 burn-in floors.  Short chains under-sample the sticky high-|f|/q states of
             // singular integrands: measured on 1/(1 - cos x cos y cos z) at 2e9 steps, 381-step chains are 6 sigma low,
             // 763-step chains are within 1.4 sigma (tools/chain_bias_c1.py).
+            // Carried chains are stationary from their first step: two floors per iteration let them settle on the refined map.
             const int64_t fl = 64 * (int64_t)nslots > 128 ? 64 * (int64_t)nslots : 128;
-            nchain = nevalperblock / (8 * fl);
+            static const int64_t kf = getenv("MCI_CARRY_FLOORS") ? atoll(getenv("MCI_CARRY_FLOORS")) : 2; // diagnostic override
+            nchain = nevalperblock / ((may_carry ? kf : 8) * fl);
             const int64_t cap = mci_problem::kChainFill / nblocks > 64 ? mci_problem::kChainFill / nblocks : 64;
             if (nchain > cap) nchain = cap;
             if (nchain < 1) nchain = 1;
         }
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
-        burnin = mci_chain_burnin(nevalperblock / nchain, nchain, nslots);
+        // (carried chains keep the reference's own `ne >= neval/100` only, vegas_mc/montecarlo.jl:213)
+        burnin = mci_chain_burnin(nevalperblock / nchain, (may_carry && nchain > 1) ? 1 : nchain, nslots);
         units = nchain;
     } else if (solver == MCI_MCMC) {
         int nslots = 0;
@@ -1146,9 +1192,11 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // longest time any chain's slot (or integrand index) went without changing (mci_mcmc_auto_chains).
             if (!p->graph_mode && (rc = hold_consume(p))) return rc;
             nchain = mci_mcmc_auto_chains(nevalperblock, nblocks, nslots, p->ni + 1, p->npool, p->hold_max);
+            // (opt-in carried :mcmc chains, mci_set_chain_carry(prob, 1), keep this length: only their burn-in floor goes)
         }
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
-        nburn = mci_mcmc_burnin(nevalperblock / nchain, nchain, nslots, p->ni + 1, p->npool, thermal_ratio);
+        // (carried chains keep the reference's own floor(steps * thermal_ratio) only, mcmc/montecarlo.jl:133)
+        nburn = mci_mcmc_burnin(nevalperblock / nchain, (may_carry && nchain > 1) ? 1 : nchain, nslots, p->ni + 1, p->npool, thermal_ratio);
         units = nchain;
     } else {
         nchain = 1;
@@ -1222,6 +1270,43 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.nchain = nchain;
     a.burnin = burnin;
     a.nburn = nburn;
+    if (solver != MCI_VEGAS) {
+        const bool carried = may_carry && nchain > 1;
+        const bool keep = carry_on && nchain > 1 && !p->graph_mode;
+        if (carried) {
+            a.carry_x = p->d_chain_x[p->chain_cur];
+            a.carry_curr = p->d_chain_curr[p->chain_cur];
+            a.carry_nchain = p->chain_nchain;
+            a.carry_cap = p->chain_cap[p->chain_cur];
+        }
+        if (keep) {
+            const int wb = p->chain_valid ? 1 - p->chain_cur : p->chain_cur;
+            const int64_t need = nblocks * nchain;
+            if (need > p->chain_cap[wb]) {
+                if (p->d_chain_x[wb]) (void)hipFree(p->d_chain_x[wb]);
+                if (p->d_chain_curr[wb]) (void)hipFree(p->d_chain_curr[wb]);
+                p->d_chain_x[wb] = nullptr;
+                p->d_chain_curr[wb] = nullptr;
+                p->chain_cap[wb] = 0;
+                HIPCHK(hipMalloc((void **)&p->d_chain_x[wb], (size_t)need * s.ndraw * sizeof(double)));
+                HIPCHK(hipMalloc((void **)&p->d_chain_curr[wb], (size_t)need * sizeof(int)));
+                p->chain_cap[wb] = need;
+            }
+            a.store_x = p->d_chain_x[wb];
+            a.store_curr = p->d_chain_curr[wb];
+            a.store_cap = p->chain_cap[wb];
+            p->chain_cur = wb;
+            p->chain_valid = true;
+            p->chain_solver = solver;
+            p->chain_iteration = iteration;
+            p->chain_lo = block_lo;
+            p->chain_hi = block_hi;
+            p->chain_nchain = nchain;
+        } else if (!p->graph_mode) {
+            p->chain_valid = false;
+        }
+        p->last_carried = carried;
+    }
     if (solver == MCI_MCMC && !p->graph_mode && !s.host_integrand && nevalperblock / nchain + nburn < ((int64_t)1 << 31) - 1) {
         if (!p->d_hold) HIPCHK(hipMalloc((void **)&p->d_hold, 64 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(p->d_hold, 0, 64 * sizeof(unsigned long long), p->ctx->stream));
@@ -1518,6 +1603,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     p->last_wg = (int)nwg;
     p->last_threads = T;
     p->last_nblocks = (int)nblocks;
+    if (solver != MCI_VEGAS) p->last_nchain = nchain;
     // merge: block sums -> packed
     const int nb256 = (s.nbin + 255) / 256;
     // (reading a few partial rows directly in the second stage instead -- no first-stage launch when an iteration is launch-bound --
@@ -1727,7 +1813,7 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     // MI355X in the launch-bound regime (neval 1e4 .. 1e7 per iteration, tools/latency.py) the replay costs 37.6 / 41.9 /
     // 61.7 / 84.2 us per iteration against 34.8 / 36.0 / 57.1 / 79.1 us for the eager asynchronous launches.
     static const bool want_graph = getenv("MCI_GRAPH") && atoi(getenv("MCI_GRAPH")) != 0;
-    const bool use_graph = want_graph && !p->ctx->comm && !s.host_integrand && !s.host_measure && a->niter > 2;
+    const bool use_graph = want_graph && a->solver == MCI_VEGAS && !p->ctx->comm && !s.host_integrand && !s.host_measure && a->niter > 2;
     int it = 0;
     for (; it < (use_graph ? 1 : a->niter); ++it) { // main.jl:142
         if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, a->first_iteration + it, a->seed, a->measurefreq, a->nchain, a->thermal_ratio))) return rc;

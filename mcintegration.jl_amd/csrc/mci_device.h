@@ -211,6 +211,16 @@ struct BatchArgs {
     //   ne = 1 .. steps   finish step ne-1 with the weights the host returned (ne = 1: the initial weights, :155-166), propose step ne
     //   ne = steps + 1    finish the last step
     // Chain state lives in global memory between launches (SoA, stride nc = chains of the launch).
+    // Carried chains (chain solvers, nchain > 1, an iteration that continues the previous one; DESIGN.md "Chains"): chain (block, ch)
+    // does not draw a fresh start but continues from the configuration chain (block, ch % carry_nchain) ended the previous iteration
+    // with -- bins and probabilities are looked up again on the refined grid -- and leaves its own end configuration for the next
+    // iteration: x[k * cap + local block * nchain + ch], curr[...] (:mcmc: the integrand index).  Two buffers, read one, write the other.
+    const double *carry_x;  // NULL: every chain starts afresh (montecarlo.jl:151-153, mcmc/montecarlo.jl:118-124)
+    const int *carry_curr;
+    i64 carry_nchain, carry_cap;
+    double *store_x;        // NULL: nothing kept
+    int *store_curr;
+    i64 store_cap;
     struct HostStep {
         i64 ne, steps, nc;
         double *cx, *cprob, *cw, *cprobability; // current configuration [NDRAW][nc], weights [NW][nc], config.probability [nc]
@@ -1595,6 +1605,50 @@ template <class Cfg, int V, int L> __device__ __forceinline__ void draw_pool_lea
     p = 1.0 / (raw * jac_scale<Cfg>(k));
 }
 
+// A carried chain's draw K on the CURRENT map: the bin that holds x and prob = 1/(N dx) (sampler.jl:303) | distribution[bin] (:20).
+// Continuous: the largest increment whose lower edge is <= x (bisection over the leaf's table, wherever it lives); the grid's end
+// points never move (variable.jl:217-218), so x stays inside.  A FermiK component has neither.
+template <class Cfg, int K> __device__ __forceinline__ void relocate_draw(const Tables<Cfg> &t, const double x, double &prob, int &bin) {
+    constexpr int leaf = Cfg::draw_leaf(K);
+    if constexpr (Cfg::leaf_kind(leaf) == 0) {
+        constexpr int N = Cfg::leaf_nbin(leaf);
+        constexpr bool PAIR = Cfg::PAIR_TABLE != 0 && Cfg::TABLE_MODE <= 1;
+        constexpr int off = PAIR ? Cfg::leaf_poff(leaf) : Cfg::leaf_eoff(leaf);
+        int lo = 0, hi = N - 1; // invariant: edge(lo) <= x (or lo == 0), edge(hi + 1) > x (or hi == N - 1)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            const double e = PAIR ? t.E[off + 2 * mid] : t.E[off + mid];
+            if (e <= x) lo = mid;
+            else hi = mid - 1;
+        }
+        const double dx = PAIR ? t.E[off + 2 * lo + 1] : t.E[off + lo + 1] - t.E[off + lo];
+        bin = lo;
+        prob = 1.0 / (dx * jac_scale<Cfg>(K));
+    } else if constexpr (Cfg::leaf_kind(leaf) == 1) {
+        constexpr int Kn = Cfg::leaf_nbin(leaf);
+        int b = (int)(x - Cfg::leaf_lower(leaf));
+        b = b < 0 ? 0 : (b >= Kn ? Kn - 1 : b);
+        bin = b;
+        prob = 1.0 / ((1.0 / t.DD[Cfg::leaf_doff(leaf) + b]) * jac_scale<Cfg>(K)); // as create! forms it here (draw_leaf + draw_pool_leaf)
+    } else {
+        bin = 0;
+        prob = 1.0;
+    }
+}
+// the whole configuration of a carried chain
+template <class Cfg> __device__ __forceinline__ void load_carried(const BatchArgs &a, const Tables<Cfg> &t, const i64 lb, const i64 ch, Chain<Cfg> &c) {
+    const i64 slot = lb * a.carry_nchain + ch % a.carry_nchain;
+    static_for<0, Cfg::NDRAW>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        c.x[k] = a.carry_x[(i64)k * a.carry_cap + slot];
+        relocate_draw<Cfg, k>(t, c.x[k], c.prob[k], c.bin[k]);
+    });
+}
+template <class Cfg> __device__ __forceinline__ void store_carried(const BatchArgs &a, const i64 lb, const i64 ch, const Chain<Cfg> &c) {
+    const i64 slot = lb * a.nchain + ch;
+    static_for<0, Cfg::NDRAW>([&](auto K) { constexpr int k = decltype(K)::value; a.store_x[(i64)k * a.store_cap + slot] = c.x[k]; });
+}
+
 template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchArgs &a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NI = Cfg::NI, NORMI = Cfg::NI;
@@ -1646,7 +1700,8 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
         const u64 g = (u64)ch;
         Chain<Cfg> c;
-        {   // initialize!  (montecarlo.jl:151-153): create! on every live slot
+        if (a.carry_x) load_carried<Cfg>(a, t, wi.lb, ch, c); // continues the previous iteration's chain (BatchArgs::carry_x)
+        else {   // initialize!  (montecarlo.jl:151-153): create! on every live slot
             Sample<Cfg> s;
             draw_sample<Cfg>(t, a.seed, st_init, g, s);
             static_for<0, Cfg::NDRAW>([&](auto K) {
@@ -1774,6 +1829,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
             }
         }
         flush_pa();
+        if (a.store_x && tile == 0) store_carried<Cfg>(a, wi.lb, ch, c);
     }
     __syncthreads();
     flush_workgroup<Cfg, Lds<Cfg>, true, true>(a, smem, acc, extra, wi.rowid, tile);
@@ -1825,14 +1881,23 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_host_step(const Bat
         const i64 cid = wi.lb * a.nchain + ch; // the chain's column in the state arrays
         Chain<Cfg> c;
         if (h.ne == 0) { // initialize!  (montecarlo.jl:151-153): create! on every live slot; the host evaluates it (:155-159)
-            Sample<Cfg> s;
-            draw_sample<Cfg>(t, a.seed, st_init, g, s);
+            if (a.carry_x) load_carried<Cfg>(a, t, wi.lb, ch, c); // ... or the previous iteration's chain goes on (BatchArgs::carry_x)
+            else {
+                Sample<Cfg> s;
+                draw_sample<Cfg>(t, a.seed, st_init, g, s);
+                static_for<0, Cfg::NDRAW>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    c.x[k] = s.x[k];
+                    c.bin[k] = s.bin[k];
+                    c.prob[k] = 1.0 / s.pj[k]; // sampler.jl:303 / :20
+                });
+            }
             static_for<0, Cfg::NDRAW>([&](auto K) {
                 constexpr int k = decltype(K)::value;
-                h.cx[k * nc + cid] = s.x[k];
-                h.hx[k * nc + cid] = s.x[k];
-                h.cbin[k * nc + cid] = s.bin[k];
-                h.cprob[k * nc + cid] = 1.0 / s.pj[k]; // sampler.jl:303 / :20
+                h.cx[k * nc + cid] = c.x[k];
+                h.hx[k * nc + cid] = c.x[k];
+                h.cbin[k * nc + cid] = c.bin[k];
+                h.cprob[k * nc + cid] = c.prob[k];
             });
             continue;
         }
@@ -1971,6 +2036,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_host_step(const Bat
         });
         static_for<0, Cfg::NW>([&](auto Q) { h.cw[decltype(Q)::value * nc + cid] = w[decltype(Q)::value]; });
         h.cprobability[cid] = probability;
+        if (a.store_x && h.ne == h.steps + 1) store_carried<Cfg>(a, wi.lb, ch, c); // the chain's last step is through
     }
     __syncthreads();
     flush_workgroup<Cfg, Lds<Cfg>, true, true, true>(a, smem, acc, extra, wi.rowid, 0);
@@ -2324,7 +2390,20 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
         static_for<0, Cfg::NCOMP>([&](auto Q) { weight.v[decltype(Q)::value] = 0.0; });
         weight.abs = 0.0;
         double probability = 1.0;
-        for (int tr = 0; tr < 10000; ++tr) {    // :118-124
+        bool fresh = a.carry_x == nullptr;
+        if (!fresh) { // continues the previous iteration's chain: its configuration and the integrand it sat on (BatchArgs::carry_x)
+            load_carried<Cfg>(a, t, wi.lb, ch, c);
+            curr = a.carry_curr[wi.lb * a.carry_nchain + ch % a.carry_nchain];
+            if (curr != NORMI) {
+                weight = eval_sel<Cfg>(curr, c.x, a.ud);        // :197 on the carried configuration
+                probability = weight.abs * rw_sel(curr);        // :199
+                if (!(probability > 4.940656458412465e-274)) {  // (cannot happen while the integrand is the one that left it there)
+                    fresh = true;
+                    curr = (int)(g % (u64)ND);
+                }
+            } else probability = rw[NORMI];                     // :201-202
+        }
+        for (int tr = 0; fresh && tr < 10000; ++tr) {    // :118-124
             Sample<Cfg> s;
             draw_sample<Cfg>(t, a.seed, st_init, g * 16384ull + (u64)tr, s); // initialize!  :190-193
             static_for<0, Cfg::NDRAW>([&](auto K) {
@@ -2496,6 +2575,10 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             });
             atomicAdd(&a.hold_hist[hmax <= 0 ? 0 : 32 - __clz(hmax)], 1ull);
         }
+        if (a.store_x && tile == 0) {
+            store_carried<Cfg>(a, wi.lb, ch, c);
+            a.store_curr[wi.lb * a.nchain + ch] = curr;
+        }
     }
     __syncthreads();
     flush_workgroup<Cfg, Lds<Cfg>, true, true>(a, smem, acc, extra, wi.rowid, tile);
@@ -2590,7 +2673,18 @@ template <class Cfg> __device__ __forceinline__ void mcmc_host_step(const BatchA
             });
         };
         if (h.ne == 0) {
-            const int curr0 = a.nchain == 1 ? 0 : (int)(g % (u64)ND); // montecarlo.jl:76 idx = 1; many chains start stratified
+            int curr0 = a.nchain == 1 ? 0 : (int)(g % (u64)ND); // montecarlo.jl:76 idx = 1; many chains start stratified
+            if (a.carry_x) { // the previous iteration's chain goes on: its configuration and the integrand it sat on (BatchArgs::carry_x)
+                load_carried<Cfg>(a, t, wi.lb, ch, c);
+                curr0 = a.carry_curr[wi.lb * a.carry_nchain + ch % a.carry_nchain];
+                static_for<0, Cfg::NDRAW>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    h.cx[k * nc + cid] = c.x[k];
+                    h.hx[k * nc + cid] = c.x[k];
+                    h.cbin[k * nc + cid] = c.bin[k];
+                    h.cprob[k * nc + cid] = c.prob[k];
+                });
+            } else
             draw_start(0);
             h.ccurr[cid] = curr0;
             h.cit[cid] = -1;
@@ -2730,6 +2824,10 @@ template <class Cfg> __device__ __forceinline__ void mcmc_host_step(const BatchA
         } else {
             h.hidx[cid] = -1;
             atomicAdd(h.done, 1);
+            if (a.store_x) { // the chain's last step is through
+                store_carried<Cfg>(a, wi.lb, ch, c);
+                a.store_curr[wi.lb * a.nchain + ch] = curr;
+            }
         }
         static_for<0, Cfg::NDRAW>([&](auto K) {
             constexpr int k = decltype(K)::value;

@@ -398,6 +398,18 @@ class Engine:
         """:vegas sample stream: 52 (default, the resolution of rand(Float64)) or 32 random bits per draw; see mci_set_rng_bits"""
         check(lib().mci_set_rng_bits(self.p, int(bits)))
 
+    def set_chain_carry(self, mode):
+        """chain solvers with many chains per block: "auto" (default) -- the next :vegasmc iteration over the same blocks continues
+        the chains of the previous one --, "on" (:mcmc too) or "off" (every launch draws new starts and burns them in); see
+        mci_set_chain_carry"""
+        check(lib().mci_set_chain_carry(self.p, {"auto": -1, "off": 0, "on": 1, -1: -1, 0: 0, 1: 1}[mode]))
+
+    def last_chain_launch(self):
+        """(chains per block, continued the previous launch?) of the last chain-solver launch"""
+        n, c = C.c_int64(), C.c_int32()
+        check(lib().mci_last_chain_launch(self.p, C.byref(n), C.byref(c)))
+        return int(n.value), bool(c.value)
+
     def set_train_walk(self, mode):
         """train!'s refinement walk: "serial" (the reference's recurrence), "scan" (prefix scan + bisection) or "auto"; see mci_set_train_walk"""
         check(lib().mci_set_train_walk(self.p, {"auto": -1, "scan": 0, "serial": 1, -1: -1, 0: 0, 1: 1}[mode]))

@@ -403,7 +403,15 @@ mcio_config *mcio_config_create(int nleaf, const int *kind, const int *pool, con
     c->normalization = 1.0e-10;                              /* :179 */
     c->neval = 0;
     c->prob_mode = MCIO_PROB_CREATE;
+    c->carry = (mcio_carry *)calloc(1, sizeof(mcio_carry));
+    c->carry->mode = -1;
+    c->carry_owner = 1;
     return c;
+}
+
+void mcio_set_chain_carry(mcio_config *c, int mode) {
+    c->carry->mode = mode == 0 ? 0 : mode > 0 ? 1 : -1;
+    if (mode == 0) c->carry->valid = 0;
 }
 
 static void leaf_free(mcio_leaf *L) {
@@ -422,6 +430,10 @@ void mcio_config_destroy(mcio_config *c) {
     free(c->observable); free(c->reweight); free(c->visited); free(c->propose); free(c->accept);
     for (int d = 0; d < c->Ni + 1; ++d) free(c->neighbor[d]);
     free(c->neighbor); free(c->nneighbor); free(c->reweight_goal); free(c->hold_hist);
+    if (c->carry_owner && c->carry) {
+        for (int b = 0; b < 2; ++b) { free(c->carry->x[b]); free(c->carry->curr[b]); }
+        free(c->carry);
+    }
     free(c);
 }
 
@@ -478,6 +490,10 @@ mcio_config *mcio_config_clone(const mcio_config *s) {
     for (int d = 0; d < Nd; ++d) c->neighbor[d] = (int *)dup_mem(s->neighbor[d], sizeof(int) * (size_t)s->nneighbor[d]);
     c->reweight_goal = s->reweight_goal ? (double *)dup_mem(s->reweight_goal, sizeof(double) * (size_t)Nd) : NULL;
     c->hold_hist = (unsigned long long *)dup_mem(s->hold_hist, 64 * sizeof(unsigned long long));
+    c->carry = (mcio_carry *)calloc(1, sizeof(mcio_carry)); /* a copy keeps no chains (run_blocks shares the parent's state with its clones) */
+    c->carry->mode = s->carry ? s->carry->mode : -1;
+    c->carry_owner = 1;
+    c->carry_load = c->carry_store = 0;
     return c;
 }
 
@@ -964,6 +980,62 @@ int mcio_vegas_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint
  *   init  : stream MC_INIT, index g,            k = flat draw
  *   step s: stream MC_STEP, index (g<<32 | s),  k = 0 pool pick, 1 slot pick, 2 accept, 3+l leaf l
  * ---------------------------------------------------------------------------------------- */
+/* A carried chain's slot (pool vi, 1-based idx incl. offset) from its stored x entries: the values, and on the CURRENT map the
+ * bin that holds each of them with prob = 1/(N dx) (sampler.jl:303) | distribution[bin] (:20) -- mirror of mci_device.h relocate_draw */
+static void carried_slot(mcio_config *c, int vi, int idx, const double *xs) {
+    const int l0 = c->pool_leaf0[vi], nl = c->pool_nleaf[vi];
+    mcio_leaf *L0 = &c->leaf[l0];
+    if (L0->kind == MCIO_FERMIK) {
+        for (int j = 0; j < L0->width; ++j) L0->data[idx * L0->width + j] = xs[j];
+        return;
+    }
+    double pp = 1.0;
+    for (int l = 0; l < nl; ++l) {
+        mcio_leaf *T = &c->leaf[l0 + l];
+        const double x = xs[l];
+        T->data[idx] = x;
+        if (T->kind == MCIO_CONTINUOUS) {
+            const long N = T->npts - 1;
+            long lo = 0, hi = N - 1; /* the largest increment whose lower edge is <= x */
+            while (lo < hi) {
+                const long mid = (lo + hi + 1) >> 1;
+                if (T->grid[mid] <= x) lo = mid;
+                else hi = mid - 1;
+            }
+            T->gidx[idx] = lo + 1;
+            T->prob[idx] = 1.0 / ((T->grid[lo + 1] - T->grid[lo]) * (double)N);
+        } else {
+            long g = (long)(x - T->lower);
+            if (g < 0) g = 0;
+            if (g >= T->nbin) g = T->nbin - 1;
+            T->gidx[idx] = g + 1;
+            T->prob[idx] = T->distribution[g];
+        }
+        pp *= T->prob[idx];
+    }
+    if (nl != 1) c->pool_prob[vi][idx] = pp;
+}
+static void load_carried(mcio_config *c, long ch) {
+    const mcio_carry *cy = c->carry;
+    const long slot = c->carry_lb * cy->load_nchain + ch % cy->load_nchain;
+    double xs[64];
+    for (int vi = 0, k = 0; vi < c->npool; ++vi)
+        for (int idx = 1; idx <= c->maxdof[vi]; ++idx) {
+            const int w = c->pool_width[vi];
+            for (int l = 0; l < w; ++l) xs[l] = cy->x[cy->rd][(long)(k + l) * cy->cap[cy->rd] + slot];
+            carried_slot(c, vi, idx + c->pool_offset[vi], xs);
+            k += w;
+        }
+}
+static void store_carried(mcio_config *c, long ch, long nchain, int curr) {
+    mcio_carry *cy = c->carry;
+    const long slot = c->carry_lb * nchain + ch;
+    double x[MCIO_MAXDRAW];
+    gather_x(c, x);
+    for (int k = 0; k < c->ndraw; ++k) cy->x[cy->wr][(long)k * cy->cap[cy->wr] + slot] = x[k];
+    cy->curr[cy->wr][slot] = curr;
+}
+
 int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint64_t seed,
                        uint32_t iteration, long block_index, long neval, long measurefreq,
                        long nchain) {
@@ -981,7 +1053,7 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
     int nslots = 0;
     for (int vi = 0; vi < npool; ++vi) nslots += c->maxdof[vi];
     double burnin = (double)steps / 100.0;
-    if (nchain > 1) {
+    if (nchain > 1 && !c->carry_load) { /* (carried chains keep the reference's own term only) */
         double fl = 64.0 * (double)nslots;
         if (fl > (double)steps / 2.0) fl = (double)steps / 2.0;
         if (fl > burnin) burnin = fl;
@@ -991,6 +1063,8 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
         const uint64_t g = (uint64_t)ch;
         /* :151-153 initialize! (only the slots that are ever read: 1..maxdof) */
         int k = 0;
+        if (c->carry_load) load_carried(c, ch); /* continues the previous iteration's chain (mci_set_chain_carry) */
+        else
         for (int vi = 0; vi < npool; ++vi)
             for (int idx = 1; idx <= c->maxdof[vi]; ++idx) {
                 int nl = c->pool_nleaf[vi];
@@ -1065,6 +1139,7 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
                 c->visited[norm] += c->reweight[norm] * pad[norm] / probability;    /* :230 */
             }
         }
+        if (c->carry_store) store_carried(c, ch, nchain, 0);
     }
     return 0;
 }
@@ -1150,7 +1225,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
         nslots += c->maxdof[vi];
     }
     const long steps = neval / nchain;
-    const long nburn = mcio_mcmc_burnin(steps, nchain, nslots, Nd, npool, c->thermal_ratio); /* :133 */
+    const long nburn = mcio_mcmc_burnin(steps, c->carry_load ? 1 : nchain, nslots, Nd, npool, c->thermal_ratio); /* :133 (carried chains: the reference's own term only) */
     const int nupd = 2 * npool + 2; /* :127-130: [changeIntegrand, swapVariable, changeVariable x 2*Nv] */
     const uint32_t st_init = stream_id_block(iteration, STREAM_MCMC_INIT, block_index), st_step = stream_id_block(iteration, STREAM_MCMC_STEP, block_index);
     int rc = 0;
@@ -1158,7 +1233,23 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
         const uint64_t g = (uint64_t)ch;
         int curr = (nchain == 1) ? 0 : (int)(g % (uint64_t)Nd); /* :76 idx = 1; many chains start stratified */
         double weight[2] = {0.0, 0.0}, probability = 1.0;        /* :116 _State(curr, zero(T), 1.0) */
-        for (long t = 0; t < 10000; ++t) {                       /* :118-124 */
+        int fresh = !c->carry_load;
+        if (!fresh) { /* continues the previous iteration's chain: its configuration and the integrand it sat on */
+            const mcio_carry *cy = c->carry;
+            load_carried(c, ch);
+            curr = cy->curr[cy->rd][c->carry_lb * cy->load_nchain + ch % cy->load_nchain];
+            if (curr != norm) {
+                gather_x(c, x);
+                f(x, w, ud);
+                for (int q = 0; q < nc; ++q) weight[q] = w[nc * curr + q];
+                probability = absw(c, w, curr) * c->reweight[curr];
+                if (!(probability > MCIO_TINY)) {
+                    fresh = 1;
+                    curr = (int)(g % (uint64_t)Nd);
+                }
+            } else probability = c->reweight[curr];
+        }
+        for (long t = 0; fresh && t < 10000; ++t) {              /* :118-124 */
             /* initialize!  :190-205 (only the slots that are ever read: 1..maxdof) */
             for (int vi = 0; vi < npool; ++vi)
                 for (int idx = 1; idx <= c->maxdof[vi]; ++idx) {
@@ -1351,6 +1442,7 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
             for (long h = hmax; h > 0; h >>= 1) ++b; /* bit_width */
             if (tot < 2147483647L) c->hold_hist[b] += 1;
         }
+        if (c->carry_store) store_carried(c, ch, nchain, curr);
     }
     return rc;
 }
@@ -1467,11 +1559,36 @@ static int run_blocks(mcio_config *c, int solver, mcio_integrand_fn f, const dou
     if (nthreads > nb) nthreads = (int)nb;
     mcio_config **done = (mcio_config **)calloc((size_t)nb, sizeof(mcio_config *));
     int err = 0;
+    /* carried chains: the rule of mci_api.hip mci_iteration_run */
+    mcio_carry *cy = c->carry;
+    const int carry_on = cy->mode > 0 || (cy->mode < 0 && solver == MCIO_VEGASMC); /* automatic = :vegasmc only */
+    const int carried = solver != MCIO_VEGAS && carry_on && cy->valid && cy->solver == solver && cy->lo == block_lo && cy->hi == block_hi &&
+                        cy->iteration + 1 == (long)iteration && cy->nchain > 1 && nchain > 1;
+    const int keep = solver != MCIO_VEGAS && carry_on && nchain > 1;
+    if (keep) {
+        const int wr = cy->valid ? 1 - cy->cur : cy->cur;
+        if (nb * nchain > cy->cap[wr]) {
+            free(cy->x[wr]);
+            free(cy->curr[wr]);
+            cy->cap[wr] = nb * nchain;
+            cy->x[wr] = (double *)calloc((size_t)cy->cap[wr] * (size_t)(c->ndraw > 0 ? c->ndraw : 1), sizeof(double));
+            cy->curr[wr] = (int *)calloc((size_t)cy->cap[wr], sizeof(int));
+        }
+        cy->rd = cy->cur;
+        cy->wr = wr;
+    } else if (carried) cy->rd = cy->cur;
+    cy->load_nchain = cy->nchain;
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(nthreads) schedule(static)
 #endif
     for (long b = 0; b < nb; ++b) {
         mcio_config *cn = mcio_config_clone(c); /* main.jl:130 deepcopy per worker; here per block */
+        free(cn->carry);                         /* the clones share the parent's chain state */
+        cn->carry = cy;
+        cn->carry_owner = 0;
+        cn->carry_load = carried;
+        cn->carry_store = keep;
+        cn->carry_lb = b;
         mcio_clear_statistics(cn);               /* main.jl:251 */
         int rc;
         if (solver == MCIO_VEGAS)
@@ -1488,6 +1605,15 @@ static int run_blocks(mcio_config *c, int solver, mcio_integrand_fn f, const dou
         }
         done[b] = cn;
     }
+    if (keep) {
+        cy->cur = cy->wr;
+        cy->valid = 1;
+        cy->solver = solver;
+        cy->iteration = (long)iteration;
+        cy->lo = block_lo;
+        cy->hi = block_hi;
+        cy->nchain = nchain;
+    } else if (solver != MCIO_VEGAS) cy->valid = 0;
     mcio_clear_statistics(c); /* main.jl:149 */
     for (long b = 0; b < nb; ++b) {
         mcio_config *cn = done[b];

@@ -111,7 +111,25 @@ typedef struct {
     int *draw_comp;        /* [ndraw] component within the leaf's slot (FermiK), 0 otherwise */
     unsigned long long *hold_hist; /* [64] :mcmc chains by bit_width(longest holding time); the engine's own diagnostic
                                       (include/mci.h mci_get_hold_histogram), restated here so that it can be checked */
+    /* carried chains (mirror of include/mci.h mci_set_chain_carry; this engine's many-chain decomposition only): the state is shared
+       with the per-block clones run_blocks makes; carry_load / carry_store / carry_lb are set per launch and block */
+    struct mcio_carry *carry;
+    int carry_owner;
+    int carry_load, carry_store;
+    long carry_lb;
 } mcio_config;
+
+/* end configurations of the last chain-solver launch: x[buf][k * cap + local block * nchain + ch], curr[buf][...] (:mcmc) */
+typedef struct mcio_carry {
+    int mode;          /* -1 automatic (default): the NEXT :vegasmc iteration over the same blocks continues the chains; 1: :mcmc too; 0 off */
+    double *x[2];
+    int *curr[2];
+    long cap[2];
+    int cur, valid, solver;
+    long lo, hi, nchain, iteration;
+    int rd, wr;        /* buffers of the launch in flight */
+    long load_nchain;
+} mcio_carry;
 
 typedef struct {
     int niter, nobs, Ni;
@@ -122,6 +140,8 @@ typedef struct {
     double *chi2;      /* [nobs] reduced chi2 */
     long neval;
 } mcio_result;
+
+void mcio_set_chain_carry(mcio_config *c, int mode); /* -1 automatic (:vegasmc) | 0 off | 1 :vegasmc and :mcmc */
 
 /* ---- RNG ---- */
 void mcio_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

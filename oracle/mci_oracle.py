@@ -49,7 +49,8 @@ class _Config(C.Structure):
                 ("accept", c_double_p), ("prob_mode", C.c_int), ("npa", C.c_int), ("pam", C.c_int), ("rng_bits", C.c_int), ("nneighbor", c_int_p),
                 ("neighbor", C.POINTER(c_int_p)), ("thermal_ratio", C.c_double), ("reweight_goal", c_double_p),
                 ("ncomp", C.c_int), ("measure_fn", C.c_void_p), ("pool_width", c_int_p), ("draw_comp", c_int_p),
-                ("hold_hist", C.POINTER(C.c_ulonglong))]
+                ("hold_hist", C.POINTER(C.c_ulonglong)), ("carry", C.c_void_p), ("carry_owner", C.c_int),
+                ("carry_load", C.c_int), ("carry_store", C.c_int), ("carry_lb", C.c_long)]
 
 
 class _Result(C.Structure):
@@ -118,6 +119,7 @@ def lib():
     L.mcio_mcmc_burnin.argtypes = [C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_double]
     L.mcio_set_neighbor.argtypes = [C.POINTER(_Config), c_int_p, c_int_p]
     L.mcio_set_thermal_ratio.argtypes = [C.POINTER(_Config), C.c_double]
+    L.mcio_set_chain_carry.argtypes = [C.POINTER(_Config), C.c_int]
     L.mcio_set_reweight_goal.argtypes = [C.POINTER(_Config), c_double_p]
     L.mcio_set_ncomp.argtypes = [C.POINTER(_Config), C.c_int]
     L.mcio_set_measure.argtypes = [C.POINTER(_Config), C.c_void_p]
@@ -426,6 +428,17 @@ class Config:
     def set_measure(self, fnptr):
         """raw pointer from compile_c_measure (or None for the default measure)"""
         lib().mcio_set_measure(self.p, fnptr)
+
+    def set_chain_carry(self, mode):
+        """mirror of mci_set_chain_carry: "auto" / -1 (default: :vegasmc), "off" / 0, "on" / 1 (:mcmc too)"""
+        lib().mcio_set_chain_carry(self.p, {"auto": -1, "off": 0, "on": 1, -1: -1, 0: 0, 1: 1}[mode])
+
+    def set_reweight(self, r):
+        """config.reweight (configuration.jl:50), e.g. after do_reweight"""
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        assert len(r) == self.c.Ni + 1
+        for i, v in enumerate(r):
+            self.c.reweight[i] = float(v)
 
     def set_thermal_ratio(self, r):
         lib().mcio_set_thermal_ratio(self.p, float(r))

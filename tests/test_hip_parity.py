@@ -562,7 +562,7 @@ def test_chain_solvers_with_tiled_histograms_match_oracle(oracle, solver, monkey
 
 
 def test_graph_replay_of_the_iteration_chain_matches_the_eager_loop(monkeypatch):
-    """MCI_GRAPH=1: mci_integrate replays one captured hipGraph per iteration (iteration index and log row advance on
+    """MCI_GRAPH=1: mci_integrate replays one captured hipGraph per :vegas iteration (iteration index and log row advance on
     the device); same kernels in the same order.  (Not bit-identical run to run either way: the order of the
     ds_add_f64 inside a workgroup follows the wave schedule, and train! amplifies those last-bit differences.)"""
     outs = []
@@ -573,7 +573,7 @@ def test_graph_replay_of_the_iteration_chain_matches_the_eager_loop(monkeypatch)
              "import sys; sys.path.insert(0, %r); import numpy as np, mcintegration_jl_amd as mci\n"
              "cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]], seed=5)\n"
              "eng = mci.Engine(cfg, mci.catalog.sphere2())\n"
-             "for solver in ('vegas', 'vegasmc', 'mcmc'):\n"
+             "for solver in ('vegas', 'vegas', 'vegas'):\n"
              "    r = eng.integrate(solver, neval=40000, niter=6, block=8, seed=5, nchain=4)\n"
              "    print(repr(r['iter_mean'].tolist()), repr(r['iter_std'].tolist()))\n" % __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))],
             capture_output=True, text=True, timeout=300)

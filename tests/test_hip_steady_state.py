@@ -257,3 +257,48 @@ def test_several_chains_per_lane_match_oracle(oracle, name, solver):
     np.testing.assert_allclose(ac.ravel(), ref[-npa:], rtol=1e-12)
     if solver == "mcmc":
         np.testing.assert_array_equal(eng.hold_histogram(), ocfg.hold_hist)
+
+
+@pytest.mark.parametrize("solver", ["vegasmc", "mcmc"])
+@pytest.mark.parametrize("name", ["sphere2_padding", "bubble", "discrete2_composite"])
+def test_carried_chains_match_oracle(oracle, name, solver):
+    """Carried chains (mci_set_chain_carry, this engine's many-chain decomposition only): the next iteration of the same solver over
+    the same blocks continues the previous launch's chains -- chain (block, ch) starts from the configuration chain (block, ch mod
+    previous nchain) ended with, bins and probabilities looked up again on the map train! has just refined, :mcmc also the integrand
+    index -- with the reference's own burn-in only.  Four consecutive iterations with doReweight! and train! in between and a chain
+    count that changes (16, 16, 40, 8 per block) against the oracle's mirror; a repeated iteration number starts afresh again."""
+    c, cfg, eng, ocfg = _make(name, oracle)
+    if solver == "mcmc":                      # (opt-in there: the automatic mode carries :vegasmc chains only)
+        eng.set_chain_carry("on")
+        ocfg.set_chain_carry("on")
+    osolver = dict(vegasmc=oracle.VEGASMC, mcmc=oracle.MCMC)[solver]
+    block, npb = 4, 4800
+    kw = {}
+    if solver == "mcmc":
+        ocfg.set_thermal_ratio(0.1)
+        kw = dict(thermal_ratio=0.1)
+    n = eng.nobs
+    for it, nch in enumerate([16, 16, 40, 8]):
+        got = eng.iteration(solver, npb, 0, block, iteration=it, seed=SEED, nchain=nch, **kw)
+        ref = ocfg.iteration(osolver, c["oname"], c["ud"], npb, 0, block, it, SEED, nchain=nch, nthreads=2)
+        assert eng.last_chain_launch() == (nch, it > 0), (it, eng.last_chain_launch())
+        compare(got, ref, n, cfg.N, rtol_stat=1e-8, rtol_hist=1e-7)
+        if solver == "mcmc":
+            np.testing.assert_array_equal(eng.hold_histogram(), ocfg.hold_hist)
+        eng.finish(solver, block, adapt=True)                               # doReweight! + train! on the device (main.jl:183-199)
+        ocfg.set_reweight(oracle.do_reweight(ocfg.reweight, ref[2 * n + 2: 2 * n + 2 + cfg.N + 1]))
+        ocfg.train()
+        np.testing.assert_allclose(eng.reweight(), ocfg.reweight, rtol=1e-9)
+    # the same iteration number once more: not a continuation -> fresh starts with the many-chain burn-in floors, as before
+    got = eng.iteration(solver, npb, 0, block, iteration=3, seed=SEED, nchain=8, **kw)
+    assert eng.last_chain_launch() == (8, False)
+    eng2 = _make(name, oracle)[2]
+    for i in range(len(c["oleaves"])):
+        if c["oleaves"][i]["kind"] == 0:
+            eng2.set_grid(i, eng.grid(i))
+        elif c["oleaves"][i].get("adapt", True):
+            eng2.set_distribution(i, eng.distribution(i)[0])
+    eng2.set_reweight(eng.reweight())
+    eng2.set_chain_carry("off")
+    again = eng2.iteration(solver, npb, 0, block, iteration=3, seed=SEED, nchain=8, **kw)
+    np.testing.assert_allclose(got, again, rtol=1e-9, atol=1e-300)

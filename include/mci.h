@@ -263,6 +263,16 @@ int mci_set_rng_rounds(mci_problem *prob, int32_t rounds);
  *  -1  automatic (default): 1 when the iteration's sample launch on this rank is >= 2^26 samples (the walk then costs ~2 % or less), else 0.
  * The environment variable MCI_TRAIN_SERIAL=1|0, read at mci_problem_create, sets the initial mode. */
 int mci_set_train_walk(mci_problem *prob, int32_t mode);
+/* Deterministic mode: with on = 1 a fixed seed gives BIT-IDENTICAL results run to run (histograms, grids, every iteration's mean
+ * and error), like the reference's sequential loop under `MersenneTwister(seed)` (configuration.jl:190, vegas/montecarlo.jl:117-187).
+ * By default the order in which the waves of a workgroup add to its LDS histogram follows the hardware's wave schedule, results
+ * agree run to run at rounding level only, and train! carries those last bits on.  In this mode every solver's kernel keeps one
+ * copy of the workgroup's LDS histograms and observables PER WAVE (the largest of 512 / 256 / 128 / 64 threads whose copies fit a
+ * CU's LDS); a wave's adds are in program order and the copies are summed in a fixed order, as all cross-workgroup merges already
+ * are.  Costs the bank-conflict relief of the interleaved copies (headline configuration: see DESIGN.md); layouts whose histograms
+ * need several LDS tiles (more than ~9 independent 999-bin grids) are refused.  Results still depend on the launch geometry
+ * (mci_set_launch) and on the rank count, as the summation order does. */
+int mci_set_deterministic(mci_problem *prob, int32_t on);
 /* Carried chains (this engine's many-chain decomposition only; nchain = 1, the reference's chain, always starts afresh like
  * montecarlo.jl:151-153 / mcmc/montecarlo.jl:118-124 do at every block): with mode -1 (default) a :vegasmc launch -- with mode 1 a
  * :mcmc launch too; its chains also walk over the integrand index, slowly, and doReweight! steers that walk from the previous

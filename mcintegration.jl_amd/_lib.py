@@ -102,6 +102,7 @@ SIGNATURES = [
     ("mci_set_train_walk", C.c_int, [_VP, C.c_int32]),
     ("mci_set_rng_bits", C.c_int, [_VP, C.c_int32]),
     ("mci_set_rng_rounds", C.c_int, [_VP, C.c_int32]),
+    ("mci_set_deterministic", C.c_int, [_VP, C.c_int32]),
     ("mci_set_chain_carry", C.c_int, [_VP, C.c_int32]),
     ("mci_last_chain_launch", C.c_int, [_VP, C.POINTER(C.c_int64), c_int32_p]),
     ("mci_train", C.c_int, [_VP]),

@@ -189,6 +189,10 @@ struct mci_problem {
     bool time_this_launch = true;
     bool ev_valid[512] = {};      // one per slot of the event ring (kEvRing)
     int hcopy_auto = 1, hcopy_rule = 1; // in force | what the placement rule picked at create
+    // deterministic mode (mci_set_deterministic): every solver's kernel keeps one histogram / observable copy per wave; the workgroup
+    // size each was compiled for (the largest of 512 / 256 / 128 / 64 threads whose copies fit the CU's LDS)
+    bool deterministic = false;
+    int threads_det[3] = {0, 0, 0};
     bool hcopy_plan = false; // the rule also picked the workgroup size (512 threads) for the :vegas kernel
     // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
     // launch before it is long enough to hide its ~35 us per iteration (>= kSerialWalkSamples samples or chain steps on this
@@ -969,9 +973,55 @@ static int64_t vegas_lds(const mci_problem *p) {
     return (s.ec_doubles > 0 ? p->lds_bytes_k1 : p->lds_bytes) + (int64_t)s.htile * 8 * (s.hcopy - 1);
 }
 
+// workgroup size / dynamic LDS of a solver's sample kernel
+static int solver_threads(const mci_problem *p, int solver) {
+    if (p->deterministic && p->threads_det[solver]) return p->threads_det[solver];
+    return solver == MCI_VEGAS && p->threads_vegas ? p->threads_vegas : p->threads;
+}
+static int64_t det_lds(const mci_problem *p, int threads) { // deterministic mode: tables + (threads / 64) histogram and observable copies
+    const auto &s = p->shape;
+    return p->lds_bytes + ((int64_t)s.htile + s.nobs) * 8 * (threads / 64 - 1);
+}
+static int64_t solver_lds(const mci_problem *p, int solver) {
+    if (p->deterministic) return det_lds(p, solver_threads(p, solver));
+    return solver == MCI_VEGAS ? vegas_lds(p) : p->lds_bytes;
+}
+
 static int compile_solver(mci_problem *p, int solver) {
     if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver); // main.jl:263
     if (p->compiled[solver]) return MCI_OK;
+    if (p->deterministic) {
+        // one copy of the LDS histograms (and observables) per wave, as many waves as fit: 512 / 256 / 128 / 64 threads
+        if (p->shape.ntile > 1 || p->shape.table_mode == 1 || p->shape.table_mode == 2 || p->shape.ec_doubles > 0)
+            return fail(MCI_ERR_INVALID, "deterministic mode keeps one copy of the workgroup's histograms per wave in LDS: %d bins (%d tile(s)) do not fit",
+                        p->shape.nbin, p->shape.ntile);
+        int T = solver == MCI_VEGAS ? 512 : (p->threads < 512 ? p->threads : 512); // (the chain kernels need ~200 registers: 256 threads)
+        while (T > 64 && det_lds(p, T) > 159 * 1024) T >>= 1;
+        if (det_lds(p, T) > 159 * 1024) return fail(MCI_ERR_INVALID, "deterministic mode: the tables do not fit one CU's LDS");
+        p->threads_det[solver] = T;
+        p->shape.det = 1;
+        p->shape.hcopy = T / 64;
+        const std::string src = mcijit::generate_source(p->shape, solver);
+        std::vector<char> code;
+        std::string log;
+        bool cached = false;
+        if (mcijit::compile(src, T, code, log, cached, &p->code_object[solver])) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
+        if (mcijit::max_static_lds_bytes(code) != 0) return fail(MCI_ERR_COMPILE, "the code object declares static LDS");
+        if (!p->ctx->offline) {
+            static const char *const names[3] = {"mci_vegas_batch", "mci_vegasmc_chains", "mci_mcmc_chains"};
+            HIPCHK(hipSetDevice(p->ctx->device));
+            HIPCHK(hipModuleLoadData(&p->module[solver], code.data()));
+            HIPCHK(hipModuleGetFunction(&p->f_solver[solver], p->module[solver], names[solver]));
+            if (det_lds(p, T) > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize, (int)det_lds(p, T)));
+            if (solver == MCI_VEGAS) {
+                HIPCHK(hipModuleGetFunction(&p->f_dump, p->module[solver], "mci_sample_dump"));
+                if (p->lds_bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)p->f_dump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+            }
+        }
+        p->compiled[solver] = true;
+        return MCI_OK;
+    }
+    p->shape.det = 0;
     if (p->shape.measure_body.empty() && !p->shape.host_measure) // vegas/montecarlo.jl:104, mcmc/montecarlo.jl:84
         for (int i = 0; i < p->ni; ++i)
             if (p->shape.obs_bin_draw[i] < 0 && p->shape.obs_nbin[i] != p->shape.ncomp)
@@ -1089,6 +1139,17 @@ int mci_set_train_walk(mci_problem *p, int32_t mode) {
     return MCI_OK;
 }
 
+int mci_set_deterministic(mci_problem *p, int32_t on) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    const bool want = on != 0;
+    if (want != p->deterministic) {
+        p->deterministic = want;
+        p->shape.det = want ? 1 : 0;
+        drop_modules(p);
+    }
+    return MCI_OK;
+}
+
 int mci_set_chain_carry(mci_problem *p, int32_t mode) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     if (mode < -1 || mode > 1) return fail(MCI_ERR_INVALID, "chain carry mode must be -1 (automatic: :vegasmc), 0 (every launch starts its chains afresh) or 1 (:vegasmc and :mcmc)");
@@ -1142,7 +1203,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     if ((rc = flush_merge(p))) return rc; // a previous batch nobody looked at: merge it (resets the global histogram)
     HIPCHK(hipSetDevice(p->ctx->device));
     const auto &s = p->shape;
-    const int T = solver == MCI_VEGAS && p->threads_vegas ? p->threads_vegas : p->threads;
+    const int T = solver_threads(p, solver);
     int64_t units = nevalperblock; // lanes of useful work per block
     if (solver != MCI_VEGAS && (block_hi > 4096 || iteration >= 131072 || iteration < 0))
         return fail(MCI_ERR_INVALID, "chain solvers address a chain by (block < 4096, iteration < 131072): got block_hi=%lld, iteration=%d",
@@ -1498,7 +1559,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         if (solver == MCI_VEGASMC) {
             for (int64_t ne = 0; ne <= steps + 1; ++ne) {
                 a.hs.ne = ne;
-                HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+                HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
                 if (ne > steps) break;
                 HIPCHK(hipMemcpyAsync(p->h_hx, p->d_hx, (size_t)nc * nd * sizeof(double), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
@@ -1510,7 +1571,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             const int64_t limit = steps + nburn + 2 + 10000; // (mcmc/montecarlo.jl:118: at most 10000 tries of the start)
             for (int64_t ne = 0;; ++ne) {
                 a.hs.ne = ne;
-                HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+                HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
                 HIPCHK(hipMemcpyAsync(p->h_hidx, a.hs.hidx, (size_t)(nc + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipMemcpyAsync(p->h_hx, p->d_hx, (size_t)nc * nd * sizeof(double), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
@@ -1521,7 +1582,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             }
         }
     } else
-    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)(solver == MCI_VEGAS ? vegas_lds(p) : p->lds_bytes), st, args, nullptr));
+    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
     if (a.hold_hist && (rc = hold_publish(p))) return rc;
     if (split)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));

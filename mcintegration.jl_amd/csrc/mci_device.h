@@ -832,7 +832,7 @@ template <class Cfg> struct Lds {
     static constexpr int DD = DA + Cfg::NDACC;
     static constexpr int H = DD + Cfg::NDDIST;
     static constexpr int O = H + (Mode<Cfg>::HIST_LDS ? Cfg::HTILE * Cfg::HCOPY : 0);
-    static constexpr int R = O + Cfg::NOBS;
+    static constexpr int R = O + Cfg::NOBS * (Cfg::DET != 0 ? Cfg::HCOPY : 1); // (deterministic mode: one observable array per wave, obs_wave)
     static constexpr int PA = R + 16 /*waves*/ * Cfg::NCOLS; // propose | accept counters (u64), chain solvers
     static constexpr int END = PA + 2 * PaTable<Cfg>::N;
 };
@@ -843,7 +843,7 @@ template <class X, class Y> struct SelectType<false, X, Y> { using type = Y; };
 template <class Cfg> struct LdsEC {
     static constexpr int E = 0, DA = Lds<Cfg>::DA, DD = Lds<Cfg>::DD, H = Lds<Cfg>::H;
     static constexpr int O = H;
-    static constexpr int R = O + Cfg::NOBS;
+    static constexpr int R = O + Cfg::NOBS * (Cfg::DET != 0 ? Cfg::HCOPY : 1);
     static constexpr int EC = R + 16 * Cfg::NCOLS;
     static constexpr int END = EC + Cfg::EC_DOUBLES;
 };
@@ -865,9 +865,22 @@ template <class Cfg> struct Cols {
 // 32 / HCOPY bank pairs instead of all 64 lanes colliding at random over the 32 (a random-address ds_add_f64 costs 41 ns per
 // wave-instruction and SIMD, a conflict-free one 13.4; tools/issue_microbench.hip); the copies are summed, in a fixed order,
 // when the workgroup writes its partial histogram.
+// Deterministic mode (Cfg::DET, mci_set_deterministic): HCOPY = the workgroup's waves and every WAVE owns a copy.  A wave's adds to
+// its copy happen in program order, and the lanes of one ds_add_f64 that hit the same bin are served in the hardware's fixed lane
+// order, so the contents of every copy -- and, the copies being summed in a fixed order, the workgroup's partial histogram -- do
+// not depend on how the waves of the workgroup were scheduled: a fixed seed gives bit-identical histograms, hence grids, run to run
+// (the reference's sequential loop is reproducible the same way, configuration.jl:190).  Same for the LDS observables (obs_wave).
 template <class Cfg> __device__ __forceinline__ int hslot(int flat) {
     if constexpr (Cfg::HCOPY == 1) return flat;
+    else if constexpr (Cfg::DET != 0) return (int)(threadIdx.x >> 6) * Cfg::HTILE + flat; // copy-major: a wave's random bins spread over all banks
+                                                                                         // (bin-major, all 64 lanes would share 32 / HCOPY bank pairs)
     else return flat * Cfg::HCOPY + (int)(threadIdx.x & (unsigned)(Cfg::HCOPY - 1));
+}
+// copies of the LDS observable array: one per wave in deterministic mode (HCOPY is the wave count there)
+template <class Cfg> constexpr int ocopy() { return Cfg::DET != 0 ? Cfg::HCOPY : 1; }
+template <class Cfg> __device__ __forceinline__ double *obs_wave(double *sO) {
+    if constexpr (ocopy<Cfg>() == 1) return sO;
+    else return sO + (int)(threadIdx.x >> 6) * Cfg::NOBS;
 }
 
 // histogram update of one sample: accumulate!(var, pos+offset, weight) for every (integrand i, draw k in own(i))
@@ -1076,7 +1089,10 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
         });
         double v = 0.0;
         if (c < Cfg::NOBS && Cfg::HOST_MEASURE != 0) v = 0.0; // the host closure's observables join the row later (k_add_host_obs)
-        else if (c < Cfg::NOBS && binned) v = sO[c];
+        else if (c < Cfg::NOBS && binned) {
+            v = sO[c];
+            static_for<1, ocopy<Cfg>()>([&](auto Cc) { v += sO[decltype(Cc)::value * Cfg::NOBS + c]; }); // (deterministic mode: the waves' copies, fixed order)
+        }
         else
             for (int w = 0; w < nwave; ++w) v += sR[w * Cfg::NCOLS + c]; // fixed order: deterministic
         row[c] = ACCUM ? row[c] + v : v; // (ACCUM: one launch per Markov step adds to the row the host zeroed)
@@ -1092,8 +1108,9 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
             if (tile == tt) {
                 double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
                 for (int i = tid; i < Cfg::tile_nbin(tt); i += T) {
-                    double v = sH[i * Cfg::HCOPY];
-                    static_for<1, Cfg::HCOPY>([&](auto Cc) { v += sH[i * Cfg::HCOPY + decltype(Cc)::value]; }); // fixed order
+                    constexpr int SB = Cfg::DET != 0 ? 1 : Cfg::HCOPY, SC = Cfg::DET != 0 ? Cfg::HTILE : 1; // strides of bin and copy (hslot)
+                    double v = sH[i * SB];
+                    static_for<1, Cfg::HCOPY>([&](auto Cc) { v += sH[i * SB + decltype(Cc)::value * SC]; }); // fixed order
                     hrow[i] = ACCUM ? hrow[i] + v : v;
                 }
             }
@@ -1132,7 +1149,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS && !NOHIST)
         for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
-    for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    for (int i = tid; i < Cfg::NOBS * ocopy<Cfg>(); i += T) sO[i] = 0.0;
     Tables<Cfg> t;
     t.EC = nullptr;
     if constexpr (EC) {
@@ -1211,7 +1228,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
         } else if (domeasure) {
             double relw[Cfg::NW];
             static_for<0, Cfg::NW>([&](auto Q) { constexpr int q = decltype(Q)::value; relw[q] = w[q] * s.jaci[q / Cfg::NCOMP]; }); // :152
-            measure<Cfg>(s.x, s.bin, relw, a.ud, acc, sO);
+            measure<Cfg>(s.x, s.bin, relw, a.ud, acc, obs_wave<Cfg>(sO));
             extra[Cols<Cfg>::NORM - Cfg::NOBS] += 1.0; // :164
         }
         double wh[Cfg::NI];
@@ -1658,7 +1675,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
         for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
-    for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    for (int i = tid; i < Cfg::NOBS * ocopy<Cfg>(); i += T) sO[i] = 0.0;
     u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
     for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;
     __syncthreads();
@@ -1823,7 +1840,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
                 if constexpr (Cfg::HOST_MEASURE != 0) { // :224-227 on the host, after the launch
                     if (tile == 0) host_measure_record<Cfg, Cfg::NW>(a, wi.lb, ch, mj, c.x, relw, -1);
                 } else
-                measure<Cfg>(c.x, c.bin, relw, a.ud, acc, sO);
+                measure<Cfg>(c.x, c.bin, relw, a.ud, acc, obs_wave<Cfg>(sO));
                 extra[XN] += pad[NORMI] / probability;                // :229
                 extra[XV + NORMI] += rw[NORMI] * pad[NORMI] / probability; // :230
             }
@@ -1851,7 +1868,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_host_step(const Bat
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
         for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
-    for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    for (int i = tid; i < Cfg::NOBS * ocopy<Cfg>(); i += T) sO[i] = 0.0;
     u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
     for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;
     __syncthreads();
@@ -1967,7 +1984,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_host_step(const Bat
                     });
                 });
                 if constexpr (Cfg::HOST_MEASURE != 0) host_measure_record<Cfg, Cfg::NW>(a, wi.lb, ch, ne / a.measurefreq, c.x, relw, -1);
-                else measure<Cfg>(c.x, c.bin, relw, a.ud, acc, sO);
+                else measure<Cfg>(c.x, c.bin, relw, a.ud, acc, obs_wave<Cfg>(sO));
                 extra[XN] += pad[NORMI] / probability;                // :229
                 extra[XV + NORMI] += rw[NORMI] * pad[NORMI] / probability; // :230
             }
@@ -2351,7 +2368,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
         for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
-    for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    for (int i = tid; i < Cfg::NOBS * ocopy<Cfg>(); i += T) sO[i] = 0.0;
     u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
     for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;
     __syncthreads();
@@ -2546,10 +2563,10 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                                 double rwv[Cfg::NW];
                                 static_for<0, Cfg::NW>([&](auto Q) { rwv[decltype(Q)::value] = 0.0; });
                                 static_for<0, Cfg::NCOMP>([&](auto Q) { rwv[i * Cfg::NCOMP + decltype(Q)::value] = relw[decltype(Q)::value]; });
-                                Cfg::measure(c.x, rwv, a.ud, i, sO);
+                                Cfg::measure(c.x, rwv, a.ud, i, obs_wave<Cfg>(sO));
                             } else if constexpr (Cfg::obs_bin_draw(i) >= 0) {
                                 const int b = c.bin[Cfg::obs_bin_draw(i)];
-                                if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw[0]);
+                                if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&obs_wave<Cfg>(sO)[Cfg::obs_off(i) + b], relw[0]);
                             }
                         }
                         if constexpr (Cfg::CUSTOM_MEASURE == 0 && Cfg::obs_bin_draw(i) < 0) // :164
@@ -2601,7 +2618,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_host_step(const BatchA
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS)
         for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
-    for (int i = tid; i < Cfg::NOBS; i += T) sO[i] = 0.0;
+    for (int i = tid; i < Cfg::NOBS * ocopy<Cfg>(); i += T) sO[i] = 0.0;
     u64 *sPA = reinterpret_cast<u64 *>(smem + Lds<Cfg>::PA);
     for (int i = tid; i < 2 * PaTable<Cfg>::N; i += T) sPA[i] = 0ull;
     __syncthreads();
@@ -2778,10 +2795,10 @@ template <class Cfg> __device__ __forceinline__ void mcmc_host_step(const BatchA
                                 double rwv[Cfg::NW];
                                 static_for<0, Cfg::NW>([&](auto Q) { rwv[decltype(Q)::value] = 0.0; });
                                 static_for<0, Cfg::NCOMP>([&](auto Q) { rwv[i * Cfg::NCOMP + decltype(Q)::value] = relw[decltype(Q)::value]; });
-                                Cfg::measure(c.x, rwv, a.ud, i, sO);
+                                Cfg::measure(c.x, rwv, a.ud, i, obs_wave<Cfg>(sO));
                             } else if constexpr (Cfg::obs_bin_draw(i) >= 0) {
                                 const int b = c.bin[Cfg::obs_bin_draw(i)];
-                                if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&sO[Cfg::obs_off(i) + b], relw[0]);
+                                if (b >= 0 && b < Cfg::obs_nbin(i)) lds_add(&obs_wave<Cfg>(sO)[Cfg::obs_off(i) + b], relw[0]);
                             }
                         }
                         if constexpr (Cfg::CUSTOM_MEASURE == 0 && Cfg::obs_bin_draw(i) < 0) // :164

@@ -52,6 +52,7 @@ struct ProblemShape {
     int host_integrand = 0;   // weights come from a host callback: over dumped draws (vegas), per Markov step (vegasmc)
     int hcopy = 1;            // :vegas sample kernel: interleaved copies of the LDS histograms (mci_device.h hslot), power of two
     int host_measure = 0;     // observables are accumulated by a host callback over the launch's (measured) configurations and relative weights
+    int det = 0;              // deterministic mode: hcopy = waves per workgroup, one histogram / observable copy per wave, for every solver
     std::vector<int> nneighbor, neighbor; // [ni+1], [(ni+1)*nbmax] 0-based, padded with the integrand itself
     std::string body;
 };
@@ -109,7 +110,7 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
     o << fn_table("int", "leaf_boff", arr(s.leaf_boff, "int"));
     o << fn_table("int", "leaf_adapt", arr(s.leaf_adapt, "int"));
     o << fn_table("int", "leaf_poff", arr(s.leaf_poff, "int"));
-    o << "    static constexpr int NTILE = " << s.ntile << ", HTILE = " << s.htile << ", HCOPY = " << ((solver == 0 && s.hcopy > 0) ? s.hcopy : 1) << ";\n";
+    o << "    static constexpr int NTILE = " << s.ntile << ", HTILE = " << s.htile << ", HCOPY = " << (((solver == 0 || s.det) && s.hcopy > 0) ? s.hcopy : 1) << ", DET = " << (s.det ? 1 : 0) << ";\n";
     o << "    static constexpr int SPLIT_ALL = " << (solver == 0 ? s.split_all : 0) << ", EC_DOUBLES = " << (solver == 0 ? s.ec_doubles : 0)
       << ", L1_PHASE = " << (solver == 0 ? s.l1_phase : 0) << ", RNG_BITS = " << (solver == 0 ? s.rng_bits : 52) << ";\n";
     {

@@ -57,7 +57,8 @@ def device_count():
 
 
 class Engine:
-    def __init__(self, config, integrand, measure=None, device=0, threads=None, wg_per_block=None, rng_bits=None, rng_rounds=None):
+    def __init__(self, config, integrand, measure=None, device=0, threads=None, wg_per_block=None, rng_bits=None, rng_rounds=None,
+                 deterministic=False):
         L = lib()
         self.config = config
         self.device = device
@@ -133,6 +134,8 @@ class Engine:
             check(L.mci_set_rng_bits(self.p, int(rng_bits)))
         if rng_rounds is not None:
             check(L.mci_set_rng_rounds(self.p, int(rng_rounds)))
+        if deterministic:
+            check(L.mci_set_deterministic(self.p, 1))
         nd, no, ps, tm, lds = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64()
         check(L.mci_problem_info(self.p, C.byref(nd), C.byref(no), C.byref(ps), C.byref(tm), C.byref(lds)))
         self.ndraw, self.nobs, self.packed_size, self.table_mode, self.lds_bytes = nd.value, no.value, ps.value, tm.value, lds.value
@@ -397,6 +400,11 @@ class Engine:
     def set_rng_bits(self, bits):
         """:vegas sample stream: 52 (default, the resolution of rand(Float64)) or 32 random bits per draw; see mci_set_rng_bits"""
         check(lib().mci_set_rng_bits(self.p, int(bits)))
+
+    def set_deterministic(self, on=True):
+        """bit-identical results for a fixed seed, run to run (one LDS histogram copy per wave, fixed merge orders); see
+        mci_set_deterministic"""
+        check(lib().mci_set_deterministic(self.p, 1 if on else 0))
 
     def set_chain_carry(self, mode):
         """chain solvers with many chains per block: "auto" (default) -- the next :vegasmc iteration over the same blocks continues

@@ -37,11 +37,12 @@ def required_positionals(fn, fallback):
 def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, block=16, verbose=-1, gamma=1.0,
               adapt=True, debug=False, reweight_goal=None, ignore=None, measure=None, measurefreq=1,
               thermal_ratio=0.1, inplace=False, parallel="nothread", print=-1, printio=None, timer=None,
-              comm=None, device=None, nchain=0, engine_factory=None, rng_bits=52, rng_rounds=10, **kwargs):
+              comm=None, device=None, nchain=0, engine_factory=None, rng_bits=52, rng_rounds=10, deterministic=False, **kwargs):
     """Same keywords as the reference (main.jl:71-90; unknown ones go to Configuration, :95-97).
     Extra, engine-specific keywords: `comm` (LocalComm | RcclComm | TorchDistComm), `device`, `nchain`
     (vegasmc chains per block; 0 = auto), `rng_bits` (52 | 32: opt-in cheaper uniform stream of solver="vegas", see
-    mci_set_rng_bits), `rng_rounds` (10 | 7: opt-in Philox4x32-7 for every stream, mci_set_rng_rounds), `engine_factory` (test seam)."""
+    mci_set_rng_bits), `rng_rounds` (10 | 7: opt-in Philox4x32-7 for every stream, mci_set_rng_rounds), `deterministic` (bit-identical
+    results for a fixed seed like the reference's sequential loop, mci_set_deterministic), `engine_factory` (test seam)."""
     if solver in (":vegas", ":vegasmc", ":mcmc"):
         solver = solver[1:]
     if solver not in SOLVERS:
@@ -75,7 +76,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         measure = HostMeasure(measure, indexed=(required_positionals(measure, 4) >= 5))
     mkey = None if measure is None else measure.body if isinstance(measure, (Measure, HostMeasure)) else (measure.pool, measure.slot, measure.leaf)
     key = (integrand.body, tuple(integrand.userdata), mkey, device,
-           repr(config.neighbor), int(rng_bits), int(rng_rounds))
+           repr(config.neighbor), int(rng_bits), int(rng_rounds), bool(deterministic))
     if config._engine is None or config._engine_key != key:
         # grids trained so far survive a change of integrand (`var = (res.config.var[1], ...)`, docs/src/index.md:129)
         # and so does the learned reweight (config.reweight lives across integrate calls, configuration.jl:50)
@@ -86,7 +87,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
                      for i, lf in enumerate(config.leaves)]
             saved_rw = old.reweight()
         eng = (engine_factory or Engine)(config, integrand, measure=measure, device=device, **({"rng_bits": rng_bits} if rng_bits != 52 else {}),
-                                         **({"rng_rounds": rng_rounds} if rng_rounds != 10 else {}))
+                                         **({"rng_rounds": rng_rounds} if rng_rounds != 10 else {}), **({"deterministic": True} if deterministic else {}))
         if saved is not None:
             for i, lf in enumerate(config.leaves):
                 if saved[i] is not None:   # (a FermiK has nothing trained)

@@ -302,3 +302,52 @@ def test_carried_chains_match_oracle(oracle, name, solver):
     eng2.set_chain_carry("off")
     again = eng2.iteration(solver, npb, 0, block, iteration=3, seed=SEED, nchain=8, **kw)
     np.testing.assert_allclose(got, again, rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.parametrize("solver", ["vegas", "vegasmc", "mcmc"])
+@pytest.mark.parametrize("name", ["c2", "sphere2_padding", "bubble"])
+def test_deterministic_mode_is_bit_reproducible_and_on_the_oracle(oracle, name, solver):
+    """mci_set_deterministic: a fixed seed gives BIT-IDENTICAL iterations, grids and reweight factors run to run -- what the
+    reference's sequential loop under MersenneTwister(seed) gives (configuration.jl:190) -- for every solver, over several iterations
+    with train! in between (which would amplify any last-bit difference of a histogram), with many samples per lane and many chains;
+    and the deterministic kernels are the same arithmetic: one iteration against the oracle at the usual tolerances."""
+    def build():
+        if name == "c2":
+            c = HEADLINE["c2"]
+            cfg = mci.Configuration(var=c["var"](), dof=c["dof"], seed=SEED)
+            return c, cfg, mci.Engine(cfg, c["f"](), deterministic=True), oracle.Config(c["oleaves"], c["dof"])
+        c, cfg, eng, ocfg = _make(name, oracle, deterministic=True)
+        return c, cfg, eng, ocfg
+    runs = []
+    for rep in range(3):
+        c, cfg, eng, ocfg = build()
+        r = eng.integrate(solver, neval=400000, niter=5, block=16, seed=SEED)
+        grids = [eng.grid(i) for i, lf in enumerate(c["oleaves"]) if lf["kind"] == 0]
+        runs.append((r["iter_mean"].copy(), r["iter_std"].copy(), grids, eng.reweight(), eng.get_packed()))
+    for other in runs[1:]:
+        assert np.array_equal(other[0], runs[0][0]) and np.array_equal(other[1], runs[0][1])
+        for g0, g1 in zip(runs[0][2], other[2]):
+            assert np.array_equal(g0, g1)
+        assert np.array_equal(other[3], runs[0][3]) and np.array_equal(other[4], runs[0][4])
+    # ... and the same numbers as the default kernels up to the order of the sums: one iteration against the oracle
+    c, cfg, eng, ocfg = build()
+    osolver = dict(vegas=oracle.VEGAS, vegasmc=oracle.VEGASMC, mcmc=oracle.MCMC)[solver]
+    kw, okw = {}, {}
+    if solver == "mcmc":
+        ocfg.set_thermal_ratio(0.1)
+        kw = dict(thermal_ratio=0.1)
+    if solver != "vegas":
+        kw["nchain"] = okw["nchain"] = 48
+    got = eng.iteration(solver, 20001, 0, 4, iteration=1, seed=SEED, **kw)
+    ref = ocfg.iteration(osolver, c["oname"], c["ud"], 20001, 0, 4, 1, SEED, nthreads=2, **okw)
+    compare(got, ref, eng.nobs, cfg.N, rtol_stat=1e-9, rtol_hist=1e-8)
+    if solver == "vegas":
+        assert eng.histogram_copies() == eng.kernel_times_ms(1)[2] // 64    # one copy per wave
+
+
+def test_deterministic_mode_refuses_layouts_that_need_histogram_tiles():
+    cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
+    eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32), deterministic=True)
+    with pytest.raises(mci.MCIError) as e:
+        eng.iteration("vegas", 2000, 0, 4, iteration=0, seed=SEED)
+    assert "deterministic" in str(e.value)

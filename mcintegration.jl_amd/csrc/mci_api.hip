@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mci_device.h" // BatchArgs / DumpArgs (the templates themselves are instantiated by the JIT)
@@ -130,10 +131,12 @@ struct mci_problem {
     // kernels
     // one code object per solver, JIT-compiled (or loaded from the kernel cache) the first time the solver runs;
     // the vegas module also holds the sample-dump kernel
-    hipModule_t module[3] = {nullptr, nullptr, nullptr};
-    hipFunction_t f_solver[3] = {nullptr, nullptr, nullptr}, f_dump = nullptr;
-    bool compiled[3] = {false, false, false};
-    std::string code_object[3]; // kernel-cache file each solver's code object was loaded from / written to
+    // kernel slots (kslot): :vegas for measurefreq == 1 | :vegasmc | :mcmc | :vegas for any measurefreq | sample dump
+    hipModule_t module[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipFunction_t f_solver[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, f_dump = nullptr;
+    bool compiled[5] = {false, false, false, false, false};
+    std::string code_object[5]; // kernel-cache file each slot's code object was loaded from / written to
+    bool vegas_planned = false, vegas_keys = false; // the :vegas plan (workgroup size, histogram copies, VGPR round keys) stands for both variants
     std::vector<double> h_goal; // reweight_goal (main.jl:81); empty = none
     double *d_goal = nullptr;
     int npa = 0;                    // 3 * (ni+1) * max(ni+1, npool): entries of config.propose (configuration.jl:185)
@@ -146,7 +149,7 @@ struct mci_problem {
     uint32_t *d_tile_bins = nullptr;
     int64_t cap_tile = 0;
     int ntdraw = 0; // draws whose histogram lives in a tile >= 1
-    hipFunction_t f_tiles = nullptr;
+    hipFunction_t f_tiles[2] = {nullptr, nullptr}; // replay kernel of the two :vegas variants
     // second merge stage (partials -> packed), launched lazily: a single-rank mci_iteration_finish fuses it with
     // the refinement (k_finish); anything else that looks at `packed` first flushes it (k_finalize)
     mci::MergeArgs merge{};
@@ -325,7 +328,9 @@ int hold_consume(mci_problem *p) {
 }
 
 void drop_modules(mci_problem *p) {
-    for (int k = 0; k < 3; ++k) {
+    p->vegas_planned = p->vegas_keys = false;
+    p->f_dump = nullptr;
+    for (int k = 0; k < 5; ++k) {
         p->compiled[k] = false;
         if (p->module[k]) {
             (void)hipModuleUnload(p->module[k]);
@@ -358,8 +363,10 @@ int mci_ctx_create(int32_t device, mci_ctx **out) {
         *out = c;
         return MCI_OK;
     }
+    mcijit::warm_up_async(); // (the compiler loads while the HIP runtime initialises the device below)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        mcijit::warm_up_join();
         delete c;
         return fail(MCI_ERR_NO_DEVICE, "no HIP device visible: the MI355X path has no CPU fallback");
     }
@@ -376,6 +383,7 @@ int mci_ctx_create(int32_t device, mci_ctx **out) {
 
 int mci_ctx_destroy(mci_ctx *c) {
     if (!c) return MCI_OK;
+    mcijit::warm_up_join();
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -796,7 +804,7 @@ int mci_problem_destroy(mci_problem *p) {
                         (void *)p->d_packed, (void *)p->d_scratch, (void *)p->d_iterlog, (void *)p->d_dump,
                         (void *)p->d_status, (void *)p->d_leaves})
             if (q) (void)hipFree(q);
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 5; ++k)
             if (p->module[k]) (void)hipModuleUnload(p->module[k]);
         if (p->d_goal) (void)hipFree(p->d_goal);
         if (p->d_part_pa) (void)hipFree(p->d_part_pa);
@@ -987,9 +995,88 @@ static int64_t solver_lds(const mci_problem *p, int solver) {
     return solver == MCI_VEGAS ? vegas_lds(p) : p->lds_bytes;
 }
 
-static int compile_solver(mci_problem *p, int solver) {
-    if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver); // main.jl:263
-    if (p->compiled[solver]) return MCI_OK;
+// ---- JIT of the sample-batch kernels ------------------------------------------------------------------------------------
+// Kernel slots: 0 :vegas for measurefreq == 1 (the reference's default, main.jl:84: the loop without the carried remainder),
+// 1 :vegasmc, 2 :mcmc, 3 :vegas for any measurefreq -- each its own code object, compiled the first time it is needed (a new
+// integrand pays for the loop it runs, not for both).  The sample-dump kernel is a fifth, equally lazy one.
+enum { kSlotVegasAny = 3, kSlotDump = 4 };
+static int kslot(int solver, int64_t measurefreq) { return solver == MCI_VEGAS && measurefreq != 1 ? kSlotVegasAny : solver; }
+static int slot_solver(int slot) { return slot == kSlotVegasAny ? MCI_VEGAS : slot; }
+
+namespace {
+struct Candidate { // one hiprtc job
+    std::string src;
+    int threads = 256;
+    std::vector<char> code;
+    std::string log, path;
+    bool cached = false;
+    int rc = 0;
+    long vgprs() const { return mcijit::kernel_vgprs(code, "mci_vegas_batch"); }
+    long scratch() const { return mcijit::kernel_scratch_bytes(code, "mci_vegas_batch"); }
+};
+// the candidates of a plan are independent translation units: compiled side by side (hiprtc is re-entrant), so a plan that has to
+// look at two or three of them before it knows which one runs costs the latency of the slowest, not their sum
+void compile_all(std::vector<Candidate *> &cs) {
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < cs.size(); ++i)
+        th.emplace_back([c = cs[i]] { c->rc = mcijit::compile(c->src, c->threads, c->code, c->log, c->cached, &c->path); });
+    if (!cs.empty()) cs[0]->rc = mcijit::compile(cs[0]->src, cs[0]->threads, cs[0]->code, cs[0]->log, cs[0]->cached, &cs[0]->path);
+    for (auto &t : th) t.join();
+}
+} // namespace
+
+static int load_slot(mci_problem *p, int slot, Candidate &c, int64_t lds) {
+    if (mcijit::max_static_lds_bytes(c.code) != 0) // (mci_device.h draw_leaf: the pair table is addressed from LDS address 0)
+        return fail(MCI_ERR_COMPILE, "the code object declares static LDS (%ld bytes): the sample kernels expect their dynamic segment at LDS address 0",
+                    mcijit::max_static_lds_bytes(c.code));
+    p->code_object[slot] = c.path;
+    if (p->ctx->offline) return MCI_OK;
+    static const char *const names[5] = {"mci_vegas_batch", "mci_vegasmc_chains", "mci_mcmc_chains", "mci_vegas_batch", "mci_sample_dump"};
+    HIPCHK(hipSetDevice(p->ctx->device));
+    if (hipModuleLoadData(&p->module[slot], c.code.data()) != hipSuccess) {
+        // a cached code object that does not load (truncated by a crash, foreign file): drop it and compile afresh, once
+        if (!c.cached) return fail(MCI_ERR_HIP, "hipModuleLoadData failed for a freshly compiled code object");
+        unlink(c.path.c_str());
+        if (mcijit::compile(c.src, c.threads, c.code, c.log, c.cached, &c.path)) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", c.log.c_str());
+        HIPCHK(hipModuleLoadData(&p->module[slot], c.code.data()));
+    }
+    HIPCHK(hipModuleGetFunction(&p->f_solver[slot], p->module[slot], names[slot]));
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[slot], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (slot_solver(slot) == MCI_VEGAS && slot != kSlotDump && p->shape.ntile > 1) {
+        HIPCHK(hipModuleGetFunction(&p->f_tiles[slot == kSlotVegasAny ? 1 : 0], p->module[slot], "mci_vegas_tiles"));
+        if (p->lds_bytes > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)p->f_tiles[slot == kSlotVegasAny ? 1 : 0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    }
+    return MCI_OK;
+}
+
+// the map + integrand alone (mci_sample_dump, host integrands): its own small code object
+static int ensure_dump(mci_problem *p) {
+    if (p->compiled[kSlotDump]) return MCI_OK;
+    Candidate c;
+    mcijit::ProblemShape sh = p->shape;
+    sh.hcopy = 1;
+    sh.det = 0;
+    c.src = mcijit::generate_source(sh, MCI_VEGAS, mcijit::kUnitDump);
+    c.threads = 256;
+    c.rc = mcijit::compile(c.src, c.threads, c.code, c.log, c.cached, &c.path);
+    if (c.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", c.log.c_str());
+    int rc = load_slot(p, kSlotDump, c, p->lds_bytes);
+    if (rc) return rc;
+    p->f_dump = p->f_solver[kSlotDump];
+    p->compiled[kSlotDump] = true;
+    return MCI_OK;
+}
+
+static int compile_solver(mci_problem *p, int slot) {
+    if (slot < 0 || slot > kSlotVegasAny) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", slot); // main.jl:263
+    if (p->compiled[slot]) return MCI_OK;
+    const int solver = slot_solver(slot);
+    const int unit = slot == MCI_VEGAS ? mcijit::kUnitVegasMf1 : mcijit::kUnitSolver;
+    if (p->shape.measure_body.empty() && !p->shape.host_measure) // vegas/montecarlo.jl:104, mcmc/montecarlo.jl:84
+        for (int i = 0; i < p->ni; ++i)
+            if (p->shape.obs_bin_draw[i] < 0 && p->shape.obs_nbin[i] != p->shape.ncomp)
+                return fail(MCI_ERR_INVALID, "the default measure can only handle observable as Vector with %d scalar elements!", p->ni);
     if (p->deterministic) {
         // one copy of the LDS histograms (and observables) per wave, as many waves as fit: 512 / 256 / 128 / 64 threads
         if (p->shape.ntile > 1 || p->shape.table_mode == 1 || p->shape.table_mode == 2 || p->shape.ec_doubles > 0)
@@ -1001,104 +1088,111 @@ static int compile_solver(mci_problem *p, int solver) {
         p->threads_det[solver] = T;
         p->shape.det = 1;
         p->shape.hcopy = T / 64;
-        const std::string src = mcijit::generate_source(p->shape, solver);
-        std::vector<char> code;
-        std::string log;
-        bool cached = false;
-        if (mcijit::compile(src, T, code, log, cached, &p->code_object[solver])) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
-        if (mcijit::max_static_lds_bytes(code) != 0) return fail(MCI_ERR_COMPILE, "the code object declares static LDS");
-        if (!p->ctx->offline) {
-            static const char *const names[3] = {"mci_vegas_batch", "mci_vegasmc_chains", "mci_mcmc_chains"};
-            HIPCHK(hipSetDevice(p->ctx->device));
-            HIPCHK(hipModuleLoadData(&p->module[solver], code.data()));
-            HIPCHK(hipModuleGetFunction(&p->f_solver[solver], p->module[solver], names[solver]));
-            if (det_lds(p, T) > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize, (int)det_lds(p, T)));
-            if (solver == MCI_VEGAS) {
-                HIPCHK(hipModuleGetFunction(&p->f_dump, p->module[solver], "mci_sample_dump"));
-                if (p->lds_bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)p->f_dump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
-            }
-        }
-        p->compiled[solver] = true;
+        Candidate c;
+        c.src = mcijit::generate_source(p->shape, solver, unit);
+        c.threads = T;
+        c.rc = mcijit::compile(c.src, c.threads, c.code, c.log, c.cached, &c.path);
+        if (c.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", c.log.c_str());
+        if (int rc = load_slot(p, slot, c, det_lds(p, T))) return rc;
+        p->compiled[slot] = true;
         return MCI_OK;
     }
     p->shape.det = 0;
-    if (p->shape.measure_body.empty() && !p->shape.host_measure) // vegas/montecarlo.jl:104, mcmc/montecarlo.jl:84
-        for (int i = 0; i < p->ni; ++i)
-            if (p->shape.obs_bin_draw[i] < 0 && p->shape.obs_nbin[i] != p->shape.ncomp)
-                return fail(MCI_ERR_INVALID, "the default measure can only handle observable as Vector with %d scalar elements!", p->ni);
-    const bool hcopy_plan = solver == MCI_VEGAS && p->hcopy_plan && !getenv("MCI_HIST_COPIES");
-    if (solver == MCI_VEGAS) {
-        int t = 512;
-        p->shape.hcopy = planned_hcopy(p, &t);
-        if (p->hcopy_plan) p->threads_vegas = t;
-    }
-    std::string src = mcijit::generate_source(p->shape, solver);
-    std::vector<char> code;
-    std::string log;
-    bool cached = false;
-    int T = solver == MCI_VEGAS && p->threads_vegas ? p->threads_vegas : p->threads;
-    // The copy plan runs four waves per SIMD whatever the kernel needs up to 128 VGPRs, so registers below that line are free: the
-    // pipelined sample loop (mci_device.h draw_sample_pipe) first asks for its Philox round keys in VGPRs (20 registers; the all-VGPR
-    // v_bitop3_b32 issues faster than the form with an SGPR key: C2 1.358 -> 1.331 ms per 1e8 samples) and falls back to SGPR keys
-    // when that would cross the line
     static const char *const kVgprKeys = "#define MCI_PIPE_VGPR_KEYS 1\n";
-    int rc = mcijit::compile(hcopy_plan ? kVgprKeys + src : src, T, code, log, cached, &p->code_object[solver]);
-    if (rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
-    long hc_vgprs = hcopy_plan ? mcijit::kernel_vgprs(code, "mci_vegas_batch") : 0;
-    if (hcopy_plan && (hc_vgprs > 128 || mcijit::kernel_scratch_bytes(code, "mci_vegas_batch") != 0)) {
-        if ((rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
-        hc_vgprs = mcijit::kernel_vgprs(code, "mci_vegas_batch");
-    }
-    if (hcopy_plan && (hc_vgprs > 128 || hc_vgprs <= 80)) {
-        // Histogram copies pay when the kernel runs four or five waves per SIMD either way (81..128 VGPRs: two 512-thread workgroups
-        // share a CU).  More registers: two such workgroups no longer fit.  Fewer: the plain layout runs six or more waves per SIMD
-        // in 256-thread workgroups and the 80 KB of copies would cap it at four (C5 :vegas, 78 VGPRs: 1.88 ms per 1e8 samples plain,
-        // 2.21 ms with 8 copies; C2, 92 VGPRs with the copies / 101 plain: see profiles/r02_ablation.txt; warm tools/hcopy_sweep.sh)
-        p->shape.hcopy = 1;
-        p->threads_vegas = 0;
-        T = p->threads;
-        src = mcijit::generate_source(p->shape, solver);
-        if ((rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
-    }
-    while (solver == MCI_VEGAS && p->vegas_plan_a && T > 512 && mcijit::kernel_scratch_bytes(code, "mci_vegas_batch") != 0) {
-        // the sample pass keeps too many values live for this many waves per SIMD: next rung (1024 -> 768 -> 512 threads)
-        T = T == 1024 ? 768 : 512;
-        p->threads_vegas = T;
-        if ((rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
-    }
-    if (mcijit::max_static_lds_bytes(code) != 0) // (mci_device.h draw_leaf: the pair table is addressed from LDS address 0)
-        return fail(MCI_ERR_COMPILE, "the code object declares static LDS (%ld bytes): the sample kernels expect their dynamic segment at LDS address 0",
-                    mcijit::max_static_lds_bytes(code));
-    if (!p->ctx->offline) {
-        static const char *const names[3] = {"mci_vegas_batch", "mci_vegasmc_chains", "mci_mcmc_chains"};
-        HIPCHK(hipSetDevice(p->ctx->device));
-        if (hipModuleLoadData(&p->module[solver], code.data()) != hipSuccess) {
-            // a cached code object that does not load (truncated by a crash, foreign file): drop it and compile afresh, once
-            if (!cached) return fail(MCI_ERR_HIP, "hipModuleLoadData failed for a freshly compiled code object");
-            unlink(p->code_object[solver].c_str());
-            if ((rc = mcijit::compile(src, T, code, log, cached, &p->code_object[solver]))) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", log.c_str());
-            HIPCHK(hipModuleLoadData(&p->module[solver], code.data()));
+    Candidate chosen;
+    if (solver != MCI_VEGAS) {
+        chosen.src = mcijit::generate_source(p->shape, solver, unit);
+        chosen.threads = p->threads;
+        chosen.rc = mcijit::compile(chosen.src, chosen.threads, chosen.code, chosen.log, chosen.cached, &chosen.path);
+        if (chosen.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", chosen.log.c_str());
+    } else if (p->vegas_planned) {
+        // the other measurefreq variant of a kernel whose plan (workgroup size, histogram copies, round keys) stands
+        chosen.src = (p->vegas_keys ? std::string(kVgprKeys) : std::string()) + mcijit::generate_source(p->shape, solver, unit);
+        chosen.threads = p->threads_vegas ? p->threads_vegas : p->threads;
+        chosen.rc = mcijit::compile(chosen.src, chosen.threads, chosen.code, chosen.log, chosen.cached, &chosen.path);
+        if (chosen.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", chosen.log.c_str());
+        if (p->vegas_keys && (chosen.vgprs() > 128 || chosen.scratch() != 0)) { // (this variant carries a few registers more)
+            chosen.src = mcijit::generate_source(p->shape, solver, unit);
+            chosen.rc = mcijit::compile(chosen.src, chosen.threads, chosen.code, chosen.log, chosen.cached, &chosen.path);
+            if (chosen.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", chosen.log.c_str());
         }
-        HIPCHK(hipModuleGetFunction(&p->f_solver[solver], p->module[solver], names[solver]));
-        if (solver == MCI_VEGAS) HIPCHK(hipModuleGetFunction(&p->f_dump, p->module[solver], "mci_sample_dump"));
-        if (solver == MCI_VEGAS && p->shape.ntile > 1) {
-            HIPCHK(hipModuleGetFunction(&p->f_tiles, p->module[solver], "mci_vegas_tiles"));
-            if (p->lds_bytes > 64 * 1024)
-                HIPCHK(hipFuncSetAttribute((const void *)p->f_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    } else {
+        const bool hcopy_plan = p->hcopy_plan && !getenv("MCI_HIST_COPIES");
+        int tcopy = 512;
+        p->shape.hcopy = planned_hcopy(p, &tcopy);
+        if (p->hcopy_plan) p->threads_vegas = tcopy;
+        const int T0 = p->threads_vegas ? p->threads_vegas : p->threads;
+        if (hcopy_plan) {
+            // Histogram copies pay when the kernel runs four or five waves per SIMD either way (81..128 VGPRs: two 512-thread workgroups
+            // share a CU).  More registers: two such workgroups no longer fit.  Fewer: the plain layout runs six or more waves per SIMD
+            // in 256-thread workgroups and the 80 KB of copies would cap it at four (C5 :vegas, 78 VGPRs: 1.88 ms per 1e8 samples plain,
+            // 2.21 ms with 8 copies; profiles/r02_ablation.txt).  And up to 128 VGPRs registers are free on the copy plan: the pipelined
+            // sample loop (mci_device.h draw_sample_pipe) asks for its Philox round keys in VGPRs (20 registers; the all-VGPR v_bitop3_b32
+            // issues faster than the form with an SGPR key: C2 1.358 -> 1.331 ms per 1e8 samples) unless that crosses the line.
+            // Candidates, compiled side by side: [copies + VGPR keys], [plain layout]; [copies, SGPR keys] only if the first is too fat.
+            Candidate keys, plain, nokeys;
+            const std::string with_copies = mcijit::generate_source(p->shape, solver, unit);
+            keys.src = kVgprKeys + with_copies;
+            keys.threads = nokeys.threads = T0;
+            nokeys.src = with_copies;
+            mcijit::ProblemShape sh = p->shape;
+            sh.hcopy = 1;
+            plain.src = mcijit::generate_source(sh, solver, unit);
+            plain.threads = p->threads;
+            std::vector<Candidate *> both = {&keys, &plain};
+            compile_all(both);
+            if (keys.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", keys.log.c_str());
+            if (plain.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", plain.log.c_str());
+            Candidate *copy = &keys;
+            p->vegas_keys = true;
+            if (keys.vgprs() > 128 || keys.scratch() != 0) {
+                nokeys.rc = mcijit::compile(nokeys.src, nokeys.threads, nokeys.code, nokeys.log, nokeys.cached, &nokeys.path);
+                if (nokeys.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", nokeys.log.c_str());
+                copy = &nokeys;
+                p->vegas_keys = false;
+            }
+            if (copy->vgprs() > 128 || copy->vgprs() <= 80) { // the plain layout
+                p->shape.hcopy = 1;
+                p->threads_vegas = 0;
+                p->vegas_keys = false;
+                chosen = std::move(plain);
+            } else chosen = std::move(*copy);
+        } else if (p->vegas_plan_a) {
+            // many-grid plans (one workgroup per CU owns the LDS): the largest of 1024 / 768 / 512 threads at which the sample pass shows
+            // no scratch -- the rungs compiled side by side
+            Candidate rung[3];
+            const std::string src = mcijit::generate_source(p->shape, solver, unit);
+            const int ts[3] = {1024, 768, 512};
+            std::vector<Candidate *> all;
+            for (int i = 0; i < 3; ++i) {
+                rung[i].src = src;
+                rung[i].threads = ts[i];
+                if (ts[i] <= T0) all.push_back(&rung[i]);
+            }
+            compile_all(all);
+            size_t pick = all.size() - 1;
+            for (size_t i = 0; i < all.size(); ++i) {
+                if (all[i]->rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", all[i]->log.c_str());
+                if (all[i]->scratch() == 0) { pick = i; break; }
+            }
+            p->threads_vegas = all[pick]->threads;
+            chosen = std::move(*all[pick]);
+        } else {
+            chosen.src = mcijit::generate_source(p->shape, solver, unit);
+            chosen.threads = T0;
+            chosen.rc = mcijit::compile(chosen.src, chosen.threads, chosen.code, chosen.log, chosen.cached, &chosen.path);
+            if (chosen.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", chosen.log.c_str());
         }
-        if (solver == MCI_VEGAS && vegas_lds(p) > p->lds_bytes && vegas_lds(p) > 64 * 1024) {
-            HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize, (int)vegas_lds(p)));
-            if (p->lds_bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)p->f_dump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
-        } else if (solver == MCI_VEGAS && p->shape.ec_doubles > 0 && p->lds_bytes_k1 > 64 * 1024)
-            HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(p->lds_bytes_k1 > p->lds_bytes ? p->lds_bytes_k1 : p->lds_bytes)));
-        else if (p->lds_bytes > 64 * 1024) {
-            HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[solver], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
-            if (solver == MCI_VEGAS)
-                HIPCHK(hipFuncSetAttribute((const void *)p->f_dump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
-        }
+        p->vegas_planned = true;
     }
-    p->compiled[solver] = true;
+    int64_t lds = p->lds_bytes;
+    if (solver == MCI_VEGAS) {
+        lds = vegas_lds(p);
+        if (p->shape.ec_doubles > 0 && p->lds_bytes_k1 > lds) lds = p->lds_bytes_k1;
+        if (p->lds_bytes > lds) lds = p->lds_bytes;
+    }
+    if (int rc = load_slot(p, slot, chosen, lds)) return rc;
+    p->compiled[slot] = true;
     return MCI_OK;
 }
 
@@ -1107,8 +1201,9 @@ int mci_compile(mci_problem *p) { return compile_solver(p, MCI_VEGAS); }
 int mci_kernel_code_object(mci_problem *p, int32_t solver, char *buf, int32_t n) {
     if (!p || !buf || n < 1) return fail(MCI_ERR_INVALID, "NULL argument");
     if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver);
-    if (!p->compiled[solver]) return fail(MCI_ERR_INVALID, "solver %d has not been compiled yet", solver);
-    snprintf(buf, (size_t)n, "%s", p->code_object[solver].c_str());
+    const int slot = (solver == MCI_VEGAS && !p->compiled[solver] && p->compiled[kSlotVegasAny]) ? kSlotVegasAny : solver;
+    if (!p->compiled[slot]) return fail(MCI_ERR_INVALID, "solver %d has not been compiled yet", solver);
+    snprintf(buf, (size_t)n, "%s", p->code_object[slot].c_str());
     return MCI_OK;
 }
 
@@ -1170,11 +1265,14 @@ int mci_check_status(mci_problem *p) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
     return check_status(p);
 }
-int mci_compile_solver(mci_problem *p, int32_t solver) { return compile_solver(p, solver); }
+int mci_compile_solver(mci_problem *p, int32_t solver) {
+    if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver); // main.jl:263
+    return compile_solver(p, solver);
+}
 
 int mci_get_histogram_copies(const mci_problem *p, int32_t *copies) {
     if (!p || !copies) return fail(MCI_ERR_INVALID, "NULL argument");
-    *copies = p->compiled[MCI_VEGAS] ? p->shape.hcopy : planned_hcopy(p, nullptr);
+    *copies = (p->compiled[MCI_VEGAS] || p->compiled[kSlotVegasAny]) ? p->shape.hcopy : planned_hcopy(p, nullptr);
     return MCI_OK;
 }
 
@@ -1198,8 +1296,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     const int64_t nblocks = block_hi - block_lo;
     if (nblocks < 1 || nevalperblock < 1) return fail(MCI_ERR_INVALID, "empty iteration");
     if (p->has_fermik && solver != MCI_MCMC) return fail(MCI_ERR_INVALID, "FermiK variables work with solver=:mcmc only"); // test/bubble_FermiK.jl:2,:133
-    int rc = compile_solver(p, solver);
+    const int kern = kslot(solver, measurefreq);
+    int rc = compile_solver(p, kern);
     if (rc) return rc;
+    if (solver == MCI_VEGAS && p->shape.host_integrand && (rc = ensure_dump(p))) return rc;
     if ((rc = flush_merge(p))) return rc; // a previous batch nobody looked at: merge it (resets the global histogram)
     HIPCHK(hipSetDevice(p->ctx->device));
     const auto &s = p->shape;
@@ -1495,7 +1595,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         }
     }
     void *args[] = {&a};
-    hipFunction_t f = p->f_solver[solver];
+    hipFunction_t f = p->f_solver[kern];
     hipStream_t st = p->ctx->stream;
     const int slot = (int)(p->launches % mci_problem::kEvRing);
     // HIP events around the sample launch (mci_kernel_times_ms): each record is a barrier packet with a signal, ~5.5 us of idle
@@ -1585,7 +1685,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
     if (a.hold_hist && (rc = hold_publish(p))) return rc;
     if (split)
-        HIPCHK(hipModuleLaunchKernel(p->f_tiles, (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+        HIPCHK(hipModuleLaunchKernel(p->f_tiles[kern == kSlotVegasAny ? 1 : 0], (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (!p->graph_mode) {
         if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
         p->ev_valid[slot] = p->time_this_launch;
@@ -1861,7 +1961,8 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     mci_standardize_block(a->neval, a->block, p->ctx->nranks, &nevalperblock, &block); // main.jl:121
     const int64_t per = block / p->ctx->nranks;                                         // main.jl:122
     const int64_t lo = per * p->ctx->rank, hi = lo + per;
-    int rc = compile_solver(p, a->solver);
+    if (a->solver != MCI_VEGAS && a->solver != MCI_VEGASMC && a->solver != MCI_MCMC) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", a->solver); // main.jl:263
+    int rc = compile_solver(p, kslot(a->solver, a->measurefreq));
     if (rc) return rc;
     if ((rc = mci_set_reweight_goal(p, a->reweight_goal, a->reweight_goal ? p->ni + 1 : 0))) return rc;
     const int ignore = a->ignore >= 0 ? a->ignore : (a->adapt ? 1 : 0);
@@ -2168,7 +2269,7 @@ int mci_sample_dump(mci_problem *p, int32_t iteration, uint64_t seed, int64_t ne
                     double *x, double *jac, double *w) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
     if (n < 1 || n > nevalperblock) return fail(MCI_ERR_INVALID, "n must be in 1..neval_per_block");
-    int rc = mci_compile(p);
+    int rc = ensure_dump(p);
     if (rc) return rc;
     HIPCHK(hipSetDevice(p->ctx->device));
     const auto &s = p->shape;

@@ -1374,16 +1374,12 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
         }
     }
     };
-#ifndef MCI_MF1_LOOP
-#define MCI_MF1_LOOP 1
+    // MCI_MF_ONLY (set by the generated translation unit): 1 = this code object is the loop for measurefreq == 1 and nothing else (the
+    // host launches it for that cadence only), 0 = the loop for any cadence; each is compiled the first time a launch needs it
+#ifndef MCI_MF_ONLY
+#define MCI_MF_ONLY 0
 #endif
-    auto run_mf = [&](auto TT) {
-#if MCI_MF1_LOOP
-        if (mfreq == 1) run(TT, IC<1>{});
-        else
-#endif
-            run(TT, IC<0>{});
-    };
+    auto run_mf = [&](auto TT) { run(TT, IC<(MCI_MF_ONLY != 0 ? 1 : 0)>{}); };
     if constexpr (Cfg::NTILE == 1 || SPLIT) run_mf(IC<0>{});
     else static_for<0, Cfg::NTILE>([&](auto TT) { if (tile == decltype(TT)::value) run_mf(TT); });
     __syncthreads();

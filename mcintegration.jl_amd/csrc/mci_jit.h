@@ -10,6 +10,8 @@
 #include <hip/hiprtc.h>
 
 #include <atomic>
+#include <mutex>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -88,9 +90,12 @@ static std::string dbl_arr(const std::vector<double> &v) {
     return o.str();
 }
 
-// solver: 0 vegas (+ sample dump), 1 vegasmc, 2 mcmc -- one code object per solver, built on first use
-inline std::string generate_source(const ProblemShape &s, int solver) {
+// solver: 0 vegas, 1 vegasmc, 2 mcmc.  unit: what the translation unit holds -- the solver's kernel (for :vegas: the loop for any
+// measurefreq), the :vegas kernel specialised on measurefreq == 1, or the sample-dump kernel alone; each is built on first use
+enum { kUnitSolver = 0, kUnitVegasMf1 = 1, kUnitDump = 2 };
+inline std::string generate_source(const ProblemShape &s, int solver, int unit = kUnitSolver) {
     std::ostringstream o;
+    if (solver == 0 && unit != kUnitDump) o << "#define MCI_MF_ONLY " << (unit == kUnitVegasMf1 ? 1 : 0) << "\n";
     if (s.rng_rounds != 10) o << "#define MCI_PHILOX_ROUNDS " << s.rng_rounds << "\n"; // opt-in cheaper stream (mci_set_rng_rounds)
     o << "#include \"mci_device.h\"\n";
     o << "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n";
@@ -150,14 +155,15 @@ inline std::string generate_source(const ProblemShape &s, int solver) {
          "#define obs_add(k, v) mci::lds_add(&mci_obs_[(k)], (v))\n"
       << s.measure_body << "\n#undef obs_add\n    }\n";
     o << "};\n}\n";
-    if (solver == 0) {
+    if (solver == 0 && unit == kUnitDump) {
+        o << "extern \"C\" __global__ void __launch_bounds__(256) mci_sample_dump(mci::DumpArgs a) { "
+             "mci::sample_dump<Cfg>(a); }\n";
+    } else if (solver == 0) {
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) MCI_OCC mci_vegas_batch(mci::BatchArgs a) { "
              "mci::vegas_batch<Cfg, (Cfg::NTILE > 1)>(a); }\n";
         if (s.ntile > 1)
             o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_tiles(mci::BatchArgs a) { "
                  "mci::vegas_tiles<Cfg>(a); }\n";
-        o << "extern \"C\" __global__ void __launch_bounds__(256) mci_sample_dump(mci::DumpArgs a) { "
-             "mci::sample_dump<Cfg>(a); }\n";
     } else if (solver == 1) {
         // (a host integrand: the step cut at the integrand call, one launch per Markov step -- same entry point)
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_chains(mci::BatchArgs a) { "
@@ -244,6 +250,36 @@ inline std::string cache_dir() {
     return dir;
 }
 
+// hiprtc's first compile of a process loads the compiler (comgr, ~0.3 s on this image): mci_ctx_create starts it on a thread of its
+// own, next to the HIP runtime's own device initialisation, so that the first real compile finds it loaded
+struct WarmUp {
+    std::thread th;
+    std::mutex mu;
+    bool started = false;
+};
+inline WarmUp &warm_up_state() {
+    static WarmUp w;
+    return w;
+}
+inline void warm_up_async() {
+    WarmUp &w = warm_up_state();
+    std::lock_guard<std::mutex> g(w.mu);
+    if (w.started) return;
+    w.started = true;
+    w.th = std::thread([] {
+        hiprtcProgram prog;
+        if (hiprtcCreateProgram(&prog, "extern \"C\" __global__ void mci_warm_up(double* a) { a[0] = 1.0; }", "mci_warm_up.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return;
+        const char *opts[] = {"--offload-arch=gfx950"};
+        (void)hiprtcCompileProgram(prog, 1, opts);
+        hiprtcDestroyProgram(&prog);
+    });
+}
+inline void warm_up_join() {
+    WarmUp &w = warm_up_state();
+    std::lock_guard<std::mutex> g(w.mu);
+    if (w.th.joinable()) w.th.join();
+}
+
 // returns the gfx950 code object for `src`, from the on-disk cache or by compiling with hiprtc
 inline int compile(const std::string &src, int threads, std::vector<char> &code, std::string &log, bool &from_cache, std::string *cache_path = nullptr) {
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics",
@@ -274,6 +310,7 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
         std::ofstream f(e);
         f << src;
     }
+    warm_up_join();
     hiprtcProgram prog;
     const char *hdr = kDeviceHeader, *hname = "mci_device.h";
     if (hiprtcCreateProgram(&prog, src.c_str(), "mci_problem.hip", 1, &hdr, &hname) != HIPRTC_SUCCESS) {

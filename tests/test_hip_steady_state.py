@@ -154,11 +154,12 @@ def test_random_pipelined_layouts_with_forced_geometry_match_oracle(oracle, case
     np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300, err_msg=what + "\n" + body)
 
 
-@pytest.mark.parametrize("threads,mfreq", [(None, 1), (None, 3), (512, 1)], ids=["plan_a_768", "plan_a_768_mf3", "plan_b_512"])
+@pytest.mark.parametrize("threads,mfreq", [(None, 1), (None, 3), (768, 1), (512, 1)], ids=["plan_a_1024", "plan_a_mf3", "768", "plan_b_512"])
 def test_c4_many_grids_many_trips_matches_oracle(oracle, threads, mfreq):
-    """BASELINE configs[3] (32 independent grids): ONE workgroup per block walks 65 (768 threads) / 97 (512) phased trips of the
-    split-all sample pass -- hand-pipelined gather phase, LDS edge cache, bins packed as drawn, weights and bins parked in HBM -- and
-    the replay kernel 9 / 13 trips of 8 (4) samples per lane into its two skewed bin-major tiles."""
+    """BASELINE configs[3] (32 independent grids): ONE workgroup per block walks 48 (1024 threads) / 65 (768) / 97 (512) phased trips of
+    the split-all sample pass -- hand-pipelined gather phase, LDS edge cache, bins packed as drawn, weights and bins parked in HBM --
+    and the replay kernel 7 / 9 / 13 trips of 8 (4) samples per lane into its two skewed bin-major tiles.  (measurefreq = 3 runs the
+    any-cadence code object, whose loop carries the remainder: it may sit one rung lower on the 1024 / 768 / 512 ladder.)"""
     ud = genz_userdata(32)
     cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
     eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32), wg_per_block=1, **(dict(threads=threads) if threads else {}))
@@ -168,7 +169,7 @@ def test_c4_many_grids_many_trips_matches_oracle(oracle, threads, mfreq):
     got = eng.iteration("vegas", npb, 2, 4, iteration=1, seed=SEED, measurefreq=mfreq)
     ref = ocfg.iteration(oracle.VEGAS, "genz_product_peak", ud, npb, 2, 4, 1, SEED, measurefreq=mfreq, nthreads=2)
     _, wg, th = eng.kernel_times_ms(1)
-    assert wg == 2 and th == (threads or 768)
+    assert wg == 2 and (th == threads if threads else th in (1024, 768)), (wg, th)
     compare(got, ref, eng.nobs, cfg.N)
     # equal totals in every grid's histogram (each sample adds its weight once per grid): a bin unpacked from the wrong field would
     # still conserve the total, a dropped or doubled sample would not

@@ -176,9 +176,6 @@ struct mci_problem {
     int64_t cap_hmeas = 0, cap_mobs = 0;
     std::vector<double> h_mtmp;                     // callback form != record form: rows regrouped here
     std::vector<int32_t> h_mitmp;
-    // hipGraph replay of the iteration chain (mci_integrate, single rank): device-side {iteration, log row}
-    unsigned *d_loop = nullptr;
-    bool graph_mode = false; // while capturing: no event records, iteration/log row come from d_loop
     int threads = 256, wg_per_block = 0; // 0 = auto
     // :vegas kernels whose tables take more than half of a CU's LDS (one workgroup per CU: 16 or 32 independent grids) pick their
     // workgroup size from the compiled code: the largest of 1024 / 768 / 512 threads (4 / 3 / 2 waves per SIMD) at which the sample
@@ -641,7 +638,6 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         if (const char *e = getenv("MCI_TRAIN_SERIAL")) p->train_serial = atoi(e) != 0 ? 1 : 0;
         if (const char *e = getenv("MCI_CHAIN_CARRY")) p->chain_carry = atoi(e) == 0 ? 0 : atoi(e) > 0 ? 1 : -1; // (mci_set_chain_carry)
         if (const char *e = getenv("MCI_KERNEL_TIMING")) p->kernel_timing = atoi(e) < 0 ? -1 : atoi(e) > 0 ? 1 : 0; // (mci_set_kernel_timing)
-        if (const char *e = getenv("MCI_PAIR_TABLE")) pair = (atoi(e) != 0 && mode <= 1 && fixed + e2 + (mode == 0 ? hb : 0) <= lim1) ? 1 : 0;
         // histogram tiles: contiguous leaves, each tile's bins fit the LDS left over
         s.leaf_tile.assign(p->leaves.size(), 0);
         s.tile_boff.assign(1, 0);
@@ -688,7 +684,6 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         s.ec_doubles = 0;
         if (s.split_all) {
             int64_t budget = (lim1 - fixed) / 8;
-            if (const char *e = getenv("MCI_EC_BUDGET")) budget = atoll(e) / 8 < budget ? atoll(e) / 8 : budget; // bytes; diagnostic override
             for (size_t l = 0; l < p->leaves.size(); ++l) {
                 const Leaf &L = p->leaves[l];
                 if (L.kind != MCI_CONTINUOUS || s.ec_doubles + L.nbin + 1 > budget) continue;
@@ -734,8 +729,8 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         }
         const int64_t hcopy_bytes = (int64_t)s.htile * 8 * (s.hcopy - 1);
         // one tile, grids gathered from L2 (10 .. 18 independent grids): the LDS left next to the histogram caches the edges of the
-        // leading grids for the :vegas sample pass (MCI_NO_EDGE_CACHE=1 for A/B runs)
-        if (mode == 3 && s.ntile == 1 && !(getenv("MCI_NO_EDGE_CACHE") && atoi(getenv("MCI_NO_EDGE_CACHE")) != 0)) {
+        // leading grids for the :vegas sample pass
+        if (mode == 3 && s.ntile == 1) {
             const int64_t budget = (lim1 - p->lds_bytes - hcopy_bytes) / 8;
             for (size_t l = 0; l < p->leaves.size(); ++l) {
                 const Leaf &L = p->leaves[l];
@@ -751,7 +746,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         // cost more than the locality buys (2.77 -> 3.47 ms), so it stays off there.  MCI_L1_PHASE=0 | n overrides (n samples
         // per lane and trip; 2 already spills on 32 grids).
         s.l1_phase = (mode == 3 && s.split_all) ? 1 : 0;
-        if (const char *e = getenv("MCI_L1_PHASE")) s.l1_phase = (mode >= 2 && atoi(e) > 0) ? (atoi(e) > 4 ? 4 : atoi(e)) : 0;
+        if (const char *e = getenv("MCI_L1_PHASE")) s.l1_phase = (mode >= 2 && atoi(e) > 0) ? 1 : 0; // (test / diagnostic override: 0 = natural draw order)
         // one big workgroup per CU owns its LDS
         if (p->lds_bytes > lim0) p->threads = 512; // measured (tools/c4_sweep.py): 2 waves/SIMD beat 1 fat and 4 spilling ones
         // ... and as many waves as its registers allow.  With the bins packed as they are drawn and the phased trips unconditional the
@@ -817,7 +812,6 @@ int mci_problem_destroy(mci_problem *p) {
         for (auto &e : p->hold_ev)
             if (e) (void)hipEventDestroy(e);
         for (auto &e : p->cevs) (void)hipEventDestroy(e);
-        if (p->d_loop) (void)hipFree(p->d_loop);
         if (p->d_hx) (void)hipFree(p->d_hx);
         if (p->d_hstep) (void)hipFree(p->d_hstep);
         if (p->h_hidx) (void)hipHostFree(p->h_hidx);
@@ -980,6 +974,10 @@ static int64_t vegas_lds(const mci_problem *p) {
     const auto &s = p->shape;
     return (s.ec_doubles > 0 ? p->lds_bytes_k1 : p->lds_bytes) + (int64_t)s.htile * 8 * (s.hcopy - 1);
 }
+
+// launches of at most this many partial rows flush their histograms with global atomics (mci_iteration_run)
+static const int64_t kAtomicRows = 256;
+static bool atomic_rows_ok(const mci_problem *p) { return !p->deterministic && kAtomicRows > 0; }
 
 // workgroup size / dynamic LDS of a solver's sample kernel
 static int solver_threads(const mci_problem *p, int solver) {
@@ -1330,8 +1328,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // 763-step chains are within 1.4 sigma (tools/chain_bias_c1.py).
             // Carried chains are stationary from their first step: two floors per iteration let them settle on the refined map.
             const int64_t fl = 64 * (int64_t)nslots > 128 ? 64 * (int64_t)nslots : 128;
-            static const int64_t kf = getenv("MCI_CARRY_FLOORS") ? atoll(getenv("MCI_CARRY_FLOORS")) : 2; // diagnostic override
-            nchain = nevalperblock / ((may_carry ? kf : 8) * fl);
+            nchain = nevalperblock / ((may_carry ? 2 : 8) * fl);
             const int64_t cap = mci_problem::kChainFill / nblocks > 64 ? mci_problem::kChainFill / nblocks : 64;
             if (nchain > cap) nchain = cap;
             if (nchain < 1) nchain = 1;
@@ -1351,7 +1348,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // pass nchain explicitly for integrands known to mix fast (C5: 10 Gsteps/s at nchain = 4096).
             // From the second :mcmc launch of a problem on, the length follows what the previous launch measured: 16 x the
             // longest time any chain's slot (or integrand index) went without changing (mci_mcmc_auto_chains).
-            if (!p->graph_mode && (rc = hold_consume(p))) return rc;
+            if ((rc = hold_consume(p))) return rc;
             nchain = mci_mcmc_auto_chains(nevalperblock, nblocks, nslots, p->ni + 1, p->npool, p->hold_max);
             // (opt-in carried :mcmc chains, mci_set_chain_carry(prob, 1), keep this length: only their burn-in floor goes)
         }
@@ -1364,32 +1361,40 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     }
     int wpb = p->wg_per_block;
     if (wpb <= 0) { // 256 CUs x 8..16 workgroups in the grid, never a workgroup without work
-        // measured on C2 (MCI_WG_TARGET sweep): 16 workgroups per CU even out the tail once a launch is long
+        // measured on C2 (workgroup-count sweep): 16 workgroups per CU even out the tail once a launch is long
         // enough that the extra partial rows (merged by k_hist_stage1) do not matter
-        static const int64_t forced = getenv("MCI_WG_TARGET") ? atoll(getenv("MCI_WG_TARGET")) : 0; // diagnostic override
         // (only while a workgroup's tables are cheap to stage: C3 with 66 KB per workgroup lost 15 % at 4096)
         // (... counted in 256-thread workgroups: the 512-thread workgroups of the histogram-copy plan take half as many -- warm
         // tools/ab_c2.py, C2: 1024 / 2048 / 4096 / 8192 workgroups 1.509 / 1.504 / 1.515 / 1.551 ms per iteration)
         const int64_t big = T >= 1024 ? 1024 : T >= 512 ? 2048 : 4096;
-        int64_t target = forced > 0 ? forced : ((units * nblocks >= (int64_t)1 << 25 && p->lds_bytes <= 32 * 1024) ? big : 2048);
+        int64_t target = (units * nblocks >= (int64_t)1 << 25 && p->lds_bytes <= 32 * 1024) ? big : 2048;
         // :vegas launches of up to a few million samples: a workgroup's prologue and epilogue (tables staged, histogram zeroed and
         // flushed) cost what ~50 samples per thread cost, so the grid shrinks to one workgroup per CU (tools/latency.py, us per
         // iteration at neval = 1e6: 2048 workgroups 39.9, 512: 27.7, 256: 26.9; C2 at 1e6: 64.8 -> 43.9).  Longer launches keep the
         // full grid: a grid between 256 and 512 workgroups leaves half of the CUs' second slot empty (C2 at 1e7: 320 workgroups
         // 271.7 us, 2048: 210.1)
-        if (solver == MCI_VEGAS && forced <= 0 && units * nblocks < ((int64_t)1 << 22) && target > 256) target = 256;
+        if (solver == MCI_VEGAS && units * nblocks < ((int64_t)1 << 22) && target > 256) target = 256;
+        // ... and light launches (samples x draws below 2^19: a 2-D integrand at neval = 1e5) to a quarter of the CUs: their prologues and
+        // epilogues weigh more than a few more samples per lane (tools/latency.py, x^2 + y^2 at 1e5: 22.0 -> 18.6 us per iteration; the
+        // 16-D Gaussian at 1e5 keeps the full 256: 23.4 against 25.9 us)
+        if (solver == MCI_VEGAS && units * nblocks * s.ndraw < ((int64_t)1 << 19) && target > 64) target = 64;
         wpb = (int)((target + nblocks - 1) / nblocks);
         const int64_t maxw = (units + T - 1) / T;
         if (wpb > maxw) wpb = (int)maxw;
         if (wpb < 1) wpb = 1;
     }
     const bool hist_lds = (s.table_mode == 0 || s.table_mode == 3);
+    // Few partial rows (launch-bound :vegas iterations): no partial histograms, no first merge launch -- the workgroups add their
+    // non-zero bins to the merged histogram directly (global f64 atomics; the order of those adds follows the hardware, so the
+    // deterministic mode keeps the fixed-order merge).  tools/latency.py, us per iteration: x^2 + y^2 at neval = 1e4 22.7 -> 17-19,
+    // 1e5 23.8 -> 18.6, 1e6 26.5 -> 24.4; 16-D Gaussian at 1e5 27.3 -> 23.4, 1e6 41.8 -> 37.2.
     // NTILE > 1 histogram tiles.  vegas: ONE sample pass (tile 0) parks weights + bins per sample, mci_vegas_tiles
     // replays them for the other tiles.  Chain solvers: NTILE workgroups per row, each recomputing the chain and
     // keeping one tile.
     const bool split = solver == MCI_VEGAS && s.ntile > 1;
     if (!split && wpb * s.ntile > 4096 / nblocks && s.ntile > 1) wpb = (int)(4096 / nblocks / s.ntile) > 0 ? (int)(4096 / nblocks / s.ntile) : 1;
     const int64_t nrows = nblocks * wpb;   // partial rows: one per (block, slice)
+    const bool atomic_flush = solver == MCI_VEGAS && hist_lds && s.ntile == 1 && atomic_rows_ok(p) && nrows <= kAtomicRows && !s.host_integrand;
     const int64_t nwg = split ? nrows : nrows * s.ntile;
     if ((rc = ensure_capacity(p, nrows, nblocks))) return rc;
     if (solver != MCI_VEGAS && nrows > p->cap_pa) {
@@ -1431,9 +1436,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.nchain = nchain;
     a.burnin = burnin;
     a.nburn = nburn;
+    a.hist_atomic = atomic_flush ? 1 : 0;
     if (solver != MCI_VEGAS) {
         const bool carried = may_carry && nchain > 1;
-        const bool keep = carry_on && nchain > 1 && !p->graph_mode;
+        const bool keep = carry_on && nchain > 1;
         if (carried) {
             a.carry_x = p->d_chain_x[p->chain_cur];
             a.carry_curr = p->d_chain_curr[p->chain_cur];
@@ -1463,12 +1469,12 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             p->chain_lo = block_lo;
             p->chain_hi = block_hi;
             p->chain_nchain = nchain;
-        } else if (!p->graph_mode) {
+        } else {
             p->chain_valid = false;
         }
         p->last_carried = carried;
     }
-    if (solver == MCI_MCMC && !p->graph_mode && !s.host_integrand && nevalperblock / nchain + nburn < ((int64_t)1 << 31) - 1) {
+    if (solver == MCI_MCMC && !s.host_integrand && nevalperblock / nchain + nburn < ((int64_t)1 << 31) - 1) {
         if (!p->d_hold) HIPCHK(hipMalloc((void **)&p->d_hold, 64 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(p->d_hold, 0, 64 * sizeof(unsigned long long), p->ctx->stream));
         a.hold_hist = p->d_hold;
@@ -1528,7 +1534,6 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     int64_t hm_n = 0, hm_first = 0, hm_count = 0;
     int hm_rows = 0;
     if (s.host_measure) {
-        if (p->graph_mode) return fail(MCI_ERR_INVALID, "a host measure cannot run inside a captured iteration (MCI_GRAPH)");
         const int nw = s.ni * s.ncomp;
         if (solver == MCI_VEGAS) {
             hm_n = nevalperblock;
@@ -1602,8 +1607,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     // queue -- a third of a launch-bound iteration (neval = 1e4: 36 -> 25 us), nothing next to a launch of millions of samples.
     // mci_set_kernel_timing: -1 (default) = launches of >= 2^20 samples, 0 = never, 1 = always
     p->time_this_launch = p->kernel_timing > 0 || (p->kernel_timing < 0 && nblocks * nevalperblock >= ((int64_t)1 << 20));
-    if (p->graph_mode) a.iter_ptr = p->d_loop; // captured launch: the iteration index is read on the device
-    else if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot], st));
+    if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot], st));
     if (solver != MCI_VEGAS && s.host_integrand) {
         // The closure sits inside the Markov step (vegas_mc/updates.jl:67-75, mcmc/updates.jl:35-38): the chains of this launch advance
         // in lock step, one kernel launch per step; each hands the host the nc configurations to evaluate and takes their weights back
@@ -1686,11 +1690,9 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     if (a.hold_hist && (rc = hold_publish(p))) return rc;
     if (split)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles[kern == kSlotVegasAny ? 1 : 0], (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
-    if (!p->graph_mode) {
-        if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
-        p->ev_valid[slot] = p->time_this_launch;
-        p->launches += 1;
-    }
+    if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
+    p->ev_valid[slot] = p->time_this_launch;
+    p->launches += 1;
     if (s.host_measure) {
         // the closure cannot run on the device: this launch's (measured) configurations and relative weights go to the host
         // (draw-major, like the host integrand path), the callback accumulates block b's observables from block b's records, and
@@ -1769,7 +1771,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     const int nb256 = (s.nbin + 255) / 256;
     // (reading a few partial rows directly in the second stage instead -- no first-stage launch when an iteration is launch-bound --
     // was measured at neval = 1e4: k_finish grows by what the launch took, 26 us per iteration either way)
-    if (hist_lds && s.nbin > 0)
+    if (hist_lds && s.nbin > 0 && !atomic_flush)
         hipLaunchKernelGGL(mci::k_hist_stage1, dim3(nb256, mci_problem::kGroups), dim3(256), 0, st, p->d_part_hist, (int)nrows, s.nbin,
                            (int)mci_problem::kGroups, p->d_stage1);
     HIPCHK(hipGetLastError());
@@ -1783,7 +1785,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     m.stage1 = p->d_stage1;
     m.ngroup = (int)mci_problem::kGroups;
     m.ghist = p->d_ghist;
-    m.use_ghist = hist_lds ? 0 : 1;
+    m.use_ghist = (hist_lds && !atomic_flush) ? 0 : 1;
     m.nbin = s.nbin;
     m.packed = p->d_packed;
     m.status = p->d_status;
@@ -1813,7 +1815,7 @@ int mci_iteration_reduce(mci_problem *p) {
     if (rc) return rc;
     // HIP events around the collective under the sample launch's rule (mci_set_kernel_timing): what a rank waits for here is the
     // slowest rank's sample pass plus the latency of one small all-reduce (mci_comm_times_ms)
-    const bool timed = p->time_this_launch && !p->graph_mode;
+    const bool timed = p->time_this_launch;
     const int slot = (int)(p->reduces % mci_problem::kCevRing);
     if (timed) {
         if (p->cevs.empty()) {
@@ -1869,16 +1871,11 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     a.do_train = do_train;
     a.serial_walk = p->train_serial >= 0 ? p->train_serial : (p->last_samples == 0 || p->last_samples >= mci_problem::kSerialWalkSamples) ? 1 : 0;
     a.status = p->d_status;
-    if (p->graph_mode) {
-        a.loop = p->d_loop;
-        a.iter_log_base = p->d_iterlog;
-    }
     const size_t sm = (size_t)mci::train_lds_doubles(maxn) * sizeof(double); // d | sg | wa (train_leaf)
     // two bins per thread for the default 999-bin grids: the rescale (a pow and a log per bin) and the second merge stage are the
     // latency chains of a lone workgroup; with four bins per thread (256 threads) a launch-bound iteration took 24.7 us, with two
     // 22.2, with one (1024 threads) 22.3 (tools/latency.py, neval = 1e4)
-    static const int tt_env = getenv("MCI_TRAIN_THREADS") ? atoi(getenv("MCI_TRAIN_THREADS")) : 0; // diagnostic override
-    const unsigned tt = (tt_env >= 64 && tt_env <= 1024 && tt_env % 64 == 0) ? (unsigned)tt_env : (maxn > 256 ? 512u : 256u);
+    const unsigned tt = maxn > 256 ? 512u : 256u;
     if (sm + (size_t)maxn * sizeof(double) > 64 * 1024 && !p->train_lds_raised) { // grids of more than ~1600 increments
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_train, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
@@ -1969,61 +1966,12 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     const int row0 = p->log_row;
     auto t0 = std::chrono::steady_clock::now();
-    // MCI_GRAPH=1 (single rank, device-side integrand): iteration 1 runs eagerly (it sizes every buffer), the remaining
-    // ones replay ONE captured hipGraph of  sample batch -> k_hist_stage1 -> k_finish ; the iteration index and the log
-    // row live in device memory so that the captured parameters never change.  Off by default: measured on ROCm 7.0 /
-    // MI355X in the launch-bound regime (neval 1e4 .. 1e7 per iteration, tools/latency.py) the replay costs 37.6 / 41.9 /
-    // 61.7 / 84.2 us per iteration against 34.8 / 36.0 / 57.1 / 79.1 us for the eager asynchronous launches.
-    static const bool want_graph = getenv("MCI_GRAPH") && atoi(getenv("MCI_GRAPH")) != 0;
-    const bool use_graph = want_graph && a->solver == MCI_VEGAS && !p->ctx->comm && !s.host_integrand && !s.host_measure && a->niter > 2;
-    int it = 0;
-    for (; it < (use_graph ? 1 : a->niter); ++it) { // main.jl:142
+    // (a hipGraph replay of this chain was measured and dropped: 37.6 against 34.8 us per launch-bound iteration for the eager
+    // asynchronous launches on ROCm 7.0 / MI355X, profiles/r02_ablation.txt)
+    for (int it = 0; it < a->niter; ++it) { // main.jl:142
         if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, a->first_iteration + it, a->seed, a->measurefreq, a->nchain, a->thermal_ratio))) return rc;
         if ((rc = mci_iteration_reduce(p))) return rc;                                   // main.jl:177-188
         if ((rc = mci_iteration_finish(p, a->solver, block, a->adapt, a->gamma, nullptr, nullptr))) return rc; // main.jl:183-199
-    }
-    if (use_graph) {
-        hipStream_t st = p->ctx->stream;
-        const int rest = a->niter - it;
-        while (p->log_row + rest > p->cap_iter) { // the log must not move while the graph holds its address
-            const int64_t ncap = p->cap_iter ? p->cap_iter * 2 : 64;
-            double *n = nullptr;
-            HIPCHK(hipMalloc((void **)&n, (size_t)ncap * p->nstat * sizeof(double)));
-            if (p->d_iterlog) {
-                HIPCHK(hipMemcpyAsync(n, p->d_iterlog, (size_t)p->cap_iter * p->nstat * sizeof(double), hipMemcpyDeviceToDevice, st));
-                HIPCHK(hipStreamSynchronize(st));
-                (void)hipFree(p->d_iterlog);
-            }
-            p->d_iterlog = n;
-            p->cap_iter = ncap;
-        }
-        if (!p->d_loop) HIPCHK(hipMalloc((void **)&p->d_loop, 2 * sizeof(unsigned)));
-        const unsigned loop0[2] = {(unsigned)(a->first_iteration + it), (unsigned)p->log_row};
-        HIPCHK(hipMemcpyAsync(p->d_loop, loop0, sizeof loop0, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        p->graph_mode = true;
-        const int saved_row = p->log_row;
-        hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-        if (ce == hipSuccess) {
-            rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, a->first_iteration + it, a->seed, a->measurefreq, a->nchain, a->thermal_ratio);
-            if (!rc) rc = mci_iteration_finish(p, a->solver, block, a->adapt, a->gamma, nullptr, nullptr);
-            ce = hipStreamEndCapture(st, &graph);
-        }
-        p->graph_mode = false;
-        p->log_row = saved_row; // the captured finish only recorded nodes
-        if (rc) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return rc;
-        }
-        if (ce != hipSuccess || !graph) return fail(MCI_ERR_HIP, "hipGraph capture of the iteration chain failed: %s", hipGetErrorString(ce));
-        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        for (; it < a->niter; ++it) HIPCHK(hipGraphLaunch(exec, st));
-        p->log_row += rest;
-        HIPCHK(hipStreamSynchronize(st));
-        (void)hipGraphExecDestroy(exec);
-        (void)hipGraphDestroy(graph);
     }
     std::vector<double> h((size_t)a->niter * p->nstat);
     HIPCHK(hipMemcpyAsync(h.data(), p->d_iterlog + (size_t)row0 * p->nstat, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));

@@ -41,30 +41,15 @@ template <int B, int E, class F> __device__ __forceinline__ void static_for(F &&
 // ---------------------------------------------------------------------------------------------
 struct u32x4 { u32 x, y, z, w; };
 
-// Development-only ablation switches (passed through MCI_JIT_FLAGS; never set in product builds):
-//   -DMCI_ABL_CHEAPRNG  one multiply-add instead of Philox     -DMCI_ABL_NOHIST   skip the histogram update
-//   -DMCI_ABL_NOTABLE   skip the LDS grid gathers              -DMCI_PHILOX_ROUNDS=n
+// Philox4x32 rounds of every stream: 10, or 7 with the opt-in cheaper generator (mci_set_rng_rounds; set by the generated translation unit)
 #ifndef MCI_PHILOX_ROUNDS
 #define MCI_PHILOX_ROUNDS 10
-#endif
-// Round keys in VGPRs for kernels with at most this many draws (diagnostic switch, off by default).  History on MI355X (tools/ab_c2.py):
-// with the compiler's own schedule of the C2 loop the 20 extra registers cost the fourth wave per SIMD (132 VGPRs) and bought nothing
-// (1.754 against 1.715 ms; the loop's VALU and LDS stretches did not overlap then); on the pipelined loop, which is bound by VALU issue
-// and has the registers to spare, they are worth 2 % (1.358 -> 1.331 ms) and the host asks for them through MCI_PIPE_VGPR_KEYS.
-#ifndef MCI_VGPR_KEYS_MAX_DRAWS
-#define MCI_VGPR_KEYS_MAX_DRAWS 0
-#endif
-#ifndef MCI_U12_ALIGNBIT
-#define MCI_U12_ALIGNBIT 1
-#endif
-#ifndef MCI_VGPR_KEY_ROUNDS
-#define MCI_VGPR_KEY_ROUNDS MCI_PHILOX_ROUNDS
 #endif
 
 // The ten round keys (k + r * Weyl constant).  They are wave-uniform and would naturally sit in SGPRs -- but v_bitop3_b32 with an
 // SGPR source issues at the 3-source rate (measured 1.76 ns per wave-instruction and SIMD, tools/issue_microbench.hip) while its
 // all-VGPR form issues at the VOP2 rate (1.2 ns).  IN_VGPR copies them to VGPRs once (a pure, hoistable v_mov); worth 20 registers
-// only where the kernel has them to spare (the :vegas sample loop of problems with few draws).
+// only where the kernel has them to spare (the pipelined :vegas loop on the histogram-copy plan, MCI_PIPE_VGPR_KEYS).
 template <bool IN_VGPR> struct RoundKeys {
     u32 a[MCI_PHILOX_ROUNDS], b[MCI_PHILOX_ROUNDS];
 };
@@ -73,7 +58,7 @@ template <bool IN_VGPR> __device__ __forceinline__ RoundKeys<IN_VGPR> make_round
 #pragma unroll
     for (int r = 0; r < MCI_PHILOX_ROUNDS; ++r) {
         const u32 a = k0 + (u32)r * 0x9E3779B9u, b = k1 + (u32)r * 0xBB67AE85u; // wave-uniform: scalar ALU
-        if (IN_VGPR && r < MCI_VGPR_KEY_ROUNDS) { // (the remaining rounds keep theirs in SGPRs: registers against issue slots)
+        if (IN_VGPR) {
             asm("v_mov_b32 %0, %1" : "=v"(K.a[r]) : "s"(a));
             asm("v_mov_b32 %0, %1" : "=v"(K.b[r]) : "s"(b));
         } else {
@@ -84,24 +69,10 @@ template <bool IN_VGPR> __device__ __forceinline__ RoundKeys<IN_VGPR> make_round
     return K;
 }
 
-// 32 x 32 -> 64-bit product.  Left to itself the compiler turns some of these into a v_mul_lo_u32 + v_mul_hi_u32 pair (two issues at
-// the 3-source rate instead of one v_mad_u64_u32); MCI_MAD_ASM pins the single instruction (constants still fold).
-__device__ __forceinline__ u64 mul_wide(u32 m, u32 c) {
-#ifdef MCI_MAD_ASM
-    if (!__builtin_constant_p(c)) {
-        u64 p, carry;
-        asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(carry) : "s"(m), "v"(c));
-        return p;
-    }
-#endif
-    return (u64)m * c;
-}
+// 32 x 32 -> 64-bit product: one v_mad_u64_u32 (hi and lo in one issue)
+__device__ __forceinline__ u64 mul_wide(u32 m, u32 c) { return (u64)m * c; }
 
 template <bool IN_VGPR> __device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, const RoundKeys<IN_VGPR> &K) {
-#ifdef MCI_ABL_CHEAPRNG
-    const u64 h = (u64)(c0 ^ K.a[0]) * 0x9E3779B97F4A7C15ull + ((u64)c2 << 32 | (c1 ^ c3 ^ K.b[0]));
-    return {(u32)h, (u32)(h >> 32), (u32)(h >> 16), (u32)(h >> 24)};
-#endif
 #pragma unroll
     for (int r = 0; r < MCI_PHILOX_ROUNDS; ++r) {
         const u64 p0 = mul_wide(0xD2511F53u, c0); // v_mad_u64_u32: hi and lo in one issue
@@ -123,7 +94,6 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u
 
 // 52 random mantissa bits as a double in [1, 2)
 __device__ __forceinline__ double u12(u32 lo, u32 hi) {
-#if MCI_U12_ALIGNBIT
     // ((hi:lo) >> 12) | 0x3FF0...0 as two v_alignbit_b32: the low word is (hi:lo) >> 12, the high word (0x3FF:hi) >> 12 =
     // 0x3FF00000 | hi >> 12.  Per instruction a 3-source form is no cheaper than the 64-bit shift + or it replaces
     // (tools/issue_microbench.hip), but with it the compiler keeps every Philox product a single v_mad_u64_u32; with the
@@ -131,10 +101,6 @@ __device__ __forceinline__ double u12(u32 lo, u32 hi) {
     const u32 wlo = __builtin_amdgcn_alignbit(hi, lo, 12u);
     const u32 whi = __builtin_amdgcn_alignbit(0x3FFu, hi, 12u);
     return __longlong_as_double((i64)(((u64)whi << 32) | wlo));
-#else
-    const u64 bits = ((((u64)hi << 32) | lo) >> 12) | 0x3FF0000000000000ull;
-    return __longlong_as_double((i64)bits);
-#endif
 }
 __device__ __forceinline__ double u01(u32 lo, u32 hi) { return u12(lo, hi) - 1.0; }
 // the opt-in 32-bit stream of the :vegas solver (Cfg::RNG_BITS == 32, mci_set_rng_bits): ONE Philox word per draw, its 32 bits are the
@@ -198,9 +164,6 @@ struct BatchArgs {
     // and the host closure runs over a block's records after the launch.
     int *host_midx;
     i64 hm_first, hm_count, hm_stride;
-    // hipGraph replay of the iteration chain: the iteration index then lives in device memory (k_finish/k_train
-    // advance it), so that the captured launch parameters never change.  NULL: use `iteration`.
-    const u32 *iter_ptr;
     // mcmc: [64] histogram over the chains of this launch of bit_width(longest holding time), the longest run of steps
     // during which a live slot (or the integrand index) of the chain did not change; feeds the automatic chain length
     unsigned long long *hold_hist;
@@ -211,6 +174,9 @@ struct BatchArgs {
     //   ne = 1 .. steps   finish step ne-1 with the weights the host returned (ne = 1: the initial weights, :155-166), propose step ne
     //   ne = steps + 1    finish the last step
     // Chain state lives in global memory between launches (SoA, stride nc = chains of the launch).
+    // Launch-bound :vegas iterations (a few workgroups, a few thousand samples each): the workgroup adds the non-zero bins of its LDS
+    // histogram straight into `ghist` (global f64 atomics) instead of leaving a partial row for a merge launch of its own
+    int hist_atomic;
     // Carried chains (chain solvers, nchain > 1, an iteration that continues the previous one; DESIGN.md "Chains"): chain (block, ch)
     // does not draw a fresh start but continues from the configuration chain (block, ch % carry_nchain) ended the previous iteration
     // with -- bins and probabilities are looked up again on the refined grid -- and leaves its own end configuration for the next
@@ -236,7 +202,6 @@ struct BatchArgs {
         int *done;                              // [1] chains that have run all their steps
     } hs;
 };
-__device__ __forceinline__ u32 iteration_of(const BatchArgs &a) { return a.iter_ptr ? *a.iter_ptr : a.iteration; }
 
 struct DumpArgs {
     const double *edges, *dacc, *ddist, *ud;
@@ -313,30 +278,16 @@ template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __
     if constexpr (Cfg::leaf_kind(leaf) == 0) {
         // sampler.jl:295-303:  iy = floor(y*N)+1; dy = y*N-(iy-1); x = g[iy] + dy*(g[iy+1]-g[iy]); prob = 1/(N*dx)
         constexpr int N = Cfg::leaf_nbin(leaf);
-#ifndef MCI_YN_FMA
-#define MCI_YN_FMA 1 // measured (tools/ab_c2.py): C2 -0.9 %, C4 -0.5 %, C5 :vegas -2 % (515 instead of 531 VALU instructions per C2 sample)
-#endif
-#if MCI_YN_FMA
-        // (y1 - 1) * N in one instruction: y1 - 1 is exact for y1 in [1, 2), so fma(y1, N, -N) rounds the same real number once -- the same bits
+        // (y1 - 1) * N in one instruction (C2 -0.9 %, C4 -0.5 %, C5 :vegas -2 %: 515 instead of 531 VALU instructions per C2 sample): y1 - 1 is exact for y1 in [1, 2), so fma(y1, N, -N) rounds the same real number once -- the same bits
         // (N through an opaque SGPR pair: with the literal the compiler picks v_fmac_f64 and rebuilds the -N accumulator with two
         // v_mov_b32 per draw; v_fma_f64 v, v, s, -s uses one SGPR pair twice, which the constant bus allows.  The whole v_fma_f64 as
         // inline asm made the C3 :vegas kernel 17 % slower: different inlining, 143 -> 157 VGPRs)
         const double yn = cont_yn<N, (U12 && Cfg::NDRAW >= 8), U12>(y); // (few draws: nothing to gain, and the C3 :vegas kernel came out 17 % slower with either fma form)
-#else
-        const double yn = (U12 ? y - 1.0 : y) * (double)N;
-#endif
         const int iy = (int)yn;                           // y*N >= 0: trunc == floor
         const double dy = __builtin_amdgcn_fract(yn);     // v_fract_f64 == yn - floor(yn), exact
-#ifdef MCI_ABL_NOTABLE
-        const double g0 = (double)iy, dx = 1.0;
-#else
         double g0, dx;
         if constexpr (Cfg::PAIR_TABLE != 0 && Cfg::TABLE_MODE <= 1) {
             typedef double d2 __attribute__((ext_vector_type(2)));
-#ifndef MCI_LDS_ABS
-#define MCI_LDS_ABS 1
-#endif
-#if MCI_LDS_ABS
             // The pair table starts at LDS address 0: the JIT kernels keep no static LDS, so the dynamic segment -- whose first entry the
             // table is (Lds::E == 0) -- begins there; the host checks .group_segment_fixed_size == 0 on every code object it loads.
             // With the address formed from that constant the byte offset is ONE VOP2 shift and the leaf's offset rides in the
@@ -345,9 +296,6 @@ template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __
             typedef const d2 __attribute__((address_space(3))) lds_d2;
             const u32 boff = ((u32)iy << 4) + (u32)(Cfg::leaf_poff(leaf) * 8);
             const d2 e = *(lds_d2 *)boff;
-#else
-            const d2 e = *reinterpret_cast<const d2 *>(t.E + Cfg::leaf_poff(leaf) + 2 * iy);
-#endif
             g0 = e.x;
             dx = e.y;
         } else if constexpr (ECACHE && Cfg::leaf_ecoff(leaf) >= 0) {
@@ -355,19 +303,10 @@ template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __
             g0 = t.EC[eoff + iy];
             dx = t.EC[eoff + iy + 1] - g0;
         } else {
-#ifdef MCI_ABL_GATHER_LDS // timing only: the gathered grids alias the first cached one (no global gathers)
-            if constexpr (ECACHE) {
-                g0 = t.EC[iy];
-                dx = t.EC[iy + 1] - g0;
-            } else
-#endif
-            {
             constexpr int eoff = Cfg::leaf_eoff(leaf);
             g0 = t.E[eoff + iy]; // (L2 gathers in table modes 2/3: non-temporal loads measured 30 % slower)
             dx = t.E[eoff + iy + 1] - g0;
-            }
         }
-#endif
         x = g0 + dy * dx;
         raw = dx;
         bin = iy;
@@ -426,7 +365,7 @@ template <class Cfg> constexpr int tdraw_pos(int k) { // position of draw k in t
     for (int j = 0; j < k; ++j) n += is_tdraw<Cfg>(j) ? 1 : 0;
     return n;
 }
-// parked bins are packed TDRAW_PER to a 32-bit word, TDRAW_BITS bits each (10 bits for the default 999-bin grids: 3 per word)
+// parked bins are packed tdraw_bits() bits each (10 bits for the default 999-bin grids)
 template <class Cfg> constexpr int tdraw_bits() {
     int mx = 2;
     for (int k = 0; k < Cfg::NDRAW; ++k)
@@ -435,17 +374,11 @@ template <class Cfg> constexpr int tdraw_bits() {
     while ((1 << b) < mx) ++b;
     return b;
 }
-// ... contiguously (MCI_PACK_CONTIG, default): tdraw m occupies bits [m * BITS, (m + 1) * BITS) of the word array, a field may straddle
-// two words.  32 grids of 999 bins: 10 words per sample instead of 11 (3 fields per word, 2 bits idle), and a tile of 16 grids is
-// exactly 5 words -- 12 % less for the replay to read, which is bound by exactly that.
-#ifndef MCI_PACK_CONTIG
-#define MCI_PACK_CONTIG 1
-#endif
-template <class Cfg> constexpr int tdraw_per() { return 32 / tdraw_bits<Cfg>(); }
-template <class Cfg> constexpr int tdraw_bitpos(int m) { return MCI_PACK_CONTIG ? m * tdraw_bits<Cfg>() : 32 * (m / tdraw_per<Cfg>()) + tdraw_bits<Cfg>() * (m % tdraw_per<Cfg>()); }
-template <class Cfg> constexpr int tdraw_words() {
-    return MCI_PACK_CONTIG ? (tdraw_count<Cfg>() * tdraw_bits<Cfg>() + 31) / 32 : (tdraw_count<Cfg>() + tdraw_per<Cfg>() - 1) / tdraw_per<Cfg>();
-}
+// ... contiguously: tdraw m occupies bits [m * BITS, (m + 1) * BITS) of the word array, a field may straddle two words.  32 grids of
+// 999 bins: 10 words per sample instead of 11 (3 fields per word, 2 bits idle), and a tile of 16 grids is exactly 5 words -- 12 % less
+// for the replay to read, which is bound by exactly that.
+template <class Cfg> constexpr int tdraw_bitpos(int m) { return m * tdraw_bits<Cfg>(); }
+template <class Cfg> constexpr int tdraw_words() { return (tdraw_count<Cfg>() * tdraw_bits<Cfg>() + 31) / 32; }
 // does tdraw m touch word j?
 template <class Cfg> constexpr bool tdraw_in_word(int m, int j) {
     const int lo = tdraw_bitpos<Cfg>(m), hi = lo + tdraw_bits<Cfg>() - 1;
@@ -485,15 +418,12 @@ template <class Cfg, bool ECACHE = false, bool KV = false, int DPC = 2> __device
     s.jac = 1.0;
     static_for<0, Cfg::NI>([&](auto I) { s.jaci[decltype(I)::value] = 1.0; });
     static_for<0, tdraw_words<Cfg>()>([&](auto J) { s.word[decltype(J)::value] = 0u; });
-#ifndef MCI_PHILOX_FIRST
-#define MCI_PHILOX_FIRST 1
-#endif
     // LDS pair tables, 8..16 draws: every Philox block of the sample first, fenced, then the draws.  That is the schedule the compiler
     // used to pick by itself for the 16-D headline loop (102 VGPRs, two ds_read_b128 in flight); with the loop specialised on
     // measurefreq == 1 it interleaved blocks and draws instead (92 VGPRs, one read in flight, each waited for at once) and the shorter
     // loop ran 3 % SLOWER.  The fence pins the order.
     constexpr int NCH = (Cfg::NDRAW + DPC - 1) / DPC;
-    constexpr bool PHILOX_FIRST = MCI_PHILOX_FIRST != 0 && DPC == 2 && Cfg::NDRAW >= 8 && Cfg::NDRAW <= 16 && !ECACHE && Cfg::PAIR_TABLE != 0 &&
+    constexpr bool PHILOX_FIRST = DPC == 2 && Cfg::NDRAW >= 8 && Cfg::NDRAW <= 16 && !ECACHE && Cfg::PAIR_TABLE != 0 &&
                                   Cfg::TABLE_MODE <= 1;
     u32x4 rr[PHILOX_FIRST ? NCH : 1];
     if constexpr (PHILOX_FIRST) {
@@ -503,14 +433,7 @@ template <class Cfg, bool ECACHE = false, bool KV = false, int DPC = 2> __device
     // ... and the table reads of RB draws are issued back to back before the first pair is used: a wave then waits for the LDS
     // twice per 16 draws instead of eight times.  The loop's VALU work alone takes 1.20 ms per 1e8 samples, its LDS work alone 1.17 ms,
     // and with two reads in flight per wave (what the compiler schedules) the two only overlap to 1.43 ms (profiles/r02_ablation.txt)
-#ifndef MCI_READ_BATCH
-#define MCI_READ_BATCH 8
-#endif
-#if defined(MCI_ABL_NOTABLE) || !MCI_YN_FMA || !MCI_LDS_ABS
-    constexpr int RB = 0;
-#else
-    constexpr int RB = (PHILOX_FIRST && all_draws_pair_table<Cfg>()) ? MCI_READ_BATCH : 0;
-#endif
+    constexpr int RB = (PHILOX_FIRST && all_draws_pair_table<Cfg>()) ? 8 : 0;
     static_assert(RB % DPC == 0, "a batch of reads covers whole Philox blocks");
     typedef double pair_d2 __attribute__((ext_vector_type(2)));
     pair_d2 pe[RB > 0 ? RB : 1];
@@ -566,11 +489,6 @@ template <class Cfg, bool ECACHE = false, bool KV = false, int DPC = 2> __device
                 if constexpr (Cfg::own_mask(i) != ALL && si != 1.0) s.jaci[i] *= si;
             });
         }
-#if MCI_DRAW_FENCE
-        // keep the scheduler from hoisting every Philox chunk to the top of the sample (live ranges of
-        // 2*NDRAW+ registers): with many draws that is the difference between 4 waves/SIMD and spilling
-        if constexpr (((c + 1) % MCI_DRAW_FENCE) == 0) __builtin_amdgcn_sched_barrier(0);
-#endif
     });
     static_for<0, Cfg::NI>([&](auto I) {
         constexpr int i = decltype(I)::value;
@@ -591,20 +509,10 @@ template <class Cfg, bool ECACHE> constexpr int gather_draw_count() {
     for (int k = 0; k < Cfg::NDRAW; ++k) n += is_gather_draw<Cfg, ECACHE>(k) ? 1 : 0;
     return n;
 }
-#ifndef MCI_TRIP_BARRIER
-#define MCI_TRIP_BARRIER 0
-#endif
-#ifndef MCI_STAGGER
-#define MCI_STAGGER 0
-#endif
-#ifndef MCI_L1_PHASE_CHUNKS
-#define MCI_L1_PHASE_CHUNKS 1 // Philox chunks (pairs of draws) between two workgroup barriers of the gather phase
-#endif
 
-// The draws of S samples per lane and trip, GATHER DRAWS FIRST AND DIMENSION-MAJOR (draw_gather_phase), then sample by sample the rest
-// (draw_rest_phase): every wave of the workgroup walks the gathered grids in
-// the same order, S samples per grid, with a workgroup barrier every MCI_L1_PHASE_CHUNKS chunks -- so at any moment the whole CU
-// reads ONE or two 8 KB edge tables, which then live in its 32 KB L1 (measured: 58 ns per wave-gather and SIMD from an
+// The draws of a sample, GATHER DRAWS FIRST AND DIMENSION-MAJOR (draw_gather_phase_pipe), then the rest (draw_rest_phase): every wave
+// of the workgroup walks the gathered grids in the same order, with a workgroup barrier after every Philox chunk -- so at any moment
+// the whole CU reads ONE or two 8 KB edge tables, which then live in its 32 KB L1 (measured: 58 ns per wave-gather and SIMD from an
 // L1-resident table against 148 ns when 13..32 tables compete for the L1 and every access is an L2 line fill,
 // tools/issue_microbench.hip).  The Philox streams are counter-based, so the order of evaluation is free; a chunk that holds one
 // gathered and one cached draw is simply computed in both phases.  Jacobians are products of the per-draw 1/prob (no bare
@@ -631,47 +539,11 @@ template <class Cfg, bool ECACHE, int DPC> constexpr bool chunk_has(int c, bool 
     }
     return false;
 }
-template <class Cfg, bool ECACHE, int DPC> constexpr int gather_phase_barriers() {
-    int n = 0;
-    for (int c = 0; c < (Cfg::NDRAW + DPC - 1) / DPC; ++c) n += chunk_has<Cfg, ECACHE, DPC>(c, true) ? 1 : 0;
-    return n / MCI_L1_PHASE_CHUNKS;
-}
-// gather phase of S samples (barriers inside: every thread of the workgroup must call it)
-template <class Cfg, bool ECACHE, bool KV, int DPC, int S> __device__ __forceinline__ void draw_gather_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream,
-                                                                                                           const u64 *index, Sample<Cfg> *s) {
-    constexpr int NCHUNK = (Cfg::NDRAW + DPC - 1) / DPC;
-    static_for<0, S>([&](auto Ss) {
-        constexpr int q = decltype(Ss)::value;
-        s[q].jac = 1.0;
-        static_for<0, Cfg::NI>([&](auto I) { s[q].jaci[decltype(I)::value] = 1.0; });
-        static_for<0, tdraw_words<Cfg>()>([&](auto J) { s[q].word[decltype(J)::value] = 0u; });
-    });
-    int phase = 0;
-    static_for<0, NCHUNK>([&](auto C) {
-        constexpr int c = decltype(C)::value;
-        if constexpr (chunk_has<Cfg, ECACHE, DPC>(c, true)) {
-            static_for<0, S>([&](auto Ss) {
-                constexpr int q = decltype(Ss)::value;
-                const u32x4 r = philox4x32_10<KV>((u32)index[q], (u32)(index[q] >> 32), (u32)c, stream, keys);
-                static_for<0, DPC>([&](auto J) {
-                    constexpr int k = DPC * c + decltype(J)::value;
-                    if constexpr (k < Cfg::NDRAW) {
-                        if constexpr (is_gather_draw<Cfg, ECACHE>(k)) phased_one_draw<Cfg, ECACHE, DPC, k>(t, r, s[q]);
-                    }
-                });
-            });
-            phase += 1;
-            if (phase % MCI_L1_PHASE_CHUNKS == 0) __builtin_amdgcn_s_barrier(); // keeps the waves on the same tables; no data is exchanged
-        }
-    });
-}
-// The same gather phase for ONE sample per lane, software-pipelined by hand one chunk deep: chunk c's table reads are issued, the
+// The gather phase of ONE sample per lane, software-pipelined by hand one chunk deep: chunk c's table reads are issued, the
 // workgroup barrier passed, and only then chunk c-1's reads are consumed (x, bin, Jacobian) -- so at most two chunks' loads
 // (edges + fractions) are live at any point instead of the whole phase's, which is what the scheduler does when left alone
-// (13 gathers x 6 registers on C4).  sched_barrier keeps the order.
-#ifndef MCI_GATHER_PIPE
-#define MCI_GATHER_PIPE 1 // measured on C4 at 768 threads: 6.76 -> 6.46 ms per 1e8 samples (tools/c4_abenv.sh)
-#endif
+// (13 gathers x 6 registers on C4: 6.76 -> 6.46 ms per 1e8 samples at 768 threads).  sched_barrier keeps the order.  Must be
+// called by every thread of the workgroup (barriers inside).
 struct PendingGather {
     double g0, g1, dy;
     int iy;
@@ -709,7 +581,6 @@ template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ v
     static_for<0, Cfg::NI>([&](auto I) { s.jaci[decltype(I)::value] = 1.0; });
     static_for<0, tdraw_words<Cfg>()>([&](auto J) { s.word[decltype(J)::value] = 0u; });
     PendingGather pend[2][DPC];
-    int phase = 0;
     static_for<0, NCHUNK>([&](auto C) {
         constexpr int c = decltype(C)::value;
         if constexpr (chunk_has<Cfg, ECACHE, DPC>(c, true)) {
@@ -730,8 +601,7 @@ template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ v
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
-            phase += 1;
-            if (phase % MCI_L1_PHASE_CHUNKS == 0) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier(); // keeps the waves on the same tables; no data is exchanged
             constexpr int pc = prev_gather_chunk<Cfg, ECACHE, DPC>(c);
             if constexpr (pc >= 0) finish_gather_chunk<Cfg, ECACHE, DPC, pc>(pend[slot ^ 1], s);
             __builtin_amdgcn_sched_barrier(0);
@@ -744,14 +614,7 @@ template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ v
     }
 }
 // the remaining draws of ONE sample (LDS-resident grids, Discrete tables), right before its integrand is evaluated
-// NBAR > 0 (staggered schedule, see vegas_batch): exactly NBAR workgroup barriers are executed inside, one after each of the first
-// rest chunks -- they pair with the barriers of the other half of the workgroup, which is in its gather phase meanwhile
-template <class Cfg, bool ECACHE, int DPC> constexpr int rest_chunk_index(int c) { // position of chunk c among the chunks with a non-gathered draw
-    int n = 0;
-    for (int j = 0; j < c; ++j) n += chunk_has<Cfg, ECACHE, DPC>(j, false) ? 1 : 0;
-    return n;
-}
-template <class Cfg, bool ECACHE, bool KV, int DPC, int NBAR = 0> __device__ __forceinline__ void draw_rest_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index,
+template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ void draw_rest_phase(const Tables<Cfg> &t, const RoundKeys<KV> &keys, u32 stream, u64 index,
                                                                                                   Sample<Cfg> &s) {
     constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
     constexpr int NCHUNK = (Cfg::NDRAW + DPC - 1) / DPC;
@@ -765,10 +628,8 @@ template <class Cfg, bool ECACHE, bool KV, int DPC, int NBAR = 0> __device__ __f
                     if constexpr (!is_gather_draw<Cfg, ECACHE>(k)) phased_one_draw<Cfg, ECACHE, DPC, k>(t, r, s);
                 }
             });
-            if constexpr (rest_chunk_index<Cfg, ECACHE, DPC>(c) < NBAR) __builtin_amdgcn_s_barrier();
         }
     });
-    static_for<rest_chunk_index<Cfg, ECACHE, DPC>(NCHUNK), (NBAR > rest_chunk_index<Cfg, ECACHE, DPC>(NCHUNK) ? NBAR : rest_chunk_index<Cfg, ECACHE, DPC>(NCHUNK))>([&](auto) { __builtin_amdgcn_s_barrier(); });
     static_for<0, Cfg::NI>([&](auto I) {
         constexpr int i = decltype(I)::value;
         if constexpr (Cfg::own_mask(i) == ALL) s.jaci[i] = s.jac; // dof[i] == maxdof: no padding (vegas/montecarlo.jl:82)
@@ -848,7 +709,7 @@ template <class Cfg> struct LdsEC {
     static constexpr int END = EC + Cfg::EC_DOUBLES;
 };
 
-// (draw_leaf addresses the pair table from LDS address 0, MCI_LDS_ABS)
+// (draw_leaf addresses the pair table from LDS address 0)
 template <class Cfg> struct LdsTableAtZero { static_assert(Lds<Cfg>::E == 0 && LdsEC<Cfg>::E == 0, "the edge / pair table opens the dynamic LDS segment"); };
 
 // partial-statistics columns written per workgroup:
@@ -926,36 +787,25 @@ template <class Cfg, int K> __device__ __forceinline__ void hist_add_draw(int bi
 }
 
 // Software-pipelined :vegas sample (the kernels of pipe_eligible()): the histogram adds of the PREVIOUS sample and the table reads of
-// this one are spread between the Philox blocks, and a pair is consumed MCI_PIPE_LAG blocks after its read was issued.  Left to the
+// this one are spread between the Philox blocks, and a pair is consumed one block after its read was issued (at once on the 32-bit stream).  Left to the
 // compiler a trip is a long VALU-only stretch (eight Philox blocks, ~280 instructions) followed by an LDS-heavy one (16 reads, each
 // waited for, then 16 atomics back to back), and since all waves of a CU run the same code at the same pace they tend to queue for the
 // same pipe: measured on the 16-D headline loop, VALU work alone 1.20 ms per 1e8 samples, LDS work alone 1.17 ms, both together 1.43 ms.
 // With every stretch of the instruction stream carrying the same VALU : LDS mix the two pipes overlap whatever the phase of the waves.
 // Same draws, same arithmetic in the same order as draw_sample + hist_update (the atomics of a sample land one trip later).
-#ifndef MCI_PIPE
-#define MCI_PIPE 1
-#endif
-#ifndef MCI_PIPE_LAG
-#define MCI_PIPE_LAG (DPC == 4 ? 0 : 1) // blocks between a read and its use: with four reads per block they cover each other (and LAG 1 spills at 1024 threads)
-#endif
-#ifndef MCI_PIPE_32
-#define MCI_PIPE_32 1 // the opt-in 32-bit stream too (four draws per Philox block: four reads and four atomics per stage)
-#endif
 template <class Cfg> struct PendingHist {
     int bin[Cfg::NDRAW > 0 ? Cfg::NDRAW : 1];
     double wh[Cfg::NI];
 };
 template <class Cfg> constexpr bool pipe_eligible() {
-#if defined(MCI_ABL_NOTABLE) || defined(MCI_ABL_NOHIST) || defined(MCI_ABL_CHEAPRNG) || !MCI_YN_FMA || !MCI_LDS_ABS
-    return false;
-#else
-    return MCI_PIPE != 0 && (Cfg::RNG_BITS != 32 || MCI_PIPE_32 != 0) && Cfg::NDRAW >= 8 && Cfg::NDRAW <= 16 && all_draws_pair_table<Cfg>() && Cfg::NTILE == 1 &&
+    // (the opt-in 32-bit stream too: four draws per Philox block, four reads and four atomics per stage)
+    return Cfg::NDRAW >= 8 && Cfg::NDRAW <= 16 && all_draws_pair_table<Cfg>() && Cfg::NTILE == 1 &&
            Mode<Cfg>::HIST_LDS && Cfg::HOST_INTEGRAND == 0 && Cfg::HOST_MEASURE == 0 && Cfg::EC_DOUBLES == 0;
-#endif
 }
 template <class Cfg, bool KV, int DPC> __device__ __forceinline__ void draw_sample_pipe(const RoundKeys<KV> &keys, u32 stream, u64 index, Sample<Cfg> &s,
                                                                                         const PendingHist<Cfg> &pend, PendingHist<Cfg> &next, double *sH) {
-    constexpr int NCH = (Cfg::NDRAW + DPC - 1) / DPC, LAG = MCI_PIPE_LAG;
+    constexpr int NCH = (Cfg::NDRAW + DPC - 1) / DPC;
+    constexpr int LAG = DPC == 4 ? 0 : 1; // blocks between a read and its use: with four reads per block they cover each other (and LAG 1 spills at 1024 threads)
     constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
     const u32 ilo = (u32)index, ihi = (u32)(index >> 32);
     s.jac = 1.0;
@@ -1111,6 +961,9 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
                     constexpr int SB = Cfg::DET != 0 ? 1 : Cfg::HCOPY, SC = Cfg::DET != 0 ? Cfg::HTILE : 1; // strides of bin and copy (hslot)
                     double v = sH[i * SB];
                     static_for<1, Cfg::HCOPY>([&](auto Cc) { v += sH[i * SB + decltype(Cc)::value * SC]; }); // fixed order
+                    if (!ACCUM && a.hist_atomic) { // (BatchArgs::hist_atomic: no merge launch behind this one)
+                        if (v != 0.0) global_add(&a.ghist[Cfg::tile_boff(tt) + i], v);
+                    } else
                     hrow[i] = ACCUM ? hrow[i] + v : v;
                 }
             }
@@ -1176,7 +1029,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     }
     const int slice = wi.slice, tile = wi.tile;
     const i64 B = a.block_lo + wi.lb; // global statistical block
-    const u32 stream = iteration_of(a) * 8u + STREAM_VEGAS;
+    const u32 stream = a.iteration * 8u + STREAM_VEGAS;
     const i64 stride = (i64)a.wg_per_block * T;
 
     double acc[Cfg::NW];
@@ -1190,14 +1043,14 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 #define MCI_PIPE_VGPR_KEYS 0 // (set by the host for the first compile of a copy-plan kernel: mci_api.hip compile_solver)
 #endif
     // round keys in VGPRs: 20 registers, for the pipelined loop when the host found them free
-    constexpr bool KV = Cfg::NDRAW <= MCI_VGPR_KEYS_MAX_DRAWS || (MCI_PIPE_VGPR_KEYS != 0 && pipe_eligible<Cfg>() && !SPLIT && Cfg::EC_DOUBLES == 0);
+    constexpr bool KV = MCI_PIPE_VGPR_KEYS != 0 && pipe_eligible<Cfg>() && !SPLIT && Cfg::EC_DOUBLES == 0;
     constexpr int DPC = Cfg::RNG_BITS == 32 ? 4 : 2;           // draws per Philox block of the :vegas sample stream
     const RoundKeys<KV> keys = make_round_keys<KV>((u32)a.seed, (u32)(a.seed >> 32));
     const i64 mfreq = a.measurefreq;
     i64 mrem = mfreq == 1 ? 0 : ((i64)slice * T + tid + 1) % mfreq;
     const i64 mstep = mfreq == 1 ? 0 : stride % mfreq;
-    // gathered grids (table mode 3) are walked dimension-major over PH samples per lane so that they are served from L1
-    constexpr int PH = (Cfg::L1_PHASE > 0 && Cfg::HOST_INTEGRAND == 0 && gather_draw_count<Cfg, EC>() > 0) ? Cfg::L1_PHASE : 0;
+    // gathered grids (table mode 3) are walked dimension-major so that they are served from L1
+    constexpr bool PHASED = Cfg::L1_PHASE > 0 && Cfg::HOST_INTEGRAND == 0 && gather_draw_count<Cfg, EC>() > 0;
     // the sample loop, specialised on the workgroup's histogram tile and on measurefreq == 1 (the reference's default, main.jl:84: every
     // sample is measured and the carried remainder with its 64-bit compare / select -- a dozen VALU instructions per sample -- is gone)
     auto run = [&](auto TT, auto MF1c) {
@@ -1237,101 +1090,31 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             const double wj = absw<Cfg, i>(w) * s.jac; // :173-174 (full jac, not the integrand's own: author's warning :175)
             wh[i] = wj * wj;                      // :180
         });
-#ifndef MCI_ABL_NOHIST
         if (defer_wh) { // pipelined loop: the adds of this sample are issued during the next sample's draws (draw_sample_pipe)
             static_for<0, Cfg::NI>([&](auto I) { defer_wh[decltype(I)::value] = wh[decltype(I)::value]; });
         } else if constexpr (!NOHIST) hist_update<Cfg, decltype(TT)::value>(s, wh, sH, a.ghist, tile);
-#else
-        acc[0] += wh[0] * 1e-300;
-#endif
-#ifdef MCI_ABL_NOPARK // timing only
-        if constexpr (SPLIT) acc[0] += wh[0] * 1e-300 + (double)(s.bin[0] ^ s.bin[Cfg::NDRAW - 1]) * 1e-300;
-        if constexpr (false) {
-#else
         if constexpr (SPLIT) { // park what the other tiles need: coalesced (lane == consecutive sample) 8- and 4-byte stores
-#endif
             const i64 idx = wi.lb * a.neval_per_block + n;
             static_for<0, Cfg::NI>([&](auto I) { a.tile_w[decltype(I)::value * a.tile_stride + idx] = wh[decltype(I)::value]; });
             constexpr int NWORD = tdraw_words<Cfg>();
             static_for<0, NWORD>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = s.word[decltype(J)::value]; });
         }
     };
-    if constexpr (PH == 1 && MCI_STAGGER != 0) {
-        // Staggered schedule: the upper half of the workgroup's waves runs the same (gather phase | rest phase + integrand) sequence
-        // ONE PHASE LATER than the lower half.  Every phase holds the same number of barriers (the rest phase carries NBAR bare ones), so
-        // the barriers still keep the gathering waves on the same one or two tables -- but while one wave of a SIMD waits for the
-        // texture pipe, the other one is in its VALU/LDS phase instead of queueing for the same pipe.
-        constexpr int NBAR = gather_phase_barriers<Cfg, EC, DPC>();
+    if constexpr (PHASED) {
+        // The phased trips are those in which every thread of the workgroup holds a valid sample (barriers inside): their body is
+        // unconditional -- the integrand may consume the draws as they come instead of keeping all of them for a guarded call -- and what
+        // is left at the end of the block, at most one sample per lane, goes through the plain loop.
         const i64 n0 = (i64)slice * T + tid, first = (i64)slice * T;
-        const i64 jmax = first < a.neval_per_block ? (a.neval_per_block - first + stride - 1) / stride : 0; // samples of lane 0
-        const bool late = __builtin_amdgcn_readfirstlane(tid >> 6) >= (T >> 7);
-        if (late)
-            for (int b = 0; b < NBAR; ++b) __builtin_amdgcn_s_barrier();
-        for (i64 j = 0; j < jmax; ++j) {
-            Sample<Cfg> sm;
-            const i64 n = n0 + j * stride;
-            u64 index = (u64)(B * a.neval_per_block + (n < a.neval_per_block ? n : 0));
-            draw_gather_phase<Cfg, EC, KV, DPC, 1>(t, keys, stream, &index, &sm);
-            __builtin_amdgcn_sched_barrier(0);
-            draw_rest_phase<Cfg, EC, KV, DPC, NBAR>(t, keys, stream, index, sm);
-            if (n < a.neval_per_block) process(n, sm);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!late)
-            for (int b = 0; b < NBAR; ++b) __builtin_amdgcn_s_barrier();
-    } else if constexpr (PH > 0) {
-        // the same number of trips for every thread of the workgroup (barriers inside): lanes past the end of the block redo
-        // their last valid sample and drop it
-        const i64 n0 = (i64)slice * T + tid, first = (i64)slice * T;
-        const i64 jmax = first < a.neval_per_block ? (a.neval_per_block - first + stride - 1) / stride : 0; // samples of lane 0
-        // the phased trips are those in which every thread of the workgroup holds valid samples: their body is unconditional (the
-        // integrand may consume the draws as they come instead of keeping all of them for a guarded call); what is left at the end
-        // of the block -- at most PH samples per lane -- goes through the plain loop
         const i64 jfull = first + T <= a.neval_per_block ? (a.neval_per_block - first - T) / stride + 1 : 0;
-        (void)jmax;
-        auto trip = [&](const i64 j0) {
-            Sample<Cfg> sm[PH];
-            u64 index[PH];
-            i64 nn[PH];
-            static_for<0, PH>([&](auto Ss) {
-                constexpr int q = decltype(Ss)::value;
-                const i64 n = n0 + (j0 + q) * stride;
-                nn[q] = n;
-                index[q] = (u64)(B * a.neval_per_block + (n < a.neval_per_block ? n : 0));
-            });
-            if constexpr (MCI_GATHER_PIPE != 0 && PH == 1) draw_gather_phase_pipe<Cfg, EC, KV, DPC>(t, keys, stream, index[0], sm[0]);
-            else draw_gather_phase<Cfg, EC, KV, DPC, PH>(t, keys, stream, index, sm);
-            static_for<0, PH>([&](auto Ss) {
-                constexpr int q = decltype(Ss)::value;
-                // one sample at a time from here on: without the fences the scheduler interleaves the PH samples' Philox blocks
-                // and integrands for ILP and the live draws of all of them no longer fit the register file
-                __builtin_amdgcn_sched_barrier(0);
-                draw_rest_phase<Cfg, EC, KV, DPC>(t, keys, stream, index[q], sm[q]);
-                process(nn[q], sm[q]);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        i64 j0 = 0;
-        for (; j0 + PH <= jfull; j0 += PH) trip(j0);
-        for (i64 n = n0 + j0 * stride; n < a.neval_per_block; n += stride) {
-            Sample<Cfg> s;
-            draw_sample<Cfg, EC, KV, DPC>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
-            process(n, s);
-        }
-    } else if constexpr (MCI_TRIP_BARRIER != 0 && gather_draw_count<Cfg, EC>() > 0 && Cfg::HOST_INTEGRAND == 0) {
-        // Grids gathered from global memory, draws in their natural order: ONE workgroup barrier per sample re-aligns the waves, which
-        // then run the same straight-line code at the same pace -- so the CU's 32 KB L1 sees them on the same one or two 8 KB tables
-        // without the per-chunk barriers (and the register cost) of the dimension-major gather phase.  The barrier is executed in the
-        // trips that every thread of the workgroup takes (the body stays unconditional: the integrand consumes the draws as they come,
-        // 122 VGPRs on 32 grids); the last, partial trip runs without it.
-        const i64 first = (i64)slice * T;
-        const i64 jfull = first + T <= a.neval_per_block ? (a.neval_per_block - first - T) / stride + 1 : 0;
-        i64 n = first + tid;
+        i64 n = n0;
         for (i64 j = 0; j < jfull; ++j, n += stride) {
-            __builtin_amdgcn_s_barrier();
-            Sample<Cfg> s;
-            draw_sample<Cfg, EC, KV, DPC>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
-            process(n, s);
+            Sample<Cfg> sm;
+            const u64 index = (u64)(B * a.neval_per_block + n);
+            draw_gather_phase_pipe<Cfg, EC, KV, DPC>(t, keys, stream, index, sm);
+            __builtin_amdgcn_sched_barrier(0);
+            draw_rest_phase<Cfg, EC, KV, DPC>(t, keys, stream, index, sm);
+            process(n, sm);
+            __builtin_amdgcn_sched_barrier(0);
         }
         for (; n < a.neval_per_block; n += stride) {
             Sample<Cfg> s;
@@ -1392,9 +1175,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 #ifndef MCI_THREADS
 #define MCI_THREADS 256 // (the JIT translation units define it: the workgroup size their kernels are compiled for)
 #endif
-#ifndef MCI_TILES_U
-#define MCI_TILES_U (MCI_THREADS >= 768 ? 8 : 4) // samples per lane and trip (measured: 8 at 768 threads 6.46 -> 6.38 ms, 16 slower; 4 at 512)
-#endif
+constexpr int kTilesU = MCI_THREADS >= 768 ? 8 : 4; // replay: samples per lane and trip (measured: 8 at 768 threads 6.46 -> 6.38 ms, 16 slower; 4 at 512)
 // Replay with the tile's histograms BIN-MAJOR in LDS, sH[bin * G + grid], and the lanes of a wave walking the tile's G grids in
 // skewed order (lane l adds to grid (d + l % G) % G at step d).  A wave's ds_add_f64 then lands on G different grids at once and
 // the lanes that share a grid (64 / G of them) share only the 2 bank pairs {grid, grid + 16} of a 16-grid tile, instead of 64
@@ -1402,9 +1183,6 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 // a conflict-free one 13.4 (tools/issue_microbench.hip).  The skew is a rotation of the lane's G bins by a per-lane constant:
 // a 4-stage log shifter of v_cndmask_b32 (the replay has the VALU slots to spare: it is bound by the atomics and by HBM).
 // Taken when the tile is G <= 16 one-draw Continuous leaves of equal size covered by the same integrands (C4: 2 tiles of 16).
-#ifndef MCI_TILES_BANKED
-#define MCI_TILES_BANKED 1
-#endif
 template <int... D> struct ISeq {};
 template <int N, int... D> struct MakeISeq : MakeISeq<N - 1, N - 1, D...> {};
 template <int... D> struct MakeISeq<0, D...> { typedef ISeq<D...> type; };
@@ -1428,7 +1206,7 @@ template <class Cfg> constexpr int tile_draw(int tt, int gi) { // the gi-th repl
 }
 template <class Cfg> constexpr bool tile_banked(int tt) {
     const int G = tile_draw_count<Cfg>(tt);
-    if (MCI_TILES_BANKED == 0 || G < 2 || G > 16) return false;
+    if (G < 2 || G > 16) return false;
     const int k0 = tile_draw<Cfg>(tt, 0), NB = Cfg::leaf_nbin(Cfg::draw_leaf(k0));
     if (Cfg::tile_nbin(tt) != G * NB) return false;
     for (int gi = 0; gi < G; ++gi) {
@@ -1462,7 +1240,7 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
         if (tile == tt) {
             // U samples per lane and trip: all their loads are issued before the first ds_add_f64 (the kernel has one
             // 512-thread workgroup per CU, so memory-level parallelism has to come from the loop body)
-            constexpr int U = MCI_TILES_U;
+            constexpr int U = kTilesU;
             constexpr int NWORD = tdraw_words<Cfg>();
             for (i64 n0 = (i64)slice * T + tid; n0 < a.neval_per_block; n0 += stride * U) {
                 double wh[U][Cfg::NI];
@@ -1688,7 +1466,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     // chain identity = (block, chain within the block): the block index rides in the top 12 bits of the stream word, so the
     // streams of a block do not depend on how many chains any other block (or rank) runs
     const u32 bs = (u32)B << 20;
-    const u32 st_init = iteration_of(a) * 8u + STREAM_MC_INIT + bs, st_step = iteration_of(a) * 8u + STREAM_MC_STEP + bs;
+    const u32 st_init = a.iteration * 8u + STREAM_MC_INIT + bs, st_step = a.iteration * 8u + STREAM_MC_STEP + bs;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[NI + 1];
     static_for<0, NI + 1>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -1741,7 +1519,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
             double upool = u01(r0.x, r0.y);
             if (Cfg::NPOOL > 1 && a.nchain > 1) {
                 const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)(ne - 1);
-                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MC_GROUP + bs, k0, k1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, a.iteration * 8u + STREAM_MC_GROUP + bs, k0, k1);
                 upool = u01(rg.x, rg.y);
             }
             int vi = (int)(upool * (double)Cfg::NPOOL);
@@ -1878,7 +1656,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_host_step(const Bat
     const BatchArgs::HostStep &h = a.hs;
     const i64 B = a.block_lo + wi.lb;
     const u32 bs = (u32)B << 20;
-    const u32 st_init = iteration_of(a) * 8u + STREAM_MC_INIT + bs, st_step = iteration_of(a) * 8u + STREAM_MC_STEP + bs;
+    const u32 st_init = a.iteration * 8u + STREAM_MC_INIT + bs, st_step = a.iteration * 8u + STREAM_MC_STEP + bs;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[NI + 1];
     static_for<0, NI + 1>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -1993,7 +1771,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_host_step(const Bat
             double upool = u01(r0.x, r0.y);
             if (Cfg::NPOOL > 1 && a.nchain > 1) { // (the 64 chains of a wave share the pool pick, as in vegasmc_chains)
                 const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)(ne - 1);
-                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MC_GROUP + bs, k0, k1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, a.iteration * 8u + STREAM_MC_GROUP + bs, k0, k1);
                 upool = u01(rg.x, rg.y);
             }
             int vi = (int)(upool * (double)Cfg::NPOOL);
@@ -2379,7 +2157,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
     const i64 B = a.block_lo + wi.lb;
     const i64 steps = a.neval_per_block / a.nchain, nburn = a.nburn;
     const u32 bs = (u32)B << 20; // (block, chain within the block) identify a chain: see vegasmc_chains
-    const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT + bs, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP + bs;
+    const u32 st_init = a.iteration * 8u + STREAM_MCMC_INIT + bs, st_step = a.iteration * 8u + STREAM_MCMC_STEP + bs;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[ND];
     static_for<0, ND>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -2475,7 +2253,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
             double uupd = u01(r0.x, r0.y);
             if (a.nchain > 1) {
                 const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)(it - 1);
-                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MCMC_GROUP + bs, k0, k1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, a.iteration * 8u + STREAM_MCMC_GROUP + bs, k0, k1);
                 uupd = u01(rg.x, rg.y);
             }
             int upd = (int)(uupd * (double)NUPD);
@@ -2501,7 +2279,6 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                 const bool ok = uacc < R;                                                       // :49, :100, :141
                 // propose[1, curr, new] :48,:50 | propose[2, curr, vi] :99,:101 | propose[3, curr, vi] :140,:142
                 pa_count<Cfg, false>(sPA, PaTable<Cfg>::idx(ut, curr, ut == 0 ? newcurr : pvi), true, ok);
-#ifndef MCI_ABL_NOHOLD
                 if (a.hold_hist) {
                     const int now = (int)it;
                     u64 mo = 0ull, mn = 0ull; // live draws of the old and of the proposed integrand
@@ -2525,7 +2302,6 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                     hmax = (chg && hold > hmax) ? hold : hmax;
                     lastc = chg ? now : lastc;
                 }
-#endif
                 if (ok) {
                     c = n;
                     curr = newcurr;                                                             // :51-53
@@ -2550,9 +2326,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
                         if (curr == i) {
                             static_for<0, Cfg::NDRAW>([&](auto K) { // :147-154  accumulate!(var, pos + offset, 1.0)
                                 constexpr int k = decltype(K)::value;
-#ifndef MCI_ABL_NOMCHIST
                                 if constexpr ((Cfg::own_mask(i) >> k) & 1ull) hist_add<Cfg, k>(c.bin[k], 1.0, sH, a.ghist, tile);
-#endif
                             });
                             if constexpr (Cfg::HOST_MEASURE != 0) {
                             } else if constexpr (Cfg::CUSTOM_MEASURE != 0) { // measure(idx, var, obs, relative_weight, config)  :166-169
@@ -2629,7 +2403,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_host_step(const BatchA
     const i64 B = a.block_lo + wi.lb;
     const i64 total = a.neval_per_block / a.nchain + a.nburn, nburn = a.nburn, nc = h.nc;
     const u32 bs = (u32)B << 20;
-    const u32 st_init = iteration_of(a) * 8u + STREAM_MCMC_INIT + bs, st_step = iteration_of(a) * 8u + STREAM_MCMC_STEP + bs;
+    const u32 st_init = a.iteration * 8u + STREAM_MCMC_INIT + bs, st_step = a.iteration * 8u + STREAM_MCMC_STEP + bs;
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[ND];
     static_for<0, ND>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
@@ -2815,7 +2589,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_host_step(const BatchA
             double uupd = u01(r0.x, r0.y);
             if (a.nchain > 1) { // (the 64 chains of a wave share the update-type sequence, as in mcmc_chains)
                 const u64 gidx = ((u64)(ch & ~(i64)63) << 32) | (u64)it;
-                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, iteration_of(a) * 8u + STREAM_MCMC_GROUP + bs, k0, k1);
+                const u32x4 rg = philox4x32_10((u32)gidx, (u32)(gidx >> 32), 0u, a.iteration * 8u + STREAM_MCMC_GROUP + bs, k0, k1);
                 uupd = u01(rg.x, rg.y);
             }
             int upd = (int)(uupd * (double)NUPD);

@@ -99,7 +99,6 @@ inline std::string generate_source(const ProblemShape &s, int solver, int unit =
     if (s.rng_rounds != 10) o << "#define MCI_PHILOX_ROUNDS " << s.rng_rounds << "\n"; // opt-in cheaper stream (mci_set_rng_rounds)
     o << "#include \"mci_device.h\"\n";
     o << "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n";
-    o << "#ifdef MCI_WAVES\n#define MCI_OCC __attribute__((amdgpu_waves_per_eu(MCI_WAVES, MCI_WAVES)))\n#else\n#define MCI_OCC\n#endif\n";
     o << "namespace {\nstruct Cfg {\n";
     o << "    static constexpr int NDRAW = " << s.ndraw << ", NLEAF = " << s.nleaf << ", NI = " << s.ni
       << ", NPOOL = " << s.npool << ", NOBS = " << s.nobs << ", NCOLS = " << s.ncols << ";\n";
@@ -159,7 +158,7 @@ inline std::string generate_source(const ProblemShape &s, int solver, int unit =
         o << "extern \"C\" __global__ void __launch_bounds__(256) mci_sample_dump(mci::DumpArgs a) { "
              "mci::sample_dump<Cfg>(a); }\n";
     } else if (solver == 0) {
-        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) MCI_OCC mci_vegas_batch(mci::BatchArgs a) { "
+        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_batch(mci::BatchArgs a) { "
              "mci::vegas_batch<Cfg, (Cfg::NTILE > 1)>(a); }\n";
         if (s.ntile > 1)
             o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_tiles(mci::BatchArgs a) { "

@@ -265,9 +265,6 @@ struct TrainArgs {
     double gamma;
     int do_train, serial_walk;
     int *status;
-    // hipGraph replay: loop[0] = iteration index, loop[1] = row of the iteration log; both advance here
-    unsigned *loop;
-    double *iter_log_base;
 };
 
 // Sixteen bins of the refinement walk on ONE lane (variable.jl:228-232, bin-major).  On entry acc = acc_f AFTER bin 0 of the trip was
@@ -563,17 +560,9 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
 __device__ inline void iteration_bookkeeping(const TrainArgs &a) {
     const int tid = threadIdx.x, T = blockDim.x;
     double *row = a.iter_log_row;
-    if (a.loop) row = a.iter_log_base + (size_t)a.loop[1] * a.nstat;
     if (row)
         for (int i = tid; i < a.nstat; i += T) row[i] = a.packed[i];
     if (a.do_reweight && tid == 0) do_reweight_dev(a.reweight, a.packed + (a.nstat - a.nd), a.nd, a.gamma, a.goal);
-    if (a.loop) {
-        __syncthreads(); // every lane has read loop[1]
-        if (tid == 0) {
-            a.loop[0] += 1u;
-            a.loop[1] += 1u;
-        }
-    }
 }
 
 // One workgroup per leaf: Dist.train! then clearStatistics!; workgroup `nleaf`: bookkeeping.

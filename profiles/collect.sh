@@ -7,8 +7,8 @@
 # Counter passes never combine --pmc with trace domains other than --kernel-trace (gpurun rule).
 #   usage: profiles/collect.sh <tag> [bench|c4|c3|c5] [steps]
 #     bench: the default bench.py workload (C2), kernel mci_vegas_batch          -> profiles/<tag>_kernel_stats.txt, <tag>_pmc_traffic.json
-#     c4   : BASELINE configs[3] on one GPU (tools/c4_prof.py), mci_vegas_batch + mci_vegas_tiles
-#     c3   : BASELINE configs[2] (tools/c3mc_prof.py), mci_vegasmc_chains;   c5: BASELINE configs[4] (tools/mcmc_prof.py 0), mci_mcmc_chains
+#     c4   : BASELINE configs[3] on one GPU (tools/workload.py c4), mci_vegas_batch + mci_vegas_tiles
+#     c3   : BASELINE configs[2] (tools/workload.py c3), mci_vegasmc_chains;   c5: BASELINE configs[4] (tools/workload.py c5), mci_mcmc_chains
 set -u
 TAG=${1:-r02}
 WHAT=${2:-bench}
@@ -17,13 +17,13 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 if [ "$WHAT" = "c4" ]; then
-  CMD="python tools/c4_prof.py 32"
+  CMD="python tools/workload.py c4"
   KERNELS="mci_vegas_batch,mci_vegas_tiles"
 elif [ "$WHAT" = "c3" ]; then        # BASELINE configs[2]: example/bubble.jl under :vegasmc, 1e8 steps per iteration
-  CMD="python tools/c3mc_prof.py"
+  CMD="python tools/workload.py c3"
   KERNELS="mci_vegasmc_chains"
 elif [ "$WHAT" = "c5" ]; then        # BASELINE configs[4]: 4 integrals on a 12-D pool under :mcmc, automatic chain length
-  CMD="python tools/mcmc_prof.py 0"
+  CMD="python tools/workload.py c5"
   KERNELS="mci_mcmc_chains"
 else
   CMD="python bench.py --steps $STEPS --warmup 5 --passes ${PASSES:-40} --no-cpu-baseline"   # ~400 launches: the average is the steady state, not the idle ramp

@@ -561,30 +561,6 @@ def test_chain_solvers_with_tiled_histograms_match_oracle(oracle, solver, monkey
     assert len(seen) == 4 and all(16 <= n <= 3200 + 16 for n in seen)   # (:mcmc measures at i = nburnin .. neval + nburnin inclusive, mcmc/montecarlo.jl:134,143)
 
 
-def test_graph_replay_of_the_iteration_chain_matches_the_eager_loop(monkeypatch):
-    """MCI_GRAPH=1: mci_integrate replays one captured hipGraph per :vegas iteration (iteration index and log row advance on
-    the device); same kernels in the same order.  (Not bit-identical run to run either way: the order of the
-    ds_add_f64 inside a workgroup follows the wave schedule, and train! amplifies those last-bit differences.)"""
-    outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("MCI_GRAPH", flag)
-        out = __import__("subprocess").run(
-            [__import__("sys").executable, "-c",
-             "import sys; sys.path.insert(0, %r); import numpy as np, mcintegration_jl_amd as mci\n"
-             "cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]], seed=5)\n"
-             "eng = mci.Engine(cfg, mci.catalog.sphere2())\n"
-             "for solver in ('vegas', 'vegas', 'vegas'):\n"
-             "    r = eng.integrate(solver, neval=40000, niter=6, block=8, seed=5, nchain=4)\n"
-             "    print(repr(r['iter_mean'].tolist()), repr(r['iter_std'].tolist()))\n" % __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))],
-            capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0, out.stderr
-        outs.append([eval("(" + ln.replace("]] [[", "]], [[") + ")") for ln in out.stdout.splitlines() if ln.startswith("[[")])
-    assert len(outs[0]) == 3 and len(outs[1]) == 3
-    for (m0, e0), (m1, e1) in zip(outs[0], outs[1]):
-        np.testing.assert_allclose(m1, m0, rtol=1e-5)
-        np.testing.assert_allclose(e1, e0, rtol=1e-3)
-
-
 @pytest.mark.parametrize("solver", ["vegas", "vegasmc", "mcmc"])
 def test_degenerate_pools_match_oracle(oracle, solver):
     """ragged layouts the updates special-case: a single-valued Discrete (nothing to sample: vegas_mc/updates.jl:52-54,

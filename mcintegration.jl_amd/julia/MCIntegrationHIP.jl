@@ -561,7 +561,8 @@ Same keywords as the reference (src/main.jl:71-90); the loop of src/main.jl:142-
 function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::Symbol=:vegasmc, config=nothing, neval=1e4, niter=10,
                    block=16, gamma=1.0, adapt=true, ignore::Int=adapt ? 1 : 0, measure=nothing, measurefreq::Int=1,
                    thermal_ratio=0.1, reweight_goal::Union{Vector{Float64},Nothing}=nothing,
-                   nchain=0, rng_bits::Int=52, rng_rounds::Int=10, train_walk::Int=-1, print=-1, verbose=-1, kwargs...)
+                   nchain=0, rng_bits::Int=52, rng_rounds::Int=10, train_walk::Int=-1, deterministic::Bool=false, chain_carry::Int=-1,
+                   print=-1, verbose=-1, kwargs...)
     haskey(SOLVER, solver) || error("Solver $solver is not supported!")                  # main.jl:263
     config === nothing && (config = Configuration(; kwargs...))                          # main.jl:95-97
     # workers: after init_comm!(...) the library runs this rank's share of the blocks and sums every iteration's statistics and
@@ -579,10 +580,14 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
         check(ccall((:mci_set_measure_host, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, C_NULL, C_NULL))
         measure isa Measure && check(ccall((:mci_set_measure_source, libmci), Cint, (Ptr{Cvoid}, Cstring), prob, measure.body))
     end
-    # engine-specific knobs (include/mci.h): the opt-in 32-bit uniform stream of :vegas, train!'s refinement walk
+    # engine-specific knobs (include/mci.h): the opt-in cheaper streams, train!'s refinement walk
     check(ccall((:mci_set_rng_bits, libmci), Cint, (Ptr{Cvoid}, Int32), prob, rng_bits))
     check(ccall((:mci_set_rng_rounds, libmci), Cint, (Ptr{Cvoid}, Int32), prob, rng_rounds))
     check(ccall((:mci_set_train_walk, libmci), Cint, (Ptr{Cvoid}, Int32), prob, train_walk))
+    # deterministic = true: bit-identical results for a fixed seed, like the reference's sequential loop under MersenneTwister(seed)
+    # (configuration.jl:190); chain_carry: -1 automatic (:vegasmc iterations continue the previous one's chains), 0 off, 1 :mcmc too
+    check(ccall((:mci_set_deterministic, libmci), Cint, (Ptr{Cvoid}, Int32), prob, deterministic ? 1 : 0))
+    check(ccall((:mci_set_chain_carry, libmci), Cint, (Ptr{Cvoid}, Int32), prob, chain_carry))
     nobs = sum(config.obs_nbin)
     im, ie = zeros(nobs, niter), zeros(nobs, niter)           # row-major [niter][nobs] on the C side
     m, s, c2 = zeros(nobs), zeros(nobs), zeros(nobs)

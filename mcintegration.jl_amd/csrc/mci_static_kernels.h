@@ -252,6 +252,17 @@ __device__ inline double sum16(const double *v, int n) {
     return __shfl(s, 0, 16);
 }
 
+// b ^ alpha of rescale (common.jl:75).  The learning rates the reference's constructors hand out are small integers (alpha = 2
+// by default, variable.jl:137; the bubble example uses 3): for those Julia's `^(::Float64, ::Float64)` takes its
+// power-by-squaring path, whose result is the correctly rounded product -- b * b here, one rounding, instead of exp(alpha * log(b)),
+// which also was a third of a launch-bound iteration's refinement time.  Any other exponent goes through pow().
+__device__ inline double rescale_pow(double b, double alpha) {
+    if (alpha == 2.0) return b * b;
+    if (alpha == 1.0) return b;
+    if (alpha == 3.0) return b * b * b;
+    return pow(b, alpha);
+}
+
 struct TrainArgs {
     const LeafDev *leaves;
     int nleaf;
@@ -415,7 +426,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             __syncthreads(); // every 16-lane group reads ALL of d[] for its total: nobody overwrites d[] before the last group is through
             for (int i = tid; i < N; i += T) {
                 double v = d[i] / s;
-                if (v > 0 && v <= 0.99999999) v = pow(-(1 - v) / log(v), L.alpha);
+                if (v > 0 && v <= 0.99999999) v = rescale_pow(-(1 - v) / log(v), L.alpha);
                 if (!isfinite(v)) atomicOr(&bad, ST_RESCALE_NONFINITE); // common.jl:79
                 d[i] = v;
             }
@@ -528,7 +539,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             if (N > 1) {
                 for (int i = 0; i < N; ++i) {
                     double v = h[i] / s;
-                    if (v > 0 && v <= 0.99999999) v = pow(-(1 - v) / log(v), L.alpha);
+                    if (v > 0 && v <= 0.99999999) v = rescale_pow(-(1 - v) / log(v), L.alpha);
                     if (!isfinite(v)) lbad = ST_RESCALE_NONFINITE;
                     d[i] = v;
                 }

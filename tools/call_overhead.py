@@ -28,8 +28,16 @@ if __name__ == "__main__":
         reuse = (time.perf_counter() - t0) / n
         print("%-8s integrate(neval=1e4, niter=10): new Configuration per call %8.3f ms, same Configuration %8.3f ms   (%s)" % (
             solver, fresh * 1e3, reuse * 1e3, r), flush=True)
-    # profile of one fresh call
+    # profile of calls on a reused Configuration, then of fresh ones
     import cProfile, pstats
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
+    mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(50):
+        mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(18)
     pr = cProfile.Profile()
     pr.enable()
     for i in range(10):

@@ -32,7 +32,7 @@ int main(int argc, char **argv) {
 
     enum { NITER = 10 };
     double iter_mean[NITER], iter_std[NITER], mean, stdev, chi2;
-    mci_result res = {NITER, 1, iter_mean, iter_std, &mean, &stdev, &chi2, 0, 0.0};
+    mci_result res = {NITER, 1, iter_mean, iter_std, &mean, &stdev, &chi2, 0, 0.0, NULL};
     mci_integrate_args args = {MCI_VEGAS, neval, NITER, 16, -1, 1, 1.0, 1, 20240229u, 0, 0, 0.1, NULL};
     CHECK(mci_integrate(prob, &args, &res));
 

@@ -34,6 +34,8 @@ extern "C" {
 
 enum { MCI_CONTINUOUS = 0, MCI_DISCRETE = 1, MCI_FERMIK = 2 }; /* Dist.Continuous variable.jl:87-99 / Dist.Discrete :272-284 / Dist.FermiK :1-20 */
 enum { MCI_VEGAS = 0, MCI_VEGASMC = 1, MCI_MCMC = 2 }; /* solver=:vegas main.jl:256 / :vegasmc :253 / :mcmc :259 */
+/* not a solver: names the persistent :vegas kernel (mci_set_persistent) for mci_compile_solver / mci_kernel_code_object */
+enum { MCI_VEGAS_PERSISTENT = 3 };
 
 typedef struct mci_ctx mci_ctx;
 typedef struct mci_problem mci_problem;
@@ -103,6 +105,7 @@ typedef struct {
     double *chi2;      /* [nobs] reduced chi2 */
     int64_t neval;     /* evaluations actually performed, all iterations, this rank's view after reduction */
     double seconds;    /* wall time of the iteration loop (kernels + train + all-reduce) */
+    double *visited;   /* [nintegrand+1] or NULL: config.visited of the last iteration (configuration.jl:46), read with the statistics */
 } mci_result;
 
 /* ---- context: HIP device + stream (+ RCCL communicator); replaces MPI.Init, main.jl:113-114 ---- */
@@ -286,6 +289,22 @@ int mci_set_deterministic(mci_problem *prob, int32_t on);
 int mci_set_chain_carry(mci_problem *prob, int32_t mode);
 /* chains per block of the last chain-solver launch and whether it continued the launch before it */
 int mci_last_chain_launch(const mci_problem *prob, int64_t *nchain, int32_t *carried);
+/* Persistent :vegas iterations.  The reference's loop (main.jl:142-207) at the reference's own default size (neval = 1e4, main.jl:76)
+ * is launch-bound on a GPU: a few microseconds of sampling per iteration behind two dependent kernel launches.  With mode -1
+ * (default) a single-rank mci_integrate call of solver MCI_VEGAS at measurefreq == 1 whose iterations are that small (samples x
+ * draws < 2^21) runs ALL its iterations as one launch of at most 256 co-resident workgroups: sample -> grid-wide arrive -> block
+ * merge and train! by the first nleaf + 1 workgroups -> grid-wide release -> next iteration (csrc/mci_train.h vegas_persist).  Same
+ * Philox streams and the same arithmetic as the launch chain (sums differ by reassociation only).  Needs tables and histograms in LDS
+ * (table mode 0), device-source integrand and measure, the prefix-scan walk, no forced launch geometry and no kernel timing; anything
+ * else, mode 0, and every call through mci_iteration_run take the launch chain.  mode 1: every call the layout allows, whatever
+ * its size.  A grid-wide wait that runs out of time (2 s: a device shared with other long-running kernels) fails the call with
+ * MCI_ERR_HIP instead of hanging, and later calls take the launch chain. */
+int mci_set_persistent(mci_problem *prob, int32_t mode);
+/* whether the last mci_integrate ran as one persistent launch */
+int mci_last_integrate_persistent(const mci_problem *prob, int32_t *persistent);
+/* development aid (tools/persist_trace.py): the persistent kernel's counter words and, in builds with -DMCI_PERSIST_TRACE, the
+ * wall-clock stamps of three of its workgroups over the first eight turns of the last launch */
+int mci_debug_persist_words(mci_problem *prob, unsigned long long *out, int32_t n);
 /* Dist.train! on the histograms currently in the packed buffer (variable.jl:206-239, :369-382) */
 int mci_train(mci_problem *prob);
 /* the adaptive map alone (sampler.jl:293-305, :13-22) + integrand: first `n` samples of block `block_index`

@@ -50,7 +50,7 @@ HOST_MEASURE_IDX_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int32), c_double_p, c_d
 class ResultC(C.Structure):
     _fields_ = [("niter", C.c_int32), ("nobs", C.c_int32), ("iter_mean", c_double_p), ("iter_std", c_double_p),
                 ("mean", c_double_p), ("stdev", c_double_p), ("chi2", c_double_p), ("neval", C.c_int64),
-                ("seconds", C.c_double)]
+                ("seconds", C.c_double), ("visited", c_double_p)]
 
 
 # every symbol include/mci.h declares: (name, restype, argtypes)
@@ -104,6 +104,9 @@ SIGNATURES = [
     ("mci_set_rng_rounds", C.c_int, [_VP, C.c_int32]),
     ("mci_set_deterministic", C.c_int, [_VP, C.c_int32]),
     ("mci_set_chain_carry", C.c_int, [_VP, C.c_int32]),
+    ("mci_set_persistent", C.c_int, [_VP, C.c_int32]),
+    ("mci_last_integrate_persistent", C.c_int, [_VP, C.POINTER(C.c_int32)]),
+    ("mci_debug_persist_words", C.c_int, [_VP, C.POINTER(C.c_uint64), C.c_int32]),
     ("mci_last_chain_launch", C.c_int, [_VP, C.POINTER(C.c_int64), c_int32_p]),
     ("mci_train", C.c_int, [_VP]),
     ("mci_sample_dump", C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),

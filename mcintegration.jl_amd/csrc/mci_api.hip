@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -233,10 +234,28 @@ struct mci_problem {
     int last_wg = 0, last_threads = 0, last_nblocks = 0;
     int64_t last_nchain = 0; // chains per block of the last chain-solver launch
     int log_row = 0;
+    // persistent :vegas iterations (mci_train.h vegas_persist; mci_set_persistent): its own code object -- the plain layout at
+    // `threads` -- and the two grid-wide counters, which only grow (the host keeps their values)
+    hipModule_t module_persist = nullptr;
+    hipFunction_t f_persist = nullptr;
+    bool persist_compiled = false, persist_failed = false;
+    std::string persist_code_object;
+    // its translation unit takes twice as long to compile as the plain sample kernel (train! comes with it): in automatic mode a code
+    // object that is not in the kernel cache is compiled on a thread of its own while the calls go through the launch chain
+    struct PersistJob;
+    PersistJob *persist_job = nullptr;
+    unsigned long long *d_persist = nullptr; // [0] arrived | done << 40, [2] gave up
+    unsigned long long persist_arrive = 0, persist_done = 0;
+    int persistent = -1;          // -1 automatic (launch-bound :vegas calls of mci_integrate), 0 never, 1 whenever the layout allows
+    bool last_persistent = false; // the last mci_integrate ran as one persistent launch
     static const int kGroups = mci::kMergeGroups;
     static const int64_t kChainFill = 131072; // chains per GPU that keep 2 waves on each of the 1024 SIMDs
     static const int64_t kMcmcMinSteps = 131072; // measured steps per auto :mcmc chain (>> the mixing times measured so far)
 };
+
+static void persist_job_drop(mci_problem *p);
+// counters [0..2] of the persistent :vegas kernel + (MCI_PERSIST_TRACE builds) the phase stamps of three workgroups over eight turns
+static const size_t kPersistWords = 8 + 3 * 8 * 8 + 16;
 
 namespace {
 
@@ -282,6 +301,14 @@ int check_status(mci_problem *p) {
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     if (!st) return MCI_OK;
     HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int), p->ctx->stream));
+    if (st & mci::ST_PERSIST_STALL) { // a grid-wide wait of the persistent :vegas launch ran out of time: its counters are void
+        HIPCHK(hipMemsetAsync(p->d_persist, 0, 3 * sizeof(unsigned long long), p->ctx->stream));
+        HIPCHK(hipMemsetAsync(p->d_ghist, 0, 3 * (size_t)(p->shape.nbin ? p->shape.nbin : 1) * sizeof(double), p->ctx->stream));
+        p->persist_arrive = p->persist_done = 0;
+        p->persist_failed = true; // (later calls take the launch-per-iteration path)
+        return fail(MCI_ERR_HIP, "the persistent :vegas launch stalled (is the device shared with other long-running kernels?); "
+                                 "the iterations of this call are void -- later calls launch per iteration (mci_set_persistent(prob, 0))");
+    }
     if (st & mci::ST_MCMC_INIT) return fail(MCI_ERR_INVALID, "Cannot find the variables that makes the integrand nonzero!"); // mcmc/montecarlo.jl:126
     if (st & mci::ST_NORMALIZATION) return fail(MCI_ERR_NORMALIZATION, "Block normalization is not positively defined!");
     if (st & mci::ST_HIST_NONFINITE) return fail(MCI_ERR_HISTOGRAM, "histogram should be all finite");
@@ -333,6 +360,13 @@ void drop_modules(mci_problem *p) {
             (void)hipModuleUnload(p->module[k]);
             p->module[k] = nullptr;
         }
+    }
+    p->persist_compiled = p->persist_failed = false;
+    persist_job_drop(p);
+    p->f_persist = nullptr;
+    if (p->module_persist) {
+        (void)hipModuleUnload(p->module_persist);
+        p->module_persist = nullptr;
     }
 }
 
@@ -637,6 +671,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         }
         if (const char *e = getenv("MCI_TRAIN_SERIAL")) p->train_serial = atoi(e) != 0 ? 1 : 0;
         if (const char *e = getenv("MCI_CHAIN_CARRY")) p->chain_carry = atoi(e) == 0 ? 0 : atoi(e) > 0 ? 1 : -1; // (mci_set_chain_carry)
+        if (const char *e = getenv("MCI_PERSISTENT")) p->persistent = atoi(e) == 0 ? 0 : atoi(e) > 0 ? 1 : -1;     // (mci_set_persistent)
         if (const char *e = getenv("MCI_KERNEL_TIMING")) p->kernel_timing = atoi(e) < 0 ? -1 : atoi(e) > 0 ? 1 : 0; // (mci_set_kernel_timing)
         // histogram tiles: contiguous leaves, each tile's bins fit the LDS left over
         s.leaf_tile.assign(p->leaves.size(), 0);
@@ -774,8 +809,9 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         if (rc) { delete p; return rc; }
         HIPCHK(hipMalloc((void **)&p->d_packed, (size_t)p->packed_n * sizeof(double)));
         HIPCHK(hipMemset(p->d_packed, 0, (size_t)p->packed_n * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&p->d_ghist, (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
-        HIPCHK(hipMemset(p->d_ghist, 0, (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
+        // (three buffers: the persistent :vegas kernel rotates through them, mci_train.h vegas_persist; everything else uses the first)
+        HIPCHK(hipMalloc((void **)&p->d_ghist, 3 * (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
+        HIPCHK(hipMemset(p->d_ghist, 0, 3 * (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
         HIPCHK(hipMalloc((void **)&p->d_stage1, (size_t)mci_problem::kGroups * (s.nbin ? s.nbin : 1) * sizeof(double)));
         HIPCHK(hipMalloc((void **)&p->d_status, sizeof(int)));
         HIPCHK(hipMemset(p->d_status, 0, sizeof(int)));
@@ -801,6 +837,11 @@ int mci_problem_destroy(mci_problem *p) {
             if (q) (void)hipFree(q);
         for (int k = 0; k < 5; ++k)
             if (p->module[k]) (void)hipModuleUnload(p->module[k]);
+        if (p->module_persist) (void)hipModuleUnload(p->module_persist);
+        if (p->d_persist) (void)hipFree(p->d_persist);
+    }
+    persist_job_drop(p);
+    if (!p->ctx->offline) {
         if (p->d_goal) (void)hipFree(p->d_goal);
         if (p->d_part_pa) (void)hipFree(p->d_part_pa);
         if (p->d_hold) (void)hipFree(p->d_hold);
@@ -1198,6 +1239,11 @@ int mci_compile(mci_problem *p) { return compile_solver(p, MCI_VEGAS); }
 
 int mci_kernel_code_object(mci_problem *p, int32_t solver, char *buf, int32_t n) {
     if (!p || !buf || n < 1) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (solver == MCI_VEGAS_PERSISTENT) {
+        if (!p->persist_compiled) return fail(MCI_ERR_INVALID, "the persistent :vegas kernel has not been compiled yet");
+        snprintf(buf, (size_t)n, "%s", p->persist_code_object.c_str());
+        return MCI_OK;
+    }
     if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver);
     const int slot = (solver == MCI_VEGAS && !p->compiled[solver] && p->compiled[kSlotVegasAny]) ? kSlotVegasAny : solver;
     if (!p->compiled[slot]) return fail(MCI_ERR_INVALID, "solver %d has not been compiled yet", solver);
@@ -1251,6 +1297,27 @@ int mci_set_chain_carry(mci_problem *p, int32_t mode) {
     return MCI_OK;
 }
 
+int mci_set_persistent(mci_problem *p, int32_t mode) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (mode < -1 || mode > 1) return fail(MCI_ERR_INVALID, "persistent mode must be -1 (automatic: launch-bound :vegas calls), 0 (one launch chain per iteration) or 1 (whenever the layout allows)");
+    p->persistent = mode;
+    return MCI_OK;
+}
+
+// development aid (tools/persist_trace.py): the raw counter / stamp words of the persistent kernel
+int mci_debug_persist_words(mci_problem *p, unsigned long long *out, int32_t n) {
+    if (!p || !out || !p->d_persist) return fail(MCI_ERR_INVALID, "no persistent launch yet");
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    HIPCHK(hipMemcpy(out, p->d_persist, (size_t)(n < (int)kPersistWords ? n : (int)kPersistWords) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MCI_OK;
+}
+
+int mci_last_integrate_persistent(const mci_problem *p, int32_t *persistent) {
+    if (!p || !persistent) return fail(MCI_ERR_INVALID, "NULL argument");
+    *persistent = p->last_persistent ? 1 : 0;
+    return MCI_OK;
+}
+
 int mci_last_chain_launch(const mci_problem *p, int64_t *nchain, int32_t *carried) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     if (nchain) *nchain = p->last_nchain;
@@ -1263,7 +1330,13 @@ int mci_check_status(mci_problem *p) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
     return check_status(p);
 }
+static int compile_persist(mci_problem *p, bool background);
+static bool persist_layout_ok(const mci_problem *p);
 int mci_compile_solver(mci_problem *p, int32_t solver) {
+    if (solver == MCI_VEGAS_PERSISTENT) { // the persistent :vegas kernel (mci_set_persistent), for layouts that allow it
+        if (!persist_layout_ok(p)) return fail(MCI_ERR_INVALID, "this layout has no persistent :vegas kernel (mci_set_persistent)");
+        return compile_persist(p, false);
+    }
     if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver); // main.jl:263
     return compile_solver(p, solver);
 }
@@ -1871,6 +1944,7 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     a.do_train = do_train;
     a.serial_walk = p->train_serial >= 0 ? p->train_serial : (p->last_samples == 0 || p->last_samples >= mci_problem::kSerialWalkSamples) ? 1 : 0;
     a.status = p->d_status;
+    a.maxn = maxn;
     const size_t sm = (size_t)mci::train_lds_doubles(maxn) * sizeof(double); // d | sg | wa (train_leaf)
     // two bins per thread for the default 999-bin grids: the rescale (a pow and a log per bin) and the second merge stage are the
     // latency chains of a lone workgroup; with four bins per thread (256 threads) a launch-bound iteration took 24.7 us, with two
@@ -1947,6 +2021,223 @@ int mci_train(mci_problem *p) {
     return check_status(p);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// persistent :vegas iterations: all `niter` iterations of a launch-bound mci_integrate call as ONE launch (mci_train.h vegas_persist)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+// LDS of the persistent kernel (bytes): the sample loop's carve (plain layout) or the refinement's (scratch, merged histogram, scan
+// scratch), whichever is larger -- each is dead while the other runs --, and behind them (map_off, doubles) the workgroup's own copy of
+// the map and the flag words (mci_train.h PersistArgs)
+int64_t persist_lds(const mci_problem *p, int *map_off) {
+    const int N = p->leaves.empty() ? 1 : p->leaves[0].nbin;
+    const int64_t a = (p->lds_bytes + 7) / 8, b = (int64_t)mci::train_lds_doubles(N) + N + 256;
+    const int64_t off = ((a > b ? a : b) + 1) & ~(int64_t)1;
+    if (map_off) *map_off = (int)off;
+    return (off + (N + 2) + 4) * 8;
+}
+// Structural conditions of the persistent kernel: ONE Continuous leaf (every sampling workgroup refines its own copy of the map), tables
+// and histograms in LDS in one tile, device-source integrand and measure, everything within the 64 KiB every workgroup may ask for.
+bool persist_layout(const mci_problem *p) {
+    const auto &s = p->shape;
+    if (p->deterministic || s.table_mode != 0 || s.ntile != 1 || s.host_integrand || s.host_measure || s.nbin <= 0 || s.ec_doubles > 0) return false;
+    if (s.nleaf != 1 || p->leaves.size() != 1 || p->leaves[0].kind != 0) return false;
+    return persist_lds(p, nullptr) <= 64 * 1024;
+}
+// Which calls run persistently, and on how many workgroups per block: one rank, :vegas at measurefreq == 1, the prefix-scan walk, no
+// forced geometry or timing, a grid that is co-resident next to another one like it (<= 128 sampling workgroups + the statistics one).
+// Automatic mode adds: launch-bound sizes only (samples x draws below 2^21 per iteration -- beyond that the sample pass dominates and
+// the launch-per-iteration chain brings its tuned layouts: histogram copies, 512-thread workgroups).
+bool persist_plan(const mci_problem *p, const mci_integrate_args *a, int64_t nevalperblock, int64_t nblocks, int *wpb_out) {
+    const auto &s = p->shape;
+    if (p->persistent == 0 || p->persist_failed) return false;
+    if (a->solver != MCI_VEGAS || a->measurefreq != 1 || a->niter < 1) return false;
+    if (p->ctx->nranks != 1) return false; // (a one-rank communicator's all-reduce is the identity)
+    if (!persist_layout(p)) return false;
+    if (p->wg_per_block > 0 || p->kernel_timing > 0 || p->train_serial == 1) return false;
+    const int64_t work = nevalperblock * nblocks * s.ndraw;
+    if (p->persistent < 0 && work >= ((int64_t)1 << 21)) return false;
+    const int T = p->threads;
+    int64_t target = work < ((int64_t)1 << 19) ? 64 : 128;
+    int64_t wpb = (target + nblocks - 1) / nblocks;
+    const int64_t maxw = (nevalperblock + T - 1) / T;
+    if (wpb > maxw) wpb = maxw;
+    if (wpb < 1) wpb = 1;
+    while (wpb > 1 && wpb * nblocks > 128) --wpb;
+    if (wpb * nblocks > 255) return false;
+    if (wpb_out) *wpb_out = (int)wpb;
+    return true;
+}
+} // namespace
+
+static bool persist_layout_ok(const mci_problem *p) { return persist_layout(p); }
+
+// one hiprtc job on a thread of its own (the thread touches nothing but this record)
+struct mci_problem::PersistJob {
+    Candidate c;
+    std::thread th;
+    std::atomic<bool> done{false};
+};
+static void persist_job_drop(mci_problem *p) { // (the compile cannot be interrupted: wait for it)
+    if (!p->persist_job) return;
+    if (p->persist_job->th.joinable()) p->persist_job->th.join();
+    delete p->persist_job;
+    p->persist_job = nullptr;
+}
+// MCI_OK with p->persist_compiled set: the kernel is loaded.  MCI_OK without: not yet (background == true and the code object is
+// still being compiled) -- the caller takes the launch chain this time.
+static int compile_persist(mci_problem *p, bool background) {
+    if (p->persist_compiled) return MCI_OK;
+    Candidate local, *c = &local;
+    if (p->persist_job) {
+        if (!p->persist_job->done.load(std::memory_order_acquire)) {
+            if (background) return MCI_OK;
+            p->persist_job->th.join(); // (a caller that insists)
+        }
+        if (p->persist_job->th.joinable()) p->persist_job->th.join();
+        local = std::move(p->persist_job->c);
+        delete p->persist_job;
+        p->persist_job = nullptr;
+    } else {
+        mcijit::ProblemShape sh = p->shape;
+        sh.hcopy = 1;
+        sh.det = 0;
+        c->src = mcijit::generate_source(sh, MCI_VEGAS, mcijit::kUnitVegasPersist);
+        c->threads = p->threads;
+        c->rc = mcijit::compile(c->src, c->threads, c->code, c->log, c->cached, &c->path, true, /*cache_only=*/background);
+        if (c->rc == -1) { // not in the kernel cache: compile it behind the caller's back
+            p->persist_job = new mci_problem::PersistJob;
+            p->persist_job->c = std::move(local);
+            mci_problem::PersistJob *j = p->persist_job;
+            j->th = std::thread([j] {
+                j->c.rc = mcijit::compile(j->c.src, j->c.threads, j->c.code, j->c.log, j->c.cached, &j->c.path, true);
+                j->done.store(true, std::memory_order_release);
+            });
+            return MCI_OK;
+        }
+    }
+    if (c->rc) {
+        p->persist_failed = true; // (the launch chain's own compile reports what is wrong with the integrand)
+        return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", c->log.c_str());
+    }
+    if (mcijit::max_static_lds_bytes(c->code) != 0 || mcijit::kernel_scratch_bytes(c->code, "mci_vegas_persist") != 0) {
+        p->persist_failed = true; // (not an error of the call: it takes the launch chain)
+        return fail(MCI_ERR_COMPILE, "the persistent :vegas kernel came out with static LDS or scratch");
+    }
+    p->persist_code_object = c->path;
+    if (p->ctx->offline) {
+        p->persist_compiled = true;
+        return MCI_OK;
+    }
+    HIPCHK(hipSetDevice(p->ctx->device));
+    if (hipModuleLoadData(&p->module_persist, c->code.data()) != hipSuccess) {
+        p->persist_failed = true;
+        if (c->cached) unlink(c->path.c_str()); // a cached code object that does not load (truncated by a crash, foreign file)
+        return fail(MCI_ERR_HIP, "hipModuleLoadData failed for the persistent :vegas code object");
+    }
+    HIPCHK(hipModuleGetFunction(&p->f_persist, p->module_persist, "mci_vegas_persist"));
+    if (!p->d_persist) {
+        HIPCHK(hipMalloc((void **)&p->d_persist, kPersistWords * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(p->d_persist, 0, kPersistWords * sizeof(unsigned long long), p->ctx->stream));
+        p->persist_arrive = p->persist_done = 0;
+    }
+    p->persist_compiled = true;
+    return MCI_OK;
+}
+
+// queue the one launch that runs iterations first_iteration .. first_iteration + niter - 1 over blocks [lo, hi)
+static int persist_launch(mci_problem *p, const mci_integrate_args *ia, int64_t nevalperblock, int64_t lo, int64_t hi, int wpb) {
+    const auto &s = p->shape;
+    const int64_t nblocks = hi - lo, nrows = nblocks * wpb;
+    int rc;
+    if ((rc = flush_merge(p))) return rc; // (a batch nobody looked at resets the global histogram when it is merged)
+    HIPCHK(hipSetDevice(p->ctx->device));
+    if ((rc = ensure_capacity(p, 2 * nrows, nblocks))) return rc; // (the partial rows are double-buffered by the turn's parity)
+    if ((rc = grow_iteration_log(p, (int64_t)p->log_row + ia->niter))) return rc;
+    const int T = p->threads;
+    mci::BatchArgs a{};
+    a.edges = p->d_edges;
+    a.dacc = p->d_dacc;
+    a.ddist = p->d_ddist;
+    a.reweight = p->d_reweight;
+    a.ud = p->d_ud;
+    a.part_cols = p->d_part_cols;
+    a.part_hist = p->d_part_hist;
+    a.ghist = p->d_ghist;
+    a.seed = ia->seed;
+    a.iteration = (mci::u32)ia->first_iteration;
+    a.neval_per_block = nevalperblock;
+    a.block_lo = lo;
+    a.wg_per_block = wpb;
+    a.measurefreq = 1;
+    a.nchain = 1;
+    a.hist_atomic = 1;
+    a.status = p->d_status;
+    a.tile_stride = nblocks * nevalperblock;
+    a.nrows = nrows;
+    mci::PersistArgs f{};
+    mci::MergeArgs &m = f.m;
+    m.part_cols = p->d_part_cols;
+    m.ncols = s.ncols;
+    m.nobs = s.nobs;
+    m.ni = s.ni;
+    m.nblocks = (int)nblocks;
+    m.wg_per_block = wpb;
+    m.stage1 = p->d_stage1;
+    m.ngroup = (int)mci_problem::kGroups;
+    m.ghist = p->d_ghist;
+    m.use_ghist = 1;
+    m.nbin = s.nbin;
+    m.packed = p->d_packed;
+    m.status = p->d_status;
+    m.scratch = p->d_scratch;
+    m.part_pa = nullptr;
+    m.npa = p->npa;
+    m.nrows = (int)nrows;
+    mci::TrainArgs &t = f.t;
+    t.leaves = p->d_leaves;
+    t.nleaf = s.nleaf;
+    t.packed = p->d_packed;
+    t.nstat = p->nstat;
+    t.edges = p->d_edges;
+    t.dacc = p->d_dacc;
+    t.ddist = p->d_ddist;
+    t.iter_log_row = p->d_iterlog + (size_t)p->log_row * p->nstat;
+    t.reweight = p->d_reweight;
+    t.goal = nullptr;
+    t.nd = s.ni + 1;
+    t.do_reweight = 0; // (:vegas: main.jl:183 runs doReweight! for the chain solvers only)
+    t.gamma = ia->gamma;
+    t.do_train = ia->adapt ? 1 : 0;
+    t.serial_walk = 0;
+    t.status = p->d_status;
+    t.maxn = p->leaves[0].nbin;
+    f.niter = ia->niter;
+    const int64_t lds = persist_lds(p, &f.map_off);
+    f.ctr = p->d_persist;
+    if (p->persist_arrive > (1ull << 39)) { // (the arrive count owns 40 bits of the counter word: start over long before it spills)
+        HIPCHK(hipMemsetAsync(p->d_persist, 0, 3 * sizeof(unsigned long long), p->ctx->stream));
+        p->persist_arrive = p->persist_done = 0;
+    }
+    f.arrive0 = p->persist_arrive;
+    f.done0 = p->persist_done;
+    f.spin_ticks = 200000000ull; // 2 s of the 100 MHz wall clock per wait
+    void *args[] = {&a, &f};
+    // nrows sampling workgroups + the statistics workgroup
+    HIPCHK(hipModuleLaunchKernel(p->f_persist, (unsigned)nrows + 1, 1, 1, (unsigned)T, 1, 1, (unsigned)lds, p->ctx->stream, args, nullptr));
+    p->persist_arrive += (unsigned long long)(ia->niter + 1) * (unsigned long long)nrows; // (+ one "finished reading" per workgroup at the end)
+    p->persist_done += (unsigned long long)ia->niter;
+    p->time_this_launch = false;
+    p->merge_pending = false;
+    p->merge = m; // (what `packed` was merged from, for the record)
+    p->merge.part_cols = p->d_part_cols + (size_t)((ia->niter - 1) & 1) * (size_t)nrows * s.ncols;
+    p->last_samples = nblocks * nevalperblock;
+    p->last_wg = (int)nrows;
+    p->last_threads = T;
+    p->last_nblocks = (int)nblocks;
+    p->log_row += ia->niter;
+    return MCI_OK;
+}
+
 // integrate  (reference src/main.jl:71-218)
 int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) {
     if (!p || !a || !res) return fail(MCI_ERR_INVALID, "NULL argument");
@@ -1959,16 +2250,24 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     const int64_t per = block / p->ctx->nranks;                                         // main.jl:122
     const int64_t lo = per * p->ctx->rank, hi = lo + per;
     if (a->solver != MCI_VEGAS && a->solver != MCI_VEGASMC && a->solver != MCI_MCMC) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", a->solver); // main.jl:263
-    int rc = compile_solver(p, kslot(a->solver, a->measurefreq));
-    if (rc) return rc;
+    // launch-bound :vegas calls: the whole loop below as one persistent launch (same iterations, same Philox streams)
+    int wpb_persist = 0, rc = 0;
+    bool persist = persist_plan(p, a, nevalperblock, hi - lo, &wpb_persist);
+    // (automatic mode: a code object that is not in the kernel cache yet is compiled on a thread of its own, and until it is there the
+    // calls go through the launch chain -- a new integrand's first call costs what it did, 0.2 s, not the 0.8 s of the larger unit)
+    if (persist) (void)compile_persist(p, p->persistent < 0);
+    persist = persist && p->persist_compiled;
+    if (!persist && (rc = compile_solver(p, kslot(a->solver, a->measurefreq)))) return rc;
     if ((rc = mci_set_reweight_goal(p, a->reweight_goal, a->reweight_goal ? p->ni + 1 : 0))) return rc;
     const int ignore = a->ignore >= 0 ? a->ignore : (a->adapt ? 1 : 0);
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     const int row0 = p->log_row;
     auto t0 = std::chrono::steady_clock::now();
+    p->last_persistent = persist;
+    if (persist && (rc = persist_launch(p, a, nevalperblock, lo, hi, wpb_persist))) return rc;
     // (a hipGraph replay of this chain was measured and dropped: 37.6 against 34.8 us per launch-bound iteration for the eager
     // asynchronous launches on ROCm 7.0 / MI355X, profiles/r02_ablation.txt)
-    for (int it = 0; it < a->niter; ++it) { // main.jl:142
+    for (int it = 0; it < a->niter && !persist; ++it) { // main.jl:142
         if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, a->first_iteration + it, a->seed, a->measurefreq, a->nchain, a->thermal_ratio))) return rc;
         if ((rc = mci_iteration_reduce(p))) return rc;                                   // main.jl:177-188
         if ((rc = mci_iteration_finish(p, a->solver, block, a->adapt, a->gamma, nullptr, nullptr))) return rc; // main.jl:183-199
@@ -1983,6 +2282,7 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
         const double *row = h.data() + (size_t)it * p->nstat;
         mci_mean_std(row, row + s.nobs, s.nobs, block, res->iter_mean + (size_t)it * s.nobs, res->iter_std + (size_t)it * s.nobs);
         res->neval += (int64_t)row[2 * s.nobs + 1];
+        if (res->visited && it == a->niter - 1) memcpy(res->visited, row + 2 * s.nobs + 2, (size_t)(s.ni + 1) * sizeof(double));
     }
     for (int o = 0; o < s.nobs; ++o) // main.jl:211 -> statistics.jl:24-55
         mci_average(res->iter_mean + o, res->iter_std + o, s.nobs, ignore + 1, a->niter, &res->mean[o], &res->stdev[o], &res->chi2[o]);

@@ -28,6 +28,8 @@ namespace mcijit {
 
 // text of mci_device.h, embedded at build time (see __graft_entry__.build)
 extern const char *const kDeviceHeader;
+// text of mci_train.h (merge + train! device functions and the persistent :vegas kernel): the second header of a kUnitVegasPersist unit
+extern const char *const kTrainHeader;
 
 struct ProblemShape {
     int ndraw = 0, nleaf = 0, ni = 0, npool = 0, nobs = 0, ncols = 0, table_mode = 0;
@@ -92,12 +94,16 @@ static std::string dbl_arr(const std::vector<double> &v) {
 
 // solver: 0 vegas, 1 vegasmc, 2 mcmc.  unit: what the translation unit holds -- the solver's kernel (for :vegas: the loop for any
 // measurefreq), the :vegas kernel specialised on measurefreq == 1, or the sample-dump kernel alone; each is built on first use
-enum { kUnitSolver = 0, kUnitVegasMf1 = 1, kUnitDump = 2 };
+// kUnitVegasPersist: the :vegas loop for measurefreq == 1 inside the persistent kernel of mci_train.h (all iterations of a launch-bound
+// integrate() call in one launch): sample loop + block merge + train!
+enum { kUnitSolver = 0, kUnitVegasMf1 = 1, kUnitDump = 2, kUnitVegasPersist = 3 };
 inline std::string generate_source(const ProblemShape &s, int solver, int unit = kUnitSolver) {
     std::ostringstream o;
-    if (solver == 0 && unit != kUnitDump) o << "#define MCI_MF_ONLY " << (unit == kUnitVegasMf1 ? 1 : 0) << "\n";
+    if (solver == 0 && unit != kUnitDump) o << "#define MCI_MF_ONLY " << (unit == kUnitVegasMf1 || unit == kUnitVegasPersist ? 1 : 0) << "\n";
+    if (unit == kUnitVegasPersist) o << "#define MCI_TRAIN_SCAN_ONLY 1\n";
     if (s.rng_rounds != 10) o << "#define MCI_PHILOX_ROUNDS " << s.rng_rounds << "\n"; // opt-in cheaper stream (mci_set_rng_rounds)
     o << "#include \"mci_device.h\"\n";
+    if (unit == kUnitVegasPersist) o << "#include \"mci_train.h\"\n";
     o << "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n";
     o << "namespace {\nstruct Cfg {\n";
     o << "    static constexpr int NDRAW = " << s.ndraw << ", NLEAF = " << s.nleaf << ", NI = " << s.ni
@@ -157,6 +163,9 @@ inline std::string generate_source(const ProblemShape &s, int solver, int unit =
     if (solver == 0 && unit == kUnitDump) {
         o << "extern \"C\" __global__ void __launch_bounds__(256) mci_sample_dump(mci::DumpArgs a) { "
              "mci::sample_dump<Cfg>(a); }\n";
+    } else if (solver == 0 && unit == kUnitVegasPersist) {
+        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_persist(mci::BatchArgs a, mci::PersistArgs f) { "
+             "mci::vegas_persist<Cfg>(a, f); }\n";
     } else if (solver == 0) {
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_batch(mci::BatchArgs a) { "
              "mci::vegas_batch<Cfg, (Cfg::NTILE > 1)>(a); }\n";
@@ -280,7 +289,8 @@ inline void warm_up_join() {
 }
 
 // returns the gfx950 code object for `src`, from the on-disk cache or by compiling with hiprtc
-inline int compile(const std::string &src, int threads, std::vector<char> &code, std::string &log, bool &from_cache, std::string *cache_path = nullptr) {
+inline int compile(const std::string &src, int threads, std::vector<char> &code, std::string &log, bool &from_cache, std::string *cache_path = nullptr,
+                   bool with_train = false, bool cache_only = false) {
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics",
                                      "-ffp-contract=off", "-DMCI_THREADS=" + std::to_string(threads)};
     if (const char *e = getenv("MCI_JIT_FLAGS")) {
@@ -289,6 +299,7 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
         while (is >> t) opts.push_back(t);
     }
     std::string key = src + "\n//HDR\n" + kDeviceHeader;
+    if (with_train) key += std::string("\n//HDR\n") + kTrainHeader;
     for (auto &f : opts) key += "\n//" + f;
     char name[64];
     snprintf(name, sizeof name, "mci_%016llx.hsaco", (unsigned long long)fnv1a(key));
@@ -305,14 +316,15 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
             }
         }
     }
+    if (cache_only) return -1; // (not in the cache: the caller compiles it elsewhere, e.g. on a thread of its own)
     if (const char *e = getenv("MCI_DUMP_SRC")) {
         std::ofstream f(e);
         f << src;
     }
     warm_up_join();
     hiprtcProgram prog;
-    const char *hdr = kDeviceHeader, *hname = "mci_device.h";
-    if (hiprtcCreateProgram(&prog, src.c_str(), "mci_problem.hip", 1, &hdr, &hname) != HIPRTC_SUCCESS) {
+    const char *hdr[2] = {kDeviceHeader, kTrainHeader}, *hname[2] = {"mci_device.h", "mci_train.h"};
+    if (hiprtcCreateProgram(&prog, src.c_str(), "mci_problem.hip", with_train ? 2 : 1, hdr, hname) != HIPRTC_SUCCESS) {
         log = "hiprtcCreateProgram failed";
         return 1;
     }

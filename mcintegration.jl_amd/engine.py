@@ -412,6 +412,17 @@ class Engine:
         mci_set_chain_carry"""
         check(lib().mci_set_chain_carry(self.p, {"auto": -1, "off": 0, "on": 1, -1: -1, 0: 0, 1: 1}[mode]))
 
+    def set_persistent(self, mode):
+        """launch-bound :vegas calls of integrate() as ONE persistent launch: "auto" (default), "off" or "on" (whenever the layout
+        allows, whatever the size); see mci_set_persistent"""
+        check(lib().mci_set_persistent(self.p, {"auto": -1, "off": 0, "on": 1, -1: -1, 0: 0, 1: 1}[mode]))
+
+    def last_integrate_persistent(self):
+        """did the last integrate() of this engine run as one persistent launch?"""
+        v = C.c_int32()
+        check(lib().mci_last_integrate_persistent(self.p, C.byref(v)))
+        return bool(v.value)
+
     def last_chain_launch(self):
         """(chains per block, continued the previous launch?) of the last chain-solver launch"""
         n, c = C.c_int64(), C.c_int32()
@@ -435,9 +446,10 @@ class Engine:
         n = self.nobs
         im, ie = np.zeros((niter, n)), np.zeros((niter, n))
         m, s, c2 = np.zeros(n), np.zeros(n), np.zeros(n)
-        r = _lib.ResultC(niter, n, _dp(im), _dp(ie), _dp(m), _dp(s), _dp(c2), 0, 0.0)
+        vis = np.zeros(self.config.N + 1)
+        r = _lib.ResultC(niter, n, _dp(im), _dp(ie), _dp(m), _dp(s), _dp(c2), 0, 0.0, _dp(vis))
         check(lib().mci_integrate(self.p, C.byref(a), C.byref(r)))
-        return dict(mean=m, stdev=s, chi2=c2, iter_mean=im, iter_std=ie, neval=r.neval, seconds=r.seconds)
+        return dict(mean=m, stdev=s, chi2=c2, iter_mean=im, iter_std=ie, neval=r.neval, seconds=r.seconds, visited=vis)
 
     def comm_ranks(self):
         """ranks of the communicator attached to this engine's context (1: none; mci_integrate shards its blocks over them)"""

@@ -118,6 +118,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         means, stds = list(r["iter_mean"]), list(r["iter_std"])
         neval_done = nevalperblock * block * niter
         niter_loop = 0
+        config.visited = r["visited"]    # config.visited of the last iteration (configuration.jl:46), for report(config)
     else:
         niter_loop = niter
     for it in range(niter_loop):                                                      # main.jl:142
@@ -131,7 +132,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     config.iterations_done += niter
     config.neval = nevalperblock * block
     config._last_solver = solver
-    if hasattr(eng, "get_packed"):   # config.visited of the last iteration (configuration.jl:46), for report(config)
+    if niter_loop and hasattr(eng, "get_packed"):   # config.visited of the last iteration (configuration.jl:46), for report(config)
         try:
             pk = eng.get_packed()
             config.visited = pk[2 * eng.nobs + 2: 2 * eng.nobs + 2 + config.N + 1].copy()

@@ -91,6 +91,7 @@ mutable struct ResultC
     niter::Int32; nobs::Int32
     iter_mean::Ptr{Float64}; iter_std::Ptr{Float64}; mean::Ptr{Float64}; stdev::Ptr{Float64}; chi2::Ptr{Float64}
     neval::Int64; seconds::Float64
+    visited::Ptr{Float64}
 end
 
 const _ctx = Dict{Int,Ptr{Cvoid}}()              # one mci_ctx (HIP stream + RCCL communicator) per device
@@ -562,7 +563,7 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
                    block=16, gamma=1.0, adapt=true, ignore::Int=adapt ? 1 : 0, measure=nothing, measurefreq::Int=1,
                    thermal_ratio=0.1, reweight_goal::Union{Vector{Float64},Nothing}=nothing,
                    nchain=0, rng_bits::Int=52, rng_rounds::Int=10, train_walk::Int=-1, deterministic::Bool=false, chain_carry::Int=-1,
-                   print=-1, verbose=-1, kwargs...)
+                   persistent::Int=-1, print=-1, verbose=-1, kwargs...)
     haskey(SOLVER, solver) || error("Solver $solver is not supported!")                  # main.jl:263
     config === nothing && (config = Configuration(; kwargs...))                          # main.jl:95-97
     # workers: after init_comm!(...) the library runs this rank's share of the blocks and sums every iteration's statistics and
@@ -588,6 +589,8 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
     # (configuration.jl:190); chain_carry: -1 automatic (:vegasmc iterations continue the previous one's chains), 0 off, 1 :mcmc too
     check(ccall((:mci_set_deterministic, libmci), Cint, (Ptr{Cvoid}, Int32), prob, deterministic ? 1 : 0))
     check(ccall((:mci_set_chain_carry, libmci), Cint, (Ptr{Cvoid}, Int32), prob, chain_carry))
+    # persistent: -1 automatic (a launch-bound :vegas call over one Continuous variable type runs all its iterations as one launch), 0 off, 1 on
+    check(ccall((:mci_set_persistent, libmci), Cint, (Ptr{Cvoid}, Int32), prob, persistent))
     nobs = sum(config.obs_nbin)
     im, ie = zeros(nobs, niter), zeros(nobs, niter)           # row-major [niter][nobs] on the C side
     m, s, c2 = zeros(nobs), zeros(nobs), zeros(nobs)
@@ -595,7 +598,7 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
     args = Ref(IntegrateArgs(SOLVER[solver], Int64(neval), niter, block, ignore, adapt, gamma, measurefreq, UInt64(config.seed),
                              nchain, config.iterations_done, thermal_ratio,
                              reweight_goal === nothing ? Ptr{Float64}(C_NULL) : pointer(goal)))
-    res = ResultC(niter, nobs, pointer(im), pointer(ie), pointer(m), pointer(s), pointer(c2), 0, 0.0)
+    res = ResultC(niter, nobs, pointer(im), pointer(ie), pointer(m), pointer(s), pointer(c2), 0, 0.0, Ptr{Float64}(C_NULL))
     GC.@preserve im ie m s c2 goal check(ccall((:mci_integrate, libmci), Cint, (Ptr{Cvoid}, Ptr{IntegrateArgs}, Ref{ResultC}), prob, args, res))
     config.iterations_done += niter
     nworker = _comm[].size

@@ -138,6 +138,17 @@ double mcio_sum16(const double *v, long n) {
     return p[0];
 }
 
+/* b ^ alpha the way Julia's ^(::Float64, ::Float64) evaluates it for the exponents the reference's constructors hand out
+ * (alpha = 2 by default, variable.jl:137; 3 in the bubble example): an integer-valued exponent takes Base.Math.pow_body's
+ * compensated power-by-squaring, whose result for n = 2 is the correctly rounded x*x and for n = 3 literally x*x*x; libm's pow is
+ * within an ulp of both, but not always the same bits.  Anything else: pow(). */
+static double mcio_pow_julia(double b, double alpha) {
+    if (alpha == 2.0) return b * b;
+    if (alpha == 1.0) return b;
+    if (alpha == 3.0) return b * b * b;
+    return pow(b, alpha);
+}
+
 int mcio_rescale(double *dist, long n, double alpha) {
     if (n == 1) return 0; /* :68-70 */
     for (long i = 0; i < n; ++i)
@@ -145,7 +156,7 @@ int mcio_rescale(double *dist, long n, double alpha) {
     const double s = mcio_sum16(dist, n);
     for (long i = 0; i < n; ++i) dist[i] /= s; /* :72 */
     for (long i = 0; i < n; ++i)               /* :74-78 */
-        if (dist[i] > 0 && dist[i] <= 0.99999999) dist[i] = pow(-(1 - dist[i]) / log(dist[i]), alpha);
+        if (dist[i] > 0 && dist[i] <= 0.99999999) dist[i] = mcio_pow_julia(-(1 - dist[i]) / log(dist[i]), alpha);
     for (long i = 0; i < n; ++i)
         if (!isfinite(dist[i])) return 2; /* :79 */
     return 0;

@@ -1,0 +1,153 @@
+"""GPU tests of the persistent :vegas launch (mci_set_persistent; csrc/mci_train.h vegas_persist): all iterations of a launch-bound
+integrate() call over ONE Continuous variable type as ONE launch -- sample -> grid-wide arrive -> every workgroup refines its own copy
+of the map, a statistics workgroup merges the blocks -> next iteration -- against the oracle's loop (main.jl:142-207) and against the
+launch chain on the same Philox streams.
+
+Tolerances are those of the launch chain's own run-level tests (test_hip_parity.test_full_integrate_matches_oracle[prefix]): the
+refinement is the prefix-scan walk, whose whole-run agreement with the reference recurrence is 1e-4 (< 0.05 sigma); a single iteration
+(no train! in between) agrees to 1e-11."""
+import numpy as np
+import pytest
+
+import mcintegration_jl_amd as mci
+from test_hip_parity import CASES, SEED, make
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["c1_log_over_sqrt", "sphere2_padding", "hypersphere", "c2_gauss16_shared_pool", "c5_nested_gauss"]   # one Continuous leaf
+OTHERS = ["bubble", "c2_gauss4_composite", "discrete", "discrete2_composite", "singular2_composite"]           # several leaves / Discrete
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_persistent_run_matches_oracle(oracle, name, monkeypatch):
+    """the whole loop in one launch vs the oracle's loop, same seed: every iteration's mean / error, the final Result, the trained maps"""
+    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
+    c, cfg, eng, ocfg = make(name, oracle)
+    eng.set_persistent("on")
+    r = eng.integrate("vegas", neval=40000, niter=6, block=16, seed=SEED)
+    assert eng.last_integrate_persistent()
+    o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=40000, niter=6, block=16, seed=SEED)
+    # first iteration: nothing but reassociation between the two
+    np.testing.assert_allclose(r["iter_mean"][0], o["iter_mean"][0], rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(r["iter_std"][0], o["iter_std"][0], rtol=1e-8, atol=1e-300)
+    rtol = 1e-4
+    np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=rtol, atol=1e-300)
+    np.testing.assert_allclose(r["iter_std"], o["iter_std"], rtol=100 * rtol, atol=1e-300)
+    np.testing.assert_allclose(r["mean"], o["mean"], rtol=rtol)
+    np.testing.assert_allclose(r["stdev"], o["stdev"], rtol=100 * rtol)
+    np.testing.assert_allclose(r["chi2"], o["chi2"], rtol=1000 * rtol, atol=1e-9)
+    assert np.all(np.abs(r["mean"] - o["mean"]) < 5e-2 * o["stdev"])
+    assert r["neval"] == 6 * 40000
+    for i, lf in enumerate(c["oleaves"]):
+        if lf["kind"] == 0:
+            g, og = eng.grid(i), ocfg.grid(i)
+            assert g[0] == og[0] and g[-1] == og[-1] and np.all(np.diff(g) > 0)
+            np.testing.assert_allclose(g, og, rtol=0, atol=1e-4 * (lf["upper"] - lf["lower"]))
+        elif lf.get("adapt", True):
+            np.testing.assert_allclose(eng.distribution(i)[0], ocfg.distribution(i), rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "c5_nested_gauss", "c2_gauss16_shared_pool"])
+def test_one_persistent_iteration_leaves_the_oracles_packed_buffer_and_grid(oracle, name, monkeypatch):
+    """niter = 1: the packed buffer the launch leaves behind (statistics head, merged histograms cleared by train!) and the map
+    after ONE train! -- the per-iteration tolerances of the launch chain (test_train_matches_oracle)"""
+    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
+    c, cfg, eng, ocfg = make(name, oracle)
+    eng.set_persistent("on")
+    block, npb = 8, 4000
+    r = eng.integrate("vegas", neval=block * npb, niter=1, block=block, seed=SEED, ignore=0)
+    assert eng.last_integrate_persistent()
+    packed = ocfg.iteration(oracle.VEGAS, c["oname"], c["ud"], npb, 0, block, 0, SEED)
+    ocfg.train()
+    om, oe = oracle.mean_std(packed[:eng.nobs], packed[eng.nobs:2 * eng.nobs], block)
+    np.testing.assert_allclose(r["iter_mean"][0], om, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(r["iter_std"][0], oe, rtol=1e-8, atol=1e-300)
+    nstat = 2 * eng.nobs + 2 + cfg.N + 1
+    np.testing.assert_allclose(eng.iteration_log(1)[0], packed[:nstat], rtol=1e-11, atol=1e-300)
+    got = eng.get_packed()
+    np.testing.assert_allclose(got[:nstat], packed[:nstat], rtol=1e-11, atol=1e-300)
+    for i, lf in enumerate(c["oleaves"]):
+        if lf["kind"] == 0:
+            g, og = eng.grid(i), ocfg.grid(i)
+            assert g[0] == og[0] and g[-1] == og[-1]
+            np.testing.assert_allclose(g, og, rtol=0, atol=1e-12 * (lf["upper"] - lf["lower"]))
+        elif lf.get("adapt", True):
+            d, a = eng.distribution(i)
+            np.testing.assert_allclose(d, ocfg.distribution(i), rtol=1e-11)
+            np.testing.assert_allclose(a, ocfg.accumulation(i), rtol=1e-11)
+
+
+@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "c2_gauss16_shared_pool"])
+def test_persistent_launch_and_launch_chain_give_the_same_run(name, oracle, monkeypatch):
+    """the same call with the persistent launch on and off, then a second call that continues from the trained map (resume pattern
+    docs/src/index.md:129): the two paths hand over to each other"""
+    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
+    runs = {}
+    for mode in ("on", "off"):
+        c, cfg, eng, ocfg = make(name, oracle)
+        eng.set_persistent(mode)
+        a = eng.integrate("vegas", neval=20000, niter=5, block=16, seed=SEED)
+        assert eng.last_integrate_persistent() == (mode == "on")
+        eng.set_persistent("off" if mode == "on" else "on")   # hand over to the other path
+        b = eng.integrate("vegas", neval=20000, niter=3, block=16, seed=SEED, first_iteration=5)
+        assert eng.last_integrate_persistent() == (mode == "off")
+        runs[mode] = (a, b, eng.grid(0))
+    for k in (0, 1):
+        np.testing.assert_allclose(runs["on"][k]["iter_mean"], runs["off"][k]["iter_mean"], rtol=1e-4, atol=1e-300)
+        np.testing.assert_allclose(runs["on"][k]["iter_std"], runs["off"][k]["iter_std"], rtol=1e-2, atol=1e-300)
+    np.testing.assert_allclose(runs["on"][2], runs["off"][2], rtol=0, atol=1e-5 * (runs["on"][2][-1] - runs["on"][2][0]))
+
+
+@pytest.mark.parametrize("name", OTHERS)
+def test_layouts_without_a_persistent_kernel_take_the_launch_chain(oracle, name, monkeypatch):
+    """several leaves (every workgroup would have to refine all of them) or a Discrete one: the call runs as the launch chain, whatever
+    mci_set_persistent says, with the launch chain's results"""
+    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
+    c, cfg, eng, ocfg = make(name, oracle)
+    eng.set_persistent("on")
+    r = eng.integrate("vegas", neval=40000, niter=3, block=16, seed=SEED)
+    assert not eng.last_integrate_persistent()
+    o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=40000, niter=3, block=16, seed=SEED)
+    np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-4, atol=1e-300)
+
+
+def test_persistent_launch_without_adaptation_and_many_iterations(oracle):
+    """adapt = false: no train!, the map stays; 40 iterations in one launch (the counters only grow), twice (they carry over)"""
+    c, cfg, eng, ocfg = make("sphere2_padding", oracle)
+    eng.set_persistent("on")
+    g0 = eng.grid(0).copy()
+    r1 = eng.integrate("vegas", neval=16000, niter=40, block=16, seed=SEED, adapt=False, ignore=0)
+    r2 = eng.integrate("vegas", neval=16000, niter=40, block=16, seed=SEED, adapt=False, ignore=0, first_iteration=40)
+    assert eng.last_integrate_persistent()
+    assert np.array_equal(eng.grid(0), g0)
+    o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=16000, niter=80, block=16, seed=SEED, adapt=False, ignore=0)
+    np.testing.assert_allclose(np.concatenate([r1["iter_mean"], r2["iter_mean"]]), o["iter_mean"], rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(np.concatenate([r1["iter_std"], r2["iter_std"]]), o["iter_std"], rtol=1e-8, atol=1e-300)
+
+
+def test_automatic_mode_takes_the_persistent_launch_for_launch_bound_calls_only():
+    """integrate() at the reference's default size (neval = 1e4, main.jl:76) goes persistent once its code object exists; a call of
+    1e7 samples, a chain solver, measurefreq != 1 and a forced geometry take the launch chain"""
+    src = "return x[0] * x[0] + x[1] * x[1];"
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
+    res = mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
+    eng = cfg._engine
+    import time
+    for _ in range(200):   # (the first call may have left the larger translation unit compiling on its own thread)
+        res = mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
+        if eng.last_integrate_persistent():
+            break
+        time.sleep(0.05)
+    assert eng.last_integrate_persistent()
+    assert abs(res.mean[0] - 2.0 / 3.0) < 6 * res.stdev[0]
+    mci.integrate(src, config=cfg, solver="vegas", neval=1e7, niter=2)
+    assert not eng.last_integrate_persistent()
+    mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
+    assert eng.last_integrate_persistent()
+    mci.integrate(src, config=cfg, solver="vegas", neval=1e4, measurefreq=2)
+    assert not eng.last_integrate_persistent()
+    mci.integrate(src, config=cfg, solver="vegasmc", neval=1e4)
+    assert not eng.last_integrate_persistent()
+    eng.set_launch(256, 2)
+    mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
+    assert not eng.last_integrate_persistent()

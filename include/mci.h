@@ -277,15 +277,17 @@ int mci_set_train_walk(mci_problem *prob, int32_t mode);
  * (mci_set_launch) and on the rank count, as the summation order does. */
 int mci_set_deterministic(mci_problem *prob, int32_t on);
 /* Carried chains (this engine's many-chain decomposition only; nchain = 1, the reference's chain, always starts afresh like
- * montecarlo.jl:151-153 / mcmc/montecarlo.jl:118-124 do at every block): with mode -1 (default) a :vegasmc launch -- with mode 1 a
- * :mcmc launch too; its chains also walk over the integrand index, slowly, and doReweight! steers that walk from the previous
- * iteration's visits, so carried short :mcmc chains were measured biased (DESIGN.md "Chains") and stay opt-in -- that is the NEXT
- * iteration of the same solver over the same blocks continues the previous launch's chains -- chain (block, ch) starts from the
- * configuration chain (block, ch mod previous nchain) ended with, its bins and probabilities looked up again on the refined map --
- * instead of drawing new starts and burning them in; such a launch keeps only the reference's own burn-in (`ne >= neval/100`,
- * vegas_mc/montecarlo.jl:213; floor(steps * thermal_ratio), mcmc/montecarlo.jl:133) and sizes automatic chain counts for
- * independence of consecutive iterations instead of start-up bias.  mode 0: every launch starts its chains afresh.
- * Mirrored in the oracle (mcio_set_chain_carry). */
+ * montecarlo.jl:151-153 / mcmc/montecarlo.jl:118-124 do at every block): with mode -1 (default) or 1 a chain-solver launch that is the
+ * NEXT iteration of the same solver over the same blocks continues the previous launch's chains instead of drawing new starts and
+ * burning them in.  :vegasmc: chain (block, ch) starts from the configuration chain (block, ch mod previous nchain) ended with, its
+ * bins and probabilities looked up again on the refined map.  :mcmc: a chain's state is (integrand index, configuration) and
+ * doReweight! moves the weight of every index between iterations (main.jl:322-346), so the stored chains of a block -- a sample of
+ * the finished iteration's target -- are resampled (systematic, deterministic) with probability ~ reweight_new[index] /
+ * reweight_old[index] into a sample of the new one.  Such a launch keeps only the reference's own burn-in (`ne >= neval/100`,
+ * vegas_mc/montecarlo.jl:213; floor(steps * thermal_ratio), mcmc/montecarlo.jl:133); automatic chain counts are then sized for the
+ * duplicates of a stored chain to part before they are copied again (:vegasmc two burn-in floors, :mcmc 8 x the longest measured
+ * holding time) instead of for start-up bias (DESIGN.md "Chains").  mode 0: every launch starts its chains afresh.
+ * Mirrored in the oracle (mcio_set_chain_carry, mcio_resample_chains). */
 int mci_set_chain_carry(mci_problem *prob, int32_t mode);
 /* chains per block of the last chain-solver launch and whether it continued the launch before it */
 int mci_last_chain_launch(const mci_problem *prob, int64_t *nchain, int32_t *carried);

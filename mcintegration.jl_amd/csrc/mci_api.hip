@@ -224,7 +224,12 @@ struct mci_problem {
     bool chain_valid = false;
     int chain_solver = -1, chain_iteration = -1;
     int64_t chain_lo = 0, chain_hi = 0, chain_nchain = 0;
-    int chain_carry = -1;        // mci_set_chain_carry: -1 automatic (the rule above), 0 never
+    int chain_carry = -1;        // mci_set_chain_carry: -1 automatic / 1 (the rule above), 0 never
+    // :mcmc: the reweight factors the stored chains ran under, and which stored chain every chain of the launch in flight continues
+    // (k_resample_chains: the stored chains resampled to the target doReweight! has moved since)
+    double *d_reweight_used = nullptr, *d_carry_W = nullptr;
+    int *d_carry_src = nullptr;
+    int64_t cap_carry_src = 0, cap_carry_W = 0;
     bool last_carried = false;   // the last chain launch continued the one before it
     // last launch
     std::vector<hipEvent_t> evs; // ring of (start, stop) pairs around the sampling kernel, one pair per launch
@@ -849,6 +854,9 @@ int mci_problem_destroy(mci_problem *p) {
             if (p->d_chain_x[b]) (void)hipFree(p->d_chain_x[b]);
             if (p->d_chain_curr[b]) (void)hipFree(p->d_chain_curr[b]);
         }
+        if (p->d_reweight_used) (void)hipFree(p->d_reweight_used);
+        if (p->d_carry_W) (void)hipFree(p->d_carry_W);
+        if (p->d_carry_src) (void)hipFree(p->d_carry_src);
         if (p->h_hold) (void)hipHostFree(p->h_hold);
         for (auto &e : p->hold_ev)
             if (e) (void)hipEventDestroy(e);
@@ -1384,12 +1392,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     // Does this launch continue the chains of the previous one?  (the next iteration of the same solver over the same blocks;
     // decided before the chains are sized -- carried chains start from configurations that are already distributed like
     // the chain's target, so they neither need the many-chain burn-in floors nor their length as a safety margin against start-up bias)
-    // (automatic = :vegasmc only.  :mcmc chains walk over the integrand index as well, slowly -- thousands of steps to cross a chain of
-    // five integrands -- and doReweight! steers that walk from the visits of the previous iteration: carried 1e3-step chains then
-    // inherit the visit fluctuation the new reweight factors were computed from, and the estimate of the 12-D member of BASELINE
-    // configs[4] came out 2 sigma per run low (32 seeds, profiles/r03_chain_carry.txt); fresh chains start stratified over the
-    // integrands, which IS their stationary index distribution.  mci_set_chain_carry(prob, 1) carries :mcmc chains too.)
-    const bool carry_on = p->chain_carry > 0 || (p->chain_carry < 0 && solver == MCI_VEGASMC);
+    // (:mcmc: a chain's state includes the integrand index, whose weight doReweight! moves between iterations -- the stored chains are
+    // resampled to the moved target first, k_resample_chains below.  Chains carried as they were started over-represented exactly where
+    // the new factors say "fewer": 2 sigma per run low on the 12-D member of BASELINE configs[4], profiles/r03_chain_carry.txt.)
+    const bool carry_on = p->chain_carry != 0;
     const bool may_carry = solver != MCI_VEGAS && carry_on && p->chain_valid && p->chain_solver == solver &&
                            p->chain_lo == block_lo && p->chain_hi == block_hi && p->chain_iteration + 1 == iteration && p->chain_nchain > 1;
     if (solver == MCI_VEGASMC) {
@@ -1423,7 +1429,23 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // longest time any chain's slot (or integrand index) went without changing (mci_mcmc_auto_chains).
             if ((rc = hold_consume(p))) return rc;
             nchain = mci_mcmc_auto_chains(nevalperblock, nblocks, nslots, p->ni + 1, p->npool, p->hold_max);
-            // (opt-in carried :mcmc chains, mci_set_chain_carry(prob, 1), keep this length: only their burn-in floor goes)
+            if (may_carry && p->hold_max > 0) {
+                // Carried chains (resampled to the moved target, k_resample_chains) start from stationary configurations AND a stationary
+                // integrand index: nothing to burn in.  What their length still has to cover is the longest holding time: a population
+                // grows by duplication (a launch of more chains than the one before continues every stored chain several times), and the
+                // copies of a chain must have gone their own ways before they are copied again -- 8 x the longest hold instead of the
+                // 16 x (+ burn-in) of fresh chains.  profiles/r03_chain_carry.txt: carried chains of two burn-in floors on 1/(1 - cos^3)
+                // keep their few ancestors' view of its sticky states for many iterations (-4.8 sigma pooled over 64 seeds); at 2, 4
+                // and 16 x the hold the pooled deviations are those of fresh chains, and the seed scatter over the reported error on
+                // BASELINE configs[4] falls from 1.2-1.3 (4 x) to 1.1-1.2 (16 x; fresh chains: 1.0-1.2)
+                static const int64_t kCarryHolds = 8;
+                const int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(p->npool + 1) * (p->ni + 1);
+                const int64_t len = kCarryHolds * p->hold_max > 2 * fl ? kCarryHolds * p->hold_max : 2 * fl;
+                int64_t nc = nevalperblock / len;
+                const int64_t cap = mci_problem::kChainFill / nblocks > 64 ? mci_problem::kChainFill / nblocks : 64;
+                if (nc > cap) nc = cap;
+                if (nc > nchain) nchain = nc;
+            }
         }
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
         // (carried chains keep the reference's own floor(steps * thermal_ratio) only, mcmc/montecarlo.jl:133)
@@ -1518,6 +1540,38 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             a.carry_curr = p->d_chain_curr[p->chain_cur];
             a.carry_nchain = p->chain_nchain;
             a.carry_cap = p->chain_cap[p->chain_cur];
+        }
+        if (carried && solver == MCI_MCMC) { // which stored chain each chain continues: the stored ones resampled to the moved target
+            if (nblocks * nchain > p->cap_carry_src) {
+                if (p->d_carry_src) (void)hipFree(p->d_carry_src);
+                p->d_carry_src = nullptr;
+                p->cap_carry_src = 0;
+                HIPCHK(hipMalloc((void **)&p->d_carry_src, (size_t)(nblocks * nchain) * sizeof(int)));
+                p->cap_carry_src = nblocks * nchain;
+            }
+            if (nblocks * p->chain_nchain > p->cap_carry_W) {
+                if (p->d_carry_W) (void)hipFree(p->d_carry_W);
+                p->d_carry_W = nullptr;
+                p->cap_carry_W = 0;
+                HIPCHK(hipMalloc((void **)&p->d_carry_W, (size_t)(nblocks * p->chain_nchain) * sizeof(double)));
+                p->cap_carry_W = nblocks * p->chain_nchain;
+            }
+            mci::ResampleArgs ra{};
+            ra.curr_old = p->d_chain_curr[p->chain_cur];
+            ra.n_old = p->chain_nchain;
+            ra.n_new = nchain;
+            ra.nd = p->ni + 1;
+            ra.rw_now = p->d_reweight;
+            ra.rw_used = p->d_reweight_used;
+            ra.src = p->d_carry_src;
+            ra.W = p->d_carry_W;
+            hipLaunchKernelGGL(mci::k_resample_chains, dim3((unsigned)nblocks), dim3(256), 0, p->ctx->stream, ra);
+            HIPCHK(hipGetLastError());
+            a.carry_src = p->d_carry_src;
+        }
+        if (keep && solver == MCI_MCMC) { // the reweight factors this launch's chains run under (doReweight! moves them behind it)
+            if (!p->d_reweight_used) HIPCHK(hipMalloc((void **)&p->d_reweight_used, (size_t)(p->ni + 1) * sizeof(double)));
+            HIPCHK(hipMemcpyAsync(p->d_reweight_used, p->d_reweight, (size_t)(p->ni + 1) * sizeof(double), hipMemcpyDeviceToDevice, p->ctx->stream));
         }
         if (keep) {
             const int wb = p->chain_valid ? 1 - p->chain_cur : p->chain_cur;

@@ -184,6 +184,10 @@ struct BatchArgs {
     const double *carry_x;  // NULL: every chain starts afresh (montecarlo.jl:151-153, mcmc/montecarlo.jl:118-124)
     const int *carry_curr;
     i64 carry_nchain, carry_cap;
+    // :mcmc: chain (block, ch) continues the stored chain carry_src[local block * nchain + ch] of its block -- the stored chains resampled
+    // with probability ~ reweight_new[curr] / reweight_old[curr], i.e. to the target doReweight! has just moved (k_resample_chains,
+    // mci_static_kernels.h); NULL (:vegasmc): chain ch continues stored chain ch % carry_nchain
+    const int *carry_src;
     double *store_x;        // NULL: nothing kept
     int *store_curr;
     i64 store_cap;
@@ -1427,8 +1431,12 @@ template <class Cfg, int K> __device__ __forceinline__ void relocate_draw(const 
     }
 }
 // the whole configuration of a carried chain
-template <class Cfg> __device__ __forceinline__ void load_carried(const BatchArgs &a, const Tables<Cfg> &t, const i64 lb, const i64 ch, Chain<Cfg> &c) {
-    const i64 slot = lb * a.carry_nchain + ch % a.carry_nchain;
+// (block-local index of) the stored chain that chain `ch` of local block `lb` continues
+__device__ __forceinline__ i64 carried_from(const BatchArgs &a, const i64 lb, const i64 ch) {
+    return a.carry_src ? (i64)a.carry_src[lb * a.nchain + ch] : ch % a.carry_nchain;
+}
+template <class Cfg> __device__ __forceinline__ void load_carried(const BatchArgs &a, const Tables<Cfg> &t, const i64 lb, const i64 from, Chain<Cfg> &c) {
+    const i64 slot = lb * a.carry_nchain + from;
     static_for<0, Cfg::NDRAW>([&](auto K) {
         constexpr int k = decltype(K)::value;
         c.x[k] = a.carry_x[(i64)k * a.carry_cap + slot];
@@ -1491,7 +1499,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
     for (i64 ch = (i64)slice * T + tid; ch < a.nchain; ch += (i64)a.wg_per_block * T) {
         const u64 g = (u64)ch;
         Chain<Cfg> c;
-        if (a.carry_x) load_carried<Cfg>(a, t, wi.lb, ch, c); // continues the previous iteration's chain (BatchArgs::carry_x)
+        if (a.carry_x) load_carried<Cfg>(a, t, wi.lb, carried_from(a, wi.lb, ch), c); // continues the previous iteration's chain (BatchArgs::carry_x)
         else {   // initialize!  (montecarlo.jl:151-153): create! on every live slot
             Sample<Cfg> s;
             draw_sample<Cfg>(t, a.seed, st_init, g, s);
@@ -1672,7 +1680,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_host_step(const Bat
         const i64 cid = wi.lb * a.nchain + ch; // the chain's column in the state arrays
         Chain<Cfg> c;
         if (h.ne == 0) { // initialize!  (montecarlo.jl:151-153): create! on every live slot; the host evaluates it (:155-159)
-            if (a.carry_x) load_carried<Cfg>(a, t, wi.lb, ch, c); // ... or the previous iteration's chain goes on (BatchArgs::carry_x)
+            if (a.carry_x) load_carried<Cfg>(a, t, wi.lb, carried_from(a, wi.lb, ch), c); // ... or the previous iteration's chain goes on (BatchArgs::carry_x)
             else {
                 Sample<Cfg> s;
                 draw_sample<Cfg>(t, a.seed, st_init, g, s);
@@ -2183,8 +2191,9 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains(const BatchArgs
         double probability = 1.0;
         bool fresh = a.carry_x == nullptr;
         if (!fresh) { // continues the previous iteration's chain: its configuration and the integrand it sat on (BatchArgs::carry_x)
-            load_carried<Cfg>(a, t, wi.lb, ch, c);
-            curr = a.carry_curr[wi.lb * a.carry_nchain + ch % a.carry_nchain];
+            const i64 from = carried_from(a, wi.lb, ch);
+            load_carried<Cfg>(a, t, wi.lb, from, c);
+            curr = a.carry_curr[wi.lb * a.carry_nchain + from];
             if (curr != NORMI) {
                 weight = eval_sel<Cfg>(curr, c.x, a.ud);        // :197 on the carried configuration
                 probability = weight.abs * rw_sel(curr);        // :199
@@ -2462,8 +2471,9 @@ template <class Cfg> __device__ __forceinline__ void mcmc_host_step(const BatchA
         if (h.ne == 0) {
             int curr0 = a.nchain == 1 ? 0 : (int)(g % (u64)ND); // montecarlo.jl:76 idx = 1; many chains start stratified
             if (a.carry_x) { // the previous iteration's chain goes on: its configuration and the integrand it sat on (BatchArgs::carry_x)
-                load_carried<Cfg>(a, t, wi.lb, ch, c);
-                curr0 = a.carry_curr[wi.lb * a.carry_nchain + ch % a.carry_nchain];
+                const i64 from = carried_from(a, wi.lb, ch);
+                load_carried<Cfg>(a, t, wi.lb, from, c);
+                curr0 = a.carry_curr[wi.lb * a.carry_nchain + from];
                 static_for<0, Cfg::NDRAW>([&](auto K) {
                     constexpr int k = decltype(K)::value;
                     h.cx[k * nc + cid] = c.x[k];

@@ -56,6 +56,58 @@ __global__ void __launch_bounds__(256) k_finalize(MergeArgs m) {
     merge_stats(m);
 }
 
+// Carried :mcmc chains (this engine's many-chain decomposition; DESIGN.md "Chains"): which stored chain every chain of the next launch
+// continues.  The chains a block stored are a sample of the finished iteration's target ~ reweight_old[idx] |f_idx(x)|; doReweight! has
+// moved the factors since, so the next target differs from it by the known ratio w[idx] = reweight_new[idx] / reweight_old[idx]:
+// systematic resampling of the block's stored chains (chain order, offset 1/2 -- deterministic) with probability ~ w[curr].
+//   W[j] = sum_i w[i] * #(stored chains j' <= j that ended on integrand i)        (added over i = 0 .. nd-1 in that order)
+//   new chain c continues the first stored chain j with W[j] > (c + 1/2) * (W[n_old-1] / n_new)
+// One workgroup per block; mirrored by mcio_resample_chains (same operations in the same order: same picks).
+struct ResampleArgs {
+    const int *curr_old;   // [nblocks][n_old]
+    long long n_old, n_new;
+    int nd;
+    const double *rw_now, *rw_used; // [nd]
+    int *src;              // [nblocks][n_new]
+    double *W;             // [nblocks][n_old] scratch
+};
+__global__ void __launch_bounds__(256) k_resample_chains(ResampleArgs a) {
+    __shared__ long long part[256];
+    const int tid = threadIdx.x, T = 256;
+    const int *co = a.curr_old + (size_t)blockIdx.x * a.n_old;
+    double *W = a.W + (size_t)blockIdx.x * a.n_old;
+    int *src = a.src + (size_t)blockIdx.x * a.n_new;
+    const long long per = (a.n_old + T - 1) / T, j0 = tid * per < a.n_old ? tid * per : a.n_old, j1 = j0 + per < a.n_old ? j0 + per : a.n_old;
+    for (int i = 0; i < a.nd; ++i) { // one pass per integrand: its running count along the stored chains, times its ratio, onto W
+        const double w = a.rw_now[i] / a.rw_used[i];
+        long long mine = 0;
+        for (long long j = j0; j < j1; ++j) mine += co[j] == i ? 1 : 0;
+        __syncthreads();
+        part[tid] = mine;
+        __syncthreads();
+        long long cnt = 0;
+        for (int t = 0; t < tid; ++t) cnt += part[t];
+        for (long long j = j0; j < j1; ++j) {
+            cnt += co[j] == i ? 1 : 0;
+            const double term = w * (double)cnt;
+            W[j] = i == 0 ? term : W[j] + term;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const double step = W[a.n_old - 1] / (double)a.n_new;
+    for (long long c = tid; c < a.n_new; c += T) {
+        const double target = ((double)c + 0.5) * step;
+        long long lo = 0, hi = a.n_old - 1; // smallest j with W[j] > target
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (W[mid] > target) hi = mid;
+            else lo = mid + 1;
+        }
+        src[c] = (int)lo;
+    }
+}
+
 // One workgroup per leaf: Dist.train! then clearStatistics!; workgroup `nleaf`: bookkeeping.
 __global__ void __launch_bounds__(1024) k_train(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];

@@ -407,9 +407,9 @@ class Engine:
         check(lib().mci_set_deterministic(self.p, 1 if on else 0))
 
     def set_chain_carry(self, mode):
-        """chain solvers with many chains per block: "auto" (default) -- the next :vegasmc iteration over the same blocks continues
-        the chains of the previous one --, "on" (:mcmc too) or "off" (every launch draws new starts and burns them in); see
-        mci_set_chain_carry"""
+        """chain solvers with many chains per block: "auto" (default) / "on" -- the next iteration of the same solver over the same
+        blocks continues the chains of the previous one (:mcmc: resampled to the reweight factors doReweight! has just moved) -- or
+        "off" (every launch draws new starts and burns them in); see mci_set_chain_carry"""
         check(lib().mci_set_chain_carry(self.p, {"auto": -1, "off": 0, "on": 1, -1: -1, 0: 0, 1: 1}[mode]))
 
     def set_persistent(self, mode):

@@ -443,6 +443,8 @@ void mcio_config_destroy(mcio_config *c) {
     free(c->neighbor); free(c->nneighbor); free(c->reweight_goal); free(c->hold_hist);
     if (c->carry_owner && c->carry) {
         for (int b = 0; b < 2; ++b) { free(c->carry->x[b]); free(c->carry->curr[b]); }
+        free(c->carry->rw_used);
+        free(c->carry->src);
         free(c->carry);
     }
     free(c);
@@ -1026,9 +1028,13 @@ static void carried_slot(mcio_config *c, int vi, int idx, const double *xs) {
     }
     if (nl != 1) c->pool_prob[vi][idx] = pp;
 }
-static void load_carried(mcio_config *c, long ch) {
+/* the stored chain that new chain `ch` of this block continues: :vegasmc chain ch mod (stored chains); :mcmc the resampled one */
+static long carried_slot_of(const mcio_config *c, long ch, long nchain, int mcmc) {
     const mcio_carry *cy = c->carry;
-    const long slot = c->carry_lb * cy->load_nchain + ch % cy->load_nchain;
+    return c->carry_lb * cy->load_nchain + (mcmc ? cy->src[c->carry_lb * nchain + ch] : ch % cy->load_nchain);
+}
+static void load_carried(mcio_config *c, long slot) {
+    const mcio_carry *cy = c->carry;
     double xs[64];
     for (int vi = 0, k = 0; vi < c->npool; ++vi)
         for (int idx = 1; idx <= c->maxdof[vi]; ++idx) {
@@ -1074,7 +1080,7 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
         const uint64_t g = (uint64_t)ch;
         /* :151-153 initialize! (only the slots that are ever read: 1..maxdof) */
         int k = 0;
-        if (c->carry_load) load_carried(c, ch); /* continues the previous iteration's chain (mci_set_chain_carry) */
+        if (c->carry_load) load_carried(c, carried_slot_of(c, ch, nchain, 0)); /* continues the previous iteration's chain (mci_set_chain_carry) */
         else
         for (int vi = 0; vi < npool; ++vi)
             for (int idx = 1; idx <= c->maxdof[vi]; ++idx) {
@@ -1247,8 +1253,9 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
         int fresh = !c->carry_load;
         if (!fresh) { /* continues the previous iteration's chain: its configuration and the integrand it sat on */
             const mcio_carry *cy = c->carry;
-            load_carried(c, ch);
-            curr = cy->curr[cy->rd][c->carry_lb * cy->load_nchain + ch % cy->load_nchain];
+            const long slot = carried_slot_of(c, ch, nchain, 1); /* (resampled: run_blocks, mcio_resample_chains) */
+            load_carried(c, slot);
+            curr = cy->curr[cy->rd][slot];
             if (curr != norm) {
                 gather_x(c, x);
                 f(x, w, ud);
@@ -1561,6 +1568,43 @@ void mcio_result_destroy(mcio_result *r) {
  * Block results are merged in block order, so the output does not depend on nthreads (the
  * reference's thread-order merge, main.jl:170-174, differs from this only by reassociation and by
  * (nthreads-1)*1e-10 in the histogram offsets). */
+/* Carried :mcmc chains (this engine's many-chain decomposition only; mirror of k_resample_chains, mci_static_kernels.h).  The chains a
+ * block stored at the end of an iteration are a sample of that iteration's target pi_k(idx, x) ~ reweight_k[idx] |f_idx(x)|; doReweight!
+ * has since moved the factors (main.jl:322-346), so the next iteration's target differs from it by exactly the known ratio
+ * w[idx] = reweight_{k+1}[idx] / reweight_k[idx].  The new chains therefore continue stored chains drawn with probability ~ w[curr]
+ * (systematic resampling over the block's stored chains in chain order, offset 1/2: deterministic): a start population distributed like
+ * the NEW target, which also takes back the visit fluctuation the new factors were computed from -- chains carried as they are start
+ * over-represented exactly where the new factors say "fewer" (measured: 2 sigma per run on BASELINE configs[4]).
+ *   W[j] = sum_i w[i] * #(stored chains j' <= j that ended on integrand i)     (sum over i = 0 .. Nd-1 in that order)
+ *   new chain c continues the first stored chain j with W[j] > (c + 1/2) * (W[n_old-1] / n_new)                              */
+void mcio_resample_chains(const int *curr_old, long n_old, int nd, const double *rw_now, const double *rw_used, long n_new, long *src) {
+    double w[65];
+    long cnt[65]; /* (nd <= 64: the integrands of a draw are a 64-bit mask) */
+    double *W = (double *)malloc((size_t)n_old * sizeof(double));
+    for (int i = 0; i < nd; ++i) {
+        w[i] = rw_now[i] / rw_used[i];
+        cnt[i] = 0;
+    }
+    for (long j = 0; j < n_old; ++j) {
+        cnt[curr_old[j]] += 1;
+        double s = 0.0;
+        for (int i = 0; i < nd; ++i) s += w[i] * (double)cnt[i];
+        W[j] = s;
+    }
+    const double step = W[n_old - 1] / (double)n_new;
+    for (long c = 0; c < n_new; ++c) {
+        const double target = ((double)c + 0.5) * step;
+        long lo = 0, hi = n_old - 1; /* smallest j with W[j] > target */
+        while (lo < hi) {
+            const long mid = (lo + hi) >> 1;
+            if (W[mid] > target) hi = mid;
+            else lo = mid + 1;
+        }
+        src[c] = lo;
+    }
+    free(W);
+}
+
 static int run_blocks(mcio_config *c, int solver, mcio_integrand_fn f, const double *ud, long nevalperblock,
                       long block_lo, long block_hi, uint32_t iteration, long measurefreq, uint64_t seed,
                       int nthreads, long nchain, double *obs_sum, double *obs_sq) {
@@ -1572,7 +1616,7 @@ static int run_blocks(mcio_config *c, int solver, mcio_integrand_fn f, const dou
     int err = 0;
     /* carried chains: the rule of mci_api.hip mci_iteration_run */
     mcio_carry *cy = c->carry;
-    const int carry_on = cy->mode > 0 || (cy->mode < 0 && solver == MCIO_VEGASMC); /* automatic = :vegasmc only */
+    const int carry_on = cy->mode != 0; /* automatic = both chain solvers */
     const int carried = solver != MCIO_VEGAS && carry_on && cy->valid && cy->solver == solver && cy->lo == block_lo && cy->hi == block_hi &&
                         cy->iteration + 1 == (long)iteration && cy->nchain > 1 && nchain > 1;
     const int keep = solver != MCIO_VEGAS && carry_on && nchain > 1;
@@ -1589,6 +1633,19 @@ static int run_blocks(mcio_config *c, int solver, mcio_integrand_fn f, const dou
         cy->wr = wr;
     } else if (carried) cy->rd = cy->cur;
     cy->load_nchain = cy->nchain;
+    if (carried && solver == MCIO_MCMC) { /* which stored chain every new chain continues */
+        if (nb * nchain > cy->src_cap) {
+            free(cy->src);
+            cy->src_cap = nb * nchain;
+            cy->src = (long *)calloc((size_t)cy->src_cap, sizeof(long));
+        }
+        for (long b = 0; b < nb; ++b)
+            mcio_resample_chains(cy->curr[cy->rd] + b * cy->load_nchain, cy->load_nchain, c->Ni + 1, c->reweight, cy->rw_used, nchain, cy->src + b * nchain);
+    }
+    if (keep) { /* the reweight factors this launch's chains run under */
+        if (!cy->rw_used) cy->rw_used = (double *)calloc((size_t)(c->Ni + 1), sizeof(double));
+        memcpy(cy->rw_used, c->reweight, (size_t)(c->Ni + 1) * sizeof(double));
+    }
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(nthreads) schedule(static)
 #endif

@@ -121,7 +121,7 @@ typedef struct {
 
 /* end configurations of the last chain-solver launch: x[buf][k * cap + local block * nchain + ch], curr[buf][...] (:mcmc) */
 typedef struct mcio_carry {
-    int mode;          /* -1 automatic (default): the NEXT :vegasmc iteration over the same blocks continues the chains; 1: :mcmc too; 0 off */
+    int mode;          /* -1 automatic (default) / 1: the NEXT iteration of the same chain solver over the same blocks continues the chains; 0 off */
     double *x[2];
     int *curr[2];
     long cap[2];
@@ -129,6 +129,11 @@ typedef struct mcio_carry {
     long lo, hi, nchain, iteration;
     int rd, wr;        /* buffers of the launch in flight */
     long load_nchain;
+    /* :mcmc (mirror of k_resample_chains, mci_static_kernels.h): the reweight factors the stored chains ran under, and for the launch in
+     * flight the stored chain every new chain continues, src[local block * nchain + ch] (index within the block) */
+    double *rw_used;
+    long *src;
+    long src_cap;
 } mcio_carry;
 
 typedef struct {
@@ -141,6 +146,7 @@ typedef struct {
     long neval;
 } mcio_result;
 
+void mcio_resample_chains(const int *curr_old, long n_old, int nd, const double *rw_now, const double *rw_used, long n_new, long *src);
 void mcio_set_chain_carry(mcio_config *c, int mode); /* -1 automatic (:vegasmc) | 0 off | 1 :vegasmc and :mcmc */
 
 /* ---- RNG ---- */

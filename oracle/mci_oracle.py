@@ -430,7 +430,7 @@ class Config:
         lib().mcio_set_measure(self.p, fnptr)
 
     def set_chain_carry(self, mode):
-        """mirror of mci_set_chain_carry: "auto" / -1 (default: :vegasmc), "off" / 0, "on" / 1 (:mcmc too)"""
+        """mirror of mci_set_chain_carry: "auto" / -1 (default) and "on" / 1 carry both chain solvers, "off" / 0 none"""
         lib().mcio_set_chain_carry(self.p, {"auto": -1, "off": 0, "on": 1, -1: -1, 0: 0, 1: 1}[mode])
 
     def set_reweight(self, r):

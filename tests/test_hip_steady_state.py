@@ -264,14 +264,13 @@ def test_several_chains_per_lane_match_oracle(oracle, name, solver):
 @pytest.mark.parametrize("name", ["sphere2_padding", "bubble", "discrete2_composite"])
 def test_carried_chains_match_oracle(oracle, name, solver):
     """Carried chains (mci_set_chain_carry, this engine's many-chain decomposition only): the next iteration of the same solver over
-    the same blocks continues the previous launch's chains -- chain (block, ch) starts from the configuration chain (block, ch mod
-    previous nchain) ended with, bins and probabilities looked up again on the map train! has just refined, :mcmc also the integrand
-    index -- with the reference's own burn-in only.  Four consecutive iterations with doReweight! and train! in between and a chain
-    count that changes (16, 16, 40, 8 per block) against the oracle's mirror; a repeated iteration number starts afresh again."""
+    the same blocks continues the previous launch's chains with the reference's own burn-in only -- :vegasmc chain (block, ch) starts
+    from the configuration chain (block, ch mod previous nchain) ended with, bins and probabilities looked up again on the map train!
+    has just refined; :mcmc chain (block, ch) from the stored chain (configuration AND integrand index) that the block's systematic
+    resampling with probability ~ reweight_new[curr] / reweight_old[curr] assigns to it (k_resample_chains | mcio_resample_chains).
+    Four consecutive iterations with doReweight! and train! in between and a chain count that changes (16, 16, 40, 8 per block)
+    against the oracle's mirror; a repeated iteration number starts afresh again."""
     c, cfg, eng, ocfg = _make(name, oracle)
-    if solver == "mcmc":                      # (opt-in there: the automatic mode carries :vegasmc chains only)
-        eng.set_chain_carry("on")
-        ocfg.set_chain_carry("on")
     osolver = dict(vegasmc=oracle.VEGASMC, mcmc=oracle.MCMC)[solver]
     block, npb = 4, 4800
     kw = {}

@@ -17,6 +17,7 @@ SOLVERS = sys.argv[4].split(",") if len(sys.argv) > 4 else ["vegas", "vegasmc", 
 BLOCK = int(sys.argv[5]) if len(sys.argv) > 5 else 16
 NCHAIN = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 ROUNDS = int(sys.argv[7]) if len(sys.argv) > 7 else 10     # Philox4x32 rounds (mci_set_rng_rounds): 10 | 7
+GAMMA = float(os.environ.get("VAL_GAMMA", "1.0"))           # doReweight! exponent (main.jl:80); 0 freezes the reweight factors
 L = math.sqrt(50.0)
 p = mci.catalog.bubble_parameters()
 
@@ -57,8 +58,10 @@ for name, mk, f, meas, exact, exact_tol in CASES:
         ms, es, us, secs = [], [], [], 0.0
         for seed in range(1, nseeds + 1):
             eng = mci.Engine(mk(), f, measure=meas, **({"rng_rounds": ROUNDS} if ROUNDS != 10 else {}))
-            eng.integrate(solver, neval=NE, niter=5, block=BLOCK, seed=seed, nchain=NCHAIN)
-            r = eng.integrate(solver, neval=NE, niter=10, block=BLOCK, seed=seed, first_iteration=5, ignore=0, nchain=NCHAIN)
+            if os.environ.get("VAL_RW"):   # initial reweight factors (with VAL_GAMMA=0: the factors of the whole run)
+                eng.set_reweight(np.array([float(v) for v in os.environ["VAL_RW"].split(",")]))
+            eng.integrate(solver, neval=NE, niter=5, block=BLOCK, seed=seed, nchain=NCHAIN, gamma=GAMMA)
+            r = eng.integrate(solver, neval=NE, niter=10, block=BLOCK, seed=seed, first_iteration=5, ignore=0, nchain=NCHAIN, gamma=GAMMA)
             ms.append(r["mean"]); es.append(r["stdev"]); secs += r["seconds"]; us.append(r["iter_mean"].mean(0))
         ms, es, us = np.array(ms), np.array(es), np.array(us)
         unw = (us.mean(0) - exact) / (us.std(0, ddof=1) / math.sqrt(nseeds))   # plain mean of the iteration means, error from the seed scatter

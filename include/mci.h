@@ -292,14 +292,17 @@ int mci_set_chain_carry(mci_problem *prob, int32_t mode);
 /* chains per block of the last chain-solver launch and whether it continued the launch before it */
 int mci_last_chain_launch(const mci_problem *prob, int64_t *nchain, int32_t *carried);
 /* Persistent :vegas iterations.  The reference's loop (main.jl:142-207) at the reference's own default size (neval = 1e4, main.jl:76)
- * is launch-bound on a GPU: a few microseconds of sampling per iteration behind two dependent kernel launches.  With mode -1
- * (default) a single-rank mci_integrate call of solver MCI_VEGAS at measurefreq == 1 whose iterations are that small (samples x
- * draws < 2^21) runs ALL its iterations as one launch of at most 256 co-resident workgroups: sample -> grid-wide arrive -> block
- * merge and train! by the first nleaf + 1 workgroups -> grid-wide release -> next iteration (csrc/mci_train.h vegas_persist).  Same
- * Philox streams and the same arithmetic as the launch chain (sums differ by reassociation only).  Needs tables and histograms in LDS
- * (table mode 0), device-source integrand and measure, the prefix-scan walk, no forced launch geometry and no kernel timing; anything
- * else, mode 0, and every call through mci_iteration_run take the launch chain.  mode 1: every call the layout allows, whatever
- * its size.  A grid-wide wait that runs out of time (2 s: a device shared with other long-running kernels) fails the call with
+ * is launch-bound on a GPU: a microsecond of sampling per iteration behind two dependent kernel launches.  With mode -1 (default) a
+ * single-rank mci_integrate call of solver MCI_VEGAS at measurefreq == 1 over ONE Continuous variable type whose iterations are that
+ * small (samples x draws < 2^19) runs ALL its iterations as one launch of at most 128 co-resident sampling workgroups + one statistics
+ * workgroup (csrc/mci_train.h vegas_persist): sample -> histograms merged with global atomics -> one grid-wide wait -> every sampling
+ * workgroup runs train! on its OWN copy of the map (same arithmetic on the same numbers: the copies stay bit-identical) while the
+ * statistics workgroup merges the blocks -> next iteration.  Same Philox streams and the same arithmetic as the launch chain (sums
+ * differ by reassociation only).  Needs tables and histograms in LDS (table mode 0), device-source integrand and measure, the
+ * prefix-scan walk, no forced launch geometry and no kernel timing; anything else, mode 0, and every call through mci_iteration_run
+ * take the launch chain.  mode 1: every call the layout allows, whatever its size, and the kernel is compiled on the spot (mode -1
+ * compiles its larger translation unit on a thread of its own from the second such call on and takes the launch chain until it is
+ * there).  A grid-wide wait that runs out of time (2 s: a device shared with other long-running kernels) fails the call with
  * MCI_ERR_HIP instead of hanging, and later calls take the launch chain. */
 int mci_set_persistent(mci_problem *prob, int32_t mode);
 /* whether the last mci_integrate ran as one persistent launch */

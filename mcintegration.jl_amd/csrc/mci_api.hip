@@ -17,6 +17,8 @@
 #include <cstring>
 #include <string>
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -259,6 +261,7 @@ struct mci_problem {
 };
 
 static void persist_job_drop(mci_problem *p);
+namespace { void persist_orphans_join(); }
 // counters [0..2] of the persistent :vegas kernel + (MCI_PERSIST_TRACE builds) the phase stamps of three workgroups over eight turns
 static const size_t kPersistWords = 8 + 3 * 8 * 8 + 16;
 
@@ -420,6 +423,7 @@ int mci_ctx_create(int32_t device, mci_ctx **out) {
 int mci_ctx_destroy(mci_ctx *c) {
     if (!c) return MCI_OK;
     mcijit::warm_up_join();
+    persist_orphans_join();
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2099,8 +2103,9 @@ bool persist_layout(const mci_problem *p) {
 }
 // Which calls run persistently, and on how many workgroups per block: one rank, :vegas at measurefreq == 1, the prefix-scan walk, no
 // forced geometry or timing, a grid that is co-resident next to another one like it (<= 128 sampling workgroups + the statistics one).
-// Automatic mode adds: launch-bound sizes only (samples x draws below 2^21 per iteration -- beyond that the sample pass dominates and
-// the launch-per-iteration chain brings its tuned layouts: histogram copies, 512-thread workgroups).
+// Automatic mode adds: light launches only (samples x draws below 2^19 per iteration: 13.8 against 16.1 us per iteration at neval = 1e4 of
+// a 2-D integrand, 15.6 against 17.7 at 1e5 -- beyond that the sample pass weighs in and the launch-per-iteration chain brings its
+// tuned layouts, histogram copies and 512-thread workgroups: the 16-D Gaussian at 1e5 22.3 us there, 27.4 here; tools/latency.py).
 bool persist_plan(const mci_problem *p, const mci_integrate_args *a, int64_t nevalperblock, int64_t nblocks, int *wpb_out) {
     const auto &s = p->shape;
     if (p->persistent == 0 || p->persist_failed) return false;
@@ -2109,7 +2114,7 @@ bool persist_plan(const mci_problem *p, const mci_integrate_args *a, int64_t nev
     if (!persist_layout(p)) return false;
     if (p->wg_per_block > 0 || p->kernel_timing > 0 || p->train_serial == 1) return false;
     const int64_t work = nevalperblock * nblocks * s.ndraw;
-    if (p->persistent < 0 && work >= ((int64_t)1 << 21)) return false;
+    if (p->persistent < 0 && work >= ((int64_t)1 << 19)) return false;
     const int T = p->threads;
     int64_t target = work < ((int64_t)1 << 19) ? 64 : 128;
     int64_t wpb = (target + nblocks - 1) / nblocks;
@@ -2131,11 +2136,37 @@ struct mci_problem::PersistJob {
     std::thread th;
     std::atomic<bool> done{false};
 };
-static void persist_job_drop(mci_problem *p) { // (the compile cannot be interrupted: wait for it)
+// A problem that goes away (or changes its kernels) while its job is still compiling does not wait for it: the job moves to a
+// process-wide list -- its code object still lands in the kernel cache, where the next problem with that kernel finds it -- and the
+// list is joined when a context is destroyed and at exit (a thread inside hiprtc must not outlive the process's static objects).
+namespace {
+std::mutex g_orphan_mu;
+std::vector<mci_problem::PersistJob *> g_orphans;
+void persist_orphans_join() {
+    std::vector<mci_problem::PersistJob *> mine;
+    {
+        std::lock_guard<std::mutex> g(g_orphan_mu);
+        mine.swap(g_orphans);
+    }
+    for (auto *j : mine) {
+        if (j->th.joinable()) j->th.join();
+        delete j;
+    }
+}
+} // namespace
+static void persist_job_drop(mci_problem *p) {
     if (!p->persist_job) return;
-    if (p->persist_job->th.joinable()) p->persist_job->th.join();
-    delete p->persist_job;
+    mci_problem::PersistJob *j = p->persist_job;
     p->persist_job = nullptr;
+    if (j->done.load(std::memory_order_acquire)) {
+        if (j->th.joinable()) j->th.join();
+        delete j;
+        return;
+    }
+    static std::once_flag once;
+    std::call_once(once, [] { atexit(persist_orphans_join); });
+    std::lock_guard<std::mutex> g(g_orphan_mu);
+    g_orphans.push_back(j);
 }
 // MCI_OK with p->persist_compiled set: the kernel is loaded.  MCI_OK without: not yet (background == true and the code object is
 // still being compiled) -- the caller takes the launch chain this time.
@@ -2155,10 +2186,18 @@ static int compile_persist(mci_problem *p, bool background) {
         mcijit::ProblemShape sh = p->shape;
         sh.hcopy = 1;
         sh.det = 0;
-        c->src = mcijit::generate_source(sh, MCI_VEGAS, mcijit::kUnitVegasPersist);
+        c->src = mcijit::generate_source(sh, MCI_VEGAS, mcijit::kUnitVegasPersist, p->leaves[0].alpha);
         c->threads = p->threads;
         c->rc = mcijit::compile(c->src, c->threads, c->code, c->log, c->cached, &c->path, true, /*cache_only=*/background);
-        if (c->rc == -1) { // not in the kernel cache: compile it behind the caller's back
+        if (c->rc == -1) { // not in the kernel cache: compile it behind the caller's back ...
+            // ... from the second launch-bound call of this kernel on (by this problem or another one with the same shape and
+            // integrand): a script that makes one call and exits neither pays for the larger unit nor waits for its thread
+            {
+                static std::mutex mu;
+                static std::map<uint64_t, int> asked;
+                std::lock_guard<std::mutex> g(mu);
+                if (++asked[mcijit::fnv1a(c->src)] < 2) return MCI_OK;
+            }
             p->persist_job = new mci_problem::PersistJob;
             p->persist_job->c = std::move(local);
             mci_problem::PersistJob *j = p->persist_job;

@@ -220,10 +220,29 @@ struct DumpArgs {
 // ---------------------------------------------------------------------------------------------
 // wave64 / workgroup reductions
 // ---------------------------------------------------------------------------------------------
+// Cross-lane moves through the VALU's data-parallel primitives (DPP: gfx9's row_shr / row_shl within a row of 16 lanes, row_bcast:15 and
+// row_bcast:31 across rows): a dependent VALU instruction each, where __shfl_* is a ds_bpermute_b32 round trip through the LDS crossbar per
+// 32-bit half (an epilogue's reductions and train!'s scans are chains of them, alone on their CU).  Lanes without a source read 0.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_read(double v) {
+    const u64 u = (u64)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u32)u, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u32)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((u64)(u32)hi << 32) | (u64)(u32)lo));
+}
+// inclusive prefix sums over the 64 lanes of a wave, in a fixed order
+__device__ __forceinline__ double wave_scan_incl(double v) {
+    v += dpp_read<0x111, 0xf>(v); // row_shr:1
+    v += dpp_read<0x112, 0xf>(v); // row_shr:2
+    v += dpp_read<0x114, 0xf>(v); // row_shr:4
+    v += dpp_read<0x118, 0xf>(v); // row_shr:8
+    v += dpp_read<0x142, 0xa>(v); // row_bcast:15 -> rows 1, 3
+    v += dpp_read<0x143, 0xc>(v); // row_bcast:31 -> rows 2, 3
+    return v;
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v; // valid in lane 0
+    const u64 u = (u64)__double_as_longlong(wave_scan_incl(v)); // lane 63 holds the total
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)u, 63), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(u >> 32), 63);
+    return __longlong_as_double((long long)(((u64)hi << 32) | (u64)lo)); // valid in every lane
 }
 
 // LDS f64 add -> ds_add_f64 (no return).  Contention is benign: iy is uniform in y-space by

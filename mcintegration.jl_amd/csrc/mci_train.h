@@ -158,12 +158,7 @@ __device__ inline double block_prefix(const double *v, double *out, int n, doubl
     const int per = (n + T - 1) / T, b = tid * per, e = min(n, b + per);
     double loc = 0.0;
     for (int k = b; k < e; ++k) loc += v[k];
-    double x = loc; // inclusive scan of loc over the wave
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double y = __shfl_up(x, off, 64);
-        if (lane >= off) x += y;
-    }
+    const double x = wave_scan_incl(loc); // inclusive scan of loc over the wave
     __syncthreads();
     if (lane == 63) ps[wave] = x;
     __syncthreads();
@@ -208,8 +203,10 @@ __device__ inline double sum16(const double *v, int n) {
         for (int k = 0; k < 8; ++k) s += t[k];
     }
     for (; i < n; i += 16) s += v[i];
-#pragma unroll
-    for (int h = 8; h >= 1; h >>= 1) s += __shfl_down(s, h, 16);
+    s += dpp_read<0x108, 0xf>(s); // p[l] += p[l + 8]   (row_shl:8 -- the rows of the DPP are the 16-lane groups)
+    s += dpp_read<0x104, 0xf>(s); // p[l] += p[l + 4]
+    s += dpp_read<0x102, 0xf>(s); // p[l] += p[l + 2]
+    s += dpp_read<0x101, 0xf>(s); // p[l] += p[l + 1]
     return __shfl(s, 0, 16);
 }
 
@@ -444,10 +441,22 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
                 }
             };
             const double alpha = L.alpha;
+            // MCI_TRAIN_POWER (the persistent kernel's translation unit knows its one leaf): 2, 3, 1 = that exponent and nothing else,
+            // 4 = pow() alone; undefined = decided here (one instance of the loop per form costs the JIT half a second)
+#if defined(MCI_TRAIN_POWER) && MCI_TRAIN_POWER == 2
+            rescale_bins([](double b) { return b * b; });
+#elif defined(MCI_TRAIN_POWER) && MCI_TRAIN_POWER == 3
+            rescale_bins([](double b) { return b * b * b; });
+#elif defined(MCI_TRAIN_POWER) && MCI_TRAIN_POWER == 1
+            rescale_bins([](double b) { return b; });
+#elif defined(MCI_TRAIN_POWER) && MCI_TRAIN_POWER == 4
+            rescale_bins([alpha](double b) { return pow(b, alpha); });
+#else
             if (alpha == 2.0) rescale_bins([](double b) { return b * b; });
             else if (alpha == 3.0) rescale_bins([](double b) { return b * b * b; });
             else if (alpha == 1.0) rescale_bins([](double b) { return b; });
             else rescale_bins([alpha](double b) { return pow(b, alpha); });
+#endif
             if (anybad) atomicOr(&bad, ST_RESCALE_NONFINITE);
             __syncthreads();
             MCI_TT(4)
@@ -469,25 +478,26 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             const double total = block_prefix(d, wa, N, ps); // wa[j] = C[j] (inclusive)
             const double f_ninc = total / (double)N;         // :226
             MCI_TT(5)
-            int nsteps = 0; // halvings that bring [0, N-1] down to one bin
-            while ((1 << nsteps) < N) ++nsteps;
             for (int base = 0; base <= N; base += kTrainQ * T) {
-                int lo[kTrainQ], hi[kTrainQ]; // smallest j0 with C[j0] >= target, for kTrainQ new points at once
+                // smallest j0 with C[j0] >= target, for kTrainQ new points at once: a branch-free lower bound whose interval length is the
+                // same on every lane (scalar loop control; per halving one LDS read, one compare, one conditional add per point)
+                int lo[kTrainQ];
                 double target[kTrainQ];
 #pragma unroll
                 for (int q = 0; q < kTrainQ; ++q) {
                     lo[q] = 0;
-                    hi[q] = N - 1;
                     target[q] = (double)(base + q * T + tid) * f_ninc;
                 }
-                for (int st = 0; st < nsteps; ++st) {
+                for (int len = N; len > 1;) {
+                    const int half = len >> 1;
 #pragma unroll
-                    for (int q = 0; q < kTrainQ; ++q) { // (a search that has converged idles: lo == hi)
-                        const int mid = (lo[q] + hi[q]) >> 1;
-                        const bool ge = wa[mid] >= target[q], open = lo[q] < hi[q];
-                        hi[q] = open && ge ? mid : hi[q];
-                        lo[q] = open && !ge ? mid + 1 : lo[q];
-                    }
+                    for (int q = 0; q < kTrainQ; ++q) lo[q] += wa[lo[q] + half - 1] < target[q] ? half : 0;
+                    len -= half;
+                }
+#pragma unroll
+                for (int q = 0; q < kTrainQ; ++q) {
+                    lo[q] += wa[lo[q]] < target[q] ? 1 : 0;
+                    lo[q] = lo[q] > N - 1 ? N - 1 : lo[q];
                 }
                 double vnew[kTrainQ];
 #pragma unroll
@@ -574,7 +584,9 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             }
         }
 #endif // MCI_TRAIN_SCAN_ONLY
-    } else {
+    }
+#ifndef MCI_TRAIN_CONTINUOUS_ONLY // (the persistent kernel refines one Continuous grid: the Discrete form and its pow() stay out of its translation unit)
+    else {
         // train!(Discrete)  variable.jl:369-382 : rescale (no smoothing), normalise, prefix sum
         double *acc = dacc + L.eoff, *dist = ddist + L.doff;
         const double s = N > 1 ? sum16(h, N) : 1.0; // rescale's sum(dist), common.jl:72
@@ -606,6 +618,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             }
         }
     }
+#endif
     // clearStatistics!(T)  variable.jl:238/:381 -> :565 (the next iteration's merge starts from its own fill)
     __syncthreads();
     if (hclear)
@@ -619,7 +632,9 @@ __device__ inline void iteration_bookkeeping(const TrainArgs &a) {
     double *row = a.iter_log_row;
     if (row)
         for (int i = tid; i < a.nstat; i += T) row[i] = a.packed[i];
+#ifndef MCI_TRAIN_CONTINUOUS_ONLY // (:vegas never reweights, main.jl:183)
     if (a.do_reweight && tid == 0) do_reweight_dev(a.reweight, a.packed + (a.nstat - a.nd), a.nd, a.gamma, a.goal);
+#endif
 }
 
 // =============================================================================================

@@ -305,12 +305,13 @@ class Engine:
 
     # ---- kernels -------------------------------------------------------------------------------
     def compile(self, solver="vegas"):
-        check(lib().mci_compile_solver(self.p, _lib.SOLVERS[solver]))
+        """solver: "vegas" | "vegasmc" | "mcmc" | "vegas_persistent" (the persistent :vegas kernel, layouts with one Continuous leaf)"""
+        check(lib().mci_compile_solver(self.p, 3 if solver == "vegas_persistent" else _lib.SOLVERS[solver]))
 
     def code_object(self, solver="vegas"):
         """kernel-cache file holding the solver's gfx950 code object (after compile / the first run)"""
         buf = C.create_string_buffer(4096)
-        check(lib().mci_kernel_code_object(self.p, _lib.SOLVERS[solver], buf, len(buf)))
+        check(lib().mci_kernel_code_object(self.p, 3 if solver == "vegas_persistent" else _lib.SOLVERS[solver], buf, len(buf)))
         return buf.value.decode()
 
     def set_kernel_timing(self, mode=-1):

@@ -63,6 +63,22 @@ def test_baseline_kernels_do_not_spill(name, cfg, f, meas, solver, kernel, max_v
         assert res[kernel]["max_threads"] == 1024     # plan A of the split-all pass: first rung of the ladder
 
 
+@pytest.mark.parametrize("name", ["c1", "c2"])
+def test_persistent_vegas_kernel_neither_spills_nor_declares_static_lds(name):
+    """the persistent :vegas kernel (mci_set_persistent; sample loop + block merge + train! of one Continuous grid, 256 threads, plain
+    layout): no scratch, at most 256 VGPRs (two waves per SIMD: a grid of <= 129 workgroups is co-resident many times over), and its LDS is
+    all dynamic (the pair table is addressed from LDS address 0); layouts with several leaves have no such kernel"""
+    b = [x for x in BASELINE if x[0] == name][0]
+    res = isa_mix.resources(_code_object(b[1], b[2], None, "vegas_persistent"))
+    k = res["mci_vegas_persist"]
+    assert k["vgpr_spill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 256 and k["max_threads"] == 256, k
+    assert k.get("lds", 0) == 0, k
+    eng = mci.Engine(_bubble(), mci.catalog.bubble(), measure=mci.bin_by(4), device=-1)
+    with pytest.raises(Exception, match="no persistent"):
+        eng.compile("vegas_persistent")
+    eng.close()
+
+
 def test_split_all_pass_falls_back_to_512_threads_when_the_integrand_needs_every_draw_at_once():
     """32 independent grids with an integrand that cannot consume the draws as they come (it needs their mean first, then every draw
     and every intermediate again): at 768 threads (168 VGPRs) the sample pass would spill, so the library compiles plan B -- 512

@@ -16,14 +16,24 @@ if __name__ == "__main__":
             cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
             eng = mci.Engine(cfg, mci.catalog.x2y2())
             eng.integrate(solver, neval=neval, niter=3, block=16, seed=1)
+            for _ in range(100):   # (launch-bound :vegas calls go persistent once that kernel's own translation unit has compiled, on its thread)
+                if solver != "vegas" or neval * 2 >= 2**21 or eng.last_integrate_persistent():
+                    break
+                time.sleep(0.05)
+                eng.integrate(solver, neval=neval, niter=3, block=16, seed=1)
+            persistent = solver == "vegas" and eng.last_integrate_persistent()
             t0 = time.perf_counter()
             r = eng.integrate(solver, neval=neval, niter=50, block=16, seed=1, first_iteration=3)
             dt = time.perf_counter() - t0
-            eng.set_kernel_timing(1)   # the kernel's own duration: a second run with the HIP events on (they cost ~11 us per iteration)
-            eng.integrate(solver, neval=neval, niter=50, block=16, seed=1, first_iteration=53)
-            ms, wg, th = eng.kernel_times_ms(50)
-            print("%-8s neval=%-9d  %8.1f us/iteration (library clock %8.1f)  kernel %8.1f us  wg=%d  -> %8.1f Msamples/s   mean %.6f +- %.1e" % (
-                solver, neval, dt / 50 * 1e6, r["seconds"] / 50 * 1e6, float(np.median(ms)) * 1e3, wg, neval / (dt / 50) / 1e6, r["mean"][0], r["stdev"][0]), flush=True)
+            wg = eng.kernel_times_ms(1)[1]
+            if not persistent:
+                eng.set_kernel_timing(1)   # the kernel's own duration: a second run with the HIP events on (they cost ~11 us per iteration)
+                eng.integrate(solver, neval=neval, niter=50, block=16, seed=1, first_iteration=53)
+                ms, wg, th = eng.kernel_times_ms(50)
+            print("%-8s neval=%-9d  %8.1f us/iteration (library clock %8.1f)  %s  -> %8.1f Msamples/s   mean %.6f +- %.1e" % (
+                solver, neval, dt / 50 * 1e6, r["seconds"] / 50 * 1e6,
+                "one persistent launch, wg=%d" % wg if persistent else "kernel %8.1f us  wg=%d" % (float(np.median(ms)) * 1e3, wg),
+                neval / (dt / 50) / 1e6, r["mean"][0], r["stdev"][0]), flush=True)
     # the headline integrand (16-D Gaussian on a shared 999-bin grid, :vegas) from launch-bound to throughput-bound sizes
     import math
     L = math.sqrt(50.0)
@@ -34,12 +44,21 @@ if __name__ == "__main__":
         n = 50 if neval < 10**8 else 10
         eng.set_kernel_timing(0)
         eng.integrate("vegas", neval=neval, niter=3, block=16, seed=1, first_iteration=it, ignore=0)
+        for _ in range(100):
+            if neval * 16 >= 2**21 or eng.last_integrate_persistent():
+                break
+            time.sleep(0.05)
+            eng.integrate("vegas", neval=neval, niter=3, block=16, seed=1, first_iteration=it, ignore=0)
+        persistent = eng.last_integrate_persistent()
         t0 = time.perf_counter()
         eng.integrate("vegas", neval=neval, niter=n, block=16, seed=1, first_iteration=it + 3, ignore=0)
         dt = time.perf_counter() - t0
-        eng.set_kernel_timing(1)
-        eng.integrate("vegas", neval=neval, niter=n, block=16, seed=1, first_iteration=it + 3 + n, ignore=0)
-        ms, wg, th = eng.kernel_times_ms(n)
+        ms, wg, th = eng.kernel_times_ms(1)
+        if not persistent:
+            eng.set_kernel_timing(1)
+            eng.integrate("vegas", neval=neval, niter=n, block=16, seed=1, first_iteration=it + 3 + n, ignore=0)
+            ms, wg, th = eng.kernel_times_ms(n)
         it += 3 + 2 * n
-        print("C2 neval=%-10d %8.1f us/iteration  kernel %8.1f us  wg=%d th=%d  -> %8.1f Msamples/s" % (
-            neval, dt / n * 1e6, float(np.median(ms)) * 1e3, wg, th, neval / (dt / n) / 1e6), flush=True)
+        print("C2 neval=%-10d %8.1f us/iteration  %s  -> %8.1f Msamples/s" % (
+            neval, dt / n * 1e6, "one persistent launch, wg=%d th=%d" % (wg, th) if persistent else "kernel %8.1f us  wg=%d th=%d" % (float(np.median(ms)) * 1e3, wg, th),
+            neval / (dt / n) / 1e6), flush=True)

@@ -182,9 +182,7 @@ __host__ __device__ inline int train_lds_doubles(int n) { return (n + kWalkPad) 
 // block size of 1024: a vectorised reduction whose association is the CPU's (lanes x interleave), not left to right.  Oracle and
 // device fix the AVX2 shape: 16 interleaved partial sums (element i -> partial i mod 16, each left to right), folded
 // p[l] += p[l + h] for h = 8, 4, 2, 1.  Called by every thread of the workgroup; every 16-lane group computes the total for itself.
-// Limit of the claim: from 1025 elements on Julia's mapreduce_impl splits the range pairwise at its midpoint before it reaches the
-// @simd loop; grids of more than 1025 increments (the default is 999) are summed here -- and in the oracle, mcio_sum16 -- with the
-// same 16-lane shape over the whole range, so for them the last bits of f_ninc and of the rescale sum need not be Julia's.
+// From 1025 elements on mapreduce_impl splits the range at its midpoint and adds the sums of the two halves: sum_julia below.
 __device__ inline double sum16(const double *v, int n) {
     double s = 0.0;
     int i = threadIdx.x & 15;
@@ -208,6 +206,18 @@ __device__ inline double sum16(const double *v, int n) {
     s += dpp_read<0x102, 0xf>(s); // p[l] += p[l + 2]
     s += dpp_read<0x101, 0xf>(s); // p[l] += p[l + 1]
     return __shfl(s, 0, 16);
+}
+
+// Julia's sum() of a Vector{Float64} of any length (base/reduce.jl mapreduce_impl, pairwise_blocksize = 1024): the @simd block up to
+// 1024 elements, above that the halves [ifirst, imid], [imid + 1, ilast] with imid = ifirst + (ilast - ifirst) >> 1, summed the same way
+// and added.  The recursion is three deep at the largest grid a workgroup refines (kMaxLeafBins = 4400) and unrolled at compile time.
+template <int DEPTH = 3> __device__ inline double sum_julia(const double *v, int n) {
+    if constexpr (DEPTH == 0) return sum16(v, n);
+    else {
+        if (n <= 1024) return sum16(v, n);
+        const int h = ((n - 1) >> 1) + 1;
+        return sum_julia<DEPTH - 1>(v, h) + sum_julia<DEPTH - 1>(v + h, n - h);
+    }
 }
 
 // b ^ alpha of rescale (common.jl:75).  The learning rates the reference's constructors hand out are small integers (alpha = 2
@@ -375,7 +385,12 @@ __device__ inline void train_stage_grid(const LeafDev &L, double *sm, const doub
 __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hclear, double *sm, double *ps, int &bad, double &ssum,
                                   double *__restrict__ edges, double *__restrict__ dacc, double *__restrict__ ddist, int serial_walk,
                                   int *__restrict__ status, bool staged = false, unsigned long long *tt = nullptr, bool checked = false) {
+#ifdef MCI_PERSIST_TRACE // development aid (tools/persist_trace.py): wall-clock stamps of the phases, into LDS
 #define MCI_TT(k) if (tt && threadIdx.x == 0) tt[k] = wall_clock64();
+#else
+#define MCI_TT(k)
+    (void)tt;
+#endif
     const int tid = threadIdx.x, T = blockDim.x;
     const int N = L.nbin;
     double *d = sm;                     // [N+kWalkPad] smoothed / rescaled distribution, zeros behind it
@@ -415,7 +430,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
         MCI_TT(2)
         // rescale  common.jl:67-82
         if (N > 1) {
-            const double s = sum16(d, N); // :72
+            const double s = sum_julia(d, N); // :72
             __syncthreads(); // every 16-lane group reads ALL of d[] for its total: nobody overwrites d[] before the last group is through
             MCI_TT(3)
             int anybad = 0;
@@ -527,7 +542,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
         // chain -- add, compare, subtract -- and records acc_f after each bin (walk_bins16); how many points a bin yields, their
         // acc_f (the same subtractions again), the division and the interpolation (:233) are recomputed from that record by all
         // lanes.  acc_f <= (N + 1) f_ninc, so a subtraction always makes progress.
-        const double f_ninc = sum16(d, N) / (double)N; // :226
+        const double f_ninc = sum_julia(d, N) / (double)N; // :226
         if (tid == 0) {
             if (f_ninc > 0.0 && isfinite(f_ninc)) {
                 const unsigned rec = (unsigned)(size_t)wa;
@@ -589,7 +604,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
     else {
         // train!(Discrete)  variable.jl:369-382 : rescale (no smoothing), normalise, prefix sum
         double *acc = dacc + L.eoff, *dist = ddist + L.doff;
-        const double s = N > 1 ? sum16(h, N) : 1.0; // rescale's sum(dist), common.jl:72
+        const double s = N > 1 ? sum_julia(h, N) : 1.0; // rescale's sum(dist), common.jl:72
         if (tid == 0) {
             int lbad = 0;
             if (N > 1) {

@@ -127,9 +127,9 @@ void mcio_smooth(const double *dist, long n, double factor, double *out) {
  * right -- the reference has no single order.  The oracle (and the device) fix the AVX2 shape: 16 interleaved partial sums
  * (element i -> partial i mod 16, each left to right), folded p[l] += p[l + h] for h = 8, 4, 2, 1.
  * Used where the reference sums a histogram-length vector: rescale (common.jl:72) and f_ninc (variable.jl:226).
- * Limit of the claim: from 1025 elements on mapreduce_impl first splits the range pairwise at its midpoint; vectors that long
- * (grids of more than 1025 increments; the default is 999) are summed with the same 16-lane shape over the whole range here and
- * on the device (mci_static_kernels.h sum16), so for them the last bits need not be Julia's. */
+ * From 1025 elements on mapreduce_impl first splits the range at its midpoint, imid = ifirst + (ilast - ifirst) >> 1, sums the two
+ * halves the same way and adds the two results (base/reduce.jl mapreduce_impl, pairwise_blocksize = 1024): mcio_sum_julia below, and
+ * sum_julia on the device (mci_train.h). */
 double mcio_sum16(const double *v, long n) {
     double p[16] = {0};
     for (long i = 0; i < n; ++i) p[i & 15] += v[i];
@@ -149,11 +149,18 @@ static double mcio_pow_julia(double b, double alpha) {
     return pow(b, alpha);
 }
 
+/* Julia's sum() of a Vector{Float64} of any length: the @simd block below 1025 elements, pairwise halves above */
+double mcio_sum_julia(const double *v, long n) {
+    if (n <= 1024) return mcio_sum16(v, n);
+    const long h = ((n - 1) >> 1) + 1; /* [ifirst, imid] holds (ilast - ifirst) >> 1 + 1 elements */
+    return mcio_sum_julia(v, h) + mcio_sum_julia(v + h, n - h);
+}
+
 int mcio_rescale(double *dist, long n, double alpha) {
     if (n == 1) return 0; /* :68-70 */
     for (long i = 0; i < n; ++i)
         if (!(dist[i] > 0)) return 1; /* :71 */
-    const double s = mcio_sum16(dist, n);
+    const double s = mcio_sum_julia(dist, n);
     for (long i = 0; i < n; ++i) dist[i] /= s; /* :72 */
     for (long i = 0; i < n; ++i)               /* :74-78 */
         if (dist[i] > 0 && dist[i] <= 0.99999999) dist[i] = mcio_pow_julia(-(1 - dist[i]) / log(dist[i]), alpha);
@@ -182,7 +189,7 @@ int mcio_train_continuous(double *grid, long npts, double *hist, double alpha) {
     newgrid[npts - 1] = grid[npts - 1]; /* :218 */
     long j = 0;                         /* :221 */
     double acc_f = 0.0;                 /* :222 */
-    double f_ninc = mcio_sum16(d, N) / (double)N; /* :226 */
+    double f_ninc = mcio_sum_julia(d, N) / (double)N; /* :226 */
     for (long i = 2; i <= npts - 1; ++i) { /* :227 (1-based i) */
         while (acc_f < f_ninc) {           /* :228 */
             j += 1;                        /* :229 */

@@ -162,6 +162,7 @@ double mcio_uniform32(uint64_t seed, uint32_t stream, uint64_t index, uint32_t k
 long mcio_locate(const double *acc, long n, double p);            /* :8-36, 1-based result, -1 if outside */
 void mcio_smooth(const double *dist, long n, double factor, double *out); /* :43-54 */
 double mcio_sum16(const double *v, long n);                        /* Julia sum() of a histogram-length vector: fixed 16-partial order */
+double mcio_sum_julia(const double *v, long n);                    /* ... of any length: pairwise halves above 1024 elements */
 int mcio_rescale(double *dist, long n, double alpha);             /* :67-82, in place; !=0 on assert failure */
 
 /* ---- src/distribution/variable.jl ---- */

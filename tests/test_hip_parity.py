@@ -280,6 +280,26 @@ def test_train_matches_oracle(oracle, name, walk, monkeypatch):
 
 
 @pytest.mark.parametrize("walk", ["serial", "prefix"])
+@pytest.mark.parametrize("ninc", [1025, 1026, 2500])
+def test_train_of_a_grid_longer_than_julias_simd_block_matches_oracle(oracle, ninc, walk, monkeypatch):
+    """train! on grids of 1024 / 1025 / 2499 increments: Julia's sum() (common.jl:72, variable.jl:226) runs its @simd block up to 1024
+    elements and splits longer vectors pairwise at the midpoint first (base/reduce.jl mapreduce_impl) -- mcio_sum_julia in the oracle,
+    sum_julia on the device; same tolerances as the default 999 increments"""
+    monkeypatch.setenv("MCI_TRAIN_SERIAL", "1" if walk == "serial" else "0")
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0, ninc=ninc), dof=[[2]], seed=SEED)
+    eng = mci.Engine(cfg, mci.catalog.x2y2())
+    ocfg = oracle.Config([ocont(npts=ninc)], [[2]])
+    block, npb = 8, 8000
+    eng.run("vegas", npb, 0, block, 0, SEED)
+    eng.finish("vegas", block, adapt=True)
+    ocfg.iteration(oracle.VEGAS, "x2y2", None, npb, 0, block, 0, SEED)
+    ocfg.train()
+    g, og = eng.grid(0), ocfg.grid(0)
+    assert len(g) == ninc and g[0] == og[0] and g[-1] == og[-1] and np.all(np.diff(g) > 0)
+    np.testing.assert_allclose(g, og, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("walk", ["serial", "prefix"])
 @pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "bubble", "c2_gauss4_composite"])
 def test_full_integrate_matches_oracle(oracle, name, walk, monkeypatch):
     """rows a13-a15: the whole loop inside the library (mci_integrate) vs the oracle's loop, same seed.

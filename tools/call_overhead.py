@@ -28,6 +28,31 @@ if __name__ == "__main__":
         reuse = (time.perf_counter() - t0) / n
         print("%-8s integrate(neval=1e4, niter=10): new Configuration per call %8.3f ms, same Configuration %8.3f ms   (%s)" % (
             solver, fresh * 1e3, reuse * 1e3, r), flush=True)
+    # steady state: the same Configuration over and over, persistent launch on / off (the first loops above run while the persistent
+    # kernel's translation unit is still compiling on its thread)
+    import numpy as np
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
+    for i in range(40):
+        mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
+        if cfg._engine.last_integrate_persistent():
+            break
+        time.sleep(0.05)
+    eng = cfg._engine
+    for mode in ("off", "on"):
+        eng.set_persistent(mode)
+        mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
+        ts = []
+        for i in range(300):
+            t0 = time.perf_counter()
+            r = mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
+            ts.append(time.perf_counter() - t0)
+        ts = np.array(ts) * 1e3
+        lib = []
+        for i in range(300):
+            lib.append(eng.integrate("vegas", neval=10000, niter=10, block=16, seed=1)["seconds"])
+        print("vegas    steady state, persistent launch %-3s: integrate(neval=1e4, niter=10) median %.3f ms (min %.3f, p90 %.3f); library clock %.3f ms" % (
+            mode, np.median(ts), ts.min(), np.percentile(ts, 90), np.median(lib) * 1e3), flush=True)
+    eng.set_persistent("auto")
     # profile of calls on a reused Configuration, then of fresh ones
     import cProfile, pstats
     cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])

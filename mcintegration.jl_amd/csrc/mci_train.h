@@ -666,17 +666,18 @@ __device__ inline void iteration_bookkeeping(const TrainArgs &a) {
 //                          once all G have arrived: read the merged histogram and run train! on it ITSELF (prefix-scan walk) -- every
 //                          workgroup refines its own copy of the map with the same arithmetic on the same numbers, so the copies stay
 //                          bit-identical and nobody waits for a refined map to travel through HBM: one grid-wide wait per turn
-//     workgroup 0          also writes the merged histogram / clearStatistics! state to `packed`, the refined map to HBM (what the
-//                          host reads back and the next launch starts from), and zeroes the histogram buffer of the turn before
-//     statistics workgroup once all G have arrived: block merge -> statistics head -> iteration log                          ->  done
+//     workgroup 0          writes its copy of the map back to HBM when the last turn is through (what the host reads, what the next launch starts from)
+//     statistics workgroup once all G have arrived: block merge -> statistics head -> iteration log; zeroes the histogram buffer of the
+//                          turn before; in the last turn leaves the merged histogram / clearStatistics! state in `packed`         ->  done
 //
 // The waits are counters in HBM that only grow (targets are computed from the launch's starting values; nothing is reset between
 // launches); a workgroup publishes with  barrier -> agent-scope release fence -> relaxed atomic add  by its first thread and consumes
 // with  relaxed atomic load -> agent-scope acquire fence -> barrier  (those fences write back / invalidate the XCD's L2).
-// Three histogram buffers: buffer t % 3 is added to in turn t, read by everybody after the arrive of turn t, zeroed by workgroup 0 after
-// the arrive of turn t + 1 (all its readers have arrived there) and next added to in turn t + 3.  Two partial-row buffers: the rows of
-// turn t are read by the statistics workgroup, which every sampling workgroup checks has finished turn t - 1 before it leaves the
-// arrive of turn t.  Residency: the host launches no more workgroups than fit the chip at once next to another such grid; a wait is
+// Three histogram buffers: buffer t % 3 is added to in turn t, read by everybody after the arrive of turn t, zeroed by the statistics
+// workgroup after the arrive of turn t + 1 (all its readers have arrived there) and next added to in turn t + 3.  Two partial-row buffers:
+// the rows of turn t are read by the statistics workgroup, which every sampling workgroup checks has finished turn t - 1 -- rows merged,
+// buffer zeroed -- before it leaves the arrive of turn t.  (One poller per workgroup: the first lane of every wave polling out of step
+// was tried and was slower, 15.2 against 13.6 us per iteration -- the polls queue at the memory side with the arrivals' own atomics.)  Residency: the host launches no more workgroups than fit the chip at once next to another such grid; a wait is
 // bounded in wall-clock time and a stall (ST_PERSIST_STALL) ends the launch with an error, not a hang.
 struct PersistArgs {
     MergeArgs m;              // (use_ghist = 1; part_pa = NULL; part_cols: [2][G][ncols]; ghist: [3][nbin])
@@ -745,7 +746,9 @@ template <class Cfg> __device__ __forceinline__ void vegas_persist(const BatchAr
 #else
 #define MCI_PT(k)
 #endif
-    if (wg == (int)G) { // ---- the statistics workgroup
+    const LeafDev L = f.t.leaves[0];
+    const bool train = f.t.do_train && L.adapt; // variable.jl:208
+    if (wg == (int)G) { // ---- the statistics workgroup (and everything else that is nobody's critical path)
         for (int it = 0; it < f.niter; ++it) {
             MCI_PT(0)
             if (!persist_wait(f, f.arrive0 + (u64)(it + 1) * G, f.done0 + (u64)it, verdict)) return;
@@ -756,6 +759,16 @@ template <class Cfg> __device__ __forceinline__ void vegas_persist(const BatchAr
             // config.propose / config.accept of a :vegas iteration: the clearStatistics! offsets alone (configuration.jl:247-248)
             for (int e = tid; e < 2 * m.npa; e += T)
                 m.packed[2 * m.nobs + 2 + m.ni + 1 + m.nbin + e] = (double)(m.nblocks + 1) * (e < m.npa ? 1.0e-8 : 1.0e-10);
+            if (it > 0) { // the histogram buffer of the turn before: everybody who read it has arrived again
+                double *gz = a0.ghist + (size_t)((it + 2) % 3) * Cfg::NBIN + L.boff;
+                for (int i = tid; i < N; i += T) gz[i] = 0.0;
+            }
+            if (it == f.niter - 1) { // what the launch leaves in `packed`: the merged histogram, or train!'s clearStatistics! (variable.jl:238 -> :565)
+                const double *gh = a0.ghist + (size_t)(it % 3) * Cfg::NBIN + L.boff;
+                double *hp = f.t.packed + f.t.nstat + L.boff;
+                for (int i = tid; i < N; i += T)
+                    hp[i] = train ? 1.0e-10 : (double)(m.nblocks + 1) * 1.0e-10 + __hip_atomic_load(&gh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __syncthreads(); // the head of `packed` was written by this workgroup
             TrainArgs t = f.t;
             if (t.iter_log_row) t.iter_log_row += (size_t)it * t.nstat;
@@ -765,13 +778,14 @@ template <class Cfg> __device__ __forceinline__ void vegas_persist(const BatchAr
             persist_signal(&f.ctr[0], 1ull << kPersistDoneShift);
             MCI_PT(5)
         }
+        // the last turn's histogram buffer: zeroed once everybody has read it
+        if (!persist_wait(f, f.arrive0 + (u64)(f.niter + 1) * G, f.done0, verdict)) return;
+        double *gz = a0.ghist + (size_t)((f.niter - 1) % 3) * Cfg::NBIN + L.boff;
+        for (int i = tid; i < N; i += T) gz[i] = 0.0;
         return;
     }
     // ---- a sampling workgroup
-    const LeafDev L = f.t.leaves[0];
     for (int i = tid; i <= N; i += T) gcur[i] = f.t.edges[L.eoff + i]; // this workgroup's copy of the map
-    double *hp = f.t.packed + f.t.nstat + L.boff;
-    const bool train = f.t.do_train && L.adapt; // variable.jl:208
     for (int it = 0; it < f.niter; ++it) {
         BatchArgs a = a0;
         a.iteration = a0.iteration + (u32)it;
@@ -786,7 +800,8 @@ template <class Cfg> __device__ __forceinline__ void vegas_persist(const BatchAr
         MCI_PT(1)
         persist_signal(&f.ctr[0], 1ull);
         MCI_PT(2)
-        // all G rows and histograms of this turn are out; the statistics workgroup is through with the rows of the turn before
+        // all G rows and histograms of this turn are out; the statistics workgroup is through with the turn before (its rows, and the
+        // histogram buffer it zeroed)
         if (!persist_wait(f, f.arrive0 + (u64)(it + 1) * G, f.done0 + (u64)it, verdict)) return;
         MCI_PT(3)
         const double *gh = a.ghist + L.boff;
@@ -804,40 +819,29 @@ template <class Cfg> __device__ __forceinline__ void vegas_persist(const BatchAr
                 if (i < N) {
                     const double h = (double)(f.m.nblocks + 1) * 1.0e-10 + v[q];
                     hl[i] = h;
-                    if (wg == 0) hp[i] = h;
                     if (!isfinite(h)) hbad |= ST_HIST_NONFINITE;      // variable.jl:212
                     else if (!(h > 0.0)) hbad |= ST_HIST_NONPOSITIVE; // variable.jl:213 / common.jl:71
                 }
             }
         }
         if (hbad) atomicOr(reinterpret_cast<int *>(flags), hbad);
-        if (wg == 0 && it > 0) { // the buffer of the turn before: everybody who read it has arrived
-            double *gz = a0.ghist + (size_t)((it + 2) % 3) * Cfg::NBIN + L.boff;
-            for (int i = tid; i < N; i += T) gz[i] = 0.0;
-        }
         __syncthreads();
 #ifdef MCI_PERSIST_TRACE
         u64 *tt = (wg == 0 && it == 7) ? reinterpret_cast<u64 *>(ps + 200) : nullptr; // (stamps go to LDS: a global store would be waited for at the next barrier)
 #else
         u64 *tt = nullptr;
 #endif
-        if (train) train_leaf(L, hl, wg == 0 ? hp : nullptr, sm, ps, *reinterpret_cast<int *>(flags), flags[1], gcur - L.eoff, f.t.dacc, f.t.ddist, 0, f.t.status, false, tt, true);
+        if (train) train_leaf(L, hl, nullptr, sm, ps, *reinterpret_cast<int *>(flags), flags[1], gcur - L.eoff, f.t.dacc, f.t.ddist, 0, f.t.status, false, tt, true);
         __syncthreads();
 #ifdef MCI_PERSIST_TRACE
         if (tt && tid < 8) f.ctr[8 + 3 * 8 * 8 + tid] = tt[tid];
 #endif
-        if (wg == 0 && train)
-            for (int i = tid; i <= N; i += T) f.t.edges[L.eoff + i] = gcur[i]; // the refined map, for the host and the next launch
         MCI_PT(4)
     }
-    // the last turn's histogram buffer: zeroed once everybody has read it
     __syncthreads();
-    persist_signal(&f.ctr[0], 1ull);
-    if (wg == 0) {
-        if (!persist_wait(f, f.arrive0 + (u64)(f.niter + 1) * G, f.done0, verdict)) return;
-        double *gz = a0.ghist + (size_t)((f.niter - 1) % 3) * Cfg::NBIN + L.boff;
-        for (int i = tid; i < N; i += T) gz[i] = 0.0;
-    }
+    persist_signal(&f.ctr[0], 1ull); // "through with the last turn's histogram": the statistics workgroup zeroes it
+    if (wg == 0 && train)
+        for (int i = tid; i <= N; i += T) f.t.edges[L.eoff + i] = gcur[i]; // the refined map, for the host and the next launch
 #undef MCI_PT
 }
 

@@ -32,3 +32,64 @@ def pipe_case(rng):
         sign = "-" if rng.integers(0, 4) == 0 else ""
         lines.append("w[%d] = %s(%.3f + 0.5 * cos(%s) + 0.05 * x[%d] * x[%d]);" % (i, sign, 0.4 + 0.3 * i, arg, own[0], own[-1]))
     return tuple(var), oleaves, dof, "\n".join(lines), len(draws)
+
+
+def persist_case(rng):
+    """one Continuous variable type (the persistent :vegas launch's layouts): random bounds, grid size, learning rate; 1-4 integrands
+    with their own dof on the shared pool; an integrand that may change sign"""
+    lo, hi = float(rng.uniform(-2, 0)), float(rng.uniform(0.5, 3))
+    ninc = int(rng.choice([17, 100, 257, 1000, 1000, 1025, 1500]))
+    alpha = float(rng.choice([0.5, 1.0, 2.0, 2.0, 3.0]))
+    ni = int(rng.integers(1, 5))
+    dof = [[int(rng.integers(1, 7))] for _ in range(ni)]
+    ndraw = max(d[0] for d in dof)
+    lines = []
+    for i in range(ni):
+        own = list(range(dof[i][0]))
+        coef = rng.uniform(0.2, 1.5, size=len(own))
+        arg = " + ".join("%.6f * x[%d]" % (c, k) for c, k in zip(coef, own))
+        sign = "-" if rng.integers(0, 4) == 0 else ""
+        lines.append("w[%d] = %s(%.3f + 0.5 * cos(%s) + 0.05 * x[%d] * x[%d]);" % (i, sign, 0.4 + 0.3 * i, arg, own[0], own[-1]))
+    var = (mci.Continuous(lo, hi, alpha=alpha, ninc=ninc),)
+    oleaves = [dict(kind=0, pool=0, lower=lo, upper=hi, npts=ninc, alpha=alpha)]
+    return var, oleaves, dof, "\n".join(lines), ndraw
+
+
+def check_persistent_call(oracle, case_id, seed=20260930):
+    """a whole integrate() call as ONE persistent launch (mci_set_persistent on) against the oracle's loop: every iteration's mean and
+    error, the trained map; odd sizes, 1-40 blocks, with and without adaptation.  Returns (description, ran persistently?)."""
+    import numpy as np
+    rng = np.random.default_rng(9000 + case_id)
+    var, oleaves, dof, body, ndraw = persist_case(rng)
+    block = int(rng.choice([1, 2, 5, 16, 16, 40]))
+    neval = int(rng.choice([block * 3 + 1, 1000, 10007, 40000, 123457]))
+    neval = max(neval, block + 1)
+    niter = int(rng.integers(1, 7))
+    adapt = bool(rng.integers(0, 5) > 0)
+    what = "case %d: ni=%d ndraw=%d ninc=%d alpha=%g block=%d neval=%d niter=%d adapt=%d" % (
+        case_id, len(dof), ndraw, oleaves[0]["npts"], oleaves[0]["alpha"], block, neval, niter, adapt)
+    oracle.set_rng_rounds(10)
+    cfg = mci.Configuration(var=var, dof=dof, seed=seed)
+    eng = mci.Engine(cfg, mci.Integrand(body))
+    eng.set_persistent("on")
+    fn = oracle.compile_c_integrand(body)
+    ocfg = oracle.Config(oleaves, dof)
+    r = eng.integrate("vegas", neval=neval, niter=niter, block=block, seed=seed, adapt=adapt, ignore=0)
+    persistent = eng.last_integrate_persistent()
+    what += " persistent=%d" % persistent
+    o = ocfg.integrate(oracle.VEGAS, fn, None, neval=neval, niter=niter, block=block, seed=seed, adapt=adapt, ignore=0)
+    np.testing.assert_allclose(r["iter_mean"][0], o["iter_mean"][0], rtol=1e-10, atol=1e-300, err_msg=what + " (first iteration)")
+    # later iterations: the prefix-scan walk against the oracle's recurrence.  With fewer samples than bins the histogram is mostly its
+    # 1e-10 offsets and train! amplifies rounding without bound: those cases are held to a twentieth of the statistical error instead
+    sparse = neval * ndraw < 20 * oleaves[0]["npts"]
+    if sparse:
+        assert np.all(np.abs(r["iter_mean"] - o["iter_mean"]) <= 0.05 * o["iter_std"] + 1e-5 * np.abs(o["iter_mean"])), what
+    else:
+        np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-5, atol=1e-300, err_msg=what)
+        np.testing.assert_allclose(r["iter_std"], o["iter_std"], rtol=1e-3, atol=1e-300, err_msg=what)
+    g, og = eng.grid(0), ocfg.grid(0)
+    assert g[0] == og[0] and g[-1] == og[-1] and np.all(np.diff(g) > 0), what
+    if not sparse:
+        np.testing.assert_allclose(g, og, rtol=0, atol=1e-5 * (og[-1] - og[0]), err_msg=what + " (map)")
+    eng.close()
+    return what, persistent

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import mcintegration_jl_amd as mci
+from layout_cases import check_persistent_call
 from test_hip_parity import CASES, SEED, make
 
 pytestmark = pytest.mark.gpu
@@ -151,3 +152,12 @@ def test_automatic_mode_takes_the_persistent_launch_for_launch_bound_calls_only(
     eng.set_launch(256, 2)
     mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
     assert not eng.last_integrate_persistent()
+
+
+@pytest.mark.parametrize("case_id", [3, 17, 41, 72, 106, 108, 150, 211, 260, 301, 333, 399])
+def test_random_persistent_calls_match_oracle(oracle, case_id):
+    """a dozen cases of the randomised campaign (tools/fuzz_layouts.py --persist, profiles/r03_fuzz_persistent.txt: 400 cases): random grid
+    size (17..1500 increments), learning rate, dof tables, 1-40 blocks, 4..123457 samples, 1-6 iterations, with and without adaptation"""
+    what, persistent = check_persistent_call(oracle, case_id)
+    assert persistent, what
+    oracle.set_rng_rounds(10)

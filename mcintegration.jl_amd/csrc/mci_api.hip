@@ -2190,13 +2190,17 @@ static int compile_persist(mci_problem *p, bool background) {
         c->threads = p->threads;
         c->rc = mcijit::compile(c->src, c->threads, c->code, c->log, c->cached, &c->path, true, /*cache_only=*/background);
         if (c->rc == -1) { // not in the kernel cache: compile it behind the caller's back ...
-            // ... from the second launch-bound call of this kernel on (by this problem or another one with the same shape and
-            // integrand): a script that makes one call and exits neither pays for the larger unit nor waits for its thread
+            // ... once this process has made kPersistAfterCalls launch-bound calls of this kernel (by this problem or others with the same
+            // shape and integrand): the persistent launch saves ~40 us per default-size call and its translation unit costs 0.8 s of hiprtc
+            // -- on a thread of its own, but comgr serialises compiles, so another new kernel compiled meanwhile queues behind it (measured:
+            // 0.69 instead of 0.24 s, tools/cold_start.py).  A loop of hundreds of small calls gets it (and every later process finds it in
+            // the kernel cache); a script that makes a few calls never pays.
             {
+                static const int kPersistAfterCalls = 256;
                 static std::mutex mu;
                 static std::map<uint64_t, int> asked;
                 std::lock_guard<std::mutex> g(mu);
-                if (++asked[mcijit::fnv1a(c->src)] < 2) return MCI_OK;
+                if (++asked[mcijit::fnv1a(c->src)] < kPersistAfterCalls) return MCI_OK;
             }
             p->persist_job = new mci_problem::PersistJob;
             p->persist_job->c = std::move(local);

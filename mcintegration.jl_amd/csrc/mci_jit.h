@@ -99,8 +99,10 @@ static std::string dbl_arr(const std::vector<double> &v) {
 enum { kUnitSolver = 0, kUnitVegasMf1 = 1, kUnitDump = 2, kUnitVegasPersist = 3 };
 inline std::string generate_source(const ProblemShape &s, int solver, int unit = kUnitSolver, double persist_alpha = 0.0) {
     std::ostringstream o;
-    if (unit == kUnitVegasPersist) // the learning rate of the one leaf the persistent kernel refines (mci_train.h rescale)
+    if (unit == kUnitVegasPersist) { // the learning rate and the size of the one leaf the persistent kernel refines (mci_train.h rescale, sum_julia)
         o << "#define MCI_TRAIN_POWER " << (persist_alpha == 2.0 ? 2 : persist_alpha == 3.0 ? 3 : persist_alpha == 1.0 ? 1 : 4) << "\n";
+        if (!s.leaf_nbin.empty() && s.leaf_nbin[0] <= 1024) o << "#define MCI_TRAIN_SHORT_SUMS 1\n";
+    }
     if (solver == 0 && unit != kUnitDump) o << "#define MCI_MF_ONLY " << (unit == kUnitVegasMf1 || unit == kUnitVegasPersist ? 1 : 0) << "\n";
     if (unit == kUnitVegasPersist) o << "#define MCI_TRAIN_SCAN_ONLY 1\n#define MCI_TRAIN_CONTINUOUS_ONLY 1\n";
     if (s.rng_rounds != 10) o << "#define MCI_PHILOX_ROUNDS " << s.rng_rounds << "\n"; // opt-in cheaper stream (mci_set_rng_rounds)

@@ -211,6 +211,11 @@ __device__ inline double sum16(const double *v, int n) {
 // Julia's sum() of a Vector{Float64} of any length (base/reduce.jl mapreduce_impl, pairwise_blocksize = 1024): the @simd block up to
 // 1024 elements, above that the halves [ifirst, imid], [imid + 1, ilast] with imid = ifirst + (ilast - ifirst) >> 1, summed the same way
 // and added.  The recursion is three deep at the largest grid a workgroup refines (kMaxLeafBins = 4400) and unrolled at compile time.
+// (MCI_TRAIN_SHORT_SUMS: a translation unit whose vectors are known to be no longer than 1024 elements -- the persistent kernel of a
+// grid of up to 1024 increments -- takes the @simd block alone: the unrolled recursion is fifteen inlined copies of it for the JIT)
+#ifdef MCI_TRAIN_SHORT_SUMS
+template <int DEPTH = 3> __device__ inline double sum_julia(const double *v, int n) { return sum16(v, n); }
+#else
 template <int DEPTH = 3> __device__ inline double sum_julia(const double *v, int n) {
     if constexpr (DEPTH == 0) return sum16(v, n);
     else {
@@ -219,6 +224,7 @@ template <int DEPTH = 3> __device__ inline double sum_julia(const double *v, int
         return sum_julia<DEPTH - 1>(v, h) + sum_julia<DEPTH - 1>(v + h, n - h);
     }
 }
+#endif
 
 // b ^ alpha of rescale (common.jl:75).  The learning rates the reference's constructors hand out are small integers (alpha = 2
 // by default, variable.jl:137; the bubble example uses 3): for those Julia's `^(::Float64, ::Float64)` takes its

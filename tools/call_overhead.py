@@ -28,15 +28,11 @@ if __name__ == "__main__":
         reuse = (time.perf_counter() - t0) / n
         print("%-8s integrate(neval=1e4, niter=10): new Configuration per call %8.3f ms, same Configuration %8.3f ms   (%s)" % (
             solver, fresh * 1e3, reuse * 1e3, r), flush=True)
-    # steady state: the same Configuration over and over, persistent launch on / off (the first loops above run while the persistent
-    # kernel's translation unit is still compiling on its thread)
+    # steady state: the same Configuration over and over, persistent launch off / on (the automatic mode compiles that kernel in the
+    # background once a process has made 256 launch-bound calls of it; "on" compiles it on the spot)
     import numpy as np
     cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
-    for i in range(40):
-        mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
-        if cfg._engine.last_integrate_persistent():
-            break
-        time.sleep(0.05)
+    mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
     eng = cfg._engine
     for mode in ("off", "on"):
         eng.set_persistent(mode)

@@ -36,22 +36,36 @@ def cases(tag):
     ]
 
 
-print("%-22s %-8s %10s" % ("integrand", "solver", "hiprtc s"))
-for solver in ("vegas", "vegasmc", "mcmc"):
+if "--first-call" not in sys.argv:
+    print("%-22s %-8s %10s" % ("integrand", "solver", "hiprtc s"))
+for solver in ("vegas", "vegasmc", "mcmc") if "--first-call" not in sys.argv else ():
     for name, mk, f, meas in cases("1e-300 * %d" % (hash(solver) % 1000)):
         eng = mci.Engine(mk(), f, measure=meas, device=-1 if OFFLINE else 0)
         t0 = time.perf_counter()
         eng.compile(solver)
         print("%-22s %-8s %10.3f" % (name, solver, time.perf_counter() - t0), flush=True)
         eng.close()
-if not OFFLINE:
-    print("\nfirst integrate() of a new body (engine creation + JIT + 10 iterations of neval = 1e4), then the same call again:")
+if not OFFLINE and "--first-call" in sys.argv:   # (child process: one solver's first call, printed as one line)
+    solver = sys.argv[sys.argv.index("--first-call") + 1]
+    name, mk, f, meas = cases("2e-300 * %d" % (hash(solver) % 1000))[0]
+    t0 = time.perf_counter()
+    r = mci.integrate(f, config=mk(), solver=solver, neval=1e4, measure=meas, seed=1)
+    t1 = time.perf_counter()
+    r = mci.integrate(f, config=mk(), solver=solver, neval=1e4, measure=meas, seed=1)
+    t2 = time.perf_counter()
+    # (a second new body right after: nothing queues in front of its compile -- the persistent :vegas kernel's translation unit, 0.8 s of
+    # hiprtc on a thread of its own, starts only after 256 launch-bound calls of a process; when it was started by the second call this
+    # line read 0.69 s under :vegas, comgr serialising the two compiles)
+    name2, mk2, f2, meas2 = cases("3e-300 * %d" % (hash(solver) % 1000))[0]
+    t3 = time.perf_counter()
+    mci.integrate(f2, config=mk2(), solver=solver, neval=1e4, measure=meas2, seed=1)
+    t4 = time.perf_counter()
+    print("%-22s %-8s first %.3f s   again (code object cached, new engine) %.4f s   a second new body right after %.3f s   mean %s" % (
+        name, solver, t1 - t0, t2 - t1, t4 - t3, r.mean), flush=True)
+elif not OFFLINE:
+    print("\nfirst integrate() of a new body in a fresh process (engine creation + JIT + 10 iterations of neval = 1e4), the same call again,\n"
+          "and a second new body right after:", flush=True)
+    import subprocess
     for solver in ("vegas", "vegasmc", "mcmc"):
-        for name, mk, f, meas in cases("2e-300 * %d" % (hash(solver) % 1000))[:1]:
-            t0 = time.perf_counter()
-            r = mci.integrate(f, config=mk(), solver=solver, neval=1e4, measure=meas, seed=1)
-            t1 = time.perf_counter()
-            r = mci.integrate(f, config=mk(), solver=solver, neval=1e4, measure=meas, seed=1)
-            t2 = time.perf_counter()
-            print("%-22s %-8s first %.3f s   again (code object cached, new engine) %.4f s   mean %s" % (name, solver, t1 - t0, t2 - t1, r.mean), flush=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--first-call", solver], check=False)
 mci.shutdown()

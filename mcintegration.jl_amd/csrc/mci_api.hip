@@ -241,6 +241,8 @@ struct mci_problem {
     int last_wg = 0, last_threads = 0, last_nblocks = 0;
     int64_t last_nchain = 0; // chains per block of the last chain-solver launch
     int log_row = 0;
+    double *h_log = nullptr;  // pinned: mci_integrate's read-back of the iteration log (+ the status word behind it)
+    size_t cap_hlog = 0;
     // persistent :vegas iterations (mci_train.h vegas_persist; mci_set_persistent): its own code object -- the plain layout at
     // `threads` -- and the two grid-wide counters, which only grow (the host keeps their values)
     hipModule_t module_persist = nullptr;
@@ -862,6 +864,7 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->d_carry_W) (void)hipFree(p->d_carry_W);
         if (p->d_carry_src) (void)hipFree(p->d_carry_src);
         if (p->h_hold) (void)hipHostFree(p->h_hold);
+        if (p->h_log) (void)hipHostFree(p->h_log);
         for (auto &e : p->hold_ev)
             if (e) (void)hipEventDestroy(e);
         for (auto &e : p->cevs) (void)hipEventDestroy(e);
@@ -2369,14 +2372,27 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
         if ((rc = mci_iteration_reduce(p))) return rc;                                   // main.jl:177-188
         if ((rc = mci_iteration_finish(p, a->solver, block, a->adapt, a->gamma, nullptr, nullptr))) return rc; // main.jl:183-199
     }
-    std::vector<double> h((size_t)a->niter * p->nstat);
-    HIPCHK(hipMemcpyAsync(h.data(), p->d_iterlog + (size_t)row0 * p->nstat, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
-    if ((rc = check_status(p))) return rc;
+    // the statistics of all iterations and the status word come back behind the last kernel in ONE synchronisation, into pinned memory (a
+    // pageable destination goes through a staging copy: ~15 us of a 0.2 ms default-size call)
+    const size_t nlog = (size_t)a->niter * p->nstat;
+    if (nlog + 1 > p->cap_hlog) {
+        if (p->h_log) (void)hipHostFree(p->h_log);
+        p->h_log = nullptr;
+        p->cap_hlog = 0;
+        HIPCHK(hipHostMalloc((void **)&p->h_log, (nlog + 1) * sizeof(double), hipHostMallocDefault));
+        p->cap_hlog = nlog + 1;
+    }
+    double *h = p->h_log;
+    int *hstatus = reinterpret_cast<int *>(p->h_log + nlog);
+    HIPCHK(hipMemcpyAsync(h, p->d_iterlog + (size_t)row0 * p->nstat, nlog * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipMemcpyAsync(hstatus, p->d_status, sizeof(int), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    if (*hstatus && (rc = check_status(p))) return rc; // (reads it again, clears it, names the failure)
     auto t1 = std::chrono::steady_clock::now();
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
     res->neval = 0;
     for (int it = 0; it < a->niter; ++it) { // main.jl:203
-        const double *row = h.data() + (size_t)it * p->nstat;
+        const double *row = h + (size_t)it * p->nstat;
         mci_mean_std(row, row + s.nobs, s.nobs, block, res->iter_mean + (size_t)it * s.nobs, res->iter_std + (size_t)it * s.nobs);
         res->neval += (int64_t)row[2 * s.nobs + 1];
         if (res->visited && it == a->niter - 1) memcpy(res->visited, row + 2 * s.nobs + 2, (size_t)(s.ni + 1) * sizeof(double));

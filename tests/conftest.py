@@ -41,3 +41,17 @@ def pytest_sessionfinish(session, exitstatus):
     mod = sys.modules.get("mcintegration_jl_amd")
     if mod is not None:
         mod.shutdown()
+    session.config._mci_exitstatus = int(exitstatus)
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_unconfigure(config):
+    """A process that created BOTH the library's own RCCL communicator and a torch NCCL process group (tests/test_hip_battery.py) can
+    abort inside the C++ static destructors of RCCL / the HIP runtime after the interpreter is gone -- glibc "double free or corruption",
+    exit code 134 with every test passed (seen with exactly those tests selected, also on the code this round started from; outside this repository's
+    code: everything of ours has been released by then).  Like bench.py, such a process leaves through os._exit once pytest has
+    reported, with pytest's own exit status."""
+    if "torch.distributed" in sys.modules and hasattr(config, "_mci_exitstatus"):
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(config._mci_exitstatus)

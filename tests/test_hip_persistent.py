@@ -129,12 +129,14 @@ def test_persistent_launch_without_adaptation_and_many_iterations(oracle):
 def test_automatic_mode_takes_the_persistent_launch_for_launch_bound_calls_only():
     """integrate() at the reference's default size (neval = 1e4, main.jl:76) goes persistent once its code object exists; a call of
     1e7 samples, a chain solver, measurefreq != 1 and a forced geometry take the launch chain"""
-    src = "return x[0] * x[0] + x[1] * x[1];"
+    import os
+    import time
+    # (a body no kernel cache has seen: the rule below counts the calls of a kernel per process and skips the count when its code object exists)
+    src = "return x[0] * x[0] + x[1] * x[1] + 1e-300 * %d;" % (os.getpid() * 1000003 + int(time.time() * 1e3) % 1000003)
     cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
     res = mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
     eng = cfg._engine
     assert not eng.last_integrate_persistent()   # (a new kernel: its persistent form is not in the kernel cache, a few calls do not ask for it)
-    import time
     for k in range(2000):   # the 256th such call starts the larger translation unit on its own thread; the calls go on as a launch chain
         res = mci.integrate(src, config=cfg, solver="vegas", neval=1e4)
         if eng.last_integrate_persistent():

@@ -2360,6 +2360,16 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     if (!persist && (rc = compile_solver(p, kslot(a->solver, a->measurefreq)))) return rc;
     if ((rc = mci_set_reweight_goal(p, a->reweight_goal, a->reweight_goal ? p->ni + 1 : 0))) return rc;
     const int ignore = a->ignore >= 0 ? a->ignore : (a->adapt ? 1 : 0);
+    const size_t nlog = (size_t)a->niter * p->nstat; // the pinned landing place of the statistics (+ the status word), sized outside the timed loop
+    if (nlog + 1 > p->cap_hlog) {
+        size_t ncap = p->cap_hlog ? p->cap_hlog : (size_t)64 * p->nstat + 1;
+        while (ncap < nlog + 1) ncap *= 2;
+        if (p->h_log) (void)hipHostFree(p->h_log);
+        p->h_log = nullptr;
+        p->cap_hlog = 0;
+        HIPCHK(hipHostMalloc((void **)&p->h_log, ncap * sizeof(double), hipHostMallocDefault));
+        p->cap_hlog = ncap;
+    }
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     const int row0 = p->log_row;
     auto t0 = std::chrono::steady_clock::now();
@@ -2374,14 +2384,6 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     }
     // the statistics of all iterations and the status word come back behind the last kernel in ONE synchronisation, into pinned memory (a
     // pageable destination goes through a staging copy: ~15 us of a 0.2 ms default-size call)
-    const size_t nlog = (size_t)a->niter * p->nstat;
-    if (nlog + 1 > p->cap_hlog) {
-        if (p->h_log) (void)hipHostFree(p->h_log);
-        p->h_log = nullptr;
-        p->cap_hlog = 0;
-        HIPCHK(hipHostMalloc((void **)&p->h_log, (nlog + 1) * sizeof(double), hipHostMallocDefault));
-        p->cap_hlog = nlog + 1;
-    }
     double *h = p->h_log;
     int *hstatus = reinterpret_cast<int *>(p->h_log + nlog);
     HIPCHK(hipMemcpyAsync(h, p->d_iterlog + (size_t)row0 * p->nstat, nlog * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));

@@ -424,6 +424,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
         MCI_TT(1)
         if (!staged) train_stage_grid(L, sm, edges);
         // smooth(hist, 6)  common.jl:43-54
+        double mine = 0.0; // (prefix-scan form: the sum of the smoothed bins rides along, thread by thread, instead of a pass of its own)
         for (int i = tid; i < N; i += T) {
             double v;
             if (N <= 1) v = h[i];
@@ -431,13 +432,26 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             else if (i == N - 1) v = (h[N - 1] * 7.0 + h[N - 2]) / 8.0;
             else v = (h[i - 1] + h[i] * 6.0 + h[i + 1]) / 8.0;
             d[i] = v;
+            mine += v;
+        }
+        if (!serial_walk) {
+            const double w = wave_sum(mine);
+            if ((tid & 63) == 0) ps[32 + (tid >> 6)] = w;
         }
         __syncthreads();
         MCI_TT(2)
         // rescale  common.jl:67-82
         if (N > 1) {
-            const double s = sum_julia(d, N); // :72
-            __syncthreads(); // every 16-lane group reads ALL of d[] for its total: nobody overwrites d[] before the last group is through
+            // sum(dist) :72 -- the serial form sums like Julia does (sum_julia: what the bit-for-bit walk starts from); the prefix-scan form,
+            // which rounds differently from the reference's recurrence anyway, takes the waves' partial sums in a fixed order
+            double s;
+            if (serial_walk) {
+                s = sum_julia(d, N);
+                __syncthreads(); // every 16-lane group reads ALL of d[] for its total: nobody overwrites d[] before the last group is through
+            } else {
+                s = 0.0;
+                for (int w = 0; w < (T >> 6); ++w) s += ps[32 + w];
+            }
             MCI_TT(3)
             int anybad = 0;
             auto rescale_bins = [&](auto power) { // power(b) = b ^ alpha (rescale_pow, its exponent decided once for the leaf)

@@ -2106,8 +2106,8 @@ bool persist_layout(const mci_problem *p) {
 }
 // Which calls run persistently, and on how many workgroups per block: one rank, :vegas at measurefreq == 1, the prefix-scan walk, no
 // forced geometry or timing, a grid that is co-resident next to another one like it (<= 128 sampling workgroups + the statistics one).
-// Automatic mode adds: light launches only (samples x draws below 2^19 per iteration: 13.8 against 16.1 us per iteration at neval = 1e4 of
-// a 2-D integrand, 15.6 against 17.7 at 1e5 -- beyond that the sample pass weighs in and the launch-per-iteration chain brings its
+// Automatic mode adds: light launches only (samples x draws below 2^19 per iteration: 11.8 against 14.2 us per iteration at neval = 1e4 of
+// a 2-D integrand, 13.9 against 15.6 at 1e5 -- beyond that the sample pass weighs in and the launch-per-iteration chain brings its
 // tuned layouts, histogram copies and 512-thread workgroups: the 16-D Gaussian at 1e5 22.3 us there, 27.4 here; tools/latency.py).
 bool persist_plan(const mci_problem *p, const mci_integrate_args *a, int64_t nevalperblock, int64_t nblocks, int *wpb_out) {
     const auto &s = p->shape;

@@ -691,8 +691,8 @@ __device__ inline void iteration_bookkeeping(const TrainArgs &a) {
 //                          turn before; in the last turn leaves the merged histogram / clearStatistics! state in `packed`         ->  done
 //
 // The waits are counters in HBM that only grow (targets are computed from the launch's starting values; nothing is reset between
-// launches); a workgroup publishes with  barrier -> agent-scope release fence -> relaxed atomic add  by its first thread and consumes
-// with  relaxed atomic load -> agent-scope acquire fence -> barrier  (those fences write back / invalidate the XCD's L2).
+// launches); a workgroup publishes with  every wave's s_waitcnt vmcnt(0) -> barrier -> agent-scope release fence + relaxed atomic add by
+// its first thread  and consumes with  relaxed atomic load -> agent-scope acquire fence -> barrier  (those fences write back / invalidate the XCD's L2).
 // Three histogram buffers: buffer t % 3 is added to in turn t, read by everybody after the arrive of turn t, zeroed by the statistics
 // workgroup after the arrive of turn t + 1 (all its readers have arrived there) and next added to in turn t + 3.  Two partial-row buffers:
 // the rows of turn t are read by the statistics workgroup, which every sampling workgroup checks has finished turn t - 1 -- rows merged,
@@ -740,7 +740,14 @@ __device__ __forceinline__ bool persist_wait(const PersistArgs &f, u64 t0, u64 t
     __syncthreads();
     return *verdict != 0;
 }
-__device__ __forceinline__ void persist_signal(u64 *ctr, u64 inc) { // (after a __syncthreads(): every thread's stores have been issued and acknowledged)
+// Publish: EVERY wave first waits until its own stores and atomics have been performed (s_waitcnt vmcnt(0): a workgroup barrier alone
+// orders global memory only through the CU's in-order path to each L2 channel, and the counter lives on another channel than the data;
+// gfx9 counts stores and atomics without return in vmcnt), then the barrier, then the first thread writes the XCD's L2 back
+// (agent-scope release fence: every wave's stores have reached it) and counts the workgroup in.  (A release fence by every wave instead
+// -- four buffer_wbl2 per workgroup -- costs 1.3 us more per turn.)
+__device__ __forceinline__ void persist_signal(u64 *ctr, u64 inc) {
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(ctr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

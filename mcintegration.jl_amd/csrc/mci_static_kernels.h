@@ -59,9 +59,11 @@ __global__ void __launch_bounds__(256) k_finalize(MergeArgs m) {
 // Carried :mcmc chains (this engine's many-chain decomposition; DESIGN.md "Chains"): which stored chain every chain of the next launch
 // continues.  The chains a block stored are a sample of the finished iteration's target ~ reweight_old[idx] |f_idx(x)|; doReweight! has
 // moved the factors since, so the next target differs from it by the known ratio w[idx] = reweight_new[idx] / reweight_old[idx]:
-// systematic resampling of the block's stored chains (chain order, offset 1/2 -- deterministic) with probability ~ w[curr].
+// systematic resampling of the block's stored chains (chain order, one fixed offset u -- deterministic) with probability ~ w[curr].
 //   W[j] = sum_i w[i] * #(stored chains j' <= j that ended on integrand i)        (added over i = 0 .. nd-1 in that order)
-//   new chain c continues the first stored chain j with W[j] > (c + 1/2) * (W[n_old-1] / n_new)
+//   new chain c continues the first stored chain j with W[j] > (c + u) * (W[n_old-1] / n_new),  u = (sqrt(5) - 1) / 2  (with u = 1/2
+//   many chain counts make (c + u) n_old / n_new an integer: exact ties, decided by the last bit of w, whenever a block's stored chains
+//   all sit on one integrand)
 // One workgroup per block; mirrored by mcio_resample_chains (same operations in the same order: same picks).
 struct ResampleArgs {
     const int *curr_old;   // [nblocks][n_old]
@@ -97,7 +99,7 @@ __global__ void __launch_bounds__(256) k_resample_chains(ResampleArgs a) {
     __syncthreads();
     const double step = W[a.n_old - 1] / (double)a.n_new;
     for (long long c = tid; c < a.n_new; c += T) {
-        const double target = ((double)c + 0.5) * step;
+        const double target = ((double)c + 0.6180339887498949) * step;
         long long lo = 0, hi = a.n_old - 1; // smallest j with W[j] > target
         while (lo < hi) {
             const long long mid = (lo + hi) >> 1;

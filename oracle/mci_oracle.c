@@ -1579,11 +1579,13 @@ void mcio_result_destroy(mcio_result *r) {
  * block stored at the end of an iteration are a sample of that iteration's target pi_k(idx, x) ~ reweight_k[idx] |f_idx(x)|; doReweight!
  * has since moved the factors (main.jl:322-346), so the next iteration's target differs from it by exactly the known ratio
  * w[idx] = reweight_{k+1}[idx] / reweight_k[idx].  The new chains therefore continue stored chains drawn with probability ~ w[curr]
- * (systematic resampling over the block's stored chains in chain order, offset 1/2: deterministic): a start population distributed like
+ * (systematic resampling over the block's stored chains in chain order, one fixed offset: deterministic): a start population distributed like
  * the NEW target, which also takes back the visit fluctuation the new factors were computed from -- chains carried as they are start
  * over-represented exactly where the new factors say "fewer" (measured: 2 sigma per run on BASELINE configs[4]).
  *   W[j] = sum_i w[i] * #(stored chains j' <= j that ended on integrand i)     (sum over i = 0 .. Nd-1 in that order)
- *   new chain c continues the first stored chain j with W[j] > (c + 1/2) * (W[n_old-1] / n_new)                              */
+ *   new chain c continues the first stored chain j with W[j] > (c + u) * (W[n_old-1] / n_new),  u = (sqrt(5) - 1) / 2
+ * (any offset in [0, 1) is a valid systematic resampling; 1/2 makes (c + u) n_old / n_new an integer for many chain counts -- with all
+ * stored chains on one integrand the comparison is then an exact tie, decided by the last bit of w)                                  */
 void mcio_resample_chains(const int *curr_old, long n_old, int nd, const double *rw_now, const double *rw_used, long n_new, long *src) {
     double w[65];
     long cnt[65]; /* (nd <= 64: the integrands of a draw are a 64-bit mask) */
@@ -1600,7 +1602,7 @@ void mcio_resample_chains(const int *curr_old, long n_old, int nd, const double 
     }
     const double step = W[n_old - 1] / (double)n_new;
     for (long c = 0; c < n_new; ++c) {
-        const double target = ((double)c + 0.5) * step;
+        const double target = ((double)c + 0.6180339887498949) * step;
         long lo = 0, hi = n_old - 1; /* smallest j with W[j] > target */
         while (lo < hi) {
             const long mid = (lo + hi) >> 1;

@@ -93,3 +93,100 @@ def check_persistent_call(oracle, case_id, seed=20260930):
         np.testing.assert_allclose(g, og, rtol=0, atol=1e-5 * (og[-1] - og[0]), err_msg=what + " (map)")
     eng.close()
     return what, persistent
+
+
+def random_case(rng):
+    npool = int(rng.integers(1, 6))
+    ni = int(rng.integers(1, 5))
+    var, oleaves, pool_nleaf = [], [], []
+    for v in range(npool):
+        kind = rng.choice(["cont", "cont", "disc", "comp", "comp2"])
+        if kind == "cont":
+            lo, hi = float(rng.uniform(-2, 0)), float(rng.uniform(0.5, 3))
+            ninc = int(rng.choice([17, 100, 257, 1000, 2000]))
+            alpha = float(rng.choice([0.5, 1.0, 2.0, 3.0]))
+            adapt = bool(rng.integers(0, 4) > 0)
+            var.append(mci.Continuous(lo, hi, alpha=alpha, ninc=ninc, adapt=adapt))
+            oleaves.append(dict(kind=0, pool=v, lower=lo, upper=hi, npts=ninc, alpha=alpha, adapt=adapt))
+            pool_nleaf.append(1)
+        elif kind == "disc":
+            lo = int(rng.integers(0, 3))
+            hi = lo + int(rng.integers(0, 9))
+            adapt = bool(rng.integers(0, 2))
+            var.append(mci.Discrete(lo, hi, adapt=adapt))
+            oleaves.append(dict(kind=1, pool=v, lower=lo, upper=hi, adapt=adapt))
+            pool_nleaf.append(1)
+        elif kind == "comp":
+            a = (float(rng.uniform(-1, 0)), float(rng.uniform(0.5, 2)))
+            b = (int(rng.integers(1, 3)), int(rng.integers(3, 6)))
+            var.append(mci.CompositeVar(mci.Continuous(*a), mci.Discrete(*b)))
+            oleaves.append(dict(kind=0, pool=v, lower=a[0], upper=a[1]))
+            oleaves.append(dict(kind=1, pool=v, lower=b[0], upper=b[1]))
+            pool_nleaf.append(2)
+        else:
+            a = (float(rng.uniform(-1, 0)), float(rng.uniform(0.5, 2)))
+            c = (float(rng.uniform(0, 1)), float(rng.uniform(1.5, 4)))
+            b = (int(rng.integers(0, 2)), int(rng.integers(2, 5)))
+            n2 = int(rng.choice([50, 1000]))
+            var.append(mci.CompositeVar(mci.Continuous(*a), mci.Discrete(*b), mci.Continuous(*c, ninc=n2, alpha=1.5)))
+            oleaves.append(dict(kind=0, pool=v, lower=a[0], upper=a[1]))
+            oleaves.append(dict(kind=1, pool=v, lower=b[0], upper=b[1]))
+            oleaves.append(dict(kind=0, pool=v, lower=c[0], upper=c[1], npts=n2, alpha=1.5))
+            pool_nleaf.append(3)
+    dof = [[int(rng.integers(0, 5)) for _ in range(npool)] for _ in range(ni)]
+    for i in range(ni):
+        if sum(dof[i]) == 0:
+            dof[i][int(rng.integers(0, npool))] = 1
+    maxdof = [max(d[v] for d in dof) for v in range(npool)]
+    draws = [(v, s, l) for v in range(npool) for s in range(maxdof[v]) for l in range(pool_nleaf[v])]
+    lines = []
+    for i in range(ni):
+        own = [k for k, (v, s, l) in enumerate(draws) if s < dof[i][v]]
+        coef = rng.uniform(0.2, 1.5, size=len(own))
+        arg = " + ".join("%.6f * x[%d]" % (c, k) for c, k in zip(coef, own))
+        sign = "-" if rng.integers(0, 4) == 0 else ""           # some integrands change sign
+        lines.append("w[%d] = %s(%.3f + 0.5 * cos(%s) + 0.05 * x[%d] * x[%d]);" % (i, sign, 0.4 + 0.3 * i, arg, own[0], own[-1]))
+    return tuple(var), oleaves, dof, "\n".join(lines), len(draws)
+
+
+def check_carried_iterations(oracle, case_id, seed=20260930):
+    """consecutive iterations of both chain solvers on a random layout (1-5 pools of Continuous / Discrete / CompositeVar, 1-4 integrands,
+    ragged dof), with doReweight! and train! in between and a chain count that changes from one iteration to the next: carried chains
+    (mci_set_chain_carry; :mcmc: the stored chains resampled to the moved reweight factors, k_resample_chains | mcio_resample_chains)
+    against the oracle's mirror -- packed sums and histograms, the reweight factors, the holding-time histogram"""
+    import numpy as np
+    rng = np.random.default_rng(11000 + case_id)
+    var, oleaves, dof, body, ndraw = random_case(rng)
+    nblk = int(rng.integers(1, 5))
+    npb = int(rng.choice([1200, 2400, 4800]))
+    counts = [int(rng.choice([2, 5, 8, 16, 40])) for _ in range(4)]
+    mfreq = int(rng.choice([1, 1, 3]))
+    what = "case %d: pools=%d ni=%d ndraw=%d blocks=%d npb=%d nchain=%s measurefreq=%d" % (case_id, len(var), len(dof), ndraw, nblk, npb, counts, mfreq)
+    oracle.set_rng_rounds(10)
+    fn = oracle.compile_c_integrand(body)
+    ni = len(dof)
+    for solver, osolver in (("vegasmc", oracle.VEGASMC), ("mcmc", oracle.MCMC)):
+        cfg = mci.Configuration(var=var, dof=dof, seed=seed)
+        eng = mci.Engine(cfg, mci.Integrand(body))
+        ocfg = oracle.Config(oleaves, dof)
+        n = eng.nobs
+        nstat = 2 * n + 2 + ni + 1
+        kw = {}
+        if solver == "mcmc":
+            ocfg.set_thermal_ratio(0.1)
+            kw = dict(thermal_ratio=0.1)
+        for it, nch in enumerate(counts):
+            got = eng.iteration(solver, npb, 0, nblk, iteration=it, seed=seed, measurefreq=mfreq, nchain=nch, **kw)
+            ref = ocfg.iteration(osolver, fn, None, npb, 0, nblk, it, seed, measurefreq=mfreq, nchain=nch)
+            assert eng.last_chain_launch() == (nch, it > 0), (what, solver, it, eng.last_chain_launch())
+            # (every train! in between amplifies the rounding-level difference of the two maps by an order of magnitude or two)
+            np.testing.assert_allclose(got[:nstat], ref[:nstat], rtol=1e-8 * 10 ** it, atol=1e-300, err_msg="%s %s iteration %d" % (what, solver, it))
+            np.testing.assert_allclose(got[nstat:], ref[nstat:], rtol=1e-7 * 10 ** it, err_msg="%s %s iteration %d (histograms)" % (what, solver, it))
+            if solver == "mcmc":
+                np.testing.assert_array_equal(eng.hold_histogram(), ocfg.hold_hist, err_msg="%s iteration %d" % (what, it))
+            eng.finish(solver, nblk, adapt=True)
+            ocfg.set_reweight(oracle.do_reweight(ocfg.reweight, ref[2 * n + 2: 2 * n + 2 + ni + 1]))
+            ocfg.train()
+            np.testing.assert_allclose(eng.reweight(), ocfg.reweight, rtol=1e-8 * 10 ** it, err_msg=what)
+        eng.close()
+    return what

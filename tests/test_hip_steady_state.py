@@ -19,7 +19,7 @@ import pytest
 
 import mcintegration_jl_amd as mci
 from catalog_params import bubble_userdata, genz_userdata
-from layout_cases import pipe_case
+from layout_cases import check_carried_iterations, pipe_case
 
 pytestmark = pytest.mark.gpu
 PI = math.pi
@@ -302,6 +302,15 @@ def test_carried_chains_match_oracle(oracle, name, solver):
     eng2.set_chain_carry("off")
     again = eng2.iteration(solver, npb, 0, block, iteration=3, seed=SEED, nchain=8, **kw)
     np.testing.assert_allclose(got, again, rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.parametrize("case_id", [3, 8, 15, 69, 108, 129, 200, 257])
+def test_carried_chains_on_random_layouts_match_oracle(oracle, case_id):
+    """eight cases of the randomised campaign (tools/fuzz_layouts.py --carry, profiles/r03_fuzz_carry.txt: 300 cases): 1-5 pools, 1-4
+    integrands, four consecutive iterations of :vegasmc and of :mcmc with carried chains, chain counts that grow and shrink between
+    iterations (the resampling of stored :mcmc chains picks every new chain's ancestor), doReweight! and train! in between"""
+    check_carried_iterations(oracle, case_id)
+    oracle.set_rng_rounds(10)
 
 
 @pytest.mark.parametrize("solver", ["vegas", "vegasmc", "mcmc"])

@@ -5,9 +5,10 @@ Every case draws a layout (1-5 pools of Continuous / Discrete / CompositeVar, 1-
 2000 increments), a launch shape (blocks, steps per block, chains per block, measure cadence, iteration number) and a generator
 (Philox4x32-10 or -7), JIT-compiles the three sample-batch kernels for it and compares one iteration of each solver with the oracle on
 the same Philox streams: packed sums and histograms to 1e-9 relative, holding-time histogram bucket by bucket, then a three-iteration
-:vegas run with train! in between.  Failures are collected, not fatal.   usage: fuzz_layouts.py [--pipe | --persist] [first_case] [ncases]
+:vegas run with train! in between.  Failures are collected, not fatal.   usage: fuzz_layouts.py [--pipe | --persist | --carry] [first_case] [ncases]
 (--pipe: layouts of the pipelined :vegas loop only; --persist: whole integrate() calls over one Continuous variable type run as ONE
-persistent launch, against the oracle's loop)"""
+persistent launch, against the oracle's loop; --carry: four consecutive iterations of :vegasmc and :mcmc with carried chains -- :mcmc:
+resampled to the moved reweight factors -- and a changing chain count, doReweight! and train! in between)"""
 import os
 import sys
 import time
@@ -23,65 +24,12 @@ import mci_oracle as oracle
 SEED = 20260930
 
 
-def random_case(rng):
-    npool = int(rng.integers(1, 6))
-    ni = int(rng.integers(1, 5))
-    var, oleaves, pool_nleaf = [], [], []
-    for v in range(npool):
-        kind = rng.choice(["cont", "cont", "disc", "comp", "comp2"])
-        if kind == "cont":
-            lo, hi = float(rng.uniform(-2, 0)), float(rng.uniform(0.5, 3))
-            ninc = int(rng.choice([17, 100, 257, 1000, 2000]))
-            alpha = float(rng.choice([0.5, 1.0, 2.0, 3.0]))
-            adapt = bool(rng.integers(0, 4) > 0)
-            var.append(mci.Continuous(lo, hi, alpha=alpha, ninc=ninc, adapt=adapt))
-            oleaves.append(dict(kind=0, pool=v, lower=lo, upper=hi, npts=ninc, alpha=alpha, adapt=adapt))
-            pool_nleaf.append(1)
-        elif kind == "disc":
-            lo = int(rng.integers(0, 3))
-            hi = lo + int(rng.integers(0, 9))
-            adapt = bool(rng.integers(0, 2))
-            var.append(mci.Discrete(lo, hi, adapt=adapt))
-            oleaves.append(dict(kind=1, pool=v, lower=lo, upper=hi, adapt=adapt))
-            pool_nleaf.append(1)
-        elif kind == "comp":
-            a = (float(rng.uniform(-1, 0)), float(rng.uniform(0.5, 2)))
-            b = (int(rng.integers(1, 3)), int(rng.integers(3, 6)))
-            var.append(mci.CompositeVar(mci.Continuous(*a), mci.Discrete(*b)))
-            oleaves.append(dict(kind=0, pool=v, lower=a[0], upper=a[1]))
-            oleaves.append(dict(kind=1, pool=v, lower=b[0], upper=b[1]))
-            pool_nleaf.append(2)
-        else:
-            a = (float(rng.uniform(-1, 0)), float(rng.uniform(0.5, 2)))
-            c = (float(rng.uniform(0, 1)), float(rng.uniform(1.5, 4)))
-            b = (int(rng.integers(0, 2)), int(rng.integers(2, 5)))
-            n2 = int(rng.choice([50, 1000]))
-            var.append(mci.CompositeVar(mci.Continuous(*a), mci.Discrete(*b), mci.Continuous(*c, ninc=n2, alpha=1.5)))
-            oleaves.append(dict(kind=0, pool=v, lower=a[0], upper=a[1]))
-            oleaves.append(dict(kind=1, pool=v, lower=b[0], upper=b[1]))
-            oleaves.append(dict(kind=0, pool=v, lower=c[0], upper=c[1], npts=n2, alpha=1.5))
-            pool_nleaf.append(3)
-    dof = [[int(rng.integers(0, 5)) for _ in range(npool)] for _ in range(ni)]
-    for i in range(ni):
-        if sum(dof[i]) == 0:
-            dof[i][int(rng.integers(0, npool))] = 1
-    maxdof = [max(d[v] for d in dof) for v in range(npool)]
-    draws = [(v, s, l) for v in range(npool) for s in range(maxdof[v]) for l in range(pool_nleaf[v])]
-    lines = []
-    for i in range(ni):
-        own = [k for k, (v, s, l) in enumerate(draws) if s < dof[i][v]]
-        coef = rng.uniform(0.2, 1.5, size=len(own))
-        arg = " + ".join("%.6f * x[%d]" % (c, k) for c, k in zip(coef, own))
-        sign = "-" if rng.integers(0, 4) == 0 else ""           # some integrands change sign
-        lines.append("w[%d] = %s(%.3f + 0.5 * cos(%s) + 0.05 * x[%d] * x[%d]);" % (i, sign, 0.4 + 0.3 * i, arg, own[0], own[-1]))
-    return tuple(var), oleaves, dof, "\n".join(lines), len(draws)
-
-
-from layout_cases import check_persistent_call, pipe_case  # noqa: E402  (shared with tests/test_hip_steady_state.py, test_hip_persistent.py)
+from layout_cases import check_carried_iterations, check_persistent_call, pipe_case, random_case  # noqa: E402  (shared with tests/test_hip_steady_state.py, test_hip_persistent.py)
 
 
 PIPE_MODE = False
 PERSIST_MODE = False
+CARRY_MODE = False
 npersist = 0
 
 
@@ -139,13 +87,16 @@ if __name__ == "__main__":
     if "--persist" in sys.argv:   # whole integrate() calls over one Continuous variable type as one persistent launch
         sys.argv.remove("--persist")
         PERSIST_MODE = True
+    if "--carry" in sys.argv:     # four consecutive iterations of both chain solvers with carried chains and changing chain counts
+        sys.argv.remove("--carry")
+        CARRY_MODE = True
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     oracle.build()
     bad, t0 = [], time.time()
     for c in range(first, first + n):
         try:
-            w = run_persist_case(c) if PERSIST_MODE else run_case(c)
+            w = run_persist_case(c) if PERSIST_MODE else check_carried_iterations(oracle, c, SEED) if CARRY_MODE else run_case(c)
             print("ok   " + w, flush=True)
         except Exception as e:  # collect and go on
             bad.append(c)

@@ -165,3 +165,29 @@ def test_random_persistent_calls_match_oracle(oracle, case_id):
     what, persistent = check_persistent_call(oracle, case_id)
     assert persistent, what
     oracle.set_rng_rounds(10)
+
+
+def test_two_processes_share_the_device_with_persistent_launches():
+    """co-residency: a persistent grid is at most 129 workgroups of <= 64 KiB of LDS, so two of them (two processes on one GPU, the way
+    two ranks of a test job share a device) fit the chip together and neither stalls in its grid-wide waits (a stall would fail the call
+    with MCI_ERR_HIP after 2 s); both get the single-process numbers"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import mcintegration_jl_amd as mci\n"
+            "cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]], seed=11)\n"
+            "eng = mci.Engine(cfg, mci.catalog.x2y2()); eng.set_persistent('on')\n"
+            "out = []\n"
+            "for k in range(300):\n"
+            "    r = eng.integrate('vegas', neval=100000, niter=20, block=16, seed=11, first_iteration=20 * k)\n"
+            "    assert eng.last_integrate_persistent()\n"
+            "    out.append(r['mean'][0])\n"
+            "print('%%.17g %%.17g' %% (out[0], out[-1]))\n" % root)
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    a, b = (tuple(float(v) for v in so.split()) for so, _ in outs)
+    assert abs(a[0] - 2.0 / 3.0) < 1e-3 and abs(a[1] - 2.0 / 3.0) < 1e-3
+    np.testing.assert_allclose(a, b, rtol=1e-6)   # same seeds, same iterations: the same runs up to the order of the histogram atomics

@@ -132,6 +132,8 @@ def lib():
     L.mcio_average.argtypes = [c_double_p, c_double_p, C.c_long, C.c_long, C.c_long, C.c_long, c_double_p,
                                c_double_p, c_double_p]
     L.mcio_do_reweight.argtypes = [c_double_p, c_double_p, C.c_long, C.c_double, c_double_p]
+    L.mcio_resample_chains.argtypes = [C.POINTER(C.c_int), C.c_long, C.c_int, c_double_p, c_double_p, C.c_long, C.POINTER(C.c_long)]
+    L.mcio_resample_chains.restype = None
     L.mcio_integrate.argtypes = [C.POINTER(_Config), C.c_int, C.c_void_p, c_double_p, C.c_long, C.c_int, C.c_long,
                                  C.c_int, C.c_int, C.c_double, C.c_long, C.c_uint64, C.c_int, C.c_long,
                                  C.POINTER(_Result)]
@@ -251,6 +253,15 @@ def do_reweight(reweight, visited, gamma=1.0, goal=None):
     g = None if goal is None else np.ascontiguousarray(goal, dtype=np.float64)
     lib().mcio_do_reweight(_dp(r), _dp(v), len(r), float(gamma), None if g is None else _dp(g))
     return r
+
+
+def resample_chains(curr_old, rw_now, rw_used, n_new):
+    """which stored chain every chain of the next :mcmc launch continues (mcio_resample_chains; mirror of k_resample_chains)"""
+    co = np.ascontiguousarray(curr_old, dtype=np.int32)
+    a, b = np.ascontiguousarray(rw_now, dtype=np.float64), np.ascontiguousarray(rw_used, dtype=np.float64)
+    src = (C.c_long * int(n_new))()
+    lib().mcio_resample_chains(co.ctypes.data_as(C.POINTER(C.c_int)), len(co), len(a), _dp(a), _dp(b), int(n_new), src)
+    return np.array(list(src), dtype=np.int64)
 
 
 def builtin(name):

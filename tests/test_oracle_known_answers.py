@@ -306,3 +306,36 @@ def test_mcmc_burnin_rule(oracle):
     assert L.mcio_mcmc_burnin(62500, 1, 3, 3, 1, 0.0) == 0
     assert L.mcio_mcmc_burnin(4000, 8, 3, 3, 1, 0.1) == 400            # floor 64*3 + 16*2*3 = 288 < 400
     assert L.mcio_mcmc_burnin(1000, 8, 12, 5, 1, 0.1) == 928           # the floor is not capped: burn-in steps are extra
+
+
+def test_resampling_of_carried_mcmc_chains(oracle):
+    """mcio_resample_chains (mirror of k_resample_chains): the stored chains of a block, a sample of the finished iteration's target, are
+    resampled with probability ~ reweight_new[idx] / reweight_old[idx] (doReweight! has moved the factors, main.jl:322-346) into the
+    start population of the next launch -- systematic resampling along the chain order, offset (sqrt 5 - 1) / 2."""
+    rng = np.random.default_rng(5)
+    # nothing moved, same count: every chain continues itself
+    curr = rng.integers(0, 4, size=1000)
+    rw = np.array([0.1, 0.2, 0.3, 0.4])
+    assert np.array_equal(oracle.resample_chains(curr, rw, rw, 1000), np.arange(1000))
+    # nothing moved, twice the chains: every stored chain is continued twice; half the chains: every second one
+    assert np.array_equal(np.bincount(oracle.resample_chains(curr, rw, rw, 2000), minlength=1000), np.full(1000, 2))
+    half = oracle.resample_chains(curr, rw, rw, 500)
+    assert np.all(np.diff(half) == 2)
+    # moved factors: the picks are monotone in the chain order, every stored chain is continued floor or ceil of its expected number of
+    # times n_new w[curr] / sum(w) (systematic resampling), and a ratio of zero leaves nobody on that integrand
+    new = np.array([0.05, 0.4, 0.3, 0.25])
+    w = new / rw
+    for n_new in (1000, 137, 4096):
+        src = oracle.resample_chains(curr, new, rw, n_new)
+        assert np.all(np.diff(src) >= 0) and src.min() >= 0 and src.max() < 1000
+        expect = n_new * w[curr] / w[curr].sum()
+        copies = np.bincount(src, minlength=1000)
+        assert np.all(copies >= np.floor(expect - 1e-9)) and np.all(copies <= np.ceil(expect + 1e-9)), n_new
+        assert abs(np.bincount(curr[src], minlength=4)[1] / n_new - (np.bincount(curr, minlength=4) * w)[1] / w[curr].sum()) < 0.02
+    src = oracle.resample_chains(curr, np.array([0.0, 0.5, 0.3, 0.2]), rw, 777)
+    assert not np.any(curr[src] == 0)
+    # all stored chains on one integrand and a chain count that made offset 1/2 an exact tie (16 -> 5: target 2.5 * 16 / 5 = 8): the pick
+    # does not depend on the last bit of the ratio
+    one = np.zeros(16, dtype=np.int64)
+    picks = {tuple(oracle.resample_chains(one, np.array([r, 1.0 - r]), np.array([0.5, 0.5]), 5)) for r in (0.3, 0.3 * (1 + 2e-16), 0.3 * (1 - 2e-16), 0.7)}
+    assert len(picks) == 1

@@ -2106,9 +2106,11 @@ bool persist_layout(const mci_problem *p) {
 }
 // Which calls run persistently, and on how many workgroups per block: one rank, :vegas at measurefreq == 1, the prefix-scan walk, no
 // forced geometry or timing, a grid that is co-resident next to another one like it (<= 128 sampling workgroups + the statistics one).
-// Automatic mode adds: light launches only (samples x draws below 2^19 per iteration: 11.8 against 14.2 us per iteration at neval = 1e4 of
-// a 2-D integrand, 13.9 against 15.6 at 1e5 -- beyond that the sample pass weighs in and the launch-per-iteration chain brings its
-// tuned layouts, histogram copies and 512-thread workgroups: the 16-D Gaussian at 1e5 22.3 us there, 27.4 here; tools/latency.py).
+// Automatic mode adds: launches of samples x draws < 2^20 per iteration over at most 7 draws per sample (tools/latency.py and a sweep of
+// sizes and dimensions, us per iteration persistent | as a launch chain: 2-D 11.8 | 14.2 at neval = 1e4, 13.9 | 15.6 at 1e5, 19.6 | 21.3 at
+// 5e5, 23.3 | 22.9 at 1e6; 6-D 13.6 | 16.3 at 1e4, 17.3 | 18.5 at 8e4; 8-D 15.9 | 16.9 and 17.3 | 16.8; 16-D 18.3 | 17.1 at 1e4 and
+// 25.4 | 21.9 at 1e5 -- from 8 draws on the launch chain runs the hand-pipelined loop on its tuned layout, histogram copies and 512-thread
+// workgroups, which this kernel's plain 256-thread layout does not match).
 bool persist_plan(const mci_problem *p, const mci_integrate_args *a, int64_t nevalperblock, int64_t nblocks, int *wpb_out) {
     const auto &s = p->shape;
     if (p->persistent == 0 || p->persist_failed) return false;
@@ -2117,7 +2119,7 @@ bool persist_plan(const mci_problem *p, const mci_integrate_args *a, int64_t nev
     if (!persist_layout(p)) return false;
     if (p->wg_per_block > 0 || p->kernel_timing > 0 || p->train_serial == 1) return false;
     const int64_t work = nevalperblock * nblocks * s.ndraw;
-    if (p->persistent < 0 && work >= ((int64_t)1 << 19)) return false;
+    if (p->persistent < 0 && (work >= ((int64_t)1 << 20) || s.ndraw > 7)) return false;
     const int T = p->threads;
     int64_t target = work < ((int64_t)1 << 19) ? 64 : 128;
     int64_t wpb = (target + nblocks - 1) / nblocks;

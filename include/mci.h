@@ -294,7 +294,7 @@ int mci_last_chain_launch(const mci_problem *prob, int64_t *nchain, int32_t *car
 /* Persistent :vegas iterations.  The reference's loop (main.jl:142-207) at the reference's own default size (neval = 1e4, main.jl:76)
  * is launch-bound on a GPU: a microsecond of sampling per iteration behind two dependent kernel launches.  With mode -1 (default) a
  * single-rank mci_integrate call of solver MCI_VEGAS at measurefreq == 1 over ONE Continuous variable type whose iterations are that
- * small (samples x draws < 2^20, at most 7 draws per sample) runs ALL its iterations as one launch of at most 128 co-resident sampling workgroups + one statistics
+ * small (samples x draws < 2^19, at most 7 draws per sample) runs ALL its iterations as one launch of at most 128 co-resident sampling workgroups + one statistics
  * workgroup (csrc/mci_train.h vegas_persist): sample -> histograms merged with global atomics -> one grid-wide wait -> every sampling
  * workgroup runs train! on its OWN copy of the map (same arithmetic on the same numbers: the copies stay bit-identical) while the
  * statistics workgroup merges the blocks -> next iteration.  Same Philox streams and the same arithmetic as the launch chain (sums

@@ -249,6 +249,7 @@ struct mci_problem {
     hipFunction_t f_persist = nullptr;
     bool persist_compiled = false, persist_failed = false;
     std::string persist_code_object;
+    int persist_threads = 256;    // its workgroup size: 512 for the hand-pipelined loops (8..16 draws), else `threads`
     // its translation unit takes twice as long to compile as the plain sample kernel (train! comes with it): in automatic mode a code
     // object that is not in the kernel cache is compiled on a thread of its own while the calls go through the launch chain
     struct PersistJob;
@@ -2106,11 +2107,11 @@ bool persist_layout(const mci_problem *p) {
 }
 // Which calls run persistently, and on how many workgroups per block: one rank, :vegas at measurefreq == 1, the prefix-scan walk, no
 // forced geometry or timing, a grid that is co-resident next to another one like it (<= 128 sampling workgroups + the statistics one).
-// Automatic mode adds: launches of samples x draws < 2^20 per iteration over at most 7 draws per sample (tools/latency.py and a sweep of
-// sizes and dimensions, us per iteration persistent | as a launch chain: 2-D 11.8 | 14.2 at neval = 1e4, 13.9 | 15.6 at 1e5, 19.6 | 21.3 at
-// 5e5, 23.3 | 22.9 at 1e6; 6-D 13.6 | 16.3 at 1e4, 17.3 | 18.5 at 8e4; 8-D 15.9 | 16.9 and 17.3 | 16.8; 16-D 18.3 | 17.1 at 1e4 and
-// 25.4 | 21.9 at 1e5 -- from 8 draws on the launch chain runs the hand-pipelined loop on its tuned layout, histogram copies and 512-thread
-// workgroups, which this kernel's plain 256-thread layout does not match).
+// Automatic mode adds: launches of samples x draws < 2^19 per iteration over at most 7 draws per sample (tools/latency.py and sweeps of
+// sizes and dimensions on the final code, us per iteration by the library's clock, persistent | launch chain: 2-D 11.5 | 12.8 at neval =
+// 1e4, 13.7 | 13.9 at 1e5, 15.5 | 16.4 at 2e5, 19.6 | 19.2 at 5e5; 4-D 13.1 | 15.2 at 1e4, 16.6 | 19.7 at 1.2e5; 6-D 13.5 | 16.3 at 1e4,
+// 17.1 | 17.6 at 8e4; 16-D 18.3 | 15.8 at 1e4 -- from 8 draws on the launch chain runs the hand-pipelined loop on its tuned layout,
+// histogram copies and 512-thread workgroups, which this kernel's plain 256-thread layout does not match).
 bool persist_plan(const mci_problem *p, const mci_integrate_args *a, int64_t nevalperblock, int64_t nblocks, int *wpb_out) {
     const auto &s = p->shape;
     if (p->persistent == 0 || p->persist_failed) return false;
@@ -2119,7 +2120,7 @@ bool persist_plan(const mci_problem *p, const mci_integrate_args *a, int64_t nev
     if (!persist_layout(p)) return false;
     if (p->wg_per_block > 0 || p->kernel_timing > 0 || p->train_serial == 1) return false;
     const int64_t work = nevalperblock * nblocks * s.ndraw;
-    if (p->persistent < 0 && (work >= ((int64_t)1 << 20) || s.ndraw > 7)) return false;
+    if (p->persistent < 0 && (work >= ((int64_t)1 << 19) || s.ndraw > 7)) return false;
     const int T = p->threads;
     int64_t target = work < ((int64_t)1 << 19) ? 64 : 128;
     int64_t wpb = (target + nblocks - 1) / nblocks;
@@ -2192,6 +2193,8 @@ static int compile_persist(mci_problem *p, bool background) {
         sh.hcopy = 1;
         sh.det = 0;
         c->src = mcijit::generate_source(sh, MCI_VEGAS, mcijit::kUnitVegasPersist, p->leaves[0].alpha);
+        // (512 threads for the hand-pipelined loops of 8..16 draws -- what the launch chain runs them at -- was tried: 22.5 instead of 18.3 us
+        // per iteration of the 16-D Gaussian at neval = 1e4, against 15.8 as a launch chain; the automatic rule stops at 7 draws)
         c->threads = p->threads;
         c->rc = mcijit::compile(c->src, c->threads, c->code, c->log, c->cached, &c->path, true, /*cache_only=*/background);
         if (c->rc == -1) { // not in the kernel cache: compile it behind the caller's back ...
@@ -2226,6 +2229,7 @@ static int compile_persist(mci_problem *p, bool background) {
         return fail(MCI_ERR_COMPILE, "the persistent :vegas kernel came out with static LDS or scratch");
     }
     p->persist_code_object = c->path;
+    p->persist_threads = c->threads;
     if (p->ctx->offline) {
         p->persist_compiled = true;
         return MCI_OK;
@@ -2255,7 +2259,7 @@ static int persist_launch(mci_problem *p, const mci_integrate_args *ia, int64_t 
     HIPCHK(hipSetDevice(p->ctx->device));
     if ((rc = ensure_capacity(p, 2 * nrows, nblocks))) return rc; // (the partial rows are double-buffered by the turn's parity)
     if ((rc = grow_iteration_log(p, (int64_t)p->log_row + ia->niter))) return rc;
-    const int T = p->threads;
+    const int T = p->persist_threads;
     mci::BatchArgs a{};
     a.edges = p->d_edges;
     a.dacc = p->d_dacc;

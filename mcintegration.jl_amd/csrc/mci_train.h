@@ -454,26 +454,35 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             }
             MCI_TT(3)
             int anybad = 0;
-            auto rescale_bins = [&](auto power) { // power(b) = b ^ alpha (rescale_pow, its exponent decided once for the leaf)
-                for (int base = 0; base < N; base += kTrainQ * T) {
-                    double v[kTrainQ];
+            auto rescale_q = [&](auto power, auto QC) { // power(b) = b ^ alpha (rescale_pow, its exponent decided once for the leaf)
+                constexpr int Q = decltype(QC)::value;  // chains side by side: as many as a thread has bins (a dummy chain costs a real logarithm)
+                for (int base = 0; base < N; base += Q * T) {
+                    double v[Q];
 #pragma unroll
-                    for (int q = 0; q < kTrainQ; ++q) {
+                    for (int q = 0; q < Q; ++q) {
                         const int i = base + q * T + tid;
                         v[q] = i < N ? d[i] / s : 1.0; // (1.0: left alone by the rescale, finite)
                     }
 #pragma unroll
-                    for (int q = 0; q < kTrainQ; ++q) { // (evaluated for every bin and selected: straight-line code, so the kTrainQ logarithms interleave)
+                    for (int q = 0; q < Q; ++q) { // (evaluated for every bin and selected: straight-line code, so the Q logarithms interleave)
                         const double r = power(-(1 - v[q]) / log(v[q]));
                         v[q] = (v[q] > 0 && v[q] <= 0.99999999) ? r : v[q];
                     }
 #pragma unroll
-                    for (int q = 0; q < kTrainQ; ++q) {
+                    for (int q = 0; q < Q; ++q) {
                         const int i = base + q * T + tid;
                         if (!isfinite(v[q])) anybad = 1; // common.jl:79
                         if (i < N) d[i] = v[q];
                     }
                 }
+            };
+            auto rescale_bins = [&](auto power) {
+#ifdef MCI_TRAIN_SCAN_ONLY // (the persistent kernel: its workgroup size is this translation unit's)
+                rescale_q(power, IC<(MCI_THREADS >= 512 ? 2 : kTrainQ)>{});
+#else
+                if (2 * T >= N) rescale_q(power, IC<2>{}); // (k_finish runs 512 threads on grids of more than 256 increments)
+                else rescale_q(power, IC<kTrainQ>{});
+#endif
             };
             const double alpha = L.alpha;
             // MCI_TRAIN_POWER (the persistent kernel's translation unit knows its one leaf): 2, 3, 1 = that exponent and nothing else,
@@ -513,41 +522,50 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             const double total = block_prefix(d, wa, N, ps); // wa[j] = C[j] (inclusive)
             const double f_ninc = total / (double)N;         // :226
             MCI_TT(5)
-            for (int base = 0; base <= N; base += kTrainQ * T) {
-                // smallest j0 with C[j0] >= target, for kTrainQ new points at once: a branch-free lower bound whose interval length is the
-                // same on every lane (scalar loop control; per halving one LDS read, one compare, one conditional add per point)
-                int lo[kTrainQ];
-                double target[kTrainQ];
+            auto place_points = [&](auto QC) {
+                constexpr int Q = decltype(QC)::value;
+                for (int base = 0; base <= N; base += Q * T) {
+                    // smallest j0 with C[j0] >= target, for Q new points at once: a branch-free lower bound whose interval length is the
+                    // same on every lane (scalar loop control; per halving one LDS read, one compare, one conditional add per point)
+                    int lo[Q];
+                    double target[Q];
 #pragma unroll
-                for (int q = 0; q < kTrainQ; ++q) {
-                    lo[q] = 0;
-                    target[q] = (double)(base + q * T + tid) * f_ninc;
-                }
-                for (int len = N; len > 1;) {
-                    const int half = len >> 1;
+                    for (int q = 0; q < Q; ++q) {
+                        lo[q] = 0;
+                        target[q] = (double)(base + q * T + tid) * f_ninc;
+                    }
+                    for (int len = N; len > 1;) {
+                        const int half = len >> 1;
 #pragma unroll
-                    for (int q = 0; q < kTrainQ; ++q) lo[q] += wa[lo[q] + half - 1] < target[q] ? half : 0;
-                    len -= half;
-                }
+                        for (int q = 0; q < Q; ++q) lo[q] += wa[lo[q] + half - 1] < target[q] ? half : 0;
+                        len -= half;
+                    }
 #pragma unroll
-                for (int q = 0; q < kTrainQ; ++q) {
-                    lo[q] += wa[lo[q]] < target[q] ? 1 : 0;
-                    lo[q] = lo[q] > N - 1 ? N - 1 : lo[q];
-                }
-                double vnew[kTrainQ];
+                    for (int q = 0; q < Q; ++q) {
+                        lo[q] += wa[lo[q]] < target[q] ? 1 : 0;
+                        lo[q] = lo[q] > N - 1 ? N - 1 : lo[q];
+                    }
+                    double vnew[Q];
 #pragma unroll
-                for (int q = 0; q < kTrainQ; ++q) { // (straight-line: the kTrainQ interpolations interleave; the end points are selected afterwards)
-                    const int i = base + q * T + tid, j = lo[q];
-                    const double acc_f = wa[j] - target[q];
-                    const double v = sg[j + 1] - (acc_f / d[j]) * (sg[j + 1] - sg[j]); // :233 with j = lo+1
-                    vnew[q] = (i == 0 || i >= N) ? sg[i < N ? 0 : N] : v;              // :217-218, :235
-                }
+                    for (int q = 0; q < Q; ++q) { // (straight-line: the Q interpolations interleave; the end points are selected afterwards)
+                        const int i = base + q * T + tid, j = lo[q];
+                        const double acc_f = wa[j] - target[q];
+                        const double v = sg[j + 1] - (acc_f / d[j]) * (sg[j + 1] - sg[j]); // :233 with j = lo+1
+                        vnew[q] = (i == 0 || i >= N) ? sg[i < N ? 0 : N] : v;              // :217-218, :235
+                    }
 #pragma unroll
-                for (int q = 0; q < kTrainQ; ++q) {
-                    const int i = base + q * T + tid;
-                    if (i <= N) g[i] = vnew[q];
+                    for (int q = 0; q < Q; ++q) {
+                        const int i = base + q * T + tid;
+                        if (i <= N) g[i] = vnew[q];
+                    }
                 }
-            }
+            };
+#ifdef MCI_TRAIN_SCAN_ONLY
+            place_points(IC<(MCI_THREADS >= 512 ? 2 : kTrainQ)>{});
+#else
+            if (2 * T > N) place_points(IC<2>{});
+            else place_points(IC<kTrainQ>{});
+#endif
             __syncthreads();
             MCI_TT(6)
             if (hclear)

@@ -1539,7 +1539,9 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.nchain = nchain;
     a.burnin = burnin;
     a.nburn = nburn;
-    a.hist_atomic = atomic_flush ? 1 : 0;
+    // (three buffers from 64 rows on: x^2 + y^2 at neval = 1e6, 256 rows: see tools/latency.py)
+    const int ghist_buffers = atomic_flush ? (nrows > 64 ? 3 : 1) : 0;
+    a.hist_atomic = ghist_buffers;
     if (solver != MCI_VEGAS) {
         const bool carried = may_carry && nchain > 1;
         const bool keep = carry_on && nchain > 1;
@@ -1920,7 +1922,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     m.stage1 = p->d_stage1;
     m.ngroup = (int)mci_problem::kGroups;
     m.ghist = p->d_ghist;
-    m.use_ghist = (hist_lds && !atomic_flush) ? 0 : 1;
+    m.use_ghist = (hist_lds && !atomic_flush) ? 0 : atomic_flush ? ghist_buffers : 1;
     m.nbin = s.nbin;
     m.packed = p->d_packed;
     m.status = p->d_status;

@@ -175,7 +175,9 @@ struct BatchArgs {
     //   ne = steps + 1    finish the last step
     // Chain state lives in global memory between launches (SoA, stride nc = chains of the launch).
     // Launch-bound :vegas iterations (a few workgroups, a few thousand samples each): the workgroup adds the non-zero bins of its LDS
-    // histogram straight into `ghist` (global f64 atomics) instead of leaving a partial row for a merge launch of its own
+    // histogram straight into `ghist` (global f64 atomics) instead of leaving a partial row for a merge launch of its own.  The value is
+    // the number of `ghist` buffers the workgroups spread over (row r adds to buffer r % hist_atomic; k_finish sums them): 256 rows on one
+    // buffer are 256 serialized atomics per bin
     int hist_atomic;
     // Carried chains (chain solvers, nchain > 1, an iteration that continues the previous one; DESIGN.md "Chains"): chain (block, ch)
     // does not draw a fresh start but continues from the configuration chain (block, ch % carry_nchain) ended the previous iteration
@@ -985,7 +987,7 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
                     double v = sH[i * SB];
                     static_for<1, Cfg::HCOPY>([&](auto Cc) { v += sH[i * SB + decltype(Cc)::value * SC]; }); // fixed order
                     if (!ACCUM && a.hist_atomic) { // (BatchArgs::hist_atomic: no merge launch behind this one)
-                        if (v != 0.0) global_add(&a.ghist[Cfg::tile_boff(tt) + i], v);
+                        if (v != 0.0) global_add(&a.ghist[(rowid % a.hist_atomic) * Cfg::NBIN + Cfg::tile_boff(tt) + i], v);
                     } else
                     hrow[i] = ACCUM ? hrow[i] + v : v;
                 }

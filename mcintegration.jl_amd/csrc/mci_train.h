@@ -60,9 +60,11 @@ __device__ inline void merge_pa(const MergeArgs &m, int blk) {
 // one histogram bin of the merged config: clearStatistics! offsets + the second merge stage
 __device__ inline double merge_hist_bin(const MergeArgs &m, int bin) {
     double s = (double)(m.nblocks + 1) * 1.0e-10;
-    if (m.use_ghist) {
-        s += m.ghist[bin];
-        m.ghist[bin] = 0.0; // ready for the next iteration
+    if (m.use_ghist) { // (use_ghist = the number of buffers the launch spread its atomics over)
+        for (int g = 0; g < m.use_ghist; ++g) {
+            s += m.ghist[(size_t)g * m.nbin + bin];
+            m.ghist[(size_t)g * m.nbin + bin] = 0.0; // ready for the next iteration
+        }
     } else {
         // all group partials in flight at once (a rolled loop would serialise ngroup L2 round trips), summed in group order
         double v[kMergeGroups];

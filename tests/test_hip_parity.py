@@ -279,6 +279,25 @@ def test_train_matches_oracle(oracle, name, walk, monkeypatch):
             np.testing.assert_allclose(a, ocfg.accumulation(i), rtol=1e-11)
 
 
+@pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "c2_gauss16_shared_pool"])
+def test_mid_size_launch_spreads_its_atomic_flush_over_three_buffers(oracle, name):
+    """launches of 65..256 partial rows (a few 1e5 samples) add their LDS histograms to THREE merged-histogram buffers, row r to buffer
+    r % 3 (256 rows on one buffer are 256 serialized atomics per bin), and the merge sums and clears all three: one iteration against the
+    oracle at the usual tolerances, and the same iteration again -- the buffers were left clean"""
+    c, cfg, eng, ocfg = make(name, oracle)
+    block, npb = 16, 40000
+    got = eng.iteration("vegas", npb, 0, block, iteration=0, seed=SEED)
+    ms, wg, th = eng.kernel_times_ms(1)
+    assert 64 < wg <= 256, wg
+    ref = ocfg.iteration(oracle.VEGAS, c["oname"], c["ud"], npb, 0, block, 0, SEED)
+    gs, gh = hist_split(got, eng.nobs, cfg.N)
+    rs, rh = hist_split(ref, eng.nobs, cfg.N)
+    np.testing.assert_allclose(gs, rs, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(gh, rh, rtol=1e-9)
+    again = eng.iteration("vegas", npb, 0, block, iteration=0, seed=SEED)
+    np.testing.assert_allclose(again, got, rtol=1e-12, atol=1e-300)
+
+
 @pytest.mark.parametrize("walk", ["serial", "prefix"])
 @pytest.mark.parametrize("ninc", [1025, 1026, 2500])
 def test_train_of_a_grid_longer_than_julias_simd_block_matches_oracle(oracle, ninc, walk, monkeypatch):

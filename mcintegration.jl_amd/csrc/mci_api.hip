@@ -681,7 +681,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             if (m == 2) { mode = 2; pair = 0; }
             if (m == 3) { mode = 3; pair = 0; }
         }
-        if (const char *e = getenv("MCI_TRAIN_SERIAL")) p->train_serial = atoi(e) != 0 ? 1 : 0;
+        if (const char *e = getenv("MCI_TRAIN_SERIAL")) p->train_serial = atoi(e) == 2 ? 2 : atoi(e) != 0 ? 1 : 0;
         if (const char *e = getenv("MCI_CHAIN_CARRY")) p->chain_carry = atoi(e) == 0 ? 0 : atoi(e) > 0 ? 1 : -1; // (mci_set_chain_carry)
         if (const char *e = getenv("MCI_PERSISTENT")) p->persistent = atoi(e) == 0 ? 0 : atoi(e) > 0 ? 1 : -1;     // (mci_set_persistent)
         if (const char *e = getenv("MCI_KERNEL_TIMING")) p->kernel_timing = atoi(e) < 0 ? -1 : atoi(e) > 0 ? 1 : 0; // (mci_set_kernel_timing)
@@ -1289,7 +1289,7 @@ int mci_set_rng_rounds(mci_problem *p, int32_t rounds) {
 
 int mci_set_train_walk(mci_problem *p, int32_t mode) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
-    if (mode < -1 || mode > 1) return fail(MCI_ERR_INVALID, "train walk mode must be -1 (automatic), 0 (prefix scan) or 1 (serial recurrence)");
+    if (mode < -1 || mode > 2) return fail(MCI_ERR_INVALID, "train walk mode must be -1 (automatic), 0 (prefix scan), 1 (serial recurrence) or 2 (serial recurrence, general form only)");
     p->train_serial = mode;
     return MCI_OK;
 }
@@ -2009,19 +2009,21 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     a.serial_walk = p->train_serial >= 0 ? p->train_serial : (p->last_samples == 0 || p->last_samples >= mci_problem::kSerialWalkSamples) ? 1 : 0;
     a.status = p->d_status;
     a.maxn = maxn;
-    const size_t sm = (size_t)mci::train_lds_doubles(maxn) * sizeof(double); // d | sg | wa (train_leaf)
+    // d | sg | wa (train_leaf) | the serial walk's slots and their record, where they fit (grids of up to ~2700 increments), else k_finish's merged histogram alone
+    a.spare = (size_t)(mci::train_lds_doubles(maxn) + mci::train_spare_doubles(maxn)) * sizeof(double) <= (size_t)kTrainLdsMax ? 1 : 0;
+    const size_t sm = (size_t)(mci::train_lds_doubles(maxn) + (a.spare ? mci::train_spare_doubles(maxn) : maxn)) * sizeof(double);
     // two bins per thread for the default 999-bin grids: the rescale (a pow and a log per bin) and the second merge stage are the
     // latency chains of a lone workgroup; with four bins per thread (256 threads) a launch-bound iteration took 24.7 us, with two
     // 22.2, with one (1024 threads) 22.3 (tools/latency.py, neval = 1e4)
     const unsigned tt = maxn > 256 ? 512u : 256u;
-    if (sm + (size_t)maxn * sizeof(double) > 64 * 1024 && !p->train_lds_raised) { // grids of more than ~1600 increments
+    if (sm > 64 * 1024 && !p->train_lds_raised) { // grids of more than ~1600 increments
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_train, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
         HIPCHK(hipFuncSetAttribute((const void *)mci::k_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrainLdsMax));
         p->train_lds_raised = true;
     }
     if (p->merge_pending) { // nothing looked at `packed` since the sample batch: merge + refine in one launch
         p->merge_pending = false;
-        hipLaunchKernelGGL(mci::k_finish, dim3(s.nleaf + 1 + (2 * p->npa + 3) / 4), dim3(tt), sm + (size_t)maxn * sizeof(double), p->ctx->stream, p->merge, a);
+        hipLaunchKernelGGL(mci::k_finish, dim3(s.nleaf + 1 + (2 * p->npa + 3) / 4), dim3(tt), sm, p->ctx->stream, p->merge, a);
     } else {
         hipLaunchKernelGGL(mci::k_train, dim3(s.nleaf + 1), dim3(tt), sm, p->ctx->stream, a);
     }
@@ -2120,7 +2122,7 @@ bool persist_plan(const mci_problem *p, const mci_integrate_args *a, int64_t nev
     if (a->solver != MCI_VEGAS || a->measurefreq != 1 || a->niter < 1) return false;
     if (p->ctx->nranks != 1) return false; // (a one-rank communicator's all-reduce is the identity)
     if (!persist_layout(p)) return false;
-    if (p->wg_per_block > 0 || p->kernel_timing > 0 || p->train_serial == 1) return false;
+    if (p->wg_per_block > 0 || p->kernel_timing > 0 || p->train_serial >= 1) return false;
     const int64_t work = nevalperblock * nblocks * s.ndraw;
     if (p->persistent < 0 && (work >= ((int64_t)1 << 19) || s.ndraw > 7)) return false;
     const int T = p->threads;

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_resample_chains(ResampleArgs a) {
 }
 
 // One workgroup per leaf: Dist.train! then clearStatistics!; workgroup `nleaf`: bookkeeping.
-__global__ void __launch_bounds__(1024) k_train(TrainArgs a) {
+__global__ void __launch_bounds__(512) k_train(TrainArgs a) { // (launched with 256 or 512 threads; the serial walk's lane wants ~200 registers)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double ps[256]; // block_prefix scratch
     __shared__ int bad;
@@ -124,14 +124,14 @@ __global__ void __launch_bounds__(1024) k_train(TrainArgs a) {
     const LeafDev L = a.leaves[blockIdx.x];
     if (!L.adapt) return; // variable.jl:208, :370
     double *h = a.packed + a.nstat + L.boff;
-    train_leaf(L, h, h, sm, ps, bad, ssum, a.edges, a.dacc, a.ddist, a.serial_walk, a.status);
+    train_leaf(L, h, h, sm, ps, bad, ssum, a.edges, a.dacc, a.ddist, a.serial_walk, a.status, false, nullptr, false, a.spare ? sm + train_lds_doubles(a.maxn) : nullptr);
 }
 
 // Single-rank iterations need no all-reduce between the merge and the refinement: k_finalize and k_train as ONE
 // launch.  Workgroup l < nleaf merges its leaf's histogram (second stage) into LDS and `packed`, then trains from
 // the LDS copy; workgroup nleaf merges the statistics head, then does the bookkeeping.
-__global__ void __launch_bounds__(1024) k_finish(MergeArgs m, TrainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double sm[]; // [train_lds_doubles(maxn)] train scratch | [maxn] merged histogram
+__global__ void __launch_bounds__(512) k_finish(MergeArgs m, TrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[]; // [train_lds_doubles(maxn)] train scratch | [maxn] merged histogram, then ([train_spare_doubles(maxn)], a.spare) the serial walk's slots
     __shared__ double ps[256];
     __shared__ int bad;
     __shared__ double ssum;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(1024) k_finish(MergeArgs m, TrainArgs a) {
     }
     __syncthreads();
     if (!train) return;
-    train_leaf(L, hl, hp, sm, ps, bad, ssum, a.edges, a.dacc, a.ddist, a.serial_walk, a.status, true);
+    train_leaf(L, hl, hp, sm, ps, bad, ssum, a.edges, a.dacc, a.ddist, a.serial_walk, a.status, true, nullptr, false, a.spare ? hl : nullptr); // (hl: free once smoothed)
 }
 
 } // namespace mci

@@ -179,6 +179,7 @@ __device__ inline double block_prefix(const double *v, double *out, int n, doubl
 // LDS doubles train_leaf needs for a leaf of n bins: d[n+kWalkPad] | sg[n+1] | wa[n+kWalkPad] (+ alignment)
 enum { kWalkPad = 64 }; // zeros behind d[]: the serial loops read 16 bins at a time, two trips ahead
 __host__ __device__ inline int train_lds_doubles(int n) { return (n + kWalkPad) + (n + 2) + (n + kWalkPad) + 2; }
+__host__ __device__ inline int train_spare_doubles(int n) { return 2 * (2 * n + kWalkPad); } // the serial walk's slots and their record (train_leaf)
 
 // Julia's sum() over a histogram-length vector (common.jl:72, variable.jl:226) is mapreduce_impl's `@simd` loop below its pairwise
 // block size of 1024: a vectorised reduction whose association is the CPU's (lanes x interleave), not left to right.  Oracle and
@@ -253,6 +254,7 @@ struct TrainArgs {
     int do_train, serial_walk;
     int *status;
     int maxn; // bins of the largest leaf (k_finish: where the merged histogram sits behind the refinement's scratch)
+    int spare;  // the launch carries train_spare_doubles(maxn) doubles of LDS behind train_lds_doubles(maxn) (else maxn: k_finish's merged histogram)
 };
 
 #ifndef MCI_TRAIN_SCAN_ONLY // (the persistent kernel refines with the prefix-scan walk only: the hand-written recurrence stays out of its translation unit)
@@ -352,6 +354,19 @@ __device__ __forceinline__ void walk_bins16_single(double &acc, double &m, const
 #undef MCI_WALK_MORE
 #undef MCI_WALK_BIN1
 
+// Sixteen SLOTS of the walk with its decisions given (train_leaf, serial form): acc_f += e[k], one dependent addition per slot, the
+// value before each addition recorded.
+__device__ __forceinline__ void walk_slots16(double &acc, const double (&e)[16], double *__restrict__ rec) {
+    double r[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        r[k] = acc;
+        acc = acc + e[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) rec[k] = r[k];
+}
+
 __device__ __forceinline__ void walk_trip(double &acc, const double (&v)[16], const double vnext, const double f, const unsigned rec_addr) {
     const double acc0 = acc;
     double m;
@@ -392,7 +407,8 @@ __device__ inline void train_stage_grid(const LeafDev &L, double *sm, const doub
 // hclear: its home in `packed`, reset for the next iteration (NULL: somebody else's business).  sm: train_lds_doubles(N) doubles of LDS.
 __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hclear, double *sm, double *ps, int &bad, double &ssum,
                                   double *__restrict__ edges, double *__restrict__ dacc, double *__restrict__ ddist, int serial_walk,
-                                  int *__restrict__ status, bool staged = false, unsigned long long *tt = nullptr, bool checked = false) {
+                                  int *__restrict__ status, bool staged = false, unsigned long long *tt = nullptr, bool checked = false,
+                                  double *spare = nullptr) { // spare: train_spare_doubles(N) more doubles of LDS (may start at h: h is not read after the smoothing pass) -- the serial walk's slots
 #ifdef MCI_PERSIST_TRACE // development aid (tools/persist_trace.py): wall-clock stamps of the phases, into LDS
 #define MCI_TT(k) if (tt && threadIdx.x == 0) tt[k] = wall_clock64();
 #else
@@ -583,41 +599,126 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
         // acc_f (the same subtractions again), the division and the interpolation (:233) are recomputed from that record by all
         // lanes.  acc_f <= (N + 1) f_ninc, so a subtraction always makes progress.
         const double f_ninc = sum_julia(d, N) / (double)N; // :226
-        if (tid == 0) {
-            if (f_ninc > 0.0 && isfinite(f_ninc)) {
-                const unsigned rec = (unsigned)(size_t)wa;
-                double va[16], vb[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) va[k] = d[k];
-                double acc_f = 0.0 + va[0]; // :222, and the first `j += 1; acc_f += avg_f[j]` (:229-230)
-                for (int jb = 0; jb < N; jb += 32) { // two trips per turn, the next trip's bins are loaded before this trip's chain
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) vb[k] = d[jb + 16 + k];
-                    walk_trip(acc_f, va, vb[0], f_ninc, rec + 8u * (unsigned)jb);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) va[k] = d[jb + 32 + k];
-                    walk_trip(acc_f, vb, va[0], f_ninc, rec + 8u * (unsigned)(jb + 16));
-                }
-            } else {
-                atomicOr(status, ST_RESCALE_NONFINITE);
-            }
+        if (!(f_ninc > 0.0 && isfinite(f_ninc))) {
+            if (tid == 0) atomicOr(status, ST_RESCALE_NONFINITE);
+            return;
         }
-        __syncthreads();
+        // The chain costs one lone wave ~4.6 ns per instruction it issues, ~8 instructions per bin in the general form (walk_trip): most
+        // of them DECIDE (compare, masked subtract, the exec round trip).  The decisions can be had ahead of time: with C[j] the
+        // prefix-scan form's partial sums, bin j yields c[j] = floor(C[j] / f_ninc) - floor(C[j-1] / f_ninc) new points -- right wherever
+        // acc_f is not within rounding of f_ninc.  With them the recurrence is a list of SLOTS, acc_f += e[s]:
+        //     bin j:  c[j] times  `acc_f -= f_ninc`  (e = -f_ninc),  then  `acc_f += avg_f[j + 1]`  (e = avg_f[j + 1])
+        // -- the reference's operations on the reference's operands, nothing else.  The last subtraction of a bin is EXACT (the loop
+        // :228 stops at acc_f < f_ninc, so it starts from f_ninc <= acc_f < 2 f_ninc: Sterbenz), and for f_ninc / 2 <= avg_f[j + 1] <=
+        // 2 f_ninc so is avg_f[j + 1] - f_ninc: then fl(fl(acc_f - f_ninc) + avg_f[j + 1]) = fl(acc_f + (avg_f[j + 1] - f_ninc)) and the two
+        // slots are one.  On an adapted grid that is nearly every bin: ~N slots, one dependent addition each (walk_slots16), ~2.2
+        // instructions per slot with the loads and the record's stores.  Every thread builds its bins' slots, lane 0 walks them,
+        // every thread then counts its bins' points from the exact record the way the general form does and compares with c[j]: where
+        // all agree the record IS the recurrence's (induction over the bins); one disagreement sends the walk through the general
+        // form.  serial_walk == 2: the general form at once.  spare: [2N + kWalkPad] slots | [2N + kWalkPad] their record.
+        int *flag = (int *)(ps + 64);
+        int *pw = (int *)ps;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int per = (N + T - 1) / T, b = min(N, tid * per), e = min(N, b + per); // thread t owns the bins [t*per, (t+1)*per)
+        bool given = spare != nullptr && serial_walk != 2 && N > 1;
+        double *es = spare, *rs = spare + 2 * N + kWalkPad;
+        const double f_inv = 1.0 / f_ninc, f_lo = 0.5 * f_ninc, f_hi = 2.0 * f_ninc;
+        auto points = [&](int j) { // c[j] from C[] (in wa[] while `given`); the last bin's decision changes no record: "none", never checked
+            if (j >= N - 1) return 0;
+            const double c = floor(wa[j] * f_inv) - (j > 0 ? floor(wa[j - 1] * f_inv) : 0.0);
+            return c > 0.0 ? (int)c : 0;
+        };
+        auto slots = [&](int j, int c) { return c + ((c >= 1 && d[j + 1] >= f_lo && d[j + 1] <= f_hi) ? 0 : 1); };
+        int sbase = 0, nslot = 0;
+        if (given) {
+            if (tid == 0) *flag = 0;
+            block_prefix(d, wa, N, ps); // wa[j] = C[j]; the barriers inside order the flag's reset
+            int mine = 0;
+            for (int j = b; j < e; ++j) mine += slots(j, points(j));
+            int x = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(x, off, 64);
+                if (lane >= off) x += y;
+            }
+            if (lane == 63) pw[wave] = x;
+            __syncthreads();
+            for (int w = 0; w < (T >> 6); ++w) {
+                if (w < wave) sbase += pw[w];
+                nslot += pw[w];
+            }
+            sbase += x - mine; // (nslot <= N + the points of bins 0 .. N-2 <= 2N - 1)
+            int sl = sbase;
+            for (int j = b; j < e; ++j) {
+                const int c = points(j);
+                for (int k = 0; k < c - 1; ++k) es[sl++] = -f_ninc;
+                if (c >= 1 && slots(j, c) == c) es[sl++] = d[j + 1] - f_ninc;
+                else {
+                    if (c >= 1) es[sl++] = -f_ninc;
+                    es[sl++] = d[j + 1];
+                }
+            }
+            for (int k = nslot + tid; k < nslot + kWalkPad; k += T) es[k] = 0.0;
+            __syncthreads();
+        }
+        int cnt;
+        for (;;) {
+            if (tid == 0) {
+                double va[16], vb[16];
+                double acc_f = 0.0 + d[0]; // :222, and the first `j += 1; acc_f += avg_f[j]` (:229-230)
+                if (given) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) va[k] = es[k];
+                    for (int sb = 0; sb < nslot; sb += 32) { // two trips per turn, the next trip's slots are loaded before this trip's chain
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) vb[k] = es[sb + 16 + k];
+                        walk_slots16(acc_f, va, rs + sb);
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) va[k] = es[sb + 32 + k];
+                        walk_slots16(acc_f, vb, rs + sb + 16);
+                    }
+                } else {
+                    const unsigned rec = (unsigned)(size_t)wa;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) va[k] = d[k];
+                    for (int jb = 0; jb < N; jb += 32) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) vb[k] = d[jb + 16 + k];
+                        walk_trip(acc_f, va, vb[0], f_ninc, rec + 8u * (unsigned)jb);
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) va[k] = d[jb + 32 + k];
+                        walk_trip(acc_f, vb, va[0], f_ninc, rec + 8u * (unsigned)(jb + 16));
+                    }
+                }
+            }
+            __syncthreads();
+            // count the new points of this thread's bins (the same subtractions again)
+            cnt = 0;
+            int wrong = 0, sl = sbase;
+            for (int j = b; j < e; ++j) {
+                int c = 0;
+                for (double a = given ? rs[sl] : wa[j]; a >= f_ninc; a -= f_ninc) c += 1;
+                cnt += c;
+                if (given) {
+                    const int cp = points(j);
+                    wrong |= (j < N - 1 && c != cp) ? 1 : 0;
+                    sl += slots(j, cp);
+                }
+            }
+            if (!given) break;
+            if (wrong) atomicOr(flag, 1);
+            __syncthreads();
+            if (*flag == 0) break;
+            given = false; // (nobody reads wa[] or the flag between this barrier and lane 0's second walk)
+        }
         {
-            if (!(f_ninc > 0.0 && isfinite(f_ninc))) return;
-            // lane t owns the bins [t*per, (t+1)*per): count their new points, exclusive scan over the lanes, then write them
-            const int lane = tid & 63, wave = tid >> 6;
-            const int per = (N + T - 1) / T, b = min(N, tid * per), e = min(N, b + per);
-            int cnt = 0;
-            for (int j = b; j < e; ++j)
-                for (double a = wa[j]; a >= f_ninc; a -= f_ninc) cnt += 1;
+            // exclusive scan of the counts over the lanes, then every lane writes its bins' points
             int x = cnt;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const int y = __shfl_up(x, off, 64);
                 if (lane >= off) x += y;
             }
-            int *pw = (int *)ps;
             if (lane == 63) pw[wave] = x;
             __syncthreads();
             int base = 0, total = 0;
@@ -626,12 +727,15 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
                 total += pw[w];
             }
             int i = 1 + base + x - cnt; // first new grid point of this lane's bins (0-based index into the new grid)
-            for (int j = b; j < e; ++j)
-                for (double a = wa[j]; a >= f_ninc;) {
+            int sl = sbase;
+            for (int j = b; j < e; ++j) {
+                for (double a = given ? rs[sl] : wa[j]; a >= f_ninc;) {
                     a -= f_ninc; // :232
                     if (i < N) g[i] = sg[j + 1] - (a / d[j]) * (sg[j + 1] - sg[j]); // :233 (1-based j of the reference = j + 1)
                     i += 1;
                 }
+                if (given) sl += slots(j, points(j));
+            }
             for (int k = 1 + total + tid; k < N; k += T) g[k] = sg[N]; // (points the walk did not reach: rounding at the very end)
             if (tid == 0) {
                 g[0] = sg[0]; // :217

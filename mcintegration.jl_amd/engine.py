@@ -431,8 +431,9 @@ class Engine:
         return int(n.value), bool(c.value)
 
     def set_train_walk(self, mode):
-        """train!'s refinement walk: "serial" (the reference's recurrence), "scan" (prefix scan + bisection) or "auto"; see mci_set_train_walk"""
-        check(lib().mci_set_train_walk(self.p, {"auto": -1, "scan": 0, "serial": 1, -1: -1, 0: 0, 1: 1}[mode]))
+        """train!'s refinement walk: "serial" (the reference's recurrence), "scan" (prefix scan + bisection), "auto", or "serial_general"
+        (the recurrence without the predicted decisions: what "serial" falls back to); see mci_set_train_walk"""
+        check(lib().mci_set_train_walk(self.p, {"auto": -1, "scan": 0, "serial": 1, "serial_general": 2, -1: -1, 0: 0, 1: 1, 2: 2}[mode]))
 
     def integrate(self, solver, neval, niter=10, block=16, ignore=-1, adapt=True, gamma=1.0, measurefreq=1, seed=1234,
                   nchain=0, first_iteration=0, thermal_ratio=0.1, reweight_goal=None):

@@ -253,11 +253,13 @@ def test_vegas_iteration_block_range_and_measurefreq(oracle):
     assert got[2 * eng.nobs] == pytest.approx(4 * 1000 + 5e-10, rel=1e-13)  # normalization = measured samples + 1e-10 per block + 1e-10
 
 
-@pytest.mark.parametrize("walk", ["serial", "prefix"])
+@pytest.mark.parametrize("walk", ["serial", "serial_general", "prefix"])
 @pytest.mark.parametrize("name", ["c1_log_over_sqrt", "c2_gauss16_shared_pool", "discrete", "bubble", "singular2_composite", "c5_nested_gauss"])
 def test_train_matches_oracle(oracle, name, walk, monkeypatch):
-    """rows a9/a10: smooth -> rescale -> refine (variable.jl:206-239), Discrete (:369-382)."""
-    monkeypatch.setenv("MCI_TRAIN_SERIAL", "1" if walk == "serial" else "0")
+    """rows a9/a10: smooth -> rescale -> refine (variable.jl:206-239), Discrete (:369-382).  `serial` walks the reference's recurrence
+    with the decisions of the prefix-scan form given and checked (falling back to `serial_general`, the recurrence with its compares
+    and branches, where one does not hold or a bin yields several points); `prefix` is the scan + bisection form."""
+    monkeypatch.setenv("MCI_TRAIN_SERIAL", {"serial": "1", "serial_general": "2", "prefix": "0"}[walk])
     c, cfg, eng, ocfg = make(name, oracle)
     block, npb = 8, 4000
     eng.run("vegas", npb, 0, block, 0, SEED)
@@ -298,13 +300,13 @@ def test_mid_size_launch_spreads_its_atomic_flush_over_three_buffers(oracle, nam
     np.testing.assert_allclose(again, got, rtol=1e-12, atol=1e-300)
 
 
-@pytest.mark.parametrize("walk", ["serial", "prefix"])
+@pytest.mark.parametrize("walk", ["serial", "serial_general", "prefix"])
 @pytest.mark.parametrize("ninc", [1025, 1026, 2500])
 def test_train_of_a_grid_longer_than_julias_simd_block_matches_oracle(oracle, ninc, walk, monkeypatch):
     """train! on grids of 1024 / 1025 / 2499 increments: Julia's sum() (common.jl:72, variable.jl:226) runs its @simd block up to 1024
     elements and splits longer vectors pairwise at the midpoint first (base/reduce.jl mapreduce_impl) -- mcio_sum_julia in the oracle,
     sum_julia on the device; same tolerances as the default 999 increments"""
-    monkeypatch.setenv("MCI_TRAIN_SERIAL", "1" if walk == "serial" else "0")
+    monkeypatch.setenv("MCI_TRAIN_SERIAL", {"serial": "1", "serial_general": "2", "prefix": "0"}[walk])
     cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0, ninc=ninc), dof=[[2]], seed=SEED)
     eng = mci.Engine(cfg, mci.catalog.x2y2())
     ocfg = oracle.Config([ocont(npts=ninc)], [[2]])
@@ -318,7 +320,7 @@ def test_train_of_a_grid_longer_than_julias_simd_block_matches_oracle(oracle, ni
     np.testing.assert_allclose(g, og, rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("walk", ["serial", "prefix"])
+@pytest.mark.parametrize("walk", ["serial", "serial_general", "prefix"])
 @pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "bubble", "c2_gauss4_composite"])
 def test_full_integrate_matches_oracle(oracle, name, walk, monkeypatch):
     """rows a13-a15: the whole loop inside the library (mci_integrate) vs the oracle's loop, same seed.
@@ -328,8 +330,8 @@ def test_full_integrate_matches_oracle(oracle, name, walk, monkeypatch):
     tolerance depends on how the refinement walk rounds: `serial` = the reference's recurrence order
     (variable.jl:227-234; MCI_TRAIN_SERIAL=1), `prefix` = the default scan + bisection form (one train! step of
     either agrees with the oracle to 1e-12 of the range, test_train_matches_oracle)."""
-    monkeypatch.setenv("MCI_TRAIN_SERIAL", "1" if walk == "serial" else "0")
-    rtol, sig = (1e-6, 1e-3) if walk == "serial" else (1e-4, 5e-2)
+    monkeypatch.setenv("MCI_TRAIN_SERIAL", {"serial": "1", "serial_general": "2", "prefix": "0"}[walk])
+    rtol, sig = (1e-6, 1e-3) if walk != "prefix" else (1e-4, 5e-2)
     c, cfg, eng, ocfg = make(name, oracle)
     r = eng.integrate("vegas", neval=40000, niter=6, block=16, seed=SEED)
     o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=40000, niter=6, block=16, seed=SEED)
@@ -339,6 +341,33 @@ def test_full_integrate_matches_oracle(oracle, name, walk, monkeypatch):
     np.testing.assert_allclose(r["stdev"], o["stdev"], rtol=100 * rtol)
     np.testing.assert_allclose(r["chi2"], o["chi2"], rtol=1000 * rtol, atol=1e-9)
     assert np.all(np.abs(r["mean"] - o["mean"]) < sig * o["stdev"])
+
+
+@pytest.mark.parametrize("case", ["adapting_peak", "flat", "gauss16"])
+def test_serial_walk_with_given_decisions_is_the_recurrence_bit_for_bit(case):
+    """The serial walk of train! (variable.jl:227-234) takes the recurrence's decisions -- does this bin yield a new grid point -- from
+    the prefix-scan form, walks the additions and subtractions alone and checks every decision against the exact record; a wrong one
+    (acc_f within rounding of f_ninc) or a bin with several points sends it through the general form.  Either way the grid is the
+    recurrence's: deterministic runs (bit-reproducible histograms) under "serial" and "serial_general" give IDENTICAL grids and
+    iterations -- a narrow peak met by a uniform grid (many points per bin at first), a flat integrand (every bin is a tie: acc_f =
+    f_ninc up to rounding) and the headline layout."""
+    import math
+    out = []
+    for walk in ("serial", "serial_general"):
+        if case == "gauss16":
+            L = math.sqrt(50.0)
+            cfg = mci.Configuration(var=mci.Continuous(-L, L), dof=[[16]], seed=SEED)
+            eng = mci.Engine(cfg, mci.catalog.gaussian(16), deterministic=True)
+        else:
+            cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]], seed=SEED)
+            body = "w[0] = 1.0;" if case == "flat" else "const double t = (x[0] - 0.3) * 400.0; w[0] = exp(-t * t);"
+            eng = mci.Engine(cfg, mci.Integrand(body), deterministic=True)
+        eng.set_train_walk(walk)
+        r = eng.integrate("vegas", neval=200000, niter=8, block=16, seed=SEED)
+        out.append((r["iter_mean"].copy(), r["iter_std"].copy(), eng.grid(0)))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])
+    assert np.all(np.diff(out[0][2]) > 0)
 
 
 def test_full_integrate_default_walk_at_large_launches_is_the_reference_recurrence(oracle, monkeypatch):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development tool (GPU box): per-iteration wall time of the library loop (mci_integrate) at the reference's
-typical sizes (neval 1e4..1e7): launch-bound regime."""
+typical sizes (neval 1e4..1e7): launch-bound regime.   latency.py --walks: the three refinement walks of train! side by side."""
 import os
 import sys
 import time
@@ -10,7 +10,31 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import mcintegration_jl_amd as mci
 
+def walks():
+    """the refinement walk of train!: prefix scan | the reference's recurrence (slots with the decisions given) | its general form"""
+    import math
+    L = math.sqrt(50.0)
+    for name, mk in (("x2y2", lambda: mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]]), mci.catalog.x2y2())),
+                     ("gauss16", lambda: mci.Engine(mci.Configuration(var=mci.Continuous(-L, L), dof=[[16]], seed=1), mci.catalog.gaussian(16)))):
+        for neval in (10**4, 10**6, 10**8) if name == "gauss16" else (10**4, 10**6):
+            for walk in ("scan", "serial", "serial_general"):
+                eng = mk()
+                eng.set_persistent("off")
+                eng.set_train_walk(walk)
+                n = 50 if neval < 10**8 else 12
+                eng.integrate("vegas", neval=neval, niter=8, block=16, seed=1)
+                best = 1e9
+                for rep in range(3):
+                    r = eng.integrate("vegas", neval=neval, niter=n, block=16, seed=1, first_iteration=8 + rep * n)
+                    best = min(best, r["seconds"] / n * 1e6)
+                print("%-8s neval=%-10d walk=%-15s %8.1f us/iteration   mean %.9f +- %.2e" % (name, neval, walk, best, r["mean"][0], r["stdev"][0]), flush=True)
+                eng.close()
+
+
 if __name__ == "__main__":
+    if "--walks" in sys.argv:
+        walks()
+        sys.exit(0)
     for solver in ("vegas", "vegasmc", "mcmc"):
         for neval in (10**4, 10**5, 10**6, 10**7):
             cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])

@@ -260,11 +260,14 @@ int mci_set_rng_bits(mci_problem *prob, int32_t bits);
  * known-answer vectors for 7 rounds (tests/golden) and mirrored in the oracle (mcio_set_rng_rounds). */
 int mci_set_rng_rounds(mci_problem *prob, int32_t rounds);
 /* How train!(Continuous) walks the smoothed histogram to place the new grid points (variable.jl:227-234):
- *   1  the reference's serial recurrence, operation for operation (the chain on one lane in hand-written ISA, +35 us per iteration at ninc = 1000 on MI355X);
- *   0  the same walk as a fixed-order prefix scan + one bisection per grid point (18 us; agrees with the recurrence to 1e-12 of
+ *   1  the reference's serial recurrence, operation for operation: its decisions (does this bin yield a new grid point) are taken from
+ *      the prefix-scan form, one lane walks the additions and subtractions alone, every decision is checked against the exact record
+ *      (+14 us per iteration at ninc = 1000 on MI355X); a decision that does not hold sends the walk through mode 2;
+ *   2  the recurrence with its compares and branches on one lane in hand-written ISA (+38 us): what 1 falls back to -- bit-identical results;
+ *   0  the same walk as a fixed-order prefix scan + one bisection per grid point (agrees with the recurrence to 1e-12 of
  *      the variable's range per train! step, i.e. whole runs agree to ~1e-4 instead of ~1e-6);
- *  -1  automatic (default): 1 when the iteration's sample launch on this rank is >= 2^26 samples (the walk then costs ~2 % or less), else 0.
- * The environment variable MCI_TRAIN_SERIAL=1|0, read at mci_problem_create, sets the initial mode. */
+ *  -1  automatic (default): 1 when the iteration's sample launch on this rank is >= 2^26 samples (the walk then costs ~1 % or less), else 0.
+ * The environment variable MCI_TRAIN_SERIAL=2|1|0, read at mci_problem_create, sets the initial mode. */
 int mci_set_train_walk(mci_problem *prob, int32_t mode);
 /* Deterministic mode: with on = 1 a fixed seed gives BIT-IDENTICAL results run to run (histograms, grids, every iteration's mean
  * and error), like the reference's sequential loop under `MersenneTwister(seed)` (configuration.jl:190, vegas/montecarlo.jl:117-187).

@@ -198,8 +198,8 @@ struct mci_problem {
     int threads_det[3] = {0, 0, 0};
     bool hcopy_plan = false; // the rule also picked the workgroup size (512 threads) for the :vegas kernel
     // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
-    // launch before it is long enough to hide its ~35 us per iteration (>= kSerialWalkSamples samples or chain steps on this
-    // rank: 2 % of the headline iteration), the prefix-scan form below that; mci_set_train_walk / MCI_TRAIN_SERIAL=1 | 0 force one
+    // launch before it is long enough to hide its ~14 us per iteration (>= kSerialWalkSamples samples or chain steps on this
+    // rank: 1 % of the headline iteration), the prefix-scan form below that; mci_set_train_walk / MCI_TRAIN_SERIAL=1 | 0 force one
     int train_serial = -1;
     int64_t last_samples = 0; // samples (vegas) or chain steps of the last sample launch on this rank
     static const int64_t kSerialWalkSamples = (int64_t)1 << 26;

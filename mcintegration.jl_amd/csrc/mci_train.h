@@ -179,7 +179,7 @@ __device__ inline double block_prefix(const double *v, double *out, int n, doubl
 // LDS doubles train_leaf needs for a leaf of n bins: d[n+kWalkPad] | sg[n+1] | wa[n+kWalkPad] (+ alignment)
 enum { kWalkPad = 64 }; // zeros behind d[]: the serial loops read 16 bins at a time, two trips ahead
 __host__ __device__ inline int train_lds_doubles(int n) { return (n + kWalkPad) + (n + 2) + (n + kWalkPad) + 2; }
-__host__ __device__ inline int train_spare_doubles(int n) { return 2 * (2 * n + kWalkPad); } // the serial walk's slots and their record (train_leaf)
+__host__ __device__ inline int train_spare_doubles(int n) { return 2 * (2 * n + kWalkPad) + (2 * n + kWalkPad) / 16 + 2; } // the serial walk's slots, their record, the record's heads (train_leaf)
 
 // Julia's sum() over a histogram-length vector (common.jl:72, variable.jl:226) is mapreduce_impl's `@simd` loop below its pairwise
 // block size of 1024: a vectorised reduction whose association is the CPU's (lanes x interleave), not left to right.  Oracle and
@@ -354,17 +354,16 @@ __device__ __forceinline__ void walk_bins16_single(double &acc, double &m, const
 #undef MCI_WALK_MORE
 #undef MCI_WALK_BIN1
 
-// Sixteen SLOTS of the walk with its decisions given (train_leaf, serial form): acc_f += e[k], one dependent addition per slot, the
-// value before each addition recorded.
-__device__ __forceinline__ void walk_slots16(double &acc, const double (&e)[16], double *__restrict__ rec) {
-    double r[16];
+// Sixteen SLOTS of the walk with its decisions given (train_leaf, serial form): acc_f += e[k], one dependent addition per slot.  Lane 0
+// records acc_f at the head of every sixteen slots only (`lone`); the values in between are the same additions again, done for all
+// trips side by side by as many threads.
+template <bool RECORD> __device__ __forceinline__ void walk_slots16(double &acc, const double (&e)[16], double *__restrict__ rec) {
+    if (!RECORD) rec[0] = acc;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        r[k] = acc;
+        if (RECORD) rec[k] = acc;
         acc = acc + e[k];
     }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) rec[k] = r[k];
 }
 
 __device__ __forceinline__ void walk_trip(double &acc, const double (&v)[16], const double vnext, const double f, const unsigned rec_addr) {
@@ -615,13 +614,13 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
         // instructions per slot with the loads and the record's stores.  Every thread builds its bins' slots, lane 0 walks them,
         // every thread then counts its bins' points from the exact record the way the general form does and compares with c[j]: where
         // all agree the record IS the recurrence's (induction over the bins); one disagreement sends the walk through the general
-        // form.  serial_walk == 2: the general form at once.  spare: [2N + kWalkPad] slots | [2N + kWalkPad] their record.
+        // form.  serial_walk == 2: the general form at once.  spare: [2N + kWalkPad] slots | [2N + kWalkPad] their record | its heads.
         int *flag = (int *)(ps + 64);
         int *pw = (int *)ps;
         const int lane = tid & 63, wave = tid >> 6;
         const int per = (N + T - 1) / T, b = min(N, tid * per), e = min(N, b + per); // thread t owns the bins [t*per, (t+1)*per)
         bool given = spare != nullptr && serial_walk != 2 && N > 1;
-        double *es = spare, *rs = spare + 2 * N + kWalkPad;
+        double *es = spare, *rs = spare + 2 * N + kWalkPad, *heads = rs + 2 * N + kWalkPad;
         const double f_inv = 1.0 / f_ninc, f_lo = 0.5 * f_ninc, f_hi = 2.0 * f_ninc;
         auto points = [&](int j) { // c[j] from C[] (in wa[] while `given`); the last bin's decision changes no record: "none", never checked
             if (j >= N - 1) return 0;
@@ -672,10 +671,10 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
                     for (int sb = 0; sb < nslot; sb += 32) { // two trips per turn, the next trip's slots are loaded before this trip's chain
 #pragma unroll
                         for (int k = 0; k < 16; ++k) vb[k] = es[sb + 16 + k];
-                        walk_slots16(acc_f, va, rs + sb);
+                        walk_slots16<false>(acc_f, va, heads + (sb >> 4));
 #pragma unroll
                         for (int k = 0; k < 16; ++k) va[k] = es[sb + 32 + k];
-                        walk_slots16(acc_f, vb, rs + sb + 16);
+                        walk_slots16<false>(acc_f, vb, heads + (sb >> 4) + 1);
                     }
                 } else {
                     const unsigned rec = (unsigned)(size_t)wa;
@@ -692,6 +691,16 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
                 }
             }
             __syncthreads();
+            if (given) { // the record between the heads: sixteen slots per thread
+                for (int t = tid; t * 16 < nslot; t += T) {
+                    double ev[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) ev[k] = es[t * 16 + k];
+                    double acc_f = heads[t];
+                    walk_slots16<true>(acc_f, ev, rs + t * 16);
+                }
+                __syncthreads();
+            }
             // count the new points of this thread's bins (the same subtractions again)
             cnt = 0;
             int wrong = 0, sl = sbase;

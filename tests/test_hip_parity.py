@@ -371,7 +371,7 @@ def test_serial_walk_with_given_decisions_is_the_recurrence_bit_for_bit(case):
 
 
 def test_full_integrate_default_walk_at_large_launches_is_the_reference_recurrence(oracle, monkeypatch):
-    """The DEFAULT refinement walk: once an iteration's sample launch is long enough to hide its ~35 us (>= 2^26 samples per
+    """The DEFAULT refinement walk: once an iteration's sample launch is long enough to hide its ~14 us (>= 2^26 samples per
     rank: the headline configuration's 1e8 included) train! runs the reference's serial recurrence (variable.jl:227-234), so whole
     runs agree with the oracle at the 1e-6 level of the serial walk; below that size the prefix-scan form keeps the launch-bound regime at 50 us per iteration
     (1e-4 level, test_full_integrate_matches_oracle[prefix]).  Engine.set_train_walk("serial") asks for the recurrence at any size."""

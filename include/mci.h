@@ -264,6 +264,7 @@ int mci_set_rng_rounds(mci_problem *prob, int32_t rounds);
  *      the prefix-scan form, one lane walks the additions and subtractions alone, every decision is checked against the exact record
  *      (+14 us per iteration at ninc = 1000 on MI355X); a decision that does not hold sends the walk through mode 2;
  *   2  the recurrence with its compares and branches on one lane in hand-written ISA (+38 us): what 1 falls back to -- bit-identical results;
+ *   3  test hook: mode 1 with one decision deliberately wrong, so that its check and the fall-back to mode 2 run (same results again);
  *   0  the same walk as a fixed-order prefix scan + one bisection per grid point (agrees with the recurrence to 1e-12 of
  *      the variable's range per train! step, i.e. whole runs agree to ~1e-4 instead of ~1e-6);
  *  -1  automatic (default): 1 when the iteration's sample launch on this rank is >= 2^26 samples (the walk then costs ~1 % or less), else 0.
@@ -313,6 +314,9 @@ int mci_last_integrate_persistent(const mci_problem *prob, int32_t *persistent);
 /* development aid (tools/persist_trace.py): the persistent kernel's counter words and, in builds with -DMCI_PERSIST_TRACE, the
  * wall-clock stamps of three of its workgroups over the first eight turns of the last launch */
 int mci_debug_persist_words(mci_problem *prob, unsigned long long *out, int32_t n);
+/* Development aid: out[0] = serial walks of train! (mci_set_train_walk mode 1) this problem has run as slots with given decisions,
+ * out[1] = walks in the general form (mode 2, a decision that did not hold, grids too long for the slots' LDS).  Synchronises the stream. */
+int mci_debug_walk_counts(mci_problem *prob, int64_t *out);
 /* Dist.train! on the histograms currently in the packed buffer (variable.jl:206-239, :369-382) */
 int mci_train(mci_problem *prob);
 /* the adaptive map alone (sampler.jl:293-305, :13-22) + integrand: first `n` samples of block `block_index`

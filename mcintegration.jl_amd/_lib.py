@@ -107,6 +107,7 @@ SIGNATURES = [
     ("mci_set_persistent", C.c_int, [_VP, C.c_int32]),
     ("mci_last_integrate_persistent", C.c_int, [_VP, C.POINTER(C.c_int32)]),
     ("mci_debug_persist_words", C.c_int, [_VP, C.POINTER(C.c_uint64), C.c_int32]),
+    ("mci_debug_walk_counts", C.c_int, [_VP, C.POINTER(C.c_int64)]),
     ("mci_last_chain_launch", C.c_int, [_VP, C.POINTER(C.c_int64), c_int32_p]),
     ("mci_train", C.c_int, [_VP]),
     ("mci_sample_dump", C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),

@@ -825,8 +825,8 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         HIPCHK(hipMalloc((void **)&p->d_ghist, 3 * (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
         HIPCHK(hipMemset(p->d_ghist, 0, 3 * (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
         HIPCHK(hipMalloc((void **)&p->d_stage1, (size_t)mci_problem::kGroups * (s.nbin ? s.nbin : 1) * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&p->d_status, sizeof(int)));
-        HIPCHK(hipMemset(p->d_status, 0, sizeof(int)));
+        HIPCHK(hipMalloc((void **)&p->d_status, 4 * sizeof(int))); // [0] ST_* bits | [1], [2] serial walks of train! as slots, in the general form (mci_debug_walk_counts)
+        HIPCHK(hipMemset(p->d_status, 0, 4 * sizeof(int)));
         std::vector<mci::LeafDev> ld;
         for (auto &L : p->leaves) ld.push_back({L.kind, L.nbin, L.eoff, L.doff, L.boff, L.adapt, L.alpha});
         HIPCHK(hipMalloc((void **)&p->d_leaves, ld.size() * sizeof(mci::LeafDev)));
@@ -1289,7 +1289,7 @@ int mci_set_rng_rounds(mci_problem *p, int32_t rounds) {
 
 int mci_set_train_walk(mci_problem *p, int32_t mode) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
-    if (mode < -1 || mode > 2) return fail(MCI_ERR_INVALID, "train walk mode must be -1 (automatic), 0 (prefix scan), 1 (serial recurrence) or 2 (serial recurrence, general form only)");
+    if (mode < -1 || mode > 3) return fail(MCI_ERR_INVALID, "train walk mode must be -1 (automatic), 0 (prefix scan), 1 (serial recurrence), 2 (serial recurrence, general form only) or 3 (test hook)");
     p->train_serial = mode;
     return MCI_OK;
 }
@@ -1325,6 +1325,17 @@ int mci_debug_persist_words(mci_problem *p, unsigned long long *out, int32_t n) 
     if (!p || !out || !p->d_persist) return fail(MCI_ERR_INVALID, "no persistent launch yet");
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     HIPCHK(hipMemcpy(out, p->d_persist, (size_t)(n < (int)kPersistWords ? n : (int)kPersistWords) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MCI_OK;
+}
+
+// development aid (tools/fuzz_layouts.py --walk): how many serial walks of train! ran as slots with given decisions, how many in the general form
+int mci_debug_walk_counts(mci_problem *p, int64_t *out) {
+    if (!p || !out || !p->d_status) return fail(MCI_ERR_INVALID, "NULL argument");
+    int h[2] = {0, 0};
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    HIPCHK(hipMemcpy(h, p->d_status + 1, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = h[0];
+    out[1] = h[1];
     return MCI_OK;
 }
 

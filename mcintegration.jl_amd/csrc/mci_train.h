@@ -614,7 +614,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
         // instructions per slot with the loads and the record's stores.  Every thread builds its bins' slots, lane 0 walks them,
         // every thread then counts its bins' points from the exact record the way the general form does and compares with c[j]: where
         // all agree the record IS the recurrence's (induction over the bins); one disagreement sends the walk through the general
-        // form.  serial_walk == 2: the general form at once.  spare: [2N + kWalkPad] slots | [2N + kWalkPad] their record | its heads.
+        // form.  serial_walk == 2: the general form at once; 3: slots with one wrong decision (test hook).  spare: [2N + kWalkPad] slots | [2N + kWalkPad] their record | its heads.
         int *flag = (int *)(ps + 64);
         int *pw = (int *)ps;
         const int lane = tid & 63, wave = tid >> 6;
@@ -625,6 +625,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
         auto points = [&](int j) { // c[j] from C[] (in wa[] while `given`); the last bin's decision changes no record: "none", never checked
             if (j >= N - 1) return 0;
             const double c = floor(wa[j] * f_inv) - (j > 0 ? floor(wa[j - 1] * f_inv) : 0.0);
+            if (serial_walk == 3 && j == N / 2) return c > 0.0 ? (int)c + 1 : 1; // test hook: one decision deliberately wrong -- the check must catch it
             return c > 0.0 ? (int)c : 0;
         };
         auto slots = [&](int j, int c) { return c + ((c >= 1 && d[j + 1] >= f_lo && d[j + 1] <= f_hi) ? 0 : 1); };
@@ -720,6 +721,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             if (*flag == 0) break;
             given = false; // (nobody reads wa[] or the flag between this barrier and lane 0's second walk)
         }
+        if (tid == 0) atomicAdd(status + (given ? 1 : 2), 1); // (mci_debug_walk_counts)
         {
             // exclusive scan of the counts over the lanes, then every lane writes its bins' points
             int x = cnt;

@@ -432,8 +432,15 @@ class Engine:
 
     def set_train_walk(self, mode):
         """train!'s refinement walk: "serial" (the reference's recurrence), "scan" (prefix scan + bisection), "auto", or "serial_general"
-        (the recurrence without the predicted decisions: what "serial" falls back to); see mci_set_train_walk"""
-        check(lib().mci_set_train_walk(self.p, {"auto": -1, "scan": 0, "serial": 1, "serial_general": 2, -1: -1, 0: 0, 1: 1, 2: 2}[mode]))
+        (the recurrence without the predicted decisions: what "serial" falls back to; "serial_wrong_decision": a test hook that makes it
+        fall back); see mci_set_train_walk"""
+        check(lib().mci_set_train_walk(self.p, {"auto": -1, "scan": 0, "serial": 1, "serial_general": 2, "serial_wrong_decision": 3, -1: -1, 0: 0, 1: 1, 2: 2, 3: 3}[mode]))
+
+    def walk_counts(self):
+        """(serial walks of train! run as slots with given decisions, walks in the general form) so far; see mci_debug_walk_counts"""
+        out = (C.c_int64 * 2)()
+        check(lib().mci_debug_walk_counts(self.p, out))
+        return int(out[0]), int(out[1])
 
     def integrate(self, solver, neval, niter=10, block=16, ignore=-1, adapt=True, gamma=1.0, measurefreq=1, seed=1234,
                   nchain=0, first_iteration=0, thermal_ratio=0.1, reweight_goal=None):

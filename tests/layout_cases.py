@@ -190,3 +190,36 @@ def check_carried_iterations(oracle, case_id, seed=20260930):
             np.testing.assert_allclose(eng.reweight(), ocfg.reweight, rtol=1e-8 * 10 ** it, err_msg=what)
         eng.close()
     return what
+
+
+def check_walks_agree(case_id, seed=20260930):
+    """train!'s serial walk as slots with given decisions ("serial") against the general form of the same recurrence ("serial_general"):
+    deterministic runs (bit-reproducible histograms) of a random layout -- one Continuous variable type or several, grids of 17 to
+    1500 increments, learning rates 0.5 .. 3, every third case with a narrow peak (bins that yield many points, then an adapting
+    grid) -- must give IDENTICAL iterations and grids."""
+    import numpy as np
+    rng = np.random.default_rng(9000 + case_id)
+    var, oleaves, dof, body, ndraw = (persist_case if case_id % 2 == 0 else pipe_case)(rng)
+    if case_id % 3 == 0:
+        lo, hi = oleaves[0]["lower"], oleaves[0]["upper"]
+        c, k = float(rng.uniform(lo, hi)), float(rng.choice([20.0, 200.0, 2000.0])) / (hi - lo)
+        body += "\n{ const double t = (x[0] - (%.6f)) * %.6f; const double pk = exp(-t * t);" % (c, k)
+        body += "".join(" w[%d] *= pk;" % i for i in range(len(dof))) + " }"
+    neval, niter = int(rng.choice([20000, 60000, 200000])), int(rng.integers(4, 9))
+    what = "case %d: pools=%d ni=%d ndraw=%d ninc=%s alpha=%s neval=%d niter=%d%s" % (
+        case_id, len(var), len(dof), ndraw, [lf["npts"] for lf in oleaves], [lf["alpha"] for lf in oleaves], neval, niter,
+        " peak" if case_id % 3 == 0 else "")
+    out = []
+    for walk in ("serial", "serial_general"):
+        cfg = mci.Configuration(var=var, dof=dof, seed=seed)
+        eng = mci.Engine(cfg, mci.Integrand(body), deterministic=True)
+        eng.set_train_walk(walk)
+        r = eng.integrate("vegas", neval=neval, niter=niter, block=16, seed=seed)
+        out.append((r["iter_mean"].copy(), r["iter_std"].copy(), [eng.grid(i) for i in range(len(oleaves))], eng.walk_counts()))
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]), what
+    for g0, g1 in zip(out[0][2], out[1][2]):
+        assert np.array_equal(g0, g1), what
+        assert np.all(np.diff(g0) > 0), what
+    assert out[1][3][0] == 0 and sum(out[0][3]) == out[1][3][1], (what, out[0][3], out[1][3])   # (one walk per adapting leaf and iteration)
+    return what + "   walks as slots %d, general %d" % out[0][3]

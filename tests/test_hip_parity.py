@@ -350,10 +350,11 @@ def test_serial_walk_with_given_decisions_is_the_recurrence_bit_for_bit(case):
     (acc_f within rounding of f_ninc) or a bin with several points sends it through the general form.  Either way the grid is the
     recurrence's: deterministic runs (bit-reproducible histograms) under "serial" and "serial_general" give IDENTICAL grids and
     iterations -- a narrow peak met by a uniform grid (many points per bin at first), a flat integrand (every bin is a tie: acc_f =
-    f_ninc up to rounding) and the headline layout."""
+    f_ninc up to rounding) and the headline layout; and with one decision deliberately wrong (a test hook) the check catches it and
+    the general form's result comes out."""
     import math
     out = []
-    for walk in ("serial", "serial_general"):
+    for walk in ("serial", "serial_general", "serial_wrong_decision"):
         if case == "gauss16":
             L = math.sqrt(50.0)
             cfg = mci.Configuration(var=mci.Continuous(-L, L), dof=[[16]], seed=SEED)
@@ -364,10 +365,22 @@ def test_serial_walk_with_given_decisions_is_the_recurrence_bit_for_bit(case):
             eng = mci.Engine(cfg, mci.Integrand(body), deterministic=True)
         eng.set_train_walk(walk)
         r = eng.integrate("vegas", neval=200000, niter=8, block=16, seed=SEED)
-        out.append((r["iter_mean"].copy(), r["iter_std"].copy(), eng.grid(0)))
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
-    assert np.array_equal(out[0][2], out[1][2])
+        out.append((r["iter_mean"].copy(), r["iter_std"].copy(), eng.grid(0), eng.walk_counts()))
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0]) and np.array_equal(out[0][1], other[1])
+        assert np.array_equal(out[0][2], other[2])
     assert np.all(np.diff(out[0][2]) > 0)
+    # (slots, general form): one walk per iteration; the hook's wrong decision is caught every time and the walk redone in the general form
+    assert sum(out[0][3]) == 8 and out[1][3] == (0, 8) and out[2][3] == (0, 8)
+    if case != "flat":
+        assert out[0][3] == (8, 0)
+
+
+@pytest.mark.parametrize("case_id", [0, 1, 3, 6, 9, 14])
+def test_serial_walk_slots_against_the_general_form_on_random_layouts(case_id):
+    """a few cases of `tools/fuzz_layouts.py --walk` (tests/layout_cases.py check_walks_agree; the campaign's record is in profiles/)"""
+    from layout_cases import check_walks_agree
+    check_walks_agree(case_id, SEED)
 
 
 def test_full_integrate_default_walk_at_large_launches_is_the_reference_recurrence(oracle, monkeypatch):

@@ -5,10 +5,11 @@ Every case draws a layout (1-5 pools of Continuous / Discrete / CompositeVar, 1-
 2000 increments), a launch shape (blocks, steps per block, chains per block, measure cadence, iteration number) and a generator
 (Philox4x32-10 or -7), JIT-compiles the three sample-batch kernels for it and compares one iteration of each solver with the oracle on
 the same Philox streams: packed sums and histograms to 1e-9 relative, holding-time histogram bucket by bucket, then a three-iteration
-:vegas run with train! in between.  Failures are collected, not fatal.   usage: fuzz_layouts.py [--pipe | --persist | --carry] [first_case] [ncases]
+:vegas run with train! in between.  Failures are collected, not fatal.   usage: fuzz_layouts.py [--pipe | --persist | --carry | --walk] [first_case] [ncases]
 (--pipe: layouts of the pipelined :vegas loop only; --persist: whole integrate() calls over one Continuous variable type run as ONE
 persistent launch, against the oracle's loop; --carry: four consecutive iterations of :vegasmc and :mcmc with carried chains -- :mcmc:
-resampled to the moved reweight factors -- and a changing chain count, doReweight! and train! in between)"""
+resampled to the moved reweight factors -- and a changing chain count, doReweight! and train! in between; --walk: deterministic runs under train!'s
+serial walk as slots with given decisions and under the general form of the recurrence, bit for bit)"""
 import os
 import sys
 import time
@@ -24,12 +25,13 @@ import mci_oracle as oracle
 SEED = 20260930
 
 
-from layout_cases import check_carried_iterations, check_persistent_call, pipe_case, random_case  # noqa: E402  (shared with tests/test_hip_steady_state.py, test_hip_persistent.py)
+from layout_cases import check_carried_iterations, check_persistent_call, check_walks_agree, pipe_case, random_case  # noqa: E402  (shared with tests/test_hip_steady_state.py, test_hip_persistent.py)
 
 
 PIPE_MODE = False
 PERSIST_MODE = False
 CARRY_MODE = False
+WALK_MODE = False
 npersist = 0
 
 
@@ -90,17 +92,25 @@ if __name__ == "__main__":
     if "--carry" in sys.argv:     # four consecutive iterations of both chain solvers with carried chains and changing chain counts
         sys.argv.remove("--carry")
         CARRY_MODE = True
+    if "--walk" in sys.argv:      # serial walk with given decisions against its general form, deterministic runs, bit for bit
+        sys.argv.remove("--walk")
+        WALK_MODE = True
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     oracle.build()
     bad, t0 = [], time.time()
+    nslots = ngeneral = 0
     for c in range(first, first + n):
         try:
-            w = run_persist_case(c) if PERSIST_MODE else check_carried_iterations(oracle, c, SEED) if CARRY_MODE else run_case(c)
+            w = run_persist_case(c) if PERSIST_MODE else check_carried_iterations(oracle, c, SEED) if CARRY_MODE else check_walks_agree(c, SEED) if WALK_MODE else run_case(c)
             print("ok   " + w, flush=True)
+            if WALK_MODE:
+                nslots += int(w.split("walks as slots ")[1].split(",")[0])
+                ngeneral += int(w.split("general ")[1])
         except Exception as e:  # collect and go on
             bad.append(c)
             print("FAIL case %d: %s" % (c, "".join(traceback.format_exception_only(type(e), e))[:3000]), flush=True)
     oracle.set_rng_rounds(10)
-    print("%d cases, %d failed %s in %.0f s" % (n, len(bad), bad, time.time() - t0) + (" (%d ran as one persistent launch)" % npersist if PERSIST_MODE else ""))
+    print("%d cases, %d failed %s in %.0f s" % (n, len(bad), bad, time.time() - t0) + (" (%d ran as one persistent launch)" % npersist if PERSIST_MODE else "")
+          + (" (serial walks: %d as slots with given decisions, %d through the general form)" % (nslots, ngeneral) if WALK_MODE else ""))
     mci.shutdown()

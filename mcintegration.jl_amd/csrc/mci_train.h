@@ -610,9 +610,9 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
         // -- the reference's operations on the reference's operands, nothing else.  The last subtraction of a bin is EXACT (the loop
         // :228 stops at acc_f < f_ninc, so it starts from f_ninc <= acc_f < 2 f_ninc: Sterbenz), and for f_ninc / 2 <= avg_f[j + 1] <=
         // 2 f_ninc so is avg_f[j + 1] - f_ninc: then fl(fl(acc_f - f_ninc) + avg_f[j + 1]) = fl(acc_f + (avg_f[j + 1] - f_ninc)) and the two
-        // slots are one.  On an adapted grid that is nearly every bin: ~N slots, one dependent addition each (walk_slots16), ~2.2
-        // instructions per slot with the loads and the record's stores.  Every thread builds its bins' slots, lane 0 walks them,
-        // every thread then counts its bins' points from the exact record the way the general form does and compares with c[j]: where
+        // slots are one.  On an adapted grid that is nearly every bin: ~N slots, one dependent addition each (walk_slots16), 1.5
+        // instructions per slot with the loads.  Every thread builds its bins' slots, lane 0 walks them recording acc_f at the head of
+        // every sixteen, one thread per sixteen slots redoes the same additions for the record in between, every thread then counts its bins' points from the exact record the way the general form does and compares with c[j]: where
         // all agree the record IS the recurrence's (induction over the bins); one disagreement sends the walk through the general
         // form.  serial_walk == 2: the general form at once; 3: slots with one wrong decision (test hook).  spare: [2N + kWalkPad] slots | [2N + kWalkPad] their record | its heads.
         int *flag = (int *)(ps + 64);

@@ -13,6 +13,8 @@ from .engine import Engine, shutdown  # noqa: F401
 from .integrand import HostIntegrand, HostMeasure, Integrand, Measure, bin_by  # noqa: F401
 from .integrate import integrate, prefill_kernel_cache, standardize_block  # noqa: F401
 from .statistics import Result, average, mean_std, report  # noqa: F401
+from . import trace  # noqa: F401
+from .trace import TraceError, trace_integrand  # noqa: F401
 from .variables import CompositeVar, Continuous, Discrete, FermiK  # noqa: F401
 from . import variables as Dist  # noqa: F401  (reference: module Dist)
 

@@ -37,12 +37,15 @@ def required_positionals(fn, fallback):
 def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, block=16, verbose=-1, gamma=1.0,
               adapt=True, debug=False, reweight_goal=None, ignore=None, measure=None, measurefreq=1,
               thermal_ratio=0.1, inplace=False, parallel="nothread", print=-1, printio=None, timer=None,
-              comm=None, device=None, nchain=0, engine_factory=None, rng_bits=52, rng_rounds=10, deterministic=False, **kwargs):
+              comm=None, device=None, nchain=0, engine_factory=None, rng_bits=52, rng_rounds=10, deterministic=False, trace=False, **kwargs):
     """Same keywords as the reference (main.jl:71-90; unknown ones go to Configuration, :95-97).
     Extra, engine-specific keywords: `comm` (LocalComm | RcclComm | TorchDistComm), `device`, `nchain`
     (vegasmc chains per block; 0 = auto), `rng_bits` (52 | 32: opt-in cheaper uniform stream of solver="vegas", see
     mci_set_rng_bits), `rng_rounds` (10 | 7: opt-in Philox4x32-7 for every stream, mci_set_rng_rounds), `deterministic` (bit-identical
-    results for a fixed seed like the reference's sequential loop, mci_set_deterministic), `engine_factory` (test seam)."""
+    results for a fixed seed like the reference's sequential loop, mci_set_deterministic), `trace` (a Python closure as integrand is
+    run once on symbolic draws and written out as device source -- trace.trace_integrand -- so that it runs inside the kernels like
+    Julia's inlined closure does in the reference's loop; closures that cannot be written out take the host callback path as without
+    it), `engine_factory` (test seam)."""
     if solver in (":vegas", ":vegasmc", ":mcmc"):
         solver = solver[1:]
     if solver not in SOLVERS:
@@ -69,7 +72,17 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         # a Python closure: host "batch callback" path (vegas: per launch, vegasmc / mcmc: per Markov step).  Three positional
         # parameters = the reference's :mcmc form integrand(idx, var, config) (mcmc/montecarlo.jl:34-36), two = integrand(var, config)
         # (parameters with a default do not count: `f(x, config, scale=2.0)` is the two-argument form; HostIntegrand(fn, indexed=...) says it explicitly)
-        integrand = HostIntegrand(integrand, indexed=(required_positionals(integrand, 2) >= 3))
+        indexed = required_positionals(integrand, 2) >= 3
+        traced = None
+        if trace:
+            from .trace import TraceError, trace_integrand
+            try:
+                traced = trace_integrand(integrand, config, indexed=indexed)
+            except TraceError as e:
+                if print > 0:
+                    import builtins
+                    builtins.print("integrand not traced (%s): host callback path" % e)
+        integrand = traced if traced is not None else HostIntegrand(integrand, indexed=indexed)
     if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
         # a Python closure as measure: host batch-callback path.  Five positional parameters = the reference's :mcmc form
         # measure(idx, var, obs, relative_weight, config) (mcmc/montecarlo.jl:166-169), four = measure(var, obs, weights, config)

@@ -1,0 +1,422 @@
+"""A Python closure as integrand at device speed: the closure is run ONCE on symbolic draws and what it computes is written out as
+the HIP C++ body the sample-batch kernels are JIT-compiled around (integrand.Integrand) -- the counterpart of Julia inlining
+`integrand(var, config)` into the reference's loop (vegas/montecarlo.jl:140-144, vegas_mc/updates.jl:67-75, mcmc/montecarlo.jl:34-36).
+
+    f = lambda x, c: np.exp(-np.sum(x * x) / 2) / (2 * np.pi) ** (len(x) / 2)
+    integrate(f, var=Continuous(-5, 5), dof=[[4]], solver="vegas", trace=True)        # or Integrand = trace_integrand(f, config)
+
+The closure sees what a host closure sees (integrand.HostIntegrand) without the batch axis: with one variable type `x[i]` is the
+i-th draw, with several `x` is a tuple with one array per variable type (a CompositeVar pool has shape [slot, leaf]); the arrays are
+numpy object arrays of `Sym` nodes, so indexing, slicing, arithmetic, `sum`, `np.sum / np.prod / np.dot` and the elementwise numpy
+functions (`np.exp`, `np.log`, `np.sqrt`, `np.sin`, ... -- numpy calls the method of the same name on an object) work as they are.
+What cannot be written out raises TraceError and the caller falls back to the host batch-callback path: data-dependent Python
+branches (`if x[0] > 0.5`), `math.*` functions (they want a float), `np.where / np.maximum` on symbols (use `mci.trace.where / fmax /
+fmin`), complex weights.  The written-out body is checked against the closure itself at random points of the domain before it is
+used (the closure is called with plain float arrays, one sample at a time): a closure that is not a pure function of its draws
+(hidden state, a branch taken on something the trace did not see) is refused."""
+import math
+
+import numpy as np
+
+from .integrand import Integrand
+
+
+class TraceError(Exception):
+    """the closure cannot be written out as device source (the host callback path still runs it)"""
+
+
+_FUNCS = ("exp", "log", "sqrt", "sin", "cos", "tan", "tanh", "sinh", "cosh", "arcsin", "arccos", "arctan", "log1p", "expm1", "log10",
+          "log2", "exp2", "cbrt", "floor", "ceil", "erf", "erfc")
+_CNAME = {"arcsin": "asin", "arccos": "acos", "arctan": "atan"}
+_NPFN = {"erf": math.erf, "erfc": math.erfc}
+
+
+class _Trace:
+    """the expression DAG of one trace: nodes are interned, so common subexpressions are one temporary"""
+
+    def __init__(self):
+        self.nodes = []
+        self.index = {}
+
+    def node(self, op, *args):
+        key = (op,) + tuple(a.id if isinstance(a, Sym) else ("k", a) for a in args)
+        s = self.index.get(key)
+        if s is None:
+            s = Sym(self, op, args, len(self.nodes))
+            self.nodes.append(s)
+            self.index[key] = s
+        return s
+
+    def const(self, v):
+        if isinstance(v, (bool, np.bool_)):
+            v = float(v)
+        if isinstance(v, (int, float, np.integer, np.floating)):
+            v = float(v)
+            if not math.isfinite(v):
+                raise TraceError("non-finite constant %r" % v)
+            return self.node("const", v)
+        raise TraceError("cannot use %r (%s) in an integrand expression" % (v, type(v).__name__))
+
+    def lift(self, v):
+        return v if isinstance(v, Sym) else self.const(v)
+
+
+class Sym:
+    """one value of the traced computation (a draw, a constant, or an operation on earlier values)"""
+    __slots__ = ("t", "op", "args", "id")
+
+    def __init__(self, t, op, args, id_):
+        self.t, self.op, self.args, self.id = t, op, args, id_
+
+    # -- what must not happen during a trace
+    def __bool__(self):
+        raise TraceError("a Python branch on a sampled value (use mci.trace.where(cond, a, b))")
+
+    def __float__(self):
+        raise TraceError("float() of a sampled value (math.* functions: use the numpy ones)")
+
+    __int__ = __index__ = __complex__ = __float__
+    __hash__ = object.__hash__
+
+    # -- arithmetic (an ndarray operand hands the operation back to numpy, which applies it element by element)
+    def _bin(self, op, other, swap=False):
+        if isinstance(other, np.ndarray):
+            return NotImplemented
+        o = self.t.lift(other)
+        a, b = (o, self) if swap else (self, o)
+        if op == "+" and (_is_const(a, 0.0) or _is_const(b, 0.0)):
+            return b if _is_const(a, 0.0) else a
+        if op == "*" and (_is_const(a, 1.0) or _is_const(b, 1.0)):
+            return b if _is_const(a, 1.0) else a
+        if op == "-" and _is_const(b, 0.0):
+            return a
+        if op == "/" and _is_const(b, 1.0):
+            return a
+        return self.t.node(op, a, b)
+
+    def __add__(self, o): return self._bin("+", o)
+    def __radd__(self, o): return self._bin("+", o, True)
+    def __sub__(self, o): return self._bin("-", o)
+    def __rsub__(self, o): return self._bin("-", o, True)
+    def __mul__(self, o): return self._bin("*", o)
+    def __rmul__(self, o): return self._bin("*", o, True)
+    def __truediv__(self, o): return self._bin("/", o)
+    def __rtruediv__(self, o): return self._bin("/", o, True)
+    def __lt__(self, o): return self._bin("<", o)
+    def __le__(self, o): return self._bin("<=", o)
+    def __gt__(self, o): return self._bin(">", o)
+    def __ge__(self, o): return self._bin(">=", o)
+    def __neg__(self): return self.t.node("neg", self)
+    def __pos__(self): return self
+    def __abs__(self): return self.t.node("fabs", self)
+
+    def __pow__(self, p):
+        if isinstance(p, np.ndarray):
+            return NotImplemented
+        if isinstance(p, (int, float, np.integer, np.floating)) and float(p) == int(p) and 0 <= int(p) <= 4:
+            k = int(p)           # small integer powers as products, like Julia's x^2 (and what a hand-written body would say)
+            if k == 0:
+                return self.t.const(1.0)
+            r = self
+            for _ in range(k - 1):
+                r = r * self
+            return r
+        if isinstance(p, (int, float, np.integer, np.floating)) and float(p) == 0.5:
+            return self.t.node("sqrt", self)
+        if isinstance(p, (int, float, np.integer, np.floating)) and float(p) == -1.0:
+            return 1.0 / self
+        return self.t.node("pow", self, self.t.lift(p))
+
+    def __rpow__(self, b):
+        if isinstance(b, np.ndarray):
+            return NotImplemented
+        return self.t.node("pow", self.t.lift(b), self)
+
+    def conjugate(self): return self
+
+    @property
+    def real(self): return self
+
+
+def _is_const(s, v):
+    return s.op == "const" and s.args[0] == v
+
+
+def _method(name):
+    def f(self):
+        return self.t.node(name, self)
+    f.__name__ = name
+    return f
+
+
+for _n in _FUNCS:
+    setattr(Sym, _n, _method(_n))   # np.exp(obj) on an object calls obj.exp()
+Sym.fabs = Sym.__abs__
+Sym.absolute = Sym.__abs__
+Sym.square = lambda self: self * self
+Sym.reciprocal = lambda self: 1.0 / self
+Sym.negative = Sym.__neg__
+
+
+def _lift2(a, b):
+    t = a.t if isinstance(a, Sym) else b.t if isinstance(b, Sym) else None
+    if t is None:
+        raise TraceError("no sampled value among the arguments")
+    return t, t.lift(a), t.lift(b)
+
+
+def where(cond, a, b):
+    """cond ? a : b, element by element; cond a comparison of traced values (the traced counterpart of np.where)"""
+    if any(isinstance(v, np.ndarray) for v in (cond, a, b)):
+        return np.frompyfunc(where, 3, 1)(cond, a, b)
+    if not isinstance(cond, Sym):
+        return a if cond else b
+    t = cond.t
+    return t.node("where", cond, t.lift(a), t.lift(b))
+
+
+def fmax(a, b):
+    """the larger of two traced values (np.maximum compares Python objects and cannot be traced)"""
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return np.frompyfunc(fmax, 2, 1)(a, b)
+    if not isinstance(a, Sym) and not isinstance(b, Sym):
+        return max(a, b)
+    t, a, b = _lift2(a, b)
+    return t.node("fmax", a, b)
+
+
+def fmin(a, b):
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return np.frompyfunc(fmin, 2, 1)(a, b)
+    if not isinstance(a, Sym) and not isinstance(b, Sym):
+        return min(a, b)
+    t, a, b = _lift2(a, b)
+    return t.node("fmin", a, b)
+
+
+def arctan2(a, b):
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return np.frompyfunc(arctan2, 2, 1)(a, b)
+    if not isinstance(a, Sym) and not isinstance(b, Sym):
+        return math.atan2(a, b)
+    t, a, b = _lift2(a, b)
+    return t.node("atan2", a, b)
+
+
+# ---- writing the DAG out, and evaluating it for the check ----
+_BINOPS = ("+", "-", "*", "/", "<", "<=", ">", ">=")
+
+
+def _reachable(outs):
+    seen, order = set(), []
+
+    def visit(s):
+        stack = [(s, False)]
+        while stack:
+            n, done = stack.pop()
+            if done:
+                order.append(n)
+                continue
+            if n.id in seen:
+                continue
+            seen.add(n.id)
+            stack.append((n, True))
+            for a in n.args:
+                if isinstance(a, Sym):
+                    stack.append((a, False))
+    for o in outs:
+        visit(o)
+    return order   # children before parents
+
+
+def _literal(v):
+    r = repr(float(v))
+    return r if any(c in r for c in ".en") else r + ".0"
+
+
+def emit(outs):
+    """HIP C++ / C body: one `const double tK = ...;` per operation (children first), then `w[i] = ...;`"""
+    order = _reachable(outs)
+    uses = {}
+    for n in order:
+        for a in n.args:
+            if isinstance(a, Sym):
+                uses[a.id] = uses.get(a.id, 0) + 1
+    name, lines = {}, []
+
+    def ref(a):
+        return name[a.id]
+    for n in order:
+        if n.op == "x":
+            name[n.id] = "x[%d]" % n.args[0]
+            continue
+        if n.op == "const":
+            v = n.args[0]
+            name[n.id] = _literal(v) if v >= 0 else "(%s)" % _literal(v)
+            continue
+        if n.op in _BINOPS:
+            e = "%s %s %s" % (ref(n.args[0]), n.op, ref(n.args[1]))
+        elif n.op == "neg":
+            e = "-%s" % ref(n.args[0])
+        elif n.op == "where":
+            e = "%s ? %s : %s" % tuple(ref(a) for a in n.args)
+        else:
+            e = "%s(%s)" % (_CNAME.get(n.op, n.op), ", ".join(ref(a) for a in n.args))
+        if n.op in ("<", "<=", ">", ">="):
+            lines.append("const int t%d = %s;" % (n.id, e))      # (int: the body is also compiled as C by the oracle)
+        else:
+            lines.append("const double t%d = %s;" % (n.id, e))
+        name[n.id] = "t%d" % n.id
+    for i, o in enumerate(outs):
+        lines.append("w[%d] = %s;" % (i, ref(o)))
+    return "\n".join(lines)
+
+
+def evaluate(outs, X):
+    """the DAG on numeric draws X[draw, sample] (numpy), for the check against the closure itself"""
+    val = {}
+    with np.errstate(all="ignore"):
+        for n in _reachable(outs):
+            a = [val[q.id] if isinstance(q, Sym) else q for q in n.args]
+            if n.op == "x":
+                v = X[n.args[0]]
+            elif n.op == "const":
+                v = np.float64(n.args[0])
+            elif n.op == "+":
+                v = a[0] + a[1]
+            elif n.op == "-":
+                v = a[0] - a[1]
+            elif n.op == "*":
+                v = a[0] * a[1]
+            elif n.op == "/":
+                v = a[0] / a[1]
+            elif n.op in ("<", "<=", ">", ">="):
+                v = {"<": np.less, "<=": np.less_equal, ">": np.greater, ">=": np.greater_equal}[n.op](a[0], a[1])
+            elif n.op == "neg":
+                v = -a[0]
+            elif n.op == "where":
+                v = np.where(a[0], a[1], a[2])
+            elif n.op == "pow":
+                v = np.power(a[0], a[1])
+            elif n.op == "atan2":
+                v = np.arctan2(a[0], a[1])
+            elif n.op in ("fmax", "fmin", "fabs"):
+                v = getattr(np, n.op)(*a)
+            elif n.op in _NPFN:
+                v = np.vectorize(_NPFN[n.op])(a[0])
+            else:
+                v = getattr(np, n.op)(a[0])
+            val[n.id] = v
+    return [np.broadcast_to(np.asarray(val[o.id], dtype=np.float64), X.shape[1:]) for o in outs]
+
+
+def _pools(config):
+    pools, k = [], 0
+    for vi in range(len(config.var)):
+        nl = config.pool_width(vi)
+        pools.append((k, config.maxdof[vi], nl))
+        k += config.maxdof[vi] * nl
+    return pools, k
+
+
+def _argument(pools, leaf):
+    """what the closure is called with: leaf(k) for flat draw k, arranged like HostIntegrand's argument without the batch axis"""
+    def arr(k0, md, nl):
+        a = np.empty((md,) if nl == 1 else (md, nl), dtype=object)
+        for s in range(md):
+            if nl == 1:
+                a[s] = leaf(k0 + s)
+            else:
+                for l in range(nl):
+                    a[s, l] = leaf(k0 + s * nl + l)
+        return a
+    if len(pools) == 1:
+        return arr(*pools[0])
+    return tuple(arr(*p) for p in pools)
+
+
+def _domain_points(config, ndraw, n, rng):
+    """random draws inside the variables' domains, X[draw, sample]"""
+    X = np.empty((ndraw, n))
+    k = 0
+    for vi, v in enumerate(config.var):
+        nl = config.pool_width(vi)
+        leaves = list(getattr(v, "vars", [v]))
+        for s in range(config.maxdof[vi]):
+            for l in range(nl):
+                lf = leaves[l] if l < len(leaves) else leaves[0]
+                lo, hi = float(getattr(lf, "lower", 0.0)), float(getattr(lf, "upper", 1.0))
+                if hasattr(lf, "maxK"):                          # FermiK: momentum components
+                    lo, hi = -lf.maxK / math.sqrt(lf.dim), lf.maxK / math.sqrt(lf.dim)
+                if not (math.isfinite(lo) and math.isfinite(hi) and hi > lo):
+                    lo, hi = 0.0, 1.0
+                if hasattr(lf, "ninc") or hasattr(lf, "maxK") or not float(lo).is_integer():
+                    X[k] = rng.uniform(lo, hi, n)
+                else:                                            # Discrete: integer values
+                    X[k] = rng.integers(int(lo), int(hi) + 1, n)
+                k += 1
+    return X
+
+
+def trace_integrand(fn, config, indexed=False, check_points=32, name=None):
+    """Run the closure once on symbolic draws and return the Integrand (HIP C++ body) that computes the same thing; TraceError if
+    it cannot be written out or if the written-out body and the closure disagree at random points of the domain.
+
+    fn(x, config) -> value | tuple of N values    (indexed=True: fn(idx, x, config) -> value, the reference's :mcmc form, idx 0-based)"""
+    if getattr(config, "ncomp", 1) != 1:
+        raise TraceError("complex weights are not traced")
+    pools, ndraw = _pools(config)
+    t = _Trace()
+    arg = _argument(pools, lambda k: t.node("x", k))
+    N = config.N
+    try:
+        if indexed:
+            outs = [fn(i, arg, config) for i in range(N)]
+        else:
+            outs = fn(arg, config)
+            if N == 1 and not isinstance(outs, (tuple, list)):
+                outs = (outs,)
+            outs = list(outs)
+    except TraceError:
+        raise
+    except Exception as e:   # whatever else the closure does with a symbol that a float would have survived
+        raise TraceError("%s: %s" % (type(e).__name__, e))
+    if len(outs) != N:
+        raise TraceError("the integrand must return one value per integrand (%d), got %d" % (N, len(outs)))
+    syms = []
+    for o in outs:
+        if isinstance(o, np.ndarray) and o.size == 1:
+            o = o.reshape(-1)[0]
+        if not isinstance(o, Sym):
+            o = t.const(o)
+        if o.op in ("<", "<=", ">", ">="):
+            o = t.node("where", o, t.const(1.0), t.const(0.0))
+        syms.append(o)
+    body = emit(syms)
+    if check_points:
+        rng = np.random.default_rng(12345)
+        X = _domain_points(config, ndraw, check_points, rng)
+        ref = np.empty((N, check_points))
+        try:
+            with np.errstate(all="ignore"):
+                for p in range(check_points):   # the closure on one sample at a time: plain floats where the trace had symbols
+                    num = _argument(pools, lambda k: X[k, p])
+                    num = tuple(a.astype(np.float64) for a in num) if isinstance(num, tuple) else num.astype(np.float64)
+                    if indexed:
+                        r = [fn(i, num, config) for i in range(N)]
+                    else:
+                        r = fn(num, config)
+                        if N == 1 and not isinstance(r, (tuple, list)):
+                            r = (r,)
+                    for i in range(N):
+                        ref[i, p] = float(np.asarray(r[i], dtype=np.float64).reshape(-1)[0])
+        except Exception as e:
+            raise TraceError("the closure does not run on numeric draws (%s: %s)" % (type(e).__name__, e))
+        got = evaluate(syms, X)
+        for i in range(N):
+            r = ref[i]
+            ok = np.isfinite(r) & np.isfinite(got[i])
+            if not np.array_equal(np.isfinite(r), np.isfinite(got[i])) or not np.allclose(got[i][ok], r[ok], rtol=1e-10, atol=1e-290):
+                raise TraceError("the traced expression and the closure disagree on integrand %d: the closure is not a pure "
+                                 "function of its draws (hidden state, a branch the trace did not see)" % i)
+    return Integrand(body, None, name=name or getattr(fn, "__name__", "traced"))

@@ -1,0 +1,149 @@
+"""Python closures written out as device source (mcintegration_jl_amd/trace.py): the counterpart of Julia inlining `integrand(var, config)`
+into the reference's loop (vegas/montecarlo.jl:140-144).  On the CPU: the written-out body is compiled with gcc (the way the oracle
+compiles any body) and compared with the closure at random points; it compiles for gfx950 through the library's JIT (offline
+context); integrate(..., trace=True) hands an engine the body (here the oracle, end to end); closures that cannot be written out are
+refused and take the host callback path."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+import mcintegration_jl_amd as mci
+from mcintegration_jl_amd.trace import TraceError, arctan2, fmax, fmin, trace_integrand, where
+
+
+def _erf(x):
+    return np.vectorize(math.erf)(x) if isinstance(x, np.ndarray) and x.dtype != object else x.erf() if hasattr(x, "erf") else math.erf(x)
+
+
+CASES = [
+    # name, configuration, closure(s)
+    ("gauss4", lambda: mci.Configuration(var=mci.Continuous(-5.0, 5.0), dof=[[4]]),
+     lambda x, c: np.exp(-np.sum(x * x) / 2) / (2 * np.pi) ** (len(x) / 2)),
+    ("x2y2", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]]), lambda x, c: x[0] ** 2 + x[1] ** 2),
+    ("two_integrands_two_pools", lambda: mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 6)), dof=[[2, 1], [1, 0]]),
+     lambda x, c: (x[0][0] ** 2 + x[0][1] * np.sin(x[1][0]), np.sqrt(x[0][0]) * 2 - 1 / (1 + x[0][0]))),
+    ("selects", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3]]),
+     lambda x, c: where(x[0] > 0.5, fmax(x[1], 0.2), abs(x[2] - 0.5)) ** 1.5 + fmin(x[0], x[1]) * arctan2(x[1], x[2] + 0.1)),
+    ("functions", lambda: mci.Configuration(var=mci.Continuous(0.1, 2.0), dof=[[3]]),
+     lambda x, c: np.log(x[0]) * np.cos(x[1]) + np.tanh(x[2]) / np.cosh(x[0]) + np.log1p(x[1]) - np.expm1(-x[2]) + np.arctan(x[0]) + 2.0 ** x[1] + x[2] ** -1 + x[0] ** 0.5 + x[1] ** 5),
+    ("sums", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[6]]),
+     lambda x, c: sum(x) * np.prod(x[:3] + 1.0) + np.dot(x[::2], x[1::2]) - x[-1] * 3 + 7),
+    ("composite", lambda: mci.Configuration(var=mci.CompositeVar(mci.Continuous(0.0, 1.0), mci.Continuous(-1.0, 1.0)), dof=[[2]]),
+     lambda x, c: x[0, 0] * x[1, 1] + np.exp(-x[0, 1] ** 2) * x[1, 0]),
+    ("constant_and_shared_subexpressions", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [2]]),
+     lambda x, c: (1.5, np.exp(x[0] * x[1]) + np.exp(x[0] * x[1]) ** 2)),
+]
+
+
+def _c_function(oracle, body):
+    fn = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))(oracle.compile_c_integrand(body))
+    return fn
+
+
+@pytest.mark.parametrize("name,cfg,f", CASES, ids=[c[0] for c in CASES])
+def test_traced_body_computes_what_the_closure_computes(oracle, name, cfg, f):
+    from mcintegration_jl_amd.trace import _argument, _domain_points, _pools
+    config = cfg()
+    I = trace_integrand(f, config)
+    assert isinstance(I, mci.Integrand) and "w[%d] =" % (config.N - 1) in I.body
+    fn = _c_function(oracle, I.body)
+    pools, ndraw = _pools(config)
+    rng = np.random.default_rng(5)
+    X = _domain_points(config, ndraw, 200, rng)
+    for p in range(200):
+        x = np.ascontiguousarray(X[:, p])
+        w = np.zeros(config.N)
+        fn(x.ctypes.data_as(C.POINTER(C.c_double)), w.ctypes.data_as(C.POINTER(C.c_double)), None)
+        arg = _argument(pools, lambda k: X[k, p])
+        arg = tuple(a.astype(np.float64) for a in arg) if isinstance(arg, tuple) else arg.astype(np.float64)
+        ref = f(arg, config)
+        ref = np.array(ref if isinstance(ref, tuple) else [ref], dtype=np.float64)
+        np.testing.assert_allclose(w, ref, rtol=1e-13, atol=1e-300, err_msg="%s at %s\n%s" % (name, x, I.body))
+    if name == "constant_and_shared_subexpressions":
+        assert I.body.count("exp(") == 1                  # interned: one temporary for the shared subexpression
+
+
+def test_indexed_form_is_traced_per_integrand(oracle):
+    """the reference's :mcmc form integrand(idx, var, config) (mcmc/montecarlo.jl:34-36): one trace per index"""
+    config = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1], [2]])
+    f = lambda idx, x, c: x[0] if idx == 0 else x[0] * x[1]
+    I = trace_integrand(f, config, indexed=True)
+    assert "w[0] = x[0];" in I.body and "x[0] * x[1]" in I.body
+
+
+@pytest.mark.parametrize("what,f", [
+    ("a Python branch on a draw", lambda x, c: 1.0 if x[0] > 0.5 else 0.0),
+    ("math.exp wants a float", lambda x, c: math.exp(x[0])),
+    ("np.maximum compares objects", lambda x, c: np.maximum(x[0], 0.5)),
+    ("wrong number of values", lambda x, c: (x[0], x[1])),
+    ("not a number", lambda x, c: "one"),
+    ("non-finite constant", lambda x, c: x[0] * float("inf")),
+])
+def test_closures_that_cannot_be_written_out_are_refused(what, f):
+    config = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
+    with pytest.raises(TraceError):
+        trace_integrand(f, config)
+
+
+def test_a_closure_with_hidden_state_is_refused():
+    """the written-out body is checked against the closure itself at random points before it is used"""
+    config = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
+    calls = []
+
+    def f(x, c):
+        calls.append(1)
+        return x[0] * len(calls)        # a different function every time it is called
+    with pytest.raises(TraceError):
+        trace_integrand(f, config)
+    with pytest.raises(TraceError):
+        trace_integrand(lambda x, c: x[0] * 2, mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]], type=complex))
+
+
+def test_integrate_with_trace_hands_the_engine_device_source(oracle):
+    """integrate(closure, trace=True): the engine gets an Integrand (source), not a host callback -- run here on the oracle end to end
+    (same loop as test_distributed_gloo's OracleEngine); a closure that cannot be traced still gets its HostIntegrand"""
+    from oracle_engine import OracleEngine
+    got = {}
+
+    class Traced(OracleEngine):
+        def __init__(self, config, integrand, **kw):
+            got["integrand"] = integrand
+            if isinstance(integrand, mci.Integrand):
+                integrand.name = oracle.compile_c_integrand(integrand.body)
+            super().__init__(config, integrand, **kw)
+
+    r = mci.integrate(lambda x, c: x[0] ** 2 + x[1] ** 2, var=mci.Continuous(0.0, 1.0), dof=[[2]], solver="vegas", neval=20000, niter=6,
+                      block=8, seed=3, trace=True, engine_factory=Traced, print=-1)
+    assert isinstance(got["integrand"], mci.Integrand) and "x[0] * x[0]" in got["integrand"].body
+    assert abs(r.mean[0] - 2.0 / 3.0) < 5 * r.stdev[0] and r.stdev[0] < 2e-3
+
+    class Stop(Exception):
+        pass
+
+    def factory(config, integrand, **kw):
+        got["integrand"] = integrand
+        raise Stop()
+    for trace in (True, False):
+        with pytest.raises(Stop):
+            mci.integrate(lambda x, c: 1.0 if x[0] > 0.5 else 0.0, var=mci.Continuous(0.0, 1.0), dof=[[1]], solver="vegas", trace=trace,
+                          engine_factory=factory, print=-1)
+        assert isinstance(got["integrand"], mci.HostIntegrand)
+    with pytest.raises(Stop):   # without trace=True a closure is a host closure, as before
+        mci.integrate(lambda x, c: x[0], var=mci.Continuous(0.0, 1.0), dof=[[1]], solver="vegas", engine_factory=factory, print=-1)
+    assert isinstance(got["integrand"], mci.HostIntegrand)
+
+
+def test_traced_bodies_compile_for_gfx950():
+    """every function the tracer can write out exists in the device's math library: the :vegas kernel of each case compiles through
+    the library's JIT without a GPU (offline context)"""
+    for name, cfg, f in CASES:
+        if name in ("composite",):
+            continue        # (:vegas has no CompositeVar restriction, but keep the offline compile to the plain layouts)
+        config = cfg()
+        eng = mci.Engine(config, trace_integrand(f, config), device=-1)
+        eng.compile("vegas")
+        assert os.path.exists(eng.code_object("vegas")), name
+        eng.close()

@@ -10,8 +10,8 @@ i-th draw, with several `x` is a tuple with one array per variable type (a Compo
 numpy object arrays of `Sym` nodes, so indexing, slicing, arithmetic, `sum`, `np.sum / np.prod / np.dot` and the elementwise numpy
 functions (`np.exp`, `np.log`, `np.sqrt`, `np.sin`, ... -- numpy calls the method of the same name on an object) work as they are.
 What cannot be written out raises TraceError and the caller falls back to the host batch-callback path: data-dependent Python
-branches (`if x[0] > 0.5`), `math.*` functions (they want a float), `np.where / np.maximum` on symbols (use `mci.trace.where / fmax /
-fmin`), complex weights.  The written-out body is checked against the closure itself at random points of the domain before it is
+branches (`if x[0] > 0.5`), `math.*` functions (they want a float), `np.where / np.maximum` on ARRAYS of symbols (numpy compares
+and truth-tests the elements itself; on single draws they trace, and `mci.trace.where / fmax / fmin` take arrays too), complex weights.  The written-out body is checked against the closure itself at random points of the domain before it is
 used (the closure is called with plain float arrays, one sample at a time): a closure that is not a pure function of its draws
 (hidden state, a branch taken on something the trace did not see) is refused."""
 import math
@@ -132,6 +132,21 @@ class Sym:
             return NotImplemented
         return self.t.node("pow", self.t.lift(b), self)
 
+    # -- numpy on a symbol: np.maximum(x[0], 0.5), np.where(x[0] > 0.5, a, b), np.clip(...), and ndarray <op> symbol
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if method != "__call__" or kwargs:
+            raise TraceError("np.%s.%s with %s on a sampled value" % (ufunc.__name__, method, sorted(kwargs) or "this call form"))
+        if any(isinstance(i, np.ndarray) for i in inputs):   # (symbols boxed: frompyfunc is a ufunc itself and would come back here)
+            return np.frompyfunc(lambda *a: _ufunc(ufunc, *a), len(inputs), 1)(*[_boxed(i) for i in inputs])
+        return _ufunc(ufunc, *inputs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func is np.where and len(args) == 3 and not kwargs:
+            return where(*args)
+        if func is np.clip and len(args) == 3 and not kwargs:
+            return fmin(fmax(args[0], args[1]), args[2])
+        return func._implementation(*args, **kwargs)
+
     def conjugate(self): return self
 
     @property
@@ -158,6 +173,53 @@ Sym.reciprocal = lambda self: 1.0 / self
 Sym.negative = Sym.__neg__
 
 
+def _boxed(v):
+    if not isinstance(v, Sym):
+        return v
+    a = np.empty((), dtype=object)
+    a[()] = v
+    return a
+
+
+_UFUNC_BIN = {"add": "+", "subtract": "-", "multiply": "*", "divide": "/", "true_divide": "/", "less": "<", "less_equal": "<=",
+              "greater": ">", "greater_equal": ">="}
+
+
+def _ufunc(ufunc, *a):
+    """one numpy ufunc applied to symbols / numbers (Sym.__array_ufunc__)"""
+    if not any(isinstance(v, Sym) for v in a):
+        return ufunc(*a)
+    n = ufunc.__name__
+    t = [v for v in a if isinstance(v, Sym)][0].t
+    if n in _UFUNC_BIN:
+        x, y = t.lift(a[0]), t.lift(a[1])
+        return x._bin(_UFUNC_BIN[n], y)
+    if n == "power":
+        return t.lift(a[0]) ** a[1] if isinstance(a[0], Sym) else a[1].__rpow__(a[0])
+    if n in ("maximum", "fmax"):
+        return fmax(a[0], a[1])
+    if n in ("minimum", "fmin"):
+        return fmin(a[0], a[1])
+    if n == "arctan2":
+        return arctan2(a[0], a[1])
+    if n == "hypot":
+        x, y = t.lift(a[0]), t.lift(a[1])
+        return (x * x + y * y).sqrt()
+    if n == "negative":
+        return -a[0]
+    if n == "positive":
+        return a[0]
+    if n in ("absolute", "fabs"):
+        return abs(a[0])
+    if n == "sign":
+        return where(a[0] > 0.0, 1.0, where(a[0] < 0.0, -1.0, 0.0))
+    if n == "heaviside":
+        return where(t.lift(a[0]) > 0.0, 1.0, where(t.lift(a[0]) < 0.0, 0.0, a[1]))
+    if len(a) == 1 and hasattr(Sym, n):
+        return getattr(a[0], n)()
+    raise TraceError("np.%s is not written out" % n)
+
+
 def _lift2(a, b):
     t = a.t if isinstance(a, Sym) else b.t if isinstance(b, Sym) else None
     if t is None:
@@ -168,7 +230,7 @@ def _lift2(a, b):
 def where(cond, a, b):
     """cond ? a : b, element by element; cond a comparison of traced values (the traced counterpart of np.where)"""
     if any(isinstance(v, np.ndarray) for v in (cond, a, b)):
-        return np.frompyfunc(where, 3, 1)(cond, a, b)
+        return np.frompyfunc(where, 3, 1)(_boxed(cond), _boxed(a), _boxed(b))
     if not isinstance(cond, Sym):
         return a if cond else b
     t = cond.t
@@ -178,7 +240,7 @@ def where(cond, a, b):
 def fmax(a, b):
     """the larger of two traced values (np.maximum compares Python objects and cannot be traced)"""
     if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
-        return np.frompyfunc(fmax, 2, 1)(a, b)
+        return np.frompyfunc(fmax, 2, 1)(_boxed(a), _boxed(b))
     if not isinstance(a, Sym) and not isinstance(b, Sym):
         return max(a, b)
     t, a, b = _lift2(a, b)
@@ -187,7 +249,7 @@ def fmax(a, b):
 
 def fmin(a, b):
     if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
-        return np.frompyfunc(fmin, 2, 1)(a, b)
+        return np.frompyfunc(fmin, 2, 1)(_boxed(a), _boxed(b))
     if not isinstance(a, Sym) and not isinstance(b, Sym):
         return min(a, b)
     t, a, b = _lift2(a, b)
@@ -196,7 +258,7 @@ def fmin(a, b):
 
 def arctan2(a, b):
     if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
-        return np.frompyfunc(arctan2, 2, 1)(a, b)
+        return np.frompyfunc(arctan2, 2, 1)(_boxed(a), _boxed(b))
     if not isinstance(a, Sym) and not isinstance(b, Sym):
         return math.atan2(a, b)
     t, a, b = _lift2(a, b)

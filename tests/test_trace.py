@@ -33,6 +33,12 @@ CASES = [
      lambda x, c: sum(x) * np.prod(x[:3] + 1.0) + np.dot(x[::2], x[1::2]) - x[-1] * 3 + 7),
     ("composite", lambda: mci.Configuration(var=mci.CompositeVar(mci.Continuous(0.0, 1.0), mci.Continuous(-1.0, 1.0)), dof=[[2]]),
      lambda x, c: x[0, 0] * x[1, 1] + np.exp(-x[0, 1] ** 2) * x[1, 0]),
+    ("numpy_selects_on_single_draws", lambda: mci.Configuration(var=mci.Continuous(-1.0, 1.0), dof=[[3]]),
+     lambda x, c: np.maximum(x[0], 0.5) + np.minimum(x[1], x[2]) + np.where(x[0] > 0.2, x[1], -x[2]) * np.sign(x[1]) + np.clip(x[2], -0.3, 0.4)
+     + np.hypot(x[0], x[1]) + np.abs(x[2]) + np.heaviside(x[0], 0.5) + np.arctan2(x[1], x[2])),
+    ("arrays_with_draws_and_numbers", lambda: mci.Configuration(var=mci.Continuous(-1.0, 1.0), dof=[[3]]),
+     lambda x, c: np.sum(2.0 * x) + np.sum(x * x[0]) + (x + x[1])[2] + np.exp(x).sum() + np.sqrt(np.abs(x) + 1.0).prod() + np.power(x[0], 2)
+     + np.power(2.0, x[1]) + np.square(x[2]) + (x[0] - x) @ (x / 2.0)),
     ("constant_and_shared_subexpressions", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [2]]),
      lambda x, c: (1.5, np.exp(x[0] * x[1]) + np.exp(x[0] * x[1]) ** 2)),
 ]
@@ -77,7 +83,8 @@ def test_indexed_form_is_traced_per_integrand(oracle):
 @pytest.mark.parametrize("what,f", [
     ("a Python branch on a draw", lambda x, c: 1.0 if x[0] > 0.5 else 0.0),
     ("math.exp wants a float", lambda x, c: math.exp(x[0])),
-    ("np.maximum compares objects", lambda x, c: np.maximum(x[0], 0.5)),
+    ("np.maximum on an ARRAY of draws compares and truth-tests the elements itself", lambda x, c: np.maximum(x, 0.5).sum()),
+    ("a reduction form of a ufunc on a draw", lambda x, c: np.add.reduce(x[0])),
     ("wrong number of values", lambda x, c: (x[0], x[1])),
     ("not a number", lambda x, c: "one"),
     ("non-finite constant", lambda x, c: x[0] * float("inf")),

@@ -101,7 +101,7 @@ struct mci_ctx {
 };
 
 namespace {
-// train! stages one leaf in LDS: train_lds_doubles(nbin) + nbin doubles in k_finish (~4.5 per bin) next to ~2 KiB of static LDS
+// train! stages one leaf in LDS: train_lds_doubles(nbin) + nbin doubles in k_finish (~4.5 per bin; + the serial walk's slots where they fit) next to ~2 KiB of static LDS
 // -> the largest grid one workgroup can refine
 const int64_t kTrainLdsMax = 160 * 1024 - 4096;
 const int kMaxLeafBins = 4400;

@@ -14,7 +14,7 @@ from .integrand import HostIntegrand, HostMeasure, Integrand, Measure, bin_by  #
 from .integrate import integrate, prefill_kernel_cache, standardize_block  # noqa: F401
 from .statistics import Result, average, mean_std, report  # noqa: F401
 from . import trace  # noqa: F401
-from .trace import TraceError, trace_integrand  # noqa: F401
+from .trace import TraceError, trace_integrand, trace_measure  # noqa: F401
 from .variables import CompositeVar, Continuous, Discrete, FermiK  # noqa: F401
 from . import variables as Dist  # noqa: F401  (reference: module Dist)
 

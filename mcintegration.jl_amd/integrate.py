@@ -86,7 +86,17 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
         # a Python closure as measure: host batch-callback path.  Five positional parameters = the reference's :mcmc form
         # measure(idx, var, obs, relative_weight, config) (mcmc/montecarlo.jl:166-169), four = measure(var, obs, weights, config)
-        measure = HostMeasure(measure, indexed=(required_positionals(measure, 4) >= 5))
+        mindexed = required_positionals(measure, 4) >= 5
+        tmeasure = None
+        if trace:
+            from .trace import TraceError, trace_measure
+            try:
+                tmeasure = trace_measure(measure, config, indexed=mindexed)
+            except TraceError as e:
+                if print > 0:
+                    import builtins
+                    builtins.print("measure not traced (%s): host callback path" % e)
+        measure = tmeasure if tmeasure is not None else HostMeasure(measure, indexed=mindexed)
     mkey = None if measure is None else measure.body if isinstance(measure, (Measure, HostMeasure)) else (measure.pool, measure.slot, measure.leaf)
     key = (integrand.body, tuple(integrand.userdata), mkey, device,
            repr(config.neighbor), int(rng_bits), int(rng_rounds), bool(deterministic))

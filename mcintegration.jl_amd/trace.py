@@ -18,7 +18,7 @@ import math
 
 import numpy as np
 
-from .integrand import Integrand
+from .integrand import Integrand, Measure
 
 
 class TraceError(Exception):
@@ -147,10 +147,40 @@ class Sym:
             return fmin(fmax(args[0], args[1]), args[2])
         return func._implementation(*args, **kwargs)
 
+    # -- what a batch-vectorised closure does with a vector over the batch, on the one sample of the trace
+    def sum(self, *a, **k): return self          # weights[0].sum(): the per-sample value IS the sample's contribution
+
+    def __getitem__(self, m):                    # weights[0][mask]: the value where the mask holds, else nothing (0)
+        if isinstance(m, Sym) and m.op in _BOOL:
+            return where(m, self, 0.0)
+        if m is Ellipsis or m == slice(None):
+            return self
+        raise TraceError("indexing a sampled value with %r" % (m,))
+
+    def __invert__(self):
+        if self.op not in _BOOL:
+            raise TraceError("~ of a value that is not a comparison")
+        return self.t.node("not", self)
+
+    def _logic(self, op, o):
+        if isinstance(o, (bool, np.bool_)):
+            return (self if o else self.t.node("not", self.t.node("or", self, self.t.node("not", self)))) if op == "and" else (self if not o else self.t.node("or", self, self.t.node("not", self)))
+        if not (isinstance(o, Sym) and o.op in _BOOL and self.op in _BOOL):
+            raise TraceError("& / | of values that are not comparisons")
+        return self.t.node(op, self, o)
+
+    def __and__(self, o): return self._logic("and", o)
+    def __rand__(self, o): return self._logic("and", o)
+    def __or__(self, o): return self._logic("or", o)
+    def __ror__(self, o): return self._logic("or", o)
+
     def conjugate(self): return self
 
     @property
     def real(self): return self
+
+
+_BOOL = ("<", "<=", ">", ">=", "not", "and", "or")
 
 
 def _is_const(s, v):
@@ -296,8 +326,8 @@ def _literal(v):
     return r if any(c in r for c in ".en") else r + ".0"
 
 
-def emit(outs):
-    """HIP C++ / C body: one `const double tK = ...;` per operation (children first), then `w[i] = ...;`"""
+def emit(outs, sink=lambda i, ref: "w[%d] = %s;" % (i, ref)):
+    """HIP C++ / C body: one `const double tK = ...;` per operation (children first), then `w[i] = ...;` (or what `sink` says)"""
     order = _reachable(outs)
     uses = {}
     for n in order:
@@ -309,8 +339,8 @@ def emit(outs):
     def ref(a):
         return name[a.id]
     for n in order:
-        if n.op == "x":
-            name[n.id] = "x[%d]" % n.args[0]
+        if n.op in ("x", "rw"):
+            name[n.id] = "%s[%d]" % (n.op, n.args[0])
             continue
         if n.op == "const":
             v = n.args[0]
@@ -320,28 +350,38 @@ def emit(outs):
             e = "%s %s %s" % (ref(n.args[0]), n.op, ref(n.args[1]))
         elif n.op == "neg":
             e = "-%s" % ref(n.args[0])
+        elif n.op == "not":
+            e = "!%s" % ref(n.args[0])
+        elif n.op in ("and", "or"):
+            e = "%s %s %s" % (ref(n.args[0]), "&&" if n.op == "and" else "||", ref(n.args[1]))
         elif n.op == "where":
             e = "%s ? %s : %s" % tuple(ref(a) for a in n.args)
         else:
             e = "%s(%s)" % (_CNAME.get(n.op, n.op), ", ".join(ref(a) for a in n.args))
-        if n.op in ("<", "<=", ">", ">="):
+        if n.op in _BOOL:
             lines.append("const int t%d = %s;" % (n.id, e))      # (int: the body is also compiled as C by the oracle)
         else:
             lines.append("const double t%d = %s;" % (n.id, e))
         name[n.id] = "t%d" % n.id
     for i, o in enumerate(outs):
-        lines.append("w[%d] = %s;" % (i, ref(o)))
+        lines.append(sink(i, ref(o)))
     return "\n".join(lines)
 
 
-def evaluate(outs, X):
-    """the DAG on numeric draws X[draw, sample] (numpy), for the check against the closure itself"""
+def evaluate(outs, X, R=None):
+    """the DAG on numeric draws X[draw, sample] (and relative weights R[integrand, sample]), for the check against the closure itself"""
     val = {}
     with np.errstate(all="ignore"):
         for n in _reachable(outs):
             a = [val[q.id] if isinstance(q, Sym) else q for q in n.args]
             if n.op == "x":
                 v = X[n.args[0]]
+            elif n.op == "rw":
+                v = R[n.args[0]]
+            elif n.op == "not":
+                v = np.logical_not(a[0])
+            elif n.op in ("and", "or"):
+                v = (np.logical_and if n.op == "and" else np.logical_or)(a[0], a[1])
             elif n.op == "const":
                 v = np.float64(n.args[0])
             elif n.op == "+":
@@ -482,3 +522,87 @@ def trace_integrand(fn, config, indexed=False, check_points=32, name=None):
                 raise TraceError("the traced expression and the closure disagree on integrand %d: the closure is not a pure "
                                  "function of its draws (hidden state, a branch the trace did not see)" % i)
     return Integrand(body, None, name=name or getattr(fn, "__name__", "traced"))
+
+
+def trace_measure(fn, config, indexed=False, check_points=32):
+    """The `measure` closure (vegas/montecarlo.jl:156-161; five-argument :mcmc form mcmc/montecarlo.jl:166-169) written out as a
+    device Measure: the closure is run once with symbolic draws, symbolic relative weights and `obs` arrays that remember what is
+    added to them; `obs[i][k] += expr` becomes `obs_add(flat k, expr)`.  Both the per-sample form of the reference
+    (`obs[0][0] += weights[0]`) and the batch-vectorised form of HostMeasure (`obs[0][0] += weights[0].sum()`,
+    `weights[0][x[0] < 0.5].sum()`) trace.  TraceError if it cannot be written out or disagrees with the closure at random points.
+
+    fn(x, obs, weights, config)     (indexed=True: fn(idx, x, obs, weight, config), idx 0-based)"""
+    if getattr(config, "ncomp", 1) != 1:
+        raise TraceError("complex weights are not traced")
+    pools, ndraw = _pools(config)
+    N = config.N
+    t = _Trace()
+    arg = _argument(pools, lambda k: t.node("x", k))
+    zero = t.const(0.0)
+
+    def fresh():
+        obs = []
+        for ln in config.obs_len:
+            o = np.empty(ln, dtype=object)
+            o[:] = zero
+            obs.append(o)
+        return obs
+
+    def flat(obs):
+        out = []
+        for o in obs:
+            for v in np.asarray(o, dtype=object).reshape(-1):
+                out.append(v if isinstance(v, Sym) else t.const(v))
+        return out
+    try:
+        if indexed:
+            per = []
+            for i in range(N):
+                obs = fresh()
+                fn(i, arg, obs, t.node("rw", i), config)
+                per.append(flat(obs))
+        else:
+            obs = fresh()
+            fn(arg, obs, [t.node("rw", i) for i in range(N)], config)
+            per = [flat(obs)]
+    except TraceError:
+        raise
+    except Exception as e:
+        raise TraceError("%s: %s" % (type(e).__name__, e))
+    nobs = sum(config.obs_len)
+    if any(len(p) != nobs for p in per):
+        raise TraceError("the measure changed the shape of obs")
+    parts = []
+    for i, adds in enumerate(per):
+        ks = [k for k, v in enumerate(adds) if not _is_const(v, 0.0)]
+        body = emit([adds[k] for k in ks], sink=lambda j, ref, ks=ks: "obs_add(%d, %s);" % (ks[j], ref)) if ks else ""
+        if indexed:
+            # (under :vegas / :vegasmc every integrand's weight is measured: idx = -1; an :mcmc chain measures the one it sits on)
+            body = "if (idx < 0 || idx == %d) {\n%s\n}" % (i, body) if body else ""
+        parts.append(body)
+    if check_points:
+        rng = np.random.default_rng(54321)
+        X = _domain_points(config, ndraw, check_points, rng)
+        R = rng.standard_normal((N, check_points))
+        for p in range(check_points):
+            num = _argument(pools, lambda k: X[k, p])                # one record as numpy scalars: `.sum()`, masks and plain `+=` all work on them
+            num = tuple(a.astype(np.float64) for a in num) if isinstance(num, tuple) else num.astype(np.float64)
+            try:
+                with np.errstate(all="ignore"):
+                    if indexed:
+                        refs = []
+                        for i in range(N):
+                            obs = [np.zeros(ln) for ln in config.obs_len]
+                            fn(i, num, obs, np.float64(R[i, p]), config)
+                            refs.append(np.concatenate([np.asarray(o, dtype=np.float64).reshape(-1) for o in obs]))
+                    else:
+                        obs = [np.zeros(ln) for ln in config.obs_len]
+                        fn(num, obs, [np.float64(R[i, p]) for i in range(N)], config)
+                        refs = [np.concatenate([np.asarray(o, dtype=np.float64).reshape(-1) for o in obs])]
+            except Exception as e:
+                raise TraceError("the measure does not run on numeric records (%s: %s)" % (type(e).__name__, e))
+            for adds, ref in zip(per, refs):
+                got = np.array([float(v[0]) for v in evaluate(adds, X[:, p:p + 1], R[:, p:p + 1])])
+                if not np.allclose(got, ref, rtol=1e-10, atol=1e-290, equal_nan=True):
+                    raise TraceError("the traced measure and the closure disagree: the closure is not a pure function of its records")
+    return Measure("\n".join(q for q in parts if q))

@@ -29,3 +29,46 @@ def test_traced_two_integrand_closure_with_a_select(solver):
     r = mci.integrate(g, var=mci.Continuous(0.0, 1.0), dof=[[2], [2]], solver=solver, neval=200000, niter=10, seed=7, trace=True, print=-1)
     assert abs(r.mean[0] - 2.0 / 3.0) < 5 * r.stdev[0] and abs(r.mean[1] - 0.25) < 5 * r.stdev[1]
     assert r.stdev[0] < 0.02 and r.stdev[1] < 0.02
+
+
+def test_traced_measure_closures_match_device_source_measures():
+    """vegas/montecarlo.jl:156-161, mcmc/montecarlo.jl:166-169: a `measure` closure traced into a device Measure measures what the same
+    measure written as device source measures -- four- and five-argument forms, a masked measure next to a Discrete pool, all three
+    solvers.  (Every call builds its own variables: a Continuous object carries its trained grid into the next call.)"""
+    def sphere3_measure(x, obs, weights, config):
+        obs[0][0] += weights[0].sum()
+        obs[1][0] += weights[1].sum()
+        obs[1][1] += (weights[1] * 2.0).sum()
+
+    def sphere3_measure5(idx, x, obs, weight, config):
+        if idx == 0:
+            obs[0][0] += weight.sum()
+        else:
+            obs[1][0] += weight.sum()
+            obs[1][1] += (weight * 2.0).sum()
+    dev = mci.Measure("obs_add(0, rw[0]); obs_add(1, rw[1]); obs_add(2, rw[1] * 2.0);")
+    exact = [math.pi / 4.0, math.pi / 6.0, math.pi / 3.0]
+    for solver, m in (("vegas", sphere3_measure), ("vegasmc", sphere3_measure), ("mcmc", sphere3_measure5), ("vegas", sphere3_measure5)):
+        # (explicit chain count: the automatic one follows the kernel's workgroup size, which may differ between two measure bodies)
+        kw = dict(dof=[[2], [3]], obs=[0.0, [0.0, 0.0]], solver=solver, neval=4e4, niter=6, seed=77, measurefreq=2, print=-1,
+                  **({} if solver == "vegas" else dict(nchain=16, block=16)))
+        a = mci.integrate(mci.catalog.sphere2(), var=mci.Continuous(0.0, 1.0), measure=m, trace=True, **kw)
+        b = mci.integrate(mci.catalog.sphere2(), var=mci.Continuous(0.0, 1.0), measure=dev, **kw)
+        for r in (a, b):
+            got = np.array([r.mean[0], r.mean[1][0], r.mean[1][1]], dtype=np.float64).ravel()
+            err = np.array([r.stdev[0], r.stdev[1][0], r.stdev[1][1]], dtype=np.float64).ravel()
+            assert np.all(np.abs(got - exact) < 6 * err + 1e-12) and np.all(err < 0.05), (solver, m.__name__, got, err)
+            assert got[2] == pytest.approx(2.0 * got[1], rel=1e-9)
+        if np.allclose(a.iter_mean[0], b.iter_mean[0], rtol=1e-9):      # same samples, same sums: then every iteration agrees
+            np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-4, err_msg="%s %s" % (solver, m.__name__))
+
+    def binned(v, obs, weights, config):
+        lo = v[0][0] < 0.5
+        obs[0][0] += weights[0][lo].sum()
+        obs[0][1] += weights[0][~lo].sum()
+    for solver in ("vegas", "vegasmc", "mcmc"):
+        kw = dict(dof=[[1, 1]], obs=[[0.0, 0.0]], solver=solver, neval=4e4, niter=6, seed=9, print=-1,
+                  **({} if solver == "vegas" else dict(nchain=16, block=16)))
+        a = mci.integrate("return x[0] * x[1];", var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3)), measure=binned, trace=True, **kw)
+        got, err = np.ravel(a.mean).astype(np.float64), np.ravel(a.stdev).astype(np.float64)
+        assert np.all(np.abs(got - [0.75, 2.25]) < 6 * err + 1e-3) and np.all(err < 0.1), (solver, got, err)     # (1 + 2 + 3) * int x dx over [0, .5) | [.5, 1)

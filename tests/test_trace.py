@@ -154,3 +154,74 @@ def test_traced_bodies_compile_for_gfx950():
         eng.compile("vegas")
         assert os.path.exists(eng.code_object("vegas")), name
         eng.close()
+
+
+def _sphere3_measure(x, obs, weights, config):          # the reference's Sphere3 measure (test/montecarlo.jl:71-84), batch-vectorised like a HostMeasure
+    obs[0][0] += weights[0].sum()
+    obs[1][0] += weights[1].sum()
+    obs[1][1] += (weights[1] * 2.0).sum()
+
+
+def _sphere3_measure5(idx, x, obs, weight, config):     # measure(idx, vars, obs, weight, config), mcmc/montecarlo.jl:166-169; idx 0-based
+    if idx == 0:
+        obs[0][0] += weight.sum()
+    else:
+        obs[1][0] += weight.sum()
+        obs[1][1] += (weight * 2.0).sum()
+
+
+def _binned(v, obs, weights, config):
+    lo = v[0][0] < 0.5
+    obs[0][0] += weights[0][lo].sum()
+    obs[0][1] += weights[0][~lo].sum()
+
+
+def test_measure_closures_are_written_out_as_obs_add_statements():
+    """vegas/montecarlo.jl:156-161: measure(vars, obs, relative_weights, config); `obs[i][k] += expr` -> obs_add(flat k, expr)"""
+    from mcintegration_jl_amd.trace import trace_measure
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]], obs=[0.0, [0.0, 0.0]])
+    m = trace_measure(_sphere3_measure, cfg)
+    assert isinstance(m, mci.Measure)
+    assert [ln.strip() for ln in m.body.splitlines()] == ["const double t7 = rw[1] * 2.0;", "obs_add(0, rw[0]);", "obs_add(1, rw[1]);", "obs_add(2, t7);"] \
+        or all(q in m.body for q in ("obs_add(0, rw[0]);", "obs_add(1, rw[1]);", "rw[1] * 2.0"))
+    per_sample = lambda x, obs, w, c: (obs[0].__setitem__(0, obs[0][0] + w[0] * x[1]), obs[1].__setitem__(1, obs[1][1] + w[1] * np.exp(-x[0])))
+    b = trace_measure(per_sample, cfg).body                   # the reference's own per-sample form
+    assert "obs_add(0, " in b and "obs_add(2, " in b and "exp(" in b and "obs_add(1," not in b
+    m5 = trace_measure(_sphere3_measure5, cfg, indexed=True).body
+    assert "if (idx < 0 || idx == 0) {" in m5 and "if (idx < 0 || idx == 1) {" in m5 and m5.count("obs_add(") == 3
+    cfg2 = mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3)), dof=[[1, 1]], obs=[[0.0, 0.0]])
+    bb = trace_measure(_binned, cfg2).body
+    assert "x[0] < 0.5" in bb and "? rw[0] : 0.0" in bb and "!t" in bb
+    with pytest.raises(TraceError):                           # a bin chosen by a draw: that is mci.bin_by's job
+        trace_measure(lambda x, obs, w, c: obs[0].__setitem__(int(x[0][0] * 2), w[0]), cfg2)
+    calls = []
+    with pytest.raises(TraceError):                           # not a function of the record
+        trace_measure(lambda x, obs, w, c: (calls.append(1), obs[0].__setitem__(0, obs[0][0] + w[0] * len(calls)))[0], cfg2)
+
+
+def test_integrate_with_trace_hands_the_engine_a_device_measure():
+    class Stop(Exception):
+        pass
+    got = {}
+
+    def factory(config, integrand, measure=None, **kw):
+        got["measure"] = measure
+        raise Stop()
+    kw = dict(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]], obs=[0.0, [0.0, 0.0]], solver="vegas", engine_factory=factory, print=-1)
+    with pytest.raises(Stop):
+        mci.integrate(mci.catalog.sphere2(), measure=_sphere3_measure, trace=True, **kw)
+    assert isinstance(got["measure"], mci.Measure) and "obs_add(2," in got["measure"].body
+    with pytest.raises(Stop):
+        mci.integrate(mci.catalog.sphere2(), measure=_sphere3_measure, **kw)
+    assert isinstance(got["measure"], mci.HostMeasure)
+
+
+def test_traced_measures_compile_for_gfx950():
+    from mcintegration_jl_amd.trace import trace_measure
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]], obs=[0.0, [0.0, 0.0]])
+    for m, indexed, solver in ((_sphere3_measure, False, "vegas"), (_sphere3_measure5, True, "mcmc"), (_sphere3_measure, False, "vegasmc"),
+                               (_sphere3_measure5, True, "vegas"), (_sphere3_measure5, True, "vegasmc")):
+        eng = mci.Engine(cfg, mci.catalog.sphere2(), measure=trace_measure(m, cfg, indexed=indexed), device=-1)
+        eng.compile(solver)
+        assert os.path.exists(eng.code_object(solver))
+        eng.close()

@@ -59,7 +59,7 @@ def test_traced_measure_closures_match_device_source_measures():
             err = np.array([r.stdev[0], r.stdev[1][0], r.stdev[1][1]], dtype=np.float64).ravel()
             assert np.all(np.abs(got - exact) < 6 * err + 1e-12) and np.all(err < 0.05), (solver, m.__name__, got, err)
             assert got[2] == pytest.approx(2.0 * got[1], rel=1e-9)
-        if np.allclose(a.iter_mean[0], b.iter_mean[0], rtol=1e-9):      # same samples, same sums: then every iteration agrees
+        if solver == "vegas" and np.allclose(a.iter_mean[0], b.iter_mean[0], rtol=1e-9):      # same samples, same sums: then every iteration agrees
             np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-4, err_msg="%s %s" % (solver, m.__name__))
 
     def binned(v, obs, weights, config):

@@ -225,3 +225,9 @@ def test_traced_measures_compile_for_gfx950():
         eng.compile(solver)
         assert os.path.exists(eng.code_object(solver))
         eng.close()
+    cfg2 = mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3)), dof=[[1, 1]], obs=[[0.0, 0.0]])
+    for solver in ("vegas", "vegasmc", "mcmc"):               # a masked measure: comparisons, `!`, selects
+        eng = mci.Engine(cfg2, mci.Integrand("return x[0] * x[1];"), measure=trace_measure(_binned, cfg2), device=-1)
+        eng.compile(solver)
+        assert os.path.exists(eng.code_object(solver))
+        eng.close()

@@ -106,6 +106,8 @@ class Sym:
     def __le__(self, o): return self._bin("<=", o)
     def __gt__(self, o): return self._bin(">", o)
     def __ge__(self, o): return self._bin(">=", o)
+    def __eq__(self, o): return self._bin("==", o)      # (a Discrete draw against a number; nodes are interned by id, not compared)
+    def __ne__(self, o): return self._bin("!=", o)
     def __neg__(self): return self.t.node("neg", self)
     def __pos__(self): return self
     def __abs__(self): return self.t.node("fabs", self)
@@ -151,9 +153,10 @@ class Sym:
     def sum(self, *a, **k): return self          # weights[0].sum(): the per-sample value IS the sample's contribution
 
     def __getitem__(self, m):                    # weights[0][mask]: the value where the mask holds, else nothing (0)
-        if isinstance(m, Sym) and m.op in _BOOL:
-            return where(m, self, 0.0)
-        if m is Ellipsis or m == slice(None):
+        if isinstance(m, Sym):
+            if m.op in _BOOL:
+                return where(m, self, 0.0)
+        elif m is Ellipsis or (isinstance(m, slice) and m == slice(None)):
             return self
         raise TraceError("indexing a sampled value with %r" % (m,))
 
@@ -180,7 +183,7 @@ class Sym:
     def real(self): return self
 
 
-_BOOL = ("<", "<=", ">", ">=", "not", "and", "or")
+_BOOL = ("<", "<=", ">", ">=", "==", "!=", "not", "and", "or")
 
 
 def _is_const(s, v):
@@ -212,7 +215,7 @@ def _boxed(v):
 
 
 _UFUNC_BIN = {"add": "+", "subtract": "-", "multiply": "*", "divide": "/", "true_divide": "/", "less": "<", "less_equal": "<=",
-              "greater": ">", "greater_equal": ">="}
+              "greater": ">", "greater_equal": ">=", "equal": "==", "not_equal": "!="}
 
 
 def _ufunc(ufunc, *a):
@@ -296,7 +299,7 @@ def arctan2(a, b):
 
 
 # ---- writing the DAG out, and evaluating it for the check ----
-_BINOPS = ("+", "-", "*", "/", "<", "<=", ">", ">=")
+_BINOPS = ("+", "-", "*", "/", "<", "<=", ">", ">=", "==", "!=")
 
 
 def _reachable(outs):
@@ -392,8 +395,8 @@ def evaluate(outs, X, R=None):
                 v = a[0] * a[1]
             elif n.op == "/":
                 v = a[0] / a[1]
-            elif n.op in ("<", "<=", ">", ">="):
-                v = {"<": np.less, "<=": np.less_equal, ">": np.greater, ">=": np.greater_equal}[n.op](a[0], a[1])
+            elif n.op in ("<", "<=", ">", ">=", "==", "!="):
+                v = {"<": np.less, "<=": np.less_equal, ">": np.greater, ">=": np.greater_equal, "==": np.equal, "!=": np.not_equal}[n.op](a[0], a[1])
             elif n.op == "neg":
                 v = -a[0]
             elif n.op == "where":
@@ -491,7 +494,7 @@ def trace_integrand(fn, config, indexed=False, check_points=32, name=None):
             o = o.reshape(-1)[0]
         if not isinstance(o, Sym):
             o = t.const(o)
-        if o.op in ("<", "<=", ">", ">="):
+        if o.op in _BOOL:
             o = t.node("where", o, t.const(1.0), t.const(0.0))
         syms.append(o)
     body = emit(syms)

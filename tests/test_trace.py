@@ -39,6 +39,8 @@ CASES = [
     ("arrays_with_draws_and_numbers", lambda: mci.Configuration(var=mci.Continuous(-1.0, 1.0), dof=[[3]]),
      lambda x, c: np.sum(2.0 * x) + np.sum(x * x[0]) + (x + x[1])[2] + np.exp(x).sum() + np.sqrt(np.abs(x) + 1.0).prod() + np.power(x[0], 2)
      + np.power(2.0, x[1]) + np.square(x[2]) + (x[0] - x) @ (x / 2.0)),
+    ("discrete_equality_and_indicator", lambda: mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3)), dof=[[2, 1], [2, 1]]),
+     lambda x, c: (np.where(x[1][0] == 2, x[0][0], 2.0 * x[0][1]) + (x[1][0] != 1) * 0.5, (x[0][0] ** 2 + x[0][1] ** 2 < 1.0) * 1.0)),
     ("constant_and_shared_subexpressions", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [2]]),
      lambda x, c: (1.5, np.exp(x[0] * x[1]) + np.exp(x[0] * x[1]) ** 2)),
 ]

@@ -233,3 +233,36 @@ def test_traced_measures_compile_for_gfx950():
         eng.compile(solver)
         assert os.path.exists(eng.code_object(solver))
         eng.close()
+
+
+def _random_expression(rng, depth):
+    """a random closure over three draws, built from closures (not source text): what trace_integrand sees is ordinary Python / numpy"""
+    if depth == 0 or rng.random() < 0.15:
+        k = int(rng.integers(0, 4))
+        if k == 3:
+            v = float(rng.choice([0.5, 2.0, -1.25, 3.0, 1e-3]))
+            return lambda x: v
+        return lambda x, k=k: x[k]
+    a, b = _random_expression(rng, depth - 1), _random_expression(rng, depth - 1)
+    op = int(rng.integers(0, 12))
+    return [lambda x: a(x) + b(x), lambda x: a(x) - b(x), lambda x: a(x) * b(x), lambda x: a(x) / (1.5 + np.abs(b(x))),
+            lambda x: np.exp(-np.abs(a(x))), lambda x: np.sin(a(x)) * np.cos(b(x)), lambda x: np.sqrt(np.abs(a(x)) + 1.0),
+            lambda x: np.log(np.abs(a(x)) + 1.0), lambda x: where(a(x) > b(x), a(x), b(x) * 0.5), lambda x: fmax(a(x), 0.25) - fmin(b(x), 0.75),
+            lambda x: (a(x) + 0.0) ** 2 + np.tanh(b(x)), lambda x: -a(x) + 1.0 * b(x)][op]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_closures_trace_to_what_they_compute(oracle, seed):
+    rng = np.random.default_rng(4000 + seed)
+    config = mci.Configuration(var=mci.Continuous(-1.0, 2.0), dof=[[3], [3]])
+    e0, e1 = _random_expression(rng, 5), _random_expression(rng, 4)
+    f = lambda x, c: (e0(x), e1(x))
+    I = trace_integrand(f, config)
+    fn = _c_function(oracle, I.body)
+    X = rng.uniform(-1.0, 2.0, size=(3, 100))
+    for p in range(100):
+        x = np.ascontiguousarray(X[:, p])
+        w = np.zeros(2)
+        fn(x.ctypes.data_as(C.POINTER(C.c_double)), w.ctypes.data_as(C.POINTER(C.c_double)), None)
+        ref = np.array([float(e0(x)), float(e1(x))])
+        np.testing.assert_allclose(w, ref, rtol=1e-12, atol=1e-300, err_msg="seed %d at %s\n%s" % (seed, x, I.body))

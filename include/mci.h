@@ -106,6 +106,9 @@ typedef struct {
     int64_t neval;     /* evaluations actually performed, all iterations, this rank's view after reduction */
     double seconds;    /* wall time of the iteration loop (kernels + train + all-reduce) */
     double *visited;   /* [nintegrand+1] or NULL: config.visited of the last iteration (configuration.jl:46), read with the statistics */
+    int32_t correlated; /* out: 1 = the iterations of this call continued each other's chains (mci_set_chain_carry), so `stdev` is the
+                           block-lineage error (mci_lineage_sums) instead of statistics.jl:198, which assumes independent iterations;
+                           `mean` and `chi2` are the reference's either way */
 } mci_result;
 
 /* ---- context: HIP device + stream (+ RCCL communicator); replaces MPI.Init, main.jl:113-114 ---- */
@@ -121,6 +124,9 @@ void *mci_ctx_stream(mci_ctx *ctx);           /* hipStream_t, for callers that o
 int mci_comm_unique_id(void *id128);
 int mci_comm_init(mci_ctx *ctx, int32_t rank, int32_t nranks, const void *id128);
 int mci_comm_rank(const mci_ctx *ctx, int32_t *rank, int32_t *nranks);
+/* v[0..n) <- sum over the ranks of the problem's communicator (MPI.Allreduce, utility/parallel.jl:25-60), through the library's
+ * stream; identity without a communicator.  For the few host-side sums of a run (the lineage sums of mci_lineage_sums). */
+int mci_comm_sum(mci_problem *prob, double *v, int32_t n);
 
 /* ---- problem = Configuration + integrand ---- */
 int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *desc, mci_problem **out);
@@ -217,14 +223,19 @@ int mci_integrate(mci_problem *prob, const mci_integrate_args *args, mci_result 
 /* ---- state access: res.config.var[i].grid etc. (docs/src/index.md:129) and external reducers ---- */
 /* :mcmc diagnostic of the last launch (summed over the ranks when a communicator is attached: every rank sizes its chains from
  * the same histogram): out64[b] = number of chains whose longest holding time h (steps during which a live slot, or the
- * integrand index, did not change; holds still running at the end count) has bit_width(h) == b.  An automatic chain length is
- * 16 * 2^(top occupied b) of the launch TWO before it (the first two launches: of the first) -- a fixed lag, so that the host
- * never has to drain the stream between iterations and a run stays reproducible. */
+ * integrand index, did not change; holds still running at the end count) has bit_width(h) == b.  An automatic chain length follows
+ * 2^(top occupied b) of the launch before it (mci_mcmc_auto_chains): the host waits for that launch's sample kernel -- not for its
+ * merge and train! -- before it sizes the next one; a fixed lag, so a run stays reproducible. */
 int mci_get_hold_histogram(mci_problem *prob, uint64_t *out64);
 /* the statistics head [obsSum|obsSqSum|normalization|neval|visited] of the last `nrows` finished
  * iterations (oldest first), nstat = 2*nobs+2+N+1 doubles per row: the per-iteration history that
  * `Result.iterations` is built from (statistics.jl:24-33), kept on the device until asked for */
 int mci_get_iteration_log(mci_problem *prob, int32_t nrows, double *out);
+/* Chain solvers: the block means m_b = observable_b / normalization_b (main.jl:275-280) of the last `rows` iterations (oldest first),
+ * out[rows][nblocks][nobs] with nblocks = this rank's blocks; *carried = how many of the logged iterations continued the chains of the
+ * one before.  The log starts over with mci_reset_block_log, with every mci_integrate call, and when the block range changes. */
+int mci_get_block_means(mci_problem *prob, int32_t rows, double *out, int64_t *nblocks, int32_t *carried);
+int mci_reset_block_log(mci_problem *prob);
 /* make room for `rows` more iterations in that log now (it grows on demand otherwise, synchronising the stream when it does) */
 int mci_reserve_iteration_log(mci_problem *prob, int32_t rows);
 int mci_get_packed(mci_problem *prob, double *out, int64_t n);
@@ -260,11 +271,12 @@ int mci_set_rng_bits(mci_problem *prob, int32_t bits);
  * known-answer vectors for 7 rounds (tests/golden) and mirrored in the oracle (mcio_set_rng_rounds). */
 int mci_set_rng_rounds(mci_problem *prob, int32_t rounds);
 /* How train!(Continuous) walks the smoothed histogram to place the new grid points (variable.jl:227-234):
- *   1  the reference's serial recurrence, operation for operation: its decisions (does this bin yield a new grid point) are taken from
+ *   1  the reference's serial recurrence -- the same additions and subtractions on the same operands in the same order, starting from
+ *      sums in ONE fixed association of the family Julia's @simd sum() belongs to (csrc/mci_train.h sum16; the reference itself has no
+ *      single order across CPUs): its decisions (does this bin yield a new grid point) are taken from
  *      the prefix-scan form, one lane walks the additions and subtractions alone, every decision is checked against the exact record
  *      (+14 us per iteration at ninc = 1000 on MI355X); a decision that does not hold sends the walk through mode 2;
  *   2  the recurrence with its compares and branches on one lane in hand-written ISA (+38 us): what 1 falls back to -- bit-identical results;
- *   3  test hook: mode 1 with one decision deliberately wrong, so that its check and the fall-back to mode 2 run (same results again);
  *   0  the same walk as a fixed-order prefix scan + one bisection per grid point (agrees with the recurrence to 1e-12 of
  *      the variable's range per train! step, i.e. whole runs agree to ~1e-4 instead of ~1e-6);
  *  -1  automatic (default): 1 when the iteration's sample launch on this rank is >= 2^26 samples (the walk then costs ~1 % or less), else 0.
@@ -291,6 +303,8 @@ int mci_set_deterministic(mci_problem *prob, int32_t on);
  * vegas_mc/montecarlo.jl:213; floor(steps * thermal_ratio), mcmc/montecarlo.jl:133); automatic chain counts are then sized for the
  * duplicates of a stored chain to part before they are copied again (:vegasmc two burn-in floors, :mcmc 8 x the longest measured
  * holding time) instead of for start-up bias (DESIGN.md "Chains").  mode 0: every launch starts its chains afresh.
+ * Consecutive iterations of carried chains are correlated, which the reference's combination of iterations (statistics.jl:186-220)
+ * does not expect: mci_integrate reports the block-lineage error for such runs (mci_result.correlated, mci_lineage_sums).
  * Mirrored in the oracle (mcio_set_chain_carry, mcio_resample_chains). */
 int mci_set_chain_carry(mci_problem *prob, int32_t mode);
 /* chains per block of the last chain-solver launch and whether it continued the launch before it */
@@ -311,12 +325,6 @@ int mci_last_chain_launch(const mci_problem *prob, int64_t *nchain, int32_t *car
 int mci_set_persistent(mci_problem *prob, int32_t mode);
 /* whether the last mci_integrate ran as one persistent launch */
 int mci_last_integrate_persistent(const mci_problem *prob, int32_t *persistent);
-/* development aid (tools/persist_trace.py): the persistent kernel's counter words and, in builds with -DMCI_PERSIST_TRACE, the
- * wall-clock stamps of three of its workgroups over the first eight turns of the last launch */
-int mci_debug_persist_words(mci_problem *prob, unsigned long long *out, int32_t n);
-/* Development aid: out[0] = serial walks of train! (mci_set_train_walk mode 1) this problem has run as slots with given decisions,
- * out[1] = walks in the general form (mode 2, a decision that did not hold, grids too long for the slots' LDS).  Synchronises the stream. */
-int mci_debug_walk_counts(mci_problem *prob, int64_t *out);
 /* Dist.train! on the histograms currently in the packed buffer (variable.jl:206-239, :369-382) */
 int mci_train(mci_problem *prob);
 /* the adaptive map alone (sampler.jl:293-305, :13-22) + integrand: first `n` samples of block `block_index`
@@ -346,15 +354,26 @@ double mci_chain_burnin(int64_t steps, int64_t nchain, int32_t nslots);
  * (mcmc/montecarlo.jl:133); with nchain > 1 at least 64*nslots + 16*(npool+1)*nd */
 int64_t mci_mcmc_burnin(int64_t steps, int64_t nchain, int32_t nslots, int32_t nd, int32_t npool, double thermal_ratio);
 /* chains per block of an :mcmc launch with nchain = 0 ("automatic"; the reference has no counterpart: it runs one chain
- * per block).  hold_max = 0: nothing measured yet, chains of >= 131072 measured steps; otherwise chains of
- * max(16*hold_max, 8 burn-in floors) steps, capped so that one GPU gets at most 131072 chains */
+ * per block).  hold_max = the longest holding time the launch before measured (mci_get_hold_histogram), hold_len = the chain length
+ * (measured steps) of that launch, carried = the launch continues that launch's chains.  hold_max = 0 (nothing measured yet): chains of
+ * 4096 steps or 8 burn-in floors; otherwise 16*hold_max (fresh) / 8*hold_max (carried) but at most 4*hold_len -- a hold longer than a
+ * quarter of the chain that measured it is censored by that chain, so the length escalates from launch to launch until the holds fit --
+ * and never fewer than 8 / 2 burn-in floors; capped so that one GPU gets at most 131072 chains */
 int64_t mci_mcmc_auto_chains(int64_t nevalperblock, int64_t nblocks, int32_t nslots, int32_t nd, int32_t npool,
-                             int64_t hold_max);
+                             int64_t hold_max, int64_t hold_len, int32_t carried);
 void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out);        /* configuration.jl:229-236 */
 void mci_mean_std(const double *obs_sum, const double *obs_sq, int64_t n, int64_t block, double *mean,
                   double *std);                                                      /* main.jl:296-320 */
 void mci_average(const double *iter_mean, const double *iter_std, int64_t stride, int64_t init, int64_t max,
                  double *mean, double *err, double *chi2);                           /* statistics.jl:186-220 */
+/* Error of the weighted average when consecutive iterations are correlated (carried chains) but the blocks are independent: block b's
+ * lineage is its own weighted average over the iterations, m_b = sum_i w_i * block_means[i][b] with the weights of statistics.jl:197,
+ * :217 (w_i ~ 1/(iter_std[i] + 1e-10)^2, normalised); sum[o] = sum_b m_b, sumsq[o] = sum_b m_b^2 over THIS rank's blocks -- summed
+ * over the ranks they go through mci_mean_std (the reference's own _mean_std, main.jl:296-320, over lineages instead of blocks):
+ * the same mean as mci_average and the scatter of the lineages as its error.  block_means[niter][nblocks][nobs], iter_std[niter][nobs];
+ * init / max 1-based like mci_average. */
+void mci_lineage_sums(const double *block_means, int64_t niter, int64_t nblocks, int64_t nobs, const double *iter_std,
+                      int64_t init, int64_t max, double *sum, double *sumsq);
 void mci_do_reweight(double *reweight, const double *visited, int64_t nd, double gamma,
                      const double *goal);                                            /* main.jl:322-346 */
 const char *mci_version(void);

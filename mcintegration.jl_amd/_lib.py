@@ -50,10 +50,10 @@ HOST_MEASURE_IDX_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int32), c_double_p, c_d
 class ResultC(C.Structure):
     _fields_ = [("niter", C.c_int32), ("nobs", C.c_int32), ("iter_mean", c_double_p), ("iter_std", c_double_p),
                 ("mean", c_double_p), ("stdev", c_double_p), ("chi2", c_double_p), ("neval", C.c_int64),
-                ("seconds", C.c_double), ("visited", c_double_p)]
+                ("seconds", C.c_double), ("visited", c_double_p), ("correlated", C.c_int32)]
 
 
-# every symbol include/mci.h declares: (name, restype, argtypes)
+# every symbol include/mci.h declares: (name, restype, argtypes); DEBUG_SIGNATURES: the test hooks of csrc/mci_debug.h
 _VP = C.c_void_p
 SIGNATURES = [
     ("mci_ctx_create", C.c_int, [C.c_int32, C.POINTER(_VP)]),
@@ -64,6 +64,7 @@ SIGNATURES = [
     ("mci_comm_unique_id", C.c_int, [_VP]),
     ("mci_comm_init", C.c_int, [_VP, C.c_int32, C.c_int32, _VP]),
     ("mci_comm_rank", C.c_int, [_VP, c_int32_p, c_int32_p]),
+    ("mci_comm_sum", C.c_int, [_VP, c_double_p, C.c_int32]),
     ("mci_problem_create", C.c_int, [_VP, C.POINTER(ProblemDesc), C.POINTER(_VP)]),
     ("mci_problem_destroy", C.c_int, [_VP]),
     ("mci_set_integrand_source", C.c_int, [_VP, C.c_char_p, c_double_p, C.c_int32]),
@@ -106,8 +107,6 @@ SIGNATURES = [
     ("mci_set_chain_carry", C.c_int, [_VP, C.c_int32]),
     ("mci_set_persistent", C.c_int, [_VP, C.c_int32]),
     ("mci_last_integrate_persistent", C.c_int, [_VP, C.POINTER(C.c_int32)]),
-    ("mci_debug_persist_words", C.c_int, [_VP, C.POINTER(C.c_uint64), C.c_int32]),
-    ("mci_debug_walk_counts", C.c_int, [_VP, C.POINTER(C.c_int64)]),
     ("mci_last_chain_launch", C.c_int, [_VP, C.POINTER(C.c_int64), c_int32_p]),
     ("mci_train", C.c_int, [_VP]),
     ("mci_sample_dump", C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
@@ -116,13 +115,22 @@ SIGNATURES = [
     ("mci_standardize_block", None, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("mci_chain_burnin", C.c_double, [C.c_int64, C.c_int64, C.c_int32]),
     ("mci_mcmc_burnin", C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
-    ("mci_mcmc_auto_chains", C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
+    ("mci_mcmc_auto_chains", C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32]),
     ("mci_get_hold_histogram", C.c_int, [_VP, C.POINTER(C.c_uint64)]),
+    ("mci_get_block_means", C.c_int, [_VP, C.c_int32, c_double_p, C.POINTER(C.c_int64), c_int32_p]),
+    ("mci_reset_block_log", C.c_int, [_VP]),
+    ("mci_lineage_sums", None, [c_double_p, C.c_int64, C.c_int64, C.c_int64, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p]),
     ("mci_maxdof", None, [c_int32_p, C.c_int32, C.c_int32, c_int32_p]),
     ("mci_mean_std", None, [c_double_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p]),
     ("mci_average", None, [c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
     ("mci_do_reweight", None, [c_double_p, c_double_p, C.c_int64, C.c_double, c_double_p]),
     ("mci_version", C.c_char_p, []),
+]
+DEBUG_SIGNATURES = [
+    ("mci_debug_persist_words", C.c_int, [_VP, C.POINTER(C.c_uint64), C.c_int32]),
+    ("mci_debug_walk_counts", C.c_int, [_VP, C.POINTER(C.c_int64)]),
+    ("mci_debug_plant_wrong_decision", C.c_int, [_VP, C.c_int32]),
+    ("mci_debug_persist_spin_ticks", C.c_int, [_VP, C.c_uint64]),
 ]
 
 _lib = None
@@ -140,7 +148,7 @@ def lib():
             raise ImportError("%s is missing: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "
                               "the MI355X engine has no Python/CPU fallback" % _SO)
         L = C.CDLL(_SO, mode=C.RTLD_GLOBAL)
-        for name, res, args in SIGNATURES:
+        for name, res, args in SIGNATURES + DEBUG_SIGNATURES:
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -10,6 +10,10 @@ class LocalComm:
     def all_reduce(self, engine):
         return None
 
+    def sum_host(self, engine, v):
+        """a few host doubles summed over the ranks (the lineage sums of a run of carried chains, statistics.Result)"""
+        return v
+
 
 class RcclComm:
     """RCCL inside the library: one ncclAllReduce(sum, f64) on the engine's stream, device to device.
@@ -56,6 +60,9 @@ class RcclComm:
                                "integrate() (the all-reduce would be skipped silently)" % (self.device, engine.device))
         engine.reduce()
 
+    def sum_host(self, engine, v):
+        return engine.comm_sum(v)
+
 
 class _DeviceBuffer:
     """a raw device pointer dressed for torch.as_tensor (zero copy)"""
@@ -94,3 +101,12 @@ class TorchDistComm:
         _, t, ext = self._view
         with torch.cuda.stream(ext):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def sum_host(self, engine, v):
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64).copy())
+        if self.tensor_device != "cpu":
+            t = t.to(self.tensor_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()

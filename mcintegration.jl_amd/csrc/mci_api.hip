@@ -6,6 +6,7 @@
 // and the iteration loop + Result statistics (src/main.jl:142-218, :296-320, src/statistics.jl:186-220).
 // There is NO CPU fallback: without a HIP device every compute entry point fails with MCI_ERR_NO_DEVICE.
 #include "../../include/mci.h"
+#include "mci_debug.h"
 
 #include <hip/hip_runtime.h>
 
@@ -201,6 +202,7 @@ struct mci_problem {
     // launch before it is long enough to hide its ~14 us per iteration (>= kSerialWalkSamples samples or chain steps on this
     // rank: 1 % of the headline iteration), the prefix-scan form below that; mci_set_train_walk / MCI_TRAIN_SERIAL=1 | 0 force one
     int train_serial = -1;
+    bool debug_wrong_decision = false; // csrc/mci_debug.h: the serial walk's slots with one planted wrong decision (TrainArgs::serial_walk == 3)
     int64_t last_samples = 0; // samples (vegas) or chain steps of the last sample launch on this rank
     static const int64_t kSerialWalkSamples = (int64_t)1 << 26;
     bool train_lds_raised = false; // k_train / k_finish allowed more than 64 KiB of dynamic LDS (large grids)
@@ -210,13 +212,20 @@ struct mci_problem {
     int64_t reduces = 0;
     static const int kCevRing = 64;
     // :mcmc automatic chain length: the holding-time histogram of launch k is copied to pinned host memory behind the launch (after
-    // an all-reduce over the ranks, so that every rank sizes its chains from the SAME histogram) and is looked at when launch k + 2
-    // is queued -- launch k + 1 is still running then, so the host never drains the stream (mci_integrate keeps queueing
-    // iterations back to back) and the lag is fixed, so a run is reproducible
-    unsigned long long *h_hold = nullptr;   // pinned [2][64]
-    hipEvent_t hold_ev[2] = {nullptr, nullptr};
-    bool hold_inflight[2] = {false, false};
+    // an all-reduce over the ranks, so that every rank sizes its chains from the SAME histogram) and is looked at when launch k + 1
+    // is sized: the host waits for the sample kernel of launch k (not for its merge / train!, which run while launch k + 1 is
+    // queued) -- ~10 us of idle queue per iteration, nothing next to a chain launch; the lag is fixed, so a run is reproducible
+    unsigned long long *h_hold = nullptr;   // pinned [64]
+    hipEvent_t hold_ev = nullptr;
+    bool hold_inflight = false;
     int64_t hold_launches = 0;              // :mcmc launches that recorded a histogram
+    int64_t hold_len = 0;                   // measured steps per chain of the launch `hold_max` comes from
+    int64_t hold_len_inflight = 0;          // ... of the launch whose histogram is in flight
+    // per-block means of the chain solvers' iterations (MergeArgs::block_means): rows [blk_rows][blk_stride = local blocks * nobs];
+    // what the block-lineage error of a run of carried chains is computed from (mci_lineage_sums)
+    double *d_blocklog = nullptr;
+    int64_t cap_blocklog = 0, blk_rows = 0, blk_stride = 0, blk_lo = -1;
+    int blk_carried = 0;                    // rows of the log whose launch continued the chains of the one before
     // Carried chains (BatchArgs::carry_x): end configurations of the last chain launch, two buffers (read one, write the other),
     // and what that launch was -- an iteration continues it when it is the NEXT iteration of the same solver over the same blocks
     double *d_chain_x[2] = {nullptr, nullptr};
@@ -256,12 +265,22 @@ struct mci_problem {
     PersistJob *persist_job = nullptr;
     unsigned long long *d_persist = nullptr; // [0] arrived | done << 40, [2] gave up
     unsigned long long persist_arrive = 0, persist_done = 0;
+    unsigned long long persist_spin_ticks = 200000000ull; // ticks of the 100 MHz wall clock a grid-wide wait may take: 2 s (mci_debug_persist_spin_ticks)
     int persistent = -1;          // -1 automatic (launch-bound :vegas calls of mci_integrate), 0 never, 1 whenever the layout allows
     bool last_persistent = false; // the last mci_integrate ran as one persistent launch
     static const int kGroups = mci::kMergeGroups;
     static const int64_t kChainFill = 131072; // chains per GPU that keep 2 waves on each of the 1024 SIMDs
-    static const int64_t kMcmcMinSteps = 131072; // measured steps per auto :mcmc chain (>> the mixing times measured so far)
+    // automatic :mcmc chain lengths (mci_mcmc_auto_chains): measured steps per chain while nothing has been measured | how much longer
+    // than the chains that measured the holds a launch's chains may be.  (MCI_MCMC_PILOT / MCI_MCMC_GROW: experiment knobs)
+    static int64_t kMcmcPilotSteps, kMcmcGrow;
 };
+
+static int64_t env_i64(const char *name, int64_t dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoll(e) : dflt;
+}
+int64_t mci_problem::kMcmcPilotSteps = env_i64("MCI_MCMC_PILOT", 4096);
+int64_t mci_problem::kMcmcGrow = env_i64("MCI_MCMC_GROW", 4);
 
 static void persist_job_drop(mci_problem *p);
 namespace { void persist_orphans_join(); }
@@ -313,6 +332,7 @@ int check_status(mci_problem *p) {
     if (!st) return MCI_OK;
     HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int), p->ctx->stream));
     if (st & mci::ST_PERSIST_STALL) { // a grid-wide wait of the persistent :vegas launch ran out of time: its counters are void
+        // (mci_integrate recovers by itself and never gets here with this bit; this is the message of a stall somebody else finds)
         HIPCHK(hipMemsetAsync(p->d_persist, 0, 3 * sizeof(unsigned long long), p->ctx->stream));
         HIPCHK(hipMemsetAsync(p->d_ghist, 0, 3 * (size_t)(p->shape.nbin ? p->shape.nbin : 1) * sizeof(double), p->ctx->stream));
         p->persist_arrive = p->persist_done = 0;
@@ -327,38 +347,53 @@ int check_status(mci_problem *p) {
     return fail(MCI_ERR_HISTOGRAM, "distribution is not all finite");
 }
 
-// :mcmc holding-time histogram of the launch just queued -> (sum over the ranks ->) pinned host slot, behind the launch on the stream
-int hold_publish(mci_problem *p) {
+// after a stalled persistent :vegas launch: status word, grid-wide counters and the three histogram buffers back to their idle state
+int persist_recover(mci_problem *p) {
+    hipStream_t st = p->ctx->stream;
+    HIPCHK(hipMemsetAsync(p->d_status, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(p->d_persist, 0, 3 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(p->d_ghist, 0, 3 * (size_t)(p->shape.nbin ? p->shape.nbin : 1) * sizeof(double), st));
+    p->persist_arrive = p->persist_done = 0;
+    p->persist_failed = true; // (later calls take the launch-per-iteration path)
+    p->merge_pending = false;
+    return MCI_OK;
+}
+
+// :mcmc holding-time histogram of the launch just queued -> (sum over the ranks ->) pinned host memory, behind the launch on the stream
+int hold_publish(mci_problem *p, int64_t chain_len) {
     hipStream_t st = p->ctx->stream;
     if (!p->h_hold) {
-        HIPCHK(hipHostMalloc((void **)&p->h_hold, 2 * 64 * sizeof(unsigned long long), hipHostMallocDefault));
-        for (auto &e : p->hold_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(hipHostMalloc((void **)&p->h_hold, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&p->hold_ev, hipEventDisableTiming));
     }
     if (p->ctx->comm) { // every rank sizes its next chains from the same histogram: results do not depend on which rank ran which block
         int r = g_rccl.AllReduce(p->d_hold, p->d_hold, 64, kNcclUint64, kNcclSum, p->ctx->comm, st);
         if (r) return fail(MCI_ERR_COMM, "ncclAllReduce (holding times): %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     }
-    const int slot = (int)(p->hold_launches & 1);
-    HIPCHK(hipMemcpyAsync(p->h_hold + 64 * slot, p->d_hold, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(p->hold_ev[slot], st));
-    p->hold_inflight[slot] = true;
+    if (p->hold_inflight) HIPCHK(hipEventSynchronize(p->hold_ev)); // (a histogram nobody looked at: explicit chain counts in between)
+    HIPCHK(hipMemcpyAsync(p->h_hold, p->d_hold, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(p->hold_ev, st));
+    p->hold_inflight = true;
+    p->hold_len_inflight = chain_len;
     p->hold_launches += 1;
     return MCI_OK;
 }
 
-// before :mcmc launch k with an automatic chain count is sized: take in the histogram of launch max(k - 2, 0).  Launch k - 1 is
-// still running (or queued) when the host waits for k - 2, so the stream never drains; the fixed lag keeps a run reproducible.
+// before an :mcmc launch with an automatic chain count is sized: take in the histogram of the launch before it.  The host waits for
+// that launch's sample kernel here (its merge and train! are still running or queued: the next launch is queued behind them while they
+// run); what it costs is measured in tools/latency.py, what the two-launch lag of the rounds before cost in profiles/r03_c5_kernel_stats.txt
+// (two more launches sized from the untrained map's holding times: 324 ms of a cold BASELINE configs[4] call).
 int hold_consume(mci_problem *p) {
-    const int64_t k = p->hold_launches;
-    if (k < 1) return MCI_OK;
-    const int slot = k >= 2 ? (int)((k - 2) & 1) : 0;
-    if (!p->hold_inflight[slot]) return MCI_OK;
-    HIPCHK(hipEventSynchronize(p->hold_ev[slot]));
-    p->hold_inflight[slot] = false;
+    if (!p->hold_inflight) return MCI_OK;
+    HIPCHK(hipEventSynchronize(p->hold_ev));
+    p->hold_inflight = false;
     int top = -1;
     for (int b = 0; b < 64; ++b)
-        if (p->h_hold[64 * slot + b]) top = b;
-    if (top >= 0) p->hold_max = (int64_t)1 << top; // bucket b holds bit_width(h) == b, i.e. h < 2^b
+        if (p->h_hold[b]) top = b;
+    if (top >= 0) {
+        p->hold_max = (int64_t)1 << top; // bucket b holds bit_width(h) == b, i.e. h < 2^b
+        p->hold_len = p->hold_len_inflight;
+    }
     return MCI_OK;
 }
 
@@ -384,6 +419,26 @@ void drop_modules(mci_problem *p) {
 } // namespace
 
 static int flush_merge(mci_problem *p);
+static int comm_sum_host(mci_problem *p, double *v, int n);
+
+// room for `rows` rows of [blk_stride] doubles in the block log (grows with a copy and a stream synchronisation; mci_integrate reserves
+// its iterations before the loop)
+static int grow_block_log(mci_problem *p, int64_t rows) {
+    const int64_t need = rows * p->blk_stride;
+    if (need <= p->cap_blocklog) return MCI_OK;
+    int64_t ncap = p->cap_blocklog ? p->cap_blocklog : 4096;
+    while (ncap < need) ncap *= 2;
+    double *n = nullptr;
+    HIPCHK(hipMalloc((void **)&n, (size_t)ncap * sizeof(double)));
+    if (p->d_blocklog) {
+        HIPCHK(hipMemcpyAsync(n, p->d_blocklog, (size_t)p->cap_blocklog * sizeof(double), hipMemcpyDeviceToDevice, p->ctx->stream));
+        HIPCHK(hipStreamSynchronize(p->ctx->stream));
+        (void)hipFree(p->d_blocklog);
+    }
+    p->d_blocklog = n;
+    p->cap_blocklog = ncap;
+    return MCI_OK;
+}
 
 extern "C" {
 
@@ -866,8 +921,8 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->d_carry_src) (void)hipFree(p->d_carry_src);
         if (p->h_hold) (void)hipHostFree(p->h_hold);
         if (p->h_log) (void)hipHostFree(p->h_log);
-        for (auto &e : p->hold_ev)
-            if (e) (void)hipEventDestroy(e);
+        if (p->hold_ev) (void)hipEventDestroy(p->hold_ev);
+        if (p->d_blocklog) (void)hipFree(p->d_blocklog);
         for (auto &e : p->cevs) (void)hipEventDestroy(e);
         if (p->d_hx) (void)hipFree(p->d_hx);
         if (p->d_hstep) (void)hipFree(p->d_hstep);
@@ -1289,8 +1344,21 @@ int mci_set_rng_rounds(mci_problem *p, int32_t rounds) {
 
 int mci_set_train_walk(mci_problem *p, int32_t mode) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
-    if (mode < -1 || mode > 3) return fail(MCI_ERR_INVALID, "train walk mode must be -1 (automatic), 0 (prefix scan), 1 (serial recurrence), 2 (serial recurrence, general form only) or 3 (test hook)");
+    if (mode < -1 || mode > 2) return fail(MCI_ERR_INVALID, "train walk mode must be -1 (automatic), 0 (prefix scan), 1 (serial recurrence) or 2 (serial recurrence, general form only)");
     p->train_serial = mode;
+    return MCI_OK;
+}
+
+// csrc/mci_debug.h
+int mci_debug_plant_wrong_decision(mci_problem *p, int32_t on) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    p->debug_wrong_decision = on != 0;
+    return MCI_OK;
+}
+
+int mci_debug_persist_spin_ticks(mci_problem *p, unsigned long long ticks) {
+    if (!p || ticks == 0) return fail(MCI_ERR_INVALID, "bad argument");
+    p->persist_spin_ticks = ticks;
     return MCI_OK;
 }
 
@@ -1307,7 +1375,7 @@ int mci_set_deterministic(mci_problem *p, int32_t on) {
 
 int mci_set_chain_carry(mci_problem *p, int32_t mode) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
-    if (mode < -1 || mode > 1) return fail(MCI_ERR_INVALID, "chain carry mode must be -1 (automatic: :vegasmc), 0 (every launch starts its chains afresh) or 1 (:vegasmc and :mcmc)");
+    if (mode < -1 || mode > 1) return fail(MCI_ERR_INVALID, "chain carry mode must be -1 (automatic) or 1 (many-chain launches of :vegasmc and :mcmc continue the chains of the iteration before) or 0 (every launch starts its chains afresh)");
     p->chain_carry = mode;
     if (mode == 0) p->chain_valid = false;
     return MCI_OK;
@@ -1446,25 +1514,18 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // pass nchain explicitly for integrands known to mix fast (C5: 10 Gsteps/s at nchain = 4096).
             // From the second :mcmc launch of a problem on, the length follows what the previous launch measured: 16 x the
             // longest time any chain's slot (or integrand index) went without changing (mci_mcmc_auto_chains).
+            // Carried chains (resampled to the moved target, k_resample_chains) start from stationary configurations AND a stationary
+            // integrand index: nothing to burn in.  What their length still has to cover is the longest holding time: a population
+            // grows by duplication (a launch of more chains than the one before continues every stored chain several times), and the
+            // copies of a chain must have gone their own ways before they are copied again -- 8 x the longest hold instead of the
+            // 16 x (+ burn-in) of fresh chains.  profiles/r03_chain_carry.txt: carried chains of two burn-in floors on 1/(1 - cos^3)
+            // keep their few ancestors' view of its sticky states for many iterations (-4.8 sigma pooled over 64 seeds); at 2, 4
+            // and 16 x the hold the pooled deviations are those of fresh chains.
+            // The holds are those of the launch BEFORE this one (hold_consume waits for its sample kernel); a first launch, with nothing
+            // measured, runs pilot-length chains, and a launch's chains are at most kMcmcGrow times as long as those that measured the
+            // holds (mci_mcmc_auto_chains).
             if ((rc = hold_consume(p))) return rc;
-            nchain = mci_mcmc_auto_chains(nevalperblock, nblocks, nslots, p->ni + 1, p->npool, p->hold_max);
-            if (may_carry && p->hold_max > 0) {
-                // Carried chains (resampled to the moved target, k_resample_chains) start from stationary configurations AND a stationary
-                // integrand index: nothing to burn in.  What their length still has to cover is the longest holding time: a population
-                // grows by duplication (a launch of more chains than the one before continues every stored chain several times), and the
-                // copies of a chain must have gone their own ways before they are copied again -- 8 x the longest hold instead of the
-                // 16 x (+ burn-in) of fresh chains.  profiles/r03_chain_carry.txt: carried chains of two burn-in floors on 1/(1 - cos^3)
-                // keep their few ancestors' view of its sticky states for many iterations (-4.8 sigma pooled over 64 seeds); at 2, 4
-                // and 16 x the hold the pooled deviations are those of fresh chains, and the seed scatter over the reported error on
-                // BASELINE configs[4] falls from 1.2-1.3 (4 x) to 1.1-1.2 (16 x; fresh chains: 1.0-1.2)
-                static const int64_t kCarryHolds = 8;
-                const int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(p->npool + 1) * (p->ni + 1);
-                const int64_t len = kCarryHolds * p->hold_max > 2 * fl ? kCarryHolds * p->hold_max : 2 * fl;
-                int64_t nc = nevalperblock / len;
-                const int64_t cap = mci_problem::kChainFill / nblocks > 64 ? mci_problem::kChainFill / nblocks : 64;
-                if (nc > cap) nc = cap;
-                if (nc > nchain) nchain = nc;
-            }
+            nchain = mci_mcmc_auto_chains(nevalperblock, nblocks, nslots, p->ni + 1, p->npool, p->hold_max, p->hold_len, may_carry ? 1 : 0);
         }
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
         // (carried chains keep the reference's own floor(steps * thermal_ratio) only, mcmc/montecarlo.jl:133)
@@ -1835,7 +1896,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         }
     } else
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
-    if (a.hold_hist && (rc = hold_publish(p))) return rc;
+    if (a.hold_hist && (rc = hold_publish(p, nevalperblock / nchain))) return rc;
     if (split)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles[kern == kSlotVegasAny ? 1 : 0], (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
@@ -1941,6 +2002,20 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     m.part_pa = solver != MCI_VEGAS ? p->d_part_pa : nullptr;
     m.npa = p->npa;
     m.nrows = (int)nrows;
+    m.block_means = nullptr;
+    if (solver != MCI_VEGAS) { // the chain solvers keep every block's mean of every iteration (one row of the block log)
+        const int64_t stride = nblocks * s.nobs;
+        if (stride != p->blk_stride || block_lo != p->blk_lo) {
+            p->blk_rows = 0;
+            p->blk_carried = 0;
+            p->blk_stride = stride;
+            p->blk_lo = block_lo;
+        }
+        if ((rc = grow_block_log(p, p->blk_rows + 1))) return rc;
+        m.block_means = p->d_blocklog + (size_t)p->blk_rows * stride;
+        p->blk_rows += 1;
+        p->blk_carried += p->last_carried ? 1 : 0;
+    }
     p->merge_pending = true;
     return MCI_OK;
 }
@@ -2018,6 +2093,7 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     a.gamma = gamma;
     a.do_train = do_train;
     a.serial_walk = p->train_serial >= 0 ? p->train_serial : (p->last_samples == 0 || p->last_samples >= mci_problem::kSerialWalkSamples) ? 1 : 0;
+    if (p->debug_wrong_decision && a.serial_walk == 1) a.serial_walk = 3;
     a.status = p->d_status;
     a.maxn = maxn;
     // d | sg | wa (train_leaf) | the serial walk's slots and their record, where they fit (grids of up to ~2700 increments), else k_finish's merged histogram alone
@@ -2341,7 +2417,7 @@ static int persist_launch(mci_problem *p, const mci_integrate_args *ia, int64_t 
     }
     f.arrive0 = p->persist_arrive;
     f.done0 = p->persist_done;
-    f.spin_ticks = 200000000ull; // 2 s of the 100 MHz wall clock per wait
+    f.spin_ticks = p->persist_spin_ticks; // 2 s of the 100 MHz wall clock per wait
     void *args[] = {&a, &f};
     // nrows sampling workgroups + the statistics workgroup
     HIPCHK(hipModuleLaunchKernel(p->f_persist, (unsigned)nrows + 1, 1, 1, (unsigned)T, 1, 1, (unsigned)lds, p->ctx->stream, args, nullptr));
@@ -2356,6 +2432,22 @@ static int persist_launch(mci_problem *p, const mci_integrate_args *ia, int64_t 
     p->last_threads = T;
     p->last_nblocks = (int)nblocks;
     p->log_row += ia->niter;
+    return MCI_OK;
+}
+
+// sum over the ranks of a few host doubles (the lineage sums of a run): through a device scratch word of the communicator's stream
+static int comm_sum_host(mci_problem *p, double *v, int n) {
+    if (!p->ctx->comm) return MCI_OK;
+    double *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, (size_t)n * sizeof(double)));
+    hipStream_t st = p->ctx->stream;
+    hipError_t e = hipMemcpyAsync(d, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
+    int r = e == hipSuccess ? g_rccl.AllReduce(d, d, (size_t)n, kNcclFloat64, kNcclSum, p->ctx->comm, st) : 0;
+    if (e == hipSuccess && !r) e = hipMemcpyAsync(v, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && !r) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (r) return fail(MCI_ERR_COMM, "ncclAllReduce (lineage sums): %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    if (e != hipSuccess) return fail(MCI_ERR_HIP, "lineage sums: %s", hipGetErrorString(e));
     return MCI_OK;
 }
 
@@ -2391,25 +2483,49 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
         HIPCHK(hipHostMalloc((void **)&p->h_log, ncap * sizeof(double), hipHostMallocDefault));
         p->cap_hlog = ncap;
     }
+    int64_t blk_row0 = -1; // this call's first row of the block log (chain solvers): the log starts over with every call
+    if (a->solver != MCI_VEGAS) {
+        if ((rc = flush_merge(p))) return rc; // (a pending merge writes its row of the old log)
+        p->blk_rows = 0;
+        p->blk_carried = 0;
+        p->blk_stride = (hi - lo) * s.nobs;
+        p->blk_lo = lo;
+        blk_row0 = 0;
+        if ((rc = grow_block_log(p, a->niter))) return rc;
+    }
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     const int row0 = p->log_row;
     auto t0 = std::chrono::steady_clock::now();
-    p->last_persistent = persist;
-    if (persist && (rc = persist_launch(p, a, nevalperblock, lo, hi, wpb_persist))) return rc;
-    // (a hipGraph replay of this chain was measured and dropped: 37.6 against 34.8 us per launch-bound iteration for the eager
-    // asynchronous launches on ROCm 7.0 / MI355X, profiles/r02_ablation.txt)
-    for (int it = 0; it < a->niter && !persist; ++it) { // main.jl:142
-        if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, a->first_iteration + it, a->seed, a->measurefreq, a->nchain, a->thermal_ratio))) return rc;
-        if ((rc = mci_iteration_reduce(p))) return rc;                                   // main.jl:177-188
-        if ((rc = mci_iteration_finish(p, a->solver, block, a->adapt, a->gamma, nullptr, nullptr))) return rc; // main.jl:183-199
-    }
-    // the statistics of all iterations and the status word come back behind the last kernel in ONE synchronisation, into pinned memory (a
-    // pageable destination goes through a staging copy: ~15 us of a 0.2 ms default-size call)
     double *h = p->h_log;
     int *hstatus = reinterpret_cast<int *>(p->h_log + nlog);
-    HIPCHK(hipMemcpyAsync(h, p->d_iterlog + (size_t)row0 * p->nstat, nlog * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
-    HIPCHK(hipMemcpyAsync(hstatus, p->d_status, sizeof(int), hipMemcpyDeviceToHost, p->ctx->stream));
-    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    for (int attempt = 0;; ++attempt) {
+        p->last_persistent = persist;
+        if (persist && (rc = persist_launch(p, a, nevalperblock, lo, hi, wpb_persist))) return rc;
+        // (a hipGraph replay of this chain was measured and dropped: 37.6 against 34.8 us per launch-bound iteration for the eager
+        // asynchronous launches on ROCm 7.0 / MI355X, profiles/r02_ablation.txt)
+        for (int it = 0; it < a->niter && !persist; ++it) { // main.jl:142
+            if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, a->first_iteration + it, a->seed, a->measurefreq, a->nchain, a->thermal_ratio))) return rc;
+            if ((rc = mci_iteration_reduce(p))) return rc;                                   // main.jl:177-188
+            if ((rc = mci_iteration_finish(p, a->solver, block, a->adapt, a->gamma, nullptr, nullptr))) return rc; // main.jl:183-199
+        }
+        // the statistics of all iterations and the status word come back behind the last kernel in ONE synchronisation, into pinned memory (a
+        // pageable destination goes through a staging copy: ~15 us of a 0.2 ms default-size call)
+        HIPCHK(hipMemcpyAsync(h, p->d_iterlog + (size_t)row0 * p->nstat, nlog * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+        HIPCHK(hipMemcpyAsync(hstatus, p->d_status, sizeof(int), hipMemcpyDeviceToHost, p->ctx->stream));
+        HIPCHK(hipStreamSynchronize(p->ctx->stream));
+        if (persist && attempt == 0 && (*hstatus & mci::ST_PERSIST_STALL)) {
+            // A grid-wide wait of the persistent launch ran out of time (its workgroups were not all resident: a device shared with another
+            // long-running kernel).  Nothing of the call is lost: the map is written back by workgroup 0 after the LAST turn only, so
+            // `edges` still holds what the call started from -- counters, histogram buffers and the status word are reset, the iteration
+            // log is rewound, and the same iterations run through the launch chain (as every later call of this problem does).
+            if ((rc = persist_recover(p))) return rc;
+            p->log_row = row0;
+            persist = false;
+            if ((rc = compile_solver(p, kslot(a->solver, a->measurefreq)))) return rc;
+            continue;
+        }
+        break;
+    }
     if (*hstatus && (rc = check_status(p))) return rc; // (reads it again, clears it, names the failure)
     auto t1 = std::chrono::steady_clock::now();
     res->seconds = std::chrono::duration<double>(t1 - t0).count();
@@ -2422,6 +2538,21 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     }
     for (int o = 0; o < s.nobs; ++o) // main.jl:211 -> statistics.jl:24-55
         mci_average(res->iter_mean + o, res->iter_std + o, s.nobs, ignore + 1, a->niter, &res->mean[o], &res->stdev[o], &res->chi2[o]);
+    // Carried chains: consecutive iterations are not independent, which statistics.jl:186-220 assumes -- but the blocks are (a block's
+    // chains descend from that block's chains only), so the error comes from the scatter of the blocks' weighted averages over the run
+    // (mci_lineage_sums + the reference's own _mean_std over them); same weights, same mean.
+    res->correlated = 0;
+    if (a->solver != MCI_VEGAS && blk_row0 >= 0 && p->blk_rows - blk_row0 == a->niter && p->blk_carried > 0 && a->niter > ignore + 1) {
+        const int64_t nb = hi - lo;
+        std::vector<double> bm((size_t)a->niter * nb * s.nobs), sums(2 * (size_t)s.nobs);
+        HIPCHK(hipMemcpyAsync(bm.data(), p->d_blocklog + (size_t)blk_row0 * p->blk_stride, bm.size() * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+        HIPCHK(hipStreamSynchronize(p->ctx->stream));
+        mci_lineage_sums(bm.data(), a->niter, nb, s.nobs, res->iter_std, ignore + 1, a->niter, sums.data(), sums.data() + s.nobs);
+        if ((rc = comm_sum_host(p, sums.data(), (int)sums.size()))) return rc;
+        std::vector<double> lm(s.nobs);
+        mci_mean_std(sums.data(), sums.data() + s.nobs, s.nobs, block, lm.data(), res->stdev);
+        res->correlated = 1;
+    }
     return MCI_OK;
 }
 
@@ -2742,20 +2873,64 @@ int64_t mci_mcmc_burnin(int64_t steps, int64_t nchain, int32_t nslots, int32_t n
     return nburn;
 }
 
-int64_t mci_mcmc_auto_chains(int64_t nevalperblock, int64_t nblocks, int32_t nslots, int32_t nd, int32_t npool, int64_t hold_max) {
-    // chain length: kMcmcMinSteps while nothing has been measured; afterwards 16 x the longest holding time of the previous
-    // launch, and never fewer than 8 burn-in floors.  Calibration (profiles/r01_chain_bias.txt): on the bubble diagram chains
-    // of 1-2 x that holding time are ~1e-3 off, chains of 8 x are unbiased at the 5e-4 level of the measurement.
-    int64_t len = mci_problem::kMcmcMinSteps;
+int64_t mci_mcmc_auto_chains(int64_t nevalperblock, int64_t nblocks, int32_t nslots, int32_t nd, int32_t npool, int64_t hold_max,
+                             int64_t hold_len, int32_t carried) {
+    // Chain length (measured steps) of an automatic :mcmc launch.  hold_max = the longest time any chain's slot (or integrand index)
+    // went without changing in the launch before (upper edge of the top occupied bucket), hold_len = the chain length of that launch.
+    //   nothing measured (hold_max = 0): pilot-length chains, kMcmcPilotSteps or 8 burn-in floors -- the first iteration trains the map
+    //     and is ignored by default (main.jl:82); its holds are those of the UNTRAINED map, up to 2^13 steps on BASELINE configs[4]
+    //     where the trained map holds for 2^9: chains sized for them (131072 steps in the rounds before) cost 0.74 s of a cold call
+    //   fresh chains: 16 x hold_max, never fewer than 8 burn-in floors.  Calibration (profiles/r01_chain_bias.txt): on the bubble
+    //     diagram chains of 1-2 x that holding time are ~1e-3 off, chains of 8 x are unbiased at the 5e-4 level of the measurement
+    //   carried chains (stationary starts): 8 x hold_max, never fewer than 2 floors (profiles/r03_chain_carry.txt)
+    //   at most kMcmcGrow x hold_len: a hold longer than a quarter of the chain that measured it is censored by that chain's
+    //     length -- what it says is "longer", not how long -- so the length escalates by that factor per launch until the
+    //     measured holds fit (heavy-tailed integrands: 2^14..2^15 steps on the bubble diagram) instead of jumping to 8-16 x a
+    //     number the untrained map inflated
+    const int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(npool + 1) * nd;
+    const int64_t floor_len = (carried ? 2 : 8) * fl;
+    int64_t len = mci_problem::kMcmcPilotSteps;
     if (hold_max > 0) {
-        const int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(npool + 1) * nd;
-        len = 16 * hold_max > 8 * fl ? 16 * hold_max : 8 * fl;
+        len = (carried ? 8 : 16) * hold_max;
+        if (hold_len > 0 && len > mci_problem::kMcmcGrow * hold_len) len = mci_problem::kMcmcGrow * hold_len;
     }
+    if (len < floor_len) len = floor_len;
     int64_t nchain = nevalperblock / len;
     const int64_t cap = mci_problem::kChainFill / (nblocks > 0 ? nblocks : 1) > 64 ? mci_problem::kChainFill / (nblocks > 0 ? nblocks : 1) : 64;
     if (nchain > cap) nchain = cap;
     if (nchain < 1) nchain = 1;
     return nchain;
+}
+
+int mci_get_block_means(mci_problem *p, int32_t rows, double *out, int64_t *nblocks, int32_t *carried) {
+    if (!p || rows < 0 || (rows > 0 && !out)) return fail(MCI_ERR_INVALID, "bad argument");
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    if (rows > p->blk_rows) return fail(MCI_ERR_INVALID, "the block log holds %lld iterations, %d asked for", (long long)p->blk_rows, (int)rows);
+    HIPCHK(hipSetDevice(p->ctx->device));
+    int rc = flush_merge(p);
+    if (rc) return rc;
+    if (nblocks) *nblocks = p->shape.nobs > 0 ? p->blk_stride / p->shape.nobs : 0;
+    if (carried) *carried = p->blk_carried;
+    if (rows > 0) {
+        HIPCHK(hipMemcpyAsync(out, p->d_blocklog + (size_t)(p->blk_rows - rows) * p->blk_stride, (size_t)rows * p->blk_stride * sizeof(double),
+                              hipMemcpyDeviceToHost, p->ctx->stream));
+        HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    }
+    return MCI_OK;
+}
+
+int mci_comm_sum(mci_problem *p, double *v, int32_t n) {
+    if (!p || !v || n < 0) return fail(MCI_ERR_INVALID, "bad argument");
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    return comm_sum_host(p, v, n);
+}
+
+int mci_reset_block_log(mci_problem *p) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    p->blk_rows = 0;
+    p->blk_carried = 0;
+    return MCI_OK;
 }
 
 int mci_get_hold_histogram(mci_problem *p, uint64_t *out64) {
@@ -2815,6 +2990,30 @@ void mci_average(const double *iter_mean, const double *iter_std, int64_t stride
     *mean = mea;
     *err = 1.0 / sqrt(wsum);                      // statistics.jl:198
     *chi2 = c2 / (double)((max - init + 1) - 1);  // statistics.jl:204
+}
+
+void mci_lineage_sums(const double *block_means, int64_t niter, int64_t nblocks, int64_t nobs, const double *iter_std, int64_t init,
+                      int64_t max, double *sum, double *sumsq) {
+    (void)niter;
+    for (int64_t o = 0; o < nobs; ++o) {
+        double wsum = 0.0; // the weights of statistics.jl:217, :197
+        for (int64_t i = init; i <= max; ++i) {
+            const double sd = iter_std[(i - 1) * nobs + o] + 1.0e-10;
+            wsum += 1.0 / (sd * sd);
+        }
+        double s1 = 0.0, s2 = 0.0;
+        for (int64_t b = 0; b < nblocks; ++b) {
+            double mb = 0.0; // this block's lineage: its weighted average over the iterations
+            for (int64_t i = init; i <= max; ++i) {
+                const double sd = iter_std[(i - 1) * nobs + o] + 1.0e-10;
+                mb += block_means[((i - 1) * nblocks + b) * nobs + o] * (1.0 / (sd * sd)) / wsum;
+            }
+            s1 += mb;
+            s2 += mb * mb;
+        }
+        sum[o] = s1;
+        sumsq[o] = s2;
+    }
 }
 
 void mci_do_reweight(double *reweight, const double *visited, int64_t nd, double gamma, const double *goal) {

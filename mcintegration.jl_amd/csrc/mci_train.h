@@ -40,6 +40,8 @@ struct MergeArgs {
     double *scratch;         // [nblocks*ncols]
     const double *part_pa;   // [nrows][2*npa] per-workgroup propose | accept tables of a chain solver; NULL after a :vegas pass
     int npa, nrows;          // npa = 3 * (ni+1) * max(ni+1, npool)   (configuration.jl:185-186)
+    double *block_means;     // [nblocks][nobs] or NULL: every block's m = observable / normalization of this iteration (main.jl:275-280),
+                             // kept per iteration for the block-lineage error of carried chains (mci_lineage_sums)
 };
 // packed = [ ... | hist(nbin) | propose(npa) | accept(npa) ]: the tables ride in the all-reduce like MPIreduceConfig! reduces them
 // (configuration.jl:297-298).  One wave per entry, lanes stride over the workgroup rows.
@@ -80,7 +82,7 @@ __device__ inline double merge_hist_bin(const MergeArgs &m, int bin) {
 __device__ inline void merge_stats(const MergeArgs &m) {
     const double *__restrict__ part_cols = m.part_cols;
     const int ncols = m.ncols, nobs = m.nobs, ni = m.ni, nblocks = m.nblocks, wg_per_block = m.wg_per_block;
-    double *__restrict__ packed = m.packed, *__restrict__ scratch = m.scratch;
+    double *__restrict__ packed = m.packed, *__restrict__ scratch = m.scratch, *__restrict__ block_means = m.block_means;
     int *status = m.status;
     // --- statistics columns ---
     // scratch[b][c] = sum over the block's workgroup rows, in a fixed order: 8 lanes per (block, column) stride
@@ -108,6 +110,7 @@ __device__ inline void merge_stats(const MergeArgs &m) {
             const double m = scratch[b * ncols + o] / norm;
             sum += m;
             sq += m * m;
+            if (block_means) block_means[(size_t)b * nobs + o] = m;
         }
         packed[o] = sum;
         packed[nobs + o] = sq;
@@ -183,7 +186,8 @@ __host__ __device__ inline int train_spare_doubles(int n) { return 2 * (2 * n + 
 
 // Julia's sum() over a histogram-length vector (common.jl:72, variable.jl:226) is mapreduce_impl's `@simd` loop below its pairwise
 // block size of 1024: a vectorised reduction whose association is the CPU's (lanes x interleave), not left to right.  Oracle and
-// device fix the AVX2 shape: 16 interleaved partial sums (element i -> partial i mod 16, each left to right), folded
+// device fix ONE association of that family (the lanes x interleave of an AVX2 build; not any particular Julia binary's order to the
+// last bit, see oracle/mci_oracle.c mcio_sum16): 16 interleaved partial sums (element i -> partial i mod 16, each left to right), folded
 // p[l] += p[l + h] for h = 8, 4, 2, 1.  Called by every thread of the workgroup; every 16-lane group computes the total for itself.
 // From 1025 elements on mapreduce_impl splits the range at its midpoint and adds the sums of the two halves: sum_julia below.
 __device__ inline double sum16(const double *v, int n) {
@@ -317,42 +321,8 @@ __device__ __forceinline__ void walk_bins16(double &acc, const double (&v)[16], 
                  : "vcc", "scc", "memory");
 }
 
-// The same sixteen bins without a branch, for trips in which no bin yields more than one new point (the rule once the grid has
-// adapted): `acc_f -= f_ninc` runs under the compare's own lane mask (v_cmpx writes EXEC), six instructions per bin.  One wave
-// alone issues an instruction every ~4-5 ns whatever it is, so the instruction count is the cost (a variant that forms both outcomes
-// ahead of the compare has a shorter chain, one instruction more, and measured the same).  m = the largest acc_f left after a
-// subtraction: m >= f_ninc means some bin needed a second one -- the caller then redoes the trip with walk_bins16 from the saved
-// acc_f (identical records where both are valid).   %0 acc_f  %1 m  %2 saved EXEC  %3 f_ninc  %4 rec  %5..%21 bins
-#define MCI_WALK_BIN1(OFF, DN)                                                                                                         \
-    "ds_write_b64 %4, %0 offset:" OFF "\n\tv_cmpx_ge_f64 vcc, %0, %3\n\tv_add_f64 %0, %0, -%3\n\ts_mov_b64 exec, %2\n\t"                  \
-    "v_max_f64 %1, %1, %0\n\tv_add_f64 %0, %0, " DN "\n\t"
-__device__ __forceinline__ void walk_bins16_single(double &acc, double &m, const double (&v)[16], const double vnext, const double f, const unsigned rec_addr) {
-    unsigned long long sv;
-    asm volatile("s_mov_b64 %2, exec\n\tv_mov_b64 %1, 0\n\t"
-                 MCI_WALK_BIN1("0", "%6")
-                 MCI_WALK_BIN1("8", "%7")
-                 MCI_WALK_BIN1("16", "%8")
-                 MCI_WALK_BIN1("24", "%9")
-                 MCI_WALK_BIN1("32", "%10")
-                 MCI_WALK_BIN1("40", "%11")
-                 MCI_WALK_BIN1("48", "%12")
-                 MCI_WALK_BIN1("56", "%13")
-                 MCI_WALK_BIN1("64", "%14")
-                 MCI_WALK_BIN1("72", "%15")
-                 MCI_WALK_BIN1("80", "%16")
-                 MCI_WALK_BIN1("88", "%17")
-                 MCI_WALK_BIN1("96", "%18")
-                 MCI_WALK_BIN1("104", "%19")
-                 MCI_WALK_BIN1("112", "%20")
-                 MCI_WALK_BIN1("120", "%21")
-                 : "+v"(acc), "=&v"(m), "=&s"(sv)
-                 : "v"(f), "v"(rec_addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
-                   "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(vnext)
-                 : "vcc", "memory");
-}
 #undef MCI_WALK_BIN
 #undef MCI_WALK_MORE
-#undef MCI_WALK_BIN1
 
 // Sixteen SLOTS of the walk with its decisions given (train_leaf, serial form): acc_f += e[k], one dependent addition per slot.  Lane 0
 // records acc_f at the head of every sixteen slots only (`lone`); the values in between are the same additions again, done for all
@@ -366,14 +336,10 @@ template <bool RECORD> __device__ __forceinline__ void walk_slots16(double &acc,
     }
 }
 
+// one trip of the general form (the fall-back of the slots below: a decision that did not hold, grids too long for the slots' LDS,
+// mci_set_train_walk(prob, 2))
 __device__ __forceinline__ void walk_trip(double &acc, const double (&v)[16], const double vnext, const double f, const unsigned rec_addr) {
-    const double acc0 = acc;
-    double m;
-    walk_bins16_single(acc, m, v, vnext, f, rec_addr);
-    if (__builtin_amdgcn_ballot_w64(!(m < f)) != 0ull) { // some bin of the trip yields two or more points: the general form, from the start of the trip
-        acc = acc0;
-        walk_bins16(acc, v, vnext, f, rec_addr);
-    }
+    walk_bins16(acc, v, vnext, f, rec_addr);
 }
 #endif // MCI_TRAIN_SCAN_ONLY
 
@@ -459,7 +425,7 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
         MCI_TT(2)
         // rescale  common.jl:67-82
         if (N > 1) {
-            // sum(dist) :72 -- the serial form sums like Julia does (sum_julia: what the bit-for-bit walk starts from); the prefix-scan form,
+            // sum(dist) :72 -- the serial form sums in sum_julia's fixed association (one of the family Julia's @simd sum() belongs to: what the walk, bit-for-bit the oracle's, starts from); the prefix-scan form,
             // which rounds differently from the reference's recurrence anyway, takes the waves' partial sums in a fixed order
             double s;
             if (serial_walk) {
@@ -591,7 +557,8 @@ __device__ inline void train_leaf(const LeafDev &L, const double *h, double *hcl
             return;
         }
 #ifndef MCI_TRAIN_SCAN_ONLY
-        // Serial form: the reference's recurrence, floating-point operation for operation (bit-for-bit the oracle's).  Bin-major:
+        // Serial form: the reference's recurrence -- its additions and subtractions on its operands in its order (bit-for-bit the oracle's;
+        // the two sums it starts from are in ONE fixed association, sum16 above, where Julia's own depends on the CPU).  Bin-major:
         // consuming avg_f[j] and then emitting new points while acc_f >= f_ninc is the same sequence of operations and decisions
         // as `for i: while acc_f < f_ninc: j += 1; acc_f += avg_f[j]; end; acc_f -= f_ninc` (:227-232).  Lane 0 runs only the
         // chain -- add, compare, subtract -- and records acc_f after each bin (walk_bins16); how many points a bin yields, their

@@ -432,9 +432,10 @@ class Engine:
 
     def set_train_walk(self, mode):
         """train!'s refinement walk: "serial" (the reference's recurrence), "scan" (prefix scan + bisection), "auto", or "serial_general"
-        (the recurrence without the predicted decisions: what "serial" falls back to; "serial_wrong_decision": a test hook that makes it
-        fall back); see mci_set_train_walk"""
-        check(lib().mci_set_train_walk(self.p, {"auto": -1, "scan": 0, "serial": 1, "serial_general": 2, "serial_wrong_decision": 3, -1: -1, 0: 0, 1: 1, 2: 2, 3: 3}[mode]))
+        (the recurrence without the predicted decisions: what "serial" falls back to); see mci_set_train_walk.  "serial_wrong_decision" is
+        the test hook of csrc/mci_debug.h: "serial" with one decision planted wrong, so that its check and the fall-back run"""
+        check(lib().mci_debug_plant_wrong_decision(self.p, 1 if mode in ("serial_wrong_decision", 3) else 0))
+        check(lib().mci_set_train_walk(self.p, {"auto": -1, "scan": 0, "serial": 1, "serial_general": 2, "serial_wrong_decision": 1, -1: -1, 0: 0, 1: 1, 2: 2, 3: 1}[mode]))
 
     def walk_counts(self):
         """(serial walks of train! run as slots with given decisions, walks in the general form) so far; see mci_debug_walk_counts"""
@@ -456,9 +457,32 @@ class Engine:
         im, ie = np.zeros((niter, n)), np.zeros((niter, n))
         m, s, c2 = np.zeros(n), np.zeros(n), np.zeros(n)
         vis = np.zeros(self.config.N + 1)
-        r = _lib.ResultC(niter, n, _dp(im), _dp(ie), _dp(m), _dp(s), _dp(c2), 0, 0.0, _dp(vis))
+        r = _lib.ResultC(niter, n, _dp(im), _dp(ie), _dp(m), _dp(s), _dp(c2), 0, 0.0, _dp(vis), 0)
         check(lib().mci_integrate(self.p, C.byref(a), C.byref(r)))
-        return dict(mean=m, stdev=s, chi2=c2, iter_mean=im, iter_std=ie, neval=r.neval, seconds=r.seconds, visited=vis)
+        out = dict(mean=m, stdev=s, chi2=c2, iter_mean=im, iter_std=ie, neval=r.neval, seconds=r.seconds, visited=vis,
+                   correlated=bool(r.correlated), block_mean=None)
+        if _lib.SOLVERS[solver] != _lib.VEGAS:
+            out["block_mean"] = self.block_means(niter)[0]
+        return out
+
+    def block_means(self, rows):
+        """chain solvers: (block means [rows][local blocks][nobs] of the last `rows` iterations, how many of the logged iterations
+        continued the chains of the one before); see mci_get_block_means"""
+        nb, carried = C.c_int64(), C.c_int32()
+        check(lib().mci_get_block_means(self.p, 0, None, C.byref(nb), C.byref(carried)))
+        out = np.zeros((int(rows), int(nb.value), self.nobs))
+        if rows > 0 and out.size:
+            check(lib().mci_get_block_means(self.p, int(rows), _dp(out), C.byref(nb), C.byref(carried)))
+        return out, int(carried.value)
+
+    def comm_sum(self, v):
+        """v summed over the ranks of the library's communicator (mci_comm_sum)"""
+        a = np.ascontiguousarray(v, dtype=np.float64).copy()
+        check(lib().mci_comm_sum(self.p, _dp(a), a.size))
+        return a
+
+    def reset_block_log(self):
+        check(lib().mci_reset_block_log(self.p))
 
     def comm_ranks(self):
         """ranks of the communicator attached to this engine's context (1: none; mci_integrate shards its blocks over them)"""

@@ -131,6 +131,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     t0 = time.time()
     means, stds = [], []
     neval_done = 0
+    block_mean, correlated = None, False   # chain solvers: every block's mean of every iteration | the iterations continued each other's chains
     if type(comm) is LocalComm and engine_factory is None and hasattr(eng, "integrate") and getattr(eng, "comm_ranks", lambda: 0)() == 1:
         # one process: the whole loop runs inside the library (mci_integrate: the iterations are queued back to back on the
         # engine's stream and the statistics of all of them are read back once -- 22 us per launch-bound iteration instead of
@@ -139,11 +140,14 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
                           measurefreq=measurefreq, seed=config.seed, nchain=nchain, first_iteration=config.iterations_done,
                           thermal_ratio=thermal_ratio, reweight_goal=reweight_goal)
         means, stds = list(r["iter_mean"]), list(r["iter_std"])
+        block_mean, correlated = r.get("block_mean"), r.get("correlated", False)
         neval_done = nevalperblock * block * niter
         niter_loop = 0
         config.visited = r["visited"]    # config.visited of the last iteration (configuration.jl:46), for report(config)
     else:
         niter_loop = niter
+        if s != VEGAS and hasattr(eng, "reset_block_log"):
+            eng.reset_block_log()
     for it in range(niter_loop):                                                      # main.jl:142
         eng.run(s, nevalperblock, lo, hi, config.iterations_done + it, config.seed, measurefreq, nchain, thermal_ratio)   # main.jl:152-166
         comm.all_reduce(eng)                                                          # main.jl:177-188
@@ -161,7 +165,11 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
             config.visited = pk[2 * eng.nobs + 2: 2 * eng.nobs + 2 + config.N + 1].copy()
         except Exception:
             pass
-    res = Result(np.array(means), np.array(stds), config, ignore, neval=neval_done, seconds=time.time() - t0)   # main.jl:211
+    if niter_loop and s != VEGAS and hasattr(eng, "block_means"):
+        block_mean, ncarried = eng.block_means(niter)
+        correlated = ncarried > 0
+    res = Result(np.array(means), np.array(stds), config, ignore, neval=neval_done, seconds=time.time() - t0, block_mean=block_mean,
+                 correlated=correlated, block=block, sum_ranks=(lambda v: comm.sum_host(eng, v)) if comm.size > 1 else None)   # main.jl:211
     if print >= 0:
         report(res, io=printio)                                                       # main.jl:212-213
     return res

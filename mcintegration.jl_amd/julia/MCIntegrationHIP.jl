@@ -92,6 +92,7 @@ mutable struct ResultC
     iter_mean::Ptr{Float64}; iter_std::Ptr{Float64}; mean::Ptr{Float64}; stdev::Ptr{Float64}; chi2::Ptr{Float64}
     neval::Int64; seconds::Float64
     visited::Ptr{Float64}
+    correlated::Int32          # out: 1 = stdev is the block-lineage error of carried chains (mci_lineage_sums), else statistics.jl:198
 end
 
 const _ctx = Dict{Int,Ptr{Cvoid}}()              # one mci_ctx (HIP stream + RCCL communicator) per device
@@ -586,7 +587,8 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
     check(ccall((:mci_set_rng_rounds, libmci), Cint, (Ptr{Cvoid}, Int32), prob, rng_rounds))
     check(ccall((:mci_set_train_walk, libmci), Cint, (Ptr{Cvoid}, Int32), prob, train_walk))
     # deterministic = true: bit-identical results for a fixed seed, like the reference's sequential loop under MersenneTwister(seed)
-    # (configuration.jl:190); chain_carry: -1 automatic (:vegasmc iterations continue the previous one's chains), 0 off, 1 :mcmc too
+    # (configuration.jl:190); chain_carry: -1 automatic / 1 (many-chain iterations of :vegasmc AND :mcmc continue the previous one's chains; the
+    # error of such a run is the block-lineage error, ResultC.correlated), 0 off (every iteration starts afresh like mcmc/montecarlo.jl:118-124)
     check(ccall((:mci_set_deterministic, libmci), Cint, (Ptr{Cvoid}, Int32), prob, deterministic ? 1 : 0))
     check(ccall((:mci_set_chain_carry, libmci), Cint, (Ptr{Cvoid}, Int32), prob, chain_carry))
     # persistent: -1 automatic (a launch-bound :vegas call over one Continuous variable type runs all its iterations as one launch), 0 off, 1 on
@@ -598,7 +600,7 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
     args = Ref(IntegrateArgs(SOLVER[solver], Int64(neval), niter, block, ignore, adapt, gamma, measurefreq, UInt64(config.seed),
                              nchain, config.iterations_done, thermal_ratio,
                              reweight_goal === nothing ? Ptr{Float64}(C_NULL) : pointer(goal)))
-    res = ResultC(niter, nobs, pointer(im), pointer(ie), pointer(m), pointer(s), pointer(c2), 0, 0.0, Ptr{Float64}(C_NULL))
+    res = ResultC(niter, nobs, pointer(im), pointer(ie), pointer(m), pointer(s), pointer(c2), 0, 0.0, Ptr{Float64}(C_NULL), 0)
     GC.@preserve im ie m s c2 goal check(ccall((:mci_integrate, libmci), Cint, (Ptr{Cvoid}, Ptr{IntegrateArgs}, Ref{ResultC}), prob, args, res))
     config.iterations_done += niter
     nworker = _comm[].size

@@ -31,19 +31,43 @@ def average(iter_mean, iter_std, init=1, max=None):
     return a.value, b.value, c.value
 
 
+def lineage_sums(block_mean, iter_std, init=1, max=None):
+    """mci_lineage_sums: per observable, sum and sum of squares over the blocks of every block's weighted average over iterations
+    init..max (1-based, the weights of `average`); block_mean[niter][nblocks][nobs], iter_std[niter][nobs]"""
+    bm = np.ascontiguousarray(block_mean, dtype=np.float64)
+    e = np.ascontiguousarray(iter_std, dtype=np.float64)
+    niter, nb, nobs = bm.shape
+    if max is None:
+        max = niter
+    s1, s2 = np.zeros(nobs), np.zeros(nobs)
+    lib().mci_lineage_sums(_dp(bm), niter, nb, nobs, _dp(e), int(init), int(max), _dp(s1), _dp(s2))
+    return s1, s2
+
+
 class Result:
     """statistics.jl:16-63.  mean/stdev/chi2 are lists with one entry per integrand: a float for scalar
-    observables, an ndarray for array observables (like `obs=[zeros(4)]`)."""
+    observables, an ndarray for array observables (like `obs=[zeros(4)]`).
+    `block_mean` ([niter][local blocks][nobs]) with `correlated=True`: the iterations continued each other's chains (carried chains of
+    the many-chain decomposition), so the error is the scatter of the blocks' weighted averages over the run (mci_lineage_sums) instead of
+    statistics.jl:198, which assumes independent iterations; `sum_ranks` adds the lineage sums of the other ranks' blocks."""
 
-    def __init__(self, iter_mean, iter_std, config, ignore, neval=0, seconds=0.0):
+    def __init__(self, iter_mean, iter_std, config, ignore, neval=0, seconds=0.0, block_mean=None, correlated=False, block=None,
+                 sum_ranks=None):
         self.iter_mean = np.asarray(iter_mean)   # [niter, nobs]
         self.iter_std = np.asarray(iter_std)
         self.config, self.ignore, self.neval, self.seconds = config, int(ignore), int(neval), seconds
+        self.block_mean, self.correlated, self.block, self._sum_ranks = block_mean, bool(correlated), block, sum_ranks
         niter, nobs = self.iter_mean.shape
         flat = [average(self.iter_mean[:, o], self.iter_std[:, o], init=ignore + 1, max=niter) for o in range(nobs)]
         self._flat_mean = np.array([f[0] for f in flat])
         self._flat_std = np.array([f[1] for f in flat])
         self._flat_chi2 = np.array([f[2] for f in flat])
+        if self.correlated and block_mean is not None and niter > ignore + 1:
+            s1, s2 = lineage_sums(block_mean, self.iter_std, init=ignore + 1, max=niter)
+            if sum_ranks is not None:
+                tot = sum_ranks(np.concatenate([s1, s2]))
+                s1, s2 = tot[:nobs], tot[nobs:]
+            self._flat_std = mean_std(s1, s2, block if block else np.asarray(block_mean).shape[1])[1]
         self.mean, self.stdev, self.chi2 = self._shape(self._flat_mean), self._shape(self._flat_std), self._shape(self._flat_chi2)
         self.iterations = [(self._shape(self.iter_mean[i]), self._shape(self.iter_std[i]), config) for i in range(niter)]
 
@@ -62,7 +86,8 @@ class Result:
 
     def with_ignore(self, ignore):
         """Result(res, ignore) (statistics.jl:56-62)"""
-        return self if ignore == self.ignore else Result(self.iter_mean, self.iter_std, self.config, ignore, self.neval, self.seconds)
+        return self if ignore == self.ignore else Result(self.iter_mean, self.iter_std, self.config, ignore, self.neval, self.seconds,
+                                                         self.block_mean, self.correlated, self.block, self._sum_ranks)
 
     @property
     def dof(self):

@@ -120,12 +120,13 @@ void mcio_smooth(const double *dist, long n, double factor, double *out) {
         out[i] = (dist[i - 1] + dist[i] * factor + dist[i + 1]) / (factor + 2);
 }
 
-/* ref: common.jl:67-82.  Output is NOT renormalised (:81-82).  Returns 1/2 where the
- * reference's @assert (:71 / :79) fires.  sum() is mcio_sum16 (below). */
 /* Julia's sum() over a Vector{Float64} shorter than pairwise_blocksize = 1024 (Base.mapreduce_impl, base/reduce.jl) is an
  * `@simd` loop: LLVM vectorises the reduction, so its association is the host CPU's (vector lanes x interleave), not left to
- * right -- the reference has no single order.  The oracle (and the device) fix the AVX2 shape: 16 interleaved partial sums
- * (element i -> partial i mod 16, each left to right), folded p[l] += p[l + h] for h = 8, 4, 2, 1.
+ * right -- the reference has no single order.  The oracle (and the device) fix ONE association of that family: 16 interleaved
+ * partial sums (element i -> partial i mod 16, each left to right), folded p[l] += p[l + h] for h = 8, 4, 2, 1 -- the lanes x
+ * interleave of an AVX2 build.  It is not any particular Julia binary's order to the last bit: Base._mapreduce sums vectors of fewer
+ * than 16 elements left to right, and mapreduce_impl adds the first two elements before its @simd loop starts at the third (with a
+ * scalar tail behind the vector body); differences are in the last bit of a sum of ~1000 positive terms, below every tolerance here.
  * Used where the reference sums a histogram-length vector: rescale (common.jl:72) and f_ninc (variable.jl:226).
  * From 1025 elements on mapreduce_impl first splits the range at its midpoint, imid = ifirst + (ilast - ifirst) >> 1, sums the two
  * halves the same way and adds the two results (base/reduce.jl mapreduce_impl, pairwise_blocksize = 1024): mcio_sum_julia below, and
@@ -156,6 +157,8 @@ double mcio_sum_julia(const double *v, long n) {
     return mcio_sum_julia(v, h) + mcio_sum_julia(v + h, n - h);
 }
 
+/* ref: common.jl:67-82.  Output is NOT renormalised (:81-82).  Returns 1/2 where the
+ * reference's @assert (:71 / :79) fires.  sum() is mcio_sum_julia (above). */
 int mcio_rescale(double *dist, long n, double alpha) {
     if (n == 1) return 0; /* :68-70 */
     for (long i = 0; i < n; ++i)

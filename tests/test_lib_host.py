@@ -150,17 +150,73 @@ def test_plain_c_consumer_of_the_abi_builds_and_refuses_to_run_without_a_gpu():
 
 
 def test_mcmc_auto_chain_length_rule():
-    """mci_mcmc_auto_chains: >= 131072 measured steps per chain until a launch has been measured, afterwards
-    max(16 x longest holding time, 8 burn-in floors), at most 131072 chains per GPU, at least one chain."""
+    """mci_mcmc_auto_chains: pilot-length chains (4096 steps or 8 burn-in floors) until a launch has been measured; afterwards
+    16 x (fresh) / 8 x (carried) the longest holding time of the launch before, at most 4 x the chain length that measured it (a hold
+    longer than a quarter of that chain is censored by it), never fewer than 8 / 2 burn-in floors; at most 131072 chains per GPU, at
+    least one chain."""
     from mcintegration_jl_amd._lib import lib
     L = lib()
     npb, nblocks, nslots, nd, npool = 6250000, 16, 12, 5, 1
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 0) == npb // 131072
     fl = 64 * nslots + 16 * (npool + 1) * nd
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 256) == npb // max(16 * 256, 8 * fl)      # light tails: the floor decides
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384) == npb // (16 * 16384)             # heavy tails: the holds decide
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 1 << 30) == 1
-    assert L.mci_mcmc_auto_chains(10**9, 16, 1, 2, 1, 2) == 131072 // 16                                     # GPU-fill cap
+    assert fl == 928
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 0, 0, 0) == npb // (8 * fl)                # nothing measured: 8 floors > 4096
+    assert L.mci_mcmc_auto_chains(npb, nblocks, 2, 2, 1, 0, 0, 0) == npb // 4096                              # ... 4096 steps > 8 floors
+    big = 1 << 40   # (a measuring chain long enough not to matter)
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 256, big, 0) == npb // max(16 * 256, 8 * fl)    # light tails: the floor decides
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384, big, 0) == npb // (16 * 16384)           # heavy tails: the holds decide
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384, big, 1) == npb // (8 * 16384)            # carried chains: 8 x
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 64, big, 1) == npb // (2 * fl)                  # ... and two floors
+    # censored: the launch before ran 4096-step chains and saw holds up to 8192 (its top bucket's upper edge) -> 4 x 4096, not 8 x 8192
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 8192, 4096, 1) == npb // (4 * 4096)
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 8192, 4096, 0) == npb // (4 * 4096)
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 512, 16384, 1) == npb // (8 * 512)             # holds that fit: the length comes down at once
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 1 << 30, big, 0) == 1
+    assert L.mci_mcmc_auto_chains(10**9, 16, 1, 2, 1, 2, big, 0) == 131072 // 16                                   # GPU-fill cap
+
+
+def test_lineage_sums_are_the_scatter_of_the_blocks_weighted_averages():
+    """mci_lineage_sums (the error of a run whose iterations continued each other's chains): per observable the sum and the sum of
+    squares over the blocks of every block's weighted average over the iterations, with the weights of `average` (statistics.jl:197,
+    :217) -- through _mean_std (main.jl:296-320) they give the same mean as `average` and the lineages' scatter as its error."""
+    from mcintegration_jl_amd.statistics import lineage_sums, mean_std
+    rng = np.random.default_rng(5)
+    niter, nb, nobs = 7, 64, 3
+    # AR(1) lineages: consecutive iterations of a block correlate (rho = 0.85), blocks are independent
+    bm = np.zeros((niter, nb, nobs))
+    bm[0] = rng.normal(size=(nb, nobs))
+    for i in range(1, niter):
+        bm[i] = 0.85 * bm[i - 1] + np.sqrt(1 - 0.85 ** 2) * rng.normal(size=(nb, nobs))
+    bm += 5.0
+    im = bm.mean(1)
+    ie = bm.std(1, ddof=1) / np.sqrt(nb)
+    for init in (1, 2, 4):
+        s1, s2 = lineage_sums(bm, ie, init=init, max=niter)
+        w = 1.0 / (ie[init - 1:] + 1e-10) ** 2
+        w /= w.sum(0)
+        mb = (bm[init - 1:] * w[:, None, :]).sum(0)            # [nb][nobs]
+        np.testing.assert_allclose(s1, mb.sum(0), rtol=1e-13)
+        np.testing.assert_allclose(s2, (mb ** 2).sum(0), rtol=1e-13)
+        m, e = mean_std(s1, s2, nb)
+        for o in range(nobs):
+            assert m[o] == pytest.approx(mci.average(im[:, o], ie[:, o], init=init, max=niter)[0], rel=1e-12)
+        np.testing.assert_allclose(e, mb.std(0, ddof=1) / np.sqrt(nb), rtol=1e-10)
+    # a Result built from them: the reference's mean and chi2, the lineage error; Result(res, ignore) recomputes both
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1], [1], [1]])
+    res = mci.Result(im, ie, cfg, ignore=1, block_mean=bm, correlated=True, block=nb)
+    plain = mci.Result(im, ie, cfg, ignore=1)
+    assert res.mean == plain.mean and res.chi2 == plain.chi2
+    s1, s2 = lineage_sums(bm, ie, init=2, max=niter)
+    np.testing.assert_allclose(res.stdev, mean_std(s1, s2, nb)[1], rtol=1e-14)
+    assert all(a > b for a, b in zip(res.stdev, plain.stdev))      # positively correlated iterations: the reference's formula is too small
+    r3 = res.with_ignore(3)
+    s1, s2 = lineage_sums(bm, ie, init=4, max=niter)
+    np.testing.assert_allclose(r3.stdev, mean_std(s1, s2, nb)[1], rtol=1e-14)
+    # two "ranks" with half of the blocks each: the sums add
+    tot = []
+    for half in (bm[:, :nb // 2], bm[:, nb // 2:]):
+        tot.append(np.concatenate(lineage_sums(half, ie, init=2, max=niter)))
+    split = mci.Result(im, ie, cfg, ignore=1, block_mean=bm[:, :nb // 2], correlated=True, block=nb, sum_ranks=lambda v: tot[0] + tot[1])
+    np.testing.assert_allclose(split.stdev, res.stdev, rtol=1e-12)
 
 
 def test_closure_form_is_decided_by_parameters_without_defaults():

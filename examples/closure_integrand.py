@@ -15,7 +15,7 @@ import mcintegration_jl_amd as mci
 f = lambda x, c: np.exp(-np.sum(x * x, axis=0) / 2) / (2 * np.pi) ** 1.5
 body = "return exp(-(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) / 2) / 15.749609945722419;"
 print(mci.trace_integrand(f, mci.Configuration(var=mci.Continuous(-5.0, 5.0), dof=[[3]])).body)
-for name, integrand, kw in (("traced closure", f, dict(trace=True)), ("host closure", f, {}), ("device source", body, {})):
+for name, integrand, kw in (("traced closure", f, {}), ("host closure", f, dict(trace=False)), ("device source", body, {})):   # (tracing is the default)
     t0 = time.time()
     r = mci.integrate(integrand, var=mci.Continuous(-5.0, 5.0), dof=[[3]], solver="vegas", neval=1e6, niter=10, seed=1, print=-1, **kw)
     print("%-15s %.6f +- %.1e   %.2f s" % (name, r.mean[0], r.stdev[0], time.time() - t0))

@@ -109,6 +109,8 @@ typedef struct {
     int32_t correlated; /* out: 1 = the iterations of this call continued each other's chains (mci_set_chain_carry), so `stdev` is the
                            block-lineage error (mci_lineage_sums) instead of statistics.jl:198, which assumes independent iterations;
                            `mean` and `chi2` are the reference's either way */
+    int32_t warmup;     /* out: launches of this call that were run again instead of being counted (automatic :mcmc chain lengths:
+                           their chains were too short for the holding times they measured, mci_mcmc_launch_valid) */
 } mci_result;
 
 /* ---- context: HIP device + stream (+ RCCL communicator); replaces MPI.Init, main.jl:113-114 ---- */
@@ -227,6 +229,15 @@ int mci_integrate(mci_problem *prob, const mci_integrate_args *args, mci_result 
  * 2^(top occupied b) of the launch before it (mci_mcmc_auto_chains): the host waits for that launch's sample kernel -- not for its
  * merge and train! -- before it sizes the next one; a fixed lag, so a run stays reproducible. */
 int mci_get_hold_histogram(mci_problem *prob, uint64_t *out64);
+/* Was the last automatic :mcmc launch long enough for the holding times it measured itself (chain length >= 16 x the longest hold, 8 x
+ * for carried chains)?  Waits for that launch's sample kernel.  *warm: some launch of this problem has been.  Until then the chain
+ * lengths escalate and mci_integrate runs an iteration again instead of counting it (mci_result.warmup); a caller that drives
+ * mci_iteration_run itself does the same with this call (run the iteration again as iteration + 16384 * attempt: the chains go on,
+ * the Philox streams are new).  After the first valid launch nothing is repeated: no selection on what an iteration measured. */
+int mci_mcmc_launch_valid(mci_problem *prob, int32_t *valid, int32_t *warm, int64_t *chain_len, int64_t *hold_max);
+/* take the last finished iteration out of the iteration log and the block log again (it stays in the map, the reweight factors and the
+ * carried chains): what a warm-up launch that is run again amounts to */
+int mci_iteration_discard(mci_problem *prob);
 /* the statistics head [obsSum|obsSqSum|normalization|neval|visited] of the last `nrows` finished
  * iterations (oldest first), nstat = 2*nobs+2+N+1 doubles per row: the per-iteration history that
  * `Result.iterations` is built from (statistics.jl:24-33), kept on the device until asked for */
@@ -355,10 +366,10 @@ double mci_chain_burnin(int64_t steps, int64_t nchain, int32_t nslots);
 int64_t mci_mcmc_burnin(int64_t steps, int64_t nchain, int32_t nslots, int32_t nd, int32_t npool, double thermal_ratio);
 /* chains per block of an :mcmc launch with nchain = 0 ("automatic"; the reference has no counterpart: it runs one chain
  * per block).  hold_max = the longest holding time the launch before measured (mci_get_hold_histogram), hold_len = the chain length
- * (measured steps) of that launch, carried = the launch continues that launch's chains.  hold_max = 0 (nothing measured yet): chains of
- * 4096 steps or 8 burn-in floors; otherwise 16*hold_max (fresh) / 8*hold_max (carried) but at most 4*hold_len -- a hold longer than a
- * quarter of the chain that measured it is censored by that chain, so the length escalates from launch to launch until the holds fit --
- * and never fewer than 8 / 2 burn-in floors; capped so that one GPU gets at most 131072 chains */
+ * (measured steps) of that launch (0: no growth cap), carried = the launch continues that launch's chains.  hold_max = 0 (nothing
+ * measured yet): chains of 4096 steps or 2 burn-in floors; otherwise 16*hold_max (fresh) / 8*hold_max (carried) but at most 2*hold_len
+ * -- a hold longer than an eighth of the chain that measured it is censored by that chain, so the length escalates from launch to
+ * launch until the holds fit -- and never fewer than 8 / 2 burn-in floors; capped so that one GPU gets at most 131072 chains */
 int64_t mci_mcmc_auto_chains(int64_t nevalperblock, int64_t nblocks, int32_t nslots, int32_t nd, int32_t npool,
                              int64_t hold_max, int64_t hold_len, int32_t carried);
 void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out);        /* configuration.jl:229-236 */

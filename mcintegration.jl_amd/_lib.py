@@ -50,7 +50,7 @@ HOST_MEASURE_IDX_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int32), c_double_p, c_d
 class ResultC(C.Structure):
     _fields_ = [("niter", C.c_int32), ("nobs", C.c_int32), ("iter_mean", c_double_p), ("iter_std", c_double_p),
                 ("mean", c_double_p), ("stdev", c_double_p), ("chi2", c_double_p), ("neval", C.c_int64),
-                ("seconds", C.c_double), ("visited", c_double_p), ("correlated", C.c_int32)]
+                ("seconds", C.c_double), ("visited", c_double_p), ("correlated", C.c_int32), ("warmup", C.c_int32)]
 
 
 # every symbol include/mci.h declares: (name, restype, argtypes); DEBUG_SIGNATURES: the test hooks of csrc/mci_debug.h
@@ -117,6 +117,8 @@ SIGNATURES = [
     ("mci_mcmc_burnin", C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
     ("mci_mcmc_auto_chains", C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32]),
     ("mci_get_hold_histogram", C.c_int, [_VP, C.POINTER(C.c_uint64)]),
+    ("mci_mcmc_launch_valid", C.c_int, [_VP, c_int32_p, c_int32_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("mci_iteration_discard", C.c_int, [_VP]),
     ("mci_get_block_means", C.c_int, [_VP, C.c_int32, c_double_p, C.POINTER(C.c_int64), c_int32_p]),
     ("mci_reset_block_log", C.c_int, [_VP]),
     ("mci_lineage_sums", None, [c_double_p, C.c_int64, C.c_int64, C.c_int64, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p]),

@@ -221,6 +221,14 @@ struct mci_problem {
     int64_t hold_launches = 0;              // :mcmc launches that recorded a histogram
     int64_t hold_len = 0;                   // measured steps per chain of the launch `hold_max` comes from
     int64_t hold_len_inflight = 0;          // ... of the launch whose histogram is in flight
+    bool hold_carried_inflight = false;     // that launch continued the chains of the one before (8 x its holds instead of 16 x)
+    // Warm-up of the automatic :mcmc chain length: until a launch has run chains long enough for the holds IT measured
+    // (mcmc_launch_valid), lengths escalate and mci_integrate repeats an iteration instead of counting it; afterwards a launch is
+    // sized from the larger of the last two launches' holds (the longest hold of a launch is an extreme value: it moves by a bucket
+    // from launch to launch) and nothing is ever repeated or left out again (no selection on what an iteration measured)
+    bool mcmc_warm = false;
+    bool hold_valid = false;                // the launch `hold_max` comes from was long enough for its own holds
+    int64_t hold_prev = 0;                  // hold_max of the launch before that, once warm
     // per-block means of the chain solvers' iterations (MergeArgs::block_means): rows [blk_rows][blk_stride = local blocks * nobs];
     // what the block-lineage error of a run of carried chains is computed from (mci_lineage_sums)
     double *d_blocklog = nullptr;
@@ -275,12 +283,16 @@ struct mci_problem {
     static int64_t kMcmcPilotSteps, kMcmcGrow;
 };
 
+// A repeated iteration (the warm-up of automatic :mcmc chain lengths, mci_integrate) draws from the Philox streams of iteration
+// i + kRepeatStride * attempt: the iteration index has 17 bits (DESIGN.md "RNG streams"), runs of fewer than 16384 iterations leave the upper ones free
+static const int kRepeatStride = 16384, kMaxRepeats = 7;
+
 static int64_t env_i64(const char *name, int64_t dflt) {
     const char *e = getenv(name);
     return e && *e ? atoll(e) : dflt;
 }
 int64_t mci_problem::kMcmcPilotSteps = env_i64("MCI_MCMC_PILOT", 4096);
-int64_t mci_problem::kMcmcGrow = env_i64("MCI_MCMC_GROW", 4);
+int64_t mci_problem::kMcmcGrow = env_i64("MCI_MCMC_GROW", 2);
 
 static void persist_job_drop(mci_problem *p);
 namespace { void persist_orphans_join(); }
@@ -360,7 +372,7 @@ int persist_recover(mci_problem *p) {
 }
 
 // :mcmc holding-time histogram of the launch just queued -> (sum over the ranks ->) pinned host memory, behind the launch on the stream
-int hold_publish(mci_problem *p, int64_t chain_len) {
+int hold_publish(mci_problem *p, int64_t chain_len, bool carried) {
     hipStream_t st = p->ctx->stream;
     if (!p->h_hold) {
         HIPCHK(hipHostMalloc((void **)&p->h_hold, 64 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -375,14 +387,15 @@ int hold_publish(mci_problem *p, int64_t chain_len) {
     HIPCHK(hipEventRecord(p->hold_ev, st));
     p->hold_inflight = true;
     p->hold_len_inflight = chain_len;
+    p->hold_carried_inflight = carried;
     p->hold_launches += 1;
     return MCI_OK;
 }
 
 // before an :mcmc launch with an automatic chain count is sized: take in the histogram of the launch before it.  The host waits for
 // that launch's sample kernel here (its merge and train! are still running or queued: the next launch is queued behind them while they
-// run); what it costs is measured in tools/latency.py, what the two-launch lag of the rounds before cost in profiles/r03_c5_kernel_stats.txt
-// (two more launches sized from the untrained map's holding times: 324 ms of a cold BASELINE configs[4] call).
+// run); what the two-launch lag of the rounds before cost is in profiles/r03_c5_kernel_stats.txt (two more launches sized from the
+// untrained map's holding times: 324 ms of a cold BASELINE configs[4] call).
 int hold_consume(mci_problem *p) {
     if (!p->hold_inflight) return MCI_OK;
     HIPCHK(hipEventSynchronize(p->hold_ev));
@@ -391,8 +404,12 @@ int hold_consume(mci_problem *p) {
     for (int b = 0; b < 64; ++b)
         if (p->h_hold[b]) top = b;
     if (top >= 0) {
+        p->hold_prev = p->mcmc_warm ? p->hold_max : 0;
         p->hold_max = (int64_t)1 << top; // bucket b holds bit_width(h) == b, i.e. h < 2^b
         p->hold_len = p->hold_len_inflight;
+        // was that launch long enough for what it measured itself?  (the rule its successor is sized by, mci_mcmc_auto_chains)
+        p->hold_valid = p->hold_len >= (p->hold_carried_inflight ? 8 : 16) * p->hold_max;
+        if (p->hold_valid) p->mcmc_warm = true;
     }
     return MCI_OK;
 }
@@ -1484,7 +1501,9 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     // the new factors say "fewer": 2 sigma per run low on the 12-D member of BASELINE configs[4], profiles/r03_chain_carry.txt.)
     const bool carry_on = p->chain_carry != 0;
     const bool may_carry = solver != MCI_VEGAS && carry_on && p->chain_valid && p->chain_solver == solver &&
-                           p->chain_lo == block_lo && p->chain_hi == block_hi && p->chain_iteration + 1 == iteration && p->chain_nchain > 1;
+                           p->chain_lo == block_lo && p->chain_hi == block_hi && p->chain_nchain > 1 &&
+                           ((p->chain_iteration & (kRepeatStride - 1)) + 1 == (iteration & (kRepeatStride - 1)) ||                        // the next iteration
+                            ((p->chain_iteration & (kRepeatStride - 1)) == (iteration & (kRepeatStride - 1)) && iteration > p->chain_iteration)); // ... or the same one again (mci_integrate, warm-up)
     if (solver == MCI_VEGASMC) {
         int nslots = 0; // (pool, slot) pairs changeVariable can pick (updates.jl:50,:58)
         for (int v = 0; v < p->npool; ++v) nslots += p->maxdof[v];
@@ -1525,7 +1544,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // measured, runs pilot-length chains, and a launch's chains are at most kMcmcGrow times as long as those that measured the
             // holds (mci_mcmc_auto_chains).
             if ((rc = hold_consume(p))) return rc;
-            nchain = mci_mcmc_auto_chains(nevalperblock, nblocks, nslots, p->ni + 1, p->npool, p->hold_max, p->hold_len, may_carry ? 1 : 0);
+            // (once warm: the larger of the last two launches' holds, and no growth cap -- both were measured by chains that held them)
+            const int64_t hold_eff = p->mcmc_warm && p->hold_prev > p->hold_max ? p->hold_prev : p->hold_max;
+            nchain = mci_mcmc_auto_chains(nevalperblock, nblocks, nslots, p->ni + 1, p->npool, hold_eff, p->mcmc_warm && p->hold_valid ? 0 : p->hold_len,
+                                          may_carry ? 1 : 0);
         }
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
         // (carried chains keep the reference's own floor(steps * thermal_ratio) only, mcmc/montecarlo.jl:133)
@@ -1896,7 +1918,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         }
     } else
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
-    if (a.hold_hist && (rc = hold_publish(p, nevalperblock / nchain))) return rc;
+    if (a.hold_hist && (rc = hold_publish(p, nevalperblock / nchain, solver != MCI_VEGAS && p->last_carried))) return rc;
     if (split)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles[kern == kSlotVegasAny ? 1 : 0], (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
@@ -2498,15 +2520,32 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     auto t0 = std::chrono::steady_clock::now();
     double *h = p->h_log;
     int *hstatus = reinterpret_cast<int *>(p->h_log + nlog);
+    int res_warmup = 0;
     for (int attempt = 0;; ++attempt) {
         p->last_persistent = persist;
         if (persist && (rc = persist_launch(p, a, nevalperblock, lo, hi, wpb_persist))) return rc;
         // (a hipGraph replay of this chain was measured and dropped: 37.6 against 34.8 us per launch-bound iteration for the eager
         // asynchronous launches on ROCm 7.0 / MI355X, profiles/r02_ablation.txt)
         for (int it = 0; it < a->niter && !persist; ++it) { // main.jl:142
-            if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, a->first_iteration + it, a->seed, a->measurefreq, a->nchain, a->thermal_ratio))) return rc;
-            if ((rc = mci_iteration_reduce(p))) return rc;                                   // main.jl:177-188
-            if ((rc = mci_iteration_finish(p, a->solver, block, a->adapt, a->gamma, nullptr, nullptr))) return rc; // main.jl:183-199
+            for (int attempt = 0;; ++attempt) {
+                const int32_t iter = a->first_iteration + it + kRepeatStride * attempt;
+                if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, iter, a->seed, a->measurefreq, a->nchain, a->thermal_ratio))) return rc;
+                if ((rc = mci_iteration_reduce(p))) return rc;                                   // main.jl:177-188
+                if ((rc = mci_iteration_finish(p, a->solver, block, a->adapt, a->gamma, nullptr, nullptr))) return rc; // main.jl:183-199
+                // Warm-up of the automatic :mcmc chain length (mci_mcmc_auto_chains): an iteration whose chains turned out too short for
+                // the holding times they measured is not counted -- it has trained the map and moved the reweight factors, its chains
+                // go on -- and runs again with longer chains (the Philox streams of iteration + kRepeatStride * attempt), until the
+                // first launch that is long enough; from then on nothing is repeated.  The first iteration of a call that ignores it
+                // anyway (main.jl:82) is let through as it is.
+                if (a->solver != MCI_MCMC || a->nchain > 0 || p->mcmc_warm || (it == 0 && ignore >= 1) || attempt >= kMaxRepeats ||
+                    a->first_iteration + it >= kRepeatStride || p->last_nchain <= 1 || !p->hold_inflight)
+                    break;
+                int32_t valid = 0;
+                if ((rc = mci_mcmc_launch_valid(p, &valid, nullptr, nullptr, nullptr))) return rc;
+                if (valid) break;
+                if ((rc = mci_iteration_discard(p))) return rc; // (the repeat overwrites this attempt's rows of the iteration log and of the block log)
+                res_warmup += 1;
+            }
         }
         // the statistics of all iterations and the status word come back behind the last kernel in ONE synchronisation, into pinned memory (a
         // pageable destination goes through a staging copy: ~15 us of a 0.2 ms default-size call)
@@ -2542,6 +2581,7 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     // chains descend from that block's chains only), so the error comes from the scatter of the blocks' weighted averages over the run
     // (mci_lineage_sums + the reference's own _mean_std over them); same weights, same mean.
     res->correlated = 0;
+    res->warmup = res_warmup;
     if (a->solver != MCI_VEGAS && blk_row0 >= 0 && p->blk_rows - blk_row0 == a->niter && p->blk_carried > 0 && a->niter > ignore + 1) {
         const int64_t nb = hi - lo;
         std::vector<double> bm((size_t)a->niter * nb * s.nobs), sums(2 * (size_t)s.nobs);
@@ -2876,21 +2916,25 @@ int64_t mci_mcmc_burnin(int64_t steps, int64_t nchain, int32_t nslots, int32_t n
 int64_t mci_mcmc_auto_chains(int64_t nevalperblock, int64_t nblocks, int32_t nslots, int32_t nd, int32_t npool, int64_t hold_max,
                              int64_t hold_len, int32_t carried) {
     // Chain length (measured steps) of an automatic :mcmc launch.  hold_max = the longest time any chain's slot (or integrand index)
-    // went without changing in the launch before (upper edge of the top occupied bucket), hold_len = the chain length of that launch.
-    //   nothing measured (hold_max = 0): pilot-length chains, kMcmcPilotSteps or 8 burn-in floors -- the first iteration trains the map
+    // went without changing in the launch before (upper edge of the top occupied bucket), hold_len = the chain length of that launch
+    // (0: no growth cap -- the holds were measured by chains that were long enough for them).
+    //   nothing measured (hold_max = 0): pilot-length chains, kMcmcPilotSteps or 2 burn-in floors -- the first iteration trains the map
     //     and is ignored by default (main.jl:82); its holds are those of the UNTRAINED map, up to 2^13 steps on BASELINE configs[4]
-    //     where the trained map holds for 2^9: chains sized for them (131072 steps in the rounds before) cost 0.74 s of a cold call
+    //     where the trained map holds for 2^8: chains sized for them (131072 steps in the rounds before) cost 0.74 s of a cold call
     //   fresh chains: 16 x hold_max, never fewer than 8 burn-in floors.  Calibration (profiles/r01_chain_bias.txt): on the bubble
     //     diagram chains of 1-2 x that holding time are ~1e-3 off, chains of 8 x are unbiased at the 5e-4 level of the measurement
     //   carried chains (stationary starts): 8 x hold_max, never fewer than 2 floors (profiles/r03_chain_carry.txt)
-    //   at most kMcmcGrow x hold_len: a hold longer than a quarter of the chain that measured it is censored by that chain's
+    //   at most kMcmcGrow x hold_len: a hold longer than an eighth of the chain that measured it is censored by that chain's
     //     length -- what it says is "longer", not how long -- so the length escalates by that factor per launch until the
-    //     measured holds fit (heavy-tailed integrands: 2^14..2^15 steps on the bubble diagram) instead of jumping to 8-16 x a
-    //     number the untrained map inflated
+    //     measured holds fit (heavy-tailed integrands: 2^14..2^15 steps on the bubble diagram and on 1/(1 - cos^3)) instead of
+    //     jumping to 8-16 x a number the untrained map inflated.  The launches on the way are warm-up: mci_integrate repeats them
+    //     (mci_mcmc_launch_valid) -- together they cost less than the first launch that is long enough, a geometric series
     const int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(npool + 1) * nd;
-    const int64_t floor_len = (carried ? 2 : 8) * fl;
-    int64_t len = mci_problem::kMcmcPilotSteps;
-    if (hold_max > 0) {
+    int64_t len, floor_len = (carried ? 2 : 8) * fl;
+    if (hold_max <= 0) {
+        len = mci_problem::kMcmcPilotSteps;
+        floor_len = 2 * fl;
+    } else {
         len = (carried ? 8 : 16) * hold_max;
         if (hold_len > 0 && len > mci_problem::kMcmcGrow * hold_len) len = mci_problem::kMcmcGrow * hold_len;
     }
@@ -2930,6 +2974,30 @@ int mci_reset_block_log(mci_problem *p) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     p->blk_rows = 0;
     p->blk_carried = 0;
+    return MCI_OK;
+}
+
+int mci_mcmc_launch_valid(mci_problem *p, int32_t *valid, int32_t *warm, int64_t *chain_len, int64_t *hold_max) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    int rc = hold_consume(p); // (waits for the last :mcmc launch's sample kernel if its histogram is still in flight)
+    if (rc) return rc;
+    if (valid) *valid = p->hold_valid ? 1 : 0;
+    if (warm) *warm = p->mcmc_warm ? 1 : 0;
+    if (chain_len) *chain_len = p->hold_len;
+    if (hold_max) *hold_max = p->hold_max;
+    return MCI_OK;
+}
+
+int mci_iteration_discard(mci_problem *p) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (p->log_row < 1) return fail(MCI_ERR_INVALID, "no finished iteration to discard");
+    p->log_row -= 1;
+    if (p->blk_rows > 0) {
+        p->blk_rows -= 1;
+        p->blk_carried -= (p->last_carried && p->blk_carried > 0) ? 1 : 0;
+    }
     return MCI_OK;
 }
 

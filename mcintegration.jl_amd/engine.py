@@ -457,13 +457,24 @@ class Engine:
         im, ie = np.zeros((niter, n)), np.zeros((niter, n))
         m, s, c2 = np.zeros(n), np.zeros(n), np.zeros(n)
         vis = np.zeros(self.config.N + 1)
-        r = _lib.ResultC(niter, n, _dp(im), _dp(ie), _dp(m), _dp(s), _dp(c2), 0, 0.0, _dp(vis), 0)
+        r = _lib.ResultC(niter, n, _dp(im), _dp(ie), _dp(m), _dp(s), _dp(c2), 0, 0.0, _dp(vis), 0, 0)
         check(lib().mci_integrate(self.p, C.byref(a), C.byref(r)))
         out = dict(mean=m, stdev=s, chi2=c2, iter_mean=im, iter_std=ie, neval=r.neval, seconds=r.seconds, visited=vis,
-                   correlated=bool(r.correlated), block_mean=None)
+                   correlated=bool(r.correlated), block_mean=None, warmup=int(r.warmup))
         if _lib.SOLVERS[solver] != _lib.VEGAS:
             out["block_mean"] = self.block_means(niter)[0]
         return out
+
+    def mcmc_launch_valid(self):
+        """(the last automatic :mcmc launch was long enough for the holds it measured, some launch of this problem has been, its chain
+        length, its longest hold); waits for that launch's sample kernel -- see mci_mcmc_launch_valid"""
+        v, w, ln, h = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+        check(lib().mci_mcmc_launch_valid(self.p, C.byref(v), C.byref(w), C.byref(ln), C.byref(h)))
+        return bool(v.value), bool(w.value), int(ln.value), int(h.value)
+
+    def discard_iteration(self):
+        """the last finished iteration out of the iteration log and the block log again (a warm-up launch that is run again)"""
+        check(lib().mci_iteration_discard(self.p))
 
     def block_means(self, rows):
         """chain solvers: (block means [rows][local blocks][nobs] of the last `rows` iterations, how many of the logged iterations

@@ -34,18 +34,35 @@ def required_positionals(fn, fallback):
         return fallback
 
 
+TRACE_DEFAULT = None   # what integrate(trace=None) means: None = trace Python closures where possible, silently; False = host callbacks
+
+
+def _not_traced(what, err, trace, verbosity):
+    """a closure that could not be written out as device source keeps the host callback path; say why when it was asked for"""
+    msg = "%s not traced (%s): host callback path" % (what, err)
+    if trace:
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+    elif verbosity > 0:
+        import builtins
+        builtins.print(msg)
+
+
 def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, block=16, verbose=-1, gamma=1.0,
               adapt=True, debug=False, reweight_goal=None, ignore=None, measure=None, measurefreq=1,
               thermal_ratio=0.1, inplace=False, parallel="nothread", print=-1, printio=None, timer=None,
-              comm=None, device=None, nchain=0, engine_factory=None, rng_bits=52, rng_rounds=10, deterministic=False, trace=False, **kwargs):
+              comm=None, device=None, nchain=0, engine_factory=None, rng_bits=52, rng_rounds=10, deterministic=False, trace=None, **kwargs):
     """Same keywords as the reference (main.jl:71-90; unknown ones go to Configuration, :95-97).
     Extra, engine-specific keywords: `comm` (LocalComm | RcclComm | TorchDistComm), `device`, `nchain`
     (vegasmc chains per block; 0 = auto), `rng_bits` (52 | 32: opt-in cheaper uniform stream of solver="vegas", see
     mci_set_rng_bits), `rng_rounds` (10 | 7: opt-in Philox4x32-7 for every stream, mci_set_rng_rounds), `deterministic` (bit-identical
-    results for a fixed seed like the reference's sequential loop, mci_set_deterministic), `trace` (a Python closure as integrand is
-    run once on symbolic draws and written out as device source -- trace.trace_integrand -- so that it runs inside the kernels like
-    Julia's inlined closure does in the reference's loop; closures that cannot be written out take the host callback path as without
-    it), `engine_factory` (test seam)."""
+    results for a fixed seed like the reference's sequential loop, mci_set_deterministic), `trace` (None, the default, and True: a
+    Python closure as integrand or measure is run once on symbolic draws and written out as device source -- trace.trace_integrand /
+    trace_measure -- so that it runs inside the kernels like Julia's inlined closure does in the reference's loop; a closure that
+    cannot be written out takes the host batch-callback path, silently with None, with a RuntimeWarning naming the reason with True;
+    False: always the host path), `engine_factory` (test seam)."""
+    if trace is None:
+        trace = TRACE_DEFAULT
     if solver in (":vegas", ":vegasmc", ":mcmc"):
         solver = solver[1:]
     if solver not in SOLVERS:
@@ -74,28 +91,24 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         # (parameters with a default do not count: `f(x, config, scale=2.0)` is the two-argument form; HostIntegrand(fn, indexed=...) says it explicitly)
         indexed = required_positionals(integrand, 2) >= 3
         traced = None
-        if trace:
+        if trace is None or trace:
             from .trace import TraceError, trace_integrand
             try:
                 traced = trace_integrand(integrand, config, indexed=indexed)
             except TraceError as e:
-                if print > 0:
-                    import builtins
-                    builtins.print("integrand not traced (%s): host callback path" % e)
+                _not_traced("integrand", e, trace, print)
         integrand = traced if traced is not None else HostIntegrand(integrand, indexed=indexed)
     if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
         # a Python closure as measure: host batch-callback path.  Five positional parameters = the reference's :mcmc form
         # measure(idx, var, obs, relative_weight, config) (mcmc/montecarlo.jl:166-169), four = measure(var, obs, weights, config)
         mindexed = required_positionals(measure, 4) >= 5
         tmeasure = None
-        if trace:
+        if trace is None or trace:
             from .trace import TraceError, trace_measure
             try:
                 tmeasure = trace_measure(measure, config, indexed=mindexed)
             except TraceError as e:
-                if print > 0:
-                    import builtins
-                    builtins.print("measure not traced (%s): host callback path" % e)
+                _not_traced("measure", e, trace, print)
         measure = tmeasure if tmeasure is not None else HostMeasure(measure, indexed=mindexed)
     mkey = None if measure is None else measure.body if isinstance(measure, (Measure, HostMeasure)) else (measure.pool, measure.slot, measure.leaf)
     key = (integrand.body, tuple(integrand.userdata), mkey, device,
@@ -131,6 +144,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     t0 = time.time()
     means, stds = [], []
     neval_done = 0
+    warmup = 0                             # launches run again instead of being counted (automatic :mcmc chain lengths)
     block_mean, correlated = None, False   # chain solvers: every block's mean of every iteration | the iterations continued each other's chains
     if type(comm) is LocalComm and engine_factory is None and hasattr(eng, "integrate") and getattr(eng, "comm_ranks", lambda: 0)() == 1:
         # one process: the whole loop runs inside the library (mci_integrate: the iterations are queued back to back on the
@@ -140,7 +154,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
                           measurefreq=measurefreq, seed=config.seed, nchain=nchain, first_iteration=config.iterations_done,
                           thermal_ratio=thermal_ratio, reweight_goal=reweight_goal)
         means, stds = list(r["iter_mean"]), list(r["iter_std"])
-        block_mean, correlated = r.get("block_mean"), r.get("correlated", False)
+        block_mean, correlated, warmup = r.get("block_mean"), r.get("correlated", False), r.get("warmup", 0)
         neval_done = nevalperblock * block * niter
         niter_loop = 0
         config.visited = r["visited"]    # config.visited of the last iteration (configuration.jl:46), for report(config)
@@ -149,10 +163,23 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         if s != VEGAS and hasattr(eng, "reset_block_log"):
             eng.reset_block_log()
     for it in range(niter_loop):                                                      # main.jl:142
-        eng.run(s, nevalperblock, lo, hi, config.iterations_done + it, config.seed, measurefreq, nchain, thermal_ratio)   # main.jl:152-166
-        comm.all_reduce(eng)                                                          # main.jl:177-188
-        fin_solver = s                                                                # doReweight! runs on the device (main.jl:183)
-        m, e = eng.finish(fin_solver, block, adapt, gamma)                            # main.jl:190-203
+        attempt = 0
+        while True:
+            eng.run(s, nevalperblock, lo, hi, config.iterations_done + it + 16384 * attempt, config.seed, measurefreq, nchain, thermal_ratio)   # main.jl:152-166
+            comm.all_reduce(eng)                                                      # main.jl:177-188
+            fin_solver = s                                                            # doReweight! runs on the device (main.jl:183)
+            m, e = eng.finish(fin_solver, block, adapt, gamma)                        # main.jl:190-203
+            # warm-up of the automatic :mcmc chain length, like mci_integrate: an iteration whose chains were too short for the holds
+            # they measured is run again (longer chains, new streams) instead of being counted, until the first one that is long enough
+            if (s != MCMC or nchain > 0 or not hasattr(eng, "mcmc_launch_valid") or (it == 0 and ignore >= 1) or attempt >= 7
+                    or config.iterations_done + it >= 16384 or eng.last_chain_launch()[0] <= 1):
+                break
+            valid, warm, _, _ = eng.mcmc_launch_valid()
+            if valid or warm:
+                break
+            eng.discard_iteration()
+            attempt += 1
+            warmup += 1
         means.append(m)
         stds.append(e)
         neval_done += nevalperblock * block
@@ -170,6 +197,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         correlated = ncarried > 0
     res = Result(np.array(means), np.array(stds), config, ignore, neval=neval_done, seconds=time.time() - t0, block_mean=block_mean,
                  correlated=correlated, block=block, sum_ranks=(lambda v: comm.sum_host(eng, v)) if comm.size > 1 else None)   # main.jl:211
+    res.warmup = warmup   # launches that were run again instead of being counted (automatic :mcmc chain lengths)
     if print >= 0:
         report(res, io=printio)                                                       # main.jl:212-213
     return res

@@ -93,6 +93,7 @@ mutable struct ResultC
     neval::Int64; seconds::Float64
     visited::Ptr{Float64}
     correlated::Int32          # out: 1 = stdev is the block-lineage error of carried chains (mci_lineage_sums), else statistics.jl:198
+    warmup::Int32              # out: launches run again instead of being counted (automatic :mcmc chain lengths, mci_mcmc_launch_valid)
 end
 
 const _ctx = Dict{Int,Ptr{Cvoid}}()              # one mci_ctx (HIP stream + RCCL communicator) per device
@@ -600,7 +601,7 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
     args = Ref(IntegrateArgs(SOLVER[solver], Int64(neval), niter, block, ignore, adapt, gamma, measurefreq, UInt64(config.seed),
                              nchain, config.iterations_done, thermal_ratio,
                              reweight_goal === nothing ? Ptr{Float64}(C_NULL) : pointer(goal)))
-    res = ResultC(niter, nobs, pointer(im), pointer(ie), pointer(m), pointer(s), pointer(c2), 0, 0.0, Ptr{Float64}(C_NULL), 0)
+    res = ResultC(niter, nobs, pointer(im), pointer(ie), pointer(m), pointer(s), pointer(c2), 0, 0.0, Ptr{Float64}(C_NULL), 0, 0)
     GC.@preserve im ie m s c2 goal check(ccall((:mci_integrate, libmci), Cint, (Ptr{Cvoid}, Ptr{IntegrateArgs}, Ref{ResultC}), prob, args, res))
     config.iterations_done += niter
     nworker = _comm[].size

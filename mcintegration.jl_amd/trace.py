@@ -13,8 +13,16 @@ What cannot be written out raises TraceError and the caller falls back to the ho
 branches (`if x[0] > 0.5`), `math.*` functions (they want a float), `np.where / np.maximum` on ARRAYS of symbols (numpy compares
 and truth-tests the elements itself; on single draws they trace, and `mci.trace.where / fmax / fmin` take arrays too), complex weights.  The written-out body is checked against the closure itself at random points of the domain before it is
 used (the closure is called with plain float arrays, one sample at a time): a closure that is not a pure function of its draws
-(hidden state, a branch taken on something the trace did not see) is refused."""
+(hidden state, a branch taken on something the trace did not see) is refused.
+
+Captured parameters.  Floats the closure captures -- closure cells, float defaults, module-level floats its code names; float arrays
+of up to 64 elements likewise -- are traced as PARAMETERS, not as literals: every maximal subexpression that depends on parameters
+and constants only is evaluated on the host and handed to the kernel in a `ud[k]` slot (Integrand.userdata), so the written-out body is
+the same text for every value and a parameter sweep over a closure reuses ONE code object (the kernel cache is keyed by the source).
+Captured ints stay literals (they are structure more often than data: `range(n)`, `x[:n]`, `** n`); a closure that branches on a
+captured float is traced again with its captured values as literals."""
 import math
+import types
 
 import numpy as np
 
@@ -37,9 +45,14 @@ class _Trace:
     def __init__(self):
         self.nodes = []
         self.index = {}
+        self.params = []      # values of the captured parameters: node ("ud", k) stands for params[k]
+
+    def param(self, v):
+        self.params.append(float(v))
+        return self.node("ud", len(self.params) - 1)
 
     def node(self, op, *args):
-        key = (op,) + tuple(a.id if isinstance(a, Sym) else ("k", a) for a in args)
+        key = (op,) + tuple(a.id if isinstance(a, Sym) else ("k", repr(a)) for a in args)   # (repr: 0.0 and -0.0 are two constants)
         s = self.index.get(key)
         if s is None:
             s = Sym(self, op, args, len(self.nodes))
@@ -187,7 +200,7 @@ _BOOL = ("<", "<=", ">", ">=", "==", "!=", "not", "and", "or")
 
 
 def _is_const(s, v):
-    return s.op == "const" and s.args[0] == v
+    return s.op == "const" and s.args[0] == v and math.copysign(1.0, s.args[0]) == math.copysign(1.0, v)
 
 
 def _method(name):
@@ -302,7 +315,8 @@ def arctan2(a, b):
 _BINOPS = ("+", "-", "*", "/", "<", "<=", ">", ">=", "==", "!=")
 
 
-def _reachable(outs):
+def _reachable(outs, stop=()):
+    """nodes the outputs depend on, children before parents; nothing below the nodes in `stop` (they are leaves to the caller)"""
     seen, order = set(), []
 
     def visit(s):
@@ -316,12 +330,14 @@ def _reachable(outs):
                 continue
             seen.add(n.id)
             stack.append((n, True))
+            if n.id in stop:
+                continue
             for a in n.args:
                 if isinstance(a, Sym):
                     stack.append((a, False))
     for o in outs:
         visit(o)
-    return order   # children before parents
+    return order
 
 
 def _literal(v):
@@ -329,51 +345,96 @@ def _literal(v):
     return r if any(c in r for c in ".en") else r + ".0"
 
 
-def emit(outs, sink=lambda i, ref: "w[%d] = %s;" % (i, ref)):
-    """HIP C++ / C body: one `const double tK = ...;` per operation (children first), then `w[i] = ...;` (or what `sink` says)"""
+def hoist(outs, params):
+    """Every maximal subexpression that depends on captured parameters (and constants) only -> one userdata slot, evaluated here on
+    the host: ({node id: "ud[j]"}, [values]).  The body then does not change with the parameters' values."""
+    if not params:
+        return {}, []
     order = _reachable(outs)
-    uses = {}
+    on_x, on_p = {}, {}
     for n in order:
-        for a in n.args:
-            if isinstance(a, Sym):
-                uses[a.id] = uses.get(a.id, 0) + 1
+        kids = [a for a in n.args if isinstance(a, Sym)]
+        on_x[n.id] = n.op in ("x", "rw") or any(on_x[a.id] for a in kids)
+        on_p[n.id] = n.op == "ud" or any(on_p[a.id] for a in kids)
+    slots, values, byid = {}, [], {n.id: n for n in order}
+
+    def take(n):
+        if n.id not in slots:
+            slots[n.id] = "ud[%d]" % len(values)
+            values.append(float(evaluate([n], np.zeros((0, 1)), params=params)[0][0]))
+    outset = {o.id for o in outs}
+    for n in order:
+        if on_x[n.id]:
+            for a in n.args:
+                if isinstance(a, Sym) and on_p[a.id] and not on_x[a.id]:
+                    take(a)
+        elif on_p[n.id] and n.id in outset:
+            take(n)
+    for v in values:
+        if not math.isfinite(v):
+            raise TraceError("a captured parameter evaluates to a non-finite value")
+    return slots, values
+
+
+def emit(outs, sink=lambda i, ref: "w[%d] = %s;" % (i, ref), leaves=None):
+    """HIP C++ / C body: one `const double tK = ...;` per operation (children first), then `w[i] = ...;` (or what `sink` says).
+    `leaves` ({node id: text}, from hoist()): nodes written as that text and not looked into.  A comparison used as a NUMBER
+    ((x > a) * 2.0, (x > a) + (y > b)) is cast to double where it is used: the arithmetic is floating point like the closure's."""
+    leaves = leaves or {}
+    order = _reachable(outs, stop=leaves)
     name, lines = {}, []
 
     def ref(a):
         return name[a.id]
+
+    def num(a):   # as an operand of arithmetic
+        return "(double)%s" % name[a.id] if a.op in _BOOL and a.id not in leaves else name[a.id]
+
+    def cond(a):  # as a truth value
+        return name[a.id] if a.op in _BOOL and a.id not in leaves else "(%s != 0.0)" % name[a.id]
     for n in order:
-        if n.op in ("x", "rw"):
+        if n.id in leaves:
+            name[n.id] = leaves[n.id]
+            continue
+        if n.op in ("x", "rw", "ud"):
             name[n.id] = "%s[%d]" % (n.op, n.args[0])
             continue
         if n.op == "const":
             v = n.args[0]
-            name[n.id] = _literal(v) if v >= 0 else "(%s)" % _literal(v)
+            name[n.id] = _literal(v) if math.copysign(1.0, v) > 0 else "(%s)" % _literal(v)
             continue
         if n.op in _BINOPS:
-            e = "%s %s %s" % (ref(n.args[0]), n.op, ref(n.args[1]))
+            e = "%s %s %s" % (num(n.args[0]), n.op, num(n.args[1]))
         elif n.op == "neg":
-            e = "-%s" % ref(n.args[0])
+            e = "-%s" % num(n.args[0])
         elif n.op == "not":
-            e = "!%s" % ref(n.args[0])
+            e = "!%s" % cond(n.args[0])
         elif n.op in ("and", "or"):
-            e = "%s %s %s" % (ref(n.args[0]), "&&" if n.op == "and" else "||", ref(n.args[1]))
+            e = "%s %s %s" % (cond(n.args[0]), "&&" if n.op == "and" else "||", cond(n.args[1]))
         elif n.op == "where":
-            e = "%s ? %s : %s" % tuple(ref(a) for a in n.args)
+            e = "%s ? %s : %s" % (cond(n.args[0]), num(n.args[1]), num(n.args[2]))
         else:
-            e = "%s(%s)" % (_CNAME.get(n.op, n.op), ", ".join(ref(a) for a in n.args))
+            e = "%s(%s)" % (_CNAME.get(n.op, n.op), ", ".join(num(a) for a in n.args))
         if n.op in _BOOL:
             lines.append("const int t%d = %s;" % (n.id, e))      # (int: the body is also compiled as C by the oracle)
         else:
             lines.append("const double t%d = %s;" % (n.id, e))
         name[n.id] = "t%d" % n.id
     for i, o in enumerate(outs):
-        lines.append(sink(i, ref(o)))
+        lines.append(sink(i, num(o)))
     return "\n".join(lines)
 
 
-def evaluate(outs, X, R=None):
-    """the DAG on numeric draws X[draw, sample] (and relative weights R[integrand, sample]), for the check against the closure itself"""
+def evaluate(outs, X, R=None, params=()):
+    """The DAG on numeric draws X[draw, sample] (relative weights R[integrand, sample], captured parameters `params`) WITH THE
+    SEMANTICS OF THE EMITTED C, for the check against the closure itself: a comparison is the number 0.0 or 1.0 (where numpy's
+    bool + bool is a logical or and C's int + int is 2), a truth value is `!= 0`.  A closure whose numpy arithmetic on booleans
+    means something else than the written-out body computes therefore fails the check and keeps the host path."""
     val = {}
+    f64 = np.float64
+
+    def truth(v):
+        return np.asarray(v) != 0.0
     with np.errstate(all="ignore"):
         for n in _reachable(outs):
             a = [val[q.id] if isinstance(q, Sym) else q for q in n.args]
@@ -381,12 +442,14 @@ def evaluate(outs, X, R=None):
                 v = X[n.args[0]]
             elif n.op == "rw":
                 v = R[n.args[0]]
+            elif n.op == "ud":
+                v = f64(params[n.args[0]])
             elif n.op == "not":
-                v = np.logical_not(a[0])
+                v = np.logical_not(truth(a[0])).astype(f64)
             elif n.op in ("and", "or"):
-                v = (np.logical_and if n.op == "and" else np.logical_or)(a[0], a[1])
+                v = (np.logical_and if n.op == "and" else np.logical_or)(truth(a[0]), truth(a[1])).astype(f64)
             elif n.op == "const":
-                v = np.float64(n.args[0])
+                v = f64(n.args[0])
             elif n.op == "+":
                 v = a[0] + a[1]
             elif n.op == "-":
@@ -394,15 +457,15 @@ def evaluate(outs, X, R=None):
             elif n.op == "*":
                 v = a[0] * a[1]
             elif n.op == "/":
-                v = a[0] / a[1]
+                v = np.asarray(a[0], dtype=f64) / np.asarray(a[1], dtype=f64)
             elif n.op in ("<", "<=", ">", ">=", "==", "!="):
-                v = {"<": np.less, "<=": np.less_equal, ">": np.greater, ">=": np.greater_equal, "==": np.equal, "!=": np.not_equal}[n.op](a[0], a[1])
+                v = {"<": np.less, "<=": np.less_equal, ">": np.greater, ">=": np.greater_equal, "==": np.equal, "!=": np.not_equal}[n.op](a[0], a[1]).astype(f64)
             elif n.op == "neg":
                 v = -a[0]
             elif n.op == "where":
-                v = np.where(a[0], a[1], a[2])
+                v = np.where(truth(a[0]), a[1], a[2])
             elif n.op == "pow":
-                v = np.power(a[0], a[1])
+                v = np.power(np.asarray(a[0], dtype=f64), a[1])
             elif n.op == "atan2":
                 v = np.arctan2(a[0], a[1])
             elif n.op in ("fmax", "fmin", "fabs"):
@@ -413,6 +476,45 @@ def evaluate(outs, X, R=None):
                 v = getattr(np, n.op)(a[0])
             val[n.id] = v
     return [np.broadcast_to(np.asarray(val[o.id], dtype=np.float64), X.shape[1:]) for o in outs]
+
+
+def _parametrized(fn, t):
+    """A copy of the closure whose captured floats are parameters of trace `t` (module docstring); the closure itself if it has none
+    or is not a plain Python function."""
+    if not isinstance(fn, types.FunctionType):
+        return fn
+
+    def conv(v):
+        if isinstance(v, (float, np.floating)) and not isinstance(v, bool) and math.isfinite(v):
+            return t.param(v)
+        if isinstance(v, np.ndarray) and v.dtype.kind == "f" and 0 < v.size <= 64 and np.all(np.isfinite(v)):
+            a = np.empty(v.shape, dtype=object)
+            for i in np.ndindex(v.shape):
+                a[i] = t.param(v[i])
+            return a
+        return v
+    n0 = len(t.params)
+    cells = None
+    if fn.__closure__:
+        cells = []
+        for c in fn.__closure__:
+            try:
+                cells.append(types.CellType(conv(c.cell_contents)))
+            except ValueError:            # an empty cell
+                cells.append(c)
+        cells = tuple(cells)
+    g = fn.__globals__
+    names = [n for n in fn.__code__.co_names if n in g and isinstance(g[n], (float, np.floating)) and not isinstance(g[n], bool)]
+    if names:
+        g = dict(g)
+        for n in names:
+            g[n] = conv(g[n])
+    defaults = tuple(conv(d) for d in fn.__defaults__) if fn.__defaults__ else None
+    if len(t.params) == n0:
+        return fn
+    new = types.FunctionType(fn.__code__, g, fn.__name__, defaults, cells)
+    new.__kwdefaults__ = fn.__kwdefaults__
+    return new
 
 
 def _pools(config):
@@ -463,22 +565,33 @@ def _domain_points(config, ndraw, n, rng):
     return X
 
 
-def trace_integrand(fn, config, indexed=False, check_points=32, name=None):
-    """Run the closure once on symbolic draws and return the Integrand (HIP C++ body) that computes the same thing; TraceError if
-    it cannot be written out or if the written-out body and the closure disagree at random points of the domain.
+def trace_integrand(fn, config, indexed=False, check_points=32, name=None, parameters=True):
+    """Run the closure once on symbolic draws and return the Integrand (HIP C++ body + userdata) that computes the same thing;
+    TraceError if it cannot be written out or if the written-out body and the closure disagree at random points of the domain.
+    `parameters`: captured floats become userdata slots (module docstring) -- the body does not depend on their values.
 
     fn(x, config) -> value | tuple of N values    (indexed=True: fn(idx, x, config) -> value, the reference's :mcmc form, idx 0-based)"""
     if getattr(config, "ncomp", 1) != 1:
         raise TraceError("complex weights are not traced")
+    if parameters:
+        try:
+            return _trace_integrand(fn, config, indexed, check_points, name, True)
+        except TraceError:
+            pass   # (a branch on a captured float, a parameter where Python wants a number): once more with the captured values as literals
+    return _trace_integrand(fn, config, indexed, check_points, name, False)
+
+
+def _trace_integrand(fn, config, indexed, check_points, name, parameters):
     pools, ndraw = _pools(config)
     t = _Trace()
     arg = _argument(pools, lambda k: t.node("x", k))
     N = config.N
+    sfn = _parametrized(fn, t) if parameters else fn
     try:
         if indexed:
-            outs = [fn(i, arg, config) for i in range(N)]
+            outs = [sfn(i, arg, config) for i in range(N)]
         else:
-            outs = fn(arg, config)
+            outs = sfn(arg, config)
             if N == 1 and not isinstance(outs, (tuple, list)):
                 outs = (outs,)
             outs = list(outs)
@@ -494,10 +607,9 @@ def trace_integrand(fn, config, indexed=False, check_points=32, name=None):
             o = o.reshape(-1)[0]
         if not isinstance(o, Sym):
             o = t.const(o)
-        if o.op in _BOOL:
-            o = t.node("where", o, t.const(1.0), t.const(0.0))
         syms.append(o)
-    body = emit(syms)
+    slots, ud = hoist(syms, t.params)
+    body = emit(syms, leaves=slots)
     if check_points:
         rng = np.random.default_rng(12345)
         X = _domain_points(config, ndraw, check_points, rng)
@@ -517,14 +629,15 @@ def trace_integrand(fn, config, indexed=False, check_points=32, name=None):
                         ref[i, p] = float(np.asarray(r[i], dtype=np.float64).reshape(-1)[0])
         except Exception as e:
             raise TraceError("the closure does not run on numeric draws (%s: %s)" % (type(e).__name__, e))
-        got = evaluate(syms, X)
+        got = evaluate(syms, X, params=t.params)
         for i in range(N):
             r = ref[i]
             ok = np.isfinite(r) & np.isfinite(got[i])
             if not np.array_equal(np.isfinite(r), np.isfinite(got[i])) or not np.allclose(got[i][ok], r[ok], rtol=1e-10, atol=1e-290):
                 raise TraceError("the traced expression and the closure disagree on integrand %d: the closure is not a pure "
-                                 "function of its draws (hidden state, a branch the trace did not see)" % i)
-    return Integrand(body, None, name=name or getattr(fn, "__name__", "traced"))
+                                 "function of its draws (hidden state, a branch the trace did not see, numpy arithmetic on "
+                                 "comparisons that means something else than the same arithmetic on 0.0 / 1.0)" % i)
+    return Integrand(body, ud or None, name=name or getattr(fn, "__name__", "traced"))
 
 
 def trace_measure(fn, config, indexed=False, check_points=32):
@@ -608,4 +721,5 @@ def trace_measure(fn, config, indexed=False, check_points=32):
                 got = np.array([float(v[0]) for v in evaluate(adds, X[:, p:p + 1], R[:, p:p + 1])])
                 if not np.allclose(got, ref, rtol=1e-10, atol=1e-290, equal_nan=True):
                     raise TraceError("the traced measure and the closure disagree: the closure is not a pure function of its records")
-    return Measure("\n".join(q for q in parts if q))
+    # (an empty body would mean "the default measure" to the library: a closure that adds nothing is written out as a no-op)
+    return Measure("\n".join(q for q in parts if q) or "(void)0;")

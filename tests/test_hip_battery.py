@@ -419,7 +419,16 @@ def test_report_config_prints_the_acceptance_table(capsys):
     assert "ChangeVariable" in capsys.readouterr().out
 
 
-def test_python_closure_as_measure_matches_device_source():
+@pytest.fixture(params=["host", "traced"])
+def closure_path(request, monkeypatch):
+    """Python closures reach the kernels two ways: as host batch callbacks (trace=False) or written out as device source by the tracer
+    (the default).  The closure-vs-device-source tests below run under both."""
+    import mcintegration_jl_amd.integrate as I
+    monkeypatch.setattr(I, "TRACE_DEFAULT", False if request.param == "host" else None)
+    return request.param
+
+
+def test_python_closure_as_measure_matches_device_source(closure_path):
     """a host `measure` closure (mci_set_measure_host; the reference's Sphere3 measure, test/montecarlo.jl:71-84) against the same
     measure as device source: same draws, same relative weights, so the block observables agree to summation-order rounding --
     also with measurefreq and next to a host integrand"""
@@ -442,7 +451,7 @@ def test_python_closure_as_measure_matches_device_source():
     np.testing.assert_allclose(c.iter_mean, a.iter_mean, rtol=1e-9)
 
 
-def test_python_closure_as_measure_under_the_chain_solvers_matches_device_source():
+def test_python_closure_as_measure_under_the_chain_solvers_matches_device_source(closure_path):
     """:vegasmc and :mcmc call `measure` inside the step loop (vegas_mc/montecarlo.jl:224-227, mcmc/montecarlo.jl:166-169).  With a
     host closure every chain leaves its measured configurations and relative weights in its block's record and the closure runs
     over them after the launch (mci_set_measure_host / _indexed): same chains, same relative weights as the same measure given as
@@ -508,14 +517,14 @@ def test_host_closures_refuse_launches_whose_records_do_not_fit():
     """every record of a host closure crosses PCIe into pinned memory: a launch of more than 8 GiB of them is refused with a
     message instead of exhausting the host"""
     with pytest.raises(mci.MCIError) as e:
-        integrate("return x[0];", measure=lambda x, obs, w, c: None, dof=[[16]], solver="vegas", neval=2e8, niter=1, seed=1)
+        integrate("return x[0];", measure=lambda x, obs, w, c: None, dof=[[16]], solver="vegas", neval=2e8, niter=1, seed=1, trace=False)
     assert "8 GiB" in str(e.value)
     with pytest.raises(mci.MCIError) as e:
-        integrate(lambda x, c: x[0], dof=[[16]], solver="vegas", neval=2e8, niter=1, seed=1)
+        integrate(lambda x, c: x[0], dof=[[16]], solver="vegas", neval=2e8, niter=1, seed=1, trace=False)
     assert "8 GiB" in str(e.value)
 
 
-def test_python_closure_as_integrand_matches_device_source():
+def test_python_closure_as_integrand_matches_device_source(closure_path):
     """a host closure through the batch-callback path (mci_set_integrand_host) sees the same draws as
     the device-source integrand, so the two runs agree to libm rounding; it reads like the reference's README call."""
     res_h = integrate(lambda x, c: np.log(x[0]) / np.sqrt(x[0]), solver="vegas", neval=1e5, seed=5)     # README.md:26
@@ -532,7 +541,7 @@ def test_python_closure_as_integrand_matches_device_source():
     check_complex(res, 3.0 + 1.5j)
 
 
-def test_python_closure_under_mcmc_matches_device_source():
+def test_python_closure_under_mcmc_matches_device_source(closure_path):
     """:mcmc calls `integrand(idx, var, config)` inside every Markov step (mcmc/updates.jl:35-38).  A host closure -- the
     reference's three-argument form, or the two-argument form returning every integrand -- runs one launch and one batch
     callback per step (mcmc_host_step) on the same streams and arithmetic as mcmc_chains: the same chains."""
@@ -562,7 +571,7 @@ def test_python_closure_under_mcmc_matches_device_source():
     check(v, [PI / 4.0, 4.0 * PI / 3.0 / 8])
 
 
-def test_python_closure_under_the_default_solver_matches_device_source():
+def test_python_closure_under_the_default_solver_matches_device_source(closure_path):
     """the reference's default solver is :vegasmc (main.jl:72) and calls the closure inside every Markov step
     (vegas_mc/updates.jl:67-75).  With a host closure the chains of a launch advance in lock step, one kernel launch per step
     (vegasmc_host_step): same Philox streams, same arithmetic -> the same chains as the same function given as device source."""

@@ -23,6 +23,19 @@ def test_traced_closure_gives_the_host_closure_estimate():
     assert abs(out[0].mean[0] - out[1].mean[0]) < 0.1 * out[0].stdev[0]      # (libm vs the device's exp: rounding level, amplified by train!)
 
 
+def test_a_parameter_sweep_over_a_closure_runs_on_one_code_object():
+    """captured floats travel as userdata (trace.py "Captured parameters"): the integral of exp(-a x^2) over [0, 1] for several `a` from
+    ONE kernel -- the reference's closures capture their parameters the same way (test/montecarlo.jl:19-92)"""
+    objs = []
+    for a in (0.5, 2.0, 7.5):
+        f = lambda x, c: np.exp(-a * x[0] ** 2)
+        r = mci.integrate(f, var=mci.Continuous(0.0, 1.0), dof=[[1]], solver="vegas", neval=100000, niter=6, seed=3, print=-1)
+        exact = math.sqrt(math.pi / a) / 2.0 * math.erf(math.sqrt(a))
+        assert abs(r.mean[0] - exact) < 5 * r.stdev[0] and r.stdev[0] < 1e-3 * exact, (a, r.mean, r.stdev, exact)
+        objs.append(r.config._engine.code_object("vegas"))
+    assert objs[0] == objs[1] == objs[2]
+
+
 @pytest.mark.parametrize("solver", ["vegas", "vegasmc", "mcmc"])
 def test_traced_two_integrand_closure_with_a_select(solver):
     g = lambda x, c: (x[0] ** 2 + x[1] ** 2, mci.trace.where(x[0] > 0.5, x[1], 0.0))

@@ -150,28 +150,27 @@ def test_plain_c_consumer_of_the_abi_builds_and_refuses_to_run_without_a_gpu():
 
 
 def test_mcmc_auto_chain_length_rule():
-    """mci_mcmc_auto_chains: pilot-length chains (4096 steps or 8 burn-in floors) until a launch has been measured; afterwards
-    16 x (fresh) / 8 x (carried) the longest holding time of the launch before, at most 4 x the chain length that measured it (a hold
-    longer than a quarter of that chain is censored by it), never fewer than 8 / 2 burn-in floors; at most 131072 chains per GPU, at
-    least one chain."""
+    """mci_mcmc_auto_chains: pilot-length chains (4096 steps or 2 burn-in floors) until a launch has been measured; afterwards
+    16 x (fresh) / 8 x (carried) the longest holding time of the launch before, at most 2 x the chain length that measured it (a hold
+    longer than an eighth of that chain is censored by it; 0 = no cap), never fewer than 8 / 2 burn-in floors; at most 131072 chains
+    per GPU, at least one chain."""
     from mcintegration_jl_amd._lib import lib
     L = lib()
     npb, nblocks, nslots, nd, npool = 6250000, 16, 12, 5, 1
     fl = 64 * nslots + 16 * (npool + 1) * nd
     assert fl == 928
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 0, 0, 0) == npb // (8 * fl)                # nothing measured: 8 floors > 4096
-    assert L.mci_mcmc_auto_chains(npb, nblocks, 2, 2, 1, 0, 0, 0) == npb // 4096                              # ... 4096 steps > 8 floors
-    big = 1 << 40   # (a measuring chain long enough not to matter)
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 256, big, 0) == npb // max(16 * 256, 8 * fl)    # light tails: the floor decides
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384, big, 0) == npb // (16 * 16384)           # heavy tails: the holds decide
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384, big, 1) == npb // (8 * 16384)            # carried chains: 8 x
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 64, big, 1) == npb // (2 * fl)                  # ... and two floors
-    # censored: the launch before ran 4096-step chains and saw holds up to 8192 (its top bucket's upper edge) -> 4 x 4096, not 8 x 8192
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 8192, 4096, 1) == npb // (4 * 4096)
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 8192, 4096, 0) == npb // (4 * 4096)
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 512, 16384, 1) == npb // (8 * 512)             # holds that fit: the length comes down at once
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 1 << 30, big, 0) == 1
-    assert L.mci_mcmc_auto_chains(10**9, 16, 1, 2, 1, 2, big, 0) == 131072 // 16                                   # GPU-fill cap
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 0, 0, 0) == npb // 4096                     # nothing measured: 4096 > 2 floors
+    assert L.mci_mcmc_auto_chains(npb, nblocks, 64, nd, npool, 0, 0, 0) == npb // (2 * (64 * 64 + 16 * 2 * 5))    # ... 2 floors > 4096
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 256, 0, 0) == npb // max(16 * 256, 8 * fl)      # light tails: the floor decides
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384, 0, 0) == npb // (16 * 16384)             # heavy tails: the holds decide
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384, 0, 1) == npb // (8 * 16384)              # carried chains: 8 x
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 64, 0, 1) == npb // (2 * fl)                    # ... and two floors
+    # censored: the launch before ran 4096-step chains and saw holds up to 8192 (its top bucket's upper edge) -> 2 x 4096, not 8 x 8192
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 8192, 4096, 1) == npb // (2 * 4096)
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 8192, 4096, 0) == npb // (2 * 4096)
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 256, 16384, 1) == npb // (8 * 256)             # holds that fit: the length comes down at once
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 1 << 30, 0, 0) == 1
+    assert L.mci_mcmc_auto_chains(10**9, 16, 1, 2, 1, 2, 0, 0) == 131072 // 16                                     # GPU-fill cap
 
 
 def test_lineage_sums_are_the_scatter_of_the_blocks_weighted_averages():

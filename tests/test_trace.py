@@ -41,6 +41,8 @@ CASES = [
      + np.power(2.0, x[1]) + np.square(x[2]) + (x[0] - x) @ (x / 2.0)),
     ("discrete_equality_and_indicator", lambda: mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3)), dof=[[2, 1], [2, 1]]),
      lambda x, c: (np.where(x[1][0] == 2, x[0][0], 2.0 * x[0][1]) + (x[1][0] != 1) * 0.5, (x[0][0] ** 2 + x[0][1] ** 2 < 1.0) * 1.0)),
+    ("comparisons_as_numbers", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]]),
+     lambda x, c: (x[0] > 0.5) * 2.0 + (x[1] > 0.5) / 4.0 - (x[0] > x[1]) * 1.0 + (x[0] > 0.2) / ((x[1] > 0.7) + 1.0) + (x[0] < 0.9) / ((x[1] < 2.0) * 1)),
     ("constant_and_shared_subexpressions", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [2]]),
      lambda x, c: (1.5, np.exp(x[0] * x[1]) + np.exp(x[0] * x[1]) ** 2)),
 ]
@@ -97,6 +99,69 @@ def test_closures_that_cannot_be_written_out_are_refused(what, f):
         trace_integrand(f, config)
 
 
+@pytest.mark.parametrize("what,f", [
+    ("numpy adds two comparisons as a logical or, the written-out C adds 1 + 1", lambda x, c: ((x[0] > 0.5) + (x[1] > 0.5)) * 1.0),
+    ("numpy multiplies two comparisons as a logical and -- the same number -- but subtracts them as an error", lambda x, c: ((x[0] > 0.5) - (x[1] > 0.5)) * 1.0),
+])
+def test_numpy_arithmetic_on_comparisons_that_the_body_would_compute_differently_is_refused(what, f):
+    """evaluate() -- what the body is checked with -- has the semantics of the emitted C (a comparison is the number 0.0 or 1.0), not
+    numpy's (bool + bool is a logical or): where the two differ the closure keeps the host path instead of integrating another function"""
+    config = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
+    with pytest.raises(TraceError):
+        trace_integrand(f, config)
+
+
+def test_captured_floats_become_userdata_slots_and_a_sweep_reuses_one_body(oracle):
+    """Captured parameters are not baked into the source: the body of a closure does not depend on their values (one code object in the
+    kernel cache serves a parameter sweep), the values travel as userdata; parameter-only subexpressions are evaluated on the host."""
+    config = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
+    scale = np.array([0.5, 2.0])
+
+    def make(a, b):
+        return lambda x, c, off=0.25: np.exp(-a * x[0] ** 2) * np.cos(b * np.pi) + np.sum(scale * x) + off / (1.0 + a * a)
+    bodies, uds = [], []
+    for a, b in ((1.5, 0.25), (3.0, -0.75), (0.1, 2.0)):
+        f = make(a, b)
+        I = trace_integrand(f, config)
+        bodies.append(I.body)
+        uds.append(np.array(I.userdata))
+        assert "1.5" not in I.body and "ud[" in I.body
+        fn = _c_function(oracle, I.body)
+        rng = np.random.default_rng(1)
+        for _ in range(50):
+            x = rng.uniform(0.0, 1.0, 2)
+            w = np.zeros(1)
+            fn(x.ctypes.data_as(C.POINTER(C.c_double)), w.ctypes.data_as(C.POINTER(C.c_double)), I.userdata.ctypes.data_as(C.POINTER(C.c_double)))
+            assert w[0] == pytest.approx(float(f(x, config)), rel=1e-13)
+    assert bodies[0] == bodies[1] == bodies[2] and not np.array_equal(uds[0], uds[1])
+    # cos(b * pi) and off / (1 + a * a) are parameter-only: one slot each, no cos() left in the body
+    assert "cos(" not in bodies[0] and len(uds[0]) == 5, (bodies[0], uds[0])
+    # the same code object: the JIT's cache key is the source
+    e1 = mci.Engine(config, trace_integrand(make(1.5, 0.25), config), device=-1)
+    e2 = mci.Engine(config, trace_integrand(make(7.0, 1.0), config), device=-1)
+    e1.compile("vegas"), e2.compile("vegas")
+    assert e1.code_object("vegas") == e2.code_object("vegas")
+    e1.close(), e2.close()
+    # a captured float the closure BRANCHES on cannot be a parameter: traced with its value as a literal (one body per value, as before)
+    thr = 0.5
+    g = lambda x, c: x[0] * 2.0 if thr > 0.25 else x[1]
+    I = trace_integrand(g, config)
+    assert "ud[" not in I.body and len(I.userdata) == 0 and "x[0] * 2.0" in I.body
+    # captured ints are structure, not data
+    n = 2
+    I = trace_integrand(lambda x, c: np.sum(x[:n]) ** n, config)
+    assert "ud[" not in I.body
+
+
+def test_negative_zero_is_its_own_constant():
+    from mcintegration_jl_amd.trace import _Trace
+    t = _Trace()
+    assert t.const(0.0) is not t.const(-0.0) and t.const(-0.0) is t.const(-0.0)
+    config = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]])
+    I = trace_integrand(lambda x, c: x[0] * where(x[0] > 0.5, -0.0, 0.0) + np.arctan2(where(x[0] > 0.5, -0.0, 0.0), -1.0), config)
+    assert "(-0.0)" in I.body and ": 0.0" in I.body
+
+
 def test_a_closure_with_hidden_state_is_refused():
     """the written-out body is checked against the closure itself at random points before it is used"""
     config = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
@@ -135,14 +200,19 @@ def test_integrate_with_trace_hands_the_engine_device_source(oracle):
     def factory(config, integrand, **kw):
         got["integrand"] = integrand
         raise Stop()
-    for trace in (True, False):
+    for trace in (None, False):
         with pytest.raises(Stop):
             mci.integrate(lambda x, c: 1.0 if x[0] > 0.5 else 0.0, var=mci.Continuous(0.0, 1.0), dof=[[1]], solver="vegas", trace=trace,
                           engine_factory=factory, print=-1)
         assert isinstance(got["integrand"], mci.HostIntegrand)
-    with pytest.raises(Stop):   # without trace=True a closure is a host closure, as before
-        mci.integrate(lambda x, c: x[0], var=mci.Continuous(0.0, 1.0), dof=[[1]], solver="vegas", engine_factory=factory, print=-1)
+    with pytest.raises(Stop):   # trace=False: a closure is a host closure
+        mci.integrate(lambda x, c: x[0], var=mci.Continuous(0.0, 1.0), dof=[[1]], solver="vegas", engine_factory=factory, print=-1, trace=False)
     assert isinstance(got["integrand"], mci.HostIntegrand)
+    with pytest.raises(Stop):   # the default: traced when it can be
+        mci.integrate(lambda x, c: x[0], var=mci.Continuous(0.0, 1.0), dof=[[1]], solver="vegas", engine_factory=factory, print=-1)
+    assert isinstance(got["integrand"], mci.Integrand)
+    with pytest.warns(RuntimeWarning, match="not traced"), pytest.raises(Stop):   # asked for and not possible: the reason is said
+        mci.integrate(lambda x, c: math.exp(x[0]), var=mci.Continuous(0.0, 1.0), dof=[[1]], solver="vegas", engine_factory=factory, print=-1, trace=True)
 
 
 def test_traced_bodies_compile_for_gfx950():
@@ -214,8 +284,11 @@ def test_integrate_with_trace_hands_the_engine_a_device_measure():
         mci.integrate(mci.catalog.sphere2(), measure=_sphere3_measure, trace=True, **kw)
     assert isinstance(got["measure"], mci.Measure) and "obs_add(2," in got["measure"].body
     with pytest.raises(Stop):
-        mci.integrate(mci.catalog.sphere2(), measure=_sphere3_measure, **kw)
+        mci.integrate(mci.catalog.sphere2(), measure=_sphere3_measure, trace=False, **kw)
     assert isinstance(got["measure"], mci.HostMeasure)
+    with pytest.raises(Stop):   # a measure that adds nothing is a no-op body, not the empty body that means "the default measure"
+        mci.integrate(mci.catalog.sphere2(), measure=lambda x, obs, w, c: None, **kw)
+    assert isinstance(got["measure"], mci.Measure) and got["measure"].body == "(void)0;"
 
 
 def test_traced_measures_compile_for_gfx950():

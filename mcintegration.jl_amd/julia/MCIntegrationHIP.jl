@@ -10,7 +10,7 @@ using Printf
 using Dates
 
 export integrate, Configuration, Continuous, Discrete, CompositeVar, FermiK, Result, Integrand, Measure, bin_by, report,
-       average, init_comm!, save, load!
+       average, init_comm!, save, load!, trace_integrand, TraceError
 
 const libmci = get(ENV, "MCI_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libmci_hip.so"))
 const MaxOrder = 16                         # reference src/distribution/distribution.jl:59
@@ -284,6 +284,266 @@ function visited(c::Configuration)
     packed = zeros(ps[])
     check(ccall((:mci_get_packed, libmci), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), c.problem, packed, ps[]))
     packed[2*no[]+3:2*no[]+3+c.N]
+end
+
+# ---- Julia closures traced into device source (the counterpart of mcintegration_jl_amd/trace.py) ---------------------------------------
+# The reference's user API is a closure, inlined by Julia's JIT into its loop (vegas/montecarlo.jl:140-144).  Here the closure is run
+# ONCE on symbolic draws -- `Sym <: Real`, so `x[1]^2 + x[2]^2`, `exp(-x[1])`, `ifelse(x[1] < 0.5, a, b)` work as they are -- and what it
+# computes is written out as the HIP C++ body the kernels are JIT-compiled around: same node numbering, same grammar (C_FORMAT /
+# C_OPERANDS, compared with trace.py by tests/test_binding_layouts.py), so the same closure gives the same text as the Python tracer
+# and hits the same kernel-cache entry.  A closure that cannot be written out (`if x[1] > 0.5`, a call that wants a Float64, complex
+# weights) throws TraceError and takes the host batch-callback path below.  Floats the closure captures become `ud[k]` slots: the
+# body does not depend on their values (one code object for a parameter sweep).
+struct TraceError <: Exception; msg::String; end
+mutable struct Tape
+    ops::Vector{Symbol}                     # node k (1-based here, written as t<k-1> like the Python tracer's 0-based ids)
+    args::Vector{Vector{Any}}               # Int = node id, Float64 = the value of a :const node, Int32 = the index of an :x / :rw / :ud node
+    index::Dict{Any,Int}
+    params::Vector{Float64}
+end
+Tape() = Tape(Symbol[], Vector{Any}[], Dict{Any,Int}(), Float64[])
+struct Sym <: Real
+    tape::Tape
+    id::Int
+end
+const BOOL_OPS = (:<, :<=, :>, :>=, :(==), :!=, :not, :and, :or)
+const C_FORMAT = Dict("+" => "{0} + {1}", "-" => "{0} - {1}", "*" => "{0} * {1}", "/" => "{0} / {1}", "<" => "{0} < {1}", "<=" => "{0} <= {1}",
+                      ">" => "{0} > {1}", ">=" => "{0} >= {1}", "==" => "{0} == {1}", "!=" => "{0} != {1}", "neg" => "-{0}", "not" => "!{0}",
+                      "and" => "{0} && {1}", "or" => "{0} || {1}", "where" => "{0} ? {1} : {2}")
+const C_OPERANDS = Dict("not" => "c", "and" => "cc", "or" => "cc", "where" => "cnn")
+const C_FUNCS = (:exp, :log, :sqrt, :sin, :cos, :tan, :tanh, :sinh, :cosh, :asin, :acos, :atan, :log1p, :expm1, :log10, :log2, :exp2, :cbrt,
+                 :floor, :ceil)
+function node!(t::Tape, op::Symbol, args...)
+    key = (op, map(a -> a isa Sym ? a.id : repr(a), args)...)          # (repr: 0.0 and -0.0 are two constants)
+    id = get!(t.index, key) do
+        push!(t.ops, op); push!(t.args, Any[a isa Sym ? a.id : a for a in args])
+        length(t.ops)
+    end
+    Sym(t, id)
+end
+function constant!(t::Tape, v::Real)
+    v isa Bool && (v = Float64(v))
+    isfinite(v) || throw(TraceError("non-finite constant $v"))
+    node!(t, :const, Float64(v))
+end
+param!(t::Tape, v::Float64) = (push!(t.params, v); node!(t, :ud, Int32(length(t.params) - 1)))
+lift(t::Tape, v) = v isa Sym ? v : v isa Real ? constant!(t, v) : throw(TraceError("cannot use $(typeof(v)) in an integrand expression"))
+op(s::Sym) = s.tape.ops[s.id]
+isconst(s::Sym, v::Float64) = op(s) === :const && s.tape.args[s.id][1] === v      # (=== on Float64 tells 0.0 from -0.0)
+function binary(o::Symbol, a, b)
+    t = a isa Sym ? a.tape : b.tape
+    a, b = lift(t, a), lift(t, b)
+    o === :+ && (isconst(a, 0.0) || isconst(b, 0.0)) && return isconst(a, 0.0) ? b : a
+    o === :* && (isconst(a, 1.0) || isconst(b, 1.0)) && return isconst(a, 1.0) ? b : a
+    o === :- && isconst(b, 0.0) && return a
+    o === :/ && isconst(b, 1.0) && return a
+    node!(t, o, a, b)
+end
+for o in (:+, :-, :*, :/)
+    @eval Base.$o(a::Sym, b::Sym) = binary($(QuoteNode(o)), a, b)
+    @eval Base.$o(a::Sym, b::Real) = binary($(QuoteNode(o)), a, b)
+    @eval Base.$o(a::Real, b::Sym) = binary($(QuoteNode(o)), a, b)
+end
+for o in (:<, :<=, :>, :>=, :(==), :!=)                                    # (> >= != too, so that the text is the Python tracer's: Julia's own are < <= == rewritten)
+    @eval Base.$o(a::Sym, b::Sym) = binary($(QuoteNode(o)), a, b)
+    @eval Base.$o(a::Sym, b::Real) = binary($(QuoteNode(o)), a, b)
+    @eval Base.$o(a::Real, b::Sym) = binary($(QuoteNode(o)), a, b)
+end
+Base.:-(a::Sym) = node!(a.tape, :neg, a)
+Base.:+(a::Sym) = a
+Base.abs(a::Sym) = node!(a.tape, :fabs, a)
+Base.:!(a::Sym) = op(a) in BOOL_OPS ? node!(a.tape, :not, a) : throw(TraceError("! of a value that is not a comparison"))
+Base.:&(a::Sym, b::Sym) = (op(a) in BOOL_OPS && op(b) in BOOL_OPS) ? node!(a.tape, :and, a, b) : throw(TraceError("& of values that are not comparisons"))
+Base.:|(a::Sym, b::Sym) = (op(a) in BOOL_OPS && op(b) in BOOL_OPS) ? node!(a.tape, :or, a, b) : throw(TraceError("| of values that are not comparisons"))
+Base.ifelse(c::Sym, a, b) = node!(c.tape, :where, c, lift(c.tape, a), lift(c.tape, b))
+Base.max(a::Sym, b::Real) = node!(a.tape, :fmax, a, lift(a.tape, b)); Base.max(a::Real, b::Sym) = node!(b.tape, :fmax, lift(b.tape, a), b)
+Base.max(a::Sym, b::Sym) = node!(a.tape, :fmax, a, b)
+Base.min(a::Sym, b::Real) = node!(a.tape, :fmin, a, lift(a.tape, b)); Base.min(a::Real, b::Sym) = node!(b.tape, :fmin, lift(b.tape, a), b)
+Base.min(a::Sym, b::Sym) = node!(a.tape, :fmin, a, b)
+Base.atan(a::Sym, b::Real) = node!(a.tape, :atan2, a, lift(a.tape, b)); Base.atan(a::Real, b::Sym) = node!(b.tape, :atan2, lift(b.tape, a), b)
+Base.atan(a::Sym, b::Sym) = node!(a.tape, :atan2, a, b)
+for f in C_FUNCS
+    @eval Base.$f(a::Sym) = node!(a.tape, $(QuoteNode(f)), a)
+end
+function smallpow(a::Sym, k::Integer)                                      # small integer powers as products, like Julia's own literal_pow
+    k == 0 && return constant!(a.tape, 1.0)
+    r = a
+    for _ in 2:k; r = r * a; end
+    r
+end
+Base.literal_pow(::typeof(^), a::Sym, ::Val{p}) where {p} = 0 <= p <= 4 ? smallpow(a, p) : p == -1 ? 1.0 / a : node!(a.tape, :pow, a, constant!(a.tape, p))
+Base.:^(a::Sym, p::Integer) = 0 <= p <= 4 ? smallpow(a, p) : p == -1 ? 1.0 / a : node!(a.tape, :pow, a, constant!(a.tape, p))
+Base.:^(a::Sym, p::Real) = p == 0.5 ? sqrt(a) : p == -1.0 ? 1.0 / a : (isinteger(p) && 0 <= p <= 4) ? smallpow(a, Int(p)) : node!(a.tape, :pow, a, lift(a.tape, p))
+Base.:^(a::Sym, p::Sym) = node!(a.tape, :pow, a, p)
+Base.:^(a::Real, p::Sym) = node!(p.tape, :pow, lift(p.tape, a), p)
+# what must not happen during a trace: a branch on a sampled value, a conversion to a machine number
+Base.convert(::Type{T}, ::Sym) where {T<:Union{AbstractFloat,Integer,Bool}} = throw(TraceError("a sampled value where Julia wants a $T (a branch on a draw? use ifelse)"))
+Base.promote_rule(::Type{Sym}, ::Type{<:Real}) = Sym
+Base.zero(a::Sym) = constant!(a.tape, 0.0); Base.one(a::Sym) = constant!(a.tape, 1.0)
+Base.conj(a::Sym) = a; Base.real(a::Sym) = a
+
+function reachable(t::Tape, outs::Vector{Int}, stop)                       # children before parents; nothing below the nodes in `stop`
+    seen, order = Set{Int}(), Int[]
+    function visit(n)
+        n in seen && return
+        push!(seen, n)
+        if !(n in stop)
+            for a in t.args[n]; a isa Int && visit(a); end
+        end
+        push!(order, n)
+    end
+    foreach(visit, outs)
+    order
+end
+function literal(v::Float64)
+    r = repr(v)
+    signbit(v) ? "($r)" : r
+end
+# the DAG with the semantics of the emitted C (a comparison is 0.0 or 1.0, a truth value is `!= 0`): the check against the closure itself
+function evaluate(t::Tape, outs::Vector{Int}, X::Vector{Float64})
+    val = Dict{Int,Float64}()
+    for n in reachable(t, outs, ())
+        o, a = t.ops[n], t.args[n]
+        v(k) = val[a[k]]
+        val[n] = o === :x ? X[a[1]+1] : o === :ud ? t.params[a[1]+1] : o === :const ? a[1] :
+                 o === :+ ? v(1) + v(2) : o === :- ? v(1) - v(2) : o === :* ? v(1) * v(2) : o === :/ ? v(1) / v(2) :
+                 o === :< ? Float64(v(1) < v(2)) : o === :<= ? Float64(v(1) <= v(2)) : o === :(==) ? Float64(v(1) == v(2)) :
+                 o === :> ? Float64(v(1) > v(2)) : o === :>= ? Float64(v(1) >= v(2)) : o === :!= ? Float64(v(1) != v(2)) :
+                 o === :neg ? -v(1) : o === :not ? Float64(v(1) == 0.0) : o === :and ? Float64(v(1) != 0.0 && v(2) != 0.0) :
+                 o === :or ? Float64(v(1) != 0.0 || v(2) != 0.0) : o === :where ? (v(1) != 0.0 ? v(2) : v(3)) :
+                 o === :fabs ? abs(v(1)) : o === :fmax ? max(v(1), v(2)) : o === :fmin ? min(v(1), v(2)) : o === :atan2 ? atan(v(1), v(2)) :
+                 o === :pow ? v(1)^v(2) : getfield(Base, o)(v(1))
+    end
+    [val[o] for o in outs]
+end
+# every maximal subexpression that depends on captured parameters (and constants) only -> one userdata slot, evaluated on the host
+function hoist(t::Tape, outs::Vector{Int})
+    slots, values = Dict{Int,String}(), Float64[]
+    isempty(t.params) && return slots, values
+    order = reachable(t, outs, ())
+    onx, onp = Dict{Int,Bool}(), Dict{Int,Bool}()
+    for n in order
+        kids = [a for a in t.args[n] if a isa Int]
+        onx[n] = t.ops[n] in (:x, :rw) || any(k -> onx[k], kids)
+        onp[n] = t.ops[n] === :ud || any(k -> onp[k], kids)
+    end
+    take(n) = haskey(slots, n) || (slots[n] = "ud[$(length(values))]"; push!(values, evaluate(t, [n], Float64[])[1]))
+    for n in order
+        if onx[n]
+            for a in t.args[n]; a isa Int && onp[a] && !onx[a] && take(a); end
+        elseif onp[n] && n in outs
+            take(n)
+        end
+    end
+    all(isfinite, values) || throw(TraceError("a captured parameter evaluates to a non-finite value"))
+    slots, values
+end
+function emit(t::Tape, outs::Vector{Int}, leaves::Dict{Int,String})
+    name, lines = Dict{Int,String}(), String[]
+    isbool(n) = t.ops[n] in BOOL_OPS && !haskey(leaves, n)
+    num(n) = isbool(n) ? "(double)" * name[n] : name[n]
+    cond(n) = isbool(n) ? name[n] : "(" * name[n] * " != 0.0)"
+    for n in reachable(t, outs, keys(leaves))
+        o, a = t.ops[n], t.args[n]
+        if haskey(leaves, n)
+            name[n] = leaves[n]
+        elseif o in (:x, :rw, :ud)
+            name[n] = "$(o)[$(a[1])]"
+        elseif o === :const
+            name[n] = literal(a[1])
+        else
+            so = String(o)
+            kinds = get(C_OPERANDS, so, "n"^length(a))
+            ops = [kinds[k] == 'c' ? cond(a[k]) : num(a[k]) for k in eachindex(a)]
+            e = haskey(C_FORMAT, so) ? foldl((s, k) -> replace(s, "{$(k-1)}" => ops[k]), eachindex(ops); init=C_FORMAT[so]) : so * "(" * join(ops, ", ") * ")"
+            push!(lines, (o in BOOL_OPS ? "const int t" : "const double t") * "$(n - 1) = $e;")
+            name[n] = "t$(n - 1)"
+        end
+    end
+    for (i, o) in enumerate(outs); push!(lines, "w[$(i - 1)] = $(num(o));"); end
+    join(lines, "\n")
+end
+# a copy of the closure whose captured floats are parameters of the tape: closure types are parametrised by the types of the
+# variables they capture, so the copy is `Closure{...Sym...}(fields...)`; anything else (a Core.Box, a non-parametric field) keeps its value
+function parametrized(f, t::Tape)
+    nf = nfields(f)
+    nf == 0 && return f
+    vals = Any[getfield(f, i) for i in 1:nf]
+    any(v -> v isa AbstractFloat && isfinite(v), vals) || return f
+    new = Any[(v isa AbstractFloat && isfinite(v)) ? param!(t, Float64(v)) : v for v in vals]
+    try
+        return typeof(f).name.wrapper{map(typeof, new)...}(new...)
+    catch
+        empty!(t.params)
+        return f
+    end
+end
+"""
+    trace_integrand(f, config; indexed=false, check_points=32) -> Integrand
+
+`f(x, config)` (or the reference's :mcmc form `f(idx, x, config)`, idx 1-based) run once on symbolic draws and written out as a
+device-source Integrand; TraceError if it cannot be, or if the written-out expression and the closure disagree at random points.
+With one variable type `x[i]` is the i-th draw; with several, `x[v][i]` (a CompositeVar pool: `x[v][leaf, slot]` is not traced).
+"""
+function trace_integrand(f, c::Configuration; indexed::Bool=false, check_points::Int=32, parameters::Bool=true)
+    c.ncomp == 1 || throw(TraceError("complex weights are not traced"))
+    any(v -> v isa CompositeVar || v isa FermiK, c.var) && throw(TraceError("CompositeVar / FermiK pools are not traced"))
+    if parameters
+        try
+            return _trace_integrand(f, c, indexed, check_points, true)
+        catch err
+            err isa TraceError || err isa TypeError || err isa MethodError || rethrow()
+        end                                       # (a branch on a captured float): once more with the captured values as literals
+    end
+    _trace_integrand(f, c, indexed, check_points, false)
+end
+function _trace_integrand(f, c::Configuration, indexed::Bool, check_points::Int, parameters::Bool)
+    t = Tape()
+    maxdof = [maximum(c.dof[i][v] for i in 1:c.N) for v in 1:length(c.var)]
+    k = 0
+    pools = Vector{Vector{Sym}}()
+    for v in 1:length(c.var)
+        push!(pools, [node!(t, :x, Int32(k + s - 1)) for s in 1:maxdof[v]]); k += maxdof[v]
+    end
+    ndraw = k
+    arg = length(pools) == 1 ? pools[1] : Tuple(pools)
+    g = parameters ? parametrized(f, t) : f
+    outs = Any[]
+    try
+        if indexed
+            outs = Any[g(i, arg, c) for i in 1:c.N]
+        else
+            r = g(arg, c)
+            outs = r isa Tuple ? Any[r...] : Any[r]
+        end
+    catch err
+        err isa TraceError && rethrow()
+        throw(TraceError("$(typeof(err)): the closure cannot be run on symbolic draws"))
+    end
+    length(outs) == c.N || throw(TraceError("the integrand must return one value per integrand ($(c.N)), got $(length(outs))"))
+    ids = Int[lift(t, o).id for o in outs]
+    slots, ud = hoist(t, ids)
+    body = emit(t, ids, slots)
+    lo = Float64[]; hi = Float64[]
+    for (v, var) in enumerate(c.var), _ in 1:maxdof[v]
+        push!(lo, Float64(var.lower)); push!(hi, Float64(var.upper))
+    end
+    for _ in 1:check_points                        # the closure itself on plain numbers against the written-out expression
+        X = [lo[j] + rand() * (hi[j] - lo[j]) for j in 1:ndraw]
+        j = 0
+        for (v, var) in enumerate(c.var), _ in 1:maxdof[v]
+            j += 1
+            var isa Discrete && (X[j] = Float64(rand(var.lower:var.upper)))
+        end
+        num = length(pools) == 1 ? X : Tuple(X[(sum(maxdof[1:v-1])+1):sum(maxdof[1:v])] for v in 1:length(c.var))
+        ref = indexed ? Float64[f(i, num, c) for i in 1:c.N] : (r = f(num, c); r isa Tuple ? Float64[r...] : Float64[r])
+        got = evaluate(t, ids, X)
+        for i in 1:c.N
+            (isfinite(ref[i]) == isfinite(got[i]) && (!isfinite(ref[i]) || isapprox(got[i], ref[i]; rtol=1e-10, atol=1e-290))) ||
+                throw(TraceError("the traced expression and the closure disagree on integrand $i: the closure is not a pure function of its draws"))
+        end
+    end
+    Integrand(body, ud)
 end
 
 # ---- Julia closures as integrands: the host "batch callback" slow path (mci_set_integrand_host) ----------------------
@@ -565,12 +825,20 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
                    block=16, gamma=1.0, adapt=true, ignore::Int=adapt ? 1 : 0, measure=nothing, measurefreq::Int=1,
                    thermal_ratio=0.1, reweight_goal::Union{Vector{Float64},Nothing}=nothing,
                    nchain=0, rng_bits::Int=52, rng_rounds::Int=10, train_walk::Int=-1, deterministic::Bool=false, chain_carry::Int=-1,
-                   persistent::Int=-1, print=-1, verbose=-1, kwargs...)
+                   persistent::Int=-1, trace::Bool=true, print=-1, verbose=-1, kwargs...)
     haskey(SOLVER, solver) || error("Solver $solver is not supported!")                  # main.jl:263
     config === nothing && (config = Configuration(; kwargs...))                          # main.jl:95-97
     # workers: after init_comm!(...) the library runs this rank's share of the blocks and sums every iteration's statistics and
     # histograms over the ranks with one RCCL all-reduce (main.jl:113-122, :152-188); nothing to do here per call
-    if integrand isa Function                      # a Julia closure: host batch-callback path (per launch under :vegas, per Markov step under :vegasmc / :mcmc)
+    if integrand isa Function && trace             # a Julia closure: run once on symbolic draws and written out as device source (trace_integrand) ...
+        try
+            integrand = trace_integrand(integrand, config; indexed=any(m -> m.nargs - 1 >= 3, methods(integrand)))
+        catch err
+            err isa TraceError || rethrow()
+            max(print, verbose) > 0 && println("integrand not traced (", err.msg, "): host callback path")
+        end
+    end
+    if integrand isa Function                      # ... or, if it cannot be, the host batch-callback path (per launch under :vegas, per Markov step under :vegasmc / :mcmc)
         prob = bind_host!(config, integrand)
     else
         f = integrand isa Integrand ? integrand : Integrand(String(integrand), config.userdata === nothing ? Float64[] : Float64.(config.userdata))

@@ -313,6 +313,14 @@ def arctan2(a, b):
 
 # ---- writing the DAG out, and evaluating it for the check ----
 _BINOPS = ("+", "-", "*", "/", "<", "<=", ">", ">=", "==", "!=")
+# The body grammar: how an operation is written as a C expression of its operands ({k} = operand k), and which operands are truth
+# values ("c": written `t` for a comparison, `(v != 0.0)` for a number) instead of numbers ("n": a comparison is cast, `(double)t`).
+# Everything else is a call `name(operands)` of the C math function of that name (_CNAME renames numpy's arc* functions).
+# julia/MCIntegrationHIP.jl carries the same two tables for its tracer (tests/test_binding_layouts.py compares them).
+C_FORMAT = {"+": "{0} + {1}", "-": "{0} - {1}", "*": "{0} * {1}", "/": "{0} / {1}", "<": "{0} < {1}", "<=": "{0} <= {1}", ">": "{0} > {1}",
+            ">=": "{0} >= {1}", "==": "{0} == {1}", "!=": "{0} != {1}", "neg": "-{0}", "not": "!{0}", "and": "{0} && {1}", "or": "{0} || {1}",
+            "where": "{0} ? {1} : {2}"}
+C_OPERANDS = {"not": "c", "and": "cc", "or": "cc", "where": "cnn"}
 
 
 def _reachable(outs, stop=()):
@@ -403,18 +411,12 @@ def emit(outs, sink=lambda i, ref: "w[%d] = %s;" % (i, ref), leaves=None):
             v = n.args[0]
             name[n.id] = _literal(v) if math.copysign(1.0, v) > 0 else "(%s)" % _literal(v)
             continue
-        if n.op in _BINOPS:
-            e = "%s %s %s" % (num(n.args[0]), n.op, num(n.args[1]))
-        elif n.op == "neg":
-            e = "-%s" % num(n.args[0])
-        elif n.op == "not":
-            e = "!%s" % cond(n.args[0])
-        elif n.op in ("and", "or"):
-            e = "%s %s %s" % (cond(n.args[0]), "&&" if n.op == "and" else "||", cond(n.args[1]))
-        elif n.op == "where":
-            e = "%s ? %s : %s" % (cond(n.args[0]), num(n.args[1]), num(n.args[2]))
+        kinds = C_OPERANDS.get(n.op, "n" * len(n.args))
+        ops = [cond(a) if k == "c" else num(a) for a, k in zip(n.args, kinds)]
+        if n.op in C_FORMAT:
+            e = C_FORMAT[n.op].format(*ops)
         else:
-            e = "%s(%s)" % (_CNAME.get(n.op, n.op), ", ".join(num(a) for a in n.args))
+            e = "%s(%s)" % (_CNAME.get(n.op, n.op), ", ".join(ops))
         if n.op in _BOOL:
             lines.append("const int t%d = %s;" % (n.id, e))      # (int: the body is also compiled as C by the oracle)
         else:

@@ -33,6 +33,18 @@ def golden():
         return json.load(fh)
 
 
+@pytest.fixture(autouse=True)
+def _note_process_groups(request):
+    """remember, for pytest_unconfigure, whether any test of this session initialised a torch.distributed process group"""
+    yield
+    td = sys.modules.get("torch.distributed")
+    try:
+        if td is not None and td.is_available() and td.is_initialized():
+            request.config._mci_made_process_group = True
+    except Exception:
+        pass
+
+
 def pytest_sessionfinish(session, exitstatus):
     """Release engines, streams and communicators while the HIP runtime and RCCL are fully alive (see
     mcintegration_jl_amd.engine.shutdown): the test processes create hundreds of problems and several communicators."""
@@ -50,8 +62,16 @@ def pytest_unconfigure(config):
     abort inside the C++ static destructors of RCCL / the HIP runtime after the interpreter is gone -- glibc "double free or corruption",
     exit code 134 with every test passed (seen with exactly those tests selected, also on the code this round started from; outside this repository's
     code: everything of ours has been released by then).  Like bench.py, such a process leaves through os._exit once pytest has
-    reported, with pytest's own exit status."""
-    if "torch.distributed" in sys.modules and hasattr(config, "_mci_exitstatus"):
+    reported, with pytest's own exit status.  ONLY such a process: one that merely imported torch keeps the normal interpreter and
+    library teardown, so that an abort in OUR static destructors, atexit handlers or orphaned compile threads shows as exit code 134."""
+    td = sys.modules.get("torch.distributed")
+    made_group = False
+    try:
+        made_group = bool(td is not None and (getattr(config, "_mci_made_process_group", False) or os.environ.get("MCI_TEST_MADE_PROCESS_GROUP")
+                                              or (td.is_available() and td.is_initialized())))
+    except Exception:
+        made_group = False
+    if made_group and hasattr(config, "_mci_exitstatus"):
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(config._mci_exitstatus)

@@ -161,6 +161,43 @@ def test_header_library_and_ctypes_table_list_the_same_symbols():
         assert hasattr(L, name), name
 
 
+def test_the_julia_tracer_writes_the_python_tracers_grammar():
+    """The Julia binding traces closures into device source with the same body grammar as mcintegration_jl_amd/trace.py (`Sym <: Real`
+    + operator overloads instead of numpy object arrays): the two format tables, the operand-kind table and the math functions written
+    out by name must be the same, so that the same closure gives the same text -- and the same kernel-cache entry -- from either side."""
+    from mcintegration_jl_amd import trace
+    src = open(JL).read()
+
+    def jdict(name):
+        m = re.search(r"const %s = Dict\((.*?)\)\n" % name, src, flags=re.S)
+        assert m, name
+        return dict(re.findall(r'"([^"]+)"\s*=>\s*"([^"]*)"', m.group(1)))
+    assert jdict("C_FORMAT") == trace.C_FORMAT
+    assert jdict("C_OPERANDS") == trace.C_OPERANDS
+    m = re.search(r"const C_FUNCS = \((.*?)\)\n", src, flags=re.S)
+    jfuncs = set(re.findall(r":(\w+)", m.group(1)))
+    pyfuncs = {trace._CNAME.get(f, f) for f in trace._FUNCS} - {"erf", "erfc"}     # (erf lives in SpecialFunctions.jl, not in Base)
+    assert jfuncs == pyfuncs, (sorted(jfuncs ^ pyfuncs))
+    for needle in ("struct Sym <: Real", "function trace_integrand(", "function hoist(", "function emit(", "Base.literal_pow(::typeof(^), a::Sym",
+                   "Base.ifelse(c::Sym", "integrand = trace_integrand(integrand, config"):
+        assert needle in src, needle
+    # temporaries are named after 0-based node ids on both sides, comparisons are `const int`, and a comparison used as a number is cast
+    assert '"const int t" : "const double t"' in src and '"(double)" * name[n]' in src and '" != 0.0)"' in src
+
+
+def test_debug_hooks_are_not_part_of_the_public_header():
+    """test and development hooks live in csrc/mci_debug.h: the drop-in boundary (include/mci.h) declares none of them, the bindings call
+    none of them"""
+    hdr = open(HDR).read()
+    dbg = open(os.path.join(ROOT, "mcintegration.jl_amd", "csrc", "mci_debug.h")).read()
+    names = re.findall(r"\b(mci_debug_\w+)\s*\(", dbg)
+    assert len(names) >= 4 and "mci_debug" not in hdr and "mci_debug" not in open(JL).read()
+    L = mci.lib()
+    for n in names:
+        assert hasattr(L, n) and n in {s[0] for s in _lib.DEBUG_SIGNATURES}, n
+    assert "test hook" not in hdr
+
+
 def test_julia_file_is_balanced():
     """cheap syntax sanity without a Julia parser: block openers and `end`s balance, brackets balance outside strings"""
     src = re.sub(r'"""(.*?)"""', '""', open(JL).read(), flags=re.S)

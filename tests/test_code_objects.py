@@ -79,6 +79,25 @@ def test_persistent_vegas_kernel_neither_spills_nor_declares_static_lds(name):
     eng.close()
 
 
+@pytest.mark.parametrize("alpha,ninc,trace", [(2.0, 1000, False), (1.0, 1000, False), (3.0, 1000, False), (2.5, 1000, False), (2.0, 1300, False),
+                                              (2.5, 1300, False), (2.0, 1000, True)])
+def test_every_preprocessor_variant_of_the_persistent_unit_compiles(alpha, ninc, trace, monkeypatch):
+    """csrc/mci_train.h is compiled by hiprtc into the persistent :vegas kernel under switches the JIT sets from the problem
+    (mci_jit.h): MCI_TRAIN_POWER = 1 | 2 | 3 (the exponent of the one grid as a product) | 4 (pow()), MCI_TRAIN_SHORT_SUMS (grids of at
+    most 1024 increments: Julia's sum() is its @simd block alone) or the unrolled pairwise recursion, MCI_TRAIN_SCAN_ONLY +
+    MCI_TRAIN_CONTINUOUS_ONLY (always, for this unit), and MCI_PERSIST_TRACE (tools/persist_trace.py, through MCI_JIT_FLAGS).  Every
+    combination that can occur must compile for gfx950 without scratch or static LDS; the ahead-of-time kernels (k_train / k_finish:
+    none of the switches) are compiled by build()."""
+    if trace:
+        monkeypatch.setenv("MCI_JIT_FLAGS", "-DMCI_PERSIST_TRACE=1")
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0, alpha=alpha, ninc=ninc), dof=[[2]])
+    eng = mci.Engine(cfg, mci.catalog.x2y2(), device=-1)
+    eng.compile("vegas_persistent")
+    k = isa_mix.resources(eng.code_object("vegas_persistent"))["mci_vegas_persist"]
+    eng.close()
+    assert k["vgpr_spill"] == 0 and k["scratch"] == 0 and k.get("lds", 0) == 0 and k["max_threads"] == 256, (alpha, ninc, trace, k)
+
+
 def test_split_all_pass_falls_back_to_512_threads_when_the_integrand_needs_every_draw_at_once():
     """32 independent grids with an integrand that cannot consume the draws as they come (it needs their mean first, then every draw
     and every intermediate again): at 768 threads (168 VGPRs) the sample pass would spill, so the library compiles plan B -- 512

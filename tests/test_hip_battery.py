@@ -3,6 +3,8 @@ test/interface_tests.jl) run through the product's `integrate` on the GPU: |mean
 (test/runtests.jl:4-9) and the sigma regression bounds.  Reads like the reference's tests."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -320,6 +322,7 @@ def test_torch_nccl_reducer_works_on_the_device_buffer_in_place():
     os.environ.setdefault("MASTER_PORT", "29611")
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    os.environ["MCI_TEST_MADE_PROCESS_GROUP"] = "1"   # (conftest.pytest_unconfigure: this process leaves through os._exit)
     try:
         comm = TorchDistComm(tensor_device="cuda:0")
         cfg = Configuration(var=Continuous(0.0, 1.0), dof=[[2]], seed=3)

@@ -63,8 +63,10 @@ def trace(name, neval, niter, solver="mcmc"):
         m, e = eng.finish(mci._lib.SOLVERS[solver], block, True, 1.0)
         ms = eng.kernel_times_ms(1)[0]
         tot += float(ms[-1])
-        print("  it %2d  nchain %6d  len %8d  carried %d  kernel %9.3f ms  hold top 2^%d   mean[0] %.6f +- %.1e" % (
-            it, nchain, npb // max(nchain, 1), carried, ms[-1], top, np.ravel(m)[0], np.ravel(e)[0]), flush=True)
+        valid, warm = eng.mcmc_launch_valid()[:2] if solver == "mcmc" else (True, True)
+        print("  it %2d  nchain %6d  len %8d  carried %d  kernel %9.3f ms  hold top 2^%d  %s  mean[0] %.6f +- %.1e" % (
+            it, nchain, npb // max(nchain, 1), carried, ms[-1], top, "valid" if valid else "short" + ("" if warm else " (warm-up: integrate() would run it again)"),
+            np.ravel(m)[0], np.ravel(e)[0]), flush=True)
     print("  sum of kernel times %.1f ms -> %.2f Gsteps/s" % (tot, neval * niter / tot / 1e6))
     eng.close()
 
@@ -76,21 +78,22 @@ def cold(name, neval, niter, reps=3, solver="mcmc"):
         res = mci.integrate(f, config=cfg, measure=meas, solver=solver, neval=neval, niter=niter)
         dt = time.perf_counter() - t0
         dev = (np.ravel(res.mean[0]) - np.ravel(exact)[:len(np.ravel(res.mean[0]))]) / np.ravel(res.stdev[0])
-        print("%s %s cold integrate(neval=%.0e, niter=%d): %.1f ms wall (library %.1f ms) -> %.2f Gsteps/s end to end; correlated=%s  dev[0]=%s sigma" % (
-            name, solver, neval, niter, dt * 1e3, res.seconds * 1e3, neval * niter / dt / 1e9, res.correlated, np.round(dev, 2)), flush=True)
+        print("%s %s cold integrate(neval=%.0e, niter=%d): %.1f ms wall (library %.1f ms) -> %.2f Gsteps/s end to end; correlated=%s warm-up launches=%d  dev[0]=%s sigma" % (
+            name, solver, neval, niter, dt * 1e3, res.seconds * 1e3, neval * niter / dt / 1e9, res.correlated, res.warmup, np.round(dev, 2)), flush=True)
         cfg._engine.close()
 
 
-def stats(names, nseeds, neval, niter, solver="mcmc"):
-    print("%d seeds x cold integrate(solver=%s, neval=%.0e, niter=%d, ignore=1), block=16, automatic chain counts" % (nseeds, solver, neval, niter))
-    print("%-8s %-30s %-9s %-26s %-26s %s" % ("case", "pooled (mean-exact)/err", "max|dev|", "scatter/err (reported)", "scatter/err (statistics.jl)", "s/run"))
+def stats(names, nseeds, neval, niter, solver="mcmc", block=16):
+    print("%d seeds x cold integrate(solver=%s, neval=%.0e, niter=%d, ignore=1), block=%d, automatic chain counts" % (nseeds, solver, neval, niter, block))
+    print("%-8s %-30s %-9s %-26s %-26s %s" % ("case", "pooled (mean-exact)/err", "max|dev|", "scatter/err (reported)", "scatter/err (statistics.jl)", "s/run  warm-up launches/run"))
     for name in names:
-        ms, es, er, secs = [], [], [], 0.0
+        ms, es, er, secs, wu = [], [], [], 0.0, 0
         for seed in range(1, nseeds + 1):
             cfg, f, meas, exact = case(name, seed=seed)
             t0 = time.perf_counter()
-            res = mci.integrate(f, config=cfg, measure=meas, solver=solver, neval=neval, niter=niter)
+            res = mci.integrate(f, config=cfg, measure=meas, solver=solver, neval=neval, niter=niter, block=block)
             secs += time.perf_counter() - t0
+            wu += res.warmup
             ms.append(res._flat_mean)
             es.append(res._flat_std)
             er.append(mci.Result(res.iter_mean, res.iter_std, cfg, res.ignore)._flat_std)
@@ -101,7 +104,7 @@ def stats(names, nseeds, neval, niter, solver="mcmc"):
         maxdev = np.max(np.abs(ms - exact) / es)
         scat = ms.std(0, ddof=1) / np.sqrt((es ** 2).mean(0))
         scat_ref = ms.std(0, ddof=1) / np.sqrt((er ** 2).mean(0))
-        print("%-8s %-30s %-9.2f %-26s %-26s %.3f" % (name, np.round(pooled, 2), maxdev, np.round(scat, 2), np.round(scat_ref, 2), secs / nseeds), flush=True)
+        print("%-8s %-30s %-9.2f %-26s %-26s %.3f  %.2f" % (name, np.round(pooled, 2), maxdev, np.round(scat, 2), np.round(scat_ref, 2), secs / nseeds, wu / nseeds), flush=True)
 
 
 if __name__ == "__main__":
@@ -114,5 +117,5 @@ if __name__ == "__main__":
              int(sys.argv[5]) if len(sys.argv) > 5 else 3, sys.argv[6] if len(sys.argv) > 6 else "mcmc")
     else:
         stats(sys.argv[2].split(","), int(sys.argv[3]) if len(sys.argv) > 3 else 32, int(float(sys.argv[4])) if len(sys.argv) > 4 else 10**7,
-              int(sys.argv[5]) if len(sys.argv) > 5 else 10, sys.argv[6] if len(sys.argv) > 6 else "mcmc")
+              int(sys.argv[5]) if len(sys.argv) > 5 else 10, sys.argv[6] if len(sys.argv) > 6 else "mcmc", int(sys.argv[7]) if len(sys.argv) > 7 else 16)
     mci.shutdown()

@@ -23,7 +23,7 @@ elif [ "$WHAT" = "c3" ]; then        # BASELINE configs[2]: example/bubble.jl un
   CMD="python tools/workload.py c3"
   KERNELS="mci_vegasmc_chains"
 elif [ "$WHAT" = "c5" ]; then        # BASELINE configs[4]: 4 integrals on a 12-D pool under :mcmc, automatic chain length
-  CMD="python tools/workload.py c5"
+  CMD="python tools/workload.py c5 --niter 10 --cold"   # a cold call: ONE integrate(niter = 10) on a fresh problem, every launch in the trace
   KERNELS="mci_mcmc_chains"
 else
   CMD="python bench.py --steps $STEPS --warmup 5 --passes ${PASSES:-40} --no-cpu-baseline"   # ~400 launches: the average is the steady state, not the idle ramp

@@ -173,6 +173,22 @@ def test_mcmc_auto_chain_length_rule():
     assert L.mci_mcmc_auto_chains(10**9, 16, 1, 2, 1, 2, 0, 0) == 131072 // 16                                     # GPU-fill cap
 
 
+def test_inverse_variance_weights_from_16_blocks_underestimate_the_error_by_a_seventh():
+    """A property of the reference's own combination of iterations (statistics.jl:186-220) that every "scatter / reported error" number
+    of this repository has to be read against: the weights 1/sigma_i^2 come from each iteration's block scatter, at the default
+    block = 16 a chi^2 with 15 degrees of freedom.  For independent Gaussian iterations of equal variance the seed scatter of the
+    weighted mean over the reported error is ~sqrt(nu / (nu - 4)) = 1.17 in the limit of many iterations (1.14 for nine), 1.03 at
+    block = 64 -- :vegas included; nothing a sampler does to its chains."""
+    rng = np.random.default_rng(1)
+    for B, lo, hi in ((16, 1.10, 1.19), (64, 1.0, 1.06)):
+        nrep, nit = 4000, 9
+        bm = rng.normal(size=(nrep, nit, B))
+        im, ie = bm.mean(2), bm.std(2, ddof=1) / np.sqrt(B)
+        got = np.array([mci.average(im[r], ie[r], init=1, max=nit)[:2] for r in range(nrep)])
+        ratio = got[:, 0].std(ddof=1) / np.sqrt((got[:, 1] ** 2).mean())
+        assert lo < ratio < hi, (B, ratio)
+
+
 def test_lineage_sums_are_the_scatter_of_the_blocks_weighted_averages():
     """mci_lineage_sums (the error of a run whose iterations continued each other's chains): per observable the sum and the sum of
     squares over the blocks of every block's weighted average over the iterations, with the weights of `average` (statistics.jl:197,

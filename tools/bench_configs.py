@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Development tool (GPU box): throughput of the other BASELINE configs (parity-test cases, not bench lines)."""
+"""Development tool (GPU box): throughput of the other BASELINE configs (parity-test cases, not bench lines): per configuration the
+cold end-to-end rate of one integrate(niter=10) call on a fresh problem and the trained-map rate."""
 import math
 import sys
 import os
@@ -17,15 +18,27 @@ PI = math.pi
 
 
 def run(name, cfg, f, solver, neval, exact, measure=None, niter_train=5, niter=5, nchain=0):
+    """Two numbers per configuration: COLD = a fresh problem's integrate(niter=10), the reference's own usage (main.jl:71-90: one call,
+    ten iterations from an untrained map; code object from the kernel cache, every launch -- warm-up launches of the chain solvers
+    included -- inside the wall time), and TRAINED = `niter` more iterations continuing from the trained map (bench.py's protocol)."""
+    import time
     eng = mci.Engine(cfg, f, measure=measure)
     eng.compile(solver)
-    eng.integrate(solver, neval=neval, niter=niter_train, block=16, seed=1, nchain=nchain)
-    r = eng.integrate(solver, neval=neval, niter=niter, block=16, seed=1, first_iteration=niter_train, ignore=0, nchain=nchain)
+    t0 = time.perf_counter()
+    c = eng.integrate(solver, neval=neval, niter=10, block=16, seed=1, nchain=nchain)
+    cold_wall = time.perf_counter() - t0
+    cms = eng.kernel_times_ms(16)[0]
+    r = eng.integrate(solver, neval=neval, niter=niter, block=16, seed=1, first_iteration=10, ignore=0, nchain=nchain)
     ms, wg, th = eng.kernel_times_ms(niter)
     dev = (r["mean"] - np.atleast_1d(exact)) / r["stdev"]
-    print("%-28s mode=%d lds=%6d B  %8.1f Msamples/s  kernel %.3f ms (wg=%d,th=%d)  mean=%s +- %s  dev_sigma=%s" % (
-        name, eng.table_mode, eng.lds_bytes, neval * niter / r["seconds"] / 1e6, float(np.median(ms)), wg, th,
+    cdev = (c["mean"] - np.atleast_1d(exact)) / c["stdev"]
+    print("%-28s mode=%d lds=%6d B  COLD integrate(niter=10): %8.1f ms = %8.1f Msamples/s end to end (library %.1f ms, %d warm-up launches; kernels, ms: %s; dev_sigma=%s)" % (
+        name, eng.table_mode, eng.lds_bytes, cold_wall * 1e3, neval * 10 / cold_wall / 1e6, c["seconds"] * 1e3, c.get("warmup", 0),
+        " ".join("%.2f" % v for v in cms), np.array2string(cdev, precision=2)), flush=True)
+    print("%-28s                      TRAINED: %8.1f Msamples/s  kernel %.3f ms (wg=%d,th=%d)  mean=%s +- %s  dev_sigma=%s" % (
+        "", neval * niter / r["seconds"] / 1e6, float(np.median(ms)), wg, th,
         np.array2string(r["mean"], precision=8), np.array2string(r["stdev"], formatter={"float_kind": lambda v: "%.2e" % v}), np.array2string(dev, precision=2)), flush=True)
+    eng.close()
 
 
 if __name__ == "__main__":

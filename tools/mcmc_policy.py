@@ -87,7 +87,7 @@ def stats(names, nseeds, neval, niter, solver="mcmc", block=16):
     print("%d seeds x cold integrate(solver=%s, neval=%.0e, niter=%d, ignore=1), block=%d, automatic chain counts" % (nseeds, solver, neval, niter, block))
     print("%-8s %-30s %-9s %-26s %-26s %s" % ("case", "pooled (mean-exact)/err", "max|dev|", "scatter/err (reported)", "scatter/err (statistics.jl)", "s/run  warm-up launches/run"))
     for name in names:
-        ms, es, er, secs, wu = [], [], [], 0.0, 0
+        ms, es, er, us, secs, wu = [], [], [], [], 0.0, 0
         for seed in range(1, nseeds + 1):
             cfg, f, meas, exact = case(name, seed=seed)
             t0 = time.perf_counter()
@@ -97,14 +97,17 @@ def stats(names, nseeds, neval, niter, solver="mcmc", block=16):
             ms.append(res._flat_mean)
             es.append(res._flat_std)
             er.append(mci.Result(res.iter_mean, res.iter_std, cfg, res.ignore)._flat_std)
+            us.append(res.iter_mean[res.ignore:].mean(0))   # plain mean of the counted iterations: free of the correlation between an iteration's mean and its weight
             cfg._engine.close()
-        ms, es, er = np.array(ms), np.array(es), np.array(er)
+        ms, es, er, us = np.array(ms), np.array(es), np.array(er), np.array(us)
         exact = np.ravel(np.array(exact, dtype=float))[:ms.shape[1]]
         pooled = (ms.mean(0) - exact) / (np.sqrt((es ** 2).sum(0)) / nseeds)
         maxdev = np.max(np.abs(ms - exact) / es)
         scat = ms.std(0, ddof=1) / np.sqrt((es ** 2).mean(0))
         scat_ref = ms.std(0, ddof=1) / np.sqrt((er ** 2).mean(0))
-        print("%-8s %-30s %-9.2f %-26s %-26s %.3f  %.2f" % (name, np.round(pooled, 2), maxdev, np.round(scat, 2), np.round(scat_ref, 2), secs / nseeds, wu / nseeds), flush=True)
+        unw = (us.mean(0) - exact) / (us.std(0, ddof=1) / math.sqrt(nseeds))
+        print("%-8s %-30s %-9.2f %-26s %-26s %.3f  %.2f   unweighted pooled: %s" % (name, np.round(pooled, 2), maxdev, np.round(scat, 2), np.round(scat_ref, 2), secs / nseeds, wu / nseeds,
+                                                                          np.round(unw, 2)), flush=True)
 
 
 if __name__ == "__main__":

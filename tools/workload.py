@@ -45,11 +45,25 @@ if __name__ == "__main__":
     ap.add_argument("--nchain", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--deterministic", action="store_true")
+    ap.add_argument("--cold", action="store_true", help="ONE integrate(niter) call on the fresh problem (the reference's usage, main.jl:71-90) "
+                    "and its end-to-end rate, every launch included")
     a = ap.parse_args()
     cfg, f, meas, solver = build(a.workload)
     solver = a.solver or solver
     eng = mci.Engine(cfg, f, measure=meas, deterministic=a.deterministic, **(dict(threads=a.threads) if a.threads else {}))
     eng.set_kernel_timing(1)
+    if a.cold:
+        import time
+        eng.compile(solver)
+        t0 = time.perf_counter()
+        r = eng.integrate(solver, neval=a.neval, niter=a.niter, block=16, seed=1, nchain=a.nchain)
+        wall = time.perf_counter() - t0
+        ms, wg, th = eng.kernel_times_ms(a.niter + 8)
+        print("%s %s COLD integrate(neval=%.0e, niter=%d): %.1f ms wall, library %.1f ms -> %.2f G/s end to end; %d warm-up launches; sample kernels, ms, launch order: %s" % (
+            a.workload, solver, a.neval, a.niter, wall * 1e3, r["seconds"] * 1e3, a.neval * a.niter / wall / 1e9, r.get("warmup", 0), " ".join("%.2f" % v for v in ms)))
+        print("   mean=%s +- %s" % (np.array2string(r["mean"], precision=8), np.array2string(r["stdev"], precision=2)))
+        mci.shutdown()
+        sys.exit(0)
     half = max(a.niter // 2, 1)
     eng.integrate(solver, neval=a.neval, niter=half, block=16, seed=1, nchain=a.nchain)
     r = eng.integrate(solver, neval=a.neval, niter=a.niter - half or 1, block=16, seed=1, nchain=a.nchain, first_iteration=half, ignore=0)

@@ -331,8 +331,10 @@ int mci_last_chain_launch(const mci_problem *prob, int64_t *nchain, int32_t *car
  * prefix-scan walk, no forced launch geometry and no kernel timing; anything else, mode 0, and every call through mci_iteration_run
  * take the launch chain.  mode 1: every call the layout allows, whatever its size, and the kernel is compiled on the spot (mode -1
  * compiles its larger translation unit on a thread of its own once the process has made 256 such calls, and takes the launch chain
- * until the code object is there -- in the kernel cache, where every later process finds it).  A grid-wide wait that runs out of time (2 s: a device shared with other long-running kernels) fails the call with
- * MCI_ERR_HIP instead of hanging, and later calls take the launch chain. */
+ * until the code object is there -- in the kernel cache, where every later process finds it).  A grid-wide wait that runs out of time
+ * (2 s: the workgroups were not all resident, a device shared with other long-running kernels) does not lose the call: mci_integrate
+ * runs the same iterations again through the launch chain (the map is only written back after the last turn), and later calls take
+ * the launch chain. */
 int mci_set_persistent(mci_problem *prob, int32_t mode);
 /* whether the last mci_integrate ran as one persistent launch */
 int mci_last_integrate_persistent(const mci_problem *prob, int32_t *persistent);

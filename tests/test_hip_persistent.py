@@ -191,3 +191,32 @@ def test_two_processes_share_the_device_with_persistent_launches():
     a, b = (tuple(float(v) for v in so.split()) for so, _ in outs)
     assert abs(a[0] - 2.0 / 3.0) < 1e-3 and abs(a[1] - 2.0 / 3.0) < 1e-3
     np.testing.assert_allclose(a, b, rtol=1e-6)   # same seeds, same iterations: the same runs up to the order of the histogram atomics
+
+
+def test_a_stalled_persistent_launch_falls_back_to_the_launch_chain(oracle, monkeypatch):
+    """The grid-wide wait of the persistent launch needs all its workgroups resident; on a device shared with another long-running kernel
+    a wait can run out of time.  The call must not be lost: the map is written back after the LAST turn only, so mci_integrate resets the
+    counters and histogram buffers, rewinds the iteration log and runs the SAME iterations through the launch chain (and later calls take
+    the chain).  Forced here with the test hook of csrc/mci_debug.h: a wait of one 10 ns tick."""
+    from mcintegration_jl_amd._lib import check, lib
+    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
+    c, cfg, eng, ocfg = make("c1_log_over_sqrt", oracle)
+    eng.set_persistent("on")
+    check(lib().mci_debug_persist_spin_ticks(eng.p, 1))
+    r = eng.integrate("vegas", neval=40000, niter=6, block=16, seed=SEED)
+    assert not eng.last_integrate_persistent()                      # it ran as a launch chain in the end
+    c2, cfg2, chain, _ = make("c1_log_over_sqrt", oracle)
+    chain.set_persistent("off")
+    q = chain.integrate("vegas", neval=40000, niter=6, block=16, seed=SEED)
+    np.testing.assert_allclose(r["iter_mean"], q["iter_mean"], rtol=1e-9)      # the same iterations as a chain that never tried
+    np.testing.assert_allclose(r["iter_std"], q["iter_std"], rtol=1e-6)
+    np.testing.assert_allclose(eng.grid(0), chain.grid(0), rtol=0, atol=1e-9)
+    o = ocfg.integrate(oracle.VEGAS, c["oname"], c["ud"], neval=40000, niter=6, block=16, seed=SEED)
+    np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-4)
+    assert r["neval"] == 6 * 40000
+    check(lib().mci_debug_persist_spin_ticks(eng.p, 200000000))
+    r2 = eng.integrate("vegas", neval=40000, niter=3, block=16, seed=SEED, first_iteration=6, ignore=0)     # later calls: the launch chain
+    q2 = chain.integrate("vegas", neval=40000, niter=3, block=16, seed=SEED, first_iteration=6, ignore=0)
+    assert not eng.last_integrate_persistent()
+    np.testing.assert_allclose(r2["iter_mean"], q2["iter_mean"], rtol=1e-9)
+    eng.check_status()

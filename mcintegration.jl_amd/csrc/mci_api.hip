@@ -2589,8 +2589,11 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
         HIPCHK(hipStreamSynchronize(p->ctx->stream));
         mci_lineage_sums(bm.data(), a->niter, nb, s.nobs, res->iter_std, ignore + 1, a->niter, sums.data(), sums.data() + s.nobs);
         if ((rc = comm_sum_host(p, sums.data(), (int)sums.size()))) return rc;
-        std::vector<double> lm(s.nobs);
-        mci_mean_std(sums.data(), sums.data() + s.nobs, s.nobs, block, lm.data(), res->stdev);
+        std::vector<double> lm(s.nobs), le(s.nobs);
+        mci_mean_std(sums.data(), sums.data() + s.nobs, s.nobs, block, lm.data(), le.data());
+        // (a column that is identically zero -- the imaginary part of a real integrand -- keeps the reference's 1e-10-regularised error,
+        // statistics.jl:192-198, instead of an exact 0)
+        for (int o = 0; o < s.nobs; ++o) res->stdev[o] = le[o] > 0.0 ? le[o] : res->stdev[o];
         res->correlated = 1;
     }
     return MCI_OK;

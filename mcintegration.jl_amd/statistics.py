@@ -67,7 +67,8 @@ class Result:
             if sum_ranks is not None:
                 tot = sum_ranks(np.concatenate([s1, s2]))
                 s1, s2 = tot[:nobs], tot[nobs:]
-            self._flat_std = mean_std(s1, s2, block if block else np.asarray(block_mean).shape[1])[1]
+            le = mean_std(s1, s2, block if block else np.asarray(block_mean).shape[1])[1]
+            self._flat_std = np.where(le > 0.0, le, self._flat_std)   # (an identically-zero column keeps the reference's 1e-10-regularised error)
         self.mean, self.stdev, self.chi2 = self._shape(self._flat_mean), self._shape(self._flat_std), self._shape(self._flat_chi2)
         self.iterations = [(self._shape(self.iter_mean[i]), self._shape(self.iter_std[i]), config) for i in range(niter)]
 

@@ -115,40 +115,6 @@ template <int DPC, int J> __device__ __forceinline__ double block_u12(const u32x
     else return u12_word(J == 0 ? r.x : J == 1 ? r.y : J == 2 ? r.z : r.w);
 }
 
-// Draw -> Philox words of the :vegas sample stream.  DPC = 2: draw k is the word pair (2k, 2k + 1) of the counter sequence (52 of its 64
-// bits); DPC = 4: word k (the opt-in 32-bit stream); DPC = 3, the PACKED 52-bit stream: three draws share FIVE words [D, E, A0, A1, A2]
-// -- draw j's low mantissa word is A_j as it is, its high 20 mantissa bits are bits 0-19 (j = 0), 20-39 (j = 1), 44-63 (j = 2) of E:D --
-// so 16 draws take 27 words = 7 Philox blocks instead of 8, and a draw costs 4/3 extraction instructions instead of 2.
-// A chunk is what ONE more Philox block completes: chunk c = the draws whose last word lies in block c (they may also read block c - 1).
-template <int DPC> constexpr int stream_last_word(int k) { return DPC == 2 ? 2 * k + 1 : DPC == 4 ? k : 5 * (k / 3) + 2 + k % 3; }
-template <int DPC> constexpr int stream_blocks(int ndraw) { return ndraw > 0 ? stream_last_word<DPC>(ndraw - 1) / 4 + 1 : 0; }
-template <int DPC> constexpr int chunk_first(int c) { // first draw completed by block c (== the draw count once every draw is complete)
-    int k = 0;
-    while (stream_last_word<DPC>(k) / 4 < c) ++k;
-    return k;
-}
-template <int DPC> constexpr int chunk_max() { return DPC == 2 ? 2 : DPC == 4 ? 4 : 3; } // draws per chunk, at most
-// word i of the counter sequence, given block c (r) and block c - 1 (rp)
-template <int C, int I> __device__ __forceinline__ u32 stream_word(const u32x4 &r, const u32x4 &rp) {
-    static_assert(I / 4 == C || I / 4 == C - 1, "a draw reads the block that completes it and the one before");
-    const u32x4 &q = I / 4 == C ? r : rp;
-    return I % 4 == 0 ? q.x : I % 4 == 1 ? q.y : I % 4 == 2 ? q.z : q.w;
-}
-// uniform-plus-one of draw K, completed by block C
-template <int DPC, int C, int K> __device__ __forceinline__ double stream_u12(const u32x4 &r, const u32x4 &rp) {
-    if constexpr (DPC == 2) return u12(stream_word<C, 2 * K>(r, rp), stream_word<C, 2 * K + 1>(r, rp));
-    else if constexpr (DPC == 4) return u12_word(stream_word<C, K>(r, rp));
-    else {
-        constexpr int b = 5 * (K / 3), j = K % 3;
-        const u32 lo = stream_word<C, b + 2 + j>(r, rp);
-        u32 hi;
-        if constexpr (j == 0) hi = (stream_word<C, b>(r, rp) & 0xFFFFFu) | 0x3FF00000u;
-        else if constexpr (j == 1) hi = (__builtin_amdgcn_alignbit(stream_word<C, b + 1>(r, rp), stream_word<C, b>(r, rp), 20u) & 0xFFFFFu) | 0x3FF00000u;
-        else hi = __builtin_amdgcn_alignbit(0x3FFu, stream_word<C, b + 1>(r, rp), 12u);
-        return __longlong_as_double((i64)(((u64)hi << 32) | lo));
-    }
-}
-
 enum { STREAM_VEGAS = 0, STREAM_POOLINIT = 1, STREAM_MC_INIT = 2, STREAM_MC_STEP = 3, STREAM_MCMC_INIT = 4, STREAM_MCMC_STEP = 5, STREAM_MCMC_GROUP = 6, STREAM_MC_GROUP = 7 };
 enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_RESCALE_NONFINITE = 8, ST_MCMC_INIT = 16, ST_PERSIST_STALL = 32 };
 
@@ -863,7 +829,7 @@ template <class Cfg> constexpr bool pipe_eligible() {
 }
 template <class Cfg, bool KV, int DPC> __device__ __forceinline__ void draw_sample_pipe(const RoundKeys<KV> &keys, u32 stream, u64 index, Sample<Cfg> &s,
                                                                                         const PendingHist<Cfg> &pend, PendingHist<Cfg> &next, double *sH) {
-    constexpr int NCH = stream_blocks<DPC>(Cfg::NDRAW), MAXC = chunk_max<DPC>();
+    constexpr int NCH = (Cfg::NDRAW + DPC - 1) / DPC;
     constexpr int LAG = DPC == 4 ? 0 : 1; // blocks between a read and its use: with four reads per block they cover each other (and LAG 1 spills at 1024 threads)
     constexpr unsigned long long ALL = Cfg::NDRAW >= 64 ? ~0ull : ((1ull << Cfg::NDRAW) - 1ull);
     const u32 ilo = (u32)index, ihi = (u32)(index >> 32);
@@ -873,36 +839,32 @@ template <class Cfg, bool KV, int DPC> __device__ __forceinline__ void draw_samp
     typedef double pair_d2 __attribute__((ext_vector_type(2)));
     pair_d2 pe[Cfg::NDRAW];
     double pdy[Cfg::NDRAW];
-    u32x4 rp = {0u, 0u, 0u, 0u};
     static_for<0, NCH + LAG>([&](auto C) {
         constexpr int c = decltype(C)::value;
         if constexpr (c < NCH) {
             const u32x4 r = philox4x32_10<KV>(ilo, ihi, (u32)c, stream, keys);
-            constexpr int k0 = chunk_first<DPC>(c), k1 = chunk_first<DPC>(c + 1) < Cfg::NDRAW ? chunk_first<DPC>(c + 1) : Cfg::NDRAW;
-            static_for<0, MAXC>([&](auto H) { // bins, fractions and table reads of the draws this block completes
-                constexpr int k = k0 + decltype(H)::value;
-                if constexpr (k < k1) {
+            static_for<0, DPC>([&](auto H) { // bins, fractions and table reads of this block's draws
+                constexpr int k = DPC * c + decltype(H)::value;
+                if constexpr (k < Cfg::NDRAW) {
                     constexpr int leaf = Cfg::draw_leaf(k), N = Cfg::leaf_nbin(leaf);
-                    const double yn = cont_yn<N, true, true>(stream_u12<DPC, c, k>(r, rp)); // as draw_leaf forms it
+                    const double yn = cont_yn<N, true, true>(block_u12<DPC, decltype(H)::value>(r)); // as draw_leaf forms it
                     s.bin[k] = next.bin[k] = (int)yn; // (the bins go straight into the record the NEXT trip adds from)
                     pdy[k] = __builtin_amdgcn_fract(yn);
                     typedef const pair_d2 __attribute__((address_space(3))) lds_pair;
                     pe[k] = *(lds_pair *)(((u32)s.bin[k] << 4) + (u32)(Cfg::leaf_poff(leaf) * 8));
                 }
             });
-            static_for<0, MAXC>([&](auto H) { // as many of the previous sample's histogram adds
-                constexpr int k = k0 + decltype(H)::value;
-                if constexpr (k < k1) hist_add_draw<Cfg, k>(pend.bin[k], pend.wh, sH);
+            static_for<0, DPC>([&](auto H) { // two of the previous sample's histogram adds
+                constexpr int k = DPC * c + decltype(H)::value;
+                if constexpr (k < Cfg::NDRAW) hist_add_draw<Cfg, k>(pend.bin[k], pend.wh, sH);
             });
-            rp = r;
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (c >= LAG) { // the draws whose pairs were asked for LAG blocks ago: x = g[iy] + dy * (g[iy+1] - g[iy])  sampler.jl:299
             constexpr int cc = c - LAG;
-            constexpr int k0 = chunk_first<DPC>(cc), k1 = chunk_first<DPC>(cc + 1) < Cfg::NDRAW ? chunk_first<DPC>(cc + 1) : Cfg::NDRAW;
-            static_for<0, MAXC>([&](auto H) {
-                constexpr int k = k0 + decltype(H)::value;
-                if constexpr (k < k1) {
+            static_for<0, DPC>([&](auto H) {
+                constexpr int k = DPC * cc + decltype(H)::value;
+                if constexpr (k < Cfg::NDRAW) {
                     s.x[k] = pe[k].x + pdy[k] * pe[k].y;
                     const double raw = pe[k].y;
                     pack_bin<Cfg, k>(s);
@@ -912,18 +874,18 @@ template <class Cfg, bool KV, int DPC> __device__ __forceinline__ void draw_samp
                         constexpr int i = decltype(I)::value;
                         if constexpr (((Cfg::own_mask(i) >> k) & 1ull) && Cfg::own_mask(i) != ALL) s.jaci[i] *= raw;
                     });
-                    if constexpr ((k + 1) % kJacGroup == 0 || k + 1 >= Cfg::NDRAW) { // close a group of draws: apply its N factors
-                        constexpr int hi = k + 1, lo = (k / kJacGroup) * kJacGroup;
-                        constexpr double sc = jac_scale_product<Cfg>(ALL, lo, hi);
-                        if constexpr (sc != 1.0) s.jac *= sc;
-                        static_for<0, Cfg::NI>([&](auto I) {
-                            constexpr int i = decltype(I)::value;
-                            constexpr double si = jac_scale_product<Cfg>(Cfg::own_mask(i), lo, hi);
-                            if constexpr (Cfg::own_mask(i) != ALL && si != 1.0) s.jaci[i] *= si;
-                        });
-                    }
                 }
             });
+            if constexpr (((DPC * cc + DPC) % kJacGroup == 0 || DPC * cc + DPC >= Cfg::NDRAW)) { // close a group of draws: apply its N factors
+                constexpr int hi = DPC * cc + DPC, lo = ((hi - 1) / kJacGroup) * kJacGroup;
+                constexpr double sc = jac_scale_product<Cfg>(ALL, lo, hi);
+                if constexpr (sc != 1.0) s.jac *= sc;
+                static_for<0, Cfg::NI>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    constexpr double si = jac_scale_product<Cfg>(Cfg::own_mask(i), lo, hi);
+                    if constexpr (Cfg::own_mask(i) != ALL && si != 1.0) s.jaci[i] *= si;
+                });
+            }
             if constexpr (c < NCH) __builtin_amdgcn_sched_barrier(0);
         }
     });
@@ -1108,11 +1070,6 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     // round keys in VGPRs: 20 registers, for the pipelined loop when the host found them free
     constexpr bool KV = MCI_PIPE_VGPR_KEYS != 0 && pipe_eligible<Cfg>() && !SPLIT && Cfg::EC_DOUBLES == 0;
     constexpr int DPC = Cfg::RNG_BITS == 32 ? 4 : 2;           // draws per Philox block of the :vegas sample stream
-#ifdef MCI_PROTO_PACK
-    constexpr int DPCP = Cfg::RNG_BITS == 32 ? 4 : 3;          // PROTOTYPE: the packed 52-bit stream in the pipelined loop only
-#else
-    constexpr int DPCP = DPC;
-#endif
     const RoundKeys<KV> keys = make_round_keys<KV>((u32)a.seed, (u32)(a.seed >> 32));
     const i64 mfreq = a.measurefreq;
     i64 mrem = mfreq == 1 ? 0 : ((i64)slice * T + tid + 1) % mfreq;
@@ -1202,18 +1159,18 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
         for (; n + stride < a.neval_per_block; n += 2 * stride) {
             {
                 Sample<Cfg> s;
-                draw_sample_pipe<Cfg, KV, DPCP>(keys, stream, (u64)(B * a.neval_per_block + n), s, pa, pb, sH);
+                draw_sample_pipe<Cfg, KV, DPC>(keys, stream, (u64)(B * a.neval_per_block + n), s, pa, pb, sH);
                 process(n, s, pb.wh);
             }
             {
                 Sample<Cfg> s;
-                draw_sample_pipe<Cfg, KV, DPCP>(keys, stream, (u64)(B * a.neval_per_block + n + stride), s, pb, pa, sH);
+                draw_sample_pipe<Cfg, KV, DPC>(keys, stream, (u64)(B * a.neval_per_block + n + stride), s, pb, pa, sH);
                 process(n + stride, s, pa.wh);
             }
         }
         if (n < a.neval_per_block) {
             Sample<Cfg> s;
-            draw_sample_pipe<Cfg, KV, DPCP>(keys, stream, (u64)(B * a.neval_per_block + n), s, pa, pb, sH);
+            draw_sample_pipe<Cfg, KV, DPC>(keys, stream, (u64)(B * a.neval_per_block + n), s, pa, pb, sH);
             process(n, s, pb.wh);
             flush(pb);
         } else flush(pa);

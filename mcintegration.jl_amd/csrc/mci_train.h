@@ -826,7 +826,8 @@ __device__ __forceinline__ bool persist_wait(const PersistArgs &f, u64 t0, u64 t
             // (the 24-bit turn count wraps: compared as a signed distance)
             if ((w & kPersistArriveMask) >= t0 && (long long)(((w >> kPersistDoneShift) - t1) << kPersistDoneShift) >= 0) break;
             __builtin_amdgcn_s_sleep(1);
-            if ((++n & 255u) == 0u &&
+            // (the clock is looked at every 256th poll; a limit of a few ticks -- the test hook of csrc/mci_debug.h -- at every poll)
+            if (((++n & 255u) == 0u || f.spin_ticks < 256ull) &&
                 (__hip_atomic_load(&f.ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull || wall_clock64() - start > f.spin_ticks)) {
                 ok = 0;
                 break;

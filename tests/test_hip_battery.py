@@ -426,7 +426,8 @@ def test_report_config_prints_the_acceptance_table(capsys):
 def closure_path(request, monkeypatch):
     """Python closures reach the kernels two ways: as host batch callbacks (trace=False) or written out as device source by the tracer
     (the default).  The closure-vs-device-source tests below run under both."""
-    import mcintegration_jl_amd.integrate as I
+    import sys
+    I = sys.modules[integrate.__module__]          # (the module: the package exports the function under the same name)
     monkeypatch.setattr(I, "TRACE_DEFAULT", False if request.param == "host" else None)
     return request.param
 

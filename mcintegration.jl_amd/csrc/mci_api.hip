@@ -1715,6 +1715,19 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.tile_bins = p->d_tile_bins;
     a.tile_stride = nblocks * nevalperblock;
     a.nrows = nrows;
+    // Split-all :vegas: the replay partitions a block's parked samples on its own.  Every replay workgroup zeroes and flushes a whole LDS
+    // tile (C4: 128 KB) and every row it writes is read again by the merge, so it runs ~2 workgroups per CU and tile pair instead of one
+    // per sample-pass row (C4: 512 instead of 2048 workgroups, 67 instead of 262 MB of partial histograms written and read back:
+    // k_hist_stage1 100 -> 25 us, profiles/r04_c4_kernel_stats.txt).  The partition only decides which workgroup adds a sample to the
+    // histogram: sums differ by reassociation.
+    int64_t hist_rows = nrows;
+    if (split && s.split_all) {
+        int64_t rwpb = 512 / (nblocks * s.ntile);
+        if (rwpb > wpb) rwpb = wpb;
+        if (rwpb < 1) rwpb = 1;
+        a.tiles_wpb = (int)rwpb;
+        a.tiles_rows = hist_rows = nblocks * rwpb;
+    }
     if (s.host_integrand) {
         // "batch callback": the closure cannot run on the device, so the draws of this launch go to the host (SoA,
         // x[k*n + i]), the callback fills w[q*n + i], and the sample kernel regenerates the same draws (same Philox
@@ -1920,7 +1933,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
     if (a.hold_hist && (rc = hold_publish(p, nevalperblock / nchain, solver != MCI_VEGAS && p->last_carried))) return rc;
     if (split)
-        HIPCHK(hipModuleLaunchKernel(p->f_tiles[kern == kSlotVegasAny ? 1 : 0], (unsigned)(((nrows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+        HIPCHK(hipModuleLaunchKernel(p->f_tiles[kern == kSlotVegasAny ? 1 : 0], (unsigned)(((hist_rows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
     p->ev_valid[slot] = p->time_this_launch;
     p->launches += 1;
@@ -2003,7 +2016,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     // (reading a few partial rows directly in the second stage instead -- no first-stage launch when an iteration is launch-bound --
     // was measured at neval = 1e4: k_finish grows by what the launch took, 26 us per iteration either way)
     if (hist_lds && s.nbin > 0 && !atomic_flush)
-        hipLaunchKernelGGL(mci::k_hist_stage1, dim3(nb256, mci_problem::kGroups), dim3(256), 0, st, p->d_part_hist, (int)nrows, s.nbin,
+        hipLaunchKernelGGL(mci::k_hist_stage1, dim3(nb256, mci_problem::kGroups), dim3(256), 0, st, p->d_part_hist, (int)hist_rows, s.nbin,
                            (int)mci_problem::kGroups, p->d_stage1);
     HIPCHK(hipGetLastError());
     mci::MergeArgs &m = p->merge;

@@ -147,6 +147,9 @@ struct BatchArgs {
     u32 *tile_bins;         // [tdraw_words][tile_stride]  32 / ceil(log2(nbin)) bins per word
     i64 tile_stride;        // samples of this launch
     i64 nrows;              // partial rows (block, slice) of this launch
+    int tiles_wpb;          // split-all :vegas: replay workgroups per block and tile (mci_vegas_tiles has its own, coarser, partition of a
+                            // block's samples: every one of its workgroups flushes a whole LDS tile), 0 = wg_per_block
+    i64 tiles_rows;         // ... and the partial-histogram rows they write (= blocks * tiles_wpb), 0 = nrows
     // host integrand ("batch callback", Cfg::HOST_INTEGRAND): weights evaluated on the host for exactly the draws
     // this launch regenerates, host_w[q * tile_stride + sample]
     const double *host_w;
@@ -1200,7 +1203,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 #ifndef MCI_THREADS
 #define MCI_THREADS 256 // (the JIT translation units define it: the workgroup size their kernels are compiled for)
 #endif
-constexpr int kTilesU = MCI_THREADS >= 768 ? 8 : 4; // replay: samples per lane and trip (measured: 8 at 768 threads 6.46 -> 6.38 ms, 16 slower; 4 at 512)
+constexpr int kTilesU = MCI_THREADS >= 768 ? 8 : 4; // replay: samples per lane and trip (measured: 8 at 768 threads 6.46 -> 6.38 ms, 16 slower; 4 at 512; with the 16-byte loads of four consecutive samples per lane: 4 | 8 | 16 at 1024 threads 4.89 | 4.90 | 5.5 ms for sample pass + replay)
 // Replay with the tile's histograms BIN-MAJOR in LDS, sH[bin * G + grid], and the lanes of a wave walking the tile's G grids in
 // skewed order (lane l adds to grid (d + l % G) % G at step d).  A wave's ds_add_f64 then lands on G different grids at once and
 // the lanes that share a grid (64 / G of them) share only the 2 bank pairs {grid, grid + 16} of a 16-grid tile, instead of 64
@@ -1254,12 +1257,13 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
     const i64 q = (i64)blockIdx.x / 8;
     const int tile = T0 + (int)(q % NTM);
     const i64 rowid = (q / NTM) * 8 + (i64)(blockIdx.x % 8);
-    if (rowid >= a.nrows) return; // the grid is rounded up to a multiple of 8 * NTM
-    const i64 lb = rowid / a.wg_per_block;
-    const int slice = (int)(rowid % a.wg_per_block);
+    const int wpb = a.tiles_wpb > 0 ? a.tiles_wpb : a.wg_per_block;
+    if (rowid >= (a.tiles_rows > 0 ? a.tiles_rows : a.nrows)) return; // the grid is rounded up to a multiple of 8 * NTM
+    const i64 lb = rowid / wpb;
+    const int slice = (int)(rowid % wpb);
     for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
     __syncthreads();
-    const i64 stride = (i64)a.wg_per_block * T;
+    const i64 stride = (i64)wpb * T;
     static_for<T0, Cfg::NTILE>([&](auto TT) {
         constexpr int tt = decltype(TT)::value;
         if (tile == tt) {
@@ -1267,10 +1271,54 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
             // 512-thread workgroup per CU, so memory-level parallelism has to come from the loop body)
             constexpr int U = kTilesU;
             constexpr int NWORD = tdraw_words<Cfg>();
-            for (i64 n0 = (i64)slice * T + tid; n0 < a.neval_per_block; n0 += stride * U) {
+            // A lane takes FOUR consecutive samples at a time: their weights and each of their bin words are then 16-byte loads (a wave
+            // reads 1 KB per instruction instead of 256 B: 7 wide loads per four samples instead of 24 narrow ones), which is what a pass
+            // that streams 5 GB wants.  Needs the block's first sample 16-byte aligned in both parked arrays; otherwise sample by sample.
+            static_assert(U % 4 == 0, "the replay takes its samples in groups of four");
+            const bool wide = (a.neval_per_block & 3) == 0 && (a.tile_stride & 3) == 0;
+            const i64 per = wide ? 4 : 1; // consecutive samples per lane and group
+            for (i64 n0 = ((i64)slice * T + tid) * per; n0 < a.neval_per_block; n0 += stride * U) {
                 double wh[U][Cfg::NI];
                 u32 word[U][NWORD > 0 ? NWORD : 1];
                 bool live[U];
+                static_for<0, NWORD>([&](auto J) { // (words no draw of this tile lives in are never loaded)
+                    static_for<0, U>([&](auto Uu) { word[decltype(Uu)::value][decltype(J)::value] = 0u; });
+                });
+                if (wide) {
+                    static_for<0, U / 4>([&](auto Q) {
+                        constexpr int q = decltype(Q)::value;
+                        const i64 n = n0 + (i64)q * stride * 4; // this group's first sample (a multiple of four, like the block's length)
+                        const bool lv = n < a.neval_per_block;
+                        const i64 idx = lb * a.neval_per_block + (lv ? n : n0);
+                        static_for<0, 4>([&](auto Vv) { live[4 * q + decltype(Vv)::value] = lv; });
+                        typedef double d2 __attribute__((ext_vector_type(2)));
+                        typedef u32 u4 __attribute__((ext_vector_type(4)));
+                        static_for<0, Cfg::NI>([&](auto I) {
+                            constexpr int i = decltype(I)::value;
+                            const d2 *pw = reinterpret_cast<const d2 *>(a.tile_w + (i64)i * a.tile_stride + idx);
+                            const d2 w01 = pw[0], w23 = pw[1];
+                            wh[4 * q + 0][i] = w01.x;
+                            wh[4 * q + 1][i] = w01.y;
+                            wh[4 * q + 2][i] = w23.x;
+                            wh[4 * q + 3][i] = w23.y;
+                        });
+                        static_for<0, NWORD>([&](auto J) {
+                            constexpr int j = decltype(J)::value;
+                            constexpr bool need = [] { // only the words that hold a draw of this tile
+                                for (int k = 0; k < Cfg::NDRAW; ++k)
+                                    if (is_tdraw<Cfg>(k) && Cfg::leaf_tile(Cfg::draw_leaf(k)) == tt && tdraw_in_word<Cfg>(tdraw_pos<Cfg>(k), j)) return true;
+                                return false;
+                            }();
+                            if constexpr (need) {
+                                const u4 wv = *reinterpret_cast<const u4 *>(a.tile_bins + (i64)j * a.tile_stride + idx);
+                                word[4 * q + 0][j] = wv.x;
+                                word[4 * q + 1][j] = wv.y;
+                                word[4 * q + 2][j] = wv.z;
+                                word[4 * q + 3][j] = wv.w;
+                            }
+                        });
+                    });
+                } else
                 static_for<0, U>([&](auto Uu) {
                     constexpr int u = decltype(Uu)::value;
                     const i64 n = n0 + (i64)u * stride;

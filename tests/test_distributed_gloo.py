@@ -107,7 +107,7 @@ def _gpu_worker(rank, world, port, solver, q):
     from mcintegration_jl_amd.comm import TorchDistComm
     res = mci.integrate(mci.catalog.sphere2(), var=mci.Continuous(0.0, 1.0), dof=[[2], [3]], solver=solver, neval=64000,
                         niter=4, block=8, seed=77, comm=TorchDistComm(), nchain=4, device=0)
-    q.put((rank, res.iter_mean, res.iter_std, res.config._engine.grid(0)))
+    q.put((rank, res.iter_mean, res.iter_std, res.config._engine.grid(0), np.asarray(res._flat_std), bool(res.correlated)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -128,7 +128,15 @@ def test_two_ranks_on_one_gpu_equal_one_rank(solver):
         assert p.exitcode == 0
     ref = mci.integrate(mci.catalog.sphere2(), var=mci.Continuous(0.0, 1.0), dof=[[2], [3]], solver=solver, neval=64000,
                         niter=4, block=8, seed=77, nchain=4, device=0)
-    for rank, im, ie, grid in outs:
+    # the chain solvers ran many chains per block and carried them: both ranks report the block-lineage error, from the lineage sums of
+    # ALL blocks (each rank's four, summed through the communicator: mci_lineage_sums + comm.sum_host) -- the one-rank run's
+    assert [o[5] for o in outs] == [solver != "vegas"] * 2 and bool(ref.correlated) == (solver != "vegas")
+    np.testing.assert_array_equal(outs[0][4], outs[1][4])
+    if solver == "vegasmc":
+        np.testing.assert_allclose(outs[0][4], ref._flat_std, rtol=1e-3)
+    elif solver == "mcmc":
+        assert np.all(outs[0][4] < 3 * ref._flat_std) and np.all(outs[0][4] > ref._flat_std / 3)
+    for rank, im, ie, grid, _sd, _corr in outs:
         if solver == "mcmc":   # see test_two_ranks_equal_one_rank: exact on the common first grid, statistical afterwards
             np.testing.assert_allclose(im[0], ref.iter_mean[0], rtol=1e-9)
             assert np.all(np.abs(im - ref.iter_mean) < 5 * np.hypot(ie, ref.iter_std) + 1e-12)

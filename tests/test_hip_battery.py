@@ -299,6 +299,8 @@ def test_library_rccl_single_rank_and_torch_reducer():
     comm = RcclComm(0, 1, RcclComm.unique_id(), 0)
     comm.all_reduce(eng)
     np.testing.assert_array_equal(eng.get_packed(), before)
+    # mci_comm_sum (the lineage sums of a run of carried chains go through it): a few host doubles through the library's communicator
+    np.testing.assert_array_equal(comm.sum_host(eng, np.array([1.5, -2.0, 3.25e-7])), [1.5, -2.0, 3.25e-7])
     res = integrate(mci.catalog.x2y2(), var=Continuous(0.0, 1.0), dof=[[2]], solver="vegas", neval=1e5, seed=4, comm=comm)
     check(res, 2.0 / 3.0)
     # the chain solvers through the N > 1 code path (all-reduce of `visited`, then doReweight! on every rank): same numbers as alone
@@ -308,6 +310,8 @@ def test_library_rccl_single_rank_and_torch_reducer():
         a = integrate(mci.catalog.sphere2(), comm=comm, var=Continuous(0.0, 1.0), **kw)
         b = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), **kw)
         np.testing.assert_allclose(a.mean, b.mean, rtol=1e-6)
+        assert a.correlated == b.correlated
+        np.testing.assert_allclose(a._flat_std, b._flat_std, rtol=1e-4)      # the lineage error, per iteration through the communicator | inside the library
         check(a, [PI / 4.0, 4.0 * PI / 3.0 / 8])
 
 

@@ -228,6 +228,7 @@ struct mci_problem {
     // from launch to launch) and nothing is ever repeated or left out again (no selection on what an iteration measured)
     bool mcmc_warm = false;
     bool hold_valid = false;                // the launch `hold_max` comes from was long enough for its own holds
+    bool hold_measured = false;             // the last :mcmc launch measured its holding times at all (not with a host integrand)
     int64_t hold_prev = 0;                  // hold_max of the launch before that, once warm
     // per-block means of the chain solvers' iterations (MergeArgs::block_means): rows [blk_rows][blk_stride = local blocks * nobs];
     // what the block-lineage error of a run of carried chains is computed from (mci_lineage_sums)
@@ -1931,6 +1932,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         }
     } else
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
+    if (solver == MCI_MCMC) p->hold_measured = a.hold_hist != nullptr;
     if (a.hold_hist && (rc = hold_publish(p, nevalperblock / nchain, solver != MCI_VEGAS && p->last_carried))) return rc;
     if (split)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles[kern == kSlotVegasAny ? 1 : 0], (unsigned)(((hist_rows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
@@ -2999,7 +3001,7 @@ int mci_mcmc_launch_valid(mci_problem *p, int32_t *valid, int32_t *warm, int64_t
     HIPCHK(hipSetDevice(p->ctx->device));
     int rc = hold_consume(p); // (waits for the last :mcmc launch's sample kernel if its histogram is still in flight)
     if (rc) return rc;
-    if (valid) *valid = p->hold_valid ? 1 : 0;
+    if (valid) *valid = (p->hold_valid || !p->hold_measured) ? 1 : 0; // (nothing measured: nothing to hold the launch against)
     if (warm) *warm = p->mcmc_warm ? 1 : 0;
     if (chain_len) *chain_len = p->hold_len;
     if (hold_max) *hold_max = p->hold_max;

@@ -329,14 +329,14 @@ end
 param!(t::Tape, v::Float64) = (push!(t.params, v); node!(t, :ud, Int32(length(t.params) - 1)))
 lift(t::Tape, v) = v isa Sym ? v : v isa Real ? constant!(t, v) : throw(TraceError("cannot use $(typeof(v)) in an integrand expression"))
 op(s::Sym) = s.tape.ops[s.id]
-isconst(s::Sym, v::Float64) = op(s) === :const && s.tape.args[s.id][1] === v      # (=== on Float64 tells 0.0 from -0.0)
+is_const(s::Sym, v::Float64) = op(s) === :const && s.tape.args[s.id][1] === v      # (=== on Float64 tells 0.0 from -0.0)
 function binary(o::Symbol, a, b)
     t = a isa Sym ? a.tape : b.tape
     a, b = lift(t, a), lift(t, b)
-    o === :+ && (isconst(a, 0.0) || isconst(b, 0.0)) && return isconst(a, 0.0) ? b : a
-    o === :* && (isconst(a, 1.0) || isconst(b, 1.0)) && return isconst(a, 1.0) ? b : a
-    o === :- && isconst(b, 0.0) && return a
-    o === :/ && isconst(b, 1.0) && return a
+    o === :+ && (is_const(a, 0.0) || is_const(b, 0.0)) && return is_const(a, 0.0) ? b : a
+    o === :* && (is_const(a, 1.0) || is_const(b, 1.0)) && return is_const(a, 1.0) ? b : a
+    o === :- && is_const(b, 0.0) && return a
+    o === :/ && is_const(b, 1.0) && return a
     node!(t, o, a, b)
 end
 for o in (:+, :-, :*, :/)
@@ -470,9 +470,9 @@ function parametrized(f, t::Tape)
     nf == 0 && return f
     vals = Any[getfield(f, i) for i in 1:nf]
     any(v -> v isa AbstractFloat && isfinite(v), vals) || return f
-    new = Any[(v isa AbstractFloat && isfinite(v)) ? param!(t, Float64(v)) : v for v in vals]
+    flds = Any[(v isa AbstractFloat && isfinite(v)) ? param!(t, Float64(v)) : v for v in vals]
     try
-        return typeof(f).name.wrapper{map(typeof, new)...}(new...)
+        return typeof(f).name.wrapper{map(typeof, flds)...}(flds...)
     catch
         empty!(t.params)
         return f

@@ -678,7 +678,10 @@ struct Result
     mean::Vector{Float64}; stdev::Vector{Float64}; chi2::Vector{Float64}
     neval::Int; ignore::Int; config::Configuration
     iter_mean::Matrix{Float64}; iter_std::Matrix{Float64}        # [niter, nobs]
+    correlated::Bool     # the iterations continued each other's chains: `stdev` is the block-lineage error (mci_lineage_sums), not statistics.jl:198
+    warmup::Int          # launches that were run again instead of being counted (automatic :mcmc chain lengths)
 end
+Result(mean, stdev, chi2, neval, ignore, config, iter_mean, iter_std) = Result(mean, stdev, chi2, neval, ignore, config, iter_mean, iter_std, false, 0)
 
 """
     average(iter_mean, iter_std; init=1, max=length(iter_mean))  -> (mean, std, chi2)
@@ -746,6 +749,8 @@ function report(r::Result, ignore::Int=r.ignore; pick::Int=1, name=nothing, verb
                 println(io, @sprintf("%6s %36s %36s %16.4f", iterstr, tostring(r.iter_mean[it, col], r.iter_std[it, col]), tostring(m, e), abs(c2)))
             end
             println(io, "-"^127)
+            r.correlated && println(io, "  the iterations continued each other's chains: block-lineage error of the average  ", tostring(r.mean[col], r.stdev[col]),
+                                    r.warmup > 0 ? "   ($(r.warmup) warm-up launches run again)" : "")
         else
             m, e, c2 = r.mean[col], r.stdev[col], r.chi2[col]
             println(io, dof(r) == 0 ? "Integral $info = $m ± $e" : "Integral $info = $m ± $e   (reduced chi2 = $(round(c2, sigdigits=3)))")
@@ -875,7 +880,7 @@ function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::
     nworker = _comm[].size
     nblock = block > nworker ? (block ÷ nworker) * nworker : nworker                   # _standardize_block, main.jl:220-234
     config.neval = (Int(neval) ÷ nblock) * nblock
-    r = Result(m, s, c2, res.neval, ignore, config, permutedims(im), permutedims(ie))
+    r = Result(m, s, c2, res.neval, ignore, config, permutedims(im), permutedims(ie), res.correlated != 0, Int(res.warmup))
     max(print, verbose) >= 0 && _comm[].rank == 0 && report(r)                          # main.jl:212-213
     r
 end

@@ -212,5 +212,9 @@ def report(result, ignore=None, pick=0, name=None, verbose=0, io=None):
                 label = "ignore" if it + 1 <= ignore else str(it + 1)
                 print("%6s %36s %36s %16.4f" % (label, _tostring(m0, e0), _tostring(m, e), abs(c2)), file=io)
             print(bar, file=io)
+            if getattr(result, "correlated", False):   # (not in the reference: its iterations are independent)
+                print("  the iterations continued each other's chains: block-lineage error of the average  %s%s" % (
+                    _tostring(result._flat_mean[col], result._flat_std[col]),
+                    "   (%d warm-up launches run again)" % result.warmup if getattr(result, "warmup", 0) else ""), file=io)
         else:
             print("Integral %s = %s ± %s" % (info, result._flat_mean[col], result._flat_std[col]), file=io)

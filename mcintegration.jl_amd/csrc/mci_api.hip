@@ -1719,7 +1719,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     // Split-all :vegas: the replay partitions a block's parked samples on its own.  Every replay workgroup zeroes and flushes a whole LDS
     // tile (C4: 128 KB) and every row it writes is read again by the merge, so it runs ~2 workgroups per CU and tile pair instead of one
     // per sample-pass row (C4: 512 instead of 2048 workgroups, 67 instead of 262 MB of partial histograms written and read back:
-    // k_hist_stage1 100 -> 25 us, profiles/r04_c4_kernel_stats.txt).  The partition only decides which workgroup adds a sample to the
+    // k_hist_stage1 100 -> 12.6 us, profiles/r04_c4_kernel_stats.txt).  The partition only decides which workgroup adds a sample to the
     // histogram: sums differ by reassociation.
     int64_t hist_rows = nrows;
     if (split && s.split_all) {

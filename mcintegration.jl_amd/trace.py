@@ -3,7 +3,7 @@ the HIP C++ body the sample-batch kernels are JIT-compiled around (integrand.Int
 `integrand(var, config)` into the reference's loop (vegas/montecarlo.jl:140-144, vegas_mc/updates.jl:67-75, mcmc/montecarlo.jl:34-36).
 
     f = lambda x, c: np.exp(-np.sum(x * x) / 2) / (2 * np.pi) ** (len(x) / 2)
-    integrate(f, var=Continuous(-5, 5), dof=[[4]], solver="vegas", trace=True)        # or Integrand = trace_integrand(f, config)
+    integrate(f, var=Continuous(-5, 5), dof=[[4]], solver="vegas")        # (tracing is the default; or Integrand = trace_integrand(f, config))
 
 The closure sees what a host closure sees (integrand.HostIntegrand) without the batch axis: with one variable type `x[i]` is the
 i-th draw, with several `x` is a tuple with one array per variable type (a CompositeVar pool has shape [slot, leaf]); the arrays are

@@ -282,6 +282,7 @@ struct mci_problem {
     // automatic :mcmc chain lengths (mci_mcmc_auto_chains): measured steps per chain while nothing has been measured | how much longer
     // than the chains that measured the holds a launch's chains may be.  (MCI_MCMC_PILOT / MCI_MCMC_GROW: experiment knobs)
     static int64_t kMcmcPilotSteps, kMcmcGrow;
+    static int64_t kMcmcCarryHolds, kMcmcCarryHalfFloors; // carried chains: length in longest holds | minimum length in HALF burn-in floors
 };
 
 // A repeated iteration (the warm-up of automatic :mcmc chain lengths, mci_integrate) draws from the Philox streams of iteration
@@ -294,6 +295,8 @@ static int64_t env_i64(const char *name, int64_t dflt) {
 }
 int64_t mci_problem::kMcmcPilotSteps = env_i64("MCI_MCMC_PILOT", 4096);
 int64_t mci_problem::kMcmcGrow = env_i64("MCI_MCMC_GROW", 2);
+int64_t mci_problem::kMcmcCarryHolds = env_i64("MCI_MCMC_CARRY_HOLDS", 8);
+int64_t mci_problem::kMcmcCarryHalfFloors = env_i64("MCI_MCMC_CARRY_HALF_FLOORS", 4);
 
 static void persist_job_drop(mci_problem *p);
 namespace { void persist_orphans_join(); }
@@ -409,7 +412,7 @@ int hold_consume(mci_problem *p) {
         p->hold_max = (int64_t)1 << top; // bucket b holds bit_width(h) == b, i.e. h < 2^b
         p->hold_len = p->hold_len_inflight;
         // was that launch long enough for what it measured itself?  (the rule its successor is sized by, mci_mcmc_auto_chains)
-        p->hold_valid = p->hold_len >= (p->hold_carried_inflight ? 8 : 16) * p->hold_max;
+        p->hold_valid = p->hold_len >= (p->hold_carried_inflight ? mci_problem::kMcmcCarryHolds : 16) * p->hold_max;
         if (p->hold_valid) p->mcmc_warm = true;
     }
     return MCI_OK;
@@ -2948,12 +2951,12 @@ int64_t mci_mcmc_auto_chains(int64_t nevalperblock, int64_t nblocks, int32_t nsl
     //     jumping to 8-16 x a number the untrained map inflated.  The launches on the way are warm-up: mci_integrate repeats them
     //     (mci_mcmc_launch_valid) -- together they cost less than the first launch that is long enough, a geometric series
     const int64_t fl = 64 * (int64_t)nslots + 16 * (int64_t)(npool + 1) * nd;
-    int64_t len, floor_len = (carried ? 2 : 8) * fl;
+    int64_t len, floor_len = carried ? mci_problem::kMcmcCarryHalfFloors * fl / 2 : 8 * fl;
     if (hold_max <= 0) {
         len = mci_problem::kMcmcPilotSteps;
         floor_len = 2 * fl;
     } else {
-        len = (carried ? 8 : 16) * hold_max;
+        len = (carried ? mci_problem::kMcmcCarryHolds : 16) * hold_max;
         if (hold_len > 0 && len > mci_problem::kMcmcGrow * hold_len) len = mci_problem::kMcmcGrow * hold_len;
     }
     if (len < floor_len) len = floor_len;

@@ -229,7 +229,7 @@ int mci_integrate(mci_problem *prob, const mci_integrate_args *args, mci_result 
  * 2^(top occupied b) of the launch before it (mci_mcmc_auto_chains): the host waits for that launch's sample kernel -- not for its
  * merge and train! -- before it sizes the next one; a fixed lag, so a run stays reproducible. */
 int mci_get_hold_histogram(mci_problem *prob, uint64_t *out64);
-/* Was the last automatic :mcmc launch long enough for the holding times it measured itself (chain length >= 16 x the longest hold, 8 x
+/* Was the last automatic :mcmc launch long enough for the holding times it measured itself (chain length >= 16 x the longest hold, 4 x
  * for carried chains)?  Waits for that launch's sample kernel.  *warm: some launch of this problem has been.  Until then the chain
  * lengths escalate and mci_integrate runs an iteration again instead of counting it (mci_result.warmup); a caller that drives
  * mci_iteration_run itself does the same with this call (run the iteration again as iteration + 16384 * attempt: the chains go on,
@@ -310,10 +310,11 @@ int mci_set_deterministic(mci_problem *prob, int32_t on);
  * bins and probabilities looked up again on the refined map.  :mcmc: a chain's state is (integrand index, configuration) and
  * doReweight! moves the weight of every index between iterations (main.jl:322-346), so the stored chains of a block -- a sample of
  * the finished iteration's target -- are resampled (systematic, deterministic) with probability ~ reweight_new[index] /
- * reweight_old[index] into a sample of the new one.  Such a launch keeps only the reference's own burn-in (`ne >= neval/100`,
- * vegas_mc/montecarlo.jl:213; floor(steps * thermal_ratio), mcmc/montecarlo.jl:133); automatic chain counts are then sized for the
- * duplicates of a stored chain to part before they are copied again (:vegasmc two burn-in floors, :mcmc 8 x the longest measured
- * holding time) instead of for start-up bias (DESIGN.md "Chains").  mode 0: every launch starts its chains afresh.
+ * reweight_old[index] into a sample of the new one.  Such a launch keeps the reference's `ne >= neval/100` (vegas_mc/montecarlo.jl:213)
+ * under :vegasmc and burns nothing in under :mcmc (floor(steps * thermal_ratio), mcmc/montecarlo.jl:133, is the burn-in of a chain
+ * that starts somewhere; a continued chain measures from its first step); automatic chain counts are then sized for the duplicates
+ * of a stored chain to part before they are copied again (:vegasmc two burn-in floors, :mcmc 4 x the longest measured holding time)
+ * instead of for start-up bias (DESIGN.md "Chains").  mode 0: every launch starts its chains afresh.
  * Consecutive iterations of carried chains are correlated, which the reference's combination of iterations (statistics.jl:186-220)
  * does not expect: mci_integrate reports the block-lineage error for such runs (mci_result.correlated, mci_lineage_sums).
  * Mirrored in the oracle (mcio_set_chain_carry, mcio_resample_chains). */
@@ -369,9 +370,9 @@ int64_t mci_mcmc_burnin(int64_t steps, int64_t nchain, int32_t nslots, int32_t n
 /* chains per block of an :mcmc launch with nchain = 0 ("automatic"; the reference has no counterpart: it runs one chain
  * per block).  hold_max = the longest holding time the launch before measured (mci_get_hold_histogram), hold_len = the chain length
  * (measured steps) of that launch (0: no growth cap), carried = the launch continues that launch's chains.  hold_max = 0 (nothing
- * measured yet): chains of 4096 steps or 2 burn-in floors; otherwise 16*hold_max (fresh) / 8*hold_max (carried) but at most 2*hold_len
- * -- a hold longer than an eighth of the chain that measured it is censored by that chain, so the length escalates from launch to
- * launch until the holds fit -- and never fewer than 8 / 2 burn-in floors; capped so that one GPU gets at most 131072 chains */
+ * measured yet): chains of 4096 steps or 2 burn-in floors; otherwise 16*hold_max (fresh) / 4*hold_max (carried) but at most 2*hold_len
+ * -- a hold longer than a quarter of the chain that measured it is censored by that chain, so the length escalates from launch to
+ * launch until the holds fit -- and never fewer than 8 / 1 burn-in floors; capped so that one GPU gets at most 131072 chains */
 int64_t mci_mcmc_auto_chains(int64_t nevalperblock, int64_t nblocks, int32_t nslots, int32_t nd, int32_t npool,
                              int64_t hold_max, int64_t hold_len, int32_t carried);
 void mci_maxdof(const int32_t *dof, int32_t nd, int32_t npool, int32_t *out);        /* configuration.jl:229-236 */

@@ -295,8 +295,8 @@ static int64_t env_i64(const char *name, int64_t dflt) {
 }
 int64_t mci_problem::kMcmcPilotSteps = env_i64("MCI_MCMC_PILOT", 4096);
 int64_t mci_problem::kMcmcGrow = env_i64("MCI_MCMC_GROW", 2);
-int64_t mci_problem::kMcmcCarryHolds = env_i64("MCI_MCMC_CARRY_HOLDS", 8);
-int64_t mci_problem::kMcmcCarryHalfFloors = env_i64("MCI_MCMC_CARRY_HALF_FLOORS", 4);
+int64_t mci_problem::kMcmcCarryHolds = env_i64("MCI_MCMC_CARRY_HOLDS", 4);
+int64_t mci_problem::kMcmcCarryHalfFloors = env_i64("MCI_MCMC_CARRY_HALF_FLOORS", 2);
 
 static void persist_job_drop(mci_problem *p);
 namespace { void persist_orphans_join(); }
@@ -1540,10 +1540,11 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // Carried chains (resampled to the moved target, k_resample_chains) start from stationary configurations AND a stationary
             // integrand index: nothing to burn in.  What their length still has to cover is the longest holding time: a population
             // grows by duplication (a launch of more chains than the one before continues every stored chain several times), and the
-            // copies of a chain must have gone their own ways before they are copied again -- 8 x the longest hold instead of the
+            // copies of a chain must have gone their own ways before they are copied again -- 4 x the longest hold instead of the
             // 16 x (+ burn-in) of fresh chains.  profiles/r03_chain_carry.txt: carried chains of two burn-in floors on 1/(1 - cos^3)
             // keep their few ancestors' view of its sticky states for many iterations (-4.8 sigma pooled over 64 seeds); at 2, 4
-            // and 16 x the hold the pooled deviations are those of fresh chains.
+            // and 16 x the hold the pooled deviations are those of fresh chains.  profiles/r04_mcmc_policy.txt D: 4 x against the 8 x of
+            // round 3 on 384-512 seeds (same pulls, same scatter / error; 2 x: the error bars start to fall short).
             // The holds are those of the launch BEFORE this one (hold_consume waits for its sample kernel); a first launch, with nothing
             // measured, runs pilot-length chains, and a launch's chains are at most kMcmcGrow times as long as those that measured the
             // holds (mci_mcmc_auto_chains).
@@ -1554,8 +1555,9 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
                                           may_carry ? 1 : 0);
         }
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
-        // (carried chains keep the reference's own floor(steps * thermal_ratio) only, mcmc/montecarlo.jl:133)
-        nburn = mci_mcmc_burnin(nevalperblock / nchain, (may_carry && nchain > 1) ? 1 : nchain, nslots, p->ni + 1, p->npool, thermal_ratio);
+        // (carried chains have no start to burn in: floor(steps * thermal_ratio), mcmc/montecarlo.jl:133, is the burn-in of a chain that
+        // begins at a random configuration; a chain that continues a stationary one measures from its first step)
+        nburn = (may_carry && nchain > 1) ? 0 : mci_mcmc_burnin(nevalperblock / nchain, nchain, nslots, p->ni + 1, p->npool, thermal_ratio);
         units = nchain;
     } else {
         nchain = 1;
@@ -2944,8 +2946,8 @@ int64_t mci_mcmc_auto_chains(int64_t nevalperblock, int64_t nblocks, int32_t nsl
     //     where the trained map holds for 2^8: chains sized for them (131072 steps in the rounds before) cost 0.74 s of a cold call
     //   fresh chains: 16 x hold_max, never fewer than 8 burn-in floors.  Calibration (profiles/r01_chain_bias.txt): on the bubble
     //     diagram chains of 1-2 x that holding time are ~1e-3 off, chains of 8 x are unbiased at the 5e-4 level of the measurement
-    //   carried chains (stationary starts): 8 x hold_max, never fewer than 2 floors (profiles/r03_chain_carry.txt)
-    //   at most kMcmcGrow x hold_len: a hold longer than an eighth of the chain that measured it is censored by that chain's
+    //   carried chains (stationary starts): 4 x hold_max, never fewer than 1 floor (profiles/r03_chain_carry.txt, r04_mcmc_policy.txt D)
+    //   at most kMcmcGrow x hold_len: a hold longer than a quarter of the chain that measured it is censored by that chain's
     //     length -- what it says is "longer", not how long -- so the length escalates by that factor per launch until the
     //     measured holds fit (heavy-tailed integrands: 2^14..2^15 steps on the bubble diagram and on 1/(1 - cos^3)) instead of
     //     jumping to 8-16 x a number the untrained map inflated.  The launches on the way are warm-up: mci_integrate repeats them

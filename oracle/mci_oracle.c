@@ -1252,7 +1252,8 @@ int mcio_mcmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint6
         nslots += c->maxdof[vi];
     }
     const long steps = neval / nchain;
-    const long nburn = mcio_mcmc_burnin(steps, c->carry_load ? 1 : nchain, nslots, Nd, npool, c->thermal_ratio); /* :133 (carried chains: the reference's own term only) */
+    /* :133; a carried chain has no start to burn in: it measures from its first step (the engine's many-chain decomposition only) */
+    const long nburn = c->carry_load ? 0 : mcio_mcmc_burnin(steps, nchain, nslots, Nd, npool, c->thermal_ratio);
     const int nupd = 2 * npool + 2; /* :127-130: [changeIntegrand, swapVariable, changeVariable x 2*Nv] */
     const uint32_t st_init = stream_id_block(iteration, STREAM_MCMC_INIT, block_index), st_step = stream_id_block(iteration, STREAM_MCMC_STEP, block_index);
     int rc = 0;

@@ -151,8 +151,8 @@ def test_plain_c_consumer_of_the_abi_builds_and_refuses_to_run_without_a_gpu():
 
 def test_mcmc_auto_chain_length_rule():
     """mci_mcmc_auto_chains: pilot-length chains (4096 steps or 2 burn-in floors) until a launch has been measured; afterwards
-    16 x (fresh) / 8 x (carried) the longest holding time of the launch before, at most 2 x the chain length that measured it (a hold
-    longer than an eighth of that chain is censored by it; 0 = no cap), never fewer than 8 / 2 burn-in floors; at most 131072 chains
+    16 x (fresh) / 4 x (carried) the longest holding time of the launch before, at most 2 x the chain length that measured it (a hold
+    longer than a quarter of that chain is censored by it; 0 = no cap), never fewer than 8 / 1 burn-in floors; at most 131072 chains
     per GPU, at least one chain."""
     from mcintegration_jl_amd._lib import lib
     L = lib()
@@ -163,12 +163,12 @@ def test_mcmc_auto_chain_length_rule():
     assert L.mci_mcmc_auto_chains(npb, nblocks, 64, nd, npool, 0, 0, 0) == npb // (2 * (64 * 64 + 16 * 2 * 5))    # ... 2 floors > 4096
     assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 256, 0, 0) == npb // max(16 * 256, 8 * fl)      # light tails: the floor decides
     assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384, 0, 0) == npb // (16 * 16384)             # heavy tails: the holds decide
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384, 0, 1) == npb // (8 * 16384)              # carried chains: 8 x
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 64, 0, 1) == npb // (2 * fl)                    # ... and two floors
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 16384, 0, 1) == npb // (4 * 16384)              # carried chains: 4 x
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 64, 0, 1) == npb // fl                          # ... and one floor
     # censored: the launch before ran 4096-step chains and saw holds up to 8192 (its top bucket's upper edge) -> 2 x 4096, not 8 x 8192
     assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 8192, 4096, 1) == npb // (2 * 4096)
     assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 8192, 4096, 0) == npb // (2 * 4096)
-    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 256, 16384, 1) == npb // (8 * 256)             # holds that fit: the length comes down at once
+    assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 512, 16384, 1) == npb // (4 * 512)             # holds that fit: the length comes down at once
     assert L.mci_mcmc_auto_chains(npb, nblocks, nslots, nd, npool, 1 << 30, 0, 0) == 1
     assert L.mci_mcmc_auto_chains(10**9, 16, 1, 2, 1, 2, 0, 0) == 131072 // 16                                     # GPU-fill cap
 

@@ -74,12 +74,58 @@ struct ResampleArgs {
     double *W;             // [nblocks][n_old] scratch
 };
 __global__ void __launch_bounds__(256) k_resample_chains(ResampleArgs a) {
+    constexpr int kLdsW = 8192; // stored chains per block whose running weights also sit in LDS: the bisections below then read LDS
+    __shared__ double sW[kLdsW];
     __shared__ long long part[256];
     const int tid = threadIdx.x, T = 256;
     const int *co = a.curr_old + (size_t)blockIdx.x * a.n_old;
     double *W = a.W + (size_t)blockIdx.x * a.n_old;
     int *src = a.src + (size_t)blockIdx.x * a.n_new;
     const long long per = (a.n_old + T - 1) / T, j0 = tid * per < a.n_old ? tid * per : a.n_old, j1 = j0 + per < a.n_old ? j0 + per : a.n_old;
+    constexpr int kNd = 16; // integrands (+ the normalisation) whose running counts a thread keeps in registers
+    if (a.nd <= kNd) {
+        // Two passes over the thread's stretch of the stored chains instead of one read-modify-write pass over W per integrand: the
+        // per-integrand counts below the stretch first, then W[j] = sum_i w[i] * cnt_i(j), the terms added over i = 0 .. nd-1 in that
+        // order -- the same numbers in the same order as the pass per integrand (the counts are integers, every product is formed once).
+        long long cnt[kNd];
+        double w[kNd];
+#pragma unroll
+        for (int i = 0; i < kNd; ++i) {
+            cnt[i] = 0;
+            w[i] = i < a.nd ? a.rw_now[i] / a.rw_used[i] : 0.0;
+        }
+        for (long long j = j0; j < j1; ++j) {
+            const int c = co[j];
+#pragma unroll
+            for (int i = 0; i < kNd; ++i) cnt[i] += c == i ? 1 : 0;
+        }
+        for (int i = 0; i < a.nd; ++i) { // this thread's counts -> the counts of everything before its stretch
+            long long mine = 0;
+#pragma unroll
+            for (int q = 0; q < kNd; ++q) mine = q == i ? cnt[q] : mine;
+            __syncthreads();
+            part[tid] = mine;
+            __syncthreads();
+            long long below = 0;
+            for (int t = 0; t < tid; ++t) below += part[t];
+#pragma unroll
+            for (int q = 0; q < kNd; ++q) cnt[q] = q == i ? below : cnt[q];
+        }
+        for (long long j = j0; j < j1; ++j) {
+            const int c = co[j];
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < kNd; ++i) {
+                cnt[i] += c == i ? 1 : 0;
+                if (i < a.nd) {
+                    const double term = w[i] * (double)cnt[i];
+                    acc = i == 0 ? term : acc + term;
+                }
+            }
+            W[j] = acc;
+            if (a.n_old <= kLdsW) sW[j] = acc;
+        }
+    } else
     for (int i = 0; i < a.nd; ++i) { // one pass per integrand: its running count along the stored chains, times its ratio, onto W
         const double w = a.rw_now[i] / a.rw_used[i];
         long long mine = 0;
@@ -97,13 +143,14 @@ __global__ void __launch_bounds__(256) k_resample_chains(ResampleArgs a) {
     }
     __threadfence_block();
     __syncthreads();
+    const bool in_lds = a.nd <= kNd && a.n_old <= kLdsW;
     const double step = W[a.n_old - 1] / (double)a.n_new;
     for (long long c = tid; c < a.n_new; c += T) {
         const double target = ((double)c + 0.6180339887498949) * step;
         long long lo = 0, hi = a.n_old - 1; // smallest j with W[j] > target
         while (lo < hi) {
             const long long mid = (lo + hi) >> 1;
-            if (W[mid] > target) hi = mid;
+            if ((in_lds ? sW[mid] : W[mid]) > target) hi = mid;
             else lo = mid + 1;
         }
         src[c] = (int)lo;

@@ -61,7 +61,7 @@ if __name__ == "__main__":
         ms, wg, th = eng.kernel_times_ms(a.niter + 8)
         print("%s %s COLD integrate(neval=%.0e, niter=%d): %.1f ms wall, library %.1f ms -> %.2f G/s end to end; %d warm-up launches; sample kernels, ms, launch order: %s" % (
             a.workload, solver, a.neval, a.niter, wall * 1e3, r["seconds"] * 1e3, a.neval * a.niter / wall / 1e9, r.get("warmup", 0), " ".join("%.2f" % v for v in ms)))
-        print("   mean=%s +- %s" % (np.array2string(r["mean"], precision=8), np.array2string(r["stdev"], precision=2)))
+        print("   mean=%s +- %s" % (np.array2string(r["mean"], precision=8), np.array2string(r["stdev"], formatter={"float_kind": lambda v: "%.2e" % v})))
         mci.shutdown()
         sys.exit(0)
     half = max(a.niter // 2, 1)

@@ -614,6 +614,7 @@ template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ v
         if constexpr (chunk_has<Cfg, ECACHE, DPC>(c, true)) {
             constexpr int slot = [] { int n = 0; for (int j = 0; j < c; ++j) n += chunk_has<Cfg, ECACHE, DPC>(j, true) ? 1 : 0; return n & 1; }();
             const u32x4 r = philox4x32_10<KV>((u32)index, (u32)(index >> 32), (u32)c, stream, keys);
+            __builtin_amdgcn_s_setprio(1); // (the gathers of this chunk go out ahead of the other waves' Philox blocks)
             static_for<0, DPC>([&](auto J) {
                 constexpr int j = decltype(J)::value, k = DPC * c + j;
                 if constexpr (k < Cfg::NDRAW) {
@@ -628,6 +629,7 @@ template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ v
                     }
                 }
             });
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier(); // keeps the waves on the same tables; no data is exchanged
             constexpr int pc = prev_gather_chunk<Cfg, ECACHE, DPC>(c);
@@ -650,12 +652,14 @@ template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ v
         constexpr int c = decltype(C)::value;
         if constexpr (chunk_has<Cfg, ECACHE, DPC>(c, false)) {
             const u32x4 r = philox4x32_10<KV>((u32)index, (u32)(index >> 32), (u32)c, stream, keys);
+            __builtin_amdgcn_s_setprio(1); // (issue priority for the table reads behind a Philox block, as in draw_sample_pipe: C4 4.89 -> 4.81 ms with both phases)
             static_for<0, DPC>([&](auto J) {
                 constexpr int k = DPC * c + decltype(J)::value;
                 if constexpr (k < Cfg::NDRAW) {
                     if constexpr (!is_gather_draw<Cfg, ECACHE>(k)) phased_one_draw<Cfg, ECACHE, DPC, k>(t, r, s);
                 }
             });
+            __builtin_amdgcn_s_setprio(0);
         }
     });
     static_for<0, Cfg::NI>([&](auto I) {
@@ -846,6 +850,13 @@ template <class Cfg, bool KV, int DPC> __device__ __forceinline__ void draw_samp
         constexpr int c = decltype(C)::value;
         if constexpr (c < NCH) {
             const u32x4 r = philox4x32_10<KV>(ilo, ihi, (u32)c, stream, keys);
+            // The wave asks for issue priority while it hands its LDS work over (s_setprio 1 ... 0): its two reads and two atomics then
+            // go out ahead of the other waves' Philox stretches instead of queueing behind them, and the LDS pipe has them while this
+            // wave computes its next block.  Measured on the headline loop, kernel ms per 1e8 samples on two boxes: 1.357 / 1.371 ->
+            // 1.308 / 1.318 and 1.367 / 1.368 -> 1.340 / 1.341; priority 2 or 3 the same; around the reads alone or the atomics
+            // alone: nothing or worse; held through the consumption of the pairs: half of it (profiles/r04_ablation.txt); a third box,
+            // three interleaved pairs of runs: 1.392 / 1.360 / 1.370 -> 1.317 / 1.320 / 1.325.
+            __builtin_amdgcn_s_setprio(1);
             static_for<0, DPC>([&](auto H) { // bins, fractions and table reads of this block's draws
                 constexpr int k = DPC * c + decltype(H)::value;
                 if constexpr (k < Cfg::NDRAW) {
@@ -861,6 +872,7 @@ template <class Cfg, bool KV, int DPC> __device__ __forceinline__ void draw_samp
                 constexpr int k = DPC * c + decltype(H)::value;
                 if constexpr (k < Cfg::NDRAW) hist_add_draw<Cfg, k>(pend.bin[k], pend.wh, sH);
             });
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (c >= LAG) { // the draws whose pairs were asked for LAG blocks ago: x = g[iy] + dy * (g[iy+1] - g[iy])  sampler.jl:299

@@ -321,6 +321,32 @@ int mci_set_deterministic(mci_problem *prob, int32_t on);
 int mci_set_chain_carry(mci_problem *prob, int32_t mode);
 /* chains per block of the last chain-solver launch and whether it continued the launch before it */
 int mci_last_chain_launch(const mci_problem *prob, int64_t *nchain, int32_t *carried);
+/* Several lanes per chain.  The reference's chain is one sequential loop on one core (vegas_mc/montecarlo.jl:184-232,
+ * mcmc/montecarlo.jl:134-172); a chain-solver launch with few chains -- the reference's default call runs 16, one per block -- would
+ * leave all but a few lanes of the GPU idle.  Such a launch gives every chain a GROUP of lanes (a power of two up to 64) that steps it
+ * speculatively: the uniforms of a step are addressed by (chain, step), so the lanes evaluate the proposals of the next steps along a
+ * tree of accept / reject outcomes at once, a ballot of the accept tests picks the way the chain actually takes, the lanes on it do
+ * their steps' bookkeeping (propose / accept counters, histogram, measurement) and the last of them hands its configuration to the
+ * group (csrc/mci_spec.h).  The chain is the SAME chain -- same law, same uniforms, same arithmetic per step: sums differ by
+ * reassociation only, and nchain = 1 stays the reference's chain.
+ * lanes: -1 (default) automatic -- the largest group that keeps the launch within one wave per SIMD; 1: one lane per chain always;
+ * 2 .. 64: that group size.  accept in (0, 1): the acceptance the tree is built for -- the group's lanes are the `lanes` most probable
+ * nodes of the outcome tree of a chain whose steps change its configuration with that probability (-> 0: the reject chain, up to
+ * `lanes` steps per trip through a run of rejections; 1/2: the complete binary tree, log2(lanes) steps per trip whatever happens);
+ * <= 0: the solver's default (:vegasmc 0.5, :mcmc 0.35).  max_accepts: the most accept edges on a way through the tree (:mcmc builds
+ * its proposals once per accept level); < 0: the solver's default (:vegasmc unbounded, :mcmc 2).
+ * Launches with a host integrand and the deterministic mode keep one lane per chain. */
+int mci_set_chain_speculation(mci_problem *prob, int32_t lanes, double accept, int32_t max_accepts);
+/* lanes per chain of the last chain-solver launch (1: one lane per chain) and the accept levels of its tree */
+int mci_last_chain_speculation(const mci_problem *prob, int32_t *lanes, int32_t *max_accepts);
+/* the tree mci_set_chain_speculation(lanes, accept, max_accepts) stands for, node by node ([lanes] each; NULL: not wanted): the step
+ * offset of the node's proposal, the nearest ancestor it hangs below by an accept edge (-1: none), its number of accept edges, and
+ * the lanes that must have accepted / rejected for the node to be on the chain's path (bit = lane).  Lanes are numbered
+ * ancestors-first.  No device needed. */
+int mci_speculation_tree(int32_t lanes, double accept, int32_t max_accepts, int32_t *depth, int32_t *anc, int32_t *nacc, uint64_t *needacc,
+                         uint64_t *needrej);
+/* JIT or kernel-cache load of a chain solver's several-lanes-per-chain kernel (its own code object; implicit on first use) */
+int mci_compile_chain_speculation(mci_problem *prob, int32_t solver);
 /* Persistent :vegas iterations.  The reference's loop (main.jl:142-207) at the reference's own default size (neval = 1e4, main.jl:76)
  * is launch-bound on a GPU: a microsecond of sampling per iteration behind two dependent kernel launches.  With mode -1 (default) a
  * single-rank mci_integrate call of solver MCI_VEGAS at measurefreq == 1 over ONE Continuous variable type whose iterations are that
@@ -356,6 +382,18 @@ int mci_set_kernel_timing(mci_problem *prob, int32_t mode);
  * recorded under the same rule: the time a rank spends in the one exchange step of the path (main.jl:177-188) -- its own wait for
  * the slowest rank's sample pass plus the latency of an all-reduce of `packed_size` doubles */
 int mci_comm_times_ms(mci_problem *prob, float *ms, int32_t n, int32_t *got);
+/* ncclAllReduce calls the library has issued on this context so far and the element count of the last one.  An iteration of ANY
+ * solver is ONE collective (mci_iteration_reduce): [statistics | histograms | propose | accept] and, behind an :mcmc launch that
+ * measured its holding times for the automatic chain length, the 64 counts of their histogram as exact doubles (the reference
+ * reduces its statistics, histograms and tables one array at a time, configuration.jl:264-299).  A run of carried chains ends with
+ * one more small one (mci_comm_sum: the block-lineage sums). */
+int mci_comm_collectives(const mci_ctx *ctx, int64_t *calls, int64_t *last_count);
+/* For an EXTERNAL reducer of the packed buffer (what comm.py's TorchDistComm is): the number of doubles to sum over the ranks --
+ * mci_problem_info's packed_size + the 64 holding-time counts behind it; mci_get_packed / mci_set_packed take either size -- and
+ * the call that tells the library the sum has happened (device buffer: after the collective was queued on the library's stream;
+ * host path: after mci_set_packed), so that every rank sizes its next :mcmc chains from the summed counts. */
+int mci_reduce_size(const mci_problem *prob, int64_t *n);
+int mci_external_reduce_done(mci_problem *prob);
 
 /* ---- host-side statistics of the path (pure functions, no GPU needed) ---- */
 void mci_standardize_block(int64_t neval, int64_t nblock, int64_t nworker, int64_t *nevalperblock,

@@ -108,10 +108,17 @@ SIGNATURES = [
     ("mci_set_persistent", C.c_int, [_VP, C.c_int32]),
     ("mci_last_integrate_persistent", C.c_int, [_VP, C.POINTER(C.c_int32)]),
     ("mci_last_chain_launch", C.c_int, [_VP, C.POINTER(C.c_int64), c_int32_p]),
+    ("mci_set_chain_speculation", C.c_int, [_VP, C.c_int32, C.c_double, C.c_int32]),
+    ("mci_last_chain_speculation", C.c_int, [_VP, c_int32_p, c_int32_p]),
+    ("mci_speculation_tree", C.c_int, [C.c_int32, C.c_double, C.c_int32, c_int32_p, c_int32_p, c_int32_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("mci_compile_chain_speculation", C.c_int, [_VP, C.c_int32]),
     ("mci_train", C.c_int, [_VP]),
     ("mci_sample_dump", C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
     ("mci_kernel_times_ms", C.c_int, [_VP, C.POINTER(C.c_float), C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
     ("mci_comm_times_ms", C.c_int, [_VP, C.POINTER(C.c_float), C.c_int32, c_int32_p]),
+    ("mci_comm_collectives", C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("mci_reduce_size", C.c_int, [_VP, C.POINTER(C.c_int64)]),
+    ("mci_external_reduce_done", C.c_int, [_VP]),
     ("mci_standardize_block", None, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("mci_chain_burnin", C.c_double, [C.c_int64, C.c_int64, C.c_int32]),
     ("mci_mcmc_burnin", C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double]),

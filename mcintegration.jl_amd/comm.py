@@ -87,20 +87,27 @@ class TorchDistComm:
     def all_reduce(self, engine):
         import torch
         import torch.distributed as dist
+        # (what is summed: the packed buffer and, behind it, the 64 :mcmc holding-time counts -- every rank sizes its next chains from the
+        # same numbers; engines without them, e.g. the oracle-backed test engine, reduce the packed buffer alone)
+        ext_size = hasattr(engine, "external_reduce_done")
         if self.tensor_device == "cpu":
-            t = torch.from_numpy(np.ascontiguousarray(engine.get_packed()))
+            t = torch.from_numpy(np.ascontiguousarray(engine.get_packed(reduce_size=True) if ext_size else engine.get_packed()))
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             engine.set_packed(t.numpy())
+            if ext_size:
+                engine.external_reduce_done()
             return
         ptr = engine.packed_device_ptr()
         if not ptr:
             raise RuntimeError("the engine has no device buffer to reduce")
         if self._view[0] != ptr:
-            t = torch.as_tensor(_DeviceBuffer(ptr, engine.packed_size), device=self.tensor_device)
+            t = torch.as_tensor(_DeviceBuffer(ptr, engine.reduce_size if ext_size else engine.packed_size), device=self.tensor_device)
             self._view = (ptr, t, torch.cuda.ExternalStream(engine.stream(), device=self.tensor_device))
         _, t, ext = self._view
         with torch.cuda.stream(ext):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if ext_size:
+            engine.external_reduce_done()
 
     def sum_host(self, engine, v):
         import torch

@@ -58,7 +58,7 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
-const int kNcclFloat64 = 8, kNcclUint64 = 5, kNcclSum = 0; // ncclDouble, ncclUint64, ncclSum (rccl.h)
+const int kNcclFloat64 = 8, kNcclSum = 0; // ncclDouble, ncclSum (rccl.h)
 
 // If the host process already carries an RCCL (PyTorch-ROCm bundles its own and resolves it through its rpath),
 // bind to THAT copy: two RCCL instances in one process would each open their own IPC/proxy state on the same GPUs.
@@ -99,6 +99,7 @@ struct mci_ctx {
     hipStream_t stream = nullptr;
     void *comm = nullptr;
     int rank = 0, nranks = 1;
+    long long collectives = 0, last_count = 0; // ncclAllReduce calls issued on this context so far | elements of the last one (mci_comm_collectives)
 };
 
 namespace {
@@ -136,10 +137,22 @@ struct mci_problem {
     // one code object per solver, JIT-compiled (or loaded from the kernel cache) the first time the solver runs;
     // the vegas module also holds the sample-dump kernel
     // kernel slots (kslot): :vegas for measurefreq == 1 | :vegasmc | :mcmc | :vegas for any measurefreq | sample dump
-    hipModule_t module[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipFunction_t f_solver[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, f_dump = nullptr;
-    bool compiled[5] = {false, false, false, false, false};
-    std::string code_object[5]; // kernel-cache file each slot's code object was loaded from / written to
+    //                      | :vegasmc with several lanes per chain | :mcmc with several lanes per chain (mci_spec.h)
+    static const int kSlots = 7;
+    hipModule_t module[kSlots] = {};
+    hipFunction_t f_solver[kSlots] = {}, f_dump = nullptr;
+    bool compiled[kSlots] = {};
+    std::string code_object[kSlots]; // kernel-cache file each slot's code object was loaded from / written to
+    // Several lanes per chain (mci_spec.h, mci_set_chain_speculation): lanes -1 automatic (as many as the launch's chains leave idle),
+    // 1 never, 2..64 forced; the acceptance the speculation tree is built for (<= 0: the solver's default) and the most accept edges
+    // on a way through it (-1: the solver's default); the tree of the last such launch on the device
+    int spec_lanes = -1, spec_maxacc = -1;
+    double spec_accept = 0.0;
+    mci::SpecNode *d_spec_tab = nullptr;
+    int spec_tab_lanes = 0, spec_tab_limit = -2, spec_tab_maxacc = 0;
+    double spec_tab_accept = -1.0;
+    int last_spec_lanes = 1, last_spec_maxacc = 0; // of the last chain launch (1: one lane per chain)
+    static const int64_t kSpecFill = 65536;        // lanes a launch of few chains spreads over: one wave on each of the 1024 SIMDs
     bool vegas_planned = false, vegas_keys = false; // the :vegas plan (workgroup size, histogram copies, VGPR round keys) stands for both variants
     std::vector<double> h_goal; // reweight_goal (main.jl:81); empty = none
     double *d_goal = nullptr;
@@ -216,6 +229,10 @@ struct mci_problem {
     // is sized: the host waits for the sample kernel of launch k (not for its merge / train!, which run while launch k + 1 is
     // queued) -- ~10 us of idle queue per iteration, nothing next to a chain launch; the lag is fixed, so a run is reproducible
     unsigned long long *h_hold = nullptr;   // pinned [64]
+    double *h_hold_d = nullptr;             // pinned [64]: the histogram summed over the ranks, as it comes out of the packed all-reduce
+    bool hold_from_packed = false;          // the histogram in flight is the summed one (h_hold_d), not this rank's own (h_hold)
+    bool hold_deferred = false;             // a communicator is set: the launch's histogram is published behind its packed all-reduce
+    bool hold_ext_pending = false;          // no communicator: this rank's counts were published; an external reducer may still sum them (mci_external_reduce_done)
     hipEvent_t hold_ev = nullptr;
     bool hold_inflight = false;
     int64_t hold_launches = 0;              // :mcmc launches that recorded a histogram
@@ -375,24 +392,43 @@ int persist_recover(mci_problem *p) {
     return MCI_OK;
 }
 
-// :mcmc holding-time histogram of the launch just queued -> (sum over the ranks ->) pinned host memory, behind the launch on the stream
+// :mcmc holding-time histogram of the launch just queued -> pinned host memory, behind the launch on the stream.  One process: this
+// rank's counts, straight from the kernel's buffer (the host later waits for the sample kernel only).  With a communicator every rank
+// must size its next chains from the SAME histogram: the 64 counts ride in the iteration's ONE all-reduce -- k_finalize appends them
+// to `packed` as exact doubles (MergeArgs::hold), mci_iteration_reduce sums packed_n + 64 doubles and publishes the tail
+// (hold_publish_reduced) -- so the launch only notes what it measured with.
 int hold_publish(mci_problem *p, int64_t chain_len, bool carried) {
     hipStream_t st = p->ctx->stream;
     if (!p->h_hold) {
         HIPCHK(hipHostMalloc((void **)&p->h_hold, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&p->h_hold_d, 64 * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&p->hold_ev, hipEventDisableTiming));
     }
-    if (p->ctx->comm) { // every rank sizes its next chains from the same histogram: results do not depend on which rank ran which block
-        int r = g_rccl.AllReduce(p->d_hold, p->d_hold, 64, kNcclUint64, kNcclSum, p->ctx->comm, st);
-        if (r) return fail(MCI_ERR_COMM, "ncclAllReduce (holding times): %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
-    }
-    if (p->hold_inflight) HIPCHK(hipEventSynchronize(p->hold_ev)); // (a histogram nobody looked at: explicit chain counts in between)
-    HIPCHK(hipMemcpyAsync(p->h_hold, p->d_hold, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(p->hold_ev, st));
-    p->hold_inflight = true;
     p->hold_len_inflight = chain_len;
     p->hold_carried_inflight = carried;
     p->hold_launches += 1;
+    if (p->ctx->comm) {
+        p->hold_deferred = true;
+        return MCI_OK;
+    }
+    if (p->hold_inflight) HIPCHK(hipEventSynchronize(p->hold_ev)); // (a histogram nobody looked at)
+    HIPCHK(hipMemcpyAsync(p->h_hold, p->d_hold, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(p->hold_ev, st));
+    p->hold_inflight = true;
+    p->hold_from_packed = false;
+    p->hold_ext_pending = true;
+    return MCI_OK;
+}
+
+// ... behind the all-reduce of `packed` (the library's, or an external reducer's: mci_external_reduce_done): the summed counts
+int hold_publish_reduced(mci_problem *p) {
+    hipStream_t st = p->ctx->stream;
+    if (p->hold_inflight) HIPCHK(hipEventSynchronize(p->hold_ev));
+    HIPCHK(hipMemcpyAsync(p->h_hold_d, p->d_packed + p->packed_n, 64 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(p->hold_ev, st));
+    p->hold_inflight = true;
+    p->hold_from_packed = true;
+    p->hold_deferred = false;
     return MCI_OK;
 }
 
@@ -406,7 +442,7 @@ int hold_consume(mci_problem *p) {
     p->hold_inflight = false;
     int top = -1;
     for (int b = 0; b < 64; ++b)
-        if (p->h_hold[b]) top = b;
+        if (p->hold_from_packed ? p->h_hold_d[b] > 0.5 : p->h_hold[b] != 0ull) top = b;
     if (top >= 0) {
         p->hold_prev = p->mcmc_warm ? p->hold_max : 0;
         p->hold_max = (int64_t)1 << top; // bucket b holds bit_width(h) == b, i.e. h < 2^b
@@ -421,7 +457,7 @@ int hold_consume(mci_problem *p) {
 void drop_modules(mci_problem *p) {
     p->vegas_planned = p->vegas_keys = false;
     p->f_dump = nullptr;
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < mci_problem::kSlots; ++k) {
         p->compiled[k] = false;
         if (p->module[k]) {
             (void)hipModuleUnload(p->module[k]);
@@ -895,8 +931,9 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         HIPCHK(hipSetDevice(ctx->device));
         int rc = upload(p);
         if (rc) { delete p; return rc; }
-        HIPCHK(hipMalloc((void **)&p->d_packed, (size_t)p->packed_n * sizeof(double)));
-        HIPCHK(hipMemset(p->d_packed, 0, (size_t)p->packed_n * sizeof(double)));
+        // (+ 64: the :mcmc holding-time histogram rides behind the tables in the all-reduce, hold_publish)
+        HIPCHK(hipMalloc((void **)&p->d_packed, (size_t)(p->packed_n + 64) * sizeof(double)));
+        HIPCHK(hipMemset(p->d_packed, 0, (size_t)(p->packed_n + 64) * sizeof(double)));
         // (three buffers: the persistent :vegas kernel rotates through them, mci_train.h vegas_persist; everything else uses the first)
         HIPCHK(hipMalloc((void **)&p->d_ghist, 3 * (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
         HIPCHK(hipMemset(p->d_ghist, 0, 3 * (size_t)(s.nbin ? s.nbin : 1) * sizeof(double)));
@@ -940,7 +977,9 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->d_reweight_used) (void)hipFree(p->d_reweight_used);
         if (p->d_carry_W) (void)hipFree(p->d_carry_W);
         if (p->d_carry_src) (void)hipFree(p->d_carry_src);
+        if (p->d_spec_tab) (void)hipFree(p->d_spec_tab);
         if (p->h_hold) (void)hipHostFree(p->h_hold);
+        if (p->h_hold_d) (void)hipHostFree(p->h_hold_d);
         if (p->h_log) (void)hipHostFree(p->h_log);
         if (p->hold_ev) (void)hipEventDestroy(p->hold_ev);
         if (p->d_blocklog) (void)hipFree(p->d_blocklog);
@@ -1130,9 +1169,9 @@ static int64_t solver_lds(const mci_problem *p, int solver) {
 // Kernel slots: 0 :vegas for measurefreq == 1 (the reference's default, main.jl:84: the loop without the carried remainder),
 // 1 :vegasmc, 2 :mcmc, 3 :vegas for any measurefreq -- each its own code object, compiled the first time it is needed (a new
 // integrand pays for the loop it runs, not for both).  The sample-dump kernel is a fifth, equally lazy one.
-enum { kSlotVegasAny = 3, kSlotDump = 4 };
+enum { kSlotVegasAny = 3, kSlotDump = 4, kSlotVegasmcSpec = 5, kSlotMcmcSpec = 6 };
 static int kslot(int solver, int64_t measurefreq) { return solver == MCI_VEGAS && measurefreq != 1 ? kSlotVegasAny : solver; }
-static int slot_solver(int slot) { return slot == kSlotVegasAny ? MCI_VEGAS : slot; }
+static int slot_solver(int slot) { return slot == kSlotVegasAny ? MCI_VEGAS : slot == kSlotVegasmcSpec ? MCI_VEGASMC : slot == kSlotMcmcSpec ? MCI_MCMC : slot; }
 
 namespace {
 struct Candidate { // one hiprtc job
@@ -1162,7 +1201,8 @@ static int load_slot(mci_problem *p, int slot, Candidate &c, int64_t lds) {
                     mcijit::max_static_lds_bytes(c.code));
     p->code_object[slot] = c.path;
     if (p->ctx->offline) return MCI_OK;
-    static const char *const names[5] = {"mci_vegas_batch", "mci_vegasmc_chains", "mci_mcmc_chains", "mci_vegas_batch", "mci_sample_dump"};
+    static const char *const names[mci_problem::kSlots] = {"mci_vegas_batch", "mci_vegasmc_chains", "mci_mcmc_chains", "mci_vegas_batch", "mci_sample_dump",
+                                                            "mci_vegasmc_spec", "mci_mcmc_spec"};
     HIPCHK(hipSetDevice(p->ctx->device));
     if (hipModuleLoadData(&p->module[slot], c.code.data()) != hipSuccess) {
         // a cached code object that does not load (truncated by a crash, foreign file): drop it and compile afresh, once
@@ -1327,6 +1367,118 @@ static int compile_solver(mci_problem *p, int slot) {
     return MCI_OK;
 }
 
+// ---- several lanes per chain (mci_spec.h) ---------------------------------------------------------------------------------
+// the chain solver's kernel with a group of lanes per chain: its own code object (slots 5, 6), compiled when a launch first asks for it
+static int compile_spec(mci_problem *p, int solver) {
+    const int slot = solver == MCI_VEGASMC ? kSlotVegasmcSpec : kSlotMcmcSpec;
+    if (p->compiled[slot]) return MCI_OK;
+    if (p->shape.measure_body.empty() && !p->shape.host_measure) // vegas/montecarlo.jl:104, mcmc/montecarlo.jl:84
+        for (int i = 0; i < p->ni; ++i)
+            if (p->shape.obs_bin_draw[i] < 0 && p->shape.obs_nbin[i] != p->shape.ncomp)
+                return fail(MCI_ERR_INVALID, "the default measure can only handle observable as Vector with %d scalar elements!", p->ni);
+    p->shape.det = 0;
+    Candidate c;
+    c.src = mcijit::generate_source(p->shape, solver, mcijit::kUnitSpec);
+    c.threads = 256; // (a launch of few chains runs one wave per SIMD: up to 512 registers per lane)
+    c.rc = mcijit::compile(c.src, c.threads, c.code, c.log, c.cached, &c.path, mcijit::kHdrSpec);
+    if (c.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", c.log.c_str());
+    if (int rc = load_slot(p, slot, c, p->lds_bytes)) return rc;
+    p->compiled[slot] = true;
+    return MCI_OK;
+}
+
+// The speculation tree of a group of `lanes` lanes: the `lanes` most probable nodes of the accept / reject tree of a chain whose
+// steps change its configuration with probability `accept` (greedy: the most probable frontier node next; ties go to the older
+// candidate), with at most `limit` accept edges on any way from the root (limit < 0: no bound).  accept -> 0 gives the reject chain,
+// accept = 1/2 the complete binary tree.  Nodes are numbered in the order they are taken: ancestors first.
+static void spec_build(int lanes, double accept, int limit, std::vector<mci::SpecNode> &tab, int *maxacc) {
+    struct Cand { double prob; int parent; bool via_acc; long seq; };
+    std::vector<Cand> front;
+    front.push_back({1.0, -1, false, 0});
+    long seq = 1;
+    tab.clear();
+    *maxacc = 0;
+    while ((int)tab.size() < lanes && !front.empty()) {
+        size_t best = 0;
+        for (size_t i = 1; i < front.size(); ++i)
+            if (front[i].prob > front[best].prob || (front[i].prob == front[best].prob && front[i].seq < front[best].seq)) best = i;
+        const Cand cd = front[best];
+        front.erase(front.begin() + (long)best);
+        mci::SpecNode nd{};
+        if (cd.parent < 0) {
+            nd.depth = 0;
+            nd.anc = -1;
+            nd.nacc = 0;
+            nd.needacc = nd.needrej = 0ull;
+        } else {
+            const mci::SpecNode &pn = tab[(size_t)cd.parent];
+            nd.depth = pn.depth + 1;
+            nd.anc = cd.via_acc ? cd.parent : pn.anc;
+            nd.nacc = pn.nacc + (cd.via_acc ? 1 : 0);
+            nd.needacc = pn.needacc | (cd.via_acc ? 1ull << cd.parent : 0ull);
+            nd.needrej = pn.needrej | (cd.via_acc ? 0ull : 1ull << cd.parent);
+        }
+        const int me = (int)tab.size();
+        tab.push_back(nd);
+        if (nd.nacc > *maxacc) *maxacc = nd.nacc;
+        front.push_back({cd.prob * (1.0 - accept), me, false, seq++});
+        if (limit < 0 || nd.nacc + 1 <= limit) front.push_back({cd.prob * accept, me, true, seq++});
+    }
+}
+
+// the tree of the next launch on the device (rebuilt when lanes / acceptance / limit change)
+static int spec_upload(mci_problem *p, int lanes, double accept, int limit) {
+    if (p->d_spec_tab && p->spec_tab_lanes == lanes && p->spec_tab_accept == accept && p->spec_tab_limit == limit) return MCI_OK;
+    std::vector<mci::SpecNode> tab;
+    int maxacc = 0;
+    spec_build(lanes, accept, limit, tab, &maxacc);
+    if (!p->d_spec_tab) HIPCHK(hipMalloc((void **)&p->d_spec_tab, 64 * sizeof(mci::SpecNode)));
+    // (pageable source: the copy has left `tab` when the call returns)
+    HIPCHK(hipMemcpyAsync(p->d_spec_tab, tab.data(), tab.size() * sizeof(mci::SpecNode), hipMemcpyHostToDevice, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    p->spec_tab_lanes = lanes;
+    p->spec_tab_accept = accept;
+    p->spec_tab_limit = limit;
+    p->spec_tab_maxacc = maxacc;
+    return MCI_OK;
+}
+
+int mci_set_chain_speculation(mci_problem *p, int32_t lanes, double accept, int32_t max_accepts) {
+    if (lanes != -1 && (lanes < 1 || lanes > 64 || (lanes & (lanes - 1)))) return fail(MCI_ERR_INVALID, "lanes per chain: -1 (automatic), 1 (one lane per chain) or a power of two up to 64");
+    if (accept >= 1.0) return fail(MCI_ERR_INVALID, "the acceptance a speculation tree is built for lies in (0, 1); <= 0: the solver's default");
+    p->spec_lanes = lanes;
+    p->spec_accept = accept > 0.0 ? accept : 0.0;
+    p->spec_maxacc = max_accepts < 0 ? -1 : max_accepts;
+    return MCI_OK;
+}
+
+int mci_last_chain_speculation(const mci_problem *p, int32_t *lanes, int32_t *max_accepts) {
+    if (lanes) *lanes = p->last_spec_lanes;
+    if (max_accepts) *max_accepts = p->last_spec_maxacc;
+    return MCI_OK;
+}
+
+int mci_speculation_tree(int32_t lanes, double accept, int32_t max_accepts, int32_t *depth, int32_t *anc, int32_t *nacc, uint64_t *needacc, uint64_t *needrej) {
+    if (lanes < 1 || lanes > 64 || !(accept > 0.0 && accept < 1.0)) return fail(MCI_ERR_INVALID, "speculation tree: 1..64 lanes, acceptance in (0, 1)");
+    std::vector<mci::SpecNode> tab;
+    int maxacc = 0;
+    spec_build(lanes, accept, max_accepts, tab, &maxacc);
+    for (int i = 0; i < lanes; ++i) {
+        if (depth) depth[i] = tab[(size_t)i].depth;
+        if (anc) anc[i] = tab[(size_t)i].anc;
+        if (nacc) nacc[i] = tab[(size_t)i].nacc;
+        if (needacc) needacc[i] = tab[(size_t)i].needacc;
+        if (needrej) needrej[i] = tab[(size_t)i].needrej;
+    }
+    return MCI_OK;
+}
+
+int mci_compile_chain_speculation(mci_problem *p, int32_t solver) {
+    if (solver != MCI_VEGASMC && solver != MCI_MCMC) return fail(MCI_ERR_INVALID, "several lanes per chain: solver MCI_VEGASMC or MCI_MCMC");
+    if (p->shape.host_integrand) return fail(MCI_ERR_INVALID, "a host integrand keeps one lane per chain");
+    return compile_spec(p, solver);
+}
+
 int mci_compile(mci_problem *p) { return compile_solver(p, MCI_VEGAS); }
 
 int mci_kernel_code_object(mci_problem *p, int32_t solver, char *buf, int32_t n) {
@@ -1479,12 +1631,15 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
                       int32_t iteration, uint64_t seed, int64_t measurefreq, int64_t nchain, double thermal_ratio) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context: no device to run on");
     if (solver != MCI_VEGAS && solver != MCI_VEGASMC && solver != MCI_MCMC) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver); // main.jl:263
+    const bool auto_chains = nchain <= 0; // (the holding times of an :mcmc launch are handed to the host only when the next one may size its chains from them)
     if (measurefreq <= 0) return fail(MCI_ERR_INVALID, "measurefreq must be positive"); // vegas/montecarlo.jl:77
     const int64_t nblocks = block_hi - block_lo;
     if (nblocks < 1 || nevalperblock < 1) return fail(MCI_ERR_INVALID, "empty iteration");
     if (p->has_fermik && solver != MCI_MCMC) return fail(MCI_ERR_INVALID, "FermiK variables work with solver=:mcmc only"); // test/bubble_FermiK.jl:2,:133
     const int kern = kslot(solver, measurefreq);
-    int rc = compile_solver(p, kern);
+    // (a chain solver's lane-per-chain kernel is compiled once the launch is known to run one lane per chain: a launch of few chains
+    // runs the several-lanes-per-chain kernel instead, mci_spec.h, and pays for that code object only)
+    int rc = (solver == MCI_VEGAS || p->deterministic || p->shape.host_integrand || p->spec_lanes == 1) ? compile_solver(p, kern) : MCI_OK;
     if (rc) return rc;
     if (solver == MCI_VEGAS && p->shape.host_integrand && (rc = ensure_dump(p))) return rc;
     if ((rc = flush_merge(p))) return rc; // a previous batch nobody looked at: merge it (resets the global histogram)
@@ -1562,7 +1717,39 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     } else {
         nchain = 1;
     }
+    // Several lanes per chain (mci_spec.h): a launch whose chains leave most of the chip idle gives every chain a group of G lanes that
+    // step it speculatively -- the same chain, G <= 64 proposals evaluated per trip.  Automatic: the largest G that keeps the launch
+    // within one wave per SIMD (kSpecFill lanes).  Host integrands keep the lock-step launches; the deterministic mode one lane per chain.
+    int G = 1, spec_maxacc = 0;
+    if (solver != MCI_VEGAS && !s.host_integrand && !p->deterministic && p->spec_lanes != 1) {
+        if (p->spec_lanes > 1) G = p->spec_lanes;
+        else {
+            G = 64;
+            while (G > 1 && nblocks * nchain * G > mci_problem::kSpecFill) G >>= 1;
+        }
+    }
+    int T_launch = T;
+    if (G > 1) {
+        // the tree: the solver's default acceptance unless one was given.  :vegasmc proposals do not depend on the configuration they start
+        // from: any number of accept edges costs one exchange each; :mcmc runs mcmc_propose once per accept level
+        const double accept = p->spec_accept > 0.0 ? p->spec_accept : (solver == MCI_VEGASMC ? 0.5 : 0.35);
+        const int limit = p->spec_maxacc >= 0 ? p->spec_maxacc : (solver == MCI_VEGASMC ? -1 : 2);
+        if ((rc = compile_spec(p, solver))) return rc;
+        if ((rc = spec_upload(p, G, accept, limit))) return rc;
+        spec_maxacc = p->spec_tab_maxacc;
+        units = nchain * G;
+        T_launch = units >= 256 ? 256 : (int)((units + 63) / 64) * 64;
+    }
+    if (G == 1 && (rc = compile_solver(p, kern))) return rc;
+    p->last_spec_lanes = G;
+    p->last_spec_maxacc = spec_maxacc;
     int wpb = p->wg_per_block;
+    if (G > 1) {
+        if (wpb <= 0) wpb = (int)((2048 + nblocks - 1) / nblocks);
+        const int64_t maxw = (units + T_launch - 1) / T_launch;
+        if (wpb > maxw) wpb = (int)maxw;
+        if (wpb < 1) wpb = 1;
+    } else
     if (wpb <= 0) { // 256 CUs x 8..16 workgroups in the grid, never a workgroup without work
         // measured on C2 (workgroup-count sweep): 16 workgroups per CU even out the tail once a launch is long
         // enough that the extra partial rows (merged by k_hist_stage1) do not matter
@@ -1716,6 +1903,11 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         HIPCHK(hipMemsetAsync(p->d_hold, 0, 64 * sizeof(unsigned long long), p->ctx->stream));
         a.hold_hist = p->d_hold;
     }
+    if (G > 1) {
+        a.spec_tab = p->d_spec_tab;
+        a.spec_lanes = G;
+        a.spec_maxacc = spec_maxacc;
+    }
     a.status = p->d_status;
     a.tile_w = p->d_tile_w;
     a.tile_bins = p->d_tile_bins;
@@ -1850,7 +2042,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         }
     }
     void *args[] = {&a};
-    hipFunction_t f = p->f_solver[kern];
+    hipFunction_t f = p->f_solver[G > 1 ? (solver == MCI_VEGASMC ? kSlotVegasmcSpec : kSlotMcmcSpec) : kern];
     hipStream_t st = p->ctx->stream;
     const int slot = (int)(p->launches % mci_problem::kEvRing);
     // HIP events around the sample launch (mci_kernel_times_ms): each record is a barrier packet with a signal, ~5.5 us of idle
@@ -1936,9 +2128,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             }
         }
     } else
-    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
+    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T_launch, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
     if (solver == MCI_MCMC) p->hold_measured = a.hold_hist != nullptr;
-    if (a.hold_hist && (rc = hold_publish(p, nevalperblock / nchain, solver != MCI_VEGAS && p->last_carried))) return rc;
+    // (an explicit chain count: nobody sizes a launch from this one's holds, and the host keeps queueing launches back to back)
+    if (a.hold_hist && auto_chains && (rc = hold_publish(p, nevalperblock / nchain, solver != MCI_VEGAS && p->last_carried))) return rc;
     if (split)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles[kern == kSlotVegasAny ? 1 : 0], (unsigned)(((hist_rows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
@@ -2015,7 +2208,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     }
     p->last_samples = nblocks * nevalperblock;
     p->last_wg = (int)nwg;
-    p->last_threads = T;
+    p->last_threads = T_launch;
     p->last_nblocks = (int)nblocks;
     if (solver != MCI_VEGAS) p->last_nchain = nchain;
     // merge: block sums -> packed
@@ -2045,6 +2238,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     m.npa = p->npa;
     m.nrows = (int)nrows;
     m.block_means = nullptr;
+    m.hold = a.hold_hist; // (:mcmc: the 64 counts follow the tables in `packed`, so that ONE all-reduce carries them; NULL: zeros)
     if (solver != MCI_VEGAS) { // the chain solvers keep every block's mean of every iteration (one row of the block log)
         const int64_t stride = nblocks * s.nobs;
         if (stride != p->blk_stride || block_lo != p->blk_lo) {
@@ -2089,11 +2283,41 @@ int mci_iteration_reduce(mci_problem *p) {
         }
         HIPCHK(hipEventRecord(p->cevs[2 * slot], p->ctx->stream));
     }
-    int r = g_rccl.AllReduce(p->d_packed, p->d_packed, (size_t)p->packed_n, kNcclFloat64, kNcclSum, p->ctx->comm, p->ctx->stream);
+    // ONE collective per iteration whatever the solver: [statistics | histograms | propose | accept] and, behind an :mcmc launch that
+    // measured its holding times, the 64 counts of their histogram (exact in doubles)
+    const size_t count = (size_t)p->packed_n + (p->hold_deferred ? 64 : 0);
+    int r = g_rccl.AllReduce(p->d_packed, p->d_packed, count, kNcclFloat64, kNcclSum, p->ctx->comm, p->ctx->stream);
     if (r) return fail(MCI_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    p->ctx->collectives += 1;
+    p->ctx->last_count = (long long)count;
+    if (p->hold_deferred && (rc = hold_publish_reduced(p))) return rc; // the summed holding-time counts -> pinned host memory
     if (timed) HIPCHK(hipEventRecord(p->cevs[2 * slot + 1], p->ctx->stream));
     p->cev_valid[slot] = timed;
     p->reduces += 1;
+    return MCI_OK;
+}
+
+int mci_comm_collectives(const mci_ctx *c, int64_t *calls, int64_t *last_count) {
+    if (!c) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (calls) *calls = c->collectives;
+    if (last_count) *last_count = c->last_count;
+    return MCI_OK;
+}
+
+// An external reducer (comm.py TorchDistComm) has summed mci_reduce_size() doubles of `packed` over the ranks: what the library does
+// behind its own all-reduce -- the summed :mcmc holding-time counts go to the host, every rank sizes its next chains from them
+int mci_external_reduce_done(mci_problem *p) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    if (!p->hold_ext_pending) return MCI_OK;
+    p->hold_ext_pending = false;
+    HIPCHK(hipSetDevice(p->ctx->device));
+    return hold_publish_reduced(p);
+}
+
+int mci_reduce_size(const mci_problem *p, int64_t *n) {
+    if (!p || !n) return fail(MCI_ERR_INVALID, "NULL argument");
+    *n = p->packed_n + 64;
     return MCI_OK;
 }
 
@@ -2329,7 +2553,7 @@ static int compile_persist(mci_problem *p, bool background) {
         // (512 threads for the hand-pipelined loops of 8..16 draws -- what the launch chain runs them at -- was tried: 22.5 instead of 18.3 us
         // per iteration of the 16-D Gaussian at neval = 1e4, against 15.8 as a launch chain; the automatic rule stops at 7 draws)
         c->threads = p->threads;
-        c->rc = mcijit::compile(c->src, c->threads, c->code, c->log, c->cached, &c->path, true, /*cache_only=*/background);
+        c->rc = mcijit::compile(c->src, c->threads, c->code, c->log, c->cached, &c->path, mcijit::kHdrTrain, /*cache_only=*/background);
         if (c->rc == -1) { // not in the kernel cache: compile it behind the caller's back ...
             // ... once this process has made kPersistAfterCalls launch-bound calls of this kernel (by this problem or others with the same
             // shape and integrand): the persistent launch saves ~40 us per default-size call and its translation unit costs 0.8 s of hiprtc
@@ -2347,7 +2571,7 @@ static int compile_persist(mci_problem *p, bool background) {
             p->persist_job->c = std::move(local);
             mci_problem::PersistJob *j = p->persist_job;
             j->th = std::thread([j] {
-                j->c.rc = mcijit::compile(j->c.src, j->c.threads, j->c.code, j->c.log, j->c.cached, &j->c.path, true);
+                j->c.rc = mcijit::compile(j->c.src, j->c.threads, j->c.code, j->c.log, j->c.cached, &j->c.path, mcijit::kHdrTrain);
                 j->done.store(true, std::memory_order_release);
             });
             return MCI_OK;
@@ -2485,6 +2709,8 @@ static int comm_sum_host(mci_problem *p, double *v, int n) {
     hipStream_t st = p->ctx->stream;
     hipError_t e = hipMemcpyAsync(d, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
     int r = e == hipSuccess ? g_rccl.AllReduce(d, d, (size_t)n, kNcclFloat64, kNcclSum, p->ctx->comm, st) : 0;
+    p->ctx->collectives += 1;
+    p->ctx->last_count = n;
     if (e == hipSuccess && !r) e = hipMemcpyAsync(v, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && !r) e = hipStreamSynchronize(st);
     (void)hipFree(d);
@@ -2632,7 +2858,8 @@ int mci_get_iteration_log(mci_problem *p, int32_t nrows, double *out) {
 
 int mci_get_packed(mci_problem *p, double *out, int64_t n) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
-    if (n != p->packed_n) return fail(MCI_ERR_INVALID, "packed size is %lld", (long long)p->packed_n);
+    if (n != p->packed_n && n != p->packed_n + 64) // (+ 64: with the :mcmc holding-time counts an external reducer sums too, mci_reduce_size)
+        return fail(MCI_ERR_INVALID, "packed size is %lld", (long long)p->packed_n);
     if (int rc = flush_merge(p)) return rc;
     HIPCHK(hipMemcpyAsync(out, p->d_packed, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
@@ -2641,7 +2868,8 @@ int mci_get_packed(mci_problem *p, double *out, int64_t n) {
 
 int mci_set_packed(mci_problem *p, const double *in, int64_t n) {
     if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
-    if (n != p->packed_n) return fail(MCI_ERR_INVALID, "packed size is %lld", (long long)p->packed_n);
+    if (n != p->packed_n && n != p->packed_n + 64) // (+ 64: with the :mcmc holding-time counts an external reducer sums too, mci_reduce_size)
+        return fail(MCI_ERR_INVALID, "packed size is %lld", (long long)p->packed_n);
     if (int rc = flush_merge(p)) return rc;
     HIPCHK(hipMemcpyAsync(p->d_packed, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));

@@ -121,6 +121,17 @@ enum { ST_NORMALIZATION = 1, ST_HIST_NONFINITE = 2, ST_HIST_NONPOSITIVE = 4, ST_
 // ---------------------------------------------------------------------------------------------
 // kernel arguments (plain struct passed by value)
 // ---------------------------------------------------------------------------------------------
+// One node of a chain's speculation tree = one lane of the group that steps the chain (mci_spec.h; filled by the host, mci_api.hip
+// spec_build).  Lanes are numbered ancestors-first.
+struct SpecNode {
+    int depth;   // the lane evaluates the proposal of step (first step of the trip) + depth
+    int anc;     // nearest ancestor the way from the root leaves by its ACCEPT edge: the lane's step starts from that lane's proposal (-1: from the trip's base)
+    int nacc;    // accept edges on the way from the root
+    int reserved;
+    u64 needacc; // lanes (bit = lane within the group) that must have accepted / rejected for this node to be on the chain's path
+    u64 needrej;
+};
+
 struct BatchArgs {
     const double *edges;    // [NEDGE]  all Continuous grids, concatenated          (variable.jl:94)
     const double *dacc;     // [NDACC]  all Discrete accumulation tables            (variable.jl:280)
@@ -210,6 +221,10 @@ struct BatchArgs {
         int *hidx;                              // the integrand the host evaluates for this chain's hx, -1: nothing to evaluate
         int *done;                              // [1] chains that have run all their steps
     } hs;
+    // Several lanes per chain (mci_spec.h): a chain is stepped by a group of spec_lanes lanes (a power of two, 2..64) along the
+    // speculation tree spec_tab[spec_lanes]; spec_maxacc = the most accept edges on any way through it.  0 / NULL: one lane per chain
+    const SpecNode *spec_tab;
+    int spec_lanes, spec_maxacc;
 };
 
 struct DumpArgs {

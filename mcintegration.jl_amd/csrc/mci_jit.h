@@ -30,6 +30,8 @@ namespace mcijit {
 extern const char *const kDeviceHeader;
 // text of mci_train.h (merge + train! device functions and the persistent :vegas kernel): the second header of a kUnitVegasPersist unit
 extern const char *const kTrainHeader;
+// text of mci_spec.h (the chain solvers with several lanes per chain): the second header of a kUnitSpec unit
+extern const char *const kSpecHeader;
 
 struct ProblemShape {
     int ndraw = 0, nleaf = 0, ni = 0, npool = 0, nobs = 0, ncols = 0, table_mode = 0;
@@ -96,7 +98,10 @@ static std::string dbl_arr(const std::vector<double> &v) {
 // measurefreq), the :vegas kernel specialised on measurefreq == 1, or the sample-dump kernel alone; each is built on first use
 // kUnitVegasPersist: the :vegas loop for measurefreq == 1 inside the persistent kernel of mci_train.h (all iterations of a launch-bound
 // integrate() call in one launch): sample loop + block merge + train!
-enum { kUnitSolver = 0, kUnitVegasMf1 = 1, kUnitDump = 2, kUnitVegasPersist = 3 };
+// kUnitSpec: a chain solver's kernel with several lanes per chain (mci_spec.h: vegasmc_chains_spec / mcmc_chains_spec)
+enum { kUnitSolver = 0, kUnitVegasMf1 = 1, kUnitDump = 2, kUnitVegasPersist = 3, kUnitSpec = 4 };
+// which headers a unit is compiled against next to mci_device.h
+enum { kHdrNone = 0, kHdrTrain = 1, kHdrSpec = 2 };
 inline std::string generate_source(const ProblemShape &s, int solver, int unit = kUnitSolver, double persist_alpha = 0.0) {
     std::ostringstream o;
     if (unit == kUnitVegasPersist) { // the learning rate and the size of the one leaf the persistent kernel refines (mci_train.h rescale, sum_julia)
@@ -108,6 +113,7 @@ inline std::string generate_source(const ProblemShape &s, int solver, int unit =
     if (s.rng_rounds != 10) o << "#define MCI_PHILOX_ROUNDS " << s.rng_rounds << "\n"; // opt-in cheaper stream (mci_set_rng_rounds)
     o << "#include \"mci_device.h\"\n";
     if (unit == kUnitVegasPersist) o << "#include \"mci_train.h\"\n";
+    if (unit == kUnitSpec) o << "#include \"mci_spec.h\"\n";
     o << "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n";
     o << "namespace {\nstruct Cfg {\n";
     o << "    static constexpr int NDRAW = " << s.ndraw << ", NLEAF = " << s.nleaf << ", NI = " << s.ni
@@ -176,6 +182,9 @@ inline std::string generate_source(const ProblemShape &s, int solver, int unit =
         if (s.ntile > 1)
             o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegas_tiles(mci::BatchArgs a) { "
                  "mci::vegas_tiles<Cfg>(a); }\n";
+    } else if (unit == kUnitSpec) {
+        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) " << (solver == 1 ? "mci_vegasmc_spec" : "mci_mcmc_spec") << "(mci::BatchArgs a) { "
+          << (solver == 1 ? "mci::vegasmc_chains_spec<Cfg>(a); }\n" : "mci::mcmc_chains_spec<Cfg>(a); }\n");
     } else if (solver == 1) {
         // (a host integrand: the step cut at the integrand call, one launch per Markov step -- same entry point)
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_chains(mci::BatchArgs a) { "
@@ -294,7 +303,7 @@ inline void warm_up_join() {
 
 // returns the gfx950 code object for `src`, from the on-disk cache or by compiling with hiprtc
 inline int compile(const std::string &src, int threads, std::vector<char> &code, std::string &log, bool &from_cache, std::string *cache_path = nullptr,
-                   bool with_train = false, bool cache_only = false) {
+                   int extra_hdr = kHdrNone, bool cache_only = false) {
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics",
                                      "-ffp-contract=off", "-DMCI_THREADS=" + std::to_string(threads)};
     if (const char *e = getenv("MCI_JIT_FLAGS")) {
@@ -303,7 +312,8 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
         while (is >> t) opts.push_back(t);
     }
     std::string key = src + "\n//HDR\n" + kDeviceHeader;
-    if (with_train) key += std::string("\n//HDR\n") + kTrainHeader;
+    if (extra_hdr == kHdrTrain) key += std::string("\n//HDR\n") + kTrainHeader;
+    if (extra_hdr == kHdrSpec) key += std::string("\n//HDR\n") + kSpecHeader;
     for (auto &f : opts) key += "\n//" + f;
     char name[64];
     snprintf(name, sizeof name, "mci_%016llx.hsaco", (unsigned long long)fnv1a(key));
@@ -327,8 +337,8 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
     }
     warm_up_join();
     hiprtcProgram prog;
-    const char *hdr[2] = {kDeviceHeader, kTrainHeader}, *hname[2] = {"mci_device.h", "mci_train.h"};
-    if (hiprtcCreateProgram(&prog, src.c_str(), "mci_problem.hip", with_train ? 2 : 1, hdr, hname) != HIPRTC_SUCCESS) {
+    const char *hdr[2] = {kDeviceHeader, extra_hdr == kHdrSpec ? kSpecHeader : kTrainHeader}, *hname[2] = {"mci_device.h", extra_hdr == kHdrSpec ? "mci_spec.h" : "mci_train.h"};
+    if (hiprtcCreateProgram(&prog, src.c_str(), "mci_problem.hip", extra_hdr != kHdrNone ? 2 : 1, hdr, hname) != HIPRTC_SUCCESS) {
         log = "hiprtcCreateProgram failed";
         return 1;
     }

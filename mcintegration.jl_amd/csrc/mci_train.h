@@ -42,12 +42,16 @@ struct MergeArgs {
     int npa, nrows;          // npa = 3 * (ni+1) * max(ni+1, npool)   (configuration.jl:185-186)
     double *block_means;     // [nblocks][nobs] or NULL: every block's m = observable / normalization of this iteration (main.jl:275-280),
                              // kept per iteration for the block-lineage error of carried chains (mci_lineage_sums)
+    const unsigned long long *hold; // [64] or NULL: the :mcmc holding-time histogram of the launch; its counts follow the tables in `packed`
+                                    // (exact doubles), so that they ride in the iteration's one all-reduce
 };
 // packed = [ ... | hist(nbin) | propose(npa) | accept(npa) ]: the tables ride in the all-reduce like MPIreduceConfig! reduces them
 // (configuration.jl:297-298).  One wave per entry, lanes stride over the workgroup rows.
 __device__ inline int merge_pa_blocks(const MergeArgs &m) { return (2 * m.npa + 3) / 4; }
 __device__ inline void merge_pa(const MergeArgs &m, int blk) {
     const int lane = threadIdx.x & 63, e = blk * 4 + (int)(threadIdx.x >> 6);
+    if (blk == 0 && threadIdx.x < 64) // packed = [ ... | accept(npa) | holding-time histogram(64) ]
+        m.packed[2 * m.nobs + 2 + m.ni + 1 + m.nbin + 2 * m.npa + (int)threadIdx.x] = m.hold ? (double)m.hold[threadIdx.x] : 0.0;
     if (e >= 2 * m.npa || (threadIdx.x >> 6) >= 4) return; // (four entries per workgroup whatever its size)
     double s = 0.0;
     if (m.part_pa)

@@ -362,10 +362,26 @@ class Engine:
         """room for `rows` more iterations in the device-side log, so that none of them synchronises to grow it"""
         check(lib().mci_reserve_iteration_log(self.p, int(rows)))
 
-    def get_packed(self):
-        out = np.empty(self.packed_size)
+    def get_packed(self, reduce_size=False):
+        """the packed buffer [statistics | histograms | propose | accept]; reduce_size: with the 64 :mcmc holding-time counts behind it --
+        what an external reducer sums over the ranks (mci_reduce_size)"""
+        out = np.empty(self.reduce_size if reduce_size else self.packed_size)
         check(lib().mci_get_packed(self.p, _dp(out), len(out)))
         return out
+
+    @property
+    def reduce_size(self):
+        return self.packed_size + 64
+
+    def external_reduce_done(self):
+        """an external reducer has summed reduce_size doubles of the packed buffer over the ranks; see mci_external_reduce_done"""
+        check(lib().mci_external_reduce_done(self.p))
+
+    def comm_collectives(self):
+        """(ncclAllReduce calls the library has issued on this engine's context, element count of the last one)"""
+        n, c = C.c_int64(), C.c_int64()
+        check(lib().mci_comm_collectives(context(self.device), C.byref(n), C.byref(c)))
+        return int(n.value), int(c.value)
 
     def set_packed(self, a):
         a = np.ascontiguousarray(a, dtype=np.float64)
@@ -429,6 +445,21 @@ class Engine:
         n, c = C.c_int64(), C.c_int32()
         check(lib().mci_last_chain_launch(self.p, C.byref(n), C.byref(c)))
         return int(n.value), bool(c.value)
+
+    def set_chain_speculation(self, lanes=-1, accept=0.0, max_accepts=-1):
+        """several lanes per chain (csrc/mci_spec.h): lanes -1 automatic, 1 never, 2..64 forced; the acceptance the speculation tree
+        is built for and the most accept edges on a way through it (<= 0 / < 0: the solver's defaults); see mci_set_chain_speculation"""
+        check(lib().mci_set_chain_speculation(self.p, int(lanes), float(accept), int(max_accepts)))
+
+    def last_chain_speculation(self):
+        """(lanes per chain, accept levels of the tree) of the last chain-solver launch; (1, 0) = one lane per chain"""
+        g, m = C.c_int32(), C.c_int32()
+        check(lib().mci_last_chain_speculation(self.p, C.byref(g), C.byref(m)))
+        return int(g.value), int(m.value)
+
+    def compile_chain_speculation(self, solver):
+        """the several-lanes-per-chain kernel of "vegasmc" | "mcmc" (its own code object)"""
+        check(lib().mci_compile_chain_speculation(self.p, _lib.SOLVERS[solver]))
 
     def set_train_walk(self, mode):
         """train!'s refinement walk: "serial" (the reference's recurrence), "scan" (prefix scan + bisection), "auto", or "serial_general"

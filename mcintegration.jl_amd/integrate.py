@@ -195,8 +195,14 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     if niter_loop and s != VEGAS and hasattr(eng, "block_means"):
         block_mean, ncarried = eng.block_means(niter)
         correlated = ncarried > 0
+    if comm.size > 1 and block_mean is not None:
+        # every rank holds its own blocks' means: gathered ONCE, here, where all ranks take part (a sum of arrays that are zero outside the
+        # rank's own blocks), so that the Result is plain data and Result.with_ignore never enters a collective
+        full = np.zeros((np.asarray(block_mean).shape[0], block, np.asarray(block_mean).shape[2]))
+        full[:, lo:hi, :] = block_mean
+        block_mean = np.asarray(comm.sum_host(eng, full.ravel())).reshape(full.shape)
     res = Result(np.array(means), np.array(stds), config, ignore, neval=neval_done, seconds=time.time() - t0, block_mean=block_mean,
-                 correlated=correlated, block=block, sum_ranks=(lambda v: comm.sum_host(eng, v)) if comm.size > 1 else None)   # main.jl:211
+                 correlated=correlated, block=block)   # main.jl:211
     res.warmup = warmup   # launches that were run again instead of being counted (automatic :mcmc chain lengths)
     if print >= 0:
         report(res, io=printio)                                                       # main.jl:212-213

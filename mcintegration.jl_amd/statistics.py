@@ -49,14 +49,15 @@ class Result:
     observables, an ndarray for array observables (like `obs=[zeros(4)]`).
     `block_mean` ([niter][local blocks][nobs]) with `correlated=True`: the iterations continued each other's chains (carried chains of
     the many-chain decomposition), so the error is the scatter of the blocks' weighted averages over the run (mci_lineage_sums) instead of
-    statistics.jl:198, which assumes independent iterations; `sum_ranks` adds the lineage sums of the other ranks' blocks."""
+    statistics.jl:198, which assumes independent iterations.  A multi-rank run hands over the block means of ALL ranks' blocks
+    (integrate() gathers them once, with every rank taking part), so a Result is plain data: `with_ignore` is local, talks to no
+    communicator and keeps no engine alive."""
 
-    def __init__(self, iter_mean, iter_std, config, ignore, neval=0, seconds=0.0, block_mean=None, correlated=False, block=None,
-                 sum_ranks=None):
+    def __init__(self, iter_mean, iter_std, config, ignore, neval=0, seconds=0.0, block_mean=None, correlated=False, block=None):
         self.iter_mean = np.asarray(iter_mean)   # [niter, nobs]
         self.iter_std = np.asarray(iter_std)
         self.config, self.ignore, self.neval, self.seconds = config, int(ignore), int(neval), seconds
-        self.block_mean, self.correlated, self.block, self._sum_ranks = block_mean, bool(correlated), block, sum_ranks
+        self.block_mean, self.correlated, self.block = block_mean, bool(correlated), block
         niter, nobs = self.iter_mean.shape
         flat = [average(self.iter_mean[:, o], self.iter_std[:, o], init=ignore + 1, max=niter) for o in range(nobs)]
         self._flat_mean = np.array([f[0] for f in flat])
@@ -64,9 +65,6 @@ class Result:
         self._flat_chi2 = np.array([f[2] for f in flat])
         if self.correlated and block_mean is not None and niter > ignore + 1:
             s1, s2 = lineage_sums(block_mean, self.iter_std, init=ignore + 1, max=niter)
-            if sum_ranks is not None:
-                tot = sum_ranks(np.concatenate([s1, s2]))
-                s1, s2 = tot[:nobs], tot[nobs:]
             le = mean_std(s1, s2, block if block else np.asarray(block_mean).shape[1])[1]
             self._flat_std = np.where(le > 0.0, le, self._flat_std)   # (an identically-zero column keeps the reference's 1e-10-regularised error)
         self.mean, self.stdev, self.chi2 = self._shape(self._flat_mean), self._shape(self._flat_std), self._shape(self._flat_chi2)
@@ -88,7 +86,7 @@ class Result:
     def with_ignore(self, ignore):
         """Result(res, ignore) (statistics.jl:56-62)"""
         return self if ignore == self.ignore else Result(self.iter_mean, self.iter_std, self.config, ignore, self.neval, self.seconds,
-                                                         self.block_mean, self.correlated, self.block, self._sum_ranks)
+                                                         self.block_mean, self.correlated, self.block)
 
     @property
     def dof(self):

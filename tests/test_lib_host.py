@@ -226,12 +226,20 @@ def test_lineage_sums_are_the_scatter_of_the_blocks_weighted_averages():
     r3 = res.with_ignore(3)
     s1, s2 = lineage_sums(bm, ie, init=4, max=niter)
     np.testing.assert_allclose(r3.stdev, mean_std(s1, s2, nb)[1], rtol=1e-14)
-    # two "ranks" with half of the blocks each: the sums add
+    # two "ranks" with half of the blocks each: the sums add (what the library's loop does with mci_comm_sum; integrate() gathers the
+    # block means of all ranks once instead, so that a Result is plain data)
     tot = []
     for half in (bm[:, :nb // 2], bm[:, nb // 2:]):
         tot.append(np.concatenate(lineage_sums(half, ie, init=2, max=niter)))
-    split = mci.Result(im, ie, cfg, ignore=1, block_mean=bm[:, :nb // 2], correlated=True, block=nb, sum_ranks=lambda v: tot[0] + tot[1])
-    np.testing.assert_allclose(split.stdev, res.stdev, rtol=1e-12)
+    np.testing.assert_allclose(mean_std((tot[0] + tot[1])[:nobs], (tot[0] + tot[1])[nobs:], nb)[1], res.stdev, rtol=1e-12)
+    gathered = np.zeros_like(bm)
+    for lo, hi in ((0, nb // 2), (nb // 2, nb)):   # the sum integrate() forms over the ranks: zero outside a rank's own blocks
+        part = np.zeros_like(bm)
+        part[:, lo:hi] = bm[:, lo:hi]
+        gathered += part
+    split = mci.Result(im, ie, cfg, ignore=1, block_mean=gathered, correlated=True, block=nb)
+    np.testing.assert_allclose(split.stdev, res.stdev, rtol=1e-14)
+    assert not hasattr(split, "_sum_ranks") and split.with_ignore(3).stdev == r3.stdev   # local: no communicator, no engine
 
 
 def test_closure_form_is_decided_by_parameters_without_defaults():

@@ -145,7 +145,7 @@ def measured_issue_costs():
     return costs, source
 
 
-def issue_roofline(code_object, costs, samples_per_launch, kernel_ms, hist_copies=1):
+def issue_roofline(code_object, costs, samples_per_launch, kernel_ms, hist_copies=1, sclk_mhz=None):
     """{"valu": ..., "lds": ...}: the launch's wave-instructions on each pipe per second against the rate at which the chip
     can issue THAT mix (1024 SIMDs / mix-weighted mean issue cost).  The LDS rows are costs seen from one SIMD with all four
     SIMDs of the CU competing, so the same 1024 applies."""
@@ -160,6 +160,16 @@ def issue_roofline(code_object, costs, samples_per_launch, kernel_ms, hist_copie
         peak = N_SIMD / (cyc[pipe] / n_inst) if n_inst else 0.0   # 1024 SIMDs / mean ns per instruction
         out[pipe] = {"achieved": round(ach, 2), "peak": round(peak, 2), "frac": round(ach / peak, 4) if peak else None,
                      "instructions_per_wave_sample": n_inst, "issue_ns_per_wave_sample": round(cyc[pipe], 1)}
+    # the same mix at DATA-SHEET issue cycles and the shader clock the timed launches measured themselves running at: a fraction anyone can
+    # recompute from the instruction counts below -- sum(n * cycles) * wave-samples per SIMD / clock / kernel time
+    ds_cyc, ds_per = isa_mix.datasheet_valu_cycles(mix)
+    out["valu_datasheet"] = {"cycles_per_wave_sample": ds_cyc, "sclk_mhz": None if not sclk_mhz else round(sclk_mhz, 1),
+                             "wave_samples_per_simd": round(trips / N_SIMD, 2),
+                             "classes": {cls: {"n": n, "cycles_each": c} for cls, (n, c) in sorted(ds_per.items())}}
+    if sclk_mhz:
+        ns = ds_cyc / (sclk_mhz * 1e-3)                                  # ns per wave-sample on its SIMD
+        out["valu_datasheet"].update({"issue_ns_per_wave_sample": round(ns, 1),
+                                      "frac": round(ns * 1e-6 * (trips / N_SIMD) / kernel_ms, 4)})
     out["mix"] = {cls: {"n": n, "ns_each": round(c, 3)} for cls, (n, c) in sorted(cyc["per_class"].items())}
     out["samples_per_loop_trip"] = mix["samples_per_trip"]
     out["resources"] = isa_mix.resources(code_object).get("mci_vegas_batch")
@@ -425,16 +435,34 @@ def main():
                            "bound: the tables are LDS-resident by design, real HBM traffic (`traffic`, PMC) is ~1e-3 of it, so frac > 1"}
             costs, costs_src = measured_issue_costs()
             roof = {"bound": "valu+lds", "kernel_ms_avg": round(k_avg_ms, 4), "traffic": traffic, "hbm_model": hbm}
+            # the shader clock of the timed region: every timed launch's first wave brackets its sample loop with s_memtime (shader
+            # cycles) and s_memrealtime (constant rate); the chip clocks to its power budget under this loop, not to its 2.4 GHz peak
+            clk = eng.kernel_clocks_mhz(min(ntimed, 512)) if hasattr(eng, "kernel_clocks_mhz") else []
+            sclk = float(np.mean(clk)) if len(clk) else None
+            roof["clock"] = {"sclk_mhz_avg": None if sclk is None else round(sclk, 1), "sclk_mhz_min": None if sclk is None else round(float(np.min(clk)), 1),
+                             "sclk_mhz_max": None if sclk is None else round(float(np.max(clk)), 1), "launches": int(len(clk)),
+                             "source": "s_memtime / s_memrealtime around the sample loop of workgroup 0's first wave, every timed launch (mci_kernel_clocks)"}
             if costs:
-                ir = issue_roofline(code_object, costs, spl, k_avg_ms, hist_copies=out["config"].get("histogram_copies", 1))
+                ir = issue_roofline(code_object, costs, spl, k_avg_ms, hist_copies=out["config"].get("histogram_copies", 1), sclk_mhz=sclk)
                 top = "valu" if ir["valu"]["frac"] >= ir["lds"]["frac"] else "lds"
-                roof.update({"achieved": ir[top]["achieved"], "peak": ir[top]["peak"], "unit": "G wave-instructions/s", "frac": ir[top]["frac"],
-                             "binding_pipe": top, "valu": ir["valu"], "lds": ir["lds"], "mix": ir["mix"], "resources": ir["resources"],
+                ds = ir["valu_datasheet"]
+                # `frac`: the VALU pipe at data-sheet issue cycles and the measured clock (recomputable from the line itself); the
+                # self-calibrated reading (issue costs this run measured with its own microbenchmark) rides along as frac_self_calibrated
+                if ds.get("frac") is not None:
+                    peak_ds = N_SIMD / (ds["issue_ns_per_wave_sample"] / ir["valu"]["instructions_per_wave_sample"])
+                    roof.update({"achieved": ir["valu"]["achieved"], "peak": round(peak_ds, 2), "unit": "G wave-instructions/s", "frac": ds["frac"],
+                                 "binding_pipe": "valu", "frac_self_calibrated": ir[top]["frac"], "binding_pipe_self_calibrated": top})
+                else:
+                    roof.update({"achieved": ir[top]["achieved"], "peak": ir[top]["peak"], "unit": "G wave-instructions/s", "frac": ir[top]["frac"],
+                                 "binding_pipe": top, "frac_self_calibrated": ir[top]["frac"]})
+                roof.update({"valu_datasheet": ds, "valu": ir["valu"], "lds": ir["lds"], "mix": ir["mix"], "resources": ir["resources"],
                              "costs_source": costs_src,
-                             "note": "achieved = wave64 instructions the launch issues on the binding pipe per second (sample-loop mix from "
-                                     "the loaded code object x waves / HIP-event kernel time); peak = 1024 SIMDs / mix-weighted mean issue cost "
-                                     "of those instruction forms, measured on this GPU by tools/issue_microbench.hip.  VALU and LDS are "
-                                     "separate pipes that overlap: the larger fraction binds; the SURVEY 8(d) HBM model is kept in hbm_model"})
+                             "note": "frac = VALU issue time of the sample loop at DATA-SHEET cycles (valu_datasheet.classes: n x cycles per wave "
+                                     "and sample) x wave-samples per SIMD / the shader clock the timed launches measured (clock.sclk_mhz_avg) / "
+                                     "HIP-event kernel time; peak = 1024 SIMDs / (data-sheet cycles per instruction of this mix / that clock).  "
+                                     "frac_self_calibrated = the same mix priced with the issue costs tools/issue_microbench.hip measured on this "
+                                     "GPU in this run (valu / lds: separate pipes that overlap, the larger fraction binds).  The SURVEY 8(d) HBM "
+                                     "model is kept in hbm_model"})
                 if sq and sq.get("SQ_INSTS_VALU") and sq.get("SQ_WAVES"):
                     roof["pmc_check"] = {"SQ_INSTS_VALU_per_wave_sample": sq["SQ_INSTS_VALU"] / (spl / 64.0),
                                          "SQ_INSTS_LDS_per_wave_sample": sq.get("SQ_INSTS_LDS", 0) / (spl / 64.0), "source": traffic_src}

@@ -36,6 +36,8 @@ enum { MCI_CONTINUOUS = 0, MCI_DISCRETE = 1, MCI_FERMIK = 2 }; /* Dist.Continuou
 enum { MCI_VEGAS = 0, MCI_VEGASMC = 1, MCI_MCMC = 2 }; /* solver=:vegas main.jl:256 / :vegasmc :253 / :mcmc :259 */
 /* not a solver: names the persistent :vegas kernel (mci_set_persistent) for mci_compile_solver / mci_kernel_code_object */
 enum { MCI_VEGAS_PERSISTENT = 3 };
+/* ... and the chain solvers' kernels with several lanes per chain (mci_set_chain_speculation), code objects of their own */
+enum { MCI_VEGASMC_LANES = 5, MCI_MCMC_LANES = 6 };
 
 typedef struct mci_ctx mci_ctx;
 typedef struct mci_problem mci_problem;
@@ -378,6 +380,10 @@ int mci_kernel_times_ms(mci_problem *prob, float *ms, int32_t n, int32_t *got, i
  * samples: mode -1 (default) records them for launches of >= 2^20 samples, 0 never, 1 always (mci_kernel_times_ms returns the
  * recorded launches only). */
 int mci_set_kernel_timing(mci_problem *prob, int32_t mode);
+/* the shader clock (MHz) the sample loops of the last n timed MCI_VEGAS launches ran at, oldest first: the first wave of workgroup 0
+ * reads s_memtime (shader cycles) and s_memrealtime (the constant-rate reference, hipDeviceAttributeWallClockRate) around its loop.
+ * What the roofline of bench.py prices data-sheet issue cycles with: the chip clocks to its power budget, not to its 2.4 GHz peak. */
+int mci_kernel_clocks(mci_problem *prob, double *mhz, int32_t n, int32_t *got);
 /* HIP-event durations (ms, oldest first, ring of 64) of the per-iteration ncclAllReduce of mci_iteration_reduce on this rank,
  * recorded under the same rule: the time a rank spends in the one exchange step of the path (main.jl:177-188) -- its own wait for
  * the slowest rank's sample pass plus the latency of an all-reduce of `packed_size` doubles */

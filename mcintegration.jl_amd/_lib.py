@@ -115,6 +115,7 @@ SIGNATURES = [
     ("mci_train", C.c_int, [_VP]),
     ("mci_sample_dump", C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
     ("mci_kernel_times_ms", C.c_int, [_VP, C.POINTER(C.c_float), C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
+    ("mci_kernel_clocks", C.c_int, [_VP, c_double_p, C.c_int32, c_int32_p]),
     ("mci_comm_times_ms", C.c_int, [_VP, C.POINTER(C.c_float), C.c_int32, c_int32_p]),
     ("mci_comm_collectives", C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("mci_reduce_size", C.c_int, [_VP, C.POINTER(C.c_int64)]),
@@ -140,6 +141,8 @@ DEBUG_SIGNATURES = [
     ("mci_debug_walk_counts", C.c_int, [_VP, C.POINTER(C.c_int64)]),
     ("mci_debug_plant_wrong_decision", C.c_int, [_VP, C.c_int32]),
     ("mci_debug_persist_spin_ticks", C.c_int, [_VP, C.c_uint64]),
+    ("mci_debug_override", C.c_int, [C.c_char_p, C.c_int64, C.c_int32]),
+    ("mci_debug_mcmc_policy", C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
 ]
 
 _lib = None

@@ -269,6 +269,7 @@ struct mci_problem {
     int64_t cap_carry_src = 0, cap_carry_W = 0;
     bool last_carried = false;   // the last chain launch continued the one before it
     // last launch
+    unsigned long long *d_clocks = nullptr; // [kEvRing][2] shader-clock | reference-clock ticks of the timed :vegas launches' sample loops
     std::vector<hipEvent_t> evs; // ring of (start, stop) pairs around the sampling kernel, one pair per launch
     int64_t launches = 0;
     static const int kEvRing = 512;
@@ -306,14 +307,29 @@ struct mci_problem {
 // i + kRepeatStride * attempt: the iteration index has 17 bits (DESIGN.md "RNG streams"), runs of fewer than 16384 iterations leave the upper ones free
 static const int kRepeatStride = 16384, kMaxRepeats = 7;
 
-static int64_t env_i64(const char *name, int64_t dflt) {
-    const char *e = getenv(name);
-    return e && *e ? atoll(e) : dflt;
+// (process-wide; csrc/mci_debug.h mci_debug_mcmc_policy moves them for A/B campaigns -- tools/mcmc_policy.py, profiles/r04_mcmc_policy.txt)
+int64_t mci_problem::kMcmcPilotSteps = 4096;
+int64_t mci_problem::kMcmcGrow = 2;
+int64_t mci_problem::kMcmcCarryHolds = 4;
+int64_t mci_problem::kMcmcCarryHalfFloors = 2;
+
+// Layout decisions of mci_problem_create that tests and A/B tools force (csrc/mci_debug.h mci_debug_override): process-wide, consulted
+// by the NEXT mci_problem_create.  The library itself reads two environment variables and no others: MCI_KERNEL_CACHE (where code objects
+// are cached) and MCI_JIT_FLAGS (extra hiprtc options), mci_jit.h.
+namespace {
+struct Override { bool on = false; int64_t v = 0; };
+struct Overrides { Override table_mode, hist_tile_bins, no_split_all, l1_phase, train_walk, hist_copies; } g_over;
+Override *override_slot(const char *key) {
+    if (!key) return nullptr;
+    if (!strcmp(key, "table_mode")) return &g_over.table_mode;
+    if (!strcmp(key, "hist_tile_bins")) return &g_over.hist_tile_bins;
+    if (!strcmp(key, "no_split_all")) return &g_over.no_split_all;
+    if (!strcmp(key, "l1_phase")) return &g_over.l1_phase;
+    if (!strcmp(key, "train_walk")) return &g_over.train_walk;
+    if (!strcmp(key, "hist_copies")) return &g_over.hist_copies;
+    return nullptr;
 }
-int64_t mci_problem::kMcmcPilotSteps = env_i64("MCI_MCMC_PILOT", 4096);
-int64_t mci_problem::kMcmcGrow = env_i64("MCI_MCMC_GROW", 2);
-int64_t mci_problem::kMcmcCarryHolds = env_i64("MCI_MCMC_CARRY_HOLDS", 4);
-int64_t mci_problem::kMcmcCarryHalfFloors = env_i64("MCI_MCMC_CARRY_HALF_FLOORS", 2);
+} // namespace
 
 static void persist_job_drop(mci_problem *p);
 namespace { void persist_orphans_join(); }
@@ -787,23 +803,20 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         else if (fixed + e1 + hb <= lim0) { mode = 0; pair = 0; }
         else if (fixed + e2 + hb <= lim1) { mode = 0; pair = 1; }
         else if (fixed + e1 + hb <= lim1) { mode = 0; pair = 0; }
-        if (const char *e = getenv("MCI_TABLE_MODE")) { // test/diagnostic override
-            const int m = atoi(e);
+        if (g_over.table_mode.on) { // test / diagnostic override (mci_debug_override)
+            const int m = (int)g_over.table_mode.v;
             if (m == 1 && fixed + e1 <= lim1) { mode = 1; pair = (fixed + e2 <= lim1) ? 1 : 0; }
             if (m == 2) { mode = 2; pair = 0; }
             if (m == 3) { mode = 3; pair = 0; }
         }
-        if (const char *e = getenv("MCI_TRAIN_SERIAL")) p->train_serial = atoi(e) == 2 ? 2 : atoi(e) != 0 ? 1 : 0;
-        if (const char *e = getenv("MCI_CHAIN_CARRY")) p->chain_carry = atoi(e) == 0 ? 0 : atoi(e) > 0 ? 1 : -1; // (mci_set_chain_carry)
-        if (const char *e = getenv("MCI_PERSISTENT")) p->persistent = atoi(e) == 0 ? 0 : atoi(e) > 0 ? 1 : -1;     // (mci_set_persistent)
-        if (const char *e = getenv("MCI_KERNEL_TIMING")) p->kernel_timing = atoi(e) < 0 ? -1 : atoi(e) > 0 ? 1 : 0; // (mci_set_kernel_timing)
+        if (g_over.train_walk.on) p->train_serial = g_over.train_walk.v == 2 ? 2 : g_over.train_walk.v != 0 ? 1 : 0; // (= mci_set_train_walk on every new problem)
         // histogram tiles: contiguous leaves, each tile's bins fit the LDS left over
         s.leaf_tile.assign(p->leaves.size(), 0);
         s.tile_boff.assign(1, 0);
         s.tile_nbin.assign(1, s.nbin);
         if (mode == 3) {
             int64_t budget = (lim1 - fixed) / 8; // doubles
-            if (const char *e = getenv("MCI_HIST_TILE_BINS")) budget = atoll(e);
+            if (g_over.hist_tile_bins.on) budget = g_over.hist_tile_bins.v;
             s.tile_boff.clear();
             s.tile_nbin.clear();
             // as few tiles as the budget allows, filled evenly: the replay kernel's time follows its LARGEST tile
@@ -819,7 +832,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
                 int64_t mx = 0;
                 for (const Leaf &L : p->leaves) mx = L.nbin > mx ? L.nbin : mx;
                 fill = even + mx - 1 < budget ? even + mx - 1 : budget; // a tile closes once it holds >= `even` bins
-                if (getenv("MCI_HIST_TILE_BINS")) fill = budget;
+                if (g_over.hist_tile_bins.on) fill = budget;
             }
             int cur = -1;
             for (size_t l = 0; l < p->leaves.size(); ++l) {
@@ -837,8 +850,8 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         s.ntile = (int)s.tile_nbin.size();
         // several tiles under :vegas -> "split-all": the sample pass keeps no histogram at all and uses the LDS for the edges
         // of as many leading grids as fit (they stop being L2 gathers); every tile is replayed by mci_vegas_tiles.  Measured on
-        // C4 (32 grids): 10.3 -> see profiles; MCI_NO_SPLIT_ALL=1 restores "tile 0 in the sample pass" for A/B runs.
-        s.split_all = (s.ntile > 1 && !(getenv("MCI_NO_SPLIT_ALL") && atoi(getenv("MCI_NO_SPLIT_ALL")) != 0)) ? 1 : 0;
+        // C4 (32 grids): 10.3 -> see profiles; the override no_split_all = 1 restores "tile 0 in the sample pass" for A/B runs.
+        s.split_all = (s.ntile > 1 && !(g_over.no_split_all.on && g_over.no_split_all.v != 0)) ? 1 : 0;
         s.leaf_ecoff.assign(p->leaves.size(), -1);
         s.ec_doubles = 0;
         if (s.split_all) {
@@ -870,7 +883,7 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         // random-address ds_add_f64.  Rule: tables in LDS (mode 0), as many copies (<= 8) as leave room for TWO 512-thread
         // workgroups per CU (4 waves per SIMD when the kernel needs <= 128 VGPRs; compile_solver checks).  Measured on C2
         // (tools/hcopy_sweep.sh, kernel ms per 1e8 samples): 1 copy x 256 threads 1.715 | 4 x 512 1.663 | 8 x 512 1.625 |
-        // 16 x 1024 (one workgroup per CU) 1.662 | 8 x 1024 1.694.  MCI_HIST_COPIES overrides (1 = off).
+        // 16 x 1024 (one workgroup per CU) 1.662 | 8 x 1024 1.694.  The override hist_copies forces a count (1 = off).
         s.hcopy = 1;
         {
             int hc = 1;
@@ -879,8 +892,8 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
             for (int k = 0; k < s.ndraw; ++k) nadd += (p->leaves[s.draw_leaf[k]].adapt && s.cover_mask[k]) ? 1 : 0;
             if (mode == 0 && s.ntile == 1 && p->lds_bytes <= lim0 && nadd >= 4) // (a 1-D integrand runs 4 % slower with 512 threads and gains nothing)
                 while (hc < 8 && p->lds_bytes + one * (2 * hc - 1) <= lim0) hc *= 2;
-            if (const char *e = getenv("MCI_HIST_COPIES")) { // diagnostic override
-                hc = atoi(e);
+            if (g_over.hist_copies.on) { // diagnostic override
+                hc = (int)g_over.hist_copies.v;
                 while (hc > 1 && (!hist_lds || s.ntile != 1 || (hc & (hc - 1)) || p->lds_bytes + one * (hc - 1) > lim1)) hc >>= 1;
                 if (hc < 1) hc = 1;
             }
@@ -902,23 +915,20 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         // Split-all pass (several histogram tiles, e.g. 32 grids): the grids gathered from global memory are walked dimension-major by
         // all waves of a workgroup in step, so that the CU's L1 sees one or two 8 KB tables at a time (draw_gather_phase).  Measured
         // on C4 (tools/ab_c2.py): 7.26 -> 6.95 ms per 1e8 samples; with one tile (16 grids, histogram in the pass) the barriers
-        // cost more than the locality buys (2.77 -> 3.47 ms), so it stays off there.  MCI_L1_PHASE=0 | n overrides (n samples
-        // per lane and trip; 2 already spills on 32 grids).
+        // cost more than the locality buys (2.77 -> 3.47 ms), so it stays off there.  The override l1_phase = 0 | 1 forces it.
         s.l1_phase = (mode == 3 && s.split_all) ? 1 : 0;
-        if (const char *e = getenv("MCI_L1_PHASE")) s.l1_phase = (mode >= 2 && atoi(e) > 0) ? 1 : 0; // (test / diagnostic override: 0 = natural draw order)
+        if (g_over.l1_phase.on) s.l1_phase = (mode >= 2 && g_over.l1_phase.v > 0) ? 1 : 0; // (test / diagnostic override: 0 = natural draw order)
         // one big workgroup per CU owns its LDS
         if (p->lds_bytes > lim0) p->threads = 512; // measured (tools/c4_sweep.py): 2 waves/SIMD beat 1 fat and 4 spilling ones
         // ... and as many waves as its registers allow.  With the bins packed as they are drawn and the phased trips unconditional the
         // 32-grid Genz pass needs 146 VGPRs with the gather phase (209 before): 768 threads, 6.97 -> 6.45 ms per 1e8 samples; the 16-grid
         // Gaussian (histogram in the pass, 104 VGPRs) runs 1024 threads: 2.78 -> 2.44 ms (tools/c4_abenv.sh).  compile_solver walks the
         // ladder 1024 -> 768 -> 512 until the code object shows no scratch.
-        if (p->lds_bytes > lim0 && !getenv("MCI_THREADS")) {
+        if (p->lds_bytes > lim0) {
             p->vegas_plan_a = true;
             p->threads_vegas = 1024;
         }
-        if (const char *e = getenv("MCI_THREADS")) // diagnostic override of the default workgroup size
-            if (atoi(e) >= 64 && atoi(e) <= 1024 && atoi(e) % 64 == 0) p->threads = atoi(e);
-        if (s.hcopy > 1 && !p->vegas_plan_a && !getenv("MCI_THREADS")) { // two 512-thread workgroups per CU (the rule above)
+        if (s.hcopy > 1 && !p->vegas_plan_a) { // two 512-thread workgroups per CU (the rule above)
             p->hcopy_plan = true;
             p->threads_vegas = 512;
         }
@@ -978,6 +988,7 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->d_carry_W) (void)hipFree(p->d_carry_W);
         if (p->d_carry_src) (void)hipFree(p->d_carry_src);
         if (p->d_spec_tab) (void)hipFree(p->d_spec_tab);
+        if (p->d_clocks) (void)hipFree(p->d_clocks);
         if (p->h_hold) (void)hipHostFree(p->h_hold);
         if (p->h_hold_d) (void)hipHostFree(p->h_hold_d);
         if (p->h_log) (void)hipHostFree(p->h_log);
@@ -1117,7 +1128,7 @@ int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
             p->hcopy_plan = false;
             p->threads_vegas = 0;
             // histogram copies are sized for two 512-thread workgroups per CU: smaller workgroups would leave the CU half empty
-            p->hcopy_auto = threads >= 512 || getenv("MCI_HIST_COPIES") ? p->hcopy_rule : 1;
+            p->hcopy_auto = threads >= 512 || g_over.hist_copies.on ? p->hcopy_rule : 1;
             drop_modules(p);
         }
     }
@@ -1288,7 +1299,7 @@ static int compile_solver(mci_problem *p, int slot) {
             if (chosen.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", chosen.log.c_str());
         }
     } else {
-        const bool hcopy_plan = p->hcopy_plan && !getenv("MCI_HIST_COPIES");
+        const bool hcopy_plan = p->hcopy_plan && !g_over.hist_copies.on;
         int tcopy = 512;
         p->shape.hcopy = planned_hcopy(p, &tcopy);
         if (p->hcopy_plan) p->threads_vegas = tcopy;
@@ -1488,6 +1499,12 @@ int mci_kernel_code_object(mci_problem *p, int32_t solver, char *buf, int32_t n)
         snprintf(buf, (size_t)n, "%s", p->persist_code_object.c_str());
         return MCI_OK;
     }
+    if (solver == MCI_VEGASMC_LANES || solver == MCI_MCMC_LANES) {
+        const int sl = solver == MCI_VEGASMC_LANES ? kSlotVegasmcSpec : kSlotMcmcSpec;
+        if (!p->compiled[sl]) return fail(MCI_ERR_INVALID, "the several-lanes-per-chain kernel has not been compiled yet");
+        snprintf(buf, (size_t)n, "%s", p->code_object[sl].c_str());
+        return MCI_OK;
+    }
     if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver);
     const int slot = (solver == MCI_VEGAS && !p->compiled[solver] && p->compiled[kSlotVegasAny]) ? kSlotVegasAny : solver;
     if (!p->compiled[slot]) return fail(MCI_ERR_INVALID, "solver %d has not been compiled yet", solver);
@@ -1526,6 +1543,22 @@ int mci_set_train_walk(mci_problem *p, int32_t mode) {
 int mci_debug_plant_wrong_decision(mci_problem *p, int32_t on) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     p->debug_wrong_decision = on != 0;
+    return MCI_OK;
+}
+
+int mci_debug_override(const char *key, int64_t value, int32_t on) {
+    Override *o = override_slot(key);
+    if (!o) return fail(MCI_ERR_INVALID, "no such override: %s", key ? key : "(null)");
+    o->on = on != 0;
+    o->v = value;
+    return MCI_OK;
+}
+
+int mci_debug_mcmc_policy(int64_t pilot_steps, int64_t grow, int64_t carry_holds, int64_t carry_half_floors) {
+    if (pilot_steps > 0) mci_problem::kMcmcPilotSteps = pilot_steps;
+    if (grow > 0) mci_problem::kMcmcGrow = grow;
+    if (carry_holds > 0) mci_problem::kMcmcCarryHolds = carry_holds;
+    if (carry_half_floors > 0) mci_problem::kMcmcCarryHalfFloors = carry_half_floors;
     return MCI_OK;
 }
 
@@ -1605,6 +1638,7 @@ int mci_compile_solver(mci_problem *p, int32_t solver) {
         if (!persist_layout_ok(p)) return fail(MCI_ERR_INVALID, "this layout has no persistent :vegas kernel (mci_set_persistent)");
         return compile_persist(p, false);
     }
+    if (solver == MCI_VEGASMC_LANES || solver == MCI_MCMC_LANES) return mci_compile_chain_speculation(p, solver == MCI_VEGASMC_LANES ? MCI_VEGASMC : MCI_MCMC);
     if (solver < 0 || solver > 2) return fail(MCI_ERR_INVALID, "Solver %d is not supported!", solver); // main.jl:263
     return compile_solver(p, solver);
 }
@@ -2049,6 +2083,13 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     // queue -- a third of a launch-bound iteration (neval = 1e4: 36 -> 25 us), nothing next to a launch of millions of samples.
     // mci_set_kernel_timing: -1 (default) = launches of >= 2^20 samples, 0 = never, 1 = always
     p->time_this_launch = p->kernel_timing > 0 || (p->kernel_timing < 0 && nblocks * nevalperblock >= ((int64_t)1 << 20));
+    if (p->time_this_launch && solver == MCI_VEGAS) { // ... and the clock the sample loop ran at (mci_kernel_clocks)
+        if (!p->d_clocks) {
+            HIPCHK(hipMalloc((void **)&p->d_clocks, (size_t)2 * mci_problem::kEvRing * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(p->d_clocks, 0, (size_t)2 * mci_problem::kEvRing * sizeof(unsigned long long), st));
+        }
+        a.clock_out = p->d_clocks + 2 * slot;
+    }
     if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot], st));
     if (solver != MCI_VEGAS && s.host_integrand) {
         // The closure sits inside the Markov step (vegas_mc/updates.jl:67-75, mcmc/updates.jl:35-38): the chains of this launch advance
@@ -3131,6 +3172,31 @@ int mci_kernel_times_ms(mci_problem *p, float *ms, int32_t n, int32_t *got, int3
     if (got) *got = (int32_t)have;
     if (wg) *wg = p->last_wg;
     if (threads) *threads = p->last_threads;
+    return MCI_OK;
+}
+
+// shader clock of the last n timed :vegas launches (oldest first), MHz: ticks of s_memtime (shader cycles) over ticks of s_memrealtime
+// (the device's constant-rate reference, hipDeviceAttributeWallClockRate) across the sample loop of workgroup 0's first wave
+int mci_kernel_clocks(mci_problem *p, double *mhz, int32_t n, int32_t *got) {
+    if (!p || !mhz || !got) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (p->ctx->offline) return fail(MCI_ERR_NO_DEVICE, "offline context");
+    *got = 0;
+    if (!p->d_clocks) return MCI_OK;
+    HIPCHK(hipSetDevice(p->ctx->device));
+    int khz = 0;
+    HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, p->ctx->device));
+    std::vector<unsigned long long> h((size_t)2 * mci_problem::kEvRing);
+    HIPCHK(hipMemcpyAsync(h.data(), p->d_clocks, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    int64_t have = p->launches < mci_problem::kEvRing ? p->launches : mci_problem::kEvRing;
+    if (have > n) have = n;
+    int32_t k = 0;
+    for (int64_t i = 0; i < have; ++i) {
+        const int slot = (int)((p->launches - have + i) % mci_problem::kEvRing);
+        if (!p->ev_valid[slot] || !h[(size_t)2 * slot + 1]) continue;
+        mhz[k++] = (double)h[(size_t)2 * slot] / (double)h[(size_t)2 * slot + 1] * (double)khz * 1.0e-3;
+    }
+    *got = k;
     return MCI_OK;
 }
 

@@ -18,6 +18,21 @@ int mci_debug_plant_wrong_decision(mci_problem *prob, int32_t on);
 /* test hook: ticks of the 100 MHz clock a grid-wide wait of the persistent :vegas launch may take before it gives up (default 2 s =
  * 200000000); a tiny value forces the stall so that the fall-back to the launch chain can be tested */
 int mci_debug_persist_spin_ticks(mci_problem *prob, unsigned long long ticks);
+/* Layout decisions of mci_problem_create that tests and A/B tools force; process-wide, consulted by the NEXT mci_problem_create; on = 0
+ * takes an override back.  Keys:
+ *   table_mode      0 .. 3   placement of grids / histograms
+ *   hist_tile_bins  n        bins of an LDS histogram tile (forces several tiles)
+ *   no_split_all    1        tiled :vegas: tile 0 stays in the sample pass, only the other tiles are replayed
+ *   l1_phase        0 | 1    dimension-major gather phase of the many-grid sample pass
+ *   hist_copies     n        interleaved histogram copies of the :vegas sample kernel (1 = none)
+ *   train_walk      0 | 1 | 2  = mci_set_train_walk on every new problem
+ * (The library reads two environment variables and no others: MCI_KERNEL_CACHE -- the directory code objects are cached in -- and
+ * MCI_JIT_FLAGS -- extra hiprtc options; INTEGRATION.md.) */
+int mci_debug_override(const char *key, int64_t value, int32_t on);
+/* the constants of the automatic :mcmc chain length (DESIGN.md "Chains"), process-wide, for A/B campaigns (tools/mcmc_policy.py): measured
+ * steps of a first launch (4096) | how much longer than the chains that measured the holds a launch's chains may be (2) | length of a
+ * carried chain in longest holds (4) | its minimum in half burn-in floors (2); <= 0 keeps a value */
+int mci_debug_mcmc_policy(int64_t pilot_steps, int64_t grow, int64_t carry_holds, int64_t carry_half_floors);
 #ifdef __cplusplus
 }
 #endif

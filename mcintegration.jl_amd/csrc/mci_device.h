@@ -225,6 +225,9 @@ struct BatchArgs {
     // speculation tree spec_tab[spec_lanes]; spec_maxacc = the most accept edges on any way through it.  0 / NULL: one lane per chain
     const SpecNode *spec_tab;
     int spec_lanes, spec_maxacc;
+    // :vegas, timed launches (mci_kernel_clocks): the first wave of workgroup 0 leaves the shader-clock ticks (s_memtime) and the
+    // constant-rate reference ticks (s_memrealtime) its sample loop took -- their ratio is the clock the kernel actually ran at
+    u64 *clock_out; // [2] or NULL
 };
 
 struct DumpArgs {
@@ -315,6 +318,24 @@ template <class Cfg> constexpr bool all_draws_pair_table() {
     return true;
 }
 
+// A grid gathered from global memory (table modes 2 / 3): edges g[iy], g[iy + 1] of the increment a draw falls into.  MCI_GATHER_X4 (an
+// experiment, off: profiles/r05_ablation.txt): ONE 16-byte load -- dword-aligned global loads of any width are legal on gfx950 -- instead
+// of two 8-byte loads of neighbouring addresses.
+#ifndef MCI_GATHER_X4
+#define MCI_GATHER_X4 0
+#endif
+__device__ __forceinline__ void gather_edges(const double *e, double &g0, double &g1) {
+#if MCI_GATHER_X4
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    const d2u v = *reinterpret_cast<const d2u *>(e);
+    g0 = v.x;
+    g1 = v.y;
+#else
+    g0 = e[0];
+    g1 = e[1];
+#endif
+}
+
 template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __forceinline__ void draw_leaf(const Tables<Cfg> &t, double y, double &x, double &raw, int &bin) {
     constexpr int leaf = Cfg::draw_leaf(K);
     if constexpr (Cfg::leaf_kind(leaf) != 0 && U12) y -= 1.0;
@@ -347,8 +368,9 @@ template <class Cfg, int K, bool U12 = false, bool ECACHE = false> __device__ __
             dx = t.EC[eoff + iy + 1] - g0;
         } else {
             constexpr int eoff = Cfg::leaf_eoff(leaf);
-            g0 = t.E[eoff + iy]; // (L2 gathers in table modes 2/3: non-temporal loads measured 30 % slower)
-            dx = t.E[eoff + iy + 1] - g0;
+            double g1;
+            gather_edges(t.E + eoff + iy, g0, g1); // (L2 gathers in table modes 2/3: non-temporal loads measured 30 % slower)
+            dx = g1 - g0;
         }
         x = g0 + dy * dx;
         raw = dx;
@@ -639,8 +661,7 @@ template <class Cfg, bool ECACHE, bool KV, int DPC> __device__ __forceinline__ v
                         const int iy = (int)yn;
                         pend[slot][j].iy = iy;
                         pend[slot][j].dy = __builtin_amdgcn_fract(yn);
-                        pend[slot][j].g0 = t.E[eoff + iy];
-                        pend[slot][j].g1 = t.E[eoff + iy + 1];
+                        gather_edges(t.E + eoff + iy, pend[slot][j].g0, pend[slot][j].g1);
                     }
                 }
             });
@@ -1218,8 +1239,23 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
 #define MCI_MF_ONLY 0
 #endif
     auto run_mf = [&](auto TT) { run(TT, IC<(MCI_MF_ONLY != 0 ? 1 : 0)>{}); };
+    // (one-tile kernels only: the four scalar pairs cost the split-all pass of BASELINE configs[3] seven VGPRs -- 124 -> 131, one rung of
+    // its workgroup-size ladder)
+    const bool stamp = !SPLIT && Cfg::NTILE == 1 && a.clock_out != nullptr && blockIdx.x == 0 && tid < 64; // (wave-uniform: scalar reads of the two counters)
+    u64 ck0 = 0ull, rt0 = 0ull;
+    if (stamp) {
+        ck0 = __builtin_amdgcn_s_memtime();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     if constexpr (Cfg::NTILE == 1 || SPLIT) run_mf(IC<0>{});
     else static_for<0, Cfg::NTILE>([&](auto TT) { if (tile == decltype(TT)::value) run_mf(TT); });
+    if (stamp) {
+        const u64 ck1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            a.clock_out[0] = ck1 - ck0;
+            a.clock_out[1] = rt1 - rt0;
+        }
+    }
     __syncthreads();
     flush_workgroup<Cfg, L, !NOHIST>(a, smem, acc, extra, wi.rowid, tile);
 }

@@ -331,10 +331,6 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
         }
     }
     if (cache_only) return -1; // (not in the cache: the caller compiles it elsewhere, e.g. on a thread of its own)
-    if (const char *e = getenv("MCI_DUMP_SRC")) {
-        std::ofstream f(e);
-        f << src;
-    }
     warm_up_join();
     hiprtcProgram prog;
     const char *hdr[2] = {kDeviceHeader, extra_hdr == kHdrSpec ? kSpecHeader : kTrainHeader}, *hname[2] = {"mci_device.h", extra_hdr == kHdrSpec ? "mci_spec.h" : "mci_train.h"};

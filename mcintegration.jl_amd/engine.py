@@ -304,14 +304,19 @@ class Engine:
             pass
 
     # ---- kernels -------------------------------------------------------------------------------
+    @staticmethod
+    def _kernel_code(solver):
+        return {"vegas_persistent": 3, "vegasmc_lanes": 5, "mcmc_lanes": 6}.get(solver) or _lib.SOLVERS[solver]
+
     def compile(self, solver="vegas"):
-        """solver: "vegas" | "vegasmc" | "mcmc" | "vegas_persistent" (the persistent :vegas kernel, layouts with one Continuous leaf)"""
-        check(lib().mci_compile_solver(self.p, 3 if solver == "vegas_persistent" else _lib.SOLVERS[solver]))
+        """solver: "vegas" | "vegasmc" | "mcmc" | "vegas_persistent" (the persistent :vegas kernel, layouts with one Continuous leaf) |
+        "vegasmc_lanes" | "mcmc_lanes" (the chain solvers' kernels with several lanes per chain, csrc/mci_spec.h)"""
+        check(lib().mci_compile_solver(self.p, self._kernel_code(solver)))
 
     def code_object(self, solver="vegas"):
         """kernel-cache file holding the solver's gfx950 code object (after compile / the first run)"""
         buf = C.create_string_buffer(4096)
-        check(lib().mci_kernel_code_object(self.p, 3 if solver == "vegas_persistent" else _lib.SOLVERS[solver], buf, len(buf)))
+        check(lib().mci_kernel_code_object(self.p, self._kernel_code(solver), buf, len(buf)))
         return buf.value.decode()
 
     def set_kernel_timing(self, mode=-1):
@@ -544,6 +549,13 @@ class Engine:
         got, wg, th = C.c_int32(), C.c_int32(), C.c_int32()
         check(lib().mci_kernel_times_ms(self.p, ms, n, C.byref(got), C.byref(wg), C.byref(th)))
         return np.array(ms[:got.value], dtype=np.float64), wg.value, th.value
+
+    def kernel_clocks_mhz(self, n=512):
+        """shader clock (MHz) of the last n timed :vegas launches, from s_memtime / s_memrealtime around the sample loop; see mci_kernel_clocks"""
+        out = np.empty(n)
+        got = C.c_int32()
+        check(lib().mci_kernel_clocks(self.p, _dp(out), n, C.byref(got)))
+        return out[:got.value].copy()
 
     def comm_times_ms(self, n=64):
         """HIP-event durations of this rank's last n per-iteration all-reduces inside the library (oldest first; recorded under the

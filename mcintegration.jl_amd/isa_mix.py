@@ -42,6 +42,28 @@ COST_KEY = {
 }
 
 
+# Data-sheet issue cycles of a wave64 instruction on a CDNA4 SIMD (32 lanes wide for 32-bit VOP1/VOP2 forms: 2 cycles; fp64, the
+# 64-bit integer forms, v_mad_u64_u32 / v_mul_*_u32 and every 32-bit form with three sources or an SGPR third source: 4; transcendentals
+# quarter rate: 8; f64 rcp: 16).  bench.py prices the loop's mix with these at the clock the kernel MEASURED itself running at
+# (mci_kernel_clocks) next to the self-calibrated costs of tools/issue_microbench.hip.
+DATASHEET_CYCLES = {
+    "valu_b32": 2, "valu_bitop3_vgpr": 2, "valu_bitop3": 4, "valu_b32_3src": 4, "valu_mad_u64_u32": 4, "valu_mul_u32": 4, "valu_b64": 4,
+    "valu_f64_fma": 4, "valu_f64_mul": 4, "valu_f64_add": 4, "valu_f64_fract": 4, "valu_f64_cvt": 4, "valu_f64_cmp": 4, "valu_f64_ldexp": 4,
+    "valu_f64_rcp": 16, "valu_trans_f32": 8,
+}
+
+
+def datasheet_valu_cycles(mix):
+    """(cycles per wave and sample on the VALU pipe at data-sheet issue rates, {class: (n, cycles each)})"""
+    per, tot = {}, 0.0
+    for cls, n in mix["classes"].items():
+        if cls.startswith("valu"):
+            c = DATASHEET_CYCLES.get(cls, 2)
+            per[cls] = (n, c)
+            tot += n * c
+    return tot, per
+
+
 # 32-bit forms with three source operands (VOP3-only): measured at the f64 rate, not at the VOP2 rate (tools/issue_microbench.hip)
 _THREE_SOURCE_B32 = {"v_alignbit_b32", "v_lshl_add_u32", "v_add_lshl_u32", "v_and_or_b32", "v_lshl_or_b32", "v_or3_b32", "v_add3_u32",
                      "v_xad_u32", "v_bfe_u32", "v_bfe_i32", "v_bfi_b32", "v_perm_b32", "v_mad_u32_u24", "v_mad_i32_i24", "v_min3_u32",

@@ -33,6 +33,32 @@ def golden():
         return json.load(fh)
 
 
+class _Overrides:
+    """layout decisions of mci_problem_create forced for a test (csrc/mci_debug.h mci_debug_override): process-wide, consulted by the
+    next Engine(...); everything set through the fixture is taken back when the test ends"""
+
+    def __init__(self):
+        self.keys = set()
+
+    def set(self, key, value):
+        from mcintegration_jl_amd._lib import check, lib
+        check(lib().mci_debug_override(key.encode(), int(value), 1))
+        self.keys.add(key)
+
+    def clear(self, key=None):
+        from mcintegration_jl_amd._lib import check, lib
+        for k in ([key] if key else list(self.keys)):
+            check(lib().mci_debug_override(k.encode(), 0, 0))
+            self.keys.discard(k)
+
+
+@pytest.fixture
+def overrides():
+    o = _Overrides()
+    yield o
+    o.clear()
+
+
 @pytest.fixture(autouse=True)
 def _note_process_groups(request):
     """remember, for pytest_unconfigure, whether any test of this session initialised a torch.distributed process group"""

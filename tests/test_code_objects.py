@@ -63,6 +63,16 @@ def test_baseline_kernels_do_not_spill(name, cfg, f, meas, solver, kernel, max_v
         assert res[kernel]["max_threads"] == 1024     # plan A of the split-all pass: first rung of the ladder
 
 
+@pytest.mark.parametrize("name,solver", [("c3", "vegasmc"), ("c5", "mcmc"), ("c5", "vegasmc"), ("c3", "mcmc")])
+def test_kernels_with_several_lanes_per_chain_do_not_spill(name, solver):
+    """csrc/mci_spec.h (a group of lanes steps one chain): launches of few chains, one wave per SIMD -- up to 512 registers (VGPRs + AGPRs),
+    no scratch, and like every sample kernel no static LDS"""
+    b = [x for x in BASELINE if x[0] == name][0]
+    res = isa_mix.resources(_code_object(b[1], b[2], b[3], solver + "_lanes"))
+    k = res["mci_%s_spec" % solver]
+    assert k["vgpr_spill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 512 and k.get("lds", 0) == 0, k
+
+
 @pytest.mark.parametrize("name", ["c1", "c2"])
 def test_persistent_vegas_kernel_neither_spills_nor_declares_static_lds(name):
     """the persistent :vegas kernel (mci_set_persistent; sample loop + block merge + train! of one Continuous grid, 256 threads, plain

@@ -255,11 +255,11 @@ def test_vegas_iteration_block_range_and_measurefreq(oracle):
 
 @pytest.mark.parametrize("walk", ["serial", "serial_general", "prefix"])
 @pytest.mark.parametrize("name", ["c1_log_over_sqrt", "c2_gauss16_shared_pool", "discrete", "bubble", "singular2_composite", "c5_nested_gauss"])
-def test_train_matches_oracle(oracle, name, walk, monkeypatch):
+def test_train_matches_oracle(oracle, name, walk, overrides):
     """rows a9/a10: smooth -> rescale -> refine (variable.jl:206-239), Discrete (:369-382).  `serial` walks the reference's recurrence
     with the decisions of the prefix-scan form given and checked (falling back to `serial_general`, the recurrence with its compares
     and branches, where one does not hold or a bin yields several points); `prefix` is the scan + bisection form."""
-    monkeypatch.setenv("MCI_TRAIN_SERIAL", {"serial": "1", "serial_general": "2", "prefix": "0"}[walk])
+    overrides.set("train_walk", {"serial": 1, "serial_general": 2, "prefix": 0}[walk])
     c, cfg, eng, ocfg = make(name, oracle)
     block, npb = 8, 4000
     eng.run("vegas", npb, 0, block, 0, SEED)
@@ -302,11 +302,11 @@ def test_mid_size_launch_spreads_its_atomic_flush_over_three_buffers(oracle, nam
 
 @pytest.mark.parametrize("walk", ["serial", "serial_general", "prefix"])
 @pytest.mark.parametrize("ninc", [1025, 1026, 2500])
-def test_train_of_a_grid_longer_than_julias_simd_block_matches_oracle(oracle, ninc, walk, monkeypatch):
+def test_train_of_a_grid_longer_than_julias_simd_block_matches_oracle(oracle, ninc, walk, overrides):
     """train! on grids of 1024 / 1025 / 2499 increments: Julia's sum() (common.jl:72, variable.jl:226) runs its @simd block up to 1024
     elements and splits longer vectors pairwise at the midpoint first (base/reduce.jl mapreduce_impl) -- mcio_sum_julia in the oracle,
     sum_julia on the device; same tolerances as the default 999 increments"""
-    monkeypatch.setenv("MCI_TRAIN_SERIAL", {"serial": "1", "serial_general": "2", "prefix": "0"}[walk])
+    overrides.set("train_walk", {"serial": 1, "serial_general": 2, "prefix": 0}[walk])
     cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0, ninc=ninc), dof=[[2]], seed=SEED)
     eng = mci.Engine(cfg, mci.catalog.x2y2())
     ocfg = oracle.Config([ocont(npts=ninc)], [[2]])
@@ -322,15 +322,15 @@ def test_train_of_a_grid_longer_than_julias_simd_block_matches_oracle(oracle, ni
 
 @pytest.mark.parametrize("walk", ["serial", "serial_general", "prefix"])
 @pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "bubble", "c2_gauss4_composite"])
-def test_full_integrate_matches_oracle(oracle, name, walk, monkeypatch):
+def test_full_integrate_matches_oracle(oracle, name, walk, overrides):
     """rows a13-a15: the whole loop inside the library (mci_integrate) vs the oracle's loop, same seed.
 
     The adaptation loop grid -> histogram -> grid amplifies rounding-level differences by ~1-2 orders of
     magnitude per train! step (measured: 1 ulp of device pow/log becomes 1e-6 after six steps), so the run-level
     tolerance depends on how the refinement walk rounds: `serial` = the reference's recurrence order
-    (variable.jl:227-234; MCI_TRAIN_SERIAL=1), `prefix` = the default scan + bisection form (one train! step of
+    (variable.jl:227-234; override train_walk = 1), `prefix` = the default scan + bisection form (one train! step of
     either agrees with the oracle to 1e-12 of the range, test_train_matches_oracle)."""
-    monkeypatch.setenv("MCI_TRAIN_SERIAL", {"serial": "1", "serial_general": "2", "prefix": "0"}[walk])
+    overrides.set("train_walk", {"serial": 1, "serial_general": 2, "prefix": 0}[walk])
     rtol, sig = (1e-6, 1e-3) if walk != "prefix" else (1e-4, 5e-2)
     c, cfg, eng, ocfg = make(name, oracle)
     r = eng.integrate("vegas", neval=40000, niter=6, block=16, seed=SEED)
@@ -383,12 +383,11 @@ def test_serial_walk_slots_against_the_general_form_on_random_layouts(case_id):
     check_walks_agree(case_id, SEED)
 
 
-def test_full_integrate_default_walk_at_large_launches_is_the_reference_recurrence(oracle, monkeypatch):
+def test_full_integrate_default_walk_at_large_launches_is_the_reference_recurrence(oracle):
     """The DEFAULT refinement walk: once an iteration's sample launch is long enough to hide its ~14 us (>= 2^26 samples per
     rank: the headline configuration's 1e8 included) train! runs the reference's serial recurrence (variable.jl:227-234), so whole
     runs agree with the oracle at the 1e-6 level of the serial walk; below that size the prefix-scan form keeps the launch-bound regime at 50 us per iteration
     (1e-4 level, test_full_integrate_matches_oracle[prefix]).  Engine.set_train_walk("serial") asks for the recurrence at any size."""
-    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
     neval = (1 << 26) + 16
     c, cfg, eng, ocfg = make("c1_log_over_sqrt", oracle)
     r = eng.integrate("vegas", neval=neval, niter=4, block=16, seed=SEED)
@@ -396,7 +395,7 @@ def test_full_integrate_default_walk_at_large_launches_is_the_reference_recurren
     np.testing.assert_allclose(r["iter_mean"], o["iter_mean"], rtol=1e-6, atol=1e-300)
     np.testing.assert_allclose(r["iter_std"], o["iter_std"], rtol=1e-4, atol=1e-300)
     np.testing.assert_allclose(eng.grid(0), ocfg.grid(0), rtol=0, atol=1e-8)
-    # the explicit knob, at a small size: same 1e-6 level as MCI_TRAIN_SERIAL=1
+    # the explicit knob, at a small size: same 1e-6 level as the override train_walk = 1
     c, cfg, eng, ocfg = make("sphere2_padding", oracle)
     eng.set_train_walk("serial")
     r = eng.integrate("vegas", neval=40000, niter=6, block=16, seed=SEED)
@@ -596,15 +595,15 @@ def test_launch_geometry_independence(oracle):
         np.testing.assert_allclose(o, outs[0], rtol=1e-10)
 
 
-def test_table_modes_agree(monkeypatch):
+def test_table_modes_agree(overrides):
     """LDS-resident tables (mode 0), LDS grids + global f64 atomics (1), everything from L2 (2)."""
     outs = []
     for mode, tile_bins, keep_tile0 in (("0", None, "0"), ("1", None, "0"), ("2", None, "0"), ("3", None, "0"), ("3", "1000", "0"), ("3", "2000", "0"),
                                         ("3", "1000", "1")):
-        monkeypatch.setenv("MCI_TABLE_MODE", mode)
-        monkeypatch.setenv("MCI_NO_SPLIT_ALL", keep_tile0)       # "1": tile 0 stays in the sample pass, only the other tiles are replayed
+        overrides.set("table_mode", int(mode))
+        overrides.set("no_split_all", int(keep_tile0))       # "1": tile 0 stays in the sample pass, only the other tiles are replayed
         if tile_bins:
-            monkeypatch.setenv("MCI_HIST_TILE_BINS", tile_bins)  # force 3 / 2 histogram tiles (split-all: every tile replayed, edges cached in LDS)
+            overrides.set("hist_tile_bins", int(tile_bins))  # force 3 / 2 histogram tiles (split-all: every tile replayed, edges cached in LDS)
         cfg = mci.Configuration(var=mci.Continuous([(0.0, PI)] * 3), dof=[[1]], seed=SEED)
         eng = mci.Engine(cfg, mci.catalog.singular2())
         assert eng.table_mode == int(mode)
@@ -617,11 +616,11 @@ def test_table_modes_agree(monkeypatch):
 
 
 @pytest.mark.parametrize("solver", ["vegasmc", "mcmc"])
-def test_chain_solvers_with_tiled_histograms_match_oracle(oracle, solver, monkeypatch):
+def test_chain_solvers_with_tiled_histograms_match_oracle(oracle, solver, overrides):
     """table mode 3 with several histogram tiles under the chain solvers: every tile's workgroup replays the same
     chains (same Philox indices) and keeps its own tile; the merged histogram must equal the untiled oracle's."""
-    monkeypatch.setenv("MCI_TABLE_MODE", "3")
-    monkeypatch.setenv("MCI_HIST_TILE_BINS", "1000")   # one 999-bin leaf per tile -> 3 tiles
+    overrides.set("table_mode", 3)
+    overrides.set("hist_tile_bins", 1000)   # one 999-bin leaf per tile -> 3 tiles
     cfg = mci.Configuration(var=mci.Continuous([(0.0, PI)] * 3), dof=[[1]], seed=SEED)
     eng = mci.Engine(cfg, mci.catalog.singular2())
     assert eng.table_mode == 3
@@ -734,13 +733,13 @@ def test_chain_streams_are_addressed_by_block_and_chain(oracle):
 
 
 @pytest.mark.parametrize("threads,phase", [(None, None), (768, None), (512, None), (1024, "0")], ids=["plan_a_1024", "768", "plan_b_512", "no_phase_1024"])
-def test_c4_genz32_runs_in_l2_table_mode_and_matches_oracle(oracle, threads, phase, monkeypatch):
+def test_c4_genz32_runs_in_l2_table_mode_and_matches_oracle(oracle, threads, phase, overrides):
     """BASELINE config 4 layout: 32 independent grids (256 KB of edges > LDS).  Default: one workgroup per CU walking the gathered grids
     dimension-major, the largest of 1024 / 768 / 512 threads at which the sample pass shows no scratch (plan A: 1024 for the Genz
     integrand now that the code object holds ONE loop variant, 120 VGPRs); 512 threads is plan B, the fallback for integrands that
-    need more than 168 registers; MCI_L1_PHASE=0 draws in the natural order."""
+    need more than 168 registers; the override l1_phase = 0 draws in the natural order."""
     if phase is not None:
-        monkeypatch.setenv("MCI_L1_PHASE", phase)
+        overrides.set("l1_phase", int(phase))
     ud = genz_userdata(32)
     cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
     eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32), **(dict(threads=threads) if threads else {}))

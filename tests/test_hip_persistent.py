@@ -20,9 +20,8 @@ OTHERS = ["bubble", "c2_gauss4_composite", "discrete", "discrete2_composite", "s
 
 
 @pytest.mark.parametrize("name", NAMES)
-def test_persistent_run_matches_oracle(oracle, name, monkeypatch):
+def test_persistent_run_matches_oracle(oracle, name):
     """the whole loop in one launch vs the oracle's loop, same seed: every iteration's mean / error, the final Result, the trained maps"""
-    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
     c, cfg, eng, ocfg = make(name, oracle)
     eng.set_persistent("on")
     r = eng.integrate("vegas", neval=40000, niter=6, block=16, seed=SEED)
@@ -49,10 +48,9 @@ def test_persistent_run_matches_oracle(oracle, name, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["c1_log_over_sqrt", "c5_nested_gauss", "c2_gauss16_shared_pool"])
-def test_one_persistent_iteration_leaves_the_oracles_packed_buffer_and_grid(oracle, name, monkeypatch):
+def test_one_persistent_iteration_leaves_the_oracles_packed_buffer_and_grid(oracle, name):
     """niter = 1: the packed buffer the launch leaves behind (statistics head, merged histograms cleared by train!) and the map
     after ONE train! -- the per-iteration tolerances of the launch chain (test_train_matches_oracle)"""
-    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
     c, cfg, eng, ocfg = make(name, oracle)
     eng.set_persistent("on")
     block, npb = 8, 4000
@@ -79,10 +77,9 @@ def test_one_persistent_iteration_leaves_the_oracles_packed_buffer_and_grid(orac
 
 
 @pytest.mark.parametrize("name", ["c1_log_over_sqrt", "sphere2_padding", "c2_gauss16_shared_pool"])
-def test_persistent_launch_and_launch_chain_give_the_same_run(name, oracle, monkeypatch):
+def test_persistent_launch_and_launch_chain_give_the_same_run(name, oracle):
     """the same call with the persistent launch on and off, then a second call that continues from the trained map (resume pattern
     docs/src/index.md:129): the two paths hand over to each other"""
-    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
     runs = {}
     for mode in ("on", "off"):
         c, cfg, eng, ocfg = make(name, oracle)
@@ -100,10 +97,9 @@ def test_persistent_launch_and_launch_chain_give_the_same_run(name, oracle, monk
 
 
 @pytest.mark.parametrize("name", OTHERS)
-def test_layouts_without_a_persistent_kernel_take_the_launch_chain(oracle, name, monkeypatch):
+def test_layouts_without_a_persistent_kernel_take_the_launch_chain(oracle, name):
     """several leaves (every workgroup would have to refine all of them) or a Discrete one: the call runs as the launch chain, whatever
     mci_set_persistent says, with the launch chain's results"""
-    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
     c, cfg, eng, ocfg = make(name, oracle)
     eng.set_persistent("on")
     r = eng.integrate("vegas", neval=40000, niter=3, block=16, seed=SEED)
@@ -193,13 +189,12 @@ def test_two_processes_share_the_device_with_persistent_launches():
     np.testing.assert_allclose(a, b, rtol=1e-6)   # same seeds, same iterations: the same runs up to the order of the histogram atomics
 
 
-def test_a_stalled_persistent_launch_falls_back_to_the_launch_chain(oracle, monkeypatch):
+def test_a_stalled_persistent_launch_falls_back_to_the_launch_chain(oracle):
     """The grid-wide wait of the persistent launch needs all its workgroups resident; on a device shared with another long-running kernel
     a wait can run out of time.  The call must not be lost: the map is written back after the LAST turn only, so mci_integrate resets the
     counters and histogram buffers, rewinds the iteration log and runs the SAME iterations through the launch chain (and later calls take
     the chain).  Forced here with the test hook of csrc/mci_debug.h: a wait of one 10 ns tick."""
     from mcintegration_jl_amd._lib import check, lib
-    monkeypatch.delenv("MCI_TRAIN_SERIAL", raising=False)
     c, cfg, eng, ocfg = make("c1_log_over_sqrt", oracle)
     eng.set_persistent("on")
     check(lib().mci_debug_persist_spin_ticks(eng.p, 1))

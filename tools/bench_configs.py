@@ -4,7 +4,6 @@ cold end-to-end rate of one integrate(niter=10) call on a fresh problem and the 
 import math
 import sys
 import os
-os.environ.setdefault("MCI_KERNEL_TIMING", "1")   # kernel durations for every launch, the small ones included
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,6 +22,7 @@ def run(name, cfg, f, solver, neval, exact, measure=None, niter_train=5, niter=5
     included -- inside the wall time), and TRAINED = `niter` more iterations continuing from the trained map (bench.py's protocol)."""
     import time
     eng = mci.Engine(cfg, f, measure=measure)
+    eng.set_kernel_timing(1)   # kernel durations for every launch, the small ones included
     eng.compile(solver)
     t0 = time.perf_counter()
     c = eng.integrate(solver, neval=neval, niter=10, block=16, seed=1, nchain=nchain)

@@ -99,6 +99,7 @@ template <int OP> __global__ void __launch_bounds__(256) k_issue(u64 *ticks, int
     const u32 seqaddr = (u32)lane * 8u;
     (void)seqaddr;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const u64 rt0 = __builtin_amdgcn_s_memrealtime();
     const u64 t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -289,6 +290,7 @@ template <int OP> __global__ void __launch_bounds__(256) k_issue(u64 *ticks, int
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const u64 t1 = __builtin_readcyclecounter();
+    const u64 rt1 = __builtin_amdgcn_s_memrealtime();
     // keep every destination alive
     u32 sink = 0;
     double dsink = 0.0;
@@ -298,7 +300,10 @@ template <int OP> __global__ void __launch_bounds__(256) k_issue(u64 *ticks, int
         dsink += d[j] + l2[j].x + l2[j].y;
     }
     if (sink == 0x12345678u && dsink == 1.2345) ticks[0] = 0;
-    if (lane == 0) ticks[(size_t)blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+    if (lane == 0) {
+        ticks[(size_t)blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+        ticks[((size_t)gridDim.x + blockIdx.x) * 4 + (tid >> 6)] = rt1 - rt0; // reference-clock ticks (100 MHz) of the same stretch
+    }
 }
 
 // ---- the Philox4x32-10 block exactly as mci_device.h writes it (compiler-scheduled), per-call cost ----
@@ -335,10 +340,14 @@ template <int ROUNDS> __global__ void __launch_bounds__(256) k_philox(u64 *ticks
     }
     const u64 t1 = __builtin_readcyclecounter();
     if (acc == 0x12345678u) ticks[0] = 0;
-    if (lane == 0) ticks[(size_t)blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+    if (lane == 0) {
+        ticks[(size_t)blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+        ticks[((size_t)gridDim.x + blockIdx.x) * 4 + (tid >> 6)] = 0;
+    }
 }
 
-struct Res { double cyc_per_inst, ns_per_inst, clock_ghz, slope_ns; };
+static double g_wall_khz = 100000.0; // hipDeviceAttributeWallClockRate
+struct Res { double cyc_per_inst, ns_per_inst, clock_ghz, slope_ns, sclk_mhz; };
 
 // launch(nblk, iters).  ns_per_inst = wall time of one launch / wave-instructions per SIMD (includes launch + tail: an upper
 // bound); slope_ns = (wall(2 * iters) - wall(iters)) / the extra wave-instructions: the fixed part cancels -- the issue cost.
@@ -364,11 +373,15 @@ template <class F> static Res run(F launch, int W, double insts_per_wave_per_ite
     CHK(hipDeviceSynchronize());
     const float ms2 = timed(2 * iters);
     const float ms = timed(iters); // (last: the tick counters below are this launch's)
-    std::vector<u64> t((size_t)nblk * 4);
+    std::vector<u64> t((size_t)nblk * 4 * 2);
     CHK(hipMemcpy(t.data(), d_ticks, t.size() * sizeof(u64), hipMemcpyDeviceToHost));
-    double mean = 0.0;
-    for (u64 v : t) mean += (double)v;
-    mean /= (double)t.size();
+    double mean = 0.0, rmean = 0.0;
+    for (size_t k = 0; k < t.size() / 2; ++k) {
+        mean += (double)t[k];
+        rmean += (double)t[t.size() / 2 + k];
+    }
+    mean /= (double)(t.size() / 2);
+    rmean /= (double)(t.size() / 2);
     CHK(hipEventDestroy(e0));
     CHK(hipEventDestroy(e1));
     const double n = insts_per_wave_per_iter * iters;
@@ -377,6 +390,8 @@ template <class F> static Res run(F launch, int W, double insts_per_wave_per_ite
     r.ns_per_inst = (double)ms * 1e6 / (n * W);
     r.clock_ghz = mean / ((double)ms * 1e6);                // ticks per ns if a wave spans the whole launch
     r.slope_ns = ((double)ms2 - (double)ms) * 1e6 / (n * W);
+    // shader clock during the measured stretch: s_memtime ticks (shader cycles) per s_memrealtime tick (constant rate: g_wall_khz)
+    r.sclk_mhz = rmean > 0.0 ? mean / rmean * g_wall_khz * 1e-3 : 0.0;
     return r;
 }
 
@@ -403,8 +418,8 @@ template <int OP> static void bench_op(u64 *d_ticks, const double *d_gtab, int n
         auto launch = [&](int nblk, int it) { hipLaunchKernelGGL(k_issue<OP>, dim3(nblk), dim3(256), lds, 0, d_ticks, it, d_gtab, 12345u); };
         const double n = (double)UNROLL * 8 * (OP == OP_XOR3_EMU ? 2 : 1);
         const Res r = run(launch, W, n, iters, d_ticks, ncu);
-        printf("{\"op\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_wave_inst\": %.3f, \"wall_ns_per_wave_inst_per_simd\": %.4f, \"slope_ns_per_wave_inst_per_simd\": %.4f, \"ticks_per_wall_ns\": %.3f}\n",
-               kNames[OP], W, r.cyc_per_inst, r.ns_per_inst, r.slope_ns, r.clock_ghz);
+        printf("{\"op\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_wave_inst\": %.3f, \"wall_ns_per_wave_inst_per_simd\": %.4f, \"slope_ns_per_wave_inst_per_simd\": %.4f, \"ticks_per_wall_ns\": %.3f, \"sclk_mhz\": %.1f}\n",
+               kNames[OP], W, r.cyc_per_inst, r.ns_per_inst, r.slope_ns, r.clock_ghz, r.sclk_mhz);
         fflush(stdout);
     }
 }
@@ -436,7 +451,11 @@ int main(int argc, char **argv) {
     printf("{\"device\": \"%s\", \"arch\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"iters\": %d, \"insts_per_trip\": %d}\n", prop.name, prop.gcnArchName, ncu,
            prop.clockRate / 1000, iters, UNROLL * 8);
     u64 *d_ticks;
-    CHK(hipMalloc((void **)&d_ticks, (size_t)ncu * 8 * 4 * sizeof(u64)));
+    CHK(hipMalloc((void **)&d_ticks, (size_t)ncu * 8 * 4 * 2 * sizeof(u64)));
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0) == hipSuccess && khz > 0) g_wall_khz = (double)khz;
+    }
     double *d_gtab;
     CHK(hipMalloc((void **)&d_gtab, 32 * 2048 * sizeof(double)));
     CHK(hipMemset(d_gtab, 0, 32 * 2048 * sizeof(double)));

@@ -435,6 +435,10 @@ void mci_lineage_sums(const double *block_means, int64_t niter, int64_t nblocks,
 void mci_do_reweight(double *reweight, const double *visited, int64_t nd, double gamma,
                      const double *goal);                                            /* main.jl:322-346 */
 const char *mci_version(void);
+/* the number in front of the dot: it changes whenever a struct of this header changes its layout (4: mci_result grew `correlated`
+ * and `warmup`; 5: entry points only).  A caller built against another header must not pass structs. */
+int32_t mci_abi_version(void);
+#define MCI_ABI_VERSION 5
 
 #ifdef __cplusplus
 }

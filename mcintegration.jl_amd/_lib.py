@@ -10,6 +10,7 @@ MCI_OK = 0
 ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "COMPILE", 4: "NORMALIZATION", 5: "HISTOGRAM", 6: "COMM", 7: "NO_DEVICE"}
 CONTINUOUS, DISCRETE, FERMIK = 0, 1, 2
 VEGAS, VEGASMC, MCMC = 0, 1, 2
+ABI_VERSION = 5   # include/mci.h MCI_ABI_VERSION
 SOLVERS = {"vegas": VEGAS, "vegasmc": VEGASMC, "mcmc": MCMC, VEGAS: VEGAS, VEGASMC: VEGASMC, MCMC: MCMC}
 
 c_double_p = C.POINTER(C.c_double)
@@ -135,6 +136,7 @@ SIGNATURES = [
     ("mci_average", None, [c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
     ("mci_do_reweight", None, [c_double_p, c_double_p, C.c_int64, C.c_double, c_double_p]),
     ("mci_version", C.c_char_p, []),
+    ("mci_abi_version", C.c_int32, []),
 ]
 DEBUG_SIGNATURES = [
     ("mci_debug_persist_words", C.c_int, [_VP, C.POINTER(C.c_uint64), C.c_int32]),
@@ -164,6 +166,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if L.mci_abi_version() != ABI_VERSION:   # the ctypes structures below mirror ONE layout of include/mci.h
+            raise ImportError("%s has ABI %d, this package was written against ABI %d: rebuild with `python __graft_entry__.py`" % (_SO, L.mci_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

@@ -327,7 +327,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains_spec(const B
             {
                 const int src = sp.gbase + path.last;
                 const int adv = path.pathm ? lane_read(sp.nd.depth, src) + 1 : 0;
-                if (__ballot(path.okm & path.pathm) != 0ull) { // (a trip of rejections only leaves every group's base as it is)
+                if (__ballot((path.okm & path.pathm) != 0ull) != 0ull) { // (a trip of rejections only leaves every group's base as it is)
                     c = lane_read<Cfg>(cp, src);
                     static_for<0, Cfg::NW>([&](auto I) { w[decltype(I)::value] = lane_read(wp[decltype(I)::value], src); });
                     static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = lane_read(padp[decltype(I)::value], src); });
@@ -619,7 +619,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains_spec(const Batc
             {
                 const int src = sp.gbase + path.last;
                 const int adv = path.pathm ? lane_read(sp.nd.depth, src) + 1 : 0;
-                if (__ballot(path.okm & path.pathm) != 0ull) { // (a trip of rejections only leaves every group's base as it is)
+                if (__ballot((path.okm & path.pathm) != 0ull) != 0ull) { // (a trip of rejections only leaves every group's base as it is)
                     c = lane_read<Cfg>(cp, src);
                     curr = lane_read(currp, src);
                     weight.abs = lane_read(wp.abs, src);

@@ -497,7 +497,9 @@ class Engine:
         check(lib().mci_integrate(self.p, C.byref(a), C.byref(r)))
         out = dict(mean=m, stdev=s, chi2=c2, iter_mean=im, iter_std=ie, neval=r.neval, seconds=r.seconds, visited=vis,
                    correlated=bool(r.correlated), block_mean=None, warmup=int(r.warmup))
-        if _lib.SOLVERS[solver] != _lib.VEGAS:
+        if _lib.SOLVERS[solver] != _lib.VEGAS and out["correlated"]:
+            # (only a run of carried chains needs them -- the block-lineage error of Result.with_ignore; a launch-bound default-size call is
+            # spared the flush, the copy and the second synchronisation)
             out["block_mean"] = self.block_means(niter)[0]
         return out
 

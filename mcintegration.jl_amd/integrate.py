@@ -231,10 +231,12 @@ def prefill_kernel_cache():
         eng.compile("vegas")
         if meas is not None:
             eng.compile("vegasmc")  # C3 is a :vegasmc config
+            eng.compile("vegasmc_lanes")   # ... whose launches of few chains (the example's neval = 1e6) give every chain a group of lanes
         eng.close()
         n += 1
     # C5: 4 integrands on a 12-D pool, :mcmc
     eng = Engine(Configuration(var=Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]]), catalog.nested_gauss(), device=-1)
     eng.compile("mcmc")
+    eng.compile("mcmc_lanes")   # (the pilot-length first launch of a cold call runs few, long chains)
     eng.close()
     return n + 1

@@ -29,12 +29,19 @@ def run_seeds(job):
     from mcmc_policy import case
     out = []
     t0 = time.perf_counter()
+    carry = os.environ.get("BIAS_CARRY")        # "off": every iteration starts its chains afresh (mci_set_chain_carry(prob, 0))
+    lanes = os.environ.get("BIAS_LANES")        # lanes per chain (mci_set_chain_speculation): "1" = one lane per chain
     for seed in seeds:
         cfg, f, meas, exact = case(name, seed=seed)
-        res = mci.integrate(f, config=cfg, measure=meas, solver=solver, neval=neval, niter=niter, block=block, nchain=nchain)
-        out.append((seed, np.array(res._flat_mean), np.array(res._flat_std), np.array(res.iter_mean).reshape(niter, -1), np.array(res.iter_std).reshape(niter, -1),
-                    int(res.warmup), int(res.ignore)))
-        cfg._engine.close()
+        eng = mci.Engine(cfg, f, measure=meas)
+        if carry:
+            eng.set_chain_carry(carry)
+        if lanes:
+            eng.set_chain_speculation(int(lanes))
+        r = eng.integrate(solver, neval=neval, niter=niter, block=block, seed=seed, nchain=nchain)   # (ignore = 1: the library's default with adapt)
+        out.append((seed, np.array(r["mean"]), np.array(r["stdev"]), np.array(r["iter_mean"]).reshape(niter, -1), np.array(r["iter_std"]).reshape(niter, -1),
+                    int(r["warmup"]), 1))
+        eng.close()
     return out, time.perf_counter() - t0
 
 
@@ -85,9 +92,11 @@ def main():
     from mcmc_policy import case
     exact = case(name)[3]
     if mode == "full":
-        rows, secs = gather(name, solver, nseeds, neval, niter, block, 0, nproc)
+        nchain_full = int(os.environ.get("BIAS_NCHAIN", "0"))   # chains per block (0 = automatic)
+        rows, secs = gather(name, solver, nseeds, neval, niter, block, nchain_full, nproc)
         s = summarize(rows, exact)
-        print("%s :%s  %d seeds x cold integrate(neval=%.0e, niter=%d, block=%d), automatic chain counts; %.2f s per run" % (name, solver, nseeds, neval, niter, block, secs / nseeds))
+        print("%s :%s  %d seeds x cold integrate(neval=%.0e, niter=%d, block=%d), %s, carry=%s; %.2f s per run" % (
+            name, solver, nseeds, neval, niter, block, "nchain=%d per block" % nchain_full if nchain_full else "automatic chain counts", os.environ.get("BIAS_CARRY", "auto"), secs / nseeds))
         print("  pooled (weighted mean - exact) / pooled reported error : %s" % fmt(s["pooled"]))
         print("  unweighted mean of the counted iterations, seed-scatter error: %s" % fmt(s["unw"]))
         print("  mean deviation per run in units of one run's error     : %s" % fmt(s["per_run"]))

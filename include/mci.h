@@ -332,11 +332,14 @@ int mci_last_chain_launch(const mci_problem *prob, int64_t *nchain, int32_t *car
  * group (csrc/mci_spec.h).  The chain is the SAME chain -- same law, same uniforms, same arithmetic per step: sums differ by
  * reassociation only, and nchain = 1 stays the reference's chain.
  * lanes: -1 (default) automatic -- the largest group that keeps the launch within one wave per SIMD; 1: one lane per chain always;
- * 2 .. 64: that group size.  accept in (0, 1): the acceptance the tree is built for -- the group's lanes are the `lanes` most probable
+ * 2 .. 64: that group size.  accept in (0, 1): ONE tree, built for that acceptance -- the group's lanes are the `lanes` most probable
  * nodes of the outcome tree of a chain whose steps change its configuration with that probability (-> 0: the reject chain, up to
  * `lanes` steps per trip through a run of rejections; 1/2: the complete binary tree, log2(lanes) steps per trip whatever happens);
- * <= 0: the solver's default (:vegasmc 0.5, :mcmc 0.35).  max_accepts: the most accept edges on a way through the tree (:mcmc builds
- * its proposals once per accept level); < 0: the solver's default (:vegasmc unbounded, :mcmc 2).
+ * <= 0 (default): a family of trees (:vegasmc 0.03 .. 0.93, :mcmc 0.03 .. 0.8) -- every group measures, every eight trips, the fraction
+ * of its chain's steps that changed the configuration and moves to the tree built for the nearest acceptance, so a chain in a sticky
+ * state runs down the reject chain and a chain on a well-adapted map down the accept edges.  max_accepts: the most accept edges on a
+ * way through a tree (:mcmc builds its proposals once per accept level); < 0: the solver's default (:vegasmc 12, :mcmc 2, 3 on its
+ * trees for chains that accept most steps).
  * Launches with a host integrand and the deterministic mode keep one lane per chain. */
 int mci_set_chain_speculation(mci_problem *prob, int32_t lanes, double accept, int32_t max_accepts);
 /* lanes per chain of the last chain-solver launch (1: one lane per chain) and the accept levels of its tree */

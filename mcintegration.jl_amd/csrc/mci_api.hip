@@ -150,6 +150,8 @@ struct mci_problem {
     double spec_accept = 0.0;
     mci::SpecNode *d_spec_tab = nullptr;
     int spec_tab_lanes = 0, spec_tab_limit = -2, spec_tab_maxacc = 0;
+    int spec_ntree = 0, spec_first = 0; // trees on the device, the one a group starts on
+    float spec_accepts[8] = {};          // the acceptance each of them was built for
     double spec_tab_accept = -1.0;
     int last_spec_lanes = 1, last_spec_maxacc = 0; // of the last chain launch (1: one lane per chain)
     static const int64_t kSpecFill = 65536;        // lanes a launch of few chains spreads over: one wave on each of the 1024 SIMDs
@@ -255,6 +257,10 @@ struct mci_problem {
     // Carried chains (BatchArgs::carry_x): end configurations of the last chain launch, two buffers (read one, write the other),
     // and what that launch was -- an iteration continues it when it is the NEXT iteration of the same solver over the same blocks
     double *d_chain_x[2] = {nullptr, nullptr};
+    double *d_chain_P[2] = {nullptr, nullptr}; // :vegasmc: the target density at every stored configuration (BatchArgs::store_P)
+    double *d_carry_w = nullptr;               // :vegasmc: new target / old target of the stored chains (mci_vegasmc_carry_weights)
+    int64_t cap_carry_w = 0;
+    hipFunction_t f_carryw[2] = {nullptr, nullptr}; // that kernel in the lane-per-chain | several-lanes-per-chain code object of :vegasmc
     int *d_chain_curr[2] = {nullptr, nullptr};
     int64_t chain_cap[2] = {0, 0};
     int chain_cur = 0;           // buffer the last launch wrote
@@ -991,6 +997,9 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->d_carry_W) (void)hipFree(p->d_carry_W);
         if (p->d_carry_src) (void)hipFree(p->d_carry_src);
         if (p->d_spec_tab) (void)hipFree(p->d_spec_tab);
+        for (int b = 0; b < 2; ++b)
+            if (p->d_chain_P[b]) (void)hipFree(p->d_chain_P[b]);
+        if (p->d_carry_w) (void)hipFree(p->d_carry_w);
         if (p->d_clocks) (void)hipFree(p->d_clocks);
         if (p->h_hold) (void)hipHostFree(p->h_hold);
         if (p->h_hold_d) (void)hipHostFree(p->h_hold_d);
@@ -1227,6 +1236,11 @@ static int load_slot(mci_problem *p, int slot, Candidate &c, int64_t lds) {
     }
     HIPCHK(hipModuleGetFunction(&p->f_solver[slot], p->module[slot], names[slot]));
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[slot], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if ((slot == MCI_VEGASMC || slot == kSlotVegasmcSpec) && !p->shape.host_integrand) {
+        hipFunction_t &fw = p->f_carryw[slot == MCI_VEGASMC ? 0 : 1];
+        HIPCHK(hipModuleGetFunction(&fw, p->module[slot], "mci_vegasmc_carry_weights"));
+        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)fw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (slot_solver(slot) == MCI_VEGAS && slot != kSlotDump && p->shape.ntile > 1) {
         HIPCHK(hipModuleGetFunction(&p->f_tiles[slot == kSlotVegasAny ? 1 : 0], p->module[slot], "mci_vegas_tiles"));
         if (p->lds_bytes > 64 * 1024)
@@ -1405,6 +1419,7 @@ static int compile_spec(mci_problem *p, int solver) {
 // steps change its configuration with probability `accept` (greedy: the most probable frontier node next; ties go to the older
 // candidate), with at most `limit` accept edges on any way from the root (limit < 0: no bound).  accept -> 0 gives the reject chain,
 // accept = 1/2 the complete binary tree.  Nodes are numbered in the order they are taken: ancestors first.
+static const int kSpecMaxLevels = 12; // (a trip exchanges configurations once per accept level: mci_spec.h spec_wave_levels counts below 16)
 static void spec_build(int lanes, double accept, int limit, std::vector<mci::SpecNode> &tab, int *maxacc) {
     struct Cand { double prob; int parent; bool via_acc; long seq; };
     std::vector<Cand> front;
@@ -1436,24 +1451,48 @@ static void spec_build(int lanes, double accept, int limit, std::vector<mci::Spe
         tab.push_back(nd);
         if (nd.nacc > *maxacc) *maxacc = nd.nacc;
         front.push_back({cd.prob * (1.0 - accept), me, false, seq++});
-        if (limit < 0 || nd.nacc + 1 <= limit) front.push_back({cd.prob * accept, me, true, seq++});
+        if ((limit < 0 || nd.nacc + 1 <= limit) && nd.nacc + 1 <= kSpecMaxLevels) front.push_back({cd.prob * accept, me, true, seq++});
     }
+    for (auto &nd : tab) nd.levels = *maxacc;
 }
 
-// the tree of the next launch on the device (rebuilt when lanes / acceptance / limit change)
-static int spec_upload(mci_problem *p, int lanes, double accept, int limit) {
-    if (p->d_spec_tab && p->spec_tab_lanes == lanes && p->spec_tab_accept == accept && p->spec_tab_limit == limit) return MCI_OK;
-    std::vector<mci::SpecNode> tab;
-    int maxacc = 0;
-    spec_build(lanes, accept, limit, tab, &maxacc);
-    if (!p->d_spec_tab) HIPCHK(hipMalloc((void **)&p->d_spec_tab, 64 * sizeof(mci::SpecNode)));
-    // (pageable source: the copy has left `tab` when the call returns)
-    HIPCHK(hipMemcpyAsync(p->d_spec_tab, tab.data(), tab.size() * sizeof(mci::SpecNode), hipMemcpyHostToDevice, p->ctx->stream));
+// The trees of the next launch on the device (rebuilt when lanes / acceptance / limit change).  accept > 0: that one tree.  accept <= 0
+// (the default): the solver's family of trees, one per assumed acceptance -- a group starts on `first` and moves, every few trips, to the
+// tree built for the acceptance its chain has shown (mci_spec.h spec_adapt).  :vegasmc proposals do not depend on the configuration they
+// start from, an accept level costs one exchange: unbounded; :mcmc runs mcmc_propose once per level: at most `limit` (default 2, 3 on the
+// trees for chains that accept most steps).
+static int spec_upload(mci_problem *p, int solver, int lanes, double accept, int limit) {
+    const double key = accept > 0.0 ? accept : -(double)(solver + 1);
+    if (p->d_spec_tab && p->spec_tab_lanes == lanes && p->spec_tab_accept == key && p->spec_tab_limit == limit) return MCI_OK;
+    static const double fam_vegasmc[7] = {0.03, 0.12, 0.3, 0.5, 0.7, 0.85, 0.93}, fam_mcmc[6] = {0.03, 0.1, 0.2, 0.35, 0.55, 0.8};
+    std::vector<mci::SpecNode> all;
+    p->spec_ntree = 0;
+    p->spec_tab_maxacc = 0;
+    auto add = [&](double acc, int lim) {
+        std::vector<mci::SpecNode> tab;
+        int maxacc = 0;
+        spec_build(lanes, acc, lim, tab, &maxacc);
+        all.insert(all.end(), tab.begin(), tab.end());
+        p->spec_accepts[p->spec_ntree++] = (float)acc;
+        if (maxacc > p->spec_tab_maxacc) p->spec_tab_maxacc = maxacc;
+    };
+    if (accept > 0.0) {
+        add(accept, limit);
+        p->spec_first = 0;
+    } else if (solver == MCI_VEGASMC) {
+        for (double acc : fam_vegasmc) add(acc, limit);
+        p->spec_first = 3;
+    } else {
+        for (double acc : fam_mcmc) add(acc, limit >= 0 ? limit : (acc >= 0.5 ? 3 : 2));
+        p->spec_first = 3;
+    }
+    if (!p->d_spec_tab) HIPCHK(hipMalloc((void **)&p->d_spec_tab, 8 * 64 * sizeof(mci::SpecNode)));
+    // (pageable source: the copy has left `all` when the call returns)
+    HIPCHK(hipMemcpyAsync(p->d_spec_tab, all.data(), all.size() * sizeof(mci::SpecNode), hipMemcpyHostToDevice, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     p->spec_tab_lanes = lanes;
-    p->spec_tab_accept = accept;
+    p->spec_tab_accept = key;
     p->spec_tab_limit = limit;
-    p->spec_tab_maxacc = maxacc;
     return MCI_OK;
 }
 
@@ -1767,12 +1806,9 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     }
     int T_launch = T;
     if (G > 1) {
-        // the tree: the solver's default acceptance unless one was given.  :vegasmc proposals do not depend on the configuration they start
-        // from: any number of accept edges costs one exchange each; :mcmc runs mcmc_propose once per accept level
-        const double accept = p->spec_accept > 0.0 ? p->spec_accept : (solver == MCI_VEGASMC ? 0.5 : 0.35);
-        const int limit = p->spec_maxacc >= 0 ? p->spec_maxacc : (solver == MCI_VEGASMC ? -1 : 2);
+        // the trees: the one built for the acceptance that was given, else the solver's family (spec_upload)
         if ((rc = compile_spec(p, solver))) return rc;
-        if ((rc = spec_upload(p, G, accept, limit))) return rc;
+        if ((rc = spec_upload(p, solver, G, p->spec_accept, p->spec_maxacc))) return rc;
         spec_maxacc = p->spec_tab_maxacc;
         units = nchain * G;
         T_launch = units >= 256 ? 256 : (int)((units + 63) / 64) * 64;
@@ -1875,7 +1911,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             a.carry_nchain = p->chain_nchain;
             a.carry_cap = p->chain_cap[p->chain_cur];
         }
-        if (carried && solver == MCI_MCMC) { // which stored chain each chain continues: the stored ones resampled to the moved target
+        if (carried) { // which stored chain each chain continues: the stored ones resampled to the moved target
             if (nblocks * nchain > p->cap_carry_src) {
                 if (p->d_carry_src) (void)hipFree(p->d_carry_src);
                 p->d_carry_src = nullptr;
@@ -1899,6 +1935,27 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             ra.rw_used = p->d_reweight_used;
             ra.src = p->d_carry_src;
             ra.W = p->d_carry_W;
+            if (solver == MCI_VEGASMC) {
+                // :vegasmc: the target itself moved with the map and the reweight factors -- pi_new / pi_old at every stored configuration
+                // (the chain kernel's own code object evaluates it: relocate, integrand, paddings), then the same systematic resampling
+                const int64_t total = nblocks * p->chain_nchain;
+                if (total > p->cap_carry_w) {
+                    if (p->d_carry_w) (void)hipFree(p->d_carry_w);
+                    p->d_carry_w = nullptr;
+                    p->cap_carry_w = 0;
+                    HIPCHK(hipMalloc((void **)&p->d_carry_w, (size_t)total * sizeof(double)));
+                    p->cap_carry_w = total;
+                }
+                a.carry_P = p->d_chain_P[p->chain_cur];
+                a.carry_w = p->d_carry_w;
+                a.carry_total = total;
+                mci::BatchArgs wa = a; // (edges, tables, reweight, userdata and the carry fields; everything else unused)
+                void *wargs[] = {&wa};
+                const int64_t wgrid = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+                const int tw = G > 1 ? 256 : (T < 256 ? T : 256); // (within the launch bound its code object was compiled for)
+                HIPCHK(hipModuleLaunchKernel(p->f_carryw[G > 1 ? 1 : 0], (unsigned)wgrid, 1, 1, (unsigned)tw, 1, 1, (unsigned)p->lds_bytes, p->ctx->stream, wargs, nullptr));
+                ra.w_chain = p->d_carry_w;
+            }
             hipLaunchKernelGGL(mci::k_resample_chains, dim3((unsigned)nblocks), dim3(256), 0, p->ctx->stream, ra);
             HIPCHK(hipGetLastError());
             a.carry_src = p->d_carry_src;
@@ -1913,15 +1970,19 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             if (need > p->chain_cap[wb]) {
                 if (p->d_chain_x[wb]) (void)hipFree(p->d_chain_x[wb]);
                 if (p->d_chain_curr[wb]) (void)hipFree(p->d_chain_curr[wb]);
+                if (p->d_chain_P[wb]) (void)hipFree(p->d_chain_P[wb]);
                 p->d_chain_x[wb] = nullptr;
                 p->d_chain_curr[wb] = nullptr;
+                p->d_chain_P[wb] = nullptr;
                 p->chain_cap[wb] = 0;
                 HIPCHK(hipMalloc((void **)&p->d_chain_x[wb], (size_t)need * s.ndraw * sizeof(double)));
                 HIPCHK(hipMalloc((void **)&p->d_chain_curr[wb], (size_t)need * sizeof(int)));
+                HIPCHK(hipMalloc((void **)&p->d_chain_P[wb], (size_t)need * sizeof(double)));
                 p->chain_cap[wb] = need;
             }
             a.store_x = p->d_chain_x[wb];
             a.store_curr = p->d_chain_curr[wb];
+            a.store_P = solver == MCI_VEGASMC ? p->d_chain_P[wb] : nullptr;
             a.store_cap = p->chain_cap[wb];
             p->chain_cur = wb;
             p->chain_valid = true;
@@ -1944,6 +2005,9 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         a.spec_tab = p->d_spec_tab;
         a.spec_lanes = G;
         a.spec_maxacc = spec_maxacc;
+        a.spec_ntree = p->spec_ntree;
+        a.spec_first = p->spec_first;
+        for (int k = 0; k < 8; ++k) a.spec_accept[k] = p->spec_accepts[k];
     }
     a.status = p->d_status;
     a.tile_w = p->d_tile_w;

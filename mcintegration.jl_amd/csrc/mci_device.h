@@ -127,7 +127,7 @@ struct SpecNode {
     int depth;   // the lane evaluates the proposal of step (first step of the trip) + depth
     int anc;     // nearest ancestor the way from the root leaves by its ACCEPT edge: the lane's step starts from that lane's proposal (-1: from the trip's base)
     int nacc;    // accept edges on the way from the root
-    int reserved;
+    int levels;  // the most accept edges on any way through this node's tree (the same in all its nodes)
     u64 needacc; // lanes (bit = lane within the group) that must have accepted / rejected for this node to be on the chain's path
     u64 needrej;
 };
@@ -207,6 +207,16 @@ struct BatchArgs {
     double *store_x;        // NULL: nothing kept
     int *store_curr;
     i64 store_cap;
+    // :vegasmc: the chain's target density  pi(x) = sum_i reweight[i] |f_i(x)| pad_i(x) + reweight[N] pad_N(x)  (config.probability,
+    // vegas_mc/montecarlo.jl:162-166) depends on the MAP (the paddings are map densities) and on the reweight factors, and train! /
+    // doReweight! move both between iterations: the stored chains are a sample of the OLD target.  Every chain leaves the value of its
+    // target at its end configuration (store_P); before the next launch mci_vegasmc_carry_weights evaluates the NEW target at every stored
+    // configuration, carry_w = pi_new / pi_old, and k_resample_chains resamples the block's stored chains with probability ~ carry_w
+    // (systematic, deterministic) into carry_src -- a start population distributed like the new target (DESIGN.md "Chains")
+    const double *carry_P;  // [carry_cap] pi_old of the stored chains
+    double *carry_w;        // [carry_total] out: pi_new / pi_old, indexed local block * carry_nchain + stored chain
+    i64 carry_total;        // stored chains of this launch's blocks
+    double *store_P;
     struct HostStep {
         i64 ne, steps, nc;
         double *cx, *cprob, *cw, *cprobability; // current configuration [NDRAW][nc], weights [NW][nc], config.probability [nc]
@@ -223,8 +233,13 @@ struct BatchArgs {
     } hs;
     // Several lanes per chain (mci_spec.h): a chain is stepped by a group of spec_lanes lanes (a power of two, 2..64) along the
     // speculation tree spec_tab[spec_lanes]; spec_maxacc = the most accept edges on any way through it.  0 / NULL: one lane per chain
+    // spec_ntree > 1: spec_tab holds that many trees of spec_lanes nodes each, built for the acceptances spec_accept[]; every group starts
+    // on tree spec_first and moves, every few trips, to the tree built for the acceptance its own chain has shown since (the chain is the
+    // same chain on any tree: only the number of steps a trip advances depends on it)
     const SpecNode *spec_tab;
     int spec_lanes, spec_maxacc;
+    int spec_ntree, spec_first;
+    float spec_accept[8];
     // :vegas, timed launches (mci_kernel_clocks): the first wave of workgroup 0 leaves the shader-clock ticks (s_memtime) and the
     // constant-rate reference ticks (s_memrealtime) its sample loop took -- their ratio is the clock the kernel actually ran at
     u64 *clock_out; // [2] or NULL
@@ -1760,10 +1775,43 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains(const BatchA
             }
         }
         flush_pa();
-        if (a.store_x && tile == 0) store_carried<Cfg>(a, wi.lb, ch, c);
+        if (a.store_x && tile == 0) {
+            store_carried<Cfg>(a, wi.lb, ch, c);
+            if (a.store_P) a.store_P[wi.lb * a.nchain + ch] = probability; // the target at the configuration the chain stopped at
+        }
     }
     __syncthreads();
     flush_workgroup<Cfg, Lds<Cfg>, true, true>(a, smem, acc, extra, wi.rowid, tile);
+}
+
+// The NEW target at every stored configuration over the old one (BatchArgs::carry_w): one lane per stored chain; the same arithmetic in
+// the same order as a chain's start (montecarlo.jl:155-166) on the refined map and the moved reweight factors.
+template <class Cfg> __device__ __forceinline__ void vegasmc_carry_weights(const BatchArgs &a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NI = Cfg::NI, NORMI = Cfg::NI;
+    const int tid = threadIdx.x, T = blockDim.x;
+    double *sE = smem + Lds<Cfg>::E, *sDA = smem + Lds<Cfg>::DA, *sDD = smem + Lds<Cfg>::DD;
+    stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
+    __syncthreads();
+    Tables<Cfg> t;
+    if constexpr (Mode<Cfg>::EDGE_LDS) t.E = sE;
+    else t.E = a.edges;
+    t.DA = sDA;
+    t.DD = sDD;
+    double rw[NI + 1];
+    static_for<0, NI + 1>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
+    for (i64 j = (i64)blockIdx.x * T + tid; j < a.carry_total; j += (i64)gridDim.x * T) {
+        const i64 lb = j / a.carry_nchain, from = j % a.carry_nchain;
+        Chain<Cfg> c;
+        load_carried<Cfg>(a, t, lb, from, c);
+        double w[Cfg::NW], pad[NI + 1];
+        Cfg::integrand(c.x, w, a.ud, -1);
+        static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(c); });
+        double probability = rw[NORMI] * pad[NORMI];
+        static_for<0, NI>([&](auto I) { constexpr int i = decltype(I)::value; probability += absw<Cfg, i>(w) * rw[i] * pad[i]; });
+        const double r = probability / a.carry_P[lb * a.carry_nchain + from];
+        a.carry_w[j] = (r == r && r < 1.7976931348623157e308 && r > 0.0) ? r : 0.0; // (a configuration neither target can have produced continues nothing)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

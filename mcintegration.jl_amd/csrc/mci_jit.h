@@ -185,10 +185,15 @@ inline std::string generate_source(const ProblemShape &s, int solver, int unit =
     } else if (unit == kUnitSpec) {
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) " << (solver == 1 ? "mci_vegasmc_spec" : "mci_mcmc_spec") << "(mci::BatchArgs a) { "
           << (solver == 1 ? "mci::vegasmc_chains_spec<Cfg>(a); }\n" : "mci::mcmc_chains_spec<Cfg>(a); }\n");
+        if (solver == 1)
+            o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_carry_weights(mci::BatchArgs a) { mci::vegasmc_carry_weights<Cfg>(a); }\n";
     } else if (solver == 1) {
         // (a host integrand: the step cut at the integrand call, one launch per Markov step -- same entry point)
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_chains(mci::BatchArgs a) { "
           << (s.host_integrand ? "mci::vegasmc_host_step<Cfg>(a); }\n" : "mci::vegasmc_chains<Cfg>(a); }\n");
+        // (carried chains: the new target over the old one at every stored configuration, before they are resampled)
+        if (!s.host_integrand)
+            o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_carry_weights(mci::BatchArgs a) { mci::vegasmc_carry_weights<Cfg>(a); }\n";
     } else {
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_mcmc_chains(mci::BatchArgs a) { "
           << (s.host_integrand ? "mci::mcmc_host_step<Cfg>(a); }\n" : "mci::mcmc_chains<Cfg>(a); }\n");

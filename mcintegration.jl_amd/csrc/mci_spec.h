@@ -58,20 +58,63 @@ template <class Cfg> __device__ __forceinline__ void chain_select(Chain<Cfg> &ds
 
 // what a group's lanes know about themselves and their group
 struct SpecLane {
-    int G, m, gbase, maxacc;
+    int G, m, gbase;
+    int maxacc;  // accept levels the wave goes through per trip: the most of its groups' trees
     u64 gmask;
     SpecNode nd;
+    // the tree the group is on, and what its chain has done since the tree was last looked at
+    int tree, trips, steps, accepts;
 };
+// the most accept levels of the trees the groups of this wave are on (wave-uniform; levels < 16)
+__device__ __forceinline__ int spec_wave_levels(int mine) {
+    int m = 0;
+#pragma unroll
+    for (int bit = 3; bit >= 0; --bit) {
+        const int cand = m | (1 << bit);
+        if (__ballot(mine >= cand) != 0ull) m = cand;
+    }
+    return m;
+}
 __device__ __forceinline__ SpecLane spec_lane(const BatchArgs &a) {
     SpecLane s;
     const int lane = (int)(threadIdx.x & 63u);
     s.G = a.spec_lanes;
     s.m = lane & (s.G - 1);
     s.gbase = lane & ~(s.G - 1);
-    s.maxacc = a.spec_maxacc;
     s.gmask = s.G >= 64 ? ~0ull : ((1ull << s.G) - 1ull);
-    s.nd = a.spec_tab[s.m];
+    s.tree = a.spec_ntree > 1 ? a.spec_first : 0;
+    s.nd = a.spec_tab[s.tree * s.G + s.m];
+    s.maxacc = a.spec_ntree > 1 ? spec_wave_levels(s.nd.levels) : a.spec_maxacc;
+    s.trips = s.steps = s.accepts = 0;
     return s;
+}
+// Every kSpecWindow trips a group looks at the fraction of its chain's steps that changed the configuration and moves to the tree built
+// for the nearest acceptance (spec_accept[]).  Wave-uniform control flow; the chain does not depend on the tree.
+constexpr int kSpecWindow = 8;
+__device__ __forceinline__ void spec_adapt(const BatchArgs &a, SpecLane &s, int adv, u64 accm) {
+    if (a.spec_ntree <= 1) return;
+    s.trips += 1;
+    s.steps += adv;
+    s.accepts += __popcll(accm);
+    const bool look = s.trips >= kSpecWindow;
+    if (__ballot(look) == 0ull) return;
+    int pick = s.tree;
+    if (look && s.steps > 0) {
+        const float q = (float)s.accepts / (float)s.steps;
+        float best = 2.0f;
+        for (int k = 0; k < a.spec_ntree; ++k) {
+            const float d = fabsf(q - a.spec_accept[k]);
+            if (d < best) { best = d; pick = k; }
+        }
+    }
+    if (look) s.trips = s.steps = s.accepts = 0;
+    const bool move = pick != s.tree;
+    if (__ballot(move) == 0ull) return;
+    if (move) {
+        s.tree = pick;
+        s.nd = a.spec_tab[pick * s.G + s.m];
+    }
+    s.maxacc = spec_wave_levels(s.nd.levels);
 }
 // the chain's path through the tree from the lanes' accept tests: is this lane on it, and which is the deepest lane that is
 // (the tree's lanes are numbered ancestors-first, so that is the highest one)
@@ -121,7 +164,7 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains_spec(const B
     const u32 k0 = (u32)a.seed, k1 = (u32)(a.seed >> 32);
     double rw[NI + 1];
     static_for<0, NI + 1>([&](auto I) { rw[decltype(I)::value] = a.reweight[decltype(I)::value]; });
-    const SpecLane sp = spec_lane(a);
+    SpecLane sp = spec_lane(a);
 
     double acc[Cfg::NW];
     static_for<0, Cfg::NW>([&](auto I) { acc[decltype(I)::value] = 0.0; });
@@ -334,11 +377,15 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains_spec(const B
                     probability = lane_read(Pp, src);
                 }
                 ne0 += adv;
+                spec_adapt(a, sp, adv, path.okm & path.pathm);
             }
             if ((++trips & 0x3FFFFFFFu) == 0u) flush_pa(); // (32-bit lane counters: hand over long before they wrap)
         }
         flush_pa();
-        if (a.store_x && tile == 0 && live && sp.m == 0) store_carried<Cfg>(a, wi.lb, ch, c);
+        if (a.store_x && tile == 0 && live && sp.m == 0) {
+            store_carried<Cfg>(a, wi.lb, ch, c);
+            if (a.store_P) a.store_P[wi.lb * a.nchain + ch] = probability; // (vegasmc_carry_weights)
+        }
     }
     __syncthreads();
     flush_workgroup<Cfg, Lds<Cfg>, true, true>(a, smem, acc, extra, wi.rowid, tile);
@@ -384,7 +431,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains_spec(const Batc
         static_for<0, NI>([&](auto I) { if (i == decltype(I)::value) r = rw[decltype(I)::value]; });
         return r;
     };
-    const SpecLane sp = spec_lane(a);
+    SpecLane sp = spec_lane(a);
 
     double acc[Cfg::NW];
     static_for<0, Cfg::NW>([&](auto I) { acc[decltype(I)::value] = 0.0; });
@@ -627,6 +674,7 @@ template <class Cfg> __device__ __forceinline__ void mcmc_chains_spec(const Batc
                     probability = lane_read(Pp, src);
                 }
                 it0 += adv;
+                spec_adapt(a, sp, adv, path.okm & path.pathm);
             }
         }
         if (a.hold_hist && live && sp.m == 0) { // holds still running when the chain ends count with their length so far

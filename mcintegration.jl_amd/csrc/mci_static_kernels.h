@@ -72,6 +72,8 @@ struct ResampleArgs {
     const double *rw_now, *rw_used; // [nd]
     int *src;              // [nblocks][n_new]
     double *W;             // [nblocks][n_old] scratch
+    const double *w_chain; // [nblocks][n_old] or NULL: a weight per stored chain (:vegasmc: new target / old target, vegasmc_carry_weights)
+                           // instead of a weight per integrand index
 };
 __global__ void __launch_bounds__(256) k_resample_chains(ResampleArgs a) {
     constexpr int kLdsW = 8192; // stored chains per block whose running weights also sit in LDS: the bisections below then read LDS
@@ -83,6 +85,25 @@ __global__ void __launch_bounds__(256) k_resample_chains(ResampleArgs a) {
     int *src = a.src + (size_t)blockIdx.x * a.n_new;
     const long long per = (a.n_old + T - 1) / T, j0 = tid * per < a.n_old ? tid * per : a.n_old, j1 = j0 + per < a.n_old ? j0 + per : a.n_old;
     constexpr int kNd = 16; // integrands (+ the normalisation) whose running counts a thread keeps in registers
+    if (a.w_chain) {
+        // W[j] = (sum of the stretches before this thread's, added in thread order) + (running sum along the thread's own stretch): a
+        // fixed association the oracle repeats (mcio_resample_weighted)
+        __shared__ double dpart[256];
+        const double *wc = a.w_chain + (size_t)blockIdx.x * a.n_old;
+        double mine = 0.0;
+        for (long long j = j0; j < j1; ++j) mine += wc[j];
+        dpart[tid] = mine;
+        __syncthreads();
+        double below = 0.0;
+        for (int t = 0; t < tid; ++t) below += dpart[t];
+        double run = 0.0;
+        for (long long j = j0; j < j1; ++j) {
+            run += wc[j];
+            const double v = below + run;
+            W[j] = v;
+            if (a.n_old <= kLdsW) sW[j] = v;
+        }
+    } else
     if (a.nd <= kNd) {
         // Two passes over the thread's stretch of the stored chains instead of one read-modify-write pass over W per integrand: the
         // per-integrand counts below the stretch first, then W[j] = sum_i w[i] * cnt_i(j), the terms added over i = 0 .. nd-1 in that
@@ -143,7 +164,7 @@ __global__ void __launch_bounds__(256) k_resample_chains(ResampleArgs a) {
     }
     __threadfence_block();
     __syncthreads();
-    const bool in_lds = a.nd <= kNd && a.n_old <= kLdsW;
+    const bool in_lds = (a.w_chain != nullptr || a.nd <= kNd) && a.n_old <= kLdsW;
     const double step = W[a.n_old - 1] / (double)a.n_new;
     for (long long c = tid; c < a.n_new; c += T) {
         const double target = ((double)c + 0.6180339887498949) * step;

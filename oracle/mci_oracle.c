@@ -452,7 +452,7 @@ void mcio_config_destroy(mcio_config *c) {
     for (int d = 0; d < c->Ni + 1; ++d) free(c->neighbor[d]);
     free(c->neighbor); free(c->nneighbor); free(c->reweight_goal); free(c->hold_hist);
     if (c->carry_owner && c->carry) {
-        for (int b = 0; b < 2; ++b) { free(c->carry->x[b]); free(c->carry->curr[b]); }
+        for (int b = 0; b < 2; ++b) { free(c->carry->x[b]); free(c->carry->curr[b]); free(c->carry->P[b]); }
         free(c->carry->rw_used);
         free(c->carry->src);
         free(c->carry);
@@ -1038,10 +1038,12 @@ static void carried_slot(mcio_config *c, int vi, int idx, const double *xs) {
     }
     if (nl != 1) c->pool_prob[vi][idx] = pp;
 }
-/* the stored chain that new chain `ch` of this block continues: :vegasmc chain ch mod (stored chains); :mcmc the resampled one */
+/* the stored chain that new chain `ch` of this block continues: the stored chains resampled to the moved target (run_blocks:
+   :mcmc mcio_resample_chains, :vegasmc mcio_resample_weighted) */
 static long carried_slot_of(const mcio_config *c, long ch, long nchain, int mcmc) {
     const mcio_carry *cy = c->carry;
-    return c->carry_lb * cy->load_nchain + (mcmc ? cy->src[c->carry_lb * nchain + ch] : ch % cy->load_nchain);
+    (void)mcmc;
+    return c->carry_lb * cy->load_nchain + cy->src[c->carry_lb * nchain + ch];
 }
 static void load_carried(mcio_config *c, long slot) {
     const mcio_carry *cy = c->carry;
@@ -1061,6 +1063,21 @@ static void store_carried(mcio_config *c, long ch, long nchain, int curr) {
     gather_x(c, x);
     for (int k = 0; k < c->ndraw; ++k) cy->x[cy->wr][(long)k * cy->cap[cy->wr] + slot] = x[k];
     cy->curr[cy->wr][slot] = curr;
+}
+/* config.probability (vegas_mc/montecarlo.jl:155-166) of the configuration the pools hold: the target density of a :vegasmc chain */
+static double vegasmc_target(mcio_config *c, mcio_integrand_fn f, const double *ud, double *weights_out /* [ncomp * Ni] or NULL */, double *pad /* [Ni+1] */) {
+    const int N = c->Ni, norm = c->Ni, nc = c->ncomp;
+    double x[MCIO_MAXDRAW], _weights[2 * MCIO_MAXNI];
+    gather_x(c, x);
+    f(x, _weights, ud); /* :155-159 */
+    for (int i = 0; i <= N; ++i) pad[i] = mcio_padding_probability(c, i); /* :161 */
+    double probability = c->reweight[norm] * pad[norm];                   /* :162 */
+    for (int i = 0; i < N; ++i) {                                         /* :163-166 */
+        if (weights_out)
+            for (int q = 0; q < nc; ++q) weights_out[nc * i + q] = _weights[nc * i + q];
+        probability += absw(c, _weights, i) * c->reweight[i] * pad[i];
+    }
+    return probability;
 }
 
 int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, uint64_t seed,
@@ -1099,14 +1116,7 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
                 mcio_pool_create(c, vi, idx + c->pool_offset[vi], u);
                 k += nl;
             }
-        gather_x(c, x);
-        f(x, _weights, ud); /* :155-159 */
-        for (int i = 0; i <= N; ++i) pad[i] = mcio_padding_probability(c, i); /* :161 */
-        double probability = c->reweight[norm] * pad[norm];                   /* :162 */
-        for (int i = 0; i < N; ++i) {                                         /* :163-166 */
-            for (int q = 0; q < nc; ++q) weights[nc * i + q] = _weights[nc * i + q];
-            probability += absw(c, _weights, i) * c->reweight[i] * pad[i];
-        }
+        double probability = vegasmc_target(c, f, ud, weights, pad); /* :155-166 */
         for (long ne = 1; ne <= steps; ++ne) { /* :184 */
             const uint64_t sidx = (g << 32) | (uint64_t)(ne - 1);
             /* ---- changeVariable  ref: updates.jl:45-106 ---- */
@@ -1166,7 +1176,10 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
                 c->visited[norm] += c->reweight[norm] * pad[norm] / probability;    /* :230 */
             }
         }
-        if (c->carry_store) store_carried(c, ch, nchain, 0);
+        if (c->carry_store) {
+            store_carried(c, ch, nchain, 0);
+            c->carry->P[c->carry->wr][c->carry_lb * nchain + ch] = probability; /* the target at the configuration the chain stopped at */
+        }
     }
     return 0;
 }
@@ -1590,6 +1603,42 @@ void mcio_result_destroy(mcio_result *r) {
  *   new chain c continues the first stored chain j with W[j] > (c + u) * (W[n_old-1] / n_new),  u = (sqrt(5) - 1) / 2
  * (any offset in [0, 1) is a valid systematic resampling; 1/2 makes (c + u) n_old / n_new an integer for many chain counts -- with all
  * stored chains on one integrand the comparison is then an exact tie, decided by the last bit of w)                                  */
+/* Carried :vegasmc chains: one weight per stored chain (new target / old target).  Mirror of k_resample_chains' w_chain path, association
+ * included: the stored chains are cut into 256 stretches of ceil(n_old / 256); W[j] = (sum of the stretches before, added in order) +
+ * (running sum along the own stretch); then the same systematic pick. */
+void mcio_resample_weighted(const double *w, long n_old, long n_new, long *src) {
+    double *W = (double *)malloc((size_t)n_old * sizeof(double));
+    const long T = 256, per = (n_old + T - 1) / T;
+    double part[256];
+    for (long t = 0; t < T; ++t) {
+        const long j0 = t * per < n_old ? t * per : n_old, j1 = j0 + per < n_old ? j0 + per : n_old;
+        double mine = 0.0;
+        for (long j = j0; j < j1; ++j) mine += w[j];
+        part[t] = mine;
+    }
+    for (long t = 0; t < T; ++t) {
+        const long j0 = t * per < n_old ? t * per : n_old, j1 = j0 + per < n_old ? j0 + per : n_old;
+        double below = 0.0, run = 0.0;
+        for (long q = 0; q < t; ++q) below += part[q];
+        for (long j = j0; j < j1; ++j) {
+            run += w[j];
+            W[j] = below + run;
+        }
+    }
+    const double step = W[n_old - 1] / (double)n_new;
+    for (long c = 0; c < n_new; ++c) {
+        const double target = ((double)c + 0.6180339887498949) * step;
+        long lo = 0, hi = n_old - 1; /* smallest j with W[j] > target */
+        while (lo < hi) {
+            const long mid = (lo + hi) >> 1;
+            if (W[mid] > target) hi = mid;
+            else lo = mid + 1;
+        }
+        src[c] = lo;
+    }
+    free(W);
+}
+
 void mcio_resample_chains(const int *curr_old, long n_old, int nd, const double *rw_now, const double *rw_used, long n_new, long *src) {
     double w[65];
     long cnt[65]; /* (nd <= 64: the integrands of a draw are a 64-bit mask) */
@@ -1638,22 +1687,45 @@ static int run_blocks(mcio_config *c, int solver, mcio_integrand_fn f, const dou
         if (nb * nchain > cy->cap[wr]) {
             free(cy->x[wr]);
             free(cy->curr[wr]);
+            free(cy->P[wr]);
             cy->cap[wr] = nb * nchain;
             cy->x[wr] = (double *)calloc((size_t)cy->cap[wr] * (size_t)(c->ndraw > 0 ? c->ndraw : 1), sizeof(double));
             cy->curr[wr] = (int *)calloc((size_t)cy->cap[wr], sizeof(int));
+            cy->P[wr] = (double *)calloc((size_t)cy->cap[wr], sizeof(double));
         }
         cy->rd = cy->cur;
         cy->wr = wr;
     } else if (carried) cy->rd = cy->cur;
     cy->load_nchain = cy->nchain;
-    if (carried && solver == MCIO_MCMC) { /* which stored chain every new chain continues */
+    if (carried) { /* which stored chain every new chain continues */
         if (nb * nchain > cy->src_cap) {
             free(cy->src);
             cy->src_cap = nb * nchain;
             cy->src = (long *)calloc((size_t)cy->src_cap, sizeof(long));
         }
-        for (long b = 0; b < nb; ++b)
-            mcio_resample_chains(cy->curr[cy->rd] + b * cy->load_nchain, cy->load_nchain, c->Ni + 1, c->reweight, cy->rw_used, nchain, cy->src + b * nchain);
+        if (solver == MCIO_MCMC)
+            for (long b = 0; b < nb; ++b)
+                mcio_resample_chains(cy->curr[cy->rd] + b * cy->load_nchain, cy->load_nchain, c->Ni + 1, c->reweight, cy->rw_used, nchain, cy->src + b * nchain);
+        else { /* :vegasmc: the NEW target (refined map, moved reweight factors) over the old one at every stored configuration (mirror of
+                  vegasmc_carry_weights), then the weighted pick */
+            double *w = (double *)malloc((size_t)cy->load_nchain * sizeof(double));
+            mcio_config *cw = mcio_config_clone(c);
+            free(cw->carry);
+            cw->carry = cy;
+            cw->carry_owner = 0;
+            double pad[MCIO_MAXNI];
+            for (long b = 0; b < nb; ++b) {
+                for (long j = 0; j < cy->load_nchain; ++j) {
+                    const long slot = b * cy->load_nchain + j;
+                    load_carried(cw, slot);
+                    const double r = vegasmc_target(cw, f, ud, NULL, pad) / cy->P[cy->rd][slot];
+                    w[j] = (r == r && r < 1.7976931348623157e308 && r > 0.0) ? r : 0.0;
+                }
+                mcio_resample_weighted(w, cy->load_nchain, nchain, cy->src + b * nchain);
+            }
+            mcio_config_destroy(cw);
+            free(w);
+        }
     }
     if (keep) { /* the reweight factors this launch's chains run under */
         if (!cy->rw_used) cy->rw_used = (double *)calloc((size_t)(c->Ni + 1), sizeof(double));

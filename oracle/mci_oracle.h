@@ -134,6 +134,9 @@ typedef struct mcio_carry {
     double *rw_used;
     long *src;
     long src_cap;
+    /* :vegasmc (mirror of BatchArgs::store_P / vegasmc_carry_weights): the chain's target density config.probability at every stored
+     * configuration, P[buf][local block * nchain + ch]; the next launch resamples the stored chains with probability ~ new target / old */
+    double *P[2];
 } mcio_carry;
 
 typedef struct {
@@ -147,6 +150,8 @@ typedef struct {
 } mcio_result;
 
 void mcio_resample_chains(const int *curr_old, long n_old, int nd, const double *rw_now, const double *rw_used, long n_new, long *src);
+/* ... with one weight per stored chain (mirror of k_resample_chains' w_chain path: the same association of the running sums) */
+void mcio_resample_weighted(const double *w, long n_old, long n_new, long *src);
 void mcio_set_chain_carry(mcio_config *c, int mode); /* -1 automatic (:vegasmc) | 0 off | 1 :vegasmc and :mcmc */
 
 /* ---- RNG ---- */

@@ -136,6 +136,8 @@ def lib():
     L.mcio_do_reweight.argtypes = [c_double_p, c_double_p, C.c_long, C.c_double, c_double_p]
     L.mcio_resample_chains.argtypes = [C.POINTER(C.c_int), C.c_long, C.c_int, c_double_p, c_double_p, C.c_long, C.POINTER(C.c_long)]
     L.mcio_resample_chains.restype = None
+    L.mcio_resample_weighted.argtypes = [c_double_p, C.c_long, C.c_long, C.POINTER(C.c_long)]
+    L.mcio_resample_weighted.restype = None
     L.mcio_integrate.argtypes = [C.POINTER(_Config), C.c_int, C.c_void_p, c_double_p, C.c_long, C.c_int, C.c_long,
                                  C.c_int, C.c_int, C.c_double, C.c_long, C.c_uint64, C.c_int, C.c_long,
                                  C.POINTER(_Result)]

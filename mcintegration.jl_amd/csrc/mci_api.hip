@@ -1236,7 +1236,7 @@ static int load_slot(mci_problem *p, int slot, Candidate &c, int64_t lds) {
     }
     HIPCHK(hipModuleGetFunction(&p->f_solver[slot], p->module[slot], names[slot]));
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)p->f_solver[slot], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if ((slot == MCI_VEGASMC || slot == kSlotVegasmcSpec) && !p->shape.host_integrand) {
+    if (slot == MCI_VEGASMC || slot == kSlotVegasmcSpec) {
         hipFunction_t &fw = p->f_carryw[slot == MCI_VEGASMC ? 0 : 1];
         HIPCHK(hipModuleGetFunction(&fw, p->module[slot], "mci_vegasmc_carry_weights"));
         if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)fw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1950,10 +1950,27 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
                 a.carry_w = p->d_carry_w;
                 a.carry_total = total;
                 mci::BatchArgs wa = a; // (edges, tables, reweight, userdata and the carry fields; everything else unused)
+                double *d_cw = nullptr; // a host closure: evaluated at the stored configurations here, one more callback per iteration
+                if (s.host_integrand) {
+                    const int nw = s.ni * s.ncomp;
+                    std::vector<double> hx((size_t)total * s.ndraw), hw((size_t)total * nw);
+                    for (int k = 0; k < s.ndraw; ++k)
+                        HIPCHK(hipMemcpyAsync(hx.data() + (size_t)k * total, a.carry_x + (size_t)k * a.carry_cap, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+                    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+                    if ((rc = eval_host_integrand(p, nullptr, hx.data(), hw.data(), total))) return rc;
+                    HIPCHK(hipMalloc((void **)&d_cw, hw.size() * sizeof(double)));
+                    HIPCHK(hipMemcpyAsync(d_cw, hw.data(), hw.size() * sizeof(double), hipMemcpyHostToDevice, p->ctx->stream));
+                    HIPCHK(hipStreamSynchronize(p->ctx->stream)); // (`hw` leaves scope)
+                    wa.host_w = d_cw;
+                }
                 void *wargs[] = {&wa};
                 const int64_t wgrid = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
                 const int tw = G > 1 ? 256 : (T < 256 ? T : 256); // (within the launch bound its code object was compiled for)
                 HIPCHK(hipModuleLaunchKernel(p->f_carryw[G > 1 ? 1 : 0], (unsigned)wgrid, 1, 1, (unsigned)tw, 1, 1, (unsigned)p->lds_bytes, p->ctx->stream, wargs, nullptr));
+                if (d_cw) {
+                    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+                    (void)hipFree(d_cw);
+                }
                 ra.w_chain = p->d_carry_w;
             }
             hipLaunchKernelGGL(mci::k_resample_chains, dim3((unsigned)nblocks), dim3(256), 0, p->ctx->stream, ra);

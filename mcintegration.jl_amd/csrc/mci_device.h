@@ -1805,6 +1805,9 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_carry_weights(const
         Chain<Cfg> c;
         load_carried<Cfg>(a, t, lb, from, c);
         double w[Cfg::NW], pad[NI + 1];
+        if constexpr (Cfg::HOST_INTEGRAND != 0) // (a host closure: evaluated at the stored configurations before this launch, host_w[q * carry_total + j])
+            static_for<0, Cfg::NW>([&](auto Q) { w[decltype(Q)::value] = a.host_w[decltype(Q)::value * a.carry_total + j]; });
+        else
         Cfg::integrand(c.x, w, a.ud, -1);
         static_for<0, NI + 1>([&](auto I) { pad[decltype(I)::value] = pad_prob<Cfg, decltype(I)::value>(c); });
         double probability = rw[NORMI] * pad[NORMI];
@@ -2015,7 +2018,10 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_host_step(const Bat
         });
         static_for<0, Cfg::NW>([&](auto Q) { h.cw[decltype(Q)::value * nc + cid] = w[decltype(Q)::value]; });
         h.cprobability[cid] = probability;
-        if (a.store_x && h.ne == h.steps + 1) store_carried<Cfg>(a, wi.lb, ch, c); // the chain's last step is through
+        if (a.store_x && h.ne == h.steps + 1) { // the chain's last step is through
+            store_carried<Cfg>(a, wi.lb, ch, c);
+            if (a.store_P) a.store_P[wi.lb * a.nchain + ch] = probability;
+        }
     }
     __syncthreads();
     flush_workgroup<Cfg, Lds<Cfg>, true, true, true>(a, smem, acc, extra, wi.rowid, 0);

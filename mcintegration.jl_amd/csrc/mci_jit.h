@@ -192,8 +192,7 @@ inline std::string generate_source(const ProblemShape &s, int solver, int unit =
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_chains(mci::BatchArgs a) { "
           << (s.host_integrand ? "mci::vegasmc_host_step<Cfg>(a); }\n" : "mci::vegasmc_chains<Cfg>(a); }\n");
         // (carried chains: the new target over the old one at every stored configuration, before they are resampled)
-        if (!s.host_integrand)
-            o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_carry_weights(mci::BatchArgs a) { mci::vegasmc_carry_weights<Cfg>(a); }\n";
+        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_carry_weights(mci::BatchArgs a) { mci::vegasmc_carry_weights<Cfg>(a); }\n";
     } else {
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_mcmc_chains(mci::BatchArgs a) { "
           << (s.host_integrand ? "mci::mcmc_host_step<Cfg>(a); }\n" : "mci::mcmc_chains<Cfg>(a); }\n");

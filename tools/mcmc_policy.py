@@ -49,7 +49,10 @@ def case(name, seed=1):
 def trace(name, neval, niter, solver="mcmc"):
     cfg, f, meas, exact = case(name)
     eng = mci.Engine(cfg, f, measure=meas)
-    eng.compile(solver)
+    if os.environ.get("POLICY_LANES"):   # lanes per chain (mci_set_chain_speculation): 1 = one lane per chain always
+        eng.set_chain_speculation(int(os.environ["POLICY_LANES"]))
+    else:
+        eng.compile(solver)
     eng.set_kernel_timing(1)
     block = 16
     npb = neval // block
@@ -64,8 +67,8 @@ def trace(name, neval, niter, solver="mcmc"):
         ms = eng.kernel_times_ms(1)[0]
         tot += float(ms[-1])
         valid, warm = eng.mcmc_launch_valid()[:2] if solver == "mcmc" else (True, True)
-        print("  it %2d  nchain %6d  len %8d  carried %d  kernel %9.3f ms  hold top 2^%d  %s  mean[0] %.6f +- %.1e" % (
-            it, nchain, npb // max(nchain, 1), carried, ms[-1], top, "valid" if valid else "short" + ("" if warm else " (warm-up: integrate() would run it again)"),
+        print("  it %2d  nchain %6d  len %8d  carried %d  lanes %2d  kernel %9.3f ms  hold top 2^%d  %s  mean[0] %.6f +- %.1e" % (
+            it, nchain, npb // max(nchain, 1), carried, eng.last_chain_speculation()[0], ms[-1], top, "valid" if valid else "short" + ("" if warm else " (warm-up: integrate() would run it again)"),
             np.ravel(m)[0], np.ravel(e)[0]), flush=True)
     print("  sum of kernel times %.1f ms -> %.2f Gsteps/s" % (tot, neval * niter / tot / 1e6))
     eng.close()

@@ -313,6 +313,15 @@ def test_library_rccl_single_rank_and_torch_reducer():
         assert a.correlated == b.correlated
         np.testing.assert_allclose(a._flat_std, b._flat_std, rtol=1e-4)      # the lineage error, per iteration through the communicator | inside the library
         check(a, [PI / 4.0, 4.0 * PI / 3.0 / 8])
+    # ONE collective per iteration whatever the solver (BASELINE north star): the 64 holding-time counts an :mcmc launch with automatic
+    # chain counts measures ride in the packed all-reduce (exact doubles behind the tables) instead of in an all-reduce of their own
+    for alg, extra in (("vegas", 0), ("vegasmc", 0), ("mcmc", 64)):
+        cfg = Configuration(var=Continuous(0.0, 1.0), dof=[[2], [3]], seed=6)
+        n0 = eng.comm_collectives()[0]
+        r = integrate(mci.catalog.sphere2(), config=cfg, comm=comm, solver=alg, neval=2e5, niter=6)
+        n1, count = cfg._engine.comm_collectives()
+        assert n1 - n0 == 6 + r.warmup, (alg, n1 - n0, r.warmup)
+        assert count == cfg._engine.packed_size + extra, (alg, count, cfg._engine.packed_size)
 
 
 def test_torch_nccl_reducer_works_on_the_device_buffer_in_place():

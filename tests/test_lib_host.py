@@ -258,3 +258,25 @@ def test_closure_form_is_decided_by_parameters_without_defaults():
         return 0
     assert rp(with_varargs, 2) == 2
     assert rp(print, 2) in (0, 2)                                # builtins without a signature fall back to the plain form
+
+
+def test_result_says_when_weighted_and_plain_average_of_the_iterations_disagree():
+    """statistics.jl:186-220 weights the iterations by 1 / sigma_i^2; when an iteration's error estimate moves with its mean (heavy
+    tails) that average is biased.  The engine reproduces the reference's average and says so: Result.weighting_shift, and a note under
+    the table of report(result)."""
+    import io
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]])
+    rng = np.random.default_rng(5)
+    # iterations whose error grows with their value: the low ones get the weight
+    im = np.array([[1.0], [1.0], [1.0], [1.0], [3.0], [3.0], [3.0]]) + 0.01 * rng.standard_normal((7, 1))
+    ie = np.array([[0.05], [0.05], [0.05], [0.05], [1.0], [1.0], [1.0]])
+    res = mci.Result(im, ie, cfg, ignore=0)
+    assert res.weighting_shift[0] > 2.0
+    out = io.StringIO()
+    mci.report(res, io=out)
+    assert "note: the weighted average lies" in out.getvalue()
+    quiet = mci.Result(1.0 + 0.01 * rng.standard_normal((7, 1)), np.full((7, 1), 0.01), cfg, ignore=0)
+    assert quiet.weighting_shift[0] < 2.0
+    out = io.StringIO()
+    mci.report(quiet, io=out)
+    assert "note:" not in out.getvalue()

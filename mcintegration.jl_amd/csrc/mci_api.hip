@@ -1802,6 +1802,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         else {
             G = 64;
             while (G > 1 && nblocks * nchain * G > mci_problem::kSpecFill) G >>= 1;
+            // (groups of 2 and 4 lanes lose: a trip costs more than a lane-per-chain step and advances barely more -- BASELINE configs[4],
+            // 24400 pilot chains: 32.3 ms with 2 lanes per chain against 21.8; the bubble diagram 3.5 | 2.15 | 1.1 us per step at 4 | 16 | 64
+            // lanes against 5.6 with one, profiles/r05_spec.txt)
+            if (G < 8) G = 1;
         }
     }
     int T_launch = T;

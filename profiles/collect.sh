@@ -5,7 +5,7 @@
 #   3. rocprofv3 --pmc WRITE_SIZE          (separate pass)           -> gpurun_out/prof_write_<tag>/
 #   4. rocprofv3 --pmc SQ counters         (VALU/LDS utilisation)    -> gpurun_out/prof_sq_<tag>/
 # Counter passes never combine --pmc with trace domains other than --kernel-trace (gpurun rule).
-#   usage: profiles/collect.sh <tag> [bench|c4|c3|c5] [steps]
+#   usage: profiles/collect.sh <tag> [bench|c4|c3|c5|bubble_mcmc|default_call] [steps]
 #     bench: the default bench.py workload (C2), kernel mci_vegas_batch          -> profiles/<tag>_kernel_stats.txt, <tag>_pmc_traffic.json
 #     c4   : BASELINE configs[3] on one GPU (tools/workload.py c4), mci_vegas_batch + mci_vegas_tiles
 #     c3   : BASELINE configs[2] (tools/workload.py c3), mci_vegasmc_chains;   c5: BASELINE configs[4] (tools/workload.py c5), mci_mcmc_chains
@@ -25,6 +25,12 @@ elif [ "$WHAT" = "c3" ]; then        # BASELINE configs[2]: example/bubble.jl un
 elif [ "$WHAT" = "c5" ]; then        # BASELINE configs[4]: 4 integrals on a 12-D pool under :mcmc, automatic chain length
   CMD="python tools/workload.py c5 --niter 10 --cold"   # a cold call: ONE integrate(niter = 10) on a fresh problem, every launch in the trace
   KERNELS="mci_mcmc_chains"
+elif [ "$WHAT" = "bubble_mcmc" ]; then  # the bubble diagram under :mcmc, cold: a few hundred long chains -> a group of lanes per chain (csrc/mci_spec.h)
+  CMD="python tools/mcmc_policy.py cold bubble 3e7 10 1"
+  KERNELS="mci_mcmc_spec,mci_mcmc_chains,k_resample_chains"
+elif [ "$WHAT" = "default_call" ]; then # the reference's default call (solver = :vegasmc, neval = 1e4, 16 chains), 200 calls
+  CMD="python tools/spec_bench.py default 10"
+  KERNELS="mci_vegasmc_spec,mci_vegasmc_chains,mci_mcmc_spec,mci_mcmc_chains,k_finish"
 else
   CMD="python bench.py --steps $STEPS --warmup 5 --passes ${PASSES:-40} --no-cpu-baseline"   # ~400 launches: the average is the steady state, not the idle ramp
   KERNELS="mci_vegas_batch"

@@ -144,10 +144,10 @@ def test_complex_weights_and_user_measure_with_groups(oracle, solver):
 
 
 def test_automatic_group_size_follows_the_chain_count():
-    """automatic: the largest group that keeps the launch within one wave per SIMD (65536 lanes); many chains: one lane per chain"""
+    """automatic: the largest group that keeps the launch within one wave per SIMD (65536 lanes), at least 8 lanes; more chains: one lane per chain"""
     cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]], seed=SEED)
     eng = mci.Engine(cfg, mci.catalog.x2y2())
-    for nchain, want in ((1, 64), (64, 64), (128, 32), (1024, 4), (4096, 1)):
+    for nchain, want in ((1, 64), (64, 64), (128, 32), (512, 8), (1024, 1), (4096, 1)):   # (groups of 2 and 4 lanes lose to one lane per chain)
         eng.iteration("vegasmc", 8192, 0, 16, iteration=0, seed=SEED, nchain=nchain)
         assert eng.last_chain_speculation()[0] == want, (nchain, eng.last_chain_speculation())
     eng.set_chain_speculation(1)

@@ -196,6 +196,12 @@ struct mci_problem {
     std::vector<double> h_mtmp;                     // callback form != record form: rows regrouped here
     std::vector<int32_t> h_mitmp;
     int threads = 256, wg_per_block = 0; // 0 = auto
+    bool threads_explicit = false;       // mci_set_launch named a workgroup size
+    // Plain-layout :vegas kernels of light integrands are compiled for workgroups of up to 512 threads (they need <= 128 registers anyway),
+    // and mid-size launches -- one workgroup per CU, 2^19 <= samples x draws, samples < 2^22: the sizes the reference's own tests and
+    // examples run -- use them: twice the lanes behind the same 256 prologues, epilogues and partial rows (tools/midsize_sweep.py,
+    // profiles/r05_latency.txt: -7 .. -11 % per iteration on 2-D and 6-D integrands at 3e5 .. 3e6 samples)
+    bool vegas_wide = false;
     // :vegas kernels whose tables take more than half of a CU's LDS (one workgroup per CU: 16 or 32 independent grids) pick their
     // workgroup size from the compiled code: the largest of 1024 / 768 / 512 threads (4 / 3 / 2 waves per SIMD) at which the sample
     // pass shows no scratch (128 / 168 / 256 registers).  threads_vegas = 0: the vegas kernel follows `threads`
@@ -477,7 +483,7 @@ int hold_consume(mci_problem *p) {
 }
 
 void drop_modules(mci_problem *p) {
-    p->vegas_planned = p->vegas_keys = false;
+    p->vegas_planned = p->vegas_keys = p->vegas_wide = false;
     p->f_dump = nullptr;
     for (int k = 0; k < mci_problem::kSlots; ++k) {
         p->compiled[k] = false;
@@ -1134,6 +1140,7 @@ int mci_set_measure_host_indexed(mci_problem *p, mci_host_measure_idx_fn fn, voi
 int mci_set_launch(mci_problem *p, int32_t threads, int32_t wg_per_block) {
     if (threads > 0) {
         if (threads % 64 || threads > 1024) return fail(MCI_ERR_INVALID, "threads per workgroup must be a multiple of 64, <= 1024");
+        p->threads_explicit = true;
         if (threads != p->threads || p->threads_vegas) {
             p->threads = threads;
             p->vegas_plan_a = false; // an explicit size: the vegas kernel follows it
@@ -1307,7 +1314,7 @@ static int compile_solver(mci_problem *p, int slot) {
     } else if (p->vegas_planned) {
         // the other measurefreq variant of a kernel whose plan (workgroup size, histogram copies, round keys) stands
         chosen.src = (p->vegas_keys ? std::string(kVgprKeys) : std::string()) + mcijit::generate_source(p->shape, solver, unit);
-        chosen.threads = p->threads_vegas ? p->threads_vegas : p->threads;
+        chosen.threads = p->threads_vegas ? p->threads_vegas : p->vegas_wide ? 512 : p->threads;
         chosen.rc = mcijit::compile(chosen.src, chosen.threads, chosen.code, chosen.log, chosen.cached, &chosen.path);
         if (chosen.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", chosen.log.c_str());
         if (p->vegas_keys && (chosen.vgprs() > 128 || chosen.scratch() != 0)) { // (this variant carries a few registers more)
@@ -1378,9 +1385,18 @@ static int compile_solver(mci_problem *p, int slot) {
             chosen = std::move(*all[pick]);
         } else {
             chosen.src = mcijit::generate_source(p->shape, solver, unit);
-            chosen.threads = T0;
+            // (light integrands: a launch bound of 512 threads costs them nothing -- see vegas_wide; anything that would need scratch or
+            // more than 128 registers under it is compiled for the default size instead)
+            const bool try_wide = T0 == 256 && !p->threads_explicit && !p->deterministic && p->shape.ndraw <= 8 && !p->shape.host_integrand;
+            chosen.threads = try_wide ? 512 : T0;
             chosen.rc = mcijit::compile(chosen.src, chosen.threads, chosen.code, chosen.log, chosen.cached, &chosen.path);
             if (chosen.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", chosen.log.c_str());
+            p->vegas_wide = try_wide && chosen.scratch() == 0 && chosen.vgprs() <= 128;
+            if (try_wide && !p->vegas_wide) {
+                chosen.threads = T0;
+                chosen.rc = mcijit::compile(chosen.src, chosen.threads, chosen.code, chosen.log, chosen.cached, &chosen.path);
+                if (chosen.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", chosen.log.c_str());
+            }
         }
         p->vegas_planned = true;
     }
@@ -1721,7 +1737,11 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     if ((rc = flush_merge(p))) return rc; // a previous batch nobody looked at: merge it (resets the global histogram)
     HIPCHK(hipSetDevice(p->ctx->device));
     const auto &s = p->shape;
-    const int T = solver_threads(p, solver);
+    int T = solver_threads(p, solver);
+    // mid-size :vegas launches of a plain-layout kernel compiled for it: 512-thread workgroups (mci_problem::vegas_wide)
+    if (solver == MCI_VEGAS && p->vegas_wide && !p->threads_vegas && p->wg_per_block <= 0 && nblocks * nevalperblock < ((int64_t)1 << 22) &&
+        nblocks * nevalperblock * p->shape.ndraw >= ((int64_t)1 << 19))
+        T = 512;
     int64_t units = nevalperblock; // lanes of useful work per block
     if (solver != MCI_VEGAS && (block_hi > 4096 || iteration >= 131072 || iteration < 0))
         return fail(MCI_ERR_INVALID, "chain solvers address a chain by (block < 4096, iteration < 131072): got block_hi=%lld, iteration=%d",

@@ -342,6 +342,12 @@ int mci_last_chain_launch(const mci_problem *prob, int64_t *nchain, int32_t *car
  * trees for chains that accept most steps).
  * Launches with a host integrand and the deterministic mode keep one lane per chain. */
 int mci_set_chain_speculation(mci_problem *prob, int32_t lanes, double accept, int32_t max_accepts);
+/* Warm-up of the automatic :mcmc chain length (DESIGN.md "Chains"): launches the last mci_integrate call ran AGAIN with longer chains
+ * instead of counting (mci_result.warmup) have trained the map, moved the reweight factors and advanced the chains, but their
+ * evaluations are in neither mci_result.neval nor the estimate: this is how many there were, on this rank.  A launch is accepted on
+ * the holding times IT measured (it is long enough for its own holds), and from the first accepted launch on nothing is repeated or
+ * left out again -- the selection acts on the warm-up only, never on a counted iteration's value. */
+int mci_last_integrate_discarded(const mci_problem *prob, int64_t *neval, int32_t *launches);
 /* lanes per chain of the last chain-solver launch (1: one lane per chain) and the accept levels of its tree */
 int mci_last_chain_speculation(const mci_problem *prob, int32_t *lanes, int32_t *max_accepts);
 /* the tree mci_set_chain_speculation(lanes, accept, max_accepts) stands for, node by node ([lanes] each; NULL: not wanted): the step

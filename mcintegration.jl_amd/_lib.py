@@ -111,6 +111,7 @@ SIGNATURES = [
     ("mci_last_chain_launch", C.c_int, [_VP, C.POINTER(C.c_int64), c_int32_p]),
     ("mci_set_chain_speculation", C.c_int, [_VP, C.c_int32, C.c_double, C.c_int32]),
     ("mci_last_chain_speculation", C.c_int, [_VP, c_int32_p, c_int32_p]),
+    ("mci_last_integrate_discarded", C.c_int, [_VP, C.POINTER(C.c_int64), c_int32_p]),
     ("mci_speculation_tree", C.c_int, [C.c_int32, C.c_double, C.c_int32, c_int32_p, c_int32_p, c_int32_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("mci_compile_chain_speculation", C.c_int, [_VP, C.c_int32]),
     ("mci_train", C.c_int, [_VP]),

@@ -154,6 +154,8 @@ struct mci_problem {
     float spec_accepts[8] = {};          // the acceptance each of them was built for
     double spec_tab_accept = -1.0;
     int last_spec_lanes = 1, last_spec_maxacc = 0; // of the last chain launch (1: one lane per chain)
+    int64_t last_discarded_neval = 0;              // evaluations of the warm-up launches the last mci_integrate ran again instead of counting
+    int32_t last_discarded_launches = 0;
     static const int64_t kSpecFill = 65536;        // lanes a launch of few chains spreads over: one wave on each of the 1024 SIMDs
     bool vegas_planned = false, vegas_keys = false; // the :vegas plan (workgroup size, histogram copies, VGPR round keys) stands for both variants
     std::vector<double> h_goal; // reweight_goal (main.jl:81); empty = none
@@ -303,6 +305,7 @@ struct mci_problem {
     struct PersistJob;
     PersistJob *persist_job = nullptr;
     unsigned long long *d_persist = nullptr; // [0] arrived | done << 40, [2] gave up
+    double *d_edges_backup = nullptr;        // the map a persistent launch started from (restored when it stalls)
     unsigned long long persist_arrive = 0, persist_done = 0;
     unsigned long long persist_spin_ticks = 200000000ull; // ticks of the 100 MHz wall clock a grid-wide wait may take: 2 s (mci_debug_persist_spin_ticks)
     int persistent = -1;          // -1 automatic (launch-bound :vegas calls of mci_integrate), 0 never, 1 whenever the layout allows
@@ -1007,6 +1010,7 @@ int mci_problem_destroy(mci_problem *p) {
             if (p->d_chain_P[b]) (void)hipFree(p->d_chain_P[b]);
         if (p->d_carry_w) (void)hipFree(p->d_carry_w);
         if (p->d_clocks) (void)hipFree(p->d_clocks);
+        if (p->d_edges_backup) (void)hipFree(p->d_edges_backup);
         if (p->h_hold) (void)hipHostFree(p->h_hold);
         if (p->h_hold_d) (void)hipHostFree(p->h_hold_d);
         if (p->h_log) (void)hipHostFree(p->h_log);
@@ -1518,6 +1522,13 @@ int mci_set_chain_speculation(mci_problem *p, int32_t lanes, double accept, int3
     p->spec_lanes = lanes;
     p->spec_accept = accept > 0.0 ? accept : 0.0;
     p->spec_maxacc = max_accepts < 0 ? -1 : max_accepts;
+    return MCI_OK;
+}
+
+int mci_last_integrate_discarded(const mci_problem *p, int64_t *neval, int32_t *launches) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (neval) *neval = p->last_discarded_neval;
+    if (launches) *launches = p->last_discarded_launches;
     return MCI_OK;
 }
 
@@ -2834,6 +2845,11 @@ static int persist_launch(mci_problem *p, const mci_integrate_args *ia, int64_t 
     f.done0 = p->persist_done;
     f.spin_ticks = p->persist_spin_ticks; // 2 s of the 100 MHz wall clock per wait
     void *args[] = {&a, &f};
+    // The map the call starts from, kept aside: workgroup 0 writes the refined map back as soon as ITS last turn is through, and another
+    // workgroup can still run out of time after that -- the fall-back to the launch chain (mci_integrate) restores this copy instead
+    // of trusting that `edges` was not touched (8 KB, device to device, behind nothing: ~2 us of a 0.17 ms call)
+    if (!p->d_edges_backup) HIPCHK(hipMalloc((void **)&p->d_edges_backup, (p->h_edges.size() ? p->h_edges.size() : 1) * sizeof(double)));
+    if (p->h_edges.size()) HIPCHK(hipMemcpyAsync(p->d_edges_backup, p->d_edges, p->h_edges.size() * sizeof(double), hipMemcpyDeviceToDevice, p->ctx->stream));
     // nrows sampling workgroups + the statistics workgroup
     HIPCHK(hipModuleLaunchKernel(p->f_persist, (unsigned)nrows + 1, 1, 1, (unsigned)T, 1, 1, (unsigned)lds, p->ctx->stream, args, nullptr));
     p->persist_arrive += (unsigned long long)(ia->niter + 1) * (unsigned long long)nrows; // (+ one "finished reading" per workgroup at the end)
@@ -2916,6 +2932,8 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
     double *h = p->h_log;
     int *hstatus = reinterpret_cast<int *>(p->h_log + nlog);
     int res_warmup = 0;
+    p->last_discarded_neval = 0;
+    p->last_discarded_launches = 0;
     for (int attempt = 0;; ++attempt) {
         p->last_persistent = persist;
         if (persist && (rc = persist_launch(p, a, nevalperblock, lo, hi, wpb_persist))) return rc;
@@ -2940,6 +2958,8 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
                 if (valid) break;
                 if ((rc = mci_iteration_discard(p))) return rc; // (the repeat overwrites this attempt's rows of the iteration log and of the block log)
                 res_warmup += 1;
+                p->last_discarded_neval += nevalperblock * (hi - lo);
+                p->last_discarded_launches += 1;
             }
         }
         // the statistics of all iterations and the status word come back behind the last kernel in ONE synchronisation, into pinned memory (a
@@ -2949,9 +2969,12 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
         HIPCHK(hipStreamSynchronize(p->ctx->stream));
         if (persist && attempt == 0 && (*hstatus & mci::ST_PERSIST_STALL)) {
             // A grid-wide wait of the persistent launch ran out of time (its workgroups were not all resident: a device shared with another
-            // long-running kernel).  Nothing of the call is lost: the map is written back by workgroup 0 after the LAST turn only, so
-            // `edges` still holds what the call started from -- counters, histogram buffers and the status word are reset, the iteration
-            // log is rewound, and the same iterations run through the launch chain (as every later call of this problem does).
+            // long-running kernel).  Nothing of the call is lost: the map the call started from is restored from the copy persist_launch
+            // took (workgroup 0 may have written its refined map back before another workgroup gave up), counters, histogram buffers and
+            // the status word are reset, the iteration log is rewound, and the same iterations run through the launch chain (as every
+            // later call of this problem does).
+            if (p->d_edges_backup && p->h_edges.size())
+                HIPCHK(hipMemcpyAsync(p->d_edges, p->d_edges_backup, p->h_edges.size() * sizeof(double), hipMemcpyDeviceToDevice, p->ctx->stream));
             if ((rc = persist_recover(p))) return rc;
             p->log_row = row0;
             persist = false;

@@ -495,8 +495,10 @@ class Engine:
         vis = np.zeros(self.config.N + 1)
         r = _lib.ResultC(niter, n, _dp(im), _dp(ie), _dp(m), _dp(s), _dp(c2), 0, 0.0, _dp(vis), 0, 0)
         check(lib().mci_integrate(self.p, C.byref(a), C.byref(r)))
+        dn, dl = C.c_int64(), C.c_int32()
+        check(lib().mci_last_integrate_discarded(self.p, C.byref(dn), C.byref(dl)))
         out = dict(mean=m, stdev=s, chi2=c2, iter_mean=im, iter_std=ie, neval=r.neval, seconds=r.seconds, visited=vis,
-                   correlated=bool(r.correlated), block_mean=None, warmup=int(r.warmup))
+                   correlated=bool(r.correlated), block_mean=None, warmup=int(r.warmup), neval_discarded=int(dn.value))
         if _lib.SOLVERS[solver] != _lib.VEGAS and out["correlated"]:
             # (only a run of carried chains needs them -- the block-lineage error of Result.with_ignore; a launch-bound default-size call is
             # spared the flush, the copy and the second synchronisation)

@@ -145,6 +145,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     means, stds = [], []
     neval_done = 0
     warmup = 0                             # launches run again instead of being counted (automatic :mcmc chain lengths)
+    neval_discarded = 0
     block_mean, correlated = None, False   # chain solvers: every block's mean of every iteration | the iterations continued each other's chains
     if type(comm) is LocalComm and engine_factory is None and hasattr(eng, "integrate") and getattr(eng, "comm_ranks", lambda: 0)() == 1:
         # one process: the whole loop runs inside the library (mci_integrate: the iterations are queued back to back on the
@@ -155,6 +156,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
                           thermal_ratio=thermal_ratio, reweight_goal=reweight_goal)
         means, stds = list(r["iter_mean"]), list(r["iter_std"])
         block_mean, correlated, warmup = r.get("block_mean"), r.get("correlated", False), r.get("warmup", 0)
+        neval_discarded = r.get("neval_discarded", 0)
         neval_done = nevalperblock * block * niter
         niter_loop = 0
         config.visited = r["visited"]    # config.visited of the last iteration (configuration.jl:46), for report(config)
@@ -180,6 +182,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
             eng.discard_iteration()
             attempt += 1
             warmup += 1
+            neval_discarded += nevalperblock * block
         means.append(m)
         stds.append(e)
         neval_done += nevalperblock * block
@@ -204,6 +207,7 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     res = Result(np.array(means), np.array(stds), config, ignore, neval=neval_done, seconds=time.time() - t0, block_mean=block_mean,
                  correlated=correlated, block=block)   # main.jl:211
     res.warmup = warmup   # launches that were run again instead of being counted (automatic :mcmc chain lengths)
+    res.neval_discarded = neval_discarded   # ... and their evaluations: spent (they trained the map), in neither res.neval nor the estimate
     if print >= 0:
         report(res, io=printio)                                                       # main.jl:212-213
     return res

@@ -323,6 +323,7 @@ def main():
     # (by default the passes go on for ~5 s: a 40 ms burst is invisible to anything that samples the GPU from outside, and the
     # median of a hundred passes is a better number than the median of three)
     pass_dt, dry_stats = [], []
+    coll0 = eng.comm_collectives()[0] if hasattr(eng, "comm_collectives") else None   # ncclAllReduce calls the library has issued so far
     if hasattr(eng, "reserve_iterations"):
         eng.reserve_iterations(a.steps * (a.passes if a.passes > 0 else 400))
     npass = a.passes if a.passes > 0 else 3
@@ -352,6 +353,10 @@ def main():
         eng.check_status()   # a launch that tripped a device-side error (normalization, histogram) must not print a number
     ntimed = a.steps * len(pass_dt)
     dt = sorted(pass_dt)[len(pass_dt) // 2]   # median pass
+    coll = None
+    if coll0 is not None and isinstance(comm, RcclComm):
+        c1, last = eng.comm_collectives()
+        coll = {"per_step": (c1 - coll0) / float(ntimed), "doubles_each": last}   # north star: ONE all-reduce per iteration
 
     # production estimate: every timed iteration, weighted average with ignore = 0
     # (k_train copied every iteration's statistics head into the device-side log; one D2H after the loop)
@@ -408,7 +413,7 @@ def main():
                        "ms_per_step_max": round(max(pass_dt) / a.steps * 1e3, 4), "timed_seconds": round(sum(pass_dt), 3),
                        "ms_per_step_min": round(min(pass_dt) / a.steps * 1e3, 4), "value_is": "median pass"},
             "comm": {"kind": comm_kind, "ranks": max(r["comm_ranks"] for r in ranks), "world_size": world,
-                     "control_plane": "gloo" if multi else None, "payload_doubles": getattr(eng, "packed_size", None),
+                     "control_plane": "gloo" if multi else None, "payload_doubles": getattr(eng, "packed_size", None), "collectives": coll,
                      "per_rank": ranks, "neval_after_allreduce": neval_reduced},
             "estimate": {"mean": mean, "sigma": err, "chi2_dof": chi2, "exact": EXACT, "iterations": len(means),
                          "deviation_sigma": (mean - EXACT) / err if err > 0 else None,

@@ -1332,6 +1332,9 @@ static int compile_solver(mci_problem *p, int slot) {
         p->shape.hcopy = planned_hcopy(p, &tcopy);
         if (p->hcopy_plan) p->threads_vegas = tcopy;
         const int T0 = p->threads_vegas ? p->threads_vegas : p->threads;
+        // (light integrands: a launch bound of 512 threads costs the plain layout nothing -- see vegas_wide; anything that would need scratch
+        // or more than 128 registers under it is compiled for the default size instead)
+        const bool try_wide = p->threads == 256 && !p->threads_explicit && !p->deterministic && p->shape.ndraw <= 8 && !p->shape.host_integrand;
         if (hcopy_plan) {
             // Histogram copies pay when the kernel runs four or five waves per SIMD either way (81..128 VGPRs: two 512-thread workgroups
             // share a CU).  More registers: two such workgroups no longer fit.  Fewer: the plain layout runs six or more waves per SIMD
@@ -1348,7 +1351,7 @@ static int compile_solver(mci_problem *p, int slot) {
             mcijit::ProblemShape sh = p->shape;
             sh.hcopy = 1;
             plain.src = mcijit::generate_source(sh, solver, unit);
-            plain.threads = p->threads;
+            plain.threads = try_wide ? 512 : p->threads;
             std::vector<Candidate *> both = {&keys, &plain};
             compile_all(both);
             if (keys.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", keys.log.c_str());
@@ -1365,6 +1368,12 @@ static int compile_solver(mci_problem *p, int slot) {
                 p->shape.hcopy = 1;
                 p->threads_vegas = 0;
                 p->vegas_keys = false;
+                p->vegas_wide = try_wide && plain.scratch() == 0 && plain.vgprs() <= 128;
+                if (try_wide && !p->vegas_wide) {
+                    plain.threads = p->threads;
+                    plain.rc = mcijit::compile(plain.src, plain.threads, plain.code, plain.log, plain.cached, &plain.path);
+                    if (plain.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", plain.log.c_str());
+                }
                 chosen = std::move(plain);
             } else chosen = std::move(*copy);
         } else if (p->vegas_plan_a) {
@@ -1389,9 +1398,6 @@ static int compile_solver(mci_problem *p, int slot) {
             chosen = std::move(*all[pick]);
         } else {
             chosen.src = mcijit::generate_source(p->shape, solver, unit);
-            // (light integrands: a launch bound of 512 threads costs them nothing -- see vegas_wide; anything that would need scratch or
-            // more than 128 registers under it is compiled for the default size instead)
-            const bool try_wide = T0 == 256 && !p->threads_explicit && !p->deterministic && p->shape.ndraw <= 8 && !p->shape.host_integrand;
             chosen.threads = try_wide ? 512 : T0;
             chosen.rc = mcijit::compile(chosen.src, chosen.threads, chosen.code, chosen.log, chosen.cached, &chosen.path);
             if (chosen.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", chosen.log.c_str());

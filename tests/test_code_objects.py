@@ -167,7 +167,9 @@ def test_histogram_copies_follow_the_placement_rule_and_the_register_budget():
     assert light.histogram_copies() == 8          # the rule's choice before the kernel exists
     light.compile("vegas")
     res = isa_mix.resources(light.code_object("vegas"))["mci_vegas_batch"]
-    assert res["vgpr"] <= 80 and light.histogram_copies() == 1 and res["max_threads"] == 256, res
+    # (launch bound 512: light plain-layout kernels are compiled for the 512-thread workgroups their mid-size launches use -- it costs a
+    # kernel of <= 128 registers nothing; big launches still run 256-thread workgroups, six or more waves per SIMD)
+    assert res["vgpr"] <= 80 and light.histogram_copies() == 1 and res["max_threads"] == 512, res
     light.close()
     # C5 :vegas (12 draws on one grid, 4 integrands): the copies that fit next to its tables, two 512-thread workgroups per CU
     c5 = [b for b in BASELINE if b[0] == "c5"][0]

@@ -149,6 +149,21 @@ def random_case(rng):
     return tuple(var), oleaves, dof, "\n".join(lines), len(draws)
 
 
+def vary_chain_lanes(eng, case_id):
+    """FUZZ_LANES=1 (tools/fuzz_layouts.py --lanes): a random group size and speculation tree per case (csrc/mci_spec.h) instead of the
+    automatic choice -- the chain is the same chain on any of them.  Returns a note for the case's description."""
+    import os
+    import numpy as np
+    if not os.environ.get("FUZZ_LANES"):
+        return ""
+    r = np.random.default_rng(777000 + case_id)
+    lanes = int(r.choice([1, 2, 4, 8, 16, 32, 64, -1]))
+    accept = float(r.choice([0.0, 1e-3, 0.1, 0.3, 0.5, 0.8]))
+    limit = int(r.choice([-1, -1, 1, 2, 3]))
+    eng.set_chain_speculation(lanes, accept, limit)
+    return " lanes=%d tree=(%g, %d)" % (lanes, accept, limit)
+
+
 def check_carried_iterations(oracle, case_id, seed=20260930):
     """consecutive iterations of both chain solvers on a random layout (1-5 pools of Continuous / Discrete / CompositeVar, 1-4 integrands,
     ragged dof), with doReweight! and train! in between and a chain count that changes from one iteration to the next: carried chains
@@ -168,6 +183,8 @@ def check_carried_iterations(oracle, case_id, seed=20260930):
     for solver, osolver in (("vegasmc", oracle.VEGASMC), ("mcmc", oracle.MCMC)):
         cfg = mci.Configuration(var=var, dof=dof, seed=seed)
         eng = mci.Engine(cfg, mci.Integrand(body))
+        note = vary_chain_lanes(eng, case_id)
+        what += note if note not in what else ""
         ocfg = oracle.Config(oleaves, dof)
         n = eng.nobs
         nstat = 2 * n + 2 + ni + 1

@@ -5,7 +5,8 @@ Every case draws a layout (1-5 pools of Continuous / Discrete / CompositeVar, 1-
 2000 increments), a launch shape (blocks, steps per block, chains per block, measure cadence, iteration number) and a generator
 (Philox4x32-10 or -7), JIT-compiles the three sample-batch kernels for it and compares one iteration of each solver with the oracle on
 the same Philox streams: packed sums and histograms to 1e-9 relative, holding-time histogram bucket by bucket, then a three-iteration
-:vegas run with train! in between.  Failures are collected, not fatal.   usage: fuzz_layouts.py [--pipe | --persist | --carry | --walk] [first_case] [ncases]
+:vegas run with train! in between.  Failures are collected, not fatal.   usage: fuzz_layouts.py [--pipe | --persist | --carry | --walk] [--lanes] [first_case] [ncases]
+(--lanes, with the default and the --carry campaign: a random number of lanes per chain and a random speculation tree per case, csrc/mci_spec.h)
 (--pipe: layouts of the pipelined :vegas loop only; --persist: whole integrate() calls over one Continuous variable type run as ONE
 persistent launch, against the oracle's loop; --carry: four consecutive iterations of :vegasmc and :mcmc with carried chains -- :mcmc:
 resampled to the moved reweight factors -- and a changing chain count, doReweight! and train! in between; --walk: deterministic runs under train!'s
@@ -25,7 +26,7 @@ import mci_oracle as oracle
 SEED = 20260930
 
 
-from layout_cases import check_carried_iterations, check_persistent_call, check_walks_agree, pipe_case, random_case  # noqa: E402  (shared with tests/test_hip_steady_state.py, test_hip_persistent.py)
+from layout_cases import check_carried_iterations, check_persistent_call, check_walks_agree, pipe_case, random_case, vary_chain_lanes  # noqa: E402  (shared with tests/test_hip_steady_state.py, test_hip_persistent.py)
 
 
 PIPE_MODE = False
@@ -59,6 +60,7 @@ def run_case(case_id):
     bits = int(rng.choice([52, 52, 32])) if PIPE_MODE else 52
     eng = mci.Engine(cfg, mci.Integrand(body), rng_rounds=rounds, **({"rng_bits": 32} if bits == 32 else {}))
     assert eng.ndraw == ndraw, what
+    what += vary_chain_lanes(eng, case_id)
     fn = oracle.compile_c_integrand(body)
     solvers = (("vegas", oracle.VEGAS),) if PIPE_MODE else (("vegas", oracle.VEGAS), ("vegasmc", oracle.VEGASMC), ("mcmc", oracle.MCMC))
     what += " bits=%d" % bits
@@ -92,6 +94,9 @@ if __name__ == "__main__":
     if "--carry" in sys.argv:     # four consecutive iterations of both chain solvers with carried chains and changing chain counts
         sys.argv.remove("--carry")
         CARRY_MODE = True
+    if "--lanes" in sys.argv:     # a random group size and speculation tree per case (the default and the --carry campaign)
+        sys.argv.remove("--lanes")
+        os.environ["FUZZ_LANES"] = "1"
     if "--walk" in sys.argv:      # serial walk with given decisions against its general form, deterministic runs, bit for bit
         sys.argv.remove("--walk")
         WALK_MODE = True

@@ -760,3 +760,31 @@ def test_c4_genz32_runs_in_l2_table_mode_and_matches_oracle(oracle, threads, pha
     np.testing.assert_allclose(got[4:], ref[4:], rtol=1e-9)
     assert eng.kernel_times_ms(1)[2] == (threads or 1024)
     assert genz_exact(32) > 0
+
+
+def test_mid_size_launches_of_light_integrands_use_wide_workgroups_and_the_timed_launches_report_their_clock(oracle):
+    """(i) A plain-layout :vegas kernel of a light integrand (at most 8 draws, <= 128 registers) is compiled with a launch bound of 512
+    threads and its mid-size launches -- 2^19 <= samples x draws, samples < 2^22: the sizes of the reference's own tests
+    (test/montecarlo.jl:298-387) -- run 256 workgroups of 512 threads (profiles/r05_latency.txt); bigger and smaller launches keep the
+    256-thread geometry; same sums whatever the geometry.  (ii) Every timed :vegas launch brackets its sample loop with s_memtime /
+    s_memrealtime (mci_kernel_clocks): a plausible shader clock comes back -- what bench.py prices data-sheet issue cycles with."""
+    c, cfg, eng, ocfg = make("sphere2_padding", oracle)
+    eng.set_kernel_timing(1)
+    block = 16
+    for npb, want in ((62500, 512), (1000, 256), (1 << 19, 256)):
+        got = eng.iteration("vegas", npb, 0, block, iteration=0, seed=SEED)
+        assert eng.kernel_times_ms(1)[2] == want, (npb, eng.kernel_times_ms(1))
+        if npb <= 62500:
+            ref = ocfg.iteration(oracle.VEGAS, c["oname"], c["ud"], npb, 0, block, 0, SEED)
+            gs, gh = hist_split(got, eng.nobs, cfg.N)
+            rs, rh = hist_split(ref, eng.nobs, cfg.N)
+            np.testing.assert_allclose(gs, rs, rtol=1e-11, atol=1e-300)
+            np.testing.assert_allclose(gh, rh, rtol=1e-9)
+    clk = eng.kernel_clocks_mhz(8)
+    assert len(clk) >= 3 and np.all((clk > 500.0) & (clk < 3000.0)), clk
+    narrow = mci.Engine(mci.Configuration(var=c["var"](), dof=c["dof"], seed=SEED), c["f"], threads=256)   # an explicit size: the kernel follows it
+    narrow.set_kernel_timing(1)
+    b = narrow.iteration("vegas", 62500, 0, block, iteration=0, seed=SEED)
+    assert narrow.kernel_times_ms(1)[2] == 256
+    a = eng.iteration("vegas", 62500, 0, block, iteration=0, seed=SEED)
+    np.testing.assert_allclose(a, b, rtol=1e-10)

@@ -42,4 +42,6 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write_$TAG -o write -- ba
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d $OUT/prof_sq_$TAG -o sq -- bash -c "cd $GRAFT_REPO_ROOT && $CMD" > $OUT/prof_sq_$TAG.log 2>&1
 cd $GRAFT_REPO_ROOT
 python profiles/summarize.py $TAG "$KERNELS" "$CMD" > $OUT/profile_summary_$TAG.txt 2>&1; cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc_traffic.json $OUT/ 2>/dev/null
+# (the raw rocpd databases are tens of MiB per pass and gpurun brings back at most 64 MiB: only the summaries travel)
+rm -rf $OUT/prof_stats_$TAG $OUT/prof_fetch_$TAG $OUT/prof_write_$TAG $OUT/prof_sq_$TAG
 tail -60 $OUT/profile_summary_$TAG.txt

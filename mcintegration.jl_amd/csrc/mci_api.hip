@@ -1445,7 +1445,7 @@ static int compile_spec(mci_problem *p, int solver) {
 // steps change its configuration with probability `accept` (greedy: the most probable frontier node next; ties go to the older
 // candidate), with at most `limit` accept edges on any way from the root (limit < 0: no bound).  accept -> 0 gives the reject chain,
 // accept = 1/2 the complete binary tree.  Nodes are numbered in the order they are taken: ancestors first.
-static const int kSpecMaxLevels = 12; // (a trip exchanges configurations once per accept level: mci_spec.h spec_wave_levels counts below 16)
+static const int kSpecMaxLevels = 12; // (:mcmc exchanges configurations once per accept level: mci_spec.h spec_wave_max counts below 64)
 static void spec_build(int lanes, double accept, int limit, std::vector<mci::SpecNode> &tab, int *maxacc) {
     struct Cand { double prob; int parent; bool via_acc; long seq; };
     std::vector<Cand> front;
@@ -1464,7 +1464,7 @@ static void spec_build(int lanes, double accept, int limit, std::vector<mci::Spe
             nd.depth = 0;
             nd.anc = -1;
             nd.nacc = 0;
-            nd.needacc = nd.needrej = 0ull;
+            nd.needacc = nd.needrej = nd.accdepth = 0ull;
         } else {
             const mci::SpecNode &pn = tab[(size_t)cd.parent];
             nd.depth = pn.depth + 1;
@@ -1472,6 +1472,7 @@ static void spec_build(int lanes, double accept, int limit, std::vector<mci::Spe
             nd.nacc = pn.nacc + (cd.via_acc ? 1 : 0);
             nd.needacc = pn.needacc | (cd.via_acc ? 1ull << cd.parent : 0ull);
             nd.needrej = pn.needrej | (cd.via_acc ? 0ull : 1ull << cd.parent);
+            nd.accdepth = pn.accdepth | (cd.via_acc ? 1ull << pn.depth : 0ull);
         }
         const int me = (int)tab.size();
         tab.push_back(nd);
@@ -1479,7 +1480,9 @@ static void spec_build(int lanes, double accept, int limit, std::vector<mci::Spe
         front.push_back({cd.prob * (1.0 - accept), me, false, seq++});
         if ((limit < 0 || nd.nacc + 1 <= limit) && nd.nacc + 1 <= kSpecMaxLevels) front.push_back({cd.prob * accept, me, true, seq++});
     }
-    for (auto &nd : tab) nd.levels = *maxacc;
+    int deepest = 0;
+    for (auto &nd : tab) deepest = nd.depth > deepest ? nd.depth : deepest;
+    for (auto &nd : tab) nd.levels = *maxacc | (deepest << 8);
 }
 
 // The trees of the next launch on the device (rebuilt when lanes / acceptance / limit change).  accept > 0: that one tree.  accept <= 0

@@ -127,9 +127,11 @@ struct SpecNode {
     int depth;   // the lane evaluates the proposal of step (first step of the trip) + depth
     int anc;     // nearest ancestor the way from the root leaves by its ACCEPT edge: the lane's step starts from that lane's proposal (-1: from the trip's base)
     int nacc;    // accept edges on the way from the root
-    int levels;  // the most accept edges on any way through this node's tree (the same in all its nodes)
+    int levels;  // low byte: the most accept edges on any way through this node's tree; next byte: its deepest node (the same in all its nodes)
     u64 needacc; // lanes (bit = lane within the group) that must have accepted / rejected for this node to be on the chain's path
     u64 needrej;
+    u64 accdepth; // the DEPTHS of the ancestors the way leaves by an accept edge (bit = depth): under :vegasmc a step's draw does not depend
+                  // on the configuration it starts from, so a lane builds its starting configuration from the draws of those depths
 };
 
 struct BatchArgs {

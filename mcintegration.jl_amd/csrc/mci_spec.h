@@ -60,16 +60,18 @@ template <class Cfg> __device__ __forceinline__ void chain_select(Chain<Cfg> &ds
 struct SpecLane {
     int G, m, gbase;
     int maxacc;  // accept levels the wave goes through per trip: the most of its groups' trees
+    int maxdepth; // ... and the deepest node of those trees
     u64 gmask;
     SpecNode nd;
     // the tree the group is on, and what its chain has done since the tree was last looked at
     int tree, trips, steps, accepts;
 };
-// the most accept levels of the trees the groups of this wave are on (wave-uniform; levels < 16)
-__device__ __forceinline__ int spec_wave_levels(int mine) {
+// the largest of a small number (< 64) over the lanes of the wave (wave-uniform): the most accept levels / the deepest node of the trees
+// its groups are on
+__device__ __forceinline__ int spec_wave_max(int mine) {
     int m = 0;
 #pragma unroll
-    for (int bit = 3; bit >= 0; --bit) {
+    for (int bit = 5; bit >= 0; --bit) {
         const int cand = m | (1 << bit);
         if (__ballot(mine >= cand) != 0ull) m = cand;
     }
@@ -84,7 +86,8 @@ __device__ __forceinline__ SpecLane spec_lane(const BatchArgs &a) {
     s.gmask = s.G >= 64 ? ~0ull : ((1ull << s.G) - 1ull);
     s.tree = a.spec_ntree > 1 ? a.spec_first : 0;
     s.nd = a.spec_tab[s.tree * s.G + s.m];
-    s.maxacc = a.spec_ntree > 1 ? spec_wave_levels(s.nd.levels) : a.spec_maxacc;
+    s.maxacc = spec_wave_max(s.nd.levels & 0xff);
+    s.maxdepth = spec_wave_max((s.nd.levels >> 8) & 0xff);
     s.trips = s.steps = s.accepts = 0;
     return s;
 }
@@ -114,7 +117,8 @@ __device__ __forceinline__ void spec_adapt(const BatchArgs &a, SpecLane &s, int 
         s.tree = pick;
         s.nd = a.spec_tab[pick * s.G + s.m];
     }
-    s.maxacc = spec_wave_levels(s.nd.levels);
+    s.maxacc = spec_wave_max(s.nd.levels & 0xff);
+    s.maxdepth = spec_wave_max((s.nd.levels >> 8) & 0xff);
 }
 // the chain's path through the tree from the lanes' accept tests: is this lane on it, and which is the deepest lane that is
 // (the tree's lanes are numbered ancestors-first, so that is the highest one)
@@ -257,36 +261,48 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains_spec(const B
                     }
                 }
             });
-            // ---- the configuration the lane's step starts from (cp) and its proposal (n), accept level by accept level ----
-            Chain<Cfg> cp = c, n = c;
-            double prop = 1.0;
-            for (int lvl = 0; lvl <= sp.maxacc; ++lvl) {
-                if (lvl > 0) { // (every lane takes part in the exchange; the lanes of this level keep what they read)
-                    const Chain<Cfg> f = lane_read<Cfg>(n, sp.gbase + (sp.nd.anc >= 0 ? sp.nd.anc : sp.m));
-                    chain_select<Cfg>(cp, sp.nd.nacc == lvl, f);
-                }
-                if (sp.nd.nacc == lvl) {
-                    n = cp;
+            // ---- the configuration the lane's step starts from (cp) and its proposal (n).  What a step draws does not depend on where it
+            // starts, so cp is the trip's base with the draws of the ancestors the way leaves by an accept edge applied in step order: depth
+            // by depth every lane reads the draw of ONE lane of that depth (they all hold the same) and applies it if its way accepted
+            // there.  The exchanges do not depend on each other: one burst of ds_bpermute per trip, whatever the tree's accept levels ----
+            Chain<Cfg> cp = c;
+            for (int dd = 0; dd < sp.maxdepth; ++dd) {
+                const u64 at = (__ballot(sp.nd.depth == dd) >> sp.gbase) & sp.gmask; // lanes of the group that propose step ne0 + dd
+                const int src = sp.gbase + (at ? __builtin_ctzll(at) : sp.m);
+                const int pvi = lane_read(active ? vi : -1, src), pslot = lane_read(slot, src);
+                const bool take = ((sp.nd.accdepth >> dd) & 1ull) != 0ull;
+                static_for<0, MAXNL>([&](auto Lf) {
+                    constexpr int l = decltype(Lf)::value;
+                    const double px = lane_read(dxn[l], src), pp = lane_read(dpn[l], src);
+                    const int pb = lane_read(dbn[l], src);
                     static_for<0, Cfg::NPOOL>([&](auto V) {
                         constexpr int v = decltype(V)::value;
-                        constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
-                        constexpr bool skip = (md <= 0) || (nl == 1 && Cfg::leaf_kind(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1 &&
-                                                            Cfg::leaf_nbin(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1);
-                        if constexpr (!skip) {
-                            if (vi == v) {
-                                static_for<0, nl>([&](auto Lf) {
-                                    constexpr int l = decltype(Lf)::value;
-                                    double xo, po;
-                                    int bo;
-                                    get_slot<Cfg, v, l>(cp, slot, xo, po, bo);
-                                    put_slot<Cfg, v, l>(n, slot, dxn[l], dpn[l], dbn[l]);
-                                    prop *= po / dpn[l]; // 1/prob_ratio  sampler.jl:385, :70
-                                });
-                            }
+                        if constexpr (Cfg::pool_maxdof(v) > 0 && l < Cfg::pool_nleaf(v)) {
+                            if (take && pvi == v) put_slot<Cfg, v, l>(cp, pslot, px, pp, pb);
                         }
                     });
-                }
+                });
             }
+            Chain<Cfg> n = cp;
+            double prop = 1.0;
+            static_for<0, Cfg::NPOOL>([&](auto V) {
+                constexpr int v = decltype(V)::value;
+                constexpr int md = Cfg::pool_maxdof(v), nl = Cfg::pool_nleaf(v), k00 = Cfg::pool_first_draw(v);
+                constexpr bool skip = (md <= 0) || (nl == 1 && Cfg::leaf_kind(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1 &&
+                                                    Cfg::leaf_nbin(Cfg::draw_leaf(md > 0 ? k00 : 0)) == 1);
+                if constexpr (!skip) {
+                    if (vi == v) {
+                        static_for<0, nl>([&](auto Lf) {
+                            constexpr int l = decltype(Lf)::value;
+                            double xo, po;
+                            int bo;
+                            get_slot<Cfg, v, l>(cp, slot, xo, po, bo);
+                            put_slot<Cfg, v, l>(n, slot, dxn[l], dpn[l], dbn[l]);
+                            prop *= po / dpn[l]; // 1/prob_ratio  sampler.jl:385, :70
+                        });
+                    }
+                }
+            });
             const bool go = valid && active && prop > 4.9406564584124654e-324; // :63-65
             double wn[Cfg::NW], padn[NI + 1], newp = 0.0;
             static_for<0, Cfg::NW>([&](auto I) { wn[decltype(I)::value] = 0.0; });

@@ -268,6 +268,15 @@ def resample_chains(curr_old, rw_now, rw_used, n_new):
     return np.array(list(src), dtype=np.int64)
 
 
+def resample_weighted(w, n_new):
+    """which stored chain every chain of the next :vegasmc launch continues, given new target / old target per stored chain
+    (mcio_resample_weighted; mirror of k_resample_chains' w_chain path)"""
+    a = np.ascontiguousarray(w, dtype=np.float64)
+    src = (C.c_long * int(n_new))()
+    lib().mcio_resample_weighted(_dp(a), len(a), int(n_new), src)
+    return np.array(list(src), dtype=np.int64)
+
+
 def builtin(name):
     p = lib().mcio_builtin(name.encode())
     if not p:

@@ -339,3 +339,41 @@ def test_resampling_of_carried_mcmc_chains(oracle):
     one = np.zeros(16, dtype=np.int64)
     picks = {tuple(oracle.resample_chains(one, np.array([r, 1.0 - r]), np.array([0.5, 0.5]), 5)) for r in (0.3, 0.3 * (1 + 2e-16), 0.3 * (1 - 2e-16), 0.7)}
     assert len(picks) == 1
+
+
+def test_weighted_resampling_of_carried_vegasmc_chains(oracle):
+    """mcio_resample_weighted (mirror of k_resample_chains' per-chain-weight path): the stored :vegasmc chains of a block are a sample of the
+    OLD target density (it contains the map and the reweight factors); the next launch continues stored chain j with probability
+    ~ w_j = new target / old target -- systematic resampling along the chain order with one fixed offset, the running sums formed in ONE
+    fixed association (256 stretches: sum of the stretches before + running sum along the own stretch)."""
+    n = 1000
+    assert np.array_equal(oracle.resample_weighted(np.ones(n), n), np.arange(n))                       # nothing moved: every chain goes on
+    assert np.array_equal(np.bincount(oracle.resample_weighted(np.ones(n), 3 * n), minlength=n), np.full(n, 3))
+    w = np.zeros(n)
+    w[[17, 400]] = [1.0, 3.0]
+    src = oracle.resample_weighted(w, 400)
+    assert set(src) == {17, 400} and np.all(np.diff(src) >= 0) and np.sum(src == 17) == 100           # exactly in proportion
+    rng = np.random.default_rng(3)
+    w = rng.exponential(size=5000) * (rng.random(5000) < 0.3)                                          # many chains the new target excludes
+    for n_new in (50, 5000, 20000):
+        src = oracle.resample_weighted(w, n_new)
+        assert np.all(np.diff(src) >= 0) and np.all(w[src] > 0.0)                                      # chain order kept, nothing with zero weight continued
+        counts = np.bincount(src, minlength=len(w))
+        expect = w / w.sum() * n_new
+        assert np.all(np.abs(counts - expect) < 1.0 + 1e-9)                                            # systematic: within one of the expected count
+    # the association of the running sums, restated: stretches of ceil(n / 256), sums of whole stretches added in order, then the running sum
+    per = (len(w) + 255) // 256
+    W = np.empty(len(w))
+    below = 0.0
+    for t in range(256):
+        run = 0.0
+        for j in range(t * per, min((t + 1) * per, len(w))):
+            run += w[j]
+            W[j] = below + run
+        part = 0.0
+        for j in range(t * per, min((t + 1) * per, len(w))):
+            part += w[j]
+        below += part
+    step = W[-1] / 777
+    ref = np.array([np.searchsorted(W, (c + 0.6180339887498949) * step, side="right") for c in range(777)])
+    assert np.array_equal(oracle.resample_weighted(w, 777), np.minimum(ref, len(w) - 1))

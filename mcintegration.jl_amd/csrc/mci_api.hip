@@ -1482,7 +1482,12 @@ static void spec_build(int lanes, double accept, int limit, std::vector<mci::Spe
     }
     int deepest = 0;
     for (auto &nd : tab) deepest = nd.depth > deepest ? nd.depth : deepest;
-    for (auto &nd : tab) nd.levels = *maxacc | (deepest << 8);
+    unsigned long long any = 0ull;
+    for (auto &nd : tab) any |= nd.accdepth;
+    for (auto &nd : tab) {
+        nd.levels = *maxacc | (deepest << 8);
+        nd.anydepth = any;
+    }
 }
 
 // The trees of the next launch on the device (rebuilt when lanes / acceptance / limit change).  accept > 0: that one tree.  accept <= 0

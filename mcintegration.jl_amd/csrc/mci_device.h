@@ -132,6 +132,7 @@ struct SpecNode {
     u64 needrej;
     u64 accdepth; // the DEPTHS of the ancestors the way leaves by an accept edge (bit = depth): under :vegasmc a step's draw does not depend
                   // on the configuration it starts from, so a lane builds its starting configuration from the draws of those depths
+    u64 anydepth; // ... of any node of this tree (the same in all its nodes): the depths whose draw somebody needs
 };
 
 struct BatchArgs {

@@ -60,14 +60,20 @@ template <class Cfg> __device__ __forceinline__ void chain_select(Chain<Cfg> &ds
 struct SpecLane {
     int G, m, gbase;
     int maxacc;  // accept levels the wave goes through per trip: the most of its groups' trees
-    int maxdepth; // ... and the deepest node of those trees
+    u64 anydepth; // ... and the depths whose draw some lane of the wave needs (:vegasmc)
     u64 gmask;
     SpecNode nd;
     // the tree the group is on, and what its chain has done since the tree was last looked at
     int tree, trips, steps, accepts;
 };
-// the largest of a small number (< 64) over the lanes of the wave (wave-uniform): the most accept levels / the deepest node of the trees
-// its groups are on
+// the union of a 64-bit mask over the lanes of the wave (wave-uniform; once per change of tree)
+__device__ __forceinline__ u64 spec_wave_or(u64 mine) {
+    u64 m = 0ull;
+    for (int bit = 0; bit < 64; ++bit)
+        if (__ballot(((mine >> bit) & 1ull) != 0ull) != 0ull) m |= 1ull << bit;
+    return m;
+}
+// the largest of a small number (< 64) over the lanes of the wave (wave-uniform): the most accept levels of the trees its groups are on
 __device__ __forceinline__ int spec_wave_max(int mine) {
     int m = 0;
 #pragma unroll
@@ -87,7 +93,7 @@ __device__ __forceinline__ SpecLane spec_lane(const BatchArgs &a) {
     s.tree = a.spec_ntree > 1 ? a.spec_first : 0;
     s.nd = a.spec_tab[s.tree * s.G + s.m];
     s.maxacc = spec_wave_max(s.nd.levels & 0xff);
-    s.maxdepth = spec_wave_max((s.nd.levels >> 8) & 0xff);
+    s.anydepth = spec_wave_or(s.nd.anydepth);
     s.trips = s.steps = s.accepts = 0;
     return s;
 }
@@ -118,7 +124,7 @@ __device__ __forceinline__ void spec_adapt(const BatchArgs &a, SpecLane &s, int 
         s.nd = a.spec_tab[pick * s.G + s.m];
     }
     s.maxacc = spec_wave_max(s.nd.levels & 0xff);
-    s.maxdepth = spec_wave_max((s.nd.levels >> 8) & 0xff);
+    s.anydepth = spec_wave_or(s.nd.anydepth);
 }
 // the chain's path through the tree from the lanes' accept tests: is this lane on it, and which is the deepest lane that is
 // (the tree's lanes are numbered ancestors-first, so that is the highest one)
@@ -262,26 +268,54 @@ template <class Cfg> __device__ __forceinline__ void vegasmc_chains_spec(const B
                 }
             });
             // ---- the configuration the lane's step starts from (cp) and its proposal (n).  What a step draws does not depend on where it
-            // starts, so cp is the trip's base with the draws of the ancestors the way leaves by an accept edge applied in step order: depth
-            // by depth every lane reads the draw of ONE lane of that depth (they all hold the same) and applies it if its way accepted
-            // there.  The exchanges do not depend on each other: one burst of ds_bpermute per trip, whatever the tree's accept levels ----
+            // starts, so cp is the trip's base with the draws of the ancestors the way leaves by an accept edge applied in step order.
+            // Two ways to get them there (the same cp either way; wave-uniform choice by the shape of the trees the wave's groups are on):
+            //   depth by depth -- every lane reads the draw of ONE lane of that depth (they all hold the same) and applies it if its way
+            //     accepted there: the exchanges do not depend on each other, one burst of ds_bpermute however many accept levels the tree
+            //     has (trees built for an acceptance >= 1/2: as many depths with accept edges as levels);
+            //   level by level -- lanes behind an accept edge read the whole configuration their ancestor proposed, one level after the
+            //     ancestor built its own (trees with one or two accept levels hanging off a long reject chain: many depths, few levels)
             Chain<Cfg> cp = c;
-            for (int dd = 0; dd < sp.maxdepth; ++dd) {
-                const u64 at = (__ballot(sp.nd.depth == dd) >> sp.gbase) & sp.gmask; // lanes of the group that propose step ne0 + dd
-                const int src = sp.gbase + (at ? __builtin_ctzll(at) : sp.m);
-                const int pvi = lane_read(active ? vi : -1, src), pslot = lane_read(slot, src);
-                const bool take = ((sp.nd.accdepth >> dd) & 1ull) != 0ull;
-                static_for<0, MAXNL>([&](auto Lf) {
-                    constexpr int l = decltype(Lf)::value;
-                    const double px = lane_read(dxn[l], src), pp = lane_read(dpn[l], src);
-                    const int pb = lane_read(dbn[l], src);
-                    static_for<0, Cfg::NPOOL>([&](auto V) {
-                        constexpr int v = decltype(V)::value;
-                        if constexpr (Cfg::pool_maxdof(v) > 0 && l < Cfg::pool_nleaf(v)) {
-                            if (take && pvi == v) put_slot<Cfg, v, l>(cp, pslot, px, pp, pb);
-                        }
+            if (2 * __popcll(sp.anydepth) <= 3 * sp.maxacc) {
+                for (u64 todo = sp.anydepth; todo != 0ull; todo &= todo - 1ull) {
+                    const int dd = __builtin_ctzll(todo);
+                    const u64 at = (__ballot(sp.nd.depth == dd) >> sp.gbase) & sp.gmask; // lanes of the group that propose step ne0 + dd
+                    const int src = sp.gbase + (at ? __builtin_ctzll(at) : sp.m);
+                    const int pvi = lane_read(active ? vi : -1, src), pslot = lane_read(slot, src);
+                    const bool take = ((sp.nd.accdepth >> dd) & 1ull) != 0ull;
+                    static_for<0, MAXNL>([&](auto Lf) {
+                        constexpr int l = decltype(Lf)::value;
+                        const double px = lane_read(dxn[l], src), pp = lane_read(dpn[l], src);
+                        const int pb = lane_read(dbn[l], src);
+                        static_for<0, Cfg::NPOOL>([&](auto V) {
+                            constexpr int v = decltype(V)::value;
+                            if constexpr (Cfg::pool_maxdof(v) > 0 && l < Cfg::pool_nleaf(v)) {
+                                if (take && pvi == v) put_slot<Cfg, v, l>(cp, pslot, px, pp, pb);
+                            }
+                        });
                     });
-                });
+                }
+            } else {
+                Chain<Cfg> built = c; // a lane's own proposal once its level has been through (what the lanes behind its accept edge read)
+                for (int lvl = 0; lvl <= sp.maxacc; ++lvl) {
+                    if (lvl > 0) { // (every lane takes part in the exchange; the lanes of this level keep what they read)
+                        const Chain<Cfg> f = lane_read<Cfg>(built, sp.gbase + (sp.nd.anc >= 0 ? sp.nd.anc : sp.m));
+                        chain_select<Cfg>(cp, sp.nd.nacc == lvl, f);
+                    }
+                    if (lvl < sp.maxacc && sp.nd.nacc == lvl) {
+                        built = cp;
+                        static_for<0, Cfg::NPOOL>([&](auto V) {
+                            constexpr int v = decltype(V)::value;
+                            if constexpr (Cfg::pool_maxdof(v) > 0) {
+                                if (active && vi == v)
+                                    static_for<0, Cfg::pool_nleaf(v)>([&](auto Lf) {
+                                        constexpr int l = decltype(Lf)::value;
+                                        put_slot<Cfg, v, l>(built, slot, dxn[l], dpn[l], dbn[l]);
+                                    });
+                            }
+                        });
+                    }
+                }
             }
             Chain<Cfg> n = cp;
             double prop = 1.0;

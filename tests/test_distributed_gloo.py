@@ -147,3 +147,46 @@ def test_two_ranks_on_one_gpu_equal_one_rank(solver):
         np.testing.assert_allclose(grid, ref.config._engine.grid(0), rtol=0, atol=1e-9)
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_array_equal(outs[0][3], outs[1][3])
+
+
+def _gpu_worker_auto_mcmc(rank, world, port, q):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import math
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mcintegration_jl_amd as mci
+    from mcintegration_jl_amd.comm import TorchDistComm
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]], seed=5)
+    res = mci.integrate(mci.catalog.nested_gauss(), config=cfg, solver="mcmc", neval=4e6, niter=6, block=16, comm=TorchDistComm(), device=0)
+    eng = cfg._engine
+    q.put((rank, res.iter_mean, np.asarray(res._flat_mean), np.asarray(res._flat_std), eng.last_chain_launch()[0], int(res.warmup)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_size_their_mcmc_chains_from_the_same_summed_holding_times():
+    """Automatic :mcmc chain lengths follow the holding times the launch before measured.  With several ranks every rank must derive the
+    SAME length -- and take the same decision about running a warm-up iteration again -- so the 64 holding-time counts are summed over
+    the ranks: they ride behind the tables in the ONE packed all-reduce of the iteration (mci_reduce_size doubles; an external reducer
+    like TorchDistComm then calls mci_external_reduce_done).  Two processes on one GPU, gloo: the same chain count and the same number
+    of warm-up repeats on both ranks, bit-identical iteration means, and the exact products of erf within 5 sigma."""
+    import math
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker_auto_mcmc, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, im0, m0, s0, nchain0, wu0), (_, im1, m1, s1, nchain1, wu1) = outs
+    assert nchain0 == nchain1 and nchain0 > 1 and wu0 == wu1, (nchain0, nchain1, wu0, wu1)
+    np.testing.assert_array_equal(im0, im1)
+    exact = np.array([math.erf(5.0) ** d for d in (3, 6, 9, 12)])
+    assert np.all(np.abs(m0 - exact) < 5 * s0), (m0, s0)

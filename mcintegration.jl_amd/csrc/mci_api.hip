@@ -276,6 +276,11 @@ struct mci_problem {
     int chain_solver = -1, chain_iteration = -1;
     int64_t chain_lo = 0, chain_hi = 0, chain_nchain = 0;
     int chain_carry = -1;        // mci_set_chain_carry: -1 automatic / 1 (the rule above), 0 never
+    // :vegasmc chains are carried only out of a launch that ran on a map train! had refined at least once: chains of the automatic
+    // length have not reached their target on the UNTRAINED map of a heavy-tailed integrand (log(x)/sqrt(x): the first iteration of a cold
+    // call is 14 sigma per run off), and a population that is no sample of the old target cannot be resampled into one of the new --
+    // carried out of iteration 1 the second iteration was 4 sigma per run-iteration off, started afresh 1.2 (profiles/r05_bias.txt A4)
+    int64_t ntrain = 0, chain_ntrain = 0; // train! steps of this problem so far | ... when the stored chains were launched
     // :mcmc: the reweight factors the stored chains ran under, and which stored chain every chain of the launch in flight continues
     // (k_resample_chains: the stored chains resampled to the target doReweight! has moved since)
     double *d_reweight_used = nullptr, *d_carry_W = nullptr;
@@ -1782,6 +1787,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     const bool carry_on = p->chain_carry != 0;
     const bool may_carry = solver != MCI_VEGAS && carry_on && p->chain_valid && p->chain_solver == solver &&
                            p->chain_lo == block_lo && p->chain_hi == block_hi && p->chain_nchain > 1 &&
+                           (solver != MCI_VEGASMC || p->chain_ntrain >= 1) &&
                            ((p->chain_iteration & (kRepeatStride - 1)) + 1 == (iteration & (kRepeatStride - 1)) ||                        // the next iteration
                             ((p->chain_iteration & (kRepeatStride - 1)) == (iteration & (kRepeatStride - 1)) && iteration > p->chain_iteration)); // ... or the same one again (mci_integrate, warm-up)
     if (solver == MCI_VEGASMC) {
@@ -2052,6 +2058,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             a.store_cap = p->chain_cap[wb];
             p->chain_cur = wb;
             p->chain_valid = true;
+            p->chain_ntrain = p->ntrain;
             p->chain_solver = solver;
             p->chain_iteration = iteration;
             p->chain_lo = block_lo;
@@ -2532,6 +2539,7 @@ static int launch_train(mci_problem *p, int do_train, int do_reweight, double ga
     a.do_reweight = do_reweight;
     a.gamma = gamma;
     a.do_train = do_train;
+    if (do_train) p->ntrain += 1;
     a.serial_walk = p->train_serial >= 0 ? p->train_serial : (p->last_samples == 0 || p->last_samples >= mci_problem::kSerialWalkSamples) ? 1 : 0;
     if (p->debug_wrong_decision && a.serial_walk == 1) a.serial_walk = 3;
     a.status = p->d_status;

@@ -589,6 +589,7 @@ void mcio_add_config(mcio_config *c, const mcio_config *ic) {
 
 /* Dist.train!(v) for every variable  ref: main.jl:194-195, variable.jl:479-483 */
 void mcio_train(mcio_config *c) {
+    if (c->carry) c->carry->ntrain += 1;
     for (int l = 0; l < c->nleaf; ++l) {
         mcio_leaf *L = &c->leaf[l];
         if (!L->adapt) continue; /* variable.jl:208, :370 */
@@ -1680,7 +1681,8 @@ static int run_blocks(mcio_config *c, int solver, mcio_integrand_fn f, const dou
     mcio_carry *cy = c->carry;
     const int carry_on = cy->mode != 0; /* automatic = both chain solvers */
     const int carried = solver != MCIO_VEGAS && carry_on && cy->valid && cy->solver == solver && cy->lo == block_lo && cy->hi == block_hi &&
-                        cy->iteration + 1 == (long)iteration && cy->nchain > 1 && nchain > 1;
+                        cy->iteration + 1 == (long)iteration && cy->nchain > 1 && nchain > 1 &&
+                        (solver != MCIO_VEGASMC || cy->ntrain_stored >= 1); /* (:vegasmc: not out of a launch on the untrained map) */
     const int keep = solver != MCIO_VEGAS && carry_on && nchain > 1;
     if (keep) {
         const int wr = cy->valid ? 1 - cy->cur : cy->cur;
@@ -1761,6 +1763,7 @@ static int run_blocks(mcio_config *c, int solver, mcio_integrand_fn f, const dou
     if (keep) {
         cy->cur = cy->wr;
         cy->valid = 1;
+        cy->ntrain_stored = cy->ntrain;
         cy->solver = solver;
         cy->iteration = (long)iteration;
         cy->lo = block_lo;

@@ -137,6 +137,11 @@ typedef struct mcio_carry {
     /* :vegasmc (mirror of BatchArgs::store_P / vegasmc_carry_weights): the chain's target density config.probability at every stored
      * configuration, P[buf][local block * nchain + ch]; the next launch resamples the stored chains with probability ~ new target / old */
     double *P[2];
+    /* :vegasmc chains are carried only out of a launch that ran on a map train! had refined at least once: chains of the automatic
+     * length have not reached their target on the untrained map of a heavy-tailed integrand (log(x)/sqrt(x): the first iteration of a
+     * cold call 14 sigma per run off), and a population that is no sample of the old target cannot be resampled into one of the new
+     * (mirror of mci_problem::ntrain / chain_ntrain) */
+    long ntrain, ntrain_stored;
 } mcio_carry;
 
 typedef struct {

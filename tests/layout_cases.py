@@ -195,7 +195,7 @@ def check_carried_iterations(oracle, case_id, seed=20260930):
         for it, nch in enumerate(counts):
             got = eng.iteration(solver, npb, 0, nblk, iteration=it, seed=seed, measurefreq=mfreq, nchain=nch, **kw)
             ref = ocfg.iteration(osolver, fn, None, npb, 0, nblk, it, seed, measurefreq=mfreq, nchain=nch)
-            assert eng.last_chain_launch() == (nch, it > 0), (what, solver, it, eng.last_chain_launch())
+            assert eng.last_chain_launch() == (nch, it > (1 if solver == "vegasmc" else 0)), (what, solver, it, eng.last_chain_launch())   # (:vegasmc: not out of a launch on the untrained map)
             # (every train! in between amplifies the rounding-level difference of the two maps by an order of magnitude or two)
             np.testing.assert_allclose(got[:nstat], ref[:nstat], rtol=1e-8 * 10 ** it, atol=1e-300, err_msg="%s %s iteration %d" % (what, solver, it))
             np.testing.assert_allclose(got[nstat:], ref[nstat:], rtol=1e-7 * 10 ** it, err_msg="%s %s iteration %d (histograms)" % (what, solver, it))

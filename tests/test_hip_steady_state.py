@@ -265,8 +265,9 @@ def test_several_chains_per_lane_match_oracle(oracle, name, solver):
 def test_carried_chains_match_oracle(oracle, name, solver):
     """Carried chains (mci_set_chain_carry, this engine's many-chain decomposition only): the next iteration of the same solver over
     the same blocks continues the previous launch's chains with the reference's own burn-in only -- :vegasmc chain (block, ch) starts
-    from the configuration chain (block, ch mod previous nchain) ended with, bins and probabilities looked up again on the map train!
-    has just refined; :mcmc chain (block, ch) from the stored chain (configuration AND integrand index) that the block's systematic
+    from the stored configuration that the block's systematic resampling with probability ~ new target density / old one assigns to
+    it (mci_vegasmc_carry_weights + k_resample_chains | mcio_resample_weighted), bins and probabilities looked up again on the map
+    train! has just refined, and only out of a launch that ran on a map refined at least once; :mcmc chain (block, ch) from the stored chain (configuration AND integrand index) that the block's systematic
     resampling with probability ~ reweight_new[curr] / reweight_old[curr] assigns to it (k_resample_chains | mcio_resample_chains).
     Four consecutive iterations with doReweight! and train! in between and a chain count that changes (16, 16, 40, 8 per block)
     against the oracle's mirror; a repeated iteration number starts afresh again."""
@@ -281,7 +282,9 @@ def test_carried_chains_match_oracle(oracle, name, solver):
     for it, nch in enumerate([16, 16, 40, 8]):
         got = eng.iteration(solver, npb, 0, block, iteration=it, seed=SEED, nchain=nch, **kw)
         ref = ocfg.iteration(osolver, c["oname"], c["ud"], npb, 0, block, it, SEED, nchain=nch, nthreads=2)
-        assert eng.last_chain_launch() == (nch, it > 0), (it, eng.last_chain_launch())
+        # (:vegasmc chains are carried only out of a launch that ran on a map train! had refined at least once: the second iteration
+        # of a fresh problem starts afresh)
+        assert eng.last_chain_launch() == (nch, it > (1 if solver == "vegasmc" else 0)), (it, eng.last_chain_launch())
         compare(got, ref, n, cfg.N, rtol_stat=1e-8, rtol_hist=1e-7)
         if solver == "mcmc":
             np.testing.assert_array_equal(eng.hold_histogram(), ocfg.hold_hist)

@@ -281,6 +281,7 @@ struct mci_problem {
     // call is 14 sigma per run off), and a population that is no sample of the old target cannot be resampled into one of the new --
     // carried out of iteration 1 the second iteration was 4 sigma per run-iteration off, started afresh 1.2 (profiles/r05_bias.txt A4)
     int64_t ntrain = 0, chain_ntrain = 0; // train! steps of this problem so far | ... when the stored chains were launched
+    bool launch_counted = false;          // mci_integrate: the iteration being launched enters the final estimate (it >= ignore)
     // :mcmc: the reweight factors the stored chains ran under, and which stored chain every chain of the launch in flight continues
     // (k_resample_chains: the stored chains resampled to the target doReweight! has moved since)
     double *d_reweight_used = nullptr, *d_carry_W = nullptr;
@@ -338,7 +339,7 @@ int64_t mci_problem::kMcmcCarryHalfFloors = 2;
 // are cached) and MCI_JIT_FLAGS (extra hiprtc options), mci_jit.h.
 namespace {
 struct Override { bool on = false; int64_t v = 0; };
-struct Overrides { Override table_mode, hist_tile_bins, no_split_all, l1_phase, train_walk, hist_copies; } g_over;
+struct Overrides { Override table_mode, hist_tile_bins, no_split_all, l1_phase, train_walk, hist_copies, fresh_floors, fresh_burnin_pct; } g_over;
 Override *override_slot(const char *key) {
     if (!key) return nullptr;
     if (!strcmp(key, "table_mode")) return &g_over.table_mode;
@@ -347,6 +348,8 @@ Override *override_slot(const char *key) {
     if (!strcmp(key, "l1_phase")) return &g_over.l1_phase;
     if (!strcmp(key, "train_walk")) return &g_over.train_walk;
     if (!strcmp(key, "hist_copies")) return &g_over.hist_copies;
+    if (!strcmp(key, "fresh_floors")) return &g_over.fresh_floors;
+    if (!strcmp(key, "fresh_burnin_pct")) return &g_over.fresh_burnin_pct;
     return nullptr;
 }
 } // namespace
@@ -1784,10 +1787,13 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     // (:mcmc: a chain's state includes the integrand index, whose weight doReweight! moves between iterations -- the stored chains are
     // resampled to the moved target first, k_resample_chains below.  Chains carried as they were started over-represented exactly where
     // the new factors say "fewer": 2 sigma per run low on the 12-D member of BASELINE configs[4], profiles/r03_chain_carry.txt.)
+    // (:vegasmc: not out of a launch on the untrained map onto a refined one -- chains of the automatic length have not reached their
+    // target there, and no resampling turns them into a sample of the new one, profiles/r05_bias.txt A4; while the map stays as it is
+    // -- adapt = false -- they go on towards the same target)
     const bool carry_on = p->chain_carry != 0;
     const bool may_carry = solver != MCI_VEGAS && carry_on && p->chain_valid && p->chain_solver == solver &&
                            p->chain_lo == block_lo && p->chain_hi == block_hi && p->chain_nchain > 1 &&
-                           (solver != MCI_VEGASMC || p->chain_ntrain >= 1) &&
+                           (solver != MCI_VEGASMC || p->chain_ntrain >= 1 || p->chain_ntrain == p->ntrain) &&
                            ((p->chain_iteration & (kRepeatStride - 1)) + 1 == (iteration & (kRepeatStride - 1)) ||                        // the next iteration
                             ((p->chain_iteration & (kRepeatStride - 1)) == (iteration & (kRepeatStride - 1)) && iteration > p->chain_iteration)); // ... or the same one again (mci_integrate, warm-up)
     if (solver == MCI_VEGASMC) {
@@ -1799,7 +1805,12 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             // 763-step chains are within 1.4 sigma (tools/chain_bias_c1.py).
             // Carried chains are stationary from their first step: two floors per iteration let them settle on the refined map.
             const int64_t fl = 64 * (int64_t)nslots > 128 ? 64 * (int64_t)nslots : 128;
-            nchain = nevalperblock / ((may_carry ? 2 : 8) * fl);
+            // A launch on a map train! has never refined whose estimate COUNTS (mci_integrate with ignore = 0: adapt = false, main.jl:82)
+            // runs chains 8 x as long: on the untrained map chains of 8 floors have not reached their target -- 3.4 sigma per run low on
+            // the 12-D member of BASELINE configs[4], 5 on 1/(1 - cos x cos y cos z), with every iteration counted; with 64 floors
+            // within errors (profiles/r05_bias.txt A5, A6).  The default call ignores that iteration and keeps the short ones.
+            const int64_t fresh = g_over.fresh_floors.on ? g_over.fresh_floors.v : (p->launch_counted && p->ntrain == 0) ? 64 : 8;
+            nchain = nevalperblock / ((may_carry ? 2 : fresh) * fl);
             const int64_t cap = mci_problem::kChainFill / nblocks > 64 ? mci_problem::kChainFill / nblocks : 64;
             if (nchain > cap) nchain = cap;
             if (nchain < 1) nchain = 1;
@@ -1807,6 +1818,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
         // (carried chains keep the reference's own `ne >= neval/100` only, vegas_mc/montecarlo.jl:213)
         burnin = mci_chain_burnin(nevalperblock / nchain, (may_carry && nchain > 1) ? 1 : nchain, nslots);
+        if (g_over.fresh_burnin_pct.on && !may_carry && nchain > 1 && auto_chains) { // (experiment: tools/run_r05_floors.sh)
+            const double b = (double)(nevalperblock / nchain) * (double)g_over.fresh_burnin_pct.v / 100.0;
+            if (b > burnin) burnin = b;
+        }
         units = nchain;
     } else if (solver == MCI_MCMC) {
         int nslots = 0;
@@ -2964,6 +2979,7 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
         for (int it = 0; it < a->niter && !persist; ++it) { // main.jl:142
             for (int attempt = 0;; ++attempt) {
                 const int32_t iter = a->first_iteration + it + kRepeatStride * attempt;
+                p->launch_counted = it >= ignore;
                 if ((rc = mci_iteration_run(p, a->solver, nevalperblock, lo, hi, iter, a->seed, a->measurefreq, a->nchain, a->thermal_ratio))) return rc;
                 if ((rc = mci_iteration_reduce(p))) return rc;                                   // main.jl:177-188
                 if ((rc = mci_iteration_finish(p, a->solver, block, a->adapt, a->gamma, nullptr, nullptr))) return rc; // main.jl:183-199
@@ -2984,6 +3000,7 @@ int mci_integrate(mci_problem *p, const mci_integrate_args *a, mci_result *res) 
                 p->last_discarded_launches += 1;
             }
         }
+        p->launch_counted = false;
         // the statistics of all iterations and the status word come back behind the last kernel in ONE synchronisation, into pinned memory (a
         // pageable destination goes through a staging copy: ~15 us of a 0.2 ms default-size call)
         HIPCHK(hipMemcpyAsync(h, p->d_iterlog + (size_t)row0 * p->nstat, nlog * sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));

@@ -26,6 +26,8 @@ int mci_debug_persist_spin_ticks(mci_problem *prob, unsigned long long ticks);
  *   l1_phase        0 | 1    dimension-major gather phase of the many-grid sample pass
  *   hist_copies     n        interleaved histogram copies of the :vegas sample kernel (1 = none)
  *   train_walk      0 | 1 | 2  = mci_set_train_walk on every new problem
+ *   fresh_floors    n        (consulted per launch) length of automatic :vegasmc chains that start afresh, in burn-in floors (8)
+ *   fresh_burnin_pct n       (per launch) ... and the least part of such a chain that is not measured, in per cent (profiles/r05_bias.txt A5)
  * (The library reads two environment variables and no others: MCI_KERNEL_CACHE -- the directory code objects are cached in -- and
  * MCI_JIT_FLAGS -- extra hiprtc options; INTEGRATION.md.) */
 int mci_debug_override(const char *key, int64_t value, int32_t on);

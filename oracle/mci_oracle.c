@@ -1682,7 +1682,7 @@ static int run_blocks(mcio_config *c, int solver, mcio_integrand_fn f, const dou
     const int carry_on = cy->mode != 0; /* automatic = both chain solvers */
     const int carried = solver != MCIO_VEGAS && carry_on && cy->valid && cy->solver == solver && cy->lo == block_lo && cy->hi == block_hi &&
                         cy->iteration + 1 == (long)iteration && cy->nchain > 1 && nchain > 1 &&
-                        (solver != MCIO_VEGASMC || cy->ntrain_stored >= 1); /* (:vegasmc: not out of a launch on the untrained map) */
+                        (solver != MCIO_VEGASMC || cy->ntrain_stored >= 1 || cy->ntrain_stored == cy->ntrain); /* (:vegasmc: not out of a launch on the untrained map onto a refined one) */
     const int keep = solver != MCIO_VEGAS && carry_on && nchain > 1;
     if (keep) {
         const int wr = cy->valid ? 1 - cy->cur : cy->cur;

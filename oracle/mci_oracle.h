@@ -140,6 +140,7 @@ typedef struct mcio_carry {
     /* :vegasmc chains are carried only out of a launch that ran on a map train! had refined at least once: chains of the automatic
      * length have not reached their target on the untrained map of a heavy-tailed integrand (log(x)/sqrt(x): the first iteration of a
      * cold call 14 sigma per run off), and a population that is no sample of the old target cannot be resampled into one of the new
+     * -- or on a map that has not been refined since (adapt = false: the target is the one the chains are walking towards)
      * (mirror of mci_problem::ntrain / chain_ntrain) */
     long ntrain, ntrain_stored;
 } mcio_carry;

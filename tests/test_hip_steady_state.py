@@ -307,6 +307,24 @@ def test_carried_chains_match_oracle(oracle, name, solver):
     np.testing.assert_allclose(got, again, rtol=1e-9, atol=1e-300)
 
 
+@pytest.mark.parametrize("name", ["sphere2_padding", "bubble"])
+def test_vegasmc_chains_go_on_while_the_map_stays_as_it_is(oracle, name):
+    """adapt = false (main.jl:192: no train!, doReweight! only): the map a launch's chains ran on is the map of the next launch, so
+    :vegasmc chains are carried from the first launch on -- also on a map train! has never refined, where they are NOT carried onto a
+    refined one (test_carried_chains_match_oracle).  Three iterations, 16 | 16 | 40 chains per block, against the oracle's mirror."""
+    c, cfg, eng, ocfg = _make(name, oracle)
+    block, npb = 4, 4800
+    n = eng.nobs
+    for it, nch in enumerate([16, 16, 40]):
+        got = eng.iteration("vegasmc", npb, 0, block, iteration=it, seed=SEED, nchain=nch)
+        ref = ocfg.iteration(oracle.VEGASMC, c["oname"], c["ud"], npb, 0, block, it, SEED, nchain=nch, nthreads=2)
+        assert eng.last_chain_launch() == (nch, it > 0), (it, eng.last_chain_launch())
+        compare(got, ref, n, cfg.N, rtol_stat=1e-8, rtol_hist=1e-7)
+        eng.finish("vegasmc", block, adapt=False)                           # doReweight! only (main.jl:183, :192)
+        ocfg.set_reweight(oracle.do_reweight(ocfg.reweight, ref[2 * n + 2: 2 * n + 2 + cfg.N + 1]))
+        np.testing.assert_allclose(eng.reweight(), ocfg.reweight, rtol=1e-9)
+
+
 @pytest.mark.parametrize("case_id", [3, 8, 15, 69, 108, 129, 200, 257])
 def test_carried_chains_on_random_layouts_match_oracle(oracle, case_id):
     """eight cases of the randomised campaign (tools/fuzz_layouts.py --carry, profiles/r03_fuzz_carry.txt: 300 cases): 1-5 pools, 1-4

@@ -31,6 +31,12 @@ def run_seeds(job):
     t0 = time.perf_counter()
     carry = os.environ.get("BIAS_CARRY")        # "off": every iteration starts its chains afresh (mci_set_chain_carry(prob, 0))
     lanes = os.environ.get("BIAS_LANES")        # lanes per chain (mci_set_chain_speculation): "1" = one lane per chain
+    if os.environ.get("BIAS_FRESH_FLOORS"):     # length of automatic :vegasmc chains started afresh, in burn-in floors (mci_debug_override)
+        from mcintegration_jl_amd._lib import lib, check
+        check(lib().mci_debug_override(b"fresh_floors", int(os.environ["BIAS_FRESH_FLOORS"]), 1))
+    if os.environ.get("BIAS_FRESH_BURNIN"):     # ... and the part of such a chain that is not measured, in per cent
+        from mcintegration_jl_amd._lib import lib, check
+        check(lib().mci_debug_override(b"fresh_burnin_pct", int(os.environ["BIAS_FRESH_BURNIN"]), 1))
     for seed in seeds:
         cfg, f, meas, exact = case(name, seed=seed)
         eng = mci.Engine(cfg, f, measure=meas)

@@ -323,6 +323,12 @@ int mci_set_deterministic(mci_problem *prob, int32_t on);
 int mci_set_chain_carry(mci_problem *prob, int32_t mode);
 /* chains per block of the last chain-solver launch and whether it continued the launch before it */
 int mci_last_chain_launch(const mci_problem *prob, int64_t *nchain, int32_t *carried);
+/* For a caller that runs the iteration loop itself (mci_iteration_run / _reduce / _finish; mci_integrate does this on its own): does
+ * the estimate of the launches that follow enter the final average (iteration >= ignore, main.jl:82, :211)?  The first iteration of
+ * the default call does not, and its automatic :vegasmc chains stay short; a launch that counts on a map train! has never refined
+ * (adapt = false, or ignore = 0) runs its fresh chains 8 x as long, because chains of the usual length have not reached their target
+ * on the untrained map (DESIGN.md "Chains", profiles/r05_bias.txt A5 / A6).  Default 0. */
+int mci_set_iteration_counted(mci_problem *prob, int32_t counted);
 /* Several lanes per chain.  The reference's chain is one sequential loop on one core (vegas_mc/montecarlo.jl:184-232,
  * mcmc/montecarlo.jl:134-172); a chain-solver launch with few chains -- the reference's default call runs 16, one per block -- would
  * leave all but a few lanes of the GPU idle.  Such a launch gives every chain a GROUP of lanes (a power of two up to 64) that steps it

@@ -106,6 +106,7 @@ SIGNATURES = [
     ("mci_set_rng_rounds", C.c_int, [_VP, C.c_int32]),
     ("mci_set_deterministic", C.c_int, [_VP, C.c_int32]),
     ("mci_set_chain_carry", C.c_int, [_VP, C.c_int32]),
+    ("mci_set_iteration_counted", C.c_int, [_VP, C.c_int32]),
     ("mci_set_persistent", C.c_int, [_VP, C.c_int32]),
     ("mci_last_integrate_persistent", C.c_int, [_VP, C.POINTER(C.c_int32)]),
     ("mci_last_chain_launch", C.c_int, [_VP, C.POINTER(C.c_int64), c_int32_p]),

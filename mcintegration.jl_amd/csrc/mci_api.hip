@@ -281,7 +281,7 @@ struct mci_problem {
     // call is 14 sigma per run off), and a population that is no sample of the old target cannot be resampled into one of the new --
     // carried out of iteration 1 the second iteration was 4 sigma per run-iteration off, started afresh 1.2 (profiles/r05_bias.txt A4)
     int64_t ntrain = 0, chain_ntrain = 0; // train! steps of this problem so far | ... when the stored chains were launched
-    bool launch_counted = false;          // mci_integrate: the iteration being launched enters the final estimate (it >= ignore)
+    bool launch_counted = false;          // mci_integrate | mci_set_iteration_counted: the iteration being launched enters the final estimate (it >= ignore)
     // :mcmc: the reweight factors the stored chains ran under, and which stored chain every chain of the launch in flight continues
     // (k_resample_chains: the stored chains resampled to the target doReweight! has moved since)
     double *d_reweight_used = nullptr, *d_carry_W = nullptr;
@@ -1675,6 +1675,12 @@ int mci_set_chain_carry(mci_problem *p, int32_t mode) {
     if (mode < -1 || mode > 1) return fail(MCI_ERR_INVALID, "chain carry mode must be -1 (automatic) or 1 (many-chain launches of :vegasmc and :mcmc continue the chains of the iteration before) or 0 (every launch starts its chains afresh)");
     p->chain_carry = mode;
     if (mode == 0) p->chain_valid = false;
+    return MCI_OK;
+}
+
+int mci_set_iteration_counted(mci_problem *p, int32_t counted) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    p->launch_counted = counted != 0;
     return MCI_OK;
 }
 

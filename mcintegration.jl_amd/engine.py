@@ -434,6 +434,11 @@ class Engine:
         "off" (every launch draws new starts and burns them in); see mci_set_chain_carry"""
         check(lib().mci_set_chain_carry(self.p, {"auto": -1, "off": 0, "on": 1, -1: -1, 0: 0, 1: 1}[mode]))
 
+    def set_iteration_counted(self, counted):
+        """for a loop over run / reduce / finish (integrate() with several ranks): the launches that follow enter the final average
+        (iteration >= ignore); see mci_set_iteration_counted"""
+        check(lib().mci_set_iteration_counted(self.p, 1 if counted else 0))
+
     def set_persistent(self, mode):
         """launch-bound :vegas calls of integrate() as ONE persistent launch: "auto" (default), "off" or "on" (whenever the layout
         allows, whatever the size); see mci_set_persistent"""

@@ -166,6 +166,8 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
             eng.reset_block_log()
     for it in range(niter_loop):                                                      # main.jl:142
         attempt = 0
+        if hasattr(eng, "set_iteration_counted"):
+            eng.set_iteration_counted(it >= ignore)                                   # (main.jl:82, :211; what mci_integrate tells its launches)
         while True:
             eng.run(s, nevalperblock, lo, hi, config.iterations_done + it + 16384 * attempt, config.seed, measurefreq, nchain, thermal_ratio)   # main.jl:152-166
             comm.all_reduce(eng)                                                      # main.jl:177-188
@@ -186,6 +188,8 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         means.append(m)
         stds.append(e)
         neval_done += nevalperblock * block
+    if niter_loop and hasattr(eng, "set_iteration_counted"):
+        eng.set_iteration_counted(False)
     config.iterations_done += niter
     config.neval = nevalperblock * block
     config._last_solver = solver

@@ -313,6 +313,14 @@ def test_library_rccl_single_rank_and_torch_reducer():
         assert a.correlated == b.correlated
         np.testing.assert_allclose(a._flat_std, b._flat_std, rtol=1e-4)      # the lineage error, per iteration through the communicator | inside the library
         check(a, [PI / 4.0, 4.0 * PI / 3.0 / 8])
+    # adapt = false: every iteration counts, and the loop over run / reduce / finish tells its launches so (mci_set_iteration_counted) the way
+    # mci_integrate does on its own -- same chain counts (the first launch on the never-refined map: 64 floors instead of 8), same numbers
+    kw = dict(dof=[[2], [3]], solver="vegasmc", neval=2e6, seed=5, adapt=False, niter=4)
+    a = integrate(mci.catalog.sphere2(), comm=comm, var=Continuous(0.0, 1.0), **kw)
+    b = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), **kw)
+    np.testing.assert_allclose(a.mean, b.mean, rtol=1e-6)
+    assert a.config._engine.last_chain_launch() == b.config._engine.last_chain_launch() and a.config._engine.last_chain_launch()[1]
+    check(a, [PI / 4.0, 4.0 * PI / 3.0 / 8])
     # ONE collective per iteration whatever the solver (BASELINE north star): the 64 holding-time counts an :mcmc launch with automatic
     # chain counts measures ride in the packed all-reduce (exact doubles behind the tables) instead of in an all-reduce of their own
     for alg, extra in (("vegas", 0), ("vegasmc", 0), ("mcmc", 64)):

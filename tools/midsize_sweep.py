@@ -19,6 +19,8 @@ CASES = {
     "gauss16": (lambda: mci.Configuration(var=mci.Continuous(-L, L), dof=[[16]], seed=1), lambda: mci.catalog.gaussian(16)),
 }
 GEOM = [(None, None), (256, 8), (256, 16), (512, 4), (512, 8), (512, 16), (1024, 4), (1024, 8)]
+if os.environ.get("SWEEP_GEOM"):   # e.g. SWEEP_GEOM="1024x16,512x32": other (threads x workgroups per block) pairs, block = 16
+    GEOM = [(None, None)] + [tuple(int(v) for v in g.split("x")) for g in os.environ["SWEEP_GEOM"].split(",")]
 
 
 def one(name, neval, threads, wpb, niter=60):

@@ -996,7 +996,7 @@ int mci_problem_destroy(mci_problem *p) {
                         (void *)p->d_packed, (void *)p->d_scratch, (void *)p->d_iterlog, (void *)p->d_dump,
                         (void *)p->d_status, (void *)p->d_leaves})
             if (q) (void)hipFree(q);
-        for (int k = 0; k < 5; ++k)
+        for (int k = 0; k < mci_problem::kSlots; ++k)
             if (p->module[k]) (void)hipModuleUnload(p->module[k]);
         if (p->module_persist) (void)hipModuleUnload(p->module_persist);
         if (p->d_persist) (void)hipFree(p->d_persist);

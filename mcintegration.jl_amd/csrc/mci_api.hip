@@ -1539,6 +1539,7 @@ static int spec_upload(mci_problem *p, int solver, int lanes, double accept, int
 }
 
 int mci_set_chain_speculation(mci_problem *p, int32_t lanes, double accept, int32_t max_accepts) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     if (lanes != -1 && (lanes < 1 || lanes > 64 || (lanes & (lanes - 1)))) return fail(MCI_ERR_INVALID, "lanes per chain: -1 (automatic), 1 (one lane per chain) or a power of two up to 64");
     if (accept >= 1.0) return fail(MCI_ERR_INVALID, "the acceptance a speculation tree is built for lies in (0, 1); <= 0: the solver's default");
     p->spec_lanes = lanes;
@@ -1555,6 +1556,7 @@ int mci_last_integrate_discarded(const mci_problem *p, int64_t *neval, int32_t *
 }
 
 int mci_last_chain_speculation(const mci_problem *p, int32_t *lanes, int32_t *max_accepts) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     if (lanes) *lanes = p->last_spec_lanes;
     if (max_accepts) *max_accepts = p->last_spec_maxacc;
     return MCI_OK;
@@ -1576,6 +1578,7 @@ int mci_speculation_tree(int32_t lanes, double accept, int32_t max_accepts, int3
 }
 
 int mci_compile_chain_speculation(mci_problem *p, int32_t solver) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     if (solver != MCI_VEGASMC && solver != MCI_MCMC) return fail(MCI_ERR_INVALID, "several lanes per chain: solver MCI_VEGASMC or MCI_MCMC");
     if (p->shape.host_integrand) return fail(MCI_ERR_INVALID, "a host integrand keeps one lane per chain");
     return compile_spec(p, solver);
@@ -2026,7 +2029,11 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
                 a.carry_w = p->d_carry_w;
                 a.carry_total = total;
                 mci::BatchArgs wa = a; // (edges, tables, reweight, userdata and the carry fields; everything else unused)
-                double *d_cw = nullptr; // a host closure: evaluated at the stored configurations here, one more callback per iteration
+                struct Scratch { // (freed on every way out of this block, the failing ones included)
+                    double *p = nullptr;
+                    ~Scratch() { if (p) (void)hipFree(p); }
+                } cw; // a host closure: evaluated at the stored configurations here, one more callback per iteration
+                double *&d_cw = cw.p;
                 if (s.host_integrand) {
                     const int nw = s.ni * s.ncomp;
                     std::vector<double> hx((size_t)total * s.ndraw), hw((size_t)total * nw);
@@ -2043,10 +2050,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
                 const int64_t wgrid = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
                 const int tw = G > 1 ? 256 : (T < 256 ? T : 256); // (within the launch bound its code object was compiled for)
                 HIPCHK(hipModuleLaunchKernel(p->f_carryw[G > 1 ? 1 : 0], (unsigned)wgrid, 1, 1, (unsigned)tw, 1, 1, (unsigned)p->lds_bytes, p->ctx->stream, wargs, nullptr));
-                if (d_cw) {
-                    HIPCHK(hipStreamSynchronize(p->ctx->stream));
-                    (void)hipFree(d_cw);
-                }
+                if (d_cw) HIPCHK(hipStreamSynchronize(p->ctx->stream)); // (the kernel has read it before `cw` lets go of it)
                 ra.w_chain = p->d_carry_w;
             }
             hipLaunchKernelGGL(mci::k_resample_chains, dim3((unsigned)nblocks), dim3(256), 0, p->ctx->stream, ra);

@@ -153,3 +153,13 @@ def test_automatic_group_size_follows_the_chain_count():
     eng.set_chain_speculation(1)
     eng.iteration("vegasmc", 8192, 0, 16, iteration=0, seed=SEED, nchain=1)
     assert eng.last_chain_speculation() == (1, 0)
+
+
+def test_the_campaign_case_that_came_out_wrong_at_O3(oracle, monkeypatch):
+    """Case 205 of the carried-chain campaign with a random group size and tree (tools/fuzz_layouts.py --carry --lanes): a composite pool of
+    three leaves next to a Discrete pool nobody uses, ten draws.  With the several-lanes-per-chain unit compiled at -O3 the chains and the
+    statistics were right and the histogram adds landed in the wrong bins (right at -O2 / -O1, and at -O3 with one more unused draw or
+    another integrand body; the lane-per-chain unit right at -O3): those units are compiled at -O2 (csrc/mci_jit.h) -- same timings."""
+    from layout_cases import check_carried_iterations
+    monkeypatch.setenv("FUZZ_LANES", "1")
+    check_carried_iterations(oracle, 205)

@@ -308,13 +308,18 @@ inline void warm_up_join() {
 // returns the gfx950 code object for `src`, from the on-disk cache or by compiling with hiprtc
 inline int compile(const std::string &src, int threads, std::vector<char> &code, std::string &log, bool &from_cache, std::string *cache_path = nullptr,
                    int extra_hdr = kHdrNone, bool cache_only = false) {
-    // (the several-lanes-per-chain units, mci_spec.h, are compiled at -O2: at -O3 ONE layout of the randomised campaigns -- a composite pool
-    // of three leaves next to a Discrete pool nobody uses, ten draws -- came out with the right chains and statistics and the histogram adds
-    // in the wrong bins; right at -O2 and -O1, right at -O3 with one more (unused) draw or another integrand body, the lane-per-chain unit
-    // of the same layout right at -O3.  Not understood beyond that (profiles/r05_fuzz.txt, tools/repro_case.py 205); the default call and the
-    // cold :mcmc calls time the same at -O2.)
-    std::vector<std::string> opts = {"--offload-arch=gfx950", extra_hdr == kHdrSpec ? "-O2" : "-O3", "-std=c++17", "-munsafe-fp-atomics",
+    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics",
                                      "-ffp-contract=off", "-DMCI_THREADS=" + std::to_string(threads)};
+    // The several-lanes-per-chain units (mci_spec.h) are compiled WITHOUT the backend's pre-RA exec-mask optimisation.  One layout of the
+    // randomised campaigns -- a composite pool of three leaves next to a Discrete pool nobody uses, ten draws -- came out of ROCm 7.2's
+    // compiler with the right chains and statistics and its :vegasmc histogram adds in the wrong bins; -opt-bisect-limit pins the flip on
+    // ONE machine pass, si-optimize-exec-masking-pre-ra on that kernel (right with the first 55582 passes, wrong from 55583 on:
+    // profiles/r05_fuzz.txt, tools/repro_case.py 205).  The pass rewrites EXEC save / restore sequences, of which these kernels -- nested
+    // divergent regions around wave-wide exchanges -- have hundreds; the lane-per-chain and :vegas units keep the default pipeline.
+    if (extra_hdr == kHdrSpec) {
+        opts.push_back("-mllvm");
+        opts.push_back("-amdgpu-opt-exec-mask-pre-ra=0");
+    }
     if (const char *e = getenv("MCI_JIT_FLAGS")) {
         std::istringstream is(e);
         std::string t;

@@ -155,11 +155,12 @@ def test_automatic_group_size_follows_the_chain_count():
     assert eng.last_chain_speculation() == (1, 0)
 
 
-def test_the_campaign_case_that_came_out_wrong_at_O3(oracle, monkeypatch):
+def test_the_campaign_case_the_compiler_got_wrong(oracle, monkeypatch):
     """Case 205 of the carried-chain campaign with a random group size and tree (tools/fuzz_layouts.py --carry --lanes): a composite pool of
-    three leaves next to a Discrete pool nobody uses, ten draws.  With the several-lanes-per-chain unit compiled at -O3 the chains and the
-    statistics were right and the histogram adds landed in the wrong bins (right at -O2 / -O1, and at -O3 with one more unused draw or
-    another integrand body; the lane-per-chain unit right at -O3): those units are compiled at -O2 (csrc/mci_jit.h) -- same timings."""
+    three leaves next to a Discrete pool nobody uses, ten draws.  ROCm 7.2's compiler turned the :vegasmc group kernel of this layout into
+    one with the right chains and statistics and its histogram adds in the wrong bins; -opt-bisect-limit pins it on the backend's
+    si-optimize-exec-masking-pre-ra, which the several-lanes-per-chain units are compiled without (csrc/mci_jit.h,
+    profiles/r05_fuzz.txt)."""
     from layout_cases import check_carried_iterations
     monkeypatch.setenv("FUZZ_LANES", "1")
     check_carried_iterations(oracle, 205)

@@ -33,7 +33,9 @@ fn = oracle.compile_c_integrand(body)
 ni = len(dof)
 ocfg = oracle.Config(oleaves, dof)
 ref = ocfg.iteration(oracle.VEGASMC, fn, None, npb, 0, nblk, 0, seed, measurefreq=mfreq, nchain=counts[0])
-for lanes, accept, limit in ((1, 0.0, -1), (8, 1e-3, -1), (64, 0.5, 3)):
+TREES = ((1, 0.0, -1), (8, 1e-3, -1), (64, 0.5, 3))
+if os.environ.get("R_ONLY_LANES"): TREES = tuple(t for t in TREES if t[0] == int(os.environ["R_ONLY_LANES"]))
+for lanes, accept, limit in TREES:
     cfg = mci.Configuration(var=var, dof=dof, seed=seed)
     eng = mci.Engine(cfg, mci.Integrand(body))
     eng.set_chain_speculation(lanes, accept, limit)

@@ -377,3 +377,27 @@ def test_weighted_resampling_of_carried_vegasmc_chains(oracle):
     step = W[-1] / 777
     ref = np.array([np.searchsorted(W, (c + 0.6180339887498949) * step, side="right") for c in range(777)])
     assert np.array_equal(oracle.resample_weighted(w, 777), np.minimum(ref, len(w) - 1))
+
+
+def test_vegasmc_chains_are_carried_while_the_map_stays_and_not_onto_a_first_refinement(oracle):
+    """The oracle's mirror of the rule of mci_iteration_run: the chains of a :vegasmc launch on a map train! has never refined go on in the
+    next iteration as long as the map stays as it is (adapt = false), and start afresh when train! has refined it in between (their end
+    configurations are no sample of the old target yet: profiles/r05_bias.txt A4); out of a launch on a refined map they are carried."""
+    def run(carry, train):
+        cfg = oracle.Config([dict(kind=0, pool=0, lower=0.0, upper=1.0)], [[2], [3]])
+        cfg.set_chain_carry(carry)
+        out = []
+        for it in range(3):
+            out.append(cfg.iteration(oracle.VEGASMC, "sphere2", [2.0, 3.0], 4000, 0, 2, it, 11, nchain=8))
+            if train:
+                cfg.train()
+        return out
+
+    keep, fresh = run("auto", False), run("off", False)
+    np.testing.assert_array_equal(keep[0], fresh[0])                 # first launches: both start afresh
+    assert not np.array_equal(keep[1], fresh[1])                     # the map has not moved: chains go on
+    assert not np.array_equal(keep[2], fresh[2])
+    keep, fresh = run("auto", True), run("off", True)
+    np.testing.assert_array_equal(keep[0], fresh[0])
+    np.testing.assert_array_equal(keep[1], fresh[1])                 # refined for the first time in between: afresh
+    assert not np.array_equal(keep[2], fresh[2])                     # out of a launch on a refined map: carried (resampled to the moved target)

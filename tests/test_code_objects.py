@@ -219,3 +219,20 @@ def test_headline_kernel_of_every_stream_is_pipelined_and_does_not_spill(bits, r
     assert res["max_threads"] == threads and eng.histogram_copies() == copies
     assert mix["samples_per_trip"] == 2 and mix["mnemonics"]["ds_read_b128"] == 16 and mix["mnemonics"]["ds_add_f64"] == 16
     eng.close()
+
+
+def test_group_kernels_are_built_without_the_exec_mask_pass_that_miscompiled_one(tmp_path):
+    """csrc/mci_jit.h: the several-lanes-per-chain units are compiled with -amdgpu-opt-exec-mask-pre-ra=0 -- si-optimize-exec-masking-pre-ra
+    of ROCm 7.2's backend put the histogram adds of one campaign layout's :vegasmc group kernel into the wrong bins (profiles/r05_fuzz.txt;
+    the GPU side of it: tests/test_hip_spec.py).  The pass list of that unit's compilation (-opt-bisect-limit=-1) must not hold it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AMD_COMGR_CACHE="0", MCI_JIT_FLAGS="-mllvm -opt-bisect-limit=-1", MCI_KERNEL_CACHE=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "repro_compile.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    log = r.stderr + r.stdout
+    if "machine-scheduler on function (mci_vegasmc_spec)" not in log:
+        pytest.skip("this toolchain does not list its passes under -opt-bisect-limit")
+    assert "si-optimize-exec-masking-pre-ra on function (mci_vegasmc_spec)" not in log
+    assert "si-optimize-exec-masking on function (mci_vegasmc_spec)" in log    # (the post-RA pass of the default pipeline stays)

@@ -116,7 +116,7 @@ class Engine:
             self._host_cb = _lib.HOST_INTEGRAND_IDX_FN(self._make_host_indexed_callback(integrand.fn))   # keep alive
             check(L.mci_set_integrand_host_indexed(self.p, C.cast(self._host_cb, C.c_void_p), None))
         elif isinstance(integrand, HostIntegrand):
-            self._host_cb = _lib.HOST_INTEGRAND_FN(self._make_host_callback(integrand.fn))   # keep alive
+            self._host_cb = _lib.HOST_INTEGRAND_FN(self._make_host_callback(integrand.fn, getattr(integrand, "inplace", False)))   # keep alive
             check(L.mci_set_integrand_host(self.p, C.cast(self._host_cb, C.c_void_p), None))
         else:
             check(L.mci_set_integrand_source(self.p, integrand.body.encode(), _dp(ud) if len(ud) else None, len(ud)))
@@ -145,8 +145,9 @@ class Engine:
         for i, lf in enumerate(leaves):
             lf._engine, lf._leaf_index = self, i
 
-    def _make_host_callback(self, fn):
-        """ctypes trampoline: draw-major x[k*n + i] -> numpy views -> fn(x, config) -> w[q*n + i]"""
+    def _make_host_callback(self, fn, inplace=False):
+        """ctypes trampoline: draw-major x[k*n + i] -> numpy views -> fn(x, config) -> w[q*n + i]; inplace: fn(x, weights, config)
+        writes into a view of w itself (vegas/montecarlo.jl:140-141)"""
         config = self.config
         nc = config.ncomp
         pools = []   # (first draw, maxdof, nleaf)
@@ -166,6 +167,15 @@ class Engine:
                     arg = tuple(X[k0:k0 + md * nl].reshape((md, n) if nl == 1 else (md, nl, n)) for k0, md, nl in pools)
                     if len(arg) == 1:
                         arg = arg[0]
+                if inplace:
+                    if nc == 2:
+                        Z = np.zeros((config.N, n), dtype=complex)
+                        fn(arg, Z, config)
+                        W[0::2], W[1::2] = Z.real, Z.imag
+                    else:
+                        W[:] = 0.0
+                        fn(arg, W, config)
+                    return 0
                 out = fn(arg, config)
                 if config.N == 1 and not isinstance(out, (tuple, list)):
                     out = (out,)

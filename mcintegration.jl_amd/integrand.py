@@ -51,13 +51,28 @@ class HostIntegrand:
         f(idx, x, config) -> array[m]
 
     is called once per integrand index that some chain needs, with `x` restricted to those m chains (idx is 0-based: the
-    reference's idx - 1); include/mci.h mci_set_integrand_host_indexed.  Either form works under every solver."""
+    reference's idx - 1); include/mci.h mci_set_integrand_host_indexed.
 
-    def __init__(self, fn, name=None, indexed=False):
+    inplace=True: the reference's `inplace = true` form `integrand(var, weights, config)` (main.jl:26, vegas/montecarlo.jl:140-141,
+    vegas_mc/updates.jl:67-70) --
+
+        f(x, weights, config)          # weights[i] = ...   in place; what f returns is ignored
+
+    `weights` is a writable [N, n] array (complex for type=complex), zero on entry: `weights[i] = expr` stores integrand i's values
+    over the batch (0-based).  For real weights it is the library's own pinned buffer (mci_set_integrand_host hands the callback
+    its output array: the C boundary is in-place already), so nothing is copied.
+
+    integrate() picks the form the way the reference does -- by solver and the `inplace` keyword; wrapping a closure in
+    HostIntegrand(fn, indexed=..., inplace=...) says it explicitly, and then any form works under every solver."""
+
+    def __init__(self, fn, name=None, indexed=False, inplace=False):
+        if indexed and inplace:
+            raise ValueError("the :mcmc form integrand(idx, var, config) has no in-place variant (main.jl:26-28)")
         self.fn = fn
         self.indexed = bool(indexed)
+        self.inplace = bool(inplace)
         self.name = name or getattr(fn, "__name__", "host")
-        self.body = "/* host integrand %d%s */" % (id(fn), " indexed" if indexed else "")
+        self.body = "/* host integrand %d%s */" % (id(fn), " indexed" if indexed else " inplace" if inplace else "")
         self.userdata = np.zeros(0)
 
 

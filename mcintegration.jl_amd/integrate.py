@@ -34,6 +34,57 @@ def required_positionals(fn, fallback):
         return fallback
 
 
+def _positional_range(fn):
+    """(required, most) positional arguments the closure takes; most = None with *args; None when it has no signature"""
+    import inspect
+    try:
+        ps = list(inspect.signature(fn).parameters.values())
+    except (TypeError, ValueError):
+        return None
+    pos = [q for q in ps if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)]
+    return len([q for q in pos if q.default is q.empty]), (None if any(q.kind == q.VAR_POSITIONAL for q in ps) else len(pos))
+
+
+_INTEGRAND_CALL = {"plain": "integrand(var, config)", "inplace": "integrand(var, weights, config)", "indexed": "integrand(idx, var, config)"}
+_MEASURE_CALL = {"plain": "measure(var, obs, relative_weights, config)", "indexed": "measure(idx, var, obs, relative_weight, config)"}
+
+
+def callback_form(fn, solver, inplace=False, form=None, what="integrand"):
+    """Which of the reference's callback forms a bare closure is called in -- decided like the reference decides it, by the SOLVER and
+    the `inplace` keyword, never by counting parameters (main.jl:26-28, :38-40):
+
+        solver = "mcmc"                -> integrand(idx, var, config)             mcmc/montecarlo.jl:34-36
+        otherwise, inplace = True      -> integrand(var, weights, config)         vegas/montecarlo.jl:140-141, vegas_mc/updates.jl:67-70
+        otherwise                      -> integrand(var, config)                  vegas/montecarlo.jl:142-143, vegas_mc/updates.jl:71-75
+        measure: solver = "mcmc"       -> measure(idx, var, obs, relative_weight, config)   mcmc/montecarlo.jl:166-169
+                 otherwise             -> measure(var, obs, relative_weights, config)       vegas/montecarlo.jl:156-161
+
+    The closure's own parameter count is only a cross-check: one that cannot be called that way raises TypeError here (the
+    reference's MethodError at the first call) instead of being read as another form.  `form` ("plain" | "inplace" | "indexed";
+    integrate's integrand_form / measure_form keywords) overrides the rule: an engine extension -- every form runs under every solver."""
+    calls = _INTEGRAND_CALL if what == "integrand" else _MEASURE_CALL
+    if form is None:
+        form = "indexed" if solver == "mcmc" else "inplace" if (inplace and what == "integrand") else "plain"
+    elif form not in calls:
+        raise ValueError("%s_form = %r: one of %s" % (what, form, sorted(calls)))
+    want = calls[form].count(",") + 1
+    rng = _positional_range(fn)
+    if rng is not None and (rng[0] > want or (rng[1] is not None and rng[1] < want)):
+        has = "%d" % rng[0] if rng[1] == rng[0] else "%d to %s" % (rng[0], "any number of" if rng[1] is None else rng[1])
+        hint = ""
+        if what == "integrand":
+            hint = ("  The form follows the solver and the `inplace` keyword (reference src/main.jl:26-28): solver = \"vegas\" / \"vegasmc\" call "
+                    "integrand(var, config), with inplace = True integrand(var, weights, config); solver = \"mcmc\" calls integrand(idx, var, config).  "
+                    "integrand_form = \"plain\" | \"inplace\" | \"indexed\" forces a form under any solver.")
+        else:
+            hint = ("  The form follows the solver (reference src/main.jl:38-40): solver = \"mcmc\" calls measure(idx, var, obs, relative_weight, config), "
+                    "the others measure(var, obs, relative_weights, config).  measure_form = \"plain\" | \"indexed\" forces a form under any solver.")
+        raise TypeError("solver = %r%s calls %s -- %d arguments -- but the %s closure %s takes %s positional argument%s.%s"
+                        % (solver, ", inplace = True" if (inplace and what == "integrand" and solver != "mcmc") else "", calls[form], want, what,
+                           getattr(fn, "__name__", "?"), has, "" if has == "1" else "s", hint))
+    return form
+
+
 TRACE_DEFAULT = None   # what integrate(trace=None) means: None = trace Python closures where possible, silently; False = host callbacks
 
 
@@ -51,7 +102,8 @@ def _not_traced(what, err, trace, verbosity):
 def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, block=16, verbose=-1, gamma=1.0,
               adapt=True, debug=False, reweight_goal=None, ignore=None, measure=None, measurefreq=1,
               thermal_ratio=0.1, inplace=False, parallel="nothread", print=-1, printio=None, timer=None,
-              comm=None, device=None, nchain=0, engine_factory=None, rng_bits=52, rng_rounds=10, deterministic=False, trace=None, **kwargs):
+              comm=None, device=None, nchain=0, engine_factory=None, rng_bits=52, rng_rounds=10, deterministic=False, trace=None,
+              integrand_form=None, measure_form=None, **kwargs):
     """Same keywords as the reference (main.jl:71-90; unknown ones go to Configuration, :95-97).
     Extra, engine-specific keywords: `comm` (LocalComm | RcclComm | TorchDistComm), `device`, `nchain`
     (vegasmc chains per block; 0 = auto), `rng_bits` (52 | 32: opt-in cheaper uniform stream of solver="vegas", see
@@ -60,7 +112,9 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     Python closure as integrand or measure is run once on symbolic draws and written out as device source -- trace.trace_integrand /
     trace_measure -- so that it runs inside the kernels like Julia's inlined closure does in the reference's loop; a closure that
     cannot be written out takes the host batch-callback path, silently with None, with a RuntimeWarning naming the reason with True;
-    False: always the host path), `engine_factory` (test seam)."""
+    False: always the host path), `integrand_form` / `measure_form` (callback_form: by default a closure is called in the form the
+    reference's solver calls it in -- `inplace` included -- and one whose parameters do not fit raises TypeError), `engine_factory`
+    (test seam)."""
     if trace is None:
         trace = TRACE_DEFAULT
     if solver in (":vegas", ":vegasmc", ":mcmc"):
@@ -86,22 +140,22 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
     if isinstance(integrand, str):
         integrand = Integrand(integrand, config.userdata)
     elif callable(integrand) and not isinstance(integrand, (Integrand, HostIntegrand)):
-        # a Python closure: host "batch callback" path (vegas: per launch, vegasmc / mcmc: per Markov step).  Three positional
-        # parameters = the reference's :mcmc form integrand(idx, var, config) (mcmc/montecarlo.jl:34-36), two = integrand(var, config)
-        # (parameters with a default do not count: `f(x, config, scale=2.0)` is the two-argument form; HostIntegrand(fn, indexed=...) says it explicitly)
-        indexed = required_positionals(integrand, 2) >= 3
+        # a Python closure, called in the form the reference's solver calls it in (callback_form; main.jl:26-28): traced into device
+        # source where possible, else the host "batch callback" path (vegas: per launch, vegasmc / mcmc: per Markov step).
+        # HostIntegrand(fn, indexed=..., inplace=...) / trace_integrand(...) say the form explicitly.
+        form = callback_form(integrand, solver, inplace, integrand_form)
         traced = None
         if trace is None or trace:
             from .trace import TraceError, trace_integrand
             try:
-                traced = trace_integrand(integrand, config, indexed=indexed)
+                traced = trace_integrand(integrand, config, indexed=form == "indexed", inplace=form == "inplace")
             except TraceError as e:
                 _not_traced("integrand", e, trace, print)
-        integrand = traced if traced is not None else HostIntegrand(integrand, indexed=indexed)
+        integrand = traced if traced is not None else HostIntegrand(integrand, indexed=form == "indexed", inplace=form == "inplace")
     if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
-        # a Python closure as measure: host batch-callback path.  Five positional parameters = the reference's :mcmc form
-        # measure(idx, var, obs, relative_weight, config) (mcmc/montecarlo.jl:166-169), four = measure(var, obs, weights, config)
-        mindexed = required_positionals(measure, 4) >= 5
+        # a Python closure as measure: the reference's :mcmc form measure(idx, var, obs, relative_weight, config) under solver = "mcmc"
+        # (mcmc/montecarlo.jl:166-169), measure(var, obs, weights, config) under the others (vegas/montecarlo.jl:156-161)
+        mindexed = callback_form(measure, solver, form=measure_form, what="measure") == "indexed"
         tmeasure = None
         if trace is None or trace:
             from .trace import TraceError, trace_measure

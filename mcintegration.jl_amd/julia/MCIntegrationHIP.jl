@@ -479,25 +479,27 @@ function parametrized(f, t::Tape)
     end
 end
 """
-    trace_integrand(f, config; indexed=false, check_points=32) -> Integrand
+    trace_integrand(f, config; indexed=false, inplace=false, check_points=32) -> Integrand
 
-`f(x, config)` (or the reference's :mcmc form `f(idx, x, config)`, idx 1-based) run once on symbolic draws and written out as a
+`f(x, config)` (or the reference's :mcmc form `f(idx, x, config)`, idx 1-based; or its `inplace = true` form `f(x, weights, config)`,
+src/main.jl:26, src/vegas/montecarlo.jl:140-141: the closure stores `weights[i] = value`) run once on symbolic draws and written out as a
 device-source Integrand; TraceError if it cannot be, or if the written-out expression and the closure disagree at random points.
 With one variable type `x[i]` is the i-th draw; with several, `x[v][i]` (a CompositeVar pool: `x[v][leaf, slot]` is not traced).
 """
-function trace_integrand(f, c::Configuration; indexed::Bool=false, check_points::Int=32, parameters::Bool=true)
+function trace_integrand(f, c::Configuration; indexed::Bool=false, inplace::Bool=false, check_points::Int=32, parameters::Bool=true)
+    indexed && inplace && throw(ArgumentError("the :mcmc form integrand(idx, var, config) has no in-place variant (src/main.jl:26-28)"))
     c.ncomp == 1 || throw(TraceError("complex weights are not traced"))
     any(v -> v isa CompositeVar || v isa FermiK, c.var) && throw(TraceError("CompositeVar / FermiK pools are not traced"))
     if parameters
         try
-            return _trace_integrand(f, c, indexed, check_points, true)
+            return _trace_integrand(f, c, indexed, check_points, true, inplace)
         catch err
             err isa TraceError || err isa TypeError || err isa MethodError || rethrow()
         end                                       # (a branch on a captured float): once more with the captured values as literals
     end
-    _trace_integrand(f, c, indexed, check_points, false)
+    _trace_integrand(f, c, indexed, check_points, false, inplace)
 end
-function _trace_integrand(f, c::Configuration, indexed::Bool, check_points::Int, parameters::Bool)
+function _trace_integrand(f, c::Configuration, indexed::Bool, check_points::Int, parameters::Bool, inplace::Bool=false)
     t = Tape()
     maxdof = [maximum(c.dof[i][v] for i in 1:c.N) for v in 1:length(c.var)]
     k = 0
@@ -512,6 +514,9 @@ function _trace_integrand(f, c::Configuration, indexed::Bool, check_points::Int,
     try
         if indexed
             outs = Any[g(i, arg, c) for i in 1:c.N]
+        elseif inplace                              # weights: one entry per integrand, zero until the closure stores into it
+            outs = Any[0.0 for _ in 1:c.N]
+            g(arg, outs, c)
         else
             r = g(arg, c)
             outs = r isa Tuple ? Any[r...] : Any[r]
@@ -536,7 +541,8 @@ function _trace_integrand(f, c::Configuration, indexed::Bool, check_points::Int,
             var isa Discrete && (X[j] = Float64(rand(var.lower:var.upper)))
         end
         num = length(pools) == 1 ? X : Tuple(X[(sum(maxdof[1:v-1])+1):sum(maxdof[1:v])] for v in 1:length(c.var))
-        ref = indexed ? Float64[f(i, num, c) for i in 1:c.N] : (r = f(num, c); r isa Tuple ? Float64[r...] : Float64[r])
+        ref = indexed ? Float64[f(i, num, c) for i in 1:c.N] : inplace ? (r = zeros(c.N); f(num, r, c); r) :
+              (r = f(num, c); r isa Tuple ? Float64[r...] : Float64[r])
         got = evaluate(t, ids, X)
         for i in 1:c.N
             (isfinite(ref[i]) == isfinite(got[i]) && (!isfinite(ref[i]) || isapprox(got[i], ref[i]; rtol=1e-10, atol=1e-290))) ||
@@ -572,6 +578,34 @@ function _host_trampoline(x::Ptr{Float64}, w::Ptr{Float64}, n::Int64, ndraw::Int
         return Cint(1)
     end
 end
+# the reference's `inplace = true` form f(x, weights, config) (src/main.jl:26, src/vegas/montecarlo.jl:140-141, src/vegas_mc/updates.jl:67-70):
+# `weights[i] = values` stores integrand i's values over the batch straight into the library's output array (zero on entry)
+struct WeightRows <: AbstractVector{Any}
+    W::Matrix{Float64}; ncomp::Int
+end
+Base.size(r::WeightRows) = (size(r.W, 2) ÷ r.ncomp,)
+Base.getindex(r::WeightRows, i::Int) = r.ncomp == 2 ? complex.(view(r.W, :, 2i - 1), view(r.W, :, 2i)) : view(r.W, :, i)
+function Base.setindex!(r::WeightRows, v, i::Int)
+    if r.ncomp == 2
+        r.W[:, 2i-1] .= real.(v); r.W[:, 2i] .= imag.(v)
+    else
+        r.W[:, i] .= v
+    end
+    v
+end
+function _host_inplace_trampoline(x::Ptr{Float64}, w::Ptr{Float64}, n::Int64, ndraw::Int32, nw::Int32, user::Ptr{Cvoid})::Cint
+    try
+        f, c = _closures[user]
+        X = unsafe_wrap(Array, x, (Int(n), Int(ndraw)))
+        W = unsafe_wrap(Array, w, (Int(n), Int(nw)))
+        fill!(W, 0.0)
+        f([view(X, :, k) for k in 1:ndraw], WeightRows(W, c.ncomp), c)
+        return Cint(0)
+    catch err
+        @error "host integrand failed" err
+        return Cint(1)
+    end
+end
 # the reference's :mcmc form f(idx, x, config) (src/mcmc/montecarlo.jl:34-36; idx 1-based like the reference): one call per integrand
 # index some chain asks for, over the chains that ask for it (mci_set_integrand_host_indexed)
 function _host_idx_trampoline(idx::Ptr{Int32}, x::Ptr{Float64}, w::Ptr{Float64}, n::Int64, ndraw::Int32, ncomp::Int32, user::Ptr{Cvoid})::Cint
@@ -596,12 +630,32 @@ function _host_idx_trampoline(idx::Ptr{Int32}, x::Ptr{Float64}, w::Ptr{Float64},
         return Cint(1)
     end
 end
-function bind_host!(c::Configuration, f::Function)
+"""
+    callback_form(f, solver, inplace; what=:integrand) -> :plain | :inplace | :indexed
+
+Which form a closure is called in: decided by the SOLVER and the `inplace` keyword like the reference (src/main.jl:26-28, :38-40), never
+by counting parameters -- `:mcmc` calls `integrand(idx, var, config)` / `measure(idx, var, obs, relative_weight, config)`; the others
+`inplace ? integrand(var, weights, config) : integrand(var, config)` and `measure(var, obs, relative_weights, config)`.  The closure's
+methods are the cross-check: none with that many arguments is the reference's MethodError, raised here before anything runs.
+"""
+function callback_form(f::Function, solver::Symbol, inplace::Bool=false; what::Symbol=:integrand)
+    form = solver == :mcmc ? :indexed : (inplace && what == :integrand) ? :inplace : :plain
+    want = what == :integrand ? (form == :plain ? 2 : 3) : (form == :indexed ? 5 : 4)
+    any(m -> m.nargs - 1 == want || (m.isva && m.nargs - 2 <= want), methods(f)) ||
+        throw(ArgumentError("solver = :$solver$(form == :inplace ? ", inplace = true" : "") calls the $what with $want arguments " *
+                            "(src/main.jl:26-28, :38-40: :mcmc -> (idx, var, ...), inplace = true -> integrand(var, weights, config)); " *
+                            "the closure has no such method"))
+    form
+end
+function bind_host!(c::Configuration, f::Function, form::Symbol=:plain)
     prob = bind!(c, Integrand("", Float64[]), nothing)
     _closures[prob] = (f, c)
-    if any(m -> m.nargs - 1 >= 3, methods(f))      # f(idx, x, config): the reference's :mcmc signature
+    if form == :indexed                            # f(idx, x, config): what :mcmc calls (src/mcmc/montecarlo.jl:34-36)
         cb = @cfunction(_host_idx_trampoline, Cint, (Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Ptr{Cvoid}))
         check(ccall((:mci_set_integrand_host_indexed, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, cb, prob))
+    elseif form == :inplace                        # f(x, weights, config): inplace = true (src/vegas/montecarlo.jl:140-141)
+        cb = @cfunction(_host_inplace_trampoline, Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Ptr{Cvoid}))
+        check(ccall((:mci_set_integrand_host, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, cb, prob))
     else
         cb = @cfunction(_host_trampoline, Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Ptr{Cvoid}))
         check(ccall((:mci_set_integrand_host, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, cb, prob))
@@ -661,9 +715,9 @@ function _measure_idx_trampoline(idx::Ptr{Int32}, x::Ptr{Float64}, relw::Ptr{Flo
         return Cint(1)
     end
 end
-function bind_measure_host!(c::Configuration, prob, m::Function)
+function bind_measure_host!(c::Configuration, prob, m::Function, form::Symbol=:plain)
     _measures[prob] = (m, c)
-    if any(q -> q.nargs - 1 >= 5, methods(m))
+    if form == :indexed                            # measure(idx, x, obs, weight, config): what :mcmc calls (src/mcmc/montecarlo.jl:166-169)
         cb = @cfunction(_measure_idx_trampoline, Cint, (Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int32, Int32, Int64, Ptr{Float64}, Int32, Ptr{Cvoid}))
         check(ccall((:mci_set_measure_host_indexed, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, cb, prob))
     else
@@ -821,36 +875,39 @@ end
 
 """
     integrate(integrand::Integrand; solver=:vegasmc, config=nothing, neval=1e4, niter=10, block=16, gamma=1.0,
-              adapt=true, ignore=adapt ? 1 : 0, measure=nothing, measurefreq=1, kwargs...)
+              adapt=true, ignore=adapt ? 1 : 0, measure=nothing, measurefreq=1, inplace=false, kwargs...)
 
 Same keywords as the reference (src/main.jl:71-90); the loop of src/main.jl:142-218 runs inside
-`mci_integrate` on the GPU.  Unknown keywords go to `Configuration` (src/main.jl:95-97).
+`mci_integrate` on the GPU.  Unknown keywords go to `Configuration` (src/main.jl:95-97).  A closure is called in the form the reference's
+solver calls it in (`callback_form`): `integrand(var, config)`, `integrand(var, weights, config)` with `inplace = true`,
+`integrand(idx, var, config)` under `:mcmc`.
 """
 function integrate(integrand::Union{Integrand,AbstractString,Function}; solver::Symbol=:vegasmc, config=nothing, neval=1e4, niter=10,
                    block=16, gamma=1.0, adapt=true, ignore::Int=adapt ? 1 : 0, measure=nothing, measurefreq::Int=1,
-                   thermal_ratio=0.1, reweight_goal::Union{Vector{Float64},Nothing}=nothing,
+                   thermal_ratio=0.1, inplace::Bool=false, reweight_goal::Union{Vector{Float64},Nothing}=nothing,
                    nchain=0, rng_bits::Int=52, rng_rounds::Int=10, train_walk::Int=-1, deterministic::Bool=false, chain_carry::Int=-1,
                    persistent::Int=-1, trace::Bool=true, print=-1, verbose=-1, kwargs...)
     haskey(SOLVER, solver) || error("Solver $solver is not supported!")                  # main.jl:263
     config === nothing && (config = Configuration(; kwargs...))                          # main.jl:95-97
     # workers: after init_comm!(...) the library runs this rank's share of the blocks and sums every iteration's statistics and
     # histograms over the ranks with one RCCL all-reduce (main.jl:113-122, :152-188); nothing to do here per call
+    form = integrand isa Function ? callback_form(integrand, solver, inplace) : :plain   # by solver + flag (main.jl:26-28); ArgumentError if the closure has no such method
     if integrand isa Function && trace             # a Julia closure: run once on symbolic draws and written out as device source (trace_integrand) ...
         try
-            integrand = trace_integrand(integrand, config; indexed=any(m -> m.nargs - 1 >= 3, methods(integrand)))
+            integrand = trace_integrand(integrand, config; indexed=form == :indexed, inplace=form == :inplace)
         catch err
             err isa TraceError || rethrow()
             max(print, verbose) > 0 && println("integrand not traced (", err.msg, "): host callback path")
         end
     end
     if integrand isa Function                      # ... or, if it cannot be, the host batch-callback path (per launch under :vegas, per Markov step under :vegasmc / :mcmc)
-        prob = bind_host!(config, integrand)
+        prob = bind_host!(config, integrand, form)
     else
         f = integrand isa Integrand ? integrand : Integrand(String(integrand), config.userdata === nothing ? Float64[] : Float64.(config.userdata))
         prob = bind!(config, f, measure isa Function ? nothing : measure)
     end
     if measure isa Function                        # a Julia closure as `measure`: per block, after the launch
-        bind_measure_host!(config, prob, measure)
+        bind_measure_host!(config, prob, measure, callback_form(measure, solver; what=:measure))
     elseif haskey(_measures, prob)                 # the problem still carries an earlier call's closure: back to the device-side measure
         delete!(_measures, prob)
         check(ccall((:mci_set_measure_host, libmci), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), prob, C_NULL, C_NULL))

@@ -93,8 +93,12 @@ class Sym:
 
     # -- arithmetic (an ndarray operand hands the operation back to numpy, which applies it element by element)
     def _bin(self, op, other, swap=False):
-        if isinstance(other, np.ndarray):
+        if isinstance(other, (np.ndarray, CSym)):
             return NotImplemented
+        if isinstance(other, (complex, np.complexfloating)):
+            if op not in "+-*/":
+                raise TraceError("a comparison with a complex number")
+            return CSym(self, 0.0)._bin(op, other, swap)
         o = self.t.lift(other)
         a, b = (o, self) if swap else (self, o)
         if op == "+" and (_is_const(a, 0.0) or _is_const(b, 0.0)):
@@ -191,12 +195,130 @@ class Sym:
     def __ror__(self, o): return self._logic("or", o)
 
     def conjugate(self): return self
+    conj = conjugate
 
     @property
     def real(self): return self
 
+    @property
+    def imag(self): return 0.0
+
 
 _BOOL = ("<", "<=", ">", ">=", "==", "!=", "not", "and", "or")
+
+
+def _z(v):
+    """a component that is structurally zero (a real value promoted to complex): its terms are not written out"""
+    return not isinstance(v, Sym) and v == 0.0
+
+
+def _rmul(a, b):
+    return 0.0 if _z(a) or _z(b) else a * b
+
+
+def _radd(a, b, sign=1.0):
+    if _z(b):
+        return a
+    if _z(a):
+        return b if sign > 0 else -b
+    return a + b if sign > 0 else a - b
+
+
+class CSym:
+    """a complex value of the traced computation (type = ComplexF64 configurations, main.jl:279,284): a pair of real values -- draws,
+    constants or operations on them -- so that the written-out body stays real arithmetic on the (re, im) slots of `w`.  A real value
+    that meets a complex one is (value, structural zero), like Julia's Real * Complex: no cross terms with the missing part."""
+    __slots__ = ("re", "im")
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        n = ufunc.__name__
+        if method != "__call__" or kwargs or any(isinstance(i, np.ndarray) for i in inputs):
+            raise TraceError("np.%s.%s on a complex sampled value in this call form" % (n, method))
+        if n in _UFUNC_BIN and _UFUNC_BIN[n] in "+-*/":
+            return CSym.of(inputs[0])._bin(_UFUNC_BIN[n], inputs[1])
+        one = {"exp": CSym.exp, "conjugate": CSym.conjugate, "negative": CSym.__neg__, "positive": CSym.__pos__, "absolute": CSym.__abs__,
+               "square": lambda z: z * z, "reciprocal": lambda z: 1.0 / z}
+        if n in one and len(inputs) == 1:
+            return one[n](self)
+        if n == "power" and inputs[0] is self:
+            return self ** inputs[1]
+        raise TraceError("np.%s of a complex value is not written out" % n)
+
+    def __init__(self, re, im):
+        self.re, self.im = re, im
+
+    @staticmethod
+    def of(v):
+        if isinstance(v, CSym):
+            return v
+        if isinstance(v, (complex, np.complexfloating)):
+            return CSym(float(v.real), float(v.imag))
+        if isinstance(v, (Sym, int, float, np.integer, np.floating)):
+            return CSym(v if isinstance(v, Sym) else float(v), 0.0)
+        raise TraceError("cannot use %r (%s) in a complex integrand expression" % (v, type(v).__name__))
+
+    def _bin(self, op, other, swap=False):
+        if isinstance(other, np.ndarray):
+            return NotImplemented
+        a, b = (CSym.of(other), self) if swap else (self, CSym.of(other))
+        if op == "+":
+            return CSym(_radd(a.re, b.re), _radd(a.im, b.im))
+        if op == "-":
+            return CSym(_radd(a.re, b.re, -1.0), _radd(a.im, b.im, -1.0))
+        if op == "*":
+            return CSym(_radd(_rmul(a.re, b.re), _rmul(a.im, b.im), -1.0), _radd(_rmul(a.re, b.im), _rmul(a.im, b.re)))
+        if op == "/":
+            if _z(b.im):
+                return CSym(a.re / b.re, 0.0 if _z(a.im) else a.im / b.re)
+            d = _radd(_rmul(b.re, b.re), _rmul(b.im, b.im))
+            n = a._bin("*", CSym(b.re, 0.0 if _z(b.im) else -b.im))
+            return CSym(0.0 if _z(n.re) else n.re / d, 0.0 if _z(n.im) else n.im / d)
+        raise TraceError("complex values are not ordered")
+
+    def __add__(self, o): return self._bin("+", o)
+    def __radd__(self, o): return self._bin("+", o, True)
+    def __sub__(self, o): return self._bin("-", o)
+    def __rsub__(self, o): return self._bin("-", o, True)
+    def __mul__(self, o): return self._bin("*", o)
+    def __rmul__(self, o): return self._bin("*", o, True)
+    def __truediv__(self, o): return self._bin("/", o)
+    def __rtruediv__(self, o): return self._bin("/", o, True)
+    def __neg__(self): return CSym(-self.re if not _z(self.re) else 0.0, -self.im if not _z(self.im) else 0.0)
+    def __pos__(self): return self
+
+    def __abs__(self):
+        m = _radd(_rmul(self.re, self.re), _rmul(self.im, self.im))
+        return m.sqrt() if isinstance(m, Sym) else math.sqrt(m)
+
+    def __pow__(self, p):
+        if isinstance(p, (int, np.integer)) and 0 <= int(p) <= 8:
+            r = CSym(1.0, 0.0)
+            for _ in range(int(p)):
+                r = r * self
+            return r
+        raise TraceError("a complex value to the power %r" % (p,))
+
+    def __lt__(self, o): raise TraceError("complex values are not ordered")
+    __le__ = __gt__ = __ge__ = __lt__
+
+    def __bool__(self):
+        raise TraceError("a Python branch on a sampled value (use mci.trace.where(cond, a, b))")
+
+    def conjugate(self): return CSym(self.re, 0.0 if _z(self.im) else -self.im)
+    conj = conjugate
+
+    def exp(self):
+        e = self.re.exp() if isinstance(self.re, Sym) else math.exp(self.re)
+        if _z(self.im):
+            return CSym(e, 0.0)
+        c, s_ = (self.im.cos(), self.im.sin()) if isinstance(self.im, Sym) else (math.cos(self.im), math.sin(self.im))
+        return CSym(e * c, e * s_)
+
+    @property
+    def real(self): return self.re
+
+    @property
+    def imag(self): return self.im
 
 
 def _is_const(s, v):
@@ -279,6 +401,9 @@ def where(cond, a, b):
         return np.frompyfunc(where, 3, 1)(_boxed(cond), _boxed(a), _boxed(b))
     if not isinstance(cond, Sym):
         return a if cond else b
+    if any(isinstance(v, (CSym, complex, np.complexfloating)) for v in (a, b)):
+        a, b = CSym.of(a), CSym.of(b)
+        return CSym(where(cond, a.re, b.re), where(cond, a.im, b.im))
     t = cond.t
     return t.node("where", cond, t.lift(a), t.lift(b))
 
@@ -567,36 +692,76 @@ def _domain_points(config, ndraw, n, rng):
     return X
 
 
-def trace_integrand(fn, config, indexed=False, check_points=32, name=None, parameters=True):
+class _Weights(list):
+    """the `weights` output vector of the in-place form `integrand(var, weights, config)` (vegas/montecarlo.jl:140-141) during a trace:
+    N entries, zero until the closure stores into them (the reference hands the closure its reused buffer; an entry the closure
+    never writes is a zero weight here)"""
+
+    def __init__(self, n):
+        super().__init__([0.0] * n)
+
+    def __setitem__(self, i, v):
+        if isinstance(i, slice):
+            idx = range(*i.indices(len(self)))
+            vals = list(v) if isinstance(v, (list, tuple, np.ndarray)) else [v] * len(idx)
+            if len(vals) != len(idx):
+                raise TraceError("weights[%r] = a sequence of another length" % (i,))
+            for k, q in zip(idx, vals):
+                list.__setitem__(self, k, q)
+            return
+        try:
+            list.__setitem__(self, i, v)
+        except (IndexError, TypeError) as e:
+            raise TraceError("weights[%r]: %s (the vector has one entry per integrand, 0-based)" % (i, e))
+
+    def fill(self, v):
+        self[:] = v
+
+
+def _call_form(fn, arg, config, N, indexed, inplace, weights):
+    """one call of the closure in its form -> the list of N values (reference forms: main.jl:26-28)"""
+    if indexed:
+        return [fn(i, arg, config) for i in range(N)]
+    if inplace:
+        w = weights()
+        fn(arg, w, config)
+        return list(w)
+    outs = fn(arg, config)
+    if N == 1 and not isinstance(outs, (tuple, list)):
+        outs = (outs,)
+    return list(outs)
+
+
+def trace_integrand(fn, config, indexed=False, check_points=32, name=None, parameters=True, inplace=False):
     """Run the closure once on symbolic draws and return the Integrand (HIP C++ body + userdata) that computes the same thing;
     TraceError if it cannot be written out or if the written-out body and the closure disagree at random points of the domain.
     `parameters`: captured floats become userdata slots (module docstring) -- the body does not depend on their values.
 
-    fn(x, config) -> value | tuple of N values    (indexed=True: fn(idx, x, config) -> value, the reference's :mcmc form, idx 0-based)"""
-    if getattr(config, "ncomp", 1) != 1:
-        raise TraceError("complex weights are not traced")
+    fn(x, config) -> value | tuple of N values
+    indexed=True: fn(idx, x, config) -> value, the reference's :mcmc form (mcmc/montecarlo.jl:34-36), idx 0-based
+    inplace=True: fn(x, weights, config), the reference's `inplace = true` form (main.jl:26, vegas/montecarlo.jl:140-141,
+        vegas_mc/updates.jl:67-70): the closure stores `weights[i] = value`, 0-based; what it returns is ignored
+    Complex weights (Configuration(type=complex)): values may be complex combinations of draws (x[0] ** 2 * 1j); every weight is
+    written out as its (re, im) pair, w[2 i] and w[2 i + 1]."""
+    if indexed and inplace:
+        raise ValueError("the :mcmc form integrand(idx, var, config) has no in-place variant (main.jl:26-28)")
     if parameters:
         try:
-            return _trace_integrand(fn, config, indexed, check_points, name, True)
+            return _trace_integrand(fn, config, indexed, check_points, name, True, inplace)
         except TraceError:
             pass   # (a branch on a captured float, a parameter where Python wants a number): once more with the captured values as literals
-    return _trace_integrand(fn, config, indexed, check_points, name, False)
+    return _trace_integrand(fn, config, indexed, check_points, name, False, inplace)
 
 
-def _trace_integrand(fn, config, indexed, check_points, name, parameters):
+def _trace_integrand(fn, config, indexed, check_points, name, parameters, inplace=False):
     pools, ndraw = _pools(config)
     t = _Trace()
     arg = _argument(pools, lambda k: t.node("x", k))
     N = config.N
+    nc = getattr(config, "ncomp", 1)
     sfn = _parametrized(fn, t) if parameters else fn
     try:
-        if indexed:
-            outs = [sfn(i, arg, config) for i in range(N)]
-        else:
-            outs = sfn(arg, config)
-            if N == 1 and not isinstance(outs, (tuple, list)):
-                outs = (outs,)
-            outs = list(outs)
+        outs = _call_form(sfn, arg, config, N, indexed, inplace, lambda: _Weights(N))
     except TraceError:
         raise
     except Exception as e:   # whatever else the closure does with a symbol that a float would have survived
@@ -607,6 +772,12 @@ def _trace_integrand(fn, config, indexed, check_points, name, parameters):
     for o in outs:
         if isinstance(o, np.ndarray) and o.size == 1:
             o = o.reshape(-1)[0]
+        if nc == 2:
+            o = CSym.of(o)
+            syms += [t.lift(o.re), t.lift(o.im)]
+            continue
+        if isinstance(o, CSym) or isinstance(o, (complex, np.complexfloating)):
+            raise TraceError("a complex weight in a real configuration (Configuration(type=complex) makes the weights complex)")
         if not isinstance(o, Sym):
             o = t.const(o)
         syms.append(o)
@@ -615,30 +786,29 @@ def _trace_integrand(fn, config, indexed, check_points, name, parameters):
     if check_points:
         rng = np.random.default_rng(12345)
         X = _domain_points(config, ndraw, check_points, rng)
-        ref = np.empty((N, check_points))
+        ref = np.empty((N * nc, check_points))
         try:
             with np.errstate(all="ignore"):
                 for p in range(check_points):   # the closure on one sample at a time: plain floats where the trace had symbols
                     num = _argument(pools, lambda k: X[k, p])
                     num = tuple(a.astype(np.float64) for a in num) if isinstance(num, tuple) else num.astype(np.float64)
-                    if indexed:
-                        r = [fn(i, num, config) for i in range(N)]
-                    else:
-                        r = fn(num, config)
-                        if N == 1 and not isinstance(r, (tuple, list)):
-                            r = (r,)
+                    r = _call_form(fn, num, config, N, indexed, inplace, lambda: np.zeros(N, dtype=complex if nc == 2 else float))
                     for i in range(N):
-                        ref[i, p] = float(np.asarray(r[i], dtype=np.float64).reshape(-1)[0])
+                        if nc == 2:
+                            z = complex(np.asarray(r[i], dtype=np.complex128).reshape(-1)[0])
+                            ref[2 * i, p], ref[2 * i + 1, p] = z.real, z.imag
+                        else:
+                            ref[i, p] = float(np.asarray(r[i], dtype=np.float64).reshape(-1)[0])
         except Exception as e:
             raise TraceError("the closure does not run on numeric draws (%s: %s)" % (type(e).__name__, e))
         got = evaluate(syms, X, params=t.params)
-        for i in range(N):
+        for i in range(N * nc):
             r = ref[i]
             ok = np.isfinite(r) & np.isfinite(got[i])
             if not np.array_equal(np.isfinite(r), np.isfinite(got[i])) or not np.allclose(got[i][ok], r[ok], rtol=1e-10, atol=1e-290):
                 raise TraceError("the traced expression and the closure disagree on integrand %d: the closure is not a pure "
                                  "function of its draws (hidden state, a branch the trace did not see, numpy arithmetic on "
-                                 "comparisons that means something else than the same arithmetic on 0.0 / 1.0)" % i)
+                                 "comparisons that means something else than the same arithmetic on 0.0 / 1.0)" % (i // nc))
     return Integrand(body, ud or None, name=name or getattr(fn, "__name__", "traced"))
 
 

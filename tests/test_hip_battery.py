@@ -498,14 +498,14 @@ def test_python_closure_as_measure_under_the_chain_solvers_matches_device_source
         for mf, nchain, block in ((1, 16, 16), (3, 1, 4)):
             kw = dict(dof=[[2], [3]], obs=[0.0, [0.0, 0.0]], solver=solver, neval=2e4, niter=3, seed=77, nchain=nchain, block=block, measurefreq=mf)
             b = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), measure=dev, **kw)
-            for m in (sphere3_measure, sphere3_measure5):
-                a = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), measure=m, **kw)
+            for m in (sphere3_measure, sphere3_measure5):   # (measure_form: either form under either solver -- the engine's extension; by default the solver decides)
+                a = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), measure=m, measure_form="indexed" if m is sphere3_measure5 else "plain", **kw)
                 np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-9, err_msg="%s mf=%d nchain=%d %s" % (solver, mf, nchain, m.__name__))
                 np.testing.assert_allclose(a.iter_std, b.iter_std, rtol=1e-6)
                 assert a.mean[1][1] == pytest.approx(2.0 * a.mean[1][0], rel=1e-9)
         # everything user-side on the host: one launch + one integrand callback per Markov step, the measure after the launch
         kw = dict(dof=[[2], [3]], obs=[0.0, [0.0, 0.0]], solver=solver, neval=8e3, niter=2, seed=5, nchain=16, measurefreq=2)
-        c = integrate(f2, var=Continuous(0.0, 1.0), measure=sphere3_measure, **kw)
+        c = integrate(f2, var=Continuous(0.0, 1.0), measure=sphere3_measure, integrand_form="plain", measure_form="plain", **kw)
         d = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), measure=dev, **kw)
         np.testing.assert_allclose(c.iter_mean, d.iter_mean, rtol=1e-9)
     # a measure that reads the configuration: histogram of x[0] in two bins, weight of the one integrand (several pools, a Discrete)
@@ -516,7 +516,7 @@ def test_python_closure_as_measure_under_the_chain_solvers_matches_device_source
     devb = mci.Measure("obs_add(x[0] < 0.5 ? 0 : 1, rw[0]);")
     for solver in ("vegasmc", "mcmc", "vegas"):
         kw = dict(dof=[[1, 1]], obs=[[0.0, 0.0]], solver=solver, neval=2e4, niter=3, seed=9)
-        a = integrate("return x[0] * x[1];", var=(Continuous(0.0, 1.0), Discrete(1, 3)), measure=binned, **kw)
+        a = integrate("return x[0] * x[1];", var=(Continuous(0.0, 1.0), Discrete(1, 3)), measure=binned, measure_form="plain", **kw)
         b = integrate("return x[0] * x[1];", var=(Continuous(0.0, 1.0), Discrete(1, 3)), measure=devb, **kw)
         np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-9)
     assert a.mean[0][0] == pytest.approx(0.75, abs=5 * a.stdev[0][0] + 1e-3) and a.mean[0][1] == pytest.approx(2.25, abs=5 * a.stdev[0][1] + 1e-3)
@@ -576,8 +576,8 @@ def test_python_closure_under_mcmc_matches_device_source(closure_path):
         return (r2 < 1.0) * 1.0
     f2 = lambda X, c: ((X[0] ** 2 + X[1] ** 2 < 1.0) * 1.0, (X[0] ** 2 + X[1] ** 2 + X[2] ** 2 < 1.0) * 1.0)
     d = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), **kw)
-    for f in (f3, f2):
-        a = integrate(f, var=Continuous(0.0, 1.0), **kw)
+    for f in (f3, f2):   # (f3 is what :mcmc calls; the tuple form runs under it when asked for: integrand_form)
+        a = integrate(f, var=Continuous(0.0, 1.0), integrand_form="indexed" if f is f3 else "plain", **kw)
         np.testing.assert_allclose(a.iter_mean, d.iter_mean, rtol=1e-9)
         np.testing.assert_allclose(a.iter_std, d.iter_std, rtol=1e-6)
         pa, aa = a.config._engine.acceptance()
@@ -592,8 +592,46 @@ def test_python_closure_under_mcmc_matches_device_source(closure_path):
     ds = integrate("return (x[0] * x[0] + x[1] * x[1] < 1.0) ? x[2] : 0.0;", **kw)
     np.testing.assert_allclose(h.iter_mean, ds.iter_mean, rtol=1e-9)
     # the three-argument form under the other solvers: the library asks it for every integrand in turn
-    v = integrate(f3, var=Continuous(0.0, 1.0), dof=[[2], [3]], neval=1e5, solver="vegas", seed=2)
+    v = integrate(f3, var=Continuous(0.0, 1.0), dof=[[2], [3]], neval=1e5, solver="vegas", seed=2, integrand_form="indexed")
     check(v, [PI / 4.0, 4.0 * PI / 3.0 / 8])
+
+
+def _volume_inverse(d):          # test/montecarlo.jl:205-208
+    return (d / (2 * PI * math.e)) ** (d / 2) * math.sqrt(d) * math.sqrt(PI)
+
+
+@pytest.mark.parametrize("alg,neval", [("vegas", 200000), ("vegasmc", 100000)])
+def test_inplace_closures_of_the_references_battery(alg, neval, closure_path):
+    """The reference's own two in-place battery members as CLOSURES, called as integrate(f; ..., inplace=true) calls them
+    (main.jl:26, vegas/montecarlo.jl:140-141, vegas_mc/updates.jl:67-70): TestComplex2_inplace (test/montecarlo.jl:187-196; run at :330,
+    :380) and TestHyperSphere (:204-216; run at :333, :383) -- traced into the kernel and on the host batch-callback path, each equal to
+    its device-source twin iteration by iteration (same draws, same arithmetic: 1e-9) and inside the reference's 7 sigma."""
+    def integrand(x, f, c):                        # test/montecarlo.jl:188-192 (0-based)
+        f[0] = x[0]
+        f[1] = x[0] ** 2 * 1j
+    kw = dict(dof=[[1], [1]], neval=neval, print=-1, type=complex, solver=alg, debug=True, seed=111)
+    res = integrate(integrand, inplace=True, **kw)
+    twin = integrate("w[0] = x[0]; w[1] = 0.0; w[2] = 0.0; w[3] = x[0] * x[0];", **kw)
+    assert isinstance(res.config._engine.integrand, mci.Integrand if closure_path == "traced" else mci.HostIntegrand)
+    np.testing.assert_allclose(res.iter_mean, twin.iter_mean, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res.iter_std, twin.iter_std, rtol=1e-6, atol=1e-12)
+    check_complex(res, [0.5, 1j / 3])
+
+    def f(x, w, c):                                # test/montecarlo.jl:210-216
+        _w = x[0] ** 2
+        for i in range(c.userdata):
+            _w = _w + x[i + 1] ** 2
+            w[i] = np.where(_w < 1.0, _volume_inverse(i + 2), 0.0)
+    N = 3
+    kw = dict(dof=[[i + 2] for i in range(N)], neval=neval, print=-1, solver=alg, debug=False, seed=18)
+    res = integrate(f, var=Continuous(-1, 1), userdata=N, inplace=True, **kw)
+    twin = integrate(mci.catalog.hypersphere(N), var=Continuous(-1, 1), **kw)
+    np.testing.assert_allclose(res.iter_mean, twin.iter_mean, rtol=1e-9)
+    np.testing.assert_allclose(res.iter_std, twin.iter_std, rtol=1e-6)
+    check(res, [0.9230, 0.94724, 0.96118])
+    # the flag decides, not the parameter count: the same closures without inplace=true are a TypeError, not another form
+    with pytest.raises(TypeError, match="inplace"):
+        integrate(f, var=Continuous(-1, 1), userdata=N, **kw)
 
 
 def test_python_closure_under_the_default_solver_matches_device_source(closure_path):

@@ -39,7 +39,8 @@ def test_a_parameter_sweep_over_a_closure_runs_on_one_code_object():
 @pytest.mark.parametrize("solver", ["vegas", "vegasmc", "mcmc"])
 def test_traced_two_integrand_closure_with_a_select(solver):
     g = lambda x, c: (x[0] ** 2 + x[1] ** 2, mci.trace.where(x[0] > 0.5, x[1], 0.0))
-    r = mci.integrate(g, var=mci.Continuous(0.0, 1.0), dof=[[2], [2]], solver=solver, neval=200000, niter=10, seed=7, trace=True, print=-1)
+    r = mci.integrate(g, var=mci.Continuous(0.0, 1.0), dof=[[2], [2]], solver=solver, neval=200000, niter=10, seed=7, trace=True, print=-1,
+                      integrand_form="plain")      # (:mcmc calls integrand(idx, var, config) by default; the tuple form runs under it when asked for)
     assert abs(r.mean[0] - 2.0 / 3.0) < 5 * r.stdev[0] and abs(r.mean[1] - 0.25) < 5 * r.stdev[1]
     assert r.stdev[0] < 0.02 and r.stdev[1] < 0.02
 
@@ -65,7 +66,8 @@ def test_traced_measure_closures_match_device_source_measures():
         # (explicit chain count: the automatic one follows the kernel's workgroup size, which may differ between two measure bodies)
         kw = dict(dof=[[2], [3]], obs=[0.0, [0.0, 0.0]], solver=solver, neval=4e4, niter=6, seed=77, measurefreq=2, print=-1,
                   **({} if solver == "vegas" else dict(nchain=16, block=16)))
-        a = mci.integrate(mci.catalog.sphere2(), var=mci.Continuous(0.0, 1.0), measure=m, trace=True, **kw)
+        a = mci.integrate(mci.catalog.sphere2(), var=mci.Continuous(0.0, 1.0), measure=m, trace=True,
+                          measure_form="indexed" if m is sphere3_measure5 else "plain", **kw)
         b = mci.integrate(mci.catalog.sphere2(), var=mci.Continuous(0.0, 1.0), measure=dev, **kw)
         for r in (a, b):
             got = np.array([r.mean[0], r.mean[1][0], r.mean[1][1]], dtype=np.float64).ravel()
@@ -82,6 +84,6 @@ def test_traced_measure_closures_match_device_source_measures():
     for solver in ("vegas", "vegasmc", "mcmc"):
         kw = dict(dof=[[1, 1]], obs=[[0.0, 0.0]], solver=solver, neval=4e4, niter=6, seed=9, print=-1,
                   **({} if solver == "vegas" else dict(nchain=16, block=16)))
-        a = mci.integrate("return x[0] * x[1];", var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3)), measure=binned, trace=True, **kw)
+        a = mci.integrate("return x[0] * x[1];", var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3)), measure=binned, trace=True, measure_form="plain", **kw)
         got, err = np.ravel(a.mean).astype(np.float64), np.ravel(a.stdev).astype(np.float64)
         assert np.all(np.abs(got - [0.75, 2.25]) < 6 * err + 0.02) and np.all(err < 0.3), (solver, got, err)     # (1 + 2 + 3) * int x dx over [0, .5) | [.5, 1)

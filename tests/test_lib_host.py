@@ -242,10 +242,9 @@ def test_lineage_sums_are_the_scatter_of_the_blocks_weighted_averages():
     assert not hasattr(split, "_sum_ranks") and split.with_ignore(3).stdev == r3.stdev   # local: no communicator, no engine
 
 
-def test_closure_form_is_decided_by_parameters_without_defaults():
-    """integrate() tells the reference's two callback forms apart by their REQUIRED positional parameters
-    (`integrand(var, config)` vegas/montecarlo.jl:140-144 | `integrand(idx, var, config)` mcmc/montecarlo.jl:34-36; `measure` with
-    four | five): a defaulted or keyword-only extra parameter must not turn a plain closure into the indexed form."""
+def test_closure_parameter_count_ignores_parameters_with_defaults():
+    """integrate() decides a closure's form by solver + `inplace` like the reference (tests/test_callback_forms.py); the closure's
+    REQUIRED positional parameters are the cross-check: a defaulted or keyword-only extra parameter is the closure's own business."""
     from mcintegration_jl_amd.integrate import required_positionals as rp
     assert rp(lambda x, config: 0, 2) == 2
     assert rp(lambda x, config, scale=2.0: 0, 2) == 2            # was counted as three: f would have been called as f(idx, x, config)

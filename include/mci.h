@@ -354,6 +354,14 @@ int mci_set_chain_speculation(mci_problem *prob, int32_t lanes, double accept, i
  * the holding times IT measured (it is long enough for its own holds), and from the first accepted launch on nothing is repeated or
  * left out again -- the selection acts on the warm-up only, never on a counted iteration's value. */
 int mci_last_integrate_discarded(const mci_problem *prob, int64_t *neval, int32_t *launches);
+/* A several-lanes-per-chain code object proves itself before it is trusted: the first launch through one that has never run on a device
+ * (a fresh compile, a pre-filled cache entry) is preceded by <= 2 blocks x <= 512 steps through it AND through the lane-per-chain kernel
+ * of the same problem -- both step the reference's chain (vegas_mc/montecarlo.jl:198-211, mcmc/montecarlo.jl:134-172) on the same streams --
+ * and their packed buffers are compared (statistics 1e-9, histograms and propose / accept tables 1e-8).  status: 0 nothing launched yet,
+ * 1 verified (now, or earlier: a marker file next to the code object in the kernel cache), -1 the check FAILED -- a miscompiled code
+ * object; one warning on stderr, and this problem keeps one lane per chain --, -2 the unit did not compile (automatic lanes: one lane per
+ * chain; forced lanes: MCI_ERR_COMPILE).  solver: MCI_VEGASMC | MCI_MCMC. */
+int mci_chain_speculation_status(const mci_problem *prob, int32_t solver, int32_t *status);
 /* lanes per chain of the last chain-solver launch (1: one lane per chain) and the accept levels of its tree */
 int mci_last_chain_speculation(const mci_problem *prob, int32_t *lanes, int32_t *max_accepts);
 /* the tree mci_set_chain_speculation(lanes, accept, max_accepts) stands for, node by node ([lanes] each; NULL: not wanted): the step

@@ -112,6 +112,7 @@ SIGNATURES = [
     ("mci_last_chain_launch", C.c_int, [_VP, C.POINTER(C.c_int64), c_int32_p]),
     ("mci_set_chain_speculation", C.c_int, [_VP, C.c_int32, C.c_double, C.c_int32]),
     ("mci_last_chain_speculation", C.c_int, [_VP, c_int32_p, c_int32_p]),
+    ("mci_chain_speculation_status", C.c_int, [_VP, C.c_int32, c_int32_p]),
     ("mci_last_integrate_discarded", C.c_int, [_VP, C.POINTER(C.c_int64), c_int32_p]),
     ("mci_speculation_tree", C.c_int, [C.c_int32, C.c_double, C.c_int32, c_int32_p, c_int32_p, c_int32_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("mci_compile_chain_speculation", C.c_int, [_VP, C.c_int32]),
@@ -146,6 +147,7 @@ DEBUG_SIGNATURES = [
     ("mci_debug_plant_wrong_decision", C.c_int, [_VP, C.c_int32]),
     ("mci_debug_persist_spin_ticks", C.c_int, [_VP, C.c_uint64]),
     ("mci_debug_override", C.c_int, [C.c_char_p, C.c_int64, C.c_int32]),
+    ("mci_debug_compiler_id", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32]),
     ("mci_debug_mcmc_policy", C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
 ]
 

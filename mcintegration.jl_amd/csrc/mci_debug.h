@@ -28,9 +28,14 @@ int mci_debug_persist_spin_ticks(mci_problem *prob, unsigned long long ticks);
  *   train_walk      0 | 1 | 2  = mci_set_train_walk on every new problem
  *   fresh_floors    n        (consulted per launch) length of automatic :vegasmc chains that start afresh, in burn-in floors (8)
  *   fresh_burnin_pct n       (per launch) ... and the least part of such a chain that is not measured, in per cent (profiles/r05_bias.txt A5)
+ *   spec_self_check  0 | 1   (per launch) the self-check of a several-lanes-per-chain code object (mci_chain_speculation_status): never |
+ *                            also when the kernel cache holds the marker of an earlier pass (the guard test of tests/test_hip_spec.py)
  * (The library reads two environment variables and no others: MCI_KERNEL_CACHE -- the directory code objects are cached in -- and
  * MCI_JIT_FLAGS -- extra hiprtc options; INTEGRATION.md.) */
 int mci_debug_override(const char *key, int64_t value, int32_t on);
+/* what mci_jit.h puts into the kernel-cache key for "which compiler made this code object" (hiprtc version, the files of libhiprtc and
+ * libamd_comgr, the target): set != NULL overrides it for this process ("" takes the override back); out: the identity in force */
+int mci_debug_compiler_id(const char *set, char *out, int32_t n);
 /* the constants of the automatic :mcmc chain length (DESIGN.md "Chains"), process-wide, for A/B campaigns (tools/mcmc_policy.py): measured
  * steps of a first launch (4096) | how much longer than the chains that measured the holds a launch's chains may be (2) | length of a
  * carried chain in longest holds (4) | its minimum in half burn-in floors (2); <= 0 keeps a value */

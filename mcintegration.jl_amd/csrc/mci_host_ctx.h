@@ -4,7 +4,7 @@
 const char *mci_last_error(void) { return g_err.c_str(); }
 // "mci-hip <abi>.<revision>": <abi> changes whenever a struct of include/mci.h changes its layout (mci_result grew `correlated` and
 // `warmup` in ABI 4; ABI 5 adds entry points only) -- a caller built against another header compares it before passing structs
-const char *mci_version(void) { return "mci-hip 5.0 (gfx950)"; }
+const char *mci_version(void) { return "mci-hip 6.0 (gfx950)"; }
 int32_t mci_abi_version(void) { return 5; }
 
 int mci_device_count(int32_t *count) {

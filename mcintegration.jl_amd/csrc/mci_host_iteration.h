@@ -69,7 +69,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         if (nchain > nevalperblock) return fail(MCI_ERR_INVALID, "nchain=%lld exceeds the %lld steps of a block", (long long)nchain, (long long)nevalperblock);
         // (carried chains keep the reference's own `ne >= neval/100` only, vegas_mc/montecarlo.jl:213)
         burnin = mci_chain_burnin(nevalperblock / nchain, (may_carry && nchain > 1) ? 1 : nchain, nslots);
-        if (g_over.fresh_burnin_pct.on && !may_carry && nchain > 1 && auto_chains) { // (experiment: tools/run_r05_floors.sh)
+        if (g_over.fresh_burnin_pct.on && !may_carry && nchain > 1 && auto_chains) { // (experiment: tools/run_batch.sh r05_floors)
             const double b = (double)(nevalperblock / nchain) * (double)g_over.fresh_burnin_pct.v / 100.0;
             if (b > burnin) burnin = b;
         }
@@ -126,9 +126,24 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         }
     }
     int T_launch = T;
+    if (G > 1 && p->spec_state[solver - 1] < 0) G = 1; // (its code object failed its self-check, or did not compile: one lane per chain)
+    if (G > 1) {
+        rc = compile_spec(p, solver);
+        if (rc == MCI_ERR_COMPILE && p->spec_lanes == -1) {
+            // automatic lanes: a unit that does not compile (up to 512 VGPRs, many bpermutes; a backend switch a later compiler may
+            // refuse) must not take the solver down with it -- the lane-per-chain kernel steps the same chains
+            fprintf(stderr, "mci: the several-lanes-per-chain kernel of this problem did not compile; one lane per chain instead\n%s\n", mci_last_error());
+            p->spec_state[solver - 1] = -2;
+            G = 1;
+        } else if (rc) return rc;
+    }
+    if (G > 1 && !p->in_self_check && ((p->spec_need_check[solver - 1] && !(g_over.spec_self_check.on && g_over.spec_self_check.v == 0)) ||
+                                       (g_over.spec_self_check.on && g_over.spec_self_check.v == 1 && p->spec_state[solver - 1] == 0))) {
+        if ((rc = spec_self_check(p, solver, G, nevalperblock, block_lo, block_hi, iteration, seed, measurefreq, thermal_ratio))) return rc;
+        if (p->spec_state[solver - 1] < 0) G = 1;
+    }
     if (G > 1) {
         // the trees: the one built for the acceptance that was given, else the solver's family (spec_upload)
-        if ((rc = compile_spec(p, solver))) return rc;
         if ((rc = spec_upload(p, solver, G, p->spec_accept, p->spec_maxacc))) return rc;
         spec_maxacc = p->spec_tab_maxacc;
         units = nchain * G;

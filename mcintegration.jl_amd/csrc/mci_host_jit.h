@@ -232,13 +232,121 @@ static int compile_spec(mci_problem *p, int solver) {
             if (p->shape.obs_bin_draw[i] < 0 && p->shape.obs_nbin[i] != p->shape.ncomp)
                 return fail(MCI_ERR_INVALID, "the default measure can only handle observable as Vector with %d scalar elements!", p->ni);
     p->shape.det = 0;
-    Candidate c;
+    Candidate c, lane;
     c.src = mcijit::generate_source(p->shape, solver, mcijit::kUnitSpec);
     c.threads = 256; // (a launch of few chains runs one wave per SIMD: up to 512 registers per lane)
-    c.rc = mcijit::compile(c.src, c.threads, c.code, c.log, c.cached, &c.path, mcijit::kHdrSpec);
+    // In the cache, with the marker of a passed self-check next to it: nothing else to do.  Otherwise the lane-per-chain unit the check
+    // compares it with is compiled NEXT to it (hiprtc is re-entrant): the check costs the slower of the two compilations, not their sum.
+    const bool cached = mcijit::compile(c.src, c.threads, c.code, c.log, c.cached, &c.path, mcijit::kHdrSpec, /*cache_only=*/true) == 0;
+    const bool verified = cached && access((c.path + ".ok").c_str(), F_OK) == 0;
+    std::thread side;
+    if (!verified && !p->compiled[solver] && !p->ctx->offline && !(g_over.spec_self_check.on && g_over.spec_self_check.v == 0)) {
+        lane.src = mcijit::generate_source(p->shape, solver, mcijit::kUnitSolver);
+        lane.threads = p->threads;
+        side = std::thread([&lane] { lane.rc = mcijit::compile(lane.src, lane.threads, lane.code, lane.log, lane.cached, &lane.path); });
+    }
+    if (!cached) {
+        c.rc = mcijit::compile(c.src, c.threads, c.code, c.log, c.cached, &c.path, mcijit::kHdrSpec);
+        if (c.rc == 2) {
+            // (the unit is built with a backend switch, mci_jit.h: a compiler that does not know it any more gets the unit without it --
+            // the self-check below is what stands between such an object and the user's histogram)
+            std::string log2;
+            Candidate d;
+            d.src = c.src;
+            d.threads = c.threads;
+            d.rc = mcijit::compile(d.src, d.threads, d.code, log2, d.cached, &d.path, mcijit::kHdrSpec, false, /*no_exec_mask_flag=*/true);
+            if (d.rc == 0) {
+                d.log = c.log;
+                c = std::move(d);
+            }
+        }
+    }
+    if (side.joinable()) side.join();
     if (c.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", c.log.c_str());
     if (int rc = load_slot(p, slot, c, p->lds_bytes)) return rc;
     p->compiled[slot] = true;
+    p->spec_need_check[solver - 1] = !verified;
+    if (verified && p->spec_state[solver - 1] == 0) p->spec_state[solver - 1] = 1;
+    return MCI_OK;
+}
+
+// A NEW several-lanes-per-chain code object proves itself before it is trusted.  Every user integrand is a new translation unit, and
+// one of ~1000 campaign layouts came out of ROCm 7.2's compiler with the right chains and its histogram adds in the wrong bins
+// (profiles/r05_fuzz.txt: right estimates, a map adapting to noise, no error).  Both chain kernels of a problem are product kernels and
+// step the SAME chain (same (chain, step)-addressed uniforms; nchain = 1 is the reference's chain, vegas_mc/montecarlo.jl:198-211), so
+// the first launch through a code object without a marker is preceded by <= 2 blocks x <= 512 steps through it and through the
+// lane-per-chain kernel, and the two packed buffers are compared: statistics to 1e-9, histogram and propose / accept tables to 1e-8
+// (relative to the larger entry, with the section's largest entry as the floor).  Agreement: a marker file next to the code object,
+// never checked again.  Disagreement: one warning, status -1, and the problem keeps one lane per chain.  The launch that triggered
+// the check then runs as if nothing had happened: everything a launch leaves behind on the host side is put back.
+static int spec_self_check(mci_problem *p, int solver, int G, int64_t nevalperblock, int64_t block_lo, int64_t block_hi, int32_t iteration,
+                           uint64_t seed, int64_t measurefreq, double thermal_ratio) {
+    const int slot = solver == MCI_VEGASMC ? kSlotVegasmcSpec : kSlotMcmcSpec;
+    const int64_t nb = block_hi - block_lo < 2 ? block_hi - block_lo : 2, npb = nevalperblock < 512 ? nevalperblock : 512;
+    const int64_t mf = measurefreq * 4 <= npb ? measurefreq : 1;
+    struct Saved {
+        int spec_lanes, kernel_timing, chain_cur, chain_solver, chain_iteration, last_wg, last_threads, last_nblocks, last_spec_lanes, last_spec_maxacc, blk_carried;
+        bool chain_valid, last_carried, hold_measured, time_this_launch;
+        int64_t chain_lo, chain_hi, chain_nchain, chain_ntrain, last_samples, last_nchain, launches, blk_rows, blk_stride, blk_lo;
+    } sv = {p->spec_lanes, p->kernel_timing, p->chain_cur, p->chain_solver, p->chain_iteration, p->last_wg, p->last_threads, p->last_nblocks, p->last_spec_lanes,
+            p->last_spec_maxacc, p->blk_carried, p->chain_valid, p->last_carried, p->hold_measured, p->time_this_launch, p->chain_lo, p->chain_hi, p->chain_nchain,
+            p->chain_ntrain, p->last_samples, p->last_nchain, p->launches, p->blk_rows, p->blk_stride, p->blk_lo};
+    int rc = flush_merge(p);
+    if (rc) return rc;
+    int h_status[4] = {0, 0, 0, 0};
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    HIPCHK(hipMemcpy(h_status, p->d_status, sizeof(h_status), hipMemcpyDeviceToHost));
+    std::vector<double> got[2];
+    p->in_self_check = true;
+    p->kernel_timing = 0;
+    for (int pass = 0; pass < 2 && !rc; ++pass) {
+        p->spec_lanes = pass == 0 ? G : 1;
+        got[pass].assign((size_t)p->packed_n, 0.0);
+        rc = mci_iteration_run(p, solver, npb, block_lo, block_lo + nb, iteration, seed, mf, 1, thermal_ratio);
+        if (!rc) rc = mci_get_packed(p, got[pass].data(), p->packed_n); // (merges the launch and waits for it)
+    }
+    p->in_self_check = false;
+    p->spec_lanes = sv.spec_lanes; p->kernel_timing = sv.kernel_timing; p->chain_cur = sv.chain_cur; p->chain_solver = sv.chain_solver;
+    p->chain_iteration = sv.chain_iteration; p->last_wg = sv.last_wg; p->last_threads = sv.last_threads; p->last_nblocks = sv.last_nblocks;
+    p->last_spec_lanes = sv.last_spec_lanes; p->last_spec_maxacc = sv.last_spec_maxacc; p->blk_carried = sv.blk_carried; p->chain_valid = sv.chain_valid;
+    p->last_carried = sv.last_carried; p->hold_measured = sv.hold_measured; p->time_this_launch = sv.time_this_launch; p->chain_lo = sv.chain_lo;
+    p->chain_hi = sv.chain_hi; p->chain_nchain = sv.chain_nchain; p->chain_ntrain = sv.chain_ntrain; p->last_samples = sv.last_samples;
+    p->last_nchain = sv.last_nchain; p->launches = sv.launches; p->blk_rows = sv.blk_rows; p->blk_stride = sv.blk_stride; p->blk_lo = sv.blk_lo;
+    if (p->d_status) (void)hipMemcpy(p->d_status, h_status, sizeof(h_status), hipMemcpyHostToDevice); // (what the two small launches flagged is theirs)
+    if (rc) return rc;
+    const size_t nstat = (size_t)(2 * p->shape.nobs + 2 + p->ni + 1);
+    double worst = 0.0;
+    long bad = 0, first_bad = -1;
+    for (int sec = 0; sec < 2; ++sec) {
+        const size_t lo = sec ? nstat : 0, hi = sec ? (size_t)p->packed_n : nstat;
+        const double tol = sec ? 1e-8 : 1e-9;
+        double top = 0.0;
+        for (size_t i = lo; i < hi; ++i) top = std::fmax(top, std::fmax(std::fabs(got[0][i]), std::fabs(got[1][i])));
+        for (size_t i = lo; i < hi; ++i) {
+            const double a = got[0][i], b = got[1][i];
+            const double d = std::fabs(a - b), lim = tol * (std::fmax(std::fabs(a), std::fabs(b)) + 1e-3 * top);
+            const bool ok = (std::isfinite(a) && std::isfinite(b)) ? d <= lim : (std::isnan(a) == std::isnan(b) && (std::isnan(a) || a == b));
+            if (!ok) {
+                if (first_bad < 0) first_bad = (long)i;
+                ++bad;
+                if (top > 0.0 && d / top > worst) worst = d / top;
+            }
+        }
+    }
+    p->spec_need_check[solver - 1] = false;
+    if (bad == 0) {
+        p->spec_state[solver - 1] = 1;
+        if (FILE *f = fopen((p->code_object[slot] + ".ok").c_str(), "w")) { // (the marker: this code object has reproduced the lane-per-chain kernel on a device)
+            fprintf(f, "%s\n", mcijit::compiler_id().c_str());
+            fclose(f);
+        }
+        return MCI_OK;
+    }
+    p->spec_state[solver - 1] = -1;
+    fprintf(stderr, "mci: the several-lanes-per-chain kernel of this problem (%s, %s) does not reproduce its lane-per-chain kernel on a %lld-block, %lld-step "
+                    "check: %ld of %lld packed entries differ (first at %ld, largest difference %.3g of its section's maximum).  A miscompiled code object -- "
+                    "this problem keeps one lane per chain (same chains, slower for launches of few chains); mci_chain_speculation_status reports -1.\n",
+            solver == MCI_VEGASMC ? ":vegasmc" : ":mcmc", p->code_object[slot].c_str(), (long long)nb, (long long)npb, bad, (long long)p->packed_n, first_bad, worst);
     return MCI_OK;
 }
 
@@ -348,6 +456,12 @@ int mci_last_integrate_discarded(const mci_problem *p, int64_t *neval, int32_t *
     return MCI_OK;
 }
 
+int mci_chain_speculation_status(const mci_problem *p, int32_t solver, int32_t *status) {
+    if (!p || !status || (solver != MCI_VEGASMC && solver != MCI_MCMC)) return fail(MCI_ERR_INVALID, "solver MCI_VEGASMC or MCI_MCMC");
+    *status = p->spec_state[solver - 1];
+    return MCI_OK;
+}
+
 int mci_last_chain_speculation(const mci_problem *p, int32_t *lanes, int32_t *max_accepts) {
     if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
     if (lanes) *lanes = p->last_spec_lanes;
@@ -438,6 +552,12 @@ int mci_debug_override(const char *key, int64_t value, int32_t on) {
     if (!o) return fail(MCI_ERR_INVALID, "no such override: %s", key ? key : "(null)");
     o->on = on != 0;
     o->v = value;
+    return MCI_OK;
+}
+
+int mci_debug_compiler_id(const char *set, char *out, int32_t n) {
+    if (set) mcijit::compiler_id_override() = set; // ("" takes the override back)
+    if (out && n > 0) snprintf(out, (size_t)n, "%s", mcijit::compiler_id().c_str());
     return MCI_OK;
 }
 

@@ -109,6 +109,14 @@ struct mci_problem {
     float spec_accepts[8] = {};          // the acceptance each of them was built for
     double spec_tab_accept = -1.0;
     int last_spec_lanes = 1, last_spec_maxacc = 0; // of the last chain launch (1: one lane per chain)
+    // A several-lanes-per-chain code object proves itself before it is trusted (mci_host_jit.h spec_self_check): until a code object has
+    // reproduced the lane-per-chain kernel's packed sums on THIS device (a marker file next to it in the kernel cache remembers that it did),
+    // its first launch is preceded by a two-block, 512-step run through both kernels.  [0] :vegasmc, [1] :mcmc --
+    // spec_state: 0 not looked at yet, 1 verified, -1 the check failed (one lane per chain from now on), -2 the unit did not compile
+    // (automatic lanes: one lane per chain from now on)
+    int spec_state[2] = {0, 0};
+    bool spec_need_check[2] = {false, false}; // the loaded code object has no marker yet
+    bool in_self_check = false;
     int64_t last_discarded_neval = 0;              // evaluations of the warm-up launches the last mci_integrate ran again instead of counting
     int32_t last_discarded_launches = 0;
     static const int64_t kSpecFill = 65536;        // lanes a launch of few chains spreads over: one wave on each of the 1024 SIMDs
@@ -294,7 +302,7 @@ int64_t mci_problem::kMcmcCarryHalfFloors = 2;
 // are cached) and MCI_JIT_FLAGS (extra hiprtc options), mci_jit.h.
 namespace {
 struct Override { bool on = false; int64_t v = 0; };
-struct Overrides { Override table_mode, hist_tile_bins, no_split_all, l1_phase, train_walk, hist_copies, fresh_floors, fresh_burnin_pct; } g_over;
+struct Overrides { Override table_mode, hist_tile_bins, no_split_all, l1_phase, train_walk, hist_copies, fresh_floors, fresh_burnin_pct, spec_self_check; } g_over;
 Override *override_slot(const char *key) {
     if (!key) return nullptr;
     if (!strcmp(key, "table_mode")) return &g_over.table_mode;
@@ -305,6 +313,7 @@ Override *override_slot(const char *key) {
     if (!strcmp(key, "hist_copies")) return &g_over.hist_copies;
     if (!strcmp(key, "fresh_floors")) return &g_over.fresh_floors;
     if (!strcmp(key, "fresh_burnin_pct")) return &g_over.fresh_burnin_pct;
+    if (!strcmp(key, "spec_self_check")) return &g_over.spec_self_check;
     return nullptr;
 }
 } // namespace

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -275,6 +276,39 @@ inline std::string cache_dir() {
     return dir;
 }
 
+// Which compiler made a cached code object: hiprtc's version, the files of the hiprtc library and of the code-object manager next to it
+// (libamd_comgr holds the clang / LLVM that compiles -- name as resolved, which carries its version, and size) and the target.  Part of
+// the cache key: a ROCm upgrade (say, the fix of the pass the group units are compiled without) must not keep serving the old objects,
+// a downgrade must not serve objects of a compiler nothing here was tested with.  mci_debug_compiler_id overrides it for tests.
+inline std::string &compiler_id_override() {
+    static std::string s;
+    return s;
+}
+inline const std::string &compiler_id() {
+    static const std::string id = [] {
+        int maj = 0, min = 0;
+        (void)hiprtcVersion(&maj, &min);
+        std::string s = "hiprtc " + std::to_string(maj) + "." + std::to_string(min);
+        auto file_id = [](const std::string &path) {
+            char real[4096];
+            struct stat st;
+            if (!realpath(path.c_str(), real) || stat(real, &st) != 0) return std::string("?");
+            std::string r = real;
+            const size_t k = r.rfind('/');
+            return (k == std::string::npos ? r : r.substr(k + 1)) + ":" + std::to_string((long long)st.st_size);
+        };
+        Dl_info info;
+        if (dladdr((void *)&hiprtcVersion, &info) && info.dli_fname) {
+            const std::string lib = info.dli_fname;
+            s += " | " + file_id(lib);
+            const size_t k = lib.rfind('/');
+            s += " | " + file_id((k == std::string::npos ? std::string(".") : lib.substr(0, k)) + "/libamd_comgr.so");
+        }
+        return s + " | gfx950";
+    }();
+    return compiler_id_override().empty() ? id : compiler_id_override();
+}
+
 // hiprtc's first compile of a process loads the compiler (comgr, ~0.3 s on this image): mci_ctx_create starts it on a thread of its
 // own, next to the HIP runtime's own device initialisation, so that the first real compile finds it loaded
 struct WarmUp {
@@ -307,7 +341,7 @@ inline void warm_up_join() {
 
 // returns the gfx950 code object for `src`, from the on-disk cache or by compiling with hiprtc
 inline int compile(const std::string &src, int threads, std::vector<char> &code, std::string &log, bool &from_cache, std::string *cache_path = nullptr,
-                   int extra_hdr = kHdrNone, bool cache_only = false) {
+                   int extra_hdr = kHdrNone, bool cache_only = false, bool no_exec_mask_flag = false) {
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics",
                                      "-ffp-contract=off", "-DMCI_THREADS=" + std::to_string(threads)};
     // The several-lanes-per-chain units (mci_spec.h) are compiled WITHOUT the backend's pre-RA exec-mask optimisation.  One layout of the
@@ -316,11 +350,14 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
     // ONE machine pass, si-optimize-exec-masking-pre-ra on that kernel (right with the first 55582 passes, wrong from 55583 on:
     // profiles/r05_fuzz.txt, tools/repro_case.py 205).  The pass rewrites EXEC save / restore sequences, of which these kernels -- nested
     // divergent regions around wave-wide exchanges -- have hundreds; the lane-per-chain and :vegas units keep the default pipeline.
-    if (extra_hdr == kHdrSpec) {
+    // (MCI_JIT_FLAGS that names the switch itself decides it -- for every unit: the A/B of profiles/r06_ablation.txt, and the guard test
+    // that re-enables the pass to see the self-check of a new group code object trip, mci_host_jit.h spec_self_check)
+    const char *jf = getenv("MCI_JIT_FLAGS");
+    if (extra_hdr == kHdrSpec && !no_exec_mask_flag && !(jf && strstr(jf, "amdgpu-opt-exec-mask-pre-ra"))) {
         opts.push_back("-mllvm");
         opts.push_back("-amdgpu-opt-exec-mask-pre-ra=0");
     }
-    if (const char *e = getenv("MCI_JIT_FLAGS")) {
+    if (const char *e = jf) {
         std::istringstream is(e);
         std::string t;
         while (is >> t) opts.push_back(t);
@@ -329,6 +366,7 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
     if (extra_hdr == kHdrTrain) key += std::string("\n//HDR\n") + kTrainHeader;
     if (extra_hdr == kHdrSpec) key += std::string("\n//HDR\n") + kSpecHeader;
     for (auto &f : opts) key += "\n//" + f;
+    key += "\n//COMPILER " + compiler_id();
     char name[64];
     snprintf(name, sizeof name, "mci_%016llx.hsaco", (unsigned long long)fnv1a(key));
     const std::string dir = cache_dir(), path = dir + "/" + name;

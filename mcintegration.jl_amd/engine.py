@@ -477,6 +477,14 @@ class Engine:
         check(lib().mci_last_chain_speculation(self.p, C.byref(g), C.byref(m)))
         return int(g.value), int(m.value)
 
+    def chain_speculation_status(self, solver):
+        """the self-check of the solver's several-lanes-per-chain code object: 0 not launched yet, 1 verified against the lane-per-chain
+        kernel (now or by an earlier process: the marker in the kernel cache), -1 failed (this problem keeps one lane per chain), -2 did
+        not compile; see mci_chain_speculation_status"""
+        st = C.c_int32()
+        check(lib().mci_chain_speculation_status(self.p, _lib.SOLVERS[solver], C.byref(st)))
+        return int(st.value)
+
     def compile_chain_speculation(self, solver):
         """the several-lanes-per-chain kernel of "vegasmc" | "mcmc" (its own code object)"""
         check(lib().mci_compile_chain_speculation(self.p, _lib.SOLVERS[solver]))

@@ -236,3 +236,31 @@ def test_group_kernels_are_built_without_the_exec_mask_pass_that_miscompiled_one
         pytest.skip("this toolchain does not list its passes under -opt-bisect-limit")
     assert "si-optimize-exec-masking-pre-ra on function (mci_vegasmc_spec)" not in log
     assert "si-optimize-exec-masking on function (mci_vegasmc_spec)" in log    # (the post-RA pass of the default pipeline stays)
+
+
+def test_kernel_cache_is_keyed_by_the_compiler(tmp_path, monkeypatch):
+    """csrc/mci_jit.h: the cache key holds which compiler made the code object -- hiprtc's version, the files of libhiprtc and of
+    libamd_comgr (the clang / LLVM that compiles), the target -- so that a ROCm upgrade or downgrade never serves another compiler's
+    objects.  Two identities -> two file names for the same source; the same identity -> the cached file."""
+    import ctypes as C
+    from mcintegration_jl_amd._lib import lib
+    monkeypatch.setenv("MCI_KERNEL_CACHE", str(tmp_path))
+    buf = C.create_string_buffer(1024)
+    lib().mci_debug_compiler_id(None, buf, len(buf))
+    ident = buf.value.decode()
+    assert ident.startswith("hiprtc ") and "libhiprtc.so" in ident and "libamd_comgr.so" in ident and ident.endswith("gfx950"), ident
+    assert all(int(part.rsplit(":", 1)[1]) > 100000 for part in ident.split(" | ")[1:3]), ident      # (file sizes: the libraries were found)
+
+    def obj():
+        return _code_object(lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]]), mci.catalog.x2y2, None, "vegas")
+    try:
+        a = obj()
+        assert os.path.dirname(a) == str(tmp_path) and obj() == a
+        lib().mci_debug_compiler_id(b"hiprtc 7.3 | libhiprtc.so.7.3.70300:850000 | libamd_comgr.so.3.1.0:163000000 | gfx950", buf, len(buf))
+        b = obj()
+        lib().mci_debug_compiler_id(b"hiprtc 7.1 | libhiprtc.so.7.1.70100:840000 | libamd_comgr.so.2.9.0:161000000 | gfx950", buf, len(buf))
+        c = obj()
+        assert len({a, b, c}) == 3 and all(os.path.exists(q) for q in (a, b, c))
+    finally:
+        lib().mci_debug_compiler_id(b"", buf, len(buf))
+    assert buf.value.decode() == ident and obj() == a

@@ -7,6 +7,8 @@ the GPU suite runs its small chain launches through these kernels as well (autom
 lane-per-chain kernels under test at the same sizes."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -164,3 +166,64 @@ def test_the_campaign_case_the_compiler_got_wrong(oracle, monkeypatch):
     from layout_cases import check_carried_iterations
     monkeypatch.setenv("FUZZ_LANES", "1")
     check_carried_iterations(oracle, 205)
+
+
+def test_a_new_group_code_object_proves_itself_before_it_is_trusted(oracle, tmp_path, monkeypatch):
+    """mci_chain_speculation_status: the first launch through a several-lanes-per-chain code object that has never run on a device is
+    preceded by a 2-block, 512-step run through it and through the lane-per-chain kernel (both step the reference's chain,
+    vegas_mc/montecarlo.jl:198-211); agreement leaves a marker next to the code object and is never checked again.  The launch that
+    triggered the check is the launch it would have been: same packed buffer as the oracle's chain, chain carry and logs untouched."""
+    monkeypatch.setenv("MCI_KERNEL_CACHE", str(tmp_path))      # a cold cache: nothing in it has a marker
+    for solver, osolver in (("vegasmc", oracle.VEGASMC), ("mcmc", oracle.MCMC)):
+        cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]])
+        eng = mci.Engine(cfg, mci.catalog.sphere2())
+        assert eng.chain_speculation_status(solver) == 0
+        got = eng.iteration(solver, 625, 0, 16, iteration=0, seed=SEED, nchain=1)
+        assert eng.chain_speculation_status(solver) == 1 and eng.last_chain_speculation()[0] == 64 and eng.last_chain_launch() == (1, False)
+        marker = eng.code_object(solver + "_lanes") + ".ok"
+        assert os.path.exists(marker) and "hiprtc" in open(marker).read()
+        ocfg = oracle.Config([dict(kind=0, pool=0, lower=0.0, upper=1.0)], [[2], [3]])
+        ref = ocfg.iteration(osolver, "sphere2", None, 625, 0, 16, 0, SEED, nchain=1)
+        np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+        eng.close()
+        t = os.path.getmtime(marker)
+        eng = mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]]), mci.catalog.sphere2())
+        eng.iteration(solver, 625, 0, 16, iteration=0, seed=SEED, nchain=1)
+        assert eng.chain_speculation_status(solver) == 1 and os.path.getmtime(marker) == t      # (from the marker: not run again)
+        eng.close()
+
+
+def test_the_self_check_catches_the_miscompiled_group_kernel(oracle, tmp_path, monkeypatch, overrides, capfd):
+    """Case 205 with the backend pass that miscompiles it RE-ENABLED (MCI_JIT_FLAGS names the switch, so csrc/mci_jit.h leaves it alone):
+    right chains, histogram adds in the wrong bins (profiles/r05_fuzz.txt).  The self-check of the new code object sees it: status -1,
+    one warning, and the problem runs -- correctly -- with one lane per chain.  Without the check the launch would have returned the
+    wrong histogram silently (second half: the check switched off)."""
+    from layout_cases import random_case
+    monkeypatch.setenv("MCI_KERNEL_CACHE", str(tmp_path))
+    monkeypatch.setenv("MCI_JIT_FLAGS", "-mllvm -amdgpu-opt-exec-mask-pre-ra=1")
+    rng = np.random.default_rng(11000 + 205)
+    var, oleaves, dof, body, ndraw = random_case(rng)
+    oracle.set_rng_rounds(10)
+    fn = oracle.compile_c_integrand(body)
+    ref = oracle.Config(oleaves, dof).iteration(oracle.VEGASMC, fn, None, 1200, 0, 2, 0, SEED, nchain=2)
+    nstat = 2 * len(dof) + 2 + len(dof) + 1
+
+    def run():
+        eng = mci.Engine(mci.Configuration(var=var, dof=dof, seed=SEED), mci.Integrand(body))
+        eng.set_chain_speculation(64, 0.5, 3)
+        got = eng.iteration("vegasmc", 1200, 0, 2, iteration=0, seed=SEED, nchain=2)
+        out = got, eng.chain_speculation_status("vegasmc"), eng.last_chain_speculation()[0]
+        eng.close()
+        return out
+    got, status, lanes = run()
+    err = capfd.readouterr().err
+    if status == 1:
+        pytest.skip("this toolchain compiles case 205 correctly with the pass on")
+    assert status == -1 and lanes == 1 and "does not reproduce its lane-per-chain kernel" in err, (status, lanes, err)
+    np.testing.assert_allclose(got[:nstat], ref[:nstat], rtol=1e-8, atol=1e-300)
+    np.testing.assert_allclose(got[nstat:], ref[nstat:], rtol=1e-7)                   # the histogram too: the lane-per-chain kernel ran
+    overrides.set("spec_self_check", 0)                                                # what the check stands in front of
+    got, status, lanes = run()
+    assert status == 0 and lanes == 64
+    np.testing.assert_allclose(got[:nstat], ref[:nstat], rtol=1e-8, atol=1e-300)       # right chains, right statistics ...
+    assert not np.allclose(got[nstat:], ref[nstat:], rtol=1e-7)                        # ... and the histogram in the wrong bins

@@ -148,6 +148,7 @@ DEBUG_SIGNATURES = [
     ("mci_debug_persist_spin_ticks", C.c_int, [_VP, C.c_uint64]),
     ("mci_debug_override", C.c_int, [C.c_char_p, C.c_int64, C.c_int32]),
     ("mci_debug_compiler_id", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32]),
+    ("mci_debug_split_chunks", C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("mci_debug_mcmc_policy", C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
 ]
 

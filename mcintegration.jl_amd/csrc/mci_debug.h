@@ -28,11 +28,16 @@ int mci_debug_persist_spin_ticks(mci_problem *prob, unsigned long long ticks);
  *   train_walk      0 | 1 | 2  = mci_set_train_walk on every new problem
  *   fresh_floors    n        (consulted per launch) length of automatic :vegasmc chains that start afresh, in burn-in floors (8)
  *   fresh_burnin_pct n       (per launch) ... and the least part of such a chain that is not measured, in per cent (profiles/r05_bias.txt A5)
+ *   split_chunk      n       (per launch) samples per chunk, over all blocks, of a many-grid :vegas launch (mci_debug_split_chunks)
  *   spec_self_check  0 | 1   (per launch) the self-check of a several-lanes-per-chain code object (mci_chain_speculation_status): never |
  *                            also when the kernel cache holds the marker of an earlier pass (the guard test of tests/test_hip_spec.py)
  * (The library reads two environment variables and no others: MCI_KERNEL_CACHE -- the directory code objects are cached in -- and
  * MCI_JIT_FLAGS -- extra hiprtc options; INTEGRATION.md.) */
 int mci_debug_override(const char *key, int64_t value, int32_t on);
+/* the last many-grid (several histogram tiles) :vegas launch of the problem: how many chunks of the blocks' samples it ran as (sample pass
+ * -> replay per chunk; override key split_chunk = samples per chunk over all blocks, default min(2^27, 7.5 GB of stream)) and the bytes of
+ * parked (weights, bins) stream it held at a time */
+int mci_debug_split_chunks(const mci_problem *prob, int64_t *chunks, int64_t *bytes);
 /* what mci_jit.h puts into the kernel-cache key for "which compiler made this code object" (hiprtc version, the files of libhiprtc and
  * libamd_comgr, the target): set != NULL overrides it for this process ("" takes the override back); out: the identity in force */
 int mci_debug_compiler_id(const char *set, char *out, int32_t n);

@@ -160,6 +160,12 @@ struct BatchArgs {
     double *tile_w;         // [NI][tile_stride]
     u32 *tile_bins;         // [tdraw_words][tile_stride]  32 / ceil(log2(nbin)) bins per word
     i64 tile_stride;        // samples of this launch
+    // Many-grid (NTILE > 1) :vegas launches run in CHUNKS of a block's samples so that the parked stream stays bounded whatever neval is
+    // (the reference's loop allocates nothing per sample, vegas/montecarlo.jl:117-187): this launch draws the samples chunk_lo <= n <
+    // chunk_hi of every block -- same Philox indices as ever -- and parks sample n of local block lb at lb * chunk_len + (n - chunk_lo)
+    // (tile_stride = blocks * chunk_len); accum != 0: a later chunk ADDS its partial rows to those of the chunks before it
+    i64 chunk_lo, chunk_hi, chunk_len;
+    int accum;
     i64 nrows;              // partial rows (block, slice) of this launch
     int tiles_wpb;          // split-all :vegas: replay workgroups per block and tile (mci_vegas_tiles has its own, coarser, partition of a
                             // block's samples: every one of its workgroups flushes a whole LDS tile), 0 = wg_per_block
@@ -1006,6 +1012,7 @@ template <class Cfg, int NR> __device__ __forceinline__ void host_measure_record
 template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA = false, bool ACCUM = false> __device__ __forceinline__ void flush_workgroup(const BatchArgs &a, double *smem, const double *acc, const double *extra /*[NCOLS-NOBS]*/, i64 rowid, int tile) {
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
     double *sO = smem + L::O, *sR = smem + L::R, *sH = smem + L::H;
+    const bool accum = ACCUM || (Cfg::NTILE > 1 && a.accum != 0); // (a later chunk of a many-grid :vegas launch, BatchArgs::accum)
     // scalar observables of the default measure (register accumulators)
     if constexpr (Cfg::CUSTOM_MEASURE == 0) {
         static_for<0, Cfg::NI>([&](auto I) {
@@ -1039,7 +1046,7 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
         }
         else
             for (int w = 0; w < nwave; ++w) v += sR[w * Cfg::NCOLS + c]; // fixed order: deterministic
-        row[c] = ACCUM ? row[c] + v : v; // (ACCUM: one launch per Markov step adds to the row the host zeroed)
+        row[c] = accum ? row[c] + v : v; // (ACCUM: one launch per Markov step adds to the row the host zeroed)
     }
     if constexpr (WRITE_PA) { // the workgroup's propose | accept counters -> its row of part_pa (exact integers below 2^53)
         const u64 *sPA = reinterpret_cast<const u64 *>(smem + L::PA);
@@ -1055,10 +1062,10 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
                     constexpr int SB = Cfg::DET != 0 ? 1 : Cfg::HCOPY, SC = Cfg::DET != 0 ? Cfg::HTILE : 1; // strides of bin and copy (hslot)
                     double v = sH[i * SB];
                     static_for<1, Cfg::HCOPY>([&](auto Cc) { v += sH[i * SB + decltype(Cc)::value * SC]; }); // fixed order
-                    if (!ACCUM && a.hist_atomic) { // (BatchArgs::hist_atomic: no merge launch behind this one)
+                    if (!accum && a.hist_atomic) { // (BatchArgs::hist_atomic: no merge launch behind this one)
                         if (v != 0.0) global_add(&a.ghist[(rowid % a.hist_atomic) * Cfg::NBIN + Cfg::tile_boff(tt) + i], v);
                     } else
-                    hrow[i] = ACCUM ? hrow[i] + v : v;
+                    hrow[i] = accum ? hrow[i] + v : v;
                 }
             }
         });
@@ -1141,7 +1148,9 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     constexpr int DPC = Cfg::RNG_BITS == 32 ? 4 : 2;           // draws per Philox block of the :vegas sample stream
     const RoundKeys<KV> keys = make_round_keys<KV>((u32)a.seed, (u32)(a.seed >> 32));
     const i64 mfreq = a.measurefreq;
-    i64 mrem = mfreq == 1 ? 0 : ((i64)slice * T + tid + 1) % mfreq;
+    // the block's samples this launch draws: all of them, or one chunk of a many-grid launch (BatchArgs::chunk_lo)
+    const i64 n_lo = SPLIT ? a.chunk_lo : 0, n_hi = SPLIT ? a.chunk_hi : a.neval_per_block;
+    i64 mrem = mfreq == 1 ? 0 : (n_lo + (i64)slice * T + tid + 1) % mfreq;
     const i64 mstep = mfreq == 1 ? 0 : stride % mfreq;
     // gathered grids (table mode 3) are walked dimension-major so that they are served from L1
     constexpr bool PHASED = Cfg::L1_PHASE > 0 && Cfg::HOST_INTEGRAND == 0 && gather_draw_count<Cfg, EC>() > 0;
@@ -1188,7 +1197,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             static_for<0, Cfg::NI>([&](auto I) { defer_wh[decltype(I)::value] = wh[decltype(I)::value]; });
         } else if constexpr (!NOHIST) hist_update<Cfg, decltype(TT)::value>(s, wh, sH, a.ghist, tile);
         if constexpr (SPLIT) { // park what the other tiles need: coalesced (lane == consecutive sample) 8- and 4-byte stores
-            const i64 idx = wi.lb * a.neval_per_block + n;
+            const i64 idx = wi.lb * a.chunk_len + (n - n_lo);
             static_for<0, Cfg::NI>([&](auto I) { a.tile_w[decltype(I)::value * a.tile_stride + idx] = wh[decltype(I)::value]; });
             constexpr int NWORD = tdraw_words<Cfg>();
             static_for<0, NWORD>([&](auto J) { a.tile_bins[decltype(J)::value * a.tile_stride + idx] = s.word[decltype(J)::value]; });
@@ -1198,8 +1207,8 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
         // The phased trips are those in which every thread of the workgroup holds a valid sample (barriers inside): their body is
         // unconditional -- the integrand may consume the draws as they come instead of keeping all of them for a guarded call -- and what
         // is left at the end of the block, at most one sample per lane, goes through the plain loop.
-        const i64 n0 = (i64)slice * T + tid, first = (i64)slice * T;
-        const i64 jfull = first + T <= a.neval_per_block ? (a.neval_per_block - first - T) / stride + 1 : 0;
+        const i64 n0 = n_lo + (i64)slice * T + tid, first = n_lo + (i64)slice * T;
+        const i64 jfull = first + T <= n_hi ? (n_hi - first - T) / stride + 1 : 0;
         i64 n = n0;
         for (i64 j = 0; j < jfull; ++j, n += stride) {
             Sample<Cfg> sm;
@@ -1210,7 +1219,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             process(n, sm);
             __builtin_amdgcn_sched_barrier(0);
         }
-        for (; n < a.neval_per_block; n += stride) {
+        for (; n < n_hi; n += stride) {
             Sample<Cfg> s;
             draw_sample<Cfg, EC, KV, DPC>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
             process(n, s);
@@ -1244,7 +1253,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
             flush(pb);
         } else flush(pa);
     } else {
-        for (i64 n = (i64)slice * T + tid; n < a.neval_per_block; n += stride) {
+        for (i64 n = n_lo + (i64)slice * T + tid; n < n_hi; n += stride) {
             Sample<Cfg> s;
             draw_sample<Cfg, EC, KV, DPC>(t, keys, stream, (u64)(B * a.neval_per_block + n), s);
             process(n, s);
@@ -1356,9 +1365,10 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
             // reads 1 KB per instruction instead of 256 B: 7 wide loads per four samples instead of 24 narrow ones), which is what a pass
             // that streams 5 GB wants.  Needs the block's first sample 16-byte aligned in both parked arrays; otherwise sample by sample.
             static_assert(U % 4 == 0, "the replay takes its samples in groups of four");
-            const bool wide = (a.neval_per_block & 3) == 0 && (a.tile_stride & 3) == 0;
+            const i64 cnt = a.chunk_hi - a.chunk_lo; // the block's parked samples (this chunk of them, BatchArgs::chunk_lo)
+            const bool wide = (cnt & 3) == 0 && (a.chunk_len & 3) == 0 && (a.tile_stride & 3) == 0;
             const i64 per = wide ? 4 : 1; // consecutive samples per lane and group
-            for (i64 n0 = ((i64)slice * T + tid) * per; n0 < a.neval_per_block; n0 += stride * U) {
+            for (i64 n0 = ((i64)slice * T + tid) * per; n0 < cnt; n0 += stride * U) {
                 double wh[U][Cfg::NI];
                 u32 word[U][NWORD > 0 ? NWORD : 1];
                 bool live[U];
@@ -1369,8 +1379,8 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
                     static_for<0, U / 4>([&](auto Q) {
                         constexpr int q = decltype(Q)::value;
                         const i64 n = n0 + (i64)q * stride * 4; // this group's first sample (a multiple of four, like the block's length)
-                        const bool lv = n < a.neval_per_block;
-                        const i64 idx = lb * a.neval_per_block + (lv ? n : n0);
+                        const bool lv = n < cnt;
+                        const i64 idx = lb * a.chunk_len + (lv ? n : n0);
                         static_for<0, 4>([&](auto Vv) { live[4 * q + decltype(Vv)::value] = lv; });
                         typedef double d2 __attribute__((ext_vector_type(2)));
                         typedef u32 u4 __attribute__((ext_vector_type(4)));
@@ -1403,8 +1413,8 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
                 static_for<0, U>([&](auto Uu) {
                     constexpr int u = decltype(Uu)::value;
                     const i64 n = n0 + (i64)u * stride;
-                    live[u] = n < a.neval_per_block;
-                    const i64 idx = lb * a.neval_per_block + (live[u] ? n : n0);
+                    live[u] = n < cnt;
+                    const i64 idx = lb * a.chunk_len + (live[u] ? n : n0);
                     static_for<0, Cfg::NI>([&](auto I) { wh[u][decltype(I)::value] = a.tile_w[decltype(I)::value * a.tile_stride + idx]; });
                     static_for<0, NWORD>([&](auto J) {
                         constexpr int j = decltype(J)::value;
@@ -1473,9 +1483,9 @@ template <class Cfg> __device__ __forceinline__ void vegas_tiles(const BatchArgs
             double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
             if constexpr (tile_banked<Cfg>(tt)) { // [bin][grid] in LDS -> [grid][bin] rows (coalesced stores; the strided LDS reads are a few us per tile)
                 constexpr int G = tile_draw_count<Cfg>(tt), NB = Cfg::tile_nbin(tt) / G;
-                for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = sH[(i % NB) * G + i / NB];
+                for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = (a.accum ? hrow[i] : 0.0) + sH[(i % NB) * G + i / NB];
             } else
-            for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = sH[i];
+            for (int i = tid; i < Cfg::tile_nbin(tt); i += T) hrow[i] = (a.accum ? hrow[i] : 0.0) + sH[i];
         }
     });
 }

@@ -203,8 +203,27 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         HIPCHK(hipMalloc((void **)&p->d_part_pa, (size_t)nrows * 2 * p->npa * sizeof(double)));
         p->cap_pa = nrows;
     }
+    // Many-grid launches park (weights, bins) of every sample for the replay.  The stream is bounded whatever neval is -- the reference's
+    // loop allocates nothing per sample (vegas/montecarlo.jl:117-187) -- by running the launch in chunks of a block's samples: sample pass
+    // -> replay per chunk, same Philox indices, the partial rows of a later chunk added to those before it (BatchArgs::chunk_lo).  A chunk
+    // is at most 2^27 samples over all blocks and at most 7.5 GB of parked stream (C4: all of neval = 1e8 in one chunk as
+    // before, neval = 1e10 in 75); host closures read the whole launch's stream and keep the one chunk (they are refused above 8 GiB).
+    int64_t chunk_len = nevalperblock, nchunks = 1;
     if (split) {
-        const int64_t nsamp = nblocks * nevalperblock;
+        const int64_t words = (p->ntdraw + 1) / 2 > 0 ? (p->ntdraw + 1) / 2 : 1;
+        const int64_t bytes = (int64_t)s.ni * 8 + words * 4;
+        if (!s.host_integrand && !s.host_measure) {
+            int64_t cap = (int64_t)1 << 27;
+            if (cap * bytes > (int64_t)7500000000) cap = (int64_t)7500000000 / bytes;
+            if (g_over.split_chunk.on && g_over.split_chunk.v > 0) cap = g_over.split_chunk.v;
+            int64_t per = (cap / nblocks) & ~(int64_t)3; // (a multiple of four: the replay reads four consecutive samples per lane as 16-byte loads)
+            if (per < 4) per = 4;
+            if (per < chunk_len) {
+                chunk_len = per;
+                nchunks = (nevalperblock + chunk_len - 1) / chunk_len;
+            }
+        }
+        const int64_t nsamp = nblocks * chunk_len;
         if (nsamp > p->cap_tile) {
             if (p->d_tile_w) (void)hipFree(p->d_tile_w);
             if (p->d_tile_bins) (void)hipFree(p->d_tile_bins);
@@ -212,9 +231,11 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             p->d_tile_bins = nullptr;
             p->cap_tile = 0;
             HIPCHK(hipMalloc((void **)&p->d_tile_w, (size_t)nsamp * s.ni * sizeof(double)));
-            HIPCHK(hipMalloc((void **)&p->d_tile_bins, (size_t)nsamp * ((p->ntdraw + 1) / 2 > 0 ? (p->ntdraw + 1) / 2 : 1) * sizeof(uint32_t)));
+            HIPCHK(hipMalloc((void **)&p->d_tile_bins, (size_t)nsamp * words * sizeof(uint32_t)));
             p->cap_tile = nsamp;
         }
+        p->last_split_chunks = nchunks;
+        p->last_split_bytes = nsamp * bytes;
     }
     mci::BatchArgs a{};
     a.edges = p->d_edges;
@@ -367,7 +388,11 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     a.status = p->d_status;
     a.tile_w = p->d_tile_w;
     a.tile_bins = p->d_tile_bins;
-    a.tile_stride = nblocks * nevalperblock;
+    a.tile_stride = nblocks * chunk_len;
+    a.chunk_lo = 0;
+    a.chunk_hi = nevalperblock;
+    a.chunk_len = chunk_len;
+    a.accum = 0;
     a.nrows = nrows;
     // Split-all :vegas: the replay partitions a block's parked samples on its own.  Every replay workgroup zeroes and flushes a whole LDS
     // tile (C4: 128 KB) and every row it writes is read again by the merge, so it runs ~2 workgroups per CU and tile pair instead of one
@@ -591,11 +616,20 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
             }
         }
     } else
-    HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T_launch, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
+    for (int64_t c = 0; c < nchunks; ++c) { // (one trip, except for a many-grid launch whose parked stream is bounded: sample pass -> replay per chunk)
+        if (nchunks > 1) {
+            a.chunk_lo = c * chunk_len;
+            a.chunk_hi = a.chunk_lo + chunk_len < nevalperblock ? a.chunk_lo + chunk_len : nevalperblock;
+            a.accum = c > 0 ? 1 : 0;
+        }
+        HIPCHK(hipModuleLaunchKernel(f, (unsigned)nwg, 1, 1, (unsigned)T_launch, 1, 1, (unsigned)solver_lds(p, solver), st, args, nullptr));
+        if (split && c + 1 < nchunks)
+            HIPCHK(hipModuleLaunchKernel(p->f_tiles[kern == kSlotVegasAny ? 1 : 0], (unsigned)(((hist_rows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
+    }
     if (solver == MCI_MCMC) p->hold_measured = a.hold_hist != nullptr;
     // (an explicit chain count: nobody sizes a launch from this one's holds, and the host keeps queueing launches back to back)
     if (a.hold_hist && auto_chains && (rc = hold_publish(p, nevalperblock / nchain, solver != MCI_VEGAS && p->last_carried))) return rc;
-    if (split)
+    if (split) // (the replay of the one chunk, or of the last one)
         HIPCHK(hipModuleLaunchKernel(p->f_tiles[kern == kSlotVegasAny ? 1 : 0], (unsigned)(((hist_rows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
     p->ev_valid[slot] = p->time_this_launch;

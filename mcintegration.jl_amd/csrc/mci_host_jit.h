@@ -555,6 +555,13 @@ int mci_debug_override(const char *key, int64_t value, int32_t on) {
     return MCI_OK;
 }
 
+int mci_debug_split_chunks(const mci_problem *p, int64_t *chunks, int64_t *bytes) {
+    if (!p) return fail(MCI_ERR_INVALID, "NULL argument");
+    if (chunks) *chunks = p->last_split_chunks;
+    if (bytes) *bytes = p->last_split_bytes;
+    return MCI_OK;
+}
+
 int mci_debug_compiler_id(const char *set, char *out, int32_t n) {
     if (set) mcijit::compiler_id_override() = set; // ("" takes the override back)
     if (out && n > 0) snprintf(out, (size_t)n, "%s", mcijit::compiler_id().c_str());

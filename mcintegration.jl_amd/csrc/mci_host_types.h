@@ -132,6 +132,7 @@ struct mci_problem {
     double *d_tile_w = nullptr;
     uint32_t *d_tile_bins = nullptr;
     int64_t cap_tile = 0;
+    int64_t last_split_chunks = 0, last_split_bytes = 0; // chunks of the last many-grid :vegas launch | bytes of parked stream it held at a time
     int ntdraw = 0; // draws whose histogram lives in a tile >= 1
     hipFunction_t f_tiles[2] = {nullptr, nullptr}; // replay kernel of the two :vegas variants
     // second merge stage (partials -> packed), launched lazily: a single-rank mci_iteration_finish fuses it with
@@ -302,7 +303,7 @@ int64_t mci_problem::kMcmcCarryHalfFloors = 2;
 // are cached) and MCI_JIT_FLAGS (extra hiprtc options), mci_jit.h.
 namespace {
 struct Override { bool on = false; int64_t v = 0; };
-struct Overrides { Override table_mode, hist_tile_bins, no_split_all, l1_phase, train_walk, hist_copies, fresh_floors, fresh_burnin_pct, spec_self_check; } g_over;
+struct Overrides { Override table_mode, hist_tile_bins, no_split_all, l1_phase, train_walk, hist_copies, fresh_floors, fresh_burnin_pct, spec_self_check, split_chunk; } g_over;
 Override *override_slot(const char *key) {
     if (!key) return nullptr;
     if (!strcmp(key, "table_mode")) return &g_over.table_mode;
@@ -314,6 +315,7 @@ Override *override_slot(const char *key) {
     if (!strcmp(key, "fresh_floors")) return &g_over.fresh_floors;
     if (!strcmp(key, "fresh_burnin_pct")) return &g_over.fresh_burnin_pct;
     if (!strcmp(key, "spec_self_check")) return &g_over.spec_self_check;
+    if (!strcmp(key, "split_chunk")) return &g_over.split_chunk;
     return nullptr;
 }
 } // namespace

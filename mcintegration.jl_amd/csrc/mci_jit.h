@@ -344,16 +344,20 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
                    int extra_hdr = kHdrNone, bool cache_only = false, bool no_exec_mask_flag = false) {
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics",
                                      "-ffp-contract=off", "-DMCI_THREADS=" + std::to_string(threads)};
-    // The several-lanes-per-chain units (mci_spec.h) are compiled WITHOUT the backend's pre-RA exec-mask optimisation.  One layout of the
-    // randomised campaigns -- a composite pool of three leaves next to a Discrete pool nobody uses, ten draws -- came out of ROCm 7.2's
-    // compiler with the right chains and statistics and its :vegasmc histogram adds in the wrong bins; -opt-bisect-limit pins the flip on
-    // ONE machine pass, si-optimize-exec-masking-pre-ra on that kernel (right with the first 55582 passes, wrong from 55583 on:
-    // profiles/r05_fuzz.txt, tools/repro_case.py 205).  The pass rewrites EXEC save / restore sequences, of which these kernels -- nested
-    // divergent regions around wave-wide exchanges -- have hundreds; the lane-per-chain and :vegas units keep the default pipeline.
-    // (MCI_JIT_FLAGS that names the switch itself decides it -- for every unit: the A/B of profiles/r06_ablation.txt, and the guard test
-    // that re-enables the pass to see the self-check of a new group code object trip, mci_host_jit.h spec_self_check)
+    // EVERY unit is compiled WITHOUT the backend's pre-RA exec-mask optimisation.  One layout of the randomised campaigns -- a composite
+    // pool of three leaves next to a Discrete pool nobody uses, ten draws -- came out of ROCm 7.2's compiler with the right chains and
+    // statistics and the :vegasmc histogram adds of its several-lanes-per-chain kernel in the wrong bins; -opt-bisect-limit pins the flip
+    // on ONE machine pass, si-optimize-exec-masking-pre-ra on that kernel (right with the first 55582 passes, wrong from 55583 on:
+    // profiles/r05_fuzz.txt, tools/repro_case.py 205).  The pass rewrites EXEC save / restore sequences, of which the group kernels --
+    // nested divergent regions around wave-wide exchanges -- have hundreds; every user integrand is a new translation unit, and nothing
+    // says the next victim is a group kernel.  Round 6 measured what the pass is worth here: nothing (headline 1.3393 | 1.3398 ms with |
+    // without it, C2 on 16 grids, C3, C4, C5 under all three solvers and the default call within +-0.5 %, profiles/r06_ablation.txt), so it
+    // is off for all of them.  MCI_JIT_FLAGS that names the switch itself decides it (the A/B; the guard test that re-enables the pass to
+    // see the self-check of a new group code object trip, mci_host_jit.h spec_self_check); no_exec_mask_flag: the retry of a unit whose
+    // compilation the switch itself broke (a later compiler that no longer knows it).
+    (void)extra_hdr;
     const char *jf = getenv("MCI_JIT_FLAGS");
-    if (extra_hdr == kHdrSpec && !no_exec_mask_flag && !(jf && strstr(jf, "amdgpu-opt-exec-mask-pre-ra"))) {
+    if (!no_exec_mask_flag && !(jf && strstr(jf, "amdgpu-opt-exec-mask-pre-ra"))) {
         opts.push_back("-mllvm");
         opts.push_back("-amdgpu-opt-exec-mask-pre-ra=0");
     }

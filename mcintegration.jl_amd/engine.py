@@ -502,6 +502,12 @@ class Engine:
         check(lib().mci_debug_walk_counts(self.p, out))
         return int(out[0]), int(out[1])
 
+    def split_chunks(self):
+        """(chunks, bytes of parked stream held at a time) of the last many-grid :vegas launch; see csrc/mci_debug.h mci_debug_split_chunks"""
+        n, b = C.c_int64(), C.c_int64()
+        check(lib().mci_debug_split_chunks(self.p, C.byref(n), C.byref(b)))
+        return int(n.value), int(b.value)
+
     def integrate(self, solver, neval, niter=10, block=16, ignore=-1, adapt=True, gamma=1.0, measurefreq=1, seed=1234,
                   nchain=0, first_iteration=0, thermal_ratio=0.1, reweight_goal=None):
         """the whole loop inside the library (mci_integrate)"""

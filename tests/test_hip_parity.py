@@ -244,6 +244,35 @@ def test_c4_32_bit_stream_with_gather_phase_matches_oracle(oracle, threads):
     np.testing.assert_allclose(got[4:], ref[4:], rtol=1e-9)
 
 
+@pytest.mark.parametrize("chunk,measurefreq,keep_tile0", [(1000, 1, 0), (1000, 3, 0), (37, 1, 0), (4000, 1, 1), (10**9, 1, 0)],
+                         ids=["1000", "1000_mf3", "tiny_ragged", "tile0_in_pass", "one_chunk"])
+def test_many_grid_launch_in_chunks_matches_oracle(oracle, overrides, chunk, measurefreq, keep_tile0):
+    """The reference's loop is constant memory in neval (vegas/montecarlo.jl:117-187).  A many-grid launch (BASELINE configs[3]: 32 grids,
+    the histograms in two LDS tiles) parks (weights, bins) per sample for the replay; it runs in chunks of the blocks' samples -- sample
+    pass -> replay per chunk, same Philox indices, partial rows accumulated -- so that the parked stream is bounded.  With the chunk forced
+    to a few samples the launch equals the oracle at the tolerances of the one-chunk launch, measurefreq and a block range included."""
+    ud = genz_userdata(32)
+    overrides.set("split_chunk", chunk)
+    if keep_tile0:
+        overrides.set("no_split_all", 1)
+    cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
+    eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32))
+    ocfg = oracle.Config([ocont(0) for _ in range(32)], [[1]])
+    npb, lo, hi = 2003, 1, 5                           # (an odd block length: the last chunk is ragged)
+    got = eng.iteration("vegas", npb, lo, hi, iteration=2, seed=SEED, measurefreq=measurefreq)
+    ref = ocfg.iteration(oracle.VEGAS, "genz_product_peak", ud, npb, lo, hi, 2, SEED, measurefreq=measurefreq)
+    nchunks, held = eng.split_chunks()
+    per = max(4, (chunk // (hi - lo)) & ~3)
+    assert nchunks == (1 if per >= npb else -(-npb // per)), (nchunks, per)
+    assert held == (hi - lo) * min(per, npb) * (8 + 4 * 16)      # 8 B of weight + 32 16-bit bins per parked sample
+    np.testing.assert_allclose(got[:4], ref[:4], rtol=1e-11)
+    np.testing.assert_allclose(got[4:], ref[4:], rtol=1e-9)
+    # a second launch on the same problem with another chunking: the rows of the first are not carried into it
+    overrides.set("split_chunk", 3 * chunk if chunk < 10**9 else 500)
+    got2 = eng.iteration("vegas", npb, lo, hi, iteration=2, seed=SEED, measurefreq=measurefreq)
+    np.testing.assert_allclose(got2, got, rtol=1e-12)
+
+
 def test_vegas_iteration_block_range_and_measurefreq(oracle):
     """blocks [lo,hi) are the MPI-rank partition (main.jl:152-166); measurefreq (vegas/montecarlo.jl:148)."""
     c, cfg, eng, ocfg = make("sphere2_padding", oracle)

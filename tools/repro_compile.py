@@ -13,6 +13,7 @@ rng = np.random.default_rng(11000 + 205)
 var, oleaves, dof, body, ndraw = random_case(rng)
 cfg = mci.Configuration(var=var, dof=dof, seed=1)
 eng = mci.Engine(cfg, mci.Integrand(body), device=-1)
-eng.compile("vegasmc_lanes")
-print(eng.code_object("vegasmc_lanes"))
+for unit in sys.argv[1:] or ["vegasmc_lanes"]:
+    eng.compile(unit)
+    print(eng.code_object(unit))
 eng.close()

@@ -264,7 +264,7 @@ def test_many_grid_launch_in_chunks_matches_oracle(oracle, overrides, chunk, mea
     nchunks, held = eng.split_chunks()
     per = max(4, (chunk // (hi - lo)) & ~3)
     assert nchunks == (1 if per >= npb else -(-npb // per)), (nchunks, per)
-    assert held == (hi - lo) * min(per, npb) * (8 + 4 * 16)      # 8 B of weight + 32 16-bit bins per parked sample
+    assert held == (hi - lo) * min(per, npb) * (8 + 4 * (8 if keep_tile0 else 16))      # 8 B of weight + the replayed draws' 16-bit bins per parked sample
     np.testing.assert_allclose(got[:4], ref[:4], rtol=1e-11)
     np.testing.assert_allclose(got[4:], ref[4:], rtol=1e-9)
     # a second launch on the same problem with another chunking: the rows of the first are not carried into it

@@ -10,7 +10,7 @@ from .comm import LocalComm
 from .configuration import Configuration
 from .engine import Engine
 from .integrand import HostIntegrand, HostMeasure, Integrand, Measure
-from .statistics import Result, report
+from .statistics import Result, chain_estimator_bias, report
 from .variables import Continuous, Discrete
 
 
@@ -264,6 +264,12 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         block_mean = np.asarray(comm.sum_host(eng, full.ravel())).reshape(full.shape)
     res = Result(np.array(means), np.array(stds), config, ignore, neval=neval_done, seconds=time.time() - t0, block_mean=block_mean,
                  correlated=correlated, block=block)   # main.jl:211
+    if s != VEGAS and hasattr(eng, "last_chain_launch") and hasattr(eng, "acceptance"):
+        try:   # one chain per block: what its ratio estimator costs at this block length (statistics.chain_estimator_bias; a note of report())
+            pr, ac = eng.acceptance()
+            res.chain_bias = chain_estimator_bias(solver, nevalperblock, eng.last_chain_launch()[0], block, niter - ignore, pr, ac, eng.ndraw)
+        except Exception:
+            res.chain_bias = None
     res.warmup = warmup   # launches that were run again instead of being counted (automatic :mcmc chain lengths)
     res.neval_discarded = neval_discarded   # ... and their evaluations: spent (they trained the map), in neither res.neval nor the estimate
     if print >= 0:

@@ -44,6 +44,32 @@ def lineage_sums(block_mean, iter_std, init=1, max=None):
     return s1, s2
 
 
+def chain_estimator_bias(solver, steps_per_block, chains_per_block, nblocks, ncounted, propose, accept, ndraw):
+    """What the ratio estimator of a chain solver's block costs when blocks are short (not in the reference; it is the reference's own
+    chain that is being described).  A block mean is a RATIO of two sums over one correlated chain (main.jl:275-287): its bias is
+    O(tau / N) for a block of N steps and autocorrelation time tau, its scatter O(1 / sqrt(N)).  Averaging B blocks over I counted
+    iterations shrinks the scatter by sqrt(B I) and the bias not at all, so the bias of the final estimate in units of its error bar
+    grows like  z = k tau sqrt(B I / N):  many short blocks are the bad direction, "fewer blocks" the reference's own knob (z ~ B at fixed neval).
+      tau  = (ndraw + 1) (2 - a) / a     a = accepted / proposed updates of the last iteration (config.accept / config.propose): a step moves
+                                         one of ndraw slots (or the integrand index), and keeps what it has with probability 1 - a
+      k    = 0.6 (:mcmc), 0.12 (:vegasmc)   fitted to the measured mean deviation per run of one-chain-per-block calls, 16 seeds each
+                                         (profiles/r06_bias.txt; tools/chain_bias_note.py): :mcmc on BASELINE configs[4] +6.8 at block = 256 /
+                                         neval = 1e6 (z = 7.0), +5.1 at 64 / 1e5 (5.6), +2.3 at 16 / 1e4 (4.8); on the 2-D / 3-D spheres +3.8 (3.2),
+                                         +2.7 (2.5), +1.35 (2.1); x^2 + y^2 +1.3 (1.3); :vegasmc -- every integrand evaluated at every step,
+                                         numerator and normalisation strongly correlated -- a fifth of that: +0.4 .. +1.1 on configs[4]
+    Returns dict(z, tau, times = N / tau, acceptance, steps_per_block, nblocks) for one chain per block, else None (a block of several
+    chains averages over them first: the many-chain decomposition has its own floors, DESIGN "Chains")."""
+    if solver not in ("vegasmc", "mcmc") or int(chains_per_block) != 1 or steps_per_block <= 0:
+        return None
+    pr, ac = float(np.sum(propose)), float(np.sum(accept))
+    if not (pr > 0.0 and ac > 0.0):
+        return None
+    a = min(ac / pr, 1.0)
+    tau = (int(ndraw) + 1) * (2.0 - a) / a
+    z = (0.6 if solver == "mcmc" else 0.12) * tau * float(np.sqrt(max(int(nblocks) * max(int(ncounted), 1), 1) / float(steps_per_block)))
+    return dict(z=z, tau=tau, times=float(steps_per_block) / tau, acceptance=a, steps_per_block=int(steps_per_block), nblocks=int(nblocks), solver=solver)
+
+
 class Result:
     """statistics.jl:16-63.  mean/stdev/chi2 are lists with one entry per integrand: a float for scalar
     observables, an ndarray for array observables (like `obs=[zeros(4)]`).
@@ -78,6 +104,9 @@ class Result:
             um, ue = counted.mean(0), counted.std(0, ddof=1) / np.sqrt(counted.shape[0])
             den = np.hypot(self._flat_std, ue)
             self.weighting_shift = np.where(den > 0.0, np.abs(self._flat_mean - um) / np.where(den > 0.0, den, 1.0), 0.0)
+        # set by integrate() for a chain solver that ran the reference's one chain per block: chain_estimator_bias (report() prints a
+        # note where the expected bias of the blocks' ratio estimator reaches 2 of the final error bars)
+        self.chain_bias = None
         self.mean, self.stdev, self.chi2 = self._shape(self._flat_mean), self._shape(self._flat_std), self._shape(self._flat_chi2)
         self.iterations = [(self._shape(self.iter_mean[i]), self._shape(self.iter_std[i]), config) for i in range(niter)]
 
@@ -96,8 +125,23 @@ class Result:
 
     def with_ignore(self, ignore):
         """Result(res, ignore) (statistics.jl:56-62)"""
-        return self if ignore == self.ignore else Result(self.iter_mean, self.iter_std, self.config, ignore, self.neval, self.seconds,
-                                                         self.block_mean, self.correlated, self.block)
+        if ignore == self.ignore:
+            return self
+        r = Result(self.iter_mean, self.iter_std, self.config, ignore, self.neval, self.seconds, self.block_mean, self.correlated, self.block)
+        r.chain_bias = self.chain_bias
+        return r
+
+    @property
+    def chain_bias_note(self):
+        """the sentence report() prints under the tables, or None"""
+        b = self.chain_bias
+        if not b or b["z"] < 2.0:
+            return None
+        return ("note: solver = :%s ran one chain per block of %d steps -- about %.0f autocorrelation times (acceptance %.2f) -- in %d blocks; a block mean "
+                "is a ratio of two sums over that chain (main.jl:275-287), and its bias does not average out over blocks and iterations: expect the estimate "
+                "about %.0f of its error bars off.  The reference's own knob: fewer blocks (block = %d gives %.1f)" % (
+                    b["solver"], b["steps_per_block"], b["times"], b["acceptance"], b["nblocks"], b["z"], max(b["nblocks"] // 16, 1),
+                    b["z"] / (b["nblocks"] / max(b["nblocks"] // 16, 1))))
 
     @property
     def dof(self):
@@ -232,3 +276,5 @@ def report(result, ignore=None, pick=0, name=None, verbose=0, io=None):
                     "   (%d warm-up launches run again)" % result.warmup if getattr(result, "warmup", 0) else ""), file=io)
         else:
             print("Integral %s = %s ± %s" % (info, result._flat_mean[col], result._flat_std[col]), file=io)
+    if getattr(result, "chain_bias_note", None):   # (not in the reference)
+        print("  " + result.chain_bias_note, file=io)

@@ -830,12 +830,13 @@ def test_automatic_chains_carry_the_bias_of_the_references_own_chain_and_no_more
 @pytest.mark.parametrize("name", ["c5", "bubble"])
 def test_cold_vegasmc_calls_at_full_size_are_unbiased_iteration_by_iteration(name):
     """integrate(solver = :vegasmc, neval = 1e8, niter = 10) on a FRESH problem, BASELINE configs[2] and the :vegasmc run of configs[4],
-    32 seeds: the iterations right behind the first refinements of the map are where carried chains used to be off by 8 .. 17 sigma per
+    64 seeds: the iterations right behind the first refinements of the map are where carried chains used to be off by 8 .. 17 sigma per
     run-iteration (the target density of a :vegasmc chain contains the map; the stored chains were a sample of the old one:
     profiles/r05_bias.txt A).  With the stored chains resampled to the moved target every counted iteration's mean over the seeds sits
-    within 5 standard errors of the exact value, and the pooled final estimate within 4."""
+    within 4 standard errors of the exact value and the pooled final estimate within 3.3 -- bounds at what was MEASURED (largest
+    per-iteration residue 2.8, pooled 2.5: profiles/r05_bias.txt A4-final, r06_bias.txt), so that a regression that doubles a residue fails."""
     from catalog_params import bubble_exact_finite_T
-    nseeds = 32
+    nseeds = 64
     if name == "c5":
         mk = lambda seed: Configuration(var=Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]], seed=seed)
         f, meas, exact = mci.catalog.nested_gauss(), None, np.array([math.erf(5.0) ** d for d in (3, 6, 9, 12)])
@@ -849,9 +850,11 @@ def test_cold_vegasmc_calls_at_full_size_are_unbiased_iteration_by_iteration(nam
         f, meas, exact = mci.catalog.bubble(), mci.bin_by(4), np.array(bubble_exact_finite_T())
     ms, es, im = _engine_runs(mk, f, meas, "vegasmc", nseeds, 10**8, 16, 0)
     per_iter = (im.mean(0) - exact) / (im.std(0, ddof=1) / math.sqrt(nseeds))
-    assert np.all(np.abs(per_iter[1:]) < 5.0), per_iter
+    print("per iteration:\n", np.round(per_iter, 2))
+    assert np.all(np.abs(per_iter[1:]) < 4.0), per_iter
     pooled = (ms.mean(0) - exact) / (np.sqrt((es ** 2).sum(0)) / nseeds)
-    assert np.all(np.abs(pooled) < 4.0), pooled
+    print("pooled:", np.round(pooled, 2))
+    assert np.all(np.abs(pooled) < 3.3), pooled
 
 
 @pytest.mark.parametrize("name", ["c5", "bubble"])
@@ -882,6 +885,43 @@ def test_vegasmc_without_adaptation_counts_every_iteration_without_bias(name):
     eng.integrate("vegasmc", neval=10**7, niter=2, block=16, seed=1, adapt=False)
     assert eng.last_chain_launch()[1] is True
     eng.close()
+
+
+def test_report_says_when_one_short_chain_per_block_biases_the_estimate():
+    """A chain solver's block mean is a ratio of two sums over one chain (main.jl:275-287); with MANY SHORT blocks the ratio estimator's
+    bias -- O(tau / N_block), the same in every block -- stands out of an error bar that shrinks with the number of blocks: :mcmc at
+    block = 256, neval = 1e6 on BASELINE configs[4] is +5.7 .. +7.3 sigma per run (profiles/r05_odd_calls.txt) with an honest-looking
+    error bar.  It is the reference's own chain, so it is reproduced -- and said: Result.chain_bias (statistics.chain_estimator_bias) and a
+    note of report(result) that names the reference's knob.  The default call, and the same call at block = 16, carry no note."""
+    import io
+    exact = np.array([math.erf(5.0) ** d for d in (3, 6, 9, 12)])
+    c5 = lambda seed: Configuration(var=Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]], seed=seed)
+    devs, zs = [], []
+    for seed in range(1, 9):
+        res = integrate(mci.catalog.nested_gauss(), config=c5(seed), solver="mcmc", neval=1e6, niter=10, block=256)
+        assert res.config._engine.last_chain_launch()[0] == 1
+        devs.append((res._flat_mean - exact) / res._flat_std)
+        zs.append(res.chain_bias["z"])
+        out = io.StringIO()
+        mci.report(res, io=out)
+        assert res.chain_bias["z"] >= 2.0 and "note: solver = :mcmc ran one chain per block of 3906 steps" in out.getvalue() and "fewer blocks" in out.getvalue()
+        res.config._engine.close()
+    devs = np.array(devs)
+    print("block = 256: measured mean deviation per run", np.round(devs.mean(0), 2), " predicted z", np.round(np.mean(zs), 2))
+    assert np.all(devs.mean(0) > 2.0)                                            # the bias is there (the reference's own) ...
+    assert 0.3 * devs.mean() < np.mean(zs) < 3.0 * devs.mean(), (devs.mean(0), zs)   # ... and the note's estimate is its size
+    for kw in (dict(solver="mcmc", neval=1e6, niter=10, block=16), dict(solver="vegasmc", neval=1e6, niter=10, block=256)):
+        res = integrate(mci.catalog.nested_gauss(), config=c5(1), **kw)
+        out = io.StringIO()
+        mci.report(res, io=out)
+        assert (res.chain_bias is None or res.chain_bias["z"] < 2.0) and "note: solver" not in out.getvalue(), (kw, res.chain_bias)
+        res.config._engine.close()
+    for solver in ("vegasmc", "mcmc"):                                           # the reference's default call (main.jl:72-76), README integrand
+        res = integrate("return log(x[0]) / sqrt(x[0]);", solver=solver, seed=3)
+        out = io.StringIO()
+        mci.report(res, io=out)
+        assert res.chain_bias is not None and res.chain_bias["z"] < 2.0 and "note: solver" not in out.getvalue(), (solver, res.chain_bias)
+        res.config._engine.close()
 
 
 def test_default_call_of_the_default_solver_is_unbiased_at_its_own_size():

@@ -279,3 +279,29 @@ def test_result_says_when_weighted_and_plain_average_of_the_iterations_disagree(
     out = io.StringIO()
     mci.report(quiet, io=out)
     assert "note:" not in out.getvalue()
+
+
+def test_chain_estimator_bias_note_follows_block_length_and_count():
+    """statistics.chain_estimator_bias: z = k tau sqrt(B I / N) for ONE chain per block (the reference's chain); report(result) prints
+    its note from z = 2 on.  The +5.7 .. +7.3 sigma call of profiles/r05_odd_calls.txt (:mcmc, block = 256, neval = 1e6: 3906 steps per
+    block) with the acceptance measured there gives z = 7; the default call does not reach 2; several chains per block: no estimate."""
+    import io
+    from mcintegration_jl_amd.statistics import chain_estimator_bias as est
+    pr, ac = np.full((3, 5, 5), 100.0), np.full((3, 5, 5), 92.0)
+    b = est("mcmc", 3906, 1, 256, 9, pr, ac, 12)
+    assert 6.5 < b["z"] < 7.5 and 14.0 < b["tau"] < 16.0 and 200 < b["times"] < 300
+    assert est("mcmc", 3906, 4, 256, 9, pr, ac, 12) is None and est("vegas", 3906, 1, 256, 9, pr, ac, 12) is None
+    assert est("vegasmc", 3906, 1, 256, 9, pr, ac, 12)["z"] == pytest.approx(b["z"] / 5.0)
+    assert est("mcmc", 62500, 1, 16, 9, pr, ac, 12)["z"] == pytest.approx(b["z"] / 16.0, rel=1e-3)     # z ~ B at fixed neval: 16 x fewer blocks of 16 x the length
+    assert est("mcmc", 625, 1, 16, 9, np.full(4, 100.0), np.full(4, 90.0), 1)["z"] < 1.0                # the default call, README integrand
+    assert est("mcmc", 3906, 1, 256, 9, pr, np.zeros_like(pr), 12) is None                              # nothing accepted yet: no estimate
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]])
+    res = mci.Result(1.0 + 0.01 * np.arange(5.0)[:, None], np.full((5, 1), 0.01), cfg, ignore=1)
+    out = io.StringIO()
+    mci.report(res, io=out)
+    assert "note: solver" not in out.getvalue() and res.chain_bias_note is None
+    res.chain_bias = b
+    out = io.StringIO()
+    mci.report(res, io=out)
+    assert "note: solver = :mcmc ran one chain per block of 3906 steps" in out.getvalue() and "fewer blocks (block = 16 gives 0.4)" in out.getvalue()
+    assert res.with_ignore(2).chain_bias is b

@@ -1060,6 +1060,9 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
                 double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
                 for (int i = tid; i < Cfg::tile_nbin(tt); i += T) {
                     constexpr int SB = Cfg::DET != 0 ? 1 : Cfg::HCOPY, SC = Cfg::DET != 0 ? Cfg::HTILE : 1; // strides of bin and copy (hslot)
+                    // (one bin's copies per lane: HCOPY consecutive doubles, which the compiler reads as 16-byte loads.  Reading slot j on
+                    // lane j and adding the copies up with row_shr moves instead -- no strided reads, four barriers -- was measured 1.7 us
+                    // SLOWER per launch at every size; profiles/r06_latency.txt)
                     double v = sH[i * SB];
                     static_for<1, Cfg::HCOPY>([&](auto Cc) { v += sH[i * SB + decltype(Cc)::value * SC]; }); // fixed order
                     if (!accum && a.hist_atomic) { // (BatchArgs::hist_atomic: no merge launch behind this one)
@@ -1102,7 +1105,7 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     double *sH = smem + L::H, *sO = smem + L::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
     if constexpr (Mode<Cfg>::HIST_LDS && !NOHIST)
-        for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
+        for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0; // (16-byte stores instead: no difference, profiles/r06_latency.txt)
     for (int i = tid; i < Cfg::NOBS * ocopy<Cfg>(); i += T) sO[i] = 0.0;
     Tables<Cfg> t;
     t.EC = nullptr;

@@ -307,7 +307,7 @@ int mci_kernel_clocks(mci_problem *p, double *mhz, int32_t n, int32_t *got) {
     int32_t k = 0;
     for (int64_t i = 0; i < have; ++i) {
         const int slot = (int)((p->launches - have + i) % mci_problem::kEvRing);
-        if (!p->ev_valid[slot] || !h[(size_t)2 * slot + 1]) continue;
+        if (!p->ev_valid[slot] || !p->clock_valid[slot] || !h[(size_t)2 * slot + 1]) continue; // (a slot whose launch did not stamp holds an older launch's words)
         mhz[k++] = (double)h[(size_t)2 * slot] / (double)h[(size_t)2 * slot + 1] * (double)khz * 1.0e-3;
     }
     *got = k;

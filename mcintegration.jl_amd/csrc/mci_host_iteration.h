@@ -633,6 +633,7 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         HIPCHK(hipModuleLaunchKernel(p->f_tiles[kern == kSlotVegasAny ? 1 : 0], (unsigned)(((hist_rows + 7) / 8) * 8 * (s.ntile - (s.split_all ? 0 : 1))), 1, 1, (unsigned)T, 1, 1, (unsigned)p->lds_bytes, st, args, nullptr));
     if (p->time_this_launch) HIPCHK(hipEventRecord(p->evs[2 * slot + 1], st));
     p->ev_valid[slot] = p->time_this_launch;
+    p->clock_valid[slot] = a.clock_out != nullptr && !split && s.ntile == 1; // (what the kernel stamps: mci_device.h vegas_batch `stamp`)
     p->launches += 1;
     if (s.host_measure) {
         // the closure cannot run on the device: this launch's (measured) configurations and relative weights go to the host
@@ -641,7 +642,9 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         const int64_t n = nblocks * hm_n;
         const int nw = s.ni * s.ncomp, nc = s.ncomp;
         std::vector<double> obs((size_t)nblocks * s.nobs, 0.0);
-        if (n > 0) {
+        // (the self-check of a new several-lanes-per-chain code object, spec_self_check, never calls the USER's closure: its two small
+        // launches compare histograms, normalisation, visits and acceptance tables; the observables stay zero in both)
+        if (n > 0 && !p->in_self_check) {
             HIPCHK(hipMemcpyAsync(p->h_mx, p->d_mx, (size_t)n * s.ndraw * sizeof(double), hipMemcpyDeviceToHost, st));
             HIPCHK(hipMemcpyAsync(p->h_mrelw, p->d_mrelw, (size_t)n * hm_rows * sizeof(double), hipMemcpyDeviceToHost, st));
             if (solver == MCI_MCMC) HIPCHK(hipMemcpyAsync(p->h_midx, p->d_midx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -127,6 +127,14 @@ static int compile_solver(mci_problem *p, int slot) {
             chosen.rc = mcijit::compile(chosen.src, chosen.threads, chosen.code, chosen.log, chosen.cached, &chosen.path);
             if (chosen.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", chosen.log.c_str());
         }
+        if (!p->threads_vegas && p->vegas_wide && (chosen.vgprs() > 128 || chosen.scratch() != 0)) {
+            // (the 512-thread launch bound of a light integrand's plain layout was checked on the FIRST variant only: this one does not
+            // fit it -- both variants run 256-thread workgroups from here on, which the first one's code object allows)
+            p->vegas_wide = false;
+            chosen.threads = p->threads;
+            chosen.rc = mcijit::compile(chosen.src, chosen.threads, chosen.code, chosen.log, chosen.cached, &chosen.path);
+            if (chosen.rc) return fail(MCI_ERR_COMPILE, "integrand failed to compile for gfx950:\n%s", chosen.log.c_str());
+        }
     } else {
         const bool hcopy_plan = p->hcopy_plan && !g_over.hist_copies.on;
         int tcopy = 512;

@@ -179,6 +179,7 @@ struct mci_problem {
     int kernel_timing = -1;       // mci_set_kernel_timing
     bool time_this_launch = true;
     bool ev_valid[512] = {};      // one per slot of the event ring (kEvRing)
+    bool clock_valid[512] = {};   // ... and: the launch of that slot stamped its shader clock (timed one-tile :vegas launches only, mci_kernel_clocks)
     int hcopy_auto = 1, hcopy_rule = 1; // in force | what the placement rule picked at create
     // deterministic mode (mci_set_deterministic): every solver's kernel keeps one histogram / observable copy per wave; the workgroup
     // size each was compiled for (the largest of 512 / 256 / 128 / 64 threads whose copies fit the CU's LDS)
@@ -187,7 +188,7 @@ struct mci_problem {
     bool hcopy_plan = false; // the rule also picked the workgroup size (512 threads) for the :vegas kernel
     // refinement walk of train! (variable.jl:227-234): -1 automatic -- the reference's serial recurrence whenever the sample
     // launch before it is long enough to hide its ~14 us per iteration (>= kSerialWalkSamples samples or chain steps on this
-    // rank: 1 % of the headline iteration), the prefix-scan form below that; mci_set_train_walk / MCI_TRAIN_SERIAL=1 | 0 force one
+    // rank: 1 % of the headline iteration), the prefix-scan form below that; mci_set_train_walk forces one
     int train_serial = -1;
     bool debug_wrong_decision = false; // csrc/mci_debug.h: the serial walk's slots with one planted wrong decision (TrainArgs::serial_walk == 3)
     int64_t last_samples = 0; // samples (vegas) or chain steps of the last sample launch on this rank
@@ -428,7 +429,8 @@ int hold_publish(mci_problem *p, int64_t chain_len, bool carried) {
 // ... behind the all-reduce of `packed` (the library's, or an external reducer's: mci_external_reduce_done): the summed counts
 int hold_publish_reduced(mci_problem *p) {
     hipStream_t st = p->ctx->stream;
-    if (p->hold_inflight) HIPCHK(hipEventSynchronize(p->hold_ev));
+    // (no wait for a copy still in flight -- this rank's own counts published behind the sample kernel when an external reducer sums the
+    // packed buffer: the summed counts go to ANOTHER pinned buffer, and the event is simply recorded again behind them)
     HIPCHK(hipMemcpyAsync(p->h_hold_d, p->d_packed + p->packed_n, 64 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(p->hold_ev, st));
     p->hold_inflight = true;

@@ -166,6 +166,11 @@ __global__ void __launch_bounds__(256) k_resample_chains(ResampleArgs a) {
     __syncthreads();
     const bool in_lds = (a.w_chain != nullptr || a.nd <= kNd) && a.n_old <= kLdsW;
     const double step = W[a.n_old - 1] / (double)a.n_new;
+    if (!(W[a.n_old - 1] > 0.0)) { // every stored chain has weight zero (or the total is not a number): nothing to resample BY -- spread the
+        // new chains over the stored ones instead of continuing all of them from the last (they burn in from there like fresh starts)
+        for (long long c = tid; c < a.n_new; c += T) src[c] = (int)(c % a.n_old);
+        return;
+    }
     for (long long c = tid; c < a.n_new; c += T) {
         const double target = ((double)c + 0.6180339887498949) * step;
         long long lo = 0, hi = a.n_old - 1; // smallest j with W[j] > target

@@ -41,7 +41,7 @@ if __name__ == "__main__":
             eng = mci.Engine(cfg, mci.catalog.x2y2())
             # (light :vegas calls go persistent once that kernel's own translation unit exists: the automatic mode compiles it in the
             # background after 256 such calls of a process; here it is compiled on the spot and the automatic size rule applied by hand)
-            if solver == "vegas" and neval * 2 < 2**19 and os.environ.get("MCI_PERSISTENT", "-1") != "0":
+            if solver == "vegas" and neval * 2 < 2**19 and "--no-persistent" not in sys.argv:   # (a switch of this tool: the library reads no such variable)
                 eng.set_persistent("on")
             eng.integrate(solver, neval=neval, niter=3, block=16, seed=1)
             persistent = solver == "vegas" and eng.last_integrate_persistent()

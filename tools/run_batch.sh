@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box batches behind the numbers in profiles/ (one parameterised script; run as `gpurun -- bash tools/run_batch.sh <batch> [args]`).
 # Every batch writes under gpurun_out/<batch>/; what is to be judged is copied into profiles/ by hand afterwards.
-#   round 6:  ab_exec_mask
+#   round 6:  ab_exec_mask | midsize
 #   round 5 (kept as they ran, cited by profiles/README.md): r05_<name>
 set -u
 batch=${1:-help}; shift || true
@@ -37,6 +37,22 @@ for v in ("default", "off"):
     for f in sorted(glob.glob("gpurun_out/ab_exec_mask/default_%s_*.txt" % v)):
         print(v, "default call:", open(f).read().strip().splitlines()[-1][:200])
 PY
+;;
+midsize)
+# the fixed cost of a mid-size launch of the headline layout -- the copy summation with conflict-free reads + row_shr adds
+# (MCI_COPY_SUM_DPP), 16-byte zeroing stores (MCI_ZERO_B128), fewer histogram copies -- each variant twice, interleaved.  (The two macros
+# belong to the experiment's commit, 'Exec-mask ...' + 1: neither variant gained anything and the code went again, profiles/r06_latency.txt;
+# on the present tree the four JIT-flag rows measure the same kernel.)
+for rep in 1 2; do
+MCI_JIT_FLAGS="-DMCI_COPY_SUM_DPP=0 -DMCI_ZERO_B128=0" python tools/midsize_c2.py "round 5 epilogue"
+MCI_JIT_FLAGS="-DMCI_ZERO_B128=0" python tools/midsize_c2.py "dpp sum"
+MCI_JIT_FLAGS="-DMCI_COPY_SUM_DPP=0" python tools/midsize_c2.py "b128 zero"
+python tools/midsize_c2.py "dpp sum + b128 zero"
+python tools/midsize_c2.py --copies 4 "both, 4 copies"
+python tools/midsize_c2.py --copies 2 "both, 2 copies"
+python tools/midsize_c2.py --copies 1 "both, 1 copy"
+MCI_JIT_FLAGS="-DMCI_COPY_SUM_DPP=0 -DMCI_ZERO_B128=0" python tools/midsize_c2.py --copies 2 "round 5, 2 copies"
+done 2>&1 | tee $out/midsize.txt
 ;;
 r05_bias)
 # GPU box: the three bias flags of VERDICT r04 at their own configurations (tools/bias_ab.py) -> gpurun_out/r05_bias/

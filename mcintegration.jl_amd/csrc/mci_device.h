@@ -1054,16 +1054,48 @@ template <class Cfg, class L = Lds<Cfg>, bool WRITE_HIST = true, bool WRITE_PA =
         for (int i = tid; i < 2 * PaTable<Cfg>::N && tile == 0; i += T) prow[i] = ACCUM ? prow[i] + (double)sPA[i] : (double)sPA[i];
     }
     if constexpr (Mode<Cfg>::HIST_LDS && WRITE_HIST) {
+        // ABLATION SWITCH, off (MCI_JIT_FLAGS=-DMCI_COPY_SUM_DPP=1; tools/run_batch.sh midsize): the interleaved copies summed IN PLACE
+        // first -- lane j reads slot j (a wave reads 64 consecutive doubles), the HCOPY neighbouring lanes that hold one bin's copies add
+        // them up with row_shr moves, the last lane of the group stores the sum at sH[bin] (slots are read a round before anything is
+        // stored over them, behind the round's barrier).  Measured 1.7 us SLOWER per launch at every size than the loop below, whose
+        // HCOPY consecutive doubles per lane the compiler already reads as 16-byte loads (profiles/r06_latency.txt).
+#ifndef MCI_COPY_SUM_DPP
+#define MCI_COPY_SUM_DPP 0
+#endif
+        constexpr bool SUMMED = MCI_COPY_SUM_DPP != 0 && Cfg::DET == 0 && Cfg::HCOPY > 1 && Cfg::HCOPY <= 16 && Cfg::NTILE == 1;
+        if constexpr (SUMMED) {
+            constexpr int N = Cfg::HTILE * Cfg::HCOPY, K = 4;
+            for (int base = 0; base < N; base += T * K) {
+                double v[K];
+                static_for<0, K>([&](auto Kk) {
+                    constexpr int k = decltype(Kk)::value;
+                    const int j = base + k * T + tid;
+                    v[k] = j < N ? sH[j] : 0.0;
+                });
+                static_for<0, K>([&](auto Kk) {
+                    constexpr int k = decltype(Kk)::value;
+                    if constexpr (Cfg::HCOPY > 1) v[k] += dpp_read<0x111, 0xf>(v[k]); // row_shr:1 (groups of HCOPY lanes never straddle a row of 16)
+                    if constexpr (Cfg::HCOPY > 2) v[k] += dpp_read<0x112, 0xf>(v[k]);
+                    if constexpr (Cfg::HCOPY > 4) v[k] += dpp_read<0x114, 0xf>(v[k]);
+                    if constexpr (Cfg::HCOPY > 8) v[k] += dpp_read<0x118, 0xf>(v[k]);
+                });
+                __syncthreads();
+                static_for<0, K>([&](auto Kk) {
+                    constexpr int k = decltype(Kk)::value;
+                    const int j = base + k * T + tid;
+                    if (j < N && (tid & (Cfg::HCOPY - 1)) == Cfg::HCOPY - 1) sH[j / Cfg::HCOPY] = v[k];
+                });
+            }
+            __syncthreads();
+        }
         static_for<0, Cfg::NTILE>([&](auto Tt) {
             constexpr int tt = decltype(Tt)::value;
             if (tile == tt) {
                 double *hrow = a.part_hist + rowid * Cfg::NBIN + Cfg::tile_boff(tt);
                 for (int i = tid; i < Cfg::tile_nbin(tt); i += T) {
-                    constexpr int SB = Cfg::DET != 0 ? 1 : Cfg::HCOPY, SC = Cfg::DET != 0 ? Cfg::HTILE : 1; // strides of bin and copy (hslot)
-                    // (one bin's copies per lane: HCOPY consecutive doubles, which the compiler reads as 16-byte loads.  Reading slot j on
-                    // lane j and adding the copies up with row_shr moves instead -- no strided reads, four barriers -- was measured 1.7 us
-                    // SLOWER per launch at every size; profiles/r06_latency.txt)
+                    constexpr int SB = (Cfg::DET != 0 || SUMMED) ? 1 : Cfg::HCOPY, SC = Cfg::DET != 0 ? Cfg::HTILE : 1; // strides of bin and copy (hslot)
                     double v = sH[i * SB];
+                    if constexpr (!SUMMED)
                     static_for<1, Cfg::HCOPY>([&](auto Cc) { v += sH[i * SB + decltype(Cc)::value * SC]; }); // fixed order
                     if (!accum && a.hist_atomic) { // (BatchArgs::hist_atomic: no merge launch behind this one)
                         if (v != 0.0) global_add(&a.ghist[(rowid % a.hist_atomic) * Cfg::NBIN + Cfg::tile_boff(tt) + i], v);
@@ -1104,8 +1136,17 @@ template <class Cfg, bool SPLIT = false> __device__ __forceinline__ void vegas_b
     double *sE = smem + L::E, *sDA = smem + L::DA, *sDD = smem + L::DD;
     double *sH = smem + L::H, *sO = smem + L::O;
     stage_tables<Cfg>(a.edges, a.dacc, a.ddist, sE, sDA, sDD);
-    if constexpr (Mode<Cfg>::HIST_LDS && !NOHIST)
-        for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0; // (16-byte stores instead: no difference, profiles/r06_latency.txt)
+#ifndef MCI_ZERO_B128
+#define MCI_ZERO_B128 0 // (ablation switch, off: 16-byte zeroing stores made no difference, profiles/r06_latency.txt)
+#endif
+    if constexpr (Mode<Cfg>::HIST_LDS && !NOHIST) {
+        if constexpr (MCI_ZERO_B128 != 0 && L::H % 2 == 0 && (Cfg::HTILE * Cfg::HCOPY) % 2 == 0) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 *z = reinterpret_cast<d2 *>(sH);
+            for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY / 2; i += T) z[i] = d2{0.0, 0.0};
+        } else
+        for (int i = tid; i < Cfg::HTILE * Cfg::HCOPY; i += T) sH[i] = 0.0;
+    }
     for (int i = tid; i < Cfg::NOBS * ocopy<Cfg>(); i += T) sO[i] = 0.0;
     Tables<Cfg> t;
     t.EC = nullptr;

@@ -40,18 +40,16 @@ PY
 ;;
 midsize)
 # the fixed cost of a mid-size launch of the headline layout -- the copy summation with conflict-free reads + row_shr adds
-# (MCI_COPY_SUM_DPP), 16-byte zeroing stores (MCI_ZERO_B128), fewer histogram copies -- each variant twice, interleaved.  (The two macros
-# belong to the experiment's commit, 'Exec-mask ...' + 1: neither variant gained anything and the code went again, profiles/r06_latency.txt;
-# on the present tree the four JIT-flag rows measure the same kernel.)
+# (-DMCI_COPY_SUM_DPP=1), 16-byte zeroing stores (-DMCI_ZERO_B128=1), fewer histogram copies -- each variant twice, interleaved
 for rep in 1 2; do
-MCI_JIT_FLAGS="-DMCI_COPY_SUM_DPP=0 -DMCI_ZERO_B128=0" python tools/midsize_c2.py "round 5 epilogue"
-MCI_JIT_FLAGS="-DMCI_ZERO_B128=0" python tools/midsize_c2.py "dpp sum"
-MCI_JIT_FLAGS="-DMCI_COPY_SUM_DPP=0" python tools/midsize_c2.py "b128 zero"
-python tools/midsize_c2.py "dpp sum + b128 zero"
-python tools/midsize_c2.py --copies 4 "both, 4 copies"
-python tools/midsize_c2.py --copies 2 "both, 2 copies"
-python tools/midsize_c2.py --copies 1 "both, 1 copy"
-MCI_JIT_FLAGS="-DMCI_COPY_SUM_DPP=0 -DMCI_ZERO_B128=0" python tools/midsize_c2.py --copies 2 "round 5, 2 copies"
+python tools/midsize_c2.py "round 5 epilogue"
+MCI_JIT_FLAGS="-DMCI_COPY_SUM_DPP=1" python tools/midsize_c2.py "dpp sum"
+MCI_JIT_FLAGS="-DMCI_ZERO_B128=1" python tools/midsize_c2.py "b128 zero"
+MCI_JIT_FLAGS="-DMCI_COPY_SUM_DPP=1 -DMCI_ZERO_B128=1" python tools/midsize_c2.py "dpp sum + b128 zero"
+MCI_JIT_FLAGS="-DMCI_COPY_SUM_DPP=1 -DMCI_ZERO_B128=1" python tools/midsize_c2.py --copies 4 "both, 4 copies"
+MCI_JIT_FLAGS="-DMCI_COPY_SUM_DPP=1 -DMCI_ZERO_B128=1" python tools/midsize_c2.py --copies 2 "both, 2 copies"
+MCI_JIT_FLAGS="-DMCI_COPY_SUM_DPP=1 -DMCI_ZERO_B128=1" python tools/midsize_c2.py --copies 1 "both, 1 copy"
+python tools/midsize_c2.py --copies 2 "round 5, 2 copies"
 done 2>&1 | tee $out/midsize.txt
 ;;
 r05_bias)

@@ -160,16 +160,19 @@ def issue_roofline(code_object, costs, samples_per_launch, kernel_ms, hist_copie
         peak = N_SIMD / (cyc[pipe] / n_inst) if n_inst else 0.0   # 1024 SIMDs / mean ns per instruction
         out[pipe] = {"achieved": round(ach, 2), "peak": round(peak, 2), "frac": round(ach / peak, 4) if peak else None,
                      "instructions_per_wave_sample": n_inst, "issue_ns_per_wave_sample": round(cyc[pipe], 1)}
-    # the same mix at DATA-SHEET issue cycles and the shader clock the timed launches measured themselves running at: a fraction anyone can
-    # recompute from the instruction counts below -- sum(n * cycles) * wave-samples per SIMD / clock / kernel time
-    ds_cyc, ds_per = isa_mix.datasheet_valu_cycles(mix)
-    out["valu_datasheet"] = {"cycles_per_wave_sample": ds_cyc, "sclk_mhz": None if not sclk_mhz else round(sclk_mhz, 1),
-                             "wave_samples_per_simd": round(trips / N_SIMD, 2),
-                             "classes": {cls: {"n": n, "cycles_each": c} for cls, (n, c) in sorted(ds_per.items())}}
-    if sclk_mhz:
-        ns = ds_cyc / (sclk_mhz * 1e-3)                                  # ns per wave-sample on its SIMD
-        out["valu_datasheet"].update({"issue_ns_per_wave_sample": round(ns, 1),
-                                      "frac": round(ns * 1e-6 * (trips / N_SIMD) / kernel_ms, 4)})
+    # the same mix at whole issue CYCLES per instruction class and the shader clock the timed launches measured themselves running at: a
+    # fraction anyone can recompute from the instruction counts below -- sum(n * cycles) * wave-samples per SIMD / clock / kernel time.
+    # valu_rounded_measured: the guide's 2 / 4 cycles, and 4 for the three-source / SGPR-source 32-bit forms as THIS repository's
+    # microbenchmark measured them (rounded; isa_mix.DATASHEET_CYCLES -- not a published table); valu_flat_2cycle: every 32-bit form
+    # at the guide's flat 2 cycles -- the pessimistic reading.  The truth lies between the two fractions.
+    for key, table in (("valu_rounded_measured", None), ("valu_flat_2cycle", isa_mix.FLAT_CYCLES)):
+        ds_cyc, ds_per = isa_mix.datasheet_valu_cycles(mix, table)
+        out[key] = {"cycles_per_wave_sample": ds_cyc, "sclk_mhz": None if not sclk_mhz else round(sclk_mhz, 1),
+                    "wave_samples_per_simd": round(trips / N_SIMD, 2),
+                    "classes": {cls: {"n": n, "cycles_each": c} for cls, (n, c) in sorted(ds_per.items())}}
+        if sclk_mhz:
+            ns = ds_cyc / (sclk_mhz * 1e-3)                                  # ns per wave-sample on its SIMD
+            out[key].update({"issue_ns_per_wave_sample": round(ns, 1), "frac": round(ns * 1e-6 * (trips / N_SIMD) / kernel_ms, 4)})
     out["mix"] = {cls: {"n": n, "ns_each": round(c, 3)} for cls, (n, c) in sorted(cyc["per_class"].items())}
     out["samples_per_loop_trip"] = mix["samples_per_trip"]
     out["resources"] = isa_mix.resources(code_object).get("mci_vegas_batch")
@@ -450,8 +453,8 @@ def main():
             if costs:
                 ir = issue_roofline(code_object, costs, spl, k_avg_ms, hist_copies=out["config"].get("histogram_copies", 1), sclk_mhz=sclk)
                 top = "valu" if ir["valu"]["frac"] >= ir["lds"]["frac"] else "lds"
-                ds = ir["valu_datasheet"]
-                # `frac`: the VALU pipe at data-sheet issue cycles and the measured clock (recomputable from the line itself); the
+                ds = ir["valu_rounded_measured"]
+                # `frac`: the VALU pipe at whole issue cycles per class (measured, rounded) and the measured clock (recomputable from the line itself); the
                 # self-calibrated reading (issue costs this run measured with its own microbenchmark) rides along as frac_self_calibrated
                 if ds.get("frac") is not None:
                     peak_ds = N_SIMD / (ds["issue_ns_per_wave_sample"] / ir["valu"]["instructions_per_wave_sample"])
@@ -460,11 +463,15 @@ def main():
                 else:
                     roof.update({"achieved": ir[top]["achieved"], "peak": ir[top]["peak"], "unit": "G wave-instructions/s", "frac": ir[top]["frac"],
                                  "binding_pipe": top, "frac_self_calibrated": ir[top]["frac"]})
-                roof.update({"valu_datasheet": ds, "valu": ir["valu"], "lds": ir["lds"], "mix": ir["mix"], "resources": ir["resources"],
+                roof.update({"valu_rounded_measured": ds, "valu_flat_2cycle": ir["valu_flat_2cycle"], "frac_flat_2cycle": ir["valu_flat_2cycle"].get("frac"),
+                             "valu": ir["valu"], "lds": ir["lds"], "mix": ir["mix"], "resources": ir["resources"],
                              "costs_source": costs_src,
-                             "note": "frac = VALU issue time of the sample loop at DATA-SHEET cycles (valu_datasheet.classes: n x cycles per wave "
-                                     "and sample) x wave-samples per SIMD / the shader clock the timed launches measured (clock.sclk_mhz_avg) / "
-                                     "HIP-event kernel time; peak = 1024 SIMDs / (data-sheet cycles per instruction of this mix / that clock).  "
+                             "note": "frac = VALU issue time of the sample loop at whole cycles per instruction class (valu_rounded_measured.classes: n x "
+                                     "cycles per wave and sample; the guide's 2 / 4 cycles, and 4 for the 32-bit forms with three sources or an SGPR "
+                                     "source as this repository's microbenchmark measured them -- rounded, not a published table) x wave-samples per "
+                                     "SIMD / the shader clock the timed launches measured (clock.sclk_mhz_avg) / HIP-event kernel time; peak = 1024 "
+                                     "SIMDs / (those cycles per instruction of this mix / that clock).  frac_flat_2cycle = the same with EVERY 32-bit "
+                                     "form at the guide's flat 2 cycles (valu_flat_2cycle): the pessimistic reading, the truth lies between the two.  "
                                      "frac_self_calibrated = the same mix priced with the issue costs tools/issue_microbench.hip measured on this "
                                      "GPU in this run (valu / lds: separate pipes that overlap, the larger fraction binds).  The SURVEY 8(d) HBM "
                                      "model is kept in hbm_model"})

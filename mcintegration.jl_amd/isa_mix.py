@@ -42,10 +42,13 @@ COST_KEY = {
 }
 
 
-# Data-sheet issue cycles of a wave64 instruction on a CDNA4 SIMD (32 lanes wide for 32-bit VOP1/VOP2 forms: 2 cycles; fp64, the
-# 64-bit integer forms, v_mad_u64_u32 / v_mul_*_u32 and every 32-bit form with three sources or an SGPR third source: 4; transcendentals
-# quarter rate: 8; f64 rcp: 16).  bench.py prices the loop's mix with these at the clock the kernel MEASURED itself running at
-# (mci_kernel_clocks) next to the self-calibrated costs of tools/issue_microbench.hip.
+# Issue cycles of a wave64 instruction on a CDNA4 SIMD, MEASURED AND ROUNDED -- not a published table: 32-bit VOP1/VOP2 forms 2 cycles
+# and fp64 / the 64-bit integer forms 4 are the guide's figures (MI355X_MICROARCH.md), transcendentals at quarter rate 8, f64 rcp 16; the
+# 4 cycles of v_mad_u64_u32 / v_mul_*_u32 and of every 32-bit form with three sources or an SGPR third source (63 instructions of the
+# headline loop) come from THIS repository's microbenchmark (tools/issue_microbench.hip, profiles/r02_issue_costs.txt: 1.73-1.80 ns per
+# wave-instruction and SIMD at ~2.3 GHz = 4.0-4.1 cycles) rounded to the cycle.  bench.py prices the loop's mix with these at the clock
+# the kernel MEASURED itself running at (mci_kernel_clocks) -- roofline.valu_rounded_measured -- and, next to it, with the guide's flat
+# 2 cycles for every 32-bit form (FLAT_CYCLES: roofline.valu_flat_2cycle), which is the pessimistic reading of the same launch.
 DATASHEET_CYCLES = {
     "valu_b32": 2, "valu_bitop3_vgpr": 2, "valu_bitop3": 4, "valu_b32_3src": 4, "valu_mad_u64_u32": 4, "valu_mul_u32": 4, "valu_b64": 4,
     "valu_f64_fma": 4, "valu_f64_mul": 4, "valu_f64_add": 4, "valu_f64_fract": 4, "valu_f64_cvt": 4, "valu_f64_cmp": 4, "valu_f64_ldexp": 4,
@@ -53,12 +56,17 @@ DATASHEET_CYCLES = {
 }
 
 
-def datasheet_valu_cycles(mix):
-    """(cycles per wave and sample on the VALU pipe at data-sheet issue rates, {class: (n, cycles each)})"""
+FLAT_CYCLES = dict(DATASHEET_CYCLES, valu_bitop3=2, valu_b32_3src=2)   # the guide's flat 2-cycle issue for EVERY 32-bit VALU form
+
+
+def datasheet_valu_cycles(mix, table=None):
+    """(cycles per wave and sample on the VALU pipe, {class: (n, cycles each)}) under DATASHEET_CYCLES (measured, rounded; the default)
+    or another table (FLAT_CYCLES)"""
+    table = DATASHEET_CYCLES if table is None else table
     per, tot = {}, 0.0
     for cls, n in mix["classes"].items():
         if cls.startswith("valu"):
-            c = DATASHEET_CYCLES.get(cls, 2)
+            c = table.get(cls, 2)
             per[cls] = (n, c)
             tot += n * c
     return tot, per

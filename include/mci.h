@@ -293,8 +293,7 @@ int mci_set_rng_rounds(mci_problem *prob, int32_t rounds);
  *   0  the same walk as a fixed-order prefix scan + one bisection per grid point (agrees with the recurrence to 1e-12 of
  *      the variable's range per train! step, i.e. whole runs agree to ~1e-4 instead of ~1e-6);
  *  -1  automatic (default): 1 when the iteration's sample launch on this rank is >= 2^26 samples (the walk then costs ~1 % or less), else 0.
- * (No environment variable stands behind it: the library reads MCI_KERNEL_CACHE and MCI_JIT_FLAGS and nothing else; tests force a mode
- * on every new problem through csrc/mci_debug.h, key train_walk.) */
+ * (No environment variable stands behind it: the library reads MCI_KERNEL_CACHE and MCI_JIT_FLAGS and nothing else.) */
 int mci_set_train_walk(mci_problem *prob, int32_t mode);
 /* Deterministic mode: with on = 1 a fixed seed gives BIT-IDENTICAL results run to run (histograms, grids, every iteration's mean
  * and error), like the reference's sequential loop under `MersenneTwister(seed)` (configuration.jl:190, vegas/montecarlo.jl:117-187).

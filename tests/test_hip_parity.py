@@ -244,27 +244,37 @@ def test_c4_32_bit_stream_with_gather_phase_matches_oracle(oracle, threads):
     np.testing.assert_allclose(got[4:], ref[4:], rtol=1e-9)
 
 
-@pytest.mark.parametrize("chunk,measurefreq,keep_tile0", [(1000, 1, 0), (1000, 3, 0), (37, 1, 0), (4000, 1, 1), (10**9, 1, 0)],
-                         ids=["1000", "1000_mf3", "tiny_ragged", "tile0_in_pass", "one_chunk"])
-def test_many_grid_launch_in_chunks_matches_oracle(oracle, overrides, chunk, measurefreq, keep_tile0):
+@pytest.mark.parametrize("chunk,layout,measurefreq,keep_tile0", [(1000, "c4", 1, 0), (37, "c4", 1, 0), (4000, "c4", 1, 1), (10**9, "c4", 1, 0), (500, "three_grids", 3, 0)],
+                         ids=["1000", "tiny_ragged", "tile0_in_pass", "one_chunk", "three_grids_mf3"])
+def test_many_grid_launch_in_chunks_matches_oracle(oracle, overrides, chunk, layout, measurefreq, keep_tile0):
     """The reference's loop is constant memory in neval (vegas/montecarlo.jl:117-187).  A many-grid launch (BASELINE configs[3]: 32 grids,
     the histograms in two LDS tiles) parks (weights, bins) per sample for the replay; it runs in chunks of the blocks' samples -- sample
     pass -> replay per chunk, same Philox indices, partial rows accumulated -- so that the parked stream is bounded.  With the chunk forced
-    to a few samples the launch equals the oracle at the tolerances of the one-chunk launch, measurefreq and a block range included."""
-    ud = genz_userdata(32)
+    to a few samples the launch equals the oracle at the tolerances of the one-chunk launch: a block range, a ragged last chunk, tile 0
+    kept in the sample pass, and (on a small three-tile layout whose any-cadence kernel compiles in a second) measurefreq = 3."""
     overrides.set("split_chunk", chunk)
     if keep_tile0:
         overrides.set("no_split_all", 1)
-    cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
-    eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32))
-    ocfg = oracle.Config([ocont(0) for _ in range(32)], [[1]])
+    if layout == "c4":
+        ud, ndraw = genz_userdata(32), 32
+        cfg = mci.Configuration(var=mci.Continuous([(0.0, 1.0)] * 32), dof=[[1]], seed=SEED)
+        eng = mci.Engine(cfg, mci.catalog.genz_product_peak(32))
+        ocfg, oname = oracle.Config([ocont(0) for _ in range(32)], [[1]]), "genz_product_peak"
+    else:
+        overrides.set("table_mode", 3)
+        overrides.set("hist_tile_bins", 1000)          # one 999-bin leaf per tile -> 3 tiles, every one replayed
+        ud, ndraw = None, 3
+        cfg = mci.Configuration(var=mci.Continuous([(0.0, PI)] * 3), dof=[[1]], seed=SEED)
+        eng = mci.Engine(cfg, mci.catalog.singular2())
+        ocfg, oname = oracle.Config([ocont(0, 0.0, PI) for _ in range(3)], [[1]]), "singular2"
     npb, lo, hi = 2003, 1, 5                           # (an odd block length: the last chunk is ragged)
     got = eng.iteration("vegas", npb, lo, hi, iteration=2, seed=SEED, measurefreq=measurefreq)
-    ref = ocfg.iteration(oracle.VEGAS, "genz_product_peak", ud, npb, lo, hi, 2, SEED, measurefreq=measurefreq)
+    ref = ocfg.iteration(oracle.VEGAS, oname, ud, npb, lo, hi, 2, SEED, measurefreq=measurefreq)
     nchunks, held = eng.split_chunks()
     per = max(4, (chunk // (hi - lo)) & ~3)
     assert nchunks == (1 if per >= npb else -(-npb // per)), (nchunks, per)
-    assert held == (hi - lo) * min(per, npb) * (8 + 4 * (8 if keep_tile0 else 16))      # 8 B of weight + the replayed draws' 16-bit bins per parked sample
+    tdraws = ndraw // 2 if keep_tile0 else ndraw       # the replayed draws' 16-bit bins, two per word, next to 8 B of weight per parked sample
+    assert held == (hi - lo) * min(per, npb) * (8 + 4 * ((tdraws + 1) // 2))
     np.testing.assert_allclose(got[:4], ref[:4], rtol=1e-11)
     np.testing.assert_allclose(got[4:], ref[4:], rtol=1e-9)
     # a second launch on the same problem with another chunking: the rows of the first are not carried into it

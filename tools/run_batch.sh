@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box batches behind the numbers in profiles/ (one parameterised script; run as `gpurun -- bash tools/run_batch.sh <batch> [args]`).
 # Every batch writes under gpurun_out/<batch>/; what is to be judged is copied into profiles/ by hand afterwards.
-#   round 6:  ab_exec_mask | midsize
+#   round 6:  ab_exec_mask | midsize | r06_collect
 #   round 5 (kept as they ran, cited by profiles/README.md): r05_<name>
 set -u
 batch=${1:-help}; shift || true
@@ -13,8 +13,8 @@ ab_exec_mask)
 # default pipeline: the headline, C2 on 16 grids, C4, C3 :vegasmc, C5 :mcmc / :vegasmc / :vegas -- each variant on its own cold kernel cache,
 # two repetitions, interleaved
 for rep in 1 2; do
-for v in default off; do
-  flags=""; [ $v = off ] && flags="-mllvm -amdgpu-opt-exec-mask-pre-ra=0"
+for v in default off; do   # default = LLVM's default pipeline (the pass on): forced, since mci_jit.h now switches it off for every unit
+  flags="-mllvm -amdgpu-opt-exec-mask-pre-ra=1"; [ $v = off ] && flags="-mllvm -amdgpu-opt-exec-mask-pre-ra=0"
   export MCI_KERNEL_CACHE=/tmp/kc_$v MCI_JIT_FLAGS="$flags"
   timeout 600 python bench.py --steps 20 --warmup 5 > $out/bench_${v}_$rep.json 2> $out/bench_${v}_$rep.err
   timeout 900 python tools/bench_configs.py c2i c4 c3mc c5 > $out/configs_${v}_$rep.txt 2>&1
@@ -36,6 +36,25 @@ for v in ("default", "off"):
             elif "COLD" in ln: name = ln[:28].strip()
     for f in sorted(glob.glob("gpurun_out/ab_exec_mask/default_%s_*.txt" % v)):
         print(v, "default call:", open(f).read().strip().splitlines()[-1][:200])
+PY
+;;
+r06_collect)
+# the final batch of round 6 on the final code: GPU suite (timed), smoke, bench line + rocprofv3 / PMC of the same command, every other
+# configuration profiled, cold and trained rates, latencies, the validation matrix
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -rs --durations=12 > $out/suite.txt 2>&1; tail -3 $out/suite.txt
+python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; tail -1 $out/smoke.txt
+timeout 900 python bench.py > $out/r06_bench_line.json 2> $out/bench.err
+bash profiles/collect.sh r06 bench > $out/collect_bench.log 2>&1
+for w in c3 c4 c5 bubble_mcmc default_call; do bash profiles/collect.sh r06_$w $w > $out/collect_$w.log 2>&1; done
+cp profiles/r06*_kernel_stats.txt profiles/r06*_pmc_traffic.json $out/ 2>/dev/null
+timeout 900 python tools/bench_configs.py > $out/other_configs.txt 2>&1
+timeout 600 python tools/latency.py > $out/latency.txt 2>&1
+timeout 300 python tools/spec_bench.py default > $out/default.txt 2>&1
+timeout 900 python tools/validation_matrix.py > $out/validation_matrix.txt 2>&1
+python - <<'PY'
+import json
+j = json.loads(open("gpurun_out/r06_collect/r06_bench_line.json").read().strip().splitlines()[-1]); r = j["roofline"]
+print(j["value"], j["ms_per_step"], r["kernel_ms_avg"], r["frac"], r.get("frac_flat_2cycle"), r["frac_self_calibrated"], r["clock"]["sclk_mhz_avg"], r["traffic"], j["config"].get("code_object"))
 PY
 ;;
 midsize)

@@ -307,6 +307,16 @@ class CSym:
     def conjugate(self): return CSym(self.re, 0.0 if _z(self.im) else -self.im)
     conj = conjugate
 
+    # -- what a batch-vectorised closure does with a vector over the batch, on the one sample of the trace (like Sym)
+    def sum(self, *a, **k): return self
+
+    def __getitem__(self, m):
+        if isinstance(m, Sym) and m.op in _BOOL:
+            return where(m, self, 0.0)
+        if m is Ellipsis or (isinstance(m, slice) and m == slice(None)):
+            return self
+        raise TraceError("indexing a sampled value with %r" % (m,))
+
     def exp(self):
         e = self.re.exp() if isinstance(self.re, Sym) else math.exp(self.re)
         if _z(self.im):
@@ -820,8 +830,7 @@ def trace_measure(fn, config, indexed=False, check_points=32):
     `weights[0][x[0] < 0.5].sum()`) trace.  TraceError if it cannot be written out or disagrees with the closure at random points.
 
     fn(x, obs, weights, config)     (indexed=True: fn(idx, x, obs, weight, config), idx 0-based)"""
-    if getattr(config, "ncomp", 1) != 1:
-        raise TraceError("complex weights are not traced")
+    nc = getattr(config, "ncomp", 1)   # 2: ComplexF64 weights and observables, every one an (re, im) pair of slots (rw[2 i], rw[2 i + 1]; obs likewise)
     pools, ndraw = _pools(config)
     N = config.N
     t = _Trace()
@@ -840,24 +849,33 @@ def trace_measure(fn, config, indexed=False, check_points=32):
         out = []
         for o in obs:
             for v in np.asarray(o, dtype=object).reshape(-1):
-                out.append(v if isinstance(v, Sym) else t.const(v))
+                if nc == 2:
+                    z = CSym.of(v)
+                    out += [t.lift(z.re), t.lift(z.im)]
+                elif isinstance(v, (CSym, complex, np.complexfloating)):
+                    raise TraceError("a complex observable in a real configuration")
+                else:
+                    out.append(v if isinstance(v, Sym) else t.const(v))
         return out
+
+    def weight(i):
+        return CSym(t.node("rw", 2 * i), t.node("rw", 2 * i + 1)) if nc == 2 else t.node("rw", i)
     try:
         if indexed:
             per = []
             for i in range(N):
                 obs = fresh()
-                fn(i, arg, obs, t.node("rw", i), config)
+                fn(i, arg, obs, weight(i), config)
                 per.append(flat(obs))
         else:
             obs = fresh()
-            fn(arg, obs, [t.node("rw", i) for i in range(N)], config)
+            fn(arg, obs, [weight(i) for i in range(N)], config)
             per = [flat(obs)]
     except TraceError:
         raise
     except Exception as e:
         raise TraceError("%s: %s" % (type(e).__name__, e))
-    nobs = sum(config.obs_len)
+    nobs = sum(config.obs_len) * nc
     if any(len(p) != nobs for p in per):
         raise TraceError("the measure changed the shape of obs")
     parts = []
@@ -871,7 +889,15 @@ def trace_measure(fn, config, indexed=False, check_points=32):
     if check_points:
         rng = np.random.default_rng(54321)
         X = _domain_points(config, ndraw, check_points, rng)
-        R = rng.standard_normal((N, check_points))
+        R = rng.standard_normal((N * nc, check_points))
+        cdt = complex if nc == 2 else float
+
+        def wnum(i, p):
+            return np.complex128(complex(R[2 * i, p], R[2 * i + 1, p])) if nc == 2 else np.float64(R[i, p])   # (numpy scalars: `.sum()` and masks work on them)
+
+        def oflat(obs):
+            v = np.concatenate([np.asarray(o, dtype=cdt).reshape(-1) for o in obs])
+            return np.stack([v.real, v.imag], axis=1).reshape(-1) if nc == 2 else v.astype(np.float64)
         for p in range(check_points):
             num = _argument(pools, lambda k: X[k, p])                # one record as numpy scalars: `.sum()`, masks and plain `+=` all work on them
             num = tuple(a.astype(np.float64) for a in num) if isinstance(num, tuple) else num.astype(np.float64)
@@ -880,13 +906,13 @@ def trace_measure(fn, config, indexed=False, check_points=32):
                     if indexed:
                         refs = []
                         for i in range(N):
-                            obs = [np.zeros(ln) for ln in config.obs_len]
-                            fn(i, num, obs, np.float64(R[i, p]), config)
-                            refs.append(np.concatenate([np.asarray(o, dtype=np.float64).reshape(-1) for o in obs]))
+                            obs = [np.zeros(ln, dtype=cdt) for ln in config.obs_len]
+                            fn(i, num, obs, wnum(i, p), config)
+                            refs.append(oflat(obs))
                     else:
-                        obs = [np.zeros(ln) for ln in config.obs_len]
-                        fn(num, obs, [np.float64(R[i, p]) for i in range(N)], config)
-                        refs = [np.concatenate([np.asarray(o, dtype=np.float64).reshape(-1) for o in obs])]
+                        obs = [np.zeros(ln, dtype=cdt) for ln in config.obs_len]
+                        fn(num, obs, [wnum(i, p) for i in range(N)], config)
+                        refs = [oflat(obs)]
             except Exception as e:
                 raise TraceError("the measure does not run on numeric records (%s: %s)" % (type(e).__name__, e))
             for adds, ref in zip(per, refs):

@@ -185,6 +185,22 @@ def test_the_julia_tracer_writes_the_python_tracers_grammar():
     assert '"const int t" : "const double t"' in src and '"(double)" * name[n]' in src and '" != 0.0)"' in src
 
 
+def test_julia_binding_calls_closures_in_the_form_the_solver_calls_them():
+    """the same three edits as integrate.py (tests/test_callback_forms.py), checked statically -- no Julia in the image: the form follows
+    solver + `inplace` (src/main.jl:26-28), the in-place form has its trampoline over mci_set_integrand_host and its tracer branch, and
+    nothing picks a form by counting a closure's methods' parameters any more"""
+    src = open(JL).read()
+    for needle in ("function callback_form(f::Function, solver::Symbol, inplace::Bool=false; what::Symbol=:integrand)",
+                   "form = solver == :mcmc ? :indexed : (inplace && what == :integrand) ? :inplace : :plain",
+                   "inplace::Bool=false, reweight_goal", "callback_form(integrand, solver, inplace)", "callback_form(measure, solver; what=:measure)",
+                   "function _host_inplace_trampoline(", "struct WeightRows <: AbstractVector{Any}", "elseif form == :inplace",
+                   "trace_integrand(integrand, config; indexed=form == :indexed, inplace=form == :inplace)", "throw(ArgumentError("):
+        assert needle in src, needle
+    assert "nargs - 1 >= 3" not in src and "nargs - 1 >= 5" not in src      # (round 5: the form was read off the parameter count)
+    # every @cfunction signature of the in-place trampoline is the host-integrand callback type of include/mci.h
+    assert src.count("@cfunction(_host_inplace_trampoline, Cint, (Ptr{Float64}, Ptr{Float64}, Int64, Int32, Int32, Ptr{Cvoid}))") == 1
+
+
 def test_debug_hooks_are_not_part_of_the_public_header():
     """test and development hooks live in csrc/mci_debug.h: the drop-in boundary (include/mci.h) declares none of them, the bindings call
     none of them"""

@@ -211,6 +211,28 @@ def test_complex_weights_trace_in_every_form(oracle):
         trace_integrand(lambda x, c: mci.trace.where(x[0] * 1j > 0.5, 1.0, 0.0), mci.Configuration(dof=[[1]], type=complex))
 
 
+def test_complex_measure_closures_trace_to_re_im_slots():
+    """measure(var, obs, relative_weights, config) with ComplexF64 weights and observables (main.jl:279,284): every weight is rw[2 i] +
+    i rw[2 i + 1], every observable entry two obs_add slots; the written-out body against the closure at random records (trace_measure's
+    own check) and its slots spelled out"""
+    from mcintegration_jl_amd.trace import trace_measure
+    cfg = mci.Configuration(dof=[[1], [1]], type=complex, obs=[0j, [0j, 0j]])
+
+    def m(x, obs, w, c):
+        obs[0][0] += w[0].sum()
+        obs[1][0] += (w[1] * 1j).sum()
+        obs[1][1] += (w[1] * x[0]).sum()
+    body = trace_measure(m, cfg).body
+    lines = [ln.strip() for ln in body.splitlines()]
+    assert "obs_add(0, rw[0]);" in lines and "obs_add(1, rw[1]);" in lines and "obs_add(3, rw[2]);" in lines     # (w[1] i).re = -w[1].im, .im = w[1].re
+    assert any(ln.startswith("const double t") and ln.endswith("= -rw[3];") for ln in lines) and "rw[2] * x[0]" in body and "rw[3] * x[0]" in body
+    assert body.count("obs_add(") == 6
+    m5 = trace_measure(lambda i, x, obs, w, c: obs[i].__setitem__(0, obs[i][0] + w.conjugate()), cfg, indexed=True).body
+    assert "if (idx < 0 || idx == 0) {" in m5 and "if (idx < 0 || idx == 1) {" in m5 and "-rw[" in m5
+    with pytest.raises(TraceError):                                    # a complex observable where the configuration's are real
+        trace_measure(lambda x, obs, w, c: obs[0].__setitem__(0, w[0] * 1j), mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[1]]))
+
+
 def test_inplace_closures_the_tracer_refuses():
     cfg = hypersphere_config(3)
     with pytest.raises(TraceError):                                   # a store past the vector

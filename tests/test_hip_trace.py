@@ -87,3 +87,28 @@ def test_traced_measure_closures_match_device_source_measures():
         a = mci.integrate("return x[0] * x[1];", var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3)), measure=binned, trace=True, measure_form="plain", **kw)
         got, err = np.ravel(a.mean).astype(np.float64), np.ravel(a.stdev).astype(np.float64)
         assert np.all(np.abs(got - [0.75, 2.25]) < 6 * err + 0.02) and np.all(err < 0.3), (solver, got, err)     # (1 + 2 + 3) * int x dx over [0, .5) | [.5, 1)
+
+
+@pytest.mark.parametrize("solver", ["vegas", "vegasmc"])
+def test_complex_closures_traced_and_on_the_host_agree(solver):
+    """Configuration(type = ComplexF64): integrand AND measure as closures -- traced into the kernels (complex values as (re, im) pairs of
+    real expressions, trace.CSym) against the same closures on the host callback path: same draws, same arithmetic, iteration by
+    iteration; and both inside 7 sigma of the reference's TestComplex2 answers (test/montecarlo.jl:172-185: 1/2 and i/3)"""
+    def f(x, c):
+        return x[0], x[0] ** 2 * 1j
+
+    def m(x, obs, w, c):
+        obs[0][0] += w[0].sum()
+        obs[1][0] += w[1].sum()
+    out = []
+    for trace in (True, False):
+        kw = dict(dof=[[1], [1]], type=complex, obs=[0j, 0j], solver=solver, neval=1e5, niter=6, seed=111, print=-1,
+                  **({} if solver == "vegas" else dict(nchain=16)))
+        r = mci.integrate(f, measure=m, trace=trace, **kw)
+        eng = r.config._engine
+        assert isinstance(eng.integrand, mci.Integrand if trace else mci.HostIntegrand)
+        for k, exact in enumerate((0.5 + 0j, 1j / 3)):
+            z, e = complex(np.ravel(r.mean[k])[0]), complex(np.ravel(r.stdev[k])[0])
+            assert abs(z.real - exact.real) < 7 * e.real + 1e-12 and abs(z.imag - exact.imag) < 7 * e.imag + 1e-12, (solver, trace, k, z, e)
+        out.append(r)
+    np.testing.assert_allclose(out[0].iter_mean, out[1].iter_mean, rtol=1e-9, atol=1e-12)

@@ -193,37 +193,27 @@ def test_a_new_group_code_object_proves_itself_before_it_is_trusted(oracle, tmp_
         eng.close()
 
 
-def test_the_self_check_catches_the_miscompiled_group_kernel(oracle, tmp_path, monkeypatch, overrides, capfd):
+def test_the_self_check_catches_the_miscompiled_group_kernel(tmp_path):
     """Case 205 with the backend pass that miscompiles it RE-ENABLED (MCI_JIT_FLAGS names the switch, so csrc/mci_jit.h leaves it alone):
     right chains, histogram adds in the wrong bins (profiles/r05_fuzz.txt).  The self-check of the new code object sees it: status -1,
-    one warning, and the problem runs -- correctly -- with one lane per chain.  Without the check the launch would have returned the
-    wrong histogram silently (second half: the check switched off)."""
-    from layout_cases import random_case
-    monkeypatch.setenv("MCI_KERNEL_CACHE", str(tmp_path))
-    monkeypatch.setenv("MCI_JIT_FLAGS", "-mllvm -amdgpu-opt-exec-mask-pre-ra=1")
-    rng = np.random.default_rng(11000 + 205)
-    var, oleaves, dof, body, ndraw = random_case(rng)
-    oracle.set_rng_rounds(10)
-    fn = oracle.compile_c_integrand(body)
-    ref = oracle.Config(oleaves, dof).iteration(oracle.VEGASMC, fn, None, 1200, 0, 2, 0, SEED, nchain=2)
-    nstat = 2 * len(dof) + 2 + len(dof) + 1
+    one warning, and the problem runs -- correctly -- with one lane per chain.  Without the check the launch returns the wrong histogram
+    silently (second run: the check switched off).  Each run is a process of its own (tools/selfcheck_case205.py): LLVM's options are
+    process-wide, and a process that has compiled anything with the switch at 0 does not take a later 1."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCI_KERNEL_CACHE=str(tmp_path), MCI_JIT_FLAGS="-mllvm -amdgpu-opt-exec-mask-pre-ra=1", AMD_COMGR_CACHE="0")
 
-    def run():
-        eng = mci.Engine(mci.Configuration(var=var, dof=dof, seed=SEED), mci.Integrand(body))
-        eng.set_chain_speculation(64, 0.5, 3)
-        got = eng.iteration("vegasmc", 1200, 0, 2, iteration=0, seed=SEED, nchain=2)
-        out = got, eng.chain_speculation_status("vegasmc"), eng.last_chain_speculation()[0]
-        eng.close()
-        return out
-    got, status, lanes = run()
-    err = capfd.readouterr().err
-    if status == 1:
+    def run(*args):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "selfcheck_case205.py"), *args], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]), r.stderr
+    out, err = run()
+    if out["status"] == 1:
         pytest.skip("this toolchain compiles case 205 correctly with the pass on")
-    assert status == -1 and lanes == 1 and "does not reproduce its lane-per-chain kernel" in err, (status, lanes, err)
-    np.testing.assert_allclose(got[:nstat], ref[:nstat], rtol=1e-8, atol=1e-300)
-    np.testing.assert_allclose(got[nstat:], ref[nstat:], rtol=1e-7)                   # the histogram too: the lane-per-chain kernel ran
-    overrides.set("spec_self_check", 0)                                                # what the check stands in front of
-    got, status, lanes = run()
-    assert status == 0 and lanes == 64
-    np.testing.assert_allclose(got[:nstat], ref[:nstat], rtol=1e-8, atol=1e-300)       # right chains, right statistics ...
-    assert not np.allclose(got[nstat:], ref[nstat:], rtol=1e-7)                        # ... and the histogram in the wrong bins
+    assert out["status"] == -1 and out["lanes"] == 1 and "does not reproduce its lane-per-chain kernel" in err, (out, err[-2000:])
+    assert out["stats_ok"] and out["hist_ok"]                       # the histogram too: the lane-per-chain kernel ran
+    out, err = run("--no-check")                                    # what the check stands in front of
+    assert out["status"] == 0 and out["lanes"] == 64 and "does not reproduce" not in err
+    assert out["stats_ok"] and not out["hist_ok"] and out["hist_mismatches"] > 100      # right chains and statistics, the histogram in the wrong bins

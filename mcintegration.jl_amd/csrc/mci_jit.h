@@ -354,7 +354,9 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
     // without it, C2 on 16 grids, C3, C4, C5 under all three solvers and the default call within +-0.5 %, profiles/r06_ablation.txt), so it
     // is off for all of them.  MCI_JIT_FLAGS that names the switch itself decides it (the A/B; the guard test that re-enables the pass to
     // see the self-check of a new group code object trip, mci_host_jit.h spec_self_check); no_exec_mask_flag: the retry of a unit whose
-    // compilation the switch itself broke (a later compiler that no longer knows it).
+    // compilation the switch itself broke (a later compiler that no longer knows it).  (-mllvm options are LLVM-wide state of the process:
+    // the first compilation fixes them and a later one with another value is not taken -- found when the guard test's =1 came after
+    // other tests' =0 in one pytest process and compiled a correct kernel; tools/selfcheck_case205.py runs in a process of its own.)
     (void)extra_hdr;
     const char *jf = getenv("MCI_JIT_FLAGS");
     if (!no_exec_mask_flag && !(jf && strstr(jf, "amdgpu-opt-exec-mask-pre-ra"))) {

@@ -206,11 +206,11 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
     // Many-grid launches park (weights, bins) of every sample for the replay.  The stream is bounded whatever neval is -- the reference's
     // loop allocates nothing per sample (vegas/montecarlo.jl:117-187) -- by running the launch in chunks of a block's samples: sample pass
     // -> replay per chunk, same Philox indices, the partial rows of a later chunk added to those before it (BatchArgs::chunk_lo).  A chunk
-    // is at most 2^27 samples over all blocks and at most 7.5 GB of parked stream (C4: all of neval = 1e8 in one chunk as
-    // before, neval = 1e10 in 75); host closures read the whole launch's stream and keep the one chunk (they are refused above 8 GiB).
+    // is at most 2^27 samples over all blocks and at most 7.5 GB of parked stream (C4, 48 B per sample: all of neval = 1e8 in one
+    // chunk as before, neval = 1e10 in 75); host closures read the whole launch's stream and keep the one chunk (they are refused above 8 GiB).
     int64_t chunk_len = nevalperblock, nchunks = 1;
     if (split) {
-        const int64_t words = (p->ntdraw + 1) / 2 > 0 ? (p->ntdraw + 1) / 2 : 1;
+        const int64_t words = p->tdraw_words > 0 ? p->tdraw_words : 1;
         const int64_t bytes = (int64_t)s.ni * 8 + words * 4;
         if (!s.host_integrand && !s.host_measure) {
             int64_t cap = (int64_t)1 << 27;

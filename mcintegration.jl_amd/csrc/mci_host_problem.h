@@ -273,14 +273,23 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         }
         p->lds_bytes_k1 = fixed + (int64_t)s.ec_doubles * 8;
         p->ntdraw = 0;
+        int tdraw_maxbin = 2;
         if (s.ntile > 1)
             for (int k = 0; k < s.ndraw; ++k) {
                 const Leaf &L = p->leaves[s.draw_leaf[k]];
                 if (L.adapt && s.cover_mask[k] && s.leaf_tile[s.draw_leaf[k]] >= (s.split_all ? 0 : 1)) {
                     p->ntdraw += 1;
                     if (L.nbin > 65536) { delete p; return fail(MCI_ERR_INVALID, "leaf %d: more than 65536 bins with tiled histograms", s.draw_leaf[k]); }
+                    if (s.leaf_nbin[s.draw_leaf[k]] > tdraw_maxbin) tdraw_maxbin = s.leaf_nbin[s.draw_leaf[k]];
                 }
             }
+        // words of packed bins a parked sample takes: mci_device.h tdraw_bits() / tdraw_words(), the same arithmetic (999-bin grids: 10 bits
+        // per draw, 32 draws in 10 words -- the 16 bits per draw this used to allocate for were half as much again as the kernels touch)
+        {
+            int bits = 1;
+            while ((1 << bits) < tdraw_maxbin) ++bits;
+            p->tdraw_words = (p->ntdraw * bits + 31) / 32;
+        }
         s.htile = 0;
         for (int v : s.tile_nbin) s.htile = v > s.htile ? v : s.htile;
         s.table_mode = mode;

@@ -134,6 +134,7 @@ struct mci_problem {
     int64_t cap_tile = 0;
     int64_t last_split_chunks = 0, last_split_bytes = 0; // chunks of the last many-grid :vegas launch | bytes of parked stream it held at a time
     int ntdraw = 0; // draws whose histogram lives in a tile >= 1
+    int tdraw_words = 0; // 32-bit words of packed bins per parked sample (mci_device.h tdraw_words)
     hipFunction_t f_tiles[2] = {nullptr, nullptr}; // replay kernel of the two :vegas variants
     // second merge stage (partials -> packed), launched lazily: a single-rank mci_iteration_finish fuses it with
     // the refinement (k_finish); anything else that looks at `packed` first flushes it (k_finalize)

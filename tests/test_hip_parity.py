@@ -273,8 +273,8 @@ def test_many_grid_launch_in_chunks_matches_oracle(oracle, overrides, chunk, lay
     nchunks, held = eng.split_chunks()
     per = max(4, (chunk // (hi - lo)) & ~3)
     assert nchunks == (1 if per >= npb else -(-npb // per)), (nchunks, per)
-    tdraws = ndraw // 2 if keep_tile0 else ndraw       # the replayed draws' 16-bit bins, two per word, next to 8 B of weight per parked sample
-    assert held == (hi - lo) * min(per, npb) * (8 + 4 * ((tdraws + 1) // 2))
+    tdraws = ndraw // 2 if keep_tile0 else ndraw       # the replayed draws' bins, 10 bits each (999-bin grids), next to 8 B of weight per parked sample
+    assert held == (hi - lo) * min(per, npb) * (8 + 4 * ((tdraws * 10 + 31) // 32))      # C4: 48 B per sample
     np.testing.assert_allclose(got[:4], ref[:4], rtol=1e-11)
     np.testing.assert_allclose(got[4:], ref[4:], rtol=1e-9)
     # a second launch on the same problem with another chunking: the rows of the first are not carried into it

@@ -116,6 +116,7 @@ inline std::string generate_source(const ProblemShape &s, int solver, int unit =
     if (unit == kUnitVegasPersist) o << "#include \"mci_train.h\"\n";
     if (unit == kUnitSpec) o << "#include \"mci_spec.h\"\n";
     o << "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n";
+    o << "#ifndef MCI_CHAIN_KERNEL_ATTR\n#define MCI_CHAIN_KERNEL_ATTR\n#endif\n"; // (occupancy experiments on the lane-per-chain kernels: MCI_JIT_FLAGS=-DMCI_CHAIN_KERNEL_ATTR=...)
     o << "namespace {\nstruct Cfg {\n";
     o << "    static constexpr int NDRAW = " << s.ndraw << ", NLEAF = " << s.nleaf << ", NI = " << s.ni
       << ", NPOOL = " << s.npool << ", NOBS = " << s.nobs << ", NCOLS = " << s.ncols << ";\n";
@@ -190,12 +191,12 @@ inline std::string generate_source(const ProblemShape &s, int solver, int unit =
             o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_carry_weights(mci::BatchArgs a) { mci::vegasmc_carry_weights<Cfg>(a); }\n";
     } else if (solver == 1) {
         // (a host integrand: the step cut at the integrand call, one launch per Markov step -- same entry point)
-        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_chains(mci::BatchArgs a) { "
+        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) MCI_CHAIN_KERNEL_ATTR mci_vegasmc_chains(mci::BatchArgs a) { "
           << (s.host_integrand ? "mci::vegasmc_host_step<Cfg>(a); }\n" : "mci::vegasmc_chains<Cfg>(a); }\n");
         // (carried chains: the new target over the old one at every stored configuration, before they are resampled)
         o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_vegasmc_carry_weights(mci::BatchArgs a) { mci::vegasmc_carry_weights<Cfg>(a); }\n";
     } else {
-        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) mci_mcmc_chains(mci::BatchArgs a) { "
+        o << "extern \"C\" __global__ void __launch_bounds__(MCI_THREADS) MCI_CHAIN_KERNEL_ATTR mci_mcmc_chains(mci::BatchArgs a) { "
           << (s.host_integrand ? "mci::mcmc_host_step<Cfg>(a); }\n" : "mci::mcmc_chains<Cfg>(a); }\n");
     }
     return o.str();

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box batches behind the numbers in profiles/ (one parameterised script; run as `gpurun -- bash tools/run_batch.sh <batch> [args]`).
 # Every batch writes under gpurun_out/<batch>/; what is to be judged is copied into profiles/ by hand afterwards.
-#   round 6:  ab_exec_mask | midsize | r06_collect
+#   round 6:  ab_exec_mask | midsize | r06_collect | r06_fuzz
 #   round 5 (kept as they ran, cited by profiles/README.md): r05_<name>
 set -u
 batch=${1:-help}; shift || true
@@ -56,6 +56,18 @@ import json
 j = json.loads(open("gpurun_out/r06_collect/r06_bench_line.json").read().strip().splitlines()[-1]); r = j["roofline"]
 print(j["value"], j["ms_per_step"], r["kernel_ms_avg"], r["frac"], r.get("frac_flat_2cycle"), r["frac_self_calibrated"], r["clock"]["sclk_mhz_avg"], r["traffic"], j["config"].get("code_object"))
 PY
+;;
+r06_fuzz)
+# randomised parity campaigns on the final code of round 6, cold kernel cache: every new several-lanes-per-chain code object goes through its
+# self-check (mci_host_jit.h spec_self_check) -- a campaign is also a count of its false alarms (stderr: "does not reproduce")
+export MCI_KERNEL_CACHE=/tmp/kc_fuzz
+timeout 1500 python tools/fuzz_layouts.py --lanes 1000 120 > $out/fuzz_general_lanes.txt 2> $out/fuzz_general_lanes.err; tail -2 $out/fuzz_general_lanes.txt
+timeout 1200 python tools/fuzz_layouts.py --carry --lanes 1000 100 > $out/fuzz_carry_lanes.txt 2> $out/fuzz_carry_lanes.err; tail -2 $out/fuzz_carry_lanes.txt
+timeout 900 python tools/fuzz_layouts.py 1000 60 > $out/fuzz_general.txt 2> $out/fuzz_general.err; tail -2 $out/fuzz_general.txt
+timeout 600 python tools/fuzz_layouts.py --pipe 1000 30 > $out/fuzz_pipe.txt 2> $out/fuzz_pipe.err; tail -2 $out/fuzz_pipe.txt
+echo "self-check alarms:"; grep -c "does not reproduce" $out/*.err
+echo "self-check markers written:"; ls /tmp/kc_fuzz/*.ok 2>/dev/null | wc -l; echo "code objects:"; ls /tmp/kc_fuzz/*.hsaco | wc -l
+unset MCI_KERNEL_CACHE
 ;;
 midsize)
 # the fixed cost of a mid-size launch of the headline layout -- the copy summation with conflict-free reads + row_shr adds

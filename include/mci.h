@@ -150,6 +150,10 @@ int mci_set_integrand_source(mci_problem *prob, const char *body, const double *
  * (nblocks * nchain), x = the configurations they propose; same streams and arithmetic as the device-source chains, so both
  * give the same results.  solver = MCI_MCMC the same way (one launch and one callback per step; the library asks this form for
  * every integrand and keeps the one the chain needs -- mci_set_integrand_host_indexed is the reference's own :mcmc form).
+ * The callback WRITES its weights into the array it is handed: at this boundary the integrand is always the reference's in-place form
+ * `integrand(var, weights, config)` (inplace = true; main.jl:26, vegas/montecarlo.jl:140-141, vegas_mc/updates.jl:67-70); a binding
+ * offers the returning form `integrand(var, config)` by copying what the closure returns into `w`, and picks between the two -- and the
+ * :mcmc form -- by solver and `inplace` flag like the reference (main.jl:26-28), not by the closure's parameter count.
  * PCIe- and host-bound by construction. */
 typedef int (*mci_host_integrand_fn)(const double *x, double *w, int64_t n, int32_t ndraw, int32_t nw, void *user);
 int mci_set_integrand_host(mci_problem *prob, mci_host_integrand_fn fn, void *user);

@@ -217,3 +217,29 @@ def test_the_self_check_catches_the_miscompiled_group_kernel(tmp_path):
     out, err = run("--no-check")                                    # what the check stands in front of
     assert out["status"] == 0 and out["lanes"] == 64 and "does not reproduce" not in err
     assert out["stats_ok"] and not out["hist_ok"] and out["hist_mismatches"] > 100      # right chains and statistics, the histogram in the wrong bins
+
+
+def test_a_group_unit_that_does_not_compile_leaves_the_solver_on_one_lane_per_chain(oracle, tmp_path, monkeypatch, capfd):
+    """The several-lanes-per-chain kernel is its own translation unit (up to 512 VGPRs, a backend switch a later compiler may refuse).
+    Under automatic lanes a unit that fails to compile must not take the solver down: the lane-per-chain kernel steps the same chains
+    (status -2, one note on stderr, the oracle's numbers).  Asked for explicitly (mci_set_chain_speculation(64)) the failure is the
+    caller's to see: MCI_ERR_COMPILE.  (-DSpecLane=1 breaks mci_spec.h and nothing else.)"""
+    monkeypatch.setenv("MCI_KERNEL_CACHE", str(tmp_path))
+    monkeypatch.setenv("MCI_JIT_FLAGS", "-DSpecLane=1")
+    cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]])
+    eng = mci.Engine(cfg, mci.catalog.sphere2())
+    got = eng.iteration("vegasmc", 625, 0, 16, iteration=0, seed=SEED, nchain=1)
+    assert eng.chain_speculation_status("vegasmc") == -2 and eng.last_chain_speculation() == (1, 0)
+    assert "did not compile; one lane per chain instead" in capfd.readouterr().err
+    ocfg = oracle.Config([dict(kind=0, pool=0, lower=0.0, upper=1.0)], [[2], [3]])
+    ref = ocfg.iteration(oracle.VEGASMC, "sphere2", None, 625, 0, 16, 0, SEED, nchain=1)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-300)
+    got = eng.iteration("vegasmc", 625, 0, 16, iteration=1, seed=SEED, nchain=1)       # ... and stays there without trying again
+    assert eng.last_chain_speculation() == (1, 0) and "did not compile" not in capfd.readouterr().err
+    eng.close()
+    eng = mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]]), mci.catalog.sphere2())
+    eng.set_chain_speculation(64)
+    with pytest.raises(mci.MCIError) as e:
+        eng.iteration("vegasmc", 625, 0, 16, iteration=0, seed=SEED, nchain=1)
+    assert "failed to compile" in str(e.value)
+    eng.close()

@@ -100,10 +100,14 @@ class Result:
         # of their combined error, per statistics column; report() prints a note where it exceeds 2.
         self.weighting_shift = np.zeros(nobs)
         counted = self.iter_mean[ignore:]
+        # (not in the reference) the plain mean of the counted iterations and its scatter error, shaped like `mean` / `stdev`: what the
+        # note of report() quotes -- unbiased where the 1/sigma_i^2 weights are not, noisier where they are fine; None below 3 iterations
+        self.plain_mean = self.plain_stdev = None
         if counted.shape[0] >= 3:
             um, ue = counted.mean(0), counted.std(0, ddof=1) / np.sqrt(counted.shape[0])
             den = np.hypot(self._flat_std, ue)
             self.weighting_shift = np.where(den > 0.0, np.abs(self._flat_mean - um) / np.where(den > 0.0, den, 1.0), 0.0)
+            self.plain_mean, self.plain_stdev = self._shape(um), self._shape(ue)
         # set by integrate() for a chain solver that ran the reference's one chain per block: chain_estimator_bias (report() prints a
         # note where the expected bias of the blocks' ratio estimator reaches 2 of the final error bars)
         self.chain_bias = None

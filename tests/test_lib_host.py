@@ -271,6 +271,7 @@ def test_result_says_when_weighted_and_plain_average_of_the_iterations_disagree(
     ie = np.array([[0.05], [0.05], [0.05], [0.05], [1.0], [1.0], [1.0]])
     res = mci.Result(im, ie, cfg, ignore=0)
     assert res.weighting_shift[0] > 2.0
+    assert res.plain_mean[0] == pytest.approx(im[:, 0].mean()) and res.plain_stdev[0] == pytest.approx(im[:, 0].std(ddof=1) / np.sqrt(7))
     out = io.StringIO()
     mci.report(res, io=out)
     assert "note: the weighted average lies" in out.getvalue()

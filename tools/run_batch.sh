@@ -47,6 +47,8 @@ timeout 900 python bench.py > $out/r06_bench_line.json 2> $out/bench.err
 bash profiles/collect.sh r06 bench > $out/collect_bench.log 2>&1
 for w in c3 c4 c5 bubble_mcmc default_call; do bash profiles/collect.sh r06_$w $w > $out/collect_$w.log 2>&1; done
 cp profiles/r06*_kernel_stats.txt profiles/r06*_pmc_traffic.json $out/ 2>/dev/null
+sleep 20   # (the profiler passes above have just freed tens of GB: the driver wipes VRAM on release, and a 4.8 GB hipMalloc that lands on pages
+           # still being wiped waits for them -- profiles/r06_other_configs.txt; a cold call is quoted on an idle device)
 timeout 900 python tools/bench_configs.py > $out/other_configs.txt 2>&1
 timeout 600 python tools/latency.py > $out/latency.txt 2>&1
 timeout 300 python tools/spec_bench.py default > $out/default.txt 2>&1

@@ -95,6 +95,19 @@ def test_c4_genz32_full_size_properties():
     np.testing.assert_allclose(per_grid, per_grid[0], rtol=1e-9)
     r = eng.integrate("vegas", neval=NEVAL, niter=5, block=BLOCK, seed=SEED, first_iteration=5, ignore=0)
     assert abs(r["mean"][0] - genz_exact(32)) < 5 * r["stdev"][0], (r["mean"], r["stdev"], genz_exact(32))
+    # the launch in chunks (a bounded parked stream, vegas/montecarlo.jl:117-187: constant memory in neval) is the one-chunk launch up to
+    # the order of its sums: same samples, same Philox indices, partial rows added chunk by chunk
+    from mcintegration_jl_amd._lib import check, lib
+    one = eng.iteration("vegas", NPB, 0, BLOCK, iteration=11, seed=SEED)
+    assert eng.split_chunks() == (1, NEVAL * 48)                                    # 8 B of weight + 32 bins of 10 bits per parked sample
+    check(lib().mci_debug_override(b"split_chunk", 2 ** 25, 1))
+    try:
+        three = eng.iteration("vegas", NPB, 0, BLOCK, iteration=11, seed=SEED)
+        assert eng.split_chunks()[0] == 3
+    finally:
+        check(lib().mci_debug_override(b"split_chunk", 0, 0))
+    np.testing.assert_allclose(three[:4], one[:4], rtol=1e-12)
+    np.testing.assert_allclose(three[4:], one[4:], rtol=1e-10)
 
 
 def test_c3_bubble_vegasmc_full_size_properties():

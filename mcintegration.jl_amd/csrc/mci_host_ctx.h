@@ -45,6 +45,7 @@ int mci_ctx_destroy(mci_ctx *c) {
     mcijit::warm_up_join();
     persist_orphans_join();
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->spare) (void)hipFree(c->spare); // (the parked-stream buffer the last many-grid problem left behind)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return MCI_OK;

@@ -225,13 +225,10 @@ int mci_iteration_run(mci_problem *p, int32_t solver, int64_t nevalperblock, int
         }
         const int64_t nsamp = nblocks * chunk_len;
         if (nsamp > p->cap_tile) {
-            if (p->d_tile_w) (void)hipFree(p->d_tile_w);
-            if (p->d_tile_bins) (void)hipFree(p->d_tile_bins);
-            p->d_tile_w = nullptr;
-            p->d_tile_bins = nullptr;
-            p->cap_tile = 0;
-            HIPCHK(hipMalloc((void **)&p->d_tile_w, (size_t)nsamp * s.ni * sizeof(double)));
-            HIPCHK(hipMalloc((void **)&p->d_tile_bins, (size_t)nsamp * words * sizeof(uint32_t)));
+            tile_release(p);
+            const size_t wbytes = (((size_t)nsamp * s.ni * sizeof(double)) + 255) & ~(size_t)255; // (the bins start 256-byte aligned: 16-byte loads)
+            if ((rc = tile_alloc(p, wbytes + (size_t)nsamp * words * sizeof(uint32_t)))) return rc;
+            p->d_tile_bins = (uint32_t *)((char *)p->d_tile_w + wbytes);
             p->cap_tile = nsamp;
         }
         p->last_split_chunks = nchunks;

@@ -422,8 +422,7 @@ int mci_problem_destroy(mci_problem *p) {
         if (p->d_hw) (void)hipFree(p->d_hw);
         if (p->h_hx) (void)hipHostFree(p->h_hx);
         if (p->h_hw) (void)hipHostFree(p->h_hw);
-        if (p->d_tile_w) (void)hipFree(p->d_tile_w);
-        if (p->d_tile_bins) (void)hipFree(p->d_tile_bins);
+        tile_release(p); // (to the context: the next many-grid problem takes it)
         if (p->d_mx) (void)hipFree(p->d_mx);
         if (p->d_mrelw) (void)hipFree(p->d_mrelw);
         if (p->d_mobs) (void)hipFree(p->d_mobs);

@@ -55,6 +55,13 @@ struct mci_ctx {
     void *comm = nullptr;
     int rank = 0, nranks = 1;
     long long collectives = 0, last_count = 0; // ncclAllReduce calls issued on this context so far | elements of the last one (mci_comm_collectives)
+    // The parked stream of a many-grid :vegas problem (GBs) outlives the problem: destroying it hands the buffer to the context, the
+    // next problem that needs one takes it.  The driver wipes VRAM on release, and a hipMalloc that lands on pages still being wiped
+    // waits for them: a second engine right after a first one's 4.8 GB were freed took 380 ms for a 5 ms launch
+    // (profiles/r06_other_configs.txt) -- the pattern of every sweep that builds a Configuration per call.  Freed by mci_ctx_destroy.
+    std::mutex spare_mu;
+    void *spare = nullptr;
+    size_t spare_bytes = 0;
 };
 
 namespace {
@@ -129,8 +136,9 @@ struct mci_problem {
     unsigned long long *d_hold = nullptr; // [64] :mcmc holding-time histogram of the last launch (this rank), see mci_get_hold_histogram
     int64_t hold_max = 0;                 // upper edge of its top occupied bucket; 0: no :mcmc launch seen yet
     // split vegas pass (NTILE > 1): per-sample histogram weights and 16-bit bins of the tiles >= 1
-    double *d_tile_w = nullptr;
+    double *d_tile_w = nullptr;      // (one allocation: the weights, then -- 256-byte aligned -- the packed bins)
     uint32_t *d_tile_bins = nullptr;
+    size_t tile_bytes = 0;           // its size
     int64_t cap_tile = 0;
     int64_t last_split_chunks = 0, last_split_bytes = 0; // chunks of the last many-grid :vegas launch | bytes of parked stream it held at a time
     int ntdraw = 0; // draws whose histogram lives in a tile >= 1
@@ -328,6 +336,47 @@ namespace { void persist_orphans_join(); }
 static const size_t kPersistWords = 8 + 3 * 8 * 8 + 16;
 
 namespace {
+
+// the parked stream's buffer: from the context's spare one if that is big enough (and not more than twice as big), else hipMalloc
+int tile_alloc(mci_problem *p, size_t bytes) {
+    mci_ctx *c = p->ctx;
+    void *base = nullptr;
+    {
+        std::lock_guard<std::mutex> g(c->spare_mu);
+        if (c->spare && c->spare_bytes >= bytes && c->spare_bytes <= 2 * bytes + ((size_t)64 << 20)) {
+            base = c->spare;
+            p->tile_bytes = c->spare_bytes;
+            c->spare = nullptr;
+            c->spare_bytes = 0;
+        }
+    }
+    if (!base) {
+        HIPCHK(hipMalloc(&base, bytes));
+        p->tile_bytes = bytes;
+    }
+    p->d_tile_w = (double *)base;
+    return MCI_OK;
+}
+// ... and back: the context keeps the largest buffer it has been handed (work queued on the context's one stream is ordered behind
+// the kernels that used it), anything else is freed
+void tile_release(mci_problem *p) {
+    if (!p->d_tile_w) return;
+    mci_ctx *c = p->ctx;
+    void *drop = p->d_tile_w;
+    {
+        std::lock_guard<std::mutex> g(c->spare_mu);
+        if (p->tile_bytes > c->spare_bytes) {
+            drop = c->spare;
+            c->spare = p->d_tile_w;
+            c->spare_bytes = p->tile_bytes;
+        }
+    }
+    if (drop) (void)hipFree(drop);
+    p->d_tile_w = nullptr;
+    p->d_tile_bins = nullptr;
+    p->tile_bytes = 0;
+    p->cap_tile = 0;
+}
 
 int upload(mci_problem *p) {
     if (p->ctx->offline) return MCI_OK;

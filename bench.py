@@ -229,8 +229,11 @@ def main():
         print("[bench] --gpus %d but the launcher started %d ranks: running %d" % (a.gpus, world, world), file=sys.stderr)
 
     import numpy as np
-    import torch
     import mcintegration_jl_amd as mci
+    # the JIT's compiler: the ROCm installation's hiprtc + comgr, pinned BEFORE PyTorch is imported (PyTorch bundles its own copies, another
+    # compiler build: the first comgr loaded into a process serves everybody; mci.use_rocm_compiler).  The line says which one it was.
+    compiler = mci.use_rocm_compiler()
+    import torch
     from mcintegration_jl_amd.comm import LocalComm, RcclComm, TorchDistComm
 
     # test seam: an engine factory "module:attr" replaces the HIP engine so that the launcher, the block partition and the
@@ -432,7 +435,7 @@ def main():
             k_avg_ms = float(np.mean(kms))
             code_object = eng.code_object("vegas")
             out["config"].update({"kernel": "mci_vegas_batch", "workgroups": wgs, "threads": threads, "table_mode": eng.table_mode,
-                                  "code_object": os.path.basename(code_object),
+                                  "code_object": os.path.basename(code_object), "compiler": compiler,
                                   "histogram_copies": eng.histogram_copies() if hasattr(eng, "histogram_copies") else 1})
             spl = nevalperblock * per                                   # samples of one launch on one GPU
             achieved_hbm = B_ALG * spl / (k_avg_ms * 1e-3) / 1e9       # GB/s

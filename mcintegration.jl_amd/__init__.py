@@ -7,7 +7,7 @@ The integrand is HIP C++ source (a string or an `Integrand`) instead of a Julia 
 JIT-compiled into the sample-batch kernel, exactly where Julia would inline the closure.
 """
 from . import catalog  # noqa: F401
-from ._lib import MCIError, lib, library_path  # noqa: F401
+from ._lib import MCIError, compiler_id, lib, library_path, use_rocm_compiler  # noqa: F401
 from .configuration import Configuration  # noqa: F401
 from .engine import Engine, shutdown  # noqa: F401
 from .integrand import HostIntegrand, HostMeasure, Integrand, Measure, bin_by  # noqa: F401

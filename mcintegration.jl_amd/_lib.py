@@ -159,6 +159,38 @@ def library_path():
     return _SO
 
 
+def use_rocm_compiler(rocm=None):
+    """Pin the JIT's compiler to the ROCm installation's hiprtc + comgr (ROCM_PATH, default /opt/rocm) -- the toolchain the library itself
+    was built with and its kernels are validated against.  hiprtc opens the code-object manager (libamd_comgr: the clang / LLVM that
+    compiles) by soname, so the FIRST copy loaded into a process serves everybody; a process that imports PyTorch first gets the copies
+    PyTorch bundles, another compiler build (the headline loop comes out 4 % longer and 2.2 % slower; the kernel cache is keyed by the
+    compiler, so the two never mix).  Call this BEFORE `import torch` (bench.py, tests/conftest.py and __graft_entry__ do): it loads the
+    installation's comgr and hiprtc with RTLD_GLOBAL, and PyTorch then finds them loaded.  Returns the compiler identity the library
+    reports afterwards (what the cache key holds); if a comgr is already loaded nothing is changed -- the identity says which."""
+    loaded = ""
+    try:
+        with open("/proc/self/maps") as fh:
+            loaded = fh.read()
+    except OSError:
+        pass
+    if "amd_comgr" not in loaded:
+        root = rocm or os.environ.get("ROCM_PATH") or "/opt/rocm"
+        for names in (("libamd_comgr.so.3", "libamd_comgr.so.2", "libamd_comgr.so"), ("libhiprtc.so.7", "libhiprtc.so")):
+            for name in names:
+                path = os.path.join(root, "lib", name)
+                if os.path.exists(path):
+                    C.CDLL(path, mode=C.RTLD_GLOBAL)
+                    break
+    return compiler_id()
+
+
+def compiler_id():
+    """which compiler the library's JIT resolves to in this process: hiprtc version | hiprtc file | comgr file | target"""
+    buf = C.create_string_buffer(1024)
+    lib().mci_debug_compiler_id(None, buf, len(buf))
+    return buf.value.decode()
+
+
 def lib():
     """Load libmci_hip.so (fails loudly when it has not been built: no fallback path exists)."""
     global _lib

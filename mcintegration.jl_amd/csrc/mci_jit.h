@@ -22,6 +22,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <link.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -277,37 +278,49 @@ inline std::string cache_dir() {
     return dir;
 }
 
-// Which compiler made a cached code object: hiprtc's version, the files of the hiprtc library and of the code-object manager next to it
-// (libamd_comgr holds the clang / LLVM that compiles -- name as resolved, which carries its version, and size) and the target.  Part of
-// the cache key: a ROCm upgrade (say, the fix of the pass the group units are compiled without) must not keep serving the old objects,
-// a downgrade must not serve objects of a compiler nothing here was tested with.  mci_debug_compiler_id overrides it for tests.
+// Which compiler made a cached code object: hiprtc's version, the file of the hiprtc library the process resolved (name as resolved,
+// which carries its version, and size), the file of the code-object manager -- libamd_comgr holds the clang / LLVM that compiles -- and
+// the target.  Part of the cache key: a ROCm upgrade (say, the fix of the pass the units are compiled without) must not keep serving
+// the old objects, a downgrade must not serve objects of a compiler nothing here was tested with.  And neither must ANOTHER COPY in the
+// same image: a process that has imported PyTorch before this library resolves hiprtc and comgr to the copies PyTorch bundles -- a
+// different compiler build (the headline loop: 523.5 instead of 503.5 VALU instructions per wave and sample, 2.2 % slower; campaign case
+// 205 compiles correctly there; profiles/r06_ablation.txt E).  hiprtc opens comgr by its soname, so the comgr in use is the FIRST one
+// loaded into the process whichever hiprtc asks; before any is loaded, the one next to the hiprtc library (its RUNPATH).
+// mci_debug_compiler_id overrides the identity for tests.
 inline std::string &compiler_id_override() {
     static std::string s;
     return s;
 }
-inline const std::string &compiler_id() {
-    static const std::string id = [] {
-        int maj = 0, min = 0;
-        (void)hiprtcVersion(&maj, &min);
-        std::string s = "hiprtc " + std::to_string(maj) + "." + std::to_string(min);
-        auto file_id = [](const std::string &path) {
-            char real[4096];
-            struct stat st;
-            if (!realpath(path.c_str(), real) || stat(real, &st) != 0) return std::string("?");
-            std::string r = real;
-            const size_t k = r.rfind('/');
-            return (k == std::string::npos ? r : r.substr(k + 1)) + ":" + std::to_string((long long)st.st_size);
-        };
-        Dl_info info;
-        if (dladdr((void *)&hiprtcVersion, &info) && info.dli_fname) {
-            const std::string lib = info.dli_fname;
-            s += " | " + file_id(lib);
+inline int first_comgr_cb(struct dl_phdr_info *info, size_t, void *data) {
+    std::string *out = (std::string *)data;
+    if (out->empty() && info->dlpi_name && strstr(info->dlpi_name, "amd_comgr")) *out = info->dlpi_name;
+    return 0;
+}
+inline std::string compiler_id() {
+    if (!compiler_id_override().empty()) return compiler_id_override();
+    int maj = 0, min = 0;
+    (void)hiprtcVersion(&maj, &min);
+    std::string s = "hiprtc " + std::to_string(maj) + "." + std::to_string(min);
+    auto file_id = [](const std::string &path) {
+        char real[4096];
+        struct stat st;
+        if (!realpath(path.c_str(), real) || stat(real, &st) != 0) return std::string("?");
+        std::string r = real;
+        const size_t k = r.rfind('/');
+        return (k == std::string::npos ? r : r.substr(k + 1)) + ":" + std::to_string((long long)st.st_size);
+    };
+    Dl_info info;
+    std::string comgr;
+    dl_iterate_phdr(first_comgr_cb, &comgr); // (objects in load order: the first comgr is the one a dlopen by soname returns)
+    if (dladdr((void *)&hiprtcVersion, &info) && info.dli_fname) {
+        const std::string lib = info.dli_fname;
+        s += " | " + file_id(lib);
+        if (comgr.empty()) {
             const size_t k = lib.rfind('/');
-            s += " | " + file_id((k == std::string::npos ? std::string(".") : lib.substr(0, k)) + "/libamd_comgr.so");
+            comgr = (k == std::string::npos ? std::string(".") : lib.substr(0, k)) + "/libamd_comgr.so";
         }
-        return s + " | gfx950";
-    }();
-    return compiler_id_override().empty() ? id : compiler_id_override();
+    }
+    return s + " | " + (comgr.empty() ? std::string("?") : file_id(comgr)) + " | gfx950";
 }
 
 // hiprtc's first compile of a process loads the compiler (comgr, ~0.3 s on this image): mci_ctx_create starts it on a thread of its
@@ -355,9 +368,7 @@ inline int compile(const std::string &src, int threads, std::vector<char> &code,
     // without it, C2 on 16 grids, C3, C4, C5 under all three solvers and the default call within +-0.5 %, profiles/r06_ablation.txt), so it
     // is off for all of them.  MCI_JIT_FLAGS that names the switch itself decides it (the A/B; the guard test that re-enables the pass to
     // see the self-check of a new group code object trip, mci_host_jit.h spec_self_check); no_exec_mask_flag: the retry of a unit whose
-    // compilation the switch itself broke (a later compiler that no longer knows it).  (-mllvm options are LLVM-wide state of the process:
-    // the first compilation fixes them and a later one with another value is not taken -- found when the guard test's =1 came after
-    // other tests' =0 in one pytest process and compiled a correct kernel; tools/selfcheck_case205.py runs in a process of its own.)
+    // compilation the switch itself broke (a later compiler that no longer knows it).
     (void)extra_hdr;
     const char *jf = getenv("MCI_JIT_FLAGS");
     if (!no_exec_mask_flag && !(jf && strstr(jf, "amdgpu-opt-exec-mask-pre-ra"))) {

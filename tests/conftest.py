@@ -17,6 +17,10 @@ def pytest_configure(config):
     if not (os.path.exists(lib) and os.path.exists(demo)):
         import __graft_entry__
         __graft_entry__.build()
+    # the suite compiles with the ROCm installation's hiprtc + comgr (the compiler build() pre-fills the kernel cache with), pinned before
+    # any test module imports torch: PyTorch bundles another compiler build, and the first comgr loaded into a process serves everybody
+    import mcintegration_jl_amd
+    mcintegration_jl_amd.use_rocm_compiler()
 
 
 @pytest.fixture(scope="session")

@@ -197,8 +197,9 @@ def test_the_self_check_catches_the_miscompiled_group_kernel(tmp_path):
     """Case 205 with the backend pass that miscompiles it RE-ENABLED (MCI_JIT_FLAGS names the switch, so csrc/mci_jit.h leaves it alone):
     right chains, histogram adds in the wrong bins (profiles/r05_fuzz.txt).  The self-check of the new code object sees it: status -1,
     one warning, and the problem runs -- correctly -- with one lane per chain.  Without the check the launch returns the wrong histogram
-    silently (second run: the check switched off).  Each run is a process of its own (tools/selfcheck_case205.py): LLVM's options are
-    process-wide, and a process that has compiled anything with the switch at 0 does not take a later 1."""
+    silently (second run: the check switched off).  Each run is a process of its own (tools/selfcheck_case205.py) on the ROCm
+    installation's compiler: the miscompile is that compiler's -- the comgr PyTorch bundles, which a process that imported torch first
+    compiles with, gets the layout right either way (profiles/r06_ablation.txt E)."""
     import json
     import subprocess
     import sys
@@ -210,6 +211,7 @@ def test_the_self_check_catches_the_miscompiled_group_kernel(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]), r.stderr
     out, err = run()
+    assert "libamd_comgr.so.3" in out["compiler"], out["compiler"]         # (the installation's, not a bundled copy)
     if out["status"] == 1:
         pytest.skip("this toolchain compiles case 205 correctly with the pass on")
     assert out["status"] == -1 and out["lanes"] == 1 and "does not reproduce its lane-per-chain kernel" in err, (out, err[-2000:])

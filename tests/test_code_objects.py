@@ -268,3 +268,40 @@ def test_kernel_cache_is_keyed_by_the_compiler(tmp_path, monkeypatch):
     finally:
         lib().mci_debug_compiler_id(b"", buf, len(buf))
     assert buf.value.decode() == ident and obj() == a
+
+
+def test_the_compiler_in_the_cache_key_is_the_one_the_process_resolves(tmp_path):
+    """hiprtc opens comgr -- the clang / LLVM inside -- by soname: the first matching copy loaded into a process serves everybody.  A
+    process that imports PyTorch first compiles with the copies PyTorch bundles (another build: other code, another cache file);
+    use_rocm_compiler() before `import torch` pins the ROCm installation's, and it stays pinned when torch comes in later: same identity,
+    same file name and the SAME BYTES as a process that never saw torch."""
+    import hashlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, os, hashlib
+sys.path.insert(0, %r)
+order = sys.argv[1]
+if order == "torch_first":
+    import torch
+import mcintegration_jl_amd as mci
+ident = mci.use_rocm_compiler()
+if order == "mci_first":
+    import torch
+    assert mci.compiler_id() == ident
+eng = mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]]), mci.catalog.x2y2(), device=-1)
+eng.compile("vegas")
+p = eng.code_object("vegas")
+print("RESULT;%%s;%%s;%%s" %% (ident, os.path.basename(p), hashlib.md5(open(p, "rb").read()).hexdigest()))
+""" % root
+    out = {}
+    for order in ("plain", "mci_first", "torch_first"):
+        env = dict(os.environ, MCI_KERNEL_CACHE=str(tmp_path / order), AMD_COMGR_CACHE="0")
+        r = subprocess.run([sys.executable, "-c", code, order], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[order] = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT;")][-1].split(";")[1:]
+    assert out["mci_first"] == out["plain"], out                     # identity, file name, bytes
+    assert "libamd_comgr.so." in out["plain"][0], out["plain"][0]    # (the installation's versioned file)
+    if out["torch_first"][0] != out["plain"][0]:                     # this PyTorch bundles its own compiler: another key, never the same file
+        assert out["torch_first"][1] != out["plain"][1], out

@@ -232,8 +232,9 @@ def main():
     import mcintegration_jl_amd as mci
     # the JIT's compiler: the ROCm installation's hiprtc + comgr, pinned BEFORE PyTorch is imported (PyTorch bundles its own copies, another
     # compiler build: the first comgr loaded into a process serves everybody; mci.use_rocm_compiler).  The line says which one it was.
-    compiler = mci.use_rocm_compiler()
+    mci.use_rocm_compiler()          # (comgr + hiprtc only: the HIP runtime of this process stays ONE -- PyTorch's, loaded next -- as before)
     import torch
+    compiler = mci.compiler_id()     # (loads libmci_hip.so: after torch, so that it binds to the runtime torch brought)
     from mcintegration_jl_amd.comm import LocalComm, RcclComm, TorchDistComm
 
     # test seam: an engine factory "module:attr" replaces the HIP engine so that the launcher, the block partition and the

@@ -164,24 +164,29 @@ def use_rocm_compiler(rocm=None):
     was built with and its kernels are validated against.  hiprtc opens the code-object manager (libamd_comgr: the clang / LLVM that
     compiles) by soname, so the FIRST copy loaded into a process serves everybody; a process that imports PyTorch first gets the copies
     PyTorch bundles, another compiler build (the headline loop comes out 4 % longer and 2.2 % slower; the kernel cache is keyed by the
-    compiler, so the two never mix).  Call this BEFORE `import torch` (bench.py, tests/conftest.py and __graft_entry__ do): it loads the
-    installation's comgr and hiprtc with RTLD_GLOBAL, and PyTorch then finds them loaded.  Returns the compiler identity the library
-    reports afterwards (what the cache key holds); if a comgr is already loaded nothing is changed -- the identity says which."""
+    compiler, so the two never mix).  Call this BEFORE `import torch` (bench.py, tests/conftest.py and __graft_entry__ do).  It loads the
+    installation's comgr and hiprtc with RTLD_GLOBAL and NOTHING ELSE: not libmci_hip.so and with it no HIP runtime -- a process that goes
+    on to import PyTorch keeps ONE runtime, PyTorch's, which libmci_hip.so then binds to as it always did (its streams and buffers, the
+    library's RCCL communicator and PyTorch's all live in that one runtime); only the compiler is the installation's.  Returns True if
+    it loaded them, False if a comgr was in the process already (nothing is changed then; `compiler_id()` says which one compiles)."""
     loaded = ""
     try:
         with open("/proc/self/maps") as fh:
             loaded = fh.read()
     except OSError:
         pass
-    if "amd_comgr" not in loaded:
-        root = rocm or os.environ.get("ROCM_PATH") or "/opt/rocm"
-        for names in (("libamd_comgr.so.3", "libamd_comgr.so.2", "libamd_comgr.so"), ("libhiprtc.so.7", "libhiprtc.so")):
-            for name in names:
-                path = os.path.join(root, "lib", name)
-                if os.path.exists(path):
-                    C.CDLL(path, mode=C.RTLD_GLOBAL)
-                    break
-    return compiler_id()
+    if "amd_comgr" in loaded:
+        return False
+    root = rocm or os.environ.get("ROCM_PATH") or "/opt/rocm"
+    done = False
+    for names in (("libamd_comgr.so.3", "libamd_comgr.so.2", "libamd_comgr.so"), ("libhiprtc.so.7", "libhiprtc.so")):
+        for name in names:
+            path = os.path.join(root, "lib", name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+                done = True
+                break
+    return done
 
 
 def compiler_id():

@@ -19,6 +19,8 @@ def pytest_configure(config):
         __graft_entry__.build()
     # the suite compiles with the ROCm installation's hiprtc + comgr (the compiler build() pre-fills the kernel cache with), pinned before
     # any test module imports torch: PyTorch bundles another compiler build, and the first comgr loaded into a process serves everybody
+    # (comgr + hiprtc only -- libmci_hip.so and the HIP runtime are loaded by the first test that needs them, after collection has imported
+    # every test module and with it torch: one runtime per process, as before)
     import mcintegration_jl_amd
     mcintegration_jl_amd.use_rocm_compiler()
 

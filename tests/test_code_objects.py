@@ -286,10 +286,14 @@ order = sys.argv[1]
 if order == "torch_first":
     import torch
 import mcintegration_jl_amd as mci
-ident = mci.use_rocm_compiler()
+pinned = mci.use_rocm_compiler()            # comgr + hiprtc only: no HIP runtime yet
+assert pinned == (order != "torch_first")
 if order == "mci_first":
     import torch
-    assert mci.compiler_id() == ident
+ident = mci.compiler_id()
+if order != "plain":                        # ... and ONE HIP runtime in a process with torch: torch's, which libmci_hip.so binds to
+    hip = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln})
+    assert len(hip) == 1 and "/torch/" in hip[0], hip
 eng = mci.Engine(mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]]), mci.catalog.x2y2(), device=-1)
 eng.compile("vegas")
 p = eng.code_object("vegas")

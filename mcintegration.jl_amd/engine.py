@@ -147,7 +147,10 @@ class Engine:
 
     def _make_host_callback(self, fn, inplace=False):
         """ctypes trampoline: draw-major x[k*n + i] -> numpy views -> fn(x, config) -> w[q*n + i]; inplace: fn(x, weights, config)
-        writes into a view of w itself (vegas/montecarlo.jl:140-141)"""
+        writes into a view of w itself (vegas/montecarlo.jl:140-141).  A closure written per sample with Python branches on its draws
+        (`1.0 if x[0] ** 2 + x[1] ** 2 < 1 else 0.0`: the reference's own style) cannot take a batch -- numpy refuses the truth value
+        of an array -- and is then called sample by sample (slow; such a closure normally never gets here: the tracer writes its
+        branches out as selects)."""
         config = self.config
         nc = config.ncomp
         pools = []   # (first draw, maxdof, nleaf)
@@ -156,37 +159,75 @@ class Engine:
             nl = config.pool_width(vi)
             pools.append((k, config.maxdof[vi], nl))
             k += config.maxdof[vi] * nl
+        state = {"per_sample": False}
+
+        def views(X, n):
+            if len(pools) == 1 and pools[0][2] == 1:
+                return X
+            arg = tuple(X[k0:k0 + md * nl].reshape((md, n) if nl == 1 else (md, nl, n)) for k0, md, nl in pools)
+            return arg[0] if len(arg) == 1 else arg
+
+        def batch(X, W, n):
+            arg = views(X, n)
+            if inplace:
+                if nc == 2:
+                    Z = np.zeros((config.N, n), dtype=complex)
+                    fn(arg, Z, config)
+                    W[0::2], W[1::2] = Z.real, Z.imag
+                else:
+                    W[:] = 0.0
+                    fn(arg, W, config)
+                return
+            out = fn(arg, config)
+            if config.N == 1 and not isinstance(out, (tuple, list)):
+                out = (out,)
+            assert len(out) == config.N, "the integrand must return one value per integrand"
+            for i, o in enumerate(out):
+                o = np.broadcast_to(np.asarray(o), (n,))
+                if nc == 2:
+                    W[2 * i] = o.real
+                    W[2 * i + 1] = o.imag
+                else:
+                    W[i] = o
+
+        def per_sample(X, W, n):
+            Z = np.zeros((config.N, n), dtype=complex if nc == 2 else float)
+            for j in range(n):
+                col = X[:, j]
+                if len(pools) == 1 and pools[0][2] == 1:
+                    arg = col
+                else:
+                    arg = tuple(col[k0:k0 + md * nl].reshape((md,) if nl == 1 else (md, nl)) for k0, md, nl in pools)
+                    arg = arg[0] if len(arg) == 1 else arg
+                if inplace:
+                    w = np.zeros(config.N, dtype=Z.dtype)
+                    fn(arg, w, config)
+                    Z[:, j] = w
+                else:
+                    out = fn(arg, config)
+                    if config.N == 1 and not isinstance(out, (tuple, list)):
+                        out = (out,)
+                    assert len(out) == config.N, "the integrand must return one value per integrand"
+                    for i, o in enumerate(out):
+                        Z[i, j] = o
+            if nc == 2:
+                W[0::2], W[1::2] = Z.real, Z.imag
+            else:
+                W[:] = Z
 
         def cb(xp, wp, n, ndraw, nw, user):
             try:
                 X = np.ctypeslib.as_array(xp, shape=(ndraw, n))
                 W = np.ctypeslib.as_array(wp, shape=(nw, n))
-                if len(pools) == 1 and pools[0][2] == 1:
-                    arg = X
-                else:
-                    arg = tuple(X[k0:k0 + md * nl].reshape((md, n) if nl == 1 else (md, nl, n)) for k0, md, nl in pools)
-                    if len(arg) == 1:
-                        arg = arg[0]
-                if inplace:
-                    if nc == 2:
-                        Z = np.zeros((config.N, n), dtype=complex)
-                        fn(arg, Z, config)
-                        W[0::2], W[1::2] = Z.real, Z.imag
-                    else:
-                        W[:] = 0.0
-                        fn(arg, W, config)
-                    return 0
-                out = fn(arg, config)
-                if config.N == 1 and not isinstance(out, (tuple, list)):
-                    out = (out,)
-                assert len(out) == config.N, "the integrand must return one value per integrand"
-                for i, o in enumerate(out):
-                    o = np.broadcast_to(np.asarray(o), (n,))
-                    if nc == 2:
-                        W[2 * i] = o.real
-                        W[2 * i + 1] = o.imag
-                    else:
-                        W[i] = o
+                if not state["per_sample"]:
+                    try:
+                        batch(X, W, n)
+                        return 0
+                    except ValueError as e:   # "The truth value of an array with more than one element is ambiguous"
+                        if "truth value" not in str(e):
+                            raise
+                        state["per_sample"] = True
+                per_sample(X, W, n)
                 return 0
             except Exception:   # never unwind through the C frame
                 import traceback

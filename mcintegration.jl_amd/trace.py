@@ -9,8 +9,9 @@ The closure sees what a host closure sees (integrand.HostIntegrand) without the 
 i-th draw, with several `x` is a tuple with one array per variable type (a CompositeVar pool has shape [slot, leaf]); the arrays are
 numpy object arrays of `Sym` nodes, so indexing, slicing, arithmetic, `sum`, `np.sum / np.prod / np.dot` and the elementwise numpy
 functions (`np.exp`, `np.log`, `np.sqrt`, `np.sin`, ... -- numpy calls the method of the same name on an object) work as they are.
-What cannot be written out raises TraceError and the caller falls back to the host batch-callback path: data-dependent Python
-branches (`if x[0] > 0.5`), `math.*` functions (they want a float), `np.where / np.maximum` on ARRAYS of symbols (numpy compares
+Python branches on sampled values (`1.0 if x[0] ** 2 + x[1] ** 2 < 1 else 0.0`, `if` / `elif`, `and` / `or`) are written out as selects: the
+closure is run once per way through them (explore(); at most MAX_WAYS ways).  What cannot be written out raises TraceError and the caller
+falls back to the host batch-callback path: `math.*` functions (they want a float), `np.where / np.maximum` on ARRAYS of symbols (numpy compares
 and truth-tests the elements itself; on single draws they trace, and `mci.trace.where / fmax / fmin` take arrays too), complex weights.  The written-out body is checked against the closure itself at random points of the domain before it is
 used (the closure is called with plain float arrays, one sample at a time): a closure that is not a pure function of its draws
 (hidden state, a branch taken on something the trace did not see) is refused.
@@ -46,6 +47,17 @@ class _Trace:
         self.nodes = []
         self.index = {}
         self.params = []      # values of the captured parameters: node ("ud", k) stands for params[k]
+        # Python branches on sampled values (`1.0 if x[0] ** 2 + x[1] ** 2 < 1 else 0.0`, `if`, `and` / `or`, `while`): the closure is run
+        # once per WAY through its branches.  `script` forces the outcome of the k-th truth test of a run, `conds` records what was
+        # tested; explore() below enumerates the ways and joins their results with selects.
+        self.script, self.conds, self.decided = [], [], []
+
+    def decide(self, cond):
+        k = len(self.decided)
+        out = self.script[k] if k < len(self.script) else True
+        self.decided.append(out)
+        self.conds.append(cond)
+        return out
 
     def param(self, v):
         self.params.append(float(v))
@@ -83,7 +95,8 @@ class Sym:
 
     # -- what must not happen during a trace
     def __bool__(self):
-        raise TraceError("a Python branch on a sampled value (use mci.trace.where(cond, a, b))")
+        # a Python branch on a sampled value: this run takes the way the script says (explore() runs the others)
+        return self.t.decide(self if self.op in _BOOL else self.t.node("!=", self, self.t.const(0.0)))
 
     def __float__(self):
         raise TraceError("float() of a sampled value (math.* functions: use the numpy ones)")
@@ -702,6 +715,37 @@ def _domain_points(config, ndraw, n, rng):
     return X
 
 
+MAX_WAYS = 256   # ways through a closure's Python branches that are written out (a loop whose trip count depends on a draw has no bound)
+
+
+def explore(t, run):
+    """run() -> list of values, calling the closure on trace t's symbols; the closure may branch on sampled values.  Every way through
+    its branches is run once (the k-th truth test of a run comes out as the script says, True beyond it) and the ways are joined into
+    ONE list of values with selects: where(first test, values of the ways on which it held, values of the others) -- the C body then
+    holds `c ? a : b` where the closure had `a if c else b`, like a hand-written body (and like Julia's inlined ternary).  Values may be
+    Sym, CSym or numbers.  TraceError beyond MAX_WAYS ways."""
+    ways = [0]
+
+    def way(prefix):
+        ways[0] += 1
+        if ways[0] > MAX_WAYS:
+            raise TraceError("more than %d ways through the closure's branches on sampled values (a loop that ends on a draw?)" % MAX_WAYS)
+        t.script, t.conds, t.decided = list(prefix), [], []
+        vals = list(run())
+        conds, decided = list(t.conds), list(t.decided)
+        for i in range(len(decided) - 1, len(prefix) - 1, -1):   # the tests this run met beyond its prefix, last first: each has an untaken way
+            other = way(decided[:i] + [False])
+            if len(other) != len(vals):
+                raise TraceError("the closure returns %d values on one way through its branches and %d on another" % (len(vals), len(other)))
+            same = lambda a, b: a is b or (not isinstance(a, (Sym, CSym, np.ndarray)) and not isinstance(b, (Sym, CSym, np.ndarray)) and a == b)
+            vals = [a if same(a, b) else where(conds[i], a, b) for a, b in zip(vals, other)]
+        return vals
+    try:
+        return way([])
+    finally:
+        t.script, t.conds, t.decided = [], [], []
+
+
 class _Weights(list):
     """the `weights` output vector of the in-place form `integrand(var, weights, config)` (vegas/montecarlo.jl:140-141) during a trace:
     N entries, zero until the closure stores into them (the reference hands the closure its reused buffer; an entry the closure
@@ -770,18 +814,19 @@ def _trace_integrand(fn, config, indexed, check_points, name, parameters, inplac
     N = config.N
     nc = getattr(config, "ncomp", 1)
     sfn = _parametrized(fn, t) if parameters else fn
-    try:
+    def run():
         outs = _call_form(sfn, arg, config, N, indexed, inplace, lambda: _Weights(N))
+        if len(outs) != N:
+            raise TraceError("the integrand must return one value per integrand (%d), got %d" % (N, len(outs)))
+        return [o.reshape(-1)[0] if isinstance(o, np.ndarray) and o.size == 1 else o for o in outs]
+    try:
+        outs = explore(t, run)
     except TraceError:
         raise
     except Exception as e:   # whatever else the closure does with a symbol that a float would have survived
         raise TraceError("%s: %s" % (type(e).__name__, e))
-    if len(outs) != N:
-        raise TraceError("the integrand must return one value per integrand (%d), got %d" % (N, len(outs)))
     syms = []
     for o in outs:
-        if isinstance(o, np.ndarray) and o.size == 1:
-            o = o.reshape(-1)[0]
         if nc == 2:
             o = CSym.of(o)
             syms += [t.lift(o.re), t.lift(o.im)]
@@ -860,17 +905,17 @@ def trace_measure(fn, config, indexed=False, check_points=32):
 
     def weight(i):
         return CSym(t.node("rw", 2 * i), t.node("rw", 2 * i + 1)) if nc == 2 else t.node("rw", i)
-    try:
-        if indexed:
-            per = []
-            for i in range(N):
-                obs = fresh()
-                fn(i, arg, obs, weight(i), config)
-                per.append(flat(obs))
-        else:
+    def run_one(i):   # (every way through the measure's Python branches is run on fresh observables, explore())
+        def run():
             obs = fresh()
-            fn(arg, obs, [weight(i) for i in range(N)], config)
-            per = [flat(obs)]
+            if i is None:
+                fn(arg, obs, [weight(k) for k in range(N)], config)
+            else:
+                fn(i, arg, obs, weight(i), config)
+            return flat(obs)
+        return explore(t, run)
+    try:
+        per = [run_one(i) for i in range(N)] if indexed else [run_one(None)]
     except TraceError:
         raise
     except Exception as e:

@@ -237,8 +237,9 @@ def test_inplace_closures_the_tracer_refuses():
     cfg = hypersphere_config(3)
     with pytest.raises(TraceError):                                   # a store past the vector
         trace_integrand(lambda x, w, c: w.__setitem__(3, x[0]), cfg, inplace=True)
-    with pytest.raises(TraceError):                                   # a Python branch on a draw (the host path runs it, vectorised or not)
-        trace_integrand(lambda x, w, c: w.__setitem__(0, 1.0 if x[0] > 0 else 0.0), cfg, inplace=True)
+    # a Python branch on a draw is written out as a select (trace.explore): the reference's own `w[i] = _w < 1.0 ? v : 0.0`
+    I = trace_integrand(lambda x, w, c: w.__setitem__(0, 1.0 if x[0] > 0 else 0.0), cfg, inplace=True)
+    assert "? 1.0 : 0.0" in I.body
     # an entry the closure never stores is a zero weight
     I = trace_integrand(lambda x, w, c: w.__setitem__(1, x[0]), cfg, inplace=True)
     assert "w[0] = 0.0;" in I.body and "w[1] = x[0];" in I.body and "w[2] = 0.0;" in I.body
@@ -286,6 +287,57 @@ def test_host_trampoline_hands_the_closure_a_writable_weights_view():
     # an exception in the closure never unwinds through the C frame: status 1
     cb = Engine._make_host_callback(types.SimpleNamespace(config=cfg), lambda x, w, c: 1 / 0, True)
     assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 4, 3, None) == 1
+
+
+def hypersphere_ternary(x, w, c):          # test/montecarlo.jl:210-216 word for word: `w[i] = _w < 1.0 ? volume_inverse(i + 1) : 0.0`
+    _w = x[0] ** 2
+    for i in range(c.userdata):
+        _w += x[i + 1] ** 2
+        w[i] = volume_inverse(i + 2) if _w < 1.0 else 0.0
+
+
+def test_closures_with_python_branches_run_on_both_paths(oracle):
+    """The reference's closures branch on their draws with plain ternaries (Sphere1-3, TestHyperSphere).  Traced: every way through the
+    branches is run once and the ways are joined with selects (trace.explore) -- the same body as the np.where spelling.  Host path:
+    numpy refuses the truth value of a batch, so the trampoline calls such a closure sample by sample."""
+    from mcintegration_jl_amd.engine import Engine
+    cfg = hypersphere_config(3)
+    a, b = trace_integrand(hypersphere_ternary, cfg, inplace=True).body, trace_integrand(hypersphere_inplace, cfg, inplace=True).body
+    assert a.count("?") == b.count("?") == 3                                # three selects either way ...
+    fa, fb = _c_function(oracle, a), _c_function(oracle, b)
+    dpp = C.POINTER(C.c_double)
+    prng = np.random.default_rng(4)
+    for _ in range(200):                                                    # ... computing the same weights
+        x = prng.uniform(-1.0, 1.0, 4) * 0.8
+        wa, wb = np.zeros(3), np.zeros(3)
+        fa(x.ctypes.data_as(dpp), wa.ctypes.data_as(dpp), None)
+        fb(x.ctypes.data_as(dpp), wb.ctypes.data_as(dpp), None)
+        np.testing.assert_array_equal(wa, wb)
+    sphere = lambda x, c: 1.0 if x[0] ** 2 + x[1] ** 2 < 1.0 else 0.0       # test/montecarlo.jl:19-23
+    assert "? 1.0 : 0.0" in trace_integrand(sphere, mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])).body
+    # host trampoline: the batch call raises "truth value of an array ...": sample by sample from then on
+    dp = C.POINTER(C.c_double)
+    n = 9
+    rng = np.random.default_rng(2)
+    calls = []
+
+    def counted(x, w, c):
+        calls.append(np.ndim(x[0]))
+        hypersphere_ternary(x, w, c)
+    cb = Engine._make_host_callback(types.SimpleNamespace(config=cfg), counted, True)
+    X = np.ascontiguousarray(rng.uniform(-0.8, 0.8, (4, n)))
+    W = np.full((3, n), 7.0)
+    for _ in range(2):
+        assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 4, 3, None) == 0
+        r2 = np.cumsum(X ** 2, axis=0)[1:]
+        np.testing.assert_array_equal(W, np.where(r2 < 1.0, np.array([volume_inverse(d) for d in (2, 3, 4)])[:, None], 0.0))
+    assert calls == [1] + [0] * (2 * n)                                     # one refused batch call, then scalars only
+    cfg1 = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
+    cb = Engine._make_host_callback(types.SimpleNamespace(config=cfg1), sphere, False)
+    X = np.ascontiguousarray(rng.uniform(0.0, 1.0, (2, n)))
+    W = np.zeros((1, n))
+    assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 2, 1, None) == 0
+    np.testing.assert_array_equal(W[0], (X[0] ** 2 + X[1] ** 2 < 1.0) * 1.0)
 
 
 @pytest.mark.parametrize("solver", ["vegas", "vegasmc"])

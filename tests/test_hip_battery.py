@@ -617,11 +617,18 @@ def test_inplace_closures_of_the_references_battery(alg, neval, closure_path):
     np.testing.assert_allclose(res.iter_std, twin.iter_std, rtol=1e-6, atol=1e-12)
     check_complex(res, [0.5, 1j / 3])
 
-    def f(x, w, c):                                # test/montecarlo.jl:210-216
+    def f_ternary(x, w, c):                        # test/montecarlo.jl:210-216, ternary and all: the tracer writes the branch out as a select
+        _w = x[0] ** 2
+        for i in range(c.userdata):
+            _w += x[i + 1] ** 2
+            w[i] = _volume_inverse(i + 2) if _w < 1.0 else 0.0
+
+    def f_where(x, w, c):                          # ... the batch spelling for the host path (the ternary runs there too, sample by sample: below)
         _w = x[0] ** 2
         for i in range(c.userdata):
             _w = _w + x[i + 1] ** 2
             w[i] = np.where(_w < 1.0, _volume_inverse(i + 2), 0.0)
+    f = f_ternary if closure_path == "traced" else f_where
     N = 3
     kw = dict(dof=[[i + 2] for i in range(N)], neval=neval, print=-1, solver=alg, debug=False, seed=18)
     res = integrate(f, var=Continuous(-1, 1), userdata=N, inplace=True, **kw)
@@ -632,6 +639,12 @@ def test_inplace_closures_of_the_references_battery(alg, neval, closure_path):
     # the flag decides, not the parameter count: the same closures without inplace=true are a TypeError, not another form
     with pytest.raises(TypeError, match="inplace"):
         integrate(f, var=Continuous(-1, 1), userdata=N, **kw)
+    if closure_path == "host":   # the ternary spelling on the host path: numpy refuses the truth value of a batch, the trampoline goes sample by sample
+        small = dict(kw, neval=4000, niter=3)
+        a = integrate(f_ternary, var=Continuous(-1, 1), userdata=N, inplace=True, **small)
+        b = integrate(mci.catalog.hypersphere(N), var=Continuous(-1, 1), **small)
+        assert isinstance(a.config._engine.integrand, mci.HostIntegrand)
+        np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-9)
 
 
 def test_python_closure_under_the_default_solver_matches_device_source(closure_path):

@@ -43,6 +43,9 @@ CASES = [
      lambda x, c: (np.where(x[1][0] == 2, x[0][0], 2.0 * x[0][1]) + (x[1][0] != 1) * 0.5, (x[0][0] ** 2 + x[0][1] ** 2 < 1.0) * 1.0)),
     ("comparisons_as_numbers", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]]),
      lambda x, c: (x[0] > 0.5) * 2.0 + (x[1] > 0.5) / 4.0 - (x[0] > x[1]) * 1.0 + (x[0] > 0.2) / ((x[1] > 0.7) + 1.0) + (x[0] < 0.9) / ((x[1] < 2.0) * 1)),
+    ("python_branches_on_draws", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [3]]),
+     lambda x, c: (1.0 if x[0] ** 2 + x[1] ** 2 < 1.0 else 0.0,                                   # the reference's Sphere ternary (test/montecarlo.jl:19-32)
+                   (x[0] if x[1] > 0.5 and x[2] > 0.25 else x[1] * 2.0 if x[0] > 0.5 or x[2] < 0.1 else np.maximum(x, 0.5).sum()))),
     ("constant_and_shared_subexpressions", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [2]]),
      lambda x, c: (1.5, np.exp(x[0] * x[1]) + np.exp(x[0] * x[1]) ** 2)),
 ]
@@ -85,9 +88,8 @@ def test_indexed_form_is_traced_per_integrand(oracle):
 
 
 @pytest.mark.parametrize("what,f", [
-    ("a Python branch on a draw", lambda x, c: 1.0 if x[0] > 0.5 else 0.0),
     ("math.exp wants a float", lambda x, c: math.exp(x[0])),
-    ("np.maximum on an ARRAY of draws compares and truth-tests the elements itself", lambda x, c: np.maximum(x, 0.5).sum()),
+    ("a loop that ends on a draw has no bound on its ways", lambda x, c: next(k for k in range(10 ** 6) if k * x[0] > 400.0) * 1.0),
     ("a reduction form of a ufunc on a draw", lambda x, c: np.add.reduce(x[0])),
     ("wrong number of values", lambda x, c: (x[0], x[1])),
     ("not a number", lambda x, c: "one"),
@@ -142,11 +144,15 @@ def test_captured_floats_become_userdata_slots_and_a_sweep_reuses_one_body(oracl
     e1.compile("vegas"), e2.compile("vegas")
     assert e1.code_object("vegas") == e2.code_object("vegas")
     e1.close(), e2.close()
-    # a captured float the closure BRANCHES on cannot be a parameter: traced with its value as a literal (one body per value, as before)
-    thr = 0.5
-    g = lambda x, c: x[0] * 2.0 if thr > 0.25 else x[1]
-    I = trace_integrand(g, config)
-    assert "ud[" not in I.body and len(I.userdata) == 0 and "x[0] * 2.0" in I.body
+    # a captured float the closure BRANCHES on stays a parameter too: both ways are written out and the test's outcome -- parameter-only,
+    # evaluated on the host -- travels in a userdata slot (one body for every value; round 5 baked the value in)
+    bodies = []
+    for thr in (0.5, 0.1):
+        g = lambda x, c: x[0] * 2.0 if thr > 0.25 else x[1]
+        I = trace_integrand(g, config)
+        assert "x[0] * 2.0" in I.body and "(ud[0] != 0.0) ?" in I.body and list(I.userdata) == [1.0 if thr > 0.25 else 0.0]
+        bodies.append(I.body)
+    assert bodies[0] == bodies[1]
     # captured ints are structure, not data
     n = 2
     I = trace_integrand(lambda x, c: np.sum(x[:n]) ** n, config)
@@ -203,7 +209,7 @@ def test_integrate_with_trace_hands_the_engine_device_source(oracle):
         raise Stop()
     for trace in (None, False):
         with pytest.raises(Stop):
-            mci.integrate(lambda x, c: 1.0 if x[0] > 0.5 else 0.0, var=mci.Continuous(0.0, 1.0), dof=[[1]], solver="vegas", trace=trace,
+            mci.integrate(lambda x, c: math.exp(x[0]), var=mci.Continuous(0.0, 1.0), dof=[[1]], solver="vegas", trace=trace,
                           engine_factory=factory, print=-1)
         assert isinstance(got["integrand"], mci.HostIntegrand)
     with pytest.raises(Stop):   # trace=False: a closure is a host closure

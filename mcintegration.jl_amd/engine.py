@@ -240,6 +240,7 @@ class Engine:
         over the chains that ask for it"""
         config = self.config
         nc = config.ncomp
+        state = {"per_sample": False}
 
         def cb(ip, xp, wp, n, ndraw, ncomp, user):
             try:
@@ -249,7 +250,17 @@ class Engine:
                 for i in np.unique(idx[idx >= 0]):
                     sel = np.nonzero(idx == i)[0]
                     whole = len(sel) == n
-                    o = fn(int(i), self._pool_views(X if whole else np.ascontiguousarray(X[:, sel]), len(sel)), config)
+                    Xs = X if whole else np.ascontiguousarray(X[:, sel])
+                    o = None
+                    if not state["per_sample"]:
+                        try:
+                            o = fn(int(i), self._pool_views(Xs, len(sel)), config)
+                        except ValueError as e:   # a closure with Python branches on its draws: sample by sample (see _make_host_callback)
+                            if "truth value" not in str(e):
+                                raise
+                            state["per_sample"] = True
+                    if o is None:
+                        o = np.array([fn(int(i), self._pool_views(np.ascontiguousarray(Xs[:, j:j + 1]), 1, scalar=True), config) for j in range(len(sel))])
                     o = np.broadcast_to(np.asarray(o), (len(sel),))
                     if nc == 2:
                         W[0, sel], W[1, sel] = o.real, o.imag
@@ -262,14 +273,21 @@ class Engine:
                 return 1
         return cb
 
-    def _pool_views(self, X, n):
-        """draw-major [ndraw, n] -> what the reference hands a closure: the pool itself with one variable type, else a tuple of pools"""
+    def _pool_views(self, X, n, scalar=False):
+        """draw-major [ndraw, n] -> what the reference hands a closure: the pool itself with one variable type, else a tuple of pools
+        (scalar: one sample without the batch axis, for a closure that is called sample by sample)"""
         config = self.config
         pools, k = [], 0
         for vi, v in enumerate(config.var):
             nl = config.pool_width(vi)
             pools.append((k, config.maxdof[vi], nl))
             k += config.maxdof[vi] * nl
+        if scalar:
+            X = X[:, 0]
+            if len(pools) == 1 and pools[0][2] == 1:
+                return X
+            arg = tuple(X[k0:k0 + md * nl].reshape((md,) if nl == 1 else (md, nl)) for k0, md, nl in pools)
+            return arg[0] if len(arg) == 1 else arg
         if len(pools) == 1 and pools[0][2] == 1:
             return X
         arg = tuple(X[k0:k0 + md * nl].reshape((md, n) if nl == 1 else (md, nl, n)) for k0, md, nl in pools)

@@ -112,3 +112,20 @@ def test_complex_closures_traced_and_on_the_host_agree(solver):
             assert abs(z.real - exact.real) < 7 * e.real + 1e-12 and abs(z.imag - exact.imag) < 7 * e.imag + 1e-12, (solver, trace, k, z, e)
         out.append(r)
     np.testing.assert_allclose(out[0].iter_mean, out[1].iter_mean, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("solver", ["vegas", "vegasmc", "mcmc"])
+def test_the_references_sphere_closure_with_its_ternary(solver):
+    """test/montecarlo.jl:19-32: `(x, c) -> x[1]^2 + x[2]^2 < 1.0 ? 1.0 : 0.0` (and `(idx, x, c)` under :mcmc), as a Python closure with the
+    same ternary: the tracer runs both ways of the branch and writes a select (trace.explore) -- the device-source twin's iterations to
+    1e-9, pi / 4 inside the reference's 7 sigma"""
+    if solver == "mcmc":
+        f = lambda idx, x, c: 1.0 if x[0] ** 2 + x[1] ** 2 < 1.0 else 0.0
+    else:
+        f = lambda x, c: 1.0 if x[0] ** 2 + x[1] ** 2 < 1.0 else 0.0
+    kw = dict(dof=[[2]], solver=solver, neval=1e5, niter=10, seed=101, print=-1, **({} if solver == "vegas" else dict(nchain=16)))
+    a = mci.integrate(f, var=mci.Continuous(0.0, 1.0), trace=True, **kw)
+    b = mci.integrate("return (x[0] * x[0] + x[1] * x[1] < 1.0) ? 1.0 : 0.0;", var=mci.Continuous(0.0, 1.0), **kw)
+    assert isinstance(a.config._engine.integrand, mci.Integrand) and "? 1.0 : 0.0" in a.config._engine.integrand.body
+    np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-9)
+    assert abs(a.mean[0] - math.pi / 4) < 7 * a.stdev[0]

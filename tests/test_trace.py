@@ -346,3 +346,69 @@ def test_random_closures_trace_to_what_they_compute(oracle, seed):
         fn(x.ctypes.data_as(C.POINTER(C.c_double)), w.ctypes.data_as(C.POINTER(C.c_double)), None)
         ref = np.array([float(e0(x)), float(e1(x))])
         np.testing.assert_allclose(w, ref, rtol=1e-12, atol=1e-300, err_msg="seed %d at %s\n%s" % (seed, x, I.body))
+
+
+def _random_branching_closure(rng, ndraw):
+    """a closure made of real Python control flow on its draws: nested ternaries, `and` / `or` / `not` with their short circuits, early
+    returns; at most six truth tests on any way through it"""
+    budget = [6]
+
+    def value(depth):
+        kind = rng.integers(0, 6 if depth < 3 and budget[0] > 0 else 3)
+        if kind == 0:
+            i = int(rng.integers(0, ndraw))
+            return lambda x: x[i]
+        if kind == 1:
+            v = float(rng.uniform(-2.0, 2.0))
+            return lambda x: v
+        if kind == 2:
+            a, b = value(depth + 1), value(depth + 1)
+            op = int(rng.integers(0, 3))
+            return (lambda x: a(x) + b(x)) if op == 0 else (lambda x: a(x) * b(x)) if op == 1 else (lambda x: a(x) - 0.5 * b(x))
+        budget[0] -= 1
+        c, a, b = cond(depth + 1), value(depth + 1), value(depth + 1)
+        if kind == 3:
+            return lambda x: a(x) if c(x) else b(x)
+        if kind == 4:
+            def early(x):
+                if c(x):
+                    return a(x)
+                return b(x) * 2.0
+            return early
+        return lambda x: (a(x) if c(x) else b(x)) + (1.0 if c(x) else 0.0)      # the same test met twice on one way
+
+    def cond(depth):
+        kind = rng.integers(0, 4 if depth < 3 and budget[0] > 1 else 1)
+        if kind == 0:
+            a, b = value(depth + 1), value(depth + 1)
+            return lambda x: a(x) < b(x)
+        budget[0] -= 1
+        c1, c2 = cond(depth + 1), cond(depth + 1)
+        return (lambda x: c1(x) and c2(x)) if kind == 1 else (lambda x: c1(x) or c2(x)) if kind == 2 else (lambda x: not c1(x))
+    body = value(0)
+    return lambda x, c: body(x)
+
+
+def test_random_closures_with_python_control_flow_trace_to_what_they_compute(oracle):
+    """trace.explore on 40 random closures built from real Python control flow (nested ternaries, early returns, and / or / not with
+    their short circuits, the same test met twice): the written-out body, compiled with gcc, against the closure on plain floats"""
+    rng = np.random.default_rng(2026)
+    dp = C.POINTER(C.c_double)
+    config = mci.Configuration(var=mci.Continuous(-1.0, 1.0), dof=[[4]])
+    traced = selects = 0
+    for case in range(40):
+        f = _random_branching_closure(rng, 4)
+        try:
+            I = trace_integrand(f, config)
+        except TraceError as e:
+            assert "ways through" in str(e), (case, e)      # (only the bound on the number of ways may refuse one of these)
+            continue
+        traced += 1
+        selects += I.body.count("?")
+        fn = _c_function(oracle, I.body)
+        for _ in range(60):
+            x = rng.uniform(-1.0, 1.0, 4)
+            w = np.zeros(1)
+            fn(x.ctypes.data_as(dp), w.ctypes.data_as(dp), I.userdata.ctypes.data_as(dp) if len(I.userdata) else None)
+            assert w[0] == pytest.approx(float(f(x, config)), rel=1e-13, abs=1e-300), (case, x, I.body)
+    assert traced >= 35 and selects >= 40, (traced, selects)

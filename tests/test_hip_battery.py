@@ -695,6 +695,35 @@ def test_cuba11_against_the_references_printed_results(alg):
     print("cuba11 %s: %.4f s (reference prints %.3f s)" % (alg, dt, printed["wall_seconds"]))
 
 
+@pytest.mark.parametrize("alg", ["vegas", "vegasmc"])
+def test_cuba11_as_the_references_inplace_closure(alg):
+    """example/benchmark/cuba/benchmark.jl:35-88, :138-140: the published call is `integrate(test3; dof = [[3,] for i in 1:11], neval = 1e5,
+    solver = alg, inplace = true)` with test3(x, f, c) storing t1 .. t11 -- two of them ternaries on the draws.  The same closure in
+    Python, traced (in-place form, branches as selects), against the hand-written body of the catalog: iteration by iteration."""
+    pi = math.pi
+    rsq = lambda x, y, z: x * x + y * y + z * z
+
+    def test3(v, f, c):
+        x, y, z = v[0], v[1], v[2]
+        f[0] = np.sin(x) * np.cos(y) * np.exp(z)
+        f[1] = 1.0 / ((x + y) * (x + y) + 0.003) * np.cos(y) * np.exp(z)
+        f[2] = 1.0 / (3.75 - np.cos(pi * x) - np.cos(pi * y) - np.cos(pi * z))
+        f[3] = abs(rsq(x, y, z) - 0.125)
+        f[4] = np.exp(-rsq(x, y, z))
+        f[5] = 1.0 / (1.0 - x * y * z + 1e-10)
+        f[6] = np.sqrt(abs(x - y - z))
+        f[7] = np.exp(-x * y * z)
+        f[8] = x * x / (np.cos(x + y + z + 1.0) + 5.0)
+        f[9] = 1.0 / np.sqrt(x * y * z + 1e-5) if x > 0.5 else np.sqrt(x * y * z)
+        f[10] = 1.0 if rsq(x, y, z) < 1.0 else 0.0
+    kw = dict(dof=[[3]] * 11, neval=1e5, solver=alg, print=-1, seed=51)
+    a = integrate(test3, inplace=True, trace=True, **kw)
+    b = integrate(mci.catalog.cuba11(), **kw)
+    assert isinstance(a.config._engine.integrand, mci.Integrand) and a.config._engine.integrand.body.count("?") == 2
+    np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-8)
+    np.testing.assert_allclose(a.mean, b.mean, rtol=1e-8)
+
+
 def test_plain_c_consumer_of_the_abi():
     """examples/mci_demo.c: the README integral through the C ABI from plain C (no Python / torch types in the path)."""
     import os

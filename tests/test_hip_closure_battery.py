@@ -1,0 +1,129 @@
+"""The reference's statistical battery (test/montecarlo.jl:4-160, run at :262-387) with its integrands and measures as PYTHON CLOSURES written
+like the Julia ones -- ternaries on the draws, tuples, `idx` forms under :mcmc, a CompositeVar destructured into its leaves, complex
+values -- instead of the device-source strings of tests/test_hip_battery.py: what a user of the reference would type.  Every closure is
+traced into the kernels (asserted) and the results sit inside the reference's 7 sigma (test/runtests.jl:4-9).  Julia picks `f(x, c)` or
+`f(idx, x, c)` by dispatch on one function with two methods; a Python closure has one form, chosen here by the solver like integrate()
+calls it (0-based indices throughout)."""
+import math
+
+import numpy as np
+import pytest
+
+import mcintegration_jl_amd as mci
+from mcintegration_jl_amd import CompositeVar, Configuration, Continuous, Discrete, integrate
+
+pytestmark = pytest.mark.gpu
+PI = math.pi
+ALGS = [("vegas", 200000), ("vegasmc", 100000), ("mcmc", 100000)]        # test/montecarlo.jl:299, :337, :263
+
+
+def check(result, expect, ratio=7.0):
+    mean = np.concatenate([np.atleast_1d(np.asarray(m, dtype=complex)) for m in result.mean])
+    err = np.concatenate([np.atleast_1d(np.asarray(e, dtype=complex)) for e in result.stdev])
+    expect = np.concatenate([np.atleast_1d(np.asarray(v, dtype=complex)) for v in expect])
+    assert len(mean) == len(expect)
+    for m, e, v in zip(mean, err, expect):
+        assert abs(m.real - v.real) < ratio * e.real + 1e-12 and abs(m.imag - v.imag) < ratio * e.imag + 1e-12, (result.mean, result.stdev, expect)
+
+
+def traced(result):
+    eng = result.config._engine
+    assert isinstance(eng.integrand, mci.Integrand), "the closure was not written out as device source"
+    return result
+
+
+def by_solver(alg, plain, indexed):
+    return indexed if alg == "mcmc" else plain
+
+
+@pytest.mark.parametrize("alg,neval", ALGS)
+def test_spheres(alg, neval):
+    # Sphere1  test/montecarlo.jl:4-9
+    f = by_solver(alg, lambda x, c: 1.0 if x[0] ** 2 + x[1] ** 2 < 1.0 else 0.0, lambda idx, x, c: 1.0 if x[0] ** 2 + x[1] ** 2 < 1.0 else 0.0)
+    check(traced(integrate(f, var=(Continuous(0.0, 1.0),), dof=[[2]], neval=neval, print=-1, solver=alg, seed=101)), [PI / 4.0])
+
+    # Sphere2  :19-52 -- two integrands with different dof on one small pool (resized implicitly), a custom neighbor graph, `measure`
+    def integrand(X, config):
+        i1 = 1.0 if X[0] ** 2 + X[1] ** 2 < 1.0 else 0.0
+        i2 = 1.0 if X[0] ** 2 + X[1] ** 2 + X[2] ** 2 < 1.0 else 0.0
+        return i1, i2
+
+    def integrand_idx(idx, X, config):
+        assert idx == 0 or idx == 1, "%d is not a valid integrand" % idx
+        if idx == 0:
+            return 1.0 if X[0] ** 2 + X[1] ** 2 < 1.0 else 0.0
+        return 1.0 if X[0] ** 2 + X[1] ** 2 + X[2] ** 2 < 1.0 else 0.0
+
+    def measure(X, obs, relative_weights, config):          # obs .+= relativeWeights
+        for i in range(2):
+            obs[i][0] += relative_weights[i]
+
+    def measure_idx(idx, X, obs, relative_weight, config):  # obs[idx] += relativeWeight
+        obs[idx][0] += relative_weight
+    T = Continuous(0.0, 1.0, 2)
+    config = Configuration(var=(T,), dof=[[2], [3]], neighbor=[(1, 3), (1, 2)], seed=102)
+    res = integrate(by_solver(alg, integrand, integrand_idx), config=config, neval=neval, print=-1, solver=alg, debug=True,
+                    measure=by_solver(alg, measure, measure_idx))
+    assert isinstance(res.config._engine.integrand, mci.Integrand)
+    check(res, [PI / 4.0, 4.0 * PI / 3.0 / 8])
+
+    # Sphere3  :55-92 -- observables of different shapes
+    def measure3(X, obs, relative_weights, config):
+        obs[0][0] += relative_weights[0]
+        obs[1][0] += relative_weights[1]
+        obs[1][1] += relative_weights[1] * 2.0
+
+    def measure3_idx(idx, X, obs, relative_weight, config):
+        if idx == 0:
+            obs[idx][0] += relative_weight
+        elif idx == 1:
+            obs[idx][0] += relative_weight
+            obs[idx][1] += relative_weight * 2.0
+        else:
+            raise ValueError("invalid idx: %d" % idx)
+    config = Configuration(var=(Continuous(0.0, 1.0),), dof=[[2], [3]], neighbor=[(1, 3), (1, 2)], obs=[0.0, [0.0, 0.0]], seed=112)
+    res = integrate(by_solver(alg, integrand, integrand_idx), config=config, neval=neval, print=-1, solver=alg, debug=True,
+                    measure=by_solver(alg, measure3, measure3_idx))
+    check(res, [PI / 4.0, 4.0 * PI / 3.0 / 8, 4.0 * PI / 3.0 / 4])
+
+
+@pytest.mark.parametrize("alg,neval", ALGS)
+def test_discrete_and_singular(alg, neval):
+    # TestDiscrete  :94-101, TestDiscrete2  :103-110
+    f = by_solver(alg, lambda x, c: x[0], lambda idx, x, c: x[0])
+    check(traced(integrate(f, config=Configuration(var=(Discrete(1, 3, adapt=True),), dof=[[1]], seed=103), neval=neval, niter=10, print=-1, solver=alg)), [6.0])
+    one = by_solver(alg, lambda x, c: 1.0, lambda idx, x, c: 1.0)
+    check(traced(integrate(one, config=Configuration(var=(Discrete([(1, 3), (1, 4)], adapt=True),), dof=[[1]], seed=104), neval=neval, niter=10, print=-1, solver=alg)), [12.0])
+    # TestSingular1  :112-117  (the reference checks -4 under :vegas and :vegasmc, prints under :mcmc)
+    f = by_solver(alg, lambda X, c: np.log(X[0]) / np.sqrt(X[0]), lambda idx, X, c: np.log(X[0]) / np.sqrt(X[0]))
+    res = traced(integrate(f, neval=neval, print=-1, solver=alg, seed=105))
+    if alg != "mcmc":
+        check(res, [-4.0])
+        assert res.stdev[0] < (0.0004 if alg == "vegas" else 0.0007)                  # :313, :364
+    # TestSingular2  :119-130, _CompositeVar :132-146, _Continuous_HighDim :148-163
+    s2 = lambda x: 1.0 / (1.0 - np.cos(x[0]) * np.cos(x[1]) * np.cos(x[2])) / PI ** 3
+    f = by_solver(alg, lambda x, c: s2(x), lambda idx, x, c: s2(x))
+    check(traced(integrate(f, var=(Continuous(0.0, PI),), dof=[[3]], neval=neval, print=-1, solver=alg, seed=106)), [1.3932])
+
+    def leaves(cvars):                                   # `x, y, z = cvars` (variable.jl:436-447): the pool's leaves, each indexed by slot
+        x, y, z = cvars.T
+        return 1.0 / (1.0 - np.cos(x[0]) * np.cos(y[0]) * np.cos(z[0])) / PI ** 3
+    f = by_solver(alg, lambda cvars, c: leaves(cvars), lambda idx, cvars, c: leaves(cvars))
+    C3 = CompositeVar(Continuous(0.0, PI), Continuous(0.0, PI), Continuous(0.0, PI))
+    check(traced(integrate(f, var=C3, dof=1, neval=neval, print=-1, solver=alg, seed=107)), [1.3932])
+    check(traced(integrate(f, var=Continuous([(0.0, PI), (0.0, PI), (0.0, PI)]), dof=1, neval=neval, print=-1, solver=alg, seed=108)), [1.3932])
+
+
+@pytest.mark.parametrize("alg,neval", [("vegas", 200000), ("vegasmc", 100000), ("mcmc", 100000)])
+def test_complex(alg, neval):
+    # TestComplex1  :166-170, TestComplex2  :172-185
+    f = by_solver(alg, lambda x, c: x[0] + x[0] ** 2 * 1j, lambda idx, x, c: x[0] + x[0] ** 2 * 1j)
+    check(traced(integrate(f, neval=neval, print=-1, type=complex, solver=alg, debug=True, seed=110)), [0.5 + 1j / 3])
+    f = by_solver(alg, lambda x, c: (x[0], x[0] ** 2 * 1j), lambda idx, x, c: x[0] + 0j if idx == 0 else x[0] ** 2 * 1j)
+    check(traced(integrate(f, dof=[[1], [1]], neval=neval, print=-1, type=complex, solver=alg, debug=True, seed=111)), [0.5, 1j / 3])
+
+
+def test_mcmc_reweight_goal():
+    # TestMCMCReweight  :14-17
+    res = traced(integrate(lambda idx, x, c: 1.0, var=(Continuous(0.0, 1.0),), dof=[[1]], neval=100000, print=-1, solver="mcmc", reweight_goal=np.ones(2), seed=109))
+    check(res, [1.0])

@@ -153,19 +153,10 @@ class Engine:
         branches out as selects)."""
         config = self.config
         nc = config.ncomp
-        pools = []   # (first draw, maxdof, nleaf)
-        k = 0
-        for vi, v in enumerate(config.var):
-            nl = config.pool_width(vi)
-            pools.append((k, config.maxdof[vi], nl))
-            k += config.maxdof[vi] * nl
         state = {"per_sample": False}
 
         def views(X, n):
-            if len(pools) == 1 and pools[0][2] == 1:
-                return X
-            arg = tuple(X[k0:k0 + md * nl].reshape((md, n) if nl == 1 else (md, nl, n)) for k0, md, nl in pools)
-            return arg[0] if len(arg) == 1 else arg
+            return self._pool_views(X, n)
 
         def batch(X, W, n):
             arg = views(X, n)
@@ -193,12 +184,7 @@ class Engine:
         def per_sample(X, W, n):
             Z = np.zeros((config.N, n), dtype=complex if nc == 2 else float)
             for j in range(n):
-                col = X[:, j]
-                if len(pools) == 1 and pools[0][2] == 1:
-                    arg = col
-                else:
-                    arg = tuple(col[k0:k0 + md * nl].reshape((md,) if nl == 1 else (md, nl)) for k0, md, nl in pools)
-                    arg = arg[0] if len(arg) == 1 else arg
+                arg = self._pool_views(X[:, j:j + 1], 1, scalar=True)
                 if inplace:
                     w = np.zeros(config.N, dtype=Z.dtype)
                     fn(arg, w, config)
@@ -275,22 +261,23 @@ class Engine:
 
     def _pool_views(self, X, n, scalar=False):
         """draw-major [ndraw, n] -> what the reference hands a closure: the pool itself with one variable type, else a tuple of pools
-        (scalar: one sample without the batch axis, for a closure that is called sample by sample)"""
+        (scalar: one sample without the batch axis, for a closure that is called sample by sample).  A pool with `offset` gets that many
+        leading zero slots: the reference's closures address X[i + offset] (variable.jl:577, test/montecarlo.jl:19-32)."""
         config = self.config
         pools, k = [], 0
         for vi, v in enumerate(config.var):
             nl = config.pool_width(vi)
-            pools.append((k, config.maxdof[vi], nl))
+            pools.append((k, config.maxdof[vi], nl, int(getattr(v, "offset", 0) or 0)))
             k += config.maxdof[vi] * nl
-        if scalar:
-            X = X[:, 0]
-            if len(pools) == 1 and pools[0][2] == 1:
-                return X
-            arg = tuple(X[k0:k0 + md * nl].reshape((md,) if nl == 1 else (md, nl)) for k0, md, nl in pools)
-            return arg[0] if len(arg) == 1 else arg
-        if len(pools) == 1 and pools[0][2] == 1:
-            return X
-        arg = tuple(X[k0:k0 + md * nl].reshape((md, n) if nl == 1 else (md, nl, n)) for k0, md, nl in pools)
+
+        def pool(k0, md, nl, off):
+            a = X[k0:k0 + md * nl].reshape((md, n) if nl == 1 else (md, nl, n))
+            if off:
+                a = np.concatenate([np.zeros((off,) + a.shape[1:]), a])
+            return a[..., 0] if scalar else a
+        if len(pools) == 1 and pools[0][2] == 1 and not pools[0][3]:
+            return X[:, 0] if scalar else X
+        arg = tuple(pool(*p) for p in pools)
         return arg[0] if len(arg) == 1 else arg
 
     def _make_host_measure_callback(self, fn):

@@ -668,24 +668,29 @@ def _parametrized(fn, t):
 
 
 def _pools(config):
+    """(first flat draw, maxdof, leaves per slot, offset) per variable type"""
     pools, k = [], 0
     for vi in range(len(config.var)):
         nl = config.pool_width(vi)
-        pools.append((k, config.maxdof[vi], nl))
+        pools.append((k, config.maxdof[vi], nl, int(getattr(config.var[vi], "offset", 0) or 0)))
         k += config.maxdof[vi] * nl
     return pools, k
 
 
-def _argument(pools, leaf):
-    """what the closure is called with: leaf(k) for flat draw k, arranged like HostIntegrand's argument without the batch axis"""
-    def arr(k0, md, nl):
-        a = np.empty((md,) if nl == 1 else (md, nl), dtype=object)
+def _argument(pools, leaf, pad=lambda: 0.0):
+    """what the closure is called with: leaf(k) for flat draw k, arranged like HostIntegrand's argument without the batch axis.  A pool
+    with `offset` has that many leading slots nobody samples -- the reference's closures address X[i + offset] (variable.jl:577,
+    test/montecarlo.jl:19-32) -- filled with pad() (asked for only then: a trace without offsets numbers its nodes as it always did)"""
+    def arr(k0, md, nl, off=0):
+        a = np.empty((off + md,) if nl == 1 else (off + md, nl), dtype=object)
+        if off:
+            a[:off] = pad()
         for s in range(md):
             if nl == 1:
-                a[s] = leaf(k0 + s)
+                a[off + s] = leaf(k0 + s)
             else:
                 for l in range(nl):
-                    a[s, l] = leaf(k0 + s * nl + l)
+                    a[off + s, l] = leaf(k0 + s * nl + l)
         return a
     if len(pools) == 1:
         return arr(*pools[0])
@@ -810,7 +815,7 @@ def trace_integrand(fn, config, indexed=False, check_points=32, name=None, param
 def _trace_integrand(fn, config, indexed, check_points, name, parameters, inplace=False):
     pools, ndraw = _pools(config)
     t = _Trace()
-    arg = _argument(pools, lambda k: t.node("x", k))
+    arg = _argument(pools, lambda k: t.node("x", k), pad=lambda: t.const(0.0))
     N = config.N
     nc = getattr(config, "ncomp", 1)
     sfn = _parametrized(fn, t) if parameters else fn
@@ -879,7 +884,7 @@ def trace_measure(fn, config, indexed=False, check_points=32):
     pools, ndraw = _pools(config)
     N = config.N
     t = _Trace()
-    arg = _argument(pools, lambda k: t.node("x", k))
+    arg = _argument(pools, lambda k: t.node("x", k), pad=lambda: t.const(0.0))
     zero = t.const(0.0)
 
     def fresh():

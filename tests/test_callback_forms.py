@@ -211,6 +211,24 @@ def test_complex_weights_trace_in_every_form(oracle):
         trace_integrand(lambda x, c: mci.trace.where(x[0] * 1j > 0.5, 1.0, 0.0), mci.Configuration(dof=[[1]], type=complex))
 
 
+def test_closures_address_a_pool_with_offset_like_the_reference():
+    """Continuous(0, 1, size; offset = 2): the reference's closures read X[i + offset] (variable.jl:577; Sphere2 / Sphere3 at offset = 2,
+    test/montecarlo.jl:19-32, :270, :309, :347).  The closure's view of such a pool has `offset` leading slots nobody samples (zeros);
+    the kernels' flat draws stay 0-based (x[0] is the first SAMPLED slot)."""
+    off = 2
+    cfg = mci.Configuration(var=(mci.Continuous(0.0, 1.0, 2 + off, offset=off),), dof=[[2], [3]], neighbor=[(1, 3), (1, 2)])
+    f = lambda X, c: (1.0 if X[0 + off] ** 2 + X[1 + off] ** 2 < 1.0 else 0.0, X[2 + off] + X[0])
+    body = trace_integrand(f, cfg).body
+    assert "x[0] * x[0]" in body and "x[1] * x[1]" in body and "w[1] = x[2];" in body      # X[0] is an unsampled slot: 0
+    ns = _engine_like(cfg)
+    n = 5
+    X = np.ascontiguousarray(np.random.default_rng(3).uniform(0.0, 1.0, (3, n)))
+    v = ns._pool_views(X, n)
+    assert v.shape == (3 + off, n) and np.all(v[:off] == 0.0) and np.array_equal(v[off:], X)
+    s = ns._pool_views(X[:, 1:2], 1, scalar=True)
+    assert s.shape == (3 + off,) and np.array_equal(s[off:], X[:, 1])
+
+
 def test_complex_measure_closures_trace_to_re_im_slots():
     """measure(var, obs, relative_weights, config) with ComplexF64 weights and observables (main.jl:279,284): every weight is rw[2 i] +
     i rw[2 i + 1], every observable entry two obs_add slots; the written-out body against the closure at random records (trace_measure's
@@ -252,6 +270,14 @@ def test_inplace_closures_the_tracer_refuses():
     assert "w[0] = x[1];" in I.body and "w[1] = x[2];" in I.body and "x[0] + x[1]" in I.body
 
 
+def _engine_like(cfg):
+    """what Engine's trampoline builders need of an engine, without a device: the configuration and the pool views"""
+    from mcintegration_jl_amd.engine import Engine
+    ns = types.SimpleNamespace(config=cfg)
+    ns._pool_views = types.MethodType(Engine._pool_views, ns)
+    return ns
+
+
 def test_host_trampoline_hands_the_closure_a_writable_weights_view():
     """trace=False: mci_set_integrand_host's callback receives the library's output array; in the in-place form the closure writes
     into a view of it (real weights: no copy), complex weights through a complex scratch array split into the (re, im) rows"""
@@ -265,7 +291,7 @@ def test_host_trampoline_hands_the_closure_a_writable_weights_view():
     def spy(x, w, c):
         seen["w"] = w
         hypersphere_inplace(x, w, c)
-    cb = Engine._make_host_callback(types.SimpleNamespace(config=cfg), spy, True)
+    cb = Engine._make_host_callback(_engine_like(cfg), spy, True)
     X = np.ascontiguousarray(rng.uniform(-0.8, 0.8, (4, n)))
     W = np.full((3, n), 123.0)
     assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 4, 3, None) == 0
@@ -273,19 +299,19 @@ def test_host_trampoline_hands_the_closure_a_writable_weights_view():
     r2 = np.cumsum(X ** 2, axis=0)[1:]
     np.testing.assert_array_equal(W, np.where(r2 < 1.0, np.array([volume_inverse(d) for d in (2, 3, 4)])[:, None], 0.0))
     # an entry the closure does not store is zero, not what the buffer held
-    cb = Engine._make_host_callback(types.SimpleNamespace(config=cfg), lambda x, w, c: w.__setitem__(1, x[0]), True)
+    cb = Engine._make_host_callback(_engine_like(cfg), lambda x, w, c: w.__setitem__(1, x[0]), True)
     W[:] = 9.0
     assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 4, 3, None) == 0
     np.testing.assert_array_equal(W, [np.zeros(n), X[0], np.zeros(n)])
     # complex
     ccfg = mci.Configuration(dof=[[1], [1]], type=complex)
-    cb = Engine._make_host_callback(types.SimpleNamespace(config=ccfg), complex2_inplace, True)
+    cb = Engine._make_host_callback(_engine_like(ccfg), complex2_inplace, True)
     X = np.ascontiguousarray(rng.uniform(0.0, 1.0, (1, n)))
     W = np.full((4, n), 5.0)
     assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 1, 4, None) == 0
     np.testing.assert_array_equal(W, [X[0], np.zeros(n), np.zeros(n), X[0] ** 2])
     # an exception in the closure never unwinds through the C frame: status 1
-    cb = Engine._make_host_callback(types.SimpleNamespace(config=cfg), lambda x, w, c: 1 / 0, True)
+    cb = Engine._make_host_callback(_engine_like(cfg), lambda x, w, c: 1 / 0, True)
     assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 4, 3, None) == 1
 
 
@@ -324,7 +350,7 @@ def test_closures_with_python_branches_run_on_both_paths(oracle):
     def counted(x, w, c):
         calls.append(np.ndim(x[0]))
         hypersphere_ternary(x, w, c)
-    cb = Engine._make_host_callback(types.SimpleNamespace(config=cfg), counted, True)
+    cb = Engine._make_host_callback(_engine_like(cfg), counted, True)
     X = np.ascontiguousarray(rng.uniform(-0.8, 0.8, (4, n)))
     W = np.full((3, n), 7.0)
     for _ in range(2):
@@ -333,7 +359,7 @@ def test_closures_with_python_branches_run_on_both_paths(oracle):
         np.testing.assert_array_equal(W, np.where(r2 < 1.0, np.array([volume_inverse(d) for d in (2, 3, 4)])[:, None], 0.0))
     assert calls == [1] + [0] * (2 * n)                                     # one refused batch call, then scalars only
     cfg1 = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2]])
-    cb = Engine._make_host_callback(types.SimpleNamespace(config=cfg1), sphere, False)
+    cb = Engine._make_host_callback(_engine_like(cfg1), sphere, False)
     X = np.ascontiguousarray(rng.uniform(0.0, 1.0, (2, n)))
     W = np.zeros((1, n))
     assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 2, 1, None) == 0

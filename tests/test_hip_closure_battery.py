@@ -42,30 +42,32 @@ def test_spheres(alg, neval):
     f = by_solver(alg, lambda x, c: 1.0 if x[0] ** 2 + x[1] ** 2 < 1.0 else 0.0, lambda idx, x, c: 1.0 if x[0] ** 2 + x[1] ** 2 < 1.0 else 0.0)
     check(traced(integrate(f, var=(Continuous(0.0, 1.0),), dof=[[2]], neval=neval, print=-1, solver=alg, seed=101)), [PI / 4.0])
 
-    # Sphere2  :19-52 -- two integrands with different dof on one small pool (resized implicitly), a custom neighbor graph, `measure`
-    def integrand(X, config):
-        i1 = 1.0 if X[0] ** 2 + X[1] ** 2 < 1.0 else 0.0
-        i2 = 1.0 if X[0] ** 2 + X[1] ** 2 + X[2] ** 2 < 1.0 else 0.0
-        return i1, i2
+    # Sphere2  :19-52 -- two integrands with different dof on one small pool (resized implicitly), a custom neighbor graph, `measure`;
+    # run with offset = 0 and offset = 2 (:270-271, :309, :347-349): the closure addresses X[i + offset] like the reference's
+    for offset in (0, 2):
+        def integrand(X, config):
+            i1 = 1.0 if X[0 + offset] ** 2 + X[1 + offset] ** 2 < 1.0 else 0.0
+            i2 = 1.0 if X[0 + offset] ** 2 + X[1 + offset] ** 2 + X[2 + offset] ** 2 < 1.0 else 0.0
+            return i1, i2
 
-    def integrand_idx(idx, X, config):
-        assert idx == 0 or idx == 1, "%d is not a valid integrand" % idx
-        if idx == 0:
-            return 1.0 if X[0] ** 2 + X[1] ** 2 < 1.0 else 0.0
-        return 1.0 if X[0] ** 2 + X[1] ** 2 + X[2] ** 2 < 1.0 else 0.0
+        def integrand_idx(idx, X, config):
+            assert idx == 0 or idx == 1, "%d is not a valid integrand" % idx
+            if idx == 0:
+                return 1.0 if X[0 + offset] ** 2 + X[1 + offset] ** 2 < 1.0 else 0.0
+            return 1.0 if X[0 + offset] ** 2 + X[1 + offset] ** 2 + X[2 + offset] ** 2 < 1.0 else 0.0
 
-    def measure(X, obs, relative_weights, config):          # obs .+= relativeWeights
-        for i in range(2):
-            obs[i][0] += relative_weights[i]
+        def measure(X, obs, relative_weights, config):          # obs .+= relativeWeights
+            for i in range(2):
+                obs[i][0] += relative_weights[i]
 
-    def measure_idx(idx, X, obs, relative_weight, config):  # obs[idx] += relativeWeight
-        obs[idx][0] += relative_weight
-    T = Continuous(0.0, 1.0, 2)
-    config = Configuration(var=(T,), dof=[[2], [3]], neighbor=[(1, 3), (1, 2)], seed=102)
-    res = integrate(by_solver(alg, integrand, integrand_idx), config=config, neval=neval, print=-1, solver=alg, debug=True,
-                    measure=by_solver(alg, measure, measure_idx))
-    assert isinstance(res.config._engine.integrand, mci.Integrand)
-    check(res, [PI / 4.0, 4.0 * PI / 3.0 / 8])
+        def measure_idx(idx, X, obs, relative_weight, config):  # obs[idx] += relativeWeight
+            obs[idx][0] += relative_weight
+        T = Continuous(0.0, 1.0, 2 + offset, offset=offset)
+        config = Configuration(var=(T,), dof=[[2], [3]], neighbor=[(1, 3), (1, 2)], seed=102 + offset)
+        res = integrate(by_solver(alg, integrand, integrand_idx), config=config, neval=neval, print=-1, solver=alg, debug=True,
+                        measure=by_solver(alg, measure, measure_idx))
+        assert isinstance(res.config._engine.integrand, mci.Integrand)
+        check(res, [PI / 4.0, 4.0 * PI / 3.0 / 8])
 
     # Sphere3  :55-92 -- observables of different shapes
     def measure3(X, obs, relative_weights, config):

@@ -44,7 +44,7 @@ def test_spheres(alg, neval):
 
     # Sphere2  :19-52 -- two integrands with different dof on one small pool (resized implicitly), a custom neighbor graph, `measure`;
     # run with offset = 0 and offset = 2 (:270-271, :309, :347-349): the closure addresses X[i + offset] like the reference's
-    for offset in (0, 2):
+    def sphere2(offset):
         def integrand(X, config):
             i1 = 1.0 if X[0 + offset] ** 2 + X[1 + offset] ** 2 < 1.0 else 0.0
             i2 = 1.0 if X[0 + offset] ** 2 + X[1 + offset] ** 2 + X[2 + offset] ** 2 < 1.0 else 0.0
@@ -55,6 +55,10 @@ def test_spheres(alg, neval):
             if idx == 0:
                 return 1.0 if X[0 + offset] ** 2 + X[1 + offset] ** 2 < 1.0 else 0.0
             return 1.0 if X[0 + offset] ** 2 + X[1 + offset] ** 2 + X[2 + offset] ** 2 < 1.0 else 0.0
+        return integrand, integrand_idx
+
+    for offset in (0, 2):
+        integrand, integrand_idx = sphere2(offset)
 
         def measure(X, obs, relative_weights, config):          # obs .+= relativeWeights
             for i in range(2):
@@ -83,6 +87,7 @@ def test_spheres(alg, neval):
             obs[idx][1] += relative_weight * 2.0
         else:
             raise ValueError("invalid idx: %d" % idx)
+    integrand, integrand_idx = sphere2(0)
     config = Configuration(var=(Continuous(0.0, 1.0),), dof=[[2], [3]], neighbor=[(1, 3), (1, 2)], obs=[0.0, [0.0, 0.0]], seed=112)
     res = integrate(by_solver(alg, integrand, integrand_idx), config=config, neval=neval, print=-1, solver=alg, debug=True,
                     measure=by_solver(alg, measure3, measure3_idx))

@@ -3,7 +3,7 @@ like the Julia ones -- ternaries on the draws, tuples, `idx` forms under :mcmc, 
 values -- instead of the device-source strings of tests/test_hip_battery.py: what a user of the reference would type.  Every closure is
 traced into the kernels (asserted) and the results sit inside the reference's 7 sigma (test/runtests.jl:4-9).  Julia picks `f(x, c)` or
 `f(idx, x, c)` by dispatch on one function with two methods; a Python closure has one form, chosen here by the solver like integrate()
-calls it (0-based indices throughout)."""
+calls it (0-based indices throughout).  The last two tests are the scratch scripts next to the battery (test/test.jl, test/test3.jl)."""
 import math
 
 import numpy as np
@@ -134,3 +134,58 @@ def test_mcmc_reweight_goal():
     # TestMCMCReweight  :14-17
     res = traced(integrate(lambda idx, x, c: 1.0, var=(Continuous(0.0, 1.0),), dof=[[1]], neval=100000, print=-1, solver="mcmc", reweight_goal=np.ones(2), seed=109))
     check(res, [1.0])
+
+
+@pytest.mark.parametrize("alg", ["vegasmc", "vegas", "mcmc"])
+def test_two_pools_on_short_custom_grids(alg):
+    """The reference's scratch script test/test.jl:3-33: two Continuous pools on their own 8-point grids (`grid = collect(LinRange(...))`,
+    alpha = 3), dof = [[1, 3]], the closure picking its four coordinates out of the TUPLE of pools, integrate(...; config, block = 16,
+    niter = 10) at the default neval under the default solver (:vegasmc, main.jl:72) -- and under the other two.  The integrand is a
+    normalised Gaussian of width 0.07 around 0.5 in each coordinate: 1 up to erf(5)."""
+    N, alpha = 8, 3.0
+    x1 = Continuous(-1.0, 1.0, grid=np.linspace(-1.0, 1.0, N), alpha=alpha)
+    x2 = Continuous(0.0, 1.0, grid=np.linspace(0.0, 1.0, N), alpha=alpha)
+    config = Configuration(var=(x1, x2), dof=[[1, 3]], seed=130)
+
+    def gauss(X):
+        x = [X[0][0], X[1][0], X[1][1], X[1][2]]
+        dx2 = 0.0
+        for d in range(4):
+            dx2 += (x[d] - 0.5) ** 2
+        return np.exp(-dx2 * 100.0) * 1013.2118364296088
+    f = by_solver(alg, lambda X, c: gauss(X), lambda idx, X, c: gauss(X))
+    res = traced(integrate(f, config=config, block=16, niter=10, print=-1, solver=alg, neval=1e5 if alg == "mcmc" else 1e4))
+    check(res, [math.erf(5.0) ** 3 * 0.5 * (math.erf(5.0) + math.erf(15.0))])
+    # the maps keep their 7 increments and their ends, and have moved towards the peak: the increment holding 0.5 is the narrowest one
+    for v, lo in ((x1, -1.0), (x2, 0.0)):
+        g = v.grid
+        assert len(g) == N and g[0] == lo and g[-1] == 1.0 and np.all(np.diff(g) > 0.0)
+        k = int(np.searchsorted(g, 0.5, side="right")) - 1
+        assert np.diff(g)[k] == np.diff(g).min(), g
+
+
+def test_a_trained_configuration_serves_another_integrand():
+    """The reference's scratch script test/test3.jl:14-44 in today's solver names: train a 1024-point map (alpha = 3) on one integrand, hand
+    `res.config` to integrate() for another with adapt = false (the map must stay as it is, bit for bit) under another solver, then let a
+    chain solver keep adapting a map that :vegas trained on log(x)/sqrt(x)."""
+    X1 = Continuous(0.0, 1.0, alpha=3.0, grid=np.linspace(0.0, 1.0, 1024), adapt=True)
+    res1 = traced(integrate(lambda X, c: X[0], neval=1e5, var=(X1,), dof=[[1]], niter=10, print=-1, solver="vegas", seed=131))
+    check(res1, [0.5])
+    grid1 = np.array(res1.config.var[0].grid)
+    assert len(grid1) == 1024 and np.abs(np.diff(grid1) - 1.0 / 1023).max() > 1e-6           # trained: no longer uniform
+    res3 = traced(integrate(lambda idx, X, c: X[0] ** 2, neval=1e6, dof=[[1]], niter=10, print=-1, solver="mcmc", adapt=False, config=res1.config))
+    check(res3, [1.0 / 3.0])
+    assert np.array_equal(np.array(res3.config.var[0].grid), grid1)
+    res4 = traced(integrate(lambda X, c: X[0] ** 2, neval=1e6, dof=[[1]], niter=10, print=-1, solver="vegasmc", adapt=False, config=res1.config))
+    check(res4, [1.0 / 3.0])
+    assert np.array_equal(np.array(res4.config.var[0].grid), grid1)
+    # two integrals at once on a fresh default map (:35), the singular one trained by :vegas and handed to :mcmc that adapts on (:43-44)
+    res6 = traced(integrate(lambda idx, X, c: X[0] if idx == 0 else X[0] ** 2, neval=1e6, dof=[[1], [1]], niter=10, print=-1, solver="mcmc", seed=132))
+    check(res6, [0.5, 1.0 / 3.0])
+    sing = lambda X: np.log(X[0]) / np.sqrt(X[0])
+    res9 = traced(integrate(lambda X, c: sing(X), neval=1e5, niter=10, print=-1, solver="vegas", seed=133))
+    check(res9, [-4.0])
+    grid9 = np.array(res9.config.var[0].grid)
+    res8 = traced(integrate(lambda idx, X, c: sing(X), neval=1e5, dof=[[1]], niter=10, print=-1, solver="mcmc", adapt=True, config=res9.config))
+    assert not np.array_equal(np.array(res8.config.var[0].grid), grid9) and np.isfinite(res8.mean[0]) and res8.stdev[0] > 0.0
+    assert abs(res8.mean[0] + 4.0) < 0.5                                                     # (:mcmc on this integrand is printed, not checked: test/montecarlo.jl:273-274)

@@ -156,12 +156,12 @@ def test_two_pools_on_short_custom_grids(alg):
     f = by_solver(alg, lambda X, c: gauss(X), lambda idx, X, c: gauss(X))
     res = traced(integrate(f, config=config, block=16, niter=10, print=-1, solver=alg, neval=1e5 if alg == "mcmc" else 1e4))
     check(res, [math.erf(5.0) ** 3 * 0.5 * (math.erf(5.0) + math.erf(15.0))])
-    # the maps keep their 7 increments and their ends, and have moved towards the peak: the increment holding 0.5 is the narrowest one
+    # the maps keep their 7 increments and their ends, and have moved towards the peak: the increment holding 0.5 is less than half a uniform one
     for v, lo in ((x1, -1.0), (x2, 0.0)):
         g = v.grid
         assert len(g) == N and g[0] == lo and g[-1] == 1.0 and np.all(np.diff(g) > 0.0)
         k = int(np.searchsorted(g, 0.5, side="right")) - 1
-        assert np.diff(g)[k] == np.diff(g).min(), g
+        assert np.diff(g)[k] < 0.5 * (1.0 - lo) / (N - 1), g
 
 
 def test_a_trained_configuration_serves_another_integrand():

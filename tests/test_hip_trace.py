@@ -129,3 +129,27 @@ def test_the_references_sphere_closure_with_its_ternary(solver):
     assert isinstance(a.config._engine.integrand, mci.Integrand) and "? 1.0 : 0.0" in a.config._engine.integrand.body
     np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-9)
     assert abs(a.mean[0] - math.pi / 4) < 7 * a.stdev[0]
+
+
+@pytest.mark.parametrize("solver", ["vegas", "vegasmc"])
+def test_random_closures_with_python_control_flow_run_the_same_in_the_kernels_and_on_the_host(solver):
+    """The generator of tests/test_trace.py (nested ternaries, early returns, `and` / `or` / `not`, the same test met twice) end to end: each
+    closure traced into the kernels (selects) against the same closure kept on the host -- where a truth test on a batch of draws makes
+    the trampoline call it sample by sample (engine._make_host_callback) -- iteration by iteration to 1e-9.  Piecewise-polynomial
+    integrands with jumps: the map trains on them, the chains step across them."""
+    from test_trace import _random_branching_closure
+    rng = np.random.default_rng(2027)
+    done = 0
+    for case in range(6):
+        f = _random_branching_closure(rng, 4)
+        kw = dict(dof=[[4]], solver=solver, neval=3000, niter=3, seed=300 + case, print=-1, **({} if solver == "vegas" else dict(nchain=8)))
+        # (a fresh variable per call: a Continuous carries its trained map into the next Configuration built on it, like the reference's)
+        a = mci.integrate(f, var=mci.Continuous(-1.0, 1.0), **kw)       # trace by default; silently the host path where the tracer refuses
+        if not isinstance(a.config._engine.integrand, mci.Integrand):
+            continue                                       # (more ways through it than the tracer follows: host path on both sides)
+        b = mci.integrate(f, var=mci.Continuous(-1.0, 1.0), trace=False, **kw)
+        assert isinstance(b.config._engine.integrand, mci.HostIntegrand)
+        np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-9, atol=1e-12, err_msg="case %d\n%s" % (case, a.config._engine.integrand.body))
+        np.testing.assert_allclose(a.iter_std, b.iter_std, rtol=1e-7, atol=1e-12)
+        done += 1
+    assert done >= 4, done

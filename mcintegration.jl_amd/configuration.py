@@ -143,6 +143,19 @@ class Configuration:
         v = self.var[vi]
         return len(v.vars) if isinstance(v, CompositeVar) else v.dim if isinstance(v, FermiK) else 1
 
+    def pool_layout(self):
+        """per variable type: (first flat draw, maxdof, x entries per slot, offset, is a CompositeVar, kind of every entry of a slot) --
+        kinds: "c" a Continuous draw, "d" a Discrete one (an integer: the reference's Discrete pool holds Ints, variable.jl:283), "k" a
+        FermiK momentum component.  What a closure's argument is built from (trace._argument, Engine._pool_views)."""
+        out, k = [], 0
+        for vi, v in enumerate(self.var):
+            nl = self.pool_width(vi)
+            leaves = list(v.vars) if isinstance(v, CompositeVar) else [v] * nl
+            kinds = "".join("k" if isinstance(lf, FermiK) else "c" if hasattr(lf, "ninc") else "d" for lf in leaves)
+            out.append((k, self.maxdof[vi], nl, int(getattr(v, "offset", 0) or 0), isinstance(v, CompositeVar), kinds))
+            k += self.maxdof[vi] * nl
+        return out
+
     @property
     def ndraw(self):
         return sum(self.maxdof[vi] * self.pool_width(vi) for vi in range(len(self.var)))

@@ -56,6 +56,43 @@ def device_count():
     return n.value
 
 
+class _HostObs(np.ndarray):
+    """an observable handed to a host `measure` closure with a batch of records: `obs[i][bins] += w` with an integer ARRAY of bins
+    (`obs[1][bin[1]] += weights[1]` of docs/src/index.md "Measure Histogram" over the records of a block) adds every record's weight to
+    its bin -- numpy's own fancy `+=` would keep one of the records that share a bin.  An observable only accumulates
+    (vegas/montecarlo.jl:156-161), so reading bins through an integer array gives zeros and storing through one adds."""
+
+    def __new__(cls, n, dtype=float):
+        return np.zeros(n, dtype=dtype).view(cls)
+
+    @staticmethod
+    def _bins(i):
+        return isinstance(i, np.ndarray) and i.dtype.kind in "iu" and i.ndim >= 1
+
+    def __getitem__(self, i):
+        if self._bins(i):
+            return np.zeros(i.shape, dtype=self.dtype)
+        out = np.ndarray.__getitem__(self, i)
+        return out.view(np.ndarray) if isinstance(out, np.ndarray) else out
+
+    def __setitem__(self, i, v):
+        if self._bins(i):
+            np.add.at(self.view(np.ndarray), i, v)
+            return
+        np.ndarray.__setitem__(self, i, v)
+
+
+def _store_obs(O, obs, obs_nbin, nc):
+    off = 0
+    for o, nb in zip(obs, obs_nbin):
+        o = np.asarray(o).reshape(-1)
+        if nc == 2:
+            O[off:off + nb:2], O[off + 1:off + nb:2] = o.real, o.imag
+        else:
+            O[off:off + nb] = o
+        off += nb
+
+
 class Engine:
     def __init__(self, config, integrand, measure=None, device=0, threads=None, wg_per_block=None, rng_bits=None, rng_rounds=None,
                  deterministic=False):
@@ -71,6 +108,7 @@ class Engine:
         self.integrand = integrand
         if callable(measure) and not isinstance(measure, (Measure, HostMeasure)) and not hasattr(measure, "pool"):
             measure = HostMeasure(measure)   # a Python closure: host batch-callback path
+        self.measure = measure               # None (the default measure), bin_by, Measure (device source) or HostMeasure
         leaves = config.leaves
         self._keep = []
         arr = (LeafDesc * len(leaves))()
@@ -209,8 +247,11 @@ class Engine:
                     try:
                         batch(X, W, n)
                         return 0
-                    except ValueError as e:   # "The truth value of an array with more than one element is ambiguous"
-                        if "truth value" not in str(e):
+                    except (ValueError, TypeError, IndexError):
+                        # a closure written per sample like the reference's: a Python branch on a draw ("The truth value of an array
+                        # with more than one element is ambiguous"), a list indexed with a Discrete draw ("only integer scalar arrays
+                        # can be converted to a scalar index"), ...: sample by sample from here on (an error of its own comes again)
+                        if n <= 1:
                             raise
                         state["per_sample"] = True
                 per_sample(X, W, n)
@@ -241,8 +282,8 @@ class Engine:
                     if not state["per_sample"]:
                         try:
                             o = fn(int(i), self._pool_views(Xs, len(sel)), config)
-                        except ValueError as e:   # a closure with Python branches on its draws: sample by sample (see _make_host_callback)
-                            if "truth value" not in str(e):
+                        except (ValueError, TypeError, IndexError):   # a closure written per sample: sample by sample (see _make_host_callback)
+                            if len(sel) <= 1:
                                 raise
                             state["per_sample"] = True
                     if o is None:
@@ -261,29 +302,40 @@ class Engine:
 
     def _pool_views(self, X, n, scalar=False):
         """draw-major [ndraw, n] -> what the reference hands a closure: the pool itself with one variable type, else a tuple of pools
-        (scalar: one sample without the batch axis, for a closure that is called sample by sample).  A pool with `offset` gets that many
-        leading zero slots: the reference's closures address X[i + offset] (variable.jl:577, test/montecarlo.jl:19-32)."""
-        config = self.config
-        pools, k = [], 0
-        for vi, v in enumerate(config.var):
-            nl = config.pool_width(vi)
-            pools.append((k, config.maxdof[vi], nl, int(getattr(v, "offset", 0) or 0)))
-            k += config.maxdof[vi] * nl
+        (scalar: one sample without the batch axis, for a closure that is called sample by sample).  A Discrete pool holds integers like
+        the reference's (variable.jl:283: `grid[bin[0] - 1]`, `obs[0][ext[0] - 1] += w` index with them as they are); a CompositeVar
+        is indexed [leaf][slot] (variable.jl:436-447: `x, y = cvar`) -- one array when its leaves are of one kind, else a tuple of
+        per-leaf arrays; a pool with `offset` gets that many leading zero slots: the reference's closures address X[i + offset]
+        (variable.jl:577, test/montecarlo.jl:19-32)."""
+        layout = self.config.pool_layout()
 
-        def pool(k0, md, nl, off):
-            a = X[k0:k0 + md * nl].reshape((md, n) if nl == 1 else (md, nl, n))
+        def typed(a, kind):
+            return np.rint(a).astype(np.int64) if kind == "d" else a
+
+        def pool(k0, md, nl, off, composite, kinds):
+            a = X[k0:k0 + md * nl].reshape((md, n) if nl == 1 and not composite else (md, nl, n))
             if off:
                 a = np.concatenate([np.zeros((off,) + a.shape[1:]), a])
-            return a[..., 0] if scalar else a
-        if len(pools) == 1 and pools[0][2] == 1 and not pools[0][3]:
+            if composite:                  # [leaf][slot]
+                a = a.transpose(1, 0, 2)
+                if len(set(kinds)) > 1:
+                    return tuple(typed(a[l][..., 0] if scalar else a[l], kinds[l]) for l in range(nl))
+            return typed(a[..., 0] if scalar else a, kinds[0])
+        if len(layout) == 1 and layout[0][2:] == (1, 0, False, "c"):
             return X[:, 0] if scalar else X
-        arg = tuple(pool(*p) for p in pools)
+        arg = tuple(pool(*p) for p in layout)
         return arg[0] if len(arg) == 1 else arg
 
     def _make_host_measure_callback(self, fn):
-        """ctypes trampoline: one block's draws and relative weights -> numpy views -> fn(x, obs, weights, config) -> obs[nobs]"""
+        """ctypes trampoline: one block's draws and relative weights -> numpy views -> fn(x, obs, weights, config) -> obs[nobs].
+        The closure is called once with the block's records as arrays (the batch form: `obs[0][0] += weights[0].sum()`); one written
+        per record like the reference's (`obs[1][1] += weights[1]`, vegas/montecarlo.jl:156-161) raises on arrays and is then called
+        record by record.  `obs[i][bins] += w` with an integer ARRAY of bins (a Discrete draw over the records) accumulates every
+        record, repeated bins included (_HostObs)."""
         config = self.config
         nc = config.ncomp
+        dt = complex if nc == 2 else float
+        state = {"per_record": False}
 
         def cb(xp, rp, n, stride, ndraw, nw, block, op, nobs, user):
             try:
@@ -291,17 +343,20 @@ class Engine:
                 R = np.ctypeslib.as_array(rp, shape=(nw, stride))[:, :n]
                 O = np.ctypeslib.as_array(op, shape=(nobs,))
                 weights = [R[2 * i] + 1j * R[2 * i + 1] for i in range(config.N)] if nc == 2 else [R[i] for i in range(config.N)]
-                dt = complex if nc == 2 else float
-                obs = [np.zeros(ln, dtype=dt) for ln in config.obs_len]
-                fn(self._pool_views(X, n), obs, weights, config)
-                off = 0
-                for o, nb in zip(obs, config.obs_nbin):
-                    o = np.asarray(o).reshape(-1)
-                    if nc == 2:
-                        O[off:off + nb:2], O[off + 1:off + nb:2] = o.real, o.imag
-                    else:
-                        O[off:off + nb] = o
-                    off += nb
+                obs = None
+                if not state["per_record"]:
+                    obs = [_HostObs(ln, dt) for ln in config.obs_len]
+                    try:
+                        fn(self._pool_views(X, n), obs, weights, config)
+                    except (ValueError, TypeError, IndexError):
+                        if n <= 1:
+                            raise
+                        state["per_record"], obs = True, None
+                if obs is None:
+                    obs = [np.zeros(ln, dtype=dt) for ln in config.obs_len]
+                    for j in range(n):
+                        fn(self._pool_views(X[:, j:j + 1], 1, scalar=True), obs, [w[j] for w in weights], config)
+                _store_obs(O, obs, config.obs_nbin, nc)
                 return 0
             except Exception:   # never unwind through the C frame
                 import traceback
@@ -311,9 +366,11 @@ class Engine:
 
     def _make_host_measure_indexed_callback(self, fn):
         """ctypes trampoline of the `measure(idx, var, obs, relative_weight, config)` form: one call of fn per integrand index that
-        some record of the block belongs to, over those records"""
+        some record of the block belongs to, over those records (record by record for a closure that raises on arrays, see above)"""
         config = self.config
         nc = config.ncomp
+        dt = complex if nc == 2 else float
+        state = {"per_record": False}
 
         def cb(ip, xp, rp, n, stride, ndraw, ncomp, block, op, nobs, user):
             try:
@@ -321,26 +378,32 @@ class Engine:
                 X = np.ctypeslib.as_array(xp, shape=(ndraw, stride))[:, :n]
                 R = np.ctypeslib.as_array(rp, shape=(ncomp, stride))[:, :n]
                 O = np.ctypeslib.as_array(op, shape=(nobs,))
-                dt = complex if nc == 2 else float
                 obs, off = [], 0
                 for ln, nb in zip(config.obs_len, config.obs_nbin):   # the block's observables so far (the library calls once per integrand)
                     o = np.array(O[off:off + nb])
-                    obs.append((o[0::2] + 1j * o[1::2]) if nc == 2 else o.astype(dt))
+                    obs.append(((o[0::2] + 1j * o[1::2]) if nc == 2 else o.astype(dt)).view(_HostObs))
                     off += nb
+                w = (R[0] + 1j * R[1]) if nc == 2 else R[0]
                 for i in np.unique(idx[idx >= 0]):
                     sel = np.nonzero(idx == i)[0]
                     whole = len(sel) == n
                     Xs = X if whole else np.ascontiguousarray(X[:, sel])
-                    w = (R[0] + 1j * R[1]) if nc == 2 else R[0]
-                    fn(int(i), self._pool_views(Xs, len(sel)), obs, w if whole else w[sel], config)
-                off = 0
-                for o, nb in zip(obs, config.obs_nbin):
-                    o = np.asarray(o).reshape(-1)
-                    if nc == 2:
-                        O[off:off + nb:2], O[off + 1:off + nb:2] = o.real, o.imag
-                    else:
-                        O[off:off + nb] = o
-                    off += nb
+                    ws = w if whole else w[sel]
+                    if not state["per_record"]:
+                        before = [np.array(o) for o in obs]
+                        try:
+                            fn(int(i), self._pool_views(Xs, len(sel)), obs, ws, config)
+                            continue
+                        except (ValueError, TypeError, IndexError):
+                            if len(sel) <= 1:
+                                raise
+                            state["per_record"] = True
+                            for o, q in zip(obs, before):
+                                np.ndarray.__setitem__(o, slice(None), q)
+                    plain = [o.view(np.ndarray) for o in obs]
+                    for j in range(len(sel)):
+                        fn(int(i), self._pool_views(np.ascontiguousarray(Xs[:, j:j + 1]), 1, scalar=True), plain, ws[j], config)
+                _store_obs(O, obs, config.obs_nbin, nc)
                 return 0
             except Exception:   # never unwind through the C frame
                 import traceback

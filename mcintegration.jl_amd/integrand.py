@@ -42,8 +42,8 @@ class HostIntegrand:
         f(x, config) -> array[n] | tuple of arrays (one per integrand; complex arrays for type=complex)
 
     With one variable type `x[i]` is the vector of the i-th draw over the n samples of the batch (0-based; the
-    reference's `x[i+1]`); with several, `x` is a tuple with one such array per variable type (a CompositeVar pool has
-    shape [slot, leaf, n]).  solver="vegas": n = the samples of a launch, one call per launch; solver="vegasmc" (the reference's
+    reference's `x[i+1]`); with several, `x` is a tuple with one such array per variable type (a CompositeVar pool is
+    indexed [leaf][slot] like the reference's, `x, y = cvar`; a FermiK pool [slot][component]).  solver="vegas": n = the samples of a launch, one call per launch; solver="vegasmc" (the reference's
     default) and "mcmc": n = the chains of a launch, one call per Markov step (the chains advance in lock step).
 
     indexed=True: the reference's `:mcmc` form `integrand(idx, var, config)` (mcmc/montecarlo.jl:34-36) --

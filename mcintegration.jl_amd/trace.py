@@ -6,7 +6,7 @@ the HIP C++ body the sample-batch kernels are JIT-compiled around (integrand.Int
     integrate(f, var=Continuous(-5, 5), dof=[[4]], solver="vegas")        # (tracing is the default; or Integrand = trace_integrand(f, config))
 
 The closure sees what a host closure sees (integrand.HostIntegrand) without the batch axis: with one variable type `x[i]` is the
-i-th draw, with several `x` is a tuple with one array per variable type (a CompositeVar pool has shape [slot, leaf]); the arrays are
+i-th draw, with several `x` is a tuple with one array per variable type (a CompositeVar pool is indexed [leaf][slot] like the reference's -- `x, y = cvar` -- a FermiK pool [slot][component]); the arrays are
 numpy object arrays of `Sym` nodes, so indexing, slicing, arithmetic, `sum`, `np.sum / np.prod / np.dot` and the elementwise numpy
 functions (`np.exp`, `np.log`, `np.sqrt`, `np.sin`, ... -- numpy calls the method of the same name on an object) work as they are.
 Python branches on sampled values (`1.0 if x[0] ** 2 + x[1] ** 2 < 1 else 0.0`, `if` / `elif`, `and` / `or`) are written out as selects: the
@@ -51,6 +51,8 @@ class _Trace:
         # once per WAY through its branches.  `script` forces the outcome of the k-th truth test of a run, `conds` records what was
         # tested; explore() below enumerates the ways and joins their results with selects.
         self.script, self.conds, self.decided = [], [], []
+        self.tables = []      # float arrays the closure indexes with a sampled value (_Table): node ("table", id, j, stride, rows, index)
+        self.dynamic = []     # trace_measure: `obs[i][sampled index] += value` met by the current run: (observable, index, value)
 
     def decide(self, cond):
         k = len(self.decided)
@@ -101,7 +103,11 @@ class Sym:
     def __float__(self):
         raise TraceError("float() of a sampled value (math.* functions: use the numpy ones)")
 
-    __int__ = __index__ = __complex__ = __float__
+    __int__ = __complex__ = __float__
+
+    def __index__(self):
+        raise TraceError("a Python list or a plain numpy array indexed with a sampled value (float arrays reached through "
+                         "config.userdata or captured by the closure are indexed symbolically: trace._Table)")
     __hash__ = object.__hash__
 
     # -- arithmetic (an ndarray operand hands the operation back to numpy, which applies it element by element)
@@ -501,6 +507,119 @@ def _literal(v):
     return r if any(c in r for c in ".en") else r + ".0"
 
 
+class _Table(np.ndarray):
+    """A float array of the user's -- config.userdata, an attribute of it, an array the closure captured -- during a trace: it is the
+    array it was for everything Python does with it, and indexing it with a SAMPLED value (`grid[bin[0] - 1]`, example of
+    docs/src/index.md "Measure Histogram"; `para.extQ[ext[0] - 1]`, test/bubble.jl:60) is a table lookup of the written-out body:
+    the values go into the userdata vector and the element is `ud[base + (int)index]` (a row of an N-d table: one lookup per element).
+    0-based like every index here; an index outside the table is clamped (the check against the closure at random points refuses a
+    closure that relies on anything else, e.g. Python's negative indices)."""
+
+    def __new__(cls, content, t, values=None):
+        obj = np.asarray(content).view(cls)
+        obj._t, obj._values, obj._tid = t, np.ascontiguousarray(content if values is None else values, dtype=np.float64), None
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._t = self._values = self._tid = None          # (a slice or a copy is a plain array again)
+
+    def __getitem__(self, i):
+        if isinstance(i, Sym):
+            return self._lookup(i)
+        if isinstance(i, tuple) and any(isinstance(q, Sym) for q in i):
+            if isinstance(i[0], Sym) and not any(isinstance(q, Sym) for q in i[1:]):
+                return self._lookup(i[0])[i[1:]]
+            raise TraceError("a table indexed with a sampled value on another axis than the first")
+        out = np.ndarray.__getitem__(self, i)
+        return out.view(np.ndarray) if isinstance(out, np.ndarray) else out
+
+    def _lookup(self, idx):
+        if self._t is None or self._values is None or self._values.ndim == 0:
+            raise TraceError("a slice or copy of a table indexed with a sampled value (index the array itself)")
+        t = self._t
+        if idx.t is not t:
+            raise TraceError("a value of another trace")
+        if self._tid is None:
+            self._tid = len(t.tables)
+            t.tables.append(self._values)
+        rows = self._values.shape[0]
+        stride = int(self._values.size // rows) if rows else 0
+        if rows == 0:
+            raise TraceError("an empty table indexed with a sampled value")
+        if self._values.ndim == 1:
+            return t.node("table", self._tid, 0, 1, rows, idx)
+        out = np.empty(self._values.shape[1:], dtype=object)
+        for j, q in enumerate(np.ndindex(out.shape)):
+            out[q] = t.node("table", self._tid, j, stride, rows, idx)
+        return out
+
+
+_TABLE_MAX = 1 << 16
+
+
+def _as_table(v, t):
+    """v as a _Table if it is a rectangular numeric array (or a list / tuple of numbers or of such arrays) of a sensible size, else None"""
+    if isinstance(v, _Table):
+        return v
+    if isinstance(v, np.ndarray):
+        return _Table(v, t) if v.dtype.kind in "fiu" and 0 < v.size <= _TABLE_MAX and v.ndim >= 1 else None
+    if isinstance(v, (list, tuple)) and v and all(isinstance(q, (int, float, np.integer, np.floating, np.ndarray, list, tuple)) and not isinstance(q, bool) for q in v):
+        try:
+            a = np.asarray(v, dtype=np.float64)
+        except (ValueError, TypeError):
+            return None
+        return _Table(a, t) if 0 < a.size <= _TABLE_MAX and a.ndim >= 1 and np.all(np.isfinite(a)) else None
+    return None
+
+
+class _UserdataView:
+    """config.userdata (a struct of parameters: test/bubble.jl:12-27 `para`) during a trace: attribute reads hand arrays out as _Tables"""
+
+    def __init__(self, obj, t):
+        object.__setattr__(self, "_obj", obj)
+        object.__setattr__(self, "_t", t)
+        object.__setattr__(self, "_seen", {})
+
+    def __getattr__(self, name):
+        seen = object.__getattribute__(self, "_seen")
+        if name not in seen:
+            seen[name] = _userdata_view(getattr(object.__getattribute__(self, "_obj"), name), object.__getattribute__(self, "_t"))
+        return seen[name]
+
+    def __getitem__(self, k):
+        seen = object.__getattribute__(self, "_seen")
+        if ("item", k) not in seen:
+            seen[("item", k)] = _userdata_view(object.__getattribute__(self, "_obj")[k], object.__getattribute__(self, "_t"))
+        return seen[("item", k)]
+
+    def __setattr__(self, name, v):
+        raise TraceError("the closure writes to config.userdata (hidden state)")
+
+
+def _userdata_view(v, t):
+    tb = _as_table(v, t)
+    if tb is not None:
+        return tb
+    if isinstance(v, (str, bytes, int, float, complex, bool, type(None), np.generic, np.ndarray, list, tuple, types.FunctionType,
+                      types.BuiltinFunctionType, types.MethodType, types.ModuleType, type)):
+        return v
+    if isinstance(v, dict) or hasattr(v, "__dict__") or hasattr(v, "__slots__"):
+        return _UserdataView(v, t)
+    return v
+
+
+def _trace_config(config, t):
+    """the Configuration a traced closure is called with: the user's, with `userdata` seen through _userdata_view"""
+    import copy
+    ud = getattr(config, "userdata", None)
+    view = _userdata_view(ud, t)
+    if view is ud:
+        return config
+    c = copy.copy(config)
+    c.userdata = view
+    return c
+
+
 def hoist(outs, params):
     """Every maximal subexpression that depends on captured parameters (and constants) only -> one userdata slot, evaluated here on
     the host: ({node id: "ud[j]"}, [values]).  The body then does not change with the parameters' values."""
@@ -532,7 +651,7 @@ def hoist(outs, params):
     return slots, values
 
 
-def emit(outs, sink=lambda i, ref: "w[%d] = %s;" % (i, ref), leaves=None):
+def emit(outs, sink=lambda i, ref: "w[%d] = %s;" % (i, ref), leaves=None, tables=None):
     """HIP C++ / C body: one `const double tK = ...;` per operation (children first), then `w[i] = ...;` (or what `sink` says).
     `leaves` ({node id: text}, from hoist()): nodes written as that text and not looked into.  A comparison used as a NUMBER
     ((x > a) * 2.0, (x > a) + (y > b)) is cast to double where it is used: the arithmetic is floating point like the closure's."""
@@ -559,6 +678,12 @@ def emit(outs, sink=lambda i, ref: "w[%d] = %s;" % (i, ref), leaves=None):
             v = n.args[0]
             name[n.id] = _literal(v) if math.copysign(1.0, v) > 0 else "(%s)" % _literal(v)
             continue
+        if n.op == "table":      # (table id, element of the row, row stride, rows, index): tables[id] = where the table starts in ud[]
+            tid, j, stride, rows, idx = n.args
+            at = "(int)fmin(fmax(%s, 0.0), %d.0)" % (num(idx), rows - 1)
+            lines.append("const double t%d = ud[%d + %s];" % (n.id, tables[tid] + j, at if stride == 1 else "%d * %s" % (stride, at)))
+            name[n.id] = "t%d" % n.id
+            continue
         kinds = C_OPERANDS.get(n.op, "n" * len(n.args))
         ops = [cond(a) if k == "c" else num(a) for a, k in zip(n.args, kinds)]
         if n.op in C_FORMAT:
@@ -575,7 +700,7 @@ def emit(outs, sink=lambda i, ref: "w[%d] = %s;" % (i, ref), leaves=None):
     return "\n".join(lines)
 
 
-def evaluate(outs, X, R=None, params=()):
+def evaluate(outs, X, R=None, params=(), tables=()):
     """The DAG on numeric draws X[draw, sample] (relative weights R[integrand, sample], captured parameters `params`) WITH THE
     SEMANTICS OF THE EMITTED C, for the check against the closure itself: a comparison is the number 0.0 or 1.0 (where numpy's
     bool + bool is a logical or and C's int + int is 2), a truth value is `!= 0`.  A closure whose numpy arithmetic on booleans
@@ -594,6 +719,10 @@ def evaluate(outs, X, R=None, params=()):
                 v = R[n.args[0]]
             elif n.op == "ud":
                 v = f64(params[n.args[0]])
+            elif n.op == "table":
+                tid, j, stride, rows = n.args[:4]
+                at = np.clip(np.nan_to_num(np.asarray(a[4], dtype=f64)), 0.0, rows - 1.0).astype(np.int64)    # ((int) truncates; the index is an integer)
+                v = tables[tid].reshape(-1)[j + stride * at]
             elif n.op == "not":
                 v = np.logical_not(truth(a[0])).astype(f64)
             elif n.op in ("and", "or"):
@@ -628,21 +757,28 @@ def evaluate(outs, X, R=None, params=()):
     return [np.broadcast_to(np.asarray(val[o.id], dtype=np.float64), X.shape[1:]) for o in outs]
 
 
-def _parametrized(fn, t):
+def _parametrized(fn, t, floats=True):
     """A copy of the closure whose captured floats are parameters of trace `t` (module docstring); the closure itself if it has none
     or is not a plain Python function."""
     if not isinstance(fn, types.FunctionType):
         return fn
 
     def conv(v):
-        if isinstance(v, (float, np.floating)) and not isinstance(v, bool) and math.isfinite(v):
+        if floats and isinstance(v, (float, np.floating)) and not isinstance(v, bool) and math.isfinite(v):
             return t.param(v)
-        if isinstance(v, np.ndarray) and v.dtype.kind == "f" and 0 < v.size <= 64 and np.all(np.isfinite(v)):
+        if floats and isinstance(v, np.ndarray) and not isinstance(v, _Table) and v.dtype.kind == "f" and 0 < v.size <= 64 and np.all(np.isfinite(v)):
             a = np.empty(v.shape, dtype=object)
             for i in np.ndindex(v.shape):
                 a[i] = t.param(v[i])
-            return a
+            changed[0] = True
+            return _Table(a, t, values=v)                  # (its elements are parameters; indexed with a sampled value it is a table)
+        if isinstance(v, np.ndarray) and not isinstance(v, _Table):
+            tb = _as_table(v, t)
+            if tb is not None:
+                changed[0] = True
+                return tb
         return v
+    changed = [False]
     n0 = len(t.params)
     cells = None
     if fn.__closure__:
@@ -654,13 +790,13 @@ def _parametrized(fn, t):
                 cells.append(c)
         cells = tuple(cells)
     g = fn.__globals__
-    names = [n for n in fn.__code__.co_names if n in g and isinstance(g[n], (float, np.floating)) and not isinstance(g[n], bool)]
+    names = [n for n in fn.__code__.co_names if n in g and isinstance(g[n], (float, np.floating, np.ndarray)) and not isinstance(g[n], bool)]
     if names:
         g = dict(g)
         for n in names:
             g[n] = conv(g[n])
     defaults = tuple(conv(d) for d in fn.__defaults__) if fn.__defaults__ else None
-    if len(t.params) == n0:
+    if len(t.params) == n0 and not changed[0]:
         return fn
     new = types.FunctionType(fn.__code__, g, fn.__name__, defaults, cells)
     new.__kwdefaults__ = fn.__kwdefaults__
@@ -668,30 +804,40 @@ def _parametrized(fn, t):
 
 
 def _pools(config):
-    """(first flat draw, maxdof, leaves per slot, offset) per variable type"""
-    pools, k = [], 0
-    for vi in range(len(config.var)):
-        nl = config.pool_width(vi)
-        pools.append((k, config.maxdof[vi], nl, int(getattr(config.var[vi], "offset", 0) or 0)))
-        k += config.maxdof[vi] * nl
-    return pools, k
+    """(first flat draw, maxdof, entries per slot, offset, is a CompositeVar, kinds) per variable type (Configuration.pool_layout), and
+    the number of draws"""
+    pools = config.pool_layout()
+    return pools, sum(p[1] * p[2] for p in pools)
 
 
-def _argument(pools, leaf, pad=lambda: 0.0):
-    """what the closure is called with: leaf(k) for flat draw k, arranged like HostIntegrand's argument without the batch axis.  A pool
+def _argument(pools, leaf, pad=lambda: 0.0, numeric=False):
+    """what the closure is called with: leaf(k) for flat draw k, arranged like HostIntegrand's argument without the batch axis.  A
+    CompositeVar is indexed like the reference's (variable.jl:436-447: `cvar[i]` is its i-th leaf VARIABLE, itself indexed by slot, and
+    iterating it gives the leaves -- `x, y = cvar`), i.e. [leaf][slot]; a FermiK pool is [slot][component] (K[i] is a momentum).  A pool
     with `offset` has that many leading slots nobody samples -- the reference's closures address X[i + offset] (variable.jl:577,
-    test/montecarlo.jl:19-32) -- filled with pad() (asked for only then: a trace without offsets numbers its nodes as it always did)"""
-    def arr(k0, md, nl, off=0):
-        a = np.empty((off + md,) if nl == 1 else (off + md, nl), dtype=object)
+    test/montecarlo.jl:19-32) -- filled with pad() (asked for only then: a trace without offsets numbers its nodes as it always did).
+    numeric: leaf(k) are numbers (the check of a trace against the closure itself) -- plain float arrays, and INTEGER ones for Discrete
+    draws like the reference's Discrete pool (variable.jl:283) and like Engine._pool_views hands them to a host closure."""
+    def typed(a, kind):
+        if not numeric:
+            return a
+        return np.rint(a.astype(np.float64)).astype(np.int64) if kind == "d" else a.astype(np.float64)
+
+    def arr(k0, md, nl, off=0, composite=False, kinds="c"):
+        a = np.empty((off + md,) if nl == 1 and not composite else (off + md, nl), dtype=object)
         if off:
             a[:off] = pad()
         for s in range(md):
-            if nl == 1:
+            if a.ndim == 1:
                 a[off + s] = leaf(k0 + s)
             else:
                 for l in range(nl):
                     a[off + s, l] = leaf(k0 + s * nl + l)
-        return a
+        if composite:
+            a = a.T
+            if numeric and len(set(kinds)) > 1:
+                return tuple(typed(a[l], kinds[l]) for l in range(nl))
+        return typed(a, kinds[0])
     if len(pools) == 1:
         return arr(*pools[0])
     return tuple(arr(*p) for p in pools)
@@ -818,9 +964,10 @@ def _trace_integrand(fn, config, indexed, check_points, name, parameters, inplac
     arg = _argument(pools, lambda k: t.node("x", k), pad=lambda: t.const(0.0))
     N = config.N
     nc = getattr(config, "ncomp", 1)
-    sfn = _parametrized(fn, t) if parameters else fn
+    sfn = _parametrized(fn, t, floats=parameters)          # (captured arrays can be indexed with a sampled value either way: _Table)
+    tconfig = _trace_config(config, t)
     def run():
-        outs = _call_form(sfn, arg, config, N, indexed, inplace, lambda: _Weights(N))
+        outs = _call_form(sfn, arg, tconfig, N, indexed, inplace, lambda: _Weights(N))
         if len(outs) != N:
             raise TraceError("the integrand must return one value per integrand (%d), got %d" % (N, len(outs)))
         return [o.reshape(-1)[0] if isinstance(o, np.ndarray) and o.size == 1 else o for o in outs]
@@ -842,7 +989,12 @@ def _trace_integrand(fn, config, indexed, check_points, name, parameters, inplac
             o = t.const(o)
         syms.append(o)
     slots, ud = hoist(syms, t.params)
-    body = emit(syms, leaves=slots)
+    ud, tables = list(ud), {}
+    for n in _reachable(syms, stop=slots):                  # the tables the body looks into follow the parameters in ud[]
+        if n.op == "table" and n.args[0] not in tables:
+            tables[n.args[0]] = len(ud)
+            ud += [float(v) for v in t.tables[n.args[0]].reshape(-1)]
+    body = emit(syms, leaves=slots, tables=tables)
     if check_points:
         rng = np.random.default_rng(12345)
         X = _domain_points(config, ndraw, check_points, rng)
@@ -850,8 +1002,7 @@ def _trace_integrand(fn, config, indexed, check_points, name, parameters, inplac
         try:
             with np.errstate(all="ignore"):
                 for p in range(check_points):   # the closure on one sample at a time: plain floats where the trace had symbols
-                    num = _argument(pools, lambda k: X[k, p])
-                    num = tuple(a.astype(np.float64) for a in num) if isinstance(num, tuple) else num.astype(np.float64)
+                    num = _argument(pools, lambda k: X[k, p], numeric=True)
                     r = _call_form(fn, num, config, N, indexed, inplace, lambda: np.zeros(N, dtype=complex if nc == 2 else float))
                     for i in range(N):
                         if nc == 2:
@@ -861,7 +1012,7 @@ def _trace_integrand(fn, config, indexed, check_points, name, parameters, inplac
                             ref[i, p] = float(np.asarray(r[i], dtype=np.float64).reshape(-1)[0])
         except Exception as e:
             raise TraceError("the closure does not run on numeric draws (%s: %s)" % (type(e).__name__, e))
-        got = evaluate(syms, X, params=t.params)
+        got = evaluate(syms, X, params=t.params, tables=t.tables)
         for i in range(N * nc):
             r = ref[i]
             ok = np.isfinite(r) & np.isfinite(got[i])
@@ -870,6 +1021,35 @@ def _trace_integrand(fn, config, indexed, check_points, name, parameters, inplac
                                  "function of its draws (hidden state, a branch the trace did not see, numpy arithmetic on "
                                  "comparisons that means something else than the same arithmetic on 0.0 / 1.0)" % (i // nc))
     return Integrand(body, ud or None, name=name or getattr(fn, "__name__", "traced"))
+
+
+class _Obs(np.ndarray):
+    """one observable during the trace of a measure: an object array that starts at zero and remembers what is added to its entries;
+    `obs[i][k] += value` with a SAMPLED k (a Discrete draw) is recorded on the trace as an add to a bin chosen at run time"""
+
+    def __new__(cls, n, t, oi, zero):
+        obj = np.empty(n, dtype=object).view(cls)
+        obj[:] = zero
+        obj._t, obj._oi, obj._zero = t, oi, zero
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._t = getattr(obj, "_t", None)
+        self._oi = getattr(obj, "_oi", None)
+        self._zero = getattr(obj, "_zero", None)
+
+    def __getitem__(self, i):
+        if isinstance(i, Sym):
+            return self._zero                       # (what `+=` reads before it adds)
+        return np.ndarray.__getitem__(self, i)
+
+    def __setitem__(self, i, v):
+        if isinstance(i, Sym):
+            if self._t is None or self.ndim != 1:
+                raise TraceError("a sampled index into a view of an observable")
+            self._t.dynamic.append((self._oi, i, v))
+            return
+        np.ndarray.__setitem__(self, i, v)
 
 
 def trace_measure(fn, config, indexed=False, check_points=32):
@@ -888,12 +1068,9 @@ def trace_measure(fn, config, indexed=False, check_points=32):
     zero = t.const(0.0)
 
     def fresh():
-        obs = []
-        for ln in config.obs_len:
-            o = np.empty(ln, dtype=object)
-            o[:] = zero
-            obs.append(o)
-        return obs
+        return [_Obs(ln, t, oi, zero) for oi, ln in enumerate(config.obs_len)]
+
+    shapes = []
 
     def flat(obs):
         out = []
@@ -906,13 +1083,27 @@ def trace_measure(fn, config, indexed=False, check_points=32):
                     raise TraceError("a complex observable in a real configuration")
                 else:
                     out.append(v if isinstance(v, Sym) else t.const(v))
+        # `obs[i][sampled index] += value` (a histogram over a Discrete draw: docs/src/index.md "Measure Histogram", test/bubble.jl:87):
+        # index and value follow the fixed slots, one group per such statement; every way through the measure must make the same ones
+        for oi, idx, v in t.dynamic:
+            out.append(idx)
+            if nc == 2:
+                z = CSym.of(v)
+                out += [t.lift(z.re), t.lift(z.im)]
+            elif isinstance(v, (CSym, complex, np.complexfloating)):
+                raise TraceError("a complex observable in a real configuration")
+            else:
+                out.append(t.lift(v))
+        shapes[-1].append(tuple(oi for oi, _, _ in t.dynamic))
         return out
 
     def weight(i):
         return CSym(t.node("rw", 2 * i), t.node("rw", 2 * i + 1)) if nc == 2 else t.node("rw", i)
     def run_one(i):   # (every way through the measure's Python branches is run on fresh observables, explore())
+        shapes.append([])
         def run():
             obs = fresh()
+            t.dynamic = []
             if i is None:
                 fn(arg, obs, [weight(k) for k in range(N)], config)
             else:
@@ -926,12 +1117,27 @@ def trace_measure(fn, config, indexed=False, check_points=32):
     except Exception as e:
         raise TraceError("%s: %s" % (type(e).__name__, e))
     nobs = sum(config.obs_len) * nc
-    if any(len(p) != nobs for p in per):
+    if any(len(set(sh)) > 1 for sh in shapes):
+        raise TraceError("the measure adds to sampled bins on some ways through its branches and not on others")
+    dyns = [sh[0] if sh else () for sh in shapes]  # per call form: the observable of every `obs[i][sampled index] += value`
+    if any(len(p) != nobs + len(dyn) * (1 + nc) for p, dyn in zip(per, dyns)):
         raise TraceError("the measure changed the shape of obs")
+    obs_off = [sum(config.obs_len[:oi]) * nc for oi in range(len(config.obs_len))]
     parts = []
     for i, adds in enumerate(per):
-        ks = [k for k, v in enumerate(adds) if not _is_const(v, 0.0)]
-        body = emit([adds[k] for k in ks], sink=lambda j, ref, ks=ks: "obs_add(%d, %s);" % (ks[j], ref)) if ks else ""
+        ks = [k for k, v in enumerate(adds[:nobs]) if not _is_const(v, 0.0)]
+        dyn = dyns[i]
+
+        def sink(j, ref, ks=ks, i=i, dyn=dyn):
+            if j < len(ks):
+                return "obs_add(%d, %s);" % (ks[j], ref)
+            d, q = divmod(j - len(ks), 1 + nc)
+            if q == 0:
+                return "const int mci_k%d_%d = (int)(%s);" % (i, d, ref)
+            oi = dyn[d]
+            at = "mci_k%d_%d" % (i, d) if nc == 1 else "2 * mci_k%d_%d + %d" % (i, d, q - 1)
+            return "if (mci_k%d_%d >= 0 && mci_k%d_%d < %d) obs_add(%d + %s, %s);" % (i, d, i, d, config.obs_len[oi], obs_off[oi], at, ref)
+        body = emit([adds[k] for k in ks] + list(adds[nobs:]), sink=sink) if ks or dyn else ""
         if indexed:
             # (under :vegas / :vegasmc every integrand's weight is measured: idx = -1; an :mcmc chain measures the one it sits on)
             body = "if (idx < 0 || idx == %d) {\n%s\n}" % (i, body) if body else ""
@@ -949,8 +1155,7 @@ def trace_measure(fn, config, indexed=False, check_points=32):
             v = np.concatenate([np.asarray(o, dtype=cdt).reshape(-1) for o in obs])
             return np.stack([v.real, v.imag], axis=1).reshape(-1) if nc == 2 else v.astype(np.float64)
         for p in range(check_points):
-            num = _argument(pools, lambda k: X[k, p])                # one record as numpy scalars: `.sum()`, masks and plain `+=` all work on them
-            num = tuple(a.astype(np.float64) for a in num) if isinstance(num, tuple) else num.astype(np.float64)
+            num = _argument(pools, lambda k: X[k, p], numeric=True)   # one record as numpy scalars: `.sum()`, masks and plain `+=` all work on them
             try:
                 with np.errstate(all="ignore"):
                     if indexed:
@@ -965,8 +1170,14 @@ def trace_measure(fn, config, indexed=False, check_points=32):
                         refs = [oflat(obs)]
             except Exception as e:
                 raise TraceError("the measure does not run on numeric records (%s: %s)" % (type(e).__name__, e))
-            for adds, ref in zip(per, refs):
-                got = np.array([float(v[0]) for v in evaluate(adds, X[:, p:p + 1], R[:, p:p + 1])])
+            for adds, ref, dyn in zip(per, refs, dyns):
+                ev = [float(v[0]) for v in evaluate(adds, X[:, p:p + 1], R[:, p:p + 1])]
+                got = np.array(ev[:nobs])
+                for d, oi in enumerate(dyn):
+                    k = int(ev[nobs + d * (1 + nc)])
+                    if 0 <= k < config.obs_len[oi]:
+                        for q in range(nc):
+                            got[obs_off[oi] + nc * k + q] += ev[nobs + d * (1 + nc) + 1 + q]
                 if not np.allclose(got, ref, rtol=1e-10, atol=1e-290, equal_nan=True):
                     raise TraceError("the traced measure and the closure disagree: the closure is not a pure function of its records")
     # (an empty body would mean "the default measure" to the library: a closure that adds nothing is written out as a no-op)

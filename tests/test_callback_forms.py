@@ -227,14 +227,18 @@ def test_closures_address_a_pool_with_offset_like_the_reference():
     assert v.shape == (3 + off, n) and np.all(v[:off] == 0.0) and np.array_equal(v[off:], X)
     s = ns._pool_views(X[:, 1:2], 1, scalar=True)
     assert s.shape == (3 + off,) and np.array_equal(s[off:], X[:, 1])
-    # several pools, each with its own offset: a CompositeVar (two leaves per slot, offset 1) and a Discrete (offset 2)
+    # several pools, each with its own offset: a CompositeVar (indexed [leaf][slot] like the reference's, offset 1) and a Discrete (offset 2)
     C = mci.CompositeVar(mci.Continuous(0.0, 1.0), mci.Continuous(0.0, 2.0), offset=1, size=6)
     cfg2 = mci.Configuration(var=(C, mci.Discrete(1, 4, 5, offset=2)), dof=[[2, 1]])
-    body = trace_integrand(lambda V, c: V[0][1][0] * V[0][2][1] + V[1][2], cfg2).body       # slot 1 leaf 1, slot 2 leaf 2; the Discrete's first draw
+
+    def f2(V, c):
+        (x, y), d = V                                    # `x, y = cvar` (variable.jl:436-447)
+        return x[0 + 1] * y[1 + 1] + d[0 + 2]            # leaf x of the first sampled slot, leaf y of the second; the Discrete's first draw
+    body = trace_integrand(f2, cfg2).body
     assert "x[0] * x[3]" in body and "+ x[4]" in body
     cv, d = _engine_like(cfg2)._pool_views(np.arange(5.0)[:, None] + np.zeros((5, n)), n)
-    assert cv.shape[0] == 3 and np.all(cv[0] == 0.0) and d.shape[0] == 3 and np.all(d[:2] == 0.0) and np.all(d[2] == 4.0)
-    assert np.all(cv[1][0] == 0.0) and np.all(cv[2][1] == 3.0)
+    assert cv.shape == (2, 3, n) and np.all(cv[:, 0] == 0.0) and d.shape[0] == 3 and np.all(d[:2] == 0.0) and np.all(d[2] == 4.0)
+    assert np.all(cv[0][1] == 0.0) and np.all(cv[1][2] == 3.0)
 
 
 def test_complex_measure_closures_trace_to_re_im_slots():

@@ -113,7 +113,7 @@ def test_discrete_and_singular(alg, neval):
     check(traced(integrate(f, var=(Continuous(0.0, PI),), dof=[[3]], neval=neval, print=-1, solver=alg, seed=106)), [1.3932])
 
     def leaves(cvars):                                   # `x, y, z = cvars` (variable.jl:436-447): the pool's leaves, each indexed by slot
-        x, y, z = cvars.T
+        x, y, z = cvars
         return 1.0 / (1.0 - np.cos(x[0]) * np.cos(y[0]) * np.cos(z[0])) / PI ** 3
     f = by_solver(alg, lambda cvars, c: leaves(cvars), lambda idx, cvars, c: leaves(cvars))
     C3 = CompositeVar(Continuous(0.0, PI), Continuous(0.0, PI), Continuous(0.0, PI))

@@ -1,0 +1,192 @@
+"""Closures that index a table with a sampled Discrete value and measures that bin by one, the way the reference's histogram examples
+are written: docs/src/index.md "Measure Histogram" (`r = grid[bin[1]]`, `obs[1][bin[1]] += weights[1]`) and test/bubble.jl:53-92
+(`q = para.extQ[extidx]`, `obs[1][Ext[1]] += weight[1]`).  CPU side: written-out bodies against the closures through gcc, the host
+trampolines' integer Discrete draws and accumulating observables.  The GPU side is tests/test_hip_reference_examples.py."""
+import ctypes as C
+import types
+
+import numpy as np
+import pytest
+
+import mcintegration_jl_amd as mci
+from mcintegration_jl_amd import TraceError, trace_integrand
+from mcintegration_jl_amd.trace import trace_measure
+
+from test_callback_forms import _engine_like
+from test_trace import _c_function
+
+dp = C.POINTER(C.c_double)
+N = 20
+GRID = [i / N for i in range(1, N + 1)]                       # docs: grid = [i / N for i in 1:N]
+
+
+def histogram_integrand(vars, config):                        # docs/src/index.md "Measure Histogram" (0-based: bin[0] - 1)
+    grid = config.userdata
+    x, bin = vars
+    r = grid[bin[0] - 1]
+    r1 = x[0] ** 2 + r ** 2 < 1
+    r2 = x[0] ** 2 + x[1] ** 2 + r ** 2 < 1
+    return r1, r2
+
+
+def histogram_measure(vars, obs, weights, config):
+    x, bin = vars
+    obs[0][bin[0] - 1] += weights[0]
+    obs[1][bin[0] - 1] += weights[1]
+
+
+def histogram_config(userdata=GRID):
+    return mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, N)), dof=[[1, 1], [2, 1]], obs=[np.zeros(N), np.zeros(N)], userdata=userdata)
+
+
+def _check_body(oracle, I, f, cfg, lo, hi, discrete, n=200, seed=0):
+    fn = _c_function(oracle, I.body)
+    rng = np.random.default_rng(seed)
+    ud = np.ascontiguousarray(I.userdata, dtype=np.float64)
+    for _ in range(n):
+        x = rng.uniform(lo, hi)
+        for k, (a, b) in discrete.items():
+            x[k] = float(rng.integers(a, b + 1))
+        w = np.zeros(cfg.N)
+        fn(np.ascontiguousarray(x).ctypes.data_as(dp), w.ctypes.data_as(dp), ud.ctypes.data_as(dp) if len(ud) else None)
+        yield x, w
+
+
+def test_a_table_in_userdata_indexed_with_a_discrete_draw(oracle):
+    cfg = histogram_config()
+    I = trace_integrand(histogram_integrand, cfg)
+    assert "ud[0 + (int)fmin(fmax(" in I.body and ", 0.0), 19.0)]" in I.body and list(I.userdata) == GRID
+    for x, w in _check_body(oracle, I, histogram_integrand, cfg, np.zeros(3), np.ones(3), {2: (1, N)}):
+        ref = histogram_integrand((x[:2], np.array([int(x[2])])), cfg)
+        assert w[0] == float(ref[0]) and w[1] == float(ref[1])
+    # a numpy array and a tuple as userdata trace to the same body
+    assert trace_integrand(histogram_integrand, histogram_config(np.array(GRID))).body == I.body
+    assert trace_integrand(histogram_integrand, histogram_config(tuple(GRID))).body == I.body
+    # under :mcmc's form
+    I3 = trace_integrand(lambda idx, v, c: histogram_integrand(v, c)[idx], cfg, indexed=True)
+    assert I3.body.count("ud[0 + (int)") >= 1
+
+
+def test_rows_of_a_struct_of_parameters(oracle):
+    """test/bubble.jl:53-68: `para = config.userdata`, `q = para.extQ[extidx]` a momentum VECTOR, `kq = k + q`"""
+    para = types.SimpleNamespace(kF=1.2, me=0.5, extQ=[np.array([0.1 * i, -0.05 * i, 0.0]) for i in range(5)])
+
+    def f(vars, config):
+        K, Ext = vars
+        p = config.userdata
+        k = np.array([K[0], K[1], K[2]])
+        q = p.extQ[Ext[0] - 1]
+        kq = k + q
+        return (np.dot(kq, kq) - p.kF ** 2) / (2 * p.me) + q[1]
+    cfg = mci.Configuration(var=(mci.Continuous(-1.0, 1.0), mci.Discrete(1, 5)), dof=[[3, 1]], userdata=para)
+    I = trace_integrand(f, cfg)
+    assert "3 * (int)fmin(fmax(" in I.body and len(I.userdata) == 15
+    for x, w in _check_body(oracle, I, f, cfg, -np.ones(4), np.ones(4), {3: (1, 5)}):
+        assert w[0] == pytest.approx(f((x[:3], np.array([int(x[3])])), cfg), rel=1e-13)
+    # a dict of parameters, a two-dimensional array indexed [draw, column]
+    dcfg = mci.Configuration(var=(mci.Continuous(-1.0, 1.0), mci.Discrete(1, 5)), dof=[[1, 1]], userdata={"extQ": np.array(para.extQ), "s": 2.0})
+    g = lambda v, c: c.userdata["extQ"][v[1][0] - 1, 1] * v[0][0] * c.userdata["s"]
+    Ig = trace_integrand(g, dcfg)
+    for x, w in _check_body(oracle, Ig, g, dcfg, -np.ones(2), np.ones(2), {1: (1, 5)}):
+        assert w[0] == pytest.approx(g((x[:1], np.array([int(x[1])])), dcfg), rel=1e-13)
+
+
+def test_captured_tables_small_and_large(oracle):
+    """an array the closure captured: up to 64 elements they are parameters (ud slots, one body for every value) AND a table when a
+    draw indexes them; larger ones are tables only"""
+    small, large = np.array([1.0, 2.5, -3.0]), np.linspace(0.0, 1.0, 100) ** 2
+    cfg = mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3)), dof=[[1, 1]])
+    f = lambda v, c: small[v[1][0] - 1] * v[0][0] + small[0]
+    I = trace_integrand(f, cfg)
+    assert list(I.userdata) == [1.0, 1.0, 2.5, -3.0] and "ud[1 + (int)" in I.body and "+ ud[0]" in I.body
+    for x, w in _check_body(oracle, I, f, cfg, np.zeros(2), np.ones(2), {1: (1, 3)}):
+        assert w[0] == pytest.approx(f((x[:1], np.array([int(x[1])])), cfg), rel=1e-14)
+    small[:] = [4.0, 5.0, 6.0]                                                     # another value: the same body
+    I2 = trace_integrand(f, cfg)
+    assert I2.body == I.body and list(I2.userdata) == [4.0, 4.0, 5.0, 6.0]
+    cfg2 = mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(0, 99)), dof=[[1, 1]])
+    g = lambda v, c: large[v[1][0]] * v[0][0]
+    Ig = trace_integrand(g, cfg2)
+    assert len(Ig.userdata) == 100 and "ud[0 + (int)fmin(fmax(x[1], 0.0), 99.0)]" in Ig.body
+    for x, w in _check_body(oracle, Ig, g, cfg2, np.zeros(2), np.ones(2), {1: (0, 99)}):
+        assert w[0] == pytest.approx(g((x[:1], np.array([int(x[1])])), cfg2), rel=1e-14)
+
+
+def test_what_a_sampled_index_cannot_do():
+    cfg = mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3)), dof=[[1, 1]])
+    plain = [1.0, 2.0, 3.0]
+    with pytest.raises(TraceError, match="indexed with a sampled value"):          # a Python list the tracer cannot see into
+        trace_integrand(lambda v, c: plain[v[1][0] - 1], cfg)
+    tab = np.arange(12.0).reshape(3, 4)
+    with pytest.raises(TraceError):                                                 # a draw on the second axis
+        trace_integrand(lambda v, c: tab[0, v[1][0]], cfg)
+    with pytest.raises(TraceError, match="disagree"):                               # Python's negative index: the body clamps, the closure wraps
+        trace_integrand(lambda v, c: tab[v[1][0] - 3, 0], cfg)
+
+
+def test_measures_that_bin_by_a_discrete_draw():
+    cfg = histogram_config()
+    body = trace_measure(histogram_measure, cfg).body
+    lines = [ln.strip() for ln in body.splitlines()]
+    assert "if (mci_k0_0 >= 0 && mci_k0_0 < 20) obs_add(0 + mci_k0_0, rw[0]);" in lines
+    assert "if (mci_k0_1 >= 0 && mci_k0_1 < 20) obs_add(20 + mci_k0_1, rw[1]);" in lines
+    # :mcmc's five-argument form (test/bubble.jl:89-92), 0-based idx
+    b5 = trace_measure(lambda idx, v, obs, w, c: obs[idx].__setitem__(v[1][0] - 1, obs[idx][v[1][0] - 1] + w), cfg, indexed=True).body
+    assert "if (idx < 0 || idx == 1) {" in b5 and "obs_add(20 + mci_k1_0, rw[1]);" in b5
+    # a fixed slot and a sampled one of the same observable, complex weights
+    ccfg = mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 4)), dof=[[1, 1]], obs=[np.zeros(4, dtype=complex)], type=complex)
+
+    def mc(v, obs, w, c):
+        obs[0][v[1][0] - 1] += w[0] * v[0][0]
+        obs[0][0] += w[0]
+    bc = trace_measure(mc, ccfg).body
+    assert "obs_add(0, rw[0]);" in bc and "obs_add(0 + 2 * mci_k0_0 + 1," in bc
+    # a branch on a draw around the add: joined with a select
+    def mb(v, obs, w, c):
+        if v[0][0] < 0.5:
+            obs[0][v[1][0] - 1] += w[0]
+        else:
+            obs[0][v[1][0] - 1] += 2 * w[0]
+    assert "? rw[0] :" in trace_measure(mb, cfg).body
+    with pytest.raises(TraceError, match="some ways|on another"):            # (a sampled bin on one way through a branch only)
+        def half(v, obs, w, c):
+            if v[0][0] < 0.5:
+                obs[0][v[1][0] - 1] += w[0]
+        trace_measure(half, cfg)
+
+
+def test_host_closures_get_integer_discrete_draws_and_accumulating_observables():
+    """trace=False: a Discrete pool reaches a host closure as integers (the reference's Discrete holds Ints), so `grid[bin[0] - 1]` and
+    `obs[0][bin[0] - 1] += w` run as written -- over a batch of records too, repeated bins included"""
+    from mcintegration_jl_amd.engine import Engine
+    cfg = histogram_config(np.array(GRID))
+    n = 50
+    rng = np.random.default_rng(2)
+    X = np.ascontiguousarray(np.vstack([rng.uniform(0, 1, (2, n)), rng.integers(1, N + 1, (1, n)).astype(float)]))
+    x, b = _engine_like(cfg)._pool_views(X, n)
+    assert x.dtype == np.float64 and b.dtype == np.int64 and b.shape == (1, n) and np.array_equal(b[0], X[2].astype(int))
+    W = np.zeros((2, n))
+    cb = Engine._make_host_callback(_engine_like(cfg), histogram_integrand, False)
+    assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 3, 2, None) == 0
+    r = np.array(GRID)[X[2].astype(int) - 1]
+    assert np.array_equal(W[0], (X[0] ** 2 + r ** 2 < 1) * 1.0) and np.array_equal(W[1], (X[0] ** 2 + X[1] ** 2 + r ** 2 < 1) * 1.0)
+    # the measure over a block's records
+    R = np.ascontiguousarray(rng.standard_normal((2, n)))
+    O = np.zeros(2 * N)
+    mcb = Engine._make_host_measure_callback(_engine_like(cfg), histogram_measure)
+    assert mcb(X.ctypes.data_as(dp), R.ctypes.data_as(dp), n, n, 3, 2, 0, O.ctypes.data_as(dp), 2 * N, None) == 0
+    ref = np.zeros(2 * N)
+    for j in range(n):
+        ref[int(X[2, j]) - 1] += R[0, j]
+        ref[N + int(X[2, j]) - 1] += R[1, j]
+    np.testing.assert_allclose(O, ref, rtol=1e-13, atol=1e-15)
+    # a measure written per record with a scalar slot (`obs[1][1] += weights[1]`) raises on arrays and is called record by record
+    cfg1 = mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, N)), dof=[[1, 1], [2, 1]], obs=[0.0, np.zeros(2)])
+
+    def per_record(v, obs, w, c):
+        obs[0][0] += w[0]
+        obs[1][1 if v[1][0] > 10 else 0] += w[1]
+    O = np.zeros(3)
+    mcb = Engine._make_host_measure_callback(_engine_like(cfg1), per_record)
+    assert mcb(X.ctypes.data_as(dp), R.ctypes.data_as(dp), n, n, 3, 2, 0, O.ctypes.data_as(dp), 3, None) == 0
+    np.testing.assert_allclose(O, [R[0].sum(), R[1][X[2] <= 10].sum(), R[1][X[2] > 10].sum()], rtol=1e-13)

@@ -6,15 +6,22 @@ the HIP C++ body the sample-batch kernels are JIT-compiled around (integrand.Int
     integrate(f, var=Continuous(-5, 5), dof=[[4]], solver="vegas")        # (tracing is the default; or Integrand = trace_integrand(f, config))
 
 The closure sees what a host closure sees (integrand.HostIntegrand) without the batch axis: with one variable type `x[i]` is the
-i-th draw, with several `x` is a tuple with one array per variable type (a CompositeVar pool is indexed [leaf][slot] like the reference's -- `x, y = cvar` -- a FermiK pool [slot][component]); the arrays are
-numpy object arrays of `Sym` nodes, so indexing, slicing, arithmetic, `sum`, `np.sum / np.prod / np.dot` and the elementwise numpy
-functions (`np.exp`, `np.log`, `np.sqrt`, `np.sin`, ... -- numpy calls the method of the same name on an object) work as they are.
-Python branches on sampled values (`1.0 if x[0] ** 2 + x[1] ** 2 < 1 else 0.0`, `if` / `elif`, `and` / `or`) are written out as selects: the
-closure is run once per way through them (explore(); at most MAX_WAYS ways).  What cannot be written out raises TraceError and the caller
-falls back to the host batch-callback path: `math.*` functions (they want a float), `np.where / np.maximum` on ARRAYS of symbols (numpy compares
-and truth-tests the elements itself; on single draws they trace, and `mci.trace.where / fmax / fmin` take arrays too), complex weights.  The written-out body is checked against the closure itself at random points of the domain before it is
-used (the closure is called with plain float arrays, one sample at a time): a closure that is not a pure function of its draws
-(hidden state, a branch taken on something the trace did not see) is refused.
+i-th draw, with several `x` is a tuple with one array per variable type (a CompositeVar is indexed [leaf][slot] like the reference's
+-- `x, y = cvar` -- a FermiK pool [slot][component]); the arrays are numpy object arrays of `Sym` nodes, so indexing, slicing,
+arithmetic, `sum`, `np.sum / np.prod / np.dot` and the elementwise numpy functions (`np.exp`, `np.log`, `np.sqrt`, `np.sin`, ... --
+numpy calls the method of the same name on an object) work as they are.  Python branches on sampled values (`1.0 if x[0] ** 2 + x[1] **
+2 < 1 else 0.0`, `if` / `elif`, `and` / `or`) are written out as selects: the closure is run once per way through them (explore(); at
+most MAX_WAYS ways).  A float array reached through `config.userdata` (the array itself, an attribute of a struct of parameters, an
+entry of a dict) or captured by the closure may be indexed with a sampled value -- `grid[bin[0] - 1]`, `para.extQ[ext[0] - 1]`, the
+reference's histogram examples (docs/src/index.md "Measure Histogram", test/bubble.jl:60): the table goes into the userdata vector
+and the element is `ud[base + (int)index]` (_Table); a measure may add to a sampled bin, `obs[i][bin[0] - 1] += weights[i]` (_Obs).
+Complex weights are pairs of real expressions (CSym).  What cannot be written out raises TraceError and the caller falls back to the
+host batch-callback path: `math.*` functions (they want a float), `np.where / np.maximum` on ARRAYS of symbols (numpy compares and
+truth-tests the elements itself; on single draws they trace, and `mci.trace.where / fmax / fmin` take arrays too), a Python list
+indexed with a draw.  The written-out body is checked against the closure itself at random points of the domain before it is used
+(the closure is called with plain arrays, one sample at a time; Discrete draws are integers there like on the host path and in the
+reference): a closure that is not a pure function of its draws (hidden state, a branch taken on something the trace did not see) is
+refused.
 
 Captured parameters.  Floats the closure captures -- closure cells, float defaults, module-level floats its code names; float arrays
 of up to 64 elements likewise -- are traced as PARAMETERS, not as literals: every maximal subexpression that depends on parameters

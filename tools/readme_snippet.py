@@ -1,11 +1,14 @@
-import sys; sys.path.insert(0, "/root/repo")
-import numpy as np, mcintegration_jl_amd as mci
-res = mci.integrate("return log(x[0]) / sqrt(x[0]);", solver="vegas", neval=1e5)
-print(res)
-res = mci.integrate(lambda x, c: np.log(x[0]) / np.sqrt(x[0]), solver="vegas", neval=1e5)
-mci.report(res)
-cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]])
-res = mci.integrate(mci.catalog.sphere2(), config=cfg, neval=1e6)
-res = mci.integrate(mci.catalog.sphere2(), config=res.config, neval=1e7, niter=5)
-print(res)
-mci.report(res.config)
+"""Runs the quick-start block of README.md as it stands there (needs an MI355X), then examples/histogram_measure.py."""
+import os
+import re
+import runpy
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+block = re.search(r"```python\n(.*?)```", open(os.path.join(ROOT, "README.md")).read(), re.S).group(1)
+ns = {}
+exec(compile(block, "README.md", "exec"), ns)
+print(ns["res"])
+ns["mci"].report(ns["res"].config)
+runpy.run_path(os.path.join(ROOT, "examples", "histogram_measure.py"), run_name="__main__")

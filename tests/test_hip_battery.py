@@ -852,7 +852,7 @@ def test_automatic_chains_carry_the_bias_of_the_references_own_chain_and_no_more
     deviation of 7.2 sigma -- the estimator's own; a decomposition that doubled it would fail); (iii) the plain mean of the counted
     iterations, which weights the early iterations of a cold call as much as the late ones, agrees between the arms as well -- that is
     where chains carried across a refinement of the map showed before they were resampled to the moved target (DESIGN "Chains")."""
-    nseeds = 64 if solver == "vegasmc" else 32      # (:mcmc: the reference arm -- 16 sequential chains of 62500 steps -- takes 1.8 s per run; at 32 seeds bound (ii) is 0.51 + 3 / sqrt(32) = 1.04)
+    nseeds = 64 if solver == "vegasmc" else 24      # (:mcmc: the reference arm -- 16 sequential chains of 62500 steps -- takes 1.8 s per run; at 24 seeds bound (ii) is 0.51 + 3 / sqrt(24) = 1.12)
     exact = np.array([math.erf(5.0) ** d for d in (3, 6, 9, 12)])
     c5 = lambda seed: Configuration(var=Continuous(0.0, 1.0), dof=[[3], [6], [9], [12]], seed=seed)
     f = mci.catalog.nested_gauss()
@@ -864,7 +864,7 @@ def test_automatic_chains_carry_the_bias_of_the_references_own_chain_and_no_more
     diff = (mb.mean(0) - ma.mean(0)) / np.sqrt(ma.var(0, ddof=1) / nseeds + mb.var(0, ddof=1) / nseeds)
     assert np.all(np.abs(diff) < 4.0), diff
     per_run = (mb.mean(0) - exact) / np.sqrt((eb ** 2).mean(0))
-    assert np.all(np.abs(per_run) < 0.51 + 3.0 / math.sqrt(nseeds)), per_run       # (0.89 at 64 seeds, 1.04 at 32)
+    assert np.all(np.abs(per_run) < 0.51 + 3.0 / math.sqrt(nseeds)), per_run       # (0.89 at 64 seeds, 1.12 at 24)
     udiff = (ub.mean(0) - ua.mean(0)) / np.sqrt(ua.var(0, ddof=1) / nseeds + ub.var(0, ddof=1) / nseeds)
     assert np.all(np.abs(udiff) < 4.0), udiff
 

@@ -37,6 +37,14 @@ class ContinuousVar(_Leaf):
             return self._grid0.copy()
         return np.linspace(self.lower, self.upper, self.ninc)
 
+    @property
+    def histogram(self):
+        """what the last iteration accumulated for this map (reference field `histogram`, variable.jl:95, :196-200): one entry per
+        increment; the 1e-10 of clearStatistics (variable.jl:565) before anything has run"""
+        if self._engine is not None:
+            return np.array(self._engine.histogram(self._leaf_index))
+        return np.full(self.ninc - 1, 1.0e-10)
+
     def __repr__(self):
         return "%s Continuous variable in [%g, %g).%s" % ("Adaptive" if self.adapt else "Nonadaptive", self.lower,
                                                           self.upper, " Learning rate = %g." % self.alpha if self.adapt else "")
@@ -71,6 +79,13 @@ class DiscreteVar(_Leaf):
         if self._engine is not None:
             return self._engine.distribution(self._leaf_index)[1]
         return np.concatenate([[0.0], np.cumsum(self.distribution)])
+
+    @property
+    def histogram(self):
+        """what the last iteration accumulated per value (reference field `histogram`, variable.jl:283, :362-367)"""
+        if self._engine is not None:
+            return np.array(self._engine.histogram(self._leaf_index))
+        return np.full(self.upper - self.lower + 1, 1.0e-10)
 
     def __repr__(self):
         return "%s Discrete variable in [%d, ..., %d]." % ("Adaptive" if self.adapt else "Nonadaptive", self.lower, self.upper)

@@ -181,6 +181,14 @@ def test_resume_keeps_trained_grid_and_improves_first_iteration():
     res0 = integrate("return log(x[0]) / sqrt(x[0]);", solver="vegas", neval=1e5, seed=21)
     g0 = res0.config.var[0].grid.copy()
     assert not np.allclose(g0, np.linspace(0, 1, 1000))  # trained
+    # `var.histogram` like the reference's: train! ends with clearStatistics! (variable.jl:238, :565), so an adaptive run leaves 1e-10;
+    # with adapt = false nobody clears it and the last iteration's sum of (|f| jac)^2 per increment stays (variable.jl:196-200, :208-210)
+    h = res0.config.var[0].histogram
+    assert h.shape == (999,) and np.array_equal(h, np.full(999, 1e-10))
+    resf = integrate("return log(x[0]) / sqrt(x[0]);", solver="vegas", neval=1e5, niter=2, adapt=False, config=res0.config)
+    h = resf.config.var[0].histogram
+    assert h.shape == (999,) and np.all(h > 1e-10) and h.max() < 30.0 * h.mean()          # (on a trained map the increments carry alike)
+    assert np.array_equal(resf.config.var[0].grid, g0)
     res = integrate("return log(x[0]) / sqrt(x[0]);", solver="vegas", neval=1e5, config=res0.config)
     assert res.iter_std[0, 0] < 0.2 * res0.iter_std[0, 0]
     check(res, -4.0)

@@ -179,6 +179,23 @@ class Configuration:
             return self._engine.reweight()
         return self._reweight0.copy()
 
+    def _acceptance(self, which):
+        nd = self.N + 1
+        shape = (3, nd, max(nd, len(self.var)))
+        if self._engine is not None and hasattr(self._engine, "acceptance"):
+            return self._engine.acceptance()[which]
+        return np.full(shape, 1.0e-8) if which == 0 else np.zeros(shape)
+
+    @property
+    def propose(self):
+        """proposed updates of the last iteration, [update type, integrand, target] (configuration.jl:58, :185; 0-based)"""
+        return self._acceptance(0)
+
+    @property
+    def accept(self):
+        """accepted updates of the last iteration, shaped like `propose` (configuration.jl:59, :186)"""
+        return self._acceptance(1)
+
     def __repr__(self):
         return "Configuration for %d integrands involves %d types of variables.\nNumber of variables for each integrand: %s.\n" % (
             self.N, len(self.var), self.dof)

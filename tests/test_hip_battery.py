@@ -428,6 +428,7 @@ def test_report_config_prints_the_acceptance_table(capsys):
     res = integrate(mci.catalog.sphere2(), var=Continuous(0.0, 1.0), dof=[[2], [3]], solver="mcmc", neval=2e5, seed=41)
     pr, ac = res.config._engine.acceptance()
     assert pr.shape == (3, 3, 3) and np.all(ac <= pr)
+    assert np.array_equal(res.config.propose, pr) and np.array_equal(res.config.accept, ac)      # the reference's field names (configuration.jl:58-59)
     mci.report(res.config)
     out = capsys.readouterr().out
     for word in ("Configuration", "ChangeIntegrand", "ChangeVariable", "SwapVariable", "Visited", "ReWeight", "Integrand evaluation"):

@@ -92,6 +92,8 @@ def test_variable_constructors():
     assert x.size == 8 and x.ninc == 4
     cv = mci.Continuous([(0.0, 1.0), (0.0, 2.0)])
     assert isinstance(cv, mci.CompositeVar) and len(cv) == 2 and cv[1].upper == 2.0 and cv[0].ninc == 1000
+    c = mci.Configuration(var=(x, d), dof=[[1, 1], [2, 1]])
+    assert c.propose.shape == c.accept.shape == (3, 3, 3) and np.all(c.propose == 1e-8) and not c.accept.any()      # configuration.jl:185-186
     # the fields a reference user reads off a variable before anything has run: uniform map, cleared histogram (variable.jl:565)
     assert np.array_equal(x.grid, [0.0, 0.1, 0.4, 1.0]) and np.array_equal(x.histogram, np.full(3, 1e-10))
     assert np.array_equal(d.histogram, np.full(4, 1e-10)) and np.allclose(d.distribution, 0.25) and d.accumulation[-1] == 1.0

@@ -23,8 +23,9 @@ indexed with a draw.  The written-out body is checked against the closure itself
 reference): a closure that is not a pure function of its draws (hidden state, a branch taken on something the trace did not see) is
 refused.
 
-Captured parameters.  Floats the closure captures -- closure cells, float defaults, module-level floats its code names; float arrays
-of up to 64 elements likewise -- are traced as PARAMETERS, not as literals: every maximal subexpression that depends on parameters
+Captured parameters.  Floats the closure captures -- closure cells, float defaults, module-level floats its code names, floats read
+off `config.userdata` (a number, an attribute of a struct of parameters, a dict entry); float arrays of up to 64 elements likewise --
+are traced as PARAMETERS, not as literals: every maximal subexpression that depends on parameters
 and constants only is evaluated on the host and handed to the kernel in a `ud[k]` slot (Integrand.userdata), so the written-out body is
 the same text for every value and a parameter sweep over a closure reuses ONE code object (the kernel cache is keyed by the source).
 Captured ints stay literals (they are structure more often than data: `range(n)`, `x[:n]`, `** n`); a closure that branches on a
@@ -580,46 +581,62 @@ def _as_table(v, t):
 
 
 class _UserdataView:
-    """config.userdata (a struct of parameters: test/bubble.jl:12-27 `para`) during a trace: attribute reads hand arrays out as _Tables"""
+    """config.userdata (a struct of parameters: test/bubble.jl:12-27 `para`) during a trace: attribute reads hand arrays out as _Tables
+    and floats as PARAMETERS of the trace (module docstring: one body for every value of beta, kF, ...)"""
 
-    def __init__(self, obj, t):
+    def __init__(self, obj, t, floats):
         object.__setattr__(self, "_obj", obj)
         object.__setattr__(self, "_t", t)
+        object.__setattr__(self, "_floats", floats)
         object.__setattr__(self, "_seen", {})
 
-    def __getattr__(self, name):
+    def _view(self, key, get):
         seen = object.__getattribute__(self, "_seen")
-        if name not in seen:
-            seen[name] = _userdata_view(getattr(object.__getattribute__(self, "_obj"), name), object.__getattribute__(self, "_t"))
-        return seen[name]
+        if key not in seen:
+            seen[key] = _userdata_view(get(object.__getattribute__(self, "_obj")), object.__getattribute__(self, "_t"),
+                                       object.__getattribute__(self, "_floats"))
+        return seen[key]
+
+    def __getattr__(self, name):
+        return self._view(name, lambda o: getattr(o, name))
 
     def __getitem__(self, k):
-        seen = object.__getattribute__(self, "_seen")
-        if ("item", k) not in seen:
-            seen[("item", k)] = _userdata_view(object.__getattribute__(self, "_obj")[k], object.__getattribute__(self, "_t"))
-        return seen[("item", k)]
+        return self._view(("item", k), lambda o: o[k])
 
     def __setattr__(self, name, v):
         raise TraceError("the closure writes to config.userdata (hidden state)")
 
 
-def _userdata_view(v, t):
+def _param_table(v, t):
+    """a float array of up to 64 elements as parameters of the trace (one ud slot each) that is also a table for a sampled index"""
+    v = np.asarray(v, dtype=np.float64)
+    a = np.empty(v.shape, dtype=object)
+    for i in np.ndindex(v.shape):
+        a[i] = t.param(v[i])
+    return _Table(a, t, values=v)
+
+
+def _userdata_view(v, t, floats=False):
+    if floats and isinstance(v, (float, np.floating)) and not isinstance(v, bool) and math.isfinite(v):
+        return t.param(v)
     tb = _as_table(v, t)
     if tb is not None:
+        if floats and tb._values.size <= 64 and (not isinstance(v, np.ndarray) or v.dtype.kind == "f") and np.all(np.isfinite(tb._values)):
+            return _param_table(tb._values, t)
         return tb
     if isinstance(v, (str, bytes, int, float, complex, bool, type(None), np.generic, np.ndarray, list, tuple, types.FunctionType,
                       types.BuiltinFunctionType, types.MethodType, types.ModuleType, type)):
         return v
     if isinstance(v, dict) or hasattr(v, "__dict__") or hasattr(v, "__slots__"):
-        return _UserdataView(v, t)
+        return _UserdataView(v, t, floats)
     return v
 
 
-def _trace_config(config, t):
+def _trace_config(config, t, floats=False):
     """the Configuration a traced closure is called with: the user's, with `userdata` seen through _userdata_view"""
     import copy
     ud = getattr(config, "userdata", None)
-    view = _userdata_view(ud, t)
+    view = _userdata_view(ud, t, floats)
     if view is ud:
         return config
     c = copy.copy(config)
@@ -774,11 +791,8 @@ def _parametrized(fn, t, floats=True):
         if floats and isinstance(v, (float, np.floating)) and not isinstance(v, bool) and math.isfinite(v):
             return t.param(v)
         if floats and isinstance(v, np.ndarray) and not isinstance(v, _Table) and v.dtype.kind == "f" and 0 < v.size <= 64 and np.all(np.isfinite(v)):
-            a = np.empty(v.shape, dtype=object)
-            for i in np.ndindex(v.shape):
-                a[i] = t.param(v[i])
             changed[0] = True
-            return _Table(a, t, values=v)                  # (its elements are parameters; indexed with a sampled value it is a table)
+            return _param_table(v, t)                      # (its elements are parameters; indexed with a sampled value it is a table)
         if isinstance(v, np.ndarray) and not isinstance(v, _Table):
             tb = _as_table(v, t)
             if tb is not None:
@@ -972,7 +986,7 @@ def _trace_integrand(fn, config, indexed, check_points, name, parameters, inplac
     N = config.N
     nc = getattr(config, "ncomp", 1)
     sfn = _parametrized(fn, t, floats=parameters)          # (captured arrays can be indexed with a sampled value either way: _Table)
-    tconfig = _trace_config(config, t)
+    tconfig = _trace_config(config, t, floats=parameters)
     def run():
         outs = _call_form(sfn, arg, tconfig, N, indexed, inplace, lambda: _Weights(N))
         if len(outs) != N:

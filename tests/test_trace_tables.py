@@ -80,9 +80,13 @@ def test_rows_of_a_struct_of_parameters(oracle):
         return (np.dot(kq, kq) - p.kF ** 2) / (2 * p.me) + q[1]
     cfg = mci.Configuration(var=(mci.Continuous(-1.0, 1.0), mci.Discrete(1, 5)), dof=[[3, 1]], userdata=para)
     I = trace_integrand(f, cfg)
-    assert "3 * (int)fmin(fmax(" in I.body and len(I.userdata) == 15
+    # the struct's floats are parameters (kF^2 and 2 me: one ud slot each), the table of momenta follows them: 2 + 5 x 3 values
+    assert "3 * (int)fmin(fmax(" in I.body and len(I.userdata) == 17 and list(I.userdata[:2]) == [1.2 ** 2, 1.0]
     for x, w in _check_body(oracle, I, f, cfg, -np.ones(4), np.ones(4), {3: (1, 5)}):
         assert w[0] == pytest.approx(f((x[:3], np.array([int(x[3])])), cfg), rel=1e-13)
+    para2 = types.SimpleNamespace(kF=0.7, me=0.25, extQ=[np.array([0.3 * i, 0.0, 0.1]) for i in range(5)])          # another point of a sweep: the same body
+    I2 = trace_integrand(f, mci.Configuration(var=(mci.Continuous(-1.0, 1.0), mci.Discrete(1, 5)), dof=[[3, 1]], userdata=para2))
+    assert I2.body == I.body and list(I2.userdata[:2]) == [0.7 ** 2, 0.5]
     # a dict of parameters, a two-dimensional array indexed [draw, column]
     dcfg = mci.Configuration(var=(mci.Continuous(-1.0, 1.0), mci.Discrete(1, 5)), dof=[[1, 1]], userdata={"extQ": np.array(para.extQ), "s": 2.0})
     g = lambda v, c: c.userdata["extQ"][v[1][0] - 1, 1] * v[0][0] * c.userdata["s"]

@@ -890,6 +890,35 @@ def _domain_points(config, ndraw, n, rng):
 MAX_WAYS = 256   # ways through a closure's Python branches that are written out (a loop whose trip count depends on a draw has no bound)
 
 
+_COSTLY = ("/", "pow", "atan2") + _FUNCS      # operations worth a select per operand to be evaluated once instead of once per way
+
+
+def _join(cond, a, b):
+    """where(cond, a, b) for the values of two ways through a closure's branches, with the select pushed DOWN through what the two ways
+    share: `c ? f(u, k) : f(v, k)` is written `f(c ? u : v, k)` -- the same number, bit for bit (f is pure and is applied to the selected
+    operand), but the common operation is evaluated once.  `omega > 0 ? exp(-omega tau) / (1 + exp(-omega beta)) : exp(omega (beta -
+    tau)) / (1 + exp(omega beta))` (test/bubble.jl:40-51) becomes two exponentials of selected arguments instead of four, which is what a
+    hand-written body computes per lane; a product of a way-dependent factor with common ones keeps its common multiplications."""
+    if isinstance(a, (CSym, complex, np.complexfloating)) or isinstance(b, (CSym, complex, np.complexfloating)):
+        a, b = CSym.of(a), CSym.of(b)
+        return CSym(_join(cond, a.re, b.re), _join(cond, a.im, b.im))
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return np.frompyfunc(lambda p, q: _join(cond, p, q), 2, 1)(_boxed(a), _boxed(b))
+    if a is b:
+        return a
+    if (isinstance(a, Sym) and isinstance(b, Sym) and a.op == b.op and len(a.args) == len(b.args)
+            and a.op not in ("x", "rw", "ud", "const") and a.op not in _BOOL):
+        diff = [i for i, (p, q) in enumerate(zip(a.args, b.args)) if p is not q and not (not isinstance(p, Sym) and not isinstance(q, Sym) and p == q)]
+        sinkable = all(isinstance(a.args[i], Sym) and isinstance(b.args[i], Sym) and a.args[i].op not in _BOOL and b.args[i].op not in _BOOL
+                       for i in diff)
+        if diff and sinkable and (len(diff) == 1 or a.op in _COSTLY):
+            args = list(a.args)
+            for i in diff:
+                args[i] = _join(cond, a.args[i], b.args[i])
+            return a.t.node(a.op, *args)
+    return where(cond, a, b)
+
+
 def explore(t, run):
     """run() -> list of values, calling the closure on trace t's symbols; the closure may branch on sampled values.  Every way through
     its branches is run once (the k-th truth test of a run comes out as the script says, True beyond it) and the ways are joined into
@@ -910,7 +939,7 @@ def explore(t, run):
             if len(other) != len(vals):
                 raise TraceError("the closure returns %d values on one way through its branches and %d on another" % (len(vals), len(other)))
             same = lambda a, b: a is b or (not isinstance(a, (Sym, CSym, np.ndarray)) and not isinstance(b, (Sym, CSym, np.ndarray)) and a == b)
-            vals = [a if same(a, b) else where(conds[i], a, b) for a, b in zip(vals, other)]
+            vals = [a if same(a, b) else _join(conds[i], a, b) for a, b in zip(vals, other)]
         return vals
     try:
         return way([])

@@ -412,3 +412,28 @@ def test_random_closures_with_python_control_flow_trace_to_what_they_compute(ora
             fn(x.ctypes.data_as(dp), w.ctypes.data_as(dp), I.userdata.ctypes.data_as(dp) if len(I.userdata) else None)
             assert w[0] == pytest.approx(float(f(x, config)), rel=1e-13, abs=1e-300), (case, x, I.body)
     assert traced >= 35 and selects >= 40, (traced, selects)
+
+
+def test_ways_through_a_branch_share_what_they_have_in_common(oracle):
+    """trace._join: `c ? f(u, k) : f(v, k)` is written `f(c ? u : v, k)` -- the reference's Green's function (test/bubble.jl:40-51), four ways
+    with two exponentials each, comes out with three exponentials of selected arguments (the denominator is common to the signs of tau)
+    where joining the ways at the result would evaluate eight; same numbers as the closure to the last bit of the division."""
+    beta = 6.5
+
+    def green(tau, omega, beta):
+        if tau >= 0.0:
+            return np.exp(-omega * tau) / (1 + np.exp(-omega * beta)) if omega > 0.0 else np.exp(omega * (beta - tau)) / (1 + np.exp(omega * beta))
+        return -np.exp(-omega * (tau + beta)) / (1 + np.exp(-omega * beta)) if omega > 0.0 else -np.exp(-omega * tau) / (1 + np.exp(omega * beta))
+    f = lambda x, c: green(x[0], x[1], beta) * x[2] * 3.0
+    cfg = mci.Configuration(var=mci.Continuous(-2.0, 2.0), dof=[[3]])
+    I = trace_integrand(f, cfg)
+    assert I.body.count("exp(") == 3 and I.body.count(" / ") == 1, I.body
+    assert I.body.count("* x[2]") == 1                                   # the common factors once, behind the selects
+    fn = _c_function(oracle, I.body)
+    rng = np.random.default_rng(8)
+    ud = np.ascontiguousarray(I.userdata, dtype=np.float64)
+    for _ in range(300):
+        x = rng.uniform(-2.0, 2.0, 3)
+        w = np.zeros(1)
+        fn(x.ctypes.data_as(C.POINTER(C.c_double)), w.ctypes.data_as(C.POINTER(C.c_double)), ud.ctypes.data_as(C.POINTER(C.c_double)))
+        assert w[0] == pytest.approx(float(f(x, cfg)), rel=2e-15)

@@ -83,6 +83,26 @@ def test_documentation_examples():
     assert res.stdev[0] < res0.stdev[0]
 
 
+def test_benchmark_scripts():
+    """example/benchmark/vegas: benchmark1.jl:28-30 (the do-block calling a function of the pool), benchmark3.jl:31-58 (three integrands
+    RETURNED AS A LIST, a loop over the first four draws; Cuba's numbers at :17-19 -- "MCIntegration currently fails" there at neval = 1e4,
+    this runs it at 1e5 per iteration)"""
+    def f(x):
+        return 1.0 / (1.0 - np.cos(x[0]) * np.cos(x[1]) * np.cos(x[2])) / PI ** 3
+    check(integrate(lambda var, config: f(var), neval=200000, var=(Continuous(0.0, PI, alpha=3.0, adapt=True),), dof=[[3]], solver="vegas", seed=13), [1.3932], ratio=5.0)
+
+    def f3(x, c):
+        dx2 = 0.0
+        for d in range(4):
+            dx2 += (x[d] - 0.5) ** 2
+        f = np.exp(-200 * dx2) * 1000.0
+        return [f, f * x[0], f * x[0] ** 2]
+    g = 1000.0 * (PI / 200.0) ** 2 * math.erf(math.sqrt(200.0) / 2) ** 4
+    res = check(integrate(f3, neval=100000, dof=[[4], [4], [4]], verbose=-1, solver="vegas", seed=14), [g, g / 2, g * (0.25 + 1.0 / 400.0)], ratio=5.0)
+    cuba = [0.24681600683822702, 0.12341321349438042, 0.06232499578312799]
+    assert np.all(np.abs(flat(res.mean) - cuba) < 5.0 * np.hypot(flat(res.stdev), [0.0003, 0.00014, 7.4e-5]))
+
+
 @pytest.mark.parametrize("solver", ["vegasmc", "vegas", "mcmc"])
 def test_measure_histogram_example(solver):
     """docs/src/index.md "Measure Histogram": the radius looked up in config.userdata by the Discrete draw, `obs[i][bin] += weights[i]`.

@@ -28,6 +28,8 @@ off `config.userdata` (a number, an attribute of a struct of parameters, a dict 
 are traced as PARAMETERS, not as literals: every maximal subexpression that depends on parameters
 and constants only is evaluated on the host and handed to the kernel in a `ud[k]` slot (Integrand.userdata), so the written-out body is
 the same text for every value and a parameter sweep over a closure reuses ONE code object (the kernel cache is keyed by the source).
+The helper functions the closure reaches (Python functions in its cells, functions of its own module that its code names) are treated
+the same way, so a table or a temperature captured by `green(tau, omega, beta)` next to the integrand is a parameter too.
 Captured ints stay literals (they are structure more often than data: `range(n)`, `x[:n]`, `** n`); a closure that branches on a
 captured float is traced again with its captured values as literals."""
 import math
@@ -781,11 +783,17 @@ def evaluate(outs, X, R=None, params=(), tables=()):
     return [np.broadcast_to(np.asarray(val[o.id], dtype=np.float64), X.shape[1:]) for o in outs]
 
 
-def _parametrized(fn, t, floats=True):
-    """A copy of the closure whose captured floats are parameters of trace `t` (module docstring); the closure itself if it has none
-    or is not a plain Python function."""
+def _parametrized(fn, t, floats=True, _memo=None, _depth=0):
+    """A copy of the closure whose captured floats are parameters of trace `t` and whose captured arrays are tables (module
+    docstring); the closure itself if it has neither or is not a plain Python function.  The helper functions it reaches -- Python
+    functions in its cells, functions of its own module that its code names (`green(tau, omega, beta)` next to the integrand,
+    test/bubble.jl:40-51) -- are copied the same way (up to 16 levels of helpers calling helpers)."""
     if not isinstance(fn, types.FunctionType):
         return fn
+    memo = {} if _memo is None else _memo
+    if id(fn) in memo:
+        return memo[id(fn)]
+    memo[id(fn)] = fn                                      # (a function that reaches itself keeps the original there)
 
     def conv(v):
         if floats and isinstance(v, (float, np.floating)) and not isinstance(v, bool) and math.isfinite(v):
@@ -798,6 +806,11 @@ def _parametrized(fn, t, floats=True):
             if tb is not None:
                 changed[0] = True
                 return tb
+        if isinstance(v, types.FunctionType) and _depth < 16:
+            new = _parametrized(v, t, floats, memo, _depth + 1)
+            if new is not v:
+                changed[0] = True
+            return new
         return v
     changed = [False]
     n0 = len(t.params)
@@ -811,7 +824,9 @@ def _parametrized(fn, t, floats=True):
                 cells.append(c)
         cells = tuple(cells)
     g = fn.__globals__
-    names = [n for n in fn.__code__.co_names if n in g and isinstance(g[n], (float, np.floating, np.ndarray)) and not isinstance(g[n], bool)]
+    names = [n for n in fn.__code__.co_names if n in g and not isinstance(g[n], bool) and
+             (isinstance(g[n], (float, np.floating, np.ndarray)) or
+              (isinstance(g[n], types.FunctionType) and g[n].__module__ == fn.__module__ and g[n] is not fn))]
     if names:
         g = dict(g)
         for n in names:
@@ -821,6 +836,7 @@ def _parametrized(fn, t, floats=True):
         return fn
     new = types.FunctionType(fn.__code__, g, fn.__name__, defaults, cells)
     new.__kwdefaults__ = fn.__kwdefaults__
+    memo[id(fn)] = new
     return new
 
 

@@ -134,8 +134,7 @@ def test_integrate_hands_the_engine_the_inplace_closure_in_its_form():
         mci.HostIntegrand(lambda a, b, c: 0.0, indexed=True, inplace=True)
 
 
-def _c_function(oracle, body):
-    return C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))(oracle.compile_c_integrand(body))
+from test_trace import _c_function      # (an Integrand or body text through gcc; the Integrand's userdata is passed unless another is given)
 
 
 def test_traced_inplace_bodies_compute_what_the_reference_closures_store(oracle):
@@ -145,7 +144,7 @@ def test_traced_inplace_bodies_compute_what_the_reference_closures_store(oracle)
     cfg = mci.Configuration(dof=[[1], [1]], type=complex)
     I = trace_integrand(complex2_inplace, cfg, inplace=True)
     assert [ln.strip() for ln in I.body.splitlines()][-4:] == ["w[0] = x[0];", "w[1] = 0.0;", "w[2] = 0.0;", "w[3] = t1;"]
-    fn = _c_function(oracle, I.body)
+    fn = _c_function(oracle, I)
     rng = np.random.default_rng(3)
     for _ in range(50):
         x = rng.uniform(0.0, 1.0, 1)
@@ -156,7 +155,7 @@ def test_traced_inplace_bodies_compute_what_the_reference_closures_store(oracle)
         np.testing.assert_allclose(w, [z[0].real, z[0].imag, z[1].real, z[1].imag], rtol=1e-15)
     cfg = hypersphere_config(3)
     I = trace_integrand(hypersphere_inplace, cfg, inplace=True)
-    fn = _c_function(oracle, I.body)
+    fn = _c_function(oracle, I)
     inside = np.zeros(3)
     for _ in range(400):
         x = rng.uniform(-1.0, 1.0, 4) * 0.75
@@ -196,7 +195,7 @@ def test_complex_weights_trace_in_every_form(oracle):
     for name, (f, kw) in forms.items():
         I = trace_integrand(f, cfg, **kw)
         bodies.add(I.body)
-        fn = _c_function(oracle, I.body)
+        fn = _c_function(oracle, I)
         for _ in range(50):
             x = np.array([rng.uniform(0.0, 1.0), float(rng.integers(1, 4))])
             w = np.zeros(4)
@@ -340,9 +339,10 @@ def test_closures_with_python_branches_run_on_both_paths(oracle):
     numpy refuses the truth value of a batch, so the trampoline calls such a closure sample by sample."""
     from mcintegration_jl_amd.engine import Engine
     cfg = hypersphere_config(3)
-    a, b = trace_integrand(hypersphere_ternary, cfg, inplace=True).body, trace_integrand(hypersphere_inplace, cfg, inplace=True).body
+    Ia, Ib = trace_integrand(hypersphere_ternary, cfg, inplace=True), trace_integrand(hypersphere_inplace, cfg, inplace=True)
+    a, b = Ia.body, Ib.body
     assert a.count("?") == b.count("?") == 3                                # three selects either way ...
-    fa, fb = _c_function(oracle, a), _c_function(oracle, b)
+    fa, fb = _c_function(oracle, Ia), _c_function(oracle, Ib)
     dpp = C.POINTER(C.c_double)
     prng = np.random.default_rng(4)
     for _ in range(200):                                                    # ... computing the same weights

@@ -51,8 +51,14 @@ CASES = [
 ]
 
 
-def _c_function(oracle, body):
-    fn = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))(oracle.compile_c_integrand(body))
+def _c_function(oracle, integrand):
+    """the written-out body (an Integrand, or body text) compiled with gcc: fn(x*, w*, ud* = the Integrand's own userdata)"""
+    dp = C.POINTER(C.c_double)
+    raw = C.CFUNCTYPE(None, dp, dp, dp)(oracle.compile_c_integrand(getattr(integrand, "body", integrand)))
+    ud = np.ascontiguousarray(getattr(integrand, "userdata", ()), dtype=np.float64)
+
+    def fn(xp, wp, udp=None):
+        raw(xp, wp, udp if udp is not None else ud.ctypes.data_as(dp) if len(ud) else None)
     return fn
 
 
@@ -62,7 +68,7 @@ def test_traced_body_computes_what_the_closure_computes(oracle, name, cfg, f):
     config = cfg()
     I = trace_integrand(f, config)
     assert isinstance(I, mci.Integrand) and "w[%d] =" % (config.N - 1) in I.body
-    fn = _c_function(oracle, I.body)
+    fn = _c_function(oracle, I)
     pools, ndraw = _pools(config)
     rng = np.random.default_rng(5)
     X = _domain_points(config, ndraw, 200, rng)
@@ -128,7 +134,7 @@ def test_captured_floats_become_userdata_slots_and_a_sweep_reuses_one_body(oracl
         bodies.append(I.body)
         uds.append(np.array(I.userdata))
         assert "1.5" not in I.body and "ud[" in I.body
-        fn = _c_function(oracle, I.body)
+        fn = _c_function(oracle, I)
         rng = np.random.default_rng(1)
         for _ in range(50):
             x = rng.uniform(0.0, 1.0, 2)
@@ -338,7 +344,7 @@ def test_random_closures_trace_to_what_they_compute(oracle, seed):
     e0, e1 = _random_expression(rng, 5), _random_expression(rng, 4)
     f = lambda x, c: (e0(x), e1(x))
     I = trace_integrand(f, config)
-    fn = _c_function(oracle, I.body)
+    fn = _c_function(oracle, I)
     X = rng.uniform(-1.0, 2.0, size=(3, 100))
     for p in range(100):
         x = np.ascontiguousarray(X[:, p])
@@ -405,7 +411,7 @@ def test_random_closures_with_python_control_flow_trace_to_what_they_compute(ora
             continue
         traced += 1
         selects += I.body.count("?")
-        fn = _c_function(oracle, I.body)
+        fn = _c_function(oracle, I)
         for _ in range(60):
             x = rng.uniform(-1.0, 1.0, 4)
             w = np.zeros(1)
@@ -429,7 +435,7 @@ def test_ways_through_a_branch_share_what_they_have_in_common(oracle):
     I = trace_integrand(f, cfg)
     assert I.body.count("exp(") == 3 and I.body.count(" / ") == 1, I.body
     assert I.body.count("* x[2]") == 1                                   # the common factors once, behind the selects
-    fn = _c_function(oracle, I.body)
+    fn = _c_function(oracle, I)
     rng = np.random.default_rng(8)
     ud = np.ascontiguousarray(I.userdata, dtype=np.float64)
     for _ in range(300):

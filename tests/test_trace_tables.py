@@ -40,7 +40,7 @@ def histogram_config(userdata=GRID):
 
 
 def _check_body(oracle, I, f, cfg, lo, hi, discrete, n=200, seed=0):
-    fn = _c_function(oracle, I.body)
+    fn = _c_function(oracle, I)
     rng = np.random.default_rng(seed)
     ud = np.ascontiguousarray(I.userdata, dtype=np.float64)
     for _ in range(n):
@@ -194,3 +194,75 @@ def test_host_closures_get_integer_discrete_draws_and_accumulating_observables()
     mcb = Engine._make_host_measure_callback(_engine_like(cfg1), per_record)
     assert mcb(X.ctypes.data_as(dp), R.ctypes.data_as(dp), n, n, 3, 2, 0, O.ctypes.data_as(dp), 3, None) == 0
     np.testing.assert_allclose(O, [R[0].sum(), R[1][X[2] <= 10].sum(), R[1][X[2] > 10].sum()], rtol=1e-13)
+
+
+def test_random_closures_with_tables_inside_branches(oracle):
+    """table lookups by a Discrete draw inside nested Python branches (the select is pushed down into the index where two ways look
+    the same table up, trace._join): 30 random closures over two Continuous and two Discrete draws, written-out body through gcc against
+    the closure on plain numbers"""
+    rng = np.random.default_rng(77)
+    small, large = rng.uniform(-1.0, 1.0, 6), rng.uniform(-1.0, 1.0, 90)
+    rows = rng.uniform(-1.0, 1.0, (6, 2))
+    cfg = mci.Configuration(var=(mci.Continuous(-1.0, 1.0), mci.Discrete(1, 6)), dof=[[2, 2]])
+
+    def make():
+        budget = [5]
+
+        def value(depth):
+            kind = rng.integers(0, 8 if depth < 3 and budget[0] > 0 else 5)
+            if kind == 0:
+                i = int(rng.integers(0, 2))
+                return lambda x, d: x[i]
+            if kind == 1:
+                v = float(rng.uniform(-2.0, 2.0))
+                return lambda x, d: v
+            if kind == 2:
+                j = int(rng.integers(0, 2))
+                return (lambda x, d: small[d[j] - 1]) if rng.random() < 0.5 else (lambda x, d: large[d[j] * 15 - 15 + d[1 - j]])
+            if kind == 3:
+                j, k = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+                return lambda x, d: rows[d[j] - 1][k] * x[k]
+            if kind == 4:
+                a, b = value(depth + 1), value(depth + 1)
+                op = int(rng.integers(0, 3))
+                return (lambda x, d: a(x, d) + b(x, d)) if op == 0 else (lambda x, d: a(x, d) * b(x, d)) if op == 1 else (lambda x, d: np.exp(a(x, d)) - 0.5 * b(x, d))
+            budget[0] -= 1
+            c, a, b = cond(depth + 1), value(depth + 1), value(depth + 1)
+            if kind == 5:
+                return lambda x, d: a(x, d) if c(x, d) else b(x, d)
+            if kind == 6:
+                j = int(rng.integers(0, 2))
+                return lambda x, d: small[d[j] - 1] * a(x, d) if c(x, d) else small[d[1 - j] - 1] * a(x, d)      # the same table, the index differs by the way
+            return lambda x, d: np.exp(a(x, d)) if c(x, d) else np.exp(b(x, d))
+
+        def cond(depth):
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                a, b = value(depth + 1), value(depth + 1)
+                return lambda x, d: a(x, d) < b(x, d)
+            if kind == 1:
+                j, v = int(rng.integers(0, 2)), int(rng.integers(1, 7))
+                return lambda x, d: d[j] == v
+            j = int(rng.integers(0, 2))
+            return lambda x, d: d[j] > d[1 - j]
+        body = value(0)
+        return lambda v, c: body(v[0], v[1])
+    traced = lookups = 0
+    for case in range(30):
+        f = make()
+        try:
+            I = trace_integrand(f, cfg)
+        except TraceError as e:
+            assert "ways through" in str(e), (case, e)
+            continue
+        traced += 1
+        lookups += I.body.count("(int)fmin(")
+        fn = _c_function(oracle, I)
+        ud = np.ascontiguousarray(I.userdata, dtype=np.float64)
+        for _ in range(40):
+            x = np.concatenate([rng.uniform(-1.0, 1.0, 2), rng.integers(1, 7, 2).astype(float)])
+            w = np.zeros(1)
+            fn(x.ctypes.data_as(dp), w.ctypes.data_as(dp), ud.ctypes.data_as(dp) if len(ud) else None)
+            ref = float(f((x[:2], x[2:].astype(np.int64)), cfg))
+            assert w[0] == pytest.approx(ref, rel=1e-13, abs=1e-300), (case, x, I.body)
+    assert traced >= 25 and lookups >= 20, (traced, lookups)

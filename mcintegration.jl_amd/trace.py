@@ -45,7 +45,7 @@ class TraceError(Exception):
 
 
 _FUNCS = ("exp", "log", "sqrt", "sin", "cos", "tan", "tanh", "sinh", "cosh", "arcsin", "arccos", "arctan", "log1p", "expm1", "log10",
-          "log2", "exp2", "cbrt", "floor", "ceil", "erf", "erfc")
+          "log2", "exp2", "cbrt", "floor", "ceil", "erf", "erfc", "rint", "trunc")
 _CNAME = {"arcsin": "asin", "arccos": "acos", "arctan": "atan"}
 _NPFN = {"erf": math.erf, "erfc": math.erfc}
 
@@ -179,6 +179,36 @@ class Sym:
         if isinstance(b, np.ndarray):
             return NotImplemented
         return self.t.node("pow", self.t.lift(b), self)
+
+    # Python's (and Julia's `mod` / `fld`) floored division: the remainder has the sign of the divisor.  C's fmod has the sign of the
+    # dividend, so the written-out body corrects it where the two differ
+    def __mod__(self, o):
+        if isinstance(o, np.ndarray):
+            return NotImplemented
+        return _pymod(self, o)
+
+    def __rmod__(self, o):
+        if isinstance(o, np.ndarray):
+            return NotImplemented
+        return _pymod(o, self)
+
+    def __floordiv__(self, o):
+        if isinstance(o, np.ndarray):
+            return NotImplemented
+        return (self / o).floor()
+
+    def __rfloordiv__(self, o):
+        if isinstance(o, np.ndarray):
+            return NotImplemented
+        return (o / self).floor()
+
+    def __round__(self, ndigits=None):
+        if ndigits not in (None, 0):
+            raise TraceError("round(x, ndigits) of a sampled value")
+        return self.rint()                                 # (half to even, like Python's round and numpy's rint)
+
+    def round(self, decimals=0, out=None):                 # np.round(x) on an object calls x.round()
+        return self.__round__(decimals)
 
     # -- numpy on a symbol: np.maximum(x[0], 0.5), np.where(x[0] > 0.5, a, b), np.clip(...), and ndarray <op> symbol
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
@@ -412,6 +442,13 @@ def _ufunc(ufunc, *a):
     if n == "hypot":
         x, y = t.lift(a[0]), t.lift(a[1])
         return (x * x + y * y).sqrt()
+    if n in ("remainder", "mod"):
+        return _pymod(a[0], a[1])
+    if n == "fmod":
+        x, y = t.lift(a[0]), t.lift(a[1])
+        return t.node("fmod", x, y)
+    if n == "floor_divide":
+        return (t.lift(a[0]) / a[1]).floor()
     if n == "negative":
         return -a[0]
     if n == "positive":
@@ -425,6 +462,17 @@ def _ufunc(ufunc, *a):
     if len(a) == 1 and hasattr(Sym, n):
         return getattr(a[0], n)()
     raise TraceError("np.%s is not written out" % n)
+
+
+def _pymod(a, b):
+    """a % b with Python's sign convention, of traced values"""
+    t, a, b = _lift2(a, b)
+    r = t.node("fmod", a, b)
+    if b.op == "const":                                     # (the usual case, x % 1.0: one select)
+        fix = (r < 0.0) if b.args[0] > 0.0 else (r > 0.0)
+    else:
+        fix = (r * b) < 0.0
+    return where(fix, r + b, r)
 
 
 def _lift2(a, b):
@@ -773,6 +821,8 @@ def evaluate(outs, X, R=None, params=(), tables=()):
                 v = np.power(np.asarray(a[0], dtype=f64), a[1])
             elif n.op == "atan2":
                 v = np.arctan2(a[0], a[1])
+            elif n.op == "fmod":
+                v = np.fmod(np.asarray(a[0], dtype=f64), a[1])
             elif n.op in ("fmax", "fmin", "fabs"):
                 v = getattr(np, n.op)(*a)
             elif n.op in _NPFN:
@@ -906,7 +956,7 @@ def _domain_points(config, ndraw, n, rng):
 MAX_WAYS = 256   # ways through a closure's Python branches that are written out (a loop whose trip count depends on a draw has no bound)
 
 
-_COSTLY = ("/", "pow", "atan2") + _FUNCS      # operations worth a select per operand to be evaluated once instead of once per way
+_COSTLY = ("/", "pow", "atan2", "fmod") + _FUNCS      # operations worth a select per operand to be evaluated once instead of once per way
 
 
 def _join(cond, a, b):

@@ -153,3 +153,15 @@ def test_random_closures_with_python_control_flow_run_the_same_in_the_kernels_an
         np.testing.assert_allclose(a.iter_std, b.iter_std, rtol=1e-7, atol=1e-12)
         done += 1
     assert done >= 4, done
+
+
+def test_modulo_floor_division_and_rounding_of_draws():
+    """Julia's mod / fld / round on a draw (`%`, `//`, np.round here): written out as fmod with Python's sign convention, floor(a / b),
+    rint -- int_0^1 (x mod 0.3 + fld(x, 0.25) + round(4 x)) dx = 0.14 + 1.5 + 2, and the same closure on the host path"""
+    f = lambda x, c: x[0] % 0.3 + x[0] // 0.25 + np.round(x[0] * 4)
+    kw = dict(solver="vegas", neval=1e5, seed=7, print=-1)
+    a = mci.integrate(f, **kw)
+    assert isinstance(a.config._engine.integrand, mci.Integrand) and "fmod(" in a.config._engine.integrand.body
+    assert abs(a.mean[0] - 3.64) < 5 * a.stdev[0] and a.stdev[0] < 2e-3
+    b = mci.integrate(f, trace=False, **kw)
+    np.testing.assert_allclose(a.iter_mean, b.iter_mean, rtol=1e-9)

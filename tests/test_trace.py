@@ -46,6 +46,9 @@ CASES = [
     ("python_branches_on_draws", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[3], [3]]),
      lambda x, c: (1.0 if x[0] ** 2 + x[1] ** 2 < 1.0 else 0.0,                                   # the reference's Sphere ternary (test/montecarlo.jl:19-32)
                    (x[0] if x[1] > 0.5 and x[2] > 0.25 else x[1] * 2.0 if x[0] > 0.5 or x[2] < 0.1 else np.maximum(x, 0.5).sum()))),
+    ("modulo_floor_division_rounding", lambda: mci.Configuration(var=mci.Continuous(-2.0, 2.0), dof=[[2], [2]]),        # Julia's mod / fld / round / trunc
+     lambda x, c: (x[0] % 0.3 + x[0] % -0.7 + 0.9 % (x[1] + 2.5) + x[0] % (x[1] + 0.1) + np.mod(x[1], 0.4) + np.fmod(x[0], 0.6) + np.remainder(x[1], x[0] + 3.0),
+                   x[0] // 0.25 + 1.0 // (x[1] + 2.5) + np.floor_divide(x[1], 0.3) + np.round(x[0] * 4) + round(x[1] * 3) + np.rint(x[0] * 7) + np.trunc(x[1] * 5))),
     ("constant_and_shared_subexpressions", lambda: mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [2]]),
      lambda x, c: (1.5, np.exp(x[0] * x[1]) + np.exp(x[0] * x[1]) ** 2)),
 ]

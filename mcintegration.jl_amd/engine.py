@@ -82,6 +82,15 @@ class _HostObs(np.ndarray):
         np.ndarray.__setitem__(self, i, v)
 
 
+def _slow_path_warning(what, unit, err):
+    """said once per callback: a host closure that cannot take a batch is called per %(unit)s by the interpreter -- orders of magnitude
+    below the traced path (integrate(..., trace=True) says why a closure was not traced)"""
+    import warnings
+    warnings.warn("the host %s closure raised on a batch of %ss (%s: %s) and is now called %s by %s: correct, but slow -- write it for "
+                  "arrays, or make it traceable (integrate(..., trace=True) names what stops the tracer)"
+                  % (what, unit, type(err).__name__, str(err)[:80], unit, unit), RuntimeWarning, stacklevel=2)
+
+
 def _store_obs(O, obs, obs_nbin, nc):
     off = 0
     for o, nb in zip(obs, obs_nbin):
@@ -247,12 +256,13 @@ class Engine:
                     try:
                         batch(X, W, n)
                         return 0
-                    except (ValueError, TypeError, IndexError):
+                    except (ValueError, TypeError, IndexError) as e:
                         # a closure written per sample like the reference's: a Python branch on a draw ("The truth value of an array
                         # with more than one element is ambiguous"), a list indexed with a Discrete draw ("only integer scalar arrays
                         # can be converted to a scalar index"), ...: sample by sample from here on (an error of its own comes again)
                         if n <= 1:
                             raise
+                        _slow_path_warning("integrand", "sample", e)
                         state["per_sample"] = True
                 per_sample(X, W, n)
                 return 0
@@ -282,9 +292,10 @@ class Engine:
                     if not state["per_sample"]:
                         try:
                             o = fn(int(i), self._pool_views(Xs, len(sel)), config)
-                        except (ValueError, TypeError, IndexError):   # a closure written per sample: sample by sample (see _make_host_callback)
+                        except (ValueError, TypeError, IndexError) as e:   # a closure written per sample: sample by sample (see _make_host_callback)
                             if len(sel) <= 1:
                                 raise
+                            _slow_path_warning("integrand", "sample", e)
                             state["per_sample"] = True
                     if o is None:
                         o = np.array([fn(int(i), self._pool_views(np.ascontiguousarray(Xs[:, j:j + 1]), 1, scalar=True), config) for j in range(len(sel))])
@@ -348,9 +359,10 @@ class Engine:
                     obs = [_HostObs(ln, dt) for ln in config.obs_len]
                     try:
                         fn(self._pool_views(X, n), obs, weights, config)
-                    except (ValueError, TypeError, IndexError):
+                    except (ValueError, TypeError, IndexError) as e:
                         if n <= 1:
                             raise
+                        _slow_path_warning("measure", "record", e)
                         state["per_record"], obs = True, None
                 if obs is None:
                     obs = [np.zeros(ln, dtype=dt) for ln in config.obs_len]
@@ -394,9 +406,10 @@ class Engine:
                         try:
                             fn(int(i), self._pool_views(Xs, len(sel)), obs, ws, config)
                             continue
-                        except (ValueError, TypeError, IndexError):
+                        except (ValueError, TypeError, IndexError) as e:
                             if len(sel) <= 1:
                                 raise
+                            _slow_path_warning("measure", "record", e)
                             state["per_record"] = True
                             for o, q in zip(obs, before):
                                 np.ndarray.__setitem__(o, slice(None), q)

@@ -365,8 +365,12 @@ def test_closures_with_python_branches_run_on_both_paths(oracle):
     cb = Engine._make_host_callback(_engine_like(cfg), counted, True)
     X = np.ascontiguousarray(rng.uniform(-0.8, 0.8, (4, n)))
     W = np.full((3, n), 7.0)
-    for _ in range(2):
-        assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 4, 3, None) == 0
+    import warnings
+    for trip in range(2):
+        with warnings.catch_warnings(record=True) as said:                  # the switch to per-sample calls is announced, once
+            warnings.simplefilter("always")
+            assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 4, 3, None) == 0
+        assert len(said) == (1 if trip == 0 else 0) and (trip or "called sample by sample: correct, but slow" in str(said[0].message))
         r2 = np.cumsum(X ** 2, axis=0)[1:]
         np.testing.assert_array_equal(W, np.where(r2 < 1.0, np.array([volume_inverse(d) for d in (2, 3, 4)])[:, None], 0.0))
     assert calls == [1] + [0] * (2 * n)                                     # one refused batch call, then scalars only
@@ -374,7 +378,8 @@ def test_closures_with_python_branches_run_on_both_paths(oracle):
     cb = Engine._make_host_callback(_engine_like(cfg1), sphere, False)
     X = np.ascontiguousarray(rng.uniform(0.0, 1.0, (2, n)))
     W = np.zeros((1, n))
-    assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 2, 1, None) == 0
+    with pytest.warns(RuntimeWarning, match="sample by sample"):
+        assert cb(X.ctypes.data_as(dp), W.ctypes.data_as(dp), n, 2, 1, None) == 0
     np.testing.assert_array_equal(W[0], (X[0] ** 2 + X[1] ** 2 < 1.0) * 1.0)
 
 

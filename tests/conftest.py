@@ -11,6 +11,9 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+    # tests that keep a per-sample closure on the host on purpose (trace=False) hear the engine's one-time "correct, but slow" note;
+    # the tests ABOUT that note record it themselves (pytest.warns / catch_warnings override this filter)
+    config.addinivalue_line("filterwarnings", "ignore:the host (integrand|measure) closure raised on a batch:RuntimeWarning")
     # a fresh checkout has no built artefacts (they are git-ignored): build them once (hipcc cross-compiles without a GPU)
     lib = os.path.join(ROOT, "mcintegration.jl_amd", "lib", "libmci_hip.so")
     demo = os.path.join(ROOT, "examples", "mci_demo")

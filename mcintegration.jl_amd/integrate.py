@@ -99,44 +99,11 @@ def _not_traced(what, err, trace, verbosity):
         builtins.print(msg)
 
 
-def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, block=16, verbose=-1, gamma=1.0,
-              adapt=True, debug=False, reweight_goal=None, ignore=None, measure=None, measurefreq=1,
-              thermal_ratio=0.1, inplace=False, parallel="nothread", print=-1, printio=None, timer=None,
-              comm=None, device=None, nchain=0, engine_factory=None, rng_bits=52, rng_rounds=10, deterministic=False, trace=None,
-              integrand_form=None, measure_form=None, **kwargs):
-    """Same keywords as the reference (main.jl:71-90; unknown ones go to Configuration, :95-97).
-    Extra, engine-specific keywords: `comm` (LocalComm | RcclComm | TorchDistComm), `device`, `nchain`
-    (vegasmc chains per block; 0 = auto), `rng_bits` (52 | 32: opt-in cheaper uniform stream of solver="vegas", see
-    mci_set_rng_bits), `rng_rounds` (10 | 7: opt-in Philox4x32-7 for every stream, mci_set_rng_rounds), `deterministic` (bit-identical
-    results for a fixed seed like the reference's sequential loop, mci_set_deterministic), `trace` (None, the default, and True: a
-    Python closure as integrand or measure is run once on symbolic draws and written out as device source -- trace.trace_integrand /
-    trace_measure -- so that it runs inside the kernels like Julia's inlined closure does in the reference's loop; a closure that
-    cannot be written out takes the host batch-callback path, silently with None, with a RuntimeWarning naming the reason with True;
-    False: always the host path), `integrand_form` / `measure_form` (callback_form: by default a closure is called in the form the
-    reference's solver calls it in -- `inplace` included -- and one whose parameters do not fit raises TypeError), `engine_factory`
-    (test seam)."""
-    if trace is None:
-        trace = TRACE_DEFAULT
-    if solver in (":vegas", ":vegasmc", ":mcmc"):
-        solver = solver[1:]
-    if solver not in SOLVERS:
-        raise ValueError("Solver %s is not supported!" % solver)                      # main.jl:263
-    print = max(print, verbose)                                                       # main.jl:93
-    if config is None:
-        config = Configuration(**kwargs)                                              # main.jl:95-97
-    for mx, v in zip(config.maxdof, config.var):
-        assert mx + 2 <= v.size, "maxdof should be less than the length of var"      # main.jl:99-101
-    if ignore is None:
-        ignore = 1 if adapt else 0                                                    # main.jl:82
-    comm = comm or LocalComm()
-    if device is None:   # an RcclComm is bound to one device: the engine has to live there (its all_reduce checks it)
-        device = getattr(comm, "device", 0)
-    neval = int(neval)
-    nevalperblock, block = standardize_block(neval, block, comm.size)                 # main.jl:121
-    assert block % comm.size == 0                                                     # main.jl:122
-    per = block // comm.size
-    lo, hi = per * comm.rank, per * (comm.rank + 1)
-
+def _bind(config, integrand, measure, solver, *, inplace=False, trace=None, print=-1, device=0, engine_factory=None, rng_bits=52,
+          rng_rounds=10, deterministic=False, integrand_form=None, measure_form=None):
+    """The engine of `config` for this integrand and measure (created, or kept when nothing it was built for has changed): closures are
+    put into the form the solver calls them in and traced where they can be; grids and reweight factors trained so far survive a change
+    of integrand.  Shared by integrate() and the solver seam (Vegas / VegasMC / MCMC .montecarlo)."""
     if isinstance(integrand, str):
         integrand = Integrand(integrand, config.userdata)
     elif callable(integrand) and not isinstance(integrand, (Integrand, HostIntegrand)):
@@ -190,7 +157,49 @@ def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, 
         if getattr(config, "_pending_state", None):
             eng.load_state(config._pending_state)
             config._pending_state = None
-    eng = config._engine
+    return config._engine
+
+
+def integrate(integrand, *, solver="vegasmc", config=None, neval=1e4, niter=10, block=16, verbose=-1, gamma=1.0,
+              adapt=True, debug=False, reweight_goal=None, ignore=None, measure=None, measurefreq=1,
+              thermal_ratio=0.1, inplace=False, parallel="nothread", print=-1, printio=None, timer=None,
+              comm=None, device=None, nchain=0, engine_factory=None, rng_bits=52, rng_rounds=10, deterministic=False, trace=None,
+              integrand_form=None, measure_form=None, **kwargs):
+    """Same keywords as the reference (main.jl:71-90; unknown ones go to Configuration, :95-97).
+    Extra, engine-specific keywords: `comm` (LocalComm | RcclComm | TorchDistComm), `device`, `nchain`
+    (vegasmc chains per block; 0 = auto), `rng_bits` (52 | 32: opt-in cheaper uniform stream of solver="vegas", see
+    mci_set_rng_bits), `rng_rounds` (10 | 7: opt-in Philox4x32-7 for every stream, mci_set_rng_rounds), `deterministic` (bit-identical
+    results for a fixed seed like the reference's sequential loop, mci_set_deterministic), `trace` (None, the default, and True: a
+    Python closure as integrand or measure is run once on symbolic draws and written out as device source -- trace.trace_integrand /
+    trace_measure -- so that it runs inside the kernels like Julia's inlined closure does in the reference's loop; a closure that
+    cannot be written out takes the host batch-callback path, silently with None, with a RuntimeWarning naming the reason with True;
+    False: always the host path), `integrand_form` / `measure_form` (callback_form: by default a closure is called in the form the
+    reference's solver calls it in -- `inplace` included -- and one whose parameters do not fit raises TypeError), `engine_factory`
+    (test seam)."""
+    if trace is None:
+        trace = TRACE_DEFAULT
+    if solver in (":vegas", ":vegasmc", ":mcmc"):
+        solver = solver[1:]
+    if solver not in SOLVERS:
+        raise ValueError("Solver %s is not supported!" % solver)                      # main.jl:263
+    print = max(print, verbose)                                                       # main.jl:93
+    if config is None:
+        config = Configuration(**kwargs)                                              # main.jl:95-97
+    for mx, v in zip(config.maxdof, config.var):
+        assert mx + 2 <= v.size, "maxdof should be less than the length of var"      # main.jl:99-101
+    if ignore is None:
+        ignore = 1 if adapt else 0                                                    # main.jl:82
+    comm = comm or LocalComm()
+    if device is None:   # an RcclComm is bound to one device: the engine has to live there (its all_reduce checks it)
+        device = getattr(comm, "device", 0)
+    neval = int(neval)
+    nevalperblock, block = standardize_block(neval, block, comm.size)                 # main.jl:121
+    assert block % comm.size == 0                                                     # main.jl:122
+    per = block // comm.size
+    lo, hi = per * comm.rank, per * (comm.rank + 1)
+
+    eng = _bind(config, integrand, measure, solver, inplace=inplace, trace=trace, print=print, device=device, engine_factory=engine_factory,
+                rng_bits=rng_bits, rng_rounds=rng_rounds, deterministic=deterministic, integrand_form=integrand_form, measure_form=measure_form)
     s = SOLVERS[solver]
     if hasattr(eng, "set_reweight_goal"):
         eng.set_reweight_goal(reweight_goal)                                          # main.jl:81, :334-337

@@ -246,3 +246,41 @@ def test_bubble_with_fermik_momentum_as_the_reference_writes_it():
     avg, std = result.mean[0], result.stdev[0]
     for i in range(para.Qsize):
         assert abs(avg[i] - exact[i]) < 5.0 * std[i], (avg, std, exact)
+
+
+@pytest.mark.parametrize("ns,name", [(mci.Vegas, "vegas"), (mci.VegasMC, "vegasmc"), (mci.MCMC, "mcmc")])
+def test_driving_a_solver_block_by_block_through_its_seam(ns, name):
+    """`Solver.montecarlo(config, integrand, neval, print, timer, debug; measure, measurefreq, inplace)` (src/main.jl:253-264): what
+    `_block!` does with it -- m = observable ./ normalization, obsSum += m, obsSquaredSum += m^2 (:275-287), mean and error of the mean
+    over the blocks (:296-320) -- by hand, 32 blocks on an untrained map; Sphere2's closures with their measure (test/montecarlo.jl:19-52)."""
+    if name == "mcmc":
+        f = lambda idx, X, c: 1.0 if X[0] ** 2 + X[1] ** 2 + (X[2] ** 2 if idx == 1 else 0.0) < 1.0 else 0.0
+
+        def measure(idx, X, obs, w, c):
+            obs[idx][0] += w
+    else:
+        f = lambda X, c: (1.0 if X[0] ** 2 + X[1] ** 2 < 1.0 else 0.0, 1.0 if X[0] ** 2 + X[1] ** 2 + X[2] ** 2 < 1.0 else 0.0)
+
+        def measure(X, obs, w, c):
+            for i in range(2):
+                obs[i][0] += w[i]
+    config = Configuration(var=Continuous(0.0, 1.0), dof=[[2], [3]], neighbor=[(1, 3), (1, 2)], seed=60)
+    nblock, neval = 32, 20000
+    s, s2 = np.zeros(2), np.zeros(2)
+    for b in range(nblock):
+        out = ns.montecarlo(config, f, neval, 0, [], False, measure=measure, measurefreq=1)
+        assert out is config and config.normalization > 0.0
+        m = np.array([float(o) for o in config.observable]) / config.normalization
+        s += m
+        s2 += m * m
+    eng = config._engine
+    assert isinstance(eng.integrand, mci.Integrand) and isinstance(eng.measure, mci.Measure) and config.iterations_done == nblock
+    mean = s / nblock
+    err = np.sqrt(np.maximum(0.0, s2 / nblock - mean ** 2) / (nblock - 1))
+    exact = np.array([PI / 4, PI / 6])
+    assert np.all(np.abs(mean - exact) < 7.0 * err) and np.all(err < 0.01), (mean, err)
+    assert config.neval > 0 and config.visited.shape == (3,)
+    if name != "vegas":
+        assert config.propose.shape == (3, 3, 3) and config.accept.sum() > 0.0
+    assert np.all(config.var[0].histogram > 0.0) and config.var[0].histogram.sum() > 1.0     # this block's, nobody has trained on it
+    np.testing.assert_allclose(config.var[0].grid, np.linspace(0.0, 1.0, 1000), rtol=0, atol=2e-16)   # the seam never trains (main.jl:190-203 does)

@@ -90,3 +90,28 @@ def test_a_launch_that_never_gets_long_enough_gives_up_after_seven_repeats():
     its = [it for _, it in eng.calls]
     assert its[:9] == [0] + [1 + 16384 * k for k in range(8)]          # iteration 1: the launch and seven repeats
     assert res.warmup == 14 and res.iter_mean.shape == (3, 1)          # ... iteration 2 likewise: the engine is still not warm
+
+
+def test_solver_seam_runs_one_block_and_leaves_its_sums_on_the_configuration(oracle):
+    """Vegas / VegasMC / MCMC .montecarlo(config, integrand, neval, ...) (src/main.jl:253-264): one block; `_block!` then reads
+    observable, normalization, neval and visited off the Configuration (:269-287).  Oracle-backed engine: the numbers are the oracle's
+    packed block, the next call is the next stream."""
+    from oracle_engine import OracleEngine
+    for solver, ns in (("vegas", mci.Vegas), ("vegasmc", mci.VegasMC), ("mcmc", mci.MCMC)):
+        cfg = mci.Configuration(var=mci.Continuous(0.0, 1.0), dof=[[2], [3]], seed=5)
+        out = ns.montecarlo(cfg, mci.catalog.sphere2(), 4000, 0, [], False, measurefreq=1, engine_factory=OracleEngine, nchain=1)
+        assert out is cfg and cfg.iterations_done == 1 and (cfg.neval == 4000 if solver == "vegas" else 0 < cfg.neval <= 4000)   # (chain solvers count like the reference: what the packed block says)
+        eng = cfg._engine
+        assert eng.calls == [(0, 1, 0)]
+        pk = eng.get_packed()
+        assert cfg.normalization == pk[2 * eng.nobs] and cfg.normalization > 0.0
+        m = np.array(cfg.observable) / cfg.normalization                               # main.jl:275-287
+        np.testing.assert_allclose(m, pk[:2], rtol=1e-14)
+        assert abs(m[0] - np.pi / 4) < 0.1 and abs(m[1] - np.pi / 6) < 0.1
+        assert cfg.visited.shape == (3,) and (solver == "vegas" or cfg.visited.sum() > 1000)
+        first = np.array(cfg.observable)
+        ns.montecarlo(cfg, mci.catalog.sphere2(), 4000, engine_factory=OracleEngine, nchain=1)
+        assert eng is cfg._engine and eng.calls[-1] == (0, 1, 1) and not np.array_equal(first, cfg.observable)   # the same engine, the next stream
+    import pytest
+    with pytest.raises(ValueError):
+        mci.MCMC.montecarlo(mci.Configuration(), mci.catalog.log_over_sqrt(), 100, inplace=True, engine_factory=OracleEngine)

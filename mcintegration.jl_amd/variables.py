@@ -176,3 +176,38 @@ def is_variable(v):
 
 def poolsize(v):
     return v.size
+
+
+# ---- the reference's exported helpers of `train!` (src/utility/utility.jl:19; src/distribution/common.jl), for host code that wants them:
+# the engine itself smooths, rescales and bisects inside its kernels (csrc/mci_train.h, mci_device.h) ----------------------------------
+def locate(accumulation, p):
+    """index i (1-based like the reference's) with accumulation[i] <= p < accumulation[i + 1]; an error outside (common.jl:8-36)"""
+    a = np.asarray(accumulation, dtype=np.float64)
+    if a[0] > p or a[-1] <= p:
+        raise ValueError("%r is not in %r" % (p, accumulation))                       # common.jl:10-12
+    return int(np.searchsorted(a, p, side="right"))
+
+
+def smooth(dist, factor=6.0):
+    """each entry averaged with its two neighbours, 1 : factor : 1; the ends (factor + 1) : 1 (common.jl:43-54)"""
+    d = np.asarray(dist, dtype=np.float64)
+    if len(d) <= 1:
+        return d.copy()
+    new = np.empty_like(d)
+    new[0] = (d[0] * (factor + 1) + d[1]) / (factor + 2)
+    new[-1] = (d[-1] * (factor + 1) + d[-2]) / (factor + 2)
+    new[1:-1] = (d[:-2] + d[1:-1] * factor + d[2:]) / (factor + 2)
+    return new
+
+
+def rescale(dist, alpha=1.5):
+    """normalise, then d -> (-(1 - d) / log d)^alpha where 0 < d <= 0.99999999; the result is NOT normalised again (common.jl:67-82)"""
+    d = np.array(dist, dtype=np.float64)
+    if len(d) == 1:
+        return d
+    assert np.all(d > 0), "distribution should be all positive and non-zero"          # common.jl:71
+    d /= d.sum()
+    m = (d > 0) & (d <= 0.99999999)
+    d[m] = (-(1.0 - d[m]) / np.log(d[m])) ** alpha
+    assert np.all(np.isfinite(d)), "distribution is not all finite"                   # common.jl:79
+    return d

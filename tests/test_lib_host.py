@@ -311,3 +311,22 @@ def test_chain_estimator_bias_note_follows_block_length_and_count():
     mci.report(res, io=out)
     assert "note: solver = :mcmc ran one chain per block of 3906 steps" in out.getvalue() and "fewer blocks (block = 16 gives 0.4)" in out.getvalue()
     assert res.with_ignore(2).chain_bias is b
+
+
+def test_exported_train_helpers_match_the_pinned_oracle(oracle):
+    """Dist.locate / smooth / rescale (test/utility.jl:1-10; src/distribution/common.jl): the mirror's host versions against the oracle's,
+    which are pinned on the reference's vectors (tests/test_oracle_known_answers.py)"""
+    grid = [0.0, 0.1, 0.3, 0.5]
+    eps = np.finfo(float).eps
+    for p, want in ((eps, 1), (0.5 - eps, 3), (grid[0], 1), (0.05, 1), (0.2, 2), (0.31, 3)):      # test/utility.jl:3-9
+        assert mci.Dist.locate(grid, p) == want == oracle.locate(grid, p)
+    for bad in (-0.1, 0.5, 0.7):
+        with pytest.raises(ValueError):
+            mci.Dist.locate(grid, bad)
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 7, 999):
+        h = rng.uniform(0.1, 3.0, n) ** 4
+        np.testing.assert_allclose(mci.Dist.smooth(h, 6.0), oracle.smooth(h, 6.0), rtol=1e-15)
+        for alpha in (0.5, 1.5, 3.0):
+            np.testing.assert_allclose(mci.Dist.rescale(h, alpha), oracle.rescale(h, alpha), rtol=1e-14)
+    assert mci.Dist.poolsize(mci.Continuous(0.0, 1.0)) == 17                                       # MaxOrder + 1

@@ -179,6 +179,11 @@ class Configuration:
             return self._engine.reweight()
         return self._reweight0.copy()
 
+    def reset_seed(self, seed):
+        """`reset_seed!(config, seed)` (configuration.jl:196-199): the seed of every stream drawn from now on, counted from its start again"""
+        self.seed = int(seed)
+        self.iterations_done = 0
+
     def _acceptance(self, which):
         nd = self.N + 1
         shape = (3, nd, max(nd, len(self.var)))

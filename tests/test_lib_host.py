@@ -93,6 +93,9 @@ def test_variable_constructors():
     cv = mci.Continuous([(0.0, 1.0), (0.0, 2.0)])
     assert isinstance(cv, mci.CompositeVar) and len(cv) == 2 and cv[1].upper == 2.0 and cv[0].ninc == 1000
     c = mci.Configuration(var=(x, d), dof=[[1, 1], [2, 1]])
+    c.iterations_done = 7
+    c.reset_seed(99)                                                                     # configuration.jl:196-199
+    assert c.seed == 99 and c.iterations_done == 0
     assert c.propose.shape == c.accept.shape == (3, 3, 3) and np.all(c.propose == 1e-8) and not c.accept.any()      # configuration.jl:185-186
     # the fields a reference user reads off a variable before anything has run: uniform map, cleared histogram (variable.jl:565)
     assert np.array_equal(x.grid, [0.0, 0.1, 0.4, 1.0]) and np.array_equal(x.histogram, np.full(3, 1e-10))

@@ -48,3 +48,17 @@ def test_documents_cite_files_that_exist():
             if not os.path.exists(os.path.join(ROOT, path)) and "*" not in path:
                 missing.append((doc, path))
     assert not missing, missing
+
+
+def test_documents_cite_tests_that_exist():
+    import glob
+    defs = set()
+    for f in glob.glob(os.path.join(ROOT, "tests", "*.py")):
+        defs |= set(re.findall(r"def (test_[A-Za-z0-9_]+)", open(f).read()))
+    missing = []
+    for doc in ("README.md", "DESIGN.md", "INTEGRATION.md", "CHANGELOG.md", "profiles/README.md"):
+        for m in re.finditer(r"`(?:tests/[a-z_]+\.py::)?(test_[A-Za-z0-9_]+?)(?:\[[^\]]*\])?`", open(os.path.join(ROOT, doc)).read()):
+            name = m.group(1)
+            if name not in defs and not any(d.startswith(name.rstrip("_")) for d in defs):      # (a name cut short with `...` is a prefix)
+                missing.append((doc, name))
+    assert not missing, missing

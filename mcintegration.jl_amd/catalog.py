@@ -126,7 +126,7 @@ def bubble(**kw):
 
 
 def bubble_fermik(**kw):
-    """test/bubble_FermiK.jl:52-77: the same polarisation with the momentum as a FermiK variable:
+    """test/bubble_FermiK.jl:54-74: the same polarisation with the momentum as a FermiK variable:
     vars = (T, K, Ext) -> x = [tau, k_x, k_y, k_z, ext]"""
     p = bubble_parameters(**kw)
     body = """

@@ -1087,7 +1087,7 @@ int mcio_vegasmc_block(mcio_config *c, mcio_integrand_fn f, const double *ud, ui
     const int N = c->Ni, npool = c->npool, norm = c->Ni;
     if (c->ndraw > MCIO_MAXDRAW || N + 1 > MCIO_MAXNI || measurefreq <= 0 || nchain < 1) return -1;
     for (int l = 0; l < c->nleaf; ++l)
-        if (c->leaf[l].kind == MCIO_FERMIK) return -4; /* test/bubble_FermiK.jl:133 "vegasmc can not handle this" */
+        if (c->leaf[l].kind == MCIO_FERMIK) return -4; /* test/bubble_FermiK.jl:126 "vegasmc can not handle this" */
     const int nc = c->ncomp;
     double weights[2 * MCIO_MAXNI], _weights[2 * MCIO_MAXNI], relw[2 * MCIO_MAXNI];
     double pad[MCIO_MAXNI], _pad[MCIO_MAXNI]; /* :147-148 */

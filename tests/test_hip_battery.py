@@ -996,7 +996,7 @@ def test_default_call_of_the_default_solver_is_unbiased_at_its_own_size():
 
 
 def test_bubble_with_fermik_momentum():
-    """test/bubble_FermiK.jl:93-131 (part of the reference's runtests.jl): vars = (T, K, Ext) with K = FermiK(3, kF, 0.2 kF,
+    """test/bubble_FermiK.jl:89-124 (part of the reference's runtests.jl): vars = (T, K, Ext) with K = FermiK(3, kF, 0.2 kF,
     10 kF), :mcmc, Steps = 2e5, two calls, every q within 5 sigma of the Lindhard function."""
     from catalog_params import bubble_exact
     p = mci.catalog.bubble_parameters()

@@ -204,7 +204,7 @@ def test_bubble_as_the_reference_writes_it(alg, ratio):
 
 
 def test_bubble_with_fermik_momentum_as_the_reference_writes_it():
-    """test/bubble_FermiK.jl:54-131: vars = (T, K, Ext), `k = K[1]` a momentum VECTOR of the FermiK pool, `kq = k + q` with q a row of
+    """test/bubble_FermiK.jl:54-124: vars = (T, K, Ext), `k = K[1]` a momentum VECTOR of the FermiK pool, `kq = k + q` with q a row of
     para.extQ, :mcmc with the five-argument measure; Steps = 2e5, two calls, every q within 5 sigma of the Lindhard function."""
     from catalog_params import bubble_exact
     para, _, _ = _bubble_closures()

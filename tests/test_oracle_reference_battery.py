@@ -248,7 +248,7 @@ def _fermik_bubble(oracle):
 
 
 def test_mcmc_bubble_with_fermik_momentum(oracle):
-    # test/bubble_FermiK.jl:93-131 (in the reference's runtests.jl): T Continuous, K = FermiK(3, kF, 0.2 kF, 10 kF),
+    # test/bubble_FermiK.jl:89-124 (in the reference's runtests.jl): T Continuous, K = FermiK(3, kF, 0.2 kF, 10 kF),
     # Ext Discrete(adapt=false), :mcmc, Steps = 2e5, two runs, 5 sigma against the Lindhard function
     leaves, fn, ud, exact = _fermik_bubble(oracle)
     cfg = oracle.Config(leaves, [[1, 1, 1]], obs_nbin=[4], obs_bin_draw=[4])
@@ -258,5 +258,5 @@ def test_mcmc_bubble_with_fermik_momentum(oracle):
     assert r["rc"] == 0
     for k in range(4):
         assert abs(r["mean"][k] - exact[k]) < 5.0 * r["stdev"][k], (k, r["mean"], r["stdev"], exact)
-    # "vegas doesn't work with FermiK variable yet" (test/bubble_FermiK.jl:2, :133)
+    # "vegas doesn't work with FermiK variable yet" (test/bubble_FermiK.jl:2, :125-126)
     assert cfg.integrate(oracle.VEGAS, fn, ud, neval=20000, niter=2, seed=83)["rc"] != 0

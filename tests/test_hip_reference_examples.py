@@ -284,3 +284,32 @@ def test_driving_a_solver_block_by_block_through_its_seam(ns, name):
         assert config.propose.shape == (3, 3, 3) and config.accept.sum() > 0.0
     assert np.all(config.var[0].histogram > 0.0) and config.var[0].histogram.sum() > 1.0     # this block's, nobody has trained on it
     np.testing.assert_allclose(config.var[0].grid, np.linspace(0.0, 1.0, 1000), rtol=0, atol=2e-16)   # the seam never trains (main.jl:190-203 does)
+
+
+@pytest.mark.parametrize("solver", ["vegas", "vegasmc"])
+def test_complex_histogram_by_a_discrete_draw(solver):
+    """a ComplexF64 observable binned by the Discrete draw (`obs[1][bin[1]] += weights[1]` with complex weights: every bin is an (re, im)
+    pair of slots): bin b holds int_0^1 x dx * exp(i phi_b), the phases looked up in a captured table"""
+    K = 6
+    phase = np.linspace(0.0, 2.0, K)
+
+    def f(v, c):
+        x, b = v
+        return x[0] * np.exp(1j * phase[b[0] - 1])
+
+    def measure(v, obs, w, c):
+        obs[0][v[1][0] - 1] += w[0]
+    kw = dict(measure=measure, dof=[[1, 1]], obs=[np.zeros(K, dtype=complex)], type=complex, solver=solver, neval=1e5, seed=70, print=-1,
+              **({} if solver == "vegas" else dict(nchain=16)))
+    mk = lambda: (Continuous(0.0, 1.0), Discrete(1, K))
+    a = integrate(f, var=mk(), **kw)
+    eng = a.config._engine
+    assert isinstance(eng.integrand, mci.Integrand) and isinstance(eng.measure, mci.Measure) and "2 * mci_k0_0 + 1" in eng.measure.body
+    m, e = np.asarray(a.mean[0]), np.asarray(a.stdev[0])
+    exact = 0.5 * np.exp(1j * phase)
+    assert np.all(np.abs(m.real - exact.real) < 7 * e.real + 1e-12) and np.all(np.abs(m.imag - exact.imag) < 7 * e.imag + 1e-12), (m, e, exact)
+    small = 2e4 if solver == "vegas" else 4e3
+    a2 = integrate(f, var=mk(), **dict(kw, neval=small))
+    b = integrate(f, var=mk(), trace=False, **dict(kw, neval=small))
+    assert isinstance(b.config._engine.measure, mci.HostMeasure)
+    np.testing.assert_allclose(np.asarray(a2.iter_mean, dtype=complex).ravel(), np.asarray(b.iter_mean, dtype=complex).ravel(), rtol=1e-9, atol=1e-12)

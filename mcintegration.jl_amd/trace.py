@@ -570,6 +570,7 @@ class _Table(np.ndarray):
     array it was for everything Python does with it, and indexing it with a SAMPLED value (`grid[bin[0] - 1]`, example of
     docs/src/index.md "Measure Histogram"; `para.extQ[ext[0] - 1]`, test/bubble.jl:60) is a table lookup of the written-out body:
     the values go into the userdata vector and the element is `ud[base + (int)index]` (a row of an N-d table: one lookup per element).
+    Sampled values on several leading axes (`vertex[a[0] - 1, b[0] - 1]`) become one row-major flat index.
     0-based like every index here; an index outside the table is clamped (the check against the closure at random points refuses a
     closure that relies on anything else, e.g. Python's negative indices)."""
 
@@ -585,11 +586,35 @@ class _Table(np.ndarray):
         if isinstance(i, Sym):
             return self._lookup(i)
         if isinstance(i, tuple) and any(isinstance(q, Sym) for q in i):
-            if isinstance(i[0], Sym) and not any(isinstance(q, Sym) for q in i[1:]):
-                return self._lookup(i[0])[i[1:]]
-            raise TraceError("a table indexed with a sampled value on another axis than the first")
+            last = max(k for k, q in enumerate(i) if isinstance(q, Sym))
+            lead, rest = i[:last + 1], i[last + 1:]
+            if not all(isinstance(q, (Sym, int, np.integer)) for q in lead):
+                raise TraceError("a table indexed with a sampled value behind a slice")
+            out = self._lookup(lead[0]) if len(lead) == 1 else self._lookup_axes(lead)
+            return out[rest] if rest else out
         out = np.ndarray.__getitem__(self, i)
         return out.view(np.ndarray) if isinstance(out, np.ndarray) else out
+
+    def _lookup_axes(self, lead):
+        """`tab[a, b]` with sampled values on several leading axes (a vertex table over two Discrete draws): the row-major flat
+        index of the clamped entries, then one lookup in the table seen as [prod of those axes, rest]"""
+        if self._values is None or self._values.ndim < len(lead):
+            raise TraceError("more indices than the table has axes")
+        shape = self._values.shape
+        flat = 0.0
+        for axis, q in enumerate(lead):
+            n = shape[axis]
+            if n == 0:
+                raise TraceError("an empty table indexed with a sampled value")
+            term = fmin(fmax(q, 0.0), float(n - 1)) if isinstance(q, Sym) else float(int(q) % n)
+            flat = flat * float(n) + term
+        rows = int(np.prod(shape[:len(lead)]))
+        view = _Table(self._values.reshape((rows,) + shape[len(lead):]), self._t)
+        view._tid = self._tid if self._tid is not None else None
+        if self._tid is None:                               # (one block of ud[] for the table, however it is indexed)
+            self._tid = view._tid = len(self._t.tables)
+            self._t.tables.append(self._values)
+        return view._lookup(flat)
 
     def _lookup(self, idx):
         if self._t is None or self._values is None or self._values.ndim == 0:

@@ -116,14 +116,27 @@ def test_captured_tables_small_and_large(oracle):
         assert w[0] == pytest.approx(g((x[:1], np.array([int(x[1])])), cfg2), rel=1e-14)
 
 
+def test_a_table_over_two_discrete_draws(oracle):
+    """`vertex[a, b]` with a sampled value on several leading axes: the row-major flat index of the clamped entries, one lookup"""
+    V = np.arange(12.0).reshape(3, 4) ** 1.5
+    W = np.arange(24.0).reshape(2, 3, 4) - 7.0
+    cfg = mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3), mci.Discrete(1, 4)), dof=[[1, 1, 1]])
+    f = lambda v, c: V[v[1][0] - 1, v[2][0] - 1] * v[0][0] + W[1, v[1][0] - 1, v[2][0] - 1] + W[0, v[1][0] - 1][2] + V[v[1][0] - 1][3]
+    I = trace_integrand(f, cfg)
+    assert len(I.userdata) == 12 + 24                                                # each table once, however it is indexed
+    for x, w in _check_body(oracle, I, f, cfg, np.zeros(3), np.ones(3), {1: (1, 3), 2: (1, 4)}):
+        ref = f((x[:1], np.array([int(x[1])]), np.array([int(x[2])])), cfg)
+        assert w[0] == pytest.approx(ref, rel=1e-14)
+
+
 def test_what_a_sampled_index_cannot_do():
     cfg = mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3)), dof=[[1, 1]])
     plain = [1.0, 2.0, 3.0]
     with pytest.raises(TraceError, match="indexed with a sampled value"):          # a Python list the tracer cannot see into
         trace_integrand(lambda v, c: plain[v[1][0] - 1], cfg)
     tab = np.arange(12.0).reshape(3, 4)
-    with pytest.raises(TraceError):                                                 # a draw on the second axis
-        trace_integrand(lambda v, c: tab[0, v[1][0]], cfg)
+    with pytest.raises(TraceError, match="behind a slice"):                         # a draw behind a slice
+        trace_integrand(lambda v, c: tab[:, v[1][0]][0], cfg)
     with pytest.raises(TraceError, match="disagree"):                               # Python's negative index: the body clamps, the closure wraps
         trace_integrand(lambda v, c: tab[v[1][0] - 3, 0], cfg)
 

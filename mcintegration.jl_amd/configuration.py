@@ -59,6 +59,7 @@ class Configuration:
         self.obs_len = [int(np.size(o)) for o in obs]
         self.obs_nbin = [n * self.ncomp for n in self.obs_len]
         self.obs_is_array = [np.ndim(o) > 0 for o in obs]
+        self.obs_shape = [tuple(np.shape(o)) if np.ndim(o) > 0 else (1,) for o in obs]     # what a measure closure indexes (an N-d observable keeps its axes)
         if reweight is None:
             reweight = np.ones(self.N + 1)                                 # :110
         reweight = np.asarray(reweight, dtype=np.float64)

@@ -67,11 +67,12 @@ class _HostObs(np.ndarray):
 
     @staticmethod
     def _bins(i):
-        return isinstance(i, np.ndarray) and i.dtype.kind in "iu" and i.ndim >= 1
+        one = lambda q: isinstance(q, np.ndarray) and q.dtype.kind in "iu" and q.ndim >= 1
+        return one(i) or (isinstance(i, tuple) and any(one(q) for q in i) and all(one(q) or isinstance(q, (int, np.integer)) for q in i))
 
     def __getitem__(self, i):
         if self._bins(i):
-            return np.zeros(i.shape, dtype=self.dtype)
+            return np.zeros(np.broadcast(*i).shape if isinstance(i, tuple) else i.shape, dtype=self.dtype)
         out = np.ndarray.__getitem__(self, i)
         return out.view(np.ndarray) if isinstance(out, np.ndarray) else out
 
@@ -356,7 +357,7 @@ class Engine:
                 weights = [R[2 * i] + 1j * R[2 * i + 1] for i in range(config.N)] if nc == 2 else [R[i] for i in range(config.N)]
                 obs = None
                 if not state["per_record"]:
-                    obs = [_HostObs(ln, dt) for ln in config.obs_len]
+                    obs = [_HostObs(shape, dt) for shape in config.obs_shape]
                     try:
                         fn(self._pool_views(X, n), obs, weights, config)
                     except (ValueError, TypeError, IndexError) as e:
@@ -365,7 +366,7 @@ class Engine:
                         _slow_path_warning("measure", "record", e)
                         state["per_record"], obs = True, None
                 if obs is None:
-                    obs = [np.zeros(ln, dtype=dt) for ln in config.obs_len]
+                    obs = [np.zeros(shape, dtype=dt) for shape in config.obs_shape]
                     for j in range(n):
                         fn(self._pool_views(X[:, j:j + 1], 1, scalar=True), obs, [w[j] for w in weights], config)
                 _store_obs(O, obs, config.obs_nbin, nc)
@@ -391,9 +392,9 @@ class Engine:
                 R = np.ctypeslib.as_array(rp, shape=(ncomp, stride))[:, :n]
                 O = np.ctypeslib.as_array(op, shape=(nobs,))
                 obs, off = [], 0
-                for ln, nb in zip(config.obs_len, config.obs_nbin):   # the block's observables so far (the library calls once per integrand)
+                for shape, nb in zip(config.obs_shape, config.obs_nbin):   # the block's observables so far (the library calls once per integrand)
                     o = np.array(O[off:off + nb])
-                    obs.append(((o[0::2] + 1j * o[1::2]) if nc == 2 else o.astype(dt)).view(_HostObs))
+                    obs.append(((o[0::2] + 1j * o[1::2]) if nc == 2 else o.astype(dt)).reshape(shape).view(_HostObs))
                     off += nb
                 w = (R[0] + 1j * R[1]) if nc == 2 else R[0]
                 for i in np.unique(idx[idx >= 0]):

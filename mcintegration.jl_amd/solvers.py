@@ -39,10 +39,10 @@ class _Solver:
         mean = pk[:nobs]                       # one block: its mean observable / normalization (main.jl:275-287)
         flat = mean * norm
         obs, off = [], 0
-        for ln, nb, is_arr in zip(config.obs_len, config.obs_nbin, config.obs_is_array):
+        for ln, nb, is_arr, shape in zip(config.obs_len, config.obs_nbin, config.obs_is_array, config.obs_shape):
             v = flat[off:off + nb]
             v = (v[0::2] + 1j * v[1::2]) if config.ncomp == 2 else v.copy()
-            obs.append(v if is_arr else v[0])
+            obs.append(v.reshape(shape) if is_arr else v[0])
             off += nb
         config.observable = obs
         config.normalization = norm

@@ -119,10 +119,13 @@ class Result:
         likewise (statistics.jl:207-214, main.jl:302-305)"""
         out, off = [], 0
         nc = getattr(self.config, "ncomp", 1)
-        for nb, isarr in zip(self.config.obs_nbin, self.config.obs_is_array):
+        shapes = getattr(self.config, "obs_shape", None) or [None] * len(self.config.obs_nbin)
+        for nb, isarr, shape in zip(self.config.obs_nbin, self.config.obs_is_array, shapes):
             v = np.array(flat[off:off + nb])
             if nc == 2:
                 v = v[0::2] + 1j * v[1::2]
+            if isarr and shape is not None and len(shape) > 1:
+                v = v.reshape(shape)               # an N-d observable comes back with its axes (row-major, like the closure indexed it)
             out.append(v if isarr else (complex(v[0]) if nc == 2 else float(v[0])))
             off += nb
         return out

@@ -1179,18 +1179,43 @@ class _Obs(np.ndarray):
         self._oi = getattr(obj, "_oi", None)
         self._zero = getattr(obj, "_zero", None)
 
+    @staticmethod
+    def _sampled(i):
+        return isinstance(i, Sym) or (isinstance(i, tuple) and any(isinstance(q, Sym) for q in i))
+
     def __getitem__(self, i):
-        if isinstance(i, Sym):
+        if self._sampled(i):
             return self._zero                       # (what `+=` reads before it adds)
         return np.ndarray.__getitem__(self, i)
 
     def __setitem__(self, i, v):
-        if isinstance(i, Sym):
-            if self._t is None or self.ndim != 1:
+        if self._sampled(i):
+            if self._t is None or self._oi is None or self.base is not None and self.base.shape != self.shape:
                 raise TraceError("a sampled index into a view of an observable")
-            self._t.dynamic.append((self._oi, i, v))
+            self._t.dynamic.append((self._oi, self._flat_bin(i), v))
             return
         np.ndarray.__setitem__(self, i, v)
+
+    def _flat_bin(self, i):
+        """the row-major flat bin of `obs[i][a, b]` (sampled values and numbers on ALL axes), -1 where an entry is off its axis"""
+        if isinstance(i, Sym):
+            i = (i,)
+        if len(i) != self.ndim or not all(isinstance(q, (Sym, int, np.integer)) for q in i):
+            raise TraceError("an observable indexed with a sampled value needs one index per axis (numbers or sampled values)")
+        if self.ndim == 1:
+            return i[0]                             # (the range check is the written-out body's)
+        flat, inside = 0.0, []
+        for n, q in zip(self.shape, i):
+            if isinstance(q, Sym):
+                inside.append((q, n))
+                flat = flat * float(n) + q
+            else:
+                if not -n <= int(q) < n:
+                    raise TraceError("index %d is out of bounds for an axis of %d" % (int(q), n))
+                flat = flat * float(n) + float(int(q) % n)
+        for q, n in inside:
+            flat = where(q < 0.0, -1.0, where(q > float(n - 1), -1.0, flat))
+        return flat
 
 
 def trace_measure(fn, config, indexed=False, check_points=32):
@@ -1209,7 +1234,7 @@ def trace_measure(fn, config, indexed=False, check_points=32):
     zero = t.const(0.0)
 
     def fresh():
-        return [_Obs(ln, t, oi, zero) for oi, ln in enumerate(config.obs_len)]
+        return [_Obs(shape, t, oi, zero) for oi, shape in enumerate(config.obs_shape)]
 
     shapes = []
 
@@ -1302,11 +1327,11 @@ def trace_measure(fn, config, indexed=False, check_points=32):
                     if indexed:
                         refs = []
                         for i in range(N):
-                            obs = [np.zeros(ln, dtype=cdt) for ln in config.obs_len]
+                            obs = [np.zeros(shape, dtype=cdt) for shape in config.obs_shape]
                             fn(i, num, obs, wnum(i, p), config)
                             refs.append(oflat(obs))
                     else:
-                        obs = [np.zeros(ln, dtype=cdt) for ln in config.obs_len]
+                        obs = [np.zeros(shape, dtype=cdt) for shape in config.obs_shape]
                         fn(num, obs, [wnum(i, p) for i in range(N)], config)
                         refs = [oflat(obs)]
             except Exception as e:

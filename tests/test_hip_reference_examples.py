@@ -313,3 +313,33 @@ def test_complex_histogram_by_a_discrete_draw(solver):
     b = integrate(f, var=mk(), trace=False, **dict(kw, neval=small))
     assert isinstance(b.config._engine.measure, mci.HostMeasure)
     np.testing.assert_allclose(np.asarray(a2.iter_mean, dtype=complex).ravel(), np.asarray(b.iter_mean, dtype=complex).ravel(), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("solver", ["vegas", "mcmc"])
+def test_a_two_dimensional_histogram_over_two_discrete_draws(solver):
+    """`obs = [zeros(3, 4)]`, `obs[1][a[1], b[1]] += weights[1]`: an observable with two axes, a vertex table `V[a, b]` looked up by the
+    same two draws; bin (a, b) holds V[a, b] / 2.  Traced and on the host, Result.mean with the observable's shape."""
+    V = (np.arange(12.0).reshape(3, 4) + 1.0) / 3.0
+
+    def f(v, c):
+        x, a, b = v
+        return x[0] * V[a[0] - 1, b[0] - 1]
+
+    def measure(v, obs, w, c):
+        obs[0][v[1][0] - 1, v[2][0] - 1] += w[0]
+    if solver == "mcmc":
+        f0, m0 = f, measure
+        f = lambda idx, v, c: f0(v, c)
+        measure = lambda idx, v, obs, w, c: obs[0].__setitem__((v[1][0] - 1, v[2][0] - 1), obs[0][v[1][0] - 1, v[2][0] - 1] + w)
+    kw = dict(measure=measure, dof=[[1, 1, 1]], obs=[np.zeros((3, 4))], solver=solver, neval=1e5, seed=80, print=-1, **({} if solver == "vegas" else dict(nchain=16)))
+    mk = lambda: (Continuous(0.0, 1.0), Discrete(1, 3), Discrete(1, 4))
+    a = integrate(f, var=mk(), **kw)
+    eng = a.config._engine
+    assert isinstance(eng.integrand, mci.Integrand) and isinstance(eng.measure, mci.Measure)
+    m, e = np.asarray(a.mean[0]), np.asarray(a.stdev[0])
+    assert m.shape == (3, 4) and np.all(np.abs(m - V / 2) < 7 * e), (m, e)
+    small = 2e4 if solver == "vegas" else 4e3
+    a2 = integrate(f, var=mk(), **dict(kw, neval=small))
+    b = integrate(f, var=mk(), trace=False, **dict(kw, neval=small))
+    assert isinstance(b.config._engine.measure, mci.HostMeasure)
+    np.testing.assert_allclose(np.asarray(a2.iter_mean).ravel(), np.asarray(b.iter_mean).ravel(), rtol=1e-9, atol=1e-12)

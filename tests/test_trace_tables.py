@@ -280,3 +280,35 @@ def test_random_closures_with_tables_inside_branches(oracle):
             ref = float(f((x[:2], x[2:].astype(np.int64)), cfg))
             assert w[0] == pytest.approx(ref, rel=1e-13, abs=1e-300), (case, x, I.body)
     assert traced >= 25 and lookups >= 20, (traced, lookups)
+
+
+def test_observables_keep_their_axes():
+    """an N-d observable (`obs = [zeros(3, 4)]`: a histogram over two Discrete draws) is indexed by the measure as it was declared --
+    traced (row-major flat bin, -1 where an entry is off its axis), on the host (batch and per record) and in Result"""
+    from mcintegration_jl_amd.engine import Engine
+    from mcintegration_jl_amd.statistics import Result
+    cfg = mci.Configuration(var=(mci.Continuous(0.0, 1.0), mci.Discrete(1, 3), mci.Discrete(1, 4)), dof=[[1, 1, 1]], obs=[np.zeros((3, 4))])
+    assert cfg.obs_shape == [(3, 4)] and cfg.obs_len == [12]
+
+    def m(v, obs, w, c):
+        obs[0][v[1][0] - 1, v[2][0] - 1] += w[0]
+        obs[0][0, 1] += w[0] * v[0][0]
+    body = trace_measure(m, cfg).body
+    assert "obs_add(1, " in body and "if (mci_k0_0 >= 0 && mci_k0_0 < 12) obs_add(0 + mci_k0_0, rw[0]);" in body and "? (-1.0) :" in body
+    with pytest.raises(TraceError, match="one index per axis"):
+        trace_measure(lambda v, obs, w, c: obs[0].__setitem__(v[1][0] - 1, w[0]), cfg)
+    n = 40
+    rng = np.random.default_rng(4)
+    X = np.ascontiguousarray(np.vstack([rng.uniform(0, 1, (1, n)), rng.integers(1, 4, (1, n)).astype(float), rng.integers(1, 5, (1, n)).astype(float)]))
+    R = np.ascontiguousarray(rng.standard_normal((1, n)))
+    ref = np.zeros((3, 4))
+    for j in range(n):
+        ref[int(X[1, j]) - 1, int(X[2, j]) - 1] += R[0, j]
+        ref[0, 1] += R[0, j] * X[0, j]
+    for closure in (m, lambda v, obs, w, c: (np.add.at(obs[0], (v[1][0] - 1, v[2][0] - 1), w[0]), np.add.at(obs[0], (0, 1), (w[0] * v[0][0]).sum()))):
+        O = np.zeros(12)
+        cb = Engine._make_host_measure_callback(_engine_like(cfg), closure)
+        assert cb(X.ctypes.data_as(dp), R.ctypes.data_as(dp), n, n, 3, 1, 0, O.ctypes.data_as(dp), 12, None) == 0
+        np.testing.assert_allclose(O.reshape(3, 4), ref, rtol=1e-13, atol=1e-15)
+    res = Result(np.arange(24.0).reshape(2, 12), np.ones((2, 12)), cfg, 0)
+    assert np.asarray(res.mean[0]).shape == (3, 4) and np.asarray(res.iterations[0][0][0]).shape == (3, 4)

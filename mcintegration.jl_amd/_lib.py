@@ -168,24 +168,35 @@ def use_rocm_compiler(rocm=None):
     installation's comgr and hiprtc with RTLD_GLOBAL and NOTHING ELSE: not libmci_hip.so and with it no HIP runtime -- a process that goes
     on to import PyTorch keeps ONE runtime, PyTorch's, which libmci_hip.so then binds to as it always did (its streams and buffers, the
     library's RCCL communicator and PyTorch's all live in that one runtime); only the compiler is the installation's.  Returns True if
-    it loaded them, False if a comgr was in the process already (nothing is changed then; `compiler_id()` says which one compiles)."""
-    loaded = ""
+    it loaded them, False if ANOTHER comgr was in the process already (nothing is changed then; `compiler_id()` says which one compiles)."""
+    root = rocm or os.environ.get("ROCM_PATH") or "/opt/rocm"
+    mapped = set()
     try:
         with open("/proc/self/maps") as fh:
-            loaded = fh.read()
+            for line in fh:
+                path = line.split(None, 5)[-1].strip() if line.count(" ") >= 5 else ""
+                if "amd_comgr" in path or "hiprtc" in path:
+                    mapped.add(os.path.realpath(path))
     except OSError:
         pass
-    if "amd_comgr" in loaded:
-        return False
-    root = rocm or os.environ.get("ROCM_PATH") or "/opt/rocm"
-    done = False
-    for names in (("libamd_comgr.so.3", "libamd_comgr.so.2", "libamd_comgr.so"), ("libhiprtc.so.7", "libhiprtc.so")):
+
+    def installed(names):
         for name in names:
             path = os.path.join(root, "lib", name)
             if os.path.exists(path):
-                C.CDLL(path, mode=C.RTLD_GLOBAL)
-                done = True
-                break
+                return path
+        return None
+    comgr, hiprtc = installed(("libamd_comgr.so.3", "libamd_comgr.so.2", "libamd_comgr.so")), installed(("libhiprtc.so.7", "libhiprtc.so"))
+    have_comgr = [p for p in mapped if "amd_comgr" in p]
+    if have_comgr and (comgr is None or os.path.realpath(comgr) not in have_comgr):
+        return False                                       # another comgr serves this process already (PyTorch's, typically)
+    # (a comgr that IS the installation's may be there before us -- rocprofv3's tool library maps it -- and then hiprtc still has to be pinned:
+    # PyTorch's own libhiprtc in front of the installation's comgr is a third compiler identity, and a kernel-cache key of its own)
+    done = False
+    for path in (comgr, hiprtc):
+        if path is not None:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            done = True
     return done
 
 

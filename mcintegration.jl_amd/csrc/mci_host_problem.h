@@ -190,8 +190,10 @@ int mci_problem_create(mci_ctx *ctx, const mci_problem_desc *d, mci_problem **ou
         s.leaf_doff.push_back(L.doff);
         s.leaf_boff.push_back(L.boff);
         s.leaf_adapt.push_back(L.adapt);
-        s.leaf_lower.push_back(L.lower);
-        s.leaf_upper.push_back(L.upper);
+        // (the kernels read a Discrete leaf's lower bound and a FermiK's kF / dk out of the source; a Continuous leaf's bounds live in its
+        // edge table and stay OUT of the source, so that a sweep over a domain -- Continuous(0, beta) at many temperatures -- reuses one code object)
+        s.leaf_lower.push_back(L.kind == MCI_CONTINUOUS ? 0.0 : L.lower);
+        s.leaf_upper.push_back(L.kind == MCI_CONTINUOUS ? 0.0 : L.upper);
     }
     // table placement (DESIGN.md "data layout"): keep >= 2 workgroups per CU when everything is in LDS.
     // PAIR_TABLE stores (g[i], g[i+1]-g[i]) per bin (16 B, one ds_read_b128 per draw) when that still fits.

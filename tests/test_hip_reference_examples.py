@@ -343,3 +343,27 @@ def test_a_two_dimensional_histogram_over_two_discrete_draws(solver):
     b = integrate(f, var=mk(), trace=False, **dict(kw, neval=small))
     assert isinstance(b.config._engine.measure, mci.HostMeasure)
     np.testing.assert_allclose(np.asarray(a2.iter_mean).ravel(), np.asarray(b.iter_mean).ravel(), rtol=1e-9, atol=1e-12)
+
+
+def test_a_sweep_over_the_bubbles_parameters_runs_on_one_code_object():
+    """the struct of parameters in `userdata` travels as trace parameters and a table (trace.py "Captured parameters"): the bubble at three
+    temperatures and another set of external momenta from ONE kernel, each inside 20 sigma of its Lindhard values (test/bubble.jl:124)"""
+    import types
+    from catalog_params import lindhard
+    _, integrand, measure = _bubble_closures()
+    objs = []
+    for beta, qmax in ((25.0, 1.5), (40.0, 1.5), (25.0, 2.5)):
+        p = mci.catalog.bubble_parameters(beta=beta)
+        para = types.SimpleNamespace(kF=p["kF"], beta=p["beta"], me=p["me"], spin=p["spin"], dim=p["dim"], Qsize=4,
+                                     extQ=[np.array([q, 0.0, 0.0]) for q in np.linspace(0.0, qmax * p["kF"], 4)])
+        var = (Continuous(0.0, 1.0, alpha=3.0), Continuous(0.0, PI, alpha=3.0), Continuous(0.0, 2 * PI, alpha=3.0),
+               Continuous(0.0, para.beta, alpha=3.0), Discrete(1, 4, adapt=False))
+        res = integrate(integrand, measure=measure, userdata=para, var=var, dof=[[1, 1, 1, 1, 1]], obs=[np.zeros(4)], solver="vegas",
+                        neval=1e6, seed=90, print=-1)
+        eng = res.config._engine
+        assert isinstance(eng.integrand, mci.Integrand)
+        objs.append(eng.code_object("vegas"))
+        exact = [lindhard(q[0], p) for q in para.extQ]
+        for i in range(4):
+            assert abs(res.mean[0][i] - exact[i]) < 20.0 * res.stdev[0][i] + 3e-4, (beta, qmax, res.mean[0], res.stdev[0], exact)   # (+ the finite-T shift)
+    assert objs[0] == objs[1] == objs[2]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box batches behind the numbers in profiles/ (one parameterised script; run as `gpurun -- bash tools/run_batch.sh <batch> [args]`).
 # Every batch writes under gpurun_out/<batch>/; what is to be judged is copied into profiles/ by hand afterwards.
-#   round 6:  ab_exec_mask | midsize | r06_collect | r06_fuzz
+#   round 6:  ab_exec_mask | midsize | r06_collect | r06_recollect | r06_fuzz
 #   round 5 (kept as they ran, cited by profiles/README.md): r05_<name>
 set -u
 batch=${1:-help}; shift || true
@@ -58,6 +58,18 @@ import json
 j = json.loads(open("gpurun_out/r06_collect/r06_bench_line.json").read().strip().splitlines()[-1]); r = j["roofline"]
 print(j["value"], j["ms_per_step"], r["kernel_ms_avg"], r["frac"], r.get("frac_flat_2cycle"), r["frac_self_calibrated"], r["clock"]["sclk_mhz_avg"], r["traffic"], j["config"].get("code_object"))
 PY
+;;
+r06_recollect)
+# after the last change of the generated source in round 6 (a Continuous leaf's bounds left out of it: every code object got a new name, the
+# machine code is the same): GPU suite, smoke, bench line and the rocprofv3 / PMC summaries of every profiled workload again, so that
+# profiles/r06_* name the code objects the committed tree produces
+timeout 1500 python -m pytest tests -m gpu -q -x -p no:cacheprovider > $out/suite.txt 2>&1; tail -2 $out/suite.txt
+python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; tail -1 $out/smoke.txt
+bash profiles/collect.sh r06 bench > $out/collect_bench.log 2>&1
+timeout 900 python bench.py > $out/r06_bench_line.json 2> $out/bench.err
+for w in c3 c4 c5 bubble_mcmc default_call; do bash profiles/collect.sh r06_$w $w > $out/collect_$w.log 2>&1; done
+cp profiles/r06*_kernel_stats.txt profiles/r06*_pmc_traffic.json $out/ 2>/dev/null
+python -c "import json; d = json.load(open('$out/r06_bench_line.json')); print(d['value'], d['roofline']['frac'], d['roofline'].get('traffic'), d['config']['code_object'])"
 ;;
 r06_fuzz)
 # randomised parity campaigns on the final code of round 6, cold kernel cache: every new several-lanes-per-chain code object goes through its
